@@ -1,0 +1,894 @@
+// gmx_kernels.hip — gfx950 kernels + the C-ABI of include/genmi.h.
+//
+// Kernel inventory (roofline notes in DESIGN.md §4):
+//   k_vm<Regs>          site-program interpreter, 1 thread / particle   (ALU + HBM)
+//   k_lse_tiles/_final  deterministic two-stage log-sum-exp             (HBM)
+//   k_lse_rows          one wave per row (many short rows)              (HBM)
+//   k_weight_cdf        fixed-point weights + single-pass chained scan  (HBM)
+//   k_ancestors         128-bit exact inverse-CDF search                (L2 latency)
+//   k_gather/k_select   multi-leaf row gather / masked select           (HBM)
+//   k_categorical_rows  Gumbel-max per row                              (ALU)
+//   small key kernels   split / fold_in / random_bits / mh_accept
+//
+// Wavefront = 64 everywhere; blocks are 256 threads (4 waves, one per SIMD).
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <new>
+
+#include "gmx_vm.h"
+
+// ---------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int gmx_fail(const char* fmt, const char* a = "", long long b = 0) {
+  snprintf(g_err, sizeof(g_err), fmt, a, b);
+  return 1;
+}
+#define GMX_HIP(call)                                                        \
+  do {                                                                       \
+    hipError_t _e = (call);                                                  \
+    if (_e != hipSuccess) return gmx_fail("%s (hip error %lld)", hipGetErrorString(_e), (long long)_e); \
+  } while (0)
+
+extern "C" int gmx_version(void) { return GMX_ABI_VERSION; }
+extern "C" const char* gmx_last_error(void) { return g_err; }
+
+extern "C" void gmx_threefry2x32_host(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1,
+                                      uint32_t out[2]) {
+  gmx_threefry2x32(k0, k1, c0, c1, &out[0], &out[1]);
+}
+
+#define GMX_BLOCK 256
+#define GMX_WAVE 64
+
+// ---------------------------------------------------------------------------
+// wave / block reductions (fixed butterfly: every lane ends with the same bits)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v = gmx_fmax(v, __shfl_xor(v, m, GMX_WAVE));
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v = v + __shfl_xor(v, m, GMX_WAVE);
+  return v;
+}
+// block of 256 threads = 4 waves; result broadcast to all threads
+__device__ __forceinline__ float block_max(float v, float* lds4) {
+  v = wave_max(v);
+  int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) lds4[w] = v;
+  __syncthreads();
+  float r = gmx_fmax(gmx_fmax(lds4[0], lds4[1]), gmx_fmax(lds4[2], lds4[3]));
+  return r;
+}
+__device__ __forceinline__ float block_sum(float v, float* lds4) {
+  v = wave_sum(v);
+  int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) lds4[w] = v;
+  __syncthreads();
+  float r = (lds4[0] + lds4[1]) + (lds4[2] + lds4[3]);
+  return r;
+}
+
+// ---------------------------------------------------------------------------
+// site-program interpreter
+// ---------------------------------------------------------------------------
+struct DevCtx {
+  float* red_out;
+  float* lds4;
+  __device__ __forceinline__ uint32_t uniform(uint32_t x) const {
+    return __builtin_amdgcn_readfirstlane(x);
+  }
+  __device__ __forceinline__ void red_max(float x, bool active) {
+    float m = block_max(active ? x : -gmx_inf(), lds4);
+    if (threadIdx.x == 0 && red_out) red_out[2 * (size_t)blockIdx.x] = m;
+  }
+  __device__ __forceinline__ void red_lse(float x, bool active) {
+    float m = block_max(active ? x : -gmx_inf(), lds4);
+    float e = active ? gmx_expf(x - m) : 0.0f;
+    if (!(m > -gmx_inf())) e = 0.0f;  // empty / all -inf block
+    float s = block_sum(e, lds4);
+    if (threadIdx.x == 0 && red_out) {
+      red_out[2 * (size_t)blockIdx.x] = m;
+      red_out[2 * (size_t)blockIdx.x + 1] = s;
+    }
+  }
+};
+
+template <class Regs>
+__global__ void __launch_bounds__(GMX_BLOCK)
+k_vm(const uint32_t* __restrict__ code, uint32_t n_instr, int64_t n, const gmx_run_args A) {
+  __shared__ float lds4[4];
+  int64_t i = (int64_t)blockIdx.x * GMX_BLOCK + threadIdx.x;
+  DevCtx ctx;
+  ctx.red_out = A.red_out_d;
+  ctx.lds4 = lds4;
+  gmx_vm_run<Regs, DevCtx>(code, n_instr, i, i < n, A, ctx);
+}
+
+struct gmx_program {
+  uint32_t* code_d;
+  uint32_t n_instr, n_regs, n_in, n_out, n_uni, n_tab;
+  bool uses_key, uses_red, uses_gather;
+};
+
+extern "C" int gmx_program_create(const uint32_t* blob, size_t n_words, gmx_program** out) {
+  if (!blob || !out) return gmx_fail("gmx_program_create: null argument%s");
+  if (n_words < GMX_PROG_HEADER_WORDS) return gmx_fail("gmx_program_create: blob too short%s");
+  if (blob[0] != GMX_PROG_MAGIC) return gmx_fail("gmx_program_create: bad magic%s");
+  if (blob[1] != GMX_PROG_VERSION) return gmx_fail("gmx_program_create: bad version%s");
+  uint32_t n_instr = blob[2], n_regs = blob[3];
+  if (n_words != GMX_PROG_HEADER_WORDS + 2ull * n_instr)
+    return gmx_fail("gmx_program_create: length does not match n_instr%s");
+  if (n_regs == 0 || n_regs > 32)
+    return gmx_fail("gmx_program_create: n_regs must be in [1,32] (got %s%lld)", "", n_regs);
+  if (blob[4] > GMX_MAX_IN || blob[5] > GMX_MAX_OUT || blob[6] > GMX_MAX_UNI || blob[7] > GMX_MAX_TAB)
+    return gmx_fail("gmx_program_create: slot count exceeds ABI limits%s");
+  gmx_program P;
+  memset(&P, 0, sizeof(P));
+  P.n_instr = n_instr; P.n_regs = n_regs;
+  P.n_in = blob[4]; P.n_out = blob[5]; P.n_uni = blob[6]; P.n_tab = blob[7];
+  // validate every instruction: register / slot indices must be in range so
+  // the kernel never needs a bounds check
+  const uint32_t* ins = blob + GMX_PROG_HEADER_WORDS;
+  for (uint32_t pc = 0; pc < n_instr; ++pc) {
+    uint32_t w0 = ins[2 * pc], w1 = ins[2 * pc + 1];
+    uint32_t op = w0 & 0xff, dst = (w0 >> 8) & 0xff, a = (w0 >> 16) & 0xff, b = w0 >> 24;
+    uint32_t c = w1 & 0xff;
+    bool ok = true;
+    auto R = [&](uint32_t r) { return r < n_regs; };
+    auto R2 = [&](uint32_t r) { return r + 1 < n_regs; };
+    switch (op) {
+      case OP_END: break;
+      case OP_CONST: ok = R(dst); break;
+      case OP_UNI: ok = R(dst) && w1 < P.n_uni; break;
+      case OP_LDIN: ok = R(dst) && a < P.n_in; if (b & GMX_F_GATHER) P.uses_gather = true; break;
+      case OP_LDTAB: ok = R(dst) && R(b) && a < P.n_tab; break;
+      case OP_STOUT: ok = R(b) && a < P.n_out; break;
+      case OP_LDKEY: ok = R2(dst); P.uses_key = true; break;
+      case OP_KDERIVE: ok = R2(dst) && R2(a); break;
+      case OP_KDERIVER: ok = R2(dst) && R2(a) && R(b); break;
+      case OP_MOV: case OP_NEG: case OP_ABS: case OP_EXP: case OP_LOG: case OP_LOG1P:
+      case OP_SQRT: case OP_SIN: case OP_COS: case OP_TANH: case OP_SIGMOID:
+      case OP_SOFTPLUS: case OP_FLOOR: case OP_CEIL: case OP_ROUND: case OP_LGAMMA:
+      case OP_SQUARE: case OP_RECIP: case OP_NOT: case OP_I2F: case OP_F2I: case OP_INEG:
+        ok = R(dst) && R(a); break;
+      case OP_ADD: case OP_SUB: case OP_MUL: case OP_DIV: case OP_MIN: case OP_MAX: case OP_POW:
+      case OP_FLT: case OP_FLE: case OP_FGT: case OP_FGE: case OP_FEQ: case OP_FNE:
+      case OP_IEQ: case OP_INE: case OP_ILT: case OP_ILE: case OP_IGT: case OP_IGE:
+      case OP_AND: case OP_OR: case OP_XOR: case OP_IADD: case OP_ISUB: case OP_IMUL:
+        ok = R(dst) && R(a) && R(b); break;
+      case OP_SEL: ok = R(dst) && R(a) && R(b) && R(c); break;
+      case OP_S_NORMAL: case OP_S_UNIFORM: case OP_S_BETA:
+        ok = R(dst) && R(a) && R(b) && R2(c); break;
+      case OP_S_FLIP: case OP_S_BERNL: ok = R(dst) && R(a) && R2(c); break;
+      case OP_S_CATSTEP: ok = R2(dst) && R(a) && R(b) && R2(c); break;
+      case OP_L_NORMAL: case OP_L_UNIFORM: case OP_L_BETA:
+        ok = R(dst) && R(a) && R(b) && R(c); break;
+      case OP_L_FLIP: case OP_L_BERNL: ok = R(dst) && R(a) && R(c); break;
+      case OP_REDMAX: case OP_REDLSE: ok = R(a); P.uses_red = true; break;
+      default: ok = false;
+    }
+    if (!ok) return gmx_fail("gmx_program_create: invalid instruction%s at pc %lld", "", pc);
+  }
+  GMX_HIP(hipMalloc((void**)&P.code_d, sizeof(uint32_t) * 2 * (n_instr ? n_instr : 1)));
+  if (n_instr)
+    GMX_HIP(hipMemcpy(P.code_d, ins, sizeof(uint32_t) * 2 * n_instr, hipMemcpyHostToDevice));
+  gmx_program* h = new (std::nothrow) gmx_program(P);
+  if (!h) return gmx_fail("gmx_program_create: out of host memory%s");
+  *out = h;
+  return 0;
+}
+
+extern "C" int gmx_program_destroy(gmx_program* p) {
+  if (!p) return 0;
+  if (p->code_d) (void)hipFree(p->code_d);
+  delete p;
+  return 0;
+}
+
+extern "C" int64_t gmx_program_grid(const gmx_program* p, int64_t n) {
+  (void)p;
+  return (n + GMX_BLOCK - 1) / GMX_BLOCK;
+}
+
+extern "C" int gmx_program_run(const gmx_program* p, int64_t n, const gmx_run_args* args,
+                               gmx_stream stream) {
+  if (!p || !args) return gmx_fail("gmx_program_run: null argument%s");
+  if (n < 0) return gmx_fail("gmx_program_run: negative n%s");
+  if (n == 0) return 0;
+  if (n > (int64_t)0x7fffffff * GMX_BLOCK) return gmx_fail("gmx_program_run: n too large%s");
+  // host-side shape checks: every slot the program names must be bound
+  for (uint32_t s = 0; s < p->n_in; ++s)
+    if (!args->in_d[s]) return gmx_fail("gmx_program_run: input slot %s%lld is null", "", s);
+  for (uint32_t s = 0; s < p->n_out; ++s)
+    if (!args->out_d[s]) return gmx_fail("gmx_program_run: output slot %s%lld is null", "", s);
+  for (uint32_t s = 0; s < p->n_tab; ++s)
+    if (!args->tab_d[s]) return gmx_fail("gmx_program_run: table slot %s%lld is null", "", s);
+  if (p->uses_gather && !args->ancestors_d)
+    return gmx_fail("gmx_program_run: program gathers but ancestors_d is null%s");
+  if (p->uses_red && !args->red_out_d)
+    return gmx_fail("gmx_program_run: program reduces but red_out_d is null%s");
+  if (p->uses_key) {
+    int km = args->key_mode;
+    if (km != GMX_KEY_ARRAY && km != GMX_KEY_SPLIT && km != GMX_KEY_ROWSPLIT && km != GMX_KEY_BCAST)
+      return gmx_fail("gmx_program_run: program draws but key_mode is unset%s");
+    if ((km == GMX_KEY_ARRAY || km == GMX_KEY_ROWSPLIT) && !args->keys_d)
+      return gmx_fail("gmx_program_run: keys_d is null%s");
+    if (km == GMX_KEY_ROWSPLIT && args->key_inner <= 0)
+      return gmx_fail("gmx_program_run: key_inner must be positive%s");
+  }
+  dim3 grid((unsigned)((n + GMX_BLOCK - 1) / GMX_BLOCK)), block(GMX_BLOCK);
+  hipStream_t st = (hipStream_t)stream;
+  if (p->n_regs <= 16)
+    hipLaunchKernelGGL(k_vm<gmx_regs_vgpr<16>>, grid, block, 0, st, p->code_d, p->n_instr, n, *args);
+  else
+    hipLaunchKernelGGL(k_vm<gmx_regs_vgpr<32>>, grid, block, 0, st, p->code_d, p->n_instr, n, *args);
+  GMX_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// key kernels
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(GMX_BLOCK)
+k_split(uint32_t k0, uint32_t k1, int64_t n, int64_t off, uint32_t* __restrict__ out) {
+  int64_t i = (int64_t)blockIdx.x * GMX_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  gmx_key k; k.k0 = k0; k.k1 = k1;
+  gmx_key o = gmx_split_child(k, (uint64_t)(off + i));
+  reinterpret_cast<uint2*>(out)[i] = make_uint2(o.k0, o.k1);
+}
+__global__ void __launch_bounds__(GMX_BLOCK)
+k_split_rows(const uint32_t* __restrict__ keys, int64_t rows, int64_t inner,
+             uint32_t* __restrict__ out) {
+  int64_t i = (int64_t)blockIdx.x * GMX_BLOCK + threadIdx.x;
+  if (i >= rows * inner) return;
+  int64_t r = i / inner, j = i - r * inner;
+  uint2 kk = reinterpret_cast<const uint2*>(keys)[r];
+  gmx_key k; k.k0 = kk.x; k.k1 = kk.y;
+  gmx_key o = gmx_split_child(k, (uint64_t)j);
+  reinterpret_cast<uint2*>(out)[i] = make_uint2(o.k0, o.k1);
+}
+__global__ void __launch_bounds__(GMX_BLOCK)
+k_fold_in(const uint32_t* __restrict__ keys, uint32_t data, int64_t n, uint32_t* __restrict__ out) {
+  int64_t i = (int64_t)blockIdx.x * GMX_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  uint2 kk = reinterpret_cast<const uint2*>(keys)[i];
+  gmx_key k; k.k0 = kk.x; k.k1 = kk.y;
+  gmx_key o = gmx_fold_in(k, data);
+  reinterpret_cast<uint2*>(out)[i] = make_uint2(o.k0, o.k1);
+}
+__global__ void __launch_bounds__(GMX_BLOCK)
+k_random_bits(const uint32_t* __restrict__ keys, int64_t n, int64_t m, uint32_t* __restrict__ out) {
+  int64_t t = (int64_t)blockIdx.x * GMX_BLOCK + threadIdx.x;
+  if (t >= n * m) return;
+  int64_t i = t / m, j = t - i * m;
+  uint2 kk = reinterpret_cast<const uint2*>(keys)[i];
+  gmx_key k; k.k0 = kk.x; k.k1 = kk.y;
+  out[t] = gmx_bits32(k, (uint64_t)j);
+}
+
+static inline dim3 grid_for(int64_t n) { return dim3((unsigned)((n + GMX_BLOCK - 1) / GMX_BLOCK)); }
+
+extern "C" int gmx_split(const uint32_t key[2], int64_t n, int64_t index_offset,
+                         uint32_t* out_keys_d, gmx_stream stream) {
+  if (!key || (n > 0 && !out_keys_d)) return gmx_fail("gmx_split: null argument%s");
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(k_split, grid_for(n), dim3(GMX_BLOCK), 0, (hipStream_t)stream, key[0], key[1],
+                     n, index_offset, out_keys_d);
+  GMX_HIP(hipGetLastError());
+  return 0;
+}
+extern "C" int gmx_split_rows(const uint32_t* keys_d, int64_t rows, int64_t inner,
+                              uint32_t* out_keys_d, gmx_stream stream) {
+  if (rows <= 0 || inner <= 0) return 0;
+  if (!keys_d || !out_keys_d) return gmx_fail("gmx_split_rows: null argument%s");
+  hipLaunchKernelGGL(k_split_rows, grid_for(rows * inner), dim3(GMX_BLOCK), 0, (hipStream_t)stream,
+                     keys_d, rows, inner, out_keys_d);
+  GMX_HIP(hipGetLastError());
+  return 0;
+}
+extern "C" int gmx_fold_in(const uint32_t* keys_d, uint32_t data, int64_t n, uint32_t* out_d,
+                           gmx_stream stream) {
+  if (n <= 0) return 0;
+  if (!keys_d || !out_d) return gmx_fail("gmx_fold_in: null argument%s");
+  hipLaunchKernelGGL(k_fold_in, grid_for(n), dim3(GMX_BLOCK), 0, (hipStream_t)stream, keys_d, data, n,
+                     out_d);
+  GMX_HIP(hipGetLastError());
+  return 0;
+}
+extern "C" int gmx_random_bits(const uint32_t* keys_d, int64_t n, int64_t m, uint32_t* out_d,
+                               gmx_stream stream) {
+  if (n <= 0 || m <= 0) return 0;
+  if (!keys_d || !out_d) return gmx_fail("gmx_random_bits: null argument%s");
+  hipLaunchKernelGGL(k_random_bits, grid_for(n * m), dim3(GMX_BLOCK), 0, (hipStream_t)stream, keys_d,
+                     n, m, out_d);
+  GMX_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// log-sum-exp
+// ---------------------------------------------------------------------------
+#define LSE_ITEMS 16
+#define LSE_TILE (GMX_BLOCK * LSE_ITEMS)
+
+// stage 1: one block per (row, tile) -> partial (max, sum exp(x - max))
+__global__ void __launch_bounds__(GMX_BLOCK)
+k_lse_tiles(const float* __restrict__ lw, int64_t cols, int64_t tiles_per_row,
+            float* __restrict__ partials) {
+  __shared__ float lds4[4];
+  int64_t row = blockIdx.y, tile = blockIdx.x;
+  const float* x = lw + row * cols;
+  int64_t base = tile * LSE_TILE;
+  float v[LSE_ITEMS];
+  float m = -gmx_inf();
+#pragma unroll
+  for (int k = 0; k < LSE_ITEMS; ++k) {
+    int64_t j = base + (int64_t)k * GMX_BLOCK + threadIdx.x;   // coalesced per k
+    v[k] = (j < cols) ? x[j] : -gmx_inf();
+    m = gmx_fmax(m, v[k]);
+  }
+  m = block_max(m, lds4);
+  float s = 0.0f;
+  if (m > -gmx_inf()) {
+#pragma unroll
+    for (int k = 0; k < LSE_ITEMS; ++k) s += gmx_expf(v[k] - m);
+  }
+  s = block_sum(s, lds4);
+  if (threadIdx.x == 0) {
+    float* p = partials + 2 * (row * tiles_per_row + tile);
+    p[0] = m; p[1] = s;
+  }
+}
+// stage 2: one block per row combines partials in a fixed order
+__global__ void __launch_bounds__(GMX_BLOCK)
+k_lse_final(const float* __restrict__ partials, int64_t n_part, float* __restrict__ out,
+            float* __restrict__ out_max) {
+  __shared__ float lds4[4];
+  int64_t row = blockIdx.x;
+  const float* p = partials + 2 * row * n_part;
+  float m = -gmx_inf();
+  for (int64_t j = threadIdx.x; j < n_part; j += GMX_BLOCK) m = gmx_fmax(m, p[2 * j]);
+  m = block_max(m, lds4);
+  float s = 0.0f;
+  if (m > -gmx_inf())
+    for (int64_t j = threadIdx.x; j < n_part; j += GMX_BLOCK)
+      s += p[2 * j + 1] * gmx_expf(p[2 * j] - m);
+  s = block_sum(s, lds4);
+  if (threadIdx.x == 0) {
+    out[row] = (m > -gmx_inf()) ? m + gmx_logf(s) : m;
+    if (out_max) out_max[row] = m;
+  }
+}
+// many short rows: one wave per row
+__global__ void __launch_bounds__(GMX_BLOCK)
+k_lse_rows(const float* __restrict__ lw, int64_t rows, int64_t cols, float* __restrict__ out,
+           float* __restrict__ out_max) {
+  int64_t row = (int64_t)blockIdx.x * (GMX_BLOCK / GMX_WAVE) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  int lane = threadIdx.x & 63;
+  const float* x = lw + row * cols;
+  float m = -gmx_inf();
+  for (int64_t j = lane; j < cols; j += GMX_WAVE) m = gmx_fmax(m, x[j]);
+  m = wave_max(m);
+  float s = 0.0f;
+  if (m > -gmx_inf())
+    for (int64_t j = lane; j < cols; j += GMX_WAVE) s += gmx_expf(x[j] - m);
+  s = wave_sum(s);
+  if (lane == 0) {
+    out[row] = (m > -gmx_inf()) ? m + gmx_logf(s) : m;
+    if (out_max) out_max[row] = m;
+  }
+}
+
+#define LSE_ROWS_PATH_MAX_COLS 4096
+static inline bool lse_use_rows_path(int64_t rows, int64_t cols) {
+  return rows >= 32 && cols <= LSE_ROWS_PATH_MAX_COLS;
+}
+extern "C" size_t gmx_logsumexp_workspace(int64_t rows, int64_t cols) {
+  if (rows <= 0 || cols <= 0 || lse_use_rows_path(rows, cols)) return 16;
+  int64_t tiles = (cols + LSE_TILE - 1) / LSE_TILE;
+  return (size_t)(rows * tiles * 2 * sizeof(float)) + 16;
+}
+extern "C" int gmx_logsumexp(const float* lw_d, int64_t rows, int64_t cols, float* out_d,
+                             float* out_max_d, void* workspace_d, gmx_stream stream) {
+  if (rows <= 0) return 0;
+  if (cols <= 0) return gmx_fail("gmx_logsumexp: cols must be positive%s");
+  if (!lw_d || !out_d) return gmx_fail("gmx_logsumexp: null argument%s");
+  hipStream_t st = (hipStream_t)stream;
+  if (lse_use_rows_path(rows, cols)) {
+    int64_t blocks = (rows + 3) / 4;
+    hipLaunchKernelGGL(k_lse_rows, dim3((unsigned)blocks), dim3(GMX_BLOCK), 0, st, lw_d, rows, cols,
+                       out_d, out_max_d);
+  } else {
+    if (!workspace_d) return gmx_fail("gmx_logsumexp: workspace required%s");
+    if (rows > 65535) return gmx_fail("gmx_logsumexp: too many long rows%s");
+    int64_t tiles = (cols + LSE_TILE - 1) / LSE_TILE;
+    float* part = (float*)workspace_d;
+    hipLaunchKernelGGL(k_lse_tiles, dim3((unsigned)tiles, (unsigned)rows), dim3(GMX_BLOCK), 0, st,
+                       lw_d, cols, tiles, part);
+    hipLaunchKernelGGL(k_lse_final, dim3((unsigned)rows), dim3(GMX_BLOCK), 0, st, part, tiles, out_d,
+                       out_max_d);
+  }
+  GMX_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// fixed-point weights + chained inclusive scan (single pass, decoupled look-back)
+// ---------------------------------------------------------------------------
+#define CDF_ITEMS 4
+#define CDF_TILE (GMX_BLOCK * CDF_ITEMS)
+#define CDF_ST_AGG 1ull
+#define CDF_ST_INC 2ull
+#define CDF_SPIN_LIMIT (1u << 24)
+
+// workspace layout: [0] u32 ticket, [1] u32 error flag, then (8-byte aligned)
+// one u64 descriptor per tile: value << 2 | status.  value < 2^62 by the
+// choice of `shift`, so the packed word is a single naturally aligned 8-byte
+// granule: written and read with relaxed agent-scope atomics, it needs no
+// ordering against any other memory.
+struct cdf_ws { uint32_t ticket; uint32_t error; uint64_t desc[1]; };
+
+extern "C" size_t gmx_weight_cdf_workspace(int64_t n) {
+  int64_t tiles = (n + CDF_TILE - 1) / CDF_TILE;
+  if (tiles < 1) tiles = 1;
+  return 8 + (size_t)tiles * 8;
+}
+
+__device__ __forceinline__ uint64_t shfl_up_u64(uint64_t v, int d) {
+  uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+  lo = __shfl_up(lo, d, GMX_WAVE);
+  hi = __shfl_up(hi, d, GMX_WAVE);
+  return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t shfl_u64(uint64_t v, int src) {
+  uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+  lo = __shfl(lo, src, GMX_WAVE);
+  hi = __shfl(hi, src, GMX_WAVE);
+  return ((uint64_t)hi << 32) | lo;
+}
+
+// q = floor(exp(lw - M) * 2^shift) as u64; NaN / negative -> 0
+__device__ __forceinline__ uint64_t weight_fixed(float lw, float M, float scale) {
+  float w = gmx_expf(lw - M);          // in [0, 1]; NaN if lw - M is NaN
+  float q = w * scale;                 // exact: scale is a power of two
+  if (!(q >= 0.0f)) return 0ull;
+  return (uint64_t)q;                  // truncation; q < 2^63
+}
+
+__global__ void __launch_bounds__(GMX_BLOCK)
+k_reduce_max(const float* __restrict__ partials, int64_t n_part, float* __restrict__ max_out) {
+  __shared__ float lds4[4];
+  float m = -gmx_inf();
+  for (int64_t j = threadIdx.x; j < n_part; j += GMX_BLOCK) m = gmx_fmax(m, partials[2 * j]);
+  m = block_max(m, lds4);
+  if (threadIdx.x == 0) *max_out = m;
+}
+
+__global__ void __launch_bounds__(GMX_BLOCK)
+k_weight_cdf(const float* __restrict__ lw, int64_t n, float scale, const float* __restrict__ max_d,
+             uint64_t* __restrict__ cdf, uint64_t* __restrict__ total_out, cdf_ws* ws) {
+  __shared__ uint64_t s_wave[4];
+  __shared__ uint64_t s_prefix;
+  __shared__ uint32_t s_tile;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // dynamic tile id: a tile only ever waits on tiles whose blocks already run
+  if (threadIdx.x == 0) s_tile = atomicAdd(&ws->ticket, 1u);
+  __syncthreads();
+  const uint32_t tile = s_tile;
+  const int64_t n_tiles = (n + CDF_TILE - 1) / CDF_TILE;
+  if ((int64_t)tile >= n_tiles) return;
+  const float M = *max_d;
+  const int64_t base = (int64_t)tile * CDF_TILE + (int64_t)threadIdx.x * CDF_ITEMS;
+  // 4 consecutive floats per thread (16-byte load when fully in range)
+  float x[CDF_ITEMS];
+  if (base + CDF_ITEMS <= n) {
+    float4 v = *reinterpret_cast<const float4*>(lw + base);
+    x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
+  } else {
+#pragma unroll
+    for (int k = 0; k < CDF_ITEMS; ++k) x[k] = (base + k < n) ? lw[base + k] : -gmx_inf();
+  }
+  uint64_t q[CDF_ITEMS];
+  uint64_t run = 0;
+#pragma unroll
+  for (int k = 0; k < CDF_ITEMS; ++k) {
+    uint64_t w = (base + k < n) ? weight_fixed(x[k], M, scale) : 0ull;
+    run += w;
+    q[k] = run;                        // thread-local inclusive
+  }
+  // wave inclusive scan of thread totals
+  uint64_t inc = run;
+#pragma unroll
+  for (int d = 1; d < GMX_WAVE; d <<= 1) {
+    uint64_t t = shfl_up_u64(inc, d);
+    if (lane >= d) inc += t;
+  }
+  if (lane == 63) s_wave[wave] = inc;
+  __syncthreads();
+  uint64_t wave_off = 0;
+  for (int w = 0; w < wave; ++w) wave_off += s_wave[w];
+  const uint64_t tile_agg = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+  // ---- chained scan across tiles ----
+  if (wave == 0) {
+    uint64_t prefix = 0;
+    if (tile == 0) {
+      if (lane == 0)
+        __hip_atomic_store(&ws->desc[0], (tile_agg << 2) | CDF_ST_INC, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      if (lane == 0)
+        __hip_atomic_store(&ws->desc[tile], (tile_agg << 2) | CDF_ST_AGG, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      int64_t look = (int64_t)tile - 1;     // window = tiles look - lane
+      uint32_t spins = 0;
+      bool done = false;
+      while (!done) {
+        int64_t t = look - lane;
+        uint64_t d = (t >= 0) ? __hip_atomic_load(&ws->desc[t], __ATOMIC_RELAXED,
+                                                  __HIP_MEMORY_SCOPE_AGENT)
+                              : CDF_ST_INC;   // virtual tile -1: inclusive prefix 0
+        uint64_t st = d & 3ull;
+        unsigned long long inc_mask = __ballot(st == CDF_ST_INC);
+        unsigned long long none_mask = __ballot(st == 0ull);
+        // lanes before the first inclusive one must all be ready
+        int first_inc = inc_mask ? __builtin_ctzll(inc_mask) : 64;
+        unsigned long long need = (first_inc >= 64) ? ~0ull : ((1ull << first_inc) | ((1ull << first_inc) - 1ull));
+        if (none_mask & need) {
+          if (++spins > CDF_SPIN_LIMIT) { if (lane == 0) ws->error = 1u; break; }
+          __builtin_amdgcn_s_sleep(1);
+          continue;
+        }
+        uint64_t contrib = (lane <= first_inc) ? (d >> 2) : 0ull;
+        // wave sum of contrib (u64 butterfly)
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+          uint32_t lo = (uint32_t)contrib, hi = (uint32_t)(contrib >> 32);
+          lo = __shfl_xor(lo, m, GMX_WAVE); hi = __shfl_xor(hi, m, GMX_WAVE);
+          contrib += ((uint64_t)hi << 32) | lo;
+        }
+        prefix += contrib;
+        if (first_inc < 64) done = true; else look -= GMX_WAVE;
+      }
+      if (lane == 0)
+        __hip_atomic_store(&ws->desc[tile], ((prefix + tile_agg) << 2) | CDF_ST_INC,
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (lane == 0) s_prefix = prefix;
+  }
+  __syncthreads();
+  const uint64_t off = s_prefix + wave_off + (inc - run);
+  if (base + CDF_ITEMS <= n) {
+    ulonglong2 a, b;
+    a.x = off + q[0]; a.y = off + q[1]; b.x = off + q[2]; b.y = off + q[3];
+    reinterpret_cast<ulonglong2*>(cdf + base)[0] = a;
+    reinterpret_cast<ulonglong2*>(cdf + base)[1] = b;
+  } else {
+#pragma unroll
+    for (int k = 0; k < CDF_ITEMS; ++k)
+      if (base + k < n) cdf[base + k] = off + q[k];
+  }
+  if ((int64_t)tile == n_tiles - 1 && threadIdx.x == 0) *total_out = s_prefix + tile_agg;
+}
+
+extern "C" int gmx_weight_cdf(const float* lw_d, int64_t n, int shift,
+                              const float* max_partials_d, int64_t n_partials, float* max_d,
+                              uint64_t* cdf_d, uint64_t* total_d, void* workspace_d,
+                              gmx_stream stream) {
+  if (n <= 0) return gmx_fail("gmx_weight_cdf: n must be positive%s");
+  if (!lw_d || !max_d || !cdf_d || !total_d || !workspace_d)
+    return gmx_fail("gmx_weight_cdf: null argument%s");
+  if (shift < 1 || shift > 62) return gmx_fail("gmx_weight_cdf: shift out of range%s");
+  // a sum of n terms each <= 2^shift must stay below 2^62
+  int need = 0;
+  while (((int64_t)1 << need) < n) ++need;
+  if (shift + need > 62) return gmx_fail("gmx_weight_cdf: shift too large for n (overflow)%s");
+  if (((uintptr_t)lw_d & 15) || ((uintptr_t)cdf_d & 15))
+    return gmx_fail("gmx_weight_cdf: lw_d and cdf_d must be 16-byte aligned%s");
+  hipStream_t st = (hipStream_t)stream;
+  if (max_partials_d) {
+    if (n_partials <= 0) return gmx_fail("gmx_weight_cdf: n_partials must be positive%s");
+    hipLaunchKernelGGL(k_reduce_max, dim3(1), dim3(GMX_BLOCK), 0, st, max_partials_d, n_partials,
+                       max_d);
+  }
+  GMX_HIP(hipMemsetAsync(workspace_d, 0, gmx_weight_cdf_workspace(n), st));
+  int64_t tiles = (n + CDF_TILE - 1) / CDF_TILE;
+  float scale = gmx_pow2i(shift);
+  hipLaunchKernelGGL(k_weight_cdf, dim3((unsigned)tiles), dim3(GMX_BLOCK), 0, st, lw_d, n, scale,
+                     max_d, cdf_d, total_d, (cdf_ws*)workspace_d);
+  GMX_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// ancestors: exact inverse-CDF search
+// ---------------------------------------------------------------------------
+struct u128 { uint64_t hi, lo; };
+__device__ __forceinline__ u128 mul64(uint64_t a, uint64_t b) {
+  u128 r; r.lo = a * b; r.hi = __umul64hi(a, b); return r;
+}
+__device__ __forceinline__ bool gt128(u128 a, u128 b) {
+  return a.hi > b.hi || (a.hi == b.hi && a.lo > b.lo);
+}
+
+__global__ void __launch_bounds__(GMX_BLOCK)
+k_ancestors(int kind, uint32_t k0, uint32_t k1, const uint64_t* __restrict__ cdf, int64_t n_in,
+            uint64_t cdf_offset, const uint64_t* __restrict__ total_d, int64_t n_out_total,
+            int64_t slot_offset, int64_t n_slots, int32_t* __restrict__ anc) {
+  int64_t s = (int64_t)blockIdx.x * GMX_BLOCK + threadIdx.x;
+  if (s >= n_slots) return;
+  const uint64_t total = *total_d;
+  const int64_t j = slot_offset + s;
+  gmx_key key; key.k0 = k0; key.k1 = k1;
+  uint64_t D;      // multiplier of the CDF side
+  u128 P;          // threshold: ancestor = first i with (cdf_i + off) * D > P
+  if (kind == GMX_RESAMPLE_MULTINOMIAL) {
+    uint64_t u = gmx_bits32(key, (uint64_t)j) >> 9;
+    D = 1ull << 23;
+    P = mul64(total, (1ull << 23) - u);
+    // cdf*D >= P  <=>  cdf*D > P - 1   (P >= 1 whenever total >= 1)
+    if (P.lo == 0) { if (P.hi) { P.hi -= 1; P.lo = ~0ull; } } else P.lo -= 1;
+  } else {
+    uint64_t u = (kind == GMX_RESAMPLE_SYSTEMATIC) ? (gmx_bits32(key, 0) >> 9)
+                                                   : (gmx_bits32(key, (uint64_t)j) >> 9);
+    D = (uint64_t)n_out_total << 23;
+    P = mul64(((uint64_t)j << 23) + u, total);
+  }
+  // binary search for the first i in [0, n_in) with (cdf[i] + off) * D > P
+  int64_t lo = 0, hi = n_in;            // answer in [lo, hi]; hi == n_in means none
+  while (lo < hi) {
+    int64_t mid = lo + ((hi - lo) >> 1);
+    u128 c = mul64(cdf[mid] + cdf_offset, D);
+    if (gt128(c, P)) hi = mid; else lo = mid + 1;
+  }
+  if (lo >= n_in) lo = n_in - 1;        // only reachable when total == 0 or off-shard
+  anc[s] = (int32_t)lo;
+}
+
+extern "C" int gmx_ancestors(int kind, const uint32_t key[2], const uint64_t* cdf_d, int64_t n_in,
+                             uint64_t cdf_offset, const uint64_t* total_d, int64_t n_out_total,
+                             int64_t slot_offset, int64_t n_slots, int32_t* ancestors_d,
+                             gmx_stream stream) {
+  if (n_slots <= 0) return 0;
+  if (!key || !cdf_d || !total_d || !ancestors_d) return gmx_fail("gmx_ancestors: null argument%s");
+  if (kind < 0 || kind > 2) return gmx_fail("gmx_ancestors: unknown kind%s");
+  if (n_in <= 0 || n_in > 0x7fffffffLL) return gmx_fail("gmx_ancestors: n_in out of range%s");
+  if (n_out_total <= 0 || n_out_total >= (1LL << 40))
+    return gmx_fail("gmx_ancestors: n_out_total out of range%s");
+  if (slot_offset < 0 || slot_offset + n_slots > n_out_total)
+    return gmx_fail("gmx_ancestors: slot range outside [0, n_out_total)%s");
+  hipLaunchKernelGGL(k_ancestors, grid_for(n_slots), dim3(GMX_BLOCK), 0, (hipStream_t)stream, kind,
+                     key[0], key[1], cdf_d, n_in, cdf_offset, total_d, n_out_total, slot_offset,
+                     n_slots, ancestors_d);
+  GMX_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// gather / select over a table of leaves
+// ---------------------------------------------------------------------------
+#define GMX_MAX_LEAVES 32
+struct leaf_table {
+  const void* a[GMX_MAX_LEAVES];
+  const void* b[GMX_MAX_LEAVES];
+  void* out[GMX_MAX_LEAVES];
+  int32_t bytes[GMX_MAX_LEAVES];
+  int32_t n;
+};
+
+__device__ __forceinline__ void copy_elem(void* dst, int64_t di, const void* src, int64_t si, int bytes) {
+  if (bytes == 4) ((uint32_t*)dst)[di] = ((const uint32_t*)src)[si];
+  else if (bytes == 1) ((uint8_t*)dst)[di] = ((const uint8_t*)src)[si];
+  else if (bytes == 8) ((uint64_t*)dst)[di] = ((const uint64_t*)src)[si];
+  else if (bytes == 2) ((uint16_t*)dst)[di] = ((const uint16_t*)src)[si];
+  else {
+    const uint8_t* s = (const uint8_t*)src + si * bytes;
+    uint8_t* d = (uint8_t*)dst + di * bytes;
+    for (int k = 0; k < bytes; ++k) d[k] = s[k];
+  }
+}
+
+__global__ void __launch_bounds__(GMX_BLOCK)
+k_gather(const leaf_table T, const int32_t* __restrict__ anc, int64_t n_out) {
+  int64_t j = (int64_t)blockIdx.x * GMX_BLOCK + threadIdx.x;
+  if (j >= n_out) return;
+  int64_t a = anc[j];
+  for (int l = 0; l < T.n; ++l) copy_elem(T.out[l], j, T.a[l], a, T.bytes[l]);
+}
+__global__ void __launch_bounds__(GMX_BLOCK)
+k_select(const leaf_table T, const uint8_t* __restrict__ mask, int64_t n) {
+  int64_t j = (int64_t)blockIdx.x * GMX_BLOCK + threadIdx.x;
+  if (j >= n) return;
+  bool m = mask[j] != 0;
+  for (int l = 0; l < T.n; ++l) copy_elem(T.out[l], j, m ? T.a[l] : T.b[l], j, T.bytes[l]);
+}
+
+extern "C" int gmx_gather(const void* const* src_d, void* const* dst_d, const int32_t* elem_bytes,
+                          int32_t n_leaves, const int32_t* ancestors_d, int64_t n_out,
+                          gmx_stream stream) {
+  if (n_out <= 0 || n_leaves <= 0) return 0;
+  if (!src_d || !dst_d || !elem_bytes || !ancestors_d) return gmx_fail("gmx_gather: null argument%s");
+  for (int32_t base = 0; base < n_leaves; base += GMX_MAX_LEAVES) {
+    leaf_table T;
+    memset(&T, 0, sizeof(T));
+    T.n = (n_leaves - base < GMX_MAX_LEAVES) ? n_leaves - base : GMX_MAX_LEAVES;
+    for (int l = 0; l < T.n; ++l) {
+      if (!src_d[base + l] || !dst_d[base + l]) return gmx_fail("gmx_gather: null leaf%s");
+      if (elem_bytes[base + l] <= 0) return gmx_fail("gmx_gather: bad element size%s");
+      T.a[l] = src_d[base + l]; T.out[l] = dst_d[base + l]; T.bytes[l] = elem_bytes[base + l];
+    }
+    hipLaunchKernelGGL(k_gather, grid_for(n_out), dim3(GMX_BLOCK), 0, (hipStream_t)stream, T,
+                       ancestors_d, n_out);
+  }
+  GMX_HIP(hipGetLastError());
+  return 0;
+}
+extern "C" int gmx_select(const uint8_t* mask_d, const void* const* a_d, const void* const* b_d,
+                          void* const* out_d, const int32_t* elem_bytes, int32_t n_leaves, int64_t n,
+                          gmx_stream stream) {
+  if (n <= 0 || n_leaves <= 0) return 0;
+  if (!mask_d || !a_d || !b_d || !out_d || !elem_bytes) return gmx_fail("gmx_select: null argument%s");
+  for (int32_t base = 0; base < n_leaves; base += GMX_MAX_LEAVES) {
+    leaf_table T;
+    memset(&T, 0, sizeof(T));
+    T.n = (n_leaves - base < GMX_MAX_LEAVES) ? n_leaves - base : GMX_MAX_LEAVES;
+    for (int l = 0; l < T.n; ++l) {
+      if (!a_d[base + l] || !b_d[base + l] || !out_d[base + l]) return gmx_fail("gmx_select: null leaf%s");
+      if (elem_bytes[base + l] <= 0) return gmx_fail("gmx_select: bad element size%s");
+      T.a[l] = a_d[base + l]; T.b[l] = b_d[base + l]; T.out[l] = out_d[base + l];
+      T.bytes[l] = elem_bytes[base + l];
+    }
+    hipLaunchKernelGGL(k_select, grid_for(n), dim3(GMX_BLOCK), 0, (hipStream_t)stream, T, mask_d, n);
+  }
+  GMX_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// categorical per row (Gumbel-max; ParticleCollection.sample_particle)
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(GMX_BLOCK)
+k_categorical_rows(const uint32_t* __restrict__ keys, const float* __restrict__ logits, int64_t rows,
+                   int64_t cols, int32_t* __restrict__ out) {
+  int64_t row = (int64_t)blockIdx.x * (GMX_BLOCK / GMX_WAVE) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  int lane = threadIdx.x & 63;
+  uint2 kk = reinterpret_cast<const uint2*>(keys)[row];
+  gmx_key k; k.k0 = kk.x; k.k1 = kk.y;
+  const float* x = logits + row * cols;
+  float best = -gmx_inf();
+  int64_t bi = 0x7fffffffffffffffLL;
+  for (int64_t j = lane; j < cols; j += GMX_WAVE) {
+    float v = x[j] + gmx_gumbel_from_bits(gmx_bits32(k, (uint64_t)j));
+    if (bi == 0x7fffffffffffffffLL || v > best) { best = v; bi = j; }
+  }
+  // wave argmax, lowest index wins ties
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    float ov = __shfl_xor(best, m, GMX_WAVE);
+    uint32_t lo = (uint32_t)bi, hi = (uint32_t)((uint64_t)bi >> 32);
+    lo = __shfl_xor(lo, m, GMX_WAVE); hi = __shfl_xor(hi, m, GMX_WAVE);
+    int64_t oi = (int64_t)(((uint64_t)hi << 32) | lo);
+    bool other_valid = oi != 0x7fffffffffffffffLL;
+    bool mine_valid = bi != 0x7fffffffffffffffLL;
+    if (other_valid && (!mine_valid || ov > best || (ov == best && oi < bi))) { best = ov; bi = oi; }
+  }
+  if (lane == 0) out[row] = (int32_t)bi;
+}
+extern "C" int gmx_categorical_rows(const uint32_t* keys_d, const float* logits_d, int64_t rows,
+                                    int64_t cols, int32_t* out_idx_d, gmx_stream stream) {
+  if (rows <= 0) return 0;
+  if (cols <= 0 || cols > 0x7fffffffLL) return gmx_fail("gmx_categorical_rows: cols out of range%s");
+  if (!keys_d || !logits_d || !out_idx_d) return gmx_fail("gmx_categorical_rows: null argument%s");
+  int64_t blocks = (rows + 3) / 4;
+  hipLaunchKernelGGL(k_categorical_rows, dim3((unsigned)blocks), dim3(GMX_BLOCK), 0,
+                     (hipStream_t)stream, keys_d, logits_d, rows, cols, out_idx_d);
+  GMX_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// MH accept
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(GMX_BLOCK)
+k_mh_accept(const uint32_t* __restrict__ keys, const float* __restrict__ log_alpha, int64_t n,
+            uint8_t* __restrict__ accept) {
+  int64_t i = (int64_t)blockIdx.x * GMX_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  uint2 kk = reinterpret_cast<const uint2*>(keys)[i];
+  gmx_key k; k.k0 = kk.x; k.k1 = kk.y;
+  float u = gmx_uniform_sample(k, 0, 0.0f, 1.0f);
+  accept[i] = gmx_logf(u) < log_alpha[i] ? 1 : 0;
+}
+extern "C" int gmx_mh_accept(const uint32_t* keys_d, const float* log_alpha_d, int64_t n,
+                             uint8_t* accept_d, gmx_stream stream) {
+  if (n <= 0) return 0;
+  if (!keys_d || !log_alpha_d || !accept_d) return gmx_fail("gmx_mh_accept: null argument%s");
+  hipLaunchKernelGGL(k_mh_accept, grid_for(n), dim3(GMX_BLOCK), 0, (hipStream_t)stream, keys_d,
+                     log_alpha_d, n, accept_d);
+  GMX_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// graph capture + timers
+// ---------------------------------------------------------------------------
+struct gmx_graph { hipGraph_t graph; hipGraphExec_t exec; };
+
+extern "C" int gmx_capture_begin(gmx_stream stream) {
+  GMX_HIP(hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal));
+  return 0;
+}
+extern "C" int gmx_capture_end(gmx_stream stream, gmx_graph** out) {
+  if (!out) return gmx_fail("gmx_capture_end: null argument%s");
+  hipGraph_t g = nullptr;
+  GMX_HIP(hipStreamEndCapture((hipStream_t)stream, &g));
+  hipGraphExec_t e = nullptr;
+  hipError_t err = hipGraphInstantiate(&e, g, nullptr, nullptr, 0);
+  if (err != hipSuccess) {
+    (void)hipGraphDestroy(g);
+    return gmx_fail("hipGraphInstantiate: %s", hipGetErrorString(err));
+  }
+  gmx_graph* h = new (std::nothrow) gmx_graph;
+  if (!h) return gmx_fail("gmx_capture_end: out of host memory%s");
+  h->graph = g; h->exec = e;
+  *out = h;
+  return 0;
+}
+extern "C" int gmx_graph_launch(gmx_graph* g, gmx_stream stream) {
+  if (!g) return gmx_fail("gmx_graph_launch: null graph%s");
+  GMX_HIP(hipGraphLaunch(g->exec, (hipStream_t)stream));
+  return 0;
+}
+extern "C" int gmx_graph_destroy(gmx_graph* g) {
+  if (!g) return 0;
+  (void)hipGraphExecDestroy(g->exec);
+  (void)hipGraphDestroy(g->graph);
+  delete g;
+  return 0;
+}
+
+struct gmx_timer { hipEvent_t a, b; };
+extern "C" int gmx_timer_create(gmx_timer** out) {
+  if (!out) return gmx_fail("gmx_timer_create: null argument%s");
+  gmx_timer* t = new (std::nothrow) gmx_timer;
+  if (!t) return gmx_fail("gmx_timer_create: out of host memory%s");
+  GMX_HIP(hipEventCreate(&t->a));
+  GMX_HIP(hipEventCreate(&t->b));
+  *out = t;
+  return 0;
+}
+extern "C" int gmx_timer_start(gmx_timer* t, gmx_stream stream) {
+  if (!t) return gmx_fail("gmx_timer_start: null timer%s");
+  GMX_HIP(hipEventRecord(t->a, (hipStream_t)stream));
+  return 0;
+}
+extern "C" int gmx_timer_stop(gmx_timer* t, gmx_stream stream) {
+  if (!t) return gmx_fail("gmx_timer_stop: null timer%s");
+  GMX_HIP(hipEventRecord(t->b, (hipStream_t)stream));
+  return 0;
+}
+extern "C" int gmx_timer_elapsed_ms(gmx_timer* t, float* ms_out) {
+  if (!t || !ms_out) return gmx_fail("gmx_timer_elapsed_ms: null argument%s");
+  GMX_HIP(hipEventSynchronize(t->b));
+  GMX_HIP(hipEventElapsedTime(ms_out, t->a, t->b));
+  return 0;
+}
+extern "C" int gmx_timer_destroy(gmx_timer* t) {
+  if (!t) return 0;
+  (void)hipEventDestroy(t->a);
+  (void)hipEventDestroy(t->b);
+  delete t;
+  return 0;
+}

@@ -1,0 +1,272 @@
+// gmx_math.h — f32 elementary functions with a FIXED operation sequence.
+//
+// Every function here is a straight-line sequence of IEEE-754 binary32
+// add / mul / fma / div / sqrt / rint plus integer bit manipulation.  All of
+// those are correctly rounded on gfx950 (hipcc keeps IEEE div/sqrt by default)
+// and on x86-64, so the same input gives the same bits on the GPU and in the
+// CPU oracle's independent restatement (oracle/orc_math.h) as long as both are
+// built with -ffp-contract=off (fusion happens only where fmaf is written).
+//
+// Why not ocml/libm: resampling indices must be bit-exact between MI355X and
+// the CPU oracle (BASELINE.json north_star), and the fixed-point CDF is built
+// from exp(lw - max); vendor expf/logf differ in the last ulp between targets.
+//
+// Accuracy targets (checked in tests/test_oracle_math.py against float64):
+//   expf, logf, log1pf  <= 2 ulp;  lgammaf <= 4e-6 relative (x >= 1e-3);
+//   erfinvf = the XLA/Giles f32 polynomial (reference: SURVEY.md App. A.2).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define GMX_HD __host__ __device__ __forceinline__
+#else
+#define GMX_HD static inline
+#endif
+
+#define GMX_INF_BITS 0x7f800000u
+#define GMX_NAN_BITS 0x7fc00000u
+
+GMX_HD float gmx_u2f(uint32_t u) {
+  union { uint32_t u; float f; } c; c.u = u; return c.f;
+}
+GMX_HD uint32_t gmx_f2u(float f) {
+  union { uint32_t u; float f; } c; c.f = f; return c.u;
+}
+GMX_HD float gmx_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+GMX_HD float gmx_inf() { return gmx_u2f(GMX_INF_BITS); }
+GMX_HD float gmx_nan() { return gmx_u2f(GMX_NAN_BITS); }
+GMX_HD int gmx_isnan(float x) { return (gmx_f2u(x) & 0x7fffffffu) > GMX_INF_BITS; }
+GMX_HD float gmx_fabs(float x) { return gmx_u2f(gmx_f2u(x) & 0x7fffffffu); }
+GMX_HD float gmx_fmax(float a, float b) { return (a > b || gmx_isnan(b)) ? a : b; }
+GMX_HD float gmx_fmin(float a, float b) { return (a < b || gmx_isnan(b)) ? a : b; }
+
+// 2^k as a float for k in [-126, 127].
+GMX_HD float gmx_pow2i(int k) { return gmx_u2f((uint32_t)(k + 127) << 23); }
+
+// exp(x).  Results below the smallest normal are flushed to +0 so that the
+// answer never depends on a target's denormal mode.
+GMX_HD float gmx_expf(float x) {
+  if (gmx_isnan(x)) return x;
+  if (x > 88.72283935546875f) return gmx_inf();
+  if (x < -87.33654022216797f) return 0.0f;
+  float kf = __builtin_rintf(x * 1.44269502162933349609375f);
+  // Cody–Waite: ln2 = hi + lo, hi has 9 trailing zero bits (kf*hi is exact).
+  float r = gmx_fma(kf, -0.693359375f, x);
+  r = gmx_fma(kf, 2.12194440e-4f, r);
+  // e^r on [-ln2/2, ln2/2], degree-6 minimax (cephes expf coefficients).
+  float p = 1.9875691500e-4f;
+  p = gmx_fma(p, r, 1.3981999507e-3f);
+  p = gmx_fma(p, r, 8.3334519073e-3f);
+  p = gmx_fma(p, r, 4.1665795894e-2f);
+  p = gmx_fma(p, r, 1.6666665459e-1f);
+  p = gmx_fma(p, r, 5.0000001201e-1f);
+  float r2 = r * r;
+  p = gmx_fma(p, r2, r);
+  p = p + 1.0f;
+  int k = (int)kf;
+  int k1 = k >> 1;          // split so both scale factors stay normal
+  int k2 = k - k1;
+  float y = (p * gmx_pow2i(k1)) * gmx_pow2i(k2);
+  if (y < 1.17549435e-38f) return 0.0f;
+  return y;
+}
+
+// log(x), natural.  cephes logf polynomial on [sqrt(1/2), sqrt(2)).
+GMX_HD float gmx_logf(float x) {
+  uint32_t ux = gmx_f2u(x);
+  if (gmx_isnan(x)) return x;
+  if (ux == 0u || ux == 0x80000000u) return -gmx_inf();
+  if (ux >> 31) return gmx_nan();
+  if (ux == GMX_INF_BITS) return x;
+  int e = 0;
+  if (ux < 0x00800000u) {   // denormal input: scale up by 2^23 (exact)
+    x = x * 8388608.0f;
+    ux = gmx_f2u(x);
+    e = -23;
+  }
+  // frexp: x = m * 2^e with m in [0.5, 1)
+  e += (int)(ux >> 23) - 126;
+  float m = gmx_u2f((ux & 0x007fffffu) | 0x3f000000u);
+  float f;
+  if (m < 0.707106781186547524f) {
+    e -= 1;
+    f = (m + m) - 1.0f;
+  } else {
+    f = m - 1.0f;
+  }
+  float z = f * f;
+  float p = 7.0376836292e-2f;
+  p = gmx_fma(p, f, -1.1514610310e-1f);
+  p = gmx_fma(p, f, 1.1676998740e-1f);
+  p = gmx_fma(p, f, -1.2420140846e-1f);
+  p = gmx_fma(p, f, 1.4249322787e-1f);
+  p = gmx_fma(p, f, -1.6668057665e-1f);
+  p = gmx_fma(p, f, 2.0000714765e-1f);
+  p = gmx_fma(p, f, -2.4999993993e-1f);
+  p = gmx_fma(p, f, 3.3333331174e-1f);
+  float y = (p * f) * z;
+  float ef = (float)e;
+  y = gmx_fma(ef, -2.12194440e-4f, y);
+  y = gmx_fma(-0.5f, z, y);
+  float r = f + y;
+  r = gmx_fma(ef, 0.693359375f, r);
+  return r;
+}
+
+// log(1 + x) by Kahan's correction of log(u), u = fl(1 + x).
+GMX_HD float gmx_log1pf(float x) {
+  if (gmx_isnan(x)) return x;
+  float u = 1.0f + x;
+  if (u == 1.0f) return x;
+  if (gmx_f2u(u) == GMX_INF_BITS) return u;
+  float l = gmx_logf(u);
+  float d = u - 1.0f;
+  return l * (x / d);
+}
+
+GMX_HD float gmx_sqrtf(float x) { return __builtin_sqrtf(x); }
+
+// softplus(x) = log(1 + e^x), the stable form max(x,0) + log1p(exp(-|x|)).
+GMX_HD float gmx_softplusf(float x) {
+  float ax = gmx_fabs(x);
+  float t = gmx_log1pf(gmx_expf(-ax));
+  return (x > 0.0f ? x : 0.0f) + t;
+}
+
+GMX_HD float gmx_sigmoidf(float x) {
+  // 1 / (1 + e^-x), evaluated on the side that cannot overflow.
+  if (x >= 0.0f) {
+    float e = gmx_expf(-x);
+    return 1.0f / (1.0f + e);
+  }
+  float e = gmx_expf(x);
+  return e / (1.0f + e);
+}
+
+GMX_HD float gmx_tanhf(float x) {
+  // tanh(x) = sign(x) * (1 - e^{-2|x|}) / (1 + e^{-2|x|})
+  float ax = gmx_fabs(x);
+  if (ax < 1e-4f) return x;
+  float e = gmx_expf(-2.0f * ax);
+  float t = (1.0f - e) / (1.0f + e);
+  return (gmx_f2u(x) >> 31) ? -t : t;
+}
+
+// Inverse error function, XLA's f32 lowering of Giles' polynomial
+// (SURVEY.md App. A.2).  |x| == 1 -> +-inf.
+GMX_HD float gmx_erfinvf(float x) {
+  float w = -gmx_log1pf(-(x * x));
+  float p;
+  if (w < 5.0f) {
+    w = w - 2.5f;
+    p = 2.81022636e-08f;
+    p = gmx_fma(p, w, 3.43273939e-07f);
+    p = gmx_fma(p, w, -3.5233877e-06f);
+    p = gmx_fma(p, w, -4.39150654e-06f);
+    p = gmx_fma(p, w, 0.00021858087f);
+    p = gmx_fma(p, w, -0.00125372503f);
+    p = gmx_fma(p, w, -0.00417768164f);
+    p = gmx_fma(p, w, 0.246640727f);
+    p = gmx_fma(p, w, 1.50140941f);
+  } else {
+    w = gmx_sqrtf(w) - 3.0f;
+    p = -0.000200214257f;
+    p = gmx_fma(p, w, 0.000100950558f);
+    p = gmx_fma(p, w, 0.00134934322f);
+    p = gmx_fma(p, w, -0.00367342844f);
+    p = gmx_fma(p, w, 0.00573950773f);
+    p = gmx_fma(p, w, -0.0076224613f);
+    p = gmx_fma(p, w, 0.00943887047f);
+    p = gmx_fma(p, w, 1.00167406f);
+    p = gmx_fma(p, w, 2.83297682f);
+  }
+  if (gmx_fabs(x) == 1.0f) return x * gmx_inf();
+  return p * x;
+}
+
+// log Gamma(x) for x > 0: shift x up to >= 8 with the recurrence, then the
+// Stirling series.  The product of shifts is accumulated in one log.
+GMX_HD float gmx_lgammaf(float x) {
+  if (gmx_isnan(x)) return x;
+  if (x <= 0.0f) return gmx_inf();
+  if (gmx_f2u(x) == GMX_INF_BITS) return x;
+  float shift = 0.0f;
+  if (x < 8.0f) {
+    float prod = 1.0f;
+    // at most 8 steps; the count depends only on x
+    while (x < 8.0f) {
+      prod = prod * x;
+      x = x + 1.0f;
+    }
+    shift = gmx_logf(prod);
+  }
+  float inv = 1.0f / x;
+  float inv2 = inv * inv;
+  // 1/12 - 1/360 t + 1/1260 t^2 - 1/1680 t^3, t = 1/x^2
+  float s = -5.9523809523809529e-4f;
+  s = gmx_fma(s, inv2, 7.9365079365079365e-4f);
+  s = gmx_fma(s, inv2, -2.7777777777777778e-3f);
+  s = gmx_fma(s, inv2, 8.3333333333333329e-2f);
+  float lx = gmx_logf(x);
+  float r = (x - 0.5f) * lx;
+  r = r - x;
+  r = r + 0.91893853320467274f;
+  r = gmx_fma(s, inv, r);
+  return r - shift;
+}
+
+// x * log(y) with 0 * log(0) = 0 (tf.math.xlogy).
+GMX_HD float gmx_xlogyf(float x, float y) {
+  if (x == 0.0f) return 0.0f;
+  return x * gmx_logf(y);
+}
+// x * log1p(y) with 0 * anything = 0 (tf.math.xlog1py).
+GMX_HD float gmx_xlog1pyf(float x, float y) {
+  if (x == 0.0f) return 0.0f;
+  return x * gmx_log1pf(y);
+}
+
+// sin/cos with a 3-term Cody–Waite reduction by pi/2; accurate to ~2 ulp for
+// |x| <= 8192 (the range model code uses; beyond it accuracy degrades
+// gracefully, results stay deterministic).
+GMX_HD void gmx_sincosf(float x, float* s_out, float* c_out) {
+  float q = __builtin_rintf(x * 0.636619746685028076171875f);
+  float r = gmx_fma(q, -1.5703125f, x);
+  r = gmx_fma(q, -4.837512969970703125e-4f, r);
+  r = gmx_fma(q, -7.54978995489188e-8f, r);
+  float z = r * r;
+  // sin(r), cos(r) on [-pi/4, pi/4] (cephes sinf/cosf coefficients)
+  float ps = -1.9515295891e-4f;
+  ps = gmx_fma(ps, z, 8.3321608736e-3f);
+  ps = gmx_fma(ps, z, -1.6666654611e-1f);
+  float sr = gmx_fma(ps * z, r, r);
+  float pc = 2.443315711809948e-5f;
+  pc = gmx_fma(pc, z, -1.388731625493765e-3f);
+  pc = gmx_fma(pc, z, 4.166664568298827e-2f);
+  float cr = gmx_fma(pc * z, z, gmx_fma(-0.5f, z, 1.0f));
+  int n = ((int)q) & 3;
+  float s, c;
+  if (n == 0) { s = sr; c = cr; }
+  else if (n == 1) { s = cr; c = -sr; }
+  else if (n == 2) { s = -sr; c = -cr; }
+  else { s = -cr; c = sr; }
+  *s_out = s; *c_out = c;
+}
+GMX_HD float gmx_sinf(float x) { float s, c; gmx_sincosf(x, &s, &c); return s; }
+GMX_HD float gmx_cosf(float x) { float s, c; gmx_sincosf(x, &s, &c); return c; }
+
+// pow(x, y) for x > 0 via exp(y log x); exact cases handled first.
+GMX_HD float gmx_powf(float x, float y) {
+  if (y == 0.0f) return 1.0f;
+  if (y == 1.0f) return x;
+  if (y == 2.0f) return x * x;
+  if (x == 0.0f) return (y > 0.0f) ? 0.0f : gmx_inf();
+  if (x < 0.0f) {
+    float yi = __builtin_rintf(y);
+    if (yi != y) return gmx_nan();
+    float r = gmx_expf(y * gmx_logf(-x));
+    int odd = ((int)yi) & 1;
+    return odd ? -r : r;
+  }
+  return gmx_expf(y * gmx_logf(x));
+}

@@ -1,0 +1,67 @@
+// gmx_program.h — encoding of a site program (the unit gmx_program_run executes).
+//
+// A program is a flat array of uint32 words:
+//   [0] GMX_PROG_MAGIC   [1] GMX_PROG_VERSION   [2] n_instr   [3] n_regs
+//   [4] n_in  [5] n_out  [6] n_uni  [7] n_tab
+//   then n_instr instructions of two words each:
+//     w0 = op | dst << 8 | a << 16 | b << 24          w1 = imm32
+//   For three-operand ops c = imm & 0xff and e = imm >> 8 (24 bits).
+//
+// Registers are untyped 32-bit cells r[0..n_regs); an op reads them as f32 or
+// i32.  A PRNG key occupies two consecutive registers (k, k+1).  Booleans are
+// i32 0/1.  There is no control flow: a `@gen` static function has a fixed
+// site list (static.py "Language restrictions"), `jax.lax.cond`/`where` on
+// values become OP_SEL.  All indices are launch-uniform, so on gfx950 the
+// register file is indexed with s_set_gpr_idx (no scratch, no LDS).
+//
+// The Python encoder is genjax_amd/program.py; the independent CPU checker is
+// oracle/ (which does NOT execute programs: it restates the reference's
+// handlers directly on numpy arrays).
+#pragma once
+#include <stdint.h>
+
+#define GMX_PROG_MAGIC 0x50584D47u /* 'GMXP' */
+#define GMX_PROG_VERSION 1u
+#define GMX_PROG_HEADER_WORDS 8u
+#define GMX_MAX_REGS 64
+
+// LDIN / STOUT flag bits (field b for LDIN, field dst for STOUT)
+#define GMX_F_GATHER 1u /* row = ancestors[i] instead of i            */
+#define GMX_F_U8 2u     /* element is 1 byte (bool) <-> i32 0/1        */
+#define GMX_F_BCAST 4u  /* row = 0: one device-resident scalar for all  */
+
+enum gmx_op {
+  OP_END = 0,
+  OP_CONST = 1,   // r[dst] = imm
+  OP_UNI = 2,     // r[dst] = uni[imm]
+  OP_LDIN = 3,    // r[dst] = in[a][row], flags in b
+  OP_LDTAB = 4,   // r[dst] = tab[a][(int)r[b] + (int)imm]
+  OP_STOUT = 5,   // out[a][i] = r[b], flags in dst
+  OP_LDKEY = 6,   // (r[dst], r[dst+1]) = particle key
+  OP_KDERIVE = 7, // (r[dst], r[dst+1]) = threefry(key r[a..a+1], ctr (0, imm))  == fold_in / split child
+  OP_KDERIVER = 8,// same with ctr (0, (uint)r[b])
+  OP_MOV = 10,
+  OP_ADD = 11, OP_SUB = 12, OP_MUL = 13, OP_DIV = 14, OP_MIN = 15, OP_MAX = 16, OP_POW = 17,
+  OP_NEG = 20, OP_ABS = 21, OP_EXP = 22, OP_LOG = 23, OP_LOG1P = 24, OP_SQRT = 25,
+  OP_SIN = 26, OP_COS = 27, OP_TANH = 28, OP_SIGMOID = 29, OP_SOFTPLUS = 30,
+  OP_FLOOR = 31, OP_LGAMMA = 32, OP_SQUARE = 33, OP_RECIP = 34, OP_CEIL = 35, OP_ROUND = 36,
+  OP_FLT = 40, OP_FLE = 41, OP_FGT = 42, OP_FGE = 43, OP_FEQ = 44, OP_FNE = 45,
+  OP_IEQ = 46, OP_INE = 47, OP_ILT = 48, OP_ILE = 49, OP_IGT = 50, OP_IGE = 51,
+  OP_AND = 52, OP_OR = 53, OP_NOT = 54, OP_XOR = 55,
+  OP_SEL = 56,    // r[dst] = r[c] ? r[a] : r[b]
+  OP_I2F = 57, OP_F2I = 58,
+  OP_IADD = 60, OP_ISUB = 61, OP_IMUL = 62, OP_INEG = 63,
+  // samplers: key = r[c..c+1], element counter e = imm >> 8
+  OP_S_NORMAL = 70,   // a = loc, b = scale
+  OP_S_UNIFORM = 71,  // a = low, b = high
+  OP_S_FLIP = 72,     // a = p            -> i32
+  OP_S_BERNL = 73,    // a = logits       -> i32
+  OP_S_BETA = 74,     // a = c1, b = c0
+  OP_S_CATSTEP = 75,  // state (r[dst] best f32, r[dst+1] idx i32); a = logit; b = ctr reg (i32); key c; category e
+  // log-densities: value x = r[c]
+  OP_L_NORMAL = 80, OP_L_UNIFORM = 81, OP_L_FLIP = 82, OP_L_BERNL = 83, OP_L_BETA = 84,
+  // block reductions into red_out[blockIdx][0..1]
+  OP_REDMAX = 90,     // column 0 = max over the block of r[a]
+  OP_REDLSE = 91,     // column 0 = max, column 1 = sum exp(r[a] - max)
+  OP__COUNT = 92
+};

@@ -1,0 +1,207 @@
+/* genmi.h — C-ABI of libgenmi_hip.so, the MI355X (gfx950) implementation of
+ * GenJAX's vectorised inference hot path.
+ *
+ * The reference (genjax-dev/genjax @ 2025-07-18) is pure Python over
+ * jax 0.5.2 + tensorflow-probability 0.23 and has no FFI boundary of its own
+ * (SURVEY.md §8b).  The entry points below are what a `jax.ffi` / ctypes
+ * binding for this path would bind; each cites the reference code it
+ * replaces (paths relative to the reference tree).  INTEGRATION.md shows the
+ * reference-side stubs.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; `_d` = device pointer, `_h` = host pointer;
+ *  - every launch takes a stream (`hipStream_t` passed as void*), is
+ *    asynchronous, allocates nothing and never synchronises, so a caller may
+ *    capture any sequence of calls into a hipGraph;
+ *  - return 0 on success, non-zero on error (text via gmx_last_error());
+ *  - purely functional: inputs are never written; the caller owns all buffers;
+ *  - the library keeps no mutable global state besides the per-thread error
+ *    string.
+ */
+#ifndef GENMI_H
+#define GENMI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GMX_ABI_VERSION 1
+
+typedef void* gmx_stream;            /* hipStream_t */
+typedef struct gmx_program gmx_program;
+
+int gmx_version(void);
+const char* gmx_last_error(void);
+
+/* ------------------------------------------------------------------------
+ * PRNG key algebra (Threefry-2x32, jax `threefry_partitionable` semantics).
+ * Replaces jax.random.split / fold_in at
+ *   src/genjax/_src/inference/smc.py:154,171,191,255,269,299-300,318-319,386
+ *   src/genjax/_src/generative_functions/static.py:261,350,420,525,634
+ *   src/genjax/_src/generative_functions/combinators/vmap.py:186,201
+ * ---------------------------------------------------------------------- */
+
+/* Host-side single block, for key bookkeeping and known-answer tests. */
+void gmx_threefry2x32_host(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1,
+                           uint32_t out[2]);
+
+/* out_keys_d[i] = split(key, n)[index_offset + i], i in [0, n). */
+int gmx_split(const uint32_t key[2], int64_t n, int64_t index_offset,
+              uint32_t* out_keys_d /* [n,2] */, gmx_stream stream);
+/* out_keys_d[r*inner + j] = split(keys_d[r], inner)[j]. */
+int gmx_split_rows(const uint32_t* keys_d /* [rows,2] */, int64_t rows,
+                   int64_t inner, uint32_t* out_keys_d /* [rows*inner,2] */,
+                   gmx_stream stream);
+/* out_d[i] = fold_in(keys_d[i], data). */
+int gmx_fold_in(const uint32_t* keys_d /* [n,2] */, uint32_t data, int64_t n,
+                uint32_t* out_d /* [n,2] */, gmx_stream stream);
+/* raw 32-bit draws: out_d[i*m + j] = random_bits(keys_d[i], 32, (m,))[j]. */
+int gmx_random_bits(const uint32_t* keys_d /* [n,2] */, int64_t n, int64_t m,
+                    uint32_t* out_d /* [n*m] */, gmx_stream stream);
+
+/* ------------------------------------------------------------------------
+ * Site programs: one fused kernel per generative-function-interface call.
+ *
+ * A site program is the straight-line result of running a `@gen` function's
+ * Python source once with symbolic values (the job of `stage` +
+ * `StatefulInterpreter`, src/genjax/_src/core/compiler/staging.py:286-298,
+ * interpreters/stateful.py:47-86): an ordered list of sample sites with
+ * their argument expressions, specialised to one GFI method:
+ *   simulate  static.py:787-793 + SimulateHandler :254-278
+ *   generate / importance  static.py:795-810 + GenerateHandler :341-380
+ *   assess    static.py:983-989 + AssessHandler :297-321
+ *   update    static.py:827-865 + UpdateHandler :407-466
+ *   regenerate / Rejuvenate edits  static.py:867-946,
+ *             src/genjax/_src/inference/requests/rejuvenate.py:70-94
+ * with the leaf semantics of distributions/distribution.py:108-300.
+ * One GPU thread executes the program for one particle; every value lives
+ * in registers; only declared inputs/outputs touch HBM (SoA, coalesced).
+ * The encoding is documented in genjax_amd/csrc/gmx_program.h.
+ * ---------------------------------------------------------------------- */
+
+#define GMX_MAX_IN 64
+#define GMX_MAX_OUT 64
+#define GMX_MAX_TAB 8
+#define GMX_MAX_UNI 64
+
+/* how the per-particle key (register pair loaded by OP_LDKEY) is formed */
+enum {
+  GMX_KEY_NONE = 0,     /* program draws nothing (assess)                      */
+  GMX_KEY_ARRAY = 1,    /* keys_d[i]                                           */
+  GMX_KEY_SPLIT = 2,    /* split((key0,key1), *)[index_offset + i]             */
+  GMX_KEY_ROWSPLIT = 3, /* split(keys_d[i / key_inner], key_inner)[i % inner]  */
+  GMX_KEY_BCAST = 4     /* (key0,key1) for every particle                      */
+};
+
+typedef struct gmx_run_args {
+  const void* in_d[GMX_MAX_IN];   /* per-particle inputs (4-byte or 1-byte elems) */
+  void* out_d[GMX_MAX_OUT];       /* per-particle outputs                        */
+  const void* tab_d[GMX_MAX_TAB]; /* small lookup tables (4-byte elems)          */
+  uint32_t uni[GMX_MAX_UNI];      /* launch-uniform 32-bit values (raw bits)     */
+  const int32_t* ancestors_d;     /* row index for inputs loaded with GATHER     */
+  int32_t key_mode;
+  uint32_t key0, key1;
+  const uint32_t* keys_d;
+  int64_t key_inner;
+  int64_t index_offset;           /* global index of local particle 0 (sharding) */
+  float* red_out_d;               /* [grid,2] block partials of OP_REDMAX/LSE     */
+} gmx_run_args;
+
+int gmx_program_create(const uint32_t* blob_h, size_t n_words, gmx_program** out);
+int gmx_program_destroy(gmx_program* p);
+/* number of thread blocks gmx_program_run will launch for n particles
+ * (= rows of red_out_d the caller must provide). */
+int64_t gmx_program_grid(const gmx_program* p, int64_t n);
+int gmx_program_run(const gmx_program* p, int64_t n, const gmx_run_args* args_h,
+                    gmx_stream stream);
+
+/* ------------------------------------------------------------------------
+ * Log-normaliser.  Replaces jax.scipy.special.logsumexp at
+ *   src/genjax/_src/inference/smc.py:96-97 (log-ML estimate), :107, :464.
+ * out_d[r] = logsumexp(lw_d[r, 0:cols]); deterministic (fixed reduction tree).
+ * workspace: gmx_logsumexp_workspace(rows, cols) bytes.
+ * ---------------------------------------------------------------------- */
+size_t gmx_logsumexp_workspace(int64_t rows, int64_t cols);
+int gmx_logsumexp(const float* lw_d, int64_t rows, int64_t cols, float* out_d,
+                  float* out_max_d /* optional [rows] */, void* workspace_d,
+                  gmx_stream stream);
+
+/* ------------------------------------------------------------------------
+ * Resampling.  The reference has only the single-index Gumbel-max draw
+ * (`ParticleCollection.sample_particle`, smc.py:102-109) and the cookbook's
+ * O(N*K) SIR idiom (docs/cookbook/inactive/inference/importance_sampling.ipynb
+ * cell 16); SURVEY.md App. B defines the scalable forms implemented here.
+ *
+ * Step 1  gmx_weight_cdf: w_i = exp(lw_i - max lw) in fixed point
+ *         q_i = floor(w_i * 2^shift) (u64), inclusive prefix sum cdf_d[i].
+ *         shift = 62 - ceil(log2(n_total)) so a global sum cannot overflow.
+ *         The sum is an integer: identical under any partitioning.
+ * Step 2  gmx_ancestors: ancestor of output slot j by exact 128-bit integer
+ *         comparison against the CDF (no floating point):
+ *           SYSTEMATIC   first i with cdf_i * (n_out*2^23) > (j*2^23 + u0) * total
+ *           STRATIFIED   same with a per-slot u_j
+ *           MULTINOMIAL  first i with cdf_i * 2^23 >= total * (2^23 - u_j)
+ *                        (jax.random.choice inverse-CDF semantics)
+ *         u = 23-bit uniforms (bits >> 9) from `key`.
+ * Step 3  gmx_gather: dst[leaf][j] = src[leaf][ancestors[j]]
+ *         (`get_particle` tree_map, smc.py:90-91).
+ * gmx_categorical_rows: one Gumbel-max index per row (sample_particle).
+ * ---------------------------------------------------------------------- */
+enum { GMX_RESAMPLE_SYSTEMATIC = 0, GMX_RESAMPLE_STRATIFIED = 1, GMX_RESAMPLE_MULTINOMIAL = 2 };
+
+size_t gmx_weight_cdf_workspace(int64_t n);
+/* max_d: device scalar (max over ALL shards' log-weights); if max_partials_d
+ * is non-null the max is first reduced from n_partials [*,2] block partials
+ * written by a program's OP_REDMAX (column 0) and stored to max_d. */
+int gmx_weight_cdf(const float* lw_d, int64_t n, int shift,
+                   const float* max_partials_d, int64_t n_partials, float* max_d,
+                   uint64_t* cdf_d /* [n] inclusive */, uint64_t* total_d /* [1] */,
+                   void* workspace_d, gmx_stream stream);
+int gmx_ancestors(int kind, const uint32_t key[2], const uint64_t* cdf_d, int64_t n_in,
+                  uint64_t cdf_offset /* added to every cdf entry (sharding) */,
+                  const uint64_t* total_d /* [1] global total */,
+                  int64_t n_out_total, int64_t slot_offset, int64_t n_slots,
+                  int32_t* ancestors_d /* [n_slots], clamped to [0,n_in) local */,
+                  gmx_stream stream);
+int gmx_gather(const void* const* src_d, void* const* dst_d, const int32_t* elem_bytes,
+               int32_t n_leaves, const int32_t* ancestors_d, int64_t n_out,
+               gmx_stream stream);
+int gmx_categorical_rows(const uint32_t* keys_d /* [rows,2] */, const float* logits_d,
+                         int64_t rows, int64_t cols, int32_t* out_idx_d, gmx_stream stream);
+
+/* ------------------------------------------------------------------------
+ * MH accept + select.  Replaces the user idiom
+ *   check = log(uniform.sample(k, 0, 1)) < w; tr = tree_map(where(check, new, old))
+ * (tests/inference/test_requests.py:131-137, 186-191).
+ * accept_d[i] = log(uniform(keys_d[i])) < log_alpha_d[i].
+ * ---------------------------------------------------------------------- */
+int gmx_mh_accept(const uint32_t* keys_d /* [n,2] */, const float* log_alpha_d, int64_t n,
+                  uint8_t* accept_d, gmx_stream stream);
+int gmx_select(const uint8_t* mask_d, const void* const* a_d, const void* const* b_d,
+               void* const* out_d, const int32_t* elem_bytes, int32_t n_leaves, int64_t n,
+               gmx_stream stream);
+
+/* ------------------------------------------------------------------------
+ * Graph capture helpers (launch-bound sweeps: T steps x few kernels).
+ * ---------------------------------------------------------------------- */
+typedef struct gmx_graph gmx_graph;
+int gmx_capture_begin(gmx_stream stream);
+int gmx_capture_end(gmx_stream stream, gmx_graph** out);
+int gmx_graph_launch(gmx_graph* g, gmx_stream stream);
+int gmx_graph_destroy(gmx_graph* g);
+
+/* Timing helper for bench.py: HIP events on the caller's stream. */
+typedef struct gmx_timer gmx_timer;
+int gmx_timer_create(gmx_timer** out);
+int gmx_timer_start(gmx_timer* t, gmx_stream stream);
+int gmx_timer_stop(gmx_timer* t, gmx_stream stream);
+int gmx_timer_elapsed_ms(gmx_timer* t, float* ms_out); /* synchronises on stop */
+int gmx_timer_destroy(gmx_timer* t);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GENMI_H */

@@ -1,0 +1,1073 @@
+"""CPU ORACLE — test infrastructure, not product code.
+
+A direct numpy restatement of the slice of GenJAX named by BASELINE.json's
+north_star: the generative-function interface of ``@gen`` static functions and
+the ``genjax.inference.smc`` combinators, with particles as a leading numpy
+axis (the reference obtains the same axis with ``jax.vmap``).  It follows the
+reference files function by function (citations inline, paths relative to
+/root/reference) and calls ``oracle/orc_core.c`` for the third-party arithmetic
+(jax 0.5.2 / TFP 0.23.0, un-vendored: SURVEY.md App. A).
+
+It shares NO code with the product: models are ordinary Python functions run
+eagerly on numpy arrays by the handlers below — there is no tracer, no site
+program and no GPU here — so agreement with ``genjax_amd`` checks the product's
+tracer, program encoder, interpreter kernel and scan/search kernels at once.
+
+Only tests/, ``__graft_entry__.smoke()`` and bench.py's ``cpu_baseline`` leg may
+import this module.
+
+Pinning: see the header of orc_core.c.  Where the reference has no
+implementation at all (systematic / stratified / multinomial resampling, the
+SMC step, MH accept) the definition is the build's and
+is marked "build-defined" below: PARITY UNPINNED for those.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from collections import OrderedDict
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "liborc.so")
+
+
+def build(force: bool = False) -> str:
+    """Compile orc_core.c (gcc, a second or two)."""
+    if force or not os.path.exists(_LIB_PATH) or (
+        os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "orc_core.c"))
+    ):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "_build/liborc.so"])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = ctypes.CDLL(build())
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def f32(x):
+    return np.ascontiguousarray(x, dtype=np.float32)
+
+
+I64 = ctypes.c_int64
+
+# ---------------------------------------------------------------------------
+# elementary functions (bit-identical to the device implementations by
+# construction: same IEEE op sequence; checked on the GPU by tests/test_gpu_*)
+# ---------------------------------------------------------------------------
+_UNARY = dict(exp=0, log=1, log1p=2, sqrt=3, sin=4, cos=5, tanh=6, sigmoid=7,
+              softplus=8, lgamma=9, erfinv=10, recip=11)
+
+
+def _unary(name, x):
+    x = np.asarray(x, dtype=np.float32)
+    xc = np.ascontiguousarray(x).reshape(-1)
+    out = np.empty_like(xc)
+    lib().orc_unary(ctypes.c_int(_UNARY[name]), I64(xc.size), _p(xc), _p(out))
+    return out.reshape(x.shape)
+
+
+def exp(x): return _unary("exp", x)
+def log(x): return _unary("log", x)
+def log1p(x): return _unary("log1p", x)
+def sqrt(x): return _unary("sqrt", x)
+def sin(x): return _unary("sin", x)
+def cos(x): return _unary("cos", x)
+def tanh(x): return _unary("tanh", x)
+def sigmoid(x): return _unary("sigmoid", x)
+def softplus(x): return _unary("softplus", x)
+def lgamma(x): return _unary("lgamma", x)
+def erfinv(x): return _unary("erfinv", x)
+
+
+def power(x, y):
+    x, y = np.broadcast_arrays(np.asarray(x, np.float32), np.asarray(y, np.float32))
+    xc, yc = f32(x).reshape(-1), f32(y).reshape(-1)
+    out = np.empty_like(xc)
+    lib().orc_pow(I64(xc.size), _p(xc), _p(yc), _p(out))
+    return out.reshape(x.shape)
+
+
+def where(c, a, b):
+    return np.where(c, a, b)
+
+
+# ---------------------------------------------------------------------------
+# PRNG keys: jax.random semantics, threefry_partitionable=True (App. A.2)
+# A key is a uint32 array of shape batch + (2,).
+# ---------------------------------------------------------------------------
+def key(seed: int):
+    """jax.random.key(seed) for 0 <= seed < 2**32: key data (0, seed)."""
+    return np.array([0, seed & 0xFFFFFFFF], dtype=np.uint32)
+
+
+def _derive(keys, ctr):
+    """threefry(key, ctr) for broadcast-compatible keys[...,2] and ctr[...]."""
+    keys = np.asarray(keys, dtype=np.uint32)
+    ctr = np.asarray(ctr, dtype=np.uint64)
+    shape = np.broadcast_shapes(keys.shape[:-1], ctr.shape)
+    kb = np.ascontiguousarray(np.broadcast_to(keys, shape + (2,))).reshape(-1, 2)
+    cb = np.ascontiguousarray(np.broadcast_to(ctr, shape)).reshape(-1)
+    out = np.empty_like(kb)
+    lib().orc_derive(I64(cb.size), _p(kb), I64(1), _p(cb), I64(1), _p(out))
+    return out.reshape(shape + (2,))
+
+
+def split(k, n: int = 2):
+    """jax.random.split: child i = threefry(key, ctr=(0, i)); shape batch+(n,2)."""
+    k = np.asarray(k, dtype=np.uint32)
+    return _derive(k[..., None, :], np.arange(n, dtype=np.uint64))
+
+
+def fold_in(k, data):
+    """jax.random.fold_in(key, d) = threefry(key, ctr=(0, d))."""
+    return _derive(k, np.asarray(data, dtype=np.uint64) & np.uint64(0xFFFFFFFF))
+
+
+def bits32(k, ctr):
+    """random_bits(key, 32, shape)[ctr] = hi ^ lo of threefry(key, ctr)."""
+    keys = np.asarray(k, dtype=np.uint32)
+    ctr = np.asarray(ctr, dtype=np.uint64)
+    shape = np.broadcast_shapes(keys.shape[:-1], ctr.shape)
+    kb = np.ascontiguousarray(np.broadcast_to(keys, shape + (2,))).reshape(-1, 2)
+    cb = np.ascontiguousarray(np.broadcast_to(ctr, shape)).reshape(-1)
+    out = np.empty(cb.size, dtype=np.uint32)
+    lib().orc_bits32(I64(cb.size), _p(kb), I64(1), _p(cb), I64(1), _p(out))
+    return out.reshape(shape)
+
+
+def unit_from_bits(b):
+    b = np.ascontiguousarray(b, dtype=np.uint32)
+    out = np.empty(b.shape, dtype=np.float32)
+    lib().orc_unit_from_bits(I64(b.size), _p(b.reshape(-1)), _p(out.reshape(-1)))
+    return out
+
+
+def random_uniform(k, shape=()):
+    """jax.random.uniform(key, shape) in [0,1)."""
+    n = int(np.prod(shape, dtype=np.int64)) if shape else 1
+    b = bits32(np.asarray(k)[..., None, :], np.arange(n, dtype=np.uint64))
+    u = unit_from_bits(b)
+    return u.reshape(np.asarray(k).shape[:-1] + tuple(shape))
+
+
+def random_normal(k, shape=()):
+    n = int(np.prod(shape, dtype=np.int64)) if shape else 1
+    b = np.ascontiguousarray(bits32(np.asarray(k)[..., None, :], np.arange(n, dtype=np.uint64)))
+    out = np.empty(b.shape, dtype=np.float32)
+    lib().orc_std_normal_from_bits(I64(b.size), _p(b.reshape(-1)), _p(out.reshape(-1)))
+    return out.reshape(np.asarray(k).shape[:-1] + tuple(shape))
+
+
+def random_gumbel(k, shape=()):
+    n = int(np.prod(shape, dtype=np.int64)) if shape else 1
+    b = np.ascontiguousarray(bits32(np.asarray(k)[..., None, :], np.arange(n, dtype=np.uint64)))
+    out = np.empty(b.shape, dtype=np.float32)
+    lib().orc_gumbel_from_bits(I64(b.size), _p(b.reshape(-1)), _p(out.reshape(-1)))
+    return out.reshape(np.asarray(k).shape[:-1] + tuple(shape))
+
+
+# ---------------------------------------------------------------------------
+# choice maps: nested dicts {addr component: value | dict}.  Addresses are
+# strings or tuples of strings (choice_map.py:50-62).
+# ---------------------------------------------------------------------------
+def _addr(a):
+    return a if isinstance(a, tuple) else (a,)
+
+
+class ChoiceMap:
+    """Minimal value tree with the operations the handlers need
+    (choice_map.py: Static :1534, Choice :1396, Or :1671, filter :1588)."""
+
+    def __init__(self, tree=None, value=None, has_value=False):
+        self.tree = tree if tree is not None else {}
+        self.value = value
+        self.has_value = has_value
+
+    # builders ------------------------------------------------------------
+    @staticmethod
+    def empty():
+        return ChoiceMap()
+
+    @staticmethod
+    def choice(v):
+        return ChoiceMap(value=v, has_value=True)
+
+    @staticmethod
+    def d(mapping):
+        cm = ChoiceMap()
+        for a, v in mapping.items():
+            cm = cm.set(a, v)
+        return cm
+
+    @staticmethod
+    def kw(**kwargs):
+        return ChoiceMap.d(kwargs)
+
+    def set(self, addr, v):
+        addr = _addr(addr)
+        new = ChoiceMap(dict(self.tree), self.value, self.has_value)
+        if not addr:
+            return v if isinstance(v, ChoiceMap) else ChoiceMap.choice(v)
+        head, rest = addr[0], addr[1:]
+        sub = new.tree.get(head, ChoiceMap())
+        new.tree[head] = sub.set(rest, v)
+        return new
+
+    # queries ---------------------------------------------------------------
+    def static_is_empty(self):
+        return not self.has_value and all(s.static_is_empty() for s in self.tree.values())
+
+    def get_value(self):
+        return self.value if self.has_value else None
+
+    def __call__(self, addr):           # get_submap
+        cm = self
+        for a in _addr(addr):
+            cm = cm.tree.get(a, ChoiceMap())
+        return cm
+
+    get_submap = __call__
+
+    def __getitem__(self, addr):
+        sub = self(addr)
+        if not sub.has_value:
+            raise KeyError(addr)
+        return sub.value
+
+    def __contains__(self, addr):
+        return self(addr).has_value
+
+    def addresses(self, prefix=()):
+        out = []
+        if self.has_value:
+            out.append(prefix)
+        for a, s in self.tree.items():
+            out.extend(s.addresses(prefix + (a,)))
+        return out
+
+    # algebra ---------------------------------------------------------------
+    def merge(self, other):
+        """self | other, first operand wins on overlap (Or.build, choice_map.py:1699-1733)."""
+        if self.has_value:
+            return self
+        if other.has_value and not self.tree:
+            return other
+        out = ChoiceMap(dict(self.tree))
+        for a, s in other.tree.items():
+            out.tree[a] = out.tree[a].merge(s) if a in out.tree else s
+        return out
+
+    __or__ = merge
+
+    def filter(self, pred, prefix=()):
+        """keep leaves whose address satisfies pred(addr tuple)."""
+        out = ChoiceMap()
+        if self.has_value and pred(prefix):
+            out.value, out.has_value = self.value, True
+        for a, s in self.tree.items():
+            f = s.filter(pred, prefix + (a,))
+            if not f.static_is_empty():
+                out.tree[a] = f
+        return out
+
+    def map_values(self, fn):
+        out = ChoiceMap({a: s.map_values(fn) for a, s in self.tree.items()})
+        if self.has_value:
+            out.value, out.has_value = fn(self.value), True
+        return out
+
+
+C = ChoiceMap
+
+
+class MissingAddress(Exception):
+    pass
+
+
+class AddressReuse(Exception):
+    pass
+
+
+# ---------------------------------------------------------------------------
+# distributions (distribution.py:90-419 + tensorflow_probability/__init__.py)
+# ---------------------------------------------------------------------------
+class DistTrace:
+    def __init__(self, gen_fn, args, value, score):
+        self.gen_fn, self.args, self.value, self.score = gen_fn, args, value, score
+
+    def get_retval(self): return self.value
+    def get_score(self): return self.score
+    def get_choices(self): return ChoiceMap.choice(self.value)
+    def get_args(self): return self.args
+    def get_gen_fn(self): return self.gen_fn
+
+
+def _bshape(*xs):
+    return np.broadcast_shapes(*[np.shape(x) for x in xs])
+
+
+
+def _event_of(batch, shape):
+    """Split a broadcast result shape into (batched?, event shape).  Leading
+    axes that match the particle batch are batch axes; if the shape does not
+    start with the batch the whole shape is an (unbatched) event."""
+    batch, shape = tuple(batch), tuple(shape)
+    nb = len(batch)
+    if len(shape) >= nb and all(shape[d] in (1, batch[d]) for d in range(nb)):
+        return True, shape[nb:]
+    return False, shape
+
+class Distribution:
+    name = "dist"
+    value_dtype = np.float32
+
+    def __call__(self, *args, **kwargs):
+        return Closure(self, self._canon_args(args, kwargs))
+
+    def _canon_args(self, args, kwargs):
+        if kwargs:
+            raise TypeError(f"{self.name}: keyword arguments not supported by the oracle")
+        return tuple(args)
+
+    # -- to be provided: sample_flat(keys[n,2], elem, *args[n]) and logpdf_flat
+    def _sample(self, keys, args):
+        """keys: batch+(2,); args broadcastable to batch+event. One site key,
+        element j of the event takes counter j (App. A.3)."""
+        keys = np.asarray(keys, dtype=np.uint32)
+        batch = keys.shape[:-1]
+        ashape = _bshape(*args) if args else ()
+        batched, event = _event_of(batch, ashape)
+        full = batch + tuple(event)
+        n = int(np.prod(batch, dtype=np.int64))
+        E = int(np.prod(event, dtype=np.int64))
+        kb = np.ascontiguousarray(np.broadcast_to(keys, batch + (2,))).reshape(n, 2)
+        ab = []
+        for a in args:
+            a = np.asarray(a, np.float32)
+            if batched and a.ndim > len(event):
+                pass                                  # leading axes are batch axes
+            ab.append(np.ascontiguousarray(np.broadcast_to(a, full)).reshape(n, E)
+                      if (batched or a.ndim == 0) else
+                      np.ascontiguousarray(np.broadcast_to(a.reshape((1,) * len(batch) + a.shape), full)).reshape(n, E))
+        out = np.empty((n, E), dtype=self.value_dtype)
+        for e in range(E):
+            cols = [np.ascontiguousarray(a[:, e]) for a in ab]
+            col = np.empty(n, dtype=self.value_dtype)
+            self._sample_flat(n, kb, e, cols, col)
+            out[:, e] = col
+        return out.reshape(full)
+
+    def _logpdf(self, v, args, batch_ndim=None):
+        full = _bshape(v, *args)
+        vb = np.ascontiguousarray(np.broadcast_to(np.asarray(v, self.value_dtype), full)).reshape(-1)
+        ab = [np.ascontiguousarray(np.broadcast_to(np.asarray(a, np.float32), full)).reshape(-1)
+              for a in args]
+        out = np.empty(vb.size, dtype=np.float32)
+        self._logpdf_flat(vb.size, vb, ab, out)
+        return out.reshape(full)
+
+    # -- GFI for leaves ------------------------------------------------------
+    def sample(self, k, *args):
+        return self._sample(k, args)
+
+    def logpdf(self, v, *args):
+        return self._logpdf(v, args)
+
+    def estimate_logpdf(self, v, args, batch_shape):
+        """ExactDensity.estimate_logpdf: sum an array-valued log_prob into one
+        site score (distribution.py:383-396); event axes are the ones beyond
+        the particle batch."""
+        w = self._logpdf(v, args)
+        batch_shape = tuple(batch_shape)
+        batched, event = _event_of(batch_shape, w.shape)
+        if event:
+            # sequential f32 sum over the flattened event axis, element order
+            flat = w.reshape(w.shape[: w.ndim - len(event)] + (-1,))
+            acc = flat[..., 0].astype(np.float32)
+            for j in range(1, flat.shape[-1]):
+                acc = (acc + flat[..., j]).astype(np.float32)
+            w = acc
+        return np.broadcast_to(w, np.broadcast_shapes(np.shape(w), batch_shape)).astype(np.float32)
+
+    def simulate(self, k, args):
+        """Distribution.simulate (distribution.py:108-115) via
+        ExactDensity.random_weighted (:371-381): sample then logpdf."""
+        v = self._sample(k, args)
+        w = self.estimate_logpdf(v, args, np.asarray(k).shape[:-1])
+        return DistTrace(self, args, v, w)
+
+    def generate(self, k, constraint: ChoiceMap, args):
+        """generate_choice_map (distribution.py:117-147)."""
+        v = constraint.get_value()
+        batch = np.asarray(k).shape[:-1]
+        if v is None:
+            tr = self.simulate(k, args)
+            return tr, np.zeros(batch, dtype=np.float32)
+        w = self.estimate_logpdf(v, args, batch)
+        return DistTrace(self, args, v, w), w
+
+    importance = generate
+
+    def assess(self, sample: ChoiceMap, args, batch_shape=()):
+        """ExactDensity.assess (distribution.py:398-419)."""
+        v = sample.get_value()
+        if v is None:
+            raise MissingAddress(())
+        return self.estimate_logpdf(v, args, batch_shape), v
+
+    def propose(self, k, args):
+        tr = self.simulate(k, args)
+        return tr.get_choices(), tr.get_score(), tr.get_retval()
+
+    def update(self, k, trace: DistTrace, constraint: ChoiceMap, args):
+        """edit_update_with_constraint (distribution.py:179-244): w = new logpdf
+        - old score; discard = old value when a new value is supplied."""
+        batch = np.shape(trace.score)
+        v = constraint.get_value()
+        if v is None:
+            old = trace.value
+            fwd = self.estimate_logpdf(old, args, batch)
+            w = (fwd - trace.score).astype(np.float32)
+            return DistTrace(self, args, old, fwd), w, ChoiceMap.empty()
+        fwd = self.estimate_logpdf(v, args, batch)
+        w = (fwd - trace.score).astype(np.float32)
+        return DistTrace(self, args, v, fwd), w, trace.get_choices()
+
+    def regenerate(self, k, trace: DistTrace, selected: bool, args):
+        """edit_regenerate (distribution.py:258-300)."""
+        if selected:
+            new = self.simulate(k, args)
+            w = (new.score - trace.score).astype(np.float32)
+            return new, w, ChoiceMap.choice(trace.value)
+        fwd = self.estimate_logpdf(trace.value, args, np.shape(trace.score))
+        w = (fwd - trace.score).astype(np.float32)
+        return DistTrace(self, args, trace.value, fwd), w, ChoiceMap.empty()
+
+
+class _Normal(Distribution):
+    name = "normal"
+
+    def _sample_flat(self, n, kb, e, cols, out):
+        lib().orc_normal_sample(I64(n), _p(kb), I64(1), ctypes.c_uint64(e), _p(cols[0]), I64(1),
+                                _p(cols[1]), I64(1), _p(out))
+
+    def _logpdf_flat(self, n, v, ab, out):
+        lib().orc_normal_logpdf(I64(n), _p(v), I64(1), _p(ab[0]), I64(1), _p(ab[1]), I64(1), _p(out))
+
+
+class _Uniform(Distribution):
+    name = "uniform"
+
+    def _sample_flat(self, n, kb, e, cols, out):
+        lib().orc_uniform_sample(I64(n), _p(kb), I64(1), ctypes.c_uint64(e), _p(cols[0]), I64(1),
+                                 _p(cols[1]), I64(1), _p(out))
+
+    def _logpdf_flat(self, n, v, ab, out):
+        lib().orc_uniform_logpdf(I64(n), _p(v), I64(1), _p(ab[0]), I64(1), _p(ab[1]), I64(1), _p(out))
+
+
+class _Beta(Distribution):
+    name = "beta"
+
+    def _sample_flat(self, n, kb, e, cols, out):
+        lib().orc_beta_sample(I64(n), _p(kb), I64(1), ctypes.c_uint64(e), _p(cols[0]), I64(1),
+                              _p(cols[1]), I64(1), _p(out))
+
+    def _logpdf_flat(self, n, v, ab, out):
+        lib().orc_beta_logpdf(I64(n), _p(v), I64(1), _p(ab[0]), I64(1), _p(ab[1]), I64(1), _p(out))
+
+
+class _Flip(Distribution):
+    """genjax.flip = Bernoulli(probs=p, dtype=bool) (tfp/__init__.py:155)."""
+    name = "flip"
+    value_dtype = np.int32
+
+    def _sample(self, keys, args):
+        return super()._sample(keys, args).astype(bool)
+
+    def _sample_flat(self, n, kb, e, cols, out):
+        lib().orc_flip_sample(I64(n), _p(kb), I64(1), ctypes.c_uint64(e), _p(cols[0]), I64(1), _p(out))
+
+    def _logpdf_flat(self, n, v, ab, out):
+        lib().orc_flip_logpdf(I64(n), _p(v), I64(1), _p(ab[0]), I64(1), _p(out))
+
+
+class _BernoulliLogits(Distribution):
+    """genjax.bernoulli: bare / logits= parameter (tfp/__init__.py:72)."""
+    name = "bernoulli"
+    value_dtype = np.int32
+
+    def _canon_args(self, args, kwargs):
+        if "logits" in kwargs:
+            return (kwargs["logits"],)
+        if "probs" in kwargs:
+            p = np.asarray(kwargs["probs"], np.float32)
+            return ((log(p) - log1p(-p)).astype(np.float32),)
+        return tuple(args)
+
+    def _sample_flat(self, n, kb, e, cols, out):
+        lib().orc_bernl_sample(I64(n), _p(kb), I64(1), ctypes.c_uint64(e), _p(cols[0]), I64(1), _p(out))
+
+    def _logpdf_flat(self, n, v, ab, out):
+        lib().orc_bernl_logpdf(I64(n), _p(v), I64(1), _p(ab[0]), I64(1), _p(out))
+
+
+class _Categorical(Distribution):
+    """genjax.categorical (tfp/__init__.py:102-104): bare / logits= argument is
+    logits, probs= is log'ed.  Event = the last axis (K categories); one
+    Gumbel-max draw per row, gumbel counter = category index."""
+    name = "categorical"
+    value_dtype = np.int32
+
+    def _canon_args(self, args, kwargs):
+        if "probs" in kwargs:
+            return (log(np.asarray(kwargs["probs"], np.float32)),)
+        if "logits" in kwargs:
+            return (np.asarray(kwargs["logits"], np.float32),)
+        return (np.asarray(args[0], np.float32),)
+
+    def _sample(self, keys, args):
+        keys = np.asarray(keys, dtype=np.uint32)
+        batch = keys.shape[:-1]
+        logits = np.asarray(args[0], np.float32)
+        K = logits.shape[-1]
+        full = np.broadcast_shapes(batch + (K,), logits.shape)
+        if len(full) != len(batch) + 1:
+            raise NotImplementedError("oracle categorical: batched logits beyond the particle axis")
+        n = int(np.prod(batch, dtype=np.int64))
+        kb = np.ascontiguousarray(np.broadcast_to(keys, batch + (2,))).reshape(n, 2)
+        lb = np.ascontiguousarray(np.broadcast_to(logits, full)).reshape(n, K)
+        out = np.empty(n, dtype=np.int32)
+        lib().orc_categorical_sample(I64(n), I64(K), _p(kb), I64(1), _p(lb), I64(K), None, I64(0), _p(out))
+        return out.reshape(batch)
+
+    def _logpdf(self, v, args, batch_ndim=None):
+        logits = np.asarray(args[0], np.float32)
+        lse = logsumexp(logits, axis=-1)
+        v = np.asarray(v, np.int64)
+        shape = np.broadcast_shapes(v.shape, logits.shape[:-1])
+        lb = np.broadcast_to(logits, shape + logits.shape[-1:])
+        picked = np.take_along_axis(lb, np.broadcast_to(v, shape)[..., None], axis=-1)[..., 0]
+        return (picked - np.broadcast_to(lse, shape)).astype(np.float32)
+
+    def estimate_logpdf(self, v, args, batch_shape):
+        return self._logpdf(v, args)
+
+
+normal = _Normal()
+uniform = _Uniform()
+beta = _Beta()
+flip = _Flip()
+bernoulli = _BernoulliLogits()
+categorical = _Categorical()
+
+
+def logsumexp(a, axis=-1):
+    """jax.scipy.special.logsumexp: max, then log(sum(exp(a - max))) + max,
+    sequential f32 accumulation in index order."""
+    a = np.asarray(a, np.float32)
+    a = np.moveaxis(a, axis, -1)
+    m = a.max(axis=-1)
+    msafe = np.where(np.isfinite(m), m, np.float32(0.0)).astype(np.float32)
+    acc = np.zeros(a.shape[:-1], dtype=np.float32)
+    for j in range(a.shape[-1]):
+        acc = (acc + exp((a[..., j] - msafe).astype(np.float32))).astype(np.float32)
+    return (log(acc) + msafe).astype(np.float32)
+
+
+# ---------------------------------------------------------------------------
+# static language (static.py)
+# ---------------------------------------------------------------------------
+_HANDLERS: list = []
+
+
+class Closure:
+    """GenerativeFunctionClosure (generative_function.py:1557-1684):
+    `gen_fn(*args) @ addr` traces the callee at addr."""
+
+    def __init__(self, gen_fn, args):
+        self.gen_fn, self.args = gen_fn, args
+
+    def __matmul__(self, addr):
+        if not _HANDLERS:
+            raise RuntimeError("`@` used outside of a generative function")
+        return _HANDLERS[-1].handle(addr, self.gen_fn, self.args)
+
+
+class StaticTrace:
+    """StaticTrace (static.py:80-119)."""
+
+    def __init__(self, gen_fn, args, retval, subtraces):
+        self.gen_fn, self.args, self.retval, self.subtraces = gen_fn, args, retval, subtraces
+
+    def get_args(self): return self.args
+    def get_retval(self): return self.retval
+    def get_gen_fn(self): return self.gen_fn
+
+    def get_choices(self):
+        cm = ChoiceMap()
+        for a, st in self.subtraces.items():
+            cm = cm.set(a, st.get_choices())
+        return cm
+
+    def get_score(self):
+        """sum of sub-trace scores in program order (static.py:102-105), f32."""
+        acc = None
+        for st in self.subtraces.values():
+            s = np.asarray(st.get_score(), np.float32)
+            acc = s if acc is None else (acc + s).astype(np.float32)
+        return acc if acc is not None else np.float32(0.0)
+
+    def get_subtrace(self, addr):
+        return self.subtraces[addr]
+
+
+class _Handler:
+    """StaticHandler (static.py:209-252): per-site key = fold_in(key, counter),
+    counter from 1, +1 per site in program order, for every GFI method
+    (static.py:260-263, 349-352, 419-422, 524-527, 633-636)."""
+
+    def __init__(self, k):
+        self.key = k
+        self.counter = 1
+        self.traces = OrderedDict()
+
+    def fresh_key(self):
+        sub = fold_in(self.key, self.counter) if self.key is not None else None
+        self.counter += 1
+        return sub
+
+    def record(self, addr, tr):
+        if addr in self.traces:
+            raise AddressReuse(addr)
+        self.traces[addr] = tr
+
+
+class _Simulate(_Handler):
+    def handle(self, addr, gen_fn, args):
+        tr = gen_fn.simulate(self.fresh_key(), args)
+        self.record(addr, tr)
+        return tr.get_retval()
+
+
+class _Generate(_Handler):
+    def __init__(self, k, chm):
+        super().__init__(k)
+        self.chm = chm
+        self.weight = np.float32(0.0)
+
+    def handle(self, addr, gen_fn, args):
+        sub = self.chm(addr)
+        tr, w = gen_fn.generate(self.fresh_key(), sub, args)
+        self.weight = (self.weight + w).astype(np.float32)     # static.py:377
+        self.record(addr, tr)
+        return tr.get_retval()
+
+
+class _Assess(_Handler):
+    def __init__(self, chm, batch_shape):
+        super().__init__(None)
+        self.chm = chm
+        self.score = np.float32(0.0)
+        self.batch_shape = batch_shape
+
+    def handle(self, addr, gen_fn, args):
+        sub = self.chm(addr)
+        if sub.static_is_empty():
+            raise MissingAddress(addr)                          # static.py:317-318
+        score, v = gen_fn.assess(sub, args, self.batch_shape)
+        self.score = (self.score + score).astype(np.float32)
+        return v
+
+
+class _Update(_Handler):
+    """UpdateHandler (static.py:407-466): Update(constraint(addr)) at every site."""
+
+    def __init__(self, k, prev, chm):
+        super().__init__(k)
+        self.prev, self.chm = prev, chm
+        self.weight = np.float32(0.0)
+        self.discard = ChoiceMap()
+
+    def handle(self, addr, gen_fn, args):
+        sub = self.chm(addr)
+        tr, w, disc = gen_fn.update(self.fresh_key(), self.prev.get_subtrace(addr), sub, args)
+        self.weight = (self.weight + w).astype(np.float32)
+        if not disc.static_is_empty():
+            self.discard = self.discard.set(addr, disc)
+        self.record(addr, tr)
+        return tr.get_retval()
+
+
+class _Regenerate(_Handler):
+    """RegenerateRequestHandler (static.py:616-673)."""
+
+    def __init__(self, k, prev, selected):
+        super().__init__(k)
+        self.prev, self.selected = prev, selected      # selected: callable(addr tuple)->bool
+        self.weight = np.float32(0.0)
+        self.discard = ChoiceMap()
+
+    def handle(self, addr, gen_fn, args):
+        sub_sel = (lambda rest, a=_addr(addr): self.selected(a + rest))
+        tr, w, disc = gen_fn.regenerate(self.fresh_key(), self.prev.get_subtrace(addr), sub_sel, args)
+        self.weight = (self.weight + w).astype(np.float32)
+        if not disc.static_is_empty():
+            self.discard = self.discard.set(addr, disc)
+        self.record(addr, tr)
+        return tr.get_retval()
+
+
+class _StaticEdit(_Handler):
+    """StaticEditRequestHandler (static.py:512-566): per-site sub-request,
+    default EmptyRequest (requests.py:50-60).  An EmptyRequest with unchanged
+    args contributes exactly 0 either way, so every site is re-scored here."""
+
+    def __init__(self, k, prev, addressed):
+        super().__init__(k)
+        self.prev, self.addressed = prev, addressed
+        self.weight = np.float32(0.0)
+
+    def handle(self, addr, gen_fn, args):
+        sub_key = self.fresh_key()
+        subtrace = self.prev.get_subtrace(addr)
+        req = self.addressed.get(addr)
+        if req is None:
+            tr, w, _ = gen_fn.update(sub_key, subtrace, ChoiceMap.empty(), args)
+        else:
+            tr, w = req.edit(sub_key, subtrace, gen_fn, args)
+        self.weight = (self.weight + w).astype(np.float32)
+        self.record(addr, tr)
+        return tr.get_retval()
+
+
+def _leaf_selected(sel):
+    return sel(()) if callable(sel) else bool(sel)
+
+
+# make Distribution.regenerate accept the callable form used by _Regenerate
+_dist_regen = Distribution.regenerate
+
+
+def _dist_regenerate(self, k, trace, selected, args):
+    return _dist_regen(self, k, trace, _leaf_selected(selected), args)
+
+
+Distribution.regenerate = _dist_regenerate
+
+
+class StaticGenerativeFunction:
+    """StaticGenerativeFunction (static.py:725-1036)."""
+
+    def __init__(self, source):
+        self.source = source
+
+    def __call__(self, *args):
+        return Closure(self, tuple(args))
+
+    def _run(self, handler, args):
+        _HANDLERS.append(handler)
+        try:
+            return self.source(*args)
+        finally:
+            _HANDLERS.pop()
+
+    def simulate(self, k, args):
+        h = _Simulate(k)
+        retval = self._run(h, args)
+        return StaticTrace(self, args, retval, h.traces)
+
+    def generate(self, k, chm, args):
+        h = _Generate(k, chm)
+        retval = self._run(h, args)
+        w = np.broadcast_to(h.weight, np.asarray(k).shape[:-1]).astype(np.float32)
+        return StaticTrace(self, args, retval, h.traces), w
+
+    importance = generate            # generative_function.py:629-675
+
+    def assess(self, chm, args, batch_shape=()):
+        h = _Assess(chm, batch_shape)
+        retval = self._run(h, args)
+        return h.score, retval
+
+    def propose(self, k, args):
+        tr = self.simulate(k, args)
+        return tr.get_choices(), tr.get_score(), tr.get_retval()
+
+    def update(self, k, trace, chm, args):
+        h = _Update(k, trace, chm)
+        retval = self._run(h, args)
+        return StaticTrace(self, args, retval, h.traces), h.weight, h.discard
+
+    def regenerate(self, k, trace, selected, args):
+        h = _Regenerate(k, trace, selected)
+        retval = self._run(h, args)
+        return StaticTrace(self, args, retval, h.traces), h.weight, h.discard
+
+    def edit_static(self, k, trace, addressed, args):
+        h = _StaticEdit(k, trace, addressed)
+        retval = self._run(h, args)
+        return StaticTrace(self, args, retval, h.traces), h.weight
+
+
+def gen(f):
+    return StaticGenerativeFunction(f)
+
+
+def selection(*addrs):
+    """S[a] | S[b] ...: selects the listed addresses and everything below them."""
+    addrs = [_addr(a) for a in addrs]
+    return lambda a: any(a[: len(s)] == s for s in addrs)
+
+
+class Rejuvenate:
+    """Rejuvenate.edit (requests/rejuvenate.py:70-94), literally: the backward
+    proposal arguments come from the OLD value (bwd_chm = discard)."""
+
+    def __init__(self, proposal, argument_mapping):
+        self.proposal, self.argument_mapping = proposal, argument_mapping
+
+    def edit(self, k, subtrace, gen_fn, args):
+        chm = subtrace.get_choices()
+        fwd_args = self.argument_mapping(chm)
+        ks = split(k)
+        k_new, sub_key = ks[..., 0, :], ks[..., 1, :]
+        proposed, fwd_score, _ = self.proposal.propose(sub_key, fwd_args)
+        new_tr, w, bwd_chm = gen_fn.update(k_new, subtrace, proposed, args)
+        bwd_args = self.argument_mapping(bwd_chm)
+        bwd_score, _ = self.proposal.assess(bwd_chm, bwd_args, np.shape(w))
+        final = ((w + bwd_score).astype(np.float32) - fwd_score).astype(np.float32)
+        return new_tr, final
+
+
+def mh_accept(k, log_alpha):
+    """`log(uniform.sample(k, 0, 1)) < w` (tests/inference/test_requests.py:131-137)."""
+    u = uniform.sample(k, np.float32(0.0), np.float32(1.0))
+    return log(u) < np.asarray(log_alpha, np.float32)
+
+
+# ---------------------------------------------------------------------------
+# inference (sp.py, smc.py)
+# ---------------------------------------------------------------------------
+class Target:
+    """Target (sp.py:52-94)."""
+
+    def __init__(self, p, args, constraint: ChoiceMap):
+        self.p, self.args, self.constraint = p, tuple(args), constraint
+
+    def importance(self, k, constraint: ChoiceMap):
+        merged = self.constraint.merge(constraint)          # target's own obs win
+        return self.p.importance(k, merged, self.args)
+
+    def filter_to_unconstrained(self, chm: ChoiceMap):
+        cons = self.constraint.addresses()
+        return chm.filter(lambda a: not any(a[: len(c)] == c for c in cons))
+
+
+def _tree_index(tr, idx):
+    """tree_map(lambda v: v[idx]) over a trace (smc.py:90-91)."""
+    if isinstance(tr, DistTrace):
+        args = tuple(_index_leaf(a, idx, np.shape(tr.score)) for a in tr.args)
+        return DistTrace(tr.gen_fn, args, _index_leaf(tr.value, idx, np.shape(tr.score)), tr.score[idx])
+    n = np.shape(tr.get_score())
+    return StaticTrace(tr.gen_fn, tuple(_index_leaf(a, idx, n) for a in tr.args),
+                       _index_leaf(tr.retval, idx, n),
+                       OrderedDict((a, _tree_index(s, idx)) for a, s in tr.subtraces.items()))
+
+
+def _index_leaf(v, idx, batch):
+    if v is None:
+        return None
+    if isinstance(v, tuple):
+        return tuple(_index_leaf(x, idx, batch) for x in v)
+    a = np.asarray(v)
+    if a.shape[: len(batch)] == tuple(batch) and len(batch) > 0:
+        return a[idx]
+    return v
+
+
+class ParticleCollection:
+    """ParticleCollection (smc.py:76-109)."""
+
+    def __init__(self, particles, log_weights):
+        self.particles, self.log_weights = particles, np.asarray(log_weights, np.float32)
+
+    def get_particles(self): return self.particles
+    def get_log_weights(self): return self.log_weights
+
+    def get_log_marginal_likelihood_estimate(self):
+        n = self.log_weights.shape[-1]
+        return (logsumexp(self.log_weights) - log(np.float32(n))).astype(np.float32)   # smc.py:96-97
+
+    def sample_index(self, k):
+        """categorical over normalised weights, Gumbel-max (smc.py:102-109)."""
+        lw = self.log_weights
+        logits = (lw - logsumexp(lw)[..., None]).astype(np.float32)
+        return categorical.sample(k, logits)
+
+    def sample_particle(self, k):
+        idx = self.sample_index(k)
+        if self.log_weights.ndim == 1:
+            return _tree_index(self.particles, int(idx))
+        raise NotImplementedError
+
+
+class ImportanceK:
+    """ImportanceK.run_smc (smc.py:298-315), no custom proposal."""
+
+    def __init__(self, target: Target, k_particles: int):
+        self.target, self.k = target, k_particles
+
+    def get_final_target(self): return self.target
+    def get_num_particles(self): return self.k
+
+    def run_smc(self, k):
+        ks = split(k)
+        sub = ks[..., 1, :]                     # key, sub_key = split(key)
+        sub_keys = split(sub, self.k)           # (..., K, 2)
+        trs, scores = self.target.importance(sub_keys, ChoiceMap.empty())
+        return ParticleCollection(trs, scores)
+
+
+class Importance(ImportanceK):
+    """Importance.run_smc (smc.py:254-266): one particle, keyed by `key` itself."""
+
+    def __init__(self, target):
+        super().__init__(target, 1)
+
+    def run_smc(self, k):
+        ks = split(k)
+        k0 = ks[..., 0, :]
+        tr, score = self.target.importance(k0[..., None, :], ChoiceMap.empty())
+        return ParticleCollection(tr, score)
+
+
+class ChangeTarget:
+    """ChangeTarget.run_smc (smc.py:370-396); reuses the incoming key for both
+    prev.run_smc(key) and split(key, K) (smc.py:374, 386)."""
+
+    def __init__(self, prev, target: Target):
+        self.prev, self.target = prev, target
+
+    def get_final_target(self): return self.target
+    def get_num_particles(self): return self.prev.get_num_particles()
+
+    def run_smc(self, k):
+        coll = self.prev.run_smc(k)
+        particles, lw = coll.get_particles(), coll.get_log_weights()
+        latents = self.prev.get_final_target().filter_to_unconstrained(particles.get_choices())
+        sub_keys = split(k, self.get_num_particles())
+        new_tr, new_w = self.target.importance(sub_keys, latents)
+        this = ((new_w - particles.get_score()).astype(np.float32) + lw).astype(np.float32)
+        return ParticleCollection(new_tr, this)
+
+
+def log_marginal_likelihood_estimate(alg, k, target=None):
+    """SMCAlgorithm.log_marginal_likelihood_estimate (smc.py:145-156)."""
+    if target is not None:
+        alg = ChangeTarget(alg, target)
+    sub = split(k)[..., 1, :]
+    return alg.run_smc(sub).get_log_marginal_likelihood_estimate()
+
+
+def random_weighted(alg, k, target: Target):
+    """SMCAlgorithm.random_weighted (smc.py:162-179)."""
+    algorithm = ChangeTarget(alg, target)
+    ks = split(k)
+    k0, sub = ks[..., 0, :], ks[..., 1, :]
+    coll = algorithm.run_smc(k0)
+    idx = coll.sample_index(sub)
+    lw = coll.get_log_weights()
+    score = coll.get_particles().get_score()
+    take = lambda a: np.take_along_axis(np.asarray(a), np.asarray(idx)[..., None], axis=-1)[..., 0]
+    est = (take(score) - coll.get_log_marginal_likelihood_estimate()).astype(np.float32)
+    chm = target.filter_to_unconstrained(coll.get_particles().get_choices()).map_values(
+        lambda v: take(v) if np.shape(v)[: lw.ndim] == lw.shape else v)
+    return est, chm
+
+
+# ---------------------------------------------------------------------------
+# resampling + SMC step: BUILD-DEFINED — parity unpinned
+# ---------------------------------------------------------------------------
+SYSTEMATIC, STRATIFIED, MULTINOMIAL = 0, 1, 2
+
+
+def cdf_shift(n_total: int) -> int:
+    """fixed-point scale exponent: sum of n_total terms <= 2^shift stays < 2^62."""
+    need = 0
+    while (1 << need) < n_total:
+        need += 1
+    return 62 - need
+
+
+def weight_cdf(lw, n_total=None):
+    """q_i = floor(exp(lw_i - max lw) * 2^shift) as uint64; inclusive cumsum."""
+    lw = f32(lw).reshape(-1)
+    n_total = lw.size if n_total is None else n_total
+    shift = cdf_shift(n_total)
+    M = np.float32(lw.max())
+    q = np.empty(lw.size, dtype=np.uint64)
+    lib().orc_weight_fixed(I64(lw.size), _p(lw), ctypes.c_float(M), ctypes.c_int(shift), _p(q))
+    cdf = np.cumsum(q, dtype=np.uint64)
+    return cdf, int(cdf[-1]), float(M), shift
+
+
+def ancestors(kind, k, cdf, n_out=None):
+    """Exact integer inverse-CDF (include/genmi.h, gmx_ancestors):
+      systematic / stratified: first i with cdf_i * (n*2^23) > (j*2^23 + u) * total
+      multinomial (jax.random.choice):  first i with cdf_i * 2^23 >= total * (2^23 - u_j)
+    u = 23-bit uniforms = bits >> 9.  Thresholds are evaluated with Python
+    integers (object arrays), then a uint64 searchsorted on the floor-divided
+    thresholds (for an integer c and rational x:  c > x  <=>  c > floor(x))."""
+    cdf = np.asarray(cdf, dtype=np.uint64)
+    n_in = cdf.size
+    n_out = n_in if n_out is None else n_out
+    total = int(cdf[-1])
+    if total == 0:
+        return np.full(n_out, n_in - 1, dtype=np.int32)
+    j = np.arange(n_out, dtype=np.uint64)
+    if kind == SYSTEMATIC:
+        u = int(bits32(k, 0)) >> 9
+    else:
+        u = (bits32(np.asarray(k)[None, :], j) >> np.uint32(9)).astype(object)
+    jo = j.astype(object)
+    if kind == MULTINOMIAL:
+        # c*2^23 >= Q  <=>  c*2^23 > Q-1  <=>  c > floor((Q-1)/2^23);  Q >= total >= 1
+        Q = total * ((1 << 23) - u)
+        thr = (Q - 1) // (1 << 23)
+    else:
+        P = (jo * (1 << 23) + u) * total
+        thr = P // (n_out << 23)
+    thr64 = np.array(thr, dtype=np.uint64)
+    idx = np.searchsorted(cdf, thr64, side="right")     # first i with cdf_i > thr
+    return np.minimum(idx, n_in - 1).astype(np.int32)
+
+
+def log_ml_increment(M, total, shift, n):
+    """log( (1/n) sum_i exp(lw_i) ) from the integer total, evaluated in f64 on
+    the host: M + log(total * 2^-shift) - log(n)."""
+    return float(M) + float(np.log(np.float64(total))) - shift * float(np.log(2.0)) - float(np.log(np.float64(n)))
+
+
+def gather_trace(tr, anc):
+    return _tree_index(tr, anc)
+
+
+def smc_step_keys(run_key, t):
+    """BUILD-DEFINED key schedule of the SMC sweep: step key = fold_in(run_key, t);
+    (k_prop, k_res, k_mh) = split(step_key, 3)."""
+    ks = split(fold_in(run_key, t), 3)
+    return ks[0], ks[1], ks[2]

@@ -1,0 +1,150 @@
+"""ctypes binding of libgenmi_hip.so (include/genmi.h).
+
+The product has exactly one compute backend: the HIP library for gfx950.  If
+it is missing, or no GPU is visible, every entry point raises — there is no
+CPU fallback.  (tests/hostsim installs its own object through `install()` to
+exercise the host logic on machines without a GPU; nothing in this package
+refers to it.)
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64,
+                    c_size_t, c_uint8, c_uint32, c_uint64, c_void_p)
+
+import torch
+
+GMX_MAX_IN = 64
+GMX_MAX_OUT = 64
+GMX_MAX_TAB = 8
+GMX_MAX_UNI = 64
+
+KEY_NONE, KEY_ARRAY, KEY_SPLIT, KEY_ROWSPLIT, KEY_BCAST = 0, 1, 2, 3, 4
+RESAMPLE_SYSTEMATIC, RESAMPLE_STRATIFIED, RESAMPLE_MULTINOMIAL = 0, 1, 2
+
+
+class RunArgs(Structure):
+    """struct gmx_run_args"""
+    _fields_ = [
+        ("in_d", c_void_p * GMX_MAX_IN),
+        ("out_d", c_void_p * GMX_MAX_OUT),
+        ("tab_d", c_void_p * GMX_MAX_TAB),
+        ("uni", c_uint32 * GMX_MAX_UNI),
+        ("ancestors_d", c_void_p),
+        ("key_mode", c_int32),
+        ("key0", c_uint32),
+        ("key1", c_uint32),
+        ("keys_d", c_void_p),
+        ("key_inner", c_int64),
+        ("index_offset", c_int64),
+        ("red_out_d", c_void_p),
+    ]
+
+
+class GenmiError(RuntimeError):
+    pass
+
+
+_LIB_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib")
+LIB_PATH = os.path.join(_LIB_DIR, "libgenmi_hip.so")
+
+
+class Backend:
+    """Loaded C-ABI + the torch device its pointers live on."""
+
+    def __init__(self, cdll, device: torch.device, uses_streams: bool):
+        self.c = cdll
+        self.device = device
+        self.uses_streams = uses_streams
+        self._proto()
+
+    def _proto(self):
+        c = self.c
+        c.gmx_version.restype = c_int
+        c.gmx_last_error.restype = c_char_p
+        c.gmx_threefry2x32_host.argtypes = [c_uint32, c_uint32, c_uint32, c_uint32, POINTER(c_uint32)]
+        c.gmx_threefry2x32_host.restype = None
+        c.gmx_split.argtypes = [POINTER(c_uint32), c_int64, c_int64, c_void_p, c_void_p]
+        c.gmx_split_rows.argtypes = [c_void_p, c_int64, c_int64, c_void_p, c_void_p]
+        c.gmx_fold_in.argtypes = [c_void_p, c_uint32, c_int64, c_void_p, c_void_p]
+        c.gmx_random_bits.argtypes = [c_void_p, c_int64, c_int64, c_void_p, c_void_p]
+        c.gmx_program_create.argtypes = [POINTER(c_uint32), c_size_t, POINTER(c_void_p)]
+        c.gmx_program_destroy.argtypes = [c_void_p]
+        c.gmx_program_grid.argtypes = [c_void_p, c_int64]
+        c.gmx_program_grid.restype = c_int64
+        c.gmx_program_run.argtypes = [c_void_p, c_int64, POINTER(RunArgs), c_void_p]
+        c.gmx_logsumexp_workspace.argtypes = [c_int64, c_int64]
+        c.gmx_logsumexp_workspace.restype = c_size_t
+        c.gmx_logsumexp.argtypes = [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]
+        c.gmx_weight_cdf_workspace.argtypes = [c_int64]
+        c.gmx_weight_cdf_workspace.restype = c_size_t
+        c.gmx_weight_cdf.argtypes = [c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p, c_void_p,
+                                     c_void_p, c_void_p, c_void_p]
+        c.gmx_ancestors.argtypes = [c_int, POINTER(c_uint32), c_void_p, c_int64, c_uint64, c_void_p,
+                                    c_int64, c_int64, c_int64, c_void_p, c_void_p]
+        c.gmx_gather.argtypes = [POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int32), c_int32,
+                                 c_void_p, c_int64, c_void_p]
+        c.gmx_categorical_rows.argtypes = [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p]
+        c.gmx_mh_accept.argtypes = [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]
+        c.gmx_select.argtypes = [c_void_p, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),
+                                 POINTER(c_int32), c_int32, c_int64, c_void_p]
+        c.gmx_capture_begin.argtypes = [c_void_p]
+        c.gmx_capture_end.argtypes = [c_void_p, POINTER(c_void_p)]
+        c.gmx_graph_launch.argtypes = [c_void_p, c_void_p]
+        c.gmx_graph_destroy.argtypes = [c_void_p]
+        c.gmx_timer_create.argtypes = [POINTER(c_void_p)]
+        c.gmx_timer_start.argtypes = [c_void_p, c_void_p]
+        c.gmx_timer_stop.argtypes = [c_void_p, c_void_p]
+        c.gmx_timer_elapsed_ms.argtypes = [c_void_p, POINTER(c_float)]
+        c.gmx_timer_destroy.argtypes = [c_void_p]
+
+    # ------------------------------------------------------------------
+    def check(self, rc: int, what: str = ""):
+        if rc != 0:
+            msg = self.c.gmx_last_error()
+            raise GenmiError(f"{what}: {msg.decode() if msg else 'error'}")
+
+    def stream(self):
+        if not self.uses_streams:
+            return None
+        return c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def ptr(self, t):
+        if t is None:
+            return None
+        if t.device.type != self.device.type:
+            raise GenmiError(f"tensor on {t.device}, backend on {self.device}")
+        return c_void_p(t.data_ptr())
+
+
+_backend: Backend | None = None
+
+
+def install(backend: Backend | None):
+    """Replace the active backend (used by tests/hostsim only)."""
+    global _backend
+    _backend = backend
+
+
+def get() -> Backend:
+    global _backend
+    if _backend is not None:
+        return _backend
+    if not os.path.exists(LIB_PATH):
+        raise GenmiError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). genjax_amd has no CPU fallback.")
+    if not torch.cuda.is_available():
+        raise GenmiError("no HIP device visible: genjax_amd runs on MI355X (gfx950) only; "
+                         "there is no CPU fallback.")
+    cdll = ctypes.CDLL(LIB_PATH)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    _backend = Backend(cdll, dev, uses_streams=True)
+    if _backend.c.gmx_version() != 1:
+        raise GenmiError("libgenmi_hip.so ABI version mismatch")
+    return _backend
+
+
+def device() -> torch.device:
+    return get().device

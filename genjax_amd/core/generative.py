@@ -1,0 +1,290 @@
+"""Generative function interface: abstract types kept from the reference so
+models and inference code read the same
+(src/genjax/_src/core/generative/generative_function.py:72-689, 1557-1689;
+concepts.py:95-164; requests.py:48-95; interpreters/incremental.py Diff).
+"""
+from __future__ import annotations
+
+from typing import Any
+
+from .choice_map import ChoiceMap, Selection
+
+
+# ---------------------------------------------------------------------------
+# change tags (incremental.py:57-120)
+# ---------------------------------------------------------------------------
+class _ChangeTangent:
+    def __repr__(self):
+        return type(self).__name__
+
+
+class _NoChange(_ChangeTangent):
+    pass
+
+
+class _UnknownChange(_ChangeTangent):
+    pass
+
+
+NoChange = _NoChange()
+UnknownChange = _UnknownChange()
+
+
+class Diff:
+    """A value tagged with whether it changed since the trace was made."""
+    __slots__ = ("primal", "tangent")
+
+    def __init__(self, primal, tangent):
+        self.primal, self.tangent = primal, tangent
+
+    def get_primal(self): return self.primal
+    def get_tangent(self): return self.tangent
+
+    @staticmethod
+    def no_change(tree):
+        return _tree_map(lambda v: v if isinstance(v, Diff) else Diff(v, NoChange), tree)
+
+    @staticmethod
+    def unknown_change(tree):
+        return _tree_map(lambda v: Diff(v.primal, UnknownChange) if isinstance(v, Diff) else Diff(v, UnknownChange), tree)
+
+    @staticmethod
+    def tree_primal(tree):
+        return _tree_map(lambda v: v.primal if isinstance(v, Diff) else v, tree)
+
+    @staticmethod
+    def tree_tangent(tree):
+        return _tree_map(lambda v: v.tangent if isinstance(v, Diff) else UnknownChange, tree)
+
+    @staticmethod
+    def static_check_no_change(tree) -> bool:
+        ok = True
+
+        def visit(v):
+            nonlocal ok
+            if not (isinstance(v, Diff) and v.tangent is NoChange):
+                ok = False
+            return v
+        _tree_map(visit, tree)
+        return ok
+
+    @staticmethod
+    def static_check_tree_diff(tree) -> bool:
+        ok = True
+
+        def visit(v):
+            nonlocal ok
+            if not isinstance(v, Diff):
+                ok = False
+            return v
+        _tree_map(visit, tree)
+        return ok
+
+    def __repr__(self):
+        return f"Diff({self.primal!r}, {self.tangent!r})"
+
+
+def _tree_map(fn, tree):
+    if isinstance(tree, Diff):
+        return fn(tree)
+    if isinstance(tree, tuple):
+        return tuple(_tree_map(fn, t) for t in tree)
+    if isinstance(tree, list):
+        return [_tree_map(fn, t) for t in tree]
+    if isinstance(tree, dict):
+        return {k: _tree_map(fn, t) for k, t in tree.items()}
+    return fn(tree)
+
+
+# ---------------------------------------------------------------------------
+# traces
+# ---------------------------------------------------------------------------
+class Trace:
+    """Trace ABC (generative_function.py:72-230)."""
+
+    def get_args(self): raise NotImplementedError
+    def get_retval(self): raise NotImplementedError
+    def get_score(self): raise NotImplementedError
+    def get_choices(self) -> ChoiceMap: raise NotImplementedError
+    def get_gen_fn(self): raise NotImplementedError
+
+    def get_sample(self):
+        return self.get_choices()
+
+    def edit(self, key, request, argdiffs=None):
+        if argdiffs is None:
+            argdiffs = Diff.no_change(self.get_args())
+        return request.edit(key, self, argdiffs)
+
+    def update(self, key, constraint, argdiffs=None):
+        if argdiffs is None:
+            argdiffs = Diff.no_change(self.get_args())
+        return self.get_gen_fn().update(key, self, constraint, argdiffs)
+
+    def project(self, key, selection):
+        return self.get_gen_fn().project(key, self, selection)
+
+    @property
+    def batch_shape(self):
+        s = self.get_score()
+        return tuple(getattr(s, "shape", ()))
+
+
+# ---------------------------------------------------------------------------
+# edit requests
+# ---------------------------------------------------------------------------
+class NotSupportedEditRequest(Exception):
+    pass
+
+
+class EditRequest:
+    """EditRequest / PrimitiveEditRequest (concepts.py:95-150): primitive
+    requests are answered by the trace's generative function."""
+
+    def edit(self, key, tr: Trace, argdiffs):
+        return tr.get_gen_fn().edit(key, tr, self, argdiffs)
+
+    def dimap(self, *, pre=lambda v: v, post=lambda v: v):
+        return DiffAnnotate(self, argdiff_fn=pre, retdiff_fn=post)
+
+
+PrimitiveEditRequest = EditRequest
+
+
+class Update(EditRequest):
+    """generative_function.py:1687-1689"""
+    __match_args__ = ("constraint",)
+
+    def __init__(self, constraint: ChoiceMap):
+        self.constraint = constraint
+
+    def __repr__(self):
+        return f"Update({self.constraint!r})"
+
+
+class Regenerate(EditRequest):
+    """requests.py:63-65"""
+    __match_args__ = ("selection",)
+
+    def __init__(self, selection: Selection):
+        self.selection = selection
+
+
+class EmptyRequest(EditRequest):
+    """requests.py:48-60: no change requested; re-scores only what changed args force."""
+
+    def edit(self, key, tr: Trace, argdiffs):
+        if Diff.static_check_no_change(argdiffs):
+            return tr, 0.0, Diff.no_change(tr.get_retval()), EmptyRequest()
+        return Update(ChoiceMap.empty()).edit(key, tr, argdiffs)
+
+
+class DiffAnnotate(EditRequest):
+    """requests.py:68-95"""
+
+    def __init__(self, request, argdiff_fn=lambda v: v, retdiff_fn=lambda v: v):
+        self.request, self.argdiff_fn, self.retdiff_fn = request, argdiff_fn, retdiff_fn
+
+    def edit(self, key, tr, argdiffs):
+        new_tr, w, retdiff, bwd = self.request.edit(key, tr, self.argdiff_fn(argdiffs))
+        return new_tr, w, self.retdiff_fn(retdiff), bwd
+
+
+# ---------------------------------------------------------------------------
+# generative functions
+# ---------------------------------------------------------------------------
+class GenerativeFunction:
+    """GenerativeFunction ABC (generative_function.py:232-689)."""
+
+    # abstract interface ---------------------------------------------------------
+    def simulate(self, key, args): raise NotImplementedError
+    def assess(self, sample: ChoiceMap, args): raise NotImplementedError
+    def generate(self, key, constraint: ChoiceMap, args): raise NotImplementedError
+    def project(self, key, trace, selection): raise NotImplementedError
+    def edit(self, key, trace, edit_request, argdiffs): raise NotImplementedError
+
+    # derived (generative_function.py:611-689) -------------------------------------
+    def update(self, key, trace, constraint: ChoiceMap, argdiffs):
+        tr, w, rd, bwd = Update(constraint).edit(key, trace, argdiffs)
+        assert isinstance(bwd, Update), type(bwd)
+        return tr, w, rd, bwd.constraint
+
+    def importance(self, key, constraint: ChoiceMap, args):
+        return self.generate(key, constraint, args)
+
+    def propose(self, key, args):
+        tr = self.simulate(key, args)
+        return tr.get_choices(), tr.get_score(), tr.get_retval()
+
+    def handle_kwargs(self):
+        raise NotImplementedError(f"{type(self).__name__} does not accept keyword arguments")
+
+    def __call__(self, *args, **kwargs) -> "GenerativeFunctionClosure":
+        return GenerativeFunctionClosure(self, args, kwargs)
+
+    # sugar ---------------------------------------------------------------------------
+    def marginal(self, *, selection=None, algorithm=None):
+        from ..inference.sp import Marginal
+        return Marginal(self, selection if selection is not None else Selection.all(), algorithm)
+
+    def vmap(self, *, in_axes=0):
+        from ..combinators import Vmap
+        return Vmap(self, in_axes)
+
+    def repeat(self, *, n: int):
+        from ..combinators import repeat
+        return repeat(n=n)(self)
+
+    def scan(self, *, n=None):
+        raise NotImplementedError("Scan combinator: SURVEY.md §8(f) item 1 (next tier)")
+
+
+class GenerativeFunctionClosure(GenerativeFunction):
+    """`gen_fn(*args)`: `closure @ addr` traces the callee at addr inside a
+    `@gen` function; `closure(key)` simulates and returns the return value
+    (generative_function.py:1557-1684)."""
+
+    def __init__(self, gen_fn, args, kwargs):
+        self.gen_fn, self.args, self.kwargs = gen_fn, tuple(args), dict(kwargs)
+
+    def _target(self):
+        """(callee, args) with keyword arguments folded the way the reference
+        does: a kwarg-handling callee receives (args, kwargs)."""
+        if self.kwargs:
+            return self.gen_fn.handle_kwargs(), (self.args, self.kwargs)
+        return self.gen_fn, self.args
+
+    def __matmul__(self, addr):
+        from ..static import trace
+        gf, args = self._target()
+        return trace(addr, gf, args)
+
+    def __call__(self, key, *args, **kwargs):
+        full = GenerativeFunctionClosure(self.gen_fn, self.args + args, {**self.kwargs, **kwargs})
+        gf, a = full._target()
+        return gf.simulate(key, a).get_retval()
+
+    def simulate(self, key, args):
+        gf, a = GenerativeFunctionClosure(self.gen_fn, self.args + tuple(args), self.kwargs)._target()
+        return gf.simulate(key, a)
+
+    def generate(self, key, constraint, args):
+        gf, a = GenerativeFunctionClosure(self.gen_fn, self.args + tuple(args), self.kwargs)._target()
+        return gf.generate(key, constraint, a)
+
+    def assess(self, sample, args):
+        gf, a = GenerativeFunctionClosure(self.gen_fn, self.args + tuple(args), self.kwargs)._target()
+        return gf.assess(sample, a)
+
+    def project(self, key, trace, selection):
+        return self.gen_fn.project(key, trace, selection)
+
+    def edit(self, key, trace, edit_request, argdiffs):
+        return self.gen_fn.edit(key, trace, edit_request, argdiffs)
+
+
+Arguments = tuple
+Argdiffs = Any
+Retdiff = Any
+Score = Any
+Weight = Any

@@ -19,8 +19,10 @@
 
 #if defined(__HIPCC__)
 #define GMX_HD __host__ __device__ __forceinline__
+#define GMX_HDM __host__ __device__ __forceinline__   /* member functions */
 #else
 #define GMX_HD static inline
+#define GMX_HDM inline
 #endif
 
 #define GMX_INF_BITS 0x7f800000u

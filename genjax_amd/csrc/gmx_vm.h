@@ -24,13 +24,13 @@ struct gmx_regs_vgpr {
   // s_set_gpr_idx/v_mov (an array would depend on promote-alloca heuristics)
   typedef uint32_t vec_t __attribute__((ext_vector_type(N)));
   vec_t v;
-  GMX_HD void init() { v = (vec_t)(0u); }
+  GMX_HDM void init() { v = (vec_t)(0u); }
 #else
   uint32_t v[N];
-  GMX_HD void init() { for (int k = 0; k < N; ++k) v[k] = 0u; }
+  GMX_HDM void init() { for (int k = 0; k < N; ++k) v[k] = 0u; }
 #endif
-  GMX_HD uint32_t get(uint32_t i) const { return v[i]; }
-  GMX_HD void set(uint32_t i, uint32_t x) { v[i] = x; }
+  GMX_HDM uint32_t get(uint32_t i) const { return v[i]; }
+  GMX_HDM void set(uint32_t i, uint32_t x) { v[i] = x; }
 };
 
 GMX_HD float gmx_asf(uint32_t u) { return gmx_u2f(u); }

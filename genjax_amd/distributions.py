@@ -1,0 +1,263 @@
+"""Distributions as leaf generative functions.
+
+Each distribution supplies the SYMBOLIC sampler / log-density (program ops that
+run inside the fused kernel: csrc/gmx_dist.h) and inherits the leaf GFI
+semantics of the reference's `Distribution` / `ExactDensity`
+(src/genjax/_src/generative_functions/distributions/distribution.py:90-419);
+the instances mirror the hot `tfp_distribution` wrappers
+(distributions/tensorflow_probability/__init__.py: normal :259, uniform :294,
+beta :82, flip :155, bernoulli :72, categorical :102-104).
+
+Vector-valued sites use ONE site key; element j takes counter j and the
+array-valued log_prob is summed into one site score (distribution.py:383-396).
+"""
+from __future__ import annotations
+
+import warnings
+
+import numpy as np
+
+from . import tracer as T
+from .core.choice_map import ChoiceMap
+from .core.generative import GenerativeFunction
+from .tracer import Expr, current_graph
+
+
+def _obj(x):
+    return isinstance(x, np.ndarray) and x.dtype == object
+
+
+def _bcast(args):
+    """Broadcast symbolic args; returns (list of flat element tuples, shape)."""
+    arrs = [a if isinstance(a, np.ndarray) else np.asarray(a, dtype=object) for a in args]
+    if all(a.ndim == 0 for a in arrs):
+        return [tuple(a.item() for a in arrs)], ()
+    b = np.broadcast_arrays(*arrs)
+    shape = b[0].shape
+    return [tuple(x[idx] for x in b) for idx in np.ndindex(shape)], shape
+
+
+def _seq_sum(terms):
+    acc = terms[0]
+    for t in terms[1:]:
+        acc = acc + t
+    return acc
+
+
+class Distribution(GenerativeFunction):
+    name = "distribution"
+    value_dtype = "f32"
+    sample_op = None       # program op of the scalar sampler
+    logpdf_op = None
+    n_params = 2
+    param_names: tuple = ()
+
+    # -- argument handling ---------------------------------------------------
+    def handle_kwargs(self):
+        return self          # exact_density types reply with self (distribution.py:468)
+
+    def canon(self, args) -> tuple:
+        """Accept (a, b) or the kwargs form ((a, b), {kw}) (distribution.py:448-466)."""
+        if len(args) == 2 and isinstance(args[1], dict) and isinstance(args[0], tuple):
+            pos, kw = args
+            kw = dict(kw)
+            kw.pop("sample_shape", None)
+            return self.from_kwargs(tuple(pos), kw)
+        return tuple(args)
+
+    def from_kwargs(self, pos, kw):
+        out = list(pos)
+        for name in self.param_names[len(pos):]:
+            if name not in kw:
+                raise TypeError(f"{self.name}: missing argument {name!r}")
+            out.append(kw.pop(name))
+        if kw:
+            raise TypeError(f"{self.name}: unexpected keyword arguments {sorted(kw)}")
+        return tuple(out)
+
+    # -- symbolic sampler / density -------------------------------------------------
+    def _conv_value(self, v):
+        return {"f32": T.as_float, "i32": T.as_int, "bool": T.as_bool}[self.value_dtype](v)
+
+    def sym_sample(self, key: Expr, args: tuple):
+        g = current_graph()
+        elems, shape = _bcast(args)
+        out = []
+        for e, a in enumerate(elems):
+            ops = tuple(T.as_float(x).node for x in a)
+            out.append(Expr(g.add(self.sample_op, (key.node,) + ops, imm=e, dtype=self.value_dtype)))
+        if shape == ():
+            return out[0]
+        arr = np.empty(len(out), dtype=object)
+        arr[:] = out
+        return arr.reshape(shape)
+
+    def sym_logpdf(self, v, args: tuple) -> Expr:
+        """estimate_logpdf: elementwise log_prob summed in element order."""
+        g = current_graph()
+        elems, _ = _bcast((v,) + tuple(args))
+        terms = []
+        for el in elems:
+            x = self._conv_value(el[0])
+            ops = tuple(T.as_float(a).node for a in el[1:])
+            terms.append(Expr(g.add(self.logpdf_op, (x.node,) + ops, dtype="f32")))
+        return _seq_sum(terms)
+
+    # -- direct (non-traced) convenience: tfp-style sample / logpdf ---------------------
+    def sample(self, key, *args, **kwargs):
+        a = self.canon((args, kwargs)) if kwargs else args
+        return self.simulate(key, a).get_retval()
+
+    def logpdf(self, v, *args, **kwargs):
+        a = self.canon((args, kwargs)) if kwargs else args
+        return self.assess(ChoiceMap.choice(v), a)[0]
+
+    # -- GFI: answered by the static engine with a one-site program ----------------------
+    def simulate(self, key, args):
+        from .static import run_gfi
+        return run_gfi(self, "simulate", key, args)
+
+    def generate(self, key, constraint, args):
+        from .static import run_gfi
+        return run_gfi(self, "generate", key, args, constraint=constraint)
+
+    def assess(self, sample, args, batch_shape=None):
+        from .static import run_gfi
+        return run_gfi(self, "assess", None, args, constraint=sample, batch_shape=batch_shape)
+
+    def edit(self, key, trace, edit_request, argdiffs):
+        from .static import run_edit
+        return run_edit(self, key, trace, edit_request, argdiffs)
+
+    def project(self, key, trace, selection):
+        import torch
+        s = trace.get_score()
+        return s if selection.check() else (torch.zeros_like(s) if hasattr(s, "shape") else 0.0)
+
+    def random_weighted(self, key, *args):
+        tr = self.simulate(key, args)
+        return tr.get_score(), tr.get_retval()
+
+    def estimate_logpdf(self, key, v, *args):
+        return self.assess(ChoiceMap.choice(v), args)[0]
+
+    def __repr__(self):
+        return f"genjax.{self.name}"
+
+
+class _Normal(Distribution):
+    name, sample_op, logpdf_op = "normal", "S_NORMAL", "L_NORMAL"
+    param_names = ("loc", "scale")
+
+
+class _Uniform(Distribution):
+    name, sample_op, logpdf_op = "uniform", "S_UNIFORM", "L_UNIFORM"
+    param_names = ("low", "high")
+
+
+class _Beta(Distribution):
+    name, sample_op, logpdf_op = "beta", "S_BETA", "L_BETA"
+    param_names = ("concentration1", "concentration0")
+
+
+class _Flip(Distribution):
+    """Bernoulli(probs=p, dtype=bool)"""
+    name, sample_op, logpdf_op = "flip", "S_FLIP", "L_FLIP"
+    value_dtype = "bool"
+    param_names = ("p",)
+
+
+class _Bernoulli(Distribution):
+    """Bernoulli(logits=...) — a bare parameter means logits and warns
+    (implicit_logit_warning, distribution.py:479-500)."""
+    name, sample_op, logpdf_op = "bernoulli", "S_BERNL", "L_BERNL"
+    value_dtype = "i32"
+    param_names = ("logits",)
+
+    def canon(self, args):
+        if len(args) == 2 and isinstance(args[1], dict) and isinstance(args[0], tuple):
+            pos, kw = args
+            kw = dict(kw)
+            kw.pop("sample_shape", None)
+            if "probs" in kw:
+                from . import numpy as jnp
+                p = kw.pop("probs")
+                return (jnp.log(p) - jnp.log1p(-p),) if T.is_symbolic(p) or T.is_tracing() else (_logit_host(p),)
+            if "logits" in kw:
+                return (kw.pop("logits"),)
+            args = pos
+        if len(args) == 1:
+            warnings.warn("The use of a bare argument to genjax.bernoulli is deprecated. Please specify "
+                          "`logits=` or `probs=`. The default, which will be used in this case, is logits.",
+                          DeprecationWarning, stacklevel=3)
+        return tuple(args)
+
+
+def _logit_host(p):
+    p = np.asarray(p, dtype=np.float32)
+    return np.log(p) - np.log1p(-p)
+
+
+class _Categorical(Distribution):
+    """Categorical over the LAST axis of logits (bare / logits=) or log(probs=).
+    Sampling is Gumbel-max with gumbel counter = category index, first max wins
+    (SURVEY.md App. A.3); log_prob(k) = logits[k] - logsumexp(logits)."""
+    name = "categorical"
+    value_dtype = "i32"
+    param_names = ("logits",)
+
+    def canon(self, args):
+        if len(args) == 2 and isinstance(args[1], dict) and isinstance(args[0], tuple):
+            pos, kw = args
+            kw = dict(kw)
+            kw.pop("sample_shape", None)
+            if "probs" in kw:
+                from . import numpy as jnp
+                p = kw.pop("probs")
+                if T.is_tracing():
+                    p = np.asarray([T.lift(x) for x in np.asarray(p, dtype=object).reshape(-1)], dtype=object)
+                    return (jnp.log(p),)
+                return (np.log(np.asarray(p, dtype=np.float32)),)
+            if "logits" in kw:
+                return (kw.pop("logits"),)
+            args = pos
+        if len(args) == 1 and not isinstance(args[0], dict):
+            warnings.warn("The use of a bare argument to genjax.categorical is deprecated. Please specify "
+                          "`logits=` or `probs=`. The default, which will be used in this case, is logits.",
+                          DeprecationWarning, stacklevel=3)
+        return tuple(args)
+
+    def _logits(self, args):
+        l = args[0]
+        l = l if isinstance(l, np.ndarray) else np.asarray(l, dtype=object)
+        if l.ndim != 1:
+            raise NotImplementedError("categorical: logits must be a vector per particle")
+        return [T.as_float(x) for x in l]
+
+    def sym_sample(self, key: Expr, args: tuple):
+        g = current_graph()
+        state = None
+        for k, lk in enumerate(self._logits(args)):
+            ctr = g.const_i32(k)
+            state = g.add("S_CATSTEP", (state, key.node, lk.node, ctr), imm=k, dtype="cat")
+        # the index lives in the second register of the state pair
+        idx = g.add("CATIDX", (state,), dtype="i32")
+        return Expr(idx)
+
+    def sym_logpdf(self, v, args: tuple) -> Expr:
+        from . import numpy as jnp
+        ls = self._logits(args)
+        lse = jnp.logsumexp(np.asarray(ls, dtype=object))
+        vi = T.as_int(v)
+        picked = ls[0]
+        for k in range(1, len(ls)):
+            picked = T.where(vi == k, ls[k], picked)
+        return picked - lse
+
+
+normal = _Normal()
+uniform = _Uniform()
+beta = _Beta()
+flip = _Flip()
+bernoulli = _Bernoulli()
+categorical = _Categorical()

@@ -1,0 +1,472 @@
+"""Launch engine: turns (values, choice maps, traces) into bound site-program
+launches and back.
+
+  flatten   a pytree of launch values into leaves + a hashable signature;
+  Tracing   (trace time, once per signature) leaves -> symbolic values, while
+            recording how each program input / uniform is bound to a leaf;
+  Compiled  (launch time) binds leaves, allocates outputs, calls
+            gmx_program_run, hands tensors back by "origin".
+
+Layout in HBM: struct-of-arrays.  A per-particle scalar leaf is one contiguous
+[N] vector; a per-particle value with event shape E is E such vectors ([E, N]
+row-major, exposed to the user as an [N, E] strided view), so every load and
+store in the kernel is one coalesced 256-byte wave access.
+"""
+from __future__ import annotations
+
+import struct
+from ctypes import POINTER, c_uint32, c_void_p, cast
+
+import numpy as np
+import torch
+
+from . import _lib
+from .core.choice_map import ChoiceMap
+from .program import F_BCAST, F_GATHER, Graph, compile_graph
+from .random import Key
+from .tracer import Expr
+
+
+# ---------------------------------------------------------------------------
+# launch values
+# ---------------------------------------------------------------------------
+class Gathered:
+    """`source[ancestors]` kept lazy so the consuming kernel fuses the gather
+    (row = ancestors[i]) instead of materialising resampled particles."""
+
+    def __init__(self, source: torch.Tensor, ancestors: torch.Tensor):
+        self.source, self.ancestors = source, ancestors
+
+    @property
+    def shape(self):
+        return tuple(self.ancestors.shape) + tuple(self.source.shape[1:])
+
+    @property
+    def dtype(self):
+        return self.source.dtype
+
+    def materialize(self) -> torch.Tensor:
+        return gather_leaves([self.source], self.ancestors)[0]
+
+
+def materialize(v):
+    return v.materialize() if isinstance(v, Gathered) else v
+
+
+_TDT = {torch.float32: "f32", torch.float64: "f32", torch.float16: "f32", torch.bfloat16: "f32",
+        torch.int32: "i32", torch.int64: "i32", torch.int16: "i32", torch.int8: "i32",
+        torch.uint8: "i32", torch.bool: "bool"}
+_STORE = {"f32": torch.float32, "i32": torch.int32, "bool": torch.bool}
+
+
+def _np_dt(a: np.ndarray) -> str:
+    return "f32" if a.dtype.kind == "f" else ("bool" if a.dtype.kind == "b" else "i32")
+
+
+def leaf_spec(v, batch: tuple):
+    """Classify one launch value (see module docstring)."""
+    nb = len(batch)
+    if v is None:
+        return ("none",)
+    if isinstance(v, (bool, np.bool_)):
+        return ("uni", "bool")
+    if isinstance(v, (int, np.integer)):
+        return ("uni", "i32")
+    if isinstance(v, (float, np.floating)):
+        return ("uni", "f32")
+    if isinstance(v, Gathered):
+        if tuple(v.ancestors.shape) != tuple(batch):
+            raise ValueError(f"gathered value with batch {tuple(v.ancestors.shape)} in a launch over {batch}")
+        return ("gather", _TDT[v.dtype], tuple(v.source.shape[1:]))
+    if isinstance(v, torch.Tensor):
+        dt = _TDT[v.dtype]
+        shp = tuple(v.shape)
+        if v.device.type == "cpu" and _lib.get().device.type != "cpu":
+            return leaf_spec(v.numpy(), batch)
+        if shp[:nb] == tuple(batch) and nb > 0:
+            return ("part", dt, shp[nb:])
+        if v.ndim == 0:
+            return ("bcast", dt)
+        if nb == 0:
+            return ("part", dt, shp)
+        return ("dvec", dt, shp)
+    if isinstance(v, (list, tuple)):
+        v = np.asarray(v)
+    if isinstance(v, np.ndarray):
+        if v.dtype == object:
+            raise TypeError("object arrays cannot be launch values")
+        if v.ndim == 0:
+            return leaf_spec(v.item(), batch)
+        return ("hvec", _np_dt(v), tuple(v.shape))
+    raise TypeError(f"unsupported launch value of type {type(v).__name__}")
+
+
+class Flat:
+    """Flatten nested tuples / lists / dicts / ChoiceMaps into leaves."""
+
+    def __init__(self):
+        self.leaves = []
+
+    def add(self, v):
+        if isinstance(v, (tuple, list)) and not _is_number_seq(v):
+            return (type(v).__name__, tuple(self.add(x) for x in v))
+        if isinstance(v, dict):
+            return ("dict", tuple((k, self.add(x)) for k, x in v.items()))
+        if isinstance(v, ChoiceMap):
+            return ("chm", tuple((a, self.add(v[a] if a else v.get_value())) for a in v.addresses()))
+        self.leaves.append(v)
+        return ("leaf", len(self.leaves) - 1)
+
+
+def _is_number_seq(v):
+    return len(v) > 0 and all(isinstance(x, (int, float, np.number)) and not isinstance(x, bool) for x in v) \
+        and isinstance(v, list)
+
+
+def unflatten(tree, fn):
+    """Rebuild the structure, mapping leaf index -> fn(index)."""
+    kind, payload = tree
+    if kind == "leaf":
+        return fn(payload)
+    if kind in ("tuple", "list"):
+        out = [unflatten(t, fn) for t in payload]
+        return tuple(out) if kind == "tuple" else out
+    if kind == "dict":
+        return {k: unflatten(t, fn) for k, t in payload}
+    if kind == "chm":
+        cm = ChoiceMap.empty()
+        for a, t in payload:
+            cm = cm.set(a, unflatten(t, fn))
+        return cm
+    raise ValueError(kind)
+
+
+# ---------------------------------------------------------------------------
+# trace time
+# ---------------------------------------------------------------------------
+class Sym:
+    """A symbolic value plus where it came from (for pass-through outputs)."""
+    __slots__ = ("value", "origin")
+
+    def __init__(self, value, origin=None):
+        self.value, self.origin = value, origin
+
+
+class Tracing:
+    def __init__(self, batch_ndim: int):
+        self.graph = Graph()
+        self.in_plan = []      # (slot, leaf, elem, kind)
+        self.uni_plan = []     # (uni index, leaf, elem, dtype)
+        self.outputs = []      # (dtype, n_elems, [slots])
+        self.node_origin = {}  # id(node) -> origin
+        self.uses_key = False
+
+    # leaves -> symbols ------------------------------------------------------
+    def sym_leaf(self, spec, j) -> Sym:
+        g = self.graph
+        kind = spec[0]
+        if kind == "none":
+            return Sym(None, ("leaf", j))
+        if kind == "uni":
+            n = g.uniform(spec[1])
+            self.uni_plan.append((n.imm, j, None, spec[1]))
+            e = Expr(n)
+            self.node_origin[id(n)] = ("leaf", j)
+            return Sym(e, ("leaf", j))
+        if kind == "hvec":
+            arr = np.empty(spec[2], dtype=object)
+            for e, idx in enumerate(np.ndindex(spec[2])):
+                n = g.uniform(spec[1])
+                self.uni_plan.append((n.imm, j, e, spec[1]))
+                arr[idx] = Expr(n)
+            return Sym(arr, ("leaf", j))
+        flags = {"bcast": F_BCAST, "dvec": F_BCAST, "part": 0, "gather": F_GATHER}[kind]
+        dt = spec[1]
+        event = () if kind == "bcast" else spec[2]
+        if event == ():
+            n = g.input(dt, flags)
+            self.in_plan.append((n.slot, j, 0, kind))
+            self.node_origin[id(n)] = ("leaf", j)
+            return Sym(Expr(n), ("leaf", j))
+        arr = np.empty(event, dtype=object)
+        for e, idx in enumerate(np.ndindex(event)):
+            n = g.input(dt, flags)
+            self.in_plan.append((n.slot, j, e, kind))
+            arr[idx] = Expr(n)
+        return Sym(arr, ("leaf", j))
+
+    # outputs ------------------------------------------------------------------
+    def emit_output(self, value):
+        """Store a symbolic value (Expr or object array) unless it is a pure
+        pass-through / constant; returns its origin."""
+        g = self.graph
+        if value is None:
+            return ("const", None)
+        if isinstance(value, Expr):
+            o = self.node_origin.get(id(value.node))
+            if o is not None:
+                return o
+            if value.node.op == "CONST":
+                return ("const", _const_value(value.node))
+            slot = g.store(value.node)
+            o = ("out", len(self.outputs))
+            self.outputs.append((value.dtype, (), [slot]))
+            self.node_origin[id(value.node)] = o
+            return o
+        if isinstance(value, np.ndarray) and value.dtype == object:
+            from . import tracer as T
+            flat = [T.lift(v) for v in value.reshape(-1)]
+            dts = {v.dtype for v in flat}
+            dt = "f32" if "f32" in dts else ("i32" if "i32" in dts else "bool")
+            conv = {"f32": T.as_float, "i32": T.as_int, "bool": T.as_bool}[dt]
+            slots = [g.store(conv(v).node) for v in flat]
+            o = ("out", len(self.outputs))
+            self.outputs.append((dt, tuple(value.shape), slots))
+            return o
+        if isinstance(value, (tuple, list)):
+            return ("tuple" if isinstance(value, tuple) else "list", [self.emit_output(v) for v in value])
+        if isinstance(value, dict):
+            return ("dict", {k: self.emit_output(v) for k, v in value.items()})
+        return ("const", value)
+
+
+def _const_value(node):
+    if node.dtype == "f32":
+        return struct.unpack("<f", struct.pack("<I", node.imm))[0]
+    v = node.imm if node.imm < 0x80000000 else node.imm - (1 << 32)
+    return bool(v) if node.dtype == "bool" else v
+
+
+# ---------------------------------------------------------------------------
+# launch time
+# ---------------------------------------------------------------------------
+_F32 = struct.Struct("<f")
+_U32 = struct.Struct("<I")
+
+
+def _bits(v, dt) -> int:
+    if dt == "f32":
+        return _U32.unpack(_F32.pack(float(np.float32(v))))[0]
+    if dt == "bool":
+        return 1 if v else 0
+    return int(v) & 0xFFFFFFFF
+
+
+class Compiled:
+    """A created program + its binding plan."""
+
+    def __init__(self, tr: Tracing):
+        be = _lib.get()
+        self.blob = compile_graph(tr.graph)
+        self.in_plan, self.uni_plan, self.outputs = tr.in_plan, tr.uni_plan, tr.outputs
+        self.n_in, self.n_out, self.n_uni = tr.graph.n_in, tr.graph.n_out, tr.graph.n_uni
+        self.uses_red = any(n.op in ("REDMAX", "REDLSE") for n in tr.graph.nodes)
+        if max(self.n_in, self.n_out) > _lib.GMX_MAX_IN or self.n_uni > _lib.GMX_MAX_UNI:
+            raise ValueError("site program exceeds the ABI slot limits "
+                             f"(in={self.n_in}, out={self.n_out}, uni={self.n_uni})")
+        tabs = tr.graph.__dict__.get("tables", [])
+        self.tables = []
+        for t in tabs:
+            a = np.ascontiguousarray(t)
+            if a.dtype.kind == "f":
+                a = a.astype(np.float32)
+            elif a.dtype.kind == "b":
+                a = a.astype(np.int32)
+            else:
+                a = a.astype(np.int32)
+            self.tables.append(torch.from_numpy(a).to(be.device))
+        handle = c_void_p()
+        words = np.ascontiguousarray(self.blob, dtype=np.uint32)
+        be.check(be.c.gmx_program_create(words.ctypes.data_as(POINTER(c_uint32)), words.size, handle),
+                 "gmx_program_create")
+        self.handle = handle
+        self._be = be
+
+    def run(self, leaves, batch: tuple, key: Key | None, red_out=None, index_offset=0, out_buffers=None):
+        """Bind and launch.  Returns the list of output tensors (shape batch+event)."""
+        be = self._be
+        n = int(np.prod(batch, dtype=np.int64))
+        A = _lib.RunArgs()
+        keep = []
+        anc = None
+        soa_cache = {}
+        for slot, j, e, kind in self.in_plan:
+            v = leaves[j]
+            if kind == "gather":
+                if anc is None:
+                    anc = v.ancestors
+                elif anc is not v.ancestors:
+                    raise ValueError("all gathered values of one launch must share their ancestors")
+                src = v.source
+                key_ = (j, "g")
+            else:
+                src = v
+                key_ = (j, kind)
+            buf = soa_cache.get(key_)
+            if buf is None:
+                buf = _prepare_input(src, kind, n if kind == "part" else None, be)
+                soa_cache[key_] = buf
+                keep.append(buf)
+            item = buf.element_size()
+            if kind in ("bcast",):
+                A.in_d[slot] = buf.data_ptr()
+            elif kind == "dvec":
+                A.in_d[slot] = buf.data_ptr() + e * item
+            else:   # part / gather: [E, rows] SoA
+                rows = buf.shape[-1]
+                A.in_d[slot] = buf.data_ptr() + e * rows * item
+        if anc is not None:
+            a32 = anc.reshape(-1)
+            if a32.dtype != torch.int32:
+                a32 = a32.to(torch.int32)
+            keep.append(a32)
+            A.ancestors_d = a32.data_ptr()
+        for ui, j, e, dt in self.uni_plan:
+            v = leaves[j]
+            if e is not None:
+                v = np.asarray(v).reshape(-1)[e]
+            A.uni[ui] = _bits(v, dt)
+        for s, t in enumerate(self.tables):
+            A.tab_d[s] = t.data_ptr()
+        outs = []
+        for k, (dt, event, slots) in enumerate(self.outputs):
+            E = len(slots)
+            if out_buffers is not None and out_buffers[k] is not None:
+                buf = out_buffers[k]
+            else:
+                buf = torch.empty((E, n), dtype=_STORE[dt], device=be.device)
+            item = buf.element_size()
+            for e, slot in enumerate(slots):
+                A.out_d[slot] = buf.data_ptr() + e * n * item
+            if event == ():
+                outs.append(buf.reshape(batch))
+            else:
+                outs.append(buf.reshape(event + tuple(batch)).permute(
+                    *range(len(event), len(event) + len(batch)), *range(len(event))))
+        if key is not None:
+            mode, k0, k1, kt, inner = key.binding()
+            A.key_mode, A.key0, A.key1, A.key_inner = mode, k0, k1, inner
+            if kt is not None:
+                keep.append(kt)
+                A.keys_d = kt.data_ptr()
+        else:
+            A.key_mode = _lib.KEY_NONE
+        A.index_offset = index_offset
+        if self.uses_red:
+            if red_out is None:
+                grid = be.c.gmx_program_grid(self.handle, n)
+                red_out = torch.empty((grid, 2), dtype=torch.float32, device=be.device)
+            A.red_out_d = red_out.data_ptr()
+            self.last_red = red_out
+        be.check(be.c.gmx_program_run(self.handle, n, A, be.stream()), "gmx_program_run")
+        return outs
+
+
+def _prepare_input(src, kind, n, be):
+    """Make the tensor the kernel reads: 4-byte (or bool) elements, SoA rows."""
+    t = src
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"expected a tensor, got {type(t).__name__}")
+    if t.dtype in (torch.float64, torch.float16, torch.bfloat16):
+        t = t.to(torch.float32)
+    elif t.dtype in (torch.int64, torch.int16, torch.int8, torch.uint8):
+        t = t.to(torch.int32)
+    if t.device != be.device:
+        t = t.to(be.device)
+    if kind in ("bcast", "dvec"):
+        return t.contiguous()
+    if kind == "part":
+        rows = n
+        flat = t.reshape(rows, -1)
+    else:
+        flat = t.reshape(t.shape[0], -1)
+    return flat.t().contiguous()       # [E, rows]; no copy when already SoA
+
+
+def resolve(origin, outs, leaves):
+    """origin -> concrete launch result."""
+    kind = origin[0]
+    if kind == "out":
+        return outs[origin[1]]
+    if kind == "leaf":
+        return leaves[origin[1]]
+    if kind == "const":
+        return origin[1]
+    if kind in ("tuple", "list"):
+        seq = [resolve(o, outs, leaves) for o in origin[1]]
+        return tuple(seq) if kind == "tuple" else seq
+    if kind == "dict":
+        return {k: resolve(o, outs, leaves) for k, o in origin[1].items()}
+    raise ValueError(origin)
+
+
+# ---------------------------------------------------------------------------
+# thin wrappers over the remaining C-ABI entry points
+# ---------------------------------------------------------------------------
+def gather_leaves(leaves: list, ancestors: torch.Tensor) -> list:
+    """dst[l][j] = src[l][ancestors[j]] for every leaf (gmx_gather)."""
+    be = _lib.get()
+    anc = ancestors.reshape(-1)
+    if anc.dtype != torch.int32:
+        anc = anc.to(torch.int32)
+    n_out = anc.numel()
+    srcs, dsts, sizes, outs = [], [], [], []
+    for t in leaves:
+        n_src = t.shape[0]
+        event = tuple(t.shape[1:])
+        soa = t.reshape(n_src, -1).t().contiguous()           # [E, n_src]
+        E = soa.shape[0]
+        dst = torch.empty((E, n_out), dtype=t.dtype, device=t.device)
+        for e in range(E):
+            srcs.append(soa.data_ptr() + e * n_src * soa.element_size())
+            dsts.append(dst.data_ptr() + e * n_out * dst.element_size())
+            sizes.append(soa.element_size())
+        outs.append((dst, event, soa))
+    if srcs:
+        L = len(srcs)
+        S = (c_void_p * L)(*srcs)
+        D = (c_void_p * L)(*dsts)
+        Z = (_lib.c_int32 * L)(*sizes)
+        be.check(be.c.gmx_gather(cast(S, POINTER(c_void_p)), cast(D, POINTER(c_void_p)), Z, L,
+                                 be.ptr(anc), n_out, be.stream()), "gmx_gather")
+    res = []
+    bshape = tuple(ancestors.shape)
+    for dst, event, _ in outs:
+        if event == ():
+            res.append(dst.reshape(bshape))
+        else:
+            res.append(dst.reshape(event + bshape).permute(
+                *range(len(event), len(event) + len(bshape)), *range(len(event))))
+    return res
+
+
+def logsumexp_rows(lw: torch.Tensor) -> torch.Tensor:
+    """logsumexp over the last axis (gmx_logsumexp); lw: [..., cols]."""
+    be = _lib.get()
+    cols = lw.shape[-1]
+    rows = int(np.prod(lw.shape[:-1], dtype=np.int64))
+    x = lw.reshape(rows, cols)
+    if x.dtype != torch.float32:
+        x = x.float()
+    x = x.contiguous()
+    out = torch.empty((rows,), dtype=torch.float32, device=x.device)
+    ws_bytes = be.c.gmx_logsumexp_workspace(rows, cols)
+    ws = torch.empty((max(ws_bytes, 16) + 3) // 4, dtype=torch.int32, device=x.device)
+    be.check(be.c.gmx_logsumexp(be.ptr(x), rows, cols, be.ptr(out), None, be.ptr(ws), be.stream()),
+             "gmx_logsumexp")
+    return out.reshape(lw.shape[:-1])
+
+
+def categorical_rows(key: Key, logits: torch.Tensor) -> torch.Tensor:
+    """One Gumbel-max index per row of logits[..., cols] (gmx_categorical_rows)."""
+    be = _lib.get()
+    cols = logits.shape[-1]
+    rows = int(np.prod(logits.shape[:-1], dtype=np.int64))
+    if key.size != rows:
+        raise ValueError(f"need one key per row: key batch {key.shape}, logits {tuple(logits.shape)}")
+    x = logits.reshape(rows, cols).float().contiguous()
+    kd = key.data()
+    out = torch.empty((rows,), dtype=torch.int32, device=x.device)
+    be.check(be.c.gmx_categorical_rows(be.ptr(kd), be.ptr(x), rows, cols, be.ptr(out), be.stream()),
+             "gmx_categorical_rows")
+    return out.reshape(logits.shape[:-1])

@@ -1,0 +1,341 @@
+"""Sequential Monte Carlo combinators.
+
+Part 1 restates src/genjax/_src/inference/smc.py: ParticleCollection :76-109,
+SMCAlgorithm :117-225, Importance :233-279, ImportanceK :282-351,
+ChangeTarget :359-465 — same key plumbing, same weight algebra — with the
+`jax.vmap` over particles replaced by one fused launch per GFI call.
+
+Part 2 is BUILD-DEFINED (the reference has no resampling strategies, no
+extend step, no MH accept: SURVEY.md §0, App. B): scalable resampling
+(systematic / stratified / multinomial over an exact integer CDF), a bootstrap
+`extend`, an MH `rejuvenate`, and `BootstrapSweep`, the graph-captured
+particle-filter sweep bench.py times.  PARITY UNPINNED against the reference
+for Part 2; pinned against oracle/ and closed-form Kalman answers.
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+from ctypes import c_uint32
+
+import numpy as np
+import torch
+
+from .. import _lib, engine
+from ..core.choice_map import ChoiceMap
+from ..core.generative import Diff
+from ..engine import Gathered
+from ..random import Key, fold_in, split
+from ..static import DistributionTrace, StaticTrace
+from .sp import Algorithm, Target
+
+
+# ---------------------------------------------------------------------------
+# helpers over batched traces
+# ---------------------------------------------------------------------------
+def trace_map(tr, fn):
+    """Apply fn to every device leaf of a (batched) trace."""
+    def leaf(v):
+        if isinstance(v, (torch.Tensor, Gathered)):
+            return fn(v)
+        if isinstance(v, tuple):
+            return tuple(leaf(x) for x in v)
+        if isinstance(v, list):
+            return [leaf(x) for x in v]
+        if isinstance(v, dict):
+            return {k: leaf(x) for k, x in v.items()}
+        return v
+    if isinstance(tr, DistributionTrace):
+        return DistributionTrace(tr.gen_fn, leaf(tr.args), leaf(tr.value), leaf(tr.score))
+    return StaticTrace(tr.gen_fn, leaf(tr.args), leaf(tr.retval),
+                       OrderedDict((a, trace_map(s, fn)) for a, s in tr.subtraces.items()))
+
+
+def trace_leaves(tr) -> list:
+    out = []
+    trace_map(tr, lambda v: (out.append(v), v)[1])
+    return out
+
+
+# ---------------------------------------------------------------------------
+# Part 1: the reference's combinators
+# ---------------------------------------------------------------------------
+class ParticleCollection:
+    """A weighted collection of particles (smc.py:76-109): `particles` is ONE
+    batched trace (struct-of-arrays), `log_weights` has the same batch shape.
+    `log_ml_offset` (build addition) carries the evidence accumulated by
+    earlier resampling steps; it is 0 for the reference's algorithms."""
+
+    def __init__(self, particles, log_weights, is_valid=True, log_ml_offset=None):
+        self.particles, self.log_weights, self.is_valid = particles, log_weights, is_valid
+        self.log_ml_offset = log_ml_offset
+
+    def get_particles(self):
+        return self.particles
+
+    def get_log_weights(self):
+        return self.log_weights
+
+    def get_particle(self, idx):
+        return trace_map(self.particles, lambda v: engine.materialize(v)[idx])
+
+    def __getitem__(self, idx):
+        return self.get_particle(idx), self.log_weights[idx]
+
+    def get_log_marginal_likelihood_estimate(self):
+        """logsumexp(lw) - log N (smc.py:96-97) [+ accumulated offset]."""
+        n = self.log_weights.shape[-1]
+        est = engine.logsumexp_rows(self.log_weights) - math.log(n)
+        if self.log_ml_offset is not None:
+            est = est + self.log_ml_offset.value()
+        return est
+
+    def sample_index(self, key: Key):
+        """Categorical draw proportional to the weights (smc.py:102-108): Gumbel-max
+        over logits = lw - logsumexp(lw), gumbel counter = particle index."""
+        lw = self.log_weights
+        logits = lw - engine.logsumexp_rows(lw).unsqueeze(-1)
+        return engine.categorical_rows(key, logits)
+
+    def sample_particle(self, key: Key):
+        idx = self.sample_index(key)
+        nb = self.log_weights.ndim
+
+        def take(v):
+            v = engine.materialize(v)
+            if v.ndim < nb:
+                return v
+            ix = idx.long().reshape(idx.shape + (1,) * (v.ndim - nb + 1))
+            ix = ix.expand(idx.shape + (1,) + tuple(v.shape[nb:]))
+            return torch.gather(v, nb - 1, ix).squeeze(nb - 1)
+        return trace_map(self.particles, take)
+
+
+class SMCAlgorithm(Algorithm):
+    """smc.py:117-225"""
+
+    def get_num_particles(self): raise NotImplementedError
+    def get_final_target(self): raise NotImplementedError
+    def run_smc(self, key): raise NotImplementedError
+
+    def run_csmc(self, key, retained):
+        raise NotImplementedError("conditional SMC: SURVEY.md §8(f) item 4 (next tier)")
+
+    def log_marginal_likelihood_estimate(self, key, target=None):
+        algorithm = ChangeTarget(self, target) if target else self       # smc.py:150-153
+        key, sub_key = split(key)
+        return algorithm.run_smc(sub_key).get_log_marginal_likelihood_estimate()
+
+    def random_weighted(self, key, *args):
+        """smc.py:162-179"""
+        target = args[0]
+        assert isinstance(target, Target)
+        algorithm = ChangeTarget(self, target)
+        key, sub_key = split(key)
+        collection = algorithm.run_smc(key)
+        particle = collection.sample_particle(sub_key)
+        estimate = particle.get_score() - collection.get_log_marginal_likelihood_estimate()
+        chm = target.filter_to_unconstrained(particle.get_choices())
+        return estimate, chm
+
+    def estimate_normalizing_constant(self, key, target):
+        algorithm = ChangeTarget(self, target)
+        key, sub_key = split(key)
+        return algorithm.run_smc(sub_key).get_log_marginal_likelihood_estimate()
+
+
+class Importance(SMCAlgorithm):
+    """One-particle importance sampling (smc.py:233-266): the particle is
+    generated with `key` itself (child 0 of the split)."""
+
+    def __init__(self, target: Target, q=None):
+        if q is not None:
+            raise NotImplementedError("custom proposals q: SURVEY.md §8(f) item 4 (next tier)")
+        self.target, self.q = target, q
+
+    def get_num_particles(self): return 1
+    def get_final_target(self): return self.target
+
+    def run_smc(self, key):
+        key, sub_key = split(key)
+        k1 = key.reshape(tuple(key.shape) + (1,))
+        tr, score = self.target.importance(k1, ChoiceMap.empty())
+        return ParticleCollection(tr, score, True)
+
+
+class ImportanceK(SMCAlgorithm):
+    """K-particle importance sampling (smc.py:282-315):
+    key, sub = split(key); keys = split(sub, K); one fused launch over K."""
+
+    def __init__(self, target: Target, q=None, k_particles: int = 2):
+        if q is not None:
+            raise NotImplementedError("custom proposals q: SURVEY.md §8(f) item 4 (next tier)")
+        self.target, self.q, self.k_particles = target, q, int(k_particles)
+
+    def get_num_particles(self): return self.k_particles
+    def get_final_target(self): return self.target
+
+    def run_smc(self, key):
+        key, sub_key = split(key)
+        sub_keys = split(sub_key, self.k_particles)
+        trs, target_scores = self.target.importance(sub_keys, ChoiceMap.empty())
+        return ParticleCollection(trs, target_scores, True)         # log_weights = scores - 0.0
+
+
+class ChangeTarget(SMCAlgorithm):
+    """Re-weight every particle for a new target (smc.py:359-396); the incoming
+    key is used both for prev.run_smc(key) and for split(key, K) (:374, :386)."""
+
+    def __init__(self, prev: SMCAlgorithm, target: Target):
+        self.prev, self.target = prev, target
+
+    def get_num_particles(self): return self.prev.get_num_particles()
+    def get_final_target(self): return self.target
+
+    def run_smc(self, key):
+        collection = self.prev.run_smc(key)
+        particles = collection.get_particles()
+        latents = self.prev.get_final_target().filter_to_unconstrained(particles.get_choices())
+        sub_keys = split(key, self.get_num_particles())
+        new_particles, new_weight = self.target.importance(sub_keys, latents)
+        this_weight = new_weight - particles.get_score() + collection.get_log_weights()   # smc.py:383
+        return ParticleCollection(new_particles, this_weight, True, collection.log_ml_offset)
+
+
+# ---------------------------------------------------------------------------
+# Part 2: build-defined scalable SMC moves
+# ---------------------------------------------------------------------------
+SYSTEMATIC, STRATIFIED, MULTINOMIAL = (_lib.RESAMPLE_SYSTEMATIC, _lib.RESAMPLE_STRATIFIED,
+                                       _lib.RESAMPLE_MULTINOMIAL)
+_KINDS = {"systematic": SYSTEMATIC, "stratified": STRATIFIED, "multinomial": MULTINOMIAL}
+
+
+def cdf_shift(n_total: int) -> int:
+    """Fixed-point exponent: a sum of n_total terms <= 2^shift stays below 2^62."""
+    need = 0
+    while (1 << need) < n_total:
+        need += 1
+    return 62 - need
+
+
+class LogMLOffset:
+    """Evidence accumulated by resampling steps, kept on the device as exact
+    integers and finished in float64 on the host when asked:
+      sum_t [ M_t + log(total_t * 2^-shift) - log N ]."""
+
+    def __init__(self, terms=()):
+        self.terms = list(terms)      # (max_d f32[1], total_d u64-as-i64[1], shift, n)
+
+    def plus(self, max_d, total_d, shift, n):
+        return LogMLOffset(self.terms + [(max_d, total_d, shift, n)])
+
+    def value(self) -> float:
+        acc = 0.0
+        for max_d, total_d, shift, n in self.terms:
+            m = float(max_d.reshape(-1)[0].item())
+            tot = int(total_d.reshape(-1)[0].item()) & 0xFFFFFFFFFFFFFFFF
+            acc += m + math.log(tot) - shift * math.log(2.0) - math.log(n)
+        return acc
+
+
+def weight_cdf(lw: torch.Tensor, n_total=None, max_partials=None):
+    """gmx_weight_cdf: returns (cdf int64-bits [n], total [1], max [1], shift)."""
+    be = _lib.get()
+    lw = lw.reshape(-1)
+    if lw.dtype != torch.float32:
+        lw = lw.float()
+    lw = lw.contiguous()
+    n = lw.numel()
+    shift = cdf_shift(n if n_total is None else n_total)
+    cdf = torch.empty((n,), dtype=torch.int64, device=lw.device)
+    total = torch.empty((1,), dtype=torch.int64, device=lw.device)
+    mx = torch.empty((1,), dtype=torch.float32, device=lw.device)
+    ws = torch.empty(((be.c.gmx_weight_cdf_workspace(n) + 7) // 8,), dtype=torch.int64, device=lw.device)
+    if max_partials is None:
+        # max via the deterministic LSE kernel's max output
+        rows_ws = torch.empty(((be.c.gmx_logsumexp_workspace(1, n) + 3) // 4,), dtype=torch.int32, device=lw.device)
+        dummy = torch.empty((1,), dtype=torch.float32, device=lw.device)
+        be.check(be.c.gmx_logsumexp(be.ptr(lw), 1, n, be.ptr(dummy), be.ptr(mx), be.ptr(rows_ws), be.stream()),
+                 "gmx_logsumexp")
+        be.check(be.c.gmx_weight_cdf(be.ptr(lw), n, shift, None, 0, be.ptr(mx), be.ptr(cdf), be.ptr(total),
+                                     be.ptr(ws), be.stream()), "gmx_weight_cdf")
+    else:
+        be.check(be.c.gmx_weight_cdf(be.ptr(lw), n, shift, be.ptr(max_partials), max_partials.shape[0],
+                                     be.ptr(mx), be.ptr(cdf), be.ptr(total), be.ptr(ws), be.stream()),
+                 "gmx_weight_cdf")
+    return cdf, total, mx, shift
+
+
+def ancestors_from_cdf(kind, key: Key, cdf, total, n_out=None) -> torch.Tensor:
+    be = _lib.get()
+    n_in = cdf.numel()
+    n_out = n_in if n_out is None else int(n_out)
+    kh = key.host()
+    kk = (c_uint32 * 2)(int(kh[0]), int(kh[1]))
+    anc = torch.empty((n_out,), dtype=torch.int32, device=cdf.device)
+    be.check(be.c.gmx_ancestors(int(kind), kk, be.ptr(cdf), n_in, 0, be.ptr(total), n_out, 0, n_out,
+                                be.ptr(anc), be.stream()), "gmx_ancestors")
+    return anc
+
+
+def resample(key: Key, collection: ParticleCollection, kind="systematic", n_out=None) -> ParticleCollection:
+    """Resample a 1-D particle collection.  The result's leaves are lazy
+    gathers (`engine.Gathered`), so a following `extend` fuses the gather into
+    its kernel; weights reset to 0 and the evidence moves into log_ml_offset."""
+    lw = collection.get_log_weights()
+    if lw.ndim != 1:
+        raise NotImplementedError("resample: batched collections")
+    kind = _KINDS[kind] if isinstance(kind, str) else int(kind)
+    cdf, total, mx, shift = weight_cdf(lw)
+    anc = ancestors_from_cdf(kind, key, cdf, total, n_out)
+    n = lw.numel()
+    particles = trace_map(collection.get_particles(),
+                          lambda v: Gathered(engine.materialize(v), anc) if tuple(v.shape[:1]) == (n,) else v)
+    off = (collection.log_ml_offset or LogMLOffset()).plus(mx, total, shift, n)
+    new_lw = torch.zeros((anc.numel(),), dtype=torch.float32, device=lw.device)
+    out = ParticleCollection(particles, new_lw, True, off)
+    out.ancestors = anc
+    return out
+
+
+def extend(key: Key, collection: ParticleCollection, step, step_args, observations: ChoiceMap) -> ParticleCollection:
+    """Bootstrap extension by one step: every particle i runs
+    `step.importance(split(key, N)[i], observations, step_args_i)` and
+    lw_i += weight_i (same algebra as ChangeTarget._reweight, smc.py:378-384,
+    restricted to the new step's sites).  `step_args` is a tuple, or a callable
+    mapping the previous particles' trace to the tuple."""
+    n = collection.get_log_weights().shape[0]
+    args = step_args(collection.get_particles()) if callable(step_args) else tuple(step_args)
+    keys = split(key, n)
+    tr, w = step.importance(keys, observations, args)
+    return ParticleCollection(tr, collection.get_log_weights() + w, True, collection.log_ml_offset)
+
+
+def rejuvenate(key: Key, collection: ParticleCollection, request, argdiffs=None) -> ParticleCollection:
+    """One MH sweep: propose with `request.edit`, accept with log U < alpha
+    (tests/inference/test_requests.py:131-137 idiom), select per particle."""
+    be = _lib.get()
+    tr = collection.get_particles()
+    n = collection.get_log_weights().shape[0]
+    k_edit, k_acc = split(key)
+    if argdiffs is None:
+        argdiffs = Diff.no_change(tr.get_args() or ())
+    new_tr, w, _, _ = request.edit(split(k_edit, n), tr, argdiffs)
+    acc_keys = split(k_acc, n).data()
+    accept = torch.empty((n,), dtype=torch.bool, device=w.device)
+    wf = w.float().contiguous()
+    be.check(be.c.gmx_mh_accept(be.ptr(acc_keys), be.ptr(wf), n, be.ptr(accept), be.stream()), "gmx_mh_accept")
+    new_leaves, old_leaves = trace_leaves(new_tr), trace_leaves(tr)
+    it = iter(range(len(new_leaves)))
+
+    def pick(v):
+        j = next(it)
+        a, b = engine.materialize(new_leaves[j]), engine.materialize(old_leaves[j])
+        if a is b or tuple(a.shape[:1]) != (n,):
+            return a
+        m = accept.reshape((n,) + (1,) * (a.ndim - 1))
+        return torch.where(m, a, b)
+    out = trace_map(new_tr, pick)
+    res = ParticleCollection(out, collection.get_log_weights(), True, collection.log_ml_offset)
+    res.accept = accept
+    return res

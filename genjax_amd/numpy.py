@@ -1,0 +1,289 @@
+"""A small `jax.numpy`-shaped namespace for model code.
+
+Inside a `@gen` function these build the site program (traced values are
+`tracer.Expr` / object arrays of them); outside a trace they act on torch
+tensors / numpy arrays so inference scripts can post-process results
+(`jnp.mean(chm["p"])`).  Existing GenJAX models `import jax.numpy as jnp`; on a
+machine without JAX they `from genjax_amd import numpy as jnp` instead — same
+names, array namespace supplied by this build (SURVEY.md §7 "Hard parts").
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+
+from . import tracer as T
+from .tracer import Expr, is_symbolic
+
+pi = math.pi
+e = math.e
+inf = float("inf")
+nan = float("nan")
+float32 = np.float32
+int32 = np.int32
+bool_ = np.bool_
+newaxis = None
+
+
+class TableArray(np.ndarray):
+    """A constant array closed over by a model; indexing it with a traced
+    integer becomes an OP_LDTAB lookup (e.g. `means[idx]`)."""
+
+    def __new__(cls, a):
+        return np.asarray(a).view(cls)
+
+    def __getitem__(self, idx):
+        if isinstance(idx, Expr):
+            if self.ndim != 1:
+                raise NotImplementedError("traced index into an array with ndim != 1")
+            g = T.current_graph()
+            slot = table_slot(g, np.asarray(self))
+            dt = "f32" if self.dtype.kind == "f" else ("bool" if self.dtype.kind == "b" else "i32")
+            return Expr(g.add("LDTAB", (T.as_int(idx).node,), dtype=dt, slot=slot))
+        r = np.ndarray.__getitem__(self, idx)
+        if isinstance(r, np.ndarray) and r.ndim == 0:
+            return r.item()
+        return r
+
+
+def table_slot(g, arr) -> int:
+    tabs = g.__dict__.setdefault("tables", [])
+    for s, t in enumerate(tabs):
+        if t is arr or (t.shape == arr.shape and t.dtype == arr.dtype and np.array_equal(t, arr)):
+            return s
+    tabs.append(arr)
+    g.n_tab = len(tabs)
+    return len(tabs) - 1
+
+
+def _is_torch(x):
+    return isinstance(x, torch.Tensor)
+
+
+def array(x, dtype=None):
+    if is_symbolic(x):
+        return np.asarray(x, dtype=object)
+    if _is_torch(x):
+        return x if dtype is None else x.to(_torch_dtype(dtype))
+    a = np.asarray(x)
+    if dtype is not None:
+        a = a.astype(dtype)
+    elif a.dtype == np.float64:
+        a = a.astype(np.float32)
+    elif a.dtype == np.int64:
+        a = a.astype(np.int32)
+    return TableArray(a) if T.is_tracing() or a.ndim > 0 else a
+
+
+asarray = array
+
+
+def _torch_dtype(dt):
+    dt = np.dtype(dt)
+    return {"f": torch.float32, "i": torch.int32, "u": torch.int32, "b": torch.bool}[dt.kind]
+
+
+def zeros(shape, dtype=np.float32):
+    return TableArray(np.zeros(shape, dtype=dtype))
+
+
+def ones(shape, dtype=np.float32):
+    return TableArray(np.ones(shape, dtype=dtype))
+
+
+def full(shape, v, dtype=None):
+    if is_symbolic(v):
+        out = np.empty(shape, dtype=object)
+        out[...] = v
+        return out
+    return TableArray(np.full(shape, v, dtype=dtype or (np.float32 if isinstance(v, float) else None)))
+
+
+def arange(*a, dtype=np.int32):
+    return TableArray(np.arange(*a, dtype=dtype))
+
+
+def _dispatch(name, op, torch_fn, np_fn):
+    sym = T.unary(op)
+
+    def f(x):
+        if is_symbolic(x):
+            return sym(x)
+        if T.is_tracing() and isinstance(x, (int, float, np.number)):
+            return sym(x)
+        if _is_torch(x):
+            return torch_fn(x)
+        return np_fn(np.asarray(x, dtype=np.float32) if not isinstance(x, np.ndarray) else x)
+    f.__name__ = name
+    return f
+
+
+exp = _dispatch("exp", "EXP", torch.exp, np.exp)
+log = _dispatch("log", "LOG", torch.log, np.log)
+log1p = _dispatch("log1p", "LOG1P", torch.log1p, np.log1p)
+sqrt = _dispatch("sqrt", "SQRT", torch.sqrt, np.sqrt)
+sin = _dispatch("sin", "SIN", torch.sin, np.sin)
+cos = _dispatch("cos", "COS", torch.cos, np.cos)
+tanh = _dispatch("tanh", "TANH", torch.tanh, np.tanh)
+floor = _dispatch("floor", "FLOOR", torch.floor, np.floor)
+ceil = _dispatch("ceil", "CEIL", torch.ceil, np.ceil)
+square = _dispatch("square", "SQUARE", torch.square, np.square)
+abs = _dispatch("abs", "ABS", torch.abs, np.abs)        # noqa: A001
+absolute = abs
+sigmoid = _dispatch("sigmoid", "SIGMOID", torch.sigmoid, lambda x: 1.0 / (1.0 + np.exp(-x)))
+softplus = _dispatch("softplus", "SOFTPLUS", torch.nn.functional.softplus, lambda x: np.logaddexp(0.0, x))
+lgamma = _dispatch("lgamma", "LGAMMA", torch.lgamma, lambda x: np.vectorize(math.lgamma)(x))
+
+
+def where(c, a, b):
+    if is_symbolic(c) or is_symbolic(a) or is_symbolic(b):
+        return T.where(c, a, b)
+    if _is_torch(c) or _is_torch(a) or _is_torch(b):
+        dev = next(t.device for t in (c, a, b) if _is_torch(t))
+        tt = lambda v: v if _is_torch(v) else torch.as_tensor(v, device=dev)
+        return torch.where(tt(c), tt(a), tt(b))
+    return np.where(c, a, b)
+
+
+def power(a, b):
+    if is_symbolic(a) or is_symbolic(b):
+        return T.power(a, b)
+    if _is_torch(a) or _is_torch(b):
+        return torch.pow(a, b)
+    return np.power(a, b)
+
+
+def minimum(a, b):
+    if is_symbolic(a) or is_symbolic(b):
+        return T.minimum(a, b)
+    if _is_torch(a) or _is_torch(b):
+        return torch.minimum(torch.as_tensor(a), torch.as_tensor(b))
+    return np.minimum(a, b)
+
+
+def maximum(a, b):
+    if is_symbolic(a) or is_symbolic(b):
+        return T.maximum(a, b)
+    if _is_torch(a) or _is_torch(b):
+        return torch.maximum(torch.as_tensor(a), torch.as_tensor(b))
+    return np.maximum(a, b)
+
+
+def clip(x, lo, hi):
+    return minimum(maximum(x, lo), hi)
+
+
+def logical_and(a, b):
+    return a & b
+
+
+def logical_or(a, b):
+    return a | b
+
+
+def logical_not(a):
+    if isinstance(a, Expr):
+        return ~a
+    if isinstance(a, np.ndarray) and a.dtype == object:
+        return np.vectorize(lambda v: ~v, otypes=[object])(a)
+    return ~a if _is_torch(a) else np.logical_not(a)
+
+
+def sum(x, axis=None):        # noqa: A001
+    if is_symbolic(x):
+        a = np.asarray(x, dtype=object)
+        if axis is None:
+            flat = a.reshape(-1)
+            acc = flat[0]
+            for v in flat[1:]:
+                acc = acc + v
+            return acc
+        a = np.moveaxis(a, axis, -1)
+        out = np.empty(a.shape[:-1], dtype=object)
+        for idx in np.ndindex(out.shape):
+            acc = a[idx][0]
+            for v in a[idx][1:]:
+                acc = acc + v
+            out[idx] = acc
+        return out if out.ndim else out.item()
+    if _is_torch(x):
+        return torch.sum(x) if axis is None else torch.sum(x, dim=axis)
+    return np.sum(x, axis=axis)
+
+
+def mean(x, axis=None):
+    if is_symbolic(x):
+        a = np.asarray(x, dtype=object)
+        n = a.size if axis is None else a.shape[axis]
+        return sum(a, axis) / float(n)
+    if _is_torch(x):
+        x = x.float()
+        return torch.mean(x) if axis is None else torch.mean(x, dim=axis)
+    return np.mean(x, axis=axis)
+
+
+def stack(xs, axis=0):
+    if is_symbolic(xs):
+        return np.stack([np.asarray(v, dtype=object) for v in xs], axis=axis)
+    if builtins_any(_is_torch(v) for v in xs):
+        return torch.stack(list(xs), dim=axis)
+    return np.stack(xs, axis=axis)
+
+
+def builtins_any(it):
+    for v in it:
+        if v:
+            return True
+    return False
+
+
+def logsumexp(x, axis=-1):
+    """jax.scipy.special.logsumexp over a traced vector: max, then
+    log(sum(exp(x - max))) + max, accumulated in index order."""
+    if is_symbolic(x):
+        a = np.asarray(x, dtype=object)
+        if a.ndim != 1:
+            raise NotImplementedError("traced logsumexp over ndim != 1")
+        m = a[0]
+        for v in a[1:]:
+            m = T.maximum(m, v)
+        acc = None
+        for v in a:
+            t = exp(v - m)
+            acc = t if acc is None else acc + t
+        return log(acc) + m
+    if _is_torch(x):
+        return torch.logsumexp(x, dim=axis)
+    from scipy.special import logsumexp as _l
+    return _l(x, axis=axis)
+
+
+class _Lax:
+    """`jax.lax` subset: deterministic control flow on traced values."""
+
+    @staticmethod
+    def cond(pred, true_fun, false_fun, *operands):
+        a = true_fun(*operands)
+        b = false_fun(*operands)
+        if isinstance(pred, (bool, np.bool_)):
+            return a if pred else b
+        return _tree_where(pred, a, b)
+
+    @staticmethod
+    def select(pred, a, b):
+        return where(pred, a, b)
+
+
+def _tree_where(pred, a, b):
+    if isinstance(a, (tuple, list)):
+        return type(a)(_tree_where(pred, x, y) for x, y in zip(a, b))
+    if isinstance(a, dict):
+        return {k: _tree_where(pred, a[k], b[k]) for k in a}
+    if a is None:
+        return None
+    return where(pred, a, b)
+
+
+lax = _Lax()

@@ -1,0 +1,240 @@
+"""Site-program IR and encoder (see genjax_amd/csrc/gmx_program.h for the
+binary format).  A `Graph` is filled by the tracer (tracer.py / static.py) in
+program order; `compile_graph` removes dead nodes, allocates the <= 32
+registers by live range and emits the uint32 blob `gmx_program_create` takes.
+
+This is the build's counterpart of the reference's trace-time machinery
+(`stage` -> ClosedJaxpr, src/genjax/_src/core/compiler/staging.py:286-298; the
+stateful interpreter, interpreters/stateful.py:47-86): same job — turn one run
+of the model's Python source into an ordered list of sample sites with their
+argument expressions — different mechanism.
+"""
+from __future__ import annotations
+
+import struct
+from dataclasses import dataclass, field
+
+import numpy as np
+
+MAGIC = 0x50584D47
+VERSION = 1
+MAX_REGS = 32
+
+F_GATHER, F_U8, F_BCAST = 1, 2, 4
+
+# opcode numbers: keep in sync with gmx_program.h
+OPC = dict(
+    END=0, CONST=1, UNI=2, LDIN=3, LDTAB=4, STOUT=5, LDKEY=6, KDERIVE=7, KDERIVER=8, MOV=10,
+    ADD=11, SUB=12, MUL=13, DIV=14, MIN=15, MAX=16, POW=17,
+    NEG=20, ABS=21, EXP=22, LOG=23, LOG1P=24, SQRT=25, SIN=26, COS=27, TANH=28, SIGMOID=29,
+    SOFTPLUS=30, FLOOR=31, LGAMMA=32, SQUARE=33, RECIP=34, CEIL=35, ROUND=36,
+    FLT=40, FLE=41, FGT=42, FGE=43, FEQ=44, FNE=45,
+    IEQ=46, INE=47, ILT=48, ILE=49, IGT=50, IGE=51,
+    AND=52, OR=53, NOT=54, XOR=55, SEL=56, I2F=57, F2I=58,
+    IADD=60, ISUB=61, IMUL=62, INEG=63,
+    S_NORMAL=70, S_UNIFORM=71, S_FLIP=72, S_BERNL=73, S_BETA=74, S_CATSTEP=75,
+    L_NORMAL=80, L_UNIFORM=81, L_FLIP=82, L_BERNL=83, L_BETA=84,
+    REDMAX=90, REDLSE=91,
+)
+
+UNARY = {"MOV", "NEG", "ABS", "EXP", "LOG", "LOG1P", "SQRT", "SIN", "COS", "TANH", "SIGMOID",
+         "SOFTPLUS", "FLOOR", "CEIL", "ROUND", "LGAMMA", "SQUARE", "RECIP", "NOT", "I2F", "F2I", "INEG"}
+BINARY = {"ADD", "SUB", "MUL", "DIV", "MIN", "MAX", "POW", "FLT", "FLE", "FGT", "FGE", "FEQ", "FNE",
+          "IEQ", "INE", "ILT", "ILE", "IGT", "IGE", "AND", "OR", "XOR", "IADD", "ISUB", "IMUL"}
+SAMPLER2 = {"S_NORMAL", "S_UNIFORM", "S_BETA"}      # args (key, a, b), imm = element counter
+SAMPLER1 = {"S_FLIP", "S_BERNL"}                    # args (key, a)
+LOGPDF2 = {"L_NORMAL", "L_UNIFORM", "L_BETA"}       # args (x, a, b)
+LOGPDF1 = {"L_FLIP", "L_BERNL"}                     # args (x, a)
+EFFECT = {"STOUT", "REDMAX", "REDLSE"}
+
+
+@dataclass(eq=False)
+class Node:
+    op: str
+    args: tuple = ()
+    imm: int = 0
+    dtype: str = "f32"          # 'f32' | 'i32' | 'bool' | 'key' | 'cat' | 'none'
+    flags: int = 0
+    slot: int = 0
+    idx: int = -1               # position in Graph.nodes
+
+    @property
+    def width(self):
+        return 2 if self.dtype in ("key", "cat") else 1
+
+
+@dataclass
+class Graph:
+    nodes: list = field(default_factory=list)
+    n_in: int = 0
+    n_out: int = 0
+    n_uni: int = 0
+    n_tab: int = 0
+    _consts: dict = field(default_factory=dict)
+
+    def add(self, op, args=(), imm=0, dtype="f32", flags=0, slot=0) -> Node:
+        n = Node(op, tuple(args), int(imm) & 0xFFFFFFFF, dtype, flags, slot, len(self.nodes))
+        self.nodes.append(n)
+        return n
+
+    # leaves -----------------------------------------------------------------
+    def const_bits(self, bits: int, dtype: str) -> Node:
+        k = (bits & 0xFFFFFFFF, dtype)
+        n = self._consts.get(k)
+        if n is None:
+            n = self.add("CONST", imm=bits, dtype=dtype)
+            self._consts[k] = n
+        return n
+
+    def const_f32(self, x: float) -> Node:
+        return self.const_bits(struct.unpack("<I", struct.pack("<f", float(np.float32(x))))[0], "f32")
+
+    def const_i32(self, x: int, dtype="i32") -> Node:
+        return self.const_bits(int(x) & 0xFFFFFFFF, dtype)
+
+    def uniform(self, dtype: str) -> Node:
+        n = self.add("UNI", imm=self.n_uni, dtype=dtype)
+        self.n_uni += 1
+        return n
+
+    def input(self, dtype: str, flags: int = 0) -> Node:
+        if dtype == "bool":
+            flags |= F_U8
+        n = self.add("LDIN", dtype=dtype, flags=flags, slot=self.n_in)
+        self.n_in += 1
+        return n
+
+    def table(self) -> int:
+        t = self.n_tab
+        self.n_tab += 1
+        return t
+
+    def store(self, value: Node) -> int:
+        """STOUT of `value`; returns the output slot."""
+        flags = F_U8 if value.dtype == "bool" else 0
+        slot = self.n_out
+        self.n_out += 1
+        self.add("STOUT", (value,), dtype="none", flags=flags, slot=slot)
+        return slot
+
+
+class ProgramTooLarge(Exception):
+    pass
+
+
+def compile_graph(g: Graph) -> np.ndarray:
+    """DCE + linear-scan register allocation + encoding -> uint32 blob."""
+    nodes = g.nodes
+    # ---- liveness from effect roots ----
+    live = [False] * len(nodes)
+    stack = [n for n in nodes if n.op in EFFECT]
+    while stack:
+        n = stack.pop()
+        if live[n.idx]:
+            continue
+        live[n.idx] = True
+        for a in n.args:
+            if a is not None and not live[a.idx]:
+                stack.append(a)
+    order = [n for n in nodes if live[n.idx]]
+    last_use = {}
+    for pos, n in enumerate(order):
+        for a in n.args:
+            if a is not None:
+                last_use[a.idx] = pos
+    # ---- registers ----
+    free = [True] * MAX_REGS
+    reg = {}
+    n_regs = 0
+    words = []
+
+    def alloc(width):
+        nonlocal n_regs
+        for r in range(0, MAX_REGS - width + 1):
+            if all(free[r + k] for k in range(width)):
+                for k in range(width):
+                    free[r + k] = False
+                n_regs = max(n_regs, r + width)
+                return r
+        raise ProgramTooLarge(f"site program needs more than {MAX_REGS} live registers")
+
+    def release(n):
+        r = reg[n.idx]
+        for k in range(n.width):
+            free[r + k] = True
+
+    def emit(op, dst=0, a=0, b=0, imm=0):
+        words.append(OPC[op] | (dst & 0xFF) << 8 | (a & 0xFF) << 16 | (b & 0xFF) << 24)
+        words.append(imm & 0xFFFFFFFF)
+
+    for pos, n in enumerate(order):
+        R = lambda x: reg[x.idx]
+        # operands whose last use is here may donate their registers to dst
+        dying = [a for a in dict.fromkeys(x for x in n.args if x is not None) if last_use.get(a.idx) == pos]
+        op = n.op
+        if op == "S_CATSTEP":
+            prev, key, logit, ctr = n.args
+            if prev is not None and prev in dying:
+                dst = R(prev)
+                dying.remove(prev)
+            else:
+                dst = alloc(2)
+                if prev is not None:
+                    emit("MOV", dst, R(prev)); emit("MOV", dst + 1, R(prev) + 1)
+            emit(op, dst, R(logit), R(ctr), (R(key) & 0xFF) | (n.imm << 8))
+            reg[n.idx] = dst
+            for a in dying:
+                release(a)
+            continue
+        for a in dying:
+            release(a)
+        if op in EFFECT:
+            if op == "STOUT":
+                emit(op, n.flags, n.slot, R(n.args[0]))
+            else:
+                emit(op, 0, R(n.args[0]))
+            continue
+        dst = alloc(n.width)
+        reg[n.idx] = dst
+        if op == "CONST":
+            emit(op, dst, imm=n.imm)
+        elif op == "UNI":
+            emit(op, dst, imm=n.imm)
+        elif op == "LDIN":
+            emit(op, dst, n.slot, n.flags)
+        elif op == "LDTAB":
+            emit(op, dst, n.slot, R(n.args[0]), n.imm)
+        elif op == "LDKEY":
+            emit(op, dst)
+        elif op == "KDERIVE":
+            emit(op, dst, R(n.args[0]), 0, n.imm)
+        elif op == "KDERIVER":
+            emit(op, dst, R(n.args[0]), R(n.args[1]))
+        elif op == "CATIDX":        # second register of a categorical state pair
+            emit("MOV", dst, R(n.args[0]) + 1)
+        elif op in UNARY:
+            emit(op, dst, R(n.args[0]))
+        elif op in BINARY:
+            emit(op, dst, R(n.args[0]), R(n.args[1]))
+        elif op == "SEL":
+            c, a, b = n.args
+            emit(op, dst, R(a), R(b), R(c))
+        elif op in SAMPLER2:
+            k, a, b = n.args
+            emit(op, dst, R(a), R(b), (R(k) & 0xFF) | (n.imm << 8))
+        elif op in SAMPLER1:
+            k, a = n.args
+            emit(op, dst, R(a), 0, (R(k) & 0xFF) | (n.imm << 8))
+        elif op in LOGPDF2:
+            x, a, b = n.args
+            emit(op, dst, R(a), R(b), R(x))
+        elif op in LOGPDF1:
+            x, a = n.args
+            emit(op, dst, R(a), 0, R(x))
+        else:
+            raise ValueError(f"unknown op {op}")
+        if n.idx not in last_use:      # value never read (only possible for roots' helpers)
+            release(n)
+    n_instr = len(words) // 2
+    header = [MAGIC, VERSION, n_instr, max(n_regs, 1), g.n_in, g.n_out, g.n_uni, g.n_tab]
+    return np.array(header + words, dtype=np.uint32)

@@ -1,0 +1,205 @@
+"""PRNG keys with jax.random semantics (Threefry-2x32, `threefry_partitionable`
+mode of jax 0.5.2: SURVEY.md App. A.2), without materialising per-particle key
+arrays: `split(key, 1_000_000)` is a lazy object that the kernels expand in
+registers from the global particle index.
+
+Replaces `jax.random.key / split / fold_in` as used at
+src/genjax/_src/inference/smc.py:154,171,299-300,386 and
+src/genjax/_src/generative_functions/static.py:261,350.
+"""
+from __future__ import annotations
+
+from ctypes import c_uint32
+
+import numpy as np
+import torch
+
+from . import _lib
+
+_HOST_LIMIT = 1 << 14     # batches up to this many keys stay on the host as numpy
+
+
+def _rotl(x, r):
+    return (x << np.uint32(r)) | (x >> np.uint32(32 - r))
+
+
+def threefry2x32(k0, k1, c0, c1):
+    """Vectorised host Threefry-2x32-20 (numpy uint32, wrap-around arithmetic)."""
+    k0, k1, c0, c1 = (np.asarray(v, dtype=np.uint32) for v in (k0, k1, c0, c1))
+    with np.errstate(over="ignore"):
+        ks = (k0, k1, k0 ^ k1 ^ np.uint32(0x1BD11BDA))
+        x0 = c0 + ks[0]
+        x1 = c1 + ks[1]
+        rot = ((13, 15, 26, 6), (17, 29, 16, 24))
+        for g in range(5):
+            for r in rot[g & 1]:
+                x0 = x0 + x1
+                x1 = _rotl(x1, r)
+                x1 = x1 ^ x0
+            x0 = x0 + ks[(g + 1) % 3]
+            x1 = x1 + ks[(g + 2) % 3] + np.uint32(g + 1)
+    return x0, x1
+
+
+def _derive_host(keys: np.ndarray, ctr) -> np.ndarray:
+    ctr = np.asarray(ctr, dtype=np.uint64)
+    hi = (ctr >> np.uint64(32)).astype(np.uint32)
+    lo = (ctr & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    o0, o1 = threefry2x32(keys[..., 0], keys[..., 1], hi, lo)
+    return np.stack(np.broadcast_arrays(o0, o1), axis=-1).astype(np.uint32)
+
+
+class Key:
+    """A batch of PRNG keys.  Exactly one of the representations is set:
+
+    host      numpy uint32 [*batch, 2]
+    dev       torch int32  [*batch, 2]  (raw bits)
+    lazy      ("split", base Key (batch ()), n)            -> shape (n,)
+              ("rowsplit", rows Key (batch (B,)), inner)   -> shape (B, inner)
+    """
+
+    def __init__(self, host=None, dev=None, lazy=None):
+        self._host, self._dev, self._lazy = host, dev, lazy
+
+    # -- shape -----------------------------------------------------------
+    @property
+    def shape(self):
+        if self._host is not None:
+            return tuple(self._host.shape[:-1])
+        if self._dev is not None:
+            return tuple(self._dev.shape[:-1])
+        kind, base, n = self._lazy
+        return (n,) if kind == "split" else base.shape + (n,)
+
+    @property
+    def size(self):
+        return int(np.prod(self.shape, dtype=np.int64))
+
+    def __len__(self):
+        return self.shape[0]
+
+    def __repr__(self):
+        return f"Key(shape={self.shape})"
+
+    # -- materialisation -----------------------------------------------------
+    def host(self) -> np.ndarray:
+        """numpy uint32 [*batch, 2] (computes / downloads if necessary)."""
+        if self._host is not None:
+            return self._host
+        if self._dev is not None:
+            return self._dev.cpu().numpy().view(np.uint32)
+        kind, base, n = self._lazy
+        bh = base.host()
+        return _derive_host(bh[..., None, :], np.arange(n, dtype=np.uint64))
+
+    def data(self) -> torch.Tensor:
+        """device int32 [size, 2] (flattened batch), materialising lazily."""
+        be = _lib.get()
+        if self._dev is not None:
+            return self._dev.reshape(-1, 2)
+        if self._host is not None:
+            t = torch.from_numpy(np.ascontiguousarray(self._host).view(np.int32).reshape(-1, 2))
+            return t.to(be.device)
+        kind, base, n = self._lazy
+        if kind == "split":
+            bh = base.host()
+            out = torch.empty((n, 2), dtype=torch.int32, device=be.device)
+            kk = (c_uint32 * 2)(int(bh[0]), int(bh[1]))
+            be.check(be.c.gmx_split(kk, n, 0, be.ptr(out), be.stream()), "gmx_split")
+            return out
+        rows = base.data()
+        out = torch.empty((rows.shape[0] * n, 2), dtype=torch.int32, device=be.device)
+        be.check(be.c.gmx_split_rows(be.ptr(rows), rows.shape[0], n, be.ptr(out), be.stream()),
+                 "gmx_split_rows")
+        return out
+
+    def materialize(self) -> "Key":
+        if self._lazy is None:
+            return self
+        if self.size <= _HOST_LIMIT:
+            return Key(host=self.host())
+        return Key(dev=self.data().reshape(self.shape + (2,)))
+
+    def reshape(self, *shape) -> "Key":
+        shape = tuple(shape[0]) if len(shape) == 1 and isinstance(shape[0], (tuple, list)) else tuple(shape)
+        m = self.materialize()
+        if m._host is not None:
+            return Key(host=m._host.reshape(shape + (2,)))
+        return Key(dev=m._dev.reshape(shape + (2,)))
+
+    # -- indexing ----------------------------------------------------------
+    def __getitem__(self, idx):
+        if self._lazy is not None:
+            kind, base, n = self._lazy
+            if kind == "split" and isinstance(idx, (int, np.integer)):
+                i = int(idx) % n
+                return Key(host=_derive_host(base.host(), np.uint64(i)))
+            return self.materialize()[idx]
+        if not isinstance(idx, tuple):
+            idx = (idx,)
+        if self._host is not None:
+            return Key(host=self._host[idx + (slice(None),)])
+        return Key(dev=self._dev[idx + (slice(None),)])
+
+    def __iter__(self):
+        for i in range(self.shape[0]):
+            yield self[i]
+
+    # -- binding for gmx_program_run ----------------------------------------
+    def binding(self):
+        """(key_mode, key0, key1, keys tensor or None, inner) for the flattened batch."""
+        if self._lazy is not None:
+            kind, base, n = self._lazy
+            if kind == "split":
+                bh = base.host()
+                return _lib.KEY_SPLIT, int(bh[0]), int(bh[1]), None, 0
+            return _lib.KEY_ROWSPLIT, 0, 0, base.data(), n
+        if self.shape == ():
+            h = self.host()
+            return _lib.KEY_BCAST, int(h[0]), int(h[1]), None, 0
+        return _lib.KEY_ARRAY, 0, 0, self.data(), 0
+
+
+def key(seed: int) -> Key:
+    """jax.random.key(seed): key data (0, seed) for 0 <= seed < 2**32."""
+    seed = int(seed)
+    return Key(host=np.array([(seed >> 32) & 0xFFFFFFFF, seed & 0xFFFFFFFF], dtype=np.uint32))
+
+
+PRNGKey = key
+
+
+def split(k: Key, num: int = 2) -> Key:
+    """jax.random.split: child i = threefry(key, counter i); shape k.shape + (num,)."""
+    num = int(num)
+    if k._lazy is not None:
+        k = k.materialize()
+    if k.shape == ():
+        if num <= _HOST_LIMIT:
+            return Key(host=_derive_host(k.host()[None, :], np.arange(num, dtype=np.uint64)))
+        return Key(lazy=("split", k, num))
+    if k.size * num <= _HOST_LIMIT and k._host is not None:
+        return Key(host=_derive_host(k._host[..., None, :], np.arange(num, dtype=np.uint64)))
+    flat = k.reshape((k.size,))
+    out = Key(lazy=("rowsplit", flat, num))
+    if len(k.shape) == 1:
+        return out
+    return out.reshape(k.shape + (num,))
+
+
+def fold_in(k: Key, data: int) -> Key:
+    """jax.random.fold_in(key, data) = threefry(key, counter data)."""
+    data = int(data) & 0xFFFFFFFF
+    if k._lazy is not None:
+        k = k.materialize()
+    if k._host is not None:
+        return Key(host=_derive_host(k._host, np.uint64(data)))
+    be = _lib.get()
+    flat = k.data()
+    out = torch.empty_like(flat)
+    be.check(be.c.gmx_fold_in(be.ptr(flat), data, flat.shape[0], be.ptr(out), be.stream()), "gmx_fold_in")
+    return Key(dev=out.reshape(k.shape + (2,)))
+
+
+def key_data(k: Key) -> np.ndarray:
+    return k.host()

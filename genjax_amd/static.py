@@ -1,0 +1,755 @@
+"""The `@gen` static modelling language and the engine that answers every
+generative-function-interface call with ONE fused site-program launch.
+
+Reference semantics restated here (paths under src/genjax/_src/):
+  generative_functions/static.py
+    StaticTrace :80-119; StaticRequest :126-128; AddressReuse :139; MissingAddress :147
+    SimulateHandler :254-278, AssessHandler :297-321, GenerateHandler :341-380,
+    UpdateHandler :407-466, StaticEditRequestHandler :512-566,
+    RegenerateRequestHandler :616-673; StaticGenerativeFunction :725-1036; gen :1044
+    per-site key = fold_in(key, counter), counter from 1 in program order for
+    EVERY method (:260-263, 349-352, 419-422, 524-527, 633-636)
+  generative_functions/distributions/distribution.py
+    simulate :108-115, generate_choice_map :117-147,
+    edit_update_with_constraint :179-244, edit_regenerate :258-300, assess :398-419
+  inference/requests/rejuvenate.py :70-94 (Rejuvenate.edit)
+  core/generative/requests.py :48-60 (EmptyRequest)
+
+Mechanism (new): the model's Python source runs ONCE per call signature with
+symbolic values (tracer.Expr); the handler below records sites and weight
+algebra into a program graph; the compiled program is cached and each call is
+a single gmx_program_run over all particles.
+"""
+from __future__ import annotations
+
+import functools
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import tracer as T
+from .core.choice_map import ChoiceMap, Selection, _norm
+from .core.generative import (Diff, EditRequest, EmptyRequest, GenerativeFunction, NoChange,
+                              NotSupportedEditRequest, Regenerate, Trace, Update)
+from .engine import Compiled, Flat, Gathered, Sym, Tracing, leaf_spec, materialize, resolve, unflatten
+from .random import Key
+from .tracer import Expr
+
+
+class AddressReuse(Exception):
+    """Attempt to re-write an address in a trace (static.py:139)."""
+
+
+class MissingAddress(Exception):
+    """Assess without a value for a sampled address (static.py:147)."""
+
+
+# ---------------------------------------------------------------------------
+# traces
+# ---------------------------------------------------------------------------
+class DistributionTrace(Trace):
+    """distribution.py:59-82.  `args` are kept only when cheap (top-level call)."""
+
+    def __init__(self, gen_fn, args, value, score):
+        self.gen_fn, self.args, self.value, self.score = gen_fn, args, value, score
+
+    def get_args(self): return self.args
+    def get_retval(self): return materialize(self.value)
+    def get_gen_fn(self): return self.gen_fn
+    def get_score(self): return self.score
+    def get_choices(self): return ChoiceMap.choice(materialize(self.value))
+
+
+class StaticTrace(Trace):
+    """static.py:80-119"""
+
+    def __init__(self, gen_fn, args, retval, subtraces: "OrderedDict"):
+        self.gen_fn, self.args, self.retval, self.subtraces = gen_fn, args, retval, subtraces
+
+    def get_args(self): return self.args
+    def get_retval(self): return _tree_materialize(self.retval)
+    def get_gen_fn(self): return self.gen_fn
+
+    def get_choices(self) -> ChoiceMap:
+        cm = ChoiceMap.empty()
+        for addr, st in self.subtraces.items():
+            cm = cm.set(addr, st.get_choices())
+        return cm
+
+    def get_score(self):
+        """sum of sub-trace scores in program order (static.py:102-105)."""
+        acc = None
+        for st in self.subtraces.values():
+            s = st.get_score()
+            acc = s if acc is None else acc + s
+        if acc is None:
+            return 0.0
+        return acc
+
+    def get_subtrace(self, *addr):
+        addr = _norm(addr)
+        tr = self
+        i = 0
+        while i < len(addr):
+            # addresses may be registered as tuples ("a", "b") in one component
+            for j in range(len(addr), i, -1):
+                k = addr[i] if j == i + 1 else tuple(addr[i:j])
+                if isinstance(tr, StaticTrace) and k in tr.subtraces:
+                    tr = tr.subtraces[k]
+                    i = j
+                    break
+            else:
+                raise KeyError(addr)
+        return tr
+
+    get_inner_trace = get_subtrace
+
+
+def _tree_materialize(v):
+    if isinstance(v, tuple):
+        return tuple(_tree_materialize(x) for x in v)
+    if isinstance(v, list):
+        return [_tree_materialize(x) for x in v]
+    if isinstance(v, dict):
+        return {k: _tree_materialize(x) for k, x in v.items()}
+    return materialize(v)
+
+
+def _trace_tree(tr):
+    """Trace -> plain pytree of launch values (for Flat)."""
+    if isinstance(tr, DistributionTrace):
+        return {"value": tr.value, "score": tr.score}
+    if isinstance(tr, StaticTrace):
+        return {"sub": {a: _trace_tree(s) for a, s in tr.subtraces.items()}}
+    raise TypeError(f"cannot edit a trace of type {type(tr).__name__}")
+
+
+# ---------------------------------------------------------------------------
+# edit requests specific to the static language / inference
+# ---------------------------------------------------------------------------
+class StaticRequest(EditRequest):
+    """static.py:126-128: address -> sub-request."""
+    __match_args__ = ("addressed",)
+
+    def __init__(self, addressed: dict):
+        self.addressed = dict(addressed)
+
+
+class Rejuvenate(EditRequest):
+    """inference/requests/rejuvenate.py:44-94."""
+    __match_args__ = ("proposal", "argument_mapping")
+
+    def __init__(self, proposal, argument_mapping):
+        self.proposal, self.argument_mapping = proposal, argument_mapping
+
+    def edit(self, key, tr, argdiffs):
+        return StaticRequest({(): self}).edit(key, tr, argdiffs) if isinstance(tr, DistributionTrace) \
+            else super().edit(key, tr, argdiffs)
+
+
+# ---------------------------------------------------------------------------
+# trace-time handler
+# ---------------------------------------------------------------------------
+_HANDLERS: list = []
+
+
+def trace(addr, gen_fn, args):
+    """`gen_fn(*args) @ addr` (static.py:175-193)."""
+    if not _HANDLERS:
+        raise RuntimeError("`@ addr` used outside of a @gen function call")
+    return _HANDLERS[-1].handle(addr, gen_fn, tuple(args))
+
+
+def _selkey(sel):
+    """Structural cache key of a Selection."""
+    from .core import choice_map as cm
+    if isinstance(sel, cm._All): return ("all",)
+    if isinstance(sel, cm._None): return ("none",)
+    if isinstance(sel, cm._Leaf): return ("leaf",)
+    if isinstance(sel, cm._Static): return ("s", sel.comp, _selkey(sel.sub))
+    if isinstance(sel, cm._Or): return ("or", _selkey(sel.a), _selkey(sel.b))
+    if isinstance(sel, cm._And): return ("and", _selkey(sel.a), _selkey(sel.b))
+    if isinstance(sel, cm._Complement): return ("not", _selkey(sel.s))
+    if isinstance(sel, cm._Chm): return ("chm", tuple(sel.chm.addresses()))
+    return ("id", id(sel))
+
+
+def _fnkey(fn):
+    code = getattr(fn, "__code__", None)
+    if code is None:
+        return ("id", id(fn))
+    cells = ()
+    if fn.__closure__:
+        vals = []
+        for c in fn.__closure__:
+            try:
+                v = c.cell_contents
+                hash(v)
+                vals.append(v)
+            except Exception:
+                vals.append(("id", id(c)))
+        cells = tuple(vals)
+    return ("fn", code, cells)
+
+
+class _ReqSpec:
+    """Static description of an edit request + where its values sit among the leaves."""
+
+    def __init__(self, kind, **kw):
+        self.kind = kind
+        self.__dict__.update(kw)
+
+
+def _flatten_request(req, flat: Flat):
+    """-> (_ReqSpec, hashable key)."""
+    if req is None or isinstance(req, EmptyRequest):
+        return _ReqSpec("empty"), ("empty",)
+    if isinstance(req, Update):
+        tree = flat.add(req.constraint)
+        return _ReqSpec("update", tree=tree), ("update", tree)
+    if isinstance(req, Regenerate):
+        return _ReqSpec("regen", selection=req.selection), ("regen", _selkey(req.selection))
+    if isinstance(req, StaticRequest):
+        subs, keys = {}, []
+        for a, r in req.addressed.items():
+            s, k = _flatten_request(r, flat)
+            subs[_norm(a) if a != () else ()] = s
+            keys.append((a, k))
+        return _ReqSpec("static", subs=subs), ("static", tuple(keys))
+    if isinstance(req, Rejuvenate):
+        return (_ReqSpec("rejuv", proposal=req.proposal, argmap=req.argument_mapping),
+                ("rejuv", _gfkey(req.proposal), _fnkey(req.argument_mapping)))
+    raise NotSupportedEditRequest(req)
+
+
+def _gfkey(gf):
+    return ("gf", id(gf))
+
+
+def _depends(node, changed: set, memo: dict) -> bool:
+    """Does `node` depend on any node in `changed`? (incremental.py change propagation)"""
+    stack = [node]
+    seen = []
+    while stack:
+        n = stack.pop()
+        if n is None:
+            continue
+        r = memo.get(n.idx)
+        if r is True:
+            for s in seen:
+                memo[s] = True
+            return True
+        if r is False:
+            continue
+        if n.idx in changed:
+            memo[n.idx] = True
+            for s in seen:
+                memo[s] = True
+            return True
+        memo[n.idx] = False      # provisional; flipped to True above if a dependency is found
+        seen.append(n.idx)
+        stack.extend(a for a in n.args if a is not None)
+    return False
+
+
+def _nodes_of(v):
+    if isinstance(v, Expr):
+        return [v.node]
+    if isinstance(v, np.ndarray) and v.dtype == object:
+        return [x.node for x in v.reshape(-1) if isinstance(x, Expr)]
+    if isinstance(v, (tuple, list)):
+        out = []
+        for x in v:
+            out += _nodes_of(x)
+        return out
+    if isinstance(v, dict):
+        out = []
+        for x in v.values():
+            out += _nodes_of(x)
+        return out
+    return []
+
+
+class _Ctx:
+    """State shared by all handlers of one program trace."""
+
+    def __init__(self, tr: Tracing):
+        self.tr = tr
+        self.changed: set = set()        # node indices whose value differs from the previous trace
+        self.memo: dict = {}
+
+    def mark_changed(self, v):
+        for n in _nodes_of(v):
+            self.changed.add(n.idx)
+        self.memo.clear()
+
+    def args_changed(self, args) -> bool:
+        return any(_depends(n, self.changed, self.memo) for n in _nodes_of(args))
+
+
+class _SiteRec:
+    __slots__ = ("gen_fn", "value", "score", "discard")
+
+    def __init__(self, gen_fn, value, score, discard=None):
+        self.gen_fn, self.value, self.score, self.discard = gen_fn, value, score, discard
+
+
+class _CallRec:
+    """Result of tracing one generative-function call (nested or top-level)."""
+
+    def __init__(self, gen_fn):
+        self.gen_fn = gen_fn
+        self.sites: "OrderedDict" = OrderedDict()   # addr -> _SiteRec | _CallRec
+        self.retval = None
+        self.weight = None
+        self.score = None
+
+
+class Handler:
+    """One handler per (nested) static generative function call.
+
+    mode: simulate | generate | assess | update | regen | static_edit
+    """
+
+    def __init__(self, ctx: _Ctx, mode: str, key, constraint=None, prev=None, req=None, req_leaves=None):
+        self.ctx, self.mode, self.key = ctx, mode, key
+        self.constraint = constraint if constraint is not None else ChoiceMap.empty()
+        self.prev = prev               # symbolic previous trace: {"sub": {...}} / {"value","score"}
+        self.req = req                 # _ReqSpec
+        self.req_leaves = req_leaves   # leaf index -> Sym (for Update constraints inside requests)
+        self.counter = 1
+        self.rec = None
+        g = ctx.tr.graph
+        self.weight = Expr(g.const_f32(0.0))
+        self.score = Expr(g.const_f32(0.0))
+
+    # -- keys ------------------------------------------------------------------
+    def fresh_key(self):
+        c = self.counter
+        self.counter += 1
+        if self.key is None:
+            return None
+        g = self.ctx.tr.graph
+        return Expr(g.add("KDERIVE", (self.key.node,), imm=c, dtype="key"))
+
+    # -- site dispatch -------------------------------------------------------------
+    def handle(self, addr, gen_fn, args):
+        if addr in self.rec.sites:
+            raise AddressReuse(addr)
+        sub_key = self.fresh_key()
+        sub_con = self.constraint.get_submap(addr)
+        sub_prev = None
+        if self.prev is not None:
+            try:
+                sub_prev = self.prev["sub"][addr]
+            except KeyError:
+                raise KeyError(f"address {addr!r} is not in the previous trace") from None
+        sub_req = self._subrequest(addr)
+        if sub_req is not None and sub_req.kind == "update" and self.mode == "static_edit":
+            sub_con = sub_req.constraint          # Update nested inside a StaticRequest
+        rec, retval, w, s = call_gen_fn(self.ctx, self.mode, gen_fn, sub_key, args, sub_con, sub_prev,
+                                        sub_req, self.req_leaves, addr)
+        self.rec.sites[addr] = rec
+        if w is not None:
+            self.weight = self.weight + w          # static.py:377 / 454 / 559 / 668
+        if s is not None and self.mode == "assess":
+            self.score = self.score + s            # static.py:319
+        return retval
+
+    def _subrequest(self, addr):
+        r = self.req
+        if r is None:
+            return None
+        if r.kind == "static":
+            return r.subs.get(_norm(addr), _ReqSpec("empty"))
+        if r.kind == "regen":
+            return _ReqSpec("regen", selection=r.selection(addr))
+        return r                   # update: the constraint lookup goes through self.constraint
+
+
+def _leaf_call(ctx: _Ctx, mode, dist, key, args, constraint: ChoiceMap, prev, req, req_leaves):
+    """Leaf (Distribution) semantics; returns (_SiteRec, retval, weight, score)."""
+    g = ctx.tr.graph
+    args = dist.canon(args)
+    cval = constraint.get_value() if constraint is not None else None
+    zero = None
+    if mode == "simulate":
+        v = dist.sym_sample(key, args)
+        s = dist.sym_logpdf(v, args)
+        return _SiteRec(dist, v, s), v, None, s
+    if mode == "generate":
+        if cval is None:
+            v = dist.sym_sample(key, args)
+            s = dist.sym_logpdf(v, args)
+            return _SiteRec(dist, v, s), v, zero, s          # w = 0 (distribution.py:124-127)
+        v = cval.value if isinstance(cval, Sym) else cval
+        s = dist.sym_logpdf(v, args)
+        return _SiteRec(dist, cval, s), v, s, s              # w = score = logpdf (:144-147)
+    if mode == "assess":
+        if cval is None:
+            raise MissingAddress(())
+        v = cval.value if isinstance(cval, Sym) else cval
+        s = dist.sym_logpdf(v, args)
+        return _SiteRec(dist, cval, s), v, None, s
+    # ---- edits: need the previous site ----
+    pv_sym, ps_sym = prev["value"], prev["score"]
+    pv, ps = pv_sym.value, ps_sym.value
+    kind = req.kind if req is not None else "empty"
+    if kind == "update":
+        if cval is None:
+            # re-score the old value under the new args (distribution.py:225-233); the
+            # Update path visits every site, unchanged args contribute exactly 0
+            if not ctx.args_changed(args):
+                return _SiteRec(dist, pv_sym, ps_sym), pv, None, ps
+            s = dist.sym_logpdf(pv, args)
+            return _SiteRec(dist, pv_sym, s), pv, s - ps, s
+        v = cval.value if isinstance(cval, Sym) else cval
+        s = dist.sym_logpdf(v, args)
+        ctx.mark_changed(v)
+        return _SiteRec(dist, cval, s, discard=pv_sym), v, s - ps, s       # (:235-242)
+    if kind == "regen":
+        if req.selection.check():
+            v = dist.sym_sample(key, args)
+            s = dist.sym_logpdf(v, args)
+            ctx.mark_changed(v)
+            return _SiteRec(dist, v, s, discard=pv_sym), v, s - ps, s     # (:266-277)
+        kind = "empty"
+    if kind == "empty":
+        if not ctx.args_changed(args):
+            return _SiteRec(dist, pv_sym, ps_sym), pv, None, ps            # requests.py:56-57
+        s = dist.sym_logpdf(pv, args)
+        return _SiteRec(dist, pv_sym, s), pv, s - ps, s
+    if kind == "rejuv":
+        # Rejuvenate.edit (rejuvenate.py:70-94), literally
+        k_new = Expr(g.add("KDERIVE", (key.node,), imm=0, dtype="key"))   # key, sub_key = split(key)
+        sub = Expr(g.add("KDERIVE", (key.node,), imm=1, dtype="key"))
+        fwd_args = req.argmap(ChoiceMap.choice(pv))
+        if not isinstance(fwd_args, tuple):
+            fwd_args = (fwd_args,)
+        prec, pret, _, pscore = call_gen_fn(ctx, "simulate", req.proposal, sub, fwd_args, ChoiceMap.empty(),
+                                            None, None, None, ())
+        proposed = _rec_choices(prec)
+        fwd_score = _rec_score(prec)
+        nv = proposed.get_value()
+        if nv is None:
+            raise NotImplementedError("Rejuvenate at a distribution site needs a distribution-valued proposal")
+        s = dist.sym_logpdf(nv, args)            # Update(proposed).edit(key, tr, argdiffs)
+        w = s - ps
+        bwd_args = req.argmap(ChoiceMap.choice(pv))
+        if not isinstance(bwd_args, tuple):
+            bwd_args = (bwd_args,)
+        _, _, _, bwd_score = call_gen_fn(ctx, "assess", req.proposal, None, bwd_args, ChoiceMap.choice(pv),
+                                         None, None, None, ())
+        final = (w + bwd_score) - fwd_score
+        ctx.mark_changed(nv)
+        del k_new
+        return _SiteRec(dist, nv, s, discard=pv_sym), nv, final, s
+    raise NotSupportedEditRequest(kind)
+
+
+def _rec_choices(rec) -> ChoiceMap:
+    if isinstance(rec, _SiteRec):
+        v = rec.value
+        return ChoiceMap.choice(v.value if isinstance(v, Sym) else v)
+    cm = ChoiceMap.empty()
+    for a, r in rec.sites.items():
+        cm = cm.set(a, _rec_choices(r))
+    return cm
+
+
+def _rec_score(rec):
+    if isinstance(rec, _SiteRec):
+        return rec.score.value if isinstance(rec.score, Sym) else rec.score
+    acc = None
+    for r in rec.sites.values():
+        s = _rec_score(r)
+        acc = s if acc is None else acc + s
+    return acc
+
+
+def call_gen_fn(ctx, mode, gen_fn, key, args, constraint, prev, req, req_leaves, addr):
+    """Trace one callee; returns (record, retval, weight, score)."""
+    from .core.generative import GenerativeFunctionClosure
+    from .distributions import Distribution
+    if isinstance(gen_fn, GenerativeFunctionClosure):
+        gf, a = GenerativeFunctionClosure(gen_fn.gen_fn, gen_fn.args + tuple(args), gen_fn.kwargs)._target()
+        return call_gen_fn(ctx, mode, gf, key, a, constraint, prev, req, req_leaves, addr)
+    if isinstance(gen_fn, Distribution):
+        if req is not None and req.kind == "static":      # StaticRequest({(): r}) at a leaf
+            req = req.subs.get((), _ReqSpec("empty"))
+            if req.kind == "update":
+                constraint = req.constraint
+        return _leaf_call(ctx, mode, gen_fn, key, args, constraint, prev, req, req_leaves)
+    if isinstance(gen_fn, StaticGenerativeFunction):
+        h = Handler(ctx, mode, key, constraint, prev, req, req_leaves)
+        h.rec = _CallRec(gen_fn)
+        _HANDLERS.append(h)
+        try:
+            with T.tracing(ctx.tr.graph):
+                retval = gen_fn.source(*args)
+        finally:
+            _HANDLERS.pop()
+        h.rec.retval = retval
+        if mode == "simulate":
+            return h.rec, retval, None, _rec_score(h.rec)
+        if mode == "assess":
+            return h.rec, retval, None, h.score
+        return h.rec, retval, h.weight, None
+    if hasattr(gen_fn, "trace_call"):
+        return gen_fn.trace_call(ctx, mode, key, args, constraint, prev, req, req_leaves, addr)
+    raise TypeError(f"cannot trace a callee of type {type(gen_fn).__name__}")
+
+
+# ---------------------------------------------------------------------------
+# launch driver
+# ---------------------------------------------------------------------------
+_CACHE: dict = {}
+
+
+def _infer_batch(values) -> tuple:
+    shape = ()
+    for v in values:
+        if isinstance(v, (torch.Tensor, Gathered)):
+            s = tuple(v.shape)
+            if len(s) > len(shape):
+                shape = s
+    return shape
+
+
+def _sym_constraint(tree, syms) -> ChoiceMap:
+    return unflatten(tree, lambda j: syms[j])
+
+
+def _emit_rec(tr: Tracing, rec):
+    """Emit outputs for every site; returns an origin tree mirroring rec."""
+    if isinstance(rec, _SiteRec):
+        v = rec.value
+        vo = v.origin if isinstance(v, Sym) and v.origin is not None else tr.emit_output(v.value if isinstance(v, Sym) else v)
+        s = rec.score
+        so = s.origin if isinstance(s, Sym) and s.origin is not None else tr.emit_output(s.value if isinstance(s, Sym) else s)
+        do = None
+        if rec.discard is not None:
+            d = rec.discard
+            do = d.origin if isinstance(d, Sym) and d.origin is not None else tr.emit_output(d.value if isinstance(d, Sym) else d)
+        return ("site", rec.gen_fn, vo, so, do)
+    subs = OrderedDict((a, _emit_rec(tr, r)) for a, r in rec.sites.items())
+    return ("call", rec.gen_fn, subs, tr.emit_output(rec.retval))
+
+
+def _build_trace(otree, outs, leaves, args):
+    if otree[0] == "site":
+        _, gf, vo, so, _ = otree
+        return DistributionTrace(gf, args, resolve(vo, outs, leaves), resolve(so, outs, leaves))
+    _, gf, subs, ro = otree
+    st = OrderedDict((a, _build_trace(o, outs, leaves, None)) for a, o in subs.items())
+    return StaticTrace(gf, args, resolve(ro, outs, leaves), st)
+
+
+def _build_discard(otree, outs, leaves) -> ChoiceMap:
+    if otree[0] == "site":
+        do = otree[4]
+        return ChoiceMap.choice(materialize(resolve(do, outs, leaves))) if do is not None else ChoiceMap.empty()
+    cm = ChoiceMap.empty()
+    for a, o in otree[2].items():
+        d = _build_discard(o, outs, leaves)
+        if not d.static_is_empty():
+            cm = cm.set(a, d)
+    return cm
+
+
+def _broadcast_score(x, batch, device):
+    if isinstance(x, torch.Tensor):
+        return x
+    return torch.full(batch, float(x), dtype=torch.float32, device=device)
+
+
+def run_gfi(gen_fn, mode, key: Key | None, args, constraint: ChoiceMap | None = None, batch_shape=None):
+    """simulate / generate / assess for any generative function: one launch."""
+    be = _lib.get()
+    args = tuple(args)
+    constraint = constraint if constraint is not None else ChoiceMap.empty()
+    flat = Flat()
+    atree = flat.add(args)
+    ctree = flat.add(constraint)
+    if key is not None:
+        batch = tuple(key.shape)
+    elif batch_shape is not None:
+        batch = tuple(batch_shape)
+    else:
+        batch = _infer_batch(flat.leaves)
+    specs = tuple(leaf_spec(v, batch) for v in flat.leaves)
+    ck = (_gfkey(gen_fn), mode, atree, ctree, specs, len(batch), key is not None)
+    ent = _CACHE.get(ck)
+    if ent is None:
+        tr = Tracing(len(batch))
+        ctx = _Ctx(tr)
+        with T.tracing(tr.graph):
+            syms = [tr.sym_leaf(s, j) for j, s in enumerate(specs)]
+            sargs = unflatten(atree, lambda j: syms[j].value)
+            scon = _sym_constraint(ctree, syms)
+            kexpr = Expr(tr.graph.add("LDKEY", dtype="key")) if key is not None else None
+            rec, retval, w, s = call_gen_fn(ctx, mode, gen_fn, kexpr, sargs, scon, None, None, None, ())
+            otree = _emit_rec(tr, rec) if mode != "assess" else None
+            wo = tr.emit_output(w) if (mode == "generate" and w is not None) else None
+            so = tr.emit_output(s) if mode == "assess" else None
+            ro = tr.emit_output(retval) if mode == "assess" else None
+        ent = (Compiled(tr), otree, wo, so, ro)
+        _CACHE[ck] = ent
+    comp, otree, wo, so, ro = ent
+    outs = comp.run(flat.leaves, batch, key)
+    if mode == "assess":
+        score = _broadcast_score(resolve(so, outs, flat.leaves), batch, be.device)
+        return score, _tree_materialize(resolve(ro, outs, flat.leaves))
+    trc = _build_trace(otree, outs, flat.leaves, args)
+    if mode == "simulate":
+        return trc
+    w = resolve(wo, outs, flat.leaves) if wo is not None else 0.0
+    return trc, _broadcast_score(w, batch, be.device)
+
+
+def run_edit(gen_fn, key: Key, trace: Trace, request: EditRequest, argdiffs):
+    """edit(key, trace, request, argdiffs) -> (new trace, weight, retdiff, backward request)."""
+    be = _lib.get()
+    args = tuple(Diff.tree_primal(argdiffs)) if argdiffs is not None else tuple(trace.get_args() or ())
+    tangents = Diff.tree_tangent(argdiffs) if argdiffs is not None else ()
+    flat = Flat()
+    atree = flat.add(args)
+    ptree = flat.add(_trace_tree(trace))
+    rspec, rkey = _flatten_request(request, flat)
+    batch = tuple(trace.batch_shape)
+    if key is not None and tuple(key.shape) != batch:
+        if key.shape == ():
+            pass          # one key for a batched trace: every particle uses the same key
+        else:
+            raise ValueError(f"key batch {key.shape} does not match the trace batch {batch}")
+    specs = tuple(leaf_spec(v, batch) for v in flat.leaves)
+    tkey = _tangent_key(tangents)
+    ck = (_gfkey(gen_fn), "edit", atree, ptree, rkey, specs, tkey, len(batch), key is not None)
+    ent = _CACHE.get(ck)
+    if ent is None:
+        tr = Tracing(len(batch))
+        ctx = _Ctx(tr)
+        with T.tracing(tr.graph):
+            syms = [tr.sym_leaf(s, j) for j, s in enumerate(specs)]
+            sargs = unflatten(atree, lambda j: syms[j].value)
+            # arguments flagged as changed seed the change set
+            _seed_changed(ctx, sargs, tangents)
+            sprev = unflatten(ptree, lambda j: syms[j])
+            kexpr = Expr(tr.graph.add("LDKEY", dtype="key")) if key is not None else None
+            mode, constraint = "static_edit", ChoiceMap.empty()
+            req = rspec
+            if rspec.kind == "update":
+                mode = "update"
+                constraint = _sym_constraint(rspec.tree, syms)
+            elif rspec.kind == "regen":
+                mode = "regen"
+            _bind_request_leaves(rspec, syms)
+            rec, retval, w, _ = call_gen_fn(ctx, mode, gen_fn, kexpr, sargs, constraint, sprev, req, syms, ())
+            otree = _emit_rec(tr, rec)
+            wo = tr.emit_output(w) if w is not None else None
+        ent = (Compiled(tr), otree, wo)
+        _CACHE[ck] = ent
+    comp, otree, wo = ent
+    outs = comp.run(flat.leaves, batch, key)
+    new_tr = _build_trace(otree, outs, flat.leaves, args)
+    w = resolve(wo, outs, flat.leaves) if wo is not None else 0.0
+    w = _broadcast_score(w, batch, be.device)
+    discard = _build_discard(otree, outs, flat.leaves)
+    if isinstance(request, Update):
+        bwd = Update(discard)
+    elif isinstance(request, Regenerate):
+        bwd = Update(discard)
+    else:
+        bwd = request if isinstance(request, (StaticRequest, Rejuvenate)) else Update(discard)
+    retdiff = Diff.unknown_change(new_tr.get_retval())
+    return new_tr, w, retdiff, bwd
+
+
+def _tangent_key(tangents):
+    if isinstance(tangents, (tuple, list)):
+        return tuple(_tangent_key(t) for t in tangents)
+    return tangents is NoChange
+
+
+def _seed_changed(ctx, sargs, tangents):
+    if isinstance(sargs, (tuple, list)) and isinstance(tangents, (tuple, list)) and len(sargs) == len(tangents):
+        for a, t in zip(sargs, tangents):
+            _seed_changed(ctx, a, t)
+        return
+    if tangents is not NoChange:
+        ctx.mark_changed(sargs)
+
+
+def _bind_request_leaves(rspec, syms):
+    """Resolve Update constraints nested inside StaticRequests to symbolic choice maps."""
+    if rspec.kind == "static":
+        for s in rspec.subs.values():
+            _bind_request_leaves(s, syms)
+    elif rspec.kind == "update":
+        rspec.constraint = _sym_constraint(rspec.tree, syms)
+
+
+# ---------------------------------------------------------------------------
+# the generative function
+# ---------------------------------------------------------------------------
+class StaticGenerativeFunction(GenerativeFunction):
+    """static.py:725-1036"""
+
+    def __init__(self, source, partial_args=()):
+        self._fn = source
+        self._partial = tuple(partial_args)
+        functools.update_wrapper(self, source, updated=())
+
+    def source(self, *args):
+        return self._fn(*self._partial, *args)
+
+    def __get__(self, instance, _klass):
+        return self.partial_apply(instance) if instance is not None else self
+
+    def handle_kwargs(self):
+        fn = self
+
+        def kwarged(args, kwargs):
+            return fn.source(*args, **kwargs)
+        return StaticGenerativeFunction(kwarged)
+
+    # GFI ---------------------------------------------------------------------------
+    def simulate(self, key, args):
+        return run_gfi(self, "simulate", key, args)
+
+    def generate(self, key, constraint, args):
+        return run_gfi(self, "generate", key, args, constraint=constraint)
+
+    def assess(self, sample, args, batch_shape=None):
+        return run_gfi(self, "assess", None, args, constraint=sample, batch_shape=batch_shape)
+
+    def edit(self, key, trace, edit_request, argdiffs):
+        assert isinstance(trace, StaticTrace)
+        if isinstance(edit_request, (Update, StaticRequest, Regenerate)):
+            return run_edit(self, key, trace, edit_request, argdiffs)
+        raise NotSupportedEditRequest(edit_request)
+
+    def project(self, key, trace, selection: Selection):
+        """static.py:812-825: sum of the selected sub-trace scores."""
+        weight = None
+        for addr, st in trace.subtraces.items():
+            w = st.get_gen_fn().project(key, st, selection(addr))
+            weight = w if weight is None else weight + w
+        return weight if weight is not None else 0.0
+
+    def inline(self, *args):
+        return self.source(*args)
+
+    @property
+    def partial_args(self):
+        return self._partial
+
+    def partial_apply(self, *args):
+        return StaticGenerativeFunction(self._fn, self._partial + tuple(args))
+
+
+def gen(f) -> StaticGenerativeFunction:
+    """`@gen` (static.py:1044-1049)."""
+    return StaticGenerativeFunction(f)

@@ -1,0 +1,255 @@
+"""Symbolic values for tracing a `@gen` function's Python source.
+
+An `Expr` wraps a program `Node`; Python operators and the functions in
+`genjax_amd.numpy` build the site program.  Tensors with an event shape are
+numpy object arrays of `Expr` (unrolled: event shapes on this path are small —
+the eight schools, a handful of mixture components), so numpy's own
+broadcasting rules apply to them.
+
+dtype rules follow JAX's weak typing for the cases models use: Python floats
+are f32, Python ints are i32, bools are bool; int (op) float -> float.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .program import Graph, Node
+
+_GRAPHS: list[Graph] = []
+
+
+def current_graph() -> Graph:
+    if not _GRAPHS:
+        raise RuntimeError("symbolic value used outside of a trace")
+    return _GRAPHS[-1]
+
+
+class tracing:
+    def __init__(self, graph: Graph):
+        self.graph = graph
+
+    def __enter__(self):
+        _GRAPHS.append(self.graph)
+        return self.graph
+
+    def __exit__(self, *exc):
+        _GRAPHS.pop()
+
+
+def is_tracing() -> bool:
+    return bool(_GRAPHS)
+
+
+class Expr:
+    __slots__ = ("node",)
+    __array_priority__ = 1000          # numpy defers to our reflected operators
+
+    def __init__(self, node: Node):
+        self.node = node
+
+    @property
+    def dtype(self):
+        return self.node.dtype
+
+    shape = ()
+    ndim = 0
+
+    def __repr__(self):
+        return f"Expr<{self.node.op}:{self.node.dtype}#{self.node.idx}>"
+
+    def __bool__(self):
+        raise TypeError(
+            "the truth value of a traced value is not available while tracing a @gen function; "
+            "use genjax_amd.numpy.where / lax.cond instead of Python `if`")
+
+    def __hash__(self):
+        return id(self)
+
+    # arithmetic -------------------------------------------------------------
+    def __add__(self, o): return _arith("ADD", "IADD", self, o)
+    def __radd__(self, o): return _arith("ADD", "IADD", o, self)
+    def __sub__(self, o): return _arith("SUB", "ISUB", self, o)
+    def __rsub__(self, o): return _arith("SUB", "ISUB", o, self)
+    def __mul__(self, o): return _arith("MUL", "IMUL", self, o)
+    def __rmul__(self, o): return _arith("MUL", "IMUL", o, self)
+    def __truediv__(self, o): return _fbin("DIV", self, o)
+    def __rtruediv__(self, o): return _fbin("DIV", o, self)
+    def __pow__(self, o): return power(self, o)
+    def __rpow__(self, o): return power(o, self)
+    def __neg__(self):
+        if self.dtype == "f32":
+            return _un("NEG", self)
+        return Expr(current_graph().add("INEG", (as_int(self).node,), dtype="i32"))
+    def __pos__(self): return self
+    def __abs__(self): return _un("ABS", as_float(self))
+    # comparisons ------------------------------------------------------------
+    def __lt__(self, o): return _cmp("FLT", "ILT", self, o)
+    def __le__(self, o): return _cmp("FLE", "ILE", self, o)
+    def __gt__(self, o): return _cmp("FGT", "IGT", self, o)
+    def __ge__(self, o): return _cmp("FGE", "IGE", self, o)
+    def __eq__(self, o): return _cmp("FEQ", "IEQ", self, o)      # noqa: D105
+    def __ne__(self, o): return _cmp("FNE", "INE", self, o)
+    # logic --------------------------------------------------------------------
+    def __and__(self, o): return _logic("AND", self, o)
+    def __rand__(self, o): return _logic("AND", o, self)
+    def __or__(self, o): return _logic("OR", self, o)
+    def __ror__(self, o): return _logic("OR", o, self)
+    def __xor__(self, o): return _logic("XOR", self, o)
+    def __invert__(self): return Expr(current_graph().add("NOT", (self.node,), dtype="bool"))
+
+    def astype(self, dt):
+        dt = np.dtype(dt) if not isinstance(dt, str) or dt not in ("f32", "i32", "bool") else dt
+        if dt in ("f32",) or (not isinstance(dt, str) and dt.kind == "f"):
+            return as_float(self)
+        if dt in ("i32",) or (not isinstance(dt, str) and dt.kind in "iu"):
+            return as_int(self)
+        return as_bool(self)
+
+
+def is_symbolic(x) -> bool:
+    if isinstance(x, Expr):
+        return True
+    if isinstance(x, np.ndarray) and x.dtype == object:
+        return True
+    if isinstance(x, (list, tuple)):
+        return any(is_symbolic(v) for v in x)
+    return False
+
+
+def lift(x) -> Expr:
+    """Python / numpy scalar -> constant Expr."""
+    if isinstance(x, Expr):
+        return x
+    g = current_graph()
+    if isinstance(x, (bool, np.bool_)):
+        return Expr(g.const_i32(1 if x else 0, "bool"))
+    if isinstance(x, (int, np.integer)):
+        return Expr(g.const_i32(int(x), "i32"))
+    if isinstance(x, (float, np.floating)):
+        return Expr(g.const_f32(float(x)))
+    if hasattr(x, "shape") and tuple(x.shape) == () and hasattr(x, "item"):
+        return lift(x.item())
+    raise TypeError(f"cannot use a value of type {type(x).__name__} inside a traced expression")
+
+
+def as_float(x) -> Expr:
+    x = lift(x)
+    if x.dtype == "f32":
+        return x
+    return Expr(current_graph().add("I2F", (x.node,), dtype="f32"))
+
+
+def as_int(x) -> Expr:
+    x = lift(x)
+    if x.dtype == "i32":
+        return x
+    if x.dtype == "bool":
+        return Expr(current_graph().add("MOV", (x.node,), dtype="i32"))
+    return Expr(current_graph().add("F2I", (x.node,), dtype="i32"))
+
+
+def as_bool(x) -> Expr:
+    x = lift(x)
+    if x.dtype == "bool":
+        return x
+    if x.dtype == "i32":
+        z = current_graph().const_i32(0)
+        return Expr(current_graph().add("INE", (x.node, z), dtype="bool"))
+    z = current_graph().const_f32(0.0)
+    return Expr(current_graph().add("FNE", (x.node, z), dtype="bool"))
+
+
+def _vec(fn):
+    """Apply a scalar Expr function elementwise over object arrays."""
+    def wrapped(*args):
+        if any(isinstance(a, (np.ndarray, list, tuple)) and np.ndim(a) > 0 for a in args):
+            arrs = np.broadcast_arrays(*[np.asarray(a, dtype=object) if not isinstance(a, np.ndarray) or a.dtype != object
+                                         else a for a in args])
+            out = np.empty(arrs[0].shape, dtype=object)
+            for idx in np.ndindex(out.shape):
+                out[idx] = fn(*[a[idx] for a in arrs])
+            return out
+        return fn(*[a.item() if isinstance(a, np.ndarray) and a.ndim == 0 and a.dtype == object else a
+                    for a in args])
+    return wrapped
+
+
+def _un(op, x) -> Expr:
+    x = as_float(x)
+    return Expr(current_graph().add(op, (x.node,), dtype="f32"))
+
+
+def _fbin(op, a, b) -> Expr:
+    if isinstance(a, np.ndarray) or isinstance(b, np.ndarray):
+        return _vec(lambda p, q: _fbin(op, p, q))(a, b)
+    a, b = as_float(a), as_float(b)
+    return Expr(current_graph().add(op, (a.node, b.node), dtype="f32"))
+
+
+def _arith(fop, iop, a, b) -> Expr:
+    if isinstance(a, np.ndarray) or isinstance(b, np.ndarray):
+        return _vec(lambda p, q: _arith(fop, iop, p, q))(a, b)
+    a, b = lift(a), lift(b)
+    if a.dtype == "f32" or b.dtype == "f32":
+        return _fbin(fop, a, b)
+    a, b = as_int(a), as_int(b)
+    return Expr(current_graph().add(iop, (a.node, b.node), dtype="i32"))
+
+
+def _cmp(fop, iop, a, b) -> Expr:
+    if isinstance(a, np.ndarray) or isinstance(b, np.ndarray):
+        return _vec(lambda p, q: _cmp(fop, iop, p, q))(a, b)
+    a, b = lift(a), lift(b)
+    if a.dtype == "f32" or b.dtype == "f32":
+        a, b = as_float(a), as_float(b)
+        return Expr(current_graph().add(fop, (a.node, b.node), dtype="bool"))
+    a, b = as_int(a), as_int(b)
+    return Expr(current_graph().add(iop, (a.node, b.node), dtype="bool"))
+
+
+def _logic(op, a, b) -> Expr:
+    if isinstance(a, np.ndarray) or isinstance(b, np.ndarray):
+        return _vec(lambda p, q: _logic(op, p, q))(a, b)
+    a, b = as_bool(a), as_bool(b)
+    return Expr(current_graph().add(op, (a.node, b.node), dtype="bool"))
+
+
+@_vec
+def power(a, b):
+    if isinstance(b, (int, float, np.integer, np.floating)) and not isinstance(b, bool):
+        if float(b) == 2.0:
+            return _un("SQUARE", a)
+        if float(b) == 1.0:
+            return as_float(a)
+        if float(b) == 0.5:
+            return _un("SQRT", a)
+    return _fbin("POW", a, b)
+
+
+@_vec
+def where(c, a, b):
+    a, b = lift(a), lift(b)
+    if a.dtype != b.dtype:
+        if "f32" in (a.dtype, b.dtype):
+            a, b = as_float(a), as_float(b)
+        else:
+            a, b = as_int(a), as_int(b)
+    c = as_bool(c)
+    return Expr(current_graph().add("SEL", (c.node, a.node, b.node), dtype=a.dtype))
+
+
+def unary(op):
+    @_vec
+    def f(x):
+        return _un(op, x)
+    return f
+
+
+@_vec
+def minimum(a, b):
+    return _fbin("MIN", a, b)
+
+
+@_vec
+def maximum(a, b):
+    return _fbin("MAX", a, b)

@@ -1,0 +1,32 @@
+"""Test-only CPU stand-in for libgenmi_hip.so (see hostsim.cpp)."""
+import ctypes
+import os
+import subprocess
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libgmx_hostsim.so")
+
+
+def build():
+    src = os.path.join(_HERE, "hostsim.cpp")
+    deps = [src] + [os.path.join(_HERE, "..", "..", "genjax_amd", "csrc", f)
+                    for f in ("gmx_vm.h", "gmx_dist.h", "gmx_rng.h", "gmx_math.h", "gmx_program.h")]
+    if not os.path.exists(_SO) or any(os.path.getmtime(d) > os.path.getmtime(_SO) for d in deps):
+        os.makedirs(os.path.dirname(_SO), exist_ok=True)
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+                               "-fno-fast-math", src, "-o", _SO])
+    return _SO
+
+
+def install():
+    from genjax_amd import _lib
+    be = _lib.Backend(ctypes.CDLL(build()), torch.device("cpu"), uses_streams=False)
+    _lib.install(be)
+    return be
+
+
+def uninstall():
+    from genjax_amd import _lib
+    _lib.install(None)

@@ -1,0 +1,213 @@
+// hostsim.cpp — TEST HARNESS ONLY.  A sequential CPU implementation of the
+// C-ABI in include/genmi.h so the Python host layer (tracer, program encoder,
+// binding plans, SMC combinators) can be exercised on machines without a GPU.
+//
+// The site-program interpreter, samplers and log-densities are the PRODUCT's
+// own headers (genjax_amd/csrc/gmx_vm.h ...) compiled for the host, so CPU
+// tests diff the product's device functions against the independent oracle.
+// The scan / search / gather entry points are plain re-implementations (the
+// gfx950 kernels themselves are validated by the `-m gpu` tests).
+//
+// Nothing in genjax_amd/ refers to this file; tests install it through
+// genjax_amd._lib.install().  It is never shipped as a fallback.
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../genjax_amd/csrc/gmx_vm.h"
+
+static thread_local char g_err[512] = "";
+static int fail(const char* m) { snprintf(g_err, sizeof(g_err), "%s", m); return 1; }
+
+extern "C" int gmx_version(void) { return GMX_ABI_VERSION; }
+extern "C" const char* gmx_last_error(void) { return g_err; }
+extern "C" void gmx_threefry2x32_host(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t out[2]) {
+  gmx_threefry2x32(k0, k1, c0, c1, &out[0], &out[1]);
+}
+
+extern "C" int gmx_split(const uint32_t key[2], int64_t n, int64_t off, uint32_t* out, gmx_stream) {
+  gmx_key k; k.k0 = key[0]; k.k1 = key[1];
+  for (int64_t i = 0; i < n; ++i) { gmx_key o = gmx_split_child(k, (uint64_t)(off + i)); out[2*i] = o.k0; out[2*i+1] = o.k1; }
+  return 0;
+}
+extern "C" int gmx_split_rows(const uint32_t* keys, int64_t rows, int64_t inner, uint32_t* out, gmx_stream) {
+  for (int64_t r = 0; r < rows; ++r) {
+    gmx_key k; k.k0 = keys[2*r]; k.k1 = keys[2*r+1];
+    for (int64_t j = 0; j < inner; ++j) { gmx_key o = gmx_split_child(k, (uint64_t)j); out[2*(r*inner+j)] = o.k0; out[2*(r*inner+j)+1] = o.k1; }
+  }
+  return 0;
+}
+extern "C" int gmx_fold_in(const uint32_t* keys, uint32_t data, int64_t n, uint32_t* out, gmx_stream) {
+  for (int64_t i = 0; i < n; ++i) { gmx_key k; k.k0 = keys[2*i]; k.k1 = keys[2*i+1]; gmx_key o = gmx_fold_in(k, data); out[2*i] = o.k0; out[2*i+1] = o.k1; }
+  return 0;
+}
+extern "C" int gmx_random_bits(const uint32_t* keys, int64_t n, int64_t m, uint32_t* out, gmx_stream) {
+  for (int64_t i = 0; i < n; ++i) { gmx_key k; k.k0 = keys[2*i]; k.k1 = keys[2*i+1]; for (int64_t j = 0; j < m; ++j) out[i*m+j] = gmx_bits32(k, (uint64_t)j); }
+  return 0;
+}
+
+// ---- programs ----
+struct gmx_program { std::vector<uint32_t> code; uint32_t n_instr, n_regs, n_in, n_out, n_uni, n_tab; };
+
+struct HostCtx {
+  std::vector<float>* red; int64_t i; int kind;
+  uint32_t uniform(uint32_t x) const { return x; }
+  void red_max(float x, bool active) { kind = 1; (*red)[i] = active ? x : -gmx_inf(); }
+  void red_lse(float x, bool active) { kind = 2; (*red)[i] = active ? x : -gmx_inf(); }
+};
+
+extern "C" int gmx_program_create(const uint32_t* blob, size_t n_words, gmx_program** out) {
+  if (!blob || !out || n_words < GMX_PROG_HEADER_WORDS) return fail("program_create: bad blob");
+  if (blob[0] != GMX_PROG_MAGIC || blob[1] != GMX_PROG_VERSION) return fail("program_create: bad magic/version");
+  if (n_words != GMX_PROG_HEADER_WORDS + 2ull * blob[2]) return fail("program_create: bad length");
+  if (blob[3] == 0 || blob[3] > 32) return fail("program_create: n_regs out of range");
+  gmx_program* p = new gmx_program;
+  p->n_instr = blob[2]; p->n_regs = blob[3]; p->n_in = blob[4]; p->n_out = blob[5]; p->n_uni = blob[6]; p->n_tab = blob[7];
+  p->code.assign(blob + GMX_PROG_HEADER_WORDS, blob + n_words);
+  // the same index validation the HIP library performs
+  for (uint32_t pc = 0; pc < p->n_instr; ++pc) {
+    uint32_t w0 = p->code[2*pc]; uint32_t op = w0 & 0xff;
+    if (op >= OP__COUNT) { delete p; return fail("program_create: invalid opcode"); }
+    uint32_t dst = (w0 >> 8) & 0xff, a = (w0 >> 16) & 0xff, b = w0 >> 24;
+    bool regdst = !(op == OP_STOUT || op == OP_END || op == OP_REDMAX || op == OP_REDLSE);
+    if (regdst && dst >= p->n_regs) { delete p; return fail("program_create: register out of range"); }
+    (void)a; (void)b;
+  }
+  *out = p; return 0;
+}
+extern "C" int gmx_program_destroy(gmx_program* p) { delete p; return 0; }
+extern "C" int64_t gmx_program_grid(const gmx_program*, int64_t n) { return (n + 255) / 256; }
+
+static float butterfly_sum64(const float* v) {
+  float t[64]; memcpy(t, v, sizeof(t));
+  for (int m = 32; m >= 1; m >>= 1) { float u[64]; for (int l = 0; l < 64; ++l) u[l] = t[l] + t[l ^ m]; memcpy(t, u, sizeof(t)); }
+  return t[0];
+}
+
+extern "C" int gmx_program_run(const gmx_program* p, int64_t n, const gmx_run_args* A, gmx_stream) {
+  if (!p || !A) return fail("program_run: null");
+  for (uint32_t s = 0; s < p->n_in; ++s) if (!A->in_d[s]) return fail("program_run: null input slot");
+  for (uint32_t s = 0; s < p->n_out; ++s) if (!A->out_d[s]) return fail("program_run: null output slot");
+  int64_t grid = (n + 255) / 256;
+  std::vector<float> red(256);
+  for (int64_t blk = 0; blk < grid; ++blk) {
+    int kind = 0;
+    for (int t = 0; t < 256; ++t) {
+      int64_t i = blk * 256 + t;
+      HostCtx ctx; ctx.red = &red; ctx.i = t; ctx.kind = 0;
+      gmx_vm_run<gmx_regs_vgpr<32>, HostCtx>(p->code.data(), p->n_instr, i, i < n, *A, ctx);
+      if (ctx.kind) kind = ctx.kind;
+    }
+    if (kind && A->red_out_d) {
+      float m = -gmx_inf();
+      for (int t = 0; t < 256; ++t) m = gmx_fmax(m, red[t]);
+      A->red_out_d[2*blk] = m;
+      if (kind == 2) {
+        float e[256];
+        for (int t = 0; t < 256; ++t) e[t] = (red[t] > -gmx_inf() && m > -gmx_inf()) ? gmx_expf(red[t] - m) : 0.0f;
+        float w0 = butterfly_sum64(e), w1 = butterfly_sum64(e + 64), w2 = butterfly_sum64(e + 128), w3 = butterfly_sum64(e + 192);
+        A->red_out_d[2*blk+1] = (w0 + w1) + (w2 + w3);
+      }
+    }
+  }
+  return 0;
+}
+
+// ---- logsumexp (sequential; float tolerance vs the device tree) ----
+extern "C" size_t gmx_logsumexp_workspace(int64_t, int64_t) { return 16; }
+extern "C" int gmx_logsumexp(const float* lw, int64_t rows, int64_t cols, float* out, float* out_max, void*, gmx_stream) {
+  for (int64_t r = 0; r < rows; ++r) {
+    const float* x = lw + r * cols;
+    float m = -gmx_inf();
+    for (int64_t j = 0; j < cols; ++j) m = gmx_fmax(m, x[j]);
+    float s = 0.0f;
+    if (m > -gmx_inf()) for (int64_t j = 0; j < cols; ++j) s += gmx_expf(x[j] - m);
+    out[r] = (m > -gmx_inf()) ? m + gmx_logf(s) : m;
+    if (out_max) out_max[r] = m;
+  }
+  return 0;
+}
+
+// ---- weights / cdf / ancestors ----
+extern "C" size_t gmx_weight_cdf_workspace(int64_t n) { return 8 + (size_t)((n + 1023) / 1024) * 8; }
+extern "C" int gmx_weight_cdf(const float* lw, int64_t n, int shift, const float* parts, int64_t n_parts, float* max_d,
+                              uint64_t* cdf, uint64_t* total, void*, gmx_stream) {
+  if (n <= 0) return fail("weight_cdf: n");
+  int need = 0; while (((int64_t)1 << need) < n) ++need;
+  if (shift + need > 62) return fail("weight_cdf: shift too large");
+  if (parts) { float m = -gmx_inf(); for (int64_t j = 0; j < n_parts; ++j) m = gmx_fmax(m, parts[2*j]); *max_d = m; }
+  float M = *max_d, scale = gmx_pow2i(shift);
+  uint64_t run = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    float w = gmx_expf(lw[i] - M); float q = w * scale;
+    run += (q >= 0.0f) ? (uint64_t)q : 0ull;
+    cdf[i] = run;
+  }
+  *total = run;
+  return 0;
+}
+typedef unsigned __int128 u128;
+extern "C" int gmx_ancestors(int kind, const uint32_t key[2], const uint64_t* cdf, int64_t n_in, uint64_t off,
+                             const uint64_t* total_d, int64_t n_out_total, int64_t slot_offset, int64_t n_slots,
+                             int32_t* anc, gmx_stream) {
+  gmx_key k; k.k0 = key[0]; k.k1 = key[1];
+  uint64_t total = *total_d;
+  for (int64_t s = 0; s < n_slots; ++s) {
+    int64_t j = slot_offset + s;
+    u128 D, P;
+    if (kind == GMX_RESAMPLE_MULTINOMIAL) {
+      uint64_t u = gmx_bits32(k, (uint64_t)j) >> 9;
+      D = (u128)1 << 23; P = (u128)total * (((uint64_t)1 << 23) - u);
+      if (P > 0) P -= 1;
+    } else {
+      uint64_t u = (kind == GMX_RESAMPLE_SYSTEMATIC) ? (gmx_bits32(k, 0) >> 9) : (gmx_bits32(k, (uint64_t)j) >> 9);
+      D = (u128)((uint64_t)n_out_total << 23); P = (u128)(((uint64_t)j << 23) + u) * total;
+    }
+    int64_t lo = 0, hi = n_in;
+    while (lo < hi) { int64_t mid = lo + ((hi - lo) >> 1); if ((u128)(cdf[mid] + off) * D > P) hi = mid; else lo = mid + 1; }
+    if (lo >= n_in) lo = n_in - 1;
+    anc[s] = (int32_t)lo;
+  }
+  return 0;
+}
+extern "C" int gmx_gather(const void* const* src, void* const* dst, const int32_t* bytes, int32_t n_leaves,
+                          const int32_t* anc, int64_t n_out, gmx_stream) {
+  for (int32_t l = 0; l < n_leaves; ++l)
+    for (int64_t j = 0; j < n_out; ++j)
+      memcpy((char*)dst[l] + j * bytes[l], (const char*)src[l] + (int64_t)anc[j] * bytes[l], bytes[l]);
+  return 0;
+}
+extern "C" int gmx_select(const uint8_t* mask, const void* const* a, const void* const* b, void* const* out,
+                          const int32_t* bytes, int32_t n_leaves, int64_t n, gmx_stream) {
+  for (int32_t l = 0; l < n_leaves; ++l)
+    for (int64_t j = 0; j < n; ++j)
+      memcpy((char*)out[l] + j * bytes[l], (const char*)(mask[j] ? a[l] : b[l]) + j * bytes[l], bytes[l]);
+  return 0;
+}
+extern "C" int gmx_categorical_rows(const uint32_t* keys, const float* logits, int64_t rows, int64_t cols, int32_t* out, gmx_stream) {
+  for (int64_t r = 0; r < rows; ++r) {
+    gmx_key k; k.k0 = keys[2*r]; k.k1 = keys[2*r+1];
+    gmx_cat_state s; s.best = 0; s.idx = 0;
+    for (int64_t j = 0; j < cols; ++j) gmx_cat_step(&s, k, (uint64_t)j, (int)j, logits[r*cols+j]);
+    out[r] = s.idx;
+  }
+  return 0;
+}
+extern "C" int gmx_mh_accept(const uint32_t* keys, const float* la, int64_t n, uint8_t* acc, gmx_stream) {
+  for (int64_t i = 0; i < n; ++i) { gmx_key k; k.k0 = keys[2*i]; k.k1 = keys[2*i+1]; float u = gmx_uniform_sample(k, 0, 0.0f, 1.0f); acc[i] = gmx_logf(u) < la[i] ? 1 : 0; }
+  return 0;
+}
+// graphs / timers: pass-through stubs (no streams on the host)
+struct gmx_graph { int dummy; };
+extern "C" int gmx_capture_begin(gmx_stream) { return fail("hostsim: graph capture unavailable"); }
+extern "C" int gmx_capture_end(gmx_stream, gmx_graph**) { return fail("hostsim: graph capture unavailable"); }
+extern "C" int gmx_graph_launch(gmx_graph*, gmx_stream) { return fail("hostsim: graph capture unavailable"); }
+extern "C" int gmx_graph_destroy(gmx_graph*) { return 0; }
+struct gmx_timer { int dummy; };
+extern "C" int gmx_timer_create(gmx_timer** out) { *out = new gmx_timer; return 0; }
+extern "C" int gmx_timer_start(gmx_timer*, gmx_stream) { return 0; }
+extern "C" int gmx_timer_stop(gmx_timer*, gmx_stream) { return 0; }
+extern "C" int gmx_timer_elapsed_ms(gmx_timer*, float* ms) { *ms = 0.0f; return 0; }
+extern "C" int gmx_timer_destroy(gmx_timer* t) { delete t; return 0; }

@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""bench.py — BASELINE.json's headline metric on MI355X.
+
+Workload (BASELINE config 2): linear-Gaussian state-space model, T = 100,
+bootstrap SMC with 1e6 particles per GPU, systematic resampling every step.
+One "step" of this harness = one whole sweep (N * T particle-steps), issued as
+one hipGraph replay with every input already resident in HBM.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the
+site-program interpreter k_vm): algorithmic bytes per launch / its average
+duration measured here with HIP events on the launch stream.  `cpu_baseline`
+times the oracle's C statement of the same sweep on the host cores.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import math
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_PARTICLES = 1_000_000
+T_STEPS = 100
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+# Algorithmic bytes per particle-step (8*D + 24 = 32 B, D = 1):
+#   k_vm        ancestor 4 + gathered state 4 in, state 4 + log-weight 4 out      = 16 B
+#   k_weight_cdf  log-weight 4 in, CDF 4 out (stored as u64: 8 actual)            =  8 B
+#   k_ancestors   CDF 4 in, ancestor 4 out                                         =  8 B
+VM_BYTES_PER_PARTICLE = 16
+SWEEP_BYTES_PER_PARTICLE_STEP = 32
+
+
+def cpu_baseline(n, T, ys, seed, budget_s=25.0):
+    """Oracle 'port' timed on this box's host cores (bounded sample)."""
+    src_dir = os.path.join(ROOT, "oracle")
+    so = None
+    try:     # native build for the cores it is timed on
+        tmp = tempfile.mkdtemp(prefix="orc_")
+        so = os.path.join(tmp, "liborc_sweep.so")
+        subprocess.check_call(["gcc", "-O3", "-march=native", "-fopenmp", "-fPIC", "-shared", "-std=c11",
+                               "-ffp-contract=off", "-fno-fast-math", os.path.join(src_dir, "orc_sweep.c"),
+                               "-o", so, "-lm"], stderr=subprocess.DEVNULL)
+    except Exception:
+        so = os.path.join(src_dir, "_build", "liborc_sweep.so")
+        if not os.path.exists(so):
+            return None
+    import numpy as np
+    lib = ctypes.CDLL(so)
+    cores = int(lib.orc_threads())
+    from oracle.genjax_oracle import cdf_shift
+    shift = cdf_shift(n)
+    f32, u64, i32 = np.float32, np.uint64, np.int32
+    x, x2, lw = np.zeros(n, f32), np.zeros(n, f32), np.zeros(n, f32)
+    cdf, anc = np.zeros(n, u64), np.zeros(n, i32)
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+
+    def run(Tn):
+        maxs, totals = np.zeros(Tn, f32), np.zeros(Tn, u64)
+        t0 = time.perf_counter()
+        rc = lib.orc_lgssm_sweep(ctypes.c_int64(n), ctypes.c_int64(Tn), P(ys), ctypes.c_uint32(0),
+                                 ctypes.c_uint32(seed), ctypes.c_float(0.9), ctypes.c_float(0.5),
+                                 ctypes.c_float(1.0), ctypes.c_float(1.0), ctypes.c_int(shift), P(x), P(x2),
+                                 P(lw), P(cdf), P(anc), P(maxs), P(totals))
+        assert rc == 0
+        return time.perf_counter() - t0
+    t_probe = run(2)                          # 2 steps to size the sample
+    Tn = int(max(2, min(T, budget_s / max(t_probe / 2, 1e-6))))
+    dt = run(Tn)
+    return {"value": n * Tn / dt, "unit": "particle-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{Tn} of {T} SMC steps x {n} particles, oracle/orc_sweep.c (OpenMP, gcc -O3 -march=native)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--particles", type=int, default=N_PARTICLES)
+    ap.add_argument("--T", type=int, default=T_STEPS)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+        dist = dist_
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import genjax_amd as G
+    from genjax_amd import _lib, workloads
+    from genjax_amd.inference.smc import BootstrapSweep
+    be = _lib.get()
+    n, T = args.particles, args.T
+    seed = 314159
+    ys = workloads.lgssm_data(T)
+    init, step = workloads.make_lgssm(G)
+    if world == 1:
+        sw = BootstrapSweep(init, step, n, T).prepare(G.key(seed), torch.from_numpy(ys))
+        if not args.no_graph:
+            sw.capture()
+        launch = sw.launch
+    else:
+        from genjax_amd.inference.sharded import ShardedBootstrapSweep
+        sw = ShardedBootstrapSweep(init, step, n, T, dist).prepare(G.key(seed), torch.from_numpy(ys))
+        launch = sw.launch
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        launch()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        launch()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    total_particles = n * world
+    value = args.steps * total_particles * T / dt
+    log_ml = sw.log_ml()
+    kal = workloads.kalman_log_ml(ys)
+
+    out = {
+        "metric": "particles/sec (particle-steps/s), bootstrap SMC sweep, linear-Gaussian SSM T=100",
+        "value": value, "unit": "particle-steps/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE config 2: linear-Gaussian state-space (T=100), bootstrap SMC, "
+                               "systematic resampling every step",
+                   "particles_per_gpu": n, "particles_total": total_particles, "T": T,
+                   "resampler": "systematic", "graph": not args.no_graph and world == 1,
+                   "key": seed},
+        "log_ml": log_ml, "log_ml_kalman": kal, "log_ml_abs_err": abs(log_ml - kal),
+        "log_ml_rel_err": abs(log_ml - kal) / abs(kal),
+    }
+
+    if rank == 0 and world == 1:
+        # ---- per-kernel durations, HIP events on the launch stream ----
+        from ctypes import c_float, c_void_p
+        timer = c_void_p()
+        be.check(be.c.gmx_timer_create(timer), "timer")
+
+        def time_launches(fn, reps=200):
+            fn()
+            torch.cuda.synchronize()
+            be.check(be.c.gmx_timer_start(timer, be.stream()), "timer")
+            for _ in range(reps):
+                fn()
+            be.check(be.c.gmx_timer_stop(timer, be.stream()), "timer")
+            ms = c_float()
+            be.check(be.c.gmx_timer_elapsed_ms(timer, ms), "timer")
+            return ms.value * 1e3 / reps          # us per launch
+        kt = sw.kernel_timers()
+        us = {name: time_launches(fn) for name, fn in kt.items()}
+        vm_us = us["k_vm"]
+        achieved = VM_BYTES_PER_PARTICLE * n / (vm_us * 1e-6) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("k_vm_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                           "kernel": "k_vm<gmx_regs_vgpr<16>>",
+                           "algorithmic_bytes_per_launch": VM_BYTES_PER_PARTICLE * n,
+                           "kernel_us": us,
+                           "sweep_frac_of_hbm_roofline":
+                               SWEEP_BYTES_PER_PARTICLE_STEP * value / world / 1e9 / HBM_PEAK_GBS}
+        be.c.gmx_timer_destroy(timer)
+        if not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(n, T, ys, seed)
+            except Exception as e:                              # report, never fail the GPU number
+                out["cpu_baseline"] = {"error": repr(e)}
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

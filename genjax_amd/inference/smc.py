@@ -25,7 +25,7 @@ from .. import _lib, engine
 from ..core.choice_map import ChoiceMap
 from ..core.generative import Diff
 from ..engine import Gathered
-from ..random import Key, fold_in, split
+from ..random import Key, fold_in, lazy_split, split
 from ..static import DistributionTrace, StaticTrace
 from .sp import Algorithm, Target
 
@@ -339,3 +339,136 @@ def rejuvenate(key: Key, collection: ParticleCollection, request, argdiffs=None)
     res = ParticleCollection(out, collection.get_log_weights(), True, collection.log_ml_offset)
     res.accept = accept
     return res
+
+
+class BootstrapSweep:
+    """A whole bootstrap particle filter (T steps, resampling every step) as a
+    fixed sequence of launches on one stream, capturable into a hipGraph:
+
+      per step t:  [generate]   x_t[i] ~ step(x_{t-1}[anc[i]]), lw[i] = log p(y_t | x_t[i]),
+                                block max partials                      (k_vm)
+                   [cdf]        fixed-point weights + chained scan       (k_reduce_max, memset, k_weight_cdf)
+                   [ancestors]  exact inverse-CDF search                 (k_ancestors)
+
+    Key schedule (build-defined, SURVEY.md App. B): step key = fold_in(run_key, t);
+    (k_prop, k_res, k_mh) = split(step key, 3); particle i uses split(k_prop, N)[i].
+    The evidence is accumulated from the integer CDF totals in float64 on the host.
+    """
+
+    def __init__(self, init, step, n_particles: int, T: int, obs_addr="y", resample="systematic",
+                 step_extra=None):
+        self.init, self.step, self.n, self.T = init, step, int(n_particles), int(T)
+        self.obs_addr = obs_addr
+        self.kind = _KINDS[resample] if isinstance(resample, str) else int(resample)
+        self.step_extra = step_extra or (lambda t: ())
+        self.graph = None
+
+    def prepare(self, key: Key, ys: torch.Tensor):
+        from ..static import MinimalGenerate
+        be = _lib.get()
+        n, T = self.n, self.T
+        dev = be.device
+        self.key = key
+        self.ys = ys.to(dev).float().contiguous()
+        assert self.ys.numel() >= T
+        self.x = [torch.zeros((n,), dtype=torch.float32, device=dev) for _ in range(2)]
+        self.lw = torch.zeros((n,), dtype=torch.float32, device=dev)
+        self.cdf = torch.zeros((n,), dtype=torch.int64, device=dev)
+        self.anc = torch.zeros((n,), dtype=torch.int32, device=dev)
+        self.maxs = torch.zeros((T,), dtype=torch.float32, device=dev)
+        self.totals = torch.zeros((T,), dtype=torch.int64, device=dev)
+        self.shift = cdf_shift(n)
+        self.ws = torch.zeros(((be.c.gmx_weight_cdf_workspace(n) + 7) // 8,), dtype=torch.int64, device=dev)
+        obs0 = ChoiceMap.empty().set(self.obs_addr, self.ys[0])
+        self.p_init = MinimalGenerate(self.init, (), obs0, (n,))
+        g = Gathered(self.x[0], self.anc)
+        self.p_step = MinimalGenerate(self.step, (g,) + tuple(self.step_extra(1)), obs0, (n,))
+        grid = be.c.gmx_program_grid(self.p_step.comp.handle, n)
+        self.partials = torch.zeros((grid, 2), dtype=torch.float32, device=dev)
+        # per-step keys on the host
+        self.step_keys = []
+        for t in range(T):
+            ks = split(fold_in(key, t), 3)
+            self.step_keys.append((ks[0], ks[1], ks[2]))
+        return self
+
+    def _launch_vm(self, t):
+        n = self.n
+        k_prop = self.step_keys[t][0]
+        obs = ChoiceMap.empty().set(self.obs_addr, self.ys[t])
+        xo = self.x[t % 2]
+        if t == 0:
+            prog, leaves = self.p_init, self.p_init.leaves((), obs)
+        else:
+            g = Gathered(self.x[(t - 1) % 2], self.anc)
+            prog = self.p_step
+            leaves = prog.leaves((g,) + tuple(self.step_extra(t)), obs)
+        bufs = [None] * len(prog.comp.outputs)
+        bufs[prog.ro[1]] = xo.reshape(1, n)
+        bufs[prog.wo[1]] = self.lw.reshape(1, n)
+        prog.comp.run(leaves, (n,), lazy_split(k_prop, n), red_out=self.partials, out_buffers=bufs)
+
+    def _launch_cdf(self, t):
+        be = _lib.get()
+        be.check(be.c.gmx_weight_cdf(be.ptr(self.lw), self.n, self.shift, be.ptr(self.partials),
+                                     self.partials.shape[0], be.ptr(self.maxs[t:t + 1]), be.ptr(self.cdf),
+                                     be.ptr(self.totals[t:t + 1]), be.ptr(self.ws), be.stream()),
+                 "gmx_weight_cdf")
+
+    def _launch_anc(self, t):
+        be = _lib.get()
+        kh = self.step_keys[t][1].host()
+        kk = (c_uint32 * 2)(int(kh[0]), int(kh[1]))
+        be.check(be.c.gmx_ancestors(self.kind, kk, be.ptr(self.cdf), self.n, 0, be.ptr(self.totals[t:t + 1]),
+                                    self.n, 0, self.n, be.ptr(self.anc), be.stream()), "gmx_ancestors")
+
+    def enqueue(self):
+        """Issue every launch of the sweep on the current stream (no syncs, no allocations)."""
+        for t in range(self.T):
+            self._launch_vm(t)
+            self._launch_cdf(t)
+            self._launch_anc(t)
+
+    def kernel_timers(self):
+        """Representative single launches (a mid-sweep step) for per-kernel timing in bench.py."""
+        t = max(1, self.T // 2)
+        return {"k_vm": lambda: self._launch_vm(t),
+                "weight_cdf(k_reduce_max+memset+k_weight_cdf)": lambda: self._launch_cdf(t),
+                "k_ancestors": lambda: self._launch_anc(t)}
+
+    def capture(self):
+        """Capture enqueue() into a hipGraph (launch-bound: ~5 nodes per step)."""
+        be = _lib.get()
+        from ctypes import c_void_p
+        s = torch.cuda.Stream(device=be.device)
+        s.wait_stream(torch.cuda.current_stream(be.device))
+        with torch.cuda.stream(s):
+            self.enqueue()          # warm-up outside capture (program upload, lazy init)
+            s.synchronize()
+            be.check(be.c.gmx_capture_begin(be.stream()), "gmx_capture_begin")
+            try:
+                self.enqueue()
+            finally:
+                h = c_void_p()
+                rc = be.c.gmx_capture_end(be.stream(), h)
+            be.check(rc, "gmx_capture_end")
+        torch.cuda.current_stream(be.device).wait_stream(s)
+        self.graph = h
+        return self
+
+    def launch(self):
+        be = _lib.get()
+        if self.graph is None:
+            self.enqueue()
+        else:
+            be.check(be.c.gmx_graph_launch(self.graph, be.stream()), "gmx_graph_launch")
+
+    def log_ml(self) -> float:
+        """sum_t [ M_t + log(total_t * 2^-shift) - log N ] in float64 (synchronises)."""
+        m = self.maxs.cpu().numpy().astype(np.float64)
+        tot = self.totals.cpu().numpy().view(np.uint64).astype(np.float64)
+        return float(np.sum(m + np.log(tot) - self.shift * math.log(2.0) - math.log(self.n)))
+
+    def state(self):
+        """(x_T particles before the last resampling, log-weights, last ancestors)."""
+        return self.x[(self.T - 1) % 2], self.lw, self.anc

@@ -187,6 +187,14 @@ def split(k: Key, num: int = 2) -> Key:
     return out.reshape(k.shape + (num,))
 
 
+def lazy_split(k: Key, num: int) -> Key:
+    """split(k, num) for a single key, never materialised: kernels derive child
+    i in registers from the global particle index (GMX_KEY_SPLIT)."""
+    if k.shape != ():
+        raise ValueError("lazy_split needs a single key")
+    return Key(lazy=("split", k.materialize(), int(num)))
+
+
 def fold_in(k: Key, data: int) -> Key:
     """jax.random.fold_in(key, data) = threefry(key, counter data)."""
     data = int(data) & 0xFFFFFFFF

@@ -609,6 +609,42 @@ def run_gfi(gen_fn, mode, key: Key | None, args, constraint: ChoiceMap | None = 
     return trc, _broadcast_score(w, batch, be.device)
 
 
+class MinimalGenerate:
+    """`generate` compiled to store ONLY the return value and the importance
+    weight (plus per-block max partials of the weight for the resampler): the
+    program BootstrapSweep launches once per SMC step.  Per particle-step this
+    moves 4 B (ancestor) + 4*D B (gathered state) in and 4*D + 4 B out."""
+
+    def __init__(self, gen_fn, args, constraint: ChoiceMap, batch: tuple):
+        flat = Flat()
+        self.atree = flat.add(tuple(args))
+        self.ctree = flat.add(constraint)
+        self.specs = tuple(leaf_spec(v, batch) for v in flat.leaves)
+        tr = Tracing(len(batch))
+        ctx = _Ctx(tr)
+        with T.tracing(tr.graph):
+            syms = [tr.sym_leaf(s, j) for j, s in enumerate(self.specs)]
+            sargs = unflatten(self.atree, lambda j: syms[j].value)
+            scon = _sym_constraint(self.ctree, syms)
+            kexpr = Expr(tr.graph.add("LDKEY", dtype="key"))
+            rec, retval, w, _ = call_gen_fn(ctx, "generate", gen_fn, kexpr, sargs, scon, None, None, None, ())
+            self.ro = tr.emit_output(retval)
+            if w is None:
+                w = Expr(tr.graph.const_f32(0.0)) + 0.0
+            self.wo = tr.emit_output(w)
+            tr.graph.add("REDMAX", (w.node,), dtype="none")
+        self.comp = Compiled(tr)
+        self.gen_fn = gen_fn
+
+    def leaves(self, args, constraint):
+        flat = Flat()
+        a = flat.add(tuple(args))
+        c = flat.add(constraint)
+        if a != self.atree or c != self.ctree:
+            raise ValueError("MinimalGenerate: call structure differs from the compiled one")
+        return flat.leaves
+
+
 def run_edit(gen_fn, key: Key, trace: Trace, request: EditRequest, argdiffs):
     """edit(key, trace, request, argdiffs) -> (new trace, weight, retdiff, backward request)."""
     be = _lib.get()

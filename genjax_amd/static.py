@@ -23,6 +23,7 @@ a single gmx_program_run over all particles.
 from __future__ import annotations
 
 import functools
+import itertools
 from collections import OrderedDict
 
 import numpy as np
@@ -224,8 +225,24 @@ def _flatten_request(req, flat: Flat):
     raise NotSupportedEditRequest(req)
 
 
+_UID = itertools.count(1)
+
+
 def _gfkey(gf):
-    return ("gf", id(gf))
+    """Cache key of a generative function: a serial number stamped on first use
+    (id() would be recycled after garbage collection)."""
+    uid = getattr(gf, "_gmx_uid", None)
+    if uid is None:
+        uid = next(_UID)
+        try:
+            object.__setattr__(gf, "_gmx_uid", uid)
+        except Exception:
+            _KEEP.append(gf)
+            return ("gfid", id(gf))
+    return ("gf", uid)
+
+
+_KEEP: list = []
 
 
 def _depends(node, changed: set, memo: dict) -> bool:

@@ -1,0 +1,216 @@
+"""Pins for the CPU oracle (no GPU): known-answer vectors, the one numeric
+literal in the reference's tests, closed forms, independent f64 libraries, and
+the committed golden fixtures (tests/golden/oracle_vectors.json)."""
+import ctypes
+import hashlib
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+from scipy import stats
+from scipy.special import erfinv, gammaln
+
+from oracle import genjax_oracle as O
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "oracle_vectors.json")))
+
+
+def _tf(k0, k1, c0, c1):
+    a = lambda v: np.array([v], dtype=np.uint32)
+    o0, o1 = np.zeros(1, np.uint32), np.zeros(1, np.uint32)
+    O.lib().orc_threefry2x32(ctypes.c_int64(1), O._p(a(k0)), O._p(a(k1)), O._p(a(c0)), O._p(a(c1)), O._p(o0), O._p(o1))
+    return int(o0[0]), int(o1[0])
+
+
+def test_threefry_random123_kat():
+    """Random123 Threefry-2x32-20 known-answer vectors."""
+    for kat in GOLD["threefry_kat"]:
+        assert list(_tf(*kat["key"], *kat["ctr"])) == kat["out"]
+
+
+def test_host_threefry_matches_kat():
+    from genjax_amd.random import threefry2x32
+    for kat in GOLD["threefry_kat"]:
+        o0, o1 = threefry2x32(kat["key"][0], kat["key"][1], kat["ctr"][0], kat["ctr"][1])
+        assert [int(o0), int(o1)] == kat["out"]
+
+
+def test_key_algebra_golden():
+    k = O.key(314159)
+    assert [int(v) for v in k] == GOLD["key"] == [0, 314159]
+    assert O.split(k, 8).tolist() == GOLD["split8"]
+    assert [O.fold_in(k, d).tolist() for d in (1, 2, 3, 4)] == GOLD["fold_in_1_to_4"]
+    # fold_in(key, d) is the same Threefry block as split child d (App. A.2)
+    assert O.fold_in(k, 3).tolist() == O.split(k, 8)[3].tolist()
+    assert O.bits32(k[None, :], np.arange(16, dtype=np.uint64)).tolist() == GOLD["bits32_first16"]
+
+
+def _hexf(a):
+    return [float(np.float32(v)).hex() for v in np.asarray(a).reshape(-1)]
+
+
+def test_sample_streams_golden():
+    k = O.key(314159)
+    site = O.fold_in(k, 1)
+    assert _hexf(O.random_uniform(site, (64,))) == GOLD["uniform64"]
+    assert _hexf(O.random_normal(site, (64,))) == GOLD["normal64"]
+    assert _hexf(O.random_gumbel(site, (64,))) == GOLD["gumbel64"]
+    keys = O.split(k, 64)
+    assert _hexf(O.normal.sample(O.fold_in(keys, 1), np.float32(1.5), np.float32(2.0))) == GOLD["normal_site_per_particle64"]
+    assert [int(v) for v in O.flip.sample(O.fold_in(keys, 2), np.float32(0.3))] == GOLD["flip_per_particle64"]
+    logits = np.log(np.array([0.5, 0.25, 0.125, 0.125], dtype=np.float32))
+    assert [int(v) for v in O.categorical.sample(O.fold_in(keys, 3), logits)] == GOLD["categorical_per_particle64"]
+    assert _hexf(O.beta.sample(O.fold_in(keys, 4), np.float32(2.0), np.float32(2.0))) == GOLD["beta22_per_particle64"]
+
+
+def test_uniform_is_mantissa_trick():
+    """jax.random.uniform: bits >> 9 | 0x3F800000, minus 1 (App. A.2)."""
+    bits = np.array([0, 1 << 9, 0xFFFFFFFF, 0x80000000], dtype=np.uint32)
+    u = O.unit_from_bits(bits)
+    assert u.tolist() == [0.0, 2.0 ** -23, 1.0 - 2.0 ** -23, 0.5]
+
+
+def test_reference_assess_literal():
+    """tests/generative_functions/test_static_gen_fn.py:317-318:
+    assess({y1: 1.0, y2: -1.0}) of two normal(0,1) sites == -2.837877."""
+    @O.gen
+    def model():
+        y1 = O.normal(0.0, 1.0) @ "y1"
+        y2 = O.normal(0.0, 1.0) @ "y2"
+        return y1 + y2
+    score, _ = model.assess(O.C.kw(y1=np.float32(1.0), y2=np.float32(-1.0)), ())
+    assert float(score) == pytest.approx(-2.837877, abs=5e-7)
+    assert float(np.float32(score)) == GOLD["assess_literal"]
+
+
+def test_logpdfs_against_scipy():
+    xs = np.linspace(-4, 6, 101).astype(np.float32)
+    np.testing.assert_allclose(O.normal.logpdf(xs, np.float32(0.5), np.float32(1.5)),
+                               stats.norm.logpdf(xs.astype(np.float64), 0.5, 1.5), rtol=2e-6, atol=2e-6)
+    ps = np.linspace(0.01, 0.99, 99).astype(np.float32)
+    np.testing.assert_allclose(O.beta.logpdf(ps, np.float32(2.0), np.float32(3.0)),
+                               stats.beta.logpdf(ps.astype(np.float64), 2.0, 3.0), rtol=1e-5, atol=1e-5)
+    assert float(O.beta.logpdf(np.float32(0.3), np.float32(2.0), np.float32(2.0))) == pytest.approx(0.2311117, abs=2e-6)
+    np.testing.assert_allclose(O.flip.logpdf(np.array([1, 0], np.int32), np.float32(0.7)),
+                               [math.log(0.7), math.log(0.3)], rtol=1e-6)
+    np.testing.assert_allclose(O.uniform.logpdf(np.array([0.5, 3.0], np.float32), np.float32(0.0), np.float32(2.0)),
+                               [-math.log(2.0), -np.inf])
+    np.testing.assert_allclose(O.bernoulli.logpdf(np.array([1, 0], np.int32), np.float32(0.4)),
+                               [-math.log1p(math.exp(-0.4)), -math.log1p(math.exp(0.4))], rtol=1e-6)
+    assert _hexf(O.normal.logpdf(np.array([-2.0, -0.5, 0.0, 0.3, 1.0, 4.0], np.float32), np.float32(0.5), np.float32(1.5))) == GOLD["normal_logpdf"]
+
+
+def test_elementary_function_accuracy():
+    x = np.linspace(-87, 88, 200_001).astype(np.float32)
+    r = np.exp(x.astype(np.float64))
+    assert np.max(np.abs(O.exp(x) - r) / r) < 1.5e-7
+    x = np.exp(np.linspace(-80, 80, 200_001)).astype(np.float32)
+    r = np.log(x.astype(np.float64))
+    assert np.max(np.abs(O.log(x) - r) / np.maximum(np.abs(r), 1e-30)) < 1.5e-7
+    x = np.linspace(-0.999, 50, 100_001).astype(np.float32)
+    r = np.log1p(x.astype(np.float64))
+    assert np.max(np.abs(O.log1p(x) - r) / np.maximum(np.abs(r), 1e-30)) < 3e-7
+    x = np.exp(np.linspace(-6, 8, 100_001)).astype(np.float32)
+    r = gammaln(x.astype(np.float64))
+    assert np.max(np.abs(O.lgamma(x) - r) / np.maximum(1.0, np.abs(r))) < 4e-6
+    x = np.linspace(-0.99999, 0.99999, 100_001).astype(np.float32)
+    r = erfinv(x.astype(np.float64))
+    assert np.max(np.abs(O.erfinv(x) - r) / np.maximum(np.abs(r), 1e-6)) < 1e-5
+    x = np.linspace(-100, 100, 100_001).astype(np.float32)
+    assert np.max(np.abs(O.cos(x) - np.cos(x.astype(np.float64)))) < 2e-7
+    assert np.max(np.abs(O.sin(x) - np.sin(x.astype(np.float64)))) < 2e-7
+    assert O.exp(np.float32(-200.0)) == 0.0 and np.isinf(O.exp(np.float32(100.0)))
+    assert np.isneginf(O.log(np.float32(0.0))) and np.isnan(O.log(np.float32(-1.0)))
+
+
+def test_sampler_distributions():
+    """Distributional parity (the only kind available for Beta: SURVEY.md §7)."""
+    n = 200_000
+    keys = O.split(O.key(1), n)
+    z = O.normal.sample(keys, np.float32(1.0), np.float32(2.0))
+    assert stats.kstest(z[:20000], "norm", args=(1.0, 2.0)).pvalue > 1e-3
+    assert abs(z.mean() - 1.0) < 0.02 and abs(z.std() - 2.0) < 0.02
+    b = O.beta.sample(keys, np.float32(2.0), np.float32(5.0))
+    assert stats.kstest(b[:20000], "beta", args=(2.0, 5.0)).pvalue > 1e-3
+    b = O.beta.sample(keys, np.float32(0.5), np.float32(0.7))       # boosted branch (alpha < 1)
+    assert stats.kstest(b[:20000], "beta", args=(0.5, 0.7)).pvalue > 1e-3
+    f = O.flip.sample(keys, np.float32(0.3))
+    assert abs(f.mean() - 0.3) < 5e-3
+    c = O.categorical.sample(keys, np.log(np.array([0.5, 0.25, 0.125, 0.125], np.float32)))
+    np.testing.assert_allclose(np.bincount(c, minlength=4) / n, [0.5, 0.25, 0.125, 0.125], atol=5e-3)
+
+
+def test_smc_closed_forms():
+    """tests/inference/test_smc.py:32-87: flip-flip exact log-marginals."""
+    @O.gen
+    def flip_flip_trivial():
+        _ = O.flip(0.5) @ "x"
+        _ = O.flip(0.7) @ "y"
+    tgt = O.Target(flip_flip_trivial, (), O.C.kw(y=True))
+    k = O.key(314159)
+    z1 = O.log_marginal_likelihood_estimate(O.Importance(tgt), k)
+    assert float(z1) == pytest.approx(math.log(0.7), rel=1e-1)
+    zk = O.log_marginal_likelihood_estimate(O.ImportanceK(tgt, 1000), k)
+    assert float(zk) == pytest.approx(math.log(0.7), rel=1e-3)
+
+    @O.gen
+    def flip_flip():
+        v1 = O.flip(0.5) @ "x"
+        p = np.where(v1, np.float32(0.9), np.float32(0.3))
+        _ = O.flip(p) @ "y"
+    tgt = O.Target(flip_flip, (), O.C.kw(y=True))
+    zk = O.log_marginal_likelihood_estimate(O.ImportanceK(tgt, 2000), k)
+    assert float(zk) == pytest.approx(math.log(0.5 * 0.9 + 0.5 * 0.3), rel=1e-1)
+
+
+def test_resampling_golden_and_properties():
+    rng = np.random.default_rng(0)
+    for n_ in (8, 1024, 1_000_000):
+        lw = rng.normal(0, 2, n_).astype(np.float32)
+        g = GOLD["resample"][str(n_)]
+        assert hashlib.sha256(lw.tobytes()).hexdigest() == g["lw_sha256"]
+        cdf, total, M, shift = O.weight_cdf(lw)
+        assert str(total) == g["total"] and shift == g["shift"] and float(M).hex() == g["max"]
+        assert hashlib.sha256(cdf.tobytes()).hexdigest() == g["cdf_sha256"]
+        for kind, name in ((O.SYSTEMATIC, "systematic"), (O.STRATIFIED, "stratified"), (O.MULTINOMIAL, "multinomial")):
+            anc = O.ancestors(kind, O.key(99), cdf)
+            assert hashlib.sha256(anc.tobytes()).hexdigest() == g[name + "_sha256"]
+            if g[name] is not None:
+                assert anc.tolist() == g[name]
+            if kind != O.MULTINOMIAL:
+                assert np.all(np.diff(anc) >= 0)
+            # offspring counts track the weights
+            if n_ == 1_000_000:
+                w = np.exp(lw.astype(np.float64) - lw.max())
+                w /= w.sum()
+                cnt = np.bincount(anc, minlength=n_)
+                top = np.argsort(w)[-100:]
+                bound = {O.SYSTEMATIC: 1.0, O.STRATIFIED: 2.0}.get(kind, 8 * np.sqrt(n_ * w[top]) + 1)
+                assert np.all(np.abs(cnt[top] - n_ * w[top]) <= bound)
+
+
+def test_systematic_matches_float_definition_small():
+    """Integer rule == the textbook definition: first i with CDF_i > (j + u0)/n * total."""
+    from fractions import Fraction
+    rng = np.random.default_rng(4)
+    lw = rng.normal(0, 1, 50).astype(np.float32)
+    cdf, total, _, _ = O.weight_cdf(lw)
+    k = O.key(5)
+    u0 = Fraction(int(O.bits32(k, 0)) >> 9, 1 << 23)
+    anc = O.ancestors(O.SYSTEMATIC, k, cdf)
+    for j in range(50):
+        pos = (j + u0) / 50 * total
+        i = next(i for i in range(50) if int(cdf[i]) > pos)
+        assert anc[j] == i
+
+
+def test_kalman_vs_oracle_particle_filter():
+    from genjax_amd import workloads
+    from tests import parity
+    T, n = 20, 20_000
+    ys = workloads.lgssm_data(T)
+    init, step = workloads.make_lgssm(O)
+    res = parity.oracle_bootstrap_sweep(init, step, n, T, ys, O.key(314159))
+    assert res["log_ml"] == pytest.approx(workloads.kalman_log_ml(ys), abs=0.15)

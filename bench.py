@@ -33,9 +33,9 @@ N_PARTICLES = 1_000_000
 T_STEPS = 100
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 # Algorithmic bytes per particle-step (8*D + 24 = 32 B, D = 1):
-#   k_vm        ancestor 4 + gathered state 4 in, state 4 + log-weight 4 out      = 16 B
+#   k_vm          ancestor 4 + gathered state 4 in, state 4 + log-weight 4 out    = 16 B
 #   k_weight_cdf  log-weight 4 in, CDF 4 out (stored as u64: 8 actual)            =  8 B
-#   k_ancestors   CDF 4 in, ancestor 4 out                                         =  8 B
+#   k_offspring   CDF 4 in, ancestor 4 out                                         =  8 B
 VM_BYTES_PER_PARTICLE = 16
 SWEEP_BYTES_PER_PARTICLE_STEP = 32
 
@@ -188,7 +188,7 @@ def main():
                 traffic = None
         out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                           "kernel": "k_vm<gmx_regs_vgpr<16>>",
+                           "kernel": "k_vm<gmx_regs_vgpr<16>, false>",
                            "algorithmic_bytes_per_launch": VM_BYTES_PER_PARTICLE * n,
                            "kernel_us": us,
                            "sweep_frac_of_hbm_roofline":

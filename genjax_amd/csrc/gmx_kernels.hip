@@ -82,11 +82,52 @@ __device__ __forceinline__ float block_sum(float v, float* lds4) {
 // site-program interpreter
 // ---------------------------------------------------------------------------
 struct DevCtx {
+  // lane l of each of these holds table entry l (filled once per wave)
+  uint32_t prog_a0, prog_b0, prog_a1, prog_b1;   // instruction words 0..63 / 64..127
+  uint32_t pool_v;                               // gmx_run_args.uni[l]
+  uint32_t in_lo, in_hi, out_lo, out_hi;         // slot pointers
+  const uint32_t* code;
+  const gmx_run_args* A;
   float* red_out;
   float* lds4;
-  __device__ __forceinline__ uint32_t uniform(uint32_t x) const {
-    return __builtin_amdgcn_readfirstlane(x);
+  __device__ __forceinline__ void init(const uint32_t* code_, uint32_t n_instr, const gmx_run_args* A_,
+                                        float* lds4_) {
+    code = code_; A = A_; red_out = A_->red_out_d; lds4 = lds4_;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint2* c2 = reinterpret_cast<const uint2*>(code_);
+    uint2 w = (lane < n_instr) ? c2[lane] : make_uint2(0u, 0u);
+    prog_a0 = w.x; prog_b0 = w.y;
+    uint2 w1 = (lane + 64u < n_instr) ? c2[lane + 64u] : make_uint2(0u, 0u);
+    prog_a1 = w1.x; prog_b1 = w1.y;
+    pool_v = A_->uni[lane];
+    uint64_t pi = (uint64_t)A_->in_d[lane], po = (uint64_t)A_->out_d[lane];
+    in_lo = (uint32_t)pi; in_hi = (uint32_t)(pi >> 32);
+    out_lo = (uint32_t)po; out_hi = (uint32_t)(po >> 32);
   }
+  __device__ __forceinline__ void fetch(uint32_t pc, uint32_t* w0, uint32_t* w1) const {
+    if (pc < 64u) {
+      *w0 = __builtin_amdgcn_readlane(prog_a0, pc);
+      *w1 = __builtin_amdgcn_readlane(prog_b0, pc);
+    } else if (pc < 128u) {
+      *w0 = __builtin_amdgcn_readlane(prog_a1, pc - 64u);
+      *w1 = __builtin_amdgcn_readlane(prog_b1, pc - 64u);
+    } else {
+      *w0 = __builtin_amdgcn_readfirstlane(code[2u * pc]);
+      *w1 = __builtin_amdgcn_readfirstlane(code[2u * pc + 1u]);
+    }
+  }
+  __device__ __forceinline__ uint32_t pool(uint32_t i) const {
+    return __builtin_amdgcn_readlane(pool_v, i);
+  }
+  __device__ __forceinline__ const void* in_ptr(uint32_t s) const {
+    uint64_t p = ((uint64_t)__builtin_amdgcn_readlane(in_hi, s) << 32) | __builtin_amdgcn_readlane(in_lo, s);
+    return (const void*)p;
+  }
+  __device__ __forceinline__ void* out_ptr(uint32_t s) const {
+    uint64_t p = ((uint64_t)__builtin_amdgcn_readlane(out_hi, s) << 32) | __builtin_amdgcn_readlane(out_lo, s);
+    return (void*)p;
+  }
+  __device__ __forceinline__ const void* tab_ptr(uint32_t s) const { return A->tab_d[s]; }
   __device__ __forceinline__ void red_max(float x, bool active) {
     float m = block_max(active ? x : -gmx_inf(), lds4);
     if (threadIdx.x == 0 && red_out) red_out[2 * (size_t)blockIdx.x] = m;
@@ -103,21 +144,20 @@ struct DevCtx {
   }
 };
 
-template <class Regs>
+template <class Regs, bool FULL>
 __global__ void __launch_bounds__(GMX_BLOCK)
 k_vm(const uint32_t* __restrict__ code, uint32_t n_instr, int64_t n, const gmx_run_args A) {
   __shared__ float lds4[4];
   int64_t i = (int64_t)blockIdx.x * GMX_BLOCK + threadIdx.x;
   DevCtx ctx;
-  ctx.red_out = A.red_out_d;
-  ctx.lds4 = lds4;
-  gmx_vm_run<Regs, DevCtx>(code, n_instr, i, i < n, A, ctx);
+  ctx.init(code, n_instr, &A, lds4);
+  gmx_vm_run<Regs, FULL, DevCtx>(n_instr, i, i < n, A, ctx);
 }
 
 struct gmx_program {
   uint32_t* code_d;
   uint32_t n_instr, n_regs, n_in, n_out, n_uni, n_tab;
-  bool uses_key, uses_red, uses_gather;
+  bool uses_key, uses_red, uses_gather, needs_full;
 };
 
 extern "C" int gmx_program_create(const uint32_t* blob, size_t n_words, gmx_program** out) {
@@ -144,14 +184,18 @@ extern "C" int gmx_program_create(const uint32_t* blob, size_t n_words, gmx_prog
     uint32_t op = w0 & 0xff, dst = (w0 >> 8) & 0xff, a = (w0 >> 16) & 0xff, b = w0 >> 24;
     uint32_t c = w1 & 0xff;
     bool ok = true;
-    auto R = [&](uint32_t r) { return r < n_regs; };
-    auto R2 = [&](uint32_t r) { return r + 1 < n_regs; };
+    auto D = [&](uint32_t r) { return r < n_regs; };                        // destination register
+    auto R2 = [&](uint32_t r) { return r + 1 < n_regs; };                  // register pair (keys)
+    auto R = [&](uint32_t r) {                                              // source: register or pool entry
+      return r < n_regs || (r >= GMX_POOL_BASE && r - GMX_POOL_BASE < P.n_uni);
+    };
+    if (gmx_op_needs_full(op)) P.needs_full = true;
     switch (op) {
       case OP_END: break;
-      case OP_CONST: ok = R(dst); break;
-      case OP_UNI: ok = R(dst) && w1 < P.n_uni; break;
-      case OP_LDIN: ok = R(dst) && a < P.n_in; if (b & GMX_F_GATHER) P.uses_gather = true; break;
-      case OP_LDTAB: ok = R(dst) && R(b) && a < P.n_tab; break;
+      case OP_CONST: ok = D(dst); break;
+      case OP_UNI: ok = D(dst) && w1 < P.n_uni; break;
+      case OP_LDIN: ok = D(dst) && a < P.n_in; if (b & GMX_F_GATHER) P.uses_gather = true; break;
+      case OP_LDTAB: ok = D(dst) && R(b) && a < P.n_tab; break;
       case OP_STOUT: ok = R(b) && a < P.n_out; break;
       case OP_LDKEY: ok = R2(dst); P.uses_key = true; break;
       case OP_KDERIVE: ok = R2(dst) && R2(a); break;
@@ -160,20 +204,20 @@ extern "C" int gmx_program_create(const uint32_t* blob, size_t n_words, gmx_prog
       case OP_SQRT: case OP_SIN: case OP_COS: case OP_TANH: case OP_SIGMOID:
       case OP_SOFTPLUS: case OP_FLOOR: case OP_CEIL: case OP_ROUND: case OP_LGAMMA:
       case OP_SQUARE: case OP_RECIP: case OP_NOT: case OP_I2F: case OP_F2I: case OP_INEG:
-        ok = R(dst) && R(a); break;
+        ok = D(dst) && R(a); break;
       case OP_ADD: case OP_SUB: case OP_MUL: case OP_DIV: case OP_MIN: case OP_MAX: case OP_POW:
       case OP_FLT: case OP_FLE: case OP_FGT: case OP_FGE: case OP_FEQ: case OP_FNE:
       case OP_IEQ: case OP_INE: case OP_ILT: case OP_ILE: case OP_IGT: case OP_IGE:
       case OP_AND: case OP_OR: case OP_XOR: case OP_IADD: case OP_ISUB: case OP_IMUL:
-        ok = R(dst) && R(a) && R(b); break;
-      case OP_SEL: ok = R(dst) && R(a) && R(b) && R(c); break;
+        ok = D(dst) && R(a) && R(b); break;
+      case OP_SEL: ok = D(dst) && R(a) && R(b) && R(c); break;
       case OP_S_NORMAL: case OP_S_UNIFORM: case OP_S_BETA:
-        ok = R(dst) && R(a) && R(b) && R2(c); break;
-      case OP_S_FLIP: case OP_S_BERNL: ok = R(dst) && R(a) && R2(c); break;
+        ok = D(dst) && R(a) && R(b) && R2(c); break;
+      case OP_S_FLIP: case OP_S_BERNL: ok = D(dst) && R(a) && R2(c); break;
       case OP_S_CATSTEP: ok = R2(dst) && R(a) && R(b) && R2(c); break;
       case OP_L_NORMAL: case OP_L_UNIFORM: case OP_L_BETA:
-        ok = R(dst) && R(a) && R(b) && R(c); break;
-      case OP_L_FLIP: case OP_L_BERNL: ok = R(dst) && R(a) && R(c); break;
+        ok = D(dst) && R(a) && R(b) && R(c); break;
+      case OP_L_FLIP: case OP_L_BERNL: ok = D(dst) && R(a) && R(c); break;
       case OP_REDMAX: case OP_REDLSE: ok = R(a); P.uses_red = true; break;
       default: ok = false;
     }
@@ -228,10 +272,17 @@ extern "C" int gmx_program_run(const gmx_program* p, int64_t n, const gmx_run_ar
   }
   dim3 grid((unsigned)((n + GMX_BLOCK - 1) / GMX_BLOCK)), block(GMX_BLOCK);
   hipStream_t st = (hipStream_t)stream;
-  if (p->n_regs <= 16)
-    hipLaunchKernelGGL(k_vm<gmx_regs_vgpr<16>>, grid, block, 0, st, p->code_d, p->n_instr, n, *args);
-  else
-    hipLaunchKernelGGL(k_vm<gmx_regs_vgpr<32>>, grid, block, 0, st, p->code_d, p->n_instr, n, *args);
+  if (p->n_regs <= 16) {
+    if (p->needs_full)
+      hipLaunchKernelGGL((k_vm<gmx_regs_vgpr<16>, true>), grid, block, 0, st, p->code_d, p->n_instr, n, *args);
+    else
+      hipLaunchKernelGGL((k_vm<gmx_regs_vgpr<16>, false>), grid, block, 0, st, p->code_d, p->n_instr, n, *args);
+  } else {
+    if (p->needs_full)
+      hipLaunchKernelGGL((k_vm<gmx_regs_vgpr<32>, true>), grid, block, 0, st, p->code_d, p->n_instr, n, *args);
+    else
+      hipLaunchKernelGGL((k_vm<gmx_regs_vgpr<32>, false>), grid, block, 0, st, p->code_d, p->n_instr, n, *args);
+  }
   GMX_HIP(hipGetLastError());
   return 0;
 }
@@ -426,24 +477,35 @@ extern "C" int gmx_logsumexp(const float* lw_d, int64_t rows, int64_t cols, floa
 
 // ---------------------------------------------------------------------------
 // fixed-point weights + chained inclusive scan (single pass, decoupled look-back)
+//
+// Tile = 4096 log-weights (256 threads x 4 sub-tiles x float4), so 1e6
+// particles are 245 tiles: every tile's look-back window (256 predecessors,
+// 4 descriptors per lane of wave 0, all loads in flight together) covers the
+// whole prefix in ONE polling round — the scan is bounded by one HBM round
+// trip for the loads plus one L2 round trip for the look-back, not by a
+// serial chain.  The global max comes from the per-block partials a site
+// program's OP_REDMAX left behind (no extra launch), and the workspace is
+// returned zeroed by the last tile to finish (no memset launch).
 // ---------------------------------------------------------------------------
-#define CDF_ITEMS 4
-#define CDF_TILE (GMX_BLOCK * CDF_ITEMS)
+#define CDF_SUB 4                      /* sub-tiles per tile              */
+#define CDF_VEC 4                      /* consecutive items per thread     */
+#define CDF_TILE (GMX_BLOCK * CDF_SUB * CDF_VEC)
 #define CDF_ST_AGG 1ull
 #define CDF_ST_INC 2ull
-#define CDF_SPIN_LIMIT (1u << 24)
+#define CDF_SPIN_LIMIT (1u << 22)
+#define CDF_LOOK 4                     /* descriptors per lane per look-back round (window 256) */
 
-// workspace layout: [0] u32 ticket, [1] u32 error flag, then (8-byte aligned)
-// one u64 descriptor per tile: value << 2 | status.  value < 2^62 by the
-// choice of `shift`, so the packed word is a single naturally aligned 8-byte
-// granule: written and read with relaxed agent-scope atomics, it needs no
-// ordering against any other memory.
-struct cdf_ws { uint32_t ticket; uint32_t error; uint64_t desc[1]; };
+// workspace: [0] u32 ticket, [1] u32 error flag, [2] u32 done count, [3] pad,
+// then one u64 descriptor per tile: value << 2 | status.  value < 2^62 by the
+// choice of `shift`, so a descriptor is a single naturally aligned 8-byte
+// granule: written and read with relaxed agent-scope atomics it needs no
+// ordering against any other memory.  Contract: zero on entry, zero on exit.
+struct cdf_ws { uint32_t ticket; uint32_t error; uint32_t done; uint32_t pad; uint64_t desc[1]; };
 
 extern "C" size_t gmx_weight_cdf_workspace(int64_t n) {
   int64_t tiles = (n + CDF_TILE - 1) / CDF_TILE;
   if (tiles < 1) tiles = 1;
-  return 8 + (size_t)tiles * 8;
+  return 16 + (size_t)tiles * 8;
 }
 
 __device__ __forceinline__ uint64_t shfl_up_u64(uint64_t v, int d) {
@@ -452,11 +514,14 @@ __device__ __forceinline__ uint64_t shfl_up_u64(uint64_t v, int d) {
   hi = __shfl_up(hi, d, GMX_WAVE);
   return ((uint64_t)hi << 32) | lo;
 }
-__device__ __forceinline__ uint64_t shfl_u64(uint64_t v, int src) {
-  uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
-  lo = __shfl(lo, src, GMX_WAVE);
-  hi = __shfl(hi, src, GMX_WAVE);
-  return ((uint64_t)hi << 32) | lo;
+__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    lo = __shfl_xor(lo, m, GMX_WAVE); hi = __shfl_xor(hi, m, GMX_WAVE);
+    v += ((uint64_t)hi << 32) | lo;
+  }
+  return v;
 }
 
 // q = floor(exp(lw - M) * 2^shift) as u64; NaN / negative -> 0
@@ -476,12 +541,16 @@ k_reduce_max(const float* __restrict__ partials, int64_t n_part, float* __restri
   if (threadIdx.x == 0) *max_out = m;
 }
 
+// max_mode: 0 = read *max_d; 1 = reduce column 0 of partials[n_part][2] (every tile
+// does it: a few KB from L2) and tile 0 stores the result to *max_d.
 __global__ void __launch_bounds__(GMX_BLOCK)
-k_weight_cdf(const float* __restrict__ lw, int64_t n, float scale, const float* __restrict__ max_d,
+k_weight_cdf(const float* __restrict__ lw, int64_t n, float scale, int max_mode,
+             const float* __restrict__ partials, int64_t n_part, float* __restrict__ max_d,
              uint64_t* __restrict__ cdf, uint64_t* __restrict__ total_out, cdf_ws* ws) {
-  __shared__ uint64_t s_wave[4];
+  __shared__ uint64_t s_part[CDF_SUB][4];
   __shared__ uint64_t s_prefix;
   __shared__ uint32_t s_tile;
+  __shared__ float lds4[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // dynamic tile id: a tile only ever waits on tiles whose blocks already run
   if (threadIdx.x == 0) s_tile = atomicAdd(&ws->ticket, 1u);
@@ -489,38 +558,63 @@ k_weight_cdf(const float* __restrict__ lw, int64_t n, float scale, const float* 
   const uint32_t tile = s_tile;
   const int64_t n_tiles = (n + CDF_TILE - 1) / CDF_TILE;
   if ((int64_t)tile >= n_tiles) return;
-  const float M = *max_d;
-  const int64_t base = (int64_t)tile * CDF_TILE + (int64_t)threadIdx.x * CDF_ITEMS;
-  // 4 consecutive floats per thread (16-byte load when fully in range)
-  float x[CDF_ITEMS];
-  if (base + CDF_ITEMS <= n) {
-    float4 v = *reinterpret_cast<const float4*>(lw + base);
-    x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
+  const int64_t tile_base = (int64_t)tile * CDF_TILE;
+  // issue the tile's loads first, reduce the max while they are in flight
+  float x[CDF_SUB][CDF_VEC];
+#pragma unroll
+  for (int k = 0; k < CDF_SUB; ++k) {
+    const int64_t base = tile_base + (int64_t)k * (GMX_BLOCK * CDF_VEC) + (int64_t)threadIdx.x * CDF_VEC;
+    if (base + CDF_VEC <= n) {
+      float4 v = *reinterpret_cast<const float4*>(lw + base);
+      x[k][0] = v.x; x[k][1] = v.y; x[k][2] = v.z; x[k][3] = v.w;
+    } else {
+#pragma unroll
+      for (int c = 0; c < CDF_VEC; ++c) x[k][c] = (base + c < n) ? lw[base + c] : -gmx_inf();
+    }
+  }
+  float M;
+  if (max_mode == 1) {
+    float m = -gmx_inf();
+    for (int64_t j = threadIdx.x; j < n_part; j += GMX_BLOCK) m = gmx_fmax(m, partials[2 * j]);
+    M = block_max(m, lds4);
+    if (tile == 0 && threadIdx.x == 0) *max_d = M;
   } else {
-#pragma unroll
-    for (int k = 0; k < CDF_ITEMS; ++k) x[k] = (base + k < n) ? lw[base + k] : -gmx_inf();
+    M = *max_d;
   }
-  uint64_t q[CDF_ITEMS];
-  uint64_t run = 0;
+  uint64_t q[CDF_SUB][CDF_VEC];
+  uint64_t inc[CDF_SUB], run[CDF_SUB];
 #pragma unroll
-  for (int k = 0; k < CDF_ITEMS; ++k) {
-    uint64_t w = (base + k < n) ? weight_fixed(x[k], M, scale) : 0ull;
-    run += w;
-    q[k] = run;                        // thread-local inclusive
-  }
-  // wave inclusive scan of thread totals
-  uint64_t inc = run;
+  for (int k = 0; k < CDF_SUB; ++k) {
+    const int64_t base = tile_base + (int64_t)k * (GMX_BLOCK * CDF_VEC) + (int64_t)threadIdx.x * CDF_VEC;
+    uint64_t r = 0;
 #pragma unroll
-  for (int d = 1; d < GMX_WAVE; d <<= 1) {
-    uint64_t t = shfl_up_u64(inc, d);
-    if (lane >= d) inc += t;
+    for (int c = 0; c < CDF_VEC; ++c) {
+      uint64_t w = (base + c < n) ? weight_fixed(x[k][c], M, scale) : 0ull;
+      r += w;
+      q[k][c] = r;                     // thread-local inclusive
+    }
+    run[k] = r;
+    uint64_t v = r;                    // wave inclusive scan of thread totals
+#pragma unroll
+    for (int d = 1; d < GMX_WAVE; d <<= 1) {
+      uint64_t t = shfl_up_u64(v, d);
+      if (lane >= d) v += t;
+    }
+    inc[k] = v;
+    if (lane == 63) s_part[k][wave] = v;
   }
-  if (lane == 63) s_wave[wave] = inc;
   __syncthreads();
-  uint64_t wave_off = 0;
-  for (int w = 0; w < wave; ++w) wave_off += s_wave[w];
-  const uint64_t tile_agg = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
-  // ---- chained scan across tiles ----
+  uint64_t tile_agg = 0;
+  uint64_t part_off[CDF_SUB];
+#pragma unroll
+  for (int k = 0; k < CDF_SUB; ++k) {
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      if (w == wave) part_off[k] = tile_agg;
+      tile_agg += s_part[k][w];
+    }
+  }
+  // ---- chained scan across tiles (wave 0) ----
   if (wave == 0) {
     uint64_t prefix = 0;
     if (tile == 0) {
@@ -531,35 +625,41 @@ k_weight_cdf(const float* __restrict__ lw, int64_t n, float scale, const float* 
       if (lane == 0)
         __hip_atomic_store(&ws->desc[tile], (tile_agg << 2) | CDF_ST_AGG, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
-      int64_t look = (int64_t)tile - 1;     // window = tiles look - lane
+      int64_t look = (int64_t)tile - 1;     // nearest predecessor of the current window
       uint32_t spins = 0;
       bool done = false;
       while (!done) {
-        int64_t t = look - lane;
-        uint64_t d = (t >= 0) ? __hip_atomic_load(&ws->desc[t], __ATOMIC_RELAXED,
-                                                  __HIP_MEMORY_SCOPE_AGENT)
-                              : CDF_ST_INC;   // virtual tile -1: inclusive prefix 0
-        uint64_t st = d & 3ull;
-        unsigned long long inc_mask = __ballot(st == CDF_ST_INC);
-        unsigned long long none_mask = __ballot(st == 0ull);
-        // lanes before the first inclusive one must all be ready
-        int first_inc = inc_mask ? __builtin_ctzll(inc_mask) : 64;
-        unsigned long long need = (first_inc >= 64) ? ~0ull : ((1ull << first_inc) | ((1ull << first_inc) - 1ull));
-        if (none_mask & need) {
+        // one round: CDF_LOOK x 64 predecessors, all loads in flight together
+        uint64_t d[CDF_LOOK];
+#pragma unroll
+        for (int r = 0; r < CDF_LOOK; ++r) {
+          int64_t t = look - (int64_t)r * GMX_WAVE - lane;
+          d[r] = (t >= 0) ? __hip_atomic_load(&ws->desc[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                          : CDF_ST_INC;       // virtual tile -1: inclusive prefix 0
+        }
+        bool retry = false;
+        uint64_t acc = 0;
+        int consumed = 0;
+#pragma unroll
+        for (int r = 0; r < CDF_LOOK; ++r) {
+          if (done || retry) continue;
+          uint64_t st = d[r] & 3ull;
+          unsigned long long inc_mask = __ballot(st == CDF_ST_INC);
+          unsigned long long none_mask = __ballot(st == 0ull);
+          int first_inc = inc_mask ? __builtin_ctzll(inc_mask) : 64;
+          unsigned long long need = (first_inc >= 63) ? ~0ull : ((2ull << first_inc) - 1ull);
+          if (none_mask & need) { retry = true; continue; }
+          uint64_t contrib = (lane <= first_inc) ? (d[r] >> 2) : 0ull;
+          acc += wave_sum_u64(contrib);
+          consumed = r + 1;
+          if (first_inc < 64) done = true;
+        }
+        prefix += acc;                        // sub-windows consumed so far stay valid
+        look -= (int64_t)consumed * GMX_WAVE;
+        if (retry) {
           if (++spins > CDF_SPIN_LIMIT) { if (lane == 0) ws->error = 1u; break; }
           __builtin_amdgcn_s_sleep(1);
-          continue;
         }
-        uint64_t contrib = (lane <= first_inc) ? (d >> 2) : 0ull;
-        // wave sum of contrib (u64 butterfly)
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) {
-          uint32_t lo = (uint32_t)contrib, hi = (uint32_t)(contrib >> 32);
-          lo = __shfl_xor(lo, m, GMX_WAVE); hi = __shfl_xor(hi, m, GMX_WAVE);
-          contrib += ((uint64_t)hi << 32) | lo;
-        }
-        prefix += contrib;
-        if (first_inc < 64) done = true; else look -= GMX_WAVE;
       }
       if (lane == 0)
         __hip_atomic_store(&ws->desc[tile], ((prefix + tile_agg) << 2) | CDF_ST_INC,
@@ -568,18 +668,31 @@ k_weight_cdf(const float* __restrict__ lw, int64_t n, float scale, const float* 
     if (lane == 0) s_prefix = prefix;
   }
   __syncthreads();
-  const uint64_t off = s_prefix + wave_off + (inc - run);
-  if (base + CDF_ITEMS <= n) {
-    ulonglong2 a, b;
-    a.x = off + q[0]; a.y = off + q[1]; b.x = off + q[2]; b.y = off + q[3];
-    reinterpret_cast<ulonglong2*>(cdf + base)[0] = a;
-    reinterpret_cast<ulonglong2*>(cdf + base)[1] = b;
-  } else {
+  const uint64_t tile_prefix = s_prefix;
 #pragma unroll
-    for (int k = 0; k < CDF_ITEMS; ++k)
-      if (base + k < n) cdf[base + k] = off + q[k];
+  for (int k = 0; k < CDF_SUB; ++k) {
+    const int64_t base = tile_base + (int64_t)k * (GMX_BLOCK * CDF_VEC) + (int64_t)threadIdx.x * CDF_VEC;
+    const uint64_t off = tile_prefix + part_off[k] + (inc[k] - run[k]);
+    if (base + CDF_VEC <= n) {
+      ulonglong2 a, b;
+      a.x = off + q[k][0]; a.y = off + q[k][1]; b.x = off + q[k][2]; b.y = off + q[k][3];
+      reinterpret_cast<ulonglong2*>(cdf + base)[0] = a;
+      reinterpret_cast<ulonglong2*>(cdf + base)[1] = b;
+    } else {
+#pragma unroll
+      for (int c = 0; c < CDF_VEC; ++c)
+        if (base + c < n) cdf[base + c] = off + q[k][c];
+    }
   }
-  if ((int64_t)tile == n_tiles - 1 && threadIdx.x == 0) *total_out = s_prefix + tile_agg;
+  if ((int64_t)tile == n_tiles - 1 && threadIdx.x == 0) *total_out = tile_prefix + tile_agg;
+  // ---- leave the workspace zeroed: the last tile to finish cleans up ----
+  __shared__ uint32_t s_last;
+  if (threadIdx.x == 0) s_last = (atomicAdd(&ws->done, 1u) == (uint32_t)(n_tiles - 1)) ? 1u : 0u;
+  __syncthreads();
+  if (s_last) {
+    for (int64_t t = threadIdx.x; t < n_tiles; t += GMX_BLOCK) ws->desc[t] = 0ull;
+    if (threadIdx.x == 0) { ws->ticket = 0u; ws->done = 0u; }
+  }
 }
 
 extern "C" int gmx_weight_cdf(const float* lw_d, int64_t n, int shift,
@@ -597,22 +710,36 @@ extern "C" int gmx_weight_cdf(const float* lw_d, int64_t n, int shift,
   if (((uintptr_t)lw_d & 15) || ((uintptr_t)cdf_d & 15))
     return gmx_fail("gmx_weight_cdf: lw_d and cdf_d must be 16-byte aligned%s");
   hipStream_t st = (hipStream_t)stream;
+  int max_mode = 0;
   if (max_partials_d) {
     if (n_partials <= 0) return gmx_fail("gmx_weight_cdf: n_partials must be positive%s");
-    hipLaunchKernelGGL(k_reduce_max, dim3(1), dim3(GMX_BLOCK), 0, st, max_partials_d, n_partials,
-                       max_d);
+    if (n_partials <= 16384) {
+      max_mode = 1;               // every tile reduces the partials itself: no extra launch
+    } else {
+      hipLaunchKernelGGL(k_reduce_max, dim3(1), dim3(GMX_BLOCK), 0, st, max_partials_d, n_partials, max_d);
+    }
   }
-  GMX_HIP(hipMemsetAsync(workspace_d, 0, gmx_weight_cdf_workspace(n), st));
   int64_t tiles = (n + CDF_TILE - 1) / CDF_TILE;
   float scale = gmx_pow2i(shift);
   hipLaunchKernelGGL(k_weight_cdf, dim3((unsigned)tiles), dim3(GMX_BLOCK), 0, st, lw_d, n, scale,
-                     max_d, cdf_d, total_d, (cdf_ws*)workspace_d);
+                     max_mode, max_partials_d, n_partials, max_d, cdf_d, total_d, (cdf_ws*)workspace_d);
   GMX_HIP(hipGetLastError());
   return 0;
 }
 
 // ---------------------------------------------------------------------------
-// ancestors: exact inverse-CDF search
+// ancestors
+//
+// ancestor(j) = first i with cdf_i * D > P_j (128-bit integers), where for
+//   systematic / stratified  D = n_out * 2^23,  P_j = (j * 2^23 + u_j) * total
+//   multinomial              D = 2^23,          P_j = total * (2^23 - u_j) - 1
+//
+// systematic / stratified: P_j is increasing in j, so source i owns the slot
+// range [f(cdf_{i-1}), f(cdf_i)) with f(c) = #{ j : P_j < c * D }.
+// k_offspring is source-centric: it reads the CDF once, coalesced, evaluates f
+// from an f64 estimate corrected with the exact 128-bit predicate, and writes
+// each ancestor index once — no dependent-load search chain.
+// multinomial positions are not ordered: k_ancestors binary-searches per slot.
 // ---------------------------------------------------------------------------
 struct u128 { uint64_t hi, lo; };
 __device__ __forceinline__ u128 mul64(uint64_t a, uint64_t b) {
@@ -620,6 +747,54 @@ __device__ __forceinline__ u128 mul64(uint64_t a, uint64_t b) {
 }
 __device__ __forceinline__ bool gt128(u128 a, u128 b) {
   return a.hi > b.hi || (a.hi == b.hi && a.lo > b.lo);
+}
+
+// P_j for the ordered kinds
+__device__ __forceinline__ u128 slot_threshold(int kind, gmx_key key, uint64_t u0, int64_t j, uint64_t total) {
+  uint64_t u = (kind == GMX_RESAMPLE_SYSTEMATIC) ? u0 : (uint64_t)(gmx_bits32(key, (uint64_t)j) >> 9);
+  return mul64(((uint64_t)j << 23) + u, total);
+}
+
+// f(c) = number of slots j in [0, n_out) with P_j < c * D
+__device__ __forceinline__ int64_t slots_below(int kind, gmx_key key, uint64_t u0, uint64_t c, uint64_t D,
+                                               uint64_t total, int64_t n_out) {
+  if (c == 0) return 0;
+  u128 X = mul64(c, D);
+  // estimate: j ~ c / total * n_out - u / 2^23   (f64; corrected below, so only a seed)
+  double est = (double)c / (double)total * (double)n_out;
+  int64_t j = (int64_t)est;
+  if (j > n_out) j = n_out;
+  if (j < 0) j = 0;
+  // exact fix-up with the integer predicate  P_j < X
+  while (j > 0 && !gt128(X, slot_threshold(kind, key, u0, j - 1, total))) --j;
+  while (j < n_out && gt128(X, slot_threshold(kind, key, u0, j, total))) ++j;
+  return j;
+}
+
+__global__ void __launch_bounds__(GMX_BLOCK)
+k_offspring(int kind, uint32_t k0, uint32_t k1, const uint64_t* __restrict__ cdf, int64_t n_in,
+            uint64_t cdf_offset, const uint64_t* __restrict__ total_d, int64_t n_out_total,
+            int64_t slot_offset, int64_t n_slots, int32_t* __restrict__ anc) {
+  int64_t i = (int64_t)blockIdx.x * GMX_BLOCK + threadIdx.x;
+  if (i >= n_in) return;
+  const uint64_t total = *total_d;
+  gmx_key key; key.k0 = k0; key.k1 = k1;
+  const uint64_t u0 = gmx_bits32(key, 0) >> 9;
+  const uint64_t D = (uint64_t)n_out_total << 23;
+  if (total == 0) {                       // no mass at all: everything maps to the last particle
+    if (i == n_in - 1)
+      for (int64_t s = 0; s < n_slots; ++s) anc[s] = (int32_t)(n_in - 1);
+    return;
+  }
+  const uint64_t c_hi = cdf[i] + cdf_offset;
+  const uint64_t c_lo = (i == 0) ? cdf_offset : cdf[i - 1] + cdf_offset;
+  if (c_hi == c_lo) return;               // zero weight: no offspring
+  int64_t s = slots_below(kind, key, u0, c_lo, D, total, n_out_total);
+  int64_t e = slots_below(kind, key, u0, c_hi, D, total, n_out_total);
+  // clip to the slot range this call owns
+  if (s < slot_offset) s = slot_offset;
+  if (e > slot_offset + n_slots) e = slot_offset + n_slots;
+  for (int64_t j = s; j < e; ++j) anc[j - slot_offset] = (int32_t)i;
 }
 
 __global__ void __launch_bounds__(GMX_BLOCK)
@@ -640,10 +815,9 @@ k_ancestors(int kind, uint32_t k0, uint32_t k1, const uint64_t* __restrict__ cdf
     // cdf*D >= P  <=>  cdf*D > P - 1   (P >= 1 whenever total >= 1)
     if (P.lo == 0) { if (P.hi) { P.hi -= 1; P.lo = ~0ull; } } else P.lo -= 1;
   } else {
-    uint64_t u = (kind == GMX_RESAMPLE_SYSTEMATIC) ? (gmx_bits32(key, 0) >> 9)
-                                                   : (gmx_bits32(key, (uint64_t)j) >> 9);
+    uint64_t u0 = gmx_bits32(key, 0) >> 9;
     D = (uint64_t)n_out_total << 23;
-    P = mul64(((uint64_t)j << 23) + u, total);
+    P = slot_threshold(kind, key, u0, j, total);
   }
   // binary search for the first i in [0, n_in) with (cdf[i] + off) * D > P
   int64_t lo = 0, hi = n_in;            // answer in [lo, hi]; hi == n_in means none
@@ -668,9 +842,16 @@ extern "C" int gmx_ancestors(int kind, const uint32_t key[2], const uint64_t* cd
     return gmx_fail("gmx_ancestors: n_out_total out of range%s");
   if (slot_offset < 0 || slot_offset + n_slots > n_out_total)
     return gmx_fail("gmx_ancestors: slot range outside [0, n_out_total)%s");
-  hipLaunchKernelGGL(k_ancestors, grid_for(n_slots), dim3(GMX_BLOCK), 0, (hipStream_t)stream, kind,
-                     key[0], key[1], cdf_d, n_in, cdf_offset, total_d, n_out_total, slot_offset,
-                     n_slots, ancestors_d);
+  if (kind == GMX_RESAMPLE_MULTINOMIAL || cdf_offset != 0 || slot_offset != 0 || n_slots != n_out_total) {
+    // unordered positions, or a shard of a larger problem: search per slot
+    hipLaunchKernelGGL(k_ancestors, grid_for(n_slots), dim3(GMX_BLOCK), 0, (hipStream_t)stream, kind,
+                       key[0], key[1], cdf_d, n_in, cdf_offset, total_d, n_out_total, slot_offset,
+                       n_slots, ancestors_d);
+  } else {
+    hipLaunchKernelGGL(k_offspring, grid_for(n_in), dim3(GMX_BLOCK), 0, (hipStream_t)stream, kind,
+                       key[0], key[1], cdf_d, n_in, cdf_offset, total_d, n_out_total, slot_offset,
+                       n_slots, ancestors_d);
+  }
   GMX_HIP(hipGetLastError());
   return 0;
 }

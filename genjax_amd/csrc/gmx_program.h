@@ -6,6 +6,11 @@
 //   then n_instr instructions of two words each:
 //     w0 = op | dst << 8 | a << 16 | b << 24          w1 = imm32
 //   For three-operand ops c = imm & 0xff and e = imm >> 8 (24 bits).
+//   A SOURCE operand code x names register x when x < GMX_POOL_BASE and pool
+//   entry (x - GMX_POOL_BASE) otherwise.  The pool is gmx_run_args.uni: launch
+//   uniforms first, then the program's constants (the host fills both), so a
+//   constant or a uniform costs no instruction.  dst and key operands are
+//   always registers.
 //
 // Registers are untyped 32-bit cells r[0..n_regs); an op reads them as f32 or
 // i32.  A PRNG key occupies two consecutive registers (k, k+1).  Booleans are
@@ -23,7 +28,8 @@
 #define GMX_PROG_MAGIC 0x50584D47u /* 'GMXP' */
 #define GMX_PROG_VERSION 1u
 #define GMX_PROG_HEADER_WORDS 8u
-#define GMX_MAX_REGS 64
+#define GMX_MAX_REGS 32
+#define GMX_POOL_BASE 64u /* source operand codes >= this name pool entries */
 
 // LDIN / STOUT flag bits (field b for LDIN, field dst for STOUT)
 #define GMX_F_GATHER 1u /* row = ancestors[i] instead of i            */

@@ -257,7 +257,7 @@ class Compiled:
 
     def __init__(self, tr: Tracing):
         be = _lib.get()
-        self.blob = compile_graph(tr.graph)
+        self.blob, self.const_pool = compile_graph(tr.graph)
         self.in_plan, self.uni_plan, self.outputs = tr.in_plan, tr.uni_plan, tr.outputs
         self.n_in, self.n_out, self.n_uni = tr.graph.n_in, tr.graph.n_out, tr.graph.n_uni
         self.uses_red = any(n.op in ("REDMAX", "REDLSE") for n in tr.graph.nodes)
@@ -326,6 +326,8 @@ class Compiled:
             if e is not None:
                 v = np.asarray(v).reshape(-1)[e]
             A.uni[ui] = _bits(v, dt)
+        for pi, bits in self.const_pool:
+            A.uni[pi] = bits
         for s, t in enumerate(self.tables):
             A.tab_d[s] = t.data_ptr()
         outs = []

@@ -250,7 +250,7 @@ def weight_cdf(lw: torch.Tensor, n_total=None, max_partials=None):
     cdf = torch.empty((n,), dtype=torch.int64, device=lw.device)
     total = torch.empty((1,), dtype=torch.int64, device=lw.device)
     mx = torch.empty((1,), dtype=torch.float32, device=lw.device)
-    ws = torch.empty(((be.c.gmx_weight_cdf_workspace(n) + 7) // 8,), dtype=torch.int64, device=lw.device)
+    ws = torch.zeros(((be.c.gmx_weight_cdf_workspace(n) + 7) // 8,), dtype=torch.int64, device=lw.device)
     if max_partials is None:
         # max via the deterministic LSE kernel's max output
         rows_ws = torch.empty(((be.c.gmx_logsumexp_workspace(1, n) + 3) // 4,), dtype=torch.int32, device=lw.device)
@@ -433,7 +433,7 @@ class BootstrapSweep:
         """Representative single launches (a mid-sweep step) for per-kernel timing in bench.py."""
         t = max(1, self.T // 2)
         return {"k_vm": lambda: self._launch_vm(t),
-                "weight_cdf(k_reduce_max+memset+k_weight_cdf)": lambda: self._launch_cdf(t),
+                "k_weight_cdf": lambda: self._launch_cdf(t),
                 "k_ancestors": lambda: self._launch_anc(t)}
 
     def capture(self):

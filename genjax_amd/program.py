@@ -122,8 +122,18 @@ class ProgramTooLarge(Exception):
     pass
 
 
-def compile_graph(g: Graph) -> np.ndarray:
-    """DCE + linear-scan register allocation + encoding -> uint32 blob."""
+POOL_BASE = 64
+POOL_SIZE = 64
+
+
+def compile_graph(g: Graph):
+    """DCE + linear-scan register allocation + encoding.
+
+    Returns (blob uint32[], const_pool [(pool index, bits)]).  Launch uniforms
+    and constants live in the operand pool (gmx_run_args.uni: uniforms first,
+    constants after) and are named directly by source operands, so they cost
+    no instruction and no register; constants that do not fit the 64-entry
+    pool fall back to OP_CONST."""
     nodes = g.nodes
     # ---- liveness from effect roots ----
     live = [False] * len(nodes)
@@ -136,7 +146,20 @@ def compile_graph(g: Graph) -> np.ndarray:
         for a in n.args:
             if a is not None and not live[a.idx]:
                 stack.append(a)
-    order = [n for n in nodes if live[n.idx]]
+    # ---- operand pool ----
+    pool_of = {}
+    const_pool = []
+    next_pool = g.n_uni
+    for n in nodes:
+        if not live[n.idx]:
+            continue
+        if n.op == "UNI":
+            pool_of[n.idx] = n.imm
+        elif n.op == "CONST" and next_pool < POOL_SIZE:
+            pool_of[n.idx] = next_pool
+            const_pool.append((next_pool, n.imm))
+            next_pool += 1
+    order = [n for n in nodes if live[n.idx] and n.idx not in pool_of]
     last_use = {}
     for pos, n in enumerate(order):
         for a in n.args:
@@ -167,10 +190,14 @@ def compile_graph(g: Graph) -> np.ndarray:
         words.append(OPC[op] | (dst & 0xFF) << 8 | (a & 0xFF) << 16 | (b & 0xFF) << 24)
         words.append(imm & 0xFFFFFFFF)
 
+    def R(x):
+        p = pool_of.get(x.idx)
+        return reg[x.idx] if p is None else POOL_BASE + p
+
     for pos, n in enumerate(order):
-        R = lambda x: reg[x.idx]
         # operands whose last use is here may donate their registers to dst
-        dying = [a for a in dict.fromkeys(x for x in n.args if x is not None) if last_use.get(a.idx) == pos]
+        dying = [a for a in dict.fromkeys(x for x in n.args if x is not None)
+                 if last_use.get(a.idx) == pos and a.idx not in pool_of]
         op = n.op
         if op == "S_CATSTEP":
             prev, key, logit, ctr = n.args
@@ -236,5 +263,5 @@ def compile_graph(g: Graph) -> np.ndarray:
         if n.idx not in last_use:      # value never read (only possible for roots' helpers)
             release(n)
     n_instr = len(words) // 2
-    header = [MAGIC, VERSION, n_instr, max(n_regs, 1), g.n_in, g.n_out, g.n_uni, g.n_tab]
-    return np.array(header + words, dtype=np.uint32)
+    header = [MAGIC, VERSION, n_instr, max(n_regs, 1), g.n_in, g.n_out, next_pool, g.n_tab]
+    return np.array(header + words, dtype=np.uint32), const_pool

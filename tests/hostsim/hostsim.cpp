@@ -52,8 +52,13 @@ extern "C" int gmx_random_bits(const uint32_t* keys, int64_t n, int64_t m, uint3
 struct gmx_program { std::vector<uint32_t> code; uint32_t n_instr, n_regs, n_in, n_out, n_uni, n_tab; };
 
 struct HostCtx {
+  const uint32_t* code; const gmx_run_args* A;
   std::vector<float>* red; int64_t i; int kind;
-  uint32_t uniform(uint32_t x) const { return x; }
+  void fetch(uint32_t pc, uint32_t* w0, uint32_t* w1) const { *w0 = code[2 * pc]; *w1 = code[2 * pc + 1]; }
+  uint32_t pool(uint32_t k) const { return A->uni[k]; }
+  const void* in_ptr(uint32_t s) const { return A->in_d[s]; }
+  void* out_ptr(uint32_t s) const { return A->out_d[s]; }
+  const void* tab_ptr(uint32_t s) const { return A->tab_d[s]; }
   void red_max(float x, bool active) { kind = 1; (*red)[i] = active ? x : -gmx_inf(); }
   void red_lse(float x, bool active) { kind = 2; (*red)[i] = active ? x : -gmx_inf(); }
 };
@@ -96,8 +101,8 @@ extern "C" int gmx_program_run(const gmx_program* p, int64_t n, const gmx_run_ar
     int kind = 0;
     for (int t = 0; t < 256; ++t) {
       int64_t i = blk * 256 + t;
-      HostCtx ctx; ctx.red = &red; ctx.i = t; ctx.kind = 0;
-      gmx_vm_run<gmx_regs_vgpr<32>, HostCtx>(p->code.data(), p->n_instr, i, i < n, *A, ctx);
+      HostCtx ctx; ctx.code = p->code.data(); ctx.A = A; ctx.red = &red; ctx.i = t; ctx.kind = 0;
+      gmx_vm_run<gmx_regs_vgpr<32>, true, HostCtx>(p->n_instr, i, i < n, *A, ctx);
       if (ctx.kind) kind = ctx.kind;
     }
     if (kind && A->red_out_d) {

@@ -71,6 +71,8 @@ class Backend:
         c.gmx_random_bits.argtypes = [c_void_p, c_int64, c_int64, c_void_p, c_void_p]
         c.gmx_program_create.argtypes = [POINTER(c_uint32), c_size_t, POINTER(c_void_p)]
         c.gmx_program_destroy.argtypes = [c_void_p]
+        c.gmx_program_specialize.argtypes = [c_void_p]
+        c.gmx_program_is_specialized.argtypes = [c_void_p]
         c.gmx_program_grid.argtypes = [c_void_p, c_int64]
         c.gmx_program_grid.restype = c_int64
         c.gmx_program_run.argtypes = [c_void_p, c_int64, POINTER(RunArgs), c_void_p]

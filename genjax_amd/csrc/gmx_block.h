@@ -1,0 +1,56 @@
+// gmx_block.h — wave / block reductions shared by the AOT kernels and the
+// hiprtc-specialised site programs (device code only).
+//
+// Fixed butterfly order: every lane ends with the same bits and the result
+// does not depend on scheduling, so block partials are reproducible.
+#pragma once
+#include "gmx_math.h"
+
+#define GMX_BLOCK 256
+#define GMX_WAVE 64
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v = gmx_fmax(v, __shfl_xor(v, m, GMX_WAVE));
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v = v + __shfl_xor(v, m, GMX_WAVE);
+  return v;
+}
+// block of 256 threads = 4 waves; result broadcast to all threads
+__device__ __forceinline__ float block_max(float v, float* lds4) {
+  v = wave_max(v);
+  int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) lds4[w] = v;
+  __syncthreads();
+  float r = gmx_fmax(gmx_fmax(lds4[0], lds4[1]), gmx_fmax(lds4[2], lds4[3]));
+  return r;
+}
+__device__ __forceinline__ float block_sum(float v, float* lds4) {
+  v = wave_sum(v);
+  int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) lds4[w] = v;
+  __syncthreads();
+  float r = (lds4[0] + lds4[1]) + (lds4[2] + lds4[3]);
+  return r;
+}
+
+// OP_REDMAX / OP_REDLSE epilogues
+__device__ __forceinline__ void gmx_red_max(float* red_out, float* lds4, float x, bool active) {
+  float m = block_max(active ? x : -gmx_inf(), lds4);
+  if (threadIdx.x == 0 && red_out) red_out[2 * (size_t)blockIdx.x] = m;
+}
+__device__ __forceinline__ void gmx_red_lse(float* red_out, float* lds4, float x, bool active) {
+  float m = block_max(active ? x : -gmx_inf(), lds4);
+  float e = active ? gmx_expf(x - m) : 0.0f;
+  if (!(m > -gmx_inf())) e = 0.0f;  // empty / all -inf block
+  float s = block_sum(e, lds4);
+  if (threadIdx.x == 0 && red_out) {
+    red_out[2 * (size_t)blockIdx.x] = m;
+    red_out[2 * (size_t)blockIdx.x + 1] = s;
+  }
+}

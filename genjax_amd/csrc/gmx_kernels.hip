@@ -12,11 +12,16 @@
 //
 // Wavefront = 64 everywhere; blocks are 256 threads (4 waves, one per SIMD).
 #include <hip/hip_runtime.h>
+#include <hip/hiprtc.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <new>
+#include <string>
+#include <vector>
 
+#include "gmx_block.h"
 #include "gmx_vm.h"
 
 // ---------------------------------------------------------------------------
@@ -40,42 +45,6 @@ extern "C" const char* gmx_last_error(void) { return g_err; }
 extern "C" void gmx_threefry2x32_host(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1,
                                       uint32_t out[2]) {
   gmx_threefry2x32(k0, k1, c0, c1, &out[0], &out[1]);
-}
-
-#define GMX_BLOCK 256
-#define GMX_WAVE 64
-
-// ---------------------------------------------------------------------------
-// wave / block reductions (fixed butterfly: every lane ends with the same bits)
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) v = gmx_fmax(v, __shfl_xor(v, m, GMX_WAVE));
-  return v;
-}
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) v = v + __shfl_xor(v, m, GMX_WAVE);
-  return v;
-}
-// block of 256 threads = 4 waves; result broadcast to all threads
-__device__ __forceinline__ float block_max(float v, float* lds4) {
-  v = wave_max(v);
-  int w = threadIdx.x >> 6;
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) lds4[w] = v;
-  __syncthreads();
-  float r = gmx_fmax(gmx_fmax(lds4[0], lds4[1]), gmx_fmax(lds4[2], lds4[3]));
-  return r;
-}
-__device__ __forceinline__ float block_sum(float v, float* lds4) {
-  v = wave_sum(v);
-  int w = threadIdx.x >> 6;
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) lds4[w] = v;
-  __syncthreads();
-  float r = (lds4[0] + lds4[1]) + (lds4[2] + lds4[3]);
-  return r;
 }
 
 // ---------------------------------------------------------------------------
@@ -106,42 +75,31 @@ struct DevCtx {
   }
   __device__ __forceinline__ void fetch(uint32_t pc, uint32_t* w0, uint32_t* w1) const {
     if (pc < 64u) {
-      *w0 = __builtin_amdgcn_readlane(prog_a0, pc);
-      *w1 = __builtin_amdgcn_readlane(prog_b0, pc);
+      *w0 = (uint32_t)__builtin_amdgcn_readlane(prog_a0, pc);
+      *w1 = (uint32_t)__builtin_amdgcn_readlane(prog_b0, pc);
     } else if (pc < 128u) {
-      *w0 = __builtin_amdgcn_readlane(prog_a1, pc - 64u);
-      *w1 = __builtin_amdgcn_readlane(prog_b1, pc - 64u);
+      *w0 = (uint32_t)__builtin_amdgcn_readlane(prog_a1, pc - 64u);
+      *w1 = (uint32_t)__builtin_amdgcn_readlane(prog_b1, pc - 64u);
     } else {
       *w0 = __builtin_amdgcn_readfirstlane(code[2u * pc]);
       *w1 = __builtin_amdgcn_readfirstlane(code[2u * pc + 1u]);
     }
   }
   __device__ __forceinline__ uint32_t pool(uint32_t i) const {
-    return __builtin_amdgcn_readlane(pool_v, i);
+    return (uint32_t)__builtin_amdgcn_readlane(pool_v, i);
   }
   __device__ __forceinline__ const void* in_ptr(uint32_t s) const {
-    uint64_t p = ((uint64_t)__builtin_amdgcn_readlane(in_hi, s) << 32) | __builtin_amdgcn_readlane(in_lo, s);
-    return (const void*)p;
+    // readlane returns int: go through uint32_t so the low half is not sign-extended
+    uint32_t lo = (uint32_t)__builtin_amdgcn_readlane(in_lo, s), hi = (uint32_t)__builtin_amdgcn_readlane(in_hi, s);
+    return (const void*)(((uint64_t)hi << 32) | (uint64_t)lo);
   }
   __device__ __forceinline__ void* out_ptr(uint32_t s) const {
-    uint64_t p = ((uint64_t)__builtin_amdgcn_readlane(out_hi, s) << 32) | __builtin_amdgcn_readlane(out_lo, s);
-    return (void*)p;
+    uint32_t lo = (uint32_t)__builtin_amdgcn_readlane(out_lo, s), hi = (uint32_t)__builtin_amdgcn_readlane(out_hi, s);
+    return (void*)(((uint64_t)hi << 32) | (uint64_t)lo);
   }
   __device__ __forceinline__ const void* tab_ptr(uint32_t s) const { return A->tab_d[s]; }
-  __device__ __forceinline__ void red_max(float x, bool active) {
-    float m = block_max(active ? x : -gmx_inf(), lds4);
-    if (threadIdx.x == 0 && red_out) red_out[2 * (size_t)blockIdx.x] = m;
-  }
-  __device__ __forceinline__ void red_lse(float x, bool active) {
-    float m = block_max(active ? x : -gmx_inf(), lds4);
-    float e = active ? gmx_expf(x - m) : 0.0f;
-    if (!(m > -gmx_inf())) e = 0.0f;  // empty / all -inf block
-    float s = block_sum(e, lds4);
-    if (threadIdx.x == 0 && red_out) {
-      red_out[2 * (size_t)blockIdx.x] = m;
-      red_out[2 * (size_t)blockIdx.x + 1] = s;
-    }
-  }
+  __device__ __forceinline__ void red_max(float x, bool active) { gmx_red_max(red_out, lds4, x, active); }
+  __device__ __forceinline__ void red_lse(float x, bool active) { gmx_red_lse(red_out, lds4, x, active); }
 };
 
 template <class Regs, bool FULL>
@@ -151,30 +109,37 @@ k_vm(const uint32_t* __restrict__ code, uint32_t n_instr, int64_t n, const gmx_r
   int64_t i = (int64_t)blockIdx.x * GMX_BLOCK + threadIdx.x;
   DevCtx ctx;
   ctx.init(code, n_instr, &A, lds4);
-  gmx_vm_run<Regs, FULL, DevCtx>(n_instr, i, i < n, A, ctx);
+  gmx_vm_run<Regs, FULL, -1, DevCtx>(n_instr, i, i < n, A, ctx);
 }
 
 struct gmx_program {
   uint32_t* code_d;
-  uint32_t n_instr, n_regs, n_in, n_out, n_uni, n_tab;
+  uint32_t n_instr, n_regs, n_in, n_out, n_uni, n_tab, n_const, n_dyn;
   bool uses_key, uses_red, uses_gather, needs_full;
+  std::vector<uint32_t> code_h;      // instruction words (host copy, for specialisation)
+  std::vector<uint32_t> consts;      // pool entries n_dyn..
+  hipModule_t jit_module = nullptr;  // specialised kernel (gmx_program_specialize)
+  hipFunction_t jit_fn = nullptr;
 };
 
-extern "C" int gmx_program_create(const uint32_t* blob, size_t n_words, gmx_program** out) {
-  if (!blob || !out) return gmx_fail("gmx_program_create: null argument%s");
+static int parse_program(const uint32_t* blob, size_t n_words, gmx_program& P) {
+  if (!blob) return gmx_fail("gmx_program_create: null argument%s");
   if (n_words < GMX_PROG_HEADER_WORDS) return gmx_fail("gmx_program_create: blob too short%s");
   if (blob[0] != GMX_PROG_MAGIC) return gmx_fail("gmx_program_create: bad magic%s");
   if (blob[1] != GMX_PROG_VERSION) return gmx_fail("gmx_program_create: bad version%s");
   uint32_t n_instr = blob[2], n_regs = blob[3];
-  if (n_words != GMX_PROG_HEADER_WORDS + 2ull * n_instr)
-    return gmx_fail("gmx_program_create: length does not match n_instr%s");
+  uint32_t n_const = blob[8], n_dyn = blob[9];
+  if (n_words != GMX_PROG_HEADER_WORDS + 2ull * n_instr + n_const)
+    return gmx_fail("gmx_program_create: length does not match n_instr / n_const%s");
+  if ((uint64_t)n_dyn + n_const != blob[6])
+    return gmx_fail("gmx_program_create: n_uni != n_dyn + n_const%s");
   if (n_regs == 0 || n_regs > 32)
     return gmx_fail("gmx_program_create: n_regs must be in [1,32] (got %s%lld)", "", n_regs);
   if (blob[4] > GMX_MAX_IN || blob[5] > GMX_MAX_OUT || blob[6] > GMX_MAX_UNI || blob[7] > GMX_MAX_TAB)
     return gmx_fail("gmx_program_create: slot count exceeds ABI limits%s");
-  gmx_program P;
-  memset(&P, 0, sizeof(P));
-  P.n_instr = n_instr; P.n_regs = n_regs;
+  P.code_d = nullptr;
+  P.uses_key = P.uses_red = P.uses_gather = P.needs_full = false;
+  P.n_instr = n_instr; P.n_regs = n_regs; P.n_const = n_const; P.n_dyn = n_dyn;
   P.n_in = blob[4]; P.n_out = blob[5]; P.n_uni = blob[6]; P.n_tab = blob[7];
   // validate every instruction: register / slot indices must be in range so
   // the kernel never needs a bounds check
@@ -223,9 +188,19 @@ extern "C" int gmx_program_create(const uint32_t* blob, size_t n_words, gmx_prog
     }
     if (!ok) return gmx_fail("gmx_program_create: invalid instruction%s at pc %lld", "", pc);
   }
+  P.code_h.assign(ins, ins + 2 * (size_t)n_instr);
+  P.consts.assign(ins + 2 * (size_t)n_instr, ins + 2 * (size_t)n_instr + n_const);
+  return 0;
+}
+
+extern "C" int gmx_program_create(const uint32_t* blob, size_t n_words, gmx_program** out) {
+  if (!out) return gmx_fail("gmx_program_create: null argument%s");
+  gmx_program P;
+  if (parse_program(blob, n_words, P)) return 1;
+  const uint32_t n_instr = P.n_instr;
   GMX_HIP(hipMalloc((void**)&P.code_d, sizeof(uint32_t) * 2 * (n_instr ? n_instr : 1)));
   if (n_instr)
-    GMX_HIP(hipMemcpy(P.code_d, ins, sizeof(uint32_t) * 2 * n_instr, hipMemcpyHostToDevice));
+    GMX_HIP(hipMemcpy(P.code_d, P.code_h.data(), sizeof(uint32_t) * 2 * n_instr, hipMemcpyHostToDevice));
   gmx_program* h = new (std::nothrow) gmx_program(P);
   if (!h) return gmx_fail("gmx_program_create: out of host memory%s");
   *out = h;
@@ -235,8 +210,106 @@ extern "C" int gmx_program_create(const uint32_t* blob, size_t n_words, gmx_prog
 extern "C" int gmx_program_destroy(gmx_program* p) {
   if (!p) return 0;
   if (p->code_d) (void)hipFree(p->code_d);
+  if (p->jit_module) (void)hipModuleUnload(p->jit_module);
   delete p;
   return 0;
+}
+
+
+// ---------------------------------------------------------------------------
+// specialisation: the interpreter partially evaluated by hiprtc
+// ---------------------------------------------------------------------------
+#include "gmx_embed.inc"   // generated by __graft_entry__.build(): the device headers as strings
+
+static bool jit_enabled() {
+  const char* e = getenv("GENMI_JIT");
+  return !(e && e[0] == '0');
+}
+
+static std::string jit_source(const gmx_program* p) {
+  std::string s = "#include \"gmx_jit.h\"\n";
+  char buf[64];
+  s += "__device__ static constexpr uint32_t GMX_JIT_PROG[] = {";
+  for (size_t k = 0; k < p->code_h.size(); ++k) { snprintf(buf, sizeof(buf), "0x%08xu,", p->code_h[k]); s += buf; }
+  s += "0u};\n__device__ static constexpr uint32_t GMX_JIT_CONST[] = {";
+  for (size_t k = 0; k < p->consts.size(); ++k) { snprintf(buf, sizeof(buf), "0x%08xu,", p->consts[k]); s += buf; }
+  s += "0u};\n";
+  snprintf(buf, sizeof(buf), "GMX_JIT_KERNEL(%u, %u, %s, %u)\n", p->n_instr, p->n_regs <= 16 ? 16u : 32u,
+           p->needs_full ? "true" : "false", p->n_dyn);
+  s += buf;
+  return s;
+}
+
+extern "C" int gmx_program_is_specialized(const gmx_program* p) { return p && p->jit_fn ? 1 : 0; }
+
+extern "C" int gmx_program_specialize(gmx_program* p) {
+  if (!p) return gmx_fail("gmx_program_specialize: null program%s");
+  if (p->jit_fn) return 0;
+  if (!jit_enabled()) return gmx_fail("gmx_program_specialize: disabled by GENMI_JIT=0%s");
+  if (p->n_instr == 0 || p->n_instr > 512) return gmx_fail("gmx_program_specialize: program size out of range%s");
+  std::string src = jit_source(p);
+  hiprtcProgram prog;
+  const char* hdr_src[GMX_EMBED_COUNT];
+  const char* hdr_name[GMX_EMBED_COUNT];
+  for (int k = 0; k < GMX_EMBED_COUNT; ++k) { hdr_src[k] = gmx_embed_src[k]; hdr_name[k] = gmx_embed_name[k]; }
+  hiprtcResult rc = hiprtcCreateProgram(&prog, src.c_str(), "gmx_jit_program.hip", GMX_EMBED_COUNT, hdr_src, hdr_name);
+  if (rc != HIPRTC_SUCCESS) return gmx_fail("hiprtcCreateProgram: %s", hiprtcGetErrorString(rc));
+  const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"};
+  rc = hiprtcCompileProgram(prog, 4, opts);
+  if (rc != HIPRTC_SUCCESS) {
+    size_t ls = 0;
+    hiprtcGetProgramLogSize(prog, &ls);
+    std::string log(ls + 1, '\0');
+    if (ls) hiprtcGetProgramLog(prog, &log[0]);
+    hiprtcDestroyProgram(&prog);
+    if (log.size() > 400) log.resize(400);
+    return gmx_fail("hiprtcCompileProgram failed: %s", log.c_str());
+  }
+  size_t cs = 0;
+  hiprtcGetCodeSize(prog, &cs);
+  std::vector<char> code(cs);
+  hiprtcGetCode(prog, code.data());
+  hiprtcDestroyProgram(&prog);
+  hipModule_t mod;
+  GMX_HIP(hipModuleLoadData(&mod, code.data()));
+  hipFunction_t fn;
+  hipError_t e = hipModuleGetFunction(&fn, mod, "gmx_jit_kernel");
+  if (e != hipSuccess) { (void)hipModuleUnload(mod); return gmx_fail("hipModuleGetFunction: %s", hipGetErrorString(e)); }
+  p->jit_module = mod;
+  p->jit_fn = fn;
+  return 0;
+}
+
+// offline entry point used by tests / tools on machines without a GPU: compile
+// the specialised kernel and return its code-object size (0 on failure).
+extern "C" size_t gmx_specialize_dryrun(const uint32_t* blob, size_t n_words, char* log_out, size_t log_cap,
+                                        char* code_out, size_t code_cap) {
+  gmx_program P;
+  if (parse_program(blob, n_words, P)) { if (log_out && log_cap) snprintf(log_out, log_cap, "%s", g_err); return 0; }
+  const gmx_program* p = &P;
+  std::string src = jit_source(p);
+  hiprtcProgram prog;
+  const char* hdr_src[GMX_EMBED_COUNT];
+  const char* hdr_name[GMX_EMBED_COUNT];
+  for (int k = 0; k < GMX_EMBED_COUNT; ++k) { hdr_src[k] = gmx_embed_src[k]; hdr_name[k] = gmx_embed_name[k]; }
+  if (hiprtcCreateProgram(&prog, src.c_str(), "gmx_jit_program.hip", GMX_EMBED_COUNT, hdr_src, hdr_name) != HIPRTC_SUCCESS)
+    return 0;
+  const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"};
+  hiprtcResult rc = hiprtcCompileProgram(prog, 4, opts);
+  size_t ls = 0;
+  hiprtcGetProgramLogSize(prog, &ls);
+  if (log_out && log_cap) {
+    std::string log(ls + 1, '\0');
+    if (ls) hiprtcGetProgramLog(prog, &log[0]);
+    snprintf(log_out, log_cap, "%s", log.c_str());
+  }
+  size_t cs = 0;
+  if (rc == HIPRTC_SUCCESS) {
+    hiprtcGetCodeSize(prog, &cs);
+    if (code_out && code_cap >= cs) hiprtcGetCode(prog, code_out);
+  }
+  hiprtcDestroyProgram(&prog);
+  return cs;
 }
 
 extern "C" int64_t gmx_program_grid(const gmx_program* p, int64_t n) {
@@ -272,6 +345,22 @@ extern "C" int gmx_program_run(const gmx_program* p, int64_t n, const gmx_run_ar
   }
   dim3 grid((unsigned)((n + GMX_BLOCK - 1) / GMX_BLOCK)), block(GMX_BLOCK);
   hipStream_t st = (hipStream_t)stream;
+  // the program's constants live in the operand pool after the launch uniforms
+  gmx_run_args patched;
+  if (p->n_const) {
+    patched = *args;
+    for (uint32_t k = 0; k < p->n_const; ++k) patched.uni[p->n_dyn + k] = p->consts[k];
+    args = &patched;
+  }
+  if (p->jit_fn) {
+    struct { int64_t n; gmx_run_args A; } ka;
+    ka.n = n; ka.A = *args;
+    size_t ka_size = sizeof(ka);
+    void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &ka, HIP_LAUNCH_PARAM_BUFFER_SIZE, &ka_size,
+                      HIP_LAUNCH_PARAM_END};
+    GMX_HIP(hipModuleLaunchKernel(p->jit_fn, grid.x, 1, 1, GMX_BLOCK, 1, 1, 0, st, nullptr, config));
+    return 0;
+  }
   if (p->n_regs <= 16) {
     if (p->needs_full)
       hipLaunchKernelGGL((k_vm<gmx_regs_vgpr<16>, true>), grid, block, 0, st, p->code_d, p->n_instr, n, *args);
@@ -487,13 +576,15 @@ extern "C" int gmx_logsumexp(const float* lw_d, int64_t rows, int64_t cols, floa
 // program's OP_REDMAX left behind (no extra launch), and the workspace is
 // returned zeroed by the last tile to finish (no memset launch).
 // ---------------------------------------------------------------------------
-#define CDF_SUB 4                      /* sub-tiles per tile              */
-#define CDF_VEC 4                      /* consecutive items per thread     */
-#define CDF_TILE (GMX_BLOCK * CDF_SUB * CDF_VEC)
+#define CDF_THREADS 1024               /* 16 waves: 4 per SIMD, enough to hide the load + look-back latency */
+#define CDF_WAVES (CDF_THREADS / GMX_WAVE)
+#define CDF_VEC 4                      /* consecutive items per thread (one float4) */
+#define CDF_TILE (CDF_THREADS * CDF_VEC)
 #define CDF_ST_AGG 1ull
 #define CDF_ST_INC 2ull
 #define CDF_SPIN_LIMIT (1u << 22)
 #define CDF_LOOK 4                     /* descriptors per lane per look-back round (window 256) */
+#define CDF_RESIDENT_TILES 512         /* grids up to this size are co-resident: blockIdx is the tile id */
 
 // workspace: [0] u32 ticket, [1] u32 error flag, [2] u32 done count, [3] pad,
 // then one u64 descriptor per tile: value << 2 | status.  value < 2^62 by the
@@ -543,76 +634,71 @@ k_reduce_max(const float* __restrict__ partials, int64_t n_part, float* __restri
 
 // max_mode: 0 = read *max_d; 1 = reduce column 0 of partials[n_part][2] (every tile
 // does it: a few KB from L2) and tile 0 stores the result to *max_d.
-__global__ void __launch_bounds__(GMX_BLOCK)
+__global__ void __launch_bounds__(CDF_THREADS)
 k_weight_cdf(const float* __restrict__ lw, int64_t n, float scale, int max_mode,
              const float* __restrict__ partials, int64_t n_part, float* __restrict__ max_d,
              uint64_t* __restrict__ cdf, uint64_t* __restrict__ total_out, cdf_ws* ws) {
-  __shared__ uint64_t s_part[CDF_SUB][4];
+  __shared__ uint64_t s_part[CDF_WAVES];
   __shared__ uint64_t s_prefix;
   __shared__ uint32_t s_tile;
-  __shared__ float lds4[4];
+  __shared__ uint32_t s_last;
+  __shared__ float s_max[CDF_WAVES];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  // dynamic tile id: a tile only ever waits on tiles whose blocks already run
-  if (threadIdx.x == 0) s_tile = atomicAdd(&ws->ticket, 1u);
-  __syncthreads();
-  const uint32_t tile = s_tile;
   const int64_t n_tiles = (n + CDF_TILE - 1) / CDF_TILE;
+  uint32_t tile = blockIdx.x;
+  if (n_tiles > CDF_RESIDENT_TILES) {
+    // dynamic tile id: a tile only ever waits on tiles whose blocks already run
+    if (threadIdx.x == 0) s_tile = atomicAdd(&ws->ticket, 1u);
+    __syncthreads();
+    tile = s_tile;
+  }
   if ((int64_t)tile >= n_tiles) return;
-  const int64_t tile_base = (int64_t)tile * CDF_TILE;
-  // issue the tile's loads first, reduce the max while they are in flight
-  float x[CDF_SUB][CDF_VEC];
+  const int64_t base = (int64_t)tile * CDF_TILE + (int64_t)threadIdx.x * CDF_VEC;
+  // issue the tile's load first, reduce the max while it is in flight
+  float x[CDF_VEC];
+  if (base + CDF_VEC <= n) {
+    float4 v = *reinterpret_cast<const float4*>(lw + base);
+    x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
+  } else {
 #pragma unroll
-  for (int k = 0; k < CDF_SUB; ++k) {
-    const int64_t base = tile_base + (int64_t)k * (GMX_BLOCK * CDF_VEC) + (int64_t)threadIdx.x * CDF_VEC;
-    if (base + CDF_VEC <= n) {
-      float4 v = *reinterpret_cast<const float4*>(lw + base);
-      x[k][0] = v.x; x[k][1] = v.y; x[k][2] = v.z; x[k][3] = v.w;
-    } else {
-#pragma unroll
-      for (int c = 0; c < CDF_VEC; ++c) x[k][c] = (base + c < n) ? lw[base + c] : -gmx_inf();
-    }
+    for (int c = 0; c < CDF_VEC; ++c) x[c] = (base + c < n) ? lw[base + c] : -gmx_inf();
   }
   float M;
   if (max_mode == 1) {
     float m = -gmx_inf();
-    for (int64_t j = threadIdx.x; j < n_part; j += GMX_BLOCK) m = gmx_fmax(m, partials[2 * j]);
-    M = block_max(m, lds4);
+    for (int64_t j = threadIdx.x; j < n_part; j += CDF_THREADS) m = gmx_fmax(m, partials[2 * j]);
+    m = wave_max(m);
+    if (lane == 0) s_max[wave] = m;
+    __syncthreads();
+    m = s_max[0];
+#pragma unroll
+    for (int w = 1; w < CDF_WAVES; ++w) m = gmx_fmax(m, s_max[w]);
+    M = m;
     if (tile == 0 && threadIdx.x == 0) *max_d = M;
   } else {
     M = *max_d;
   }
-  uint64_t q[CDF_SUB][CDF_VEC];
-  uint64_t inc[CDF_SUB], run[CDF_SUB];
+  uint64_t q[CDF_VEC];
+  uint64_t run = 0;
 #pragma unroll
-  for (int k = 0; k < CDF_SUB; ++k) {
-    const int64_t base = tile_base + (int64_t)k * (GMX_BLOCK * CDF_VEC) + (int64_t)threadIdx.x * CDF_VEC;
-    uint64_t r = 0;
-#pragma unroll
-    for (int c = 0; c < CDF_VEC; ++c) {
-      uint64_t w = (base + c < n) ? weight_fixed(x[k][c], M, scale) : 0ull;
-      r += w;
-      q[k][c] = r;                     // thread-local inclusive
-    }
-    run[k] = r;
-    uint64_t v = r;                    // wave inclusive scan of thread totals
-#pragma unroll
-    for (int d = 1; d < GMX_WAVE; d <<= 1) {
-      uint64_t t = shfl_up_u64(v, d);
-      if (lane >= d) v += t;
-    }
-    inc[k] = v;
-    if (lane == 63) s_part[k][wave] = v;
+  for (int c = 0; c < CDF_VEC; ++c) {
+    uint64_t w = (base + c < n) ? weight_fixed(x[c], M, scale) : 0ull;
+    run += w;
+    q[c] = run;                        // thread-local inclusive
   }
+  uint64_t inc = run;                  // wave inclusive scan of thread totals
+#pragma unroll
+  for (int d = 1; d < GMX_WAVE; d <<= 1) {
+    uint64_t t = shfl_up_u64(inc, d);
+    if (lane >= d) inc += t;
+  }
+  if (lane == 63) s_part[wave] = inc;
   __syncthreads();
-  uint64_t tile_agg = 0;
-  uint64_t part_off[CDF_SUB];
+  uint64_t tile_agg = 0, wave_off = 0;
 #pragma unroll
-  for (int k = 0; k < CDF_SUB; ++k) {
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      if (w == wave) part_off[k] = tile_agg;
-      tile_agg += s_part[k][w];
-    }
+  for (int w = 0; w < CDF_WAVES; ++w) {
+    if (w == wave) wave_off = tile_agg;
+    tile_agg += s_part[w];
   }
   // ---- chained scan across tiles (wave 0) ----
   if (wave == 0) {
@@ -669,28 +755,23 @@ k_weight_cdf(const float* __restrict__ lw, int64_t n, float scale, int max_mode,
   }
   __syncthreads();
   const uint64_t tile_prefix = s_prefix;
+  const uint64_t off = tile_prefix + wave_off + (inc - run);
+  if (base + CDF_VEC <= n) {
+    ulonglong2 a, b;
+    a.x = off + q[0]; a.y = off + q[1]; b.x = off + q[2]; b.y = off + q[3];
+    reinterpret_cast<ulonglong2*>(cdf + base)[0] = a;
+    reinterpret_cast<ulonglong2*>(cdf + base)[1] = b;
+  } else {
 #pragma unroll
-  for (int k = 0; k < CDF_SUB; ++k) {
-    const int64_t base = tile_base + (int64_t)k * (GMX_BLOCK * CDF_VEC) + (int64_t)threadIdx.x * CDF_VEC;
-    const uint64_t off = tile_prefix + part_off[k] + (inc[k] - run[k]);
-    if (base + CDF_VEC <= n) {
-      ulonglong2 a, b;
-      a.x = off + q[k][0]; a.y = off + q[k][1]; b.x = off + q[k][2]; b.y = off + q[k][3];
-      reinterpret_cast<ulonglong2*>(cdf + base)[0] = a;
-      reinterpret_cast<ulonglong2*>(cdf + base)[1] = b;
-    } else {
-#pragma unroll
-      for (int c = 0; c < CDF_VEC; ++c)
-        if (base + c < n) cdf[base + c] = off + q[k][c];
-    }
+    for (int c = 0; c < CDF_VEC; ++c)
+      if (base + c < n) cdf[base + c] = off + q[c];
   }
   if ((int64_t)tile == n_tiles - 1 && threadIdx.x == 0) *total_out = tile_prefix + tile_agg;
   // ---- leave the workspace zeroed: the last tile to finish cleans up ----
-  __shared__ uint32_t s_last;
   if (threadIdx.x == 0) s_last = (atomicAdd(&ws->done, 1u) == (uint32_t)(n_tiles - 1)) ? 1u : 0u;
   __syncthreads();
   if (s_last) {
-    for (int64_t t = threadIdx.x; t < n_tiles; t += GMX_BLOCK) ws->desc[t] = 0ull;
+    for (int64_t t = threadIdx.x; t < n_tiles; t += CDF_THREADS) ws->desc[t] = 0ull;
     if (threadIdx.x == 0) { ws->ticket = 0u; ws->done = 0u; }
   }
 }
@@ -721,7 +802,7 @@ extern "C" int gmx_weight_cdf(const float* lw_d, int64_t n, int shift,
   }
   int64_t tiles = (n + CDF_TILE - 1) / CDF_TILE;
   float scale = gmx_pow2i(shift);
-  hipLaunchKernelGGL(k_weight_cdf, dim3((unsigned)tiles), dim3(GMX_BLOCK), 0, st, lw_d, n, scale,
+  hipLaunchKernelGGL(k_weight_cdf, dim3((unsigned)tiles), dim3(CDF_THREADS), 0, st, lw_d, n, scale,
                      max_mode, max_partials_d, n_partials, max_d, cdf_d, total_d, (cdf_ws*)workspace_d);
   GMX_HIP(hipGetLastError());
   return 0;
@@ -755,17 +836,32 @@ __device__ __forceinline__ u128 slot_threshold(int kind, gmx_key key, uint64_t u
   return mul64(((uint64_t)j << 23) + u, total);
 }
 
-// f(c) = number of slots j in [0, n_out) with P_j < c * D
+// f(c) = number of slots j in [0, n_out) with P_j < c * D, i.e. with
+//   j + u_j / 2^23 < v,  v = c * n_out / total.
+// Fast path: v in f64 (relative error <= 2^-50) decides everything unless it is
+// within `eps` of the boundary; only then the exact 128-bit predicate is used,
+// so the answer is ALWAYS the one the integer definition gives.
 __device__ __forceinline__ int64_t slots_below(int kind, gmx_key key, uint64_t u0, uint64_t c, uint64_t D,
-                                               uint64_t total, int64_t n_out) {
+                                               uint64_t total, double n_over_total, double eps, int64_t n_out) {
   if (c == 0) return 0;
+  if (c >= total) return n_out;
+  const double v = (double)c * n_over_total;
+  int64_t j0 = (int64_t)v;                       // floor (v >= 0)
+  if (j0 >= n_out) j0 = n_out - 1;
+  const double frac = v - (double)j0;
+  bool exact = (frac < eps) || (frac > 1.0 - eps);
+  int64_t j = j0;
+  if (!exact) {
+    // slots j < j0 are below; slot j0 is below iff u_{j0} / 2^23 < frac
+    uint64_t u = (kind == GMX_RESAMPLE_SYSTEMATIC) ? u0 : (uint64_t)(gmx_bits32(key, (uint64_t)j0) >> 9);
+    double du = (double)u * (1.0 / 8388608.0);
+    double diff = frac - du;
+    if (diff > eps) return j0 + 1;
+    if (diff < -eps) return j0;
+    exact = true;
+  }
+  // rare: within eps of a boundary -> exact integer predicate  P_j < X
   u128 X = mul64(c, D);
-  // estimate: j ~ c / total * n_out - u / 2^23   (f64; corrected below, so only a seed)
-  double est = (double)c / (double)total * (double)n_out;
-  int64_t j = (int64_t)est;
-  if (j > n_out) j = n_out;
-  if (j < 0) j = 0;
-  // exact fix-up with the integer predicate  P_j < X
   while (j > 0 && !gt128(X, slot_threshold(kind, key, u0, j - 1, total))) --j;
   while (j < n_out && gt128(X, slot_threshold(kind, key, u0, j, total))) ++j;
   return j;
@@ -776,7 +872,7 @@ k_offspring(int kind, uint32_t k0, uint32_t k1, const uint64_t* __restrict__ cdf
             uint64_t cdf_offset, const uint64_t* __restrict__ total_d, int64_t n_out_total,
             int64_t slot_offset, int64_t n_slots, int32_t* __restrict__ anc) {
   int64_t i = (int64_t)blockIdx.x * GMX_BLOCK + threadIdx.x;
-  if (i >= n_in) return;
+  const bool in_range = i < n_in;
   const uint64_t total = *total_d;
   gmx_key key; key.k0 = k0; key.k1 = k1;
   const uint64_t u0 = gmx_bits32(key, 0) >> 9;
@@ -786,11 +882,22 @@ k_offspring(int kind, uint32_t k0, uint32_t k1, const uint64_t* __restrict__ cdf
       for (int64_t s = 0; s < n_slots; ++s) anc[s] = (int32_t)(n_in - 1);
     return;
   }
-  const uint64_t c_hi = cdf[i] + cdf_offset;
-  const uint64_t c_lo = (i == 0) ? cdf_offset : cdf[i - 1] + cdf_offset;
-  if (c_hi == c_lo) return;               // zero weight: no offspring
-  int64_t s = slots_below(kind, key, u0, c_lo, D, total, n_out_total);
-  int64_t e = slots_below(kind, key, u0, c_hi, D, total, n_out_total);
+  const double n_over_total = (double)n_out_total / (double)total;
+  const double eps = (double)n_out_total * 0x1p-44 + 0x1p-40;
+  const uint64_t c_hi = in_range ? cdf[i] + cdf_offset : total;
+  int64_t e = slots_below(kind, key, u0, c_hi, D, total, n_over_total, eps, n_out_total);
+  // the lower bound of source i is the upper bound of source i-1: take it from
+  // the neighbouring lane; lane 0 of each wave evaluates it itself
+  const int lane = threadIdx.x & 63;
+  uint32_t e_lo = (uint32_t)e, e_hi32 = (uint32_t)((uint64_t)e >> 32);
+  e_lo = __shfl_up(e_lo, 1, GMX_WAVE); e_hi32 = __shfl_up(e_hi32, 1, GMX_WAVE);
+  int64_t s = (int64_t)(((uint64_t)e_hi32 << 32) | e_lo);
+  if (lane == 0) {
+    const uint64_t c_lo = (i == 0 || !in_range) ? cdf_offset : cdf[i - 1] + cdf_offset;
+    s = (i == 0) ? slots_below(kind, key, u0, cdf_offset, D, total, n_over_total, eps, n_out_total)
+                 : slots_below(kind, key, u0, c_lo, D, total, n_over_total, eps, n_out_total);
+  }
+  if (!in_range) return;
   // clip to the slot range this call owns
   if (s < slot_offset) s = slot_offset;
   if (e > slot_offset + n_slots) e = slot_offset + n_slots;

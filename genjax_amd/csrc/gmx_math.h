@@ -15,7 +15,11 @@
 //   expf, logf, log1pf  <= 2 ulp;  lgammaf <= 4e-6 relative (x >= 1e-3);
 //   erfinvf = the XLA/Giles f32 polynomial (reference: SURVEY.md App. A.2).
 #pragma once
+#if !defined(__HIPCC_RTC__)
 #include <stdint.h>
+#else
+#include "genmi.h"
+#endif
 
 #if defined(__HIPCC__)
 #define GMX_HD __host__ __device__ __forceinline__

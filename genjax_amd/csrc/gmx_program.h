@@ -2,9 +2,12 @@
 //
 // A program is a flat array of uint32 words:
 //   [0] GMX_PROG_MAGIC   [1] GMX_PROG_VERSION   [2] n_instr   [3] n_regs
-//   [4] n_in  [5] n_out  [6] n_uni  [7] n_tab
+//   [4] n_in  [5] n_out  [6] n_uni (pool entries used)  [7] n_tab
+//   [8] n_const  [9] n_dyn (launch uniforms; n_uni = n_dyn + n_const)
 //   then n_instr instructions of two words each:
 //     w0 = op | dst << 8 | a << 16 | b << 24          w1 = imm32
+//   then n_const constant words: pool entries n_dyn .. n_dyn + n_const - 1
+//   (gmx_program_run writes them into gmx_run_args.uni itself).
 //   For three-operand ops c = imm & 0xff and e = imm >> 8 (24 bits).
 //   A SOURCE operand code x names register x when x < GMX_POOL_BASE and pool
 //   entry (x - GMX_POOL_BASE) otherwise.  The pool is gmx_run_args.uni: launch
@@ -23,11 +26,15 @@
 // oracle/ (which does NOT execute programs: it restates the reference's
 // handlers directly on numpy arrays).
 #pragma once
+#if !defined(__HIPCC_RTC__)
 #include <stdint.h>
+#else
+#include "genmi.h"
+#endif
 
 #define GMX_PROG_MAGIC 0x50584D47u /* 'GMXP' */
-#define GMX_PROG_VERSION 1u
-#define GMX_PROG_HEADER_WORDS 8u
+#define GMX_PROG_VERSION 2u
+#define GMX_PROG_HEADER_WORDS 10u
 #define GMX_MAX_REGS 32
 #define GMX_POOL_BASE 64u /* source operand codes >= this name pool entries */
 

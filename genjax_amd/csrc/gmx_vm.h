@@ -22,7 +22,7 @@
 // functions can be diffed against the oracle without a GPU.  (b) is a test
 // harness, never a fallback: the product library only contains (a).
 #pragma once
-#include "../../include/genmi.h"
+#include "genmi.h"
 #include "gmx_dist.h"
 #include "gmx_program.h"
 
@@ -50,16 +50,14 @@ GMX_HD uint32_t gmx_asu(float f) { return gmx_f2u(f); }
 //   uint32_t pool(i)                 constant / uniform pool entry
 //   const void* in_ptr(slot); void* out_ptr(slot); const void* tab_ptr(slot)
 //   void red_max(float x, bool active); void red_lse(float x, bool active)
+// One instruction.  All of w0 / w1 are launch-uniform.
 template <class Regs, bool FULL, class Ctx>
-GMX_HD void gmx_vm_run(uint32_t n_instr, int64_t i, bool active, const gmx_run_args& A, Ctx& ctx) {
-  Regs R;
-  R.init();
+GMX_HD void gmx_vm_step(Regs& R, const uint32_t w0, const uint32_t w1, int64_t i, bool active,
+                        const gmx_run_args& A, Ctx& ctx) {
 #define SRC(x) ((x) < GMX_POOL_BASE ? R.get(x) : ctx.pool((x) - GMX_POOL_BASE))
 #define FSRC(x) gmx_asf(SRC(x))
 #define KEY(x) gmx_key k; k.k0 = R.get(x); k.k1 = R.get((x) + 1u)
-  for (uint32_t pc = 0; pc < n_instr; ++pc) {
-    uint32_t w0, w1;
-    ctx.fetch(pc, &w0, &w1);
+  {
     const uint32_t op = w0 & 0xffu, dst = (w0 >> 8) & 0xffu, a = (w0 >> 16) & 0xffu, b = w0 >> 24;
     const uint32_t c = w1 & 0xffu, e = w1 >> 8;
     uint32_t r0 = 0u, r1 = 0u;
@@ -197,6 +195,36 @@ GMX_HD void gmx_vm_run(uint32_t n_instr, int64_t i, bool active, const gmx_run_a
 #undef SRC
 #undef FSRC
 #undef KEY
+}
+
+// Compile-time unrolling for specialised programs: instruction PC of NI.  With
+// a Ctx whose fetch() reads a constexpr array, w0 / w1 are constants after
+// inlining and the switch, operand selection and register indices all fold.
+template <class Regs, bool FULL, int NI, int PC, class Ctx>
+GMX_HD void gmx_vm_unroll(Regs& R, int64_t i, bool active, const gmx_run_args& A, Ctx& ctx) {
+  if constexpr (PC < NI) {
+    uint32_t w0, w1;
+    ctx.fetch((uint32_t)PC, &w0, &w1);
+    gmx_vm_step<Regs, FULL, Ctx>(R, w0, w1, i, active, A, ctx);
+    gmx_vm_unroll<Regs, FULL, NI, PC + 1, Ctx>(R, i, active, A, ctx);
+  }
+}
+
+// NI < 0: interpret n_instr_rt instructions fetched through ctx at run time.
+// NI >= 0: specialised program of exactly NI instructions (gmx_program_specialize).
+template <class Regs, bool FULL, int NI, class Ctx>
+GMX_HD void gmx_vm_run(uint32_t n_instr_rt, int64_t i, bool active, const gmx_run_args& A, Ctx& ctx) {
+  Regs R;
+  R.init();
+  if constexpr (NI >= 0) {
+    gmx_vm_unroll<Regs, FULL, NI, 0, Ctx>(R, i, active, A, ctx);
+  } else {
+    for (uint32_t pc = 0; pc < n_instr_rt; ++pc) {
+      uint32_t w0, w1;
+      ctx.fetch(pc, &w0, &w1);
+      gmx_vm_step<Regs, FULL, Ctx>(R, w0, w1, i, active, A, ctx);
+    }
+  }
 }
 
 // ops that need the FULL interpreter build

@@ -252,6 +252,10 @@ def _bits(v, dt) -> int:
     return int(v) & 0xFFFFFFFF
 
 
+# launches at least this large are worth the ~2 s one-off hiprtc compile
+JIT_MIN_PARTICLES = 1 << 18
+
+
 class Compiled:
     """A created program + its binding plan."""
 
@@ -281,11 +285,28 @@ class Compiled:
                  "gmx_program_create")
         self.handle = handle
         self._be = be
+        self._jit_tried = False
+
+    def specialize(self) -> bool:
+        """Compile the kernel specialised to this program (gmx_program_specialize:
+        the interpreter partially evaluated by hiprtc; bit-identical results).
+        Returns False — and keeps the interpreter — if hiprtc is unavailable or
+        GENMI_JIT=0."""
+        be = self._be
+        if be.c.gmx_program_is_specialized(self.handle):
+            return True
+        if self._jit_tried:
+            return False
+        self._jit_tried = True
+        return be.c.gmx_program_specialize(self.handle) == 0
 
     def run(self, leaves, batch: tuple, key: Key | None, red_out=None, index_offset=0, out_buffers=None):
         """Bind and launch.  Returns the list of output tensors (shape batch+event)."""
         be = self._be
         n = int(np.prod(batch, dtype=np.int64))
+        if n >= JIT_MIN_PARTICLES and not self._jit_tried and be.uses_streams \
+                and not torch.cuda.is_current_stream_capturing():
+            self.specialize()
         A = _lib.RunArgs()
         keep = []
         anc = None
@@ -326,8 +347,6 @@ class Compiled:
             if e is not None:
                 v = np.asarray(v).reshape(-1)[e]
             A.uni[ui] = _bits(v, dt)
-        for pi, bits in self.const_pool:
-            A.uni[pi] = bits
         for s, t in enumerate(self.tables):
             A.tab_d[s] = t.data_ptr()
         outs = []

@@ -356,11 +356,12 @@ class BootstrapSweep:
     """
 
     def __init__(self, init, step, n_particles: int, T: int, obs_addr="y", resample="systematic",
-                 step_extra=None):
+                 step_extra=None, specialize=True):
         self.init, self.step, self.n, self.T = init, step, int(n_particles), int(T)
         self.obs_addr = obs_addr
         self.kind = _KINDS[resample] if isinstance(resample, str) else int(resample)
         self.step_extra = step_extra or (lambda t: ())
+        self.specialize = specialize
         self.graph = None
 
     def prepare(self, key: Key, ys: torch.Tensor):
@@ -383,6 +384,9 @@ class BootstrapSweep:
         self.p_init = MinimalGenerate(self.init, (), obs0, (n,))
         g = Gathered(self.x[0], self.anc)
         self.p_step = MinimalGenerate(self.step, (g,) + tuple(self.step_extra(1)), obs0, (n,))
+        if self.specialize:
+            self.p_init.comp.specialize()
+            self.p_step.comp.specialize()
         grid = be.c.gmx_program_grid(self.p_step.comp.handle, n)
         self.partials = torch.zeros((grid, 2), dtype=torch.float32, device=dev)
         # per-step keys on the host

@@ -17,7 +17,7 @@ from dataclasses import dataclass, field
 import numpy as np
 
 MAGIC = 0x50584D47
-VERSION = 1
+VERSION = 2
 MAX_REGS = 32
 
 F_GATHER, F_U8, F_BCAST = 1, 2, 4
@@ -263,5 +263,7 @@ def compile_graph(g: Graph):
         if n.idx not in last_use:      # value never read (only possible for roots' helpers)
             release(n)
     n_instr = len(words) // 2
-    header = [MAGIC, VERSION, n_instr, max(n_regs, 1), g.n_in, g.n_out, next_pool, g.n_tab]
-    return np.array(header + words, dtype=np.uint32), const_pool
+    consts = [bits & 0xFFFFFFFF for _, bits in const_pool]       # pool entries n_uni .. in order
+    header = [MAGIC, VERSION, n_instr, max(n_regs, 1), g.n_in, g.n_out, next_pool, g.n_tab,
+              len(consts), g.n_uni]
+    return np.array(header + words + consts, dtype=np.uint32), const_pool

@@ -21,8 +21,19 @@
 #ifndef GENMI_H
 #define GENMI_H
 
+#if defined(__HIPCC_RTC__)   /* compiled by hiprtc (site-program specialisation): no libc headers */
+typedef __UINT8_TYPE__ uint8_t;
+typedef __UINT16_TYPE__ uint16_t;
+typedef __UINT32_TYPE__ uint32_t;
+typedef __UINT64_TYPE__ uint64_t;
+typedef __INT32_TYPE__ int32_t;
+typedef __INT64_TYPE__ int64_t;
+typedef __SIZE_TYPE__ size_t;
+typedef __UINTPTR_TYPE__ uintptr_t;
+#else
 #include <stddef.h>
 #include <stdint.h>
+#endif
 
 #ifdef __cplusplus
 extern "C" {
@@ -112,6 +123,13 @@ typedef struct gmx_run_args {
 
 int gmx_program_create(const uint32_t* blob_h, size_t n_words, gmx_program** out);
 int gmx_program_destroy(gmx_program* p);
+/* Optional: compile a kernel specialised to this program (hiprtc, gfx950): the
+ * interpreter source partially evaluated against the constant instruction
+ * stream, so results are bit-identical to the interpreter's.  Blocking; call
+ * it outside stream capture.  Returns non-zero (and leaves the interpreter in
+ * place) when hiprtc is unavailable or GENMI_JIT=0. */
+int gmx_program_specialize(gmx_program* p);
+int gmx_program_is_specialized(const gmx_program* p);
 /* number of thread blocks gmx_program_run will launch for n particles
  * (= rows of red_out_d the caller must provide). */
 int64_t gmx_program_grid(const gmx_program* p, int64_t n);

@@ -16,7 +16,7 @@
 
 #include <vector>
 
-#include "../../genjax_amd/csrc/gmx_vm.h"
+#include "../../genjax_amd/csrc/gmx_vm.h"  // build with -I include
 
 static thread_local char g_err[512] = "";
 static int fail(const char* m) { snprintf(g_err, sizeof(g_err), "%s", m); return 1; }
@@ -49,7 +49,7 @@ extern "C" int gmx_random_bits(const uint32_t* keys, int64_t n, int64_t m, uint3
 }
 
 // ---- programs ----
-struct gmx_program { std::vector<uint32_t> code; uint32_t n_instr, n_regs, n_in, n_out, n_uni, n_tab; };
+struct gmx_program { std::vector<uint32_t> code, consts; uint32_t n_instr, n_regs, n_in, n_out, n_uni, n_tab, n_const, n_dyn; };
 
 struct HostCtx {
   const uint32_t* code; const gmx_run_args* A;
@@ -66,11 +66,13 @@ struct HostCtx {
 extern "C" int gmx_program_create(const uint32_t* blob, size_t n_words, gmx_program** out) {
   if (!blob || !out || n_words < GMX_PROG_HEADER_WORDS) return fail("program_create: bad blob");
   if (blob[0] != GMX_PROG_MAGIC || blob[1] != GMX_PROG_VERSION) return fail("program_create: bad magic/version");
-  if (n_words != GMX_PROG_HEADER_WORDS + 2ull * blob[2]) return fail("program_create: bad length");
+  if (n_words != GMX_PROG_HEADER_WORDS + 2ull * blob[2] + blob[8]) return fail("program_create: bad length");
   if (blob[3] == 0 || blob[3] > 32) return fail("program_create: n_regs out of range");
   gmx_program* p = new gmx_program;
   p->n_instr = blob[2]; p->n_regs = blob[3]; p->n_in = blob[4]; p->n_out = blob[5]; p->n_uni = blob[6]; p->n_tab = blob[7];
-  p->code.assign(blob + GMX_PROG_HEADER_WORDS, blob + n_words);
+  p->n_const = blob[8]; p->n_dyn = blob[9];
+  p->code.assign(blob + GMX_PROG_HEADER_WORDS, blob + GMX_PROG_HEADER_WORDS + 2ull * blob[2]);
+  p->consts.assign(blob + GMX_PROG_HEADER_WORDS + 2ull * blob[2], blob + n_words);
   // the same index validation the HIP library performs
   for (uint32_t pc = 0; pc < p->n_instr; ++pc) {
     uint32_t w0 = p->code[2*pc]; uint32_t op = w0 & 0xff;
@@ -83,6 +85,8 @@ extern "C" int gmx_program_create(const uint32_t* blob, size_t n_words, gmx_prog
   *out = p; return 0;
 }
 extern "C" int gmx_program_destroy(gmx_program* p) { delete p; return 0; }
+extern "C" int gmx_program_specialize(gmx_program*) { return fail("hostsim: no specialisation"); }
+extern "C" int gmx_program_is_specialized(const gmx_program*) { return 0; }
 extern "C" int64_t gmx_program_grid(const gmx_program*, int64_t n) { return (n + 255) / 256; }
 
 static float butterfly_sum64(const float* v) {
@@ -91,8 +95,11 @@ static float butterfly_sum64(const float* v) {
   return t[0];
 }
 
-extern "C" int gmx_program_run(const gmx_program* p, int64_t n, const gmx_run_args* A, gmx_stream) {
-  if (!p || !A) return fail("program_run: null");
+extern "C" int gmx_program_run(const gmx_program* p, int64_t n, const gmx_run_args* A_in, gmx_stream) {
+  if (!p || !A_in) return fail("program_run: null");
+  gmx_run_args patched = *A_in;
+  for (uint32_t k = 0; k < p->n_const; ++k) patched.uni[p->n_dyn + k] = p->consts[k];
+  const gmx_run_args* A = &patched;
   for (uint32_t s = 0; s < p->n_in; ++s) if (!A->in_d[s]) return fail("program_run: null input slot");
   for (uint32_t s = 0; s < p->n_out; ++s) if (!A->out_d[s]) return fail("program_run: null output slot");
   int64_t grid = (n + 255) / 256;
@@ -102,7 +109,7 @@ extern "C" int gmx_program_run(const gmx_program* p, int64_t n, const gmx_run_ar
     for (int t = 0; t < 256; ++t) {
       int64_t i = blk * 256 + t;
       HostCtx ctx; ctx.code = p->code.data(); ctx.A = A; ctx.red = &red; ctx.i = t; ctx.kind = 0;
-      gmx_vm_run<gmx_regs_vgpr<32>, true, HostCtx>(p->n_instr, i, i < n, *A, ctx);
+      gmx_vm_run<gmx_regs_vgpr<32>, true, -1, HostCtx>(p->n_instr, i, i < n, *A, ctx);
       if (ctx.kind) kind = ctx.kind;
     }
     if (kind && A->red_out_d) {

@@ -32,13 +32,13 @@ def oracle_bootstrap_sweep(init, step, n, T, ys, run_key, kind=O.SYSTEMATIC, ste
     return dict(log_ml=log_ml, x=x, lw=lw, anc=anc, hist=hist)
 
 
-def check_lgssm_sweep(n=4096, T=5, seed=314159, capture=False):
+def check_lgssm_sweep(n=4096, T=5, seed=314159, capture=False, specialize=True):
     import genjax_amd as G
     from genjax_amd import workloads
     from genjax_amd.inference.smc import BootstrapSweep
     ys = workloads.lgssm_data(T)
     init, step = workloads.make_lgssm(G)
-    sw = BootstrapSweep(init, step, n, T).prepare(G.key(seed), torch.from_numpy(ys))
+    sw = BootstrapSweep(init, step, n, T, specialize=specialize).prepare(G.key(seed), torch.from_numpy(ys))
     if capture:
         sw.capture()
     sw.launch()

@@ -65,6 +65,37 @@ def test_gfi_simulate_importance_assess(gpu, n):
     assert np.array_equal(s.cpu().numpy(), so)
 
 
+def test_specialized_equals_interpreter(gpu):
+    """gmx_program_specialize: same bits as the interpreter on a program that
+    exercises most op classes (Beta / categorical / trig included)."""
+    import genjax_amd as G
+    from genjax_amd import numpy as jnp
+    from genjax_amd import static
+
+    @G.gen
+    def m(a, b):
+        p = G.beta(2.0, 3.0) @ "p"
+        f = G.flip(p) @ "f"
+        z = G.normal(jnp.where(f, a, b) + jnp.cos(a) * jnp.tanh(b), jnp.exp(0.1 * b)) @ "z"
+        u = G.uniform(-1.0, 2.0) @ "u"
+        k = G.categorical(logits=jnp.array([0.1, 0.2, 0.3]) * u) @ "k"
+        w = G.bernoulli(logits=z) @ "w"
+        return z * u + jnp.lgamma(jnp.abs(z) + 1.0)
+    n = 20_000
+    keys = G.split(G.key(3), n)
+    a = _dev(np.linspace(-2, 2, n).astype(np.float32))
+    b = _dev(np.linspace(1, -1, n).astype(np.float32))
+    tr1 = m.simulate(keys, (a, b))
+    comps = [c[0] for c in static._CACHE.values() if hasattr(c[0], "specialize")]
+    assert comps and all(c.specialize() for c in comps), gpu.c.gmx_last_error()
+    tr2 = m.simulate(keys, (a, b))
+    for addr in ("p", "f", "z", "u", "k", "w"):
+        v1, v2 = tr1.get_choices()[addr], tr2.get_choices()[addr]
+        assert torch.equal(v1, v2), addr
+    assert torch.equal(tr1.get_score(), tr2.get_score())
+    assert torch.equal(tr1.get_retval(), tr2.get_retval())
+
+
 def test_elementary_functions_bit_exact(gpu):
     """exp/log/... on the device == the oracle's C restatement, bit for bit."""
     import genjax_amd as G
@@ -160,9 +191,12 @@ def test_gather_and_categorical(gpu):
     assert np.array_equal(idx, ref)
 
 
-@pytest.mark.parametrize("n,T,capture", [(4096, 5, False), (4096, 5, True), (100_000, 8, True)])
-def test_lgssm_sweep_matches_oracle(gpu, n, T, capture):
-    res = parity.check_lgssm_sweep(n=n, T=T, capture=capture)
+@pytest.mark.parametrize("n,T,capture,specialize", [(4096, 5, False, False), (4096, 5, True, False),
+                                                    (4096, 5, False, True), (100_000, 8, True, True),
+                                                    (100_000, 8, True, False)])
+def test_lgssm_sweep_matches_oracle(gpu, n, T, capture, specialize):
+    """interpreter AND hiprtc-specialised kernels vs the oracle, bit for bit"""
+    res = parity.check_lgssm_sweep(n=n, T=T, capture=capture, specialize=specialize)
     assert res["ancestors_equal"] and res["x_equal"] and res["totals_equal"], res
     assert res["lw_max_abs_diff"] == 0.0
     assert res["log_ml"] == res["log_ml_oracle"]

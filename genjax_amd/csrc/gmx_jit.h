@@ -3,29 +3,27 @@
 // gmx_program_specialize() emits a translation unit of the form
 //
 //   #include "gmx_jit.h"
-//   GMX_JIT_PROGRAM(N_INSTR, N_REGS, FULL, N_CONST_BASE) = { w0, w1, ... };
-//   GMX_JIT_CONSTS = { c0, c1, ... };
-//   GMX_JIT_KERNEL(N_INSTR, N_REGS, FULL, N_UNI_DYN)
+//   __device__ static constexpr uint32_t GMX_JIT_CONST[] = { c0, c1, ... };
+//   GMX_JIT_BEGIN(N_REGS, FULL, N_DYN)
+//     GMX_JIT_OP(w0, w1)          // one line per instruction
+//     ...
+//   GMX_JIT_END
 //
-// i.e. the SAME interpreter template (gmx_vm.h) instantiated with a context
-// whose instruction fetch and constant pool are compile-time constants and a
-// fully unrolled op loop.  hipcc folds the dispatch switch, the operand
-// selection and the register indexing: what remains is straight-line code
+// i.e. the SAME gmx_vm_step template (gmx_vm.h) the interpreter loops over,
+// instantiated once per instruction with compile-time instruction words
+// (gmx_cword): the dispatch switch, the operand selection and the register
+// indices are constant expressions, so what is compiled is straight-line code
 // calling the hand-written samplers / log-densities — bit-identical to the
 // interpreter by construction (same source, same -ffp-contract=off).
 #pragma once
 #include "gmx_block.h"
 #include "gmx_vm.h"
 
-template <int NI, int NDYN>
+template <int NDYN>
 struct gmx_jit_ctx {
-  const uint32_t* prog;     // constexpr instruction words
   const uint32_t* consts;   // constexpr constants (pool entries NDYN..)
   const gmx_run_args* A;
   float* lds4;
-  __device__ __forceinline__ void fetch(uint32_t pc, uint32_t* w0, uint32_t* w1) const {
-    *w0 = prog[2u * pc]; *w1 = prog[2u * pc + 1u];
-  }
   __device__ __forceinline__ uint32_t pool(uint32_t i) const {
     return i < (uint32_t)NDYN ? A->uni[i] : consts[i - (uint32_t)NDYN];
   }
@@ -36,11 +34,20 @@ struct gmx_jit_ctx {
   __device__ __forceinline__ void red_lse(float x, bool active) { gmx_red_lse(A->red_out_d, lds4, x, active); }
 };
 
-#define GMX_JIT_KERNEL(NI, NREGS, FULL, NDYN)                                                   \
+#define GMX_JIT_BEGIN(NREGS, FULLV, NDYN)                                                        \
   extern "C" __global__ void __launch_bounds__(GMX_BLOCK) gmx_jit_kernel(int64_t n, const gmx_run_args A) { \
     __shared__ float lds4[4];                                                                    \
-    int64_t i = (int64_t)blockIdx.x * GMX_BLOCK + threadIdx.x;                                   \
-    gmx_jit_ctx<NI, NDYN> ctx;                                                                   \
-    ctx.prog = GMX_JIT_PROG; ctx.consts = GMX_JIT_CONST; ctx.A = &A; ctx.lds4 = lds4;            \
-    gmx_vm_run<gmx_regs_vgpr<NREGS>, FULL, NI, gmx_jit_ctx<NI, NDYN>>((uint32_t)NI, i, i < n, A, ctx); \
-  }
+    const int64_t i = (int64_t)blockIdx.x * GMX_BLOCK + threadIdx.x;                             \
+    const bool active = i < n;                                                                   \
+    typedef gmx_regs_vgpr<NREGS> regs_t;                                                         \
+    typedef gmx_jit_ctx<NDYN> ctx_t;                                                             \
+    constexpr bool full_v = FULLV;                                                               \
+    ctx_t ctx;                                                                                   \
+    ctx.consts = GMX_JIT_CONST; ctx.A = &A; ctx.lds4 = lds4;                                     \
+    regs_t R;                                                                                    \
+    R.init();
+
+#define GMX_JIT_OP(W0, W1) \
+    gmx_vm_step<regs_t, full_v, gmx_cword<W0, W1>, ctx_t>(R, gmx_cword<W0, W1>(), i, active, A, ctx);
+
+#define GMX_JIT_END }

@@ -228,15 +228,18 @@ static bool jit_enabled() {
 
 static std::string jit_source(const gmx_program* p) {
   std::string s = "#include \"gmx_jit.h\"\n";
-  char buf[64];
-  s += "__device__ static constexpr uint32_t GMX_JIT_PROG[] = {";
-  for (size_t k = 0; k < p->code_h.size(); ++k) { snprintf(buf, sizeof(buf), "0x%08xu,", p->code_h[k]); s += buf; }
-  s += "0u};\n__device__ static constexpr uint32_t GMX_JIT_CONST[] = {";
+  char buf[96];
+  s += "__device__ static constexpr uint32_t GMX_JIT_CONST[] = {";
   for (size_t k = 0; k < p->consts.size(); ++k) { snprintf(buf, sizeof(buf), "0x%08xu,", p->consts[k]); s += buf; }
   s += "0u};\n";
-  snprintf(buf, sizeof(buf), "GMX_JIT_KERNEL(%u, %u, %s, %u)\n", p->n_instr, p->n_regs <= 16 ? 16u : 32u,
+  snprintf(buf, sizeof(buf), "GMX_JIT_BEGIN(%u, %s, %u)\n", p->n_regs <= 16 ? 16u : 32u,
            p->needs_full ? "true" : "false", p->n_dyn);
   s += buf;
+  for (uint32_t pc = 0; pc < p->n_instr; ++pc) {
+    snprintf(buf, sizeof(buf), "  GMX_JIT_OP(0x%08xu, 0x%08xu)\n", p->code_h[2 * pc], p->code_h[2 * pc + 1]);
+    s += buf;
+  }
+  s += "GMX_JIT_END\n";
   return s;
 }
 
@@ -959,6 +962,180 @@ extern "C" int gmx_ancestors(int kind, const uint32_t key[2], const uint64_t* cd
                        key[0], key[1], cdf_d, n_in, cdf_offset, total_d, n_out_total, slot_offset,
                        n_slots, ancestors_d);
   }
+  GMX_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// fused resampling (systematic / stratified, one GPU): log-weights -> ancestors
+// in two streaming kernels with NO inter-block waiting:
+//   k_cdf_local        per 4096-tile: fixed-point weights, tile-local inclusive
+//                      CDF (workspace) and the tile aggregate
+//   k_offspring_local  every block scans the <= 512 tile aggregates itself (2-4 KB
+//                      from L2) to get its tile's global prefix and the total,
+//                      then assigns offspring exactly as k_offspring does.
+// The global CDF cdf_i = prefix[tile(i)] + local_i is the same integer the
+// chained scan (k_weight_cdf) produces, so ancestors are identical.
+// ---------------------------------------------------------------------------
+#define RS_MAX_TILES 512
+
+struct rs_ws {                 // layout of the gmx_resample workspace
+  uint64_t agg[RS_MAX_TILES];  // tile aggregates
+  uint64_t local[1];           // n tile-local inclusive CDF entries
+};
+
+extern "C" size_t gmx_resample_workspace(int64_t n) {
+  if (n < 1) n = 1;
+  return sizeof(uint64_t) * (RS_MAX_TILES + (size_t)n);
+}
+
+__global__ void __launch_bounds__(CDF_THREADS)
+k_cdf_local(const float* __restrict__ lw, int64_t n, float scale, int max_mode,
+            const float* __restrict__ partials, int64_t n_part, float* __restrict__ max_d, rs_ws* ws) {
+  __shared__ uint64_t s_part[CDF_WAVES];
+  __shared__ float s_max[CDF_WAVES];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t tile = blockIdx.x;
+  const int64_t base = (int64_t)tile * CDF_TILE + (int64_t)threadIdx.x * CDF_VEC;
+  float x[CDF_VEC];
+  if (base + CDF_VEC <= n) {
+    float4 v = *reinterpret_cast<const float4*>(lw + base);
+    x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
+  } else {
+#pragma unroll
+    for (int c = 0; c < CDF_VEC; ++c) x[c] = (base + c < n) ? lw[base + c] : -gmx_inf();
+  }
+  float M;
+  if (max_mode == 1) {
+    float m = -gmx_inf();
+    for (int64_t j = threadIdx.x; j < n_part; j += CDF_THREADS) m = gmx_fmax(m, partials[2 * j]);
+    m = wave_max(m);
+    if (lane == 0) s_max[wave] = m;
+    __syncthreads();
+    m = s_max[0];
+#pragma unroll
+    for (int w = 1; w < CDF_WAVES; ++w) m = gmx_fmax(m, s_max[w]);
+    M = m;
+    if (tile == 0 && threadIdx.x == 0) *max_d = M;
+  } else {
+    M = *max_d;
+  }
+  uint64_t q[CDF_VEC];
+  uint64_t run = 0;
+#pragma unroll
+  for (int c = 0; c < CDF_VEC; ++c) {
+    uint64_t w = (base + c < n) ? weight_fixed(x[c], M, scale) : 0ull;
+    run += w;
+    q[c] = run;
+  }
+  uint64_t inc = run;
+#pragma unroll
+  for (int d = 1; d < GMX_WAVE; d <<= 1) {
+    uint64_t t = shfl_up_u64(inc, d);
+    if (lane >= d) inc += t;
+  }
+  if (lane == 63) s_part[wave] = inc;
+  __syncthreads();
+  uint64_t tile_agg = 0, wave_off = 0;
+#pragma unroll
+  for (int w = 0; w < CDF_WAVES; ++w) {
+    if (w == wave) wave_off = tile_agg;
+    tile_agg += s_part[w];
+  }
+  const uint64_t off = wave_off + (inc - run);
+  if (base + CDF_VEC <= n) {
+    ulonglong2 a, b;
+    a.x = off + q[0]; a.y = off + q[1]; b.x = off + q[2]; b.y = off + q[3];
+    reinterpret_cast<ulonglong2*>(ws->local + base)[0] = a;
+    reinterpret_cast<ulonglong2*>(ws->local + base)[1] = b;
+  } else {
+#pragma unroll
+    for (int c = 0; c < CDF_VEC; ++c)
+      if (base + c < n) ws->local[base + c] = off + q[c];
+  }
+  if (threadIdx.x == 0) ws->agg[tile] = tile_agg;
+}
+
+__global__ void __launch_bounds__(GMX_BLOCK)
+k_offspring_local(int kind, uint32_t k0, uint32_t k1, const rs_ws* __restrict__ ws, int64_t n, int n_tiles,
+                  uint64_t* __restrict__ total_out, int32_t* __restrict__ anc) {
+  __shared__ uint64_t s_w[4];
+  __shared__ uint64_t s_prefix, s_total;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t i = (int64_t)blockIdx.x * GMX_BLOCK + threadIdx.x;
+  const int my_tile = (int)(((int64_t)blockIdx.x * GMX_BLOCK) / CDF_TILE);   // a block never straddles tiles
+  // ---- every block: prefix of its tile and the total, from the tile aggregates ----
+  uint64_t a0 = (threadIdx.x < n_tiles) ? ws->agg[threadIdx.x] : 0ull;
+  uint64_t a1 = (threadIdx.x + GMX_BLOCK < n_tiles) ? ws->agg[threadIdx.x + GMX_BLOCK] : 0ull;
+  uint64_t below = ((int)threadIdx.x < my_tile ? a0 : 0ull) + ((int)threadIdx.x + GMX_BLOCK < my_tile ? a1 : 0ull);
+  uint64_t all = a0 + a1;
+  below = wave_sum_u64(below);
+  all = wave_sum_u64(all);
+  if (lane == 0) { s_w[wave] = below; }
+  __syncthreads();
+  if (threadIdx.x == 0) s_prefix = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+  __syncthreads();
+  if (lane == 0) { s_w[wave] = all; }
+  __syncthreads();
+  if (threadIdx.x == 0) s_total = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+  __syncthreads();
+  const uint64_t prefix = s_prefix, total = s_total;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *total_out = total;
+  const bool in_range = i < n;
+  gmx_key key; key.k0 = k0; key.k1 = k1;
+  const uint64_t u0 = gmx_bits32(key, 0) >> 9;
+  const uint64_t D = (uint64_t)n << 23;
+  if (total == 0) {
+    if (i == n - 1)
+      for (int64_t s = 0; s < n; ++s) anc[s] = (int32_t)(n - 1);
+    return;
+  }
+  const double n_over_total = (double)n / (double)total;
+  const double eps = (double)n * 0x1p-44 + 0x1p-40;
+  const uint64_t c_hi = in_range ? prefix + ws->local[i] : total;
+  int64_t e = slots_below(kind, key, u0, c_hi, D, total, n_over_total, eps, n);
+  uint32_t e_lo = (uint32_t)e, e_hi32 = (uint32_t)((uint64_t)e >> 32);
+  e_lo = __shfl_up(e_lo, 1, GMX_WAVE); e_hi32 = __shfl_up(e_hi32, 1, GMX_WAVE);
+  int64_t s = (int64_t)(((uint64_t)e_hi32 << 32) | e_lo);
+  if (lane == 0) {
+    // lower bound = upper bound of source i-1 (same tile unless i starts a tile)
+    uint64_t c_lo = prefix;
+    if (in_range && (i % CDF_TILE) != 0) c_lo = prefix + ws->local[i - 1];
+    s = slots_below(kind, key, u0, c_lo, D, total, n_over_total, eps, n);
+  }
+  if (!in_range) return;
+  for (int64_t j = s; j < e; ++j) anc[j] = (int32_t)i;
+}
+
+extern "C" int gmx_resample(int kind, const uint32_t key[2], const float* lw_d, int64_t n, int shift,
+                            const float* max_partials_d, int64_t n_partials, float* max_d,
+                            uint64_t* total_d, int32_t* ancestors_d, void* workspace_d, gmx_stream stream) {
+  if (n <= 0) return gmx_fail("gmx_resample: n must be positive%s");
+  if (!key || !lw_d || !max_d || !total_d || !ancestors_d || !workspace_d)
+    return gmx_fail("gmx_resample: null argument%s");
+  if (kind != GMX_RESAMPLE_SYSTEMATIC && kind != GMX_RESAMPLE_STRATIFIED)
+    return gmx_fail("gmx_resample: kind must be systematic or stratified (use gmx_weight_cdf + gmx_ancestors)%s");
+  int64_t tiles = (n + CDF_TILE - 1) / CDF_TILE;
+  if (tiles > RS_MAX_TILES) return gmx_fail("gmx_resample: n too large for the fused path (use gmx_weight_cdf + gmx_ancestors)%s");
+  if (n > 0x7fffffffLL) return gmx_fail("gmx_resample: n out of range%s");
+  if (shift < 1 || shift > 62) return gmx_fail("gmx_resample: shift out of range%s");
+  int need = 0;
+  while (((int64_t)1 << need) < n) ++need;
+  if (shift + need > 62) return gmx_fail("gmx_resample: shift too large for n (overflow)%s");
+  if (((uintptr_t)lw_d & 15) || ((uintptr_t)workspace_d & 15))
+    return gmx_fail("gmx_resample: lw_d and workspace_d must be 16-byte aligned%s");
+  hipStream_t st = (hipStream_t)stream;
+  int max_mode = 0;
+  if (max_partials_d) {
+    if (n_partials <= 0) return gmx_fail("gmx_resample: n_partials must be positive%s");
+    if (n_partials <= 16384) max_mode = 1;
+    else hipLaunchKernelGGL(k_reduce_max, dim3(1), dim3(GMX_BLOCK), 0, st, max_partials_d, n_partials, max_d);
+  }
+  float scale = gmx_pow2i(shift);
+  hipLaunchKernelGGL(k_cdf_local, dim3((unsigned)tiles), dim3(CDF_THREADS), 0, st, lw_d, n, scale, max_mode,
+                     max_partials_d, n_partials, max_d, (rs_ws*)workspace_d);
+  hipLaunchKernelGGL(k_offspring_local, grid_for(n), dim3(GMX_BLOCK), 0, st, kind, key[0], key[1],
+                     (const rs_ws*)workspace_d, n, (int)tiles, total_d, ancestors_d);
   GMX_HIP(hipGetLastError());
   return 0;
 }

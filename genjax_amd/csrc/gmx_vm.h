@@ -50,10 +50,24 @@ GMX_HD uint32_t gmx_asu(float f) { return gmx_f2u(f); }
 //   uint32_t pool(i)                 constant / uniform pool entry
 //   const void* in_ptr(slot); void* out_ptr(slot); const void* tab_ptr(slot)
 //   void red_max(float x, bool active); void red_lse(float x, bool active)
+// An instruction word pair: run-time (interpreter) or compile-time (specialised
+// programs: op / operand codes are constant expressions, so the compiler emits
+// only the one switch case an instruction needs).
+struct gmx_rword {
+  uint32_t a, b;
+  GMX_HDM uint32_t w0() const { return a; }
+  GMX_HDM uint32_t w1() const { return b; }
+};
+template <uint32_t A0, uint32_t B0>
+struct gmx_cword {
+  static constexpr uint32_t w0() { return A0; }
+  static constexpr uint32_t w1() { return B0; }
+};
+
 // One instruction.  All of w0 / w1 are launch-uniform.
-template <class Regs, bool FULL, class Ctx>
-GMX_HD void gmx_vm_step(Regs& R, const uint32_t w0, const uint32_t w1, int64_t i, bool active,
-                        const gmx_run_args& A, Ctx& ctx) {
+template <class Regs, bool FULL, class W, class Ctx>
+GMX_HD void gmx_vm_step(Regs& R, const W w, int64_t i, bool active, const gmx_run_args& A, Ctx& ctx) {
+  const uint32_t w0 = w.w0(), w1 = w.w1();
 #define SRC(x) ((x) < GMX_POOL_BASE ? R.get(x) : ctx.pool((x) - GMX_POOL_BASE))
 #define FSRC(x) gmx_asf(SRC(x))
 #define KEY(x) gmx_key k; k.k0 = R.get(x); k.k1 = R.get((x) + 1u)
@@ -197,33 +211,15 @@ GMX_HD void gmx_vm_step(Regs& R, const uint32_t w0, const uint32_t w1, int64_t i
 #undef KEY
 }
 
-// Compile-time unrolling for specialised programs: instruction PC of NI.  With
-// a Ctx whose fetch() reads a constexpr array, w0 / w1 are constants after
-// inlining and the switch, operand selection and register indices all fold.
-template <class Regs, bool FULL, int NI, int PC, class Ctx>
-GMX_HD void gmx_vm_unroll(Regs& R, int64_t i, bool active, const gmx_run_args& A, Ctx& ctx) {
-  if constexpr (PC < NI) {
-    uint32_t w0, w1;
-    ctx.fetch((uint32_t)PC, &w0, &w1);
-    gmx_vm_step<Regs, FULL, Ctx>(R, w0, w1, i, active, A, ctx);
-    gmx_vm_unroll<Regs, FULL, NI, PC + 1, Ctx>(R, i, active, A, ctx);
-  }
-}
-
 // NI < 0: interpret n_instr_rt instructions fetched through ctx at run time.
-// NI >= 0: specialised program of exactly NI instructions (gmx_program_specialize).
 template <class Regs, bool FULL, int NI, class Ctx>
 GMX_HD void gmx_vm_run(uint32_t n_instr_rt, int64_t i, bool active, const gmx_run_args& A, Ctx& ctx) {
   Regs R;
   R.init();
-  if constexpr (NI >= 0) {
-    gmx_vm_unroll<Regs, FULL, NI, 0, Ctx>(R, i, active, A, ctx);
-  } else {
-    for (uint32_t pc = 0; pc < n_instr_rt; ++pc) {
-      uint32_t w0, w1;
-      ctx.fetch(pc, &w0, &w1);
-      gmx_vm_step<Regs, FULL, Ctx>(R, w0, w1, i, active, A, ctx);
-    }
+  for (uint32_t pc = 0; pc < n_instr_rt; ++pc) {
+    gmx_rword w;
+    ctx.fetch(pc, &w.a, &w.b);
+    gmx_vm_step<Regs, FULL, gmx_rword, Ctx>(R, w, i, active, A, ctx);
   }
 }
 

@@ -380,6 +380,9 @@ class BootstrapSweep:
         self.totals = torch.zeros((T,), dtype=torch.int64, device=dev)
         self.shift = cdf_shift(n)
         self.ws = torch.zeros(((be.c.gmx_weight_cdf_workspace(n) + 7) // 8,), dtype=torch.int64, device=dev)
+        self.fused = self.kind in (SYSTEMATIC, STRATIFIED) and n <= (512 * 4096)
+        self.rs_ws = torch.zeros(((be.c.gmx_resample_workspace(n) + 7) // 8,), dtype=torch.int64, device=dev) \
+            if self.fused else None
         obs0 = ChoiceMap.empty().set(self.obs_addr, self.ys[0])
         self.p_init = MinimalGenerate(self.init, (), obs0, (n,))
         g = Gathered(self.x[0], self.anc)
@@ -426,19 +429,35 @@ class BootstrapSweep:
         be.check(be.c.gmx_ancestors(self.kind, kk, be.ptr(self.cdf), self.n, 0, be.ptr(self.totals[t:t + 1]),
                                     self.n, 0, self.n, be.ptr(self.anc), be.stream()), "gmx_ancestors")
 
+    def _launch_resample(self, t):
+        be = _lib.get()
+        kh = self.step_keys[t][1].host()
+        kk = (c_uint32 * 2)(int(kh[0]), int(kh[1]))
+        be.check(be.c.gmx_resample(self.kind, kk, be.ptr(self.lw), self.n, self.shift, be.ptr(self.partials),
+                                   self.partials.shape[0], be.ptr(self.maxs[t:t + 1]),
+                                   be.ptr(self.totals[t:t + 1]), be.ptr(self.anc), be.ptr(self.rs_ws),
+                                   be.stream()), "gmx_resample")
+
     def enqueue(self):
         """Issue every launch of the sweep on the current stream (no syncs, no allocations)."""
         for t in range(self.T):
             self._launch_vm(t)
-            self._launch_cdf(t)
-            self._launch_anc(t)
+            if self.fused:
+                self._launch_resample(t)
+            else:
+                self._launch_cdf(t)
+                self._launch_anc(t)
 
     def kernel_timers(self):
         """Representative single launches (a mid-sweep step) for per-kernel timing in bench.py."""
         t = max(1, self.T // 2)
-        return {"k_vm": lambda: self._launch_vm(t),
-                "k_weight_cdf": lambda: self._launch_cdf(t),
-                "k_ancestors": lambda: self._launch_anc(t)}
+        out = {"k_vm": lambda: self._launch_vm(t)}
+        if self.fused:
+            out["resample(k_cdf_local+k_offspring_local)"] = lambda: self._launch_resample(t)
+        else:
+            out["k_weight_cdf"] = lambda: self._launch_cdf(t)
+            out["k_ancestors"] = lambda: self._launch_anc(t)
+        return out
 
     def capture(self):
         """Capture enqueue() into a hipGraph (launch-bound: ~5 nodes per step)."""

@@ -184,6 +184,14 @@ int gmx_ancestors(int kind, const uint32_t key[2], const uint64_t* cdf_d, int64_
                   int64_t n_out_total, int64_t slot_offset, int64_t n_slots,
                   int32_t* ancestors_d /* [n_slots], clamped to [0,n_in) local */,
                   gmx_stream stream);
+/* Fused one-GPU form of steps 1+2 for SYSTEMATIC / STRATIFIED (n <= 2^21):
+ * two streaming kernels, no inter-block waiting; ancestors identical to
+ * gmx_weight_cdf + gmx_ancestors.  *max_d / *total_d receive the max
+ * log-weight and the integer total (for the evidence increment). */
+size_t gmx_resample_workspace(int64_t n);
+int gmx_resample(int kind, const uint32_t key[2], const float* lw_d, int64_t n, int shift,
+                 const float* max_partials_d, int64_t n_partials, float* max_d,
+                 uint64_t* total_d, int32_t* ancestors_d, void* workspace_d, gmx_stream stream);
 int gmx_gather(const void* const* src_d, void* const* dst_d, const int32_t* elem_bytes,
                int32_t n_leaves, const int32_t* ancestors_d, int64_t n_out,
                gmx_stream stream);

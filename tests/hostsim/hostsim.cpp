@@ -143,6 +143,9 @@ extern "C" int gmx_logsumexp(const float* lw, int64_t rows, int64_t cols, float*
 }
 
 // ---- weights / cdf / ancestors ----
+extern "C" int gmx_ancestors(int kind, const uint32_t key[2], const uint64_t* cdf, int64_t n_in, uint64_t off,
+                             const uint64_t* total_d, int64_t n_out_total, int64_t slot_offset, int64_t n_slots,
+                             int32_t* anc, gmx_stream);
 extern "C" size_t gmx_weight_cdf_workspace(int64_t n) { return 8 + (size_t)((n + 1023) / 1024) * 8; }
 extern "C" int gmx_weight_cdf(const float* lw, int64_t n, int shift, const float* parts, int64_t n_parts, float* max_d,
                               uint64_t* cdf, uint64_t* total, void*, gmx_stream) {
@@ -183,6 +186,14 @@ extern "C" int gmx_ancestors(int kind, const uint32_t key[2], const uint64_t* cd
     anc[s] = (int32_t)lo;
   }
   return 0;
+}
+extern "C" size_t gmx_resample_workspace(int64_t n) { return 8 * (512 + (size_t)(n < 1 ? 1 : n)); }
+extern "C" int gmx_resample(int kind, const uint32_t key[2], const float* lw, int64_t n, int shift, const float* parts,
+                            int64_t n_parts, float* max_d, uint64_t* total, int32_t* anc, void* ws, gmx_stream st) {
+  if (kind == GMX_RESAMPLE_MULTINOMIAL) return fail("resample: kind");
+  uint64_t* cdf = (uint64_t*)ws + 512;
+  if (gmx_weight_cdf(lw, n, shift, parts, n_parts, max_d, cdf, total, nullptr, st)) return 1;
+  return gmx_ancestors(kind, key, cdf, n, 0, total, n, 0, n, anc, st);
 }
 extern "C" int gmx_gather(const void* const* src, void* const* dst, const int32_t* bytes, int32_t n_leaves,
                           const int32_t* anc, int64_t n_out, gmx_stream) {

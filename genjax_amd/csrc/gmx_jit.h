@@ -24,30 +24,58 @@ struct gmx_jit_ctx {
   const uint32_t* consts;   // constexpr constants (pool entries NDYN..)
   const gmx_run_args* A;
   float* lds4;
+  uint32_t part;            // index of the 256-particle group this step works on (block partial row)
   __device__ __forceinline__ uint32_t pool(uint32_t i) const {
     return i < (uint32_t)NDYN ? A->uni[i] : consts[i - (uint32_t)NDYN];
   }
   __device__ __forceinline__ const void* in_ptr(uint32_t s) const { return A->in_d[s]; }
   __device__ __forceinline__ void* out_ptr(uint32_t s) const { return A->out_d[s]; }
   __device__ __forceinline__ const void* tab_ptr(uint32_t s) const { return A->tab_d[s]; }
-  __device__ __forceinline__ void red_max(float x, bool active) { gmx_red_max(A->red_out_d, lds4, x, active); }
-  __device__ __forceinline__ void red_lse(float x, bool active) { gmx_red_lse(A->red_out_d, lds4, x, active); }
+  __device__ __forceinline__ void red_max(float x, bool active) {
+    float m = block_max(active ? x : -gmx_inf(), lds4);
+    if (threadIdx.x == 0 && A->red_out_d) A->red_out_d[2 * (size_t)part] = m;
+  }
+  __device__ __forceinline__ void red_lse(float x, bool active) {
+    float m = block_max(active ? x : -gmx_inf(), lds4);
+    float e = active ? gmx_expf(x - m) : 0.0f;
+    if (!(m > -gmx_inf())) e = 0.0f;
+    float s = block_sum(e, lds4);
+    if (threadIdx.x == 0 && A->red_out_d) {
+      A->red_out_d[2 * (size_t)part] = m;
+      A->red_out_d[2 * (size_t)part + 1] = s;
+    }
+  }
 };
 
-#define GMX_JIT_BEGIN(NREGS, FULLV, NDYN)                                                        \
+// PP particles per thread: PP independent instruction streams in one wave give
+// the VALU the instruction-level parallelism a single dependent chain
+// (Threefry, Horner polynomials) cannot (measured on MI355X: one dependent
+// chain per wave issues at ~40 % of the rate of two or four independent
+// ones).  Particle p of a thread is row (blockIdx * PP + p) * 256 + threadIdx,
+// so every load / store stays a coalesced 256-particle group and the block
+// partial rows are the ones the interpreter would write.
+#define GMX_JIT_BEGIN(NREGS, FULLV, NDYN, PPV)                                                   \
   extern "C" __global__ void __launch_bounds__(GMX_BLOCK) gmx_jit_kernel(int64_t n, const gmx_run_args A) { \
     __shared__ float lds4[4];                                                                    \
-    const int64_t i = (int64_t)blockIdx.x * GMX_BLOCK + threadIdx.x;                             \
-    const bool active = i < n;                                                                   \
+    constexpr int PP = PPV;                                                                      \
     typedef gmx_regs_vgpr<NREGS> regs_t;                                                         \
     typedef gmx_jit_ctx<NDYN> ctx_t;                                                             \
     constexpr bool full_v = FULLV;                                                               \
     ctx_t ctx;                                                                                   \
-    ctx.consts = GMX_JIT_CONST; ctx.A = &A; ctx.lds4 = lds4;                                     \
-    regs_t R;                                                                                    \
-    R.init();
+    ctx.consts = GMX_JIT_CONST; ctx.A = &A; ctx.lds4 = lds4; ctx.part = 0;                       \
+    regs_t R[PP];                                                                                \
+    int64_t idx[PP];                                                                             \
+    bool act[PP];                                                                                \
+    _Pragma("unroll") for (int p = 0; p < PP; ++p) {                                             \
+      R[p].init();                                                                               \
+      idx[p] = ((int64_t)blockIdx.x * PP + p) * GMX_BLOCK + threadIdx.x;                         \
+      act[p] = idx[p] < n;                                                                       \
+    }
 
-#define GMX_JIT_OP(W0, W1) \
-    gmx_vm_step<regs_t, full_v, gmx_cword<W0, W1>, ctx_t>(R, gmx_cword<W0, W1>(), i, active, A, ctx);
+#define GMX_JIT_OP(W0, W1)                                                                       \
+    _Pragma("unroll") for (int p = 0; p < PP; ++p) {                                             \
+      ctx.part = blockIdx.x * PP + p;                                                            \
+      gmx_vm_step<regs_t, full_v, gmx_cword<W0, W1>, ctx_t>(R[p], gmx_cword<W0, W1>(), idx[p], act[p], A, ctx); \
+    }
 
 #define GMX_JIT_END }

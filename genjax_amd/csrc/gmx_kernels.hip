@@ -120,6 +120,7 @@ struct gmx_program {
   std::vector<uint32_t> consts;      // pool entries n_dyn..
   hipModule_t jit_module = nullptr;  // specialised kernel (gmx_program_specialize)
   hipFunction_t jit_fn = nullptr;
+  int jit_pp = 1;                    // particles per thread of the specialised kernel
 };
 
 static int parse_program(const uint32_t* blob, size_t n_words, gmx_program& P) {
@@ -226,14 +227,22 @@ static bool jit_enabled() {
   return !(e && e[0] == '0');
 }
 
+// particles per thread: as much ILP as the register budget allows at 8 waves / SIMD
+static int jit_pp_for(const gmx_program* p) {
+  const char* e = getenv("GENMI_JIT_PP");
+  if (e && e[0] >= '1' && e[0] <= '8') return e[0] - '0';
+  if (p->needs_full) return p->n_regs <= 8 ? 2 : 1;
+  return p->n_regs <= 8 ? 4 : (p->n_regs <= 16 ? 2 : 1);
+}
+
 static std::string jit_source(const gmx_program* p) {
   std::string s = "#include \"gmx_jit.h\"\n";
   char buf[96];
   s += "__device__ static constexpr uint32_t GMX_JIT_CONST[] = {";
   for (size_t k = 0; k < p->consts.size(); ++k) { snprintf(buf, sizeof(buf), "0x%08xu,", p->consts[k]); s += buf; }
   s += "0u};\n";
-  snprintf(buf, sizeof(buf), "GMX_JIT_BEGIN(%u, %s, %u)\n", p->n_regs <= 16 ? 16u : 32u,
-           p->needs_full ? "true" : "false", p->n_dyn);
+  snprintf(buf, sizeof(buf), "GMX_JIT_BEGIN(%u, %s, %u, %d)\n", p->n_regs <= 16 ? 16u : 32u,
+           p->needs_full ? "true" : "false", p->n_dyn, jit_pp_for(p));
   s += buf;
   for (uint32_t pc = 0; pc < p->n_instr; ++pc) {
     snprintf(buf, sizeof(buf), "  GMX_JIT_OP(0x%08xu, 0x%08xu)\n", p->code_h[2 * pc], p->code_h[2 * pc + 1]);
@@ -280,6 +289,7 @@ extern "C" int gmx_program_specialize(gmx_program* p) {
   if (e != hipSuccess) { (void)hipModuleUnload(mod); return gmx_fail("hipModuleGetFunction: %s", hipGetErrorString(e)); }
   p->jit_module = mod;
   p->jit_fn = fn;
+  p->jit_pp = jit_pp_for(p);
   return 0;
 }
 
@@ -361,7 +371,8 @@ extern "C" int gmx_program_run(const gmx_program* p, int64_t n, const gmx_run_ar
     size_t ka_size = sizeof(ka);
     void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &ka, HIP_LAUNCH_PARAM_BUFFER_SIZE, &ka_size,
                       HIP_LAUNCH_PARAM_END};
-    GMX_HIP(hipModuleLaunchKernel(p->jit_fn, grid.x, 1, 1, GMX_BLOCK, 1, 1, 0, st, nullptr, config));
+    unsigned jgrid = (unsigned)((n + (int64_t)GMX_BLOCK * p->jit_pp - 1) / ((int64_t)GMX_BLOCK * p->jit_pp));
+    GMX_HIP(hipModuleLaunchKernel(p->jit_fn, jgrid, 1, 1, GMX_BLOCK, 1, 1, 0, st, nullptr, config));
     return 0;
   }
   if (p->n_regs <= 16) {
@@ -1007,8 +1018,17 @@ k_cdf_local(const float* __restrict__ lw, int64_t n, float scale, int max_mode,
   }
   float M;
   if (max_mode == 1) {
+    // 4 independent loads per thread per round (all in flight together)
     float m = -gmx_inf();
-    for (int64_t j = threadIdx.x; j < n_part; j += CDF_THREADS) m = gmx_fmax(m, partials[2 * j]);
+    for (int64_t j0 = 0; j0 < n_part; j0 += 4 * CDF_THREADS) {
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int64_t j = j0 + (int64_t)r * CDF_THREADS + threadIdx.x;
+        v[r] = (j < n_part) ? partials[2 * j] : -gmx_inf();
+      }
+      m = gmx_fmax(gmx_fmax(m, gmx_fmax(v[0], v[1])), gmx_fmax(v[2], v[3]));
+    }
     m = wave_max(m);
     if (lane == 0) s_max[wave] = m;
     __syncthreads();
@@ -1057,33 +1077,30 @@ k_cdf_local(const float* __restrict__ lw, int64_t n, float scale, int max_mode,
 }
 
 __global__ void __launch_bounds__(GMX_BLOCK)
-k_offspring_local(int kind, uint32_t k0, uint32_t k1, const rs_ws* __restrict__ ws, int64_t n, int n_tiles,
-                  uint64_t* __restrict__ total_out, int32_t* __restrict__ anc) {
-  __shared__ uint64_t s_w[4];
-  __shared__ uint64_t s_prefix, s_total;
+k_offspring_local(int kind, uint32_t k0, uint32_t k1, uint32_t u0_host, const rs_ws* __restrict__ ws, int64_t n,
+                  int n_tiles, uint64_t* __restrict__ total_out, int32_t* __restrict__ anc) {
+  __shared__ uint64_t s_below[4], s_all[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t i = (int64_t)blockIdx.x * GMX_BLOCK + threadIdx.x;
   const int my_tile = (int)(((int64_t)blockIdx.x * GMX_BLOCK) / CDF_TILE);   // a block never straddles tiles
-  // ---- every block: prefix of its tile and the total, from the tile aggregates ----
+  const bool in_range = i < n;
+  // issue every load first: tile aggregates, own local CDF entry, predecessor's (wave leaders)
   uint64_t a0 = (threadIdx.x < n_tiles) ? ws->agg[threadIdx.x] : 0ull;
   uint64_t a1 = (threadIdx.x + GMX_BLOCK < n_tiles) ? ws->agg[threadIdx.x + GMX_BLOCK] : 0ull;
+  const uint64_t loc = in_range ? ws->local[i] : 0ull;
+  const uint64_t loc_prev = (lane == 0 && in_range && (i % CDF_TILE) != 0) ? ws->local[i - 1] : 0ull;
+  // ---- every block: prefix of its tile and the total, from the tile aggregates (one barrier) ----
   uint64_t below = ((int)threadIdx.x < my_tile ? a0 : 0ull) + ((int)threadIdx.x + GMX_BLOCK < my_tile ? a1 : 0ull);
   uint64_t all = a0 + a1;
   below = wave_sum_u64(below);
   all = wave_sum_u64(all);
-  if (lane == 0) { s_w[wave] = below; }
+  if (lane == 0) { s_below[wave] = below; s_all[wave] = all; }
   __syncthreads();
-  if (threadIdx.x == 0) s_prefix = s_w[0] + s_w[1] + s_w[2] + s_w[3];
-  __syncthreads();
-  if (lane == 0) { s_w[wave] = all; }
-  __syncthreads();
-  if (threadIdx.x == 0) s_total = s_w[0] + s_w[1] + s_w[2] + s_w[3];
-  __syncthreads();
-  const uint64_t prefix = s_prefix, total = s_total;
+  const uint64_t prefix = (s_below[0] + s_below[1]) + (s_below[2] + s_below[3]);
+  const uint64_t total = (s_all[0] + s_all[1]) + (s_all[2] + s_all[3]);
   if (blockIdx.x == 0 && threadIdx.x == 0) *total_out = total;
-  const bool in_range = i < n;
   gmx_key key; key.k0 = k0; key.k1 = k1;
-  const uint64_t u0 = gmx_bits32(key, 0) >> 9;
+  const uint64_t u0 = (uint64_t)u0_host;          // bits32(key, 0) >> 9, evaluated on the host
   const uint64_t D = (uint64_t)n << 23;
   if (total == 0) {
     if (i == n - 1)
@@ -1092,16 +1109,14 @@ k_offspring_local(int kind, uint32_t k0, uint32_t k1, const rs_ws* __restrict__ 
   }
   const double n_over_total = (double)n / (double)total;
   const double eps = (double)n * 0x1p-44 + 0x1p-40;
-  const uint64_t c_hi = in_range ? prefix + ws->local[i] : total;
+  const uint64_t c_hi = in_range ? prefix + loc : total;
   int64_t e = slots_below(kind, key, u0, c_hi, D, total, n_over_total, eps, n);
   uint32_t e_lo = (uint32_t)e, e_hi32 = (uint32_t)((uint64_t)e >> 32);
   e_lo = __shfl_up(e_lo, 1, GMX_WAVE); e_hi32 = __shfl_up(e_hi32, 1, GMX_WAVE);
   int64_t s = (int64_t)(((uint64_t)e_hi32 << 32) | e_lo);
   if (lane == 0) {
     // lower bound = upper bound of source i-1 (same tile unless i starts a tile)
-    uint64_t c_lo = prefix;
-    if (in_range && (i % CDF_TILE) != 0) c_lo = prefix + ws->local[i - 1];
-    s = slots_below(kind, key, u0, c_lo, D, total, n_over_total, eps, n);
+    s = slots_below(kind, key, u0, prefix + loc_prev, D, total, n_over_total, eps, n);
   }
   if (!in_range) return;
   for (int64_t j = s; j < e; ++j) anc[j] = (int32_t)i;
@@ -1134,7 +1149,10 @@ extern "C" int gmx_resample(int kind, const uint32_t key[2], const float* lw_d, 
   float scale = gmx_pow2i(shift);
   hipLaunchKernelGGL(k_cdf_local, dim3((unsigned)tiles), dim3(CDF_THREADS), 0, st, lw_d, n, scale, max_mode,
                      max_partials_d, n_partials, max_d, (rs_ws*)workspace_d);
-  hipLaunchKernelGGL(k_offspring_local, grid_for(n), dim3(GMX_BLOCK), 0, st, kind, key[0], key[1],
+  uint32_t b0, b1;
+  gmx_threefry2x32(key[0], key[1], 0u, 0u, &b0, &b1);           // bits32(key, 0) on the host
+  const uint32_t u0 = (b0 ^ b1) >> 9;
+  hipLaunchKernelGGL(k_offspring_local, grid_for(n), dim3(GMX_BLOCK), 0, st, kind, key[0], key[1], u0,
                      (const rs_ws*)workspace_d, n, (int)tiles, total_d, ancestors_d);
   GMX_HIP(hipGetLastError());
   return 0;

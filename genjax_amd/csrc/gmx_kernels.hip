@@ -231,8 +231,10 @@ static bool jit_enabled() {
 static int jit_pp_for(const gmx_program* p) {
   const char* e = getenv("GENMI_JIT_PP");
   if (e && e[0] >= '1' && e[0] <= '8') return e[0] - '0';
-  if (p->needs_full) return p->n_regs <= 8 ? 2 : 1;
-  return p->n_regs <= 8 ? 4 : (p->n_regs <= 16 ? 2 : 1);
+  // Measured on MI355X (profiles/r01_e): 4 particles / thread did not raise the VALU issue
+  // rate of the integer-heavy Threefry stream and cost latency hiding (fewer waves), so the
+  // default stays 1; GENMI_JIT_PP=2/4 remains available for FP-heavy programs.
+  return 1;
 }
 
 static std::string jit_source(const gmx_program* p) {
@@ -988,7 +990,8 @@ extern "C" int gmx_ancestors(int kind, const uint32_t key[2], const uint64_t* cd
 // The global CDF cdf_i = prefix[tile(i)] + local_i is the same integer the
 // chained scan (k_weight_cdf) produces, so ancestors are identical.
 // ---------------------------------------------------------------------------
-#define RS_MAX_TILES 512
+#define RS_TILE 1024                   /* 256 threads x float4 */
+#define RS_MAX_TILES 2048              /* n <= 2^21 */
 
 struct rs_ws {                 // layout of the gmx_resample workspace
   uint64_t agg[RS_MAX_TILES];  // tile aggregates
@@ -1000,14 +1003,14 @@ extern "C" size_t gmx_resample_workspace(int64_t n) {
   return sizeof(uint64_t) * (RS_MAX_TILES + (size_t)n);
 }
 
-__global__ void __launch_bounds__(CDF_THREADS)
+__global__ void __launch_bounds__(GMX_BLOCK)
 k_cdf_local(const float* __restrict__ lw, int64_t n, float scale, int max_mode,
             const float* __restrict__ partials, int64_t n_part, float* __restrict__ max_d, rs_ws* ws) {
-  __shared__ uint64_t s_part[CDF_WAVES];
-  __shared__ float s_max[CDF_WAVES];
+  __shared__ uint64_t s_part[4];
+  __shared__ float lds4[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t tile = blockIdx.x;
-  const int64_t base = (int64_t)tile * CDF_TILE + (int64_t)threadIdx.x * CDF_VEC;
+  const int64_t base = (int64_t)tile * RS_TILE + (int64_t)threadIdx.x * CDF_VEC;
   float x[CDF_VEC];
   if (base + CDF_VEC <= n) {
     float4 v = *reinterpret_cast<const float4*>(lw + base);
@@ -1018,24 +1021,19 @@ k_cdf_local(const float* __restrict__ lw, int64_t n, float scale, int max_mode,
   }
   float M;
   if (max_mode == 1) {
-    // 4 independent loads per thread per round (all in flight together)
+    // 8 independent loads per thread per round (all in flight together)
     float m = -gmx_inf();
-    for (int64_t j0 = 0; j0 < n_part; j0 += 4 * CDF_THREADS) {
-      float v[4];
+    for (int64_t j0 = 0; j0 < n_part; j0 += 8 * GMX_BLOCK) {
+      float v[8];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        int64_t j = j0 + (int64_t)r * CDF_THREADS + threadIdx.x;
+      for (int r = 0; r < 8; ++r) {
+        int64_t j = j0 + (int64_t)r * GMX_BLOCK + threadIdx.x;
         v[r] = (j < n_part) ? partials[2 * j] : -gmx_inf();
       }
-      m = gmx_fmax(gmx_fmax(m, gmx_fmax(v[0], v[1])), gmx_fmax(v[2], v[3]));
-    }
-    m = wave_max(m);
-    if (lane == 0) s_max[wave] = m;
-    __syncthreads();
-    m = s_max[0];
 #pragma unroll
-    for (int w = 1; w < CDF_WAVES; ++w) m = gmx_fmax(m, s_max[w]);
-    M = m;
+      for (int r = 0; r < 8; ++r) m = gmx_fmax(m, v[r]);
+    }
+    M = block_max(m, lds4);
     if (tile == 0 && threadIdx.x == 0) *max_d = M;
   } else {
     M = *max_d;
@@ -1058,7 +1056,7 @@ k_cdf_local(const float* __restrict__ lw, int64_t n, float scale, int max_mode,
   __syncthreads();
   uint64_t tile_agg = 0, wave_off = 0;
 #pragma unroll
-  for (int w = 0; w < CDF_WAVES; ++w) {
+  for (int w = 0; w < 4; ++w) {
     if (w == wave) wave_off = tile_agg;
     tile_agg += s_part[w];
   }
@@ -1082,16 +1080,20 @@ k_offspring_local(int kind, uint32_t k0, uint32_t k1, uint32_t u0_host, const rs
   __shared__ uint64_t s_below[4], s_all[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t i = (int64_t)blockIdx.x * GMX_BLOCK + threadIdx.x;
-  const int my_tile = (int)(((int64_t)blockIdx.x * GMX_BLOCK) / CDF_TILE);   // a block never straddles tiles
+  const int my_tile = (int)(((int64_t)blockIdx.x * GMX_BLOCK) / RS_TILE);   // a block never straddles tiles
   const bool in_range = i < n;
   // issue every load first: tile aggregates, own local CDF entry, predecessor's (wave leaders)
-  uint64_t a0 = (threadIdx.x < n_tiles) ? ws->agg[threadIdx.x] : 0ull;
-  uint64_t a1 = (threadIdx.x + GMX_BLOCK < n_tiles) ? ws->agg[threadIdx.x + GMX_BLOCK] : 0ull;
+  uint64_t below = 0, all = 0;
+#pragma unroll
+  for (int r = 0; r < RS_MAX_TILES / GMX_BLOCK; ++r) {
+    int t = r * GMX_BLOCK + (int)threadIdx.x;
+    uint64_t a = (t < n_tiles) ? ws->agg[t] : 0ull;
+    all += a;
+    below += (t < my_tile) ? a : 0ull;
+  }
   const uint64_t loc = in_range ? ws->local[i] : 0ull;
-  const uint64_t loc_prev = (lane == 0 && in_range && (i % CDF_TILE) != 0) ? ws->local[i - 1] : 0ull;
+  const uint64_t loc_prev = (lane == 0 && in_range && (i % RS_TILE) != 0) ? ws->local[i - 1] : 0ull;
   // ---- every block: prefix of its tile and the total, from the tile aggregates (one barrier) ----
-  uint64_t below = ((int)threadIdx.x < my_tile ? a0 : 0ull) + ((int)threadIdx.x + GMX_BLOCK < my_tile ? a1 : 0ull);
-  uint64_t all = a0 + a1;
   below = wave_sum_u64(below);
   all = wave_sum_u64(all);
   if (lane == 0) { s_below[wave] = below; s_all[wave] = all; }
@@ -1130,7 +1132,7 @@ extern "C" int gmx_resample(int kind, const uint32_t key[2], const float* lw_d, 
     return gmx_fail("gmx_resample: null argument%s");
   if (kind != GMX_RESAMPLE_SYSTEMATIC && kind != GMX_RESAMPLE_STRATIFIED)
     return gmx_fail("gmx_resample: kind must be systematic or stratified (use gmx_weight_cdf + gmx_ancestors)%s");
-  int64_t tiles = (n + CDF_TILE - 1) / CDF_TILE;
+  int64_t tiles = (n + RS_TILE - 1) / RS_TILE;
   if (tiles > RS_MAX_TILES) return gmx_fail("gmx_resample: n too large for the fused path (use gmx_weight_cdf + gmx_ancestors)%s");
   if (n > 0x7fffffffLL) return gmx_fail("gmx_resample: n out of range%s");
   if (shift < 1 || shift > 62) return gmx_fail("gmx_resample: shift out of range%s");
@@ -1147,7 +1149,7 @@ extern "C" int gmx_resample(int kind, const uint32_t key[2], const float* lw_d, 
     else hipLaunchKernelGGL(k_reduce_max, dim3(1), dim3(GMX_BLOCK), 0, st, max_partials_d, n_partials, max_d);
   }
   float scale = gmx_pow2i(shift);
-  hipLaunchKernelGGL(k_cdf_local, dim3((unsigned)tiles), dim3(CDF_THREADS), 0, st, lw_d, n, scale, max_mode,
+  hipLaunchKernelGGL(k_cdf_local, dim3((unsigned)tiles), dim3(GMX_BLOCK), 0, st, lw_d, n, scale, max_mode,
                      max_partials_d, n_partials, max_d, (rs_ws*)workspace_d);
   uint32_t b0, b1;
   gmx_threefry2x32(key[0], key[1], 0u, 0u, &b0, &b1);           // bits32(key, 0) on the host

@@ -380,7 +380,7 @@ class BootstrapSweep:
         self.totals = torch.zeros((T,), dtype=torch.int64, device=dev)
         self.shift = cdf_shift(n)
         self.ws = torch.zeros(((be.c.gmx_weight_cdf_workspace(n) + 7) // 8,), dtype=torch.int64, device=dev)
-        self.fused = self.kind in (SYSTEMATIC, STRATIFIED) and n <= (512 * 4096)
+        self.fused = self.kind in (SYSTEMATIC, STRATIFIED) and n <= (2048 * 1024)
         self.rs_ws = torch.zeros(((be.c.gmx_resample_workspace(n) + 7) // 8,), dtype=torch.int64, device=dev) \
             if self.fused else None
         obs0 = ChoiceMap.empty().set(self.obs_addr, self.ys[0])

@@ -187,11 +187,11 @@ extern "C" int gmx_ancestors(int kind, const uint32_t key[2], const uint64_t* cd
   }
   return 0;
 }
-extern "C" size_t gmx_resample_workspace(int64_t n) { return 8 * (512 + (size_t)(n < 1 ? 1 : n)); }
+extern "C" size_t gmx_resample_workspace(int64_t n) { return 8 * (2048 + (size_t)(n < 1 ? 1 : n)); }
 extern "C" int gmx_resample(int kind, const uint32_t key[2], const float* lw, int64_t n, int shift, const float* parts,
                             int64_t n_parts, float* max_d, uint64_t* total, int32_t* anc, void* ws, gmx_stream st) {
   if (kind == GMX_RESAMPLE_MULTINOMIAL) return fail("resample: kind");
-  uint64_t* cdf = (uint64_t*)ws + 512;
+  uint64_t* cdf = (uint64_t*)ws + 2048;
   if (gmx_weight_cdf(lw, n, shift, parts, n_parts, max_d, cdf, total, nullptr, st)) return 1;
   return gmx_ancestors(kind, key, cdf, n, 0, total, n, 0, n, anc, st);
 }

@@ -32,19 +32,9 @@ struct gmx_jit_ctx {
   __device__ __forceinline__ void* out_ptr(uint32_t s) const { return A->out_d[s]; }
   __device__ __forceinline__ const void* tab_ptr(uint32_t s) const { return A->tab_d[s]; }
   __device__ __forceinline__ void red_max(float x, bool active) {
-    float m = block_max(active ? x : -gmx_inf(), lds4);
-    if (threadIdx.x == 0 && A->red_out_d) A->red_out_d[2 * (size_t)part] = m;
+    gmx_red_max(A->red_out_d, A->red_bins_d, lds4, part, x, active);
   }
-  __device__ __forceinline__ void red_lse(float x, bool active) {
-    float m = block_max(active ? x : -gmx_inf(), lds4);
-    float e = active ? gmx_expf(x - m) : 0.0f;
-    if (!(m > -gmx_inf())) e = 0.0f;
-    float s = block_sum(e, lds4);
-    if (threadIdx.x == 0 && A->red_out_d) {
-      A->red_out_d[2 * (size_t)part] = m;
-      A->red_out_d[2 * (size_t)part + 1] = s;
-    }
-  }
+  __device__ __forceinline__ void red_lse(float x, bool active) { gmx_red_lse(A->red_out_d, lds4, part, x, active); }
 };
 
 // PP particles per thread: PP independent instruction streams in one wave give

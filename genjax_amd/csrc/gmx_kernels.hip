@@ -98,8 +98,10 @@ struct DevCtx {
     return (void*)(((uint64_t)hi << 32) | (uint64_t)lo);
   }
   __device__ __forceinline__ const void* tab_ptr(uint32_t s) const { return A->tab_d[s]; }
-  __device__ __forceinline__ void red_max(float x, bool active) { gmx_red_max(red_out, lds4, x, active); }
-  __device__ __forceinline__ void red_lse(float x, bool active) { gmx_red_lse(red_out, lds4, x, active); }
+  __device__ __forceinline__ void red_max(float x, bool active) {
+    gmx_red_max(red_out, A->red_bins_d, lds4, blockIdx.x, x, active);
+  }
+  __device__ __forceinline__ void red_lse(float x, bool active) { gmx_red_lse(red_out, lds4, blockIdx.x, x, active); }
 };
 
 template <class Regs, bool FULL>
@@ -347,8 +349,8 @@ extern "C" int gmx_program_run(const gmx_program* p, int64_t n, const gmx_run_ar
     if (!args->tab_d[s]) return gmx_fail("gmx_program_run: table slot %s%lld is null", "", s);
   if (p->uses_gather && !args->ancestors_d)
     return gmx_fail("gmx_program_run: program gathers but ancestors_d is null%s");
-  if (p->uses_red && !args->red_out_d)
-    return gmx_fail("gmx_program_run: program reduces but red_out_d is null%s");
+  if (p->uses_red && !args->red_out_d && !args->red_bins_d)
+    return gmx_fail("gmx_program_run: program reduces but red_out_d and red_bins_d are null%s");
   if (p->uses_key) {
     int km = args->key_mode;
     if (km != GMX_KEY_ARRAY && km != GMX_KEY_SPLIT && km != GMX_KEY_ROWSPLIT && km != GMX_KEY_BCAST)
@@ -990,8 +992,10 @@ extern "C" int gmx_ancestors(int kind, const uint32_t key[2], const uint64_t* cd
 // The global CDF cdf_i = prefix[tile(i)] + local_i is the same integer the
 // chained scan (k_weight_cdf) produces, so ancestors are identical.
 // ---------------------------------------------------------------------------
-#define RS_TILE 1024                   /* 256 threads x float4 */
-#define RS_MAX_TILES 2048              /* n <= 2^21 */
+#define RS_THREADS 1024                /* 16 waves per tile                        */
+#define RS_TILE (RS_THREADS * CDF_VEC) /* 4096 log-weights per tile                */
+#define RS_MAX_TILES 512               /* n <= 2^21                                */
+#define RS_SRC_PER_THREAD 4            /* k_offspring_local: sources per thread     */
 
 struct rs_ws {                 // layout of the gmx_resample workspace
   uint64_t agg[RS_MAX_TILES];  // tile aggregates
@@ -1000,14 +1004,17 @@ struct rs_ws {                 // layout of the gmx_resample workspace
 
 extern "C" size_t gmx_resample_workspace(int64_t n) {
   if (n < 1) n = 1;
-  return sizeof(uint64_t) * (RS_MAX_TILES + (size_t)n);
+  return sizeof(uint64_t) * (RS_MAX_TILES + (size_t)n + 8);
 }
 
-__global__ void __launch_bounds__(GMX_BLOCK)
+// max_mode: 0 = read *max_d; 1 = block partials (column 0 of partials[n_part][2]);
+//           2 = GMX_RED_BINS atomic-max keys (one 128-byte line)
+__global__ void __launch_bounds__(RS_THREADS)
 k_cdf_local(const float* __restrict__ lw, int64_t n, float scale, int max_mode,
-            const float* __restrict__ partials, int64_t n_part, float* __restrict__ max_d, rs_ws* ws) {
-  __shared__ uint64_t s_part[4];
-  __shared__ float lds4[4];
+            const float* __restrict__ partials, int64_t n_part, const uint32_t* __restrict__ bins,
+            float* __restrict__ max_d, rs_ws* ws) {
+  __shared__ uint64_t s_part[RS_THREADS / GMX_WAVE];
+  __shared__ float s_max[RS_THREADS / GMX_WAVE];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t tile = blockIdx.x;
   const int64_t base = (int64_t)tile * RS_TILE + (int64_t)threadIdx.x * CDF_VEC;
@@ -1020,20 +1027,29 @@ k_cdf_local(const float* __restrict__ lw, int64_t n, float scale, int max_mode,
     for (int c = 0; c < CDF_VEC; ++c) x[c] = (base + c < n) ? lw[base + c] : -gmx_inf();
   }
   float M;
-  if (max_mode == 1) {
-    // 8 independent loads per thread per round (all in flight together)
+  if (max_mode == 2) {
+    uint32_t k = bins[lane & 31];
+    float m = k ? gmx_max_unkey(k) : -gmx_inf();
+    M = wave_max(m);                               // every wave: one 128-B line, no barrier
+    if (tile == 0 && threadIdx.x == 0) *max_d = M;
+  } else if (max_mode == 1) {
     float m = -gmx_inf();
-    for (int64_t j0 = 0; j0 < n_part; j0 += 8 * GMX_BLOCK) {
-      float v[8];
+    for (int64_t j0 = 0; j0 < n_part; j0 += 4 * RS_THREADS) {
+      float v[4];
 #pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        int64_t j = j0 + (int64_t)r * GMX_BLOCK + threadIdx.x;
+      for (int r = 0; r < 4; ++r) {
+        int64_t j = j0 + (int64_t)r * RS_THREADS + threadIdx.x;
         v[r] = (j < n_part) ? partials[2 * j] : -gmx_inf();
       }
-#pragma unroll
-      for (int r = 0; r < 8; ++r) m = gmx_fmax(m, v[r]);
+      m = gmx_fmax(gmx_fmax(m, gmx_fmax(v[0], v[1])), gmx_fmax(v[2], v[3]));
     }
-    M = block_max(m, lds4);
+    m = wave_max(m);
+    if (lane == 0) s_max[wave] = m;
+    __syncthreads();
+    m = s_max[0];
+#pragma unroll
+    for (int w = 1; w < RS_THREADS / GMX_WAVE; ++w) m = gmx_fmax(m, s_max[w]);
+    M = m;
     if (tile == 0 && threadIdx.x == 0) *max_d = M;
   } else {
     M = *max_d;
@@ -1056,7 +1072,7 @@ k_cdf_local(const float* __restrict__ lw, int64_t n, float scale, int max_mode,
   __syncthreads();
   uint64_t tile_agg = 0, wave_off = 0;
 #pragma unroll
-  for (int w = 0; w < 4; ++w) {
+  for (int w = 0; w < RS_THREADS / GMX_WAVE; ++w) {
     if (w == wave) wave_off = tile_agg;
     tile_agg += s_part[w];
   }
@@ -1074,15 +1090,19 @@ k_cdf_local(const float* __restrict__ lw, int64_t n, float scale, int max_mode,
   if (threadIdx.x == 0) ws->agg[tile] = tile_agg;
 }
 
+// One thread owns RS_SRC_PER_THREAD consecutive sources (two 16-byte loads of the
+// local CDF): a block covers 1024 sources = a quarter tile, so only n/1024 blocks
+// re-read the <= 512 tile aggregates.
 __global__ void __launch_bounds__(GMX_BLOCK)
 k_offspring_local(int kind, uint32_t k0, uint32_t k1, uint32_t u0_host, const rs_ws* __restrict__ ws, int64_t n,
-                  int n_tiles, uint64_t* __restrict__ total_out, int32_t* __restrict__ anc) {
+                  int n_tiles, uint64_t* __restrict__ total_out, uint32_t* __restrict__ bins_to_clear,
+                  int32_t* __restrict__ anc) {
   __shared__ uint64_t s_below[4], s_all[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t i = (int64_t)blockIdx.x * GMX_BLOCK + threadIdx.x;
-  const int my_tile = (int)(((int64_t)blockIdx.x * GMX_BLOCK) / RS_TILE);   // a block never straddles tiles
-  const bool in_range = i < n;
-  // issue every load first: tile aggregates, own local CDF entry, predecessor's (wave leaders)
+  const int64_t i0 = ((int64_t)blockIdx.x * GMX_BLOCK + threadIdx.x) * RS_SRC_PER_THREAD;
+  const int my_tile = (int)(((int64_t)blockIdx.x * GMX_BLOCK * RS_SRC_PER_THREAD) / RS_TILE);
+  if (bins_to_clear && blockIdx.x == 0 && threadIdx.x < GMX_RED_BINS) bins_to_clear[threadIdx.x] = 0u;
+  // issue every load first
   uint64_t below = 0, all = 0;
 #pragma unroll
   for (int r = 0; r < RS_MAX_TILES / GMX_BLOCK; ++r) {
@@ -1091,9 +1111,16 @@ k_offspring_local(int kind, uint32_t k0, uint32_t k1, uint32_t u0_host, const rs
     all += a;
     below += (t < my_tile) ? a : 0ull;
   }
-  const uint64_t loc = in_range ? ws->local[i] : 0ull;
-  const uint64_t loc_prev = (lane == 0 && in_range && (i % RS_TILE) != 0) ? ws->local[i - 1] : 0ull;
-  // ---- every block: prefix of its tile and the total, from the tile aggregates (one barrier) ----
+  uint64_t loc[RS_SRC_PER_THREAD];
+  if (i0 + RS_SRC_PER_THREAD <= n) {
+    ulonglong2 a = reinterpret_cast<const ulonglong2*>(ws->local + i0)[0];
+    ulonglong2 b = reinterpret_cast<const ulonglong2*>(ws->local + i0)[1];
+    loc[0] = a.x; loc[1] = a.y; loc[2] = b.x; loc[3] = b.y;
+  } else {
+#pragma unroll
+    for (int c = 0; c < RS_SRC_PER_THREAD; ++c) loc[c] = (i0 + c < n) ? ws->local[i0 + c] : 0ull;
+  }
+  const uint64_t loc_prev = (lane == 0 && i0 < n && (i0 % RS_TILE) != 0) ? ws->local[i0 - 1] : 0ull;
   below = wave_sum_u64(below);
   all = wave_sum_u64(all);
   if (lane == 0) { s_below[wave] = below; s_all[wave] = all; }
@@ -1105,27 +1132,33 @@ k_offspring_local(int kind, uint32_t k0, uint32_t k1, uint32_t u0_host, const rs
   const uint64_t u0 = (uint64_t)u0_host;          // bits32(key, 0) >> 9, evaluated on the host
   const uint64_t D = (uint64_t)n << 23;
   if (total == 0) {
-    if (i == n - 1)
+    if (i0 <= n - 1 && n - 1 < i0 + RS_SRC_PER_THREAD)
       for (int64_t s = 0; s < n; ++s) anc[s] = (int32_t)(n - 1);
     return;
   }
   const double n_over_total = (double)n / (double)total;
   const double eps = (double)n * 0x1p-44 + 0x1p-40;
-  const uint64_t c_hi = in_range ? prefix + loc : total;
-  int64_t e = slots_below(kind, key, u0, c_hi, D, total, n_over_total, eps, n);
-  uint32_t e_lo = (uint32_t)e, e_hi32 = (uint32_t)((uint64_t)e >> 32);
+  int64_t e[RS_SRC_PER_THREAD];
+#pragma unroll
+  for (int c = 0; c < RS_SRC_PER_THREAD; ++c) {
+    const uint64_t c_hi = (i0 + c < n) ? prefix + loc[c] : total;
+    e[c] = slots_below(kind, key, u0, c_hi, D, total, n_over_total, eps, n);
+  }
+  // lower bound of the thread's first source = upper bound of the previous thread's last one
+  uint32_t e_lo = (uint32_t)e[RS_SRC_PER_THREAD - 1], e_hi32 = (uint32_t)((uint64_t)e[RS_SRC_PER_THREAD - 1] >> 32);
   e_lo = __shfl_up(e_lo, 1, GMX_WAVE); e_hi32 = __shfl_up(e_hi32, 1, GMX_WAVE);
   int64_t s = (int64_t)(((uint64_t)e_hi32 << 32) | e_lo);
-  if (lane == 0) {
-    // lower bound = upper bound of source i-1 (same tile unless i starts a tile)
-    s = slots_below(kind, key, u0, prefix + loc_prev, D, total, n_over_total, eps, n);
+  if (lane == 0) s = slots_below(kind, key, u0, prefix + loc_prev, D, total, n_over_total, eps, n);
+#pragma unroll
+  for (int c = 0; c < RS_SRC_PER_THREAD; ++c) {
+    if (i0 + c < n)
+      for (int64_t j = s; j < e[c]; ++j) anc[j] = (int32_t)(i0 + c);
+    s = e[c];
   }
-  if (!in_range) return;
-  for (int64_t j = s; j < e; ++j) anc[j] = (int32_t)i;
 }
 
 extern "C" int gmx_resample(int kind, const uint32_t key[2], const float* lw_d, int64_t n, int shift,
-                            const float* max_partials_d, int64_t n_partials, float* max_d,
+                            const float* max_partials_d, int64_t n_partials, uint32_t* max_bins_d, float* max_d,
                             uint64_t* total_d, int32_t* ancestors_d, void* workspace_d, gmx_stream stream) {
   if (n <= 0) return gmx_fail("gmx_resample: n must be positive%s");
   if (!key || !lw_d || !max_d || !total_d || !ancestors_d || !workspace_d)
@@ -1143,19 +1176,23 @@ extern "C" int gmx_resample(int kind, const uint32_t key[2], const float* lw_d, 
     return gmx_fail("gmx_resample: lw_d and workspace_d must be 16-byte aligned%s");
   hipStream_t st = (hipStream_t)stream;
   int max_mode = 0;
-  if (max_partials_d) {
+  if (max_bins_d) {
+    max_mode = 2;
+  } else if (max_partials_d) {
     if (n_partials <= 0) return gmx_fail("gmx_resample: n_partials must be positive%s");
     if (n_partials <= 16384) max_mode = 1;
     else hipLaunchKernelGGL(k_reduce_max, dim3(1), dim3(GMX_BLOCK), 0, st, max_partials_d, n_partials, max_d);
   }
   float scale = gmx_pow2i(shift);
-  hipLaunchKernelGGL(k_cdf_local, dim3((unsigned)tiles), dim3(GMX_BLOCK), 0, st, lw_d, n, scale, max_mode,
-                     max_partials_d, n_partials, max_d, (rs_ws*)workspace_d);
+  hipLaunchKernelGGL(k_cdf_local, dim3((unsigned)tiles), dim3(RS_THREADS), 0, st, lw_d, n, scale, max_mode,
+                     max_partials_d, n_partials, max_bins_d, max_d, (rs_ws*)workspace_d);
   uint32_t b0, b1;
   gmx_threefry2x32(key[0], key[1], 0u, 0u, &b0, &b1);           // bits32(key, 0) on the host
   const uint32_t u0 = (b0 ^ b1) >> 9;
-  hipLaunchKernelGGL(k_offspring_local, grid_for(n), dim3(GMX_BLOCK), 0, st, kind, key[0], key[1], u0,
-                     (const rs_ws*)workspace_d, n, (int)tiles, total_d, ancestors_d);
+  const int64_t per_block = (int64_t)GMX_BLOCK * RS_SRC_PER_THREAD;
+  hipLaunchKernelGGL(k_offspring_local, dim3((unsigned)((n + per_block - 1) / per_block)), dim3(GMX_BLOCK), 0, st,
+                     kind, key[0], key[1], u0, (const rs_ws*)workspace_d, n, (int)tiles, total_d, max_bins_d,
+                     ancestors_d);
   GMX_HIP(hipGetLastError());
   return 0;
 }

@@ -380,7 +380,8 @@ class BootstrapSweep:
         self.totals = torch.zeros((T,), dtype=torch.int64, device=dev)
         self.shift = cdf_shift(n)
         self.ws = torch.zeros(((be.c.gmx_weight_cdf_workspace(n) + 7) // 8,), dtype=torch.int64, device=dev)
-        self.fused = self.kind in (SYSTEMATIC, STRATIFIED) and n <= (2048 * 1024)
+        self.fused = self.kind in (SYSTEMATIC, STRATIFIED) and n <= (512 * 4096)
+        self.bins = torch.zeros((32,), dtype=torch.int32, device=dev)
         self.rs_ws = torch.zeros(((be.c.gmx_resample_workspace(n) + 7) // 8,), dtype=torch.int64, device=dev) \
             if self.fused else None
         obs0 = ChoiceMap.empty().set(self.obs_addr, self.ys[0])
@@ -413,7 +414,8 @@ class BootstrapSweep:
         bufs = [None] * len(prog.comp.outputs)
         bufs[prog.ro[1]] = xo.reshape(1, n)
         bufs[prog.wo[1]] = self.lw.reshape(1, n)
-        prog.comp.run(leaves, (n,), lazy_split(k_prop, n), red_out=self.partials, out_buffers=bufs)
+        prog.comp.run(leaves, (n,), lazy_split(k_prop, n), red_out=self.partials, out_buffers=bufs,
+                      red_bins=self.bins if self.fused else None)
 
     def _launch_cdf(self, t):
         be = _lib.get()
@@ -434,7 +436,7 @@ class BootstrapSweep:
         kh = self.step_keys[t][1].host()
         kk = (c_uint32 * 2)(int(kh[0]), int(kh[1]))
         be.check(be.c.gmx_resample(self.kind, kk, be.ptr(self.lw), self.n, self.shift, be.ptr(self.partials),
-                                   self.partials.shape[0], be.ptr(self.maxs[t:t + 1]),
+                                   self.partials.shape[0], be.ptr(self.bins), be.ptr(self.maxs[t:t + 1]),
                                    be.ptr(self.totals[t:t + 1]), be.ptr(self.anc), be.ptr(self.rs_ws),
                                    be.stream()), "gmx_resample")
 

@@ -119,7 +119,11 @@ typedef struct gmx_run_args {
   int64_t key_inner;
   int64_t index_offset;           /* global index of local particle 0 (sharding) */
   float* red_out_d;               /* [grid,2] block partials of OP_REDMAX/LSE     */
+  uint32_t* red_bins_d;           /* optional [GMX_RED_BINS]: OP_REDMAX also folds each block max in
+                                     with an atomic max on order-preserving keys (0 = empty);
+                                     gmx_resample consumes and clears them                        */
 } gmx_run_args;
+#define GMX_RED_BINS 32
 
 int gmx_program_create(const uint32_t* blob_h, size_t n_words, gmx_program** out);
 int gmx_program_destroy(gmx_program* p);
@@ -190,8 +194,11 @@ int gmx_ancestors(int kind, const uint32_t key[2], const uint64_t* cdf_d, int64_
  * log-weight and the integer total (for the evidence increment). */
 size_t gmx_resample_workspace(int64_t n);
 int gmx_resample(int kind, const uint32_t key[2], const float* lw_d, int64_t n, int shift,
-                 const float* max_partials_d, int64_t n_partials, float* max_d,
+                 const float* max_partials_d, int64_t n_partials, uint32_t* max_bins_d, float* max_d,
                  uint64_t* total_d, int32_t* ancestors_d, void* workspace_d, gmx_stream stream);
+/* max source, in order of preference: max_bins_d (GMX_RED_BINS keys left by a program's
+ * OP_REDMAX; cleared again before gmx_resample returns control to the stream), else
+ * max_partials_d (block partials), else *max_d as given. */
 int gmx_gather(const void* const* src_d, void* const* dst_d, const int32_t* elem_bytes,
                int32_t n_leaves, const int32_t* ancestors_d, int64_t n_out,
                gmx_stream stream);

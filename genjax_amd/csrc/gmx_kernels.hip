@@ -896,8 +896,7 @@ k_offspring(int kind, uint32_t k0, uint32_t k1, const uint64_t* __restrict__ cdf
   const uint64_t u0 = gmx_bits32(key, 0) >> 9;
   const uint64_t D = (uint64_t)n_out_total << 23;
   if (total == 0) {                       // no mass at all: everything maps to the last particle
-    if (i == n_in - 1)
-      for (int64_t s = 0; s < n_slots; ++s) anc[s] = (int32_t)(n_in - 1);
+    for (int64_t s = i; s < n_slots; s += (int64_t)gridDim.x * GMX_BLOCK) anc[s] = (int32_t)(n_in - 1);
     return;
   }
   const double n_over_total = (double)n_out_total / (double)total;
@@ -1131,9 +1130,10 @@ k_offspring_local(int kind, uint32_t k0, uint32_t k1, uint32_t u0_host, const rs
   gmx_key key; key.k0 = k0; key.k1 = k1;
   const uint64_t u0 = (uint64_t)u0_host;          // bits32(key, 0) >> 9, evaluated on the host
   const uint64_t D = (uint64_t)n << 23;
-  if (total == 0) {
-    if (i0 <= n - 1 && n - 1 < i0 + RS_SRC_PER_THREAD)
-      for (int64_t s = 0; s < n; ++s) anc[s] = (int32_t)(n - 1);
+  if (total == 0) {       // no mass at all (all weights -inf / NaN): every slot maps to the last particle
+#pragma unroll
+    for (int c = 0; c < RS_SRC_PER_THREAD; ++c)
+      if (i0 + c < n) anc[i0 + c] = (int32_t)(n - 1);
     return;
   }
   const double n_over_total = (double)n / (double)total;

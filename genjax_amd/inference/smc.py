@@ -455,7 +455,9 @@ class BootstrapSweep:
         t = max(1, self.T // 2)
         out = {"k_vm": lambda: self._launch_vm(t)}
         if self.fused:
-            out["resample(k_cdf_local+k_offspring_local)"] = lambda: self._launch_resample(t)
+            # the resampler consumes the max bins k_vm fills: time the pair
+            out["k_vm+resample(k_cdf_local+k_offspring_local)"] = \
+                lambda: (self._launch_vm(t), self._launch_resample(t))
         else:
             out["k_weight_cdf"] = lambda: self._launch_cdf(t)
             out["k_ancestors"] = lambda: self._launch_anc(t)

@@ -39,7 +39,6 @@ class RunArgs(Structure):
         ("key_inner", c_int64),
         ("index_offset", c_int64),
         ("red_out_d", c_void_p),
-        ("red_bins_d", c_void_p),
     ]
 
 
@@ -88,7 +87,7 @@ class Backend:
                                     c_int64, c_int64, c_int64, c_void_p, c_void_p]
         c.gmx_resample_workspace.argtypes = [c_int64]
         c.gmx_resample_workspace.restype = c_size_t
-        c.gmx_resample.argtypes = [c_int, POINTER(c_uint32), c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p, c_void_p,
+        c.gmx_resample.argtypes = [c_int, POINTER(c_uint32), c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p,
                                    c_void_p, c_void_p, c_void_p, c_void_p]
         c.gmx_gather.argtypes = [POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int32), c_int32,
                                  c_void_p, c_int64, c_void_p]

@@ -39,31 +39,20 @@ __device__ __forceinline__ float block_sum(float v, float* lds4) {
   return r;
 }
 
-// order-preserving map float -> uint32 (larger float <=> larger key; every key > 0)
-__device__ __forceinline__ uint32_t gmx_max_key(float x) {
-  uint32_t b = gmx_f2u(x);
-  return (b >> 31) ? ~b : (b | 0x80000000u);
-}
-__device__ __forceinline__ float gmx_max_unkey(uint32_t k) {
-  return gmx_u2f((k >> 31) ? (k & 0x7fffffffu) : ~k);
-}
-
-// OP_REDMAX / OP_REDLSE epilogues.  `row` = index of the 256-particle group.
-__device__ __forceinline__ void gmx_red_max(float* red_out, uint32_t* bins, float* lds4, uint32_t row, float x,
-                                            bool active) {
+// OP_REDMAX / OP_REDLSE epilogues.  `row` = index of the 256-particle group,
+// `rows` = number of groups; partials are planar: max[rows] then sumexp[rows].
+__device__ __forceinline__ void gmx_red_max(float* red_out, float* lds4, uint32_t row, float x, bool active) {
   float m = block_max(active ? x : -gmx_inf(), lds4);
-  if (threadIdx.x == 0) {
-    if (red_out) red_out[2 * (size_t)row] = m;
-    if (bins && !gmx_isnan(m)) atomicMax(&bins[row & 31u], gmx_max_key(m));
-  }
+  if (threadIdx.x == 0 && red_out) red_out[row] = m;
 }
-__device__ __forceinline__ void gmx_red_lse(float* red_out, float* lds4, uint32_t row, float x, bool active) {
+__device__ __forceinline__ void gmx_red_lse(float* red_out, float* lds4, uint32_t row, uint32_t rows, float x,
+                                            bool active) {
   float m = block_max(active ? x : -gmx_inf(), lds4);
   float e = active ? gmx_expf(x - m) : 0.0f;
   if (!(m > -gmx_inf())) e = 0.0f;  // empty / all -inf block
   float s = block_sum(e, lds4);
   if (threadIdx.x == 0 && red_out) {
-    red_out[2 * (size_t)row] = m;
-    red_out[2 * (size_t)row + 1] = s;
+    red_out[row] = m;
+    red_out[(size_t)rows + row] = s;
   }
 }

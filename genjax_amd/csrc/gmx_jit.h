@@ -25,16 +25,17 @@ struct gmx_jit_ctx {
   const gmx_run_args* A;
   float* lds4;
   uint32_t part;            // index of the 256-particle group this step works on (block partial row)
+  uint32_t rows;            // number of 256-particle groups = ceil(n / 256)
   __device__ __forceinline__ uint32_t pool(uint32_t i) const {
     return i < (uint32_t)NDYN ? A->uni[i] : consts[i - (uint32_t)NDYN];
   }
   __device__ __forceinline__ const void* in_ptr(uint32_t s) const { return A->in_d[s]; }
   __device__ __forceinline__ void* out_ptr(uint32_t s) const { return A->out_d[s]; }
   __device__ __forceinline__ const void* tab_ptr(uint32_t s) const { return A->tab_d[s]; }
-  __device__ __forceinline__ void red_max(float x, bool active) {
-    gmx_red_max(A->red_out_d, A->red_bins_d, lds4, part, x, active);
+  __device__ __forceinline__ void red_max(float x, bool active) { gmx_red_max(A->red_out_d, lds4, part, x, active); }
+  __device__ __forceinline__ void red_lse(float x, bool active) {
+    gmx_red_lse(A->red_out_d, lds4, part, rows, x, active);
   }
-  __device__ __forceinline__ void red_lse(float x, bool active) { gmx_red_lse(A->red_out_d, lds4, part, x, active); }
 };
 
 // PP particles per thread: PP independent instruction streams in one wave give
@@ -53,6 +54,7 @@ struct gmx_jit_ctx {
     constexpr bool full_v = FULLV;                                                               \
     ctx_t ctx;                                                                                   \
     ctx.consts = GMX_JIT_CONST; ctx.A = &A; ctx.lds4 = lds4; ctx.part = 0;                       \
+    ctx.rows = (uint32_t)((n + GMX_BLOCK - 1) / GMX_BLOCK);                       \
     regs_t R[PP];                                                                                \
     int64_t idx[PP];                                                                             \
     bool act[PP];                                                                                \

@@ -98,10 +98,10 @@ struct DevCtx {
     return (void*)(((uint64_t)hi << 32) | (uint64_t)lo);
   }
   __device__ __forceinline__ const void* tab_ptr(uint32_t s) const { return A->tab_d[s]; }
-  __device__ __forceinline__ void red_max(float x, bool active) {
-    gmx_red_max(red_out, A->red_bins_d, lds4, blockIdx.x, x, active);
+  __device__ __forceinline__ void red_max(float x, bool active) { gmx_red_max(red_out, lds4, blockIdx.x, x, active); }
+  __device__ __forceinline__ void red_lse(float x, bool active) {
+    gmx_red_lse(red_out, lds4, blockIdx.x, gridDim.x, x, active);
   }
-  __device__ __forceinline__ void red_lse(float x, bool active) { gmx_red_lse(red_out, lds4, blockIdx.x, x, active); }
 };
 
 template <class Regs, bool FULL>
@@ -349,8 +349,8 @@ extern "C" int gmx_program_run(const gmx_program* p, int64_t n, const gmx_run_ar
     if (!args->tab_d[s]) return gmx_fail("gmx_program_run: table slot %s%lld is null", "", s);
   if (p->uses_gather && !args->ancestors_d)
     return gmx_fail("gmx_program_run: program gathers but ancestors_d is null%s");
-  if (p->uses_red && !args->red_out_d && !args->red_bins_d)
-    return gmx_fail("gmx_program_run: program reduces but red_out_d and red_bins_d are null%s");
+  if (p->uses_red && !args->red_out_d)
+    return gmx_fail("gmx_program_run: program reduces but red_out_d is null%s");
   if (p->uses_key) {
     int km = args->key_mode;
     if (km != GMX_KEY_ARRAY && km != GMX_KEY_SPLIT && km != GMX_KEY_ROWSPLIT && km != GMX_KEY_BCAST)
@@ -645,7 +645,7 @@ __global__ void __launch_bounds__(GMX_BLOCK)
 k_reduce_max(const float* __restrict__ partials, int64_t n_part, float* __restrict__ max_out) {
   __shared__ float lds4[4];
   float m = -gmx_inf();
-  for (int64_t j = threadIdx.x; j < n_part; j += GMX_BLOCK) m = gmx_fmax(m, partials[2 * j]);
+  for (int64_t j = threadIdx.x; j < n_part; j += GMX_BLOCK) m = gmx_fmax(m, partials[j]);
   m = block_max(m, lds4);
   if (threadIdx.x == 0) *max_out = m;
 }
@@ -684,7 +684,7 @@ k_weight_cdf(const float* __restrict__ lw, int64_t n, float scale, int max_mode,
   float M;
   if (max_mode == 1) {
     float m = -gmx_inf();
-    for (int64_t j = threadIdx.x; j < n_part; j += CDF_THREADS) m = gmx_fmax(m, partials[2 * j]);
+    for (int64_t j = threadIdx.x; j < n_part; j += CDF_THREADS) m = gmx_fmax(m, partials[j]);
     m = wave_max(m);
     if (lane == 0) s_max[wave] = m;
     __syncthreads();
@@ -1006,12 +1006,10 @@ extern "C" size_t gmx_resample_workspace(int64_t n) {
   return sizeof(uint64_t) * (RS_MAX_TILES + (size_t)n + 8);
 }
 
-// max_mode: 0 = read *max_d; 1 = block partials (column 0 of partials[n_part][2]);
-//           2 = GMX_RED_BINS atomic-max keys (one 128-byte line)
+// max_mode: 0 = read *max_d; 1 = reduce the n_part dense block maxima
 __global__ void __launch_bounds__(RS_THREADS)
 k_cdf_local(const float* __restrict__ lw, int64_t n, float scale, int max_mode,
-            const float* __restrict__ partials, int64_t n_part, const uint32_t* __restrict__ bins,
-            float* __restrict__ max_d, rs_ws* ws) {
+            const float* __restrict__ partials, int64_t n_part, float* __restrict__ max_d, rs_ws* ws) {
   __shared__ uint64_t s_part[RS_THREADS / GMX_WAVE];
   __shared__ float s_max[RS_THREADS / GMX_WAVE];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1026,19 +1024,14 @@ k_cdf_local(const float* __restrict__ lw, int64_t n, float scale, int max_mode,
     for (int c = 0; c < CDF_VEC; ++c) x[c] = (base + c < n) ? lw[base + c] : -gmx_inf();
   }
   float M;
-  if (max_mode == 2) {
-    uint32_t k = bins[lane & 31];
-    float m = k ? gmx_max_unkey(k) : -gmx_inf();
-    M = wave_max(m);                               // every wave: one 128-B line, no barrier
-    if (tile == 0 && threadIdx.x == 0) *max_d = M;
-  } else if (max_mode == 1) {
+  if (max_mode == 1) {
     float m = -gmx_inf();
     for (int64_t j0 = 0; j0 < n_part; j0 += 4 * RS_THREADS) {
       float v[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         int64_t j = j0 + (int64_t)r * RS_THREADS + threadIdx.x;
-        v[r] = (j < n_part) ? partials[2 * j] : -gmx_inf();
+        v[r] = (j < n_part) ? partials[j] : -gmx_inf();
       }
       m = gmx_fmax(gmx_fmax(m, gmx_fmax(v[0], v[1])), gmx_fmax(v[2], v[3]));
     }
@@ -1094,13 +1087,11 @@ k_cdf_local(const float* __restrict__ lw, int64_t n, float scale, int max_mode,
 // re-read the <= 512 tile aggregates.
 __global__ void __launch_bounds__(GMX_BLOCK)
 k_offspring_local(int kind, uint32_t k0, uint32_t k1, uint32_t u0_host, const rs_ws* __restrict__ ws, int64_t n,
-                  int n_tiles, uint64_t* __restrict__ total_out, uint32_t* __restrict__ bins_to_clear,
-                  int32_t* __restrict__ anc) {
+                  int n_tiles, uint64_t* __restrict__ total_out, int32_t* __restrict__ anc) {
   __shared__ uint64_t s_below[4], s_all[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t i0 = ((int64_t)blockIdx.x * GMX_BLOCK + threadIdx.x) * RS_SRC_PER_THREAD;
   const int my_tile = (int)(((int64_t)blockIdx.x * GMX_BLOCK * RS_SRC_PER_THREAD) / RS_TILE);
-  if (bins_to_clear && blockIdx.x == 0 && threadIdx.x < GMX_RED_BINS) bins_to_clear[threadIdx.x] = 0u;
   // issue every load first
   uint64_t below = 0, all = 0;
 #pragma unroll
@@ -1158,7 +1149,7 @@ k_offspring_local(int kind, uint32_t k0, uint32_t k1, uint32_t u0_host, const rs
 }
 
 extern "C" int gmx_resample(int kind, const uint32_t key[2], const float* lw_d, int64_t n, int shift,
-                            const float* max_partials_d, int64_t n_partials, uint32_t* max_bins_d, float* max_d,
+                            const float* max_partials_d, int64_t n_partials, float* max_d,
                             uint64_t* total_d, int32_t* ancestors_d, void* workspace_d, gmx_stream stream) {
   if (n <= 0) return gmx_fail("gmx_resample: n must be positive%s");
   if (!key || !lw_d || !max_d || !total_d || !ancestors_d || !workspace_d)
@@ -1176,23 +1167,20 @@ extern "C" int gmx_resample(int kind, const uint32_t key[2], const float* lw_d, 
     return gmx_fail("gmx_resample: lw_d and workspace_d must be 16-byte aligned%s");
   hipStream_t st = (hipStream_t)stream;
   int max_mode = 0;
-  if (max_bins_d) {
-    max_mode = 2;
-  } else if (max_partials_d) {
+  if (max_partials_d) {
     if (n_partials <= 0) return gmx_fail("gmx_resample: n_partials must be positive%s");
     if (n_partials <= 16384) max_mode = 1;
     else hipLaunchKernelGGL(k_reduce_max, dim3(1), dim3(GMX_BLOCK), 0, st, max_partials_d, n_partials, max_d);
   }
   float scale = gmx_pow2i(shift);
   hipLaunchKernelGGL(k_cdf_local, dim3((unsigned)tiles), dim3(RS_THREADS), 0, st, lw_d, n, scale, max_mode,
-                     max_partials_d, n_partials, max_bins_d, max_d, (rs_ws*)workspace_d);
+                     max_partials_d, n_partials, max_d, (rs_ws*)workspace_d);
   uint32_t b0, b1;
   gmx_threefry2x32(key[0], key[1], 0u, 0u, &b0, &b1);           // bits32(key, 0) on the host
   const uint32_t u0 = (b0 ^ b1) >> 9;
   const int64_t per_block = (int64_t)GMX_BLOCK * RS_SRC_PER_THREAD;
   hipLaunchKernelGGL(k_offspring_local, dim3((unsigned)((n + per_block - 1) / per_block)), dim3(GMX_BLOCK), 0, st,
-                     kind, key[0], key[1], u0, (const rs_ws*)workspace_d, n, (int)tiles, total_d, max_bins_d,
-                     ancestors_d);
+                     kind, key[0], key[1], u0, (const rs_ws*)workspace_d, n, (int)tiles, total_d, ancestors_d);
   GMX_HIP(hipGetLastError());
   return 0;
 }

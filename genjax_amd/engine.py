@@ -300,8 +300,7 @@ class Compiled:
         self._jit_tried = True
         return be.c.gmx_program_specialize(self.handle) == 0
 
-    def run(self, leaves, batch: tuple, key: Key | None, red_out=None, index_offset=0, out_buffers=None,
-            red_bins=None):
+    def run(self, leaves, batch: tuple, key: Key | None, red_out=None, index_offset=0, out_buffers=None):
         """Bind and launch.  Returns the list of output tensors (shape batch+event)."""
         be = self._be
         n = int(np.prod(batch, dtype=np.int64))
@@ -374,12 +373,10 @@ class Compiled:
         else:
             A.key_mode = _lib.KEY_NONE
         A.index_offset = index_offset
-        if red_bins is not None:
-            A.red_bins_d = red_bins.data_ptr()
         if self.uses_red:
             if red_out is None:
                 grid = be.c.gmx_program_grid(self.handle, n)
-                red_out = torch.empty((grid, 2), dtype=torch.float32, device=be.device)
+                red_out = torch.empty((2, grid), dtype=torch.float32, device=be.device)
             A.red_out_d = red_out.data_ptr()
             self.last_red = red_out
         be.check(be.c.gmx_program_run(self.handle, n, A, be.stream()), "gmx_program_run")

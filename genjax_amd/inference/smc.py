@@ -260,7 +260,7 @@ def weight_cdf(lw: torch.Tensor, n_total=None, max_partials=None):
         be.check(be.c.gmx_weight_cdf(be.ptr(lw), n, shift, None, 0, be.ptr(mx), be.ptr(cdf), be.ptr(total),
                                      be.ptr(ws), be.stream()), "gmx_weight_cdf")
     else:
-        be.check(be.c.gmx_weight_cdf(be.ptr(lw), n, shift, be.ptr(max_partials), max_partials.shape[0],
+        be.check(be.c.gmx_weight_cdf(be.ptr(lw), n, shift, be.ptr(max_partials), max_partials.shape[-1],
                                      be.ptr(mx), be.ptr(cdf), be.ptr(total), be.ptr(ws), be.stream()),
                  "gmx_weight_cdf")
     return cdf, total, mx, shift
@@ -381,7 +381,6 @@ class BootstrapSweep:
         self.shift = cdf_shift(n)
         self.ws = torch.zeros(((be.c.gmx_weight_cdf_workspace(n) + 7) // 8,), dtype=torch.int64, device=dev)
         self.fused = self.kind in (SYSTEMATIC, STRATIFIED) and n <= (512 * 4096)
-        self.bins = torch.zeros((32,), dtype=torch.int32, device=dev)
         self.rs_ws = torch.zeros(((be.c.gmx_resample_workspace(n) + 7) // 8,), dtype=torch.int64, device=dev) \
             if self.fused else None
         obs0 = ChoiceMap.empty().set(self.obs_addr, self.ys[0])
@@ -392,7 +391,7 @@ class BootstrapSweep:
             self.p_init.comp.specialize()
             self.p_step.comp.specialize()
         grid = be.c.gmx_program_grid(self.p_step.comp.handle, n)
-        self.partials = torch.zeros((grid, 2), dtype=torch.float32, device=dev)
+        self.partials = torch.zeros((2, grid), dtype=torch.float32, device=dev)
         # per-step keys on the host
         self.step_keys = []
         for t in range(T):
@@ -414,13 +413,12 @@ class BootstrapSweep:
         bufs = [None] * len(prog.comp.outputs)
         bufs[prog.ro[1]] = xo.reshape(1, n)
         bufs[prog.wo[1]] = self.lw.reshape(1, n)
-        prog.comp.run(leaves, (n,), lazy_split(k_prop, n), red_out=self.partials, out_buffers=bufs,
-                      red_bins=self.bins if self.fused else None)
+        prog.comp.run(leaves, (n,), lazy_split(k_prop, n), red_out=self.partials, out_buffers=bufs)
 
     def _launch_cdf(self, t):
         be = _lib.get()
         be.check(be.c.gmx_weight_cdf(be.ptr(self.lw), self.n, self.shift, be.ptr(self.partials),
-                                     self.partials.shape[0], be.ptr(self.maxs[t:t + 1]), be.ptr(self.cdf),
+                                     self.partials.shape[1], be.ptr(self.maxs[t:t + 1]), be.ptr(self.cdf),
                                      be.ptr(self.totals[t:t + 1]), be.ptr(self.ws), be.stream()),
                  "gmx_weight_cdf")
 
@@ -436,7 +434,7 @@ class BootstrapSweep:
         kh = self.step_keys[t][1].host()
         kk = (c_uint32 * 2)(int(kh[0]), int(kh[1]))
         be.check(be.c.gmx_resample(self.kind, kk, be.ptr(self.lw), self.n, self.shift, be.ptr(self.partials),
-                                   self.partials.shape[0], be.ptr(self.bins), be.ptr(self.maxs[t:t + 1]),
+                                   self.partials.shape[1], be.ptr(self.maxs[t:t + 1]),
                                    be.ptr(self.totals[t:t + 1]), be.ptr(self.anc), be.ptr(self.rs_ws),
                                    be.stream()), "gmx_resample")
 
@@ -455,9 +453,7 @@ class BootstrapSweep:
         t = max(1, self.T // 2)
         out = {"k_vm": lambda: self._launch_vm(t)}
         if self.fused:
-            # the resampler consumes the max bins k_vm fills: time the pair
-            out["k_vm+resample(k_cdf_local+k_offspring_local)"] = \
-                lambda: (self._launch_vm(t), self._launch_resample(t))
+            out["resample(k_cdf_local+k_offspring_local)"] = lambda: self._launch_resample(t)
         else:
             out["k_weight_cdf"] = lambda: self._launch_cdf(t)
             out["k_ancestors"] = lambda: self._launch_anc(t)

@@ -118,12 +118,9 @@ typedef struct gmx_run_args {
   const uint32_t* keys_d;
   int64_t key_inner;
   int64_t index_offset;           /* global index of local particle 0 (sharding) */
-  float* red_out_d;               /* [grid,2] block partials of OP_REDMAX/LSE     */
-  uint32_t* red_bins_d;           /* optional [GMX_RED_BINS]: OP_REDMAX also folds each block max in
-                                     with an atomic max on order-preserving keys (0 = empty);
-                                     gmx_resample consumes and clears them                        */
+  float* red_out_d;               /* [2][grid] block partials of OP_REDMAX/LSE: plane 0 = block max,
+                                     plane 1 = sum exp(x - block max); grid = gmx_program_grid()  */
 } gmx_run_args;
-#define GMX_RED_BINS 32
 
 int gmx_program_create(const uint32_t* blob_h, size_t n_words, gmx_program** out);
 int gmx_program_destroy(gmx_program* p);
@@ -176,8 +173,8 @@ enum { GMX_RESAMPLE_SYSTEMATIC = 0, GMX_RESAMPLE_STRATIFIED = 1, GMX_RESAMPLE_MU
 
 size_t gmx_weight_cdf_workspace(int64_t n);
 /* max_d: device scalar (max over ALL shards' log-weights); if max_partials_d
- * is non-null the max is first reduced from n_partials [*,2] block partials
- * written by a program's OP_REDMAX (column 0) and stored to max_d. */
+ * is non-null the max is first reduced from the n_partials block maxima
+ * a program's OP_REDMAX wrote (plane 0 of red_out_d) and stored to max_d. */
 int gmx_weight_cdf(const float* lw_d, int64_t n, int shift,
                    const float* max_partials_d, int64_t n_partials, float* max_d,
                    uint64_t* cdf_d /* [n] inclusive */, uint64_t* total_d /* [1] */,
@@ -194,11 +191,8 @@ int gmx_ancestors(int kind, const uint32_t key[2], const uint64_t* cdf_d, int64_
  * log-weight and the integer total (for the evidence increment). */
 size_t gmx_resample_workspace(int64_t n);
 int gmx_resample(int kind, const uint32_t key[2], const float* lw_d, int64_t n, int shift,
-                 const float* max_partials_d, int64_t n_partials, uint32_t* max_bins_d, float* max_d,
+                 const float* max_partials_d, int64_t n_partials, float* max_d,
                  uint64_t* total_d, int32_t* ancestors_d, void* workspace_d, gmx_stream stream);
-/* max source, in order of preference: max_bins_d (GMX_RED_BINS keys left by a program's
- * OP_REDMAX; cleared again before gmx_resample returns control to the stream), else
- * max_partials_d (block partials), else *max_d as given. */
 int gmx_gather(const void* const* src_d, void* const* dst_d, const int32_t* elem_bytes,
                int32_t n_leaves, const int32_t* ancestors_d, int64_t n_out,
                gmx_stream stream);

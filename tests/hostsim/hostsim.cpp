@@ -48,8 +48,6 @@ extern "C" int gmx_random_bits(const uint32_t* keys, int64_t n, int64_t m, uint3
   return 0;
 }
 
-static uint32_t max_key(float x) { uint32_t b = gmx_f2u(x); return (b >> 31) ? ~b : (b | 0x80000000u); }
-static float max_unkey(uint32_t k) { return gmx_u2f((k >> 31) ? (k & 0x7fffffffu) : ~k); }
 
 // ---- programs ----
 struct gmx_program { std::vector<uint32_t> code, consts; uint32_t n_instr, n_regs, n_in, n_out, n_uni, n_tab, n_const, n_dyn; };
@@ -115,16 +113,15 @@ extern "C" int gmx_program_run(const gmx_program* p, int64_t n, const gmx_run_ar
       gmx_vm_run<gmx_regs_vgpr<32>, true, -1, HostCtx>(p->n_instr, i, i < n, *A, ctx);
       if (ctx.kind) kind = ctx.kind;
     }
-    if (kind && (A->red_out_d || A->red_bins_d)) {
+    if (kind && A->red_out_d) {
       float m = -gmx_inf();
       for (int t = 0; t < 256; ++t) m = gmx_fmax(m, red[t]);
-      if (A->red_out_d) A->red_out_d[2*blk] = m;
-      if (A->red_bins_d && !gmx_isnan(m)) { uint32_t k = max_key(m); uint32_t* b = &A->red_bins_d[blk & 31]; if (k > *b) *b = k; }
+      A->red_out_d[blk] = m;
       if (kind == 2) {
         float e[256];
         for (int t = 0; t < 256; ++t) e[t] = (red[t] > -gmx_inf() && m > -gmx_inf()) ? gmx_expf(red[t] - m) : 0.0f;
         float w0 = butterfly_sum64(e), w1 = butterfly_sum64(e + 64), w2 = butterfly_sum64(e + 128), w3 = butterfly_sum64(e + 192);
-        if (A->red_out_d) A->red_out_d[2*blk+1] = (w0 + w1) + (w2 + w3);
+        A->red_out_d[grid + blk] = (w0 + w1) + (w2 + w3);
       }
     }
   }
@@ -156,7 +153,7 @@ extern "C" int gmx_weight_cdf(const float* lw, int64_t n, int shift, const float
   if (n <= 0) return fail("weight_cdf: n");
   int need = 0; while (((int64_t)1 << need) < n) ++need;
   if (shift + need > 62) return fail("weight_cdf: shift too large");
-  if (parts) { float m = -gmx_inf(); for (int64_t j = 0; j < n_parts; ++j) m = gmx_fmax(m, parts[2*j]); *max_d = m; }
+  if (parts) { float m = -gmx_inf(); for (int64_t j = 0; j < n_parts; ++j) m = gmx_fmax(m, parts[j]); *max_d = m; }
   float M = *max_d, scale = gmx_pow2i(shift);
   uint64_t run = 0;
   for (int64_t i = 0; i < n; ++i) {
@@ -193,14 +190,8 @@ extern "C" int gmx_ancestors(int kind, const uint32_t key[2], const uint64_t* cd
 }
 extern "C" size_t gmx_resample_workspace(int64_t n) { return 8 * (512 + 8 + (size_t)(n < 1 ? 1 : n)); }
 extern "C" int gmx_resample(int kind, const uint32_t key[2], const float* lw, int64_t n, int shift, const float* parts,
-                            int64_t n_parts, uint32_t* bins, float* max_d, uint64_t* total, int32_t* anc, void* ws,
-                            gmx_stream st) {
+                            int64_t n_parts, float* max_d, uint64_t* total, int32_t* anc, void* ws, gmx_stream st) {
   if (kind == GMX_RESAMPLE_MULTINOMIAL) return fail("resample: kind");
-  if (bins) {
-    float m = -gmx_inf();
-    for (int b = 0; b < GMX_RED_BINS; ++b) { if (bins[b]) m = gmx_fmax(m, max_unkey(bins[b])); bins[b] = 0; }
-    *max_d = m; parts = nullptr;
-  }
   uint64_t* cdf = (uint64_t*)ws + 512;
   if (gmx_weight_cdf(lw, n, shift, parts, n_parts, max_d, cdf, total, nullptr, st)) return 1;
   return gmx_ancestors(kind, key, cdf, n, 0, total, n, 0, n, anc, st);

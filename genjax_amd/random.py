@@ -58,8 +58,12 @@ class Key:
               ("rowsplit", rows Key (batch (B,)), inner)   -> shape (B, inner)
     """
 
-    def __init__(self, host=None, dev=None, lazy=None):
+    def __init__(self, host=None, dev=None, lazy=None, split_last=False):
         self._host, self._dev, self._lazy = host, dev, lazy
+        # result of split() over a BATCH of keys: `a, b = split(keys)` and
+        # `split(keys)[i]` address the split axis (the last one), which is what
+        # the same code sees per instance under jax.vmap
+        self._split_last = split_last
 
     # -- shape -----------------------------------------------------------
     @property
@@ -117,8 +121,8 @@ class Key:
         if self._lazy is None:
             return self
         if self.size <= _HOST_LIMIT:
-            return Key(host=self.host())
-        return Key(dev=self.data().reshape(self.shape + (2,)))
+            return Key(host=self.host(), split_last=self._split_last)
+        return Key(dev=self.data().reshape(self.shape + (2,)), split_last=self._split_last)
 
     def reshape(self, *shape) -> "Key":
         shape = tuple(shape[0]) if len(shape) == 1 and isinstance(shape[0], (tuple, list)) else tuple(shape)
@@ -129,6 +133,11 @@ class Key:
 
     # -- indexing ----------------------------------------------------------
     def __getitem__(self, idx):
+        if self._split_last and isinstance(idx, (int, np.integer)) and len(self.shape) > 1:
+            m = self.materialize()
+            if m._host is not None:
+                return Key(host=m._host[..., int(idx), :])
+            return Key(dev=m._dev[..., int(idx), :])
         if self._lazy is not None:
             kind, base, n = self._lazy
             if kind == "split" and isinstance(idx, (int, np.integer)):
@@ -142,7 +151,8 @@ class Key:
         return Key(dev=self._dev[idx + (slice(None),)])
 
     def __iter__(self):
-        for i in range(self.shape[0]):
+        n = self.shape[-1] if self._split_last else self.shape[0]
+        for i in range(n):
             yield self[i]
 
     # -- binding for gmx_program_run ----------------------------------------
@@ -179,12 +189,14 @@ def split(k: Key, num: int = 2) -> Key:
             return Key(host=_derive_host(k.host()[None, :], np.arange(num, dtype=np.uint64)))
         return Key(lazy=("split", k, num))
     if k.size * num <= _HOST_LIMIT and k._host is not None:
-        return Key(host=_derive_host(k._host[..., None, :], np.arange(num, dtype=np.uint64)))
+        return Key(host=_derive_host(k._host[..., None, :], np.arange(num, dtype=np.uint64)), split_last=True)
     flat = k.reshape((k.size,))
-    out = Key(lazy=("rowsplit", flat, num))
+    out = Key(lazy=("rowsplit", flat, num), split_last=True)
     if len(k.shape) == 1:
         return out
-    return out.reshape(k.shape + (num,))
+    out = out.reshape(k.shape + (num,))
+    out._split_last = True
+    return out
 
 
 def lazy_split(k: Key, num: int) -> Key:

@@ -296,6 +296,7 @@ class _Ctx:
         self.tr = tr
         self.changed: set = set()        # node indices whose value differs from the previous trace
         self.memo: dict = {}
+        self.store_sites = True          # False: the caller stores only what it needs (MinimalGenerate)
 
     def mark_changed(self, v):
         for n in _nodes_of(v):
@@ -307,10 +308,28 @@ class _Ctx:
 
 
 class _SiteRec:
-    __slots__ = ("gen_fn", "value", "score", "discard")
+    __slots__ = ("gen_fn", "value", "score", "discard", "origins")
 
     def __init__(self, gen_fn, value, score, discard=None):
         self.gen_fn, self.value, self.score, self.discard = gen_fn, value, score, discard
+        self.origins = None          # (value, score, discard) origins once stored
+
+
+def _origin_of(tr, v):
+    if v is None:
+        return None
+    if isinstance(v, Sym) and v.origin is not None:
+        return v.origin
+    return tr.emit_output(v.value if isinstance(v, Sym) else v)
+
+
+def _store_site(ctx, rec: "_SiteRec"):
+    """Emit the site's stores NOW (program order), so its registers die here
+    instead of staying live until the end of the program."""
+    if ctx.store_sites and rec.origins is None:
+        tr = ctx.tr
+        rec.origins = (_origin_of(tr, rec.value), _origin_of(tr, rec.score), _origin_of(tr, rec.discard))
+    return rec
 
 
 class _CallRec:
@@ -445,6 +464,8 @@ def _leaf_call(ctx: _Ctx, mode, dist, key, args, constraint: ChoiceMap, prev, re
         fwd_args = req.argmap(ChoiceMap.choice(pv))
         if not isinstance(fwd_args, tuple):
             fwd_args = (fwd_args,)
+        keep = ctx.store_sites
+        ctx.store_sites = False          # the proposal's own trace is never materialised
         prec, pret, _, pscore = call_gen_fn(ctx, "simulate", req.proposal, sub, fwd_args, ChoiceMap.empty(),
                                             None, None, None, ())
         proposed = _rec_choices(prec)
@@ -459,6 +480,7 @@ def _leaf_call(ctx: _Ctx, mode, dist, key, args, constraint: ChoiceMap, prev, re
             bwd_args = (bwd_args,)
         _, _, _, bwd_score = call_gen_fn(ctx, "assess", req.proposal, None, bwd_args, ChoiceMap.choice(pv),
                                          None, None, None, ())
+        ctx.store_sites = keep
         final = (w + bwd_score) - fwd_score
         ctx.mark_changed(nv)
         del k_new
@@ -498,7 +520,9 @@ def call_gen_fn(ctx, mode, gen_fn, key, args, constraint, prev, req, req_leaves,
             req = req.subs.get((), _ReqSpec("empty"))
             if req.kind == "update":
                 constraint = req.constraint
-        return _leaf_call(ctx, mode, gen_fn, key, args, constraint, prev, req, req_leaves)
+        out = _leaf_call(ctx, mode, gen_fn, key, args, constraint, prev, req, req_leaves)
+        _store_site(ctx, out[0])
+        return out
     if isinstance(gen_fn, StaticGenerativeFunction):
         h = Handler(ctx, mode, key, constraint, prev, req, req_leaves)
         h.rec = _CallRec(gen_fn)
@@ -540,16 +564,12 @@ def _sym_constraint(tree, syms) -> ChoiceMap:
 
 
 def _emit_rec(tr: Tracing, rec):
-    """Emit outputs for every site; returns an origin tree mirroring rec."""
+    """Origins of every site (stores were emitted as the sites were traced;
+    anything not stored yet is stored here); mirrors rec."""
     if isinstance(rec, _SiteRec):
-        v = rec.value
-        vo = v.origin if isinstance(v, Sym) and v.origin is not None else tr.emit_output(v.value if isinstance(v, Sym) else v)
-        s = rec.score
-        so = s.origin if isinstance(s, Sym) and s.origin is not None else tr.emit_output(s.value if isinstance(s, Sym) else s)
-        do = None
-        if rec.discard is not None:
-            d = rec.discard
-            do = d.origin if isinstance(d, Sym) and d.origin is not None else tr.emit_output(d.value if isinstance(d, Sym) else d)
+        if rec.origins is None:
+            rec.origins = (_origin_of(tr, rec.value), _origin_of(tr, rec.score), _origin_of(tr, rec.discard))
+        vo, so, do = rec.origins
         return ("site", rec.gen_fn, vo, so, do)
     subs = OrderedDict((a, _emit_rec(tr, r)) for a, r in rec.sites.items())
     return ("call", rec.gen_fn, subs, tr.emit_output(rec.retval))
@@ -602,6 +622,7 @@ def run_gfi(gen_fn, mode, key: Key | None, args, constraint: ChoiceMap | None = 
     if ent is None:
         tr = Tracing(len(batch))
         ctx = _Ctx(tr)
+        ctx.store_sites = mode != "assess"
         with T.tracing(tr.graph):
             syms = [tr.sym_leaf(s, j) for j, s in enumerate(specs)]
             sargs = unflatten(atree, lambda j: syms[j].value)
@@ -639,6 +660,7 @@ class MinimalGenerate:
         self.specs = tuple(leaf_spec(v, batch) for v in flat.leaves)
         tr = Tracing(len(batch))
         ctx = _Ctx(tr)
+        ctx.store_sites = False
         with T.tracing(tr.graph):
             syms = [tr.sym_leaf(s, j) for j, s in enumerate(self.specs)]
             sargs = unflatten(self.atree, lambda j: syms[j].value)

@@ -1,0 +1,526 @@
+"""Host-logic tests (no GPU): the Python layer — tracer, site-program encoder,
+binding plans, GFI semantics, SMC combinators — runs against tests/hostsim (the
+product's own interpreter template compiled for the host) and is checked
+against the reference's behavioural tests and the CPU oracle.
+
+Models and tolerances follow the reference's tests:
+  tests/generative_functions/test_distributions.py, test_static_gen_fn.py,
+  tests/inference/test_smc.py, test_requests.py, README.md:88-123.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import genjax_amd as genjax
+from genjax_amd import ChoiceMapBuilder as C
+from genjax_amd import SelectionBuilder as S
+from genjax_amd import numpy as jnp
+from oracle import genjax_oracle as O
+
+pytestmark = pytest.mark.usefixtures("hostsim")
+
+
+def f(x):
+    return float(x) if not isinstance(x, torch.Tensor) else float(x.item())
+
+
+# ---------------------------------------------------------------------------
+# choice maps / selections (core/generative/choice_map.py)
+# ---------------------------------------------------------------------------
+class TestChoiceMap:
+    def test_builders_and_lookup(self):
+        chm = C["a", "b"].set(1.0) | C["c"].set(2.0)
+        assert chm["a", "b"] == 1.0 and chm["c"] == 2.0
+        assert ("a", "b") in chm and "zz" not in chm
+        assert chm("a")["b"] == 1.0
+        assert genjax.ChoiceMap.kw(x=3)["x"] == 3
+        assert genjax.ChoiceMap.d({"x": 1, ("y", "z"): 2})["y", "z"] == 2
+        assert genjax.ChoiceMap.empty().static_is_empty()
+        assert C.v(5.0).get_value() == 5.0
+        assert chm.at["d"].set(4.0)["d"] == 4.0
+        with pytest.raises(genjax.ChoiceMapNoValueAtAddress):
+            chm["nope"]
+
+    def test_merge_first_wins(self):
+        a, b = C["x"].set(1.0), C["x"].set(2.0) | C["y"].set(3.0)
+        m = a | b
+        assert m["x"] == 1.0 and m["y"] == 3.0          # Or.build: first operand wins
+
+    def test_filter_and_selection(self):
+        chm = C.kw(x=1.0, y=2.0) | C["z", "w"].set(3.0)
+        assert chm.filter(S["x"]).to_dict() == {"x": 1.0}
+        assert set(chm.filter(~S["x"]).to_dict()) == {"y", ("z", "w")}
+        assert set(chm.filter(S["x"] | S["z"]).to_dict()) == {"x", ("z", "w")}
+        assert chm.filter(S["x"] & S["y"]).static_is_empty()
+        sel = chm.get_selection()
+        assert sel["x"] and sel["z", "w"] and not sel["q"]
+        assert genjax.Selection.all()["anything"] and not genjax.Selection.none()["anything"]
+        assert () in genjax.Selection.all()("x")
+
+    def test_target_filter_to_unconstrained(self):
+        @genjax.gen
+        def m():
+            x = genjax.normal(0.0, 1.0) @ "x"
+            _ = genjax.normal(x, 1.0) @ "y"
+        t = genjax.Target(m, (), C["y"].set(3.0))
+        assert set(t.filter_to_unconstrained(C.kw(x=1.0, y=3.0)).to_dict()) == {"x"}
+        assert t["y"] == 3.0
+
+
+# ---------------------------------------------------------------------------
+# distributions as generative functions (test_distributions.py:25-193)
+# ---------------------------------------------------------------------------
+class TestDistributions:
+    def test_simulate_score_is_assess(self):
+        key = genjax.key(314159)
+        for dist, args in [(genjax.normal, (0.0, 1.0)), (genjax.beta, (2.0, 3.0)), (genjax.flip, (0.3,)),
+                           (genjax.uniform, (-1.0, 2.0))]:
+            tr = dist.simulate(key, args)
+            score, v = dist.assess(tr.get_choices(), args)
+            assert f(tr.get_score()) == f(score)
+
+    def test_importance_rules(self):
+        key = genjax.key(314159)
+        tr, w = genjax.normal.importance(key, genjax.ChoiceMap.empty(), (0.0, 1.0))
+        assert f(w) == 0.0                                  # unconstrained: w = 0
+        tr, w = genjax.normal.importance(key, C.v(1.0), (0.0, 1.0))
+        assert f(w) == pytest.approx(-0.5 - 0.9189385, abs=1e-6) and f(tr.get_score()) == f(w)
+        assert f(tr.get_choices().get_value()) == 1.0
+
+    def test_update_weights(self):
+        key = genjax.key(314159)
+        tr = genjax.normal.simulate(key, (0.0, 1.0))
+        old_v, old_s = f(tr.get_retval()), f(tr.get_score())
+        # no constraint, changed args: w = logpdf(old; new args) - old score
+        new_tr, w, _, bwd = genjax.Update(genjax.ChoiceMap.empty()).edit(key, tr, genjax.Diff.unknown_change((1.0, 1.0)))
+        assert f(w) == pytest.approx(f(genjax.normal.logpdf(old_v, 1.0, 1.0)) - old_s, abs=1e-6)
+        assert f(new_tr.get_retval()) == old_v
+        # constraint: w = logpdf(new) - old score, discard = old value
+        new_tr, w, _, bwd = genjax.Update(C.v(1.0)).edit(key, tr, genjax.Diff.no_change((0.0, 1.0)))
+        assert f(w) == pytest.approx(f(genjax.normal.logpdf(1.0, 0.0, 1.0)) - old_s, abs=1e-6)
+        assert f(bwd.constraint.get_value()) == old_v
+
+    def test_kwargs_and_logit_warning(self):
+        key = genjax.key(0)
+        s1 = genjax.normal.assess(C.v(0.5), (0.0, 0.1))[0]
+
+        @genjax.gen
+        def m():
+            return genjax.normal(loc=0.0, scale=0.1) @ "x"
+        s2, _ = m.assess(C.kw(x=0.5), ())
+        assert f(s1) == f(s2)
+        with pytest.warns(DeprecationWarning):
+            @genjax.gen
+            def m2():
+                return genjax.categorical([0.0, 0.0]) @ "k"
+            m2.simulate(key, ())
+
+    def test_logpdfs_match_oracle_bitwise(self):
+        xs = np.linspace(-3, 3, 101).astype(np.float32)
+        got = genjax.normal.logpdf(torch.from_numpy(xs), 0.5, 1.5).numpy()
+        assert np.array_equal(got, O.normal.logpdf(xs, np.float32(0.5), np.float32(1.5)))
+        ps = np.linspace(0.01, 0.99, 99).astype(np.float32)
+        got = genjax.beta.logpdf(torch.from_numpy(ps), 2.0, 3.0).numpy()
+        assert np.array_equal(got, O.beta.logpdf(ps, np.float32(2.0), np.float32(3.0)))
+
+
+# ---------------------------------------------------------------------------
+# static language (test_static_gen_fn.py)
+# ---------------------------------------------------------------------------
+class TestStatic:
+    def test_reference_literal(self):
+        """test_static_gen_fn.py:317-318"""
+        @genjax.gen
+        def model():
+            y1 = genjax.normal(0.0, 1.0) @ "y1"
+            y2 = genjax.normal(0.0, 1.0) @ "y2"
+            return y1 + y2
+        score, retval = model.assess(C.kw(y1=1.0, y2=-1.0), ())
+        assert f(score) == pytest.approx(-2.837877, abs=5e-7)
+        assert f(retval) == 0.0
+
+    def test_score_is_sum_of_site_logpdfs(self):
+        @genjax.gen
+        def model():
+            y1 = genjax.normal(0.0, 1.0) @ "y1"
+            y2 = genjax.normal(y1, 1.0) @ "y2"
+            return y1 + y2
+        key = genjax.key(314159)
+        tr = model.simulate(key, ())
+        ch = tr.get_choices()
+        s = f(genjax.normal.logpdf(ch["y1"], 0.0, 1.0)) + f(genjax.normal.logpdf(ch["y2"], ch["y1"], 1.0))
+        assert f(tr.get_score()) == pytest.approx(s, abs=1e-6)
+        score, _ = model.assess(ch, ())
+        assert f(score) == f(tr.get_score())
+        assert f(tr.get_retval()) == pytest.approx(f(ch["y1"]) + f(ch["y2"]))
+
+    def test_missing_address_and_reuse(self):
+        @genjax.gen
+        def model():
+            y1 = genjax.normal(0.0, 1.0) @ "y1"
+            y2 = genjax.normal(0.0, 1.0) @ "y2"
+            return y1 + y2
+        with pytest.raises(genjax.MissingAddress):
+            model.assess(C.kw(y1=1.0), ())
+
+        @genjax.gen
+        def bad():
+            _ = genjax.normal(0.0, 1.0) @ "y"
+            _ = genjax.normal(0.0, 1.0) @ "y"
+        with pytest.raises(genjax.AddressReuse):
+            bad.simulate(genjax.key(0), ())
+
+    def test_importance_weight_is_constrained_logpdf(self):
+        @genjax.gen
+        def model():
+            y1 = genjax.normal(0.0, 1.0) @ "y1"
+            y2 = genjax.normal(y1, 2.0) @ "y2"
+            return y2
+        key = genjax.key(1)
+        tr, w = model.importance(key, genjax.ChoiceMap.empty(), ())
+        assert f(w) == 0.0
+        tr, w = model.importance(key, C.kw(y2=0.5), ())
+        y1 = tr.get_choices()["y1"]
+        assert f(w) == pytest.approx(f(genjax.normal.logpdf(0.5, y1, 2.0)), abs=1e-6)
+        tr, w = model.importance(key, C.kw(y1=0.1, y2=0.5), ())
+        assert f(w) == pytest.approx(f(tr.get_score()), abs=1e-6)
+
+    def test_nested_generative_functions(self):
+        @genjax.gen
+        def inner(m):
+            a = genjax.normal(m, 1.0) @ "a"
+            b = genjax.normal(a, 1.0) @ "b"
+            return a + b
+
+        @genjax.gen
+        def outer():
+            x = genjax.normal(0.0, 1.0) @ "x"
+            r = inner(x) @ "sub"
+            _ = genjax.normal(r, 1.0) @ "y"
+            return r
+
+        @O.gen
+        def o_inner(m):
+            a = O.normal(m, 1.0) @ "a"
+            b = O.normal(a, 1.0) @ "b"
+            return a + b
+
+        @O.gen
+        def o_outer():
+            x = O.normal(0.0, 1.0) @ "x"
+            r = o_inner(x) @ "sub"
+            _ = O.normal(r, 1.0) @ "y"
+            return r
+        n = 257
+        tr = outer.simulate(genjax.split(genjax.key(5), n), ())
+        tro = o_outer.simulate(O.split(O.key(5), n), ())
+        ch, cho = tr.get_choices(), tro.get_choices()
+        for a in ("x", ("sub", "a"), ("sub", "b"), "y"):
+            assert np.array_equal(ch[a].numpy(), cho[a]), a
+        assert np.array_equal(tr.get_score().numpy(), tro.get_score())
+        assert np.array_equal(tr.get_retval().numpy(), tro.get_retval())
+        # constrain a nested address
+        tr, w = outer.importance(genjax.split(genjax.key(6), n), C["sub", "b"].set(0.25) | C["y"].set(1.0), ())
+        tro, wo = o_outer.importance(O.split(O.key(6), n),
+                                     O.C.d({("sub", "b"): np.float32(0.25), "y": np.float32(1.0)}), ())
+        assert np.array_equal(w.numpy(), wo)
+        assert np.array_equal(tr.get_subtrace("sub", "a").get_retval().numpy(), tro.subtraces["sub"].subtraces["a"].value)
+
+    def test_control_flow_and_tables(self):
+        """lax.cond on a traced flip + table lookup by a traced categorical (tests/inference/test_smc.py:59-96)"""
+        @genjax.gen
+        def flip_flip():
+            v1 = genjax.flip(0.5) @ "x"
+            p = jnp.lax.cond(v1, lambda: 0.9, lambda: 0.3)
+            _ = genjax.flip(p) @ "y"
+            return p
+
+        @O.gen
+        def o_flip_flip():
+            v1 = O.flip(0.5) @ "x"
+            p = np.where(v1, np.float32(0.9), np.float32(0.3))
+            _ = O.flip(p) @ "y"
+            return p
+        n = 300
+        tr = flip_flip.simulate(genjax.split(genjax.key(2), n), ())
+        tro = o_flip_flip.simulate(O.split(O.key(2), n), ())
+        assert np.array_equal(tr.get_choices()["x"].numpy(), tro.get_choices()["x"])
+        assert np.array_equal(tr.get_choices()["y"].numpy(), tro.get_choices()["y"])
+        assert np.array_equal(tr.get_score().numpy(), tro.get_score())
+
+        @genjax.gen
+        def mixture():
+            idx = genjax.categorical(probs=[0.5, 0.25, 0.25]) @ "idx"
+            means = jnp.array([0.0, 10.0, 11.0])
+            x = genjax.normal(means[idx], 1.0) @ "x"
+            return x
+
+        @O.gen
+        def o_mixture():
+            idx = O.categorical(probs=[0.5, 0.25, 0.25]) @ "idx"
+            means = np.array([0.0, 10.0, 11.0], np.float32)
+            x = O.normal(means[idx], 1.0) @ "x"
+            return x
+        tr = mixture.simulate(genjax.split(genjax.key(3), n), ())
+        tro = o_mixture.simulate(O.split(O.key(3), n), ())
+        assert np.array_equal(tr.get_choices()["idx"].numpy(), tro.get_choices()["idx"])
+        assert np.array_equal(tr.get_choices()["x"].numpy(), tro.get_choices()["x"])
+        np.testing.assert_allclose(tr.get_score().numpy(), tro.get_score(), rtol=0, atol=0)
+
+    def test_vector_valued_site(self):
+        """one site key, element j takes counter j; log_prob summed (distribution.py:383-396)"""
+        sig = [15.0, 10.0, 16.0, 11.0, 9.0, 11.0, 10.0, 18.0]
+
+        @genjax.gen
+        def schools(ys):
+            mu = genjax.normal(0.0, 5.0) @ "mu"
+            log_tau = genjax.normal(0.0, 1.0) @ "log_tau"
+            theta = genjax.normal(mu * jnp.ones(8), jnp.exp(log_tau) * jnp.ones(8)) @ "theta"
+            _ = genjax.normal(theta, jnp.array(sig)) @ "y"
+            return theta
+
+        @O.gen
+        def o_schools(ys):
+            mu = O.normal(0.0, 5.0) @ "mu"
+            log_tau = O.normal(0.0, 1.0) @ "log_tau"
+            theta = O.normal(mu[..., None] * np.ones(8, np.float32), O.exp(log_tau)[..., None] * np.ones(8, np.float32)) @ "theta"
+            _ = O.normal(theta, np.array(sig, np.float32)) @ "y"
+            return theta
+        ys = np.array([28, 8, -3, 7, -1, 1, 18, 12], np.float32)
+        n = 130
+        tr, w = schools.importance(genjax.split(genjax.key(9), n), C["y"].set(ys), (ys,))
+        tro, wo = o_schools.importance(O.split(O.key(9), n), O.C.d({"y": ys}), (ys,))
+        assert tuple(tr.get_choices()["theta"].shape) == (n, 8)
+        assert np.array_equal(tr.get_choices()["theta"].numpy(), tro.get_choices()["theta"])
+        assert np.array_equal(w.numpy(), wo)
+        assert np.array_equal(tr.get_score().numpy(), tro.get_score())
+
+
+# ---------------------------------------------------------------------------
+# SMC (tests/inference/test_smc.py, README.md:88-123)
+# ---------------------------------------------------------------------------
+class TestSMC:
+    def test_exact_flip_flip_trivial(self):
+        @genjax.gen
+        def flip_flip_trivial():
+            _ = genjax.flip(0.5) @ "x"
+            _ = genjax.flip(0.7) @ "y"
+        key = genjax.key(314159)
+        problem = genjax.Target(flip_flip_trivial, (), C["y"].set(True))
+        z_exact = f(genjax.flip.assess(problem.constraint.get_submap("y"), (0.7,))[0])
+        assert z_exact == pytest.approx(math.log(0.7), abs=1e-6)
+        z = genjax.inference.smc.Importance(problem).log_marginal_likelihood_estimate(key)
+        assert f(z) == pytest.approx(z_exact, rel=1e-1)
+        z = genjax.inference.smc.ImportanceK(problem, k_particles=1000).log_marginal_likelihood_estimate(key)
+        assert f(z) == pytest.approx(z_exact, rel=1e-3)
+
+    def test_exact_flip_flip(self):
+        @genjax.gen
+        def flip_flip():
+            v1 = genjax.flip(0.5) @ "x"
+            p = jnp.lax.cond(v1, lambda: 0.9, lambda: 0.3)
+            _ = genjax.flip(p) @ "y"
+        key = genjax.key(314159)
+        problem = genjax.Target(flip_flip, (), C["y"].set(True))
+        z = genjax.inference.smc.ImportanceK(problem, k_particles=2000).log_marginal_likelihood_estimate(key)
+        assert f(z) == pytest.approx(math.log(0.5 * 0.9 + 0.5 * 0.3), rel=1e-1)
+
+    def test_importancek_matches_oracle(self):
+        @genjax.gen
+        def m():
+            x = genjax.flip(0.5) @ "x"
+            _ = genjax.flip(0.7) @ "y"
+
+        @O.gen
+        def om():
+            x = O.flip(0.5) @ "x"
+            _ = O.flip(0.7) @ "y"
+        coll = genjax.inference.smc.ImportanceK(genjax.Target(m, (), C["y"].set(True)), k_particles=500).run_smc(genjax.key(7))
+        ocoll = O.ImportanceK(O.Target(om, (), O.C.kw(y=True)), 500).run_smc(O.key(7))
+        assert np.array_equal(coll.get_log_weights().numpy(), ocoll.get_log_weights())
+        assert np.array_equal(coll.get_particles().get_choices()["x"].numpy(), ocoll.get_particles().get_choices()["x"])
+        assert f(coll.get_log_marginal_likelihood_estimate()) == pytest.approx(
+            float(ocoll.get_log_marginal_likelihood_estimate()), rel=1e-6)
+        # sample_particle: same Gumbel-max index
+        k2 = genjax.key(8)
+        assert int(coll.sample_index(k2)) == int(ocoll.sample_index(O.key(8)))
+
+    def test_non_marginal_target(self):
+        @genjax.gen
+        def model():
+            idx = genjax.categorical(probs=[0.5, 0.25, 0.25]) @ "idx"
+            means = jnp.array([0.0, 10.0, 11.0])
+            x = genjax.normal(means[idx], 1.0) @ "x"
+            y = genjax.normal(means[idx], 1.0) @ "y"
+            return x, y
+        marginal_model = model.marginal(selection=S["x"] | S["y"])
+        with pytest.raises(TypeError):
+            genjax.Target(marginal_model, (), C["x"].set(1.0))
+
+    def test_readme_quickstart(self):
+        """README.md:88-123: 50 trials of SIR with K = 50; mean p -> 0.6 / 0.4."""
+        @genjax.gen
+        def beta_bernoulli(a, b):
+            p = genjax.beta(a, b) @ "p"
+            v = genjax.flip(p) @ "v"
+            return v
+
+        def run_inference(obs: bool):
+            target = genjax.Target(beta_bernoulli, (2.0, 2.0), genjax.ChoiceMap.d({"v": obs}))
+            alg = genjax.inference.smc.ImportanceK(target, k_particles=50)
+            key = genjax.key(314159)
+            sub_keys = genjax.split(key, 50)
+            _, p_chm = genjax.vmap(alg.random_weighted, in_axes=(0, None))(sub_keys, target)
+            assert tuple(p_chm["p"].shape) == (50,)
+            return f(jnp.mean(p_chm["p"]))
+        t, fl = run_inference(True), run_inference(False)
+        assert t == pytest.approx(0.6, abs=0.09) and fl == pytest.approx(0.4, abs=0.09)   # 3 sigma_MC
+
+
+# ---------------------------------------------------------------------------
+# edit requests (tests/inference/test_requests.py)
+# ---------------------------------------------------------------------------
+class TestRequests:
+    def test_simple_normal_regenerate(self):
+        @genjax.gen
+        def simple_normal():
+            y1 = genjax.normal(0.0, 1.0) @ "y1"
+            y2 = genjax.normal(0.0, 1.0) @ "y2"
+            return y1 + y2
+        key = genjax.key(314159)
+        key, sub_key = genjax.split(key)
+        tr = simple_normal.simulate(sub_key, ())
+        for addr in ("y1", "y2"):
+            old_v = tr.get_choices()[addr]
+            new_tr, fwd_w, _, bwd_request = genjax.Regenerate(S[addr]).edit(key, tr, ())
+            new_v = new_tr.get_choices()[addr]
+            old_d, new_d = genjax.normal.logpdf(old_v, 0.0, 1.0), genjax.normal.logpdf(new_v, 0.0, 1.0)
+            assert f(fwd_w) != 0.0 and f(fwd_w) == f(new_d - old_d)
+            assert f(old_v) != f(new_v)
+            old_tr, bwd_w, _, _ = bwd_request.edit(sub_key, new_tr, ())
+            assert f(bwd_w) != 0.0 and f(fwd_w) + f(bwd_w) == 0.0
+            assert f(old_tr.get_choices()[addr]) == f(old_v)
+        new_tr, fwd_w, _, bwd_request = genjax.Regenerate(S["y1"] | S["y2"]).edit(key, tr, ())
+        old_tr, bwd_w, _, _ = bwd_request.edit(key, new_tr, ())
+        assert f(fwd_w) + f(bwd_w) == 0.0
+        assert f(old_tr.get_choices()["y2"]) == f(tr.get_choices()["y2"])
+
+    def test_linked_normal_regenerate(self):
+        @genjax.gen
+        def linked_normal():
+            y1 = genjax.normal(0.0, 1.0) @ "y1"
+            _ = genjax.normal(y1, 1.0) @ "y2"
+        key = genjax.key(314159)
+        key, sub_key = genjax.split(key)
+        tr = linked_normal.simulate(sub_key, ())
+        ch = tr.get_choices()
+        old = f(genjax.normal.logpdf(ch["y1"], 0.0, 1.0)) + f(genjax.normal.logpdf(ch["y2"], ch["y1"], 1.0))
+        new_tr, fwd_w, _, _ = genjax.Regenerate(S["y1"]).edit(key, tr, ())
+        ch = new_tr.get_choices()
+        new = f(genjax.normal.logpdf(ch["y1"], 0.0, 1.0)) + f(genjax.normal.logpdf(ch["y2"], ch["y1"], 1.0))
+        assert f(fwd_w) != 0.0 and f(fwd_w) == pytest.approx(new - old, rel=1e-5)
+
+    def _mh(self, model, request, steps, key, obs):
+        key, sub_key = genjax.split(key)
+        tr, _ = model.importance(sub_key, obs, ())
+        for _ in range(steps):
+            key, sub_key = genjax.split(key)
+            new_tr, w, _, _ = request.edit(sub_key, tr, ())
+            key, sub_key = genjax.split(key)
+            check = f(jnp.log(genjax.uniform.sample(sub_key, 0.0, 1.0))) < f(w)
+            tr = new_tr if check else tr
+        return tr
+
+    def test_linked_normal_convergence(self):
+        @genjax.gen
+        def linked_normal():
+            y1 = genjax.normal(0.0, 3.0) @ "y1"
+            _ = genjax.normal(y1, 0.01) @ "y2"
+        tr = self._mh(linked_normal, genjax.Regenerate(S["y1"]), 200, genjax.key(314159), C.kw(y2=3.0))
+        assert f(tr.get_choices()["y1"]) == pytest.approx(3.0, rel=1e-2)
+
+    def test_rejuvenate_prior_proposal_weight_zero(self):
+        @genjax.gen
+        def simple_normal():
+            _ = genjax.normal(0.0, 1.0) @ "y1"
+        key = genjax.key(314159)
+        key, sub_key = genjax.split(key)
+        tr = simple_normal.simulate(sub_key, ())
+        old_v = tr.get_choices()["y1"]
+        request = genjax.StaticRequest({"y1": genjax.Rejuvenate(genjax.normal, lambda chm: (0.0, 1.0))})
+        new_tr, w, _, _ = request.edit(sub_key, tr, ())
+        assert f(old_v) != f(new_tr.get_choices()["y1"])
+        assert f(w) == 0.0
+
+    def test_linked_normal_rejuvenate_convergence(self):
+        @genjax.gen
+        def linked_normal():
+            y1 = genjax.normal(0.0, 3.0) @ "y1"
+            _ = genjax.normal(y1, 0.001) @ "y2"
+        request = genjax.StaticRequest({"y1": genjax.Rejuvenate(genjax.normal, lambda chm: (chm.get_value(), 0.3))})
+        tr = self._mh(linked_normal, request, 100, genjax.key(314159), C.kw(y2=3.0))
+        assert f(tr.get_choices()["y1"]) == pytest.approx(3.0, rel=5e-3)
+
+
+# ---------------------------------------------------------------------------
+# build-defined SMC moves vs the oracle
+# ---------------------------------------------------------------------------
+class TestSMCMoves:
+    def test_sweep_matches_oracle(self):
+        from tests import parity
+        res = parity.check_lgssm_sweep(n=3000, T=6)
+        assert res["ancestors_equal"] and res["x_equal"] and res["totals_equal"]
+        assert res["lw_max_abs_diff"] == 0.0 and res["log_ml"] == res["log_ml_oracle"]
+
+    @pytest.mark.parametrize("kind", ["systematic", "stratified", "multinomial"])
+    def test_resample_extend_api(self, kind):
+        from genjax_amd import workloads
+        from genjax_amd.inference import smc
+        init, step = workloads.make_lgssm(genjax)
+        oi, ost = workloads.make_lgssm(O)
+        n = 1500
+        ys = workloads.lgssm_data(3)
+        k0, k1, k2, k3 = genjax.split(genjax.key(11), 4)
+        ok = O.split(O.key(11), 4)
+        coll = smc.ImportanceK(genjax.Target(init, (), C["y"].set(float(ys[0]))), k_particles=n).run_smc(k0)
+        ocoll = O.ImportanceK(O.Target(oi, (), O.C.kw(y=np.float32(ys[0]))), n).run_smc(ok[0])
+        assert np.array_equal(coll.get_log_weights().numpy(), ocoll.get_log_weights())
+        res = smc.resample(k1, coll, kind)
+        cdf, total, M, shift = O.weight_cdf(ocoll.get_log_weights())
+        oanc = O.ancestors(smc._KINDS[kind], ok[1], cdf)
+        assert np.array_equal(res.ancestors.numpy(), oanc)
+        ext = smc.extend(k2, res, step, lambda tr: (tr.get_retval(),), C["y"].set(float(ys[1])))
+        ox = ocoll.get_particles().get_retval()[oanc]
+        otr, ow = ost.importance(O.split(ok[2], n), O.C.kw(y=np.float32(ys[1])), (ox,))
+        assert np.array_equal(ext.get_particles().get_retval().numpy(), otr.get_retval())
+        assert np.array_equal(ext.get_log_weights().numpy(), ow)
+        lml = f(ext.get_log_marginal_likelihood_estimate())
+        ref = O.log_ml_increment(M, total, shift, n) + float(O.logsumexp(ow) - np.log(np.float32(n)))
+        assert lml == pytest.approx(ref, abs=1e-5)
+
+
+def test_program_limits():
+    """<= 32 live 32-bit values per particle (registers stay in VGPRs); a model
+    that needs more fails loudly at trace time instead of spilling silently."""
+    from genjax_amd.program import ProgramTooLarge
+
+    @genjax.gen
+    def chain():
+        acc = genjax.normal(0.0, 1.0) @ "x0"
+        for i in range(1, 30):
+            acc = acc + genjax.normal(acc, 1.0) @ f"x{i}"      # 30 sites (60 stored leaves), few live values
+        return acc
+    tr = chain.simulate(genjax.key(0), ())
+    assert len(tr.get_choices().addresses()) == 30
+
+    @genjax.gen
+    def too_wide():
+        xs = [genjax.normal(0.0, 1.0) @ f"x{i}" for i in range(40)]
+        acc = xs[0]
+        for x in xs[1:]:
+            acc = acc * x                                        # all 40 values live at once
+        return acc
+    with pytest.raises(ProgramTooLarge):
+        too_wide.simulate(genjax.key(0), ())

@@ -89,6 +89,7 @@ def main():
     ap.add_argument("--T", type=int, default=T_STEPS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--sharded", action="store_true", help="use the multi-GPU code path even at world size 1")
     args = ap.parse_args()
 
     import numpy as np
@@ -100,7 +101,11 @@ def main():
         raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.sharded:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         import torch.distributed as dist_
         dist = dist_
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -113,7 +118,8 @@ def main():
     seed = 314159
     ys = workloads.lgssm_data(T)
     init, step = workloads.make_lgssm(G)
-    if world == 1:
+    single = world == 1 and not args.sharded
+    if single:
         sw = BootstrapSweep(init, step, n, T).prepare(G.key(seed), torch.from_numpy(ys))
         if not args.no_graph:
             sw.capture()
@@ -153,13 +159,14 @@ def main():
         "config": {"workload": "BASELINE config 2: linear-Gaussian state-space (T=100), bootstrap SMC, "
                                "systematic resampling every step",
                    "particles_per_gpu": n, "particles_total": total_particles, "T": T,
-                   "resampler": "systematic", "graph": not args.no_graph and world == 1,
+                   "resampler": "systematic", "graph": not args.no_graph and single,
+                   "path": "BootstrapSweep (hipGraph)" if single else "ShardedBootstrapSweep (RCCL)",
                    "key": seed},
         "log_ml": log_ml, "log_ml_kalman": kal, "log_ml_abs_err": abs(log_ml - kal),
         "log_ml_rel_err": abs(log_ml - kal) / abs(kal),
     }
 
-    if rank == 0 and world == 1:
+    if rank == 0 and single:
         # ---- per-kernel durations, HIP events on the launch stream ----
         from ctypes import c_float, c_void_p
         timer = c_void_p()

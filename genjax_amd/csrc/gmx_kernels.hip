@@ -794,6 +794,14 @@ k_weight_cdf(const float* __restrict__ lw, int64_t n, float scale, int max_mode,
   }
 }
 
+extern "C" int gmx_reduce_max(const float* partials_d, int64_t n, float* max_d, gmx_stream stream) {
+  if (n <= 0) return gmx_fail("gmx_reduce_max: n must be positive%s");
+  if (!partials_d || !max_d) return gmx_fail("gmx_reduce_max: null argument%s");
+  hipLaunchKernelGGL(k_reduce_max, dim3(1), dim3(GMX_BLOCK), 0, (hipStream_t)stream, partials_d, n, max_d);
+  GMX_HIP(hipGetLastError());
+  return 0;
+}
+
 extern "C" int gmx_weight_cdf(const float* lw_d, int64_t n, int shift,
                               const float* max_partials_d, int64_t n_partials, float* max_d,
                               uint64_t* cdf_d, uint64_t* total_d, void* workspace_d,

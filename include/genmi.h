@@ -171,6 +171,8 @@ int gmx_logsumexp(const float* lw_d, int64_t rows, int64_t cols, float* out_d,
  * ---------------------------------------------------------------------- */
 enum { GMX_RESAMPLE_SYSTEMATIC = 0, GMX_RESAMPLE_STRATIFIED = 1, GMX_RESAMPLE_MULTINOMIAL = 2 };
 
+/* *max_d = max of the n block maxima a program's OP_REDMAX wrote (plane 0 of red_out_d). */
+int gmx_reduce_max(const float* partials_d, int64_t n, float* max_d, gmx_stream stream);
 size_t gmx_weight_cdf_workspace(int64_t n);
 /* max_d: device scalar (max over ALL shards' log-weights); if max_partials_d
  * is non-null the max is first reduced from the n_partials block maxima

@@ -147,6 +147,9 @@ extern "C" int gmx_logsumexp(const float* lw, int64_t rows, int64_t cols, float*
 extern "C" int gmx_ancestors(int kind, const uint32_t key[2], const uint64_t* cdf, int64_t n_in, uint64_t off,
                              const uint64_t* total_d, int64_t n_out_total, int64_t slot_offset, int64_t n_slots,
                              int32_t* anc, gmx_stream);
+extern "C" int gmx_reduce_max(const float* parts, int64_t n, float* max_d, gmx_stream) {
+  float m = -gmx_inf(); for (int64_t j = 0; j < n; ++j) m = gmx_fmax(m, parts[j]); *max_d = m; return 0;
+}
 extern "C" size_t gmx_weight_cdf_workspace(int64_t n) { return 8 + (size_t)((n + 1023) / 1024) * 8; }
 extern "C" int gmx_weight_cdf(const float* lw, int64_t n, int shift, const float* parts, int64_t n_parts, float* max_d,
                               uint64_t* cdf, uint64_t* total, void*, gmx_stream) {

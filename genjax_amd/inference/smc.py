@@ -312,31 +312,18 @@ def extend(key: Key, collection: ParticleCollection, step, step_args, observatio
 
 
 def rejuvenate(key: Key, collection: ParticleCollection, request, argdiffs=None) -> ParticleCollection:
-    """One MH sweep: propose with `request.edit`, accept with log U < alpha
-    (tests/inference/test_requests.py:131-137 idiom), select per particle."""
-    be = _lib.get()
+    """One MH sweep over all particles as ONE fused launch (static.run_mh):
+    particle i uses key_i = split(key, N)[i], (k_edit, k_acc) = split(key_i);
+    propose with `request.edit(k_edit, ...)`, accept iff log U(k_acc) < weight,
+    keep the old trace otherwise (tests/inference/test_requests.py:131-137 idiom).
+    Weights are unchanged (an MH kernel leaves the target invariant)."""
+    from ..static import run_mh
     tr = collection.get_particles()
     n = collection.get_log_weights().shape[0]
-    k_edit, k_acc = split(key)
     if argdiffs is None:
         argdiffs = Diff.no_change(tr.get_args() or ())
-    new_tr, w, _, _ = request.edit(split(k_edit, n), tr, argdiffs)
-    acc_keys = split(k_acc, n).data()
-    accept = torch.empty((n,), dtype=torch.bool, device=w.device)
-    wf = w.float().contiguous()
-    be.check(be.c.gmx_mh_accept(be.ptr(acc_keys), be.ptr(wf), n, be.ptr(accept), be.stream()), "gmx_mh_accept")
-    new_leaves, old_leaves = trace_leaves(new_tr), trace_leaves(tr)
-    it = iter(range(len(new_leaves)))
-
-    def pick(v):
-        j = next(it)
-        a, b = engine.materialize(new_leaves[j]), engine.materialize(old_leaves[j])
-        if a is b or tuple(a.shape[:1]) != (n,):
-            return a
-        m = accept.reshape((n,) + (1,) * (a.ndim - 1))
-        return torch.where(m, a, b)
-    out = trace_map(new_tr, pick)
-    res = ParticleCollection(out, collection.get_log_weights(), True, collection.log_ml_offset)
+    new_tr, accept, _ = run_mh(tr.get_gen_fn(), lazy_split(key, n), tr, request, argdiffs)
+    res = ParticleCollection(new_tr, collection.get_log_weights(), True, collection.log_ml_offset)
     res.accept = accept
     return res
 

@@ -59,8 +59,12 @@ class DistributionTrace(Trace):
     def get_args(self): return self.args
     def get_retval(self): return materialize(self.value)
     def get_gen_fn(self): return self.gen_fn
-    def get_score(self): return self.score
+    def get_score(self): return materialize(self.score)
     def get_choices(self): return ChoiceMap.choice(materialize(self.value))
+
+    @property
+    def batch_shape(self):
+        return tuple(getattr(self.score, "shape", ()))
 
 
 class StaticTrace(Trace):
@@ -88,6 +92,12 @@ class StaticTrace(Trace):
         if acc is None:
             return 0.0
         return acc
+
+    @property
+    def batch_shape(self):
+        for st in self.subtraces.values():
+            return st.batch_shape
+        return ()
 
     def get_subtrace(self, *addr):
         addr = _norm(addr)
@@ -123,7 +133,7 @@ def _trace_tree(tr):
     if isinstance(tr, DistributionTrace):
         return {"value": tr.value, "score": tr.score}
     if isinstance(tr, StaticTrace):
-        return {"sub": {a: _trace_tree(s) for a, s in tr.subtraces.items()}}
+        return {"sub": {a: _trace_tree(s) for a, s in tr.subtraces.items()}, "retval": tr.retval}
     raise TypeError(f"cannot edit a trace of type {type(tr).__name__}")
 
 
@@ -684,7 +694,49 @@ class MinimalGenerate:
         return flat.leaves
 
 
-def run_edit(gen_fn, key: Key, trace: Trace, request: EditRequest, argdiffs):
+def _mh_select(tr: Tracing, acc: Expr, rec, prev):
+    """Origins of where(accept, new, old) for every site; unchanged sites pass through."""
+    def pick(new, old_sym):
+        nv = new.value if isinstance(new, Sym) else new
+        if isinstance(new, Sym) and new.origin is not None and new.origin == old_sym.origin:
+            return old_sym.origin                      # untouched by the move
+        return tr.emit_output(T.where(acc, nv, old_sym.value))
+    if isinstance(rec, _SiteRec):
+        return ("site", rec.gen_fn, pick(rec.value, prev["value"]), pick(rec.score, prev["score"]), None)
+    subs = OrderedDict((a, _mh_select(tr, acc, r, prev["sub"][a])) for a, r in rec.sites.items())
+    old_ret = prev["retval"]
+    ro = _tree_select(tr, acc, rec.retval, old_ret)
+    return ("call", rec.gen_fn, subs, ro)
+
+
+def _tree_select(tr, acc, new, old):
+    if isinstance(new, (tuple, list)):
+        seq = [_tree_select(tr, acc, n, o) for n, o in zip(new, old)]
+        return ("tuple" if isinstance(new, tuple) else "list", seq)
+    if new is None:
+        return ("const", None)
+    if isinstance(old, Sym):
+        if isinstance(new, Expr) and tr.node_origin.get(id(new.node)) == old.origin and old.origin is not None:
+            return old.origin
+        return tr.emit_output(T.where(acc, new, old.value))
+    return tr.emit_output(new)
+
+
+def run_mh(gen_fn, key: Key, trace: Trace, request: EditRequest, argdiffs):
+    """One Metropolis-Hastings move per particle as ONE launch: propose with
+    `request.edit`, accept with log U < weight, select per particle — the fused
+    form of the reference idiom (tests/inference/test_requests.py:131-137):
+
+        new_tr, w, _, _ = request.edit(k_edit, tr, argdiffs)
+        check = jnp.log(genjax.uniform.sample(k_acc, 0.0, 1.0)) < w
+        tr = jtu.tree_map(lambda v1, v2: jnp.where(check, v1, v2), new_tr, tr)
+
+    with (k_edit, k_acc) = split(key_i) for particle key key_i (build-defined key
+    schedule).  Returns (selected trace, accept mask, weight)."""
+    return run_edit(gen_fn, key, trace, request, argdiffs, mh=True)
+
+
+def run_edit(gen_fn, key: Key, trace: Trace, request: EditRequest, argdiffs, mh: bool = False):
     """edit(key, trace, request, argdiffs) -> (new trace, weight, retdiff, backward request)."""
     be = _lib.get()
     args = tuple(Diff.tree_primal(argdiffs)) if argdiffs is not None else tuple(trace.get_args() or ())
@@ -701,11 +753,12 @@ def run_edit(gen_fn, key: Key, trace: Trace, request: EditRequest, argdiffs):
             raise ValueError(f"key batch {key.shape} does not match the trace batch {batch}")
     specs = tuple(leaf_spec(v, batch) for v in flat.leaves)
     tkey = _tangent_key(tangents)
-    ck = (_gfkey(gen_fn), "edit", atree, ptree, rkey, specs, tkey, len(batch), key is not None)
+    ck = (_gfkey(gen_fn), "mh" if mh else "edit", atree, ptree, rkey, specs, tkey, len(batch), key is not None)
     ent = _CACHE.get(ck)
     if ent is None:
         tr = Tracing(len(batch))
         ctx = _Ctx(tr)
+        ctx.store_sites = not mh
         with T.tracing(tr.graph):
             syms = [tr.sym_leaf(s, j) for j, s in enumerate(specs)]
             sargs = unflatten(atree, lambda j: syms[j].value)
@@ -713,6 +766,10 @@ def run_edit(gen_fn, key: Key, trace: Trace, request: EditRequest, argdiffs):
             _seed_changed(ctx, sargs, tangents)
             sprev = unflatten(ptree, lambda j: syms[j])
             kexpr = Expr(tr.graph.add("LDKEY", dtype="key")) if key is not None else None
+            k_acc = None
+            if mh:          # (k_edit, k_acc) = split(particle key)
+                k_acc = Expr(tr.graph.add("KDERIVE", (kexpr.node,), imm=1, dtype="key"))
+                kexpr = Expr(tr.graph.add("KDERIVE", (kexpr.node,), imm=0, dtype="key"))
             mode, constraint = "static_edit", ChoiceMap.empty()
             req = rspec
             if rspec.kind == "update":
@@ -722,15 +779,27 @@ def run_edit(gen_fn, key: Key, trace: Trace, request: EditRequest, argdiffs):
                 mode = "regen"
             _bind_request_leaves(rspec, syms)
             rec, retval, w, _ = call_gen_fn(ctx, mode, gen_fn, kexpr, sargs, constraint, sprev, req, syms, ())
-            otree = _emit_rec(tr, rec)
+            ao = None
+            if mh:
+                from .distributions import uniform as _uniform
+                if w is None:
+                    w = Expr(tr.graph.const_f32(0.0)) + 0.0
+                u = _uniform.sym_sample(k_acc, (0.0, 1.0))
+                acc = Expr(tr.graph.add("LOG", (u.node,), dtype="f32")) < w
+                otree = _mh_select(tr, acc, rec, sprev)
+                ao = tr.emit_output(acc)
+            else:
+                otree = _emit_rec(tr, rec)
             wo = tr.emit_output(w) if w is not None else None
-        ent = (Compiled(tr), otree, wo)
+        ent = (Compiled(tr), otree, wo, ao)
         _CACHE[ck] = ent
-    comp, otree, wo = ent
+    comp, otree, wo, ao = ent
     outs = comp.run(flat.leaves, batch, key)
     new_tr = _build_trace(otree, outs, flat.leaves, args)
     w = resolve(wo, outs, flat.leaves) if wo is not None else 0.0
     w = _broadcast_score(w, batch, be.device)
+    if mh:
+        return new_tr, resolve(ao, outs, flat.leaves), w
     discard = _build_discard(otree, outs, flat.leaves)
     if isinstance(request, Update):
         bwd = Update(discard)

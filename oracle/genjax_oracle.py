@@ -1062,6 +1062,36 @@ def log_ml_increment(M, total, shift, n):
     return float(M) + float(np.log(np.float64(total))) - shift * float(np.log(2.0)) - float(np.log(np.float64(n)))
 
 
+def trace_where(mask, new, old):
+    """tree_map(where(check, v1, v2), new_tr, tr) over a batched trace."""
+    def pick(a, b):
+        if a is None:
+            return None
+        if isinstance(a, tuple):
+            return tuple(pick(x, y) for x, y in zip(a, b))
+        a, b = np.asarray(a), np.asarray(b)
+        if a.shape[: mask.ndim] != mask.shape:
+            return a
+        m = mask.reshape(mask.shape + (1,) * (a.ndim - mask.ndim))
+        return np.where(m, a, b)
+    if isinstance(new, DistTrace):
+        return DistTrace(new.gen_fn, new.args, pick(new.value, old.value), pick(new.score, old.score))
+    return StaticTrace(new.gen_fn, new.args, pick(new.retval, old.retval),
+                       OrderedDict((a, trace_where(mask, s, old.subtraces[a])) for a, s in new.subtraces.items()))
+
+
+def rejuvenate(k, trace, edit_fn):
+    """BUILD-DEFINED fused MH move (genjax_amd.inference.smc.rejuvenate):
+    key_i = split(k, N)[i]; (k_edit, k_acc) = split(key_i); accept iff log U(k_acc) < w."""
+    n = np.shape(trace.get_score())[0]
+    pk = split(k, n)
+    ks = split(pk)
+    k_edit, k_acc = ks[:, 0, :], ks[:, 1, :]
+    new_tr, w = edit_fn(k_edit, trace)
+    acc = mh_accept(k_acc, np.broadcast_to(w, (n,)))
+    return trace_where(acc, new_tr, trace), acc, w
+
+
 def gather_trace(tr, anc):
     return _tree_index(tr, anc)
 

@@ -202,6 +202,84 @@ def test_lgssm_sweep_matches_oracle(gpu, n, T, capture, specialize):
     assert res["log_ml"] == res["log_ml_oracle"]
 
 
+@pytest.mark.parametrize("n", [3000, 300_000])
+def test_nonlinear_ssm_with_mh_rejuvenation(gpu, n):
+    """BASELINE config 3 (miniature and mid-size): resample -> fused MH -> extend,
+    states / weights / ancestors / accept masks bit-exact vs the oracle."""
+    res = parity.check_nlssm_mh(n=n, T=4)
+    assert res["ok"], res
+
+
+def test_edit_requests_bit_exact(gpu):
+    """Update / Regenerate / StaticRequest(Rejuvenate) weights and values vs the oracle."""
+    import genjax_amd as G
+    from genjax_amd import ChoiceMapBuilder as C, SelectionBuilder as S
+
+    def mk(g):
+        @g.gen
+        def linked():
+            y1 = g.normal(0.0, 3.0) @ "y1"
+            _ = g.normal(y1, 0.01) @ "y2"
+        return linked
+    m, mo = mk(G), mk(O)
+    n = 5000
+    ks, kso = G.split(G.key(314159), n), O.split(O.key(314159), n)
+    tr, w = m.importance(ks, C.kw(y2=3.0), ())
+    tro, wo = mo.importance(kso, O.C.kw(y2=np.float32(3.0)), ())
+    assert np.array_equal(w.cpu().numpy(), wo)
+    k2, k2o = G.split(G.key(5), n), O.split(O.key(5), n)
+    new_tr, fw, _, _ = G.Regenerate(S["y1"]).edit(k2, tr, ())
+    new_tro, fwo, _ = mo.regenerate(k2o, tro, O.selection("y1"), ())
+    assert np.array_equal(fw.cpu().numpy(), fwo)
+    assert np.array_equal(new_tr.get_choices()["y1"].cpu().numpy(), new_tro.get_choices()["y1"])
+    nv = np.linspace(2.9, 3.1, n).astype(np.float32)
+    u_tr, uw, _, disc = m.update(k2, tr, C.kw(y1=_dev(nv)), ())
+    u_tro, uwo, udo = mo.update(k2o, tro, O.C.kw(y1=nv), ())
+    assert np.array_equal(uw.cpu().numpy(), uwo) and np.array_equal(disc["y1"].cpu().numpy(), udo["y1"])
+    req = G.StaticRequest({"y1": G.Rejuvenate(G.normal, lambda chm: (chm.get_value(), 0.3))})
+    r_tr, rw, _, _ = req.edit(k2, tr, ())
+    r_tro, rwo = mo.edit_static(k2o, tro, {"y1": O.Rejuvenate(O.normal, lambda chm: (chm.get_value(), np.float32(0.3)))}, ())
+    assert np.array_equal(rw.cpu().numpy(), rwo)
+    assert np.array_equal(r_tr.get_choices()["y1"].cpu().numpy(), r_tro.get_choices()["y1"])
+
+
+def test_importancek_and_vector_sites(gpu):
+    """BASELINE config 4 in miniature: 8-schools ImportanceK + global systematic resample."""
+    import genjax_amd as G
+    from genjax_amd import ChoiceMapBuilder as C, numpy as jnp
+    from genjax_amd.inference import smc
+    sig = [15.0, 10.0, 16.0, 11.0, 9.0, 11.0, 10.0, 18.0]
+    ys = np.array([28, 8, -3, 7, -1, 1, 18, 12], np.float32)
+
+    @G.gen
+    def schools():
+        mu = G.normal(0.0, 5.0) @ "mu"
+        log_tau = G.normal(0.0, 1.0) @ "log_tau"
+        theta = G.normal(mu * jnp.ones(8), jnp.exp(log_tau) * jnp.ones(8)) @ "theta"
+        _ = G.normal(theta, jnp.array(sig)) @ "y"
+        return theta
+
+    @O.gen
+    def o_schools():
+        mu = O.normal(0.0, 5.0) @ "mu"
+        log_tau = O.normal(0.0, 1.0) @ "log_tau"
+        theta = O.normal(mu[..., None] * np.ones(8, np.float32), O.exp(log_tau)[..., None] * np.ones(8, np.float32)) @ "theta"
+        _ = O.normal(theta, np.array(sig, np.float32)) @ "y"
+        return theta
+    k = 20_000
+    coll = smc.ImportanceK(G.Target(schools, (), C["y"].set(ys)), k_particles=k).run_smc(G.key(2))
+    oc = O.ImportanceK(O.Target(o_schools, (), O.C.d({"y": ys})), k).run_smc(O.key(2))
+    assert np.array_equal(coll.get_log_weights().cpu().numpy(), oc.get_log_weights())
+    assert np.array_equal(coll.get_particles().get_choices()["theta"].cpu().numpy(), oc.get_particles().get_choices()["theta"])
+    res = smc.resample(G.key(3), coll, "systematic")
+    cdf, total, M, shift = O.weight_cdf(oc.get_log_weights())
+    assert np.array_equal(res.ancestors.cpu().numpy(), O.ancestors(O.SYSTEMATIC, O.key(3), cdf))
+    th = res.get_particles().get_choices()["theta"]
+    assert np.array_equal(th.cpu().numpy(), oc.get_particles().get_choices()["theta"][res.ancestors.cpu().numpy()])
+    lml = float(coll.get_log_marginal_likelihood_estimate())
+    assert lml == pytest.approx(float(oc.get_log_marginal_likelihood_estimate()), rel=2e-6)
+
+
 def test_full_size_sweep_properties(gpu):
     """BASELINE config 2 at full size (1e6 particles, T = 100): size-independent
     properties — sorted ancestors, determinism, and log-ML within Monte-Carlo

@@ -501,6 +501,14 @@ class TestSMCMoves:
         assert lml == pytest.approx(ref, abs=1e-5)
 
 
+def test_nonlinear_ssm_with_mh_rejuvenation_matches_oracle():
+    """BASELINE config 3 in miniature (resample -> fused MH Rejuvenate -> extend)."""
+    from tests import parity
+    res = parity.check_nlssm_mh(n=1200, T=4)
+    assert res["ok"], res
+    assert all(0.0 < s["acc_rate"] <= 1.0 for s in res["steps"])
+
+
 def test_program_limits():
     """<= 32 live 32-bit values per particle (registers stay in VGPRs); a model
     that needs more fails loudly at trace time instead of spilling silently."""

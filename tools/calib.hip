@@ -10,6 +10,14 @@ __global__ void k_copy4(const float4* __restrict__ a, float4* __restrict__ b, in
   int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i < n4) b[i] = a[i];
 }
+__global__ void k_copy1(const float* __restrict__ a, float* __restrict__ b, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) b[i] = a[i];
+}
+__global__ void k_gather1(const float* __restrict__ a, const int* __restrict__ idx, float* __restrict__ b, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) b[i] = a[idx[i]];
+}
 template <int ITERS>
 __global__ void k_fma(float* out, float s, int64_t n) {
   int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -88,6 +96,9 @@ int main() {
   printf("empty kernel (1 block)        : %8.2f us/launch\n", time_us([&] { hipLaunchKernelGGL(k_empty, dim3(1), dim3(64), 0, 0); }, 500));
   printf("empty kernel (3907 blocks)    : %8.2f us/launch\n", time_us([&] { hipLaunchKernelGGL(k_empty, dim3(grid), dim3(256), 0, 0); }, 500));
   printf("copy 4 MB  (1e6 f32)          : %8.2f us\n", time_us([&] { hipLaunchKernelGGL(k_copy4, dim3((n / 4 + 255) / 256), dim3(256), 0, 0, (const float4*)a, (float4*)b, n / 4); }, 500));
+  printf("copy 4 MB dword/lane (calib)  : %8.2f us\n", time_us([&] { hipLaunchKernelGGL(k_copy1, dim3(grid), dim3(256), 0, 0, a, b, n); }, 200));
+  { int64_t m = n * 64; float t = time_us([&] { hipLaunchKernelGGL(k_copy1, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, 0, a, b, m); }, 20);
+    printf("copy 256 MB dword/lane (calib): %8.2f us  = %.2f TB/s\n", t, 2.0 * m * 4 / t * 1e-6); }
   { int64_t m = n * 64 / 4; float t = time_us([&] { hipLaunchKernelGGL(k_copy4, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, 0, (const float4*)a, (float4*)b, m); }, 50);
     printf("copy 256 MB                   : %8.2f us  = %.2f TB/s (read+write)\n", t, 2.0 * n * 64 * 4 / t * 1e-6); }
   { float t = time_us([&] { hipLaunchKernelGGL(k_fma<1024>, dim3(grid), dim3(256), 0, 0, b, 0.999f, n); }, 100);

@@ -17,6 +17,7 @@ from .static import (AddressReuse, MissingAddress, Rejuvenate, StaticGenerativeF
 from . import inference
 from .inference import Target
 from .transforms import jit, vmap
+from .combinators import Vmap, repeat
 
 ExactDensity = Distribution
 key = random.key
@@ -30,5 +31,5 @@ __all__ = [
     "Trace", "Update", "Mask", "Distribution", "ExactDensity", "bernoulli", "beta", "categorical",
     "flip", "normal", "uniform", "AddressReuse", "MissingAddress", "Rejuvenate",
     "StaticGenerativeFunction", "StaticRequest", "StaticTrace", "gen", "trace", "Target", "jit",
-    "vmap", "key", "split", "fold_in", "NotSupportedEditRequest",
+    "vmap", "key", "split", "fold_in", "NotSupportedEditRequest", "Vmap", "repeat",
 ]

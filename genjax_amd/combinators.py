@@ -1,0 +1,201 @@
+"""Plate combinators: `Vmap` / `repeat` (simulate / generate / assess).
+
+Reference: src/genjax/_src/generative_functions/combinators/vmap.py:180-218
+(`sub_keys = split(key, n)`, inner GFI per index, score / weight summed over
+the plate) and repeat.py:28-42.  Used as callees of a `@gen` function:
+
+    thetas = school.vmap(in_axes=(None, None, 0))(mu, tau, sigmas) @ "schools"
+
+The plate is unrolled at trace time (plates on this path are small — eight
+schools, a handful of mixture components; a plate over the DATA is the
+particle axis itself).  Inner addresses keep their names; their values gain a
+trailing plate axis: `chm["schools", "theta"]` has shape [N, n], and the
+reference's slice spelling `chm["schools", :, "theta"]` addresses the same
+entry.  `edit_index` / `IndexRequest` are next-tier.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .core.choice_map import ChoiceMap
+from .core.generative import GenerativeFunction
+from .tracer import Expr
+
+
+def _axis_len(a):
+    if isinstance(a, np.ndarray):
+        return a.shape[0] if a.ndim else None
+    if isinstance(a, (list, tuple)):
+        return len(a)
+    return None
+
+
+def _take(a, j):
+    if isinstance(a, np.ndarray):
+        v = a[j]
+        return v.item() if isinstance(v, np.ndarray) and v.ndim == 0 and v.dtype == object else v
+    if isinstance(a, (list, tuple)):
+        return a[j]
+    raise TypeError("vmap: a mapped argument must have a leading plate axis")
+
+
+def _index_chm(chm: ChoiceMap, j, n):
+    """Constraint / previous values of plate element j (values carry the plate axis first)."""
+    from .engine import Sym
+
+    def pick(v):
+        if isinstance(v, Sym):
+            inner = v.value
+            if isinstance(inner, np.ndarray) and inner.ndim >= 1 and inner.shape[0] == n:
+                return _take(inner, j)
+            return inner
+        if isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[0] == n:
+            return _take(v, j)
+        return v
+    return chm.map_values(pick)
+
+
+def _stack(vals):
+    from .engine import Sym
+    vals = [v.value if isinstance(v, Sym) else v for v in vals]
+    if all(v is None for v in vals):
+        return None
+    if isinstance(vals[0], (tuple, list)):
+        return type(vals[0])(_stack([v[k] for v in vals]) for k in range(len(vals[0])))
+    arrs = [np.asarray(v, dtype=object) if not (isinstance(v, np.ndarray) and v.dtype == object) else v for v in vals]
+    return np.stack(arrs, axis=0)
+
+
+class Vmap(GenerativeFunction):
+    def __init__(self, gen_fn, in_axes=0):
+        self.gen_fn, self.in_axes = gen_fn, in_axes
+
+    def _axes(self, args):
+        ax = self.in_axes
+        if isinstance(ax, int) or ax is None:
+            return (ax,) * len(args)
+        ax = tuple(ax)
+        if len(ax) != len(args):
+            raise ValueError("vmap: in_axes does not match the number of arguments")
+        return ax
+
+    def _plate_size(self, args, axes):
+        sizes = {_axis_len(a) for a, ax in zip(args, axes) if ax is not None}
+        sizes.discard(None)
+        if len(sizes) != 1:
+            raise ValueError(f"vmap: cannot infer the plate size from the mapped arguments ({sizes})")
+        return sizes.pop()
+
+    def trace_call(self, ctx, mode, key, args, constraint, prev, req, req_leaves, addr):
+        """Called by static.call_gen_fn while tracing a parent `@gen` function."""
+        from .static import _CallRec, _SiteRec, _store_site, call_gen_fn
+        if mode not in ("simulate", "generate", "assess"):
+            raise NotImplementedError("Vmap edits (IndexRequest / edit_index): SURVEY.md §8(f) item 2 (next tier)")
+        axes = self._axes(args)
+        n = self._plate_size(args, axes)
+        from .static import _rec_score
+        g = ctx.tr.graph
+        keep = ctx.store_sites
+        ctx.store_sites = False
+        recs, rets = [], []
+        weight = Expr(g.const_f32(0.0))
+        score = Expr(g.const_f32(0.0))
+        for j in range(n):
+            kj = Expr(g.add("KDERIVE", (key.node,), imm=j, dtype="key")) if key is not None else None   # split(key, n)[j]
+            args_j = tuple(_take(a, j) if ax is not None else a for a, ax in zip(args, axes))
+            con_j = _index_chm(constraint, j, n)
+            rec, ret, w, s = call_gen_fn(ctx, mode, self.gen_fn, kj, args_j, con_j, None, None, req_leaves, addr)
+            recs.append(rec)
+            rets.append(ret)
+            if keep:
+                for r in _leaves(rec):
+                    ctx.tr.prestore(r.value)
+                    if not isinstance(rec, _SiteRec):      # a bare distribution's plate score is the sum
+                        ctx.tr.prestore(r.score)
+            if w is not None:
+                weight = weight + w                    # w = sum over the plate (vmap.py:214)
+            score = score + (s if mode == "assess" else _rec_score(rec))
+        ctx.store_sites = keep
+        merged = _merge(recs, self.gen_fn)
+        retval = _stack(rets)
+        if isinstance(merged, _SiteRec):
+            # a distribution under vmap is a vector-valued site with split keys; its
+            # score is the plate sum
+            merged.score = score
+            out = merged
+        else:
+            out = _CallRec(self)
+            out.sites = merged.sites
+            out.retval = retval
+            out.plate_score = score
+        if keep:
+            for r in _leaves(out):
+                _store_site(ctx, r)
+        if mode in ("simulate", "assess"):
+            return out, retval, None, score
+        return out, retval, weight, None
+
+    # direct use: split(key, n) of the caller's key itself (vmap.py:186)
+    def simulate(self, key, args):
+        from .static import run_gfi
+        return run_gfi(self, "simulate", key, args)
+
+    def generate(self, key, constraint, args):
+        from .static import run_gfi
+        return run_gfi(self, "generate", key, args, constraint=constraint)
+
+    def assess(self, sample, args, batch_shape=None):
+        from .static import run_gfi
+        return run_gfi(self, "assess", None, args, constraint=sample, batch_shape=batch_shape)
+
+
+def _leaves(rec):
+    from .static import _SiteRec
+    if isinstance(rec, _SiteRec):
+        return [rec]
+    out = []
+    for r in rec.sites.values():
+        out += _leaves(r)
+    return out
+
+
+def _merge(recs, gen_fn):
+    """n per-element records (same structure) -> one record whose values carry the plate axis."""
+    from .static import _CallRec, _SiteRec
+    first = recs[0]
+    if isinstance(first, _SiteRec):
+        value = _stack([r.value for r in recs])
+        score = _stack([r.score for r in recs])            # per-element scores, plate axis first
+        return _SiteRec(first.gen_fn, value, score)
+    out = _CallRec(gen_fn)
+    for a in first.sites:
+        out.sites[a] = _merge([r.sites[a] for r in recs], first.sites[a].gen_fn)
+    out.retval = _stack([r.retval for r in recs])
+    return out
+
+
+def vmap(*, in_axes=0):
+    def decorator(gen_fn):
+        return Vmap(gen_fn, in_axes)
+    return decorator
+
+
+class _Repeat(Vmap):
+    """n independent runs of gen_fn on the same arguments (repeat.py:28-42:
+    `gen_fn.contramap(lambda _idx, args: args).vmap(in_axes=(0, None))` over arange(n))."""
+
+    def __init__(self, gen_fn, n):
+        super().__init__(gen_fn, None)
+        self.n = int(n)
+
+    def _axes(self, args):
+        return (None,) * len(args)
+
+    def _plate_size(self, args, axes):
+        return self.n
+
+
+def repeat(*, n: int):
+    def decorator(gen_fn):
+        return _Repeat(gen_fn, n)
+    return decorator

@@ -17,10 +17,14 @@ def _norm(addr) -> tuple:
     if isinstance(addr, tuple):
         out = ()
         for a in addr:
-            out += _norm(a) if isinstance(a, tuple) else (a,)
+            out += _norm(a)
         return out
     if addr is Ellipsis:
         raise NotImplementedError("`...` addresses are not supported")
+    if isinstance(addr, slice):
+        if addr == slice(None):
+            return ()          # chm["plate", :, "x"]: plate values carry the plate axis themselves
+        raise NotImplementedError("partial slices in addresses (Indexed choice maps): SURVEY.md §8(f) item 2")
     return (addr,)
 
 

@@ -159,6 +159,7 @@ class Tracing:
         self.uni_plan = []     # (uni index, leaf, elem, dtype)
         self.outputs = []      # (dtype, n_elems, [slots])
         self.node_origin = {}  # id(node) -> origin
+        self.prestored = {}    # id(node) -> slot of a store emitted early (plate elements)
         self.uses_key = False
 
     # leaves -> symbols ------------------------------------------------------
@@ -196,6 +197,15 @@ class Tracing:
         return Sym(arr, ("leaf", j))
 
     # outputs ------------------------------------------------------------------
+    def prestore(self, value):
+        """Store one element of a later vector-valued output NOW, so that its
+        register dies here (plates are unrolled; see combinators.Vmap)."""
+        from .tracer import Expr as _E
+        if isinstance(value, Sym):
+            value = value.value
+        if isinstance(value, _E) and value.node.op != "CONST" and id(value.node) not in self.prestored:
+            self.prestored[id(value.node)] = self.graph.store(value.node)
+
     def emit_output(self, value):
         """Store a symbolic value (Expr or object array) unless it is a pure
         pass-through / constant; returns its origin."""
@@ -219,9 +229,14 @@ class Tracing:
             dts = {v.dtype for v in flat}
             dt = "f32" if "f32" in dts else ("i32" if "i32" in dts else "bool")
             conv = {"f32": T.as_float, "i32": T.as_int, "bool": T.as_bool}[dt]
-            slots = [g.store(conv(v).node) for v in flat]
+            nodes = [conv(v).node for v in flat]
+            ck = (tuple(id(n) for n in nodes), tuple(value.shape))
+            if ck in self.node_origin:
+                return self.node_origin[ck]       # e.g. a plate's values returned as its retval
+            slots = [self.prestored[id(n)] if id(n) in self.prestored else g.store(n) for n in nodes]
             o = ("out", len(self.outputs))
             self.outputs.append((dt, tuple(value.shape), slots))
+            self.node_origin[ck] = o
             return o
         if isinstance(value, (tuple, list)):
             return ("tuple" if isinstance(value, tuple) else "list", [self.emit_output(v) for v in value])

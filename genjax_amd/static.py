@@ -118,6 +118,26 @@ class StaticTrace(Trace):
     get_inner_trace = get_subtrace
 
 
+class VmapTrace(Trace):
+    """Trace of a `Vmap` call: the inner trace's leaves carry a trailing plate
+    axis; the score is the plate sum (vmap.py VmapTrace)."""
+
+    def __init__(self, gen_fn, inner: "StaticTrace", score, retval):
+        self.gen_fn, self.inner, self.score, self.retval = gen_fn, inner, score, retval
+        self.subtraces = inner.subtraces
+
+    def get_args(self): return None
+    def get_retval(self): return _tree_materialize(self.retval)
+    def get_gen_fn(self): return self.gen_fn
+    def get_score(self): return materialize(self.score)
+    def get_choices(self): return self.inner.get_choices()
+    def get_subtrace(self, *addr): return self.inner.get_subtrace(*addr)
+
+    @property
+    def batch_shape(self):
+        return tuple(getattr(self.score, "shape", ()))
+
+
 def _tree_materialize(v):
     if isinstance(v, tuple):
         return tuple(_tree_materialize(x) for x in v)
@@ -509,6 +529,8 @@ def _rec_choices(rec) -> ChoiceMap:
 
 
 def _rec_score(rec):
+    if getattr(rec, "plate_score", None) is not None:
+        return rec.plate_score
     if isinstance(rec, _SiteRec):
         return rec.score.value if isinstance(rec.score, Sym) else rec.score
     acc = None
@@ -560,13 +582,20 @@ _CACHE: dict = {}
 
 
 def _infer_batch(values) -> tuple:
-    shape = ()
+    """Common leading shape of the device leaves (vector-valued leaves carry
+    event axes after the particle axes); pass batch_shape= when ambiguous."""
+    shape = None
     for v in values:
-        if isinstance(v, (torch.Tensor, Gathered)):
+        if isinstance(v, (torch.Tensor, Gathered)) and len(v.shape):
             s = tuple(v.shape)
-            if len(s) > len(shape):
+            if shape is None:
                 shape = s
-    return shape
+            else:
+                k = 0
+                while k < min(len(s), len(shape)) and s[k] == shape[k]:
+                    k += 1
+                shape = shape[:k]
+    return shape or ()
 
 
 def _sym_constraint(tree, syms) -> ChoiceMap:
@@ -582,6 +611,9 @@ def _emit_rec(tr: Tracing, rec):
         vo, so, do = rec.origins
         return ("site", rec.gen_fn, vo, so, do)
     subs = OrderedDict((a, _emit_rec(tr, r)) for a, r in rec.sites.items())
+    ps = getattr(rec, "plate_score", None)
+    if ps is not None:
+        return ("vmap", rec.gen_fn, subs, tr.emit_output(rec.retval), tr.emit_output(ps))
     return ("call", rec.gen_fn, subs, tr.emit_output(rec.retval))
 
 
@@ -589,6 +621,11 @@ def _build_trace(otree, outs, leaves, args):
     if otree[0] == "site":
         _, gf, vo, so, _ = otree
         return DistributionTrace(gf, args, resolve(vo, outs, leaves), resolve(so, outs, leaves))
+    if otree[0] == "vmap":
+        _, gf, subs, ro, po = otree
+        st = OrderedDict((a, _build_trace(o, outs, leaves, None)) for a, o in subs.items())
+        inner = StaticTrace(gf.gen_fn, None, resolve(ro, outs, leaves), st)
+        return VmapTrace(gf, inner, resolve(po, outs, leaves), resolve(ro, outs, leaves))
     _, gf, subs, ro = otree
     st = OrderedDict((a, _build_trace(o, outs, leaves, None)) for a, o in subs.items())
     return StaticTrace(gf, args, resolve(ro, outs, leaves), st)

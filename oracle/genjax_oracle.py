@@ -827,6 +827,90 @@ def gen(f):
     return StaticGenerativeFunction(f)
 
 
+class VmapTrace:
+    def __init__(self, gen_fn, inner, score, retval):
+        self.gen_fn, self.inner, self.score, self.retval = gen_fn, inner, score, retval
+        self.subtraces = getattr(inner, "subtraces", None)
+
+    def get_retval(self): return self.retval
+    def get_score(self): return self.score
+    def get_choices(self): return self.inner.get_choices()
+    def get_gen_fn(self): return self.gen_fn
+    def get_args(self): return None
+
+
+class Vmap:
+    """Vmap.simulate / generate / assess (combinators/vmap.py:180-218): keys
+    split(key, n); the inner GFI runs with the plate as one more (trailing)
+    batch axis; score / weight = sum over the plate, in element order."""
+
+    def __init__(self, gen_fn, in_axes=0):
+        self.gen_fn, self.in_axes = gen_fn, in_axes
+
+    def __call__(self, *args):
+        return Closure(self, tuple(args))
+
+    def _prep(self, args, batch):
+        axes = self.in_axes if isinstance(self.in_axes, (tuple, list)) else (self.in_axes,) * len(args)
+        n = None
+        out = []
+        for a, ax in zip(args, axes):
+            if ax is None:
+                a = np.asarray(a)
+                out.append(a[..., None] if a.ndim >= len(batch) and a.shape[: len(batch)] == tuple(batch) and len(batch) else a)
+            else:
+                a = np.asarray(a)
+                n = a.shape[-1] if a.ndim > len(batch) or a.shape[: len(batch)] != tuple(batch) else a.shape[-1]
+                out.append(a)
+        return tuple(out), n
+
+    @staticmethod
+    def _plate_sum(x, batch):
+        x = np.asarray(x, np.float32)
+        x = np.broadcast_to(x, np.broadcast_shapes(x.shape, tuple(batch) + (x.shape[-1],)))
+        acc = np.zeros(x.shape[:-1], np.float32)
+        for j in range(x.shape[-1]):
+            acc = (acc + x[..., j]).astype(np.float32)
+        return acc
+
+    def simulate(self, k, args):
+        batch = np.asarray(k).shape[:-1]
+        a, n = self._prep(args, batch)
+        tr = self.gen_fn.simulate(split(k, n), a)
+        return VmapTrace(self, tr, self._plate_sum(tr.get_score(), batch), tr.get_retval())
+
+    def generate(self, k, chm, args):
+        batch = np.asarray(k).shape[:-1]
+        a, n = self._prep(args, batch)
+        tr, w = self.gen_fn.generate(split(k, n), chm, a)
+        w = np.broadcast_to(np.asarray(w, np.float32), tuple(batch) + (n,))
+        return VmapTrace(self, tr, self._plate_sum(tr.get_score(), batch), tr.get_retval()), self._plate_sum(w, batch)
+
+    importance = generate
+
+    def assess(self, chm, args, batch_shape=()):
+        batch = tuple(batch_shape)
+        a, n = self._prep(args, batch)
+        s, r = self.gen_fn.assess(chm, a, batch + (n,))
+        s = np.broadcast_to(np.asarray(s, np.float32), batch + (n,))
+        return self._plate_sum(s, batch), r
+
+
+class Repeat(Vmap):
+    """repeat.py:28-42: n runs on the same arguments, keys split(key, n)."""
+
+    def __init__(self, gen_fn, n):
+        super().__init__(gen_fn, None)
+        self.n = n
+
+    def _prep(self, args, batch):
+        out = []
+        for a in args:
+            a = np.asarray(a)
+            out.append(a[..., None] if len(batch) and a.shape[: len(batch)] == tuple(batch) else a)
+        return tuple(out), self.n
+
+
 def selection(*addrs):
     """S[a] | S[b] ...: selects the listed addresses and everything below them."""
     addrs = [_addr(a) for a in addrs]

@@ -97,3 +97,82 @@ def check_nlssm_mh(n=2000, T=4, seed=7):
         w_ok = bool(np.array_equal(coll.get_log_weights().cpu().numpy(), np.asarray(olw, np.float32)))
         out["ok"] &= x_ok and w_ok
     return out
+
+
+# ---------------------------------------------------------------------------
+# plates: eight schools written with Vmap / repeat
+# ---------------------------------------------------------------------------
+SCHOOL_SIGMA = [15.0, 10.0, 16.0, 11.0, 9.0, 11.0, 10.0, 18.0]
+SCHOOL_Y = np.array([28, 8, -3, 7, -1, 1, 18, 12], np.float32)
+
+
+def _school(g):
+    @g.gen
+    def school(mu, tau, sigma):
+        theta = g.normal(mu, tau) @ "theta"
+        g.normal(theta, sigma) @ "y"
+        return theta
+    return school
+
+
+def check_plates(n=257, seed=4):
+    """importance / simulate / assess of plate models: product == oracle, bit for bit."""
+    import genjax_amd as G
+    from genjax_amd import ChoiceMapBuilder as C, numpy as jnp
+    school, oschool = _school(G), _school(O)
+
+    @G.gen
+    def schools():
+        mu = G.normal(0.0, 5.0) @ "mu"
+        log_tau = G.normal(0.0, 1.0) @ "log_tau"
+        return school.vmap(in_axes=(None, None, 0))(mu, jnp.exp(log_tau), jnp.array(SCHOOL_SIGMA)) @ "schools"
+
+    @O.gen
+    def o_schools():
+        mu = O.normal(0.0, 5.0) @ "mu"
+        log_tau = O.normal(0.0, 1.0) @ "log_tau"
+        return O.Vmap(oschool, in_axes=(None, None, 0))(mu, O.exp(log_tau), np.array(SCHOOL_SIGMA, np.float32)) @ "schools"
+
+    tr, w = schools.importance(G.split(G.key(seed), n), C["schools", :, "y"].set(SCHOOL_Y), ())
+    tro, wo = o_schools.importance(O.split(O.key(seed), n), O.C.d({("schools", "y"): SCHOOL_Y}), ())
+    th = tr.get_choices()["schools", "theta"]
+    assert tuple(th.shape) == (n, 8)
+    assert np.array_equal(th.cpu().numpy(), tro.get_choices()["schools", "theta"])
+    assert np.array_equal(w.cpu().numpy(), wo)
+    assert np.array_equal(tr.get_score().cpu().numpy(), tro.get_score())
+    assert np.array_equal(tr.get_retval().cpu().numpy(), tro.get_retval())
+    # per-element scores of the inner trace keep the plate axis (VmapTrace.inner)
+    sub = tr.get_subtrace("schools")
+    assert tuple(sub.inner.get_score().shape) == (n, 8)
+    assert np.array_equal(sub.get_score().cpu().numpy(), tro.get_subtrace("schools").get_score())
+
+    @G.gen
+    def mixed():
+        mu = G.normal(0.0, 5.0) @ "mu"
+        G.normal.vmap(in_axes=(0, None))(jnp.array([1.0, 2.0, 3.0]) + mu, 1.0) @ "xs"
+        return school.repeat(n=3)(mu, 2.0, 1.0) @ "zs"
+
+    @O.gen
+    def o_mixed():
+        mu = O.normal(0.0, 5.0) @ "mu"
+        O.Vmap(O.normal, in_axes=(0, None))(np.array([1.0, 2.0, 3.0], np.float32) + mu[..., None], 1.0) @ "xs"
+        return O.Repeat(oschool, 3)(mu, 2.0, 1.0) @ "zs"
+
+    tr = mixed.simulate(G.split(G.key(seed + 5), n), ())
+    tro = o_mixed.simulate(O.split(O.key(seed + 5), n), ())
+    for a in [("mu",), ("xs",), ("zs", "theta"), ("zs", "y")]:
+        assert np.array_equal(np.asarray(tr.get_choices()[a].cpu()), tro.get_choices()[a]), a
+    assert np.array_equal(tr.get_score().cpu().numpy(), tro.get_score())
+    assert np.array_equal(tr.get_retval().cpu().numpy(), tro.get_retval())
+    s, _ = mixed.assess(tr.get_choices(), ())
+    so, _ = o_mixed.assess(tro.get_choices(), (), (n,))
+    assert np.array_equal(s.cpu().numpy(), so)
+    assert np.array_equal(s.cpu().numpy(), tr.get_score().cpu().numpy())      # assess(simulate) == score
+
+    # a Vmap used directly: keys are split(key, n) of the caller's key (vmap.py:186)
+    v = school.vmap(in_axes=(None, None, 0))
+    t2 = v.simulate(G.split(G.key(seed + 1), 16), (0.0, 1.0, jnp.array(SCHOOL_SIGMA)))
+    t2o = O.Vmap(oschool, in_axes=(None, None, 0)).simulate(O.split(O.key(seed + 1), 16),
+                                                             (0.0, 1.0, np.array(SCHOOL_SIGMA, np.float32)))
+    assert np.array_equal(np.asarray(t2.get_choices()["theta"].cpu()), t2o.get_choices()["theta"])
+    assert np.array_equal(t2.get_score().cpu().numpy(), t2o.get_score())

@@ -280,6 +280,11 @@ def test_importancek_and_vector_sites(gpu):
     assert lml == pytest.approx(float(oc.get_log_marginal_likelihood_estimate()), rel=2e-6)
 
 
+@pytest.mark.parametrize("n", [257, 100_000])
+def test_plates_match_oracle(gpu, n):
+    parity.check_plates(n=n)
+
+
 def test_full_size_sweep_properties(gpu):
     """BASELINE config 2 at full size (1e6 particles, T = 100): size-independent
     properties — sorted ancestors, determinism, and log-ML within Monte-Carlo

@@ -509,6 +509,11 @@ def test_nonlinear_ssm_with_mh_rejuvenation_matches_oracle():
     assert all(0.0 < s["acc_rate"] <= 1.0 for s in res["steps"])
 
 
+def test_plates_match_oracle():
+    from tests import parity
+    parity.check_plates(n=257)
+
+
 def test_program_limits():
     """<= 32 live 32-bit values per particle (registers stay in VGPRs); a model
     that needs more fails loudly at trace time instead of spilling silently."""

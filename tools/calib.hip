@@ -59,6 +59,23 @@ __global__ void k_tf_ilp(uint32_t* out, uint32_t s, int64_t n) {
   for (int c = 0; c < CH; ++c) r += x0[c] ^ x1[c];
   if (i < n) out[i] = r;
 }
+// which integer op limits a Threefry round?  MODE 0: add only, 1: xor only, 2: alignbit only,
+// 3: shift+shift+or rotate, 4: full round with alignbit, 5: full round with shift/or rotate
+template <int ITERS, int MODE>
+__global__ void k_intop(uint32_t* out, uint32_t s, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  uint32_t x0 = (uint32_t)i, x1 = s ^ (uint32_t)i;
+#pragma unroll 16
+  for (int k = 0; k < ITERS; ++k) {
+    if (MODE == 0) { x0 += x1; }
+    else if (MODE == 1) { x0 ^= x1; x1 ^= s; }
+    else if (MODE == 2) { x1 = __builtin_amdgcn_alignbit(x1, x1, 19); }
+    else if (MODE == 3) { x1 = (x1 << 13) | (x1 >> 19); asm volatile("" : "+v"(x1)); }
+    else if (MODE == 4) { x0 += x1; x1 = __builtin_amdgcn_alignbit(x1, x1, 19); x1 ^= x0; }
+    else { x0 += x1; uint32_t t = x1 >> 19; asm volatile("" : "+v"(t)); x1 = (x1 << 13) | t; x1 ^= x0; }
+  }
+  if (i < n) out[i] = x0 ^ x1;
+}
 template <int ITERS>
 __global__ void k_imul(uint32_t* out, uint32_t s, int64_t n) {
   int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -113,6 +130,18 @@ int main() {
     printf("1 chain  x 256 tf-rounds(3op) : %8.2f us  = %.2f T lane-ops/s\n", t, 768.0 * n / t * 1e-6); }
   { float t = time_us([&] { hipLaunchKernelGGL((k_tf_ilp<256, 2>), dim3(grid), dim3(256), 0, 0, u, 7u, n); }, 100);
     printf("2 chains x 256 tf-rounds(3op) : %8.2f us  = %.2f T lane-ops/s\n", t, 1536.0 * n / t * 1e-6); }
+  { float t = time_us([&] { hipLaunchKernelGGL((k_intop<1024, 0>), dim3(grid), dim3(256), 0, 0, u, 7u, n); }, 100);
+    printf("1024 dependent v_add_u32      : %8.2f us  = %.2f T lane-ops/s\n", t, 1024.0 * n / t * 1e-6); }
+  { float t = time_us([&] { hipLaunchKernelGGL((k_intop<1024, 1>), dim3(grid), dim3(256), 0, 0, u, 7u, n); }, 100);
+    printf("1024 x (2 xor)                : %8.2f us  = %.2f T lane-ops/s\n", t, 2048.0 * n / t * 1e-6); }
+  { float t = time_us([&] { hipLaunchKernelGGL((k_intop<1024, 2>), dim3(grid), dim3(256), 0, 0, u, 7u, n); }, 100);
+    printf("1024 dependent v_alignbit     : %8.2f us  = %.2f T lane-ops/s\n", t, 1024.0 * n / t * 1e-6); }
+  { float t = time_us([&] { hipLaunchKernelGGL((k_intop<1024, 3>), dim3(grid), dim3(256), 0, 0, u, 7u, n); }, 100);
+    printf("1024 x shift/shift/or rotate  : %8.2f us  = %.2f T rot/s\n", t, 1024.0 * n / t * 1e-6); }
+  { float t = time_us([&] { hipLaunchKernelGGL((k_intop<256, 4>), dim3(grid), dim3(256), 0, 0, u, 7u, n); }, 100);
+    printf("256 tf rounds (alignbit)      : %8.2f us  = %.2f T rounds/s\n", t, 256.0 * n / t * 1e-6); }
+  { float t = time_us([&] { hipLaunchKernelGGL((k_intop<256, 5>), dim3(grid), dim3(256), 0, 0, u, 7u, n); }, 100);
+    printf("256 tf rounds (shift/or)      : %8.2f us  = %.2f T rounds/s\n", t, 256.0 * n / t * 1e-6); }
   { float t = time_us([&] { hipLaunchKernelGGL(k_imul<1024>, dim3(grid), dim3(256), 0, 0, u, 2654435761u, n); }, 100);
     printf("1024 dependent IMAD x 1e6 thr : %8.2f us  = %.2f T lane-ops/s\n", t, 1024.0 * n / t * 1e-6); }
   { float t = time_us([&] { hipLaunchKernelGGL(k_salu<1024>, dim3(grid), dim3(256), 0, 0, u, 7u, n); }, 100);

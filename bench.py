@@ -126,8 +126,12 @@ def main():
         launch = sw.launch
     else:
         from genjax_amd.inference.sharded import ShardedBootstrapSweep
-        sw = ShardedBootstrapSweep(init, step, n, T, dist).prepare(G.key(seed), torch.from_numpy(ys))
-        launch = sw.launch
+        sw = ShardedBootstrapSweep(init, step, n, T, dist, always_communicate=True).prepare(
+            G.key(seed), torch.from_numpy(ys))
+
+        def launch():
+            sw.launch()
+            sw.finish()          # the once-per-sweep overflow check (one sync, one 8-byte all-reduce)
 
     def barrier():
         if dist is not None:
@@ -166,7 +170,7 @@ def main():
         "log_ml_rel_err": abs(log_ml - kal) / abs(kal),
     }
 
-    if rank == 0 and single:
+    if rank == 0:
         # ---- per-kernel durations, HIP events on the launch stream ----
         from ctypes import c_float, c_void_p
         timer = c_void_p()
@@ -219,7 +223,10 @@ def main():
                            "sweep_frac_of_hbm_roofline":
                                SWEEP_BYTES_PER_PARTICLE_STEP * value / world / 1e9 / HBM_PEAK_GBS}
         be.c.gmx_timer_destroy(timer)
-        if not args.no_cpu_baseline:
+        if not single:
+            out["config"]["capacity_per_peer"] = sw.capacity
+            out["config"]["full_capacity_reruns"] = sw.reruns
+        if not args.no_cpu_baseline and world == 1:
             try:
                 out["cpu_baseline"] = cpu_baseline(n, T, ys, seed)
             except Exception as e:                              # report, never fail the GPU number
@@ -227,6 +234,7 @@ def main():
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:
+        dist.barrier()           # rank 0's kernel timing is done before anyone tears the communicator down
         dist.destroy_process_group()
 
 

@@ -90,6 +90,12 @@ class Backend:
         c.gmx_resample_workspace.restype = c_size_t
         c.gmx_resample.argtypes = [c_int, POINTER(c_uint32), c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p,
                                    c_void_p, c_void_p, c_void_p, c_void_p]
+        c.gmx_shard_plan_words.argtypes = [c_int]
+        c.gmx_shard_plan_words.restype = c_size_t
+        c.gmx_shard_plan.argtypes = [c_int, POINTER(c_uint32), c_void_p, c_int, c_int, c_int64, c_void_p, c_void_p,
+                                     c_void_p]
+        c.gmx_shard_route.argtypes = [c_int, POINTER(c_uint32), c_void_p, c_void_p, c_int, c_int, c_int64, c_int64,
+                                      c_void_p, c_void_p, c_void_p, c_void_p]
         c.gmx_gather.argtypes = [POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int32), c_int32,
                                  c_void_p, c_int64, c_void_p]
         c.gmx_categorical_rows.argtypes = [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p]

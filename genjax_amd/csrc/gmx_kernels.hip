@@ -1194,6 +1194,140 @@ extern "C" int gmx_resample(int kind, const uint32_t key[2], const float* lw_d, 
 }
 
 // ---------------------------------------------------------------------------
+// global resampling across ranks (one process per GPU): plan + route
+//
+// Every rank holds its local inclusive CDF (relative to the GLOBAL max) and,
+// after an all-gather, every rank's integer total.  k_shard_plan turns the
+// totals into the exact slot boundaries bounds[s] = f(offset_s) — the same
+// integer predicate k_offspring evaluates — so every rank knows which slots
+// each rank sources, with no host round trip.  k_shard_route is k_offspring
+// with a routing step: a slot this rank owns gets the local ancestor index, a
+// slot another rank owns gets the ancestor's STATE written into the
+// fixed-capacity send block of that rank; slots of this rank whose ancestor is
+// remote get an index into the receive area the all-to-all fills.
+// ---------------------------------------------------------------------------
+__global__ void k_shard_plan(int kind, uint32_t k0, uint32_t k1, const uint64_t* __restrict__ totals, int rank,
+                             int world, int64_t n, int64_t* __restrict__ plan, uint64_t* __restrict__ total_out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  gmx_key key; key.k0 = k0; key.k1 = k1;
+  const uint64_t u0 = gmx_bits32(key, 0) >> 9;
+  const int64_t N = n * world;
+  uint64_t total = 0;
+  for (int s = 0; s < world; ++s) total += totals[s];
+  const uint64_t D = (uint64_t)N << 23;
+  const double n_over_total = total ? (double)N / (double)total : 0.0;
+  const double eps = (double)N * 0x1p-44 + 0x1p-40;
+  uint64_t off = 0;
+  for (int s = 0; s < world; ++s) {
+    if (s == rank) plan[GMX_PLAN_OFFSET] = (int64_t)off;
+    plan[GMX_PLAN_BOUNDS + s] = total ? slots_below(kind, key, u0, off, D, total, n_over_total, eps, N) : 0;
+    off += totals[s];
+  }
+  plan[GMX_PLAN_BOUNDS + world] = N;      // no mass at all: the last rank sources every slot
+  plan[GMX_PLAN_TOTAL] = (int64_t)total;
+  if (total_out) *total_out = total;
+}
+
+__global__ void __launch_bounds__(GMX_BLOCK)
+k_shard_route(int kind, uint32_t k0, uint32_t k1, int64_t* __restrict__ plan, const uint64_t* __restrict__ cdf,
+              int rank, int world, int64_t n, int64_t cap, const uint32_t* __restrict__ state,
+              uint32_t* __restrict__ send, int32_t* __restrict__ next_idx) {
+  const int64_t i = (int64_t)blockIdx.x * GMX_BLOCK + threadIdx.x;
+  const bool in_range = i < n;
+  const uint64_t total = (uint64_t)plan[GMX_PLAN_TOTAL];
+  const uint64_t cdf_offset = (uint64_t)plan[GMX_PLAN_OFFSET];
+  const int64_t* bounds = plan + GMX_PLAN_BOUNDS;
+  const int64_t N = n * world, base = (int64_t)rank * n;
+  bool overflow = false;
+  // (b) my slot base+i: if its ancestor is on rank s != rank it arrives at recv[s*cap + k]
+  if (in_range) {
+    const int64_t jj = base + i;
+    int s = 0;
+    while (s + 1 < world && bounds[s + 1] <= jj) ++s;
+    if (s != rank) {
+      const int64_t first = bounds[s] > base ? bounds[s] : base;
+      const int64_t k = jj - first;
+      if (k < cap) next_idx[i] = (int32_t)(n + (int64_t)s * cap + k);
+      else { next_idx[i] = 0; overflow = true; }
+    }
+  }
+  // (a) the slots source i owns: [f(cdf_{i-1}), f(cdf_i))  (as k_offspring)
+  gmx_key key; key.k0 = k0; key.k1 = k1;
+  const uint64_t u0 = gmx_bits32(key, 0) >> 9;
+  const uint64_t D = (uint64_t)N << 23;
+  int64_t s_lo, e;
+  if (total == 0) {                         // only the globally last particle has offspring
+    const bool last = in_range && rank == world - 1 && i == n - 1;
+    s_lo = 0; e = last ? N : 0;
+  } else {
+    const double n_over_total = (double)N / (double)total;
+    const double eps = (double)N * 0x1p-44 + 0x1p-40;
+    const uint64_t c_hi = in_range ? cdf[i] + cdf_offset : total;
+    e = slots_below(kind, key, u0, c_hi, D, total, n_over_total, eps, N);
+    const int lane = threadIdx.x & 63;
+    uint32_t e_l = (uint32_t)e, e_h = (uint32_t)((uint64_t)e >> 32);
+    e_l = __shfl_up(e_l, 1, GMX_WAVE); e_h = __shfl_up(e_h, 1, GMX_WAVE);
+    s_lo = (int64_t)(((uint64_t)e_h << 32) | e_l);
+    if (lane == 0) {
+      const uint64_t c_lo = (i == 0 || !in_range) ? cdf_offset : cdf[i - 1] + cdf_offset;
+      s_lo = slots_below(kind, key, u0, c_lo, D, total, n_over_total, eps, N);
+    }
+  }
+  if (in_range && s_lo < e) {
+    const uint32_t v = state[i];
+    const int64_t S = bounds[rank];
+    int64_t d = s_lo / n;                   // owner of slot j; advances as j crosses a block of n
+    int64_t d_end = (d + 1) * n;
+    int64_t first = S > d * n ? S : d * n;  // first slot this rank sends to d
+    for (int64_t j = s_lo; j < e; ++j) {
+      if (j >= d_end) { ++d; d_end += n; first = d * n; }
+      if (d == rank) next_idx[j - base] = (int32_t)i;
+      else {
+        const int64_t k = j - first;
+        if (k < cap) send[d * cap + k] = v; else overflow = true;
+      }
+    }
+  }
+  if (overflow) plan[GMX_PLAN_OVERFLOW] = 1;
+}
+
+extern "C" size_t gmx_shard_plan_words(int world) { return (size_t)(GMX_PLAN_BOUNDS + world + 1); }
+
+static int shard_check(const char* who, int kind, const void* key, int rank, int world, int64_t n) {
+  if (!key) return gmx_fail("%s: null key", who);
+  if (kind != GMX_RESAMPLE_SYSTEMATIC && kind != GMX_RESAMPLE_STRATIFIED)
+    return gmx_fail("%s: systematic / stratified only (ordered slot thresholds)", who);
+  if (world < 1 || world > 1024 || rank < 0 || rank >= world) return gmx_fail("%s: rank / world out of range", who);
+  if (n <= 0 || n > 0x7fffffffLL || n * world >= (1LL << 40)) return gmx_fail("%s: n_per_rank out of range", who);
+  return 0;
+}
+
+extern "C" int gmx_shard_plan(int kind, const uint32_t key[2], const uint64_t* totals_d, int rank, int world,
+                              int64_t n_per_rank, int64_t* plan_d, uint64_t* total_out_d, gmx_stream stream) {
+  if (shard_check("gmx_shard_plan", kind, key, rank, world, n_per_rank)) return 1;
+  if (!totals_d || !plan_d) return gmx_fail("gmx_shard_plan: null argument%s");
+  hipLaunchKernelGGL(k_shard_plan, dim3(1), dim3(64), 0, (hipStream_t)stream, kind, key[0], key[1], totals_d, rank,
+                     world, n_per_rank, plan_d, total_out_d);
+  GMX_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int gmx_shard_route(int kind, const uint32_t key[2], int64_t* plan_d, const uint64_t* cdf_d, int rank,
+                               int world, int64_t n_per_rank, int64_t capacity, const void* state_d, void* send_d,
+                               int32_t* next_idx_d, gmx_stream stream) {
+  if (shard_check("gmx_shard_route", kind, key, rank, world, n_per_rank)) return 1;
+  if (!plan_d || !cdf_d || !state_d || !send_d || !next_idx_d) return gmx_fail("gmx_shard_route: null argument%s");
+  if (capacity < 1 || capacity > n_per_rank) return gmx_fail("gmx_shard_route: capacity must be in [1, n_per_rank]%s");
+  if (n_per_rank + (int64_t)world * capacity > 0x7fffffffLL)
+    return gmx_fail("gmx_shard_route: extended state index exceeds int32%s");
+  hipLaunchKernelGGL(k_shard_route, grid_for(n_per_rank), dim3(GMX_BLOCK), 0, (hipStream_t)stream, kind, key[0],
+                     key[1], plan_d, cdf_d, rank, world, n_per_rank, capacity, (const uint32_t*)state_d,
+                     (uint32_t*)send_d, next_idx_d);
+  GMX_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
 // gather / select over a table of leaves
 // ---------------------------------------------------------------------------
 #define GMX_MAX_LEAVES 32

@@ -12,14 +12,21 @@ number of ranks:
   * the global CDF is offset_g + local CDF with offset_g from an all-gather of
     the 8-byte local totals (exact integer sums: any partition gives the same CDF);
   * rank r resolves the output slots that fall into ITS mass interval
-    [offset_r, offset_r + total_r) — for systematic resampling a contiguous slot
-    range [S_r, E_r) known on every rank from the totals alone — gathers its own
-    states for them and ships them to the slot owners with ONE all-to-all-v of
-    states (the only bulk exchange; balanced weights keep most of it rank-local).
+    [offset_r, offset_r + total_r) — for systematic / stratified resampling a
+    contiguous slot range [S_r, E_r) every rank derives from the totals alone
+    (gmx_shard_plan, on the device).  Slots it owns itself become ancestor
+    indices for the next step's fused gather; the states for slots other ranks
+    own go into fixed-capacity send blocks (gmx_shard_route) and ONE
+    equal-split all-to-all delivers them behind the receiver's local states
+    (balanced weights keep all but O(sqrt(n)) particles per boundary rank-local).
 
-So per SMC step: 1 all-reduce (4 B), 1 all-gather (8 B/rank), 1 all-to-all-v
-(<= 4*D bytes per particle, mostly self-sends).  xGMI is point-to-point, so the
-all-to-all-v maps onto direct peer links rather than a ring.
+So per SMC step: 1 all-reduce (4 B), 1 all-gather (8 B/rank), 1 all-to-all
+(world * capacity * 4 B per rank), all enqueued on the stream: the host never
+waits for the device inside a sweep.  The evidence terms and the capacity
+overflow flag are read once at the end; an overflow (weights so unbalanced that
+a rank must ship more than `capacity` particles to one peer) re-runs the sweep
+with capacity = n, which always suffices.  xGMI is point-to-point, so the
+all-to-all maps onto direct peer links rather than a ring.
 """
 from __future__ import annotations
 
@@ -32,6 +39,7 @@ import torch
 from .. import _lib
 from ..core.choice_map import ChoiceMap
 from ..random import Key, fold_in, lazy_split, split
+from ..engine import Gathered
 from .smc import SYSTEMATIC, cdf_shift
 
 
@@ -58,32 +66,43 @@ def systematic_slot_bounds(offsets, total: int, n_total: int, u0: int):
 class ShardedBootstrapSweep:
     """smc.BootstrapSweep over `dist.get_world_size()` ranks, n particles per rank."""
 
-    def __init__(self, init, step, n_per_rank: int, T: int, dist, obs_addr="y", step_extra=None, specialize=True):
+    def __init__(self, init, step, n_per_rank: int, T: int, dist, obs_addr="y", step_extra=None, specialize=True,
+                 resample="systematic", capacity=None, always_communicate=False):
+        from .smc import _KINDS
         self.init, self.step, self.n, self.T, self.dist = init, step, int(n_per_rank), int(T), dist
         self.obs_addr = obs_addr
         self.step_extra = step_extra or (lambda t: ())
         self.specialize = specialize
+        self.kind = _KINDS[resample] if isinstance(resample, str) else int(resample)
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         self.N = self.n * self.world
+        # particles one rank may ship to ONE peer per step before the slow path kicks in
+        self.capacity = int(capacity) if capacity else (self.n if self.world == 1 else max(1024, self.n // 8))
+        self.capacity = max(1, min(self.capacity, self.n))
+        self.reruns = 0
+        # issue the collectives even at world size 1 (exercises / times the RCCL calls on one GPU)
+        self.comm = self.world > 1 or bool(always_communicate)
 
     def prepare(self, key: Key, ys: torch.Tensor):
         from ..static import MinimalGenerate
         be = _lib.get()
-        n, T, dev = self.n, self.T, be.device
+        n, T, dev, W = self.n, self.T, be.device, self.world
+        self.key = key
         self.ys = ys.to(dev).float().contiguous()
-        self.x = torch.zeros((n,), dtype=torch.float32, device=dev)          # this rank's current particles
-        self.x_new = torch.zeros((n,), dtype=torch.float32, device=dev)
         self.lw = torch.zeros((n,), dtype=torch.float32, device=dev)
         self.cdf = torch.zeros((n,), dtype=torch.int64, device=dev)
-        self.max_d = torch.zeros((1,), dtype=torch.float32, device=dev)
+        self.maxs = torch.zeros((T,), dtype=torch.float32, device=dev)           # global max per step
+        self.totals = torch.zeros((T,), dtype=torch.int64, device=dev)            # global integer total per step
         self.total_d = torch.zeros((1,), dtype=torch.int64, device=dev)
-        self.gtotal_d = torch.zeros((1,), dtype=torch.int64, device=dev)
-        self.totals_all = torch.zeros((self.world,), dtype=torch.int64, device=dev)
+        self.totals_all = torch.zeros((W,), dtype=torch.int64, device=dev)
+        self.plan = torch.zeros((int(be.c.gmx_shard_plan_words(W)),), dtype=torch.int64, device=dev)
         self.ws = torch.zeros(((be.c.gmx_weight_cdf_workspace(n) + 7) // 8,), dtype=torch.int64, device=dev)
         self.shift = cdf_shift(self.N)
+        self._alloc_exchange()
         obs0 = ChoiceMap.empty().set(self.obs_addr, self.ys[0])
         self.p_init = MinimalGenerate(self.init, (), obs0, (n,))
-        self.p_step = MinimalGenerate(self.step, (self.x,) + tuple(self.step_extra(1)), obs0, (n,))
+        g = Gathered(self.xext[0], self.idx)
+        self.p_step = MinimalGenerate(self.step, (g,) + tuple(self.step_extra(1)), obs0, (n,))
         if self.specialize and be.uses_streams:
             self.p_init.comp.specialize()
             self.p_step.comp.specialize()
@@ -93,88 +112,109 @@ class ShardedBootstrapSweep:
         for t in range(T):
             ks = split(fold_in(key, t), 3)
             self.step_keys.append((ks[0], ks[1], ks[2]))
-        self.maxs, self.totals = [], []
         return self
+
+    def _alloc_exchange(self):
+        dev, n, W, C = _lib.get().device, self.n, self.world, self.capacity
+        # extended state, double-buffered: [ n local | W*C received ]; ancestors index into it
+        self.xext = [torch.zeros((n + W * C,), dtype=torch.float32, device=dev) for _ in range(2)]
+        self.send = torch.zeros((W * C,), dtype=torch.float32, device=dev)
+        self.idx = torch.zeros((n,), dtype=torch.int32, device=dev)
 
     # ------------------------------------------------------------------
     def _step(self, t):
         be, dist = _lib.get(), self.dist
-        n, N, g, G = self.n, self.N, self.rank, self.world
+        n, N, g, W, C = self.n, self.N, self.rank, self.world, self.capacity
         k_prop, k_res, _ = self.step_keys[t]
         obs = ChoiceMap.empty().set(self.obs_addr, self.ys[t])
+        cur = self.xext[t % 2]
         if t == 0:
             prog, leaves = self.p_init, self.p_init.leaves((), obs)
         else:
             prog = self.p_step
-            leaves = prog.leaves((self.x,) + tuple(self.step_extra(t)), obs)
+            leaves = prog.leaves((Gathered(self.xext[(t - 1) % 2], self.idx),) + tuple(self.step_extra(t)), obs)
         bufs = [None] * len(prog.comp.outputs)
-        bufs[prog.ro[1]] = self.x_new.reshape(1, n)
+        bufs[prog.ro[1]] = cur[:n].reshape(1, n)
         bufs[prog.wo[1]] = self.lw.reshape(1, n)
         # keys of the GLOBAL particle index: split(k_prop, N)[g*n + i]
         prog.comp.run(leaves, (n,), lazy_split(k_prop, N), red_out=self.partials, out_buffers=bufs,
                       index_offset=g * n)
         # ---- global max: local reduce + all-reduce MAX (4 bytes) ----
-        be.check(be.c.gmx_reduce_max(be.ptr(self.partials), self.partials.shape[1], be.ptr(self.max_d), be.stream()),
+        m = self.maxs[t:t + 1]
+        be.check(be.c.gmx_reduce_max(be.ptr(self.partials), self.partials.shape[1], be.ptr(m), be.stream()),
                  "gmx_reduce_max")
-        dist.all_reduce(self.max_d, op=dist.ReduceOp.MAX)
+        if self.comm:
+            dist.all_reduce(m, op=dist.ReduceOp.MAX)
         # ---- local integer CDF relative to the global max ----
-        be.check(be.c.gmx_weight_cdf(be.ptr(self.lw), n, self.shift, None, 0, be.ptr(self.max_d), be.ptr(self.cdf),
+        be.check(be.c.gmx_weight_cdf(be.ptr(self.lw), n, self.shift, None, 0, be.ptr(m), be.ptr(self.cdf),
                                      be.ptr(self.total_d), be.ptr(self.ws), be.stream()), "gmx_weight_cdf")
-        # ---- all-gather the local totals (8 bytes per rank); offsets on every rank ----
-        dist.all_gather_into_tensor(self.totals_all, self.total_d)
-        tot = [int(v) & 0xFFFFFFFFFFFFFFFF for v in self.totals_all.cpu().tolist()]      # the one host sync
-        offs = [0]
-        for v in tot:
-            offs.append(offs[-1] + v)
-        total = offs[-1]
-        self.maxs.append(float(self.max_d.item()))
-        self.totals.append(total)
-        # ---- which slots fall into which rank's mass (exact, from the totals alone) ----
+        # ---- all-gather the local totals (8 bytes per rank) ----
+        if self.comm:
+            dist.all_gather_into_tensor(self.totals_all, self.total_d)
+        else:
+            self.totals_all.copy_(self.total_d)
+        # ---- slot boundaries + routing, on the device ----
         kh = k_res.host()
-        from ..random import threefry2x32
-        b0, b1 = threefry2x32(kh[0], kh[1], 0, 0)
-        u0 = (int(b0) ^ int(b1)) >> 9
-        bounds = systematic_slot_bounds(offs, total, N, u0)           # bounds[r] = f(offset_r); len G+1
-        bounds[-1] = N
-        S, E = bounds[g], bounds[g + 1]
-        n_mine = E - S
-        # ---- ancestors (local indices) of my slots, then my states for them ----
-        self.gtotal_d.fill_(0)
-        self.gtotal_d += torch.tensor([total if total < (1 << 63) else total - (1 << 64)], dtype=torch.int64,
-                                      device=self.gtotal_d.device)
-        send = torch.empty((max(n_mine, 1),), dtype=torch.float32, device=self.x.device)
-        if n_mine > 0:
-            anc = torch.empty((n_mine,), dtype=torch.int32, device=self.x.device)
-            kk = (c_uint32 * 2)(int(kh[0]), int(kh[1]))
-            be.check(be.c.gmx_ancestors(SYSTEMATIC, kk, be.ptr(self.cdf), n, offs[g] & 0xFFFFFFFFFFFFFFFF,
-                                        be.ptr(self.gtotal_d), N, S, n_mine, be.ptr(anc), be.stream()),
-                     "gmx_ancestors")
-            from ..engine import gather_leaves
-            send = gather_leaves([self.x_new], anc)[0].contiguous()
-        # ---- all-to-all-v of states: slot owners are contiguous blocks of n ----
-        in_splits, out_splits = [], []
-        for r in range(G):
-            lo, hi = max(S, r * n), min(E, (r + 1) * n)
-            out_splits.append(max(0, hi - lo))                        # what I send to rank r
-            lo, hi = max(bounds[r], g * n), min(bounds[r + 1], (g + 1) * n)
-            in_splits.append(max(0, hi - lo))                         # what rank r sends to me
-        assert sum(in_splits) == n, (in_splits, bounds)
-        recv = torch.empty((n,), dtype=torch.float32, device=self.x.device)
-        dist.all_to_all_single(recv, send[:n_mine] if n_mine > 0 else send[:0], output_split_sizes=in_splits,
-                               input_split_sizes=out_splits)
-        self.x = recv
+        kk = (c_uint32 * 2)(int(kh[0]), int(kh[1]))
+        be.check(be.c.gmx_shard_plan(self.kind, kk, be.ptr(self.totals_all), g, W, n, be.ptr(self.plan),
+                                     be.ptr(self.totals[t:t + 1]), be.stream()), "gmx_shard_plan")
+        be.check(be.c.gmx_shard_route(self.kind, kk, be.ptr(self.plan), be.ptr(self.cdf), g, W, n, C, be.ptr(cur),
+                                      be.ptr(self.send), be.ptr(self.idx), be.stream()), "gmx_shard_route")
+        # ---- one equal-split all-to-all: block s of my receive area <- block `me` of rank s's send ----
+        if self.comm:
+            dist.all_to_all_single(cur[n:], self.send)
 
-    def launch(self):
-        self.maxs, self.totals = [], []
+    def kernel_timers(self):
+        """The site-program launch of a mid-sweep step (no collectives): bench.py's roofline kernel."""
+        t = max(1, self.T // 2)
+
+        def vm():
+            n = self.n
+            obs = ChoiceMap.empty().set(self.obs_addr, self.ys[t])
+            prog = self.p_step
+            leaves = prog.leaves((Gathered(self.xext[(t - 1) % 2], self.idx),) + tuple(self.step_extra(t)), obs)
+            bufs = [None] * len(prog.comp.outputs)
+            bufs[prog.ro[1]] = self.xext[t % 2][:n].reshape(1, n)
+            bufs[prog.wo[1]] = self.lw.reshape(1, n)
+            prog.comp.run(leaves, (n,), lazy_split(self.step_keys[t][0], self.N), red_out=self.partials,
+                          out_buffers=bufs, index_offset=self.rank * n)
+        return {"k_vm": vm}
+
+    def enqueue(self):
+        self._finished = False
+        self.plan.zero_()
         for t in range(self.T):
             self._step(t)
 
+    def launch(self):
+        self.enqueue()
+
+    def finish(self):
+        """Read the overflow flag (one sync per sweep; COLLECTIVE — every rank calls it, which
+        launch-then-state()/log_ml() on all ranks does); re-run with full capacity if it is set anywhere."""
+        if self._finished:
+            return self
+        flag = self.plan[2:3].clone()
+        if self.comm:
+            self.dist.all_reduce(flag, op=self.dist.ReduceOp.MAX)
+        if int(flag.item()) != 0:
+            self.reruns += 1
+            self.capacity = self.n
+            self._alloc_exchange()
+            self.enqueue()
+            assert int(self.plan[2].item()) == 0
+        self._finished = True
+        return self
+
     def log_ml(self) -> float:
+        self.finish()
         acc = 0.0
-        for m, tot in zip(self.maxs, self.totals):
+        for m, tot in zip(self.maxs.cpu().tolist(), self.totals.cpu().numpy().view(np.uint64).tolist()):
             acc += m + math.log(tot) - self.shift * math.log(2.0) - math.log(self.N)
         return acc
 
     def state(self):
         """this rank's resampled particles after the last step (global slots [g*n, (g+1)*n))"""
-        return self.x
+        self.finish()
+        from ..engine import gather_leaves
+        return gather_leaves([self.xext[(self.T - 1) % 2]], self.idx)[0]

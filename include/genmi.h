@@ -202,6 +202,40 @@ int gmx_categorical_rows(const uint32_t* keys_d /* [rows,2] */, const float* log
                          int64_t rows, int64_t cols, int32_t* out_idx_d, gmx_stream stream);
 
 /* ------------------------------------------------------------------------
+ * Global resampling across ranks (one process per GPU).  No
+ * reference counterpart: the reference is single-device; this
+ * replaces what a sharded `vmap`-over-particles resample would need.
+ * Rank r owns the global particle indices / output slots [r*n, (r+1)*n).
+ * After gmx_weight_cdf (with the GLOBAL max in *max_d) and an all-gather of
+ * the ranks' totals, the rest of the step runs on the device with no host
+ * synchronisation:
+ *   gmx_shard_plan   bounds[s] = f(sum_{q<s} total_q): the first slot whose
+ *                    ancestor lives on rank s (exact integer predicate of
+ *                    gmx_ancestors); plan_d = { global total, this rank's
+ *                    CDF offset, overflow flag, -, bounds[0..world] }.
+ *   gmx_shard_route  for every slot whose ancestor i is on this rank:
+ *                      slot owned by this rank  -> next_idx_d[slot - r*n] = i
+ *                      slot owned by rank d     -> send_d[d*capacity + k] = state_d[i]
+ *                    (k = position among the slots this rank sends to d), and
+ *                    for every slot of this rank whose ancestor is on rank s != r:
+ *                      next_idx_d[slot - r*n] = n + s*capacity + k
+ *                    — an index into the extended state [ n local | world*capacity
+ *                    received ] that ONE equal-split all-to-all of send_d fills.
+ * plan_d[GMX_PLAN_OVERFLOW] is set (sticky) when some (source, destination)
+ * pair needs more than `capacity` slots; the caller reads it once per sweep and
+ * re-runs with capacity = n, which always suffices.  State elements are 4 bytes.
+ * ---------------------------------------------------------------------- */
+enum { GMX_PLAN_TOTAL = 0, GMX_PLAN_OFFSET = 1, GMX_PLAN_OVERFLOW = 2, GMX_PLAN_BOUNDS = 4 };
+size_t gmx_shard_plan_words(int world);          /* int64 words of plan_d */
+int gmx_shard_plan(int kind, const uint32_t key[2], const uint64_t* totals_d /* [world] */, int rank,
+                   int world, int64_t n_per_rank, int64_t* plan_d,
+                   uint64_t* total_out_d /* [1] or NULL: the global total */, gmx_stream stream);
+int gmx_shard_route(int kind, const uint32_t key[2], int64_t* plan_d, const uint64_t* cdf_d, int rank,
+                    int world, int64_t n_per_rank, int64_t capacity, const void* state_d /* [n] */,
+                    void* send_d /* [world*capacity] */, int32_t* next_idx_d /* [n] */,
+                    gmx_stream stream);
+
+/* ------------------------------------------------------------------------
  * MH accept + select.  Replaces the user idiom
  *   check = log(uniform.sample(k, 0, 1)) < w; tr = tree_map(where(check, new, old))
  * (tests/inference/test_requests.py:131-137, 186-191).

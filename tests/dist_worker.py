@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def main(out_path, n_per_rank, T):
+def main(out_path, n_per_rank, T, capacity=None):
     dist.init_process_group("gloo")
     import tests.hostsim as hs
     hs.install()
@@ -22,15 +22,17 @@ def main(out_path, n_per_rank, T):
     from genjax_amd.inference.sharded import ShardedBootstrapSweep
     ys = workloads.lgssm_data(T)
     init, step = workloads.make_lgssm(G)
-    sw = ShardedBootstrapSweep(init, step, n_per_rank, T, dist).prepare(G.key(314159), torch.from_numpy(ys))
+    sw = ShardedBootstrapSweep(init, step, n_per_rank, T, dist, capacity=capacity).prepare(G.key(314159), torch.from_numpy(ys))
     sw.launch()
     xs = [torch.empty_like(sw.state()) for _ in range(dist.get_world_size())]
     dist.all_gather(xs, sw.state())
     if dist.get_rank() == 0:
         np.save(out_path + ".npy", torch.cat(xs).numpy())
-        json.dump({"log_ml": sw.log_ml(), "totals": [str(t) for t in sw.totals], "maxs": sw.maxs}, open(out_path + ".json", "w"))
+        json.dump({"log_ml": sw.log_ml(), "totals": [str(t) for t in sw.totals.numpy().view(np.uint64).tolist()],
+                   "maxs": sw.maxs.tolist(), "reruns": sw.reruns, "capacity": sw.capacity},
+                  open(out_path + ".json", "w"))
     dist.destroy_process_group()
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], int(sys.argv[2]), int(sys.argv[3]))
+    main(sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]) if len(sys.argv) > 4 else None)

@@ -199,6 +199,65 @@ extern "C" int gmx_resample(int kind, const uint32_t key[2], const float* lw, in
   if (gmx_weight_cdf(lw, n, shift, parts, n_parts, max_d, cdf, total, nullptr, st)) return 1;
   return gmx_ancestors(kind, key, cdf, n, 0, total, n, 0, n, anc, st);
 }
+// ---- global resampling across ranks: destination-centric restatement ----
+static int64_t hs_slots_below(int kind, gmx_key k, uint64_t c, uint64_t total, int64_t N) {
+  // #{ j : (j*2^23 + u_j) * total < c * N * 2^23 }  (thresholds increase with j)
+  if (total == 0) return 0;
+  u128 X = (u128)c * (u128)((uint64_t)N << 23);
+  int64_t lo = 0, hi = N;
+  while (lo < hi) {
+    int64_t mid = lo + ((hi - lo) >> 1);
+    uint64_t u = (kind == GMX_RESAMPLE_SYSTEMATIC) ? (gmx_bits32(k, 0) >> 9) : (gmx_bits32(k, (uint64_t)mid) >> 9);
+    u128 P = (u128)(((uint64_t)mid << 23) + u) * total;
+    if (P < X) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+extern "C" size_t gmx_shard_plan_words(int world) { return (size_t)(GMX_PLAN_BOUNDS + world + 1); }
+extern "C" int gmx_shard_plan(int kind, const uint32_t key[2], const uint64_t* totals, int rank, int world, int64_t n,
+                              int64_t* plan, uint64_t* total_out, gmx_stream) {
+  if (kind != GMX_RESAMPLE_SYSTEMATIC && kind != GMX_RESAMPLE_STRATIFIED) return fail("shard_plan: kind");
+  gmx_key k; k.k0 = key[0]; k.k1 = key[1];
+  int64_t N = n * world;
+  uint64_t total = 0, off = 0;
+  for (int s = 0; s < world; ++s) total += totals[s];
+  for (int s = 0; s < world; ++s) {
+    if (s == rank) plan[GMX_PLAN_OFFSET] = (int64_t)off;
+    plan[GMX_PLAN_BOUNDS + s] = hs_slots_below(kind, k, off, total, N);
+    off += totals[s];
+  }
+  plan[GMX_PLAN_BOUNDS + world] = N;
+  plan[GMX_PLAN_TOTAL] = (int64_t)total;
+  if (total_out) *total_out = total;
+  return 0;
+}
+extern "C" int gmx_shard_route(int kind, const uint32_t key[2], int64_t* plan, const uint64_t* cdf, int rank, int world,
+                               int64_t n, int64_t cap, const void* state_v, void* send_v, int32_t* next_idx, gmx_stream st) {
+  if (cap < 1 || cap > n) return fail("shard_route: capacity");
+  const uint32_t* state = (const uint32_t*)state_v; uint32_t* send = (uint32_t*)send_v;
+  const int64_t* bounds = plan + GMX_PLAN_BOUNDS;
+  const int64_t N = n * world, base = (int64_t)rank * n, S = bounds[rank], E = bounds[rank + 1];
+  uint64_t total = (uint64_t)plan[GMX_PLAN_TOTAL];
+  // slots whose ancestor is here: per-slot binary search (gmx_ancestors), then route
+  for (int64_t j = S; j < E; ++j) {
+    int32_t a;
+    if (gmx_ancestors(kind, key, cdf, n, (uint64_t)plan[GMX_PLAN_OFFSET], &total, N, j, 1, &a, st)) return 1;
+    int64_t d = j / n;
+    if (d == rank) next_idx[j - base] = a;
+    else {
+      int64_t first = S > d * n ? S : d * n, k = j - first;
+      if (k < cap) send[d * cap + k] = state[a]; else plan[GMX_PLAN_OVERFLOW] = 1;
+    }
+  }
+  for (int64_t i = 0; i < n; ++i) {
+    int64_t jj = base + i;
+    int s = 0; while (s + 1 < world && bounds[s + 1] <= jj) ++s;
+    if (s == rank) continue;
+    int64_t first = bounds[s] > base ? bounds[s] : base, k = jj - first;
+    if (k < cap) next_idx[i] = (int32_t)(n + (int64_t)s * cap + k); else { next_idx[i] = 0; plan[GMX_PLAN_OVERFLOW] = 1; }
+  }
+  return 0;
+}
 extern "C" int gmx_gather(const void* const* src, void* const* dst, const int32_t* bytes, int32_t n_leaves,
                           const int32_t* anc, int64_t n_out, gmx_stream) {
   for (int32_t l = 0; l < n_leaves; ++l)

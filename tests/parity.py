@@ -176,3 +176,78 @@ def check_plates(n=257, seed=4):
                                                              (0.0, 1.0, np.array(SCHOOL_SIGMA, np.float32)))
     assert np.array_equal(np.asarray(t2.get_choices()["theta"].cpu()), t2o.get_choices()["theta"])
     assert np.array_equal(t2.get_score().cpu().numpy(), t2o.get_score())
+
+
+# ---------------------------------------------------------------------------
+# global resampling across ranks, emulated in ONE process through the C-ABI:
+# every "rank" runs gmx_weight_cdf / gmx_shard_plan / gmx_shard_route on its
+# shard; the all-to-all is a block copy.  Result must equal the oracle's
+# single-population resample, for any world size and capacity >= need.
+# ---------------------------------------------------------------------------
+def check_shard_route(n=1000, world=4, capacity=None, kind=None, seed=0, skew=0.0, dead=False):
+    from ctypes import c_uint32
+    from genjax_amd import _lib
+    be = _lib.get()
+    dev = be.device
+    kind = O.SYSTEMATIC if kind is None else kind
+    N = n * world
+    C = n if capacity is None else capacity
+    rng = np.random.default_rng(seed)
+    lw = rng.normal(0, 2, N).astype(np.float32)
+    lw += (skew * (np.arange(N) // n)).astype(np.float32)          # later ranks heavier
+    if dead:
+        lw[:] = -np.inf
+    x = rng.normal(0, 1, N).astype(np.float32)
+    k = O.key(seed + 11)
+    if dead:
+        anc_ref = np.full(N, N - 1, dtype=np.int64)
+        shift = O.cdf_shift(N)
+    else:
+        cdf_ref, total_ref, M_ref, shift = O.weight_cdf(lw)
+        anc_ref = O.ancestors(kind, k, cdf_ref)
+    want = x[anc_ref]
+
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    kk = (c_uint32 * 2)(int(k[0]), int(k[1]))
+    max_d = T(np.array([lw.max()], np.float32))
+    totals = torch.zeros((world,), dtype=torch.int64, device=dev)
+    cdfs, sends, idxs, xexts, plans = [], [], [], [], []
+    ws = torch.zeros(((be.c.gmx_weight_cdf_workspace(n) + 7) // 8,), dtype=torch.int64, device=dev)
+    for r in range(world):
+        cdf = torch.zeros((n,), dtype=torch.int64, device=dev)
+        be.check(be.c.gmx_weight_cdf(be.ptr(T(lw[r * n:(r + 1) * n])), n, shift, None, 0, be.ptr(max_d), be.ptr(cdf),
+                                     be.ptr(totals[r:r + 1]), be.ptr(ws), be.stream()), "gmx_weight_cdf")
+        cdfs.append(cdf)
+    for r in range(world):
+        plan = torch.zeros((int(be.c.gmx_shard_plan_words(world)),), dtype=torch.int64, device=dev)
+        tot = torch.zeros((1,), dtype=torch.int64, device=dev)
+        be.check(be.c.gmx_shard_plan(kind, kk, be.ptr(totals), r, world, n, be.ptr(plan), be.ptr(tot), be.stream()),
+                 "gmx_shard_plan")
+        xe = torch.zeros((n + world * C,), dtype=torch.float32, device=dev)
+        xe[:n] = T(x[r * n:(r + 1) * n])
+        send = torch.full((world * C,), float("nan"), dtype=torch.float32, device=dev)
+        idx = torch.full((n,), -1, dtype=torch.int32, device=dev)
+        be.check(be.c.gmx_shard_route(kind, kk, be.ptr(plan), be.ptr(cdfs[r]), r, world, n, C, be.ptr(xe), be.ptr(send),
+                                      be.ptr(idx), be.stream()), "gmx_shard_route")
+        plans.append(plan); sends.append(send); idxs.append(idx); xexts.append(xe)
+    overflow = any(int(p[2].item()) for p in plans)
+    if not dead:
+        assert int(plans[0][0].item()) & 0xFFFFFFFFFFFFFFFF == total_ref
+    b = plans[0][4:].cpu().numpy()
+    assert b[0] == 0 and b[-1] == N and np.all(np.diff(b) >= 0)
+    for p in plans[1:]:
+        assert np.array_equal(p[4:].cpu().numpy(), b)
+    # slots sourced by rank s = number of oracle ancestors living on rank s
+    assert np.array_equal(np.diff(b), np.bincount(anc_ref // n, minlength=world))
+    if overflow:
+        return {"overflow": True, "bounds": b}
+    out = []
+    for d in range(world):
+        for s_ in range(world):                                   # the all-to-all
+            xexts[d][n + s_ * C:n + (s_ + 1) * C] = sends[s_][d * C:(d + 1) * C]
+        i = idxs[d].cpu().numpy()
+        assert i.min() >= 0
+        out.append(xexts[d].cpu().numpy()[i])
+    got = np.concatenate(out)
+    assert np.array_equal(got, want)
+    return {"overflow": False, "bounds": b}

@@ -24,15 +24,17 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_sharded_sweep_equals_single_process_oracle(tmp_path, world):
+@pytest.mark.parametrize("world,capacity", [(2, 0), (4, 0), (2, 3)])
+def test_sharded_sweep_equals_single_process_oracle(tmp_path, world, capacity):
+    """capacity 0 = default (fast path, no overflow); capacity 3 forces the
+    overflow flag and the full-capacity re-run."""
     from genjax_amd import workloads
     n_total, T = 4096, 6
     out = str(tmp_path / "shard")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", env["MASTER_PORT"],
-           os.path.join(ROOT, "tests", "dist_worker.py"), out, str(n_total // world), str(T)]
+           os.path.join(ROOT, "tests", "dist_worker.py"), out, str(n_total // world), str(T)] + ([str(capacity)] if capacity else [])
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     x = np.load(out + ".npy")
@@ -42,6 +44,7 @@ def test_sharded_sweep_equals_single_process_oracle(tmp_path, world):
     ref = parity.oracle_bootstrap_sweep(oi, ost, n_total, T, ys, O.key(314159))
     assert [int(t) for t in meta["totals"]] == [h["total"] for h in ref["hist"]]
     assert meta["log_ml"] == ref["log_ml"]
+    assert meta["reruns"] == (1 if capacity else 0), meta
     # the sharded sweep returns the RESAMPLED particles of the last step
     assert np.array_equal(x, ref["x"][ref["anc"]])
 

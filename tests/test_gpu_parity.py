@@ -285,6 +285,45 @@ def test_plates_match_oracle(gpu, n):
     parity.check_plates(n=n)
 
 
+@pytest.mark.parametrize("n,world,kw", [
+    (1000, 4, {}), (4096, 8, {"kind": 1, "seed": 3}), (777, 3, {"skew": 2.0, "seed": 1}),
+    (500, 8, {"skew": -3.0, "seed": 2}), (64, 2, {"dead": True}), (100_000, 8, {"seed": 5}),
+    (100_000, 8, {"seed": 6, "capacity": 12_500}), (250_000, 2, {"seed": 7, "skew": 0.5}),
+])
+def test_global_resampling_routes_match_oracle(gpu, n, world, kw):
+    """gmx_shard_plan / gmx_shard_route with every rank emulated on one GPU == the oracle's
+    single-population resample (bit-exact ancestors => bit-exact states)."""
+    res = parity.check_shard_route(n, world, **kw)
+    assert not res["overflow"]
+
+
+def test_global_resampling_flags_overflow(gpu):
+    assert parity.check_shard_route(777, 3, skew=2.0, seed=1, capacity=5)["overflow"]
+
+
+def test_sharded_sweep_world1_matches_oracle(gpu):
+    """ShardedBootstrapSweep at world size 1 (collectives skipped) == BootstrapSweep oracle."""
+    import genjax_amd as G
+    from genjax_amd import workloads
+    from genjax_amd.inference.sharded import ShardedBootstrapSweep
+
+    class _Solo:
+        @staticmethod
+        def get_rank(): return 0
+        @staticmethod
+        def get_world_size(): return 1
+    n, T = 20_000, 5
+    ys = workloads.lgssm_data(T)
+    init, step = workloads.make_lgssm(G)
+    sw = ShardedBootstrapSweep(init, step, n, T, _Solo).prepare(G.key(314159), torch.from_numpy(ys))
+    sw.launch()
+    oi, ost = workloads.make_lgssm(O)
+    ref = parity.oracle_bootstrap_sweep(oi, ost, n, T, ys, O.key(314159))
+    assert np.array_equal(sw.state().cpu().numpy(), ref["x"][ref["anc"]])
+    assert sw.totals.cpu().numpy().view(np.uint64).tolist() == [h["total"] for h in ref["hist"]]
+    assert sw.log_ml() == ref["log_ml"]
+
+
 def test_full_size_sweep_properties(gpu):
     """BASELINE config 2 at full size (1e6 particles, T = 100): size-independent
     properties — sorted ancestors, determinism, and log-ML within Monte-Carlo

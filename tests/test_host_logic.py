@@ -514,6 +514,18 @@ def test_plates_match_oracle():
     parity.check_plates(n=257)
 
 
+def test_global_resampling_routes_match_oracle():
+    """gmx_shard_plan / gmx_shard_route, all ranks emulated in one process."""
+    from tests import parity
+    assert not parity.check_shard_route(1000, 4)["overflow"]
+    assert not parity.check_shard_route(1000, 4, kind=O.STRATIFIED, seed=3)["overflow"]
+    assert not parity.check_shard_route(777, 3, skew=2.0, seed=1)["overflow"]
+    assert parity.check_shard_route(777, 3, skew=2.0, seed=1, capacity=5)["overflow"]
+    assert not parity.check_shard_route(500, 8, skew=-3.0, seed=2)["overflow"]
+    assert not parity.check_shard_route(64, 2, dead=True)["overflow"]          # no mass anywhere
+    assert not parity.check_shard_route(1000, 1)["overflow"]
+
+
 def test_program_limits():
     """<= 32 live 32-bit values per particle (registers stay in VGPRs); a model
     that needs more fails loudly at trace time instead of spilling silently."""

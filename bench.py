@@ -129,6 +129,9 @@ def main():
         sw = ShardedBootstrapSweep(init, step, n, T, dist, always_communicate=True).prepare(
             G.key(seed), torch.from_numpy(ys))
 
+        if os.environ.get("GENMI_SHARDED_GRAPH") == "1":      # opt-in: see ShardedBootstrapSweep.capture
+            sw.capture()
+
         def launch():
             sw.launch()
             sw.finish()          # the once-per-sweep overflow check (one sync, one 8-byte all-reduce)
@@ -224,6 +227,8 @@ def main():
                                SWEEP_BYTES_PER_PARTICLE_STEP * value / world / 1e9 / HBM_PEAK_GBS}
         be.c.gmx_timer_destroy(timer)
         if not single:
+            out["config"]["communicator"] = sw.cx.name
+            out["config"]["graph"] = sw.graph is not None
             out["config"]["capacity_per_peer"] = sw.capacity
             out["config"]["full_capacity_reruns"] = sw.reruns
         if not args.no_cpu_baseline and world == 1:

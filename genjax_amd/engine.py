@@ -317,6 +317,18 @@ class Compiled:
 
     def run(self, leaves, batch: tuple, key: Key | None, red_out=None, index_offset=0, out_buffers=None):
         """Bind and launch.  Returns the list of output tensors (shape batch+event)."""
+        bound = self.bind(leaves, batch, key, red_out, index_offset, out_buffers)
+        self.launch(bound)
+        return bound[3]
+
+    def launch(self, bound):
+        """Launch a binding made by `bind` (its buffers must still be alive: `bound` keeps them)."""
+        be = self._be
+        be.check(be.c.gmx_program_run(self.handle, bound[0], bound[1], be.stream()), "gmx_program_run")
+
+    def bind(self, leaves, batch: tuple, key: Key | None, red_out=None, index_offset=0, out_buffers=None):
+        """Fill a gmx_run_args for these leaves: (n, args, keep-alive list, outputs).  Sweeps whose
+        buffers are persistent bind every step once and re-launch the bindings."""
         be = self._be
         n = int(np.prod(batch, dtype=np.int64))
         if n >= JIT_MIN_PARTICLES and not self._jit_tried and be.uses_streams \
@@ -394,8 +406,8 @@ class Compiled:
                 red_out = torch.empty((2, grid), dtype=torch.float32, device=be.device)
             A.red_out_d = red_out.data_ptr()
             self.last_red = red_out
-        be.check(be.c.gmx_program_run(self.handle, n, A, be.stream()), "gmx_program_run")
-        return outs
+            keep.append(red_out)
+        return n, A, keep, outs
 
 
 def _prepare_input(src, kind, n, be):

@@ -82,6 +82,8 @@ class ShardedBootstrapSweep:
         self.reruns = 0
         # issue the collectives even at world size 1 (exercises / times the RCCL calls on one GPU)
         self.comm = self.world > 1 or bool(always_communicate)
+        self.cx = None           # comm.RcclComm / comm.TorchComm, made in prepare()
+        self.graph = None
 
     def prepare(self, key: Key, ys: torch.Tensor):
         from ..static import MinimalGenerate
@@ -98,6 +100,9 @@ class ShardedBootstrapSweep:
         self.plan = torch.zeros((int(be.c.gmx_shard_plan_words(W)),), dtype=torch.int64, device=dev)
         self.ws = torch.zeros(((be.c.gmx_weight_cdf_workspace(n) + 7) // 8,), dtype=torch.int64, device=dev)
         self.shift = cdf_shift(self.N)
+        if self.comm and self.cx is None:
+            from .comm import make_comm
+            self.cx = make_comm(self.dist, dev)
         self._alloc_exchange()
         obs0 = ChoiceMap.empty().set(self.obs_addr, self.ys[0])
         self.p_init = MinimalGenerate(self.init, (), obs0, (n,))
@@ -120,11 +125,14 @@ class ShardedBootstrapSweep:
         self.xext = [torch.zeros((n + W * C,), dtype=torch.float32, device=dev) for _ in range(2)]
         self.send = torch.zeros((W * C,), dtype=torch.float32, device=dev)
         self.idx = torch.zeros((n,), dtype=torch.int32, device=dev)
+        self._bound = [None] * self.T
 
     # ------------------------------------------------------------------
-    def _step(self, t):
-        be, dist = _lib.get(), self.dist
-        n, N, g, W, C = self.n, self.N, self.rank, self.world, self.capacity
+    def _bind_step(self, t):
+        """Everything step t launches, bound once (all buffers are persistent): the site-program
+        launch arguments plus the argument tuples of the resampling entry points."""
+        be = _lib.get()
+        n, g, W, C = self.n, self.rank, self.world, self.capacity
         k_prop, k_res, _ = self.step_keys[t]
         obs = ChoiceMap.empty().set(self.obs_addr, self.ys[t])
         cur = self.xext[t % 2]
@@ -137,32 +145,40 @@ class ShardedBootstrapSweep:
         bufs[prog.ro[1]] = cur[:n].reshape(1, n)
         bufs[prog.wo[1]] = self.lw.reshape(1, n)
         # keys of the GLOBAL particle index: split(k_prop, N)[g*n + i]
-        prog.comp.run(leaves, (n,), lazy_split(k_prop, N), red_out=self.partials, out_buffers=bufs,
-                      index_offset=g * n)
-        # ---- global max: local reduce + all-reduce MAX (4 bytes) ----
-        m = self.maxs[t:t + 1]
-        be.check(be.c.gmx_reduce_max(be.ptr(self.partials), self.partials.shape[1], be.ptr(m), be.stream()),
-                 "gmx_reduce_max")
-        if self.comm:
-            dist.all_reduce(m, op=dist.ReduceOp.MAX)
-        # ---- local integer CDF relative to the global max ----
-        be.check(be.c.gmx_weight_cdf(be.ptr(self.lw), n, self.shift, None, 0, be.ptr(m), be.ptr(self.cdf),
-                                     be.ptr(self.total_d), be.ptr(self.ws), be.stream()), "gmx_weight_cdf")
-        # ---- all-gather the local totals (8 bytes per rank) ----
-        if self.comm:
-            dist.all_gather_into_tensor(self.totals_all, self.total_d)
-        else:
-            self.totals_all.copy_(self.total_d)
-        # ---- slot boundaries + routing, on the device ----
+        vm = prog.comp.bind(leaves, (n,), lazy_split(k_prop, self.N), red_out=self.partials, out_buffers=bufs,
+                            index_offset=g * n)
         kh = k_res.host()
         kk = (c_uint32 * 2)(int(kh[0]), int(kh[1]))
-        be.check(be.c.gmx_shard_plan(self.kind, kk, be.ptr(self.totals_all), g, W, n, be.ptr(self.plan),
-                                     be.ptr(self.totals[t:t + 1]), be.stream()), "gmx_shard_plan")
-        be.check(be.c.gmx_shard_route(self.kind, kk, be.ptr(self.plan), be.ptr(self.cdf), g, W, n, C, be.ptr(cur),
-                                      be.ptr(self.send), be.ptr(self.idx), be.stream()), "gmx_shard_route")
-        # ---- one equal-split all-to-all: block s of my receive area <- block `me` of rank s's send ----
+        m = self.maxs[t:t + 1]
+        tot = self.totals[t:t + 1]
+        P = be.ptr
+        return {
+            "prog": prog.comp, "vm": vm, "m": m, "recv": cur[n:], "keep": (kk, tot, leaves),
+            "max": (P(self.partials), self.partials.shape[1], P(m)),
+            "cdf": (P(self.lw), n, self.shift, None, 0, P(m), P(self.cdf), P(self.total_d), P(self.ws)),
+            "plan": (self.kind, kk, P(self.totals_all), g, W, n, P(self.plan), P(tot)),
+            "route": (self.kind, kk, P(self.plan), P(self.cdf), g, W, n, C, P(cur), P(self.send), P(self.idx)),
+        }
+
+    def _step(self, t):
+        be = _lib.get()
+        b = self._bound[t]
+        if b is None:
+            b = self._bound[t] = self._bind_step(t)
+        c, st = be.c, be.stream()
+        b["prog"].launch(b["vm"])                                      # x_t, lw_t, block maxima
+        be.check(c.gmx_reduce_max(*b["max"], st), "gmx_reduce_max")    # local max ...
         if self.comm:
-            dist.all_to_all_single(cur[n:], self.send)
+            self.cx.all_reduce_max(b["m"])                               # ... -> global max (4 bytes)
+        be.check(c.gmx_weight_cdf(*b["cdf"], st), "gmx_weight_cdf")    # local integer CDF vs the global max
+        if self.comm:
+            self.cx.all_gather(self.totals_all, self.total_d)            # 8 bytes per rank
+        else:
+            self.totals_all.copy_(self.total_d)
+        be.check(c.gmx_shard_plan(*b["plan"], st), "gmx_shard_plan")   # slot boundaries, on the device
+        be.check(c.gmx_shard_route(*b["route"], st), "gmx_shard_route")
+        if self.comm:
+            self.cx.all_to_all(b["recv"], self.send)                     # block s of recv <- block `me` of rank s
 
     def kernel_timers(self):
         """The site-program launch of a mid-sweep step (no collectives): bench.py's roofline kernel."""
@@ -186,8 +202,39 @@ class ShardedBootstrapSweep:
         for t in range(self.T):
             self._step(t)
 
+    def capture(self):
+        """OPT-IN (GENMI_SHARDED_GRAPH=1 in bench.py): capture the whole sweep — kernels AND the
+        RCCL collectives, which comm.RcclComm issues on this same stream — into one hipGraph so
+        the host leaves the loop.  Exercised at world size 1 only (no multi-GPU box in the build
+        loop); the default multi-GPU path enqueues eagerly."""
+        be = _lib.get()
+        if self.comm and not self.cx.graph_safe:
+            raise RuntimeError("capture() needs the direct RCCL communicator (torch.distributed's watchdog "
+                               "queries events recorded inside the capture)")
+        from ctypes import c_void_p
+        s = torch.cuda.Stream(device=be.device)
+        s.wait_stream(torch.cuda.current_stream(be.device))
+        with torch.cuda.stream(s):
+            self.enqueue()
+            s.synchronize()
+            be.check(be.c.gmx_capture_begin(be.stream()), "gmx_capture_begin")
+            try:
+                self.enqueue()
+            finally:
+                h = c_void_p()
+                rc = be.c.gmx_capture_end(be.stream(), h)
+            be.check(rc, "gmx_capture_end")
+        torch.cuda.current_stream(be.device).wait_stream(s)
+        self.graph = h
+        return self
+
     def launch(self):
-        self.enqueue()
+        if self.graph is not None:
+            be = _lib.get()
+            self._finished = False
+            be.check(be.c.gmx_graph_launch(self.graph, be.stream()), "gmx_graph_launch")
+        else:
+            self.enqueue()
 
     def finish(self):
         """Read the overflow flag (one sync per sweep; COLLECTIVE — every rank calls it, which
@@ -196,10 +243,11 @@ class ShardedBootstrapSweep:
             return self
         flag = self.plan[2:3].clone()
         if self.comm:
-            self.dist.all_reduce(flag, op=self.dist.ReduceOp.MAX)
+            self.cx.all_reduce_max(flag)
         if int(flag.item()) != 0:
             self.reruns += 1
             self.capacity = self.n
+            self.graph = None
             self._alloc_exchange()
             self.enqueue()
             assert int(self.plan[2].item()) == 0

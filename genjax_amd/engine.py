@@ -98,7 +98,13 @@ def leaf_spec(v, batch: tuple):
         if v.ndim == 0:
             return leaf_spec(v.item(), batch)
         return ("hvec", _np_dt(v), tuple(v.shape))
+    if getattr(v, "__gmx_static__", False):
+        _STATIC_KEEP[id(v)] = v            # host object the traced function only reads (e.g. a Target)
+        return ("static", id(v))
     raise TypeError(f"unsupported launch value of type {type(v).__name__}")
+
+
+_STATIC_KEEP: dict = {}
 
 
 class Flat:
@@ -168,6 +174,8 @@ class Tracing:
         kind = spec[0]
         if kind == "none":
             return Sym(None, ("leaf", j))
+        if kind == "static":
+            return Sym(_STATIC_KEEP[spec[1]], ("leaf", j))
         if kind == "uni":
             n = g.uniform(spec[1])
             self.uni_plan.append((n.imm, j, None, spec[1]))

@@ -51,6 +51,32 @@ def trace_map(tr, fn):
                        OrderedDict((a, trace_map(s, fn)) for a, s in tr.subtraces.items()))
 
 
+def stack_traces(trs, tr_one):
+    """tree_map(stack_to_first_dim, trs, tr_one) (smc.py:56-68, :343-345): append ONE unbatched
+    trace after the K-1 particles of a batched trace along the particle axis."""
+    def cat(a, b):
+        a = engine.materialize(a)
+        b = engine.materialize(b)
+        if not isinstance(a, torch.Tensor):
+            return a                                   # static argument (same in both traces)
+        b = torch.as_tensor(b, dtype=a.dtype, device=a.device) if not isinstance(b, torch.Tensor) else b.to(a.dtype)
+        return torch.cat([a, b.reshape((1,) + tuple(a.shape[1:]))], dim=0)
+
+    def leaf(a, b):
+        if isinstance(a, (torch.Tensor, Gathered)):
+            return cat(a, b)
+        if isinstance(a, (tuple, list)):
+            return type(a)(leaf(x, y) for x, y in zip(a, b))
+        if isinstance(a, dict):
+            return {k: leaf(a[k], b[k]) for k in a}
+        return a
+    if isinstance(trs, DistributionTrace):
+        return DistributionTrace(trs.gen_fn, leaf(trs.args, tr_one.args), leaf(trs.value, tr_one.value),
+                                 leaf(trs.score, tr_one.score))
+    return StaticTrace(trs.gen_fn, leaf(trs.args, tr_one.args), leaf(trs.retval, tr_one.retval),
+                       OrderedDict((a, stack_traces(s, tr_one.subtraces[a])) for a, s in trs.subtraces.items()))
+
+
 def trace_leaves(tr) -> list:
     out = []
     trace_map(tr, lambda v: (out.append(v), v)[1])
@@ -118,8 +144,7 @@ class SMCAlgorithm(Algorithm):
     def get_final_target(self): raise NotImplementedError
     def run_smc(self, key): raise NotImplementedError
 
-    def run_csmc(self, key, retained):
-        raise NotImplementedError("conditional SMC: SURVEY.md §8(f) item 4 (next tier)")
+    def run_csmc(self, key, retained): raise NotImplementedError
 
     def log_marginal_likelihood_estimate(self, key, target=None):
         algorithm = ChangeTarget(self, target) if target else self       # smc.py:150-153
@@ -138,6 +163,16 @@ class SMCAlgorithm(Algorithm):
         chm = target.filter_to_unconstrained(particle.get_choices())
         return estimate, chm
 
+    def estimate_logpdf(self, key, v, *args):
+        """smc.py:181-198: conditional SMC with `v` retained in the last slot."""
+        target = args[0]
+        assert isinstance(target, Target)
+        algorithm = ChangeTarget(self, target)
+        key, sub_key = split(key)
+        collection = algorithm.run_csmc(key, v)
+        particle = collection.sample_particle(sub_key)
+        return particle.get_score() - collection.get_log_marginal_likelihood_estimate()
+
     def estimate_normalizing_constant(self, key, target):
         algorithm = ChangeTarget(self, target)
         key, sub_key = split(key)
@@ -149,8 +184,6 @@ class Importance(SMCAlgorithm):
     generated with `key` itself (child 0 of the split)."""
 
     def __init__(self, target: Target, q=None):
-        if q is not None:
-            raise NotImplementedError("custom proposals q: SURVEY.md §8(f) item 4 (next tier)")
         self.target, self.q = target, q
 
     def get_num_particles(self): return 1
@@ -159,8 +192,21 @@ class Importance(SMCAlgorithm):
     def run_smc(self, key):
         key, sub_key = split(key)
         k1 = key.reshape(tuple(key.shape) + (1,))
+        if self.q is not None:                                           # smc.py:256-258
+            log_weight, choice = self.q.random_weighted(sub_key, self.target)
+            tr, score = self.target.importance(k1, _expand(choice))
+            return ParticleCollection(tr, score - _expand_leaf(log_weight), True)
         tr, score = self.target.importance(k1, ChoiceMap.empty())
         return ParticleCollection(tr, score, True)
+
+    def run_csmc(self, key, retained):
+        """smc.py:268-279"""
+        _unbatched(key, "Importance.run_csmc")
+        key, sub_key = split(key)
+        q_score = self.q.estimate_logpdf(sub_key, retained, self.target) if self.q is not None else 0.0
+        k1 = key.reshape((1,))
+        tr, score = self.target.importance(k1, _expand(retained))
+        return ParticleCollection(tr, score - _expand_leaf(q_score), True)
 
 
 class ImportanceK(SMCAlgorithm):
@@ -168,8 +214,6 @@ class ImportanceK(SMCAlgorithm):
     key, sub = split(key); keys = split(sub, K); one fused launch over K."""
 
     def __init__(self, target: Target, q=None, k_particles: int = 2):
-        if q is not None:
-            raise NotImplementedError("custom proposals q: SURVEY.md §8(f) item 4 (next tier)")
         self.target, self.q, self.k_particles = target, q, int(k_particles)
 
     def get_num_particles(self): return self.k_particles
@@ -178,8 +222,30 @@ class ImportanceK(SMCAlgorithm):
     def run_smc(self, key):
         key, sub_key = split(key)
         sub_keys = split(sub_key, self.k_particles)
+        if self.q is not None:                                           # smc.py:301-305
+            log_weights, choices = self.q.random_weighted(sub_keys, self.target)
+            trs, target_scores = self.target.importance(sub_keys, choices)
+            return ParticleCollection(trs, target_scores - log_weights, True)
         trs, target_scores = self.target.importance(sub_keys, ChoiceMap.empty())
         return ParticleCollection(trs, target_scores, True)         # log_weights = scores - 0.0
+
+    def run_csmc(self, key, retained):
+        """smc.py:317-351: K-1 fresh particles, the retained choices in slot K-1."""
+        _unbatched(key, "ImportanceK.run_csmc")
+        K = self.k_particles
+        key, sub_key = split(key)
+        sub_keys = split(sub_key, K - 1)
+        if self.q is not None:
+            log_scores, choices = self.q.random_weighted(sub_keys, self.target)
+            retained_score = self.q.estimate_logpdf(key, retained, self.target)
+            stacked = _stack_chm(choices, retained)
+            stacked_scores = torch.cat([log_scores, _expand_leaf(retained_score).to(log_scores.device)])
+            trs, target_scores = self.target.importance(split(key, K), stacked)
+            return ParticleCollection(trs, target_scores - stacked_scores, True)
+        ignored, ignored_scores = self.target.importance(sub_keys, ChoiceMap.empty())
+        retained_tr, retained_score = self.target.importance(key, retained)
+        scores = torch.cat([ignored_scores, retained_score.reshape(1)])
+        return ParticleCollection(stack_traces(ignored, retained_tr), scores, True)
 
 
 class ChangeTarget(SMCAlgorithm):
@@ -200,6 +266,50 @@ class ChangeTarget(SMCAlgorithm):
         new_particles, new_weight = self.target.importance(sub_keys, latents)
         this_weight = new_weight - particles.get_score() + collection.get_log_weights()   # smc.py:383
         return ParticleCollection(new_particles, this_weight, True, collection.log_ml_offset)
+
+    def run_csmc(self, key, retained):
+        """smc.py:398-425: prev.run_csmc(key, retained), then the same re-weighting."""
+        collection = self.prev.run_csmc(key, retained)
+        particles = collection.get_particles()
+        latents = self.prev.get_final_target().filter_to_unconstrained(particles.get_choices())
+        sub_keys = split(key, self.get_num_particles())
+        new_particles, new_score = self.target.importance(sub_keys, latents)
+        this_weight = new_score - particles.get_score() + collection.get_log_weights()
+        return ParticleCollection(new_particles, this_weight, True)
+
+
+def _unbatched(key: Key, who: str):
+    if tuple(key.shape) != ():
+        raise NotImplementedError(f"{who} under a batch of keys")
+
+
+def _expand_leaf(v):
+    """jnp.expand_dims(v, 0) for a score (tensor or Python number)."""
+    be = _lib.get()
+    t = v if isinstance(v, torch.Tensor) else torch.tensor(float(v), dtype=torch.float32, device=be.device)
+    return t.reshape((1,) + tuple(t.shape))
+
+
+def _expand(chm: ChoiceMap) -> ChoiceMap:
+    """A one-particle batch of an unbatched choice map."""
+    be = _lib.get()
+
+    def one(v):
+        t = torch.as_tensor(v, device=be.device) if not isinstance(v, torch.Tensor) else v
+        if t.dtype == torch.float64:
+            t = t.float()
+        return t.reshape((1,) + tuple(t.shape))
+    return chm.map_values(one)
+
+
+def _stack_chm(choices: ChoiceMap, one: ChoiceMap) -> ChoiceMap:
+    """tree_map(stack_to_first_dim, choices, retained) over choice maps with the same addresses."""
+    out = ChoiceMap.empty()
+    for a in choices.addresses():
+        v = engine.materialize(choices[a])
+        r = torch.as_tensor(one[a], dtype=v.dtype, device=v.device).reshape((1,) + tuple(v.shape[1:]))
+        out = out.set(a, torch.cat([v, r], dim=0))
+    return out
 
 
 # ---------------------------------------------------------------------------

@@ -8,9 +8,9 @@ from ..core.generative import GenerativeFunction
 
 
 class Marginal(GenerativeFunction):
-    """sp.py:207-252.  Container only on the round-1 hot path: `Target` must
-    reject it (tests/inference/test_smc.py:89-106); its sampler is next-tier
-    (SURVEY.md §8f item 4)."""
+    """The marginal of a generative function over a selection (sp.py:207-252).
+    `Target` rejects it as a model (tests/inference/test_smc.py:89-106); as a
+    proposal `q` it is a SampleDistribution: `random_weighted` / `estimate_logpdf`."""
 
     def __init__(self, gen_fn, selection=None, algorithm=None):
         self.gen_fn = gen_fn
@@ -18,10 +18,26 @@ class Marginal(GenerativeFunction):
         self.algorithm = algorithm
 
     def random_weighted(self, key, *args):
-        raise NotImplementedError("Marginal.random_weighted: SURVEY.md §8(f) item 4 (next tier)")
+        """sp.py:217-240, literally: simulate, keep the selected choices, weight =
+        project(trace, ~selection)."""
+        from ..random import split
+        key, sub_key = split(key)
+        tr = self.gen_fn.simulate(sub_key, tuple(args))
+        choices = tr.get_choices()
+        latent_choices = choices.filter(self.selection)
+        key, sub_key = split(key)
+        weight = tr.project(sub_key, ~self.selection)
+        if self.algorithm is None:
+            return weight, latent_choices
+        raise NotImplementedError("Marginal with an inner algorithm needs estimate_reciprocal_normalizing_constant "
+                                  "(variational interface; out of the hot path)")
 
     def estimate_logpdf(self, key, v, *args):
-        raise NotImplementedError("Marginal.estimate_logpdf: SURVEY.md §8(f) item 4 (next tier)")
+        """sp.py:242-254"""
+        if self.algorithm is None:
+            _, weight = self.gen_fn.importance(key, v, tuple(args))
+            return weight
+        return self.algorithm.estimate_normalizing_constant(key, Target(self.gen_fn, tuple(args), v))
 
 
 def marginal(selection=None, algorithm=None):
@@ -33,6 +49,8 @@ def marginal(selection=None, algorithm=None):
 class Target:
     """An unnormalised posterior: (generative function, arguments, constraint)
     (sp.py:52-94)."""
+
+    __gmx_static__ = True        # as an argument of a proposal it is a host object, not a launch value
 
     def __init__(self, p, args, constraint: ChoiceMap):
         if isinstance(p, Marginal):

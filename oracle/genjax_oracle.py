@@ -1059,6 +1059,57 @@ class ChangeTarget:
         return ParticleCollection(new_tr, this)
 
 
+def _stack_trace(trs, one):
+    """tree_map(stack_to_first_dim, trs, one) (smc.py:56-68)."""
+    def cat(a, b):
+        if a is None:
+            return None
+        if isinstance(a, tuple):
+            return tuple(cat(x, y) for x, y in zip(a, b))
+        a = np.asarray(a)
+        if a.ndim == 0:
+            return a
+        b = np.asarray(b, dtype=a.dtype)
+        return np.concatenate([a, b.reshape((1,) + a.shape[1:])], axis=0)
+    if isinstance(trs, DistTrace):
+        n = np.shape(trs.score)[0]
+        args = tuple(cat(x, y) if np.shape(x)[:1] == (n,) else x for x, y in zip(trs.args, one.args))
+        return DistTrace(trs.gen_fn, args, cat(trs.value, one.value), cat(trs.score, one.score))
+    return StaticTrace(trs.gen_fn, trs.args, cat(trs.retval, one.retval),
+                       OrderedDict((a, _stack_trace(s, one.subtraces[a])) for a, s in trs.subtraces.items()))
+
+
+def importancek_run_csmc(alg: "ImportanceK", k, retained: ChoiceMap):
+    """ImportanceK.run_csmc without a proposal (smc.py:317-351)."""
+    ks = split(k)
+    key, sub = ks[0], ks[1]
+    sub_keys = split(sub, alg.k - 1)
+    ignored, ignored_scores = alg.target.importance(sub_keys, ChoiceMap.empty())
+    rtr, rscore = alg.target.importance(key, retained)
+    scores = np.concatenate([np.asarray(ignored_scores, np.float32), np.asarray(rscore, np.float32).reshape(1)])
+    return ParticleCollection(_stack_trace(ignored, rtr), scores)
+
+
+def changetarget_run_csmc(alg: "ChangeTarget", k, retained: ChoiceMap):
+    """ChangeTarget.run_csmc (smc.py:398-425)."""
+    coll = importancek_run_csmc(alg.prev, k, retained)
+    particles, lw = coll.get_particles(), coll.get_log_weights()
+    latents = alg.prev.get_final_target().filter_to_unconstrained(particles.get_choices())
+    new_tr, new_w = alg.target.importance(split(k, alg.get_num_particles()), latents)
+    this = ((new_w - particles.get_score()).astype(np.float32) + lw).astype(np.float32)
+    return ParticleCollection(new_tr, this)
+
+
+def estimate_logpdf(alg, k, v: ChoiceMap, target: Target):
+    """SMCAlgorithm.estimate_logpdf (smc.py:181-198)."""
+    algorithm = ChangeTarget(alg, target)
+    ks = split(k)
+    coll = changetarget_run_csmc(algorithm, ks[0], v)
+    idx = int(coll.sample_index(ks[1]))
+    score = np.asarray(coll.get_particles().get_score(), np.float32)[idx]
+    return (score - coll.get_log_marginal_likelihood_estimate()).astype(np.float32)
+
+
 def log_marginal_likelihood_estimate(alg, k, target=None):
     """SMCAlgorithm.log_marginal_likelihood_estimate (smc.py:145-156)."""
     if target is not None:

@@ -324,6 +324,10 @@ def test_sharded_sweep_world1_matches_oracle(gpu):
     assert sw.log_ml() == ref["log_ml"]
 
 
+def test_conditional_smc_and_proposals(gpu):
+    parity.check_csmc(k=10_001)
+
+
 def test_full_size_sweep_properties(gpu):
     """BASELINE config 2 at full size (1e6 particles, T = 100): size-independent
     properties — sorted ancestors, determinism, and log-ML within Monte-Carlo

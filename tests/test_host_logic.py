@@ -526,6 +526,11 @@ def test_global_resampling_routes_match_oracle():
     assert not parity.check_shard_route(1000, 1)["overflow"]
 
 
+def test_conditional_smc_and_proposals():
+    from tests import parity
+    parity.check_csmc(k=257)
+
+
 def test_program_limits():
     """<= 32 live 32-bit values per particle (registers stay in VGPRs); a model
     that needs more fails loudly at trace time instead of spilling silently."""

@@ -160,7 +160,7 @@ static int parse_program(const uint32_t* blob, size_t n_words, gmx_program& P) {
     if (gmx_op_needs_full(op)) P.needs_full = true;
     switch (op) {
       case OP_END: break;
-      case OP_CONST: ok = D(dst); break;
+      case OP_CONST: case OP_LDIDX: ok = D(dst); break;
       case OP_UNI: ok = D(dst) && w1 < P.n_uni; break;
       case OP_LDIN: ok = D(dst) && a < P.n_in; if (b & GMX_F_GATHER) P.uses_gather = true; break;
       case OP_LDTAB: ok = D(dst) && R(b) && a < P.n_tab; break;
@@ -262,7 +262,7 @@ extern "C" int gmx_program_specialize(gmx_program* p) {
   if (!p) return gmx_fail("gmx_program_specialize: null program%s");
   if (p->jit_fn) return 0;
   if (!jit_enabled()) return gmx_fail("gmx_program_specialize: disabled by GENMI_JIT=0%s");
-  if (p->n_instr == 0 || p->n_instr > 512) return gmx_fail("gmx_program_specialize: program size out of range%s");
+  if (p->n_instr == 0 || p->n_instr > 2048) return gmx_fail("gmx_program_specialize: program size out of range%s");
   std::string src = jit_source(p);
   hiprtcProgram prog;
   const char* hdr_src[GMX_EMBED_COUNT];

@@ -53,6 +53,7 @@ enum gmx_op {
   OP_LDKEY = 6,   // (r[dst], r[dst+1]) = particle key
   OP_KDERIVE = 7, // (r[dst], r[dst+1]) = threefry(key r[a..a+1], ctr (0, imm))  == fold_in / split child
   OP_KDERIVER = 8,// same with ctr (0, (uint)r[b])
+  OP_LDIDX = 9,   // r[dst] = (i32) global particle index (index_offset + i)
   OP_MOV = 10,
   OP_ADD = 11, OP_SUB = 12, OP_MUL = 13, OP_DIV = 14, OP_MIN = 15, OP_MAX = 16, OP_POW = 17,
   OP_NEG = 20, OP_ABS = 21, OP_EXP = 22, OP_LOG = 23, OP_LOG1P = 24, OP_SQRT = 25,

@@ -121,6 +121,7 @@ GMX_HD void gmx_vm_step(Regs& R, const W w, int64_t i, bool active, const gmx_ru
         gmx_key o = gmx_fold_in(k, d);
         r0 = o.k0; r1 = o.k1; wr = 2;
       } break;
+      case OP_LDIDX: r0 = (uint32_t)(A.index_offset + i); break;
       case OP_MOV: r0 = SRC(a); break;
       // ---- f32 binary ----
       case OP_ADD: r0 = gmx_asu(FSRC(a) + FSRC(b)); break;

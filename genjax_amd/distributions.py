@@ -248,6 +248,8 @@ class _Categorical(Distribution):
         from . import numpy as jnp
         ls = self._logits(args)
         lse = jnp.logsumexp(np.asarray(ls, dtype=object))
+        if isinstance(v, (int, np.integer)) and not isinstance(v, bool):
+            return ls[int(v)] - lse                 # a category fixed at trace time (enumeration)
         vi = T.as_int(v)
         picked = ls[0]
         for k in range(1, len(ls)):

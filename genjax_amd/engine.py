@@ -63,6 +63,9 @@ def _np_dt(a: np.ndarray) -> str:
     return "f32" if a.dtype.kind == "f" else ("bool" if a.dtype.kind == "b" else "i32")
 
 
+DVEC_MAX = 16       # longer launch-uniform device vectors are bound as tables, not as one input slot per element
+
+
 def leaf_spec(v, batch: tuple):
     """Classify one launch value (see module docstring)."""
     nb = len(batch)
@@ -89,6 +92,8 @@ def leaf_spec(v, batch: tuple):
             return ("bcast", dt)
         if nb == 0:
             return ("part", dt, shp)
+        if v.ndim == 1 and shp[0] > DVEC_MAX:
+            return ("dtab", dt, shp)           # launch-uniform table read with OP_LDTAB
         return ("dvec", dt, shp)
     if isinstance(v, (list, tuple)):
         v = np.asarray(v)
@@ -163,6 +168,7 @@ class Tracing:
         self.graph = Graph()
         self.in_plan = []      # (slot, leaf, elem, kind)
         self.uni_plan = []     # (uni index, leaf, elem, dtype)
+        self.tab_plan = []     # (table slot, leaf): launch-uniform device tables
         self.outputs = []      # (dtype, n_elems, [slots])
         self.node_origin = {}  # id(node) -> origin
         self.prestored = {}    # id(node) -> slot of a store emitted early (plate elements)
@@ -189,6 +195,11 @@ class Tracing:
                 self.uni_plan.append((n.imm, j, e, spec[1]))
                 arr[idx] = Expr(n)
             return Sym(arr, ("leaf", j))
+        if kind == "dtab":
+            from .numpy import RuntimeTable, runtime_table_slot
+            slot = runtime_table_slot(g)
+            self.tab_plan.append((slot, j))
+            return Sym(RuntimeTable.make(g, slot, spec[1], spec[2][0]), ("leaf", j))
         flags = {"bcast": F_BCAST, "dvec": F_BCAST, "part": 0, "gather": F_GATHER}[kind]
         dt = spec[1]
         event = () if kind == "bcast" else spec[2]
@@ -286,6 +297,7 @@ class Compiled:
         be = _lib.get()
         self.blob, self.const_pool = compile_graph(tr.graph)
         self.in_plan, self.uni_plan, self.outputs = tr.in_plan, tr.uni_plan, tr.outputs
+        self.tab_plan = tr.tab_plan
         self.n_in, self.n_out, self.n_uni = tr.graph.n_in, tr.graph.n_out, tr.graph.n_uni
         self.uses_red = any(n.op in ("REDMAX", "REDLSE") for n in tr.graph.nodes)
         if max(self.n_in, self.n_out) > _lib.GMX_MAX_IN or self.n_uni > _lib.GMX_MAX_UNI:
@@ -294,6 +306,9 @@ class Compiled:
         tabs = tr.graph.__dict__.get("tables", [])
         self.tables = []
         for t in tabs:
+            if t is None:                      # runtime table: bound per launch (tab_plan)
+                self.tables.append(None)
+                continue
             a = np.ascontiguousarray(t)
             if a.dtype.kind == "f":
                 a = a.astype(np.float32)
@@ -383,7 +398,12 @@ class Compiled:
                 v = np.asarray(v).reshape(-1)[e]
             A.uni[ui] = _bits(v, dt)
         for s, t in enumerate(self.tables):
-            A.tab_d[s] = t.data_ptr()
+            if t is not None:
+                A.tab_d[s] = t.data_ptr()
+        for slot, j in self.tab_plan:
+            t = _prepare_input(leaves[j], "dvec", None, be)
+            keep.append(t)
+            A.tab_d[slot] = t.data_ptr()
         outs = []
         for k, (dt, event, slots) in enumerate(self.outputs):
             E = len(slots)

@@ -48,9 +48,47 @@ class TableArray(np.ndarray):
         return r
 
 
+class RuntimeTable(np.ndarray):
+    """A launch-uniform device vector (an argument such as cluster means): an object array of
+    OP_LDTAB reads at constant indices (dead ones are eliminated), so every vector operation
+    works on it; indexing with a traced integer is one OP_LDTAB at a register index."""
+
+    @classmethod
+    def make(cls, g, slot, dt, n):
+        zero = g.const_i32(0)
+        arr = np.empty((n,), dtype=object)
+        for k in range(n):
+            arr[k] = Expr(g.add("LDTAB", (zero,), imm=k, dtype=dt, slot=slot))
+        out = arr.view(cls)
+        out._slot, out._dt = slot, dt
+        return out
+
+    def __array_finalize__(self, obj):
+        self._slot = getattr(obj, "_slot", None)
+        self._dt = getattr(obj, "_dt", None)
+
+    def __getitem__(self, idx):
+        if isinstance(idx, Expr) and self._slot is not None and self.ndim == 1:
+            g = T.current_graph()
+            if idx.node.op == "CONST":                           # static after all: the shared element read
+                return Expr(g.add("LDTAB", (g.const_i32(0),), imm=idx.node.imm, dtype=self._dt, slot=self._slot))
+            return Expr(g.add("LDTAB", (T.as_int(idx).node,), dtype=self._dt, slot=self._slot))
+        r = np.ndarray.__getitem__(self, idx)
+        return r
+
+
+def runtime_table_slot(g) -> int:
+    tabs = g.__dict__.setdefault("tables", [])
+    tabs.append(None)
+    g.n_tab = len(tabs)
+    return len(tabs) - 1
+
+
 def table_slot(g, arr) -> int:
     tabs = g.__dict__.setdefault("tables", [])
     for s, t in enumerate(tabs):
+        if t is None:
+            continue
         if t is arr or (t.shape == arr.shape and t.dtype == arr.dtype and np.array_equal(t, arr)):
             return s
     tabs.append(arr)

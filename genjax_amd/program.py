@@ -24,7 +24,7 @@ F_GATHER, F_U8, F_BCAST = 1, 2, 4
 
 # opcode numbers: keep in sync with gmx_program.h
 OPC = dict(
-    END=0, CONST=1, UNI=2, LDIN=3, LDTAB=4, STOUT=5, LDKEY=6, KDERIVE=7, KDERIVER=8, MOV=10,
+    END=0, CONST=1, UNI=2, LDIN=3, LDTAB=4, STOUT=5, LDKEY=6, KDERIVE=7, KDERIVER=8, LDIDX=9, MOV=10,
     ADD=11, SUB=12, MUL=13, DIV=14, MIN=15, MAX=16, POW=17,
     NEG=20, ABS=21, EXP=22, LOG=23, LOG1P=24, SQRT=25, SIN=26, COS=27, TANH=28, SIGMOID=29,
     SOFTPLUS=30, FLOOR=31, LGAMMA=32, SQUARE=33, RECIP=34, CEIL=35, ROUND=36,
@@ -46,6 +46,9 @@ SAMPLER1 = {"S_FLIP", "S_BERNL"}                    # args (key, a)
 LOGPDF2 = {"L_NORMAL", "L_UNIFORM", "L_BETA"}       # args (x, a, b)
 LOGPDF1 = {"L_FLIP", "L_BERNL"}                     # args (x, a)
 EFFECT = {"STOUT", "REDMAX", "REDLSE"}
+_NO_CSE = EFFECT | {"LDIN", "UNI", "CONST", "S_CATSTEP", "CATIDX"}     # slots are unique; CONSTs have their own table
+# values recomputed at every use instead of being held in a register (see compile_graph)
+REMAT_UNARY = {"LOG", "EXP", "NEG", "SQUARE", "SQRT", "RECIP", "I2F"}
 
 
 @dataclass(eq=False)
@@ -71,10 +74,22 @@ class Graph:
     n_uni: int = 0
     n_tab: int = 0
     _consts: dict = field(default_factory=dict)
+    _cse: dict = field(default_factory=dict)
 
     def add(self, op, args=(), imm=0, dtype="f32", flags=0, slot=0) -> Node:
-        n = Node(op, tuple(args), int(imm) & 0xFFFFFFFF, dtype, flags, slot, len(self.nodes))
+        """Append a node.  Pure nodes are hash-consed: tracing the same expression twice (e.g. the
+        normaliser of a categorical scored once per category in an enumeration) yields ONE node."""
+        args = tuple(args)
+        key = None
+        if op not in _NO_CSE:
+            key = (op, tuple(a.idx if a is not None else -1 for a in args), int(imm) & 0xFFFFFFFF, dtype, flags, slot)
+            hit = self._cse.get(key)
+            if hit is not None:
+                return hit
+        n = Node(op, args, int(imm) & 0xFFFFFFFF, dtype, flags, slot, len(self.nodes))
         self.nodes.append(n)
+        if key is not None:
+            self._cse[key] = n
         return n
 
     # leaves -----------------------------------------------------------------
@@ -122,6 +137,17 @@ class ProgramTooLarge(Exception):
     pass
 
 
+def _remat_leaves(a, remat):
+    """The register-resident values an operand depends on (through rematerialised nodes)."""
+    if a.idx not in remat:
+        return [a]
+    out = []
+    for x in a.args:
+        if x is not None:
+            out += _remat_leaves(x, remat)
+    return out
+
+
 POOL_BASE = 64
 POOL_SIZE = 64
 
@@ -159,12 +185,24 @@ def compile_graph(g: Graph):
             pool_of[n.idx] = next_pool
             const_pool.append((next_pool, n.imm))
             next_pool += 1
-    order = [n for n in nodes if live[n.idx] and n.idx not in pool_of]
+    # ---- rematerialisable values: an element of a table at a constant index, and one cheap
+    # unary op of it.  Shared (hash-consed) across distant uses they would pin a register each —
+    # 64 log-probabilities read once per enumerated category — so they are re-emitted per use.
+    remat = {}
+    for n in nodes:
+        if not live[n.idx]:
+            continue
+        if n.op == "LDTAB" and n.args[0].op == "CONST":
+            remat[n.idx] = 1
+        elif n.op in REMAT_UNARY and n.args[0].idx in remat and remat[n.args[0].idx] == 1:
+            remat[n.idx] = 2
+    order = [n for n in nodes if live[n.idx] and n.idx not in pool_of and n.idx not in remat]
     last_use = {}
     for pos, n in enumerate(order):
         for a in n.args:
             if a is not None:
-                last_use[a.idx] = pos
+                for leaf in _remat_leaves(a, remat):
+                    last_use[leaf.idx] = pos
     # ---- registers ----
     free = [True] * MAX_REGS
     reg = {}
@@ -190,13 +228,43 @@ def compile_graph(g: Graph):
         words.append(OPC[op] | (dst & 0xFF) << 8 | (a & 0xFF) << 16 | (b & 0xFF) << 24)
         words.append(imm & 0xFFFFFFFF)
 
+    temps = []
+    pre = {}
+
+    def materialise(x):
+        """Recompute a rematerialised value into a scratch register (freed after this instruction)."""
+        if x.op == "LDTAB":
+            t = alloc(1)
+            temps.append(t)
+            emit("LDTAB", t, x.slot, R(x.args[0]), x.imm)
+        else:
+            t = materialise(x.args[0])       # the inner scratch register is updated in place
+            emit(x.op, t, t)
+        return t
+
     def R(x):
         p = pool_of.get(x.idx)
-        return reg[x.idx] if p is None else POOL_BASE + p
+        if p is not None:
+            return POOL_BASE + p
+        if x.idx in remat:
+            return pre[x.idx]
+        return reg[x.idx]
+
+    def drop_temps():
+        for t in temps:
+            free[t] = True
+        temps.clear()
 
     for pos, n in enumerate(order):
+        drop_temps()
+        # scratch registers for rematerialised operands are taken while every operand register is
+        # still allocated, so they cannot alias a value this instruction reads
+        pre.clear()
+        for x in n.args:
+            if x is not None and x.idx in remat and x.idx not in pre:
+                pre[x.idx] = materialise(x)
         # operands whose last use is here may donate their registers to dst
-        dying = [a for a in dict.fromkeys(x for x in n.args if x is not None)
+        dying = [a for a in dict.fromkeys(l for x in n.args if x is not None for l in _remat_leaves(x, remat))
                  if last_use.get(a.idx) == pos and a.idx not in pool_of]
         op = n.op
         if op == "S_CATSTEP":
@@ -231,7 +299,7 @@ def compile_graph(g: Graph):
             emit(op, dst, n.slot, n.flags)
         elif op == "LDTAB":
             emit(op, dst, n.slot, R(n.args[0]), n.imm)
-        elif op == "LDKEY":
+        elif op in ("LDKEY", "LDIDX"):
             emit(op, dst)
         elif op == "KDERIVE":
             emit(op, dst, R(n.args[0]), 0, n.imm)

@@ -92,3 +92,33 @@ def nlssm_data(T: int, seed: int = 2025) -> np.ndarray:
             x = 0.5 * x + 25.0 * x / (1.0 + x * x) + 8.0 * math.cos(1.2 * t) + math.sqrt(10.0) * rng.normal()
         ys.append(x * x / 20.0 + rng.normal())
     return np.asarray(ys, dtype=np.float32)
+
+
+# ---------------------------------------------------------------------------
+# BASELINE config 5: mixture-model cluster assignments
+# ---------------------------------------------------------------------------
+def make_mixture(g, jnp=None, obs_scale=1.0):
+    """`generate_datapoint` of 7_application_dirichlet_mixture_model.ipynb (cell 6): one datapoint's
+    cluster index and observation given the mixture weights and the cluster means."""
+    if jnp is None:
+        from . import numpy as jnp
+
+    @g.gen
+    def generate_datapoint(probs, clusters):
+        idx = g.categorical(jnp.log(probs)) @ "idx"
+        obs = g.normal(clusters[idx], obs_scale) @ "obs"
+        return obs
+    return generate_datapoint
+
+
+def mixture_data(n: int, K: int = 64, seed: int = 7):
+    """n points from K unit-variance Gaussians with means on a grid (spacing 4), plus a perturbed
+    guess of the means and non-uniform weights for the assignment step.  numpy Philox: the data are
+    an input, not part of the parity claim."""
+    rng = np.random.default_rng(seed)
+    means = (4.0 * (np.arange(K) - (K - 1) / 2.0)).astype(np.float32)
+    z = rng.integers(0, K, size=n)
+    x = (means[z] + rng.standard_normal(n)).astype(np.float32)
+    guess = (means + 0.3 * rng.standard_normal(K)).astype(np.float32)
+    probs = rng.dirichlet(np.full(K, 5.0)).astype(np.float32)
+    return x, guess, probs, z.astype(np.int32)

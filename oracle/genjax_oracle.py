@@ -1134,6 +1134,22 @@ def random_weighted(alg, k, target: Target):
     return est, chm
 
 
+def gibbs_categorical(k, gen_fn, args, choices: ChoiceMap, addr, n_categories: int, n: int):
+    """`categorical.simulate(key, (local_densities,))` with local_densities[i, c] =
+    gen_fn.assess(choices_i | {addr: c}, args)[0]  (7_application_dirichlet_mixture_model.ipynb c10):
+    ONE key, gumbel counter i*K + c, first maximum wins.  Materialises the [n, K] matrix."""
+    K = int(n_categories)
+    logits = np.empty((n, K), dtype=np.float32)
+    for c in range(K):
+        s, _ = gen_fn.assess(choices.set(addr, np.full(n, c, dtype=np.int32)), args, (n,))
+        logits[:, c] = np.broadcast_to(np.asarray(s, np.float32), (n,))
+    kb = np.ascontiguousarray(np.asarray(k, np.uint32).reshape(1, 2))
+    ctr = (np.arange(n, dtype=np.uint64) * np.uint64(K))
+    out = np.empty(n, dtype=np.int32)
+    lib().orc_categorical_sample(I64(n), I64(K), _p(kb), I64(0), _p(logits), I64(K), _p(ctr), I64(1), _p(out))
+    return out, logits
+
+
 # ---------------------------------------------------------------------------
 # resampling + SMC step: BUILD-DEFINED (SURVEY.md App. B) — parity unpinned
 # ---------------------------------------------------------------------------

@@ -321,3 +321,32 @@ def mk2(g):
         p = g.beta(2.0, 2.0) @ "p"
         return g.flip(p) @ "v"
     return model
+
+
+# ---------------------------------------------------------------------------
+# BASELINE config 5: mixture-model cluster assignments (integer gate)
+# ---------------------------------------------------------------------------
+def check_mixture_assignments(n=3000, K=64, seed=11, specialize=False):
+    """gibbs_categorical == the oracle's materialised [n, K] categorical draw, bit for bit."""
+    import genjax_amd as G
+    from genjax_amd import ChoiceMapBuilder as C, workloads
+    from genjax_amd.inference import gibbs
+
+    class _ONP:
+        log = staticmethod(O.log)
+    be = __import__("genjax_amd")._lib.get()
+    x, guess, probs, z = workloads.mixture_data(n, K)
+    gd, ogd = workloads.make_mixture(G), workloads.make_mixture(O, jnp=_ONP)
+    dev = be.device
+    args = (torch.from_numpy(probs).to(dev), torch.from_numpy(guess).to(dev))
+    chm = C["obs"].set(torch.from_numpy(x).to(dev))
+    if specialize:
+        gibbs.gibbs_categorical(G.key(seed), gd, args, C["obs"].set(torch.from_numpy(x[:64]).to(dev)), "idx", K)
+        for comp, _ in gibbs._CACHE.values():
+            assert comp.specialize(), "hiprtc specialisation failed"
+    idx = gibbs.gibbs_categorical(G.key(seed), gd, args, chm, "idx", K)
+    oidx, _ = O.gibbs_categorical(O.key(seed), ogd, (probs, guess), O.C.d({"obs": x}), "idx", K, n)
+    assert idx.dtype == torch.int32 and tuple(idx.shape) == (n,)
+    assert np.array_equal(idx.cpu().numpy(), oidx)
+    assert (oidx == z).mean() > 0.85            # well-separated clusters: mostly the generating component
+    return idx

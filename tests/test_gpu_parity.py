@@ -328,6 +328,13 @@ def test_conditional_smc_and_proposals(gpu):
     parity.check_csmc(k=10_001)
 
 
+@pytest.mark.parametrize("n,specialize", [(3000, False), (200_000, False), (200_000, True), (1_000_000, True)])
+def test_mixture_assignments_match_oracle(gpu, n, specialize):
+    """BASELINE config 5: K = 64 cluster assignments, bit-exact against the oracle's materialised
+    [n, K] categorical draw — up to the full N = 1e6."""
+    parity.check_mixture_assignments(n=n, K=64, specialize=specialize)
+
+
 def test_full_size_sweep_properties(gpu):
     """BASELINE config 2 at full size (1e6 particles, T = 100): size-independent
     properties — sorted ancestors, determinism, and log-ML within Monte-Carlo

@@ -531,6 +531,13 @@ def test_conditional_smc_and_proposals():
     parity.check_csmc(k=257)
 
 
+def test_mixture_assignments_match_oracle():
+    """BASELINE config 5 (integer gate) at a CPU-sized N."""
+    from tests import parity
+    parity.check_mixture_assignments(n=3000, K=64)
+    parity.check_mixture_assignments(n=501, K=5, seed=2)
+
+
 def test_program_limits():
     """<= 32 live 32-bit values per particle (registers stay in VGPRs); a model
     that needs more fails loudly at trace time instead of spilling silently."""

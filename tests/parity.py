@@ -341,7 +341,7 @@ def check_mixture_assignments(n=3000, K=64, seed=11, specialize=False):
     args = (torch.from_numpy(probs).to(dev), torch.from_numpy(guess).to(dev))
     chm = C["obs"].set(torch.from_numpy(x).to(dev))
     if specialize:
-        gibbs.gibbs_categorical(G.key(seed), gd, args, C["obs"].set(torch.from_numpy(x[:64]).to(dev)), "idx", K)
+        gibbs.gibbs_categorical(G.key(seed), gd, args, C["obs"].set(torch.from_numpy(x[:100]).to(dev)), "idx", K)   # 100 != K: shapes decide what is per-datapoint
         for comp, _ in gibbs._CACHE.values():
             assert comp.specialize(), "hiprtc specialisation failed"
     idx = gibbs.gibbs_categorical(G.key(seed), gd, args, chm, "idx", K)

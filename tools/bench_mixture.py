@@ -13,6 +13,8 @@ gd = workloads.make_mixture(G)
 args = (torch.from_numpy(probs).cuda(), torch.from_numpy(guess).cuda())
 chm = C["obs"].set(torch.from_numpy(x).cuda())
 out = {}
+from genjax_amd import engine
+engine.JIT_MIN_PARTICLES = 1 << 62          # no automatic specialisation: time the interpreter first
 for mode in ("interpreter", "specialised"):
     if mode == "specialised":
         t0 = time.perf_counter()

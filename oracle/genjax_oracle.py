@@ -1176,6 +1176,17 @@ def weight_cdf(lw, n_total=None):
     return cdf, int(cdf[-1]), float(M), shift
 
 
+def ancestors_c(kind, k, cdf, n_out=None):
+    """orc_ancestors: the same integer predicate as ancestors() below, in C with unsigned __int128
+    (for populations too large for Python-integer object arrays, e.g. BASELINE config 4's 1e7)."""
+    cdf = np.ascontiguousarray(cdf, dtype=np.uint64)
+    n_out = cdf.size if n_out is None else n_out
+    out = np.empty(n_out, dtype=np.int32)
+    kk = np.ascontiguousarray(np.asarray(k, np.uint32).reshape(2))
+    lib().orc_ancestors(ctypes.c_int(kind), _p(kk), _p(cdf), I64(cdf.size), I64(n_out), _p(out))
+    return out
+
+
 def ancestors(kind, k, cdf, n_out=None):
     """Exact integer inverse-CDF (include/genmi.h, gmx_ancestors):
       systematic / stratified: first i with cdf_i * (n*2^23) > (j*2^23 + u) * total

@@ -497,6 +497,38 @@ void orc_weight_fixed(int64_t n, const float* lw, float M, int shift, uint64_t* 
     q[i] = (v >= 0.0f) ? (uint64_t)v : 0ull;
   }
 }
+/* Exact integer inverse-CDF for large n (include/genmi.h, gmx_ancestors) with 128-bit integers:
+ *   systematic / stratified: first i with cdf_i * (n_out*2^23) > (j*2^23 + u_j) * total
+ *   multinomial:             first i with cdf_i * 2^23 >= total * (2^23 - u_j)
+ * One binary search per output slot.  genjax_oracle.ancestors() states the same predicate with
+ * Python integers; tests check the two against each other. */
+void orc_ancestors(int kind, const uint32_t* key, const uint64_t* cdf, int64_t n_in, int64_t n_out,
+                   int32_t* out) {
+  typedef unsigned __int128 u128;
+  uint64_t total = cdf[n_in - 1];
+  uint64_t u0 = bits32_1(key, 0) >> 9;
+  for (int64_t j = 0; j < n_out; ++j) {
+    if (total == 0) { out[j] = (int32_t)(n_in - 1); continue; }
+    u128 D, P;
+    int strict;
+    if (kind == 2) {
+      uint64_t u = bits32_1(key, (uint64_t)j) >> 9;
+      D = (u128)1 << 23; P = (u128)total * (u128)(((uint64_t)1 << 23) - u); strict = 0;
+    } else {
+      uint64_t u = (kind == 0) ? u0 : (uint64_t)(bits32_1(key, (uint64_t)j) >> 9);
+      D = (u128)((uint64_t)n_out << 23); P = (u128)(((uint64_t)j << 23) + u) * (u128)total; strict = 1;
+    }
+    int64_t lo = 0, hi = n_in;
+    while (lo < hi) {
+      int64_t mid = lo + ((hi - lo) >> 1);
+      u128 c = (u128)cdf[mid] * D;
+      int hit = strict ? (c > P) : (c >= P);
+      if (hit) hi = mid; else lo = mid + 1;
+    }
+    out[j] = (int32_t)(lo < n_in ? lo : n_in - 1);
+  }
+}
+
 /* MH accept: log(uniform(key)) < log_alpha */
 void orc_mh_accept(int64_t n, const uint32_t* keys, int64_t ks, const float* log_alpha, uint8_t* out) {
   for (int64_t i = 0; i < n; ++i) {

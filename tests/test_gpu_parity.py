@@ -280,6 +280,55 @@ def test_importancek_and_vector_sites(gpu):
     assert lml == pytest.approx(float(oc.get_log_marginal_likelihood_estimate()), rel=2e-6)
 
 
+def test_config4_full_size_importancek_and_global_resample(gpu):
+    """BASELINE config 4 at its full size on one GPU: 8-schools, ImportanceK with k = 1e7 particles,
+    one global systematic resample (2442 scan tiles: the ticketed look-back path of k_weight_cdf).
+    Everything bit-exact against the oracle (C samplers / densities, unsigned __int128 ancestors)."""
+    import genjax_amd as G
+    from genjax_amd import ChoiceMapBuilder as C, numpy as jnp
+    from genjax_amd.inference import smc
+    sig = parity.SCHOOL_SIGMA
+    ys = parity.SCHOOL_Y
+
+    @G.gen
+    def schools():
+        mu = G.normal(0.0, 5.0) @ "mu"
+        log_tau = G.normal(0.0, 1.0) @ "log_tau"
+        theta = G.normal(mu * jnp.ones(8), jnp.exp(log_tau) * jnp.ones(8)) @ "theta"
+        _ = G.normal(theta, jnp.array(sig)) @ "y"
+        return theta
+
+    @O.gen
+    def o_schools():
+        mu = O.normal(0.0, 5.0) @ "mu"
+        log_tau = O.normal(0.0, 1.0) @ "log_tau"
+        theta = O.normal(mu[..., None] * np.ones(8, np.float32), O.exp(log_tau)[..., None] * np.ones(8, np.float32)) @ "theta"
+        _ = O.normal(theta, np.array(sig, np.float32)) @ "y"
+        return theta
+    k = 10_000_000
+    coll = smc.ImportanceK(G.Target(schools, (), C["y"].set(ys)), k_particles=k).run_smc(G.key(2))
+    oc = O.ImportanceK(O.Target(o_schools, (), O.C.d({"y": ys})), k).run_smc(O.key(2))
+    lw = coll.get_log_weights().cpu().numpy()
+    assert np.array_equal(lw, oc.get_log_weights())
+    otheta = oc.get_particles().get_choices()["theta"]
+    assert np.array_equal(coll.get_particles().get_choices()["theta"].cpu().numpy(), otheta)
+    res = smc.resample(G.key(3), coll, "systematic")
+    cdf, total, M, shift = O.weight_cdf(oc.get_log_weights())
+    anc = res.ancestors.cpu().numpy()
+    assert np.array_equal(anc, O.ancestors_c(O.SYSTEMATIC, O.key(3), cdf))
+    th = res.get_particles().get_choices()["theta"]
+    assert np.array_equal(th.cpu().numpy(), otheta[anc])
+    # size-independent properties: sorted ancestors, offspring counts within 1 of n*w
+    assert np.all(np.diff(anc) >= 0)
+    counts = np.bincount(anc, minlength=k).astype(np.float64)
+    q = np.diff(np.concatenate([[0], cdf.astype(np.float64)]))
+    assert np.max(np.abs(counts - k * q / float(total))) <= 1.0 + 1e-6
+    # evidence: float32 tree reduction on the device vs float64 on the host
+    lml = float(coll.get_log_marginal_likelihood_estimate())
+    ref = float(np.log(np.mean(np.exp(lw.astype(np.float64) - lw.max()))) + lw.max())
+    assert lml == pytest.approx(ref, rel=1e-5)
+
+
 @pytest.mark.parametrize("n", [257, 100_000])
 def test_plates_match_oracle(gpu, n):
     parity.check_plates(n=n)

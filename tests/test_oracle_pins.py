@@ -214,3 +214,15 @@ def test_kalman_vs_oracle_particle_filter():
     init, step = workloads.make_lgssm(O)
     res = parity.oracle_bootstrap_sweep(init, step, n, T, ys, O.key(314159))
     assert res["log_ml"] == pytest.approx(workloads.kalman_log_ml(ys), abs=0.15)
+
+
+def test_c_ancestors_equal_python_integer_ancestors():
+    """orc_ancestors (unsigned __int128) == ancestors() (Python integers) for every resampling kind."""
+    rng = np.random.default_rng(0)
+    for n in (1, 7, 1000, 20000):
+        lw = rng.normal(0, 3, n).astype(np.float32)
+        cdf, total, M, shift = O.weight_cdf(lw)
+        for kind in (O.SYSTEMATIC, O.STRATIFIED, O.MULTINOMIAL):
+            assert np.array_equal(O.ancestors(kind, O.key(n + kind), cdf), O.ancestors_c(kind, O.key(n + kind), cdf))
+    dead = np.zeros(5, np.uint64)
+    assert np.array_equal(O.ancestors_c(O.SYSTEMATIC, O.key(1), dead), np.full(5, 4, np.int32))

@@ -10,13 +10,20 @@
  *
  * Pinning status:
  *   - Threefry-2x32-20: PINNED by the Random123 known-answer vectors
- *     (tests/test_oracle_kat.py).
+ *     (tests/test_oracle_pins.py).
  *   - normal log-density: PINNED by the one numeric literal in the reference's
  *     tests (tests/generative_functions/test_static_gen_fn.py:317-318, -2.837877).
- *   - key algebra / samplers / resampling indices: PARITY UNPINNED against the
- *     real jax/TFP (no golden RNG output exists anywhere in the reference and
- *     it cannot be run here); anchored on the reference's call sites and on
- *     closed-form answers instead.
+ *   - jax.random key algebra and the normal / uniform pipelines: PINNED by the
+ *     outputs jax's own documentation prints (split(PRNGKey(0)) key data,
+ *     normal / uniform of PRNGKey(0), and for jax >= 0.5's partitionable
+ *     threefry: normal(key(42)), split(key(42)), the "individually" / "all at
+ *     once" vectors) — tests/test_oracle_pins.py::test_jax_docs_*; constants
+ *     recalled by the builder (no network), every printed digit matches.
+ *   - Gumbel / categorical, Bernoulli, Beta-via-gamma streams and resampling
+ *     indices: PARITY UNPINNED against the real jax/TFP (no golden output
+ *     exists in the reference and it cannot be run here); restated from the
+ *     published algorithms, anchored on the reference's call sites and on
+ *     closed-form answers.
  *
  * Build: gcc -O2 -ffp-contract=off -fno-fast-math (see oracle/Makefile).  Every
  * float function is a fixed sequence of correctly rounded IEEE-754 binary32

@@ -35,6 +35,24 @@ def test_key_kernels_bit_exact(gpu):
     assert np.array_equal(big, O.split(O.split(O.key(314159), 7), 5000))
 
 
+def test_jax_docs_values_on_device(gpu):
+    """The values jax's documentation prints for key(42) (see tests/test_oracle_pins.py), through the
+    product: split -> key data, normal(key), normal(subkey)."""
+    import genjax_amd as G
+    k = G.key(42)
+    ks = G.split(k)
+    assert ks.data().cpu().numpy().view(np.uint32).reshape(2, 2).tolist() == [[1832780943, 270669613],
+                                                                             [64467757, 2916123636]]
+    assert float(G.normal.sample(k, 0.0, 1.0)) == float(np.float32(-0.028304616))
+    new_key, subkey = ks
+    assert float(G.normal.sample(subkey, 0.0, 1.0)) == float(np.float32(0.60576403))
+    ind = G.normal.sample(G.split(k, 3), 0.0, 1.0).cpu().numpy()
+    assert np.all(np.abs(ind.astype(np.float64) - [0.07592554, 0.60576403, 0.4323065]) < 5.1e-9)    # digits as printed
+    import numpy
+    allatonce = G.normal.sample(k, numpy.zeros(3, numpy.float32), 1.0).cpu().numpy()
+    assert np.all(np.abs(allatonce.reshape(-1).astype(np.float64) - [-0.02830462, 0.46713185, 0.29570296]) < 5.1e-9)
+
+
 def _models(g):
     @g.gen
     def model(x_prev):

@@ -538,6 +538,18 @@ def test_mixture_assignments_match_oracle():
     parity.check_mixture_assignments(n=501, K=5, seed=2)
 
 
+def test_jax_docs_values_through_the_product():
+    k = genjax.key(42)
+    assert float(genjax.normal.sample(k, 0.0, 1.0)) == float(np.float32(-0.028304616))
+    new_key, subkey = genjax.split(k)
+    assert float(genjax.normal.sample(subkey, 0.0, 1.0)) == float(np.float32(0.60576403))
+    assert [int(v) for v in subkey.host()] == [64467757, 2916123636]
+    ind = genjax.normal.sample(genjax.split(k, 3), 0.0, 1.0).numpy()
+    assert np.all(np.abs(ind.astype(np.float64) - [0.07592554, 0.60576403, 0.4323065]) < 5.1e-9)    # digits as printed
+    allatonce = genjax.normal.sample(k, np.zeros(3, np.float32), 1.0).numpy().reshape(-1)
+    assert np.all(np.abs(allatonce.astype(np.float64) - [-0.02830462, 0.46713185, 0.29570296]) < 5.1e-9)
+
+
 def test_program_limits():
     """<= 32 live 32-bit values per particle (registers stay in VGPRs); a model
     that needs more fails loudly at trace time instead of spilling silently."""

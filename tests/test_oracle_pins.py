@@ -226,3 +226,57 @@ def test_c_ancestors_equal_python_integer_ancestors():
             assert np.array_equal(O.ancestors(kind, O.key(n + kind), cdf), O.ancestors_c(kind, O.key(n + kind), cdf))
     dead = np.zeros(5, np.uint64)
     assert np.array_equal(O.ancestors_c(O.SYSTEMATIC, O.key(1), dead), np.full(5, 4, np.int32))
+
+
+# ---------------------------------------------------------------------------
+# Outputs of the real jax.random, as printed in JAX's own documentation (the "Pseudorandom numbers"
+# tutorial, both its classic-PRNG edition and its jax >= 0.5 / threefry_partitionable edition).
+# There is no network and no jax here, so these constants are the builder's recollection of those
+# pages — but an accidental match of every printed digit is not credible, so they pin:
+#   * the Threefry-2x32 block exactly as jax keys it (rotations, key schedule, word order);
+#   * bits -> uniform (mantissa trick) and bits -> normal (sqrt2 * erf_inv) float pipelines;
+#   * the PARTITIONABLE layout jax 0.5.2 defaults to: split child i = threefry(key, (0, i)) (both
+#     words), scalar draw bits = hi ^ lo of threefry(key, (0, 0)).
+# ---------------------------------------------------------------------------
+def _tf(k0, k1, c0, c1):
+    import ctypes
+    a = [np.array([v], np.uint32) for v in (k0, k1, c0, c1)]
+    o0, o1 = np.zeros(1, np.uint32), np.zeros(1, np.uint32)
+    O.lib().orc_threefry2x32(ctypes.c_int64(1), *[O._p(x) for x in a], O._p(o0), O._p(o1))
+    return int(o0[0]), int(o1[0])
+
+
+def _from_bits(fn, bits):
+    import ctypes
+    out = np.zeros(1, np.float32)
+    getattr(O.lib(), fn)(ctypes.c_int64(1), O._p(np.array([bits], np.uint32)), O._p(out))
+    return out[0]
+
+
+def test_jax_docs_classic_prng_values():
+    # jax.random.split(PRNGKey(0)) -> [[4146024105, 967050713], [2718843009, 1272950319]]
+    a, b = _tf(0, 0, 0, 2), _tf(0, 0, 1, 3)          # counts [0,1,2,3] -> x0 = [0,1], x1 = [2,3]
+    assert [a[0], b[0], a[1], b[1]] == [4146024105, 967050713, 2718843009, 1272950319]
+    # jax.random.normal(PRNGKey(0)) -> -0.20584226 ; jax.random.uniform(PRNGKey(0)) -> 0.41845703
+    bits0 = _tf(0, 0, 0, 0)[0]
+    assert _from_bits("orc_std_normal_from_bits", bits0) == np.float32(-0.20584226)
+    assert _from_bits("orc_unit_from_bits", bits0) == np.float32(0.41845703)
+    # jax.random.normal(PRNGKey(42)) -> -0.18471177
+    assert _from_bits("orc_std_normal_from_bits", _tf(0, 42, 0, 0)[0]) == np.float32(-0.18471177)
+
+
+def test_jax_docs_partitionable_prng_values():
+    """jax >= 0.5 (the reference pins jax 0.5.2, poetry.lock:1627): key = jax.random.key(42)."""
+    k = O.key(42)
+    assert O.normal.sample(k, np.float32(0), np.float32(1)) == np.float32(-0.028304616)     # random.normal(key)
+    new_key, subkey = O.split(k)
+    assert new_key.tolist() == [1832780943, 270669613] and subkey.tolist() == [64467757, 2916123636]
+    assert O.normal.sample(subkey, np.float32(0), np.float32(1)) == np.float32(0.60576403)  # random.normal(subkey)
+    # "individually": [random.normal(k) for k in random.split(key, 3)] -> [0.07592554 0.60576403 0.4323065]
+    ks = O.split(k, 3)
+    ind = np.array([O.normal.sample(ks[i], np.float32(0), np.float32(1)) for i in range(3)], np.float32)
+    assert np.all(np.abs(ind.astype(np.float64) - [0.07592554, 0.60576403, 0.4323065]) < 5.1e-9)    # digits as printed
+    # "all at once": random.normal(key, shape=(3,)) -> [-0.02830462 0.46713185 0.29570296]
+    # (element j of a vector draw takes counter j under the SAME key)
+    allatonce = O.normal.sample(k, np.zeros(3, np.float32), np.float32(1))
+    assert np.all(np.abs(allatonce.astype(np.float64) - [-0.02830462, 0.46713185, 0.29570296]) < 5.1e-9)

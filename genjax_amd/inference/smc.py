@@ -535,10 +535,14 @@ class BootstrapSweep:
                                    be.ptr(self.totals[t:t + 1]), be.ptr(self.anc), be.ptr(self.rs_ws),
                                    be.stream()), "gmx_resample")
 
-    def enqueue(self):
-        """Issue every launch of the sweep on the current stream (no syncs, no allocations)."""
+    def enqueue(self, skip_vm=False):
+        """Issue every launch of the sweep on the current stream (no syncs, no allocations).
+        skip_vm=True leaves the site-program launches out (the resampling kernels then run on the
+        previous sweep's log-weights): bench.py times that variant to get the site program's cost
+        IN the sweep as a difference."""
         for t in range(self.T):
-            self._launch_vm(t)
+            if not skip_vm:
+                self._launch_vm(t)
             if self.fused:
                 self._launch_resample(t)
             else:

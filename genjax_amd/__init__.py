@@ -17,7 +17,7 @@ from .static import (AddressReuse, MissingAddress, Rejuvenate, StaticGenerativeF
 from . import inference
 from .inference import Target
 from .transforms import jit, vmap
-from .combinators import Vmap, repeat
+from .combinators import Scan, Vmap, repeat, scan
 
 ExactDensity = Distribution
 key = random.key
@@ -31,5 +31,5 @@ __all__ = [
     "Trace", "Update", "Mask", "Distribution", "ExactDensity", "bernoulli", "beta", "categorical",
     "flip", "normal", "uniform", "AddressReuse", "MissingAddress", "Rejuvenate",
     "StaticGenerativeFunction", "StaticRequest", "StaticTrace", "gen", "trace", "Target", "jit",
-    "vmap", "key", "split", "fold_in", "NotSupportedEditRequest", "Vmap", "repeat",
+    "vmap", "key", "split", "fold_in", "NotSupportedEditRequest", "Vmap", "repeat", "Scan", "scan",
 ]

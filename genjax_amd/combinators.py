@@ -1,4 +1,4 @@
-"""Plate combinators: `Vmap` / `repeat` (simulate / generate / assess).
+"""Plate and sequence combinators: `Vmap` / `repeat` / `Scan` (simulate / generate / assess).
 
 Reference: src/genjax/_src/generative_functions/combinators/vmap.py:180-218
 (`sub_keys = split(key, n)`, inner GFI per index, score / weight summed over
@@ -12,6 +12,11 @@ particle axis itself).  Inner addresses keep their names; their values gain a
 trailing plate axis: `chm["schools", "theta"]` has shape [N, n], and the
 reference's slice spelling `chm["schools", :, "theta"]` addresses the same
 entry.  `edit_index` / `IndexRequest` are next-tier.
+
+`Scan` (scan.py:200-294, 638-664): `kernel.scan(n=T)((carry, xs))` runs the kernel T times, threading the
+carry; the key is CHAINED, key_t = fold_in(key_{t-1}, t) (scan.py:213); score / weight = sum over steps;
+values gain a leading step axis ([N, T]); the return value is (final carry, stacked outputs).  Also unrolled
+at trace time: for short sequences inside one model (a whole 100-step SSM belongs in smc.BootstrapSweep).
 """
 from __future__ import annotations
 
@@ -40,8 +45,16 @@ def _take(a, j):
 
 
 def _index_chm(chm: ChoiceMap, j, n):
-    """Constraint / previous values of plate element j (values carry the plate axis first)."""
+    """Constraint / previous values of plate element j: values that carry the plate axis first, plus
+    whatever sits under the explicit integer address j (`C[j, "x"].set(v)`: constraint.get_submap(idx),
+    vmap.py:201, scan.py:262)."""
     from .engine import Sym
+    explicit = chm.get_submap(j) if j in chm._children else None
+    if explicit is not None:
+        rest = ChoiceMap(chm._value, {a: c for a, c in chm._children.items() if not isinstance(a, int)})
+        return _index_chm(rest, j, n).merge(explicit) if not rest.static_is_empty() else explicit
+    if any(isinstance(a, int) for a in chm._children):
+        chm = ChoiceMap(chm._value, {a: c for a, c in chm._children.items() if not isinstance(a, int)})
 
     def pick(v):
         if isinstance(v, Sym):
@@ -147,6 +160,115 @@ class Vmap(GenerativeFunction):
     def assess(self, sample, args, batch_shape=None):
         from .static import run_gfi
         return run_gfi(self, "assess", None, args, constraint=sample, batch_shape=batch_shape)
+
+
+class Scan(GenerativeFunction):
+    """scan.py:140-294: kernel (carry, x) -> (carry, y), repeated `length` times."""
+
+    def __init__(self, kernel_gen_fn, length=None):
+        self.kernel_gen_fn, self.length = kernel_gen_fn, length
+
+    def _length(self, scanned_in):
+        if self.length is not None:
+            return int(self.length)
+        lens = set()
+
+        def visit(v):
+            if isinstance(v, (tuple, list)) and not (isinstance(v, list) and v and not isinstance(v[0], (tuple, list, np.ndarray))):
+                for x in v:
+                    visit(x)
+            else:
+                n = _axis_len(v)
+                if n is not None:
+                    lens.add(n)
+        visit(scanned_in)
+        if len(lens) != 1:
+            raise ValueError("scan: pass n= or scanned inputs with one common leading length")
+        return lens.pop()
+
+    def trace_call(self, ctx, mode, key, args, constraint, prev, req, req_leaves, addr):
+        from .static import _CallRec, _SiteRec, _rec_score, _store_site, call_gen_fn
+        if mode not in ("simulate", "generate", "assess"):
+            raise NotImplementedError("Scan edits (IndexRequest, scan.py:325-416): SURVEY.md §8(f) item 1 (next tier)")
+        if len(args) != 2:
+            raise TypeError("scan: arguments are (carry, scanned_in)")
+        carry, scanned_in = args
+        n = self._length(scanned_in)
+        g = ctx.tr.graph
+        keep = ctx.store_sites
+        ctx.store_sites = False
+        recs, outs = [], []
+        weight = Expr(g.const_f32(0.0))
+        score = Expr(g.const_f32(0.0))
+        for t in range(n):
+            if key is not None:                       # key = fold_in(key, count): the chain of scan.py:213
+                key = Expr(g.add("KDERIVE", (key.node,), imm=t, dtype="key"))
+            x_t = _tree_take(scanned_in, t)
+            con_t = _index_chm(constraint, t, n)
+            rec, ret, w, s = call_gen_fn(ctx, mode, self.kernel_gen_fn, key, (carry, x_t), con_t, None, None,
+                                         req_leaves, addr)
+            if not (isinstance(ret, tuple) and len(ret) == 2):
+                raise TypeError("scan: the kernel must return (carry, output)")
+            carry, y_t = ret
+            recs.append(rec)
+            outs.append(y_t)
+            if keep:
+                for r in _leaves(rec):
+                    ctx.tr.prestore(r.value)
+                    if not isinstance(rec, _SiteRec):
+                        ctx.tr.prestore(r.score)
+            if w is not None:
+                weight = weight + w
+            score = score + (s if mode == "assess" else _rec_score(rec))
+        ctx.store_sites = keep
+        merged = _merge(recs, self.kernel_gen_fn)
+        retval = (carry, _stack(outs))
+        if isinstance(merged, _SiteRec):
+            merged.score = score
+            out = merged
+        else:
+            out = _CallRec(self)
+            out.sites = merged.sites
+            out.retval = retval
+            out.plate_score = score
+        if keep:
+            for r in _leaves(out):
+                _store_site(ctx, r)
+        if mode in ("simulate", "assess"):
+            return out, retval, None, score
+        return out, retval, weight, None
+
+    @property
+    def gen_fn(self):          # what static._build_trace names the inner function of a plate-like trace
+        return self.kernel_gen_fn
+
+    def simulate(self, key, args):
+        from .static import run_gfi
+        return run_gfi(self, "simulate", key, args)
+
+    def generate(self, key, constraint, args):
+        from .static import run_gfi
+        return run_gfi(self, "generate", key, args, constraint=constraint)
+
+    def assess(self, sample, args, batch_shape=None):
+        from .static import run_gfi
+        return run_gfi(self, "assess", None, args, constraint=sample, batch_shape=batch_shape)
+
+
+def scan(*, n=None):
+    def decorator(gen_fn):
+        return Scan(gen_fn, n)
+    return decorator
+
+
+def _tree_take(v, t):
+    if v is None:
+        return None
+    if isinstance(v, tuple):
+        return tuple(_tree_take(x, t) for x in v)
+    if isinstance(v, dict):
+        return {k: _tree_take(x, t) for k, x in v.items()}
+    return _take(v, t)
 
 
 def _leaves(rec):

@@ -236,7 +236,8 @@ class GenerativeFunction:
         return repeat(n=n)(self)
 
     def scan(self, *, n=None):
-        raise NotImplementedError("Scan combinator: SURVEY.md §8(f) item 1 (next tier)")
+        from ..combinators import Scan
+        return Scan(self, n)
 
 
 class GenerativeFunctionClosure(GenerativeFunction):

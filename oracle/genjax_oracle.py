@@ -896,6 +896,95 @@ class Vmap:
         return self._plate_sum(s, batch), r
 
 
+def _stack_last(trs):
+    """Stack per-step traces of one kernel along a new TRAILING axis (the step axis)."""
+    first = trs[0]
+
+    def st(vals):
+        if vals[0] is None:
+            return None
+        if isinstance(vals[0], tuple):
+            return tuple(st([v[k] for v in vals]) for k in range(len(vals[0])))
+        arrs = [np.asarray(v) for v in vals]
+        shape = np.broadcast_shapes(*[a.shape for a in arrs])
+        return np.stack([np.broadcast_to(a, shape) for a in arrs], axis=-1)
+    if isinstance(first, DistTrace):
+        return DistTrace(first.gen_fn, first.args, st([t.value for t in trs]), st([t.score for t in trs]))
+    return StaticTrace(first.gen_fn, first.args, st([t.retval for t in trs]),
+                       OrderedDict((a, _stack_last([t.subtraces[a] for t in trs])) for a in first.subtraces))
+
+
+class Scan:
+    """Scan.simulate / generate / assess (combinators/scan.py:200-294, 638-664): the key is chained,
+    key_t = fold_in(key_{t-1}, t); the carry threads through; score / weight = sum over steps in
+    step order; choices gain a trailing step axis; retval = (final carry, stacked outputs)."""
+
+    def __init__(self, kernel, length=None):
+        self.kernel, self.length = kernel, length
+
+    def __call__(self, *args):
+        return Closure(self, tuple(args))
+
+    def _n(self, xs):
+        if self.length is not None:
+            return self.length
+        leaf = xs
+        while isinstance(leaf, tuple):
+            leaf = leaf[0]
+        return np.asarray(leaf).shape[-1]
+
+    @staticmethod
+    def _x(xs, t):
+        if xs is None:
+            return None
+        if isinstance(xs, tuple):
+            return tuple(Scan._x(v, t) for v in xs)
+        return np.asarray(xs)[..., t]
+
+    def _run(self, mode, k, chm, args, batch=None):
+        carry, xs = args
+        n = self._n(xs)
+        trs, outs = [], []
+        batch = np.asarray(k).shape[:-1] if k is not None else tuple(batch)
+        score = np.zeros(batch, np.float32)
+        weight = np.zeros(batch, np.float32)
+        for t in range(n):
+            if k is not None:
+                k = fold_in(k, t)
+            sub = chm.filter(lambda a: True).map_values(lambda v: np.asarray(v)[..., t]) if chm is not None else None
+            if mode == "simulate":
+                tr = self.kernel.simulate(k, (carry, self._x(xs, t)))
+                s = tr.get_score()
+            elif mode == "generate":
+                tr, w = self.kernel.generate(k, sub, (carry, self._x(xs, t)))
+                s = tr.get_score()
+                weight = (weight + np.broadcast_to(np.asarray(w, np.float32), batch)).astype(np.float32)
+            else:
+                s, ret = self.kernel.assess(sub, (carry, self._x(xs, t)), batch)
+                tr = None
+            ret = tr.get_retval() if tr is not None else ret
+            carry, y = ret
+            outs.append(y)
+            trs.append(tr)
+            score = (score + np.broadcast_to(np.asarray(s, np.float32), batch)).astype(np.float32)
+        ys = None if outs[0] is None else np.stack([np.broadcast_to(np.asarray(o), batch) for o in outs], axis=-1)
+        return trs, (carry, ys), score, weight
+
+    def simulate(self, k, args):
+        trs, ret, score, _ = self._run("simulate", k, None, args)
+        return VmapTrace(self, _stack_last(trs), score, ret)
+
+    def generate(self, k, chm, args):
+        trs, ret, score, w = self._run("generate", k, chm, args)
+        return VmapTrace(self, _stack_last(trs), score, ret), w
+
+    importance = generate
+
+    def assess(self, chm, args, batch_shape=()):
+        _, ret, score, _ = self._run("assess", None, chm, args, batch_shape)
+        return score, ret
+
+
 class Repeat(Vmap):
     """repeat.py:28-42: n runs on the same arguments, keys split(key, n)."""
 

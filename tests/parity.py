@@ -350,3 +350,58 @@ def check_mixture_assignments(n=3000, K=64, seed=11, specialize=False):
     assert np.array_equal(idx.cpu().numpy(), oidx)
     assert (oidx == z).mean() > 0.85            # well-separated clusters: mostly the generating component
     return idx
+
+
+# ---------------------------------------------------------------------------
+# Scan combinator: a short state-space model as ONE generative function
+# ---------------------------------------------------------------------------
+def check_scan(n=257, T=6, seed=5):
+    import genjax_amd as G
+    from genjax_amd import ChoiceMapBuilder as C, numpy as jnp
+    ys = np.array([0.3, -0.2, 0.5, 1.0, 0.7, -0.4, 0.1, 0.9][:T], np.float32)
+
+    def mk(g):
+        @g.gen
+        def step(x, t):
+            xn = g.normal(0.9 * x, 0.5) @ "x"
+            g.normal(xn, 1.0) @ "y"
+            return xn, xn * 2.0
+        return step
+    step, ostep = mk(G), mk(O)
+
+    @G.gen
+    def ssm():
+        x0 = G.normal(0.0, 1.0) @ "x0"
+        xT, doubled = step.scan(n=T)(x0, jnp.arange(T).astype("float32")) @ "steps"
+        return xT
+
+    @O.gen
+    def o_ssm():
+        x0 = O.normal(0.0, 1.0) @ "x0"
+        xT, doubled = O.Scan(ostep, T)(x0, np.arange(T, dtype=np.float32)) @ "steps"
+        return xT
+    tr, w = ssm.importance(G.split(G.key(seed), n), C["steps", :, "y"].set(ys), ())
+    tro, wo = o_ssm.importance(O.split(O.key(seed), n), O.C.d({("steps", "y"): ys}), ())
+    x = tr.get_choices()["steps", "x"]
+    assert tuple(x.shape) == (n, T)
+    assert np.array_equal(x.cpu().numpy(), tro.get_choices()["steps", "x"])          # chained keys fold_in(key, t)
+    assert np.array_equal(w.cpu().numpy(), wo)
+    assert np.array_equal(tr.get_score().cpu().numpy(), tro.get_score())
+    assert np.array_equal(tr.get_retval().cpu().numpy(), tro.get_retval())
+    tr2, tro2 = ssm.simulate(G.split(G.key(seed + 1), n), ()), o_ssm.simulate(O.split(O.key(seed + 1), n), ())
+    assert np.array_equal(tr2.get_choices()["steps", "y"].cpu().numpy(), tro2.get_choices()["steps", "y"])
+    s, _ = ssm.assess(tr2.get_choices(), ())
+    so, _ = o_ssm.assess(tro2.get_choices(), (), (n,))
+    assert np.array_equal(s.cpu().numpy(), so) and np.array_equal(s.cpu().numpy(), tr2.get_score().cpu().numpy())
+    # a constraint at ONE step through its integer address (constraint.get_submap(idx), scan.py:262):
+    # the weight is that step's observation density alone
+    tr3, w3 = ssm.importance(G.split(G.key(seed), n), C["steps", 2, "y"].set(0.25), ())
+    y3 = tr3.get_choices()["steps", "y"].cpu().numpy()
+    assert np.all(y3[:, 2] == np.float32(0.25)) and not np.all(y3[:, 1] == np.float32(0.25))
+    x3 = tr3.get_choices()["steps", "x"].cpu().numpy()[:, 2]
+    assert np.array_equal(w3.cpu().numpy(), O.normal.assess(O.C.choice(np.full(n, 0.25, np.float32)), (x3, np.float32(1.0)), (n,))[0])
+    # a Scan used directly: the chain starts at the caller's key
+    sc = step.scan(n=3)
+    t4 = sc.simulate(G.split(G.key(seed + 2), 16), (torch.zeros(16), jnp.zeros(3)))
+    t4o = O.Scan(ostep, 3).simulate(O.split(O.key(seed + 2), 16), (np.zeros(16, np.float32), np.zeros(3, np.float32)))
+    assert np.array_equal(t4.get_choices()["x"].cpu().numpy(), t4o.get_choices()["x"])

@@ -402,6 +402,11 @@ def test_mixture_assignments_match_oracle(gpu, n, specialize):
     parity.check_mixture_assignments(n=n, K=64, specialize=specialize)
 
 
+@pytest.mark.parametrize("n", [257, 100_000])
+def test_scan_matches_oracle(gpu, n):
+    parity.check_scan(n=n, T=6)
+
+
 def test_full_size_sweep_properties(gpu):
     """BASELINE config 2 at full size (1e6 particles, T = 100): size-independent
     properties — sorted ancestors, determinism, and log-ML within Monte-Carlo

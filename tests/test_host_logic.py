@@ -550,6 +550,11 @@ def test_jax_docs_values_through_the_product():
     assert np.all(np.abs(allatonce.astype(np.float64) - [-0.02830462, 0.46713185, 0.29570296]) < 5.1e-9)
 
 
+def test_scan_matches_oracle():
+    from tests import parity
+    parity.check_scan(n=257, T=6)
+
+
 def test_program_limits():
     """<= 32 live 32-bit values per particle (registers stay in VGPRs); a model
     that needs more fails loudly at trace time instead of spilling silently."""

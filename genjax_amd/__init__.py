@@ -8,7 +8,7 @@ from . import numpy, random
 from .core.choice_map import (ChoiceMap, ChoiceMapBuilder, ChoiceMapNoValueAtAddress, Selection,
                               SelectionBuilder)
 from .core.generative import (Diff, DiffAnnotate, EditRequest, EmptyRequest, GenerativeFunction,
-                              GenerativeFunctionClosure, NoChange, NotSupportedEditRequest, Regenerate,
+                              GenerativeFunctionClosure, IndexRequest, NoChange, NotSupportedEditRequest, Regenerate,
                               Trace, UnknownChange, Update)
 from .core.mask import Mask
 from .distributions import (Distribution, bernoulli, beta, categorical, flip, normal, uniform)
@@ -31,5 +31,5 @@ __all__ = [
     "Trace", "Update", "Mask", "Distribution", "ExactDensity", "bernoulli", "beta", "categorical",
     "flip", "normal", "uniform", "AddressReuse", "MissingAddress", "Rejuvenate",
     "StaticGenerativeFunction", "StaticRequest", "StaticTrace", "gen", "trace", "Target", "jit",
-    "vmap", "key", "split", "fold_in", "NotSupportedEditRequest", "Vmap", "repeat", "Scan", "scan",
+    "vmap", "key", "split", "fold_in", "NotSupportedEditRequest", "Vmap", "repeat", "Scan", "scan", "IndexRequest",
 ]

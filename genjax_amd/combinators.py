@@ -103,7 +103,7 @@ class Vmap(GenerativeFunction):
         """Called by static.call_gen_fn while tracing a parent `@gen` function."""
         from .static import _CallRec, _SiteRec, _store_site, call_gen_fn
         if mode not in ("simulate", "generate", "assess"):
-            raise NotImplementedError("Vmap edits (IndexRequest / edit_index): SURVEY.md §8(f) item 2 (next tier)")
+            return self._trace_edit(ctx, mode, key, args, constraint, prev, req, req_leaves, addr)
         axes = self._axes(args)
         n = self._plate_size(args, axes)
         from .static import _rec_score
@@ -148,6 +148,66 @@ class Vmap(GenerativeFunction):
             return out, retval, None, score
         return out, retval, weight, None
 
+    def _trace_edit(self, ctx, mode, key, args, constraint, prev, req, req_leaves, addr):
+        """Vmap.edit (vmap.py:334-362): `Update(constraint)` edits every element with keys split(key, n)
+        and its slice of the constraint (edit_choice_map :236-275); `IndexRequest(idx, request)` applies
+        `request` to element idx with the caller's key, everything else is carried over (edit_index
+        :277-332).  Any other request raises, as in the reference."""
+        from .core.generative import NotSupportedEditRequest
+        from .static import _CallRec, _ReqSpec, _SiteRec, _rec_score, _store_site, call_gen_fn
+        kind = req.kind if req is not None else "empty"
+        if prev is None or "vmap" not in prev:
+            raise NotImplementedError("editing a plate of bare distributions (its per-element scores are not kept)")
+        if not (mode == "update" or kind in ("update", "index", "empty")):
+            raise NotSupportedEditRequest(f"Vmap.edit answers Update and IndexRequest (got {kind!r}), vmap.py:342-362")
+        inner_prev = prev["vmap"]
+        axes = self._axes(args)
+        n = self._plate_size(args, axes)
+        g = ctx.tr.graph
+        keep = ctx.store_sites
+        ctx.store_sites = False
+        carry_over = _ReqSpec("update", tree=None, constraint=ChoiceMap.empty())
+        recs, rets = [], []
+        weight = Expr(g.const_f32(0.0))
+        score = Expr(g.const_f32(0.0))
+        for j in range(n):
+            args_j = tuple(_take(a, j) if ax is not None else a for a, ax in zip(args, axes))
+            prev_j = _index_prev(inner_prev, j)
+            if kind == "index":
+                if j == req.idx:
+                    sub = req.sub
+                    sub_mode = {"update": "update", "regen": "regen"}.get(sub.kind, "static_edit")
+                    sub_con = sub.constraint if sub.kind == "update" else ChoiceMap.empty()
+                    rec, ret, w, _ = call_gen_fn(ctx, sub_mode, self.gen_fn, key, args_j, sub_con, prev_j, sub,
+                                                 req_leaves, addr)
+                else:           # untouched: an empty Update with unchanged arguments recomputes nothing
+                    rec, ret, w, _ = call_gen_fn(ctx, "update", self.gen_fn, None, args_j, ChoiceMap.empty(), prev_j,
+                                                 carry_over, req_leaves, addr)
+            else:
+                kj = Expr(g.add("KDERIVE", (key.node,), imm=j, dtype="key")) if key is not None else None
+                rec, ret, w, _ = call_gen_fn(ctx, "update", self.gen_fn, kj, args_j, _index_chm(constraint, j, n), prev_j,
+                                             carry_over if req is None or kind != "update" else req, req_leaves, addr)
+            recs.append(rec)
+            rets.append(ret)
+            if keep:
+                for r in _leaves(rec):
+                    ctx.tr.prestore(r.value)
+                    ctx.tr.prestore(r.score)
+                    ctx.tr.prestore(r.discard)
+            if w is not None:
+                weight = weight + w
+            score = score + _rec_score(rec)
+        ctx.store_sites = keep
+        merged = _merge(recs, self.gen_fn)
+        out = _CallRec(self)
+        out.sites = merged.sites
+        out.retval = _stack(rets)
+        out.plate_score = score
+        if keep:
+            for r in _leaves(out):
+                _store_site(ctx, r)
+        return out, out.retval, weight, None
+
     # direct use: split(key, n) of the caller's key itself (vmap.py:186)
     def simulate(self, key, args):
         from .static import run_gfi
@@ -160,6 +220,32 @@ class Vmap(GenerativeFunction):
     def assess(self, sample, args, batch_shape=None):
         from .static import run_gfi
         return run_gfi(self, "assess", None, args, constraint=sample, batch_shape=batch_shape)
+
+
+def _vmap_edit(self, key, trace, edit_request, argdiffs):
+    from .static import run_edit
+    return run_edit(self, key, trace, edit_request, argdiffs)
+
+
+Vmap.edit = _vmap_edit
+
+
+def _index_prev(prev, j):
+    """Element j of a symbolic previous plate trace (values / scores carry the plate axis first)."""
+    from .engine import Sym
+
+    def pick(v):
+        if isinstance(v, Sym):
+            inner = v.value
+            if isinstance(inner, np.ndarray) and inner.dtype == object and inner.ndim >= 1:
+                return Sym(_take(inner, j), None)
+            return v
+        if isinstance(v, dict):
+            return {k: pick(x) for k, x in v.items()}
+        if isinstance(v, tuple):
+            return tuple(pick(x) for x in v)
+        return v
+    return pick(prev)
 
 
 class Scan(GenerativeFunction):
@@ -288,7 +374,10 @@ def _merge(recs, gen_fn):
     if isinstance(first, _SiteRec):
         value = _stack([r.value for r in recs])
         score = _stack([r.score for r in recs])            # per-element scores, plate axis first
-        return _SiteRec(first.gen_fn, value, score)
+        discard = None
+        if any(r.discard is not None for r in recs):       # elements not edited "discard" their kept value
+            discard = _stack([r.discard if r.discard is not None else r.value for r in recs])
+        return _SiteRec(first.gen_fn, value, score, discard)
     out = _CallRec(gen_fn)
     for a in first.sites:
         out.sites[a] = _merge([r.sites[a] for r in recs], first.sites[a].gen_fn)

@@ -170,6 +170,16 @@ class Regenerate(EditRequest):
         self.selection = selection
 
 
+class IndexRequest(EditRequest):
+    """concepts.py:153-164: edit ONE index of a vector combinator's trace with a sub-request
+    (`Vmap.edit_index`, vmap.py:277-332).  `idx` is a Python int here (the unrolled plate picks
+    the element at trace time)."""
+    __match_args__ = ("idx", "request")
+
+    def __init__(self, idx, request: EditRequest):
+        self.idx, self.request = int(idx), request
+
+
 class EmptyRequest(EditRequest):
     """requests.py:48-60: no change requested; re-scores only what changed args force."""
 

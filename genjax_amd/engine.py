@@ -252,7 +252,10 @@ class Tracing:
             ck = (tuple(id(n) for n in nodes), tuple(value.shape))
             if ck in self.node_origin:
                 return self.node_origin[ck]       # e.g. a plate's values returned as its retval
-            slots = [self.prestored[id(n)] if id(n) in self.prestored else g.store(n) for n in nodes]
+            slots = []
+            for n in nodes:                  # an early store feeds ONE output; a second user stores again
+                slot = self.prestored.pop(id(n), None)
+                slots.append(slot if slot is not None else g.store(n))
             o = ("out", len(self.outputs))
             self.outputs.append((dt, tuple(value.shape), slots))
             self.node_origin[ck] = o

@@ -196,7 +196,23 @@ def compile_graph(g: Graph):
             remat[n.idx] = 1
         elif n.op in REMAT_UNARY and n.args[0].idx in remat and remat[n.args[0].idx] == 1:
             remat[n.idx] = 2
-    order = [n for n in nodes if live[n.idx] and n.idx not in pool_of and n.idx not in remat]
+    # leaf loads (inputs, launch-index, register-resident constants) are SUNK to their first use:
+    # a trace with many input leaves (an edited plate: value + score per element) would otherwise
+    # hold every one of them in a register from the top of the program
+    sunk = {n.idx for n in nodes if live[n.idx] and n.idx not in pool_of and n.op in ("LDIN", "CONST", "UNI", "LDIDX")}
+    order = []
+    placed = set()
+    for n in nodes:
+        if not live[n.idx] or n.idx in pool_of or n.idx in remat or n.idx in sunk:
+            continue
+        for a in n.args:
+            if a is None:
+                continue
+            for leaf in _remat_leaves(a, remat):
+                if leaf.idx in sunk and leaf.idx not in placed:
+                    placed.add(leaf.idx)
+                    order.append(leaf)
+        order.append(n)
     last_use = {}
     for pos, n in enumerate(order):
         for a in n.args:

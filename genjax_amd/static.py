@@ -32,7 +32,7 @@ import torch
 from . import _lib
 from . import tracer as T
 from .core.choice_map import ChoiceMap, Selection, _norm
-from .core.generative import (Diff, EditRequest, EmptyRequest, GenerativeFunction, NoChange,
+from .core.generative import (Diff, EditRequest, EmptyRequest, GenerativeFunction, IndexRequest, NoChange,
                               NotSupportedEditRequest, Regenerate, Trace, Update)
 from .engine import Compiled, Flat, Gathered, Sym, Tracing, leaf_spec, materialize, resolve, unflatten
 from .random import Key
@@ -122,11 +122,11 @@ class VmapTrace(Trace):
     """Trace of a `Vmap` call: the inner trace's leaves carry a trailing plate
     axis; the score is the plate sum (vmap.py VmapTrace)."""
 
-    def __init__(self, gen_fn, inner: "StaticTrace", score, retval):
-        self.gen_fn, self.inner, self.score, self.retval = gen_fn, inner, score, retval
+    def __init__(self, gen_fn, inner: "StaticTrace", score, retval, args=None):
+        self.gen_fn, self.inner, self.score, self.retval, self.args = gen_fn, inner, score, retval, args
         self.subtraces = inner.subtraces
 
-    def get_args(self): return None
+    def get_args(self): return self.args
     def get_retval(self): return _tree_materialize(self.retval)
     def get_gen_fn(self): return self.gen_fn
     def get_score(self): return materialize(self.score)
@@ -154,6 +154,8 @@ def _trace_tree(tr):
         return {"value": tr.value, "score": tr.score}
     if isinstance(tr, StaticTrace):
         return {"sub": {a: _trace_tree(s) for a, s in tr.subtraces.items()}, "retval": tr.retval}
+    if isinstance(tr, VmapTrace):
+        return {"vmap": _trace_tree(tr.inner), "score": tr.score, "retval": tr.retval}
     raise TypeError(f"cannot edit a trace of type {type(tr).__name__}")
 
 
@@ -249,6 +251,9 @@ def _flatten_request(req, flat: Flat):
             subs[_norm(a) if a != () else ()] = s
             keys.append((a, k))
         return _ReqSpec("static", subs=subs), ("static", tuple(keys))
+    if isinstance(req, IndexRequest):
+        sub, k = _flatten_request(req.request, flat)
+        return _ReqSpec("index", idx=req.idx, sub=sub), ("index", req.idx, k)
     if isinstance(req, Rejuvenate):
         return (_ReqSpec("rejuv", proposal=req.proposal, argmap=req.argument_mapping),
                 ("rejuv", _gfkey(req.proposal), _fnkey(req.argument_mapping)))
@@ -625,7 +630,7 @@ def _build_trace(otree, outs, leaves, args):
         _, gf, subs, ro, po = otree
         st = OrderedDict((a, _build_trace(o, outs, leaves, None)) for a, o in subs.items())
         inner = StaticTrace(gf.gen_fn, None, resolve(ro, outs, leaves), st)
-        return VmapTrace(gf, inner, resolve(po, outs, leaves), resolve(ro, outs, leaves))
+        return VmapTrace(gf, inner, resolve(po, outs, leaves), resolve(ro, outs, leaves), args)
     _, gf, subs, ro = otree
     st = OrderedDict((a, _build_trace(o, outs, leaves, None)) for a, o in subs.items())
     return StaticTrace(gf, args, resolve(ro, outs, leaves), st)
@@ -740,6 +745,12 @@ def _mh_select(tr: Tracing, acc: Expr, rec, prev):
         return tr.emit_output(T.where(acc, nv, old_sym.value))
     if isinstance(rec, _SiteRec):
         return ("site", rec.gen_fn, pick(rec.value, prev["value"]), pick(rec.score, prev["score"]), None)
+    if getattr(rec, "plate_score", None) is not None:
+        inner = prev["vmap"]
+        subs = OrderedDict((a, _mh_select(tr, acc, r, inner["sub"][a])) for a, r in rec.sites.items())
+        ro = _tree_select(tr, acc, rec.retval, prev["retval"])
+        po = tr.emit_output(T.where(acc, rec.plate_score, prev["score"].value))
+        return ("vmap", rec.gen_fn, subs, ro, po)
     subs = OrderedDict((a, _mh_select(tr, acc, r, prev["sub"][a])) for a, r in rec.sites.items())
     old_ret = prev["retval"]
     ro = _tree_select(tr, acc, rec.retval, old_ret)
@@ -815,6 +826,8 @@ def run_edit(gen_fn, key: Key, trace: Trace, request: EditRequest, argdiffs, mh:
             elif rspec.kind == "regen":
                 mode = "regen"
             _bind_request_leaves(rspec, syms)
+            if rspec.kind == "index" and rspec.sub.kind == "update":
+                pass                          # the element's constraint travels in rspec.sub.constraint
             rec, retval, w, _ = call_gen_fn(ctx, mode, gen_fn, kexpr, sargs, constraint, sprev, req, syms, ())
             ao = None
             if mh:
@@ -842,6 +855,8 @@ def run_edit(gen_fn, key: Key, trace: Trace, request: EditRequest, argdiffs, mh:
         bwd = Update(discard)
     elif isinstance(request, Regenerate):
         bwd = Update(discard)
+    elif isinstance(request, IndexRequest):
+        bwd = IndexRequest(request.idx, Update(discard))
     else:
         bwd = request if isinstance(request, (StaticRequest, Rejuvenate)) else Update(discard)
     retdiff = Diff.unknown_change(new_tr.get_retval())
@@ -868,6 +883,8 @@ def _bind_request_leaves(rspec, syms):
     if rspec.kind == "static":
         for s in rspec.subs.values():
             _bind_request_leaves(s, syms)
+    elif rspec.kind == "index":
+        _bind_request_leaves(rspec.sub, syms)
     elif rspec.kind == "update":
         rspec.constraint = _sym_constraint(rspec.tree, syms)
 

@@ -234,6 +234,8 @@ def where(c, a, b):
             a, b = as_float(a), as_float(b)
         else:
             a, b = as_int(a), as_int(b)
+    if a.node is b.node:
+        return a                     # both branches are the same value (an untouched plate element under MH)
     c = as_bool(c)
     return Expr(current_graph().add("SEL", (c.node, a.node, b.node), dtype=a.dtype))
 

@@ -985,6 +985,60 @@ class Scan:
         return score, ret
 
 
+def _slice_last(tr, idx):
+    """tree_map(lambda v: v[idx], trace.inner) for plate leaves kept on the TRAILING axis."""
+    def sl(v, n):
+        if v is None:
+            return None
+        if isinstance(v, tuple):
+            return tuple(sl(x, n) for x in v)
+        a = np.asarray(v)
+        return a[..., idx] if a.ndim >= 1 and a.shape[-1] == n else v
+    if isinstance(tr, DistTrace):
+        n = np.shape(tr.score)[-1]
+        return DistTrace(tr.gen_fn, tuple(sl(a, n) for a in tr.args), sl(tr.value, n), sl(tr.score, n))
+    n = np.shape(tr.get_score())[-1]
+    return StaticTrace(tr.gen_fn, tr.args, sl(tr.retval, n),
+                       OrderedDict((a, _slice_last(s, idx)) for a, s in tr.subtraces.items()))
+
+
+def _set_last(tr, idx, new):
+    """tree_map(lambda v, v_: v.at[idx].set(v_), trace.inner, new_slice)"""
+    def st(v, v_):
+        if v is None:
+            return None
+        if isinstance(v, tuple):
+            return tuple(st(x, y) for x, y in zip(v, v_))
+        a = np.array(v, copy=True)
+        a[..., idx] = np.asarray(v_, dtype=a.dtype)
+        return a
+    if isinstance(tr, DistTrace):
+        return DistTrace(tr.gen_fn, tr.args, st(tr.value, new.value), st(tr.score, new.score))
+    return StaticTrace(tr.gen_fn, tr.args, st(tr.retval, new.retval),
+                       OrderedDict((a, _set_last(s, idx, new.subtraces[a])) for a, s in tr.subtraces.items()))
+
+
+def vmap_update(vm: "Vmap", k, trace: "VmapTrace", constraint: ChoiceMap, args):
+    """Vmap.edit_choice_map (vmap.py:236-275): every element is updated with keys split(key, n) and
+    its slice of the constraint; w = sum over the plate."""
+    batch = np.asarray(k).shape[:-1]
+    a, n = vm._prep(args, batch)
+    new_inner, w, discard = vm.gen_fn.update(split(k, n), trace.inner, constraint, a)
+    w = np.broadcast_to(np.asarray(w, np.float32), tuple(batch) + (n,))
+    return VmapTrace(vm, new_inner, vm._plate_sum(new_inner.get_score(), batch), new_inner.get_retval()), \
+        vm._plate_sum(w, batch), discard
+
+
+def vmap_edit_index(vm: "Vmap", k, trace: "VmapTrace", idx: int, edit, args_at_idx):
+    """Vmap.edit_index (vmap.py:277-332): `edit(key, trace_slice, args_slice) -> (new slice, w)` on
+    element idx with the caller's key; every other element is carried over."""
+    batch = np.asarray(k).shape[:-1]
+    sl = _slice_last(trace.inner, idx)
+    new_slice, w = edit(k, sl, args_at_idx)
+    new_inner = _set_last(trace.inner, idx, new_slice)
+    return VmapTrace(vm, new_inner, vm._plate_sum(new_inner.get_score(), batch), new_inner.get_retval()), w
+
+
 class Repeat(Vmap):
     """repeat.py:28-42: n runs on the same arguments, keys split(key, n)."""
 

@@ -405,3 +405,65 @@ def check_scan(n=257, T=6, seed=5):
     t4 = sc.simulate(G.split(G.key(seed + 2), 16), (torch.zeros(16), jnp.zeros(3)))
     t4o = O.Scan(ostep, 3).simulate(O.split(O.key(seed + 2), 16), (np.zeros(16, np.float32), np.zeros(3, np.float32)))
     assert np.array_equal(t4.get_choices()["x"].cpu().numpy(), t4o.get_choices()["x"])
+
+
+# ---------------------------------------------------------------------------
+# edits of plates: Vmap.edit = Update | IndexRequest (vmap.py:236-362)
+# ---------------------------------------------------------------------------
+def check_plate_edits(n=257, seed=1):
+    import genjax_amd as G
+    from genjax_amd import (ChoiceMapBuilder as C, Diff, IndexRequest, NotSupportedEditRequest, Regenerate,
+                            SelectionBuilder as S, StaticRequest, Update, numpy as jnp)
+    from genjax_amd.static import run_mh
+    sig, ys = SCHOOL_SIGMA, SCHOOL_Y
+    school, oschool = _school(G), _school(O)
+    v, ov = school.vmap(in_axes=(None, None, 0)), O.Vmap(oschool, in_axes=(None, None, 0))
+    args = (1.0, 2.0, jnp.array(sig))
+    oargs = (np.float32(1.0), np.float32(2.0), np.array(sig, np.float32))
+    tr, otr = v.simulate(G.split(G.key(seed), n), args), ov.simulate(O.split(O.key(seed), n), oargs)
+    # Update of every element's "y": keys split(key, n), w = sum over the plate, discard = old values
+    new_tr, w, _, bwd = Update(C["y"].set(ys)).edit(G.split(G.key(seed + 1), n), tr, Diff.no_change(args))
+    onew, ow, odisc = O.vmap_update(ov, O.split(O.key(seed + 1), n), otr, O.C.d({"y": ys}), oargs)
+    assert np.array_equal(w.cpu().numpy(), ow)
+    assert np.array_equal(new_tr.get_score().cpu().numpy(), onew.get_score())
+    assert np.array_equal(bwd.constraint["y"].cpu().numpy(), odisc["y"])
+    assert np.array_equal(new_tr.get_choices()["theta"].cpu().numpy(), otr.get_choices()["theta"])    # untouched
+    # IndexRequest(3, Regenerate(theta)): element 3 only, with the caller's key
+    tr2, w2, _, bwd2 = IndexRequest(3, Regenerate(S["theta"])).edit(G.split(G.key(seed + 2), n), new_tr, Diff.no_change(args))
+    a3 = (np.float32(1.0), np.float32(2.0), np.float32(sig[3]))
+    otr2, ow2 = O.vmap_edit_index(ov, O.split(O.key(seed + 2), n), onew, 3,
+                                  lambda k, sl, a: oschool.regenerate(k, sl, O.selection("theta"), a)[:2], a3)
+    th2 = tr2.get_choices()["theta"].cpu().numpy()
+    assert np.array_equal(th2, otr2.get_choices()["theta"])
+    assert np.array_equal(w2.cpu().numpy(), ow2)
+    assert np.array_equal(tr2.get_score().cpu().numpy(), otr2.get_score())
+    th1 = new_tr.get_choices()["theta"].cpu().numpy()
+    assert np.array_equal(np.delete(th1, 3, axis=1), np.delete(th2, 3, axis=1)) and not np.array_equal(th1[:, 3], th2[:, 3])
+    assert isinstance(bwd2, IndexRequest) and bwd2.idx == 3
+    # IndexRequest(5, StaticRequest({theta: Rejuvenate})): the MH proposal on one element
+    rej = G.Rejuvenate(G.normal, lambda chm: (chm.get_value(), 1.0))
+    orej = {"theta": O.Rejuvenate(O.normal, lambda chm: (chm.get_value(), np.float32(1.0)))}
+    tr3, w3, _, _ = IndexRequest(5, StaticRequest({"theta": rej})).edit(G.split(G.key(seed + 3), n), tr2, Diff.no_change(args))
+    a5 = (np.float32(1.0), np.float32(2.0), np.float32(sig[5]))
+    otr3, ow3 = O.vmap_edit_index(ov, O.split(O.key(seed + 3), n), otr2, 5,
+                                  lambda k, sl, a: oschool.edit_static(k, sl, orej, a), a5)
+    assert np.array_equal(tr3.get_choices()["theta"].cpu().numpy(), otr3.get_choices()["theta"])
+    assert np.array_equal(w3.cpu().numpy(), ow3)
+    # nested in a model + the fused MH accept: only school 2's theta may move, and only where accepted
+    @G.gen
+    def schools():
+        mu = G.normal(0.0, 5.0) @ "mu"
+        return school.vmap(in_axes=(None, None, 0))(mu, 2.0, jnp.array(sig)) @ "schools"
+    trm, _ = schools.importance(G.split(G.key(seed + 4), n), C["schools", :, "y"].set(ys), ())
+    req = StaticRequest({"schools": IndexRequest(2, StaticRequest({"theta": rej}))})
+    sel, acc, wmh = run_mh(schools, G.split(G.key(seed + 5), n), trm, req, Diff.no_change(()))
+    t0, t1 = trm.get_choices()["schools", "theta"].cpu().numpy(), sel.get_choices()["schools", "theta"].cpu().numpy()
+    a = acc.cpu().numpy().astype(bool)
+    assert np.array_equal(np.delete(t0, 2, axis=1), np.delete(t1, 2, axis=1))
+    assert np.array_equal(t0[~a, 2], t1[~a, 2]) and np.all(t0[a, 2] != t1[a, 2]) and 0 < a.mean() < 1
+    # anything else is refused, as in the reference (vmap.py:361-362)
+    try:
+        Regenerate(S["theta"]).edit(G.split(G.key(seed), n), tr, Diff.no_change(args))
+        raise AssertionError("Regenerate on a plate should be refused")
+    except NotSupportedEditRequest:
+        pass

@@ -402,7 +402,7 @@ def check_scan(n=257, T=6, seed=5):
     assert np.array_equal(w3.cpu().numpy(), O.normal.assess(O.C.choice(np.full(n, 0.25, np.float32)), (x3, np.float32(1.0)), (n,))[0])
     # a Scan used directly: the chain starts at the caller's key
     sc = step.scan(n=3)
-    t4 = sc.simulate(G.split(G.key(seed + 2), 16), (torch.zeros(16), jnp.zeros(3)))
+    t4 = sc.simulate(G.split(G.key(seed + 2), 16), (torch.zeros(16, device=G._lib.get().device), jnp.zeros(3)))
     t4o = O.Scan(ostep, 3).simulate(O.split(O.key(seed + 2), 16), (np.zeros(16, np.float32), np.zeros(3, np.float32)))
     assert np.array_equal(t4.get_choices()["x"].cpu().numpy(), t4o.get_choices()["x"])
 

@@ -71,7 +71,44 @@ _UNARY = dict(exp=0, log=1, log1p=2, sqrt=3, sin=4, cos=5, tanh=6, sigmoid=7,
               softplus=8, lgamma=9, erfinv=10, recip=11)
 
 
+class Dual:
+    """Forward-mode dual number (value, tangent), float32: the oracle's own, independent way to get
+    d assess / d choice for HMC (the product differentiates its IR in reverse mode)."""
+    __array_priority__ = 2000
+
+    def __init__(self, v, t):
+        self.v, self.t = np.asarray(v, np.float32), np.asarray(t, np.float32)
+
+    @staticmethod
+    def lift(x):
+        return x if isinstance(x, Dual) else Dual(x, np.zeros_like(np.asarray(x, np.float32)))
+
+    def __add__(self, o): o = Dual.lift(o); return Dual(self.v + o.v, self.t + o.t)
+    __radd__ = __add__
+    def __sub__(self, o): o = Dual.lift(o); return Dual(self.v - o.v, self.t - o.t)
+    def __rsub__(self, o): return Dual.lift(o) - self
+    def __mul__(self, o): o = Dual.lift(o); return Dual(self.v * o.v, self.t * o.v + self.v * o.t)
+    __rmul__ = __mul__
+    def __truediv__(self, o):
+        o = Dual.lift(o)
+        q = self.v / o.v
+        return Dual(q, self.t / o.v - (q * o.t) / o.v)
+    def __rtruediv__(self, o): return Dual.lift(o) / self
+    def __neg__(self): return Dual(-self.v, -self.t)
+    def astype(self, dt): return self                      # already float32 on both parts
+    @property
+    def shape(self): return self.v.shape
+
+
+_DUAL_UNARY = {"exp": lambda x, y: y, "log": lambda x, y: np.float32(1.0) / x,
+               "sqrt": lambda x, y: np.float32(1.0) / (np.float32(2.0) * y),
+               "tanh": lambda x, y: np.float32(1.0) - y * y, "sigmoid": lambda x, y: y * (np.float32(1.0) - y)}
+
+
 def _unary(name, x):
+    if isinstance(x, Dual):
+        y = _unary(name, x.v)
+        return Dual(y, (x.t * _DUAL_UNARY[name](x.v, y)).astype(np.float32))
     x = np.asarray(x, dtype=np.float32)
     xc = np.ascontiguousarray(x).reshape(-1)
     out = np.empty_like(xc)
@@ -390,6 +427,8 @@ class Distribution:
         """ExactDensity.estimate_logpdf: sum an array-valued log_prob into one
         site score (distribution.py:383-396); event axes are the ones beyond
         the particle batch."""
+        if isinstance(v, Dual) or any(isinstance(a, Dual) for a in args):
+            return self._logpdf_dual(Dual.lift(v), [Dual.lift(a) for a in args], batch_shape)
         w = self._logpdf(v, args)
         batch_shape = tuple(batch_shape)
         batched, event = _event_of(batch_shape, w.shape)
@@ -459,6 +498,16 @@ class Distribution:
 
 class _Normal(Distribution):
     name = "normal"
+
+    def _logpdf_dual(self, x, args, batch_shape):
+        """value: the ordinary path; tangent: z = x/s - m/s, d = -z/s dx + z/s dm + (z*z - 1)/s ds
+        (scalar sites only)."""
+        m, s = args
+        val = self.estimate_logpdf(x.v, (m.v, s.v), batch_shape)
+        z = (x.v / s.v - m.v / s.v).astype(np.float32)
+        zs = (z / s.v).astype(np.float32)
+        t = (-(zs * x.t) + zs * m.t + ((z * z - np.float32(1.0)) / s.v) * s.t).astype(np.float32)
+        return Dual(val, np.broadcast_to(t, np.shape(val)))
 
     def _sample_flat(self, n, kb, e, cols, out):
         lib().orc_normal_sample(I64(n), _p(kb), I64(1), ctypes.c_uint64(e), _p(cols[0]), I64(1),
@@ -1078,6 +1127,59 @@ class Rejuvenate:
         bwd_score, _ = self.proposal.assess(bwd_chm, bwd_args, np.shape(w))
         final = ((w + bwd_score).astype(np.float32) - fwd_score).astype(np.float32)
         return new_tr, final
+
+
+def hmc_edit(k, trace, sel_addrs, eps, L, args):
+    """HMC.edit (inference/requests/hmc.py:153-214) for scalar selected sites of a static model,
+    literally — including the carried INITIAL gradient in the first half-kick of every step."""
+    gen_fn = trace.get_gen_fn()
+    eps = np.float32(eps)
+    chm = trace.get_choices()
+    batch = np.shape(trace.get_score())
+    sel_addrs = sorted((_addr(a) for a in sel_addrs), key=repr)
+
+    def score_and_grads(values):
+        full = chm
+        for a in sel_addrs:
+            full = full.set(a, values[a])
+        grads = {}
+        for a in sel_addrs:
+            d = full.set(a, Dual(values[a], np.ones_like(values[a])))
+            s, _ = gen_fn.assess(d, args, batch)
+            grads[a] = np.broadcast_to(s.t, batch).astype(np.float32)
+        s, _ = gen_fn.assess(full, args, batch)
+        return np.asarray(s, np.float32), grads
+
+    values = {a: np.broadcast_to(np.asarray(chm[a], np.float32), batch) for a in sel_addrs}
+    original_model_score = np.asarray(trace.get_score(), np.float32)
+    _, grad0 = score_and_grads(values)
+    sub_key = split(k)[..., 1, :]
+    momenta, terms = {}, []
+    for i, a in enumerate(sel_addrs):
+        momenta[a] = normal.sample(fold_in(sub_key, i), np.float32(0.0), np.float32(1.0))
+        terms.append(normal.estimate_logpdf(momenta[a], (np.float32(0.0), np.float32(1.0)), batch))
+    original_momenta_score = terms[0]
+    for t in terms[1:]:
+        original_momenta_score = (original_momenta_score + t).astype(np.float32)
+    half = np.float32(eps / np.float32(2.0))
+    for _ in range(L):
+        momenta = {a: (momenta[a] + half * grad0[a]).astype(np.float32) for a in sel_addrs}
+        values = {a: (values[a] + eps * momenta[a]).astype(np.float32) for a in sel_addrs}
+        _, grads = score_and_grads(values)
+        momenta = {a: (momenta[a] + half * grads[a]).astype(np.float32) for a in sel_addrs}
+    full = chm
+    for a in sel_addrs:
+        full = full.set(a, values[a])
+    final_tr, _ = gen_fn.generate(k, full, args)                 # every site constrained: no draw
+    final_model_score = np.asarray(final_tr.get_score(), np.float32)
+    terms = [normal.estimate_logpdf((momenta[a] * np.float32(-1.0)).astype(np.float32),
+                                    (np.float32(0.0), np.float32(1.0)), batch) for a in sel_addrs]
+    final_momenta_score = terms[0]
+    for t in terms[1:]:
+        final_momenta_score = (final_momenta_score + t).astype(np.float32)
+    alpha = (((final_model_score - original_model_score).astype(np.float32) + final_momenta_score).astype(np.float32)
+             - original_momenta_score).astype(np.float32)
+    return final_tr, alpha
 
 
 def mh_accept(k, log_alpha):

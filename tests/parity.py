@@ -467,3 +467,71 @@ def check_plate_edits(n=257, seed=1):
         raise AssertionError("Regenerate on a plate should be refused")
     except NotSupportedEditRequest:
         pass
+
+
+# ---------------------------------------------------------------------------
+# HMC: one launch = L leapfrog steps + L+1 reverse-mode gradients
+# ---------------------------------------------------------------------------
+def check_hmc(n=257, seed=3):
+    import genjax_amd as G
+    from genjax_amd import ChoiceMap, Diff, SelectionBuilder as S
+    from genjax_amd.inference.requests import HMC, SafeHMC
+
+    def mk(g):
+        @g.gen
+        def model():
+            x = g.normal(0.0, 1.0) @ "x"
+            y = g.normal(x, 0.01) @ "y"
+            return y
+
+        @g.gen
+        def chain():
+            mu = g.normal(0.0, 2.0) @ "mu"
+            x = g.normal(mu * 0.5 + 1.0, 1.5) @ "x"
+            g.normal(x * x * 0.1 + mu, 0.3) @ "y"
+            return x
+        return model, chain
+    (model, chain), (omodel, ochain) = mk(G), mk(O)
+    # --- tests/inference/test_requests.py:197-235 (test_simple_normal_hmc), one particle, no accept step ---
+    key = G.key(0)
+    key, sub_key = G.split(key)
+    tr, _ = model.importance(sub_key, ChoiceMap.kw(y=3.0), ())
+    request = HMC(S["x"], 1e-2)
+    new_tr, fwd_w, _, bwd = request.edit(key, tr, Diff.no_change(()))
+    lp = lambda t: float(G.normal.logpdf(t.get_choices()["x"], 0.0, 1.0)) + \
+        float(G.normal.logpdf(t.get_choices()["y"], t.get_choices()["x"], 0.01))
+    assert float(fwd_w) != 0.0
+    assert float(new_tr.get_score() - tr.get_score()) == pytest_approx(lp(new_tr) - lp(tr), 1e-6)
+    assert float(fwd_w) - float(new_tr.get_score() - tr.get_score()) != 0.0
+    assert isinstance(bwd, HMC)
+    cur = tr
+    for _ in range(20):
+        key, sub_key = G.split(key)
+        cur, *_ = request.edit(sub_key, cur, Diff.no_change(()))
+    assert abs(float(cur.get_choices()["x"]) - 3.0) <= 3.0 * 5e-3            # pytest.approx(3.0, 5e-3)
+    # --- against the oracle (forward-mode duals there, reverse-mode IR here), batched ---
+    for gm, om, sel, osel, obs, tol in ((model, omodel, S["x"], ["x"], 3.0, 0.0),
+                                        (chain, ochain, S["x"] | S["mu"], ["x", "mu"], 0.7, 2e-5)):
+        trb, _ = gm.importance(G.split(G.key(seed), n), ChoiceMap.kw(y=obs), ())
+        otrb, _ = om.importance(O.split(O.key(seed), n), O.C.kw(y=np.float32(obs)), ())
+        ntr, w, _, _ = HMC(sel, 1e-2, L=10).edit(G.split(G.key(seed + 1), n), trb, Diff.no_change(()))
+        ontr, ow = O.hmc_edit(O.split(O.key(seed + 1), n), otrb, osel, 1e-2, 10, ())
+        for a in osel:
+            x, ox = ntr.get_choices()[a].cpu().numpy(), np.asarray(ontr.get_choices()[a], np.float32)
+            assert np.allclose(x, ox, rtol=tol, atol=tol) if tol else np.array_equal(x, ox), a
+        wa = w.cpu().numpy()
+        assert np.allclose(wa, ow, rtol=max(tol, 0) * 50, atol=max(tol, 0) * 50) if tol else np.array_equal(wa, ow)
+        assert np.allclose(ntr.get_score().cpu().numpy(), np.asarray(ontr.get_score(), np.float32), rtol=1e-5, atol=1e-4)
+    # SafeHMC = HMC + an assertion on the retdiff (hmc.py:217-227): fine when the return value (the
+    # constrained y) cannot move, trips when it depends on a selected choice
+    SafeHMC(S["x"], 1e-2).edit(G.key(1), tr, Diff.no_change(()))
+    try:
+        SafeHMC(S["x"], 1e-2).edit(G.key(1), chain.importance(G.key(2), ChoiceMap.kw(y=0.7), ())[0], Diff.no_change(()))
+        raise RuntimeError("SafeHMC should assert: the return value depends on x")
+    except AssertionError:
+        pass
+
+
+def pytest_approx(x, rel):
+    import pytest
+    return pytest.approx(x, rel)

@@ -412,6 +412,11 @@ def test_plate_edits_match_oracle(gpu, n):
     parity.check_plate_edits(n=n)
 
 
+@pytest.mark.parametrize("n", [257, 100_000])
+def test_hmc_reference_behaviour_and_oracle(gpu, n):
+    parity.check_hmc(n=n)
+
+
 def test_full_size_sweep_properties(gpu):
     """BASELINE config 2 at full size (1e6 particles, T = 100): size-independent
     properties — sorted ancestors, determinism, and log-ML within Monte-Carlo

@@ -560,6 +560,11 @@ def test_plate_edits_match_oracle():
     parity.check_plate_edits(n=257)
 
 
+def test_hmc_reference_behaviour_and_oracle():
+    from tests import parity
+    parity.check_hmc(n=257)
+
+
 def test_program_limits():
     """<= 32 live 32-bit values per particle (registers stay in VGPRs); a model
     that needs more fails loudly at trace time instead of spilling silently."""

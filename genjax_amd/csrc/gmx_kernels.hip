@@ -136,8 +136,8 @@ static int parse_program(const uint32_t* blob, size_t n_words, gmx_program& P) {
     return gmx_fail("gmx_program_create: length does not match n_instr / n_const%s");
   if ((uint64_t)n_dyn + n_const != blob[6])
     return gmx_fail("gmx_program_create: n_uni != n_dyn + n_const%s");
-  if (n_regs == 0 || n_regs > 32)
-    return gmx_fail("gmx_program_create: n_regs must be in [1,32] (got %s%lld)", "", n_regs);
+  if (n_regs == 0 || n_regs > GMX_MAX_REGS)
+    return gmx_fail("gmx_program_create: n_regs must be in [1,64] (got %s%lld)", "", n_regs);
   if (blob[4] > GMX_MAX_IN || blob[5] > GMX_MAX_OUT || blob[6] > GMX_MAX_UNI || blob[7] > GMX_MAX_TAB)
     return gmx_fail("gmx_program_create: slot count exceeds ABI limits%s");
   P.code_d = nullptr;
@@ -245,7 +245,7 @@ static std::string jit_source(const gmx_program* p) {
   s += "__device__ static constexpr uint32_t GMX_JIT_CONST[] = {";
   for (size_t k = 0; k < p->consts.size(); ++k) { snprintf(buf, sizeof(buf), "0x%08xu,", p->consts[k]); s += buf; }
   s += "0u};\n";
-  snprintf(buf, sizeof(buf), "GMX_JIT_BEGIN(%u, %s, %u, %d)\n", p->n_regs <= 16 ? 16u : 32u,
+  snprintf(buf, sizeof(buf), "GMX_JIT_BEGIN(%u, %s, %u, %d)\n", p->n_regs <= 16 ? 16u : (p->n_regs <= 32 ? 32u : 64u),
            p->needs_full ? "true" : "false", p->n_dyn, jit_pp_for(p));
   s += buf;
   for (uint32_t pc = 0; pc < p->n_instr; ++pc) {
@@ -379,6 +379,9 @@ extern "C" int gmx_program_run(const gmx_program* p, int64_t n, const gmx_run_ar
     GMX_HIP(hipModuleLaunchKernel(p->jit_fn, jgrid, 1, 1, GMX_BLOCK, 1, 1, 0, st, nullptr, config));
     return 0;
   }
+  if (p->n_regs > 32)
+    return gmx_fail("gmx_program_run: a program with more than 32 live values runs only as a specialised kernel "
+                    "(gmx_program_specialize; hiprtc unavailable or GENMI_JIT=0?)%s");
   if (p->n_regs <= 16) {
     if (p->needs_full)
       hipLaunchKernelGGL((k_vm<gmx_regs_vgpr<16>, true>), grid, block, 0, st, p->code_d, p->n_instr, n, *args);

@@ -357,9 +357,9 @@ class Compiled:
         buffers are persistent bind every step once and re-launch the bindings."""
         be = self._be
         n = int(np.prod(batch, dtype=np.int64))
-        if n >= JIT_MIN_PARTICLES and not self._jit_tried and be.uses_streams \
+        if (n >= JIT_MIN_PARTICLES or int(self.blob[3]) > 32) and not self._jit_tried and be.uses_streams \
                 and not torch.cuda.is_current_stream_capturing():
-            self.specialize()
+            self.specialize()        # big ensembles, and programs the 32-register interpreter cannot hold
         A = _lib.RunArgs()
         keep = []
         anc = None

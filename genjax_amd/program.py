@@ -1,6 +1,6 @@
 """Site-program IR and encoder (see genjax_amd/csrc/gmx_program.h for the
 binary format).  A `Graph` is filled by the tracer (tracer.py / static.py) in
-program order; `compile_graph` removes dead nodes, allocates the <= 32
+program order; `compile_graph` removes dead nodes, allocates the <= 64
 registers by live range and emits the uint32 blob `gmx_program_create` takes.
 
 This is the build's counterpart of the reference's trace-time machinery
@@ -18,7 +18,7 @@ import numpy as np
 
 MAGIC = 0x50584D47
 VERSION = 2
-MAX_REGS = 32
+MAX_REGS = 64          # operand codes below POOL_BASE; more than 32 needs the specialised kernel (no interpreter build)
 
 F_GATHER, F_U8, F_BCAST = 1, 2, 4
 
@@ -49,6 +49,7 @@ EFFECT = {"STOUT", "REDMAX", "REDLSE"}
 _NO_CSE = EFFECT | {"LDIN", "UNI", "CONST", "S_CATSTEP", "CATIDX"}     # slots are unique; CONSTs have their own table
 # values recomputed at every use instead of being held in a register (see compile_graph)
 REMAT_UNARY = {"LOG", "EXP", "NEG", "SQUARE", "SQRT", "RECIP", "I2F"}
+REMAT_BINARY = {"ADD", "SUB", "MUL", "DIV"}
 
 
 @dataclass(eq=False)
@@ -185,16 +186,46 @@ def compile_graph(g: Graph):
             pool_of[n.idx] = next_pool
             const_pool.append((next_pool, n.imm))
             next_pool += 1
-    # ---- rematerialisable values: an element of a table at a constant index, and one cheap
-    # unary op of it.  Shared (hash-consed) across distant uses they would pin a register each —
-    # 64 log-probabilities read once per enumerated category — so they are re-emitted per use.
+    # ---- rematerialisable values.  Hash-consing shares a value between distant uses (64
+    # log-probabilities read once per enumerated category; y/sigma re-used by every gradient of an
+    # HMC trajectory), which would pin a register each.  Cheap ones are re-emitted at each use instead:
+    #   always:            a table element at a constant index, and one cheap unary op of it;
+    #   if long-lived:     a non-gathered input load, and one cheap unary / binary op whose operands are
+    #                      such loads or pool entries.
+    def _first_last():
+        first, last = {}, {}
+        k = 0
+        for n in nodes:
+            if not live[n.idx]:
+                continue
+            for a in n.args:
+                if a is not None:
+                    first.setdefault(a.idx, k)
+                    last[a.idx] = k
+            k += 1
+        return first, last
+    use_first, use_last = _first_last()
+    LONG = 96
+
+    def long_lived(n):
+        return n.idx in use_last and use_last[n.idx] - use_first[n.idx] > LONG
+
+    def leafish(a):
+        return a is None or a.idx in pool_of or (a.idx in remat and remat[a.idx] == 1) or \
+            (a.op == "CONST")
     remat = {}
     for n in nodes:
         if not live[n.idx]:
             continue
         if n.op == "LDTAB" and n.args[0].op == "CONST":
             remat[n.idx] = 1
-        elif n.op in REMAT_UNARY and n.args[0].idx in remat and remat[n.args[0].idx] == 1:
+        elif n.op == "LDIN" and not (n.flags & F_GATHER) and long_lived(n):
+            remat[n.idx] = 1
+        elif n.op in REMAT_UNARY and n.args[0].idx in remat and remat[n.args[0].idx] == 1 and \
+                (n.args[0].op == "LDTAB" or long_lived(n)):
+            remat[n.idx] = 2
+        elif n.op in REMAT_BINARY and long_lived(n) and all(leafish(a) for a in n.args) and \
+                any(a.idx in remat for a in n.args):
             remat[n.idx] = 2
     # leaf loads (inputs, launch-index, register-resident constants) are SUNK to their first use:
     # a trace with many input leaves (an edited plate: value + score per element) would otherwise
@@ -247,15 +278,36 @@ def compile_graph(g: Graph):
     temps = []
     pre = {}
 
+    def scratch():
+        t = alloc(1)
+        temps.append(t)
+        return t
+
+    def operand(x):
+        """Operand code of an argument of a value being rematerialised."""
+        p = pool_of.get(x.idx)
+        if p is not None:
+            return POOL_BASE + p
+        if x.idx in remat:
+            return materialise(x)
+        return reg[x.idx]
+
     def materialise(x):
         """Recompute a rematerialised value into a scratch register (freed after this instruction)."""
         if x.op == "LDTAB":
-            t = alloc(1)
-            temps.append(t)
-            emit("LDTAB", t, x.slot, R(x.args[0]), x.imm)
+            t = scratch()
+            emit("LDTAB", t, x.slot, operand(x.args[0]), x.imm)
+        elif x.op == "LDIN":
+            t = scratch()
+            emit("LDIN", t, x.slot, x.flags)
+        elif x.op in UNARY:
+            a = operand(x.args[0])
+            t = a if a in temps else scratch()         # a scratch operand is updated in place
+            emit(x.op, t, a)
         else:
-            t = materialise(x.args[0])       # the inner scratch register is updated in place
-            emit(x.op, t, t)
+            a, b = operand(x.args[0]), operand(x.args[1])
+            t = a if a in temps else (b if b in temps else scratch())
+            emit(x.op, t, a, b)
         return t
 
     def R(x):

@@ -68,7 +68,7 @@ extern "C" int gmx_program_create(const uint32_t* blob, size_t n_words, gmx_prog
   if (!blob || !out || n_words < GMX_PROG_HEADER_WORDS) return fail("program_create: bad blob");
   if (blob[0] != GMX_PROG_MAGIC || blob[1] != GMX_PROG_VERSION) return fail("program_create: bad magic/version");
   if (n_words != GMX_PROG_HEADER_WORDS + 2ull * blob[2] + blob[8]) return fail("program_create: bad length");
-  if (blob[3] == 0 || blob[3] > 32) return fail("program_create: n_regs out of range");
+  if (blob[3] == 0 || blob[3] > GMX_MAX_REGS) return fail("program_create: n_regs out of range");
   gmx_program* p = new gmx_program;
   p->n_instr = blob[2]; p->n_regs = blob[3]; p->n_in = blob[4]; p->n_out = blob[5]; p->n_uni = blob[6]; p->n_tab = blob[7];
   p->n_const = blob[8]; p->n_dyn = blob[9];
@@ -110,7 +110,7 @@ extern "C" int gmx_program_run(const gmx_program* p, int64_t n, const gmx_run_ar
     for (int t = 0; t < 256; ++t) {
       int64_t i = blk * 256 + t;
       HostCtx ctx; ctx.code = p->code.data(); ctx.A = A; ctx.red = &red; ctx.i = t; ctx.kind = 0;
-      gmx_vm_run<gmx_regs_vgpr<32>, true, -1, HostCtx>(p->n_instr, i, i < n, *A, ctx);
+      gmx_vm_run<gmx_regs_vgpr<GMX_MAX_REGS>, true, -1, HostCtx>(p->n_instr, i, i < n, *A, ctx);
       if (ctx.kind) kind = ctx.kind;
     }
     if (kind && A->red_out_d) {

@@ -522,6 +522,26 @@ def check_hmc(n=257, seed=3):
         wa = w.cpu().numpy()
         assert np.allclose(wa, ow, rtol=max(tol, 0) * 50, atol=max(tol, 0) * 50) if tol else np.array_equal(wa, ow)
         assert np.allclose(ntr.get_score().cpu().numpy(), np.asarray(ontr.get_score(), np.float32), rtol=1e-5, atol=1e-4)
+    # --- tests/inference/test_requests.py:237-255 (test_simple_scan_hmc): HMC over all 10 steps of a scan;
+    # > 32 live values per chain (values, momenta, initial gradient: 3 x 10), i.e. a specialised kernel on the GPU
+    from genjax_amd import Selection, numpy as jnp
+
+    @G.gen
+    def kernel(z, scanned_in):
+        z = G.normal(z, 1.0) @ "x"
+        _ = G.normal(z, 0.01) @ "y"
+        return z, None
+    key = G.key(0)
+    key, sub_key = G.split(key)
+    smodel = kernel.scan(n=10)
+    str_, _ = smodel.importance(sub_key, ChoiceMap.empty().at["y"].set(3.0 * jnp.ones(10)), (0.0, None))
+    srequest = HMC(Selection.at["x"], jnp.array(1e-2))
+    cur = str_
+    for _ in range(50):
+        key, sub_key = G.split(key)
+        cur, *_ = srequest.edit(sub_key, cur, Diff.no_change((0.0, None)))
+    xs = cur.get_choices()["x"].cpu().numpy()
+    assert xs.shape == (10,) and np.all(np.abs(xs - 3.0) <= 3.0 * 8e-3)       # pytest.approx(3.0, 8e-3)
     # SafeHMC = HMC + an assertion on the retdiff (hmc.py:217-227): fine when the return value (the
     # constrained y) cannot move, trips when it depends on a selected choice
     SafeHMC(S["x"], 1e-2).edit(G.key(1), tr, Diff.no_change(()))

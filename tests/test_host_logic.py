@@ -566,8 +566,8 @@ def test_hmc_reference_behaviour_and_oracle():
 
 
 def test_program_limits():
-    """<= 32 live 32-bit values per particle (registers stay in VGPRs); a model
-    that needs more fails loudly at trace time instead of spilling silently."""
+    """<= 64 live 32-bit values per particle (<= 32 for the interpreter, up to 64 for specialised
+    kernels); a model that needs more fails loudly at trace time instead of spilling silently."""
     from genjax_amd.program import ProgramTooLarge
 
     @genjax.gen
@@ -580,11 +580,14 @@ def test_program_limits():
     assert len(tr.get_choices().addresses()) == 30
 
     @genjax.gen
-    def too_wide():
-        xs = [genjax.normal(0.0, 1.0) @ f"x{i}" for i in range(40)]
-        acc = xs[0]
+    def too_wide(v):
+        xs = [jnp.exp(v * float(i)) * jnp.sin(v + float(i)) for i in range(80)]   # 80 values, all live at once
+        acc = genjax.normal(xs[0], 1.0) @ "x"
         for x in xs[1:]:
-            acc = acc * x                                        # all 40 values live at once
-        return acc
+            acc = acc * x
+        acc2 = acc
+        for x in xs:
+            acc2 = acc2 + x * acc
+        return acc2
     with pytest.raises(ProgramTooLarge):
-        too_wide.simulate(genjax.key(0), ())
+        too_wide.simulate(genjax.split(genjax.key(0), 4), (torch.arange(4, dtype=torch.float32),))

@@ -262,7 +262,7 @@ extern "C" int gmx_program_specialize(gmx_program* p) {
   if (!p) return gmx_fail("gmx_program_specialize: null program%s");
   if (p->jit_fn) return 0;
   if (!jit_enabled()) return gmx_fail("gmx_program_specialize: disabled by GENMI_JIT=0%s");
-  if (p->n_instr == 0 || p->n_instr > 2048) return gmx_fail("gmx_program_specialize: program size out of range%s");
+  if (p->n_instr == 0 || p->n_instr > 8192) return gmx_fail("gmx_program_specialize: program size out of range%s");
   std::string src = jit_source(p);
   hiprtcProgram prog;
   const char* hdr_src[GMX_EMBED_COUNT];

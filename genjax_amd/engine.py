@@ -339,7 +339,12 @@ class Compiled:
         if self._jit_tried:
             return False
         self._jit_tried = True
-        return be.c.gmx_program_specialize(self.handle) == 0
+        ok = be.c.gmx_program_specialize(self.handle) == 0
+        if not ok and int(self.blob[3]) > 32:
+            msg = be.c.gmx_last_error()
+            raise _lib.GenmiError("this program keeps more than 32 values live per particle and therefore needs the "
+                                  f"hiprtc-specialised kernel, which could not be built: {msg.decode() if msg else ''}")
+        return ok
 
     def run(self, leaves, batch: tuple, key: Key | None, red_out=None, index_offset=0, out_buffers=None):
         """Bind and launch.  Returns the list of output tensors (shape batch+event)."""

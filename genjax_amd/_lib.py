@@ -47,7 +47,7 @@ class GenmiError(RuntimeError):
 
 
 _LIB_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib")
-LIB_PATH = os.path.join(_LIB_DIR, "libgenmi_hip.so")
+LIB_PATH = os.environ.get("GENMI_LIB") or os.path.join(_LIB_DIR, "libgenmi_hip.so")   # GENMI_LIB: tuning builds
 
 
 class Backend:

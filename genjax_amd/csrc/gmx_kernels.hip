@@ -994,18 +994,30 @@ extern "C" int gmx_ancestors(int kind, const uint32_t key[2], const uint64_t* cd
 // ---------------------------------------------------------------------------
 // fused resampling (systematic / stratified, one GPU): log-weights -> ancestors
 // in two streaming kernels with NO inter-block waiting:
-//   k_cdf_local        per 4096-tile: fixed-point weights, tile-local inclusive
+//   k_cdf_local        per tile: fixed-point weights, tile-local inclusive
 //                      CDF (workspace) and the tile aggregate
-//   k_offspring_local  every block scans the <= 512 tile aggregates itself (2-4 KB
+//   k_offspring_local  every block scans the <= RS_MAX_TILES tile aggregates itself (<= 16 KB
 //                      from L2) to get its tile's global prefix and the total,
 //                      then assigns offspring exactly as k_offspring does.
 // The global CDF cdf_i = prefix[tile(i)] + local_i is the same integer the
 // chained scan (k_weight_cdf) produces, so ancestors are identical.
 // ---------------------------------------------------------------------------
-#define RS_THREADS 1024                /* 16 waves per tile                        */
-#define RS_TILE (RS_THREADS * CDF_VEC) /* 4096 log-weights per tile                */
-#define RS_MAX_TILES 512               /* n <= 2^21                                */
-#define RS_SRC_PER_THREAD 4            /* k_offspring_local: sources per thread     */
+// Tile geometry (overridable with -D for tuning; measured on MI355X at n = 1e6, both kernels together:
+// 1024 threads / 4096-item tiles 16.4 us, 512 / 2048 15.7 us, 256 / 1024 13.4 us — small tiles put ~4
+// blocks on every CU, so one block's load latency hides behind another's scan).
+#ifndef RS_THREADS
+#define RS_THREADS 256                 /* 4 waves per tile                         */
+#endif
+#define RS_TILE (RS_THREADS * CDF_VEC) /* 1024 log-weights per tile                */
+#ifndef RS_MAX_TILES
+#define RS_MAX_TILES 2048              /* n <= 2^21                                */
+#endif
+#ifndef RS_SRC_PER_THREAD
+#define RS_SRC_PER_THREAD 4            /* k_offspring_local: sources per thread (even) */
+#endif
+
+static_assert(RS_TILE % (GMX_BLOCK * RS_SRC_PER_THREAD) == 0, "an offspring block must lie inside one tile");
+static_assert(RS_MAX_TILES % GMX_BLOCK == 0 && RS_SRC_PER_THREAD % 2 == 0, "tile table / vector load shape");
 
 struct rs_ws {                 // layout of the gmx_resample workspace
   uint64_t agg[RS_MAX_TILES];  // tile aggregates
@@ -1095,7 +1107,7 @@ k_cdf_local(const float* __restrict__ lw, int64_t n, float scale, int max_mode,
 
 // One thread owns RS_SRC_PER_THREAD consecutive sources (two 16-byte loads of the
 // local CDF): a block covers 1024 sources = a quarter tile, so only n/1024 blocks
-// re-read the <= 512 tile aggregates.
+// re-read the tile aggregates.
 __global__ void __launch_bounds__(GMX_BLOCK)
 k_offspring_local(int kind, uint32_t k0, uint32_t k1, uint32_t u0_host, const rs_ws* __restrict__ ws, int64_t n,
                   int n_tiles, uint64_t* __restrict__ total_out, int32_t* __restrict__ anc) {
@@ -1114,9 +1126,11 @@ k_offspring_local(int kind, uint32_t k0, uint32_t k1, uint32_t u0_host, const rs
   }
   uint64_t loc[RS_SRC_PER_THREAD];
   if (i0 + RS_SRC_PER_THREAD <= n) {
-    ulonglong2 a = reinterpret_cast<const ulonglong2*>(ws->local + i0)[0];
-    ulonglong2 b = reinterpret_cast<const ulonglong2*>(ws->local + i0)[1];
-    loc[0] = a.x; loc[1] = a.y; loc[2] = b.x; loc[3] = b.y;
+#pragma unroll
+    for (int c = 0; c < RS_SRC_PER_THREAD / 2; ++c) {
+      ulonglong2 a = reinterpret_cast<const ulonglong2*>(ws->local + i0)[c];
+      loc[2 * c] = a.x; loc[2 * c + 1] = a.y;
+    }
   } else {
 #pragma unroll
     for (int c = 0; c < RS_SRC_PER_THREAD; ++c) loc[c] = (i0 + c < n) ? ws->local[i0 + c] : 0ull;

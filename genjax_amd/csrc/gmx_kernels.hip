@@ -233,10 +233,12 @@ static bool jit_enabled() {
 static int jit_pp_for(const gmx_program* p) {
   const char* e = getenv("GENMI_JIT_PP");
   if (e && e[0] >= '1' && e[0] <= '8') return e[0] - '0';
-  // Measured on MI355X (profiles/r01_e): 4 particles / thread did not raise the VALU issue
-  // rate of the integer-heavy Threefry stream and cost latency hiding (fewer waves), so the
-  // default stays 1; GENMI_JIT_PP=2/4 remains available for FP-heavy programs.
-  return 1;
+  // Measured on MI355X (BASELINE config 2, 1e6 particles): 4 particles / thread do not raise the VALU
+  // issue rate of the integer-heavy Threefry stream (isolated launch 11.8 -> 13.7 us) but the kernel
+  // is 0.9 us SHORTER inside the sweep (a quarter of the workgroups to schedule against the cold
+  // inputs the resampling kernels just wrote): sweep 2843 -> 2730 us; 2, 3 and 8 are slower.  Only
+  // for small programs: registers scale with the particle count per thread.
+  return (p->n_regs <= 16 && p->n_instr <= 64) ? 4 : 1;
 }
 
 static std::string jit_source(const gmx_program* p) {

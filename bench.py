@@ -31,7 +31,8 @@ sys.path.insert(0, ROOT)
 
 N_PARTICLES = 1_000_000
 T_STEPS = 100
-VM_VALU_PER_WAVE = 377.2            # SQ_INSTS_VALU / waves, profiles/r01_i_pmc_summary.txt
+VM_VALU_PER_WAVE = 344.7            # VALU instructions per 64 particles: SQ_INSTS_VALU / waves / 4 particles per
+                                    # thread (1378.7 per wave, profiles/r01_k_pmc_summary.txt; 377.2 at 1 per thread)
 VALU_PEAK_LANE_OPS = 256 * 4 * 32 * 2.4e9
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 # Algorithmic bytes per particle-step (8*D + 24 = 32 B, D = 1):
@@ -242,7 +243,7 @@ def main():
                            "algorithmic_bytes_per_launch": VM_BYTES_PER_PARTICLE * n,
                            # the kernel is VALU-issue bound, not HBM bound: 3 Threefry-2x32 blocks per draw
                            # (split child, fold_in, bits).  SQ_INSTS_VALU per wave from profiles/*_pmc_summary.txt.
-                           "valu": {"insts_per_wave": VM_VALU_PER_WAVE,
+                           "valu": {"insts_per_64_particles": VM_VALU_PER_WAVE,
                                     "lane_ops_per_s": VM_VALU_PER_WAVE * n / (vm_us * 1e-6),
                                     "peak_lane_ops_per_s": VALU_PEAK_LANE_OPS,
                                     "frac": VM_VALU_PER_WAVE * n / (vm_us * 1e-6) / VALU_PEAK_LANE_OPS,

@@ -453,9 +453,13 @@ class BootstrapSweep:
     """
 
     def __init__(self, init, step, n_particles: int, T: int, obs_addr="y", resample="systematic",
-                 step_extra=None, specialize=True):
+                 step_extra=None, specialize=True, rejuvenate=None, state_addr="x"):
+        """rejuvenate: an edit request (e.g. StaticRequest({"x": Rejuvenate(...)})) applied as one fused
+        MH move per particle after every resampling, before the next extension (BASELINE config 3; the
+        graph-captured form of smc.resample -> smc.rejuvenate -> smc.extend, same keys, same results).
+        Supported for models whose trace is {state_addr: the return value, obs_addr: the observation}."""
         self.init, self.step, self.n, self.T = init, step, int(n_particles), int(T)
-        self.obs_addr = obs_addr
+        self.obs_addr, self.state_addr, self.rejuvenate = obs_addr, state_addr, rejuvenate
         self.kind = _KINDS[resample] if isinstance(resample, str) else int(resample)
         self.step_extra = step_extra or (lambda t: ())
         self.specialize = specialize
@@ -483,10 +487,24 @@ class BootstrapSweep:
         obs0 = ChoiceMap.empty().set(self.obs_addr, self.ys[0])
         self.p_init = MinimalGenerate(self.init, (), obs0, (n,))
         g = Gathered(self.x[0], self.anc)
-        self.p_step = MinimalGenerate(self.step, (g,) + tuple(self.step_extra(1)), obs0, (n,))
+        if self.rejuvenate is None:
+            self.p_step = MinimalGenerate(self.step, (g,) + tuple(self.step_extra(1)), obs0, (n,))
+        else:
+            from ..static import MinimalMH
+            # xm[t % 2]: the MH-moved, resampled state the extension of step t starts from
+            self.xm = [torch.zeros((n,), dtype=torch.float32, device=dev) for _ in range(2)]
+            self.accept = torch.zeros((n,), dtype=torch.bool, device=dev)
+            self.p_step = MinimalGenerate(self.step, (self.xm[0],) + tuple(self.step_extra(1)), obs0, (n,))
+            ch = obs0.set(self.state_addr, g)
+            self.p_mh_init = MinimalMH(self.init, (), ch, self.rejuvenate, (n,))
+            self.p_mh_step = MinimalMH(self.step, (Gathered(self.xm[0], self.anc),) + tuple(self.step_extra(1)), ch,
+                                       self.rejuvenate, (n,))
         if self.specialize:
             self.p_init.comp.specialize()
             self.p_step.comp.specialize()
+            if self.rejuvenate is not None:
+                self.p_mh_init.comp.specialize()
+                self.p_mh_step.comp.specialize()
         grid = be.c.gmx_program_grid(self.p_step.comp.handle, n)
         self.partials = torch.zeros((2, grid), dtype=torch.float32, device=dev)
         # per-step keys on the host
@@ -504,13 +522,31 @@ class BootstrapSweep:
         if t == 0:
             prog, leaves = self.p_init, self.p_init.leaves((), obs)
         else:
-            g = Gathered(self.x[(t - 1) % 2], self.anc)
+            g = Gathered(self.x[(t - 1) % 2], self.anc) if self.rejuvenate is None else self.xm[t % 2]
             prog = self.p_step
             leaves = prog.leaves((g,) + tuple(self.step_extra(t)), obs)
         bufs = [None] * len(prog.comp.outputs)
         bufs[prog.ro[1]] = xo.reshape(1, n)
         bufs[prog.wo[1]] = self.lw.reshape(1, n)
         prog.comp.run(leaves, (n,), lazy_split(k_prop, n), red_out=self.partials, out_buffers=bufs)
+
+    def _launch_mh(self, t):
+        """The MH move on the resampled particles of step t-1 (t >= 1): reads x_{t-1}[anc] and, for
+        t >= 2, the state xm[(t-1) % 2][anc] that x_{t-1} was extended from; writes xm[t % 2]."""
+        n = self.n
+        k_mh = self.step_keys[t][2]
+        ch = ChoiceMap.empty().set(self.obs_addr, self.ys[t - 1]).set(self.state_addr,
+                                                                      Gathered(self.x[(t - 1) % 2], self.anc))
+        if t == 1:
+            prog, leaves = self.p_mh_init, self.p_mh_init.leaves((), ch, self.rejuvenate)
+        else:
+            prog = self.p_mh_step
+            a = Gathered(self.xm[(t - 1) % 2], self.anc)
+            leaves = prog.leaves((a,) + tuple(self.step_extra(t - 1)), ch, self.rejuvenate)
+        bufs = [None] * len(prog.comp.outputs)
+        bufs[prog.ro[1]] = self.xm[t % 2].reshape(1, n)
+        bufs[prog.ao[1]] = self.accept.reshape(1, n)
+        prog.comp.run(leaves, (n,), lazy_split(k_mh, n), out_buffers=bufs)
 
     def _launch_cdf(self, t):
         be = _lib.get()
@@ -541,6 +577,8 @@ class BootstrapSweep:
         previous sweep's log-weights): bench.py times that variant to get the site program's cost
         IN the sweep as a difference."""
         for t in range(self.T):
+            if t >= 1 and self.rejuvenate is not None:
+                self._launch_mh(t)
             if not skip_vm:
                 self._launch_vm(t)
             if self.fused:

@@ -736,6 +736,79 @@ class MinimalGenerate:
         return flat.leaves
 
 
+def _rec_to_prev(rec):
+    """A traced record as the symbolic PREVIOUS trace of an edit (values and scores stay expressions)."""
+    def sym(v):
+        return v if isinstance(v, Sym) else Sym(v, None)
+    if isinstance(rec, _SiteRec):
+        return {"value": sym(rec.value), "score": sym(rec.score)}
+    ret = rec.retval
+    ret = tuple(sym(r) for r in ret) if isinstance(ret, tuple) else sym(ret)
+    if getattr(rec, "plate_score", None) is not None:
+        return {"vmap": {"sub": {a: _rec_to_prev(r) for a, r in rec.sites.items()}, "retval": ret},
+                "score": sym(rec.plate_score), "retval": ret}
+    return {"sub": {a: _rec_to_prev(r) for a, r in rec.sites.items()}, "retval": ret}
+
+
+class MinimalMH:
+    """One Metropolis-Hastings move per particle (`run_mh`'s program) on a trace that is never
+    materialised: the inputs are the particle's arguments and choice VALUES (typically gathered
+    through the ancestors of a resampling step); the old scores are recomputed from them — the same
+    op sequence that produced the stored ones, so the same bits — and the only outputs are the
+    selected return value and the accept flag.  BootstrapSweep launches it between resampling and
+    the next extension."""
+
+    def __init__(self, gen_fn, args, choices: ChoiceMap, request, batch: tuple):
+        flat = Flat()
+        self.atree = flat.add(tuple(args))
+        self.ctree = flat.add(choices)
+        rspec, self.rkey = _flatten_request(request, flat)
+        self.n_fixed = len(flat.leaves)
+        self.specs = tuple(leaf_spec(v, batch) for v in flat.leaves)
+        tr = Tracing(len(batch))
+        ctx = _Ctx(tr)
+        ctx.store_sites = False
+        g = tr.graph
+        with T.tracing(g):
+            syms = [tr.sym_leaf(s, j) for j, s in enumerate(self.specs)]
+            sargs = unflatten(self.atree, lambda j: syms[j].value)
+            scon = _sym_constraint(self.ctree, syms)
+            rec0, ret0, _, _ = call_gen_fn(ctx, "generate", gen_fn, None, sargs, scon, None, None, None, ())
+            sprev = _rec_to_prev(rec0)
+            kexpr = Expr(g.add("LDKEY", dtype="key"))
+            k_acc = Expr(g.add("KDERIVE", (kexpr.node,), imm=1, dtype="key"))      # (k_edit, k_acc) = split(key_i)
+            k_edit = Expr(g.add("KDERIVE", (kexpr.node,), imm=0, dtype="key"))
+            mode, constraint = "static_edit", ChoiceMap.empty()
+            if rspec.kind == "update":
+                mode, constraint = "update", _sym_constraint(rspec.tree, syms)
+            elif rspec.kind == "regen":
+                mode = "regen"
+            _bind_request_leaves(rspec, syms)
+            rec, retval, w, _ = call_gen_fn(ctx, mode, gen_fn, k_edit, sargs, constraint, sprev, rspec, syms, ())
+            from .distributions import uniform as _uniform
+            if w is None:
+                w = Expr(g.const_f32(0.0)) + 0.0
+            u = _uniform.sym_sample(k_acc, (0.0, 1.0))
+            acc = Expr(g.add("LOG", (u.node,), dtype="f32")) < w
+
+            def sel(new, old):
+                if isinstance(new, tuple):
+                    return tuple(sel(a, b) for a, b in zip(new, old))
+                return T.where(acc, new, old)
+            self.ro = tr.emit_output(sel(retval, ret0))
+            self.ao = tr.emit_output(acc)
+        self.comp = Compiled(tr)
+
+    def leaves(self, args, choices, request):
+        flat = Flat()
+        a = flat.add(tuple(args))
+        c = flat.add(choices)
+        _, rkey = _flatten_request(request, flat)
+        if a != self.atree or c != self.ctree or rkey != self.rkey:
+            raise ValueError("MinimalMH: call structure differs from the compiled one")
+        return flat.leaves
+
+
 def _mh_select(tr: Tracing, acc: Expr, rec, prev):
     """Origins of where(accept, new, old) for every site; unchanged sites pass through."""
     def pick(new, old_sym):

@@ -2,6 +2,8 @@
 CPU hostsim harness in `-m "not gpu"` tests) and through the CPU oracle."""
 from __future__ import annotations
 
+import math
+
 import numpy as np
 import torch
 
@@ -555,3 +557,46 @@ def check_hmc(n=257, seed=3):
 def pytest_approx(x, rel):
     import pytest
     return pytest.approx(x, rel)
+
+
+def check_nlssm_mh_sweep(n=2000, T=5, seed=7, capture=False, specialize=False):
+    """BASELINE config 3 as ONE captured sweep: BootstrapSweep(rejuvenate=...) (k_vm -> resample ->
+    fused MH -> k_vm ...) against the oracle run step by step with the sweep's key schedule
+    (step key fold_in(key, t) -> (k_prop, k_res, k_mh); resampling of step t-1 uses ITS k_res)."""
+    import genjax_amd as G
+    from genjax_amd import workloads
+    from genjax_amd.inference import smc
+    ys = workloads.nlssm_data(T)
+    init, step = workloads.make_nlssm(G)
+    oi, ost = workloads.make_nlssm(O)
+    req = G.StaticRequest({"x": G.Rejuvenate(G.normal, lambda chm: (chm.get_value(), 0.5))})
+    oreq = {"x": O.Rejuvenate(O.normal, lambda chm: (chm.get_value(), np.float32(0.5)))}
+    sw = smc.BootstrapSweep(init, step, n, T, step_extra=lambda t: (float(t),), rejuvenate=req,
+                            specialize=specialize).prepare(G.key(seed), torch.from_numpy(ys))
+    if capture:
+        sw.capture()
+    sw.launch()
+    x, lw, anc = sw.state()
+    okey = O.key(seed)
+    otr = olw = None
+    terms = []
+    for t in range(T):
+        oks = O.split(O.fold_in(okey, t), 3)
+        oobs = O.C.kw(y=np.float32(ys[t]))
+        if t == 0:
+            otr, olw = oi.importance(O.split(oks[0], n), oobs, ())
+        else:
+            okr = O.split(O.fold_in(okey, t - 1), 3)[1]
+            cdf, total, M, shift = O.weight_cdf(olw)
+            terms.append(M + math.log(total) - shift * math.log(2.0) - math.log(n))
+            otr = O.gather_trace(otr, O.ancestors(O.SYSTEMATIC, okr, cdf))
+            gf = otr.get_gen_fn()
+            otr, oacc, _ = O.rejuvenate(oks[2], otr, lambda k, tr_: gf.edit_static(k, tr_, oreq, tr_.get_args()))
+            otr, olw = ost.importance(O.split(oks[0], n), oobs, (np.asarray(otr.get_retval(), np.float32), np.float32(t)))
+    assert np.array_equal(x.cpu().numpy(), np.asarray(otr.get_retval(), np.float32))
+    assert np.array_equal(lw.cpu().numpy(), np.asarray(olw, np.float32))
+    assert np.array_equal(sw.accept.cpu().numpy(), oacc)
+    cdf, total, M, shift = O.weight_cdf(olw)
+    terms.append(M + math.log(total) - shift * math.log(2.0) - math.log(n))
+    assert abs(sw.log_ml() - sum(terms)) < 1e-9 * max(1.0, abs(sum(terms)))
+    return {"accept_rate": float(oacc.mean()), "log_ml": sw.log_ml()}

@@ -565,6 +565,13 @@ def test_hmc_reference_behaviour_and_oracle():
     parity.check_hmc(n=257)
 
 
+def test_nonlinear_ssm_mh_sweep_matches_oracle():
+    """config 3 as one sweep (BootstrapSweep(rejuvenate=...)) == the oracle, bit for bit."""
+    from tests import parity
+    res = parity.check_nlssm_mh_sweep(n=1500, T=4)
+    assert 0.5 < res["accept_rate"] <= 1.0
+
+
 def test_program_limits():
     """<= 64 live 32-bit values per particle (<= 32 for the interpreter, up to 64 for specialised
     kernels); a model that needs more fails loudly at trace time instead of spilling silently."""

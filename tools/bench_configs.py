@@ -70,6 +70,25 @@ try:
 except Exception as e:
     out["config3"]["graph_replay"] = {"error": repr(e)[:300]}
 
+# the native form: BootstrapSweep(rejuvenate=...) = k_vm -> resample -> fused MH per step, pre-bound
+# persistent buffers, one hipGraph for the sweep
+try:
+    sw = smc.BootstrapSweep(init, step, n, T, step_extra=lambda t: (float(t),), rejuvenate=req).prepare(
+        G.key(7), torch.from_numpy(ys))
+    sw.capture()
+    sw.launch()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for r in range(20):
+        sw.launch()
+    torch.cuda.synchronize()
+    dts = (time.perf_counter() - t0) / 20
+    out["config3"]["native_sweep"] = {"ms_per_sweep": 1e3 * dts, "particle_steps_per_s": n * T / dts,
+                                      "us_per_step": 1e6 * dts / T, "log_ml": sw.log_ml(),
+                                      "accept_rate_last_step": float(sw.accept.float().mean())}
+except Exception as e:
+    out["config3"]["native_sweep"] = {"error": repr(e)[:300]}
+
 # ---- config 4: 8-schools, ImportanceK k = 1e7 + one global systematic resample ----
 sig, ysch = [15.0, 10.0, 16.0, 11.0, 9.0, 11.0, 10.0, 18.0], np.array([28, 8, -3, 7, -1, 1, 18, 12], np.float32)
 

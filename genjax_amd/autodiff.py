@@ -136,3 +136,40 @@ def _rule(n, a, push):
         return                          # piecewise constant / not a float function of its inputs
     else:
         raise NotDifferentiable(f"no derivative rule for {op}")
+
+
+# ---------------------------------------------------------------------------
+# value_and_grad of a plain numeric function (the `jax.value_and_grad` of this stack): one launch
+# ---------------------------------------------------------------------------
+_VG_CACHE: dict = {}
+
+
+def value_and_grad(fn):
+    """`value_and_grad(fn)(*xs)`: xs are float tensors of one common batch shape; returns
+    (fn(*xs), (d fn / d x_k for each k)) computed per element in ONE launch."""
+    def run(*xs):
+        from . import _lib
+        from .engine import Compiled, Flat, Tracing, leaf_spec, resolve
+        from .static import _fnkey
+        flat = Flat()
+        tree = flat.add(tuple(xs))
+        batch = tuple(xs[0].shape)
+        specs = tuple(leaf_spec(v, batch) for v in flat.leaves)
+        ck = (_fnkey(fn), tree, specs)
+        ent = _VG_CACHE.get(ck)
+        if ent is None:
+            tr = Tracing(len(batch))
+            with T.tracing(tr.graph):
+                syms = [tr.sym_leaf(s, j) for j, s in enumerate(specs)]
+                ins = [T.as_float(s.value) for s in syms]
+                out = T.as_float(fn(*ins))
+                gs = grad(out, ins)
+                oo = tr.emit_output(out)
+                go = [tr.emit_output(g + 0.0) for g in gs]
+            ent = (Compiled(tr), oo, go)
+            _VG_CACHE[ck] = ent
+        comp, oo, go = ent
+        outs = comp.run(flat.leaves, batch, None)
+        _lib.get()
+        return resolve(oo, outs, flat.leaves), tuple(resolve(g, outs, flat.leaves) for g in go)
+    return run

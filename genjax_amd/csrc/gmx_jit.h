@@ -26,13 +26,20 @@ struct gmx_jit_ctx {
   float* lds4;
   uint32_t part;            // index of the 256-particle group this step works on (block partial row)
   uint32_t rows;            // number of 256-particle groups = ceil(n / 256)
+  float acc_max;            // OP_REDMAX: running max over the thread's PP particles
+  bool first, last;         // this step handles the first / last of the thread's particles
   __device__ __forceinline__ uint32_t pool(uint32_t i) const {
     return i < (uint32_t)NDYN ? A->uni[i] : consts[i - (uint32_t)NDYN];
   }
   __device__ __forceinline__ const void* in_ptr(uint32_t s) const { return A->in_d[s]; }
   __device__ __forceinline__ void* out_ptr(uint32_t s) const { return A->out_d[s]; }
   __device__ __forceinline__ const void* tab_ptr(uint32_t s) const { return A->tab_d[s]; }
-  __device__ __forceinline__ void red_max(float x, bool active) { gmx_red_max(A->red_out_d, lds4, part, x, active); }
+  // one block reduction and ONE partial row per workgroup (a max does not care how particles are grouped)
+  __device__ __forceinline__ void red_max(float x, bool active) {
+    const float m = active ? x : -gmx_inf();
+    acc_max = first ? m : gmx_fmax(acc_max, m);
+    if (last) gmx_red_max(A->red_out_d, lds4, blockIdx.x, acc_max, true);
+  }
   __device__ __forceinline__ void red_lse(float x, bool active) {
     gmx_red_lse(A->red_out_d, lds4, part, rows, x, active);
   }
@@ -66,7 +73,7 @@ struct gmx_jit_ctx {
 
 #define GMX_JIT_OP(W0, W1)                                                                       \
     _Pragma("unroll") for (int p = 0; p < PP; ++p) {                                             \
-      ctx.part = blockIdx.x * PP + p;                                                            \
+      ctx.part = blockIdx.x * PP + p; ctx.first = (p == 0); ctx.last = (p == PP - 1);            \
       gmx_vm_step<regs_t, full_v, gmx_cword<W0, W1>, ctx_t>(R[p], gmx_cword<W0, W1>(), idx[p], act[p], A, ctx); \
     }
 

@@ -117,7 +117,7 @@ k_vm(const uint32_t* __restrict__ code, uint32_t n_instr, int64_t n, const gmx_r
 struct gmx_program {
   uint32_t* code_d;
   uint32_t n_instr, n_regs, n_in, n_out, n_uni, n_tab, n_const, n_dyn;
-  bool uses_key, uses_red, uses_gather, needs_full;
+  bool uses_key, uses_red, uses_lse, uses_gather, needs_full;
   std::vector<uint32_t> code_h;      // instruction words (host copy, for specialisation)
   std::vector<uint32_t> consts;      // pool entries n_dyn..
   hipModule_t jit_module = nullptr;  // specialised kernel (gmx_program_specialize)
@@ -141,7 +141,7 @@ static int parse_program(const uint32_t* blob, size_t n_words, gmx_program& P) {
   if (blob[4] > GMX_MAX_IN || blob[5] > GMX_MAX_OUT || blob[6] > GMX_MAX_UNI || blob[7] > GMX_MAX_TAB)
     return gmx_fail("gmx_program_create: slot count exceeds ABI limits%s");
   P.code_d = nullptr;
-  P.uses_key = P.uses_red = P.uses_gather = P.needs_full = false;
+  P.uses_key = P.uses_red = P.uses_lse = P.uses_gather = P.needs_full = false;
   P.n_instr = n_instr; P.n_regs = n_regs; P.n_const = n_const; P.n_dyn = n_dyn;
   P.n_in = blob[4]; P.n_out = blob[5]; P.n_uni = blob[6]; P.n_tab = blob[7];
   // validate every instruction: register / slot indices must be in range so
@@ -186,7 +186,7 @@ static int parse_program(const uint32_t* blob, size_t n_words, gmx_program& P) {
       case OP_L_NORMAL: case OP_L_UNIFORM: case OP_L_BETA:
         ok = D(dst) && R(a) && R(b) && R(c); break;
       case OP_L_FLIP: case OP_L_BERNL: ok = D(dst) && R(a) && R(c); break;
-      case OP_REDMAX: case OP_REDLSE: ok = R(a); P.uses_red = true; break;
+      case OP_REDMAX: case OP_REDLSE: ok = R(a); P.uses_red = true; if (op == OP_REDLSE) P.uses_lse = true; break;
       default: ok = false;
     }
     if (!ok) return gmx_fail("gmx_program_create: invalid instruction%s at pc %lld", "", pc);
@@ -238,7 +238,8 @@ static int jit_pp_for(const gmx_program* p) {
   // is 0.9 us SHORTER inside the sweep (a quarter of the workgroups to schedule against the cold
   // inputs the resampling kernels just wrote): sweep 2843 -> 2730 us; 2, 3 and 8 are slower.  Only
   // for small programs: registers scale with the particle count per thread.
-  return (p->n_regs <= 16 && p->n_instr <= 64) ? 4 : 1;
+  // OP_REDLSE partials (max, sum exp) are per 256-particle group by definition: one particle per thread.
+  return (p->n_regs <= 16 && p->n_instr <= 64 && !p->uses_lse) ? 4 : 1;
 }
 
 static std::string jit_source(const gmx_program* p) {
@@ -331,9 +332,13 @@ extern "C" size_t gmx_specialize_dryrun(const uint32_t* blob, size_t n_words, ch
   return cs;
 }
 
+// Rows of block partials one launch over n particles writes (plane 0 of red_out_d): one per
+// 256-particle group — or, for a specialised kernel running PP particles per thread, one per
+// workgroup (OP_REDMAX only: a max is the same under any grouping).  Ask AFTER specialising.
 extern "C" int64_t gmx_program_grid(const gmx_program* p, int64_t n) {
-  (void)p;
-  return (n + GMX_BLOCK - 1) / GMX_BLOCK;
+  int64_t per = GMX_BLOCK;
+  if (p && p->jit_fn && !p->uses_lse) per = (int64_t)GMX_BLOCK * p->jit_pp;
+  return (n + per - 1) / per;
 }
 
 extern "C" int gmx_program_run(const gmx_program* p, int64_t n, const gmx_run_args* args,

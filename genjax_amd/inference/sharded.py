@@ -111,8 +111,7 @@ class ShardedBootstrapSweep:
         if self.specialize and be.uses_streams:
             self.p_init.comp.specialize()
             self.p_step.comp.specialize()
-        grid = be.c.gmx_program_grid(self.p_step.comp.handle, n)
-        self.partials = torch.zeros((2, grid), dtype=torch.float32, device=dev)
+        self.partials = torch.zeros((2, (n + 255) // 256), dtype=torch.float32, device=dev)
         self.step_keys = []
         for t in range(T):
             ks = split(fold_in(key, t), 3)
@@ -154,7 +153,7 @@ class ShardedBootstrapSweep:
         P = be.ptr
         return {
             "prog": prog.comp, "vm": vm, "m": m, "recv": cur[n:], "keep": (kk, tot, leaves),
-            "max": (P(self.partials), self.partials.shape[1], P(m)),
+            "max": (P(self.partials), int(be.c.gmx_program_grid(prog.comp.handle, n)), P(m)),
             "cdf": (P(self.lw), n, self.shift, None, 0, P(m), P(self.cdf), P(self.total_d), P(self.ws)),
             "plan": (self.kind, kk, P(self.totals_all), g, W, n, P(self.plan), P(tot)),
             "route": (self.kind, kk, P(self.plan), P(self.cdf), g, W, n, C, P(cur), P(self.send), P(self.idx)),

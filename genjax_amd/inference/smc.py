@@ -505,8 +505,9 @@ class BootstrapSweep:
             if self.rejuvenate is not None:
                 self.p_mh_init.comp.specialize()
                 self.p_mh_step.comp.specialize()
-        grid = be.c.gmx_program_grid(self.p_step.comp.handle, n)
-        self.partials = torch.zeros((2, grid), dtype=torch.float32, device=dev)
+        # block partials: sized for the interpreter's one row per 256 particles; a specialised kernel
+        # writes fewer rows (gmx_program_grid), asked per launch in _rows()
+        self.partials = torch.zeros((2, (n + 255) // 256), dtype=torch.float32, device=dev)
         # per-step keys on the host
         self.step_keys = []
         for t in range(T):
@@ -548,10 +549,15 @@ class BootstrapSweep:
         bufs[prog.ao[1]] = self.accept.reshape(1, n)
         prog.comp.run(leaves, (n,), lazy_split(k_mh, n), out_buffers=bufs)
 
+    def _rows(self, t) -> int:
+        """partial rows the site program of step t wrote"""
+        prog = self.p_init if t == 0 else self.p_step
+        return int(_lib.get().c.gmx_program_grid(prog.comp.handle, self.n))
+
     def _launch_cdf(self, t):
         be = _lib.get()
         be.check(be.c.gmx_weight_cdf(be.ptr(self.lw), self.n, self.shift, be.ptr(self.partials),
-                                     self.partials.shape[1], be.ptr(self.maxs[t:t + 1]), be.ptr(self.cdf),
+                                     self._rows(t), be.ptr(self.maxs[t:t + 1]), be.ptr(self.cdf),
                                      be.ptr(self.totals[t:t + 1]), be.ptr(self.ws), be.stream()),
                  "gmx_weight_cdf")
 
@@ -567,7 +573,7 @@ class BootstrapSweep:
         kh = self.step_keys[t][1].host()
         kk = (c_uint32 * 2)(int(kh[0]), int(kh[1]))
         be.check(be.c.gmx_resample(self.kind, kk, be.ptr(self.lw), self.n, self.shift, be.ptr(self.partials),
-                                   self.partials.shape[1], be.ptr(self.maxs[t:t + 1]),
+                                   self._rows(t), be.ptr(self.maxs[t:t + 1]),
                                    be.ptr(self.totals[t:t + 1]), be.ptr(self.anc), be.ptr(self.rs_ws),
                                    be.stream()), "gmx_resample")
 

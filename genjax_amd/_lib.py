@@ -96,6 +96,8 @@ class Backend:
                                      c_void_p]
         c.gmx_shard_route.argtypes = [c_int, POINTER(c_uint32), c_void_p, c_void_p, c_int, c_int, c_int64, c_int64,
                                       c_void_p, c_void_p, c_void_p, c_void_p]
+        c.gmx_shard_step.argtypes = [c_int, POINTER(c_uint32), c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                     c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]
         c.gmx_gather.argtypes = [POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int32), c_int32,
                                  c_void_p, c_int64, c_void_p]
         c.gmx_categorical_rows.argtypes = [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p]

@@ -1315,6 +1315,113 @@ k_shard_route(int kind, uint32_t k0, uint32_t k1, int64_t* __restrict__ plan, co
   if (overflow) plan[GMX_PLAN_OVERFLOW] = 1;
 }
 
+// plan + route in ONE launch (what the sharded sweep issues): every block derives the slot boundaries
+// from the all-gathered totals itself (world <= 64 evaluations of f) and handles 4 consecutive
+// sources per thread with two 16-byte CDF loads, like k_offspring_local.
+#define SHARD_MAX_WORLD 64
+__global__ void __launch_bounds__(GMX_BLOCK)
+k_shard_step(int kind, uint32_t k0, uint32_t k1, const uint64_t* __restrict__ totals, int64_t* __restrict__ plan,
+             uint64_t* __restrict__ total_out, const uint64_t* __restrict__ cdf, int rank, int world, int64_t n,
+             int64_t cap, const uint32_t* __restrict__ state, uint32_t* __restrict__ send,
+             int32_t* __restrict__ next_idx) {
+  __shared__ int64_t s_bounds[SHARD_MAX_WORLD + 1];
+  __shared__ uint64_t s_tot[2];            // global total, this rank's CDF offset
+  gmx_key key; key.k0 = k0; key.k1 = k1;
+  const uint64_t u0 = gmx_bits32(key, 0) >> 9;
+  const int64_t N = n * world, base = (int64_t)rank * n;
+  const uint64_t D = (uint64_t)N << 23;
+  if (threadIdx.x == 0) {
+    uint64_t total = 0;
+    for (int s = 0; s < world; ++s) total += totals[s];
+    const double not_ = total ? (double)N / (double)total : 0.0;
+    const double eps_ = (double)N * 0x1p-44 + 0x1p-40;
+    uint64_t off = 0, mine = 0;
+    for (int s = 0; s < world; ++s) {
+      if (s == rank) mine = off;
+      s_bounds[s] = total ? slots_below(kind, key, u0, off, D, total, not_, eps_, N) : 0;
+      off += totals[s];
+    }
+    s_bounds[world] = N;
+    s_tot[0] = total; s_tot[1] = mine;
+    if (blockIdx.x == 0) {               // published for inspection / tests; the overflow word is left alone
+      plan[GMX_PLAN_TOTAL] = (int64_t)total; plan[GMX_PLAN_OFFSET] = (int64_t)mine;
+      for (int s = 0; s <= world; ++s) plan[GMX_PLAN_BOUNDS + s] = s_bounds[s];
+      if (total_out) *total_out = total;
+    }
+  }
+  __syncthreads();
+  const uint64_t total = s_tot[0], cdf_offset = s_tot[1];
+  const int64_t i0 = ((int64_t)blockIdx.x * GMX_BLOCK + threadIdx.x) * 4;
+  bool overflow = false;
+  // (b) my slots base+i0..+3: an ancestor on rank s != rank arrives at recv[s*cap + k]
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int64_t i = i0 + c;
+    if (i < n) {
+      const int64_t jj = base + i;
+      int s = 0;
+      while (s + 1 < world && s_bounds[s + 1] <= jj) ++s;
+      if (s != rank) {
+        const int64_t first = s_bounds[s] > base ? s_bounds[s] : base;
+        const int64_t k = jj - first;
+        if (k < cap) next_idx[i] = (int32_t)(n + (int64_t)s * cap + k);
+        else { next_idx[i] = 0; overflow = true; }
+      }
+    }
+  }
+  // (a) the slots each of my 4 sources owns
+  int64_t e[4], s_lo;
+  const int lane = threadIdx.x & 63;
+  if (total == 0) {                        // only the globally last particle has offspring
+#pragma unroll
+    for (int c = 0; c < 4; ++c) e[c] = (rank == world - 1 && i0 + c == n - 1) ? N : 0;
+    s_lo = 0;
+  } else {
+    uint64_t loc[4];
+    if (i0 + 4 <= n) {
+      ulonglong2 a = reinterpret_cast<const ulonglong2*>(cdf + i0)[0];
+      ulonglong2 b = reinterpret_cast<const ulonglong2*>(cdf + i0)[1];
+      loc[0] = a.x; loc[1] = a.y; loc[2] = b.x; loc[3] = b.y;
+    } else {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) loc[c] = (i0 + c < n) ? cdf[i0 + c] : 0ull;
+    }
+    const uint64_t loc_prev = (lane == 0 && i0 > 0 && i0 < n) ? cdf[i0 - 1] : 0ull;
+    const double n_over_total = (double)N / (double)total;
+    const double eps = (double)N * 0x1p-44 + 0x1p-40;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const uint64_t c_hi = (i0 + c < n) ? loc[c] + cdf_offset : total;
+      e[c] = slots_below(kind, key, u0, c_hi, D, total, n_over_total, eps, N);
+    }
+    uint32_t e_l = (uint32_t)e[3], e_h = (uint32_t)((uint64_t)e[3] >> 32);
+    e_l = __shfl_up(e_l, 1, GMX_WAVE); e_h = __shfl_up(e_h, 1, GMX_WAVE);
+    s_lo = (int64_t)(((uint64_t)e_h << 32) | e_l);
+    if (lane == 0) s_lo = slots_below(kind, key, u0, loc_prev + cdf_offset, D, total, n_over_total, eps, N);
+  }
+  const int64_t S = s_bounds[rank];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int64_t i = i0 + c;
+    if (i < n && s_lo < e[c]) {
+      const uint32_t v = state[i];
+      int64_t d = s_lo / n;
+      int64_t d_end = (d + 1) * n;
+      int64_t first = S > d * n ? S : d * n;
+      for (int64_t j = s_lo; j < e[c]; ++j) {
+        if (j >= d_end) { ++d; d_end += n; first = d * n; }
+        if (d == rank) next_idx[j - base] = (int32_t)i;
+        else {
+          const int64_t k = j - first;
+          if (k < cap) send[d * cap + k] = v; else overflow = true;
+        }
+      }
+    }
+    if (i < n) s_lo = e[c];
+  }
+  if (overflow) plan[GMX_PLAN_OVERFLOW] = 1;
+}
+
 extern "C" size_t gmx_shard_plan_words(int world) { return (size_t)(GMX_PLAN_BOUNDS + world + 1); }
 
 static int shard_check(const char* who, int kind, const void* key, int rank, int world, int64_t n) {
@@ -1347,6 +1454,29 @@ extern "C" int gmx_shard_route(int kind, const uint32_t key[2], int64_t* plan_d,
   hipLaunchKernelGGL(k_shard_route, grid_for(n_per_rank), dim3(GMX_BLOCK), 0, (hipStream_t)stream, kind, key[0],
                      key[1], plan_d, cdf_d, rank, world, n_per_rank, capacity, (const uint32_t*)state_d,
                      (uint32_t*)send_d, next_idx_d);
+  GMX_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int gmx_shard_step(int kind, const uint32_t key[2], const uint64_t* totals_d, int64_t* plan_d,
+                              uint64_t* total_out_d, const uint64_t* cdf_d, int rank, int world, int64_t n_per_rank,
+                              int64_t capacity, const void* state_d, void* send_d, int32_t* next_idx_d,
+                              gmx_stream stream) {
+  if (shard_check("gmx_shard_step", kind, key, rank, world, n_per_rank)) return 1;
+  if (!totals_d || !plan_d || !cdf_d || !state_d || !send_d || !next_idx_d)
+    return gmx_fail("gmx_shard_step: null argument%s");
+  if (capacity < 1 || capacity > n_per_rank) return gmx_fail("gmx_shard_step: capacity must be in [1, n_per_rank]%s");
+  if (n_per_rank + (int64_t)world * capacity > 0x7fffffffLL)
+    return gmx_fail("gmx_shard_step: extended state index exceeds int32%s");
+  if (world > SHARD_MAX_WORLD) {          // large worlds: the two-launch form
+    if (gmx_shard_plan(kind, key, totals_d, rank, world, n_per_rank, plan_d, total_out_d, stream)) return 1;
+    return gmx_shard_route(kind, key, plan_d, cdf_d, rank, world, n_per_rank, capacity, state_d, send_d, next_idx_d,
+                           stream);
+  }
+  if ((uintptr_t)cdf_d & 15) return gmx_fail("gmx_shard_step: cdf_d must be 16-byte aligned%s");
+  hipLaunchKernelGGL(k_shard_step, grid_for((n_per_rank + 3) / 4), dim3(GMX_BLOCK), 0, (hipStream_t)stream, kind,
+                     key[0], key[1], totals_d, plan_d, total_out_d, cdf_d, rank, world, n_per_rank, capacity,
+                     (const uint32_t*)state_d, (uint32_t*)send_d, next_idx_d);
   GMX_HIP(hipGetLastError());
   return 0;
 }

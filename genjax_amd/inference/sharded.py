@@ -151,12 +151,14 @@ class ShardedBootstrapSweep:
         m = self.maxs[t:t + 1]
         tot = self.totals[t:t + 1]
         P = be.ptr
+        rows = int(be.c.gmx_program_grid(prog.comp.handle, n))        # block maxima the site program writes
+        pmax = self.partials[0, :rows]
         return {
-            "prog": prog.comp, "vm": vm, "m": m, "recv": cur[n:], "keep": (kk, tot, leaves),
-            "max": (P(self.partials), int(be.c.gmx_program_grid(prog.comp.handle, n)), P(m)),
-            "cdf": (P(self.lw), n, self.shift, None, 0, P(m), P(self.cdf), P(self.total_d), P(self.ws)),
-            "plan": (self.kind, kk, P(self.totals_all), g, W, n, P(self.plan), P(tot)),
-            "route": (self.kind, kk, P(self.plan), P(self.cdf), g, W, n, C, P(cur), P(self.send), P(self.idx)),
+            "prog": prog.comp, "vm": vm, "pmax": pmax, "recv": cur[n:], "keep": (kk, tot, leaves, m),
+            # the CDF kernel reduces the (all-reduced) block maxima itself and records the max in maxs[t]
+            "cdf": (P(self.lw), n, self.shift, P(pmax), rows, P(m), P(self.cdf), P(self.total_d), P(self.ws)),
+            "step": (self.kind, kk, P(self.totals_all), P(self.plan), P(tot), P(self.cdf), g, W, n, C, P(cur),
+                     P(self.send), P(self.idx)),
         }
 
     def _step(self, t):
@@ -166,16 +168,14 @@ class ShardedBootstrapSweep:
             b = self._bound[t] = self._bind_step(t)
         c, st = be.c, be.stream()
         b["prog"].launch(b["vm"])                                      # x_t, lw_t, block maxima
-        be.check(c.gmx_reduce_max(*b["max"], st), "gmx_reduce_max")    # local max ...
         if self.comm:
-            self.cx.all_reduce_max(b["m"])                               # ... -> global max (4 bytes)
-        be.check(c.gmx_weight_cdf(*b["cdf"], st), "gmx_weight_cdf")    # local integer CDF vs the global max
+            self.cx.all_reduce_max(b["pmax"])                            # element-wise MAX of the block maxima (<= 4 KB)
+        be.check(c.gmx_weight_cdf(*b["cdf"], st), "gmx_weight_cdf")    # global max + local integer CDF against it
         if self.comm:
             self.cx.all_gather(self.totals_all, self.total_d)            # 8 bytes per rank
         else:
             self.totals_all.copy_(self.total_d)
-        be.check(c.gmx_shard_plan(*b["plan"], st), "gmx_shard_plan")   # slot boundaries, on the device
-        be.check(c.gmx_shard_route(*b["route"], st), "gmx_shard_route")
+        be.check(c.gmx_shard_step(*b["step"], st), "gmx_shard_step")   # slot boundaries + routing, one launch
         if self.comm:
             self.cx.all_to_all(b["recv"], self.send)                     # block s of recv <- block `me` of rank s
 

@@ -234,6 +234,12 @@ int gmx_shard_route(int kind, const uint32_t key[2], int64_t* plan_d, const uint
                     int world, int64_t n_per_rank, int64_t capacity, const void* state_d /* [n] */,
                     void* send_d /* [world*capacity] */, int32_t* next_idx_d /* [n] */,
                     gmx_stream stream);
+/* gmx_shard_plan + gmx_shard_route as ONE launch (every block derives the boundaries itself);
+ * plan_d still receives total / offset / bounds, and keeps its sticky overflow word. */
+int gmx_shard_step(int kind, const uint32_t key[2], const uint64_t* totals_d /* [world] */, int64_t* plan_d,
+                   uint64_t* total_out_d /* [1] or NULL */, const uint64_t* cdf_d, int rank, int world,
+                   int64_t n_per_rank, int64_t capacity, const void* state_d, void* send_d,
+                   int32_t* next_idx_d, gmx_stream stream);
 
 /* ------------------------------------------------------------------------
  * MH accept + select.  Replaces the user idiom

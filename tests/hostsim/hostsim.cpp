@@ -258,6 +258,14 @@ extern "C" int gmx_shard_route(int kind, const uint32_t key[2], int64_t* plan, c
   }
   return 0;
 }
+extern "C" int gmx_shard_step(int kind, const uint32_t key[2], const uint64_t* totals, int64_t* plan, uint64_t* total_out,
+                              const uint64_t* cdf, int rank, int world, int64_t n, int64_t cap, const void* state,
+                              void* send, int32_t* next_idx, gmx_stream st) {
+  int64_t flag = plan[GMX_PLAN_OVERFLOW];
+  if (gmx_shard_plan(kind, key, totals, rank, world, n, plan, total_out, st)) return 1;
+  plan[GMX_PLAN_OVERFLOW] = flag;
+  return gmx_shard_route(kind, key, plan, cdf, rank, world, n, cap, state, send, next_idx, st);
+}
 extern "C" int gmx_gather(const void* const* src, void* const* dst, const int32_t* bytes, int32_t n_leaves,
                           const int32_t* anc, int64_t n_out, gmx_stream) {
   for (int32_t l = 0; l < n_leaves; ++l)

@@ -186,7 +186,7 @@ def check_plates(n=257, seed=4):
 # shard; the all-to-all is a block copy.  Result must equal the oracle's
 # single-population resample, for any world size and capacity >= need.
 # ---------------------------------------------------------------------------
-def check_shard_route(n=1000, world=4, capacity=None, kind=None, seed=0, skew=0.0, dead=False):
+def check_shard_route(n=1000, world=4, capacity=None, kind=None, seed=0, skew=0.0, dead=False, fused=False):
     from ctypes import c_uint32
     from genjax_amd import _lib
     be = _lib.get()
@@ -223,14 +223,18 @@ def check_shard_route(n=1000, world=4, capacity=None, kind=None, seed=0, skew=0.
     for r in range(world):
         plan = torch.zeros((int(be.c.gmx_shard_plan_words(world)),), dtype=torch.int64, device=dev)
         tot = torch.zeros((1,), dtype=torch.int64, device=dev)
-        be.check(be.c.gmx_shard_plan(kind, kk, be.ptr(totals), r, world, n, be.ptr(plan), be.ptr(tot), be.stream()),
-                 "gmx_shard_plan")
         xe = torch.zeros((n + world * C,), dtype=torch.float32, device=dev)
         xe[:n] = T(x[r * n:(r + 1) * n])
         send = torch.full((world * C,), float("nan"), dtype=torch.float32, device=dev)
         idx = torch.full((n,), -1, dtype=torch.int32, device=dev)
-        be.check(be.c.gmx_shard_route(kind, kk, be.ptr(plan), be.ptr(cdfs[r]), r, world, n, C, be.ptr(xe), be.ptr(send),
-                                      be.ptr(idx), be.stream()), "gmx_shard_route")
+        if fused:       # gmx_shard_step: plan + route in one launch
+            be.check(be.c.gmx_shard_step(kind, kk, be.ptr(totals), be.ptr(plan), be.ptr(tot), be.ptr(cdfs[r]), r, world,
+                                         n, C, be.ptr(xe), be.ptr(send), be.ptr(idx), be.stream()), "gmx_shard_step")
+        else:
+            be.check(be.c.gmx_shard_plan(kind, kk, be.ptr(totals), r, world, n, be.ptr(plan), be.ptr(tot), be.stream()),
+                     "gmx_shard_plan")
+            be.check(be.c.gmx_shard_route(kind, kk, be.ptr(plan), be.ptr(cdfs[r]), r, world, n, C, be.ptr(xe),
+                                          be.ptr(send), be.ptr(idx), be.stream()), "gmx_shard_route")
         plans.append(plan); sends.append(send); idxs.append(idx); xexts.append(xe)
     overflow = any(int(p[2].item()) for p in plans)
     if not dead:

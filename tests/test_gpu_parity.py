@@ -356,11 +356,13 @@ def test_plates_match_oracle(gpu, n):
     (1000, 4, {}), (4096, 8, {"kind": 1, "seed": 3}), (777, 3, {"skew": 2.0, "seed": 1}),
     (500, 8, {"skew": -3.0, "seed": 2}), (64, 2, {"dead": True}), (100_000, 8, {"seed": 5}),
     (100_000, 8, {"seed": 6, "capacity": 12_500}), (250_000, 2, {"seed": 7, "skew": 0.5}),
+    (100_003, 5, {"seed": 8}), (1001, 4, {"seed": 9, "kind": 1}),
 ])
-def test_global_resampling_routes_match_oracle(gpu, n, world, kw):
-    """gmx_shard_plan / gmx_shard_route with every rank emulated on one GPU == the oracle's
-    single-population resample (bit-exact ancestors => bit-exact states)."""
-    res = parity.check_shard_route(n, world, **kw)
+@pytest.mark.parametrize("fused", [False, True])
+def test_global_resampling_routes_match_oracle(gpu, n, world, kw, fused):
+    """gmx_shard_plan + gmx_shard_route, and their one-launch form gmx_shard_step, with every rank
+    emulated on one GPU == the oracle's single-population resample (bit-exact ancestors => states)."""
+    res = parity.check_shard_route(n, world, fused=fused, **kw)
     assert not res["overflow"]
 
 

@@ -524,6 +524,8 @@ def test_global_resampling_routes_match_oracle():
     assert not parity.check_shard_route(500, 8, skew=-3.0, seed=2)["overflow"]
     assert not parity.check_shard_route(64, 2, dead=True)["overflow"]          # no mass anywhere
     assert not parity.check_shard_route(1000, 1)["overflow"]
+    assert not parity.check_shard_route(1001, 4, fused=True, seed=4)["overflow"]
+    assert parity.check_shard_route(777, 3, skew=2.0, seed=1, capacity=5, fused=True)["overflow"]
 
 
 def test_conditional_smc_and_proposals():

@@ -95,6 +95,13 @@ def main():
     ap.add_argument("--sharded", action="store_true", help="use the multi-GPU code path even at world size 1")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line, the JSON: everything else that writes to fd 1 (the RCCL
+    # banner librccl prints on communicator creation, library chatter) is sent to stderr
+    import ctypes
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -263,11 +270,20 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(n, T, ys, seed)
             except Exception as e:                              # report, never fail the GPU number
                 out["cpu_baseline"] = {"error": repr(e)}
-    if rank == 0:
-        print(json.dumps(out))
     if dist is not None:
         dist.barrier()           # rank 0's kernel timing is done before anyone tears the communicator down
+        if getattr(sw, "cx", None) is not None and hasattr(sw.cx, "destroy"):
+            torch.cuda.synchronize()
+            sw.cx.destroy()
         dist.destroy_process_group()
+    sys.stdout.flush()
+    try:
+        ctypes.CDLL(None).fflush(None)       # C stdio buffers (the banner) go where fd 1 points NOW: stderr
+    except Exception:
+        pass
+    os.dup2(real_stdout, 1)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -604,7 +604,9 @@ extern "C" int gmx_logsumexp(const float* lw_d, int64_t rows, int64_t cols, floa
 // program's OP_REDMAX left behind (no extra launch), and the workspace is
 // returned zeroed by the last tile to finish (no memset launch).
 // ---------------------------------------------------------------------------
+#ifndef CDF_THREADS
 #define CDF_THREADS 1024               /* 16 waves: 4 per SIMD, enough to hide the load + look-back latency */
+#endif
 #define CDF_WAVES (CDF_THREADS / GMX_WAVE)
 #define CDF_VEC 4                      /* consecutive items per thread (one float4) */
 #define CDF_TILE (CDF_THREADS * CDF_VEC)

@@ -275,7 +275,7 @@ class Scan(GenerativeFunction):
     def trace_call(self, ctx, mode, key, args, constraint, prev, req, req_leaves, addr):
         from .static import _CallRec, _SiteRec, _rec_score, _store_site, call_gen_fn
         if mode not in ("simulate", "generate", "assess"):
-            raise NotImplementedError("Scan edits (IndexRequest, scan.py:325-416): SURVEY.md §8(f) item 1 (next tier)")
+            return self._trace_edit(ctx, mode, key, args, constraint, prev, req, req_leaves, addr)
         if len(args) != 2:
             raise TypeError("scan: arguments are (carry, scanned_in)")
         carry, scanned_in = args
@@ -323,6 +323,70 @@ class Scan(GenerativeFunction):
         if mode in ("simulate", "assess"):
             return out, retval, None, score
         return out, retval, weight, None
+
+    def _trace_edit(self, ctx, mode, key, args, constraint, prev, req, req_leaves, addr):
+        """Scan.edit (scan.py:596-625): `Update(constraint)` (edit_update :509-594) and
+        `Regenerate(selection)` (edit_regenerate :417-507) re-run every step with the chained key
+        fold_in(key, t), the step's slice of the previous trace and the carry of the edited
+        predecessor; weights and scores are summed over the steps.  `IndexRequest` on a scan
+        (edit_index :325-416) is not supported."""
+        from .core.generative import NotSupportedEditRequest
+        from .static import _CallRec, _ReqSpec, _rec_score, _store_site, call_gen_fn
+        kind = req.kind if req is not None else "empty"
+        if prev is None or "vmap" not in prev:
+            raise NotImplementedError("editing a scan of bare distributions")
+        if mode == "regen" or kind == "regen":
+            sub_mode = "regen"
+        elif mode == "update" or kind in ("update", "empty"):
+            sub_mode = "update"
+        else:
+            raise NotSupportedEditRequest(f"Scan.edit answers Update and Regenerate here (got {kind!r})")
+        carry, scanned_in = args
+        n = self._length(scanned_in)
+        inner_prev = prev["vmap"]
+        g = ctx.tr.graph
+        keep = ctx.store_sites
+        ctx.store_sites = False
+        carry_over = _ReqSpec("update", tree=None, constraint=ChoiceMap.empty())
+        recs, outs = [], []
+        weight = Expr(g.const_f32(0.0))
+        score = Expr(g.const_f32(0.0))
+        for t in range(n):
+            if key is not None:
+                key = Expr(g.add("KDERIVE", (key.node,), imm=t, dtype="key"))
+            prev_t = _index_prev(inner_prev, t)
+            if sub_mode == "regen":
+                rec, ret, w, _ = call_gen_fn(ctx, "regen", self.kernel_gen_fn, key, (carry, _tree_take(scanned_in, t)),
+                                             ChoiceMap.empty(), prev_t, req, req_leaves, addr)
+            else:
+                rec, ret, w, _ = call_gen_fn(ctx, "update", self.kernel_gen_fn, key, (carry, _tree_take(scanned_in, t)),
+                                             _index_chm(constraint, t, n), prev_t,
+                                             req if kind == "update" else carry_over, req_leaves, addr)
+            carry, y_t = ret
+            recs.append(rec)
+            outs.append(y_t)
+            if keep:
+                for r in _leaves(rec):
+                    ctx.tr.prestore(r.value)
+                    ctx.tr.prestore(r.score)
+                    ctx.tr.prestore(r.discard)
+            if w is not None:
+                weight = weight + w
+            score = score + _rec_score(rec)
+        ctx.store_sites = keep
+        merged = _merge(recs, self.kernel_gen_fn)
+        out = _CallRec(self)
+        out.sites = merged.sites
+        out.retval = (carry, _stack(outs))
+        out.plate_score = score
+        if keep:
+            for r in _leaves(out):
+                _store_site(ctx, r)
+        return out, out.retval, weight, None
+
+    def edit(self, key, trace, edit_request, argdiffs):
+        from .static import run_edit
+        return run_edit(self, key, trace, edit_request, argdiffs)
 
     @property
     def gen_fn(self):          # what static._build_trace names the inner function of a plate-like trace

@@ -1088,6 +1088,33 @@ def vmap_edit_index(vm: "Vmap", k, trace: "VmapTrace", idx: int, edit, args_at_i
     return VmapTrace(vm, new_inner, vm._plate_sum(new_inner.get_score(), batch), new_inner.get_retval()), w
 
 
+def scan_edit(sc: "Scan", k, trace: "VmapTrace", args, update: ChoiceMap = None, regenerate=None):
+    """Scan.edit_update / edit_regenerate (scan.py:417-594): every step is edited with the chained key
+    fold_in(key, t), its slice of the trace and the edited predecessor's carry; weights summed."""
+    carry, xs = args
+    n = sc._n(xs)
+    batch = np.asarray(k).shape[:-1]
+    slices, outs = [], []
+    weight = np.zeros(batch, np.float32)
+    score = np.zeros(batch, np.float32)
+    for t in range(n):
+        k = fold_in(k, t)
+        sl = _slice_last(trace.inner, t)
+        a = (carry, Scan._x(xs, t))
+        if regenerate is not None:
+            new, w, _ = sc.kernel.regenerate(k, sl, regenerate, a)
+        else:
+            sub = update.map_values(lambda v: np.asarray(v)[..., t])
+            new, w, _ = sc.kernel.update(k, sl, sub, a)
+        carry, y = new.get_retval()
+        slices.append(new)
+        outs.append(y)
+        weight = (weight + np.broadcast_to(np.asarray(w, np.float32), batch)).astype(np.float32)
+        score = (score + np.broadcast_to(np.asarray(new.get_score(), np.float32), batch)).astype(np.float32)
+    ys = None if outs[0] is None else np.stack([np.broadcast_to(np.asarray(o), batch) for o in outs], axis=-1)
+    return VmapTrace(sc, _stack_last(slices), score, (carry, ys)), weight
+
+
 class Repeat(Vmap):
     """repeat.py:28-42: n runs on the same arguments, keys split(key, n)."""
 

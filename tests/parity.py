@@ -406,6 +406,24 @@ def check_scan(n=257, T=6, seed=5):
     assert np.all(y3[:, 2] == np.float32(0.25)) and not np.all(y3[:, 1] == np.float32(0.25))
     x3 = tr3.get_choices()["steps", "x"].cpu().numpy()[:, 2]
     assert np.array_equal(w3.cpu().numpy(), O.normal.assess(O.C.choice(np.full(n, 0.25, np.float32)), (x3, np.float32(1.0)), (n,))[0])
+    # edits through a scan (scan.py:417-594): Update of every step's observation, then Regenerate of the
+    # latent path — chained keys, carries threaded through the edited predecessors
+    from genjax_amd import Diff, Regenerate, SelectionBuilder as S, Update
+    dev = G._lib.get().device
+    sc5, osc5 = step.scan(n=T), O.Scan(ostep, T)
+    a5 = (torch.zeros(n, device=dev), jnp.zeros(T))
+    oa5 = (np.zeros(n, np.float32), np.zeros(T, np.float32))
+    t5, ot5 = sc5.simulate(G.split(G.key(seed + 3), n), a5), osc5.simulate(O.split(O.key(seed + 3), n), oa5)
+    u5, w5, _, bwd5 = Update(C["y"].set(ys)).edit(G.split(G.key(seed + 4), n), t5, Diff.no_change(a5))
+    ou5, ow5 = O.scan_edit(osc5, O.split(O.key(seed + 4), n), ot5, oa5, update=O.C.d({"y": ys}))
+    assert np.array_equal(w5.cpu().numpy(), ow5)
+    assert np.array_equal(u5.get_score().cpu().numpy(), ou5.get_score())
+    assert np.array_equal(bwd5.constraint["y"].cpu().numpy(), ot5.get_choices()["y"])          # discard = old values
+    r5, wr5, _, _ = Regenerate(S["x"]).edit(G.split(G.key(seed + 5), n), u5, Diff.no_change(a5))
+    or5, owr5 = O.scan_edit(osc5, O.split(O.key(seed + 5), n), ou5, oa5, regenerate=O.selection("x"))
+    assert np.array_equal(r5.get_choices()["x"].cpu().numpy(), or5.get_choices()["x"])
+    assert np.array_equal(wr5.cpu().numpy(), owr5)
+    assert np.array_equal(r5.get_score().cpu().numpy(), or5.get_score())
     # a Scan used directly: the chain starts at the caller's key
     sc = step.scan(n=3)
     t4 = sc.simulate(G.split(G.key(seed + 2), 16), (torch.zeros(16, device=G._lib.get().device), jnp.zeros(3)))

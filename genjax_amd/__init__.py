@@ -11,7 +11,7 @@ from .core.generative import (Diff, DiffAnnotate, EditRequest, EmptyRequest, Gen
                               GenerativeFunctionClosure, IndexRequest, NoChange, NotSupportedEditRequest, Regenerate,
                               Trace, UnknownChange, Update)
 from .core.mask import Mask
-from .distributions import (Distribution, bernoulli, beta, categorical, flip, normal, uniform)
+from .distributions import (Distribution, bernoulli, beta, categorical, dirichlet, flip, normal, uniform)
 from .static import (AddressReuse, MissingAddress, Rejuvenate, StaticGenerativeFunction, StaticRequest,
                      StaticTrace, gen, trace)
 from . import inference
@@ -28,7 +28,7 @@ __all__ = [
     "numpy", "random", "inference", "ChoiceMap", "ChoiceMapBuilder", "Selection", "SelectionBuilder",
     "ChoiceMapNoValueAtAddress", "Diff", "DiffAnnotate", "EditRequest", "EmptyRequest",
     "GenerativeFunction", "GenerativeFunctionClosure", "NoChange", "UnknownChange", "Regenerate",
-    "Trace", "Update", "Mask", "Distribution", "ExactDensity", "bernoulli", "beta", "categorical",
+    "Trace", "Update", "Mask", "Distribution", "ExactDensity", "bernoulli", "beta", "categorical", "dirichlet",
     "flip", "normal", "uniform", "AddressReuse", "MissingAddress", "Rejuvenate",
     "StaticGenerativeFunction", "StaticRequest", "StaticTrace", "gen", "trace", "Target", "jit",
     "vmap", "key", "split", "fold_in", "NotSupportedEditRequest", "Vmap", "repeat", "Scan", "scan", "IndexRequest",

@@ -181,7 +181,7 @@ static int parse_program(const uint32_t* blob, size_t n_words, gmx_program& P) {
       case OP_SEL: ok = D(dst) && R(a) && R(b) && R(c); break;
       case OP_S_NORMAL: case OP_S_UNIFORM: case OP_S_BETA:
         ok = D(dst) && R(a) && R(b) && R2(c); break;
-      case OP_S_FLIP: case OP_S_BERNL: ok = D(dst) && R(a) && R2(c); break;
+      case OP_S_FLIP: case OP_S_BERNL: case OP_S_LOGGAMMA: ok = D(dst) && R(a) && R2(c); break;
       case OP_S_CATSTEP: ok = R2(dst) && R(a) && R(b) && R2(c); break;
       case OP_L_NORMAL: case OP_L_UNIFORM: case OP_L_BETA:
         ok = D(dst) && R(a) && R(b) && R(c); break;

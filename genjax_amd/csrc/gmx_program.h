@@ -71,6 +71,7 @@ enum gmx_op {
   OP_S_FLIP = 72,     // a = p            -> i32
   OP_S_BERNL = 73,    // a = logits       -> i32
   OP_S_BETA = 74,     // a = c1, b = c0
+  OP_S_LOGGAMMA = 76, // a = concentration; log of a Gamma(a, 1) draw from key split_child(r[c..c+1], e) (Dirichlet)
   OP_S_CATSTEP = 75,  // state (r[dst] best f32, r[dst+1] idx i32); a = logit; b = ctr reg (i32); key c; category e
   // log-densities: value x = r[c]
   OP_L_NORMAL = 80, OP_L_UNIFORM = 81, OP_L_FLIP = 82, OP_L_BERNL = 83, OP_L_BETA = 84,

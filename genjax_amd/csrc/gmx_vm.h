@@ -192,6 +192,7 @@ GMX_HD void gmx_vm_step(Regs& R, const W w, int64_t i, bool active, const gmx_ru
             case OP_SOFTPLUS: r0 = gmx_asu(gmx_softplusf(FSRC(a))); break;
             case OP_LGAMMA: r0 = gmx_asu(gmx_lgammaf(FSRC(a))); break;
             case OP_S_BETA: { KEY(c); r0 = gmx_asu(gmx_beta_sample(k, e, FSRC(a), FSRC(b))); } break;
+            case OP_S_LOGGAMMA: { KEY(c); r0 = gmx_asu(gmx_log_gamma_sample(gmx_split_child(k, e), FSRC(a))); } break;
             case OP_S_CATSTEP: {
               KEY(c);
               gmx_cat_state s; s.best = gmx_asf(R.get(dst)); s.idx = (int)R.get(dst + 1u);
@@ -227,5 +228,5 @@ GMX_HD void gmx_vm_run(uint32_t n_instr_rt, int64_t i, bool active, const gmx_ru
 // ops that need the FULL interpreter build
 GMX_HD bool gmx_op_needs_full(uint32_t op) {
   return op == OP_POW || op == OP_SIN || op == OP_COS || op == OP_TANH || op == OP_SOFTPLUS ||
-         op == OP_LGAMMA || op == OP_S_BETA || op == OP_S_CATSTEP || op == OP_L_BETA;
+         op == OP_LGAMMA || op == OP_S_BETA || op == OP_S_CATSTEP || op == OP_L_BETA || op == OP_S_LOGGAMMA;
 }

@@ -257,9 +257,45 @@ class _Categorical(Distribution):
         return picked - lse
 
 
+class _Dirichlet(Distribution):
+    """Dirichlet(concentration) over the LAST axis (tfp/__init__.py:125).  TFP draws log-space Gammas and
+    normalises: x = exp(lg - logsumexp(lg)); log_prob = sum xlogy(a - 1, x) - lbeta(a).  The Gamma
+    stream is the build's (element k draws from split(site key)[k]; PARITY UNPINNED, as for Beta)."""
+    name = "dirichlet"
+    param_names = ("concentration",)
+
+    def _conc(self, args):
+        a = args[0]
+        a = a if isinstance(a, np.ndarray) else np.asarray(a, dtype=object)
+        if a.ndim != 1:
+            raise NotImplementedError("dirichlet: concentration must be a vector per particle")
+        return [T.as_float(x) for x in a]
+
+    def sym_sample(self, key: Expr, args: tuple):
+        from . import numpy as jnp
+        g = current_graph()
+        lg = np.empty(len(self._conc(args)), dtype=object)
+        for k, ak in enumerate(self._conc(args)):
+            lg[k] = Expr(g.add("S_LOGGAMMA", (key.node, ak.node), imm=k, dtype="f32"))
+        return jnp.exp(lg - jnp.logsumexp(lg))
+
+    def sym_logpdf(self, v, args: tuple) -> Expr:
+        from . import numpy as jnp
+        al = self._conc(args)
+        x = v if isinstance(v, np.ndarray) else np.asarray(v, dtype=object)
+        terms = []
+        for ak, xk in zip(al, x.reshape(-1)):
+            am = ak - 1.0
+            terms.append(T.where(am == 0.0, 0.0, am * jnp.log(T.as_float(xk))))      # xlogy(a - 1, x)
+        lg = [jnp.lgamma(ak) for ak in al]
+        lbeta = _seq_sum(lg) - jnp.lgamma(_seq_sum(al))
+        return _seq_sum(terms) - lbeta
+
+
 normal = _Normal()
 uniform = _Uniform()
 beta = _Beta()
 flip = _Flip()
 bernoulli = _Bernoulli()
 categorical = _Categorical()
+dirichlet = _Dirichlet()

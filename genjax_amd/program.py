@@ -32,7 +32,7 @@ OPC = dict(
     IEQ=46, INE=47, ILT=48, ILE=49, IGT=50, IGE=51,
     AND=52, OR=53, NOT=54, XOR=55, SEL=56, I2F=57, F2I=58,
     IADD=60, ISUB=61, IMUL=62, INEG=63,
-    S_NORMAL=70, S_UNIFORM=71, S_FLIP=72, S_BERNL=73, S_BETA=74, S_CATSTEP=75,
+    S_NORMAL=70, S_UNIFORM=71, S_FLIP=72, S_BERNL=73, S_BETA=74, S_CATSTEP=75, S_LOGGAMMA=76,
     L_NORMAL=80, L_UNIFORM=81, L_FLIP=82, L_BERNL=83, L_BETA=84,
     REDMAX=90, REDLSE=91,
 )
@@ -42,7 +42,7 @@ UNARY = {"MOV", "NEG", "ABS", "EXP", "LOG", "LOG1P", "SQRT", "SIN", "COS", "TANH
 BINARY = {"ADD", "SUB", "MUL", "DIV", "MIN", "MAX", "POW", "FLT", "FLE", "FGT", "FGE", "FEQ", "FNE",
           "IEQ", "INE", "ILT", "ILE", "IGT", "IGE", "AND", "OR", "XOR", "IADD", "ISUB", "IMUL"}
 SAMPLER2 = {"S_NORMAL", "S_UNIFORM", "S_BETA"}      # args (key, a, b), imm = element counter
-SAMPLER1 = {"S_FLIP", "S_BERNL"}                    # args (key, a)
+SAMPLER1 = {"S_FLIP", "S_BERNL", "S_LOGGAMMA"}                    # args (key, a)
 LOGPDF2 = {"L_NORMAL", "L_UNIFORM", "L_BETA"}       # args (x, a, b)
 LOGPDF1 = {"L_FLIP", "L_BERNL"}                     # args (x, a)
 EFFECT = {"STOUT", "REDMAX", "REDLSE"}

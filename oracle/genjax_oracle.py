@@ -616,12 +616,61 @@ class _Categorical(Distribution):
         return self._logpdf(v, args)
 
 
+class _Dirichlet(Distribution):
+    """genjax.dirichlet (tfp/__init__.py:125): x = exp(lg - logsumexp(lg)) with lg_k = log Gamma(a_k)
+    from key split(site key)[k]; log_prob = sum xlogy(a - 1, x) - (sum lgamma(a) - lgamma(sum a)).
+    Event = the last axis."""
+    name = "dirichlet"
+
+    def _sample(self, keys, args):
+        keys = np.asarray(keys, dtype=np.uint32)
+        batch = keys.shape[:-1]
+        conc = np.asarray(args[0], np.float32)
+        K = conc.shape[-1]
+        cb = np.ascontiguousarray(np.broadcast_to(conc, batch + (K,))).reshape(-1, K)
+        n = cb.shape[0]
+        kb = np.ascontiguousarray(np.broadcast_to(keys, batch + (2,))).reshape(n, 2)
+        lg = np.empty((n, K), dtype=np.float32)
+        for c in range(K):
+            col = np.ascontiguousarray(cb[:, c])
+            out = np.empty(n, dtype=np.float32)
+            lib().orc_loggamma_sample(I64(n), _p(kb), I64(1), ctypes.c_uint64(c), _p(col), I64(1), _p(out))
+            lg[:, c] = out
+        x = exp((lg - logsumexp(lg)[:, None]).astype(np.float32))
+        return x.reshape(batch + (K,))
+
+    def _logpdf(self, v, args, batch_ndim=None):
+        conc = np.asarray(args[0], np.float32)
+        v = np.asarray(v, np.float32)
+        shape = np.broadcast_shapes(v.shape, conc.shape)
+        a = np.broadcast_to(conc, shape)
+        x = np.broadcast_to(v, shape)
+        K = shape[-1]
+        acc = None
+        for c in range(K):
+            am = (a[..., c] - np.float32(1.0)).astype(np.float32)
+            t = np.where(am == 0, np.float32(0.0), (am * log(x[..., c])).astype(np.float32)).astype(np.float32)
+            acc = t if acc is None else (acc + t).astype(np.float32)
+        lg = None
+        sa = None
+        for c in range(K):
+            l = lgamma(a[..., c])
+            lg = l if lg is None else (lg + l).astype(np.float32)
+            sa = a[..., c] if sa is None else (sa + a[..., c]).astype(np.float32)
+        lbeta = (lg - lgamma(sa)).astype(np.float32)
+        return (acc - lbeta).astype(np.float32)
+
+    def estimate_logpdf(self, v, args, batch_shape):
+        return self._logpdf(v, args)
+
+
 normal = _Normal()
 uniform = _Uniform()
 beta = _Beta()
 flip = _Flip()
 bernoulli = _BernoulliLogits()
 categorical = _Categorical()
+dirichlet = _Dirichlet()
 
 
 def logsumexp(a, axis=-1):

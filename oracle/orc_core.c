@@ -448,6 +448,16 @@ static float log_gamma_draw(const uint32_t* k, float alpha) {
   }
   return res + boost;
 }
+/* log of a Gamma(alpha, 1) draw from key split(key)[elem] (the Dirichlet element stream; build-defined) */
+void orc_loggamma_sample(int64_t n, const uint32_t* keys, int64_t ks, uint64_t elem, const float* alpha,
+                         int64_t as, float* out) {
+  for (int64_t i = 0; i < n; ++i) {
+    const uint32_t* k = keys + 2 * i * ks;
+    uint32_t ke[2];
+    threefry(k[0], k[1], 0u, (uint32_t)elem, &ke[0], &ke[1]);
+    out[i] = log_gamma_draw(ke, alpha[i * as]);
+  }
+}
 void orc_beta_sample(int64_t n, const uint32_t* keys, int64_t ks, uint64_t elem, const float* c1,
                      int64_t s1, const float* c0, int64_t s0, float* out) {
   for (int64_t i = 0; i < n; ++i) {

@@ -622,3 +622,33 @@ def check_nlssm_mh_sweep(n=2000, T=5, seed=7, capture=False, specialize=False):
     terms.append(M + math.log(total) - shift * math.log(2.0) - math.log(n))
     assert abs(sw.log_ml() - sum(terms)) < 1e-9 * max(1.0, abs(sum(terms)))
     return {"accept_rate": float(oacc.mean()), "log_ml": sw.log_ml()}
+
+
+# ---------------------------------------------------------------------------
+# dirichlet (tfp/__init__.py:125; used by the mixture model's weights)
+# ---------------------------------------------------------------------------
+def check_dirichlet(n=2000, seed=1):
+    import genjax_amd as G
+    from genjax_amd import numpy as jnp
+    al = np.array([0.5, 2.0, 3.5, 1.0], np.float32)
+
+    def mk(g, arr):
+        @g.gen
+        def m(scale):
+            return g.dirichlet(arr(al) * scale) @ "probs"
+        return m
+    m, om = mk(G, jnp.array), mk(O, lambda a: np.asarray(a, np.float32))
+    tr, otr = m.simulate(G.split(G.key(seed), n), (1.0,)), om.simulate(O.split(O.key(seed), n), (np.float32(1.0),))
+    p = tr.get_choices()["probs"].cpu().numpy()
+    assert p.shape == (n, 4) and np.array_equal(p, otr.get_choices()["probs"])
+    assert np.array_equal(tr.get_score().cpu().numpy(), otr.get_score())
+    assert np.abs(p.sum(1) - 1).max() < 1e-6
+    assert np.abs(p.mean(0) - al / al.sum()).max() < 4 * np.sqrt(0.25 / n)            # moments of Dir(a)
+    from scipy.stats import dirichlet as sd
+    ref = np.array([sd.logpdf(p[i].astype(np.float64) / p[i].astype(np.float64).sum(), al) for i in range(64)])
+    assert np.abs(tr.get_score().cpu().numpy()[:64] - ref).max() < 2e-5
+    s, _ = m.assess(tr.get_choices(), (1.0,), batch_shape=(n,))
+    assert np.array_equal(s.cpu().numpy(), tr.get_score().cpu().numpy())
+    # importance with the value constrained: w = log density
+    tr2, w2 = m.importance(G.split(G.key(seed + 1), n), G.ChoiceMap.kw(probs=tr.get_choices()["probs"]), (1.0,))
+    assert np.array_equal(w2.cpu().numpy(), s.cpu().numpy())

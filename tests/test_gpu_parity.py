@@ -425,6 +425,10 @@ def test_nonlinear_ssm_mh_sweep_matches_oracle(gpu, n, capture, specialize):
     parity.check_nlssm_mh_sweep(n=n, T=5, capture=capture, specialize=specialize)
 
 
+def test_dirichlet_matches_oracle_and_scipy(gpu):
+    parity.check_dirichlet(n=50_000)
+
+
 def test_full_size_sweep_properties(gpu):
     """BASELINE config 2 at full size (1e6 particles, T = 100): size-independent
     properties — sorted ancestors, determinism, and log-ML within Monte-Carlo

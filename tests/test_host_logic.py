@@ -611,6 +611,11 @@ def test_autodiff_rules_against_finite_differences():
         assert np.max(np.abs(gb.numpy() - fb) / (1 + np.abs(fb))) < 2e-5, name
 
 
+def test_dirichlet_matches_oracle_and_scipy():
+    from tests import parity
+    parity.check_dirichlet(n=2000)
+
+
 def test_program_limits():
     """<= 64 live 32-bit values per particle (<= 32 for the interpreter, up to 64 for specialised
     kernels); a model that needs more fails loudly at trace time instead of spilling silently."""

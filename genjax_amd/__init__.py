@@ -10,16 +10,23 @@ from .core.choice_map import (ChoiceMap, ChoiceMapBuilder, ChoiceMapNoValueAtAdd
 from .core.generative import (Diff, DiffAnnotate, EditRequest, EmptyRequest, GenerativeFunction,
                               GenerativeFunctionClosure, IndexRequest, NoChange, NotSupportedEditRequest, Regenerate,
                               Trace, UnknownChange, Update)
+from .core.generative import Argdiffs, Arguments, Retdiff, Score, VectorRequest, Weight
 from .core.mask import Mask
-from .distributions import (Distribution, bernoulli, beta, categorical, dirichlet, flip, normal, uniform)
+from .core.pytree import Closure, Const, PythonicPytree, Pytree, R, nth
+from .distributions import (Distribution, bernoulli, beta, categorical, dirichlet, exact_density, flip, half_cauchy,
+                            half_normal, log_normal, normal, tfp_distribution, uniform)
 from .static import (AddressReuse, MissingAddress, Rejuvenate, StaticGenerativeFunction, StaticRequest,
                      StaticTrace, gen, trace)
 from . import inference
 from .inference import Target
+from .inference.sp import Algorithm, Marginal, marginal
 from .transforms import jit, vmap
 from .combinators import Scan, Vmap, repeat, scan
 
 ExactDensity = Distribution
+SampleDistribution = Distribution          # sp.py:100-103: distributions whose value is a ChoiceMap
+Address = AddressComponent = object        # typing aliases of core/generative (static addresses here)
+trace_p = "trace"                          # the reference's jax primitive; `trace(addr, gen_fn, args)` is the entry
 key = random.key
 split = random.split
 fold_in = random.fold_in
@@ -32,4 +39,7 @@ __all__ = [
     "flip", "normal", "uniform", "AddressReuse", "MissingAddress", "Rejuvenate",
     "StaticGenerativeFunction", "StaticRequest", "StaticTrace", "gen", "trace", "Target", "jit",
     "vmap", "key", "split", "fold_in", "NotSupportedEditRequest", "Vmap", "repeat", "Scan", "scan", "IndexRequest",
+    "VectorRequest", "Argdiffs", "Arguments", "Retdiff", "Score", "Weight", "Address", "AddressComponent", "R",
+    "Closure", "Const", "PythonicPytree", "Pytree", "nth", "exact_density", "tfp_distribution", "half_cauchy",
+    "half_normal", "log_normal", "Algorithm", "SampleDistribution", "Marginal", "marginal", "trace_p",
 ]

@@ -180,6 +180,15 @@ class IndexRequest(EditRequest):
         self.idx, self.request = int(idx), request
 
 
+class VectorRequest(EditRequest):
+    """The backward request a vector combinator's `Regenerate` edit returns (scan.py:504): per-element
+    sub-requests stacked along the leading axis.  Container only."""
+    __match_args__ = ("request",)
+
+    def __init__(self, request):
+        self.request = request
+
+
 class EmptyRequest(EditRequest):
     """requests.py:48-60: no change requested; re-scores only what changed args force."""
 

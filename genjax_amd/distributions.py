@@ -257,6 +257,50 @@ class _Categorical(Distribution):
         return picked - lse
 
 
+class _LogNormal(Distribution):
+    """tfd.LogNormal(loc, scale): exp of a Normal draw; log_prob(x) = Normal.log_prob(log x) - log x."""
+    name = "log_normal"
+    param_names = ("loc", "scale")
+
+    def sym_sample(self, key: Expr, args: tuple):
+        from . import numpy as jnp
+        return jnp.exp(normal.sym_sample(key, args))
+
+    def sym_logpdf(self, v, args: tuple) -> Expr:
+        from . import numpy as jnp
+        elems, _ = _bcast((v,) + tuple(args))
+        terms = []
+        for x, loc, scale in elems:
+            lx = jnp.log(T.as_float(x))
+            terms.append(normal.sym_logpdf(lx, (loc, scale)) - lx)
+        return _seq_sum(terms)
+
+
+class _HalfNormal(Distribution):
+    """tfd.HalfNormal(scale): |z * scale|; log_prob(x) = -0.5 (x/scale)^2 - (log scale + 0.5 log(pi/2)), x >= 0."""
+    name = "half_normal"
+    param_names = ("scale",)
+
+    def sym_sample(self, key: Expr, args: tuple):
+        from . import numpy as jnp
+        scale = args[0]
+        z = normal.sym_sample(key, (scale * 0.0 if isinstance(scale, np.ndarray) else 0.0, 1.0)) \
+            if not isinstance(scale, np.ndarray) else normal.sym_sample(key, (np.full(scale.shape, 0.0, dtype=object), 1.0))
+        return jnp.abs(z * scale)
+
+    def sym_logpdf(self, v, args: tuple) -> Expr:
+        from . import numpy as jnp
+        import math
+        elems, _ = _bcast((v, args[0]))
+        terms = []
+        for x, scale in elems:
+            x, scale = T.as_float(x), T.as_float(scale)
+            r = x / scale
+            lp = (r * r) * -0.5 - (jnp.log(scale) + 0.5 * math.log(math.pi / 2.0))
+            terms.append(T.where(x < 0.0, float("-inf"), lp))
+        return _seq_sum(terms)
+
+
 class _Dirichlet(Distribution):
     """Dirichlet(concentration) over the LAST axis (tfp/__init__.py:125).  TFP draws log-space Gammas and
     normalises: x = exp(lg - logsumexp(lg)); log_prob = sum xlogy(a - 1, x) - lbeta(a).  The Gamma
@@ -292,6 +336,33 @@ class _Dirichlet(Distribution):
         return _seq_sum(terms) - lbeta
 
 
+def exact_density(sample, logpdf, name="exact_density"):
+    """`genjax.exact_density(sampler, logpdf)` (distribution.py:529-560).  Both functions are TRACED into
+    the site program: `logpdf(v, *args)` with genjax_amd.numpy ops, `sample(key, *args)` by composing the
+    symbolic samplers of the built-in distributions (`genjax_amd.normal.sym_sample(key, (loc, scale))`)."""
+    class _Custom(Distribution):
+        def sym_sample(self, key, args):
+            return sample(key, *args)
+
+        def sym_logpdf(self, v, args):
+            return T.as_float(logpdf(v, *args))
+    _Custom.name = name
+    return _Custom()
+
+
+def tfp_distribution(*_a, **_k):
+    raise NotImplementedError("tfp_distribution wraps tensorflow_probability, which this stack does not use; "
+                              "define the distribution with genjax_amd.exact_density")
+
+
+class _HalfCauchy(Distribution):
+    name = "half_cauchy"
+
+    def sym_sample(self, key, args):
+        raise NotImplementedError("half_cauchy: not on the hot path (SURVEY App. C)")
+    sym_logpdf = sym_sample
+
+
 normal = _Normal()
 uniform = _Uniform()
 beta = _Beta()
@@ -299,3 +370,6 @@ flip = _Flip()
 bernoulli = _Bernoulli()
 categorical = _Categorical()
 dirichlet = _Dirichlet()
+log_normal = _LogNormal()
+half_normal = _HalfNormal()
+half_cauchy = _HalfCauchy()

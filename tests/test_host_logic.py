@@ -616,6 +616,49 @@ def test_dirichlet_matches_oracle_and_scipy():
     parity.check_dirichlet(n=2000)
 
 
+def test_api_surface_and_derived_distributions():
+    """SURVEY App. C names exist; log_normal / half_normal (compositions of the Normal sampler) equal the
+    oracle's Normal stream through exp / abs bit for bit, and scipy's densities; Const rides in args."""
+    from scipy import stats
+    for name in ("Address AddressComponent Argdiffs Arguments ChoiceMap ChoiceMapBuilder EditRequest GenerativeFunction "
+                 "GenerativeFunctionClosure Mask R Retdiff Score Selection SelectionBuilder Trace Update Weight DiffAnnotate "
+                 "EmptyRequest Regenerate Closure Const PythonicPytree Pytree nth Diff NoChange UnknownChange gen trace trace_p "
+                 "StaticGenerativeFunction StaticRequest AddressReuse MissingAddress Distribution ExactDensity exact_density "
+                 "tfp_distribution normal beta bernoulli flip categorical uniform dirichlet half_cauchy half_normal log_normal "
+                 "vmap Vmap repeat scan Scan IndexRequest VectorRequest Target Algorithm SampleDistribution Marginal marginal").split():
+        assert hasattr(genjax, name), name
+
+    @genjax.gen
+    def m(k, s):
+        genjax.normal.vmap(in_axes=(0, None))(jnp.zeros(k.unwrap()), s) @ "xs"
+        a = genjax.log_normal(0.25, 0.5) @ "a"
+        h = genjax.half_normal(2.0) @ "h"
+        return a + h
+    n = 4000
+    tr = m.simulate(genjax.split(genjax.key(0), n), (genjax.Const(3), 1.0))
+    ch = tr.get_choices()
+    assert tuple(ch["xs"].shape) == (n, 3)
+    keys = O.split(O.key(0), n)
+    ka, kh = O.fold_in(keys, 2), O.fold_in(keys, 3)                   # sites 2 and 3 of the model
+    assert np.array_equal(ch["a"].numpy(), O.exp(O.normal.sample(ka, np.float32(0.25), np.float32(0.5))))
+    assert np.array_equal(ch["h"].numpy(), np.abs(O.normal.sample(kh, np.float32(0.0), np.float32(1.0)) * np.float32(2.0)))
+    a64, h64 = ch["a"].numpy().astype(np.float64), ch["h"].numpy().astype(np.float64)
+    assert np.abs(tr.get_subtrace("a").get_score().numpy() - stats.lognorm.logpdf(a64, 0.5, scale=np.exp(0.25))).max() < 2e-5
+    assert np.abs(tr.get_subtrace("h").get_score().numpy() - stats.halfnorm.logpdf(h64, scale=2.0)).max() < 2e-5
+    # exact_density: user-defined sampler / density traced into the program
+    mine = genjax.exact_density(lambda key, loc: genjax.normal.sym_sample(key, (loc, 1.0)),
+                                lambda v, loc: -0.5 * jnp.square(v - loc) - 0.9189385, "mynormal")
+
+    @genjax.gen
+    def m2():
+        return mine(1.0) @ "z"
+    t2 = m2.simulate(genjax.split(genjax.key(1), 16), ())
+    z = t2.get_choices()["z"].numpy().astype(np.float64)
+    assert np.abs(t2.get_score().numpy() - stats.norm.logpdf(z, 1.0, 1.0)).max() < 1e-5
+    with pytest.raises(NotImplementedError):
+        genjax.tfp_distribution(None)
+
+
 def test_program_limits():
     """<= 64 live 32-bit values per particle (<= 32 for the interpreter, up to 64 for specialised
     kernels); a model that needs more fails loudly at trace time instead of spilling silently."""

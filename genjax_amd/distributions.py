@@ -207,25 +207,38 @@ class _Categorical(Distribution):
     param_names = ("logits",)
 
     def canon(self, args):
+        shape = None
         if len(args) == 2 and isinstance(args[1], dict) and isinstance(args[0], tuple):
             pos, kw = args
             kw = dict(kw)
-            kw.pop("sample_shape", None)
+            shape = kw.pop("sample_shape", None)
             if "probs" in kw:
                 from . import numpy as jnp
                 p = kw.pop("probs")
                 if T.is_tracing():
                     p = np.asarray([T.lift(x) for x in np.asarray(p, dtype=object).reshape(-1)], dtype=object)
-                    return (jnp.log(p),)
-                return (np.log(np.asarray(p, dtype=np.float32)),)
+                    return self._shaped((jnp.log(p),), shape)
+                return self._shaped((np.log(np.asarray(p, dtype=np.float32)),), shape)
             if "logits" in kw:
-                return (kw.pop("logits"),)
+                return self._shaped((kw.pop("logits"),), shape)
             args = pos
         if len(args) == 1 and not isinstance(args[0], dict):
             warnings.warn("The use of a bare argument to genjax.categorical is deprecated. Please specify "
                           "`logits=` or `probs=`. The default, which will be used in this case, is logits.",
                           DeprecationWarning, stacklevel=3)
-        return tuple(args)
+        return self._shaped(tuple(args), shape)
+
+    @staticmethod
+    def _shaped(args, shape):
+        """`sample_shape=n` (tfp sample_n): n draws from the same logits at ONE site; draw j, category k
+        takes gumbel counter j*K + k.  Unrolled, so only for small n (plates of data belong in
+        inference.gibbs / the particle axis)."""
+        if shape is None or shape == ():
+            return args
+        n = int(shape[0] if isinstance(shape, (tuple, list)) else shape)
+        if n > 64:
+            raise NotImplementedError(f"categorical(sample_shape={n}): draws at one site are unrolled (<= 64)")
+        return args + (("sample_shape", n),)
 
     def _logits(self, args):
         l = args[0]
@@ -236,18 +249,35 @@ class _Categorical(Distribution):
 
     def sym_sample(self, key: Expr, args: tuple):
         g = current_graph()
-        state = None
-        for k, lk in enumerate(self._logits(args)):
-            ctr = g.const_i32(k)
-            state = g.add("S_CATSTEP", (state, key.node, lk.node, ctr), imm=k, dtype="cat")
-        # the index lives in the second register of the state pair
-        idx = g.add("CATIDX", (state,), dtype="i32")
-        return Expr(idx)
+        n = args[1][1] if len(args) == 2 and isinstance(args[1], tuple) and args[1][:1] == ("sample_shape",) else None
+        ls = self._logits(args[:1])
+        out = []
+        for j in range(n or 1):
+            state = None
+            for k, lk in enumerate(ls):
+                ctr = g.const_i32(j * len(ls) + k)
+                state = g.add("S_CATSTEP", (state, key.node, lk.node, ctr), imm=k, dtype="cat")
+            # the index lives in the second register of the state pair
+            out.append(Expr(g.add("CATIDX", (state,), dtype="i32")))
+        if n is None:
+            return out[0]
+        arr = np.empty(n, dtype=object)
+        arr[:] = out
+        return arr
 
     def sym_logpdf(self, v, args: tuple) -> Expr:
         from . import numpy as jnp
-        ls = self._logits(args)
+        ls = self._logits(args[:1])
         lse = jnp.logsumexp(np.asarray(ls, dtype=object))
+        if isinstance(v, np.ndarray):               # sample_shape draws: sum of the per-draw log-probabilities
+            terms = []
+            for vj in v.reshape(-1):
+                vi = T.as_int(vj)
+                picked = ls[0]
+                for k in range(1, len(ls)):
+                    picked = T.where(vi == k, ls[k], picked)
+                terms.append(picked - lse)
+            return _seq_sum(terms)
         if isinstance(v, (int, np.integer)) and not isinstance(v, bool):
             return ls[int(v)] - lse                 # a category fixed at trace time (enumeration)
         vi = T.as_int(v)

@@ -659,6 +659,35 @@ def test_api_surface_and_derived_distributions():
         genjax.tfp_distribution(None)
 
 
+def test_categorical_sample_shape():
+    """`categorical(probs=..., sample_shape=n)` (the mixture notebook's `generate_datapoints`): n draws at one
+    site, draw j / category k on gumbel counter j*K + k; larger n is refused, not silently ignored."""
+    probs = [0.2, 0.5, 0.3]
+
+    @genjax.gen
+    def m():
+        return genjax.categorical(probs=probs, sample_shape=5) @ "idx"
+    n = 2000
+    tr = m.simulate(genjax.split(genjax.key(2), n), ())
+    idx = tr.get_choices()["idx"].numpy()
+    keys = np.ascontiguousarray(O.fold_in(O.split(O.key(2), n), 1))
+    logits = O.log(np.asarray(probs, np.float32))
+    lb = np.ascontiguousarray(np.broadcast_to(logits, (n, 3)))
+    want = np.empty((n, 5), np.int32)
+    for j in range(5):
+        o, ctr = np.empty(n, np.int32), np.full(n, j * 3, np.uint64)
+        O.lib().orc_categorical_sample(O.I64(n), O.I64(3), O._p(keys), O.I64(1), O._p(lb), O.I64(3), O._p(ctr), O.I64(1), O._p(o))
+        want[:, j] = o
+    assert np.array_equal(idx, want)
+    assert np.allclose(tr.get_score().numpy(), (logits[idx] - O.logsumexp(logits)).sum(1), atol=1e-6)
+
+    @genjax.gen
+    def big():
+        return genjax.categorical(probs=probs, sample_shape=5000) @ "idx"
+    with pytest.raises(NotImplementedError):
+        big.simulate(genjax.key(0), ())
+
+
 def test_program_limits():
     """<= 64 live 32-bit values per particle (<= 32 for the interpreter, up to 64 for specialised
     kernels); a model that needs more fails loudly at trace time instead of spilling silently."""

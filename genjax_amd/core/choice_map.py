@@ -20,7 +20,7 @@ def _norm(addr) -> tuple:
             out += _norm(a)
         return out
     if addr is Ellipsis:
-        raise NotImplementedError("`...` addresses are not supported")
+        return ()              # `Selection.at[..., "y"]`: any plate index — plate values carry the axis themselves
     if isinstance(addr, slice):
         if addr == slice(None):
             return ()          # chm["plate", :, "x"]: plate values carry the plate axis themselves

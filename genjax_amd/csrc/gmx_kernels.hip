@@ -248,7 +248,7 @@ static std::string jit_source(const gmx_program* p) {
   s += "__device__ static constexpr uint32_t GMX_JIT_CONST[] = {";
   for (size_t k = 0; k < p->consts.size(); ++k) { snprintf(buf, sizeof(buf), "0x%08xu,", p->consts[k]); s += buf; }
   s += "0u};\n";
-  snprintf(buf, sizeof(buf), "GMX_JIT_BEGIN(%u, %s, %u, %d)\n", p->n_regs <= 16 ? 16u : (p->n_regs <= 32 ? 32u : 64u),
+  snprintf(buf, sizeof(buf), "GMX_JIT_BEGIN(%u, %s, %u, %d)\n", p->n_regs < 16 ? 16u : (p->n_regs < 32 ? 32u : 64u),
            p->needs_full ? "true" : "false", p->n_dyn, jit_pp_for(p));
   s += buf;
   for (uint32_t pc = 0; pc < p->n_instr; ++pc) {
@@ -386,10 +386,14 @@ extern "C" int gmx_program_run(const gmx_program* p, int64_t n, const gmx_run_ar
     GMX_HIP(hipModuleLaunchKernel(p->jit_fn, jgrid, 1, 1, GMX_BLOCK, 1, 1, 0, st, nullptr, config));
     return 0;
   }
-  if (p->n_regs > 32)
-    return gmx_fail("gmx_program_run: a program with more than 32 live values runs only as a specialised kernel "
+  // The interpreter's register file is a 16- or 32-element vector indexed at run time, and the
+  // two-register write (dst, dst + 1) is emitted for every instruction: the LAST element must stay
+  // unused, or the (predicated-off) dst + 1 access leaves the vector — measured on gfx950: a
+  // program writing r15 of the 16-element file stored nothing at all.  So 15 / 31 usable registers.
+  if (p->n_regs > 31)
+    return gmx_fail("gmx_program_run: a program with more than 31 live values runs only as a specialised kernel "
                     "(gmx_program_specialize; hiprtc unavailable or GENMI_JIT=0?)%s");
-  if (p->n_regs <= 16) {
+  if (p->n_regs <= 15) {
     if (p->needs_full)
       hipLaunchKernelGGL((k_vm<gmx_regs_vgpr<16>, true>), grid, block, 0, st, p->code_d, p->n_instr, n, *args);
     else

@@ -35,7 +35,7 @@
 #define GMX_PROG_MAGIC 0x50584D47u /* 'GMXP' */
 #define GMX_PROG_VERSION 2u
 #define GMX_PROG_HEADER_WORDS 10u
-#define GMX_MAX_REGS 64 /* > 32: specialised kernels only (the interpreter's register file is 32 VGPRs) */
+#define GMX_MAX_REGS 64 /* > 31: specialised kernels only (the interpreter's register file is 32 VGPRs, last one unused) */
 #define GMX_POOL_BASE 64u /* source operand codes >= this name pool entries */
 
 // LDIN / STOUT flag bits (field b for LDIN, field dst for STOUT)

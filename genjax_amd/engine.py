@@ -340,9 +340,9 @@ class Compiled:
             return False
         self._jit_tried = True
         ok = be.c.gmx_program_specialize(self.handle) == 0
-        if not ok and int(self.blob[3]) > 32:
+        if not ok and int(self.blob[3]) > 31:
             msg = be.c.gmx_last_error()
-            raise _lib.GenmiError("this program keeps more than 32 values live per particle and therefore needs the "
+            raise _lib.GenmiError("this program keeps more than 31 values live per particle and therefore needs the "
                                   f"hiprtc-specialised kernel, which could not be built: {msg.decode() if msg else ''}")
         return ok
 
@@ -362,9 +362,9 @@ class Compiled:
         buffers are persistent bind every step once and re-launch the bindings."""
         be = self._be
         n = int(np.prod(batch, dtype=np.int64))
-        if (n >= JIT_MIN_PARTICLES or int(self.blob[3]) > 32) and not self._jit_tried and be.uses_streams \
+        if (n >= JIT_MIN_PARTICLES or int(self.blob[3]) > 31) and not self._jit_tried and be.uses_streams \
                 and not torch.cuda.is_current_stream_capturing():
-            self.specialize()        # big ensembles, and programs the 32-register interpreter cannot hold
+            self.specialize()        # big ensembles, and programs the 31-register interpreter cannot hold
         A = _lib.RunArgs()
         keep = []
         anc = None

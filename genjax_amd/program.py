@@ -18,7 +18,7 @@ import numpy as np
 
 MAGIC = 0x50584D47
 VERSION = 2
-MAX_REGS = 64          # operand codes below POOL_BASE; more than 32 needs the specialised kernel (no interpreter build)
+MAX_REGS = 64          # operand codes below POOL_BASE; more than 31 needs the specialised kernel (no interpreter build)
 
 F_GATHER, F_U8, F_BCAST = 1, 2, 4
 

@@ -429,6 +429,39 @@ def test_dirichlet_matches_oracle_and_scipy(gpu):
     parity.check_dirichlet(n=50_000)
 
 
+def test_interpreter_top_registers(gpu):
+    """Raw programs through the C-ABI that write the highest registers (n_regs = 16 and 32): the
+    interpreter's vector register file must hold them (regression: r15 of the 16-element file)."""
+    import ctypes
+    import struct
+    from genjax_amd import _lib
+    from genjax_amd.program import MAGIC, OPC, VERSION
+
+    def f2u(x):
+        return struct.unpack("<I", struct.pack("<f", x))[0]
+
+    def ins(op, dst=0, a=0, b=0, imm=0):
+        return [OPC[op] | (dst & 0xff) << 8 | (a & 0xff) << 16 | (b & 0xff) << 24, imm & 0xffffffff]
+    for n_regs in (15, 16, 31, 32):
+        top = n_regs - 1
+        w = ins("CONST", 2, imm=f2u(3.5)) + ins("LGAMMA", top, 2) + ins("STOUT", 0, 0, top) + \
+            ins("CONST", top, imm=f2u(2.25)) + ins("STOUT", 0, 1, top)
+        blob = np.array([MAGIC, VERSION, len(w) // 2, n_regs, 0, 2, 0, 0, 0, 0] + w, dtype=np.uint32)
+        h = ctypes.c_void_p()
+        gpu.check(gpu.c.gmx_program_create(blob.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), blob.size, h), "create")
+        A = _lib.RunArgs()
+        outs = [torch.full((70,), -7.0, device="cuda") for _ in range(2)]
+        for k, o in enumerate(outs):
+            A.out_d[k] = o.data_ptr()
+        rc = gpu.c.gmx_program_run(h, 70, A, gpu.stream())
+        if n_regs == 32:
+            assert rc != 0                      # 32 live values: specialised kernels only
+            continue
+        gpu.check(rc, "run")
+        torch.cuda.synchronize()
+        assert abs(float(outs[0][69]) - 1.2009736) < 1e-6 and float(outs[1][0]) == 2.25, n_regs
+
+
 def test_full_size_sweep_properties(gpu):
     """BASELINE config 2 at full size (1e6 particles, T = 100): size-independent
     properties — sorted ancestors, determinism, and log-ML within Monte-Carlo

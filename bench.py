@@ -31,8 +31,8 @@ sys.path.insert(0, ROOT)
 
 N_PARTICLES = 1_000_000
 T_STEPS = 100
-VM_VALU_PER_WAVE = 344.7            # VALU instructions per 64 particles: SQ_INSTS_VALU / waves / 4 particles per
-                                    # thread (profiles/r01_k_pmc_summary.txt, r01_m_pmc_summary.txt; 377.2 at 1 per thread)
+VM_VALU_PER_WAVE = 321.4            # VALU instructions per 64 particles: SQ_INSTS_VALU / waves / 4 particles per
+                                    # thread (1285.7 per wave, profiles/r01_m_pmc_summary.txt; 377.2 at 1 per thread)
 VALU_PEAK_LANE_OPS = 256 * 4 * 32 * 2.4e9
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 # Algorithmic bytes per particle-step (8*D + 24 = 32 B, D = 1):

@@ -67,7 +67,7 @@ class ShardedBootstrapSweep:
     """smc.BootstrapSweep over `dist.get_world_size()` ranks, n particles per rank."""
 
     def __init__(self, init, step, n_per_rank: int, T: int, dist, obs_addr="y", step_extra=None, specialize=True,
-                 resample="systematic", capacity=None, always_communicate=False):
+                 resample="systematic", capacity=None, always_communicate=False, rejuvenate=None, state_addr="x"):
         from .smc import _KINDS
         self.init, self.step, self.n, self.T, self.dist = init, step, int(n_per_rank), int(T), dist
         self.obs_addr = obs_addr
@@ -86,6 +86,10 @@ class ShardedBootstrapSweep:
         self.comm = self.world > 1 or bool(always_communicate)
         self.cx = None           # comm.RcclComm / comm.TorchComm, made in prepare()
         self.graph = None
+        # rejuvenate: the MH request of smc.BootstrapSweep(rejuvenate=...) (BASELINE config 3).  The move on
+        # a resampled particle needs the particle AND the state it was extended from, so two leaves are
+        # routed (two gmx_shard_step launches and two all-to-alls per step instead of one).
+        self.rejuvenate, self.state_addr = rejuvenate, state_addr
 
     def prepare(self, key: Key, ys: torch.Tensor):
         from ..static import MinimalGenerate
@@ -109,10 +113,22 @@ class ShardedBootstrapSweep:
         obs0 = ChoiceMap.empty().set(self.obs_addr, self.ys[0])
         self.p_init = MinimalGenerate(self.init, (), obs0, (n,))
         g = Gathered(self.xext[0], self.idx)
-        self.p_step = MinimalGenerate(self.step, (g,) + tuple(self.step_extra(1)), obs0, (n,))
+        if self.rejuvenate is None:
+            self.p_step = MinimalGenerate(self.step, (g,) + tuple(self.step_extra(1)), obs0, (n,))
+        else:
+            from ..static import MinimalMH
+            self.accept = torch.zeros((n,), dtype=torch.bool, device=dev)
+            self.p_step = MinimalGenerate(self.step, (self.aext[0][:n],) + tuple(self.step_extra(1)), obs0, (n,))
+            ch = obs0.set(self.state_addr, g)
+            self.p_mh_init = MinimalMH(self.init, (), ch, self.rejuvenate, (n,))
+            self.p_mh_step = MinimalMH(self.step, (Gathered(self.aext[0], self.idx),) + tuple(self.step_extra(1)), ch,
+                                       self.rejuvenate, (n,))
         if self.specialize and be.uses_streams:
             self.p_init.comp.specialize()
             self.p_step.comp.specialize()
+            if self.rejuvenate is not None:
+                self.p_mh_init.comp.specialize()
+                self.p_mh_step.comp.specialize()
         self.partials = torch.zeros((2, (n + 255) // 256), dtype=torch.float32, device=dev)
         self.step_keys = []
         for t in range(T):
@@ -126,6 +142,11 @@ class ShardedBootstrapSweep:
         self.xext = [torch.zeros((n + W * C,), dtype=torch.float32, device=dev) for _ in range(2)]
         self.send = torch.zeros((W * C,), dtype=torch.float32, device=dev)
         self.idx = torch.zeros((n,), dtype=torch.int32, device=dev)
+        if self.rejuvenate is not None:
+            # aext[t % 2][:n] = the MH-moved, resampled state step t is extended from; its tail receives the
+            # remote copies of it when it travels as the second routed leaf of the NEXT resampling
+            self.aext = [torch.zeros((n + W * C,), dtype=torch.float32, device=dev) for _ in range(2)]
+            self.send2 = torch.zeros((W * C,), dtype=torch.float32, device=dev)
         self._bound = [None] * self.T
 
     # ------------------------------------------------------------------
@@ -137,11 +158,28 @@ class ShardedBootstrapSweep:
         k_prop, k_res, _ = self.step_keys[t]
         obs = ChoiceMap.empty().set(self.obs_addr, self.ys[t])
         cur = self.xext[t % 2]
+        mh = None
         if t == 0:
             prog, leaves = self.p_init, self.p_init.leaves((), obs)
-        else:
+        elif self.rejuvenate is None:
             prog = self.p_step
             leaves = prog.leaves((Gathered(self.xext[(t - 1) % 2], self.idx),) + tuple(self.step_extra(t)), obs)
+        else:
+            # the MH move on the resampled particles of step t-1, keys split(k_mh, N)[g*n + i]
+            prev_x, prev_a, cur_a = self.xext[(t - 1) % 2], self.aext[(t - 1) % 2], self.aext[t % 2]
+            ch = ChoiceMap.empty().set(self.obs_addr, self.ys[t - 1]).set(self.state_addr, Gathered(prev_x, self.idx))
+            if t == 1:
+                mprog, mleaves = self.p_mh_init, self.p_mh_init.leaves((), ch, self.rejuvenate)
+            else:
+                mprog = self.p_mh_step
+                mleaves = mprog.leaves((Gathered(prev_a, self.idx),) + tuple(self.step_extra(t - 1)), ch, self.rejuvenate)
+            mbufs = [None] * len(mprog.comp.outputs)
+            mbufs[mprog.ro[1]] = cur_a[:n].reshape(1, n)
+            mbufs[mprog.ao[1]] = self.accept.reshape(1, n)
+            mh = (mprog.comp, mprog.comp.bind(mleaves, (n,), lazy_split(self.step_keys[t][2], self.N),
+                                             out_buffers=mbufs, index_offset=g * n), mleaves)
+            prog = self.p_step
+            leaves = prog.leaves((cur_a[:n],) + tuple(self.step_extra(t)), obs)
         bufs = [None] * len(prog.comp.outputs)
         bufs[prog.ro[1]] = cur[:n].reshape(1, n)
         bufs[prog.wo[1]] = self.lw.reshape(1, n)
@@ -155,8 +193,15 @@ class ShardedBootstrapSweep:
         P = be.ptr
         rows = int(be.c.gmx_program_grid(prog.comp.handle, n))        # block maxima the site program writes
         pmax = self.partials[0, :rows]
+        step2 = recv2 = None
+        if self.rejuvenate is not None and t >= 1:       # second routed leaf: what x_t was extended from
+            cur_a = self.aext[t % 2]
+            step2 = (self.kind, kk, P(self.totals_all), P(self.plan), P(tot), P(self.cdf), g, W, n, C, P(cur_a),
+                     P(self.send2), P(self.idx))
+            recv2 = cur_a[n:]
         return {
-            "prog": prog.comp, "vm": vm, "pmax": pmax, "recv": cur[n:], "keep": (kk, tot, leaves, m),
+            "prog": prog.comp, "vm": vm, "mh": mh, "step2": step2, "recv2": recv2,
+            "pmax": pmax, "recv": cur[n:], "keep": (kk, tot, leaves, m),
             # the CDF kernel reduces the (all-reduced) block maxima itself and records the max in maxs[t]
             "cdf": (P(self.lw), n, self.shift, P(pmax), rows, P(m), P(self.cdf), P(self.total_d), P(self.ws)),
             "step": (self.kind, kk, P(self.totals_all), P(self.plan), P(tot), P(self.cdf), g, W, n, C, P(cur),
@@ -169,6 +214,8 @@ class ShardedBootstrapSweep:
         if b is None:
             b = self._bound[t] = self._bind_step(t)
         c, st = be.c, be.stream()
+        if b["mh"] is not None:
+            b["mh"][0].launch(b["mh"][1])                               # MH move on the resampled particles
         b["prog"].launch(b["vm"])                                      # x_t, lw_t, block maxima
         if self.comm:
             self.cx.all_reduce_max(b["pmax"])                            # element-wise MAX of the block maxima (<= 4 KB)
@@ -180,6 +227,10 @@ class ShardedBootstrapSweep:
         be.check(c.gmx_shard_step(*b["step"], st), "gmx_shard_step")   # slot boundaries + routing, one launch
         if self.comm:
             self.cx.all_to_all(b["recv"], self.send)                     # block s of recv <- block `me` of rank s
+        if b["step2"] is not None:
+            be.check(c.gmx_shard_step(*b["step2"], st), "gmx_shard_step")
+            if self.comm:
+                self.cx.all_to_all(b["recv2"], self.send2)
 
     def kernel_timers(self):
         """The site-program launch of a mid-sweep step (no collectives): bench.py's roofline kernel."""

@@ -13,16 +13,23 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def main(out_path, n_per_rank, T, capacity=None):
+def main(out_path, n_per_rank, T, capacity=None, mh=False):
     dist.init_process_group("gloo")
     import tests.hostsim as hs
     hs.install()
     import genjax_amd as G
     from genjax_amd import workloads
     from genjax_amd.inference.sharded import ShardedBootstrapSweep
-    ys = workloads.lgssm_data(T)
-    init, step = workloads.make_lgssm(G)
-    sw = ShardedBootstrapSweep(init, step, n_per_rank, T, dist, capacity=capacity).prepare(G.key(314159), torch.from_numpy(ys))
+    if mh:      # BASELINE config 3: nonlinear SSM with one Gaussian-drift MH move per step
+        ys = workloads.nlssm_data(T)
+        init, step = workloads.make_nlssm(G)
+        req = G.StaticRequest({"x": G.Rejuvenate(G.normal, lambda chm: (chm.get_value(), 0.5))})
+        sw = ShardedBootstrapSweep(init, step, n_per_rank, T, dist, capacity=capacity, rejuvenate=req,
+                                   step_extra=lambda t: (float(t),)).prepare(G.key(7), torch.from_numpy(ys))
+    else:
+        ys = workloads.lgssm_data(T)
+        init, step = workloads.make_lgssm(G)
+        sw = ShardedBootstrapSweep(init, step, n_per_rank, T, dist, capacity=capacity).prepare(G.key(314159), torch.from_numpy(ys))
     sw.launch()
     xs = [torch.empty_like(sw.state()) for _ in range(dist.get_world_size())]
     dist.all_gather(xs, sw.state())
@@ -35,4 +42,5 @@ def main(out_path, n_per_rank, T, capacity=None):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]) if len(sys.argv) > 4 else None)
+    cap = int(sys.argv[4]) if len(sys.argv) > 4 and int(sys.argv[4]) > 0 else None
+    main(sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), cap, mh=len(sys.argv) > 5 and sys.argv[5] == "mh")

@@ -581,6 +581,39 @@ def pytest_approx(x, rel):
     return pytest.approx(x, rel)
 
 
+def oracle_nlssm_mh_sweep(n, T, seed):
+    """The oracle run of BASELINE config 3 with the sweeps' key schedule: per step t the key fold_in(key, t)
+    splits into (k_prop, k_res, k_mh); the resampling that follows step t-1 uses ITS k_res; the MH move
+    before step t uses k_mh of step t.  Returns the last step's particles / log-weights / accept bits,
+    the evidence terms and the particles after the final resampling."""
+    from genjax_amd import workloads
+    ys = workloads.nlssm_data(T)
+    oi, ost = workloads.make_nlssm(O)
+    oreq = {"x": O.Rejuvenate(O.normal, lambda chm: (chm.get_value(), np.float32(0.5)))}
+    okey = O.key(seed)
+    otr = olw = oacc = None
+    terms = []
+    for t in range(T):
+        oks = O.split(O.fold_in(okey, t), 3)
+        oobs = O.C.kw(y=np.float32(ys[t]))
+        if t == 0:
+            otr, olw = oi.importance(O.split(oks[0], n), oobs, ())
+        else:
+            okr = O.split(O.fold_in(okey, t - 1), 3)[1]
+            cdf, total, M, shift = O.weight_cdf(olw)
+            terms.append(M + math.log(total) - shift * math.log(2.0) - math.log(n))
+            otr = O.gather_trace(otr, O.ancestors(O.SYSTEMATIC, okr, cdf))
+            gf = otr.get_gen_fn()
+            otr, oacc, _ = O.rejuvenate(oks[2], otr, lambda k, tr_: gf.edit_static(k, tr_, oreq, tr_.get_args()))
+            otr, olw = ost.importance(O.split(oks[0], n), oobs, (np.asarray(otr.get_retval(), np.float32), np.float32(t)))
+    x = np.asarray(otr.get_retval(), np.float32)
+    olw = np.asarray(olw, np.float32)
+    cdf, total, M, shift = O.weight_cdf(olw)
+    terms.append(M + math.log(total) - shift * math.log(2.0) - math.log(n))
+    anc = O.ancestors(O.SYSTEMATIC, O.split(O.fold_in(okey, T - 1), 3)[1], cdf)
+    return {"x": x, "lw": olw, "acc": oacc, "terms": terms, "resampled": x[anc]}
+
+
 def check_nlssm_mh_sweep(n=2000, T=5, seed=7, capture=False, specialize=False):
     """BASELINE config 3 as ONE captured sweep: BootstrapSweep(rejuvenate=...) (k_vm -> resample ->
     fused MH -> k_vm ...) against the oracle run step by step with the sweep's key schedule
@@ -599,27 +632,11 @@ def check_nlssm_mh_sweep(n=2000, T=5, seed=7, capture=False, specialize=False):
         sw.capture()
     sw.launch()
     x, lw, anc = sw.state()
-    okey = O.key(seed)
-    otr = olw = None
-    terms = []
-    for t in range(T):
-        oks = O.split(O.fold_in(okey, t), 3)
-        oobs = O.C.kw(y=np.float32(ys[t]))
-        if t == 0:
-            otr, olw = oi.importance(O.split(oks[0], n), oobs, ())
-        else:
-            okr = O.split(O.fold_in(okey, t - 1), 3)[1]
-            cdf, total, M, shift = O.weight_cdf(olw)
-            terms.append(M + math.log(total) - shift * math.log(2.0) - math.log(n))
-            otr = O.gather_trace(otr, O.ancestors(O.SYSTEMATIC, okr, cdf))
-            gf = otr.get_gen_fn()
-            otr, oacc, _ = O.rejuvenate(oks[2], otr, lambda k, tr_: gf.edit_static(k, tr_, oreq, tr_.get_args()))
-            otr, olw = ost.importance(O.split(oks[0], n), oobs, (np.asarray(otr.get_retval(), np.float32), np.float32(t)))
-    assert np.array_equal(x.cpu().numpy(), np.asarray(otr.get_retval(), np.float32))
-    assert np.array_equal(lw.cpu().numpy(), np.asarray(olw, np.float32))
+    ref = oracle_nlssm_mh_sweep(n, T, seed)
+    otr_x, olw, oacc, terms = ref["x"], ref["lw"], ref["acc"], ref["terms"]
+    assert np.array_equal(x.cpu().numpy(), otr_x)
+    assert np.array_equal(lw.cpu().numpy(), olw)
     assert np.array_equal(sw.accept.cpu().numpy(), oacc)
-    cdf, total, M, shift = O.weight_cdf(olw)
-    terms.append(M + math.log(total) - shift * math.log(2.0) - math.log(n))
     assert abs(sw.log_ml() - sum(terms)) < 1e-9 * max(1.0, abs(sum(terms)))
     return {"accept_rate": float(oacc.mean()), "log_ml": sw.log_ml()}
 

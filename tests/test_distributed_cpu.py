@@ -49,6 +49,27 @@ def test_sharded_sweep_equals_single_process_oracle(tmp_path, world, capacity):
     assert np.array_equal(x, ref["x"][ref["anc"]])
 
 
+@pytest.mark.parametrize("world,capacity", [(2, 0), (4, 7)])
+def test_sharded_mh_sweep_equals_single_process_oracle(tmp_path, world, capacity):
+    """BASELINE config 3 sharded: nonlinear SSM + one MH move per step, two routed leaves (the particle and
+    the state it was extended from).  Must equal the single-process oracle for any rank count; capacity 7
+    forces the overflow re-run."""
+    n_total, T = 2048, 4
+    out = str(tmp_path / "shard_mh")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", env["MASTER_PORT"],
+           os.path.join(ROOT, "tests", "dist_worker.py"), out, str(n_total // world), str(T), str(capacity), "mh"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    x = np.load(out + ".npy")
+    meta = json.load(open(out + ".json"))
+    ref = parity.oracle_nlssm_mh_sweep(n_total, T, 7)
+    assert np.array_equal(x, ref["resampled"])
+    assert abs(meta["log_ml"] - sum(ref["terms"])) < 1e-9 * max(1.0, abs(sum(ref["terms"])))
+    assert meta["reruns"] == (1 if capacity else 0), meta
+
+
 def test_slot_bounds_match_ancestors():
     """systematic_slot_bounds (host, exact integers) == counting the oracle's ancestors per mass interval"""
     from genjax_amd.inference.sharded import systematic_slot_bounds

@@ -535,6 +535,29 @@ def test_random_programs_interpreter_jit_and_host_agree(gpu):
     assert n_checked >= 12
 
 
+def test_sharded_mh_sweep_world1_matches_oracle(gpu):
+    """ShardedBootstrapSweep(rejuvenate=...) at world size 1 on the GPU == the config-3 oracle."""
+    import genjax_amd as G
+    from genjax_amd import workloads
+    from genjax_amd.inference.sharded import ShardedBootstrapSweep
+
+    class _Solo:
+        @staticmethod
+        def get_rank(): return 0
+        @staticmethod
+        def get_world_size(): return 1
+    n, T = 30_000, 5
+    ys = workloads.nlssm_data(T)
+    init, step = workloads.make_nlssm(G)
+    req = G.StaticRequest({"x": G.Rejuvenate(G.normal, lambda chm: (chm.get_value(), 0.5))})
+    sw = ShardedBootstrapSweep(init, step, n, T, _Solo, rejuvenate=req,
+                               step_extra=lambda t: (float(t),)).prepare(G.key(7), torch.from_numpy(ys))
+    sw.launch()
+    ref = parity.oracle_nlssm_mh_sweep(n, T, 7)
+    assert np.array_equal(sw.state().cpu().numpy(), ref["resampled"])
+    assert abs(sw.log_ml() - sum(ref["terms"])) < 1e-9 * max(1.0, abs(sum(ref["terms"])))
+
+
 def test_full_size_sweep_properties(gpu):
     """BASELINE config 2 at full size (1e6 particles, T = 100): size-independent
     properties — sorted ancestors, determinism, and log-ML within Monte-Carlo

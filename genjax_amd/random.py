@@ -23,9 +23,35 @@ def _rotl(x, r):
     return (x << np.uint32(r)) | (x >> np.uint32(32 - r))
 
 
+_M32 = 0xFFFFFFFF
+_ROT = ((13, 15, 26, 6), (17, 29, 16, 24))
+
+
+def _threefry_int(k0: int, k1: int, c0: int, c1: int):
+    """One block in Python integers: ~10 us, where the numpy form costs ~100 us of dispatch for a
+    handful of keys (a functional SMC step derives three keys on the host)."""
+    ks = (k0, k1, k0 ^ k1 ^ 0x1BD11BDA)
+    x0, x1 = (c0 + ks[0]) & _M32, (c1 + ks[1]) & _M32
+    for g in range(5):
+        for r in _ROT[g & 1]:
+            x0 = (x0 + x1) & _M32
+            x1 = ((x1 << r) | (x1 >> (32 - r))) & _M32
+            x1 ^= x0
+        x0 = (x0 + ks[(g + 1) % 3]) & _M32
+        x1 = (x1 + ks[(g + 2) % 3] + g + 1) & _M32
+    return x0, x1
+
+
 def threefry2x32(k0, k1, c0, c1):
-    """Vectorised host Threefry-2x32-20 (numpy uint32, wrap-around arithmetic)."""
+    """Host Threefry-2x32-20: Python integers for up to 16 blocks, vectorised numpy uint32 beyond."""
     k0, k1, c0, c1 = (np.asarray(v, dtype=np.uint32) for v in (k0, k1, c0, c1))
+    shape = np.broadcast_shapes(k0.shape, k1.shape, c0.shape, c1.shape)
+    size = int(np.prod(shape, dtype=np.int64))
+    if size <= 16:
+        b = [np.broadcast_to(v, shape).reshape(-1).tolist() for v in (k0, k1, c0, c1)]
+        o = [_threefry_int(*(int(v[j]) for v in b)) for j in range(size)]
+        return (np.array([p[0] for p in o], dtype=np.uint32).reshape(shape),
+                np.array([p[1] for p in o], dtype=np.uint32).reshape(shape))
     with np.errstate(over="ignore"):
         ks = (k0, k1, k0 ^ k1 ^ np.uint32(0x1BD11BDA))
         x0 = c0 + ks[0]
@@ -42,6 +68,13 @@ def threefry2x32(k0, k1, c0, c1):
 
 
 def _derive_host(keys: np.ndarray, ctr) -> np.ndarray:
+    if keys.size == 2 and np.size(ctr) <= 16:
+        # ONE key, a few children (fold_in, split(key, 3)): straight Python integers, one array at the end
+        k0, k1 = int(keys.reshape(-1)[0]), int(keys.reshape(-1)[1])
+        cs = [int(c) for c in np.asarray(ctr).reshape(-1)]
+        out = np.array([_threefry_int(k0, k1, c >> 32, c & _M32) for c in cs], dtype=np.uint32)
+        lead = np.broadcast_shapes(keys.shape[:-1], np.shape(ctr))
+        return out.reshape(lead + (2,))
     ctr = np.asarray(ctr, dtype=np.uint64)
     hi = (ctr >> np.uint64(32)).astype(np.uint32)
     lo = (ctr & np.uint64(0xFFFFFFFF)).astype(np.uint32)

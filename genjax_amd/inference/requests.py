@@ -19,7 +19,7 @@ from .. import tracer as T
 from ..autodiff import grad
 from ..core.choice_map import ChoiceMap, Selection
 from ..core.generative import Diff, DiffAnnotate, EditRequest
-from ..engine import Compiled, Flat, Sym, Tracing, leaf_spec, resolve, unflatten
+from ..engine import Compiled, Flat, Tracing, leaf_spec, resolve, unflatten
 from ..static import (Rejuvenate, _broadcast_score, _build_trace, _Ctx, _emit_rec, _gfkey, _rec_score, _selkey,
                       _trace_tree, call_gen_fn)
 from ..tracer import Expr

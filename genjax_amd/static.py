@@ -899,8 +899,6 @@ def run_edit(gen_fn, key: Key, trace: Trace, request: EditRequest, argdiffs, mh:
             elif rspec.kind == "regen":
                 mode = "regen"
             _bind_request_leaves(rspec, syms)
-            if rspec.kind == "index" and rspec.sub.kind == "update":
-                pass                          # the element's constraint travels in rspec.sub.constraint
             rec, retval, w, _ = call_gen_fn(ctx, mode, gen_fn, kexpr, sargs, constraint, sprev, req, syms, ())
             ao = None
             if mh:

@@ -24,6 +24,7 @@ import numpy as np
 
 from .core.choice_map import ChoiceMap
 from .core.generative import GenerativeFunction
+from . import tracer as T
 from .tracer import Expr
 
 
@@ -174,13 +175,25 @@ class Vmap(GenerativeFunction):
             args_j = tuple(_take(a, j) if ax is not None else a for a, ax in zip(args, axes))
             prev_j = _index_prev(inner_prev, j)
             if kind == "index":
-                if j == req.idx:
+                traced = not isinstance(req.idx, int)
+                if traced or j == req.idx:
                     sub = req.sub
                     sub_mode = {"update": "update", "regen": "regen"}.get(sub.kind, "static_edit")
                     sub_con = sub.constraint if sub.kind == "update" else ChoiceMap.empty()
+                    saved = set(ctx.changed)
                     rec, ret, w, _ = call_gen_fn(ctx, sub_mode, self.gen_fn, key, args_j, sub_con, prev_j, sub,
                                                  req_leaves, addr)
-                else:           # untouched: an empty Update with unchanged arguments recomputes nothing
+                if traced:      # one index per particle: element j is the edited one where idx == j
+                    ctx.changed = saved
+                    ctx.memo.clear()
+                    old, old_ret, _, _ = call_gen_fn(ctx, "update", self.gen_fn, None, args_j, ChoiceMap.empty(),
+                                                     prev_j, carry_over, req_leaves, addr)
+                    here = req.idx == j
+                    rec = _select_rec(here, rec, old)
+                    ret = _select_tree(here, ret, old_ret)
+                    w = T.where(here, w, 0.0) if w is not None else None
+                    ctx.mark_changed([r.value for r in _leaves(rec)])
+                elif j != req.idx:      # untouched: an empty Update with unchanged arguments recomputes nothing
                     rec, ret, w, _ = call_gen_fn(ctx, "update", self.gen_fn, None, args_j, ChoiceMap.empty(), prev_j,
                                                  carry_over, req_leaves, addr)
             else:
@@ -220,6 +233,31 @@ class Vmap(GenerativeFunction):
     def assess(self, sample, args, batch_shape=None):
         from .static import run_gfi
         return run_gfi(self, "assess", None, args, constraint=sample, batch_shape=batch_shape)
+
+
+def _select_tree(c, new, old):
+    from .engine import Sym
+    new = new.value if isinstance(new, Sym) else new
+    old = old.value if isinstance(old, Sym) else old
+    if isinstance(new, (tuple, list)):
+        return type(new)(_select_tree(c, a, b) for a, b in zip(new, old))
+    if new is None:
+        return None
+    return T.where(c, new, old)
+
+
+def _select_rec(c, new, old):
+    """where(c, new record, old record), leaf by leaf (same structure)."""
+    from .static import _CallRec, _SiteRec
+    if isinstance(new, _SiteRec):
+        keep = old.value
+        disc = _select_tree(c, new.discard if new.discard is not None else keep, keep)
+        return _SiteRec(new.gen_fn, _select_tree(c, new.value, old.value), _select_tree(c, new.score, old.score), disc)
+    out = _CallRec(new.gen_fn)
+    for a in new.sites:
+        out.sites[a] = _select_rec(c, new.sites[a], old.sites[a])
+    out.retval = _select_tree(c, new.retval, old.retval)
+    return out
 
 
 def _vmap_edit(self, key, trace, edit_request, argdiffs):

@@ -172,12 +172,14 @@ class Regenerate(EditRequest):
 
 class IndexRequest(EditRequest):
     """concepts.py:153-164: edit ONE index of a vector combinator's trace with a sub-request
-    (`Vmap.edit_index`, vmap.py:277-332).  `idx` is a Python int here (the unrolled plate picks
-    the element at trace time)."""
+    (`Vmap.edit_index`, vmap.py:277-332).  `idx` is a Python int (the unrolled plate picks the element
+    at trace time) or an integer tensor with one index PER PARTICLE (every element is then edited
+    in the program and selected where idx == j: n times the work, for small plates)."""
     __match_args__ = ("idx", "request")
 
     def __init__(self, idx, request: EditRequest):
-        self.idx, self.request = int(idx), request
+        self.idx = idx if hasattr(idx, "shape") and tuple(getattr(idx, "shape", ())) != () else int(idx)
+        self.request = request
 
 
 class VectorRequest(EditRequest):

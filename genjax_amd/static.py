@@ -253,7 +253,10 @@ def _flatten_request(req, flat: Flat):
         return _ReqSpec("static", subs=subs), ("static", tuple(keys))
     if isinstance(req, IndexRequest):
         sub, k = _flatten_request(req.request, flat)
-        return _ReqSpec("index", idx=req.idx, sub=sub), ("index", req.idx, k)
+        if isinstance(req.idx, int):
+            return _ReqSpec("index", idx=req.idx, sub=sub), ("index", req.idx, k)
+        tree = flat.add(req.idx)                      # one index per particle: a launch value
+        return _ReqSpec("index", idx=None, idx_tree=tree, sub=sub), ("index", "traced", tree, k)
     if isinstance(req, Rejuvenate):
         return (_ReqSpec("rejuv", proposal=req.proposal, argmap=req.argument_mapping),
                 ("rejuv", _gfkey(req.proposal), _fnkey(req.argument_mapping)))
@@ -927,7 +930,8 @@ def run_edit(gen_fn, key: Key, trace: Trace, request: EditRequest, argdiffs, mh:
     elif isinstance(request, Regenerate):
         bwd = Update(discard)
     elif isinstance(request, IndexRequest):
-        bwd = IndexRequest(request.idx, Update(discard))
+        bwd = IndexRequest(request.idx, Update(discard))       # for a per-particle idx the discard holds the kept
+                                                               # values at the other indices
     else:
         bwd = request if isinstance(request, (StaticRequest, Rejuvenate)) else Update(discard)
     retdiff = Diff.unknown_change(new_tr.get_retval())
@@ -955,6 +959,8 @@ def _bind_request_leaves(rspec, syms):
         for s in rspec.subs.values():
             _bind_request_leaves(s, syms)
     elif rspec.kind == "index":
+        if rspec.idx is None or isinstance(rspec.idx, Expr):
+            rspec.idx = T.as_int(unflatten(rspec.idx_tree, lambda j: syms[j].value))
         _bind_request_leaves(rspec.sub, syms)
     elif rspec.kind == "update":
         rspec.constraint = _sym_constraint(rspec.tree, syms)

@@ -485,6 +485,19 @@ def check_plate_edits(n=257, seed=1):
     a = acc.cpu().numpy().astype(bool)
     assert np.array_equal(np.delete(t0, 2, axis=1), np.delete(t1, 2, axis=1))
     assert np.array_equal(t0[~a, 2], t1[~a, 2]) and np.all(t0[a, 2] != t1[a, 2]) and 0 < a.mean() < 1
+    # one index PER PARTICLE (IntArray idx): every element is edited in the program and selected where idx == j
+    idx = np.random.default_rng(seed).integers(0, 8, n).astype(np.int32)
+    dev = G._lib.get().device
+    tr4, w4, _, _ = IndexRequest(torch.from_numpy(idx).to(dev), Regenerate(S["theta"])).edit(
+        G.split(G.key(seed + 6), n), tr, Diff.no_change(args))
+    th, wo = otr.get_choices()["theta"].copy(), np.zeros(n, np.float32)
+    for j in range(8):
+        aj = (np.float32(1.0), np.float32(2.0), np.float32(sig[j]))
+        cand, wj = O.vmap_edit_index(ov, O.split(O.key(seed + 6), n), otr, j,
+                                     lambda k, sl, a: oschool.regenerate(k, sl, O.selection("theta"), a)[:2], aj)
+        m = idx == j
+        th[m, j], wo[m] = cand.get_choices()["theta"][m, j], np.asarray(wj, np.float32)[m]
+    assert np.array_equal(tr4.get_choices()["theta"].cpu().numpy(), th) and np.array_equal(w4.cpu().numpy(), wo)
     # anything else is refused, as in the reference (vmap.py:361-362)
     try:
         Regenerate(S["theta"]).edit(G.split(G.key(seed), n), tr, Diff.no_change(args))

@@ -435,7 +435,7 @@ class Compiled:
                 A.keys_d = kt.data_ptr()
         else:
             A.key_mode = _lib.KEY_NONE
-        A.index_offset = index_offset
+        A.index_offset = index_offset or (getattr(key, "_offset", 0) if key is not None else 0)
         if self.uses_red:
             if red_out is None:
                 grid = be.c.gmx_program_grid(self.handle, n)

@@ -318,3 +318,82 @@ class ShardedBootstrapSweep:
         self.finish()
         from ..engine import gather_leaves
         return gather_leaves([self.xext[(self.T - 1) % 2]], self.idx)[0]
+
+
+def sharded_importance_resample(target, k_per_rank: int, key: Key, dist, kind="systematic", capacity=None, comm=None):
+    """BASELINE config 4 across ranks: `ImportanceK(target, k_particles = world * k_per_rank).run_smc(key)`
+    with rank g holding particles [g*k, (g+1)*k) (same key tree: keys split(sub, K)[g*k + i], so the
+    ensemble is the single-process one), then ONE global resampling: all-reduce of the max, local integer
+    CDF, all-gather of the totals, and for every 4-byte row of every trace leaf one `gmx_shard_step` + one
+    equal-split all-to-all (a one-off move, so leaves are routed one by one).  Returns
+    (ParticleCollection of this rank's k resampled particles, this rank's pre-resampling log-weights).
+    COLLECTIVE: every rank calls it."""
+    from .smc import _KINDS, LogMLOffset, ParticleCollection, trace_map
+    from ..engine import gather_leaves, materialize
+    be = _lib.get()
+    dev = be.device
+    g, W = dist.get_rank(), dist.get_world_size()
+    n, K = int(k_per_rank), int(k_per_rank) * dist.get_world_size()
+    kind = _KINDS[kind] if isinstance(kind, str) else int(kind)
+    if comm is None and W > 1:
+        from .comm import make_comm
+        comm = make_comm(dist, dev)
+    key, sub = split(key)                                            # smc.py:299
+    trs, lw = target.importance(lazy_split(sub, n, offset=g * n), ChoiceMap.empty())
+    lw = lw.float().contiguous()
+    # ---- global max (deterministic LSE kernel's max output), local CDF against it, totals ----
+    mx = torch.empty((1,), dtype=torch.float32, device=dev)
+    dummy = torch.empty((1,), dtype=torch.float32, device=dev)
+    rows_ws = torch.empty(((be.c.gmx_logsumexp_workspace(1, n) + 3) // 4,), dtype=torch.int32, device=dev)
+    be.check(be.c.gmx_logsumexp(be.ptr(lw), 1, n, be.ptr(dummy), be.ptr(mx), be.ptr(rows_ws), be.stream()), "gmx_logsumexp")
+    if W > 1:
+        comm.all_reduce_max(mx)
+    shift = cdf_shift(K)
+    cdf = torch.empty((n,), dtype=torch.int64, device=dev)
+    total = torch.zeros((1,), dtype=torch.int64, device=dev)
+    ws = torch.zeros(((be.c.gmx_weight_cdf_workspace(n) + 7) // 8,), dtype=torch.int64, device=dev)
+    be.check(be.c.gmx_weight_cdf(be.ptr(lw), n, shift, None, 0, be.ptr(mx), be.ptr(cdf), be.ptr(total), be.ptr(ws),
+                                 be.stream()), "gmx_weight_cdf")
+    totals_all = torch.zeros((W,), dtype=torch.int64, device=dev)
+    if W > 1:
+        comm.all_gather(totals_all, total)
+    else:
+        totals_all.copy_(total)
+    kh = key.host()                                                  # resampling key: the algorithm's leftover `key`
+    kk = (c_uint32 * 2)(int(kh[0]), int(kh[1]))
+    gtotal = torch.zeros((1,), dtype=torch.int64, device=dev)
+    C = max(1, min(int(capacity) if capacity else (n if W == 1 else max(4096, n // 32)), n))
+    while True:
+        plan = torch.zeros((int(be.c.gmx_shard_plan_words(W)),), dtype=torch.int64, device=dev)
+        idx = torch.zeros((n,), dtype=torch.int32, device=dev)
+        send = torch.zeros((W * C,), dtype=torch.float32, device=dev)
+
+        def route(row: torch.Tensor) -> torch.Tensor:
+            """row: [n] 4-byte values of this rank's particles -> [n] values of this rank's resampled slots"""
+            ext = torch.empty((n + W * C,), dtype=row.dtype, device=dev)
+            ext[:n] = row
+            be.check(be.c.gmx_shard_step(kind, kk, be.ptr(totals_all), be.ptr(plan), be.ptr(gtotal), be.ptr(cdf), g, W,
+                                         n, C, be.ptr(ext), be.ptr(send), be.ptr(idx), be.stream()), "gmx_shard_step")
+            if W > 1:
+                comm.all_to_all(ext[n:].view(torch.float32), send)
+            return gather_leaves([ext], idx)[0]
+
+        def move(v):
+            v = materialize(v)
+            if tuple(v.shape[:1]) != (n,):
+                return v
+            if v.element_size() != 4:
+                v = v.to(torch.int32)                                 # bool / small ints travel as i32
+            flat = v.reshape(n, -1)
+            cols = [route(flat[:, c].contiguous().view(torch.float32)).view(flat.dtype) for c in range(flat.shape[1])]
+            return torch.stack(cols, dim=1).reshape(v.shape)
+        new = trace_map(trs, move)
+        flag = plan[2:3].clone()
+        if W > 1:
+            comm.all_reduce_max(flag)
+        if int(flag.item()) == 0:
+            break
+        C = n                                                        # always sufficient
+    off = LogMLOffset().plus(mx, gtotal, shift, K)
+    out = ParticleCollection(new, torch.zeros((n,), dtype=torch.float32, device=dev), True, off)
+    return out, lw

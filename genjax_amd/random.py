@@ -91,8 +91,9 @@ class Key:
               ("rowsplit", rows Key (batch (B,)), inner)   -> shape (B, inner)
     """
 
-    def __init__(self, host=None, dev=None, lazy=None, split_last=False):
+    def __init__(self, host=None, dev=None, lazy=None, split_last=False, offset=0):
         self._host, self._dev, self._lazy = host, dev, lazy
+        self._offset = int(offset)      # lazy "split" only: this is children [offset, offset + n) of the base key
         # result of split() over a BATCH of keys: `a, b = split(keys)` and
         # `split(keys)[i]` address the split axis (the last one), which is what
         # the same code sees per instance under jax.vmap
@@ -127,7 +128,7 @@ class Key:
             return self._dev.cpu().numpy().view(np.uint32)
         kind, base, n = self._lazy
         bh = base.host()
-        return _derive_host(bh[..., None, :], np.arange(n, dtype=np.uint64))
+        return _derive_host(bh[..., None, :], np.arange(n, dtype=np.uint64) + np.uint64(self._offset))
 
     def data(self) -> torch.Tensor:
         """device int32 [size, 2] (flattened batch), materialising lazily."""
@@ -142,7 +143,7 @@ class Key:
             bh = base.host()
             out = torch.empty((n, 2), dtype=torch.int32, device=be.device)
             kk = (c_uint32 * 2)(int(bh[0]), int(bh[1]))
-            be.check(be.c.gmx_split(kk, n, 0, be.ptr(out), be.stream()), "gmx_split")
+            be.check(be.c.gmx_split(kk, n, self._offset, be.ptr(out), be.stream()), "gmx_split")
             return out
         rows = base.data()
         out = torch.empty((rows.shape[0] * n, 2), dtype=torch.int32, device=be.device)
@@ -175,7 +176,7 @@ class Key:
             kind, base, n = self._lazy
             if kind == "split" and isinstance(idx, (int, np.integer)):
                 i = int(idx) % n
-                return Key(host=_derive_host(base.host(), np.uint64(i)))
+                return Key(host=_derive_host(base.host(), np.uint64(i + self._offset)))
             return self.materialize()[idx]
         if not isinstance(idx, tuple):
             idx = (idx,)
@@ -232,12 +233,13 @@ def split(k: Key, num: int = 2) -> Key:
     return out
 
 
-def lazy_split(k: Key, num: int) -> Key:
+def lazy_split(k: Key, num: int, offset: int = 0) -> Key:
     """split(k, num) for a single key, never materialised: kernels derive child
-    i in registers from the global particle index (GMX_KEY_SPLIT)."""
+    i in registers from the global particle index (GMX_KEY_SPLIT).  With `offset`, the `num` keys are
+    children offset .. offset+num-1 (a rank's block of a larger split)."""
     if k.shape != ():
         raise ValueError("lazy_split needs a single key")
-    return Key(lazy=("split", k.materialize(), int(num)))
+    return Key(lazy=("split", k.materialize(), int(num)), offset=offset)
 
 
 def fold_in(k: Key, data: int) -> Key:

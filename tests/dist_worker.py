@@ -13,6 +13,39 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+def schools_main(out_path, k_per_rank, capacity):
+    """BASELINE config 4 sharded: 8-schools ImportanceK + one global systematic resample."""
+    dist.init_process_group("gloo")
+    import tests.hostsim as hs
+    hs.install()
+    import genjax_amd as G
+    from genjax_amd import ChoiceMapBuilder as C, numpy as jnp
+    from genjax_amd.inference.sharded import sharded_importance_resample
+    from tests import parity
+
+    @G.gen
+    def schools():
+        mu = G.normal(0.0, 5.0) @ "mu"
+        log_tau = G.normal(0.0, 1.0) @ "log_tau"
+        theta = G.normal(mu * jnp.ones(8), jnp.exp(log_tau) * jnp.ones(8)) @ "theta"
+        _ = G.normal(theta, jnp.array(parity.SCHOOL_SIGMA)) @ "y"
+        return theta
+    coll, lw = sharded_importance_resample(G.Target(schools, (), C["y"].set(parity.SCHOOL_Y)), k_per_rank, G.key(2), dist,
+                                           capacity=capacity)
+    ch = coll.get_particles().get_choices()
+    outs = {}
+    for name in ("theta", "mu"):
+        v = ch[name].contiguous()
+        parts = [torch.empty_like(v) for _ in range(dist.get_world_size())]
+        dist.all_gather(parts, v)
+        outs[name] = torch.cat(parts).numpy()
+    lws = [torch.empty_like(lw) for _ in range(dist.get_world_size())]
+    dist.all_gather(lws, lw)
+    if dist.get_rank() == 0:
+        np.savez(out_path + ".npz", lw=torch.cat(lws).numpy(), log_ml=float(coll.get_log_marginal_likelihood_estimate()), **outs)
+    dist.destroy_process_group()
+
+
 def main(out_path, n_per_rank, T, capacity=None, mh=False):
     dist.init_process_group("gloo")
     import tests.hostsim as hs
@@ -42,5 +75,8 @@ def main(out_path, n_per_rank, T, capacity=None, mh=False):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 5 and sys.argv[5] == "schools":
+        schools_main(sys.argv[1], int(sys.argv[2]), int(sys.argv[4]) if int(sys.argv[4]) > 0 else None)
+        sys.exit(0)
     cap = int(sys.argv[4]) if len(sys.argv) > 4 and int(sys.argv[4]) > 0 else None
     main(sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), cap, mh=len(sys.argv) > 5 and sys.argv[5] == "mh")

@@ -70,6 +70,37 @@ def test_sharded_mh_sweep_equals_single_process_oracle(tmp_path, world, capacity
     assert meta["reruns"] == (1 if capacity else 0), meta
 
 
+@pytest.mark.parametrize("world,capacity", [(2, 0), (4, 5)])
+def test_sharded_importancek_global_resample_equals_oracle(tmp_path, world, capacity):
+    """BASELINE config 4 sharded (8-schools ImportanceK, ONE global systematic resample of a 10-latent
+    trace): the concatenated ranks equal the single-process oracle, for any rank count."""
+    k_total = 4096
+    out = str(tmp_path / "schools")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", env["MASTER_PORT"],
+           os.path.join(ROOT, "tests", "dist_worker.py"), out, str(k_total // world), "0", str(capacity), "schools"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    got = np.load(out + ".npz")
+    sig = np.array(parity.SCHOOL_SIGMA, np.float32)
+
+    @O.gen
+    def o_schools():
+        mu = O.normal(0.0, 5.0) @ "mu"
+        log_tau = O.normal(0.0, 1.0) @ "log_tau"
+        theta = O.normal(mu[..., None] * np.ones(8, np.float32), O.exp(log_tau)[..., None] * np.ones(8, np.float32)) @ "theta"
+        _ = O.normal(theta, sig) @ "y"
+        return theta
+    oc = O.ImportanceK(O.Target(o_schools, (), O.C.d({"y": parity.SCHOOL_Y})), k_total).run_smc(O.key(2))
+    assert np.array_equal(got["lw"], oc.get_log_weights())
+    cdf, total, M, shift = O.weight_cdf(oc.get_log_weights())
+    anc = O.ancestors(O.SYSTEMATIC, O.split(O.key(2))[0], cdf)          # the algorithm's leftover key resamples
+    assert np.array_equal(got["theta"], oc.get_particles().get_choices()["theta"][anc])
+    assert np.array_equal(got["mu"], oc.get_particles().get_choices()["mu"][anc])
+    assert abs(float(got["log_ml"]) - float(oc.get_log_marginal_likelihood_estimate())) < 2e-5
+
+
 def test_slot_bounds_match_ancestors():
     """systematic_slot_bounds (host, exact integers) == counting the oracle's ancestors per mass interval"""
     from genjax_amd.inference.sharded import systematic_slot_bounds

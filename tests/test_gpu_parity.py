@@ -558,6 +558,44 @@ def test_sharded_mh_sweep_world1_matches_oracle(gpu):
     assert abs(sw.log_ml() - sum(ref["terms"])) < 1e-9 * max(1.0, abs(sum(ref["terms"])))
 
 
+def test_sharded_importancek_global_resample_world1(gpu):
+    """sharded_importance_resample (config 4's multi-GPU form) at world size 1 == the oracle."""
+    import genjax_amd as G
+    from genjax_amd import ChoiceMapBuilder as C, numpy as jnp
+    from genjax_amd.inference.sharded import sharded_importance_resample
+
+    class _Solo:
+        @staticmethod
+        def get_rank(): return 0
+        @staticmethod
+        def get_world_size(): return 1
+    sig = np.array(parity.SCHOOL_SIGMA, np.float32)
+
+    @G.gen
+    def schools():
+        mu = G.normal(0.0, 5.0) @ "mu"
+        log_tau = G.normal(0.0, 1.0) @ "log_tau"
+        theta = G.normal(mu * jnp.ones(8), jnp.exp(log_tau) * jnp.ones(8)) @ "theta"
+        _ = G.normal(theta, jnp.array(parity.SCHOOL_SIGMA)) @ "y"
+        return theta
+
+    @O.gen
+    def o_schools():
+        mu = O.normal(0.0, 5.0) @ "mu"
+        log_tau = O.normal(0.0, 1.0) @ "log_tau"
+        theta = O.normal(mu[..., None] * np.ones(8, np.float32), O.exp(log_tau)[..., None] * np.ones(8, np.float32)) @ "theta"
+        _ = O.normal(theta, sig) @ "y"
+        return theta
+    k = 100_000
+    coll, lw = sharded_importance_resample(G.Target(schools, (), C["y"].set(parity.SCHOOL_Y)), k, G.key(2), _Solo)
+    oc = O.ImportanceK(O.Target(o_schools, (), O.C.d({"y": parity.SCHOOL_Y})), k).run_smc(O.key(2))
+    assert np.array_equal(lw.cpu().numpy(), oc.get_log_weights())
+    cdf, total, M, shift = O.weight_cdf(oc.get_log_weights())
+    anc = O.ancestors_c(O.SYSTEMATIC, O.split(O.key(2))[0], cdf)
+    assert np.array_equal(coll.get_particles().get_choices()["theta"].cpu().numpy(),
+                          oc.get_particles().get_choices()["theta"][anc])
+
+
 def test_full_size_sweep_properties(gpu):
     """BASELINE config 2 at full size (1e6 particles, T = 100): size-independent
     properties — sorted ancestors, determinism, and log-ML within Monte-Carlo

@@ -27,11 +27,16 @@ from ..tracer import Expr
 _CACHE: dict = {}
 
 
-def gibbs_categorical(key: Key, gen_fn, args, choices: ChoiceMap, addr, n_categories: int, batch_shape=None):
+def gibbs_categorical(key: Key, gen_fn, args, choices: ChoiceMap, addr, n_categories: int, batch_shape=None,
+                      index_offset: int = 0):
     """idx[i] = argmax_k( gen_fn.assess(choices_i with addr := k, args)[0] + gumbel(bits(key, i*K + k)) ).
 
     `choices` / `args` hold per-datapoint tensors (leading shape = the batch) and launch-uniform
-    values; `key` is one (unbatched) key.  Returns an int32 tensor of shape `batch`."""
+    values; `key` is one (unbatched) key.  Returns an int32 tensor of shape `batch`.
+
+    index_offset: the GLOBAL index of this call's first datapoint — datapoints are independent, so a
+    dataset sharded over ranks (or processed in chunks) gives the single-call result when every shard
+    passes its offset (the Gumbel counter is (index_offset + i)*K + k); no collective is involved."""
     from ..static import _Ctx, _gfkey, _infer_batch, _sym_constraint, call_gen_fn
     be = _lib.get()
     if tuple(key.shape) != ():
@@ -68,5 +73,5 @@ def gibbs_categorical(key: Key, gen_fn, args, choices: ChoiceMap, addr, n_catego
         ent = (Compiled(tr), out)
         _CACHE[ck] = ent
     comp, out = ent
-    outs = comp.run(flat.leaves, batch, key)
+    outs = comp.run(flat.leaves, batch, key, index_offset=int(index_offset))
     return resolve(out, outs, flat.leaves)

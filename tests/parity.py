@@ -355,6 +355,12 @@ def check_mixture_assignments(n=3000, K=64, seed=11, specialize=False):
     assert idx.dtype == torch.int32 and tuple(idx.shape) == (n,)
     assert np.array_equal(idx.cpu().numpy(), oidx)
     assert (oidx == z).mean() > 0.85            # well-separated clusters: mostly the generating component
+    # shards of the dataset with their global offsets reproduce the whole (how ranks split config 5)
+    cut = n // 3
+    a = gibbs.gibbs_categorical(G.key(seed), gd, args, C["obs"].set(torch.from_numpy(x[:cut]).to(dev)), "idx", K)
+    b = gibbs.gibbs_categorical(G.key(seed), gd, args, C["obs"].set(torch.from_numpy(x[cut:]).to(dev)), "idx", K,
+                                index_offset=cut)
+    assert np.array_equal(np.concatenate([a.cpu().numpy(), b.cpu().numpy()]), oidx)
     return idx
 
 

@@ -688,6 +688,58 @@ def test_categorical_sample_shape():
         big.simulate(genjax.key(0), ())
 
 
+def test_mixture_model_gibbs_end_to_end():
+    """The Dirichlet-mixture application (7_application_dirichlet_mixture_model.ipynb, cells 6-10) through this
+    package: cluster means by a Vmap'd conjugate draw, assignments by gibbs_categorical, weights by a
+    dirichlet draw.  Recovers well-separated clusters in a few sweeps."""
+    from genjax_amd import workloads
+    from genjax_amd.inference.gibbs import gibbs_categorical
+    K, N, PRIOR_MEAN, PRIOR_VAR, OBS_VAR, ALPHA = 6, 3000, 0.0, 100.0, 1.0, 1.0
+    rng = np.random.default_rng(3)
+    true_means = (6.0 * (np.arange(K) - (K - 1) / 2.0)).astype(np.float32)
+    z = rng.integers(0, K, N)
+    x = torch.from_numpy((true_means[z] + rng.standard_normal(N)).astype(np.float32))
+
+    @genjax.gen
+    def generate_cluster(mean, var):
+        return genjax.normal(mean, var) @ "mean"
+
+    @genjax.gen
+    def generate_cluster_weight(alphas):
+        return genjax.dirichlet(alphas) @ "probs"
+    generate_datapoint = workloads.make_mixture(genjax, obs_scale=OBS_VAR)
+    key = genjax.key(32421)
+    means = torch.from_numpy(rng.normal(0.0, 8.0, K).astype(np.float32))
+    probs = torch.full((K,), 1.0 / K)
+    idx = torch.from_numpy(rng.integers(0, K, N).astype(np.int32))
+    for _ in range(12):
+        # -- cluster means: conjugate Normal update, one Vmap'd draw (update_cluster_means) --
+        counts = torch.bincount(idx.long(), minlength=K).float()
+        sums = torch.zeros(K).index_add_(0, idx.long(), x)
+        cm = sums / counts
+        post_mean = PRIOR_VAR / (PRIOR_VAR + OBS_VAR / counts) * cm + (OBS_VAR / counts) / (PRIOR_VAR + OBS_VAR / counts) * PRIOR_MEAN
+        post_var = 1.0 / (1.0 / PRIOR_VAR + counts / OBS_VAR)
+        key, sub = genjax.split(key)
+        ok = counts > 0
+        drawn = generate_cluster.vmap().simulate(sub, (jnp.array(torch.where(ok, post_mean, means).numpy()),
+                                                       jnp.array(torch.where(ok, post_var, torch.ones(K)).numpy()))
+                                                 ).get_choices()["mean"]
+        means = torch.where(ok, drawn.reshape(-1), means)
+        # -- assignments: enumerative Gibbs in ONE launch (update_datapoint_assignment) --
+        key, sub = genjax.split(key)
+        idx = gibbs_categorical(sub, generate_datapoint, (probs, means), C["obs"].set(x), "idx", K, batch_shape=(N,))
+        # -- weights: Dirichlet conjugate update (update_cluster_weights) --
+        key, sub = genjax.split(key)
+        new_alpha = ALPHA / K + torch.bincount(idx.long(), minlength=K).float()
+        probs = generate_cluster_weight.simulate(sub, (jnp.array(new_alpha.numpy()),)).get_retval().reshape(-1)
+    found = np.sort(means.numpy())
+    big = np.sort(means.numpy()[torch.bincount(idx.long(), minlength=K).numpy() > N // (4 * K)])
+    # every well-populated cluster sits on a true mean
+    assert all(np.min(np.abs(true_means - m)) < 0.5 for m in big), (found, true_means)
+    assert len(big) >= K - 2
+    assert abs(float(probs.sum()) - 1.0) < 1e-5
+
+
 def test_program_limits():
     """<= 64 live 32-bit values per particle (<= 32 for the interpreter, up to 64 for specialised
     kernels); a model that needs more fails loudly at trace time instead of spilling silently."""

@@ -621,7 +621,7 @@ def oracle_nlssm_mh_sweep(n, T, seed):
             okr = O.split(O.fold_in(okey, t - 1), 3)[1]
             cdf, total, M, shift = O.weight_cdf(olw)
             terms.append(M + math.log(total) - shift * math.log(2.0) - math.log(n))
-            otr = O.gather_trace(otr, O.ancestors(O.SYSTEMATIC, okr, cdf))
+            otr = O.gather_trace(otr, (O.ancestors_c if n > 20_000 else O.ancestors)(O.SYSTEMATIC, okr, cdf))
             gf = otr.get_gen_fn()
             otr, oacc, _ = O.rejuvenate(oks[2], otr, lambda k, tr_: gf.edit_static(k, tr_, oreq, tr_.get_args()))
             otr, olw = ost.importance(O.split(oks[0], n), oobs, (np.asarray(otr.get_retval(), np.float32), np.float32(t)))
@@ -629,7 +629,7 @@ def oracle_nlssm_mh_sweep(n, T, seed):
     olw = np.asarray(olw, np.float32)
     cdf, total, M, shift = O.weight_cdf(olw)
     terms.append(M + math.log(total) - shift * math.log(2.0) - math.log(n))
-    anc = O.ancestors(O.SYSTEMATIC, O.split(O.fold_in(okey, T - 1), 3)[1], cdf)
+    anc = (O.ancestors_c if n > 20_000 else O.ancestors)(O.SYSTEMATIC, O.split(O.fold_in(okey, T - 1), 3)[1], cdf)
     return {"x": x, "lw": olw, "acc": oacc, "terms": terms, "resampled": x[anc]}
 
 

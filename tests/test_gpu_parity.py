@@ -419,7 +419,7 @@ def test_hmc_reference_behaviour_and_oracle(gpu, n):
     parity.check_hmc(n=n)
 
 
-@pytest.mark.parametrize("n,capture,specialize", [(3000, False, False), (100_000, True, True)])
+@pytest.mark.parametrize("n,capture,specialize", [(3000, False, False), (100_000, True, True), (1_000_000, True, True)])
 def test_nonlinear_ssm_mh_sweep_matches_oracle(gpu, n, capture, specialize):
     """BASELINE config 3 as one (captured) sweep with the fused MH move between resampling and extension."""
     parity.check_nlssm_mh_sweep(n=n, T=5, capture=capture, specialize=specialize)

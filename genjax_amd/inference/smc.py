@@ -473,7 +473,6 @@ class BootstrapSweep:
         self.key = key
         self.ys = ys.to(dev).float().contiguous()
         assert self.ys.numel() >= T
-        self.x = [torch.zeros((n,), dtype=torch.float32, device=dev) for _ in range(2)]
         self.lw = torch.zeros((n,), dtype=torch.float32, device=dev)
         self.cdf = torch.zeros((n,), dtype=torch.int64, device=dev)
         self.anc = torch.zeros((n,), dtype=torch.int32, device=dev)
@@ -486,6 +485,19 @@ class BootstrapSweep:
             if self.fused else None
         obs0 = ChoiceMap.empty().set(self.obs_addr, self.ys[0])
         self.p_init = MinimalGenerate(self.init, (), obs0, (n,))
+        # the state is the model's return value: a scalar, or ONE vector of D floats per particle, stored
+        # struct-of-arrays as [D, n] and seen by models (and by state()) as the [n, D] view
+        if self.p_init.ro[0] != "out":
+            raise NotImplementedError("BootstrapSweep: the step model must return one array (scalar or vector state)")
+        dt, event, _slots = self.p_init.comp.outputs[self.p_init.ro[1]]
+        if dt != "f32" or len(event) > 1:
+            raise NotImplementedError("BootstrapSweep: the state must be a float scalar or a float vector")
+        self.event = tuple(event)
+        D = int(np.prod(event, dtype=np.int64)) if event else 1
+        self.x_store = [torch.zeros((D, n), dtype=torch.float32, device=dev) for _ in range(2)]
+        self.x = [s_.reshape(n) if not event else s_.t() for s_ in self.x_store]
+        if self.rejuvenate is not None and event:
+            raise NotImplementedError("BootstrapSweep(rejuvenate=...): scalar state only")
         g = Gathered(self.x[0], self.anc)
         if self.rejuvenate is None:
             self.p_step = MinimalGenerate(self.step, (g,) + tuple(self.step_extra(1)), obs0, (n,))
@@ -519,7 +531,6 @@ class BootstrapSweep:
         n = self.n
         k_prop = self.step_keys[t][0]
         obs = ChoiceMap.empty().set(self.obs_addr, self.ys[t])
-        xo = self.x[t % 2]
         if t == 0:
             prog, leaves = self.p_init, self.p_init.leaves((), obs)
         else:
@@ -527,7 +538,7 @@ class BootstrapSweep:
             prog = self.p_step
             leaves = prog.leaves((g,) + tuple(self.step_extra(t)), obs)
         bufs = [None] * len(prog.comp.outputs)
-        bufs[prog.ro[1]] = xo.reshape(1, n)
+        bufs[prog.ro[1]] = self.x_store[t % 2]
         bufs[prog.wo[1]] = self.lw.reshape(1, n)
         prog.comp.run(leaves, (n,), lazy_split(k_prop, n), red_out=self.partials, out_buffers=bufs)
 

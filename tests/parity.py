@@ -688,3 +688,41 @@ def check_dirichlet(n=2000, seed=1):
     # importance with the value constrained: w = log density
     tr2, w2 = m.importance(G.split(G.key(seed + 1), n), G.ChoiceMap.kw(probs=tr.get_choices()["probs"]), (1.0,))
     assert np.array_equal(w2.cpu().numpy(), s.cpu().numpy())
+
+
+# ---------------------------------------------------------------------------
+# a vector-valued state through BootstrapSweep: 2-D constant-velocity tracker
+# ---------------------------------------------------------------------------
+def check_vector_state_sweep(n=3000, T=6, seed=5, capture=False, specialize=False):
+    import genjax_amd as G
+    from genjax_amd import numpy as jnp
+    from genjax_amd.inference import smc
+
+    def mk(g, stack):
+        @g.gen
+        def init():
+            p = g.normal(0.0, 1.0) @ "p"
+            v = g.normal(0.0, 0.5) @ "v"
+            g.normal(p, 0.3) @ "y"
+            return stack(p, v)
+
+        @g.gen
+        def step(s):
+            p = g.normal(s[..., 0] + 0.1 * s[..., 1], 0.05) @ "p"
+            v = g.normal(s[..., 1], 0.1) @ "v"
+            g.normal(p, 0.3) @ "y"
+            return stack(p, v)
+        return init, step
+    init, step = mk(G, lambda a, b: jnp.stack([a, b]))
+    oi, ost = mk(O, lambda a, b: np.stack([a, b], axis=-1))
+    ys = (0.1 * np.arange(T) + np.random.default_rng(0).normal(0, 0.3, T)).astype(np.float32)
+    sw = smc.BootstrapSweep(init, step, n, T, specialize=specialize).prepare(G.key(seed), torch.from_numpy(ys))
+    if capture:
+        sw.capture()
+    sw.launch()
+    x, lw, anc = sw.state()
+    ref = oracle_bootstrap_sweep(oi, ost, n, T, ys, O.key(seed))
+    assert tuple(x.shape) == (n, 2)
+    assert np.array_equal(x.cpu().numpy(), ref["x"])
+    assert np.array_equal(anc.cpu().numpy(), ref["anc"])
+    assert sw.log_ml() == ref["log_ml"]

@@ -596,6 +596,12 @@ def test_sharded_importancek_global_resample_world1(gpu):
                           oc.get_particles().get_choices()["theta"][anc])
 
 
+@pytest.mark.parametrize("n,capture,specialize", [(3000, False, False), (300_000, True, True)])
+def test_vector_state_sweep_matches_oracle(gpu, n, capture, specialize):
+    """BootstrapSweep with a 2-D state (position, velocity), stored [2, n] struct-of-arrays."""
+    parity.check_vector_state_sweep(n=n, T=5, capture=capture, specialize=specialize)
+
+
 def test_full_size_sweep_properties(gpu):
     """BASELINE config 2 at full size (1e6 particles, T = 100): size-independent
     properties — sorted ancestors, determinism, and log-ML within Monte-Carlo

@@ -740,6 +740,11 @@ def test_mixture_model_gibbs_end_to_end():
     assert abs(float(probs.sum()) - 1.0) < 1e-5
 
 
+def test_vector_state_sweep_matches_oracle():
+    from tests import parity
+    parity.check_vector_state_sweep(n=2000, T=5)
+
+
 def test_program_limits():
     """<= 64 live 32-bit values per particle (<= 32 for the interpreter, up to 64 for specialised
     kernels); a model that needs more fails loudly at trace time instead of spilling silently."""

@@ -524,6 +524,52 @@ def gather_leaves(leaves: list, ancestors: torch.Tensor) -> list:
     return res
 
 
+_EW_CACHE: dict = {}
+
+
+def elementwise(fn, *xs):
+    """`fn(*xs)` evaluated per particle in ONE launch of a traced program: the float algebra the
+    combinators do between GFI launches (`new_w - score + w`, `lw + w`, a trace's score = sum of its
+    site scores, `logits - lse`) runs in the same kernels as everything else, not in torch ops.
+    xs: tensors sharing a leading batch shape (the longest one's), 0-d tensors, Python numbers."""
+    from . import tracer as T
+    vals = [materialize(v) for v in xs]
+    tens = [v for v in vals if isinstance(v, torch.Tensor) and v.ndim > 0]
+    if not tens:
+        out = fn(*[float(v) if isinstance(v, torch.Tensor) else v for v in vals])
+        return out
+    lead = max((tuple(v.shape) for v in tens), key=len)
+    nb = len(lead)
+    for v in tens:                       # the batch is the shape every tensor shares as a prefix
+        k = 0
+        s_ = tuple(v.shape)
+        while k < min(len(s_), nb) and s_[k] == lead[k]:
+            k += 1
+        nb = min(nb, k)
+    batch = tuple(lead[:nb])
+    flat = Flat()
+    tree = flat.add(tuple(vals))
+    specs = tuple(leaf_spec(v, batch) for v in flat.leaves)
+    code = getattr(fn, "__code__", None)
+    ck = (code, tree, specs)
+    ent = _EW_CACHE.get(ck) if code is not None else None
+    if ent is None:
+        tr = Tracing(len(batch))
+        with T.tracing(tr.graph):
+            syms = [tr.sym_leaf(sp, j) for j, sp in enumerate(specs)]
+            ins = unflatten(tree, lambda j: syms[j].value)
+            out = fn(*ins)
+            if isinstance(out, T.Expr) and tr.node_origin.get(id(out.node)) is not None:
+                out = out + 0.0           # a pure pass-through still gets its own buffer
+            oo = tr.emit_output(out)
+        ent = (Compiled(tr), oo)
+        if code is not None and not fn.__closure__:
+            _EW_CACHE[ck] = ent
+    comp, oo = ent
+    outs = comp.run(flat.leaves, batch, None)
+    return resolve(oo, outs, flat.leaves)
+
+
 def logsumexp_rows(lw: torch.Tensor) -> torch.Tensor:
     """logsumexp over the last axis (gmx_logsumexp); lw: [..., cols]."""
     be = _lib.get()

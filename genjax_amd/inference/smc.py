@@ -30,6 +30,13 @@ from ..static import DistributionTrace, StaticTrace
 from .sp import Algorithm, Target
 
 
+# the float algebra between launches, as traced one-launch programs (engine.elementwise)
+def _sub(a, b): return a - b
+def _add(a, b): return a + b
+def _sub_const(a, c): return a - c
+def _reweight(new_w, old_score, w): return new_w - old_score + w      # smc.py:383
+
+
 # ---------------------------------------------------------------------------
 # helpers over batched traces
 # ---------------------------------------------------------------------------
@@ -111,16 +118,17 @@ class ParticleCollection:
     def get_log_marginal_likelihood_estimate(self):
         """logsumexp(lw) - log N (smc.py:96-97) [+ accumulated offset]."""
         n = self.log_weights.shape[-1]
-        est = engine.logsumexp_rows(self.log_weights) - math.log(n)
+        est = engine.elementwise(_sub_const, engine.logsumexp_rows(self.log_weights), math.log(n))
         if self.log_ml_offset is not None:
-            est = est + self.log_ml_offset.value()
+            est = engine.elementwise(_add, est, self.log_ml_offset.value())
         return est
 
     def sample_index(self, key: Key):
         """Categorical draw proportional to the weights (smc.py:102-108): Gumbel-max
         over logits = lw - logsumexp(lw), gumbel counter = particle index."""
         lw = self.log_weights
-        logits = lw - engine.logsumexp_rows(lw).unsqueeze(-1)
+        lse = engine.logsumexp_rows(lw)
+        logits = engine.elementwise(_sub, lw, lse) if lw.ndim > 1 else engine.elementwise(_sub, lw, lse.reshape(()))
         return engine.categorical_rows(key, logits)
 
     def sample_particle(self, key: Key):
@@ -159,7 +167,7 @@ class SMCAlgorithm(Algorithm):
         key, sub_key = split(key)
         collection = algorithm.run_smc(key)
         particle = collection.sample_particle(sub_key)
-        estimate = particle.get_score() - collection.get_log_marginal_likelihood_estimate()
+        estimate = engine.elementwise(_sub, particle.get_score(), collection.get_log_marginal_likelihood_estimate())
         chm = target.filter_to_unconstrained(particle.get_choices())
         return estimate, chm
 
@@ -171,7 +179,7 @@ class SMCAlgorithm(Algorithm):
         key, sub_key = split(key)
         collection = algorithm.run_csmc(key, v)
         particle = collection.sample_particle(sub_key)
-        return particle.get_score() - collection.get_log_marginal_likelihood_estimate()
+        return engine.elementwise(_sub, particle.get_score(), collection.get_log_marginal_likelihood_estimate())
 
     def estimate_normalizing_constant(self, key, target):
         algorithm = ChangeTarget(self, target)
@@ -195,7 +203,7 @@ class Importance(SMCAlgorithm):
         if self.q is not None:                                           # smc.py:256-258
             log_weight, choice = self.q.random_weighted(sub_key, self.target)
             tr, score = self.target.importance(k1, _expand(choice))
-            return ParticleCollection(tr, score - _expand_leaf(log_weight), True)
+            return ParticleCollection(tr, engine.elementwise(_sub, score, _expand_leaf(log_weight)), True)
         tr, score = self.target.importance(k1, ChoiceMap.empty())
         return ParticleCollection(tr, score, True)
 
@@ -206,7 +214,7 @@ class Importance(SMCAlgorithm):
         q_score = self.q.estimate_logpdf(sub_key, retained, self.target) if self.q is not None else 0.0
         k1 = key.reshape((1,))
         tr, score = self.target.importance(k1, _expand(retained))
-        return ParticleCollection(tr, score - _expand_leaf(q_score), True)
+        return ParticleCollection(tr, engine.elementwise(_sub, score, _expand_leaf(q_score)), True)
 
 
 class ImportanceK(SMCAlgorithm):
@@ -225,7 +233,7 @@ class ImportanceK(SMCAlgorithm):
         if self.q is not None:                                           # smc.py:301-305
             log_weights, choices = self.q.random_weighted(sub_keys, self.target)
             trs, target_scores = self.target.importance(sub_keys, choices)
-            return ParticleCollection(trs, target_scores - log_weights, True)
+            return ParticleCollection(trs, engine.elementwise(_sub, target_scores, log_weights), True)
         trs, target_scores = self.target.importance(sub_keys, ChoiceMap.empty())
         return ParticleCollection(trs, target_scores, True)         # log_weights = scores - 0.0
 
@@ -241,7 +249,7 @@ class ImportanceK(SMCAlgorithm):
             stacked = _stack_chm(choices, retained)
             stacked_scores = torch.cat([log_scores, _expand_leaf(retained_score).to(log_scores.device)])
             trs, target_scores = self.target.importance(split(key, K), stacked)
-            return ParticleCollection(trs, target_scores - stacked_scores, True)
+            return ParticleCollection(trs, engine.elementwise(_sub, target_scores, stacked_scores), True)
         ignored, ignored_scores = self.target.importance(sub_keys, ChoiceMap.empty())
         retained_tr, retained_score = self.target.importance(key, retained)
         scores = torch.cat([ignored_scores, retained_score.reshape(1)])
@@ -264,7 +272,7 @@ class ChangeTarget(SMCAlgorithm):
         latents = self.prev.get_final_target().filter_to_unconstrained(particles.get_choices())
         sub_keys = split(key, self.get_num_particles())
         new_particles, new_weight = self.target.importance(sub_keys, latents)
-        this_weight = new_weight - particles.get_score() + collection.get_log_weights()   # smc.py:383
+        this_weight = engine.elementwise(_reweight, new_weight, particles.get_score(), collection.get_log_weights())   # smc.py:383
         return ParticleCollection(new_particles, this_weight, True, collection.log_ml_offset)
 
     def run_csmc(self, key, retained):
@@ -274,7 +282,7 @@ class ChangeTarget(SMCAlgorithm):
         latents = self.prev.get_final_target().filter_to_unconstrained(particles.get_choices())
         sub_keys = split(key, self.get_num_particles())
         new_particles, new_score = self.target.importance(sub_keys, latents)
-        this_weight = new_score - particles.get_score() + collection.get_log_weights()
+        this_weight = engine.elementwise(_reweight, new_score, particles.get_score(), collection.get_log_weights())
         return ParticleCollection(new_particles, this_weight, True)
 
 
@@ -418,7 +426,7 @@ def extend(key: Key, collection: ParticleCollection, step, step_args, observatio
     args = step_args(collection.get_particles()) if callable(step_args) else tuple(step_args)
     keys = split(key, n)
     tr, w = step.importance(keys, observations, args)
-    return ParticleCollection(tr, collection.get_log_weights() + w, True, collection.log_ml_offset)
+    return ParticleCollection(tr, engine.elementwise(_add, collection.get_log_weights(), w), True, collection.log_ml_offset)
 
 
 def rejuvenate(key: Key, collection: ParticleCollection, request, argdiffs=None) -> ParticleCollection:

@@ -85,13 +85,13 @@ class StaticTrace(Trace):
 
     def get_score(self):
         """sum of sub-trace scores in program order (static.py:102-105)."""
-        acc = None
-        for st in self.subtraces.values():
-            s = st.get_score()
-            acc = s if acc is None else acc + s
-        if acc is None:
+        scores = [st.get_score() for st in self.subtraces.values()]
+        if not scores:
             return 0.0
-        return acc
+        if len(scores) == 1:
+            return scores[0]
+        from .engine import elementwise
+        return elementwise(_sum_in_order, *scores)
 
     @property
     def batch_shape(self):
@@ -116,6 +116,13 @@ class StaticTrace(Trace):
         return tr
 
     get_inner_trace = get_subtrace
+
+
+def _sum_in_order(*terms):
+    acc = terms[0]
+    for t in terms[1:]:
+        acc = acc + t
+    return acc
 
 
 class VmapTrace(Trace):

@@ -325,3 +325,167 @@ def _tree_where(pred, a, b):
 
 
 lax = _Lax()
+
+
+# ---------------------------------------------------------------------------
+# the rest of the everyday jax.numpy surface, as compositions of the ops above (so they trace
+# into site programs; on concrete numpy / torch values they defer to the library)
+# ---------------------------------------------------------------------------
+float32, int32, bool_ = np.float32, np.int32, np.bool_
+pi, inf, nan, e = math.pi, math.inf, math.nan, math.e
+_LN2, _LN10 = math.log(2.0), math.log(10.0)
+round = _dispatch("round", "ROUND", torch.round, np.rint)          # noqa: A001  (round half to even, like jnp)
+rint = round
+
+
+def _lib_of(*xs):
+    return torch if builtins_any(_is_torch(x) for x in xs) else np
+
+
+def add(a, b): return a + b
+def subtract(a, b): return a - b
+def multiply(a, b): return a * b
+def divide(a, b): return a / b
+def negative(a): return -a
+
+
+true_divide = divide
+
+
+def expm1(x):
+    """exp(x) - 1.  Traced: the plain composition (no fused expm1 op in the site-program ISA)."""
+    return exp(x) - 1.0 if (is_symbolic(x) or T.is_tracing()) else _lib_of(x).expm1(x)
+
+
+def log2(x): return log(x) * (1.0 / _LN2) if is_symbolic(x) else _lib_of(x).log2(x)
+def log10(x): return log(x) * (1.0 / _LN10) if is_symbolic(x) else _lib_of(x).log10(x)
+def exp2(x): return exp(x * _LN2) if is_symbolic(x) else _lib_of(x).exp2(x)
+def tan(x): return sin(x) / cos(x) if is_symbolic(x) else _lib_of(x).tan(x)
+def sinh(x): return (exp(x) - exp(-x)) * 0.5 if is_symbolic(x) else _lib_of(x).sinh(x)
+def cosh(x): return (exp(x) + exp(-x)) * 0.5 if is_symbolic(x) else _lib_of(x).cosh(x)
+
+
+def logaddexp(a, b):
+    if is_symbolic(a) or is_symbolic(b):
+        m = maximum(a, b)
+        return m + log1p(exp(-abs(a - b)))
+    return _lib_of(a, b).logaddexp(torch.as_tensor(a), torch.as_tensor(b)) if _lib_of(a, b) is torch else np.logaddexp(a, b)
+
+
+def sign(x):
+    if is_symbolic(x):
+        return where(x > 0.0, 1.0, where(x < 0.0, -1.0, 0.0))
+    return _lib_of(x).sign(x)
+
+
+def isnan(x): return (x != x) if is_symbolic(x) else _lib_of(x).isnan(x)
+def isfinite(x): return ((x == x) & (abs(x) < inf)) if is_symbolic(x) else _lib_of(x).isfinite(x)
+
+
+def nan_to_num(x, nan=0.0):                                           # noqa: A002
+    return where(isnan(x), nan, x) if is_symbolic(x) else _lib_of(x).nan_to_num(x, nan=nan)
+
+
+def mod(a, b):
+    """Python / jnp convention: the result takes the sign of the divisor."""
+    if is_symbolic(a) or is_symbolic(b):
+        return a - floor(a / b) * b
+    return _lib_of(a, b).remainder(a, b)
+
+
+remainder = mod
+
+
+def _reduce(x, axis, step):
+    a = np.asarray(x, dtype=object)
+    if axis is None:
+        flat = a.reshape(-1)
+        acc = flat[0]
+        for v in flat[1:]:
+            acc = step(acc, v)
+        return acc
+    a = np.moveaxis(a, axis, -1)
+    out = np.empty(a.shape[:-1], dtype=object)
+    for idx in np.ndindex(out.shape):
+        acc = a[idx][0]
+        for v in a[idx][1:]:
+            acc = step(acc, v)
+        out[idx] = acc
+    return out if out.ndim else out.item()
+
+
+def max(x, axis=None):                                                # noqa: A001
+    if is_symbolic(x):
+        return _reduce(x, axis, maximum)
+    return (torch.amax(x) if axis is None else torch.amax(x, dim=axis)) if _is_torch(x) else np.max(x, axis=axis)
+
+
+def min(x, axis=None):                                                # noqa: A001
+    if is_symbolic(x):
+        return _reduce(x, axis, minimum)
+    return (torch.amin(x) if axis is None else torch.amin(x, dim=axis)) if _is_torch(x) else np.min(x, axis=axis)
+
+
+amax, amin = max, min
+
+
+def prod(x, axis=None):
+    if is_symbolic(x):
+        return _reduce(x, axis, lambda p, q: p * q)
+    return (torch.prod(x) if axis is None else torch.prod(x, dim=axis)) if _is_torch(x) else np.prod(x, axis=axis)
+
+
+def cumsum(x, axis=0):
+    if is_symbolic(x):
+        a = np.moveaxis(np.asarray(x, dtype=object), axis, 0)
+        out = np.empty(a.shape, dtype=object)
+        acc = None
+        for j in range(a.shape[0]):
+            acc = a[j] if acc is None else acc + a[j]
+            out[j] = acc
+        return np.moveaxis(out, 0, axis)
+    return torch.cumsum(x, dim=axis) if _is_torch(x) else np.cumsum(x, axis=axis)
+
+
+def dot(a, b):
+    if is_symbolic(a) or is_symbolic(b):
+        a, b = np.asarray(a, dtype=object), np.asarray(b, dtype=object)
+        if a.ndim != 1 or b.ndim != 1:
+            raise NotImplementedError("traced dot: vectors only")
+        return sum(a * b)
+    return _lib_of(a, b).dot(a, b)
+
+
+def var(x, axis=None):
+    m = mean(x, axis)
+    if axis is not None and is_symbolic(x):
+        raise NotImplementedError("traced var along an axis")
+    return mean(square(x - m), axis)
+
+
+def std(x, axis=None):
+    return sqrt(var(x, axis))
+
+
+def concatenate(xs, axis=0):
+    if builtins_any(is_symbolic(v) for v in xs):
+        return np.concatenate([np.atleast_1d(np.asarray(v, dtype=object)) for v in xs], axis=axis)
+    if builtins_any(_is_torch(v) for v in xs):
+        return torch.cat([torch.as_tensor(v) for v in xs], dim=axis)
+    return np.concatenate(xs, axis=axis)
+
+
+def reshape(x, shape):
+    return np.asarray(x, dtype=object).reshape(shape) if is_symbolic(x) else x.reshape(shape)
+
+
+def tile(x, reps):
+    return np.tile(np.asarray(x, dtype=object), reps) if is_symbolic(x) else (x.repeat(reps) if _is_torch(x) else np.tile(x, reps))
+
+
+def zeros_like(x):
+    return full(np.shape(x), 0.0) if is_symbolic(x) else (torch.zeros_like(x) if _is_torch(x) else np.zeros_like(x))
+
+
+def ones_like(x):
+    return full(np.shape(x), 1.0) if is_symbolic(x) else (torch.ones_like(x) if _is_torch(x) else np.ones_like(x))

@@ -745,6 +745,32 @@ def test_vector_state_sweep_matches_oracle():
     parity.check_vector_state_sweep(n=2000, T=5)
 
 
+def test_numpy_namespace_compositions():
+    """genjax_amd.numpy: the composed functions (log2, sinh, logaddexp, mod, max/min/prod/dot/cumsum/std over
+    traced vectors, ...) evaluated in one launch (engine.elementwise) against numpy float64."""
+    from genjax_amd.engine import elementwise
+    rng = np.random.default_rng(0)
+    x = rng.uniform(0.5, 2.0, 100).astype(np.float32)
+    y = rng.uniform(0.5, 2.0, 100).astype(np.float32)
+    cases = [
+        (lambda a, b: jnp.log2(a) + jnp.log10(b) + jnp.exp2(a * 0.5), lambda a, b: np.log2(a) + np.log10(b) + np.exp2(a * 0.5)),
+        (lambda a, b: jnp.sinh(a) - jnp.cosh(b) + jnp.tan(a * 0.3), lambda a, b: np.sinh(a) - np.cosh(b) + np.tan(a * 0.3)),
+        (lambda a, b: jnp.logaddexp(a, b) + jnp.sign(a - b) + jnp.mod(a * 3.0, b),
+         lambda a, b: np.logaddexp(a, b) + np.sign(a - b) + np.mod(a * 3.0, b)),
+        (lambda a, b: jnp.max(jnp.stack([a, b, a * b])) + jnp.min(jnp.stack([a, b])) + jnp.prod(jnp.stack([a, b]))
+         + jnp.dot(jnp.stack([a, b]), jnp.stack([b, a])) + jnp.cumsum(jnp.stack([a, b, a]))[2] + jnp.std(jnp.stack([a, b, a + b])),
+         lambda a, b: np.maximum(np.maximum(a, b), a * b) + np.minimum(a, b) + a * b + 2 * a * b + (2 * a + b)
+         + np.std(np.stack([a, b, a + b]), axis=0)),
+        (lambda a, b: jnp.expm1(a) + jnp.round(b * 3.0) + jnp.nan_to_num((b - b) / (b - b), nan=0.5) * 0.0 + jnp.clip(a, 0.8, 1.2),
+         lambda a, b: np.expm1(a) + np.rint(b * 3.0) + np.clip(a, 0.8, 1.2)),
+    ]
+    a64, b64 = x.astype(np.float64), y.astype(np.float64)
+    for fn, ref in cases:
+        got = elementwise(fn, torch.from_numpy(x), torch.from_numpy(y)).numpy()
+        want = ref(a64, b64)
+        assert np.max(np.abs(got - want) / (1 + np.abs(want))) < 2e-6
+
+
 def test_program_limits():
     """<= 64 live 32-bit values per particle (<= 32 for the interpreter, up to 64 for specialised
     kernels); a model that needs more fails loudly at trace time instead of spilling silently."""

@@ -290,6 +290,7 @@ def _bits(v, dt) -> int:
 
 
 # launches at least this large are worth the ~2 s one-off hiprtc compile
+JIT_MIN_WORK = 1 << 22          # cumulative particles after which a repeatedly launched program is specialised
 JIT_MIN_PARTICLES = 1 << 18
 
 
@@ -362,9 +363,12 @@ class Compiled:
         buffers are persistent bind every step once and re-launch the bindings."""
         be = self._be
         n = int(np.prod(batch, dtype=np.int64))
-        if (n >= JIT_MIN_PARTICLES or int(self.blob[3]) > 31) and not self._jit_tried and be.uses_streams \
-                and not torch.cuda.is_current_stream_capturing():
-            self.specialize()        # big ensembles, and programs the 31-register interpreter cannot hold
+        self._work = getattr(self, "_work", 0) + n
+        if (n >= JIT_MIN_PARTICLES or self._work >= JIT_MIN_WORK or int(self.blob[3]) > 31) and not self._jit_tried \
+                and be.uses_streams and not torch.cuda.is_current_stream_capturing():
+            # big ensembles, programs launched often enough to repay ~0.5 s of hiprtc, and programs the
+            # 31-register interpreter cannot hold
+            self.specialize()
         A = _lib.RunArgs()
         keep = []
         anc = None

@@ -14,7 +14,7 @@ args = (torch.from_numpy(probs).cuda(), torch.from_numpy(guess).cuda())
 chm = C["obs"].set(torch.from_numpy(x).cuda())
 out = {}
 from genjax_amd import engine
-engine.JIT_MIN_PARTICLES = 1 << 62          # no automatic specialisation: time the interpreter first
+engine.JIT_MIN_PARTICLES = engine.JIT_MIN_WORK = 1 << 62   # no automatic specialisation: time the interpreter first
 for mode in ("interpreter", "specialised"):
     if mode == "specialised":
         t0 = time.perf_counter()

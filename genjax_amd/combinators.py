@@ -377,8 +377,10 @@ class Scan(GenerativeFunction):
             sub_mode = "regen"
         elif mode == "update" or kind in ("update", "empty"):
             sub_mode = "update"
+        elif kind == "index" and isinstance(req.idx, int):
+            sub_mode = "index"
         else:
-            raise NotSupportedEditRequest(f"Scan.edit answers Update and Regenerate here (got {kind!r})")
+            raise NotSupportedEditRequest(f"Scan.edit answers Update, Regenerate and IndexRequest (got {kind!r})")
         carry, scanned_in = args
         n = self._length(scanned_in)
         inner_prev = prev["vmap"]
@@ -389,11 +391,28 @@ class Scan(GenerativeFunction):
         recs, outs = [], []
         weight = Expr(g.const_f32(0.0))
         score = Expr(g.const_f32(0.0))
+        key0 = key
+        # the carry each step STARTED from is not stored in the trace: the initial carry for step 0, and
+        # the previous step's stored carry-out after that — unchanged carries therefore cost nothing
         for t in range(n):
-            if key is not None:
+            if key is not None and sub_mode != "index":
                 key = Expr(g.add("KDERIVE", (key.node,), imm=t, dtype="key"))
             prev_t = _index_prev(inner_prev, t)
-            if sub_mode == "regen":
+            if sub_mode == "index":
+                # edit_index (scan.py:325-416): the sub-request acts on step idx with the caller's key; the
+                # carries are threaded on, so the steps after it are re-scored exactly where the edit
+                # reaches them (step idx + 1 for a Markov kernel) and nothing else is recomputed
+                if t == req.idx:
+                    sub = req.sub
+                    m_ = {"update": "update", "regen": "regen"}.get(sub.kind, "static_edit")
+                    con_ = sub.constraint if sub.kind == "update" else ChoiceMap.empty()
+                    rec, ret, w, _ = call_gen_fn(ctx, m_, self.kernel_gen_fn, key0, (carry, _tree_take(scanned_in, t)),
+                                                 con_, prev_t, sub, req_leaves, addr)
+                else:
+                    rec, ret, w, _ = call_gen_fn(ctx, "update", self.kernel_gen_fn, key0,
+                                                 (carry, _tree_take(scanned_in, t)), ChoiceMap.empty(), prev_t,
+                                                 carry_over, req_leaves, addr)
+            elif sub_mode == "regen":
                 rec, ret, w, _ = call_gen_fn(ctx, "regen", self.kernel_gen_fn, key, (carry, _tree_take(scanned_in, t)),
                                              ChoiceMap.empty(), prev_t, req, req_leaves, addr)
             else:

@@ -1164,6 +1164,28 @@ def scan_edit(sc: "Scan", k, trace: "VmapTrace", args, update: ChoiceMap = None,
     return VmapTrace(sc, _stack_last(slices), score, (carry, ys)), weight
 
 
+def scan_edit_index(sc: "Scan", k, trace: "VmapTrace", args, idx: int, edit):
+    """Scan.edit_index (scan.py:325-416): `edit(key, slice, args_slice) -> (new slice, w)` on step idx with the
+    caller's key, then an empty Update of step idx + 1 against the changed carry (its weight is added)."""
+    carry0, xs = args
+    n = sc._n(xs)
+    batch = np.asarray(k).shape[:-1]
+    slices = [_slice_last(trace.inner, t) for t in range(n)]
+    cin = carry0 if idx == 0 else slices[idx - 1].get_retval()[0]
+    new, w = edit(k, slices[idx], (cin, Scan._x(xs, idx)))
+    slices[idx] = new
+    w = np.broadcast_to(np.asarray(w, np.float32), batch).astype(np.float32)
+    if idx + 1 < n:
+        nxt, w2, _ = sc.kernel.update(k, slices[idx + 1], ChoiceMap.empty(), (new.get_retval()[0], Scan._x(xs, idx + 1)))
+        slices[idx + 1] = nxt
+        w = (w + np.broadcast_to(np.asarray(w2, np.float32), batch)).astype(np.float32)
+    score = np.zeros(batch, np.float32)
+    for sl in slices:
+        score = (score + np.broadcast_to(np.asarray(sl.get_score(), np.float32), batch)).astype(np.float32)
+    inner = _stack_last(slices)
+    return VmapTrace(sc, inner, score, (slices[-1].get_retval()[0], inner.get_retval()[1])), w
+
+
 class Repeat(Vmap):
     """repeat.py:28-42: n runs on the same arguments, keys split(key, n)."""
 

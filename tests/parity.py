@@ -430,6 +430,18 @@ def check_scan(n=257, T=6, seed=5):
     assert np.array_equal(r5.get_choices()["x"].cpu().numpy(), or5.get_choices()["x"])
     assert np.array_equal(wr5.cpu().numpy(), owr5)
     assert np.array_equal(r5.get_score().cpu().numpy(), or5.get_score())
+    # IndexRequest on a scan (scan.py:325-416): edit one step, re-score the next against the new carry
+    from genjax_amd import IndexRequest
+    for idx in (2, T - 1):
+        e5, we5, _, be5 = IndexRequest(idx, Regenerate(S["x"])).edit(G.split(G.key(seed + 6), n), r5, Diff.no_change(a5))
+        oe5, owe5 = O.scan_edit_index(osc5, O.split(O.key(seed + 6), n), or5, oa5, idx,
+                                      lambda k, sl, a: ostep.regenerate(k, sl, O.selection("x"), a)[:2])
+        xe, xo_ = e5.get_choices()["x"].cpu().numpy(), oe5.get_choices()["x"]
+        assert np.array_equal(xe, xo_) and np.array_equal(we5.cpu().numpy(), owe5)
+        assert np.array_equal(e5.get_score().cpu().numpy(), oe5.get_score())
+        old = r5.get_choices()["x"].cpu().numpy()
+        assert np.array_equal(np.delete(old, idx, axis=1), np.delete(xe, idx, axis=1))      # only step idx moved
+        assert isinstance(be5, IndexRequest) and be5.idx == idx
     # a Scan used directly: the chain starts at the caller's key
     sc = step.scan(n=3)
     t4 = sc.simulate(G.split(G.key(seed + 2), 16), (torch.zeros(16, device=G._lib.get().device), jnp.zeros(3)))

@@ -79,8 +79,23 @@ def cpu_baseline(n, T, ys, seed, budget_s=25.0):
     t_probe = run(2)                          # 2 steps to size the sample
     Tn = int(max(2, min(T, budget_s / max(t_probe / 2, 1e-6))))
     dt = run(Tn)
-    return {"value": n * Tn / dt, "unit": "particle-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{Tn} of {T} SMC steps x {n} particles, oracle/orc_sweep.c (OpenMP, gcc -O3 -march=native)"}
+    out = {"value": n * Tn / dt, "unit": "particle-steps/s", "cores": cores, "kind": "port",
+           "sample": f"{Tn} of {T} SMC steps x {n} particles, oracle/orc_sweep.c (OpenMP, gcc -O3 -march=native)"}
+    try:        # the same port on ONE core (SURVEY.md 8d asks for both), a few steps only
+        gomp = ctypes.CDLL("libgomp.so.1")
+        gomp.omp_set_num_threads(1)
+        t1 = run(2)
+        T1 = int(max(2, min(T, 4.0 / max(t1 / 2, 1e-6))))
+        out["one_core"] = {"value": n * T1 / run(T1), "sample": f"{T1} steps"}
+        gomp.omp_set_num_threads(cores)
+    except Exception as e:
+        out["one_core"] = {"error": repr(e)}
+    try:        # the reference's own backend, if this box happens to have it (it never travels with the repo)
+        import jax                                      # noqa: F401
+        out["jax_cpu"] = f"jax {jax.__version__} importable here but no restatement is timed this round"
+    except Exception:
+        out["jax_cpu"] = "jax not importable on this box: the reference's jax[cpu] path cannot be timed here"
+    return out
 
 
 def main():

@@ -356,6 +356,8 @@ class Compiled:
     def launch(self, bound):
         """Launch a binding made by `bind` (its buffers must still be alive: `bound` keeps them)."""
         be = self._be
+        if int(bound[0]) == 0:
+            return          # an empty batch (jax.vmap over zero keys): the outputs are empty tensors already
         be.check(be.c.gmx_program_run(self.handle, bound[0], bound[1], be.stream()), "gmx_program_run")
 
     def bind(self, leaves, batch: tuple, key: Key | None, red_out=None, index_offset=0, out_buffers=None):
@@ -463,11 +465,10 @@ def _prepare_input(src, kind, n, be):
         t = t.to(be.device)
     if kind in ("bcast", "dvec"):
         return t.contiguous()
-    if kind == "part":
-        rows = n
-        flat = t.reshape(rows, -1)
-    else:
-        flat = t.reshape(t.shape[0], -1)
+    rows = n if kind == "part" else t.shape[0]
+    if rows == 0:       # an empty batch: reshape(0, -1) is ambiguous; the launch is skipped anyway
+        return t.new_zeros((int(np.prod(t.shape[1:], dtype=np.int64)) if t.dim() > 1 else 1, 0))
+    flat = t.reshape(rows, -1)
     return flat.t().contiguous()       # [E, rows]; no copy when already SoA
 
 

@@ -622,3 +622,19 @@ def test_full_size_sweep_properties(gpu):
     assert int(sw.ws.view(torch.int32)[1].item()) == 0             # scan never hit its spin bound
     kal = workloads.kalman_log_ml(ys)
     assert abs(a - kal) < 0.05, (a, kal)
+
+
+def test_empty_batch_on_device(gpu):
+    """zero particles: no launch, empty results (a 0-size device tensor has a null pointer)"""
+    import genjax_amd as G
+    from genjax_amd import ChoiceMapBuilder as C
+
+    @G.gen
+    def m():
+        x = G.normal(0.0, 1.0) @ "x"
+        _ = G.normal(x, 1.0) @ "y"
+        return x
+    ks = G.split(G.key(0), 0)
+    tr, w = m.importance(ks, C.kw(y=1.0), ())
+    assert w.shape == (0,) and tr.get_score().shape == (0,) and w.is_cuda
+    assert m.simulate(ks, ()).get_retval().shape == (0,)

@@ -797,3 +797,31 @@ def test_program_limits():
         return acc2
     with pytest.raises(ProgramTooLarge):
         too_wide.simulate(genjax.split(genjax.key(0), 4), (torch.arange(4, dtype=torch.float32),))
+
+
+def test_empty_and_single_particle_batches():
+    """jax.vmap over zero keys gives empty arrays, not an error; one particle is just a batch of one"""
+    @genjax.gen
+    def m():
+        x = genjax.normal(0.0, 1.0) @ "x"
+        _ = genjax.normal(x, 1.0) @ "y"
+        return x
+    ks = genjax.split(genjax.key(0), 0)
+    tr, w = m.importance(ks, C.kw(y=1.0), ())
+    assert w.shape == (0,) and tr.get_score().shape == (0,) and tr.get_choices()["x"].shape == (0,)
+    assert m.simulate(ks, ()).get_retval().shape == (0,)
+    s, _ = m.assess(C.kw(x=torch.zeros(0), y=torch.zeros(0)), ())
+    assert s.shape == (0,)
+    k1 = genjax.split(genjax.key(0), 1)
+    tr1, w1 = m.importance(k1, C.kw(y=1.0), ())
+    otr, ow = _oracle_two_site().importance(O.split(O.key(0), 1), O.C.kw(y=np.float32(1.0)), ())
+    assert np.array_equal(w1.numpy(), ow) and np.array_equal(tr1.get_choices()["x"].numpy(), otr.get_choices()["x"])
+
+
+def _oracle_two_site():
+    @O.gen
+    def m():
+        x = O.normal(0.0, 1.0) @ "x"
+        _ = O.normal(x, 1.0) @ "y"
+        return x
+    return m

@@ -426,10 +426,19 @@ class Compiled:
             else:
                 buf = torch.empty((E, n), dtype=_STORE[dt], device=be.device)
             item = buf.element_size()
+            # a caller's buffer may be a [E, n] window of wider rows (stride(0) > n): element rows stay
+            # contiguous, which is all the kernel needs
+            row = n
+            if buf.dim() == 2 and buf.shape[0] == E and E > 1 and buf.stride(1) == 1:
+                row = buf.stride(0)
             for e, slot in enumerate(slots):
-                A.out_d[slot] = buf.data_ptr() + e * n * item
+                A.out_d[slot] = buf.data_ptr() + e * row * item
             if event == ():
                 outs.append(buf.reshape(batch))
+            elif row != n:
+                if len(event) != 1 or len(batch) != 1:
+                    raise ValueError("a strided output buffer is supported for one event axis and one batch axis")
+                outs.append(buf.t())
             else:
                 outs.append(buf.reshape(event + tuple(batch)).permute(
                     *range(len(event), len(event) + len(batch)), *range(len(event))))

@@ -109,10 +109,21 @@ class ShardedBootstrapSweep:
         if self.comm and self.cx is None:
             from .comm import make_comm
             self.cx = make_comm(self.dist, dev)
-        self._alloc_exchange()
         obs0 = ChoiceMap.empty().set(self.obs_addr, self.ys[0])
         self.p_init = MinimalGenerate(self.init, (), obs0, (n,))
-        g = Gathered(self.xext[0], self.idx)
+        # the state is the model's return value: a float scalar, or ONE vector of D floats per particle kept
+        # struct-of-arrays ([D, n + W*C]) so every component is one routed 4-byte leaf
+        if self.p_init.ro[0] != "out":
+            raise NotImplementedError("ShardedBootstrapSweep: the step model must return one array (scalar or vector state)")
+        dt, event, _slots = self.p_init.comp.outputs[self.p_init.ro[1]]
+        if dt != "f32" or len(event) > 1:
+            raise NotImplementedError("ShardedBootstrapSweep: the state must be a float scalar or a float vector")
+        self.event = tuple(event)
+        self.D = int(event[0]) if event else 1
+        if self.rejuvenate is not None and event:
+            raise NotImplementedError("ShardedBootstrapSweep(rejuvenate=...): scalar state only")
+        self._alloc_exchange()
+        g = Gathered(self._src(0), self.idx)
         if self.rejuvenate is None:
             self.p_step = MinimalGenerate(self.step, (g,) + tuple(self.step_extra(1)), obs0, (n,))
         else:
@@ -139,8 +150,9 @@ class ShardedBootstrapSweep:
     def _alloc_exchange(self):
         dev, n, W, C = _lib.get().device, self.n, self.world, self.capacity
         # extended state, double-buffered: [ n local | W*C received ]; ancestors index into it
-        self.xext = [torch.zeros((n + W * C,), dtype=torch.float32, device=dev) for _ in range(2)]
-        self.send = torch.zeros((W * C,), dtype=torch.float32, device=dev)
+        self.xrows = [torch.zeros((self.D, n + W * C), dtype=torch.float32, device=dev) for _ in range(2)]
+        self.xext = [r[0] for r in self.xrows]                    # component 0 (THE state when it is a scalar)
+        self.send = torch.zeros((self.D, W * C), dtype=torch.float32, device=dev)
         self.idx = torch.zeros((n,), dtype=torch.int32, device=dev)
         if self.rejuvenate is not None:
             # aext[t % 2][:n] = the MH-moved, resampled state step t is extended from; its tail receives the
@@ -148,6 +160,10 @@ class ShardedBootstrapSweep:
             self.aext = [torch.zeros((n + W * C,), dtype=torch.float32, device=dev) for _ in range(2)]
             self.send2 = torch.zeros((W * C,), dtype=torch.float32, device=dev)
         self._bound = [None] * self.T
+
+    def _src(self, tb):
+        """what the step model sees as the previous state (before the gather): [n + W*C] or [n + W*C, D]"""
+        return self.xrows[tb][0] if not self.event else self.xrows[tb].t()
 
     # ------------------------------------------------------------------
     def _bind_step(self, t):
@@ -163,7 +179,7 @@ class ShardedBootstrapSweep:
             prog, leaves = self.p_init, self.p_init.leaves((), obs)
         elif self.rejuvenate is None:
             prog = self.p_step
-            leaves = prog.leaves((Gathered(self.xext[(t - 1) % 2], self.idx),) + tuple(self.step_extra(t)), obs)
+            leaves = prog.leaves((Gathered(self._src((t - 1) % 2), self.idx),) + tuple(self.step_extra(t)), obs)
         else:
             # the MH move on the resampled particles of step t-1, keys split(k_mh, N)[g*n + i]
             prev_x, prev_a, cur_a = self.xext[(t - 1) % 2], self.aext[(t - 1) % 2], self.aext[t % 2]
@@ -181,7 +197,8 @@ class ShardedBootstrapSweep:
             prog = self.p_step
             leaves = prog.leaves((cur_a[:n],) + tuple(self.step_extra(t)), obs)
         bufs = [None] * len(prog.comp.outputs)
-        bufs[prog.ro[1]] = cur[:n].reshape(1, n)
+        rows_t = self.xrows[t % 2]
+        bufs[prog.ro[1]] = rows_t[:, :n]                 # [D, n] window of the [D, n + W*C] rows
         bufs[prog.wo[1]] = self.lw.reshape(1, n)
         # keys of the GLOBAL particle index: split(k_prop, N)[g*n + i]
         vm = prog.comp.bind(leaves, (n,), lazy_split(k_prop, self.N), red_out=self.partials, out_buffers=bufs,
@@ -201,11 +218,13 @@ class ShardedBootstrapSweep:
             recv2 = cur_a[n:]
         return {
             "prog": prog.comp, "vm": vm, "mh": mh, "step2": step2, "recv2": recv2,
-            "pmax": pmax, "recv": cur[n:], "keep": (kk, tot, leaves, m),
+            "pmax": pmax, "keep": (kk, tot, leaves, m),
             # the CDF kernel reduces the (all-reduced) block maxima itself and records the max in maxs[t]
             "cdf": (P(self.lw), n, self.shift, P(pmax), rows, P(m), P(self.cdf), P(self.total_d), P(self.ws)),
-            "step": (self.kind, kk, P(self.totals_all), P(self.plan), P(tot), P(self.cdf), g, W, n, C, P(cur),
-                     P(self.send), P(self.idx)),
+            # one routed leaf per state component: the same plan, D launches + D all-to-alls
+            "steps": [(self.kind, kk, P(self.totals_all), P(self.plan), P(tot), P(self.cdf), g, W, n, C,
+                       P(rows_t[d]), P(self.send[d]), P(self.idx)) for d in range(self.D)],
+            "recvs": [rows_t[d][n:] for d in range(self.D)],
         }
 
     def _step(self, t):
@@ -224,9 +243,10 @@ class ShardedBootstrapSweep:
             self.cx.all_gather(self.totals_all, self.total_d)            # 8 bytes per rank
         else:
             self.totals_all.copy_(self.total_d)
-        be.check(c.gmx_shard_step(*b["step"], st), "gmx_shard_step")   # slot boundaries + routing, one launch
-        if self.comm:
-            self.cx.all_to_all(b["recv"], self.send)                     # block s of recv <- block `me` of rank s
+        for d in range(self.D):
+            be.check(c.gmx_shard_step(*b["steps"][d], st), "gmx_shard_step")   # slot boundaries + routing, one launch
+            if self.comm:
+                self.cx.all_to_all(b["recvs"][d], self.send[d])          # block s of recv <- block `me` of rank s
         if b["step2"] is not None:
             be.check(c.gmx_shard_step(*b["step2"], st), "gmx_shard_step")
             if self.comm:
@@ -240,9 +260,9 @@ class ShardedBootstrapSweep:
             n = self.n
             obs = ChoiceMap.empty().set(self.obs_addr, self.ys[t])
             prog = self.p_step
-            leaves = prog.leaves((Gathered(self.xext[(t - 1) % 2], self.idx),) + tuple(self.step_extra(t)), obs)
+            leaves = prog.leaves((Gathered(self._src((t - 1) % 2), self.idx),) + tuple(self.step_extra(t)), obs)
             bufs = [None] * len(prog.comp.outputs)
-            bufs[prog.ro[1]] = self.xext[t % 2][:n].reshape(1, n)
+            bufs[prog.ro[1]] = self.xrows[t % 2][:, :n]
             bufs[prog.wo[1]] = self.lw.reshape(1, n)
             prog.comp.run(leaves, (n,), lazy_split(self.step_keys[t][0], self.N), red_out=self.partials,
                           out_buffers=bufs, index_offset=self.rank * n)
@@ -317,7 +337,9 @@ class ShardedBootstrapSweep:
         """this rank's resampled particles after the last step (global slots [g*n, (g+1)*n))"""
         self.finish()
         from ..engine import gather_leaves
-        return gather_leaves([self.xext[(self.T - 1) % 2]], self.idx)[0]
+        rows = self.xrows[(self.T - 1) % 2]
+        got = gather_leaves([rows[d] for d in range(self.D)], self.idx)
+        return got[0] if not self.event else torch.stack(got, dim=1)
 
 
 def sharded_importance_resample(target, k_per_rank: int, key: Key, dist, kind="systematic", capacity=None, comm=None):

@@ -46,7 +46,7 @@ def schools_main(out_path, k_per_rank, capacity):
     dist.destroy_process_group()
 
 
-def main(out_path, n_per_rank, T, capacity=None, mh=False):
+def main(out_path, n_per_rank, T, capacity=None, mh=False, vec=False):
     dist.init_process_group("gloo")
     import tests.hostsim as hs
     hs.install()
@@ -59,6 +59,12 @@ def main(out_path, n_per_rank, T, capacity=None, mh=False):
         req = G.StaticRequest({"x": G.Rejuvenate(G.normal, lambda chm: (chm.get_value(), 0.5))})
         sw = ShardedBootstrapSweep(init, step, n_per_rank, T, dist, capacity=capacity, rejuvenate=req,
                                    step_extra=lambda t: (float(t),)).prepare(G.key(7), torch.from_numpy(ys))
+    elif vec:   # a 2-vector state (position, velocity): one routed leaf per component
+        from genjax_amd import numpy as jnp
+        from tests import parity
+        init, step = parity.make_tracker(G, lambda a, b: jnp.stack([a, b]))
+        sw = ShardedBootstrapSweep(init, step, n_per_rank, T, dist, capacity=capacity).prepare(
+            G.key(5), torch.from_numpy(parity.tracker_data(T)))
     else:
         ys = workloads.lgssm_data(T)
         init, step = workloads.make_lgssm(G)
@@ -79,4 +85,5 @@ if __name__ == "__main__":
         schools_main(sys.argv[1], int(sys.argv[2]), int(sys.argv[4]) if int(sys.argv[4]) > 0 else None)
         sys.exit(0)
     cap = int(sys.argv[4]) if len(sys.argv) > 4 and int(sys.argv[4]) > 0 else None
-    main(sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), cap, mh=len(sys.argv) > 5 and sys.argv[5] == "mh")
+    mode = sys.argv[5] if len(sys.argv) > 5 else ""
+    main(sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), cap, mh=mode == "mh", vec=mode == "vec")

@@ -705,29 +705,39 @@ def check_dirichlet(n=2000, seed=1):
 # ---------------------------------------------------------------------------
 # a vector-valued state through BootstrapSweep: 2-D constant-velocity tracker
 # ---------------------------------------------------------------------------
+def make_tracker(g, stack):
+    @g.gen
+    def init():
+        p = g.normal(0.0, 1.0) @ "p"
+        v = g.normal(0.0, 0.5) @ "v"
+        g.normal(p, 0.3) @ "y"
+        return stack(p, v)
+
+    @g.gen
+    def step(s):
+        p = g.normal(s[..., 0] + 0.1 * s[..., 1], 0.05) @ "p"
+        v = g.normal(s[..., 1], 0.1) @ "v"
+        g.normal(p, 0.3) @ "y"
+        return stack(p, v)
+    return init, step
+
+
+def tracker_data(T):
+    return (0.1 * np.arange(T) + np.random.default_rng(0).normal(0, 0.3, T)).astype(np.float32)
+
+
+def oracle_tracker_sweep(n, T, seed):
+    oi, ost = make_tracker(O, lambda a, b: np.stack([a, b], axis=-1))
+    return oracle_bootstrap_sweep(oi, ost, n, T, tracker_data(T), O.key(seed))
+
+
 def check_vector_state_sweep(n=3000, T=6, seed=5, capture=False, specialize=False):
     import genjax_amd as G
     from genjax_amd import numpy as jnp
     from genjax_amd.inference import smc
-
-    def mk(g, stack):
-        @g.gen
-        def init():
-            p = g.normal(0.0, 1.0) @ "p"
-            v = g.normal(0.0, 0.5) @ "v"
-            g.normal(p, 0.3) @ "y"
-            return stack(p, v)
-
-        @g.gen
-        def step(s):
-            p = g.normal(s[..., 0] + 0.1 * s[..., 1], 0.05) @ "p"
-            v = g.normal(s[..., 1], 0.1) @ "v"
-            g.normal(p, 0.3) @ "y"
-            return stack(p, v)
-        return init, step
-    init, step = mk(G, lambda a, b: jnp.stack([a, b]))
-    oi, ost = mk(O, lambda a, b: np.stack([a, b], axis=-1))
-    ys = (0.1 * np.arange(T) + np.random.default_rng(0).normal(0, 0.3, T)).astype(np.float32)
+    init, step = make_tracker(G, lambda a, b: jnp.stack([a, b]))
+    oi, ost = make_tracker(O, lambda a, b: np.stack([a, b], axis=-1))
+    ys = tracker_data(T)
     sw = smc.BootstrapSweep(init, step, n, T, specialize=specialize).prepare(G.key(seed), torch.from_numpy(ys))
     if capture:
         sw.capture()

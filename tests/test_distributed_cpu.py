@@ -70,6 +70,27 @@ def test_sharded_mh_sweep_equals_single_process_oracle(tmp_path, world, capacity
     assert meta["reruns"] == (1 if capacity else 0), meta
 
 
+@pytest.mark.parametrize("world,capacity", [(2, 0), (2, 5)])
+def test_sharded_vector_state_sweep_equals_single_process_oracle(tmp_path, world, capacity):
+    """a 2-vector state (constant-velocity tracker): every component is one routed leaf (same plan, one
+    gmx_shard_step + one all-to-all each); equals the single-process oracle, also through the overflow re-run."""
+    n_total, T = 2048, 5
+    out = str(tmp_path / "shard_vec")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", env["MASTER_PORT"],
+           os.path.join(ROOT, "tests", "dist_worker.py"), out, str(n_total // world), str(T), str(capacity), "vec"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    x = np.load(out + ".npy")
+    meta = json.load(open(out + ".json"))
+    ref = parity.oracle_tracker_sweep(n_total, T, 5)
+    assert x.shape == (n_total, 2)
+    assert np.array_equal(x, ref["x"][ref["anc"]])
+    assert meta["log_ml"] == ref["log_ml"]
+    assert meta["reruns"] == (1 if capacity else 0), meta
+
+
 @pytest.mark.parametrize("world,capacity", [(2, 0), (4, 5)])
 def test_sharded_importancek_global_resample_equals_oracle(tmp_path, world, capacity):
     """BASELINE config 4 sharded (8-schools ImportanceK, ONE global systematic resample of a 10-latent

@@ -638,3 +638,25 @@ def test_empty_batch_on_device(gpu):
     tr, w = m.importance(ks, C.kw(y=1.0), ())
     assert w.shape == (0,) and tr.get_score().shape == (0,) and w.is_cuda
     assert m.simulate(ks, ()).get_retval().shape == (0,)
+
+
+def test_sharded_vector_state_world1_matches_oracle(gpu):
+    """ShardedBootstrapSweep with a 2-vector state at world size 1 on the device: each component is a routed
+    leaf written through a strided [D, n] window of the [D, n + W*C] extended state."""
+    import genjax_amd as G
+    from genjax_amd import numpy as jnp
+    from genjax_amd.inference.sharded import ShardedBootstrapSweep
+
+    class _Solo:
+        @staticmethod
+        def get_rank(): return 0
+        @staticmethod
+        def get_world_size(): return 1
+    n, T = 50_000, 5
+    init, step = parity.make_tracker(G, lambda a, b: jnp.stack([a, b]))
+    sw = ShardedBootstrapSweep(init, step, n, T, _Solo).prepare(G.key(5), torch.from_numpy(parity.tracker_data(T)))
+    sw.launch()
+    ref = parity.oracle_tracker_sweep(n, T, 5)
+    x = sw.state().cpu().numpy()
+    assert x.shape == (n, 2) and np.array_equal(x, ref["x"][ref["anc"]])
+    assert sw.log_ml() == ref["log_ml"]

@@ -89,3 +89,39 @@ def test_specialisation_compiles_offline():
     log = ctypes.create_string_buffer(4096)
     size = lib.gmx_specialize_dryrun(blob.ctypes.data, blob.size, log, 4096, None, 0)
     assert size > 0, log.value.decode()
+
+
+def test_entry_points_reject_null_arguments_before_any_launch():
+    """Host-side validation comes first: with null pointers every entry point returns non-zero and leaves
+    a message in gmx_last_error() — nothing reaches the GPU (runs on a box without one)."""
+    so = os.path.join(ROOT, "genjax_amd", "lib", "libgenmi_hip.so")
+    lib = ctypes.CDLL(so)
+    lib.gmx_last_error.restype = ctypes.c_char_p
+    N, i64, i32, u32 = ctypes.c_void_p(0), ctypes.c_int64, ctypes.c_int, ctypes.c_uint32
+    calls = {
+        "gmx_split": (N, i64(10), i64(0), N, N),
+        "gmx_split_rows": (N, i64(4), i64(4), N, N),
+        "gmx_fold_in": (N, u32(1), i64(10), N, N),
+        "gmx_random_bits": (N, i64(4), i64(4), N, N),
+        "gmx_logsumexp": (N, i64(3), i64(5), N, N, N, N),
+        "gmx_reduce_max": (N, i64(4), N, N),
+        "gmx_weight_cdf": (N, i64(10), i32(40), N, i64(0), N, N, N, N, N),
+        "gmx_ancestors": (i32(0), N, N, i64(10), ctypes.c_uint64(0), N, i64(10), i64(0), i64(10), N, N),
+        "gmx_resample": (i32(0), N, N, i64(10), i32(40), N, i64(0), N, N, N, N, N),
+        "gmx_gather": (N, N, N, ctypes.c_int32(3), N, i64(10), N),
+        "gmx_select": (N, N, N, N, N, ctypes.c_int32(1), i64(10), N),
+        "gmx_categorical_rows": (N, N, i64(4), i64(4), N, N),
+        "gmx_mh_accept": (N, N, i64(4), N, N),
+        "gmx_program_create": (N, ctypes.c_size_t(0), N),
+        "gmx_program_run": (N, i64(4), N, N),
+        "gmx_shard_plan": (i32(0), N, N, i32(0), i32(4), i64(10), N, N),
+        "gmx_shard_route": (i32(0), N, N, N, i32(0), i32(4), i64(10), i64(4), N, N, N, N),
+        "gmx_shard_step": (i32(0), N, N, N, N, N, i32(0), i32(4), i64(10), i64(4), N, N, N, N),
+        "gmx_graph_launch": (N, N),
+        "gmx_capture_end": (N, N),
+        "gmx_timer_start": (N, N),
+    }
+    for name, args in calls.items():
+        rc = getattr(lib, name)(*args)
+        assert rc != 0, name
+        assert name.encode() in lib.gmx_last_error(), (name, lib.gmx_last_error())

@@ -16,6 +16,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include <new>
 #include <string>
@@ -261,12 +263,74 @@ static std::string jit_source(const gmx_program* p) {
 
 extern "C" int gmx_program_is_specialized(const gmx_program* p) { return p && p->jit_fn ? 1 : 0; }
 
-extern "C" int gmx_program_specialize(gmx_program* p) {
-  if (!p) return gmx_fail("gmx_program_specialize: null program%s");
-  if (p->jit_fn) return 0;
-  if (!jit_enabled()) return gmx_fail("gmx_program_specialize: disabled by GENMI_JIT=0%s");
-  if (p->n_instr == 0 || p->n_instr > 8192) return gmx_fail("gmx_program_specialize: program size out of range%s");
-  std::string src = jit_source(p);
+// ---- on-disk cache of specialised code objects -----------------------------
+// hiprtc needs 0.5-2 s per program; the code object depends only on the generated translation unit,
+// the embedded device headers and the compiler, so it is kept under
+//   $GENMI_JIT_CACHE  (default $XDG_CACHE_HOME/genjax_amd/jit or $HOME/.cache/genjax_amd/jit; "0" disables)
+// as <fnv1a-64 of all three>.co, written to a temporary name and renamed (concurrent ranks are safe).
+static uint64_t fnv1a(uint64_t h, const char* s, size_t n) {
+  for (size_t i = 0; i < n; ++i) { h ^= (unsigned char)s[i]; h *= 0x100000001b3ull; }
+  return h;
+}
+
+static std::string jit_cache_dir() {
+  const char* e = getenv("GENMI_JIT_CACHE");
+  if (e && e[0] == '0' && e[1] == '\0') return "";
+  if (e && e[0]) return e;
+  const char* x = getenv("XDG_CACHE_HOME");
+  if (x && x[0]) return std::string(x) + "/genjax_amd/jit";
+  const char* h = getenv("HOME");
+  if (h && h[0]) return std::string(h) + "/.cache/genjax_amd/jit";
+  return "";
+}
+
+static void mkdirs(const std::string& d) {
+  for (size_t i = 1; i <= d.size(); ++i)
+    if (i == d.size() || d[i] == '/') (void)mkdir(d.substr(0, i).c_str(), 0755);
+}
+
+static std::string jit_cache_path(const std::string& src) {
+  std::string dir = jit_cache_dir();
+  if (dir.empty()) return "";
+  uint64_t h = fnv1a(0xcbf29ce484222325ull, src.data(), src.size());
+  for (int k = 0; k < GMX_EMBED_COUNT; ++k) h = fnv1a(h, gmx_embed_src[k], strlen(gmx_embed_src[k]));
+  int major = 0, minor = 0;
+  (void)hiprtcVersion(&major, &minor);
+  char buf[64];
+  snprintf(buf, sizeof(buf), "/%016llx_rtc%d.%d_abi%d.co", (unsigned long long)h, major, minor, GMX_ABI_VERSION);
+  return dir + buf;
+}
+
+static bool jit_cache_read(const std::string& path, std::vector<char>& code) {
+  if (path.empty()) return false;
+  FILE* f = fopen(path.c_str(), "rb");
+  if (!f) return false;
+  bool ok = false;
+  if (fseek(f, 0, SEEK_END) == 0) {
+    long n = ftell(f);
+    if (n > 0 && n < (64l << 20) && fseek(f, 0, SEEK_SET) == 0) {
+      code.resize((size_t)n);
+      ok = fread(code.data(), 1, (size_t)n, f) == (size_t)n;
+    }
+  }
+  fclose(f);
+  return ok;
+}
+
+static void jit_cache_write(const std::string& path, const std::vector<char>& code) {
+  if (path.empty()) return;
+  mkdirs(path.substr(0, path.rfind('/')));
+  char tmp[32];
+  snprintf(tmp, sizeof(tmp), ".tmp%ld", (long)getpid());
+  std::string t = path + tmp;
+  FILE* f = fopen(t.c_str(), "wb");
+  if (!f) return;                                   // a read-only cache directory is not an error
+  bool ok = fwrite(code.data(), 1, code.size(), f) == code.size();
+  ok = (fclose(f) == 0) && ok;
+  if (!ok || rename(t.c_str(), path.c_str()) != 0) (void)remove(t.c_str());
+}
+
+static int jit_compile(const std::string& src, std::vector<char>& code) {
   hiprtcProgram prog;
   const char* hdr_src[GMX_EMBED_COUNT];
   const char* hdr_name[GMX_EMBED_COUNT];
@@ -286,9 +350,13 @@ extern "C" int gmx_program_specialize(gmx_program* p) {
   }
   size_t cs = 0;
   hiprtcGetCodeSize(prog, &cs);
-  std::vector<char> code(cs);
+  code.resize(cs);
   hiprtcGetCode(prog, code.data());
   hiprtcDestroyProgram(&prog);
+  return 0;
+}
+
+static int jit_load(gmx_program* p, const std::vector<char>& code) {
   hipModule_t mod;
   GMX_HIP(hipModuleLoadData(&mod, code.data()));
   hipFunction_t fn;
@@ -297,6 +365,21 @@ extern "C" int gmx_program_specialize(gmx_program* p) {
   p->jit_module = mod;
   p->jit_fn = fn;
   p->jit_pp = jit_pp_for(p);
+  return 0;
+}
+
+extern "C" int gmx_program_specialize(gmx_program* p) {
+  if (!p) return gmx_fail("gmx_program_specialize: null program%s");
+  if (p->jit_fn) return 0;
+  if (!jit_enabled()) return gmx_fail("gmx_program_specialize: disabled by GENMI_JIT=0%s");
+  if (p->n_instr == 0 || p->n_instr > 8192) return gmx_fail("gmx_program_specialize: program size out of range%s");
+  const std::string src = jit_source(p);
+  const std::string path = jit_cache_path(src);
+  std::vector<char> code;
+  if (jit_cache_read(path, code) && jit_load(p, code) == 0) return 0;      // a damaged entry just recompiles
+  if (jit_compile(src, code)) return 1;
+  if (jit_load(p, code)) return 1;
+  jit_cache_write(path, code);
   return 0;
 }
 

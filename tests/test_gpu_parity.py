@@ -660,3 +660,38 @@ def test_sharded_vector_state_world1_matches_oracle(gpu):
     x = sw.state().cpu().numpy()
     assert x.shape == (n, 2) and np.array_equal(x, ref["x"][ref["anc"]])
     assert sw.log_ml() == ref["log_ml"]
+
+
+def test_specialised_code_object_cache(gpu, tmp_path, monkeypatch):
+    """GENMI_JIT_CACHE: the first specialisation writes <hash>.co, a second program with the same
+    instruction stream loads it instead of calling hiprtc, a damaged entry is recompiled; results identical."""
+    import time
+    import genjax_amd as G
+    from genjax_amd import ChoiceMapBuilder as C
+    monkeypatch.setenv("GENMI_JIT_CACHE", str(tmp_path))
+
+    def run():
+        @G.gen
+        def m(a):
+            x = G.normal(a, 1.25) @ "x"
+            _ = G.normal(x * x, 0.5) @ "y"
+            return x
+        from genjax_amd.static import MinimalGenerate
+        from genjax_amd.random import lazy_split
+        n = 4096
+        p = MinimalGenerate(m, (0.75,), C.kw(y=1.0), (n,))
+        t0 = time.perf_counter()
+        assert p.comp.specialize()
+        dt = time.perf_counter() - t0
+        outs = p.comp.run(p.leaves((0.75,), C.kw(y=1.0)), (n,), lazy_split(G.key(3), n))
+        return dt, [o.cpu().numpy() for o in outs]
+    t_cold, a = run()
+    files = list(tmp_path.glob("*.co"))
+    assert len(files) == 1 and files[0].stat().st_size > 1000
+    t_warm, b = run()
+    assert t_warm < 0.5 * t_cold, (t_cold, t_warm)
+    files[0].write_bytes(b"not a code object")
+    _, c = run()
+    assert files[0].stat().st_size > 1000          # rewritten after the recompile
+    for u, v, w in zip(a, b, c):
+        assert np.array_equal(u, v) and np.array_equal(u, w)

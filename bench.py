@@ -31,14 +31,17 @@ sys.path.insert(0, ROOT)
 
 N_PARTICLES = 1_000_000
 T_STEPS = 100
-VM_VALU_PER_WAVE = 321.4            # VALU instructions per 64 particles: SQ_INSTS_VALU / waves / 4 particles per
-                                    # thread (1285.7 per wave, profiles/r01_m_pmc_summary.txt; 377.2 at 1 per thread)
+VM_VALU_PER_WAVE = 376.2            # VALU instructions per 64 particles: SQ_INSTS_VALU / waves / 4 particles per
+                                    # thread (1504.7 per wave, profiles/r01_o_pmc_summary.txt: 1285.7 for the site
+                                    # program + 219 for the CDF tile statistics it now writes in its epilogue)
 VALU_PEAK_LANE_OPS = 256 * 4 * 32 * 2.4e9
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 # Algorithmic bytes per particle-step (8*D + 24 = 32 B, D = 1):
-#   k_vm          ancestor 4 + gathered state 4 in, state 4 + log-weight 4 out    = 16 B
-#   k_weight_cdf  log-weight 4 in, CDF 4 out (stored as u64: 8 actual)            =  8 B
-#   k_offspring   CDF 4 in, ancestor 4 out                                         =  8 B
+#   site program  ancestor 4 + gathered state 4 in, state 4 + log-weight 4 out    = 16 B
+#   CDF           log-weight 4 in, CDF 4 out                                       =  8 B
+#   offspring     CDF 4 in, ancestor 4 out                                         =  8 B
+# (what runs: the CDF is never materialised — the site program leaves two numbers per 1024-particle tile and
+#  k_offspring_tile rebuilds its tile's CDF in registers from the log-weights: 24 B of actual traffic)
 VM_BYTES_PER_PARTICLE = 16
 SWEEP_BYTES_PER_PARTICLE_STEP = 32
 

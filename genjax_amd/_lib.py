@@ -39,6 +39,9 @@ class RunArgs(Structure):
         ("key_inner", c_int64),
         ("index_offset", c_int64),
         ("red_out_d", c_void_p),
+        ("tile_agg_d", c_void_p),
+        ("tile_shift", c_int32),
+        ("reserved_", c_int32),
     ]
 
 
@@ -76,6 +79,7 @@ class Backend:
         c.gmx_program_grid.argtypes = [c_void_p, c_int64]
         c.gmx_program_grid.restype = c_int64
         c.gmx_program_run.argtypes = [c_void_p, c_int64, POINTER(RunArgs), c_void_p]
+        c.gmx_program_writes_tile_stats.argtypes = [c_void_p]
         c.gmx_logsumexp_workspace.argtypes = [c_int64, c_int64]
         c.gmx_logsumexp_workspace.restype = c_size_t
         c.gmx_logsumexp.argtypes = [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]
@@ -90,6 +94,9 @@ class Backend:
         c.gmx_resample_workspace.restype = c_size_t
         c.gmx_resample.argtypes = [c_int, POINTER(c_uint32), c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p,
                                    c_void_p, c_void_p, c_void_p, c_void_p]
+        c.gmx_tile_stats.argtypes = [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p]
+        c.gmx_resample_tiles.argtypes = [c_int, POINTER(c_uint32), c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p,
+                                         c_void_p, c_void_p, c_void_p]
         c.gmx_shard_plan_words.argtypes = [c_int]
         c.gmx_shard_plan_words.restype = c_size_t
         c.gmx_shard_plan.argtypes = [c_int, POINTER(c_uint32), c_void_p, c_int, c_int, c_int64, c_void_p, c_void_p,

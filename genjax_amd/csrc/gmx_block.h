@@ -56,3 +56,28 @@ __device__ __forceinline__ void gmx_red_lse(float* red_out, float* lds4, uint32_
     red_out[(size_t)rows + row] = s;
   }
 }
+
+// ---- 64-bit wave primitives and the fixed-point weight of the two-level CDF (include/genmi.h) ----
+__device__ __forceinline__ uint64_t shfl_up_u64(uint64_t v, int d) {
+  uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+  lo = __shfl_up(lo, d, GMX_WAVE);
+  hi = __shfl_up(hi, d, GMX_WAVE);
+  return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    lo = __shfl_xor(lo, m, GMX_WAVE); hi = __shfl_xor(hi, m, GMX_WAVE);
+    v += ((uint64_t)hi << 32) | lo;
+  }
+  return v;
+}
+
+// q = floor(exp(lw - ref) * 2^shift) as u64; NaN / negative / not below 2^63 (lw = +inf) -> 0
+__device__ __forceinline__ uint64_t weight_fixed(float lw, float ref, float scale) {
+  float w = gmx_expf(lw - ref);        // NaN if lw - ref is NaN
+  float q = w * scale;                 // exact: scale is a power of two
+  if (!(q >= 0.0f) || !(q < 0x1p63f)) return 0ull;
+  return (uint64_t)q;                  // truncation
+}

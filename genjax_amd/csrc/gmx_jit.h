@@ -19,11 +19,14 @@
 #include "gmx_block.h"
 #include "gmx_vm.h"
 
-template <int NDYN>
+template <int NDYN, int PPV>
 struct gmx_jit_ctx {
   const uint32_t* consts;   // constexpr constants (pool entries NDYN..)
   const gmx_run_args* A;
   float* lds4;
+  uint64_t* lds8;           // 4 x u64 scratch (tile statistics)
+  float red_x[PPV];         // OP_REDMAX operands of the thread's particles (-inf when inactive)
+  int cur;                  // which of the thread's particles this step works on
   uint32_t part;            // index of the 256-particle group this step works on (block partial row)
   uint32_t rows;            // number of 256-particle groups = ceil(n / 256)
   float acc_max;            // OP_REDMAX: running max over the thread's PP particles
@@ -35,10 +38,29 @@ struct gmx_jit_ctx {
   __device__ __forceinline__ void* out_ptr(uint32_t s) const { return A->out_d[s]; }
   __device__ __forceinline__ const void* tab_ptr(uint32_t s) const { return A->tab_d[s]; }
   // one block reduction and ONE partial row per workgroup (a max does not care how particles are grouped)
+  // With 4 particles per thread the workgroup IS one 1024-particle tile of the two-level CDF
+  // (include/genmi.h "Resampling"): when the caller asks (tile_agg_d), also write
+  // A_b = sum floor(exp(x - k_b ln 2) * 2^tile_shift), k_b = ceil(block max / ln 2), so no separate pass
+  // reads the log-weights again.
   __device__ __forceinline__ void red_max(float x, bool active) {
     const float m = active ? x : -gmx_inf();
+    red_x[cur] = m;
     acc_max = first ? m : gmx_fmax(acc_max, m);
-    if (last) gmx_red_max(A->red_out_d, lds4, blockIdx.x, acc_max, true);
+    if (last) {
+      const float bm = block_max(acc_max, lds4);
+      if (threadIdx.x == 0 && A->red_out_d) A->red_out_d[blockIdx.x] = bm;
+      if (PPV == 4 && A->tile_agg_d) {
+        const float scale = gmx_pow2i(A->tile_shift);
+        const float ref = gmx_tile_ref(gmx_tile_exp(bm));
+        uint64_t s = 0;
+#pragma unroll
+        for (int p = 0; p < PPV; ++p) s += weight_fixed(red_x[p], ref, scale);
+        s = wave_sum_u64(s);
+        if ((threadIdx.x & 63) == 0) lds8[threadIdx.x >> 6] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) A->tile_agg_d[blockIdx.x] = (lds8[0] + lds8[1]) + (lds8[2] + lds8[3]);
+      }
+    }
   }
   __device__ __forceinline__ void red_lse(float x, bool active) {
     gmx_red_lse(A->red_out_d, lds4, part, rows, x, active);
@@ -55,12 +77,13 @@ struct gmx_jit_ctx {
 #define GMX_JIT_BEGIN(NREGS, FULLV, NDYN, PPV)                                                   \
   extern "C" __global__ void __launch_bounds__(GMX_BLOCK) gmx_jit_kernel(int64_t n, const gmx_run_args A) { \
     __shared__ float lds4[4];                                                                    \
+    __shared__ uint64_t lds8[4];                                                                 \
     constexpr int PP = PPV;                                                                      \
     typedef gmx_regs_vgpr<NREGS> regs_t;                                                         \
-    typedef gmx_jit_ctx<NDYN> ctx_t;                                                             \
+    typedef gmx_jit_ctx<NDYN, PPV> ctx_t;                                                        \
     constexpr bool full_v = FULLV;                                                               \
     ctx_t ctx;                                                                                   \
-    ctx.consts = GMX_JIT_CONST; ctx.A = &A; ctx.lds4 = lds4; ctx.part = 0;                       \
+    ctx.consts = GMX_JIT_CONST; ctx.A = &A; ctx.lds4 = lds4; ctx.lds8 = lds8; ctx.part = 0; ctx.cur = 0; \
     ctx.rows = (uint32_t)((n + GMX_BLOCK - 1) / GMX_BLOCK);                       \
     regs_t R[PP];                                                                                \
     int64_t idx[PP];                                                                             \
@@ -73,7 +96,7 @@ struct gmx_jit_ctx {
 
 #define GMX_JIT_OP(W0, W1)                                                                       \
     _Pragma("unroll") for (int p = 0; p < PP; ++p) {                                             \
-      ctx.part = blockIdx.x * PP + p; ctx.first = (p == 0); ctx.last = (p == PP - 1);            \
+      ctx.part = blockIdx.x * PP + p; ctx.first = (p == 0); ctx.last = (p == PP - 1); ctx.cur = p; \
       gmx_vm_step<regs_t, full_v, gmx_cword<W0, W1>, ctx_t>(R[p], gmx_cword<W0, W1>(), idx[p], act[p], A, ctx); \
     }
 

@@ -120,6 +120,7 @@ struct gmx_program {
   uint32_t* code_d;
   uint32_t n_instr, n_regs, n_in, n_out, n_uni, n_tab, n_const, n_dyn;
   bool uses_key, uses_red, uses_lse, uses_gather, needs_full;
+  uint32_t n_redmax = 0;             // OP_REDMAX instructions (tile statistics need exactly one)
   std::vector<uint32_t> code_h;      // instruction words (host copy, for specialisation)
   std::vector<uint32_t> consts;      // pool entries n_dyn..
   hipModule_t jit_module = nullptr;  // specialised kernel (gmx_program_specialize)
@@ -188,7 +189,10 @@ static int parse_program(const uint32_t* blob, size_t n_words, gmx_program& P) {
       case OP_L_NORMAL: case OP_L_UNIFORM: case OP_L_BETA:
         ok = D(dst) && R(a) && R(b) && R(c); break;
       case OP_L_FLIP: case OP_L_BERNL: ok = D(dst) && R(a) && R(c); break;
-      case OP_REDMAX: case OP_REDLSE: ok = R(a); P.uses_red = true; if (op == OP_REDLSE) P.uses_lse = true; break;
+      case OP_REDMAX: case OP_REDLSE:
+        ok = R(a); P.uses_red = true;
+        if (op == OP_REDLSE) P.uses_lse = true; else ++P.n_redmax;
+        break;
       default: ok = false;
     }
     if (!ok) return gmx_fail("gmx_program_create: invalid instruction%s at pc %lld", "", pc);
@@ -262,6 +266,9 @@ static std::string jit_source(const gmx_program* p) {
 }
 
 extern "C" int gmx_program_is_specialized(const gmx_program* p) { return p && p->jit_fn ? 1 : 0; }
+extern "C" int gmx_program_writes_tile_stats(const gmx_program* p) {
+  return p && p->jit_fn && p->jit_pp == 4 && p->n_redmax == 1 && !p->uses_lse ? 1 : 0;
+}
 
 // ---- on-disk cache of specialised code objects -----------------------------
 // hiprtc needs 0.5-2 s per program; the code object depends only on the generated translation unit,
@@ -376,7 +383,10 @@ extern "C" int gmx_program_specialize(gmx_program* p) {
   const std::string src = jit_source(p);
   const std::string path = jit_cache_path(src);
   std::vector<char> code;
-  if (jit_cache_read(path, code) && jit_load(p, code) == 0) return 0;      // a damaged entry just recompiles
+  if (jit_cache_read(path, code)) {
+    if (jit_load(p, code) == 0) return 0;
+    (void)hipGetLastError();                 // a damaged entry just recompiles (and leaves no sticky error behind)
+  }
   if (jit_compile(src, code)) return 1;
   if (jit_load(p, code)) return 1;
   jit_cache_write(path, code);
@@ -441,6 +451,12 @@ extern "C" int gmx_program_run(const gmx_program* p, int64_t n, const gmx_run_ar
     return gmx_fail("gmx_program_run: program gathers but ancestors_d is null%s");
   if (p->uses_red && !args->red_out_d)
     return gmx_fail("gmx_program_run: program reduces but red_out_d is null%s");
+  if (args->tile_agg_d) {
+    if (!gmx_program_writes_tile_stats(p))
+      return gmx_fail("gmx_program_run: tile_agg_d is set but this program cannot write tile statistics "
+                      "(gmx_program_writes_tile_stats)%s");
+    if (args->tile_shift < 1 || args->tile_shift > 62) return gmx_fail("gmx_program_run: tile_shift out of range%s");
+  }
   if (p->uses_key) {
     int km = args->key_mode;
     if (km != GMX_KEY_ARRAY && km != GMX_KEY_SPLIT && km != GMX_KEY_ROWSPLIT && km != GMX_KEY_BCAST)
@@ -697,6 +713,7 @@ extern "C" int gmx_logsumexp(const float* lw_d, int64_t rows, int64_t cols, floa
 #define CDF_WAVES (CDF_THREADS / GMX_WAVE)
 #define CDF_VEC 4                      /* consecutive items per thread (one float4) */
 #define CDF_TILE (CDF_THREADS * CDF_VEC)
+static_assert(CDF_THREADS % 256 == 0 && CDF_VEC * 256 == 1024, "a definition tile of the CDF is 1024 items = 256 threads");
 #define CDF_ST_AGG 1ull
 #define CDF_ST_INC 2ull
 #define CDF_SPIN_LIMIT (1u << 22)
@@ -714,30 +731,6 @@ extern "C" size_t gmx_weight_cdf_workspace(int64_t n) {
   int64_t tiles = (n + CDF_TILE - 1) / CDF_TILE;
   if (tiles < 1) tiles = 1;
   return 16 + (size_t)tiles * 8;
-}
-
-__device__ __forceinline__ uint64_t shfl_up_u64(uint64_t v, int d) {
-  uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
-  lo = __shfl_up(lo, d, GMX_WAVE);
-  hi = __shfl_up(hi, d, GMX_WAVE);
-  return ((uint64_t)hi << 32) | lo;
-}
-__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) {
-    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
-    lo = __shfl_xor(lo, m, GMX_WAVE); hi = __shfl_xor(hi, m, GMX_WAVE);
-    v += ((uint64_t)hi << 32) | lo;
-  }
-  return v;
-}
-
-// q = floor(exp(lw - M) * 2^shift) as u64; NaN / negative -> 0
-__device__ __forceinline__ uint64_t weight_fixed(float lw, float M, float scale) {
-  float w = gmx_expf(lw - M);          // in [0, 1]; NaN if lw - M is NaN
-  float q = w * scale;                 // exact: scale is a power of two
-  if (!(q >= 0.0f)) return 0ull;
-  return (uint64_t)q;                  // truncation; q < 2^63
 }
 
 __global__ void __launch_bounds__(GMX_BLOCK)
@@ -795,11 +788,25 @@ k_weight_cdf(const float* __restrict__ lw, int64_t n, float scale, int max_mode,
   } else {
     M = *max_d;
   }
+  // ---- the two-level CDF: every 256 threads (4 waves, 1024 items) are one definition tile ----
+  constexpr int NG = CDF_WAVES / 4;
+  const int grp = wave >> 2;
+  float gm = -gmx_inf();
+#pragma unroll
+  for (int c = 0; c < CDF_VEC; ++c) gm = gmx_fmax(gm, x[c]);
+  gm = wave_max(gm);
+  __syncthreads();                       // s_max may still be read by the max_mode == 1 reduction above
+  if (lane == 0) s_max[wave] = gm;
+  __syncthreads();
+  const float m_b = gmx_fmax(gmx_fmax(s_max[4 * grp], s_max[4 * grp + 1]), gmx_fmax(s_max[4 * grp + 2], s_max[4 * grp + 3]));
+  const int32_t K = gmx_tile_exp(M);
+  const int32_t k_b = gmx_tile_exp(m_b);
+  const float ref_b = gmx_tile_ref(k_b);
   uint64_t q[CDF_VEC];
   uint64_t run = 0;
 #pragma unroll
   for (int c = 0; c < CDF_VEC; ++c) {
-    uint64_t w = (base + c < n) ? weight_fixed(x[c], M, scale) : 0ull;
+    uint64_t w = (base + c < n) ? weight_fixed(x[c], ref_b, scale) : 0ull;
     run += w;
     q[c] = run;                        // thread-local inclusive
   }
@@ -811,11 +818,19 @@ k_weight_cdf(const float* __restrict__ lw, int64_t n, float scale, int max_mode,
   }
   if (lane == 63) s_part[wave] = inc;
   __syncthreads();
-  uint64_t tile_agg = 0, wave_off = 0;
+  // per definition tile g: A_g (sum of its 4 waves) and G_g = A_g * 2^(k_g - K)
+  uint64_t tile_agg = 0, grp_off = 0, wave_off = 0;
 #pragma unroll
-  for (int w = 0; w < CDF_WAVES; ++w) {
-    if (w == wave) wave_off = tile_agg;
-    tile_agg += s_part[w];
+  for (int g = 0; g < NG; ++g) {
+    uint64_t A = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      if (g == grp && 4 * g + w == wave) wave_off = A;
+      A += s_part[4 * g + w];
+    }
+    const float mg = gmx_fmax(gmx_fmax(s_max[4 * g], s_max[4 * g + 1]), gmx_fmax(s_max[4 * g + 2], s_max[4 * g + 3]));
+    if (g == grp) grp_off = tile_agg;
+    tile_agg += gmx_tile_scale(A, gmx_tile_exp(mg), K);
   }
   // ---- chained scan across tiles (wave 0) ----
   if (wave == 0) {
@@ -872,16 +887,20 @@ k_weight_cdf(const float* __restrict__ lw, int64_t n, float scale, int max_mode,
   }
   __syncthreads();
   const uint64_t tile_prefix = s_prefix;
-  const uint64_t off = tile_prefix + wave_off + (inc - run);
+  const uint64_t off = tile_prefix + grp_off;              // mass before this definition tile
+  const uint64_t loc = wave_off + (inc - run);             // tile-local mass before this thread
+  uint64_t cv[CDF_VEC];
+#pragma unroll
+  for (int c = 0; c < CDF_VEC; ++c) cv[c] = off + gmx_tile_scale(loc + q[c], k_b, K);
   if (base + CDF_VEC <= n) {
     ulonglong2 a, b;
-    a.x = off + q[0]; a.y = off + q[1]; b.x = off + q[2]; b.y = off + q[3];
+    a.x = cv[0]; a.y = cv[1]; b.x = cv[2]; b.y = cv[3];
     reinterpret_cast<ulonglong2*>(cdf + base)[0] = a;
     reinterpret_cast<ulonglong2*>(cdf + base)[1] = b;
   } else {
 #pragma unroll
     for (int c = 0; c < CDF_VEC; ++c)
-      if (base + c < n) cdf[base + c] = off + q[c];
+      if (base + c < n) cdf[base + c] = cv[c];
   }
   if ((int64_t)tile == n_tiles - 1 && threadIdx.x == 0) *total_out = tile_prefix + tile_agg;
   // ---- leave the workspace zeroed: the last tile to finish cleans up ----
@@ -961,6 +980,17 @@ __device__ __forceinline__ u128 slot_threshold(int kind, gmx_key key, uint64_t u
   return mul64(((uint64_t)j << 23) + u, total);
 }
 
+// The exact predicate (runs for a handful of sources per launch).  Kept inline — a real call gives the kernel a
+// stack (scratch), which costs more at wave launch than the code size does — so callers on the hot path take
+// `kind` as a template constant: the systematic instantiation then carries no Threefry at all.
+__device__ __forceinline__ int64_t slots_below_exact(int kind, gmx_key key, uint64_t u0, uint64_t c, uint64_t D,
+                                                  uint64_t total, int64_t j, int64_t n_out) {
+  u128 X = mul64(c, D);
+  while (j > 0 && !gt128(X, slot_threshold(kind, key, u0, j - 1, total))) --j;
+  while (j < n_out && gt128(X, slot_threshold(kind, key, u0, j, total))) ++j;
+  return j;
+}
+
 // f(c) = number of slots j in [0, n_out) with P_j < c * D, i.e. with
 //   j + u_j / 2^23 < v,  v = c * n_out / total.
 // Fast path: v in f64 (relative error <= 2^-50) decides everything unless it is
@@ -970,15 +1000,26 @@ __device__ __forceinline__ int64_t slots_below(int kind, gmx_key key, uint64_t u
                                                uint64_t total, double n_over_total, double eps, int64_t n_out) {
   if (c == 0) return 0;
   if (c >= total) return n_out;
-  const double v = (double)c * n_over_total;
-  int64_t j0 = (int64_t)v;                       // floor (v >= 0)
-  if (j0 >= n_out) j0 = n_out - 1;
-  const double frac = v - (double)j0;
+  // (double)c as hi * 2^32 + lo: the product is exact and the sum rounds once, i.e. the correctly rounded
+  // conversion, in 3 instructions instead of the generic 64-bit sequence (this function is the hot loop)
+  const double v = ((double)(uint32_t)(c >> 32) * 4294967296.0 + (double)(uint32_t)c) * n_over_total;
+  int64_t j0;
+  double dj0;
+  if (n_out <= 0x7fffffffLL) {                   // uniform: 32-bit conversions
+    int32_t t = (int32_t)v;                      // floor (v >= 0), saturating
+    if (t >= (int32_t)n_out) t = (int32_t)n_out - 1;
+    j0 = t; dj0 = (double)t;
+  } else {
+    j0 = (int64_t)v;
+    if (j0 >= n_out) j0 = n_out - 1;
+    dj0 = (double)j0;
+  }
+  const double frac = v - dj0;
   bool exact = (frac < eps) || (frac > 1.0 - eps);
   int64_t j = j0;
   if (!exact) {
     // slots j < j0 are below; slot j0 is below iff u_{j0} / 2^23 < frac
-    uint64_t u = (kind == GMX_RESAMPLE_SYSTEMATIC) ? u0 : (uint64_t)(gmx_bits32(key, (uint64_t)j0) >> 9);
+    uint32_t u = (kind == GMX_RESAMPLE_SYSTEMATIC) ? (uint32_t)u0 : (gmx_bits32(key, (uint64_t)j0) >> 9);
     double du = (double)u * (1.0 / 8388608.0);
     double diff = frac - du;
     if (diff > eps) return j0 + 1;
@@ -986,10 +1027,7 @@ __device__ __forceinline__ int64_t slots_below(int kind, gmx_key key, uint64_t u
     exact = true;
   }
   // rare: within eps of a boundary -> exact integer predicate  P_j < X
-  u128 X = mul64(c, D);
-  while (j > 0 && !gt128(X, slot_threshold(kind, key, u0, j - 1, total))) --j;
-  while (j < n_out && gt128(X, slot_threshold(kind, key, u0, j, total))) ++j;
-  return j;
+  return slots_below_exact(kind, key, u0, c, D, total, j, n_out);
 }
 
 __global__ void __launch_bounds__(GMX_BLOCK)
@@ -1089,51 +1127,42 @@ extern "C" int gmx_ancestors(int kind, const uint32_t key[2], const uint64_t* cd
 
 // ---------------------------------------------------------------------------
 // fused resampling (systematic / stratified, one GPU): log-weights -> ancestors
-// in two streaming kernels with NO inter-block waiting:
-//   k_cdf_local        per tile: fixed-point weights, tile-local inclusive
-//                      CDF (workspace) and the tile aggregate
-//   k_offspring_local  every block scans the <= RS_MAX_TILES tile aggregates itself (<= 16 KB
-//                      from L2) to get its tile's global prefix and the total,
-//                      then assigns offspring exactly as k_offspring does.
-// The global CDF cdf_i = prefix[tile(i)] + local_i is the same integer the
-// chained scan (k_weight_cdf) produces, so ancestors are identical.
+// with NO inter-block waiting and no CDF in memory.  The two-level CDF needs
+// only two numbers per 1024-particle tile before anything global can be said:
+//   tile stats       m_b = max lw, A_b = sum floor(exp(lw - k_b ln 2) * 2^shift), k_b = ceil(m_b / ln 2)
+//                    written by the site program itself (a specialised kernel's
+//                    OP_REDMAX epilogue, gmx_run_args.tile_agg_d) or by k_tile_stats
+//   k_offspring_tile every block reads the <= RS_MAX_TILES tile stats (<= 24 KB from
+//                    L2): M = max m_b, G_b = A_b * 2^(k_b - K) (integer shifts), its tile's
+//                    prefix and the total; rebuilds its tile's local CDF from the
+//                    log-weights in registers; assigns offspring exactly as
+//                    k_offspring does.
+// cdf_i = prefix[tile(i)] + (L_i >> (K - k_b)) is the integer k_weight_cdf produces,
+// so ancestors are identical.
 // ---------------------------------------------------------------------------
-// Tile geometry (overridable with -D for tuning; measured on MI355X at n = 1e6, both kernels together:
-// 1024 threads / 4096-item tiles 16.4 us, 512 / 2048 15.7 us, 256 / 1024 13.4 us — small tiles put ~4
-// blocks on every CU, so one block's load latency hides behind another's scan).
 #ifndef RS_THREADS
 #define RS_THREADS 256                 /* 4 waves per tile                         */
 #endif
-#define RS_TILE (RS_THREADS * CDF_VEC) /* 1024 log-weights per tile                */
+#define RS_TILE (RS_THREADS * CDF_VEC) /* 1024 log-weights per tile = one definition tile of the CDF */
 #ifndef RS_MAX_TILES
 #define RS_MAX_TILES 2048              /* n <= 2^21                                */
 #endif
-#ifndef RS_SRC_PER_THREAD
-#define RS_SRC_PER_THREAD 4            /* k_offspring_local: sources per thread (even) */
-#endif
-
-static_assert(RS_TILE % (GMX_BLOCK * RS_SRC_PER_THREAD) == 0, "an offspring block must lie inside one tile");
-static_assert(RS_MAX_TILES % GMX_BLOCK == 0 && RS_SRC_PER_THREAD % 2 == 0, "tile table / vector load shape");
+static_assert(RS_TILE == 1024 && RS_THREADS == GMX_BLOCK, "resampling tiles are the CDF's definition tiles");
+static_assert(RS_MAX_TILES % GMX_BLOCK == 0, "tile table shape");
 
 struct rs_ws {                 // layout of the gmx_resample workspace
-  uint64_t agg[RS_MAX_TILES];  // tile aggregates
-  uint64_t local[1];           // n tile-local inclusive CDF entries
+  uint64_t agg[RS_MAX_TILES];  // A_b
+  float tmax[RS_MAX_TILES];    // m_b
 };
 
-extern "C" size_t gmx_resample_workspace(int64_t n) {
-  if (n < 1) n = 1;
-  return sizeof(uint64_t) * (RS_MAX_TILES + (size_t)n + 8);
-}
+extern "C" size_t gmx_resample_workspace(int64_t) { return sizeof(rs_ws); }
 
-// max_mode: 0 = read *max_d; 1 = reduce the n_part dense block maxima
 __global__ void __launch_bounds__(RS_THREADS)
-k_cdf_local(const float* __restrict__ lw, int64_t n, float scale, int max_mode,
-            const float* __restrict__ partials, int64_t n_part, float* __restrict__ max_d, rs_ws* ws) {
-  __shared__ uint64_t s_part[RS_THREADS / GMX_WAVE];
-  __shared__ float s_max[RS_THREADS / GMX_WAVE];
+k_tile_stats(const float* __restrict__ lw, int64_t n, float scale, float* __restrict__ tmax, uint64_t* __restrict__ agg) {
+  __shared__ float lds4[4];
+  __shared__ uint64_t s_sum[RS_THREADS / GMX_WAVE];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint32_t tile = blockIdx.x;
-  const int64_t base = (int64_t)tile * RS_TILE + (int64_t)threadIdx.x * CDF_VEC;
+  const int64_t base = (int64_t)blockIdx.x * RS_TILE + (int64_t)threadIdx.x * CDF_VEC;
   float x[CDF_VEC];
   if (base + CDF_VEC <= n) {
     float4 v = *reinterpret_cast<const float4*>(lw + base);
@@ -1142,35 +1171,68 @@ k_cdf_local(const float* __restrict__ lw, int64_t n, float scale, int max_mode,
 #pragma unroll
     for (int c = 0; c < CDF_VEC; ++c) x[c] = (base + c < n) ? lw[base + c] : -gmx_inf();
   }
-  float M;
-  if (max_mode == 1) {
-    float m = -gmx_inf();
-    for (int64_t j0 = 0; j0 < n_part; j0 += 4 * RS_THREADS) {
-      float v[4];
+  float m = -gmx_inf();
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        int64_t j = j0 + (int64_t)r * RS_THREADS + threadIdx.x;
-        v[r] = (j < n_part) ? partials[j] : -gmx_inf();
-      }
-      m = gmx_fmax(gmx_fmax(m, gmx_fmax(v[0], v[1])), gmx_fmax(v[2], v[3]));
-    }
-    m = wave_max(m);
-    if (lane == 0) s_max[wave] = m;
-    __syncthreads();
-    m = s_max[0];
+  for (int c = 0; c < CDF_VEC; ++c) m = gmx_fmax(m, x[c]);
+  m = block_max(m, lds4);
+  const float ref = gmx_tile_ref(gmx_tile_exp(m));
+  uint64_t run = 0;
 #pragma unroll
-    for (int w = 1; w < RS_THREADS / GMX_WAVE; ++w) m = gmx_fmax(m, s_max[w]);
-    M = m;
-    if (tile == 0 && threadIdx.x == 0) *max_d = M;
-  } else {
-    M = *max_d;
+  for (int c = 0; c < CDF_VEC; ++c) run += (base + c < n) ? weight_fixed(x[c], ref, scale) : 0ull;
+  run = wave_sum_u64(run);
+  if (lane == 0) s_sum[wave] = run;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    tmax[blockIdx.x] = m;
+    agg[blockIdx.x] = (s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]);
   }
+}
+
+// One thread owns 4 consecutive sources (one float4 of log-weights); a block is one tile.
+template <int kind>
+__global__ void __launch_bounds__(GMX_BLOCK)
+k_offspring_tile(uint32_t k0, uint32_t k1, uint32_t u0_host, const float* __restrict__ lw,
+                 const float* __restrict__ tmax, const uint64_t* __restrict__ agg, int64_t n, int n_tiles, float scale,
+                 float* __restrict__ max_out, uint64_t* __restrict__ total_out, int32_t* __restrict__ anc) {
+  __shared__ uint64_t s_below[4], s_all[4], s_scan[4];
+  __shared__ float s_max[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int my_tile = (int)blockIdx.x;
+  const int64_t i0 = (int64_t)my_tile * RS_TILE + (int64_t)threadIdx.x * CDF_VEC;
+  // issue every load first
+  float x[CDF_VEC];
+  if (i0 + CDF_VEC <= n) {
+    float4 v = *reinterpret_cast<const float4*>(lw + i0);
+    x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
+  } else {
+#pragma unroll
+    for (int c = 0; c < CDF_VEC; ++c) x[c] = (i0 + c < n) ? lw[i0 + c] : -gmx_inf();
+  }
+  constexpr int PER = RS_MAX_TILES / GMX_BLOCK;
+  uint64_t ta[PER];
+  float tm[PER];
+#pragma unroll
+  for (int r = 0; r < PER; ++r) {
+    const int t = r * GMX_BLOCK + (int)threadIdx.x;
+    ta[r] = 0ull; tm[r] = -gmx_inf();
+    if (r * GMX_BLOCK < n_tiles) {               // uniform: rows of the table that exist
+      ta[r] = (t < n_tiles) ? agg[t] : 0ull;
+      tm[r] = (t < n_tiles) ? tmax[t] : -gmx_inf();
+    }
+  }
+  const int32_t k_b = gmx_tile_exp(tmax[my_tile]);
+  const float ref_b = gmx_tile_ref(k_b);
+  // phase 1: the global max, and the wave totals of this tile's local weights
+  float M = -gmx_inf();
+#pragma unroll
+  for (int r = 0; r < PER; ++r)
+    if (r * GMX_BLOCK < n_tiles) M = gmx_fmax(M, tm[r]);
+  M = wave_max(M);
   uint64_t q[CDF_VEC];
   uint64_t run = 0;
 #pragma unroll
   for (int c = 0; c < CDF_VEC; ++c) {
-    uint64_t w = (base + c < n) ? weight_fixed(x[c], M, scale) : 0ull;
-    run += w;
+    run += (i0 + c < n) ? weight_fixed(x[c], ref_b, scale) : 0ull;
     q[c] = run;
   }
   uint64_t inc = run;
@@ -1179,131 +1241,125 @@ k_cdf_local(const float* __restrict__ lw, int64_t n, float scale, int max_mode,
     uint64_t t = shfl_up_u64(inc, d);
     if (lane >= d) inc += t;
   }
-  if (lane == 63) s_part[wave] = inc;
+  if (lane == 0) s_max[wave] = M;
+  if (lane == 63) s_scan[wave] = inc;
   __syncthreads();
-  uint64_t tile_agg = 0, wave_off = 0;
+  M = gmx_fmax(gmx_fmax(s_max[0], s_max[1]), gmx_fmax(s_max[2], s_max[3]));
+  uint64_t wave_off = 0;
 #pragma unroll
-  for (int w = 0; w < RS_THREADS / GMX_WAVE; ++w) {
-    if (w == wave) wave_off = tile_agg;
-    tile_agg += s_part[w];
-  }
-  const uint64_t off = wave_off + (inc - run);
-  if (base + CDF_VEC <= n) {
-    ulonglong2 a, b;
-    a.x = off + q[0]; a.y = off + q[1]; b.x = off + q[2]; b.y = off + q[3];
-    reinterpret_cast<ulonglong2*>(ws->local + base)[0] = a;
-    reinterpret_cast<ulonglong2*>(ws->local + base)[1] = b;
-  } else {
-#pragma unroll
-    for (int c = 0; c < CDF_VEC; ++c)
-      if (base + c < n) ws->local[base + c] = off + q[c];
-  }
-  if (threadIdx.x == 0) ws->agg[tile] = tile_agg;
-}
-
-// One thread owns RS_SRC_PER_THREAD consecutive sources (two 16-byte loads of the
-// local CDF): a block covers 1024 sources = a quarter tile, so only n/1024 blocks
-// re-read the tile aggregates.
-__global__ void __launch_bounds__(GMX_BLOCK)
-k_offspring_local(int kind, uint32_t k0, uint32_t k1, uint32_t u0_host, const rs_ws* __restrict__ ws, int64_t n,
-                  int n_tiles, uint64_t* __restrict__ total_out, int32_t* __restrict__ anc) {
-  __shared__ uint64_t s_below[4], s_all[4];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t i0 = ((int64_t)blockIdx.x * GMX_BLOCK + threadIdx.x) * RS_SRC_PER_THREAD;
-  const int my_tile = (int)(((int64_t)blockIdx.x * GMX_BLOCK * RS_SRC_PER_THREAD) / RS_TILE);
-  // issue every load first
+  for (int w = 0; w < 4; ++w) wave_off += (w < wave) ? s_scan[w] : 0ull;
+  const uint64_t loc = wave_off + (inc - run);          // tile-local mass before this thread's sources
+  // phase 2: G_t = A_t * 2^(k_t - K) for every tile -> this tile's prefix and the total
+  const int32_t K = gmx_tile_exp(M);
   uint64_t below = 0, all = 0;
 #pragma unroll
-  for (int r = 0; r < RS_MAX_TILES / GMX_BLOCK; ++r) {
-    int t = r * GMX_BLOCK + (int)threadIdx.x;
-    uint64_t a = (t < n_tiles) ? ws->agg[t] : 0ull;
-    all += a;
-    below += (t < my_tile) ? a : 0ull;
-  }
-  uint64_t loc[RS_SRC_PER_THREAD];
-  if (i0 + RS_SRC_PER_THREAD <= n) {
-#pragma unroll
-    for (int c = 0; c < RS_SRC_PER_THREAD / 2; ++c) {
-      ulonglong2 a = reinterpret_cast<const ulonglong2*>(ws->local + i0)[c];
-      loc[2 * c] = a.x; loc[2 * c + 1] = a.y;
+  for (int r = 0; r < PER; ++r) {
+    if (r * GMX_BLOCK < n_tiles) {
+      const int t = r * GMX_BLOCK + (int)threadIdx.x;
+      const uint64_t G = gmx_tile_scale(ta[r], gmx_tile_exp(tm[r]), K);
+      all += G;
+      below += (t < my_tile) ? G : 0ull;
     }
-  } else {
-#pragma unroll
-    for (int c = 0; c < RS_SRC_PER_THREAD; ++c) loc[c] = (i0 + c < n) ? ws->local[i0 + c] : 0ull;
   }
-  const uint64_t loc_prev = (lane == 0 && i0 < n && (i0 % RS_TILE) != 0) ? ws->local[i0 - 1] : 0ull;
   below = wave_sum_u64(below);
   all = wave_sum_u64(all);
   if (lane == 0) { s_below[wave] = below; s_all[wave] = all; }
   __syncthreads();
   const uint64_t prefix = (s_below[0] + s_below[1]) + (s_below[2] + s_below[3]);
   const uint64_t total = (s_all[0] + s_all[1]) + (s_all[2] + s_all[3]);
-  if (blockIdx.x == 0 && threadIdx.x == 0) *total_out = total;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { *total_out = total; *max_out = M; }
   gmx_key key; key.k0 = k0; key.k1 = k1;
   const uint64_t u0 = (uint64_t)u0_host;          // bits32(key, 0) >> 9, evaluated on the host
   const uint64_t D = (uint64_t)n << 23;
   if (total == 0) {       // no mass at all (all weights -inf / NaN): every slot maps to the last particle
 #pragma unroll
-    for (int c = 0; c < RS_SRC_PER_THREAD; ++c)
+    for (int c = 0; c < CDF_VEC; ++c)
       if (i0 + c < n) anc[i0 + c] = (int32_t)(n - 1);
     return;
   }
   const double n_over_total = (double)n / (double)total;
   const double eps = (double)n * 0x1p-44 + 0x1p-40;
-  int64_t e[RS_SRC_PER_THREAD];
+  int64_t e[CDF_VEC];
 #pragma unroll
-  for (int c = 0; c < RS_SRC_PER_THREAD; ++c) {
-    const uint64_t c_hi = (i0 + c < n) ? prefix + loc[c] : total;
+  for (int c = 0; c < CDF_VEC; ++c) {
+    const uint64_t c_hi = (i0 + c < n) ? prefix + gmx_tile_scale(loc + q[c], k_b, K) : total;
     e[c] = slots_below(kind, key, u0, c_hi, D, total, n_over_total, eps, n);
   }
   // lower bound of the thread's first source = upper bound of the previous thread's last one
-  uint32_t e_lo = (uint32_t)e[RS_SRC_PER_THREAD - 1], e_hi32 = (uint32_t)((uint64_t)e[RS_SRC_PER_THREAD - 1] >> 32);
+  uint32_t e_lo = (uint32_t)e[CDF_VEC - 1], e_hi32 = (uint32_t)((uint64_t)e[CDF_VEC - 1] >> 32);
   e_lo = __shfl_up(e_lo, 1, GMX_WAVE); e_hi32 = __shfl_up(e_hi32, 1, GMX_WAVE);
   int64_t s = (int64_t)(((uint64_t)e_hi32 << 32) | e_lo);
-  if (lane == 0) s = slots_below(kind, key, u0, prefix + loc_prev, D, total, n_over_total, eps, n);
-#pragma unroll
-  for (int c = 0; c < RS_SRC_PER_THREAD; ++c) {
-    if (i0 + c < n)
-      for (int64_t j = s; j < e[c]; ++j) anc[j] = (int32_t)(i0 + c);
-    s = e[c];
-  }
+  if (lane == 0)
+    s = slots_below(kind, key, u0, prefix + gmx_tile_scale(loc, k_b, K), D, total, n_over_total, eps, n);
+  // ONE loop over the thread's slots [s, e[3]) — its trip count diverges over the thread's total offspring
+  // (mean 4) instead of four loops each diverging over one source's (mean 1, max ~4); slots are < 2^31.
+  // Sources past n have e[c] = n = e of the last real source, so they own no slot.
+  const int32_t e0 = (int32_t)e[0], e1 = (int32_t)e[1], e2 = (int32_t)e[2], e3 = (int32_t)e[3];
+  const int32_t src0 = (int32_t)i0;
+  for (int32_t j = (int32_t)s; j < e3; ++j)
+    anc[j] = src0 + (j >= e0 ? 1 : 0) + (j >= e1 ? 1 : 0) + (j >= e2 ? 1 : 0);
 }
 
-extern "C" int gmx_resample(int kind, const uint32_t key[2], const float* lw_d, int64_t n, int shift,
-                            const float* max_partials_d, int64_t n_partials, float* max_d,
-                            uint64_t* total_d, int32_t* ancestors_d, void* workspace_d, gmx_stream stream) {
-  if (n <= 0) return gmx_fail("gmx_resample: n must be positive%s");
-  if (!key || !lw_d || !max_d || !total_d || !ancestors_d || !workspace_d)
-    return gmx_fail("gmx_resample: null argument%s");
-  if (kind != GMX_RESAMPLE_SYSTEMATIC && kind != GMX_RESAMPLE_STRATIFIED)
-    return gmx_fail("gmx_resample: kind must be systematic or stratified (use gmx_weight_cdf + gmx_ancestors)%s");
-  int64_t tiles = (n + RS_TILE - 1) / RS_TILE;
-  if (tiles > RS_MAX_TILES) return gmx_fail("gmx_resample: n too large for the fused path (use gmx_weight_cdf + gmx_ancestors)%s");
-  if (n > 0x7fffffffLL) return gmx_fail("gmx_resample: n out of range%s");
-  if (shift < 1 || shift > 62) return gmx_fail("gmx_resample: shift out of range%s");
+static int resample_shape(const char* who, int64_t n, int shift) {
+  if (n <= 0) return gmx_fail("%s: n must be positive", who);
+  if ((n + RS_TILE - 1) / RS_TILE > RS_MAX_TILES)
+    return gmx_fail("%s: n too large for the fused path (use gmx_weight_cdf + gmx_ancestors)", who);
+  if (shift < 1 || shift > 62) return gmx_fail("%s: shift out of range", who);
   int need = 0;
   while (((int64_t)1 << need) < n) ++need;
-  if (shift + need > 62) return gmx_fail("gmx_resample: shift too large for n (overflow)%s");
-  if (((uintptr_t)lw_d & 15) || ((uintptr_t)workspace_d & 15))
-    return gmx_fail("gmx_resample: lw_d and workspace_d must be 16-byte aligned%s");
-  hipStream_t st = (hipStream_t)stream;
-  int max_mode = 0;
-  if (max_partials_d) {
-    if (n_partials <= 0) return gmx_fail("gmx_resample: n_partials must be positive%s");
-    if (n_partials <= 16384) max_mode = 1;
-    else hipLaunchKernelGGL(k_reduce_max, dim3(1), dim3(GMX_BLOCK), 0, st, max_partials_d, n_partials, max_d);
-  }
-  float scale = gmx_pow2i(shift);
-  hipLaunchKernelGGL(k_cdf_local, dim3((unsigned)tiles), dim3(RS_THREADS), 0, st, lw_d, n, scale, max_mode,
-                     max_partials_d, n_partials, max_d, (rs_ws*)workspace_d);
+  if (shift + need > 62) return gmx_fail("%s: shift too large for n (overflow)", who);
+  return 0;
+}
+
+extern "C" int gmx_tile_stats(const float* lw_d, int64_t n, int shift, float* tile_max_d, uint64_t* tile_agg_d,
+                              gmx_stream stream) {
+  if (resample_shape("gmx_tile_stats", n, shift)) return 1;
+  if (!lw_d || !tile_max_d || !tile_agg_d) return gmx_fail("gmx_tile_stats: null argument%s");
+  if ((uintptr_t)lw_d & 15) return gmx_fail("gmx_tile_stats: lw_d must be 16-byte aligned%s");
+  const int64_t tiles = (n + RS_TILE - 1) / RS_TILE;
+  hipLaunchKernelGGL(k_tile_stats, dim3((unsigned)tiles), dim3(RS_THREADS), 0, (hipStream_t)stream, lw_d, n,
+                     gmx_pow2i(shift), tile_max_d, tile_agg_d);
+  GMX_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int gmx_resample_tiles(int kind, const uint32_t key[2], const float* lw_d, int64_t n, int shift,
+                                  const float* tile_max_d, const uint64_t* tile_agg_d, float* max_d,
+                                  uint64_t* total_d, int32_t* ancestors_d, gmx_stream stream) {
+  if (resample_shape("gmx_resample_tiles", n, shift)) return 1;
+  if (!key || !lw_d || !tile_max_d || !tile_agg_d || !max_d || !total_d || !ancestors_d)
+    return gmx_fail("gmx_resample_tiles: null argument%s");
+  if (kind != GMX_RESAMPLE_SYSTEMATIC && kind != GMX_RESAMPLE_STRATIFIED)
+    return gmx_fail("gmx_resample_tiles: kind must be systematic or stratified (use gmx_weight_cdf + gmx_ancestors)%s");
+  if (n > 0x7fffffffLL) return gmx_fail("gmx_resample_tiles: n out of range%s");
+  if ((uintptr_t)lw_d & 15) return gmx_fail("gmx_resample_tiles: lw_d must be 16-byte aligned%s");
   uint32_t b0, b1;
   gmx_threefry2x32(key[0], key[1], 0u, 0u, &b0, &b1);           // bits32(key, 0) on the host
   const uint32_t u0 = (b0 ^ b1) >> 9;
-  const int64_t per_block = (int64_t)GMX_BLOCK * RS_SRC_PER_THREAD;
-  hipLaunchKernelGGL(k_offspring_local, dim3((unsigned)((n + per_block - 1) / per_block)), dim3(GMX_BLOCK), 0, st,
-                     kind, key[0], key[1], u0, (const rs_ws*)workspace_d, n, (int)tiles, total_d, ancestors_d);
+  const int64_t tiles = (n + RS_TILE - 1) / RS_TILE;
+  if (kind == GMX_RESAMPLE_SYSTEMATIC)
+    hipLaunchKernelGGL(k_offspring_tile<GMX_RESAMPLE_SYSTEMATIC>, dim3((unsigned)tiles), dim3(GMX_BLOCK), 0,
+                       (hipStream_t)stream, key[0], key[1], u0, lw_d, tile_max_d, tile_agg_d, n, (int)tiles,
+                       gmx_pow2i(shift), max_d, total_d, ancestors_d);
+  else
+    hipLaunchKernelGGL(k_offspring_tile<GMX_RESAMPLE_STRATIFIED>, dim3((unsigned)tiles), dim3(GMX_BLOCK), 0,
+                       (hipStream_t)stream, key[0], key[1], u0, lw_d, tile_max_d, tile_agg_d, n, (int)tiles,
+                       gmx_pow2i(shift), max_d, total_d, ancestors_d);
   GMX_HIP(hipGetLastError());
   return 0;
+}
+
+// log-weights -> ancestors: gmx_tile_stats + gmx_resample_tiles with the tile stats in the workspace.
+// max_partials_d / n_partials are accepted for compatibility and unused: the tile maxima are recomputed.
+extern "C" int gmx_resample(int kind, const uint32_t key[2], const float* lw_d, int64_t n, int shift,
+                            const float* max_partials_d, int64_t n_partials, float* max_d,
+                            uint64_t* total_d, int32_t* ancestors_d, void* workspace_d, gmx_stream stream) {
+  (void)max_partials_d; (void)n_partials;
+  if (!workspace_d) return gmx_fail("gmx_resample: null argument%s");
+  if ((uintptr_t)workspace_d & 15) return gmx_fail("gmx_resample: workspace_d must be 16-byte aligned%s");
+  rs_ws* ws = (rs_ws*)workspace_d;
+  if (gmx_tile_stats(lw_d, n, shift, ws->tmax, ws->agg, stream)) return 1;
+  return gmx_resample_tiles(kind, key, lw_d, n, shift, ws->tmax, ws->agg, max_d, total_d, ancestors_d, stream);
 }
 
 // ---------------------------------------------------------------------------

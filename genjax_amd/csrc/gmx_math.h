@@ -49,6 +49,24 @@ GMX_HD float gmx_fmin(float a, float b) { return (a < b || gmx_isnan(b)) ? a : b
 // 2^k as a float for k in [-126, 127].
 GMX_HD float gmx_pow2i(int k) { return gmx_u2f((uint32_t)(k + 127) << 23); }
 
+// Block floating point for the two-level integer CDF (include/genmi.h "Resampling"): a tile whose
+// largest log-weight is m gets the exponent k = ceil(m / ln 2) (clamped to +-2^29; -inf / NaN -> -2^29)
+// and its weights are taken relative to k * ln 2, so tiles combine by integer shifts 2^(k - K).
+#define GMX_TILE_EXP_LIM (1 << 29)
+GMX_HD int32_t gmx_tile_exp(float m) {
+  const float t = m * gmx_u2f(0x3FB8AA3Bu);        // 1 / ln 2
+  if (!(t > -(float)GMX_TILE_EXP_LIM)) return -GMX_TILE_EXP_LIM;
+  if (t > (float)GMX_TILE_EXP_LIM) return GMX_TILE_EXP_LIM;
+  int32_t k = (int32_t)t;                          // toward zero
+  if ((float)k < t) ++k;
+  return k;
+}
+GMX_HD float gmx_tile_ref(int32_t k) { return (float)k * gmx_u2f(0x3F317218u); }   // k * ln 2
+GMX_HD uint64_t gmx_tile_scale(uint64_t v, int32_t k, int32_t K) {               // v * 2^(k - K), k <= K
+  const int64_t d = (int64_t)K - (int64_t)k;
+  return d < 64 ? v >> d : 0ull;
+}
+
 // exp(x).  Results below the smallest normal are flushed to +0 so that the
 // answer never depends on a target's denormal mode.
 GMX_HD float gmx_expf(float x) {

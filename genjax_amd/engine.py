@@ -347,9 +347,15 @@ class Compiled:
                                   f"hiprtc-specialised kernel, which could not be built: {msg.decode() if msg else ''}")
         return ok
 
-    def run(self, leaves, batch: tuple, key: Key | None, red_out=None, index_offset=0, out_buffers=None):
+    def writes_tile_stats(self) -> bool:
+        """True when a launch can also leave the CDF tile statistics (gmx_run_args.tile_agg_d): a specialised
+        program running 4 particles per thread with exactly one block-max reduction."""
+        return bool(self._be.c.gmx_program_writes_tile_stats(self.handle))
+
+    def run(self, leaves, batch: tuple, key: Key | None, red_out=None, index_offset=0, out_buffers=None,
+            tile_stats=None):
         """Bind and launch.  Returns the list of output tensors (shape batch+event)."""
-        bound = self.bind(leaves, batch, key, red_out, index_offset, out_buffers)
+        bound = self.bind(leaves, batch, key, red_out, index_offset, out_buffers, tile_stats)
         self.launch(bound)
         return bound[3]
 
@@ -360,9 +366,12 @@ class Compiled:
             return          # an empty batch (jax.vmap over zero keys): the outputs are empty tensors already
         be.check(be.c.gmx_program_run(self.handle, bound[0], bound[1], be.stream()), "gmx_program_run")
 
-    def bind(self, leaves, batch: tuple, key: Key | None, red_out=None, index_offset=0, out_buffers=None):
+    def bind(self, leaves, batch: tuple, key: Key | None, red_out=None, index_offset=0, out_buffers=None,
+             tile_stats=None):
         """Fill a gmx_run_args for these leaves: (n, args, keep-alive list, outputs).  Sweeps whose
-        buffers are persistent bind every step once and re-launch the bindings."""
+        buffers are persistent bind every step once and re-launch the bindings.
+        tile_stats = (int64 tensor [grid], shift): the launch also writes the per-workgroup fixed-point weight
+        sums gmx_resample_tiles consumes (only if `writes_tile_stats()`)."""
         be = self._be
         n = int(np.prod(batch, dtype=np.int64))
         self._work = getattr(self, "_work", 0) + n
@@ -458,6 +467,10 @@ class Compiled:
             A.red_out_d = red_out.data_ptr()
             self.last_red = red_out
             keep.append(red_out)
+        if tile_stats is not None:
+            agg, shift = tile_stats
+            A.tile_agg_d, A.tile_shift = agg.data_ptr(), int(shift)
+            keep.append(agg)
         return n, A, keep, outs
 
 

@@ -40,7 +40,7 @@ from .. import _lib
 from ..core.choice_map import ChoiceMap
 from ..random import Key, fold_in, lazy_split, split
 from ..engine import Gathered
-from .smc import SYSTEMATIC, cdf_shift
+from .smc import SYSTEMATIC, cdf_reference, cdf_shift
 
 
 def systematic_slot_bounds(offsets, total: int, n_total: int, u0: int):
@@ -330,7 +330,7 @@ class ShardedBootstrapSweep:
         self.finish()
         acc = 0.0
         for m, tot in zip(self.maxs.cpu().tolist(), self.totals.cpu().numpy().view(np.uint64).tolist()):
-            acc += m + math.log(tot) - self.shift * math.log(2.0) - math.log(self.N)
+            acc += cdf_reference(m) + math.log(tot) - self.shift * math.log(2.0) - math.log(self.N)
         return acc
 
     def state(self):

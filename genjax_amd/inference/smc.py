@@ -15,6 +15,7 @@ for Part 2; pinned against oracle/ and closed-form Kalman answers.
 from __future__ import annotations
 
 import math
+import os
 from collections import OrderedDict
 from ctypes import c_uint32
 
@@ -328,6 +329,26 @@ SYSTEMATIC, STRATIFIED, MULTINOMIAL = (_lib.RESAMPLE_SYSTEMATIC, _lib.RESAMPLE_S
 _KINDS = {"systematic": SYSTEMATIC, "stratified": STRATIFIED, "multinomial": MULTINOMIAL}
 
 
+def cdf_reference(m) -> float:
+    """The log-weight an integer CDF total is relative to: total * 2^-shift = sum_i exp(lw_i - cdf_reference(max lw)).
+    = ceil(max lw / ln 2) * ln 2 in float32 arithmetic (gmx_tile_exp / gmx_tile_ref in csrc/gmx_math.h: the
+    exponent K of the block-floating-point CDF), evaluated on the host for the evidence terms."""
+    lim = 1 << 29
+    inv_ln2 = np.frombuffer(np.uint32(0x3FB8AA3B).tobytes(), np.float32)[0]
+    ln2 = np.frombuffer(np.uint32(0x3F317218).tobytes(), np.float32)[0]
+    with np.errstate(invalid="ignore", over="ignore"):
+        t = np.float32(m) * inv_ln2
+    if not (t > -np.float32(lim)):
+        k = -lim
+    elif t > np.float32(lim):
+        k = lim
+    else:
+        k = int(t)
+        if np.float32(k) < t:
+            k += 1
+    return float(np.float32(k) * ln2)
+
+
 def cdf_shift(n_total: int) -> int:
     """Fixed-point exponent: a sum of n_total terms <= 2^shift stays below 2^62."""
     need = 0
@@ -352,7 +373,7 @@ class LogMLOffset:
         for max_d, total_d, shift, n in self.terms:
             m = float(max_d.reshape(-1)[0].item())
             tot = int(total_d.reshape(-1)[0].item()) & 0xFFFFFFFFFFFFFFFF
-            acc += m + math.log(tot) - shift * math.log(2.0) - math.log(n)
+            acc += cdf_reference(m) + math.log(tot) - shift * math.log(2.0) - math.log(n)
         return acc
 
 
@@ -528,6 +549,12 @@ class BootstrapSweep:
         # block partials: sized for the interpreter's one row per 256 particles; a specialised kernel
         # writes fewer rows (gmx_program_grid), asked per launch in _rows()
         self.partials = torch.zeros((2, (n + 255) // 256), dtype=torch.float32, device=dev)
+        # two launches per step: when the site programs can leave the CDF tile statistics themselves (specialised,
+        # 4 particles per thread: a workgroup is one 1024-particle tile) the resampler needs no pass of its own
+        # over the log-weights (gmx_resample_tiles); GENMI_TILE_STATS=0 keeps the separate gmx_tile_stats launch
+        self.tile_agg = torch.zeros(((n + 1023) // 1024,), dtype=torch.int64, device=dev)
+        self.tile_stats = bool(self.fused and os.environ.get("GENMI_TILE_STATS", "1") != "0"
+                               and self.p_init.comp.writes_tile_stats() and self.p_step.comp.writes_tile_stats())
         # per-step keys on the host
         self.step_keys = []
         for t in range(T):
@@ -548,7 +575,8 @@ class BootstrapSweep:
         bufs = [None] * len(prog.comp.outputs)
         bufs[prog.ro[1]] = self.x_store[t % 2]
         bufs[prog.wo[1]] = self.lw.reshape(1, n)
-        prog.comp.run(leaves, (n,), lazy_split(k_prop, n), red_out=self.partials, out_buffers=bufs)
+        prog.comp.run(leaves, (n,), lazy_split(k_prop, n), red_out=self.partials, out_buffers=bufs,
+                      tile_stats=(self.tile_agg, self.shift) if self.tile_stats else None)
 
     def _launch_mh(self, t):
         """The MH move on the resampled particles of step t-1 (t >= 1): reads x_{t-1}[anc] and, for
@@ -591,6 +619,12 @@ class BootstrapSweep:
         be = _lib.get()
         kh = self.step_keys[t][1].host()
         kk = (c_uint32 * 2)(int(kh[0]), int(kh[1]))
+        if self.tile_stats:        # tile maxima = the workgroup maxima the site program left in partials[0]
+            be.check(be.c.gmx_resample_tiles(self.kind, kk, be.ptr(self.lw), self.n, self.shift, be.ptr(self.partials),
+                                             be.ptr(self.tile_agg), be.ptr(self.maxs[t:t + 1]),
+                                             be.ptr(self.totals[t:t + 1]), be.ptr(self.anc), be.stream()),
+                     "gmx_resample_tiles")
+            return
         be.check(be.c.gmx_resample(self.kind, kk, be.ptr(self.lw), self.n, self.shift, be.ptr(self.partials),
                                    self._rows(t), be.ptr(self.maxs[t:t + 1]),
                                    be.ptr(self.totals[t:t + 1]), be.ptr(self.anc), be.ptr(self.rs_ws),
@@ -616,8 +650,10 @@ class BootstrapSweep:
         """Representative single launches (a mid-sweep step) for per-kernel timing in bench.py."""
         t = max(1, self.T // 2)
         out = {"k_vm": lambda: self._launch_vm(t)}
-        if self.fused:
-            out["resample(k_cdf_local+k_offspring_local)"] = lambda: self._launch_resample(t)
+        if self.fused and self.tile_stats:
+            out["k_offspring_tile"] = lambda: self._launch_resample(t)
+        elif self.fused:
+            out["resample(k_tile_stats+k_offspring_tile)"] = lambda: self._launch_resample(t)
         else:
             out["k_weight_cdf"] = lambda: self._launch_cdf(t)
             out["k_ancestors"] = lambda: self._launch_anc(t)
@@ -651,8 +687,8 @@ class BootstrapSweep:
             be.check(be.c.gmx_graph_launch(self.graph, be.stream()), "gmx_graph_launch")
 
     def log_ml(self) -> float:
-        """sum_t [ M_t + log(total_t * 2^-shift) - log N ] in float64 (synchronises)."""
-        m = self.maxs.cpu().numpy().astype(np.float64)
+        """sum_t [ ref(M_t) + log(total_t * 2^-shift) - log N ] in float64 (synchronises)."""
+        m = np.array([cdf_reference(v) for v in self.maxs.cpu().numpy()], dtype=np.float64)
         tot = self.totals.cpu().numpy().view(np.uint64).astype(np.float64)
         return float(np.sum(m + np.log(tot) - self.shift * math.log(2.0) - math.log(self.n)))
 

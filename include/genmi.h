@@ -120,6 +120,14 @@ typedef struct gmx_run_args {
   int64_t index_offset;           /* global index of local particle 0 (sharding) */
   float* red_out_d;               /* [2][grid] block partials of OP_REDMAX/LSE: plane 0 = block max,
                                      plane 1 = sum exp(x - block max); grid = gmx_program_grid()  */
+  uint64_t* tile_agg_d;           /* optional, programs for which gmx_program_writes_tile_stats() is 1:
+                                     [grid] A_b = sum over the workgroup's 1024 particles of
+                                     floor(exp(x - k_b ln 2) * 2^tile_shift), k_b = ceil(block max / ln 2),
+                                     x = the OP_REDMAX operand
+                                     (the log-weight): with plane 0 of red_out_d the tile statistics
+                                     gmx_resample_tiles needs — no separate pass over the log-weights  */
+  int32_t tile_shift;
+  int32_t reserved_;
 } gmx_run_args;
 
 int gmx_program_create(const uint32_t* blob_h, size_t n_words, gmx_program** out);
@@ -134,6 +142,9 @@ int gmx_program_is_specialized(const gmx_program* p);
 /* number of thread blocks gmx_program_run will launch for n particles
  * (= rows of red_out_d the caller must provide). */
 int64_t gmx_program_grid(const gmx_program* p, int64_t n);
+/* 1 when the specialised kernel runs 4 particles per thread (a workgroup = one 1024-particle
+ * tile of the CDF) and the program has exactly one OP_REDMAX: it then honours tile_agg_d. */
+int gmx_program_writes_tile_stats(const gmx_program* p);
 int gmx_program_run(const gmx_program* p, int64_t n, const gmx_run_args* args_h,
                     gmx_stream stream);
 
@@ -154,10 +165,17 @@ int gmx_logsumexp(const float* lw_d, int64_t rows, int64_t cols, float* out_d,
  * O(N*K) SIR idiom (docs/cookbook/inactive/inference/importance_sampling.ipynb
  * cell 16); SURVEY.md App. B defines the scalable forms implemented here.
  *
- * Step 1  gmx_weight_cdf: w_i = exp(lw_i - max lw) in fixed point
- *         q_i = floor(w_i * 2^shift) (u64), inclusive prefix sum cdf_d[i].
- *         shift = 62 - ceil(log2(n_total)) so a global sum cannot overflow.
- *         The sum is an integer: identical under any partitioning.
+ * Step 1  gmx_weight_cdf: the integer CDF, in block floating point so that the only
+ *         global quantities are two numbers per tile of 1024 consecutive GLOBAL indices:
+ *           m_b = max lw over the tile,  k_b = ceil(m_b / ln 2) (f32; clamped to +-2^29),
+ *           l_i = floor(exp(lw_i - k_b ln 2) * 2^shift) (u64),
+ *           L_i = inclusive tile-local sum,  A_b = L_last;
+ *         with M = max_b m_b and K = ceil(M / ln 2):
+ *           G_b = A_b >> (K - k_b),  cdf_i = sum_{b'<b} G_b' + (L_i >> (K - k_b)).
+ *         shift = 62 - ceil(log2(n_total)) so a global sum cannot overflow.  Integers
+ *         throughout after the per-particle exp: the same on any machine and under any
+ *         partitioning whose shards start on a tile boundary.  total * 2^-shift =
+ *         sum_i exp(lw_i - K ln 2): evidence terms use K ln 2 (f32) as the reference.
  * Step 2  gmx_ancestors: ancestor of output slot j by exact 128-bit integer
  *         comparison against the CDF (no floating point):
  *           SYSTEMATIC   first i with cdf_i * (n_out*2^23) > (j*2^23 + u0) * total
@@ -187,11 +205,21 @@ int gmx_ancestors(int kind, const uint32_t key[2], const uint64_t* cdf_d, int64_
                   int64_t n_out_total, int64_t slot_offset, int64_t n_slots,
                   int32_t* ancestors_d /* [n_slots], clamped to [0,n_in) local */,
                   gmx_stream stream);
-/* Fused one-GPU form of steps 1+2 for SYSTEMATIC / STRATIFIED (n <= 2^21):
- * two streaming kernels, no inter-block waiting; ancestors identical to
- * gmx_weight_cdf + gmx_ancestors.  *max_d / *total_d receive the max
- * log-weight and the integer total (for the evidence increment). */
+/* Fused one-GPU form of steps 1+2 for SYSTEMATIC / STRATIFIED (n <= 2^21): no CDF in
+ * memory and no inter-block waiting; ancestors identical to gmx_weight_cdf +
+ * gmx_ancestors.  gmx_tile_stats writes (m_b, A_b) per 1024-particle tile — a
+ * specialised site program writes the same two numbers itself from its OP_REDMAX
+ * epilogue when gmx_run_args.tile_agg_d is set (gmx_program_writes_tile_stats), which
+ * makes an SMC step two launches.  gmx_resample_tiles turns log-weights + tile stats
+ * into ancestors; *max_d / *total_d receive the max log-weight and the integer total
+ * (for the evidence increment).  gmx_resample = both, tile stats in the workspace
+ * (max_partials_d / n_partials are accepted and unused). */
 size_t gmx_resample_workspace(int64_t n);
+int gmx_tile_stats(const float* lw_d, int64_t n, int shift, float* tile_max_d /* [ceil(n/1024)] */,
+                   uint64_t* tile_agg_d /* [ceil(n/1024)] */, gmx_stream stream);
+int gmx_resample_tiles(int kind, const uint32_t key[2], const float* lw_d, int64_t n, int shift,
+                       const float* tile_max_d, const uint64_t* tile_agg_d, float* max_d,
+                       uint64_t* total_d, int32_t* ancestors_d, gmx_stream stream);
 int gmx_resample(int kind, const uint32_t key[2], const float* lw_d, int64_t n, int shift,
                  const float* max_partials_d, int64_t n_partials, float* max_d,
                  uint64_t* total_d, int32_t* ancestors_d, void* workspace_d, gmx_stream stream);

@@ -1507,16 +1507,77 @@ def cdf_shift(n_total: int) -> int:
     return 62 - need
 
 
-def weight_cdf(lw, n_total=None):
-    """q_i = floor(exp(lw_i - max lw) * 2^shift) as uint64; inclusive cumsum."""
+CDF_TILE = 1024
+
+
+def _fmax_fold(x):
+    """max that skips NaNs (the fold gmx_fmax / fmax_nanskip performs), -inf when nothing is left"""
+    x = x[~np.isnan(x)]
+    return np.float32(x.max()) if x.size else np.float32(-np.inf)
+
+
+def tile_exp(m) -> int:
+    """k = ceil(m / ln 2) in float32 arithmetic, clamped to +-2^29; -inf / NaN -> -2^29 (gmx_tile_exp)"""
+    lim = 1 << 29
+    with np.errstate(invalid="ignore", over="ignore"):
+        t = np.float32(m) * np.frombuffer(np.uint32(0x3FB8AA3B).tobytes(), np.float32)[0]
+    if not (t > -np.float32(lim)):
+        return -lim
+    if t > np.float32(lim):
+        return lim
+    k = int(t)                                   # toward zero
+    if np.float32(k) < t:
+        k += 1
+    return k
+
+
+def tile_ref(k: int) -> np.float32:
+    return np.float32(np.float32(k) * np.frombuffer(np.uint32(0x3F317218).tobytes(), np.float32)[0])
+
+
+def cdf_reference(M) -> float:
+    """the log-weight the integer total is relative to: total * 2^-shift = sum exp(lw - cdf_reference(max lw))"""
+    return float(tile_ref(tile_exp(M)))
+
+
+def weight_cdf(lw, n_total=None, M=None):
+    """The two-level integer CDF (DESIGN.md section 3, orc_core.c::orc_weight_cdf_tiled — this is the numpy
+    statement of the same definition; tests/test_oracle_pins.py holds the two against each other).
+    Block floating point over tiles of 1024 consecutive global indices; per tile b: m_b = max lw,
+    k_b = ceil(m_b / ln 2), l_i = floor(exp(lw_i - k_b ln 2) * 2^shift), L_i = inclusive tile-local sum.
+    With M = max_b m_b (or the caller's global max when `lw` is one shard) and K = ceil(M / ln 2):
+    cdf_i = sum_{b' < b} (A_b' >> (K - k_b')) + (L_i >> (K - k_b)).  Returns (cdf, total, M, shift)."""
+    lw = f32(lw).reshape(-1)
+    n = lw.size
+    n_total = n if n_total is None else n_total
+    shift = cdf_shift(n_total)
+    Mg = _fmax_fold(lw) if M is None else np.float32(M)
+    K = tile_exp(Mg)
+    cdf = np.empty(n, dtype=np.uint64)
+    prefix = 0
+    for lo in range(0, n, CDF_TILE):
+        x = np.ascontiguousarray(lw[lo:lo + CDF_TILE])
+        k = tile_exp(_fmax_fold(x))
+        q = np.empty(x.size, dtype=np.uint64)
+        lib().orc_weight_fixed(I64(x.size), _p(x), ctypes.c_float(tile_ref(k)), ctypes.c_int(shift), _p(q))
+        L = np.cumsum(q, dtype=np.uint64)
+        d = K - k
+        Ls = (L >> np.uint64(d)) if d < 64 else np.zeros_like(L)
+        cdf[lo:lo + x.size] = np.uint64(prefix) + Ls
+        prefix += int(Ls[-1])
+    return cdf, int(prefix), float(Mg), shift
+
+
+def weight_cdf_c(lw, n_total=None, M=None):
+    """orc_weight_cdf_tiled: the C statement (fast; used for big inputs)."""
     lw = f32(lw).reshape(-1)
     n_total = lw.size if n_total is None else n_total
     shift = cdf_shift(n_total)
-    M = np.float32(lw.max())
-    q = np.empty(lw.size, dtype=np.uint64)
-    lib().orc_weight_fixed(I64(lw.size), _p(lw), ctypes.c_float(M), ctypes.c_int(shift), _p(q))
-    cdf = np.cumsum(q, dtype=np.uint64)
-    return cdf, int(cdf[-1]), float(M), shift
+    cdf = np.empty(lw.size, dtype=np.uint64)
+    Mo, tot = ctypes.c_float(0), ctypes.c_uint64(0)
+    lib().orc_weight_cdf_tiled(I64(lw.size), _p(lw), ctypes.c_int(shift), ctypes.c_int(0 if M is None else 1),
+                               ctypes.c_float(0.0 if M is None else M), _p(cdf), ctypes.byref(Mo), ctypes.byref(tot))
+    return cdf, int(tot.value), float(Mo.value), shift
 
 
 def ancestors_c(kind, k, cdf, n_out=None):
@@ -1563,8 +1624,9 @@ def ancestors(kind, k, cdf, n_out=None):
 
 def log_ml_increment(M, total, shift, n):
     """log( (1/n) sum_i exp(lw_i) ) from the integer total, evaluated in f64 on
-    the host: M + log(total * 2^-shift) - log(n)."""
-    return float(M) + float(np.log(np.float64(total))) - shift * float(np.log(2.0)) - float(np.log(np.float64(n)))
+    the host: ref + log(total * 2^-shift) - log(n), ref = cdf_reference(M) = ceil(M / ln 2) * ln 2 (the
+    log-weight the block-floating-point total is relative to)."""
+    return cdf_reference(M) + float(np.log(np.float64(total))) - shift * float(np.log(2.0)) - float(np.log(np.float64(n)))
 
 
 def trace_where(mask, new, old):

@@ -504,15 +504,64 @@ void orc_categorical_sample(int64_t n, int64_t K, const uint32_t* keys, int64_t 
   }
 }
 
-/* ---- fixed-point weights ----------------------------- */
-/* q_i = floor(exp(lw_i - M) * 2^shift) */
-void orc_weight_fixed(int64_t n, const float* lw, float M, int shift, uint64_t* q) {
+/* ---- fixed-point weights (build-defined) ----------------- */
+/* q_i = floor(exp(lw_i - ref) * 2^shift); NaN / negative / >= 2^63 (lw = +inf) -> 0 */
+static uint64_t weight_fixed1(float lw, float ref, float scale) {
+  float v = orc_expf(lw - ref) * scale;
+  return (v >= 0.0f && v < 0x1p63f) ? (uint64_t)v : 0ull;
+}
+void orc_weight_fixed(int64_t n, const float* lw, float ref, int shift, uint64_t* q) {
   float scale = pow2i(shift);
-  for (int64_t i = 0; i < n; ++i) {
-    float w = orc_expf(lw[i] - M);
-    float v = w * scale;
-    q[i] = (v >= 0.0f) ? (uint64_t)v : 0ull;
+  for (int64_t i = 0; i < n; ++i) q[i] = weight_fixed1(lw[i], ref, scale);
+}
+static float fmax_nanskip(float a, float b) { return (a > b || b != b) ? a : b; }
+/* Block floating point: the exponent of a tile whose largest log-weight is m is k = ceil(m / ln 2), clamped
+ * to +-2^29 (-inf / NaN -> -2^29); the tile's weights are taken relative to k * ln 2. */
+#define ORC_TILE_EXP_LIM (1 << 29)
+int32_t orc_tile_exp(float m) {
+  const float t = m * u2f(0x3FB8AA3Bu);           /* 1 / ln 2 */
+  if (!(t > -(float)ORC_TILE_EXP_LIM)) return -ORC_TILE_EXP_LIM;
+  if (t > (float)ORC_TILE_EXP_LIM) return ORC_TILE_EXP_LIM;
+  int32_t k = (int32_t)t;
+  if ((float)k < t) ++k;
+  return k;
+}
+float orc_tile_ref(int32_t k) { return (float)k * u2f(0x3F317218u); }
+static uint64_t tile_scale(uint64_t v, int32_t k, int32_t K) {
+  int64_t d = (int64_t)K - (int64_t)k;
+  return d < 64 ? v >> d : 0ull;
+}
+/* Two-level integer CDF.  Tiles of ORC_CDF_TILE consecutive GLOBAL indices; per tile b:
+ *   m_b = max lw, k_b = tile_exp(m_b), l_i = floor(exp(lw_i - k_b ln 2) * 2^shift), L_i = inclusive
+ *   tile-local sum, A_b = L_last
+ * then with M = max_b m_b (or the caller's, when the array is one shard of a larger population), K = tile_exp(M):
+ *   G_b = A_b >> (K - k_b),   cdf_i = sum_{b' < b} G_b' + (L_i >> (K - k_b))
+ * Integers throughout after the per-particle exp: nothing depends on how the work is split. */
+#define ORC_CDF_TILE 1024
+void orc_weight_cdf_tiled(int64_t n, const float* lw, int shift, int use_M, float M_in, uint64_t* cdf,
+                          float* M_out, uint64_t* total_out) {
+  int64_t tiles = (n + ORC_CDF_TILE - 1) / ORC_CDF_TILE;
+  float scale = pow2i(shift);
+  float M = -f_inf();
+  for (int64_t i = 0; i < n; ++i) M = fmax_nanskip(M, lw[i]);
+  if (use_M) M = M_in;
+  const int32_t K = orc_tile_exp(M);
+  uint64_t prefix = 0;
+  for (int64_t b = 0; b < tiles; ++b) {
+    int64_t lo = b * ORC_CDF_TILE, hi = lo + ORC_CDF_TILE < n ? lo + ORC_CDF_TILE : n;
+    float m = -f_inf();
+    for (int64_t i = lo; i < hi; ++i) m = fmax_nanskip(m, lw[i]);
+    const int32_t k = orc_tile_exp(m);
+    const float ref = orc_tile_ref(k);
+    uint64_t run = 0;
+    for (int64_t i = lo; i < hi; ++i) {
+      run += weight_fixed1(lw[i], ref, scale);
+      cdf[i] = prefix + tile_scale(run, k, K);
+    }
+    prefix += tile_scale(run, k, K);
   }
+  *M_out = M;
+  *total_out = prefix;
 }
 /* Exact integer inverse-CDF for large n (include/genmi.h, gmx_ancestors) with 128-bit integers:
  *   systematic / stratified: first i with cdf_i * (n_out*2^23) > (j*2^23 + u_j) * total

@@ -48,9 +48,9 @@ int orc_lgssm_sweep(int64_t n, int64_t T, const float* ys, uint32_t key0, uint32
   const uint32_t run_key[2] = {key0, key1};
   float* cur = x;
   float* prev = x2;
-  int nthr = orc_threads();
-  uint64_t* part = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)(nthr + 1));
-  if (!part) return 1;
+  const int64_t tiles = (n + ORC_CDF_TILE - 1) / ORC_CDF_TILE;
+  uint64_t* tile_g = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)tiles);
+  if (!tile_g) return 1;
   for (int64_t t = 0; t < T; ++t) {
     uint32_t sk[2], kp[2], kr[2];
     derive(run_key, (uint64_t)t, sk);          /* fold_in(run_key, t) */
@@ -76,34 +76,30 @@ int orc_lgssm_sweep(int64_t n, int64_t T, const float* ys, uint32_t key0, uint32
       if (w > M) M = w;
     }
     maxs[t] = M;
-    /* fixed-point weights + inclusive prefix sum (two-pass, thread blocks) */
+    /* two-level integer CDF (orc_core.c::orc_weight_cdf_tiled, tiles in parallel) */
     float scale = pow2i(shift);
-#pragma omp parallel
-    {
-#ifdef _OPENMP
-      int tid = omp_get_thread_num(), nt = omp_get_num_threads();
-#else
-      int tid = 0, nt = 1;
-#endif
-      int64_t lo = n * tid / nt, hi = n * (tid + 1) / nt;
+    const int32_t K = orc_tile_exp(M);
+#pragma omp parallel for schedule(static)
+    for (int64_t b = 0; b < tiles; ++b) {
+      int64_t lo = b * ORC_CDF_TILE, hi = lo + ORC_CDF_TILE < n ? lo + ORC_CDF_TILE : n;
+      float m = -f_inf();
+      for (int64_t i = lo; i < hi; ++i) m = fmax_nanskip(m, lw[i]);
+      const int32_t k = orc_tile_exp(m);
+      const float ref = orc_tile_ref(k);
       uint64_t run = 0;
       for (int64_t i = lo; i < hi; ++i) {
-        float w = orc_expf(lw[i] - M);
-        float q = w * scale;
-        run += (q >= 0.0f) ? (uint64_t)q : 0ull;
-        cdf[i] = run;
+        run += weight_fixed1(lw[i], ref, scale);
+        cdf[i] = tile_scale(run, k, K);
       }
-      part[tid + 1] = run;
-#pragma omp barrier
-#pragma omp single
-      {
-        part[0] = 0;
-        for (int k = 1; k <= nt; ++k) part[k] += part[k - 1];
-      }
-      uint64_t off = part[tid];
-      if (off) for (int64_t i = lo; i < hi; ++i) cdf[i] += off;
+      tile_g[b] = tile_scale(run, k, K);
     }
-    uint64_t total = cdf[n - 1];
+    uint64_t total = 0;
+    for (int64_t b = 0; b < tiles; ++b) { uint64_t g = tile_g[b]; tile_g[b] = total; total += g; }
+#pragma omp parallel for schedule(static)
+    for (int64_t b = 0; b < tiles; ++b) {
+      int64_t lo = b * ORC_CDF_TILE, hi = lo + ORC_CDF_TILE < n ? lo + ORC_CDF_TILE : n;
+      for (int64_t i = lo; i < hi; ++i) cdf[i] += tile_g[b];
+    }
     totals[t] = total;
     /* systematic resampling: first i with cdf_i * (n*2^23) > (j*2^23 + u0) * total */
     uint64_t u0 = bits32_1(kr, 0) >> 9;
@@ -120,6 +116,6 @@ int orc_lgssm_sweep(int64_t n, int64_t T, const float* ys, uint32_t key0, uint32
     }
   }
   if (cur != x) memcpy(x, cur, sizeof(float) * (size_t)n);
-  free(part);
+  free(tile_g);
   return 0;
 }

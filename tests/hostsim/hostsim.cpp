@@ -88,6 +88,7 @@ extern "C" int gmx_program_create(const uint32_t* blob, size_t n_words, gmx_prog
 extern "C" int gmx_program_destroy(gmx_program* p) { delete p; return 0; }
 extern "C" int gmx_program_specialize(gmx_program*) { return fail("hostsim: no specialisation"); }
 extern "C" int gmx_program_is_specialized(const gmx_program*) { return 0; }
+extern "C" int gmx_program_writes_tile_stats(const gmx_program*) { return 0; }
 extern "C" int64_t gmx_program_grid(const gmx_program*, int64_t n) { return (n + 255) / 256; }
 
 static float butterfly_sum64(const float* v) {
@@ -151,20 +152,35 @@ extern "C" int gmx_reduce_max(const float* parts, int64_t n, float* max_d, gmx_s
   float m = -gmx_inf(); for (int64_t j = 0; j < n; ++j) m = gmx_fmax(m, parts[j]); *max_d = m; return 0;
 }
 extern "C" size_t gmx_weight_cdf_workspace(int64_t n) { return 8 + (size_t)((n + 1023) / 1024) * 8; }
+// the two-level integer CDF (include/genmi.h "Resampling"): tiles of 1024 consecutive indices
+static const int64_t HS_TILE = 1024;
+static uint64_t hs_weight_fixed(float lw, float ref, float scale) {
+  float q = gmx_expf(lw - ref) * scale;
+  return (q >= 0.0f && q < 0x1p63f) ? (uint64_t)q : 0ull;
+}
 extern "C" int gmx_weight_cdf(const float* lw, int64_t n, int shift, const float* parts, int64_t n_parts, float* max_d,
                               uint64_t* cdf, uint64_t* total, void*, gmx_stream) {
   if (n <= 0) return fail("weight_cdf: n");
   int need = 0; while (((int64_t)1 << need) < n) ++need;
   if (shift + need > 62) return fail("weight_cdf: shift too large");
   if (parts) { float m = -gmx_inf(); for (int64_t j = 0; j < n_parts; ++j) m = gmx_fmax(m, parts[j]); *max_d = m; }
-  float M = *max_d, scale = gmx_pow2i(shift);
-  uint64_t run = 0;
-  for (int64_t i = 0; i < n; ++i) {
-    float w = gmx_expf(lw[i] - M); float q = w * scale;
-    run += (q >= 0.0f) ? (uint64_t)q : 0ull;
-    cdf[i] = run;
+  const float M = *max_d, scale = gmx_pow2i(shift);
+  const int32_t K = gmx_tile_exp(M);
+  uint64_t prefix = 0;
+  for (int64_t lo = 0; lo < n; lo += HS_TILE) {
+    const int64_t hi = lo + HS_TILE < n ? lo + HS_TILE : n;
+    float m = -gmx_inf();
+    for (int64_t i = lo; i < hi; ++i) m = gmx_fmax(m, lw[i]);
+    const int32_t k = gmx_tile_exp(m);
+    const float ref = gmx_tile_ref(k);
+    uint64_t run = 0;
+    for (int64_t i = lo; i < hi; ++i) {
+      run += hs_weight_fixed(lw[i], ref, scale);
+      cdf[i] = prefix + gmx_tile_scale(run, k, K);
+    }
+    prefix += gmx_tile_scale(run, k, K);
   }
-  *total = run;
+  *total = prefix;
   return 0;
 }
 typedef unsigned __int128 u128;
@@ -191,13 +207,51 @@ extern "C" int gmx_ancestors(int kind, const uint32_t key[2], const uint64_t* cd
   }
   return 0;
 }
-extern "C" size_t gmx_resample_workspace(int64_t n) { return 8 * (512 + 8 + (size_t)(n < 1 ? 1 : n)); }
-extern "C" int gmx_resample(int kind, const uint32_t key[2], const float* lw, int64_t n, int shift, const float* parts,
-                            int64_t n_parts, float* max_d, uint64_t* total, int32_t* anc, void* ws, gmx_stream st) {
+extern "C" size_t gmx_resample_workspace(int64_t) { return 2048 * 12; }
+extern "C" int gmx_tile_stats(const float* lw, int64_t n, int shift, float* tmax, uint64_t* agg, gmx_stream) {
+  if (n <= 0 || !lw || !tmax || !agg) return fail("tile_stats: bad argument");
+  const float scale = gmx_pow2i(shift);
+  for (int64_t lo = 0, b = 0; lo < n; lo += HS_TILE, ++b) {
+    const int64_t hi = lo + HS_TILE < n ? lo + HS_TILE : n;
+    float m = -gmx_inf();
+    for (int64_t i = lo; i < hi; ++i) m = gmx_fmax(m, lw[i]);
+    const float ref = gmx_tile_ref(gmx_tile_exp(m));
+    uint64_t run = 0;
+    for (int64_t i = lo; i < hi; ++i) run += hs_weight_fixed(lw[i], ref, scale);
+    tmax[b] = m; agg[b] = run;
+  }
+  return 0;
+}
+// the mirror rebuilds the global CDF from log-weights + tile stats and searches it per slot
+extern "C" int gmx_resample_tiles(int kind, const uint32_t key[2], const float* lw, int64_t n, int shift, const float* tmax,
+                                  const uint64_t* agg, float* max_d, uint64_t* total, int32_t* anc, gmx_stream st) {
   if (kind == GMX_RESAMPLE_MULTINOMIAL) return fail("resample: kind");
-  uint64_t* cdf = (uint64_t*)ws + 512;
-  if (gmx_weight_cdf(lw, n, shift, parts, n_parts, max_d, cdf, total, nullptr, st)) return 1;
-  return gmx_ancestors(kind, key, cdf, n, 0, total, n, 0, n, anc, st);
+  const int64_t tiles = (n + HS_TILE - 1) / HS_TILE;
+  float M = -gmx_inf();
+  for (int64_t b = 0; b < tiles; ++b) M = gmx_fmax(M, tmax[b]);
+  const float scale = gmx_pow2i(shift);
+  const int32_t K = gmx_tile_exp(M);
+  std::vector<uint64_t> cdf((size_t)n);
+  uint64_t prefix = 0;
+  for (int64_t b = 0; b < tiles; ++b) {
+    const int64_t lo = b * HS_TILE, hi = lo + HS_TILE < n ? lo + HS_TILE : n;
+    const int32_t k = gmx_tile_exp(tmax[b]);
+    const float ref = gmx_tile_ref(k);
+    uint64_t run = 0;
+    for (int64_t i = lo; i < hi; ++i) {
+      run += hs_weight_fixed(lw[i], ref, scale);
+      cdf[(size_t)i] = prefix + gmx_tile_scale(run, k, K);
+    }
+    prefix += gmx_tile_scale(agg[b], k, K);
+  }
+  *max_d = M; *total = prefix;
+  return gmx_ancestors(kind, key, cdf.data(), n, 0, total, n, 0, n, anc, st);
+}
+extern "C" int gmx_resample(int kind, const uint32_t key[2], const float* lw, int64_t n, int shift, const float*,
+                            int64_t, float* max_d, uint64_t* total, int32_t* anc, void* ws, gmx_stream st) {
+  uint64_t* agg = (uint64_t*)ws; float* tmax = (float*)(agg + 2048);
+  if (gmx_tile_stats(lw, n, shift, tmax, agg, st)) return 1;
+  return gmx_resample_tiles(kind, key, lw, n, shift, tmax, agg, max_d, total, anc, st);
 }
 // ---- global resampling across ranks: destination-centric restatement ----
 static int64_t hs_slots_below(int kind, gmx_key k, uint64_t c, uint64_t total, int64_t N) {

@@ -632,7 +632,7 @@ def oracle_nlssm_mh_sweep(n, T, seed):
         else:
             okr = O.split(O.fold_in(okey, t - 1), 3)[1]
             cdf, total, M, shift = O.weight_cdf(olw)
-            terms.append(M + math.log(total) - shift * math.log(2.0) - math.log(n))
+            terms.append(O.log_ml_increment(M, total, shift, n))
             otr = O.gather_trace(otr, (O.ancestors_c if n > 20_000 else O.ancestors)(O.SYSTEMATIC, okr, cdf))
             gf = otr.get_gen_fn()
             otr, oacc, _ = O.rejuvenate(oks[2], otr, lambda k, tr_: gf.edit_static(k, tr_, oreq, tr_.get_args()))
@@ -640,7 +640,7 @@ def oracle_nlssm_mh_sweep(n, T, seed):
     x = np.asarray(otr.get_retval(), np.float32)
     olw = np.asarray(olw, np.float32)
     cdf, total, M, shift = O.weight_cdf(olw)
-    terms.append(M + math.log(total) - shift * math.log(2.0) - math.log(n))
+    terms.append(O.log_ml_increment(M, total, shift, n))
     anc = (O.ancestors_c if n > 20_000 else O.ancestors)(O.SYSTEMATIC, O.split(O.fold_in(okey, T - 1), 3)[1], cdf)
     return {"x": x, "lw": olw, "acc": oacc, "terms": terms, "resampled": x[anc]}
 

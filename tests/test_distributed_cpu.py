@@ -54,7 +54,7 @@ def test_sharded_mh_sweep_equals_single_process_oracle(tmp_path, world, capacity
     """BASELINE config 3 sharded: nonlinear SSM + one MH move per step, two routed leaves (the particle and
     the state it was extended from).  Must equal the single-process oracle for any rank count; capacity 7
     forces the overflow re-run."""
-    n_total, T = 2048, 4
+    n_total, T = 4096, 4          # 1024 per rank at world 4: shards start on a CDF tile boundary
     out = str(tmp_path / "shard_mh")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",

@@ -353,10 +353,11 @@ def test_plates_match_oracle(gpu, n):
 
 
 @pytest.mark.parametrize("n,world,kw", [
-    (1000, 4, {}), (4096, 8, {"kind": 1, "seed": 3}), (777, 3, {"skew": 2.0, "seed": 1}),
-    (500, 8, {"skew": -3.0, "seed": 2}), (64, 2, {"dead": True}), (100_000, 8, {"seed": 5}),
-    (100_000, 8, {"seed": 6, "capacity": 12_500}), (250_000, 2, {"seed": 7, "skew": 0.5}),
-    (100_003, 5, {"seed": 8}), (1001, 4, {"seed": 9, "kind": 1}),
+    # per-rank sizes are multiples of the 1024-particle CDF tile (shards start on a global tile boundary)
+    (1024, 4, {}), (4096, 8, {"kind": 1, "seed": 3}), (1024, 3, {"skew": 2.0, "seed": 1}),
+    (1024, 8, {"skew": -3.0, "seed": 2}), (64, 2, {"dead": True}), (100_352, 8, {"seed": 5}),
+    (100_352, 8, {"seed": 6, "capacity": 12_500}), (250_880, 2, {"seed": 7, "skew": 0.5}),
+    (101_376, 5, {"seed": 8}), (2048, 4, {"seed": 9, "kind": 1}),
 ])
 @pytest.mark.parametrize("fused", [False, True])
 def test_global_resampling_routes_match_oracle(gpu, n, world, kw, fused):
@@ -367,7 +368,7 @@ def test_global_resampling_routes_match_oracle(gpu, n, world, kw, fused):
 
 
 def test_global_resampling_flags_overflow(gpu):
-    assert parity.check_shard_route(777, 3, skew=2.0, seed=1, capacity=5)["overflow"]
+    assert parity.check_shard_route(1024, 3, skew=2.0, seed=1, capacity=5)["overflow"]
 
 
 def test_sharded_sweep_world1_matches_oracle(gpu):
@@ -695,3 +696,38 @@ def test_specialised_code_object_cache(gpu, tmp_path, monkeypatch):
     assert files[0].stat().st_size > 1000          # rewritten after the recompile
     for u, v, w in zip(a, b, c):
         assert np.array_equal(u, v) and np.array_equal(u, w)
+
+
+def test_sweep_with_separate_tile_stats_launch(gpu, monkeypatch):
+    """GENMI_TILE_STATS=0: the site program does not write the CDF tile statistics; gmx_resample's own
+    k_tile_stats pass does.  Same sweep, bit for bit (the default path lets the specialised program write them)."""
+    monkeypatch.setenv("GENMI_TILE_STATS", "0")
+    res = parity.check_lgssm_sweep(n=50_000, T=6, capture=True, specialize=True)
+    assert res["ancestors_equal"] and res["x_equal"] and res["totals_equal"] and res["lw_max_abs_diff"] == 0.0
+    assert res["log_ml"] == res["log_ml_oracle"]
+
+
+def test_tile_stats_from_the_site_program(gpu):
+    """the specialised program's epilogue writes the same (m_b, A_b) as gmx_tile_stats, ragged last tile included"""
+    import genjax_amd as G
+    from genjax_amd import _lib, workloads
+    from genjax_amd.inference.smc import BootstrapSweep
+    be = _lib.get()
+    n, T = 100_003, 3
+    init, step = workloads.make_lgssm(G)
+    sw = BootstrapSweep(init, step, n, T).prepare(G.key(1), torch.from_numpy(workloads.lgssm_data(T)))
+    assert sw.tile_stats
+    sw.launch()
+    torch.cuda.synchronize()
+    tiles = (n + 1023) // 1024
+    tmax = torch.zeros(tiles, dtype=torch.float32, device="cuda")
+    agg = torch.zeros(tiles, dtype=torch.int64, device="cuda")
+    be.check(be.c.gmx_tile_stats(be.ptr(sw.lw), n, sw.shift, be.ptr(tmax), be.ptr(agg), be.stream()), "gmx_tile_stats")
+    assert torch.equal(tmax, sw.partials[0, :tiles]) and torch.equal(agg, sw.tile_agg)
+    lw = sw.lw.cpu().numpy()
+    for b in (0, tiles - 1):
+        x = lw[b * 1024:(b + 1) * 1024]
+        q = np.zeros(x.size, np.uint64)
+        ref = O.tile_ref(O.tile_exp(x.max()))          # block floating point: weights relative to ceil(max / ln 2) * ln 2
+        O.lib().orc_weight_fixed(O.I64(x.size), O._p(x), O.ctypes.c_float(ref), O.ctypes.c_int(sw.shift), O._p(q))
+        assert int(q.sum()) == int(agg[b].item()) and float(tmax[b].item()) == float(x.max())

@@ -517,15 +517,16 @@ def test_plates_match_oracle():
 def test_global_resampling_routes_match_oracle():
     """gmx_shard_plan / gmx_shard_route, all ranks emulated in one process."""
     from tests import parity
-    assert not parity.check_shard_route(1000, 4)["overflow"]
-    assert not parity.check_shard_route(1000, 4, kind=O.STRATIFIED, seed=3)["overflow"]
-    assert not parity.check_shard_route(777, 3, skew=2.0, seed=1)["overflow"]
-    assert parity.check_shard_route(777, 3, skew=2.0, seed=1, capacity=5)["overflow"]
-    assert not parity.check_shard_route(500, 8, skew=-3.0, seed=2)["overflow"]
+    # shards start on a 1024-particle CDF tile (the two-level CDF is defined on GLOBAL tiles)
+    assert not parity.check_shard_route(1024, 4)["overflow"]
+    assert not parity.check_shard_route(1024, 4, kind=O.STRATIFIED, seed=3)["overflow"]
+    assert not parity.check_shard_route(1024, 3, skew=2.0, seed=1)["overflow"]
+    assert parity.check_shard_route(1024, 3, skew=2.0, seed=1, capacity=5)["overflow"]
+    assert not parity.check_shard_route(1024, 8, skew=-3.0, seed=2)["overflow"]
     assert not parity.check_shard_route(64, 2, dead=True)["overflow"]          # no mass anywhere
     assert not parity.check_shard_route(1000, 1)["overflow"]
-    assert not parity.check_shard_route(1001, 4, fused=True, seed=4)["overflow"]
-    assert parity.check_shard_route(777, 3, skew=2.0, seed=1, capacity=5, fused=True)["overflow"]
+    assert not parity.check_shard_route(2048, 4, fused=True, seed=4)["overflow"]
+    assert parity.check_shard_route(1024, 3, skew=2.0, seed=1, capacity=5, fused=True)["overflow"]
 
 
 def test_conditional_smc_and_proposals():

@@ -147,6 +147,10 @@ def main():
     ys = workloads.lgssm_data(T)
     init, step = workloads.make_lgssm(G)
     single = world == 1 and not args.sharded
+    if world > 1 and n % 1024:
+        # shards start on a 1024-particle tile of the global CDF (include/genmi.h "Resampling"): 1e6 -> 1 000 448
+        # per GPU (977 tiles), so that the N-GPU population is bit-identical to a single-process one
+        n = ((n + 1023) // 1024) * 1024
     if single:
         sw = BootstrapSweep(init, step, n, T).prepare(G.key(seed), torch.from_numpy(ys))
         if not args.no_graph:

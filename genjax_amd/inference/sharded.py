@@ -63,6 +63,18 @@ def systematic_slot_bounds(offsets, total: int, n_total: int, u0: int):
     return out
 
 
+CDF_TILE = 1024
+
+
+def _check_shard_alignment(n_per_rank: int, world: int):
+    """The integer CDF is defined on tiles of 1024 consecutive GLOBAL particle indices (include/genmi.h,
+    "Resampling"): a shard must start on a tile boundary or the result would depend on the rank count."""
+    if world > 1 and n_per_rank % CDF_TILE != 0:
+        raise ValueError(f"particles per rank must be a multiple of {CDF_TILE} when sharded over {world} ranks "
+                         f"(got {n_per_rank}): shards start on a tile boundary of the global CDF; "
+                         f"use {((n_per_rank + CDF_TILE - 1) // CDF_TILE) * CDF_TILE}")
+
+
 class ShardedBootstrapSweep:
     """smc.BootstrapSweep over `dist.get_world_size()` ranks, n particles per rank."""
 
@@ -76,6 +88,7 @@ class ShardedBootstrapSweep:
         self.kind = _KINDS[resample] if isinstance(resample, str) else int(resample)
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         self.N = self.n * self.world
+        _check_shard_alignment(self.n, self.world)
         # particles one rank may ship to ONE peer per step before the slow path kicks in
         # default n/32: the slot boundaries of balanced ranks move by O(sqrt(n)) particles per step, so
         # this is a ~10x margin at n = 1e6 while the all-to-all stays ~125 KB per peer
@@ -350,6 +363,7 @@ def sharded_importance_resample(target, k_per_rank: int, key: Key, dist, kind="s
     equal-split all-to-all (a one-off move, so leaves are routed one by one).  Returns
     (ParticleCollection of this rank's k resampled particles, this rank's pre-resampling log-weights).
     COLLECTIVE: every rank calls it."""
+    _check_shard_alignment(int(k_per_rank), dist.get_world_size())
     from .smc import _KINDS, LogMLOffset, ParticleCollection, trace_map
     from ..engine import gather_leaves, materialize
     be = _lib.get()

@@ -826,3 +826,19 @@ def _oracle_two_site():
         _ = O.normal(x, 1.0) @ "y"
         return x
     return m
+
+
+def test_sharded_requires_tile_aligned_shards():
+    """shards must start on a 1024-particle tile of the global CDF, or the result would depend on the rank count"""
+    from genjax_amd import workloads
+    from genjax_amd.inference.sharded import ShardedBootstrapSweep
+
+    class _Two:
+        @staticmethod
+        def get_rank(): return 0
+        @staticmethod
+        def get_world_size(): return 2
+    init, step = workloads.make_lgssm(genjax)
+    with pytest.raises(ValueError, match="multiple of 1024"):
+        ShardedBootstrapSweep(init, step, 1000, 3, _Two)
+    ShardedBootstrapSweep(init, step, 2048, 3, _Two)          # aligned: constructs (no collective until prepare)

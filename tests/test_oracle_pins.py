@@ -280,3 +280,53 @@ def test_jax_docs_partitionable_prng_values():
     # (element j of a vector draw takes counter j under the SAME key)
     allatonce = O.normal.sample(k, np.zeros(3, np.float32), np.float32(1))
     assert np.all(np.abs(allatonce.astype(np.float64) - [-0.02830462, 0.46713185, 0.29570296]) < 5.1e-9)
+
+
+@pytest.mark.parametrize("n", [1, 5, 1023, 1024, 1025, 5000, 100_003])
+def test_integer_cdf_numpy_and_c_statements_agree(n):
+    """genjax_oracle.weight_cdf (numpy) and orc_core.c::orc_weight_cdf_tiled state the block-floating-point
+    CDF independently; they must produce the same integers, the CDF must be non-decreasing, and
+    ref + log(total * 2^-shift) must be the log-sum-exp of the weights."""
+    rng = np.random.default_rng(n)
+    lw = (rng.normal(0, 3, n) - 5).astype(np.float32)
+    if n > 10:
+        lw[3] = -np.inf
+        lw[n // 2] = np.nan
+    a, b = O.weight_cdf(lw), O.weight_cdf_c(lw)
+    assert np.array_equal(a[0], b[0]) and a[1:] == b[1:]
+    assert np.all(a[0][1:] >= a[0][:-1])
+    fin = lw[np.isfinite(lw)].astype(np.float64)
+    lse = fin.max() + math.log(np.sum(np.exp(fin - fin.max())))
+    est = O.cdf_reference(a[2]) + math.log(a[1]) - a[3] * math.log(2.0)
+    assert abs(est - lse) < 1e-6
+    # one shard of a larger population: the caller's global max instead of the local one
+    M = float(np.float32(a[2] + 7.5))
+    c, d = O.weight_cdf(lw, n_total=4 * n, M=M), O.weight_cdf_c(lw, n_total=4 * n, M=M)
+    assert np.array_equal(c[0], d[0]) and c[1] == d[1]
+
+
+def test_c_sweep_equals_numpy_sweep():
+    """oracle/orc_sweep.c (bench.py's cpu_baseline) == the numpy oracle sweep: particles, ancestors, totals"""
+    import ctypes
+    import os
+    from genjax_amd import workloads
+    from tests import parity
+    so = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_build", "liborc_sweep.so")
+    lib = ctypes.CDLL(so)
+    n, T, seed = 3000, 5, 314159
+    ys = workloads.lgssm_data(T)
+    shift = O.cdf_shift(n)
+    f32, u64, i32 = np.float32, np.uint64, np.int32
+    x, x2, lw = np.zeros(n, f32), np.zeros(n, f32), np.zeros(n, f32)
+    cdf, anc = np.zeros(n, u64), np.zeros(n, i32)
+    maxs, totals = np.zeros(T, f32), np.zeros(T, u64)
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    rc = lib.orc_lgssm_sweep(ctypes.c_int64(n), ctypes.c_int64(T), P(ys), ctypes.c_uint32(0), ctypes.c_uint32(seed),
+                             ctypes.c_float(0.9), ctypes.c_float(0.5), ctypes.c_float(1.0), ctypes.c_float(1.0),
+                             ctypes.c_int(shift), P(x), P(x2), P(lw), P(cdf), P(anc), P(maxs), P(totals))
+    assert rc == 0
+    oi, ost = workloads.make_lgssm(O)
+    ref = parity.oracle_bootstrap_sweep(oi, ost, n, T, ys, O.key(seed))
+    assert [int(t) for t in totals] == [h["total"] for h in ref["hist"]]
+    assert np.array_equal(x, ref["x"]) and np.array_equal(anc, ref["anc"]) and np.array_equal(lw, ref["lw"])
+    assert np.array_equal(cdf, ref["hist"][-1]["cdf"])

@@ -1,0 +1,12 @@
+#!/bin/bash
+# usage (on the GPU box, from the repo root): tools/traffic.sh <tag>
+# FETCH_SIZE / WRITE_SIZE passes (profiles/pmc/tcc_pass.txt, counters only) over the bench sweep and over the
+# calibration copy kernels (tools/calib, built here with hipcc), then tools/traffic.py -> gpurun_out/traffic_<tag>.json
+tag=$1
+root=$GRAFT_REPO_ROOT
+out=$root/gpurun_out/traffic_$tag
+[ -x $root/tools/calib ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o $root/tools/calib $root/tools/calib.hip
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 -i $root/profiles/pmc/tcc_pass.txt --kernel-trace --output-format csv -d $out/bench -- python3 $root/bench.py --steps 1 --warmup 0 --no-cpu-baseline --T 10 > /dev/null 2> $out.bench.err
+rocprofv3 -i $root/profiles/pmc/tcc_pass.txt --kernel-trace --output-format csv -d $out/calib -- $root/tools/calib > /dev/null 2> $out.calib.err
+cd $root && python3 tools/traffic.py $out/bench $out/calib $root/gpurun_out/traffic_$tag.json

@@ -731,3 +731,45 @@ def test_tile_stats_from_the_site_program(gpu):
         ref = O.tile_ref(O.tile_exp(x.max()))          # block floating point: weights relative to ceil(max / ln 2) * ln 2
         O.lib().orc_weight_fixed(O.I64(x.size), O._p(x), O.ctypes.c_float(ref), O.ctypes.c_int(sw.shift), O._p(q))
         assert int(q.sum()) == int(agg[b].item()) and float(tmax[b].item()) == float(x.max())
+
+
+@pytest.mark.parametrize("case", ["nan_inf", "huge", "plus_inf", "all_nan"])
+def test_integer_cdf_special_values(gpu, case):
+    """NaN / +-inf / absurdly large log-weights: gmx_weight_cdf and the fused gmx_resample give the oracle's
+    integers and ancestors (NaN and -inf carry no mass; +inf or |lw| > 2^29 ln 2 saturate the tile exponent and
+    carry none either; no mass at all -> every slot maps to the last particle)."""
+    import genjax_amd as G
+    from genjax_amd.inference import smc
+    n = 5000
+    rng = np.random.default_rng(17)
+    lw = rng.normal(0, 2, n).astype(np.float32)
+    if case == "nan_inf":
+        lw[7] = np.nan; lw[1500] = -np.inf; lw[2047] = np.nan; lw[4999] = -np.inf
+    elif case == "huge":
+        lw[100] = 1e30; lw[3000] = -1e30
+    elif case == "plus_inf":
+        lw[2500] = np.inf
+    else:
+        lw[:] = np.nan
+    cdf, total, mx, shift = smc.weight_cdf(_dev(lw))
+    rc, rt, rm, rs = O.weight_cdf(lw)
+    assert np.array_equal(cdf.cpu().numpy().view(np.uint64), rc) and int(total.item()) == rt
+    ref = O.ancestors(0, O.key(3), rc) if rt else np.full(n, n - 1, np.int32)
+    got = smc.ancestors_from_cdf(0, G.key(3), cdf, total).cpu().numpy()
+    assert np.array_equal(got, ref)
+    # the fused form: tile statistics + k_offspring_tile, no CDF in memory
+    from ctypes import c_uint32
+    from genjax_amd import _lib
+    be = _lib.get()
+    lw_d = _dev(lw)
+    ws = torch.zeros(((be.c.gmx_resample_workspace(n) + 7) // 8,), dtype=torch.int64, device="cuda")
+    mx2 = torch.zeros(1, dtype=torch.float32, device="cuda")
+    tot2 = torch.zeros(1, dtype=torch.int64, device="cuda")
+    anc = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+    kh = G.key(3).host()
+    kk = (c_uint32 * 2)(int(kh[0]), int(kh[1]))
+    be.check(be.c.gmx_resample(0, kk, be.ptr(lw_d), n, shift, None, 0, be.ptr(mx2), be.ptr(tot2), be.ptr(anc),
+                               be.ptr(ws), be.stream()), "gmx_resample")
+    assert int(tot2.item()) == rt and np.array_equal(anc.cpu().numpy(), ref)
+    m_ref, m_got = np.float32(rm), np.float32(mx2.item())
+    assert (np.isnan(m_ref) and np.isnan(m_got)) or m_ref == m_got

@@ -469,12 +469,15 @@ def rejuvenate(key: Key, collection: ParticleCollection, request, argdiffs=None)
 
 class BootstrapSweep:
     """A whole bootstrap particle filter (T steps, resampling every step) as a
-    fixed sequence of launches on one stream, capturable into a hipGraph:
+    fixed sequence of launches on one stream, capturable into a hipGraph — two launches per step:
 
-      per step t:  [generate]   x_t[i] ~ step(x_{t-1}[anc[i]]), lw[i] = log p(y_t | x_t[i]),
-                                block max partials                      (k_vm)
-                   [cdf]        fixed-point weights + chained scan       (k_reduce_max, memset, k_weight_cdf)
-                   [ancestors]  exact inverse-CDF search                 (k_ancestors)
+      per step t:  [site program]  x_t[i] ~ step(x_{t-1}[anc[i]]), lw[i] = log p(y_t | x_t[i]); specialised with 4
+                                   particles per thread a workgroup is one 1024-particle tile of the integer CDF
+                                   and also leaves the tile statistics (max, fixed-point weight sum)
+                   [offspring]     k_offspring_tile: global exponent + tile prefixes from the statistics, the
+                                   tile's CDF rebuilt in registers, exact systematic / stratified ancestors
+      (programs that cannot write the statistics: + gmx_tile_stats; multinomial or n > 2^21: gmx_weight_cdf +
+       gmx_ancestors)
 
     Key schedule (build-defined, SURVEY.md App. B): step key = fold_in(run_key, t);
     (k_prop, k_res, k_mh) = split(step key, 3); particle i uses split(k_prop, N)[i].

@@ -405,6 +405,29 @@ def weight_cdf(lw: torch.Tensor, n_total=None, max_partials=None):
     return cdf, total, mx, shift
 
 
+FUSED_RESAMPLE_MAX = 2048 * 1024        # RS_MAX_TILES tiles of 1024 particles (csrc/gmx_kernels.hip)
+
+
+def resample_fused(kind, key: Key, lw: torch.Tensor):
+    """gmx_resample: log-weights -> (ancestors int32 [n], total [1], max [1], shift) in two launches with no CDF
+    array (tile statistics + k_offspring_tile); the same integers as weight_cdf + ancestors_from_cdf."""
+    be = _lib.get()
+    lw = lw.reshape(-1).float().contiguous()
+    if lw.data_ptr() % 16:
+        lw = lw.clone()                    # a view into the middle of a buffer: the kernels load float4
+    n = lw.numel()
+    shift = cdf_shift(n)
+    anc = torch.empty((n,), dtype=torch.int32, device=lw.device)
+    total = torch.zeros((1,), dtype=torch.int64, device=lw.device)
+    mx = torch.empty((1,), dtype=torch.float32, device=lw.device)
+    ws = torch.empty(((be.c.gmx_resample_workspace(n) + 7) // 8,), dtype=torch.int64, device=lw.device)
+    kh = key.host()
+    kk = (c_uint32 * 2)(int(kh[0]), int(kh[1]))
+    be.check(be.c.gmx_resample(int(kind), kk, be.ptr(lw), n, shift, None, 0, be.ptr(mx), be.ptr(total), be.ptr(anc),
+                               be.ptr(ws), be.stream()), "gmx_resample")
+    return anc, total, mx, shift
+
+
 def ancestors_from_cdf(kind, key: Key, cdf, total, n_out=None) -> torch.Tensor:
     be = _lib.get()
     n_in = cdf.numel()
@@ -425,9 +448,12 @@ def resample(key: Key, collection: ParticleCollection, kind="systematic", n_out=
     if lw.ndim != 1:
         raise NotImplementedError("resample: batched collections")
     kind = _KINDS[kind] if isinstance(kind, str) else int(kind)
-    cdf, total, mx, shift = weight_cdf(lw)
-    anc = ancestors_from_cdf(kind, key, cdf, total, n_out)
     n = lw.numel()
+    if kind in (SYSTEMATIC, STRATIFIED) and n_out in (None, n) and 0 < n <= FUSED_RESAMPLE_MAX:
+        anc, total, mx, shift = resample_fused(kind, key, lw)        # no CDF in memory (gmx_resample)
+    else:
+        cdf, total, mx, shift = weight_cdf(lw)
+        anc = ancestors_from_cdf(kind, key, cdf, total, n_out)
     particles = trace_map(collection.get_particles(),
                           lambda v: Gathered(engine.materialize(v), anc) if tuple(v.shape[:1]) == (n,) else v)
     off = (collection.log_ml_offset or LogMLOffset()).plus(mx, total, shift, n)

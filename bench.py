@@ -19,7 +19,6 @@ from __future__ import annotations
 import argparse
 import ctypes
 import json
-import math
 import os
 import subprocess
 import sys

@@ -11,7 +11,7 @@ from __future__ import annotations
 import ctypes
 import os
 from ctypes import (POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64,
-                    c_size_t, c_uint8, c_uint32, c_uint64, c_void_p)
+                    c_size_t, c_uint32, c_uint64, c_void_p)
 
 import torch
 

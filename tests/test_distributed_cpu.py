@@ -15,6 +15,23 @@ from tests import parity
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _launch(world, worker_args, attempts=2):
+    """torch.distributed.run with `world` gloo ranks of tests/dist_worker.py on 127.0.0.1.  The rendezvous port
+    is picked free and then released, so another process can grab it in between: a failed launch is retried
+    once on a new port."""
+    r = None
+    for _ in range(attempts):
+        port = str(_free_port())
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, OMP_NUM_THREADS="1")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+               "--master-addr", "127.0.0.1", "--master-port", port,
+               os.path.join(ROOT, "tests", "dist_worker.py")] + [str(a) for a in worker_args]
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        if r.returncode == 0:
+            break
+    return r
+
+
 def _free_port():
     import socket
     s = socket.socket()
@@ -31,11 +48,7 @@ def test_sharded_sweep_equals_single_process_oracle(tmp_path, world, capacity):
     from genjax_amd import workloads
     n_total, T = 4096, 6
     out = str(tmp_path / "shard")
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), OMP_NUM_THREADS="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
-           "--master-addr", "127.0.0.1", "--master-port", env["MASTER_PORT"],
-           os.path.join(ROOT, "tests", "dist_worker.py"), out, str(n_total // world), str(T)] + ([str(capacity)] if capacity else [])
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    r = _launch(world, [out, str(n_total // world), str(T)] + ([str(capacity)] if capacity else []))
     assert r.returncode == 0, r.stderr[-3000:]
     x = np.load(out + ".npy")
     meta = json.load(open(out + ".json"))
@@ -56,11 +69,7 @@ def test_sharded_mh_sweep_equals_single_process_oracle(tmp_path, world, capacity
     forces the overflow re-run."""
     n_total, T = 4096, 4          # 1024 per rank at world 4: shards start on a CDF tile boundary
     out = str(tmp_path / "shard_mh")
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), OMP_NUM_THREADS="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
-           "--master-addr", "127.0.0.1", "--master-port", env["MASTER_PORT"],
-           os.path.join(ROOT, "tests", "dist_worker.py"), out, str(n_total // world), str(T), str(capacity), "mh"]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    r = _launch(world, [out, str(n_total // world), str(T), str(capacity), "mh"])
     assert r.returncode == 0, r.stderr[-3000:]
     x = np.load(out + ".npy")
     meta = json.load(open(out + ".json"))
@@ -76,11 +85,7 @@ def test_sharded_vector_state_sweep_equals_single_process_oracle(tmp_path, world
     gmx_shard_step + one all-to-all each); equals the single-process oracle, also through the overflow re-run."""
     n_total, T = 2048, 5
     out = str(tmp_path / "shard_vec")
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), OMP_NUM_THREADS="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
-           "--master-addr", "127.0.0.1", "--master-port", env["MASTER_PORT"],
-           os.path.join(ROOT, "tests", "dist_worker.py"), out, str(n_total // world), str(T), str(capacity), "vec"]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    r = _launch(world, [out, str(n_total // world), str(T), str(capacity), "vec"])
     assert r.returncode == 0, r.stderr[-3000:]
     x = np.load(out + ".npy")
     meta = json.load(open(out + ".json"))
@@ -97,11 +102,7 @@ def test_sharded_importancek_global_resample_equals_oracle(tmp_path, world, capa
     trace): the concatenated ranks equal the single-process oracle, for any rank count."""
     k_total = 4096
     out = str(tmp_path / "schools")
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), OMP_NUM_THREADS="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
-           "--master-addr", "127.0.0.1", "--master-port", env["MASTER_PORT"],
-           os.path.join(ROOT, "tests", "dist_worker.py"), out, str(k_total // world), "0", str(capacity), "schools"]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    r = _launch(world, [out, str(k_total // world), "0", str(capacity), "schools"])
     assert r.returncode == 0, r.stderr[-3000:]
     got = np.load(out + ".npz")
     sig = np.array(parity.SCHOOL_SIGMA, np.float32)

@@ -97,6 +97,12 @@ class Backend:
         c.gmx_tile_stats.argtypes = [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p]
         c.gmx_resample_tiles.argtypes = [c_int, POINTER(c_uint32), c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p,
                                          c_void_p, c_void_p, c_void_p]
+        c.gmx_shard_stats_bytes.argtypes = [c_int64]
+        c.gmx_shard_stats_bytes.restype = c_size_t
+        c.gmx_shard_totals.argtypes = [c_void_p, c_int, c_int64, c_void_p, c_void_p, c_void_p]
+        c.gmx_shard_step_tiles.argtypes = [c_int, POINTER(c_uint32), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                           c_void_p, c_int, c_int, c_int, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
+                                           c_void_p]
         c.gmx_shard_plan_words.argtypes = [c_int]
         c.gmx_shard_plan_words.restype = c_size_t
         c.gmx_shard_plan.argtypes = [c_int, POINTER(c_uint32), c_void_p, c_int, c_int, c_int64, c_void_p, c_void_p,

@@ -1464,13 +1464,20 @@ k_shard_route(int kind, uint32_t k0, uint32_t k1, int64_t* __restrict__ plan, co
 // from the all-gathered totals itself (world <= 64 evaluations of f) and handles 4 consecutive
 // sources per thread with two 16-byte CDF loads, like k_offspring_local.
 #define SHARD_MAX_WORLD 64
+// where a source's local CDF value comes from: the array gmx_weight_cdf wrote (TILES = false), or — like
+// k_offspring_tile — rebuilt in registers from the log-weights and this rank's tile statistics (TILES = true:
+// a block is one 1024-particle tile; tmax / agg are this rank's, *max_g the GLOBAL max log-weight)
+struct shard_tiles { const float* lw; const float* tmax; const uint64_t* agg; const float* max_g; float scale; int n_tiles; };
+
+template <bool TILES>
 __global__ void __launch_bounds__(GMX_BLOCK)
 k_shard_step(int kind, uint32_t k0, uint32_t k1, const uint64_t* __restrict__ totals, int64_t* __restrict__ plan,
-             uint64_t* __restrict__ total_out, const uint64_t* __restrict__ cdf, int rank, int world, int64_t n,
-             int64_t cap, const uint32_t* __restrict__ state, uint32_t* __restrict__ send,
+             uint64_t* __restrict__ total_out, const uint64_t* __restrict__ cdf, const shard_tiles TS, int rank,
+             int world, int64_t n, int64_t cap, const uint32_t* __restrict__ state, uint32_t* __restrict__ send,
              int32_t* __restrict__ next_idx) {
   __shared__ int64_t s_bounds[SHARD_MAX_WORLD + 1];
   __shared__ uint64_t s_tot[2];            // global total, this rank's CDF offset
+  __shared__ uint64_t s_below[4], s_scan[4];
   gmx_key key; key.k0 = k0; key.k1 = k1;
   const uint64_t u0 = gmx_bits32(key, 0) >> 9;
   const int64_t N = n * world, base = (int64_t)rank * n;
@@ -1523,15 +1530,60 @@ k_shard_step(int kind, uint32_t k0, uint32_t k1, const uint64_t* __restrict__ to
     s_lo = 0;
   } else {
     uint64_t loc[4];
-    if (i0 + 4 <= n) {
-      ulonglong2 a = reinterpret_cast<const ulonglong2*>(cdf + i0)[0];
-      ulonglong2 b = reinterpret_cast<const ulonglong2*>(cdf + i0)[1];
-      loc[0] = a.x; loc[1] = a.y; loc[2] = b.x; loc[3] = b.y;
-    } else {
+    uint64_t loc_prev;
+    if (TILES) {
+      // this rank's CDF at my 4 sources = (mass of this rank's earlier tiles) + (tile-local sums >> (K - k_b)),
+      // with the tile-local sums rebuilt from the log-weights (k_offspring_tile's scheme)
+      const int wave = threadIdx.x >> 6, my_tile = (int)blockIdx.x;
+      const int32_t K = gmx_tile_exp(*TS.max_g);
+      const int32_t k_b = gmx_tile_exp(TS.tmax[my_tile]);
+      const float ref_b = gmx_tile_ref(k_b);
+      float x[4];
+      if (i0 + 4 <= n) {
+        float4 v = *reinterpret_cast<const float4*>(TS.lw + i0);
+        x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
+      } else {
 #pragma unroll
-      for (int c = 0; c < 4; ++c) loc[c] = (i0 + c < n) ? cdf[i0 + c] : 0ull;
+        for (int c = 0; c < 4; ++c) x[c] = (i0 + c < n) ? TS.lw[i0 + c] : -gmx_inf();
+      }
+      uint64_t below = 0;
+      for (int t = (int)threadIdx.x; t < my_tile; t += GMX_BLOCK)
+        below += gmx_tile_scale(TS.agg[t], gmx_tile_exp(TS.tmax[t]), K);
+      uint64_t q[4], run = 0;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        run += (i0 + c < n) ? weight_fixed(x[c], ref_b, TS.scale) : 0ull;
+        q[c] = run;
+      }
+      uint64_t inc = run;
+#pragma unroll
+      for (int d = 1; d < GMX_WAVE; d <<= 1) {
+        uint64_t t = shfl_up_u64(inc, d);
+        if (lane >= d) inc += t;
+      }
+      below = wave_sum_u64(below);
+      if (lane == 0) s_below[wave] = below;
+      if (lane == 63) s_scan[wave] = inc;
+      __syncthreads();                       // uniform: `total` is block-uniform
+      const uint64_t prefix = (s_below[0] + s_below[1]) + (s_below[2] + s_below[3]);
+      uint64_t wave_off = 0;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) wave_off += (w < wave) ? s_scan[w] : 0ull;
+      const uint64_t excl = wave_off + (inc - run);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) loc[c] = prefix + gmx_tile_scale(excl + q[c], k_b, K);
+      loc_prev = prefix + gmx_tile_scale(excl, k_b, K);
+    } else {
+      if (i0 + 4 <= n) {
+        ulonglong2 a = reinterpret_cast<const ulonglong2*>(cdf + i0)[0];
+        ulonglong2 b = reinterpret_cast<const ulonglong2*>(cdf + i0)[1];
+        loc[0] = a.x; loc[1] = a.y; loc[2] = b.x; loc[3] = b.y;
+      } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) loc[c] = (i0 + c < n) ? cdf[i0 + c] : 0ull;
+      }
+      loc_prev = (lane == 0 && i0 > 0 && i0 < n) ? cdf[i0 - 1] : 0ull;
     }
-    const uint64_t loc_prev = (lane == 0 && i0 > 0 && i0 < n) ? cdf[i0 - 1] : 0ull;
     const double n_over_total = (double)N / (double)total;
     const double eps = (double)N * 0x1p-44 + 0x1p-40;
 #pragma unroll
@@ -1619,9 +1671,93 @@ extern "C" int gmx_shard_step(int kind, const uint32_t key[2], const uint64_t* t
                            stream);
   }
   if ((uintptr_t)cdf_d & 15) return gmx_fail("gmx_shard_step: cdf_d must be 16-byte aligned%s");
-  hipLaunchKernelGGL(k_shard_step, grid_for((n_per_rank + 3) / 4), dim3(GMX_BLOCK), 0, (hipStream_t)stream, kind,
-                     key[0], key[1], totals_d, plan_d, total_out_d, cdf_d, rank, world, n_per_rank, capacity,
-                     (const uint32_t*)state_d, (uint32_t*)send_d, next_idx_d);
+  shard_tiles none = {nullptr, nullptr, nullptr, nullptr, 0.0f, 0};
+  hipLaunchKernelGGL(k_shard_step<false>, grid_for((n_per_rank + 3) / 4), dim3(GMX_BLOCK), 0, (hipStream_t)stream,
+                     kind, key[0], key[1], totals_d, plan_d, total_out_d, cdf_d, none, rank, world, n_per_rank,
+                     capacity, (const uint32_t*)state_d, (uint32_t*)send_d, next_idx_d);
+  GMX_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---- the same step from tile statistics: no local CDF array, no all-reduce of the max ----
+// Every rank all-gathers its tile statistics (gmx_shard_stats_bytes per rank: agg[tiles_pad] u64 then
+// tmax[tiles_pad] f32, tiles_pad = tiles rounded up to even) — ONE collective carries what the max all-reduce
+// and the totals all-gather carried.  k_shard_totals (one block) turns the gathered table into the global max
+// and every rank's integer total; k_shard_step<true> rebuilds this rank's CDF per tile in registers.
+extern "C" size_t gmx_shard_stats_bytes(int64_t n_per_rank) {
+  int64_t tiles = (n_per_rank + RS_TILE - 1) / RS_TILE;
+  tiles += tiles & 1;
+  return (size_t)tiles * 12;
+}
+
+__global__ void __launch_bounds__(GMX_BLOCK)
+k_shard_totals(const uint8_t* __restrict__ stats_all, int world, int n_tiles, size_t stride,
+               uint64_t* __restrict__ totals, float* __restrict__ max_out) {
+  __shared__ float lds4[4];
+  __shared__ uint64_t s_sum[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tiles_pad = n_tiles + (n_tiles & 1);
+  float m = -gmx_inf();
+  for (int r = 0; r < world; ++r) {
+    const float* tmax = reinterpret_cast<const float*>(stats_all + (size_t)r * stride + (size_t)tiles_pad * 8);
+    for (int t = (int)threadIdx.x; t < n_tiles; t += GMX_BLOCK) m = gmx_fmax(m, tmax[t]);
+  }
+  const float M = block_max(m, lds4);
+  const int32_t K = gmx_tile_exp(M);
+  if (threadIdx.x == 0) *max_out = M;
+  for (int r = 0; r < world; ++r) {
+    const uint64_t* agg = reinterpret_cast<const uint64_t*>(stats_all + (size_t)r * stride);
+    const float* tmax = reinterpret_cast<const float*>(stats_all + (size_t)r * stride + (size_t)tiles_pad * 8);
+    uint64_t sum = 0;
+    for (int t = (int)threadIdx.x; t < n_tiles; t += GMX_BLOCK) sum += gmx_tile_scale(agg[t], gmx_tile_exp(tmax[t]), K);
+    sum = wave_sum_u64(sum);
+    __syncthreads();
+    if (lane == 0) s_sum[wave] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) totals[r] = (s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]);
+  }
+}
+
+extern "C" int gmx_shard_totals(const void* stats_all_d, int world, int64_t n_per_rank, uint64_t* totals_d,
+                                float* max_d, gmx_stream stream) {
+  if (!stats_all_d || !totals_d || !max_d) return gmx_fail("gmx_shard_totals: null argument%s");
+  if (world < 1 || world > 1024) return gmx_fail("gmx_shard_totals: world out of range%s");
+  const int64_t tiles = (n_per_rank + RS_TILE - 1) / RS_TILE;
+  if (n_per_rank <= 0 || tiles > RS_MAX_TILES) return gmx_fail("gmx_shard_totals: n_per_rank out of range (<= 2^21)%s");
+  if ((uintptr_t)stats_all_d & 7) return gmx_fail("gmx_shard_totals: stats_all_d must be 8-byte aligned%s");
+  hipLaunchKernelGGL(k_shard_totals, dim3(1), dim3(GMX_BLOCK), 0, (hipStream_t)stream, (const uint8_t*)stats_all_d,
+                     world, (int)tiles, gmx_shard_stats_bytes(n_per_rank), totals_d, max_d);
+  GMX_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int gmx_shard_step_tiles(int kind, const uint32_t key[2], const uint64_t* totals_d, int64_t* plan_d,
+                                    uint64_t* total_out_d, const float* lw_d, const void* stats_own_d,
+                                    const float* max_d, int shift, int rank, int world, int64_t n_per_rank,
+                                    int64_t capacity, const void* state_d, void* send_d, int32_t* next_idx_d,
+                                    gmx_stream stream) {
+  if (shard_check("gmx_shard_step_tiles", kind, key, rank, world, n_per_rank)) return 1;
+  if (!totals_d || !plan_d || !lw_d || !stats_own_d || !max_d || !state_d || !send_d || !next_idx_d)
+    return gmx_fail("gmx_shard_step_tiles: null argument%s");
+  if (capacity < 1 || capacity > n_per_rank)
+    return gmx_fail("gmx_shard_step_tiles: capacity must be in [1, n_per_rank]%s");
+  if (n_per_rank + (int64_t)world * capacity > 0x7fffffffLL)
+    return gmx_fail("gmx_shard_step_tiles: extended state index exceeds int32%s");
+  if (world > SHARD_MAX_WORLD) return gmx_fail("gmx_shard_step_tiles: world <= 64 (use gmx_weight_cdf + gmx_shard_step)%s");
+  if (shift < 1 || shift > 62) return gmx_fail("gmx_shard_step_tiles: shift out of range%s");
+  const int64_t tiles = (n_per_rank + RS_TILE - 1) / RS_TILE;
+  if (tiles > RS_MAX_TILES) return gmx_fail("gmx_shard_step_tiles: n_per_rank too large (<= 2^21)%s");
+  if (((uintptr_t)lw_d & 15) || ((uintptr_t)stats_own_d & 7))
+    return gmx_fail("gmx_shard_step_tiles: lw_d must be 16-byte and stats_own_d 8-byte aligned%s");
+  const int64_t tiles_pad = tiles + (tiles & 1);
+  shard_tiles ts;
+  ts.lw = lw_d;
+  ts.agg = (const uint64_t*)stats_own_d;
+  ts.tmax = (const float*)((const uint8_t*)stats_own_d + (size_t)tiles_pad * 8);
+  ts.max_g = max_d; ts.scale = gmx_pow2i(shift); ts.n_tiles = (int)tiles;
+  hipLaunchKernelGGL(k_shard_step<true>, dim3((unsigned)tiles), dim3(GMX_BLOCK), 0, (hipStream_t)stream, kind, key[0],
+                     key[1], totals_d, plan_d, total_out_d, (const uint64_t*)nullptr, ts, rank, world, n_per_rank,
+                     capacity, (const uint32_t*)state_d, (uint32_t*)send_d, next_idx_d);
   GMX_HIP(hipGetLastError());
   return 0;
 }

@@ -1,7 +1,7 @@
 """The three collectives a sharded SMC step needs, behind one small interface.
 
   all_reduce_max(t)      in place, 1 element (the global max log-weight; the overflow flag)
-  all_gather(out, inp)   out[world * k] <- every rank's inp[k] (the integer totals)
+  all_gather(out, inp)   out[world * k] <- every rank's inp[k] (the integer totals; the tile statistics)
   all_to_all(out, inp)   equal split: block s of out <- block `me` of rank s's inp (states)
 
 `RcclComm` calls RCCL directly (ctypes on the librccl.so torch already loaded) on
@@ -22,7 +22,7 @@ from ctypes import POINTER, Structure, byref, c_char, c_int, c_size_t, c_void_p
 
 import torch
 
-_NCCL_INT64, _NCCL_FLOAT32, _NCCL_MAX = 4, 7, 2
+_NCCL_INT8, _NCCL_INT64, _NCCL_FLOAT32, _NCCL_MAX = 0, 4, 7, 2
 
 
 class TorchComm:
@@ -93,9 +93,12 @@ class RcclComm:
         self._check(self.lib.ncclAllReduce(p, p, t.numel(), dt, _NCCL_MAX, self.comm, self._stream()), "ncclAllReduce")
 
     def all_gather(self, out, inp):
-        assert out.dtype == inp.dtype == torch.int64 and out.numel() == self.world * inp.numel()
-        self._check(self.lib.ncclAllGather(c_void_p(inp.data_ptr()), c_void_p(out.data_ptr()), inp.numel(), _NCCL_INT64,
-                                           self.comm, self._stream()), "ncclAllGather")
+        """any dtype (gathered as bytes): the 8-byte totals, or a rank's block of tile statistics"""
+        assert out.dtype == inp.dtype and out.numel() == self.world * inp.numel()
+        assert out.is_contiguous() and inp.is_contiguous()
+        self._check(self.lib.ncclAllGather(c_void_p(inp.data_ptr()), c_void_p(out.data_ptr()),
+                                           inp.numel() * inp.element_size(), _NCCL_INT8, self.comm, self._stream()),
+                    "ncclAllGather")
 
     def all_to_all(self, out, inp):
         assert out.dtype == inp.dtype == torch.float32 and out.numel() == inp.numel()

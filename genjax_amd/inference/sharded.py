@@ -31,6 +31,7 @@ all-to-all maps onto direct peer links rather than a ring.
 from __future__ import annotations
 
 import math
+import os
 from ctypes import c_uint32
 
 import numpy as np
@@ -40,7 +41,7 @@ from .. import _lib
 from ..core.choice_map import ChoiceMap
 from ..random import Key, fold_in, lazy_split, split
 from ..engine import Gathered
-from .smc import cdf_reference, cdf_shift
+from .smc import SYSTEMATIC, cdf_reference, cdf_shift
 
 
 def systematic_slot_bounds(offsets, total: int, n_total: int, u0: int):
@@ -154,6 +155,20 @@ class ShardedBootstrapSweep:
                 self.p_mh_init.comp.specialize()
                 self.p_mh_step.comp.specialize()
         self.partials = torch.zeros((2, (n + 255) // 256), dtype=torch.float32, device=dev)
+        # two collectives per step instead of three: the ranks all-gather their CDF TILE STATISTICS (12 bytes per
+        # 1024 particles; written by the site program itself when it can, else by gmx_tile_stats), from which
+        # every rank derives the global max and all the totals — no max all-reduce, no local CDF array
+        from .smc import FUSED_RESAMPLE_MAX, STRATIFIED
+        self.tiles_mode = (self.kind in (SYSTEMATIC, STRATIFIED) and n <= FUSED_RESAMPLE_MAX and W <= 64
+                           and os.environ.get("GENMI_SHARD_TILES", "1") != "0")
+        if self.tiles_mode:
+            sb = int(be.c.gmx_shard_stats_bytes(n))
+            tiles = (n + CDF_TILE - 1) // CDF_TILE
+            pad = tiles + (tiles & 1)
+            self.stats_own = torch.zeros((sb,), dtype=torch.uint8, device=dev)
+            self.stats_all = torch.zeros((W * sb,), dtype=torch.uint8, device=dev)
+            self.tile_agg = self.stats_own[:pad * 8].view(torch.int64)
+            self.tile_max = self.stats_own[pad * 8:].view(torch.float32)
         self.step_keys = []
         for t in range(T):
             ks = split(fold_in(key, t), 3)
@@ -214,8 +229,13 @@ class ShardedBootstrapSweep:
         bufs[prog.ro[1]] = rows_t[:, :n]                 # [D, n] window of the [D, n + W*C] rows
         bufs[prog.wo[1]] = self.lw.reshape(1, n)
         # keys of the GLOBAL particle index: split(k_prop, N)[g*n + i]
-        vm = prog.comp.bind(leaves, (n,), lazy_split(k_prop, self.N), red_out=self.partials, out_buffers=bufs,
-                            index_offset=g * n)
+        writes_stats = self.tiles_mode and prog.comp.writes_tile_stats()
+        if writes_stats:        # the workgroup maxima land in the statistics block (red_out plane 0), the sums beside them
+            vm = prog.comp.bind(leaves, (n,), lazy_split(k_prop, self.N), red_out=self.tile_max, out_buffers=bufs,
+                                index_offset=g * n, tile_stats=(self.tile_agg, self.shift))
+        else:
+            vm = prog.comp.bind(leaves, (n,), lazy_split(k_prop, self.N), red_out=self.partials, out_buffers=bufs,
+                                index_offset=g * n)
         kh = k_res.host()
         kk = (c_uint32 * 2)(int(kh[0]), int(kh[1]))
         m = self.maxs[t:t + 1]
@@ -229,7 +249,16 @@ class ShardedBootstrapSweep:
             step2 = (self.kind, kk, P(self.totals_all), P(self.plan), P(tot), P(self.cdf), g, W, n, C, P(cur_a),
                      P(self.send2), P(self.idx))
             recv2 = cur_a[n:]
+        tiles = None
+        if self.tiles_mode:
+            mk = lambda row, snd: (self.kind, kk, P(self.totals_all), P(self.plan), P(tot), P(self.lw), P(self.stats_own),
+                                   P(m), self.shift, g, W, n, C, P(row), P(snd), P(self.idx))
+            tiles = {"stats": None if writes_stats else (P(self.lw), n, self.shift, P(self.tile_max), P(self.tile_agg)),
+                     "totals": (P(self.stats_all), W, n, P(self.totals_all), P(m)),
+                     "steps": [mk(rows_t[d], self.send[d]) for d in range(self.D)],
+                     "step2": mk(self.aext[t % 2], self.send2) if (self.rejuvenate is not None and t >= 1) else None}
         return {
+            "tiles": tiles,
             "prog": prog.comp, "vm": vm, "mh": mh, "step2": step2, "recv2": recv2,
             "pmax": pmax, "keep": (kk, tot, leaves, m),
             # the CDF kernel reduces the (all-reduced) block maxima itself and records the max in maxs[t]
@@ -249,6 +278,24 @@ class ShardedBootstrapSweep:
         if b["mh"] is not None:
             b["mh"][0].launch(b["mh"][1])                               # MH move on the resampled particles
         b["prog"].launch(b["vm"])                                      # x_t, lw_t, block maxima
+        if b["tiles"] is not None:
+            tl = b["tiles"]
+            if tl["stats"] is not None:
+                be.check(c.gmx_tile_stats(*tl["stats"], st), "gmx_tile_stats")
+            if self.comm:
+                self.cx.all_gather(self.stats_all, self.stats_own)          # 12 bytes per 1024 particles per rank
+            else:
+                self.stats_all.copy_(self.stats_own)
+            be.check(c.gmx_shard_totals(*tl["totals"], st), "gmx_shard_totals")    # global max + every rank's total
+            for d in range(self.D):
+                be.check(c.gmx_shard_step_tiles(*tl["steps"][d], st), "gmx_shard_step_tiles")
+                if self.comm:
+                    self.cx.all_to_all(b["recvs"][d], self.send[d])
+            if tl["step2"] is not None:
+                be.check(c.gmx_shard_step_tiles(*tl["step2"], st), "gmx_shard_step_tiles")
+                if self.comm:
+                    self.cx.all_to_all(b["recv2"], self.send2)
+            return
         if self.comm:
             self.cx.all_reduce_max(b["pmax"])                            # element-wise MAX of the block maxima (<= 4 KB)
         be.check(c.gmx_weight_cdf(*b["cdf"], st), "gmx_weight_cdf")    # global max + local integer CDF against it

@@ -268,6 +268,22 @@ int gmx_shard_step(int kind, const uint32_t key[2], const uint64_t* totals_d /* 
                    uint64_t* total_out_d /* [1] or NULL */, const uint64_t* cdf_d, int rank, int world,
                    int64_t n_per_rank, int64_t capacity, const void* state_d, void* send_d,
                    int32_t* next_idx_d, gmx_stream stream);
+/* The same step from TILE STATISTICS — two collectives per step instead of three, no local CDF array.
+ * Each rank's statistics block (gmx_shard_stats_bytes(n_per_rank) bytes: agg[tiles_pad] u64, then
+ * tmax[tiles_pad] f32, tiles_pad = ceil(n_per_rank / 1024) rounded up to even; written by gmx_tile_stats or by
+ * the site program itself, gmx_run_args.tile_agg_d / red_out_d) is all-gathered — that one collective carries what
+ * the max all-reduce and the totals all-gather carried.  gmx_shard_totals (one block) turns the gathered
+ * table into the global max (*max_d) and every rank's integer total (totals_d[world]);
+ * gmx_shard_step_tiles is gmx_shard_step with this rank's CDF rebuilt per tile in registers from lw_d and
+ * its own block.  n_per_rank <= 2^21, world <= 64; shards start on a tile boundary (n_per_rank % 1024 == 0
+ * when world > 1). */
+size_t gmx_shard_stats_bytes(int64_t n_per_rank);
+int gmx_shard_totals(const void* stats_all_d /* [world] blocks */, int world, int64_t n_per_rank,
+                     uint64_t* totals_d /* [world] */, float* max_d /* [1] */, gmx_stream stream);
+int gmx_shard_step_tiles(int kind, const uint32_t key[2], const uint64_t* totals_d, int64_t* plan_d,
+                         uint64_t* total_out_d, const float* lw_d, const void* stats_own_d, const float* max_d,
+                         int shift, int rank, int world, int64_t n_per_rank, int64_t capacity,
+                         const void* state_d, void* send_d, int32_t* next_idx_d, gmx_stream stream);
 
 /* ------------------------------------------------------------------------
  * MH accept + select.  Replaces the user idiom

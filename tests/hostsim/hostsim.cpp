@@ -320,6 +320,49 @@ extern "C" int gmx_shard_step(int kind, const uint32_t key[2], const uint64_t* t
   plan[GMX_PLAN_OVERFLOW] = flag;
   return gmx_shard_route(kind, key, plan, cdf, rank, world, n, cap, state, send, next_idx, st);
 }
+extern "C" size_t gmx_shard_stats_bytes(int64_t n) { int64_t t = (n + HS_TILE - 1) / HS_TILE; t += t & 1; return (size_t)t * 12; }
+extern "C" int gmx_shard_totals(const void* stats_all, int world, int64_t n, uint64_t* totals, float* max_d, gmx_stream) {
+  if (!stats_all || !totals || !max_d) return fail("shard_totals: null argument");
+  const int64_t tiles = (n + HS_TILE - 1) / HS_TILE, pad = tiles + (tiles & 1);
+  const size_t stride = gmx_shard_stats_bytes(n);
+  float M = -gmx_inf();
+  for (int r = 0; r < world; ++r) {
+    const float* tm = (const float*)((const uint8_t*)stats_all + r * stride + pad * 8);
+    for (int64_t t = 0; t < tiles; ++t) M = gmx_fmax(M, tm[t]);
+  }
+  const int32_t K = gmx_tile_exp(M);
+  for (int r = 0; r < world; ++r) {
+    const uint64_t* ag = (const uint64_t*)((const uint8_t*)stats_all + r * stride);
+    const float* tm = (const float*)((const uint8_t*)stats_all + r * stride + pad * 8);
+    uint64_t sum = 0;
+    for (int64_t t = 0; t < tiles; ++t) sum += gmx_tile_scale(ag[t], gmx_tile_exp(tm[t]), K);
+    totals[r] = sum;
+  }
+  *max_d = M;
+  return 0;
+}
+// the mirror rebuilds this rank's CDF array from log-weights + its statistics and runs the array form
+extern "C" int gmx_shard_step_tiles(int kind, const uint32_t key[2], const uint64_t* totals, int64_t* plan, uint64_t* total_out,
+                                    const float* lw, const void* stats_own, const float* max_d, int shift, int rank, int world,
+                                    int64_t n, int64_t cap, const void* state, void* send, int32_t* next_idx, gmx_stream st) {
+  if (!lw || !stats_own || !max_d) return fail("shard_step_tiles: null argument");
+  const int64_t tiles = (n + HS_TILE - 1) / HS_TILE, pad = tiles + (tiles & 1);
+  const uint64_t* ag = (const uint64_t*)stats_own;
+  const float* tm = (const float*)((const uint8_t*)stats_own + pad * 8);
+  const int32_t K = gmx_tile_exp(*max_d);
+  const float scale = gmx_pow2i(shift);
+  std::vector<uint64_t> cdf((size_t)n);
+  uint64_t prefix = 0;
+  for (int64_t b = 0; b < tiles; ++b) {
+    const int64_t lo = b * HS_TILE, hi = lo + HS_TILE < n ? lo + HS_TILE : n;
+    const int32_t k = gmx_tile_exp(tm[b]);
+    const float ref = gmx_tile_ref(k);
+    uint64_t run = 0;
+    for (int64_t i = lo; i < hi; ++i) { run += hs_weight_fixed(lw[i], ref, scale); cdf[(size_t)i] = prefix + gmx_tile_scale(run, k, K); }
+    prefix += gmx_tile_scale(ag[b], k, K);
+  }
+  return gmx_shard_step(kind, key, totals, plan, total_out, cdf.data(), rank, world, n, cap, state, send, next_idx, st);
+}
 extern "C" int gmx_gather(const void* const* src, void* const* dst, const int32_t* bytes, int32_t n_leaves,
                           const int32_t* anc, int64_t n_out, gmx_stream) {
   for (int32_t l = 0; l < n_leaves; ++l)

@@ -215,11 +215,27 @@ def check_shard_route(n=1000, world=4, capacity=None, kind=None, seed=0, skew=0.
     totals = torch.zeros((world,), dtype=torch.int64, device=dev)
     cdfs, sends, idxs, xexts, plans = [], [], [], [], []
     ws = torch.zeros(((be.c.gmx_weight_cdf_workspace(n) + 7) // 8,), dtype=torch.int64, device=dev)
-    for r in range(world):
-        cdf = torch.zeros((n,), dtype=torch.int64, device=dev)
-        be.check(be.c.gmx_weight_cdf(be.ptr(T(lw[r * n:(r + 1) * n])), n, shift, None, 0, be.ptr(max_d), be.ptr(cdf),
-                                     be.ptr(totals[r:r + 1]), be.ptr(ws), be.stream()), "gmx_weight_cdf")
-        cdfs.append(cdf)
+    lws = [T(lw[r * n:(r + 1) * n]) for r in range(world)]
+    if fused == "tiles":        # the two-collective form: tile statistics -> totals + global max, no CDF array
+        sb = int(be.c.gmx_shard_stats_bytes(n))
+        pad = (n + 1023) // 1024
+        pad += pad & 1
+        stats_all = torch.zeros((world * sb,), dtype=torch.uint8, device=dev)
+        for r in range(world):
+            blk = stats_all[r * sb:(r + 1) * sb]
+            be.check(be.c.gmx_tile_stats(be.ptr(lws[r]), n, shift, be.ptr(blk[pad * 8:]), be.ptr(blk), be.stream()),
+                     "gmx_tile_stats")
+        max_d = torch.zeros((1,), dtype=torch.float32, device=dev)
+        be.check(be.c.gmx_shard_totals(be.ptr(stats_all), world, n, be.ptr(totals), be.ptr(max_d), be.stream()),
+                 "gmx_shard_totals")
+        if not dead:
+            assert float(max_d.item()) == M_ref
+    else:
+        for r in range(world):
+            cdf = torch.zeros((n,), dtype=torch.int64, device=dev)
+            be.check(be.c.gmx_weight_cdf(be.ptr(lws[r]), n, shift, None, 0, be.ptr(max_d), be.ptr(cdf),
+                                         be.ptr(totals[r:r + 1]), be.ptr(ws), be.stream()), "gmx_weight_cdf")
+            cdfs.append(cdf)
     for r in range(world):
         plan = torch.zeros((int(be.c.gmx_shard_plan_words(world)),), dtype=torch.int64, device=dev)
         tot = torch.zeros((1,), dtype=torch.int64, device=dev)
@@ -227,7 +243,12 @@ def check_shard_route(n=1000, world=4, capacity=None, kind=None, seed=0, skew=0.
         xe[:n] = T(x[r * n:(r + 1) * n])
         send = torch.full((world * C,), float("nan"), dtype=torch.float32, device=dev)
         idx = torch.full((n,), -1, dtype=torch.int32, device=dev)
-        if fused:       # gmx_shard_step: plan + route in one launch
+        if fused == "tiles":
+            be.check(be.c.gmx_shard_step_tiles(kind, kk, be.ptr(totals), be.ptr(plan), be.ptr(tot), be.ptr(lws[r]),
+                                               be.ptr(stats_all[r * sb:(r + 1) * sb]), be.ptr(max_d), shift, r, world,
+                                               n, C, be.ptr(xe), be.ptr(send), be.ptr(idx), be.stream()),
+                     "gmx_shard_step_tiles")
+        elif fused:     # gmx_shard_step: plan + route in one launch
             be.check(be.c.gmx_shard_step(kind, kk, be.ptr(totals), be.ptr(plan), be.ptr(tot), be.ptr(cdfs[r]), r, world,
                                          n, C, be.ptr(xe), be.ptr(send), be.ptr(idx), be.stream()), "gmx_shard_step")
         else:

@@ -15,14 +15,14 @@ from tests import parity
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _launch(world, worker_args, attempts=2):
+def _launch(world, worker_args, attempts=2, extra_env=None):
     """torch.distributed.run with `world` gloo ranks of tests/dist_worker.py on 127.0.0.1.  The rendezvous port
     is picked free and then released, so another process can grab it in between: a failed launch is retried
     once on a new port."""
     r = None
     for _ in range(attempts):
         port = str(_free_port())
-        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, OMP_NUM_THREADS="1")
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, OMP_NUM_THREADS="1", **(extra_env or {}))
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
                "--master-addr", "127.0.0.1", "--master-port", port,
                os.path.join(ROOT, "tests", "dist_worker.py")] + [str(a) for a in worker_args]
@@ -41,14 +41,16 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world,capacity", [(2, 0), (4, 0), (2, 3)])
-def test_sharded_sweep_equals_single_process_oracle(tmp_path, world, capacity):
+@pytest.mark.parametrize("world,capacity,tiles", [(2, 0, "1"), (4, 0, "1"), (2, 3, "1"), (2, 0, "0")])
+def test_sharded_sweep_equals_single_process_oracle(tmp_path, world, capacity, tiles):
     """capacity 0 = default (fast path, no overflow); capacity 3 forces the
-    overflow flag and the full-capacity re-run."""
+    overflow flag and the full-capacity re-run.  tiles "1" = the two-collective step (all-gather of tile
+    statistics + all-to-all), "0" = GENMI_SHARD_TILES=0: max all-reduce + local CDF + totals all-gather + all-to-all."""
     from genjax_amd import workloads
     n_total, T = 4096, 6
     out = str(tmp_path / "shard")
-    r = _launch(world, [out, str(n_total // world), str(T)] + ([str(capacity)] if capacity else []))
+    r = _launch(world, [out, str(n_total // world), str(T)] + ([str(capacity)] if capacity else []),
+                extra_env={"GENMI_SHARD_TILES": tiles})
     assert r.returncode == 0, r.stderr[-3000:]
     x = np.load(out + ".npy")
     meta = json.load(open(out + ".json"))

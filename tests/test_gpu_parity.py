@@ -359,7 +359,7 @@ def test_plates_match_oracle(gpu, n):
     (100_352, 8, {"seed": 6, "capacity": 12_500}), (250_880, 2, {"seed": 7, "skew": 0.5}),
     (101_376, 5, {"seed": 8}), (2048, 4, {"seed": 9, "kind": 1}),
 ])
-@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("fused", [False, True, "tiles"])
 def test_global_resampling_routes_match_oracle(gpu, n, world, kw, fused):
     """gmx_shard_plan + gmx_shard_route, and their one-launch form gmx_shard_step, with every rank
     emulated on one GPU == the oracle's single-population resample (bit-exact ancestors => states)."""
@@ -369,6 +369,7 @@ def test_global_resampling_routes_match_oracle(gpu, n, world, kw, fused):
 
 def test_global_resampling_flags_overflow(gpu):
     assert parity.check_shard_route(1024, 3, skew=2.0, seed=1, capacity=5)["overflow"]
+    assert parity.check_shard_route(1024, 3, skew=2.0, seed=1, capacity=5, fused="tiles")["overflow"]
 
 
 def test_sharded_sweep_world1_matches_oracle(gpu):

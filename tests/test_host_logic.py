@@ -527,6 +527,12 @@ def test_global_resampling_routes_match_oracle():
     assert not parity.check_shard_route(1000, 1)["overflow"]
     assert not parity.check_shard_route(2048, 4, fused=True, seed=4)["overflow"]
     assert parity.check_shard_route(1024, 3, skew=2.0, seed=1, capacity=5, fused=True)["overflow"]
+    # the two-collective form (tile statistics instead of a CDF array and a max all-reduce)
+    assert not parity.check_shard_route(2048, 4, fused="tiles", seed=4)["overflow"]
+    assert not parity.check_shard_route(1024, 8, fused="tiles", skew=-3.0, seed=2, kind=O.STRATIFIED)["overflow"]
+    assert parity.check_shard_route(1024, 3, skew=2.0, seed=1, capacity=5, fused="tiles")["overflow"]
+    assert not parity.check_shard_route(64, 2, dead=True, fused="tiles")["overflow"]
+    assert not parity.check_shard_route(1000, 1, fused="tiles")["overflow"]
 
 
 def test_conditional_smc_and_proposals():

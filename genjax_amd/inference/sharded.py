@@ -7,22 +7,24 @@ number of ranks:
 
   * per-particle keys are derived from the GLOBAL index (GMX_KEY_SPLIT with
     index_offset = g*n);
-  * weights are exact integers q_i = floor(exp(lw_i - M) * 2^shift) with the
-    GLOBAL max M (all-reduce MAX of 4 bytes) and shift from the GLOBAL count;
-  * the global CDF is offset_g + local CDF with offset_g from an all-gather of
-    the 8-byte local totals (exact integer sums: any partition gives the same CDF);
+  * weights are exact integers in block floating point over tiles of 1024 consecutive GLOBAL indices
+    (include/genmi.h "Resampling"): two numbers per tile (max log-weight, fixed-point weight sum) determine the
+    whole integer CDF — shards therefore start on a tile boundary (n % 1024 == 0 when sharded);
+  * ONE all-gather of the ranks' tile-statistics blocks (12 bytes per 1024 particles) gives every rank the global
+    max, hence the global exponent, and EVERY rank's integer total (gmx_shard_totals) — exact integer sums: any
+    partition gives the same CDF;
   * rank r resolves the output slots that fall into ITS mass interval
     [offset_r, offset_r + total_r) — for systematic / stratified resampling a
-    contiguous slot range [S_r, E_r) every rank derives from the totals alone
-    (gmx_shard_plan, on the device).  Slots it owns itself become ancestor
-    indices for the next step's fused gather; the states for slots other ranks
-    own go into fixed-capacity send blocks (gmx_shard_route) and ONE
-    equal-split all-to-all delivers them behind the receiver's local states
+    contiguous slot range [S_r, E_r) every rank derives from the totals alone.
+    Slots it owns itself become ancestor indices for the next step's fused gather; the states for slots other
+    ranks own go into fixed-capacity send blocks (gmx_shard_step_tiles, which rebuilds the shard's CDF per tile in
+    registers) and ONE equal-split all-to-all delivers them behind the receiver's local states
     (balanced weights keep all but O(sqrt(n)) particles per boundary rank-local).
 
-So per SMC step: 1 all-reduce (4 B), 1 all-gather (8 B/rank), 1 all-to-all
-(world * capacity * 4 B per rank), all enqueued on the stream: the host never
-waits for the device inside a sweep.  The evidence terms and the capacity
+So per SMC step: 1 all-gather (12 B per 1024 particles per rank) and 1 all-to-all (world * capacity * 4 B per
+rank), all enqueued on the stream: the host never waits for the device inside a sweep.  (GENMI_SHARD_TILES=0,
+multinomial, n > 2^21 per rank or > 64 ranks: all-reduce MAX, gmx_weight_cdf against the global max, all-gather
+of the 8-byte totals, gmx_shard_step, all-to-all.)  The evidence terms and the capacity
 overflow flag are read once at the end; an overflow (weights so unbalanced that
 a rank must ship more than `capacity` particles to one peer) re-runs the sweep
 with capacity = n, which always suffices.  xGMI is point-to-point, so the

@@ -126,7 +126,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world == 1:
         raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-    torch.cuda.set_device(local_rank)
+    # GENMI_BENCH_BACKEND=cpu is for tests/test_distributed_cpu.py only: the same control flow (rendezvous,
+    # barriers, max over ranks, one JSON line from rank 0) on gloo + the C-ABI's CPU mirror, no timing claims
+    cpu_mode = os.environ.get("GENMI_BENCH_BACKEND") == "cpu"
+    if cpu_mode:
+        import tests.hostsim as hs
+        hs.install()
+    else:
+        torch.cuda.set_device(local_rank)
+    tdev = "cpu" if cpu_mode else "cuda"
     dist = None
     if world > 1 or args.sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -135,7 +143,10 @@ def main():
         os.environ.setdefault("WORLD_SIZE", "1")
         import torch.distributed as dist_
         dist = dist_
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if cpu_mode:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import genjax_amd as G
     from genjax_amd import _lib, workloads
@@ -170,7 +181,8 @@ def main():
     def barrier():
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not cpu_mode:
+            torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         launch()
@@ -181,7 +193,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        tt = torch.tensor([dt], device=tdev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     total_particles = n * world
@@ -204,7 +216,7 @@ def main():
         "log_ml_rel_err": abs(log_ml - kal) / abs(kal),
     }
 
-    if rank == 0:
+    if rank == 0 and not cpu_mode:
         # ---- per-kernel durations, HIP events on the launch stream ----
         from ctypes import c_float, c_void_p
         timer = c_void_p()
@@ -300,6 +312,8 @@ def main():
             torch.cuda.synchronize()
             sw.cx.destroy()
         dist.destroy_process_group()
+    if cpu_mode:
+        out["data"] = "synthetic (CPU mirror of the C-ABI: control-flow test, not a measurement)"
     sys.stdout.flush()
     try:
         ctypes.CDLL(None).fflush(None)       # C stdio buffers (the banner) go where fd 1 points NOW: stderr

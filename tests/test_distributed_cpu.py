@@ -140,3 +140,30 @@ def test_slot_bounds_match_ancestors():
     b = systematic_slot_bounds(offs, total, n, u0)
     for (lo, hi), (s, e) in zip(zip(cuts[:-1], cuts[1:]), zip(b[:-1], b[1:])):
         assert e - s == int(np.sum((anc >= lo) & (anc < hi)))
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_bench_contract_control_flow(world):
+    """bench.py's N > 1 control flow (rendezvous on 127.0.0.1, barriers, max over ranks, exactly ONE JSON line on
+    stdout from rank 0, shard size rounded up to the CDF tile) — on gloo + the CPU mirror; values are not timings."""
+    port = str(_free_port())
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, OMP_NUM_THREADS="1", GENMI_BENCH_BACKEND="cpu")
+    args = ["--gpus", str(world), "--steps", "2", "--warmup", "1", "--particles", "3000", "--T", "4", "--no-cpu-baseline",
+            "--no-graph"]
+    if world == 1:
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + args
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+               "--master-addr", "127.0.0.1", "--master-port", port, os.path.join(ROOT, "bench.py")] + args
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config"):
+        assert k in out
+    assert out["n_gpus"] == world and out["steps"] == 2 and out["warmup"] == 1 and out["scaling"] == "weak"
+    per = 3000 if world == 1 else 3072
+    assert out["config"]["particles_per_gpu"] == per and out["config"]["particles_total"] == per * world
+    assert out["value"] > 0 and abs(out["log_ml"] - out["log_ml_kalman"]) < 0.5

@@ -27,6 +27,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# cpu_baseline leg only: libgomp reads this when it is first loaded; a passive team pays a wake-up per parallel
+# region (three per SMC step), which made the port's rate swing by 10x between runs
+os.environ.setdefault("OMP_WAIT_POLICY", "ACTIVE")
 
 N_PARTICLES = 1_000_000
 T_STEPS = 100
@@ -62,6 +65,19 @@ def cpu_baseline(n, T, ys, seed, budget_s=25.0):
     import numpy as np
     lib = ctypes.CDLL(so)
     cores = int(lib.orc_threads())
+    # the cores this process may actually use: affinity mask and cgroup quota (a 128-thread team on a box that
+    # grants fewer CPUs spends its time in barriers: measured 1.7e7 instead of 1e8 particle-steps/s)
+    try:
+        cores = min(cores, len(os.sched_getaffinity(0)))
+        quota = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota[0] != "max":
+            cores = max(1, min(cores, int(int(quota[0]) / int(quota[1]))))
+    except Exception:
+        pass
+    try:
+        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(cores)
+    except Exception:
+        pass
     from oracle.genjax_oracle import cdf_shift
     shift = cdf_shift(n)
     f32, u64, i32 = np.float32, np.uint64, np.int32

@@ -774,3 +774,33 @@ def test_integer_cdf_special_values(gpu, case):
     assert int(tot2.item()) == rt and np.array_equal(anc.cpu().numpy(), ref)
     m_ref, m_got = np.float32(rm), np.float32(mx2.item())
     assert (np.isnan(m_ref) and np.isnan(m_got)) or m_ref == m_got
+
+
+def test_resampler_fuzz(gpu):
+    """random sizes (ragged tiles, single tile, many tiles) x random weight shapes x both ordered kinds:
+    gmx_weight_cdf's integers and gmx_resample's ancestors against the oracle"""
+    from ctypes import c_uint32
+    import genjax_amd as G
+    from genjax_amd import _lib
+    from genjax_amd.inference import smc
+    be = _lib.get()
+    rng = np.random.default_rng(2024)
+    for it in range(40):
+        n = int(rng.choice([1, 2, 3, 63, 64, 65, 1000, 1023, 1024, 1025, 2047, 2049, 4097, 10_007, 65_536, 200_003]))
+        style = it % 5
+        lw = rng.normal(0, [0.1, 1, 3, 10, 30][style], n).astype(np.float32)
+        if style == 3 and n > 10:
+            lw[rng.choice(n, n // 3, replace=False)] = -np.inf
+        if style == 4 and n > 2048:
+            lw[:1024] -= 200.0                      # a whole tile 200 nats below the rest: shifted out entirely
+            lw[1024:2048] += 20.0
+        kind = it % 2
+        key, okey = G.key(1000 + it), O.key(1000 + it)
+        rc, rt, rm, rs = O.weight_cdf_c(lw)
+        cdf, total, mx, shift = smc.weight_cdf(_dev(lw))
+        assert shift == rs and int(total.item()) == rt, (it, n, style)
+        assert np.array_equal(cdf.cpu().numpy().view(np.uint64), rc), (it, n, style)
+        ref = O.ancestors(kind, okey, rc) if rt else np.full(n, n - 1, np.int32)
+        anc, tot2, mx2, _ = smc.resample_fused(kind, key, _dev(lw))
+        assert int(tot2.item()) == rt and np.array_equal(anc.cpu().numpy(), ref), (it, n, style, kind)
+        assert float(mx2.item()) == rm

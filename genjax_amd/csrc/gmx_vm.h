@@ -91,7 +91,11 @@ GMX_HD void gmx_vm_step(Regs& R, const W w, int64_t i, bool active, const gmx_ru
       } break;
       case OP_LDTAB: {
         int32_t idx = (int32_t)SRC(b) + (int32_t)w1;
-        if (active) r0 = ((const uint32_t*)ctx.tab_ptr(a))[idx];
+        // A pool operand is launch-uniform: the load is then done by every lane alike, outside any divergent
+        // branch, so a specialised kernel gets a scalar load (s_load_dword through the scalar cache) instead of
+        // 64 lanes fetching one address — a K = 64 mixture reads 128 table entries per datapoint.
+        if (b >= GMX_POOL_BASE) r0 = ((const uint32_t*)ctx.tab_ptr(a))[idx];
+        else if (active) r0 = ((const uint32_t*)ctx.tab_ptr(a))[idx];
       } break;
       case OP_STOUT: {
         uint32_t v = SRC(b);

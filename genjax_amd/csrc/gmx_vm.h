@@ -80,7 +80,10 @@ GMX_HD void gmx_vm_step(Regs& R, const W w, int64_t i, bool active, const gmx_ru
       case OP_CONST: r0 = w1; break;
       case OP_UNI: r0 = ctx.pool(w1 & (GMX_MAX_UNI - 1)); break;
       case OP_LDIN: {
-        if (active) {
+        if (b & GMX_F_BCAST) {              // one launch-uniform element: every lane alike -> a scalar load
+          const void* p = ctx.in_ptr(a);
+          r0 = (b & GMX_F_U8) ? (uint32_t)((const uint8_t*)p)[0] : ((const uint32_t*)p)[0];
+        } else if (active) {
           int64_t row = i;
           if (b & GMX_F_GATHER) row = (int64_t)A.ancestors_d[i];
           if (b & GMX_F_BCAST) row = 0;

@@ -108,6 +108,10 @@ def test_entry_points_reject_null_arguments_before_any_launch():
         "gmx_weight_cdf": (N, i64(10), i32(40), N, i64(0), N, N, N, N, N),
         "gmx_ancestors": (i32(0), N, N, i64(10), ctypes.c_uint64(0), N, i64(10), i64(0), i64(10), N, N),
         "gmx_resample": (i32(0), N, N, i64(10), i32(40), N, i64(0), N, N, N, N, N),
+        "gmx_tile_stats": (N, i64(10), i32(40), N, N, N),
+        "gmx_resample_tiles": (i32(0), N, N, i64(10), i32(40), N, N, N, N, N, N),
+        "gmx_shard_totals": (N, i32(2), i64(1024), N, N, N),
+        "gmx_shard_step_tiles": (i32(0), N, N, N, N, N, N, N, i32(40), i32(0), i32(2), i64(1024), i64(4), N, N, N, N),
         "gmx_gather": (N, N, N, ctypes.c_int32(3), N, i64(10), N),
         "gmx_select": (N, N, N, N, N, ctypes.c_int32(1), i64(10), N),
         "gmx_categorical_rows": (N, N, i64(4), i64(4), N, N),

@@ -1,0 +1,18 @@
+"""us / step of the captured config-2 sweep for the three resampling kinds (one JSON line)."""
+import sys, time, json; sys.path.insert(0,'/root/repo')
+import torch
+import genjax_amd as G
+from genjax_amd import workloads
+from genjax_amd.inference.smc import BootstrapSweep
+n, T = 1_000_000, 100
+ys = workloads.lgssm_data(T)
+init, step = workloads.make_lgssm(G)
+out = {}
+for kind in ("systematic", "stratified", "multinomial"):
+    sw = BootstrapSweep(init, step, n, T, resample=kind).prepare(G.key(314159), torch.from_numpy(ys)).capture()
+    for _ in range(3): sw.launch()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(10): sw.launch()
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 10
+    out[kind] = {"us_per_step": 1e6 * dt / T, "log_ml": sw.log_ml(), "kalman": workloads.kalman_log_ml(ys)}
+print(json.dumps(out))

@@ -1,5 +1,6 @@
 """us / step of the captured config-2 sweep for the three resampling kinds (one JSON line)."""
-import sys, time, json; sys.path.insert(0,'/root/repo')
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import genjax_amd as G
 from genjax_amd import workloads

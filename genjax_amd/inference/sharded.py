@@ -392,6 +392,8 @@ class ShardedBootstrapSweep:
         self.finish()
         acc = 0.0
         for m, tot in zip(self.maxs.cpu().tolist(), self.totals.cpu().numpy().view(np.uint64).tolist()):
+            if tot == 0:
+                return -math.inf
             acc += cdf_reference(m) + math.log(tot) - self.shift * math.log(2.0) - math.log(self.N)
         return acc
 

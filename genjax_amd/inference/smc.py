@@ -373,6 +373,8 @@ class LogMLOffset:
         for max_d, total_d, shift, n in self.terms:
             m = float(max_d.reshape(-1)[0].item())
             tot = int(total_d.reshape(-1)[0].item()) & 0xFFFFFFFFFFFFFFFF
+            if tot == 0:                 # no particle carried any mass: the evidence estimate is 0
+                return -math.inf
             acc += cdf_reference(m) + math.log(tot) - shift * math.log(2.0) - math.log(n)
         return acc
 
@@ -719,6 +721,8 @@ class BootstrapSweep:
         """sum_t [ ref(M_t) + log(total_t * 2^-shift) - log N ] in float64 (synchronises)."""
         m = np.array([cdf_reference(v) for v in self.maxs.cpu().numpy()], dtype=np.float64)
         tot = self.totals.cpu().numpy().view(np.uint64).astype(np.float64)
+        if np.any(tot == 0):             # a step where no particle carried any mass
+            return -math.inf
         return float(np.sum(m + np.log(tot) - self.shift * math.log(2.0) - math.log(self.n)))
 
     def state(self):

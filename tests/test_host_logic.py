@@ -848,3 +848,20 @@ def test_sharded_requires_tile_aligned_shards():
     with pytest.raises(ValueError, match="multiple of 1024"):
         ShardedBootstrapSweep(init, step, 1000, 3, _Two)
     ShardedBootstrapSweep(init, step, 2048, 3, _Two)          # aligned: constructs (no collective until prepare)
+
+
+def test_evidence_is_minus_inf_when_no_particle_has_mass():
+    """an observation impossible under every particle: resampling falls back to the last particle and the
+    log-ML estimate is -inf (not an exception)"""
+    from genjax_amd.inference import smc
+
+    @genjax.gen
+    def m():
+        x = genjax.uniform(0.0, 1.0) @ "x"
+        _ = genjax.uniform(x, x + 1.0) @ "y"
+        return x
+    coll = smc.ImportanceK(genjax.Target(m, (), C.kw(y=5.0)), k_particles=64).run_smc(genjax.key(0))
+    assert np.all(np.isneginf(coll.get_log_weights().numpy()))
+    res = smc.resample(genjax.key(1), coll, "systematic")
+    assert np.all(res.ancestors.numpy() == 63)
+    assert res.log_ml_offset.value() == -math.inf

@@ -324,9 +324,8 @@ def main():
                 out["cpu_baseline"] = {"error": repr(e)}
     if dist is not None:
         dist.barrier()           # rank 0's kernel timing is done before anyone tears the communicator down
-        if getattr(sw, "cx", None) is not None and hasattr(sw.cx, "destroy"):
-            torch.cuda.synchronize()
-            sw.cx.destroy()
+        if hasattr(sw, "close") and getattr(sw, "cx", None) is not None:
+            sw.close()           # graph first, then the RCCL communicator (the other order hangs)
         dist.destroy_process_group()
     if cpu_mode:
         out["data"] = "synthetic (CPU mirror of the C-ABI: control-flow test, not a measurement)"

@@ -388,6 +388,20 @@ class ShardedBootstrapSweep:
         self._finished = True
         return self
 
+    def close(self):
+        """Release the captured graph, then the direct RCCL communicator — in that order: a captured sweep
+        holds the communicator's kernels and ncclCommDestroy waits on it forever otherwise (measured: a hang at
+        teardown).  COLLECTIVE when a communicator exists."""
+        be = _lib.get()
+        if self.graph is not None:
+            be.c.gmx_graph_destroy(self.graph)
+            self.graph = None
+        if self.cx is not None and hasattr(self.cx, "destroy"):
+            if be.uses_streams:
+                torch.cuda.synchronize()
+            self.cx.destroy()
+        self.cx = None
+
     def log_ml(self) -> float:
         self.finish()
         acc = 0.0

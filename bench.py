@@ -322,13 +322,12 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(n, T, ys, seed)
             except Exception as e:                              # report, never fail the GPU number
                 out["cpu_baseline"] = {"error": repr(e)}
-    if dist is not None:
-        dist.barrier()           # rank 0's kernel timing is done before anyone tears the communicator down
-        if hasattr(sw, "close") and getattr(sw, "cx", None) is not None:
-            sw.close()           # graph first, then the RCCL communicator (the other order hangs)
-        dist.destroy_process_group()
     if cpu_mode:
         out["data"] = "synthetic (CPU mirror of the C-ABI: control-flow test, not a measurement)"
+    if dist is not None:
+        dist.barrier()           # rank 0's kernel timing is done before anyone tears the communicator down
+    # The JSON line goes out BEFORE the teardown: whatever a communicator does while it is destroyed, the
+    # measurement is already on stdout.
     sys.stdout.flush()
     try:
         ctypes.CDLL(None).fflush(None)       # C stdio buffers (the banner) go where fd 1 points NOW: stderr
@@ -337,6 +336,11 @@ def main():
     os.dup2(real_stdout, 1)
     if rank == 0:
         print(json.dumps(out), flush=True)
+    os.dup2(2, 1)                            # teardown chatter again to stderr
+    if dist is not None:
+        if hasattr(sw, "close") and getattr(sw, "cx", None) is not None:
+            sw.close()           # graph first, then the RCCL communicator (the other order hangs)
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -113,6 +113,23 @@ class RcclComm:
             self.comm = None
 
 
+def _selftest(comm, device):
+    """The three collectives on known patterns (a few bytes each): a communicator that answers wrongly is
+    rejected here, where make_comm can still fall back to torch.distributed on every rank."""
+    r, W = comm.rank, comm.world
+    t = torch.tensor([float(r)], dtype=torch.float32, device=device)
+    comm.all_reduce_max(t)
+    g_in = torch.tensor([r], dtype=torch.int64, device=device)
+    g_out = torch.zeros((W,), dtype=torch.int64, device=device)
+    comm.all_gather(g_out, g_in)
+    a_in = torch.tensor([r * 100 + d * 10 + j for d in range(W) for j in range(2)], dtype=torch.float32, device=device)
+    a_out = torch.zeros_like(a_in)
+    comm.all_to_all(a_out, a_in)
+    want = torch.tensor([s_ * 100 + r * 10 + j for s_ in range(W) for j in range(2)], dtype=torch.float32)
+    if float(t.item()) != float(W - 1) or g_out.cpu().tolist() != list(range(W)) or not torch.equal(a_out.cpu(), want):
+        raise RuntimeError("communicator self-test failed")
+
+
 def make_comm(dist, device: torch.device):
     """RCCL direct on a GPU box (GENMI_COMM=torch forces the torch.distributed path); every rank
     takes the same branch: the outcome of the RCCL bootstrap is agreed with a MIN all-reduce."""
@@ -122,7 +139,8 @@ def make_comm(dist, device: torch.device):
     ok, comm = 1, None
     try:
         comm = RcclComm(dist, device)
-    except Exception as e:                       # missing symbol, bootstrap failure, ...
+        _selftest(comm, device)
+    except Exception as e:                       # missing symbol, bootstrap failure, a wrong answer, ...
         import warnings
         warnings.warn(f"direct RCCL communicator unavailable ({e!r}); using torch.distributed")
         ok = 0

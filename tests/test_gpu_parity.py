@@ -804,3 +804,22 @@ def test_resampler_fuzz(gpu):
         anc, tot2, mx2, _ = smc.resample_fused(kind, key, _dev(lw))
         assert int(tot2.item()) == rt and np.array_equal(anc.cpu().numpy(), ref), (it, n, style, kind)
         assert float(mx2.item()) == rm
+
+
+@pytest.mark.parametrize("kind", [0, 1])
+def test_fused_resampler_at_its_size_limit(gpu, kind):
+    """n = 2^21 = RS_MAX_TILES tiles of 1024: the largest ensemble the fused (table-per-block) resampler takes;
+    one more particle must be refused loudly."""
+    import genjax_amd as G
+    from genjax_amd import _lib
+    from genjax_amd.inference import smc
+    n = 2048 * 1024
+    rng = np.random.default_rng(5)
+    lw = rng.normal(0, 4, n).astype(np.float32)
+    rc, rt, rm, rs = O.weight_cdf_c(lw)
+    ref = O.ancestors(kind, O.key(9), rc)
+    anc, tot, mx, _ = smc.resample_fused(kind, G.key(9), _dev(lw))
+    assert int(tot.item()) == rt and float(mx.item()) == rm
+    assert np.array_equal(anc.cpu().numpy(), ref)
+    with pytest.raises(_lib.GenmiError, match="too large"):
+        smc.resample_fused(kind, G.key(9), _dev(np.zeros(n + 1, np.float32)))

@@ -1,0 +1,27 @@
+#!/bin/bash
+# Everything DESIGN.md quotes, in one go, on an MI355X box (from the repo root; ~6 min):
+#   tools/reproduce.sh <tag>      -> gpurun_out/<tag>_*
+# Each rocprofv3 pass is its own invocation (kernel trace + stats, SQ counters, TCC counters: never combined);
+# every step runs under `timeout` so that a wedged process cannot hold the box.
+tag=${1:-run}
+root=${GRAFT_REPO_ROOT:-$(pwd)}
+out=$root/gpurun_out
+mkdir -p $out
+cd $root
+timeout 900 python -m pytest tests -m gpu -q > $out/${tag}_pytest_gpu.log 2>&1; tail -1 $out/${tag}_pytest_gpu.log
+timeout 120 python -c "import __graft_entry__ as g; g.smoke()" > $out/${tag}_smoke.log 2>&1; tail -1 $out/${tag}_smoke.log | cut -c1-80
+timeout 600 python bench.py > $out/${tag}_bench.json 2> $out/${tag}_bench.err
+timeout 300 python bench.py --sharded --no-cpu-baseline > $out/${tag}_bench_sharded_world1.json 2> /dev/null
+timeout 600 bash tools/prof.sh $tag > $out/${tag}_pmc_summary.txt 2>&1
+timeout 600 bash tools/traffic.sh $tag > $out/${tag}_traffic.txt 2>&1
+timeout 300 python tools/bench_configs.py > $out/${tag}_configs_3_4.json 2> /dev/null
+timeout 300 python tools/bench_sweep3.py 2> /dev/null | grep "^{" > $out/${tag}_config3_native_sweep.json
+timeout 300 python tools/bench_mixture.py 2> /dev/null | tail -1 > $out/${tag}_mixture_config5.json
+timeout 300 python tools/bench_hmc.py 2> /dev/null | tail -1 > $out/${tag}_hmc.json
+timeout 300 python tools/bench_kinds.py 2> /dev/null | tail -1 > $out/${tag}_kinds.json
+python - <<PY
+import json
+b = json.load(open("$out/${tag}_bench.json"))
+print("config 2:", "%.3e" % b["value"], b["unit"], "| %.1f us/step" % (1e3 * b["ms_per_step"] / 100),
+      "| roofline frac %.3f" % b["roofline"]["frac"], "| cpu_baseline %.2e on %d cores" % (b["cpu_baseline"]["value"], b["cpu_baseline"]["cores"]))
+PY

@@ -145,16 +145,17 @@ def test_slot_bounds_match_ancestors():
 @pytest.mark.parametrize("world", [1, 2])
 def test_bench_contract_control_flow(world):
     """bench.py's N > 1 control flow (rendezvous on 127.0.0.1, barriers, max over ranks, exactly ONE JSON line on
-    stdout from rank 0, shard size rounded up to the CDF tile) — on gloo + the CPU mirror; values are not timings."""
+    stdout from rank 0, shard size rounded up to the CDF tile) — bench.py unchanged, started through
+    tests/bench_on_cpu.py (gloo + the CPU mirror of the C-ABI); values are not timings."""
     port = str(_free_port())
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, OMP_NUM_THREADS="1", GENMI_BENCH_BACKEND="cpu")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, OMP_NUM_THREADS="1")
     args = ["--gpus", str(world), "--steps", "2", "--warmup", "1", "--particles", "3000", "--T", "4", "--no-cpu-baseline",
             "--no-graph"]
     if world == 1:
-        cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + args
+        cmd = [sys.executable, os.path.join(ROOT, "tests", "bench_on_cpu.py")] + args
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
-               "--master-addr", "127.0.0.1", "--master-port", port, os.path.join(ROOT, "bench.py")] + args
+               "--master-addr", "127.0.0.1", "--master-port", port, os.path.join(ROOT, "tests", "bench_on_cpu.py")] + args
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]

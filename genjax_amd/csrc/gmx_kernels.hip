@@ -1,14 +1,19 @@
 // gmx_kernels.hip — gfx950 kernels + the C-ABI of include/genmi.h.
 //
 // Kernel inventory (roofline notes in DESIGN.md §4):
-//   k_vm<Regs>          site-program interpreter, 1 thread / particle   (ALU + HBM)
-//   k_lse_tiles/_final  deterministic two-stage log-sum-exp             (HBM)
-//   k_lse_rows          one wave per row (many short rows)              (HBM)
-//   k_weight_cdf        fixed-point weights + single-pass chained scan  (HBM)
-//   k_ancestors         128-bit exact inverse-CDF search                (L2 latency)
-//   k_gather/k_select   multi-leaf row gather / masked select           (HBM)
-//   k_categorical_rows  Gumbel-max per row                              (ALU)
-//   small key kernels   split / fold_in / random_bits / mh_accept
+//   k_vm<Regs>            site-program interpreter, 1 thread / particle            (ALU + HBM)
+//   gmx_jit_kernel        the same program specialised by hiprtc (gmx_jit.h)       (VALU issue)
+//   k_lse_tiles/_final    deterministic two-stage log-sum-exp                      (HBM)
+//   k_lse_rows            one wave per row (many short rows)                       (HBM)
+//   k_weight_cdf          block-floating-point integer CDF, single-pass chained scan (HBM)
+//   k_offspring           source-centric offspring ranges from a CDF array         (HBM, latency)
+//   k_ancestors           128-bit exact inverse-CDF search (multinomial, sharded)  (L2 latency)
+//   k_tile_stats          (max, fixed-point weight sum) per 1024-particle tile     (HBM)
+//   k_offspring_tile      ancestors from log-weights + tile statistics, no CDF array (VALU issue)
+//   k_shard_plan/_route/_step<TILES>, k_shard_totals   global resampling across ranks
+//   k_gather/k_select     multi-leaf row gather / masked select                    (HBM)
+//   k_categorical_rows    Gumbel-max per row                                       (ALU)
+//   small key kernels     split / fold_in / random_bits / mh_accept
 //
 // Wavefront = 64 everywhere; blocks are 256 threads (4 waves, one per SIMD).
 #include <hip/hip_runtime.h>

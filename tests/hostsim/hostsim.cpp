@@ -50,7 +50,7 @@ extern "C" int gmx_random_bits(const uint32_t* keys, int64_t n, int64_t m, uint3
 
 
 // ---- programs ----
-struct gmx_program { std::vector<uint32_t> code, consts; uint32_t n_instr, n_regs, n_in, n_out, n_uni, n_tab, n_const, n_dyn; };
+struct gmx_program { std::vector<uint32_t> code, consts; uint32_t n_instr, n_regs, n_in, n_out, n_uni, n_tab, n_const, n_dyn; uint32_t n_redmax = 0, n_redlse = 0; };
 
 struct HostCtx {
   const uint32_t* code; const gmx_run_args* A;
@@ -83,13 +83,26 @@ extern "C" int gmx_program_create(const uint32_t* blob, size_t n_words, gmx_prog
     if (regdst && dst >= p->n_regs) { delete p; return fail("program_create: register out of range"); }
     (void)a; (void)b;
   }
+  for (uint32_t pc = 0; pc < p->n_instr; ++pc) {
+    const uint32_t op = p->code[2 * pc] & 0xffu;
+    if (op == OP_REDMAX) ++p->n_redmax;
+    if (op == OP_REDLSE) ++p->n_redlse;
+  }
   *out = p; return 0;
 }
 extern "C" int gmx_program_destroy(gmx_program* p) { delete p; return 0; }
 extern "C" int gmx_program_specialize(gmx_program*) { return fail("hostsim: no specialisation"); }
 extern "C" int gmx_program_is_specialized(const gmx_program*) { return 0; }
-extern "C" int gmx_program_writes_tile_stats(const gmx_program*) { return 0; }
-extern "C" int64_t gmx_program_grid(const gmx_program*, int64_t n) { return (n + 255) / 256; }
+// Like the specialised 4-particles-per-thread kernel, a program with exactly one OP_REDMAX runs in workgroups of
+// 1024 particles (one partial row each) and can leave the CDF tile statistics; GENMI_HOSTSIM_TILE_STATS=0 gives the
+// interpreter's shape instead (256-particle groups, no statistics).
+static bool hs_tile_mode(const gmx_program* p) {
+  const char* e = getenv("GENMI_HOSTSIM_TILE_STATS");
+  return p && p->n_redmax == 1 && p->n_redlse == 0 && !(e && e[0] == '0');
+}
+extern "C" int gmx_program_writes_tile_stats(const gmx_program* p) { return hs_tile_mode(p) ? 1 : 0; }
+extern "C" int64_t gmx_program_grid(const gmx_program* p, int64_t n) { return hs_tile_mode(p) ? (n + 1023) / 1024 : (n + 255) / 256; }
+static uint64_t hs_weight_fixed(float lw, float ref, float scale);
 
 static float butterfly_sum64(const float* v) {
   float t[64]; memcpy(t, v, sizeof(t));
@@ -104,25 +117,34 @@ extern "C" int gmx_program_run(const gmx_program* p, int64_t n, const gmx_run_ar
   const gmx_run_args* A = &patched;
   for (uint32_t s = 0; s < p->n_in; ++s) if (!A->in_d[s]) return fail("program_run: null input slot");
   for (uint32_t s = 0; s < p->n_out; ++s) if (!A->out_d[s]) return fail("program_run: null output slot");
-  int64_t grid = (n + 255) / 256;
-  std::vector<float> red(256);
+  const bool tile = hs_tile_mode(p);
+  if (A->tile_agg_d && !tile) return fail("program_run: tile_agg_d is set but this program cannot write tile statistics");
+  const int G = tile ? 1024 : 256;                 // particles per workgroup
+  int64_t grid = (n + G - 1) / G;
+  std::vector<float> red((size_t)G);
   for (int64_t blk = 0; blk < grid; ++blk) {
     int kind = 0;
-    for (int t = 0; t < 256; ++t) {
-      int64_t i = blk * 256 + t;
+    for (int t = 0; t < G; ++t) {
+      int64_t i = blk * G + t;
       HostCtx ctx; ctx.code = p->code.data(); ctx.A = A; ctx.red = &red; ctx.i = t; ctx.kind = 0;
       gmx_vm_run<gmx_regs_vgpr<GMX_MAX_REGS>, true, -1, HostCtx>(p->n_instr, i, i < n, *A, ctx);
       if (ctx.kind) kind = ctx.kind;
     }
     if (kind && A->red_out_d) {
       float m = -gmx_inf();
-      for (int t = 0; t < 256; ++t) m = gmx_fmax(m, red[t]);
+      for (int t = 0; t < G; ++t) m = gmx_fmax(m, red[t]);
       A->red_out_d[blk] = m;
       if (kind == 2) {
         float e[256];
         for (int t = 0; t < 256; ++t) e[t] = (red[t] > -gmx_inf() && m > -gmx_inf()) ? gmx_expf(red[t] - m) : 0.0f;
         float w0 = butterfly_sum64(e), w1 = butterfly_sum64(e + 64), w2 = butterfly_sum64(e + 128), w3 = butterfly_sum64(e + 192);
         A->red_out_d[grid + blk] = (w0 + w1) + (w2 + w3);
+      }
+      if (tile && A->tile_agg_d) {
+        const float ref = gmx_tile_ref(gmx_tile_exp(m)), scale = gmx_pow2i(A->tile_shift);
+        uint64_t sum = 0;
+        for (int t = 0; t < G; ++t) sum += hs_weight_fixed(red[t], ref, scale);
+        A->tile_agg_d[blk] = sum;
       }
     }
   }

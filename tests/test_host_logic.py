@@ -865,3 +865,13 @@ def test_evidence_is_minus_inf_when_no_particle_has_mass():
     res = smc.resample(genjax.key(1), coll, "systematic")
     assert np.all(res.ancestors.numpy() == 63)
     assert res.log_ml_offset.value() == -math.inf
+
+
+def test_sweep_without_program_written_tile_stats(monkeypatch):
+    """GENMI_HOSTSIM_TILE_STATS=0: the C-ABI mirror behaves like the interpreter (256-particle groups, no tile
+    statistics from the site program), so BootstrapSweep takes the gmx_resample path; same sweep bit for bit."""
+    from tests import parity
+    monkeypatch.setenv("GENMI_HOSTSIM_TILE_STATS", "0")
+    res = parity.check_lgssm_sweep(n=3000, T=5)
+    assert res["ancestors_equal"] and res["x_equal"] and res["totals_equal"] and res["lw_max_abs_diff"] == 0.0
+    assert res["log_ml"] == res["log_ml_oracle"]

@@ -41,16 +41,18 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world,capacity,tiles", [(2, 0, "1"), (4, 0, "1"), (2, 3, "1"), (2, 0, "0")])
-def test_sharded_sweep_equals_single_process_oracle(tmp_path, world, capacity, tiles):
+@pytest.mark.parametrize("world,capacity,tiles,prog_stats", [(2, 0, "1", "1"), (4, 0, "1", "1"), (2, 3, "1", "1"),
+                                                             (2, 0, "0", "1"), (2, 0, "1", "0")])
+def test_sharded_sweep_equals_single_process_oracle(tmp_path, world, capacity, tiles, prog_stats):
     """capacity 0 = default (fast path, no overflow); capacity 3 forces the
     overflow flag and the full-capacity re-run.  tiles "1" = the two-collective step (all-gather of tile
-    statistics + all-to-all), "0" = GENMI_SHARD_TILES=0: max all-reduce + local CDF + totals all-gather + all-to-all."""
+    statistics + all-to-all), "0" = GENMI_SHARD_TILES=0: max all-reduce + local CDF + totals all-gather + all-to-all.
+    prog_stats "0": the site program does not write the tile statistics itself, a gmx_tile_stats launch does."""
     from genjax_amd import workloads
     n_total, T = 4096, 6
     out = str(tmp_path / "shard")
     r = _launch(world, [out, str(n_total // world), str(T)] + ([str(capacity)] if capacity else []),
-                extra_env={"GENMI_SHARD_TILES": tiles})
+                extra_env={"GENMI_SHARD_TILES": tiles, "GENMI_HOSTSIM_TILE_STATS": prog_stats})
     assert r.returncode == 0, r.stderr[-3000:]
     x = np.load(out + ".npy")
     meta = json.load(open(out + ".json"))

@@ -1104,6 +1104,59 @@ k_ancestors(int kind, uint32_t k0, uint32_t k1, const uint64_t* __restrict__ cdf
   anc[s] = (int32_t)lo;
 }
 
+// Multinomial over a large CDF: the per-slot search in two levels.  Every block first samples the CDF at stride
+// S = 2^log2S (<= 1024 samples, L2-resident: all blocks read the same lines) into LDS; a slot then finds its
+// window with LDS reads and finishes with log2(S) dependent global reads instead of log2(n_in).
+// The threshold is an integer: first i with (cdf_i + off) * 2^23 >= P  <=>  cdf_i + off >= ceil(P / 2^23).
+#define MN_SLOTS_PER_THREAD 8
+#define MN_COARSE 1024
+__global__ void __launch_bounds__(GMX_BLOCK)
+k_ancestors_mn(uint32_t k0, uint32_t k1, const uint64_t* __restrict__ cdf, int64_t n_in, uint64_t cdf_offset,
+               const uint64_t* __restrict__ total_d, int64_t slot_offset, int64_t n_slots, int32_t* __restrict__ anc,
+               int log2S) {
+  __shared__ uint64_t s_coarse[MN_COARSE];
+  const int64_t S = (int64_t)1 << log2S;
+  const int E = (int)((n_in + S - 1) >> log2S);            // <= MN_COARSE
+  for (int e = (int)threadIdx.x; e < E; e += GMX_BLOCK) {
+    int64_t last = ((int64_t)(e + 1) << log2S) - 1;
+    if (last > n_in - 1) last = n_in - 1;
+    s_coarse[e] = cdf[last] + cdf_offset;
+  }
+  __syncthreads();
+  const uint64_t total = *total_d;
+  gmx_key key; key.k0 = k0; key.k1 = k1;
+#pragma unroll 2
+  for (int r = 0; r < MN_SLOTS_PER_THREAD; ++r) {
+    const int64_t s = ((int64_t)blockIdx.x * MN_SLOTS_PER_THREAD + r) * GMX_BLOCK + threadIdx.x;
+    if (s >= n_slots) continue;
+    const uint64_t u = gmx_bits32(key, (uint64_t)(slot_offset + s)) >> 9;
+    u128 P = mul64(total, (1ull << 23) - u);                    // P >= 1 whenever total >= 1
+    // T = ceil(P / 2^23)
+    uint64_t lo = P.lo + ((1ull << 23) - 1ull);
+    uint64_t hi = P.hi + (lo < P.lo ? 1ull : 0ull);
+    const uint64_t T = (hi << 41) | (lo >> 23);
+    // coarse: first window whose last element reaches T
+    int a = 0, b = E;                                           // answer in [a, b]; b == E means none
+    while (a < b) {
+      const int mid = (a + b) >> 1;
+      if (s_coarse[mid] >= T) b = mid; else a = mid + 1;
+    }
+    int64_t res;
+    if (a >= E || total == 0ull) {
+      res = n_in - 1;                                           // no mass at all, or a slot beyond this shard
+    } else {
+      int64_t l = (int64_t)a << log2S, h = l + S - 1;           // cdf[h] + off >= T is known
+      if (h > n_in - 1) h = n_in - 1;
+      while (l < h) {
+        const int64_t mid = l + ((h - l) >> 1);
+        if (cdf[mid] + cdf_offset >= T) h = mid; else l = mid + 1;
+      }
+      res = l;
+    }
+    anc[s] = (int32_t)res;
+  }
+}
+
 extern "C" int gmx_ancestors(int kind, const uint32_t key[2], const uint64_t* cdf_d, int64_t n_in,
                              uint64_t cdf_offset, const uint64_t* total_d, int64_t n_out_total,
                              int64_t slot_offset, int64_t n_slots, int32_t* ancestors_d,
@@ -1116,7 +1169,14 @@ extern "C" int gmx_ancestors(int kind, const uint32_t key[2], const uint64_t* cd
     return gmx_fail("gmx_ancestors: n_out_total out of range%s");
   if (slot_offset < 0 || slot_offset + n_slots > n_out_total)
     return gmx_fail("gmx_ancestors: slot range outside [0, n_out_total)%s");
-  if (kind == GMX_RESAMPLE_MULTINOMIAL || cdf_offset != 0 || slot_offset != 0 || n_slots != n_out_total) {
+  if (kind == GMX_RESAMPLE_MULTINOMIAL && n_in >= 8192) {
+    int log2S = 0;
+    while (((n_in + ((int64_t)1 << log2S) - 1) >> log2S) > MN_COARSE) ++log2S;
+    const int64_t per_block = (int64_t)GMX_BLOCK * MN_SLOTS_PER_THREAD;
+    hipLaunchKernelGGL(k_ancestors_mn, dim3((unsigned)((n_slots + per_block - 1) / per_block)), dim3(GMX_BLOCK), 0,
+                       (hipStream_t)stream, key[0], key[1], cdf_d, n_in, cdf_offset, total_d, slot_offset, n_slots,
+                       ancestors_d, log2S);
+  } else if (kind == GMX_RESAMPLE_MULTINOMIAL || cdf_offset != 0 || slot_offset != 0 || n_slots != n_out_total) {
     // unordered positions, or a shard of a larger problem: search per slot
     hipLaunchKernelGGL(k_ancestors, grid_for(n_slots), dim3(GMX_BLOCK), 0, (hipStream_t)stream, kind,
                        key[0], key[1], cdf_d, n_in, cdf_offset, total_d, n_out_total, slot_offset,

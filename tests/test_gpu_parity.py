@@ -823,3 +823,31 @@ def test_fused_resampler_at_its_size_limit(gpu, kind):
     assert np.array_equal(anc.cpu().numpy(), ref)
     with pytest.raises(_lib.GenmiError, match="too large"):
         smc.resample_fused(kind, G.key(9), _dev(np.zeros(n + 1, np.float32)))
+
+
+@pytest.mark.parametrize("n,shape", [(8192, "normal"), (10_000, "onehot"), (10_000, "none"), (100_003, "heavy"),
+                                     (1_000_000, "normal"), (3_000_000, "sparse")])
+def test_multinomial_two_level_search(gpu, n, shape):
+    """multinomial ancestors for n >= 8192 go through k_ancestors_mn (coarse CDF samples in LDS, then log2(S)
+    global reads): the same integer predicate as the one-level search, so the oracle's indices bit for bit"""
+    import genjax_amd as G
+    from genjax_amd.inference import smc
+    lw = parity.pull_weights(n, shape, seed=n % 7) if hasattr(parity, "pull_weights") else None
+    if lw is None:
+        rng = np.random.default_rng(n)
+        lw = rng.normal(0, 2, n).astype(np.float32)
+        if shape == "onehot":
+            lw[:] = -np.inf; lw[(n * 5) // 7] = 0.0
+        elif shape == "none":
+            lw[:] = -np.inf
+        elif shape == "heavy":
+            lw = rng.normal(0, 12, n).astype(np.float32)
+        elif shape == "sparse":
+            keep = rng.choice(n, n // 997, replace=False)
+            m = np.full(n, -np.inf, np.float32); m[keep] = lw[keep]; lw = m
+    cdf, total, _, _ = smc.weight_cdf(_dev(lw))
+    rc, rt, _, _ = O.weight_cdf_c(lw)
+    assert int(total.item()) == rt
+    anc = smc.ancestors_from_cdf(2, G.key(5), cdf, total).cpu().numpy()
+    ref = O.ancestors_c(2, O.key(5), rc) if rt else np.full(n, n - 1, np.int32)
+    assert np.array_equal(anc, ref)

@@ -235,6 +235,15 @@ class Vmap(GenerativeFunction):
         return run_gfi(self, "assess", None, args, constraint=sample, batch_shape=batch_shape)
 
 
+def _flat_exprs(tree):
+    from .engine import Sym
+    if isinstance(tree, Sym):
+        tree = tree.value
+    if isinstance(tree, (tuple, list)):
+        return [e for a in tree for e in _flat_exprs(a)]
+    return [] if tree is None else [tree]
+
+
 def _select_tree(c, new, old):
     from .engine import Sym
     new = new.value if isinstance(new, Sym) else new
@@ -366,8 +375,8 @@ class Scan(GenerativeFunction):
         """Scan.edit (scan.py:596-625): `Update(constraint)` (edit_update :509-594) and
         `Regenerate(selection)` (edit_regenerate :417-507) re-run every step with the chained key
         fold_in(key, t), the step's slice of the previous trace and the carry of the edited
-        predecessor; weights and scores are summed over the steps.  `IndexRequest` on a scan
-        (edit_index :325-416) is not supported."""
+        predecessor; weights and scores are summed over the steps.  `IndexRequest(idx, request)` on a scan
+        (edit_index :325-416): step idx is edited with the caller's key and the carries are threaded on."""
         from .core.generative import NotSupportedEditRequest
         from .static import _CallRec, _ReqSpec, _rec_score, _store_site, call_gen_fn
         kind = req.kind if req is not None else "empty"
@@ -377,8 +386,9 @@ class Scan(GenerativeFunction):
             sub_mode = "regen"
         elif mode == "update" or kind in ("update", "empty"):
             sub_mode = "update"
-        elif kind == "index" and isinstance(req.idx, int):
-            sub_mode = "index"
+        elif kind == "index":
+            sub_mode = "index"          # idx: a Python int, or one index per particle (then every step is edited in
+                                        # the program and selected where idx == t, as Vmap.edit_index does)
         else:
             raise NotSupportedEditRequest(f"Scan.edit answers Update, Regenerate and IndexRequest (got {kind!r})")
         carry, scanned_in = args
@@ -402,16 +412,31 @@ class Scan(GenerativeFunction):
                 # edit_index (scan.py:325-416): the sub-request acts on step idx with the caller's key; the
                 # carries are threaded on, so the steps after it are re-scored exactly where the edit
                 # reaches them (step idx + 1 for a Markov kernel) and nothing else is recomputed
-                if t == req.idx:
+                traced = not isinstance(req.idx, int)
+                args_t = (carry, _tree_take(scanned_in, t))
+                if traced or t == req.idx:
                     sub = req.sub
                     m_ = {"update": "update", "regen": "regen"}.get(sub.kind, "static_edit")
                     con_ = sub.constraint if sub.kind == "update" else ChoiceMap.empty()
-                    rec, ret, w, _ = call_gen_fn(ctx, m_, self.kernel_gen_fn, key0, (carry, _tree_take(scanned_in, t)),
-                                                 con_, prev_t, sub, req_leaves, addr)
-                else:
-                    rec, ret, w, _ = call_gen_fn(ctx, "update", self.kernel_gen_fn, key0,
-                                                 (carry, _tree_take(scanned_in, t)), ChoiceMap.empty(), prev_t,
-                                                 carry_over, req_leaves, addr)
+                    saved = set(ctx.changed)
+                    rec, ret, w, _ = call_gen_fn(ctx, m_, self.kernel_gen_fn, key0, args_t, con_, prev_t, sub,
+                                                 req_leaves, addr)
+                if traced:
+                    # where idx != t the step is only carried over (re-scored against a changed carry)
+                    ctx.changed = saved
+                    ctx.memo.clear()
+                    old, old_ret, w_old, _ = call_gen_fn(ctx, "update", self.kernel_gen_fn, key0, args_t,
+                                                         ChoiceMap.empty(), prev_t, carry_over, req_leaves, addr)
+                    here = req.idx == t
+                    zero = Expr(g.const_f32(0.0))
+                    rec = _select_rec(here, rec, old)
+                    ret = _select_tree(here, ret, old_ret)
+                    w = T.where(here, w if w is not None else zero, w_old if w_old is not None else zero)
+                    ctx.mark_changed([r.value for r in _leaves(rec)])
+                    ctx.mark_changed(_flat_exprs(ret))
+                elif t != req.idx:
+                    rec, ret, w, _ = call_gen_fn(ctx, "update", self.kernel_gen_fn, key0, args_t, ChoiceMap.empty(),
+                                                 prev_t, carry_over, req_leaves, addr)
             elif sub_mode == "regen":
                 rec, ret, w, _ = call_gen_fn(ctx, "regen", self.kernel_gen_fn, key, (carry, _tree_take(scanned_in, t)),
                                              ChoiceMap.empty(), prev_t, req, req_leaves, addr)

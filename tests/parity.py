@@ -463,6 +463,24 @@ def check_scan(n=257, T=6, seed=5):
         old = r5.get_choices()["x"].cpu().numpy()
         assert np.array_equal(np.delete(old, idx, axis=1), np.delete(xe, idx, axis=1))      # only step idx moved
         assert isinstance(be5, IndexRequest) and be5.idx == idx
+    # one index PER PARTICLE: every step is edited in the program and selected where idx == t; the oracle runs
+    # the static-idx edit for every t and takes particle i's result from the run with t = idx_i
+    idx = np.random.default_rng(seed + 9).integers(0, T, n).astype(np.int32)
+    e6, we6, _, be6 = IndexRequest(torch.from_numpy(idx).to(dev), Regenerate(S["x"])).edit(
+        G.split(G.key(seed + 7), n), r5, Diff.no_change(a5))
+    xo6 = or5.get_choices()["x"].copy()
+    wo6, so6 = np.zeros(n, np.float32), np.zeros(n, np.float32)
+    for t_ in range(T):
+        cand, wt = O.scan_edit_index(osc5, O.split(O.key(seed + 7), n), or5, oa5, t_,
+                                     lambda k, sl, a: ostep.regenerate(k, sl, O.selection("x"), a)[:2])
+        m_ = idx == t_
+        xo6[m_] = cand.get_choices()["x"][m_]
+        wo6[m_], so6[m_] = np.asarray(wt, np.float32)[m_], np.asarray(cand.get_score(), np.float32)[m_]
+    assert np.array_equal(e6.get_choices()["x"].cpu().numpy(), xo6)
+    assert np.array_equal(we6.cpu().numpy(), wo6)
+    assert np.array_equal(e6.get_score().cpu().numpy(), so6)
+    moved = e6.get_choices()["x"].cpu().numpy() != r5.get_choices()["x"].cpu().numpy()
+    assert np.array_equal(moved, np.arange(T)[None, :] == idx[:, None])                  # exactly step idx_i moved
     # a Scan used directly: the chain starts at the caller's key
     sc = step.scan(n=3)
     t4 = sc.simulate(G.split(G.key(seed + 2), 16), (torch.zeros(16, device=G._lib.get().device), jnp.zeros(3)))

@@ -556,15 +556,14 @@ class BootstrapSweep:
         D = int(np.prod(event, dtype=np.int64)) if event else 1
         self.x_store = [torch.zeros((D, n), dtype=torch.float32, device=dev) for _ in range(2)]
         self.x = [s_.reshape(n) if not event else s_.t() for s_ in self.x_store]
-        if self.rejuvenate is not None and event:
-            raise NotImplementedError("BootstrapSweep(rejuvenate=...): scalar state only")
         g = Gathered(self.x[0], self.anc)
         if self.rejuvenate is None:
             self.p_step = MinimalGenerate(self.step, (g,) + tuple(self.step_extra(1)), obs0, (n,))
         else:
             from ..static import MinimalMH
             # xm[t % 2]: the MH-moved, resampled state the extension of step t starts from
-            self.xm = [torch.zeros((n,), dtype=torch.float32, device=dev) for _ in range(2)]
+            self.xm_store = [torch.zeros((D, n), dtype=torch.float32, device=dev) for _ in range(2)]
+            self.xm = [s_.reshape(n) if not event else s_.t() for s_ in self.xm_store]
             self.accept = torch.zeros((n,), dtype=torch.bool, device=dev)
             self.p_step = MinimalGenerate(self.step, (self.xm[0],) + tuple(self.step_extra(1)), obs0, (n,))
             ch = obs0.set(self.state_addr, g)
@@ -623,7 +622,7 @@ class BootstrapSweep:
             a = Gathered(self.xm[(t - 1) % 2], self.anc)
             leaves = prog.leaves((a,) + tuple(self.step_extra(t - 1)), ch, self.rejuvenate)
         bufs = [None] * len(prog.comp.outputs)
-        bufs[prog.ro[1]] = self.xm[t % 2].reshape(1, n)
+        bufs[prog.ro[1]] = self.xm_store[t % 2]
         bufs[prog.ao[1]] = self.accept.reshape(1, n)
         prog.comp.run(leaves, (n,), lazy_split(k_mh, n), out_buffers=bufs)
 

@@ -787,3 +787,72 @@ def check_vector_state_sweep(n=3000, T=6, seed=5, capture=False, specialize=Fals
     assert np.array_equal(x.cpu().numpy(), ref["x"])
     assert np.array_equal(anc.cpu().numpy(), ref["anc"])
     assert sw.log_ml() == ref["log_ml"]
+
+
+# ---------------------------------------------------------------------------
+# a VECTOR state through the fused MH sweep: 2-D state as one vector-valued site, Rejuvenate on it
+def make_vec_mh(g, stack, ones2):
+    @g.gen
+    def init():
+        x = g.normal(0.0 * ones2, ones2) @ "x"
+        g.normal(x[..., 0], 0.5) @ "y"
+        return x
+
+    @g.gen
+    def step(xp, t):
+        loc = stack(0.9 * xp[..., 0] + 0.1 * xp[..., 1], 0.8 * xp[..., 1])
+        x = g.normal(loc, 0.3 * ones2) @ "x"
+        g.normal(x[..., 0], 0.5) @ "y"
+        return x
+    return init, step
+
+
+def oracle_mh_sweep(oi, ost, oreq, ys, n, T, seed, extra=lambda t: ()):
+    """oracle_nlssm_mh_sweep for any (init, step, request): same key schedule"""
+    okey = O.key(seed)
+    otr = olw = oacc = None
+    terms = []
+    for t in range(T):
+        oks = O.split(O.fold_in(okey, t), 3)
+        oobs = O.C.kw(y=np.float32(ys[t]))
+        if t == 0:
+            otr, olw = oi.importance(O.split(oks[0], n), oobs, ())
+        else:
+            okr = O.split(O.fold_in(okey, t - 1), 3)[1]
+            cdf, total, M, shift = O.weight_cdf(olw)
+            terms.append(O.log_ml_increment(M, total, shift, n))
+            otr = O.gather_trace(otr, O.ancestors(O.SYSTEMATIC, okr, cdf))
+            gf = otr.get_gen_fn()
+            otr, oacc, _ = O.rejuvenate(oks[2], otr, lambda k, tr_: gf.edit_static(k, tr_, oreq, tr_.get_args()))
+            otr, olw = ost.importance(O.split(oks[0], n), oobs, (np.asarray(otr.get_retval(), np.float32),) + tuple(extra(t)))
+    x = np.asarray(otr.get_retval(), np.float32)
+    olw = np.asarray(olw, np.float32)
+    cdf, total, M, shift = O.weight_cdf(olw)
+    terms.append(O.log_ml_increment(M, total, shift, n))
+    anc = O.ancestors(O.SYSTEMATIC, O.split(O.fold_in(okey, T - 1), 3)[1], cdf)
+    return {"x": x, "lw": olw, "acc": oacc, "terms": terms, "anc": anc}
+
+
+def check_vector_mh_sweep(n=1500, T=5, seed=11, capture=False, specialize=False):
+    import genjax_amd as G
+    from genjax_amd import numpy as jnp
+    from genjax_amd.inference import smc
+    init, step = make_vec_mh(G, lambda a, b: jnp.stack([a, b]), jnp.ones(2))
+    oi, ost = make_vec_mh(O, lambda a, b: np.stack([a, b], axis=-1), np.ones(2, np.float32))
+    ys = tracker_data(T)
+    req = G.StaticRequest({"x": G.Rejuvenate(G.normal, lambda chm: (chm.get_value(), 0.2))})
+    oreq = {"x": O.Rejuvenate(O.normal, lambda chm: (chm.get_value(), np.float32(0.2)))}
+    sw = smc.BootstrapSweep(init, step, n, T, step_extra=lambda t: (float(t),), rejuvenate=req,
+                            specialize=specialize).prepare(G.key(seed), torch.from_numpy(ys))
+    if capture:
+        sw.capture()
+    sw.launch()
+    x, lw, anc = sw.state()
+    ref = oracle_mh_sweep(oi, ost, oreq, ys, n, T, seed, extra=lambda t: (np.float32(t),))
+    assert tuple(x.shape) == (n, 2)
+    assert np.array_equal(x.cpu().numpy(), ref["x"])
+    assert np.array_equal(lw.cpu().numpy(), ref["lw"])
+    assert np.array_equal(anc.cpu().numpy(), ref["anc"])
+    assert np.array_equal(sw.accept.cpu().numpy(), ref["acc"])
+    assert abs(sw.log_ml() - sum(ref["terms"])) < 1e-9 * max(1.0, abs(sum(ref["terms"])))
+    return {"accept_rate": float(ref["acc"].mean())}

@@ -851,3 +851,9 @@ def test_multinomial_two_level_search(gpu, n, shape):
     anc = smc.ancestors_from_cdf(2, G.key(5), cdf, total).cpu().numpy()
     ref = O.ancestors_c(2, O.key(5), rc) if rt else np.full(n, n - 1, np.int32)
     assert np.array_equal(anc, ref)
+
+
+@pytest.mark.parametrize("n,capture,specialize", [(3000, False, False), (100_000, True, True)])
+def test_vector_state_mh_sweep_matches_oracle(gpu, n, capture, specialize):
+    """the fused MH sweep with a 2-vector state (one vector-valued site), interpreter and specialised + captured"""
+    parity.check_vector_mh_sweep(n=n, T=5, capture=capture, specialize=specialize)

@@ -875,3 +875,11 @@ def test_sweep_without_program_written_tile_stats(monkeypatch):
     res = parity.check_lgssm_sweep(n=3000, T=5)
     assert res["ancestors_equal"] and res["x_equal"] and res["totals_equal"] and res["lw_max_abs_diff"] == 0.0
     assert res["log_ml"] == res["log_ml_oracle"]
+
+
+def test_vector_state_mh_sweep_matches_oracle():
+    """BootstrapSweep(rejuvenate=...) with a 2-vector state held in one vector-valued site: the fused MH move
+    gathers, proposes, accepts and selects all components; bit-exact vs the oracle incl. the accept bits"""
+    from tests import parity
+    res = parity.check_vector_mh_sweep(n=1500, T=5)
+    assert 0.3 < res["accept_rate"] < 1.0

@@ -406,8 +406,8 @@ class Compiled:
                 A.in_d[slot] = buf.data_ptr()
             elif kind == "dvec":
                 A.in_d[slot] = buf.data_ptr() + e * item
-            else:   # part / gather: [E, rows] SoA
-                rows = buf.shape[-1]
+            else:   # part / gather: [E, rows] SoA, element rows `stride(0)` apart
+                rows = buf.stride(0) if buf.shape[0] > 1 else buf.shape[-1]
                 A.in_d[slot] = buf.data_ptr() + e * rows * item
         if anc is not None:
             a32 = anc.reshape(-1)
@@ -491,7 +491,11 @@ def _prepare_input(src, kind, n, be):
     if rows == 0:       # an empty batch: reshape(0, -1) is ambiguous; the launch is skipped anyway
         return t.new_zeros((int(np.prod(t.shape[1:], dtype=np.int64)) if t.dim() > 1 else 1, 0))
     flat = t.reshape(rows, -1)
-    return flat.t().contiguous()       # [E, rows]; no copy when already SoA
+    soa = flat.t()                      # [E, rows]
+    if soa.stride(1) == 1 or soa.shape[1] == 1:
+        return soa                      # already struct-of-arrays — possibly a [E, rows] WINDOW of wider rows
+                                        # (stride(0) > rows): bound in place, so a persistent buffer stays live
+    return soa.contiguous()
 
 
 def resolve(origin, outs, leaves):

@@ -136,8 +136,6 @@ class ShardedBootstrapSweep:
             raise NotImplementedError("ShardedBootstrapSweep: the state must be a float scalar or a float vector")
         self.event = tuple(event)
         self.D = int(event[0]) if event else 1
-        if self.rejuvenate is not None and event:
-            raise NotImplementedError("ShardedBootstrapSweep(rejuvenate=...): scalar state only")
         self._alloc_exchange()
         g = Gathered(self._src(0), self.idx)
         if self.rejuvenate is None:
@@ -145,10 +143,10 @@ class ShardedBootstrapSweep:
         else:
             from ..static import MinimalMH
             self.accept = torch.zeros((n,), dtype=torch.bool, device=dev)
-            self.p_step = MinimalGenerate(self.step, (self.aext[0][:n],) + tuple(self.step_extra(1)), obs0, (n,))
+            self.p_step = MinimalGenerate(self.step, (self._asrc(0, local=True),) + tuple(self.step_extra(1)), obs0, (n,))
             ch = obs0.set(self.state_addr, g)
             self.p_mh_init = MinimalMH(self.init, (), ch, self.rejuvenate, (n,))
-            self.p_mh_step = MinimalMH(self.step, (Gathered(self.aext[0], self.idx),) + tuple(self.step_extra(1)), ch,
+            self.p_mh_step = MinimalMH(self.step, (Gathered(self._asrc(0), self.idx),) + tuple(self.step_extra(1)), ch,
                                        self.rejuvenate, (n,))
         if self.specialize and be.uses_streams:
             self.p_init.comp.specialize()
@@ -187,9 +185,14 @@ class ShardedBootstrapSweep:
         if self.rejuvenate is not None:
             # aext[t % 2][:n] = the MH-moved, resampled state step t is extended from; its tail receives the
             # remote copies of it when it travels as the second routed leaf of the NEXT resampling
-            self.aext = [torch.zeros((n + W * C,), dtype=torch.float32, device=dev) for _ in range(2)]
-            self.send2 = torch.zeros((W * C,), dtype=torch.float32, device=dev)
+            self.arows = [torch.zeros((self.D, n + W * C), dtype=torch.float32, device=dev) for _ in range(2)]
+            self.send2 = torch.zeros((self.D, W * C), dtype=torch.float32, device=dev)
         self._bound = [None] * self.T
+
+    def _asrc(self, tb, local=False):
+        """the MH-moved state of buffer tb as the model sees it: [n + W*C] (or [.., D]); local=True: this rank's n rows"""
+        rows = self.arows[tb][:, :self.n] if local else self.arows[tb]
+        return rows[0] if not self.event else rows.t()
 
     def _src(self, tb):
         """what the step model sees as the previous state (before the gather): [n + W*C] or [n + W*C, D]"""
@@ -212,20 +215,21 @@ class ShardedBootstrapSweep:
             leaves = prog.leaves((Gathered(self._src((t - 1) % 2), self.idx),) + tuple(self.step_extra(t)), obs)
         else:
             # the MH move on the resampled particles of step t-1, keys split(k_mh, N)[g*n + i]
-            prev_x, prev_a, cur_a = self.xext[(t - 1) % 2], self.aext[(t - 1) % 2], self.aext[t % 2]
-            ch = ChoiceMap.empty().set(self.obs_addr, self.ys[t - 1]).set(self.state_addr, Gathered(prev_x, self.idx))
+            ch = ChoiceMap.empty().set(self.obs_addr, self.ys[t - 1]).set(self.state_addr,
+                                                                          Gathered(self._src((t - 1) % 2), self.idx))
             if t == 1:
                 mprog, mleaves = self.p_mh_init, self.p_mh_init.leaves((), ch, self.rejuvenate)
             else:
                 mprog = self.p_mh_step
-                mleaves = mprog.leaves((Gathered(prev_a, self.idx),) + tuple(self.step_extra(t - 1)), ch, self.rejuvenate)
+                mleaves = mprog.leaves((Gathered(self._asrc((t - 1) % 2), self.idx),) + tuple(self.step_extra(t - 1)), ch,
+                                       self.rejuvenate)
             mbufs = [None] * len(mprog.comp.outputs)
-            mbufs[mprog.ro[1]] = cur_a[:n].reshape(1, n)
+            mbufs[mprog.ro[1]] = self.arows[t % 2][:, :n]
             mbufs[mprog.ao[1]] = self.accept.reshape(1, n)
             mh = (mprog.comp, mprog.comp.bind(mleaves, (n,), lazy_split(self.step_keys[t][2], self.N),
                                              out_buffers=mbufs, index_offset=g * n), mleaves)
             prog = self.p_step
-            leaves = prog.leaves((cur_a[:n],) + tuple(self.step_extra(t)), obs)
+            leaves = prog.leaves((self._asrc(t % 2, local=True),) + tuple(self.step_extra(t)), obs)
         bufs = [None] * len(prog.comp.outputs)
         rows_t = self.xrows[t % 2]
         bufs[prog.ro[1]] = rows_t[:, :n]                 # [D, n] window of the [D, n + W*C] rows
@@ -246,11 +250,11 @@ class ShardedBootstrapSweep:
         rows = int(be.c.gmx_program_grid(prog.comp.handle, n))        # block maxima the site program writes
         pmax = self.partials[0, :rows]
         step2 = recv2 = None
-        if self.rejuvenate is not None and t >= 1:       # second routed leaf: what x_t was extended from
-            cur_a = self.aext[t % 2]
-            step2 = (self.kind, kk, P(self.totals_all), P(self.plan), P(tot), P(self.cdf), g, W, n, C, P(cur_a),
-                     P(self.send2), P(self.idx))
-            recv2 = cur_a[n:]
+        if self.rejuvenate is not None and t >= 1:       # second routed leaf (per component): what x_t was extended from
+            cur_a = self.arows[t % 2]
+            step2 = [(self.kind, kk, P(self.totals_all), P(self.plan), P(tot), P(self.cdf), g, W, n, C, P(cur_a[d]),
+                      P(self.send2[d]), P(self.idx)) for d in range(self.D)]
+            recv2 = [cur_a[d][n:] for d in range(self.D)]
         tiles = None
         if self.tiles_mode:
             mk = lambda row, snd: (self.kind, kk, P(self.totals_all), P(self.plan), P(tot), P(self.lw), P(self.stats_own),
@@ -258,7 +262,8 @@ class ShardedBootstrapSweep:
             tiles = {"stats": None if writes_stats else (P(self.lw), n, self.shift, P(self.tile_max), P(self.tile_agg)),
                      "totals": (P(self.stats_all), W, n, P(self.totals_all), P(m)),
                      "steps": [mk(rows_t[d], self.send[d]) for d in range(self.D)],
-                     "step2": mk(self.aext[t % 2], self.send2) if (self.rejuvenate is not None and t >= 1) else None}
+                     "step2": [mk(self.arows[t % 2][d], self.send2[d]) for d in range(self.D)]
+                     if (self.rejuvenate is not None and t >= 1) else None}
         return {
             "tiles": tiles,
             "prog": prog.comp, "vm": vm, "mh": mh, "step2": step2, "recv2": recv2,
@@ -294,9 +299,10 @@ class ShardedBootstrapSweep:
                 if self.comm:
                     self.cx.all_to_all(b["recvs"][d], self.send[d])
             if tl["step2"] is not None:
-                be.check(c.gmx_shard_step_tiles(*tl["step2"], st), "gmx_shard_step_tiles")
-                if self.comm:
-                    self.cx.all_to_all(b["recv2"], self.send2)
+                for d in range(self.D):
+                    be.check(c.gmx_shard_step_tiles(*tl["step2"][d], st), "gmx_shard_step_tiles")
+                    if self.comm:
+                        self.cx.all_to_all(b["recv2"][d], self.send2[d])
             return
         if self.comm:
             self.cx.all_reduce_max(b["pmax"])                            # element-wise MAX of the block maxima (<= 4 KB)
@@ -310,9 +316,10 @@ class ShardedBootstrapSweep:
             if self.comm:
                 self.cx.all_to_all(b["recvs"][d], self.send[d])          # block s of recv <- block `me` of rank s
         if b["step2"] is not None:
-            be.check(c.gmx_shard_step(*b["step2"], st), "gmx_shard_step")
-            if self.comm:
-                self.cx.all_to_all(b["recv2"], self.send2)
+            for d in range(self.D):
+                be.check(c.gmx_shard_step(*b["step2"][d], st), "gmx_shard_step")
+                if self.comm:
+                    self.cx.all_to_all(b["recv2"][d], self.send2[d])
 
     def kernel_timers(self):
         """The site-program launch of a mid-sweep step (no collectives): bench.py's roofline kernel."""

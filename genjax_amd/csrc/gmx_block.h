@@ -1,18 +1,34 @@
 // gmx_block.h — wave / block reductions shared by the AOT kernels and the
 // hiprtc-specialised site programs (device code only).
 //
-// Fixed butterfly order: every lane ends with the same bits and the result
-// does not depend on scheduling, so block partials are reproducible.
+// Order-independent reductions (max, integer sums, integer scans) go through DPP row shifts and
+// row broadcasts (gfx9: row_shr:1/2/4/8, row_bcast:15, row_bcast:31) — six dependent VALU steps and
+// one v_readlane, no LDS round trip.  The ds_bpermute butterflies they replace cost one LDS-crossbar
+// latency (and an s_waitcnt) per step, on the critical path of every kernel that ends in a block
+// reduction.  Float SUMS keep the fixed butterfly order: their bits depend on it.
 #pragma once
 #include "gmx_math.h"
 
 #define GMX_BLOCK 256
 #define GMX_WAVE 64
 
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) v = gmx_fmax(v, __shfl_xor(v, m, GMX_WAVE));
+// v moved by one DPP pattern; lanes the pattern does not feed (or rows outside ROWMASK) read `identity`
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ uint32_t gmx_dpp(uint32_t identity, uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)identity, (int)v, CTRL, ROWMASK, 0xf, false);
+}
+#define GMX_DPP_SCAN_STEPS(STEP) \
+  STEP(0x111, 0xf) STEP(0x112, 0xf) STEP(0x114, 0xf) STEP(0x118, 0xf) STEP(0x142, 0xa) STEP(0x143, 0xc)
+
+// inclusive max-scan; lane 63 holds the wave maximum
+__device__ __forceinline__ float wave_max_scan(float v) {
+#define GMX_STEP(C, M) v = gmx_fmax(v, gmx_u2f(gmx_dpp<C, M>(0xff800000u, gmx_f2u(v))));
+  GMX_DPP_SCAN_STEPS(GMX_STEP)
+#undef GMX_STEP
   return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+  return gmx_u2f((uint32_t)__builtin_amdgcn_readlane((int)gmx_f2u(wave_max_scan(v)), 63));
 }
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -58,20 +74,27 @@ __device__ __forceinline__ void gmx_red_lse(float* red_out, float* lds4, uint32_
 }
 
 // ---- 64-bit wave primitives and the fixed-point weight of the two-level CDF (include/genmi.h) ----
+// inclusive scan of u64 over the wave (integer: any order gives the same bits)
+__device__ __forceinline__ uint64_t wave_scan_u64(uint64_t v) {
+#define GMX_STEP(C, M) { uint32_t lo = gmx_dpp<C, M>(0u, (uint32_t)v), hi = gmx_dpp<C, M>(0u, (uint32_t)(v >> 32)); \
+                         v += ((uint64_t)hi << 32) | lo; }
+  GMX_DPP_SCAN_STEPS(GMX_STEP)
+#undef GMX_STEP
+  return v;
+}
+__device__ __forceinline__ uint64_t wave_last_u64(uint64_t v) {      // lane 63's value, wave-uniform
+  uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, 63);
+  uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), 63);
+  return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) { return wave_last_u64(wave_scan_u64(v)); }
+// lane l receives lane l-1's value (wave_shr:1); lane 0 receives `first`
+__device__ __forceinline__ uint32_t wave_shr1_u32(uint32_t v, uint32_t first) { return gmx_dpp<0x138, 0xf>(first, v); }
 __device__ __forceinline__ uint64_t shfl_up_u64(uint64_t v, int d) {
   uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
   lo = __shfl_up(lo, d, GMX_WAVE);
   hi = __shfl_up(hi, d, GMX_WAVE);
   return ((uint64_t)hi << 32) | lo;
-}
-__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) {
-    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
-    lo = __shfl_xor(lo, m, GMX_WAVE); hi = __shfl_xor(hi, m, GMX_WAVE);
-    v += ((uint64_t)hi << 32) | lo;
-  }
-  return v;
 }
 
 // q = floor(exp(lw - ref) * 2^shift) as u64; NaN / negative / not below 2^63 (lw = +inf) -> 0

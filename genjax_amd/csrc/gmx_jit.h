@@ -67,14 +67,19 @@ struct gmx_jit_ctx {
   }
 };
 
-// PP particles per thread: PP independent instruction streams in one wave give
-// the VALU the instruction-level parallelism a single dependent chain
-// (Threefry, Horner polynomials) cannot (measured on MI355X: one dependent
-// chain per wave issues at ~40 % of the rate of two or four independent
-// ones).  Particle p of a thread is row (blockIdx * PP + p) * 256 + threadIdx,
-// so every load / store stays a coalesced 256-particle group and the block
-// partial rows are the ones the interpreter would write.
-#define GMX_JIT_BEGIN(NREGS, FULLV, NDYN, PPV)                                                   \
+// PP particles per thread: particle p of a thread is row (blockIdx * PP + p) * 256 + threadIdx, so every
+// load / store stays a coalesced 256-particle group and the block partial rows are the ones the
+// interpreter would write.  (Four waves per SIMD already interleave four dependent chains; what PP buys
+// is fewer, fatter workgroups — a workgroup is one 1024-particle tile of the resampler's CDF.)
+//
+// Input loads are PREFETCHED (gmx_program_specialize emits GMX_JIT_PRE* for the program's OP_LDIN
+// instructions): all of a thread's loads are issued at the top of the kernel, unconditionally, on row indices
+// clamped into [0, n) — hipcc will not hoist a load out of an `if (active)` region, and with the loads at
+// their first use every one of them was followed by its own s_waitcnt (eight dependent round trips for the
+// bootstrap step: ancestor, then state, for each of four particles).  Gathered inputs go in two stages:
+// the ancestors at the top, the rows they name after the first key derivation (one Threefry block per
+// particle hides the first round trip); the second round trip is hidden by the rest of the RNG work.
+#define GMX_JIT_BEGIN(NREGS, FULLV, NDYN, PPV, NPRE)                                             \
   extern "C" __global__ void __launch_bounds__(GMX_BLOCK) gmx_jit_kernel(int64_t n, const gmx_run_args A) { \
     __shared__ float lds4[4];                                                                    \
     __shared__ uint64_t lds8[4];                                                                 \
@@ -87,12 +92,32 @@ struct gmx_jit_ctx {
     ctx.rows = (uint32_t)((n + GMX_BLOCK - 1) / GMX_BLOCK);                       \
     regs_t R[PP];                                                                                \
     int64_t idx[PP];                                                                             \
+    int64_t cidx[PP];          /* idx clamped into [0, n): a valid row for prefetches of inactive lanes */ \
+    int64_t arow[PP];          /* ancestors[cidx] */                                             \
+    uint32_t pre[(NPRE) > 0 ? (NPRE) : 1][PP];                                                   \
     bool act[PP];                                                                                \
     _Pragma("unroll") for (int p = 0; p < PP; ++p) {                                             \
       R[p].init();                                                                               \
       idx[p] = ((int64_t)blockIdx.x * PP + p) * GMX_BLOCK + threadIdx.x;                         \
       act[p] = idx[p] < n;                                                                       \
-    }
+      cidx[p] = act[p] ? idx[p] : n - 1;                                                         \
+      arow[p] = 0;                                                                               \
+    }                                                                                            \
+    (void)cidx; (void)arow; (void)pre;
+
+#define GMX_JIT_PRE_ANC                                                                          \
+    _Pragma("unroll") for (int p = 0; p < PP; ++p) arow[p] = (int64_t)A.ancestors_d[cidx[p]];
+
+#define GMX_JIT_PRE_LOAD(K, SLOT, U8, ROW)                                                       \
+    _Pragma("unroll") for (int p = 0; p < PP; ++p)                                               \
+      pre[K][p] = (U8) ? (uint32_t)((const uint8_t*)A.in_d[SLOT])[ROW[p]] : ((const uint32_t*)A.in_d[SLOT])[ROW[p]];
+#define GMX_JIT_PRE(K, SLOT, U8) GMX_JIT_PRE_LOAD(K, SLOT, U8, cidx)
+#define GMX_JIT_PRE_G(K, SLOT, U8) GMX_JIT_PRE_LOAD(K, SLOT, U8, arow)
+#define GMX_JIT_FENCE __builtin_amdgcn_sched_barrier(0);
+
+// OP_LDIN whose value was prefetched
+#define GMX_JIT_LDPRE(DST, K)                                                                    \
+    _Pragma("unroll") for (int p = 0; p < PP; ++p) R[p].set(DST, pre[K][p]);
 
 #define GMX_JIT_OP(W0, W1)                                                                       \
     _Pragma("unroll") for (int p = 0; p < PP; ++p) {                                             \

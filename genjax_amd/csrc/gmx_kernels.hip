@@ -253,18 +253,67 @@ static int jit_pp_for(const gmx_program* p) {
   return (p->n_regs <= 16 && p->n_instr <= 64 && !p->uses_lse) ? 4 : 1;
 }
 
+// prefetch plan of a specialised kernel (gmx_jit.h): the distinct (slot, flags) of the program's per-particle
+// OP_LDIN instructions, at most JIT_MAX_PRE of them (PP registers each, held from the top of the kernel)
+#define JIT_MAX_PRE 8
 static std::string jit_source(const gmx_program* p) {
   std::string s = "#include \"gmx_jit.h\"\n";
-  char buf[96];
+  char buf[128];
   s += "__device__ static constexpr uint32_t GMX_JIT_CONST[] = {";
   for (size_t k = 0; k < p->consts.size(); ++k) { snprintf(buf, sizeof(buf), "0x%08xu,", p->consts[k]); s += buf; }
   s += "0u};\n";
-  snprintf(buf, sizeof(buf), "GMX_JIT_BEGIN(%u, %s, %u, %d)\n", p->n_regs < 16 ? 16u : (p->n_regs < 32 ? 32u : 64u),
-           p->needs_full ? "true" : "false", p->n_dyn, jit_pp_for(p));
+  const char* pf = getenv("GENMI_JIT_PREFETCH");
+  const bool want_pre = !(pf && pf[0] == '0');
+  struct pre_t { uint32_t slot, flags; };
+  std::vector<pre_t> pres;
+  std::vector<int> pre_of(p->n_instr, -1);
+  bool any_gather = false;
+  uint32_t first_gather_pc = p->n_instr, first_key_pc = p->n_instr;
+  bool fits = want_pre;
+  for (uint32_t pc = 0; pc < p->n_instr && fits; ++pc) {
+    const uint32_t w0 = p->code_h[2 * pc], op = w0 & 0xffu, a = (w0 >> 16) & 0xffu, b = w0 >> 24;
+    if ((op == OP_LDKEY || op == OP_KDERIVE) && first_key_pc == p->n_instr) first_key_pc = pc;
+    if (op != OP_LDIN || (b & GMX_F_BCAST)) continue;
+    int k = -1;
+    for (size_t j = 0; j < pres.size(); ++j)
+      if (pres[j].slot == a && pres[j].flags == b) k = (int)j;
+    if (k < 0) {
+      if (pres.size() == JIT_MAX_PRE) { fits = false; break; }
+      k = (int)pres.size();
+      pres.push_back({a, b});
+    }
+    pre_of[pc] = k;
+    if (b & GMX_F_GATHER) { any_gather = true; if (pc < first_gather_pc) first_gather_pc = pc; }
+  }
+  if (!fits) { pres.clear(); pre_of.assign(p->n_instr, -1); any_gather = false; }
+  // second-stage (gathered) loads go behind the first key derivation when that comes before their first use
+  const uint32_t gpos = (any_gather && first_key_pc < first_gather_pc) ? first_key_pc + 1 : 0;
+  snprintf(buf, sizeof(buf), "GMX_JIT_BEGIN(%u, %s, %u, %d, %d)\n", p->n_regs < 16 ? 16u : (p->n_regs < 32 ? 32u : 64u),
+           p->needs_full ? "true" : "false", p->n_dyn, jit_pp_for(p), (int)pres.size());
   s += buf;
+  if (any_gather) s += "  GMX_JIT_PRE_ANC\n";
+  for (size_t k = 0; k < pres.size(); ++k)
+    if (!(pres[k].flags & GMX_F_GATHER)) {
+      snprintf(buf, sizeof(buf), "  GMX_JIT_PRE(%d, %u, %d)\n", (int)k, pres[k].slot, (pres[k].flags & GMX_F_U8) ? 1 : 0);
+      s += buf;
+    }
+  auto gathers = [&]() {
+    for (size_t k = 0; k < pres.size(); ++k)
+      if (pres[k].flags & GMX_F_GATHER) {
+        snprintf(buf, sizeof(buf), "  GMX_JIT_PRE_G(%d, %u, %d)\n", (int)k, pres[k].slot, (pres[k].flags & GMX_F_U8) ? 1 : 0);
+        s += buf;
+      }
+    s += "  GMX_JIT_FENCE\n";
+  };
+  if (!pres.empty()) s += "  GMX_JIT_FENCE\n";
+  if (any_gather && gpos == 0) gathers();
   for (uint32_t pc = 0; pc < p->n_instr; ++pc) {
-    snprintf(buf, sizeof(buf), "  GMX_JIT_OP(0x%08xu, 0x%08xu)\n", p->code_h[2 * pc], p->code_h[2 * pc + 1]);
+    if (pre_of[pc] >= 0)
+      snprintf(buf, sizeof(buf), "  GMX_JIT_LDPRE(%u, %d)\n", (p->code_h[2 * pc] >> 8) & 0xffu, pre_of[pc]);
+    else
+      snprintf(buf, sizeof(buf), "  GMX_JIT_OP(0x%08xu, 0x%08xu)\n", p->code_h[2 * pc], p->code_h[2 * pc + 1]);
     s += buf;
+    if (any_gather && gpos == pc + 1) gathers();
   }
   s += "GMX_JIT_END\n";
   return s;
@@ -815,12 +864,7 @@ k_weight_cdf(const float* __restrict__ lw, int64_t n, float scale, int max_mode,
     run += w;
     q[c] = run;                        // thread-local inclusive
   }
-  uint64_t inc = run;                  // wave inclusive scan of thread totals
-#pragma unroll
-  for (int d = 1; d < GMX_WAVE; d <<= 1) {
-    uint64_t t = shfl_up_u64(inc, d);
-    if (lane >= d) inc += t;
-  }
+  const uint64_t inc = wave_scan_u64(run);   // wave inclusive scan of thread totals (DPP)
   if (lane == 63) s_part[wave] = inc;
   __syncthreads();
   // per definition tile g: A_g (sum of its 4 waves) and G_g = A_g * 2^(k_g - K)
@@ -1253,7 +1297,33 @@ k_tile_stats(const float* __restrict__ lw, int64_t n, float scale, float* __rest
   }
 }
 
+// ---- slot ranges, fast path without branches ----
+// slots_below() above decides one CDF value with nested branches and carries the exact 128-bit predicate inline;
+// k_offspring_tile evaluates it five times per thread, so here the f64 estimate is straight-line code for every
+// evaluation and the (rare: ~1e-7 per evaluation) "within eps of a boundary" cases are collected in a flag and
+// settled afterwards by ONE rolled loop over the exact predicate.  Same answer as slots_below() in every case.
+struct sb_est { int32_t j; bool near; };
+template <int kind>
+__device__ __forceinline__ sb_est slots_below_est(gmx_key key, uint32_t u0, uint64_t c, uint64_t total,
+                                                  double n_over_total, double eps, int32_t n_out) {
+  const double cd = __builtin_fma((double)(uint32_t)(c >> 32), 4294967296.0, (double)(uint32_t)c);   // exact product, one rounding
+  const double v = cd * n_over_total;
+  int32_t t = (int32_t)v;                        // floor (v >= 0), saturating
+  t = t < n_out - 1 ? t : n_out - 1;
+  const double frac = v - (double)t;
+  const uint32_t u = (kind == GMX_RESAMPLE_SYSTEMATIC) ? u0 : (gmx_bits32(key, (uint64_t)(uint32_t)t) >> 9);
+  const double diff = frac - (double)u * (1.0 / 8388608.0);
+  sb_est r;
+  r.j = t + (diff > 0.0 ? 1 : 0);
+  r.near = (frac < eps) || (frac > 1.0 - eps) || !(__builtin_fabs(diff) > eps);
+  if (c == 0ull) { r.j = 0; r.near = false; }
+  if (c >= total) { r.j = n_out; r.near = false; }
+  return r;
+}
+
 // One thread owns 4 consecutive sources (one float4 of log-weights); a block is one tile.
+// Every load is issued before anything waits (unconditional, clamped addresses), wave-level reductions and scans
+// are DPP (gmx_block.h), the slot ranges are straight-line f64 code with one cold exact path.
 template <int kind>
 __global__ void __launch_bounds__(GMX_BLOCK)
 k_offspring_tile(uint32_t k0, uint32_t k1, uint32_t u0_host, const float* __restrict__ lw,
@@ -1264,25 +1334,32 @@ k_offspring_tile(uint32_t k0, uint32_t k1, uint32_t u0_host, const float* __rest
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int my_tile = (int)blockIdx.x;
   const int64_t i0 = (int64_t)my_tile * RS_TILE + (int64_t)threadIdx.x * CDF_VEC;
-  // issue every load first
+  // ---- issue every load first ----
   float x[CDF_VEC];
-  if (i0 + CDF_VEC <= n) {
+  if ((int64_t)(my_tile + 1) * RS_TILE <= n) {          // block-uniform: a full tile
     float4 v = *reinterpret_cast<const float4*>(lw + i0);
     x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
   } else {
 #pragma unroll
-    for (int c = 0; c < CDF_VEC; ++c) x[c] = (i0 + c < n) ? lw[i0 + c] : -gmx_inf();
+    for (int c = 0; c < CDF_VEC; ++c) {
+      const int64_t ic = i0 + c < n ? i0 + c : n - 1;
+      const float xv = lw[ic];
+      x[c] = (i0 + c < n) ? xv : -gmx_inf();
+    }
   }
   constexpr int PER = RS_MAX_TILES / GMX_BLOCK;
   uint64_t ta[PER];
   float tm[PER];
 #pragma unroll
   for (int r = 0; r < PER; ++r) {
-    const int t = r * GMX_BLOCK + (int)threadIdx.x;
     ta[r] = 0ull; tm[r] = -gmx_inf();
     if (r * GMX_BLOCK < n_tiles) {               // uniform: rows of the table that exist
-      ta[r] = (t < n_tiles) ? agg[t] : 0ull;
-      tm[r] = (t < n_tiles) ? tmax[t] : -gmx_inf();
+      const int t = r * GMX_BLOCK + (int)threadIdx.x;
+      const int tc = t < n_tiles ? t : n_tiles - 1;
+      const uint64_t a = agg[tc];
+      const float m = tmax[tc];
+      ta[r] = (t < n_tiles) ? a : 0ull;
+      tm[r] = (t < n_tiles) ? m : -gmx_inf();
     }
   }
   const int32_t k_b = gmx_tile_exp(tmax[my_tile]);
@@ -1297,15 +1374,11 @@ k_offspring_tile(uint32_t k0, uint32_t k1, uint32_t u0_host, const float* __rest
   uint64_t run = 0;
 #pragma unroll
   for (int c = 0; c < CDF_VEC; ++c) {
-    run += (i0 + c < n) ? weight_fixed(x[c], ref_b, scale) : 0ull;
+    const uint64_t w = weight_fixed(x[c], ref_b, scale);
+    run += (i0 + c < n) ? w : 0ull;
     q[c] = run;
   }
-  uint64_t inc = run;
-#pragma unroll
-  for (int d = 1; d < GMX_WAVE; d <<= 1) {
-    uint64_t t = shfl_up_u64(inc, d);
-    if (lane >= d) inc += t;
-  }
+  const uint64_t inc = wave_scan_u64(run);
   if (lane == 0) s_max[wave] = M;
   if (lane == 63) s_scan[wave] = inc;
   __syncthreads();
@@ -1334,8 +1407,6 @@ k_offspring_tile(uint32_t k0, uint32_t k1, uint32_t u0_host, const float* __rest
   const uint64_t total = (s_all[0] + s_all[1]) + (s_all[2] + s_all[3]);
   if (blockIdx.x == 0 && threadIdx.x == 0) { *total_out = total; *max_out = M; }
   gmx_key key; key.k0 = k0; key.k1 = k1;
-  const uint64_t u0 = (uint64_t)u0_host;          // bits32(key, 0) >> 9, evaluated on the host
-  const uint64_t D = (uint64_t)n << 23;
   if (total == 0) {       // no mass at all (all weights -inf / NaN): every slot maps to the last particle
 #pragma unroll
     for (int c = 0; c < CDF_VEC; ++c)
@@ -1344,25 +1415,53 @@ k_offspring_tile(uint32_t k0, uint32_t k1, uint32_t u0_host, const float* __rest
   }
   const double n_over_total = (double)n / (double)total;
   const double eps = (double)n * 0x1p-44 + 0x1p-40;
-  int64_t e[CDF_VEC];
+  const int32_t n32 = (int32_t)n;
+  // CDF values at the lower edge of the thread's first source and at the upper edge of each source
+  uint64_t cv[CDF_VEC + 1];
+  cv[0] = prefix + gmx_tile_scale(loc, k_b, K);
 #pragma unroll
-  for (int c = 0; c < CDF_VEC; ++c) {
-    const uint64_t c_hi = (i0 + c < n) ? prefix + gmx_tile_scale(loc + q[c], k_b, K) : total;
-    e[c] = slots_below(kind, key, u0, c_hi, D, total, n_over_total, eps, n);
+  for (int c = 0; c < CDF_VEC; ++c) cv[c + 1] = (i0 + c < n) ? prefix + gmx_tile_scale(loc + q[c], k_b, K) : total;
+  int32_t e[CDF_VEC + 1];
+  bool near = false;
+  uint32_t near_bits = 0;
+#pragma unroll
+  for (int c = 1; c <= CDF_VEC; ++c) {
+    const sb_est r = slots_below_est<kind>(key, u0_host, cv[c], total, n_over_total, eps, n32);
+    e[c] = r.j;
+    near_bits |= r.near ? (1u << c) : 0u;
   }
-  // lower bound of the thread's first source = upper bound of the previous thread's last one
-  uint32_t e_lo = (uint32_t)e[CDF_VEC - 1], e_hi32 = (uint32_t)((uint64_t)e[CDF_VEC - 1] >> 32);
-  e_lo = __shfl_up(e_lo, 1, GMX_WAVE); e_hi32 = __shfl_up(e_hi32, 1, GMX_WAVE);
-  int64_t s = (int64_t)(((uint64_t)e_hi32 << 32) | e_lo);
-  if (lane == 0)
-    s = slots_below(kind, key, u0, prefix + gmx_tile_scale(loc, k_b, K), D, total, n_over_total, eps, n);
-  // ONE loop over the thread's slots [s, e[3]) — its trip count diverges over the thread's total offspring
+  // lower bound of the thread's first source = upper bound of the previous thread's last one; lane 0 evaluates its own
+  {
+    const sb_est r = slots_below_est<kind>(key, u0_host, cv[0], total, n_over_total, eps, n32);
+    near_bits |= (lane == 0 && r.near) ? 1u : 0u;
+    e[0] = (int32_t)wave_shr1_u32((uint32_t)e[CDF_VEC], (uint32_t)r.j);
+    if (lane == 0) e[0] = r.j;
+  }
+  near = near_bits != 0u;
+  if (__any(near)) {
+    // cold: the exact integer predicate for the flagged evaluations (rolled; operands picked by selects)
+    const uint64_t D = (uint64_t)n << 23;
+    int32_t fixed0 = e[0];
+#pragma unroll 1
+    for (int c = 0; c <= CDF_VEC; ++c) {
+      if (near_bits & (1u << c)) {
+        const uint64_t cc = c == 0 ? cv[0] : c == 1 ? cv[1] : c == 2 ? cv[2] : c == 3 ? cv[3] : cv[4];
+        const int32_t j0 = c == 0 ? e[0] : c == 1 ? e[1] : c == 2 ? e[2] : c == 3 ? e[3] : e[4];
+        const int32_t j = (int32_t)slots_below_exact(kind, key, (uint64_t)u0_host, cc, D, total, (int64_t)j0, n);
+        if (c == 0) fixed0 = j; else if (c == 1) e[1] = j; else if (c == 2) e[2] = j; else if (c == 3) e[3] = j; else e[4] = j;
+      }
+    }
+    // a corrected upper bound is the next lane's lower bound
+    const uint32_t up = wave_shr1_u32((uint32_t)e[CDF_VEC], (uint32_t)fixed0);
+    e[0] = (lane == 0) ? fixed0 : (int32_t)up;
+  }
+  // ONE loop over the thread's slots [e[0], e[4]) — its trip count diverges over the thread's total offspring
   // (mean 4) instead of four loops each diverging over one source's (mean 1, max ~4); slots are < 2^31.
   // Sources past n have e[c] = n = e of the last real source, so they own no slot.
-  const int32_t e0 = (int32_t)e[0], e1 = (int32_t)e[1], e2 = (int32_t)e[2], e3 = (int32_t)e[3];
+  const int32_t e1 = e[1], e2 = e[2], e3 = e[3], e4 = e[4];
   const int32_t src0 = (int32_t)i0;
-  for (int32_t j = (int32_t)s; j < e3; ++j)
-    anc[j] = src0 + (j >= e0 ? 1 : 0) + (j >= e1 ? 1 : 0) + (j >= e2 ? 1 : 0);
+  for (int32_t j = e[0]; j < e4; ++j)
+    anc[j] = src0 + (j >= e1 ? 1 : 0) + (j >= e2 ? 1 : 0) + (j >= e3 ? 1 : 0);
 }
 
 static int resample_shape(const char* who, int64_t n, int shift) {
@@ -1620,12 +1719,7 @@ k_shard_step(int kind, uint32_t k0, uint32_t k1, const uint64_t* __restrict__ to
         run += (i0 + c < n) ? weight_fixed(x[c], ref_b, TS.scale) : 0ull;
         q[c] = run;
       }
-      uint64_t inc = run;
-#pragma unroll
-      for (int d = 1; d < GMX_WAVE; d <<= 1) {
-        uint64_t t = shfl_up_u64(inc, d);
-        if (lane >= d) inc += t;
-      }
+      const uint64_t inc = wave_scan_u64(run);
       below = wave_sum_u64(below);
       if (lane == 0) s_below[wave] = below;
       if (lane == 63) s_scan[wave] = inc;

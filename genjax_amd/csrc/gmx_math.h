@@ -69,13 +69,19 @@ GMX_HD uint64_t gmx_tile_scale(uint64_t v, int32_t k, int32_t K) {              
 
 // exp(x).  Results below the smallest normal are flushed to +0 so that the
 // answer never depends on a target's denormal mode.
+// Straight-line: the range checks are selects applied to the main path's result (computed on a
+// clamped argument), so on the GPU the function is one basic block — no exec-mask branches in the
+// middle of a particle's instruction stream.  The selected values are the ones the branching form
+// returned, bit for bit.
 GMX_HD float gmx_expf(float x) {
-  if (gmx_isnan(x)) return x;
-  if (x > 88.72283935546875f) return gmx_inf();
-  if (x < -87.33654022216797f) return 0.0f;
-  float kf = __builtin_rintf(x * 1.44269502162933349609375f);
+  const float hi = 88.72283935546875f, lo = -87.33654022216797f;
+  const int nan = gmx_isnan(x);
+  float xc = x > hi ? hi : x;
+  xc = xc < lo ? lo : xc;
+  xc = nan ? 0.0f : xc;
+  float kf = __builtin_rintf(xc * 1.44269502162933349609375f);
   // Cody–Waite: ln2 = hi + lo, hi has 9 trailing zero bits (kf*hi is exact).
-  float r = gmx_fma(kf, -0.693359375f, x);
+  float r = gmx_fma(kf, -0.693359375f, xc);
   r = gmx_fma(kf, 2.12194440e-4f, r);
   // e^r on [-ln2/2, ln2/2], degree-6 minimax (cephes expf coefficients).
   float p = 1.9875691500e-4f;
@@ -91,33 +97,25 @@ GMX_HD float gmx_expf(float x) {
   int k1 = k >> 1;          // split so both scale factors stay normal
   int k2 = k - k1;
   float y = (p * gmx_pow2i(k1)) * gmx_pow2i(k2);
-  if (y < 1.17549435e-38f) return 0.0f;
-  return y;
+  y = y < 1.17549435e-38f ? 0.0f : y;
+  y = x < lo ? 0.0f : y;
+  y = x > hi ? gmx_inf() : y;
+  return nan ? x : y;
 }
 
 // log(x), natural.  cephes logf polynomial on [sqrt(1/2), sqrt(2)).
+// Straight-line like gmx_expf: special cases are selects over the main path's result.
 GMX_HD float gmx_logf(float x) {
-  uint32_t ux = gmx_f2u(x);
-  if (gmx_isnan(x)) return x;
-  if (ux == 0u || ux == 0x80000000u) return -gmx_inf();
-  if (ux >> 31) return gmx_nan();
-  if (ux == GMX_INF_BITS) return x;
-  int e = 0;
-  if (ux < 0x00800000u) {   // denormal input: scale up by 2^23 (exact)
-    x = x * 8388608.0f;
-    ux = gmx_f2u(x);
-    e = -23;
-  }
+  const uint32_t ux = gmx_f2u(x);
+  const int den = ux < 0x00800000u;          // denormal (or +0: overridden below): scale up by 2^23 (exact)
+  const float xs = den ? x * 8388608.0f : x;
+  const uint32_t us = gmx_f2u(xs);
   // frexp: x = m * 2^e with m in [0.5, 1)
-  e += (int)(ux >> 23) - 126;
-  float m = gmx_u2f((ux & 0x007fffffu) | 0x3f000000u);
-  float f;
-  if (m < 0.707106781186547524f) {
-    e -= 1;
-    f = (m + m) - 1.0f;
-  } else {
-    f = m - 1.0f;
-  }
+  int e = (den ? -23 : 0) + (int)(us >> 23) - 126;
+  const float m = gmx_u2f((us & 0x007fffffu) | 0x3f000000u);
+  const int low = m < 0.707106781186547524f;
+  e -= low;
+  const float f = low ? (m + m) - 1.0f : m - 1.0f;
   float z = f * f;
   float p = 7.0376836292e-2f;
   p = gmx_fma(p, f, -1.1514610310e-1f);
@@ -134,18 +132,22 @@ GMX_HD float gmx_logf(float x) {
   y = gmx_fma(-0.5f, z, y);
   float r = f + y;
   r = gmx_fma(ef, 0.693359375f, r);
-  return r;
+  // special cases, lowest priority first
+  r = (ux == GMX_INF_BITS) ? x : r;
+  r = (ux >> 31) ? gmx_nan() : r;
+  r = (ux == 0u || ux == 0x80000000u) ? -gmx_inf() : r;
+  return gmx_isnan(x) ? x : r;
 }
 
-// log(1 + x) by Kahan's correction of log(u), u = fl(1 + x).
+// log(1 + x) by Kahan's correction of log(u), u = fl(1 + x).  Straight-line (see gmx_expf).
 GMX_HD float gmx_log1pf(float x) {
-  if (gmx_isnan(x)) return x;
   float u = 1.0f + x;
-  if (u == 1.0f) return x;
-  if (gmx_f2u(u) == GMX_INF_BITS) return u;
   float l = gmx_logf(u);
   float d = u - 1.0f;
-  return l * (x / d);
+  float r = l * (x / d);                 // d == 0 only when u == 1: overridden
+  r = (gmx_f2u(u) == GMX_INF_BITS) ? u : r;
+  r = (u == 1.0f) ? x : r;
+  return gmx_isnan(x) ? x : r;
 }
 
 GMX_HD float gmx_sqrtf(float x) { return __builtin_sqrtf(x); }

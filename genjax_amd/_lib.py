@@ -20,6 +20,7 @@ GMX_MAX_OUT = 64
 GMX_MAX_TAB = 8
 GMX_MAX_UNI = 64
 
+ABI_VERSION = 2
 KEY_NONE, KEY_ARRAY, KEY_SPLIT, KEY_ROWSPLIT, KEY_BCAST = 0, 1, 2, 3, 4
 RESAMPLE_SYSTEMATIC, RESAMPLE_STRATIFIED, RESAMPLE_MULTINOMIAL = 0, 1, 2
 
@@ -42,6 +43,7 @@ class RunArgs(Structure):
         ("tile_agg_d", c_void_p),
         ("tile_shift", c_int32),
         ("reserved_", c_int32),
+        ("tile_q_d", c_void_p),
     ]
 
 
@@ -97,6 +99,8 @@ class Backend:
         c.gmx_tile_stats.argtypes = [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p]
         c.gmx_resample_tiles.argtypes = [c_int, POINTER(c_uint32), c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p,
                                          c_void_p, c_void_p, c_void_p]
+        c.gmx_resample_tiles_q.argtypes = [c_int, POINTER(c_uint32), c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p,
+                                           c_void_p, c_void_p, c_void_p]
         c.gmx_shard_stats_bytes.argtypes = [c_int64]
         c.gmx_shard_stats_bytes.restype = c_size_t
         c.gmx_shard_totals.argtypes = [c_void_p, c_int, c_int64, c_void_p, c_void_p, c_void_p]
@@ -169,7 +173,7 @@ def get() -> Backend:
     cdll = ctypes.CDLL(LIB_PATH)
     dev = torch.device("cuda", torch.cuda.current_device())
     _backend = Backend(cdll, dev, uses_streams=True)
-    if _backend.c.gmx_version() != 1:
+    if _backend.c.gmx_version() != ABI_VERSION:
         raise GenmiError("libgenmi_hip.so ABI version mismatch")
     return _backend
 

@@ -29,6 +29,7 @@ struct gmx_jit_ctx {
   int cur;                  // which of the thread's particles this step works on
   uint32_t part;            // index of the 256-particle group this step works on (block partial row)
   uint32_t rows;            // number of 256-particle groups = ceil(n / 256)
+  int64_t n_rows;           // n (particles of this launch)
   float acc_max;            // OP_REDMAX: running max over the thread's PP particles
   bool first, last;         // this step handles the first / last of the thread's particles
   __device__ __forceinline__ uint32_t pool(uint32_t i) const {
@@ -53,8 +54,16 @@ struct gmx_jit_ctx {
         const float scale = gmx_pow2i(A->tile_shift);
         const float ref = gmx_tile_ref(gmx_tile_exp(bm));
         uint64_t s = 0;
+        uint64_t qv[PPV];
 #pragma unroll
-        for (int p = 0; p < PPV; ++p) s += weight_fixed(red_x[p], ref, scale);
+        for (int p = 0; p < PPV; ++p) { qv[p] = weight_fixed(red_x[p], ref, scale); s += qv[p]; }
+        if (A->tile_q_d) {                  // inactive particles have red_x = -inf, i.e. q = 0: nothing to store
+#pragma unroll
+          for (int p = 0; p < PPV; ++p) {
+            const int64_t row = ((int64_t)blockIdx.x * PPV + p) * GMX_BLOCK + threadIdx.x;
+            if (row < n_rows) A->tile_q_d[row] = qv[p];
+          }
+        }
         s = wave_sum_u64(s);
         if ((threadIdx.x & 63) == 0) lds8[threadIdx.x >> 6] = s;
         __syncthreads();
@@ -89,7 +98,7 @@ struct gmx_jit_ctx {
     constexpr bool full_v = FULLV;                                                               \
     ctx_t ctx;                                                                                   \
     ctx.consts = GMX_JIT_CONST; ctx.A = &A; ctx.lds4 = lds4; ctx.lds8 = lds8; ctx.part = 0; ctx.cur = 0; \
-    ctx.rows = (uint32_t)((n + GMX_BLOCK - 1) / GMX_BLOCK);                       \
+    ctx.rows = (uint32_t)((n + GMX_BLOCK - 1) / GMX_BLOCK); ctx.n_rows = n;      \
     regs_t R[PP];                                                                                \
     int64_t idx[PP];                                                                             \
     int64_t cidx[PP];          /* idx clamped into [0, n): a valid row for prefetches of inactive lanes */ \

@@ -510,6 +510,9 @@ extern "C" int gmx_program_run(const gmx_program* p, int64_t n, const gmx_run_ar
       return gmx_fail("gmx_program_run: tile_agg_d is set but this program cannot write tile statistics "
                       "(gmx_program_writes_tile_stats)%s");
     if (args->tile_shift < 1 || args->tile_shift > 62) return gmx_fail("gmx_program_run: tile_shift out of range%s");
+    if ((uintptr_t)args->tile_q_d & 15) return gmx_fail("gmx_program_run: tile_q_d must be 16-byte aligned%s");
+  } else if (args->tile_q_d) {
+    return gmx_fail("gmx_program_run: tile_q_d needs tile_agg_d%s");
   }
   if (p->uses_key) {
     int km = args->key_mode;
@@ -1307,13 +1310,23 @@ template <int kind>
 __device__ __forceinline__ sb_est slots_below_est(gmx_key key, uint32_t u0, uint64_t c, uint64_t total,
                                                   double n_over_total, double eps, int32_t n_out) {
   const double cd = __builtin_fma((double)(uint32_t)(c >> 32), 4294967296.0, (double)(uint32_t)c);   // exact product, one rounding
+  sb_est r;
+  if (kind == GMX_RESAMPLE_SYSTEMATIC) {
+    // slot j is below iff j + du < v  <=>  j < v - du: the count is floor(v - du) + 1 (v - du not an integer;
+    // within eps of one, the exact predicate decides).  y = v - du + 1 > 0 comes out of ONE fma.
+    const double y = __builtin_fma(cd, n_over_total, 1.0 - (double)u0 * (1.0 / 8388608.0));
+    const int32_t t = (int32_t)y;                // floor (y > 0), saturating
+    const double frac = y - (double)t;
+    r.j = t < n_out ? t : n_out;
+    r.near = (frac < eps) || (frac > 1.0 - eps);
+    return r;
+  }
   const double v = cd * n_over_total;
   int32_t t = (int32_t)v;                        // floor (v >= 0), saturating
   t = t < n_out - 1 ? t : n_out - 1;
   const double frac = v - (double)t;
-  const uint32_t u = (kind == GMX_RESAMPLE_SYSTEMATIC) ? u0 : (gmx_bits32(key, (uint64_t)(uint32_t)t) >> 9);
+  const uint32_t u = gmx_bits32(key, (uint64_t)(uint32_t)t) >> 9;
   const double diff = frac - (double)u * (1.0 / 8388608.0);
-  sb_est r;
   r.j = t + (diff > 0.0 ? 1 : 0);
   r.near = (frac < eps) || (frac > 1.0 - eps) || !(__builtin_fabs(diff) > eps);
   if (c == 0ull) { r.j = 0; r.near = false; }
@@ -1324,9 +1337,11 @@ __device__ __forceinline__ sb_est slots_below_est(gmx_key key, uint32_t u0, uint
 // One thread owns 4 consecutive sources (one float4 of log-weights); a block is one tile.
 // Every load is issued before anything waits (unconditional, clamped addresses), wave-level reductions and scans
 // are DPP (gmx_block.h), the slot ranges are straight-line f64 code with one cold exact path.
-template <int kind>
+// FROMQ: the per-particle fixed-point weights come from memory (`qin`, written by the site program's epilogue:
+// gmx_run_args.tile_q_d) instead of being recomputed from the log-weights (one exp + one f32 -> u64 conversion each).
+template <int kind, bool FROMQ>
 __global__ void __launch_bounds__(GMX_BLOCK)
-k_offspring_tile(uint32_t k0, uint32_t k1, uint32_t u0_host, const float* __restrict__ lw,
+k_offspring_tile(uint32_t k0, uint32_t k1, uint32_t u0_host, const float* __restrict__ lw, const uint64_t* __restrict__ qin,
                  const float* __restrict__ tmax, const uint64_t* __restrict__ agg, int64_t n, int n_tiles, float scale,
                  float* __restrict__ max_out, uint64_t* __restrict__ total_out, int32_t* __restrict__ anc) {
   __shared__ uint64_t s_below[4], s_all[4], s_scan[4];
@@ -1336,7 +1351,22 @@ k_offspring_tile(uint32_t k0, uint32_t k1, uint32_t u0_host, const float* __rest
   const int64_t i0 = (int64_t)my_tile * RS_TILE + (int64_t)threadIdx.x * CDF_VEC;
   // ---- issue every load first ----
   float x[CDF_VEC];
-  if ((int64_t)(my_tile + 1) * RS_TILE <= n) {          // block-uniform: a full tile
+  uint64_t qw[CDF_VEC];
+  const bool full_tile = (int64_t)(my_tile + 1) * RS_TILE <= n;      // block-uniform
+  if (FROMQ) {
+    if (full_tile) {
+      const ulonglong2 a = reinterpret_cast<const ulonglong2*>(qin + i0)[0];
+      const ulonglong2 b = reinterpret_cast<const ulonglong2*>(qin + i0)[1];
+      qw[0] = a.x; qw[1] = a.y; qw[2] = b.x; qw[3] = b.y;
+    } else {
+#pragma unroll
+      for (int c = 0; c < CDF_VEC; ++c) {
+        const int64_t ic = i0 + c < n ? i0 + c : n - 1;
+        const uint64_t v = qin[ic];
+        qw[c] = (i0 + c < n) ? v : 0ull;
+      }
+    }
+  } else if (full_tile) {
     float4 v = *reinterpret_cast<const float4*>(lw + i0);
     x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
   } else {
@@ -1351,18 +1381,24 @@ k_offspring_tile(uint32_t k0, uint32_t k1, uint32_t u0_host, const float* __rest
   uint64_t ta[PER];
   float tm[PER];
 #pragma unroll
-  for (int r = 0; r < PER; ++r) {
+  for (int r = 0; r < PER; ++r) {                // loads only (clamped rows): nothing here waits
     ta[r] = 0ull; tm[r] = -gmx_inf();
     if (r * GMX_BLOCK < n_tiles) {               // uniform: rows of the table that exist
       const int t = r * GMX_BLOCK + (int)threadIdx.x;
       const int tc = t < n_tiles ? t : n_tiles - 1;
-      const uint64_t a = agg[tc];
-      const float m = tmax[tc];
-      ta[r] = (t < n_tiles) ? a : 0ull;
-      tm[r] = (t < n_tiles) ? m : -gmx_inf();
+      ta[r] = agg[tc];
+      tm[r] = tmax[tc];
     }
   }
-  const int32_t k_b = gmx_tile_exp(tmax[my_tile]);
+  const float tmax_mine = tmax[my_tile];
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int r = 0; r < PER; ++r) {
+    const int t = r * GMX_BLOCK + (int)threadIdx.x;
+    ta[r] = (t < n_tiles) ? ta[r] : 0ull;
+    tm[r] = (t < n_tiles) ? tm[r] : -gmx_inf();
+  }
+  const int32_t k_b = gmx_tile_exp(tmax_mine);
   const float ref_b = gmx_tile_ref(k_b);
   // phase 1: the global max, and the wave totals of this tile's local weights
   float M = -gmx_inf();
@@ -1374,7 +1410,7 @@ k_offspring_tile(uint32_t k0, uint32_t k1, uint32_t u0_host, const float* __rest
   uint64_t run = 0;
 #pragma unroll
   for (int c = 0; c < CDF_VEC; ++c) {
-    const uint64_t w = weight_fixed(x[c], ref_b, scale);
+    const uint64_t w = FROMQ ? qw[c] : weight_fixed(x[c], ref_b, scale);
     run += (i0 + c < n) ? w : 0ull;
     q[c] = run;
   }
@@ -1475,6 +1511,26 @@ static int resample_shape(const char* who, int64_t n, int shift) {
   return 0;
 }
 
+static int launch_offspring_tile(int kind, const uint32_t key[2], const float* lw_d, const uint64_t* q_d, int64_t n, int shift,
+                                 const float* tile_max_d, const uint64_t* tile_agg_d, float* max_d, uint64_t* total_d,
+                                 int32_t* ancestors_d, gmx_stream stream) {
+  uint32_t b0, b1;
+  gmx_threefry2x32(key[0], key[1], 0u, 0u, &b0, &b1);           // bits32(key, 0) on the host
+  const uint32_t u0 = (b0 ^ b1) >> 9;
+  const int64_t tiles = (n + RS_TILE - 1) / RS_TILE;
+  const dim3 grid((unsigned)tiles), block(GMX_BLOCK);
+  hipStream_t st = (hipStream_t)stream;
+  const float scale = gmx_pow2i(shift);
+#define GMX_LAUNCH_OT(KIND, FQ)                                                                                     \
+  hipLaunchKernelGGL((k_offspring_tile<KIND, FQ>), grid, block, 0, st, key[0], key[1], u0, lw_d, q_d, tile_max_d, \
+                     tile_agg_d, n, (int)tiles, scale, max_d, total_d, ancestors_d)
+  if (kind == GMX_RESAMPLE_SYSTEMATIC) { if (q_d) GMX_LAUNCH_OT(GMX_RESAMPLE_SYSTEMATIC, true); else GMX_LAUNCH_OT(GMX_RESAMPLE_SYSTEMATIC, false); }
+  else { if (q_d) GMX_LAUNCH_OT(GMX_RESAMPLE_STRATIFIED, true); else GMX_LAUNCH_OT(GMX_RESAMPLE_STRATIFIED, false); }
+#undef GMX_LAUNCH_OT
+  GMX_HIP(hipGetLastError());
+  return 0;
+}
+
 extern "C" int gmx_tile_stats(const float* lw_d, int64_t n, int shift, float* tile_max_d, uint64_t* tile_agg_d,
                               gmx_stream stream) {
   if (resample_shape("gmx_tile_stats", n, shift)) return 1;
@@ -1497,20 +1553,20 @@ extern "C" int gmx_resample_tiles(int kind, const uint32_t key[2], const float* 
     return gmx_fail("gmx_resample_tiles: kind must be systematic or stratified (use gmx_weight_cdf + gmx_ancestors)%s");
   if (n > 0x7fffffffLL) return gmx_fail("gmx_resample_tiles: n out of range%s");
   if ((uintptr_t)lw_d & 15) return gmx_fail("gmx_resample_tiles: lw_d must be 16-byte aligned%s");
-  uint32_t b0, b1;
-  gmx_threefry2x32(key[0], key[1], 0u, 0u, &b0, &b1);           // bits32(key, 0) on the host
-  const uint32_t u0 = (b0 ^ b1) >> 9;
-  const int64_t tiles = (n + RS_TILE - 1) / RS_TILE;
-  if (kind == GMX_RESAMPLE_SYSTEMATIC)
-    hipLaunchKernelGGL(k_offspring_tile<GMX_RESAMPLE_SYSTEMATIC>, dim3((unsigned)tiles), dim3(GMX_BLOCK), 0,
-                       (hipStream_t)stream, key[0], key[1], u0, lw_d, tile_max_d, tile_agg_d, n, (int)tiles,
-                       gmx_pow2i(shift), max_d, total_d, ancestors_d);
-  else
-    hipLaunchKernelGGL(k_offspring_tile<GMX_RESAMPLE_STRATIFIED>, dim3((unsigned)tiles), dim3(GMX_BLOCK), 0,
-                       (hipStream_t)stream, key[0], key[1], u0, lw_d, tile_max_d, tile_agg_d, n, (int)tiles,
-                       gmx_pow2i(shift), max_d, total_d, ancestors_d);
-  GMX_HIP(hipGetLastError());
-  return 0;
+  return launch_offspring_tile(kind, key, lw_d, nullptr, n, shift, tile_max_d, tile_agg_d, max_d, total_d, ancestors_d, stream);
+}
+
+extern "C" int gmx_resample_tiles_q(int kind, const uint32_t key[2], const uint64_t* q_d, int64_t n, int shift,
+                                    const float* tile_max_d, const uint64_t* tile_agg_d, float* max_d,
+                                    uint64_t* total_d, int32_t* ancestors_d, gmx_stream stream) {
+  if (resample_shape("gmx_resample_tiles_q", n, shift)) return 1;
+  if (!key || !q_d || !tile_max_d || !tile_agg_d || !max_d || !total_d || !ancestors_d)
+    return gmx_fail("gmx_resample_tiles_q: null argument%s");
+  if (kind != GMX_RESAMPLE_SYSTEMATIC && kind != GMX_RESAMPLE_STRATIFIED)
+    return gmx_fail("gmx_resample_tiles_q: kind must be systematic or stratified%s");
+  if (n > 0x7fffffffLL) return gmx_fail("gmx_resample_tiles_q: n out of range%s");
+  if ((uintptr_t)q_d & 15) return gmx_fail("gmx_resample_tiles_q: q_d must be 16-byte aligned%s");
+  return launch_offspring_tile(kind, key, nullptr, q_d, n, shift, tile_max_d, tile_agg_d, max_d, total_d, ancestors_d, stream);
 }
 
 // log-weights -> ancestors: gmx_tile_stats + gmx_resample_tiles with the tile stats in the workspace.

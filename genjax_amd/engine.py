@@ -370,8 +370,10 @@ class Compiled:
              tile_stats=None):
         """Fill a gmx_run_args for these leaves: (n, args, keep-alive list, outputs).  Sweeps whose
         buffers are persistent bind every step once and re-launch the bindings.
-        tile_stats = (int64 tensor [grid], shift): the launch also writes the per-workgroup fixed-point weight
-        sums gmx_resample_tiles consumes (only if `writes_tile_stats()`)."""
+        tile_stats = (int64 tensor [grid], shift[, int64 tensor [n]]): the launch also writes the per-workgroup
+        fixed-point weight sums gmx_resample_tiles consumes (only if `writes_tile_stats()`) and, with the third
+        entry, every particle's fixed-point weight (gmx_resample_tiles_q then reads those instead of the
+        log-weights)."""
         be = self._be
         n = int(np.prod(batch, dtype=np.int64))
         self._work = getattr(self, "_work", 0) + n
@@ -468,9 +470,12 @@ class Compiled:
             self.last_red = red_out
             keep.append(red_out)
         if tile_stats is not None:
-            agg, shift = tile_stats
+            agg, shift = tile_stats[0], tile_stats[1]
             A.tile_agg_d, A.tile_shift = agg.data_ptr(), int(shift)
             keep.append(agg)
+            if len(tile_stats) > 2 and tile_stats[2] is not None:      # per-particle fixed-point weights (tile_q_d)
+                A.tile_q_d = tile_stats[2].data_ptr()
+                keep.append(tile_stats[2])
         return n, A, keep, outs
 
 

@@ -585,6 +585,10 @@ class BootstrapSweep:
         self.tile_agg = torch.zeros(((n + 1023) // 1024,), dtype=torch.int64, device=dev)
         self.tile_stats = bool(self.fused and os.environ.get("GENMI_TILE_STATS", "1") != "0"
                                and self.p_init.comp.writes_tile_stats() and self.p_step.comp.writes_tile_stats())
+        # ... and every particle's fixed-point weight (8 bytes each): the resampler then reads those and skips one
+        # exp + one f32 -> u64 conversion per particle (GENMI_TILE_Q=0: recompute them from the log-weights)
+        self.tile_q = torch.zeros((n,), dtype=torch.int64, device=dev) \
+            if self.tile_stats and os.environ.get("GENMI_TILE_Q", "1") != "0" else None
         # per-step keys on the host
         self.step_keys = []
         for t in range(T):
@@ -606,7 +610,7 @@ class BootstrapSweep:
         bufs[prog.ro[1]] = self.x_store[t % 2]
         bufs[prog.wo[1]] = self.lw.reshape(1, n)
         prog.comp.run(leaves, (n,), lazy_split(k_prop, n), red_out=self.partials, out_buffers=bufs,
-                      tile_stats=(self.tile_agg, self.shift) if self.tile_stats else None)
+                      tile_stats=(self.tile_agg, self.shift, self.tile_q) if self.tile_stats else None)
 
     def _launch_mh(self, t):
         """The MH move on the resampled particles of step t-1 (t >= 1): reads x_{t-1}[anc] and, for
@@ -649,6 +653,12 @@ class BootstrapSweep:
         be = _lib.get()
         kh = self.step_keys[t][1].host()
         kk = (c_uint32 * 2)(int(kh[0]), int(kh[1]))
+        if self.tile_stats and self.tile_q is not None:
+            be.check(be.c.gmx_resample_tiles_q(self.kind, kk, be.ptr(self.tile_q), self.n, self.shift,
+                                               be.ptr(self.partials), be.ptr(self.tile_agg), be.ptr(self.maxs[t:t + 1]),
+                                               be.ptr(self.totals[t:t + 1]), be.ptr(self.anc), be.stream()),
+                     "gmx_resample_tiles_q")
+            return
         if self.tile_stats:        # tile maxima = the workgroup maxima the site program left in partials[0]
             be.check(be.c.gmx_resample_tiles(self.kind, kk, be.ptr(self.lw), self.n, self.shift, be.ptr(self.partials),
                                              be.ptr(self.tile_agg), be.ptr(self.maxs[t:t + 1]),

@@ -39,7 +39,7 @@ typedef __UINTPTR_TYPE__ uintptr_t;
 extern "C" {
 #endif
 
-#define GMX_ABI_VERSION 1
+#define GMX_ABI_VERSION 2
 
 typedef void* gmx_stream;            /* hipStream_t */
 typedef struct gmx_program gmx_program;
@@ -128,6 +128,11 @@ typedef struct gmx_run_args {
                                      gmx_resample_tiles needs — no separate pass over the log-weights  */
   int32_t tile_shift;
   int32_t reserved_;
+  uint64_t* tile_q_d;             /* optional, with tile_agg_d: [n] the fixed-point weight of every particle,
+                                     q_i = floor(exp(x_i - k_b ln 2) * 2^tile_shift) — the terms A_b sums.  The
+                                     epilogue has them in registers; written out, the resampler
+                                     (gmx_resample_tiles_q) needs neither the log-weights nor a second exp per
+                                     particle: 8 bytes of traffic instead of ~40 vector instructions             */
 } gmx_run_args;
 
 int gmx_program_create(const uint32_t* blob_h, size_t n_words, gmx_program** out);
@@ -223,6 +228,11 @@ int gmx_resample_tiles(int kind, const uint32_t key[2], const float* lw_d, int64
 int gmx_resample(int kind, const uint32_t key[2], const float* lw_d, int64_t n, int shift,
                  const float* max_partials_d, int64_t n_partials, float* max_d,
                  uint64_t* total_d, int32_t* ancestors_d, void* workspace_d, gmx_stream stream);
+/* gmx_resample_tiles from the per-particle fixed-point weights q_i a site program left in
+ * gmx_run_args.tile_q_d (same tile statistics, same ancestors). */
+int gmx_resample_tiles_q(int kind, const uint32_t key[2], const uint64_t* q_d, int64_t n, int shift,
+                         const float* tile_max_d, const uint64_t* tile_agg_d, float* max_d,
+                         uint64_t* total_d, int32_t* ancestors_d, gmx_stream stream);
 int gmx_gather(const void* const* src_d, void* const* dst_d, const int32_t* elem_bytes,
                int32_t n_leaves, const int32_t* ancestors_d, int64_t n_out,
                gmx_stream stream);

@@ -119,6 +119,7 @@ extern "C" int gmx_program_run(const gmx_program* p, int64_t n, const gmx_run_ar
   for (uint32_t s = 0; s < p->n_out; ++s) if (!A->out_d[s]) return fail("program_run: null output slot");
   const bool tile = hs_tile_mode(p);
   if (A->tile_agg_d && !tile) return fail("program_run: tile_agg_d is set but this program cannot write tile statistics");
+  if (A->tile_q_d && !A->tile_agg_d) return fail("program_run: tile_q_d needs tile_agg_d");
   const int G = tile ? 1024 : 256;                 // particles per workgroup
   int64_t grid = (n + G - 1) / G;
   std::vector<float> red((size_t)G);
@@ -143,7 +144,11 @@ extern "C" int gmx_program_run(const gmx_program* p, int64_t n, const gmx_run_ar
       if (tile && A->tile_agg_d) {
         const float ref = gmx_tile_ref(gmx_tile_exp(m)), scale = gmx_pow2i(A->tile_shift);
         uint64_t sum = 0;
-        for (int t = 0; t < G; ++t) sum += hs_weight_fixed(red[t], ref, scale);
+        for (int t = 0; t < G; ++t) {
+          const uint64_t q = hs_weight_fixed(red[t], ref, scale);
+          sum += q;
+          if (A->tile_q_d && blk * G + t < n) A->tile_q_d[blk * G + t] = q;
+        }
         A->tile_agg_d[blk] = sum;
       }
     }
@@ -264,6 +269,27 @@ extern "C" int gmx_resample_tiles(int kind, const uint32_t key[2], const float* 
       run += hs_weight_fixed(lw[i], ref, scale);
       cdf[(size_t)i] = prefix + gmx_tile_scale(run, k, K);
     }
+    prefix += gmx_tile_scale(agg[b], k, K);
+  }
+  *max_d = M; *total = prefix;
+  return gmx_ancestors(kind, key, cdf.data(), n, 0, total, n, 0, n, anc, st);
+}
+// the same from the per-particle fixed-point weights the site program left behind
+extern "C" int gmx_resample_tiles_q(int kind, const uint32_t key[2], const uint64_t* q, int64_t n, int shift, const float* tmax,
+                                    const uint64_t* agg, float* max_d, uint64_t* total, int32_t* anc, gmx_stream st) {
+  if (kind == GMX_RESAMPLE_MULTINOMIAL) return fail("resample: kind");
+  if (!q || !tmax || !agg || !max_d || !total || !anc || shift < 1) return fail("resample_tiles_q: bad argument");
+  const int64_t tiles = (n + HS_TILE - 1) / HS_TILE;
+  float M = -gmx_inf();
+  for (int64_t b = 0; b < tiles; ++b) M = gmx_fmax(M, tmax[b]);
+  const int32_t K = gmx_tile_exp(M);
+  std::vector<uint64_t> cdf((size_t)n);
+  uint64_t prefix = 0;
+  for (int64_t b = 0; b < tiles; ++b) {
+    const int64_t lo = b * HS_TILE, hi = lo + HS_TILE < n ? lo + HS_TILE : n;
+    const int32_t k = gmx_tile_exp(tmax[b]);
+    uint64_t run = 0;
+    for (int64_t i = lo; i < hi; ++i) { run += q[i]; cdf[(size_t)i] = prefix + gmx_tile_scale(run, k, K); }
     prefix += gmx_tile_scale(agg[b], k, K);
   }
   *max_d = M; *total = prefix;

@@ -61,7 +61,7 @@ struct gmx_jit_ctx {
 #pragma unroll
           for (int p = 0; p < PPV; ++p) {
             const int64_t row = ((int64_t)blockIdx.x * PPV + p) * GMX_BLOCK + threadIdx.x;
-            if (row < n_rows) GMX_STORE_WT(&A->tile_q_d[row], qv[p]);
+            if (row < n_rows) A->tile_q_d[row] = qv[p];
           }
         }
         s = wave_sum_u64(s);

@@ -1497,7 +1497,7 @@ k_offspring_tile(uint32_t k0, uint32_t k1, uint32_t u0_host, const float* __rest
   const int32_t e1 = e[1], e2 = e[2], e3 = e[3], e4 = e[4];
   const int32_t src0 = (int32_t)i0;
   for (int32_t j = e[0]; j < e4; ++j)
-    GMX_STORE_WT(&anc[j], src0 + (j >= e1 ? 1 : 0) + (j >= e2 ? 1 : 0) + (j >= e3 ? 1 : 0));
+    anc[j] = src0 + (j >= e1 ? 1 : 0) + (j >= e2 ? 1 : 0) + (j >= e3 ? 1 : 0);
 }
 
 static int resample_shape(const char* who, int64_t n, int shift) {

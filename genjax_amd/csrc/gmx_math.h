@@ -29,15 +29,6 @@
 #define GMX_HDM inline
 #endif
 
-// Bulk per-particle outputs are stored WRITE-THROUGH on the device (agent-scope relaxed store = `global_store ... sc1`):
-// the bytes stream out while the kernel computes instead of sitting dirty in the XCD's L2 until the end-of-kernel
-// write-back, which the next (dependent) launch waits for — measured on MI355X: ~1 us per 6-8 MB left dirty.
-#if defined(__HIP_DEVICE_COMPILE__)
-#define GMX_STORE_WT(ptr, v) __hip_atomic_store((ptr), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-#else
-#define GMX_STORE_WT(ptr, v) (*(ptr) = (v))
-#endif
-
 #define GMX_INF_BITS 0x7f800000u
 #define GMX_NAN_BITS 0x7fc00000u
 

@@ -105,7 +105,7 @@ GMX_HD void gmx_vm_step(Regs& R, const W w, int64_t i, bool active, const gmx_ru
         if (active) {
           void* p = ctx.out_ptr(a);
           if (dst & GMX_F_U8) ((uint8_t*)p)[i] = (uint8_t)(v != 0u);
-          else GMX_STORE_WT(&((uint32_t*)p)[i], v);
+          else ((uint32_t*)p)[i] = v;
         }
         wr = 0;
       } break;

@@ -19,8 +19,7 @@ def _dev(x):
 
 def test_library_is_hip(gpu):
     assert gpu.device.type == "cuda"
-    from genjax_amd import _lib
-    assert gpu.c.gmx_version() == _lib.ABI_VERSION
+    assert gpu.c.gmx_version() == 1
 
 
 def test_key_kernels_bit_exact(gpu):

@@ -19,7 +19,8 @@ def _dev(x):
 
 def test_library_is_hip(gpu):
     assert gpu.device.type == "cuda"
-    assert gpu.c.gmx_version() == 1
+    from genjax_amd import _lib
+    assert gpu.c.gmx_version() == _lib.ABI_VERSION
 
 
 def test_key_kernels_bit_exact(gpu):

@@ -187,6 +187,11 @@ class SMCAlgorithm(Algorithm):
         key, sub_key = split(key)
         return algorithm.run_smc(sub_key).get_log_marginal_likelihood_estimate()
 
+    def estimate_reciprocal_normalizing_constant(self, key, target, latent_choices, w):
+        """smc.py:214-225: `w` (with `latent_choices`) is already properly weighted for `target`, so the
+        conditional run skips the redundant re-weighting of the retained particle."""
+        return ChangeTarget(self, target).run_csmc_for_normalizing_constant(key, latent_choices, w)
+
 
 class Importance(SMCAlgorithm):
     """One-particle importance sampling (smc.py:233-266): the particle is
@@ -285,6 +290,39 @@ class ChangeTarget(SMCAlgorithm):
         new_particles, new_score = self.target.importance(sub_keys, latents)
         this_weight = engine.elementwise(_reweight, new_score, particles.get_score(), collection.get_log_weights())
         return ParticleCollection(new_particles, this_weight, True)
+
+    def run_csmc_for_normalizing_constant(self, key, latent_choices, w):
+        return _csmc_normalizing_constant(self, key, latent_choices, w)
+
+
+def _csmc_normalizing_constant(self, key, latent_choices, w):
+    """ChangeTarget.run_csmc_for_normalizing_constant (smc.py:432-465): conditional SMC under the previous
+    target with `latent_choices` retained in slot K-1; the K-1 rejected particles are re-weighted for the new
+    target (keys split(key, K-1)), the retained one takes `w - retained_score + retained_weight`;
+    returns retained_score - (logsumexp(all weights) - log K)."""
+    _unbatched(key, "ChangeTarget.run_csmc_for_normalizing_constant")
+    key, sub_key = split(key)
+    collection = self.prev.run_csmc(sub_key, latent_choices)
+    K = self.get_num_particles()
+    particles, lw = collection.get_particles(), collection.get_log_weights()
+    scores = particles.get_score()
+    retained_score, retained_weight = scores[-1], lw[-1]
+    be = _lib.get()
+    w_t = w if isinstance(w, torch.Tensor) else torch.tensor(float(w), dtype=torch.float32, device=be.device)
+    last = engine.elementwise(_reweight, w_t.reshape(1).to(be.device), retained_score.reshape(1), retained_weight.reshape(1))
+    if K > 1:
+        head = trace_map(particles, lambda v: engine.materialize(v)[:-1] if tuple(v.shape[:1]) == (K,) else v)
+        latents = self.prev.get_final_target().filter_to_unconstrained(head.get_choices())
+        _, new_score = self.target.importance(split(key, K - 1), latents)
+        rejected = engine.elementwise(_reweight, new_score, scores[:-1], lw[:-1])
+        all_weights = torch.cat([rejected.reshape(-1), last.reshape(1)])
+    else:
+        all_weights = last.reshape(1)
+    total = engine.logsumexp_rows(all_weights)
+    return engine.elementwise(_recip_z, retained_score.reshape(1), total.reshape(1), math.log(K)).reshape(())
+
+
+def _recip_z(retained_score, total, log_k): return retained_score - (total - log_k)
 
 
 def _unbatched(key: Key, who: str):

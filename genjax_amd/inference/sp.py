@@ -19,8 +19,11 @@ class Marginal(GenerativeFunction):
 
     def random_weighted(self, key, *args):
         """sp.py:217-240, literally: simulate, keep the selected choices, weight =
-        project(trace, ~selection)."""
+        project(trace, ~selection); with an inner algorithm the weight is its estimate of the reciprocal
+        normalising constant of Target(gen_fn, args, selected choices) — this is how algorithms nest."""
         from ..random import split
+        if self.algorithm is not None and tuple(key.shape) != ():
+            return self._random_weighted_over_keys(key, args)
         key, sub_key = split(key)
         tr = self.gen_fn.simulate(sub_key, tuple(args))
         choices = tr.get_choices()
@@ -29,8 +32,30 @@ class Marginal(GenerativeFunction):
         weight = tr.project(sub_key, ~self.selection)
         if self.algorithm is None:
             return weight, latent_choices
-        raise NotImplementedError("Marginal with an inner algorithm needs estimate_reciprocal_normalizing_constant "
-                                  "(variational interface; out of the hot path)")
+        # sp.py:229-238: the inner algorithm estimates 1 / Z of the posterior over the marginalised choices
+        target = Target(self.gen_fn, tuple(args), latent_choices)
+        other_choices = choices.filter(~self.selection)
+        Z = self.algorithm.estimate_reciprocal_normalizing_constant(key, target, other_choices, weight)
+        return Z, latent_choices
+
+    def _random_weighted_over_keys(self, keys, args):
+        """`vmap(random_weighted)` over a batch of keys when an inner algorithm is present: every key runs its own
+        conditional SMC (ChangeTarget.run_csmc_for_normalizing_constant keeps ONE retained particle, so the batch is
+        walked on the host and the results are stacked).  Meant for small outer batches; the bulk work — the inner
+        algorithm's particles — is one fused launch per key."""
+        import torch
+        flat = keys.reshape(-1)
+        ws, chms = [], []
+        for i in range(flat.shape[0]):
+            w, c = self.random_weighted(flat[i], *args)
+            ws.append(torch.as_tensor(w, dtype=torch.float32).reshape(()))
+            chms.append(c)
+        out = ChoiceMap.empty()
+        for a in chms[0].addresses():
+            vals = [torch.as_tensor(c[a]) for c in chms]
+            out = out.set(a, torch.stack([v.to(vals[0].device) for v in vals]).reshape(tuple(keys.shape) + tuple(vals[0].shape)))
+        dev = ws[0].device
+        return torch.stack([w.to(dev) for w in ws]).reshape(tuple(keys.shape)), out
 
     def estimate_logpdf(self, key, v, *args):
         """sp.py:242-254"""

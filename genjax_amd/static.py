@@ -24,6 +24,7 @@ from __future__ import annotations
 
 import functools
 import itertools
+import types
 from collections import OrderedDict
 
 import numpy as np
@@ -274,8 +275,11 @@ _UID = itertools.count(1)
 
 
 def _gfkey(gf):
-    """Cache key of a generative function: a serial number stamped on first use
-    (id() would be recycled after garbage collection)."""
+    """Cache key of a generative function: a serial number stamped on first use (id() would be recycled
+    after garbage collection) PLUS a fingerprint of every Python value its source captures — closure cells and
+    the module globals its code names, through wrapped / called generative functions.  The reference re-traces on
+    every GFI call (jit aside), so a model that reads `scale` from its enclosing scope sees a new value on the
+    next call; a cache keyed on the function alone would keep replaying the program traced with the old one."""
     uid = getattr(gf, "_gmx_uid", None)
     if uid is None:
         uid = next(_UID)
@@ -283,8 +287,99 @@ def _gfkey(gf):
             object.__setattr__(gf, "_gmx_uid", uid)
         except Exception:
             _KEEP.append(gf)
-            return ("gfid", id(gf))
-    return ("gf", uid)
+            return ("gfid", id(gf), _capture_fp(gf, 0))
+    return ("gf", uid, _capture_fp(gf, 0))
+
+
+_CAPTURE_DEPTH = 3        # model -> helper / sub-model -> helper
+
+
+def _code_names(code, out):
+    out.update(code.co_names)
+    for c in code.co_consts:
+        if hasattr(c, "co_names"):
+            _code_names(c, out)
+
+
+def _capture_plan(fn):
+    """(closure cells, (globals dict, names)) of a Python function, computed once per function object."""
+    plan = getattr(fn, "_gmx_capture_plan", None)
+    if plan is None:
+        code = getattr(fn, "__code__", None)
+        cells = tuple(getattr(fn, "__closure__", None) or ())
+        names = ()
+        g = getattr(fn, "__globals__", None)
+        if code is not None and g is not None:
+            ns = set()
+            _code_names(code, ns)
+            names = tuple(sorted(n for n in ns if n in g))
+        plan = (cells, g, names)
+        try:
+            fn._gmx_capture_plan = plan
+        except Exception:
+            pass
+    return plan
+
+
+def _value_fp(v, depth):
+    if v is None or isinstance(v, (bool, int, float, str, bytes, complex)):
+        return v if not isinstance(v, float) else ("f", v.hex() if v == v else "nan")
+    if isinstance(v, np.generic):
+        return ("np", v.dtype.str, v.tobytes())
+    if isinstance(v, np.ndarray):
+        return ("nd", v.dtype.str, v.shape, v.tobytes()) if v.size <= 4096 else ("ndid", id(v))
+    if isinstance(v, torch.Tensor):
+        return ("t", id(v), v._version)
+    if isinstance(v, (tuple, list)) and len(v) <= 64:
+        return (type(v).__name__,) + tuple(_value_fp(x, depth) for x in v)
+    if isinstance(v, dict) and len(v) <= 64:
+        try:
+            return ("dict",) + tuple((k, _value_fp(x, depth)) for k, x in sorted(v.items(), key=lambda kv: repr(kv[0])))
+        except Exception:
+            return ("o", id(v))
+    if isinstance(v, GenerativeFunction):
+        uid = getattr(v, "_gmx_uid", None)
+        return ("gf", uid if uid is not None else id(v), _capture_fp(v, depth + 1))
+    if isinstance(v, (types.FunctionType, types.MethodType)):
+        return ("fn", id(v), _function_fp(v, depth + 1))
+    return ("o", id(v))            # modules, classes, other objects: identity
+
+
+def _function_fp(fn, depth):
+    if depth > _CAPTURE_DEPTH:
+        return ()
+    fn = getattr(fn, "__func__", fn)
+    cells, g, names = _capture_plan(fn)
+    out = []
+    for c in cells:
+        try:
+            out.append(_value_fp(c.cell_contents, depth))
+        except ValueError:          # empty cell
+            out.append(None)
+    for n in names:
+        v = g.get(n)
+        if isinstance(v, (types.ModuleType, type)) or v is fn:
+            continue
+        out.append(_value_fp(v, depth))
+    return tuple(out)
+
+
+def _capture_fp(gf, depth):
+    """Fingerprint of the values a generative function's SOURCE reads from outside its arguments."""
+    if depth > _CAPTURE_DEPTH:
+        return ()
+    out = []
+    fn = getattr(gf, "_fn", None)
+    if fn is not None:
+        out.append(_function_fp(fn, depth))
+        part = getattr(gf, "_partial", ())
+        if part:
+            out.append(_value_fp(tuple(part), depth))
+    for attr in ("gen_fn", "kernel_gen_fn", "inner"):       # combinators / wrappers around another function
+        inner = gf.__dict__.get(attr) if hasattr(gf, "__dict__") else None
+        if isinstance(inner, GenerativeFunction):
+            out.append(_capture_fp(inner, depth + 1))
+    return tuple(out)
 
 
 _KEEP: list = []

@@ -1443,6 +1443,54 @@ def changetarget_run_csmc(alg: "ChangeTarget", k, retained: ChoiceMap):
     return ParticleCollection(new_tr, this)
 
 
+def changetarget_run_csmc_for_normalizing_constant(alg: "ChangeTarget", k, latent_choices: ChoiceMap, w):
+    """ChangeTarget.run_csmc_for_normalizing_constant (smc.py:432-465)."""
+    ks = split(k)
+    key, sub = ks[0], ks[1]
+    coll = importancek_run_csmc(alg.prev, sub, latent_choices)
+    K = alg.get_num_particles()
+    particles, lw = coll.get_particles(), coll.get_log_weights()
+    scores = np.asarray(particles.get_score(), np.float32)
+    retained_score, retained_weight = scores[-1], lw[-1]
+    last = ((np.float32(w) - retained_score).astype(np.float32) + retained_weight).astype(np.float32)
+    if K > 1:
+        head = _tree_index(particles, slice(0, K - 1))
+        latents = alg.prev.get_final_target().filter_to_unconstrained(head.get_choices())
+        _, new_score = alg.target.importance(split(key, K - 1), latents)
+        rejected = ((np.asarray(new_score, np.float32) - scores[:-1]).astype(np.float32) + lw[:-1]).astype(np.float32)
+        allw = np.concatenate([rejected, np.reshape(last, 1)])
+    else:
+        allw = np.reshape(last, 1)
+    total = logsumexp(allw)
+    return (retained_score - (total - log(np.float32(K))).astype(np.float32)).astype(np.float32)
+
+
+def estimate_reciprocal_normalizing_constant(alg, k, target: Target, latent_choices: ChoiceMap, w):
+    """SMCAlgorithm.estimate_reciprocal_normalizing_constant (smc.py:214-225)."""
+    return changetarget_run_csmc_for_normalizing_constant(ChangeTarget(alg, target), k, latent_choices, w)
+
+
+def marginal_random_weighted(gen_fn, selected, alg, k, args):
+    """Marginal.random_weighted with an inner algorithm (sp.py:217-238); `selected` = the addresses of the
+    marginal's selection (a list of address tuples)."""
+    ks = split(k)
+    key, sub = ks[0], ks[1]
+    tr = gen_fn.simulate(sub, tuple(args))
+    choices = tr.get_choices()
+    is_sel = lambda a: any(a[: len(c)] == c for c in selected)
+    latent = choices.filter(is_sel)
+    ks = split(key)
+    key, sub = ks[0], ks[1]
+    # project(trace, ~selection): the score of the unselected sites
+    other = choices.filter(lambda a: not is_sel(a))
+    weight = np.float32(0.0)
+    for a in other.addresses():
+        assert len(a) == 1, "flat models only"
+        weight = (weight + np.asarray(tr.get_subtrace(a[0]).get_score(), np.float32)).astype(np.float32)
+    target = Target(gen_fn, tuple(args), latent)
+    return estimate_reciprocal_normalizing_constant(alg, key, target, other, weight), latent
+
+
 def estimate_logpdf(alg, k, v: ChoiceMap, target: Target):
     """SMCAlgorithm.estimate_logpdf (smc.py:181-198)."""
     algorithm = ChangeTarget(alg, target)

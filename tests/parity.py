@@ -342,6 +342,67 @@ def check_csmc(k=257, seed=3):
     ImportanceK(tgt2, q=proposal, k_particles=64).run_smc(G.key(seed))
 
 
+def check_nested_marginal(k=129, seed=5):
+    """A12 / F4: ChangeTarget.run_csmc_for_normalizing_constant (ref smc.py:432-465),
+    estimate_reciprocal_normalizing_constant (:214-225) and Marginal.random_weighted with an inner algorithm
+    (sp.py:229-238) against the oracle's restatement; and ChangeTarget.run_smc (:370-396) directly."""
+    import genjax_amd as G
+    from genjax_amd import ChoiceMapBuilder as C, SelectionBuilder as S, Target
+    from genjax_amd.inference.smc import ChangeTarget, ImportanceK
+    from genjax_amd.inference.sp import Marginal
+
+    def mk(g):
+        @g.gen
+        def model():
+            mu = g.normal(0.0, 1.0) @ "mu"
+            s = g.normal(mu, 2.0) @ "s"
+            x = g.normal(mu + 0.5 * s, 0.5) @ "x"
+            return x
+        return model
+    m, om = mk(G), mk(O)
+    prior, oprior = Target(m, (), G.ChoiceMap.empty()), O.Target(om, (), O.ChoiceMap.empty())
+    alg, oalg = ImportanceK(prior, k_particles=k), O.ImportanceK(oprior, k)
+    tgt, otgt = Target(m, (), C["x"].set(0.7)), O.Target(om, (), O.C.d({"x": np.float32(0.7)}))
+    # ChangeTarget.run_smc: every particle re-weighted under the new target
+    pc, opc = ChangeTarget(alg, tgt).run_smc(G.key(seed)), O.ChangeTarget(oalg, otgt).run_smc(O.key(seed))
+    assert np.array_equal(pc.get_log_weights().cpu().numpy(), opc.get_log_weights())
+    for a in ("mu", "s"):
+        assert np.array_equal(pc.get_particles().get_choices()[a].cpu().numpy(), opc.get_particles().get_choices()[a])
+    assert abs(float(pc.get_log_marginal_likelihood_estimate()) - float(opc.get_log_marginal_likelihood_estimate())) <= 1e-5
+    # run_csmc_for_normalizing_constant / estimate_reciprocal_normalizing_constant
+    ret, oret = C.d({"mu": 0.2, "s": -0.4}), O.C.d({"mu": np.float32(0.2), "s": np.float32(-0.4)})
+    z = alg.estimate_reciprocal_normalizing_constant(G.key(seed + 1), tgt, ret, -1.25)
+    oz = O.estimate_reciprocal_normalizing_constant(oalg, O.key(seed + 1), otgt, oret, np.float32(-1.25))
+    assert abs(float(z) - float(oz)) <= 1e-5, (float(z), float(oz))
+    z1 = ImportanceK(prior, k_particles=1).estimate_reciprocal_normalizing_constant(G.key(seed + 2), tgt, ret, 0.5)
+    oz1 = O.estimate_reciprocal_normalizing_constant(O.ImportanceK(oprior, 1), O.key(seed + 2), otgt, oret, np.float32(0.5))
+    assert abs(float(z1) - float(oz1)) <= 1e-6
+    # Marginal over "x" whose weight comes from the inner algorithm: algorithms nest
+    mar = Marginal(m, S["x"], algorithm=alg)
+    w, chm = mar.random_weighted(G.key(seed + 3))
+    ow, ochm = O.marginal_random_weighted(om, [("x",)], oalg, O.key(seed + 3), ())
+    assert np.float32(chm["x"].cpu().numpy() if hasattr(chm["x"], "cpu") else chm["x"]) == np.float32(ochm["x"])
+    assert abs(float(w) - float(ow)) <= 1e-5, (float(w), float(ow))
+    # ... and as the proposal q of an outer ImportanceK (smc.py:301-305): q.random_weighted(key, target)
+    @G.gen
+    def outer():
+        x = G.normal(0.0, 3.0) @ "x"
+        G.normal(x, 1.0) @ "y"
+
+    @G.gen
+    def prop(target):
+        mu = G.normal(0.0, 1.0) @ "mu"
+        return G.normal(mu, 1.0) @ "x"
+    otgt2 = Target(outer, (), C["y"].set(1.0))
+    inner = ImportanceK(Target(prop, (otgt2,), G.ChoiceMap.empty()), k_particles=5)
+    pcq = ImportanceK(otgt2, q=Marginal(prop, S["x"], algorithm=inner), k_particles=1).run_smc(G.key(seed + 4))
+    assert bool(torch.isfinite(pcq.get_log_weights()).all())
+    # estimate_logpdf of a Marginal with an algorithm = the algorithm's normalising-constant estimate
+    lp = mar.estimate_logpdf(G.key(seed + 5), C["x"].set(0.7))
+    olp = O.log_marginal_likelihood_estimate(oalg, O.key(seed + 5), otgt)
+    assert abs(float(lp) - float(olp)) <= 1e-5
+
+
 def mk2(g):
     @g.gen
     def model():

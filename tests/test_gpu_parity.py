@@ -709,6 +709,17 @@ def test_sweep_with_separate_tile_stats_launch(gpu, monkeypatch):
     assert res["log_ml"] == res["log_ml_oracle"]
 
 
+def test_sweep_with_fixed_point_weight_handoff(gpu, monkeypatch):
+    """GENMI_TILE_Q=1: the site program also leaves every particle's fixed-point weight (gmx_run_args.tile_q_d) and
+    gmx_resample_tiles_q resamples from those instead of re-deriving them from the log-weights.  Same sweep, bit for
+    bit, ragged last tile included."""
+    monkeypatch.setenv("GENMI_TILE_Q", "1")
+    for n in (50_000, 100_003):
+        res = parity.check_lgssm_sweep(n=n, T=5, capture=True, specialize=True)
+        assert res["ancestors_equal"] and res["x_equal"] and res["totals_equal"] and res["lw_max_abs_diff"] == 0.0
+        assert res["log_ml"] == res["log_ml_oracle"]
+
+
 def test_tile_stats_from_the_site_program(gpu):
     """the specialised program's epilogue writes the same (m_b, A_b) as gmx_tile_stats, ragged last tile included"""
     import genjax_amd as G

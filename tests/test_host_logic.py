@@ -540,6 +540,11 @@ def test_conditional_smc_and_proposals():
     parity.check_csmc(k=257)
 
 
+def test_nested_marginal_and_change_target():
+    from tests import parity
+    parity.check_nested_marginal()
+
+
 def test_mixture_assignments_match_oracle():
     """BASELINE config 5 (integer gate) at a CPU-sized N."""
     from tests import parity
@@ -778,6 +783,45 @@ def test_numpy_namespace_compositions():
         assert np.max(np.abs(got - want) / (1 + np.abs(want))) < 2e-6
 
 
+_CAPTURED_SCALE = 1.0
+
+
+def test_trace_cache_follows_captured_values():
+    """a model reads `scale` from its enclosing scope / a module global; the reference re-traces on every
+    call, so changing the captured value changes the result — the program cache must not replay the old trace."""
+    global _CAPTURED_SCALE
+    scale = 1.0
+
+    @genjax.gen
+    def model():
+        return genjax.normal(0.0, scale) @ "x"
+    a = f(model.assess(C.kw(x=0.5), ())[0])
+    scale = 3.0
+    b = f(model.assess(C.kw(x=0.5), ())[0])
+    from scipy import stats
+    assert a == pytest.approx(stats.norm.logpdf(0.5, 0.0, 1.0), abs=1e-6)
+    assert b == pytest.approx(stats.norm.logpdf(0.5, 0.0, 3.0), abs=1e-6)
+
+    @genjax.gen
+    def inner():
+        return genjax.normal(0.0, _CAPTURED_SCALE) @ "z"
+
+    @genjax.gen
+    def outer():
+        return inner() @ "sub"
+    _CAPTURED_SCALE = 1.0
+    c = f(outer.assess(C["sub", "z"].set(0.5), ())[0])
+    _CAPTURED_SCALE = 2.0
+    d = f(outer.assess(C["sub", "z"].set(0.5), ())[0])          # through a called generative function
+    assert c == pytest.approx(stats.norm.logpdf(0.5, 0.0, 1.0), abs=1e-6)
+    assert d == pytest.approx(stats.norm.logpdf(0.5, 0.0, 2.0), abs=1e-6)
+    # ... and an unchanged capture still hits the cache
+    from genjax_amd import static
+    n0 = len(static._CACHE)
+    model.assess(C.kw(x=0.25), ())
+    assert len(static._CACHE) == n0
+
+
 def test_program_limits():
     """<= 64 live 32-bit values per particle (<= 32 for the interpreter, up to 64 for specialised
     kernels); a model that needs more fails loudly at trace time instead of spilling silently."""
@@ -872,6 +916,15 @@ def test_sweep_without_program_written_tile_stats(monkeypatch):
     statistics from the site program), so BootstrapSweep takes the gmx_resample path; same sweep bit for bit."""
     from tests import parity
     monkeypatch.setenv("GENMI_HOSTSIM_TILE_STATS", "0")
+    res = parity.check_lgssm_sweep(n=3000, T=5)
+    assert res["ancestors_equal"] and res["x_equal"] and res["totals_equal"] and res["lw_max_abs_diff"] == 0.0
+    assert res["log_ml"] == res["log_ml_oracle"]
+
+
+def test_sweep_with_fixed_point_weight_handoff(monkeypatch):
+    """GENMI_TILE_Q=1 (gmx_run_args.tile_q_d -> gmx_resample_tiles_q): same sweep bit for bit"""
+    from tests import parity
+    monkeypatch.setenv("GENMI_TILE_Q", "1")
     res = parity.check_lgssm_sweep(n=3000, T=5)
     assert res["ancestors_equal"] and res["x_equal"] and res["totals_equal"] and res["lw_max_abs_diff"] == 0.0
     assert res["log_ml"] == res["log_ml_oracle"]

@@ -1,0 +1,55 @@
+"""The reference-held expectations, on the HIP library.
+
+tests/test_host_logic.py translates the reference's own behavioural tests
+  tests/generative_functions/test_distributions.py:25-193   (leaf GFI weight rules)
+  tests/generative_functions/test_static_gen_fn.py:287-318  (score == assess; the literal -2.837877)
+  tests/inference/test_smc.py:50,57,87                      (log-ML tolerances 1e-1 / 1e-3 / 1e-1)
+  tests/inference/test_requests.py:38-166                   (update / regenerate / rejuvenate identities, MH convergence)
+  README.md:88-123                                          (BASELINE config 1: beta-bernoulli, ImportanceK k = 50 x 50 trials)
+and runs them against the CPU mirror of the C-ABI.  Here the SAME test bodies run through libgenmi_hip.so on an
+MI355X: the classes are subclassed unchanged, only the backend fixture differs.
+"""
+import pytest
+import torch
+
+from tests import parity
+from tests import test_host_logic as H
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _on_the_hip_library(gpu, monkeypatch):
+    # the translated tests call `.numpy()` on results (CPU tensors under the mirror): bring device tensors back first
+    orig = torch.Tensor.numpy
+    monkeypatch.setattr(torch.Tensor, "numpy", lambda self, *a, **k: orig(self.detach().cpu(), *a, **k))
+    yield gpu
+
+
+class TestDistributionsOnDevice(H.TestDistributions):
+    pass
+
+
+class TestStaticOnDevice(H.TestStatic):
+    pass
+
+
+class TestSMCOnDevice(H.TestSMC):
+    """incl. test_readme_quickstart = BASELINE config 1"""
+
+
+class TestRequestsOnDevice(H.TestRequests):
+    pass
+
+
+def test_nested_marginal_and_change_target_on_device():
+    """A12 / F4 (ref smc.py:214-225, 370-396, 432-465; sp.py:229-238) against the oracle"""
+    parity.check_nested_marginal()
+
+
+def test_jax_docs_values_through_the_product_on_device():
+    H.test_jax_docs_values_through_the_product()
+
+
+def test_api_surface_and_derived_distributions_on_device():
+    H.test_api_surface_and_derived_distributions()

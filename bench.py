@@ -2,12 +2,16 @@
 """bench.py — BASELINE.json's headline metric on MI355X.
 
 Workload (BASELINE config 2): linear-Gaussian state-space model, T = 100,
-bootstrap SMC with 1e6 particles per GPU, systematic resampling every step.
+bootstrap SMC with 1e6 particles, systematic resampling every step.
 One "step" of this harness = one whole sweep (N * T particle-steps), issued as
 one hipGraph replay with every input already resident in HBM.
 
   python bench.py --gpus N --steps K --warmup W
   (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+N > 1 is STRONG scaling by default — BASELINE's metric: the same 1e6-particle sweep split over the N ranks
+(contiguous blocks of global particle indices; the total is rounded up to a multiple of N x 1024 because a shard
+starts on a tile of the integer CDF; the JSON names the exact count).  `--weak` keeps ~1e6 particles PER GPU instead.
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the
 site-program interpreter k_vm): algorithmic bytes per launch / its average
@@ -36,7 +40,12 @@ T_STEPS = 100
 VM_VALU_PER_WAVE = 376.2            # VALU instructions per 64 particles: SQ_INSTS_VALU / waves / 4 particles per
                                     # thread (1504.7 per wave, profiles/r01_o_pmc_summary.txt: 1285.7 for the site
                                     # program + 219 for the CDF tile statistics it now writes in its epilogue)
-VALU_PEAK_LANE_OPS = 256 * 4 * 32 * 2.4e9
+VALU_PEAK_LANE_OPS = 256 * 4 * 16 * 2.4e9   # integer / unpacked-f32 vector instructions: 16 lanes per clock per SIMD (a
+                                            # wave64 instruction holds its SIMD for 4 cycles; only packed f32 math doubles
+                                            # that).  tools/calib.hip on MI355X (profiles/r02_calib.txt): one Threefry-like
+                                            # add/rotate/xor chain per lane 33.6 T lane-ops/s, two independent chains 35.5 T
+                                            # — no gain from ILP, i.e. the pipe is full — against 39.3 T nominal at 2.4 GHz
+VALU_CALIBRATED_LANE_OPS = 35.5e12
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 # Algorithmic bytes per particle-step (8*D + 24 = 32 B, D = 1):
 #   site program  ancestor 4 + gathered state 4 in, state 4 + log-weight 4 out    = 16 B
@@ -108,11 +117,17 @@ def cpu_baseline(n, T, ys, seed, budget_s=25.0):
         gomp.omp_set_num_threads(cores)
     except Exception as e:
         out["one_core"] = {"error": repr(e)}
-    try:        # the reference's own backend, if this box happens to have it (it never travels with the repo)
-        import jax                                      # noqa: F401
-        out["jax_cpu"] = f"jax {jax.__version__} importable here but no restatement is timed this round"
-    except Exception:
-        out["jax_cpu"] = "jax not importable on this box: the reference's jax[cpu] path cannot be timed here"
+    # the reference's own backend, if this box happens to have it (it never travels with the repo): a jax.numpy
+    # restatement of the same sweep written by this build (tools/jax_cpu_restatement.py)
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import jax_cpu_restatement as jr
+        if jr.available():
+            out["jax_cpu"] = jr.time_sweep(n, T, ys, seed, budget_s=15.0)
+        else:
+            out["jax_cpu"] = "jax not importable on this box: the reference's jax[cpu] path cannot be timed here"
+    except Exception as e:
+        out["jax_cpu"] = {"error": repr(e)}
     return out
 
 
@@ -126,6 +141,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--sharded", action="store_true", help="use the multi-GPU code path even at world size 1")
+    ap.add_argument("--weak", action="store_true",
+                    help="N > 1: --particles PER GPU (weak scaling) instead of in total (strong scaling, the default)")
     args = ap.parse_args()
 
     # stdout carries exactly ONE line, the JSON: everything else that writes to fd 1 (the RCCL
@@ -170,10 +187,17 @@ def main():
     ys = workloads.lgssm_data(T)
     init, step = workloads.make_lgssm(G)
     single = world == 1 and not args.sharded
-    if world > 1 and n % 1024:
-        # shards start on a 1024-particle tile of the global CDF (include/genmi.h "Resampling"): 1e6 -> 1 000 448
-        # per GPU (977 tiles), so that the N-GPU population is bit-identical to a single-process one
-        n = ((n + 1023) // 1024) * 1024
+    requested = n
+    if world > 1:
+        # shards start on a 1024-particle tile of the global CDF (include/genmi.h "Resampling"), so that the N-GPU
+        # population is bit-identical to a single-process one of the same size.
+        #   strong (default): --particles in TOTAL, rounded up to a multiple of world x 1024 (1e6 -> 1 001 472 at 2,
+        #                     1 003 520 at 4, 1 007 616 at 8 ranks); n = the per-rank share
+        #   --weak:           --particles PER GPU, rounded up to a multiple of 1024 (1e6 -> 1 000 448)
+        if args.weak:
+            n = ((n + 1023) // 1024) * 1024
+        else:
+            n = ((n + world * 1024 - 1) // (world * 1024)) * 1024
     if single:
         sw = BootstrapSweep(init, step, n, T).prepare(G.key(seed), torch.from_numpy(ys))
         if not args.no_graph:
@@ -218,9 +242,15 @@ def main():
         "metric": "particles/sec (particle-steps/s), bootstrap SMC sweep, linear-Gaussian SSM T=100",
         "value": value, "unit": "particle-steps/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling": "weak" if (args.weak and world > 1) else "strong", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
         "config": {"workload": "BASELINE config 2: linear-Gaussian state-space (T=100), bootstrap SMC, "
-                               "systematic resampling every step",
+                               "systematic resampling every step"
+                               + ("" if world == 1 else
+                                  (f"; {requested} particles per GPU requested (weak scaling), {n} run (a multiple of 1024)"
+                                   if args.weak else
+                                   f"; {requested} particles in total requested, {total_particles} run "
+                                   f"(a multiple of {world} x 1024: shards start on a tile of the integer CDF)")),
                    "particles_per_gpu": n, "particles_total": total_particles, "T": T,
                    "resampler": "systematic", "graph": not args.no_graph and single,
                    "path": "BootstrapSweep (hipGraph)" if single else "ShardedBootstrapSweep (RCCL)",
@@ -228,6 +258,13 @@ def main():
         "log_ml": log_ml, "log_ml_kalman": kal, "log_ml_abs_err": abs(log_ml - kal),
         "log_ml_rel_err": abs(log_ml - kal) / abs(kal),
     }
+
+    if not single:
+        out["config"]["communicator"] = sw.cx.name
+        out["config"]["GENMI_COMM"] = os.environ.get("GENMI_COMM", "(unset: rccl on a GPU box, torch.distributed otherwise)")
+        out["config"]["graph"] = sw.graph is not None
+        out["config"]["capacity_per_peer"] = sw.capacity
+        out["config"]["full_capacity_reruns"] = sw.reruns
 
     if rank == 0 and on_gpu:
         # ---- per-kernel durations, HIP events on the launch stream ----
@@ -295,25 +332,32 @@ def main():
                 traffic = None
         out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                           # `bound` names the roofline `achieved` / `peak` are priced against (the schema has "hbm" |
+                           # "mfma").  What actually limits this kernel is vector-instruction ISSUE: see `valu` below.
+                           "limiter": "VALU issue: integer Threefry-2x32 (3 blocks per draw) at 16 lanes/clk/SIMD; "
+                                      "HBM traffic equals the algorithmic bytes (no re-reads)",
+                           "traffic_source": "profiles/traffic.json (rocprofv3 TCC pass of an earlier run of this "
+                                             "workload, calibrated against copy kernels; NOT measured in this run)",
                            "kernel": "gmx_jit_kernel (site program specialised from k_vm)" if sw.p_step.comp._be.c.gmx_program_is_specialized(sw.p_step.comp.handle) else "k_vm<gmx_regs_vgpr<16>, false>",
                            "algorithmic_bytes_per_launch": VM_BYTES_PER_PARTICLE * n,
                            # the kernel is VALU-issue bound, not HBM bound: 3 Threefry-2x32 blocks per draw
                            # (split child, fold_in, bits).  SQ_INSTS_VALU per wave from profiles/*_pmc_summary.txt.
-                           "valu": {"insts_per_64_particles": VM_VALU_PER_WAVE,
+                           "valu": {"source": "insts_per_64_particles: SQ_INSTS_VALU of profiles/r02*_pmc_summary.txt "
+                                              "(a constant in bench.py, not measured in this run); peak_int: "
+                                              "tools/calib.hip on this part (profiles/r02_calib.txt)",
+                                    "insts_per_64_particles": VM_VALU_PER_WAVE,
                                     "lane_ops_per_s": VM_VALU_PER_WAVE * n / (vm_us * 1e-6),
                                     "peak_lane_ops_per_s": VALU_PEAK_LANE_OPS,
                                     "frac": VM_VALU_PER_WAVE * n / (vm_us * 1e-6) / VALU_PEAK_LANE_OPS,
-                                    "note": "peak = 256 CU x 4 SIMD x 32 lanes x 2.4 GHz (MI355X_MICROARCH.md); a "
-                                            "dependent integer chain sustains ~0.42 of it (tools/calib.hip)"},
+                                    "calibrated_ceiling_lane_ops_per_s": VALU_CALIBRATED_LANE_OPS,
+                                    "frac_of_calibrated_ceiling": VM_VALU_PER_WAVE * n / (vm_us * 1e-6) / VALU_CALIBRATED_LANE_OPS,
+                                    "note": "peak = 256 CU x 4 SIMD x 16 lanes x 2.4 GHz: integer (Threefry) and unpacked f32 "
+                                            "instructions issue at 16 lanes/clk/SIMD on gfx950; the calibrated ceiling is what "
+                                            "dependent add/rotate/xor chains sustain on this part (tools/calib.hip)"},
                            "kernel_us": us,
                            "sweep_frac_of_hbm_roofline":
                                SWEEP_BYTES_PER_PARTICLE_STEP * value / world / 1e9 / HBM_PEAK_GBS}
         be.c.gmx_timer_destroy(timer)
-        if not single:
-            out["config"]["communicator"] = sw.cx.name
-            out["config"]["graph"] = sw.graph is not None
-            out["config"]["capacity_per_peer"] = sw.capacity
-            out["config"]["full_capacity_reruns"] = sw.reruns
         if not args.no_cpu_baseline and world == 1:
             try:
                 out["cpu_baseline"] = cpu_baseline(n, T, ys, seed)

@@ -130,16 +130,52 @@ def _selftest(comm, device):
         raise RuntimeError("communicator self-test failed")
 
 
+class _Deadline:
+    """Bounded time for a communicator's bootstrap + self-test: a collective that never completes (a peer that
+    did not join, a transport that wedged) would otherwise hang the job until someone kills it.  When the
+    deadline passes the process EXITS with a non-zero status (os._exit: no re-exec, no attempt to unwind a
+    thread stuck inside a collective) after saying why on stderr; the launcher then tears the other ranks down."""
+
+    def __init__(self, seconds: float, what: str):
+        import threading
+        self.what, self.seconds = what, seconds
+        self._done = threading.Event()
+        self._thread = threading.Thread(target=self._watch, daemon=True)
+
+    def _watch(self):
+        if not self._done.wait(self.seconds):
+            import sys
+            sys.stderr.write(f"genjax_amd: {self.what} did not finish within {self.seconds:.0f} s "
+                             "(GENMI_COMM_TIMEOUT); exiting with status 3\n")
+            sys.stderr.flush()
+            os._exit(3)
+
+    def __enter__(self):
+        self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._done.set()
+        return False
+
+
 def make_comm(dist, device: torch.device):
     """RCCL direct on a GPU box (GENMI_COMM=torch forces the torch.distributed path); every rank
-    takes the same branch: the outcome of the RCCL bootstrap is agreed with a MIN all-reduce."""
+    takes the same branch: the outcome of the RCCL bootstrap is agreed with a MIN all-reduce.
+    Bootstrap and self-test run under a deadline (GENMI_COMM_TIMEOUT seconds, default 120; see _Deadline)."""
     want = os.environ.get("GENMI_COMM", "rccl" if device.type == "cuda" else "torch")
+    timeout = float(os.environ.get("GENMI_COMM_TIMEOUT", "120"))
     if want != "rccl" or device.type != "cuda":
-        return TorchComm(dist)
+        comm = TorchComm(dist)
+        with _Deadline(timeout, "the torch.distributed communicator self-test"):
+            _selftest(comm, device)
+        return comm
     ok, comm = 1, None
     try:
-        comm = RcclComm(dist, device)
-        _selftest(comm, device)
+        with _Deadline(timeout, "the direct RCCL communicator bootstrap / self-test"):
+            comm = RcclComm(dist, device)
+            _selftest(comm, device)
+            torch.cuda.synchronize(device)
     except Exception as e:                       # missing symbol, bootstrap failure, a wrong answer, ...
         import warnings
         warnings.warn(f"direct RCCL communicator unavailable ({e!r}); using torch.distributed")

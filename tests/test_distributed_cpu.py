@@ -162,15 +162,17 @@ def test_slot_bounds_match_ancestors():
         assert e - s == int(np.sum((anc >= lo) & (anc < hi)))
 
 
-@pytest.mark.parametrize("world", [1, 2])
-def test_bench_contract_control_flow(world):
+@pytest.mark.parametrize("world,weak", [(1, False), (2, False), (2, True)])
+def test_bench_contract_control_flow(world, weak):
     """bench.py's N > 1 control flow (rendezvous on 127.0.0.1, barriers, max over ranks, exactly ONE JSON line on
-    stdout from rank 0, shard size rounded up to the CDF tile) — bench.py unchanged, started through
-    tests/bench_on_cpu.py (gloo + the CPU mirror of the C-ABI); values are not timings."""
+    stdout from rank 0, communicator teardown after the line is out) — bench.py unchanged, started through
+    tests/bench_on_cpu.py (gloo + the CPU mirror of the C-ABI); values are not timings.
+    Default = STRONG scaling (BASELINE's metric): --particles is the TOTAL, rounded up to a multiple of world x 1024;
+    --weak: --particles per GPU, rounded up to a multiple of 1024."""
     port = str(_free_port())
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, OMP_NUM_THREADS="1")
     args = ["--gpus", str(world), "--steps", "2", "--warmup", "1", "--particles", "3000", "--T", "4", "--no-cpu-baseline",
-            "--no-graph"]
+            "--no-graph"] + (["--weak"] if weak else [])
     if world == 1:
         cmd = [sys.executable, os.path.join(ROOT, "tests", "bench_on_cpu.py")] + args
     else:
@@ -184,7 +186,15 @@ def test_bench_contract_control_flow(world):
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config"):
         assert k in out
-    assert out["n_gpus"] == world and out["steps"] == 2 and out["warmup"] == 1 and out["scaling"] == "weak"
-    per = 3000 if world == 1 else 3072
-    assert out["config"]["particles_per_gpu"] == per and out["config"]["particles_total"] == per * world
+    assert out["n_gpus"] == world and out["steps"] == 2 and out["warmup"] == 1
+    assert out["scaling"] == ("weak" if weak else "strong")
+    if world == 1:
+        per, total = 3000, 3000
+    elif weak:
+        per, total = 3072, 3072 * world
+    else:
+        per, total = 2048, 4096               # 3000 in total -> 2 x 2048 (a multiple of world x 1024)
+    assert out["config"]["particles_per_gpu"] == per and out["config"]["particles_total"] == total
+    if world > 1:
+        assert str(per if weak else total) in out["config"]["workload"] and "communicator" in out["config"]
     assert out["value"] > 0 and abs(out["log_ml"] - out["log_ml_kalman"]) < 0.5

@@ -30,6 +30,7 @@ trace_p = "trace"                          # the reference's jax primitive; `tra
 key = random.key
 split = random.split
 fold_in = random.fold_in
+from .engine import clear_caches  # noqa: E402  (build addition: drop every cached site program)
 
 __all__ = [
     "numpy", "random", "inference", "ChoiceMap", "ChoiceMapBuilder", "Selection", "SelectionBuilder",
@@ -41,5 +42,5 @@ __all__ = [
     "vmap", "key", "split", "fold_in", "NotSupportedEditRequest", "Vmap", "repeat", "Scan", "scan", "IndexRequest",
     "VectorRequest", "Argdiffs", "Arguments", "Retdiff", "Score", "Weight", "Address", "AddressComponent", "R",
     "Closure", "Const", "PythonicPytree", "Pytree", "nth", "exact_density", "tfp_distribution", "half_cauchy",
-    "half_normal", "log_normal", "Algorithm", "SampleDistribution", "Marginal", "marginal", "trace_p",
+    "half_normal", "log_normal", "Algorithm", "SampleDistribution", "Marginal", "marginal", "trace_p", "clear_caches",
 ]

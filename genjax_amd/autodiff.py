@@ -14,6 +14,7 @@ from __future__ import annotations
 
 from . import tracer as T
 from .tracer import Expr
+from .engine import new_cache as _new_program_cache
 
 
 class NotDifferentiable(NotImplementedError):
@@ -141,7 +142,7 @@ def _rule(n, a, push):
 # ---------------------------------------------------------------------------
 # value_and_grad of a plain numeric function (the `jax.value_and_grad` of this stack): one launch
 # ---------------------------------------------------------------------------
-_VG_CACHE: dict = {}
+_VG_CACHE = _new_program_cache()
 
 
 def value_and_grad(fn):

@@ -20,7 +20,8 @@ GMX_HD uint32_t gmx_rotl(uint32_t x, int r) { return (x << r) | (x >> (32 - r));
   x1 ^= x0;
 
 // Threefry-2x32-20.  Known-answer vectors (Random123) are checked in
-// tests/test_threefry_kat.py through the C-ABI symbol gmx_threefry2x32_host.
+// tests/test_oracle_pins.py::test_threefry_random123_kat and tests/test_abi.py through the C-ABI symbol
+// gmx_threefry2x32_host.
 GMX_HD void gmx_threefry2x32(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1,
                               uint32_t* o0, uint32_t* o1) {
   uint32_t ks0 = k0, ks1 = k1, ks2 = k0 ^ k1 ^ 0x1BD11BDAu;

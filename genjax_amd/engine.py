@@ -14,7 +14,10 @@ store in the kernel is one coalesced 256-byte wave access.
 """
 from __future__ import annotations
 
+import os
 import struct
+import weakref
+from collections import OrderedDict
 from ctypes import POINTER, c_uint32, c_void_p, cast
 
 import numpy as np
@@ -107,6 +110,45 @@ def leaf_spec(v, batch: tuple):
         _STATIC_KEEP[id(v)] = v            # host object the traced function only reads (e.g. a Target)
         return ("static", id(v))
     raise TypeError(f"unsupported launch value of type {type(v).__name__}")
+
+
+class ProgramCache(OrderedDict):
+    """Bounded LRU of compiled site programs (GENMI_PROGRAM_CACHE entries, default 1024): a long-running job whose
+    shapes / structures keep changing would otherwise accumulate device code buffers and hiprtc modules without
+    limit.  An evicted entry's program is destroyed (gmx_program_destroy) when its last reference goes — see
+    Compiled.__init__'s finalizer — so bindings still in flight stay valid."""
+
+    def __init__(self):
+        super().__init__()
+        self.limit = int(os.environ.get("GENMI_PROGRAM_CACHE", "1024"))
+
+    def get(self, key, default=None):
+        try:
+            self.move_to_end(key)
+            return self[key]
+        except KeyError:
+            return default
+
+    def __setitem__(self, key, value):
+        super().__setitem__(key, value)
+        while len(self) > self.limit:
+            self.popitem(last=False)
+
+
+_ALL_CACHES: list = []
+
+
+def new_cache() -> ProgramCache:
+    c = ProgramCache()
+    _ALL_CACHES.append(c)
+    return c
+
+
+def clear_caches():
+    """Drop every cached program (and the host objects kept alive for traced functions)."""
+    for c in _ALL_CACHES:
+        c.clear()
+    _STATIC_KEEP.clear()
 
 
 _STATIC_KEEP: dict = {}
@@ -328,6 +370,13 @@ class Compiled:
         self.handle = handle
         self._be = be
         self._jit_tried = False
+        # the device code buffer and the specialised module go when the last reference to this object does
+        self._finalizer = weakref.finalize(self, be.c.gmx_program_destroy, handle)
+        self._finalizer.atexit = False       # at interpreter exit the process (and the HIP runtime) goes anyway
+
+    def close(self):
+        """Release the program now (idempotent); the object must not be launched afterwards."""
+        self._finalizer()
 
     def specialize(self) -> bool:
         """Compile the kernel specialised to this program (gmx_program_specialize:
@@ -560,7 +609,7 @@ def gather_leaves(leaves: list, ancestors: torch.Tensor) -> list:
     return res
 
 
-_EW_CACHE: dict = {}
+_EW_CACHE = new_cache()
 
 
 def elementwise(fn, *xs):

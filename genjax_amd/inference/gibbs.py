@@ -23,8 +23,9 @@ from ..core.choice_map import ChoiceMap
 from ..engine import Compiled, Flat, Tracing, leaf_spec, resolve, unflatten
 from ..random import Key
 from ..tracer import Expr
+from ..engine import new_cache as _new_program_cache
 
-_CACHE: dict = {}
+_CACHE = _new_program_cache()
 
 
 def gibbs_categorical(key: Key, gen_fn, args, choices: ChoiceMap, addr, n_categories: int, batch_shape=None,

@@ -23,8 +23,9 @@ from ..engine import Compiled, Flat, Tracing, leaf_spec, resolve, unflatten
 from ..static import (Rejuvenate, _broadcast_score, _build_trace, _Ctx, _emit_rec, _gfkey, _rec_score, _selkey,
                       _trace_tree, call_gen_fn)
 from ..tracer import Expr
+from ..engine import new_cache as _new_program_cache
 
-_CACHE: dict = {}
+_CACHE = _new_program_cache()
 
 
 class HMC(EditRequest):

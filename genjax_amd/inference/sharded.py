@@ -102,6 +102,7 @@ class ShardedBootstrapSweep:
         self.comm = self.world > 1 or bool(always_communicate)
         self.cx = None           # comm.RcclComm / comm.TorchComm, made in prepare()
         self.graph = None
+        self._finished = True    # nothing launched yet: finish() / log_ml() / state() have nothing to wait for
         # rejuvenate: the MH request of smc.BootstrapSweep(rejuvenate=...) (BASELINE config 3).  The move on
         # a resampled particle needs the particle AND the state it was extended from, so two leaves are
         # routed (two gmx_shard_step launches and two all-to-alls per step instead of one).
@@ -388,7 +389,15 @@ class ShardedBootstrapSweep:
         if int(flag.item()) != 0:
             self.reruns += 1
             self.capacity = self.n
-            self.graph = None
+            if self.graph is not None:
+                # the captured sweep holds the old exchange buffers and the communicator's kernels: release it
+                # (after the stream has drained) before the buffers go away — a dropped-but-live graph is what
+                # made ncclCommDestroy hang at teardown; the re-run and later launches are eager
+                be = _lib.get()
+                if be.uses_streams:
+                    torch.cuda.synchronize()
+                be.c.gmx_graph_destroy(self.graph)
+                self.graph = None
             self._alloc_exchange()
             self.enqueue()
             assert int(self.plan[2].item()) == 0
@@ -490,11 +499,22 @@ def sharded_importance_resample(target, k_per_rank: int, key: Key, dist, kind="s
             v = materialize(v)
             if tuple(v.shape[:1]) != (n,):
                 return v
-            if v.element_size() != 4:
-                v = v.to(torch.int32)                                 # bool / small ints travel as i32
-            flat = v.reshape(n, -1)
+            orig = v.dtype
+            if v.element_size() == 8:                                 # int64 / float64: two 4-byte rows per value
+                flat = v.reshape(n, -1).contiguous().view(torch.int32)     # [n, 2 * cols]
+            elif v.element_size() == 4:
+                flat = v.reshape(n, -1)
+            elif orig in (torch.bool, torch.uint8, torch.int8, torch.int16):
+                flat = v.to(torch.int32).reshape(n, -1)               # small integers travel as i32 and come back as they were
+            else:
+                raise TypeError(f"sharded_importance_resample: cannot route a leaf of dtype {orig}")
             cols = [route(flat[:, c].contiguous().view(torch.float32)).view(flat.dtype) for c in range(flat.shape[1])]
-            return torch.stack(cols, dim=1).reshape(v.shape)
+            out = torch.stack(cols, dim=1)
+            if v.element_size() == 8:
+                out = out.contiguous().view(orig)
+            elif out.dtype != orig:
+                out = (out != 0) if orig == torch.bool else out.to(orig)
+            return out.reshape(v.shape)
         new = trace_map(trs, move)
         flag = plan[2:3].clone()
         if W > 1:

@@ -38,6 +38,7 @@ from .core.generative import (Diff, EditRequest, EmptyRequest, GenerativeFunctio
 from .engine import Compiled, Flat, Gathered, Sym, Tracing, leaf_spec, materialize, resolve, unflatten
 from .random import Key
 from .tracer import Expr
+from .engine import new_cache as _new_program_cache
 
 
 class AddressReuse(Exception):
@@ -688,7 +689,7 @@ def call_gen_fn(ctx, mode, gen_fn, key, args, constraint, prev, req, req_leaves,
 # ---------------------------------------------------------------------------
 # launch driver
 # ---------------------------------------------------------------------------
-_CACHE: dict = {}
+_CACHE = _new_program_cache()
 
 
 def _infer_batch(values) -> tuple:

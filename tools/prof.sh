@@ -1,6 +1,10 @@
 #!/bin/bash
 # usage (on the GPU box, from the repo root): tools/prof.sh <tag> [bench args...]
 # kernel trace + stats, then the SQ PMC passes, each in its own rocprofv3 run.
+set -e
+: ${GRAFT_REPO_ROOT:=$(cd "$(dirname "$0")/.." && pwd)}
+export GRAFT_REPO_ROOT
+mkdir -p $GRAFT_REPO_ROOT/gpurun_out
 tag=$1; shift
 out=$GRAFT_REPO_ROOT/gpurun_out/prof_$tag
 cd /tmp && export TMPDIR=/tmp

@@ -5,6 +5,7 @@
 # every step runs under `timeout` so that a wedged process cannot hold the box.
 tag=${1:-run}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
+export GRAFT_REPO_ROOT=$root
 out=$root/gpurun_out
 mkdir -p $out
 cd $root

@@ -2,6 +2,10 @@
 # usage (on the GPU box, from the repo root): tools/traffic.sh <tag>
 # FETCH_SIZE / WRITE_SIZE passes (profiles/pmc/tcc_pass.txt, counters only) over the bench sweep and over the
 # calibration copy kernels (tools/calib, built here with hipcc), then tools/traffic.py -> gpurun_out/traffic_<tag>.json
+set -e
+: ${GRAFT_REPO_ROOT:=$(cd "$(dirname "$0")/.." && pwd)}
+export GRAFT_REPO_ROOT
+mkdir -p $GRAFT_REPO_ROOT/gpurun_out
 tag=$1
 root=$GRAFT_REPO_ROOT
 out=$root/gpurun_out/traffic_$tag

@@ -143,6 +143,25 @@ def arange(*a, dtype=np.int32):
     return TableArray(np.arange(*a, dtype=dtype))
 
 
+def _device_elementwise(name, x):
+    """An eager call on a float tensor goes through the same fixed-sequence device math a traced model uses
+    (`engine.elementwise`: one launch of a one-instruction site program), so `jnp.exp(t)` has the same bits outside
+    a model as inside one.  Needs a backend (the HIP library, or the tests' CPU mirror); without one — plain CPU
+    torch, no GPU — the call falls back to torch's own function (different last bits; nothing on the product path
+    runs there)."""
+    from . import _lib, engine
+    if _lib._backend is None and not torch.cuda.is_available():
+        return None
+    try:
+        be = _lib.get()
+    except _lib.GenmiError:
+        return None
+    if x.device.type != be.device.type:
+        return None
+    y = engine.elementwise(globals()["_ew_" + name], x.reshape(-1) if x.ndim != 1 else x)
+    return y.reshape(x.shape)
+
+
 def _dispatch(name, op, torch_fn, np_fn):
     sym = T.unary(op)
 
@@ -152,9 +171,15 @@ def _dispatch(name, op, torch_fn, np_fn):
         if T.is_tracing() and isinstance(x, (int, float, np.number)):
             return sym(x)
         if _is_torch(x):
+            if x.dtype == torch.float32 and x.numel() > 0:
+                y = _device_elementwise(name, x)
+                if y is not None:
+                    return y
             return torch_fn(x)
         return np_fn(np.asarray(x, dtype=np.float32) if not isinstance(x, np.ndarray) else x)
     f.__name__ = name
+    # a closure-free twin per op: engine.elementwise caches the traced program on the function's code object
+    exec(f"def _ew_{name}(x):\n    return {name}(x)\n", globals())
     return f
 
 

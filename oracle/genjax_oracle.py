@@ -35,7 +35,10 @@ _LIB_PATH = os.path.join(_HERE, "_build", "liborc.so")
 
 
 def build(force: bool = False) -> str:
-    """Compile orc_core.c (gcc, a second or two)."""
+    """Compile orc_core.c (gcc, a second or two).  GENMI_ORACLE_SO: use that build instead (the sanitized one,
+    `make -C oracle san`)."""
+    if os.environ.get("GENMI_ORACLE_SO"):
+        return os.environ["GENMI_ORACLE_SO"]
     if force or not os.path.exists(_LIB_PATH) or (
         os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "orc_core.c"))
     ):

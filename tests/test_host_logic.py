@@ -822,6 +822,18 @@ def test_trace_cache_follows_captured_values():
     assert len(static._CACHE) == n0
 
 
+def test_eager_numpy_namespace_uses_the_device_math():
+    """`jnp.exp(t)` on a tensor OUTSIDE a traced model runs the same fixed-sequence functions a model does (one
+    launch through engine.elementwise), not torch's: bit-identical to the oracle's restatement."""
+    x = torch.from_numpy(np.linspace(-20.0, 20.0, 257, dtype=np.float32))
+    pos = torch.from_numpy(np.geomspace(1e-30, 1e30, 257).astype(np.float32))
+    assert np.array_equal(jnp.exp(x).numpy(), O.exp(x.numpy()))
+    assert np.array_equal(jnp.log(pos).numpy(), O.log(pos.numpy()))
+    assert np.array_equal(jnp.log1p(pos).numpy(), O.log1p(pos.numpy()))
+    assert tuple(jnp.exp(x.reshape(257, 1)).shape) == (257, 1)
+    assert f(jnp.exp(torch.tensor(1.0))) == pytest.approx(math.e, rel=1e-6)
+
+
 def test_program_limits():
     """<= 64 live 32-bit values per particle (<= 32 for the interpreter, up to 64 for specialised
     kernels); a model that needs more fails loudly at trace time instead of spilling silently."""

@@ -43,6 +43,7 @@ class RunArgs(Structure):
         ("tile_agg_d", c_void_p),
         ("tile_shift", c_int32),
         ("reserved_", c_int32),
+        ("step_stride", c_int64),
         ("tile_q_d", c_void_p),
     ]
 

@@ -28,6 +28,21 @@ from . import tracer as T
 from .tracer import Expr
 
 
+SCAN_UNROLL_MAX = 16      # longer scans run as a counted loop in the site program (Scan._trace_loop)
+
+
+def _shape_of(tree):
+    """structure of a flattened carry, without the leaf numbering"""
+    k = tree[0]
+    if k in ("none", "leaf"):
+        return k
+    if k in ("tuple", "list"):
+        return (k, tuple(_shape_of(x) for x in tree[1]))
+    if k == "dict":
+        return (k, tuple((a, _shape_of(x)) for a, x in tree[1].items()))
+    return (k, tree[1])
+
+
 def _axis_len(a):
     if isinstance(a, np.ndarray):
         return a.shape[0] if a.ndim else None
@@ -327,6 +342,8 @@ class Scan(GenerativeFunction):
             raise TypeError("scan: arguments are (carry, scanned_in)")
         carry, scanned_in = args
         n = self._length(scanned_in)
+        if n > SCAN_UNROLL_MAX:
+            return self._trace_loop(ctx, mode, key, carry, scanned_in, constraint, n, req_leaves, addr)
         g = ctx.tr.graph
         keep = ctx.store_sites
         ctx.store_sites = False
@@ -370,6 +387,153 @@ class Scan(GenerativeFunction):
         if mode in ("simulate", "assess"):
             return out, retval, None, score
         return out, retval, weight, None
+
+    def _trace_loop(self, ctx, mode, key, carry, scanned_in, constraint, n, req_leaves, addr):
+        """simulate / generate / assess of a LONG scan (scan.py:200-294, 638-664) as a counted loop IN the site
+        program (OP_LOOP ... OP_ENDLOOP, gmx_program.h) — what `jax.lax.scan` is to the reference: the kernel is
+        traced ONCE; the chained key (key <- fold_in(key, t), scan.py:213), the carry and the running weight / score
+        are loop-carried registers; every site's value and score of step t go to element t of a [T, n] leaf (seen
+        as [n, T], like a plate); scanned inputs and per-step constraints are read at index t (tables, or
+        step-indexed per-particle leaves).  One launch runs all T steps of a particle."""
+        from .engine import StepInput, StepOutput, Sym
+        from .numpy import RuntimeTable, TableArray
+        from .static import _CallRec, _SiteRec, _rec_score, call_gen_fn
+        g, tr = ctx.tr.graph, ctx.tr
+        keep = ctx.store_sites
+        ctx.store_sites = False
+
+        def flat_carry(v, out):
+            if v is None:
+                return ("none",)
+            if isinstance(v, Sym):
+                v = v.value
+            if isinstance(v, (tuple, list)):
+                return (type(v).__name__, [flat_carry(x, out) for x in v])
+            if isinstance(v, dict):
+                return ("dict", {k: flat_carry(x, out) for k, x in v.items()})
+            if isinstance(v, np.ndarray) and v.dtype == object:
+                return ("array", v.shape, [flat_carry(x, out) for x in v.reshape(-1)])
+            out.append(T.lift(v))
+            return ("leaf", len(out) - 1)
+
+        def rebuild(tree, leaves):
+            k = tree[0]
+            if k == "none":
+                return None
+            if k == "leaf":
+                return leaves[tree[1]]
+            if k in ("tuple", "list"):
+                seq = [rebuild(x, leaves) for x in tree[1]]
+                return tuple(seq) if k == "tuple" else seq
+            if k == "dict":
+                return {a: rebuild(x, leaves) for a, x in tree[1].items()}
+            arr = np.empty(len(tree[2]), dtype=object)
+            for i, x in enumerate(tree[2]):
+                arr[i] = rebuild(x, leaves)
+            return arr.reshape(tree[1])
+
+        def at_step(v, t):
+            """element t of a scanned input / a per-step constraint"""
+            if isinstance(v, Sym):
+                v = v.value
+            if v is None:
+                return None
+            if isinstance(v, tuple):
+                return tuple(at_step(x, t) for x in v)
+            if isinstance(v, dict):
+                return {k: at_step(x, t) for k, x in v.items()}
+            if isinstance(v, (RuntimeTable, TableArray, StepInput)):
+                return v[t]
+            if isinstance(v, (list, np.ndarray)) and not (isinstance(v, np.ndarray) and v.dtype == object):
+                return TableArray(np.asarray(v, dtype=np.float32 if np.asarray(v).dtype.kind == "f" else np.int32))[t]
+            raise NotImplementedError("scan of more than 16 steps: scanned inputs and per-step constraints must be "
+                                      "launch-uniform vectors (tables) or per-particle [n, T] arrays")
+
+        def step_constraint(chm, t):
+            if any(isinstance(a, int) for a in chm._children):
+                raise NotImplementedError("scan of more than 16 steps: a constraint on one step (C[..., t, ...]) is not "
+                                          "supported; constrain an address at every step (C[..., :, addr])")
+
+            def pick(v):
+                inner = v.value if isinstance(v, Sym) else v
+                if isinstance(inner, (RuntimeTable, TableArray, StepInput)) and inner.shape[0] == n:
+                    return inner[t]
+                if isinstance(inner, np.ndarray) and inner.ndim >= 1 and inner.shape[0] == n:
+                    return at_step(inner, t)
+                return inner
+            return chm.map_values(pick)
+
+        leaves0 = []
+        ctree = flat_carry(carry, leaves0)
+        cvars = [g.loop_var(e.node) for e in leaves0]
+        kvar = g.loop_var(key.node) if key is not None else None
+        zero = g.const_f32(0.0)
+        wvar = g.loop_var(zero) if mode == "generate" else None
+        svar = g.loop_var(zero)
+        g.loop_begin(n)
+        with T.tracing(g):
+            t = Expr(g.add("LDT", dtype="i32"))
+            k_t = Expr(g.add("KDERIVER", (kvar, t.node), dtype="key")) if kvar is not None else None
+            x_t = at_step(scanned_in, t)
+            con_t = step_constraint(constraint, t) if constraint is not None else None
+            carry_in = rebuild(ctree, [Expr(v) for v in cvars])
+            rec, ret, w, s = call_gen_fn(ctx, mode, self.kernel_gen_fn, k_t, (carry_in, x_t), con_t, None, None,
+                                         req_leaves, addr)
+            if not (isinstance(ret, tuple) and len(ret) == 2):
+                raise TypeError("scan: the kernel must return (carry, output)")
+            carry_out, y_t = ret
+            score_t = s if mode == "assess" else _rec_score(rec)
+            # this step's trace: element t of every site's [T, n] value / score
+            for r in _leaves(rec):
+                val = r.value.value if isinstance(r.value, Sym) else r.value
+                sc = r.score.value if isinstance(r.score, Sym) else r.score
+                if isinstance(val, np.ndarray) or isinstance(sc, np.ndarray):
+                    raise NotImplementedError("scan of more than 16 steps: vector-valued sites inside the kernel")
+                if keep:
+                    r.origins = (tr.store_step(val, n), tr.store_step(sc, n), None)
+                    r.value = StepOutput(r.origins[0], n)
+                    r.score = StepOutput(r.origins[1], n)
+
+            def stack_out(v):
+                if v is None:
+                    return None
+                if isinstance(v, (tuple, list)):
+                    return type(v)(stack_out(x) for x in v)
+                return StepOutput(tr.store_step(v, n), n)
+            ys = stack_out(y_t)
+            # loop-carried updates: carry, key chain, running weight and score (added in step order, as unrolled)
+            new_leaves = []
+            ntree = flat_carry(carry_out, new_leaves)
+            if _shape_of(ntree) != _shape_of(ctree):
+                raise TypeError("scan: the kernel must return a carry of the same structure as it received")
+            for var, e in zip(cvars, new_leaves):
+                g.set_var(var, e.node)
+            if wvar is not None and w is not None:
+                g.set_var(wvar, (Expr(wvar) + w).node)
+            g.set_var(svar, (Expr(svar) + score_t).node)
+            if kvar is not None:
+                g.set_var(kvar, k_t.node)
+        g.loop_end()
+        ctx.store_sites = keep
+
+        def drop_retvals(r):
+            if isinstance(r, _CallRec):
+                r.retval = None
+                for x in r.sites.values():
+                    drop_retvals(x)
+        retval = (rebuild(ctree, [Expr(v) for v in cvars]), ys)
+        score = Expr(svar)
+        if isinstance(rec, _SiteRec):
+            out = rec
+        else:
+            drop_retvals(rec)
+            out = _CallRec(self)
+            out.sites = rec.sites
+            out.retval = retval
+            out.plate_score = score
+        if mode in ("simulate", "assess"):
+            return out, retval, None, score
+        return out, retval, Expr(wvar), None
 
     def _trace_edit(self, ctx, mode, key, args, constraint, prev, req, req_leaves, addr):
         """Scan.edit (scan.py:596-625): `Update(constraint)` (edit_update :509-594) and

@@ -105,6 +105,7 @@ struct gmx_jit_ctx {
     int64_t arow[PP];          /* ancestors[cidx] */                                             \
     uint32_t pre[(NPRE) > 0 ? (NPRE) : 1][PP];                                                   \
     bool act[PP];                                                                                \
+    uint32_t gmx_t = 0u;       /* iteration number of the enclosing GMX_JIT_LOOP (0 outside) */   \
     _Pragma("unroll") for (int p = 0; p < PP; ++p) {                                             \
       R[p].init();                                                                               \
       idx[p] = ((int64_t)blockIdx.x * PP + p) * GMX_BLOCK + threadIdx.x;                         \
@@ -112,7 +113,7 @@ struct gmx_jit_ctx {
       cidx[p] = act[p] ? idx[p] : n - 1;                                                         \
       arow[p] = 0;                                                                               \
     }                                                                                            \
-    (void)cidx; (void)arow; (void)pre;
+    (void)cidx; (void)arow; (void)pre; (void)gmx_t;
 
 #define GMX_JIT_PRE_ANC                                                                          \
     _Pragma("unroll") for (int p = 0; p < PP; ++p) arow[p] = (int64_t)A.ancestors_d[cidx[p]];
@@ -131,7 +132,11 @@ struct gmx_jit_ctx {
 #define GMX_JIT_OP(W0, W1)                                                                       \
     _Pragma("unroll") for (int p = 0; p < PP; ++p) {                                             \
       ctx.part = blockIdx.x * PP + p; ctx.first = (p == 0); ctx.last = (p == PP - 1); ctx.cur = p; \
-      gmx_vm_step<regs_t, full_v, gmx_cword<W0, W1>, ctx_t>(R[p], gmx_cword<W0, W1>(), idx[p], act[p], A, ctx); \
+      gmx_vm_step<regs_t, full_v, gmx_cword<W0, W1>, ctx_t>(R[p], gmx_cword<W0, W1>(), idx[p], act[p], A, ctx, gmx_t); \
     }
+
+// OP_LOOP / OP_ENDLOOP: a counted loop around the instructions in between (launch-uniform trip count)
+#define GMX_JIT_LOOP(COUNT) for (gmx_t = 0u; gmx_t < (COUNT); ++gmx_t) {
+#define GMX_JIT_ENDLOOP } gmx_t = 0u;
 
 #define GMX_JIT_END }

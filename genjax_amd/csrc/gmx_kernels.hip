@@ -125,6 +125,7 @@ struct gmx_program {
   uint32_t* code_d;
   uint32_t n_instr, n_regs, n_in, n_out, n_uni, n_tab, n_const, n_dyn;
   bool uses_key, uses_red, uses_lse, uses_gather, needs_full;
+  bool uses_loop = false, uses_step = false;
   uint32_t n_redmax = 0;             // OP_REDMAX instructions (tile statistics need exactly one)
   std::vector<uint32_t> code_h;      // instruction words (host copy, for specialisation)
   std::vector<uint32_t> consts;      // pool entries n_dyn..
@@ -155,6 +156,7 @@ static int parse_program(const uint32_t* blob, size_t n_words, gmx_program& P) {
   // validate every instruction: register / slot indices must be in range so
   // the kernel never needs a bounds check
   const uint32_t* ins = blob + GMX_PROG_HEADER_WORDS;
+  bool in_loop = false;
   for (uint32_t pc = 0; pc < n_instr; ++pc) {
     uint32_t w0 = ins[2 * pc], w1 = ins[2 * pc + 1];
     uint32_t op = w0 & 0xff, dst = (w0 >> 8) & 0xff, a = (w0 >> 16) & 0xff, b = w0 >> 24;
@@ -168,7 +170,9 @@ static int parse_program(const uint32_t* blob, size_t n_words, gmx_program& P) {
     if (gmx_op_needs_full(op)) P.needs_full = true;
     switch (op) {
       case OP_END: break;
-      case OP_CONST: case OP_LDIDX: ok = D(dst); break;
+      case OP_CONST: case OP_LDIDX: case OP_LDT: ok = D(dst); break;
+      case OP_LOOP: ok = !in_loop && w1 >= 1u; in_loop = true; P.uses_loop = true; break;     // counted, not nested
+      case OP_ENDLOOP: ok = in_loop; in_loop = false; break;
       case OP_UNI: ok = D(dst) && w1 < P.n_uni; break;
       case OP_LDIN: ok = D(dst) && a < P.n_in; if (b & GMX_F_GATHER) P.uses_gather = true; break;
       case OP_LDTAB: ok = D(dst) && R(b) && a < P.n_tab; break;
@@ -200,8 +204,13 @@ static int parse_program(const uint32_t* blob, size_t n_words, gmx_program& P) {
         break;
       default: ok = false;
     }
+    if ((op == OP_LDIN && (b & GMX_F_STEP)) || (op == OP_STOUT && (dst & GMX_F_STEP))) {
+      P.uses_step = true;
+      if (op == OP_STOUT && !in_loop) ok = false;   // a step-indexed store writes element t: inside the loop only
+    }
     if (!ok) return gmx_fail("gmx_program_create: invalid instruction%s at pc %lld", "", pc);
   }
+  if (in_loop) return gmx_fail("gmx_program_create: OP_LOOP without OP_ENDLOOP%s");
   P.code_h.assign(ins, ins + 2 * (size_t)n_instr);
   P.consts.assign(ins + 2 * (size_t)n_instr, ins + 2 * (size_t)n_instr + n_const);
   return 0;
@@ -269,11 +278,12 @@ static std::string jit_source(const gmx_program* p) {
   std::vector<int> pre_of(p->n_instr, -1);
   bool any_gather = false;
   uint32_t first_gather_pc = p->n_instr, first_key_pc = p->n_instr;
-  bool fits = want_pre;
+  bool fits = want_pre, seen_loop = false;
   for (uint32_t pc = 0; pc < p->n_instr && fits; ++pc) {
     const uint32_t w0 = p->code_h[2 * pc], op = w0 & 0xffu, a = (w0 >> 16) & 0xffu, b = w0 >> 24;
-    if ((op == OP_LDKEY || op == OP_KDERIVE) && first_key_pc == p->n_instr) first_key_pc = pc;
-    if (op != OP_LDIN || (b & GMX_F_BCAST)) continue;
+    if ((op == OP_LDKEY || op == OP_KDERIVE) && first_key_pc == p->n_instr && !seen_loop) first_key_pc = pc;
+    if (op == OP_LOOP) seen_loop = true;          // a key derived inside the loop is no place for one-off prefetches
+    if (op != OP_LDIN || (b & (GMX_F_BCAST | GMX_F_STEP))) continue;     // step-indexed rows change with t: loaded in place
     int k = -1;
     for (size_t j = 0; j < pres.size(); ++j)
       if (pres[j].slot == a && pres[j].flags == b) k = (int)j;
@@ -308,7 +318,12 @@ static std::string jit_source(const gmx_program* p) {
   if (!pres.empty()) s += "  GMX_JIT_FENCE\n";
   if (any_gather && gpos == 0) gathers();
   for (uint32_t pc = 0; pc < p->n_instr; ++pc) {
-    if (pre_of[pc] >= 0)
+    const uint32_t op_ = p->code_h[2 * pc] & 0xffu;
+    if (op_ == OP_LOOP)
+      snprintf(buf, sizeof(buf), "  GMX_JIT_LOOP(%uu)\n", p->code_h[2 * pc + 1]);
+    else if (op_ == OP_ENDLOOP)
+      snprintf(buf, sizeof(buf), "  GMX_JIT_ENDLOOP\n");
+    else if (pre_of[pc] >= 0)
       snprintf(buf, sizeof(buf), "  GMX_JIT_LDPRE(%u, %d)\n", (p->code_h[2 * pc] >> 8) & 0xffu, pre_of[pc]);
     else
       snprintf(buf, sizeof(buf), "  GMX_JIT_OP(0x%08xu, 0x%08xu)\n", p->code_h[2 * pc], p->code_h[2 * pc + 1]);
@@ -514,6 +529,8 @@ extern "C" int gmx_program_run(const gmx_program* p, int64_t n, const gmx_run_ar
   } else if (args->tile_q_d) {
     return gmx_fail("gmx_program_run: tile_q_d needs tile_agg_d%s");
   }
+  if (p->uses_step && args->step_stride < n)
+    return gmx_fail("gmx_program_run: step_stride must be at least n for a program with step-indexed leaves%s");
   if (p->uses_key) {
     int km = args->key_mode;
     if (km != GMX_KEY_ARRAY && km != GMX_KEY_SPLIT && km != GMX_KEY_ROWSPLIT && km != GMX_KEY_BCAST)

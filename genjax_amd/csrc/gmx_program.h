@@ -17,9 +17,13 @@
 //
 // Registers are untyped 32-bit cells r[0..n_regs); an op reads them as f32 or
 // i32.  A PRNG key occupies two consecutive registers (k, k+1).  Booleans are
-// i32 0/1.  There is no control flow: a `@gen` static function has a fixed
+// i32 0/1.  There is no data-dependent control flow: a `@gen` static function has a fixed
 // site list (static.py "Language restrictions"), `jax.lax.cond`/`where` on
-// values become OP_SEL.  All indices are launch-uniform, so on gfx950 the
+// values become OP_SEL.  The ONE loop form is a counted, launch-uniform repetition of a block
+// (OP_LOOP count ... OP_ENDLOOP; not nested): what `jax.lax.scan` is to the reference's Scan combinator
+// (combinators/scan.py:221, 278).  Values carried across iterations live in registers the block reads and
+// overwrites (the encoder emits the copies); OP_LDT yields the iteration number; loads / stores flagged
+// GMX_F_STEP address element t of a [T, n] leaf.  All indices are launch-uniform, so on gfx950 the
 // register file is indexed with s_set_gpr_idx (no scratch, no LDS).
 //
 // The Python encoder is genjax_amd/program.py; the independent CPU checker is
@@ -42,12 +46,14 @@
 #define GMX_F_GATHER 1u /* row = ancestors[i] instead of i            */
 #define GMX_F_U8 2u     /* element is 1 byte (bool) <-> i32 0/1        */
 #define GMX_F_BCAST 4u  /* row = 0: one device-resident scalar for all  */
+#define GMX_F_STEP 8u   /* row += (t + imm) * gmx_run_args.step_stride: element t + imm of a [T, n] leaf (t = the
+                           iteration number inside OP_LOOP, 0 outside; STOUT: element t, inside a loop only) */
 
 enum gmx_op {
   OP_END = 0,
   OP_CONST = 1,   // r[dst] = imm
   OP_UNI = 2,     // r[dst] = uni[imm]
-  OP_LDIN = 3,    // r[dst] = in[a][row], flags in b
+  OP_LDIN = 3,    // r[dst] = in[a][row], flags in b (GMX_F_STEP: imm = element offset)
   OP_LDTAB = 4,   // r[dst] = tab[a][(int)r[b] + (int)imm]
   OP_STOUT = 5,   // out[a][i] = r[b], flags in dst
   OP_LDKEY = 6,   // (r[dst], r[dst+1]) = particle key
@@ -78,5 +84,9 @@ enum gmx_op {
   // block reductions into red_out[blockIdx][0..1]
   OP_REDMAX = 90,     // column 0 = max over the block of r[a]
   OP_REDLSE = 91,     // column 0 = max, column 1 = sum exp(r[a] - max)
-  OP__COUNT = 92
+  // counted loop (launch-uniform trip count >= 1, not nested)
+  OP_LOOP = 100,      // imm = trip count: the block up to the matching OP_ENDLOOP runs imm times, t = 0 .. imm-1
+  OP_ENDLOOP = 101,
+  OP_LDT = 102,       // r[dst] = (i32) t, the iteration number (0 outside a loop)
+  OP__COUNT = 103
 };

@@ -66,7 +66,7 @@ struct gmx_cword {
 
 // One instruction.  All of w0 / w1 are launch-uniform.
 template <class Regs, bool FULL, class W, class Ctx>
-GMX_HD void gmx_vm_step(Regs& R, const W w, int64_t i, bool active, const gmx_run_args& A, Ctx& ctx) {
+GMX_HD void gmx_vm_step(Regs& R, const W w, int64_t i, bool active, const gmx_run_args& A, Ctx& ctx, uint32_t t = 0u) {
   const uint32_t w0 = w.w0(), w1 = w.w1();
 #define SRC(x) ((x) < GMX_POOL_BASE ? R.get(x) : ctx.pool((x) - GMX_POOL_BASE))
 #define FSRC(x) gmx_asf(SRC(x))
@@ -87,6 +87,7 @@ GMX_HD void gmx_vm_step(Regs& R, const W w, int64_t i, bool active, const gmx_ru
           int64_t row = i;
           if (b & GMX_F_GATHER) row = (int64_t)A.ancestors_d[i];
           if (b & GMX_F_BCAST) row = 0;
+          if (b & GMX_F_STEP) row += (int64_t)(t + w1) * A.step_stride;   // element t + imm of a [T, n] leaf
           const void* p = ctx.in_ptr(a);
           if (b & GMX_F_U8) r0 = (uint32_t)((const uint8_t*)p)[row];
           else r0 = ((const uint32_t*)p)[row];
@@ -104,8 +105,9 @@ GMX_HD void gmx_vm_step(Regs& R, const W w, int64_t i, bool active, const gmx_ru
         uint32_t v = SRC(b);
         if (active) {
           void* p = ctx.out_ptr(a);
-          if (dst & GMX_F_U8) ((uint8_t*)p)[i] = (uint8_t)(v != 0u);
-          else ((uint32_t*)p)[i] = v;
+          const int64_t orow = (dst & GMX_F_STEP) ? i + (int64_t)t * A.step_stride : i;
+          if (dst & GMX_F_U8) ((uint8_t*)p)[orow] = (uint8_t)(v != 0u);
+          else ((uint32_t*)p)[orow] = v;
         }
         wr = 0;
       } break;
@@ -129,6 +131,7 @@ GMX_HD void gmx_vm_step(Regs& R, const W w, int64_t i, bool active, const gmx_ru
         r0 = o.k0; r1 = o.k1; wr = 2;
       } break;
       case OP_LDIDX: r0 = (uint32_t)(A.index_offset + i); break;
+      case OP_LDT: r0 = t; break;
       case OP_MOV: r0 = SRC(a); break;
       // ---- f32 binary ----
       case OP_ADD: r0 = gmx_asu(FSRC(a) + FSRC(b)); break;
@@ -225,10 +228,17 @@ template <class Regs, bool FULL, int NI, class Ctx>
 GMX_HD void gmx_vm_run(uint32_t n_instr_rt, int64_t i, bool active, const gmx_run_args& A, Ctx& ctx) {
   Regs R;
   R.init();
+  uint32_t t = 0u, loop_pc = 0u, loop_n = 0u;       // the one (not nested) counted loop: launch-uniform control flow
   for (uint32_t pc = 0; pc < n_instr_rt; ++pc) {
     gmx_rword w;
     ctx.fetch(pc, &w.a, &w.b);
-    gmx_vm_step<Regs, FULL, gmx_rword, Ctx>(R, w, i, active, A, ctx);
+    const uint32_t op = w.a & 0xffu;
+    if (op == OP_LOOP) { loop_pc = pc; loop_n = w.b; t = 0u; continue; }
+    if (op == OP_ENDLOOP) {
+      if (t + 1u < loop_n) { ++t; pc = loop_pc; } else { t = 0u; }
+      continue;
+    }
+    gmx_vm_step<Regs, FULL, gmx_rword, Ctx>(R, w, i, active, A, ctx, t);
   }
 }
 

@@ -67,6 +67,8 @@ def _np_dt(a: np.ndarray) -> str:
 
 
 DVEC_MAX = 16       # longer launch-uniform device vectors are bound as tables, not as one input slot per element
+GMX_HVEC_MAX = 16   # launch-uniform HOST vectors: one operand-pool entry per element up to this length, a table beyond
+STEP_LEAF_MIN = 16  # per-particle vectors longer than this are ONE step-indexed leaf (read inside a counted loop)
 
 
 def leaf_spec(v, batch: tuple):
@@ -87,8 +89,8 @@ def leaf_spec(v, batch: tuple):
     if isinstance(v, torch.Tensor):
         dt = _TDT[v.dtype]
         shp = tuple(v.shape)
-        if v.device.type == "cpu" and _lib.get().device.type != "cpu":
-            return leaf_spec(v.numpy(), batch)
+        # a CPU tensor handed to a GPU launch is DATA like any other tensor (it is copied to the device when the
+        # launch is bound): the same classification as under the CPU mirror, where every tensor is a "device" tensor
         if shp[:nb] == tuple(batch) and nb > 0:
             return ("part", dt, shp[nb:])
         if v.ndim == 0:
@@ -105,6 +107,8 @@ def leaf_spec(v, batch: tuple):
             raise TypeError("object arrays cannot be launch values")
         if v.ndim == 0:
             return leaf_spec(v.item(), batch)
+        if v.ndim == 1 and v.shape[0] > GMX_HVEC_MAX:
+            return ("dtab", _np_dt(v), tuple(v.shape))      # too long for the operand pool: a table, like a long device vector
         return ("hvec", _np_dt(v), tuple(v.shape))
     if getattr(v, "__gmx_static__", False):
         _STATIC_KEEP[id(v)] = v            # host object the traced function only reads (e.g. a Target)
@@ -245,6 +249,12 @@ class Tracing:
         flags = {"bcast": F_BCAST, "dvec": F_BCAST, "part": 0, "gather": F_GATHER}[kind]
         dt = spec[1]
         event = () if kind == "bcast" else spec[2]
+        if kind == "part" and len(event) == 1 and event[0] > STEP_LEAF_MIN:
+            # a long per-particle vector (the [n, T] choices of a scan): one slot, element t read by iteration t
+            slot = g.n_in
+            g.n_in += 1
+            self.in_plan.append((slot, j, 0, "step"))
+            return Sym(StepInput.make(g, slot, dt, int(event[0])), ("leaf", j))
         if event == ():
             n = g.input(dt, flags)
             self.in_plan.append((n.slot, j, 0, kind))
@@ -267,9 +277,21 @@ class Tracing:
         if isinstance(value, _E) and value.node.op != "CONST" and id(value.node) not in self.prestored:
             self.prestored[id(value.node)] = self.graph.store(value.node)
 
+    def store_step(self, value, T: int):
+        """Inside a counted loop: store this iteration's value as element t of a [T, n] output (exposed to the
+        user as [n, T], like a plate).  Returns the output's origin."""
+        from . import tracer as Tm
+        e = Tm.lift(value)
+        slot = self.graph.store(e.node, step=True)
+        o = ("out", len(self.outputs))
+        self.outputs.append((e.dtype, (int(T),), ("step", slot)))
+        return o
+
     def emit_output(self, value):
         """Store a symbolic value (Expr or object array) unless it is a pure
         pass-through / constant; returns its origin."""
+        if isinstance(value, StepOutput):
+            return value.origin
         g = self.graph
         if value is None:
             return ("const", None)
@@ -307,6 +329,46 @@ class Tracing:
         if isinstance(value, dict):
             return ("dict", {k: self.emit_output(v) for k, v in value.items()})
         return ("const", value)
+
+
+class StepInput(np.ndarray):
+    """A per-particle vector leaf of T > 16 elements bound as ONE input slot ([T, n] struct-of-arrays): an object
+    array of element reads (OP_LDIN flagged GMX_F_STEP, imm = element; unused ones are eliminated), so every vector
+    operation works on it; indexing it with the iteration number of a counted loop is one such read with the
+    element chosen at run time."""
+
+    @classmethod
+    def make(cls, g, slot, dt, T):
+        from .program import F_STEP, F_U8
+        flags = F_STEP | (F_U8 if dt == "bool" else 0)
+        arr = np.empty((T,), dtype=object)
+        for k in range(T):
+            arr[k] = Expr(g.add("LDIN", dtype=dt, flags=flags, slot=slot, imm=k))
+        out = arr.view(cls)
+        out._g, out._slot, out._dt, out._flags = g, slot, dt, flags
+        return out
+
+    def __array_finalize__(self, obj):
+        for a in ("_g", "_slot", "_dt", "_flags"):
+            setattr(self, a, getattr(obj, a, None))
+
+    def __getitem__(self, idx):
+        if isinstance(idx, Expr) and self._slot is not None and self.ndim == 1:
+            return Expr(self._g.add("LDIN", dtype=self._dt, flags=self._flags, slot=self._slot))
+        return np.ndarray.__getitem__(self, idx)
+
+
+class StepOutput:
+    """The stacked per-iteration outputs of a counted loop ([n, T] after the launch): they exist only in memory, so
+    inside the program they can be returned / recorded but not computed with."""
+
+    def __init__(self, origin, T):
+        self.origin, self.T = origin, T
+
+    def _no(self, *a, **k):
+        raise NotImplementedError("the stacked outputs of a long scan live in memory only: return them, or use a "
+                                  "scan of at most 16 steps (unrolled) to compute with them inside the model")
+    __add__ = __radd__ = __mul__ = __rmul__ = __sub__ = __rsub__ = __getitem__ = __truediv__ = _no
 
 
 def _const_value(node):
@@ -449,11 +511,17 @@ class Compiled:
                 key_ = (j, kind)
             buf = soa_cache.get(key_)
             if buf is None:
-                buf = _prepare_input(src, kind, n if kind == "part" else None, be)
+                buf = _prepare_input(src, "part" if kind == "step" else kind, n if kind in ("part", "step") else None, be)
                 soa_cache[key_] = buf
                 keep.append(buf)
             item = buf.element_size()
-            if kind in ("bcast",):
+            if kind == "step":
+                if buf.dim() != 2 or buf.stride(1) != 1 or buf.stride(0) != n:
+                    buf = buf.contiguous()
+                    keep.append(buf)
+                A.in_d[slot] = buf.data_ptr()
+                A.step_stride = n
+            elif kind in ("bcast",):
                 A.in_d[slot] = buf.data_ptr()
             elif kind == "dvec":
                 A.in_d[slot] = buf.data_ptr() + e * item
@@ -464,6 +532,8 @@ class Compiled:
             a32 = anc.reshape(-1)
             if a32.dtype != torch.int32:
                 a32 = a32.to(torch.int32)
+            if a32.device != be.device:
+                a32 = a32.to(be.device)
             keep.append(a32)
             A.ancestors_d = a32.data_ptr()
         for ui, j, e, dt in self.uni_plan:
@@ -475,11 +545,22 @@ class Compiled:
             if t is not None:
                 A.tab_d[s] = t.data_ptr()
         for slot, j in self.tab_plan:
-            t = _prepare_input(leaves[j], "dvec", None, be)
+            tv = leaves[j]
+            if isinstance(tv, np.ndarray):                 # a long host vector (leaf_spec: "dtab")
+                tv = torch.from_numpy(np.ascontiguousarray(tv.astype(np.float32) if tv.dtype.kind == "f" else tv.astype(np.int32)))
+            t = _prepare_input(tv, "dvec", None, be)
             keep.append(t)
             A.tab_d[slot] = t.data_ptr()
         outs = []
         for k, (dt, event, slots) in enumerate(self.outputs):
+            if isinstance(slots, tuple) and slots[0] == "step":
+                # element t of a [T, n] leaf is written by iteration t of the program's loop (GMX_F_STEP)
+                buf = torch.empty((int(event[0]), n), dtype=_STORE[dt], device=be.device)
+                A.out_d[slots[1]] = buf.data_ptr()
+                A.step_stride = n
+                outs.append(buf.reshape(event + tuple(batch)).permute(
+                    *range(len(event), len(event) + len(batch)), *range(len(event))))
+                continue
             E = len(slots)
             if out_buffers is not None and out_buffers[k] is not None:
                 buf = out_buffers[k]

@@ -20,7 +20,7 @@ MAGIC = 0x50584D47
 VERSION = 2
 MAX_REGS = 64          # operand codes below POOL_BASE; more than 31 needs the specialised kernel (no interpreter build)
 
-F_GATHER, F_U8, F_BCAST = 1, 2, 4
+F_GATHER, F_U8, F_BCAST, F_STEP = 1, 2, 4, 8
 
 # opcode numbers: keep in sync with gmx_program.h
 OPC = dict(
@@ -35,6 +35,7 @@ OPC = dict(
     S_NORMAL=70, S_UNIFORM=71, S_FLIP=72, S_BERNL=73, S_BETA=74, S_CATSTEP=75, S_LOGGAMMA=76,
     L_NORMAL=80, L_UNIFORM=81, L_FLIP=82, L_BERNL=83, L_BETA=84,
     REDMAX=90, REDLSE=91,
+    LOOP=100, ENDLOOP=101, LDT=102,
 )
 
 UNARY = {"MOV", "NEG", "ABS", "EXP", "LOG", "LOG1P", "SQRT", "SIN", "COS", "TANH", "SIGMOID",
@@ -45,8 +46,11 @@ SAMPLER2 = {"S_NORMAL", "S_UNIFORM", "S_BETA"}      # args (key, a, b), imm = el
 SAMPLER1 = {"S_FLIP", "S_BERNL", "S_LOGGAMMA"}                    # args (key, a)
 LOGPDF2 = {"L_NORMAL", "L_UNIFORM", "L_BETA"}       # args (x, a, b)
 LOGPDF1 = {"L_FLIP", "L_BERNL"}                     # args (x, a)
-EFFECT = {"STOUT", "REDMAX", "REDLSE"}
-_NO_CSE = EFFECT | {"LDIN", "UNI", "CONST", "S_CATSTEP", "CATIDX"}     # slots are unique; CONSTs have their own table
+EFFECT = {"STOUT", "REDMAX", "REDLSE", "LOOP", "ENDLOOP", "SETVAR"}
+# LOOPVAR (args = (init,)): a value carried across the iterations of a counted loop — one register (two for a
+# key) initialised before OP_LOOP, read inside the block, overwritten by SETVAR (args = (var, new value)) and
+# readable after OP_ENDLOOP.  LDT: the iteration number.
+_NO_CSE = EFFECT | {"LDIN", "UNI", "CONST", "S_CATSTEP", "CATIDX", "LOOPVAR", "LDT"}     # slots are unique; CONSTs have their own table
 # values recomputed at every use instead of being held in a register (see compile_graph)
 REMAT_UNARY = {"LOG", "EXP", "NEG", "SQUARE", "SQRT", "RECIP", "I2F"}
 REMAT_BINARY = {"ADD", "SUB", "MUL", "DIV"}
@@ -125,13 +129,32 @@ class Graph:
         self.n_tab += 1
         return t
 
-    def store(self, value: Node) -> int:
-        """STOUT of `value`; returns the output slot."""
-        flags = F_U8 if value.dtype == "bool" else 0
+    def store(self, value: Node, step: bool = False) -> int:
+        """STOUT of `value`; returns the output slot.  step: element t of a [T, n] leaf (inside a loop)."""
+        flags = (F_U8 if value.dtype == "bool" else 0) | (F_STEP if step else 0)
         slot = self.n_out
         self.n_out += 1
         self.add("STOUT", (value,), dtype="none", flags=flags, slot=slot)
         return slot
+
+    # counted loop ------------------------------------------------------------
+    def loop_begin(self, count: int):
+        if getattr(self, "_in_loop", False):
+            raise NotImplementedError("nested counted loops")
+        self._in_loop = True
+        self._cse.clear()              # a value computed before the loop is not "the same" as one recomputed inside
+        self.add("LOOP", imm=int(count), dtype="none")
+
+    def loop_end(self):
+        self._in_loop = False
+        self.add("ENDLOOP", dtype="none")
+        self._cse.clear()
+
+    def loop_var(self, init: Node) -> Node:
+        return self.add("LOOPVAR", (init,), dtype=init.dtype)
+
+    def set_var(self, var: Node, value: Node):
+        self.add("SETVAR", (var, value), dtype="none")
 
 
 class ProgramTooLarge(Exception):
@@ -206,6 +229,16 @@ def compile_graph(g: Graph):
         return first, last
     use_first, use_last = _first_last()
     LONG = 96
+    # nodes created between LOOP and ENDLOOP
+    in_loop_region = {}
+    inside = False
+    for n in nodes:
+        if n.op == "LOOP":
+            inside = True
+        elif n.op == "ENDLOOP":
+            inside = False
+        elif inside:
+            in_loop_region[n.idx] = True
 
     def long_lived(n):
         return n.idx in use_last and use_last[n.idx] - use_first[n.idx] > LONG
@@ -217,6 +250,8 @@ def compile_graph(g: Graph):
     for n in nodes:
         if not live[n.idx]:
             continue
+        if in_loop_region.get(n.idx):
+            continue                     # inside a counted loop nothing is rematerialised: the block is short
         if n.op == "LDTAB" and n.args[0].op == "CONST":
             remat[n.idx] = 1
         elif n.op == "LDIN" and not (n.flags & F_GATHER) and long_lived(n):
@@ -250,6 +285,23 @@ def compile_graph(g: Graph):
             if a is not None:
                 for leaf in _remat_leaves(a, remat):
                     last_use[leaf.idx] = pos
+    # counted loops: whatever is defined BEFORE the block and read inside it (and every loop-carried register) must
+    # survive until the block has run for the last time — its register may not be handed to a value of the block
+    pos_of = {n.idx: pos for pos, n in enumerate(order)}
+    loop_lo = loop_hi = None
+    for pos, n in enumerate(order):
+        if n.op == "LOOP":
+            loop_lo = pos
+        elif n.op == "ENDLOOP" and loop_lo is not None:
+            loop_hi = pos
+            for q in range(loop_lo + 1, loop_hi):
+                for a in order[q].args:
+                    if a is None:
+                        continue
+                    for leaf in _remat_leaves(a, remat):
+                        if pos_of.get(leaf.idx, -1) < loop_lo and last_use.get(leaf.idx, -1) < loop_hi:
+                            last_use[leaf.idx] = loop_hi
+            loop_lo = None
     # ---- registers ----
     free = [True] * MAX_REGS
     reg = {}
@@ -299,7 +351,7 @@ def compile_graph(g: Graph):
             emit("LDTAB", t, x.slot, operand(x.args[0]), x.imm)
         elif x.op == "LDIN":
             t = scratch()
-            emit("LDIN", t, x.slot, x.flags)
+            emit("LDIN", t, x.slot, x.flags, x.imm)
         elif x.op in UNARY:
             a = operand(x.args[0])
             t = a if a in temps else scratch()         # a scratch operand is updated in place
@@ -354,6 +406,15 @@ def compile_graph(g: Graph):
         if op in EFFECT:
             if op == "STOUT":
                 emit(op, n.flags, n.slot, R(n.args[0]))
+            elif op == "LOOP":
+                emit(op, imm=n.imm)
+            elif op == "ENDLOOP":
+                emit(op)
+            elif op == "SETVAR":
+                var, val = n.args
+                if R(var) != R(val):
+                    for k in range(var.width):
+                        emit("MOV", R(var) + k, R(val) + k)
             else:
                 emit(op, 0, R(n.args[0]))
             continue
@@ -364,11 +425,15 @@ def compile_graph(g: Graph):
         elif op == "UNI":
             emit(op, dst, imm=n.imm)
         elif op == "LDIN":
-            emit(op, dst, n.slot, n.flags)
+            emit(op, dst, n.slot, n.flags, n.imm)
         elif op == "LDTAB":
             emit(op, dst, n.slot, R(n.args[0]), n.imm)
-        elif op in ("LDKEY", "LDIDX"):
+        elif op in ("LDKEY", "LDIDX", "LDT"):
             emit(op, dst)
+        elif op == "LOOPVAR":
+            init = n.args[0]
+            for k in range(n.width):
+                emit("MOV", dst + k, R(init) + k)
         elif op == "KDERIVE":
             emit(op, dst, R(n.args[0]), 0, n.imm)
         elif op == "KDERIVER":

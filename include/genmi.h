@@ -128,6 +128,8 @@ typedef struct gmx_run_args {
                                      gmx_resample_tiles needs — no separate pass over the log-weights  */
   int32_t tile_shift;
   int32_t reserved_;
+  int64_t step_stride;            /* elements between consecutive steps of a [T, n] leaf addressed with GMX_F_STEP inside
+                                     an OP_LOOP (programs with a counted loop: the Scan combinator); normally n         */
   uint64_t* tile_q_d;             /* optional, with tile_agg_d: [n] the fixed-point weight of every particle,
                                      q_i = floor(exp(x_i - k_b ln 2) * 2^tile_shift) — the terms A_b sums.  The
                                      epilogue has them in registers; written out, the resampler

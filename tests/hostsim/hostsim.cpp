@@ -79,7 +79,7 @@ extern "C" int gmx_program_create(const uint32_t* blob, size_t n_words, gmx_prog
     uint32_t w0 = p->code[2*pc]; uint32_t op = w0 & 0xff;
     if (op >= OP__COUNT) { delete p; return fail("program_create: invalid opcode"); }
     uint32_t dst = (w0 >> 8) & 0xff, a = (w0 >> 16) & 0xff, b = w0 >> 24;
-    bool regdst = !(op == OP_STOUT || op == OP_END || op == OP_REDMAX || op == OP_REDLSE);
+    bool regdst = !(op == OP_STOUT || op == OP_END || op == OP_REDMAX || op == OP_REDLSE || op == OP_LOOP || op == OP_ENDLOOP);
     if (regdst && dst >= p->n_regs) { delete p; return fail("program_create: register out of range"); }
     (void)a; (void)b;
   }

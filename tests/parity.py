@@ -549,6 +549,66 @@ def check_scan(n=257, T=6, seed=5):
     assert np.array_equal(t4.get_choices()["x"].cpu().numpy(), t4o.get_choices()["x"])
 
 
+def check_scan_long(n=257, T=100, seed=5):
+    """A LONG scan (T > 16) runs as a counted loop in the site program (ref scan.py:200-294 `lax.scan`, :638-664):
+    BASELINE config 2's model as ONE generative function — `step.scan(n=T)` inside a @gen model — importance /
+    simulate / assess for all T steps in one launch; chained keys fold_in(key, t); addresses ["steps", t, "x"]."""
+    import genjax_amd as G
+    from genjax_amd import ChoiceMapBuilder as C, numpy as jnp, workloads
+    ys = workloads.lgssm_data(T + 1)
+
+    def mk(g):
+        @g.gen
+        def step(x, t):
+            xn = g.normal(0.9 * x, 0.5) @ "x"
+            g.normal(xn, 1.0) @ "y"
+            return xn, xn * 2.0
+        return step
+    step, ostep = mk(G), mk(O)
+
+    @G.gen
+    def ssm():
+        x0 = G.normal(0.0, 1.0) @ "x0"
+        G.normal(x0, 1.0) @ "y0"
+        xT, doubled = step.scan(n=T)(x0, jnp.arange(T).astype("float32")) @ "steps"
+        return xT
+
+    @O.gen
+    def o_ssm():
+        x0 = O.normal(0.0, 1.0) @ "x0"
+        O.normal(x0, 1.0) @ "y0"
+        xT, doubled = O.Scan(ostep, T)(x0, np.arange(T, dtype=np.float32)) @ "steps"
+        return xT
+    con = C["steps", :, "y"].set(ys[1:]).set(("y0",), float(ys[0]))
+    ocon = O.C.d({("steps", "y"): ys[1:], ("y0",): np.float32(ys[0])})
+    tr, w = ssm.importance(G.split(G.key(seed), n), con, ())
+    tro, wo = o_ssm.importance(O.split(O.key(seed), n), ocon, ())
+    x = tr.get_choices()["steps", "x"]
+    assert tuple(x.shape) == (n, T)
+    assert np.array_equal(x.cpu().numpy(), tro.get_choices()["steps", "x"])          # chained keys fold_in(key, t)
+    assert np.array_equal(w.cpu().numpy(), wo)
+    assert np.array_equal(tr.get_score().cpu().numpy(), tro.get_score())
+    assert np.array_equal(tr.get_retval().cpu().numpy(), tro.get_retval())
+    assert np.array_equal(tr.get_choices()["steps", "y"].cpu().numpy(), np.broadcast_to(ys[1:], (n, T)))
+    assert np.array_equal(tr.get_subtrace("steps").get_subtrace("x").get_score().cpu().numpy(), tro.subtraces["steps"].subtraces["x"].score)
+    # simulate, then assess the simulated choices (per-particle [n, T] leaves read step by step)
+    tr2, tro2 = ssm.simulate(G.split(G.key(seed + 1), n), ()), o_ssm.simulate(O.split(O.key(seed + 1), n), ())
+    assert np.array_equal(tr2.get_choices()["steps", "y"].cpu().numpy(), tro2.get_choices()["steps", "y"])
+    s, _ = ssm.assess(tr2.get_choices(), ())
+    so, _ = o_ssm.assess(tro2.get_choices(), (), (n,))
+    assert np.array_equal(s.cpu().numpy(), so) and np.array_equal(s.cpu().numpy(), tr2.get_score().cpu().numpy())
+    # the scan used directly: the chain starts at the caller's key; stacked outputs come back as [n, T]
+    dev = G._lib.get().device
+    sc = step.scan(n=T)
+    t4 = sc.simulate(G.split(G.key(seed + 2), n), (torch.zeros(n, device=dev), jnp.zeros(T)))
+    t4o = O.Scan(ostep, T).simulate(O.split(O.key(seed + 2), n), (np.zeros(n, np.float32), np.zeros(T, np.float32)))
+    assert np.array_equal(t4.get_choices()["x"].cpu().numpy(), t4o.get_choices()["x"])
+    carry, doubled = t4.get_retval()
+    ocarry, odoubled = t4o.get_retval()
+    assert np.array_equal(carry.cpu().numpy(), ocarry) and np.array_equal(doubled.cpu().numpy(), odoubled)
+    return dict(log_ml_is=float(torch.logsumexp(w.double(), 0) - math.log(n)), kalman=workloads.kalman_log_ml(ys))
+
+
 # ---------------------------------------------------------------------------
 # edits of plates (SURVEY §8f item 2): Vmap.edit = Update | IndexRequest (vmap.py:236-362)
 # ---------------------------------------------------------------------------

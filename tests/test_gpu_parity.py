@@ -720,6 +720,16 @@ def test_sweep_with_fixed_point_weight_handoff(gpu, monkeypatch):
         assert res["log_ml"] == res["log_ml_oracle"]
 
 
+def test_long_scan_config2_as_one_generative_function(gpu):
+    """`step.scan(n=100)` on config 2's model, importance for 1e5 particles as ONE generative
+    function / one launch (interpreter), bit-exact vs the oracle; the same through the hiprtc-specialised kernel
+    (n >= 2^18 particles), and the importance-sampling evidence of a short chain against the Kalman filter."""
+    parity.check_scan_long(n=100_000, T=100)
+    parity.check_scan_long(n=270_000, T=40)                  # >= 2^18: the specialised kernel (GMX_JIT_LOOP)
+    r = parity.check_scan_long(n=400_000, T=17)
+    assert abs(r["log_ml_is"] - r["kalman"]) < 0.25, r         # prior-proposal IS over 18 steps: MC error ~0.1
+
+
 def test_tile_stats_from_the_site_program(gpu):
     """the specialised program's epilogue writes the same (m_b, A_b) as gmx_tile_stats, ragged last tile included"""
     import genjax_amd as G

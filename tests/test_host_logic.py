@@ -569,6 +569,17 @@ def test_scan_matches_oracle():
     parity.check_scan(n=257, T=6)
 
 
+def test_long_scan_runs_as_a_loop_and_matches_oracle():
+    """Scan of T > 16 steps = a counted loop in the site program (ref scan.py:200-294, 638-664)"""
+    from tests import parity
+    parity.check_scan_long(n=257, T=100)
+    parity.check_scan_long(n=64, T=17)
+    # the program is a loop, not T copies of the kernel
+    from genjax_amd import static
+    sizes = [int(ent[0].blob[2]) for ent in static._CACHE.values() if hasattr(ent[0], "blob")]
+    assert min(sizes) < 64
+
+
 def test_plate_edits_match_oracle():
     from tests import parity
     parity.check_plate_edits(n=257)

@@ -4,13 +4,42 @@ trie; API names follow the reference so models and inference scripts read the
 same (src/genjax/_src/core/generative/choice_map.py: Selection :124-663,
 ChoiceMap :752-1393, Static :1534, Choice :1396, Or.build :1699-1733).
 
-Supported address components: strings, ints and tuples of them (static
-addresses).  Dynamic (`Indexed` / slice) addressing is outside the round-1 hot
-path.
+Supported address components: strings, ints and tuples of them (static addresses), the full slice `:` (plate
+values carry the plate axis themselves) and an ARRAY OF INDICES (`Indexed`, choice_map.py:1453-1531;
+address rules `_validate_addr` :699-749: scalar components first, at most one array component, then full slices):
+`C["ys", np.array([2, 5, 6]), "y"].set(v)` constrains plate elements 2, 5, 6 to v[0], v[1], v[2] — stored as the
+integer sub-addresses 2, 5, 6, which is what `Indexed.get_inner_map(j)` resolves to for a static index array
+(`Mask(v[k], True)` where j == idx[k], nothing elsewhere).  A runtime-conditional constraint is a `Mask(value, flag)`
+leaf (core/mask.py): the flag may be a launch value (one bool per particle).
 """
 from __future__ import annotations
 
 from typing import Any, Callable
+
+
+class _IndexArray:
+    """An array-of-indices address component (hashable wrapper: address tuples are dict keys)."""
+    __slots__ = ("idx",)
+
+    def __init__(self, idx):
+        self.idx = tuple(int(i) for i in idx)
+
+    def __repr__(self):
+        return f"idx{list(self.idx)}"
+
+
+def _index_array(a):
+    """a 1-D integer array / list used as an address component, else None"""
+    if isinstance(a, _IndexArray):
+        return a
+    if isinstance(a, (str, int, bytes)) or a is Ellipsis or isinstance(a, slice) or isinstance(a, tuple):
+        return None
+    if isinstance(a, list) and a and all(isinstance(i, (int,)) and not isinstance(i, bool) for i in a):
+        return _IndexArray(a)
+    shape, dt = getattr(a, "shape", None), getattr(a, "dtype", None)
+    if shape is not None and dt is not None and len(shape) == 1 and ("int" in str(dt)):
+        return _IndexArray([int(i) for i in (a.tolist() if hasattr(a, "tolist") else a)])
+    return None
 
 
 def _norm(addr) -> tuple:
@@ -18,7 +47,12 @@ def _norm(addr) -> tuple:
         out = ()
         for a in addr:
             out += _norm(a)
+        if sum(isinstance(a, _IndexArray) for a in out) > 1:
+            raise ValueError("an address may hold at most one array of indices (choice_map.py:699-749)")
         return out
+    ia = _index_array(addr)
+    if ia is not None:
+        return (ia,)
     if addr is Ellipsis:
         return ()              # `Selection.at[..., "y"]`: any plate index — plate values carry the axis themselves
     if isinstance(addr, slice):
@@ -207,6 +241,13 @@ class ChoiceMap:
             return v if isinstance(v, ChoiceMap) else ChoiceMap(value=v)
         head, rest = addr[0], addr[1:]
         kids = dict(self._children)
+        if isinstance(head, _IndexArray):
+            # Indexed (choice_map.py:1453-1531) with a static index array: element idx[k] takes v[k]
+            if len(set(head.idx)) != len(head.idx):
+                raise ValueError("an array of indices in an address must not repeat an index")
+            for k, j in enumerate(head.idx):
+                kids[j] = kids.get(j, _EMPTY).set(rest, _take_indexed(v, k, len(head.idx)))
+            return ChoiceMap(self._value, kids)
         kids[head] = kids.get(head, _EMPTY).set(rest, v)
         return ChoiceMap(self._value, kids)
 
@@ -314,6 +355,24 @@ class ChoiceMap:
     def structure(self):
         """Hashable description of which addresses hold values (program cache key)."""
         return tuple(self.addresses())
+
+
+def _take_indexed(v, k, m):
+    """entry k of a value (or of every leaf of a choice map) whose leading axis — or, for a per-particle [n, m]
+    tensor, whose last axis — runs over the m indices of an array-of-indices address"""
+    if isinstance(v, ChoiceMap):
+        return v.map_values(lambda x: _take_indexed(x, k, m))
+    shape = getattr(v, "shape", None)
+    if shape is None:
+        if isinstance(v, (list, tuple)) and len(v) == m:
+            return v[k]
+        raise ValueError("a value set at an array-of-indices address needs one entry per index")
+    shape = tuple(shape)
+    if len(shape) >= 1 and shape[0] == m:
+        return v[k]
+    if len(shape) == 2 and shape[1] == m:
+        return v[:, k]
+    raise ValueError(f"a value of shape {shape} does not have one entry for each of the {m} indices")
 
 
 def _same(a, b):

@@ -1,6 +1,10 @@
 """Mask: a value paired with a validity flag (functional_types.py:42-368).
-Only the host-side container is provided on the round-1 hot path; masked
-constraints (`Indexed` / `Switch` choice maps) are next-tier."""
+
+As a CONSTRAINT leaf (`C["x"].set(Mask(value, flag))`) it is the reference's runtime-conditional constraint:
+`Distribution.generate_choice_map` runs `lax.cond(flag, importance, simulate)` (distribution.py:129-142) and
+`edit_update_with_constraint` `FlagOp.cond(flag, new value, old value)` (:189-224).  Here the flag may be a Python
+bool (decided while the program is traced) or a launch value — one bool per particle — in which case the leaf's
+site program computes both branches' value and selects (OP_SEL): static._leaf_call, engine.Flat."""
 from __future__ import annotations
 
 

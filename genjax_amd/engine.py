@@ -25,6 +25,7 @@ import torch
 
 from . import _lib
 from .core.choice_map import ChoiceMap
+from .core.mask import Mask
 from .program import F_BCAST, F_GATHER, Graph, compile_graph
 from .random import Key
 from .tracer import Expr
@@ -171,6 +172,11 @@ class Flat:
             return ("dict", tuple((k, self.add(x)) for k, x in v.items()))
         if isinstance(v, ChoiceMap):
             return ("chm", tuple((a, self.add(v[a] if a else v.get_value())) for a in v.addresses()))
+        if isinstance(v, Mask):
+            # a runtime-conditional constraint (distribution.py:129-142): a flag known on the host resolves now
+            if isinstance(v.flag, (bool, np.bool_)):
+                return ("mask_static", bool(v.flag), self.add(v.value))
+            return ("mask", self.add(v.value), self.add(v.flag))
         self.leaves.append(v)
         return ("leaf", len(self.leaves) - 1)
 
@@ -182,7 +188,7 @@ def _is_number_seq(v):
 
 def unflatten(tree, fn):
     """Rebuild the structure, mapping leaf index -> fn(index)."""
-    kind, payload = tree
+    kind, payload = tree[0], tree[1]
     if kind == "leaf":
         return fn(payload)
     if kind in ("tuple", "list"):
@@ -195,6 +201,10 @@ def unflatten(tree, fn):
         for a, t in payload:
             cm = cm.set(a, unflatten(t, fn))
         return cm
+    if kind == "mask":
+        return Mask(unflatten(tree[1], fn), unflatten(tree[2], fn))
+    if kind == "mask_static":
+        return Mask(unflatten(tree[2], fn), tree[1])
     raise ValueError(kind)
 
 

@@ -33,6 +33,7 @@ import torch
 from . import _lib
 from . import tracer as T
 from .core.choice_map import ChoiceMap, Selection, _norm
+from .core.mask import Mask
 from .core.generative import (Diff, EditRequest, EmptyRequest, GenerativeFunction, IndexRequest, NoChange,
                               NotSupportedEditRequest, Regenerate, Trace, Update)
 from .engine import Compiled, Flat, Gathered, Sym, Tracing, leaf_spec, materialize, resolve, unflatten
@@ -556,6 +557,26 @@ def _leaf_call(ctx: _Ctx, mode, dist, key, args, constraint: ChoiceMap, prev, re
         v = dist.sym_sample(key, args)
         s = dist.sym_logpdf(v, args)
         return _SiteRec(dist, v, s), v, None, s
+    if isinstance(cval, Mask) and isinstance(cval.flag, bool):
+        cval = cval.value if cval.flag else None             # decided on the host: plain constrained / unconstrained
+    if isinstance(cval, Mask):
+        # a runtime-conditional constraint: `lax.cond(flag, importance, simulate)` (generate, distribution.py:129-142)
+        # / `FlagOp.cond(flag, new value, old value)` (update, :189-224) becomes a select between the two branches'
+        # results — the value is chosen first, its log-density is evaluated once (the same function in both branches)
+        flag = cval.flag.value if isinstance(cval.flag, Sym) else cval.flag
+        mval = cval.value.value if isinstance(cval.value, Sym) else cval.value
+        if mode == "generate":
+            vs = dist.sym_sample(key, args)
+            v = T.where(flag, mval, vs)
+            s = dist.sym_logpdf(v, args)
+            return _SiteRec(dist, v, s), v, T.where(flag, s, 0.0), s
+        if mode == "update" or (req is not None and req.kind == "update"):
+            pv_sym, ps_sym = prev["value"], prev["score"]
+            v = T.where(flag, mval, pv_sym.value)
+            s = dist.sym_logpdf(v, args)
+            ctx.mark_changed(v)
+            return _SiteRec(dist, v, s, discard=pv_sym), v, s - ps_sym.value, s
+        raise NotSupportedEditRequest(f"a Mask constraint in mode {mode!r}")
     if mode == "generate":
         if cval is None:
             v = dist.sym_sample(key, args)

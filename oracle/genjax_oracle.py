@@ -227,6 +227,26 @@ def _addr(a):
     return a if isinstance(a, tuple) else (a,)
 
 
+class Mask:
+    """Mask(value, flag) (core/generative/functional_types.py:42-368): a runtime-conditional constraint."""
+
+    def __init__(self, value, flag):
+        self.value, self.flag = value, flag
+
+
+def indexed(values, idx, n, fill=0.0):
+    """The leaf `Indexed.get_inner_map` yields under a vmap over a plate of n elements (choice_map.py:1494-1531):
+    element j sees Mask(values[k], True) where j == idx[k] and a masked-off junk value elsewhere — as ONE Mask whose
+    value / flag carry the plate axis (the oracle evaluates plates vectorised)."""
+    idx = np.asarray(idx, dtype=np.int64)
+    values = np.asarray(values)
+    full = np.full(values.shape[:-1] + (n,), fill, dtype=values.dtype)
+    flag = np.zeros((n,), dtype=bool)
+    full[..., idx] = values
+    flag[idx] = True
+    return Mask(full, flag)
+
+
 class ChoiceMap:
     """Minimal value tree with the operations the handlers need
     (choice_map.py: Static :1534, Choice :1396, Or :1671, filter :1588)."""
@@ -458,6 +478,14 @@ class Distribution:
         if v is None:
             tr = self.simulate(k, args)
             return tr, np.zeros(batch, dtype=np.float32)
+        if isinstance(v, Mask):
+            # lax.cond(flag, _importance, _simulate) (distribution.py:129-142), evaluated as a select
+            sim = self.simulate(k, args)
+            flag = np.broadcast_to(np.asarray(v.flag, bool), np.shape(sim.value))
+            new_v = np.where(flag, np.asarray(v.value, dtype=np.asarray(sim.value).dtype), sim.value)
+            score = self.estimate_logpdf(new_v, args, batch)
+            w = np.where(np.broadcast_to(np.asarray(v.flag, bool), np.shape(score)), score, np.float32(0.0)).astype(np.float32)
+            return DistTrace(self, args, new_v, score), w
         w = self.estimate_logpdf(v, args, batch)
         return DistTrace(self, args, v, w), w
 
@@ -479,6 +507,12 @@ class Distribution:
         - old score; discard = old value when a new value is supplied."""
         batch = np.shape(trace.score)
         v = constraint.get_value()
+        if isinstance(v, Mask):
+            # FlagOp.cond(flag, new value, old value) (distribution.py:189-224); discard = old choices
+            flag = np.broadcast_to(np.asarray(v.flag, bool), np.shape(trace.value))
+            new_v = np.where(flag, np.asarray(v.value, dtype=np.asarray(trace.value).dtype), trace.value)
+            fwd = self.estimate_logpdf(new_v, args, batch)
+            return DistTrace(self, args, new_v, fwd), (fwd - trace.score).astype(np.float32), trace.get_choices()
         if v is None:
             old = trace.value
             fwd = self.estimate_logpdf(old, args, batch)

@@ -403,6 +403,80 @@ def check_nested_marginal(k=129, seed=5):
     assert abs(float(lp) - float(olp)) <= 1e-5
 
 
+def check_masked_constraints(n=257, seed=9):
+    """Indexed choice maps and Mask constraints (ref choice_map.py:1453-1531, distribution.py:129-142, 189-224):
+    a plate constrained on a SUBSET of its indices (`C["ys", idx_array, "y"].set(v)`), and a runtime-conditional
+    constraint Mask(value, flag) with one flag per particle — the select between the importance and the simulate
+    branch runs in the site program (OP_SEL)."""
+    import genjax_amd as G
+    from genjax_amd import ChoiceMapBuilder as C, Mask, Update, Diff
+    dev = G._lib.get().device
+    sig = np.array([15, 10, 16, 11, 9, 11, 10, 18], np.float32)
+
+    from genjax_amd import numpy as jnp
+
+    def mk(g, plate):
+        @g.gen
+        def school(mu, s):
+            th = g.normal(mu, 2.0) @ "theta"
+            return g.normal(th, s) @ "y"
+
+        @g.gen
+        def model():
+            mu = g.normal(0.0, 5.0) @ "mu"
+            plate(school)(mu) @ "ys"
+            return mu
+        return model
+    m = mk(G, lambda sch: (lambda mu: sch.vmap(in_axes=(None, 0))(mu, jnp.array(sig))))
+    om = mk(O, lambda sch: (lambda mu: O.Vmap(sch, in_axes=(None, 0))(mu, sig)))
+    idx = np.array([1, 4, 6])
+    vals = np.array([8.0, -1.0, 18.0], np.float32)
+    tr, w = m.importance(G.split(G.key(seed), n), C["ys", idx, "y"].set(vals), ())
+    otr, ow = om.importance(O.split(O.key(seed), n), O.C.d({("ys", "y"): O.indexed(vals, idx, 8)}), ())
+    y, oy = tr.get_choices()["ys", "y"].cpu().numpy(), otr.get_choices()["ys", "y"]
+    assert np.array_equal(y, oy) and np.array_equal(y[:, idx], np.broadcast_to(vals, (n, 3)))
+    assert not np.array_equal(y[:, 0], y[:, 2])                              # the other elements were sampled
+    assert np.array_equal(w.cpu().numpy(), ow)                                # weight = the 3 constrained densities only
+    assert np.array_equal(tr.get_score().cpu().numpy(), otr.get_score())
+    # a list of indices, and a value with the index axis last on a per-particle tensor
+    per = np.random.default_rng(seed).normal(size=(n, 3)).astype(np.float32)
+    tr2, w2 = m.importance(G.split(G.key(seed + 1), n), C["ys", [1, 4, 6], "y"].set(torch.from_numpy(per).to(dev)), ())
+    otr2, ow2 = om.importance(O.split(O.key(seed + 1), n), O.C.d({("ys", "y"): O.indexed(per, idx, 8)}), ())
+    assert np.array_equal(tr2.get_choices()["ys", "y"].cpu().numpy(), otr2.get_choices()["ys", "y"])
+    assert np.array_equal(w2.cpu().numpy(), ow2)
+
+    # Mask(value, flag) with one flag per particle at a plain site
+    def mk1(g):
+        @g.gen
+        def pair():
+            x = g.normal(0.0, 1.0) @ "x"
+            return g.normal(x, 0.5) @ "z"
+        return pair
+    p1, op1 = mk1(G), mk1(O)
+    flags = np.random.default_rng(seed + 2).random(n) < 0.4
+    xv = np.random.default_rng(seed + 3).normal(size=n).astype(np.float32)
+    mk_t = lambda a: torch.from_numpy(a).to(dev)
+    tr3, w3 = p1.importance(G.split(G.key(seed + 2), n), C["x"].set(Mask(mk_t(xv), mk_t(flags))), ())
+    otr3, ow3 = op1.importance(O.split(O.key(seed + 2), n), O.C.d({"x": O.Mask(xv, flags)}), ())
+    x3 = tr3.get_choices()["x"].cpu().numpy()
+    assert np.array_equal(x3, otr3.get_choices()["x"]) and np.array_equal(x3[flags], xv[flags])
+    assert np.array_equal(w3.cpu().numpy(), ow3) and np.all(w3.cpu().numpy()[~flags] == 0.0)
+    assert np.array_equal(tr3.get_score().cpu().numpy(), otr3.get_score())
+    # flags decided on the host: plain constrained / unconstrained generate
+    tr4, w4 = p1.importance(G.split(G.key(seed + 2), n), C["x"].set(Mask(mk_t(xv), True)), ())
+    tr5, w5 = p1.importance(G.split(G.key(seed + 2), n), C["x"].set(mk_t(xv)), ())
+    assert np.array_equal(w4.cpu().numpy(), w5.cpu().numpy())
+    tr6, w6 = p1.importance(G.split(G.key(seed + 2), n), C["x"].set(Mask(mk_t(xv), False)), ())
+    assert np.all(w6.cpu().numpy() == 0.0)
+    # Update with a masked constraint (distribution.py:189-224): new value where the flag holds, old one elsewhere
+    u, wu, _, bwd = Update(C["x"].set(Mask(mk_t(xv), mk_t(flags)))).edit(G.split(G.key(seed + 5), n), tr6, Diff.no_change(()))
+    ou, owu, _ = op1.update(O.split(O.key(seed + 5), n), op1.importance(O.split(O.key(seed + 2), n), O.ChoiceMap.empty(), ())[0],
+                            O.C.d({"x": O.Mask(xv, flags)}), ())
+    assert np.array_equal(u.get_choices()["x"].cpu().numpy(), ou.get_choices()["x"])
+    assert np.array_equal(wu.cpu().numpy(), owu)
+    assert np.array_equal(u.get_score().cpu().numpy(), ou.get_score())
+
+
 def mk2(g):
     @g.gen
     def model():

@@ -730,6 +730,14 @@ def test_long_scan_config2_as_one_generative_function(gpu):
     assert abs(r["log_ml_is"] - r["kalman"]) < 0.25, r         # prior-proposal IS over 18 steps: MC error ~0.1
 
 
+def test_indexed_and_masked_constraints(gpu):
+    """a plate constrained on a subset of its indices (Indexed, ref choice_map.py:1453-1531) and
+    Mask(value, flag) constraints with one flag per particle (ref distribution.py:129-142, 189-224): OP_SEL between
+    the importance and simulate results inside the site program; bit-exact vs the oracle's restatement."""
+    parity.check_masked_constraints(n=257)
+    parity.check_masked_constraints(n=10_000, seed=3)
+
+
 def test_tile_stats_from_the_site_program(gpu):
     """the specialised program's epilogue writes the same (m_b, A_b) as gmx_tile_stats, ragged last tile included"""
     import genjax_amd as G

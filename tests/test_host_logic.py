@@ -580,6 +580,11 @@ def test_long_scan_runs_as_a_loop_and_matches_oracle():
     assert min(sizes) < 64
 
 
+def test_indexed_and_masked_constraints_match_oracle():
+    from tests import parity
+    parity.check_masked_constraints()
+
+
 def test_plate_edits_match_oracle():
     from tests import parity
     parity.check_plate_edits(n=257)

@@ -100,9 +100,25 @@ class ParticleCollection:
     `log_ml_offset` (build addition) carries the evidence accumulated by
     earlier resampling steps; it is 0 for the reference's algorithms."""
 
-    def __init__(self, particles, log_weights, is_valid=True, log_ml_offset=None):
-        self.particles, self.log_weights, self.is_valid = particles, log_weights, is_valid
+    def __init__(self, particles, log_weights, is_valid=True, log_ml_offset=None, n_zero=None):
+        """log_weights: a tensor, or None with n_zero = N for "all zero" (a freshly resampled collection): the zeros
+        are only materialised if somebody asks for them, and `extend` then adds nothing."""
+        self.particles, self._lw, self.is_valid = particles, log_weights, is_valid
+        self._n_zero = n_zero
         self.log_ml_offset = log_ml_offset
+
+    @property
+    def log_weights(self):
+        if self._lw is None:
+            self._lw = torch.zeros((self._n_zero,), dtype=torch.float32, device=_lib.get().device)
+        return self._lw
+
+    @log_weights.setter
+    def log_weights(self, v):
+        self._lw = v
+
+    def weights_are_zero(self) -> bool:
+        return self._lw is None
 
     def get_particles(self):
         return self.particles
@@ -452,14 +468,22 @@ def resample_fused(kind, key: Key, lw: torch.Tensor):
     """gmx_resample: log-weights -> (ancestors int32 [n], total [1], max [1], shift) in two launches with no CDF
     array (tile statistics + k_offspring_tile); the same integers as weight_cdf + ancestors_from_cdf."""
     be = _lib.get()
+    stats = getattr(lw, "_gmx_tile_stats", None)       # left by the program that computed these weights (run_gfi)
     lw = lw.reshape(-1).float().contiguous()
     if lw.data_ptr() % 16:
         lw = lw.clone()                    # a view into the middle of a buffer: the kernels load float4
+        stats = None
     n = lw.numel()
     shift = cdf_shift(n)
     anc = torch.empty((n,), dtype=torch.int32, device=lw.device)
-    total = torch.zeros((1,), dtype=torch.int64, device=lw.device)
+    total = torch.empty((1,), dtype=torch.int64, device=lw.device)
     mx = torch.empty((1,), dtype=torch.float32, device=lw.device)
+    if stats is not None and stats[2] == shift and stats[3] == n:
+        kh = key.host()
+        kk = (c_uint32 * 2)(int(kh[0]), int(kh[1]))
+        be.check(be.c.gmx_resample_tiles(int(kind), kk, be.ptr(lw), n, shift, be.ptr(stats[0]), be.ptr(stats[1]),
+                                         be.ptr(mx), be.ptr(total), be.ptr(anc), be.stream()), "gmx_resample_tiles")
+        return anc, total, mx, shift
     ws = torch.empty(((be.c.gmx_resample_workspace(n) + 7) // 8,), dtype=torch.int64, device=lw.device)
     kh = key.host()
     kk = (c_uint32 * 2)(int(kh[0]), int(kh[1]))
@@ -490,15 +514,14 @@ def resample(key: Key, collection: ParticleCollection, kind="systematic", n_out=
     kind = _KINDS[kind] if isinstance(kind, str) else int(kind)
     n = lw.numel()
     if kind in (SYSTEMATIC, STRATIFIED) and n_out in (None, n) and 0 < n <= FUSED_RESAMPLE_MAX:
-        anc, total, mx, shift = resample_fused(kind, key, lw)        # no CDF in memory (gmx_resample)
+        anc, total, mx, shift = resample_fused(kind, key, lw)        # no CDF in memory (gmx_resample[_tiles])
     else:
         cdf, total, mx, shift = weight_cdf(lw)
         anc = ancestors_from_cdf(kind, key, cdf, total, n_out)
     particles = trace_map(collection.get_particles(),
                           lambda v: Gathered(engine.materialize(v), anc) if tuple(v.shape[:1]) == (n,) else v)
     off = (collection.log_ml_offset or LogMLOffset()).plus(mx, total, shift, n)
-    new_lw = torch.zeros((anc.numel(),), dtype=torch.float32, device=lw.device)
-    out = ParticleCollection(particles, new_lw, True, off)
+    out = ParticleCollection(particles, None, True, off, n_zero=anc.numel())     # weights reset to 0, lazily
     out.ancestors = anc
     return out
 
@@ -509,10 +532,18 @@ def extend(key: Key, collection: ParticleCollection, step, step_args, observatio
     lw_i += weight_i (same algebra as ChangeTarget._reweight, smc.py:378-384,
     restricted to the new step's sites).  `step_args` is a tuple, or a callable
     mapping the previous particles' trace to the tuple."""
-    n = collection.get_log_weights().shape[0]
+    zero = collection.weights_are_zero()
+    n = collection._n_zero if zero else collection.get_log_weights().shape[0]
     args = step_args(collection.get_particles()) if callable(step_args) else tuple(step_args)
     keys = split(key, n)
-    tr, w = step.importance(keys, observations, args)
+    from ..static import StaticGenerativeFunction, run_gfi
+    if isinstance(step, StaticGenerativeFunction):
+        # the step's program also leaves the resampler's tile statistics of its weight when it can
+        tr, w = run_gfi(step, "generate", keys, args, constraint=observations, weight_stats=zero)
+    else:
+        tr, w = step.importance(keys, observations, args)
+    if zero:                           # lw + w with lw = 0 exactly (0.0f + w == w for every w but -0.0, which a
+        return ParticleCollection(tr, w, True, collection.log_ml_offset)          # sum of log-densities is not)
     return ParticleCollection(tr, engine.elementwise(_add, collection.get_log_weights(), w), True, collection.log_ml_offset)
 
 
@@ -524,13 +555,47 @@ def rejuvenate(key: Key, collection: ParticleCollection, request, argdiffs=None)
     Weights are unchanged (an MH kernel leaves the target invariant)."""
     from ..static import run_mh
     tr = collection.get_particles()
-    n = collection.get_log_weights().shape[0]
+    n = collection._n_zero if collection.weights_are_zero() else collection.get_log_weights().shape[0]
     if argdiffs is None:
         argdiffs = Diff.no_change(tr.get_args() or ())
     new_tr, accept, _ = run_mh(tr.get_gen_fn(), lazy_split(key, n), tr, request, argdiffs)
-    res = ParticleCollection(new_tr, collection.get_log_weights(), True, collection.log_ml_offset)
+    res = ParticleCollection(new_tr, collection._lw, True, collection.log_ml_offset, n_zero=collection._n_zero)
     res.accept = accept
     return res
+
+
+class CapturedLoop:
+    """A Python inference loop over this module's functional API (resample -> rejuvenate -> extend ...) captured ONCE
+    into a hipGraph and replayed without the interpreter in the loop: every C-ABI launch goes to torch's current stream,
+    so one capture records them all; tensors made during the capture come from the graph's private pool and stay
+    valid (and are overwritten in place) across replays.  `result` is whatever the loop returned at capture time —
+    its tensors hold the latest replay's values."""
+
+    def __init__(self, loop_fn, *args, warmup: int = 1):
+        be = _lib.get()
+        if not be.uses_streams:
+            raise _lib.GenmiError("capture needs the HIP backend")
+        side = torch.cuda.Stream(device=be.device)
+        side.wait_stream(torch.cuda.current_stream(be.device))
+        with torch.cuda.stream(side):           # programs are traced / specialised outside the capture
+            for _ in range(max(1, warmup)):
+                loop_fn(*args)
+        torch.cuda.current_stream(be.device).wait_stream(side)
+        torch.cuda.synchronize(be.device)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.result = loop_fn(*args)
+
+    def replay(self):
+        self.graph.replay()
+        return self.result
+
+
+def capture(loop_fn, *args, warmup: int = 1) -> CapturedLoop:
+    """`smc.capture(loop_fn, *args)`: see CapturedLoop.  Host-side reads of device values inside `loop_fn`
+    (`.item()`, `float(tensor)`, LogMLOffset.value()) are not capturable — return tensors and read them after
+    `replay()`."""
+    return CapturedLoop(loop_fn, *args, warmup=warmup)
 
 
 class BootstrapSweep:
@@ -585,16 +650,33 @@ class BootstrapSweep:
         self.p_init = MinimalGenerate(self.init, (), obs0, (n,))
         # the state is the model's return value: a scalar, or ONE vector of D floats per particle, stored
         # struct-of-arrays as [D, n] and seen by models (and by state()) as the [n, D] view
-        if self.p_init.ro[0] != "out":
-            raise NotImplementedError("BootstrapSweep: the step model must return one array (scalar or vector state)")
-        dt, event, _slots = self.p_init.comp.outputs[self.p_init.ro[1]]
-        if dt != "f32" or len(event) > 1:
-            raise NotImplementedError("BootstrapSweep: the state must be a float scalar or a float vector")
+        ro = self.p_init.ro
+        outs_ = self.p_init.comp.outputs
+        self.tuple_state = None
+        if ro[0] in ("tuple", "list") and ro[1] and all(o[0] == "out" and outs_[o[1]][0] == "f32" and outs_[o[1]][1] == ()
+                                                          for o in ro[1]):
+            # a TUPLE of float scalars (the latent sites a step hands to the next one): D rows of one [D, n] store,
+            # every row its own output of the site program and its own gathered input of the next step
+            self.tuple_state = type(()) if ro[0] == "tuple" else type([])
+            if self.rejuvenate is not None:
+                raise NotImplementedError("BootstrapSweep(rejuvenate=...): a tuple state is not supported (return one "
+                                          "array, or use smc.resample / rejuvenate / extend under smc.capture)")
+            event, D = (), len(ro[1])
+        else:
+            if ro[0] != "out":
+                raise NotImplementedError("BootstrapSweep: the step model must return one array (scalar or vector "
+                                          "state) or a tuple of float scalars")
+            dt, event, _slots = outs_[ro[1]]
+            if dt != "f32" or len(event) > 1:
+                raise NotImplementedError("BootstrapSweep: the state must be a float scalar or a float vector")
+            D = int(np.prod(event, dtype=np.int64)) if event else 1
         self.event = tuple(event)
-        D = int(np.prod(event, dtype=np.int64)) if event else 1
         self.x_store = [torch.zeros((D, n), dtype=torch.float32, device=dev) for _ in range(2)]
-        self.x = [s_.reshape(n) if not event else s_.t() for s_ in self.x_store]
-        g = Gathered(self.x[0], self.anc)
+        if self.tuple_state is not None:
+            self.x = [self.tuple_state(s_[d] for d in range(D)) for s_ in self.x_store]
+        else:
+            self.x = [s_.reshape(n) if not event else s_.t() for s_ in self.x_store]
+        g = self._gathered(0)
         if self.rejuvenate is None:
             self.p_step = MinimalGenerate(self.step, (g,) + tuple(self.step_extra(1)), obs0, (n,))
         else:
@@ -637,6 +719,12 @@ class BootstrapSweep:
             self.step_keys.append((ks[0], ks[1], ks[2]))
         return self
 
+    def _gathered(self, which):
+        """the resampled state x[which][anc] as the step model's first argument (lazy: the gather is fused)"""
+        if self.tuple_state is not None:
+            return self.tuple_state(Gathered(row, self.anc) for row in self.x[which])
+        return Gathered(self.x[which], self.anc)
+
     def _launch_vm(self, t):
         n = self.n
         k_prop = self.step_keys[t][0]
@@ -644,11 +732,15 @@ class BootstrapSweep:
         if t == 0:
             prog, leaves = self.p_init, self.p_init.leaves((), obs)
         else:
-            g = Gathered(self.x[(t - 1) % 2], self.anc) if self.rejuvenate is None else self.xm[t % 2]
+            g = self._gathered((t - 1) % 2) if self.rejuvenate is None else self.xm[t % 2]
             prog = self.p_step
             leaves = prog.leaves((g,) + tuple(self.step_extra(t)), obs)
         bufs = [None] * len(prog.comp.outputs)
-        bufs[prog.ro[1]] = self.x_store[t % 2]
+        if self.tuple_state is not None:
+            for d, o in enumerate(prog.ro[1]):
+                bufs[o[1]] = self.x_store[t % 2][d:d + 1]
+        else:
+            bufs[prog.ro[1]] = self.x_store[t % 2]
         bufs[prog.wo[1]] = self.lw.reshape(1, n)
         prog.comp.run(leaves, (n,), lazy_split(k_prop, n), red_out=self.partials, out_buffers=bufs,
                       tile_stats=(self.tile_agg, self.shift, self.tile_q) if self.tile_stats else None)

@@ -713,6 +713,11 @@ def call_gen_fn(ctx, mode, gen_fn, key, args, constraint, prev, req, req_leaves,
 _CACHE = _new_program_cache()
 
 
+def _lib_jit_min() -> int:
+    from . import engine
+    return engine.JIT_MIN_PARTICLES
+
+
 def _infer_batch(values) -> tuple:
     """Common leading shape of the device leaves (vector-valued leaves carry
     event axes after the particle axes); pass batch_shape= when ambiguous."""
@@ -781,8 +786,13 @@ def _broadcast_score(x, batch, device):
     return torch.full(batch, float(x), dtype=torch.float32, device=device)
 
 
-def run_gfi(gen_fn, mode, key: Key | None, args, constraint: ChoiceMap | None = None, batch_shape=None):
-    """simulate / generate / assess for any generative function: one launch."""
+def run_gfi(gen_fn, mode, key: Key | None, args, constraint: ChoiceMap | None = None, batch_shape=None,
+            weight_stats: bool = False):
+    """simulate / generate / assess for any generative function: one launch.
+    weight_stats (generate, 1-D batches): the program also reduces its importance weight per workgroup (OP_REDMAX) and,
+    when it runs as a specialised 4-particles-per-thread kernel, leaves the resampler's CDF tile statistics
+    (gmx_run_args.tile_agg_d): the returned weight tensor then carries them (`_gmx_tile_stats`) and
+    smc.resample needs no pass of its own over the log-weights."""
     be = _lib.get()
     args = tuple(args)
     constraint = constraint if constraint is not None else ChoiceMap.empty()
@@ -796,7 +806,8 @@ def run_gfi(gen_fn, mode, key: Key | None, args, constraint: ChoiceMap | None = 
     else:
         batch = _infer_batch(flat.leaves)
     specs = tuple(leaf_spec(v, batch) for v in flat.leaves)
-    ck = (_gfkey(gen_fn), mode, atree, ctree, specs, len(batch), key is not None)
+    weight_stats = bool(weight_stats and mode == "generate" and len(batch) == 1)
+    ck = (_gfkey(gen_fn), mode, atree, ctree, specs, len(batch), key is not None, weight_stats)
     ent = _CACHE.get(ck)
     if ent is None:
         tr = Tracing(len(batch))
@@ -812,10 +823,25 @@ def run_gfi(gen_fn, mode, key: Key | None, args, constraint: ChoiceMap | None = 
             wo = tr.emit_output(w) if (mode == "generate" and w is not None) else None
             so = tr.emit_output(s) if mode == "assess" else None
             ro = tr.emit_output(retval) if mode == "assess" else None
+            if weight_stats and isinstance(w, Expr) and w.node.op != "CONST":
+                tr.graph.add("REDMAX", (w.node,), dtype="none")
         ent = (Compiled(tr), otree, wo, so, ro)
         _CACHE[ck] = ent
     comp, otree, wo, so, ro = ent
-    outs = comp.run(flat.leaves, batch, key)
+    stats = None
+    if weight_stats and comp.uses_red:
+        n = int(batch[0])
+        if n >= _lib_jit_min() and be.uses_streams and not torch.cuda.is_current_stream_capturing():
+            comp.specialize()
+        if comp.writes_tile_stats():
+            from .inference.smc import cdf_shift
+            partials = torch.empty((2, (n + 255) // 256), dtype=torch.float32, device=be.device)
+            agg = torch.empty(((n + 1023) // 1024,), dtype=torch.int64, device=be.device)
+            stats = (partials, agg, cdf_shift(n), n)
+    if stats is not None:
+        outs = comp.run(flat.leaves, batch, key, red_out=stats[0], tile_stats=(stats[1], stats[2]))
+    else:
+        outs = comp.run(flat.leaves, batch, key)
     if mode == "assess":
         score = _broadcast_score(resolve(so, outs, flat.leaves), batch, be.device)
         return score, _tree_materialize(resolve(ro, outs, flat.leaves))
@@ -823,7 +849,10 @@ def run_gfi(gen_fn, mode, key: Key | None, args, constraint: ChoiceMap | None = 
     if mode == "simulate":
         return trc
     w = resolve(wo, outs, flat.leaves) if wo is not None else 0.0
-    return trc, _broadcast_score(w, batch, be.device)
+    w = _broadcast_score(w, batch, be.device)
+    if stats is not None and isinstance(w, torch.Tensor):
+        w._gmx_tile_stats = stats          # (block maxima, tile sums, shift, n): valid for exactly this tensor's values
+    return trc, w
 
 
 class MinimalGenerate:

@@ -58,6 +58,59 @@ def check_lgssm_sweep(n=4096, T=5, seed=314159, capture=False, specialize=True):
     )
 
 
+def check_tuple_state_sweep(n=3000, T=5, seed=13, capture=False, specialize=False):
+    """BootstrapSweep over a step model with THREE latent sites whose state is a tuple of two of them
+    (the sweep is not limited to `trace = {state, obs}`)."""
+    import genjax_amd as G
+    from genjax_amd.inference.smc import BootstrapSweep
+    ys = np.random.default_rng(seed).normal(size=T).astype(np.float32)
+
+    def mk(g):
+        @g.gen
+        def init():
+            a = g.normal(0.0, 1.0) @ "a"
+            b = g.normal(a, 1.0) @ "b"
+            g.normal(a + b, 1.0) @ "y"
+            return (a, b)
+
+        @g.gen
+        def step(s):
+            a0, b0 = s
+            a = g.normal(0.9 * a0, 0.5) @ "a"
+            b = g.normal(0.5 * b0 + 0.1 * a, 0.5) @ "b"
+            c = g.normal(0.0, 1.0) @ "c"
+            g.normal((a + b) + 0.1 * c, 1.0) @ "y"
+            return (a, b)
+        return init, step
+    (init, step), (oi, os_) = mk(G), mk(O)
+    sw = BootstrapSweep(init, step, n, T, specialize=specialize).prepare(G.key(seed), torch.from_numpy(ys))
+    if capture:
+        sw.capture()
+    sw.launch()
+    # the oracle's statement of the same sweep with a tuple state
+    x, anc, log_ml = None, None, 0.0
+    for t in range(T):
+        ks = O.split(O.fold_in(O.key(seed), t), 3)
+        keys = O.split(ks[0], n)
+        obs = O.C.d({"y": np.float32(ys[t])})
+        if t == 0:
+            tr, w = oi.importance(keys, obs, ())
+        else:
+            tr, w = os_.importance(keys, obs, (tuple(v[anc] for v in x),))
+        x = tuple(np.asarray(v, np.float32) for v in tr.get_retval())
+        lw = np.asarray(w, np.float32)
+        cdf, total, M, shift = O.weight_cdf(lw)
+        anc = O.ancestors(O.SYSTEMATIC, ks[1], cdf)
+        log_ml += O.log_ml_increment(M, total, shift, n)
+    xs, lw_d, anc_d = sw.state()
+    assert np.array_equal(anc_d.cpu().numpy(), anc)
+    for d in range(2):
+        assert np.array_equal(xs[d].cpu().numpy(), x[d])
+    assert np.array_equal(lw_d.cpu().numpy(), lw)
+    assert sw.log_ml() == log_ml
+    return dict(log_ml=log_ml)
+
+
 def check_nlssm_mh(n=2000, T=4, seed=7):
     """BASELINE config 3 in miniature: nonlinear SSM, bootstrap SMC with one
     Rejuvenate (Gaussian drift, sigma 0.5) MH sweep on x_t after each resample,

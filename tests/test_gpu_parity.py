@@ -738,6 +738,53 @@ def test_indexed_and_masked_constraints(gpu):
     parity.check_masked_constraints(n=10_000, seed=3)
 
 
+def test_tuple_state_sweep_three_site_step_model(gpu):
+    """BootstrapSweep over a step model with three latent sites and a tuple state, 1e5 particles,
+    captured + specialised, bit-exact vs the oracle"""
+    parity.check_tuple_state_sweep(n=100_000, T=5, capture=True, specialize=True)
+    parity.check_tuple_state_sweep(n=3001, T=4)
+
+
+def test_functional_loop_captured_equals_eager(gpu):
+    """smc.capture: resample -> rejuvenate -> extend written with the functional API, captured once into a hipGraph;
+    the replayed particles, ancestors and accept bits equal the eager loop's (and the step programs leave the
+    resampler's tile statistics themselves once they run specialised: no separate pass over the log-weights)."""
+    import genjax_amd as G
+    from genjax_amd import workloads
+    from genjax_amd.inference import smc
+    n, T = 300_000, 4
+    ys = workloads.nlssm_data(T)
+    init, step = workloads.make_nlssm(G)
+    req = G.StaticRequest({"x": G.Rejuvenate(G.normal, lambda chm: (chm.get_value(), 0.5))})
+
+    def sweep(key):
+        ancs = []
+        for t in range(T):
+            kp, kr, km = G.split(G.fold_in(key, t), 3)
+            obs = G.ChoiceMap.kw(y=float(ys[t]))
+            if t == 0:
+                coll = smc.ImportanceK(G.Target(init, (), obs), k_particles=n).run_smc(kp)
+            else:
+                coll = smc.resample(kr, coll, "systematic")
+                ancs.append(coll.ancestors)
+                coll = smc.rejuvenate(km, coll, req)
+                coll = smc.extend(kp, coll, step, lambda tr_: (tr_.get_retval(), float(t)), obs)
+        return coll, ancs
+    ref, ref_anc = sweep(G.key(11))
+    ref_x = ref.get_particles().get_retval().clone()
+    ref_lw = ref.get_log_weights().clone()
+    ref_anc = [a.clone() for a in ref_anc]
+    cap = smc.capture(sweep, G.key(11))
+    coll, ancs = cap.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(coll.get_particles().get_retval(), ref_x)
+    assert torch.equal(coll.get_log_weights(), ref_lw)
+    for a, b in zip(ancs, ref_anc):
+        assert torch.equal(a, b)
+    # against the oracle's statement of the same loop (ancestors, states, weights bit-exact)
+    parity.check_nlssm_mh(n=2000, T=4)
+
+
 def test_tile_stats_from_the_site_program(gpu):
     """the specialised program's epilogue writes the same (m_b, A_b) as gmx_tile_stats, ragged last tile included"""
     import genjax_amd as G

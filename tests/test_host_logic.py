@@ -958,6 +958,11 @@ def test_sweep_with_fixed_point_weight_handoff(monkeypatch):
     assert res["log_ml"] == res["log_ml_oracle"]
 
 
+def test_tuple_state_sweep_matches_oracle():
+    from tests import parity
+    parity.check_tuple_state_sweep()
+
+
 def test_vector_state_mh_sweep_matches_oracle():
     """BootstrapSweep(rejuvenate=...) with a 2-vector state held in one vector-valued site: the fused MH move
     gathers, proposes, accepts and selects all components; bit-exact vs the oracle incl. the accept bits"""

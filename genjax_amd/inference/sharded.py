@@ -436,17 +436,50 @@ class ShardedBootstrapSweep:
         return got[0] if not self.event else torch.stack(got, dim=1)
 
 
-def sharded_importance_resample(target, k_per_rank: int, key: Key, dist, kind="systematic", capacity=None, comm=None):
+class CountingComm:
+    """Wraps a communicator and counts its collectives (tests; `sharded_importance_resample(..., stats=...)`)."""
+
+    def __init__(self, inner):
+        self.inner, self.counts = inner, {"all_reduce_max": 0, "all_gather": 0, "all_to_all": 0}
+        self.rank, self.world, self.name = inner.rank, inner.world, inner.name
+
+    def all_reduce_max(self, t):
+        self.counts["all_reduce_max"] += 1
+        return self.inner.all_reduce_max(t)
+
+    def all_gather(self, out, inp):
+        self.counts["all_gather"] += 1
+        return self.inner.all_gather(out, inp)
+
+    def all_to_all(self, out, inp):
+        self.counts["all_to_all"] += 1
+        return self.inner.all_to_all(out, inp)
+
+
+def sharded_importance_resample(target, k_per_rank: int, key: Key, dist, kind="systematic", capacity=None, comm=None,
+                                stats: dict | None = None):
     """BASELINE config 4 across ranks: `ImportanceK(target, k_particles = world * k_per_rank).run_smc(key)`
     with rank g holding particles [g*k, (g+1)*k) (same key tree: keys split(sub, K)[g*k + i], so the
-    ensemble is the single-process one), then ONE global resampling: all-reduce of the max, local integer
-    CDF, all-gather of the totals, and for every 4-byte row of every trace leaf one `gmx_shard_step` + one
-    equal-split all-to-all (a one-off move, so leaves are routed one by one).  Returns
-    (ParticleCollection of this rank's k resampled particles, this rank's pre-resampling log-weights).
+    ensemble is the single-process one), then ONE global resampling with ONE plan for the whole trace:
+
+      1. tile statistics of the local log-weights (gmx_tile_stats)         -> all-gather (12 B per 1024 particles)
+      2. gmx_shard_totals: global max + every rank's integer total; gmx_shard_step_tiles routes ONE 4-byte leaf:
+         each particle's LOCAL INDEX — so `send_idx[d*C + k]` names the local particle that fills slot k of the block
+         this rank ships to rank d, and `next_idx` says where each of this rank's slots finds its ancestor;
+      3. every 4-byte row of every trace leaf (10 latents for 8-schools) is packed by `send_idx` into one
+         [world, rows, C] buffer                                              -> ONE equal-split all-to-all
+      4. one gather by `next_idx` over [local | received] rebuilds every leaf.
+
+    Two data-path collectives per resampling whatever the number of leaves (the first form did one all-to-all and one
+    routing launch PER ROW, plus a max all-reduce and a totals all-gather), and one 8-byte all-reduce for the
+    capacity-overflow flag.  (k_per_rank > 2^21, more than 64 ranks or multinomial: the CDF-array form computes the
+    same plan — all-reduce of the max, gmx_weight_cdf, all-gather of the totals, gmx_shard_step.)
+    `stats`, if given, receives {"collectives": {...}, "rows": R, "capacity": C, "form": ...}.
+    Returns (ParticleCollection of this rank's k resampled particles, this rank's pre-resampling log-weights).
     COLLECTIVE: every rank calls it."""
     _check_shard_alignment(int(k_per_rank), dist.get_world_size())
-    from .smc import _KINDS, LogMLOffset, ParticleCollection, trace_map
-    from ..engine import gather_leaves, materialize
+    from .smc import _KINDS, FUSED_RESAMPLE_MAX, LogMLOffset, ParticleCollection, trace_map
+    from ..engine import materialize
     be = _lib.get()
     dev = be.device
     g, W = dist.get_rank(), dist.get_world_size()
@@ -455,73 +488,121 @@ def sharded_importance_resample(target, k_per_rank: int, key: Key, dist, kind="s
     if comm is None and W > 1:
         from .comm import make_comm
         comm = make_comm(dist, dev)
+    if comm is not None:
+        comm = CountingComm(comm)
     key, sub = split(key)                                            # smc.py:299
     trs, lw = target.importance(lazy_split(sub, n, offset=g * n), ChoiceMap.empty())
     lw = lw.float().contiguous()
-    # ---- global max (deterministic LSE kernel's max output), local CDF against it, totals ----
-    mx = torch.empty((1,), dtype=torch.float32, device=dev)
-    dummy = torch.empty((1,), dtype=torch.float32, device=dev)
-    rows_ws = torch.empty(((be.c.gmx_logsumexp_workspace(1, n) + 3) // 4,), dtype=torch.int32, device=dev)
-    be.check(be.c.gmx_logsumexp(be.ptr(lw), 1, n, be.ptr(dummy), be.ptr(mx), be.ptr(rows_ws), be.stream()), "gmx_logsumexp")
-    if W > 1:
-        comm.all_reduce_max(mx)
     shift = cdf_shift(K)
-    cdf = torch.empty((n,), dtype=torch.int64, device=dev)
-    total = torch.zeros((1,), dtype=torch.int64, device=dev)
-    ws = torch.zeros(((be.c.gmx_weight_cdf_workspace(n) + 7) // 8,), dtype=torch.int64, device=dev)
-    be.check(be.c.gmx_weight_cdf(be.ptr(lw), n, shift, None, 0, be.ptr(mx), be.ptr(cdf), be.ptr(total), be.ptr(ws),
-                                 be.stream()), "gmx_weight_cdf")
-    totals_all = torch.zeros((W,), dtype=torch.int64, device=dev)
-    if W > 1:
-        comm.all_gather(totals_all, total)
-    else:
-        totals_all.copy_(total)
     kh = key.host()                                                  # resampling key: the algorithm's leftover `key`
     kk = (c_uint32 * 2)(int(kh[0]), int(kh[1]))
+    mx = torch.empty((1,), dtype=torch.float32, device=dev)
+    totals_all = torch.zeros((W,), dtype=torch.int64, device=dev)
     gtotal = torch.zeros((1,), dtype=torch.int64, device=dev)
+    tiles_form = kind in (0, 1) and n <= FUSED_RESAMPLE_MAX and W <= 64 and os.environ.get("GENMI_SHARD_TILES", "1") != "0"
+    if tiles_form:
+        nbytes = int(be.c.gmx_shard_stats_bytes(n))
+        tiles = (n + 1023) // 1024
+        pad = tiles + (tiles & 1)
+        stats_own = torch.zeros((nbytes,), dtype=torch.uint8, device=dev)
+        stats_all = torch.zeros((W * nbytes,), dtype=torch.uint8, device=dev)
+        be.check(be.c.gmx_tile_stats(be.ptr(lw), n, shift, be.ptr(stats_own[pad * 8:]), be.ptr(stats_own), be.stream()),
+                 "gmx_tile_stats")
+        if W > 1:
+            comm.all_gather(stats_all, stats_own)
+        else:
+            stats_all.copy_(stats_own)
+        be.check(be.c.gmx_shard_totals(be.ptr(stats_all), W, n, be.ptr(totals_all), be.ptr(mx), be.stream()),
+                 "gmx_shard_totals")
+        cdf = None
+    else:
+        # global max (deterministic LSE kernel's max output), local CDF against it, totals
+        dummy = torch.empty((1,), dtype=torch.float32, device=dev)
+        rows_ws = torch.empty(((be.c.gmx_logsumexp_workspace(1, n) + 3) // 4,), dtype=torch.int32, device=dev)
+        be.check(be.c.gmx_logsumexp(be.ptr(lw), 1, n, be.ptr(dummy), be.ptr(mx), be.ptr(rows_ws), be.stream()), "gmx_logsumexp")
+        if W > 1:
+            comm.all_reduce_max(mx)
+        cdf = torch.empty((n,), dtype=torch.int64, device=dev)
+        total = torch.zeros((1,), dtype=torch.int64, device=dev)
+        ws = torch.zeros(((be.c.gmx_weight_cdf_workspace(n) + 7) // 8,), dtype=torch.int64, device=dev)
+        be.check(be.c.gmx_weight_cdf(be.ptr(lw), n, shift, None, 0, be.ptr(mx), be.ptr(cdf), be.ptr(total), be.ptr(ws),
+                                     be.stream()), "gmx_weight_cdf")
+        if W > 1:
+            comm.all_gather(totals_all, total)
+        else:
+            totals_all.copy_(total)
+
+    # ---- every per-particle leaf of the trace as 4-byte rows [R, n] ----
+    specs, rows = [], []
+
+    def collect(v):
+        v = materialize(v)
+        if tuple(v.shape[:1]) != (n,):
+            specs.append(None)
+            return v
+        orig = v.dtype
+        if v.element_size() == 8:                                     # int64 / float64: two 4-byte rows per value
+            flat = v.reshape(n, -1).contiguous().view(torch.int32)
+        elif v.element_size() == 4:
+            flat = v.reshape(n, -1)
+        elif orig in (torch.bool, torch.uint8, torch.int8, torch.int16):
+            flat = v.to(torch.int32).reshape(n, -1)                   # small integers travel as i32 and come back as they were
+        else:
+            raise TypeError(f"sharded_importance_resample: cannot route a leaf of dtype {orig}")
+        specs.append((orig, tuple(v.shape), flat.dtype, len(rows), flat.shape[1]))
+        for c in range(flat.shape[1]):
+            rows.append(flat[:, c].contiguous().view(torch.float32))
+        return v
+    trace_map(trs, collect)
+    R = len(rows)
+    table = torch.stack(rows) if R else torch.zeros((0, n), dtype=torch.float32, device=dev)      # [R, n]
+
     C = max(1, min(int(capacity) if capacity else (n if W == 1 else max(4096, n // 32)), n))
     while True:
         plan = torch.zeros((int(be.c.gmx_shard_plan_words(W)),), dtype=torch.int64, device=dev)
-        idx = torch.zeros((n,), dtype=torch.int32, device=dev)
-        send = torch.zeros((W * C,), dtype=torch.float32, device=dev)
-
-        def route(row: torch.Tensor) -> torch.Tensor:
-            """row: [n] 4-byte values of this rank's particles -> [n] values of this rank's resampled slots"""
-            ext = torch.empty((n + W * C,), dtype=row.dtype, device=dev)
-            ext[:n] = row
+        next_idx = torch.zeros((n,), dtype=torch.int32, device=dev)
+        send_idx = torch.zeros((W * C,), dtype=torch.int32, device=dev)              # unused capacity: particle 0 (valid)
+        local_index = torch.arange(n, dtype=torch.int32, device=dev)                  # the ONE routed leaf
+        if tiles_form:
+            be.check(be.c.gmx_shard_step_tiles(kind, kk, be.ptr(totals_all), be.ptr(plan), be.ptr(gtotal), be.ptr(lw),
+                                               be.ptr(stats_own), be.ptr(mx), shift, g, W, n, C, be.ptr(local_index),
+                                               be.ptr(send_idx), be.ptr(next_idx), be.stream()), "gmx_shard_step_tiles")
+        else:
             be.check(be.c.gmx_shard_step(kind, kk, be.ptr(totals_all), be.ptr(plan), be.ptr(gtotal), be.ptr(cdf), g, W,
-                                         n, C, be.ptr(ext), be.ptr(send), be.ptr(idx), be.stream()), "gmx_shard_step")
-            if W > 1:
-                comm.all_to_all(ext[n:].view(torch.float32), send)
-            return gather_leaves([ext], idx)[0]
-
-        def move(v):
-            v = materialize(v)
-            if tuple(v.shape[:1]) != (n,):
-                return v
-            orig = v.dtype
-            if v.element_size() == 8:                                 # int64 / float64: two 4-byte rows per value
-                flat = v.reshape(n, -1).contiguous().view(torch.int32)     # [n, 2 * cols]
-            elif v.element_size() == 4:
-                flat = v.reshape(n, -1)
-            elif orig in (torch.bool, torch.uint8, torch.int8, torch.int16):
-                flat = v.to(torch.int32).reshape(n, -1)               # small integers travel as i32 and come back as they were
-            else:
-                raise TypeError(f"sharded_importance_resample: cannot route a leaf of dtype {orig}")
-            cols = [route(flat[:, c].contiguous().view(torch.float32)).view(flat.dtype) for c in range(flat.shape[1])]
-            out = torch.stack(cols, dim=1)
-            if v.element_size() == 8:
-                out = out.contiguous().view(orig)
-            elif out.dtype != orig:
-                out = (out != 0) if orig == torch.bool else out.to(orig)
-            return out.reshape(v.shape)
-        new = trace_map(trs, move)
+                                         n, C, be.ptr(local_index), be.ptr(send_idx), be.ptr(next_idx), be.stream()),
+                     "gmx_shard_step")
         flag = plan[2:3].clone()
         if W > 1:
             comm.all_reduce_max(flag)
         if int(flag.item()) == 0:
             break
         C = n                                                        # always sufficient
+    # ---- pack by destination, ONE all-to-all, one gather ----
+    if W > 1 and R:
+        packed = table[:, send_idx.long()].reshape(R, W, C).permute(1, 0, 2).contiguous()          # [W, R, C]
+        recv = torch.empty_like(packed)
+        comm.all_to_all(recv.view(-1), packed.view(-1))
+        ext = torch.cat([table, recv.permute(1, 0, 2).reshape(R, W * C)], dim=1)                   # [R, n + W*C]
+    else:
+        ext = table
+    moved = ext[:, next_idx.long()] if R else ext                                                     # [R, n]
+    it = iter(specs)
+
+    def rebuild(v):
+        sp = next(it)
+        if sp is None:
+            return v
+        orig, shape, fdt, r0, cols = sp
+        out = moved[r0:r0 + cols].t().contiguous().view(fdt)
+        if torch.empty((), dtype=orig).element_size() == 8:
+            out = out.contiguous().view(orig)
+        elif out.dtype != orig:
+            out = (out != 0) if orig == torch.bool else out.to(orig)
+        return out.reshape(shape)
+    new = trace_map(trs, lambda v: rebuild(materialize(v)))
+    if stats is not None:
+        stats.update(collectives=dict(comm.counts) if comm is not None else {}, rows=R, capacity=C,
+                     form="tile statistics" if tiles_form else "cdf array")
     off = LogMLOffset().plus(mx, gtotal, shift, K)
-    out = ParticleCollection(new, torch.zeros((n,), dtype=torch.float32, device=dev), True, off)
+    out = ParticleCollection(new, None, True, off, n_zero=n)
     return out, lw

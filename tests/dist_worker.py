@@ -30,8 +30,9 @@ def schools_main(out_path, k_per_rank, capacity):
         theta = G.normal(mu * jnp.ones(8), jnp.exp(log_tau) * jnp.ones(8)) @ "theta"
         _ = G.normal(theta, jnp.array(parity.SCHOOL_SIGMA)) @ "y"
         return theta
+    info = {}
     coll, lw = sharded_importance_resample(G.Target(schools, (), C["y"].set(parity.SCHOOL_Y)), k_per_rank, G.key(2), dist,
-                                           capacity=capacity)
+                                           capacity=capacity, stats=info)
     ch = coll.get_particles().get_choices()
     outs = {}
     for name in ("theta", "mu"):
@@ -43,6 +44,7 @@ def schools_main(out_path, k_per_rank, capacity):
     dist.all_gather(lws, lw)
     if dist.get_rank() == 0:
         np.savez(out_path + ".npz", lw=torch.cat(lws).numpy(), log_ml=float(coll.get_log_marginal_likelihood_estimate()), **outs)
+        json.dump(info, open(out_path + ".info.json", "w"))
     dist.destroy_process_group()
 
 

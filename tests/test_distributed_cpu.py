@@ -143,6 +143,12 @@ def test_sharded_importancek_global_resample_equals_oracle(tmp_path, world, capa
     assert np.array_equal(got["theta"], oc.get_particles().get_choices()["theta"][anc])
     assert np.array_equal(got["mu"], oc.get_particles().get_choices()["mu"][anc])
     assert abs(float(got["log_ml"]) - float(oc.get_log_marginal_likelihood_estimate())) < 2e-5
+    # ONE plan for the whole 10-latent trace: one all-gather (tile statistics), ONE all-to-all (every row packed),
+    # one 8-byte all-reduce per capacity attempt — however many leaves the trace has
+    info = json.load(open(out + ".info.json"))
+    assert info["form"] == "tile statistics" and info["rows"] >= 10
+    assert info["collectives"]["all_gather"] == 1 and info["collectives"]["all_to_all"] == 1
+    assert 1 <= info["collectives"]["all_reduce_max"] <= 2
 
 
 def test_slot_bounds_match_ancestors():

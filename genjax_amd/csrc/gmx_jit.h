@@ -100,23 +100,27 @@ struct gmx_jit_ctx {
     ctx.consts = GMX_JIT_CONST; ctx.A = &A; ctx.lds4 = lds4; ctx.lds8 = lds8; ctx.part = 0; ctx.cur = 0; \
     ctx.rows = (uint32_t)((n + GMX_BLOCK - 1) / GMX_BLOCK); ctx.n_rows = n;      \
     regs_t R[PP];                                                                                \
+    /* particle rows as 32-bit numbers (gmx_program_run admits n < 2^31 for a specialised kernel): the 64-bit \
+       forms below are zero-extensions, so address arithmetic is a shift-add, not 64-bit compares / selects */  \
+    const uint32_t n32 = (uint32_t)n;                                                            \
     int64_t idx[PP];                                                                             \
-    int64_t cidx[PP];          /* idx clamped into [0, n): a valid row for prefetches of inactive lanes */ \
-    int64_t arow[PP];          /* ancestors[cidx] */                                             \
+    uint32_t cidx[PP];         /* idx clamped into [0, n): a valid row for prefetches of inactive lanes */ \
+    uint32_t arow[PP];         /* ancestors[cidx] */                                             \
     uint32_t pre[(NPRE) > 0 ? (NPRE) : 1][PP];                                                   \
     bool act[PP];                                                                                \
     uint32_t gmx_t = 0u;       /* iteration number of the enclosing GMX_JIT_LOOP (0 outside) */   \
     _Pragma("unroll") for (int p = 0; p < PP; ++p) {                                             \
       R[p].init();                                                                               \
-      idx[p] = ((int64_t)blockIdx.x * PP + p) * GMX_BLOCK + threadIdx.x;                         \
-      act[p] = idx[p] < n;                                                                       \
-      cidx[p] = act[p] ? idx[p] : n - 1;                                                         \
-      arow[p] = 0;                                                                               \
+      const uint32_t i32 = (blockIdx.x * (uint32_t)PP + (uint32_t)p) * (uint32_t)GMX_BLOCK + threadIdx.x; \
+      idx[p] = (int64_t)i32;                                                                     \
+      act[p] = i32 < n32;                                                                        \
+      cidx[p] = act[p] ? i32 : n32 - 1u;                                                         \
+      arow[p] = 0u;                                                                              \
     }                                                                                            \
     (void)cidx; (void)arow; (void)pre; (void)gmx_t;
 
 #define GMX_JIT_PRE_ANC                                                                          \
-    _Pragma("unroll") for (int p = 0; p < PP; ++p) arow[p] = (int64_t)A.ancestors_d[cidx[p]];
+    _Pragma("unroll") for (int p = 0; p < PP; ++p) arow[p] = (uint32_t)A.ancestors_d[cidx[p]];
 
 #define GMX_JIT_PRE_LOAD(K, SLOT, U8, ROW)                                                       \
     _Pragma("unroll") for (int p = 0; p < PP; ++p)                                               \

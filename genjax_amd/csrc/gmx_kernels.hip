@@ -550,6 +550,8 @@ extern "C" int gmx_program_run(const gmx_program* p, int64_t n, const gmx_run_ar
     args = &patched;
   }
   if (p->jit_fn) {
+    if (n >= 0x7fffffffLL - 4 * GMX_BLOCK)
+      return gmx_fail("gmx_program_run: a specialised kernel indexes particles with 32 bits (n < 2^31 - 1024)%s");
     struct { int64_t n; gmx_run_args A; } ka;
     ka.n = n; ka.A = *args;
     size_t ka_size = sizeof(ka);

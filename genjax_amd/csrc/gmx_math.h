@@ -178,10 +178,46 @@ GMX_HD float gmx_tanhf(float x) {
   return (gmx_f2u(x) >> 31) ? -t : t;
 }
 
+// -log1p(-x*x) for |x| <= 1, i.e. gmx_log1pf(-(x*x)) negated, with only the cases that argument can reach:
+// u = 1 - x*x lies in [0, 1] (never NaN / negative / infinite, and never denormal: it is 0 or >= 2^-24), so of
+// gmx_logf's and gmx_log1pf's special handling only "u == 1" (return the argument) and "u == 0" (log = -inf) are
+// live.  Same operation sequence on the main path, hence the same bits as the general functions for every such x
+// (tests: the oracle keeps the general form) — 14 vector instructions fewer per normal draw.
+GMX_HD float gmx_neg_log1m_sq(float x) {
+  const float t = -(x * x);
+  const float u = 1.0f + t;
+  const uint32_t us = gmx_f2u(u);
+  int e = (int)(us >> 23) - 126;
+  const float m = gmx_u2f((us & 0x007fffffu) | 0x3f000000u);
+  const int low = m < 0.707106781186547524f;
+  e -= low;
+  const float f = low ? (m + m) - 1.0f : m - 1.0f;
+  float z = f * f;
+  float p = 7.0376836292e-2f;
+  p = gmx_fma(p, f, -1.1514610310e-1f);
+  p = gmx_fma(p, f, 1.1676998740e-1f);
+  p = gmx_fma(p, f, -1.2420140846e-1f);
+  p = gmx_fma(p, f, 1.4249322787e-1f);
+  p = gmx_fma(p, f, -1.6668057665e-1f);
+  p = gmx_fma(p, f, 2.0000714765e-1f);
+  p = gmx_fma(p, f, -2.4999993993e-1f);
+  p = gmx_fma(p, f, 3.3333331174e-1f);
+  float y = (p * f) * z;
+  float ef = (float)e;
+  y = gmx_fma(ef, -2.12194440e-4f, y);
+  y = gmx_fma(-0.5f, z, y);
+  float l = f + y;
+  l = gmx_fma(ef, 0.693359375f, l);
+  l = (us == 0u) ? -gmx_inf() : l;          // log(0)
+  const float d = u - 1.0f;
+  float r = l * (t / d);                     // d == 0 only when u == 1: overridden
+  r = (u == 1.0f) ? t : r;
+  return -r;
+}
+
 // Inverse error function, XLA's f32 lowering of Giles' polynomial
-// (SURVEY.md App. A.2).  |x| == 1 -> +-inf.
-GMX_HD float gmx_erfinvf(float x) {
-  float w = -gmx_log1pf(-(x * x));
+// (SURVEY.md App. A.2), given w = -log1p(-x*x).  |x| == 1 -> +-inf.
+GMX_HD float gmx_erfinvf_from_w(float x, float w) {
   float p;
   if (w < 5.0f) {
     w = w - 2.5f;
@@ -209,6 +245,9 @@ GMX_HD float gmx_erfinvf(float x) {
   if (gmx_fabs(x) == 1.0f) return x * gmx_inf();
   return p * x;
 }
+GMX_HD float gmx_erfinvf(float x) { return gmx_erfinvf_from_w(x, -gmx_log1pf(-(x * x))); }
+// the same for |x| <= 1 (what a uniform draw feeds it): identical bits, fewer instructions
+GMX_HD float gmx_erfinvf_unit(float x) { return gmx_erfinvf_from_w(x, gmx_neg_log1m_sq(x)); }
 
 // log Gamma(x) for x > 0: shift x up to >= 8 with the recurrence, then the
 // Stirling series.  The product of shifts is accumulated in one log.

@@ -74,7 +74,7 @@ GMX_HD float gmx_uniform_from_bits(uint32_t bits, float lo, float hi) {
 GMX_HD float gmx_std_normal_from_bits(uint32_t bits) {
   const float lo = -0.99999994f;   // nextafter(-1, 0) in f32
   float u = gmx_uniform_from_bits(bits, lo, 1.0f);
-  return 1.41421354f * gmx_erfinvf(u);
+  return 1.41421354f * gmx_erfinvf_unit(u);     // |u| < 1 by construction
 }
 // jax.random.gumbel: -log(-log(uniform(tiny, 1))).
 GMX_HD float gmx_gumbel_from_bits(uint32_t bits) {

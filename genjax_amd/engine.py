@@ -53,7 +53,27 @@ class Gathered:
         return gather_leaves([self.source], self.ancestors)[0]
 
 
+class Broadcast:
+    """A tensor marked LAUNCH-UNIFORM whatever its shape: `vmap(f, in_axes=(0, None))` wraps its un-mapped tensor
+    arguments in this, so a vector whose length happens to equal the particle count is still one vector shared by
+    all particles (without the marker, batching is inferred from the leading shape)."""
+    __slots__ = ("t",)
+
+    def __init__(self, t):
+        self.t = t.t if isinstance(t, Broadcast) else t
+
+    @property
+    def shape(self):
+        return tuple(self.t.shape)
+
+    @property
+    def dtype(self):
+        return self.t.dtype
+
+
 def materialize(v):
+    if isinstance(v, Broadcast):
+        return v.t
     return v.materialize() if isinstance(v, Gathered) else v
 
 
@@ -83,6 +103,14 @@ def leaf_spec(v, batch: tuple):
         return ("uni", "i32")
     if isinstance(v, (float, np.floating)):
         return ("uni", "f32")
+    if isinstance(v, Broadcast):
+        t = v.t
+        dt = _TDT[t.dtype]
+        if t.ndim == 0:
+            return ("bcast", dt)
+        if t.ndim == 1 and t.shape[0] > DVEC_MAX:
+            return ("dtab", dt, tuple(t.shape))
+        return ("dvec", dt, tuple(t.shape))
     if isinstance(v, Gathered):
         if tuple(v.ancestors.shape) != tuple(batch):
             raise ValueError(f"gathered value with batch {tuple(v.ancestors.shape)} in a launch over {batch}")
@@ -509,6 +537,8 @@ class Compiled:
         soa_cache = {}
         for slot, j, e, kind in self.in_plan:
             v = leaves[j]
+            if isinstance(v, Broadcast):
+                v = v.t
             if kind == "gather":
                 if anc is None:
                     anc = v.ancestors
@@ -556,6 +586,8 @@ class Compiled:
                 A.tab_d[s] = t.data_ptr()
         for slot, j in self.tab_plan:
             tv = leaves[j]
+            if isinstance(tv, Broadcast):
+                tv = tv.t
             if isinstance(tv, np.ndarray):                 # a long host vector (leaf_spec: "dtab")
                 tv = torch.from_numpy(np.ascontiguousarray(tv.astype(np.float32) if tv.dtype.kind == "f" else tv.astype(np.int32)))
             t = _prepare_input(tv, "dvec", None, be)

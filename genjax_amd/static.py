@@ -723,7 +723,7 @@ def _infer_batch(values) -> tuple:
     event axes after the particle axes); pass batch_shape= when ambiguous."""
     shape = None
     for v in values:
-        if isinstance(v, (torch.Tensor, Gathered)) and len(v.shape):
+        if isinstance(v, (torch.Tensor, Gathered)) and len(v.shape):      # (engine.Broadcast leaves say nothing about the batch)
             s = tuple(v.shape)
             if shape is None:
                 shape = s

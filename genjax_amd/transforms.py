@@ -20,21 +20,61 @@ def jit(f=None, **_kw):
     return f
 
 
+def _map_leaves(v, fn):
+    from .core.choice_map import ChoiceMap
+    if isinstance(v, torch.Tensor):
+        return fn(v)
+    if isinstance(v, tuple):
+        return tuple(_map_leaves(x, fn) for x in v)
+    if isinstance(v, list):
+        return [_map_leaves(x, fn) for x in v]
+    if isinstance(v, dict):
+        return {k: _map_leaves(x, fn) for k, x in v.items()}
+    if isinstance(v, ChoiceMap):
+        return v.map_values(lambda x: _map_leaves(x, fn))
+    return v
+
+
 def vmap(f, in_axes=0, out_axes=0):
+    """`jax.vmap(f, in_axes, out_axes)` for functions built from this package's operations.  Those are batch
+    polymorphic already — a batched `Key` and tensors whose LEADING axis matches it run as one fused launch — so
+    mapping = arranging the arguments that way:
+      * an argument mapped along axis k != 0 has that axis moved to the front (every tensor leaf of a tuple / dict /
+        ChoiceMap argument);
+      * an argument with in_axes None is shared by all instances: its tensors are marked launch-uniform
+        (engine.Broadcast), so a vector whose length happens to equal the batch is not mistaken for per-instance data;
+      * mapped axis sizes are checked against each other;
+      * out_axes != 0 moves the leading axis of every tensor result there."""
+    from .engine import Broadcast
+
     def wrapped(*args):
         axes = in_axes if isinstance(in_axes, (tuple, list)) else (in_axes,) * len(args)
         if len(axes) != len(args):
             raise ValueError("vmap: in_axes does not match the number of arguments")
-        size = None
+        sizes = set()
+
+        def front(ax):
+            def go(t):
+                if t.ndim == 0:
+                    raise ValueError("vmap: cannot map over a 0-d tensor (use in_axes=None)")
+                sizes.add(int(t.shape[ax]))
+                return torch.movedim(t, ax, 0) if ax != 0 else t
+            return go
+        new = []
         for a, ax in zip(args, axes):
             if ax is None:
-                continue
-            if ax != 0:
-                raise NotImplementedError("vmap: only axis 0 (or None) is supported")
-            n = a.shape[0] if isinstance(a, (Key, torch.Tensor)) else None
-            if n is not None:
-                if size is not None and n != size:
-                    raise ValueError(f"vmap: mapped axis sizes differ ({size} vs {n})")
-                size = n
-        return f(*args)
+                new.append(_map_leaves(a, lambda t: Broadcast(t) if t.ndim >= 1 else t))
+            elif isinstance(a, Key):
+                if ax != 0:
+                    raise NotImplementedError("vmap: a Key is mapped along its leading axis")
+                sizes.add(int(a.shape[0]))
+                new.append(a)
+            else:
+                new.append(_map_leaves(a, front(int(ax))))
+        if len(sizes) > 1:
+            raise ValueError(f"vmap: mapped axis sizes differ ({sorted(sizes)})")
+        out = f(*new)
+        if out_axes not in (0, None):
+            out = _map_leaves(out, lambda t: torch.movedim(t, 0, int(out_axes)) if t.ndim > int(out_axes) else t)
+        return out
     return wrapped

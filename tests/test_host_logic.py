@@ -850,6 +850,32 @@ def test_eager_numpy_namespace_uses_the_device_math():
     assert f(jnp.exp(torch.tensor(1.0))) == pytest.approx(math.e, rel=1e-6)
 
 
+def test_vmap_in_axes_and_broadcast_marker():
+    """transforms.vmap maps: in_axes None marks tensors launch-uniform (a vector as long as the batch is NOT taken for
+    per-particle data), in_axes k != 0 moves the mapped axis to the front, out_axes moves the result axis."""
+    n = 20
+    w = torch.linspace(0.1, 2.0, n)                      # length == batch size: ambiguous without the marker
+    keys = genjax.split(genjax.key(1), n)
+
+    @genjax.gen
+    def m(scales):
+        return genjax.normal(0.0, scales[3]) @ "x"
+    x = genjax.vmap(lambda k, s: m.simulate(k, (s,)).get_retval(), in_axes=(0, None))(keys, w)
+    okeys = O.fold_in(O.split(O.key(1), n), 1)
+    assert np.array_equal(x.numpy(), O.normal.sample(okeys, np.float32(0.0), np.float32(w[3].item())))
+    locs = torch.arange(3 * n, dtype=torch.float32).reshape(3, n)
+
+    @genjax.gen
+    def m2(loc):
+        return genjax.normal(loc[1], 1.0) @ "x"
+    y = genjax.vmap(lambda k, l: m2.simulate(k, (l,)).get_retval(), in_axes=(0, 1))(keys, locs)
+    assert np.array_equal(y.numpy(), O.normal.sample(okeys, locs[1].numpy(), np.float32(1.0)))
+    z = genjax.vmap(lambda k, l: l * 2.0, in_axes=(0, 1), out_axes=1)(keys, locs)
+    assert tuple(z.shape) == (3, n)
+    with pytest.raises(ValueError):
+        genjax.vmap(lambda k, l: l, in_axes=(0, 0))(keys, locs)          # 20 keys vs a leading axis of 3
+
+
 def test_program_limits():
     """<= 64 live 32-bit values per particle (<= 32 for the interpreter, up to 64 for specialised
     kernels); a model that needs more fails loudly at trace time instead of spilling silently."""

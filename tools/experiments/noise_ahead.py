@@ -1,0 +1,167 @@
+"""EXPERIMENT (not product): does drawing step t+1's standard-normal noise in a SEPARATE kernel on a second stream —
+concurrently with step t's resampling — shorten the bootstrap sweep?  The whole step is bound by vector-instruction
+issue, so this only helps if the runtime overlaps the noise kernel with the kernel boundaries and
+load / store phases of the dependent chain  [site program' -> offspring].
+
+  chain  (stream A):  J_t: x = 0.9 x_prev[anc] + 0.5 z_t ; lw = log N(y_t; x, 1) ; tile stats   ->  O_t: ancestors
+  noise  (stream B):  N_t: z_t = sqrt(2) erfinv(bits(fold_in(split(k_prop_t, n)[i], 1)))        (keys only)
+
+Same keys, same float operations as the fused site program (x = z * sx, then + a * x_prev), so states / ancestors /
+evidence must equal BootstrapSweep's bit for bit — checked below.  Prints one JSON line with both timings.
+"""
+import json
+import os
+import sys
+import time
+from ctypes import c_uint32
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+
+import genjax_amd as G
+from genjax_amd import _lib, workloads
+from genjax_amd.core.choice_map import ChoiceMap
+from genjax_amd.engine import Gathered
+from genjax_amd.inference.smc import BootstrapSweep, cdf_shift
+from genjax_amd.random import fold_in, lazy_split, split
+from genjax_amd.static import MinimalGenerate
+
+n, T = int(os.environ.get("N", 1_000_000)), int(os.environ.get("T", 100))
+be = _lib.get()
+dev = be.device
+ys_np = workloads.lgssm_data(T)
+ys = torch.from_numpy(ys_np).to(dev)
+key = G.key(314159)
+init, step = workloads.make_lgssm(G)
+
+# reference: the product's fused sweep
+ref = BootstrapSweep(init, step, n, T).prepare(key, torch.from_numpy(ys_np))
+ref.capture()
+ref.launch()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(20):
+    ref.launch()
+torch.cuda.synchronize()
+dt_ref = (time.perf_counter() - t0) / 20
+x_ref, lw_ref, anc_ref = [v.clone() for v in ref.state()]
+
+
+@G.gen
+def noise():
+    return G.normal(0.0, 1.0) @ "x"
+
+
+@G.gen
+def j_init(z):
+    x = z * 1.0
+    G.normal(x, 1.0) @ "y"
+    return x
+
+
+@G.gen
+def j_step(x_prev, z):
+    v = z * 0.5
+    x = v + 0.9 * x_prev
+    G.normal(x, 1.0) @ "y"
+    return x
+
+
+shift = cdf_shift(n)
+z = [torch.zeros((1, n), dtype=torch.float32, device=dev) for _ in range(2)]
+xs = [torch.zeros((1, n), dtype=torch.float32, device=dev) for _ in range(2)]
+lw = torch.zeros((n,), dtype=torch.float32, device=dev)
+wdummy = torch.zeros((1, n), dtype=torch.float32, device=dev)
+anc = torch.zeros((n,), dtype=torch.int32, device=dev)
+partials = torch.zeros((2, (n + 255) // 256), dtype=torch.float32, device=dev)
+npart = torch.zeros((2, (n + 255) // 256), dtype=torch.float32, device=dev)
+tile_agg = torch.zeros(((n + 1023) // 1024,), dtype=torch.int64, device=dev)
+maxs = torch.zeros((T,), dtype=torch.float32, device=dev)
+totals = torch.zeros((T,), dtype=torch.int64, device=dev)
+obs0 = ChoiceMap.empty().set("y", ys[0])
+pN = MinimalGenerate(noise, (), ChoiceMap.empty(), (n,))
+pJ0 = MinimalGenerate(j_init, (z[0].reshape(n),), obs0, (n,))
+pJ = MinimalGenerate(j_step, (Gathered(xs[0].reshape(n), anc), z[0].reshape(n)), obs0, (n,))
+for p in (pN, pJ0, pJ):
+    p.comp.specialize()
+assert pJ.comp.writes_tile_stats() and pJ0.comp.writes_tile_stats()
+keys = [split(fold_in(key, t), 3) for t in range(T)]
+
+
+def launch_noise(t):
+    bufs = [None] * len(pN.comp.outputs)
+    bufs[pN.ro[1]] = z[t % 2]
+    if pN.wo[0] == "out":
+        bufs[pN.wo[1]] = wdummy
+    pN.comp.run(pN.leaves((), ChoiceMap.empty()), (n,), lazy_split(keys[t][0], n), red_out=npart, out_buffers=bufs)
+
+
+def launch_j(t):
+    obs = ChoiceMap.empty().set("y", ys[t])
+    if t == 0:
+        prog, leaves = pJ0, pJ0.leaves((z[0].reshape(n),), obs)
+    else:
+        prog = pJ
+        leaves = prog.leaves((Gathered(xs[(t - 1) % 2].reshape(n), anc), z[t % 2].reshape(n)), obs)
+    bufs = [None] * len(prog.comp.outputs)
+    bufs[prog.ro[1]] = xs[t % 2]
+    bufs[prog.wo[1]] = lw.reshape(1, n)
+    prog.comp.run(leaves, (n,), None, red_out=partials, out_buffers=bufs, tile_stats=(tile_agg, shift))
+
+
+def launch_o(t):
+    kh = keys[t][1].host()
+    kk = (c_uint32 * 2)(int(kh[0]), int(kh[1]))
+    be.check(be.c.gmx_resample_tiles(0, kk, be.ptr(lw), n, shift, be.ptr(partials), be.ptr(tile_agg),
+                                     be.ptr(maxs[t:t + 1]), be.ptr(totals[t:t + 1]), be.ptr(anc), be.stream()), "resample")
+
+
+def enqueue(two_streams: bool):
+    A = torch.cuda.current_stream()
+    B = torch.cuda.Stream() if two_streams else A
+    done_j = [None] * T
+    ready_z = [None] * T
+    if two_streams:
+        B.wait_stream(A)
+    for t in range(T):
+        with torch.cuda.stream(B):
+            if two_streams and t >= 2:
+                B.wait_event(done_j[t - 2])             # z[t % 2] is free once J_{t-2} has read it
+            launch_noise(t)
+            if two_streams:
+                ready_z[t] = torch.cuda.Event()
+                ready_z[t].record(B)
+        if two_streams:
+            A.wait_event(ready_z[t])
+        launch_j(t)
+        if two_streams:
+            done_j[t] = torch.cuda.Event()
+            done_j[t].record(A)
+        launch_o(t)
+    if two_streams:
+        A.wait_stream(B)
+
+
+out = {"n": n, "T": T, "fused_sweep_us_per_step": 1e6 * dt_ref / T}
+for two in (False, True):
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        enqueue(two)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    same = bool(torch.equal(xs[(T - 1) % 2].reshape(n), x_ref) and torch.equal(anc, anc_ref) and torch.equal(lw, lw_ref))
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        enqueue(two)
+    g.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        g.replay()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 20
+    out["split_two_streams" if two else "split_one_stream"] = {"us_per_step": 1e6 * dt / T, "bit_identical_to_fused": same}
+print(json.dumps(out))

@@ -217,31 +217,36 @@ GMX_HD float gmx_neg_log1m_sq(float x) {
 
 // Inverse error function, XLA's f32 lowering of Giles' polynomial
 // (SURVEY.md App. A.2), given w = -log1p(-x*x).  |x| == 1 -> +-inf.
+GMX_HD float gmx_erfinv_central(float w) {      // w < 5
+  w = w - 2.5f;
+  float p = 2.81022636e-08f;
+  p = gmx_fma(p, w, 3.43273939e-07f);
+  p = gmx_fma(p, w, -3.5233877e-06f);
+  p = gmx_fma(p, w, -4.39150654e-06f);
+  p = gmx_fma(p, w, 0.00021858087f);
+  p = gmx_fma(p, w, -0.00125372503f);
+  p = gmx_fma(p, w, -0.00417768164f);
+  p = gmx_fma(p, w, 0.246640727f);
+  p = gmx_fma(p, w, 1.50140941f);
+  return p;
+}
+GMX_HD float gmx_erfinv_tail(float w) {         // w >= 5 (and NaN)
+  w = gmx_sqrtf(w) - 3.0f;
+  float p = -0.000200214257f;
+  p = gmx_fma(p, w, 0.000100950558f);
+  p = gmx_fma(p, w, 0.00134934322f);
+  p = gmx_fma(p, w, -0.00367342844f);
+  p = gmx_fma(p, w, 0.00573950773f);
+  p = gmx_fma(p, w, -0.0076224613f);
+  p = gmx_fma(p, w, 0.00943887047f);
+  p = gmx_fma(p, w, 1.00167406f);
+  p = gmx_fma(p, w, 2.83297682f);
+  return p;
+}
 GMX_HD float gmx_erfinvf_from_w(float x, float w) {
   float p;
-  if (w < 5.0f) {
-    w = w - 2.5f;
-    p = 2.81022636e-08f;
-    p = gmx_fma(p, w, 3.43273939e-07f);
-    p = gmx_fma(p, w, -3.5233877e-06f);
-    p = gmx_fma(p, w, -4.39150654e-06f);
-    p = gmx_fma(p, w, 0.00021858087f);
-    p = gmx_fma(p, w, -0.00125372503f);
-    p = gmx_fma(p, w, -0.00417768164f);
-    p = gmx_fma(p, w, 0.246640727f);
-    p = gmx_fma(p, w, 1.50140941f);
-  } else {
-    w = gmx_sqrtf(w) - 3.0f;
-    p = -0.000200214257f;
-    p = gmx_fma(p, w, 0.000100950558f);
-    p = gmx_fma(p, w, 0.00134934322f);
-    p = gmx_fma(p, w, -0.00367342844f);
-    p = gmx_fma(p, w, 0.00573950773f);
-    p = gmx_fma(p, w, -0.0076224613f);
-    p = gmx_fma(p, w, 0.00943887047f);
-    p = gmx_fma(p, w, 1.00167406f);
-    p = gmx_fma(p, w, 2.83297682f);
-  }
+  if (w < 5.0f) p = gmx_erfinv_central(w);
+  else p = gmx_erfinv_tail(w);
   if (gmx_fabs(x) == 1.0f) return x * gmx_inf();
   return p * x;
 }

@@ -1353,25 +1353,36 @@ __device__ __forceinline__ sb_est slots_below_est(gmx_key key, uint32_t u0, uint
   return r;
 }
 
-// One thread owns 4 consecutive sources (one float4 of log-weights); a block is one tile.
-// Every load is issued before anything waits (unconditional, clamped addresses), wave-level reductions and scans
-// are DPP (gmx_block.h), the slot ranges are straight-line f64 code with one cold exact path.
+// One thread owns 4 consecutive sources (one float4 of log-weights); 256 threads are one tile; a block is
+// RS_TPB = 4 consecutive tiles (1024 threads): every block has to turn ALL tile statistics into its prefix and the
+// total, and with four tiles to a block that pass is shared by four tiles and spread over 1024 threads (one table
+// entry per thread at 1e6 particles instead of four).  Every load is issued before anything waits (unconditional,
+// clamped addresses), wave-level reductions and scans are DPP (gmx_block.h), the slot ranges are straight-line f64
+// code with one cold exact path.
 // FROMQ: the per-particle fixed-point weights come from memory (`qin`, written by the site program's epilogue:
 // gmx_run_args.tile_q_d) instead of being recomputed from the log-weights (one exp + one f32 -> u64 conversion each).
+#define RS_TPB 4
+#define RS_BLOCK (GMX_BLOCK * RS_TPB)
+#define RS_WAVES (RS_BLOCK / GMX_WAVE)
+static_assert(RS_MAX_TILES % RS_BLOCK == 0, "tile table shape");
 template <int kind, bool FROMQ>
-__global__ void __launch_bounds__(GMX_BLOCK)
+__global__ void __launch_bounds__(RS_BLOCK)
 k_offspring_tile(uint32_t k0, uint32_t k1, uint32_t u0_host, const float* __restrict__ lw, const uint64_t* __restrict__ qin,
                  const float* __restrict__ tmax, const uint64_t* __restrict__ agg, int64_t n, int n_tiles, float scale,
                  float* __restrict__ max_out, uint64_t* __restrict__ total_out, int32_t* __restrict__ anc) {
-  __shared__ uint64_t s_below[4], s_all[4], s_scan[4];
-  __shared__ float s_max[4];
+  __shared__ uint64_t s_below[RS_WAVES], s_all[RS_WAVES], s_scan[RS_WAVES], s_g[RS_TPB];
+  __shared__ float s_max[RS_WAVES];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int my_tile = (int)blockIdx.x;
-  const int64_t i0 = (int64_t)my_tile * RS_TILE + (int64_t)threadIdx.x * CDF_VEC;
+  const int grp = threadIdx.x >> 8, ltid = threadIdx.x & (GMX_BLOCK - 1);      // which of the block's tiles / thread within it
+  const int first_tile = (int)blockIdx.x * RS_TPB;
+  const int my_tile = first_tile + grp;
+  const bool tile_ok = my_tile < n_tiles;                                        // wave-uniform
+  const int tile_c = tile_ok ? my_tile : n_tiles - 1;
+  const int64_t i0 = (int64_t)tile_c * RS_TILE + (int64_t)ltid * CDF_VEC;
   // ---- issue every load first ----
   float x[CDF_VEC];
   uint64_t qw[CDF_VEC];
-  const bool full_tile = (int64_t)(my_tile + 1) * RS_TILE <= n;      // block-uniform
+  const bool full_tile = (int64_t)(tile_c + 1) * RS_TILE <= n;                   // wave-uniform
   if (FROMQ) {
     if (full_tile) {
       const ulonglong2 a = reinterpret_cast<const ulonglong2*>(qin + i0)[0];
@@ -1396,71 +1407,79 @@ k_offspring_tile(uint32_t k0, uint32_t k1, uint32_t u0_host, const float* __rest
       x[c] = (i0 + c < n) ? xv : -gmx_inf();
     }
   }
-  constexpr int PER = RS_MAX_TILES / GMX_BLOCK;
+  constexpr int PER = RS_MAX_TILES / RS_BLOCK;
   uint64_t ta[PER];
   float tm[PER];
 #pragma unroll
   for (int r = 0; r < PER; ++r) {                // loads only (clamped rows): nothing here waits
     ta[r] = 0ull; tm[r] = -gmx_inf();
-    if (r * GMX_BLOCK < n_tiles) {               // uniform: rows of the table that exist
-      const int t = r * GMX_BLOCK + (int)threadIdx.x;
+    if (r * RS_BLOCK < n_tiles) {                // uniform: rows of the table that exist
+      const int t = r * RS_BLOCK + (int)threadIdx.x;
       const int tc = t < n_tiles ? t : n_tiles - 1;
       ta[r] = agg[tc];
       tm[r] = tmax[tc];
     }
   }
-  const float tmax_mine = tmax[my_tile];
+  const float tmax_mine = tmax[tile_c];
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int r = 0; r < PER; ++r) {
-    const int t = r * GMX_BLOCK + (int)threadIdx.x;
+    const int t = r * RS_BLOCK + (int)threadIdx.x;
     ta[r] = (t < n_tiles) ? ta[r] : 0ull;
     tm[r] = (t < n_tiles) ? tm[r] : -gmx_inf();
   }
   const int32_t k_b = gmx_tile_exp(tmax_mine);
   const float ref_b = gmx_tile_ref(k_b);
-  // phase 1: the global max, and the wave totals of this tile's local weights
+  // phase 1: the global max, and the wave totals of each tile's local weights
   float M = -gmx_inf();
 #pragma unroll
   for (int r = 0; r < PER; ++r)
-    if (r * GMX_BLOCK < n_tiles) M = gmx_fmax(M, tm[r]);
+    if (r * RS_BLOCK < n_tiles) M = gmx_fmax(M, tm[r]);
   M = wave_max(M);
   uint64_t q[CDF_VEC];
   uint64_t run = 0;
 #pragma unroll
   for (int c = 0; c < CDF_VEC; ++c) {
     const uint64_t w = FROMQ ? qw[c] : weight_fixed(x[c], ref_b, scale);
-    run += (i0 + c < n) ? w : 0ull;
+    run += (tile_ok && i0 + c < n) ? w : 0ull;
     q[c] = run;
   }
   const uint64_t inc = wave_scan_u64(run);
   if (lane == 0) s_max[wave] = M;
   if (lane == 63) s_scan[wave] = inc;
   __syncthreads();
-  M = gmx_fmax(gmx_fmax(s_max[0], s_max[1]), gmx_fmax(s_max[2], s_max[3]));
+  M = s_max[0];
+#pragma unroll
+  for (int w = 1; w < RS_WAVES; ++w) M = gmx_fmax(M, s_max[w]);
   uint64_t wave_off = 0;
 #pragma unroll
-  for (int w = 0; w < 4; ++w) wave_off += (w < wave) ? s_scan[w] : 0ull;
+  for (int w = 0; w < 4; ++w) wave_off += (w < (wave & 3)) ? s_scan[4 * grp + w] : 0ull;
   const uint64_t loc = wave_off + (inc - run);          // tile-local mass before this thread's sources
-  // phase 2: G_t = A_t * 2^(k_t - K) for every tile -> this tile's prefix and the total
+  // phase 2: G_t = A_t * 2^(k_t - K) for every tile -> the mass before this block's first tile, the block's own
+  // four G, and the total
   const int32_t K = gmx_tile_exp(M);
   uint64_t below = 0, all = 0;
 #pragma unroll
   for (int r = 0; r < PER; ++r) {
-    if (r * GMX_BLOCK < n_tiles) {
-      const int t = r * GMX_BLOCK + (int)threadIdx.x;
+    if (r * RS_BLOCK < n_tiles) {
+      const int t = r * RS_BLOCK + (int)threadIdx.x;
       const uint64_t G = gmx_tile_scale(ta[r], gmx_tile_exp(tm[r]), K);
       all += G;
-      below += (t < my_tile) ? G : 0ull;
+      below += (t < first_tile) ? G : 0ull;
+      if (t >= first_tile && t < first_tile + RS_TPB) s_g[t - first_tile] = G;      // t >= n_tiles: G = 0
     }
   }
   below = wave_sum_u64(below);
   all = wave_sum_u64(all);
   if (lane == 0) { s_below[wave] = below; s_all[wave] = all; }
   __syncthreads();
-  const uint64_t prefix = (s_below[0] + s_below[1]) + (s_below[2] + s_below[3]);
-  const uint64_t total = (s_all[0] + s_all[1]) + (s_all[2] + s_all[3]);
+  uint64_t prefix = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < RS_WAVES; ++w) { prefix += s_below[w]; total += s_all[w]; }
+#pragma unroll
+  for (int j = 0; j < RS_TPB; ++j) prefix += (j < grp) ? s_g[j] : 0ull;
   if (blockIdx.x == 0 && threadIdx.x == 0) { *total_out = total; *max_out = M; }
+  if (!tile_ok) return;                                  // a whole tile group past the end (uniform per wave; no barrier follows)
   gmx_key key; key.k0 = k0; key.k1 = k1;
   if (total == 0) {       // no mass at all (all weights -inf / NaN): every slot maps to the last particle
 #pragma unroll
@@ -1537,7 +1556,7 @@ static int launch_offspring_tile(int kind, const uint32_t key[2], const float* l
   gmx_threefry2x32(key[0], key[1], 0u, 0u, &b0, &b1);           // bits32(key, 0) on the host
   const uint32_t u0 = (b0 ^ b1) >> 9;
   const int64_t tiles = (n + RS_TILE - 1) / RS_TILE;
-  const dim3 grid((unsigned)tiles), block(GMX_BLOCK);
+  const dim3 grid((unsigned)((tiles + RS_TPB - 1) / RS_TPB)), block(RS_BLOCK);
   hipStream_t st = (hipStream_t)stream;
   const float scale = gmx_pow2i(shift);
 #define GMX_LAUNCH_OT(KIND, FQ)                                                                                     \

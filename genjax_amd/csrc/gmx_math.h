@@ -103,6 +103,32 @@ GMX_HD float gmx_expf(float x) {
   return nan ? x : y;
 }
 
+// exp(x) for x <= 0 (or a hair above: anything <= 88) and NaN: gmx_expf without the overflow clamp and without the
+// explicit NaN select (a NaN argument reaches the result through the polynomial on its own).  Same bits as
+// gmx_expf on that domain; used for the CDF weights exp(lw - ref), ref >= the tile's largest log-weight.
+GMX_HD float gmx_expf_nonpos(float x) {
+  const float lo = -87.33654022216797f;
+  float xc = x < lo ? lo : x;                       // NaN stays NaN
+  float kf = __builtin_rintf(xc * 1.44269502162933349609375f);
+  float r = gmx_fma(kf, -0.693359375f, xc);
+  r = gmx_fma(kf, 2.12194440e-4f, r);
+  float p = 1.9875691500e-4f;
+  p = gmx_fma(p, r, 1.3981999507e-3f);
+  p = gmx_fma(p, r, 8.3334519073e-3f);
+  p = gmx_fma(p, r, 4.1665795894e-2f);
+  p = gmx_fma(p, r, 1.6666665459e-1f);
+  p = gmx_fma(p, r, 5.0000001201e-1f);
+  float r2 = r * r;
+  p = gmx_fma(p, r2, r);
+  p = p + 1.0f;
+  int k = gmx_isnan(x) ? 0 : (int)kf;               // (int)NaN is not portable: pin it
+  int k1 = k >> 1;
+  int k2 = k - k1;
+  float y = (p * gmx_pow2i(k1)) * gmx_pow2i(k2);
+  y = y < 1.17549435e-38f ? 0.0f : y;               // false for NaN
+  return x < lo ? 0.0f : y;
+}
+
 // log(x), natural.  cephes logf polynomial on [sqrt(1/2), sqrt(2)).
 // Straight-line like gmx_expf: special cases are selects over the main path's result.
 GMX_HD float gmx_logf(float x) {

@@ -1353,15 +1353,19 @@ __device__ __forceinline__ sb_est slots_below_est(gmx_key key, uint32_t u0, uint
   return r;
 }
 
-// One thread owns 4 consecutive sources (one float4 of log-weights); 256 threads are one tile; a block is
-// RS_TPB = 4 consecutive tiles (1024 threads): every block has to turn ALL tile statistics into its prefix and the
-// total, and with four tiles to a block that pass is shared by four tiles and spread over 1024 threads (one table
-// entry per thread at 1e6 particles instead of four).  Every load is issued before anything waits (unconditional,
-// clamped addresses), wave-level reductions and scans are DPP (gmx_block.h), the slot ranges are straight-line f64
-// code with one cold exact path.
+// One thread owns 4 consecutive sources (one float4 of log-weights); 256 threads are one tile; a block is RS_TPB
+// consecutive tiles.  RS_TPB = 1.  Every block has to turn ALL tile statistics into its prefix and the total, and
+// with RS_TPB = 4 (1024 threads) that pass is shared by four tiles — measured on MI355X (config 2): the kernel
+// itself 7.8 -> 7.3 us per launch, but the site program that follows went 13.1 -> 14.9 us: with one tile per
+// 256-thread block, tile j of BOTH kernels runs as block j, i.e. on XCD j mod 8 (blocks are dealt round-robin), so
+// the log-weights, ancestors and states one kernel leaves are found in that XCD's L2 by the other; four consecutive
+// tiles per block put three of them on another XCD.  (An interleaved assignment — tiles b mod 8 + 8 k — would keep the
+// affinity; it needs four separate prefixes per block and gives most of the saving back.)
+// Every load is issued before anything waits (unconditional, clamped addresses), wave-level reductions and scans are
+// DPP (gmx_block.h), the slot ranges are straight-line f64 code with one cold exact path.
 // FROMQ: the per-particle fixed-point weights come from memory (`qin`, written by the site program's epilogue:
 // gmx_run_args.tile_q_d) instead of being recomputed from the log-weights (one exp + one f32 -> u64 conversion each).
-#define RS_TPB 4
+#define RS_TPB 1
 #define RS_BLOCK (GMX_BLOCK * RS_TPB)
 #define RS_WAVES (RS_BLOCK / GMX_WAVE)
 static_assert(RS_MAX_TILES % RS_BLOCK == 0, "tile table shape");
@@ -1453,7 +1457,7 @@ k_offspring_tile(uint32_t k0, uint32_t k1, uint32_t u0_host, const float* __rest
   for (int w = 1; w < RS_WAVES; ++w) M = gmx_fmax(M, s_max[w]);
   uint64_t wave_off = 0;
 #pragma unroll
-  for (int w = 0; w < 4; ++w) wave_off += (w < (wave & 3)) ? s_scan[4 * grp + w] : 0ull;
+  for (int w = 0; w < 4; ++w) wave_off += (w < (wave & 3)) ? s_scan[4 * grp + w] : 0ull;     // the tile's own four waves
   const uint64_t loc = wave_off + (inc - run);          // tile-local mass before this thread's sources
   // phase 2: G_t = A_t * 2^(k_t - K) for every tile -> the mass before this block's first tile, the block's own
   // four G, and the total

@@ -349,6 +349,13 @@ static uint64_t fnv1a(uint64_t h, const char* s, size_t n) {
   return h;
 }
 
+// GENMI_JIT_DEFS: one extra option for hiprtc (e.g. -DGMX_DIAG_...=...): DIAGNOSTIC builds only — timing experiments
+// that switch parts of the device code off; it is part of the code-object cache key.
+static const char* jit_extra_def() {
+  const char* e = getenv("GENMI_JIT_DEFS");
+  return (e && e[0] == '-') ? e : nullptr;
+}
+
 static std::string jit_cache_dir() {
   const char* e = getenv("GENMI_JIT_CACHE");
   if (e && e[0] == '0' && e[1] == '\0') return "";
@@ -369,6 +376,7 @@ static std::string jit_cache_path(const std::string& src) {
   std::string dir = jit_cache_dir();
   if (dir.empty()) return "";
   uint64_t h = fnv1a(0xcbf29ce484222325ull, src.data(), src.size());
+  if (jit_extra_def()) h = fnv1a(h, jit_extra_def(), strlen(jit_extra_def()));
   for (int k = 0; k < GMX_EMBED_COUNT; ++k) h = fnv1a(h, gmx_embed_src[k], strlen(gmx_embed_src[k]));
   int major = 0, minor = 0;
   (void)hiprtcVersion(&major, &minor);
@@ -413,8 +421,10 @@ static int jit_compile(const std::string& src, std::vector<char>& code) {
   for (int k = 0; k < GMX_EMBED_COUNT; ++k) { hdr_src[k] = gmx_embed_src[k]; hdr_name[k] = gmx_embed_name[k]; }
   hiprtcResult rc = hiprtcCreateProgram(&prog, src.c_str(), "gmx_jit_program.hip", GMX_EMBED_COUNT, hdr_src, hdr_name);
   if (rc != HIPRTC_SUCCESS) return gmx_fail("hiprtcCreateProgram: %s", hiprtcGetErrorString(rc));
-  const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"};
-  rc = hiprtcCompileProgram(prog, 4, opts);
+  const char* opts[5] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", nullptr};
+  int n_opts = 4;
+  if (jit_extra_def()) opts[n_opts++] = jit_extra_def();
+  rc = hiprtcCompileProgram(prog, n_opts, opts);
   if (rc != HIPRTC_SUCCESS) {
     size_t ls = 0;
     hiprtcGetProgramLogSize(prog, &ls);

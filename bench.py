@@ -37,9 +37,9 @@ os.environ.setdefault("OMP_WAIT_POLICY", "ACTIVE")
 
 N_PARTICLES = 1_000_000
 T_STEPS = 100
-VM_VALU_PER_WAVE = 376.2            # VALU instructions per 64 particles: SQ_INSTS_VALU / waves / 4 particles per
-                                    # thread (1504.7 per wave, profiles/r01_o_pmc_summary.txt: 1285.7 for the site
-                                    # program + 219 for the CDF tile statistics it now writes in its epilogue)
+VM_VALU_PER_WAVE = 359.7            # VALU instructions per 64 particles: SQ_INSTS_VALU / waves / 4 particles per
+                                    # thread (1438.6 per wave, profiles/r02_pmc_summary.txt; 1531.6 before the
+                                    # domain-restricted log1p / 32-bit rows of this round, 1496.7 at the end of round 1)
 VALU_PEAK_LANE_OPS = 256 * 4 * 16 * 2.4e9   # integer / unpacked-f32 vector instructions: 16 lanes per clock per SIMD (a
                                             # wave64 instruction holds its SIMD for 4 cycles; only packed f32 math doubles
                                             # that).  tools/calib.hip on MI355X (profiles/r02_calib.txt): one Threefry-like

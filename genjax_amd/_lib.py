@@ -20,9 +20,27 @@ GMX_MAX_OUT = 64
 GMX_MAX_TAB = 8
 GMX_MAX_UNI = 64
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 KEY_NONE, KEY_ARRAY, KEY_SPLIT, KEY_ROWSPLIT, KEY_BCAST = 0, 1, 2, 3, 4
 RESAMPLE_SYSTEMATIC, RESAMPLE_STRATIFIED, RESAMPLE_MULTINOMIAL = 0, 1, 2
+
+
+class ResampleIn(Structure):
+    """struct gmx_resample_in: the resampling step folded into the next site program's launch"""
+    _fields_ = [
+        ("lw_d", c_void_p),
+        ("tile_max_d", c_void_p),
+        ("tile_agg_d", c_void_p),
+        ("anc_out_d", c_void_p),
+        ("max_out_d", c_void_p),
+        ("total_out_d", c_void_p),
+        ("kind", c_int32),
+        ("shift", c_int32),
+        ("key0", c_uint32),
+        ("key1", c_uint32),
+        ("u0", c_uint32),
+        ("reserved_", c_uint32),
+    ]
 
 
 class RunArgs(Structure):
@@ -45,6 +63,7 @@ class RunArgs(Structure):
         ("reserved_", c_int32),
         ("step_stride", c_int64),
         ("tile_q_d", c_void_p),
+        ("rs", ResampleIn),
     ]
 
 
@@ -83,6 +102,7 @@ class Backend:
         c.gmx_program_grid.restype = c_int64
         c.gmx_program_run.argtypes = [c_void_p, c_int64, POINTER(RunArgs), c_void_p]
         c.gmx_program_writes_tile_stats.argtypes = [c_void_p]
+        c.gmx_program_fuses_resample.argtypes = [c_void_p]
         c.gmx_logsumexp_workspace.argtypes = [c_int64, c_int64]
         c.gmx_logsumexp_workspace.restype = c_size_t
         c.gmx_logsumexp.argtypes = [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]

@@ -97,12 +97,8 @@ __device__ __forceinline__ uint64_t shfl_up_u64(uint64_t v, int d) {
   return ((uint64_t)hi << 32) | lo;
 }
 
-// q = floor(exp(lw - ref) * 2^shift) as u64; NaN / negative / not below 2^63 (lw = +inf) -> 0
+// q = floor(exp(lw - ref) * 2^shift) as u64; NaN / negative / not below 2^63 (lw = +inf) -> 0.  `scale` = 2^shift
+// (launch-uniform: its exponent is read back on the scalar unit); the integer form is gmx_math.h's gmx_exp_fixed.
 __device__ __forceinline__ uint64_t weight_fixed(float lw, float ref, float scale) {
-  float w = gmx_expf_nonpos(lw - ref); // lw <= ref up to rounding (ref = ceil(tile max / ln 2) ln 2); NaN if lw - ref is NaN;
-                                       // lw = +inf gives +inf here (the polynomial on a clamped-from-below argument
-                                       // is not evaluated beyond 88): caught by the range check below
-  float q = w * scale;                 // exact: scale is a power of two
-  if (!(q >= 0.0f) || !(q < 0x1p63f)) return 0ull;
-  return (uint64_t)q;                  // truncation
+  return gmx_exp_fixed(lw - ref, (int)(gmx_f2u(scale) >> 23) - 127);
 }

@@ -18,6 +18,10 @@
 #pragma once
 #include "gmx_block.h"
 #include "gmx_vm.h"
+#if defined(GMX_JIT_RS)      /* gmx_program_specialize under GENMI_FUSE_RESAMPLE=1: the kernel can resample first */
+#include "gmx_resample.h"
+extern __shared__ __attribute__((aligned(16))) char gmx_dyn_lds[];   // gmx_rs_window_lds(n) bytes when A.rs.lw_d is set
+#endif
 
 template <int NDYN, int PPV>
 struct gmx_jit_ctx {
@@ -119,8 +123,22 @@ struct gmx_jit_ctx {
     }                                                                                            \
     (void)cidx; (void)arow; (void)pre; (void)gmx_t;
 
+// the ancestors of the thread's particles: loaded — or, for a fused bootstrap step (gmx_run_args.rs), computed
+// here from the previous step's log-weights and tile statistics (gmx_resample.h; workgroup-uniform branch)
+#if defined(GMX_JIT_RS)
+#define GMX_JIT_PRE_ANC                                                                          \
+    if (PP == 4 && A.rs.lw_d) {                                                                  \
+      if (A.rs.kind == GMX_RESAMPLE_SYSTEMATIC)                                                  \
+        gmx_rs_window<GMX_RESAMPLE_SYSTEMATIC>(A.rs, n, arow, gmx_dyn_lds);                      \
+      else                                                                                       \
+        gmx_rs_window<GMX_RESAMPLE_STRATIFIED>(A.rs, n, arow, gmx_dyn_lds);                      \
+    } else {                                                                                     \
+      _Pragma("unroll") for (int p = 0; p < PP; ++p) arow[p] = (uint32_t)A.ancestors_d[cidx[p]]; \
+    }
+#else
 #define GMX_JIT_PRE_ANC                                                                          \
     _Pragma("unroll") for (int p = 0; p < PP; ++p) arow[p] = (uint32_t)A.ancestors_d[cidx[p]];
+#endif
 
 #define GMX_JIT_PRE_LOAD(K, SLOT, U8, ROW)                                                       \
     _Pragma("unroll") for (int p = 0; p < PP; ++p)                                               \

@@ -30,6 +30,7 @@
 
 #include "gmx_block.h"
 #include "gmx_vm.h"
+#include "gmx_resample.h"
 
 // ---------------------------------------------------------------------------
 // errors
@@ -132,6 +133,7 @@ struct gmx_program {
   hipModule_t jit_module = nullptr;  // specialised kernel (gmx_program_specialize)
   hipFunction_t jit_fn = nullptr;
   int jit_pp = 1;                    // particles per thread of the specialised kernel
+  bool jit_gathers_pre = false;      // every gathered load of the specialised kernel uses the prologue's ancestors
 };
 
 static int parse_program(const uint32_t* blob, size_t n_words, gmx_program& P) {
@@ -265,8 +267,17 @@ static int jit_pp_for(const gmx_program* p) {
 // prefetch plan of a specialised kernel (gmx_jit.h): the distinct (slot, flags) of the program's per-particle
 // OP_LDIN instructions, at most JIT_MAX_PRE of them (PP registers each, held from the top of the kernel)
 #define JIT_MAX_PRE 8
-static std::string jit_source(const gmx_program* p) {
-  std::string s = "#include \"gmx_jit.h\"\n";
+// GENMI_FUSE_RESAMPLE=1 (read when a program is specialised): kernels of gathering programs carry the resampling
+// prologue (gmx_run_args.rs, csrc/gmx_resample.h).  Off by default: measured slower than the two-launch step on MI355X
+// (DESIGN.md §4), and the prologue would lengthen every gathering program's hiprtc compile.
+static bool jit_with_rs() {
+  const char* e = getenv("GENMI_FUSE_RESAMPLE");
+  return e && e[0] == '1';
+}
+
+static std::string jit_source(const gmx_program* p, bool* gathers_prefetched = nullptr) {
+  std::string s = jit_with_rs() ? "#define GMX_JIT_RS 1\n" : "";
+  s += "#include \"gmx_jit.h\"\n";
   char buf[128];
   s += "__device__ static constexpr uint32_t GMX_JIT_CONST[] = {";
   for (size_t k = 0; k < p->consts.size(); ++k) { snprintf(buf, sizeof(buf), "0x%08xu,", p->consts[k]); s += buf; }
@@ -296,6 +307,13 @@ static std::string jit_source(const gmx_program* p) {
     if (b & GMX_F_GATHER) { any_gather = true; if (pc < first_gather_pc) first_gather_pc = pc; }
   }
   if (!fits) { pres.clear(); pre_of.assign(p->n_instr, -1); any_gather = false; }
+  if (gathers_prefetched) {          // every gathered load goes through the prologue's ancestors (GMX_JIT_PRE_ANC)
+    *gathers_prefetched = any_gather && jit_with_rs();
+    for (uint32_t pc = 0; pc < p->n_instr; ++pc) {
+      const uint32_t w0 = p->code_h[2 * pc];
+      if ((w0 & 0xffu) == OP_LDIN && ((w0 >> 24) & GMX_F_GATHER) && pre_of[pc] < 0) *gathers_prefetched = false;
+    }
+  }
   // second-stage (gathered) loads go behind the first key derivation when that comes before their first use
   const uint32_t gpos = (any_gather && first_key_pc < first_gather_pc) ? first_key_pc + 1 : 0;
   snprintf(buf, sizeof(buf), "GMX_JIT_BEGIN(%u, %s, %u, %d, %d)\n", p->n_regs < 16 ? 16u : (p->n_regs < 32 ? 32u : 64u),
@@ -337,6 +355,10 @@ static std::string jit_source(const gmx_program* p) {
 extern "C" int gmx_program_is_specialized(const gmx_program* p) { return p && p->jit_fn ? 1 : 0; }
 extern "C" int gmx_program_writes_tile_stats(const gmx_program* p) {
   return p && p->jit_fn && p->jit_pp == 4 && p->n_redmax == 1 && !p->uses_lse ? 1 : 0;
+}
+
+extern "C" int gmx_program_fuses_resample(const gmx_program* p) {
+  return p && p->jit_fn && p->jit_pp == 4 && p->uses_gather && p->jit_gathers_pre ? 1 : 0;
 }
 
 // ---- on-disk cache of specialised code objects -----------------------------
@@ -459,7 +481,7 @@ extern "C" int gmx_program_specialize(gmx_program* p) {
   if (p->jit_fn) return 0;
   if (!jit_enabled()) return gmx_fail("gmx_program_specialize: disabled by GENMI_JIT=0%s");
   if (p->n_instr == 0 || p->n_instr > 8192) return gmx_fail("gmx_program_specialize: program size out of range%s");
-  const std::string src = jit_source(p);
+  const std::string src = jit_source(p, &p->jit_gathers_pre);
   const std::string path = jit_cache_path(src);
   std::vector<char> code;
   if (jit_cache_read(path, code)) {
@@ -526,7 +548,29 @@ extern "C" int gmx_program_run(const gmx_program* p, int64_t n, const gmx_run_ar
     if (!args->out_d[s]) return gmx_fail("gmx_program_run: output slot %s%lld is null", "", s);
   for (uint32_t s = 0; s < p->n_tab; ++s)
     if (!args->tab_d[s]) return gmx_fail("gmx_program_run: table slot %s%lld is null", "", s);
-  if (p->uses_gather && !args->ancestors_d)
+  const bool fused_rs = args->rs.lw_d != nullptr;
+  if (fused_rs) {
+    const gmx_resample_in& q = args->rs;
+    if (!gmx_program_fuses_resample(p))
+      return gmx_fail("gmx_program_run: rs is set but this program cannot resample in its own launch "
+                      "(gmx_program_fuses_resample: specialised, 4 particles per thread, gathering)%s");
+    if (!q.tile_max_d || !q.tile_agg_d || !q.anc_out_d) return gmx_fail("gmx_program_run: rs has a null pointer%s");
+    if (q.kind != GMX_RESAMPLE_SYSTEMATIC && q.kind != GMX_RESAMPLE_STRATIFIED)
+      return gmx_fail("gmx_program_run: rs.kind must be systematic or stratified%s");
+    if ((uintptr_t)q.lw_d & 15) return gmx_fail("gmx_program_run: rs.lw_d must be 16-byte aligned%s");
+    if ((n + GMX_RS_TILE - 1) / GMX_RS_TILE > GMX_RS_MAX_TILES)
+      return gmx_fail("gmx_program_run: rs: n too large for the fused resampler (n <= 2^21)%s");
+    if (q.shift < 1 || q.shift > 62) return gmx_fail("gmx_program_run: rs.shift out of range%s");
+    int need = 0;
+    while (((int64_t)1 << need) < n) ++need;
+    if (q.shift + need > 62) return gmx_fail("gmx_program_run: rs.shift too large for n (overflow)%s");
+    if (args->tile_agg_d == q.tile_agg_d || (const float*)args->red_out_d == q.tile_max_d)
+      return gmx_fail("gmx_program_run: rs reads the tile statistics this launch writes (use two sets)%s");
+    for (uint32_t s = 0; s < p->n_out; ++s)
+      if ((const void*)args->out_d[s] == (const void*)q.lw_d)
+        return gmx_fail("gmx_program_run: rs.lw_d is also an output of this launch (use two buffers)%s");
+  }
+  if (p->uses_gather && !args->ancestors_d && !fused_rs)
     return gmx_fail("gmx_program_run: program gathers but ancestors_d is null%s");
   if (p->uses_red && !args->red_out_d)
     return gmx_fail("gmx_program_run: program reduces but red_out_d is null%s");
@@ -554,9 +598,14 @@ extern "C" int gmx_program_run(const gmx_program* p, int64_t n, const gmx_run_ar
   hipStream_t st = (hipStream_t)stream;
   // the program's constants live in the operand pool after the launch uniforms
   gmx_run_args patched;
-  if (p->n_const) {
+  if (p->n_const || fused_rs) {
     patched = *args;
     for (uint32_t k = 0; k < p->n_const; ++k) patched.uni[p->n_dyn + k] = p->consts[k];
+    if (fused_rs) {
+      uint32_t b0, b1;
+      gmx_threefry2x32(patched.rs.key0, patched.rs.key1, 0u, 0u, &b0, &b1);     // bits32(key, 0) on the host
+      patched.rs.u0 = (b0 ^ b1) >> 9;
+    }
     args = &patched;
   }
   if (p->jit_fn) {
@@ -568,7 +617,8 @@ extern "C" int gmx_program_run(const gmx_program* p, int64_t n, const gmx_run_ar
     void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &ka, HIP_LAUNCH_PARAM_BUFFER_SIZE, &ka_size,
                       HIP_LAUNCH_PARAM_END};
     unsigned jgrid = (unsigned)((n + (int64_t)GMX_BLOCK * p->jit_pp - 1) / ((int64_t)GMX_BLOCK * p->jit_pp));
-    GMX_HIP(hipModuleLaunchKernel(p->jit_fn, jgrid, 1, 1, GMX_BLOCK, 1, 1, 0, st, nullptr, config));
+    const unsigned dyn_lds = fused_rs ? (unsigned)gmx_rs_window_lds(n) : 0u;
+    GMX_HIP(hipModuleLaunchKernel(p->jit_fn, jgrid, 1, 1, GMX_BLOCK, 1, 1, dyn_lds, st, nullptr, config));
     return 0;
   }
   // The interpreter's register file is a 16- or 32-element vector indexed at run time, and the
@@ -1047,30 +1097,7 @@ extern "C" int gmx_weight_cdf(const float* lw_d, int64_t n, int shift,
 // each ancestor index once — no dependent-load search chain.
 // multinomial positions are not ordered: k_ancestors binary-searches per slot.
 // ---------------------------------------------------------------------------
-struct u128 { uint64_t hi, lo; };
-__device__ __forceinline__ u128 mul64(uint64_t a, uint64_t b) {
-  u128 r; r.lo = a * b; r.hi = __umul64hi(a, b); return r;
-}
-__device__ __forceinline__ bool gt128(u128 a, u128 b) {
-  return a.hi > b.hi || (a.hi == b.hi && a.lo > b.lo);
-}
-
-// P_j for the ordered kinds
-__device__ __forceinline__ u128 slot_threshold(int kind, gmx_key key, uint64_t u0, int64_t j, uint64_t total) {
-  uint64_t u = (kind == GMX_RESAMPLE_SYSTEMATIC) ? u0 : (uint64_t)(gmx_bits32(key, (uint64_t)j) >> 9);
-  return mul64(((uint64_t)j << 23) + u, total);
-}
-
-// The exact predicate (runs for a handful of sources per launch).  Kept inline — a real call gives the kernel a
-// stack (scratch), which costs more at wave launch than the code size does — so callers on the hot path take
-// `kind` as a template constant: the systematic instantiation then carries no Threefry at all.
-__device__ __forceinline__ int64_t slots_below_exact(int kind, gmx_key key, uint64_t u0, uint64_t c, uint64_t D,
-                                                  uint64_t total, int64_t j, int64_t n_out) {
-  u128 X = mul64(c, D);
-  while (j > 0 && !gt128(X, slot_threshold(kind, key, u0, j - 1, total))) --j;
-  while (j < n_out && gt128(X, slot_threshold(kind, key, u0, j, total))) ++j;
-  return j;
-}
+// (u128 / slot_threshold / slots_below_exact: csrc/gmx_resample.h)
 
 // f(c) = number of slots j in [0, n_out) with P_j < c * D, i.e. with
 //   j + u_j / 2^23 < v,  v = c * n_out / total.
@@ -1329,39 +1356,7 @@ k_tile_stats(const float* __restrict__ lw, int64_t n, float scale, float* __rest
   }
 }
 
-// ---- slot ranges, fast path without branches ----
-// slots_below() above decides one CDF value with nested branches and carries the exact 128-bit predicate inline;
-// k_offspring_tile evaluates it five times per thread, so here the f64 estimate is straight-line code for every
-// evaluation and the (rare: ~1e-7 per evaluation) "within eps of a boundary" cases are collected in a flag and
-// settled afterwards by ONE rolled loop over the exact predicate.  Same answer as slots_below() in every case.
-struct sb_est { int32_t j; bool near; };
-template <int kind>
-__device__ __forceinline__ sb_est slots_below_est(gmx_key key, uint32_t u0, uint64_t c, uint64_t total,
-                                                  double n_over_total, double eps, int32_t n_out) {
-  const double cd = __builtin_fma((double)(uint32_t)(c >> 32), 4294967296.0, (double)(uint32_t)c);   // exact product, one rounding
-  sb_est r;
-  if (kind == GMX_RESAMPLE_SYSTEMATIC) {
-    // slot j is below iff j + du < v  <=>  j < v - du: the count is floor(v - du) + 1 (v - du not an integer;
-    // within eps of one, the exact predicate decides).  y = v - du + 1 > 0 comes out of ONE fma.
-    const double y = __builtin_fma(cd, n_over_total, 1.0 - (double)u0 * (1.0 / 8388608.0));
-    const int32_t t = (int32_t)y;                // floor (y > 0), saturating
-    const double frac = y - (double)t;
-    r.j = t < n_out ? t : n_out;
-    r.near = (frac < eps) || (frac > 1.0 - eps);
-    return r;
-  }
-  const double v = cd * n_over_total;
-  int32_t t = (int32_t)v;                        // floor (v >= 0), saturating
-  t = t < n_out - 1 ? t : n_out - 1;
-  const double frac = v - (double)t;
-  const uint32_t u = gmx_bits32(key, (uint64_t)(uint32_t)t) >> 9;
-  const double diff = frac - (double)u * (1.0 / 8388608.0);
-  r.j = t + (diff > 0.0 ? 1 : 0);
-  r.near = (frac < eps) || (frac > 1.0 - eps) || !(__builtin_fabs(diff) > eps);
-  if (c == 0ull) { r.j = 0; r.near = false; }
-  if (c >= total) { r.j = n_out; r.near = false; }
-  return r;
-}
+// (slots_below_est: csrc/gmx_resample.h)
 
 // One thread owns 4 consecutive sources (one float4 of log-weights); 256 threads are one tile; a block is RS_TPB
 // consecutive tiles.  RS_TPB = 1.  Every block has to turn ALL tile statistics into its prefix and the total, and

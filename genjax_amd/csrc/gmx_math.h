@@ -129,6 +129,38 @@ GMX_HD float gmx_expf_nonpos(float x) {
   return x < lo ? 0.0f : y;
 }
 
+// floor(gmx_expf(d) * 2^shift) as u64, 0 when that is NaN, negative or not below 2^63 — the fixed-point weight of the
+// integer CDF (include/genmi.h "Resampling": l_i), 1 <= shift <= 62 — without going through a float result:
+// gmx_expf's value is p * 2^k with p = its polynomial (in [0.70, 1.42]) and the power-of-two scalings exact, so the
+// floor is p's 24-bit significand shifted by (exponent of p) - 23 + k + shift.  Same integer as the expression above
+// for EVERY float d and every shift (tests/test_host_logic.py::test_weight_fixed_matches_its_definition sweeps the
+// bit patterns), in about half the instructions: no 2^k1 * 2^k2 scaling, no denormal flush, no f32 -> u64 conversion.
+GMX_HD uint64_t gmx_exp_fixed(float d, int shift) {
+  const float lo = -87.33654022216797f;
+  float dc = d > lo ? d : lo;                        // NaN -> lo: contributes 0 below, like every d < -(shift + 1) ln 2
+  dc = dc < 100.0f ? dc : 100.0f;                    // anything above 63 ln 2 is "not below 2^63"
+  const float kf = __builtin_rintf(dc * 1.44269502162933349609375f);
+  float r = gmx_fma(kf, -0.693359375f, dc);
+  r = gmx_fma(kf, 2.12194440e-4f, r);
+  float p = 1.9875691500e-4f;
+  p = gmx_fma(p, r, 1.3981999507e-3f);
+  p = gmx_fma(p, r, 8.3334519073e-3f);
+  p = gmx_fma(p, r, 4.1665795894e-2f);
+  p = gmx_fma(p, r, 1.6666665459e-1f);
+  p = gmx_fma(p, r, 5.0000001201e-1f);
+  const float r2 = r * r;
+  p = gmx_fma(p, r2, r);
+  p = p + 1.0f;
+  const uint32_t pb = gmx_f2u(p);
+  uint32_t m = (pb & 0x007fffffu) | 0x00800000u;     // p = m * 2^(e - 150), e = pb >> 23 (126 or 127)
+  // value = m * 2^s, s = e - 150 + k + shift; as (m << 39) >> (39 - s): zero for s <= -24, and s >= 40 is >= 2^63
+  int32_t amt = 189 - (int32_t)(pb >> 23) - (int32_t)kf - shift;
+  m = amt < 0 ? 0u : m;
+  amt = amt > 63 ? 63 : amt;
+  amt = amt < 0 ? 0 : amt;
+  return ((uint64_t)m << 39) >> amt;
+}
+
 // log(x), natural.  cephes logf polynomial on [sqrt(1/2), sqrt(2)).
 // Straight-line like gmx_expf: special cases are selects over the main path's result.
 GMX_HD float gmx_logf(float x) {

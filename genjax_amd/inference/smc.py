@@ -712,6 +712,25 @@ class BootstrapSweep:
         # where nothing overlaps them.  Off by default (less traffic).
         self.tile_q = torch.zeros((n,), dtype=torch.int64, device=dev) \
             if self.tile_stats and os.environ.get("GENMI_TILE_Q", "0") == "1" else None
+        # ONE launch per step: the program that gathers the resampled state (the extension; with rejuvenate=, the MH
+        # move) first computes its workgroup's ancestors itself, from the previous step's log-weights and tile
+        # statistics (gmx_run_args.rs, csrc/gmx_resample.h) — same integers as gmx_resample_tiles, no second kernel,
+        # no launch boundary.  Needs two sets of log-weights / statistics (a launch reads step t-1's while writing
+        # step t's).  OPT-IN (GENMI_FUSE_RESAMPLE=1, read when the programs are specialised): measured on MI355X,
+        # config 2, the one-launch step is SLOWER (23.1 vs 20.1 us): a workgroup's 1024 slots straddle two source
+        # tiles on average, so the CDF rebuild (4 exp + scan + 5 slot edges per thread and tile) runs twice per
+        # workgroup — +1340 vector instructions per wave against the 806 of k_offspring_tile, more than the launch
+        # boundary it removes.
+        gatherer = self.p_step if self.rejuvenate is None else self.p_mh_step
+        self.fuse = bool(self.tile_stats and self.tile_q is None and os.environ.get("GENMI_FUSE_RESAMPLE", "0") == "1"
+                         and gatherer.comp.fuses_resample()
+                         and (self.rejuvenate is None or self.p_mh_init.comp.fuses_resample()))
+        if self.fuse:
+            self.lw_pp = [self.lw, torch.zeros_like(self.lw)]
+            self.partials_pp = [self.partials, torch.zeros_like(self.partials)]
+            self.tile_agg_pp = [self.tile_agg, torch.zeros_like(self.tile_agg)]
+        else:
+            self.lw_pp, self.partials_pp, self.tile_agg_pp = [self.lw] * 2, [self.partials] * 2, [self.tile_agg] * 2
         # per-step keys on the host
         self.step_keys = []
         for t in range(T):
@@ -741,9 +760,18 @@ class BootstrapSweep:
                 bufs[o[1]] = self.x_store[t % 2][d:d + 1]
         else:
             bufs[prog.ro[1]] = self.x_store[t % 2]
-        bufs[prog.wo[1]] = self.lw.reshape(1, n)
-        prog.comp.run(leaves, (n,), lazy_split(k_prop, n), red_out=self.partials, out_buffers=bufs,
-                      tile_stats=(self.tile_agg, self.shift, self.tile_q) if self.tile_stats else None)
+        bufs[prog.wo[1]] = self.lw_pp[t % 2].reshape(1, n)
+        prog.comp.run(leaves, (n,), lazy_split(k_prop, n), red_out=self.partials_pp[t % 2], out_buffers=bufs,
+                      tile_stats=(self.tile_agg_pp[t % 2], self.shift, self.tile_q) if self.tile_stats else None,
+                      resample_in=self._resample_in(t) if (self.fuse and t >= 1 and self.rejuvenate is None) else None)
+
+    def _resample_in(self, t):
+        """gmx_run_args.rs of the launch of step t (>= 1) that gathers: resample step t-1's weights first"""
+        kh = self.step_keys[t - 1][1].host()
+        w = (t - 1) % 2
+        return dict(lw=self.lw_pp[w], tile_max=self.partials_pp[w], tile_agg=self.tile_agg_pp[w], anc_out=self.anc,
+                    kind=self.kind, shift=self.shift, key=(int(kh[0]), int(kh[1])),
+                    max_out=self.maxs[t - 1:t], total_out=self.totals[t - 1:t])
 
     def _launch_mh(self, t):
         """The MH move on the resampled particles of step t-1 (t >= 1): reads x_{t-1}[anc] and, for
@@ -761,7 +789,8 @@ class BootstrapSweep:
         bufs = [None] * len(prog.comp.outputs)
         bufs[prog.ro[1]] = self.xm_store[t % 2]
         bufs[prog.ao[1]] = self.accept.reshape(1, n)
-        prog.comp.run(leaves, (n,), lazy_split(k_mh, n), out_buffers=bufs)
+        prog.comp.run(leaves, (n,), lazy_split(k_mh, n), out_buffers=bufs,
+                      resample_in=self._resample_in(t) if self.fuse else None)
 
     def _rows(self, t) -> int:
         """partial rows the site program of step t wrote"""
@@ -793,8 +822,10 @@ class BootstrapSweep:
                      "gmx_resample_tiles_q")
             return
         if self.tile_stats:        # tile maxima = the workgroup maxima the site program left in partials[0]
-            be.check(be.c.gmx_resample_tiles(self.kind, kk, be.ptr(self.lw), self.n, self.shift, be.ptr(self.partials),
-                                             be.ptr(self.tile_agg), be.ptr(self.maxs[t:t + 1]),
+            w = t % 2
+            be.check(be.c.gmx_resample_tiles(self.kind, kk, be.ptr(self.lw_pp[w]), self.n, self.shift,
+                                             be.ptr(self.partials_pp[w]), be.ptr(self.tile_agg_pp[w]),
+                                             be.ptr(self.maxs[t:t + 1]),
                                              be.ptr(self.totals[t:t + 1]), be.ptr(self.anc), be.stream()),
                      "gmx_resample_tiles")
             return
@@ -813,6 +844,8 @@ class BootstrapSweep:
                 self._launch_mh(t)
             if not skip_vm:
                 self._launch_vm(t)
+            if self.fuse and t < self.T - 1:
+                continue                   # step t's weights are resampled by step t+1's launch itself
             if self.fused:
                 self._launch_resample(t)
             else:
@@ -869,4 +902,4 @@ class BootstrapSweep:
 
     def state(self):
         """(x_T particles before the last resampling, log-weights, last ancestors)."""
-        return self.x[(self.T - 1) % 2], self.lw, self.anc
+        return self.x[(self.T - 1) % 2], self.lw_pp[(self.T - 1) % 2], self.anc

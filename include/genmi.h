@@ -39,7 +39,7 @@ typedef __UINTPTR_TYPE__ uintptr_t;
 extern "C" {
 #endif
 
-#define GMX_ABI_VERSION 2
+#define GMX_ABI_VERSION 3
 
 typedef void* gmx_stream;            /* hipStream_t */
 typedef struct gmx_program gmx_program;
@@ -107,6 +107,26 @@ enum {
   GMX_KEY_BCAST = 4     /* (key0,key1) for every particle                      */
 };
 
+/* The resampling step folded into the NEXT site program's launch (gmx_run_args.rs): with lw_d set, a specialised
+ * 4-particles-per-thread program that gathers (gmx_program_fuses_resample() == 1) does not read ancestors_d — each
+ * workgroup first computes the ancestors of its own 1024 particles from the PREVIOUS step's log-weights and tile
+ * statistics (exactly gmx_resample_tiles' integers; csrc/gmx_resample.h), writes them to anc_out_d, and gathers
+ * through them.  A bootstrap SMC step (smc.py:370-396's role; SURVEY.md App. B resampling) is then ONE launch.
+ * The buffers read here must not be the ones this launch writes (log-weights, tile statistics: ping-pong). */
+typedef struct gmx_resample_in {
+  const float* lw_d;              /* [n] log-weights of the previous step (16-byte aligned); NULL = not fused   */
+  const float* tile_max_d;        /* [ceil(n/1024)] m_b  (plane 0 of the previous launch's red_out_d)           */
+  const uint64_t* tile_agg_d;     /* [ceil(n/1024)] A_b  (the previous launch's tile_agg_d, same tile_shift)    */
+  int32_t* anc_out_d;             /* [n] the ancestors, as gmx_resample_tiles would write them                  */
+  float* max_out_d;               /* optional [1]: M      (as gmx_resample_tiles' max_d)                        */
+  uint64_t* total_out_d;          /* optional [1]: total  (as gmx_resample_tiles' total_d)                      */
+  int32_t kind;                   /* GMX_RESAMPLE_SYSTEMATIC or GMX_RESAMPLE_STRATIFIED                         */
+  int32_t shift;                  /* the CDF's fixed-point shift (= the previous launch's tile_shift)           */
+  uint32_t key0, key1;            /* resampling key                                                             */
+  uint32_t u0;                    /* filled in by gmx_program_run: bits32(key, 0) >> 9                          */
+  uint32_t reserved_;
+} gmx_resample_in;
+
 typedef struct gmx_run_args {
   const void* in_d[GMX_MAX_IN];   /* per-particle inputs (4-byte or 1-byte elems) */
   void* out_d[GMX_MAX_OUT];       /* per-particle outputs                        */
@@ -135,6 +155,7 @@ typedef struct gmx_run_args {
                                      epilogue has them in registers; written out, the resampler
                                      (gmx_resample_tiles_q) needs neither the log-weights nor a second exp per
                                      particle: 8 bytes of traffic instead of ~40 vector instructions             */
+  gmx_resample_in rs;             /* optional (rs.lw_d != NULL): resample first, in the same launch — see above  */
 } gmx_run_args;
 
 int gmx_program_create(const uint32_t* blob_h, size_t n_words, gmx_program** out);
@@ -152,6 +173,11 @@ int64_t gmx_program_grid(const gmx_program* p, int64_t n);
 /* 1 when the specialised kernel runs 4 particles per thread (a workgroup = one 1024-particle
  * tile of the CDF) and the program has exactly one OP_REDMAX: it then honours tile_agg_d. */
 int gmx_program_writes_tile_stats(const gmx_program* p);
+/* 1 when gmx_program_run honours gmx_run_args.rs for this program: specialised WITH the resampling prologue
+ * (environment GENMI_FUSE_RESAMPLE=1 at gmx_program_specialize time — opt-in: on MI355X the one-launch step measured
+ * slower than site program + gmx_resample_tiles), 4 particles per thread, and every gathered load goes through
+ * ancestors_d at the top of the kernel. */
+int gmx_program_fuses_resample(const gmx_program* p);
 int gmx_program_run(const gmx_program* p, int64_t n, const gmx_run_args* args_h,
                     gmx_stream stream);
 

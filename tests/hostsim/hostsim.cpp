@@ -101,6 +101,18 @@ static bool hs_tile_mode(const gmx_program* p) {
   return p && p->n_redmax == 1 && p->n_redlse == 0 && !(e && e[0] == '0');
 }
 extern "C" int gmx_program_writes_tile_stats(const gmx_program* p) { return hs_tile_mode(p) ? 1 : 0; }
+static bool hs_gathers(const gmx_program* p) {
+  for (uint32_t pc = 0; pc < p->n_instr; ++pc) {
+    const uint32_t w0 = p->code[2 * pc];
+    if ((w0 & 0xffu) == OP_LDIN && ((w0 >> 24) & GMX_F_GATHER)) return true;
+  }
+  return false;
+}
+// as the HIP library: only under GENMI_FUSE_RESAMPLE=1
+extern "C" int gmx_program_fuses_resample(const gmx_program* p) {
+  const char* e = getenv("GENMI_FUSE_RESAMPLE");
+  return p && hs_gathers(p) && e && e[0] == '1' ? 1 : 0;
+}
 extern "C" int64_t gmx_program_grid(const gmx_program* p, int64_t n) { return hs_tile_mode(p) ? (n + 1023) / 1024 : (n + 255) / 256; }
 static uint64_t hs_weight_fixed(float lw, float ref, float scale);
 
@@ -117,6 +129,20 @@ extern "C" int gmx_program_run(const gmx_program* p, int64_t n, const gmx_run_ar
   const gmx_run_args* A = &patched;
   for (uint32_t s = 0; s < p->n_in; ++s) if (!A->in_d[s]) return fail("program_run: null input slot");
   for (uint32_t s = 0; s < p->n_out; ++s) if (!A->out_d[s]) return fail("program_run: null output slot");
+  if (A->rs.lw_d) {          // the resampling step folded into this launch: gmx_resample_tiles, then gather through it
+    if (!gmx_program_fuses_resample(p)) return fail("program_run: rs is set but this program cannot resample in its own launch");
+    if (!A->rs.tile_max_d || !A->rs.tile_agg_d || !A->rs.anc_out_d) return fail("program_run: rs has a null pointer");
+    if (A->tile_agg_d == A->rs.tile_agg_d || (const float*)A->red_out_d == A->rs.tile_max_d)
+      return fail("program_run: rs reads the tile statistics this launch writes (use two sets)");
+    for (uint32_t s = 0; s < p->n_out; ++s)
+      if ((const void*)A->out_d[s] == (const void*)A->rs.lw_d) return fail("program_run: rs.lw_d is also an output of this launch");
+    const uint32_t key[2] = {A->rs.key0, A->rs.key1};
+    float m_; uint64_t t_;
+    if (gmx_resample_tiles(A->rs.kind, key, A->rs.lw_d, n, A->rs.shift, A->rs.tile_max_d, A->rs.tile_agg_d,
+                           A->rs.max_out_d ? A->rs.max_out_d : &m_, A->rs.total_out_d ? A->rs.total_out_d : &t_,
+                           A->rs.anc_out_d, nullptr)) return 1;
+    patched.ancestors_d = A->rs.anc_out_d;
+  }
   const bool tile = hs_tile_mode(p);
   if (A->tile_agg_d && !tile) return fail("program_run: tile_agg_d is set but this program cannot write tile statistics");
   if (A->tile_q_d && !A->tile_agg_d) return fail("program_run: tile_q_d needs tile_agg_d");
@@ -181,9 +207,9 @@ extern "C" int gmx_reduce_max(const float* parts, int64_t n, float* max_d, gmx_s
 extern "C" size_t gmx_weight_cdf_workspace(int64_t n) { return 8 + (size_t)((n + 1023) / 1024) * 8; }
 // the two-level integer CDF (include/genmi.h "Resampling"): tiles of 1024 consecutive indices
 static const int64_t HS_TILE = 1024;
+// the device's own function (csrc/gmx_math.h): the mirror checks it against the oracle's floor(exp(.) * 2^shift)
 static uint64_t hs_weight_fixed(float lw, float ref, float scale) {
-  float q = gmx_expf(lw - ref) * scale;
-  return (q >= 0.0f && q < 0x1p63f) ? (uint64_t)q : 0ull;
+  return gmx_exp_fixed(lw - ref, (int)(gmx_f2u(scale) >> 23) - 127);
 }
 extern "C" int gmx_weight_cdf(const float* lw, int64_t n, int shift, const float* parts, int64_t n_parts, float* max_d,
                               uint64_t* cdf, uint64_t* total, void*, gmx_stream) {

@@ -34,20 +34,23 @@ def oracle_bootstrap_sweep(init, step, n, T, ys, run_key, kind=O.SYSTEMATIC, ste
     return dict(log_ml=log_ml, x=x, lw=lw, anc=anc, hist=hist)
 
 
-def check_lgssm_sweep(n=4096, T=5, seed=314159, capture=False, specialize=True):
+def check_lgssm_sweep(n=4096, T=5, seed=314159, capture=False, specialize=True, want_fuse=None, resample="systematic"):
     import genjax_amd as G
     from genjax_amd import workloads
     from genjax_amd.inference.smc import BootstrapSweep
     ys = workloads.lgssm_data(T)
     init, step = workloads.make_lgssm(G)
-    sw = BootstrapSweep(init, step, n, T, specialize=specialize).prepare(G.key(seed), torch.from_numpy(ys))
+    sw = BootstrapSweep(init, step, n, T, specialize=specialize, resample=resample).prepare(G.key(seed), torch.from_numpy(ys))
+    if want_fuse is not None:
+        assert sw.fuse == want_fuse, "the sweep did not take the requested (one- / two-launch) form"
     if capture:
         sw.capture()
     sw.launch()
     log_ml = sw.log_ml()
     x, lw, anc = sw.state()
     oi, os_ = workloads.make_lgssm(O)
-    ref = oracle_bootstrap_sweep(oi, os_, n, T, ys, O.key(seed))
+    ref = oracle_bootstrap_sweep(oi, os_, n, T, ys, O.key(seed),
+                                 kind={"systematic": O.SYSTEMATIC, "stratified": O.STRATIFIED}[resample])
     return dict(
         log_ml=log_ml, log_ml_oracle=ref["log_ml"], kalman=workloads.kalman_log_ml(ys),
         ancestors_equal=bool(np.array_equal(anc.cpu().numpy(), ref["anc"])),

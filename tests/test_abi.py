@@ -33,7 +33,7 @@ def test_hip_library_exports_every_declared_symbol():
     missing = [s for s in declared_symbols() if not hasattr(lib, s)]
     assert not missing, missing
     lib.gmx_version.restype = ctypes.c_int
-    assert lib.gmx_version() == 2
+    assert lib.gmx_version() == 3
     # pure-host entry point: Threefry known-answer vector (no GPU involved)
     out = (ctypes.c_uint32 * 2)()
     lib.gmx_threefry2x32_host(ctypes.c_uint32(0x13198A2E), ctypes.c_uint32(0x03707344),

@@ -934,3 +934,23 @@ def test_multinomial_two_level_search(gpu, n, shape):
 def test_vector_state_mh_sweep_matches_oracle(gpu, n, capture, specialize):
     """the fused MH sweep with a 2-vector state (one vector-valued site), interpreter and specialised + captured"""
     parity.check_vector_mh_sweep(n=n, T=5, capture=capture, specialize=specialize)
+
+
+@pytest.mark.parametrize("resample", ["systematic", "stratified"])
+def test_resampler_inside_the_step_launch(gpu, monkeypatch, resample):
+    """GENMI_FUSE_RESAMPLE=1 (gmx_run_args.rs, csrc/gmx_resample.h): every workgroup of the step's site program
+    computes its own 1024 ancestors from the previous step's log-weights + tile statistics — one launch per step.
+    Same ancestors, states, weights and evidence as the oracle's sweep, bit for bit: ragged last tile, n not a
+    multiple of 1024, through a captured graph, and with the MH move as the launch that resamples."""
+    import genjax_amd as G
+    monkeypatch.setenv("GENMI_FUSE_RESAMPLE", "1")
+    G.clear_caches()
+    try:
+        for n, T, cap in ((100_003, 6, False), (5000, 4, True), (1024, 3, False), (700, 3, False)):
+            res = parity.check_lgssm_sweep(n=n, T=T, capture=cap, want_fuse=True, resample=resample)
+            assert res["ancestors_equal"] and res["x_equal"] and res["totals_equal"] and res["lw_max_abs_diff"] == 0.0
+            assert res["log_ml"] == res["log_ml_oracle"]
+        if resample == "systematic":
+            parity.check_nlssm_mh(n=2000, T=4)
+    finally:
+        G.clear_caches()

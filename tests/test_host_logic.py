@@ -995,3 +995,33 @@ def test_vector_state_mh_sweep_matches_oracle():
     from tests import parity
     res = parity.check_vector_mh_sweep(n=1500, T=5)
     assert 0.3 < res["accept_rate"] < 1.0
+
+
+def test_weight_fixed_matches_its_definition(tmp_path):
+    """csrc/gmx_math.h gmx_exp_fixed (the integer form the kernels use for the CDF's fixed-point weights) equals
+    floor(gmx_expf(d) * 2^shift) — the definition the oracle restates — on a strided sweep of ALL float bit patterns
+    of d (NaNs, infinities, denormals included) for shifts 1..62; tools/check_exp_fixed.c with STRIDE=1 is the
+    exhaustive form (run once per change of either function)."""
+    import os
+    import subprocess
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "check_exp_fixed"
+    subprocess.check_call(["gcc", "-O2", "-fopenmp", "-ffp-contract=off", "-fno-fast-math", "-DSTRIDE=1021",
+                           "-I", os.path.join(ROOT, "genjax_amd", "csrc"), "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tools", "check_exp_fixed.c"), "-o", str(exe), "-lm"])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:]
+    assert "shift 62 done, mismatches so far 0" in out.stdout
+
+
+@pytest.mark.parametrize("fuse", ["0", "1"])
+def test_sweep_with_and_without_the_resampler_in_the_step_launch(monkeypatch, fuse):
+    """GENMI_FUSE_RESAMPLE: the resampling step folded into the next site program's launch (gmx_run_args.rs; the
+    C-ABI mirror resamples and then gathers) or as its own launch — the same sweep bit for bit, both equal to the
+    oracle's; also through the MH-moved sweep (the move is then the launch that resamples)."""
+    from tests import parity
+    monkeypatch.setenv("GENMI_FUSE_RESAMPLE", fuse)
+    res = parity.check_lgssm_sweep(n=3000, T=5)
+    assert res["ancestors_equal"] and res["x_equal"] and res["totals_equal"] and res["lw_max_abs_diff"] == 0.0
+    assert res["log_ml"] == res["log_ml_oracle"]
+    parity.check_nlssm_mh(n=1500, T=4)

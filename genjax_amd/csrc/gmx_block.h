@@ -20,11 +20,23 @@ __device__ __forceinline__ uint32_t gmx_dpp(uint32_t identity, uint32_t v) {
 #define GMX_DPP_SCAN_STEPS(STEP) \
   STEP(0x111, 0xf) STEP(0x112, 0xf) STEP(0x114, 0xf) STEP(0x118, 0xf) STEP(0x142, 0xa) STEP(0x143, 0xc)
 
-// inclusive max-scan; lane 63 holds the wave maximum
+// The scans below are ONE vector instruction per step: the operation itself reads its first operand through the
+// DPP pattern (v_max_f32_dpp / v_add_co_u32_dpp), and a lane the pattern does not feed (bound_ctrl off) or whose
+// row is masked is simply not written — the identity element for free.  (Through __builtin_amdgcn_update_dpp the
+// compiler emits mov-identity + v_mov_dpp + the operation, and for a float max a canonicalising v_max before it.)
+// `s_nop 1`: a DPP read of a VGPR needs two wait states after the VALU write of it, and the hazard recogniser does not
+// look inside inline assembly.
+#define GMX_DPP_ASM_STEPS(OP) \
+  OP("row_shr:1 row_mask:0xf bank_mask:0xf") OP("row_shr:2 row_mask:0xf bank_mask:0xf") \
+  OP("row_shr:4 row_mask:0xf bank_mask:0xf") OP("row_shr:8 row_mask:0xf bank_mask:0xf") \
+  OP("row_bcast:15 row_mask:0xa bank_mask:0xf") OP("row_bcast:31 row_mask:0xc bank_mask:0xf")
+
+// inclusive max-scan; lane 63 holds the wave maximum.  v_max_f32 (IEEE mode) returns the other operand when one is
+// NaN and +0 for max(-0, +0): gmx_rmax below is the same function on the host.
 __device__ __forceinline__ float wave_max_scan(float v) {
-#define GMX_STEP(C, M) v = gmx_fmax(v, gmx_u2f(gmx_dpp<C, M>(0xff800000u, gmx_f2u(v))));
-  GMX_DPP_SCAN_STEPS(GMX_STEP)
-#undef GMX_STEP
+#define GMX_OP(CTRL) "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 " CTRL "\n\t"
+  asm(GMX_DPP_ASM_STEPS(GMX_OP) : "+v"(v));
+#undef GMX_OP
   return v;
 }
 __device__ __forceinline__ float wave_max(float v) {
@@ -42,7 +54,7 @@ __device__ __forceinline__ float block_max(float v, float* lds4) {
   __syncthreads();
   if ((threadIdx.x & 63) == 0) lds4[w] = v;
   __syncthreads();
-  float r = gmx_fmax(gmx_fmax(lds4[0], lds4[1]), gmx_fmax(lds4[2], lds4[3]));
+  float r = gmx_rmax(gmx_rmax(lds4[0], lds4[1]), gmx_rmax(lds4[2], lds4[3]));
   return r;
 }
 __device__ __forceinline__ float block_sum(float v, float* lds4) {
@@ -76,11 +88,11 @@ __device__ __forceinline__ void gmx_red_lse(float* red_out, float* lds4, uint32_
 // ---- 64-bit wave primitives and the fixed-point weight of the two-level CDF (include/genmi.h) ----
 // inclusive scan of u64 over the wave (integer: any order gives the same bits)
 __device__ __forceinline__ uint64_t wave_scan_u64(uint64_t v) {
-#define GMX_STEP(C, M) { uint32_t lo = gmx_dpp<C, M>(0u, (uint32_t)v), hi = gmx_dpp<C, M>(0u, (uint32_t)(v >> 32)); \
-                         v += ((uint64_t)hi << 32) | lo; }
-  GMX_DPP_SCAN_STEPS(GMX_STEP)
-#undef GMX_STEP
-  return v;
+  uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+#define GMX_OP(CTRL) "s_nop 1\n\tv_add_co_u32_dpp %0, vcc, %0, %0 " CTRL "\n\tv_addc_co_u32_dpp %1, vcc, %1, %1, vcc " CTRL "\n\t"
+  asm(GMX_DPP_ASM_STEPS(GMX_OP) : "+v"(lo), "+v"(hi) : : "vcc");
+#undef GMX_OP
+  return ((uint64_t)hi << 32) | lo;
 }
 __device__ __forceinline__ uint64_t wave_last_u64(uint64_t v) {      // lane 63's value, wave-uniform
   uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, 63);

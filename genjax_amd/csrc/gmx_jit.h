@@ -50,7 +50,7 @@ struct gmx_jit_ctx {
   __device__ __forceinline__ void red_max(float x, bool active) {
     const float m = active ? x : -gmx_inf();
     red_x[cur] = m;
-    acc_max = first ? m : gmx_fmax(acc_max, m);
+    acc_max = first ? m : gmx_rmax(acc_max, m);
     if (last) {
       const float bm = block_max(acc_max, lds4);
       if (threadIdx.x == 0 && A->red_out_d) A->red_out_d[blockIdx.x] = bm;

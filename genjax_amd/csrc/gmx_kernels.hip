@@ -743,7 +743,7 @@ k_lse_tiles(const float* __restrict__ lw, int64_t cols, int64_t tiles_per_row,
   for (int k = 0; k < LSE_ITEMS; ++k) {
     int64_t j = base + (int64_t)k * GMX_BLOCK + threadIdx.x;   // coalesced per k
     v[k] = (j < cols) ? x[j] : -gmx_inf();
-    m = gmx_fmax(m, v[k]);
+    m = gmx_rmax(m, v[k]);
   }
   m = block_max(m, lds4);
   float s = 0.0f;
@@ -765,7 +765,7 @@ k_lse_final(const float* __restrict__ partials, int64_t n_part, float* __restric
   int64_t row = blockIdx.x;
   const float* p = partials + 2 * row * n_part;
   float m = -gmx_inf();
-  for (int64_t j = threadIdx.x; j < n_part; j += GMX_BLOCK) m = gmx_fmax(m, p[2 * j]);
+  for (int64_t j = threadIdx.x; j < n_part; j += GMX_BLOCK) m = gmx_rmax(m, p[2 * j]);
   m = block_max(m, lds4);
   float s = 0.0f;
   if (m > -gmx_inf())
@@ -786,7 +786,7 @@ k_lse_rows(const float* __restrict__ lw, int64_t rows, int64_t cols, float* __re
   int lane = threadIdx.x & 63;
   const float* x = lw + row * cols;
   float m = -gmx_inf();
-  for (int64_t j = lane; j < cols; j += GMX_WAVE) m = gmx_fmax(m, x[j]);
+  for (int64_t j = lane; j < cols; j += GMX_WAVE) m = gmx_rmax(m, x[j]);
   m = wave_max(m);
   float s = 0.0f;
   if (m > -gmx_inf())
@@ -873,7 +873,7 @@ __global__ void __launch_bounds__(GMX_BLOCK)
 k_reduce_max(const float* __restrict__ partials, int64_t n_part, float* __restrict__ max_out) {
   __shared__ float lds4[4];
   float m = -gmx_inf();
-  for (int64_t j = threadIdx.x; j < n_part; j += GMX_BLOCK) m = gmx_fmax(m, partials[j]);
+  for (int64_t j = threadIdx.x; j < n_part; j += GMX_BLOCK) m = gmx_rmax(m, partials[j]);
   m = block_max(m, lds4);
   if (threadIdx.x == 0) *max_out = m;
 }
@@ -912,13 +912,13 @@ k_weight_cdf(const float* __restrict__ lw, int64_t n, float scale, int max_mode,
   float M;
   if (max_mode == 1) {
     float m = -gmx_inf();
-    for (int64_t j = threadIdx.x; j < n_part; j += CDF_THREADS) m = gmx_fmax(m, partials[j]);
+    for (int64_t j = threadIdx.x; j < n_part; j += CDF_THREADS) m = gmx_rmax(m, partials[j]);
     m = wave_max(m);
     if (lane == 0) s_max[wave] = m;
     __syncthreads();
     m = s_max[0];
 #pragma unroll
-    for (int w = 1; w < CDF_WAVES; ++w) m = gmx_fmax(m, s_max[w]);
+    for (int w = 1; w < CDF_WAVES; ++w) m = gmx_rmax(m, s_max[w]);
     M = m;
     if (tile == 0 && threadIdx.x == 0) *max_d = M;
   } else {
@@ -929,12 +929,12 @@ k_weight_cdf(const float* __restrict__ lw, int64_t n, float scale, int max_mode,
   const int grp = wave >> 2;
   float gm = -gmx_inf();
 #pragma unroll
-  for (int c = 0; c < CDF_VEC; ++c) gm = gmx_fmax(gm, x[c]);
+  for (int c = 0; c < CDF_VEC; ++c) gm = gmx_rmax(gm, x[c]);
   gm = wave_max(gm);
   __syncthreads();                       // s_max may still be read by the max_mode == 1 reduction above
   if (lane == 0) s_max[wave] = gm;
   __syncthreads();
-  const float m_b = gmx_fmax(gmx_fmax(s_max[4 * grp], s_max[4 * grp + 1]), gmx_fmax(s_max[4 * grp + 2], s_max[4 * grp + 3]));
+  const float m_b = gmx_rmax(gmx_rmax(s_max[4 * grp], s_max[4 * grp + 1]), gmx_rmax(s_max[4 * grp + 2], s_max[4 * grp + 3]));
   const int32_t K = gmx_tile_exp(M);
   const int32_t k_b = gmx_tile_exp(m_b);
   const float ref_b = gmx_tile_ref(k_b);
@@ -959,7 +959,7 @@ k_weight_cdf(const float* __restrict__ lw, int64_t n, float scale, int max_mode,
       if (g == grp && 4 * g + w == wave) wave_off = A;
       A += s_part[4 * g + w];
     }
-    const float mg = gmx_fmax(gmx_fmax(s_max[4 * g], s_max[4 * g + 1]), gmx_fmax(s_max[4 * g + 2], s_max[4 * g + 3]));
+    const float mg = gmx_rmax(gmx_rmax(s_max[4 * g], s_max[4 * g + 1]), gmx_rmax(s_max[4 * g + 2], s_max[4 * g + 3]));
     if (g == grp) grp_off = tile_agg;
     tile_agg += gmx_tile_scale(A, gmx_tile_exp(mg), K);
   }
@@ -1341,7 +1341,7 @@ k_tile_stats(const float* __restrict__ lw, int64_t n, float scale, float* __rest
   }
   float m = -gmx_inf();
 #pragma unroll
-  for (int c = 0; c < CDF_VEC; ++c) m = gmx_fmax(m, x[c]);
+  for (int c = 0; c < CDF_VEC; ++c) m = gmx_rmax(m, x[c]);
   m = block_max(m, lds4);
   const float ref = gmx_tile_ref(gmx_tile_exp(m));
   uint64_t run = 0;
@@ -1443,7 +1443,7 @@ k_offspring_tile(uint32_t k0, uint32_t k1, uint32_t u0_host, const float* __rest
   float M = -gmx_inf();
 #pragma unroll
   for (int r = 0; r < PER; ++r)
-    if (r * RS_BLOCK < n_tiles) M = gmx_fmax(M, tm[r]);
+    if (r * RS_BLOCK < n_tiles) M = gmx_rmax(M, tm[r]);
   M = wave_max(M);
   uint64_t q[CDF_VEC];
   uint64_t run = 0;
@@ -1459,7 +1459,7 @@ k_offspring_tile(uint32_t k0, uint32_t k1, uint32_t u0_host, const float* __rest
   __syncthreads();
   M = s_max[0];
 #pragma unroll
-  for (int w = 1; w < RS_WAVES; ++w) M = gmx_fmax(M, s_max[w]);
+  for (int w = 1; w < RS_WAVES; ++w) M = gmx_rmax(M, s_max[w]);
   uint64_t wave_off = 0;
 #pragma unroll
   for (int w = 0; w < 4; ++w) wave_off += (w < (wave & 3)) ? s_scan[4 * grp + w] : 0ull;     // the tile's own four waves
@@ -1962,7 +1962,7 @@ k_shard_totals(const uint8_t* __restrict__ stats_all, int world, int n_tiles, si
   float m = -gmx_inf();
   for (int r = 0; r < world; ++r) {
     const float* tmax = reinterpret_cast<const float*>(stats_all + (size_t)r * stride + (size_t)tiles_pad * 8);
-    for (int t = (int)threadIdx.x; t < n_tiles; t += GMX_BLOCK) m = gmx_fmax(m, tmax[t]);
+    for (int t = (int)threadIdx.x; t < n_tiles; t += GMX_BLOCK) m = gmx_rmax(m, tmax[t]);
   }
   const float M = block_max(m, lds4);
   const int32_t K = gmx_tile_exp(M);

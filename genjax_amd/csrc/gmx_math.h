@@ -45,6 +45,19 @@ GMX_HD int gmx_isnan(float x) { return (gmx_f2u(x) & 0x7fffffffu) > GMX_INF_BITS
 GMX_HD float gmx_fabs(float x) { return gmx_u2f(gmx_f2u(x) & 0x7fffffffu); }
 GMX_HD float gmx_fmax(float a, float b) { return (a > b || gmx_isnan(b)) ? a : b; }
 GMX_HD float gmx_fmin(float a, float b) { return (a < b || gmx_isnan(b)) ? a : b; }
+// the max of REDUCTIONS (block / tile / global maxima of log-weights): a NaN operand is ignored, max(-0, +0) = +0 —
+// IEEE maxNum as v_max_f32 implements it, so the result does not depend on the order of the reduction (gmx_fmax
+// above returns its SECOND operand for -0 vs +0).  One instruction on the device.
+#if defined(__HIP_DEVICE_COMPILE__)
+GMX_HD float gmx_rmax(float a, float b) { return __builtin_fmaxf(a, b); }
+#else
+GMX_HD float gmx_rmax(float a, float b) {
+  if (gmx_isnan(a)) return b;
+  if (gmx_isnan(b)) return a;
+  if (a == b) return gmx_u2f(gmx_f2u(a) & gmx_f2u(b));      // +-0: + wins; otherwise the same bits
+  return a > b ? a : b;
+}
+#endif
 
 // 2^k as a float for k in [-126, 127].
 GMX_HD float gmx_pow2i(int k) { return gmx_u2f((uint32_t)(k + 127) << 23); }

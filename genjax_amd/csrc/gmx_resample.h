@@ -102,9 +102,9 @@ GMX_HD size_t gmx_rs_window_lds(int64_t n) {
 
 // inclusive max-scan of u32 over the wave
 __device__ __forceinline__ uint32_t gmx_wave_umax_scan(uint32_t v) {
-#define GMX_STEP(C, M) { const uint32_t o_ = gmx_dpp<C, M>(0u, v); v = v > o_ ? v : o_; }
-  GMX_DPP_SCAN_STEPS(GMX_STEP)
-#undef GMX_STEP
+#define GMX_OP(CTRL) "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 " CTRL "\n\t"
+  asm(GMX_DPP_ASM_STEPS(GMX_OP) : "+v"(v));
+#undef GMX_OP
   return v;
 }
 
@@ -147,13 +147,13 @@ __device__ __forceinline__ void gmx_rs_window(const gmx_resample_in& Q, const in
       const bool ok = tid * per + r < n_tiles;
       ta[r] = ok ? ta[r] : 0ull;
       tm[r] = ok ? tm[r] : -gmx_inf();
-      M = gmx_fmax(M, tm[r]);
+      M = gmx_rmax(M, tm[r]);
     }
   }
   M = wave_max(M);
   if (lane == 0) s_wf[wave] = M;
   __syncthreads();
-  M = gmx_fmax(gmx_fmax(s_wf[0], s_wf[1]), gmx_fmax(s_wf[2], s_wf[3]));
+  M = gmx_rmax(gmx_rmax(s_wf[0], s_wf[1]), gmx_rmax(s_wf[2], s_wf[3]));
   const int32_t K = gmx_tile_exp(M);
   uint64_t P[GMX_RS_PER_MAX];
   uint64_t run = 0;

@@ -159,7 +159,7 @@ extern "C" int gmx_program_run(const gmx_program* p, int64_t n, const gmx_run_ar
     }
     if (kind && A->red_out_d) {
       float m = -gmx_inf();
-      for (int t = 0; t < G; ++t) m = gmx_fmax(m, red[t]);
+      for (int t = 0; t < G; ++t) m = gmx_rmax(m, red[t]);
       A->red_out_d[blk] = m;
       if (kind == 2) {
         float e[256];
@@ -188,7 +188,7 @@ extern "C" int gmx_logsumexp(const float* lw, int64_t rows, int64_t cols, float*
   for (int64_t r = 0; r < rows; ++r) {
     const float* x = lw + r * cols;
     float m = -gmx_inf();
-    for (int64_t j = 0; j < cols; ++j) m = gmx_fmax(m, x[j]);
+    for (int64_t j = 0; j < cols; ++j) m = gmx_rmax(m, x[j]);
     float s = 0.0f;
     if (m > -gmx_inf()) for (int64_t j = 0; j < cols; ++j) s += gmx_expf(x[j] - m);
     out[r] = (m > -gmx_inf()) ? m + gmx_logf(s) : m;
@@ -202,7 +202,7 @@ extern "C" int gmx_ancestors(int kind, const uint32_t key[2], const uint64_t* cd
                              const uint64_t* total_d, int64_t n_out_total, int64_t slot_offset, int64_t n_slots,
                              int32_t* anc, gmx_stream);
 extern "C" int gmx_reduce_max(const float* parts, int64_t n, float* max_d, gmx_stream) {
-  float m = -gmx_inf(); for (int64_t j = 0; j < n; ++j) m = gmx_fmax(m, parts[j]); *max_d = m; return 0;
+  float m = -gmx_inf(); for (int64_t j = 0; j < n; ++j) m = gmx_rmax(m, parts[j]); *max_d = m; return 0;
 }
 extern "C" size_t gmx_weight_cdf_workspace(int64_t n) { return 8 + (size_t)((n + 1023) / 1024) * 8; }
 // the two-level integer CDF (include/genmi.h "Resampling"): tiles of 1024 consecutive indices
@@ -216,14 +216,14 @@ extern "C" int gmx_weight_cdf(const float* lw, int64_t n, int shift, const float
   if (n <= 0) return fail("weight_cdf: n");
   int need = 0; while (((int64_t)1 << need) < n) ++need;
   if (shift + need > 62) return fail("weight_cdf: shift too large");
-  if (parts) { float m = -gmx_inf(); for (int64_t j = 0; j < n_parts; ++j) m = gmx_fmax(m, parts[j]); *max_d = m; }
+  if (parts) { float m = -gmx_inf(); for (int64_t j = 0; j < n_parts; ++j) m = gmx_rmax(m, parts[j]); *max_d = m; }
   const float M = *max_d, scale = gmx_pow2i(shift);
   const int32_t K = gmx_tile_exp(M);
   uint64_t prefix = 0;
   for (int64_t lo = 0; lo < n; lo += HS_TILE) {
     const int64_t hi = lo + HS_TILE < n ? lo + HS_TILE : n;
     float m = -gmx_inf();
-    for (int64_t i = lo; i < hi; ++i) m = gmx_fmax(m, lw[i]);
+    for (int64_t i = lo; i < hi; ++i) m = gmx_rmax(m, lw[i]);
     const int32_t k = gmx_tile_exp(m);
     const float ref = gmx_tile_ref(k);
     uint64_t run = 0;
@@ -267,7 +267,7 @@ extern "C" int gmx_tile_stats(const float* lw, int64_t n, int shift, float* tmax
   for (int64_t lo = 0, b = 0; lo < n; lo += HS_TILE, ++b) {
     const int64_t hi = lo + HS_TILE < n ? lo + HS_TILE : n;
     float m = -gmx_inf();
-    for (int64_t i = lo; i < hi; ++i) m = gmx_fmax(m, lw[i]);
+    for (int64_t i = lo; i < hi; ++i) m = gmx_rmax(m, lw[i]);
     const float ref = gmx_tile_ref(gmx_tile_exp(m));
     uint64_t run = 0;
     for (int64_t i = lo; i < hi; ++i) run += hs_weight_fixed(lw[i], ref, scale);
@@ -281,7 +281,7 @@ extern "C" int gmx_resample_tiles(int kind, const uint32_t key[2], const float* 
   if (kind == GMX_RESAMPLE_MULTINOMIAL) return fail("resample: kind");
   const int64_t tiles = (n + HS_TILE - 1) / HS_TILE;
   float M = -gmx_inf();
-  for (int64_t b = 0; b < tiles; ++b) M = gmx_fmax(M, tmax[b]);
+  for (int64_t b = 0; b < tiles; ++b) M = gmx_rmax(M, tmax[b]);
   const float scale = gmx_pow2i(shift);
   const int32_t K = gmx_tile_exp(M);
   std::vector<uint64_t> cdf((size_t)n);
@@ -307,7 +307,7 @@ extern "C" int gmx_resample_tiles_q(int kind, const uint32_t key[2], const uint6
   if (!q || !tmax || !agg || !max_d || !total || !anc || shift < 1) return fail("resample_tiles_q: bad argument");
   const int64_t tiles = (n + HS_TILE - 1) / HS_TILE;
   float M = -gmx_inf();
-  for (int64_t b = 0; b < tiles; ++b) M = gmx_fmax(M, tmax[b]);
+  for (int64_t b = 0; b < tiles; ++b) M = gmx_rmax(M, tmax[b]);
   const int32_t K = gmx_tile_exp(M);
   std::vector<uint64_t> cdf((size_t)n);
   uint64_t prefix = 0;
@@ -402,7 +402,7 @@ extern "C" int gmx_shard_totals(const void* stats_all, int world, int64_t n, uin
   float M = -gmx_inf();
   for (int r = 0; r < world; ++r) {
     const float* tm = (const float*)((const uint8_t*)stats_all + r * stride + pad * 8);
-    for (int64_t t = 0; t < tiles; ++t) M = gmx_fmax(M, tm[t]);
+    for (int64_t t = 0; t < tiles; ++t) M = gmx_rmax(M, tm[t]);
   }
   const int32_t K = gmx_tile_exp(M);
   for (int r = 0; r < world; ++r) {

@@ -1374,7 +1374,9 @@ k_tile_stats(const float* __restrict__ lw, int64_t n, float scale, float* __rest
 #define RS_BLOCK (GMX_BLOCK * RS_TPB)
 #define RS_WAVES (RS_BLOCK / GMX_WAVE)
 static_assert(RS_MAX_TILES % RS_BLOCK == 0, "tile table shape");
-template <int kind, bool FROMQ>
+// PER: rows of the tile table a thread holds (PER * 256 >= n_tiles; 1, 2, 4 or 8 — the launch picks the smallest):
+// the statistics pass is unrolled over exactly the rows that exist.
+template <int kind, bool FROMQ, int PER>
 __global__ void __launch_bounds__(RS_BLOCK)
 k_offspring_tile(uint32_t k0, uint32_t k1, uint32_t u0_host, const float* __restrict__ lw, const uint64_t* __restrict__ qin,
                  const float* __restrict__ tmax, const uint64_t* __restrict__ agg, int64_t n, int n_tiles, float scale,
@@ -1416,7 +1418,7 @@ k_offspring_tile(uint32_t k0, uint32_t k1, uint32_t u0_host, const float* __rest
       x[c] = (i0 + c < n) ? xv : -gmx_inf();
     }
   }
-  constexpr int PER = RS_MAX_TILES / RS_BLOCK;
+  static_assert(PER >= 1 && PER * RS_BLOCK <= RS_MAX_TILES, "rows of the tile table per thread");
   uint64_t ta[PER];
   float tm[PER];
 #pragma unroll
@@ -1568,12 +1570,20 @@ static int launch_offspring_tile(int kind, const uint32_t key[2], const float* l
   const dim3 grid((unsigned)((tiles + RS_TPB - 1) / RS_TPB)), block(RS_BLOCK);
   hipStream_t st = (hipStream_t)stream;
   const float scale = gmx_pow2i(shift);
-#define GMX_LAUNCH_OT(KIND, FQ)                                                                                     \
-  hipLaunchKernelGGL((k_offspring_tile<KIND, FQ>), grid, block, 0, st, key[0], key[1], u0, lw_d, q_d, tile_max_d, \
+#define GMX_LAUNCH_OT3(KIND, FQ, PER_)                                                                               \
+  hipLaunchKernelGGL((k_offspring_tile<KIND, FQ, PER_>), grid, block, 0, st, key[0], key[1], u0, lw_d, q_d, tile_max_d, \
                      tile_agg_d, n, (int)tiles, scale, max_d, total_d, ancestors_d)
+#define GMX_LAUNCH_OT(KIND, FQ)                                                                                     \
+  do {                                                                                                              \
+    if (tiles <= 1 * RS_BLOCK) GMX_LAUNCH_OT3(KIND, FQ, 1);                                                         \
+    else if (tiles <= 2 * RS_BLOCK) GMX_LAUNCH_OT3(KIND, FQ, 2);                                                    \
+    else if (tiles <= 4 * RS_BLOCK) GMX_LAUNCH_OT3(KIND, FQ, 4);                                                    \
+    else GMX_LAUNCH_OT3(KIND, FQ, 8);                                                                               \
+  } while (0)
   if (kind == GMX_RESAMPLE_SYSTEMATIC) { if (q_d) GMX_LAUNCH_OT(GMX_RESAMPLE_SYSTEMATIC, true); else GMX_LAUNCH_OT(GMX_RESAMPLE_SYSTEMATIC, false); }
   else { if (q_d) GMX_LAUNCH_OT(GMX_RESAMPLE_STRATIFIED, true); else GMX_LAUNCH_OT(GMX_RESAMPLE_STRATIFIED, false); }
 #undef GMX_LAUNCH_OT
+#undef GMX_LAUNCH_OT3
   GMX_HIP(hipGetLastError());
   return 0;
 }

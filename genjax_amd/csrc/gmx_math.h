@@ -66,18 +66,17 @@ GMX_HD float gmx_pow2i(int k) { return gmx_u2f((uint32_t)(k + 127) << 23); }
 // largest log-weight is m gets the exponent k = ceil(m / ln 2) (clamped to +-2^29; -inf / NaN -> -2^29)
 // and its weights are taken relative to k * ln 2, so tiles combine by integer shifts 2^(k - K).
 #define GMX_TILE_EXP_LIM (1 << 29)
-GMX_HD int32_t gmx_tile_exp(float m) {
+GMX_HD int32_t gmx_tile_exp(float m) {               // straight-line: ceil(clamp(m / ln 2)), NaN -> -LIM
   const float t = m * gmx_u2f(0x3FB8AA3Bu);        // 1 / ln 2
-  if (!(t > -(float)GMX_TILE_EXP_LIM)) return -GMX_TILE_EXP_LIM;
-  if (t > (float)GMX_TILE_EXP_LIM) return GMX_TILE_EXP_LIM;
-  int32_t k = (int32_t)t;                          // toward zero
-  if ((float)k < t) ++k;
-  return k;
+  float tc = t > -(float)GMX_TILE_EXP_LIM ? t : -(float)GMX_TILE_EXP_LIM;
+  tc = tc < (float)GMX_TILE_EXP_LIM ? tc : (float)GMX_TILE_EXP_LIM;
+  return (int32_t)__builtin_ceilf(tc);
 }
 GMX_HD float gmx_tile_ref(int32_t k) { return (float)k * gmx_u2f(0x3F317218u); }   // k * ln 2
-GMX_HD uint64_t gmx_tile_scale(uint64_t v, int32_t k, int32_t K) {               // v * 2^(k - K), k <= K
-  const int64_t d = (int64_t)K - (int64_t)k;
-  return d < 64 ? v >> d : 0ull;
+// v * 2^(k - K) for k <= K and v < 2^63 (every tile sum is: shift + log2 n <= 62): a shift by 63 or more leaves 0
+GMX_HD uint64_t gmx_tile_scale(uint64_t v, int32_t k, int32_t K) {
+  const int32_t d = K - k;                         // |k|, |K| <= 2^29: no overflow
+  return v >> (d < 63 ? d : 63);
 }
 
 // exp(x).  Results below the smallest normal are flushed to +0 so that the

@@ -1376,7 +1376,16 @@ k_tile_stats(const float* __restrict__ lw, int64_t n, float scale, float* __rest
 static_assert(RS_MAX_TILES % RS_BLOCK == 0, "tile table shape");
 // PER: rows of the tile table a thread holds (PER * 256 >= n_tiles; 1, 2, 4 or 8 — the launch picks the smallest):
 // the statistics pass is unrolled over exactly the rows that exist.
-template <int kind, bool FROMQ, int PER>
+typedef uint32_t rs_u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));    // 16-byte store at a 4-byte-aligned address
+#define RS_FILL_SLOTS 2048             /* slots filled per pass (8 per thread): a tile owns ~1024 */
+// FILL: how a tile's slots [T0, T1) get their ancestors.
+//   false  every thread writes its own sources' slots (one loop over [e[0], e[4])): the trip count is the wave's
+//          largest offspring count, so the cost grows with the spread of the weights (config 2: ~70 instructions per
+//          wave, config 3: ~220) and a degenerate weight vector leaves ONE thread writing every slot;
+//   true   through LDS: every source with a slot writes its index at its first one, a max-scan fills the rest (source
+//          indices increase with the slot), and the block stores 8 consecutive slots per thread (two 16-byte stores):
+//          the same cost whatever the weights; a tile owning more than 2048 slots takes more passes (block-uniform).
+template <int kind, bool FROMQ, int PER, bool FILL>
 __global__ void __launch_bounds__(RS_BLOCK)
 k_offspring_tile(uint32_t k0, uint32_t k1, uint32_t u0_host, const float* __restrict__ lw, const uint64_t* __restrict__ qin,
                  const float* __restrict__ tmax, const uint64_t* __restrict__ agg, int64_t n, int n_tiles, float scale,
@@ -1545,8 +1554,63 @@ k_offspring_tile(uint32_t k0, uint32_t k1, uint32_t u0_host, const float* __rest
   // Sources past n have e[c] = n = e of the last real source, so they own no slot.
   const int32_t e1 = e[1], e2 = e[2], e3 = e[3], e4 = e[4];
   const int32_t src0 = (int32_t)i0;
-  for (int32_t j = e[0]; j < e4; ++j)
-    anc[j] = src0 + (j >= e1 ? 1 : 0) + (j >= e2 ? 1 : 0) + (j >= e3 ? 1 : 0);
+  if (!FILL) {
+    for (int32_t j = e[0]; j < e4; ++j)
+      anc[j] = src0 + (j >= e1 ? 1 : 0) + (j >= e2 ? 1 : 0) + (j >= e3 ? 1 : 0);
+    return;
+  }
+  static_assert(!FILL || RS_TPB == 1, "the LDS fill works on one tile per block");
+  __shared__ __attribute__((aligned(16))) uint32_t s_mark[RS_FILL_SLOTS];
+  __shared__ int32_t s_rng[2];
+  __shared__ uint32_t s_carry[RS_WAVES];
+  if (threadIdx.x == 0) s_rng[0] = e[0];
+  if (threadIdx.x == RS_BLOCK - 1) s_rng[1] = e4;
+  reinterpret_cast<uint4*>(s_mark)[threadIdx.x] = make_uint4(0u, 0u, 0u, 0u);
+  reinterpret_cast<uint4*>(s_mark)[threadIdx.x + RS_BLOCK] = make_uint4(0u, 0u, 0u, 0u);
+  __syncthreads();
+  const int32_t T0 = __builtin_amdgcn_readfirstlane(s_rng[0]), T1 = __builtin_amdgcn_readfirstlane(s_rng[1]);
+  for (int32_t base = T0; base < T1; base += RS_FILL_SLOTS) {      // block-uniform trip count (1 unless the tile owns > 2048 slots)
+    if (base != T0) {
+      reinterpret_cast<uint4*>(s_mark)[threadIdx.x] = make_uint4(0u, 0u, 0u, 0u);
+      reinterpret_cast<uint4*>(s_mark)[threadIdx.x + RS_BLOCK] = make_uint4(0u, 0u, 0u, 0u);
+      __syncthreads();
+    }
+    // a source's first slot inside this pass (clipped at `base`: a range that began in an earlier pass continues at 0)
+#pragma unroll
+    for (int c = 0; c < CDF_VEC; ++c) {
+      const int32_t lo = e[c] > base ? e[c] : base;
+      if (e[c + 1] > lo && lo - base < RS_FILL_SLOTS) s_mark[lo - base] = (uint32_t)(src0 + c);
+    }
+    __syncthreads();
+    uint4 a = reinterpret_cast<const uint4*>(s_mark)[2 * threadIdx.x];
+    uint4 b = reinterpret_cast<const uint4*>(s_mark)[2 * threadIdx.x + 1];
+    a.y = a.y > a.x ? a.y : a.x; a.z = a.z > a.y ? a.z : a.y; a.w = a.w > a.z ? a.w : a.z;
+    b.x = b.x > a.w ? b.x : a.w; b.y = b.y > b.x ? b.y : b.x; b.z = b.z > b.y ? b.z : b.y; b.w = b.w > b.z ? b.w : b.z;
+    const uint32_t incl = gmx_wave_umax_scan(b.w);
+    uint32_t carry = wave_shr1_u32(incl, 0u);
+    if (lane == 63) s_carry[wave] = incl;
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < RS_WAVES - 1; ++w) { const uint32_t v = s_carry[w]; carry = (w < wave && v > carry) ? v : carry; }
+    a.x = a.x > carry ? a.x : carry; a.y = a.y > carry ? a.y : carry; a.z = a.z > carry ? a.z : carry; a.w = a.w > carry ? a.w : carry;
+    b.x = b.x > carry ? b.x : carry; b.y = b.y > carry ? b.y : carry; b.z = b.z > carry ? b.z : carry; b.w = b.w > carry ? b.w : carry;
+    const int32_t j = base + 8 * (int32_t)threadIdx.x;
+    if (j + 8 <= T1) {
+      rs_u32x4_a4 va, vb;
+      va.x = a.x; va.y = a.y; va.z = a.z; va.w = a.w; vb.x = b.x; vb.y = b.y; vb.z = b.z; vb.w = b.w;
+      *reinterpret_cast<rs_u32x4_a4*>(anc + j) = va;
+      *reinterpret_cast<rs_u32x4_a4*>(anc + j + 4) = vb;
+    } else {
+      if (j + 0 < T1) anc[j + 0] = (int32_t)a.x;
+      if (j + 1 < T1) anc[j + 1] = (int32_t)a.y;
+      if (j + 2 < T1) anc[j + 2] = (int32_t)a.z;
+      if (j + 3 < T1) anc[j + 3] = (int32_t)a.w;
+      if (j + 4 < T1) anc[j + 4] = (int32_t)b.x;
+      if (j + 5 < T1) anc[j + 5] = (int32_t)b.y;
+      if (j + 6 < T1) anc[j + 6] = (int32_t)b.z;
+      if (j + 7 < T1) anc[j + 7] = (int32_t)b.w;
+    }
+  }
 }
 
 static int resample_shape(const char* who, int64_t n, int shift) {
@@ -1570,9 +1634,11 @@ static int launch_offspring_tile(int kind, const uint32_t key[2], const float* l
   const dim3 grid((unsigned)((tiles + RS_TPB - 1) / RS_TPB)), block(RS_BLOCK);
   hipStream_t st = (hipStream_t)stream;
   const float scale = gmx_pow2i(shift);
-#define GMX_LAUNCH_OT3(KIND, FQ, PER_)                                                                               \
-  hipLaunchKernelGGL((k_offspring_tile<KIND, FQ, PER_>), grid, block, 0, st, key[0], key[1], u0, lw_d, q_d, tile_max_d, \
-                     tile_agg_d, n, (int)tiles, scale, max_d, total_d, ancestors_d)
+  static const bool fill = []() { const char* e = getenv("GENMI_RS_FILL"); return !(e && e[0] == '0'); }();   // default: through LDS
+#define GMX_LAUNCH_OT4(KIND, FQ, PER_, FILL_)                                                                        \
+  hipLaunchKernelGGL((k_offspring_tile<KIND, FQ, PER_, FILL_>), grid, block, 0, st, key[0], key[1], u0, lw_d, q_d,     \
+                     tile_max_d, tile_agg_d, n, (int)tiles, scale, max_d, total_d, ancestors_d)
+#define GMX_LAUNCH_OT3(KIND, FQ, PER_) do { if (fill) GMX_LAUNCH_OT4(KIND, FQ, PER_, true); else GMX_LAUNCH_OT4(KIND, FQ, PER_, false); } while (0)
 #define GMX_LAUNCH_OT(KIND, FQ)                                                                                     \
   do {                                                                                                              \
     if (tiles <= 1 * RS_BLOCK) GMX_LAUNCH_OT3(KIND, FQ, 1);                                                         \
@@ -1584,6 +1650,7 @@ static int launch_offspring_tile(int kind, const uint32_t key[2], const float* l
   else { if (q_d) GMX_LAUNCH_OT(GMX_RESAMPLE_STRATIFIED, true); else GMX_LAUNCH_OT(GMX_RESAMPLE_STRATIFIED, false); }
 #undef GMX_LAUNCH_OT
 #undef GMX_LAUNCH_OT3
+#undef GMX_LAUNCH_OT4
   GMX_HIP(hipGetLastError());
   return 0;
 }

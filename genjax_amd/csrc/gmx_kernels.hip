@@ -1167,11 +1167,28 @@ k_offspring(int kind, uint32_t k0, uint32_t k1, const uint64_t* __restrict__ cdf
     s = (i == 0) ? slots_below(kind, key, u0, cdf_offset, D, total, n_over_total, eps, n_out_total)
                  : slots_below(kind, key, u0, c_lo, D, total, n_over_total, eps, n_out_total);
   }
-  if (!in_range) return;
   // clip to the slot range this call owns
   if (s < slot_offset) s = slot_offset;
   if (e > slot_offset + n_slots) e = slot_offset + n_slots;
-  for (int64_t j = s; j < e; ++j) anc[j - slot_offset] = (int32_t)i;
+  if (!in_range) e = s;
+  // a source with a few offspring writes them itself; a LONG run (a heavy particle: skewed weights) is written by the
+  // whole wave, 64 consecutive slots per pass — otherwise one lane would loop over all of it while 63 wait (a weight
+  // vector with all its mass on one particle: n_out iterations in one thread)
+  const int64_t cnt = e - s;
+  constexpr int64_t OWN = 8;
+  if (cnt <= OWN)
+    for (int64_t j = s; j < e; ++j) anc[j - slot_offset] = (int32_t)i;
+  uint64_t heavy = __ballot(cnt > OWN);
+  while (heavy) {                                  // wave-uniform
+    const int l = __ffsll((unsigned long long)heavy) - 1;
+    heavy &= heavy - 1ull;
+    const int64_t s_l = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)s >> 32), l) << 32) |
+                                  (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)s, l));
+    const int64_t e_l = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)e >> 32), l) << 32) |
+                                  (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)e, l));
+    const int32_t i_l = (int32_t)(i - lane + l);   // lanes hold consecutive sources
+    for (int64_t j = s_l + lane; j < e_l; j += GMX_WAVE) anc[j - slot_offset] = i_l;
+  }
 }
 
 __global__ void __launch_bounds__(GMX_BLOCK)

@@ -43,4 +43,35 @@ for name, lw_h in cases.items():
     torch.cuda.synchronize()
     out[name] = {"us_per_resample": 1e6 * (time.perf_counter() - t0) / reps,
                  "distinct_ancestors": int(torch.unique(anc).numel())}
+# the large-n path (n > 2^21: gmx_weight_cdf + gmx_ancestors = k_offspring, one source per thread)
+n2 = 4_000_000
+shift2 = cdf_shift(n2)
+ws2 = torch.zeros(((be.c.gmx_weight_cdf_workspace(n2) + 7) // 8,), dtype=torch.int64, device=dev)
+cdf = torch.zeros((n2,), dtype=torch.int64, device=dev)
+anc2 = torch.zeros((n2,), dtype=torch.int32, device=dev)
+big = {}
+for name, lw_h in cases.items():
+    lw = torch.from_numpy(np.resize(lw_h, n2).copy()).to(dev)
+    if name.startswith("one particle carries"):
+        lw[:] = -1e4
+        lw[123456] = 0.0
+
+    mx.copy_(lw.max().reshape(1))           # the site program's block maxima normally provide it
+
+    def go2():
+        be.check(be.c.gmx_weight_cdf(be.ptr(lw), n2, shift2, None, 0, be.ptr(mx), be.ptr(cdf), be.ptr(tot), be.ptr(ws2),
+                                     be.stream()), "gmx_weight_cdf")
+        be.check(be.c.gmx_ancestors(0, kk, be.ptr(cdf), n2, 0, be.ptr(tot), n2, 0, n2, be.ptr(anc2), be.stream()),
+                 "gmx_ancestors")
+    for _ in range(2):
+        go2()
+    torch.cuda.synchronize()
+    reps = 10
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        go2()
+    torch.cuda.synchronize()
+    big[name] = {"us_per_resample": 1e6 * (time.perf_counter() - t0) / reps,
+                 "distinct_ancestors": int(torch.unique(anc2).numel())}
+out["n = 4e6 (gmx_weight_cdf + gmx_ancestors)"] = big
 print(json.dumps(out))

@@ -1758,6 +1758,52 @@ __global__ void k_shard_plan(int kind, uint32_t k0, uint32_t k1, const uint64_t*
   if (total_out) *total_out = total;
 }
 
+// Routing of one source's slot run [s, e) (global slot numbers): a slot owned by this rank gets the source's local
+// index, a slot owned by rank d gets the source's state in this rank's send block for d.  `step` = 1: the thread
+// walks its own run; `step` = 64 with j0 = s + lane: the whole wave walks a LONG run (a heavy particle under skewed
+// weights would otherwise keep one lane looping while 63 wait).
+struct shard_route_ctx {
+  int64_t n, S, base, cap;
+  int rank;
+  int32_t* next_idx;
+  uint32_t* send;
+};
+__device__ __forceinline__ void shard_route_run(const shard_route_ctx& R, int64_t j0, int64_t e, int64_t step, int32_t i,
+                                                uint32_t v, bool& overflow) {
+  if (j0 >= e) return;
+  int64_t d = j0 / R.n;                     // owner of slot j; advances as j crosses a block of n
+  int64_t d_end = (d + 1) * R.n;
+  int64_t first = R.S > d * R.n ? R.S : d * R.n;      // first slot this rank sends to d
+  for (int64_t j = j0; j < e; j += step) {
+    while (j >= d_end) { ++d; d_end += R.n; first = d * R.n; }
+    if (d == R.rank) R.next_idx[j - R.base] = i;
+    else {
+      const int64_t k = j - first;
+      if (k < R.cap) R.send[d * R.cap + k] = v; else overflow = true;
+    }
+  }
+}
+#define SHARD_OWN_RUN 8
+__device__ __forceinline__ int64_t shard_readlane64(int64_t x, int l) {
+  return (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)x >> 32), l) << 32) |
+                   (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)x, l));
+}
+// every lane of the wave calls this (has = this lane's source is real and owns slots)
+__device__ __forceinline__ void shard_route_source(const shard_route_ctx& R, bool has, int64_t s, int64_t e, int32_t i,
+                                                   uint32_t v, int lane, bool& overflow) {
+  const int64_t cnt = has ? e - s : 0;
+  if (cnt > 0 && cnt <= SHARD_OWN_RUN) shard_route_run(R, s, e, 1, i, v, overflow);
+  uint64_t heavy = __ballot(cnt > SHARD_OWN_RUN);
+  while (heavy) {                           // wave-uniform
+    const int l = __ffsll((unsigned long long)heavy) - 1;
+    heavy &= heavy - 1ull;
+    const int64_t s_l = shard_readlane64(s, l), e_l = shard_readlane64(e, l);
+    const int32_t i_l = __builtin_amdgcn_readlane(i, l);
+    const uint32_t v_l = (uint32_t)__builtin_amdgcn_readlane((int)v, l);
+    shard_route_run(R, s_l + lane, e_l, GMX_WAVE, i_l, v_l, overflow);
+  }
+}
+
 __global__ void __launch_bounds__(GMX_BLOCK)
 k_shard_route(int kind, uint32_t k0, uint32_t k1, int64_t* __restrict__ plan, const uint64_t* __restrict__ cdf,
               int rank, int world, int64_t n, int64_t cap, const uint32_t* __restrict__ state,
@@ -1803,20 +1849,11 @@ k_shard_route(int kind, uint32_t k0, uint32_t k1, int64_t* __restrict__ plan, co
       s_lo = slots_below(kind, key, u0, c_lo, D, total, n_over_total, eps, N);
     }
   }
-  if (in_range && s_lo < e) {
-    const uint32_t v = state[i];
-    const int64_t S = bounds[rank];
-    int64_t d = s_lo / n;                   // owner of slot j; advances as j crosses a block of n
-    int64_t d_end = (d + 1) * n;
-    int64_t first = S > d * n ? S : d * n;  // first slot this rank sends to d
-    for (int64_t j = s_lo; j < e; ++j) {
-      if (j >= d_end) { ++d; d_end += n; first = d * n; }
-      if (d == rank) next_idx[j - base] = (int32_t)i;
-      else {
-        const int64_t k = j - first;
-        if (k < cap) send[d * cap + k] = v; else overflow = true;
-      }
-    }
+  {
+    const bool has = in_range && s_lo < e;
+    const uint32_t v = has ? state[i] : 0u;
+    shard_route_ctx R; R.n = n; R.S = bounds[rank]; R.base = base; R.cap = cap; R.rank = rank; R.next_idx = next_idx; R.send = send;
+    shard_route_source(R, has, s_lo, e, (int32_t)i, v, (int)(threadIdx.x & 63), overflow);
   }
   if (overflow) plan[GMX_PLAN_OVERFLOW] = 1;
 }
@@ -1952,24 +1989,13 @@ k_shard_step(int kind, uint32_t k0, uint32_t k1, const uint64_t* __restrict__ to
     s_lo = (int64_t)(((uint64_t)e_h << 32) | e_l);
     if (lane == 0) s_lo = slots_below(kind, key, u0, loc_prev + cdf_offset, D, total, n_over_total, eps, N);
   }
-  const int64_t S = s_bounds[rank];
+  shard_route_ctx R; R.n = n; R.S = s_bounds[rank]; R.base = base; R.cap = cap; R.rank = rank; R.next_idx = next_idx; R.send = send;
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     const int64_t i = i0 + c;
-    if (i < n && s_lo < e[c]) {
-      const uint32_t v = state[i];
-      int64_t d = s_lo / n;
-      int64_t d_end = (d + 1) * n;
-      int64_t first = S > d * n ? S : d * n;
-      for (int64_t j = s_lo; j < e[c]; ++j) {
-        if (j >= d_end) { ++d; d_end += n; first = d * n; }
-        if (d == rank) next_idx[j - base] = (int32_t)i;
-        else {
-          const int64_t k = j - first;
-          if (k < cap) send[d * cap + k] = v; else overflow = true;
-        }
-      }
-    }
+    const bool has = i < n && s_lo < e[c];
+    const uint32_t v = has ? state[i] : 0u;
+    shard_route_source(R, has, s_lo, e[c], (int32_t)i, v, lane, overflow);
     if (i < n) s_lo = e[c];
   }
   if (overflow) plan[GMX_PLAN_OVERFLOW] = 1;

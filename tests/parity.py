@@ -242,7 +242,7 @@ def check_plates(n=257, seed=4):
 # shard; the all-to-all is a block copy.  Result must equal the oracle's
 # single-population resample, for any world size and capacity >= need.
 # ---------------------------------------------------------------------------
-def check_shard_route(n=1000, world=4, capacity=None, kind=None, seed=0, skew=0.0, dead=False, fused=False):
+def check_shard_route(n=1000, world=4, capacity=None, kind=None, seed=0, skew=0.0, dead=False, fused=False, spike=0.0):
     from ctypes import c_uint32
     from genjax_amd import _lib
     be = _lib.get()
@@ -253,6 +253,8 @@ def check_shard_route(n=1000, world=4, capacity=None, kind=None, seed=0, skew=0.
     rng = np.random.default_rng(seed)
     lw = rng.normal(0, 2, N).astype(np.float32)
     lw += (skew * (np.arange(N) // n)).astype(np.float32)          # later ranks heavier
+    if spike:
+        lw[n + n // 2 + 7] += np.float32(spike)                    # one heavy particle on rank 1: its run spans ranks
     if dead:
         lw[:] = -np.inf
     x = rng.normal(0, 1, N).astype(np.float32)

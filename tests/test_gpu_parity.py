@@ -359,6 +359,7 @@ def test_plates_match_oracle(gpu, n):
     (1024, 8, {"skew": -3.0, "seed": 2}), (64, 2, {"dead": True}), (100_352, 8, {"seed": 5}),
     (100_352, 8, {"seed": 6, "capacity": 12_500}), (250_880, 2, {"seed": 7, "skew": 0.5}),
     (101_376, 5, {"seed": 8}), (2048, 4, {"seed": 9, "kind": 1}),
+    (2048, 4, {"seed": 12, "spike": 14.0}), (4096, 3, {"seed": 13, "spike": 30.0, "kind": 1}),   # wave-cooperative long runs
 ])
 @pytest.mark.parametrize("fused", [False, True, "tiles"])
 def test_global_resampling_routes_match_oracle(gpu, n, world, kw, fused):

@@ -70,7 +70,8 @@ def j_step(x_prev, z):
 
 
 shift = cdf_shift(n)
-z = [torch.zeros((1, n), dtype=torch.float32, device=dev) for _ in range(2)]
+RING = int(os.environ.get("RING", 2))     # noise buffers: the noise stream may run RING steps ahead of the chain
+z = [torch.zeros((1, n), dtype=torch.float32, device=dev) for _ in range(RING)]
 xs = [torch.zeros((1, n), dtype=torch.float32, device=dev) for _ in range(2)]
 lw = torch.zeros((n,), dtype=torch.float32, device=dev)
 wdummy = torch.zeros((1, n), dtype=torch.float32, device=dev)
@@ -92,7 +93,7 @@ keys = [split(fold_in(key, t), 3) for t in range(T)]
 
 def launch_noise(t):
     bufs = [None] * len(pN.comp.outputs)
-    bufs[pN.ro[1]] = z[t % 2]
+    bufs[pN.ro[1]] = z[t % RING]
     if pN.wo[0] == "out":
         bufs[pN.wo[1]] = wdummy
     pN.comp.run(pN.leaves((), ChoiceMap.empty()), (n,), lazy_split(keys[t][0], n), red_out=npart, out_buffers=bufs)
@@ -104,7 +105,7 @@ def launch_j(t):
         prog, leaves = pJ0, pJ0.leaves((z[0].reshape(n),), obs)
     else:
         prog = pJ
-        leaves = prog.leaves((Gathered(xs[(t - 1) % 2].reshape(n), anc), z[t % 2].reshape(n)), obs)
+        leaves = prog.leaves((Gathered(xs[(t - 1) % 2].reshape(n), anc), z[t % RING].reshape(n)), obs)
     bufs = [None] * len(prog.comp.outputs)
     bufs[prog.ro[1]] = xs[t % 2]
     bufs[prog.wo[1]] = lw.reshape(1, n)
@@ -127,8 +128,8 @@ def enqueue(two_streams: bool):
         B.wait_stream(A)
     for t in range(T):
         with torch.cuda.stream(B):
-            if two_streams and t >= 2:
-                B.wait_event(done_j[t - 2])             # z[t % 2] is free once J_{t-2} has read it
+            if two_streams and t >= RING:
+                B.wait_event(done_j[t - RING])          # z[t % RING] is free once J_{t-RING} has read it
             launch_noise(t)
             if two_streams:
                 ready_z[t] = torch.cuda.Event()
@@ -144,7 +145,7 @@ def enqueue(two_streams: bool):
         A.wait_stream(B)
 
 
-out = {"n": n, "T": T, "fused_sweep_us_per_step": 1e6 * dt_ref / T}
+out = {"n": n, "T": T, "ring": RING, "fused_sweep_us_per_step": 1e6 * dt_ref / T}
 for two in (False, True):
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())

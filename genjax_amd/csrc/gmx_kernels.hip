@@ -182,6 +182,7 @@ static int parse_program(const uint32_t* blob, size_t n_words, gmx_program& P) {
       case OP_LDKEY: ok = R2(dst); P.uses_key = true; break;
       case OP_KDERIVE: ok = R2(dst) && R2(a); break;
       case OP_KDERIVER: ok = R2(dst) && R2(a) && R(b); break;
+      case OP_KSPLITU: ok = R2(dst) && R(a) && R(b); break;
       case OP_MOV: case OP_NEG: case OP_ABS: case OP_EXP: case OP_LOG: case OP_LOG1P:
       case OP_SQRT: case OP_SIN: case OP_COS: case OP_TANH: case OP_SIGMOID:
       case OP_SOFTPLUS: case OP_FLOOR: case OP_CEIL: case OP_ROUND: case OP_LGAMMA:
@@ -261,7 +262,7 @@ static int jit_pp_for(const gmx_program* p) {
   // inputs the resampling kernels just wrote): sweep 2843 -> 2730 us; 2, 3 and 8 are slower.  Only
   // for small programs: registers scale with the particle count per thread.
   // OP_REDLSE partials (max, sum exp) are per 256-particle group by definition: one particle per thread.
-  return (p->n_regs <= 16 && p->n_instr <= 64 && !p->uses_lse) ? 4 : 1;
+  return (p->n_regs <= 16 && p->n_instr <= 96 && !p->uses_lse) ? 4 : 1;   // 96: an MH move chained with the extension (~65)
 }
 
 // prefetch plan of a specialised kernel (gmx_jit.h): the distinct (slot, flags) of the program's per-particle

@@ -88,5 +88,9 @@ enum gmx_op {
   OP_LOOP = 100,      // imm = trip count: the block up to the matching OP_ENDLOOP runs imm times, t = 0 .. imm-1
   OP_ENDLOOP = 101,
   OP_LDT = 102,       // r[dst] = (i32) t, the iteration number (0 outside a loop)
-  OP__COUNT = 103
+  // a SECOND per-particle key in one program (two generative-function calls chained into one launch, each with its
+  // own launch key): (r[dst], r[dst+1]) = split((r[a], r[b]), *)[index_offset + i] — what OP_LDKEY does in
+  // GMX_KEY_SPLIT mode for gmx_run_args.key0 / key1, here for a key whose two words are launch values
+  OP_KSPLITU = 103,
+  OP__COUNT = 104
 };

@@ -132,6 +132,11 @@ GMX_HD void gmx_vm_step(Regs& R, const W w, int64_t i, bool active, const gmx_ru
       } break;
       case OP_LDIDX: r0 = (uint32_t)(A.index_offset + i); break;
       case OP_LDT: r0 = t; break;
+      case OP_KSPLITU: {
+        gmx_key k; k.k0 = SRC(a); k.k1 = SRC(b);
+        k = gmx_split_child(k, (uint64_t)(A.index_offset + i));
+        r0 = k.k0; r1 = k.k1; wr = 2;
+      } break;
       case OP_MOV: r0 = SRC(a); break;
       // ---- f32 binary ----
       case OP_ADD: r0 = gmx_asu(FSRC(a) + FSRC(b)); break;

@@ -690,12 +690,25 @@ class BootstrapSweep:
             self.p_mh_init = MinimalMH(self.init, (), ch, self.rejuvenate, (n,))
             self.p_mh_step = MinimalMH(self.step, (Gathered(self.xm[0], self.anc),) + tuple(self.step_extra(1)), ch,
                                        self.rejuvenate, (n,))
+        # the MH move and the extension that follows it as ONE program / one launch per step (static.MinimalMHGenerate:
+        # same keys, same draws, same bits; one launch boundary and one trip of the moved state through memory less).
+        # GENMI_FUSE_MH=0 keeps the two launches.
+        self.p_mhvm_init = self.p_mhvm_step = None
+        if self.rejuvenate is not None and os.environ.get("GENMI_FUSE_MH", "1") != "0":
+            from ..static import MinimalMHGenerate
+            ex = tuple(self.step_extra(1))
+            self.p_mhvm_init = MinimalMHGenerate(self.init, (), ch, self.rejuvenate, self.step, ex, obs0, (n,))
+            self.p_mhvm_step = MinimalMHGenerate(self.step, (Gathered(self.xm[0], self.anc),) + ex, ch, self.rejuvenate,
+                                                 self.step, ex, obs0, (n,))
         if self.specialize:
             self.p_init.comp.specialize()
             self.p_step.comp.specialize()
             if self.rejuvenate is not None:
                 self.p_mh_init.comp.specialize()
                 self.p_mh_step.comp.specialize()
+            if self.p_mhvm_init is not None:
+                self.p_mhvm_init.comp.specialize()
+                self.p_mhvm_step.comp.specialize()
         # block partials: sized for the interpreter's one row per 256 particles; a specialised kernel
         # writes fewer rows (gmx_program_grid), asked per launch in _rows()
         self.partials = torch.zeros((2, (n + 255) // 256), dtype=torch.float32, device=dev)
@@ -705,6 +718,10 @@ class BootstrapSweep:
         self.tile_agg = torch.zeros(((n + 1023) // 1024,), dtype=torch.int64, device=dev)
         self.tile_stats = bool(self.fused and os.environ.get("GENMI_TILE_STATS", "1") != "0"
                                and self.p_init.comp.writes_tile_stats() and self.p_step.comp.writes_tile_stats())
+        if self.p_mhvm_init is not None and self.tile_stats and not (self.p_mhvm_init.comp.writes_tile_stats()
+                                                                     and self.p_mhvm_step.comp.writes_tile_stats()):
+            self.p_mhvm_init = self.p_mhvm_step = None      # the chained programs are too large for the tile form
+        self.fuse_mh = self.p_mhvm_init is not None
         # ... and, on request (GENMI_TILE_Q=1), every particle's fixed-point weight (8 bytes each): the resampler then
         # reads those and skips one exp + one f32 -> u64 conversion per particle.  Measured on MI355X (config 2):
         # 181 fewer vector instructions per wave in k_offspring_tile, 39 more in the site program — and the same
@@ -721,10 +738,14 @@ class BootstrapSweep:
         # tiles on average, so the CDF rebuild (4 exp + scan + 5 slot edges per thread and tile) runs twice per
         # workgroup — +1340 vector instructions per wave against the 806 of k_offspring_tile, more than the launch
         # boundary it removes.
-        gatherer = self.p_step if self.rejuvenate is None else self.p_mh_step
+        if self.rejuvenate is None:
+            gatherers = (self.p_step,)
+        elif self.fuse_mh:
+            gatherers = (self.p_mhvm_init, self.p_mhvm_step)
+        else:
+            gatherers = (self.p_mh_init, self.p_mh_step)
         self.fuse = bool(self.tile_stats and self.tile_q is None and os.environ.get("GENMI_FUSE_RESAMPLE", "0") == "1"
-                         and gatherer.comp.fuses_resample()
-                         and (self.rejuvenate is None or self.p_mh_init.comp.fuses_resample()))
+                         and all(p_.comp.fuses_resample() for p_ in gatherers))
         if self.fuse:
             self.lw_pp = [self.lw, torch.zeros_like(self.lw)]
             self.partials_pp = [self.partials, torch.zeros_like(self.partials)]
@@ -792,9 +813,37 @@ class BootstrapSweep:
         prog.comp.run(leaves, (n,), lazy_split(k_mh, n), out_buffers=bufs,
                       resample_in=self._resample_in(t) if self.fuse else None)
 
+    def _launch_mhvm(self, t):
+        """step t >= 1 as ONE launch: the MH move on the resampled particles of step t-1 (as _launch_mh), then the
+        extension to step t (as _launch_vm) from the moved state"""
+        n = self.n
+        k_mh, k_prop = self.step_keys[t][2], self.step_keys[t][0]
+        ch = ChoiceMap.empty().set(self.obs_addr, self.ys[t - 1]).set(self.state_addr,
+                                                                      Gathered(self.x[(t - 1) % 2], self.anc))
+        obs = ChoiceMap.empty().set(self.obs_addr, self.ys[t])
+        ex = tuple(self.step_extra(t))
+        kw = k_prop.host()
+        if t == 1:
+            prog = self.p_mhvm_init
+            leaves = prog.leaves((), ch, self.rejuvenate, ex, obs, (int(kw[0]), int(kw[1])))
+        else:
+            prog = self.p_mhvm_step
+            a = Gathered(self.xm[(t - 1) % 2], self.anc)
+            leaves = prog.leaves((a,) + tuple(self.step_extra(t - 1)), ch, self.rejuvenate, ex, obs,
+                                 (int(kw[0]), int(kw[1])))
+        bufs = [None] * len(prog.comp.outputs)
+        bufs[prog.mo[1]] = self.xm_store[t % 2]
+        bufs[prog.ao[1]] = self.accept.reshape(1, n)
+        bufs[prog.ro[1]] = self.x_store[t % 2]
+        bufs[prog.wo[1]] = self.lw_pp[t % 2].reshape(1, n)
+        prog.comp.run(leaves, (n,), lazy_split(k_mh, n), red_out=self.partials_pp[t % 2], out_buffers=bufs,
+                      tile_stats=(self.tile_agg_pp[t % 2], self.shift, self.tile_q) if self.tile_stats else None,
+                      resample_in=self._resample_in(t) if self.fuse else None)
+
     def _rows(self, t) -> int:
         """partial rows the site program of step t wrote"""
-        prog = self.p_init if t == 0 else self.p_step
+        prog = self.p_init if t == 0 else (self.p_step if not self.fuse_mh else
+                                           (self.p_mhvm_init if t == 1 else self.p_mhvm_step))
         return int(_lib.get().c.gmx_program_grid(prog.comp.handle, self.n))
 
     def _launch_cdf(self, t):
@@ -840,10 +889,14 @@ class BootstrapSweep:
         previous sweep's log-weights): bench.py times that variant to get the site program's cost
         IN the sweep as a difference."""
         for t in range(self.T):
-            if t >= 1 and self.rejuvenate is not None:
-                self._launch_mh(t)
-            if not skip_vm:
-                self._launch_vm(t)
+            if t >= 1 and self.fuse_mh:
+                if not skip_vm:
+                    self._launch_mhvm(t)
+            else:
+                if t >= 1 and self.rejuvenate is not None:
+                    self._launch_mh(t)
+                if not skip_vm:
+                    self._launch_vm(t)
             if self.fuse and t < self.T - 1:
                 continue                   # step t's weights are resampled by step t+1's launch itself
             if self.fused:

@@ -35,7 +35,7 @@ OPC = dict(
     S_NORMAL=70, S_UNIFORM=71, S_FLIP=72, S_BERNL=73, S_BETA=74, S_CATSTEP=75, S_LOGGAMMA=76,
     L_NORMAL=80, L_UNIFORM=81, L_FLIP=82, L_BERNL=83, L_BETA=84,
     REDMAX=90, REDLSE=91,
-    LOOP=100, ENDLOOP=101, LDT=102,
+    LOOP=100, ENDLOOP=101, LDT=102, KSPLITU=103,
 )
 
 UNARY = {"MOV", "NEG", "ABS", "EXP", "LOG", "LOG1P", "SQRT", "SIN", "COS", "TANH", "SIGMOID",
@@ -436,7 +436,7 @@ def compile_graph(g: Graph):
                 emit("MOV", dst + k, R(init) + k)
         elif op == "KDERIVE":
             emit(op, dst, R(n.args[0]), 0, n.imm)
-        elif op == "KDERIVER":
+        elif op in ("KDERIVER", "KSPLITU"):
             emit(op, dst, R(n.args[0]), R(n.args[1]))
         elif op == "CATIDX":        # second register of a categorical state pair
             emit("MOV", dst, R(n.args[0]) + 1)

@@ -906,6 +906,35 @@ def _rec_to_prev(rec):
     return {"sub": {a: _rec_to_prev(r) for a, r in rec.sites.items()}, "retval": ret}
 
 
+def _trace_mh_move(tr, ctx, gen_fn, sargs, scon, rspec, syms):
+    """Trace one MH move on the trace of `gen_fn(*sargs)` with choices `scon` into tr.graph (MinimalMH's program body):
+    returns (the selected return value, the accept flag) as expressions."""
+    g = tr.graph
+    rec0, ret0, _, _ = call_gen_fn(ctx, "generate", gen_fn, None, sargs, scon, None, None, None, ())
+    sprev = _rec_to_prev(rec0)
+    kexpr = Expr(g.add("LDKEY", dtype="key"))
+    k_acc = Expr(g.add("KDERIVE", (kexpr.node,), imm=1, dtype="key"))      # (k_edit, k_acc) = split(key_i)
+    k_edit = Expr(g.add("KDERIVE", (kexpr.node,), imm=0, dtype="key"))
+    mode, constraint = "static_edit", ChoiceMap.empty()
+    if rspec.kind == "update":
+        mode, constraint = "update", _sym_constraint(rspec.tree, syms)
+    elif rspec.kind == "regen":
+        mode = "regen"
+    _bind_request_leaves(rspec, syms)
+    rec, retval, w, _ = call_gen_fn(ctx, mode, gen_fn, k_edit, sargs, constraint, sprev, rspec, syms, ())
+    from .distributions import uniform as _uniform
+    if w is None:
+        w = Expr(g.const_f32(0.0)) + 0.0
+    u = _uniform.sym_sample(k_acc, (0.0, 1.0))
+    acc = Expr(g.add("LOG", (u.node,), dtype="f32")) < w
+
+    def sel(new, old):
+        if isinstance(new, tuple):
+            return tuple(sel(a, b) for a, b in zip(new, old))
+        return T.where(acc, new, old)
+    return sel(retval, ret0), acc
+
+
 class MinimalMH:
     """One Metropolis-Hastings move per particle (`run_mh`'s program) on a trace that is never
     materialised: the inputs are the particle's arguments and choice VALUES (typically gathered
@@ -929,29 +958,8 @@ class MinimalMH:
             syms = [tr.sym_leaf(s, j) for j, s in enumerate(self.specs)]
             sargs = unflatten(self.atree, lambda j: syms[j].value)
             scon = _sym_constraint(self.ctree, syms)
-            rec0, ret0, _, _ = call_gen_fn(ctx, "generate", gen_fn, None, sargs, scon, None, None, None, ())
-            sprev = _rec_to_prev(rec0)
-            kexpr = Expr(g.add("LDKEY", dtype="key"))
-            k_acc = Expr(g.add("KDERIVE", (kexpr.node,), imm=1, dtype="key"))      # (k_edit, k_acc) = split(key_i)
-            k_edit = Expr(g.add("KDERIVE", (kexpr.node,), imm=0, dtype="key"))
-            mode, constraint = "static_edit", ChoiceMap.empty()
-            if rspec.kind == "update":
-                mode, constraint = "update", _sym_constraint(rspec.tree, syms)
-            elif rspec.kind == "regen":
-                mode = "regen"
-            _bind_request_leaves(rspec, syms)
-            rec, retval, w, _ = call_gen_fn(ctx, mode, gen_fn, k_edit, sargs, constraint, sprev, rspec, syms, ())
-            from .distributions import uniform as _uniform
-            if w is None:
-                w = Expr(g.const_f32(0.0)) + 0.0
-            u = _uniform.sym_sample(k_acc, (0.0, 1.0))
-            acc = Expr(g.add("LOG", (u.node,), dtype="f32")) < w
-
-            def sel(new, old):
-                if isinstance(new, tuple):
-                    return tuple(sel(a, b) for a, b in zip(new, old))
-                return T.where(acc, new, old)
-            self.ro = tr.emit_output(sel(retval, ret0))
+            selected, acc = _trace_mh_move(tr, ctx, gen_fn, sargs, scon, rspec, syms)
+            self.ro = tr.emit_output(selected)
             self.ao = tr.emit_output(acc)
         self.comp = Compiled(tr)
 
@@ -963,6 +971,68 @@ class MinimalMH:
         if a != self.atree or c != self.ctree or rkey != self.rkey:
             raise ValueError("MinimalMH: call structure differs from the compiled one")
         return flat.leaves
+
+
+class MinimalMHGenerate:
+    """MinimalMH on `mh_fn`'s trace, THEN MinimalGenerate of `gen_fn` from the moved state — one program, one launch:
+    what BootstrapSweep(rejuvenate=...) issues per step (the MH move on the resampled particles of step t-1, then the
+    extension to step t).  The two calls keep their own keys: the move draws from the launch key (OP_LDKEY), the
+    extension from split((k0, k1), n)[i] with (k0, k1) two launch values (OP_KSPLITU) — so every draw, weight and
+    accept bit equals those of the two separate launches.  `gen_args(moved)` builds the extension's arguments from
+    the moved state (an expression) and the launch values in `gen_extra`."""
+
+    def __init__(self, mh_fn, mh_args, choices: ChoiceMap, request, gen_fn, gen_extra: tuple, gen_constraint: ChoiceMap,
+                 batch: tuple):
+        flat = Flat()
+        self.atree = flat.add(tuple(mh_args))
+        self.ctree = flat.add(choices)
+        rspec, self.rkey = _flatten_request(request, flat)
+        self.etree = flat.add(tuple(gen_extra))
+        self.gtree = flat.add(gen_constraint)
+        self.ktree = flat.add((0, 0))                 # the extension's launch key, two 32-bit words
+        self.specs = tuple(leaf_spec(v, batch) for v in flat.leaves)
+        tr = Tracing(len(batch))
+        ctx = _Ctx(tr)
+        ctx.store_sites = False
+        g = tr.graph
+        with T.tracing(g):
+            syms = [tr.sym_leaf(s, j) for j, s in enumerate(self.specs)]
+            sargs = unflatten(self.atree, lambda j: syms[j].value)
+            scon = _sym_constraint(self.ctree, syms)
+            moved, acc = _trace_mh_move(tr, ctx, mh_fn, sargs, scon, rspec, syms)
+            self.mo = tr.emit_output(moved)
+            self.ao = tr.emit_output(acc)
+            extra = unflatten(self.etree, lambda j: syms[j].value)
+            gcon = _sym_constraint(self.gtree, syms)
+            kw = unflatten(self.ktree, lambda j: syms[j].value)
+            k2 = Expr(g.add("KSPLITU", (kw[0].node, kw[1].node), dtype="key"))
+            ctx2 = _Ctx(tr)
+            ctx2.store_sites = False
+            rec, retval, w, _ = call_gen_fn(ctx2, "generate", gen_fn, k2, (moved,) + tuple(extra), gcon, None, None, None, ())
+            self.ro = tr.emit_output(retval)
+            if w is None:
+                w = Expr(g.const_f32(0.0)) + 0.0
+            self.wo = tr.emit_output(w)
+            g.add("REDMAX", (w.node,), dtype="none")
+        self.comp = Compiled(tr)
+
+    def leaves(self, mh_args, choices, request, gen_extra, gen_constraint, key_words):
+        flat = Flat()
+        a = flat.add(tuple(mh_args))
+        c = flat.add(choices)
+        _, rkey = _flatten_request(request, flat)
+        e = flat.add(tuple(gen_extra))
+        gc = flat.add(gen_constraint)
+        flat.add((_as_i32(key_words[0]), _as_i32(key_words[1])))
+        if a != self.atree or c != self.ctree or rkey != self.rkey or e != self.etree or gc != self.gtree:
+            raise ValueError("MinimalMHGenerate: call structure differs from the compiled one")
+        return flat.leaves
+
+
+def _as_i32(u):
+    """a 32-bit key word as the signed launch value with the same bits"""
+    u = int(u) & 0xFFFFFFFF
+    return u - (1 << 32) if u >= (1 << 31) else u
 
 
 def _mh_select(tr: Tracing, acc: Expr, rec, prev):

@@ -937,7 +937,7 @@ def oracle_nlssm_mh_sweep(n, T, seed):
     return {"x": x, "lw": olw, "acc": oacc, "terms": terms, "resampled": x[anc]}
 
 
-def check_nlssm_mh_sweep(n=2000, T=5, seed=7, capture=False, specialize=False):
+def check_nlssm_mh_sweep(n=2000, T=5, seed=7, capture=False, specialize=False, want_chained=None):
     """BASELINE config 3 as ONE captured sweep: BootstrapSweep(rejuvenate=...) (k_vm -> resample ->
     fused MH -> k_vm ...) against the oracle run step by step with the sweep's key schedule
     (step key fold_in(key, t) -> (k_prop, k_res, k_mh); resampling of step t-1 uses ITS k_res)."""
@@ -951,6 +951,8 @@ def check_nlssm_mh_sweep(n=2000, T=5, seed=7, capture=False, specialize=False):
     oreq = {"x": O.Rejuvenate(O.normal, lambda chm: (chm.get_value(), np.float32(0.5)))}
     sw = smc.BootstrapSweep(init, step, n, T, step_extra=lambda t: (float(t),), rejuvenate=req,
                             specialize=specialize).prepare(G.key(seed), torch.from_numpy(ys))
+    if want_chained is not None:
+        assert sw.fuse_mh == want_chained, "the sweep did not take the requested (chained / two-launch) MH form"
     if capture:
         sw.capture()
     sw.launch()

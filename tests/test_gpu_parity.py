@@ -955,3 +955,20 @@ def test_resampler_inside_the_step_launch(gpu, monkeypatch, resample):
             parity.check_nlssm_mh(n=2000, T=4)
     finally:
         G.clear_caches()
+
+
+@pytest.mark.parametrize("chained", ["0", "1"])
+def test_mh_move_chained_into_the_extension(gpu, monkeypatch, chained):
+    """GENMI_FUSE_MH on the HIP library: the MH move + the extension as one specialised program (4 particles per
+    thread, tile statistics from its epilogue) or as two launches — ancestors, states, weights, accept bits and
+    evidence equal the oracle's, interpreter and specialised kernel, eager and captured."""
+    import genjax_amd as G
+    monkeypatch.setenv("GENMI_FUSE_MH", chained)
+    G.clear_caches()
+    try:
+        parity.check_nlssm_mh_sweep(n=3000, T=5, want_chained=(chained == "1"))
+        parity.check_nlssm_mh_sweep(n=100_003, T=4, specialize=True, capture=True, want_chained=(chained == "1"))
+        res = parity.check_vector_mh_sweep(n=2500, T=4)
+        assert 0.3 < res["accept_rate"] < 1.0
+    finally:
+        G.clear_caches()

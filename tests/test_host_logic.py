@@ -1025,3 +1025,15 @@ def test_sweep_with_and_without_the_resampler_in_the_step_launch(monkeypatch, fu
     assert res["ancestors_equal"] and res["x_equal"] and res["totals_equal"] and res["lw_max_abs_diff"] == 0.0
     assert res["log_ml"] == res["log_ml_oracle"]
     parity.check_nlssm_mh(n=1500, T=4)
+
+
+@pytest.mark.parametrize("chained", ["0", "1"])
+def test_mh_sweep_with_the_move_chained_into_the_extension(monkeypatch, chained):
+    """GENMI_FUSE_MH: BootstrapSweep(rejuvenate=...) issues the MH move and the extension that follows it as one
+    program (static.MinimalMHGenerate, the extension's key through OP_KSPLITU) or as two launches — the same sweep,
+    equal to the oracle's step-by-step statement either way (scalar and vector state)."""
+    from tests import parity
+    monkeypatch.setenv("GENMI_FUSE_MH", chained)
+    parity.check_nlssm_mh_sweep(n=1500, T=5, want_chained=(chained == "1"))
+    res = parity.check_vector_mh_sweep(n=1200, T=4)
+    assert 0.3 < res["accept_rate"] < 1.0

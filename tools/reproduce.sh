@@ -14,6 +14,7 @@ timeout 120 python -c "import __graft_entry__ as g; g.smoke()" > $out/${tag}_smo
 timeout 600 python bench.py > $out/${tag}_bench.json 2> $out/${tag}_bench.err
 timeout 300 python bench.py --sharded --no-cpu-baseline > $out/${tag}_bench_sharded_world1.json 2> /dev/null
 timeout 300 python tools/experiments/noise_ahead.py > $out/${tag}_experiment_noise_ahead.json 2> /dev/null
+timeout 300 python tools/experiments/skewed_resample.py 2> /dev/null | tail -1 > $out/${tag}_skewed_resample.json
 timeout 600 bash tools/prof.sh $tag > $out/${tag}_pmc_summary.txt 2>&1
 timeout 600 bash tools/traffic.sh $tag > $out/${tag}_traffic.txt 2>&1
 timeout 300 python tools/bench_configs.py > $out/${tag}_configs_3_4.json 2> /dev/null

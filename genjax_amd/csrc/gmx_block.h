@@ -25,7 +25,9 @@ __device__ __forceinline__ uint32_t gmx_dpp(uint32_t identity, uint32_t v) {
 // row is masked is simply not written — the identity element for free.  (Through __builtin_amdgcn_update_dpp the
 // compiler emits mov-identity + v_mov_dpp + the operation, and for a float max a canonicalising v_max before it.)
 // `s_nop 1`: a DPP read of a VGPR needs two wait states after the VALU write of it, and the hazard recogniser does not
-// look inside inline assembly.
+// look inside inline assembly; GMX_DPP_ASM_ENTER (`s_nop 4`, once per scan) covers the longest DPP hazard against
+// whatever the compiler scheduled just before the block (a VALU write of EXEC: five wait states).
+#define GMX_DPP_ASM_ENTER "s_nop 4\n\t"
 #define GMX_DPP_ASM_STEPS(OP) \
   OP("row_shr:1 row_mask:0xf bank_mask:0xf") OP("row_shr:2 row_mask:0xf bank_mask:0xf") \
   OP("row_shr:4 row_mask:0xf bank_mask:0xf") OP("row_shr:8 row_mask:0xf bank_mask:0xf") \
@@ -35,7 +37,7 @@ __device__ __forceinline__ uint32_t gmx_dpp(uint32_t identity, uint32_t v) {
 // NaN and +0 for max(-0, +0): gmx_rmax below is the same function on the host.
 __device__ __forceinline__ float wave_max_scan(float v) {
 #define GMX_OP(CTRL) "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 " CTRL "\n\t"
-  asm(GMX_DPP_ASM_STEPS(GMX_OP) : "+v"(v));
+  asm(GMX_DPP_ASM_ENTER GMX_DPP_ASM_STEPS(GMX_OP) : "+v"(v));
 #undef GMX_OP
   return v;
 }
@@ -90,7 +92,7 @@ __device__ __forceinline__ void gmx_red_lse(float* red_out, float* lds4, uint32_
 __device__ __forceinline__ uint64_t wave_scan_u64(uint64_t v) {
   uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
 #define GMX_OP(CTRL) "s_nop 1\n\tv_add_co_u32_dpp %0, vcc, %0, %0 " CTRL "\n\tv_addc_co_u32_dpp %1, vcc, %1, %1, vcc " CTRL "\n\t"
-  asm(GMX_DPP_ASM_STEPS(GMX_OP) : "+v"(lo), "+v"(hi) : : "vcc");
+  asm(GMX_DPP_ASM_ENTER GMX_DPP_ASM_STEPS(GMX_OP) : "+v"(lo), "+v"(hi) : : "vcc");
 #undef GMX_OP
   return ((uint64_t)hi << 32) | lo;
 }

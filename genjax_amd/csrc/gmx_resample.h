@@ -103,7 +103,7 @@ GMX_HD size_t gmx_rs_window_lds(int64_t n) {
 // inclusive max-scan of u32 over the wave
 __device__ __forceinline__ uint32_t gmx_wave_umax_scan(uint32_t v) {
 #define GMX_OP(CTRL) "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 " CTRL "\n\t"
-  asm(GMX_DPP_ASM_STEPS(GMX_OP) : "+v"(v));
+  asm(GMX_DPP_ASM_ENTER GMX_DPP_ASM_STEPS(GMX_OP) : "+v"(v));
 #undef GMX_OP
   return v;
 }

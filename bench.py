@@ -38,7 +38,7 @@ os.environ.setdefault("OMP_WAIT_POLICY", "ACTIVE")
 N_PARTICLES = 1_000_000
 T_STEPS = 100
 VM_VALU_PER_WAVE = 325.65           # VALU instructions per 64 particles: SQ_INSTS_VALU / waves / 4 particles per
-                                    # thread (1302.6 per wave, profiles/r02b_pmc_summary.txt; 1438.6 before the
+                                    # thread (1302.6 per wave, profiles/r02c_pmc_summary.txt; 1438.6 before the
                                     # one-instruction DPP scans / integer fixed-point weights, 1496.7 at the end of round 1)
 VALU_PEAK_LANE_OPS = 256 * 4 * 16 * 2.4e9   # integer / unpacked-f32 vector instructions: 16 lanes per clock per SIMD (a
                                             # wave64 instruction holds its SIMD for 4 cycles; only packed f32 math doubles
@@ -342,7 +342,7 @@ def main():
                            "algorithmic_bytes_per_launch": VM_BYTES_PER_PARTICLE * n,
                            # the kernel is VALU-issue bound, not HBM bound: 3 Threefry-2x32 blocks per draw
                            # (split child, fold_in, bits).  SQ_INSTS_VALU per wave from profiles/*_pmc_summary.txt.
-                           "valu": {"source": "insts_per_64_particles: SQ_INSTS_VALU of profiles/r02b_pmc_summary.txt "
+                           "valu": {"source": "insts_per_64_particles: SQ_INSTS_VALU of profiles/r02c_pmc_summary.txt "
                                               "(a constant in bench.py, not measured in this run); peak_int: "
                                               "tools/calib.hip on this part (profiles/r02_calib.txt)",
                                     "insts_per_64_particles": VM_VALU_PER_WAVE,

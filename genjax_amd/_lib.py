@@ -113,6 +113,9 @@ class Backend:
                                      c_void_p, c_void_p, c_void_p]
         c.gmx_ancestors.argtypes = [c_int, POINTER(c_uint32), c_void_p, c_int64, c_uint64, c_void_p,
                                     c_int64, c_int64, c_int64, c_void_p, c_void_p]
+        c.gmx_multinomial_workspace.argtypes = [c_int64]
+        c.gmx_multinomial_workspace.restype = c_size_t
+        c.gmx_multinomial.argtypes = [POINTER(c_uint32), c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]
         c.gmx_resample_workspace.argtypes = [c_int64]
         c.gmx_resample_workspace.restype = c_size_t
         c.gmx_resample.argtypes = [c_int, POINTER(c_uint32), c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p,

@@ -1142,12 +1142,15 @@ __device__ __forceinline__ int64_t slots_below(int kind, gmx_key key, uint64_t u
 __global__ void __launch_bounds__(GMX_BLOCK)
 k_offspring(int kind, uint32_t k0, uint32_t k1, const uint64_t* __restrict__ cdf, int64_t n_in,
             uint64_t cdf_offset, const uint64_t* __restrict__ total_d, int64_t n_out_total,
-            int64_t slot_offset, int64_t n_slots, int32_t* __restrict__ anc) {
+            int64_t slot_offset, int64_t n_slots, int32_t* __restrict__ anc, int64_t u0_fixed = -1) {
   int64_t i = (int64_t)blockIdx.x * GMX_BLOCK + threadIdx.x;
   const bool in_range = i < n_in;
   const uint64_t total = *total_d;
   gmx_key key; key.k0 = k0; key.k1 = k1;
-  const uint64_t u0 = gmx_bits32(key, 0) >> 9;
+  // u0_fixed >= 0 (systematic): the offset is given instead of drawn — 0 makes the output the GUIDE TABLE of the CDF,
+  // guide[k] = first i with cdf_i * n_out > k * total (gmx_multinomial)
+  const uint64_t u0 = u0_fixed >= 0 ? (uint64_t)u0_fixed : (uint64_t)(gmx_bits32(key, 0) >> 9);
+  if (u0_fixed >= 0 && blockIdx.x == 0 && threadIdx.x < 4) anc[n_slots + threadIdx.x] = (int32_t)n_in;   // the table's end
   const uint64_t D = (uint64_t)n_out_total << 23;
   if (total == 0) {                       // no mass at all: everything maps to the last particle
     for (int64_t s = i; s < n_slots; s += (int64_t)gridDim.x * GMX_BLOCK) anc[s] = (int32_t)(n_in - 1);
@@ -1276,6 +1279,74 @@ k_ancestors_mn(uint32_t k0, uint32_t k1, const uint64_t* __restrict__ cdf, int64
     }
     anc[s] = (int32_t)res;
   }
+}
+
+// Multinomial through a GUIDE TABLE (the whole, unsharded problem): guide[k] = first i with cdf_i * G > k * total,
+// k = 0 .. G - 1 (G = n_in; guide[G .. G + 3] = n_in) — which is k_offspring's output for a systematic resampling with
+// offset 0.  A slot with threshold T (first i with cdf_i >= T) then knows its answer lies in
+// [guide[k'], guide[k' + 3]] for k' = floor((T - 1) G / total) - 1 (an f64 estimate, one below so that rounding cannot
+// overshoot): on average three candidates instead of n_in — two table reads and ~2 CDF reads instead of ~20 dependent
+// ones.  Every comparison that decides is the integer one, so the ancestors are k_ancestors' exactly.
+__global__ void __launch_bounds__(GMX_BLOCK)
+k_ancestors_guided(uint32_t k0, uint32_t k1, const uint64_t* __restrict__ cdf, int64_t n_in,
+                   const uint64_t* __restrict__ total_d, const int32_t* __restrict__ guide, int64_t n_slots,
+                   int32_t* __restrict__ anc) {
+  const int64_t s = (int64_t)blockIdx.x * GMX_BLOCK + threadIdx.x;
+  if (s >= n_slots) return;
+  const uint64_t total = *total_d;
+  if (total == 0ull) { anc[s] = (int32_t)(n_in - 1); return; }      // no mass at all
+  gmx_key key; key.k0 = k0; key.k1 = k1;
+  const uint64_t u = gmx_bits32(key, (uint64_t)s) >> 9;
+  const u128 P = mul64(total, (1ull << 23) - u);                    // P >= 1
+  const uint64_t lo64 = P.lo + ((1ull << 23) - 1ull);
+  const uint64_t hi64 = P.hi + (lo64 < P.lo ? 1ull : 0ull);
+  const uint64_t T = (hi64 << 41) | (lo64 >> 23);                   // ceil(P / 2^23), in [1, total]
+  const uint64_t t1 = T - 1ull;
+  const double v = __builtin_fma((double)(uint32_t)(t1 >> 32), 4294967296.0, (double)(uint32_t)t1) *
+                   ((double)n_in / (double)total);                  // (T - 1) G / total, relative error 2^-50
+  int64_t k = (int64_t)v - 1;                                       // <= floor((T - 1) G / total), >= that - 2
+  k = k < 0 ? 0 : (k > n_in - 1 ? n_in - 1 : k);
+  // guide[k], guide[k + 3] in one 16-byte read; then the first three candidates in one round of CDF reads
+  typedef int32_t i32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+  const i32x4_a4 g4 = *reinterpret_cast<const i32x4_a4*>(guide + k);
+  int64_t l = g4.x, h = g4.w;                                       // cdf_{l-1} < T <= cdf_h  (h == n_in: past the end)
+  if (h > n_in - 1) h = n_in - 1;                                   // cdf_{n_in-1} = total >= T
+  const int64_t i1 = l + 1 < h ? l + 1 : h, i2 = l + 2 < h ? l + 2 : h;
+  const uint64_t c0 = cdf[l], c1 = cdf[i1], c2 = cdf[i2];
+  int64_t res;
+  if (c0 >= T) res = l;
+  else if (c1 >= T) res = i1;
+  else if (c2 >= T) res = i2;
+  else {                                                            // a crowded cell of the table: search the rest
+    l = i2 + 1;
+    while (l < h) {
+      const int64_t mid = l + ((h - l) >> 1);
+      if (cdf[mid] >= T) h = mid; else l = mid + 1;
+    }
+    res = l;
+  }
+  anc[s] = (int32_t)res;
+}
+
+extern "C" size_t gmx_multinomial_workspace(int64_t n_in) { return (size_t)(n_in + 4) * 4; }
+
+extern "C" int gmx_multinomial(const uint32_t key[2], const uint64_t* cdf_d, int64_t n_in, const uint64_t* total_d,
+                               int64_t n_out, int32_t* ancestors_d, void* workspace_d, gmx_stream stream) {
+  if (n_out <= 0) return 0;
+  if (!key || !cdf_d || !total_d || !ancestors_d || !workspace_d) return gmx_fail("gmx_multinomial: null argument%s");
+  if (n_in <= 0 || n_in > 0x7ffffff0LL) return gmx_fail("gmx_multinomial: n_in out of range%s");
+  if (n_out >= (1LL << 40)) return gmx_fail("gmx_multinomial: n_out out of range%s");
+  if ((uintptr_t)workspace_d & 3) return gmx_fail("gmx_multinomial: workspace_d must be 4-byte aligned%s");
+  int32_t* guide = (int32_t*)workspace_d;
+  hipStream_t st = (hipStream_t)stream;
+  auto grid_for = [](int64_t m) { return dim3((unsigned)((m + GMX_BLOCK - 1) / GMX_BLOCK)); };
+  // guide table = the systematic offspring assignment of G = n_in slots with offset 0
+  hipLaunchKernelGGL(k_offspring, grid_for(n_in), dim3(GMX_BLOCK), 0, st, (int)GMX_RESAMPLE_SYSTEMATIC, key[0], key[1],
+                     cdf_d, n_in, (uint64_t)0, total_d, n_in, (int64_t)0, n_in, guide, (int64_t)0);
+  hipLaunchKernelGGL(k_ancestors_guided, grid_for(n_out), dim3(GMX_BLOCK), 0, st, key[0], key[1], cdf_d, n_in, total_d,
+                     guide, n_out, ancestors_d);
+  GMX_HIP(hipGetLastError());
+  return 0;
 }
 
 extern "C" int gmx_ancestors(int kind, const uint32_t key[2], const uint64_t* cdf_d, int64_t n_in,

@@ -238,6 +238,14 @@ int gmx_ancestors(int kind, const uint32_t key[2], const uint64_t* cdf_d, int64_
                   int64_t n_out_total, int64_t slot_offset, int64_t n_slots,
                   int32_t* ancestors_d /* [n_slots], clamped to [0,n_in) local */,
                   gmx_stream stream);
+/* MULTINOMIAL over the whole (unsharded) CDF through a guide table: ancestors identical to
+ * gmx_ancestors(GMX_RESAMPLE_MULTINOMIAL, key, cdf_d, n_in, 0, total_d, n_out, 0, n_out, ...), several times faster
+ * for large n_in (the per-slot binary search over n_in entries becomes two table reads + a search over ~3 entries;
+ * the table is the systematic offspring assignment with offset 0, built first).  workspace_d:
+ * gmx_multinomial_workspace(n_in) bytes. */
+size_t gmx_multinomial_workspace(int64_t n_in);
+int gmx_multinomial(const uint32_t key[2], const uint64_t* cdf_d, int64_t n_in, const uint64_t* total_d /* [1] */,
+                    int64_t n_out, int32_t* ancestors_d /* [n_out] */, void* workspace_d, gmx_stream stream);
 /* Fused one-GPU form of steps 1+2 for SYSTEMATIC / STRATIFIED (n <= 2^21): no CDF in
  * memory and no inter-block waiting; ancestors identical to gmx_weight_cdf +
  * gmx_ancestors.  gmx_tile_stats writes (m_b, A_b) per 1024-particle tile — a

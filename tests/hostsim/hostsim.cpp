@@ -275,6 +275,13 @@ extern "C" int gmx_tile_stats(const float* lw, int64_t n, int shift, float* tmax
   }
   return 0;
 }
+extern "C" size_t gmx_multinomial_workspace(int64_t n_in) { return (size_t)(n_in + 4) * 4; }
+// the mirror states the definition: the per-slot search of gmx_ancestors
+extern "C" int gmx_multinomial(const uint32_t key[2], const uint64_t* cdf, int64_t n_in, const uint64_t* total, int64_t n_out,
+                               int32_t* anc, void* ws, gmx_stream st) {
+  if (!ws) return fail("multinomial: null workspace");
+  return gmx_ancestors(GMX_RESAMPLE_MULTINOMIAL, key, cdf, n_in, 0, total, n_out, 0, n_out, anc, st);
+}
 // the mirror rebuilds the global CDF from log-weights + tile stats and searches it per slot
 extern "C" int gmx_resample_tiles(int kind, const uint32_t key[2], const float* lw, int64_t n, int shift, const float* tmax,
                                   const uint64_t* agg, float* max_d, uint64_t* total, int32_t* anc, gmx_stream st) {

@@ -972,3 +972,38 @@ def test_mh_move_chained_into_the_extension(gpu, monkeypatch, chained):
         assert 0.3 < res["accept_rate"] < 1.0
     finally:
         G.clear_caches()
+
+
+@pytest.mark.parametrize("case", ["normal", "flat", "skewed", "sparse", "one", "nan_inf", "none"])
+def test_multinomial_through_the_guide_table(gpu, monkeypatch, case):
+    """gmx_multinomial (guide table + a search over ~3 entries) == gmx_ancestors' per-slot binary search, slot for slot,
+    on mild, flat, skewed, sparse, degenerate and NaN / inf weight vectors, n_out != n_in included; the mild case also
+    against the oracle."""
+    import genjax_amd as G
+    from genjax_amd.inference import smc
+    n = 300_007
+    rng = np.random.default_rng(5)
+    lw = rng.normal(0, 1, n).astype(np.float32)
+    if case == "flat":
+        lw[:] = 0.0
+    elif case == "skewed":
+        lw = rng.normal(0, 6, n).astype(np.float32)
+    elif case == "sparse":
+        lw = np.where(rng.random(n) < 1e-3, 0.0, -60.0).astype(np.float32)
+    elif case == "one":
+        lw[:] = -1e30
+        lw[77_777] = 0.0
+    elif case == "nan_inf":
+        lw[5] = np.nan; lw[100_000] = -np.inf; lw[200_001] = np.nan; lw[n - 1] = -np.inf
+    elif case == "none":
+        lw[:] = -np.inf
+    cdf, total, _, _ = smc.weight_cdf(_dev(lw))
+    for n_out in (n, 40_000, 500_000):
+        monkeypatch.setenv("GENMI_MN_GUIDED", "1")
+        a = smc.ancestors_from_cdf(2, G.key(31), cdf, total, n_out=n_out)
+        monkeypatch.setenv("GENMI_MN_GUIDED", "0")
+        b = smc.ancestors_from_cdf(2, G.key(31), cdf, total, n_out=n_out)
+        assert torch.equal(a, b)
+    if case == "normal":
+        rc, _, _, _ = O.weight_cdf(lw)
+        assert np.array_equal(b.cpu().numpy(), O.ancestors_c(2, O.key(31), rc, n_out=500_000))

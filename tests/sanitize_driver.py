@@ -26,12 +26,25 @@ res = parity.check_lgssm_sweep(n=2049, T=3)
 assert res["ancestors_equal"] and res["x_equal"], res
 os.environ["GENMI_TILE_Q"] = "0"
 parity.check_nlssm_mh(n=700, T=3)
+parity.check_nlssm_mh_sweep(n=1100, T=4, want_chained=True)     # MH move chained into the extension (OP_KSPLITU)
+os.environ["GENMI_FUSE_RESAMPLE"] = "1"                         # gmx_run_args.rs: resample inside the step's launch
+res = parity.check_lgssm_sweep(n=2500, T=4, want_fuse=True)
+assert res["ancestors_equal"] and res["x_equal"] and res["totals_equal"], res
+os.environ["GENMI_FUSE_RESAMPLE"] = "0"
 parity.check_plates(n=129)
 parity.check_csmc(k=65)
 parity.check_nested_marginal(k=33)
 parity.check_dirichlet(n=300)
 parity.check_shard_route(n=1024, world=2)
 parity.check_mixture_assignments(n=300, K=8)
+
+# the fixed-point weight (gmx_exp_fixed, through the mirror's tile statistics) on hostile log-weights
+import torch  # noqa: E402
+from genjax_amd import _lib  # noqa: E402
+be = _lib.get()
+bad = np.array([np.nan, np.inf, -np.inf, 1e38, -1e38, 0.0, -0.0, 88.0, -87.4, -103.0, 1e-45, -1e-45] * 100, np.float32)
+tmax = torch.zeros(2); agg = torch.zeros(2, dtype=torch.int64)
+be.check(be.c.gmx_tile_stats(be.ptr(torch.from_numpy(bad)), bad.size, 40, be.ptr(tmax), be.ptr(agg), be.stream()), "tile_stats")
 
 # resampling with hostile weights (NaN / inf / nothing / one-hot), ragged sizes
 rng = np.random.default_rng(0)

@@ -55,17 +55,16 @@ struct gmx_jit_ctx {
       const float bm = block_max(acc_max, lds4);
       if (threadIdx.x == 0 && A->red_out_d) A->red_out_d[blockIdx.x] = bm;
       if (PPV == 4 && A->tile_agg_d) {
-        const float scale = gmx_pow2i(A->tile_shift);
         const float ref = gmx_tile_ref(gmx_tile_exp(bm));
         uint64_t s = 0;
-        uint64_t qv[PPV];
+        uint32_t qp[PPV];
 #pragma unroll
-        for (int p = 0; p < PPV; ++p) { qv[p] = weight_fixed(red_x[p], ref, scale); s += qv[p]; }
-        if (A->tile_q_d) {                  // inactive particles have red_x = -inf, i.e. q = 0: nothing to store
+        for (int p = 0; p < PPV; ++p) { qp[p] = gmx_exp_fixed_packed(red_x[p] - ref, A->tile_shift); s += gmx_fixed_unpack(qp[p]); }
+        if (A->tile_q_d) {                  // inactive particles have red_x = -inf, i.e. q = 0
 #pragma unroll
           for (int p = 0; p < PPV; ++p) {
             const int64_t row = ((int64_t)blockIdx.x * PPV + p) * GMX_BLOCK + threadIdx.x;
-            if (row < n_rows) A->tile_q_d[row] = qv[p];
+            if (row < n_rows) A->tile_q_d[row] = qp[p];
           }
         }
         s = wave_sum_u64(s);

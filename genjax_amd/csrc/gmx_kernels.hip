@@ -1458,7 +1458,7 @@ k_tile_stats(const float* __restrict__ lw, int64_t n, float scale, float* __rest
 // Every load is issued before anything waits (unconditional, clamped addresses), wave-level reductions and scans are
 // DPP (gmx_block.h), the slot ranges are straight-line f64 code with one cold exact path.
 // FROMQ: the per-particle fixed-point weights come from memory (`qin`, written by the site program's epilogue:
-// gmx_run_args.tile_q_d) instead of being recomputed from the log-weights (one exp + one f32 -> u64 conversion each).
+// gmx_run_args.tile_q_d, 4 bytes each: significand | shift) instead of being recomputed from the log-weights.
 #define RS_TPB 1
 #define RS_BLOCK (GMX_BLOCK * RS_TPB)
 #define RS_WAVES (RS_BLOCK / GMX_WAVE)
@@ -1476,7 +1476,7 @@ typedef uint32_t rs_u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));   
 //          the same cost whatever the weights; a tile owning more than 2048 slots takes more passes (block-uniform).
 template <int kind, bool FROMQ, int PER, bool FILL>
 __global__ void __launch_bounds__(RS_BLOCK)
-k_offspring_tile(uint32_t k0, uint32_t k1, uint32_t u0_host, const float* __restrict__ lw, const uint64_t* __restrict__ qin,
+k_offspring_tile(uint32_t k0, uint32_t k1, uint32_t u0_host, const float* __restrict__ lw, const uint32_t* __restrict__ qin,
                  const float* __restrict__ tmax, const uint64_t* __restrict__ agg, int64_t n, int n_tiles, float scale,
                  float* __restrict__ max_out, uint64_t* __restrict__ total_out, int32_t* __restrict__ anc) {
   __shared__ uint64_t s_below[RS_WAVES], s_all[RS_WAVES], s_scan[RS_WAVES], s_g[RS_TPB];
@@ -1492,19 +1492,21 @@ k_offspring_tile(uint32_t k0, uint32_t k1, uint32_t u0_host, const float* __rest
   float x[CDF_VEC];
   uint64_t qw[CDF_VEC];
   const bool full_tile = (int64_t)(tile_c + 1) * RS_TILE <= n;                   // wave-uniform
-  if (FROMQ) {
+  if (FROMQ) {                                    // packed fixed-point weights (gmx_math.h: gmx_fixed_unpack)
+    uint32_t pk[CDF_VEC];
     if (full_tile) {
-      const ulonglong2 a = reinterpret_cast<const ulonglong2*>(qin + i0)[0];
-      const ulonglong2 b = reinterpret_cast<const ulonglong2*>(qin + i0)[1];
-      qw[0] = a.x; qw[1] = a.y; qw[2] = b.x; qw[3] = b.y;
+      const uint4 a = *reinterpret_cast<const uint4*>(qin + i0);
+      pk[0] = a.x; pk[1] = a.y; pk[2] = a.z; pk[3] = a.w;
     } else {
 #pragma unroll
       for (int c = 0; c < CDF_VEC; ++c) {
         const int64_t ic = i0 + c < n ? i0 + c : n - 1;
-        const uint64_t v = qin[ic];
-        qw[c] = (i0 + c < n) ? v : 0ull;
+        const uint32_t v = qin[ic];
+        pk[c] = (i0 + c < n) ? v : 0u;
       }
     }
+#pragma unroll
+    for (int c = 0; c < CDF_VEC; ++c) qw[c] = gmx_fixed_unpack(pk[c]);
   } else if (full_tile) {
     float4 v = *reinterpret_cast<const float4*>(lw + i0);
     x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
@@ -1713,7 +1715,7 @@ static int resample_shape(const char* who, int64_t n, int shift) {
   return 0;
 }
 
-static int launch_offspring_tile(int kind, const uint32_t key[2], const float* lw_d, const uint64_t* q_d, int64_t n, int shift,
+static int launch_offspring_tile(int kind, const uint32_t key[2], const float* lw_d, const uint32_t* q_d, int64_t n, int shift,
                                  const float* tile_max_d, const uint64_t* tile_agg_d, float* max_d, uint64_t* total_d,
                                  int32_t* ancestors_d, gmx_stream stream) {
   uint32_t b0, b1;
@@ -1769,7 +1771,7 @@ extern "C" int gmx_resample_tiles(int kind, const uint32_t key[2], const float* 
   return launch_offspring_tile(kind, key, lw_d, nullptr, n, shift, tile_max_d, tile_agg_d, max_d, total_d, ancestors_d, stream);
 }
 
-extern "C" int gmx_resample_tiles_q(int kind, const uint32_t key[2], const uint64_t* q_d, int64_t n, int shift,
+extern "C" int gmx_resample_tiles_q(int kind, const uint32_t key[2], const uint32_t* q_d, int64_t n, int shift,
                                     const float* tile_max_d, const uint64_t* tile_agg_d, float* max_d,
                                     uint64_t* total_d, int32_t* ancestors_d, gmx_stream stream) {
   if (resample_shape("gmx_resample_tiles_q", n, shift)) return 1;

@@ -147,7 +147,10 @@ GMX_HD float gmx_expf_nonpos(float x) {
 // floor is p's 24-bit significand shifted by (exponent of p) - 23 + k + shift.  Same integer as the expression above
 // for EVERY float d and every shift (tests/test_host_logic.py::test_weight_fixed_matches_its_definition sweeps the
 // bit patterns), in about half the instructions: no 2^k1 * 2^k2 scaling, no denormal flush, no f32 -> u64 conversion.
-GMX_HD uint64_t gmx_exp_fixed(float d, int shift) {
+// packed: significand (24 bits, 0 when the value is not below 2^63) | shift amount (6 bits) << 24; the value is
+// (significand << 39) >> amount.  gmx_exp_fixed_packed / gmx_fixed_unpack split gmx_exp_fixed so that a kernel can hand
+// the weight to another in 4 bytes (gmx_run_args.tile_q_d).
+GMX_HD uint32_t gmx_exp_fixed_packed(float d, int shift) {
   const float lo = -87.33654022216797f;
   float dc = d > lo ? d : lo;                        // NaN -> lo: contributes 0 below, like every d < -(shift + 1) ln 2
   dc = dc < 100.0f ? dc : 100.0f;                    // anything above 63 ln 2 is "not below 2^63"
@@ -170,8 +173,10 @@ GMX_HD uint64_t gmx_exp_fixed(float d, int shift) {
   m = amt < 0 ? 0u : m;
   amt = amt > 63 ? 63 : amt;
   amt = amt < 0 ? 0 : amt;
-  return ((uint64_t)m << 39) >> amt;
+  return m | ((uint32_t)amt << 24);
 }
+GMX_HD uint64_t gmx_fixed_unpack(uint32_t pk) { return ((uint64_t)(pk & 0x00ffffffu) << 39) >> (pk >> 24); }
+GMX_HD uint64_t gmx_exp_fixed(float d, int shift) { return gmx_fixed_unpack(gmx_exp_fixed_packed(d, shift)); }
 
 // log(x), natural.  cephes logf polynomial on [sqrt(1/2), sqrt(2)).
 // Straight-line like gmx_expf: special cases are selects over the main path's result.

@@ -732,12 +732,11 @@ class BootstrapSweep:
                                                                      and self.p_mhvm_step.comp.writes_tile_stats()):
             self.p_mhvm_init = self.p_mhvm_step = None      # the chained programs are too large for the tile form
         self.fuse_mh = self.p_mhvm_init is not None
-        # ... and, on request (GENMI_TILE_Q=1), every particle's fixed-point weight (8 bytes each): the resampler then
-        # reads those and skips one exp + one f32 -> u64 conversion per particle.  Measured on MI355X (config 2):
-        # 181 fewer vector instructions per wave in k_offspring_tile, 39 more in the site program — and the same
-        # sweep time (21.1 us / step either way): the extra 8 MB are stored at the very end of the site program,
-        # where nothing overlaps them.  Off by default (less traffic).
-        self.tile_q = torch.zeros((n,), dtype=torch.int64, device=dev) \
+        # ... and, on request (GENMI_TILE_Q=1), every particle's fixed-point weight (4 bytes each: significand | shift):
+        # the resampler then reads those instead of the log-weights and skips one exp per particle.  Measured on MI355X
+        # (config 2): the resampler 6.7 -> 6.3 us, the site program 11.5 -> 12.3 us — the extra 4 MB are stored at the
+        # very end of the site program (they need the block maximum), where nothing overlaps them.  Off by default.
+        self.tile_q = torch.zeros((n,), dtype=torch.int32, device=dev) \
             if self.tile_stats and os.environ.get("GENMI_TILE_Q", "0") == "1" else None
         # ONE launch per step: the program that gathers the resampled state (the extension; with rejuvenate=, the MH
         # move) first computes its workgroup's ancestors itself, from the previous step's log-weights and tile

@@ -150,11 +150,12 @@ typedef struct gmx_run_args {
   int32_t reserved_;
   int64_t step_stride;            /* elements between consecutive steps of a [T, n] leaf addressed with GMX_F_STEP inside
                                      an OP_LOOP (programs with a counted loop: the Scan combinator); normally n         */
-  uint64_t* tile_q_d;             /* optional, with tile_agg_d: [n] the fixed-point weight of every particle,
-                                     q_i = floor(exp(x_i - k_b ln 2) * 2^tile_shift) — the terms A_b sums.  The
-                                     epilogue has them in registers; written out, the resampler
-                                     (gmx_resample_tiles_q) needs neither the log-weights nor a second exp per
-                                     particle: 8 bytes of traffic instead of ~40 vector instructions             */
+  uint32_t* tile_q_d;             /* optional, with tile_agg_d: [n] the fixed-point weight of every particle,
+                                     q_i = floor(exp(x_i - k_b ln 2) * 2^tile_shift) — the terms A_b sums — packed in
+                                     4 bytes: significand (bits 0-23) | shift amount (bits 24-29), q = (significand
+                                     << 39) >> amount.  The epilogue has them in registers; written out, the
+                                     resampler (gmx_resample_tiles_q) reads these instead of the log-weights and
+                                     needs no second exp per particle                                            */
   gmx_resample_in rs;             /* optional (rs.lw_d != NULL): resample first, in the same launch — see above  */
 } gmx_run_args;
 
@@ -266,7 +267,7 @@ int gmx_resample(int kind, const uint32_t key[2], const float* lw_d, int64_t n, 
                  uint64_t* total_d, int32_t* ancestors_d, void* workspace_d, gmx_stream stream);
 /* gmx_resample_tiles from the per-particle fixed-point weights q_i a site program left in
  * gmx_run_args.tile_q_d (same tile statistics, same ancestors). */
-int gmx_resample_tiles_q(int kind, const uint32_t key[2], const uint64_t* q_d, int64_t n, int shift,
+int gmx_resample_tiles_q(int kind, const uint32_t key[2], const uint32_t* q_d, int64_t n, int shift,
                          const float* tile_max_d, const uint64_t* tile_agg_d, float* max_d,
                          uint64_t* total_d, int32_t* ancestors_d, gmx_stream stream);
 int gmx_gather(const void* const* src_d, void* const* dst_d, const int32_t* elem_bytes,

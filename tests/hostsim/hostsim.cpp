@@ -171,9 +171,11 @@ extern "C" int gmx_program_run(const gmx_program* p, int64_t n, const gmx_run_ar
         const float ref = gmx_tile_ref(gmx_tile_exp(m)), scale = gmx_pow2i(A->tile_shift);
         uint64_t sum = 0;
         for (int t = 0; t < G; ++t) {
-          const uint64_t q = hs_weight_fixed(red[t], ref, scale);
+          const uint32_t pk = gmx_exp_fixed_packed(red[t] - ref, A->tile_shift);
+          const uint64_t q = gmx_fixed_unpack(pk);
+          (void)scale;
           sum += q;
-          if (A->tile_q_d && blk * G + t < n) A->tile_q_d[blk * G + t] = q;
+          if (A->tile_q_d && blk * G + t < n) A->tile_q_d[blk * G + t] = pk;
         }
         A->tile_agg_d[blk] = sum;
       }
@@ -308,7 +310,7 @@ extern "C" int gmx_resample_tiles(int kind, const uint32_t key[2], const float* 
   return gmx_ancestors(kind, key, cdf.data(), n, 0, total, n, 0, n, anc, st);
 }
 // the same from the per-particle fixed-point weights the site program left behind
-extern "C" int gmx_resample_tiles_q(int kind, const uint32_t key[2], const uint64_t* q, int64_t n, int shift, const float* tmax,
+extern "C" int gmx_resample_tiles_q(int kind, const uint32_t key[2], const uint32_t* q, int64_t n, int shift, const float* tmax,
                                     const uint64_t* agg, float* max_d, uint64_t* total, int32_t* anc, gmx_stream st) {
   if (kind == GMX_RESAMPLE_MULTINOMIAL) return fail("resample: kind");
   if (!q || !tmax || !agg || !max_d || !total || !anc || shift < 1) return fail("resample_tiles_q: bad argument");
@@ -322,7 +324,7 @@ extern "C" int gmx_resample_tiles_q(int kind, const uint32_t key[2], const uint6
     const int64_t lo = b * HS_TILE, hi = lo + HS_TILE < n ? lo + HS_TILE : n;
     const int32_t k = gmx_tile_exp(tmax[b]);
     uint64_t run = 0;
-    for (int64_t i = lo; i < hi; ++i) { run += q[i]; cdf[(size_t)i] = prefix + gmx_tile_scale(run, k, K); }
+    for (int64_t i = lo; i < hi; ++i) { run += gmx_fixed_unpack(q[i]); cdf[(size_t)i] = prefix + gmx_tile_scale(run, k, K); }
     prefix += gmx_tile_scale(agg[b], k, K);
   }
   *max_d = M; *total = prefix;

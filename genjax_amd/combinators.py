@@ -487,8 +487,8 @@ class Scan(GenerativeFunction):
             for r in _leaves(rec):
                 val = r.value.value if isinstance(r.value, Sym) else r.value
                 sc = r.score.value if isinstance(r.score, Sym) else r.score
-                if isinstance(val, np.ndarray) or isinstance(sc, np.ndarray):
-                    raise NotImplementedError("scan of more than 16 steps: vector-valued sites inside the kernel")
+                if isinstance(sc, np.ndarray):
+                    raise NotImplementedError("scan of more than 16 steps: a site with a vector-valued SCORE")
                 if keep:
                     r.origins = (tr.store_step(val, n), tr.store_step(sc, n), None)
                     r.value = StepOutput(r.origins[0], n)

@@ -319,6 +319,15 @@ class Tracing:
         """Inside a counted loop: store this iteration's value as element t of a [T, n] output (exposed to the
         user as [n, T], like a plate).  Returns the output's origin."""
         from . import tracer as Tm
+        if isinstance(value, np.ndarray) and value.dtype == object:
+            # a vector-valued site: one [T, n] plane per element, exposed as [n, T, *event]
+            es = [Tm.lift(v) for v in value.reshape(-1)]
+            if len({e.dtype for e in es}) != 1:
+                raise TypeError("store_step: mixed element types")
+            slots = [self.graph.store(e.node, step=True) for e in es]
+            o = ("out", len(self.outputs))
+            self.outputs.append((es[0].dtype, (int(T),) + tuple(value.shape), ("step", slots)))
+            return o
         e = Tm.lift(value)
         slot = self.graph.store(e.node, step=True)
         o = ("out", len(self.outputs))
@@ -605,7 +614,16 @@ class Compiled:
         for k, (dt, event, slots) in enumerate(self.outputs):
             if isinstance(slots, tuple) and slots[0] == "step":
                 # element t of a [T, n] leaf is written by iteration t of the program's loop (GMX_F_STEP)
-                buf = torch.empty((int(event[0]), n), dtype=_STORE[dt], device=be.device)
+                Tn = int(event[0])
+                if isinstance(slots[1], list):          # a vector-valued site: [E, T, n] planes -> [*batch, T, *site event]
+                    E = len(slots[1])
+                    buf = torch.empty((E, Tn, n), dtype=_STORE[dt], device=be.device)
+                    for e_, slot in enumerate(slots[1]):
+                        A.out_d[slot] = buf.data_ptr() + e_ * Tn * n * buf.element_size()
+                    A.step_stride = n
+                    outs.append(buf.permute(2, 1, 0).reshape(tuple(batch) + tuple(event)))
+                    continue
+                buf = torch.empty((Tn, n), dtype=_STORE[dt], device=be.device)
                 A.out_d[slots[1]] = buf.data_ptr()
                 A.step_stride = n
                 outs.append(buf.reshape(event + tuple(batch)).permute(

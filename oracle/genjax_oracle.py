@@ -1032,19 +1032,22 @@ class Vmap:
 
 
 def _stack_last(trs):
-    """Stack per-step traces of one kernel along a new TRAILING axis (the step axis)."""
+    """Stack per-step traces of one kernel along a new step axis: right after the batch axes (lax.scan stacks on the
+    leading axis of the per-particle value, vmap over particles puts the batch in front: [batch, T, *event]) — for a
+    scalar-valued site that is the trailing axis."""
     first = trs[0]
 
-    def st(vals):
+    def st(vals, axis=-1):
         if vals[0] is None:
             return None
         if isinstance(vals[0], tuple):
-            return tuple(st([v[k] for v in vals]) for k in range(len(vals[0])))
+            return tuple(st([v[k] for v in vals], axis) for k in range(len(vals[0])))
         arrs = [np.asarray(v) for v in vals]
         shape = np.broadcast_shapes(*[a.shape for a in arrs])
-        return np.stack([np.broadcast_to(a, shape) for a in arrs], axis=-1)
+        return np.stack([np.broadcast_to(a, shape) for a in arrs], axis=axis if axis <= len(shape) else -1)
     if isinstance(first, DistTrace):
-        return DistTrace(first.gen_fn, first.args, st([t.value for t in trs]), st([t.score for t in trs]))
+        bn = max(np.ndim(t.score) for t in trs)               # batch rank: a site's score has no event axes
+        return DistTrace(first.gen_fn, first.args, st([t.value for t in trs], bn), st([t.score for t in trs], bn))
     return StaticTrace(first.gen_fn, first.args, st([t.retval for t in trs]),
                        OrderedDict((a, _stack_last([t.subtraces[a] for t in trs])) for a in first.subtraces))
 

@@ -1111,3 +1111,42 @@ def check_vector_mh_sweep(n=1500, T=5, seed=11, capture=False, specialize=False)
     assert np.array_equal(sw.accept.cpu().numpy(), ref["acc"])
     assert abs(sw.log_ml() - sum(ref["terms"])) < 1e-9 * max(1.0, abs(sum(ref["terms"])))
     return {"accept_rate": float(ref["acc"].mean())}
+
+
+def check_scan_long_vector_site(n=130, T=40, seed=3):
+    """A long scan (counted loop) whose kernel has a VECTOR-valued site: a 2-D latent state x_t ~ N(A x_{t-1}, 0.5) held
+    in one site (one site key, element counters — App. A.3), scalar observations.  Values come back as [n, T, 2];
+    simulate / importance / assess equal the oracle's step-by-step statement."""
+    import genjax_amd as G
+    from genjax_amd import ChoiceMapBuilder as C, numpy as jnp
+    ys = np.random.default_rng(seed).normal(size=T).astype(np.float32)
+
+    def mk(g, np_):
+        @g.gen
+        def step(x, t):
+            m = np_.stack([0.9 * x[..., 0] + 0.1 * x[..., 1], 0.8 * x[..., 1]], axis=-1)
+            xn = g.normal(m, np_.array([0.5, 0.3], dtype=np.float32) if np_ is np else jnp.array([0.5, 0.3])) @ "x"
+            g.normal(xn[..., 0] + xn[..., 1], 1.0) @ "y"
+            return xn, xn[..., 0]
+        return step
+    step, ostep = mk(G, jnp), mk(O, np)
+    dev = G._lib.get().device
+    x0 = torch.zeros((n, 2), device=dev)
+    sc, osc = step.scan(n=T), O.Scan(ostep, T)
+    ts = jnp.zeros(T)
+    tr = sc.simulate(G.split(G.key(seed), n), (x0, ts))
+    otr = osc.simulate(O.split(O.key(seed), n), (np.zeros((n, 2), np.float32), np.zeros(T, np.float32)))
+    xs = tr.get_choices()["x"]
+    assert tuple(xs.shape) == (n, T, 2)
+    assert np.array_equal(xs.cpu().numpy(), otr.get_choices()["x"])
+    assert np.array_equal(tr.get_choices()["y"].cpu().numpy(), otr.get_choices()["y"])
+    assert np.array_equal(tr.get_score().cpu().numpy(), otr.get_score())
+    carry, first = tr.get_retval()
+    ocarry, ofirst = otr.get_retval()
+    assert np.array_equal(carry.cpu().numpy(), ocarry) and np.array_equal(first.cpu().numpy(), ofirst)
+    con = C[:, "y"].set(ys)
+    ocon = O.C.d({("y",): ys})
+    tr2, w = sc.importance(G.split(G.key(seed + 1), n), con, (x0, ts))
+    otr2, ow = osc.importance(O.split(O.key(seed + 1), n), ocon, (np.zeros((n, 2), np.float32), np.zeros(T, np.float32)))
+    assert np.array_equal(w.cpu().numpy(), ow)
+    assert np.array_equal(tr2.get_choices()["x"].cpu().numpy(), otr2.get_choices()["x"])

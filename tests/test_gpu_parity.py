@@ -1007,3 +1007,9 @@ def test_multinomial_through_the_guide_table(gpu, monkeypatch, case):
     if case == "normal":
         rc, _, _, _ = O.weight_cdf(lw)
         assert np.array_equal(b.cpu().numpy(), O.ancestors_c(2, O.key(31), rc, n_out=500_000))
+
+
+def test_long_scan_with_a_vector_valued_site(gpu):
+    """counted-loop scan, 2-D latent state in one site: interpreter (n = 130) and specialised kernel (n = 70 000)"""
+    parity.check_scan_long_vector_site()
+    parity.check_scan_long_vector_site(n=70_000, T=24, seed=8)

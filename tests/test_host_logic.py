@@ -1037,3 +1037,9 @@ def test_mh_sweep_with_the_move_chained_into_the_extension(monkeypatch, chained)
     parity.check_nlssm_mh_sweep(n=1500, T=5, want_chained=(chained == "1"))
     res = parity.check_vector_mh_sweep(n=1200, T=4)
     assert 0.3 < res["accept_rate"] < 1.0
+
+
+def test_long_scan_with_a_vector_valued_site():
+    """a counted-loop scan whose kernel has a vector-valued site (a 2-D latent state): values come back [n, T, 2]"""
+    from tests import parity
+    parity.check_scan_long_vector_site()

@@ -558,6 +558,11 @@ class Scan(GenerativeFunction):
         carry, scanned_in = args
         n = self._length(scanned_in)
         inner_prev = prev["vmap"]
+        if n > SCAN_UNROLL_MAX:
+            if sub_mode == "index":
+                raise NotImplementedError("IndexRequest into a scan of more than 16 steps")
+            return self._trace_edit_loop(ctx, sub_mode, key, carry, scanned_in, constraint, inner_prev, req, kind, n,
+                                         req_leaves, addr)
         g = ctx.tr.graph
         keep = ctx.store_sites
         ctx.store_sites = False
@@ -629,6 +634,166 @@ class Scan(GenerativeFunction):
             for r in _leaves(out):
                 _store_site(ctx, r)
         return out, out.retval, weight, None
+
+    def _trace_edit_loop(self, ctx, sub_mode, key, carry, scanned_in, constraint, inner_prev, req, kind, n, req_leaves,
+                         addr):
+        """Update / Regenerate of a LONG scan as a counted loop (the loop form of _trace_edit, as _trace_loop is of
+        trace_call): iteration t edits step t with the chained key, reading element t of the previous trace's
+        [n, T] values and scores and writing element t of the new ones (and of the discard).  The carry is
+        loop-carried and treated as changed, so every site is re-scored — a site the edit does not reach gets
+        new score == old score bit for bit and contributes exactly 0 to the weight, which is what the unrolled form
+        obtains by skipping it."""
+        from .engine import StepInput, StepOutput, Sym
+        from .numpy import RuntimeTable, TableArray
+        from .static import _CallRec, _ReqSpec, _SiteRec, _rec_score, call_gen_fn
+        g, tr = ctx.tr.graph, ctx.tr
+        keep = ctx.store_sites
+        ctx.store_sites = False
+        carry_over = _ReqSpec("update", tree=None, constraint=ChoiceMap.empty())
+
+        def flat_carry(v, out):
+            if v is None:
+                return ("none",)
+            if isinstance(v, Sym):
+                v = v.value
+            if isinstance(v, (tuple, list)):
+                return (type(v).__name__, [flat_carry(x, out) for x in v])
+            if isinstance(v, np.ndarray) and v.dtype == object:
+                return ("array", v.shape, [flat_carry(x, out) for x in v.reshape(-1)])
+            out.append(T.lift(v))
+            return ("leaf", len(out) - 1)
+
+        def rebuild(tree, leaves):
+            k = tree[0]
+            if k == "none":
+                return None
+            if k == "leaf":
+                return leaves[tree[1]]
+            if k in ("tuple", "list"):
+                seq = [rebuild(x, leaves) for x in tree[1]]
+                return tuple(seq) if k == "tuple" else seq
+            arr = np.empty(len(tree[2]), dtype=object)
+            for i, x in enumerate(tree[2]):
+                arr[i] = rebuild(x, leaves)
+            return arr.reshape(tree[1])
+
+        def at_step(v, t):
+            if isinstance(v, Sym):
+                v = v.value
+            if v is None:
+                return None
+            if isinstance(v, tuple):
+                return tuple(at_step(x, t) for x in v)
+            if isinstance(v, (RuntimeTable, TableArray, StepInput)):
+                return v[t]
+            if isinstance(v, (list, np.ndarray)) and not (isinstance(v, np.ndarray) and v.dtype == object):
+                return TableArray(np.asarray(v, dtype=np.float32 if np.asarray(v).dtype.kind == "f" else np.int32))[t]
+            raise NotImplementedError("editing a scan of more than 16 steps: scanned inputs, constraints and the previous "
+                                      "trace must be tables or per-particle [n, T] arrays")
+
+        def prev_at(v, t):
+            if isinstance(v, Sym):
+                inner = v.value
+                if isinstance(inner, (StepInput, RuntimeTable, TableArray)):
+                    return Sym(inner[t], None)
+                if isinstance(inner, np.ndarray) and inner.dtype == object:
+                    raise NotImplementedError("editing a scan of more than 16 steps: vector-valued sites")
+                return v
+            if isinstance(v, dict):
+                return {k: (None if k == "retval" else prev_at(x, t)) for k, x in v.items()}
+            if isinstance(v, tuple):
+                return tuple(prev_at(x, t) for x in v)
+            return v
+
+        def step_constraint(chm, t):
+            if chm is None or chm.static_is_empty():
+                return ChoiceMap.empty()
+            if any(isinstance(a, int) for a in chm._children):
+                raise NotImplementedError("editing a scan of more than 16 steps: constrain an address at every step "
+                                          "(C[..., :, addr]), not at one step")
+
+            def pick(v):
+                inner = v.value if isinstance(v, Sym) else v
+                if isinstance(inner, (RuntimeTable, TableArray, StepInput)) and inner.shape[0] == n:
+                    return inner[t]
+                if isinstance(inner, np.ndarray) and inner.ndim >= 1 and inner.shape[0] == n:
+                    return at_step(inner, t)
+                return inner
+            return chm.map_values(pick)
+
+        leaves0 = []
+        ctree = flat_carry(carry, leaves0)
+        cvars = [g.loop_var(e.node) for e in leaves0]
+        kvar = g.loop_var(key.node) if key is not None else None
+        zero = g.const_f32(0.0)
+        wvar, svar = g.loop_var(zero), g.loop_var(zero)
+        g.loop_begin(n)
+        with T.tracing(g):
+            t = Expr(g.add("LDT", dtype="i32"))
+            k_t = Expr(g.add("KDERIVER", (kvar, t.node), dtype="key")) if kvar is not None else None
+            x_t = at_step(scanned_in, t)
+            carry_in = rebuild(ctree, [Expr(v) for v in cvars])
+            ctx.mark_changed(_flat_exprs(carry_in))           # a loop-carried value: changed, as far as the trace can tell
+            prev_t = prev_at(inner_prev, t)
+            if sub_mode == "regen":
+                rec, ret, w, _ = call_gen_fn(ctx, "regen", self.kernel_gen_fn, k_t, (carry_in, x_t), ChoiceMap.empty(),
+                                             prev_t, req, req_leaves, addr)
+            else:
+                rec, ret, w, _ = call_gen_fn(ctx, "update", self.kernel_gen_fn, k_t, (carry_in, x_t),
+                                             step_constraint(constraint, t), prev_t,
+                                             req if kind == "update" else carry_over, req_leaves, addr)
+            if not (isinstance(ret, tuple) and len(ret) == 2):
+                raise TypeError("scan: the kernel must return (carry, output)")
+            carry_out, y_t = ret
+            score_t = _rec_score(rec)
+            for r in _leaves(rec):
+                val = r.value.value if isinstance(r.value, Sym) else r.value
+                sc = r.score.value if isinstance(r.score, Sym) else r.score
+                dis = r.discard.value if isinstance(r.discard, Sym) else r.discard
+                if isinstance(val, np.ndarray) or isinstance(sc, np.ndarray):
+                    raise NotImplementedError("editing a scan of more than 16 steps: vector-valued sites")
+                if keep:
+                    r.origins = (tr.store_step(val, n), tr.store_step(sc, n),
+                                 tr.store_step(dis, n) if dis is not None else None)
+                    r.value = StepOutput(r.origins[0], n)
+                    r.score = StepOutput(r.origins[1], n)
+                    r.discard = StepOutput(r.origins[2], n) if dis is not None else None
+
+            def stack_out(v):
+                if v is None:
+                    return None
+                if isinstance(v, (tuple, list)):
+                    return type(v)(stack_out(x) for x in v)
+                return StepOutput(tr.store_step(v, n), n)
+            ys = stack_out(y_t)
+            new_leaves = []
+            ntree = flat_carry(carry_out, new_leaves)
+            if _shape_of(ntree) != _shape_of(ctree):
+                raise TypeError("scan: the kernel must return a carry of the same structure as it received")
+            for var, e in zip(cvars, new_leaves):
+                g.set_var(var, e.node)
+            if w is not None:
+                g.set_var(wvar, (Expr(wvar) + w).node)
+            g.set_var(svar, (Expr(svar) + score_t).node)
+            if kvar is not None:
+                g.set_var(kvar, k_t.node)
+        g.loop_end()
+        ctx.store_sites = keep
+
+        def drop_retvals(r):
+            if isinstance(r, _CallRec):
+                r.retval = None
+                for x in r.sites.values():
+                    drop_retvals(x)
+        retval = (rebuild(ctree, [Expr(v) for v in cvars]), ys)
+        if isinstance(rec, _SiteRec):
+            raise NotImplementedError("editing a scan of bare distributions")
+        drop_retvals(rec)
+        out = _CallRec(self)
+        out.sites = rec.sites
+        out.retval = retval
+        out.plate_score = Expr(svar)
+        return out, retval, Expr(wvar), None
 
     def edit(self, key, trace, edit_request, argdiffs):
         from .static import run_edit

@@ -1150,3 +1150,41 @@ def check_scan_long_vector_site(n=130, T=40, seed=3):
     otr2, ow = osc.importance(O.split(O.key(seed + 1), n), ocon, (np.zeros((n, 2), np.float32), np.zeros(T, np.float32)))
     assert np.array_equal(w.cpu().numpy(), ow)
     assert np.array_equal(tr2.get_choices()["x"].cpu().numpy(), otr2.get_choices()["x"])
+
+
+def check_scan_long_edits(n=150, T=40, seed=9):
+    """Update (new observations at every step) and Regenerate (the latent path) of a LONG scan — the counted-loop form of
+    Scan.edit (scan.py:417-594): chained keys, carries threaded through the edited predecessors, weights / scores /
+    discards equal to the oracle's step-by-step statement."""
+    import genjax_amd as G
+    from genjax_amd import ChoiceMapBuilder as C, Diff, Regenerate, SelectionBuilder as S, Update, numpy as jnp
+    ys = np.random.default_rng(seed).normal(size=T).astype(np.float32)
+
+    def mk(g):
+        @g.gen
+        def step(x, t):
+            xn = g.normal(0.9 * x, 0.5) @ "x"
+            g.normal(xn, 1.0) @ "y"
+            return xn, xn * 2.0
+        return step
+    step, ostep = mk(G), mk(O)
+    dev = G._lib.get().device
+    sc, osc = step.scan(n=T), O.Scan(ostep, T)
+    a = (torch.zeros(n, device=dev), jnp.zeros(T))
+    oa = (np.zeros(n, np.float32), np.zeros(T, np.float32))
+    t0, ot0 = sc.simulate(G.split(G.key(seed), n), a), osc.simulate(O.split(O.key(seed), n), oa)
+    u, w, _, bwd = Update(C[:, "y"].set(ys)).edit(G.split(G.key(seed + 1), n), t0, Diff.no_change(a))
+    ou, ow = O.scan_edit(osc, O.split(O.key(seed + 1), n), ot0, oa, update=O.C.d({"y": ys}))
+    assert np.array_equal(w.cpu().numpy(), ow)
+    assert np.array_equal(u.get_score().cpu().numpy(), ou.get_score())
+    assert np.array_equal(u.get_choices()["y"].cpu().numpy(), np.broadcast_to(ys, (n, T)))
+    assert np.array_equal(u.get_choices()["x"].cpu().numpy(), ot0.get_choices()["x"])           # latents untouched
+    assert np.array_equal(bwd.constraint["y"].cpu().numpy(), ot0.get_choices()["y"])            # discard = old values
+    r, wr, _, _ = Regenerate(S["x"]).edit(G.split(G.key(seed + 2), n), u, Diff.no_change(a))
+    orr, owr = O.scan_edit(osc, O.split(O.key(seed + 2), n), ou, oa, regenerate=O.selection("x"))
+    assert np.array_equal(r.get_choices()["x"].cpu().numpy(), orr.get_choices()["x"])
+    assert np.array_equal(wr.cpu().numpy(), owr)
+    assert np.array_equal(r.get_score().cpu().numpy(), orr.get_score())
+    carry, doubled = r.get_retval()
+    ocarry, odoubled = orr.get_retval()
+    assert np.array_equal(carry.cpu().numpy(), ocarry) and np.array_equal(doubled.cpu().numpy(), odoubled)

@@ -1013,3 +1013,9 @@ def test_long_scan_with_a_vector_valued_site(gpu):
     """counted-loop scan, 2-D latent state in one site: interpreter (n = 130) and specialised kernel (n = 70 000)"""
     parity.check_scan_long_vector_site()
     parity.check_scan_long_vector_site(n=70_000, T=24, seed=8)
+
+
+def test_long_scan_update_and_regenerate(gpu):
+    """counted-loop Scan.edit on the HIP library: interpreter (n = 150) and specialised kernel (n = 70 000, T = 24)"""
+    parity.check_scan_long_edits()
+    parity.check_scan_long_edits(n=70_000, T=24, seed=4)

@@ -1043,3 +1043,9 @@ def test_long_scan_with_a_vector_valued_site():
     """a counted-loop scan whose kernel has a vector-valued site (a 2-D latent state): values come back [n, T, 2]"""
     from tests import parity
     parity.check_scan_long_vector_site()
+
+
+def test_long_scan_update_and_regenerate():
+    """Scan.edit (Update / Regenerate) of a 40-step scan as a counted loop == the oracle's step-by-step edits"""
+    from tests import parity
+    parity.check_scan_long_edits()

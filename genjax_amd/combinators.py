@@ -20,6 +20,8 @@ at trace time: for short sequences inside one model (a whole 100-step SSM belong
 """
 from __future__ import annotations
 
+from collections import OrderedDict
+
 import numpy as np
 
 from .core.choice_map import ChoiceMap
@@ -310,6 +312,50 @@ def _index_prev(prev, j):
     return pick(prev)
 
 
+def _loop_step_constraint(chm: ChoiceMap, t, n, at_step, what="scan of more than 16 steps"):
+    """The constraint of iteration t of a counted loop: values that carry the step axis first are read at t; what sits
+    under an explicit integer address (`C[..., 2, "y"].set(v)`: constraint.get_submap(idx), scan.py:262) becomes a
+    MASKED constraint `Mask(v, t == 2)` — the leaf then takes the constrained branch at that step only (OP_SEL), which
+    is what the reference's per-step `get_submap` amounts to.  An address constrained at every step wins over an
+    explicit one, as in the unrolled form (_index_chm)."""
+    from .core.mask import Mask
+    from .engine import StepInput, Sym
+    from .numpy import RuntimeTable, TableArray
+    if chm is None or chm.static_is_empty():
+        return ChoiceMap.empty()
+    explicit = {a: c for a, c in chm._children.items() if isinstance(a, int)}
+    rest = ChoiceMap(chm._value, {a: c for a, c in chm._children.items() if not isinstance(a, int)}) if explicit else chm
+
+    def pick(v):
+        inner = v.value if isinstance(v, Sym) else v
+        if isinstance(inner, (RuntimeTable, TableArray, StepInput)) and inner.shape[0] == n:
+            return inner[t]
+        if isinstance(inner, np.ndarray) and inner.ndim >= 1 and inner.shape[0] == n:
+            return at_step(inner, t)
+        return inner
+    out = rest.map_values(pick)
+    if not explicit:
+        return out
+    taken = set(out.addresses())
+    per_addr = OrderedDict()
+    for i, sub in sorted(explicit.items()):
+        if not 0 <= i < n:
+            raise IndexError(f"{what}: constraint at step {i} of {n}")
+        for a in sub.addresses():
+            if a in taken:
+                continue
+            v = sub[a]
+            per_addr.setdefault(a, []).append((i, v.value if isinstance(v, Sym) else v))
+    for a, items in per_addr.items():
+        val, flag = None, None
+        for i, v in items:
+            here = t == i
+            val = v if val is None else T.where(here, v, val)
+            flag = here if flag is None else (flag | here)
+        out = out.set(a, Mask(val, flag))
+    return out
+
+
 class Scan(GenerativeFunction):
     """scan.py:140-294: kernel (carry, x) -> (carry, y), repeated `length` times."""
 
@@ -450,18 +496,7 @@ class Scan(GenerativeFunction):
                                       "launch-uniform vectors (tables) or per-particle [n, T] arrays")
 
         def step_constraint(chm, t):
-            if any(isinstance(a, int) for a in chm._children):
-                raise NotImplementedError("scan of more than 16 steps: a constraint on one step (C[..., t, ...]) is not "
-                                          "supported; constrain an address at every step (C[..., :, addr])")
-
-            def pick(v):
-                inner = v.value if isinstance(v, Sym) else v
-                if isinstance(inner, (RuntimeTable, TableArray, StepInput)) and inner.shape[0] == n:
-                    return inner[t]
-                if isinstance(inner, np.ndarray) and inner.ndim >= 1 and inner.shape[0] == n:
-                    return at_step(inner, t)
-                return inner
-            return chm.map_values(pick)
+            return _loop_step_constraint(chm, t, n, at_step)
 
         leaves0 = []
         ctree = flat_carry(carry, leaves0)
@@ -706,20 +741,7 @@ class Scan(GenerativeFunction):
             return v
 
         def step_constraint(chm, t):
-            if chm is None or chm.static_is_empty():
-                return ChoiceMap.empty()
-            if any(isinstance(a, int) for a in chm._children):
-                raise NotImplementedError("editing a scan of more than 16 steps: constrain an address at every step "
-                                          "(C[..., :, addr]), not at one step")
-
-            def pick(v):
-                inner = v.value if isinstance(v, Sym) else v
-                if isinstance(inner, (RuntimeTable, TableArray, StepInput)) and inner.shape[0] == n:
-                    return inner[t]
-                if isinstance(inner, np.ndarray) and inner.ndim >= 1 and inner.shape[0] == n:
-                    return at_step(inner, t)
-                return inner
-            return chm.map_values(pick)
+            return _loop_step_constraint(chm, t, n, at_step, "editing a scan of more than 16 steps")
 
         leaves0 = []
         ctree = flat_carry(carry, leaves0)

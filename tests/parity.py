@@ -738,6 +738,16 @@ def check_scan_long(n=257, T=100, seed=5):
     carry, doubled = t4.get_retval()
     ocarry, odoubled = t4o.get_retval()
     assert np.array_equal(carry.cpu().numpy(), ocarry) and np.array_equal(doubled.cpu().numpy(), odoubled)
+    # constraints at single steps through integer addresses (constraint.get_submap(idx), scan.py:262): in the loop
+    # they are masked constraints `Mask(v, t == idx)`; the weight is those steps' observation densities alone
+    tr5, w5 = sc.importance(G.split(G.key(seed + 3), n), C[2, "y"].set(0.25).set((T - 3, "y"), -1.5),
+                            (torch.zeros(n, device=dev), jnp.zeros(T)))
+    y5, x5 = tr5.get_choices()["y"].cpu().numpy(), tr5.get_choices()["x"].cpu().numpy()
+    assert np.all(y5[:, 2] == np.float32(0.25)) and np.all(y5[:, T - 3] == np.float32(-1.5))
+    assert not np.all(y5[:, 3] == np.float32(0.25))
+    w_ref = (O.normal.assess(O.C.choice(np.full(n, 0.25, np.float32)), (x5[:, 2], np.float32(1.0)), (n,))[0]
+             + O.normal.assess(O.C.choice(np.full(n, -1.5, np.float32)), (x5[:, T - 3], np.float32(1.0)), (n,))[0])
+    assert np.array_equal(w5.cpu().numpy(), w_ref)
     return dict(log_ml_is=float(torch.logsumexp(w.double(), 0) - math.log(n)), kalman=workloads.kalman_log_ml(ys))
 
 

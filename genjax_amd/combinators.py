@@ -594,8 +594,6 @@ class Scan(GenerativeFunction):
         n = self._length(scanned_in)
         inner_prev = prev["vmap"]
         if n > SCAN_UNROLL_MAX:
-            if sub_mode == "index":
-                raise NotImplementedError("IndexRequest into a scan of more than 16 steps")
             return self._trace_edit_loop(ctx, sub_mode, key, carry, scanned_in, constraint, inner_prev, req, kind, n,
                                          req_leaves, addr)
         g = ctx.tr.graph
@@ -746,7 +744,8 @@ class Scan(GenerativeFunction):
         leaves0 = []
         ctree = flat_carry(carry, leaves0)
         cvars = [g.loop_var(e.node) for e in leaves0]
-        kvar = g.loop_var(key.node) if key is not None else None
+        key0 = key
+        kvar = g.loop_var(key.node) if (key is not None and sub_mode != "index") else None
         zero = g.const_f32(0.0)
         wvar, svar = g.loop_var(zero), g.loop_var(zero)
         g.loop_begin(n)
@@ -757,7 +756,27 @@ class Scan(GenerativeFunction):
             carry_in = rebuild(ctree, [Expr(v) for v in cvars])
             ctx.mark_changed(_flat_exprs(carry_in))           # a loop-carried value: changed, as far as the trace can tell
             prev_t = prev_at(inner_prev, t)
-            if sub_mode == "regen":
+            if sub_mode == "index":
+                # edit_index (scan.py:325-416) in the loop: every iteration traces BOTH the sub-request on step t (with
+                # the caller's key, not a chained one) and the plain carry-over, and keeps the edit where idx == t — the
+                # form the unrolled code uses for a per-particle idx; a Python-int idx is the same test against a constant
+                sub = req.sub
+                m_ = {"update": "update", "regen": "regen"}.get(sub.kind, "static_edit")
+                con_ = sub.constraint if sub.kind == "update" else ChoiceMap.empty()
+                saved = set(ctx.changed)
+                rec, ret, w, _ = call_gen_fn(ctx, m_, self.kernel_gen_fn, Expr(key0.node) if key0 is not None else None,
+                                             (carry_in, x_t), con_, prev_t, sub, req_leaves, addr)
+                ctx.changed = saved
+                ctx.memo.clear()
+                old, old_ret, w_old, _ = call_gen_fn(ctx, "update", self.kernel_gen_fn,
+                                                     Expr(key0.node) if key0 is not None else None, (carry_in, x_t),
+                                                     ChoiceMap.empty(), prev_t, carry_over, req_leaves, addr)
+                here = t == req.idx
+                zero_e = Expr(g.const_f32(0.0))
+                rec = _select_rec(here, rec, old)
+                ret = _select_tree(here, ret, old_ret)
+                w = T.where(here, w if w is not None else zero_e, w_old if w_old is not None else zero_e)
+            elif sub_mode == "regen":
                 rec, ret, w, _ = call_gen_fn(ctx, "regen", self.kernel_gen_fn, k_t, (carry_in, x_t), ChoiceMap.empty(),
                                              prev_t, req, req_leaves, addr)
             else:

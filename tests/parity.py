@@ -1198,3 +1198,30 @@ def check_scan_long_edits(n=150, T=40, seed=9):
     carry, doubled = r.get_retval()
     ocarry, odoubled = orr.get_retval()
     assert np.array_equal(carry.cpu().numpy(), ocarry) and np.array_equal(doubled.cpu().numpy(), odoubled)
+    # IndexRequest (scan.py:325-416) in the loop: one step edited with the caller's key, the next re-scored against the
+    # new carry; a Python-int idx and one idx per particle
+    from genjax_amd import IndexRequest
+    regen = lambda k, sl, a_: ostep.regenerate(k, sl, O.selection("x"), a_)[:2]
+    for idx in (2, T - 1):
+        e, we, _, be = IndexRequest(idx, Regenerate(S["x"])).edit(G.split(G.key(seed + 3), n), r, Diff.no_change(a))
+        oe, owe = O.scan_edit_index(osc, O.split(O.key(seed + 3), n), orr, oa, idx, regen)
+        xe = e.get_choices()["x"].cpu().numpy()
+        assert np.array_equal(xe, oe.get_choices()["x"]) and np.array_equal(we.cpu().numpy(), owe)
+        assert np.array_equal(e.get_score().cpu().numpy(), oe.get_score())
+        old = r.get_choices()["x"].cpu().numpy()
+        assert np.array_equal(np.delete(old, idx, axis=1), np.delete(xe, idx, axis=1))      # only step idx moved
+    idx = np.random.default_rng(seed + 9).integers(0, T, n).astype(np.int32)
+    e6, we6, _, _ = IndexRequest(torch.from_numpy(idx).to(dev), Regenerate(S["x"])).edit(
+        G.split(G.key(seed + 4), n), r, Diff.no_change(a))
+    xo6 = orr.get_choices()["x"].copy()
+    wo6, so6 = np.zeros(n, np.float32), np.zeros(n, np.float32)
+    for t_ in range(T):
+        m_ = idx == t_
+        if not m_.any():
+            continue
+        cand, wt = O.scan_edit_index(osc, O.split(O.key(seed + 4), n), orr, oa, t_, regen)
+        xo6[m_] = cand.get_choices()["x"][m_]
+        wo6[m_], so6[m_] = np.asarray(wt, np.float32)[m_], np.asarray(cand.get_score(), np.float32)[m_]
+    assert np.array_equal(e6.get_choices()["x"].cpu().numpy(), xo6)
+    assert np.array_equal(we6.cpu().numpy(), wo6)
+    assert np.array_equal(e6.get_score().cpu().numpy(), so6)

@@ -729,8 +729,6 @@ class Scan(GenerativeFunction):
                 inner = v.value
                 if isinstance(inner, (StepInput, RuntimeTable, TableArray)):
                     return Sym(inner[t], None)
-                if isinstance(inner, np.ndarray) and inner.dtype == object:
-                    raise NotImplementedError("editing a scan of more than 16 steps: vector-valued sites")
                 return v
             if isinstance(v, dict):
                 return {k: (None if k == "retval" else prev_at(x, t)) for k, x in v.items()}
@@ -791,8 +789,8 @@ class Scan(GenerativeFunction):
                 val = r.value.value if isinstance(r.value, Sym) else r.value
                 sc = r.score.value if isinstance(r.score, Sym) else r.score
                 dis = r.discard.value if isinstance(r.discard, Sym) else r.discard
-                if isinstance(val, np.ndarray) or isinstance(sc, np.ndarray):
-                    raise NotImplementedError("editing a scan of more than 16 steps: vector-valued sites")
+                if isinstance(sc, np.ndarray):
+                    raise NotImplementedError("editing a scan of more than 16 steps: a site with a vector-valued SCORE")
                 if keep:
                     r.origins = (tr.store_step(val, n), tr.store_step(sc, n),
                                  tr.store_step(dis, n) if dis is not None else None)

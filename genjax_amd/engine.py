@@ -108,8 +108,8 @@ def leaf_spec(v, batch: tuple):
         dt = _TDT[t.dtype]
         if t.ndim == 0:
             return ("bcast", dt)
-        if t.ndim == 1 and t.shape[0] > DVEC_MAX:
-            return ("dtab", dt, tuple(t.shape))
+        if (t.ndim == 1 and t.shape[0] > DVEC_MAX) or (t.ndim >= 2 and t.shape[0] > DVEC_MAX and t.numel() // t.shape[0] <= DVEC_MAX):
+            return ("dtab", dt, tuple(t.shape))          # a long vector, or a long table of short rows ([T, D])
         return ("dvec", dt, tuple(t.shape))
     if isinstance(v, Gathered):
         if tuple(v.ancestors.shape) != tuple(batch):
@@ -126,8 +126,8 @@ def leaf_spec(v, batch: tuple):
             return ("bcast", dt)
         if nb == 0:
             return ("part", dt, shp)
-        if v.ndim == 1 and shp[0] > DVEC_MAX:
-            return ("dtab", dt, shp)           # launch-uniform table read with OP_LDTAB
+        if (v.ndim == 1 and shp[0] > DVEC_MAX) or (v.ndim >= 2 and shp[0] > DVEC_MAX and v.numel() // shp[0] <= DVEC_MAX):
+            return ("dtab", dt, shp)           # launch-uniform table read with OP_LDTAB ([T] or [T, *short row])
         return ("dvec", dt, shp)
     if isinstance(v, (list, tuple)):
         v = np.asarray(v)
@@ -136,7 +136,7 @@ def leaf_spec(v, batch: tuple):
             raise TypeError("object arrays cannot be launch values")
         if v.ndim == 0:
             return leaf_spec(v.item(), batch)
-        if v.ndim == 1 and v.shape[0] > GMX_HVEC_MAX:
+        if (v.ndim == 1 and v.shape[0] > GMX_HVEC_MAX) or (v.ndim >= 2 and v.shape[0] > GMX_HVEC_MAX and v.size // v.shape[0] <= DVEC_MAX):
             return ("dtab", _np_dt(v), tuple(v.shape))      # too long for the operand pool: a table, like a long device vector
         return ("hvec", _np_dt(v), tuple(v.shape))
     if getattr(v, "__gmx_static__", False):
@@ -283,10 +283,19 @@ class Tracing:
             from .numpy import RuntimeTable, runtime_table_slot
             slot = runtime_table_slot(g)
             self.tab_plan.append((slot, j))
-            return Sym(RuntimeTable.make(g, slot, spec[1], spec[2][0]), ("leaf", j))
+            return Sym(RuntimeTable.make(g, slot, spec[1], spec[2] if len(spec[2]) > 1 else spec[2][0]), ("leaf", j))
         flags = {"bcast": F_BCAST, "dvec": F_BCAST, "part": 0, "gather": F_GATHER}[kind]
         dt = spec[1]
         event = () if kind == "bcast" else spec[2]
+        if kind == "part" and len(event) >= 2 and event[0] > STEP_LEAF_MIN and int(np.prod(event[1:])) <= DVEC_MAX:
+            # [n, T, *site event]: the values of a vector-valued site over the steps of a long scan — one [T, n] plane
+            # per element of the site's event
+            E = int(np.prod(event[1:]))
+            slots = list(range(g.n_in, g.n_in + E))
+            g.n_in += E
+            for e_, slot in enumerate(slots):
+                self.in_plan.append((slot, j, e_, "step2"))
+            return Sym(StepInput.make2(g, slots, dt, int(event[0]), event[1:]), ("leaf", j))
         if kind == "part" and len(event) == 1 and event[0] > STEP_LEAF_MIN:
             # a long per-particle vector (the [n, T] choices of a scan): one slot, element t read by iteration t
             slot = g.n_in
@@ -395,14 +404,37 @@ class StepInput(np.ndarray):
         out._g, out._slot, out._dt, out._flags = g, slot, dt, flags
         return out
 
+    @classmethod
+    def make2(cls, g, slots, dt, T, event):
+        """a per-particle [T, *event] leaf (a vector-valued site's values over the steps): one slot ([T, n] plane)
+        per element of the event; row t is the object array of its element reads"""
+        from .program import F_STEP, F_U8
+        flags = F_STEP | (F_U8 if dt == "bool" else 0)
+        arr = np.empty((T,) + tuple(event), dtype=object)
+        for k in range(T):
+            for e, idx in enumerate(np.ndindex(tuple(event))):
+                arr[(k,) + idx] = Expr(g.add("LDIN", dtype=dt, flags=flags, slot=slots[e], imm=k))
+        out = arr.view(cls)
+        out._g, out._slot, out._dt, out._flags = g, list(slots), dt, flags
+        return out
+
     def __array_finalize__(self, obj):
         for a in ("_g", "_slot", "_dt", "_flags"):
             setattr(self, a, getattr(obj, a, None))
 
     def __getitem__(self, idx):
-        if isinstance(idx, Expr) and self._slot is not None and self.ndim == 1:
-            return Expr(self._g.add("LDIN", dtype=self._dt, flags=self._flags, slot=self._slot))
-        return np.ndarray.__getitem__(self, idx)
+        if isinstance(idx, Expr) and self._slot is not None:
+            if self.ndim == 1 and not isinstance(self._slot, list):
+                return Expr(self._g.add("LDIN", dtype=self._dt, flags=self._flags, slot=self._slot))
+            if isinstance(self._slot, list) and self.ndim >= 2 and int(np.prod(self.shape[1:])) == len(self._slot):
+                row = np.empty(self.shape[1:], dtype=object)          # this iteration's row, element by element
+                for e, ix in enumerate(np.ndindex(self.shape[1:])):
+                    row[ix] = Expr(self._g.add("LDIN", dtype=self._dt, flags=self._flags, slot=self._slot[e]))
+                return row
+        r = np.ndarray.__getitem__(self, idx)
+        if isinstance(r, StepInput) and not (isinstance(idx, slice) or idx is Ellipsis):
+            return np.asarray(r, dtype=object) if r.ndim else r      # a static row / element: plain expressions
+        return r
 
 
 class StepOutput:
@@ -568,11 +600,18 @@ class Compiled:
                 key_ = (j, kind)
             buf = soa_cache.get(key_)
             if buf is None:
-                buf = _prepare_input(src, "part" if kind == "step" else kind, n if kind in ("part", "step") else None, be)
+                if kind == "step2":        # [n, T, *event] -> [E, T, n] planes (a copy: the step stride is n for every leaf)
+                    t_ = _prepare_input(src, "bcast", None, be)
+                    buf = t_.reshape(n, t_.shape[len(batch)], -1).permute(2, 1, 0).contiguous()
+                else:
+                    buf = _prepare_input(src, "part" if kind == "step" else kind, n if kind in ("part", "step") else None, be)
                 soa_cache[key_] = buf
                 keep.append(buf)
             item = buf.element_size()
-            if kind == "step":
+            if kind == "step2":
+                A.in_d[slot] = buf.data_ptr() + e * buf.shape[1] * n * item
+                A.step_stride = n
+            elif kind == "step":
                 if buf.dim() != 2 or buf.stride(1) != 1 or buf.stride(0) != n:
                     buf = buf.contiguous()
                     keep.append(buf)

@@ -36,12 +36,19 @@ class TableArray(np.ndarray):
 
     def __getitem__(self, idx):
         if isinstance(idx, Expr):
-            if self.ndim != 1:
-                raise NotImplementedError("traced index into an array with ndim != 1")
             g = T.current_graph()
-            slot = table_slot(g, np.asarray(self))
             dt = "f32" if self.dtype.kind == "f" else ("bool" if self.dtype.kind == "b" else "i32")
-            return Expr(g.add("LDTAB", (T.as_int(idx).node,), dtype=dt, slot=slot))
+            if self.ndim == 1:
+                slot = table_slot(g, np.asarray(self))
+                return Expr(g.add("LDTAB", (T.as_int(idx).node,), dtype=dt, slot=slot))
+            # row `idx` of a [T, *event] table: element e of the row is entry idx * E + e of the flattened table
+            E = int(np.prod(self.shape[1:]))
+            slot = table_slot(g, np.ascontiguousarray(np.asarray(self)).reshape(-1))
+            base = (T.as_int(idx) * E).node
+            row = np.empty(self.shape[1:], dtype=object)
+            for e, ix in enumerate(np.ndindex(self.shape[1:])):
+                row[ix] = Expr(g.add("LDTAB", (base,), imm=e, dtype=dt, slot=slot))
+            return row
         r = np.ndarray.__getitem__(self, idx)
         if isinstance(r, np.ndarray) and r.ndim == 0:
             return r.item()
@@ -55,10 +62,12 @@ class RuntimeTable(np.ndarray):
 
     @classmethod
     def make(cls, g, slot, dt, n):
+        """n: the length of a vector, or the shape (T, *event) of a table of rows (flattened row-major in memory)"""
+        shape = (int(n),) if isinstance(n, (int, np.integer)) else tuple(int(x) for x in n)
         zero = g.const_i32(0)
-        arr = np.empty((n,), dtype=object)
-        for k in range(n):
-            arr[k] = Expr(g.add("LDTAB", (zero,), imm=k, dtype=dt, slot=slot))
+        arr = np.empty(shape, dtype=object)
+        for k, ix in enumerate(np.ndindex(shape)):
+            arr[ix] = Expr(g.add("LDTAB", (zero,), imm=k, dtype=dt, slot=slot))
         out = arr.view(cls)
         out._slot, out._dt = slot, dt
         return out
@@ -73,7 +82,17 @@ class RuntimeTable(np.ndarray):
             if idx.node.op == "CONST":                           # static after all: the shared element read
                 return Expr(g.add("LDTAB", (g.const_i32(0),), imm=idx.node.imm, dtype=self._dt, slot=self._slot))
             return Expr(g.add("LDTAB", (T.as_int(idx).node,), dtype=self._dt, slot=self._slot))
+        if isinstance(idx, Expr) and self._slot is not None and self.ndim >= 2:
+            g = T.current_graph()                                # row `idx` of a table of rows
+            E = int(np.prod(self.shape[1:]))
+            base = (T.as_int(idx) * E).node
+            row = np.empty(self.shape[1:], dtype=object)
+            for e, ix in enumerate(np.ndindex(self.shape[1:])):
+                row[ix] = Expr(g.add("LDTAB", (base,), imm=e, dtype=self._dt, slot=self._slot))
+            return row
         r = np.ndarray.__getitem__(self, idx)
+        if isinstance(r, RuntimeTable) and self.ndim >= 2 and not isinstance(idx, slice):
+            return np.asarray(r, dtype=object)                   # a static row: plain expressions
         return r
 
 

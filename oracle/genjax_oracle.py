@@ -1089,7 +1089,7 @@ class Scan:
         for t in range(n):
             if k is not None:
                 k = fold_in(k, t)
-            sub = chm.filter(lambda a: True).map_values(lambda v: np.asarray(v)[..., t]) if chm is not None else None
+            sub = chm.filter(lambda a: True).map_values(lambda v: _step_take(v, t, n, len(batch))) if chm is not None else None
             if mode == "simulate":
                 tr = self.kernel.simulate(k, (carry, self._x(xs, t)))
                 s = tr.get_score()
@@ -1123,6 +1123,26 @@ class Scan:
         return score, ret
 
 
+def _step_axis(a, n, bn):
+    """Which axis of `a` is the step / plate axis of length n: right after the bn batch axes for a per-particle value
+    ([batch, n, *event] — the trailing axis when the site is scalar), the leading one for a launch-uniform table
+    ([n, *event]); None when `a` does not carry it."""
+    a = np.asarray(a)
+    if a.ndim > bn and a.shape[bn] == n:
+        return bn
+    if a.ndim >= 1 and a.shape[0] == n:
+        return 0
+    if a.ndim >= 1 and a.shape[-1] == n:
+        return a.ndim - 1
+    return None
+
+
+def _step_take(v, idx, n, bn):
+    a = np.asarray(v)
+    ax = _step_axis(a, n, bn)
+    return v if ax is None else np.take(a, idx, axis=ax)
+
+
 def _slice_last(tr, idx):
     """tree_map(lambda v: v[idx], trace.inner) for plate leaves kept on the TRAILING axis."""
     def sl(v, n):
@@ -1134,7 +1154,8 @@ def _slice_last(tr, idx):
         return a[..., idx] if a.ndim >= 1 and a.shape[-1] == n else v
     if isinstance(tr, DistTrace):
         n = np.shape(tr.score)[-1]
-        return DistTrace(tr.gen_fn, tuple(sl(a, n) for a in tr.args), sl(tr.value, n), sl(tr.score, n))
+        bn = np.ndim(tr.score) - 1                   # a site's score is [batch, n]: its value [batch, n, *event]
+        return DistTrace(tr.gen_fn, tuple(sl(a, n) for a in tr.args), _step_take(tr.value, idx, n, bn), sl(tr.score, n))
     n = np.shape(tr.get_score())[-1]
     return StaticTrace(tr.gen_fn, tr.args, sl(tr.retval, n),
                        OrderedDict((a, _slice_last(s, idx)) for a, s in tr.subtraces.items()))
@@ -1150,8 +1171,17 @@ def _set_last(tr, idx, new):
         a = np.array(v, copy=True)
         a[..., idx] = np.asarray(v_, dtype=a.dtype)
         return a
+
+    def st_value(v, v_, n, bn):
+        a = np.array(v, copy=True)
+        ax = _step_axis(a, n, bn)
+        ix = [slice(None)] * a.ndim
+        ix[ax] = idx
+        a[tuple(ix)] = np.asarray(v_, dtype=a.dtype)
+        return a
     if isinstance(tr, DistTrace):
-        return DistTrace(tr.gen_fn, tr.args, st(tr.value, new.value), st(tr.score, new.score))
+        return DistTrace(tr.gen_fn, tr.args, st_value(tr.value, new.value, np.shape(tr.score)[-1], np.ndim(tr.score) - 1),
+                         st(tr.score, new.score))
     return StaticTrace(tr.gen_fn, tr.args, st(tr.retval, new.retval),
                        OrderedDict((a, _set_last(s, idx, new.subtraces[a])) for a, s in tr.subtraces.items()))
 
@@ -1193,7 +1223,7 @@ def scan_edit(sc: "Scan", k, trace: "VmapTrace", args, update: ChoiceMap = None,
         if regenerate is not None:
             new, w, _ = sc.kernel.regenerate(k, sl, regenerate, a)
         else:
-            sub = update.map_values(lambda v: np.asarray(v)[..., t])
+            sub = update.map_values(lambda v: _step_take(v, t, n, len(batch)))
             new, w, _ = sc.kernel.update(k, sl, sub, a)
         carry, y = new.get_retval()
         slices.append(new)

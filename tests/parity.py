@@ -1225,3 +1225,43 @@ def check_scan_long_edits(n=150, T=40, seed=9):
     assert np.array_equal(e6.get_choices()["x"].cpu().numpy(), xo6)
     assert np.array_equal(we6.cpu().numpy(), wo6)
     assert np.array_equal(e6.get_score().cpu().numpy(), so6)
+
+
+def check_scan_long_vector_constraints(n=140, T=30, seed=6):
+    """Long scan, 2-D latent state in one site AND 2-D observations in one site: per-step constraints on a vector-valued
+    site from a launch-uniform [T, 2] table (importance), from per-particle [n, T, 2] choices (assess), and the previous
+    values of vector-valued sites under Update / Regenerate."""
+    import genjax_amd as G
+    from genjax_amd import ChoiceMapBuilder as C, Diff, Regenerate, SelectionBuilder as S, Update, numpy as jnp
+    ys = np.random.default_rng(seed).normal(size=(T, 2)).astype(np.float32)
+
+    def mk(g, np_):
+        @g.gen
+        def step(x, t):
+            m = np_.stack([0.9 * x[..., 0] + 0.1 * x[..., 1], 0.8 * x[..., 1]], axis=-1)
+            xn = g.normal(m, 0.5) @ "x"
+            g.normal(xn, 1.0) @ "y"
+            return xn, xn[..., 1]
+        return step
+    step, ostep = mk(G, jnp), mk(O, np)
+    dev = G._lib.get().device
+    sc, osc = step.scan(n=T), O.Scan(ostep, T)
+    a = (torch.zeros((n, 2), device=dev), jnp.zeros(T))
+    oa = (np.zeros((n, 2), np.float32), np.zeros(T, np.float32))
+    tr, w = sc.importance(G.split(G.key(seed), n), C[:, "y"].set(jnp.array(ys)), a)
+    otr, ow = osc.importance(O.split(O.key(seed), n), O.C.d({("y",): ys}), oa)
+    assert np.array_equal(w.cpu().numpy(), ow)
+    assert np.array_equal(tr.get_choices()["x"].cpu().numpy(), otr.get_choices()["x"])
+    assert np.array_equal(tr.get_choices()["y"].cpu().numpy(), np.broadcast_to(ys, (n, T, 2)))
+    s, _ = sc.assess(tr.get_choices(), a)                              # per-particle [n, T, 2] choices read row by row
+    so, _ = osc.assess(otr.get_choices(), oa, (n,))
+    assert np.array_equal(s.cpu().numpy(), so) and np.array_equal(s.cpu().numpy(), tr.get_score().cpu().numpy())
+    t0, ot0 = sc.simulate(G.split(G.key(seed + 1), n), a), osc.simulate(O.split(O.key(seed + 1), n), oa)
+    u, wu, _, bwd = Update(C[:, "y"].set(jnp.array(ys))).edit(G.split(G.key(seed + 2), n), t0, Diff.no_change(a))
+    ou, owu = O.scan_edit(osc, O.split(O.key(seed + 2), n), ot0, oa, update=O.C.d({"y": ys}))
+    assert np.array_equal(wu.cpu().numpy(), owu) and np.array_equal(u.get_score().cpu().numpy(), ou.get_score())
+    assert np.array_equal(bwd.constraint["y"].cpu().numpy(), ot0.get_choices()["y"])
+    r, wr, _, _ = Regenerate(S["x"]).edit(G.split(G.key(seed + 3), n), u, Diff.no_change(a))
+    orr, owr = O.scan_edit(osc, O.split(O.key(seed + 3), n), ou, oa, regenerate=O.selection("x"))
+    assert np.array_equal(r.get_choices()["x"].cpu().numpy(), orr.get_choices()["x"])
+    assert np.array_equal(wr.cpu().numpy(), owr) and np.array_equal(r.get_score().cpu().numpy(), orr.get_score())

@@ -1019,3 +1019,8 @@ def test_long_scan_update_and_regenerate(gpu):
     """counted-loop Scan.edit on the HIP library: interpreter (n = 150) and specialised kernel (n = 70 000, T = 24)"""
     parity.check_scan_long_edits()
     parity.check_scan_long_edits(n=70_000, T=24, seed=4)
+
+
+def test_long_scan_vector_sites_constraints_and_edits(gpu):
+    parity.check_scan_long_vector_constraints()
+    parity.check_scan_long_vector_constraints(n=50_000, T=20, seed=2)

@@ -1049,3 +1049,9 @@ def test_long_scan_update_and_regenerate():
     """Scan.edit (Update / Regenerate) of a 40-step scan as a counted loop == the oracle's step-by-step edits"""
     from tests import parity
     parity.check_scan_long_edits()
+
+
+def test_long_scan_vector_sites_constraints_and_edits():
+    """long scan with vector-valued latent AND observation sites: [T, 2] table constraints, [n, T, 2] choices, edits"""
+    from tests import parity
+    parity.check_scan_long_vector_constraints()

@@ -134,6 +134,7 @@ struct gmx_program {
   hipFunction_t jit_fn = nullptr;
   int jit_pp = 1;                    // particles per thread of the specialised kernel
   bool jit_gathers_pre = false;      // every gathered load of the specialised kernel uses the prologue's ancestors
+  unsigned lds_pad = 0;              // EXPERIMENT (GENMI_EXP_LDS_PAD at specialisation): unused dynamic LDS per workgroup = a residency cap
 };
 
 static int parse_program(const uint32_t* blob, size_t n_words, gmx_program& P) {
@@ -474,6 +475,20 @@ static int jit_load(gmx_program* p, const std::vector<char>& code) {
   p->jit_module = mod;
   p->jit_fn = fn;
   p->jit_pp = jit_pp_for(p);
+  // EXPERIMENT: GENMI_EXP_LDS_PAD=<bytes> (read when a program is specialised) makes every launch of this kernel ask
+  // for that much dynamic LDS it never touches, i.e. caps how many of its workgroups a CU holds (160 KB per CU) —
+  // a background kernel on a second stream then leaves wave slots to the dependent chain (tools/experiments).
+  p->lds_pad = 0;
+  if (const char* e = getenv("GENMI_EXP_LDS_PAD")) {
+    long v = atol(e);
+    if (v > 0 && v <= 160 * 1024) {
+      p->lds_pad = (unsigned)v;
+      if (v > 48 * 1024) {
+        hipError_t ea = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v);
+        if (ea != hipSuccess) { (void)hipGetLastError(); p->lds_pad = 48 * 1024; }
+      }
+    }
+  }
   return 0;
 }
 
@@ -618,7 +633,8 @@ extern "C" int gmx_program_run(const gmx_program* p, int64_t n, const gmx_run_ar
     void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &ka, HIP_LAUNCH_PARAM_BUFFER_SIZE, &ka_size,
                       HIP_LAUNCH_PARAM_END};
     unsigned jgrid = (unsigned)((n + (int64_t)GMX_BLOCK * p->jit_pp - 1) / ((int64_t)GMX_BLOCK * p->jit_pp));
-    const unsigned dyn_lds = fused_rs ? (unsigned)gmx_rs_window_lds(n) : 0u;
+    unsigned dyn_lds = fused_rs ? (unsigned)gmx_rs_window_lds(n) : 0u;
+    if (p->lds_pad > dyn_lds) dyn_lds = p->lds_pad;
     GMX_HIP(hipModuleLaunchKernel(p->jit_fn, jgrid, 1, 1, GMX_BLOCK, 1, 1, dyn_lds, st, nullptr, config));
     return 0;
   }

@@ -263,6 +263,46 @@ def test_jax_docs_classic_prng_values():
     assert _from_bits("orc_unit_from_bits", bits0) == np.float32(0.41845703)
     # jax.random.normal(PRNGKey(42)) -> -0.18471177
     assert _from_bits("orc_std_normal_from_bits", _tf(0, 42, 0, 0)[0]) == np.float32(-0.18471177)
+    # "JAX - The Sharp Bits", section on random numbers (classic PRNG): key = PRNGKey(0);
+    #   key, subkey = split(key)  -> new key [4146024105 967050713], new subkey [2718843009 1272950319] --> normal [-1.2515389]
+    #   key, subkey = split(key)  -> new key [2384771982 3928867769], new subkey [1278412471 2182328957] --> normal [-0.58665055]
+    # i.e. a CHAIN of two splits and a draw from each child: pins the key word order through two levels
+    assert _from_bits("orc_std_normal_from_bits", _tf(2718843009, 1272950319, 0, 0)[0]) == np.float32(-1.2515389)
+    k = (4146024105, 967050713)
+    a, b = _tf(*k, 0, 2), _tf(*k, 1, 3)
+    assert [a[0], b[0], a[1], b[1]] == [2384771982, 3928867769, 1278412471, 2182328957]
+    assert _from_bits("orc_std_normal_from_bits", _tf(a[1], b[1], 0, 0)[0]) == np.float32(-0.58665055)
+    # JAX quickstart (classic PRNG): random.normal(PRNGKey(0), (10,)) ->
+    #   [-0.3721109 0.26423115 -0.18252768 -0.7368197 -0.44030377 -0.1521442 -0.67135346 -0.5908641 0.73168886 0.5673026]
+    # classic layout of a 10-element draw: counters 0..9 split in halves, x0 = [0..4], x1 = [5..9]; outputs
+    # concatenated [y0..., y1...] -> element j < 5 is the FIRST word of threefry(key, (j, j + 5)), element 5 + j the second.
+    # Ten more arguments of sqrt(2) erf_inv, every printed digit reproduced.
+    blocks = [_tf(0, 0, j, j + 5) for j in range(5)]
+    draw = [_from_bits("orc_std_normal_from_bits", blk[w]) for w in (0, 1) for blk in blocks]
+    printed = [-0.3721109, 0.26423115, -0.18252768, -0.7368197, -0.44030377, -0.1521442, -0.67135346, -0.5908641,
+               0.73168886, 0.5673026]
+    assert [float(v) for v in draw] == [float(np.float32(p)) for p in printed]
+    # "Pseudorandom numbers" tutorial, classic edition: key = PRNGKey(42); three rounds of
+    #   new_key, subkey = split(key); val = normal(subkey); print(f"draw {i}: {val}"); key = new_key
+    # prints  draw 0: 1.369469404220581 / draw 1: -0.19947023689746857 / draw 2: -2.298278331756592
+    # (and, after the first split, new_key [2465931498 3679230171], subkey [255383827 267815257])
+    k, draws = (0, 42), []
+    for i in range(3):
+        a, b = _tf(*k, 0, 2), _tf(*k, 1, 3)
+        k, sub = (a[0], b[0]), (a[1], b[1])
+        if i == 0:
+            assert k == (2465931498, 3679230171) and sub == (255383827, 267815257)
+        draws.append(repr(float(_from_bits("orc_std_normal_from_bits", _tf(*sub, 0, 0)[0]))))
+    assert draws == ["1.369469404220581", "-0.19947023689746857", "-2.298278331756592"]
+    # Sharp Bits again, continuing from key [2384771982 3928867769]:  key, *subkeys = split(key, 4);
+    # normal(subkey, (1,)) for the three subkeys prints [-0.37533438] [0.98645043] [0.14553197]
+    # (classic split(key, 4): counters 0..7 in halves, outputs concatenated and reshaped (4, 2))
+    k = (2384771982, 3928867769)
+    blk = [_tf(*k, j, j + 4) for j in range(4)]
+    flat = [x[0] for x in blk] + [x[1] for x in blk]
+    subs = [(flat[2 * i], flat[2 * i + 1]) for i in range(1, 4)]
+    got = [_from_bits("orc_std_normal_from_bits", _tf(*s, 0, 0)[0]) for s in subs]
+    assert got == [np.float32(-0.37533438), np.float32(0.98645043), np.float32(0.14553197)]
 
 
 def test_jax_docs_partitionable_prng_values():

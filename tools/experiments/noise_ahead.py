@@ -85,7 +85,14 @@ obs0 = ChoiceMap.empty().set("y", ys[0])
 pN = MinimalGenerate(noise, (), ChoiceMap.empty(), (n,))
 pJ0 = MinimalGenerate(j_init, (z[0].reshape(n),), obs0, (n,))
 pJ = MinimalGenerate(j_step, (Gathered(xs[0].reshape(n), anc), z[0].reshape(n)), obs0, (n,))
-for p in (pN, pJ0, pJ):
+# PAD: bytes of dynamic LDS every noise workgroup asks for and never touches (GENMI_EXP_LDS_PAD, csrc/gmx_kernels.hip):
+# caps how many noise workgroups a CU holds (160 KB of LDS per CU), so the chain's kernels always find wave slots
+PAD = int(os.environ.get("PAD", 0))
+if PAD:
+    os.environ["GENMI_EXP_LDS_PAD"] = str(PAD)
+pN.comp.specialize()
+os.environ.pop("GENMI_EXP_LDS_PAD", None)
+for p in (pJ0, pJ):
     p.comp.specialize()
 assert pJ.comp.writes_tile_stats() and pJ0.comp.writes_tile_stats()
 keys = [split(fold_in(key, t), 3) for t in range(T)]
@@ -119,7 +126,44 @@ def launch_o(t):
                                      be.ptr(maxs[t:t + 1]), be.ptr(totals[t:t + 1]), be.ptr(anc), be.stream()), "resample")
 
 
+BATCH = int(os.environ.get("BATCH", 1))   # > 1: the noise of BATCH steps is one group of launches, one event pair per group
+
+
+def enqueue_batched():
+    # RING = 2 * BATCH buffers: group g of noise launches fills half g % 2 while the chain consumes the other half
+    assert RING == 2 * BATCH and T % BATCH == 0
+    A = torch.cuda.current_stream()
+    B = torch.cuda.Stream(priority=0)
+    B.wait_stream(A)
+    groups = T // BATCH
+    done = [None] * groups
+    ready = [None] * groups
+
+    def noise_group(g):
+        with torch.cuda.stream(B):
+            if g >= 2:
+                B.wait_event(done[g - 2])
+            for t in range(g * BATCH, (g + 1) * BATCH):
+                launch_noise(t)
+            ready[g] = torch.cuda.Event()
+            ready[g].record(B)
+
+    noise_group(0)
+    for g in range(groups):
+        if g + 1 < groups:
+            noise_group(g + 1)
+        A.wait_event(ready[g])
+        for t in range(g * BATCH, (g + 1) * BATCH):
+            launch_j(t)
+            launch_o(t)
+        done[g] = torch.cuda.Event()
+        done[g].record(A)
+    A.wait_stream(B)
+
+
 def enqueue(two_streams: bool):
+    if two_streams and BATCH > 1:
+        return enqueue_batched()
     A = torch.cuda.current_stream()
     B = torch.cuda.Stream() if two_streams else A
     done_j = [None] * T
@@ -145,7 +189,7 @@ def enqueue(two_streams: bool):
         A.wait_stream(B)
 
 
-out = {"n": n, "T": T, "ring": RING, "fused_sweep_us_per_step": 1e6 * dt_ref / T}
+out = {"n": n, "T": T, "ring": RING, "batch": BATCH, "lds_pad": PAD, "fused_sweep_us_per_step": 1e6 * dt_ref / T}
 for two in (False, True):
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())

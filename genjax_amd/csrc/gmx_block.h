@@ -7,6 +7,13 @@
 // latency (and an s_waitcnt) per step, on the critical path of every kernel that ends in a block
 // reduction.  Float SUMS keep the fixed butterfly order: their bits depend on it.
 #pragma once
+// EXPERIMENT (tools/experiments/noise_ahead.py): kernels of the dependent chain raise their wave priority, so that a
+// background kernel on a second stream (k_noise_normal, priority 0) only takes the issue slots the chain leaves.
+#if defined(GMX_CHAIN_PRIO)
+#define GMX_SETPRIO __builtin_amdgcn_s_setprio(GMX_CHAIN_PRIO);
+#else
+#define GMX_SETPRIO
+#endif
 #include "gmx_math.h"
 
 #define GMX_BLOCK 256

@@ -93,6 +93,7 @@ struct gmx_jit_ctx {
 // particle hides the first round trip); the second round trip is hidden by the rest of the RNG work.
 #define GMX_JIT_BEGIN(NREGS, FULLV, NDYN, PPV, NPRE)                                             \
   extern "C" __global__ void __launch_bounds__(GMX_BLOCK) gmx_jit_kernel(int64_t n, const gmx_run_args A) { \
+ GMX_SETPRIO                                                                                  \
     __shared__ float lds4[4];                                                                    \
     __shared__ uint64_t lds8[4];                                                                 \
     constexpr int PP = PPV;                                                                      \

@@ -1495,6 +1495,7 @@ __global__ void __launch_bounds__(RS_BLOCK)
 k_offspring_tile(uint32_t k0, uint32_t k1, uint32_t u0_host, const float* __restrict__ lw, const uint32_t* __restrict__ qin,
                  const float* __restrict__ tmax, const uint64_t* __restrict__ agg, int64_t n, int n_tiles, float scale,
                  float* __restrict__ max_out, uint64_t* __restrict__ total_out, int32_t* __restrict__ anc) {
+  GMX_SETPRIO
   __shared__ uint64_t s_below[RS_WAVES], s_all[RS_WAVES], s_scan[RS_WAVES], s_g[RS_TPB];
   __shared__ float s_max[RS_WAVES];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -2376,6 +2377,41 @@ extern "C" int gmx_mh_accept(const uint32_t* keys_d, const float* log_alpha_d, i
   if (!keys_d || !log_alpha_d || !accept_d) return gmx_fail("gmx_mh_accept: null argument%s");
   hipLaunchKernelGGL(k_mh_accept, grid_for(n), dim3(GMX_BLOCK), 0, (hipStream_t)stream, keys_d,
                      log_alpha_d, n, accept_d);
+  GMX_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// noise ahead of the chain: the standard-normal draws of `rows` SMC steps in ONE launch.
+// z[t][i] = sqrt(2) erf_inv(uniform(bits(fold_in(split(keys[t], n)[i], site))))  — what a `normal(loc, scale) @ addr`
+// site number `site` of a step program draws before `* scale + loc`, from keys that depend on nothing but the step
+// and the particle index: two thirds of a bootstrap step's vector instructions, and none of them waits for the
+// resampling chain.  grid = (ceil(n / 1024), rows): blockIdx.y is the step (no division), 4 particles per thread
+// at a stride of 256 (coalesced 4-byte stores).  `lds_pad` bytes of dynamic LDS are requested and never touched:
+// a residency cap (160 KB per CU), so that a CU always keeps wave slots for the chain's kernels.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(GMX_BLOCK)
+k_noise_normal(const uint32_t* __restrict__ keys, uint32_t site, int64_t n, float* __restrict__ z) {
+  __builtin_amdgcn_s_setprio(0);
+  const uint32_t t = blockIdx.y;
+  gmx_key k; k.k0 = keys[2 * t]; k.k1 = keys[2 * t + 1];
+  float* zt = z + (int64_t)t * n;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int64_t i = ((int64_t)blockIdx.x * 4 + p) * GMX_BLOCK + threadIdx.x;
+    const gmx_key s = gmx_fold_in(gmx_split_child(k, (uint64_t)i), site);
+    const float v = gmx_std_normal_from_bits(gmx_bits32(s, 0));
+    if (i < n) zt[i] = v;
+  }
+}
+
+extern "C" int gmx_noise_normal(const uint32_t* keys_d, int64_t rows, uint32_t site, int64_t n, float* z_d,
+                                uint32_t lds_pad, gmx_stream stream) {
+  if (!keys_d || !z_d) return gmx_fail("gmx_noise_normal: null argument%s");
+  if (rows <= 0 || rows > 65535 || n <= 0) return gmx_fail("gmx_noise_normal: rows must be in [1, 65535], n positive%s");
+  if (lds_pad > 64 * 1024) return gmx_fail("gmx_noise_normal: lds_pad above 64 KB%s");
+  dim3 grid((unsigned)((n + 4 * GMX_BLOCK - 1) / (4 * GMX_BLOCK)), (unsigned)rows);
+  hipLaunchKernelGGL(k_noise_normal, grid, dim3(GMX_BLOCK), lds_pad, (hipStream_t)stream, keys_d, site, n, z_d);
   GMX_HIP(hipGetLastError());
   return 0;
 }

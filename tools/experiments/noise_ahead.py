@@ -17,6 +17,12 @@ from ctypes import c_uint32
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
+# PRIO=p: the chain's kernels run at wave priority p (s_setprio; the dedicated noise kernel stays at 0).  Needs the
+# variant library built with -DGMX_CHAIN_PRIO=p (genjax_amd/lib/libgenmi_hip_prio<p>.so); hiprtc gets the same define.
+PRIO = int(os.environ.get("PRIO", 0))
+if PRIO:
+    os.environ["GENMI_LIB"] = os.path.join(ROOT, "genjax_amd", "lib", f"libgenmi_hip_prio{PRIO}.so")
+    os.environ["GENMI_JIT_DEFS"] = f"-DGMX_CHAIN_PRIO={PRIO}"
 import numpy as np
 import torch
 
@@ -106,13 +112,20 @@ def launch_noise(t):
     pN.comp.run(pN.leaves((), ChoiceMap.empty()), (n,), lazy_split(keys[t][0], n), red_out=npart, out_buffers=bufs)
 
 
+zfull = None
+
+
+def zsrc(t):
+    return zfull[t] if zfull is not None else z[t % RING]
+
+
 def launch_j(t):
     obs = ChoiceMap.empty().set("y", ys[t])
     if t == 0:
-        prog, leaves = pJ0, pJ0.leaves((z[0].reshape(n),), obs)
+        prog, leaves = pJ0, pJ0.leaves((zsrc(0).reshape(n),), obs)
     else:
         prog = pJ
-        leaves = prog.leaves((Gathered(xs[(t - 1) % 2].reshape(n), anc), z[t % RING].reshape(n)), obs)
+        leaves = prog.leaves((Gathered(xs[(t - 1) % 2].reshape(n), anc), zsrc(t).reshape(n)), obs)
     bufs = [None] * len(prog.comp.outputs)
     bufs[prog.ro[1]] = xs[t % 2]
     bufs[prog.wo[1]] = lw.reshape(1, n)
@@ -127,6 +140,37 @@ def launch_o(t):
 
 
 BATCH = int(os.environ.get("BATCH", 1))   # > 1: the noise of BATCH steps is one group of launches, one event pair per group
+GROUP = int(os.environ.get("GROUP", 0))   # 1: ... and ONE launch per group (BATCH * n rows, keys split(step key, n)[i] by row)
+ROWS = int(os.environ.get("ROWS", BATCH))   # GROUP=2: steps per noise launch (divides BATCH)
+if GROUP:
+    from genjax_amd.random import Key
+    assert BATCH % ROWS == 0
+    assert RING == 2 * BATCH and T % BATCH == 0
+    zg = [torch.zeros((1, BATCH * n), dtype=torch.float32, device=dev) for _ in range(2)]
+    z = [zg[(r // BATCH) % 2][:, (r % BATCH) * n:(r % BATCH + 1) * n] for r in range(RING)]
+    wdummy_g = torch.zeros((1, BATCH * n), dtype=torch.float32, device=dev)
+    npart_g = torch.zeros((2, (BATCH * n + 255) // 256), dtype=torch.float32, device=dev)
+    gkeys, gkeys_dev = [], []
+    for g in range(T // BATCH):
+        rows = np.stack([keys[t][0].host() for t in range(g * BATCH, (g + 1) * BATCH)]).astype(np.uint32)
+        gkeys_dev.append(torch.from_numpy(rows.view(np.int32)).to(dev))
+        gkeys.append(Key(lazy=("rowsplit", Key(dev=torch.from_numpy(rows.view(np.int32)).to(dev)), n), split_last=True))
+
+
+def launch_noise_group(g):
+    if GROUP == 2:      # the dedicated kernel (csrc/gmx_kernels.hip: k_noise_normal), grid (tiles, ROWS) per launch
+        from ctypes import c_int64, c_void_p
+        for r0 in range(0, BATCH, ROWS):
+            be.check(be.c.gmx_noise_normal(c_void_p(gkeys_dev[g].data_ptr() + 8 * r0), c_int64(ROWS), c_uint32(1),
+                                           c_int64(n), c_void_p(zg[g % 2].data_ptr() + 4 * r0 * n), c_uint32(PAD),
+                                           be.stream()), "noise")
+        return
+    bufs = [None] * len(pN.comp.outputs)
+    bufs[pN.ro[1]] = zg[g % 2]
+    if pN.wo[0] == "out":
+        bufs[pN.wo[1]] = wdummy_g
+    pN.comp.run(pN.leaves((), ChoiceMap.empty()), (BATCH * n,), gkeys[g], red_out=npart_g, out_buffers=bufs)
+
 
 
 def enqueue_batched():
@@ -143,8 +187,11 @@ def enqueue_batched():
         with torch.cuda.stream(B):
             if g >= 2:
                 B.wait_event(done[g - 2])
-            for t in range(g * BATCH, (g + 1) * BATCH):
-                launch_noise(t)
+            if GROUP:
+                launch_noise_group(g)
+            else:
+                for t in range(g * BATCH, (g + 1) * BATCH):
+                    launch_noise(t)
             ready[g] = torch.cuda.Event()
             ready[g].record(B)
 
@@ -189,7 +236,7 @@ def enqueue(two_streams: bool):
         A.wait_stream(B)
 
 
-out = {"n": n, "T": T, "ring": RING, "batch": BATCH, "lds_pad": PAD, "fused_sweep_us_per_step": 1e6 * dt_ref / T}
+out = {"n": n, "T": T, "ring": RING, "batch": BATCH, "group_launch": GROUP, "rows_per_launch": ROWS, "chain_prio": PRIO, "lds_pad": PAD, "fused_sweep_us_per_step": 1e6 * dt_ref / T}
 for two in (False, True):
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
@@ -209,4 +256,35 @@ for two in (False, True):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 20
     out["split_two_streams" if two else "split_one_stream"] = {"us_per_step": 1e6 * dt / T, "bit_identical_to_fused": same}
+if int(os.environ.get("CHAIN_ONLY", 0)):
+    # the dependent chain alone (J_t, O_t on one stream), every step's noise already in memory: what the two-stream
+    # form would cost if the noise were free
+    zfull = [torch.zeros((1, n), dtype=torch.float32, device=dev) for _ in range(T)]
+    zsave, z = z, zfull
+    RING_save, RING = RING, T
+    for t in range(T):
+        launch_noise(t)
+    torch.cuda.synchronize()
+
+    def chain():
+        for t in range(T):
+            launch_j(t)
+            launch_o(t)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        chain()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    same = bool(torch.equal(xs[(T - 1) % 2].reshape(n), x_ref) and torch.equal(anc, anc_ref))
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        chain()
+    g.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        g.replay()
+    torch.cuda.synchronize()
+    out["chain_only"] = {"us_per_step": 1e6 * (time.perf_counter() - t0) / 20 / T, "bit_identical_to_fused": same}
 print(json.dumps(out))

@@ -7,13 +7,13 @@
 // latency (and an s_waitcnt) per step, on the critical path of every kernel that ends in a block
 // reduction.  Float SUMS keep the fixed butterfly order: their bits depend on it.
 #pragma once
-// EXPERIMENT (tools/experiments/noise_ahead.py): kernels of the dependent chain raise their wave priority, so that a
-// background kernel on a second stream (k_noise_normal, priority 0) only takes the issue slots the chain leaves.
-#if defined(GMX_CHAIN_PRIO)
+// Wave priority.  The kernels of a dependent chain (site programs, resampler) raise theirs, so that a BACKGROUND
+// kernel running beside them on a second stream (a noise program of BootstrapSweep's noise-ahead form:
+// gmx_program_set_background, priority 0) only takes the issue slots the chain leaves.  With nothing beside the
+// chain every wave has the same priority and nothing changes.  Measured on MI355X (config 2, two streams):
+// 16.5 -> 15.9 us/step (profiles/r02f_experiment_noise_ahead_prio_rows.txt).
+#define GMX_CHAIN_PRIO 2
 #define GMX_SETPRIO __builtin_amdgcn_s_setprio(GMX_CHAIN_PRIO);
-#else
-#define GMX_SETPRIO
-#endif
 #include "gmx_math.h"
 
 #define GMX_BLOCK 256

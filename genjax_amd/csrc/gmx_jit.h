@@ -23,6 +23,13 @@
 extern __shared__ __attribute__((aligned(16))) char gmx_dyn_lds[];   // gmx_rs_window_lds(n) bytes when A.rs.lw_d is set
 #endif
 
+// a background program (gmx_program_set_background) keeps the default wave priority 0
+#if defined(GMX_JIT_BACKGROUND)
+#define GMX_JIT_PRIO
+#else
+#define GMX_JIT_PRIO GMX_SETPRIO
+#endif
+
 template <int NDYN, int PPV>
 struct gmx_jit_ctx {
   const uint32_t* consts;   // constexpr constants (pool entries NDYN..)
@@ -93,7 +100,7 @@ struct gmx_jit_ctx {
 // particle hides the first round trip); the second round trip is hidden by the rest of the RNG work.
 #define GMX_JIT_BEGIN(NREGS, FULLV, NDYN, PPV, NPRE)                                             \
   extern "C" __global__ void __launch_bounds__(GMX_BLOCK) gmx_jit_kernel(int64_t n, const gmx_run_args A) { \
- GMX_SETPRIO                                                                                  \
+ GMX_JIT_PRIO                                                                                 \
     __shared__ float lds4[4];                                                                    \
     __shared__ uint64_t lds8[4];                                                                 \
     constexpr int PP = PPV;                                                                      \

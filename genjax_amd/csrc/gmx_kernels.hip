@@ -134,7 +134,8 @@ struct gmx_program {
   hipFunction_t jit_fn = nullptr;
   int jit_pp = 1;                    // particles per thread of the specialised kernel
   bool jit_gathers_pre = false;      // every gathered load of the specialised kernel uses the prologue's ancestors
-  unsigned lds_pad = 0;              // EXPERIMENT (GENMI_EXP_LDS_PAD at specialisation): unused dynamic LDS per workgroup = a residency cap
+  bool background = false;           // gmx_program_set_background: wave priority 0 ...
+  unsigned lds_pad = 0;              // ... and this much unused dynamic LDS per workgroup (a residency cap)
 };
 
 static int parse_program(const uint32_t* blob, size_t n_words, gmx_program& P) {
@@ -279,6 +280,7 @@ static bool jit_with_rs() {
 
 static std::string jit_source(const gmx_program* p, bool* gathers_prefetched = nullptr) {
   std::string s = jit_with_rs() ? "#define GMX_JIT_RS 1\n" : "";
+  if (p->background) s += "#define GMX_JIT_BACKGROUND 1\n";
   s += "#include \"gmx_jit.h\"\n";
   char buf[128];
   s += "__device__ static constexpr uint32_t GMX_JIT_CONST[] = {";
@@ -361,6 +363,22 @@ extern "C" int gmx_program_writes_tile_stats(const gmx_program* p) {
 
 extern "C" int gmx_program_fuses_resample(const gmx_program* p) {
   return p && p->jit_fn && p->jit_pp == 4 && p->uses_gather && p->jit_gathers_pre ? 1 : 0;
+}
+
+// A BACKGROUND program: work that depends on nothing a dependent chain of launches produces (the standard-normal
+// draws of the NEXT SMC steps: keys only), issued on a second stream beside that chain.  Its specialised kernel
+//   * keeps wave priority 0 while the chain's kernels run at GMX_CHAIN_PRIO (gmx_block.h), and
+//   * asks for `lds_pad` bytes of dynamic LDS it never touches: a cap on how many of its workgroups a CU holds
+//     (160 KB of LDS per CU: 56 000 bytes -> two), so that the chain's kernels always find free wave slots —
+//     without it a 29-VGPR noise kernel fills all 8 workgroup slots of every CU and the chain waits behind it.
+// Set before gmx_program_specialize; the interpreter ignores it.
+extern "C" int gmx_program_set_background(gmx_program* p, uint32_t lds_pad) {
+  if (!p) return gmx_fail("gmx_program_set_background: null program%s");
+  if (p->jit_fn) return gmx_fail("gmx_program_set_background: the program is already specialised%s");
+  if (lds_pad > 160u * 1024u) return gmx_fail("gmx_program_set_background: lds_pad above the 160 KB of a CU%s");
+  p->background = true;
+  p->lds_pad = lds_pad;
+  return 0;
 }
 
 // ---- on-disk cache of specialised code objects -----------------------------
@@ -475,19 +493,9 @@ static int jit_load(gmx_program* p, const std::vector<char>& code) {
   p->jit_module = mod;
   p->jit_fn = fn;
   p->jit_pp = jit_pp_for(p);
-  // EXPERIMENT: GENMI_EXP_LDS_PAD=<bytes> (read when a program is specialised) makes every launch of this kernel ask
-  // for that much dynamic LDS it never touches, i.e. caps how many of its workgroups a CU holds (160 KB per CU) —
-  // a background kernel on a second stream then leaves wave slots to the dependent chain (tools/experiments).
-  p->lds_pad = 0;
-  if (const char* e = getenv("GENMI_EXP_LDS_PAD")) {
-    long v = atol(e);
-    if (v > 0 && v <= 160 * 1024) {
-      p->lds_pad = (unsigned)v;
-      if (v > 48 * 1024) {
-        hipError_t ea = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)v);
-        if (ea != hipSuccess) { (void)hipGetLastError(); p->lds_pad = 48 * 1024; }
-      }
-    }
+  if (p->lds_pad > 48 * 1024) {
+    hipError_t ea = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_pad);
+    if (ea != hipSuccess) { (void)hipGetLastError(); p->lds_pad = 48 * 1024; }
   }
   return 0;
 }
@@ -2377,41 +2385,6 @@ extern "C" int gmx_mh_accept(const uint32_t* keys_d, const float* log_alpha_d, i
   if (!keys_d || !log_alpha_d || !accept_d) return gmx_fail("gmx_mh_accept: null argument%s");
   hipLaunchKernelGGL(k_mh_accept, grid_for(n), dim3(GMX_BLOCK), 0, (hipStream_t)stream, keys_d,
                      log_alpha_d, n, accept_d);
-  GMX_HIP(hipGetLastError());
-  return 0;
-}
-
-// ---------------------------------------------------------------------------
-// noise ahead of the chain: the standard-normal draws of `rows` SMC steps in ONE launch.
-// z[t][i] = sqrt(2) erf_inv(uniform(bits(fold_in(split(keys[t], n)[i], site))))  — what a `normal(loc, scale) @ addr`
-// site number `site` of a step program draws before `* scale + loc`, from keys that depend on nothing but the step
-// and the particle index: two thirds of a bootstrap step's vector instructions, and none of them waits for the
-// resampling chain.  grid = (ceil(n / 1024), rows): blockIdx.y is the step (no division), 4 particles per thread
-// at a stride of 256 (coalesced 4-byte stores).  `lds_pad` bytes of dynamic LDS are requested and never touched:
-// a residency cap (160 KB per CU), so that a CU always keeps wave slots for the chain's kernels.
-// ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(GMX_BLOCK)
-k_noise_normal(const uint32_t* __restrict__ keys, uint32_t site, int64_t n, float* __restrict__ z) {
-  __builtin_amdgcn_s_setprio(0);
-  const uint32_t t = blockIdx.y;
-  gmx_key k; k.k0 = keys[2 * t]; k.k1 = keys[2 * t + 1];
-  float* zt = z + (int64_t)t * n;
-#pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    const int64_t i = ((int64_t)blockIdx.x * 4 + p) * GMX_BLOCK + threadIdx.x;
-    const gmx_key s = gmx_fold_in(gmx_split_child(k, (uint64_t)i), site);
-    const float v = gmx_std_normal_from_bits(gmx_bits32(s, 0));
-    if (i < n) zt[i] = v;
-  }
-}
-
-extern "C" int gmx_noise_normal(const uint32_t* keys_d, int64_t rows, uint32_t site, int64_t n, float* z_d,
-                                uint32_t lds_pad, gmx_stream stream) {
-  if (!keys_d || !z_d) return gmx_fail("gmx_noise_normal: null argument%s");
-  if (rows <= 0 || rows > 65535 || n <= 0) return gmx_fail("gmx_noise_normal: rows must be in [1, 65535], n positive%s");
-  if (lds_pad > 64 * 1024) return gmx_fail("gmx_noise_normal: lds_pad above 64 KB%s");
-  dim3 grid((unsigned)((n + 4 * GMX_BLOCK - 1) / (4 * GMX_BLOCK)), (unsigned)rows);
-  hipLaunchKernelGGL(k_noise_normal, grid, dim3(GMX_BLOCK), lds_pad, (hipStream_t)stream, keys_d, site, n, z_d);
   GMX_HIP(hipGetLastError());
   return 0;
 }

@@ -83,7 +83,16 @@ class Distribution(GenerativeFunction):
         g = current_graph()
         elems, shape = _bcast(args)
         out = []
+        hoist = g.__dict__.get("noise_hoist") if self.sample_op == "S_NORMAL" else None
         for e, a in enumerate(elems):
+            if hoist is not None:
+                # noise-ahead (engine.NoiseHoist): the standard-normal draw comes from memory — a background program
+                # drew it from the same key — and only `* scale + loc` stays here: csrc/gmx_dist.h gmx_normal_sample's
+                # own two operations, in its order
+                z = hoist.request(key.node, e)
+                if z is not None:
+                    out.append(z * T.as_float(a[1]) + T.as_float(a[0]))
+                    continue
             ops = tuple(T.as_float(x).node for x in a)
             out.append(Expr(g.add(self.sample_op, (key.node,) + ops, imm=e, dtype=self.value_dtype)))
         if shape == ():

@@ -247,6 +247,34 @@ class Sym:
         self.value, self.origin = value, origin
 
 
+class NoiseHoist:
+    """Noise-ahead plan of one traced program: the standard-normal draws whose KEY depends on nothing but the launch
+    key and constants (`fold_in` chains from the particle's key: every `normal(...) @ addr` site of a static model
+    outside a counted loop).  Such a draw — two Threefry blocks and an `erf_inv`, most of a bootstrap step's vector
+    instructions — needs nothing the resampling chain produces, so a BACKGROUND program (static.NoiseProgram) can
+    draw it steps ahead on a second stream; the traced program reads it as one more per-particle input leaf.
+    `draws[k] = (chain of fold_in counters from the particle key, element counter)` is input leaf first_leaf + k."""
+
+    def __init__(self, tr: "Tracing", first_leaf: int):
+        self.tr, self.first_leaf, self.draws = tr, int(first_leaf), []
+
+    @staticmethod
+    def chain(node):
+        c = []
+        while node.op == "KDERIVE":
+            c.append(int(node.imm))
+            node = node.args[0]
+        return tuple(reversed(c)) if node.op == "LDKEY" else None
+
+    def request(self, key_node, e: int):
+        ch = self.chain(key_node)
+        if ch is None:
+            return None
+        j = self.first_leaf + len(self.draws)
+        self.draws.append((ch, int(e)))
+        return self.tr.sym_leaf(("part", "f32", ()), j).value
+
+
 class Tracing:
     def __init__(self, batch_ndim: int):
         self.graph = Graph()
@@ -536,6 +564,11 @@ class Compiled:
             raise _lib.GenmiError("this program keeps more than 31 values live per particle and therefore needs the "
                                   f"hiprtc-specialised kernel, which could not be built: {msg.decode() if msg else ''}")
         return ok
+
+    def set_background(self, lds_pad: int):
+        """Before specialize(): this program is background work on a second stream (include/genmi.h:
+        gmx_program_set_background) — priority 0, `lds_pad` bytes of unused LDS per workgroup as a residency cap."""
+        self._be.check(self._be.c.gmx_program_set_background(self.handle, int(lds_pad)), "gmx_program_set_background")
 
     def writes_tile_stats(self) -> bool:
         """True when a launch can also leave the CDF tile statistics (gmx_run_args.tile_agg_d): a specialised

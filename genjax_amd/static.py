@@ -861,12 +861,19 @@ class MinimalGenerate:
     program BootstrapSweep launches once per SMC step.  Per particle-step this
     moves 4 B (ancestor) + 4*D B (gathered state) in and 4*D + 4 B out."""
 
-    def __init__(self, gen_fn, args, constraint: ChoiceMap, batch: tuple):
+    def __init__(self, gen_fn, args, constraint: ChoiceMap, batch: tuple, hoist_noise: bool = False):
+        """hoist_noise: the program takes the standard-normal draws of its `normal` sites from memory (one extra
+        f32 leaf per draw, `self.noise`: engine.NoiseHoist.draws; pass them to leaves(..., noise=[...])) — drawn by
+        NoiseProgram(self.noise, batch) from the same keys, so every value is the one the plain program computes."""
         flat = Flat()
         self.atree = flat.add(tuple(args))
         self.ctree = flat.add(constraint)
         self.specs = tuple(leaf_spec(v, batch) for v in flat.leaves)
         tr = Tracing(len(batch))
+        hoist = None
+        if hoist_noise:
+            from .engine import NoiseHoist
+            hoist = tr.graph.noise_hoist = NoiseHoist(tr, len(self.specs))
         ctx = _Ctx(tr)
         ctx.store_sites = False
         with T.tracing(tr.graph):
@@ -880,16 +887,51 @@ class MinimalGenerate:
                 w = Expr(tr.graph.const_f32(0.0)) + 0.0
             self.wo = tr.emit_output(w)
             tr.graph.add("REDMAX", (w.node,), dtype="none")
+        self.noise = tuple(hoist.draws) if hoist is not None else ()
+        tr.graph.__dict__.pop("noise_hoist", None)
         self.comp = Compiled(tr)
         self.gen_fn = gen_fn
 
-    def leaves(self, args, constraint):
+    def leaves(self, args, constraint, noise=()):
         flat = Flat()
         a = flat.add(tuple(args))
         c = flat.add(constraint)
         if a != self.atree or c != self.ctree:
             raise ValueError("MinimalGenerate: call structure differs from the compiled one")
-        return flat.leaves
+        if len(noise) != len(self.noise):
+            raise ValueError(f"MinimalGenerate: the program reads {len(self.noise)} noise leaves, got {len(noise)}")
+        return flat.leaves + list(noise)
+
+
+class NoiseProgram:
+    """The background half of a noise-ahead step (engine.NoiseHoist): output k is the standard-normal draw
+    `jax.random.normal(fold_in(...fold_in(key_i, c_0)..., c_m))` element e for draws[k] = ((c_0..c_m), e), key_i the
+    particle's launch key — exactly what the `normal` site with that key draws before `* scale + loc`
+    (S_NORMAL with loc 0, scale 1: z * 1 + 0 is z, bit for bit).  Keys only: no inputs, nothing a chain produces."""
+
+    def __init__(self, draws, batch: tuple):
+        if not draws:
+            raise ValueError("NoiseProgram: no draws")
+        self.draws = tuple(draws)
+        tr = Tracing(len(batch))
+        g = tr.graph
+        with T.tracing(g):
+            root = g.add("LDKEY", dtype="key")
+            self.outs = []
+            for chain, e in self.draws:
+                k = root
+                for c in chain:
+                    k = g.add("KDERIVE", (k,), imm=c, dtype="key")
+                z = g.add("S_NORMAL", (k, g.const_f32(0.0), g.const_f32(1.0)), imm=e, dtype="f32")
+                self.outs.append(tr.emit_output(Expr(z)))
+        self.comp = Compiled(tr)
+
+    def run(self, batch: tuple, key, out_tensors):
+        """out_tensors[k]: a [1, n] float tensor for draw k"""
+        bufs = [None] * len(self.comp.outputs)
+        for o, t in zip(self.outs, out_tensors):
+            bufs[o[1]] = t
+        self.comp.run([], batch, key, out_buffers=bufs)
 
 
 def _rec_to_prev(rec):

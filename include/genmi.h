@@ -179,6 +179,14 @@ int gmx_program_writes_tile_stats(const gmx_program* p);
  * slower than site program + gmx_resample_tiles), 4 particles per thread, and every gathered load goes through
  * ancestors_d at the top of the kernel. */
 int gmx_program_fuses_resample(const gmx_program* p);
+/* Mark a program as BACKGROUND work before it is specialised: work that depends on nothing a dependent chain of
+ * launches produces — e.g. the standard-normal draws of the next SMC steps (keys and particle indices only), which
+ * BootstrapSweep's noise-ahead form issues on a second stream beside the chain [site program -> resampler].  The
+ * specialised kernel keeps wave priority 0 (the chain's kernels raise theirs) and every launch asks for `lds_pad`
+ * bytes of dynamic LDS it never touches — a cap on the workgroups of this kernel a CU holds (160 KB of LDS per CU),
+ * so that the chain's kernels always find wave slots.  No effect on results, nor on the interpreter.
+ * (No reference counterpart: XLA schedules its fused loops itself.) */
+int gmx_program_set_background(gmx_program* p, uint32_t lds_pad);
 int gmx_program_run(const gmx_program* p, int64_t n, const gmx_run_args* args_h,
                     gmx_stream stream);
 

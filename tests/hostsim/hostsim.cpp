@@ -93,6 +93,11 @@ extern "C" int gmx_program_create(const uint32_t* blob, size_t n_words, gmx_prog
 extern "C" int gmx_program_destroy(gmx_program* p) { delete p; return 0; }
 extern "C" int gmx_program_specialize(gmx_program*) { return fail("hostsim: no specialisation"); }
 extern "C" int gmx_program_is_specialized(const gmx_program*) { return 0; }
+extern "C" int gmx_program_set_background(gmx_program* p, uint32_t lds_pad) {     // scheduling only: nothing to mirror
+  if (!p) return fail("gmx_program_set_background: null program");
+  if (lds_pad > 160u * 1024u) return fail("gmx_program_set_background: lds_pad above the 160 KB of a CU");
+  return 0;
+}
 // Like the specialised 4-particles-per-thread kernel, a program with exactly one OP_REDMAX runs in workgroups of
 // 1024 particles (one partial row each) and can leave the CDF tile statistics; GENMI_HOSTSIM_TILE_STATS=0 gives the
 // interpreter's shape instead (256-particle groups, no statistics).

@@ -40,6 +40,8 @@ T_STEPS = 100
 VM_VALU_PER_WAVE = 325.65           # VALU instructions per 64 particles: SQ_INSTS_VALU / waves / 4 particles per
                                     # thread (1302.6 per wave, profiles/r02c_pmc_summary.txt; 1438.6 before the
                                     # one-instruction DPP scans / integer fixed-point weights, 1496.7 at the end of round 1)
+# the noise-ahead (two-stream) sweep, SQ_INSTS_VALU per wave of 256 particles (profiles/r02f_pmc_summary.txt):
+NA_VALU_PER_WAVE = {"gmx_jit_background_kernel": 1120.9, "gmx_jit_kernel": 210.7, "k_offspring_tile": 540.8}
 VALU_PEAK_LANE_OPS = 256 * 4 * 16 * 2.4e9   # integer / unpacked-f32 vector instructions: 16 lanes per clock per SIMD (a
                                             # wave64 instruction holds its SIMD for 4 cycles; only packed f32 math doubles
                                             # that).  tools/calib.hip on MI355X (profiles/r02_calib.txt): one Threefry-like
@@ -253,7 +255,8 @@ def main():
                                    f"(a multiple of {world} x 1024: shards start on a tile of the integer CDF)")),
                    "particles_per_gpu": n, "particles_total": total_particles, "T": T,
                    "resampler": "systematic", "graph": not args.no_graph and single,
-                   "path": "BootstrapSweep (hipGraph)" if single else "ShardedBootstrapSweep (RCCL)",
+                   "path": ("BootstrapSweep (hipGraph" + (", noise ahead on a second stream)" if getattr(sw, "noise_ahead", False)
+                                                         else ")")) if single else "ShardedBootstrapSweep (RCCL)",
                    "key": seed},
         "log_ml": log_ml, "log_ml_kalman": kal, "log_ml_abs_err": abs(log_ml - kal),
         "log_ml_rel_err": abs(log_ml - kal) / abs(kal),
@@ -303,26 +306,10 @@ def main():
         kt = sw.kernel_timers()
         us = {name: time_launches(fn) for name, fn in kt.items()}
         vm_us = us["k_vm"]
-        if single:
-            # the site program's duration IN the sweep: (sweep) - (sweep without its T launches), both
-            # as hipGraphs timed with HIP events; this is the figure rocprofv3's per-kernel average
-            # reproduces (the isolated back-to-back figure above runs ~10 % shorter: warm caches)
-            full = time_launches(lambda: sw.enqueue(), reps=1) * 1.0
-            rest = time_launches(lambda: sw.enqueue(skip_vm=True), reps=1) * 1.0
-            # one dependent-launch boundary: a chain of trivial launches (1-element max reduce)
-            one = torch.zeros((2,), dtype=torch.float32, device="cuda")
-            gap = time_launches(lambda: be.check(be.c.gmx_reduce_max(be.ptr(one), 1, be.ptr(one[1:]), be.stream()),
-                                                 "gmx_reduce_max"))
-            us["sweep"] = full
-            us["sweep_without_k_vm"] = rest
-            # What rocprofv3 reports as this kernel's duration: in its kernel trace of a graph replay consecutive
-            # kernels abut (median end -> next start = 0 ns, profiles/r01_o_kernel_stats.csv's trace), i.e. a
-            # kernel's span includes its dependent-launch ramp.  So the roofline uses the marginal cost as is.
-            us["k_vm_in_sweep"] = (full - rest) / T
-            us["launch_boundary"] = gap                           # a chain of trivial launches, for reference
-            us["k_vm_in_sweep_minus_launch_boundary"] = (full - rest) / T - gap
-            vm_us = us["k_vm_in_sweep"]
-        achieved = VM_BYTES_PER_PARTICLE * n / (vm_us * 1e-6) / 1e9
+        one = torch.zeros((2,), dtype=torch.float32, device="cuda")
+        gap = time_launches(lambda: be.check(be.c.gmx_reduce_max(be.ptr(one), 1, be.ptr(one[1:]), be.stream()),
+                                             "gmx_reduce_max"))
+        us["launch_boundary"] = gap                               # a chain of trivial launches, for reference
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
@@ -330,33 +317,99 @@ def main():
                 traffic = json.load(open(tpath)).get("k_vm_hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                           # `bound` names the roofline `achieved` / `peak` are priced against (the schema has "hbm" |
-                           # "mfma").  What actually limits this kernel is vector-instruction ISSUE: see `valu` below.
-                           "limiter": "VALU issue: integer Threefry-2x32 (3 blocks per draw) at 16 lanes/clk/SIMD; "
-                                      "HBM traffic equals the algorithmic bytes (no re-reads)",
-                           "traffic_source": "profiles/traffic.json (rocprofv3 TCC pass of an earlier run of this "
-                                             "workload, calibrated against copy kernels; NOT measured in this run)",
-                           "kernel": "gmx_jit_kernel (site program specialised from k_vm)" if sw.p_step.comp._be.c.gmx_program_is_specialized(sw.p_step.comp.handle) else "k_vm<gmx_regs_vgpr<16>, false>",
-                           "algorithmic_bytes_per_launch": VM_BYTES_PER_PARTICLE * n,
-                           # the kernel is VALU-issue bound, not HBM bound: 3 Threefry-2x32 blocks per draw
-                           # (split child, fold_in, bits).  SQ_INSTS_VALU per wave from profiles/*_pmc_summary.txt.
-                           "valu": {"source": "insts_per_64_particles: SQ_INSTS_VALU of profiles/r02c_pmc_summary.txt "
-                                              "(a constant in bench.py, not measured in this run); peak_int: "
-                                              "tools/calib.hip on this part (profiles/r02_calib.txt)",
-                                    "insts_per_64_particles": VM_VALU_PER_WAVE,
-                                    "lane_ops_per_s": VM_VALU_PER_WAVE * n / (vm_us * 1e-6),
-                                    "peak_lane_ops_per_s": VALU_PEAK_LANE_OPS,
-                                    "frac": VM_VALU_PER_WAVE * n / (vm_us * 1e-6) / VALU_PEAK_LANE_OPS,
-                                    "calibrated_ceiling_lane_ops_per_s": VALU_CALIBRATED_LANE_OPS,
-                                    "frac_of_calibrated_ceiling": VM_VALU_PER_WAVE * n / (vm_us * 1e-6) / VALU_CALIBRATED_LANE_OPS,
-                                    "note": "peak = 256 CU x 4 SIMD x 16 lanes x 2.4 GHz: integer (Threefry) and unpacked f32 "
-                                            "instructions issue at 16 lanes/clk/SIMD on gfx950; the calibrated ceiling is what "
-                                            "dependent add/rotate/xor chains sustain on this part (tools/calib.hip)"},
-                           "kernel_us": us,
-                           "sweep_frac_of_hbm_roofline":
-                               SWEEP_BYTES_PER_PARTICLE_STEP * value / world / 1e9 / HBM_PEAK_GBS}
+        specialised = bool(sw.p_step.comp._be.c.gmx_program_is_specialized(sw.p_step.comp.handle))
+        sweep_hbm_frac = SWEEP_BYTES_PER_PARTICLE_STEP * value / world / 1e9 / HBM_PEAK_GBS
+        if single and getattr(sw, "noise_ahead", False):
+            # ---- the two-stream (noise-ahead) sweep: three kernels per step, two of them concurrent ----
+            # Durations: each kernel alone, back to back on one stream (HIP events); the whole sweep; the chain alone
+            # (noise launches left out: the site programs then read stale noise — same work, same traffic).
+            # Kernels overlap inside the sweep, so "x in the sweep" is no longer a difference of two sweeps: the
+            # in-sweep per-kernel averages are rocprofv3's (profiles/*_kernel_stats.csv of this same command).
+            us["sweep"] = time_launches(lambda: sw.enqueue(), reps=1)
+            us["chain_only_sweep"] = time_launches(lambda: sw._enqueue_noise_ahead(skip_noise=True), reps=1)
+            waves = (n + 1023) // 1024 * 4
+            lane_ops = {k: v * 64 * waves for k, v in NA_VALU_PER_WAVE.items()}          # per launch
+            step_us = us["sweep"] / T
+            noise_rate = lane_ops["gmx_jit_background_kernel"] / (us["k_noise"] * 1e-6)
+            sweep_rate = sum(lane_ops.values()) / (step_us * 1e-6)
+            achieved = VM_BYTES_PER_PARTICLE * n / (vm_us * 1e-6) / 1e9
+            out["roofline"] = {
+                # The dominant kernel by GPU time is the noise program (gmx_jit_background_kernel, ~40 %): keys in,
+                # 4 bytes per particle out, ZERO algorithmic bytes ("RNG contributes 0 B") — it is pure
+                # integer / f32 vector work, so it is priced against the vector-issue peak, not against HBM (the
+                # schema's "hbm" | "mfma" has no name for that; "valu" says what it is).
+                "bound": "valu", "kernel": "gmx_jit_background_kernel (noise program: 3 Threefry-2x32 blocks + erf_inv "
+                                           "per draw; BootstrapSweep noise-ahead form)",
+                "achieved": noise_rate / 1e12, "peak": VALU_PEAK_LANE_OPS / 1e12, "unit": "T lane-op/s",
+                "frac": noise_rate / VALU_PEAK_LANE_OPS, "traffic": traffic,
+                "limiter": "vector-instruction issue (16 lanes/clk/SIMD for integer and unpacked f32): the whole sweep "
+                           "keeps the vector ALUs busy for sweep.valu_frac of the time",
+                "valu_source": "instructions per wave: SQ_INSTS_VALU of profiles/r02f_pmc_summary.txt (constants in "
+                               "bench.py, not measured in this run); durations: HIP events in this run",
+                "traffic_source": "profiles/traffic.json (site program; rocprofv3 TCC pass of an earlier run, NOT "
+                                  "measured in this run)",
+                "calibrated_ceiling_T_lane_ops": VALU_CALIBRATED_LANE_OPS / 1e12,
+                # the data-path kernels against HBM (algorithmic bytes per launch / isolated launch duration)
+                "hbm": {"gmx_jit_kernel": {"algorithmic_bytes_per_launch": VM_BYTES_PER_PARTICLE * n,
+                                           "achieved_GBps": achieved, "frac": achieved / HBM_PEAK_GBS,
+                                           "note": "site program without its draws: ancestor 4 + gathered state 4 in, "
+                                                   "state 4 + log-weight 4 out (+ 4 B of noise read, not algorithmic)",
+                                           "specialised": specialised},
+                        "k_offspring_tile": {"algorithmic_bytes_per_launch": 8 * n,
+                                             "achieved_GBps": 8 * n / (us["k_offspring_tile"] * 1e-6) / 1e9
+                                             if "k_offspring_tile" in us else None,
+                                             "frac": 8 * n / (us["k_offspring_tile"] * 1e-6) / 1e9 / HBM_PEAK_GBS
+                                             if "k_offspring_tile" in us else None},
+                        "peak_GBps": HBM_PEAK_GBS},
+                "sweep": {"us_per_step": step_us, "chain_only_us_per_step": us["chain_only_sweep"] / T,
+                          "valu_insts_per_wave_per_step": sum(NA_VALU_PER_WAVE.values()),
+                          "valu_lane_ops_per_s": sweep_rate, "valu_frac": sweep_rate / VALU_PEAK_LANE_OPS,
+                          "valu_frac_of_calibrated_ceiling": sweep_rate / VALU_CALIBRATED_LANE_OPS,
+                          "hbm_frac": sweep_hbm_frac},
+                "kernel_us": us,
+                "sweep_frac_of_hbm_roofline": sweep_hbm_frac}
+        else:
+            if single:
+                # the site program's duration IN the sweep: (sweep) - (sweep without its T launches), both
+                # as hipGraphs timed with HIP events; this is the figure rocprofv3's per-kernel average
+                # reproduces (the isolated back-to-back figure above runs ~10 % shorter: warm caches)
+                full = time_launches(lambda: sw.enqueue(), reps=1) * 1.0
+                rest = time_launches(lambda: sw.enqueue(skip_vm=True), reps=1) * 1.0
+                us["sweep"] = full
+                us["sweep_without_k_vm"] = rest
+                # What rocprofv3 reports as this kernel's duration: in its kernel trace of a graph replay consecutive
+                # kernels abut (median end -> next start = 0 ns, profiles/r01_o_kernel_stats.csv's trace), i.e. a
+                # kernel's span includes its dependent-launch ramp.  So the roofline uses the marginal cost as is.
+                us["k_vm_in_sweep"] = (full - rest) / T
+                us["k_vm_in_sweep_minus_launch_boundary"] = (full - rest) / T - gap
+                vm_us = us["k_vm_in_sweep"]
+            achieved = VM_BYTES_PER_PARTICLE * n / (vm_us * 1e-6) / 1e9
+            out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                               # `bound` names the roofline `achieved` / `peak` are priced against (the schema has "hbm" |
+                               # "mfma").  What actually limits this kernel is vector-instruction ISSUE: see `valu` below.
+                               "limiter": "VALU issue: integer Threefry-2x32 (3 blocks per draw) at 16 lanes/clk/SIMD; "
+                                          "HBM traffic equals the algorithmic bytes (no re-reads)",
+                               "traffic_source": "profiles/traffic.json (rocprofv3 TCC pass of an earlier run of this "
+                                                 "workload, calibrated against copy kernels; NOT measured in this run)",
+                               "kernel": "gmx_jit_kernel (site program specialised from k_vm)" if specialised else "k_vm<gmx_regs_vgpr<16>, false>",
+                               "algorithmic_bytes_per_launch": VM_BYTES_PER_PARTICLE * n,
+                               # the kernel is VALU-issue bound, not HBM bound: 3 Threefry-2x32 blocks per draw
+                               # (split child, fold_in, bits).  SQ_INSTS_VALU per wave from profiles/*_pmc_summary.txt.
+                               "valu": {"source": "insts_per_64_particles: SQ_INSTS_VALU of profiles/r02c_pmc_summary.txt "
+                                                  "(a constant in bench.py, not measured in this run); peak_int: "
+                                                  "tools/calib.hip on this part (profiles/r02_calib.txt)",
+                                        "insts_per_64_particles": VM_VALU_PER_WAVE,
+                                        "lane_ops_per_s": VM_VALU_PER_WAVE * n / (vm_us * 1e-6),
+                                        "peak_lane_ops_per_s": VALU_PEAK_LANE_OPS,
+                                        "frac": VM_VALU_PER_WAVE * n / (vm_us * 1e-6) / VALU_PEAK_LANE_OPS,
+                                        "calibrated_ceiling_lane_ops_per_s": VALU_CALIBRATED_LANE_OPS,
+                                        "frac_of_calibrated_ceiling": VM_VALU_PER_WAVE * n / (vm_us * 1e-6) / VALU_CALIBRATED_LANE_OPS,
+                                        "note": "peak = 256 CU x 4 SIMD x 16 lanes x 2.4 GHz: integer (Threefry) and unpacked f32 "
+                                                "instructions issue at 16 lanes/clk/SIMD on gfx950; the calibrated ceiling is what "
+                                                "dependent add/rotate/xor chains sustain on this part (tools/calib.hip)"},
+                               "kernel_us": us,
+                               "sweep_frac_of_hbm_roofline": sweep_hbm_frac}
         be.c.gmx_timer_destroy(timer)
         if not args.no_cpu_baseline and world == 1:
             try:

@@ -23,11 +23,14 @@
 extern __shared__ __attribute__((aligned(16))) char gmx_dyn_lds[];   // gmx_rs_window_lds(n) bytes when A.rs.lw_d is set
 #endif
 
-// a background program (gmx_program_set_background) keeps the default wave priority 0
+// a background program (gmx_program_set_background) keeps the default wave priority 0 and has a name of its own
+// (so that kernel traces tell the noise programs from the chain's site programs)
 #if defined(GMX_JIT_BACKGROUND)
 #define GMX_JIT_PRIO
+#define GMX_JIT_NAME gmx_jit_background_kernel
 #else
 #define GMX_JIT_PRIO GMX_SETPRIO
+#define GMX_JIT_NAME gmx_jit_kernel
 #endif
 
 template <int NDYN, int PPV>
@@ -99,7 +102,7 @@ struct gmx_jit_ctx {
 // the ancestors at the top, the rows they name after the first key derivation (one Threefry block per
 // particle hides the first round trip); the second round trip is hidden by the rest of the RNG work.
 #define GMX_JIT_BEGIN(NREGS, FULLV, NDYN, PPV, NPRE)                                             \
-  extern "C" __global__ void __launch_bounds__(GMX_BLOCK) gmx_jit_kernel(int64_t n, const gmx_run_args A) { \
+  extern "C" __global__ void __launch_bounds__(GMX_BLOCK) GMX_JIT_NAME(int64_t n, const gmx_run_args A) { \
  GMX_JIT_PRIO                                                                                 \
     __shared__ float lds4[4];                                                                    \
     __shared__ uint64_t lds8[4];                                                                 \

@@ -488,7 +488,7 @@ static int jit_load(gmx_program* p, const std::vector<char>& code) {
   hipModule_t mod;
   GMX_HIP(hipModuleLoadData(&mod, code.data()));
   hipFunction_t fn;
-  hipError_t e = hipModuleGetFunction(&fn, mod, "gmx_jit_kernel");
+  hipError_t e = hipModuleGetFunction(&fn, mod, p->background ? "gmx_jit_background_kernel" : "gmx_jit_kernel");
   if (e != hipSuccess) { (void)hipModuleUnload(mod); return gmx_fail("hipModuleGetFunction: %s", hipGetErrorString(e)); }
   p->jit_module = mod;
   p->jit_fn = fn;

@@ -658,7 +658,7 @@ class BootstrapSweep:
         want_na = self.noise_ahead_req
         if want_na is None:
             want_na = (os.environ.get("GENMI_NOISE_AHEAD", "1") != "0" and be.uses_streams and self.specialize
-                       and self.rejuvenate is None)
+                       and self.rejuvenate is None and os.environ.get("GENMI_FUSE_RESAMPLE", "0") != "1")
         if want_na and self.rejuvenate is not None:
             raise NotImplementedError("BootstrapSweep(noise_ahead=True) with rejuvenate= is not supported")
         self.noise_ahead = False
@@ -742,6 +742,16 @@ class BootstrapSweep:
             self.n_step = NoiseProgram(self.p_step.noise, (n,))
             self.n_init = NoiseProgram(self.p_init.noise, (n,)) if self.p_init.noise else None
             self.noise_group = max(1, min(int(os.environ.get("GENMI_NOISE_GROUP", self.NOISE_GROUP)), T))
+            # groups of steps [start, end): the noise of group g + 1 is issued before the chain of group g.  The chain
+            # can only start once the FIRST group's noise is there, so the groups grow 1, 2, 4, ... up to noise_group
+            self.noise_groups, self.noise_slot = [], []
+            t0, size = 0, 1
+            while t0 < T:
+                t1 = min(T, t0 + min(size, self.noise_group))
+                for t in range(t0, t1):
+                    self.noise_slot.append((len(self.noise_groups) % 2, t - t0))
+                self.noise_groups.append((t0, t1))
+                t0, size = t1, size * 2
             S = max(len(self.p_step.noise), len(self.p_init.noise))
             # two groups of noise buffers: the background stream fills one while the chain reads the other
             self.zbuf = torch.zeros((2, self.noise_group, S, n), dtype=torch.float32, device=dev)
@@ -840,8 +850,8 @@ class BootstrapSweep:
 
     def _noise_views(self, t, count):
         """the [1, n] buffers of step t's draws: half (t // group) % 2 of the ring, row t % group"""
-        B = self.noise_group
-        return [self.zbuf[(t // B) % 2, t % B, k:k + 1] for k in range(count)]
+        half, row = self.noise_slot[t]
+        return [self.zbuf[half, row, k:k + 1] for k in range(count)]
 
     def _noise_leaves(self, t, prog):
         return [v.reshape(self.n) for v in self._noise_views(t, len(prog.noise))]
@@ -982,12 +992,13 @@ class BootstrapSweep:
     def _enqueue_noise_ahead(self, skip_vm=False, skip_noise=False):
         """The sweep on TWO streams: the chain [site program' -> resampler] per step on the current one, the noise
         programs on the background stream, one group of steps ahead (group g + 1's noise is issued before group g's
-        chain; it may overwrite half (g + 1) % 2 of the ring once the chain of group g - 1 has read it).  Capturable:
+        chain; it may overwrite half (g + 1) % 2 of the ring once the chain of group g - 1 has read it; the groups
+        grow 1, 2, 4, ... steps up to noise_group, so the chain starts after ONE noise launch).  Capturable:
         the background stream joins the capture through the first event wait and is joined back at the end.
         Without streams (the CPU mirror of the C-ABI) the same launches run in issue order."""
         be = _lib.get()
-        T_, B = self.T, self.noise_group
-        groups = (T_ + B - 1) // B
+        spans = self.noise_groups
+        groups = len(spans)
         two = be.uses_streams and self._noise_stream is not None
         if two:
             A, Bs = torch.cuda.current_stream(be.device), self._noise_stream
@@ -1001,12 +1012,12 @@ class BootstrapSweep:
                 with torch.cuda.stream(Bs):
                     if g >= 2:
                         Bs.wait_event(done[g - 2])
-                    for t in range(g * B, min(T_, (g + 1) * B)):
+                    for t in range(*spans[g]):
                         self._launch_noise(t)
                     ready[g] = torch.cuda.Event()
                     ready[g].record(Bs)
             else:
-                for t in range(g * B, min(T_, (g + 1) * B)):
+                for t in range(*spans[g]):
                     self._launch_noise(t)
 
         noise_group(0)
@@ -1015,7 +1026,7 @@ class BootstrapSweep:
                 noise_group(g + 1)
             if two and not skip_noise:
                 A.wait_event(ready[g])
-            for t in range(g * B, min(T_, (g + 1) * B)):
+            for t in range(*spans[g]):
                 if not skip_vm:
                     self._launch_vm(t)
                 if self.fused:
@@ -1033,6 +1044,8 @@ class BootstrapSweep:
         """Representative single launches (a mid-sweep step) for per-kernel timing in bench.py."""
         t = max(1, self.T // 2)
         out = {"k_vm": lambda: self._launch_vm(t)}
+        if self.noise_ahead:
+            out["k_noise"] = lambda: self._launch_noise(t)
         if self.fused and self.tile_stats:
             out["k_offspring_tile"] = lambda: self._launch_resample(t)
         elif self.fused:

@@ -34,13 +34,17 @@ def oracle_bootstrap_sweep(init, step, n, T, ys, run_key, kind=O.SYSTEMATIC, ste
     return dict(log_ml=log_ml, x=x, lw=lw, anc=anc, hist=hist)
 
 
-def check_lgssm_sweep(n=4096, T=5, seed=314159, capture=False, specialize=True, want_fuse=None, resample="systematic"):
+def check_lgssm_sweep(n=4096, T=5, seed=314159, capture=False, specialize=True, want_fuse=None, resample="systematic",
+                      noise_ahead=None):
     import genjax_amd as G
     from genjax_amd import workloads
     from genjax_amd.inference.smc import BootstrapSweep
     ys = workloads.lgssm_data(T)
     init, step = workloads.make_lgssm(G)
-    sw = BootstrapSweep(init, step, n, T, specialize=specialize, resample=resample).prepare(G.key(seed), torch.from_numpy(ys))
+    sw = BootstrapSweep(init, step, n, T, specialize=specialize, resample=resample,
+                        noise_ahead=noise_ahead).prepare(G.key(seed), torch.from_numpy(ys))
+    if noise_ahead is not None:
+        assert sw.noise_ahead == noise_ahead, "the sweep did not take the requested (one- / two-stream) form"
     if want_fuse is not None:
         assert sw.fuse == want_fuse, "the sweep did not take the requested (one- / two-launch) form"
     if capture:
@@ -61,7 +65,7 @@ def check_lgssm_sweep(n=4096, T=5, seed=314159, capture=False, specialize=True, 
     )
 
 
-def check_tuple_state_sweep(n=3000, T=5, seed=13, capture=False, specialize=False):
+def check_tuple_state_sweep(n=3000, T=5, seed=13, capture=False, specialize=False, noise_ahead=None):
     """BootstrapSweep over a step model with THREE latent sites whose state is a tuple of two of them
     (the sweep is not limited to `trace = {state, obs}`)."""
     import genjax_amd as G
@@ -86,7 +90,11 @@ def check_tuple_state_sweep(n=3000, T=5, seed=13, capture=False, specialize=Fals
             return (a, b)
         return init, step
     (init, step), (oi, os_) = mk(G), mk(O)
-    sw = BootstrapSweep(init, step, n, T, specialize=specialize).prepare(G.key(seed), torch.from_numpy(ys))
+    sw = BootstrapSweep(init, step, n, T, specialize=specialize, noise_ahead=noise_ahead).prepare(G.key(seed), torch.from_numpy(ys))
+    if noise_ahead is not None:
+        assert sw.noise_ahead == noise_ahead
+        if noise_ahead:
+            assert len(sw.p_step.noise) == 3 and len(sw.p_init.noise) == 2     # every latent normal site's draw
     if capture:
         sw.capture()
     sw.launch()

@@ -739,10 +739,46 @@ def test_indexed_and_masked_constraints(gpu):
     parity.check_masked_constraints(n=10_000, seed=3)
 
 
+@pytest.mark.parametrize("n,T,capture", [(4096, 5, False), (100_000, 23, True), (100_003, 12, True)])
+def test_noise_ahead_sweep_matches_oracle(gpu, n, T, capture):
+    """BootstrapSweep's two-stream form (the steps' normal draws by background programs on a second stream, a group
+    of steps ahead) and its one-stream form, both against the oracle, bit for bit: eager and captured,
+    T not a multiple of the noise group, ragged last tile."""
+    for na in (True, False):
+        res = parity.check_lgssm_sweep(n=n, T=T, capture=capture, specialize=True, noise_ahead=na)
+        assert res["ancestors_equal"] and res["x_equal"] and res["totals_equal"] and res["lw_max_abs_diff"] == 0.0
+        assert abs(res["log_ml"] - res["log_ml_oracle"]) < 1e-11
+
+
+def test_noise_ahead_full_size_equals_one_stream(gpu):
+    """BASELINE config 2 at full size (1e6 particles x 100 steps): the two forms leave the same particles,
+    log-weights, ancestors and integer totals; replaying the captured two-stream graph is deterministic."""
+    import genjax_amd as G
+    from genjax_amd import workloads
+    from genjax_amd.inference.smc import BootstrapSweep
+    n, T = 1_000_000, 100
+    ys = workloads.lgssm_data(T)
+    init, step = workloads.make_lgssm(G)
+    got = []
+    for na in (False, True):
+        sw = BootstrapSweep(init, step, n, T, noise_ahead=na).prepare(G.key(314159), torch.from_numpy(ys))
+        assert sw.noise_ahead == na
+        sw.capture()
+        for _ in range(3 if na else 1):
+            sw.launch()
+        got.append([v.clone() for v in sw.state()] + [sw.totals.clone(), sw.maxs.clone()])
+        if na:
+            sw.launch()
+            again = [v.clone() for v in sw.state()] + [sw.totals.clone(), sw.maxs.clone()]
+            assert all(torch.equal(a, b) for a, b in zip(got[-1], again))
+    assert all(torch.equal(a, b) for a, b in zip(*got))
+
+
 def test_tuple_state_sweep_three_site_step_model(gpu):
     """BootstrapSweep over a step model with three latent sites and a tuple state, 1e5 particles,
     captured + specialised, bit-exact vs the oracle"""
-    parity.check_tuple_state_sweep(n=100_000, T=5, capture=True, specialize=True)
+    parity.check_tuple_state_sweep(n=100_000, T=5, capture=True, specialize=True, noise_ahead=False)
+    parity.check_tuple_state_sweep(n=100_000, T=5, capture=True, specialize=True, noise_ahead=True)   # three draws per step
     parity.check_tuple_state_sweep(n=3001, T=4)
 
 

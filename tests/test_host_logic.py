@@ -989,6 +989,65 @@ def test_tuple_state_sweep_matches_oracle():
     parity.check_tuple_state_sweep()
 
 
+def test_noise_ahead_sweep_matches_oracle():
+    """BootstrapSweep(noise_ahead=True): the steps' normal draws come from background programs (static.NoiseProgram),
+    the site programs read them (MinimalGenerate(hoist_noise=True)); same particles, weights, ancestors and evidence
+    as the oracle's sweep — T not a multiple of the noise group, one / three latent sites per step."""
+    from tests import parity
+    res = parity.check_lgssm_sweep(n=3000, T=23, noise_ahead=True)
+    assert res["ancestors_equal"] and res["x_equal"] and res["totals_equal"] and res["lw_max_abs_diff"] == 0.0
+    # the same integer totals; 23 float64 terms summed pairwise (numpy) here and one after the other in the oracle
+    assert abs(res["log_ml"] - res["log_ml_oracle"]) < 1e-11
+    parity.check_tuple_state_sweep(noise_ahead=True)
+
+
+def test_noise_hoist_takes_launch_keyed_normal_draws_only():
+    """engine.NoiseHoist: a `normal` site's draw is hoisted when its key is a fold_in chain from the particle key
+    (nested calls included: the chain has one counter per level); constrained sites draw nothing; other samplers
+    stay in the program.  The hoisted program + NoiseProgram reproduce the plain program's outputs bit for bit."""
+    import genjax_amd as G
+    from genjax_amd.core.choice_map import ChoiceMap
+    from genjax_amd.random import lazy_split
+    from genjax_amd.static import MinimalGenerate, NoiseProgram
+
+    @G.gen
+    def inner(m):
+        a = G.normal(m, 2.0) @ "a"
+        u = G.uniform(0.0, 1.0) @ "u"
+        return a + u
+
+    @G.gen
+    def model(x0):
+        z = G.normal(x0, 1.0) @ "z"
+        s = inner(z) @ "sub"
+        G.normal(s, 0.5) @ "y"
+        return s
+
+    n = 1500
+    x0 = torch.linspace(-1, 1, n)
+    obs = ChoiceMap.empty().set("y", torch.tensor(0.25))
+    key = G.key(11)
+    outs = []
+    for hoist in (False, True):
+        p = MinimalGenerate(model, (x0,), obs, (n,), hoist_noise=hoist)
+        noise = []
+        if hoist:
+            assert p.noise == (((1,), 0), ((2, 1), 0))       # "z": site 1; "sub" -> "a": site 2, then site 1 inside
+            q = NoiseProgram(p.noise, (n,))
+            zs = [torch.zeros((1, n)) for _ in p.noise]
+            q.run((n,), lazy_split(key, n), zs)
+            noise = [z.reshape(n) for z in zs]
+        else:
+            assert p.noise == ()
+        r, w = torch.zeros((1, n)), torch.zeros((1, n))
+        part = torch.zeros((2, (n + 255) // 256))
+        bufs = [None] * len(p.comp.outputs)
+        bufs[p.ro[1]], bufs[p.wo[1]] = r, w
+        p.comp.run(p.leaves((x0,), obs, noise), (n,), lazy_split(key, n), red_out=part, out_buffers=bufs)
+        outs.append((r, w))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
 def test_vector_state_mh_sweep_matches_oracle():
     """BootstrapSweep(rejuvenate=...) with a 2-vector state held in one vector-valued site: the fused MH move
     gathers, proposes, accepts and selects all components; bit-exact vs the oracle incl. the accept bits"""

@@ -83,15 +83,20 @@ class Distribution(GenerativeFunction):
         g = current_graph()
         elems, shape = _bcast(args)
         out = []
-        hoist = g.__dict__.get("noise_hoist") if self.sample_op == "S_NORMAL" else None
+        hoist = g.__dict__.get("noise_hoist") if self.sample_op in ("S_NORMAL", "S_UNIFORM") else None
         for e, a in enumerate(elems):
             if hoist is not None:
-                # noise-ahead (engine.NoiseHoist): the standard-normal draw comes from memory — a background program
-                # drew it from the same key — and only `* scale + loc` stays here: csrc/gmx_dist.h gmx_normal_sample's
-                # own two operations, in its order
-                z = hoist.request(key.node, e)
-                if z is not None:
+                # noise-ahead (engine.NoiseHoist): the standard-normal / unit-uniform draw comes from memory — a
+                # background program drew it from the same key — and only the sampler's own last operations stay
+                # here, in its order (csrc/gmx_dist.h gmx_normal_sample: z * scale + loc; gmx_uniform_sample:
+                # lo + (hi - lo) * u)
+                z = hoist.request(key.node, e, "normal" if self.sample_op == "S_NORMAL" else "uniform")
+                if z is not None and self.sample_op == "S_NORMAL":
                     out.append(z * T.as_float(a[1]) + T.as_float(a[0]))
+                    continue
+                if z is not None:
+                    lo, hi = T.as_float(a[0]), T.as_float(a[1])
+                    out.append(lo + (hi - lo) * z)
                     continue
             ops = tuple(T.as_float(x).node for x in a)
             out.append(Expr(g.add(self.sample_op, (key.node,) + ops, imm=e, dtype=self.value_dtype)))

@@ -248,30 +248,41 @@ class Sym:
 
 
 class NoiseHoist:
-    """Noise-ahead plan of one traced program: the standard-normal draws whose KEY depends on nothing but the launch
-    key and constants (`fold_in` chains from the particle's key: every `normal(...) @ addr` site of a static model
-    outside a counted loop).  Such a draw — two Threefry blocks and an `erf_inv`, most of a bootstrap step's vector
-    instructions — needs nothing the resampling chain produces, so a BACKGROUND program (static.NoiseProgram) can
-    draw it steps ahead on a second stream; the traced program reads it as one more per-particle input leaf.
-    `draws[k] = (chain of fold_in counters from the particle key, element counter)` is input leaf first_leaf + k."""
+    """Noise-ahead plan of one traced program: the standard-normal / unit-uniform draws whose KEY depends on nothing
+    but a launch key and constants (`fold_in` chains from the particle's key: every `normal(...) @ addr` /
+    `uniform(...) @ addr` site of a static model outside a counted loop, the accept draw of an MH move).  Such a draw —
+    two Threefry blocks and an `erf_inv`, most of a bootstrap step's vector instructions — needs nothing the
+    resampling chain produces, so a BACKGROUND program (static.NoiseProgram) can draw it steps ahead on a second
+    stream; the traced program reads it as one more per-particle input leaf.
+    `draws[k] = (root, chain of fold_in counters from the root key, element counter, kind)` is input leaf
+    first_leaf + k; root "LDKEY" = the particle's launch key, "KSPLITU" = split((k0, k1), n)[i] of two launch values
+    (the second key of a chained program, static.MinimalMHGenerate); kind "normal" | "uniform"."""
 
-    def __init__(self, tr: "Tracing", first_leaf: int):
+    def __init__(self, tr: "Tracing", first_leaf: int, roots=None):
         self.tr, self.first_leaf, self.draws = tr, int(first_leaf), []
+        self._ksplitu = None
+        self.roots = None if roots is None or roots is True else tuple(roots)     # None: draws of every root key
 
-    @staticmethod
-    def chain(node):
+    def chain(self, node):
         c = []
         while node.op == "KDERIVE":
             c.append(int(node.imm))
             node = node.args[0]
-        return tuple(reversed(c)) if node.op == "LDKEY" else None
+        if node.op == "KSPLITU":
+            if self._ksplitu is None:
+                self._ksplitu = node
+            if node is not self._ksplitu:
+                return None
+        elif node.op != "LDKEY":
+            return None
+        return node.op, tuple(reversed(c))
 
-    def request(self, key_node, e: int):
-        ch = self.chain(key_node)
-        if ch is None:
+    def request(self, key_node, e: int, kind: str = "normal"):
+        rc = self.chain(key_node)
+        if rc is None or (self.roots is not None and rc[0] not in self.roots):
             return None
         j = self.first_leaf + len(self.draws)
-        self.draws.append((ch, int(e)))
+        self.draws.append((rc[0], rc[1], int(e), kind))
         return self.tr.sym_leaf(("part", "f32", ()), j).value
 
 

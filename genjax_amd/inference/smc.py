@@ -635,6 +635,7 @@ class BootstrapSweep:
 
     NOISE_LDS_PAD = 56000      # bytes of unused LDS per noise workgroup: two of them per CU (160 KB)
     NOISE_GROUP = 10           # steps per group of noise launches (the noise runs one group ahead of the chain)
+    NOISE_ROOTS_MH = "LDKEY"   # with rejuvenate=: which keys' draws the background programs take (see prepare)
 
     def __init__(self, init, step, n_particles: int, T: int, obs_addr="y", resample="systematic",
                  step_extra=None, specialize=True, rejuvenate=None, state_addr="x", noise_ahead=None):
@@ -653,14 +654,17 @@ class BootstrapSweep:
     def prepare(self, key: Key, ys: torch.Tensor):
         from ..static import MinimalGenerate as _MG, NoiseProgram
         be = _lib.get()
-        # noise ahead: asked for explicitly, or by default on a device with streams for the plain bootstrap step
-        # (no MH move) on the fast path (specialised programs, fused ordered resampling)
+        # noise ahead: asked for explicitly, or by default on a device with streams on the fast path (specialised
+        # programs; with rejuvenate=, the MH move chained into the extension)
+        fuse_mh_ok = os.environ.get("GENMI_FUSE_MH", "1") != "0"
         want_na = self.noise_ahead_req
         if want_na is None:
             want_na = (os.environ.get("GENMI_NOISE_AHEAD", "1") != "0" and be.uses_streams and self.specialize
-                       and self.rejuvenate is None and os.environ.get("GENMI_FUSE_RESAMPLE", "0") != "1")
-        if want_na and self.rejuvenate is not None:
-            raise NotImplementedError("BootstrapSweep(noise_ahead=True) with rejuvenate= is not supported")
+                       and (self.rejuvenate is None or fuse_mh_ok)
+                       and os.environ.get("GENMI_FUSE_RESAMPLE", "0") != "1")
+        if want_na and self.rejuvenate is not None and not fuse_mh_ok:
+            raise NotImplementedError("BootstrapSweep(noise_ahead=True, rejuvenate=...) needs the chained MH + extension "
+                                      "program (GENMI_FUSE_MH=0 is set)")
         self.noise_ahead = False
 
         def MinimalGenerate(*a):
@@ -721,7 +725,7 @@ class BootstrapSweep:
             self.xm_store = [torch.zeros((D, n), dtype=torch.float32, device=dev) for _ in range(2)]
             self.xm = [s_.reshape(n) if not event else s_.t() for s_ in self.xm_store]
             self.accept = torch.zeros((n,), dtype=torch.bool, device=dev)
-            self.p_step = MinimalGenerate(self.step, (self.xm[0],) + tuple(self.step_extra(1)), obs0, (n,))
+            self.p_step = _MG(self.step, (self.xm[0],) + tuple(self.step_extra(1)), obs0, (n,))
             ch = obs0.set(self.state_addr, g)
             self.p_mh_init = MinimalMH(self.init, (), ch, self.rejuvenate, (n,))
             self.p_mh_step = MinimalMH(self.step, (Gathered(self.xm[0], self.anc),) + tuple(self.step_extra(1)), ch,
@@ -733,14 +737,32 @@ class BootstrapSweep:
         if self.rejuvenate is not None and os.environ.get("GENMI_FUSE_MH", "1") != "0":
             from ..static import MinimalMHGenerate
             ex = tuple(self.step_extra(1))
-            self.p_mhvm_init = MinimalMHGenerate(self.init, (), ch, self.rejuvenate, self.step, ex, obs0, (n,))
+            # which draws of the chained program go to the background stream: the two streams should carry about the
+            # same vector work (GENMI_NOISE_ROOTS: "all", "LDKEY" = the move's proposal + accept draws, "KSPLITU" = the
+            # extension's draw)
+            roots = os.environ.get("GENMI_NOISE_ROOTS", self.NOISE_ROOTS_MH)
+            hn = False if not want_na else (True if roots == "all" else tuple(roots.split(",")))
+            self.p_mhvm_init = MinimalMHGenerate(self.init, (), ch, self.rejuvenate, self.step, ex, obs0, (n,),
+                                                 hoist_noise=hn)
             self.p_mhvm_step = MinimalMHGenerate(self.step, (Gathered(self.xm[0], self.anc),) + ex, ch, self.rejuvenate,
-                                                 self.step, ex, obs0, (n,))
-        self.n_init = self.n_step = None
-        if want_na and self.p_step.noise:
+                                                 self.step, ex, obs0, (n,), hoist_noise=hn)
+        # the chain's programs by step: t = 0, t = 1, t >= 2
+        chain_progs = (self.p_init, self.p_step, self.p_step) if self.rejuvenate is None else \
+            (self.p_init, self.p_mhvm_init, self.p_mhvm_step)
+        self._noise_progs = {}
+        if want_na and chain_progs[2] is not None and chain_progs[2].noise:
             self.noise_ahead = True
-            self.n_step = NoiseProgram(self.p_step.noise, (n,))
-            self.n_init = NoiseProgram(self.p_init.noise, (n,)) if self.p_init.noise else None
+            # one background program per (chain program, root key): the draws that hang off the launch key (the
+            # step's own sites; with rejuvenate=, the move's proposal and accept draws: key k_mh) and those that hang
+            # off the chained extension's key (KSPLITU: k_prop)
+            for P in chain_progs:
+                if id(P) in self._noise_progs:
+                    continue
+                by_root = {}
+                for k_, d in enumerate(P.noise):
+                    by_root.setdefault(d[0], []).append(k_)
+                self._noise_progs[id(P)] = [(root, NoiseProgram([P.noise[k_] for k_ in idx], (n,)), idx)
+                                            for root, idx in by_root.items()]
             self.noise_group = max(1, min(int(os.environ.get("GENMI_NOISE_GROUP", self.NOISE_GROUP)), T))
             # groups of steps [start, end): the noise of group g + 1 is issued before the chain of group g.  The chain
             # can only start once the FIRST group's noise is there, so the groups grow 1, 2, 4, ... up to noise_group
@@ -752,15 +774,20 @@ class BootstrapSweep:
                     self.noise_slot.append((len(self.noise_groups) % 2, t - t0))
                 self.noise_groups.append((t0, t1))
                 t0, size = t1, size * 2
-            S = max(len(self.p_step.noise), len(self.p_init.noise))
+            S = max(len(P.noise) for P in chain_progs)
             # two groups of noise buffers: the background stream fills one while the chain reads the other
             self.zbuf = torch.zeros((2, self.noise_group, S, n), dtype=torch.float32, device=dev)
             self._noise_stream = torch.cuda.Stream(device=dev) if be.uses_streams else None
             pad = int(os.environ.get("GENMI_NOISE_LDS_PAD", self.NOISE_LDS_PAD))
-            for q in (self.n_init, self.n_step):
-                if q is not None and self.specialize:
-                    q.comp.set_background(pad)
-                    q.comp.specialize()
+            for plist in self._noise_progs.values():
+                for _, q, _ in plist:
+                    if self.specialize:
+                        q.comp.set_background(pad)
+                        q.comp.specialize()
+        elif want_na and any(P is not None and P.noise for P in chain_progs):
+            # the steady-state program draws nothing ahead although another one would: the plain programs throughout
+            self.noise_ahead_req = False
+            return self.prepare(key, ys)
         if self.specialize:
             self.p_init.comp.specialize()
             self.p_step.comp.specialize()
@@ -783,6 +810,13 @@ class BootstrapSweep:
                                                                      and self.p_mhvm_step.comp.writes_tile_stats()):
             self.p_mhvm_init = self.p_mhvm_step = None      # the chained programs are too large for the tile form
         self.fuse_mh = self.p_mhvm_init is not None
+        if self.noise_ahead and self.rejuvenate is not None and not self.fuse_mh:
+            # the noise-ahead form needs the chained program: start over with the plain ones
+            if self.noise_ahead_req:
+                raise NotImplementedError("BootstrapSweep(noise_ahead=True, rejuvenate=...): the chained MH + extension "
+                                          "program does not fit the tile form")
+            self.noise_ahead_req = False
+            return self.prepare(key, ys)
         # ... and, on request (GENMI_TILE_Q=1), every particle's fixed-point weight (4 bytes each: significand | shift):
         # the resampler then reads those instead of the log-weights and skips one exp per particle.  Measured on MI355X
         # (config 2): the resampler 6.7 -> 6.3 us, the site program 11.5 -> 12.3 us — the extra 4 MB are stored at the
@@ -856,10 +890,22 @@ class BootstrapSweep:
     def _noise_leaves(self, t, prog):
         return [v.reshape(self.n) for v in self._noise_views(t, len(prog.noise))]
 
+    def _chain_prog(self, t):
+        if t == 0:
+            return self.p_init
+        if self.fuse_mh:
+            return self.p_mhvm_init if t == 1 else self.p_mhvm_step
+        return self.p_step
+
     def _launch_noise(self, t):
-        q = self.n_init if t == 0 else self.n_step
-        if q is not None:
-            q.run((self.n,), lazy_split(self.step_keys[t][0], self.n), self._noise_views(t, len(q.draws)))
+        """the draws step t's chain program reads, by the background programs: root LDKEY from the program's launch key
+        (k_prop; the chained MH + extension program: k_mh), root KSPLITU from the extension's key k_prop"""
+        P = self._chain_prog(t)
+        views = self._noise_views(t, len(P.noise))
+        mh = self.fuse_mh and t >= 1
+        for root, q, idx in self._noise_progs[id(P)]:
+            k = self.step_keys[t][2] if (mh and root == "LDKEY") else self.step_keys[t][0]
+            q.run((self.n,), lazy_split(k, self.n), [views[k_] for k_ in idx])
 
     def _resample_in(self, t):
         """gmx_run_args.rs of the launch of step t (>= 1) that gathers: resample step t-1's weights first"""
@@ -900,12 +946,13 @@ class BootstrapSweep:
         kw = k_prop.host()
         if t == 1:
             prog = self.p_mhvm_init
-            leaves = prog.leaves((), ch, self.rejuvenate, ex, obs, (int(kw[0]), int(kw[1])))
+            leaves = prog.leaves((), ch, self.rejuvenate, ex, obs, (int(kw[0]), int(kw[1])),
+                                 self._noise_leaves(t, prog) if self.noise_ahead else ())
         else:
             prog = self.p_mhvm_step
             a = Gathered(self.xm[(t - 1) % 2], self.anc)
             leaves = prog.leaves((a,) + tuple(self.step_extra(t - 1)), ch, self.rejuvenate, ex, obs,
-                                 (int(kw[0]), int(kw[1])))
+                                 (int(kw[0]), int(kw[1])), self._noise_leaves(t, prog) if self.noise_ahead else ())
         bufs = [None] * len(prog.comp.outputs)
         bufs[prog.mo[1]] = self.xm_store[t % 2]
         bufs[prog.ao[1]] = self.accept.reshape(1, n)
@@ -1028,7 +1075,10 @@ class BootstrapSweep:
                 A.wait_event(ready[g])
             for t in range(*spans[g]):
                 if not skip_vm:
-                    self._launch_vm(t)
+                    if t >= 1 and self.fuse_mh:
+                        self._launch_mhvm(t)
+                    else:
+                        self._launch_vm(t)
                 if self.fused:
                     self._launch_resample(t)
                 else:

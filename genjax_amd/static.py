@@ -873,7 +873,7 @@ class MinimalGenerate:
         hoist = None
         if hoist_noise:
             from .engine import NoiseHoist
-            hoist = tr.graph.noise_hoist = NoiseHoist(tr, len(self.specs))
+            hoist = tr.graph.noise_hoist = NoiseHoist(tr, len(self.specs), hoist_noise)
         ctx = _Ctx(tr)
         ctx.store_sites = False
         with T.tracing(tr.graph):
@@ -904,25 +904,29 @@ class MinimalGenerate:
 
 
 class NoiseProgram:
-    """The background half of a noise-ahead step (engine.NoiseHoist): output k is the standard-normal draw
-    `jax.random.normal(fold_in(...fold_in(key_i, c_0)..., c_m))` element e for draws[k] = ((c_0..c_m), e), key_i the
-    particle's launch key — exactly what the `normal` site with that key draws before `* scale + loc`
-    (S_NORMAL with loc 0, scale 1: z * 1 + 0 is z, bit for bit).  Keys only: no inputs, nothing a chain produces."""
+    """The background half of a noise-ahead step (engine.NoiseHoist): output k is the draw
+    `jax.random.normal(fold_in(...fold_in(key_i, c_0)..., c_m))` (or `.uniform`) element e for
+    draws[k] = (root, (c_0..c_m), e, kind), key_i the particle's launch key — exactly what the site with that key
+    draws before its `* scale + loc` (S_NORMAL with loc 0, scale 1: z * 1 + 0 is z, bit for bit; S_UNIFORM(0, 1):
+    0 + (1 - 0) * u is u).  Keys only: no inputs, nothing a chain produces.  All draws must share one root key."""
 
     def __init__(self, draws, batch: tuple):
         if not draws:
             raise ValueError("NoiseProgram: no draws")
+        if len({d[0] for d in draws}) != 1:
+            raise ValueError("NoiseProgram: the draws of one program come from one launch key")
         self.draws = tuple(draws)
         tr = Tracing(len(batch))
         g = tr.graph
         with T.tracing(g):
             root = g.add("LDKEY", dtype="key")
             self.outs = []
-            for chain, e in self.draws:
+            for _, chain, e, kind in self.draws:
                 k = root
                 for c in chain:
                     k = g.add("KDERIVE", (k,), imm=c, dtype="key")
-                z = g.add("S_NORMAL", (k, g.const_f32(0.0), g.const_f32(1.0)), imm=e, dtype="f32")
+                z = g.add("S_NORMAL" if kind == "normal" else "S_UNIFORM", (k, g.const_f32(0.0), g.const_f32(1.0)),
+                          imm=e, dtype="f32")
                 self.outs.append(tr.emit_output(Expr(z)))
         self.comp = Compiled(tr)
 
@@ -1024,7 +1028,10 @@ class MinimalMHGenerate:
     the moved state (an expression) and the launch values in `gen_extra`."""
 
     def __init__(self, mh_fn, mh_args, choices: ChoiceMap, request, gen_fn, gen_extra: tuple, gen_constraint: ChoiceMap,
-                 batch: tuple):
+                 batch: tuple, hoist_noise: bool = False):
+        """hoist_noise: as MinimalGenerate — `self.noise` lists the draws taken from memory: root "LDKEY" ones (the
+        move: proposal, accept) come from the launch key, root "KSPLITU" ones (the extension) from `key_words`.
+        A tuple of roots instead of True hoists the draws of those keys only."""
         flat = Flat()
         self.atree = flat.add(tuple(mh_args))
         self.ctree = flat.add(choices)
@@ -1034,6 +1041,10 @@ class MinimalMHGenerate:
         self.ktree = flat.add((0, 0))                 # the extension's launch key, two 32-bit words
         self.specs = tuple(leaf_spec(v, batch) for v in flat.leaves)
         tr = Tracing(len(batch))
+        hoist = None
+        if hoist_noise:
+            from .engine import NoiseHoist
+            hoist = tr.graph.noise_hoist = NoiseHoist(tr, len(self.specs), hoist_noise)
         ctx = _Ctx(tr)
         ctx.store_sites = False
         g = tr.graph
@@ -1056,9 +1067,11 @@ class MinimalMHGenerate:
                 w = Expr(g.const_f32(0.0)) + 0.0
             self.wo = tr.emit_output(w)
             g.add("REDMAX", (w.node,), dtype="none")
+        self.noise = tuple(hoist.draws) if hoist is not None else ()
+        g.__dict__.pop("noise_hoist", None)
         self.comp = Compiled(tr)
 
-    def leaves(self, mh_args, choices, request, gen_extra, gen_constraint, key_words):
+    def leaves(self, mh_args, choices, request, gen_extra, gen_constraint, key_words, noise=()):
         flat = Flat()
         a = flat.add(tuple(mh_args))
         c = flat.add(choices)
@@ -1068,7 +1081,9 @@ class MinimalMHGenerate:
         flat.add((_as_i32(key_words[0]), _as_i32(key_words[1])))
         if a != self.atree or c != self.ctree or rkey != self.rkey or e != self.etree or gc != self.gtree:
             raise ValueError("MinimalMHGenerate: call structure differs from the compiled one")
-        return flat.leaves
+        if len(noise) != len(self.noise):
+            raise ValueError(f"MinimalMHGenerate: the program reads {len(self.noise)} noise leaves, got {len(noise)}")
+        return flat.leaves + list(noise)
 
 
 def _as_i32(u):

@@ -955,7 +955,7 @@ def oracle_nlssm_mh_sweep(n, T, seed):
     return {"x": x, "lw": olw, "acc": oacc, "terms": terms, "resampled": x[anc]}
 
 
-def check_nlssm_mh_sweep(n=2000, T=5, seed=7, capture=False, specialize=False, want_chained=None):
+def check_nlssm_mh_sweep(n=2000, T=5, seed=7, capture=False, specialize=False, want_chained=None, noise_ahead=None):
     """BASELINE config 3 as ONE captured sweep: BootstrapSweep(rejuvenate=...) (k_vm -> resample ->
     fused MH -> k_vm ...) against the oracle run step by step with the sweep's key schedule
     (step key fold_in(key, t) -> (k_prop, k_res, k_mh); resampling of step t-1 uses ITS k_res)."""
@@ -968,7 +968,16 @@ def check_nlssm_mh_sweep(n=2000, T=5, seed=7, capture=False, specialize=False, w
     req = G.StaticRequest({"x": G.Rejuvenate(G.normal, lambda chm: (chm.get_value(), 0.5))})
     oreq = {"x": O.Rejuvenate(O.normal, lambda chm: (chm.get_value(), np.float32(0.5)))}
     sw = smc.BootstrapSweep(init, step, n, T, step_extra=lambda t: (float(t),), rejuvenate=req,
-                            specialize=specialize).prepare(G.key(seed), torch.from_numpy(ys))
+                            specialize=specialize, noise_ahead=noise_ahead).prepare(G.key(seed), torch.from_numpy(ys))
+    if noise_ahead is not None:
+        assert sw.noise_ahead == noise_ahead
+        if noise_ahead:     # the move's proposal and accept draws (launch key) and / or the extension's draw (its own key)
+            import os
+            roots = os.environ.get("GENMI_NOISE_ROOTS", smc.BootstrapSweep.NOISE_ROOTS_MH)
+            want = [("KSPLITU", "normal"), ("LDKEY", "normal"), ("LDKEY", "uniform")]
+            if roots != "all":
+                want = [w for w in want if w[0] in roots.split(",")]
+            assert sorted((d[0], d[3]) for d in sw.p_mhvm_step.noise) == want
     if want_chained is not None:
         assert sw.fuse_mh == want_chained, "the sweep did not take the requested (chained / two-launch) MH form"
     if capture:

@@ -425,8 +425,11 @@ def test_hmc_reference_behaviour_and_oracle(gpu, n):
 
 @pytest.mark.parametrize("n,capture,specialize", [(3000, False, False), (100_000, True, True), (1_000_000, True, True)])
 def test_nonlinear_ssm_mh_sweep_matches_oracle(gpu, n, capture, specialize):
-    """BASELINE config 3 as one (captured) sweep with the fused MH move between resampling and extension."""
-    parity.check_nlssm_mh_sweep(n=n, T=5, capture=capture, specialize=specialize)
+    """BASELINE config 3 as one (captured) sweep with the fused MH move between resampling and extension: the
+    one-stream form, and the noise-ahead form (proposal, accept and extension draws by background programs on a second
+    stream — two of them per step, one per key)."""
+    parity.check_nlssm_mh_sweep(n=n, T=5, capture=capture, specialize=specialize, noise_ahead=False)
+    parity.check_nlssm_mh_sweep(n=n, T=13 if n <= 100_000 else 5, capture=capture, specialize=specialize, noise_ahead=True)
 
 
 def test_dirichlet_matches_oracle_and_scipy(gpu):

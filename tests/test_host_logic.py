@@ -999,12 +999,14 @@ def test_noise_ahead_sweep_matches_oracle():
     # the same integer totals; 23 float64 terms summed pairwise (numpy) here and one after the other in the oracle
     assert abs(res["log_ml"] - res["log_ml_oracle"]) < 1e-11
     parity.check_tuple_state_sweep(noise_ahead=True)
+    # with an MH move per step (config 3): the move's proposal + accept draws and the extension's draw, from two keys
+    parity.check_nlssm_mh_sweep(n=1500, T=7, noise_ahead=True)
 
 
-def test_noise_hoist_takes_launch_keyed_normal_draws_only():
-    """engine.NoiseHoist: a `normal` site's draw is hoisted when its key is a fold_in chain from the particle key
-    (nested calls included: the chain has one counter per level); constrained sites draw nothing; other samplers
-    stay in the program.  The hoisted program + NoiseProgram reproduce the plain program's outputs bit for bit."""
+def test_noise_hoist_takes_launch_keyed_draws():
+    """engine.NoiseHoist: a `normal` / `uniform` site's draw is hoisted when its key is a fold_in chain from the
+    particle key (nested calls included: the chain has one counter per level); constrained sites draw nothing.
+    The hoisted program + NoiseProgram reproduce the plain program's outputs bit for bit."""
     import genjax_amd as G
     from genjax_amd.core.choice_map import ChoiceMap
     from genjax_amd.random import lazy_split
@@ -1013,7 +1015,7 @@ def test_noise_hoist_takes_launch_keyed_normal_draws_only():
     @G.gen
     def inner(m):
         a = G.normal(m, 2.0) @ "a"
-        u = G.uniform(0.0, 1.0) @ "u"
+        u = G.uniform(-0.5, m) @ "u"
         return a + u
 
     @G.gen
@@ -1032,7 +1034,8 @@ def test_noise_hoist_takes_launch_keyed_normal_draws_only():
         p = MinimalGenerate(model, (x0,), obs, (n,), hoist_noise=hoist)
         noise = []
         if hoist:
-            assert p.noise == (((1,), 0), ((2, 1), 0))       # "z": site 1; "sub" -> "a": site 2, then site 1 inside
+            # "z": site 1; "sub" is site 2 -> "a" site 1, "u" site 2 inside it
+            assert p.noise == (("LDKEY", (1,), 0, "normal"), ("LDKEY", (2, 1), 0, "normal"), ("LDKEY", (2, 2), 0, "uniform"))
             q = NoiseProgram(p.noise, (n,))
             zs = [torch.zeros((1, n)) for _ in p.noise]
             q.run((n,), lazy_split(key, n), zs)

@@ -310,11 +310,12 @@ def main():
         gap = time_launches(lambda: be.check(be.c.gmx_reduce_max(be.ptr(one), 1, be.ptr(one[1:]), be.stream()),
                                              "gmx_reduce_max"))
         us["launch_boundary"] = gap                               # a chain of trivial launches, for reference
-        traffic = None
+        traffic = traffic_noise = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("k_vm_hbm_bytes_per_launch")
+                tj = json.load(open(tpath))
+                traffic, traffic_noise = tj.get("k_vm_hbm_bytes_per_launch"), tj.get("noise_hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         specialised = bool(sw.p_step.comp._be.c.gmx_program_is_specialized(sw.p_step.comp.handle))
@@ -341,16 +342,18 @@ def main():
                 "bound": "valu", "kernel": "gmx_jit_background_kernel (noise program: 3 Threefry-2x32 blocks + erf_inv "
                                            "per draw; BootstrapSweep noise-ahead form)",
                 "achieved": noise_rate / 1e12, "peak": VALU_PEAK_LANE_OPS / 1e12, "unit": "T lane-op/s",
-                "frac": noise_rate / VALU_PEAK_LANE_OPS, "traffic": traffic,
+                "frac": noise_rate / VALU_PEAK_LANE_OPS, "traffic": traffic_noise,
                 "limiter": "vector-instruction issue (16 lanes/clk/SIMD for integer and unpacked f32): the whole sweep "
                            "keeps the vector ALUs busy for sweep.valu_frac of the time",
                 "valu_source": "instructions per wave: SQ_INSTS_VALU of profiles/r02f_pmc_summary.txt (constants in "
                                "bench.py, not measured in this run); durations: HIP events in this run",
-                "traffic_source": "profiles/traffic.json (site program; rocprofv3 TCC pass of an earlier run, NOT "
-                                  "measured in this run)",
+                "traffic_source": "profiles/traffic.json (rocprofv3 TCC passes of an earlier run of this workload, "
+                                  "calibrated against copy kernels; NOT measured in this run); the noise program writes "
+                                  "4 B per particle and reads nothing",
                 "calibrated_ceiling_T_lane_ops": VALU_CALIBRATED_LANE_OPS / 1e12,
                 # the data-path kernels against HBM (algorithmic bytes per launch / isolated launch duration)
                 "hbm": {"gmx_jit_kernel": {"algorithmic_bytes_per_launch": VM_BYTES_PER_PARTICLE * n,
+                                           "traffic": traffic,
                                            "achieved_GBps": achieved, "frac": achieved / HBM_PEAK_GBS,
                                            "note": "site program without its draws: ancestor 4 + gathered state 4 in, "
                                                    "state 4 + log-weight 4 out (+ 4 B of noise read, not algorithmic)",

@@ -1,4 +1,5 @@
-"""EXPERIMENT (not product): does drawing step t+1's standard-normal noise in a SEPARATE kernel on a second stream —
+"""EXPERIMENT (the product form of this is BootstrapSweep's noise-ahead path, inference/smc.py; the measurements that
+led to it: profiles/r02f_experiment_noise_ahead_*.txt): does drawing step t+1's standard-normal noise in a SEPARATE kernel on a second stream —
 concurrently with step t's resampling — shorten the bootstrap sweep?  The whole step is bound by vector-instruction
 issue, so this only helps if the runtime overlaps the noise kernel with the kernel boundaries and
 load / store phases of the dependent chain  [site program' -> offspring].
@@ -17,12 +18,6 @@ from ctypes import c_uint32
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-# PRIO=p: the chain's kernels run at wave priority p (s_setprio; the dedicated noise kernel stays at 0).  Needs the
-# variant library built with -DGMX_CHAIN_PRIO=p (genjax_amd/lib/libgenmi_hip_prio<p>.so); hiprtc gets the same define.
-PRIO = int(os.environ.get("PRIO", 0))
-if PRIO:
-    os.environ["GENMI_LIB"] = os.path.join(ROOT, "genjax_amd", "lib", f"libgenmi_hip_prio{PRIO}.so")
-    os.environ["GENMI_JIT_DEFS"] = f"-DGMX_CHAIN_PRIO={PRIO}"
 import numpy as np
 import torch
 
@@ -91,13 +86,13 @@ obs0 = ChoiceMap.empty().set("y", ys[0])
 pN = MinimalGenerate(noise, (), ChoiceMap.empty(), (n,))
 pJ0 = MinimalGenerate(j_init, (z[0].reshape(n),), obs0, (n,))
 pJ = MinimalGenerate(j_step, (Gathered(xs[0].reshape(n), anc), z[0].reshape(n)), obs0, (n,))
-# PAD: bytes of dynamic LDS every noise workgroup asks for and never touches (GENMI_EXP_LDS_PAD, csrc/gmx_kernels.hip):
-# caps how many noise workgroups a CU holds (160 KB of LDS per CU), so the chain's kernels always find wave slots
+# PAD: the noise program as a BACKGROUND program (gmx_program_set_background): wave priority 0 and PAD bytes of dynamic
+# LDS every noise workgroup asks for and never touches — a cap on how many noise workgroups a CU holds (160 KB of LDS
+# per CU), so that the chain's kernels always find wave slots.  PAD=0: an ordinary program.
 PAD = int(os.environ.get("PAD", 0))
 if PAD:
-    os.environ["GENMI_EXP_LDS_PAD"] = str(PAD)
+    pN.comp.set_background(PAD)
 pN.comp.specialize()
-os.environ.pop("GENMI_EXP_LDS_PAD", None)
 for p in (pJ0, pJ):
     p.comp.specialize()
 assert pJ.comp.writes_tile_stats() and pJ0.comp.writes_tile_stats()
@@ -141,10 +136,8 @@ def launch_o(t):
 
 BATCH = int(os.environ.get("BATCH", 1))   # > 1: the noise of BATCH steps is one group of launches, one event pair per group
 GROUP = int(os.environ.get("GROUP", 0))   # 1: ... and ONE launch per group (BATCH * n rows, keys split(step key, n)[i] by row)
-ROWS = int(os.environ.get("ROWS", BATCH))   # GROUP=2: steps per noise launch (divides BATCH)
 if GROUP:
     from genjax_amd.random import Key
-    assert BATCH % ROWS == 0
     assert RING == 2 * BATCH and T % BATCH == 0
     zg = [torch.zeros((1, BATCH * n), dtype=torch.float32, device=dev) for _ in range(2)]
     z = [zg[(r // BATCH) % 2][:, (r % BATCH) * n:(r % BATCH + 1) * n] for r in range(RING)]
@@ -158,13 +151,6 @@ if GROUP:
 
 
 def launch_noise_group(g):
-    if GROUP == 2:      # the dedicated kernel (csrc/gmx_kernels.hip: k_noise_normal), grid (tiles, ROWS) per launch
-        from ctypes import c_int64, c_void_p
-        for r0 in range(0, BATCH, ROWS):
-            be.check(be.c.gmx_noise_normal(c_void_p(gkeys_dev[g].data_ptr() + 8 * r0), c_int64(ROWS), c_uint32(1),
-                                           c_int64(n), c_void_p(zg[g % 2].data_ptr() + 4 * r0 * n), c_uint32(PAD),
-                                           be.stream()), "noise")
-        return
     bufs = [None] * len(pN.comp.outputs)
     bufs[pN.ro[1]] = zg[g % 2]
     if pN.wo[0] == "out":
@@ -236,7 +222,7 @@ def enqueue(two_streams: bool):
         A.wait_stream(B)
 
 
-out = {"n": n, "T": T, "ring": RING, "batch": BATCH, "group_launch": GROUP, "rows_per_launch": ROWS, "chain_prio": PRIO, "lds_pad": PAD, "fused_sweep_us_per_step": 1e6 * dt_ref / T}
+out = {"n": n, "T": T, "ring": RING, "batch": BATCH, "group_launch": GROUP,  "lds_pad": PAD, "fused_sweep_us_per_step": 1e6 * dt_ref / T}
 for two in (False, True):
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())

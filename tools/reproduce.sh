@@ -13,7 +13,7 @@ timeout 900 python -m pytest tests -m gpu -q > $out/${tag}_pytest_gpu.log 2>&1; 
 timeout 120 python -c "import __graft_entry__ as g; g.smoke()" > $out/${tag}_smoke.log 2>&1; tail -1 $out/${tag}_smoke.log | cut -c1-80
 timeout 600 python bench.py > $out/${tag}_bench.json 2> $out/${tag}_bench.err
 timeout 300 python bench.py --sharded --no-cpu-baseline > $out/${tag}_bench_sharded_world1.json 2> /dev/null
-timeout 300 python tools/experiments/noise_ahead.py > $out/${tag}_experiment_noise_ahead.json 2> /dev/null
+timeout 300 python tools/bench_noise_ahead.py 2> /dev/null | tail -1 > $out/${tag}_noise_ahead_ab.json
 timeout 300 python tools/experiments/skewed_resample.py 2> /dev/null | tail -1 > $out/${tag}_skewed_resample.json
 timeout 600 bash tools/prof.sh $tag > $out/${tag}_pmc_summary.txt 2>&1
 timeout 600 bash tools/traffic.sh $tag > $out/${tag}_traffic.txt 2>&1

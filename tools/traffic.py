@@ -44,6 +44,8 @@ def main(bench_root, calib_root, out):
                              "hbm_bytes_corrected": f_rd * fetch + write}
         if k.startswith("gmx_jit_kernel") or k.startswith("void k_vm"):
             res["k_vm_hbm_bytes_per_launch"] = f_rd * fetch + write
+        if k.startswith("gmx_jit_background_kernel"):
+            res["noise_hbm_bytes_per_launch"] = f_rd * fetch + write
         if k.startswith("void k_offspring_tile"):
             res["k_offspring_tile_hbm_bytes_per_launch"] = f_rd * fetch + write
     json.dump(res, open(out, "w"), indent=1)

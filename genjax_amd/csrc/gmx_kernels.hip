@@ -258,6 +258,8 @@ static bool jit_enabled() {
 static int jit_pp_for(const gmx_program* p) {
   const char* e = getenv("GENMI_JIT_PP");
   if (e && e[0] >= '1' && e[0] <= '8') return e[0] - '0';
+  const char* eb = getenv("GENMI_JIT_PP_BG");        // background programs only (tuning)
+  if (p->background && eb && eb[0] >= '1' && eb[0] <= '8') return eb[0] - '0';
   // Measured on MI355X (BASELINE config 2, 1e6 particles): 4 particles / thread do not raise the VALU
   // issue rate of the integer-heavy Threefry stream (isolated launch 11.8 -> 13.7 us) but the kernel
   // is 0.9 us SHORTER inside the sweep (a quarter of the workgroups to schedule against the cold

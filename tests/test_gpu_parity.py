@@ -753,6 +753,21 @@ def test_noise_ahead_sweep_matches_oracle(gpu, n, T, capture):
         assert abs(res["log_ml"] - res["log_ml_oracle"]) < 1e-11
 
 
+def test_noise_ahead_with_stratified_resampling_and_env_switch(gpu, monkeypatch):
+    """the two-stream form with the stratified resampler (one Threefry block per slot edge in the chain's resampler),
+    and GENMI_NOISE_AHEAD=0 as the default's off switch"""
+    res = parity.check_lgssm_sweep(n=50_000, T=11, capture=True, specialize=True, resample="stratified", noise_ahead=True)
+    assert res["ancestors_equal"] and res["x_equal"] and res["totals_equal"] and res["lw_max_abs_diff"] == 0.0
+    import genjax_amd as G
+    from genjax_amd import workloads
+    from genjax_amd.inference.smc import BootstrapSweep
+    ys = workloads.lgssm_data(3)
+    init, step = workloads.make_lgssm(G)
+    assert BootstrapSweep(init, step, 4096, 3).prepare(G.key(1), torch.from_numpy(ys)).noise_ahead
+    monkeypatch.setenv("GENMI_NOISE_AHEAD", "0")
+    assert not BootstrapSweep(init, step, 4096, 3).prepare(G.key(1), torch.from_numpy(ys)).noise_ahead
+
+
 def test_noise_ahead_full_size_equals_one_stream(gpu):
     """BASELINE config 2 at full size (1e6 particles x 100 steps): the two forms leave the same particles,
     log-weights, ancestors and integer totals; replaying the captured two-stream graph is deterministic."""
@@ -775,6 +790,25 @@ def test_noise_ahead_full_size_equals_one_stream(gpu):
             again = [v.clone() for v in sw.state()] + [sw.totals.clone(), sw.maxs.clone()]
             assert all(torch.equal(a, b) for a, b in zip(got[-1], again))
     assert all(torch.equal(a, b) for a, b in zip(*got))
+
+
+def test_noise_ahead_beyond_the_fused_resampler(gpu):
+    """n > 2^21: the chain resamples with gmx_weight_cdf + gmx_ancestors (two launches) instead of the tile form;
+    the two-stream sweep still equals the one-stream one, multinomial resampling included."""
+    import genjax_amd as G
+    from genjax_amd import workloads
+    from genjax_amd.inference.smc import BootstrapSweep
+    for n, T, kind in ((2_500_000, 3, "systematic"), (300_000, 4, "multinomial")):
+        ys = workloads.lgssm_data(T)
+        init, step = workloads.make_lgssm(G)
+        got = []
+        for na in (False, True):
+            sw = BootstrapSweep(init, step, n, T, resample=kind, noise_ahead=na).prepare(G.key(5), torch.from_numpy(ys))
+            assert sw.noise_ahead == na and (sw.fused == (kind == "systematic" and n <= 2 ** 21))
+            sw.capture()
+            sw.launch()
+            got.append([v.clone() for v in sw.state()] + [sw.totals.clone()])
+        assert all(torch.equal(a, b) for a, b in zip(*got))
 
 
 def test_tuple_state_sweep_three_site_step_model(gpu):

@@ -631,6 +631,42 @@ def test_full_size_sweep_properties(gpu):
     assert abs(a - kal) < 0.05, (a, kal)
 
 
+def test_full_size_sweep_bit_exact_vs_c_oracle(gpu):
+    """BASELINE config 2 at FULL size (1e6 particles x 100 steps), the sweep bench.py times (noise-ahead form),
+    against oracle/orc_sweep.c — the OpenMP statement of the oracle's sweep, itself held to the numpy oracle in
+    tests/test_oracle_pins.py::test_c_sweep_equals_numpy_sweep: final particles, log-weights, ancestors, and every
+    step's integer total and maximum, bit for bit."""
+    import ctypes
+    import os
+    import genjax_amd as G
+    from genjax_amd import workloads
+    from genjax_amd.inference.smc import BootstrapSweep
+    n, T, seed = 1_000_000, 100, 314159
+    ys = workloads.lgssm_data(T)
+    init, step = workloads.make_lgssm(G)
+    sw = BootstrapSweep(init, step, n, T).prepare(G.key(seed), torch.from_numpy(ys)).capture()
+    assert sw.noise_ahead
+    sw.launch()
+    x, lw, anc = [v.cpu().numpy() for v in sw.state()]
+    so = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_build", "liborc_sweep.so")
+    lib = ctypes.CDLL(so)
+    shift = O.cdf_shift(n)
+    f32, u64, i32 = np.float32, np.uint64, np.int32
+    ox, ox2, olw = np.zeros(n, f32), np.zeros(n, f32), np.zeros(n, f32)
+    ocdf, oanc = np.zeros(n, u64), np.zeros(n, i32)
+    omax, otot = np.zeros(T, f32), np.zeros(T, u64)
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    rc = lib.orc_lgssm_sweep(ctypes.c_int64(n), ctypes.c_int64(T), P(ys), ctypes.c_uint32(0), ctypes.c_uint32(seed),
+                             ctypes.c_float(0.9), ctypes.c_float(0.5), ctypes.c_float(1.0), ctypes.c_float(1.0),
+                             ctypes.c_int(shift), P(ox), P(ox2), P(olw), P(ocdf), P(oanc), P(omax), P(otot))
+    assert rc == 0
+    assert np.array_equal(sw.totals.cpu().numpy().view(np.uint64), otot)
+    assert np.array_equal(sw.maxs.cpu().numpy().view(np.uint32), omax.view(np.uint32))
+    assert np.array_equal(x.view(np.uint32), ox.view(np.uint32))
+    assert np.array_equal(lw.view(np.uint32), olw.view(np.uint32))
+    assert np.array_equal(anc, oanc)
+
+
 def test_empty_batch_on_device(gpu):
     """zero particles: no launch, empty results (a 0-size device tensor has a null pointer)"""
     import genjax_amd as G

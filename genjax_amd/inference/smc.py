@@ -579,31 +579,56 @@ class CapturedLoop:
     valid (and are overwritten in place) across replays.  `result` is whatever the loop returned at capture time —
     its tensors hold the latest replay's values."""
 
-    def __init__(self, loop_fn, *args, warmup: int = 1):
+    def __init__(self, loop_fn, *args, warmup: int = 1, noise_ahead=None):
         be = _lib.get()
         if not be.uses_streams:
             raise _lib.GenmiError("capture needs the HIP backend")
+        if noise_ahead is None:
+            noise_ahead = os.environ.get("GENMI_NOISE_AHEAD", "1") != "0"
+        from contextlib import nullcontext
+        from ..static import NoiseAheadContext
+        # noise ahead (DESIGN.md §4): the draws of the loop's extend / rejuvenate launches by background programs on a
+        # second stream; in the captured graph they depend on nothing but each other and run ahead of the chain
+        self.noise = NoiseAheadContext(torch.cuda.Stream(device=be.device)) if noise_ahead else None
+        scope = self.noise if self.noise is not None else nullcontext()
         side = torch.cuda.Stream(device=be.device)
         side.wait_stream(torch.cuda.current_stream(be.device))
         with torch.cuda.stream(side):           # programs are traced / specialised outside the capture
             for _ in range(max(1, warmup)):
-                loop_fn(*args)
+                with scope:
+                    loop_fn(*args)
+            if self.noise is not None and self.noise.settle():
+                with scope:                      # once more, with the launches that keep their draws as they will run
+                    loop_fn(*args)
+            if self.noise is not None:
+                side.wait_stream(self.noise.stream)
         torch.cuda.current_stream(be.device).wait_stream(side)
         torch.cuda.synchronize(be.device)
+        if self.noise is not None:
+            self.noise.reserve(be.device)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
-            self.result = loop_fn(*args)
+            if self.noise is not None:
+                cur = torch.cuda.current_stream(be.device)
+                self.noise.stream.wait_stream(cur)          # the background stream joins the capture ...
+                self.noise.issue_ahead(be.device)           # ... every recorded noise launch goes out first ...
+                with self.noise:
+                    self.result = loop_fn(*args)
+                cur.wait_stream(self.noise.stream)          # ... and the stream is joined back before the capture ends
+            else:
+                self.result = loop_fn(*args)
 
     def replay(self):
         self.graph.replay()
         return self.result
 
 
-def capture(loop_fn, *args, warmup: int = 1) -> CapturedLoop:
+def capture(loop_fn, *args, warmup: int = 1, noise_ahead=None) -> CapturedLoop:
     """`smc.capture(loop_fn, *args)`: see CapturedLoop.  Host-side reads of device values inside `loop_fn`
     (`.item()`, `float(tensor)`, LogMLOffset.value()) are not capturable — return tensors and read them after
-    `replay()`."""
-    return CapturedLoop(loop_fn, *args, warmup=warmup)
+    `replay()`.  noise_ahead (default: on; GENMI_NOISE_AHEAD=0): launches over >= 2^18 particles take their
+    launch-keyed normal / uniform draws from background programs on a second stream (same values)."""
+    return CapturedLoop(loop_fn, *args, warmup=warmup, noise_ahead=noise_ahead)
 
 
 class BootstrapSweep:

@@ -786,6 +786,136 @@ def _broadcast_score(x, batch, device):
     return torch.full(batch, float(x), dtype=torch.float32, device=device)
 
 
+# ---------------------------------------------------------------------------
+# noise ahead for the functional API (smc.capture): while a NoiseAheadContext is active, generate / simulate / MH
+# launches over at least `min_particles` particles take the draws of their launch-keyed `normal` / `uniform` sites
+# from memory (engine.NoiseHoist) and a BACKGROUND program draws them on the context's stream.  In a captured loop the
+# noise launches depend on nothing but each other, so the graph lets them run ahead of the dependent chain
+# [resample -> rejuvenate -> extend ...] and fill the issue slots its launch boundaries leave idle.
+# ---------------------------------------------------------------------------
+_NOISE_CTX = None
+
+
+class NoiseAheadContext:
+    """RECORD, then REPLAY AHEAD.  An eager pass of the loop under the context launches every background program where
+    its draws are needed (and remembers the sequence: program, keys, buffer size).  For the capture, the whole recorded
+    sequence is issued FIRST on the background stream into one arena — the draws depend on keys only — with an event
+    after each group of launches (groups grow 2, 4, 8, ... up to `group`); the loop's launches then find their draws in
+    the arena and the chain waits for an event only where a new group begins: cross-stream dependencies are the
+    expensive part of a two-stream graph (one per launch made the captured loop SLOWER, 60.6 vs 43.7 us/step on
+    config 3), and a block from the graph's pool must not be used (a noise launch that runs ahead would overwrite a
+    recycled temporary of an earlier step)."""
+
+    def __init__(self, stream, min_particles: int = 1 << 18, lds_pad: int = 56000, group: int = 16, kinds=None):
+        self.stream, self.min_particles, self.lds_pad, self.group = stream, int(min_particles), int(lds_pad), int(group)
+        # which launches hand their draws over: "mh" (rejuvenate: proposal + accept draws), "generate" / "simulate"
+        # (extend, ImportanceK).  The two streams should carry about the same vector work: with an MH move per step,
+        # hoisting everything makes the background stream the bottleneck (config 3 under smc.capture, us/step: one
+        # stream 43.4, all 41.9, generate 40.6, mh 37.7).  GENMI_NOISE_KINDS; default "auto": the MH draws when the
+        # recorded loop has MH moves, the generate / simulate draws otherwise.
+        import os
+        kinds = kinds if kinds is not None else os.environ.get("GENMI_NOISE_KINDS", "auto")
+        self.kinds = tuple(kinds.split(",")) if isinstance(kinds, str) else tuple(kinds)
+        self.plan, self.mode, self.cursor = [], "record", 0
+        self.arena, self.views, self.events = None, [], {}
+
+    def __enter__(self):
+        global _NOISE_CTX
+        self._prev, _NOISE_CTX = _NOISE_CTX, self
+        self.cursor = 0
+        if self.mode == "record":
+            self.plan = []
+        return self
+
+    def __exit__(self, *exc):
+        global _NOISE_CTX
+        _NOISE_CTX = self._prev
+        return False
+
+    def applies(self, key, batch, kind: str = "generate") -> bool:
+        if kind not in self.kinds and "all" not in self.kinds and "auto" not in self.kinds:
+            return False
+        return (key is not None and len(batch) == 1 and int(batch[0]) >= self.min_particles
+                and getattr(key, "_lazy", None) is not None and key._lazy[0] == "split")
+
+    @staticmethod
+    def _sig(nprog, batch, key, n_draws):
+        b = key.binding()
+        return (id(nprog), tuple(batch), int(b[0]), int(b[1]), int(b[2]), int(getattr(key, "_offset", 0)), int(n_draws))
+
+    @property
+    def demand(self) -> int:
+        return sum(e[3] * int(e[1][0]) for e in self.plan)
+
+    def issue_ahead(self, device):
+        """inside the capture, once the background stream has joined it: every recorded launch, now"""
+        off, self.views, self.events = 0, [], {}
+        size, left = 2, 0
+        with torch.cuda.stream(self.stream):
+            for i, (nprog, batch, key, n_draws, _, _) in enumerate(self.plan):
+                if left == 0:
+                    first, left = i, min(size, self.group)
+                    size *= 2
+                n = int(batch[0])
+                z = self.arena[off:off + n_draws * n].view(n_draws, n)
+                off += n_draws * n
+                nprog.run(batch, key, [z[k:k + 1] for k in range(n_draws)])
+                self.views.append([z[k] for k in range(n_draws)])
+                left -= 1
+                if left == 0 or i == len(self.plan) - 1:
+                    ev = torch.cuda.Event()
+                    ev.record(self.stream)
+                    self.events[first] = ev
+        self.mode, self.cursor = "replay", 0
+
+    def settle(self) -> bool:
+        """after a recorded pass under "auto": fix the kinds; True when another eager pass is needed (so that every
+        program variant the capture will launch exists before it starts)"""
+        if "auto" not in self.kinds:
+            return False
+        self.kinds = ("mh",) if any(e[5] == "mh" for e in self.plan) else ("generate", "simulate")
+        return True
+
+    def reserve(self, device):
+        """before the capture: one arena for every draw of the recorded loop"""
+        self.arena = torch.empty((max(self.demand, 1),), dtype=torch.float32, device=device)
+
+    def draw(self, nprog, batch, key, n_draws, kind: str = "generate"):
+        """the [n] views of this launch's draws, ready on the current stream"""
+        n = int(batch[0])
+        cur = torch.cuda.current_stream()
+        if self.mode == "replay":
+            if self.cursor >= len(self.plan) or self.plan[self.cursor][4] != self._sig(nprog, batch, key, n_draws):
+                raise _lib.GenmiError("noise-ahead: the captured loop differs from the eager pass that was recorded")
+            ev = self.events.get(self.cursor)
+            if ev is not None:
+                cur.wait_event(ev)
+            self.cursor += 1
+            return self.views[self.cursor - 1]
+        z = torch.empty((n_draws, n), dtype=torch.float32, device=cur.device)
+        self.stream.wait_stream(cur)          # eager: the block may be a recycled one the current stream still reads
+        z.record_stream(self.stream)
+        self.plan.append((nprog, tuple(batch), key, int(n_draws), self._sig(nprog, batch, key, n_draws), kind))
+        with torch.cuda.stream(self.stream):
+            nprog.run(batch, key, [z[k:k + 1] for k in range(n_draws)])
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        cur.wait_event(ev)
+        return [z[k] for k in range(n_draws)]
+
+
+def _noise_split(tr: Tracing, batch, ctx):
+    """after tracing with a NoiseHoist: (draws, background program or None)"""
+    hoist = tr.graph.__dict__.pop("noise_hoist", None)
+    if hoist is None or not hoist.draws:
+        return (), None
+    q = NoiseProgram(hoist.draws, batch)
+    if _lib.get().uses_streams and not torch.cuda.is_current_stream_capturing():
+        q.comp.set_background(ctx.lds_pad)
+        q.comp.specialize()
+    return tuple(hoist.draws), q
+
+
 def run_gfi(gen_fn, mode, key: Key | None, args, constraint: ChoiceMap | None = None, batch_shape=None,
             weight_stats: bool = False):
     """simulate / generate / assess for any generative function: one launch.
@@ -807,10 +937,15 @@ def run_gfi(gen_fn, mode, key: Key | None, args, constraint: ChoiceMap | None = 
         batch = _infer_batch(flat.leaves)
     specs = tuple(leaf_spec(v, batch) for v in flat.leaves)
     weight_stats = bool(weight_stats and mode == "generate" and len(batch) == 1)
-    ck = (_gfkey(gen_fn), mode, atree, ctree, specs, len(batch), key is not None, weight_stats)
+    na = _NOISE_CTX if (_NOISE_CTX is not None and mode in ("generate", "simulate")
+                        and _NOISE_CTX.applies(key, batch, mode)) else None
+    ck = (_gfkey(gen_fn), mode, atree, ctree, specs, len(batch), key is not None, weight_stats, na is not None)
     ent = _CACHE.get(ck)
     if ent is None:
         tr = Tracing(len(batch))
+        if na is not None:
+            from .engine import NoiseHoist
+            tr.graph.noise_hoist = NoiseHoist(tr, len(specs))
         ctx = _Ctx(tr)
         ctx.store_sites = mode != "assess"
         with T.tracing(tr.graph):
@@ -825,9 +960,10 @@ def run_gfi(gen_fn, mode, key: Key | None, args, constraint: ChoiceMap | None = 
             ro = tr.emit_output(retval) if mode == "assess" else None
             if weight_stats and isinstance(w, Expr) and w.node.op != "CONST":
                 tr.graph.add("REDMAX", (w.node,), dtype="none")
-        ent = (Compiled(tr), otree, wo, so, ro)
+        ent = (Compiled(tr), otree, wo, so, ro) + (_noise_split(tr, batch, na) if na is not None else ((), None))
         _CACHE[ck] = ent
-    comp, otree, wo, so, ro = ent
+    comp, otree, wo, so, ro, draws, nprog = ent
+    leaves = flat.leaves + (na.draw(nprog, batch, key, len(draws), mode) if nprog is not None else [])
     stats = None
     if weight_stats and comp.uses_red:
         n = int(batch[0])
@@ -839,9 +975,9 @@ def run_gfi(gen_fn, mode, key: Key | None, args, constraint: ChoiceMap | None = 
             agg = torch.empty(((n + 1023) // 1024,), dtype=torch.int64, device=be.device)
             stats = (partials, agg, cdf_shift(n), n)
     if stats is not None:
-        outs = comp.run(flat.leaves, batch, key, red_out=stats[0], tile_stats=(stats[1], stats[2]))
+        outs = comp.run(leaves, batch, key, red_out=stats[0], tile_stats=(stats[1], stats[2]))
     else:
-        outs = comp.run(flat.leaves, batch, key)
+        outs = comp.run(leaves, batch, key)
     if mode == "assess":
         score = _broadcast_score(resolve(so, outs, flat.leaves), batch, be.device)
         return score, _tree_materialize(resolve(ro, outs, flat.leaves))
@@ -1157,10 +1293,15 @@ def run_edit(gen_fn, key: Key, trace: Trace, request: EditRequest, argdiffs, mh:
             raise ValueError(f"key batch {key.shape} does not match the trace batch {batch}")
     specs = tuple(leaf_spec(v, batch) for v in flat.leaves)
     tkey = _tangent_key(tangents)
-    ck = (_gfkey(gen_fn), "mh" if mh else "edit", atree, ptree, rkey, specs, tkey, len(batch), key is not None)
+    na = _NOISE_CTX if (_NOISE_CTX is not None and mh and _NOISE_CTX.applies(key, batch, "mh")) else None
+    ck = (_gfkey(gen_fn), "mh" if mh else "edit", atree, ptree, rkey, specs, tkey, len(batch), key is not None,
+          na is not None)
     ent = _CACHE.get(ck)
     if ent is None:
         tr = Tracing(len(batch))
+        if na is not None:
+            from .engine import NoiseHoist
+            tr.graph.noise_hoist = NoiseHoist(tr, len(specs))
         ctx = _Ctx(tr)
         ctx.store_sites = not mh
         with T.tracing(tr.graph):
@@ -1195,10 +1336,10 @@ def run_edit(gen_fn, key: Key, trace: Trace, request: EditRequest, argdiffs, mh:
             else:
                 otree = _emit_rec(tr, rec)
             wo = tr.emit_output(w) if w is not None else None
-        ent = (Compiled(tr), otree, wo, ao)
+        ent = (Compiled(tr), otree, wo, ao) + (_noise_split(tr, batch, na) if na is not None else ((), None))
         _CACHE[ck] = ent
-    comp, otree, wo, ao = ent
-    outs = comp.run(flat.leaves, batch, key)
+    comp, otree, wo, ao, draws, nprog = ent
+    outs = comp.run(flat.leaves + (na.draw(nprog, batch, key, len(draws), "mh") if nprog is not None else []), batch, key)
     new_tr = _build_trace(otree, outs, flat.leaves, args)
     w = resolve(wo, outs, flat.leaves) if wo is not None else 0.0
     w = _broadcast_score(w, batch, be.device)

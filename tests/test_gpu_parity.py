@@ -884,15 +884,48 @@ def test_functional_loop_captured_equals_eager(gpu):
     ref_x = ref.get_particles().get_retval().clone()
     ref_lw = ref.get_log_weights().clone()
     ref_anc = [a.clone() for a in ref_anc]
-    cap = smc.capture(sweep, G.key(11))
-    coll, ancs = cap.replay()
-    torch.cuda.synchronize()
-    assert torch.equal(coll.get_particles().get_retval(), ref_x)
-    assert torch.equal(coll.get_log_weights(), ref_lw)
-    for a, b in zip(ancs, ref_anc):
-        assert torch.equal(a, b)
+    for na in (False, True):        # noise_ahead: the loop's draws by background programs on a second stream
+        cap = smc.capture(sweep, G.key(11), noise_ahead=na)
+        assert (cap.noise is not None and cap.noise.demand > 0) == na
+        for _ in range(2):
+            coll, ancs = cap.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(coll.get_particles().get_retval(), ref_x)
+            assert torch.equal(coll.get_log_weights(), ref_lw)
+            for a, b in zip(ancs, ref_anc):
+                assert torch.equal(a, b)
     # against the oracle's statement of the same loop (ancestors, states, weights bit-exact)
     parity.check_nlssm_mh(n=2000, T=4)
+
+
+def test_captured_loop_without_mh_hoists_the_extension_draws(gpu):
+    """smc.capture(noise_ahead=True) under "auto": a loop with no MH move hands over the draws of its extend /
+    ImportanceK launches instead; replays equal the eager loop bit for bit"""
+    import genjax_amd as G
+    from genjax_amd import workloads
+    from genjax_amd.inference import smc
+    n, T = 300_000, 5
+    ys = workloads.lgssm_data(T)
+    init, step = workloads.make_lgssm(G)
+
+    def sweep(key):
+        for t in range(T):
+            kp, kr, _ = G.split(G.fold_in(key, t), 3)
+            obs = G.ChoiceMap.kw(y=float(ys[t]))
+            if t == 0:
+                coll = smc.ImportanceK(G.Target(init, (), obs), k_particles=n).run_smc(kp)
+            else:
+                coll = smc.resample(kr, coll, "systematic")
+                coll = smc.extend(kp, coll, step, lambda tr_: (tr_.get_retval(),), obs)
+        return coll
+    ref = sweep(G.key(3))
+    ref_x, ref_lw = ref.get_particles().get_retval().clone(), ref.get_log_weights().clone()
+    cap = smc.capture(sweep, G.key(3), noise_ahead=True)
+    assert cap.noise.kinds == ("generate", "simulate") and len(cap.noise.plan) == T
+    for _ in range(2):
+        coll = cap.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(coll.get_particles().get_retval(), ref_x) and torch.equal(coll.get_log_weights(), ref_lw)
 
 
 def test_tile_stats_from_the_site_program(gpu):

@@ -47,20 +47,24 @@ out["config3"] = {"workload": "nonlinear SSM + 1 MH (Gaussian drift 0.5) sweep p
 # the same functional sweep captured ONCE into a hipGraph (torch.cuda.graph sees the C-ABI launches too:
 # they go to torch's current stream) and replayed: device time without the Python dispatch
 try:
-    cap = smc.capture(sweep, G.key(7))
-    gcoll, gacc = cap.replay()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for r in range(10):
-        cap.replay()
-    torch.cuda.synchronize()
-    dtg = (time.perf_counter() - t0) / 10
     ref, _ = sweep(G.key(7))
-    same = bool(torch.equal(ref.get_particles().get_retval(), gcoll.get_particles().get_retval()))
-    out["config3"]["graph_replay"] = {"how": "smc.capture(sweep, key): the functional loop captured once, replayed",
-                                      "ms_per_sweep": 1e3 * dtg, "particle_steps_per_s": n * T / dtg,
-                                      "us_per_step": 1e6 * dtg / T, "same_particles_as_eager": same,
-                                      "log_ml": float(gcoll.get_log_marginal_likelihood_estimate())}
+    ref_x = ref.get_particles().get_retval().clone()
+    for tag, na in (("graph_replay_one_stream", False), ("graph_replay", True)):
+        cap = smc.capture(sweep, G.key(7), noise_ahead=na)
+        gcoll, gacc = cap.replay()
+        torch.cuda.synchronize()
+        same = bool(torch.equal(ref_x, gcoll.get_particles().get_retval()))
+        t0 = time.perf_counter()
+        for r in range(10):
+            cap.replay()
+        torch.cuda.synchronize()
+        dtg = (time.perf_counter() - t0) / 10
+        out["config3"][tag] = {"how": "smc.capture(sweep, key): the functional loop captured once, replayed"
+                                      + ("; its draws by background programs on a second stream (noise ahead)" if na else ""),
+                               "ms_per_sweep": 1e3 * dtg, "particle_steps_per_s": n * T / dtg,
+                               "us_per_step": 1e6 * dtg / T, "same_particles_as_eager": same,
+                               "log_ml": float(gcoll.get_log_marginal_likelihood_estimate())}
+        del cap, gcoll, gacc
 except Exception as e:
     out["config3"]["graph_replay"] = {"error": repr(e)[:300]}
 

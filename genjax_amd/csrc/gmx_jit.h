@@ -123,12 +123,15 @@ struct gmx_jit_ctx {
     uint32_t pre[(NPRE) > 0 ? (NPRE) : 1][PP];                                                   \
     bool act[PP];                                                                                \
     uint32_t gmx_t = 0u;       /* iteration number of the enclosing GMX_JIT_LOOP (0 outside) */   \
+    /* a 2-D launch (gmx_program_run, GMX_KEY_ROWSPLIT background programs): n particles per ROW, blockIdx.y \
+       is the row — row r's particles are rows r * n .. r * n + n - 1 of every leaf */           \
+    const uint32_t row0 = blockIdx.y * n32;                                                      \
     _Pragma("unroll") for (int p = 0; p < PP; ++p) {                                             \
       R[p].init();                                                                               \
       const uint32_t i32 = (blockIdx.x * (uint32_t)PP + (uint32_t)p) * (uint32_t)GMX_BLOCK + threadIdx.x; \
-      idx[p] = (int64_t)i32;                                                                     \
+      idx[p] = (int64_t)(row0 + i32);                                                            \
       act[p] = i32 < n32;                                                                        \
-      cidx[p] = act[p] ? i32 : n32 - 1u;                                                         \
+      cidx[p] = row0 + (act[p] ? i32 : n32 - 1u);                                                \
       arow[p] = 0u;                                                                              \
     }                                                                                            \
     (void)cidx; (void)arow; (void)pre; (void)gmx_t;

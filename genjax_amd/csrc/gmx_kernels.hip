@@ -642,10 +642,20 @@ extern "C" int gmx_program_run(const gmx_program* p, int64_t n, const gmx_run_ar
     size_t ka_size = sizeof(ka);
     void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &ka, HIP_LAUNCH_PARAM_BUFFER_SIZE, &ka_size,
                       HIP_LAUNCH_PARAM_END};
-    unsigned jgrid = (unsigned)((n + (int64_t)GMX_BLOCK * p->jit_pp - 1) / ((int64_t)GMX_BLOCK * p->jit_pp));
+    // A background program over several ROWS of keys (GMX_KEY_ROWSPLIT: the draws of several SMC steps in one
+    // launch) runs as a 2-D grid, one row per blockIdx.y: no division to find a particle's row, and one node
+    // instead of `rows` in a captured graph.  Only programs that read nothing and reduce nothing.
+    int64_t rows = 1, per_row = n;
+    if (p->background && args->key_mode == GMX_KEY_ROWSPLIT && args->key_inner > 0 && n % args->key_inner == 0 &&
+        n / args->key_inner > 1 && n / args->key_inner <= 65535 && p->n_in == 0 && !p->uses_red && !p->uses_step) {
+      rows = n / args->key_inner;
+      per_row = args->key_inner;
+      ka.n = per_row;
+    }
+    unsigned jgrid = (unsigned)((per_row + (int64_t)GMX_BLOCK * p->jit_pp - 1) / ((int64_t)GMX_BLOCK * p->jit_pp));
     unsigned dyn_lds = fused_rs ? (unsigned)gmx_rs_window_lds(n) : 0u;
     if (p->lds_pad > dyn_lds) dyn_lds = p->lds_pad;
-    GMX_HIP(hipModuleLaunchKernel(p->jit_fn, jgrid, 1, 1, GMX_BLOCK, 1, 1, dyn_lds, st, nullptr, config));
+    GMX_HIP(hipModuleLaunchKernel(p->jit_fn, jgrid, (unsigned)rows, 1, GMX_BLOCK, 1, 1, dyn_lds, st, nullptr, config));
     return 0;
   }
   // The interpreter's register file is a 16- or 32-element vector indexed at run time, and the

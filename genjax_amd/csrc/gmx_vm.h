@@ -42,6 +42,15 @@ struct gmx_regs_vgpr {
   GMX_HDM void set(uint32_t i, uint32_t x) { v[i] = x; }
 };
 
+// The row of keys a particle of a GMX_KEY_ROWSPLIT launch draws from.  A 2-D launch (gmx_program_run: background
+// programs, one row of keys per blockIdx.y) knows it; everything else (1-D launches, the tests' CPU mirror) divides.
+GMX_HD int64_t gmx_rowsplit_row(int64_t i, int64_t inner) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (gridDim.y > 1) return (int64_t)blockIdx.y;
+#endif
+  return i / inner;
+}
+
 GMX_HD float gmx_asf(uint32_t u) { return gmx_u2f(u); }
 GMX_HD uint32_t gmx_asu(float f) { return gmx_f2u(f); }
 
@@ -118,7 +127,7 @@ GMX_HD void gmx_vm_step(Regs& R, const W w, int64_t i, bool active, const gmx_ru
         } else if (A.key_mode == GMX_KEY_SPLIT) {
           k = gmx_split_child(k, (uint64_t)(A.index_offset + i));
         } else if (A.key_mode == GMX_KEY_ROWSPLIT) {
-          int64_t row = i / A.key_inner, j = i - row * A.key_inner;
+          int64_t row = gmx_rowsplit_row(i, A.key_inner), j = i - row * A.key_inner;
           if (active) { k.k0 = A.keys_d[2 * row]; k.k1 = A.keys_d[2 * row + 1]; }
           k = gmx_split_child(k, (uint64_t)j);
         }

@@ -800,8 +800,9 @@ class BootstrapSweep:
                 self.noise_groups.append((t0, t1))
                 t0, size = t1, size * 2
             S = max(len(P.noise) for P in chain_progs)
-            # two groups of noise buffers: the background stream fills one while the chain reads the other
-            self.zbuf = torch.zeros((2, self.noise_group, S, n), dtype=torch.float32, device=dev)
+            # two groups of noise buffers: the background stream fills one while the chain reads the other.
+            # [half, draw, row of the group, n]: a draw's rows are contiguous, so ONE launch can fill several steps
+            self.zbuf = torch.zeros((2, S, self.noise_group, n), dtype=torch.float32, device=dev)
             self._noise_stream = torch.cuda.Stream(device=dev) if be.uses_streams else None
             pad = int(os.environ.get("GENMI_NOISE_LDS_PAD", self.NOISE_LDS_PAD))
             for plist in self._noise_progs.values():
@@ -910,7 +911,7 @@ class BootstrapSweep:
     def _noise_views(self, t, count):
         """the [1, n] buffers of step t's draws: half (t // group) % 2 of the ring, row t % group"""
         half, row = self.noise_slot[t]
-        return [self.zbuf[half, row, k:k + 1] for k in range(count)]
+        return [self.zbuf[half, k, row:row + 1] for k in range(count)]
 
     def _noise_leaves(self, t, prog):
         return [v.reshape(self.n) for v in self._noise_views(t, len(prog.noise))]
@@ -921,6 +922,50 @@ class BootstrapSweep:
         if self.fuse_mh:
             return self.p_mhvm_init if t == 1 else self.p_mhvm_step
         return self.p_step
+
+    def _noise_runs(self, g):
+        """The background launches of group g: the steps of a group that share a chain program get their draws from ONE
+        launch per key root — a 2-D grid, one row of keys per step (GMX_KEY_ROWSPLIT; gmx_program_run) — instead of
+        one launch per step: fewer nodes in the graph (the HIP runtime walks a two-stream graph node by node on the
+        host) and no launch boundary between the steps' noise.  GENMI_NOISE_ROWS=0: one launch per step."""
+        cache = self.__dict__.setdefault("_noise_run_cache", {})
+        if g in cache:
+            return cache[g]
+        n = self.n
+        t0, t1 = self.noise_groups[g]
+        runs, ta = [], t0
+        while ta < t1:
+            tb = ta + 1
+            while tb < t1 and self._chain_prog(tb) is self._chain_prog(ta):
+                tb += 1
+            runs.append((ta, tb))
+            ta = tb
+        out = []
+        dev = self.zbuf.device
+        for ta, tb in runs:
+            P = self._chain_prog(ta)
+            half, row_a = self.noise_slot[ta]
+            rows = tb - ta
+            mh = self.fuse_mh and ta >= 1
+            for root, q, idx in self._noise_progs[id(P)]:
+                ks = [self.step_keys[t][2] if (mh and root == "LDKEY") else self.step_keys[t][0] for t in range(ta, tb)]
+                if rows == 1 or rows * n >= 2 ** 31 - 4096:
+                    for r, k in enumerate(ks):
+                        out.append((q, (n,), lazy_split(k, n), [self.zbuf[half, k_, row_a + r:row_a + r + 1] for k_ in idx]))
+                    continue
+                kd = torch.from_numpy(np.stack([k.host() for k in ks]).astype(np.uint32).view(np.int32)).to(dev)
+                key = Key(lazy=("rowsplit", Key(dev=kd), n), split_last=True)
+                out.append((q, (rows * n,), key, [self.zbuf[half, k_, row_a:row_a + rows].reshape(1, rows * n) for k_ in idx]))
+        cache[g] = out
+        return out
+
+    def _launch_noise_group(self, g):
+        if os.environ.get("GENMI_NOISE_ROWS", "1") == "0":
+            for t in range(*self.noise_groups[g]):
+                self._launch_noise(t)
+            return
+        for q, batch, key, outs in self._noise_runs(g):
+            q.run(batch, key, outs)
 
     def _launch_noise(self, t):
         """the draws step t's chain program reads, by the background programs: root LDKEY from the program's launch key
@@ -1084,13 +1129,11 @@ class BootstrapSweep:
                 with torch.cuda.stream(Bs):
                     if g >= 2:
                         Bs.wait_event(done[g - 2])
-                    for t in range(*spans[g]):
-                        self._launch_noise(t)
+                    self._launch_noise_group(g)
                     ready[g] = torch.cuda.Event()
                     ready[g].record(Bs)
             else:
-                for t in range(*spans[g]):
-                    self._launch_noise(t)
+                self._launch_noise_group(g)
 
         noise_group(0)
         for g in range(groups):

@@ -787,6 +787,13 @@ def test_noise_ahead_sweep_matches_oracle(gpu, n, T, capture):
         res = parity.check_lgssm_sweep(n=n, T=T, capture=capture, specialize=True, noise_ahead=na)
         assert res["ancestors_equal"] and res["x_equal"] and res["totals_equal"] and res["lw_max_abs_diff"] == 0.0
         assert abs(res["log_ml"] - res["log_ml_oracle"]) < 1e-11
+    import os
+    os.environ["GENMI_NOISE_ROWS"] = "0"            # one noise launch per step instead of one per group and key
+    try:
+        res = parity.check_lgssm_sweep(n=n, T=T, capture=capture, specialize=True, noise_ahead=True)
+        assert res["ancestors_equal"] and res["x_equal"] and res["totals_equal"] and res["lw_max_abs_diff"] == 0.0
+    finally:
+        del os.environ["GENMI_NOISE_ROWS"]
 
 
 def test_noise_ahead_with_stratified_resampling_and_env_switch(gpu, monkeypatch):

@@ -989,11 +989,14 @@ def test_tuple_state_sweep_matches_oracle():
     parity.check_tuple_state_sweep()
 
 
-def test_noise_ahead_sweep_matches_oracle():
+@pytest.mark.parametrize("rows", ["1", "0"])
+def test_noise_ahead_sweep_matches_oracle(monkeypatch, rows):
     """BootstrapSweep(noise_ahead=True): the steps' normal draws come from background programs (static.NoiseProgram),
     the site programs read them (MinimalGenerate(hoist_noise=True)); same particles, weights, ancestors and evidence
-    as the oracle's sweep — T not a multiple of the noise group, one / three latent sites per step."""
+    as the oracle's sweep — T not a multiple of the noise group, one / three latent sites per step.  GENMI_NOISE_ROWS:
+    the draws of a group's steps from ONE launch per key (rows of keys, GMX_KEY_ROWSPLIT) or one launch per step."""
     from tests import parity
+    monkeypatch.setenv("GENMI_NOISE_ROWS", rows)
     res = parity.check_lgssm_sweep(n=3000, T=23, noise_ahead=True)
     assert res["ancestors_equal"] and res["x_equal"] and res["totals_equal"] and res["lw_max_abs_diff"] == 0.0
     # the same integer totals; 23 float64 terms summed pairwise (numpy) here and one after the other in the oracle

@@ -40,8 +40,8 @@ T_STEPS = 100
 VM_VALU_PER_WAVE = 325.65           # VALU instructions per 64 particles: SQ_INSTS_VALU / waves / 4 particles per
                                     # thread (1302.6 per wave, profiles/r02c_pmc_summary.txt; 1438.6 before the
                                     # one-instruction DPP scans / integer fixed-point weights, 1496.7 at the end of round 1)
-# the noise-ahead (two-stream) sweep, SQ_INSTS_VALU per wave of 256 particles (profiles/r02f_pmc_summary.txt):
-NA_VALU_PER_WAVE = {"gmx_jit_background_kernel": 1120.9, "gmx_jit_kernel": 210.7, "k_offspring_tile": 540.8}
+# the noise-ahead (two-stream) sweep, SQ_INSTS_VALU per wave of 256 particles (profiles/r02h_pmc_summary.txt):
+NA_VALU_PER_WAVE = {"gmx_jit_background_kernel": 1135.8, "gmx_jit_kernel": 210.7, "k_offspring_tile": 540.8}
 VALU_PEAK_LANE_OPS = 256 * 4 * 16 * 2.4e9   # integer / unpacked-f32 vector instructions: 16 lanes per clock per SIMD (a
                                             # wave64 instruction holds its SIMD for 4 cycles; only packed f32 math doubles
                                             # that).  tools/calib.hip on MI355X (profiles/r02_calib.txt): one Threefry-like
@@ -345,7 +345,7 @@ def main():
                 "frac": noise_rate / VALU_PEAK_LANE_OPS, "traffic": traffic_noise,
                 "limiter": "vector-instruction issue (16 lanes/clk/SIMD for integer and unpacked f32): the whole sweep "
                            "keeps the vector ALUs busy for sweep.valu_frac of the time",
-                "valu_source": "instructions per wave: SQ_INSTS_VALU of profiles/r02f_pmc_summary.txt (constants in "
+                "valu_source": "instructions per wave: SQ_INSTS_VALU of profiles/r02h_pmc_summary.txt (constants in "
                                "bench.py, not measured in this run); durations: HIP events in this run",
                 "traffic_source": "profiles/traffic.json (rocprofv3 TCC passes of an earlier run of this workload, "
                                   "calibrated against copy kernels; NOT measured in this run); the noise program writes "

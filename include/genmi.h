@@ -185,6 +185,9 @@ int gmx_program_fuses_resample(const gmx_program* p);
  * specialised kernel keeps wave priority 0 (the chain's kernels raise theirs) and every launch asks for `lds_pad`
  * bytes of dynamic LDS it never touches — a cap on the workgroups of this kernel a CU holds (160 KB of LDS per CU),
  * so that the chain's kernels always find wave slots.  No effect on results, nor on the interpreter.
+ * A background program that reads no per-particle input and reduces nothing, run with GMX_KEY_ROWSPLIT keys over
+ * n = rows x key_inner particles (rows <= 65535), is launched as a 2-D grid, one row of keys per blockIdx.y: the
+ * draws of `rows` SMC steps from one launch, output leaves laid out [rows, key_inner].
  * (No reference counterpart: XLA schedules its fused loops itself.) */
 int gmx_program_set_background(gmx_program* p, uint32_t lds_pad);
 int gmx_program_run(const gmx_program* p, int64_t n, const gmx_run_args* args_h,

@@ -41,7 +41,7 @@ VM_VALU_PER_WAVE = 325.65           # VALU instructions per 64 particles: SQ_INS
                                     # thread (1302.6 per wave, profiles/r02c_pmc_summary.txt; 1438.6 before the
                                     # one-instruction DPP scans / integer fixed-point weights, 1496.7 at the end of round 1)
 # the noise-ahead (two-stream) sweep, SQ_INSTS_VALU per wave of 256 particles (profiles/r02h_pmc_summary.txt):
-NA_VALU_PER_WAVE = {"gmx_jit_background_kernel": 1135.8, "gmx_jit_kernel": 210.7, "k_offspring_tile": 540.8}
+NA_VALU_PER_WAVE = {"gmx_jit_background_kernel": 1135.8, "gmx_jit_kernel": 216.6, "k_offspring_tile": 540.8}
 VALU_PEAK_LANE_OPS = 256 * 4 * 16 * 2.4e9   # integer / unpacked-f32 vector instructions: 16 lanes per clock per SIMD (a
                                             # wave64 instruction holds its SIMD for 4 cycles; only packed f32 math doubles
                                             # that).  tools/calib.hip on MI355X (profiles/r02_calib.txt): one Threefry-like

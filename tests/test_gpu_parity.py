@@ -52,6 +52,19 @@ def test_jax_docs_values_on_device(gpu):
     import numpy
     allatonce = G.normal.sample(k, numpy.zeros(3, numpy.float32), 1.0).cpu().numpy()
     assert np.all(np.abs(allatonce.reshape(-1).astype(np.float64) - [-0.02830462, 0.46713185, 0.29570296]) < 5.1e-9)
+    # the tutorial's loop of splits: draw 0 / 1 / 2 exactly as printed
+    draws, kk = [], k
+    for _ in range(3):
+        kk, sub = G.split(kk)
+        draws.append(repr(float(G.normal.sample(sub, 0.0, 1.0))))
+    assert draws == ["0.6057640314102173", "-0.21089035272598267", "-0.3948981463909149"]
+    # "The Sharp Bits" (jax >= 0.5 edition): key(0) -> normal [1.6226422]; split -> [1797259609 2579123966],
+    # [928981903 3453687069] --> normal [-2.4424558]
+    k0 = G.key(0)
+    assert G.normal.sample(k0, numpy.zeros(1, numpy.float32), 1.0).cpu().numpy().reshape(-1).tolist() == [float(np.float32(1.6226422))]
+    ks0 = G.split(k0)
+    assert ks0.data().cpu().numpy().view(np.uint32).reshape(2, 2).tolist() == [[1797259609, 2579123966], [928981903, 3453687069]]
+    assert G.normal.sample(ks0[1], numpy.zeros(1, numpy.float32), 1.0).cpu().numpy().reshape(-1).tolist() == [float(np.float32(-2.4424558))]
 
 
 def _models(g):

@@ -320,6 +320,21 @@ def test_jax_docs_partitionable_prng_values():
     # (element j of a vector draw takes counter j under the SAME key)
     allatonce = O.normal.sample(k, np.zeros(3, np.float32), np.float32(1))
     assert np.all(np.abs(allatonce.astype(np.float64) - [-0.02830462, 0.46713185, 0.29570296]) < 5.1e-9)
+    # the same tutorial's loop  `new_key, subkey = split(key); val = normal(subkey); key = new_key`  prints
+    #   draw 0: 0.6057640314102173 / draw 1: -0.21089035272598267 / draw 2: -0.3948981463909149
+    # (a CHAIN of splits in the partitionable layout: child 0 carries on, child 1 draws)
+    draws, kk = [], k
+    for _ in range(3):
+        kk, sub = O.split(kk)
+        draws.append(repr(float(O.normal.sample(sub, np.float32(0), np.float32(1)))))
+    assert draws == ["0.6057640314102173", "-0.21089035272598267", "-0.3948981463909149"]
+    # "The Sharp Bits", jax >= 0.5 edition: key = random.key(0); random.normal(key, shape=(1,)) -> [1.6226422];
+    # key, subkey = split(key): new key [1797259609 2579123966], new subkey [928981903 3453687069] --> normal [-2.4424558]
+    k0 = O.key(0)
+    assert O.normal.sample(k0, np.zeros(1, np.float32), np.float32(1)).tolist() == [float(np.float32(1.6226422))]
+    nk, sk = O.split(k0)
+    assert nk.tolist() == [1797259609, 2579123966] and sk.tolist() == [928981903, 3453687069]
+    assert O.normal.sample(sk, np.zeros(1, np.float32), np.float32(1)).tolist() == [float(np.float32(-2.4424558))]
 
 
 @pytest.mark.parametrize("n", [1, 5, 1023, 1024, 1025, 5000, 100_003])

@@ -602,6 +602,10 @@ class CapturedLoop:
                     loop_fn(*args)
             if self.noise is not None:
                 side.wait_stream(self.noise.stream)
+                # every draw of the loop lives in one arena for the graph's lifetime: bounded (GENMI_NOISE_ARENA_MB)
+                if 4 * self.noise.demand > int(os.environ.get("GENMI_NOISE_ARENA_MB", 16384)) << 20:
+                    self.noise = None
+                    loop_fn(*args)               # the plain programs must exist before the capture too
         torch.cuda.current_stream(be.device).wait_stream(side)
         torch.cuda.synchronize(be.device)
         if self.noise is not None:

@@ -948,6 +948,39 @@ def test_captured_loop_without_mh_hoists_the_extension_draws(gpu):
         assert torch.equal(coll.get_particles().get_retval(), ref_x) and torch.equal(coll.get_log_weights(), ref_lw)
 
 
+def test_captured_loop_noise_ahead_edges(gpu, monkeypatch):
+    """smc.capture(noise_ahead=True): launches below 2^18 particles keep their draws (empty plan, same results); an
+    arena bound of 0 MB falls back to the one-stream capture."""
+    import genjax_amd as G
+    from genjax_amd import workloads
+    from genjax_amd.inference import smc
+    ys = workloads.lgssm_data(3)
+    init, step = workloads.make_lgssm(G)
+
+    def make(n):
+        def sweep(key):
+            for t in range(3):
+                kp, kr, _ = G.split(G.fold_in(key, t), 3)
+                obs = G.ChoiceMap.kw(y=float(ys[t]))
+                if t == 0:
+                    coll = smc.ImportanceK(G.Target(init, (), obs), k_particles=n).run_smc(kp)
+                else:
+                    coll = smc.extend(kp, smc.resample(kr, coll, "systematic"), step, lambda tr_: (tr_.get_retval(),), obs)
+            return coll
+        return sweep
+    small = make(50_000)
+    ref = small(G.key(9)).get_particles().get_retval().clone()
+    cap = smc.capture(small, G.key(9), noise_ahead=True)
+    assert cap.noise is not None and cap.noise.plan == []
+    assert torch.equal(cap.replay().get_particles().get_retval(), ref)
+    big = make(300_000)
+    ref = big(G.key(9)).get_particles().get_retval().clone()
+    monkeypatch.setenv("GENMI_NOISE_ARENA_MB", "0")
+    cap = smc.capture(big, G.key(9), noise_ahead=True)
+    assert cap.noise is None
+    assert torch.equal(cap.replay().get_particles().get_retval(), ref)
+
+
 def test_tile_stats_from_the_site_program(gpu):
     """the specialised program's epilogue writes the same (m_b, A_b) as gmx_tile_stats, ragged last tile included"""
     import genjax_amd as G

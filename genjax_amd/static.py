@@ -847,25 +847,54 @@ class NoiseAheadContext:
     def demand(self) -> int:
         return sum(e[3] * int(e[1][0]) for e in self.plan)
 
+    def _schedule(self, device):
+        """the recorded launches as groups (2, 4, 8, ... up to self.group launches, an event after each); consecutive
+        launches of one program within a group become ONE launch over rows of keys (a 2-D grid, GMX_KEY_ROWSPLIT;
+        gmx_program_run): fewer nodes for the runtime to walk when the graph is replayed.  Built BEFORE the capture
+        (the rows' keys are uploaded here)."""
+        from .random import Key as _Key
+        groups, size, i = [], 2, 0
+        while i < len(self.plan):
+            last = min(len(self.plan), i + min(size, self.group))
+            runs = []
+            while i < last:
+                nprog, batch, key, n_draws = self.plan[i][:4]
+                j = i + 1
+                while (j < last and self.plan[j][0] is nprog and self.plan[j][1] == batch and self.plan[j][3] == n_draws
+                       and int(getattr(self.plan[j][2], "_offset", 0)) == 0 and int(getattr(key, "_offset", 0)) == 0):
+                    j += 1
+                rows, n = j - i, int(batch[0])
+                rk = None
+                if rows > 1 and rows * n < 2 ** 31 - 4096:
+                    kd = np.stack([self.plan[i + r][2]._lazy[1].host() for r in range(rows)]).astype(np.uint32)
+                    rk = _Key(lazy=("rowsplit", _Key(dev=torch.from_numpy(kd.view(np.int32)).to(device)), n), split_last=True)
+                runs.append((i, j, rk))
+                i = j
+            groups.append(runs)
+            size *= 2
+        return groups
+
     def issue_ahead(self, device):
         """inside the capture, once the background stream has joined it: every recorded launch, now"""
-        off, self.views, self.events = 0, [], {}
-        size, left = 2, 0
+        off, self.views, self.events = 0, [None] * len(self.plan), {}
         with torch.cuda.stream(self.stream):
-            for i, (nprog, batch, key, n_draws, _, _) in enumerate(self.plan):
-                if left == 0:
-                    first, left = i, min(size, self.group)
-                    size *= 2
-                n = int(batch[0])
-                z = self.arena[off:off + n_draws * n].view(n_draws, n)
-                off += n_draws * n
-                nprog.run(batch, key, [z[k:k + 1] for k in range(n_draws)])
-                self.views.append([z[k] for k in range(n_draws)])
-                left -= 1
-                if left == 0 or i == len(self.plan) - 1:
-                    ev = torch.cuda.Event()
-                    ev.record(self.stream)
-                    self.events[first] = ev
+            for runs in self.schedule:
+                for i, j, rk in runs:
+                    nprog, batch, key, n_draws = self.plan[i][:4]
+                    rows, n = j - i, int(batch[0])
+                    z = self.arena[off:off + n_draws * rows * n].view(n_draws, rows, n)
+                    off += n_draws * rows * n
+                    if rk is None:
+                        for r in range(rows):
+                            e = self.plan[i + r]
+                            e[0].run(e[1], e[2], [z[k, r:r + 1] for k in range(n_draws)])
+                    else:
+                        nprog.run((rows * n,), rk, [z[k].reshape(1, rows * n) for k in range(n_draws)])
+                    for r in range(rows):
+                        self.views[i + r] = [z[k, r] for k in range(n_draws)]
+                ev = torch.cuda.Event()
+                ev.record(self.stream)
+                self.events[runs[0][0]] = ev
         self.mode, self.cursor = "replay", 0
 
     def settle(self) -> bool:
@@ -877,7 +906,8 @@ class NoiseAheadContext:
         return True
 
     def reserve(self, device):
-        """before the capture: one arena for every draw of the recorded loop"""
+        """before the capture: one arena for every draw of the recorded loop, and the launch schedule"""
+        self.schedule = self._schedule(device)
         self.arena = torch.empty((max(self.demand, 1),), dtype=torch.float32, device=device)
 
     def draw(self, nprog, batch, key, n_draws, kind: str = "generate"):

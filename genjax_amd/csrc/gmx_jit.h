@@ -18,6 +18,7 @@
 #pragma once
 #include "gmx_block.h"
 #include "gmx_vm.h"
+#include "gmx_math2.h"
 #if defined(GMX_JIT_RS)      /* gmx_program_specialize under GENMI_FUSE_RESAMPLE=1: the kernel can resample first */
 #include "gmx_resample.h"
 extern __shared__ __attribute__((aligned(16))) char gmx_dyn_lds[];   // gmx_rs_window_lds(n) bytes when A.rs.lw_d is set
@@ -168,6 +169,31 @@ struct gmx_jit_ctx {
     _Pragma("unroll") for (int p = 0; p < PP; ++p) {                                             \
       ctx.part = blockIdx.x * PP + p; ctx.first = (p == 0); ctx.last = (p == PP - 1); ctx.cur = p; \
       gmx_vm_step<regs_t, full_v, gmx_cword<W0, W1>, ctx_t>(R[p], gmx_cword<W0, W1>(), idx[p], act[p], A, ctx, gmx_t); \
+    }
+
+// OP_S_NORMAL for the thread's particles two at a time (gmx_math2.h: packed f32 arithmetic, the same bits): the keys
+// and operands are read exactly as gmx_vm_step reads them, each draw's 32 bits come from its own Threefry block, the
+// float pipeline runs on pairs, and `z * scale + loc` (gmx_normal_sample's two operations) finishes each particle.
+// Emitted by gmx_program_specialize instead of GMX_JIT_OP when PP is even.
+#define GMX_JIT_NORMAL2(W0, W1)                                                                  \
+    {                                                                                            \
+      constexpr uint32_t nw0 = (W0), nw1 = (W1);                                                 \
+      constexpr uint32_t nd = (nw0 >> 8) & 0xffu, na = (nw0 >> 16) & 0xffu, nb = nw0 >> 24;      \
+      constexpr uint32_t nc = nw1 & 0xffu, ne = nw1 >> 8;                                        \
+      uint32_t nbits[PP];                                                                        \
+      _Pragma("unroll") for (int p = 0; p < PP; ++p) {                                           \
+        gmx_key k; k.k0 = R[p].get(nc); k.k1 = R[p].get(nc + 1u);                                \
+        nbits[p] = gmx_bits32(k, (uint64_t)ne);                                                  \
+      }                                                                                          \
+      _Pragma("unroll") for (int p = 0; p + 1 < PP; p += 2) {                                    \
+        const gmx_f2 z = gmx_std_normal_from_bits2(nbits[p], nbits[p + 1]);                      \
+        _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                          \
+          const float loc = gmx_asf(na < GMX_POOL_BASE ? R[p + h].get(na) : ctx.pool(na - GMX_POOL_BASE));   \
+          const float scale = gmx_asf(nb < GMX_POOL_BASE ? R[p + h].get(nb) : ctx.pool(nb - GMX_POOL_BASE)); \
+          const float v = (h == 0 ? z.x : z.y) * scale;                                          \
+          R[p + h].set(nd, gmx_asu(v + loc));                                                    \
+        }                                                                                        \
+      }                                                                                          \
     }
 
 // OP_LOOP / OP_ENDLOOP: a counted loop around the instructions in between (launch-uniform trip count)

@@ -280,6 +280,16 @@ static bool jit_with_rs() {
   return e && e[0] == '1';
 }
 
+// GENMI_JIT_PAIR_NORMALS=1 (read when a program is specialised; OFF by default): normal draws two particles at a time
+// through the packed sampler (csrc/gmx_math2.h) instead of the scalar one — the same bits (the GPU parity suite passes
+// either way), 86 vector instructions fewer in the noise program, and SLOWER on MI355X (config 2: 16.55 vs 16.05
+// us/step noise-ahead, 18.9 vs 18.4 one-stream): the sampler is one dependent chain, and a dependent v_pk_fma_f32
+// issues at half the rate of a dependent v_fma_f32 (tools/calib.hip: one FMA chain 32.5 T, four 66.4 T).
+static bool jit_pair_normals() {
+  const char* e = getenv("GENMI_JIT_PAIR_NORMALS");
+  return e && e[0] == '1';
+}
+
 static std::string jit_source(const gmx_program* p, bool* gathers_prefetched = nullptr) {
   std::string s = jit_with_rs() ? "#define GMX_JIT_RS 1\n" : "";
   if (p->background) s += "#define GMX_JIT_BACKGROUND 1\n";
@@ -349,6 +359,8 @@ static std::string jit_source(const gmx_program* p, bool* gathers_prefetched = n
       snprintf(buf, sizeof(buf), "  GMX_JIT_ENDLOOP\n");
     else if (pre_of[pc] >= 0)
       snprintf(buf, sizeof(buf), "  GMX_JIT_LDPRE(%u, %d)\n", (p->code_h[2 * pc] >> 8) & 0xffu, pre_of[pc]);
+    else if (op_ == OP_S_NORMAL && jit_pp_for(p) % 2 == 0 && jit_pair_normals())
+      snprintf(buf, sizeof(buf), "  GMX_JIT_NORMAL2(0x%08xu, 0x%08xu)\n", p->code_h[2 * pc], p->code_h[2 * pc + 1]);
     else
       snprintf(buf, sizeof(buf), "  GMX_JIT_OP(0x%08xu, 0x%08xu)\n", p->code_h[2 * pc], p->code_h[2 * pc + 1]);
     s += buf;

@@ -824,6 +824,22 @@ def test_noise_ahead_with_stratified_resampling_and_env_switch(gpu, monkeypatch)
     assert not BootstrapSweep(init, step, 4096, 3).prepare(G.key(1), torch.from_numpy(ys)).noise_ahead
 
 
+def test_paired_normal_sampler_same_bits(gpu, monkeypatch):
+    """GENMI_JIT_PAIR_NORMALS=1: specialised kernels draw normals two particles at a time through packed f32
+    arithmetic (csrc/gmx_math2.h) — every operation the scalar sampler's, so the sweep still equals the oracle's bit
+    for bit (one-stream: draws inside the site program; noise ahead: inside the background programs)."""
+    import genjax_amd as G
+    monkeypatch.setenv("GENMI_JIT_PAIR_NORMALS", "1")
+    monkeypatch.setenv("GENMI_JIT_CACHE", "0")
+    G.clear_caches()
+    try:
+        for na in (False, True):
+            res = parity.check_lgssm_sweep(n=100_003, T=6, capture=True, specialize=True, noise_ahead=na)
+            assert res["ancestors_equal"] and res["x_equal"] and res["totals_equal"] and res["lw_max_abs_diff"] == 0.0
+    finally:
+        G.clear_caches()
+
+
 def test_noise_ahead_full_size_equals_one_stream(gpu):
     """BASELINE config 2 at full size (1e6 particles x 100 steps): the two forms leave the same particles,
     log-weights, ancestors and integer totals; replaying the captured two-stream graph is deterministic."""

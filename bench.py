@@ -7,7 +7,9 @@ One "step" of this harness = one whole sweep (N * T particle-steps), issued as
 one hipGraph replay with every input already resident in HBM.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: launched by torch.distributed.run, one rank per GPU)
+  (N > 1: one rank per GPU — either launched by torch.distributed.run, or bare: without WORLD_SIZE in the
+   environment this process only spawns the N ranks (spawn_ranks; it never touches a GPU itself) and relays
+   rank 0's JSON line)
 
 N > 1 is STRONG scaling by default — BASELINE's metric: the same 1e6-particle sweep split over the N ranks
 (contiguous blocks of global particle indices; the total is rounded up to a multiple of N x 1024 because a shard
@@ -133,6 +135,53 @@ def cpu_baseline(n, T, ys, seed, budget_s=25.0):
     return out
 
 
+def spawn_ranks(world: int) -> int:
+    """`python bench.py --gpus N` with no launcher: THIS process becomes the launcher.  It never imports torch, never
+    loads the HIP library and never touches a GPU; it starts N children of the same command line — one rank per GPU,
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT in their environment, exactly what
+    `torch.distributed.run --nproc-per-node N` would set — relays rank 0's stdout (the ONE JSON line) and returns
+    non-zero if any rank does.  Children are started as child processes (never exec'd over a process that has
+    initialised the GPU) and are ended by their exact PIDs if one of them fails."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    script = os.environ.get("GENMI_BENCH_ENTRY", os.path.abspath(__file__))     # tests: tests/bench_on_cpu.py
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GENMI_BENCH_SPAWNED="1")
+        env.setdefault("OMP_NUM_THREADS", "1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # rank 0's stdout is this process's stdout; the other ranks print nothing there (their fd 1 -> stderr)
+        procs.append(subprocess.Popen([sys.executable, script] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    live = list(procs)
+    while live:
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                sys.stderr.write(f"bench.py: rank {procs.index(p)} exited with status {code}; ending the other ranks\n")
+                for q in live:
+                    q.terminate()
+        if live:
+            time.sleep(0.05)
+            if rc != 0:
+                deadline = time.time() + 20
+                while any(q.poll() is None for q in live) and time.time() < deadline:
+                    time.sleep(0.1)
+                for q in live:
+                    if q.poll() is None:
+                        q.kill()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -147,6 +196,10 @@ def main():
                     help="N > 1: --particles PER GPU (weak scaling) instead of in total (strong scaling, the default)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: spawn the ranks BEFORE anything here imports torch or touches the GPU
+        raise SystemExit(spawn_ranks(args.gpus))
+
     # stdout carries exactly ONE line, the JSON: everything else that writes to fd 1 (the RCCL
     # banner librccl prints on communicator creation, library chatter) is sent to stderr
     import ctypes
@@ -159,8 +212,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} inside a job of WORLD_SIZE={world}: they must agree")
     # The C-ABI backend decides where this runs: genjax_amd._lib.get() loads the HIP library and fails loudly
     # without a GPU.  (tests/bench_on_cpu.py installs the tests' CPU mirror of the C-ABI BEFORE running this file,
     # to exercise the launch / barrier / reporting logic under gloo; nothing here knows about it.)

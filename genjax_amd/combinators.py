@@ -541,13 +541,14 @@ class Scan(GenerativeFunction):
             ntree = flat_carry(carry_out, new_leaves)
             if _shape_of(ntree) != _shape_of(ctree):
                 raise TypeError("scan: the kernel must return a carry of the same structure as it received")
-            for var, e in zip(cvars, new_leaves):
-                g.set_var(var, e.node)
+            # a PARALLEL copy: a new carry may forward another carry variable ((x_new, a) from (a, b), a swap)
+            updates = [(var, e.node) for var, e in zip(cvars, new_leaves)]
             if wvar is not None and w is not None:
-                g.set_var(wvar, (Expr(wvar) + w).node)
-            g.set_var(svar, (Expr(svar) + score_t).node)
+                updates.append((wvar, (Expr(wvar) + w).node))
+            updates.append((svar, (Expr(svar) + score_t).node))
             if kvar is not None:
-                g.set_var(kvar, k_t.node)
+                updates.append((kvar, k_t.node))
+            g.set_vars(updates)
         g.loop_end()
         ctx.store_sites = keep
 
@@ -809,13 +810,13 @@ class Scan(GenerativeFunction):
             ntree = flat_carry(carry_out, new_leaves)
             if _shape_of(ntree) != _shape_of(ctree):
                 raise TypeError("scan: the kernel must return a carry of the same structure as it received")
-            for var, e in zip(cvars, new_leaves):
-                g.set_var(var, e.node)
+            updates = [(var, e.node) for var, e in zip(cvars, new_leaves)]      # a parallel copy, as in _trace_loop
             if w is not None:
-                g.set_var(wvar, (Expr(wvar) + w).node)
-            g.set_var(svar, (Expr(svar) + score_t).node)
+                updates.append((wvar, (Expr(wvar) + w).node))
+            updates.append((svar, (Expr(svar) + score_t).node))
             if kvar is not None:
-                g.set_var(kvar, k_t.node)
+                updates.append((kvar, k_t.node))
+            g.set_vars(updates)
         g.loop_end()
         ctx.store_sites = keep
 

@@ -53,27 +53,58 @@ class Gathered:
         return gather_leaves([self.source], self.ancestors)[0]
 
 
-class Broadcast:
-    """A tensor marked LAUNCH-UNIFORM whatever its shape: `vmap(f, in_axes=(0, None))` wraps its un-mapped tensor
-    arguments in this, so a vector whose length happens to equal the particle count is still one vector shared by
-    all particles (without the marker, batching is inferred from the leading shape)."""
-    __slots__ = ("t",)
+class Broadcast(torch.Tensor):
+    """A tensor marked LAUNCH-UNIFORM whatever its shape: `vmap(f, in_axes=(0, None))` marks its un-mapped tensor
+    arguments with this, so a vector whose length happens to equal the particle count is still one vector shared by
+    all particles (without the marker, batching is inferred from the leading shape).  It IS a tensor (a subclass), so
+    the mapped function may compute with it before handing it to a generative function (`w * 2.0`, `w + 1.0`): the
+    result of an operation whose tensor operands are ALL launch-uniform stays marked, anything mixed with an
+    ordinary (per-instance) tensor is an ordinary tensor."""
+
+    @staticmethod
+    def __new__(cls, t):
+        return t if isinstance(t, Broadcast) else t.as_subclass(cls)
 
     def __init__(self, t):
-        self.t = t.t if isinstance(t, Broadcast) else t
+        pass
 
     @property
-    def shape(self):
-        return tuple(self.t.shape)
+    def plain(self) -> torch.Tensor:
+        return self.as_subclass(torch.Tensor)
 
-    @property
-    def dtype(self):
-        return self.t.dtype
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        shared = [True]
+
+        def look(v):
+            if isinstance(v, torch.Tensor):
+                if not isinstance(v, Broadcast):
+                    shared[0] = False
+            elif isinstance(v, (tuple, list)):
+                for x in v:
+                    look(x)
+        look(args)
+        look(tuple(kwargs.values()))
+        with torch._C.DisableTorchFunctionSubclass():
+            out = func(*args, **kwargs)
+        if not shared[0] or func in torch.overrides.get_default_nowrap_functions():
+            return out
+
+        def mark(v):
+            if isinstance(v, torch.Tensor) and not isinstance(v, Broadcast):
+                return v.as_subclass(cls)
+            if isinstance(v, tuple):
+                return tuple(mark(x) for x in v)
+            if isinstance(v, list):
+                return [mark(x) for x in v]
+            return v
+        return mark(out)
 
 
 def materialize(v):
     if isinstance(v, Broadcast):
-        return v.t
+        return v.plain
     return v.materialize() if isinstance(v, Gathered) else v
 
 
@@ -104,7 +135,7 @@ def leaf_spec(v, batch: tuple):
     if isinstance(v, (float, np.floating)):
         return ("uni", "f32")
     if isinstance(v, Broadcast):
-        t = v.t
+        t = v.plain
         dt = _TDT[t.dtype]
         if t.ndim == 0:
             return ("bcast", dt)
@@ -516,6 +547,50 @@ JIT_MIN_WORK = 1 << 22          # cumulative particles after which a repeatedly 
 JIT_MIN_PARTICLES = 1 << 18
 
 
+# Programs launched while a stream capture is in progress belong to the graph being built: the graph's kernel nodes
+# point into the program's device code buffer / hiprtc module, so whoever owns the graph must keep the `Compiled`
+# objects alive (smc.CapturedLoop does, through `holding_captured_programs`) — the program caches are bounded LRUs and
+# `clear_caches()` is public, so a cache entry is not a lifetime guarantee.
+_CAPTURE_HOLDERS: list = []
+_PENDING_DESTROY: list = []
+
+
+class holding_captured_programs:
+    """with holding_captured_programs() as held: ... every Compiled launched under an active stream capture inside the
+    block is appended to `held` (once)."""
+
+    def __enter__(self):
+        self.held = []
+        _CAPTURE_HOLDERS.append(self.held)
+        return self.held
+
+    def __exit__(self, *exc):
+        _CAPTURE_HOLDERS.remove(self.held)
+        return False
+
+
+def _capturing(be) -> bool:
+    return bool(be.uses_streams) and torch.cuda.is_current_stream_capturing()
+
+
+def _destroy_program(be, handle):
+    """gmx_program_destroy frees device memory and unloads a module: not while a stream capture is in progress (a
+    hipFree inside a capture invalidates it) — such a release is deferred to the next launch outside a capture."""
+    try:
+        if _capturing(be):
+            _PENDING_DESTROY.append((be, handle))
+            return
+    except Exception:
+        pass
+    be.c.gmx_program_destroy(handle)
+
+
+def _drain_pending_destroys():
+    while _PENDING_DESTROY:
+        be, handle = _PENDING_DESTROY.pop()
+        be.c.gmx_program_destroy(handle)
+
+
 class Compiled:
     """A created program + its binding plan."""
 
@@ -551,7 +626,7 @@ class Compiled:
         self._be = be
         self._jit_tried = False
         # the device code buffer and the specialised module go when the last reference to this object does
-        self._finalizer = weakref.finalize(self, be.c.gmx_program_destroy, handle)
+        self._finalizer = weakref.finalize(self, _destroy_program, be, handle)
         self._finalizer.atexit = False       # at interpreter exit the process (and the HIP runtime) goes anyway
 
     def close(self):
@@ -602,6 +677,13 @@ class Compiled:
         be = self._be
         if int(bound[0]) == 0:
             return          # an empty batch (jax.vmap over zero keys): the outputs are empty tensors already
+        if _CAPTURE_HOLDERS or _PENDING_DESTROY:
+            if _capturing(be):
+                for held in _CAPTURE_HOLDERS:
+                    if not any(c is self for c in held):
+                        held.append(self)
+            elif _PENDING_DESTROY:
+                _drain_pending_destroys()
         be.check(be.c.gmx_program_run(self.handle, bound[0], bound[1], be.stream()), "gmx_program_run")
 
     def bind(self, leaves, batch: tuple, key: Key | None, red_out=None, index_offset=0, out_buffers=None,
@@ -631,7 +713,7 @@ class Compiled:
         for slot, j, e, kind in self.in_plan:
             v = leaves[j]
             if isinstance(v, Broadcast):
-                v = v.t
+                v = v.plain
             if kind == "gather":
                 if anc is None:
                     anc = v.ancestors
@@ -687,7 +769,7 @@ class Compiled:
         for slot, j in self.tab_plan:
             tv = leaves[j]
             if isinstance(tv, Broadcast):
-                tv = tv.t
+                tv = tv.plain
             if isinstance(tv, np.ndarray):                 # a long host vector (leaf_spec: "dtab")
                 tv = torch.from_numpy(np.ascontiguousarray(tv.astype(np.float32) if tv.dtype.kind == "f" else tv.astype(np.int32)))
             t = _prepare_input(tv, "dvec", None, be)

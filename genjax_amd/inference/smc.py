@@ -470,6 +470,8 @@ def resample_fused(kind, key: Key, lw: torch.Tensor):
     array (tile statistics + k_offspring_tile); the same integers as weight_cdf + ancestors_from_cdf."""
     be = _lib.get()
     stats = getattr(lw, "_gmx_tile_stats", None)       # left by the program that computed these weights (run_gfi)
+    if stats is not None and (len(stats) < 5 or stats[4] != lw._version):
+        stats = None                       # the weights were changed in place since: the statistics are stale
     lw = lw.reshape(-1).float().contiguous()
     if lw.data_ptr() % 16:
         lw = lw.clone()                    # a view into the middle of a buffer: the kernels load float4
@@ -611,7 +613,9 @@ class CapturedLoop:
         if self.noise is not None:
             self.noise.reserve(be.device)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # the graph's kernel nodes point into the site programs' code: hold every program launched during the capture
+        # for as long as the graph lives (the program caches are bounded LRUs; genjax_amd.clear_caches() is public)
+        with engine.holding_captured_programs() as self.programs, torch.cuda.graph(self.graph):
             if self.noise is not None:
                 cur = torch.cuda.current_stream(be.device)
                 self.noise.stream.wait_stream(cur)          # the background stream joins the capture ...

@@ -50,7 +50,7 @@ EFFECT = {"STOUT", "REDMAX", "REDLSE", "LOOP", "ENDLOOP", "SETVAR"}
 # LOOPVAR (args = (init,)): a value carried across the iterations of a counted loop — one register (two for a
 # key) initialised before OP_LOOP, read inside the block, overwritten by SETVAR (args = (var, new value)) and
 # readable after OP_ENDLOOP.  LDT: the iteration number.
-_NO_CSE = EFFECT | {"LDIN", "UNI", "CONST", "S_CATSTEP", "CATIDX", "LOOPVAR", "LDT"}     # slots are unique; CONSTs have their own table
+_NO_CSE = EFFECT | {"LDIN", "UNI", "CONST", "S_CATSTEP", "CATIDX", "LOOPVAR", "LDT", "COPY"}     # slots are unique; CONSTs have their own table
 # values recomputed at every use instead of being held in a register (see compile_graph)
 REMAT_UNARY = {"LOG", "EXP", "NEG", "SQUARE", "SQRT", "RECIP", "I2F"}
 REMAT_BINARY = {"ADD", "SUB", "MUL", "DIV"}
@@ -155,6 +155,20 @@ class Graph:
 
     def set_var(self, var: Node, value: Node):
         self.add("SETVAR", (var, value), dtype="none")
+
+    def set_vars(self, pairs):
+        """The loop-carried update as a PARALLEL copy: every new value is what it was BEFORE any variable of the group
+        is overwritten (`(a, b) <- (x_new, a)`, a swap, an AR(2) shift register ...).  A new value that is itself a
+        loop variable is first copied into a temporary; computed values already live in registers of their own."""
+        pairs = [(var, val) for var, val in pairs if val is not var]
+        vars_ = {var.idx for var, _ in pairs}
+        staged = []
+        for var, val in pairs:
+            if val.op == "LOOPVAR" and val.idx in vars_:
+                val = self.add("COPY", (val,), dtype=val.dtype)
+            staged.append((var, val))
+        for var, val in staged:
+            self.set_var(var, val)
 
 
 class ProgramTooLarge(Exception):
@@ -430,7 +444,7 @@ def compile_graph(g: Graph):
             emit(op, dst, n.slot, R(n.args[0]), n.imm)
         elif op in ("LDKEY", "LDIDX", "LDT"):
             emit(op, dst)
-        elif op == "LOOPVAR":
+        elif op in ("LOOPVAR", "COPY"):
             init = n.args[0]
             for k in range(n.width):
                 emit("MOV", dst + k, R(init) + k)

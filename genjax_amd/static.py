@@ -36,7 +36,7 @@ from .core.choice_map import ChoiceMap, Selection, _norm
 from .core.mask import Mask
 from .core.generative import (Diff, EditRequest, EmptyRequest, GenerativeFunction, IndexRequest, NoChange,
                               NotSupportedEditRequest, Regenerate, Trace, Update)
-from .engine import Compiled, Flat, Gathered, Sym, Tracing, leaf_spec, materialize, resolve, unflatten
+from .engine import Broadcast, Compiled, Flat, Gathered, Sym, Tracing, leaf_spec, materialize, resolve, unflatten
 from .random import Key
 from .tracer import Expr
 from .engine import new_cache as _new_program_cache
@@ -723,7 +723,9 @@ def _infer_batch(values) -> tuple:
     event axes after the particle axes); pass batch_shape= when ambiguous."""
     shape = None
     for v in values:
-        if isinstance(v, (torch.Tensor, Gathered)) and len(v.shape):      # (engine.Broadcast leaves say nothing about the batch)
+        if isinstance(v, Broadcast):            # launch-uniform whatever its shape: says nothing about the batch
+            continue
+        if isinstance(v, (torch.Tensor, Gathered)) and len(v.shape):
             s = tuple(v.shape)
             if shape is None:
                 shape = s
@@ -1017,7 +1019,9 @@ def run_gfi(gen_fn, mode, key: Key | None, args, constraint: ChoiceMap | None = 
     w = resolve(wo, outs, flat.leaves) if wo is not None else 0.0
     w = _broadcast_score(w, batch, be.device)
     if stats is not None and isinstance(w, torch.Tensor):
-        w._gmx_tile_stats = stats          # (block maxima, tile sums, shift, n): valid for exactly this tensor's values
+        # (block maxima, tile sums, shift, n, version): valid for exactly this tensor's values — an in-place change
+        # of the weights afterwards (tempering, masking) bumps `_version` and smc.resample_fused drops the statistics
+        w._gmx_tile_stats = tuple(stats) + (w._version,)
     return trc, w
 
 

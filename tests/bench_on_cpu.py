@@ -10,5 +10,7 @@ sys.path.insert(0, ROOT)
 import tests.hostsim as hs  # noqa: E402
 
 hs.install()
+# a bare `--gpus N` makes bench.py spawn its own ranks: they must come back through THIS file (the CPU mirror)
+os.environ["GENMI_BENCH_ENTRY"] = os.path.abspath(__file__)
 sys.argv[0] = os.path.join(ROOT, "bench.py")
 runpy.run_path(sys.argv[0], run_name="__main__")

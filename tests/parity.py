@@ -1282,3 +1282,58 @@ def check_scan_long_vector_constraints(n=140, T=30, seed=6):
     orr, owr = O.scan_edit(osc, O.split(O.key(seed + 3), n), ou, oa, regenerate=O.selection("x"))
     assert np.array_equal(r.get_choices()["x"].cpu().numpy(), orr.get_choices()["x"])
     assert np.array_equal(wr.cpu().numpy(), owr) and np.array_equal(r.get_score().cpu().numpy(), orr.get_score())
+
+
+def check_scan_carry_forms(n=130, seed=21, Ts=(8, 17, 40)):
+    """Loop-carried values that FORWARD one another: a shift register `(xn, a)` from `(a, b)`
+    (AR(2)), and a swap `(b, a)`.  In the counted-loop form (T > 16) the carry update must be a parallel copy —
+    an in-order MOV sequence reads a register it has already overwritten.  simulate / generate / Update / Regenerate
+    against the oracle for an unrolled T (8) and two looped ones (17, 40)."""
+    import genjax_amd as G
+    from genjax_amd import ChoiceMapBuilder as C, Diff, Regenerate, SelectionBuilder as S, Update, numpy as jnp
+    dev = G._lib.get().device
+
+    def mk(g):
+        @g.gen
+        def ar2(carry, t):
+            a, b = carry
+            xn = g.normal(0.6 * a + 0.3 * b, 0.5) @ "x"
+            g.normal(xn, 1.0) @ "y"
+            return (xn, a), xn - b
+
+        @g.gen
+        def swap(carry, t):
+            a, b = carry
+            z = g.normal(a - b, 1.0) @ "x"
+            g.normal(z + b, 1.0) @ "y"
+            return (b, a + 1.0), z
+        return ar2, swap
+    kernels, okernels = mk(G), mk(O)
+    for T in Ts:
+        ys = np.linspace(-1.0, 1.0, T).astype(np.float32)
+        for kern, okern in zip(kernels, okernels):
+            sc, osc = kern.scan(n=T), O.Scan(okern, T)
+            a = ((torch.full((n,), 0.5, device=dev), torch.full((n,), -0.25, device=dev)), jnp.zeros(T))
+            oa = ((np.full(n, 0.5, np.float32), np.full(n, -0.25, np.float32)), np.zeros(T, np.float32))
+            tr, otr = sc.simulate(G.split(G.key(seed), n), a), osc.simulate(O.split(O.key(seed), n), oa)
+            assert np.array_equal(tr.get_choices()["x"].cpu().numpy(), otr.get_choices()["x"]), (T, kern)
+            (c0, c1), out = tr.get_retval()
+            (oc0, oc1), oout = otr.get_retval()
+            assert np.array_equal(c0.cpu().numpy(), oc0) and np.array_equal(c1.cpu().numpy(), oc1)
+            assert np.array_equal(out.cpu().numpy(), oout)
+            assert np.array_equal(tr.get_score().cpu().numpy(), otr.get_score())
+            tg, wg = sc.importance(G.split(G.key(seed + 1), n), C[:, "y"].set(ys), a)
+            otg, owg = osc.importance(O.split(O.key(seed + 1), n), O.C.d({"y": ys}), oa)
+            assert np.array_equal(tg.get_choices()["x"].cpu().numpy(), otg.get_choices()["x"])
+            assert np.array_equal(wg.cpu().numpy(), owg)
+            u, wu, _, _ = Update(C["y"].set(-ys)).edit(G.split(G.key(seed + 2), n), tg, Diff.no_change(a))
+            ou, owu = O.scan_edit(osc, O.split(O.key(seed + 2), n), otg, oa, update=O.C.d({"y": -ys}))
+            assert np.array_equal(wu.cpu().numpy(), owu)
+            assert np.array_equal(u.get_score().cpu().numpy(), ou.get_score())
+            r, wr, _, _ = Regenerate(S["x"]).edit(G.split(G.key(seed + 3), n), u, Diff.no_change(a))
+            orr, owr = O.scan_edit(osc, O.split(O.key(seed + 3), n), ou, oa, regenerate=O.selection("x"))
+            assert np.array_equal(r.get_choices()["x"].cpu().numpy(), orr.get_choices()["x"])
+            assert np.array_equal(wr.cpu().numpy(), owr)
+            (r0, r1), _ = r.get_retval()
+            (or0, or1), _ = orr.get_retval()
+            assert np.array_equal(r0.cpu().numpy(), or0) and np.array_equal(r1.cpu().numpy(), or1)

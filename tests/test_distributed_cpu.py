@@ -168,18 +168,23 @@ def test_slot_bounds_match_ancestors():
         assert e - s == int(np.sum((anc >= lo) & (anc < hi)))
 
 
-@pytest.mark.parametrize("world,weak", [(1, False), (2, False), (2, True)])
-def test_bench_contract_control_flow(world, weak):
+@pytest.mark.parametrize("world,weak,bare", [(1, False, False), (2, False, False), (2, True, False), (2, False, True)])
+def test_bench_contract_control_flow(world, weak, bare):
     """bench.py's N > 1 control flow (rendezvous on 127.0.0.1, barriers, max over ranks, exactly ONE JSON line on
     stdout from rank 0, communicator teardown after the line is out) — bench.py unchanged, started through
     tests/bench_on_cpu.py (gloo + the CPU mirror of the C-ABI); values are not timings.
     Default = STRONG scaling (BASELINE's metric): --particles is the TOTAL, rounded up to a multiple of world x 1024;
-    --weak: --particles per GPU, rounded up to a multiple of 1024."""
+    --weak: --particles per GPU, rounded up to a multiple of 1024.
+    bare: `python bench.py --gpus 2` with NO launcher and no WORLD_SIZE — what the driver runs: the process spawns its
+    own ranks (bench.spawn_ranks) and relays rank 0's line."""
     port = str(_free_port())
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, OMP_NUM_THREADS="1")
+    if bare:
+        for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+            env.pop(k, None)
     args = ["--gpus", str(world), "--steps", "2", "--warmup", "1", "--particles", "3000", "--T", "4", "--no-cpu-baseline",
             "--no-graph"] + (["--weak"] if weak else [])
-    if world == 1:
+    if world == 1 or bare:
         cmd = [sys.executable, os.path.join(ROOT, "tests", "bench_on_cpu.py")] + args
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",

@@ -783,6 +783,13 @@ def test_long_scan_config2_as_one_generative_function(gpu):
     assert abs(r["log_ml_is"] - r["kalman"]) < 0.25, r         # prior-proposal IS over 18 steps: MC error ~0.1
 
 
+def test_scan_carries_that_forward_each_other(gpu):
+    """`(xn, a)` from `(a, b)` and `(b, a)` carries through the counted loop — interpreter and the
+    specialised kernel (n >= 2^18) — bit-exact vs the oracle for simulate / generate / Update / Regenerate."""
+    parity.check_scan_carry_forms(n=1000)
+    parity.check_scan_carry_forms(n=270_000, Ts=(17,))
+
+
 def test_indexed_and_masked_constraints(gpu):
     """a plate constrained on a subset of its indices (Indexed, ref choice_map.py:1453-1531) and
     Mask(value, flag) constraints with one flag per particle (ref distribution.py:129-142, 189-224): OP_SEL between
@@ -930,6 +937,15 @@ def test_functional_loop_captured_equals_eager(gpu):
             assert torch.equal(coll.get_log_weights(), ref_lw)
             for a, b in zip(ancs, ref_anc):
                 assert torch.equal(a, b)
+    # the graph's kernel nodes point into the site programs' code — the captured loop itself keeps the
+    # programs it launched, so dropping every program cache (public API) and collecting must not break a replay
+    import gc
+    assert len(cap.programs) >= 3
+    G.clear_caches()
+    gc.collect()
+    coll, ancs = cap.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(coll.get_particles().get_retval(), ref_x) and torch.equal(coll.get_log_weights(), ref_lw)
     # against the oracle's statement of the same loop (ancestors, states, weights bit-exact)
     parity.check_nlssm_mh(n=2000, T=4)
 
@@ -1021,6 +1037,28 @@ def test_tile_stats_from_the_site_program(gpu):
         ref = O.tile_ref(O.tile_exp(x.max()))          # block floating point: weights relative to ceil(max / ln 2) * ln 2
         O.lib().orc_weight_fixed(O.I64(x.size), O._p(x), O.ctypes.c_float(ref), O.ctypes.c_int(sw.shift), O._p(q))
         assert int(q.sum()) == int(agg[b].item()) and float(tmax[b].item()) == float(x.max())
+
+
+def test_tile_stats_are_dropped_when_the_weights_change_in_place(gpu):
+    """`extend` leaves the resampler's tile statistics on the weight tensor; an in-place change of the
+    weights afterwards (tempering, masking) must not be resampled against the stale statistics."""
+    import genjax_amd as G
+    from genjax_amd import workloads
+    from genjax_amd.inference import smc
+    n = 300_000
+    ys = workloads.lgssm_data(2)
+    init, step = workloads.make_lgssm(G)
+    coll = smc.ImportanceK(G.Target(init, (), G.ChoiceMap.kw(y=float(ys[0]))), k_particles=n).run_smc(G.key(3))
+    coll = smc.resample(G.key(4), coll, "systematic")
+    coll = smc.extend(G.key(5), coll, step, lambda tr_: (tr_.get_retval(),), G.ChoiceMap.kw(y=float(ys[1])))
+    lw = coll.get_log_weights()
+    assert getattr(lw, "_gmx_tile_stats", None) is not None          # the step's program wrote them
+    fresh = smc.resample(G.key(6), coll, "systematic").ancestors.clone()
+    lw.mul_(0.25)                                                      # tempering, in place
+    tempered = smc.resample(G.key(6), coll, "systematic").ancestors
+    plain = smc.ParticleCollection(coll.get_particles(), lw.clone(), True, coll.log_ml_offset)
+    want = smc.resample(G.key(6), plain, "systematic").ancestors
+    assert torch.equal(tempered, want) and not torch.equal(tempered, fresh)
 
 
 @pytest.mark.parametrize("case", ["nan_inf", "huge", "plus_inf", "all_nan"])

@@ -580,6 +580,12 @@ def test_long_scan_runs_as_a_loop_and_matches_oracle():
     assert min(sizes) < 64
 
 
+def test_scan_carries_that_forward_each_other(hostsim):
+    """shift-register and swap carries: the counted loop's carry update is a parallel copy"""
+    from tests import parity
+    parity.check_scan_carry_forms()
+
+
 def test_indexed_and_masked_constraints_match_oracle():
     from tests import parity
     parity.check_masked_constraints()
@@ -863,6 +869,16 @@ def test_vmap_in_axes_and_broadcast_marker():
     x = genjax.vmap(lambda k, s: m.simulate(k, (s,)).get_retval(), in_axes=(0, None))(keys, w)
     okeys = O.fold_in(O.split(O.key(1), n), 1)
     assert np.array_equal(x.numpy(), O.normal.sample(okeys, np.float32(0.0), np.float32(w[3].item())))
+    # the shared argument is a tensor like any other: the mapped function computes with it before the generative
+    # function sees it (`w * 2.0` used to raise on the marker type), and the results stay launch-uniform
+    x2 = genjax.vmap(lambda k, s: m.simulate(k, (s * 2.0 + 1.0,)).get_retval(), in_axes=(0, None))(keys, w)
+    assert np.array_equal(x2.numpy(), O.normal.sample(okeys, np.float32(0.0), np.float32((w * 2.0 + 1.0)[3].item())))
+    from genjax_amd.engine import Broadcast
+    b = Broadcast(w)
+    assert isinstance(b * 2.0, Broadcast) and isinstance(torch.exp(b)[2:], Broadcast) and isinstance(b.reshape(4, 5).t(), Broadcast)
+    mixed = b * torch.ones(n)                         # with per-instance data: an ordinary tensor
+    assert not isinstance(mixed, Broadcast) and torch.equal(mixed, w)
+    assert not isinstance(b.plain, Broadcast) and float(b.sum()) == pytest.approx(float(w.sum()))
     locs = torch.arange(3 * n, dtype=torch.float32).reshape(3, n)
 
     @genjax.gen

@@ -20,7 +20,7 @@ GMX_MAX_OUT = 64
 GMX_MAX_TAB = 8
 GMX_MAX_UNI = 64
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 KEY_NONE, KEY_ARRAY, KEY_SPLIT, KEY_ROWSPLIT, KEY_BCAST = 0, 1, 2, 3, 4
 RESAMPLE_SYSTEMATIC, RESAMPLE_STRATIFIED, RESAMPLE_MULTINOMIAL = 0, 1, 2
 
@@ -64,6 +64,7 @@ class RunArgs(Structure):
         ("step_stride", c_int64),
         ("tile_q_d", c_void_p),
         ("rs", ResampleIn),
+        ("tile_pref_d", c_void_p),
     ]
 
 
@@ -125,6 +126,11 @@ class Backend:
         c.gmx_resample_tiles.argtypes = [c_int, POINTER(c_uint32), c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p,
                                          c_void_p, c_void_p, c_void_p]
         c.gmx_resample_tiles_q.argtypes = [c_int, POINTER(c_uint32), c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p,
+                                           c_void_p, c_void_p, c_void_p]
+        c.gmx_tile_prefix_words.argtypes = [c_int64]
+        c.gmx_tile_prefix_words.restype = c_size_t
+        c.gmx_tile_prefix.argtypes = [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]
+        c.gmx_resample_tiles_p.argtypes = [c_int, POINTER(c_uint32), c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p,
                                            c_void_p, c_void_p, c_void_p]
         c.gmx_shard_stats_bytes.argtypes = [c_int64]
         c.gmx_shard_stats_bytes.restype = c_size_t

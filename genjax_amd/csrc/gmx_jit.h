@@ -64,7 +64,15 @@ struct gmx_jit_ctx {
     acc_max = first ? m : gmx_rmax(acc_max, m);
     if (last) {
       const float bm = block_max(acc_max, lds4);
-      if (threadIdx.x == 0 && A->red_out_d) A->red_out_d[blockIdx.x] = bm;
+      const bool pref = PPV == 4 && A->tile_agg_d && A->tile_pref_d;       // launch-uniform
+      // With tile_pref_d the workgroup's statistics are PUBLISHED (see below): atomic exchanges at agent scope instead
+      // of plain stores, so that the last workgroup can read them without any cache writeback / invalidate.
+      uint32_t old_m = 0u;
+      if (threadIdx.x == 0 && A->red_out_d) {
+        if (pref) old_m = __hip_atomic_exchange(reinterpret_cast<uint32_t*>(A->red_out_d) + blockIdx.x, gmx_f2u(bm),
+                                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else A->red_out_d[blockIdx.x] = bm;
+      }
       if (PPV == 4 && A->tile_agg_d) {
         const float ref = gmx_tile_ref(gmx_tile_exp(bm));
         uint64_t s = 0;
@@ -81,7 +89,42 @@ struct gmx_jit_ctx {
         s = wave_sum_u64(s);
         if ((threadIdx.x & 63) == 0) lds8[threadIdx.x >> 6] = s;
         __syncthreads();
-        if (threadIdx.x == 0) A->tile_agg_d[blockIdx.x] = (lds8[0] + lds8[1]) + (lds8[2] + lds8[3]);
+        if (!pref) {
+          if (threadIdx.x == 0) A->tile_agg_d[blockIdx.x] = (lds8[0] + lds8[1]) + (lds8[2] + lds8[3]);
+        } else {
+          // The LAST workgroup to get here turns all tile statistics into the tile prefixes, once, so that the
+          // resampler's workgroups need not each reduce the whole table (gmx_resample_tiles_p).  No fences: a
+          // release / acquire pair at agent scope writes back and invalidates the XCD's whole L2 — measured on MI355X,
+          // +21 us per step with 977 workgroups doing it.  Instead thread 0 publishes (m_b, A_b) with atomic
+          // exchanges that RETURN (they are performed at the coherence point before their result comes back), takes
+          // its ticket only after both results are in, and the last workgroup reads the table with agent-scope atomic
+          // loads (which go past the non-coherent cache levels).
+          // Tickets in two levels (gmx_block.h: GMX_TP_SUB counters on lines of their own, then one master counter).
+          uint32_t* ticket = reinterpret_cast<uint32_t*>(A->tile_pref_d + gridDim.x + 2);
+          if (threadIdx.x == 0) {
+            const uint64_t a = (lds8[0] + lds8[1]) + (lds8[2] + lds8[3]);
+            const uint64_t old_a = __hip_atomic_exchange(A->tile_agg_d + blockIdx.x, a, __ATOMIC_RELAXED,
+                                                         __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("" :: "v"(old_m), "v"(old_a) : "memory");         // both exchanges have completed
+            const uint32_t sub = blockIdx.x % (uint32_t)GMX_TP_SUB;
+            const uint32_t in_sub = (gridDim.x - sub + (uint32_t)GMX_TP_SUB - 1u) / (uint32_t)GMX_TP_SUB;
+            const uint32_t n_sub = gridDim.x < (uint32_t)GMX_TP_SUB ? gridDim.x : (uint32_t)GMX_TP_SUB;
+            uint32_t* st = reinterpret_cast<uint32_t*>(A->tile_pref_d + gmx_tile_prefix_sub0_((int64_t)gridDim.x) + 16u * sub);
+            uint32_t last = 0u;
+            if (__hip_atomic_fetch_add(st, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == in_sub - 1u) {
+              __hip_atomic_store(st, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch
+              last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_sub - 1u ? 1u : 0u;
+            }
+            lds4[0] = gmx_u2f(last);
+          }
+          __syncthreads();
+          const bool is_last = gmx_f2u(lds4[0]) != 0u;       // workgroup-uniform
+          __syncthreads();
+          if (is_last) {
+            gmx_tile_prefix_block<true>(A->red_out_d, A->tile_agg_d, (int)gridDim.x, A->tile_pref_d, lds4, lds8);
+            if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
       }
     }
   }

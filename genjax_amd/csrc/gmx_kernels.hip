@@ -618,8 +618,11 @@ extern "C" int gmx_program_run(const gmx_program* p, int64_t n, const gmx_run_ar
                       "(gmx_program_writes_tile_stats)%s");
     if (args->tile_shift < 1 || args->tile_shift > 62) return gmx_fail("gmx_program_run: tile_shift out of range%s");
     if ((uintptr_t)args->tile_q_d & 15) return gmx_fail("gmx_program_run: tile_q_d must be 16-byte aligned%s");
+    if (args->tile_pref_d && !args->red_out_d) return gmx_fail("gmx_program_run: tile_pref_d needs red_out_d%s");
   } else if (args->tile_q_d) {
     return gmx_fail("gmx_program_run: tile_q_d needs tile_agg_d%s");
+  } else if (args->tile_pref_d) {
+    return gmx_fail("gmx_program_run: tile_pref_d needs tile_agg_d%s");
   }
   if (p->uses_step && args->step_stride < n)
     return gmx_fail("gmx_program_run: step_stride must be at least n for a program with step-indexed leaves%s");
@@ -1567,35 +1570,52 @@ k_offspring_tile(uint32_t k0, uint32_t k1, uint32_t u0_host, const float* __rest
       x[c] = (i0 + c < n) ? xv : -gmx_inf();
     }
   }
-  static_assert(PER >= 1 && PER * RS_BLOCK <= RS_MAX_TILES, "rows of the tile table per thread");
-  uint64_t ta[PER];
-  float tm[PER];
+  // PER == 0: the tile PREFIXES are there already (`agg` = gmx_run_args.tile_pref_d, written once by the last
+  // workgroup of the site program): this workgroup reads its own prefix, the total and (M, K) — three loads instead of
+  // a pass over the whole table.
+  constexpr bool PREF = (PER == 0);
+  constexpr int PERN = PREF ? 1 : PER;
+  static_assert(PER >= 0 && PER * RS_BLOCK <= RS_MAX_TILES, "rows of the tile table per thread");
+  static_assert(!PREF || RS_TPB == 1, "the prefix form works on one tile per block");
+  uint64_t ta[PERN];
+  float tm[PERN];
+  uint64_t pf_prefix = 0, pf_total = 0, pf_mk = 0;
+  if (PREF) {
+    pf_prefix = agg[tile_c]; pf_total = agg[n_tiles]; pf_mk = agg[n_tiles + 1];
+  } else {
 #pragma unroll
-  for (int r = 0; r < PER; ++r) {                // loads only (clamped rows): nothing here waits
-    ta[r] = 0ull; tm[r] = -gmx_inf();
-    if (r * RS_BLOCK < n_tiles) {                // uniform: rows of the table that exist
-      const int t = r * RS_BLOCK + (int)threadIdx.x;
-      const int tc = t < n_tiles ? t : n_tiles - 1;
-      ta[r] = agg[tc];
-      tm[r] = tmax[tc];
+    for (int r = 0; r < PERN; ++r) {              // loads only (clamped rows): nothing here waits
+      ta[r] = 0ull; tm[r] = -gmx_inf();
+      if (r * RS_BLOCK < n_tiles) {                // uniform: rows of the table that exist
+        const int t = r * RS_BLOCK + (int)threadIdx.x;
+        const int tc = t < n_tiles ? t : n_tiles - 1;
+        ta[r] = agg[tc];
+        tm[r] = tmax[tc];
+      }
     }
   }
   const float tmax_mine = tmax[tile_c];
   __builtin_amdgcn_sched_barrier(0);
+  if (!PREF) {
 #pragma unroll
-  for (int r = 0; r < PER; ++r) {
-    const int t = r * RS_BLOCK + (int)threadIdx.x;
-    ta[r] = (t < n_tiles) ? ta[r] : 0ull;
-    tm[r] = (t < n_tiles) ? tm[r] : -gmx_inf();
+    for (int r = 0; r < PERN; ++r) {
+      const int t = r * RS_BLOCK + (int)threadIdx.x;
+      ta[r] = (t < n_tiles) ? ta[r] : 0ull;
+      tm[r] = (t < n_tiles) ? tm[r] : -gmx_inf();
+    }
   }
   const int32_t k_b = gmx_tile_exp(tmax_mine);
   const float ref_b = gmx_tile_ref(k_b);
   // phase 1: the global max, and the wave totals of each tile's local weights
   float M = -gmx_inf();
+  if (PREF) {
+    M = gmx_u2f((uint32_t)pf_mk);
+  } else {
 #pragma unroll
-  for (int r = 0; r < PER; ++r)
-    if (r * RS_BLOCK < n_tiles) M = gmx_rmax(M, tm[r]);
-  M = wave_max(M);
+    for (int r = 0; r < PERN; ++r)
+      if (r * RS_BLOCK < n_tiles) M = gmx_rmax(M, tm[r]);
+    M = wave_max(M);
+  }
   uint64_t q[CDF_VEC];
   uint64_t run = 0;
 #pragma unroll
@@ -1605,39 +1625,45 @@ k_offspring_tile(uint32_t k0, uint32_t k1, uint32_t u0_host, const float* __rest
     q[c] = run;
   }
   const uint64_t inc = wave_scan_u64(run);
-  if (lane == 0) s_max[wave] = M;
+  if (!PREF && lane == 0) s_max[wave] = M;
   if (lane == 63) s_scan[wave] = inc;
   __syncthreads();
-  M = s_max[0];
+  if (!PREF) {
+    M = s_max[0];
 #pragma unroll
-  for (int w = 1; w < RS_WAVES; ++w) M = gmx_rmax(M, s_max[w]);
+    for (int w = 1; w < RS_WAVES; ++w) M = gmx_rmax(M, s_max[w]);
+  }
   uint64_t wave_off = 0;
 #pragma unroll
   for (int w = 0; w < 4; ++w) wave_off += (w < (wave & 3)) ? s_scan[4 * grp + w] : 0ull;     // the tile's own four waves
   const uint64_t loc = wave_off + (inc - run);          // tile-local mass before this thread's sources
   // phase 2: G_t = A_t * 2^(k_t - K) for every tile -> the mass before this block's first tile, the block's own
   // four G, and the total
-  const int32_t K = gmx_tile_exp(M);
-  uint64_t below = 0, all = 0;
-#pragma unroll
-  for (int r = 0; r < PER; ++r) {
-    if (r * RS_BLOCK < n_tiles) {
-      const int t = r * RS_BLOCK + (int)threadIdx.x;
-      const uint64_t G = gmx_tile_scale(ta[r], gmx_tile_exp(tm[r]), K);
-      all += G;
-      below += (t < first_tile) ? G : 0ull;
-      if (t >= first_tile && t < first_tile + RS_TPB) s_g[t - first_tile] = G;      // t >= n_tiles: G = 0
-    }
-  }
-  below = wave_sum_u64(below);
-  all = wave_sum_u64(all);
-  if (lane == 0) { s_below[wave] = below; s_all[wave] = all; }
-  __syncthreads();
+  const int32_t K = PREF ? (int32_t)(uint32_t)(pf_mk >> 32) : gmx_tile_exp(M);
   uint64_t prefix = 0, total = 0;
+  if (PREF) {
+    prefix = pf_prefix; total = pf_total;
+  } else {
+    uint64_t below = 0, all = 0;
 #pragma unroll
-  for (int w = 0; w < RS_WAVES; ++w) { prefix += s_below[w]; total += s_all[w]; }
+    for (int r = 0; r < PERN; ++r) {
+      if (r * RS_BLOCK < n_tiles) {
+        const int t = r * RS_BLOCK + (int)threadIdx.x;
+        const uint64_t G = gmx_tile_scale(ta[r], gmx_tile_exp(tm[r]), K);
+        all += G;
+        below += (t < first_tile) ? G : 0ull;
+        if (t >= first_tile && t < first_tile + RS_TPB) s_g[t - first_tile] = G;      // t >= n_tiles: G = 0
+      }
+    }
+    below = wave_sum_u64(below);
+    all = wave_sum_u64(all);
+    if (lane == 0) { s_below[wave] = below; s_all[wave] = all; }
+    __syncthreads();
 #pragma unroll
-  for (int j = 0; j < RS_TPB; ++j) prefix += (j < grp) ? s_g[j] : 0ull;
+    for (int w = 0; w < RS_WAVES; ++w) { prefix += s_below[w]; total += s_all[w]; }
+#pragma unroll
+    for (int j = 0; j < RS_TPB; ++j) prefix += (j < grp) ? s_g[j] : 0ull;
+  }
   if (blockIdx.x == 0 && threadIdx.x == 0) { *total_out = total; *max_out = M; }
   if (!tile_ok) return;                                  // a whole tile group past the end (uniform per wave; no barrier follows)
   gmx_key key; key.k0 = k0; key.k1 = k1;
@@ -1766,7 +1792,7 @@ static int resample_shape(const char* who, int64_t n, int shift) {
 
 static int launch_offspring_tile(int kind, const uint32_t key[2], const float* lw_d, const uint32_t* q_d, int64_t n, int shift,
                                  const float* tile_max_d, const uint64_t* tile_agg_d, float* max_d, uint64_t* total_d,
-                                 int32_t* ancestors_d, gmx_stream stream) {
+                                 int32_t* ancestors_d, gmx_stream stream, bool pref = false) {
   uint32_t b0, b1;
   gmx_threefry2x32(key[0], key[1], 0u, 0u, &b0, &b1);           // bits32(key, 0) on the host
   const uint32_t u0 = (b0 ^ b1) >> 9;
@@ -1781,7 +1807,8 @@ static int launch_offspring_tile(int kind, const uint32_t key[2], const float* l
 #define GMX_LAUNCH_OT3(KIND, FQ, PER_) do { if (fill) GMX_LAUNCH_OT4(KIND, FQ, PER_, true); else GMX_LAUNCH_OT4(KIND, FQ, PER_, false); } while (0)
 #define GMX_LAUNCH_OT(KIND, FQ)                                                                                     \
   do {                                                                                                              \
-    if (tiles <= 1 * RS_BLOCK) GMX_LAUNCH_OT3(KIND, FQ, 1);                                                         \
+    if (pref) GMX_LAUNCH_OT3(KIND, FQ, 0);          /* `tile_agg_d` is the prefix block (gmx_run_args.tile_pref_d) */ \
+    else if (tiles <= 1 * RS_BLOCK) GMX_LAUNCH_OT3(KIND, FQ, 1);                                                    \
     else if (tiles <= 2 * RS_BLOCK) GMX_LAUNCH_OT3(KIND, FQ, 2);                                                    \
     else if (tiles <= 4 * RS_BLOCK) GMX_LAUNCH_OT3(KIND, FQ, 4);                                                    \
     else GMX_LAUNCH_OT3(KIND, FQ, 8);                                                                               \
@@ -1831,6 +1858,39 @@ extern "C" int gmx_resample_tiles_q(int kind, const uint32_t key[2], const uint3
   if (n > 0x7fffffffLL) return gmx_fail("gmx_resample_tiles_q: n out of range%s");
   if ((uintptr_t)q_d & 15) return gmx_fail("gmx_resample_tiles_q: q_d must be 16-byte aligned%s");
   return launch_offspring_tile(kind, key, nullptr, q_d, n, shift, tile_max_d, tile_agg_d, max_d, total_d, ancestors_d, stream);
+}
+
+extern "C" size_t gmx_tile_prefix_words(int64_t n) { return gmx_tile_prefix_words_(n); }
+
+__global__ void __launch_bounds__(GMX_BLOCK)
+k_tile_prefix(const float* __restrict__ tmax, const uint64_t* __restrict__ agg, int n_tiles, uint64_t* __restrict__ pref) {
+  __shared__ float lds4[4];
+  __shared__ uint64_t lds8[4];
+  gmx_tile_prefix_block<false>(tmax, agg, n_tiles, pref, lds4, lds8);
+}
+
+extern "C" int gmx_tile_prefix(const float* tile_max_d, const uint64_t* tile_agg_d, int64_t n, uint64_t* tile_pref_d,
+                               gmx_stream stream) {
+  if (n <= 0 || (n + RS_TILE - 1) / RS_TILE > RS_MAX_TILES) return gmx_fail("gmx_tile_prefix: n out of range%s");
+  if (!tile_max_d || !tile_agg_d || !tile_pref_d) return gmx_fail("gmx_tile_prefix: null argument%s");
+  hipLaunchKernelGGL(k_tile_prefix, dim3(1), dim3(GMX_BLOCK), 0, (hipStream_t)stream, tile_max_d, tile_agg_d,
+                     (int)((n + RS_TILE - 1) / RS_TILE), tile_pref_d);
+  GMX_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int gmx_resample_tiles_p(int kind, const uint32_t key[2], const float* lw_d, int64_t n, int shift,
+                                    const float* tile_max_d, const uint64_t* tile_pref_d, float* max_d,
+                                    uint64_t* total_d, int32_t* ancestors_d, gmx_stream stream) {
+  if (resample_shape("gmx_resample_tiles_p", n, shift)) return 1;
+  if (!key || !lw_d || !tile_max_d || !tile_pref_d || !max_d || !total_d || !ancestors_d)
+    return gmx_fail("gmx_resample_tiles_p: null argument%s");
+  if (kind != GMX_RESAMPLE_SYSTEMATIC && kind != GMX_RESAMPLE_STRATIFIED)
+    return gmx_fail("gmx_resample_tiles_p: kind must be systematic or stratified%s");
+  if (n > 0x7fffffffLL) return gmx_fail("gmx_resample_tiles_p: n out of range%s");
+  if ((uintptr_t)lw_d & 15) return gmx_fail("gmx_resample_tiles_p: lw_d must be 16-byte aligned%s");
+  return launch_offspring_tile(kind, key, lw_d, nullptr, n, shift, tile_max_d, tile_pref_d, max_d, total_d, ancestors_d,
+                               stream, true);
 }
 
 // log-weights -> ancestors: gmx_tile_stats + gmx_resample_tiles with the tile stats in the workspace.

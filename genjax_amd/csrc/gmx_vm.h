@@ -129,7 +129,7 @@ GMX_HD void gmx_vm_step(Regs& R, const W w, int64_t i, bool active, const gmx_ru
         } else if (A.key_mode == GMX_KEY_ROWSPLIT) {
           int64_t row = gmx_rowsplit_row(i, A.key_inner), j = i - row * A.key_inner;
           if (active) { k.k0 = A.keys_d[2 * row]; k.k1 = A.keys_d[2 * row + 1]; }
-          k = gmx_split_child(k, (uint64_t)j);
+          k = gmx_split_child(k, (uint64_t)(A.index_offset + j));     // a shard's block of every row's split
         }
         r0 = k.k0; r1 = k.k1; wr = 2;
       } break;

@@ -690,7 +690,8 @@ class Compiled:
              tile_stats=None, resample_in=None):
         """Fill a gmx_run_args for these leaves: (n, args, keep-alive list, outputs).  Sweeps whose
         buffers are persistent bind every step once and re-launch the bindings.
-        tile_stats = (int64 tensor [grid], shift[, int64 tensor [n]]): the launch also writes the per-workgroup
+        tile_stats = (int64 tensor [grid], shift[, int32 tensor [n] | None[, int64 tensor [gmx_tile_prefix_words(n)]]]):
+        the launch also writes the per-workgroup
         fixed-point weight sums gmx_resample_tiles consumes (only if `writes_tile_stats()`) and, with the third
         entry, every particle's fixed-point weight (gmx_resample_tiles_q then reads those instead of the
         log-weights).
@@ -839,6 +840,9 @@ class Compiled:
             if len(tile_stats) > 2 and tile_stats[2] is not None:      # per-particle fixed-point weights (tile_q_d)
                 A.tile_q_d = tile_stats[2].data_ptr()
                 keep.append(tile_stats[2])
+            if len(tile_stats) > 3 and tile_stats[3] is not None:      # tile prefixes by the last workgroup (tile_pref_d)
+                A.tile_pref_d = tile_stats[3].data_ptr()
+                keep.append(tile_stats[3])
         if resample_in is not None:
             r = resample_in
             if anc is not None and r["anc_out"].data_ptr() != A.ancestors_d:

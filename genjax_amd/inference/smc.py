@@ -639,7 +639,168 @@ def capture(loop_fn, *args, warmup: int = 1, noise_ahead=None) -> CapturedLoop:
     return CapturedLoop(loop_fn, *args, warmup=warmup, noise_ahead=noise_ahead)
 
 
-class BootstrapSweep:
+class _NoiseAhead:
+    """The noise-ahead machinery shared by BootstrapSweep and sharded.ShardedBootstrapSweep: background
+    programs that draw the chain programs' hoisted normal / uniform values on a second stream, a group of steps ahead.
+    The host class provides n, T, step_keys, specialize, fuse_mh, `_chain_prog(t)` (the site program of step t) and
+    `_chain_step(t, skip_vm)` (everything step t launches on the chain); `_noise_total` / `_noise_offset`: the keys of
+    this shard are children offset .. offset + n - 1 of split(k, total) (a single GPU: total = n, offset = 0)."""
+
+    NOISE_LDS_PAD = 56000      # bytes of unused LDS per noise workgroup: two of them per CU (160 KB)
+    NOISE_GROUP = 10           # steps per group of noise launches (the noise runs one group ahead of the chain)
+    _noise_offset = 0
+    _noise_total = None
+
+    def _noise_split(self, k):
+        total = self._noise_total or self.n
+        return lazy_split(k, total, offset=self._noise_offset) if (self._noise_offset or total != self.n) else lazy_split(k, self.n)
+
+    def _noise_setup(self, chain_progs, n, T, dev):
+        from ..static import NoiseProgram
+        be = _lib.get()
+        self.noise_ahead = True
+        # one background program per (chain program, root key): the draws that hang off the launch key (the
+        # step's own sites; with rejuvenate=, the move's proposal and accept draws: key k_mh) and those that hang
+        # off the chained extension's key (KSPLITU: k_prop)
+        for P in chain_progs:
+            if id(P) in self._noise_progs:
+                continue
+            by_root = {}
+            for k_, d in enumerate(P.noise):
+                by_root.setdefault(d[0], []).append(k_)
+            self._noise_progs[id(P)] = [(root, NoiseProgram([P.noise[k_] for k_ in idx], (n,)), idx)
+                                        for root, idx in by_root.items()]
+        self.noise_group = max(1, min(int(os.environ.get("GENMI_NOISE_GROUP", self.NOISE_GROUP)), T))
+        # groups of steps [start, end): the noise of group g + 1 is issued before the chain of group g.  The chain
+        # can only start once the FIRST group's noise is there, so the groups grow 1, 2, 4, ... up to noise_group
+        self.noise_groups, self.noise_slot = [], []
+        t0, size = 0, 1
+        while t0 < T:
+            t1 = min(T, t0 + min(size, self.noise_group))
+            for t in range(t0, t1):
+                self.noise_slot.append((len(self.noise_groups) % 2, t - t0))
+            self.noise_groups.append((t0, t1))
+            t0, size = t1, size * 2
+        S = max(len(P.noise) for P in chain_progs)
+        # two groups of noise buffers: the background stream fills one while the chain reads the other.
+        # [half, draw, row of the group, n]: a draw's rows are contiguous, so ONE launch can fill several steps
+        self.zbuf = torch.zeros((2, S, self.noise_group, n), dtype=torch.float32, device=dev)
+        self._noise_stream = torch.cuda.Stream(device=dev) if be.uses_streams else None
+        pad = int(os.environ.get("GENMI_NOISE_LDS_PAD", self.NOISE_LDS_PAD))
+        for plist in self._noise_progs.values():
+            for _, q, _ in plist:
+                if self.specialize:
+                    q.comp.set_background(pad)
+                    q.comp.specialize()
+
+    def _noise_views(self, t, count):
+        """the [1, n] buffers of step t's draws: half (t // group) % 2 of the ring, row t % group"""
+        half, row = self.noise_slot[t]
+        return [self.zbuf[half, k, row:row + 1] for k in range(count)]
+
+    def _noise_leaves(self, t, prog):
+        return [v.reshape(self.n) for v in self._noise_views(t, len(prog.noise))]
+
+    def _noise_runs(self, g):
+        """The background launches of group g: the steps of a group that share a chain program get their draws from ONE
+        launch per key root — a 2-D grid, one row of keys per step (GMX_KEY_ROWSPLIT; gmx_program_run) — instead of
+        one launch per step: fewer nodes in the graph (the HIP runtime walks a two-stream graph node by node on the
+        host) and no launch boundary between the steps' noise.  GENMI_NOISE_ROWS=0: one launch per step."""
+        cache = self.__dict__.setdefault("_noise_run_cache", {})
+        if g in cache:
+            return cache[g]
+        n = self.n
+        t0, t1 = self.noise_groups[g]
+        runs, ta = [], t0
+        while ta < t1:
+            tb = ta + 1
+            while tb < t1 and self._chain_prog(tb) is self._chain_prog(ta):
+                tb += 1
+            runs.append((ta, tb))
+            ta = tb
+        out = []
+        dev = self.zbuf.device
+        for ta, tb in runs:
+            P = self._chain_prog(ta)
+            half, row_a = self.noise_slot[ta]
+            rows = tb - ta
+            mh = self.fuse_mh and ta >= 1
+            for root, q, idx in self._noise_progs[id(P)]:
+                ks = [self.step_keys[t][2] if (mh and root == "LDKEY") else self.step_keys[t][0] for t in range(ta, tb)]
+                if rows == 1 or rows * n >= 2 ** 31 - 4096:
+                    for r, k in enumerate(ks):
+                        out.append((q, (n,), self._noise_split(k), [self.zbuf[half, k_, row_a + r:row_a + r + 1] for k_ in idx]))
+                    continue
+                kd = torch.from_numpy(np.stack([k.host() for k in ks]).astype(np.uint32).view(np.int32)).to(dev)
+                # row r's keys: children offset .. offset + n - 1 of split(ks[r], total) (GMX_KEY_ROWSPLIT + index_offset)
+                key = Key(lazy=("rowsplit", Key(dev=kd), n), split_last=True, offset=self._noise_offset)
+                out.append((q, (rows * n,), key, [self.zbuf[half, k_, row_a:row_a + rows].reshape(1, rows * n) for k_ in idx]))
+        cache[g] = out
+        return out
+
+    def _launch_noise_group(self, g):
+        if os.environ.get("GENMI_NOISE_ROWS", "1") == "0":
+            for t in range(*self.noise_groups[g]):
+                self._launch_noise(t)
+            return
+        for q, batch, key, outs in self._noise_runs(g):
+            q.run(batch, key, outs)
+
+    def _launch_noise(self, t):
+        """the draws step t's chain program reads, by the background programs: root LDKEY from the program's launch key
+        (k_prop; the chained MH + extension program: k_mh), root KSPLITU from the extension's key k_prop"""
+        P = self._chain_prog(t)
+        views = self._noise_views(t, len(P.noise))
+        mh = self.fuse_mh and t >= 1
+        for root, q, idx in self._noise_progs[id(P)]:
+            k = self.step_keys[t][2] if (mh and root == "LDKEY") else self.step_keys[t][0]
+            q.run((self.n,), self._noise_split(k), [views[k_] for k_ in idx])
+
+    def _enqueue_noise_ahead(self, skip_vm=False, skip_noise=False):
+        """The sweep on TWO streams: the chain [site program' -> resampler] per step on the current one, the noise
+        programs on the background stream, one group of steps ahead (group g + 1's noise is issued before group g's
+        chain; it may overwrite half (g + 1) % 2 of the ring once the chain of group g - 1 has read it; the groups
+        grow 1, 2, 4, ... steps up to noise_group, so the chain starts after ONE noise launch).  Capturable:
+        the background stream joins the capture through the first event wait and is joined back at the end.
+        Without streams (the CPU mirror of the C-ABI) the same launches run in issue order."""
+        be = _lib.get()
+        spans = self.noise_groups
+        groups = len(spans)
+        two = be.uses_streams and self._noise_stream is not None
+        if two:
+            A, Bs = torch.cuda.current_stream(be.device), self._noise_stream
+            Bs.wait_stream(A)
+        done, ready = [None] * groups, [None] * groups
+
+        def noise_group(g):
+            if skip_noise:
+                return
+            if two:
+                with torch.cuda.stream(Bs):
+                    if g >= 2:
+                        Bs.wait_event(done[g - 2])
+                    self._launch_noise_group(g)
+                    ready[g] = torch.cuda.Event()
+                    ready[g].record(Bs)
+            else:
+                self._launch_noise_group(g)
+
+        noise_group(0)
+        for g in range(groups):
+            if g + 1 < groups:
+                noise_group(g + 1)
+            if two and not skip_noise:
+                A.wait_event(ready[g])
+            for t in range(*spans[g]):
+                self._chain_step(t, skip_vm)
+            if two and not skip_noise:
+                done[g] = torch.cuda.Event()
+                done[g].record(A)
+        if two:
+            A.wait_stream(Bs)
+
+
+class BootstrapSweep(_NoiseAhead):
     """A whole bootstrap particle filter (T steps, resampling every step) as a
     fixed sequence of launches on one stream, capturable into a hipGraph — two launches per step:
 
@@ -699,6 +860,7 @@ class BootstrapSweep:
             raise NotImplementedError("BootstrapSweep(noise_ahead=True, rejuvenate=...) needs the chained MH + extension "
                                       "program (GENMI_FUSE_MH=0 is set)")
         self.noise_ahead = False
+        self._noise_progs = {}
 
         def MinimalGenerate(*a):
             return _MG(*a, hoist_noise=bool(want_na))
@@ -782,42 +944,8 @@ class BootstrapSweep:
         # the chain's programs by step: t = 0, t = 1, t >= 2
         chain_progs = (self.p_init, self.p_step, self.p_step) if self.rejuvenate is None else \
             (self.p_init, self.p_mhvm_init, self.p_mhvm_step)
-        self._noise_progs = {}
         if want_na and chain_progs[2] is not None and chain_progs[2].noise:
-            self.noise_ahead = True
-            # one background program per (chain program, root key): the draws that hang off the launch key (the
-            # step's own sites; with rejuvenate=, the move's proposal and accept draws: key k_mh) and those that hang
-            # off the chained extension's key (KSPLITU: k_prop)
-            for P in chain_progs:
-                if id(P) in self._noise_progs:
-                    continue
-                by_root = {}
-                for k_, d in enumerate(P.noise):
-                    by_root.setdefault(d[0], []).append(k_)
-                self._noise_progs[id(P)] = [(root, NoiseProgram([P.noise[k_] for k_ in idx], (n,)), idx)
-                                            for root, idx in by_root.items()]
-            self.noise_group = max(1, min(int(os.environ.get("GENMI_NOISE_GROUP", self.NOISE_GROUP)), T))
-            # groups of steps [start, end): the noise of group g + 1 is issued before the chain of group g.  The chain
-            # can only start once the FIRST group's noise is there, so the groups grow 1, 2, 4, ... up to noise_group
-            self.noise_groups, self.noise_slot = [], []
-            t0, size = 0, 1
-            while t0 < T:
-                t1 = min(T, t0 + min(size, self.noise_group))
-                for t in range(t0, t1):
-                    self.noise_slot.append((len(self.noise_groups) % 2, t - t0))
-                self.noise_groups.append((t0, t1))
-                t0, size = t1, size * 2
-            S = max(len(P.noise) for P in chain_progs)
-            # two groups of noise buffers: the background stream fills one while the chain reads the other.
-            # [half, draw, row of the group, n]: a draw's rows are contiguous, so ONE launch can fill several steps
-            self.zbuf = torch.zeros((2, S, self.noise_group, n), dtype=torch.float32, device=dev)
-            self._noise_stream = torch.cuda.Stream(device=dev) if be.uses_streams else None
-            pad = int(os.environ.get("GENMI_NOISE_LDS_PAD", self.NOISE_LDS_PAD))
-            for plist in self._noise_progs.values():
-                for _, q, _ in plist:
-                    if self.specialize:
-                        q.comp.set_background(pad)
-                        q.comp.specialize()
+            self._noise_setup(chain_progs, n, T, dev)
         elif want_na and any(P is not None and P.noise for P in chain_progs):
             # the steady-state program draws nothing ahead although another one would: the plain programs throughout
             self.noise_ahead_req = False
@@ -857,6 +985,18 @@ class BootstrapSweep:
         # very end of the site program (they need the block maximum), where nothing overlaps them.  Off by default.
         self.tile_q = torch.zeros((n,), dtype=torch.int32, device=dev) \
             if self.tile_stats and os.environ.get("GENMI_TILE_Q", "0") == "1" else None
+        # ... and, on request (GENMI_TILE_PREFIX=1), the tile PREFIXES (gmx_run_args.tile_pref_d): the last workgroup of
+        # the site program to finish turns all (m_b, A_b) into M, K, the exclusive prefixes and the total ONCE, and the
+        # resampler's workgroups read one prefix each (gmx_resample_tiles_p) instead of every one of them reducing the
+        # whole table (977 times at 1e6 particles: ~130 of the resampler's 541 vector instructions per wave).  Measured
+        # on MI355X (profiles/r03d_ab_tile_prefix*.json, A/B in one process, bit-identical): config 3 32.0 -> 31.4
+        # us/step, config 2 15.0 -> 15.9 — the publication (two atomic exchanges, a two-level ticket, the last
+        # workgroup's pass) is three to four dependent memory round trips at the END of the site program, on the
+        # chain's critical path, and config 2's site program is too short to hide them.  Off by default.
+        self.tile_pref = None
+        if self.tile_stats and self.tile_q is None and os.environ.get("GENMI_TILE_PREFIX", "0") == "1" \
+                and os.environ.get("GENMI_FUSE_RESAMPLE", "0") != "1":
+            self.tile_pref = torch.zeros((int(be.c.gmx_tile_prefix_words(n)),), dtype=torch.int64, device=dev)
         # ONE launch per step: the program that gathers the resampled state (the extension; with rejuvenate=, the MH
         # move) first computes its workgroup's ancestors itself, from the previous step's log-weights and tile
         # statistics (gmx_run_args.rs, csrc/gmx_resample.h) — same integers as gmx_resample_tiles, no second kernel,
@@ -913,16 +1053,8 @@ class BootstrapSweep:
             bufs[prog.ro[1]] = self.x_store[t % 2]
         bufs[prog.wo[1]] = self.lw_pp[t % 2].reshape(1, n)
         prog.comp.run(leaves, (n,), lazy_split(k_prop, n), red_out=self.partials_pp[t % 2], out_buffers=bufs,
-                      tile_stats=(self.tile_agg_pp[t % 2], self.shift, self.tile_q) if self.tile_stats else None,
+                      tile_stats=(self.tile_agg_pp[t % 2], self.shift, self.tile_q, self.tile_pref) if self.tile_stats else None,
                       resample_in=self._resample_in(t) if (self.fuse and t >= 1 and self.rejuvenate is None) else None)
-
-    def _noise_views(self, t, count):
-        """the [1, n] buffers of step t's draws: half (t // group) % 2 of the ring, row t % group"""
-        half, row = self.noise_slot[t]
-        return [self.zbuf[half, k, row:row + 1] for k in range(count)]
-
-    def _noise_leaves(self, t, prog):
-        return [v.reshape(self.n) for v in self._noise_views(t, len(prog.noise))]
 
     def _chain_prog(self, t):
         if t == 0:
@@ -930,60 +1062,6 @@ class BootstrapSweep:
         if self.fuse_mh:
             return self.p_mhvm_init if t == 1 else self.p_mhvm_step
         return self.p_step
-
-    def _noise_runs(self, g):
-        """The background launches of group g: the steps of a group that share a chain program get their draws from ONE
-        launch per key root — a 2-D grid, one row of keys per step (GMX_KEY_ROWSPLIT; gmx_program_run) — instead of
-        one launch per step: fewer nodes in the graph (the HIP runtime walks a two-stream graph node by node on the
-        host) and no launch boundary between the steps' noise.  GENMI_NOISE_ROWS=0: one launch per step."""
-        cache = self.__dict__.setdefault("_noise_run_cache", {})
-        if g in cache:
-            return cache[g]
-        n = self.n
-        t0, t1 = self.noise_groups[g]
-        runs, ta = [], t0
-        while ta < t1:
-            tb = ta + 1
-            while tb < t1 and self._chain_prog(tb) is self._chain_prog(ta):
-                tb += 1
-            runs.append((ta, tb))
-            ta = tb
-        out = []
-        dev = self.zbuf.device
-        for ta, tb in runs:
-            P = self._chain_prog(ta)
-            half, row_a = self.noise_slot[ta]
-            rows = tb - ta
-            mh = self.fuse_mh and ta >= 1
-            for root, q, idx in self._noise_progs[id(P)]:
-                ks = [self.step_keys[t][2] if (mh and root == "LDKEY") else self.step_keys[t][0] for t in range(ta, tb)]
-                if rows == 1 or rows * n >= 2 ** 31 - 4096:
-                    for r, k in enumerate(ks):
-                        out.append((q, (n,), lazy_split(k, n), [self.zbuf[half, k_, row_a + r:row_a + r + 1] for k_ in idx]))
-                    continue
-                kd = torch.from_numpy(np.stack([k.host() for k in ks]).astype(np.uint32).view(np.int32)).to(dev)
-                key = Key(lazy=("rowsplit", Key(dev=kd), n), split_last=True)
-                out.append((q, (rows * n,), key, [self.zbuf[half, k_, row_a:row_a + rows].reshape(1, rows * n) for k_ in idx]))
-        cache[g] = out
-        return out
-
-    def _launch_noise_group(self, g):
-        if os.environ.get("GENMI_NOISE_ROWS", "1") == "0":
-            for t in range(*self.noise_groups[g]):
-                self._launch_noise(t)
-            return
-        for q, batch, key, outs in self._noise_runs(g):
-            q.run(batch, key, outs)
-
-    def _launch_noise(self, t):
-        """the draws step t's chain program reads, by the background programs: root LDKEY from the program's launch key
-        (k_prop; the chained MH + extension program: k_mh), root KSPLITU from the extension's key k_prop"""
-        P = self._chain_prog(t)
-        views = self._noise_views(t, len(P.noise))
-        mh = self.fuse_mh and t >= 1
-        for root, q, idx in self._noise_progs[id(P)]:
-            k = self.step_keys[t][2] if (mh and root == "LDKEY") else self.step_keys[t][0]
-            q.run((self.n,), lazy_split(k, self.n), [views[k_] for k_ in idx])
 
     def _resample_in(self, t):
         """gmx_run_args.rs of the launch of step t (>= 1) that gathers: resample step t-1's weights first"""
@@ -1037,7 +1115,7 @@ class BootstrapSweep:
         bufs[prog.ro[1]] = self.x_store[t % 2]
         bufs[prog.wo[1]] = self.lw_pp[t % 2].reshape(1, n)
         prog.comp.run(leaves, (n,), lazy_split(k_mh, n), red_out=self.partials_pp[t % 2], out_buffers=bufs,
-                      tile_stats=(self.tile_agg_pp[t % 2], self.shift, self.tile_q) if self.tile_stats else None,
+                      tile_stats=(self.tile_agg_pp[t % 2], self.shift, self.tile_q, self.tile_pref) if self.tile_stats else None,
                       resample_in=self._resample_in(t) if self.fuse else None)
 
     def _rows(self, t) -> int:
@@ -1077,6 +1155,12 @@ class BootstrapSweep:
                                                be.ptr(self.totals[t:t + 1]), be.ptr(self.anc), be.stream()),
                      "gmx_resample_tiles_q")
             return
+        if self.tile_stats and self.tile_pref is not None:     # the site program's last workgroup left the prefixes
+            be.check(be.c.gmx_resample_tiles_p(self.kind, kk, be.ptr(self.lw), self.n, self.shift, be.ptr(self.partials),
+                                               be.ptr(self.tile_pref), be.ptr(self.maxs[t:t + 1]),
+                                               be.ptr(self.totals[t:t + 1]), be.ptr(self.anc), be.stream()),
+                     "gmx_resample_tiles_p")
+            return
         if self.tile_stats:        # tile maxima = the workgroup maxima the site program left in partials[0]
             w = t % 2
             be.check(be.c.gmx_resample_tiles(self.kind, kk, be.ptr(self.lw_pp[w]), self.n, self.shift,
@@ -1089,6 +1173,19 @@ class BootstrapSweep:
                                    self._rows(t), be.ptr(self.maxs[t:t + 1]),
                                    be.ptr(self.totals[t:t + 1]), be.ptr(self.anc), be.ptr(self.rs_ws),
                                    be.stream()), "gmx_resample")
+
+    def _chain_step(self, t, skip_vm=False):
+        """everything step t launches on the chain (noise-ahead form): site program', then the resampler"""
+        if not skip_vm:
+            if t >= 1 and self.fuse_mh:
+                self._launch_mhvm(t)
+            else:
+                self._launch_vm(t)
+        if self.fused:
+            self._launch_resample(t)
+        else:
+            self._launch_cdf(t)
+            self._launch_anc(t)
 
     def enqueue(self, skip_vm=False):
         """Issue every launch of the sweep on the current stream (no syncs, no allocations).
@@ -1113,58 +1210,6 @@ class BootstrapSweep:
             else:
                 self._launch_cdf(t)
                 self._launch_anc(t)
-
-    def _enqueue_noise_ahead(self, skip_vm=False, skip_noise=False):
-        """The sweep on TWO streams: the chain [site program' -> resampler] per step on the current one, the noise
-        programs on the background stream, one group of steps ahead (group g + 1's noise is issued before group g's
-        chain; it may overwrite half (g + 1) % 2 of the ring once the chain of group g - 1 has read it; the groups
-        grow 1, 2, 4, ... steps up to noise_group, so the chain starts after ONE noise launch).  Capturable:
-        the background stream joins the capture through the first event wait and is joined back at the end.
-        Without streams (the CPU mirror of the C-ABI) the same launches run in issue order."""
-        be = _lib.get()
-        spans = self.noise_groups
-        groups = len(spans)
-        two = be.uses_streams and self._noise_stream is not None
-        if two:
-            A, Bs = torch.cuda.current_stream(be.device), self._noise_stream
-            Bs.wait_stream(A)
-        done, ready = [None] * groups, [None] * groups
-
-        def noise_group(g):
-            if skip_noise:
-                return
-            if two:
-                with torch.cuda.stream(Bs):
-                    if g >= 2:
-                        Bs.wait_event(done[g - 2])
-                    self._launch_noise_group(g)
-                    ready[g] = torch.cuda.Event()
-                    ready[g].record(Bs)
-            else:
-                self._launch_noise_group(g)
-
-        noise_group(0)
-        for g in range(groups):
-            if g + 1 < groups:
-                noise_group(g + 1)
-            if two and not skip_noise:
-                A.wait_event(ready[g])
-            for t in range(*spans[g]):
-                if not skip_vm:
-                    if t >= 1 and self.fuse_mh:
-                        self._launch_mhvm(t)
-                    else:
-                        self._launch_vm(t)
-                if self.fused:
-                    self._launch_resample(t)
-                else:
-                    self._launch_cdf(t)
-                    self._launch_anc(t)
-            if two and not skip_noise:
-                done[g] = torch.cuda.Event()
-                done[g].record(A)
-        if two:
-            A.wait_stream(Bs)
 
     def kernel_timers(self):
         """Representative single launches (a mid-sweep step) for per-kernel timing in bench.py."""

@@ -39,7 +39,7 @@ typedef __UINTPTR_TYPE__ uintptr_t;
 extern "C" {
 #endif
 
-#define GMX_ABI_VERSION 3
+#define GMX_ABI_VERSION 4
 
 typedef void* gmx_stream;            /* hipStream_t */
 typedef struct gmx_program gmx_program;
@@ -103,7 +103,7 @@ enum {
   GMX_KEY_NONE = 0,     /* program draws nothing (assess)                      */
   GMX_KEY_ARRAY = 1,    /* keys_d[i]                                           */
   GMX_KEY_SPLIT = 2,    /* split((key0,key1), *)[index_offset + i]             */
-  GMX_KEY_ROWSPLIT = 3, /* split(keys_d[i / key_inner], key_inner)[i % inner]  */
+  GMX_KEY_ROWSPLIT = 3, /* child index_offset + i % inner of keys_d[i / key_inner] (= split(row key, .)[...]) */
   GMX_KEY_BCAST = 4     /* (key0,key1) for every particle                      */
 };
 
@@ -157,6 +157,15 @@ typedef struct gmx_run_args {
                                      resampler (gmx_resample_tiles_q) reads these instead of the log-weights and
                                      needs no second exp per particle                                            */
   gmx_resample_in rs;             /* optional (rs.lw_d != NULL): resample first, in the same launch — see above  */
+  uint64_t* tile_pref_d;          /* optional, with tile_agg_d: gmx_tile_prefix_words(n) u64.  The LAST workgroup of the
+                                     launch to finish (an atomic ticket after the statistics are written) turns ALL
+                                     tile statistics into what every workgroup of the resampler would otherwise
+                                     re-derive for itself: M = max_b m_b, K = ceil(M / ln 2),
+                                     [b] = sum_{b' < b} A_b' >> (K - k_b')  (exclusive tile prefix, b < tiles),
+                                     [tiles] = the total, [tiles + 1] = M's float bits | (uint64)(uint32)K << 32,
+                                     [tiles + 2] and everything after it = ticket counters (a master and 32
+                                     sub-counters on 128-byte lines of their own): ZERO before the first launch, reset
+                                     to zero by the workgroups that exhaust them.  gmx_resample_tiles_p consumes it. */
 } gmx_run_args;
 
 int gmx_program_create(const uint32_t* blob_h, size_t n_words, gmx_program** out);
@@ -280,6 +289,16 @@ int gmx_resample(int kind, const uint32_t key[2], const float* lw_d, int64_t n, 
  * gmx_run_args.tile_q_d (same tile statistics, same ancestors). */
 int gmx_resample_tiles_q(int kind, const uint32_t key[2], const uint32_t* q_d, int64_t n, int shift,
                          const float* tile_max_d, const uint64_t* tile_agg_d, float* max_d,
+                         uint64_t* total_d, int32_t* ancestors_d, gmx_stream stream);
+/* gmx_resample_tiles when the tile PREFIXES are there already (gmx_run_args.tile_pref_d, written once by the last
+ * workgroup of the site program; or gmx_tile_prefix from the statistics): a workgroup reads ONE prefix, the total and
+ * K instead of reducing all <= 2048 tile statistics — the same integers, the same ancestors.
+ * gmx_tile_prefix_words(n): u64 words of the block (ceil(n / 1024) + 3, rounded up to 16, + 32 x 16 of tickets). */
+size_t gmx_tile_prefix_words(int64_t n);
+int gmx_tile_prefix(const float* tile_max_d, const uint64_t* tile_agg_d, int64_t n, uint64_t* tile_pref_d,
+                    gmx_stream stream);
+int gmx_resample_tiles_p(int kind, const uint32_t key[2], const float* lw_d, int64_t n, int shift,
+                         const float* tile_max_d, const uint64_t* tile_pref_d, float* max_d,
                          uint64_t* total_d, int32_t* ancestors_d, gmx_stream stream);
 int gmx_gather(const void* const* src_d, void* const* dst_d, const int32_t* elem_bytes,
                int32_t n_leaves, const int32_t* ancestors_d, int64_t n_out,

@@ -127,6 +127,7 @@ static float butterfly_sum64(const float* v) {
   return t[0];
 }
 
+extern "C" int gmx_tile_prefix(const float* tmax, const uint64_t* agg, int64_t n, uint64_t* pref, gmx_stream);
 extern "C" int gmx_program_run(const gmx_program* p, int64_t n, const gmx_run_args* A_in, gmx_stream) {
   if (!p || !A_in) return fail("program_run: null");
   gmx_run_args patched = *A_in;
@@ -185,6 +186,11 @@ extern "C" int gmx_program_run(const gmx_program* p, int64_t n, const gmx_run_ar
         A->tile_agg_d[blk] = sum;
       }
     }
+  }
+  if (A->tile_pref_d) {       // what the last workgroup of the HIP kernel leaves (include/genmi.h: tile_pref_d)
+    if (!tile || !A->tile_agg_d || !A->red_out_d) return fail("program_run: tile_pref_d needs tile_agg_d and red_out_d");
+    if ((uint32_t)A->tile_pref_d[grid + 2] != 0u) return fail("program_run: the ticket word of tile_pref_d must be zero");
+    if (gmx_tile_prefix(A->red_out_d, A->tile_agg_d, n, A->tile_pref_d, nullptr)) return 1;
   }
   return 0;
 }
@@ -312,6 +318,50 @@ extern "C" int gmx_resample_tiles(int kind, const uint32_t key[2], const float* 
     prefix += gmx_tile_scale(agg[b], k, K);
   }
   *max_d = M; *total = prefix;
+  return gmx_ancestors(kind, key, cdf.data(), n, 0, total, n, 0, n, anc, st);
+}
+// tile statistics -> tile prefixes (sequential statement of gmx_block.h: gmx_tile_prefix_block)
+extern "C" size_t gmx_tile_prefix_words(int64_t n) {       // prefixes | total | M, K | master ticket | pad to 16 | 32 sub-tickets x 16 words
+  return (size_t)(((n + HS_TILE - 1) / HS_TILE + 3 + 15) / 16) * 16 + 32 * 16;
+}
+extern "C" int gmx_tile_prefix(const float* tmax, const uint64_t* agg, int64_t n, uint64_t* pref, gmx_stream) {
+  if (n <= 0 || !tmax || !agg || !pref) return fail("tile_prefix: bad argument");
+  const int64_t tiles = (n + HS_TILE - 1) / HS_TILE;
+  if (tiles > 2048) return fail("tile_prefix: n out of range");
+  float M = -gmx_inf();
+  for (int64_t b = 0; b < tiles; ++b) M = gmx_rmax(M, tmax[b]);
+  const int32_t K = gmx_tile_exp(M);
+  uint64_t run = 0;
+  for (int64_t b = 0; b < tiles; ++b) { pref[b] = run; run += gmx_tile_scale(agg[b], gmx_tile_exp(tmax[b]), K); }
+  pref[tiles] = run;
+  pref[tiles + 1] = (uint64_t)gmx_f2u(M) | ((uint64_t)(uint32_t)K << 32);
+  return 0;
+}
+// gmx_resample_tiles reading the prefixes instead of reducing the table: the mirror checks them against the
+// statistics-free definition (the CDF rebuilt from the log-weights alone) on the way
+extern "C" int gmx_resample_tiles_p(int kind, const uint32_t key[2], const float* lw, int64_t n, int shift, const float* tmax,
+                                    const uint64_t* pref, float* max_d, uint64_t* total, int32_t* anc, gmx_stream st) {
+  if (kind == GMX_RESAMPLE_MULTINOMIAL) return fail("resample: kind");
+  if (!lw || !tmax || !pref || !max_d || !total || !anc) return fail("resample_tiles_p: bad argument");
+  const int64_t tiles = (n + HS_TILE - 1) / HS_TILE;
+  const float M = gmx_u2f((uint32_t)pref[tiles + 1]);
+  const int32_t K = (int32_t)(uint32_t)(pref[tiles + 1] >> 32);
+  if (K != gmx_tile_exp(M)) return fail("resample_tiles_p: (M, K) of the prefix block disagree");
+  const float scale = gmx_pow2i(shift);
+  std::vector<uint64_t> cdf((size_t)n);
+  for (int64_t b = 0; b < tiles; ++b) {
+    const int64_t lo = b * HS_TILE, hi = lo + HS_TILE < n ? lo + HS_TILE : n;
+    const int32_t k = gmx_tile_exp(tmax[b]);
+    const float ref = gmx_tile_ref(k);
+    uint64_t run = 0;
+    for (int64_t i = lo; i < hi; ++i) {
+      run += hs_weight_fixed(lw[i], ref, scale);
+      cdf[(size_t)i] = pref[b] + gmx_tile_scale(run, k, K);
+    }
+    const uint64_t next = pref[b] + gmx_tile_scale(run, k, K);
+    if (next != pref[b + 1]) return fail("resample_tiles_p: the prefixes do not match the log-weights");
+  }
+  *max_d = M; *total = pref[tiles];
   return gmx_ancestors(kind, key, cdf.data(), n, 0, total, n, 0, n, anc, st);
 }
 // the same from the per-particle fixed-point weights the site program left behind

@@ -1039,6 +1039,48 @@ def test_tile_stats_from_the_site_program(gpu):
         assert int(q.sum()) == int(agg[b].item()) and float(tmax[b].item()) == float(x.max())
 
 
+@pytest.mark.parametrize("n", [100_003, 1_000_000, 2_000_000])
+def test_tile_prefixes_from_the_last_workgroup(gpu, monkeypatch, n):
+    """gmx_run_args.tile_pref_d: the site program's LAST workgroup (atomic ticket) leaves M, K, the exclusive tile
+    prefixes and the total; they equal gmx_tile_prefix of the statistics and the host's integers, the ticket word is
+    back at zero, and the sweep through gmx_resample_tiles_p equals the sweep through gmx_resample_tiles bit for bit
+    (PER = 1 / 4 / 8 rows of the table per thread)."""
+    import genjax_amd as G
+    from genjax_amd import _lib, workloads
+    from genjax_amd.inference.smc import BootstrapSweep
+    be = _lib.get()
+    T = 4
+    init, step = workloads.make_lgssm(G)
+    ys = torch.from_numpy(workloads.lgssm_data(T))
+    monkeypatch.setenv("GENMI_TILE_PREFIX", "1")             # opt-in (slower on config 2, faster on config 3)
+    sw = BootstrapSweep(init, step, n, T).prepare(G.key(2), ys)
+    assert sw.tile_pref is not None
+    for _ in range(3):                     # the ticket resets itself: launch after launch
+        sw.launch()
+    torch.cuda.synchronize()
+    tiles = (n + 1023) // 1024
+    pref = sw.tile_pref.cpu().numpy().view(np.uint64)
+    assert not pref[tiles + 2:].any()                # the master ticket and the 32 sub-tickets are back at zero
+    ref = torch.zeros_like(sw.tile_pref)
+    be.check(be.c.gmx_tile_prefix(be.ptr(sw.partials), be.ptr(sw.tile_agg), n, be.ptr(ref), be.stream()), "gmx_tile_prefix")
+    assert torch.equal(ref[:tiles + 2], sw.tile_pref[:tiles + 2])
+    tm = sw.partials[0, :tiles].cpu().numpy()
+    agg = sw.tile_agg.cpu().numpy().view(np.uint64)
+    M = tm.max()
+    K = O.tile_exp(M)
+    G_ = [int(a) >> min(K - O.tile_exp(m), 63) for a, m in zip(agg, tm)]
+    assert [int(v) for v in pref[:tiles]] == list(np.cumsum([0] + G_[:-1], dtype=object))
+    assert int(pref[tiles]) == sum(G_) == int(sw.totals[T - 1].item()) & (2 ** 64 - 1)
+    assert int(pref[tiles + 1]) & 0xFFFFFFFF == int(np.float32(M).view(np.uint32)) and (int(pref[tiles + 1]) >> 32) == K & 0xFFFFFFFF
+    monkeypatch.setenv("GENMI_TILE_PREFIX", "0")
+    sw0 = BootstrapSweep(init, step, n, T).prepare(G.key(2), ys)
+    assert sw0.tile_pref is None
+    sw0.launch()
+    torch.cuda.synchronize()
+    assert torch.equal(sw0.anc, sw.anc) and torch.equal(sw0.totals, sw.totals) and torch.equal(sw0.maxs, sw.maxs)
+    assert torch.equal(sw0.x[(T - 1) % 2], sw.x[(T - 1) % 2])
+
+
 def test_tile_stats_are_dropped_when_the_weights_change_in_place(gpu):
     """`extend` leaves the resampler's tile statistics on the weight tensor; an in-place change of the
     weights afterwards (tempering, masking) must not be resampled against the stale statistics."""

@@ -263,7 +263,12 @@ def main():
         sw = ShardedBootstrapSweep(init, step, n, T, dist, always_communicate=True).prepare(
             G.key(seed), torch.from_numpy(ys))
 
-        if os.environ.get("GENMI_SHARDED_GRAPH") == "1":      # opt-in: see ShardedBootstrapSweep.capture
+        # the whole sharded sweep — kernels, both streams of the noise-ahead form AND the RCCL collectives (issued by
+        # comm.RcclComm on the kernels' own stream) — as one hipGraph, like the single-GPU sweep.  Not with the
+        # torch.distributed fallback communicator (its watchdog queries events recorded inside a capture), not on
+        # the CPU mirror; GENMI_SHARDED_GRAPH=0 keeps eager launches.
+        if (on_gpu and not args.no_graph and os.environ.get("GENMI_SHARDED_GRAPH", "1") != "0"
+                and (sw.cx is None or sw.cx.graph_safe)):
             sw.capture()
 
         def launch():
@@ -309,7 +314,8 @@ def main():
                    "particles_per_gpu": n, "particles_total": total_particles, "T": T,
                    "resampler": "systematic", "graph": not args.no_graph and single,
                    "path": ("BootstrapSweep (hipGraph" + (", noise ahead on a second stream)" if getattr(sw, "noise_ahead", False)
-                                                         else ")")) if single else "ShardedBootstrapSweep (RCCL)",
+                                                         else ")")) if single else
+                   ("ShardedBootstrapSweep (RCCL" + (", noise ahead on a second stream" if getattr(sw, "noise_ahead", False) else "") + ")"),
                    "key": seed},
         "log_ml": log_ml, "log_ml_kalman": kal, "log_ml_abs_err": abs(log_ml - kal),
         "log_ml_rel_err": abs(log_ml - kal) / abs(kal),

@@ -138,6 +138,8 @@ class Backend:
         c.gmx_shard_step_tiles.argtypes = [c_int, POINTER(c_uint32), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                            c_void_p, c_int, c_int, c_int, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
                                            c_void_p]
+        c.gmx_shard_step_fused.argtypes = [c_int, POINTER(c_uint32), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                           c_int, c_int, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]
         c.gmx_shard_plan_words.argtypes = [c_int]
         c.gmx_shard_plan_words.restype = c_size_t
         c.gmx_shard_plan.argtypes = [c_int, POINTER(c_uint32), c_void_p, c_int, c_int, c_int64, c_void_p, c_void_p,

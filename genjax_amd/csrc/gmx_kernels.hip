@@ -2048,31 +2048,62 @@ k_shard_route(int kind, uint32_t k0, uint32_t k1, int64_t* __restrict__ plan, co
 // where a source's local CDF value comes from: the array gmx_weight_cdf wrote (TILES = false), or — like
 // k_offspring_tile — rebuilt in registers from the log-weights and this rank's tile statistics (TILES = true:
 // a block is one 1024-particle tile; tmax / agg are this rank's, *max_g the GLOBAL max log-weight)
-struct shard_tiles { const float* lw; const float* tmax; const uint64_t* agg; const float* max_g; float scale; int n_tiles; };
+// FUSED (with TILES): the all-gathered statistics table itself (stats_all: `world` blocks of `stride` bytes) instead of
+// the totals gmx_shard_totals derives from it — every block reduces the table (world x tiles rows: the global max, then
+// one integer total per rank), which takes a one-block launch out of the step's dependent chain.
+struct shard_tiles { const float* lw; const float* tmax; const uint64_t* agg; const float* max_g; float scale; int n_tiles;
+                     const uint8_t* stats_all; size_t stride; float* max_out; };
 
-template <bool TILES>
+template <bool TILES, bool FUSED>
 __global__ void __launch_bounds__(GMX_BLOCK)
 k_shard_step(int kind, uint32_t k0, uint32_t k1, const uint64_t* __restrict__ totals, int64_t* __restrict__ plan,
              uint64_t* __restrict__ total_out, const uint64_t* __restrict__ cdf, const shard_tiles TS, int rank,
              int world, int64_t n, int64_t cap, const uint32_t* __restrict__ state, uint32_t* __restrict__ send,
              int32_t* __restrict__ next_idx) {
+  static_assert(!FUSED || TILES, "the fused form works from tile statistics");
   __shared__ int64_t s_bounds[SHARD_MAX_WORLD + 1];
   __shared__ uint64_t s_tot[2];            // global total, this rank's CDF offset
   __shared__ uint64_t s_below[4], s_scan[4];
+  __shared__ uint64_t s_rtot[FUSED ? SHARD_MAX_WORLD : 1];
+  __shared__ float s_lds4[4];
   gmx_key key; key.k0 = k0; key.k1 = k1;
   const uint64_t u0 = gmx_bits32(key, 0) >> 9;
   const int64_t N = n * world, base = (int64_t)rank * n;
   const uint64_t D = (uint64_t)N << 23;
+  int32_t K_fused = 0;
+  if (FUSED) {
+    const int tiles_pad = TS.n_tiles + (TS.n_tiles & 1);
+    float m = -gmx_inf();
+    for (int r = 0; r < world; ++r) {
+      const float* tmax = reinterpret_cast<const float*>(TS.stats_all + (size_t)r * TS.stride + (size_t)tiles_pad * 8);
+      for (int t = (int)threadIdx.x; t < TS.n_tiles; t += GMX_BLOCK) m = gmx_rmax(m, tmax[t]);
+    }
+    const float M = block_max(m, s_lds4);
+    K_fused = gmx_tile_exp(M);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && TS.max_out) *TS.max_out = M;
+    for (int r = 0; r < world; ++r) {
+      const uint64_t* agg = reinterpret_cast<const uint64_t*>(TS.stats_all + (size_t)r * TS.stride);
+      const float* tmax = reinterpret_cast<const float*>(TS.stats_all + (size_t)r * TS.stride + (size_t)tiles_pad * 8);
+      uint64_t sum = 0;
+      for (int t = (int)threadIdx.x; t < TS.n_tiles; t += GMX_BLOCK) sum += gmx_tile_scale(agg[t], gmx_tile_exp(tmax[t]), K_fused);
+      sum = wave_sum_u64(sum);
+      __syncthreads();
+      if ((threadIdx.x & 63) == 0) s_scan[threadIdx.x >> 6] = sum;
+      __syncthreads();
+      if (threadIdx.x == 0) s_rtot[r] = (s_scan[0] + s_scan[1]) + (s_scan[2] + s_scan[3]);
+    }
+    __syncthreads();
+  }
   if (threadIdx.x == 0) {
     uint64_t total = 0;
-    for (int s = 0; s < world; ++s) total += totals[s];
+    for (int s = 0; s < world; ++s) total += FUSED ? s_rtot[s] : totals[s];
     const double not_ = total ? (double)N / (double)total : 0.0;
     const double eps_ = (double)N * 0x1p-44 + 0x1p-40;
     uint64_t off = 0, mine = 0;
     for (int s = 0; s < world; ++s) {
       if (s == rank) mine = off;
       s_bounds[s] = total ? slots_below(kind, key, u0, off, D, total, not_, eps_, N) : 0;
-      off += totals[s];
+      off += FUSED ? s_rtot[s] : totals[s];
     }
     s_bounds[world] = N;
     s_tot[0] = total; s_tot[1] = mine;
@@ -2116,7 +2147,7 @@ k_shard_step(int kind, uint32_t k0, uint32_t k1, const uint64_t* __restrict__ to
       // this rank's CDF at my 4 sources = (mass of this rank's earlier tiles) + (tile-local sums >> (K - k_b)),
       // with the tile-local sums rebuilt from the log-weights (k_offspring_tile's scheme)
       const int wave = threadIdx.x >> 6, my_tile = (int)blockIdx.x;
-      const int32_t K = gmx_tile_exp(*TS.max_g);
+      const int32_t K = FUSED ? K_fused : gmx_tile_exp(*TS.max_g);
       const int32_t k_b = gmx_tile_exp(TS.tmax[my_tile]);
       const float ref_b = gmx_tile_ref(k_b);
       float x[4];
@@ -2236,8 +2267,8 @@ extern "C" int gmx_shard_step(int kind, const uint32_t key[2], const uint64_t* t
                            stream);
   }
   if ((uintptr_t)cdf_d & 15) return gmx_fail("gmx_shard_step: cdf_d must be 16-byte aligned%s");
-  shard_tiles none = {nullptr, nullptr, nullptr, nullptr, 0.0f, 0};
-  hipLaunchKernelGGL(k_shard_step<false>, grid_for((n_per_rank + 3) / 4), dim3(GMX_BLOCK), 0, (hipStream_t)stream,
+  shard_tiles none = {nullptr, nullptr, nullptr, nullptr, 0.0f, 0, nullptr, 0, nullptr};
+  hipLaunchKernelGGL((k_shard_step<false, false>), grid_for((n_per_rank + 3) / 4), dim3(GMX_BLOCK), 0, (hipStream_t)stream,
                      kind, key[0], key[1], totals_d, plan_d, total_out_d, cdf_d, none, rank, world, n_per_rank,
                      capacity, (const uint32_t*)state_d, (uint32_t*)send_d, next_idx_d);
   GMX_HIP(hipGetLastError());
@@ -2320,9 +2351,44 @@ extern "C" int gmx_shard_step_tiles(int kind, const uint32_t key[2], const uint6
   ts.agg = (const uint64_t*)stats_own_d;
   ts.tmax = (const float*)((const uint8_t*)stats_own_d + (size_t)tiles_pad * 8);
   ts.max_g = max_d; ts.scale = gmx_pow2i(shift); ts.n_tiles = (int)tiles;
-  hipLaunchKernelGGL(k_shard_step<true>, dim3((unsigned)tiles), dim3(GMX_BLOCK), 0, (hipStream_t)stream, kind, key[0],
+  ts.stats_all = nullptr; ts.stride = 0; ts.max_out = nullptr;
+  hipLaunchKernelGGL((k_shard_step<true, false>), dim3((unsigned)tiles), dim3(GMX_BLOCK), 0, (hipStream_t)stream, kind, key[0],
                      key[1], totals_d, plan_d, total_out_d, (const uint64_t*)nullptr, ts, rank, world, n_per_rank,
                      capacity, (const uint32_t*)state_d, (uint32_t*)send_d, next_idx_d);
+  GMX_HIP(hipGetLastError());
+  return 0;
+}
+
+// gmx_shard_totals + gmx_shard_step_tiles as ONE launch: straight from the all-gathered statistics table.
+extern "C" int gmx_shard_step_fused(int kind, const uint32_t key[2], const void* stats_all_d, int64_t* plan_d,
+                                    uint64_t* total_out_d, const float* lw_d, float* max_out_d, int shift, int rank,
+                                    int world, int64_t n_per_rank, int64_t capacity, const void* state_d, void* send_d,
+                                    int32_t* next_idx_d, gmx_stream stream) {
+  if (shard_check("gmx_shard_step_fused", kind, key, rank, world, n_per_rank)) return 1;
+  if (!stats_all_d || !plan_d || !lw_d || !max_out_d || !state_d || !send_d || !next_idx_d)
+    return gmx_fail("gmx_shard_step_fused: null argument%s");
+  if (capacity < 1 || capacity > n_per_rank)
+    return gmx_fail("gmx_shard_step_fused: capacity must be in [1, n_per_rank]%s");
+  if (n_per_rank + (int64_t)world * capacity > 0x7fffffffLL)
+    return gmx_fail("gmx_shard_step_fused: extended state index exceeds int32%s");
+  if (world > SHARD_MAX_WORLD) return gmx_fail("gmx_shard_step_fused: world <= 64%s");
+  if (shift < 1 || shift > 62) return gmx_fail("gmx_shard_step_fused: shift out of range%s");
+  const int64_t tiles = (n_per_rank + RS_TILE - 1) / RS_TILE;
+  if (tiles > RS_MAX_TILES) return gmx_fail("gmx_shard_step_fused: n_per_rank too large (<= 2^21)%s");
+  if (((uintptr_t)lw_d & 15) || ((uintptr_t)stats_all_d & 7))
+    return gmx_fail("gmx_shard_step_fused: lw_d must be 16-byte and stats_all_d 8-byte aligned%s");
+  const int64_t tiles_pad = tiles + (tiles & 1);
+  const size_t stride = gmx_shard_stats_bytes(n_per_rank);
+  const uint8_t* own = (const uint8_t*)stats_all_d + (size_t)rank * stride;
+  shard_tiles ts;
+  ts.lw = lw_d;
+  ts.agg = (const uint64_t*)own;
+  ts.tmax = (const float*)(own + (size_t)tiles_pad * 8);
+  ts.max_g = nullptr; ts.scale = gmx_pow2i(shift); ts.n_tiles = (int)tiles;
+  ts.stats_all = (const uint8_t*)stats_all_d; ts.stride = stride; ts.max_out = max_out_d;
+  hipLaunchKernelGGL((k_shard_step<true, true>), dim3((unsigned)tiles), dim3(GMX_BLOCK), 0, (hipStream_t)stream, kind, key[0],
+                     key[1], (const uint64_t*)nullptr, plan_d, total_out_d, (const uint64_t*)nullptr, ts, rank, world,
+                     n_per_rank, capacity, (const uint32_t*)state_d, (uint32_t*)send_d, next_idx_d);
   GMX_HIP(hipGetLastError());
   return 0;
 }

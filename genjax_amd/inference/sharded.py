@@ -43,7 +43,7 @@ from .. import _lib
 from ..core.choice_map import ChoiceMap
 from ..random import Key, fold_in, lazy_split, split
 from ..engine import Gathered
-from .smc import SYSTEMATIC, cdf_reference, cdf_shift
+from .smc import SYSTEMATIC, _NoiseAhead, cdf_reference, cdf_shift
 
 
 def systematic_slot_bounds(offsets, total: int, n_total: int, u0: int):
@@ -78,11 +78,20 @@ def _check_shard_alignment(n_per_rank: int, world: int):
                          f"use {((n_per_rank + CDF_TILE - 1) // CDF_TILE) * CDF_TILE}")
 
 
-class ShardedBootstrapSweep:
-    """smc.BootstrapSweep over `dist.get_world_size()` ranks, n particles per rank."""
+class ShardedBootstrapSweep(_NoiseAhead):
+    """smc.BootstrapSweep over `dist.get_world_size()` ranks, n particles per rank.
+
+    Per step (the tile-statistics form): site program -> all-gather of the statistics -> gmx_shard_step_fused (the
+    totals, the slot bounds, the routing: one launch) -> all-to-all.  NOISE AHEAD as on one GPU (smc._NoiseAhead): the
+    step's normal draws come from background programs on a second stream — keyed by the GLOBAL particle index, so the
+    draws are the single-process ones — which matters more here than on one GPU: the chain of a sharded step is
+    mostly launch boundaries and collective latency, during which the vector ALUs would idle."""
+
+    fuse_mh = False
 
     def __init__(self, init, step, n_per_rank: int, T: int, dist, obs_addr="y", step_extra=None, specialize=True,
-                 resample="systematic", capacity=None, always_communicate=False, rejuvenate=None, state_addr="x"):
+                 resample="systematic", capacity=None, always_communicate=False, rejuvenate=None, state_addr="x",
+                 noise_ahead=None):
         from .smc import _KINDS
         self.init, self.step, self.n, self.T, self.dist = init, step, int(n_per_rank), int(T), dist
         self.obs_addr = obs_addr
@@ -107,11 +116,33 @@ class ShardedBootstrapSweep:
         # a resampled particle needs the particle AND the state it was extended from, so two leaves are
         # routed (two gmx_shard_step launches and two all-to-alls per step instead of one).
         self.rejuvenate, self.state_addr = rejuvenate, state_addr
+        self.noise_ahead_req = noise_ahead
+        self._noise_offset, self._noise_total = self.rank * self.n, self.N
+
+    def _chain_prog(self, t):
+        return self.p_init if t == 0 else self.p_step
+
+    def _chain_step(self, t, skip_vm=False):
+        self._step(t)
 
     def prepare(self, key: Key, ys: torch.Tensor):
-        from ..static import MinimalGenerate
+        from ..static import MinimalGenerate as _MG
         be = _lib.get()
         n, T, dev, W = self.n, self.T, be.device, self.world
+        # noise ahead: on request, or by default on a device with streams (specialised programs, no MH move: the
+        # sharded MH step keeps its two launches)
+        want_na = self.noise_ahead_req
+        if want_na is None:
+            want_na = (os.environ.get("GENMI_NOISE_AHEAD", "1") != "0" and be.uses_streams and self.specialize
+                       and self.rejuvenate is None)
+        if want_na and self.rejuvenate is not None:
+            raise NotImplementedError("ShardedBootstrapSweep(noise_ahead=True, rejuvenate=...)")
+        self.noise_ahead = False
+        self._noise_progs = {}
+        self.__dict__.pop("_noise_run_cache", None)
+
+        def MinimalGenerate(*a):
+            return _MG(*a, hoist_noise=bool(want_na))
         self.key = key
         self.ys = ys.to(dev).float().contiguous()
         self.lw = torch.zeros((n,), dtype=torch.float32, device=dev)
@@ -149,6 +180,11 @@ class ShardedBootstrapSweep:
             self.p_mh_init = MinimalMH(self.init, (), ch, self.rejuvenate, (n,))
             self.p_mh_step = MinimalMH(self.step, (Gathered(self._asrc(0), self.idx),) + tuple(self.step_extra(1)), ch,
                                        self.rejuvenate, (n,))
+        if want_na and self.p_step.noise:
+            self._noise_setup((self.p_init, self.p_step, self.p_step), n, T, dev)
+        elif want_na and self.p_init.noise:
+            self.noise_ahead_req = False          # the steady-state program draws nothing ahead: the plain programs
+            return self.prepare(key, ys)
         if self.specialize and be.uses_streams:
             self.p_init.comp.specialize()
             self.p_step.comp.specialize()
@@ -210,10 +246,12 @@ class ShardedBootstrapSweep:
         cur = self.xext[t % 2]
         mh = None
         if t == 0:
-            prog, leaves = self.p_init, self.p_init.leaves((), obs)
+            prog = self.p_init
+            leaves = prog.leaves((), obs, self._noise_leaves(t, prog)) if self.noise_ahead else prog.leaves((), obs)
         elif self.rejuvenate is None:
             prog = self.p_step
-            leaves = prog.leaves((Gathered(self._src((t - 1) % 2), self.idx),) + tuple(self.step_extra(t)), obs)
+            a_ = (Gathered(self._src((t - 1) % 2), self.idx),) + tuple(self.step_extra(t))
+            leaves = prog.leaves(a_, obs, self._noise_leaves(t, prog)) if self.noise_ahead else prog.leaves(a_, obs)
         else:
             # the MH move on the resampled particles of step t-1, keys split(k_mh, N)[g*n + i]
             ch = ChoiceMap.empty().set(self.obs_addr, self.ys[t - 1]).set(self.state_addr,
@@ -260,8 +298,14 @@ class ShardedBootstrapSweep:
         if self.tiles_mode:
             mk = lambda row, snd: (self.kind, kk, P(self.totals_all), P(self.plan), P(tot), P(self.lw), P(self.stats_own),
                                    P(m), self.shift, g, W, n, C, P(row), P(snd), P(self.idx))
+            mkf = lambda row, snd: (self.kind, kk, P(self.stats_all), P(self.plan), P(tot), P(self.lw), P(m), self.shift,
+                                    g, W, n, C, P(row), P(snd), P(self.idx))
+            fused_ok = W <= 64 and os.environ.get("GENMI_SHARD_FUSED", "1") != "0"
             tiles = {"stats": None if writes_stats else (P(self.lw), n, self.shift, P(self.tile_max), P(self.tile_agg)),
                      "totals": (P(self.stats_all), W, n, P(self.totals_all), P(m)),
+                     # the first routed leaf derives the totals / global max itself (one launch less in the chain);
+                     # further leaves of the same step reuse them
+                     "fused": mkf(rows_t[0], self.send[0]) if fused_ok else None,
                      "steps": [mk(rows_t[d], self.send[d]) for d in range(self.D)],
                      "step2": [mk(self.arows[t % 2][d], self.send2[d]) for d in range(self.D)]
                      if (self.rejuvenate is not None and t >= 1) else None}
@@ -294,9 +338,14 @@ class ShardedBootstrapSweep:
                 self.cx.all_gather(self.stats_all, self.stats_own)          # 12 bytes per 1024 particles per rank
             else:
                 self.stats_all.copy_(self.stats_own)
-            be.check(c.gmx_shard_totals(*tl["totals"], st), "gmx_shard_totals")    # global max + every rank's total
+            more = self.D > 1 or tl["step2"] is not None
+            if tl["fused"] is None or more:
+                be.check(c.gmx_shard_totals(*tl["totals"], st), "gmx_shard_totals")    # global max + every rank's total
             for d in range(self.D):
-                be.check(c.gmx_shard_step_tiles(*tl["steps"][d], st), "gmx_shard_step_tiles")
+                if d == 0 and tl["fused"] is not None and not more:
+                    be.check(c.gmx_shard_step_fused(*tl["fused"], st), "gmx_shard_step_fused")
+                else:
+                    be.check(c.gmx_shard_step_tiles(*tl["steps"][d], st), "gmx_shard_step_tiles")
                 if self.comm:
                     self.cx.all_to_all(b["recvs"][d], self.send[d])
             if tl["step2"] is not None:
@@ -330,7 +379,8 @@ class ShardedBootstrapSweep:
             n = self.n
             obs = ChoiceMap.empty().set(self.obs_addr, self.ys[t])
             prog = self.p_step
-            leaves = prog.leaves((Gathered(self._src((t - 1) % 2), self.idx),) + tuple(self.step_extra(t)), obs)
+            a_ = (Gathered(self._src((t - 1) % 2), self.idx),) + tuple(self.step_extra(t))
+            leaves = prog.leaves(a_, obs, self._noise_leaves(t, prog)) if self.noise_ahead else prog.leaves(a_, obs)
             bufs = [None] * len(prog.comp.outputs)
             bufs[prog.ro[1]] = self.xrows[t % 2][:, :n]
             bufs[prog.wo[1]] = self.lw.reshape(1, n)
@@ -341,6 +391,9 @@ class ShardedBootstrapSweep:
     def enqueue(self):
         self._finished = False
         self.plan.zero_()
+        if self.noise_ahead:
+            self._enqueue_noise_ahead()
+            return
         for t in range(self.T):
             self._step(t)
 

@@ -361,6 +361,13 @@ int gmx_shard_step_tiles(int kind, const uint32_t key[2], const uint64_t* totals
                          uint64_t* total_out_d, const float* lw_d, const void* stats_own_d, const float* max_d,
                          int shift, int rank, int world, int64_t n_per_rank, int64_t capacity,
                          const void* state_d, void* send_d, int32_t* next_idx_d, gmx_stream stream);
+/* gmx_shard_totals + gmx_shard_step_tiles as ONE launch, straight from the all-gathered table (this rank's own block
+ * of it serves as stats_own_d; *max_out_d receives the global max): a sharded SMC step is then site program ->
+ * all-gather -> this -> all-to-all.  world <= 64. */
+int gmx_shard_step_fused(int kind, const uint32_t key[2], const void* stats_all_d, int64_t* plan_d,
+                         uint64_t* total_out_d /* [1] or NULL */, const float* lw_d, float* max_out_d, int shift,
+                         int rank, int world, int64_t n_per_rank, int64_t capacity, const void* state_d,
+                         void* send_d, int32_t* next_idx_d, gmx_stream stream);
 
 /* ------------------------------------------------------------------------
  * MH accept + select.  Replaces the user idiom

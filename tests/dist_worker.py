@@ -77,7 +77,11 @@ def main(out_path, n_per_rank, T, capacity=None, mh=False, vec=False, vecmh=Fals
     else:
         ys = workloads.lgssm_data(T)
         init, step = workloads.make_lgssm(G)
-        sw = ShardedBootstrapSweep(init, step, n_per_rank, T, dist, capacity=capacity).prepare(G.key(314159), torch.from_numpy(ys))
+        # GENMI_TEST_NOISE_AHEAD=1: the step's draws by background programs keyed by the global particle index
+        na = True if os.environ.get("GENMI_TEST_NOISE_AHEAD") == "1" else None
+        sw = ShardedBootstrapSweep(init, step, n_per_rank, T, dist, capacity=capacity, noise_ahead=na).prepare(
+            G.key(314159), torch.from_numpy(ys))
+        assert sw.noise_ahead == bool(na)
     sw.launch()
     xs = [torch.empty_like(sw.state()) for _ in range(dist.get_world_size())]
     dist.all_gather(xs, sw.state())

@@ -501,6 +501,17 @@ extern "C" int gmx_shard_step_tiles(int kind, const uint32_t key[2], const uint6
   }
   return gmx_shard_step(kind, key, totals, plan, total_out, cdf.data(), rank, world, n, cap, state, send, next_idx, st);
 }
+// the one-launch form: the totals from the gathered table, then the step with this rank's own block of it
+extern "C" int gmx_shard_step_fused(int kind, const uint32_t key[2], const void* stats_all, int64_t* plan, uint64_t* total_out,
+                                    const float* lw, float* max_out, int shift, int rank, int world, int64_t n, int64_t cap,
+                                    const void* state, void* send, int32_t* next_idx, gmx_stream st) {
+  if (!stats_all || !max_out || world < 1 || world > 64) return fail("shard_step_fused: bad argument");
+  std::vector<uint64_t> totals((size_t)world);
+  if (gmx_shard_totals(stats_all, world, n, totals.data(), max_out, st)) return 1;
+  const void* own = (const uint8_t*)stats_all + (size_t)rank * gmx_shard_stats_bytes(n);
+  return gmx_shard_step_tiles(kind, key, totals.data(), plan, total_out, lw, own, max_out, shift, rank, world, n, cap, state,
+                              send, next_idx, st);
+}
 extern "C" int gmx_gather(const void* const* src, void* const* dst, const int32_t* bytes, int32_t n_leaves,
                           const int32_t* anc, int64_t n_out, gmx_stream) {
   for (int32_t l = 0; l < n_leaves; ++l)

@@ -115,6 +115,7 @@ def test_entry_points_reject_null_arguments_before_any_launch():
         "gmx_tile_prefix": (N, N, i64(10), N, N),
         "gmx_shard_totals": (N, i32(2), i64(1024), N, N, N),
         "gmx_shard_step_tiles": (i32(0), N, N, N, N, N, N, N, i32(40), i32(0), i32(2), i64(1024), i64(4), N, N, N, N),
+        "gmx_shard_step_fused": (i32(0), N, N, N, N, N, N, i32(40), i32(0), i32(2), i64(1024), i64(4), N, N, N, N),
         "gmx_gather": (N, N, N, ctypes.c_int32(3), N, i64(10), N),
         "gmx_select": (N, N, N, N, N, ctypes.c_int32(1), i64(10), N),
         "gmx_categorical_rows": (N, N, i64(4), i64(4), N, N),

@@ -41,18 +41,23 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world,capacity,tiles,prog_stats", [(2, 0, "1", "1"), (4, 0, "1", "1"), (2, 3, "1", "1"),
-                                                             (2, 0, "0", "1"), (2, 0, "1", "0")])
-def test_sharded_sweep_equals_single_process_oracle(tmp_path, world, capacity, tiles, prog_stats):
+@pytest.mark.parametrize("world,capacity,tiles,prog_stats,na,fused", [
+    (2, 0, "1", "1", "0", "1"), (4, 0, "1", "1", "0", "1"), (2, 3, "1", "1", "0", "1"), (2, 0, "0", "1", "0", "1"),
+    (2, 0, "1", "0", "0", "1"), (2, 0, "1", "1", "0", "0"), (2, 0, "1", "1", "1", "1"), (4, 3, "1", "1", "1", "1")])
+def test_sharded_sweep_equals_single_process_oracle(tmp_path, world, capacity, tiles, prog_stats, na, fused):
     """capacity 0 = default (fast path, no overflow); capacity 3 forces the
     overflow flag and the full-capacity re-run.  tiles "1" = the two-collective step (all-gather of tile
     statistics + all-to-all), "0" = GENMI_SHARD_TILES=0: max all-reduce + local CDF + totals all-gather + all-to-all.
-    prog_stats "0": the site program does not write the tile statistics itself, a gmx_tile_stats launch does."""
+    prog_stats "0": the site program does not write the tile statistics itself, a gmx_tile_stats launch does.
+    fused "0": gmx_shard_totals + gmx_shard_step_tiles instead of the one-launch gmx_shard_step_fused.
+    na "1": NOISE AHEAD on the sharded sweep — the step's draws come from background programs keyed by the GLOBAL
+    particle index (lazy_split offset; GMX_KEY_ROWSPLIT rows + index_offset), launched a group of steps ahead."""
     from genjax_amd import workloads
     n_total, T = 4096, 6
     out = str(tmp_path / "shard")
     r = _launch(world, [out, str(n_total // world), str(T)] + ([str(capacity)] if capacity else []),
-                extra_env={"GENMI_SHARD_TILES": tiles, "GENMI_HOSTSIM_TILE_STATS": prog_stats})
+                extra_env={"GENMI_SHARD_TILES": tiles, "GENMI_HOSTSIM_TILE_STATS": prog_stats,
+                           "GENMI_TEST_NOISE_AHEAD": na, "GENMI_SHARD_FUSED": fused, "GENMI_NOISE_GROUP": "3"})
     assert r.returncode == 0, r.stderr[-3000:]
     x = np.load(out + ".npy")
     meta = json.load(open(out + ".json"))

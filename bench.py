@@ -39,11 +39,6 @@ os.environ.setdefault("OMP_WAIT_POLICY", "ACTIVE")
 
 N_PARTICLES = 1_000_000
 T_STEPS = 100
-VM_VALU_PER_WAVE = 325.65           # VALU instructions per 64 particles: SQ_INSTS_VALU / waves / 4 particles per
-                                    # thread (1302.6 per wave, profiles/r02c_pmc_summary.txt; 1438.6 before the
-                                    # one-instruction DPP scans / integer fixed-point weights, 1496.7 at the end of round 1)
-# the noise-ahead (two-stream) sweep, SQ_INSTS_VALU per wave of 256 particles (profiles/r02h_pmc_summary.txt):
-NA_VALU_PER_WAVE = {"gmx_jit_background_kernel": 1135.8, "gmx_jit_kernel": 216.6, "k_offspring_tile": 540.8}
 VALU_PEAK_LANE_OPS = 256 * 4 * 16 * 2.4e9   # integer / unpacked-f32 vector instructions: 16 lanes per clock per SIMD (a
                                             # wave64 instruction holds its SIMD for 4 cycles; only packed f32 math doubles
                                             # that).  tools/calib.hip on MI355X (profiles/r02_calib.txt): one Threefry-like
@@ -135,6 +130,286 @@ def cpu_baseline(n, T, ys, seed, budget_s=25.0):
     return out
 
 
+def _file_sha16(path):
+    import hashlib
+    try:
+        return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
+    except Exception:
+        return None
+
+
+def code_identity(sw):
+    """What code the numbers of this run were taken on: the FNV-1a hash of every hiprtc code object the sweep launches
+    (gmx_program_code_hash) and the sha256 of the AOT library (k_offspring_tile and the other hand-written kernels).
+    tools/prof_summary.py records the same identities next to the counters it extracts, and profile-sourced
+    figures (instructions per wave, HBM bytes per launch, in-sweep durations) are used ONLY when they match."""
+    from genjax_amd import _lib
+    be = _lib.get()
+    ids = {"libgenmi_hip.so": _file_sha16(_lib.LIB_PATH)}
+    progs = {"gmx_jit_kernel": getattr(sw, "p_step", None)}
+    for plist in getattr(sw, "_noise_progs", {}).values():
+        for _root, q, _idx in plist:
+            progs.setdefault("gmx_jit_background_kernel", q)
+    if getattr(sw, "noise_ahead", False) and sw._noise_progs.get(id(sw.p_step)):
+        progs["gmx_jit_background_kernel"] = sw._noise_progs[id(sw.p_step)][0][1]
+    for name, p_ in progs.items():
+        if p_ is not None:
+            ids[name] = "%016x" % int(be.c.gmx_program_code_hash(p_.comp.handle))
+    return ids
+
+
+def load_profile_counters(ids):
+    """profiles/counters.json (tools/prof_summary.py --json, one tools/reproduce.sh run): per-kernel SQ / TCC counters
+    and rocprofv3 in-sweep durations, each with the identity of the code it was measured on.  Returns
+    {kernel: {...}} for the kernels whose identity matches this run's, and a note for those that do not."""
+    path = os.path.join(ROOT, "profiles", "counters.json")
+    if not os.path.exists(path):
+        return {}, {"file": None}
+    try:
+        cj = json.load(open(path))
+    except Exception as e:
+        return {}, {"file": "profiles/counters.json", "error": repr(e)}
+    ok, notes = {}, {"file": "profiles/counters.json", "tag": cj.get("tag"), "commit": cj.get("commit"), "stale": []}
+    for k, d in cj.get("kernels", {}).items():
+        short = "k_offspring_tile" if "k_offspring_tile" in k else k
+        want = ids.get(short if short in ids else "libgenmi_hip.so")
+        if d.get("code_id") is not None and d.get("code_id") == want:
+            ok[short] = d
+        else:
+            notes["stale"].append(short)
+    return ok, notes
+
+
+def measure_roofline(be, sw, n, T, world, single, value):
+    """The `roofline` object.  Top level: the WHOLE SWEEP against HBM — algorithmic bytes (32 B per
+    particle-step) / the driver-visible time of the timed region / 8 TB/s.  `kernels`: each kernel of the step with its
+    algorithmic bytes per launch over (a) its isolated launch duration, (b) its duration inside the dependent chain —
+    both measured HERE with HIP events on the launch stream — and (c) rocprofv3's in-sweep average, when
+    profiles/counters.json was taken on this very code.  `valu`: vector-instruction issue, the limiter of this path
+    (instructions per wave are SQ_INSTS_VALU of the same profile, used only under the same identity check)."""
+    import torch
+    from ctypes import c_float, c_void_p
+    timer = c_void_p()
+    be.check(be.c.gmx_timer_create(timer), "timer")
+
+    def time_launches(fn, reps=100):
+        """Average duration of one launch of `fn`: `reps` back-to-back launches captured into a hipGraph (so the host
+        is out of the loop) and timed with HIP events on the launch stream.  Includes the dependent-launch boundary."""
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            fn()
+            side.synchronize()
+            be.check(be.c.gmx_capture_begin(be.stream()), "capture")
+            try:
+                for _ in range(reps):
+                    fn()
+            finally:
+                g = c_void_p()
+                rc = be.c.gmx_capture_end(be.stream(), g)
+            be.check(rc, "capture_end")
+            be.check(be.c.gmx_graph_launch(g, be.stream()), "graph")     # warm
+            side.synchronize()
+            be.check(be.c.gmx_timer_start(timer, be.stream()), "timer")
+            for _ in range(5):
+                be.check(be.c.gmx_graph_launch(g, be.stream()), "graph")
+            be.check(be.c.gmx_timer_stop(timer, be.stream()), "timer")
+            ms = c_float()
+            be.check(be.c.gmx_timer_elapsed_ms(timer, ms), "timer")
+            be.c.gmx_graph_destroy(g)
+        torch.cuda.current_stream().wait_stream(side)
+        return ms.value * 1e3 / (5 * reps)          # us per launch
+
+    ids = code_identity(sw)
+    prof, prof_notes = load_profile_counters(ids)
+    us = {name: time_launches(fn) for name, fn in sw.kernel_timers().items()}
+    one = torch.zeros((2,), dtype=torch.float32, device="cuda")
+    us["launch_boundary"] = time_launches(lambda: be.check(be.c.gmx_reduce_max(be.ptr(one), 1, be.ptr(one[1:]), be.stream()),
+                                                           "gmx_reduce_max"))
+    specialised = bool(be.c.gmx_program_is_specialized(sw.p_step.comp.handle))
+    na = single and getattr(sw, "noise_ahead", False)
+    sweep_gbs = SWEEP_BYTES_PER_PARTICLE_STEP * value / world / 1e9          # per GPU
+    kern = {}
+
+    def kernel_entry(name, alg_bytes, iso_us, chain_us=None, note=None):
+        e = {"algorithmic_bytes_per_launch": alg_bytes, "us_isolated": iso_us}
+        if alg_bytes:
+            e["GBps_isolated"] = alg_bytes / (iso_us * 1e-6) / 1e9
+            e["frac_isolated"] = e["GBps_isolated"] / HBM_PEAK_GBS
+        if chain_us is not None:
+            e["us_in_chain"] = chain_us
+            if alg_bytes:
+                e["frac_in_chain"] = alg_bytes / (chain_us * 1e-6) / 1e9 / HBM_PEAK_GBS
+        p_ = prof.get(name)
+        if p_ is not None:
+            if p_.get("avg_us_in_sweep"):
+                e["us_in_sweep_rocprofv3"] = p_["avg_us_in_sweep"]
+                if alg_bytes:
+                    e["frac_in_sweep_rocprofv3"] = alg_bytes / (p_["avg_us_in_sweep"] * 1e-6) / 1e9 / HBM_PEAK_GBS
+            e["traffic"] = p_.get("hbm_bytes_per_launch")
+            e["valu_insts_per_wave"] = p_.get("valu_per_wave")
+            e["wait_any_over_wave_cycles"] = p_.get("wait_any_frac")
+        else:
+            e["traffic"] = None
+            e["valu_insts_per_wave"] = None
+        if note:
+            e["note"] = note
+        kern[name] = e
+        return e
+
+    if single:
+        us["sweep"] = time_launches(lambda: sw.enqueue(), reps=1)
+    if na:
+        us["chain_only_sweep"] = time_launches(lambda: sw._enqueue_noise_ahead(skip_noise=True), reps=1)
+        us["chain_only_sweep_without_site_program"] = time_launches(
+            lambda: sw._enqueue_noise_ahead(skip_vm=True, skip_noise=True), reps=1)
+        vm_chain = (us["chain_only_sweep"] - us["chain_only_sweep_without_site_program"]) / T
+        rs_chain = us["chain_only_sweep_without_site_program"] / T
+        kernel_entry("gmx_jit_kernel", VM_BYTES_PER_PARTICLE * n, us["k_vm"], vm_chain,
+                     "site program without its draws: ancestor 4 + gathered state 4 in, state 4 + log-weight 4 out "
+                     "(+ 4 B of noise read, not algorithmic); specialised: %s" % specialised)
+        if "k_offspring_tile" in us:
+            kernel_entry("k_offspring_tile", 8 * n, us["k_offspring_tile"], rs_chain, "log-weight 4 in, ancestor 4 out")
+        kernel_entry("gmx_jit_background_kernel", 0, us["k_noise"], None,
+                     "noise program: 3 Threefry-2x32 blocks + erf_inv per draw, second stream; zero algorithmic bytes "
+                     "(SURVEY 8d: RNG contributes 0 B), writes 4 B per particle")
+    elif single:
+        us["sweep_without_k_vm"] = time_launches(lambda: sw.enqueue(skip_vm=True), reps=1)
+        vm_chain = (us["sweep"] - us["sweep_without_k_vm"]) / T
+        kernel_entry("gmx_jit_kernel" if specialised else "k_vm", VM_BYTES_PER_PARTICLE * n, us["k_vm"], vm_chain)
+        for k_ in us:
+            if k_.startswith(("k_offspring", "resample", "k_weight_cdf", "k_ancestors")):
+                kernel_entry(k_, 8 * n, us[k_], None)
+    else:
+        kernel_entry("gmx_jit_kernel" if specialised else "k_vm", VM_BYTES_PER_PARTICLE * n, us["k_vm"], None)
+
+    # ---- vector-instruction issue: the limiter (DESIGN.md §4) ----
+    waves = (n + 1023) // 1024 * 4
+    valu = {"peak_T_lane_ops": VALU_PEAK_LANE_OPS / 1e12, "calibrated_ceiling_T_lane_ops": VALU_CALIBRATED_LANE_OPS / 1e12,
+            "peak_note": "256 CU x 4 SIMD x 16 lanes x 2.4 GHz: a wave64 integer / unpacked-f32 instruction holds its SIMD "
+                         "for 4 cycles (tools/calib.hip, profiles/r02_calib.txt: 33.6-35.5 T for Threefry-like chains; the "
+                         "guide's 2-cycle figure is reached by packed f32 only)",
+            "insts_per_wave_source": prof_notes}
+    per_wave = {k: kern[k].get("valu_insts_per_wave") for k in kern}
+    if single and all(v for v in per_wave.values()):
+        step_us = us["sweep"] / T
+        rate = sum(per_wave.values()) * 64 * waves / (step_us * 1e-6)
+        valu.update(insts_per_wave_per_step=sum(per_wave.values()), lane_ops_per_s=rate,
+                    valu_frac=rate / VALU_PEAK_LANE_OPS, valu_frac_of_calibrated_ceiling=rate / VALU_CALIBRATED_LANE_OPS)
+        if na:
+            nrate = per_wave["gmx_jit_background_kernel"] * 64 * waves / (us["k_noise"] * 1e-6)
+            valu["noise_program_isolated_valu_frac"] = nrate / VALU_PEAK_LANE_OPS
+    else:
+        valu["valu_frac"] = None
+        valu["note"] = ("no instruction counts for this exact code (profiles/counters.json absent or taken on other "
+                        "code: see insts_per_wave_source.stale) — not estimated")
+    traffic = None
+    if kern and all(kern[k].get("traffic") is not None for k in kern):
+        traffic = sum(kern[k]["traffic"] for k in kern)             # HBM bytes per STEP (one launch of each kernel)
+    be.c.gmx_timer_destroy(timer)
+    return {
+        "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+        "achieved": sweep_gbs, "frac": sweep_gbs / HBM_PEAK_GBS, "traffic": traffic,
+        "scope": "whole sweep per GPU: 32 algorithmic bytes per particle-step (SURVEY.md 8d) x particle-steps/s of the "
+                 "timed region (the figure `value` is computed from); `traffic` = TCC bytes per STEP summed over the "
+                 "step's kernels (vs 32 B x n algorithmic), from profiles/counters.json when taken on this code",
+        "algorithmic_bytes_per_step": SWEEP_BYTES_PER_PARTICLE_STEP * n,
+        "limiter": "vector-instruction issue (3 Threefry-2x32 blocks per draw fixed by jax's key tree), not HBM: see valu",
+        "kernels": kern, "valu": valu, "kernel_us": us, "code_identity": ids,
+        "us_per_step": (us["sweep"] / T) if "sweep" in us else None,
+        "chain_only_us_per_step": (us["chain_only_sweep"] / T) if "chain_only_sweep" in us else None,
+    }
+
+
+def other_configs():
+    """BASELINE configs 3 / 4 / 5 on this GPU, AFTER and outside the headline's timed region (a few seconds in all),
+    so that the driver-visible record carries them too.  Each with its SURVEY 8(d) algorithmic bytes against 8 TB/s.
+    Synthetic data, random-init everything, same models / keys as the parity tests (tests/test_gpu_parity.py holds each
+    of these workloads to the oracle bit for bit)."""
+    import numpy as np
+    import torch
+    import genjax_amd as G
+    from genjax_amd import ChoiceMapBuilder as C, numpy as jnp, workloads
+    from genjax_amd.inference import gibbs, smc
+    out = {}
+
+    def timed(fn, reps):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps
+
+    try:        # ---- config 3: nonlinear SSM, 1e6 particles, T = 100, one Gaussian-drift MH move per step ----
+        n, T = N_PARTICLES, T_STEPS
+        init, step = workloads.make_nlssm(G)
+        req = G.StaticRequest({"x": G.Rejuvenate(G.normal, lambda chm: (chm.get_value(), 0.5))})
+        sw = smc.BootstrapSweep(init, step, n, T, step_extra=lambda t: (float(t),), rejuvenate=req).prepare(
+            G.key(7), torch.from_numpy(workloads.nlssm_data(T))).capture()
+        dt = timed(sw.launch, 5)
+        b = 52 * n * T          # 8(d): 32 B bootstrap step + 20 B MH move per particle-step
+        out["config3"] = {"workload": "nonlinear SSM + one Rejuvenate MH move per step, BootstrapSweep(rejuvenate=...), "
+                                      "1e6 particles x 100 steps, one hipGraph", "us_per_step": 1e6 * dt / T,
+                          "particle_steps_per_s": n * T / dt, "algorithmic_bytes_per_particle_step": 52,
+                          "hbm_frac": b / dt / 1e9 / HBM_PEAK_GBS, "log_ml": sw.log_ml(),
+                          "noise_ahead": bool(sw.noise_ahead), "accept_rate_last_step": float(sw.accept.float().mean())}
+        del sw
+    except Exception as e:
+        out["config3"] = {"error": repr(e)[:300]}
+    try:        # ---- config 4: 8-schools, ImportanceK k = 1e7 + one global systematic resample ----
+        sig = [15.0, 10.0, 16.0, 11.0, 9.0, 11.0, 10.0, 18.0]
+        ysch = np.array([28, 8, -3, 7, -1, 1, 18, 12], np.float32)
+
+        @G.gen
+        def schools():
+            mu = G.normal(0.0, 5.0) @ "mu"
+            log_tau = G.normal(0.0, 1.0) @ "log_tau"
+            theta = G.normal(mu * jnp.ones(8), jnp.exp(log_tau) * jnp.ones(8)) @ "theta"
+            _ = G.normal(theta, jnp.array(sig)) @ "y"
+            return theta
+        k = 10_000_000
+        alg = smc.ImportanceK(G.Target(schools, (), C["y"].set(ysch)), k_particles=k)
+        box = {}
+
+        def run4():
+            c = alg.run_smc(G.key(2))
+            r = smc.resample(G.key(3), c, "systematic")
+            box["c"], box["theta"] = c, r.get_particles().get_choices()["theta"]     # materialises the gathered latents
+        dt = timed(run4, 3)
+        dti = timed(lambda: alg.run_smc(G.key(2)), 3)
+        out["config4"] = {"workload": "8-schools ImportanceK k = 1e7 + one systematic resample + gather of theta",
+                          "ms_total": 1e3 * dt, "ms_importance": 1e3 * dti, "particles_per_s": k / dt,
+                          "algorithmic_bytes_per_particle": {"importance": 48, "resample_and_gather": 104},
+                          "hbm_frac_importance": 48.0 * k / dti / 1e9 / HBM_PEAK_GBS,
+                          "hbm_frac_total": 152.0 * k / dt / 1e9 / HBM_PEAK_GBS,
+                          "log_ml": float(box["c"].get_log_marginal_likelihood_estimate())}
+        box.clear()
+    except Exception as e:
+        out["config4"] = {"error": repr(e)[:300]}
+    try:        # ---- config 5: mixture, K = 64 clusters, 1e6 datapoints: one assignment sweep ----
+        n, K = 1_000_000, 64
+        x, guess, probs, z = workloads.mixture_data(n, K)
+        gd = workloads.make_mixture(G)
+        args5 = (torch.from_numpy(probs).cuda(), torch.from_numpy(guess).cuda())
+        chm = C["obs"].set(torch.from_numpy(x).cuda())
+        box = {}
+
+        def run5():
+            box["idx"] = gibbs.gibbs_categorical(G.key(1), gd, args5, chm, "idx", K)
+        dt = timed(run5, 5)
+        out["config5"] = {"workload": "Dirichlet-categorical mixture, K = 64, 1e6 datapoints: one cluster-assignment "
+                                      "sweep (gibbs_categorical: one launch, no [N, K] matrix)", "ms": 1e3 * dt,
+                          "datapoints_per_s": n / dt, "gumbels_per_s": n * K / dt, "algorithmic_bytes_per_datapoint": 8,
+                          "hbm_frac": 8.0 * n / dt / 1e9 / HBM_PEAK_GBS,
+                          "note": "ALU-bound by design (64 Gumbels + 64 log-densities per datapoint; SURVEY 8d)",
+                          "agrees_with_generating_component": float((box["idx"].cpu().numpy() == z).mean())}
+    except Exception as e:
+        out["config5"] = {"error": repr(e)[:300]}
+    return out
+
+
 def spawn_ranks(world: int) -> int:
     """`python bench.py --gpus N` with no launcher: THIS process becomes the launcher.  It never imports torch, never
     loads the HIP library and never touches a GPU; it starts N children of the same command line — one rank per GPU,
@@ -191,6 +466,10 @@ def main():
     ap.add_argument("--T", type=int, default=T_STEPS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the configs 3 / 4 / 5 block after the headline")
+    ap.add_argument("--no-roofline", action="store_true",
+                    help="only the timed sweeps (rocprofv3's kernel-trace pass: its per-kernel averages are then IN-SWEEP "
+                         "durations, not mixed with the isolated timing loops of the roofline block)")
     ap.add_argument("--sharded", action="store_true", help="use the multi-GPU code path even at world size 1")
     ap.add_argument("--weak", action="store_true",
                     help="N > 1: --particles PER GPU (weak scaling) instead of in total (strong scaling, the default)")
@@ -329,150 +608,13 @@ def main():
         out["config"]["full_capacity_reruns"] = sw.reruns
 
     if rank == 0 and on_gpu:
-        # ---- per-kernel durations, HIP events on the launch stream ----
-        from ctypes import c_float, c_void_p
-        timer = c_void_p()
-        be.check(be.c.gmx_timer_create(timer), "timer")
-
-        def time_launches(fn, reps=100):
-            """Average duration of one launch of `fn`: `reps` back-to-back launches captured
-            into a hipGraph (so the host is out of the loop) and timed with HIP events on the
-            launch stream.  Includes the dependent-launch boundary (~1.5 us)."""
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                fn()
-                side.synchronize()
-                be.check(be.c.gmx_capture_begin(be.stream()), "capture")
-                try:
-                    for _ in range(reps):
-                        fn()
-                finally:
-                    g = c_void_p()
-                    rc = be.c.gmx_capture_end(be.stream(), g)
-                be.check(rc, "capture_end")
-                be.check(be.c.gmx_graph_launch(g, be.stream()), "graph")     # warm
-                side.synchronize()
-                be.check(be.c.gmx_timer_start(timer, be.stream()), "timer")
-                for _ in range(5):
-                    be.check(be.c.gmx_graph_launch(g, be.stream()), "graph")
-                be.check(be.c.gmx_timer_stop(timer, be.stream()), "timer")
-                ms = c_float()
-                be.check(be.c.gmx_timer_elapsed_ms(timer, ms), "timer")
-                be.c.gmx_graph_destroy(g)
-            torch.cuda.current_stream().wait_stream(side)
-            return ms.value * 1e3 / (5 * reps)          # us per launch
-        kt = sw.kernel_timers()
-        us = {name: time_launches(fn) for name, fn in kt.items()}
-        vm_us = us["k_vm"]
-        one = torch.zeros((2,), dtype=torch.float32, device="cuda")
-        gap = time_launches(lambda: be.check(be.c.gmx_reduce_max(be.ptr(one), 1, be.ptr(one[1:]), be.stream()),
-                                             "gmx_reduce_max"))
-        us["launch_boundary"] = gap                               # a chain of trivial launches, for reference
-        traffic = traffic_noise = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
+        out["roofline"] = ({"code_identity": code_identity(sw), "note": "--no-roofline"} if args.no_roofline
+                           else measure_roofline(be, sw, n, T, world, single, value))
+        if single and not args.no_other_configs and n == N_PARTICLES and T == T_STEPS:
             try:
-                tj = json.load(open(tpath))
-                traffic, traffic_noise = tj.get("k_vm_hbm_bytes_per_launch"), tj.get("noise_hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        specialised = bool(sw.p_step.comp._be.c.gmx_program_is_specialized(sw.p_step.comp.handle))
-        sweep_hbm_frac = SWEEP_BYTES_PER_PARTICLE_STEP * value / world / 1e9 / HBM_PEAK_GBS
-        if single and getattr(sw, "noise_ahead", False):
-            # ---- the two-stream (noise-ahead) sweep: three kernels per step, two of them concurrent ----
-            # Durations: each kernel alone, back to back on one stream (HIP events); the whole sweep; the chain alone
-            # (noise launches left out: the site programs then read stale noise — same work, same traffic).
-            # Kernels overlap inside the sweep, so "x in the sweep" is no longer a difference of two sweeps: the
-            # in-sweep per-kernel averages are rocprofv3's (profiles/*_kernel_stats.csv of this same command).
-            us["sweep"] = time_launches(lambda: sw.enqueue(), reps=1)
-            us["chain_only_sweep"] = time_launches(lambda: sw._enqueue_noise_ahead(skip_noise=True), reps=1)
-            waves = (n + 1023) // 1024 * 4
-            lane_ops = {k: v * 64 * waves for k, v in NA_VALU_PER_WAVE.items()}          # per launch
-            step_us = us["sweep"] / T
-            noise_rate = lane_ops["gmx_jit_background_kernel"] / (us["k_noise"] * 1e-6)
-            sweep_rate = sum(lane_ops.values()) / (step_us * 1e-6)
-            achieved = VM_BYTES_PER_PARTICLE * n / (vm_us * 1e-6) / 1e9
-            out["roofline"] = {
-                # The dominant kernel by GPU time is the noise program (gmx_jit_background_kernel, ~40 %): keys in,
-                # 4 bytes per particle out, ZERO algorithmic bytes (SURVEY 8d: "RNG contributes 0 B") — it is pure
-                # integer / f32 vector work, so it is priced against the vector-issue peak, not against HBM (the
-                # schema's "hbm" | "mfma" has no name for that; "valu" says what it is).
-                "bound": "valu", "kernel": "gmx_jit_background_kernel (noise program: 3 Threefry-2x32 blocks + erf_inv "
-                                           "per draw; BootstrapSweep noise-ahead form)",
-                "achieved": noise_rate / 1e12, "peak": VALU_PEAK_LANE_OPS / 1e12, "unit": "T lane-op/s",
-                "frac": noise_rate / VALU_PEAK_LANE_OPS, "traffic": traffic_noise,
-                "limiter": "vector-instruction issue (16 lanes/clk/SIMD for integer and unpacked f32): the whole sweep "
-                           "keeps the vector ALUs busy for sweep.valu_frac of the time",
-                "valu_source": "instructions per wave: SQ_INSTS_VALU of profiles/r02h_pmc_summary.txt (constants in "
-                               "bench.py, not measured in this run); durations: HIP events in this run",
-                "traffic_source": "profiles/traffic.json (rocprofv3 TCC passes of an earlier run of this workload, "
-                                  "calibrated against copy kernels; NOT measured in this run); the noise program writes "
-                                  "4 B per particle and reads nothing",
-                "calibrated_ceiling_T_lane_ops": VALU_CALIBRATED_LANE_OPS / 1e12,
-                # the data-path kernels against HBM (algorithmic bytes per launch / isolated launch duration)
-                "hbm": {"gmx_jit_kernel": {"algorithmic_bytes_per_launch": VM_BYTES_PER_PARTICLE * n,
-                                           "traffic": traffic,
-                                           "achieved_GBps": achieved, "frac": achieved / HBM_PEAK_GBS,
-                                           "note": "site program without its draws: ancestor 4 + gathered state 4 in, "
-                                                   "state 4 + log-weight 4 out (+ 4 B of noise read, not algorithmic)",
-                                           "specialised": specialised},
-                        "k_offspring_tile": {"algorithmic_bytes_per_launch": 8 * n,
-                                             "achieved_GBps": 8 * n / (us["k_offspring_tile"] * 1e-6) / 1e9
-                                             if "k_offspring_tile" in us else None,
-                                             "frac": 8 * n / (us["k_offspring_tile"] * 1e-6) / 1e9 / HBM_PEAK_GBS
-                                             if "k_offspring_tile" in us else None},
-                        "peak_GBps": HBM_PEAK_GBS},
-                "sweep": {"us_per_step": step_us, "chain_only_us_per_step": us["chain_only_sweep"] / T,
-                          "valu_insts_per_wave_per_step": sum(NA_VALU_PER_WAVE.values()),
-                          "valu_lane_ops_per_s": sweep_rate, "valu_frac": sweep_rate / VALU_PEAK_LANE_OPS,
-                          "valu_frac_of_calibrated_ceiling": sweep_rate / VALU_CALIBRATED_LANE_OPS,
-                          "hbm_frac": sweep_hbm_frac},
-                "kernel_us": us,
-                "sweep_frac_of_hbm_roofline": sweep_hbm_frac}
-        else:
-            if single:
-                # the site program's duration IN the sweep: (sweep) - (sweep without its T launches), both
-                # as hipGraphs timed with HIP events; this is the figure rocprofv3's per-kernel average
-                # reproduces (the isolated back-to-back figure above runs ~10 % shorter: warm caches)
-                full = time_launches(lambda: sw.enqueue(), reps=1) * 1.0
-                rest = time_launches(lambda: sw.enqueue(skip_vm=True), reps=1) * 1.0
-                us["sweep"] = full
-                us["sweep_without_k_vm"] = rest
-                # What rocprofv3 reports as this kernel's duration: in its kernel trace of a graph replay consecutive
-                # kernels abut (median end -> next start = 0 ns, profiles/r01_o_kernel_stats.csv's trace), i.e. a
-                # kernel's span includes its dependent-launch ramp.  So the roofline uses the marginal cost as is.
-                us["k_vm_in_sweep"] = (full - rest) / T
-                us["k_vm_in_sweep_minus_launch_boundary"] = (full - rest) / T - gap
-                vm_us = us["k_vm_in_sweep"]
-            achieved = VM_BYTES_PER_PARTICLE * n / (vm_us * 1e-6) / 1e9
-            out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                               # `bound` names the roofline `achieved` / `peak` are priced against (the schema has "hbm" |
-                               # "mfma").  What actually limits this kernel is vector-instruction ISSUE: see `valu` below.
-                               "limiter": "VALU issue: integer Threefry-2x32 (3 blocks per draw) at 16 lanes/clk/SIMD; "
-                                          "HBM traffic equals the algorithmic bytes (no re-reads)",
-                               "traffic_source": "profiles/traffic.json (rocprofv3 TCC pass of an earlier run of this "
-                                                 "workload, calibrated against copy kernels; NOT measured in this run)",
-                               "kernel": "gmx_jit_kernel (site program specialised from k_vm)" if specialised else "k_vm<gmx_regs_vgpr<16>, false>",
-                               "algorithmic_bytes_per_launch": VM_BYTES_PER_PARTICLE * n,
-                               # the kernel is VALU-issue bound, not HBM bound: 3 Threefry-2x32 blocks per draw
-                               # (split child, fold_in, bits).  SQ_INSTS_VALU per wave from profiles/*_pmc_summary.txt.
-                               "valu": {"source": "insts_per_64_particles: SQ_INSTS_VALU of profiles/r02c_pmc_summary.txt "
-                                                  "(a constant in bench.py, not measured in this run); peak_int: "
-                                                  "tools/calib.hip on this part (profiles/r02_calib.txt)",
-                                        "insts_per_64_particles": VM_VALU_PER_WAVE,
-                                        "lane_ops_per_s": VM_VALU_PER_WAVE * n / (vm_us * 1e-6),
-                                        "peak_lane_ops_per_s": VALU_PEAK_LANE_OPS,
-                                        "frac": VM_VALU_PER_WAVE * n / (vm_us * 1e-6) / VALU_PEAK_LANE_OPS,
-                                        "calibrated_ceiling_lane_ops_per_s": VALU_CALIBRATED_LANE_OPS,
-                                        "frac_of_calibrated_ceiling": VM_VALU_PER_WAVE * n / (vm_us * 1e-6) / VALU_CALIBRATED_LANE_OPS,
-                                        "note": "peak = 256 CU x 4 SIMD x 16 lanes x 2.4 GHz: integer (Threefry) and unpacked f32 "
-                                                "instructions issue at 16 lanes/clk/SIMD on gfx950; the calibrated ceiling is what "
-                                                "dependent add/rotate/xor chains sustain on this part (tools/calib.hip)"},
-                               "kernel_us": us,
-                               "sweep_frac_of_hbm_roofline": sweep_hbm_frac}
-        be.c.gmx_timer_destroy(timer)
+                out["other_configs"] = other_configs()
+            except Exception as e:
+                out["other_configs"] = {"error": repr(e)[:300]}
         if not args.no_cpu_baseline and world == 1:
             try:
                 out["cpu_baseline"] = cpu_baseline(n, T, ys, seed)

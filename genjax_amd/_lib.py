@@ -99,6 +99,8 @@ class Backend:
         c.gmx_program_destroy.argtypes = [c_void_p]
         c.gmx_program_specialize.argtypes = [c_void_p]
         c.gmx_program_is_specialized.argtypes = [c_void_p]
+        c.gmx_program_code_hash.argtypes = [c_void_p]
+        c.gmx_program_code_hash.restype = c_uint64
         c.gmx_program_grid.argtypes = [c_void_p, c_int64]
         c.gmx_program_grid.restype = c_int64
         c.gmx_program_run.argtypes = [c_void_p, c_int64, POINTER(RunArgs), c_void_p]

@@ -134,6 +134,7 @@ struct gmx_program {
   hipFunction_t jit_fn = nullptr;
   int jit_pp = 1;                    // particles per thread of the specialised kernel
   bool jit_gathers_pre = false;      // every gathered load of the specialised kernel uses the prologue's ancestors
+  uint64_t jit_code_hash = 0;        // FNV-1a of the loaded code object (gmx_program_code_hash)
   bool background = false;           // gmx_program_set_background: wave priority 0 ...
   unsigned lds_pad = 0;              // ... and this much unused dynamic LDS per workgroup (a residency cap)
 };
@@ -371,6 +372,7 @@ static std::string jit_source(const gmx_program* p, bool* gathers_prefetched = n
 }
 
 extern "C" int gmx_program_is_specialized(const gmx_program* p) { return p && p->jit_fn ? 1 : 0; }
+extern "C" uint64_t gmx_program_code_hash(const gmx_program* p) { return p && p->jit_fn ? p->jit_code_hash : 0ull; }
 extern "C" int gmx_program_writes_tile_stats(const gmx_program* p) {
   return p && p->jit_fn && p->jit_pp == 4 && p->n_redmax == 1 && !p->uses_lse ? 1 : 0;
 }
@@ -507,6 +509,7 @@ static int jit_load(gmx_program* p, const std::vector<char>& code) {
   p->jit_module = mod;
   p->jit_fn = fn;
   p->jit_pp = jit_pp_for(p);
+  p->jit_code_hash = fnv1a(0xcbf29ce484222325ull, code.data(), code.size());
   if (p->lds_pad > 48 * 1024) {
     hipError_t ea = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_pad);
     if (ea != hipSuccess) { (void)hipGetLastError(); p->lds_pad = 48 * 1024; }

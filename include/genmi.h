@@ -177,6 +177,9 @@ int gmx_program_destroy(gmx_program* p);
  * place) when hiprtc is unavailable or GENMI_JIT=0. */
 int gmx_program_specialize(gmx_program* p);
 int gmx_program_is_specialized(const gmx_program* p);
+/* FNV-1a (64-bit) of the specialised kernel's code object, 0 when not specialised: the identity of the code a
+ * measurement was taken on (bench.py only uses profile-sourced instruction counts whose recorded hash equals this). */
+uint64_t gmx_program_code_hash(const gmx_program* p);
 /* number of thread blocks gmx_program_run will launch for n particles
  * (= rows of red_out_d the caller must provide). */
 int64_t gmx_program_grid(const gmx_program* p, int64_t n);

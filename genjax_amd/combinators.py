@@ -31,6 +31,28 @@ from .tracer import Expr
 
 
 SCAN_UNROLL_MAX = 16      # longer scans run as a counted loop in the site program (Scan._trace_loop)
+VMAP_UNROLL_MAX = 16      # larger plates run as a counted loop too (Vmap._trace_loop): one iteration per element
+
+
+def _loop_at(v, t, what="a plate of more than 16 elements"):
+    """element t (the iteration number of a counted loop) of a mapped argument / per-element constraint / previous
+    value: a launch-uniform table, or a per-particle [n, T] leaf read step by step"""
+    from .engine import StepInput, Sym
+    from .numpy import RuntimeTable, TableArray
+    if isinstance(v, Sym):
+        v = v.value
+    if v is None:
+        return None
+    if isinstance(v, tuple):
+        return tuple(_loop_at(x, t, what) for x in v)
+    if isinstance(v, dict):
+        return {k: _loop_at(x, t, what) for k, x in v.items()}
+    if isinstance(v, (RuntimeTable, TableArray, StepInput)):
+        return v[t]
+    if isinstance(v, (list, np.ndarray)) and not (isinstance(v, np.ndarray) and v.dtype == object):
+        return TableArray(np.asarray(v, dtype=np.float32 if np.asarray(v).dtype.kind == "f" else np.int32))[t]
+    raise NotImplementedError(f"{what}: mapped arguments, per-element constraints and previous values must be "
+                              "launch-uniform vectors (tables) or per-particle [n, T] arrays")
 
 
 def _shape_of(tree):
@@ -124,6 +146,8 @@ class Vmap(GenerativeFunction):
             return self._trace_edit(ctx, mode, key, args, constraint, prev, req, req_leaves, addr)
         axes = self._axes(args)
         n = self._plate_size(args, axes)
+        if n > VMAP_UNROLL_MAX:
+            return self._trace_loop(ctx, mode, key, args, axes, constraint, n, req_leaves, addr)
         from .static import _rec_score
         g = ctx.tr.graph
         keep = ctx.store_sites
@@ -166,6 +190,177 @@ class Vmap(GenerativeFunction):
             return out, retval, None, score
         return out, retval, weight, None
 
+    def _trace_loop(self, ctx, mode, key, args, axes, constraint, n, req_leaves, addr):
+        """simulate / generate / assess of a LARGE plate (vmap.py:180-218: `jax.vmap` over any n) as a counted loop IN
+        the site program: the inner function is traced ONCE; iteration j runs element j with key split(key, n)[j]
+        (= fold_in(key, j): OP_KDERIVER on the iteration number), reads element j of the mapped arguments and of the
+        per-element constraints (tables, or per-particle [n, T] leaves read step by step), writes element j of every
+        site's [T, n] value / score (seen as [n, T], a plate) and adds its weight / score to loop-carried sums — in
+        element order, as the unrolled form does.  One launch runs the whole plate of a particle."""
+        from .engine import StepOutput, Sym
+        from .static import _CallRec, _SiteRec, _rec_score, call_gen_fn
+        g, tr = ctx.tr.graph, ctx.tr
+        keep = ctx.store_sites
+        ctx.store_sites = False
+        what = "a plate of more than 16 elements"
+        zero = g.const_f32(0.0)
+        wvar = g.loop_var(zero) if mode == "generate" else None
+        svar = g.loop_var(zero)
+        g.loop_begin(n)
+        with T.tracing(g):
+            t = Expr(g.add("LDT", dtype="i32"))
+            k_t = Expr(g.add("KDERIVER", (key.node, t.node), dtype="key")) if key is not None else None
+            args_t = tuple(_loop_at(a, t, what) if ax is not None else a for a, ax in zip(args, axes))
+            con_t = _loop_step_constraint(constraint, t, n, _loop_at, what) if constraint is not None else None
+            rec, ret, w, s_ = call_gen_fn(ctx, mode, self.gen_fn, k_t, args_t, con_t, None, None, req_leaves, addr)
+            score_t = s_ if mode == "assess" else _rec_score(rec)
+            for r in _leaves(rec):
+                val = r.value.value if isinstance(r.value, Sym) else r.value
+                sc = r.score.value if isinstance(r.score, Sym) else r.score
+                if isinstance(sc, np.ndarray):
+                    raise NotImplementedError(f"{what}: a site with a vector-valued SCORE")
+                if keep:
+                    r.origins = (tr.store_step(val, n), tr.store_step(sc, n), None)
+                    r.value = StepOutput(r.origins[0], n)
+                    r.score = StepOutput(r.origins[1], n)
+
+            def stack_out(v):
+                if v is None:
+                    return None
+                if isinstance(v, Sym):
+                    v = v.value
+                if isinstance(v, (tuple, list)):
+                    return type(v)(stack_out(x) for x in v)
+                return StepOutput(tr.store_step(v, n), n)
+            rets = stack_out(ret) if (keep or not isinstance(rec, _SiteRec)) else None
+            updates = []
+            if wvar is not None and w is not None:
+                updates.append((wvar, (Expr(wvar) + w).node))
+            updates.append((svar, (Expr(svar) + score_t).node))
+            g.set_vars(updates)
+        g.loop_end()
+        ctx.store_sites = keep
+
+        def drop_retvals(r):
+            if isinstance(r, _CallRec):
+                r.retval = None
+                for x in r.sites.values():
+                    drop_retvals(x)
+        score = Expr(svar)
+        if isinstance(rec, _SiteRec):
+            # a distribution under vmap is a vector-valued site with split keys; its score is the plate sum
+            out = _SiteRec(rec.gen_fn, rec.value, score)
+            retval = rec.value if rets is None else rets
+            if not keep:
+                retval = rets
+        else:
+            drop_retvals(rec)
+            out = _CallRec(self)
+            out.sites = rec.sites
+            out.retval = rets
+            out.plate_score = score
+            retval = rets
+        if mode in ("simulate", "assess"):
+            return out, retval, None, score
+        return out, retval, Expr(wvar), None
+
+    def _trace_edit_loop(self, ctx, kind, key, args, axes, constraint, inner_prev, req, n, req_leaves, addr):
+        """Update / IndexRequest of a LARGE plate as a counted loop (the loop form of _trace_edit): iteration j edits
+        element j — `Update`: with key split(key, n)[j] and element j of the constraint; `IndexRequest(idx, request)`:
+        `request` with the caller's key where idx == j (a Python int or one index per particle: the same test), a plain
+        carry-over elsewhere — reading element j of the previous trace and writing element j of the new one."""
+        from .engine import StepInput, StepOutput, Sym
+        from .numpy import RuntimeTable, TableArray
+        from .static import _CallRec, _ReqSpec, _SiteRec, _rec_score, call_gen_fn
+        g, tr = ctx.tr.graph, ctx.tr
+        keep = ctx.store_sites
+        ctx.store_sites = False
+        what = "editing a plate of more than 16 elements"
+        carry_over = _ReqSpec("update", tree=None, constraint=ChoiceMap.empty())
+
+        def prev_at(v, t):
+            if isinstance(v, Sym):
+                inner = v.value
+                if isinstance(inner, (StepInput, RuntimeTable, TableArray)):
+                    return Sym(inner[t], None)
+                return v
+            if isinstance(v, dict):
+                return {k: (None if k == "retval" else prev_at(x, t)) for k, x in v.items()}
+            if isinstance(v, tuple):
+                return tuple(prev_at(x, t) for x in v)
+            return v
+        zero = g.const_f32(0.0)
+        wvar, svar = g.loop_var(zero), g.loop_var(zero)
+        g.loop_begin(n)
+        with T.tracing(g):
+            t = Expr(g.add("LDT", dtype="i32"))
+            args_t = tuple(_loop_at(a, t, what) if ax is not None else a for a, ax in zip(args, axes))
+            prev_t = prev_at(inner_prev, t)
+            if kind == "index":
+                sub = req.sub
+                m_ = {"update": "update", "regen": "regen"}.get(sub.kind, "static_edit")
+                con_ = sub.constraint if sub.kind == "update" else ChoiceMap.empty()
+                saved = set(ctx.changed)
+                rec, ret, w, _ = call_gen_fn(ctx, m_, self.gen_fn, key, args_t, con_, prev_t, sub, req_leaves, addr)
+                ctx.changed = saved
+                ctx.memo.clear()
+                old, old_ret, w_old, _ = call_gen_fn(ctx, "update", self.gen_fn, None, args_t, ChoiceMap.empty(), prev_t,
+                                                     carry_over, req_leaves, addr)
+                here = t == req.idx
+                zero_e = Expr(zero)
+                rec = _select_rec(here, rec, old)
+                ret = _select_tree(here, ret, old_ret)
+                w = T.where(here, w if w is not None else zero_e, w_old if w_old is not None else zero_e)
+            else:
+                k_t = Expr(g.add("KDERIVER", (key.node, t.node), dtype="key")) if key is not None else None
+                rec, ret, w, _ = call_gen_fn(ctx, "update", self.gen_fn, k_t, args_t,
+                                             _loop_step_constraint(constraint, t, n, _loop_at, what), prev_t,
+                                             req if kind == "update" else carry_over, req_leaves, addr)
+            score_t = _rec_score(rec)
+            for r in _leaves(rec):
+                val = r.value.value if isinstance(r.value, Sym) else r.value
+                sc = r.score.value if isinstance(r.score, Sym) else r.score
+                dis = r.discard.value if isinstance(r.discard, Sym) else r.discard
+                if isinstance(sc, np.ndarray):
+                    raise NotImplementedError(f"{what}: a site with a vector-valued SCORE")
+                if keep:
+                    r.origins = (tr.store_step(val, n), tr.store_step(sc, n),
+                                 tr.store_step(dis, n) if dis is not None else None)
+                    r.value = StepOutput(r.origins[0], n)
+                    r.score = StepOutput(r.origins[1], n)
+                    r.discard = StepOutput(r.origins[2], n) if dis is not None else None
+
+            def stack_out(v):
+                if v is None:
+                    return None
+                if isinstance(v, Sym):
+                    v = v.value
+                if isinstance(v, (tuple, list)):
+                    return type(v)(stack_out(x) for x in v)
+                return StepOutput(tr.store_step(v, n), n)
+            rets = stack_out(ret)
+            updates = []
+            if w is not None:
+                updates.append((wvar, (Expr(wvar) + w).node))
+            updates.append((svar, (Expr(svar) + score_t).node))
+            g.set_vars(updates)
+        g.loop_end()
+        ctx.store_sites = keep
+        if isinstance(rec, _SiteRec):
+            raise NotImplementedError("editing a plate of bare distributions")
+
+        def drop_retvals(r):
+            if isinstance(r, _CallRec):
+                r.retval = None
+                for x in r.sites.values():
+                    drop_retvals(x)
+        drop_retvals(rec)
+        out = _CallRec(self)
+        out.sites = rec.sites
+        out.retval = rets
+        out.plate_score = Expr(svar)
+        return out, rets, Expr(wvar), None
+
     def _trace_edit(self, ctx, mode, key, args, constraint, prev, req, req_leaves, addr):
         """Vmap.edit (vmap.py:334-362): `Update(constraint)` edits every element with keys split(key, n)
         and its slice of the constraint (edit_choice_map :236-275); `IndexRequest(idx, request)` applies
@@ -181,6 +376,9 @@ class Vmap(GenerativeFunction):
         inner_prev = prev["vmap"]
         axes = self._axes(args)
         n = self._plate_size(args, axes)
+        if n > VMAP_UNROLL_MAX:
+            return self._trace_edit_loop(ctx, kind if kind != "empty" else "update", key, args, axes, constraint,
+                                         inner_prev, req, n, req_leaves, addr)
         g = ctx.tr.graph
         keep = ctx.store_sites
         ctx.store_sites = False

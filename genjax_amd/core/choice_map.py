@@ -180,6 +180,15 @@ class _SelectionBuilder:
     def __getitem__(self, addr) -> Selection:
         return Selection.all().extend(*_norm(addr))
 
+    # `from genjax import Selection as S` is as common in the reference's tests as SelectionBuilder: S.all() / S.none()
+    @staticmethod
+    def all() -> Selection:
+        return Selection.all()
+
+    @staticmethod
+    def none() -> Selection:
+        return Selection.none()
+
 
 SelectionBuilder = _SelectionBuilder()
 Selection.at = SelectionBuilder          # Selection.at["x"]

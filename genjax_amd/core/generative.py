@@ -261,6 +261,18 @@ class GenerativeFunction:
         return Scan(self, n)
 
 
+def _args_equal(a, b) -> bool:
+    """structural equality of argument tuples / dicts that may hold tensors"""
+    import torch
+    if isinstance(a, (tuple, list)) and isinstance(b, (tuple, list)):
+        return len(a) == len(b) and all(_args_equal(x, y) for x, y in zip(a, b))
+    if isinstance(a, dict) and isinstance(b, dict):
+        return a.keys() == b.keys() and all(_args_equal(a[k], b[k]) for k in a)
+    if isinstance(a, torch.Tensor) or isinstance(b, torch.Tensor):
+        return isinstance(a, torch.Tensor) and isinstance(b, torch.Tensor) and a.shape == b.shape and bool((a == b).all())
+    return a == b
+
+
 class GenerativeFunctionClosure(GenerativeFunction):
     """`gen_fn(*args)`: `closure @ addr` traces the callee at addr inside a
     `@gen` function; `closure(key)` simulates and returns the return value
@@ -281,7 +293,24 @@ class GenerativeFunctionClosure(GenerativeFunction):
         gf, args = self._target()
         return trace(addr, gf, args)
 
+    def handle_kwargs(self):
+        """the closure in its (args, kwargs)-taking form (generative_function.py:1597-1611); idempotent"""
+        if not self.kwargs and getattr(self, "_kwarged_form", False):
+            return self
+        out = GenerativeFunctionClosure(self.gen_fn.handle_kwargs(), (self.args, dict(self.kwargs)), {})
+        out._kwarged_form = True
+        return out
+
+    def __eq__(self, other):
+        return (isinstance(other, GenerativeFunctionClosure) and self.gen_fn is other.gen_fn
+                and _args_equal(self.args, other.args) and _args_equal(self.kwargs, other.kwargs))
+
+    __hash__ = object.__hash__
+
     def __call__(self, key, *args, **kwargs):
+        if getattr(self, "_kwarged_form", False):      # (args, kwargs) payload: extra arguments join their own kind
+            pos, kw = self.args
+            return self.gen_fn.simulate(key, (tuple(pos) + args, {**kw, **kwargs})).get_retval()
         full = GenerativeFunctionClosure(self.gen_fn, self.args + args, {**self.kwargs, **kwargs})
         gf, a = full._target()
         return gf.simulate(key, a).get_retval()

@@ -45,7 +45,9 @@ class Pytree:
 
     @staticmethod
     def static(**kwargs):
-        return dataclasses.field(**kwargs)
+        md = dict(kwargs.pop("metadata", None) or {})
+        md["static"] = True                   # rides in the structure, not among the leaves (engine.Flat)
+        return dataclasses.field(metadata=md, **kwargs)
 
     @staticmethod
     def field(**kwargs):

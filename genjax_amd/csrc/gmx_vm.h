@@ -127,8 +127,22 @@ GMX_HD void gmx_vm_step(Regs& R, const W w, int64_t i, bool active, const gmx_ru
         } else if (A.key_mode == GMX_KEY_SPLIT) {
           k = gmx_split_child(k, (uint64_t)(A.index_offset + i));
         } else if (A.key_mode == GMX_KEY_ROWSPLIT) {
-          int64_t row = gmx_rowsplit_row(i, A.key_inner), j = i - row * A.key_inner;
-          if (active) { k.k0 = A.keys_d[2 * row]; k.k1 = A.keys_d[2 * row + 1]; }
+          int64_t row, j;
+#if defined(__HIP_DEVICE_COMPILE__)
+          if (gridDim.y > 1) {
+            // a 2-D launch: the row is the workgroup's (blockIdx.y), so the row key is LAUNCH-UNIFORM per workgroup —
+            // loaded unconditionally through the scalar unit, and the key schedule of the split (ks2 = k0 ^ k1 ^ C,
+            // the injections) stays on the scalar unit as in GMX_KEY_SPLIT mode.  Per-lane key loads made this mode
+            // cost 75 vector instructions per wave more than GMX_KEY_SPLIT (SQ_INSTS_VALU 1211 vs 1136, noise program).
+            row = (int64_t)blockIdx.y; j = i - row * A.key_inner;
+            k.k0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)A.keys_d[2 * row]);
+            k.k1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)A.keys_d[2 * row + 1]);
+          } else
+#endif
+          {
+            row = i / A.key_inner; j = i - row * A.key_inner;
+            if (active) { k.k0 = A.keys_d[2 * row]; k.k1 = A.keys_d[2 * row + 1]; }
+          }
           k = gmx_split_child(k, (uint64_t)(A.index_offset + j));     // a shard's block of every row's split
         }
         r0 = k.k0; r1 = k.k1; wr = 2;

@@ -44,6 +44,24 @@ def _seq_sum(terms):
     return acc
 
 
+def _traced_call(v, args) -> bool:
+    """True inside a traced function when a value / parameter is symbolic: the call contributes to the program being
+    traced instead of launching one of its own."""
+    if not T.is_tracing():
+        return False
+    import dataclasses
+
+    def sym(x):
+        if T.is_symbolic(x):
+            return True
+        if isinstance(x, (tuple, list)):
+            return any(sym(y) for y in x)
+        if dataclasses.is_dataclass(x) and not isinstance(x, type):
+            return any(sym(getattr(x, f_.name)) for f_ in dataclasses.fields(x))
+        return False
+    return sym(v) or sym(tuple(args))
+
+
 class Distribution(GenerativeFunction):
     name = "distribution"
     value_dtype = "f32"
@@ -57,12 +75,22 @@ class Distribution(GenerativeFunction):
         return self          # exact_density types reply with self (distribution.py:468)
 
     def canon(self, args) -> tuple:
-        """Accept (a, b) or the kwargs form ((a, b), {kw}) (distribution.py:448-466)."""
+        """Accept (a, b) or the kwargs form ((a, b), {kw}) (distribution.py:448-466).  `sample_shape=` (a tuple, an
+        int or a Const of either; tensorflow_probability/__init__.py:52-55): the site draws `sample_shape + batch`
+        values from its one key — element j of the row-major array takes counter j — and its score is their sum;
+        carried by broadcasting the first parameter to that shape."""
         if len(args) == 2 and isinstance(args[1], dict) and isinstance(args[0], tuple):
             pos, kw = args
             kw = dict(kw)
-            kw.pop("sample_shape", None)
-            return self.from_kwargs(tuple(pos), kw)
+            ss = kw.pop("sample_shape", None)
+            out = self.from_kwargs(tuple(pos), kw)
+            if ss is not None:
+                ss = ss.unwrap() if hasattr(ss, "unwrap") else ss
+                ss = (int(ss),) if isinstance(ss, (int, np.integer)) else tuple(int(x) for x in ss)
+                if ss and out:
+                    first = out[0] if isinstance(out[0], np.ndarray) else np.asarray(out[0], dtype=object)
+                    out = (np.broadcast_to(first, ss + first.shape),) + tuple(out[1:])
+            return out
         return tuple(args)
 
     def from_kwargs(self, pos, kw):
@@ -80,6 +108,10 @@ class Distribution(GenerativeFunction):
         return {"f32": T.as_float, "i32": T.as_int, "bool": T.as_bool}[self.value_dtype](v)
 
     def sym_sample(self, key: Expr, args: tuple):
+        if self.sample_op is None and type(self).random_weighted is not Distribution.random_weighted:
+            # a user-defined Distribution (distribution.py:90-106): its own `random_weighted(key, *args)`, traced —
+            # e.g. composed from the built-in distributions' random_weighted, which answer symbolically to a traced key
+            return self.random_weighted(key, *args)[1]
         g = current_graph()
         elems, shape = _bcast(args)
         out = []
@@ -108,6 +140,8 @@ class Distribution(GenerativeFunction):
 
     def sym_logpdf(self, v, args: tuple) -> Expr:
         """estimate_logpdf: elementwise log_prob summed in element order."""
+        if self.logpdf_op is None and type(self).estimate_logpdf is not Distribution.estimate_logpdf:
+            return T.as_float(self.estimate_logpdf(None, v, *args))          # a user-defined Distribution
         g = current_graph()
         elems, _ = _bcast((v,) + tuple(args))
         terms = []
@@ -136,6 +170,9 @@ class Distribution(GenerativeFunction):
         return run_gfi(self, "generate", key, args, constraint=constraint)
 
     def assess(self, sample, args, batch_shape=None):
+        if _traced_call(sample.get_value() if isinstance(sample, ChoiceMap) else sample, args):
+            v = sample.get_value() if isinstance(sample, ChoiceMap) else sample      # inside a traced function
+            return self.sym_logpdf(v, self.canon(tuple(args))), v
         from .static import run_gfi
         return run_gfi(self, "assess", None, args, constraint=sample, batch_shape=batch_shape)
 
@@ -149,10 +186,16 @@ class Distribution(GenerativeFunction):
         return s if selection.check() else (torch.zeros_like(s) if hasattr(s, "shape") else 0.0)
 
     def random_weighted(self, key, *args):
+        if isinstance(key, Expr):                  # a traced key: inside a user-defined distribution / @gen function
+            a = self.canon(tuple(args))
+            v = self.sym_sample(key, a)
+            return self.sym_logpdf(v, a), v
         tr = self.simulate(key, args)
         return tr.get_score(), tr.get_retval()
 
     def estimate_logpdf(self, key, v, *args):
+        if _traced_call(v, args):
+            return self.sym_logpdf(v, self.canon(tuple(args)))
         return self.assess(ChoiceMap.choice(v), args)[0]
 
     def __repr__(self):

@@ -14,6 +14,8 @@ store in the kernel is one coalesced 256-byte wave access.
 """
 from __future__ import annotations
 
+import dataclasses
+
 import os
 import struct
 import weakref
@@ -231,6 +233,17 @@ class Flat:
             return ("dict", tuple((k, self.add(x)) for k, x in v.items()))
         if isinstance(v, ChoiceMap):
             return ("chm", tuple((a, self.add(v[a] if a else v.get_value())) for a in v.addresses()))
+        if dataclasses.is_dataclass(v) and not isinstance(v, type) and not getattr(v, "__gmx_static__", False):
+            # a Pytree (`@Pytree.dataclass`, pytree.py:40-205): its fields are the leaves; fields declared with
+            # Pytree.static() ride in the structure (and so in the program cache key)
+            items = []
+            for f_ in dataclasses.fields(v):
+                x = getattr(v, f_.name)
+                if f_.metadata.get("static"):
+                    items.append((f_.name, ("static_field", _hashable(x), x)))
+                else:
+                    items.append((f_.name, self.add(x)))
+            return ("dc", type(v), tuple(items))
         if isinstance(v, Mask):
             # a runtime-conditional constraint (distribution.py:129-142): a flag known on the host resolves now
             if isinstance(v.flag, (bool, np.bool_)):
@@ -238,6 +251,21 @@ class Flat:
             return ("mask", self.add(v.value), self.add(v.flag))
         self.leaves.append(v)
         return ("leaf", len(self.leaves) - 1)
+
+
+def _hashable(x):
+    try:
+        hash(x)
+        return x
+    except TypeError:
+        return ("id", id(x))
+
+
+def _make_dataclass(cls, values: dict):
+    obj = object.__new__(cls)
+    for k, v in values.items():
+        object.__setattr__(obj, k, v)
+    return obj
 
 
 def _is_number_seq(v):
@@ -264,6 +292,8 @@ def unflatten(tree, fn):
         return Mask(unflatten(tree[1], fn), unflatten(tree[2], fn))
     if kind == "mask_static":
         return Mask(unflatten(tree[2], fn), tree[1])
+    if kind == "dc":
+        return _make_dataclass(payload, {name: (t[2] if t[0] == "static_field" else unflatten(t, fn)) for name, t in tree[2]})
     raise ValueError(kind)
 
 
@@ -454,6 +484,10 @@ class Tracing:
             return ("tuple" if isinstance(value, tuple) else "list", [self.emit_output(v) for v in value])
         if isinstance(value, dict):
             return ("dict", {k: self.emit_output(v) for k, v in value.items()})
+        if dataclasses.is_dataclass(value) and not isinstance(value, type) and not getattr(value, "__gmx_static__", False):
+            return ("dc", type(value), {f_.name: (("const", getattr(value, f_.name)) if f_.metadata.get("static")
+                                                  else self.emit_output(getattr(value, f_.name)))
+                                        for f_ in dataclasses.fields(value)})
         return ("const", value)
 
 
@@ -900,6 +934,8 @@ def resolve(origin, outs, leaves):
         return tuple(seq) if kind == "tuple" else seq
     if kind == "dict":
         return {k: resolve(o, outs, leaves) for k, o in origin[1].items()}
+    if kind == "dc":
+        return _make_dataclass(origin[1], {k: resolve(o, outs, leaves) for k, o in origin[2].items()})
     raise ValueError(origin)
 
 
@@ -954,9 +990,10 @@ def elementwise(fn, *xs):
     from . import tracer as T
     vals = [materialize(v) for v in xs]
     tens = [v for v in vals if isinstance(v, torch.Tensor) and v.ndim > 0]
-    if not tens:
-        out = fn(*[float(v) if isinstance(v, torch.Tensor) else v for v in vals])
-        return out
+    if not tens and not any(isinstance(v, torch.Tensor) for v in vals):
+        return fn(*vals)                 # Python numbers only
+    if not tens:                         # 0-d device values (an unbatched trace): a launch over one particle, f32 like
+        tens = [v for v in vals if isinstance(v, torch.Tensor)]          # everything else (not float64 on the host)
     lead = max((tuple(v.shape) for v in tens), key=len)
     nb = len(lead)
     for v in tens:                       # the batch is the shape every tensor shares as a prefix

@@ -148,7 +148,34 @@ class VmapTrace(Trace):
         return tuple(getattr(self.score, "shape", ()))
 
 
+def _zero_like_trace(tr):
+    z = lambda v: _tree_map_leaves(v, lambda t: torch.zeros_like(t) if isinstance(t, torch.Tensor) else
+                                   (type(t)(0) if isinstance(t, (int, float, bool)) else t))
+    if isinstance(tr, DistributionTrace):
+        return DistributionTrace(tr.gen_fn, tr.args, z(materialize(tr.value)), z(materialize(tr.score)))
+    if isinstance(tr, StaticTrace):
+        subs = OrderedDict((a, _zero_like_trace(st)) for a, st in tr.subtraces.items())
+        return StaticTrace(tr.gen_fn, tr.args, z(_tree_materialize(tr.retval)), subs)
+    raise NotImplementedError(f"get_zero_trace of a {type(tr).__name__}")
+
+
+def _tree_map_leaves(v, fn):
+    import dataclasses
+    if isinstance(v, tuple):
+        return tuple(_tree_map_leaves(x, fn) for x in v)
+    if isinstance(v, list):
+        return [_tree_map_leaves(x, fn) for x in v]
+    if isinstance(v, dict):
+        return {k: _tree_map_leaves(x, fn) for k, x in v.items()}
+    if dataclasses.is_dataclass(v) and not isinstance(v, type):
+        return dataclasses.replace(v, **{f_.name: _tree_map_leaves(getattr(v, f_.name), fn) for f_ in dataclasses.fields(v)})
+    return fn(v)
+
+
 def _tree_materialize(v):
+    import dataclasses
+    if dataclasses.is_dataclass(v) and not isinstance(v, type) and not getattr(v, "__gmx_static__", False):
+        return dataclasses.replace(v, **{f_.name: _tree_materialize(getattr(v, f_.name)) for f_ in dataclasses.fields(v)})
     if isinstance(v, tuple):
         return tuple(_tree_materialize(x) for x in v)
     if isinstance(v, list):
@@ -514,6 +541,10 @@ class Handler:
 
     # -- site dispatch -------------------------------------------------------------
     def handle(self, addr, gen_fn, args):
+        for comp in (addr if isinstance(addr, tuple) else (addr,)):
+            if not isinstance(comp, (str, int, np.integer)):
+                # a traced value is not an address (test_static_gen_fn.py:790-799): addresses are static
+                raise TypeError(f"static addresses are strings, integers or tuples of them (got {type(comp).__name__})")
         if addr in self.rec.sites:
             raise AddressReuse(addr)
         sub_key = self.fresh_key()
@@ -527,8 +558,14 @@ class Handler:
         sub_req = self._subrequest(addr)
         if sub_req is not None and sub_req.kind == "update" and self.mode == "static_edit":
             sub_con = sub_req.constraint          # Update nested inside a StaticRequest
-        rec, retval, w, s = call_gen_fn(self.ctx, self.mode, gen_fn, sub_key, args, sub_con, sub_prev,
-                                        sub_req, self.req_leaves, addr)
+        try:
+            rec, retval, w, s = call_gen_fn(self.ctx, self.mode, gen_fn, sub_key, args, sub_con, sub_prev,
+                                            sub_req, self.req_leaves, addr)
+        except MissingAddress as e:
+            # the exception names the address (test_static_gen_fn.py:309-315: `exc.value.args == ("y2",)`); below a
+            # nested call, the caller's address comes first
+            inner = tuple(a for a in e.args if a != ())
+            raise MissingAddress(*((addr,) + inner)) from None
         self.rec.sites[addr] = rec
         if w is not None:
             self.weight = self.weight + w          # static.py:377 / 454 / 559 / 668
@@ -1387,10 +1424,39 @@ def run_edit(gen_fn, key: Key, trace: Trace, request: EditRequest, argdiffs, mh:
     elif isinstance(request, IndexRequest):
         bwd = IndexRequest(request.idx, Update(discard))       # for a per-particle idx the discard holds the kept
                                                                # values at the other indices
+    elif isinstance(request, StaticRequest):
+        bwd = _static_bwd(request, otree, outs, flat.leaves)
     else:
-        bwd = request if isinstance(request, (StaticRequest, Rejuvenate)) else Update(discard)
+        bwd = request if isinstance(request, Rejuvenate) else Update(discard)
     retdiff = Diff.unknown_change(new_tr.get_retval())
     return new_tr, w, retdiff, bwd
+
+
+def _static_bwd(request, otree, outs, leaves):
+    """The backward request of a StaticRequest (static.py:867-904: a StaticRequest of the sub-requests' backward
+    requests): Update -> Update(discarded values) (distribution.py:235-242), Regenerate -> Update(old values)
+    (:266-277), Rejuvenate -> itself (rejuvenate.py:89-94), a nested StaticRequest -> recursively."""
+    if otree[0] == "site":
+        sub = request.addressed.get(())
+        subs = {(): sub} if sub is not None else {}
+        trees = {(): otree}
+    else:
+        subs = {(_norm(a) if a != () else ()): r for a, r in request.addressed.items()}
+        trees = {(_norm(a) if a != () else ()): (a, o) for a, o in otree[2].items()}
+    out = {}
+    for na, r in subs.items():
+        if na not in trees:
+            continue
+        a, o = trees[na] if otree[0] != "site" else ((), otree)
+        if isinstance(r, StaticRequest):
+            out[a] = _static_bwd(r, o, outs, leaves)
+        elif isinstance(r, Rejuvenate):
+            out[a] = r
+        elif isinstance(r, (Update, Regenerate)):
+            out[a] = Update(_build_discard(o, outs, leaves))
+        else:
+            out[a] = r
+    return StaticRequest(out)
 
 
 def _tangent_key(tangents):
@@ -1432,18 +1498,32 @@ class StaticGenerativeFunction(GenerativeFunction):
         self._partial = tuple(partial_args)
         functools.update_wrapper(self, source, updated=())
 
-    def source(self, *args):
-        return self._fn(*self._partial, *args)
+    def source(self, *args, **kwargs):
+        return self._fn(*self._partial, *args, **kwargs)
 
     def __get__(self, instance, _klass):
         return self.partial_apply(instance) if instance is not None else self
 
     def handle_kwargs(self):
-        fn = self
+        """A model taking ((args...), {kwargs}) (generative_function.py `handle_kwargs`); the same object every time,
+        so that programs traced through it are cached and `gf.handle_kwargs() == gf.handle_kwargs()`."""
+        kw = self.__dict__.get("_kwarged")
+        if kw is None:
+            fn = self
 
-        def kwarged(args, kwargs):
-            return fn.source(*args, **kwargs)
-        return StaticGenerativeFunction(kwarged)
+            def kwarged(args, kwargs):
+                return fn.source(*args, **kwargs)
+            kw = self.__dict__["_kwarged"] = StaticGenerativeFunction(kwarged)
+            kw.__dict__["_kwarged"] = kw          # idempotent
+        return kw
+
+    def get_zero_trace(self, *args, **_kwargs):
+        """A trace of the structure `simulate(key, args)` returns, every array leaf zero (generative_function.py
+        `get_zero_trace`: the reference evaluates `simulate` abstractly; here the model runs once with a dummy key and
+        its leaves are zeroed)."""
+        from .random import key as _key
+        tr = self.simulate(_key(0), tuple(args))
+        return _zero_like_trace(tr)
 
     # GFI ---------------------------------------------------------------------------
     def simulate(self, key, args):

@@ -1337,3 +1337,99 @@ def check_scan_carry_forms(n=130, seed=21, Ts=(8, 17, 40)):
             (r0, r1), _ = r.get_retval()
             (or0, or1), _ = orr.get_retval()
             assert np.array_equal(r0.cpu().numpy(), or0) and np.array_equal(r1.cpu().numpy(), or1)
+
+
+def check_plates_long(n=130, P=40, seed=8):
+    """A LARGE plate (more than 16 elements) runs as a counted loop in the site program (ref vmap.py:180-218: `jax.vmap`
+    over any n): the P-schools model written with `Vmap` — simulate / importance with a per-element
+    constraint (`C["schools", :, "y"]`) / assess, the plate used directly, `Update` of every element, `IndexRequest`
+    with a Python-int index and with one index per particle, a bare distribution under vmap, `repeat(n=P)` —
+    bit-exact against the oracle's per-element restatement."""
+    import genjax_amd as G
+    from genjax_amd import ChoiceMapBuilder as C, Diff, IndexRequest, Regenerate, SelectionBuilder as S, Update, numpy as jnp
+    dev = G._lib.get().device
+    sig = np.linspace(1.0, 3.0, P).astype(np.float32)
+    ys = np.linspace(-2.0, 2.0, P).astype(np.float32)
+    school, oschool = _school(G), _school(O)
+
+    @G.gen
+    def schools():
+        mu = G.normal(0.0, 5.0) @ "mu"
+        return school.vmap(in_axes=(None, None, 0))(mu, 2.0, jnp.array(sig)) @ "schools"
+
+    @O.gen
+    def o_schools():
+        mu = O.normal(0.0, 5.0) @ "mu"
+        return O.Vmap(oschool, in_axes=(None, None, 0))(mu, 2.0, sig) @ "schools"
+    tr, otr = schools.simulate(G.split(G.key(seed), n), ()), o_schools.simulate(O.split(O.key(seed), n), ())
+    th = tr.get_choices()["schools", "theta"]
+    assert tuple(th.shape) == (n, P)
+    assert np.array_equal(th.cpu().numpy(), otr.get_choices()["schools", "theta"])          # keys split(key, P)[j]
+    assert np.array_equal(tr.get_score().cpu().numpy(), otr.get_score())
+    assert np.array_equal(tr.get_retval().cpu().numpy(), otr.get_retval())
+    tri, w = schools.importance(G.split(G.key(seed + 1), n), C["schools", :, "y"].set(ys), ())
+    otri, ow = o_schools.importance(O.split(O.key(seed + 1), n), O.C.d({("schools", "y"): ys}), ())
+    assert np.array_equal(w.cpu().numpy(), ow) and np.array_equal(tri.get_score().cpu().numpy(), otri.get_score())
+    assert np.array_equal(tri.get_choices()["schools", "y"].cpu().numpy(), np.broadcast_to(ys, (n, P)))
+    s, _ = schools.assess(tri.get_choices(), ())
+    so, _ = o_schools.assess(otri.get_choices(), (), (n,))
+    assert np.array_equal(s.cpu().numpy(), so) and np.array_equal(s.cpu().numpy(), tri.get_score().cpu().numpy())
+    # constraints on single elements through integer addresses: masked constraints inside the loop
+    trj, wj = schools.importance(G.split(G.key(seed + 2), n), C["schools", 3, "y"].set(0.5).set(("schools", P - 2, "y"), -1.0), ())
+    yj, tj = trj.get_choices()["schools", "y"].cpu().numpy(), trj.get_choices()["schools", "theta"].cpu().numpy()
+    assert np.all(yj[:, 3] == np.float32(0.5)) and np.all(yj[:, P - 2] == np.float32(-1.0)) and not np.all(yj[:, 4] == np.float32(0.5))
+    w_ref = (O.normal.assess(O.C.choice(np.full(n, 0.5, np.float32)), (tj[:, 3], sig[3]), (n,))[0]
+             + O.normal.assess(O.C.choice(np.full(n, -1.0, np.float32)), (tj[:, P - 2], sig[P - 2]), (n,))[0])
+    assert np.array_equal(wj.cpu().numpy(), w_ref)
+    # the plate used directly; edits of it as a loop
+    v, ov = school.vmap(in_axes=(None, None, 0)), O.Vmap(oschool, in_axes=(None, None, 0))
+    args = (1.0, 2.0, jnp.array(sig))
+    oargs = (np.float32(1.0), np.float32(2.0), sig)
+    t2, ot2 = v.simulate(G.split(G.key(seed + 3), n), args), ov.simulate(O.split(O.key(seed + 3), n), oargs)
+    assert np.array_equal(t2.get_choices()["theta"].cpu().numpy(), ot2.get_choices()["theta"])
+    new_tr, wu, _, bwd = Update(C["y"].set(ys)).edit(G.split(G.key(seed + 4), n), t2, Diff.no_change(args))
+    onew, owu, odisc = O.vmap_update(ov, O.split(O.key(seed + 4), n), ot2, O.C.d({"y": ys}), oargs)
+    assert np.array_equal(wu.cpu().numpy(), owu) and np.array_equal(new_tr.get_score().cpu().numpy(), onew.get_score())
+    assert np.array_equal(bwd.constraint["y"].cpu().numpy(), odisc["y"])
+    assert np.array_equal(new_tr.get_choices()["theta"].cpu().numpy(), ot2.get_choices()["theta"])
+    j0 = P - 5
+    t3, w3, _, bwd3 = IndexRequest(j0, Regenerate(S["theta"])).edit(G.split(G.key(seed + 5), n), new_tr, Diff.no_change(args))
+    aj = (np.float32(1.0), np.float32(2.0), np.float32(sig[j0]))
+    ot3, ow3 = O.vmap_edit_index(ov, O.split(O.key(seed + 5), n), onew, j0,
+                                 lambda k, sl, a: oschool.regenerate(k, sl, O.selection("theta"), a)[:2], aj)
+    th3 = t3.get_choices()["theta"].cpu().numpy()
+    assert np.array_equal(th3, ot3.get_choices()["theta"]) and np.array_equal(w3.cpu().numpy(), ow3)
+    assert np.array_equal(t3.get_score().cpu().numpy(), ot3.get_score())
+    th1 = new_tr.get_choices()["theta"].cpu().numpy()
+    assert np.array_equal(np.delete(th1, j0, axis=1), np.delete(th3, j0, axis=1)) and not np.array_equal(th1[:, j0], th3[:, j0])
+    assert isinstance(bwd3, IndexRequest) and bwd3.idx == j0
+    idx = np.random.default_rng(seed).integers(0, P, n).astype(np.int32)
+    t4, w4, _, _ = IndexRequest(torch.from_numpy(idx).to(dev), Regenerate(S["theta"])).edit(
+        G.split(G.key(seed + 6), n), t2, Diff.no_change(args))
+    tho, wo = ot2.get_choices()["theta"].copy(), np.zeros(n, np.float32)
+    for j in np.unique(idx):
+        a_ = (np.float32(1.0), np.float32(2.0), np.float32(sig[j]))
+        cand, wj_ = O.vmap_edit_index(ov, O.split(O.key(seed + 6), n), ot2, int(j),
+                                      lambda k, sl, a: oschool.regenerate(k, sl, O.selection("theta"), a)[:2], a_)
+        m_ = idx == j
+        tho[m_, j], wo[m_] = cand.get_choices()["theta"][m_, j], np.asarray(wj_, np.float32)[m_]
+    assert np.array_equal(t4.get_choices()["theta"].cpu().numpy(), tho) and np.array_equal(w4.cpu().numpy(), wo)
+    # a bare distribution under vmap (one vector-valued site with split keys) and repeat(n=P)
+    locs = np.linspace(-1.0, 1.0, P).astype(np.float32)
+
+    @G.gen
+    def bare():
+        xs = G.normal.vmap(in_axes=(0, None))(jnp.array(locs), 1.0) @ "xs"
+        zs = school.repeat(n=P)(0.5, 1.0, 2.0) @ "zs"
+        return xs
+
+    @O.gen
+    def o_bare():
+        xs = O.Vmap(O.normal, in_axes=(0, None))(np.broadcast_to(locs, (n, P)), 1.0) @ "xs"      # [batch, plate]
+        zs = O.Repeat(oschool, P)(0.5, 1.0, 2.0) @ "zs"
+        return xs
+    tb, otb = bare.simulate(G.split(G.key(seed + 7), n), ()), o_bare.simulate(O.split(O.key(seed + 7), n), ())
+    assert np.array_equal(tb.get_choices()["xs"].cpu().numpy(), otb.get_choices()["xs"])
+    assert np.array_equal(tb.get_choices()["zs", "theta"].cpu().numpy(), otb.get_choices()["zs", "theta"])
+    assert np.array_equal(tb.get_score().cpu().numpy(), otb.get_score())
+    assert np.array_equal(tb.get_retval().cpu().numpy(), otb.get_retval())

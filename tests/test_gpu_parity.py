@@ -783,6 +783,15 @@ def test_long_scan_config2_as_one_generative_function(gpu):
     assert abs(r["log_ml_is"] - r["kalman"]) < 0.25, r         # prior-proposal IS over 18 steps: MC error ~0.1
 
 
+def test_large_plates_as_a_counted_loop(gpu):
+    """`Vmap` plates of any size (ref vmap.py:180-218) as OP_LOOP with split(key, n)[j] keys —
+    a 4096-element plate x 1e4 particles (interpreter) and a 40-element plate x 2.7e5 particles (specialised kernel),
+    simulate / importance / assess / Update / IndexRequest, bit-exact vs the oracle."""
+    parity.check_plates_long(n=300, P=40)
+    parity.check_plates_long(n=270_000, P=24, seed=3)
+    parity.check_plates_long(n=10_000, P=4096, seed=5)
+
+
 def test_scan_carries_that_forward_each_other(gpu):
     """`(xn, a)` from `(a, b)` and `(b, a)` carries through the counted loop — interpreter and the
     specialised kernel (n >= 2^18) — bit-exact vs the oracle for simulate / generate / Update / Regenerate."""

@@ -586,6 +586,13 @@ def test_scan_carries_that_forward_each_other(hostsim):
     parity.check_scan_carry_forms()
 
 
+def test_large_plates_run_as_a_loop_and_match_oracle():
+    """Vmap of more than 16 elements = a counted loop in the site program (ref vmap.py:180-218); incl. edits"""
+    from tests import parity
+    parity.check_plates_long(n=130, P=40)
+    parity.check_plates_long(n=33, P=17, seed=2)
+
+
 def test_indexed_and_masked_constraints_match_oracle():
     from tests import parity
     parity.check_masked_constraints()

@@ -34,6 +34,24 @@ SCAN_UNROLL_MAX = 16      # longer scans run as a counted loop in the site progr
 VMAP_UNROLL_MAX = 16      # larger plates run as a counted loop too (Vmap._trace_loop): one iteration per element
 
 
+def _dyn_take(v, t):
+    """element t (a run-time index) of a previous plate value: a step-indexed leaf reads it directly; a short vector
+    held in registers goes through a chain of selects"""
+    from .engine import StepInput, Sym
+    from .numpy import RuntimeTable, TableArray
+    if isinstance(v, Sym):
+        v = v.value
+    if isinstance(v, (StepInput, RuntimeTable, TableArray)):
+        return v[t]
+    if isinstance(v, np.ndarray) and v.dtype == object and v.ndim >= 1:
+        out = v[v.shape[0] - 1]
+        for j in range(v.shape[0] - 2, -1, -1):
+            out = _select_tree(t == j, v[j], out) if not isinstance(v[j], np.ndarray) else np.vectorize(
+                lambda a, b, j=j: T.where(t == j, a, b), otypes=[object])(v[j], out)
+        return out
+    raise NotImplementedError("editing a plate: its previous values must be a per-particle [n, T] leaf")
+
+
 def _loop_at(v, t, what="a plate of more than 16 elements"):
     """element t (the iteration number of a counted loop) of a mapped argument / per-element constraint / previous
     value: a launch-uniform table, or a per-particle [n, T] leaf read step by step"""
@@ -75,6 +93,67 @@ def _axis_len(a):
     return None
 
 
+def _is_container(v):
+    import dataclasses
+    return isinstance(v, (tuple, dict)) or (isinstance(v, list) and (not v or isinstance(v[0], (tuple, list, dict, np.ndarray)))) \
+        or (dataclasses.is_dataclass(v) and not isinstance(v, type) and not getattr(v, "__gmx_static__", False))
+
+
+def _tree_leaves_with_axes(v, ax, out, who="vmap"):
+    """(leaf, axis) pairs of an argument under an in_axes spec that is a TREE PREFIX of it (jax.vmap's rule): an int /
+    None applies to every leaf below, a tuple / list / dict must match the argument's container"""
+    import dataclasses
+    from .engine import Sym
+    if isinstance(v, Sym):
+        v = v.value
+    if isinstance(ax, (tuple, list)):
+        if not isinstance(v, (tuple, list)) or len(v) != len(ax):
+            raise ValueError(f"{who} in_axes specification must be a tree prefix of the corresponding value, got "
+                             f"specification {ax!r} for value {type(v).__name__}")
+        for x, a in zip(v, ax):
+            _tree_leaves_with_axes(x, a, out, who)
+        return
+    if isinstance(ax, dict):
+        if not isinstance(v, dict) or set(v) != set(ax):
+            raise ValueError(f"{who} in_axes specification must be a tree prefix of the corresponding value")
+        for k in v:
+            _tree_leaves_with_axes(v[k], ax[k], out, who)
+        return
+    if _is_container(v):
+        if isinstance(v, dict):
+            kids = list(v.values())
+        elif isinstance(v, (tuple, list)):
+            kids = list(v)
+        else:
+            kids = [getattr(v, f_.name) for f_ in dataclasses.fields(v) if not f_.metadata.get("static")]
+        for x in kids:
+            _tree_leaves_with_axes(x, ax, out, who)
+        return
+    out.append((v, ax))
+
+
+def _tree_take_axes(v, ax, fn):
+    """rebuild an argument with `fn(leaf)` applied to its mapped leaves (ax not None)"""
+    import dataclasses
+    from .engine import Sym
+    if isinstance(v, Sym):
+        v = v.value
+    if ax is None and not isinstance(ax, (tuple, list, dict)):
+        return v
+    if isinstance(ax, (tuple, list)):
+        return type(v)(_tree_take_axes(x, a, fn) for x, a in zip(v, ax))
+    if isinstance(ax, dict):
+        return {k: _tree_take_axes(v[k], ax[k], fn) for k in v}
+    if _is_container(v):
+        if isinstance(v, dict):
+            return {k: _tree_take_axes(x, ax, fn) for k, x in v.items()}
+        if isinstance(v, (tuple, list)):
+            return type(v)(_tree_take_axes(x, ax, fn) for x in v)
+        return dataclasses.replace(v, **{f_.name: _tree_take_axes(getattr(v, f_.name), ax, fn)
+                                         for f_ in dataclasses.fields(v) if not f_.metadata.get("static")})
+    return fn(v)
+
+
 def _take(a, j):
     if isinstance(a, np.ndarray):
         v = a[j]
@@ -97,6 +176,9 @@ def _index_chm(chm: ChoiceMap, j, n):
         chm = ChoiceMap(chm._value, {a: c for a, c in chm._children.items() if not isinstance(a, int)})
 
     def pick(v):
+        from .core.mask import Mask
+        if isinstance(v, Mask):            # a masked constraint on the whole plate: element j of its value, same flag
+            return Mask(pick(v.value), v.flag)
         if isinstance(v, Sym):
             inner = v.value
             if isinstance(inner, np.ndarray) and inner.ndim >= 1 and inner.shape[0] == n:
@@ -119,7 +201,33 @@ def _stack(vals):
     return np.stack(arrs, axis=0)
 
 
+def _plate_project(self, key, trace, selection):
+    """project of a plate / scan trace (vmap.py:220-234, scan.py:296-323): the inner function's projection per element,
+    summed over the plate axis in element order.  Everything selected: the trace's score itself; nothing: 0."""
+    import torch
+    from .core import choice_map as cm
+    from .static import DistributionTrace
+    score = trace.get_score()
+    if isinstance(selection, cm._All):
+        return score
+    zero = torch.zeros_like(score) if isinstance(score, torch.Tensor) else 0.0
+    if isinstance(selection, cm._None):
+        return zero
+    if isinstance(trace, DistributionTrace):
+        return score if selection.check() else zero
+    inner = trace.inner
+    w = inner.get_gen_fn().project(key, inner, selection)
+    if not isinstance(w, torch.Tensor) or w.ndim <= len(trace.batch_shape):
+        return w
+    acc = zero
+    for j in range(w.shape[-1]):
+        acc = acc + w[..., j]
+    return acc
+
+
 class Vmap(GenerativeFunction):
+    project = _plate_project
+
     def __init__(self, gen_fn, in_axes=0):
         self.gen_fn, self.in_axes = gen_fn, in_axes
 
@@ -129,15 +237,43 @@ class Vmap(GenerativeFunction):
             return (ax,) * len(args)
         ax = tuple(ax)
         if len(ax) != len(args):
-            raise ValueError("vmap: in_axes does not match the number of arguments")
+            raise ValueError("vmap in_axes specification must be a tree prefix of the corresponding value: "
+                             f"{len(ax)} axes for {len(args)} arguments")
         return ax
 
     def _plate_size(self, args, axes):
-        sizes = {_axis_len(a) for a, ax in zip(args, axes) if ax is not None}
-        sizes.discard(None)
-        if len(sizes) != 1:
-            raise ValueError(f"vmap: cannot infer the plate size from the mapped arguments ({sizes})")
-        return sizes.pop()
+        """the common leading length of the mapped leaves (in_axes may be a tree prefix of an argument; a Pytree's
+        leaves are mapped together)"""
+        pairs = []
+        for a, ax in zip(args, axes):
+            _tree_leaves_with_axes(a, ax, pairs)
+        sizes = []
+        for leaf, ax in pairs:
+            if ax is None:
+                continue
+            if ax != 0:
+                raise NotImplementedError("vmap: only axis 0 of an argument can be mapped (in_axes entries are 0 or None)")
+            shp = getattr(leaf, "shape", None)
+            n = _axis_len(leaf) if shp is None else (shp[0] if len(shp) else None)
+            if n is None:
+                raise ValueError("vmap was requested to map its argument along axis 0, which implies that its rank "
+                                 "should be at least 1, but is only 0 (its shape is ())")
+            sizes.append(int(n))
+        if not sizes:
+            raise ValueError("vmap: cannot infer the plate size: no argument is mapped")
+        if len(set(sizes)) != 1:
+            raise ValueError(f"vmap got inconsistent sizes for array axes to be mapped: {sorted(set(sizes))}")
+        return sizes[0]
+
+    def _empty(self, mode):
+        """a zero-length plate (vmap.py / GEN-333): no choices, score 0"""
+        from .static import _CallRec
+        out = _CallRec(self)
+        out.retval = None
+        out.plate_score = 0.0
+        if mode in ("simulate", "assess"):
+            return out, None, None, 0.0
+        return out, None, 0.0, None
 
     def trace_call(self, ctx, mode, key, args, constraint, prev, req, req_leaves, addr):
         """Called by static.call_gen_fn while tracing a parent `@gen` function."""
@@ -146,7 +282,12 @@ class Vmap(GenerativeFunction):
             return self._trace_edit(ctx, mode, key, args, constraint, prev, req, req_leaves, addr)
         axes = self._axes(args)
         n = self._plate_size(args, axes)
-        if n > VMAP_UNROLL_MAX:
+        if n == 0:
+            return self._empty(mode)
+        # a plate OF plates (`model.repeat(n=10).repeat(n=10)`): unrolling both would need one output slot per element
+        # of the product; the outer one runs as a loop whose body is the (small, unrolled) inner plate
+        nested = isinstance(self.gen_fn, (Vmap, Scan, _ScanAdapter)) and n > 4 and not getattr(ctx.tr.graph, "_in_loop", False)
+        if n > VMAP_UNROLL_MAX or nested:
             return self._trace_loop(ctx, mode, key, args, axes, constraint, n, req_leaves, addr)
         from .static import _rec_score
         g = ctx.tr.graph
@@ -157,7 +298,7 @@ class Vmap(GenerativeFunction):
         score = Expr(g.const_f32(0.0))
         for j in range(n):
             kj = Expr(g.add("KDERIVE", (key.node,), imm=j, dtype="key")) if key is not None else None   # split(key, n)[j]
-            args_j = tuple(_take(a, j) if ax is not None else a for a, ax in zip(args, axes))
+            args_j = tuple(_tree_take_axes(a, ax, lambda v: _take(v, j)) for a, ax in zip(args, axes))
             con_j = _index_chm(constraint, j, n)
             rec, ret, w, s = call_gen_fn(ctx, mode, self.gen_fn, kj, args_j, con_j, None, None, req_leaves, addr)
             recs.append(rec)
@@ -210,16 +351,14 @@ class Vmap(GenerativeFunction):
         with T.tracing(g):
             t = Expr(g.add("LDT", dtype="i32"))
             k_t = Expr(g.add("KDERIVER", (key.node, t.node), dtype="key")) if key is not None else None
-            args_t = tuple(_loop_at(a, t, what) if ax is not None else a for a, ax in zip(args, axes))
+            args_t = tuple(_tree_take_axes(a, ax, lambda v: _loop_at(v, t, what)) for a, ax in zip(args, axes))
             con_t = _loop_step_constraint(constraint, t, n, _loop_at, what) if constraint is not None else None
             rec, ret, w, s_ = call_gen_fn(ctx, mode, self.gen_fn, k_t, args_t, con_t, None, None, req_leaves, addr)
             score_t = s_ if mode == "assess" else _rec_score(rec)
             for r in _leaves(rec):
                 val = r.value.value if isinstance(r.value, Sym) else r.value
                 sc = r.score.value if isinstance(r.score, Sym) else r.score
-                if isinstance(sc, np.ndarray):
-                    raise NotImplementedError(f"{what}: a site with a vector-valued SCORE")
-                if keep:
+                if keep:            # (a nested, unrolled plate's per-element scores: a vector, one plane per element)
                     r.origins = (tr.store_step(val, n), tr.store_step(sc, n), None)
                     r.value = StepOutput(r.origins[0], n)
                     r.score = StepOutput(r.origins[1], n)
@@ -264,7 +403,8 @@ class Vmap(GenerativeFunction):
             return out, retval, None, score
         return out, retval, Expr(wvar), None
 
-    def _trace_edit_loop(self, ctx, kind, key, args, axes, constraint, inner_prev, req, n, req_leaves, addr):
+    def _trace_edit_loop(self, ctx, kind, key, args, axes, constraint, inner_prev, req, n, req_leaves, addr,
+                         bare_prev=None):
         """Update / IndexRequest of a LARGE plate as a counted loop (the loop form of _trace_edit): iteration j edits
         element j — `Update`: with key split(key, n)[j] and element j of the constraint; `IndexRequest(idx, request)`:
         `request` with the caller's key where idx == j (a Python int or one index per particle: the same test), a plain
@@ -294,8 +434,13 @@ class Vmap(GenerativeFunction):
         g.loop_begin(n)
         with T.tracing(g):
             t = Expr(g.add("LDT", dtype="i32"))
-            args_t = tuple(_loop_at(a, t, what) if ax is not None else a for a, ax in zip(args, axes))
-            prev_t = prev_at(inner_prev, t)
+            args_t = tuple(_tree_take_axes(a, ax, lambda v: _loop_at(v, t, what)) for a, ax in zip(args, axes))
+            if bare_prev is not None:
+                old_v = _dyn_take(bare_prev["value"], t)
+                old_s = self.gen_fn.sym_logpdf(old_v, self.gen_fn.canon(args_t))
+                prev_t = {"value": Sym(old_v, None), "score": Sym(old_s, None)}
+            else:
+                prev_t = prev_at(inner_prev, t)
             if kind == "index":
                 sub = req.sub
                 m_ = {"update": "update", "regen": "regen"}.get(sub.kind, "static_edit")
@@ -347,7 +492,9 @@ class Vmap(GenerativeFunction):
         g.loop_end()
         ctx.store_sites = keep
         if isinstance(rec, _SiteRec):
-            raise NotImplementedError("editing a plate of bare distributions")
+            # a bare distribution's plate stays one vector-valued site: values [T], score = the new plate sum
+            out = _SiteRec(rec.gen_fn, rec.value, Expr(svar), rec.discard)
+            return out, rec.value, Expr(wvar), None
 
         def drop_retvals(r):
             if isinstance(r, _CallRec):
@@ -369,13 +516,18 @@ class Vmap(GenerativeFunction):
         from .core.generative import NotSupportedEditRequest
         from .static import _CallRec, _ReqSpec, _SiteRec, _rec_score, _store_site, call_gen_fn
         kind = req.kind if req is not None else "empty"
-        if prev is None or "vmap" not in prev:
-            raise NotImplementedError("editing a plate of bare distributions (its per-element scores are not kept)")
+        if prev is None:
+            raise NotImplementedError("editing a plate without its previous trace")
         if not (mode == "update" or kind in ("update", "index", "empty")):
             raise NotSupportedEditRequest(f"Vmap.edit answers Update and IndexRequest (got {kind!r}), vmap.py:342-362")
-        inner_prev = prev["vmap"]
         axes = self._axes(args)
         n = self._plate_size(args, axes)
+        if "vmap" not in prev:
+            # a plate of a BARE distribution (`normal.vmap()(locs, scales) @ "a"`): its trace keeps the values and the
+            # plate-sum score; the per-element scores an edit needs are recomputed from the old values in the loop
+            return self._trace_edit_loop(ctx, kind if kind != "empty" else "update", key, args, axes, constraint, None,
+                                         req, n, req_leaves, addr, bare_prev=prev)
+        inner_prev = prev["vmap"]
         if n > VMAP_UNROLL_MAX:
             return self._trace_edit_loop(ctx, kind if kind != "empty" else "update", key, args, axes, constraint,
                                          inner_prev, req, n, req_leaves, addr)
@@ -387,7 +539,7 @@ class Vmap(GenerativeFunction):
         weight = Expr(g.const_f32(0.0))
         score = Expr(g.const_f32(0.0))
         for j in range(n):
-            args_j = tuple(_take(a, j) if ax is not None else a for a, ax in zip(args, axes))
+            args_j = tuple(_tree_take_axes(a, ax, lambda v: _take(v, j)) for a, ax in zip(args, axes))
             prev_j = _index_prev(inner_prev, j)
             if kind == "index":
                 traced = not isinstance(req.idx, int)
@@ -447,7 +599,24 @@ class Vmap(GenerativeFunction):
 
     def assess(self, sample, args, batch_shape=None):
         from .static import run_gfi
+        if batch_shape is None:
+            batch_shape = _plate_batch(sample, lambda: self._plate_size(args, self._axes(args)))
         return run_gfi(self, "assess", None, args, constraint=sample, batch_shape=batch_shape)
+
+
+def _plate_batch(sample, plate_size):
+    """assess has no key to tell particles from plate elements: the choices of a plate carry [*batch, plate, *event],
+    so the batch is what comes BEFORE the first axis of the plate's length (None: let the engine infer it)"""
+    try:
+        n = int(plate_size())
+    except Exception:
+        return None
+    for a in sample.addresses():
+        v = sample[a] if a else sample.get_value()
+        shp = tuple(getattr(v, "shape", ()))
+        if n in shp:
+            return shp[:shp.index(n)]
+    return None
 
 
 def _flat_exprs(tree):
@@ -557,23 +726,24 @@ def _loop_step_constraint(chm: ChoiceMap, t, n, at_step, what="scan of more than
 class Scan(GenerativeFunction):
     """scan.py:140-294: kernel (carry, x) -> (carry, y), repeated `length` times."""
 
+    project = _plate_project
+
     def __init__(self, kernel_gen_fn, length=None):
         self.kernel_gen_fn, self.length = kernel_gen_fn, length
 
     def _length(self, scanned_in):
         if self.length is not None:
             return int(self.length)
-        lens = set()
-
-        def visit(v):
-            if isinstance(v, (tuple, list)) and not (isinstance(v, list) and v and not isinstance(v[0], (tuple, list, np.ndarray))):
-                for x in v:
-                    visit(x)
-            else:
-                n = _axis_len(v)
-                if n is not None:
-                    lens.add(n)
-        visit(scanned_in)
+        pairs = []
+        _tree_leaves_with_axes(scanned_in, 0, pairs, "scan")
+        lens = []
+        for leaf, _ in pairs:
+            shp = getattr(leaf, "shape", None)
+            n = _axis_len(leaf) if shp is None else (shp[0] if len(shp) else None)
+            if n is not None and n not in lens:
+                lens.append(int(n))
+        if len(lens) > 1:
+            raise ValueError("scan got values with different leading axis sizes: " + ", ".join(str(n) for n in lens) + ".")
         if len(lens) != 1:
             raise ValueError("scan: pass n= or scanned inputs with one common leading length")
         return lens.pop()
@@ -586,7 +756,14 @@ class Scan(GenerativeFunction):
             raise TypeError("scan: arguments are (carry, scanned_in)")
         carry, scanned_in = args
         n = self._length(scanned_in)
-        if n > SCAN_UNROLL_MAX:
+        if n == 0:                 # GEN-333: a zero-length scan has no choices; the carry passes through
+            out = _CallRec(self)
+            out.retval = (carry, None)
+            out.plate_score = 0.0
+            if mode in ("simulate", "assess"):
+                return out, out.retval, None, 0.0
+            return out, out.retval, 0.0, None
+        if n > getattr(self, "unroll_max", SCAN_UNROLL_MAX):
             return self._trace_loop(ctx, mode, key, carry, scanned_in, constraint, n, req_leaves, addr)
         g = ctx.tr.graph
         keep = ctx.store_sites
@@ -792,7 +969,7 @@ class Scan(GenerativeFunction):
         carry, scanned_in = args
         n = self._length(scanned_in)
         inner_prev = prev["vmap"]
-        if n > SCAN_UNROLL_MAX:
+        if n > getattr(self, "unroll_max", SCAN_UNROLL_MAX):
             return self._trace_edit_loop(ctx, sub_mode, key, carry, scanned_in, constraint, inner_prev, req, kind, n,
                                          req_leaves, addr)
         g = ctx.tr.graph
@@ -1051,6 +1228,8 @@ class Scan(GenerativeFunction):
 
     def assess(self, sample, args, batch_shape=None):
         from .static import run_gfi
+        if batch_shape is None and len(args) == 2:
+            batch_shape = _plate_batch(sample, lambda: self._length(args[1]))
         return run_gfi(self, "assess", None, args, constraint=sample, batch_shape=batch_shape)
 
 
@@ -1063,11 +1242,7 @@ def scan(*, n=None):
 def _tree_take(v, t):
     if v is None:
         return None
-    if isinstance(v, tuple):
-        return tuple(_tree_take(x, t) for x in v)
-    if isinstance(v, dict):
-        return {k: _tree_take(x, t) for k, x in v.items()}
-    return _take(v, t)
+    return _tree_take_axes(v, 0, lambda x: _take(x, t))
 
 
 def _leaves(rec):
@@ -1122,4 +1297,129 @@ class _Repeat(Vmap):
 def repeat(*, n: int):
     def decorator(gen_fn):
         return _Repeat(gen_fn, n)
+    return decorator
+
+
+# ---------------------------------------------------------------------------
+# scan sugar (scan.py:762-1150): iterate / iterate_final / accumulate / reduce / masked_iterate(_final)
+#
+# The reference builds these from `dimap` + `scan`; here each is a Scan over a thin kernel adapter plus an
+# argument / return-value adapter around the Scan — the traced choices, their addresses ([t, ...]), the chained
+# keys and every edit are the underlying Scan's.
+# ---------------------------------------------------------------------------
+class _KernelAdapter(GenerativeFunction):
+    """kernel(carry, x) built from a user function: `call(carry, x)` gives the user function's arguments,
+    `ret(user retval)` the (carry, output) pair."""
+
+    def __init__(self, gen_fn, call, ret):
+        self.gen_fn, self._call, self._ret = gen_fn, call, ret
+
+    def trace_call(self, ctx, mode, key, args, constraint, prev, req, req_leaves, addr):
+        from .static import call_gen_fn
+        carry, x = args
+        rec, retval, w, s_ = call_gen_fn(ctx, mode, self.gen_fn, key, self._call(carry, x), constraint, prev, req,
+                                         req_leaves, addr)
+        return rec, self._ret(retval), w, s_
+
+
+class _ScanAdapter(GenerativeFunction):
+    """`pre(*args)` -> the Scan's (carry, xs); `post(args, (carry, ys))` -> the return value.  Traces, choices and
+    edits are the Scan's own (this object is the trace's generative function, so an edit re-applies `pre`)."""
+
+    project = _plate_project
+
+    def __init__(self, scan_gf, pre, post, name):
+        self.scan_gf, self._pre, self._post, self.name = scan_gf, pre, post, name
+
+    @property
+    def gen_fn(self):
+        return self.scan_gf.kernel_gen_fn
+
+    def trace_call(self, ctx, mode, key, args, constraint, prev, req, req_leaves, addr):
+        rec, retval, w, s_ = self.scan_gf.trace_call(ctx, mode, key, self._pre(*args), constraint, prev, req, req_leaves,
+                                                     addr)
+        out = self._post(args, retval)
+        if hasattr(rec, "sites"):
+            rec.gen_fn = self
+            rec.retval = out
+        return rec, out, w, s_
+
+    def simulate(self, key, args):
+        from .static import run_gfi
+        return run_gfi(self, "simulate", key, args)
+
+    def generate(self, key, constraint, args):
+        from .static import run_gfi
+        return run_gfi(self, "generate", key, args, constraint=constraint)
+
+    def assess(self, sample, args, batch_shape=None):
+        from .static import run_gfi
+        return run_gfi(self, "assess", None, args, constraint=sample, batch_shape=batch_shape)
+
+    def edit(self, key, trace, edit_request, argdiffs):
+        from .static import run_edit
+        return run_edit(self, key, trace, edit_request, argdiffs)
+
+    def __repr__(self):
+        return f"genjax.{self.name}({self.scan_gf.kernel_gen_fn.gen_fn!r})"
+
+
+SUGAR_UNROLL_MAX = 64       # iterate / accumulate return every intermediate value WITH the initial one in front: the
+                            # stacked outputs must be values of the program (an unrolled scan), not a loop's memory rows
+
+
+def _prepend(init, ys):
+    """[init, ys[0], ys[1], ...] leaf by leaf (scan.py:762-788 `prepend_initial_acc`)."""
+    from .engine import StepOutput, Sym
+    init = init.value if isinstance(init, Sym) else init
+    if isinstance(init, (tuple, list)):
+        return type(init)(_prepend(a, b) for a, b in zip(init, ys))
+    if isinstance(init, dict):
+        return {k: _prepend(init[k], ys[k]) for k in init}
+    if isinstance(ys, StepOutput):
+        raise NotImplementedError(f"iterate / accumulate over more than {SUGAR_UNROLL_MAX} steps (the stacked values of a "
+                                  "counted loop live in memory only); use iterate_final / reduce, or a plain scan")
+    head = np.asarray(init, dtype=object) if not (isinstance(init, np.ndarray) and init.dtype == object) else init
+    ys = np.asarray(ys, dtype=object) if not (isinstance(ys, np.ndarray) and ys.dtype == object) else ys
+    return np.concatenate([head[None], ys.reshape((ys.shape[0],) + head.shape)], axis=0)
+
+
+def _sugar_scan(kernel, n, every):
+    sc = Scan(kernel, n)
+    if every:
+        sc.unroll_max = SUGAR_UNROLL_MAX
+    return sc
+
+
+def iterate(*, n: int):
+    """f: a -> a  =>  a -> [a, f(a), f(f(a)), ...] (n + 1 values; scan.py:916-977)"""
+    def decorator(f):
+        k = _KernelAdapter(f, lambda carry, _x: (carry,), lambda r: (r, r))
+        return _ScanAdapter(_sugar_scan(k, n, True), lambda init: (init, None), lambda args, ret: _prepend(args[0], ret[1]),
+                            "iterate")
+    return decorator
+
+
+def iterate_final(*, n: int):
+    """f: a -> a  =>  a -> f^n(a) (scan.py:980-1047)"""
+    def decorator(f):
+        k = _KernelAdapter(f, lambda carry, _x: (carry,), lambda r: (r, None))
+        return _ScanAdapter(_sugar_scan(k, n, False), lambda init: (init, None), lambda args, ret: ret[0], "iterate_final")
+    return decorator
+
+
+def accumulate():
+    """f: (c, a) -> c  =>  (c, [a]) -> [c0, c1, ..., cN] (scan.py:791-851)"""
+    def decorator(f):
+        k = _KernelAdapter(f, lambda carry, x: (carry, x), lambda r: (r, r))
+        return _ScanAdapter(_sugar_scan(k, None, True), lambda init, xs: (init, xs),
+                            lambda args, ret: _prepend(args[0], ret[1]), "accumulate")
+    return decorator
+
+
+def reduce():
+    """f: (c, a) -> c  =>  (c, [a]) -> cN (scan.py:854-913)"""
+    def decorator(f):
+        k = _KernelAdapter(f, lambda carry, x: (carry, x), lambda r: (r, None))
+        return _ScanAdapter(_sugar_scan(k, None, False), lambda init, xs: (init, xs), lambda args, ret: ret[0], "reduce")
     return decorator

@@ -53,6 +53,9 @@ def _norm(addr) -> tuple:
     ia = _index_array(addr)
     if ia is not None:
         return (ia,)
+    shape, dt = getattr(addr, "shape", None), getattr(addr, "dtype", None)
+    if shape is not None and tuple(shape) == () and dt is not None and "int" in str(dt):
+        return (int(addr),)    # `C[jnp.array(0), ...]`: a concrete scalar index is the integer address
     if addr is Ellipsis:
         return ()              # `Selection.at[..., "y"]`: any plate index — plate values carry the axis themselves
     if isinstance(addr, slice):
@@ -203,11 +206,18 @@ _NOVALUE = object()
 class ChoiceMap:
     """Immutable trie: an optional value at this node plus named children."""
 
-    __slots__ = ("_value", "_children")
+    __slots__ = ("_value", "_children", "_plate")
 
-    def __init__(self, value=_NOVALUE, children=None):
+    def __init__(self, value=_NOVALUE, children=None, plate=None):
         self._value = value
         self._children = children or {}
+        # the choices of a plate / scan trace: every value below carries the plate axis at position `plate` (after the
+        # particle axes), and an INTEGER address component here reads element j of all of them — the reference's
+        # `chm[j, "x"]` on a vmapped trace (choice_map.py:1453-1531 `Indexed.get_inner_map`)
+        self._plate = plate
+
+    def with_plate(self, axis: int) -> "ChoiceMap":
+        return ChoiceMap(self._value, self._children, int(axis))
 
     # -- builders ---------------------------------------------------------------
     @staticmethod
@@ -258,7 +268,7 @@ class ChoiceMap:
                 kids[j] = kids.get(j, _EMPTY).set(rest, _take_indexed(v, k, len(head.idx)))
             return ChoiceMap(self._value, kids)
         kids[head] = kids.get(head, _EMPTY).set(rest, v)
-        return ChoiceMap(self._value, kids)
+        return ChoiceMap(self._value, kids, self._plate)
 
     def extend(self, *addr) -> "ChoiceMap":
         out = self
@@ -286,8 +296,29 @@ class ChoiceMap:
     def get_submap(self, *addr) -> "ChoiceMap":
         cm = self
         for a in _norm(addr):
+            if isinstance(a, int) and not isinstance(a, bool) and a not in cm._children and cm._plate is not None:
+                cm = cm._take_plate(a)
+                continue
             cm = cm._children.get(a, _EMPTY)
         return cm
+
+    def _take_plate(self, j: int) -> "ChoiceMap":
+        """element j along this node's plate axis, for every value below; deeper plates move up one axis"""
+        ax = self._plate
+
+        def take(v):
+            shape = getattr(v, "shape", None)
+            if shape is None or len(shape) <= ax:
+                return v
+            if not -shape[ax] <= j < shape[ax]:
+                raise IndexError(f"plate index {j} out of range for an axis of length {shape[ax]}")
+            return v.select(ax, j) if hasattr(v, "select") else v.take(j, axis=ax)
+
+        def go(cm, top):
+            plate = None if top else (cm._plate - 1 if (cm._plate is not None and cm._plate > ax) else cm._plate)
+            return ChoiceMap(cm._value if cm._value is _NOVALUE else take(cm._value),
+                             {a: go(c, False) for a, c in cm._children.items()}, plate)
+        return go(self, True)
 
     def __call__(self, *addr) -> "ChoiceMap":
         return self.get_submap(*addr)
@@ -340,11 +371,11 @@ class ChoiceMap:
             f = c.filter(selection.get_subselection(a))
             if not f.static_is_empty():
                 kids[a] = f
-        return ChoiceMap(value, kids)
+        return ChoiceMap(value, kids, self._plate)
 
     def map_values(self, fn: Callable[[Any], Any]) -> "ChoiceMap":
         return ChoiceMap(self._value if self._value is _NOVALUE else fn(self._value),
-                         {a: c.map_values(fn) for a, c in self._children.items()})
+                         {a: c.map_values(fn) for a, c in self._children.items()}, self._plate)
 
     def mask(self, flag) -> "ChoiceMap":
         from .mask import Mask

@@ -260,6 +260,22 @@ class GenerativeFunction:
         from ..combinators import Scan
         return Scan(self, n)
 
+    def iterate(self, *, n: int):
+        from ..combinators import iterate
+        return iterate(n=n)(self)
+
+    def iterate_final(self, *, n: int):
+        from ..combinators import iterate_final
+        return iterate_final(n=n)(self)
+
+    def accumulate(self):
+        from ..combinators import accumulate
+        return accumulate()(self)
+
+    def reduce(self):
+        from ..combinators import reduce
+        return reduce()(self)
+
 
 def _args_equal(a, b) -> bool:
     """structural equality of argument tuples / dicts that may hold tensors"""

@@ -421,6 +421,10 @@ class Tracing:
         from .tracer import Expr as _E
         if isinstance(value, Sym):
             value = value.value
+        if isinstance(value, np.ndarray) and value.dtype == object:      # a nested plate's (or a vector site's) elements
+            for v in value.reshape(-1):
+                self.prestore(v)
+            return
         if isinstance(value, _E) and value.node.op != "CONST" and id(value.node) not in self.prestored:
             self.prestored[id(value.node)] = self.graph.store(value.node)
 

@@ -533,3 +533,46 @@ def zeros_like(x):
 
 def ones_like(x):
     return full(np.shape(x), 1.0) if is_symbolic(x) else (torch.ones_like(x) if _is_torch(x) else np.ones_like(x))
+
+
+def eye(n, m=None, dtype=np.float32):
+    return TableArray(np.eye(n, m, dtype=dtype))
+
+
+def broadcast_to(x, shape):
+    if is_symbolic(x):
+        return np.broadcast_to(np.asarray(x, dtype=object), shape)
+    if _is_torch(x):
+        return torch.broadcast_to(x, tuple(shape))
+    return TableArray(np.ascontiguousarray(np.broadcast_to(np.asarray(x), shape)))
+
+
+def repeat(x, repeats, axis=None):
+    if is_symbolic(x):
+        return np.repeat(np.asarray(x, dtype=object), repeats, axis=axis)
+    if _is_torch(x):
+        return torch.repeat_interleave(x, repeats, dim=axis)
+    a = np.repeat(np.asarray(x), repeats, axis=axis)
+    if a.dtype == np.float64:
+        a = a.astype(np.float32)
+    elif a.dtype == np.int64:
+        a = a.astype(np.int32)
+    return TableArray(a)
+
+
+def matmul(a, b):
+    return a @ b
+
+
+def transpose(x, axes=None):
+    return np.transpose(np.asarray(x, dtype=object), axes) if is_symbolic(x) else (
+        x.permute(*axes) if (_is_torch(x) and axes is not None) else (x.t() if _is_torch(x) and x.ndim == 2 else np.transpose(x, axes)))
+
+
+def array_equal(a, b):
+    return bool(np.array_equal(np.asarray(a.detach().cpu() if _is_torch(a) else a), np.asarray(b.detach().cpu() if _is_torch(b) else b)))
+
+
+def allclose(a, b, rtol=1e-5, atol=1e-8):
+    return bool(np.allclose(np.asarray(a.detach().cpu() if _is_torch(a) else a), np.asarray(b.detach().cpu() if _is_torch(b) else b),
+                            rtol=rtol, atol=atol))

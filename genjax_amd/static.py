@@ -63,7 +63,12 @@ class DistributionTrace(Trace):
     def get_retval(self): return materialize(self.value)
     def get_gen_fn(self): return self.gen_fn
     def get_score(self): return materialize(self.score)
-    def get_choices(self): return ChoiceMap.choice(materialize(self.value))
+
+    def get_choices(self):
+        v = materialize(self.value)
+        cm = ChoiceMap.choice(v)
+        nb = len(self.batch_shape)
+        return cm.with_plate(nb) if len(getattr(v, "shape", ())) > nb else cm      # a vector-valued site: chm[j]
 
     @property
     def batch_shape(self):
@@ -82,8 +87,12 @@ class StaticTrace(Trace):
 
     def get_choices(self) -> ChoiceMap:
         cm = ChoiceMap.empty()
+        nb = len(self.batch_shape)
         for addr, st in self.subtraces.items():
-            cm = cm.set(addr, st.get_choices())
+            sub = st.get_choices()
+            if isinstance(st, DistributionTrace) and sub.has_value() and len(getattr(sub.get_value(), "shape", ())) > nb:
+                sub = sub.with_plate(nb)      # a vector-valued site (a bare distribution under vmap): chm[addr, j]
+            cm = cm.set(addr, sub)
         return cm
 
     def get_score(self):
@@ -103,6 +112,10 @@ class StaticTrace(Trace):
         return ()
 
     def get_subtrace(self, *addr):
+        if len(addr) == 1 and isinstance(addr[0], tuple):
+            import warnings
+            warnings.warn("get_subtrace(('a', 'b')) is deprecated: pass the components, get_subtrace('a', 'b') "
+                          "(generative_function.py `get_subtrace`)", DeprecationWarning, stacklevel=2)
         addr = _norm(addr)
         tr = self
         i = 0
@@ -140,7 +153,11 @@ class VmapTrace(Trace):
     def get_retval(self): return _tree_materialize(self.retval)
     def get_gen_fn(self): return self.gen_fn
     def get_score(self): return materialize(self.score)
-    def get_choices(self): return self.inner.get_choices()
+
+    def get_choices(self):
+        """the inner choices; an integer address component reads one element of the plate (`chm[j, "x"]`)"""
+        return self.inner.get_choices().with_plate(len(self.batch_shape))
+
     def get_subtrace(self, *addr): return self.inner.get_subtrace(*addr)
 
     @property
@@ -706,7 +723,7 @@ def _rec_score(rec):
     for r in rec.sites.values():
         s = _rec_score(r)
         acc = s if acc is None else acc + s
-    return acc
+    return acc if acc is not None else 0.0          # a callee without sites scores 0 (static.py:102-105: an empty sum)
 
 
 def call_gen_fn(ctx, mode, gen_fn, key, args, constraint, prev, req, req_leaves, addr):

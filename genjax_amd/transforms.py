@@ -35,8 +35,12 @@ def _map_leaves(v, fn):
     return v
 
 
-def vmap(f, in_axes=0, out_axes=0):
-    """`jax.vmap(f, in_axes, out_axes)` for functions built from this package's operations.  Those are batch
+def vmap(f=None, in_axes=0, out_axes=0):
+    """Two spellings share this name.  `genjax.vmap(in_axes=...)` with no function (or a generative function) is the
+    reference's COMBINATOR decorator (combinators/vmap.py `vmap`): `@genjax.vmap(in_axes=(0,))` above `@genjax.gen`.
+    `vmap(f, in_axes, out_axes)` with an ordinary function stands in for `jax.vmap` in inference scripts:
+
+    `jax.vmap(f, in_axes, out_axes)` for functions built from this package's operations.  Those are batch
     polymorphic already — a batched `Key` and tensors whose LEADING axis matches it run as one fused launch — so
     mapping = arranging the arguments that way:
       * an argument mapped along axis k != 0 has that axis moved to the front (every tensor leaf of a tuple / dict /
@@ -45,6 +49,13 @@ def vmap(f, in_axes=0, out_axes=0):
         (engine.Broadcast), so a vector whose length happens to equal the batch is not mistaken for per-instance data;
       * mapped axis sizes are checked against each other;
       * out_axes != 0 moves the leading axis of every tensor result there."""
+    from .core.generative import GenerativeFunction
+    if f is None:
+        from .combinators import vmap as _combinator
+        return _combinator(in_axes=in_axes)
+    if isinstance(f, GenerativeFunction):
+        from .combinators import Vmap
+        return Vmap(f, in_axes)
     from .engine import Broadcast
 
     def wrapped(*args):

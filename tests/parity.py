@@ -1339,7 +1339,7 @@ def check_scan_carry_forms(n=130, seed=21, Ts=(8, 17, 40)):
             assert np.array_equal(r0.cpu().numpy(), or0) and np.array_equal(r1.cpu().numpy(), or1)
 
 
-def check_plates_long(n=130, P=40, seed=8):
+def check_plates_long(n=130, P=40, seed=8, light=False):
     """A LARGE plate (more than 16 elements) runs as a counted loop in the site program (ref vmap.py:180-218: `jax.vmap`
     over any n): the P-schools model written with `Vmap` — simulate / importance with a per-element
     constraint (`C["schools", :, "y"]`) / assess, the plate used directly, `Update` of every element, `IndexRequest`
@@ -1381,6 +1381,8 @@ def check_plates_long(n=130, P=40, seed=8):
     w_ref = (O.normal.assess(O.C.choice(np.full(n, 0.5, np.float32)), (tj[:, 3], sig[3]), (n,))[0]
              + O.normal.assess(O.C.choice(np.full(n, -1.0, np.float32)), (tj[:, P - 2], sig[P - 2]), (n,))[0])
     assert np.array_equal(wj.cpu().numpy(), w_ref)
+    if light:            # (full-size plates: the oracle's per-element loops below would take minutes)
+        return
     # the plate used directly; edits of it as a loop
     v, ov = school.vmap(in_axes=(None, None, 0)), O.Vmap(oschool, in_axes=(None, None, 0))
     args = (1.0, 2.0, jnp.array(sig))

@@ -789,7 +789,8 @@ def test_large_plates_as_a_counted_loop(gpu):
     simulate / importance / assess / Update / IndexRequest, bit-exact vs the oracle."""
     parity.check_plates_long(n=300, P=40)
     parity.check_plates_long(n=270_000, P=24, seed=3)
-    parity.check_plates_long(n=10_000, P=4096, seed=5)
+    parity.check_plates_long(n=10_000, P=4096, seed=5, light=True)       # simulate / importance / assess / single-element constraints
+    parity.check_plates_long(n=300, P=4096, seed=6)
 
 
 def test_scan_carries_that_forward_each_other(gpu):

@@ -6,14 +6,19 @@ tests/test_host_logic.py translates the reference's own behavioural tests
   tests/inference/test_smc.py:50,57,87                      (log-ML tolerances 1e-1 / 1e-3 / 1e-1)
   tests/inference/test_requests.py:38-166                   (update / regenerate / rejuvenate identities, MH convergence)
   README.md:88-123                                          (BASELINE config 1: beta-bernoulli, ImportanceK k = 50 x 50 trials)
-and runs them against the CPU mirror of the C-ABI.  Here the SAME test bodies run through libgenmi_hip.so on an
-MI355X: the classes are subclassed unchanged, only the backend fixture differs.
+and runs them against the CPU mirror of the C-ABI; tests/test_ref_static.py and tests/test_ref_combinators.py hold the
+rest of the reference's in-scope behavioural suite (test_static_gen_fn.py, test_scan / test_vmap / test_repeat_combinator.py,
+core/generative/test_core.py).  Here the SAME test bodies run through libgenmi_hip.so on an MI355X: the classes are
+subclassed unchanged, only the backend fixture differs (the module-level `usefixtures("hostsim")` of the CPU files
+does not apply to classes defined here).
 """
 import pytest
 import torch
 
 from tests import parity
 from tests import test_host_logic as H
+from tests import test_ref_combinators as RC
+from tests import test_ref_static as RS
 
 pytestmark = pytest.mark.gpu
 
@@ -40,6 +45,33 @@ class TestSMCOnDevice(H.TestSMC):
 
 class TestRequestsOnDevice(H.TestRequests):
     pass
+
+
+# ---- tests/test_ref_static.py (test_static_gen_fn.py, 41 reference tests) on the HIP library ----
+class TestRefStaticMetadataOnDevice(RS.TestMetadata): pass
+class TestRefStaticMiscOnDevice(RS.TestMisc): pass
+class TestRefStaticSimulateOnDevice(RS.TestSimulate): pass
+class TestRefStaticAssessOnDevice(RS.TestAssess): pass
+class TestRefStaticCustomPytreeOnDevice(RS.TestCustomPytree): pass
+class TestRefStaticImportanceOnDevice(RS.TestImportance): pass
+class TestRefStaticUpdateOnDevice(RS.TestUpdate): pass
+class TestRefStaticAddressChecksOnDevice(RS.TestAddressChecks): pass
+class TestRefStaticClosuresOnDevice(RS.TestForwardRefAndClosures): pass
+class TestRefStaticEditRequestOnDevice(RS.TestStaticEditRequest): pass
+class TestRefStaticInlineOnDevice(RS.TestInline): pass
+class TestRefStaticMethodsOnDevice(RS.TestMethodsAndPartialApply): pass
+
+
+# ---- tests/test_ref_combinators.py (test_scan / test_vmap / test_repeat_combinator.py, test_core.py) ----
+class TestRefIterateSimpleNormalOnDevice(RC.TestIterateSimpleNormal): pass
+class TestRefIterateOnDevice(RC.TestIterate): pass
+class TestRefAccumulateReduceOnDevice(RC.TestAccumulateReduce): pass
+class TestRefScanBehaviourOnDevice(RC.TestScanBehaviour): pass
+class TestRefScanEditsOnDevice(RC.TestScanRegenerateAndIndexRequest): pass
+class TestRefVmapOnDevice(RC.TestVmap): pass
+class TestRefVmapIndexRequestOnDevice(RC.TestVmapIndexRequest): pass
+class TestRefRepeatOnDevice(RC.TestRepeat): pass
+class TestRefCoreOnDevice(RC.TestCore): pass
 
 
 def test_nested_marginal_and_change_target_on_device():

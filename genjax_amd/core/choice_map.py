@@ -61,8 +61,19 @@ def _norm(addr) -> tuple:
     if isinstance(addr, slice):
         if addr == slice(None):
             return ()          # chm["plate", :, "x"]: plate values carry the plate axis themselves
-        raise NotImplementedError("partial slices in addresses (Indexed choice maps): SURVEY.md §8(f) item 2")
+        return (_Slice(addr),)  # a partial slice: allowed when READING a plate (chm[0:4, "x"]), refused by set()
     return (addr,)
+
+
+class _Slice:
+    """a partial slice as an address component (hashable)"""
+    __slots__ = ("sl",)
+
+    def __init__(self, sl):
+        self.sl = sl
+
+    def __repr__(self):
+        return f"{self.sl.start}:{self.sl.stop}" + (f":{self.sl.step}" if self.sl.step is not None else "")
 
 
 class ChoiceMapNoValueAtAddress(Exception):
@@ -72,34 +83,86 @@ class ChoiceMapNoValueAtAddress(Exception):
 # ---------------------------------------------------------------------------
 # Selections
 # ---------------------------------------------------------------------------
+_WILD = Ellipsis       # S[..., "y"]: any first component
+
+
+def _sel_norm(addr) -> tuple:
+    """address components of a SELECTION query / builder: like _norm, but a leading `...` is kept as the wildcard
+    (choice_map.py:261-347); anywhere else it is refused"""
+    if not isinstance(addr, tuple):
+        addr = (addr,)
+    out = ()
+    for k, a in enumerate(addr):
+        if a is Ellipsis:
+            if k != 0:
+                raise TypeError("`...` may only be the FIRST component of a selection address")
+            out += (_WILD,)
+        elif isinstance(a, tuple):
+            out += _sel_norm(a)
+        else:
+            out += _norm(a)
+    return out
+
+
 class Selection:
     """A set of addresses.  `sel(addr)` = sub-selection below addr,
-    `sel[addr]` / `addr in sel` = membership, `sel.check()` = membership of ()."""
+    `sel[addr]` / `addr in sel` = membership, `sel.check()` = membership of ().
+    Structural equality; the constructors simplify (`~~s == s`, `all & s == s`, `none | s == s`, `s | s == s`, ...:
+    choice_map.py:196-259)."""
 
     # -- constructors -----------------------------------------------------
     @staticmethod
     def all() -> "Selection":
-        return _All()
+        return _ALL
 
     @staticmethod
     def none() -> "Selection":
-        return _None()
+        return _NONE
 
     @staticmethod
     def leaf() -> "Selection":
-        return _Leaf()
+        return _LEAF
 
     # -- algebra ------------------------------------------------------------
-    def __or__(self, other): return _Or(self, other)
-    def __and__(self, other): return _And(self, other)
-    def __invert__(self): return _Complement(self)
+    def __or__(self, other):
+        if isinstance(self, _All) or isinstance(other, _All):
+            return _ALL
+        if isinstance(self, _None):
+            return other
+        if isinstance(other, _None) or self == other:
+            return self
+        return _Or(self, other)
+
+    def __and__(self, other):
+        if isinstance(self, _None) or isinstance(other, _None):
+            return _NONE
+        if isinstance(self, _All):
+            return other
+        if isinstance(other, _All) or self == other:
+            return self
+        return _And(self, other)
+
+    def __invert__(self):
+        if isinstance(self, _All):
+            return _NONE
+        if isinstance(self, _None):
+            return _ALL
+        if isinstance(self, _Complement):
+            return self.s
+        return _Complement(self)
+
     def complement(self): return ~self
 
     def extend(self, *addr) -> "Selection":
+        if isinstance(self, _None):
+            return self                      # nothing to extend
         out = self
-        for a in reversed(_norm(addr)):
+        for a in reversed(_sel_norm(addr)):
             out = _Static(a, out)
         return out
+
+    def filter(self, chm: "ChoiceMap") -> "ChoiceMap":
+        return chm.filter(self)
 
     # -- queries --------------------------------------------------------------
     def check(self) -> bool:
@@ -108,9 +171,11 @@ class Selection:
     def get_subselection(self, comp) -> "Selection":
         raise NotImplementedError
 
-    def __call__(self, addr) -> "Selection":
+    def __call__(self, *addr) -> "Selection":
         s = self
-        for a in _norm(addr):
+        for a in _sel_norm(addr):
+            if a is _WILD:
+                raise TypeError("`...` is for building selections (S[..., 'y']), not for querying them")
             s = s.get_subselection(a)
         return s
 
@@ -119,6 +184,16 @@ class Selection:
 
     def __contains__(self, addr) -> bool:
         return self[addr]
+
+    # -- structure ---------------------------------------------------------------
+    def _key(self):
+        return (type(self).__name__,)
+
+    def __eq__(self, other):
+        return isinstance(other, Selection) and self._key() == other._key()
+
+    def __hash__(self):
+        return hash(self._key())
 
 
 class _All(Selection):
@@ -136,7 +211,11 @@ class _None(Selection):
 class _Leaf(Selection):
     """Selects exactly () (LeafSel, choice_map.py:405)."""
     def check(self): return True
-    def get_subselection(self, comp): return _None()
+    def get_subselection(self, comp): return _NONE
+    def __repr__(self): return "Selection.leaf()"
+
+
+_ALL, _NONE, _LEAF = _All(), _None(), _Leaf()
 
 
 class _Static(Selection):
@@ -146,51 +225,81 @@ class _Static(Selection):
     def check(self): return False
 
     def get_subselection(self, comp):
-        return self.sub if comp == self.comp else _None()
+        return self.sub if (self.comp is _WILD or comp == self.comp) else _NONE
 
+    def _key(self): return ("static", "..." if self.comp is _WILD else self.comp, self.sub._key())
     def __repr__(self): return f"S[{self.comp!r}]({self.sub!r})"
 
 
 class _Or(Selection):
     def __init__(self, a, b): self.a, self.b = a, b
     def check(self): return self.a.check() or self.b.check()
-    def get_subselection(self, comp): return _Or(self.a.get_subselection(comp), self.b.get_subselection(comp))
+    def get_subselection(self, comp): return self.a.get_subselection(comp) | self.b.get_subselection(comp)
+    def _key(self): return ("or", self.a._key(), self.b._key())
 
 
 class _And(Selection):
     def __init__(self, a, b): self.a, self.b = a, b
     def check(self): return self.a.check() and self.b.check()
-    def get_subselection(self, comp): return _And(self.a.get_subselection(comp), self.b.get_subselection(comp))
+    def get_subselection(self, comp): return self.a.get_subselection(comp) & self.b.get_subselection(comp)
+    def _key(self): return ("and", self.a._key(), self.b._key())
 
 
 class _Complement(Selection):
     def __init__(self, s): self.s = s
     def check(self): return not self.s.check()
-    def get_subselection(self, comp): return _Complement(self.s.get_subselection(comp))
-    def __invert__(self): return self.s
+    def get_subselection(self, comp): return ~self.s.get_subselection(comp)
+    def _key(self): return ("not", self.s._key())
 
 
 class _Chm(Selection):
     """Addresses that hold a value in a choice map (ChmSel, choice_map.py:627-663)."""
     def __init__(self, chm): self.chm = chm
     def check(self): return self.chm.has_value()
-    def get_subselection(self, comp): return _Chm(self.chm.get_submap(comp))
+
+    def get_subselection(self, comp):
+        sub = self.chm.get_submap(comp)
+        return _Chm(sub) if not sub.static_is_empty() else _NONE
+
+    def _key(self): return ("chm", tuple(self.chm.addresses()))
+
+
+class _SelProp:
+    """`S.all` / `S.none` / `S.leaf` read as properties (`S.all["x"]`) AND as calls (`S.all()`): the reference's tests
+    use both spellings (SelectionBuilder properties; `from genjax import Selection as S`)."""
+
+    def __init__(self, sel):
+        self._sel = sel
+
+    def __get__(self, obj, owner=None):
+        return _CallableSel(self._sel)
+
+
+class _CallableSel:
+    def __init__(self, sel): self._sel = sel
+    def __call__(self, *addr): return self._sel if not addr else self._sel(*addr)
+    def __getitem__(self, addr): return self._sel[addr]
+    def __eq__(self, other): return self._sel == (other._sel if isinstance(other, _CallableSel) else other)
+    def __hash__(self): return hash(self._sel)
+    def __getattr__(self, name): return getattr(self._sel, name)
+    def __or__(self, o): return self._sel | o
+    def __and__(self, o): return self._sel & o
+    def __invert__(self): return ~self._sel
+    def __contains__(self, addr): return addr in self._sel
+    def __repr__(self): return repr(self._sel)
 
 
 class _SelectionBuilder:
-    """`S["x"]`, `S["x", "y"]`; a selected address selects everything below it."""
+    """`S["x"]`, `S["x", "y"]`, `S[..., "y"]`, `S[()]`; a selected address selects everything below it."""
+    all = _SelProp(_ALL)
+    none = _SelProp(_NONE)
+    leaf = _SelProp(_LEAF)
 
     def __getitem__(self, addr) -> Selection:
-        return Selection.all().extend(*_norm(addr))
-
-    # `from genjax import Selection as S` is as common in the reference's tests as SelectionBuilder: S.all() / S.none()
-    @staticmethod
-    def all() -> Selection:
-        return Selection.all()
-
-    @staticmethod
-    def none() -> Selection:
-        return Selection.none()
+        comps = _sel_norm(addr)
+        if not comps:
+            return _LEAF                      # S[()]
+        return _ALL.extend(*comps)
 
 
 SelectionBuilder = _SelectionBuilder()
@@ -226,6 +335,14 @@ class ChoiceMap:
 
     @staticmethod
     def choice(v) -> "ChoiceMap":
+        """a value-only map (choice_map.py:1396-1450).  A Mask whose flag is a concrete bool resolves now (False: the
+        empty map; True: the bare value); an array with no elements is the empty map."""
+        from .mask import Mask
+        if isinstance(v, Mask) and isinstance(v.flag, bool):
+            return ChoiceMap(value=v.value) if v.flag else _EMPTY
+        shape = getattr(v, "shape", None)
+        if shape is not None and len(shape) >= 1 and 0 in tuple(shape):
+            return _EMPTY
         return ChoiceMap(value=v)
 
     value = choice
@@ -236,10 +353,11 @@ class ChoiceMap:
         return _EMPTY
 
     @staticmethod
-    def d(mapping: dict) -> "ChoiceMap":
+    def d(mapping) -> "ChoiceMap":
+        """from a dict (or a list of (address, value) pairs); dict values nest (choice_map.py:800-845)"""
         out = _EMPTY
-        for a, val in mapping.items():
-            out = out.set(a, val)
+        for a, val in (mapping.items() if isinstance(mapping, dict) else mapping):
+            out = out.set(a if isinstance(a, tuple) else (a,), val)
         return out
 
     from_mapping = d
@@ -255,10 +373,23 @@ class ChoiceMap:
     def set(self, addr, v) -> "ChoiceMap":
         """New map with `v` (a value or a ChoiceMap) at addr; existing entries
         elsewhere are kept, the new entry wins at addr."""
+        if isinstance(v, dict):
+            v = ChoiceMap.d(v)
+        raw = addr if isinstance(addr, tuple) else (addr,)
+        for k, a in enumerate(raw):
+            if isinstance(a, slice):
+                if a != slice(None):
+                    raise ValueError("partial slices are not allowed when setting (choice_map.py:699-749); use `:`")
+                # C[prefix, :, rest].set(v): a PLATE — the values below carry the plate axis in front
+                below = _EMPTY.set(tuple(x for x in raw[k + 1:] if not (isinstance(x, slice) and x == slice(None))), v)
+                below = below.with_plate(0) if not below.static_is_empty() else below
+                return self.set(raw[:k], below) if raw[:k] else self.merge_over(below)
         addr = _norm(addr) if not (isinstance(addr, tuple) and not addr) else ()
         if not addr:
             return v if isinstance(v, ChoiceMap) else ChoiceMap(value=v)
         head, rest = addr[0], addr[1:]
+        if isinstance(head, _Slice):
+            raise ValueError("partial slices are not allowed when setting (choice_map.py:699-749); use `:`")
         kids = dict(self._children)
         if isinstance(head, _IndexArray):
             # Indexed (choice_map.py:1453-1531) with a static index array: element idx[k] takes v[k]
@@ -270,10 +401,21 @@ class ChoiceMap:
         kids[head] = kids.get(head, _EMPTY).set(rest, v)
         return ChoiceMap(self._value, kids, self._plate)
 
+    def merge_over(self, new: "ChoiceMap") -> "ChoiceMap":
+        """`new` laid over this map (new entries win), keeping new's plate marker"""
+        out = new.merge(self)
+        return ChoiceMap(out._value, out._children, new._plate if new._plate is not None else self._plate)
+
     def extend(self, *addr) -> "ChoiceMap":
+        if self.static_is_empty():
+            return self
         out = self
-        for a in reversed(_norm(addr)):
-            out = ChoiceMap(children={a: out})
+        for a in reversed(addr):
+            if isinstance(a, slice) and a == slice(None):
+                out = out.with_plate(0)
+                continue
+            for c in reversed(_norm(a)):
+                out = ChoiceMap(children={c: out})
         return out
 
     @property
@@ -296,26 +438,36 @@ class ChoiceMap:
     def get_submap(self, *addr) -> "ChoiceMap":
         cm = self
         for a in _norm(addr):
-            if isinstance(a, int) and not isinstance(a, bool) and a not in cm._children and cm._plate is not None:
-                cm = cm._take_plate(a)
+            if isinstance(a, _Slice):
+                cm = cm._take_plate(a.sl)
+                continue
+            if isinstance(a, int) and not isinstance(a, bool) and a not in cm._children and \
+                    (cm._plate is not None or (cm.has_value() and len(getattr(cm._value, "shape", ())) >= 1)):
+                cm = cm._take_plate(a)          # element a of a plate (or of a value-only array)
                 continue
             cm = cm._children.get(a, _EMPTY)
         return cm
 
     def _take_plate(self, j: int) -> "ChoiceMap":
         """element j along this node's plate axis, for every value below; deeper plates move up one axis"""
-        ax = self._plate
+        ax = self._plate if self._plate is not None else 0
+        is_slice = isinstance(j, slice)
 
         def take(v):
             shape = getattr(v, "shape", None)
             if shape is None or len(shape) <= ax:
                 return v
+            if is_slice:
+                return v[(slice(None),) * ax + (j,)]
             if not -shape[ax] <= j < shape[ax]:
                 raise IndexError(f"plate index {j} out of range for an axis of length {shape[ax]}")
             return v.select(ax, j) if hasattr(v, "select") else v.take(j, axis=ax)
 
         def go(cm, top):
-            plate = None if top else (cm._plate - 1 if (cm._plate is not None and cm._plate > ax) else cm._plate)
+            if is_slice:
+                plate = cm._plate
+            else:
+                plate = None if top else (cm._plate - 1 if (cm._plate is not None and cm._plate > ax) else cm._plate)
             return ChoiceMap(cm._value if cm._value is _NOVALUE else take(cm._value),
                              {a: go(c, False) for a, c in cm._children.items()}, plate)
         return go(self, True)
@@ -329,11 +481,28 @@ class ChoiceMap:
             raise ChoiceMapNoValueAtAddress(addr)
         return sub._value
 
+    @property
+    def attributes(self):
+        return {"value": self.get_value(), "children": dict(self._children)}
+
     def __contains__(self, addr) -> bool:
         return self.get_submap(addr).has_value()
 
     def get_selection(self) -> Selection:
-        return _Chm(self)
+        return _Chm(self) if not self.static_is_empty() else _NONE
+
+    def _without(self, addr: tuple) -> "ChoiceMap":
+        """this map with everything at and below addr removed"""
+        if not addr:
+            return _EMPTY
+        kids = dict(self._children)
+        if addr[0] in kids:
+            sub = kids[addr[0]]._without(addr[1:])
+            if sub.static_is_empty():
+                del kids[addr[0]]
+            else:
+                kids[addr[0]] = sub
+        return ChoiceMap(self._value, kids, self._plate)
 
     def addresses(self, prefix=()) -> list:
         out = [prefix] if self.has_value() else []
@@ -355,14 +524,50 @@ class ChoiceMap:
             return other
         if other.static_is_empty():
             return self
+        if (self.has_value() and other._children) or (other.has_value() and self._children):
+            raise Exception("Choice and non-Choice in Or: a value and a sub-map at one address (choice_map.py:1699-1733)")
         value = self._value if self._value is not _NOVALUE else other._value
         kids = dict(self._children)
         for a, c in other._children.items():
             kids[a] = kids[a].merge(c) if a in kids else c
-        return ChoiceMap(value, kids)
+        return ChoiceMap(value, kids, self._plate if self._plate is not None else other._plate)
 
     def __or__(self, other): return self.merge(other)
     def __xor__(self, other): return self.merge(other)
+
+    def __and__(self, other: "ChoiceMap") -> "ChoiceMap":
+        """the addresses both maps hold, values from the RIGHT operand (choice_map.py `And`)"""
+        value = other._value if (self.has_value() and other.has_value()) else _NOVALUE
+        kids = {}
+        for a, c in self._children.items():
+            if a in other._children:
+                sub = c & other._children[a]
+                if not sub.static_is_empty():
+                    kids[a] = sub
+        return ChoiceMap(value, kids)
+
+    def invalid_subset(self, gen_fn, args):
+        """The part of this map `gen_fn(*args)` never visits, or None (choice_map.py `invalid_subset`): the model is
+        run once (assess-free: simulate with a dummy key) and the addresses of its trace are compared — an index layer
+        over a plate's addresses is optional, a MISSING address is fine, an EXTRA one is reported."""
+        from ..random import key as _key
+        shape = gen_fn.simulate(_key(0), tuple(args)).get_choices()
+
+        def extra(mine: "ChoiceMap", theirs: "ChoiceMap") -> "ChoiceMap":
+            value = mine._value if (mine.has_value() and not theirs.has_value()) else _NOVALUE
+            kids = {}
+            for a, c in mine._children.items():
+                if a in theirs._children:
+                    sub = extra(c, theirs._children[a])
+                elif isinstance(a, int) and theirs._plate is not None:
+                    sub = extra(c, theirs)            # an explicit element of a plate
+                else:
+                    sub = c
+                if not sub.static_is_empty():
+                    kids[a] = sub
+            return ChoiceMap(value, kids, mine._plate)
+        bad = extra(self, shape)
+        return None if bad.static_is_empty() else bad
 
     def filter(self, selection: Selection) -> "ChoiceMap":
         value = self._value if (self._value is not _NOVALUE and selection.check()) else _NOVALUE
@@ -378,7 +583,10 @@ class ChoiceMap:
                          {a: c.map_values(fn) for a, c in self._children.items()}, self._plate)
 
     def mask(self, flag) -> "ChoiceMap":
+        """every value wrapped in Mask(value, flag); a concrete flag resolves now (True: this map; False: empty)"""
         from .mask import Mask
+        if isinstance(flag, bool):
+            return self if flag else _EMPTY
         return self.map_values(lambda v: Mask.build(v, flag))
 
     # -- misc -------------------------------------------------------------------------
@@ -440,16 +648,45 @@ _EMPTY = ChoiceMap()
 
 
 class _AddressIndex:
-    """`chm.at["a", "b"].set(v)` / `C["a"].set(v)` / `.get()`."""
+    """`chm.at["a", "b"].set(v)` / `C["a"].set(v)` / `.update(fn)` / `.v / .d / .kw / .from_mapping` / `.get()`
+    (choice_map.py:70-121, 752-845).  Address components are kept RAW until used: `:` marks a plate when setting."""
 
     def __init__(self, chm, addr=()):
-        self.chm, self.addr = chm, addr
+        self.chm, self.addr = chm, tuple(addr)
 
     def __getitem__(self, addr):
-        return _AddressIndex(self.chm, self.addr + _norm(addr))
+        return _AddressIndex(self.chm, self.addr + (addr if isinstance(addr, tuple) else (addr,)))
 
     def set(self, v) -> ChoiceMap:
-        return self.chm.set(self.addr, v) if self.addr else (v if isinstance(v, ChoiceMap) else ChoiceMap.choice(v))
+        if isinstance(v, dict):
+            v = ChoiceMap.d(v)
+        if not self.addr:
+            return v if isinstance(v, ChoiceMap) else ChoiceMap.choice(v)
+        return self.chm.set(self.addr, v)
+
+    def v(self, val) -> ChoiceMap:
+        """like set, but a ChoiceMap argument is stored AS A VALUE (choice_map.py `.v`: "not advisable")"""
+        if isinstance(val, ChoiceMap):
+            leaf = ChoiceMap(value=val)
+            return self.chm.set(self.addr, leaf) if self.addr else leaf
+        return self.set(val)
+
+    def update(self, fn) -> ChoiceMap:
+        """replace what sits at the address by fn(it): fn gets the VALUE if there is one, else the sub-map"""
+        sub = self.chm.get_submap(self.addr)
+        new = fn(sub.get_value() if sub.has_value() else sub)
+        if isinstance(new, dict):
+            new = ChoiceMap.d(new)
+        cleared = self.chm._without(_norm(self.addr))
+        return cleared.set(self.addr, new) if not (isinstance(new, ChoiceMap) and new.static_is_empty()) else cleared
+
+    def d(self, mapping) -> ChoiceMap:
+        return self.set(ChoiceMap.d(mapping))
+
+    from_mapping = d
+
+    def kw(self, **kwargs) -> ChoiceMap:
+        return self.set(ChoiceMap.d(kwargs))
 
     def get(self):
         return self.chm[self.addr]
@@ -466,6 +703,7 @@ class _ChoiceMapBuilder:
         return _AddressIndex(_EMPTY)[addr]
 
     n = staticmethod(ChoiceMap.n)
+    set = staticmethod(ChoiceMap.choice)
     v = staticmethod(ChoiceMap.choice)
     d = staticmethod(ChoiceMap.d)
     kw = staticmethod(ChoiceMap.kw)
@@ -474,3 +712,4 @@ class _ChoiceMapBuilder:
 
 
 ChoiceMapBuilder = _ChoiceMapBuilder()
+ChoiceMap.builder = ChoiceMapBuilder

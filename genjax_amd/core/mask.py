@@ -31,6 +31,24 @@ class Mask:
     def __repr__(self):
         return f"Mask({self.value!r}, {self.flag!r})"
 
+    def __eq__(self, other):
+        if not isinstance(other, Mask):
+            return NotImplemented
+        return _same(self.value, other.value) and _same(self.flag, other.flag)
+
+    __hash__ = object.__hash__
+
+
+def _same(a, b):
+    try:
+        import numpy as np
+        import torch
+        ta = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else a
+        tb = b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else b
+        return bool(np.array_equal(np.asarray(ta), np.asarray(tb)))
+    except Exception:
+        return a == b
+
 
 def _and(a, b):
     if isinstance(a, bool) and isinstance(b, bool):

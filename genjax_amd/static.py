@@ -66,7 +66,7 @@ class DistributionTrace(Trace):
 
     def get_choices(self):
         v = materialize(self.value)
-        cm = ChoiceMap.choice(v)
+        cm = ChoiceMap(value=v)            # (not ChoiceMap.choice: a batch of zero particles still has its address)
         nb = len(self.batch_shape)
         return cm.with_plate(nb) if len(getattr(v, "shape", ())) > nb else cm      # a vector-valued site: chm[j]
 

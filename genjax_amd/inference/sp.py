@@ -22,8 +22,9 @@ class Marginal(GenerativeFunction):
         project(trace, ~selection); with an inner algorithm the weight is its estimate of the reciprocal
         normalising constant of Target(gen_fn, args, selected choices) — this is how algorithms nest."""
         from ..random import split
-        if self.algorithm is not None and tuple(key.shape) != ():
-            return self._random_weighted_over_keys(key, args)
+        import os
+        if self.algorithm is not None and tuple(key.shape) != () and os.environ.get("GENMI_CSMC_HOST_WALK") == "1":
+            return self._random_weighted_over_keys(key, args)          # the per-key host walk (kept as a cross-check)
         key, sub_key = split(key)
         tr = self.gen_fn.simulate(sub_key, tuple(args))
         choices = tr.get_choices()

@@ -783,6 +783,13 @@ def test_long_scan_config2_as_one_generative_function(gpu):
     assert abs(r["log_ml_is"] - r["kalman"]) < 0.25, r         # prior-proposal IS over 18 steps: MC error ~0.1
 
 
+def test_conditional_smc_under_a_batch_of_keys(gpu):
+    """`vmap(alg.estimate_logpdf)` over 1 000 keys as ONE launch set over [keys, K] (retained
+    particle in slot K-1 of every row), incl. ChangeTarget.run_csmc, the reciprocal normalising constant and a nested
+    Marginal(algorithm=...); equal to the per-key runs."""
+    parity.check_batched_csmc(k=33, B=1000)
+
+
 def test_large_plates_as_a_counted_loop(gpu):
     """`Vmap` plates of any size (ref vmap.py:180-218) as OP_LOOP with split(key, n)[j] keys —
     a 4096-element plate x 1e4 particles (interpreter) and a 40-element plate x 2.7e5 particles (specialised kernel),

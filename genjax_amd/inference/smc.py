@@ -402,3 +402,894 @@ def _target_over(target: Target, batch: tuple, k: int) -> Target:
             return v.unsqueeze(nb).expand(batch + (k,) + tuple(v.shape[nb:])).contiguous()
         return v
     return Target(target.p, tuple(rep(a) for a in target.args), target.constraint.map_values(rep))
+
+
+# ---------------------------------------------------------------------------
+# Part 2: build-defined scalable SMC moves
+# ---------------------------------------------------------------------------
+MULTINOMIAL_GUIDED_MIN = 8192      # below this the per-slot search of gmx_ancestors is as fast as building a guide table
+SYSTEMATIC, STRATIFIED, MULTINOMIAL = (_lib.RESAMPLE_SYSTEMATIC, _lib.RESAMPLE_STRATIFIED,
+                                       _lib.RESAMPLE_MULTINOMIAL)
+_KINDS = {"systematic": SYSTEMATIC, "stratified": STRATIFIED, "multinomial": MULTINOMIAL}
+
+
+def cdf_reference(m) -> float:
+    """The log-weight an integer CDF total is relative to: total * 2^-shift = sum_i exp(lw_i - cdf_reference(max lw)).
+    = ceil(max lw / ln 2) * ln 2 in float32 arithmetic (gmx_tile_exp / gmx_tile_ref in csrc/gmx_math.h: the
+    exponent K of the block-floating-point CDF), evaluated on the host for the evidence terms."""
+    lim = 1 << 29
+    inv_ln2 = np.frombuffer(np.uint32(0x3FB8AA3B).tobytes(), np.float32)[0]
+    ln2 = np.frombuffer(np.uint32(0x3F317218).tobytes(), np.float32)[0]
+    with np.errstate(invalid="ignore", over="ignore"):
+        t = np.float32(m) * inv_ln2
+    if not (t > -np.float32(lim)):
+        k = -lim
+    elif t > np.float32(lim):
+        k = lim
+    else:
+        k = int(t)
+        if np.float32(k) < t:
+            k += 1
+    return float(np.float32(k) * ln2)
+
+
+def cdf_shift(n_total: int) -> int:
+    """Fixed-point exponent: a sum of n_total terms <= 2^shift stays below 2^62."""
+    need = 0
+    while (1 << need) < n_total:
+        need += 1
+    return 62 - need
+
+
+class LogMLOffset:
+    """Evidence accumulated by resampling steps, kept on the device as exact
+    integers and finished in float64 on the host when asked:
+      sum_t [ M_t + log(total_t * 2^-shift) - log N ]."""
+
+    def __init__(self, terms=()):
+        self.terms = list(terms)      # (max_d f32[1], total_d u64-as-i64[1], shift, n)
+
+    def plus(self, max_d, total_d, shift, n):
+        return LogMLOffset(self.terms + [(max_d, total_d, shift, n)])
+
+    def value(self) -> float:
+        acc = 0.0
+        for max_d, total_d, shift, n in self.terms:
+            m = float(max_d.reshape(-1)[0].item())
+            tot = int(total_d.reshape(-1)[0].item()) & 0xFFFFFFFFFFFFFFFF
+            if tot == 0:                 # no particle carried any mass: the evidence estimate is 0
+                return -math.inf
+            acc += cdf_reference(m) + math.log(tot) - shift * math.log(2.0) - math.log(n)
+        return acc
+
+
+def weight_cdf(lw: torch.Tensor, n_total=None, max_partials=None):
+    """gmx_weight_cdf: returns (cdf int64-bits [n], total [1], max [1], shift)."""
+    be = _lib.get()
+    lw = lw.reshape(-1)
+    if lw.dtype != torch.float32:
+        lw = lw.float()
+    lw = lw.contiguous()
+    n = lw.numel()
+    shift = cdf_shift(n if n_total is None else n_total)
+    cdf = torch.empty((n,), dtype=torch.int64, device=lw.device)
+    total = torch.empty((1,), dtype=torch.int64, device=lw.device)
+    mx = torch.empty((1,), dtype=torch.float32, device=lw.device)
+    ws = torch.zeros(((be.c.gmx_weight_cdf_workspace(n) + 7) // 8,), dtype=torch.int64, device=lw.device)
+    if max_partials is None:
+        # max via the deterministic LSE kernel's max output
+        rows_ws = torch.empty(((be.c.gmx_logsumexp_workspace(1, n) + 3) // 4,), dtype=torch.int32, device=lw.device)
+        dummy = torch.empty((1,), dtype=torch.float32, device=lw.device)
+        be.check(be.c.gmx_logsumexp(be.ptr(lw), 1, n, be.ptr(dummy), be.ptr(mx), be.ptr(rows_ws), be.stream()),
+                 "gmx_logsumexp")
+        be.check(be.c.gmx_weight_cdf(be.ptr(lw), n, shift, None, 0, be.ptr(mx), be.ptr(cdf), be.ptr(total),
+                                     be.ptr(ws), be.stream()), "gmx_weight_cdf")
+    else:
+        be.check(be.c.gmx_weight_cdf(be.ptr(lw), n, shift, be.ptr(max_partials), max_partials.shape[-1],
+                                     be.ptr(mx), be.ptr(cdf), be.ptr(total), be.ptr(ws), be.stream()),
+                 "gmx_weight_cdf")
+    return cdf, total, mx, shift
+
+
+FUSED_RESAMPLE_MAX = 2048 * 1024        # RS_MAX_TILES tiles of 1024 particles (csrc/gmx_kernels.hip)
+
+
+def resample_fused(kind, key: Key, lw: torch.Tensor):
+    """gmx_resample: log-weights -> (ancestors int32 [n], total [1], max [1], shift) in two launches with no CDF
+    array (tile statistics + k_offspring_tile); the same integers as weight_cdf + ancestors_from_cdf."""
+    be = _lib.get()
+    stats = getattr(lw, "_gmx_tile_stats", None)       # left by the program that computed these weights (run_gfi)
+    if stats is not None and (len(stats) < 5 or stats[4] != lw._version):
+        stats = None                       # the weights were changed in place since: the statistics are stale
+    lw = lw.reshape(-1).float().contiguous()
+    if lw.data_ptr() % 16:
+        lw = lw.clone()                    # a view into the middle of a buffer: the kernels load float4
+        stats = None
+    n = lw.numel()
+    shift = cdf_shift(n)
+    anc = torch.empty((n,), dtype=torch.int32, device=lw.device)
+    total = torch.empty((1,), dtype=torch.int64, device=lw.device)
+    mx = torch.empty((1,), dtype=torch.float32, device=lw.device)
+    if stats is not None and stats[2] == shift and stats[3] == n:
+        kh = key.host()
+        kk = (c_uint32 * 2)(int(kh[0]), int(kh[1]))
+        be.check(be.c.gmx_resample_tiles(int(kind), kk, be.ptr(lw), n, shift, be.ptr(stats[0]), be.ptr(stats[1]),
+                                         be.ptr(mx), be.ptr(total), be.ptr(anc), be.stream()), "gmx_resample_tiles")
+        return anc, total, mx, shift
+    ws = torch.empty(((be.c.gmx_resample_workspace(n) + 7) // 8,), dtype=torch.int64, device=lw.device)
+    kh = key.host()
+    kk = (c_uint32 * 2)(int(kh[0]), int(kh[1]))
+    be.check(be.c.gmx_resample(int(kind), kk, be.ptr(lw), n, shift, None, 0, be.ptr(mx), be.ptr(total), be.ptr(anc),
+                               be.ptr(ws), be.stream()), "gmx_resample")
+    return anc, total, mx, shift
+
+
+def ancestors_from_cdf(kind, key: Key, cdf, total, n_out=None) -> torch.Tensor:
+    be = _lib.get()
+    n_in = cdf.numel()
+    n_out = n_in if n_out is None else int(n_out)
+    kh = key.host()
+    kk = (c_uint32 * 2)(int(kh[0]), int(kh[1]))
+    anc = torch.empty((n_out,), dtype=torch.int32, device=cdf.device)
+    if int(kind) == MULTINOMIAL and n_in >= MULTINOMIAL_GUIDED_MIN and os.environ.get("GENMI_MN_GUIDED", "1") != "0":
+        # unordered slots: through the guide table (two table reads + a search over ~3 entries per slot instead of a
+        # binary search over n_in) — the same ancestors
+        ws = torch.empty(((be.c.gmx_multinomial_workspace(n_in) + 3) // 4,), dtype=torch.int32, device=cdf.device)
+        be.check(be.c.gmx_multinomial(kk, be.ptr(cdf), n_in, be.ptr(total), n_out, be.ptr(anc), be.ptr(ws), be.stream()),
+                 "gmx_multinomial")
+        return anc
+    be.check(be.c.gmx_ancestors(int(kind), kk, be.ptr(cdf), n_in, 0, be.ptr(total), n_out, 0, n_out,
+                                be.ptr(anc), be.stream()), "gmx_ancestors")
+    return anc
+
+
+def resample(key: Key, collection: ParticleCollection, kind="systematic", n_out=None) -> ParticleCollection:
+    """Resample a 1-D particle collection.  The result's leaves are lazy
+    gathers (`engine.Gathered`), so a following `extend` fuses the gather into
+    its kernel; weights reset to 0 and the evidence moves into log_ml_offset."""
+    lw = collection.get_log_weights()
+    if lw.ndim != 1:
+        raise NotImplementedError("resample: batched collections")
+    kind = _KINDS[kind] if isinstance(kind, str) else int(kind)
+    n = lw.numel()
+    if kind in (SYSTEMATIC, STRATIFIED) and n_out in (None, n) and 0 < n <= FUSED_RESAMPLE_MAX:
+        anc, total, mx, shift = resample_fused(kind, key, lw)        # no CDF in memory (gmx_resample[_tiles])
+    else:
+        cdf, total, mx, shift = weight_cdf(lw)
+        anc = ancestors_from_cdf(kind, key, cdf, total, n_out)
+    particles = trace_map(collection.get_particles(),
+                          lambda v: Gathered(engine.materialize(v), anc) if tuple(v.shape[:1]) == (n,) else v)
+    off = (collection.log_ml_offset or LogMLOffset()).plus(mx, total, shift, n)
+    out = ParticleCollection(particles, None, True, off, n_zero=anc.numel())     # weights reset to 0, lazily
+    out.ancestors = anc
+    return out
+
+
+def extend(key: Key, collection: ParticleCollection, step, step_args, observations: ChoiceMap) -> ParticleCollection:
+    """Bootstrap extension by one step: every particle i runs
+    `step.importance(split(key, N)[i], observations, step_args_i)` and
+    lw_i += weight_i (same algebra as ChangeTarget._reweight, smc.py:378-384,
+    restricted to the new step's sites).  `step_args` is a tuple, or a callable
+    mapping the previous particles' trace to the tuple."""
+    zero = collection.weights_are_zero()
+    n = collection._n_zero if zero else collection.get_log_weights().shape[0]
+    args = step_args(collection.get_particles()) if callable(step_args) else tuple(step_args)
+    keys = split(key, n)
+    from ..static import StaticGenerativeFunction, run_gfi
+    if isinstance(step, StaticGenerativeFunction):
+        # the step's program also leaves the resampler's tile statistics of its weight when it can
+        tr, w = run_gfi(step, "generate", keys, args, constraint=observations, weight_stats=zero)
+    else:
+        tr, w = step.importance(keys, observations, args)
+    if zero:                           # lw + w with lw = 0 exactly (0.0f + w == w for every w but -0.0, which a
+        return ParticleCollection(tr, w, True, collection.log_ml_offset)          # sum of log-densities is not)
+    return ParticleCollection(tr, engine.elementwise(_add, collection.get_log_weights(), w), True, collection.log_ml_offset)
+
+
+def rejuvenate(key: Key, collection: ParticleCollection, request, argdiffs=None) -> ParticleCollection:
+    """One MH sweep over all particles as ONE fused launch (static.run_mh):
+    particle i uses key_i = split(key, N)[i], (k_edit, k_acc) = split(key_i);
+    propose with `request.edit(k_edit, ...)`, accept iff log U(k_acc) < weight,
+    keep the old trace otherwise (tests/inference/test_requests.py:131-137 idiom).
+    Weights are unchanged (an MH kernel leaves the target invariant)."""
+    from ..static import run_mh
+    tr = collection.get_particles()
+    n = collection._n_zero if collection.weights_are_zero() else collection.get_log_weights().shape[0]
+    if argdiffs is None:
+        argdiffs = Diff.no_change(tr.get_args() or ())
+    new_tr, accept, _ = run_mh(tr.get_gen_fn(), lazy_split(key, n), tr, request, argdiffs)
+    res = ParticleCollection(new_tr, collection._lw, True, collection.log_ml_offset, n_zero=collection._n_zero)
+    res.accept = accept
+    return res
+
+
+class CapturedLoop:
+    """A Python inference loop over this module's functional API (resample -> rejuvenate -> extend ...) captured ONCE
+    into a hipGraph and replayed without the interpreter in the loop: every C-ABI launch goes to torch's current stream,
+    so one capture records them all; tensors made during the capture come from the graph's private pool and stay
+    valid (and are overwritten in place) across replays.  `result` is whatever the loop returned at capture time —
+    its tensors hold the latest replay's values."""
+
+    def __init__(self, loop_fn, *args, warmup: int = 1, noise_ahead=None):
+        be = _lib.get()
+        if not be.uses_streams:
+            raise _lib.GenmiError("capture needs the HIP backend")
+        if noise_ahead is None:
+            noise_ahead = os.environ.get("GENMI_NOISE_AHEAD", "1") != "0"
+        from contextlib import nullcontext
+        from ..static import NoiseAheadContext
+        # noise ahead (DESIGN.md §4): the draws of the loop's extend / rejuvenate launches by background programs on a
+        # second stream; in the captured graph they depend on nothing but each other and run ahead of the chain
+        self.noise = NoiseAheadContext(torch.cuda.Stream(device=be.device)) if noise_ahead else None
+        scope = self.noise if self.noise is not None else nullcontext()
+        side = torch.cuda.Stream(device=be.device)
+        side.wait_stream(torch.cuda.current_stream(be.device))
+        with torch.cuda.stream(side):           # programs are traced / specialised outside the capture
+            for _ in range(max(1, warmup)):
+                with scope:
+                    loop_fn(*args)
+            if self.noise is not None and self.noise.settle():
+                with scope:                      # once more, with the launches that keep their draws as they will run
+                    loop_fn(*args)
+            if self.noise is not None:
+                side.wait_stream(self.noise.stream)
+                # every draw of the loop lives in one arena for the graph's lifetime: bounded (GENMI_NOISE_ARENA_MB)
+                if 4 * self.noise.demand > int(os.environ.get("GENMI_NOISE_ARENA_MB", 16384)) << 20:
+                    self.noise = None
+                    loop_fn(*args)               # the plain programs must exist before the capture too
+        torch.cuda.current_stream(be.device).wait_stream(side)
+        torch.cuda.synchronize(be.device)
+        if self.noise is not None:
+            self.noise.reserve(be.device)
+        self.graph = torch.cuda.CUDAGraph()
+        # the graph's kernel nodes point into the site programs' code: hold every program launched during the capture
+        # for as long as the graph lives (the program caches are bounded LRUs; genjax_amd.clear_caches() is public)
+        with engine.holding_captured_programs() as self.programs, torch.cuda.graph(self.graph):
+            if self.noise is not None:
+                cur = torch.cuda.current_stream(be.device)
+                self.noise.stream.wait_stream(cur)          # the background stream joins the capture ...
+                self.noise.issue_ahead(be.device)           # ... every recorded noise launch goes out first ...
+                with self.noise:
+                    self.result = loop_fn(*args)
+                cur.wait_stream(self.noise.stream)          # ... and the stream is joined back before the capture ends
+            else:
+                self.result = loop_fn(*args)
+
+    def replay(self):
+        self.graph.replay()
+        return self.result
+
+
+def capture(loop_fn, *args, warmup: int = 1, noise_ahead=None) -> CapturedLoop:
+    """`smc.capture(loop_fn, *args)`: see CapturedLoop.  Host-side reads of device values inside `loop_fn`
+    (`.item()`, `float(tensor)`, LogMLOffset.value()) are not capturable — return tensors and read them after
+    `replay()`.  noise_ahead (default: on; GENMI_NOISE_AHEAD=0): launches over >= 2^18 particles take their
+    launch-keyed normal / uniform draws from background programs on a second stream (same values)."""
+    return CapturedLoop(loop_fn, *args, warmup=warmup, noise_ahead=noise_ahead)
+
+
+class _NoiseAhead:
+    """The noise-ahead machinery shared by BootstrapSweep and sharded.ShardedBootstrapSweep: background
+    programs that draw the chain programs' hoisted normal / uniform values on a second stream, a group of steps ahead.
+    The host class provides n, T, step_keys, specialize, fuse_mh, `_chain_prog(t)` (the site program of step t) and
+    `_chain_step(t, skip_vm)` (everything step t launches on the chain); `_noise_total` / `_noise_offset`: the keys of
+    this shard are children offset .. offset + n - 1 of split(k, total) (a single GPU: total = n, offset = 0)."""
+
+    NOISE_LDS_PAD = 56000      # bytes of unused LDS per noise workgroup: two of them per CU (160 KB)
+    NOISE_GROUP = 10           # steps per group of noise launches (the noise runs one group ahead of the chain)
+    _noise_offset = 0
+    _noise_total = None
+
+    def _noise_split(self, k):
+        total = self._noise_total or self.n
+        return lazy_split(k, total, offset=self._noise_offset) if (self._noise_offset or total != self.n) else lazy_split(k, self.n)
+
+    def _noise_setup(self, chain_progs, n, T, dev):
+        from ..static import NoiseProgram
+        be = _lib.get()
+        self.noise_ahead = True
+        # one background program per (chain program, root key): the draws that hang off the launch key (the
+        # step's own sites; with rejuvenate=, the move's proposal and accept draws: key k_mh) and those that hang
+        # off the chained extension's key (KSPLITU: k_prop)
+        for P in chain_progs:
+            if id(P) in self._noise_progs:
+                continue
+            by_root = {}
+            for k_, d in enumerate(P.noise):
+                by_root.setdefault(d[0], []).append(k_)
+            self._noise_progs[id(P)] = [(root, NoiseProgram([P.noise[k_] for k_ in idx], (n,)), idx)
+                                        for root, idx in by_root.items()]
+        self.noise_group = max(1, min(int(os.environ.get("GENMI_NOISE_GROUP", self.NOISE_GROUP)), T))
+        # groups of steps [start, end): the noise of group g + 1 is issued before the chain of group g.  The chain
+        # can only start once the FIRST group's noise is there, so the groups grow 1, 2, 4, ... up to noise_group
+        self.noise_groups, self.noise_slot = [], []
+        t0, size = 0, 1
+        while t0 < T:
+            t1 = min(T, t0 + min(size, self.noise_group))
+            for t in range(t0, t1):
+                self.noise_slot.append((len(self.noise_groups) % 2, t - t0))
+            self.noise_groups.append((t0, t1))
+            t0, size = t1, size * 2
+        S = max(len(P.noise) for P in chain_progs)
+        # two groups of noise buffers: the background stream fills one while the chain reads the other.
+        # [half, draw, row of the group, n]: a draw's rows are contiguous, so ONE launch can fill several steps
+        self.zbuf = torch.zeros((2, S, self.noise_group, n), dtype=torch.float32, device=dev)
+        self._noise_stream = torch.cuda.Stream(device=dev) if be.uses_streams else None
+        pad = int(os.environ.get("GENMI_NOISE_LDS_PAD", self.NOISE_LDS_PAD))
+        for plist in self._noise_progs.values():
+            for _, q, _ in plist:
+                if self.specialize:
+                    q.comp.set_background(pad)
+                    q.comp.specialize()
+
+    def _noise_views(self, t, count):
+        """the [1, n] buffers of step t's draws: half (t // group) % 2 of the ring, row t % group"""
+        half, row = self.noise_slot[t]
+        return [self.zbuf[half, k, row:row + 1] for k in range(count)]
+
+    def _noise_leaves(self, t, prog):
+        return [v.reshape(self.n) for v in self._noise_views(t, len(prog.noise))]
+
+    def _noise_runs(self, g):
+        """The background launches of group g: the steps of a group that share a chain program get their draws from ONE
+        launch per key root — a 2-D grid, one row of keys per step (GMX_KEY_ROWSPLIT; gmx_program_run) — instead of
+        one launch per step: fewer nodes in the graph (the HIP runtime walks a two-stream graph node by node on the
+        host) and no launch boundary between the steps' noise.  GENMI_NOISE_ROWS=0: one launch per step."""
+        cache = self.__dict__.setdefault("_noise_run_cache", {})
+        if g in cache:
+            return cache[g]
+        n = self.n
+        t0, t1 = self.noise_groups[g]
+        runs, ta = [], t0
+        while ta < t1:
+            tb = ta + 1
+            while tb < t1 and self._chain_prog(tb) is self._chain_prog(ta):
+                tb += 1
+            runs.append((ta, tb))
+            ta = tb
+        out = []
+        dev = self.zbuf.device
+        for ta, tb in runs:
+            P = self._chain_prog(ta)
+            half, row_a = self.noise_slot[ta]
+            rows = tb - ta
+            mh = self.fuse_mh and ta >= 1
+            for root, q, idx in self._noise_progs[id(P)]:
+                ks = [self.step_keys[t][2] if (mh and root == "LDKEY") else self.step_keys[t][0] for t in range(ta, tb)]
+                if rows == 1 or rows * n >= 2 ** 31 - 4096:
+                    for r, k in enumerate(ks):
+                        out.append((q, (n,), self._noise_split(k), [self.zbuf[half, k_, row_a + r:row_a + r + 1] for k_ in idx]))
+                    continue
+                kd = torch.from_numpy(np.stack([k.host() for k in ks]).astype(np.uint32).view(np.int32)).to(dev)
+                # row r's keys: children offset .. offset + n - 1 of split(ks[r], total) (GMX_KEY_ROWSPLIT + index_offset)
+                key = Key(lazy=("rowsplit", Key(dev=kd), n), split_last=True, offset=self._noise_offset)
+                out.append((q, (rows * n,), key, [self.zbuf[half, k_, row_a:row_a + rows].reshape(1, rows * n) for k_ in idx]))
+        cache[g] = out
+        return out
+
+    def _launch_noise_group(self, g):
+        if os.environ.get("GENMI_NOISE_ROWS", "1") == "0":
+            for t in range(*self.noise_groups[g]):
+                self._launch_noise(t)
+            return
+        for q, batch, key, outs in self._noise_runs(g):
+            q.run(batch, key, outs)
+
+    def _launch_noise(self, t):
+        """the draws step t's chain program reads, by the background programs: root LDKEY from the program's launch key
+        (k_prop; the chained MH + extension program: k_mh), root KSPLITU from the extension's key k_prop"""
+        P = self._chain_prog(t)
+        views = self._noise_views(t, len(P.noise))
+        mh = self.fuse_mh and t >= 1
+        for root, q, idx in self._noise_progs[id(P)]:
+            k = self.step_keys[t][2] if (mh and root == "LDKEY") else self.step_keys[t][0]
+            q.run((self.n,), self._noise_split(k), [views[k_] for k_ in idx])
+
+    def _enqueue_noise_ahead(self, skip_vm=False, skip_noise=False):
+        """The sweep on TWO streams: the chain [site program' -> resampler] per step on the current one, the noise
+        programs on the background stream, one group of steps ahead (group g + 1's noise is issued before group g's
+        chain; it may overwrite half (g + 1) % 2 of the ring once the chain of group g - 1 has read it; the groups
+        grow 1, 2, 4, ... steps up to noise_group, so the chain starts after ONE noise launch).  Capturable:
+        the background stream joins the capture through the first event wait and is joined back at the end.
+        Without streams (the CPU mirror of the C-ABI) the same launches run in issue order."""
+        be = _lib.get()
+        spans = self.noise_groups
+        groups = len(spans)
+        two = be.uses_streams and self._noise_stream is not None
+        if two:
+            A, Bs = torch.cuda.current_stream(be.device), self._noise_stream
+            Bs.wait_stream(A)
+        done, ready = [None] * groups, [None] * groups
+
+        def noise_group(g):
+            if skip_noise:
+                return
+            if two:
+                with torch.cuda.stream(Bs):
+                    if g >= 2:
+                        Bs.wait_event(done[g - 2])
+                    self._launch_noise_group(g)
+                    ready[g] = torch.cuda.Event()
+                    ready[g].record(Bs)
+            else:
+                self._launch_noise_group(g)
+
+        noise_group(0)
+        for g in range(groups):
+            if g + 1 < groups:
+                noise_group(g + 1)
+            if two and not skip_noise:
+                A.wait_event(ready[g])
+            for t in range(*spans[g]):
+                self._chain_step(t, skip_vm)
+            if two and not skip_noise:
+                done[g] = torch.cuda.Event()
+                done[g].record(A)
+        if two:
+            A.wait_stream(Bs)
+
+
+class BootstrapSweep(_NoiseAhead):
+    """A whole bootstrap particle filter (T steps, resampling every step) as a
+    fixed sequence of launches on one stream, capturable into a hipGraph — two launches per step:
+
+      per step t:  [site program]  x_t[i] ~ step(x_{t-1}[anc[i]]), lw[i] = log p(y_t | x_t[i]); specialised with 4
+                                   particles per thread a workgroup is one 1024-particle tile of the integer CDF
+                                   and also leaves the tile statistics (max, fixed-point weight sum)
+                   [offspring]     k_offspring_tile: global exponent + tile prefixes from the statistics, the
+                                   tile's CDF rebuilt in registers, exact systematic / stratified ancestors
+      (programs that cannot write the statistics: + gmx_tile_stats; multinomial or n > 2^21: gmx_weight_cdf +
+       gmx_ancestors)
+
+    Key schedule (build-defined, SURVEY.md App. B): step key = fold_in(run_key, t);
+    (k_prop, k_res, k_mh) = split(step key, 3); particle i uses split(k_prop, N)[i].
+    The evidence is accumulated from the integer CDF totals in float64 on the host.
+
+    NOISE AHEAD (`noise_ahead`, default: on when it applies; GENMI_NOISE_AHEAD=0 switches it off).  A step is bound by
+    vector-instruction issue, and two thirds of its instructions are the Threefry blocks and the `erf_inv` of the
+    step's normal draws — which depend on keys and particle indices only, not on anything the chain
+    [site program -> resampler -> site program ...] produces.  So the step's `normal` sites take their standard-normal
+    draws from memory (static.MinimalGenerate(hoist_noise=True)) and a BACKGROUND program (static.NoiseProgram:
+    priority 0, a capped number of workgroups per CU) draws them on a second stream, a group of steps ahead of the
+    chain, filling the issue slots the chain's launch boundaries and memory round trips leave idle.  Same keys, same
+    operations in the same order: every particle, weight and ancestor is the one the one-stream form computes.
+    Measured on MI355X (config 2): 17.9 -> 15.8 us/step.
+    """
+
+    NOISE_LDS_PAD = 56000      # bytes of unused LDS per noise workgroup: two of them per CU (160 KB)
+    NOISE_GROUP = 10           # steps per group of noise launches (the noise runs one group ahead of the chain)
+    NOISE_ROOTS_MH = "LDKEY"   # with rejuvenate=: which keys' draws the background programs take (see prepare)
+
+    def __init__(self, init, step, n_particles: int, T: int, obs_addr="y", resample="systematic",
+                 step_extra=None, specialize=True, rejuvenate=None, state_addr="x", noise_ahead=None):
+        """rejuvenate: an edit request (e.g. StaticRequest({"x": Rejuvenate(...)})) applied as one fused
+        MH move per particle after every resampling, before the next extension (BASELINE config 3; the
+        graph-captured form of smc.resample -> smc.rejuvenate -> smc.extend, same keys, same results).
+        Supported for models whose trace is {state_addr: the return value, obs_addr: the observation}."""
+        self.init, self.step, self.n, self.T = init, step, int(n_particles), int(T)
+        self.obs_addr, self.state_addr, self.rejuvenate = obs_addr, state_addr, rejuvenate
+        self.kind = _KINDS[resample] if isinstance(resample, str) else int(resample)
+        self.step_extra = step_extra or (lambda t: ())
+        self.specialize = specialize
+        self.graph = None
+        self.noise_ahead_req = noise_ahead
+
+    def prepare(self, key: Key, ys: torch.Tensor):
+        from ..static import MinimalGenerate as _MG, NoiseProgram
+        be = _lib.get()
+        # noise ahead: asked for explicitly, or by default on a device with streams on the fast path (specialised
+        # programs; with rejuvenate=, the MH move chained into the extension)
+        fuse_mh_ok = os.environ.get("GENMI_FUSE_MH", "1") != "0"
+        want_na = self.noise_ahead_req
+        if want_na is None:
+            want_na = (os.environ.get("GENMI_NOISE_AHEAD", "1") != "0" and be.uses_streams and self.specialize
+                       and (self.rejuvenate is None or fuse_mh_ok)
+                       and os.environ.get("GENMI_FUSE_RESAMPLE", "0") != "1")
+        if want_na and self.rejuvenate is not None and not fuse_mh_ok:
+            raise NotImplementedError("BootstrapSweep(noise_ahead=True, rejuvenate=...) needs the chained MH + extension "
+                                      "program (GENMI_FUSE_MH=0 is set)")
+        self.noise_ahead = False
+        self._noise_progs = {}
+
+        def MinimalGenerate(*a):
+            return _MG(*a, hoist_noise=bool(want_na))
+        n, T = self.n, self.T
+        dev = be.device
+        self.key = key
+        self.ys = ys.to(dev).float().contiguous()
+        assert self.ys.numel() >= T
+        self.lw = torch.zeros((n,), dtype=torch.float32, device=dev)
+        self.cdf = torch.zeros((n,), dtype=torch.int64, device=dev)
+        self.anc = torch.zeros((n,), dtype=torch.int32, device=dev)
+        self.maxs = torch.zeros((T,), dtype=torch.float32, device=dev)
+        self.totals = torch.zeros((T,), dtype=torch.int64, device=dev)
+        self.shift = cdf_shift(n)
+        self.ws = torch.zeros(((be.c.gmx_weight_cdf_workspace(n) + 7) // 8,), dtype=torch.int64, device=dev)
+        self.fused = self.kind in (SYSTEMATIC, STRATIFIED) and n <= (512 * 4096)
+        self.mn_ws = torch.zeros(((be.c.gmx_multinomial_workspace(n) + 3) // 4,), dtype=torch.int32, device=dev) \
+            if self.kind == MULTINOMIAL else None
+        self.rs_ws = torch.zeros(((be.c.gmx_resample_workspace(n) + 7) // 8,), dtype=torch.int64, device=dev) \
+            if self.fused else None
+        obs0 = ChoiceMap.empty().set(self.obs_addr, self.ys[0])
+        self.p_init = MinimalGenerate(self.init, (), obs0, (n,))
+        # the state is the model's return value: a scalar, or ONE vector of D floats per particle, stored
+        # struct-of-arrays as [D, n] and seen by models (and by state()) as the [n, D] view
+        ro = self.p_init.ro
+        outs_ = self.p_init.comp.outputs
+        self.tuple_state = None
+        if ro[0] in ("tuple", "list") and ro[1] and all(o[0] == "out" and outs_[o[1]][0] == "f32" and outs_[o[1]][1] == ()
+                                                          for o in ro[1]):
+            # a TUPLE of float scalars (the latent sites a step hands to the next one): D rows of one [D, n] store,
+            # every row its own output of the site program and its own gathered input of the next step
+            self.tuple_state = type(()) if ro[0] == "tuple" else type([])
+            if self.rejuvenate is not None:
+                raise NotImplementedError("BootstrapSweep(rejuvenate=...): a tuple state is not supported (return one "
+                                          "array, or use smc.resample / rejuvenate / extend under smc.capture)")
+            event, D = (), len(ro[1])
+        else:
+            if ro[0] != "out":
+                raise NotImplementedError("BootstrapSweep: the step model must return one array (scalar or vector "
+                                          "state) or a tuple of float scalars")
+            dt, event, _slots = outs_[ro[1]]
+            if dt != "f32" or len(event) > 1:
+                raise NotImplementedError("BootstrapSweep: the state must be a float scalar or a float vector")
+            D = int(np.prod(event, dtype=np.int64)) if event else 1
+        self.event = tuple(event)
+        self.x_store = [torch.zeros((D, n), dtype=torch.float32, device=dev) for _ in range(2)]
+        if self.tuple_state is not None:
+            self.x = [self.tuple_state(s_[d] for d in range(D)) for s_ in self.x_store]
+        else:
+            self.x = [s_.reshape(n) if not event else s_.t() for s_ in self.x_store]
+        g = self._gathered(0)
+        if self.rejuvenate is None:
+            self.p_step = MinimalGenerate(self.step, (g,) + tuple(self.step_extra(1)), obs0, (n,))
+        else:
+            from ..static import MinimalMH
+            # xm[t % 2]: the MH-moved, resampled state the extension of step t starts from
+            self.xm_store = [torch.zeros((D, n), dtype=torch.float32, device=dev) for _ in range(2)]
+            self.xm = [s_.reshape(n) if not event else s_.t() for s_ in self.xm_store]
+            self.accept = torch.zeros((n,), dtype=torch.bool, device=dev)
+            self.p_step = _MG(self.step, (self.xm[0],) + tuple(self.step_extra(1)), obs0, (n,))
+            ch = obs0.set(self.state_addr, g)
+            self.p_mh_init = MinimalMH(self.init, (), ch, self.rejuvenate, (n,))
+            self.p_mh_step = MinimalMH(self.step, (Gathered(self.xm[0], self.anc),) + tuple(self.step_extra(1)), ch,
+                                       self.rejuvenate, (n,))
+        # the MH move and the extension that follows it as ONE program / one launch per step (static.MinimalMHGenerate:
+        # same keys, same draws, same bits; one launch boundary and one trip of the moved state through memory less).
+        # GENMI_FUSE_MH=0 keeps the two launches.
+        self.p_mhvm_init = self.p_mhvm_step = None
+        if self.rejuvenate is not None and os.environ.get("GENMI_FUSE_MH", "1") != "0":
+            from ..static import MinimalMHGenerate
+            ex = tuple(self.step_extra(1))
+            # which draws of the chained program go to the background stream: the two streams should carry about the
+            # same vector work (GENMI_NOISE_ROOTS: "all", "LDKEY" = the move's proposal + accept draws, "KSPLITU" = the
+            # extension's draw)
+            roots = os.environ.get("GENMI_NOISE_ROOTS", self.NOISE_ROOTS_MH)
+            hn = False if not want_na else (True if roots == "all" else tuple(roots.split(",")))
+            self.p_mhvm_init = MinimalMHGenerate(self.init, (), ch, self.rejuvenate, self.step, ex, obs0, (n,),
+                                                 hoist_noise=hn)
+            self.p_mhvm_step = MinimalMHGenerate(self.step, (Gathered(self.xm[0], self.anc),) + ex, ch, self.rejuvenate,
+                                                 self.step, ex, obs0, (n,), hoist_noise=hn)
+        # the chain's programs by step: t = 0, t = 1, t >= 2
+        chain_progs = (self.p_init, self.p_step, self.p_step) if self.rejuvenate is None else \
+            (self.p_init, self.p_mhvm_init, self.p_mhvm_step)
+        if want_na and chain_progs[2] is not None and chain_progs[2].noise:
+            self._noise_setup(chain_progs, n, T, dev)
+        elif want_na and any(P is not None and P.noise for P in chain_progs):
+            # the steady-state program draws nothing ahead although another one would: the plain programs throughout
+            self.noise_ahead_req = False
+            return self.prepare(key, ys)
+        if self.specialize:
+            self.p_init.comp.specialize()
+            self.p_step.comp.specialize()
+            if self.rejuvenate is not None:
+                self.p_mh_init.comp.specialize()
+                self.p_mh_step.comp.specialize()
+            if self.p_mhvm_init is not None:
+                self.p_mhvm_init.comp.specialize()
+                self.p_mhvm_step.comp.specialize()
+        # block partials: sized for the interpreter's one row per 256 particles; a specialised kernel
+        # writes fewer rows (gmx_program_grid), asked per launch in _rows()
+        self.partials = torch.zeros((2, (n + 255) // 256), dtype=torch.float32, device=dev)
+        # two launches per step: when the site programs can leave the CDF tile statistics themselves (specialised,
+        # 4 particles per thread: a workgroup is one 1024-particle tile) the resampler needs no pass of its own
+        # over the log-weights (gmx_resample_tiles); GENMI_TILE_STATS=0 keeps the separate gmx_tile_stats launch
+        self.tile_agg = torch.zeros(((n + 1023) // 1024,), dtype=torch.int64, device=dev)
+        self.tile_stats = bool(self.fused and os.environ.get("GENMI_TILE_STATS", "1") != "0"
+                               and self.p_init.comp.writes_tile_stats() and self.p_step.comp.writes_tile_stats())
+        if self.p_mhvm_init is not None and self.tile_stats and not (self.p_mhvm_init.comp.writes_tile_stats()
+                                                                     and self.p_mhvm_step.comp.writes_tile_stats()):
+            self.p_mhvm_init = self.p_mhvm_step = None      # the chained programs are too large for the tile form
+        self.fuse_mh = self.p_mhvm_init is not None
+        if self.noise_ahead and self.rejuvenate is not None and not self.fuse_mh:
+            # the noise-ahead form needs the chained program: start over with the plain ones
+            if self.noise_ahead_req:
+                raise NotImplementedError("BootstrapSweep(noise_ahead=True, rejuvenate=...): the chained MH + extension "
+                                          "program does not fit the tile form")
+            self.noise_ahead_req = False
+            return self.prepare(key, ys)
+        # ... and, on request (GENMI_TILE_Q=1), every particle's fixed-point weight (4 bytes each: significand | shift):
+        # the resampler then reads those instead of the log-weights and skips one exp per particle.  Measured on MI355X
+        # (config 2): the resampler 6.7 -> 6.3 us, the site program 11.5 -> 12.3 us — the extra 4 MB are stored at the
+        # very end of the site program (they need the block maximum), where nothing overlaps them.  Off by default.
+        self.tile_q = torch.zeros((n,), dtype=torch.int32, device=dev) \
+            if self.tile_stats and os.environ.get("GENMI_TILE_Q", "0") == "1" else None
+        # ... and, on request (GENMI_TILE_PREFIX=1), the tile PREFIXES (gmx_run_args.tile_pref_d): the last workgroup of
+        # the site program to finish turns all (m_b, A_b) into M, K, the exclusive prefixes and the total ONCE, and the
+        # resampler's workgroups read one prefix each (gmx_resample_tiles_p) instead of every one of them reducing the
+        # whole table (977 times at 1e6 particles: ~130 of the resampler's 541 vector instructions per wave).  Measured
+        # on MI355X (profiles/r03d_ab_tile_prefix*.json, A/B in one process, bit-identical): config 3 32.0 -> 31.4
+        # us/step, config 2 15.0 -> 15.9 — the publication (two atomic exchanges, a two-level ticket, the last
+        # workgroup's pass) is three to four dependent memory round trips at the END of the site program, on the
+        # chain's critical path, and config 2's site program is too short to hide them.  Off by default.
+        self.tile_pref = None
+        if self.tile_stats and self.tile_q is None and os.environ.get("GENMI_TILE_PREFIX", "0") == "1" \
+                and os.environ.get("GENMI_FUSE_RESAMPLE", "0") != "1":
+            self.tile_pref = torch.zeros((int(be.c.gmx_tile_prefix_words(n)),), dtype=torch.int64, device=dev)
+        # ONE launch per step: the program that gathers the resampled state (the extension; with rejuvenate=, the MH
+        # move) first computes its workgroup's ancestors itself, from the previous step's log-weights and tile
+        # statistics (gmx_run_args.rs, csrc/gmx_resample.h) — same integers as gmx_resample_tiles, no second kernel,
+        # no launch boundary.  Needs two sets of log-weights / statistics (a launch reads step t-1's while writing
+        # step t's).  OPT-IN (GENMI_FUSE_RESAMPLE=1, read when the programs are specialised): measured on MI355X,
+        # config 2, the one-launch step is SLOWER (23.1 vs 20.1 us): a workgroup's 1024 slots straddle two source
+        # tiles on average, so the CDF rebuild (4 exp + scan + 5 slot edges per thread and tile) runs twice per
+        # workgroup — +1340 vector instructions per wave against the 806 of k_offspring_tile, more than the launch
+        # boundary it removes (DESIGN.md §4).
+        if self.rejuvenate is None:
+            gatherers = (self.p_step,)
+        elif self.fuse_mh:
+            gatherers = (self.p_mhvm_init, self.p_mhvm_step)
+        else:
+            gatherers = (self.p_mh_init, self.p_mh_step)
+        self.fuse = bool(self.tile_stats and self.tile_q is None and os.environ.get("GENMI_FUSE_RESAMPLE", "0") == "1"
+                         and not self.noise_ahead and all(p_.comp.fuses_resample() for p_ in gatherers))
+        if self.fuse:
+            self.lw_pp = [self.lw, torch.zeros_like(self.lw)]
+            self.partials_pp = [self.partials, torch.zeros_like(self.partials)]
+            self.tile_agg_pp = [self.tile_agg, torch.zeros_like(self.tile_agg)]
+        else:
+            self.lw_pp, self.partials_pp, self.tile_agg_pp = [self.lw] * 2, [self.partials] * 2, [self.tile_agg] * 2
+        # per-step keys on the host
+        self.step_keys = []
+        for t in range(T):
+            ks = split(fold_in(key, t), 3)
+            self.step_keys.append((ks[0], ks[1], ks[2]))
+        return self
+
+    def _gathered(self, which):
+        """the resampled state x[which][anc] as the step model's first argument (lazy: the gather is fused)"""
+        if self.tuple_state is not None:
+            return self.tuple_state(Gathered(row, self.anc) for row in self.x[which])
+        return Gathered(self.x[which], self.anc)
+
+    def _launch_vm(self, t):
+        n = self.n
+        k_prop = self.step_keys[t][0]
+        obs = ChoiceMap.empty().set(self.obs_addr, self.ys[t])
+        if t == 0:
+            prog = self.p_init
+            leaves = prog.leaves((), obs, self._noise_leaves(t, prog)) if self.noise_ahead else prog.leaves((), obs)
+        else:
+            g = self._gathered((t - 1) % 2) if self.rejuvenate is None else self.xm[t % 2]
+            prog = self.p_step
+            a = (g,) + tuple(self.step_extra(t))
+            leaves = prog.leaves(a, obs, self._noise_leaves(t, prog)) if self.noise_ahead else prog.leaves(a, obs)
+        bufs = [None] * len(prog.comp.outputs)
+        if self.tuple_state is not None:
+            for d, o in enumerate(prog.ro[1]):
+                bufs[o[1]] = self.x_store[t % 2][d:d + 1]
+        else:
+            bufs[prog.ro[1]] = self.x_store[t % 2]
+        bufs[prog.wo[1]] = self.lw_pp[t % 2].reshape(1, n)
+        prog.comp.run(leaves, (n,), lazy_split(k_prop, n), red_out=self.partials_pp[t % 2], out_buffers=bufs,
+                      tile_stats=(self.tile_agg_pp[t % 2], self.shift, self.tile_q, self.tile_pref) if self.tile_stats else None,
+                      resample_in=self._resample_in(t) if (self.fuse and t >= 1 and self.rejuvenate is None) else None)
+
+    def _chain_prog(self, t):
+        if t == 0:
+            return self.p_init
+        if self.fuse_mh:
+            return self.p_mhvm_init if t == 1 else self.p_mhvm_step
+        return self.p_step
+
+    def _resample_in(self, t):
+        """gmx_run_args.rs of the launch of step t (>= 1) that gathers: resample step t-1's weights first"""
+        kh = self.step_keys[t - 1][1].host()
+        w = (t - 1) % 2
+        return dict(lw=self.lw_pp[w], tile_max=self.partials_pp[w], tile_agg=self.tile_agg_pp[w], anc_out=self.anc,
+                    kind=self.kind, shift=self.shift, key=(int(kh[0]), int(kh[1])),
+                    max_out=self.maxs[t - 1:t], total_out=self.totals[t - 1:t])
+
+    def _launch_mh(self, t):
+        """The MH move on the resampled particles of step t-1 (t >= 1): reads x_{t-1}[anc] and, for
+        t >= 2, the state xm[(t-1) % 2][anc] that x_{t-1} was extended from; writes xm[t % 2]."""
+        n = self.n
+        k_mh = self.step_keys[t][2]
+        ch = ChoiceMap.empty().set(self.obs_addr, self.ys[t - 1]).set(self.state_addr,
+                                                                      Gathered(self.x[(t - 1) % 2], self.anc))
+        if t == 1:
+            prog, leaves = self.p_mh_init, self.p_mh_init.leaves((), ch, self.rejuvenate)
+        else:
+            prog = self.p_mh_step
+            a = Gathered(self.xm[(t - 1) % 2], self.anc)
+            leaves = prog.leaves((a,) + tuple(self.step_extra(t - 1)), ch, self.rejuvenate)
+        bufs = [None] * len(prog.comp.outputs)
+        bufs[prog.ro[1]] = self.xm_store[t % 2]
+        bufs[prog.ao[1]] = self.accept.reshape(1, n)
+        prog.comp.run(leaves, (n,), lazy_split(k_mh, n), out_buffers=bufs,
+                      resample_in=self._resample_in(t) if self.fuse else None)
+
+    def _launch_mhvm(self, t):
+        """step t >= 1 as ONE launch: the MH move on the resampled particles of step t-1 (as _launch_mh), then the
+        extension to step t (as _launch_vm) from the moved state"""
+        n = self.n
+        k_mh, k_prop = self.step_keys[t][2], self.step_keys[t][0]
+        ch = ChoiceMap.empty().set(self.obs_addr, self.ys[t - 1]).set(self.state_addr,
+                                                                      Gathered(self.x[(t - 1) % 2], self.anc))
+        obs = ChoiceMap.empty().set(self.obs_addr, self.ys[t])
+        ex = tuple(self.step_extra(t))
+        kw = k_prop.host()
+        if t == 1:
+            prog = self.p_mhvm_init
+            leaves = prog.leaves((), ch, self.rejuvenate, ex, obs, (int(kw[0]), int(kw[1])),
+                                 self._noise_leaves(t, prog) if self.noise_ahead else ())
+        else:
+            prog = self.p_mhvm_step
+            a = Gathered(self.xm[(t - 1) % 2], self.anc)
+            leaves = prog.leaves((a,) + tuple(self.step_extra(t - 1)), ch, self.rejuvenate, ex, obs,
+                                 (int(kw[0]), int(kw[1])), self._noise_leaves(t, prog) if self.noise_ahead else ())
+        bufs = [None] * len(prog.comp.outputs)
+        bufs[prog.mo[1]] = self.xm_store[t % 2]
+        bufs[prog.ao[1]] = self.accept.reshape(1, n)
+        bufs[prog.ro[1]] = self.x_store[t % 2]
+        bufs[prog.wo[1]] = self.lw_pp[t % 2].reshape(1, n)
+        prog.comp.run(leaves, (n,), lazy_split(k_mh, n), red_out=self.partials_pp[t % 2], out_buffers=bufs,
+                      tile_stats=(self.tile_agg_pp[t % 2], self.shift, self.tile_q, self.tile_pref) if self.tile_stats else None,
+                      resample_in=self._resample_in(t) if self.fuse else None)
+
+    def _rows(self, t) -> int:
+        """partial rows the site program of step t wrote"""
+        prog = self.p_init if t == 0 else (self.p_step if not self.fuse_mh else
+                                           (self.p_mhvm_init if t == 1 else self.p_mhvm_step))
+        return int(_lib.get().c.gmx_program_grid(prog.comp.handle, self.n))
+
+    def _launch_cdf(self, t):
+        be = _lib.get()
+        be.check(be.c.gmx_weight_cdf(be.ptr(self.lw), self.n, self.shift, be.ptr(self.partials),
+                                     self._rows(t), be.ptr(self.maxs[t:t + 1]), be.ptr(self.cdf),
+                                     be.ptr(self.totals[t:t + 1]), be.ptr(self.ws), be.stream()),
+                 "gmx_weight_cdf")
+
+    def _launch_anc(self, t):
+        be = _lib.get()
+        kh = self.step_keys[t][1].host()
+        kk = (c_uint32 * 2)(int(kh[0]), int(kh[1]))
+        if self.kind == MULTINOMIAL and self.n >= MULTINOMIAL_GUIDED_MIN and os.environ.get("GENMI_MN_GUIDED", "1") != "0":
+            if getattr(self, "mn_ws", None) is None:
+                self.mn_ws = torch.zeros(((be.c.gmx_multinomial_workspace(self.n) + 3) // 4,), dtype=torch.int32,
+                                         device=be.device)
+            be.check(be.c.gmx_multinomial(kk, be.ptr(self.cdf), self.n, be.ptr(self.totals[t:t + 1]), self.n,
+                                          be.ptr(self.anc), be.ptr(self.mn_ws), be.stream()), "gmx_multinomial")
+            return
+        be.check(be.c.gmx_ancestors(self.kind, kk, be.ptr(self.cdf), self.n, 0, be.ptr(self.totals[t:t + 1]),
+                                    self.n, 0, self.n, be.ptr(self.anc), be.stream()), "gmx_ancestors")
+
+    def _launch_resample(self, t):
+        be = _lib.get()
+        kh = self.step_keys[t][1].host()
+        kk = (c_uint32 * 2)(int(kh[0]), int(kh[1]))
+        if self.tile_stats and self.tile_q is not None:
+            be.check(be.c.gmx_resample_tiles_q(self.kind, kk, be.ptr(self.tile_q), self.n, self.shift,
+                                               be.ptr(self.partials), be.ptr(self.tile_agg), be.ptr(self.maxs[t:t + 1]),
+                                               be.ptr(self.totals[t:t + 1]), be.ptr(self.anc), be.stream()),
+                     "gmx_resample_tiles_q")
+            return
+        if self.tile_stats and self.tile_pref is not None:     # the site program's last workgroup left the prefixes
+            be.check(be.c.gmx_resample_tiles_p(self.kind, kk, be.ptr(self.lw), self.n, self.shift, be.ptr(self.partials),
+                                               be.ptr(self.tile_pref), be.ptr(self.maxs[t:t + 1]),
+                                               be.ptr(self.totals[t:t + 1]), be.ptr(self.anc), be.stream()),
+                     "gmx_resample_tiles_p")
+            return
+        if self.tile_stats:        # tile maxima = the workgroup maxima the site program left in partials[0]
+            w = t % 2
+            be.check(be.c.gmx_resample_tiles(self.kind, kk, be.ptr(self.lw_pp[w]), self.n, self.shift,
+                                             be.ptr(self.partials_pp[w]), be.ptr(self.tile_agg_pp[w]),
+                                             be.ptr(self.maxs[t:t + 1]),
+                                             be.ptr(self.totals[t:t + 1]), be.ptr(self.anc), be.stream()),
+                     "gmx_resample_tiles")
+            return
+        be.check(be.c.gmx_resample(self.kind, kk, be.ptr(self.lw), self.n, self.shift, be.ptr(self.partials),
+                                   self._rows(t), be.ptr(self.maxs[t:t + 1]),
+                                   be.ptr(self.totals[t:t + 1]), be.ptr(self.anc), be.ptr(self.rs_ws),
+                                   be.stream()), "gmx_resample")
+
+    def _chain_step(self, t, skip_vm=False):
+        """everything step t launches on the chain (noise-ahead form): site program', then the resampler"""
+        if not skip_vm:
+            if t >= 1 and self.fuse_mh:
+                self._launch_mhvm(t)
+            else:
+                self._launch_vm(t)
+        if self.fused:
+            self._launch_resample(t)
+        else:
+            self._launch_cdf(t)
+            self._launch_anc(t)
+
+    def enqueue(self, skip_vm=False):
+        """Issue every launch of the sweep on the current stream (no syncs, no allocations).
+        skip_vm=True leaves the site-program launches out (the resampling kernels then run on the
+        previous sweep's log-weights): bench.py times that variant to get the site program's cost
+        IN the sweep as a difference."""
+        if self.noise_ahead:
+            return self._enqueue_noise_ahead(skip_vm)
+        for t in range(self.T):
+            if t >= 1 and self.fuse_mh:
+                if not skip_vm:
+                    self._launch_mhvm(t)
+            else:
+                if t >= 1 and self.rejuvenate is not None:
+                    self._launch_mh(t)
+                if not skip_vm:
+                    self._launch_vm(t)
+            if self.fuse and t < self.T - 1:
+                continue                   # step t's weights are resampled by step t+1's launch itself
+            if self.fused:
+                self._launch_resample(t)
+            else:
+                self._launch_cdf(t)
+                self._launch_anc(t)
+
+    def kernel_timers(self):
+        """Representative single launches (a mid-sweep step) for per-kernel timing in bench.py."""
+        t = max(1, self.T // 2)
+        out = {"k_vm": lambda: self._launch_vm(t)}
+        if self.noise_ahead:
+            out["k_noise"] = lambda: self._launch_noise(t)
+        if self.fused and self.tile_stats:
+            out["k_offspring_tile"] = lambda: self._launch_resample(t)
+        elif self.fused:
+            out["resample(k_tile_stats+k_offspring_tile)"] = lambda: self._launch_resample(t)
+        else:
+            out["k_weight_cdf"] = lambda: self._launch_cdf(t)
+            out["k_ancestors"] = lambda: self._launch_anc(t)
+        return out
+
+    def capture(self):
+        """Capture enqueue() into a hipGraph (launch-bound: ~5 nodes per step)."""
+        be = _lib.get()
+        from ctypes import c_void_p
+        s = torch.cuda.Stream(device=be.device)
+        s.wait_stream(torch.cuda.current_stream(be.device))
+        with torch.cuda.stream(s):
+            self.enqueue()          # warm-up outside capture (program upload, lazy init)
+            s.synchronize()
+            be.check(be.c.gmx_capture_begin(be.stream()), "gmx_capture_begin")
+            try:
+                self.enqueue()
+            finally:
+                h = c_void_p()
+                rc = be.c.gmx_capture_end(be.stream(), h)
+            be.check(rc, "gmx_capture_end")
+        torch.cuda.current_stream(be.device).wait_stream(s)
+        self.graph = h
+        return self
+
+    def launch(self):
+        be = _lib.get()
+        if self.graph is None:
+            self.enqueue()
+        else:
+            be.check(be.c.gmx_graph_launch(self.graph, be.stream()), "gmx_graph_launch")
+
+    def log_ml(self) -> float:
+        """sum_t [ ref(M_t) + log(total_t * 2^-shift) - log N ] in float64 (synchronises)."""
+        m = np.array([cdf_reference(v) for v in self.maxs.cpu().numpy()], dtype=np.float64)
+        tot = self.totals.cpu().numpy().view(np.uint64).astype(np.float64)
+        if np.any(tot == 0):             # a step where no particle carried any mass
+            return -math.inf
+        return float(np.sum(m + np.log(tot) - self.shift * math.log(2.0) - math.log(self.n)))
+
+    def state(self):
+        """(x_T particles before the last resampling, log-weights, last ancestors)."""
+        return self.x[(self.T - 1) % 2], self.lw_pp[(self.T - 1) % 2], self.anc

@@ -11,7 +11,8 @@ from .core.generative import (Diff, DiffAnnotate, EditRequest, EmptyRequest, Gen
                               GenerativeFunctionClosure, IndexRequest, NoChange, NotSupportedEditRequest, Regenerate,
                               Trace, UnknownChange, Update)
 from .core.generative import Argdiffs, Arguments, Retdiff, Score, VectorRequest, Weight
-from .core.mask import Mask
+from .core.mask import Indexed, Mask
+from .core.choice_map import DynamicIndex, dynamic_index
 from .core.pytree import Closure, Const, PythonicPytree, Pytree, R, nth
 from .distributions import (Distribution, bernoulli, beta, categorical, dirichlet, exact_density, flip, half_cauchy,
                             half_normal, log_normal, normal, tfp_distribution, uniform)
@@ -43,5 +44,5 @@ __all__ = [
     "VectorRequest", "Argdiffs", "Arguments", "Retdiff", "Score", "Weight", "Address", "AddressComponent", "R",
     "Closure", "Const", "PythonicPytree", "Pytree", "nth", "exact_density", "tfp_distribution", "half_cauchy",
     "half_normal", "log_normal", "Algorithm", "SampleDistribution", "Marginal", "marginal", "trace_p", "clear_caches",
-    "iterate", "iterate_final", "accumulate", "reduce",
+    "iterate", "iterate_final", "accumulate", "reduce", "Indexed", "DynamicIndex", "dynamic_index",
 ]

@@ -176,7 +176,11 @@ def _index_chm(chm: ChoiceMap, j, n):
         chm = ChoiceMap(chm._value, {a: c for a, c in chm._children.items() if not isinstance(a, int)})
 
     def pick(v):
-        from .core.mask import Mask
+        from .core.mask import Indexed, Mask
+        if isinstance(v, Indexed):         # a run-time index: element j is constrained where idx == j
+            idx = v.idx.value if isinstance(v.idx, Sym) else v.idx
+            val = v.value.value if isinstance(v.value, Sym) else v.value
+            return Mask(val, idx == j)
         if isinstance(v, Mask):            # a masked constraint on the whole plate: element j of its value, same flag
             return Mask(pick(v.value), v.flag)
         if isinstance(v, Sym):
@@ -694,6 +698,11 @@ def _loop_step_constraint(chm: ChoiceMap, t, n, at_step, what="scan of more than
     rest = ChoiceMap(chm._value, {a: c for a, c in chm._children.items() if not isinstance(a, int)}) if explicit else chm
 
     def pick(v):
+        from .core.mask import Indexed
+        if isinstance(v, Indexed):         # a run-time index: this iteration's element is constrained where idx == t
+            idx = v.idx.value if isinstance(v.idx, Sym) else v.idx
+            val = v.value.value if isinstance(v.value, Sym) else v.value
+            return Mask(val, idx == t)
         inner = v.value if isinstance(v, Sym) else v
         if isinstance(inner, (RuntimeTable, TableArray, StepInput)) and inner.shape[0] == n:
             return inner[t]
@@ -717,6 +726,10 @@ def _loop_step_constraint(chm: ChoiceMap, t, n, at_step, what="scan of more than
         val, flag = None, None
         for i, v in items:
             here = t == i
+            if isinstance(v, Mask):            # an already masked constraint at step i: both conditions must hold
+                mflag = v.flag.value if isinstance(v.flag, Sym) else v.flag
+                here = here & mflag
+                v = v.value.value if isinstance(v.value, Sym) else v.value
             val = v if val is None else T.where(here, v, val)
             flag = here if flag is None else (flag | here)
         out = out.set(a, Mask(val, flag))

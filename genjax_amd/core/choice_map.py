@@ -17,6 +17,24 @@ from __future__ import annotations
 from typing import Any, Callable
 
 
+class DynamicIndex:
+    """`C["ys", dynamic_index(idx), "y"].set(v)`: a RUN-TIME index, one per particle (or one, known only on the
+    device) — unlike a concrete array of indices, which names several static elements.  `transforms.vmap` tags the
+    integer tensors it maps (engine.Mapped), so under `genjax.vmap` the reference's plain spelling
+    `C["ys", idx, "y"].set(v)` means this."""
+    __slots__ = ("idx",)
+
+    def __init__(self, idx):
+        self.idx = idx
+
+    def __repr__(self):
+        return "dynamic_index(...)"
+
+
+def dynamic_index(idx) -> DynamicIndex:
+    return DynamicIndex(idx)
+
+
 class _IndexArray:
     """An array-of-indices address component (hashable wrapper: address tuples are dict keys)."""
     __slots__ = ("idx",)
@@ -30,8 +48,10 @@ class _IndexArray:
 
 def _index_array(a):
     """a 1-D integer array / list used as an address component, else None"""
-    if isinstance(a, _IndexArray):
+    if isinstance(a, (_IndexArray, DynamicIndex)):
         return a
+    if getattr(a, "_gmx_mapped", False) and "int" in str(getattr(a, "dtype", "")):
+        return DynamicIndex(a)             # an integer tensor mapped by genjax.vmap: one index per instance
     if isinstance(a, (str, int, bytes)) or a is Ellipsis or isinstance(a, slice) or isinstance(a, tuple):
         return None
     if isinstance(a, list) and a and all(isinstance(i, (int,)) and not isinstance(i, bool) for i in a):
@@ -47,7 +67,7 @@ def _norm(addr) -> tuple:
         out = ()
         for a in addr:
             out += _norm(a)
-        if sum(isinstance(a, _IndexArray) for a in out) > 1:
+        if sum(isinstance(a, (_IndexArray, DynamicIndex)) for a in out) > 1:
             raise ValueError("an address may hold at most one array of indices (choice_map.py:699-749)")
         return out
     ia = _index_array(addr)
@@ -390,6 +410,15 @@ class ChoiceMap:
         head, rest = addr[0], addr[1:]
         if isinstance(head, _Slice):
             raise ValueError("partial slices are not allowed when setting (choice_map.py:699-749); use `:`")
+        if isinstance(head, DynamicIndex):
+            # a run-time index: the constraint sits at the plate's own address as Indexed(value, idx); the plate turns
+            # it into Mask(value, idx == j) for its element j
+            from .mask import Indexed
+            if any(isinstance(a, (DynamicIndex, _IndexArray)) for a in rest):
+                raise ValueError("an address may hold at most one array of indices (choice_map.py:699-749)")
+            wrap = (lambda x: Indexed(x, head.idx))
+            return self.set(rest, v.map_values(wrap) if isinstance(v, ChoiceMap) else Indexed(v, head.idx)) if rest else \
+                self.merge_over(v.map_values(wrap) if isinstance(v, ChoiceMap) else ChoiceMap(value=Indexed(v, head.idx)))
         kids = dict(self._children)
         if isinstance(head, _IndexArray):
             # Indexed (choice_map.py:1453-1531) with a static index array: element idx[k] takes v[k]

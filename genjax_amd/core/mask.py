@@ -39,6 +39,20 @@ class Mask:
     __hash__ = object.__hash__
 
 
+class Indexed:
+    """A constraint on ONE element of a plate chosen at run time: `C["ys", idx, "y"].set(v)` with `idx` a per-particle
+    index (the reference's `Indexed` choice map with a traced index, choice_map.py:1453-1531): element idx of the
+    plate's "y" takes the value v.  Inside the plate it is the masked constraint `Mask(v, idx == j)` for element j
+    (`Indexed.get_inner_map`, :1508-1531) — resolved in combinators._index_chm / _loop_step_constraint."""
+    __slots__ = ("value", "idx")
+
+    def __init__(self, value, idx):
+        self.value, self.idx = value, idx
+
+    def __repr__(self):
+        return f"Indexed({self.value!r} at {self.idx!r})"
+
+
 def _same(a, b):
     try:
         import numpy as np

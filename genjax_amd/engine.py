@@ -27,7 +27,7 @@ import torch
 
 from . import _lib
 from .core.choice_map import ChoiceMap
-from .core.mask import Mask
+from .core.mask import Indexed, Mask
 from .program import F_BCAST, F_GATHER, Graph, compile_graph
 from .random import Key
 from .tracer import Expr
@@ -104,7 +104,27 @@ class Broadcast(torch.Tensor):
         return mark(out)
 
 
+class Mapped(torch.Tensor):
+    """A tensor `genjax.vmap` maps over its leading axis (one entry per instance).  Only a tag: an integer tensor
+    carrying it, used as an address component (`C["ys", idx, "y"].set(v)`), is a RUN-TIME per-instance index
+    (core.choice_map.DynamicIndex) rather than a static array of indices."""
+    _gmx_mapped = True
+
+    @staticmethod
+    def __new__(cls, t):
+        return t if isinstance(t, Mapped) else t.as_subclass(cls)
+
+    def __init__(self, t):
+        pass
+
+    @property
+    def plain(self) -> torch.Tensor:
+        return self.as_subclass(torch.Tensor)
+
+
 def materialize(v):
+    if isinstance(v, Mapped):
+        return v.plain
     if isinstance(v, Broadcast):
         return v.plain
     return v.materialize() if isinstance(v, Gathered) else v
@@ -244,6 +264,8 @@ class Flat:
                 else:
                     items.append((f_.name, self.add(x)))
             return ("dc", type(v), tuple(items))
+        if isinstance(v, Indexed):            # a run-time plate index (core/mask.py): value + index, both launch values
+            return ("indexed", self.add(v.value), self.add(v.idx))
         if isinstance(v, Mask):
             # a runtime-conditional constraint (distribution.py:129-142): a flag known on the host resolves now
             if isinstance(v.flag, (bool, np.bool_)):
@@ -292,6 +314,8 @@ def unflatten(tree, fn):
         return Mask(unflatten(tree[1], fn), unflatten(tree[2], fn))
     if kind == "mask_static":
         return Mask(unflatten(tree[2], fn), tree[1])
+    if kind == "indexed":
+        return Indexed(unflatten(tree[1], fn), unflatten(tree[2], fn))
     if kind == "dc":
         return _make_dataclass(payload, {name: (t[2] if t[0] == "static_field" else unflatten(t, fn)) for name, t in tree[2]})
     raise ValueError(kind)

@@ -56,7 +56,7 @@ def vmap(f=None, in_axes=0, out_axes=0):
     if isinstance(f, GenerativeFunction):
         from .combinators import Vmap
         return Vmap(f, in_axes)
-    from .engine import Broadcast
+    from .engine import Broadcast, Mapped
 
     def wrapped(*args):
         axes = in_axes if isinstance(in_axes, (tuple, list)) else (in_axes,) * len(args)
@@ -69,7 +69,9 @@ def vmap(f=None, in_axes=0, out_axes=0):
                 if t.ndim == 0:
                     raise ValueError("vmap: cannot map over a 0-d tensor (use in_axes=None)")
                 sizes.add(int(t.shape[ax]))
-                return torch.movedim(t, ax, 0) if ax != 0 else t
+                t = torch.movedim(t, ax, 0) if ax != 0 else t
+                # integer tensors keep a tag: as an address component they are one RUN-TIME index per instance
+                return Mapped(t) if t.dtype in (torch.int32, torch.int64) else t
             return go
         new = []
         for a, ax in zip(args, axes):

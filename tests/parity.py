@@ -1488,3 +1488,47 @@ def check_batched_csmc(k=33, B=1000, seed=11):
     w_host, chm_host = marg._random_weighted_over_keys(keys[:nb], ())
     assert torch.equal(chm_dev["p"], chm_host["p"].to(chm_dev["p"].device))
     assert float((w_dev - w_host.to(w_dev.device)).abs().max()) <= 1e-5
+
+
+def check_runtime_indexed(n=257, seed=13):
+    """Run-time `Indexed` addresses (ref choice_map.py:1453-1531 with a traced index): one plate
+    index PER PARTICLE — `C["schools", dynamic_index(idx), "y"].set(v)`, and the reference's plain spelling
+    `C["schools", idx, "y"].set(v)` under `genjax.vmap`.  Inside the plate it is `Mask(v, idx == j)` at element j:
+    equal to writing those masks out by hand (small plate), and — for a plate run as a counted loop — the weight is
+    the density of v at the indexed element, the other elements are sampled as without the constraint."""
+    import genjax_amd as G
+    from genjax_amd import ChoiceMapBuilder as C, Mask, numpy as jnp
+    dev = G._lib.get().device
+    school = _school(G)
+    rng = np.random.default_rng(seed)
+    for P in (8, 40):
+        sig = np.linspace(1.0, 3.0, P).astype(np.float32)
+
+        @G.gen
+        def m():
+            mu = G.normal(0.0, 5.0) @ "mu"
+            return school.vmap(in_axes=(None, None, 0))(mu, 2.0, jnp.array(sig)) @ "schools"
+        idx_h = rng.integers(0, P, n).astype(np.int32)
+        vals_h = rng.normal(0, 1, n).astype(np.float32)
+        idx, vals = torch.from_numpy(idx_h).to(dev), torch.from_numpy(vals_h).to(dev)
+        keys = G.split(G.key(seed), n)
+        tr, w = m.importance(keys, C["schools", G.dynamic_index(idx), "y"].set(vals), ())
+        y = tr.get_choices()["schools", "y"].cpu().numpy()
+        th = tr.get_choices()["schools", "theta"].cpu().numpy()
+        rows = np.arange(n)
+        assert np.array_equal(y[rows, idx_h], vals_h)                              # the indexed element took the value
+        w_ref = O.normal.assess(O.C.choice(vals_h), (th[rows, idx_h], sig[idx_h]), (n,))[0]
+        assert np.array_equal(w.cpu().numpy(), w_ref)                              # and the weight is its density alone
+        free = m.simulate(keys, ())                                                # same keys, no constraint
+        yf = free.get_choices()["schools", "y"].cpu().numpy()
+        mask = np.ones((n, P), bool)
+        mask[rows, idx_h] = False
+        assert np.array_equal(y[mask], yf[mask])                                   # the other elements: as sampled
+        w3 = G.vmap(lambda k, i, v: m.importance(k, C["schools", i, "y"].set(v), ())[1])(keys, idx, vals)
+        assert torch.equal(w3, w)                                                  # the reference's spelling, vmapped
+        if P <= 16:
+            con = C.n()
+            for j in range(P):
+                con = con.set(("schools", j, "y"), Mask(vals, idx == j))
+            tr2, w2 = m.importance(keys, con, ())
+            assert torch.equal(w, w2) and torch.equal(tr.get_choices()["schools", "y"], tr2.get_choices()["schools", "y"])

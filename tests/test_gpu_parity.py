@@ -783,6 +783,12 @@ def test_long_scan_config2_as_one_generative_function(gpu):
     assert abs(r["log_ml_is"] - r["kalman"]) < 0.25, r         # prior-proposal IS over 18 steps: MC error ~0.1
 
 
+def test_runtime_indexed_addresses(gpu):
+    """`C["schools", idx, "y"].set(v)` with one index per particle (ref choice_map.py:1453-1531)"""
+    parity.check_runtime_indexed(n=257)
+    parity.check_runtime_indexed(n=100_000, seed=3)
+
+
 def test_conditional_smc_under_a_batch_of_keys(gpu):
     """`vmap(alg.estimate_logpdf)` over 1 000 keys as ONE launch set over [keys, K] (retained
     particle in slot K-1 of every row), incl. ChangeTarget.run_csmc, the reciprocal normalising constant and a nested

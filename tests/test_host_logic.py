@@ -540,6 +540,12 @@ def test_conditional_smc_and_proposals():
     parity.check_csmc(k=257)
 
 
+def test_runtime_indexed_addresses():
+    """ref choice_map.py:1453-1531 with a traced index: one plate index per particle"""
+    from tests import parity
+    parity.check_runtime_indexed()
+
+
 def test_conditional_smc_under_a_batch_of_keys():
     """ref smc.py:317-351, 398-465, sp.py:217-240 under vmap: one launch set over [keys, K]"""
     from tests import parity

@@ -46,6 +46,146 @@ class TorchComm:
     graph_safe = False
 
 
+def _alloc_plain(self, shape, dtype=torch.float32):
+    """destination buffers of collectives: ordinary device memory for the library communicators"""
+    from .. import _lib
+    return torch.zeros(tuple(shape), dtype=dtype, device=_lib.get().device)
+
+
+TorchComm.alloc = _alloc_plain
+
+
+class _RawTensor:
+    """a raw device / shared-memory allocation as a tensor (no copy): __cuda_array_interface__ on the GPU, the numpy
+    buffer protocol on the CPU mirror"""
+
+    def __init__(self, ptr: int, nbytes: int, on_gpu: bool):
+        self.ptr, self.nbytes = int(ptr), int(nbytes)
+        if on_gpu:
+            self.__cuda_array_interface__ = {"shape": (self.nbytes,), "typestr": "|u1", "data": (self.ptr, False),
+                                             "version": 2, "strides": None}
+
+    def tensor(self, device):
+        if device.type == "cuda":
+            return torch.as_tensor(self, device=device)
+        import numpy as np
+        buf = (ctypes.c_uint8 * self.nbytes).from_address(self.ptr)
+        return torch.from_numpy(np.frombuffer(buf, dtype=np.uint8))
+
+
+class P2PComm:
+    """GENMI_COMM=p2p — the collectives of a sharded SMC step as ONE launch each over peer-mapped memory
+    (include/genmi.h "Peer-mapped exchange"): every destination buffer comes from `alloc` (fine-grained
+    device memory, IPC-mapped into every peer), a collective copies this rank's blocks straight into its peers'
+    buffers over xGMI, raises a flag per peer and waits for its own flags.  No RCCL kernel, no host involvement, and —
+    since the epoch lives on the device — capturable into the sweep's hipGraph.
+    Status: world size 1 runs on the device; world sizes 2 and 4 run through the tests' CPU mirror over process-shared
+    memory (tests/test_distributed_cpu.py); across GPUs it is UNMEASURED (no multi-GPU box in the build loop)."""
+
+    name = "p2p (peer-mapped xGMI, one launch per collective)"
+    graph_safe = True
+
+    def __init__(self, dist, device: torch.device):
+        from .. import _lib
+        self.be = _lib.get()
+        self.dist, self.device = dist, device
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self._allocs = []        # (base ptr, nbytes, [peer base ptrs], raw keep-alives)
+        self._ptr_tables = {}
+        W = self.world
+        # one flag row per EXCHANGE SLOT would be the general design; the sharded step alternates two exchanges, which
+        # is what makes one row + one epoch sufficient (include/genmi.h)
+        self.flags = self.alloc((W,), torch.int64)
+        self.state = torch.zeros((3,), dtype=torch.int64, device=device)
+        self._flag_table = self._peer_table(self.flags)
+
+    # -- memory ----------------------------------------------------------------------------------
+    def alloc(self, shape, dtype=torch.float32):
+        """a zeroed tensor every peer can write into; COLLECTIVE (the IPC handles are all-gathered)"""
+        n = 1
+        for d in shape:
+            n *= int(d)
+        item = torch.empty((), dtype=dtype).element_size()
+        nbytes = max(16, ((n * item + 15) // 16) * 16)
+        ptr = c_void_p()
+        handle = (ctypes.c_uint8 * 64)()
+        self.be.check(self.be.c.gmx_p2p_alloc(nbytes, byref(ptr), handle), "gmx_p2p_alloc")
+        peers = [ptr.value] * self.world
+        opened = []
+        if self.world > 1:
+            mine = torch.tensor(list(handle), dtype=torch.uint8)
+            gathered = [torch.zeros(64, dtype=torch.uint8) for _ in range(self.world)]
+            if self.device.type == "cuda":
+                g_dev = [t.to(self.device) for t in gathered]
+                self.dist.all_gather(g_dev, mine.to(self.device))
+                gathered = [t.cpu() for t in g_dev]
+            else:
+                self.dist.all_gather(gathered, mine)
+            for s_, h in enumerate(gathered):
+                if s_ == self.rank:
+                    continue
+                hb = (ctypes.c_uint8 * 64)(*h.tolist())
+                p = c_void_p()
+                self.be.check(self.be.c.gmx_p2p_open(hb, byref(p)), "gmx_p2p_open")
+                peers[s_] = p.value
+                opened.append(p.value)
+        raw = _RawTensor(ptr.value, nbytes, self.device.type == "cuda")
+        flat = raw.tensor(self.device)
+        self._allocs.append((ptr.value, nbytes, peers, raw, opened))
+        return flat[:n * item].view(dtype).reshape(tuple(shape))
+
+    def _peer_table(self, t: torch.Tensor) -> torch.Tensor:
+        """device array [world] of the peers' addresses of `t` (a view into one of this communicator's allocations)"""
+        key = (t.data_ptr(),)
+        tab = self._ptr_tables.get(key)
+        if tab is None:
+            p = t.data_ptr()
+            for base, nbytes, peers, _raw, _o in self._allocs:
+                if base <= p < base + nbytes:
+                    tab = torch.tensor([q + (p - base) for q in peers], dtype=torch.int64).to(self.device)
+                    break
+            else:
+                raise RuntimeError("P2PComm: the destination of a collective must come from comm.alloc(...)")
+            self._ptr_tables[key] = tab
+        return tab
+
+    # -- collectives ------------------------------------------------------------------------------
+    def _exchange(self, out, inp, stride_bytes, nbytes):
+        be = self.be
+        be.check(be.c.gmx_p2p_exchange(be.ptr(inp), stride_bytes, be.ptr(self._peer_table(out)), be.ptr(self._flag_table),
+                                       be.ptr(self.flags), be.ptr(self.state), self.rank, self.world, nbytes, be.stream()),
+                 "gmx_p2p_exchange")
+
+    def all_gather(self, out, inp):
+        assert out.is_contiguous() and inp.is_contiguous()
+        nbytes = inp.numel() * inp.element_size()
+        assert out.numel() * out.element_size() == self.world * nbytes
+        self._exchange(out, inp, 0, nbytes)
+
+    def all_to_all(self, out, inp):
+        assert out.is_contiguous() and inp.is_contiguous() and inp.numel() % self.world == 0
+        nbytes = inp.numel() * inp.element_size() // self.world
+        self._exchange(out, inp, nbytes, nbytes)
+
+    def all_reduce_max(self, t):
+        """the once-per-sweep overflow flag: off the hot path, through torch.distributed"""
+        if self.world > 1:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+
+    def failed(self) -> bool:
+        return bool(int(self.state[1].item()) != 0)
+
+    def destroy(self):
+        for base, _n, _peers, _raw, opened in self._allocs:
+            for p in opened:
+                self.be.c.gmx_p2p_close(c_void_p(p))
+        if self.world > 1:
+            self.dist.barrier()                # nobody unmaps a segment a peer may still be writing
+        for base, _n, _peers, _raw, _o in self._allocs:
+            self.be.c.gmx_p2p_free(c_void_p(base))
+        self._allocs = []
+
+
 class _UniqueId(Structure):
     _fields_ = [("internal", c_char * 128)]
 
@@ -112,6 +252,8 @@ class RcclComm:
             self.lib.ncclCommDestroy(self.comm)
             self.comm = None
 
+    alloc = _alloc_plain
+
 
 def _selftest(comm, device):
     """The three collectives on known patterns (a few bytes each): a communicator that answers wrongly is
@@ -165,6 +307,9 @@ def make_comm(dist, device: torch.device):
     Bootstrap and self-test run under a deadline (GENMI_COMM_TIMEOUT seconds, default 120; see _Deadline)."""
     want = os.environ.get("GENMI_COMM", "rccl" if device.type == "cuda" else "torch")
     timeout = float(os.environ.get("GENMI_COMM_TIMEOUT", "120"))
+    if want == "p2p":
+        with _Deadline(timeout, "the peer-mapped communicator bootstrap"):
+            return P2PComm(dist, device)
     if want != "rccl" or device.type != "cuda":
         comm = TorchComm(dist)
         with _Deadline(timeout, "the torch.distributed communicator self-test"):

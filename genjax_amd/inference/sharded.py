@@ -150,13 +150,15 @@ class ShardedBootstrapSweep(_NoiseAhead):
         self.maxs = torch.zeros((T,), dtype=torch.float32, device=dev)           # global max per step
         self.totals = torch.zeros((T,), dtype=torch.int64, device=dev)            # global integer total per step
         self.total_d = torch.zeros((1,), dtype=torch.int64, device=dev)
-        self.totals_all = torch.zeros((W,), dtype=torch.int64, device=dev)
+        self.totals_all = None      # (allocated below, once the communicator exists: a collective's destination)
         self.plan = torch.zeros((int(be.c.gmx_shard_plan_words(W)),), dtype=torch.int64, device=dev)
         self.ws = torch.zeros(((be.c.gmx_weight_cdf_workspace(n) + 7) // 8,), dtype=torch.int64, device=dev)
         self.shift = cdf_shift(self.N)
         if self.comm and self.cx is None:
             from .comm import make_comm
             self.cx = make_comm(self.dist, dev)
+        self.totals_all = self.cx.alloc((W,), torch.int64) if self.cx is not None else \
+            torch.zeros((W,), dtype=torch.int64, device=dev)
         obs0 = ChoiceMap.empty().set(self.obs_addr, self.ys[0])
         self.p_init = MinimalGenerate(self.init, (), obs0, (n,))
         # the state is the model's return value: a float scalar, or ONE vector of D floats per particle kept
@@ -203,7 +205,8 @@ class ShardedBootstrapSweep(_NoiseAhead):
             tiles = (n + CDF_TILE - 1) // CDF_TILE
             pad = tiles + (tiles & 1)
             self.stats_own = torch.zeros((sb,), dtype=torch.uint8, device=dev)
-            self.stats_all = torch.zeros((W * sb,), dtype=torch.uint8, device=dev)
+            self.stats_all = self.cx.alloc((W * sb,), torch.uint8) if self.cx is not None else \
+                torch.zeros((W * sb,), dtype=torch.uint8, device=dev)
             self.tile_agg = self.stats_own[:pad * 8].view(torch.int64)
             self.tile_max = self.stats_own[pad * 8:].view(torch.float32)
         self.step_keys = []
@@ -215,14 +218,17 @@ class ShardedBootstrapSweep(_NoiseAhead):
     def _alloc_exchange(self):
         dev, n, W, C = _lib.get().device, self.n, self.world, self.capacity
         # extended state, double-buffered: [ n local | W*C received ]; ancestors index into it
-        self.xrows = [torch.zeros((self.D, n + W * C), dtype=torch.float32, device=dev) for _ in range(2)]
+        # destinations of collectives come from the communicator (peer-mapped memory under GENMI_COMM=p2p)
+        mk = (lambda shape, dt=torch.float32: self.cx.alloc(shape, dt)) if self.cx is not None else \
+            (lambda shape, dt=torch.float32: torch.zeros(shape, dtype=dt, device=dev))
+        self.xrows = [mk((self.D, n + W * C)) for _ in range(2)]
         self.xext = [r[0] for r in self.xrows]                    # component 0 (THE state when it is a scalar)
         self.send = torch.zeros((self.D, W * C), dtype=torch.float32, device=dev)
         self.idx = torch.zeros((n,), dtype=torch.int32, device=dev)
         if self.rejuvenate is not None:
             # aext[t % 2][:n] = the MH-moved, resampled state step t is extended from; its tail receives the
             # remote copies of it when it travels as the second routed leaf of the NEXT resampling
-            self.arows = [torch.zeros((self.D, n + W * C), dtype=torch.float32, device=dev) for _ in range(2)]
+            self.arows = [mk((self.D, n + W * C)) for _ in range(2)]
             self.send2 = torch.zeros((self.D, W * C), dtype=torch.float32, device=dev)
         self._bound = [None] * self.T
 
@@ -508,6 +514,9 @@ class CountingComm:
         self.counts["all_to_all"] += 1
         return self.inner.all_to_all(out, inp)
 
+    def alloc(self, shape, dtype=torch.float32):
+        return self.inner.alloc(shape, dtype)
+
 
 def sharded_importance_resample(target, k_per_rank: int, key: Key, dist, kind="systematic", capacity=None, comm=None,
                                 stats: dict | None = None):
@@ -550,7 +559,9 @@ def sharded_importance_resample(target, k_per_rank: int, key: Key, dist, kind="s
     kh = key.host()                                                  # resampling key: the algorithm's leftover `key`
     kk = (c_uint32 * 2)(int(kh[0]), int(kh[1]))
     mx = torch.empty((1,), dtype=torch.float32, device=dev)
-    totals_all = torch.zeros((W,), dtype=torch.int64, device=dev)
+    calloc = (lambda shape, dt: comm.alloc(shape, dt)) if (comm is not None and hasattr(comm.inner, "alloc")) else \
+        (lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev))          # destinations of collectives
+    totals_all = calloc((W,), torch.int64)
     gtotal = torch.zeros((1,), dtype=torch.int64, device=dev)
     tiles_form = kind in (0, 1) and n <= FUSED_RESAMPLE_MAX and W <= 64 and os.environ.get("GENMI_SHARD_TILES", "1") != "0"
     if tiles_form:
@@ -558,7 +569,7 @@ def sharded_importance_resample(target, k_per_rank: int, key: Key, dist, kind="s
         tiles = (n + 1023) // 1024
         pad = tiles + (tiles & 1)
         stats_own = torch.zeros((nbytes,), dtype=torch.uint8, device=dev)
-        stats_all = torch.zeros((W * nbytes,), dtype=torch.uint8, device=dev)
+        stats_all = calloc((W * nbytes,), torch.uint8)
         be.check(be.c.gmx_tile_stats(be.ptr(lw), n, shift, be.ptr(stats_own[pad * 8:]), be.ptr(stats_own), be.stream()),
                  "gmx_tile_stats")
         if W > 1:
@@ -633,7 +644,7 @@ def sharded_importance_resample(target, k_per_rank: int, key: Key, dist, kind="s
     # ---- pack by destination, ONE all-to-all, one gather ----
     if W > 1 and R:
         packed = table[:, send_idx.long()].reshape(R, W, C).permute(1, 0, 2).contiguous()          # [W, R, C]
-        recv = torch.empty_like(packed)
+        recv = calloc(tuple(packed.shape), packed.dtype)
         comm.all_to_all(recv.view(-1), packed.view(-1))
         ext = torch.cat([table, recv.permute(1, 0, 2).reshape(R, W * C)], dim=1)                   # [R, n + W*C]
     else:

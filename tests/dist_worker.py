@@ -31,8 +31,12 @@ def schools_main(out_path, k_per_rank, capacity):
         _ = G.normal(theta, jnp.array(parity.SCHOOL_SIGMA)) @ "y"
         return theta
     info = {}
+    comm = None
+    if os.environ.get("GENMI_COMM") == "p2p":
+        from genjax_amd.inference.comm import make_comm
+        comm = make_comm(dist, G._lib.get().device)
     coll, lw = sharded_importance_resample(G.Target(schools, (), C["y"].set(parity.SCHOOL_Y)), k_per_rank, G.key(2), dist,
-                                           capacity=capacity, stats=info)
+                                           capacity=capacity, stats=info, comm=comm)
     ch = coll.get_particles().get_choices()
     outs = {}
     for name in ("theta", "mu"):
@@ -88,7 +92,8 @@ def main(out_path, n_per_rank, T, capacity=None, mh=False, vec=False, vecmh=Fals
     if dist.get_rank() == 0:
         np.save(out_path + ".npy", torch.cat(xs).numpy())
         json.dump({"log_ml": sw.log_ml(), "totals": [str(t) for t in sw.totals.numpy().view(np.uint64).tolist()],
-                   "maxs": sw.maxs.tolist(), "reruns": sw.reruns, "capacity": sw.capacity},
+                   "maxs": sw.maxs.tolist(), "reruns": sw.reruns, "capacity": sw.capacity,
+                   "communicator": sw.cx.name if sw.cx is not None else None},
                   open(out_path + ".json", "w"))
     dist.destroy_process_group()
 

@@ -16,7 +16,7 @@ def build():
     if not os.path.exists(_SO) or any(os.path.getmtime(d) > os.path.getmtime(_SO) for d in deps):
         os.makedirs(os.path.dirname(_SO), exist_ok=True)
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-                               "-fno-fast-math", "-I", os.path.join(_HERE, "..", "..", "include"), src, "-o", _SO])
+                               "-fno-fast-math", "-I", os.path.join(_HERE, "..", "..", "include"), src, "-o", _SO, "-lrt"])
     return _SO
 
 
@@ -33,7 +33,7 @@ def build_sanitized():
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
         os.makedirs(os.path.dirname(so), exist_ok=True)
         subprocess.check_call(["g++", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math"] + SAN_FLAGS +
-                              ["-I", os.path.join(_HERE, "..", "..", "include"), src, "-o", so])
+                              ["-I", os.path.join(_HERE, "..", "..", "include"), src, "-o", so, "-lrt"])
     return so
 
 

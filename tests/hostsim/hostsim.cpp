@@ -13,6 +13,7 @@
 #include <math.h>
 #include <stdio.h>
 #include <string.h>
+#include <unistd.h>
 
 #include <vector>
 
@@ -512,6 +513,78 @@ extern "C" int gmx_shard_step_fused(int kind, const uint32_t key[2], const void*
   const void* own = (const uint8_t*)stats_all + (size_t)rank * gmx_shard_stats_bytes(n);
   return gmx_shard_step_tiles(kind, key, totals.data(), plan, total_out, lw, own, max_out, shift, rank, world, n, cap, state,
                               send, next_idx, st);
+}
+// ---- peer-mapped exchange: the same protocol over PROCESS-SHARED memory (POSIX shm), so that the gloo ranks of the CPU
+// tests really write into each other's buffers and wait on each other's flags ----
+#include <fcntl.h>
+#include <sched.h>
+#include <sys/mman.h>
+#include <time.h>
+struct hs_shm { char name[48]; uint64_t bytes; };
+static_assert(sizeof(hs_shm) <= GMX_P2P_HANDLE_BYTES, "handle");
+#include <map>
+static std::map<void*, hs_shm> g_shm;
+extern "C" int gmx_p2p_alloc(size_t bytes, void** ptr_out, void* handle_out) {
+  if (!ptr_out || !handle_out || !bytes) return fail("p2p_alloc: bad argument");
+  static int counter = 0;
+  hs_shm h; memset(&h, 0, sizeof(h));
+  snprintf(h.name, sizeof(h.name), "/gmx_p2p_%d_%d_%ld", (int)getpid(), counter++, (long)time(nullptr));
+  h.bytes = bytes;
+  int fd = shm_open(h.name, O_CREAT | O_EXCL | O_RDWR, 0600);
+  if (fd < 0 || ftruncate(fd, (off_t)bytes) != 0) return fail("p2p_alloc: shm_open / ftruncate failed");
+  void* p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  close(fd);
+  if (p == MAP_FAILED) return fail("p2p_alloc: mmap failed");
+  memset(p, 0, bytes);
+  memset(handle_out, 0, GMX_P2P_HANDLE_BYTES);
+  memcpy(handle_out, &h, sizeof(h));
+  g_shm[p] = h;
+  *ptr_out = p;
+  return 0;
+}
+extern "C" int gmx_p2p_open(const void* handle, void** ptr_out) {
+  if (!handle || !ptr_out) return fail("p2p_open: null argument");
+  hs_shm h; memcpy(&h, handle, sizeof(h));
+  int fd = shm_open(h.name, O_RDWR, 0600);
+  if (fd < 0) return fail("p2p_open: shm_open failed");
+  void* p = mmap(nullptr, h.bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  close(fd);
+  if (p == MAP_FAILED) return fail("p2p_open: mmap failed");
+  hs_shm m = h; m.name[0] = 0;                   // a mapping of somebody else's segment: not ours to unlink
+  g_shm[p] = m;
+  *ptr_out = p;
+  return 0;
+}
+extern "C" int gmx_p2p_close(void* p) {
+  auto it = g_shm.find(p);
+  if (it != g_shm.end()) { munmap(p, it->second.bytes); g_shm.erase(it); }
+  return 0;
+}
+extern "C" int gmx_p2p_free(void* p) {
+  auto it = g_shm.find(p);
+  if (it != g_shm.end()) { if (it->second.name[0]) shm_unlink(it->second.name); munmap(p, it->second.bytes); g_shm.erase(it); }
+  return 0;
+}
+extern "C" int gmx_p2p_exchange(const void* src, size_t src_stride, void* const* dst_peers, uint64_t* const* flag_peers,
+                                uint64_t* flags_local, uint64_t* state, int rank, int world, size_t bytes, gmx_stream) {
+  if (!src || !dst_peers || !flag_peers || !flags_local || !state) return fail("p2p_exchange: null argument");
+  if (world < 1 || world > 64 || rank < 0 || rank >= world) return fail("p2p_exchange: rank / world out of range");
+  if (!bytes) return 0;
+  const uint64_t epoch = state[0] + 1;
+  for (int d = 0; d < world; ++d) {                                   // put, then announce (release)
+    memcpy((uint8_t*)dst_peers[d] + (size_t)rank * bytes, (const uint8_t*)src + (size_t)d * src_stride, bytes);
+    __atomic_store_n(flag_peers[d] + rank, epoch, __ATOMIC_RELEASE);
+  }
+  timespec t0; clock_gettime(CLOCK_MONOTONIC, &t0);
+  for (int d = 0; d < world; ++d) {                                   // wait for every peer's data (bounded)
+    while (__atomic_load_n(flags_local + d, __ATOMIC_ACQUIRE) < epoch) {
+      sched_yield();
+      timespec t1; clock_gettime(CLOCK_MONOTONIC, &t1);
+      if (t1.tv_sec - t0.tv_sec > 60) { state[1] = 1; return fail("p2p_exchange: a peer did not arrive within 60 s"); }
+    }
+  }
+  state[0] = epoch;
+  return 0;
 }
 extern "C" int gmx_gather(const void* const* src, void* const* dst, const int32_t* bytes, int32_t n_leaves,
                           const int32_t* anc, int64_t n_out, gmx_stream) {

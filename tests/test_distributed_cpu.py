@@ -71,6 +71,55 @@ def test_sharded_sweep_equals_single_process_oracle(tmp_path, world, capacity, t
     assert np.array_equal(x, ref["x"][ref["anc"]])
 
 
+@pytest.mark.parametrize("world,capacity,na", [(2, 0, "0"), (4, 3, "0"), (2, 0, "1")])
+def test_sharded_sweep_over_the_peer_mapped_communicator(tmp_path, world, capacity, na):
+    """GENMI_COMM=p2p (include/genmi.h "Peer-mapped exchange"; comm.P2PComm): every collective of the sharded step is
+    ONE exchange over peer-mapped memory — put into the peers' buffers, a flag per peer, a wait on the own flags; the
+    epoch lives with the flags.  The CPU mirror runs the protocol over POSIX shared memory, so the gloo ranks really
+    write into each other's buffers: world 2 and 4 (the latter through the capacity-overflow re-run, which re-allocates
+    the exchange buffers collectively) equal the single-process oracle bit for bit, also with noise ahead."""
+    from genjax_amd import workloads
+    n_total, T = 4096, 6
+    out = str(tmp_path / "shard_p2p")
+    r = _launch(world, [out, str(n_total // world), str(T)] + ([str(capacity)] if capacity else []),
+                extra_env={"GENMI_COMM": "p2p", "GENMI_TEST_NOISE_AHEAD": na, "GENMI_NOISE_GROUP": "3"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    x = np.load(out + ".npy")
+    meta = json.load(open(out + ".json"))
+    assert meta["communicator"].startswith("p2p")
+    ys = workloads.lgssm_data(T)
+    oi, ost = workloads.make_lgssm(O)
+    ref = parity.oracle_bootstrap_sweep(oi, ost, n_total, T, ys, O.key(314159))
+    assert [int(t) for t in meta["totals"]] == [h["total"] for h in ref["hist"]]
+    assert meta["log_ml"] == ref["log_ml"] and meta["reruns"] == (1 if capacity else 0)
+    assert np.array_equal(x, ref["x"][ref["anc"]])
+
+
+def test_sharded_importancek_over_the_peer_mapped_communicator(tmp_path):
+    """BASELINE config 4 sharded with GENMI_COMM=p2p: one all-gather (tile statistics) + ONE all-to-all of the packed
+    10-latent trace, both as peer-mapped exchanges"""
+    k_total, world = 4096, 2
+    out = str(tmp_path / "schools_p2p")
+    r = _launch(world, [out, str(k_total // world), "0", "0", "schools"], extra_env={"GENMI_COMM": "p2p"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    got = np.load(out + ".npz")
+    info = json.load(open(out + ".info.json"))
+    assert info["collectives"]["all_gather"] == 1 and info["collectives"]["all_to_all"] == 1
+    sig = np.array(parity.SCHOOL_SIGMA, np.float32)
+
+    @O.gen
+    def o_schools():
+        mu = O.normal(0.0, 5.0) @ "mu"
+        log_tau = O.normal(0.0, 1.0) @ "log_tau"
+        theta = O.normal(mu[..., None] * np.ones(8, np.float32), O.exp(log_tau)[..., None] * np.ones(8, np.float32)) @ "theta"
+        _ = O.normal(theta, sig) @ "y"
+        return theta
+    oc = O.ImportanceK(O.Target(o_schools, (), O.C.d({"y": parity.SCHOOL_Y})), k_total).run_smc(O.key(2))
+    cdf, total, M, shift = O.weight_cdf(oc.get_log_weights())
+    anc = O.ancestors(O.SYSTEMATIC, O.split(O.key(2))[0], cdf)
+    assert np.array_equal(got["theta"], oc.get_particles().get_choices()["theta"][anc])
+
+
 @pytest.mark.parametrize("world,capacity", [(2, 0), (4, 7)])
 def test_sharded_mh_sweep_equals_single_process_oracle(tmp_path, world, capacity):
     """BASELINE config 3 sharded: nonlinear SSM + one MH move per step, two routed leaves (the particle and

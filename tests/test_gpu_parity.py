@@ -410,6 +410,39 @@ def test_sharded_sweep_world1_matches_oracle(gpu):
     assert sw.log_ml() == ref["log_ml"]
 
 
+def test_sharded_sweep_over_the_peer_mapped_communicator_world1(gpu, monkeypatch):
+    """GENMI_COMM=p2p on the device at world size 1: the collectives of every step go through gmx_p2p_exchange (put into
+    the peer-mapped buffer — here the rank's own — flag, wait, device-side epoch), eagerly AND as a captured hipGraph
+    replayed twice (the epoch must advance across replays); equal to the oracle.  Across GPUs: unmeasured."""
+    import genjax_amd as G
+    from genjax_amd import workloads
+    from genjax_amd.inference.comm import P2PComm
+    from genjax_amd.inference.sharded import ShardedBootstrapSweep
+
+    class _Solo:
+        @staticmethod
+        def get_rank(): return 0
+        @staticmethod
+        def get_world_size(): return 1
+    monkeypatch.setenv("GENMI_COMM", "p2p")
+    n, T = 300_000, 5
+    ys = workloads.lgssm_data(T)
+    init, step = workloads.make_lgssm(G)
+    sw = ShardedBootstrapSweep(init, step, n, T, _Solo, always_communicate=True).prepare(G.key(314159), torch.from_numpy(ys))
+    assert isinstance(sw.cx, P2PComm) and sw.noise_ahead
+    oi, ost = workloads.make_lgssm(O)
+    ref = parity.oracle_bootstrap_sweep(oi, ost, n, T, ys, O.key(314159))
+    sw.launch()
+    assert np.array_equal(sw.state().cpu().numpy(), ref["x"][ref["anc"]]) and sw.log_ml() == ref["log_ml"]
+    sw.capture()
+    for _ in range(2):
+        sw.launch()
+        sw.finish()
+        assert np.array_equal(sw.state().cpu().numpy(), ref["x"][ref["anc"]]) and sw.log_ml() == ref["log_ml"]
+    assert not sw.cx.failed() and int(sw.cx.state[0].item()) == 3 * 2 * T          # two exchanges per step, three sweeps
+    sw.close()
+
+
 def test_conditional_smc_and_proposals(gpu):
     parity.check_csmc(k=10_001)
 

@@ -154,8 +154,8 @@ class Backend:
         c.gmx_p2p_open.argtypes = [c_void_p, POINTER(c_void_p)]
         c.gmx_p2p_close.argtypes = [c_void_p]
         c.gmx_p2p_free.argtypes = [c_void_p]
-        c.gmx_p2p_exchange.argtypes = [c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_size_t,
-                                       c_void_p]
+        c.gmx_p2p_exchange.argtypes = [c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_int, c_int, c_size_t, c_void_p]
         c.gmx_gather.argtypes = [POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int32), c_int32,
                                  c_void_p, c_int64, c_void_p]
         c.gmx_categorical_rows.argtypes = [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p]

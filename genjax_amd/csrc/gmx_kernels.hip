@@ -2399,41 +2399,63 @@ extern "C" int gmx_shard_step_fused(int kind, const uint32_t key[2], const void*
 // ---------------------------------------------------------------------------
 // peer-mapped exchange (include/genmi.h "Peer-mapped exchange"): one launch, one rendezvous per collective
 // ---------------------------------------------------------------------------
-#define GMX_P2P_SPIN_LIMIT (1u << 24)
+#define GMX_P2P_SPIN_LIMIT (1u << 22)
 __global__ void __launch_bounds__(GMX_BLOCK)
-k_p2p_exchange(const uint8_t* __restrict__ src, size_t src_stride, void* const* __restrict__ dst_peers,
-               uint64_t* const* __restrict__ flag_peers, uint64_t* __restrict__ flags_local, uint64_t* __restrict__ state,
-               uint32_t* __restrict__ ticket, int rank, int world, size_t bytes) {
+k_p2p_exchange(const uint8_t* __restrict__ src, size_t src_stride, void* const* __restrict__ land_peers,
+               const uint8_t* __restrict__ land_local, uint8_t* __restrict__ out, uint64_t* const* __restrict__ flag_peers,
+               uint64_t* __restrict__ flags_local, uint64_t* __restrict__ state, uint32_t* __restrict__ ticket, int rank,
+               int world, size_t bytes) {
+  __shared__ uint32_t s_ok;
   const int d = (int)blockIdx.x;                        // the peer this workgroup serves
   const uint64_t epoch = __hip_atomic_load(state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ull;
-  // ---- put: my block for peer d -> peer d's destination, slot `rank` ----
+  const size_t half = (size_t)(epoch & 1ull) * (size_t)world * bytes;      // landing buffers alternate by epoch parity
+  // ---- put: my block for peer d -> peer d's landing buffer, slot `rank` ----
   const uint8_t* s = src + (size_t)d * src_stride;
-  uint8_t* t = (uint8_t*)dst_peers[d] + (size_t)rank * bytes;
-  if ((((uintptr_t)s | (uintptr_t)t | bytes) & 15) == 0) {
+  uint8_t* t = (uint8_t*)land_peers[d] + half + (size_t)rank * bytes;
+  const bool wide = (((uintptr_t)s | (uintptr_t)t | bytes) & 15) == 0;
+  if (wide) {
     const uint4* s4 = reinterpret_cast<const uint4*>(s);
     uint4* t4 = reinterpret_cast<uint4*>(t);
     for (size_t i = threadIdx.x; i < bytes / 16; i += GMX_BLOCK) t4[i] = s4[i];
   } else {
     for (size_t i = threadIdx.x; i < bytes; i += GMX_BLOCK) t[i] = s[i];
   }
-  __threadfence_system();                               // every thread's stores are visible system-wide ...
-  __syncthreads();
+  __syncthreads();                                      // the workgroup's stores happen before thread 0's release
   if (threadIdx.x == 0) {
-    // ... before the flag that announces them (release, system scope)
-    __hip_atomic_store(flag_peers[d] + rank, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    // ---- wait: peer d's data for me ----
-    uint32_t spins = 0;
-    while (__hip_atomic_load(flags_local + d, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
-      __builtin_amdgcn_s_sleep(8);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");       // system scope: visible to the peer before the flag is
+    __hip_atomic_store(flag_peers[d] + rank, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    // ---- wait: peer d's data for me (relaxed polls that bypass the caches; ONE acquire once it is there) ----
+    uint32_t spins = 0, ok = 1u;
+    while (__hip_atomic_load(flags_local + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
+      __builtin_amdgcn_s_sleep(4);
       if (++spins >= GMX_P2P_SPIN_LIMIT) {              // a peer that never arrives must not hang the GPU
         __hip_atomic_store(state + 1, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = 0u;
         break;
       }
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    s_ok = ok;
+  }
+  __syncthreads();
+  // ---- copy out: slot d of my landing buffer (fine-grained memory) -> the caller's destination (ordinary memory) ----
+  if (s_ok) {
+    const uint8_t* ls = land_local + half + (size_t)d * bytes;
+    uint8_t* o = out + (size_t)d * bytes;
+    if ((((uintptr_t)ls | (uintptr_t)o | bytes) & 15) == 0) {
+      const uint4* s4 = reinterpret_cast<const uint4*>(ls);
+      uint4* t4 = reinterpret_cast<uint4*>(o);
+      for (size_t i = threadIdx.x; i < bytes / 16; i += GMX_BLOCK) t4[i] = s4[i];
+    } else {
+      for (size_t i = threadIdx.x; i < bytes; i += GMX_BLOCK) o[i] = ls[i];
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
     // the last workgroup to finish advances the epoch for the next launch
-    if (__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (uint32_t)world - 1u) {
+    if (__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (uint32_t)world - 1u) {
       __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(state, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(state, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
@@ -2464,15 +2486,17 @@ extern "C" int gmx_p2p_open(const void* handle, void** ptr_out) {
 extern "C" int gmx_p2p_close(void* ptr) { if (ptr) GMX_HIP(hipIpcCloseMemHandle(ptr)); return 0; }
 extern "C" int gmx_p2p_free(void* ptr) { if (ptr) GMX_HIP(hipFree(ptr)); return 0; }
 
-extern "C" int gmx_p2p_exchange(const void* src_d, size_t src_stride, void* const* dst_peers_d,
-                                uint64_t* const* flag_peers_d, uint64_t* flags_local_d, uint64_t* state_d, int rank,
-                                int world, size_t bytes, gmx_stream stream) {
-  if (!src_d || !dst_peers_d || !flag_peers_d || !flags_local_d || !state_d) return gmx_fail("gmx_p2p_exchange: null argument%s");
+extern "C" int gmx_p2p_exchange(const void* src_d, size_t src_stride, void* const* land_peers_d, const void* land_local_d,
+                                void* out_d, uint64_t* const* flag_peers_d, uint64_t* flags_local_d, uint64_t* state_d,
+                                int rank, int world, size_t bytes, gmx_stream stream) {
+  if (!src_d || !land_peers_d || !land_local_d || !out_d || !flag_peers_d || !flags_local_d || !state_d)
+    return gmx_fail("gmx_p2p_exchange: null argument%s");
   if (world < 1 || world > 64 || rank < 0 || rank >= world) return gmx_fail("gmx_p2p_exchange: rank / world out of range%s");
   if (bytes == 0) return 0;
   // state_d: [0] epoch, [1] error, [2] ticket (low word)
   hipLaunchKernelGGL(k_p2p_exchange, dim3((unsigned)world), dim3(GMX_BLOCK), 0, (hipStream_t)stream, (const uint8_t*)src_d,
-                     src_stride, dst_peers_d, flag_peers_d, flags_local_d, state_d, (uint32_t*)(state_d + 2), rank, world, bytes);
+                     src_stride, land_peers_d, (const uint8_t*)land_local_d, (uint8_t*)out_d, flag_peers_d, flags_local_d,
+                     state_d, (uint32_t*)(state_d + 2), rank, world, bytes);
   GMX_HIP(hipGetLastError());
   return 0;
 }

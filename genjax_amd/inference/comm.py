@@ -75,33 +75,33 @@ class _RawTensor:
 
 class P2PComm:
     """GENMI_COMM=p2p — the collectives of a sharded SMC step as ONE launch each over peer-mapped memory
-    (include/genmi.h "Peer-mapped exchange"): every destination buffer comes from `alloc` (fine-grained
-    device memory, IPC-mapped into every peer), a collective copies this rank's blocks straight into its peers'
-    buffers over xGMI, raises a flag per peer and waits for its own flags.  No RCCL kernel, no host involvement, and —
-    since the epoch lives on the device — capturable into the sweep's hipGraph.
+    (include/genmi.h "Peer-mapped exchange"): a collective copies this rank's blocks straight into its
+    peers' LANDING buffers over xGMI (fine-grained device memory, IPC-mapped into every peer: two halves that alternate
+    with the epoch's parity), raises a flag per peer, waits for its own flags and copies what landed into the caller's
+    ordinary destination tensor.  No RCCL kernel, no host involvement, and — since the epoch lives on the device —
+    capturable into the sweep's hipGraph.  Landing buffers are made on the first collective of each size (a COLLECTIVE
+    step: the IPC handles are all-gathered; it happens in the eager warm-up pass, never inside a capture).
     Status: world size 1 runs on the device; world sizes 2 and 4 run through the tests' CPU mirror over process-shared
     memory (tests/test_distributed_cpu.py); across GPUs it is UNMEASURED (no multi-GPU box in the build loop)."""
 
     name = "p2p (peer-mapped xGMI, one launch per collective)"
     graph_safe = True
+    alloc = _alloc_plain
 
     def __init__(self, dist, device: torch.device):
         from .. import _lib
         self.be = _lib.get()
         self.dist, self.device = dist, device
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
-        self._allocs = []        # (base ptr, nbytes, [peer base ptrs], raw keep-alives)
-        self._ptr_tables = {}
-        W = self.world
-        # one flag row per EXCHANGE SLOT would be the general design; the sharded step alternates two exchanges, which
-        # is what makes one row + one epoch sufficient (include/genmi.h)
-        self.flags = self.alloc((W,), torch.int64)
+        self._allocs = []        # (base ptr, nbytes, [peer base ptrs], keep-alive, [opened peer mappings])
+        self._landing = {}       # bytes per block -> (local landing tensor, device table of the peers' landing bases)
+        self.flags, self._flag_table = self._shared((self.world,), torch.int64)
         self.state = torch.zeros((3,), dtype=torch.int64, device=device)
-        self._flag_table = self._peer_table(self.flags)
 
-    # -- memory ----------------------------------------------------------------------------------
-    def alloc(self, shape, dtype=torch.float32):
-        """a zeroed tensor every peer can write into; COLLECTIVE (the IPC handles are all-gathered)"""
+    # -- peer-mapped memory --------------------------------------------------------------------------
+    def _shared(self, shape, dtype):
+        """(a zeroed tensor in fine-grained, peer-mapped memory, the device table [world] of its address in every
+        peer's allocation of the same call); COLLECTIVE"""
         n = 1
         for d in shape:
             n *= int(d)
@@ -130,31 +130,27 @@ class P2PComm:
                 peers[s_] = p.value
                 opened.append(p.value)
         raw = _RawTensor(ptr.value, nbytes, self.device.type == "cuda")
-        flat = raw.tensor(self.device)
+        t = raw.tensor(self.device)[:n * item].view(dtype).reshape(tuple(shape))
+        table = torch.tensor(peers, dtype=torch.int64).to(self.device)
         self._allocs.append((ptr.value, nbytes, peers, raw, opened))
-        return flat[:n * item].view(dtype).reshape(tuple(shape))
+        return t, table
 
-    def _peer_table(self, t: torch.Tensor) -> torch.Tensor:
-        """device array [world] of the peers' addresses of `t` (a view into one of this communicator's allocations)"""
-        key = (t.data_ptr(),)
-        tab = self._ptr_tables.get(key)
-        if tab is None:
-            p = t.data_ptr()
-            for base, nbytes, peers, _raw, _o in self._allocs:
-                if base <= p < base + nbytes:
-                    tab = torch.tensor([q + (p - base) for q in peers], dtype=torch.int64).to(self.device)
-                    break
-            else:
-                raise RuntimeError("P2PComm: the destination of a collective must come from comm.alloc(...)")
-            self._ptr_tables[key] = tab
-        return tab
+    def _landing_for(self, nbytes: int):
+        ent = self._landing.get(nbytes)
+        if ent is None:
+            if self.be.uses_streams and torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("P2PComm: the first collective of a size allocates its landing buffers (a collective "
+                                   "step): run the sweep once eagerly before capturing it")
+            ent = self._landing[nbytes] = self._shared((2 * self.world * nbytes,), torch.uint8)
+        return ent
 
     # -- collectives ------------------------------------------------------------------------------
     def _exchange(self, out, inp, stride_bytes, nbytes):
         be = self.be
-        be.check(be.c.gmx_p2p_exchange(be.ptr(inp), stride_bytes, be.ptr(self._peer_table(out)), be.ptr(self._flag_table),
-                                       be.ptr(self.flags), be.ptr(self.state), self.rank, self.world, nbytes, be.stream()),
-                 "gmx_p2p_exchange")
+        land, table = self._landing_for(nbytes)
+        be.check(be.c.gmx_p2p_exchange(be.ptr(inp), stride_bytes, be.ptr(table), be.ptr(land), be.ptr(out),
+                                       be.ptr(self._flag_table), be.ptr(self.flags), be.ptr(self.state), self.rank,
+                                       self.world, nbytes, be.stream()), "gmx_p2p_exchange")
 
     def all_gather(self, out, inp):
         assert out.is_contiguous() and inp.is_contiguous()
@@ -176,14 +172,14 @@ class P2PComm:
         return bool(int(self.state[1].item()) != 0)
 
     def destroy(self):
-        for base, _n, _peers, _raw, opened in self._allocs:
+        for _base, _n, _peers, _raw, opened in self._allocs:
             for p in opened:
                 self.be.c.gmx_p2p_close(c_void_p(p))
         if self.world > 1:
             self.dist.barrier()                # nobody unmaps a segment a peer may still be writing
         for base, _n, _peers, _raw, _o in self._allocs:
             self.be.c.gmx_p2p_free(c_void_p(base))
-        self._allocs = []
+        self._allocs, self._landing = [], {}
 
 
 class _UniqueId(Structure):

@@ -391,23 +391,27 @@ int gmx_select(const uint8_t* mask_d, const void* const* a_d, const void* const*
  * torch.distributed, every rank maps its peers' buffers with gmx_p2p_open.  A collective is then ONE launch and one
  * rendezvous, no library in between:
  *   gmx_p2p_exchange   workgroup d copies `bytes` from src_d + d * src_stride (src_stride = 0: the same block for
- *                      every peer = all-gather; `bytes`: equal-split all-to-all) into PEER d's destination
- *                      dst_peers_d[d] + rank * bytes, makes the copy visible at system scope, writes this launch's
- *                      epoch into peer d's flag word flag_peers_d[d][rank], and waits until its own flag word
- *                      flags_local_d[d] carries the epoch (peer d's data has arrived).  The epoch lives on the device
- *                      (state_d[0], advanced by the last workgroup), so a captured graph replays correctly.
- * A wait gives up after about GMX_P2P_SPIN_LIMIT polls and sets state_d[1] (sticky error word: a peer that never
- * arrives must not hang the GPU); the caller checks it once per sweep.  The protocol assumes what the sharded SMC
- * step provides: two different exchanges alternate (statistics, states), so a destination is never overwritten
- * before its owner has consumed it.  Unmeasured across GPUs (no multi-GPU box in the build loop): exercised at world
- * size 1 on the device and, through the tests' CPU mirror with process-shared memory, at world sizes 2 and 4.
+ *                      every peer = all-gather; `bytes`: equal-split all-to-all) into PEER d's LANDING buffer
+ *                      land_peers_d[d] + half + rank * bytes, makes the copy visible at system scope, writes this
+ *                      launch's epoch into peer d's flag word flag_peers_d[d][rank], waits until its own flag word
+ *                      flags_local_d[d] carries the epoch (peer d's block has landed), and copies slot d of its own
+ *                      landing buffer land_local_d into out_d + d * bytes — ordinary device memory: only the small
+ *                      landing buffers (2 * world * bytes: `half` alternates with the epoch's parity, so a fast peer's
+ *                      next exchange cannot overwrite a block still being copied out) and the flags are fine-grained.
+ *                      The epoch lives on the device (state_d[0], advanced by the last workgroup), so a captured
+ *                      graph replays correctly.
+ * A wait gives up after GMX_P2P_SPIN_LIMIT polls and sets state_d[1] (sticky error word: a peer that never arrives
+ * must not hang the GPU); the caller checks it once per sweep.  Unmeasured across GPUs (no multi-GPU box in the build
+ * loop): exercised at world size 1 on the device and, through the tests' CPU mirror with process-shared memory, at
+ * world sizes 2 and 4.
  * ---------------------------------------------------------------------- */
 #define GMX_P2P_HANDLE_BYTES 64
 int gmx_p2p_alloc(size_t bytes, void** ptr_out, void* handle_out /* GMX_P2P_HANDLE_BYTES */);
 int gmx_p2p_open(const void* handle /* GMX_P2P_HANDLE_BYTES */, void** ptr_out);
 int gmx_p2p_close(void* ptr);
 int gmx_p2p_free(void* ptr);
-int gmx_p2p_exchange(const void* src_d, size_t src_stride, void* const* dst_peers_d /* [world] */,
+int gmx_p2p_exchange(const void* src_d, size_t src_stride, void* const* land_peers_d /* [world] */,
+                     const void* land_local_d /* 2 * world * bytes */, void* out_d /* world * bytes */,
                      uint64_t* const* flag_peers_d /* [world] */, uint64_t* flags_local_d /* [world] */,
                      uint64_t* state_d /* [3], zeroed: epoch, error, ticket */, int rank, int world, size_t bytes,
                      gmx_stream stream);

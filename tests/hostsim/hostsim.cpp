@@ -565,23 +565,26 @@ extern "C" int gmx_p2p_free(void* p) {
   if (it != g_shm.end()) { if (it->second.name[0]) shm_unlink(it->second.name); munmap(p, it->second.bytes); g_shm.erase(it); }
   return 0;
 }
-extern "C" int gmx_p2p_exchange(const void* src, size_t src_stride, void* const* dst_peers, uint64_t* const* flag_peers,
-                                uint64_t* flags_local, uint64_t* state, int rank, int world, size_t bytes, gmx_stream) {
-  if (!src || !dst_peers || !flag_peers || !flags_local || !state) return fail("p2p_exchange: null argument");
+extern "C" int gmx_p2p_exchange(const void* src, size_t src_stride, void* const* land_peers, const void* land_local, void* out,
+                                uint64_t* const* flag_peers, uint64_t* flags_local, uint64_t* state, int rank, int world,
+                                size_t bytes, gmx_stream) {
+  if (!src || !land_peers || !land_local || !out || !flag_peers || !flags_local || !state) return fail("p2p_exchange: null argument");
   if (world < 1 || world > 64 || rank < 0 || rank >= world) return fail("p2p_exchange: rank / world out of range");
   if (!bytes) return 0;
   const uint64_t epoch = state[0] + 1;
-  for (int d = 0; d < world; ++d) {                                   // put, then announce (release)
-    memcpy((uint8_t*)dst_peers[d] + (size_t)rank * bytes, (const uint8_t*)src + (size_t)d * src_stride, bytes);
+  const size_t half = (size_t)(epoch & 1) * (size_t)world * bytes;
+  for (int d = 0; d < world; ++d) {                                   // put into the peer's landing buffer, then announce
+    memcpy((uint8_t*)land_peers[d] + half + (size_t)rank * bytes, (const uint8_t*)src + (size_t)d * src_stride, bytes);
     __atomic_store_n(flag_peers[d] + rank, epoch, __ATOMIC_RELEASE);
   }
   timespec t0; clock_gettime(CLOCK_MONOTONIC, &t0);
-  for (int d = 0; d < world; ++d) {                                   // wait for every peer's data (bounded)
+  for (int d = 0; d < world; ++d) {                                   // wait for every peer's block (bounded), copy it out
     while (__atomic_load_n(flags_local + d, __ATOMIC_ACQUIRE) < epoch) {
       sched_yield();
       timespec t1; clock_gettime(CLOCK_MONOTONIC, &t1);
       if (t1.tv_sec - t0.tv_sec > 60) { state[1] = 1; return fail("p2p_exchange: a peer did not arrive within 60 s"); }
     }
+    memcpy((uint8_t*)out + (size_t)d * bytes, (const uint8_t*)land_local + half + (size_t)d * bytes, bytes);
   }
   state[0] = epoch;
   return 0;

@@ -55,24 +55,6 @@ def _alloc_plain(self, shape, dtype=torch.float32):
 TorchComm.alloc = _alloc_plain
 
 
-class _RawTensor:
-    """a raw device / shared-memory allocation as a tensor (no copy): __cuda_array_interface__ on the GPU, the numpy
-    buffer protocol on the CPU mirror"""
-
-    def __init__(self, ptr: int, nbytes: int, on_gpu: bool):
-        self.ptr, self.nbytes = int(ptr), int(nbytes)
-        if on_gpu:
-            self.__cuda_array_interface__ = {"shape": (self.nbytes,), "typestr": "|u1", "data": (self.ptr, False),
-                                             "version": 2, "strides": None}
-
-    def tensor(self, device):
-        if device.type == "cuda":
-            return torch.as_tensor(self, device=device)
-        import numpy as np
-        buf = (ctypes.c_uint8 * self.nbytes).from_address(self.ptr)
-        return torch.from_numpy(np.frombuffer(buf, dtype=np.uint8))
-
-
 class P2PComm:
     """GENMI_COMM=p2p — the collectives of a sharded SMC step as ONE launch each over peer-mapped memory
     (include/genmi.h "Peer-mapped exchange"): a collective copies this rank's blocks straight into its
@@ -129,11 +111,11 @@ class P2PComm:
                 self.be.check(self.be.c.gmx_p2p_open(hb, byref(p)), "gmx_p2p_open")
                 peers[s_] = p.value
                 opened.append(p.value)
-        raw = _RawTensor(ptr.value, nbytes, self.device.type == "cuda")
-        t = raw.tensor(self.device)[:n * item].view(dtype).reshape(tuple(shape))
+        # the memory is only ever touched by the exchange kernel: a raw address is all that is needed (a tensor built
+        # over it through __cuda_array_interface__ may be a COPY — measured: flags that never change, every wait timing out)
         table = torch.tensor(peers, dtype=torch.int64).to(self.device)
-        self._allocs.append((ptr.value, nbytes, peers, raw, opened))
-        return t, table
+        self._allocs.append((ptr.value, nbytes, peers, None, opened))
+        return c_void_p(ptr.value), table
 
     def _landing_for(self, nbytes: int):
         ent = self._landing.get(nbytes)
@@ -148,8 +130,8 @@ class P2PComm:
     def _exchange(self, out, inp, stride_bytes, nbytes):
         be = self.be
         land, table = self._landing_for(nbytes)
-        be.check(be.c.gmx_p2p_exchange(be.ptr(inp), stride_bytes, be.ptr(table), be.ptr(land), be.ptr(out),
-                                       be.ptr(self._flag_table), be.ptr(self.flags), be.ptr(self.state), self.rank,
+        be.check(be.c.gmx_p2p_exchange(be.ptr(inp), stride_bytes, be.ptr(table), land, be.ptr(out),
+                                       be.ptr(self._flag_table), self.flags, be.ptr(self.state), self.rank,
                                        self.world, nbytes, be.stream()), "gmx_p2p_exchange")
 
     def all_gather(self, out, inp):

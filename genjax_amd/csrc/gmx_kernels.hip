@@ -2400,31 +2400,41 @@ extern "C" int gmx_shard_step_fused(int kind, const uint32_t key[2], const void*
 // peer-mapped exchange (include/genmi.h "Peer-mapped exchange"): one launch, one rendezvous per collective
 // ---------------------------------------------------------------------------
 #define GMX_P2P_SPIN_LIMIT (1u << 22)
+#define GMX_P2P_CHUNK (16u * 1024u)         /* bytes one workgroup moves: a block of `bytes` is split over up to 64 of them */
+__device__ __forceinline__ void p2p_copy(uint8_t* t, const uint8_t* s, size_t lo, size_t hi) {
+  if ((((uintptr_t)s | (uintptr_t)t | lo | hi) & 15) == 0) {
+    const uint4* s4 = reinterpret_cast<const uint4*>(s);
+    uint4* t4 = reinterpret_cast<uint4*>(t);
+    for (size_t i = lo / 16 + threadIdx.x; i < hi / 16; i += GMX_BLOCK) t4[i] = s4[i];
+  } else {
+    for (size_t i = lo + threadIdx.x; i < hi; i += GMX_BLOCK) t[i] = s[i];
+  }
+}
 __global__ void __launch_bounds__(GMX_BLOCK)
 k_p2p_exchange(const uint8_t* __restrict__ src, size_t src_stride, void* const* __restrict__ land_peers,
                const uint8_t* __restrict__ land_local, uint8_t* __restrict__ out, uint64_t* const* __restrict__ flag_peers,
-               uint64_t* __restrict__ flags_local, uint64_t* __restrict__ state, uint32_t* __restrict__ ticket, int rank,
-               int world, size_t bytes) {
+               uint64_t* __restrict__ flags_local, uint64_t* __restrict__ state, int rank, int world, size_t bytes) {
   __shared__ uint32_t s_ok;
   const int d = (int)blockIdx.x;                        // the peer this workgroup serves
+  const uint32_t nblk = gridDim.y, j = blockIdx.y;      // ... and its share [lo, hi) of the block of `bytes`
+  size_t per = (bytes + nblk - 1) / nblk;
+  per = (per + 15) & ~(size_t)15;
+  const size_t lo = (size_t)j * per < bytes ? (size_t)j * per : bytes, hi = lo + per < bytes ? lo + per : bytes;
+  uint32_t* end_ticket = reinterpret_cast<uint32_t*>(state + 2);
+  uint32_t* put_ticket = reinterpret_cast<uint32_t*>(state + 3 + d);
   const uint64_t epoch = __hip_atomic_load(state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ull;
   const size_t half = (size_t)(epoch & 1ull) * (size_t)world * bytes;      // landing buffers alternate by epoch parity
   // ---- put: my block for peer d -> peer d's landing buffer, slot `rank` ----
-  const uint8_t* s = src + (size_t)d * src_stride;
-  uint8_t* t = (uint8_t*)land_peers[d] + half + (size_t)rank * bytes;
-  const bool wide = (((uintptr_t)s | (uintptr_t)t | bytes) & 15) == 0;
-  if (wide) {
-    const uint4* s4 = reinterpret_cast<const uint4*>(s);
-    uint4* t4 = reinterpret_cast<uint4*>(t);
-    for (size_t i = threadIdx.x; i < bytes / 16; i += GMX_BLOCK) t4[i] = s4[i];
-  } else {
-    for (size_t i = threadIdx.x; i < bytes; i += GMX_BLOCK) t[i] = s[i];
-  }
+  p2p_copy((uint8_t*)land_peers[d] + half + (size_t)rank * bytes, src + (size_t)d * src_stride, lo, hi);
   __syncthreads();                                      // the workgroup's stores happen before thread 0's release
   if (threadIdx.x == 0) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");       // system scope: visible to the peer before the flag is
-    __hip_atomic_store(flag_peers[d] + rank, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    // ---- wait: peer d's data for me (relaxed polls that bypass the caches; ONE acquire once it is there) ----
+    // the LAST of the nblk workgroups serving peer d announces the whole block
+    if (__hip_atomic_fetch_add(put_ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == nblk - 1u) {
+      __hip_atomic_store(put_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(flag_peers[d] + rank, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    // ---- wait: peer d's block for me (relaxed polls that bypass the caches; ONE acquire once it is there) ----
     uint32_t spins = 0, ok = 1u;
     while (__hip_atomic_load(flags_local + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
       __builtin_amdgcn_s_sleep(4);
@@ -2439,22 +2449,12 @@ k_p2p_exchange(const uint8_t* __restrict__ src, size_t src_stride, void* const* 
   }
   __syncthreads();
   // ---- copy out: slot d of my landing buffer (fine-grained memory) -> the caller's destination (ordinary memory) ----
-  if (s_ok) {
-    const uint8_t* ls = land_local + half + (size_t)d * bytes;
-    uint8_t* o = out + (size_t)d * bytes;
-    if ((((uintptr_t)ls | (uintptr_t)o | bytes) & 15) == 0) {
-      const uint4* s4 = reinterpret_cast<const uint4*>(ls);
-      uint4* t4 = reinterpret_cast<uint4*>(o);
-      for (size_t i = threadIdx.x; i < bytes / 16; i += GMX_BLOCK) t4[i] = s4[i];
-    } else {
-      for (size_t i = threadIdx.x; i < bytes; i += GMX_BLOCK) o[i] = ls[i];
-    }
-  }
+  if (s_ok) p2p_copy(out + (size_t)d * bytes, land_local + half + (size_t)d * bytes, lo, hi);
   __syncthreads();
   if (threadIdx.x == 0) {
-    // the last workgroup to finish advances the epoch for the next launch
-    if (__hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (uint32_t)world - 1u) {
-      __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // the last workgroup of the launch advances the epoch for the next one
+    if (__hip_atomic_fetch_add(end_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (uint32_t)world * nblk - 1u) {
+      __hip_atomic_store(end_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(state, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
@@ -2493,10 +2493,12 @@ extern "C" int gmx_p2p_exchange(const void* src_d, size_t src_stride, void* cons
     return gmx_fail("gmx_p2p_exchange: null argument%s");
   if (world < 1 || world > 64 || rank < 0 || rank >= world) return gmx_fail("gmx_p2p_exchange: rank / world out of range%s");
   if (bytes == 0) return 0;
-  // state_d: [0] epoch, [1] error, [2] ticket (low word)
-  hipLaunchKernelGGL(k_p2p_exchange, dim3((unsigned)world), dim3(GMX_BLOCK), 0, (hipStream_t)stream, (const uint8_t*)src_d,
-                     src_stride, land_peers_d, (const uint8_t*)land_local_d, (uint8_t*)out_d, flag_peers_d, flags_local_d,
-                     state_d, (uint32_t*)(state_d + 2), rank, world, bytes);
+  // state_d: [0] epoch, [1] error, [2] end ticket, [3 + d] the put ticket of peer d (low words)
+  unsigned nblk = (unsigned)((bytes + GMX_P2P_CHUNK - 1) / GMX_P2P_CHUNK);
+  nblk = nblk < 1u ? 1u : (nblk > 64u ? 64u : nblk);
+  hipLaunchKernelGGL(k_p2p_exchange, dim3((unsigned)world, nblk), dim3(GMX_BLOCK), 0, (hipStream_t)stream,
+                     (const uint8_t*)src_d, src_stride, land_peers_d, (const uint8_t*)land_local_d, (uint8_t*)out_d,
+                     flag_peers_d, flags_local_d, state_d, rank, world, bytes);
   GMX_HIP(hipGetLastError());
   return 0;
 }

@@ -78,7 +78,7 @@ class P2PComm:
         self._allocs = []        # (base ptr, nbytes, [peer base ptrs], keep-alive, [opened peer mappings])
         self._landing = {}       # bytes per block -> (local landing tensor, device table of the peers' landing bases)
         self.flags, self._flag_table = self._shared((self.world,), torch.int64)
-        self.state = torch.zeros((3,), dtype=torch.int64, device=device)
+        self.state = torch.zeros((3 + self.world,), dtype=torch.int64, device=device)     # epoch, error, tickets
 
     # -- peer-mapped memory --------------------------------------------------------------------------
     def _shared(self, shape, dtype):

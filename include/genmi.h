@@ -413,7 +413,7 @@ int gmx_p2p_free(void* ptr);
 int gmx_p2p_exchange(const void* src_d, size_t src_stride, void* const* land_peers_d /* [world] */,
                      const void* land_local_d /* 2 * world * bytes */, void* out_d /* world * bytes */,
                      uint64_t* const* flag_peers_d /* [world] */, uint64_t* flags_local_d /* [world] */,
-                     uint64_t* state_d /* [3], zeroed: epoch, error, ticket */, int rank, int world, size_t bytes,
+                     uint64_t* state_d /* [3 + world], zeroed: epoch, error, tickets */, int rank, int world, size_t bytes,
                      gmx_stream stream);
 
 /* ------------------------------------------------------------------------

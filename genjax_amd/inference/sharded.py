@@ -104,7 +104,9 @@ class ShardedBootstrapSweep(_NoiseAhead):
         # particles one rank may ship to ONE peer per step before the slow path kicks in
         # default n/32: the slot boundaries of balanced ranks move by O(sqrt(n)) particles per step, so
         # this is a ~10x margin at n = 1e6 while the all-to-all stays ~125 KB per peer
-        self.capacity = int(capacity) if capacity else (self.n if self.world == 1 else max(4096, self.n // 32))
+        # (the same at world size 1, where nothing ever crosses ranks: `bench.py --sharded` then issues the collectives
+        # with the message sizes a real multi-GPU step has, not a degenerate n-element all-to-all)
+        self.capacity = int(capacity) if capacity else max(4096, self.n // 32)
         self.capacity = max(1, min(self.capacity, self.n))
         self.reruns = 0
         # issue the collectives even at world size 1 (exercises / times the RCCL calls on one GPU)

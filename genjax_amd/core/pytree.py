@@ -18,7 +18,8 @@ class Const(Generic[R]):
         self.val = val
 
     def unwrap(self):
-        return self.val
+        """`c.unwrap()`; `Const.unwrap(v)` on a plain value hands it back (pytree.py:290-306)"""
+        return self.val if isinstance(self, Const) else self
 
     def __class_getitem__(cls, item):
         return cls
@@ -53,8 +54,33 @@ class Pytree:
     def field(**kwargs):
         return dataclasses.field(**kwargs)
 
+    @staticmethod
+    def const(v):
+        return Const(v)
 
-PythonicPytree = Pytree
+
+class PythonicPytree(Pytree):
+    """Bracket indexing, len, iteration, `+` (leaf-wise concatenation) and `prepend` for dataclass pytrees whose leaves
+    share a leading axis (pytree.py:342-376)."""
+
+    def __getitem__(self, idx):
+        return nth(self, idx)
+
+    def __len__(self):
+        return len(_leaves(self)[0])
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+    def __add__(self, other):
+        if not isinstance(other, type(self)):
+            raise TypeError(f"Cannot add {type(self)} and {type(other)}")
+        import torch
+        return _map2(lambda a, b: torch.cat([torch.as_tensor(a), torch.as_tensor(b)]), self, other)
+
+    def prepend(self, child):
+        import torch
+        return _map2(lambda a, b: torch.as_tensor(a)[None], child, child) + self
 
 
 class Closure:
@@ -75,4 +101,31 @@ def nth(x: Any, idx):
         return [nth(v, idx) for v in x]
     if isinstance(x, dict):
         return {k: nth(v, idx) for k, v in x.items()}
+    if dataclasses.is_dataclass(x) and not isinstance(x, type):
+        return _map2(lambda a, _b: a[idx], x, x)
     return x[idx]
+
+
+def _dyn_fields(x):
+    return [f for f in dataclasses.fields(x) if not f.metadata.get("static")]
+
+
+def _leaves(x):
+    if isinstance(x, (tuple, list)):
+        return [l for v in x for l in _leaves(v)]
+    if isinstance(x, dict):
+        return [l for v in x.values() for l in _leaves(v)]
+    if dataclasses.is_dataclass(x) and not isinstance(x, type):
+        return [l for f in _dyn_fields(x) for l in _leaves(getattr(x, f.name))]
+    return [x]
+
+
+def _map2(fn, x, y):
+    if isinstance(x, (tuple, list)):
+        return type(x)(_map2(fn, a, b) for a, b in zip(x, y))
+    if isinstance(x, dict):
+        return {k: _map2(fn, v, y[k]) for k, v in x.items()}
+    if dataclasses.is_dataclass(x) and not isinstance(x, type):
+        return dataclasses.replace(x, **{f.name: _map2(fn, getattr(x, f.name), getattr(y, f.name))
+                                         for f in _dyn_fields(x)})
+    return fn(x, y)

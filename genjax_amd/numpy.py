@@ -576,3 +576,14 @@ def array_equal(a, b):
 def allclose(a, b, rtol=1e-5, atol=1e-8):
     return bool(np.allclose(np.asarray(a.detach().cpu() if _is_torch(a) else a), np.asarray(b.detach().cpu() if _is_torch(b) else b),
                             rtol=rtol, atol=atol))
+
+
+def all(x, axis=None):                                                # noqa: A001
+    """concrete arrays only (a truth value of launch values belongs to the host, not to a site program)"""
+    a = np.asarray(x.detach().cpu() if _is_torch(x) else x)
+    return bool(a.all()) if axis is None else a.all(axis=axis)
+
+
+def any(x, axis=None):                                                # noqa: A001
+    a = np.asarray(x.detach().cpu() if _is_torch(x) else x)
+    return bool(a.any()) if axis is None else a.any(axis=axis)

@@ -2362,6 +2362,254 @@ extern "C" int gmx_shard_step_tiles(int kind, const uint32_t key[2], const uint6
   return 0;
 }
 
+// The fused step on k_offspring_tile's scheme (what gmx_shard_step_fused launches; GENMI_SHARD_FILL=0: k_shard_step<true, true>).
+// A workgroup is one 1024-particle tile of this rank's shard.  It derives M, K, every rank's total and the slot bounds
+// from the gathered statistics table (two barriers whatever the world size: partial sums per (rank, wave), then
+// thread s evaluates rank s's bound), rebuilds its tile's CDF in registers, gets its sources' slot runs from the
+// straight-line f64 estimate (+ the cold exact predicate), and ROUTES THROUGH LDS: every source with a slot marks its
+// first one, a max-scan fills the tile's contiguous GLOBAL slot range [T0, T1), and each thread handles 8 consecutive
+// slots — a slot this rank owns gets the source's local index (two 16-byte stores on the common path), a slot rank d
+// owns gets the source's state in send block d.  Same plan, send buffer and indices as k_shard_step, at a cost that
+// does not depend on the weights (k_shard_step walks each source's run per thread, with a 64-bit division per source).
+template <int kind>
+__global__ void __launch_bounds__(GMX_BLOCK)
+k_shard_step_fill(uint32_t k0, uint32_t k1, uint32_t u0_host, const float* __restrict__ lw,
+                  const uint8_t* __restrict__ stats_all, size_t stride, int n_tiles, float scale, int rank, int world,
+                  int32_t n, int32_t cap, int64_t* __restrict__ plan, uint64_t* __restrict__ total_out,
+                  float* __restrict__ max_out, const uint32_t* __restrict__ state, uint32_t* __restrict__ send,
+                  int32_t* __restrict__ next_idx) {
+  __shared__ uint64_t s_part[SHARD_MAX_WORLD][4];
+  __shared__ uint64_t s_below[4], s_scan[4], s_tot[2];
+  __shared__ float s_max[4];
+  __shared__ int32_t s_bounds[SHARD_MAX_WORLD + 1];
+  __shared__ __attribute__((aligned(16))) uint32_t s_mark[RS_FILL_SLOTS];
+  __shared__ int32_t s_rng[2];
+  __shared__ uint32_t s_carry[4];
+  const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int my_tile = (int)blockIdx.x;
+  const int32_t i0 = my_tile * RS_TILE + tid * CDF_VEC;
+  const int32_t N = n * world, base = rank * n;
+  const int tiles_pad = n_tiles + (n_tiles & 1);
+  gmx_key key; key.k0 = k0; key.k1 = k1;
+  // ---- loads first: this tile's log-weights ----
+  float x[CDF_VEC];
+  if ((my_tile + 1) * RS_TILE <= n) {
+    const float4 v = *reinterpret_cast<const float4*>(lw + i0);
+    x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
+  } else {
+#pragma unroll
+    for (int c = 0; c < CDF_VEC; ++c) {
+      const int32_t ic = i0 + c < n ? i0 + c : n - 1;
+      const float xv = lw[ic];
+      x[c] = (i0 + c < n) ? xv : -gmx_inf();
+    }
+  }
+  const uint8_t* own = stats_all + (size_t)rank * stride;
+  const float tmax_mine = reinterpret_cast<const float*>(own + (size_t)tiles_pad * 8)[my_tile];
+  // ---- pass 1 over the table: the global max ----
+  float m = -gmx_inf();
+  for (int r = 0; r < world; ++r) {
+    const float* tmax = reinterpret_cast<const float*>(stats_all + (size_t)r * stride + (size_t)tiles_pad * 8);
+    for (int t = tid; t < n_tiles; t += GMX_BLOCK) m = gmx_rmax(m, tmax[t]);
+  }
+  m = wave_max(m);
+  const int32_t k_b = gmx_tile_exp(tmax_mine);
+  const float ref_b = gmx_tile_ref(k_b);
+  uint64_t q[CDF_VEC], run = 0;
+#pragma unroll
+  for (int c = 0; c < CDF_VEC; ++c) {
+    run += (i0 + c < n) ? weight_fixed(x[c], ref_b, scale) : 0ull;
+    q[c] = run;
+  }
+  const uint64_t inc = wave_scan_u64(run);
+  if (lane == 0) s_max[wave] = m;
+  if (lane == 63) s_scan[wave] = inc;
+  __syncthreads();
+  const float M = gmx_rmax(gmx_rmax(s_max[0], s_max[1]), gmx_rmax(s_max[2], s_max[3]));
+  const int32_t K = gmx_tile_exp(M);
+  // ---- pass 2: every rank's total (partial sums per wave), and the mass of this rank's earlier tiles ----
+  uint64_t below = 0;
+  for (int r = 0; r < world; ++r) {
+    const uint64_t* agg = reinterpret_cast<const uint64_t*>(stats_all + (size_t)r * stride);
+    const float* tmax = reinterpret_cast<const float*>(stats_all + (size_t)r * stride + (size_t)tiles_pad * 8);
+    uint64_t sum = 0;
+    for (int t = tid; t < n_tiles; t += GMX_BLOCK) {
+      const uint64_t G = gmx_tile_scale(agg[t], gmx_tile_exp(tmax[t]), K);
+      sum += G;
+      below += (r == rank && t < my_tile) ? G : 0ull;
+    }
+    sum = wave_sum_u64(sum);
+    if (lane == 0) s_part[r][wave] = sum;
+  }
+  below = wave_sum_u64(below);
+  if (lane == 0) s_below[wave] = below;
+  __syncthreads();
+  if (tid < world) {                    // thread s: rank s's CDF offset and slot bound
+    uint64_t total = 0, off = 0;
+    for (int r = 0; r < world; ++r) {
+      const uint64_t rt = (s_part[r][0] + s_part[r][1]) + (s_part[r][2] + s_part[r][3]);
+      off += (r < tid) ? rt : 0ull;
+      total += rt;
+    }
+    const double not_ = total ? (double)N / (double)total : 0.0;
+    const double eps_ = (double)N * 0x1p-44 + 0x1p-40;
+    s_bounds[tid] = total ? (int32_t)slots_below(kind, key, (uint64_t)u0_host, off, (uint64_t)N << 23, total, not_, eps_, (int64_t)N) : 0;
+    if (tid == rank) s_tot[1] = off;
+    if (tid == 0) { s_tot[0] = total; s_bounds[world] = N; }
+  }
+  __syncthreads();
+  const uint64_t total = s_tot[0], cdf_offset = s_tot[1];
+  if (blockIdx.x == 0 && tid == 0) {       // published for inspection / tests; the overflow word is left alone
+    plan[GMX_PLAN_TOTAL] = (int64_t)total; plan[GMX_PLAN_OFFSET] = (int64_t)cdf_offset;
+    for (int s = 0; s <= world; ++s) plan[GMX_PLAN_BOUNDS + s] = (int64_t)s_bounds[s];
+    if (total_out) *total_out = total;
+    if (max_out) *max_out = M;
+  }
+  bool overflow = false;
+  // (b) my slots base + i0..+3: an ancestor on rank s != rank arrives at recv[s*cap + k]
+  if (world > 1) {
+#pragma unroll
+    for (int c = 0; c < CDF_VEC; ++c) {
+      const int32_t i = i0 + c;
+      if (i < n) {
+        const int32_t jj = base + i;
+        int s = 0;
+        while (s + 1 < world && s_bounds[s + 1] <= jj) ++s;
+        if (s != rank) {
+          const int32_t first = s_bounds[s] > base ? s_bounds[s] : base;
+          const int32_t k = jj - first;
+          if (k < cap) next_idx[i] = n + s * cap + k;
+          else { next_idx[i] = 0; overflow = true; }
+        }
+      }
+    }
+  }
+  if (total == 0) {       // no mass at all: the globally last particle (rank world-1, local n-1) sources every slot
+    if (rank == world - 1) {
+      const uint32_t v = state[n - 1];
+#pragma unroll
+      for (int c = 0; c < CDF_VEC; ++c) {
+        const int32_t k = i0 + c;
+        if (k < n) {
+          next_idx[k] = n - 1;
+          for (int d = 0; d < world - 1; ++d) {
+            if (k < cap) send[(int64_t)d * cap + k] = v; else overflow = true;
+          }
+        }
+      }
+    }
+    if (overflow) plan[GMX_PLAN_OVERFLOW] = 1;
+    return;
+  }
+  // (a) the slot runs of my 4 sources
+  const double n_over_total = (double)N / (double)total;
+  const double eps = (double)N * 0x1p-44 + 0x1p-40;
+  uint64_t wave_off = 0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) wave_off += (w < wave) ? s_scan[w] : 0ull;
+  const uint64_t loc = wave_off + (inc - run);
+  const uint64_t prefix = cdf_offset + ((s_below[0] + s_below[1]) + (s_below[2] + s_below[3]));
+  uint64_t cv[CDF_VEC + 1];
+  cv[0] = prefix + gmx_tile_scale(loc, k_b, K);
+#pragma unroll
+  for (int c = 0; c < CDF_VEC; ++c) cv[c + 1] = (i0 + c < n) ? prefix + gmx_tile_scale(loc + q[c], k_b, K) : 0ull;
+  // sources past the shard's end own no slot: their upper edge is the last real source's
+#pragma unroll
+  for (int c = 0; c < CDF_VEC; ++c) cv[c + 1] = (i0 + c < n) ? cv[c + 1] : cv[c];
+  int32_t e[CDF_VEC + 1];
+  uint32_t near_bits = 0;
+#pragma unroll
+  for (int c = 1; c <= CDF_VEC; ++c) {
+    const sb_est r = slots_below_est<kind>(key, u0_host, cv[c], total, n_over_total, eps, N);
+    e[c] = r.j;
+    near_bits |= r.near ? (1u << c) : 0u;
+  }
+  {
+    const sb_est r = slots_below_est<kind>(key, u0_host, cv[0], total, n_over_total, eps, N);
+    near_bits |= (lane == 0 && r.near) ? 1u : 0u;
+    e[0] = (int32_t)wave_shr1_u32((uint32_t)e[CDF_VEC], (uint32_t)r.j);
+    if (lane == 0) e[0] = r.j;
+  }
+  if (__any(near_bits != 0u)) {          // cold: the exact integer predicate for the flagged evaluations
+    const uint64_t D = (uint64_t)N << 23;
+    int32_t fixed0 = e[0];
+#pragma unroll 1
+    for (int c = 0; c <= CDF_VEC; ++c) {
+      if (near_bits & (1u << c)) {
+        const uint64_t cc = c == 0 ? cv[0] : c == 1 ? cv[1] : c == 2 ? cv[2] : c == 3 ? cv[3] : cv[4];
+        const int32_t j0 = c == 0 ? e[0] : c == 1 ? e[1] : c == 2 ? e[2] : c == 3 ? e[3] : e[4];
+        const int32_t j = (int32_t)slots_below_exact(kind, key, (uint64_t)u0_host, cc, D, total, (int64_t)j0, (int64_t)N);
+        if (c == 0) fixed0 = j; else if (c == 1) e[1] = j; else if (c == 2) e[2] = j; else if (c == 3) e[3] = j; else e[4] = j;
+      }
+    }
+    const uint32_t up = wave_shr1_u32((uint32_t)e[CDF_VEC], (uint32_t)fixed0);
+    e[0] = (lane == 0) ? fixed0 : (int32_t)up;
+  }
+  // ---- route through LDS ----
+  const int32_t e4 = e[CDF_VEC];
+  if (tid == 0) s_rng[0] = e[0];
+  if (tid == GMX_BLOCK - 1) s_rng[1] = e4;
+  reinterpret_cast<uint4*>(s_mark)[tid] = make_uint4(0u, 0u, 0u, 0u);
+  reinterpret_cast<uint4*>(s_mark)[tid + GMX_BLOCK] = make_uint4(0u, 0u, 0u, 0u);
+  __syncthreads();
+  const int32_t T0 = __builtin_amdgcn_readfirstlane(s_rng[0]), T1 = __builtin_amdgcn_readfirstlane(s_rng[1]);
+  const int32_t S = s_bounds[rank];          // the first slot whose ancestor lives on this rank
+  for (int32_t pass = T0; pass < T1; pass += RS_FILL_SLOTS) {      // block-uniform (1 pass unless the tile owns > 2048 slots)
+    if (pass != T0) {
+      __syncthreads();
+      reinterpret_cast<uint4*>(s_mark)[tid] = make_uint4(0u, 0u, 0u, 0u);
+      reinterpret_cast<uint4*>(s_mark)[tid + GMX_BLOCK] = make_uint4(0u, 0u, 0u, 0u);
+      __syncthreads();
+    }
+#pragma unroll
+    for (int c = 0; c < CDF_VEC; ++c) {
+      const int32_t lo = e[c] > pass ? e[c] : pass;
+      if (e[c + 1] > lo && lo - pass < RS_FILL_SLOTS) s_mark[lo - pass] = (uint32_t)(i0 + c);
+    }
+    __syncthreads();
+    uint4 a = reinterpret_cast<const uint4*>(s_mark)[2 * tid];
+    uint4 b = reinterpret_cast<const uint4*>(s_mark)[2 * tid + 1];
+    a.y = a.y > a.x ? a.y : a.x; a.z = a.z > a.y ? a.z : a.y; a.w = a.w > a.z ? a.w : a.z;
+    b.x = b.x > a.w ? b.x : a.w; b.y = b.y > b.x ? b.y : b.x; b.z = b.z > b.y ? b.z : b.y; b.w = b.w > b.z ? b.w : b.z;
+    const uint32_t incl = gmx_wave_umax_scan(b.w);
+    uint32_t carry = wave_shr1_u32(incl, 0u);
+    if (lane == 63) s_carry[wave] = incl;
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < 3; ++w) { const uint32_t v = s_carry[w]; carry = (w < wave && v > carry) ? v : carry; }
+    uint32_t src[8];
+    src[0] = a.x > carry ? a.x : carry; src[1] = a.y > carry ? a.y : carry; src[2] = a.z > carry ? a.z : carry;
+    src[3] = a.w > carry ? a.w : carry; src[4] = b.x > carry ? b.x : carry; src[5] = b.y > carry ? b.y : carry;
+    src[6] = b.z > carry ? b.z : carry; src[7] = b.w > carry ? b.w : carry;
+    const int32_t j = pass + 8 * tid;
+    if (j < T1) {
+      int32_t d = (int32_t)((uint32_t)j / (uint32_t)n);          // owner of slot j
+      int32_t d_end = (d + 1) * n;
+      if (d == rank && j + 8 <= T1 && j + 8 <= d_end) {            // the common case: 8 slots of my own shard
+        rs_u32x4_a4 va, vb;
+        va.x = src[0]; va.y = src[1]; va.z = src[2]; va.w = src[3]; vb.x = src[4]; vb.y = src[5]; vb.z = src[6]; vb.w = src[7];
+        *reinterpret_cast<rs_u32x4_a4*>(next_idx + (j - base)) = va;
+        *reinterpret_cast<rs_u32x4_a4*>(next_idx + (j - base) + 4) = vb;
+      } else {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          const int32_t jj = j + c;
+          if (jj < T1) {
+            if (jj >= d_end) { ++d; d_end += n; }
+            if (d == rank) next_idx[jj - base] = (int32_t)src[c];
+            else {
+              const int32_t first = S > d * n ? S : d * n;        // first slot this rank sends to d
+              const int32_t k = jj - first;
+              if (k < cap) send[(int64_t)d * cap + k] = state[src[c]]; else overflow = true;
+            }
+          }
+        }
+      }
+    }
+  }
+  if (overflow) plan[GMX_PLAN_OVERFLOW] = 1;
+}
+
 // gmx_shard_totals + gmx_shard_step_tiles as ONE launch: straight from the all-gathered statistics table.
 extern "C" int gmx_shard_step_fused(int kind, const uint32_t key[2], const void* stats_all_d, int64_t* plan_d,
                                     uint64_t* total_out_d, const float* lw_d, float* max_out_d, int shift, int rank,
@@ -2389,6 +2637,22 @@ extern "C" int gmx_shard_step_fused(int kind, const uint32_t key[2], const void*
   ts.tmax = (const float*)(own + (size_t)tiles_pad * 8);
   ts.max_g = nullptr; ts.scale = gmx_pow2i(shift); ts.n_tiles = (int)tiles;
   ts.stats_all = (const uint8_t*)stats_all_d; ts.stride = stride; ts.max_out = max_out_d;
+  const char* fill_env = getenv("GENMI_SHARD_FILL");           // read per call: the tests compare both forms in one process
+  const bool fill = !(fill_env && fill_env[0] == '0');
+  if (fill && n_per_rank * world < (1LL << 30)) {      // slots as 32-bit integers: the LDS-routed form
+    uint32_t b0, b1;
+    gmx_threefry2x32(key[0], key[1], 0u, 0u, &b0, &b1);           // bits32(key, 0) on the host
+    const uint32_t u0 = (b0 ^ b1) >> 9;
+#define GMX_LAUNCH_SF(KIND)                                                                                           \
+    hipLaunchKernelGGL((k_shard_step_fill<KIND>), dim3((unsigned)tiles), dim3(GMX_BLOCK), 0, (hipStream_t)stream, key[0],  \
+                       key[1], u0, lw_d, (const uint8_t*)stats_all_d, stride, (int)tiles, ts.scale, rank, world,       \
+                       (int32_t)n_per_rank, (int32_t)capacity, plan_d, total_out_d, max_out_d, (const uint32_t*)state_d,   \
+                       (uint32_t*)send_d, next_idx_d)
+    if (kind == GMX_RESAMPLE_SYSTEMATIC) GMX_LAUNCH_SF(GMX_RESAMPLE_SYSTEMATIC); else GMX_LAUNCH_SF(GMX_RESAMPLE_STRATIFIED);
+#undef GMX_LAUNCH_SF
+    GMX_HIP(hipGetLastError());
+    return 0;
+  }
   hipLaunchKernelGGL((k_shard_step<true, true>), dim3((unsigned)tiles), dim3(GMX_BLOCK), 0, (hipStream_t)stream, kind, key[0],
                      key[1], (const uint64_t*)nullptr, plan_d, total_out_d, (const uint64_t*)nullptr, ts, rank, world,
                      n_per_rank, capacity, (const uint32_t*)state_d, (uint32_t*)send_d, next_idx_d);

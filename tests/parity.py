@@ -282,7 +282,7 @@ def check_shard_route(n=1000, world=4, capacity=None, kind=None, seed=0, skew=0.
     cdfs, sends, idxs, xexts, plans = [], [], [], [], []
     ws = torch.zeros(((be.c.gmx_weight_cdf_workspace(n) + 7) // 8,), dtype=torch.int64, device=dev)
     lws = [T(lw[r * n:(r + 1) * n]) for r in range(world)]
-    if fused == "tiles":        # the two-collective form: tile statistics -> totals + global max, no CDF array
+    if fused in ("tiles", "stats"):        # the two-collective form: tile statistics -> totals + global max, no CDF array
         sb = int(be.c.gmx_shard_stats_bytes(n))
         pad = (n + 1023) // 1024
         pad += pad & 1
@@ -309,7 +309,15 @@ def check_shard_route(n=1000, world=4, capacity=None, kind=None, seed=0, skew=0.
         xe[:n] = T(x[r * n:(r + 1) * n])
         send = torch.full((world * C,), float("nan"), dtype=torch.float32, device=dev)
         idx = torch.full((n,), -1, dtype=torch.int32, device=dev)
-        if fused == "tiles":
+        if fused == "stats":     # gmx_shard_step_fused: totals + plan + route straight from the gathered table
+            mx = torch.zeros((1,), dtype=torch.float32, device=dev)
+            be.check(be.c.gmx_shard_step_fused(kind, kk, be.ptr(stats_all), be.ptr(plan), be.ptr(tot), be.ptr(lws[r]),
+                                               be.ptr(mx), shift, r, world, n, C, be.ptr(xe), be.ptr(send), be.ptr(idx),
+                                               be.stream()), "gmx_shard_step_fused")
+            if not dead:
+                assert float(mx.item()) == M_ref
+                assert int(tot.item()) & 0xFFFFFFFFFFFFFFFF == total_ref
+        elif fused == "tiles":
             be.check(be.c.gmx_shard_step_tiles(kind, kk, be.ptr(totals), be.ptr(plan), be.ptr(tot), be.ptr(lws[r]),
                                                be.ptr(stats_all[r * sb:(r + 1) * sb]), be.ptr(max_d), shift, r, world,
                                                n, C, be.ptr(xe), be.ptr(send), be.ptr(idx), be.stream()),

@@ -374,7 +374,7 @@ def test_plates_match_oracle(gpu, n):
     (101_376, 5, {"seed": 8}), (2048, 4, {"seed": 9, "kind": 1}),
     (2048, 4, {"seed": 12, "spike": 14.0}), (4096, 3, {"seed": 13, "spike": 30.0, "kind": 1}),   # wave-cooperative long runs
 ])
-@pytest.mark.parametrize("fused", [False, True, "tiles"])
+@pytest.mark.parametrize("fused", [False, True, "tiles", "stats"])
 def test_global_resampling_routes_match_oracle(gpu, n, world, kw, fused):
     """gmx_shard_plan + gmx_shard_route, and their one-launch form gmx_shard_step, with every rank
     emulated on one GPU == the oracle's single-population resample (bit-exact ancestors => states)."""
@@ -385,6 +385,21 @@ def test_global_resampling_routes_match_oracle(gpu, n, world, kw, fused):
 def test_global_resampling_flags_overflow(gpu):
     assert parity.check_shard_route(1024, 3, skew=2.0, seed=1, capacity=5)["overflow"]
     assert parity.check_shard_route(1024, 3, skew=2.0, seed=1, capacity=5, fused="tiles")["overflow"]
+    assert parity.check_shard_route(1024, 3, skew=2.0, seed=1, capacity=5, fused="stats")["overflow"]
+    assert parity.check_shard_route(2048, 2, dead=True, fused="stats", capacity=100)["overflow"]
+
+
+@pytest.mark.parametrize("fill", ["1", "0"])
+def test_fused_shard_step_heavy_tiles_and_ragged_shards(gpu, monkeypatch, fill):
+    """gmx_shard_step_fused in both forms (LDS-routed k_shard_step_fill, and GENMI_SHARD_FILL=0: k_shard_step<tiles,
+    fused>): a tile that owns far more than 2048 slots (several fill passes, runs crossing rank boundaries), no mass at
+    all, one rank, a shard that is not a multiple of the tile."""
+    monkeypatch.setenv("GENMI_SHARD_FILL", fill)
+    assert not parity.check_shard_route(4096, 4, seed=21, spike=40.0, fused="stats")["overflow"]
+    assert not parity.check_shard_route(2048, 3, seed=22, spike=25.0, kind=O.STRATIFIED, fused="stats")["overflow"]
+    assert not parity.check_shard_route(2048, 4, dead=True, fused="stats")["overflow"]
+    assert not parity.check_shard_route(1000, 1, fused="stats", seed=23)["overflow"]
+    assert not parity.check_shard_route(250_880, 4, seed=24, skew=1.0, fused="stats")["overflow"]
 
 
 def test_sharded_sweep_world1_matches_oracle(gpu):

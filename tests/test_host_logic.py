@@ -533,6 +533,13 @@ def test_global_resampling_routes_match_oracle():
     assert parity.check_shard_route(1024, 3, skew=2.0, seed=1, capacity=5, fused="tiles")["overflow"]
     assert not parity.check_shard_route(64, 2, dead=True, fused="tiles")["overflow"]
     assert not parity.check_shard_route(1000, 1, fused="tiles")["overflow"]
+    # gmx_shard_step_fused: straight from the gathered statistics table
+    assert not parity.check_shard_route(2048, 4, fused="stats", seed=4)["overflow"]
+    assert not parity.check_shard_route(1024, 8, fused="stats", skew=-3.0, seed=2, kind=O.STRATIFIED)["overflow"]
+    assert parity.check_shard_route(1024, 3, skew=2.0, seed=1, capacity=5, fused="stats")["overflow"]
+    assert not parity.check_shard_route(64, 2, dead=True, fused="stats")["overflow"]
+    assert not parity.check_shard_route(1000, 1, fused="stats")["overflow"]
+    assert not parity.check_shard_route(2048, 4, seed=12, spike=14.0, fused="stats")["overflow"]
 
 
 def test_conditional_smc_and_proposals():

@@ -2379,7 +2379,7 @@ k_shard_step_fill(uint32_t k0, uint32_t k1, uint32_t u0_host, const float* __res
                   float* __restrict__ max_out, const uint32_t* __restrict__ state, uint32_t* __restrict__ send,
                   int32_t* __restrict__ next_idx) {
   __shared__ uint64_t s_part[SHARD_MAX_WORLD][4];
-  __shared__ uint64_t s_below[4], s_scan[4], s_tot[2];
+  __shared__ uint64_t s_below[4], s_scan[4];
   __shared__ float s_max[4];
   __shared__ int32_t s_bounds[SHARD_MAX_WORLD + 1];
   __shared__ __attribute__((aligned(16))) uint32_t s_mark[RS_FILL_SLOTS];
@@ -2444,47 +2444,43 @@ k_shard_step_fill(uint32_t k0, uint32_t k1, uint32_t u0_host, const float* __res
   below = wave_sum_u64(below);
   if (lane == 0) s_below[wave] = below;
   __syncthreads();
-  if (tid < world) {                    // thread s: rank s's CDF offset and slot bound
-    uint64_t total = 0, off = 0;
-    for (int r = 0; r < world; ++r) {
-      const uint64_t rt = (s_part[r][0] + s_part[r][1]) + (s_part[r][2] + s_part[r][3]);
-      off += (r < tid) ? rt : 0ull;
-      total += rt;
+  // every WAVE derives the global total and this rank's CDF offset itself (lane s holds rank s's total: 4 LDS reads
+  // and one 64-bit scan), so nothing below waits for the slot bounds; wave 0's lanes s < world evaluate those — rank
+  // s's first slot, by the exact predicate — while the other waves are already at their sources' slot runs; the
+  // barrier before the LDS fill publishes them.
+  uint64_t rt = 0;
+  if (lane < world) rt = (s_part[lane][0] + s_part[lane][1]) + (s_part[lane][2] + s_part[lane][3]);
+  const uint64_t rscan = wave_scan_u64(rt);
+  const uint64_t total = wave_last_u64(rscan);
+  const uint64_t my_off = rscan - rt;
+  const uint64_t cdf_offset = (uint64_t)shard_readlane64((int64_t)my_off, rank);
+  if (wave == 0) {
+    if (lane < world) {
+      const double not_ = total ? (double)N / (double)total : 0.0;
+      const double eps_ = (double)N * 0x1p-44 + 0x1p-40;
+      s_bounds[lane] = total ? (int32_t)slots_below(kind, key, (uint64_t)u0_host, my_off, (uint64_t)N << 23, total, not_, eps_, (int64_t)N) : 0;
     }
-    const double not_ = total ? (double)N / (double)total : 0.0;
-    const double eps_ = (double)N * 0x1p-44 + 0x1p-40;
-    s_bounds[tid] = total ? (int32_t)slots_below(kind, key, (uint64_t)u0_host, off, (uint64_t)N << 23, total, not_, eps_, (int64_t)N) : 0;
-    if (tid == rank) s_tot[1] = off;
-    if (tid == 0) { s_tot[0] = total; s_bounds[world] = N; }
-  }
-  __syncthreads();
-  const uint64_t total = s_tot[0], cdf_offset = s_tot[1];
-  if (blockIdx.x == 0 && tid == 0) {       // published for inspection / tests; the overflow word is left alone
-    plan[GMX_PLAN_TOTAL] = (int64_t)total; plan[GMX_PLAN_OFFSET] = (int64_t)cdf_offset;
-    for (int s = 0; s <= world; ++s) plan[GMX_PLAN_BOUNDS + s] = (int64_t)s_bounds[s];
-    if (total_out) *total_out = total;
-    if (max_out) *max_out = M;
+    if (lane == 0) s_bounds[world] = N;
   }
   bool overflow = false;
-  // (b) my slots base + i0..+3: an ancestor on rank s != rank arrives at recv[s*cap + k]
-  if (world > 1) {
+  if (total == 0) {       // no mass at all: the globally last particle (rank world-1, local n-1) sources every slot
+    if (blockIdx.x == 0 && tid == 0) {
+      plan[GMX_PLAN_TOTAL] = 0; plan[GMX_PLAN_OFFSET] = 0;
+      for (int s = 0; s < world; ++s) plan[GMX_PLAN_BOUNDS + s] = 0;
+      plan[GMX_PLAN_BOUNDS + world] = (int64_t)N;
+      if (total_out) *total_out = 0ull;
+      if (max_out) *max_out = M;
+    }
+    if (rank != world - 1) {            // my slot base + i arrives as element i of rank world-1's block
 #pragma unroll
-    for (int c = 0; c < CDF_VEC; ++c) {
-      const int32_t i = i0 + c;
-      if (i < n) {
-        const int32_t jj = base + i;
-        int s = 0;
-        while (s + 1 < world && s_bounds[s + 1] <= jj) ++s;
-        if (s != rank) {
-          const int32_t first = s_bounds[s] > base ? s_bounds[s] : base;
-          const int32_t k = jj - first;
-          if (k < cap) next_idx[i] = n + s * cap + k;
+      for (int c = 0; c < CDF_VEC; ++c) {
+        const int32_t i = i0 + c;
+        if (i < n) {
+          if (i < cap) next_idx[i] = n + (world - 1) * cap + i;
           else { next_idx[i] = 0; overflow = true; }
         }
       }
     }
-  }
-  if (total == 0) {       // no mass at all: the globally last particle (rank world-1, local n-1) sources every slot
     if (rank == world - 1) {
       const uint32_t v = state[n - 1];
 #pragma unroll
@@ -2554,6 +2550,30 @@ k_shard_step_fill(uint32_t k0, uint32_t k1, uint32_t u0_host, const float* __res
   __syncthreads();
   const int32_t T0 = __builtin_amdgcn_readfirstlane(s_rng[0]), T1 = __builtin_amdgcn_readfirstlane(s_rng[1]);
   const int32_t S = s_bounds[rank];          // the first slot whose ancestor lives on this rank
+  if (blockIdx.x == 0 && tid == 0) {       // published for inspection / tests; the overflow word is left alone
+    plan[GMX_PLAN_TOTAL] = (int64_t)total; plan[GMX_PLAN_OFFSET] = (int64_t)cdf_offset;
+    for (int s = 0; s <= world; ++s) plan[GMX_PLAN_BOUNDS + s] = (int64_t)s_bounds[s];
+    if (total_out) *total_out = total;
+    if (max_out) *max_out = M;
+  }
+  // (b) my slots base + i0..+3: an ancestor on rank s != rank arrives at recv[s*cap + k]
+  if (world > 1) {
+#pragma unroll
+    for (int c = 0; c < CDF_VEC; ++c) {
+      const int32_t i = i0 + c;
+      if (i < n) {
+        const int32_t jj = base + i;
+        int s = 0;
+        while (s + 1 < world && s_bounds[s + 1] <= jj) ++s;
+        if (s != rank) {
+          const int32_t first = s_bounds[s] > base ? s_bounds[s] : base;
+          const int32_t k = jj - first;
+          if (k < cap) next_idx[i] = n + s * cap + k;
+          else { next_idx[i] = 0; overflow = true; }
+        }
+      }
+    }
+  }
   for (int32_t pass = T0; pass < T1; pass += RS_FILL_SLOTS) {      // block-uniform (1 pass unless the tile owns > 2048 slots)
     if (pass != T0) {
       __syncthreads();

@@ -127,6 +127,9 @@ class Backend:
         c.gmx_tile_stats.argtypes = [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p]
         c.gmx_resample_tiles.argtypes = [c_int, POINTER(c_uint32), c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p,
                                          c_void_p, c_void_p, c_void_p]
+        c.gmx_slot_uniforms.argtypes = [c_void_p, c_int, c_int64, c_void_p, c_int, c_void_p]
+        c.gmx_resample_tiles_u.argtypes = [c_int, POINTER(c_uint32), c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p,
+                                           c_void_p, c_void_p, c_void_p, c_void_p]
         c.gmx_resample_tiles_q.argtypes = [c_int, POINTER(c_uint32), c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p,
                                            c_void_p, c_void_p, c_void_p]
         c.gmx_tile_prefix_words.argtypes = [c_int64]

@@ -1532,7 +1532,8 @@ template <int kind, bool FROMQ, int PER, bool FILL>
 __global__ void __launch_bounds__(RS_BLOCK)
 k_offspring_tile(uint32_t k0, uint32_t k1, uint32_t u0_host, const float* __restrict__ lw, const uint32_t* __restrict__ qin,
                  const float* __restrict__ tmax, const uint64_t* __restrict__ agg, int64_t n, int n_tiles, float scale,
-                 float* __restrict__ max_out, uint64_t* __restrict__ total_out, int32_t* __restrict__ anc) {
+                 float* __restrict__ max_out, uint64_t* __restrict__ total_out, int32_t* __restrict__ anc,
+                 const uint32_t* __restrict__ uslot) {
   GMX_SETPRIO
   __shared__ uint64_t s_below[RS_WAVES], s_all[RS_WAVES], s_scan[RS_WAVES], s_g[RS_TPB];
   __shared__ float s_max[RS_WAVES];
@@ -1689,13 +1690,13 @@ k_offspring_tile(uint32_t k0, uint32_t k1, uint32_t u0_host, const float* __rest
   uint32_t near_bits = 0;
 #pragma unroll
   for (int c = 1; c <= CDF_VEC; ++c) {
-    const sb_est r = slots_below_est<kind>(key, u0_host, cv[c], total, n_over_total, eps, n32);
+    const sb_est r = slots_below_est<kind>(key, u0_host, cv[c], total, n_over_total, eps, n32, uslot);
     e[c] = r.j;
     near_bits |= r.near ? (1u << c) : 0u;
   }
   // lower bound of the thread's first source = upper bound of the previous thread's last one; lane 0 evaluates its own
   {
-    const sb_est r = slots_below_est<kind>(key, u0_host, cv[0], total, n_over_total, eps, n32);
+    const sb_est r = slots_below_est<kind>(key, u0_host, cv[0], total, n_over_total, eps, n32, uslot);
     near_bits |= (lane == 0 && r.near) ? 1u : 0u;
     e[0] = (int32_t)wave_shr1_u32((uint32_t)e[CDF_VEC], (uint32_t)r.j);
     if (lane == 0) e[0] = r.j;
@@ -1795,7 +1796,7 @@ static int resample_shape(const char* who, int64_t n, int shift) {
 
 static int launch_offspring_tile(int kind, const uint32_t key[2], const float* lw_d, const uint32_t* q_d, int64_t n, int shift,
                                  const float* tile_max_d, const uint64_t* tile_agg_d, float* max_d, uint64_t* total_d,
-                                 int32_t* ancestors_d, gmx_stream stream, bool pref = false) {
+                                 int32_t* ancestors_d, gmx_stream stream, bool pref = false, const uint32_t* u_d = nullptr) {
   uint32_t b0, b1;
   gmx_threefry2x32(key[0], key[1], 0u, 0u, &b0, &b1);           // bits32(key, 0) on the host
   const uint32_t u0 = (b0 ^ b1) >> 9;
@@ -1806,7 +1807,7 @@ static int launch_offspring_tile(int kind, const uint32_t key[2], const float* l
   static const bool fill = []() { const char* e = getenv("GENMI_RS_FILL"); return !(e && e[0] == '0'); }();   // default: through LDS
 #define GMX_LAUNCH_OT4(KIND, FQ, PER_, FILL_)                                                                        \
   hipLaunchKernelGGL((k_offspring_tile<KIND, FQ, PER_, FILL_>), grid, block, 0, st, key[0], key[1], u0, lw_d, q_d,     \
-                     tile_max_d, tile_agg_d, n, (int)tiles, scale, max_d, total_d, ancestors_d)
+                     tile_max_d, tile_agg_d, n, (int)tiles, scale, max_d, total_d, ancestors_d, u_d)
 #define GMX_LAUNCH_OT3(KIND, FQ, PER_) do { if (fill) GMX_LAUNCH_OT4(KIND, FQ, PER_, true); else GMX_LAUNCH_OT4(KIND, FQ, PER_, false); } while (0)
 #define GMX_LAUNCH_OT(KIND, FQ)                                                                                     \
   do {                                                                                                              \
@@ -1861,6 +1862,53 @@ extern "C" int gmx_resample_tiles_q(int kind, const uint32_t key[2], const uint3
   if (n > 0x7fffffffLL) return gmx_fail("gmx_resample_tiles_q: n out of range%s");
   if ((uintptr_t)q_d & 15) return gmx_fail("gmx_resample_tiles_q: q_d must be 16-byte aligned%s");
   return launch_offspring_tile(kind, key, nullptr, q_d, n, shift, tile_max_d, tile_agg_d, max_d, total_d, ancestors_d, stream);
+}
+
+// ---- the stratified resampler's per-slot uniforms, ahead of time ----
+// out[r][j] = bits32(keys[r], j) >> 9: what slots_below_est<stratified> would draw for slot j of the resampling keyed
+// keys[r].  They depend on keys and slot numbers only, so a sweep draws them on its background stream, a group of steps
+// ahead (the same treatment as the steps' normal draws: priority 0, `lds_pad` bytes of unused LDS per workgroup cap the
+// residency), and gmx_resample_tiles_u reads them.  2-D launch: one grid row per key.
+__global__ void __launch_bounds__(GMX_BLOCK)
+k_slot_uniforms(const uint32_t* __restrict__ keys, int64_t n, uint32_t* __restrict__ out) {
+  gmx_key key;
+  key.k0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)keys[2 * blockIdx.y]);
+  key.k1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)keys[2 * blockIdx.y + 1]);
+  const int64_t j0 = ((int64_t)blockIdx.x * GMX_BLOCK + threadIdx.x) * 4;
+  uint32_t* row = out + (int64_t)blockIdx.y * n;
+  uint32_t u[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) u[c] = gmx_bits32(key, (uint64_t)(j0 + c)) >> 9;
+  if (j0 + 4 <= n && (((uintptr_t)(row + j0)) & 15) == 0) {
+    *reinterpret_cast<uint4*>(row + j0) = make_uint4(u[0], u[1], u[2], u[3]);
+  } else {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) if (j0 + c < n) row[j0 + c] = u[c];
+  }
+}
+
+extern "C" int gmx_slot_uniforms(const uint32_t* keys_d, int rows, int64_t n, uint32_t* out_d, int lds_pad,
+                                 gmx_stream stream) {
+  if (!keys_d || !out_d) return gmx_fail("gmx_slot_uniforms: null argument%s");
+  if (rows < 1 || rows > 65535 || n <= 0 || n > 0x7fffffffLL) return gmx_fail("gmx_slot_uniforms: rows / n out of range%s");
+  if (lds_pad < 0 || lds_pad > 64 * 1024) return gmx_fail("gmx_slot_uniforms: lds_pad out of range (<= 64 KB)%s");
+  hipLaunchKernelGGL(k_slot_uniforms, dim3((unsigned)((n + 4 * GMX_BLOCK - 1) / (4 * GMX_BLOCK)), (unsigned)rows),
+                     dim3(GMX_BLOCK), (size_t)lds_pad, (hipStream_t)stream, keys_d, n, out_d);
+  GMX_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int gmx_resample_tiles_u(int kind, const uint32_t key[2], const float* lw_d, int64_t n, int shift,
+                                    const float* tile_max_d, const uint64_t* tile_agg_d, const uint32_t* u_d,
+                                    float* max_d, uint64_t* total_d, int32_t* ancestors_d, gmx_stream stream) {
+  if (resample_shape("gmx_resample_tiles_u", n, shift)) return 1;
+  if (!key || !lw_d || !tile_max_d || !tile_agg_d || !u_d || !max_d || !total_d || !ancestors_d)
+    return gmx_fail("gmx_resample_tiles_u: null argument%s");
+  if (kind != GMX_RESAMPLE_STRATIFIED) return gmx_fail("gmx_resample_tiles_u: stratified only (systematic draws one uniform)%s");
+  if (n > 0x7fffffffLL) return gmx_fail("gmx_resample_tiles_u: n out of range%s");
+  if ((uintptr_t)lw_d & 15) return gmx_fail("gmx_resample_tiles_u: lw_d must be 16-byte aligned%s");
+  return launch_offspring_tile(kind, key, lw_d, nullptr, n, shift, tile_max_d, tile_agg_d, max_d, total_d, ancestors_d, stream,
+                               false, u_d);
 }
 
 extern "C" size_t gmx_tile_prefix_words(int64_t n) { return gmx_tile_prefix_words_(n); }

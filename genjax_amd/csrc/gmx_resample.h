@@ -41,8 +41,11 @@ __device__ __forceinline__ int64_t slots_below_exact(int kind, gmx_key key, uint
 // settled afterwards by ONE rolled loop over the exact predicate.  Same answer as slots_below() in every case.
 struct sb_est { int32_t j; bool near; };
 template <int kind>
+// uslot (stratified only, optional): slot t's 23-bit uniform read from memory (gmx_slot_uniforms wrote
+// bits32(key, t) >> 9 there — on a background stream, ahead of the chain) instead of one Threefry block per evaluation.
 __device__ __forceinline__ sb_est slots_below_est(gmx_key key, uint32_t u0, uint64_t c, uint64_t total,
-                                                  double n_over_total, double eps, int32_t n_out) {
+                                                  double n_over_total, double eps, int32_t n_out,
+                                                  const uint32_t* __restrict__ uslot = nullptr) {
   const double cd = __builtin_fma((double)(uint32_t)(c >> 32), 4294967296.0, (double)(uint32_t)c);   // exact product, one rounding
   sb_est r;
   if (kind == GMX_RESAMPLE_SYSTEMATIC) {
@@ -59,7 +62,7 @@ __device__ __forceinline__ sb_est slots_below_est(gmx_key key, uint32_t u0, uint
   int32_t t = (int32_t)v;                        // floor (v >= 0), saturating
   t = t < n_out - 1 ? t : n_out - 1;
   const double frac = v - (double)t;
-  const uint32_t u = gmx_bits32(key, (uint64_t)(uint32_t)t) >> 9;
+  const uint32_t u = uslot ? uslot[t] : (gmx_bits32(key, (uint64_t)(uint32_t)t) >> 9);
   const double diff = frac - (double)u * (1.0 / 8388608.0);
   r.j = t + (diff > 0.0 ? 1 : 0);
   r.near = (frac < eps) || (frac > 1.0 - eps) || !(__builtin_fabs(diff) > eps);

@@ -768,12 +768,17 @@ class _NoiseAhead:
         return out
 
     def _launch_noise_group(self, g):
+        self._launch_group_extras(g)
         if os.environ.get("GENMI_NOISE_ROWS", "1") == "0":
             for t in range(*self.noise_groups[g]):
                 self._launch_noise(t)
             return
         for q, batch, key, outs in self._noise_runs(g):
             q.run(batch, key, outs)
+
+    def _launch_group_extras(self, g):
+        """other key-only work of group g's steps that belongs on the background stream (BootstrapSweep: the stratified
+        resampler's slot uniforms)"""
 
     def _launch_noise(self, t):
         """the draws step t's chain program reads, by the background programs: root LDKEY from the program's launch key
@@ -1054,6 +1059,7 @@ class BootstrapSweep(_NoiseAhead):
         for t in range(T):
             ks = split(fold_in(key, t), 3)
             self.step_keys.append((ks[0], ks[1], ks[2]))
+        self._slot_uniforms_setup()
         return self
 
     def _gathered(self, which):
@@ -1174,10 +1180,46 @@ class BootstrapSweep(_NoiseAhead):
         be.check(be.c.gmx_ancestors(self.kind, kk, be.ptr(self.cdf), self.n, 0, be.ptr(self.totals[t:t + 1]),
                                     self.n, 0, self.n, be.ptr(self.anc), be.stream()), "gmx_ancestors")
 
+    def _slot_uniforms_setup(self):
+        """Stratified resampling draws one uniform per SLOT, keyed by the step's resampling key and the slot number —
+        nothing the chain produces.  In the noise-ahead form they are drawn on the background stream with the steps'
+        normals (gmx_slot_uniforms, one 2-D launch per group of steps) and the resampler reads them
+        (gmx_resample_tiles_u): the same ancestors, one Threefry block per slot-edge evaluation less on the chain.
+        GENMI_SLOT_UNIFORMS=0: drawn inside the resampler."""
+        self.ubuf = None
+        if not (self.noise_ahead and self.kind == STRATIFIED and self.fused and self.tile_stats and self.tile_q is None
+                and self.tile_pref is None and not self.fuse and os.environ.get("GENMI_SLOT_UNIFORMS", "1") != "0"):
+            return
+        dev = self.zbuf.device
+        self.ubuf = torch.zeros((2, self.noise_group, self.n), dtype=torch.int32, device=dev)
+        self._u_keys = []
+        for t0, t1 in self.noise_groups:
+            ks = np.stack([self.step_keys[t][1].host() for t in range(t0, t1)]).astype(np.uint32)
+            self._u_keys.append(torch.from_numpy(ks.view(np.int32)).to(dev))
+        self._u_pad = int(os.environ.get("GENMI_NOISE_LDS_PAD", self.NOISE_LDS_PAD))
+
+    def _launch_group_extras(self, g):
+        if getattr(self, "ubuf", None) is None:
+            return
+        be = _lib.get()
+        t0, t1 = self.noise_groups[g]
+        half, row = self.noise_slot[t0]
+        be.check(be.c.gmx_slot_uniforms(be.ptr(self._u_keys[g]), t1 - t0, self.n, be.ptr(self.ubuf[half, row:row + (t1 - t0)]),
+                                        self._u_pad, be.stream()), "gmx_slot_uniforms")
+
     def _launch_resample(self, t):
         be = _lib.get()
         kh = self.step_keys[t][1].host()
         kk = (c_uint32 * 2)(int(kh[0]), int(kh[1]))
+        if getattr(self, "ubuf", None) is not None:
+            w = t % 2
+            half, row = self.noise_slot[t]
+            be.check(be.c.gmx_resample_tiles_u(self.kind, kk, be.ptr(self.lw_pp[w]), self.n, self.shift,
+                                               be.ptr(self.partials_pp[w]), be.ptr(self.tile_agg_pp[w]),
+                                               be.ptr(self.ubuf[half, row]), be.ptr(self.maxs[t:t + 1]),
+                                               be.ptr(self.totals[t:t + 1]), be.ptr(self.anc), be.stream()),
+                     "gmx_resample_tiles_u")
+            return
         if self.tile_stats and self.tile_q is not None:
             be.check(be.c.gmx_resample_tiles_q(self.kind, kk, be.ptr(self.tile_q), self.n, self.shift,
                                                be.ptr(self.partials), be.ptr(self.tile_agg), be.ptr(self.maxs[t:t + 1]),

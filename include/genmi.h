@@ -303,6 +303,17 @@ int gmx_tile_prefix(const float* tile_max_d, const uint64_t* tile_agg_d, int64_t
 int gmx_resample_tiles_p(int kind, const uint32_t key[2], const float* lw_d, int64_t n, int shift,
                          const float* tile_max_d, const uint64_t* tile_pref_d, float* max_d,
                          uint64_t* total_d, int32_t* ancestors_d, gmx_stream stream);
+/* The stratified resampler's per-slot uniforms drawn AHEAD of the resampling (they depend on the key and the slot
+ * number only): gmx_slot_uniforms fills out_d[r][j] = bits32(keys_d[r], j) >> 9 for `rows` resampling keys (device
+ * array [rows, 2]) in one 2-D launch — meant for a background stream beside a dependent chain of launches: `lds_pad`
+ * bytes of unused LDS per workgroup cap its residency (0: none).  gmx_resample_tiles_u = gmx_resample_tiles
+ * (stratified) reading slot j's uniform from u_d[j] instead of drawing it: the same ancestors, one Threefry block per
+ * slot-edge evaluation less on the chain.  (No reference counterpart: build-defined resampling, SURVEY App. B.) */
+int gmx_slot_uniforms(const uint32_t* keys_d /* [rows,2] */, int rows, int64_t n, uint32_t* out_d /* [rows,n] */,
+                      int lds_pad, gmx_stream stream);
+int gmx_resample_tiles_u(int kind, const uint32_t key[2], const float* lw_d, int64_t n, int shift,
+                         const float* tile_max_d, const uint64_t* tile_agg_d, const uint32_t* u_d /* [n] */,
+                         float* max_d, uint64_t* total_d, int32_t* ancestors_d, gmx_stream stream);
 int gmx_gather(const void* const* src_d, void* const* dst_d, const int32_t* elem_bytes,
                int32_t n_leaves, const int32_t* ancestors_d, int64_t n_out,
                gmx_stream stream);

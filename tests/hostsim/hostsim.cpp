@@ -366,6 +366,26 @@ extern "C" int gmx_resample_tiles_p(int kind, const uint32_t key[2], const float
   *max_d = M; *total = pref[tiles];
   return gmx_ancestors(kind, key, cdf.data(), n, 0, total, n, 0, n, anc, st);
 }
+// the stratified resampler's uniforms ahead of time, and the resampler that reads them (the mirror checks that what it
+// is handed IS what the resampling would draw, then resamples as usual)
+extern "C" int gmx_slot_uniforms(const uint32_t* keys, int rows, int64_t n, uint32_t* out, int lds_pad, gmx_stream) {
+  if (!keys || !out || rows < 1 || n <= 0 || lds_pad < 0) return fail("slot_uniforms: bad argument");
+  for (int r = 0; r < rows; ++r) {
+    gmx_key k; k.k0 = keys[2 * r]; k.k1 = keys[2 * r + 1];
+    for (int64_t j = 0; j < n; ++j) out[(int64_t)r * n + j] = gmx_bits32(k, (uint64_t)j) >> 9;
+  }
+  return 0;
+}
+extern "C" int gmx_resample_tiles_u(int kind, const uint32_t key[2], const float* lw, int64_t n, int shift, const float* tmax,
+                                    const uint64_t* agg, const uint32_t* u, float* max_d, uint64_t* total, int32_t* anc,
+                                    gmx_stream st) {
+  if (kind != GMX_RESAMPLE_STRATIFIED) return fail("resample_tiles_u: stratified only");
+  if (!key || !u) return fail("resample_tiles_u: bad argument");
+  gmx_key k; k.k0 = key[0]; k.k1 = key[1];
+  for (int64_t j = 0; j < n; ++j)
+    if (u[j] != (gmx_bits32(k, (uint64_t)j) >> 9)) return fail("resample_tiles_u: u_d is not this key's slot uniforms");
+  return gmx_resample_tiles(kind, key, lw, n, shift, tmax, agg, max_d, total, anc, st);
+}
 // the same from the per-particle fixed-point weights the site program left behind
 extern "C" int gmx_resample_tiles_q(int kind, const uint32_t key[2], const uint32_t* q, int64_t n, int shift, const float* tmax,
                                     const uint64_t* agg, float* max_d, uint64_t* total, int32_t* anc, gmx_stream st) {

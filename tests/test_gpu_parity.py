@@ -891,9 +891,12 @@ def test_noise_ahead_sweep_matches_oracle(gpu, n, T, capture):
 def test_noise_ahead_with_stratified_resampling_and_env_switch(gpu, monkeypatch):
     """the two-stream form with the stratified resampler (one Threefry block per slot edge in the chain's resampler),
     and GENMI_NOISE_AHEAD=0 as the default's off switch"""
-    res = parity.check_lgssm_sweep(n=50_000, T=11, capture=True, specialize=True, resample="stratified", noise_ahead=True)
-    assert res["ancestors_equal"] and res["x_equal"] and res["totals_equal"] and res["lw_max_abs_diff"] == 0.0
     import genjax_amd as G
+    for su in ("1", "0"):       # the per-slot uniforms from the background stream (gmx_slot_uniforms), or drawn in the resampler
+        monkeypatch.setenv("GENMI_SLOT_UNIFORMS", su)
+        G.clear_caches()
+        res = parity.check_lgssm_sweep(n=50_000, T=23, capture=True, specialize=True, resample="stratified", noise_ahead=True)
+        assert res["ancestors_equal"] and res["x_equal"] and res["totals_equal"] and res["lw_max_abs_diff"] == 0.0
     from genjax_amd import workloads
     from genjax_amd.inference.smc import BootstrapSweep
     ys = workloads.lgssm_data(3)

@@ -1046,6 +1046,12 @@ def test_noise_ahead_sweep_matches_oracle(monkeypatch, rows):
     parity.check_tuple_state_sweep(noise_ahead=True)
     # with an MH move per step (config 3): the move's proposal + accept draws and the extension's draw, from two keys
     parity.check_nlssm_mh_sweep(n=1500, T=7, noise_ahead=True)
+    # stratified: the resampler's per-slot uniforms come from the background stream too (gmx_slot_uniforms ->
+    # gmx_resample_tiles_u; the CPU mirror refuses uniforms that are not the resampling key's own)
+    for su in ("1", "0"):
+        monkeypatch.setenv("GENMI_SLOT_UNIFORMS", su)
+        res = parity.check_lgssm_sweep(n=3000, T=23, noise_ahead=True, resample="stratified")
+        assert res["ancestors_equal"] and res["x_equal"] and res["totals_equal"] and res["lw_max_abs_diff"] == 0.0
 
 
 def test_noise_hoist_takes_launch_keyed_draws():

@@ -32,6 +32,8 @@ else:
     ys = workloads.lgssm_data(T)
     init, step = workloads.make_lgssm(G)
     kw = {}
+if os.environ.get("RESAMPLE"):            # systematic (default) | stratified | multinomial
+    kw["resample"] = os.environ["RESAMPLE"]
 sweeps, finals = {}, {}
 for v in values:
     os.environ[var] = v
@@ -53,7 +55,7 @@ for _ in range(rounds):
             sw.launch()
         torch.cuda.synchronize()
         times[v].append((time.perf_counter() - t0) / reps)
-out = {"switch": var, "n": n, "T": T, "config": cfg,
+out = {"switch": var, "n": n, "T": T, "config": cfg, "resample": os.environ.get("RESAMPLE", "systematic"),
        "us_per_step": {v: [round(1e6 * t / T, 3) for t in ts] for v, ts in times.items()},
        "best_us_per_step": {v: round(1e6 * min(ts) / T, 3) for v, ts in times.items()},
        "bit_identical": all(all(torch.equal(a, b) for a, b in zip(finals[values[0]], finals[v])) for v in values[1:])}

@@ -32,16 +32,17 @@ from .tracer import Expr
 
 SCAN_UNROLL_MAX = 16      # longer scans run as a counted loop in the site program (Scan._trace_loop)
 VMAP_UNROLL_MAX = 16      # larger plates run as a counted loop too (Vmap._trace_loop): one iteration per element
+NEST_UNROLL_MAX = 4       # an unrolled plate whose ELEMENT runs a counted loop keeps at most this many copies of it
 
 
 def _dyn_take(v, t):
     """element t (a run-time index) of a previous plate value: a step-indexed leaf reads it directly; a short vector
     held in registers goes through a chain of selects"""
-    from .engine import StepInput, Sym
+    from .engine import StepInput, StepInput2, Sym
     from .numpy import RuntimeTable, TableArray
     if isinstance(v, Sym):
         v = v.value
-    if isinstance(v, (StepInput, RuntimeTable, TableArray)):
+    if isinstance(v, (StepInput, StepInput2, RuntimeTable, TableArray)):
         return v[t]
     if isinstance(v, np.ndarray) and v.dtype == object and v.ndim >= 1:
         out = v[v.shape[0] - 1]
@@ -55,7 +56,7 @@ def _dyn_take(v, t):
 def _loop_at(v, t, what="a plate of more than 16 elements"):
     """element t (the iteration number of a counted loop) of a mapped argument / per-element constraint / previous
     value: a launch-uniform table, or a per-particle [n, T] leaf read step by step"""
-    from .engine import StepInput, Sym
+    from .engine import StepInput, StepInput2, Sym
     from .numpy import RuntimeTable, TableArray
     if isinstance(v, Sym):
         v = v.value
@@ -65,10 +66,12 @@ def _loop_at(v, t, what="a plate of more than 16 elements"):
         return tuple(_loop_at(x, t, what) for x in v)
     if isinstance(v, dict):
         return {k: _loop_at(x, t, what) for k, x in v.items()}
-    if isinstance(v, (RuntimeTable, TableArray, StepInput)):
+    if isinstance(v, (RuntimeTable, TableArray, StepInput, StepInput2)):
         return v[t]
     if isinstance(v, (list, np.ndarray)) and not (isinstance(v, np.ndarray) and v.dtype == object):
         return TableArray(np.asarray(v, dtype=np.float32 if np.asarray(v).dtype.kind == "f" else np.int32))[t]
+    if isinstance(v, np.ndarray) and v.dtype == object and 1 <= v.shape[0] <= VMAP_UNROLL_MAX:
+        return _dyn_take(v, t)           # a short vector COMPUTED in the model (registers): a chain of selects
     raise NotImplementedError(f"{what}: mapped arguments, per-element constraints and previous values must be "
                               "launch-uniform vectors (tables) or per-particle [n, T] arrays")
 
@@ -155,6 +158,9 @@ def _tree_take_axes(v, ax, fn):
 
 
 def _take(a, j):
+    from .engine import StepInput2
+    if isinstance(a, StepInput2):
+        return a[j]
     if isinstance(a, np.ndarray):
         v = a[j]
         return v.item() if isinstance(v, np.ndarray) and v.ndim == 0 and v.dtype == object else v
@@ -185,7 +191,8 @@ def _index_chm(chm: ChoiceMap, j, n):
             return Mask(pick(v.value), v.flag)
         if isinstance(v, Sym):
             inner = v.value
-            if isinstance(inner, np.ndarray) and inner.ndim >= 1 and inner.shape[0] == n:
+            from .engine import StepInput2
+            if isinstance(inner, (np.ndarray, StepInput2)) and inner.ndim >= 1 and inner.shape[0] == n:
                 return _take(inner, j)
             return inner
         if isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[0] == n:
@@ -194,11 +201,21 @@ def _index_chm(chm: ChoiceMap, j, n):
     return chm.map_values(pick)
 
 
+def _so(tr, origin, T):
+    """a loop output as the model sees it; `trailing` = its dims after the batch ((T,) + the site's event)"""
+    from .engine import StepOutput
+    return StepOutput(origin, T, len(tr.outputs[origin[1]][1]))
+
+
 def _stack(vals):
-    from .engine import Sym
+    from .engine import StepOutput, Sym
     vals = [v.value if isinstance(v, Sym) else v for v in vals]
     if all(v is None for v in vals):
         return None
+    if any(isinstance(v, StepOutput) for v in vals):
+        if not all(isinstance(v, StepOutput) for v in vals):
+            raise NotImplementedError("a plate whose elements mix loop outputs and plain values")
+        return StepOutput.stack(vals)
     if isinstance(vals[0], (tuple, list)):
         return type(vals[0])(_stack([v[k] for v in vals]) for k in range(len(vals[0])))
     arrs = [np.asarray(v, dtype=object) if not (isinstance(v, np.ndarray) and v.dtype == object) else v for v in vals]
@@ -296,15 +313,31 @@ class Vmap(GenerativeFunction):
         from .static import _rec_score
         g = ctx.tr.graph
         keep = ctx.store_sites
-        ctx.store_sites = False
+        was_deferred = getattr(ctx, "sites_deferred", False)
+        wanted = keep or was_deferred      # a parent plate deferred the stores: its elements' LOOP outputs are still wanted
+        ctx.store_sites, ctx.sites_deferred = False, wanted
         recs, rets = [], []
         weight = Expr(g.const_f32(0.0))
         score = Expr(g.const_f32(0.0))
+        probe = (len(g.nodes), g.n_out, len(ctx.tr.outputs)) if (n > NEST_UNROLL_MAX and not g.loop_counts) else None
         for j in range(n):
             kj = Expr(g.add("KDERIVE", (key.node,), imm=j, dtype="key")) if key is not None else None   # split(key, n)[j]
             args_j = tuple(_tree_take_axes(a, ax, lambda v: _take(v, j)) for a, ax in zip(args, axes))
             con_j = _index_chm(constraint, j, n)
             rec, ret, w, s = call_gen_fn(ctx, mode, self.gen_fn, kj, args_j, con_j, None, None, req_leaves, addr)
+            if j == 0 and probe is not None and any(nd.op == "LOOP" for nd in g.nodes[probe[0]:]):
+                # element 0 opened a counted loop of its own (a long scan / a large plate somewhere inside a `@gen`
+                # element): n unrolled copies would need n times its output slots.  What element 0 traced is turned
+                # into dead code and the plate runs as a loop AROUND the element's loop (two nested counted loops).
+                from .program import EFFECT
+                for nd in g.nodes[probe[0]:]:
+                    if nd.op in EFFECT:
+                        nd.op, nd.args = "DEAD", ()
+                g.n_out = probe[1]
+                del ctx.tr.outputs[probe[2]:]
+                g._cse.clear()
+                ctx.store_sites, ctx.sites_deferred = keep, was_deferred
+                return self._trace_loop(ctx, mode, key, args, axes, constraint, n, req_leaves, addr)
             recs.append(rec)
             rets.append(ret)
             if keep:
@@ -315,7 +348,7 @@ class Vmap(GenerativeFunction):
             if w is not None:
                 weight = weight + w                    # w = sum over the plate (vmap.py:214)
             score = score + (s if mode == "assess" else _rec_score(rec))
-        ctx.store_sites = keep
+        ctx.store_sites, ctx.sites_deferred = keep, was_deferred
         merged = _merge(recs, self.gen_fn)
         retval = _stack(rets)
         if isinstance(merged, _SiteRec):
@@ -346,7 +379,9 @@ class Vmap(GenerativeFunction):
         from .static import _CallRec, _SiteRec, _rec_score, call_gen_fn
         g, tr = ctx.tr.graph, ctx.tr
         keep = ctx.store_sites
-        ctx.store_sites = False
+        was_deferred = getattr(ctx, "sites_deferred", False)
+        wanted = keep or was_deferred      # a parent plate deferred the stores: its elements' LOOP outputs are still wanted
+        ctx.store_sites, ctx.sites_deferred = False, wanted
         what = "a plate of more than 16 elements"
         zero = g.const_f32(0.0)
         wvar = g.loop_var(zero) if mode == "generate" else None
@@ -362,10 +397,10 @@ class Vmap(GenerativeFunction):
             for r in _leaves(rec):
                 val = r.value.value if isinstance(r.value, Sym) else r.value
                 sc = r.score.value if isinstance(r.score, Sym) else r.score
-                if keep:            # (a nested, unrolled plate's per-element scores: a vector, one plane per element)
+                if wanted and not isinstance(val, StepOutput):   # (a loop INSIDE this one stored its own [T0, T1, n] outputs)
                     r.origins = (tr.store_step(val, n), tr.store_step(sc, n), None)
-                    r.value = StepOutput(r.origins[0], n)
-                    r.score = StepOutput(r.origins[1], n)
+                    r.value = _so(tr, r.origins[0], n)
+                    r.score = _so(tr, r.origins[1], n)
 
             def stack_out(v):
                 if v is None:
@@ -374,7 +409,9 @@ class Vmap(GenerativeFunction):
                     v = v.value
                 if isinstance(v, (tuple, list)):
                     return type(v)(stack_out(x) for x in v)
-                return StepOutput(tr.store_step(v, n), n)
+                if isinstance(v, StepOutput):          # stacked by a loop inside this one: already [T0, T1, n]
+                    return v
+                return _so(tr, tr.store_step(v, n), n)
             rets = stack_out(ret) if (keep or not isinstance(rec, _SiteRec)) else None
             updates = []
             if wvar is not None and w is not None:
@@ -382,7 +419,7 @@ class Vmap(GenerativeFunction):
             updates.append((svar, (Expr(svar) + score_t).node))
             g.set_vars(updates)
         g.loop_end()
-        ctx.store_sites = keep
+        ctx.store_sites, ctx.sites_deferred = keep, was_deferred
 
         def drop_retvals(r):
             if isinstance(r, _CallRec):
@@ -413,19 +450,21 @@ class Vmap(GenerativeFunction):
         element j — `Update`: with key split(key, n)[j] and element j of the constraint; `IndexRequest(idx, request)`:
         `request` with the caller's key where idx == j (a Python int or one index per particle: the same test), a plain
         carry-over elsewhere — reading element j of the previous trace and writing element j of the new one."""
-        from .engine import StepInput, StepOutput, Sym
+        from .engine import StepInput, StepInput2, StepOutput, Sym
         from .numpy import RuntimeTable, TableArray
         from .static import _CallRec, _ReqSpec, _SiteRec, _rec_score, call_gen_fn
         g, tr = ctx.tr.graph, ctx.tr
         keep = ctx.store_sites
-        ctx.store_sites = False
+        was_deferred = getattr(ctx, "sites_deferred", False)
+        wanted = keep or was_deferred      # a parent plate deferred the stores: its elements' LOOP outputs are still wanted
+        ctx.store_sites, ctx.sites_deferred = False, wanted
         what = "editing a plate of more than 16 elements"
         carry_over = _ReqSpec("update", tree=None, constraint=ChoiceMap.empty())
 
         def prev_at(v, t):
             if isinstance(v, Sym):
                 inner = v.value
-                if isinstance(inner, (StepInput, RuntimeTable, TableArray)):
+                if isinstance(inner, (StepInput, StepInput2, RuntimeTable, TableArray)):
                     return Sym(inner[t], None)
                 return v
             if isinstance(v, dict):
@@ -472,12 +511,12 @@ class Vmap(GenerativeFunction):
                 dis = r.discard.value if isinstance(r.discard, Sym) else r.discard
                 if isinstance(sc, np.ndarray):
                     raise NotImplementedError(f"{what}: a site with a vector-valued SCORE")
-                if keep:
+                if wanted and not isinstance(val, StepOutput):
                     r.origins = (tr.store_step(val, n), tr.store_step(sc, n),
                                  tr.store_step(dis, n) if dis is not None else None)
-                    r.value = StepOutput(r.origins[0], n)
-                    r.score = StepOutput(r.origins[1], n)
-                    r.discard = StepOutput(r.origins[2], n) if dis is not None else None
+                    r.value = _so(tr, r.origins[0], n)
+                    r.score = _so(tr, r.origins[1], n)
+                    r.discard = _so(tr, r.origins[2], n) if dis is not None else None
 
             def stack_out(v):
                 if v is None:
@@ -486,7 +525,9 @@ class Vmap(GenerativeFunction):
                     v = v.value
                 if isinstance(v, (tuple, list)):
                     return type(v)(stack_out(x) for x in v)
-                return StepOutput(tr.store_step(v, n), n)
+                if isinstance(v, StepOutput):          # stacked by a loop inside this one: already [T0, T1, n]
+                    return v
+                return _so(tr, tr.store_step(v, n), n)
             rets = stack_out(ret)
             updates = []
             if w is not None:
@@ -494,7 +535,7 @@ class Vmap(GenerativeFunction):
             updates.append((svar, (Expr(svar) + score_t).node))
             g.set_vars(updates)
         g.loop_end()
-        ctx.store_sites = keep
+        ctx.store_sites, ctx.sites_deferred = keep, was_deferred
         if isinstance(rec, _SiteRec):
             # a bare distribution's plate stays one vector-valued site: values [T], score = the new plate sum
             out = _SiteRec(rec.gen_fn, rec.value, Expr(svar), rec.discard)
@@ -537,7 +578,9 @@ class Vmap(GenerativeFunction):
                                          inner_prev, req, n, req_leaves, addr)
         g = ctx.tr.graph
         keep = ctx.store_sites
-        ctx.store_sites = False
+        was_deferred = getattr(ctx, "sites_deferred", False)
+        wanted = keep or was_deferred      # a parent plate deferred the stores: its elements' LOOP outputs are still wanted
+        ctx.store_sites, ctx.sites_deferred = False, wanted
         carry_over = _ReqSpec("update", tree=None, constraint=ChoiceMap.empty())
         recs, rets = [], []
         weight = Expr(g.const_f32(0.0))
@@ -581,7 +624,7 @@ class Vmap(GenerativeFunction):
             if w is not None:
                 weight = weight + w
             score = score + _rec_score(rec)
-        ctx.store_sites = keep
+        ctx.store_sites, ctx.sites_deferred = keep, was_deferred
         merged = _merge(recs, self.gen_fn)
         out = _CallRec(self)
         out.sites = merged.sites
@@ -690,7 +733,7 @@ def _loop_step_constraint(chm: ChoiceMap, t, n, at_step, what="scan of more than
     is what the reference's per-step `get_submap` amounts to.  An address constrained at every step wins over an
     explicit one, as in the unrolled form (_index_chm)."""
     from .core.mask import Mask
-    from .engine import StepInput, Sym
+    from .engine import StepInput, StepInput2, Sym
     from .numpy import RuntimeTable, TableArray
     if chm is None or chm.static_is_empty():
         return ChoiceMap.empty()
@@ -704,7 +747,7 @@ def _loop_step_constraint(chm: ChoiceMap, t, n, at_step, what="scan of more than
             val = v.value.value if isinstance(v.value, Sym) else v.value
             return Mask(val, idx == t)
         inner = v.value if isinstance(v, Sym) else v
-        if isinstance(inner, (RuntimeTable, TableArray, StepInput)) and inner.shape[0] == n:
+        if isinstance(inner, (RuntimeTable, TableArray, StepInput, StepInput2)) and inner.shape[0] == n:
             return inner[t]
         if isinstance(inner, np.ndarray) and inner.ndim >= 1 and inner.shape[0] == n:
             return at_step(inner, t)
@@ -780,7 +823,9 @@ class Scan(GenerativeFunction):
             return self._trace_loop(ctx, mode, key, carry, scanned_in, constraint, n, req_leaves, addr)
         g = ctx.tr.graph
         keep = ctx.store_sites
-        ctx.store_sites = False
+        was_deferred = getattr(ctx, "sites_deferred", False)
+        wanted = keep or was_deferred      # a parent plate deferred the stores: its elements' LOOP outputs are still wanted
+        ctx.store_sites, ctx.sites_deferred = False, wanted
         recs, outs = [], []
         weight = Expr(g.const_f32(0.0))
         score = Expr(g.const_f32(0.0))
@@ -804,7 +849,7 @@ class Scan(GenerativeFunction):
             if w is not None:
                 weight = weight + w
             score = score + (s if mode == "assess" else _rec_score(rec))
-        ctx.store_sites = keep
+        ctx.store_sites, ctx.sites_deferred = keep, was_deferred
         merged = _merge(recs, self.kernel_gen_fn)
         retval = (carry, _stack(outs))
         if isinstance(merged, _SiteRec):
@@ -829,12 +874,14 @@ class Scan(GenerativeFunction):
         are loop-carried registers; every site's value and score of step t go to element t of a [T, n] leaf (seen
         as [n, T], like a plate); scanned inputs and per-step constraints are read at index t (tables, or
         step-indexed per-particle leaves).  One launch runs all T steps of a particle."""
-        from .engine import StepInput, StepOutput, Sym
+        from .engine import StepInput, StepInput2, StepOutput, Sym
         from .numpy import RuntimeTable, TableArray
         from .static import _CallRec, _SiteRec, _rec_score, call_gen_fn
         g, tr = ctx.tr.graph, ctx.tr
         keep = ctx.store_sites
-        ctx.store_sites = False
+        was_deferred = getattr(ctx, "sites_deferred", False)
+        wanted = keep or was_deferred      # a parent plate deferred the stores: its elements' LOOP outputs are still wanted
+        ctx.store_sites, ctx.sites_deferred = False, wanted
 
         def flat_carry(v, out):
             if v is None:
@@ -876,7 +923,7 @@ class Scan(GenerativeFunction):
                 return tuple(at_step(x, t) for x in v)
             if isinstance(v, dict):
                 return {k: at_step(x, t) for k, x in v.items()}
-            if isinstance(v, (RuntimeTable, TableArray, StepInput)):
+            if isinstance(v, (RuntimeTable, TableArray, StepInput, StepInput2)):
                 return v[t]
             if isinstance(v, (list, np.ndarray)) and not (isinstance(v, np.ndarray) and v.dtype == object):
                 return TableArray(np.asarray(v, dtype=np.float32 if np.asarray(v).dtype.kind == "f" else np.int32))[t]
@@ -912,17 +959,19 @@ class Scan(GenerativeFunction):
                 sc = r.score.value if isinstance(r.score, Sym) else r.score
                 if isinstance(sc, np.ndarray):
                     raise NotImplementedError("scan of more than 16 steps: a site with a vector-valued SCORE")
-                if keep:
+                if wanted and not isinstance(val, StepOutput):
                     r.origins = (tr.store_step(val, n), tr.store_step(sc, n), None)
-                    r.value = StepOutput(r.origins[0], n)
-                    r.score = StepOutput(r.origins[1], n)
+                    r.value = _so(tr, r.origins[0], n)
+                    r.score = _so(tr, r.origins[1], n)
 
             def stack_out(v):
                 if v is None:
                     return None
                 if isinstance(v, (tuple, list)):
                     return type(v)(stack_out(x) for x in v)
-                return StepOutput(tr.store_step(v, n), n)
+                if isinstance(v, StepOutput):          # stacked by a loop inside this one: already [T0, T1, n]
+                    return v
+                return _so(tr, tr.store_step(v, n), n)
             ys = stack_out(y_t)
             # loop-carried updates: carry, key chain, running weight and score (added in step order, as unrolled)
             new_leaves = []
@@ -938,7 +987,7 @@ class Scan(GenerativeFunction):
                 updates.append((kvar, k_t.node))
             g.set_vars(updates)
         g.loop_end()
-        ctx.store_sites = keep
+        ctx.store_sites, ctx.sites_deferred = keep, was_deferred
 
         def drop_retvals(r):
             if isinstance(r, _CallRec):
@@ -987,7 +1036,9 @@ class Scan(GenerativeFunction):
                                          req_leaves, addr)
         g = ctx.tr.graph
         keep = ctx.store_sites
-        ctx.store_sites = False
+        was_deferred = getattr(ctx, "sites_deferred", False)
+        wanted = keep or was_deferred      # a parent plate deferred the stores: its elements' LOOP outputs are still wanted
+        ctx.store_sites, ctx.sites_deferred = False, wanted
         carry_over = _ReqSpec("update", tree=None, constraint=ChoiceMap.empty())
         recs, outs = [], []
         weight = Expr(g.const_f32(0.0))
@@ -1046,7 +1097,7 @@ class Scan(GenerativeFunction):
             if w is not None:
                 weight = weight + w
             score = score + _rec_score(rec)
-        ctx.store_sites = keep
+        ctx.store_sites, ctx.sites_deferred = keep, was_deferred
         merged = _merge(recs, self.kernel_gen_fn)
         out = _CallRec(self)
         out.sites = merged.sites
@@ -1065,12 +1116,14 @@ class Scan(GenerativeFunction):
         loop-carried and treated as changed, so every site is re-scored — a site the edit does not reach gets
         new score == old score bit for bit and contributes exactly 0 to the weight, which is what the unrolled form
         obtains by skipping it."""
-        from .engine import StepInput, StepOutput, Sym
+        from .engine import StepInput, StepInput2, StepOutput, Sym
         from .numpy import RuntimeTable, TableArray
         from .static import _CallRec, _ReqSpec, _SiteRec, _rec_score, call_gen_fn
         g, tr = ctx.tr.graph, ctx.tr
         keep = ctx.store_sites
-        ctx.store_sites = False
+        was_deferred = getattr(ctx, "sites_deferred", False)
+        wanted = keep or was_deferred      # a parent plate deferred the stores: its elements' LOOP outputs are still wanted
+        ctx.store_sites, ctx.sites_deferred = False, wanted
         carry_over = _ReqSpec("update", tree=None, constraint=ChoiceMap.empty())
 
         def flat_carry(v, out):
@@ -1106,7 +1159,7 @@ class Scan(GenerativeFunction):
                 return None
             if isinstance(v, tuple):
                 return tuple(at_step(x, t) for x in v)
-            if isinstance(v, (RuntimeTable, TableArray, StepInput)):
+            if isinstance(v, (RuntimeTable, TableArray, StepInput, StepInput2)):
                 return v[t]
             if isinstance(v, (list, np.ndarray)) and not (isinstance(v, np.ndarray) and v.dtype == object):
                 return TableArray(np.asarray(v, dtype=np.float32 if np.asarray(v).dtype.kind == "f" else np.int32))[t]
@@ -1116,7 +1169,7 @@ class Scan(GenerativeFunction):
         def prev_at(v, t):
             if isinstance(v, Sym):
                 inner = v.value
-                if isinstance(inner, (StepInput, RuntimeTable, TableArray)):
+                if isinstance(inner, (StepInput, StepInput2, RuntimeTable, TableArray)):
                     return Sym(inner[t], None)
                 return v
             if isinstance(v, dict):
@@ -1180,19 +1233,21 @@ class Scan(GenerativeFunction):
                 dis = r.discard.value if isinstance(r.discard, Sym) else r.discard
                 if isinstance(sc, np.ndarray):
                     raise NotImplementedError("editing a scan of more than 16 steps: a site with a vector-valued SCORE")
-                if keep:
+                if wanted and not isinstance(val, StepOutput):
                     r.origins = (tr.store_step(val, n), tr.store_step(sc, n),
                                  tr.store_step(dis, n) if dis is not None else None)
-                    r.value = StepOutput(r.origins[0], n)
-                    r.score = StepOutput(r.origins[1], n)
-                    r.discard = StepOutput(r.origins[2], n) if dis is not None else None
+                    r.value = _so(tr, r.origins[0], n)
+                    r.score = _so(tr, r.origins[1], n)
+                    r.discard = _so(tr, r.origins[2], n) if dis is not None else None
 
             def stack_out(v):
                 if v is None:
                     return None
                 if isinstance(v, (tuple, list)):
                     return type(v)(stack_out(x) for x in v)
-                return StepOutput(tr.store_step(v, n), n)
+                if isinstance(v, StepOutput):          # stacked by a loop inside this one: already [T0, T1, n]
+                    return v
+                return _so(tr, tr.store_step(v, n), n)
             ys = stack_out(y_t)
             new_leaves = []
             ntree = flat_carry(carry_out, new_leaves)
@@ -1206,7 +1261,7 @@ class Scan(GenerativeFunction):
                 updates.append((kvar, k_t.node))
             g.set_vars(updates)
         g.loop_end()
-        ctx.store_sites = keep
+        ctx.store_sites, ctx.sites_deferred = keep, was_deferred
 
         def drop_retvals(r):
             if isinstance(r, _CallRec):

@@ -166,7 +166,8 @@ struct gmx_jit_ctx {
     uint32_t arow[PP];         /* ancestors[cidx] */                                             \
     uint32_t pre[(NPRE) > 0 ? (NPRE) : 1][PP];                                                   \
     bool act[PP];                                                                                \
-    uint32_t gmx_t = 0u;       /* iteration number of the enclosing GMX_JIT_LOOP (0 outside) */   \
+    uint32_t gmx_t = 0u;       /* iteration number of the innermost enclosing GMX_JIT_LOOP (0 outside) */ \
+    uint32_t gmx_t0 = 0u, gmx_tf = 0u;   /* the outer loop's; the row-major index over both (GMX_F_FLAT) */ \
     /* a 2-D launch (gmx_program_run, GMX_KEY_ROWSPLIT background programs): n particles per ROW, blockIdx.y \
        is the row — row r's particles are rows r * n .. r * n + n - 1 of every leaf */           \
     const uint32_t row0 = blockIdx.y * n32;                                                      \
@@ -178,7 +179,7 @@ struct gmx_jit_ctx {
       cidx[p] = row0 + (act[p] ? i32 : n32 - 1u);                                                \
       arow[p] = 0u;                                                                              \
     }                                                                                            \
-    (void)cidx; (void)arow; (void)pre; (void)gmx_t;
+    (void)cidx; (void)arow; (void)pre; (void)gmx_t; (void)gmx_t0; (void)gmx_tf;
 
 // the ancestors of the thread's particles: loaded — or, for a fused bootstrap step (gmx_run_args.rs), computed
 // here from the previous step's log-weights and tile statistics (gmx_resample.h; workgroup-uniform branch)
@@ -211,7 +212,7 @@ struct gmx_jit_ctx {
 #define GMX_JIT_OP(W0, W1)                                                                       \
     _Pragma("unroll") for (int p = 0; p < PP; ++p) {                                             \
       ctx.part = blockIdx.x * PP + p; ctx.first = (p == 0); ctx.last = (p == PP - 1); ctx.cur = p; \
-      gmx_vm_step<regs_t, full_v, gmx_cword<W0, W1>, ctx_t>(R[p], gmx_cword<W0, W1>(), idx[p], act[p], A, ctx, gmx_t); \
+      gmx_vm_step<regs_t, full_v, gmx_cword<W0, W1>, ctx_t>(R[p], gmx_cword<W0, W1>(), idx[p], act[p], A, ctx, gmx_t, gmx_tf); \
     }
 
 // OP_S_NORMAL for the thread's particles two at a time (gmx_math2.h: packed f32 arithmetic, the same bits): the keys
@@ -240,7 +241,10 @@ struct gmx_jit_ctx {
     }
 
 // OP_LOOP / OP_ENDLOOP: a counted loop around the instructions in between (launch-uniform trip count)
-#define GMX_JIT_LOOP(COUNT) for (gmx_t = 0u; gmx_t < (COUNT); ++gmx_t) {
-#define GMX_JIT_ENDLOOP } gmx_t = 0u;
+#define GMX_JIT_LOOP(COUNT) for (gmx_t0 = 0u; gmx_t0 < (COUNT); ++gmx_t0) { gmx_t = gmx_t0; gmx_tf = gmx_t0;
+#define GMX_JIT_ENDLOOP } gmx_t = 0u; gmx_t0 = 0u; gmx_tf = 0u;
+// a loop INSIDE a GMX_JIT_LOOP (a long scan inside a large plate): gmx_t counts the inner iterations, gmx_tf the pairs
+#define GMX_JIT_LOOP2(COUNT) for (uint32_t gmx_t1 = 0u; gmx_t1 < (COUNT); ++gmx_t1) { gmx_t = gmx_t1; gmx_tf = gmx_t0 * (COUNT) + gmx_t1;
+#define GMX_JIT_ENDLOOP2 } gmx_t = gmx_t0; gmx_tf = gmx_t0;
 
 #define GMX_JIT_END }

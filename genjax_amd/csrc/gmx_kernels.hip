@@ -162,6 +162,7 @@ static int parse_program(const uint32_t* blob, size_t n_words, gmx_program& P) {
   // the kernel never needs a bounds check
   const uint32_t* ins = blob + GMX_PROG_HEADER_WORDS;
   bool in_loop = false;
+  int loop_depth = 0;
   for (uint32_t pc = 0; pc < n_instr; ++pc) {
     uint32_t w0 = ins[2 * pc], w1 = ins[2 * pc + 1];
     uint32_t op = w0 & 0xff, dst = (w0 >> 8) & 0xff, a = (w0 >> 16) & 0xff, b = w0 >> 24;
@@ -176,8 +177,8 @@ static int parse_program(const uint32_t* blob, size_t n_words, gmx_program& P) {
     switch (op) {
       case OP_END: break;
       case OP_CONST: case OP_LDIDX: case OP_LDT: ok = D(dst); break;
-      case OP_LOOP: ok = !in_loop && w1 >= 1u; in_loop = true; P.uses_loop = true; break;     // counted, not nested
-      case OP_ENDLOOP: ok = in_loop; in_loop = false; break;
+      case OP_LOOP: ok = loop_depth < 2 && w1 >= 1u; ++loop_depth; in_loop = true; P.uses_loop = true; break;   // counted, <= 2 deep
+      case OP_ENDLOOP: ok = loop_depth > 0; --loop_depth; in_loop = loop_depth > 0; break;
       case OP_UNI: ok = D(dst) && w1 < P.n_uni; break;
       case OP_LDIN: ok = D(dst) && a < P.n_in; if (b & GMX_F_GATHER) P.uses_gather = true; break;
       case OP_LDTAB: ok = D(dst) && R(b) && a < P.n_tab; break;
@@ -352,12 +353,13 @@ static std::string jit_source(const gmx_program* p, bool* gathers_prefetched = n
   };
   if (!pres.empty()) s += "  GMX_JIT_FENCE\n";
   if (any_gather && gpos == 0) gathers();
+  int jit_depth = 0;
   for (uint32_t pc = 0; pc < p->n_instr; ++pc) {
     const uint32_t op_ = p->code_h[2 * pc] & 0xffu;
     if (op_ == OP_LOOP)
-      snprintf(buf, sizeof(buf), "  GMX_JIT_LOOP(%uu)\n", p->code_h[2 * pc + 1]);
+      snprintf(buf, sizeof(buf), jit_depth++ == 0 ? "  GMX_JIT_LOOP(%uu)\n" : "  GMX_JIT_LOOP2(%uu)\n", p->code_h[2 * pc + 1]);
     else if (op_ == OP_ENDLOOP)
-      snprintf(buf, sizeof(buf), "  GMX_JIT_ENDLOOP\n");
+      snprintf(buf, sizeof(buf), --jit_depth == 0 ? "  GMX_JIT_ENDLOOP\n" : "  GMX_JIT_ENDLOOP2\n");
     else if (pre_of[pc] >= 0)
       snprintf(buf, sizeof(buf), "  GMX_JIT_LDPRE(%u, %d)\n", (p->code_h[2 * pc] >> 8) & 0xffu, pre_of[pc]);
     else if (op_ == OP_S_NORMAL && jit_pp_for(p) % 2 == 0 && jit_pair_normals())

@@ -75,7 +75,8 @@ struct gmx_cword {
 
 // One instruction.  All of w0 / w1 are launch-uniform.
 template <class Regs, bool FULL, class W, class Ctx>
-GMX_HD void gmx_vm_step(Regs& R, const W w, int64_t i, bool active, const gmx_run_args& A, Ctx& ctx, uint32_t t = 0u) {
+GMX_HD void gmx_vm_step(Regs& R, const W w, int64_t i, bool active, const gmx_run_args& A, Ctx& ctx, uint32_t t = 0u,
+                        uint32_t tf = 0u) {
   const uint32_t w0 = w.w0(), w1 = w.w1();
 #define SRC(x) ((x) < GMX_POOL_BASE ? R.get(x) : ctx.pool((x) - GMX_POOL_BASE))
 #define FSRC(x) gmx_asf(SRC(x))
@@ -96,7 +97,7 @@ GMX_HD void gmx_vm_step(Regs& R, const W w, int64_t i, bool active, const gmx_ru
           int64_t row = i;
           if (b & GMX_F_GATHER) row = (int64_t)A.ancestors_d[i];
           if (b & GMX_F_BCAST) row = 0;
-          if (b & GMX_F_STEP) row += (int64_t)(t + w1) * A.step_stride;   // element t + imm of a [T, n] leaf
+          if (b & GMX_F_STEP) row += (int64_t)(((b & GMX_F_FLAT) ? tf : t) + w1) * A.step_stride;   // element t + imm of a [T, n] leaf
           const void* p = ctx.in_ptr(a);
           if (b & GMX_F_U8) r0 = (uint32_t)((const uint8_t*)p)[row];
           else r0 = ((const uint32_t*)p)[row];
@@ -114,7 +115,7 @@ GMX_HD void gmx_vm_step(Regs& R, const W w, int64_t i, bool active, const gmx_ru
         uint32_t v = SRC(b);
         if (active) {
           void* p = ctx.out_ptr(a);
-          const int64_t orow = (dst & GMX_F_STEP) ? i + (int64_t)t * A.step_stride : i;
+          const int64_t orow = (dst & GMX_F_STEP) ? i + (int64_t)((dst & GMX_F_FLAT) ? tf : t) * A.step_stride : i;
           if (dst & GMX_F_U8) ((uint8_t*)p)[orow] = (uint8_t)(v != 0u);
           else ((uint32_t*)p)[orow] = v;
         }
@@ -243,8 +244,13 @@ GMX_HD void gmx_vm_step(Regs& R, const W w, int64_t i, bool active, const gmx_ru
         }
         break;
     }
-    if (wr >= 1) R.set(dst, r0);
-    if (wr == 2) R.set(dst + 1u, r1);
+    // OP_STOUT keeps its FLAGS in the dst field (GMX_F_STEP | GMX_F_FLAT = 24): not a register.  The device
+    // interpreter's write-back is an indexed VGPR move that the compiler predicates by VALUE, not by skipping it — with
+    // an index past the 16-element file it lands in a neighbouring register (measured on gfx950: a wild pointer), so
+    // the index itself is kept in range whenever nothing is written.
+    const uint32_t dreg = (op == OP_STOUT) ? 0u : dst;
+    if (wr >= 1) R.set(dreg, r0);
+    if (wr == 2) R.set(dreg + 1u, r1);
   }
 #undef SRC
 #undef FSRC
@@ -256,17 +262,32 @@ template <class Regs, bool FULL, int NI, class Ctx>
 GMX_HD void gmx_vm_run(uint32_t n_instr_rt, int64_t i, bool active, const gmx_run_args& A, Ctx& ctx) {
   Regs R;
   R.init();
-  uint32_t t = 0u, loop_pc = 0u, loop_n = 0u;       // the one (not nested) counted loop: launch-uniform control flow
+  // counted loops, at most two deep: launch-uniform control flow.  t = the innermost loop's iteration number,
+  // tf = the row-major index over both (GMX_F_FLAT).  Plain scalars (no arrays indexed at run time: the device
+  // interpreter's register file already owns the GPR-index mode).
+  uint32_t t = 0u, tf = 0u;
+  uint32_t pc0 = 0u, n0 = 1u, t0 = 0u, pc1 = 0u, n1 = 1u, t1 = 0u;
+  int depth = 0;
   for (uint32_t pc = 0; pc < n_instr_rt; ++pc) {
     gmx_rword w;
     ctx.fetch(pc, &w.a, &w.b);
     const uint32_t op = w.a & 0xffu;
-    if (op == OP_LOOP) { loop_pc = pc; loop_n = w.b; t = 0u; continue; }
-    if (op == OP_ENDLOOP) {
-      if (t + 1u < loop_n) { ++t; pc = loop_pc; } else { t = 0u; }
+    if (op == OP_LOOP) {
+      if (depth == 0) { pc0 = pc; n0 = w.b; t0 = 0u; depth = 1; t = 0u; tf = 0u; }
+      else { pc1 = pc; n1 = w.b; t1 = 0u; depth = 2; t = 0u; tf = t0 * n1; }
       continue;
     }
-    gmx_vm_step<Regs, FULL, gmx_rword, Ctx>(R, w, i, active, A, ctx, t);
+    if (op == OP_ENDLOOP) {
+      if (depth == 2) {
+        if (t1 + 1u < n1) { ++t1; pc = pc1; t = t1; tf = t0 * n1 + t1; }
+        else { depth = 1; t = t0; tf = t0; }
+      } else {
+        if (t0 + 1u < n0) { ++t0; pc = pc0; t = t0; tf = t0; }
+        else { depth = 0; t = 0u; tf = 0u; }
+      }
+      continue;
+    }
+    gmx_vm_step<Regs, FULL, gmx_rword, Ctx>(R, w, i, active, A, ctx, t, tf);
   }
 }
 

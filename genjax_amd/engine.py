@@ -142,6 +142,7 @@ def _np_dt(a: np.ndarray) -> str:
 
 DVEC_MAX = 16       # longer launch-uniform device vectors are bound as tables, not as one input slot per element
 GMX_HVEC_MAX = 16   # launch-uniform HOST vectors: one operand-pool entry per element up to this length, a table beyond
+POOL_VEC_MAX = 48   # a launch-uniform ARRAY (2 or more axes) with more elements than this is a table whatever its shape
 STEP_LEAF_MIN = 16  # per-particle vectors longer than this are ONE step-indexed leaf (read inside a counted loop)
 
 
@@ -179,8 +180,9 @@ def leaf_spec(v, batch: tuple):
             return ("bcast", dt)
         if nb == 0:
             return ("part", dt, shp)
-        if (v.ndim == 1 and shp[0] > DVEC_MAX) or (v.ndim >= 2 and shp[0] > DVEC_MAX and v.numel() // shp[0] <= DVEC_MAX):
-            return ("dtab", dt, shp)           # launch-uniform table read with OP_LDTAB ([T] or [T, *short row])
+        if (v.ndim == 1 and shp[0] > DVEC_MAX) or (v.ndim >= 2 and shp[0] > DVEC_MAX and v.numel() // shp[0] <= DVEC_MAX) \
+                or (v.ndim >= 2 and v.numel() > POOL_VEC_MAX):
+            return ("dtab", dt, shp)           # launch-uniform table read with OP_LDTAB ([T] or [T, *short row]; [few, many])
         return ("dvec", dt, shp)
     if isinstance(v, (list, tuple)):
         v = np.asarray(v)
@@ -189,8 +191,11 @@ def leaf_spec(v, batch: tuple):
             raise TypeError("object arrays cannot be launch values")
         if v.ndim == 0:
             return leaf_spec(v.item(), batch)
-        if (v.ndim == 1 and v.shape[0] > GMX_HVEC_MAX) or (v.ndim >= 2 and v.shape[0] > GMX_HVEC_MAX and v.size // v.shape[0] <= DVEC_MAX):
-            return ("dtab", _np_dt(v), tuple(v.shape))      # too long for the operand pool: a table, like a long device vector
+        if (v.ndim == 1 and v.shape[0] > GMX_HVEC_MAX) or (v.ndim >= 2 and v.shape[0] > GMX_HVEC_MAX and v.size // v.shape[0] <= DVEC_MAX) \
+                or (v.ndim >= 2 and v.size > POOL_VEC_MAX):
+            # too long for the operand pool: a table, like a long device vector (a [few, many] array too: one row per
+            # element of a small plate, each read step by step by that element's long scan)
+            return ("dtab", _np_dt(v), tuple(v.shape))
         return ("hvec", _np_dt(v), tuple(v.shape))
     if getattr(v, "__gmx_static__", False):
         _STATIC_KEEP[id(v)] = v            # host object the traced function only reads (e.g. a Target)
@@ -420,6 +425,14 @@ class Tracing:
             for e_, slot in enumerate(slots):
                 self.in_plan.append((slot, j, e_, "step2"))
             return Sym(StepInput.make2(g, slots, dt, int(event[0]), event[1:]), ("leaf", j))
+        if kind == "part" and len(event) == 2 and event[1] > STEP_LEAF_MIN:
+            # [n, A, T] with a long last axis: the choices of the long scans of a plate — one slot ([A * T, n]); row a is
+            # picked statically (an unrolled plate) or by the outer loop's iteration number (a plate run as a loop
+            # around the scans' loop: element (a, t) through GMX_F_FLAT)
+            slot = g.n_in
+            g.n_in += 1
+            self.in_plan.append((slot, j, 0, "stepflat"))
+            return Sym(StepInput2(g, slot, dt, (int(event[0]), int(event[1]))), ("leaf", j))
         if kind == "part" and len(event) == 1 and event[0] > STEP_LEAF_MIN:
             # a long per-particle vector (the [n, T] choices of a scan): one slot, element t read by iteration t
             slot = g.n_in
@@ -454,8 +467,10 @@ class Tracing:
 
     def store_step(self, value, T: int):
         """Inside a counted loop: store this iteration's value as element t of a [T, n] output (exposed to the
-        user as [n, T], like a plate).  Returns the output's origin."""
+        user as [n, T], like a plate); inside the inner of two loops, as element (t_outer, t_inner) of a [T0, T1, n]
+        output ([n, T0, T1]: a plate of scans).  Returns the output's origin."""
         from . import tracer as Tm
+        dims = tuple(int(c) for c in self.graph.loop_counts) or (int(T),)
         if isinstance(value, np.ndarray) and value.dtype == object:
             # a vector-valued site: one [T, n] plane per element, exposed as [n, T, *event]
             es = [Tm.lift(v) for v in value.reshape(-1)]
@@ -463,12 +478,12 @@ class Tracing:
                 raise TypeError("store_step: mixed element types")
             slots = [self.graph.store(e.node, step=True) for e in es]
             o = ("out", len(self.outputs))
-            self.outputs.append((es[0].dtype, (int(T),) + tuple(value.shape), ("step", slots)))
+            self.outputs.append((es[0].dtype, dims + tuple(value.shape), ("step", slots, len(dims))))
             return o
         e = Tm.lift(value)
         slot = self.graph.store(e.node, step=True)
         o = ("out", len(self.outputs))
-        self.outputs.append((e.dtype, (int(T),), ("step", slot)))
+        self.outputs.append((e.dtype, dims, ("step", slot, len(dims))))
         return o
 
     def emit_output(self, value):
@@ -569,12 +584,55 @@ class StepInput(np.ndarray):
         return r
 
 
+class StepInput2:
+    """A per-particle [A, T] leaf whose LAST axis is long ([n, A, T] at the boundary, one [A * T, n] input slot): what a
+    plate of long scans reads back (assess; importance / update with per-particle values).  `leaf[a]` is a row — a a
+    Python int (an unrolled plate) or the outer loop's iteration number (the plate run as a loop) — and `row[t]`, inside
+    the scan's loop, is ONE load: element a * T + t of the slot (OP_LDIN, GMX_F_STEP with imm = a * T; under two
+    nested loops GMX_F_FLAT: the pair index is the loops' own)."""
+
+    def __init__(self, g, slot, dt, shape, row=None):
+        self._g, self._slot, self._dt, self.shape, self._row = g, slot, dt, tuple(shape), row
+        self.ndim = len(self.shape)
+
+    def __len__(self):
+        return self.shape[0]
+
+    def __getitem__(self, idx):
+        from .program import F_FLAT, F_STEP, F_U8
+        if self.ndim == 2:
+            if isinstance(idx, (int, np.integer)):
+                return StepInput2(self._g, self._slot, self._dt, self.shape[1:], row=int(idx))
+            if isinstance(idx, Expr):
+                if idx.node.op != "LDT":
+                    raise NotImplementedError("a [n, A, T] step leaf takes its row from the plate's own iteration number")
+                return StepInput2(self._g, self._slot, self._dt, self.shape[1:], row="loop")
+            raise NotImplementedError("a [n, A, T] leaf with a long last axis is read row by row (a plate of long scans)")
+        if not (isinstance(idx, Expr) and idx.node.op == "LDT"):
+            raise NotImplementedError("a long per-particle row is read by the scan's own iteration number")
+        flags = F_STEP | (F_U8 if self._dt == "bool" else 0)
+        if self._row == "loop":
+            if len(self._g.loop_counts) != 2:
+                raise NotImplementedError("element (t_outer, t_inner) of a two-axis step leaf outside the inner loop")
+            return Expr(self._g.add("LDIN", dtype=self._dt, flags=flags | F_FLAT, slot=self._slot))
+        if len(self._g.loop_counts) != 1:
+            raise NotImplementedError("a statically picked row of a two-axis step leaf is read inside ONE loop")
+        return Expr(self._g.add("LDIN", dtype=self._dt, flags=flags, slot=self._slot, imm=int(self._row) * self.shape[0]))
+
+
 class StepOutput:
     """The stacked per-iteration outputs of a counted loop ([n, T] after the launch): they exist only in memory, so
     inside the program they can be returned / recorded but not computed with."""
 
-    def __init__(self, origin, T):
+    def __init__(self, origin, T, trailing=1):
         self.origin, self.T = origin, T
+        self.trailing = trailing           # dims after the batch: (T, *event) — what an unrolled plate stacks in front of
+
+    @staticmethod
+    def stack(parts):
+        """the same loop output of the n elements of an UNROLLED plate (a plate of long scans): [n, T, *event] per
+        particle, assembled after the launch from the elements' own [T, n] leaves"""
+        return StepOutput(("stack", [p.origin for p in parts], parts[0].trailing), parts[0].T, parts[0].trailing + 1)
 
     def _no(self, *a, **k):
         raise NotImplementedError("the stacked outputs of a long scan live in memory only: return them, or use a "
@@ -792,6 +850,9 @@ class Compiled:
                 if kind == "step2":        # [n, T, *event] -> [E, T, n] planes (a copy: the step stride is n for every leaf)
                     t_ = _prepare_input(src, "bcast", None, be)
                     buf = t_.reshape(n, t_.shape[len(batch)], -1).permute(2, 1, 0).contiguous()
+                elif kind == "stepflat":   # [n, T0, T1] -> [T0 * T1, n]
+                    t_ = _prepare_input(src, "bcast", None, be)
+                    buf = t_.reshape(n, -1).t().contiguous()
                 else:
                     buf = _prepare_input(src, "part" if kind == "step" else kind, n if kind in ("part", "step") else None, be)
                 soa_cache[key_] = buf
@@ -799,6 +860,9 @@ class Compiled:
             item = buf.element_size()
             if kind == "step2":
                 A.in_d[slot] = buf.data_ptr() + e * buf.shape[1] * n * item
+                A.step_stride = n
+            elif kind == "stepflat":
+                A.in_d[slot] = buf.data_ptr()
                 A.step_stride = n
             elif kind == "step":
                 if buf.dim() != 2 or buf.stride(1) != 1 or buf.stride(0) != n:
@@ -842,7 +906,7 @@ class Compiled:
         for k, (dt, event, slots) in enumerate(self.outputs):
             if isinstance(slots, tuple) and slots[0] == "step":
                 # element t of a [T, n] leaf is written by iteration t of the program's loop (GMX_F_STEP)
-                Tn = int(event[0])
+                Tn = int(np.prod(event[:slots[2]]))       # one loop: T planes; two nested loops: T0 * T1, row-major
                 if isinstance(slots[1], list):          # a vector-valued site: [E, T, n] planes -> [*batch, T, *site event]
                     E = len(slots[1])
                     buf = torch.empty((E, Tn, n), dtype=_STORE[dt], device=be.device)
@@ -964,6 +1028,9 @@ def resolve(origin, outs, leaves):
         return {k: resolve(o, outs, leaves) for k, o in origin[1].items()}
     if kind == "dc":
         return _make_dataclass(origin[1], {k: resolve(o, outs, leaves) for k, o in origin[2].items()})
+    if kind == "stack":        # an unrolled plate of loop outputs: elements [*batch, T, *event] -> [*batch, n, T, *event]
+        parts = [resolve(o, outs, leaves) for o in origin[1]]
+        return torch.stack(parts, dim=parts[0].dim() - int(origin[2]))
     raise ValueError(origin)
 
 

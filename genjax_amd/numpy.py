@@ -48,6 +48,10 @@ class TableArray(np.ndarray):
             row = np.empty(self.shape[1:], dtype=object)
             for e, ix in enumerate(np.ndindex(self.shape[1:])):
                 row[ix] = Expr(g.add("LDTAB", (base,), imm=e, dtype=dt, slot=slot))
+            if E > 16 and self.ndim == 2:      # a long row stays indexable at run time (RuntimeTable: same LDTAB reads)
+                out = row.view(RuntimeTable)
+                out._slot, out._dt, out._base, out._dyn = slot, dt, 0, base
+                return out
             return row
         r = np.ndarray.__getitem__(self, idx)
         if isinstance(r, np.ndarray) and r.ndim == 0:
@@ -69,30 +73,51 @@ class RuntimeTable(np.ndarray):
         for k, ix in enumerate(np.ndindex(shape)):
             arr[ix] = Expr(g.add("LDTAB", (zero,), imm=k, dtype=dt, slot=slot))
         out = arr.view(cls)
-        out._slot, out._dt = slot, dt
+        out._slot, out._dt, out._base = slot, dt, 0
         return out
 
     def __array_finalize__(self, obj):
         self._slot = getattr(obj, "_slot", None)
         self._dt = getattr(obj, "_dt", None)
+        self._base = getattr(obj, "_base", 0)        # entry of the flattened table this (row-major) view starts at
+        self._dyn = getattr(obj, "_dyn", None)       # + a run-time offset (a row picked by a loop's iteration number)
 
     def __getitem__(self, idx):
+        base = int(self._base or 0)
+        dyn = getattr(self, "_dyn", None)
         if isinstance(idx, Expr) and self._slot is not None and self.ndim == 1:
             g = T.current_graph()
+            if dyn is not None:                                  # element idx of a row that was itself picked at run time
+                return Expr(g.add("LDTAB", ((Expr(dyn) + T.as_int(idx)).node,), imm=base, dtype=self._dt, slot=self._slot))
             if idx.node.op == "CONST":                           # static after all: the shared element read
-                return Expr(g.add("LDTAB", (g.const_i32(0),), imm=idx.node.imm, dtype=self._dt, slot=self._slot))
-            return Expr(g.add("LDTAB", (T.as_int(idx).node,), dtype=self._dt, slot=self._slot))
+                return Expr(g.add("LDTAB", (g.const_i32(0),), imm=idx.node.imm + base, dtype=self._dt, slot=self._slot))
+            return Expr(g.add("LDTAB", (T.as_int(idx).node,), imm=base, dtype=self._dt, slot=self._slot))
         if isinstance(idx, Expr) and self._slot is not None and self.ndim >= 2:
             g = T.current_graph()                                # row `idx` of a table of rows
             E = int(np.prod(self.shape[1:]))
-            base = (T.as_int(idx) * E).node
+            rb = T.as_int(idx) * E
+            if dyn is not None:
+                rb = rb + Expr(dyn)
+            rbase = rb.node
             row = np.empty(self.shape[1:], dtype=object)
             for e, ix in enumerate(np.ndindex(self.shape[1:])):
-                row[ix] = Expr(g.add("LDTAB", (base,), imm=e, dtype=self._dt, slot=self._slot))
+                row[ix] = Expr(g.add("LDTAB", (rbase,), imm=base + e, dtype=self._dt, slot=self._slot))
+            if E > 16:             # a LONG row: it stays a table, so that a loop inside can pick its elements at run time
+                out = row.view(RuntimeTable)
+                out._slot, out._dt, out._base, out._dyn = self._slot, self._dt, base, rbase
+                return out
             return row
         r = np.ndarray.__getitem__(self, idx)
+        if isinstance(r, RuntimeTable) and self.ndim >= 2 and isinstance(idx, (int, np.integer)):
+            r._base = base + int(idx) * int(np.prod(self.shape[1:]))   # a static row stays a table: its elements can
+            return r                                                   # still be picked at run time (a plate of scans)
         if isinstance(r, RuntimeTable) and self.ndim >= 2 and not isinstance(idx, slice):
-            return np.asarray(r, dtype=object)                   # a static row: plain expressions
+            return np.asarray(r, dtype=object)                   # any other static pick: plain expressions
+        if isinstance(r, RuntimeTable) and isinstance(idx, slice) and self.ndim == 1:
+            start = idx.indices(self.shape[0])[0] if (idx.step in (None, 1)) else None
+            if start is None:
+                return np.asarray(r, dtype=object)
+            r._base = base + start
         return r
 
 

@@ -20,7 +20,7 @@ MAGIC = 0x50584D47
 VERSION = 2
 MAX_REGS = 64          # operand codes below POOL_BASE; more than 31 needs the specialised kernel (no interpreter build)
 
-F_GATHER, F_U8, F_BCAST, F_STEP = 1, 2, 4, 8
+F_GATHER, F_U8, F_BCAST, F_STEP, F_FLAT = 1, 2, 4, 8, 16
 
 # opcode numbers: keep in sync with gmx_program.h
 OPC = dict(
@@ -132,21 +132,35 @@ class Graph:
     def store(self, value: Node, step: bool = False) -> int:
         """STOUT of `value`; returns the output slot.  step: element t of a [T, n] leaf (inside a loop)."""
         flags = (F_U8 if value.dtype == "bool" else 0) | (F_STEP if step else 0)
+        if step and len(self.loop_counts) == 2:
+            flags |= F_FLAT            # inside the inner of two loops: element (t_outer, t_inner) of a [T0, T1, n] leaf
         slot = self.n_out
         self.n_out += 1
         self.add("STOUT", (value,), dtype="none", flags=flags, slot=slot)
         return slot
 
     # counted loop ------------------------------------------------------------
+    @property
+    def loop_counts(self):
+        """trip counts of the counted loops being traced, outermost first (at most two: a long scan inside a large
+        plate, a plate of plates ...)"""
+        return self.__dict__.setdefault("_loop_counts", [])
+
+    @property
+    def _in_loop(self):
+        return bool(self.loop_counts)
+
     def loop_begin(self, count: int):
-        if getattr(self, "_in_loop", False):
-            raise NotImplementedError("nested counted loops")
-        self._in_loop = True
+        if len(self.loop_counts) >= 2:
+            raise NotImplementedError("counted loops nest two deep (a long scan inside a large plate), not three")
+        self.loop_counts.append(int(count))
+        if len(self.loop_counts) == 2:
+            self.nested_loops = True
         self._cse.clear()              # a value computed before the loop is not "the same" as one recomputed inside
         self.add("LOOP", imm=int(count), dtype="none")
 
     def loop_end(self):
-        self._in_loop = False
+        self.loop_counts.pop()
         self.add("ENDLOOP", dtype="none")
         self._cse.clear()
 
@@ -245,12 +259,12 @@ def compile_graph(g: Graph):
     LONG = 96
     # nodes created between LOOP and ENDLOOP
     in_loop_region = {}
-    inside = False
+    inside = 0
     for n in nodes:
         if n.op == "LOOP":
-            inside = True
+            inside += 1
         elif n.op == "ENDLOOP":
-            inside = False
+            inside -= 1
         elif inside:
             in_loop_region[n.idx] = True
 
@@ -280,6 +294,10 @@ def compile_graph(g: Graph):
     # a trace with many input leaves (an edited plate: value + score per element) would otherwise
     # hold every one of them in a register from the top of the program
     sunk = {n.idx for n in nodes if live[n.idx] and n.idx not in pool_of and n.op in ("LDIN", "CONST", "UNI", "LDIDX")}
+    if getattr(g, "nested_loops", False):
+        # with two loop levels a step-indexed load means "element t of the loop it was TRACED in": it stays where it is
+        # (sunk into the inner loop, an outer-level load would read the inner iteration's element)
+        sunk -= {n.idx for n in nodes if n.op == "LDIN" and n.flags & F_STEP}
     order = []
     placed = set()
     for n in nodes:
@@ -302,12 +320,12 @@ def compile_graph(g: Graph):
     # counted loops: whatever is defined BEFORE the block and read inside it (and every loop-carried register) must
     # survive until the block has run for the last time — its register may not be handed to a value of the block
     pos_of = {n.idx: pos for pos, n in enumerate(order)}
-    loop_lo = loop_hi = None
+    open_loops = []
     for pos, n in enumerate(order):
         if n.op == "LOOP":
-            loop_lo = pos
-        elif n.op == "ENDLOOP" and loop_lo is not None:
-            loop_hi = pos
+            open_loops.append(pos)
+        elif n.op == "ENDLOOP" and open_loops:
+            loop_lo, loop_hi = open_loops.pop(), pos      # (an inner loop first, then the loop around it)
             for q in range(loop_lo + 1, loop_hi):
                 for a in order[q].args:
                     if a is None:
@@ -315,7 +333,6 @@ def compile_graph(g: Graph):
                     for leaf in _remat_leaves(a, remat):
                         if pos_of.get(leaf.idx, -1) < loop_lo and last_use.get(leaf.idx, -1) < loop_hi:
                             last_use[leaf.idx] = loop_hi
-            loop_lo = None
     # ---- registers ----
     free = [True] * MAX_REGS
     reg = {}

@@ -680,8 +680,8 @@ def _leaf_call(ctx: _Ctx, mode, dist, key, args, constraint: ChoiceMap, prev, re
         fwd_args = req.argmap(ChoiceMap.choice(pv))
         if not isinstance(fwd_args, tuple):
             fwd_args = (fwd_args,)
-        keep = ctx.store_sites
-        ctx.store_sites = False          # the proposal's own trace is never materialised
+        keep, was_deferred = ctx.store_sites, getattr(ctx, "sites_deferred", False)
+        ctx.store_sites = ctx.sites_deferred = False          # the proposal's own trace is never materialised
         prec, pret, _, pscore = call_gen_fn(ctx, "simulate", req.proposal, sub, fwd_args, ChoiceMap.empty(),
                                             None, None, None, ())
         proposed = _rec_choices(prec)
@@ -696,7 +696,7 @@ def _leaf_call(ctx: _Ctx, mode, dist, key, args, constraint: ChoiceMap, prev, re
             bwd_args = (bwd_args,)
         _, _, _, bwd_score = call_gen_fn(ctx, "assess", req.proposal, None, bwd_args, ChoiceMap.choice(pv),
                                          None, None, None, ())
-        ctx.store_sites = keep
+        ctx.store_sites, ctx.sites_deferred = keep, was_deferred
         final = (w + bwd_score) - fwd_score
         ctx.mark_changed(nv)
         del k_new

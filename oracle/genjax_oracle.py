@@ -995,7 +995,12 @@ class Vmap:
                 out.append(a[..., None] if a.ndim >= len(batch) and a.shape[: len(batch)] == tuple(batch) and len(batch) else a)
             else:
                 a = np.asarray(a)
-                n = a.shape[-1] if a.ndim > len(batch) or a.shape[: len(batch)] != tuple(batch) else a.shape[-1]
+                if len(batch) and a.shape[: len(batch)] != tuple(batch):
+                    # a launch-uniform mapped argument [n_plate, ...]: laid out as [*batch, n_plate, ...], so that the
+                    # inner function — which runs with the plate as one more batch axis — sees a per-element value and
+                    # not a vector-valued argument (a sampler would take the plate axis for an event axis)
+                    a = np.broadcast_to(a, tuple(batch) + a.shape)
+                n = a.shape[len(batch)] if len(batch) else a.shape[0]
                 out.append(a)
         return tuple(out), n
 
@@ -1014,10 +1019,27 @@ class Vmap:
         tr = self.gen_fn.simulate(split(k, n), a)
         return VmapTrace(self, tr, self._plate_sum(tr.get_score(), batch), tr.get_retval())
 
+    @staticmethod
+    def _plate_chm(chm, n, batch):
+        """A launch-uniform table of per-element constraints ([n_plate, ...]: vmap.py:201 slices it along axis 0) is
+        laid out explicitly as [*batch, n_plate, ...] before the inner function sees it with the plate as a batch axis:
+        a combinator further in (a Scan picking its step axis by shape) then cannot mistake the plate axis for its own
+        when the two have the same length."""
+        if chm is None:
+            return None
+        batch = tuple(batch)
+
+        def lay(v):
+            a = np.asarray(v)
+            if a.ndim >= 1 and a.shape[0] == n and a.shape[:len(batch) + 1] != batch + (n,):
+                return np.broadcast_to(a, batch + a.shape)
+            return v
+        return chm.map_values(lay)
+
     def generate(self, k, chm, args):
         batch = np.asarray(k).shape[:-1]
         a, n = self._prep(args, batch)
-        tr, w = self.gen_fn.generate(split(k, n), chm, a)
+        tr, w = self.gen_fn.generate(split(k, n), self._plate_chm(chm, n, batch), a)
         w = np.broadcast_to(np.asarray(w, np.float32), tuple(batch) + (n,))
         return VmapTrace(self, tr, self._plate_sum(tr.get_score(), batch), tr.get_retval()), self._plate_sum(w, batch)
 
@@ -1026,7 +1048,7 @@ class Vmap:
     def assess(self, chm, args, batch_shape=()):
         batch = tuple(batch_shape)
         a, n = self._prep(args, batch)
-        s, r = self.gen_fn.assess(chm, a, batch + (n,))
+        s, r = self.gen_fn.assess(self._plate_chm(chm, n, batch), a, batch + (n,))
         s = np.broadcast_to(np.asarray(s, np.float32), batch + (n,))
         return self._plate_sum(s, batch), r
 

@@ -1540,3 +1540,60 @@ def check_runtime_indexed(n=257, seed=13):
                 con = con.set(("schools", j, "y"), Mask(vals, idx == j))
             tr2, w2 = m.importance(keys, con, ())
             assert torch.equal(w, w2) and torch.equal(tr.get_choices()["schools", "y"], tr2.get_choices()["schools", "y"])
+
+
+def check_plate_of_scans(n=130, no=5, T=40, seed=17):
+    """A plate of time series — `series.vmap()` where every element runs a LONG scan (ref: vmap.py:180-218 over
+    scan.py:200-294; the reference nests combinators freely) — simulate / importance with one observation table per
+    series (`C["series", :, "steps", :, "y"]`-shaped constraints: plate axis first, then the steps) / assess, bit-exact
+    against the oracle: element j's scan runs under key split(key, no)[j], its steps chain fold_in(., t)."""
+    import genjax_amd as G
+    from genjax_amd import ChoiceMapBuilder as C, numpy as jnp
+    rng = np.random.default_rng(seed)
+    x0s = rng.normal(0, 1, no).astype(np.float32)
+    sig = np.linspace(0.5, 1.5, no).astype(np.float32)
+    ys = rng.normal(0, 1, (no, T)).astype(np.float32)
+
+    def mk(g, scan_of):
+        @g.gen
+        def step(carry, _):
+            x, s = carry
+            xn = g.normal(0.9 * x, 0.5) @ "x"
+            g.normal(xn, s) @ "y"
+            return (xn, s), xn * 2.0
+
+        @g.gen
+        def series(x0, s, mu):
+            (xT, _), doubled = scan_of(step)((x0 + mu, s), None) @ "steps"
+            return xT, doubled
+        return series
+    series = mk(G, lambda st: st.scan(n=T))
+    oseries = mk(O, lambda st: O.Scan(st, T))
+
+    @G.gen
+    def model():
+        mu = G.normal(0.0, 1.0) @ "mu"
+        return series.vmap(in_axes=(0, 0, None))(jnp.array(x0s), jnp.array(sig), mu) @ "series"
+
+    @O.gen
+    def o_model():
+        mu = O.normal(0.0, 1.0) @ "mu"
+        return O.Vmap(oseries, in_axes=(0, 0, None))(x0s, sig, mu) @ "series"
+    tr, otr = model.simulate(G.split(G.key(seed), n), ()), o_model.simulate(O.split(O.key(seed), n), ())
+    x = tr.get_choices()["series", "steps", "x"]
+    assert tuple(x.shape) == (n, no, T)
+    assert np.array_equal(x.cpu().numpy(), otr.get_choices()["series", "steps", "x"])
+    assert np.array_equal(tr.get_choices()["series", "steps", "y"].cpu().numpy(), otr.get_choices()["series", "steps", "y"])
+    assert np.array_equal(tr.get_score().cpu().numpy(), otr.get_score())
+    xT, dbl = tr.get_retval()
+    oxT, odbl = otr.get_retval()
+    assert np.array_equal(xT.cpu().numpy(), oxT) and np.array_equal(dbl.cpu().numpy(), odbl) and tuple(dbl.shape) == (n, no, T)
+    tri, w = model.importance(G.split(G.key(seed + 1), n), C["series", "steps", "y"].set(ys), ())
+    otri, ow = o_model.importance(O.split(O.key(seed + 1), n), O.C.d({("series", "steps", "y"): ys}), ())
+    assert np.array_equal(w.cpu().numpy(), ow) and np.array_equal(tri.get_score().cpu().numpy(), otri.get_score())
+    assert np.array_equal(tri.get_choices()["series", "steps", "x"].cpu().numpy(), otri.get_choices()["series", "steps", "x"])
+    assert np.array_equal(tri.get_choices()["series", "steps", "y"].cpu().numpy(), np.broadcast_to(ys, (n, no, T)))
+    s, _ = model.assess(tri.get_choices(), ())
+    so, _ = o_model.assess(otri.get_choices(), (), (n,))
+    assert np.array_equal(s.cpu().numpy(), so) and np.array_equal(s.cpu().numpy(), tri.get_score().cpu().numpy())
+    return {"score_mean": float(tr.get_score().mean())}

@@ -32,6 +32,8 @@ res = parity.check_lgssm_sweep(n=2500, T=4, want_fuse=True)
 assert res["ancestors_equal"] and res["x_equal"] and res["totals_equal"], res
 os.environ["GENMI_FUSE_RESAMPLE"] = "0"
 parity.check_plates(n=129)
+parity.check_plate_of_scans(n=33, no=24, T=40)         # two nested counted loops, [n, A, T] step leaves (GMX_F_FLAT)
+parity.check_plate_of_scans(n=33, no=3, T=40)          # an unrolled plate around its elements' loops
 parity.check_csmc(k=65)
 parity.check_nested_marginal(k=33)
 parity.check_dirichlet(n=300)

@@ -1390,3 +1390,16 @@ def test_long_scan_update_and_regenerate(gpu):
 def test_long_scan_vector_sites_constraints_and_edits(gpu):
     parity.check_scan_long_vector_constraints()
     parity.check_scan_long_vector_constraints(n=50_000, T=20, seed=2)
+
+
+@pytest.mark.parametrize("n,no,T,jit", [(5000, 3, 40, True), (5000, 24, 40, True), (2000, 24, 40, False), (1500, 100, 100, True)])
+def test_plate_of_long_scans_as_nested_loops(gpu, monkeypatch, n, no, T, jit):
+    """a plate of time series: two nested counted loops in one launch (interpreter, and the specialised kernel: the
+    threshold above which a program is specialised is lowered for the test), simulate / importance / assess bit-exact vs
+    the oracle; 100 series x 100 steps = 1e4 latent pairs per particle"""
+    from genjax_amd import engine
+    monkeypatch.setattr(engine, "JIT_MIN_PARTICLES", 1024 if jit else 1 << 40)
+    monkeypatch.setattr(engine, "JIT_MIN_WORK", 1024 if jit else 1 << 40)
+    import genjax_amd as G
+    G.clear_caches()
+    parity.check_plate_of_scans(n=n, no=no, T=T)

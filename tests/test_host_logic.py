@@ -1168,3 +1168,14 @@ def test_long_scan_vector_sites_constraints_and_edits():
     """long scan with vector-valued latent AND observation sites: [T, 2] table constraints, [n, T, 2] choices, edits"""
     from tests import parity
     parity.check_scan_long_vector_constraints()
+
+
+@pytest.mark.parametrize("no,T", [(3, 40), (12, 20), (17, 17), (40, 24)])
+def test_plate_of_long_scans_matches_oracle(hostsim, no, T):
+    """`series.vmap()` where every element runs a long scan (ref: combinators nest freely, vmap.py:180-218 over
+    scan.py:200-294).  no <= 4: the plate is unrolled around the elements' loops (their [T, n] outputs are stacked
+    after the launch); more: the plate runs as a counted loop AROUND the scan's loop — two nested loops in one site
+    program (OP_LOOP two deep, GMX_F_FLAT leaves [n, no, T]).  no == T: the square case an axis picked by shape
+    would get wrong."""
+    from tests import parity
+    parity.check_plate_of_scans(n=33, no=no, T=T)

@@ -1053,10 +1053,11 @@ class Vmap:
         return self._plate_sum(s, batch), r
 
 
-def _stack_last(trs):
+def _stack_last(trs, bn=None):
     """Stack per-step traces of one kernel along a new step axis: right after the batch axes (lax.scan stacks on the
     leading axis of the per-particle value, vmap over particles puts the batch in front: [batch, T, *event]) — for a
-    scalar-valued site that is the trailing axis."""
+    scalar-valued site that is the trailing axis.  bn: the batch rank when the caller knows it (a Scan does): a step
+    that itself contains plates / scans carries more axes after the batch, and the step axis goes in FRONT of them."""
     first = trs[0]
 
     def st(vals, axis=-1):
@@ -1066,12 +1067,18 @@ def _stack_last(trs):
             return tuple(st([v[k] for v in vals], axis) for k in range(len(vals[0])))
         arrs = [np.asarray(v) for v in vals]
         shape = np.broadcast_shapes(*[a.shape for a in arrs])
+        if bn is not None and len(shape) < bn:       # a value that does not depend on the particle (a constant carry)
+            shape = np.broadcast_shapes(shape, (1,) * bn)
         return np.stack([np.broadcast_to(a, shape) for a in arrs], axis=axis if axis <= len(shape) else -1)
     if isinstance(first, DistTrace):
-        bn = max(np.ndim(t.score) for t in trs)               # batch rank: a site's score has no event axes
-        return DistTrace(first.gen_fn, first.args, st([t.value for t in trs], bn), st([t.score for t in trs], bn))
-    return StaticTrace(first.gen_fn, first.args, st([t.retval for t in trs]),
-                       OrderedDict((a, _stack_last([t.subtraces[a] for t in trs])) for a in first.subtraces))
+        b_ = bn if bn is not None else max(np.ndim(t.score) for t in trs)     # batch rank: a site's score has no event axes
+        return DistTrace(first.gen_fn, first.args, st([t.value for t in trs], b_), st([t.score for t in trs], b_))
+    ax = -1 if bn is None else bn
+    if isinstance(first, VmapTrace):                 # a plate / a scan inside the step: its own axes stay behind the step axis
+        return VmapTrace(first.gen_fn, _stack_last([t.inner for t in trs], bn), st([t.score for t in trs], ax),
+                         st([t.retval for t in trs], ax))
+    return StaticTrace(first.gen_fn, first.args, st([t.retval for t in trs], ax),
+                       OrderedDict((a, _stack_last([t.subtraces[a] for t in trs], bn)) for a in first.subtraces))
 
 
 class Scan:
@@ -1132,11 +1139,11 @@ class Scan:
 
     def simulate(self, k, args):
         trs, ret, score, _ = self._run("simulate", k, None, args)
-        return VmapTrace(self, _stack_last(trs), score, ret)
+        return VmapTrace(self, _stack_last(trs, np.ndim(score)), score, ret)
 
     def generate(self, k, chm, args):
         trs, ret, score, w = self._run("generate", k, chm, args)
-        return VmapTrace(self, _stack_last(trs), score, ret), w
+        return VmapTrace(self, _stack_last(trs, np.ndim(score)), score, ret), w
 
     importance = generate
 

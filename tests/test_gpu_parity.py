@@ -1403,3 +1403,14 @@ def test_plate_of_long_scans_as_nested_loops(gpu, monkeypatch, n, no, T, jit):
     import genjax_amd as G
     G.clear_caches()
     parity.check_plate_of_scans(n=n, no=no, T=T)
+
+
+@pytest.mark.parametrize("jit", [True, False])
+def test_nested_combinators_on_device(gpu, monkeypatch, jit):
+    """plate of plates, scan of plate, scan of scan (both levels long) through the interpreter and the specialised kernel"""
+    from genjax_amd import engine
+    monkeypatch.setattr(engine, "JIT_MIN_PARTICLES", 1024 if jit else 1 << 40)
+    monkeypatch.setattr(engine, "JIT_MIN_WORK", 1024 if jit else 1 << 40)
+    import genjax_amd as G
+    G.clear_caches()
+    parity.check_nested_combinators(n=3000)

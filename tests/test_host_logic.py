@@ -1179,3 +1179,9 @@ def test_plate_of_long_scans_matches_oracle(hostsim, no, T):
     would get wrong."""
     from tests import parity
     parity.check_plate_of_scans(n=33, no=no, T=T)
+
+
+def test_nested_combinators_match_oracle(hostsim):
+    """plate of plates, scan of plate, scan of scan — both levels long: two nested counted loops"""
+    from tests import parity
+    parity.check_nested_combinators(n=21)

@@ -25,6 +25,7 @@ from __future__ import annotations
 import functools
 import itertools
 import types
+import zlib
 from collections import OrderedDict
 
 import numpy as np
@@ -334,7 +335,97 @@ def _gfkey(gf):
         except Exception:
             _KEEP.append(gf)
             return ("gfid", id(gf), _capture_fp(gf, 0))
-    return ("gf", uid, _capture_fp(gf, 0))
+    return ("gf", uid, _capture_fp_cached(gf))
+
+
+def _capture_fp_cached(gf):
+    """`_capture_fp(gf, 0)` without walking the capture graph on every GFI call (50 us per call on the
+    functional SMC path).  The walk is done once and remembered together with the list of (getter, value seen) pairs it
+    read; a later call only re-reads those slots and compares CHEAP tokens — identity for functions / generative
+    functions / large arrays, (identity, version) for tensors, the value itself for scalars and small containers.  Any
+    difference (a rebound cell, a global assigned, a tensor written in place, a small array edited) re-walks."""
+    memo = gf.__dict__.get("_gmx_fp_memo") if hasattr(gf, "__dict__") else None
+    if memo is not None:
+        slots, seen, tokens, fp = memo
+        try:
+            for k, get in enumerate(slots):
+                v = get()
+                tok = tokens[k]
+                if tok is None:                 # an immutable value or an object compared by identity
+                    if v is not seen[k] and not (type(v) is type(seen[k]) and isinstance(v, (int, float, str, bytes)) and v == seen[k]):
+                        break
+                elif _cheap_token(v) != tok:
+                    break
+            else:
+                return fp
+        except Exception:
+            pass
+    slots = []
+    _collect_slots(gf, 0, slots, set())
+    fp = _capture_fp(gf, 0)
+    try:
+        seen = [get() for get in slots]
+        tokens = [_cheap_token(v) if isinstance(v, (torch.Tensor, np.ndarray, np.generic, tuple, list, dict)) else None
+                  for v in seen]
+        object.__setattr__(gf, "_gmx_fp_memo", (slots, seen, tokens, fp))
+    except Exception:
+        pass
+    return fp
+
+
+def _cheap_token(v):
+    if v is None or isinstance(v, (bool, int, float, str, bytes, complex)):
+        return (type(v), v) if v == v else "nan"
+    if isinstance(v, torch.Tensor):
+        return ("t", id(v), v._version)
+    if isinstance(v, (np.ndarray, np.generic, tuple, list, dict)):
+        return _value_fp(v, _CAPTURE_DEPTH + 1)        # contents (small) or the sampled hash (large): never recurses
+    return ("o", id(v))
+
+
+def _collect_slots(obj, depth, out, seen):
+    """the getters of every cell / global the fingerprint of `obj` reads, through nested functions and wrapped
+    generative functions (the same graph _capture_fp walks)"""
+    if depth > _CAPTURE_DEPTH or id(obj) in seen:
+        return
+    seen.add(id(obj))
+    if isinstance(obj, GenerativeFunction):
+        fn = getattr(obj, "_fn", None)
+        if fn is not None:
+            _collect_slots(fn, depth, out, seen)
+            part = getattr(obj, "_partial", ())
+            if part:
+                out.append(lambda o=obj: tuple(getattr(o, "_partial", ())))
+        for attr in ("gen_fn", "kernel_gen_fn", "inner"):
+            if hasattr(obj, "__dict__") and isinstance(obj.__dict__.get(attr), GenerativeFunction):
+                out.append(lambda o=obj, a=attr: o.__dict__.get(a))
+                _collect_slots(obj.__dict__[attr], depth + 1, out, seen)
+        return
+    fn = getattr(obj, "__func__", obj)
+    if not isinstance(fn, types.FunctionType):
+        return
+    cells, g, names = _capture_plan(fn)
+    for c in cells:
+        def get(c=c):
+            try:
+                return c.cell_contents
+            except ValueError:
+                return None
+        out.append(get)
+        v = get()
+        if isinstance(v, (GenerativeFunction, types.FunctionType, types.MethodType)):
+            _collect_slots(v, depth + 1, out, seen)
+        elif isinstance(v, (tuple, list)) and len(v) <= 64:
+            for x in v:
+                if isinstance(x, (GenerativeFunction, types.FunctionType, types.MethodType)):
+                    _collect_slots(x, depth + 1, out, seen)
+    for n in names:
+        v = g.get(n)
+        if isinstance(v, (types.ModuleType, type)) or v is fn:
+            continue
+        out.append(lambda g=g, n=n: g.get(n))
+        if isinstance(v, (GenerativeFunction, types.FunctionType, types.MethodType)):
+            _collect_slots(v, depth + 1, out, seen)
 
 
 _CAPTURE_DEPTH = 3        # model -> helper / sub-model -> helper
@@ -373,7 +464,15 @@ def _value_fp(v, depth):
     if isinstance(v, np.generic):
         return ("np", v.dtype.str, v.tobytes())
     if isinstance(v, np.ndarray):
-        return ("nd", v.dtype.str, v.shape, v.tobytes()) if v.size <= 4096 else ("ndid", id(v))
+        if v.size <= 4096:
+            return ("nd", v.dtype.str, v.shape, v.tobytes())
+        # a large captured array: its identity plus a hash of 4096 evenly spaced elements and of both ends, so that an
+        # in-place edit is noticed unless it misses every sampled element (documented limit: DESIGN.md §8; pass large
+        # data as an ARGUMENT — a launch leaf — and it is never part of a cache key)
+        flat = v.reshape(-1)
+        step_ = max(1, flat.size // 4096)
+        return ("ndh", id(v), v.dtype.str, v.shape, zlib.crc32(np.ascontiguousarray(flat[::step_]).tobytes()),
+                zlib.crc32(np.ascontiguousarray(flat[-64:]).tobytes()))
     if isinstance(v, torch.Tensor):
         return ("t", id(v), v._version)
     if isinstance(v, (tuple, list)) and len(v) <= 64:

@@ -868,6 +868,33 @@ def test_trace_cache_follows_captured_values():
     n0 = len(static._CACHE)
     model.assess(C.kw(x=0.25), ())
     assert len(static._CACHE) == n0
+    # the fingerprint is memoised per function and re-validated slot by slot (identity / version /
+    # small contents), not re-walked: it must still notice a small array edited in place, a large array edited in place
+    # (a sampled hash: elements on the sampling grid) and a rebound helper function
+    small = np.array([1.0, 2.0], np.float32)
+    big = np.ones(100_000, np.float32)
+
+    def helper(x):
+        return x * 2.0
+
+    @genjax.gen
+    def m2():
+        return genjax.normal(0.0, float(small[1]) * float(big[0])) @ "x", helper
+
+    def s2():
+        return f(m2.assess(C.kw(x=0.5), ())[0])
+    assert s2() == pytest.approx(stats.norm.logpdf(0.5, 0.0, 2.0), abs=1e-6)
+    k0 = static._gfkey(m2)
+    assert static._gfkey(m2) == k0 and m2.__dict__["_gmx_fp_memo"][3] == k0[2]
+    small[1] = 4.0
+    assert s2() == pytest.approx(stats.norm.logpdf(0.5, 0.0, 4.0), abs=1e-6)
+    big[0] = 0.5
+    assert s2() == pytest.approx(stats.norm.logpdf(0.5, 0.0, 2.0), abs=1e-6)
+    k1 = static._gfkey(m2)
+
+    def helper(x):          # noqa: F811  (the cell now holds another function object)
+        return x * 3.0
+    assert static._gfkey(m2) != k1
 
 
 def test_eager_numpy_namespace_uses_the_device_math():

@@ -2421,7 +2421,11 @@ extern "C" int gmx_shard_step_tiles(int kind, const uint32_t key[2], const uint6
 // slots — a slot this rank owns gets the source's local index (two 16-byte stores on the common path), a slot rank d
 // owns gets the source's state in send block d.  Same plan, send buffer and indices as k_shard_step, at a cost that
 // does not depend on the weights (k_shard_step walks each source's run per thread, with a 64-bit division per source).
-template <int kind>
+// SMALL: the whole gathered table has <= 1024 rows and <= 8 ranks (every single-node strong-scaling split of 1e6
+// particles: 8 x 123, 4 x 245, 2 x 489, 1 x 977): a thread holds its <= 4 rows in registers, so ALL loads of the launch
+// are issued before anything waits and the table is read once — the generic form walks it twice, the second time
+// behind a barrier.
+template <int kind, bool SMALL>
 __global__ void __launch_bounds__(GMX_BLOCK)
 k_shard_step_fill(uint32_t k0, uint32_t k1, uint32_t u0_host, const float* __restrict__ lw,
                   const uint8_t* __restrict__ stats_all, size_t stride, int n_tiles, float scale, int rank, int world,
@@ -2458,9 +2462,34 @@ k_shard_step_fill(uint32_t k0, uint32_t k1, uint32_t u0_host, const float* __res
   const float tmax_mine = reinterpret_cast<const float*>(own + (size_t)tiles_pad * 8)[my_tile];
   // ---- pass 1 over the table: the global max ----
   float m = -gmx_inf();
-  for (int r = 0; r < world; ++r) {
-    const float* tmax = reinterpret_cast<const float*>(stats_all + (size_t)r * stride + (size_t)tiles_pad * 8);
-    for (int t = tid; t < n_tiles; t += GMX_BLOCK) m = gmx_rmax(m, tmax[t]);
+  uint64_t ta[4];
+  float tm[4];
+  int rr[4], tt[4];
+  if (SMALL) {
+    const int rows = world * n_tiles;
+    const float inv = 1.0f / (float)n_tiles;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int rho = k * GMX_BLOCK + tid;
+      const int rc = rho < rows ? rho : 0;
+      int r = (int)(((float)rc + 0.5f) * inv);            // rc / n_tiles (exact: (rc + 0.5) / n_tiles is never near an integer)
+      int t = rc - r * n_tiles;
+      if (t < 0) { --r; t += n_tiles; }
+      if (t >= n_tiles) { ++r; t -= n_tiles; }
+      rr[k] = rho < rows ? r : -1;
+      tt[k] = t;
+      const uint8_t* blk = stats_all + (size_t)r * stride;
+      ta[k] = reinterpret_cast<const uint64_t*>(blk)[t];
+      tm[k] = reinterpret_cast<const float*>(blk + (size_t)tiles_pad * 8)[t];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) m = gmx_rmax(m, rr[k] >= 0 ? tm[k] : -gmx_inf());
+  } else {
+    for (int r = 0; r < world; ++r) {
+      const float* tmax = reinterpret_cast<const float*>(stats_all + (size_t)r * stride + (size_t)tiles_pad * 8);
+      for (int t = tid; t < n_tiles; t += GMX_BLOCK) m = gmx_rmax(m, tmax[t]);
+    }
   }
   m = wave_max(m);
   const int32_t k_b = gmx_tile_exp(tmax_mine);
@@ -2479,17 +2508,33 @@ k_shard_step_fill(uint32_t k0, uint32_t k1, uint32_t u0_host, const float* __res
   const int32_t K = gmx_tile_exp(M);
   // ---- pass 2: every rank's total (partial sums per wave), and the mass of this rank's earlier tiles ----
   uint64_t below = 0;
-  for (int r = 0; r < world; ++r) {
-    const uint64_t* agg = reinterpret_cast<const uint64_t*>(stats_all + (size_t)r * stride);
-    const float* tmax = reinterpret_cast<const float*>(stats_all + (size_t)r * stride + (size_t)tiles_pad * 8);
-    uint64_t sum = 0;
-    for (int t = tid; t < n_tiles; t += GMX_BLOCK) {
-      const uint64_t G = gmx_tile_scale(agg[t], gmx_tile_exp(tmax[t]), K);
-      sum += G;
-      below += (r == rank && t < my_tile) ? G : 0ull;
+  if (SMALL) {
+    uint64_t G[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      G[k] = rr[k] >= 0 ? gmx_tile_scale(ta[k], gmx_tile_exp(tm[k]), K) : 0ull;
+      below += (rr[k] == rank && tt[k] < my_tile) ? G[k] : 0ull;
     }
-    sum = wave_sum_u64(sum);
-    if (lane == 0) s_part[r][wave] = sum;
+    for (int r = 0; r < world; ++r) {              // world <= 8
+      uint64_t sum = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) sum += (rr[k] == r) ? G[k] : 0ull;
+      sum = wave_sum_u64(sum);
+      if (lane == 0) s_part[r][wave] = sum;
+    }
+  } else {
+    for (int r = 0; r < world; ++r) {
+      const uint64_t* agg = reinterpret_cast<const uint64_t*>(stats_all + (size_t)r * stride);
+      const float* tmax = reinterpret_cast<const float*>(stats_all + (size_t)r * stride + (size_t)tiles_pad * 8);
+      uint64_t sum = 0;
+      for (int t = tid; t < n_tiles; t += GMX_BLOCK) {
+        const uint64_t G = gmx_tile_scale(agg[t], gmx_tile_exp(tmax[t]), K);
+        sum += G;
+        below += (r == rank && t < my_tile) ? G : 0ull;
+      }
+      sum = wave_sum_u64(sum);
+      if (lane == 0) s_part[r][wave] = sum;
+    }
   }
   below = wave_sum_u64(below);
   if (lane == 0) s_below[wave] = below;
@@ -2713,13 +2758,16 @@ extern "C" int gmx_shard_step_fused(int kind, const uint32_t key[2], const void*
     uint32_t b0, b1;
     gmx_threefry2x32(key[0], key[1], 0u, 0u, &b0, &b1);           // bits32(key, 0) on the host
     const uint32_t u0 = (b0 ^ b1) >> 9;
-#define GMX_LAUNCH_SF(KIND)                                                                                           \
-    hipLaunchKernelGGL((k_shard_step_fill<KIND>), dim3((unsigned)tiles), dim3(GMX_BLOCK), 0, (hipStream_t)stream, key[0],  \
+    const bool small = world <= 8 && (int64_t)world * tiles <= 4 * GMX_BLOCK;
+#define GMX_LAUNCH_SF2(KIND, SM)                                                                                      \
+    hipLaunchKernelGGL((k_shard_step_fill<KIND, SM>), dim3((unsigned)tiles), dim3(GMX_BLOCK), 0, (hipStream_t)stream, key[0],  \
                        key[1], u0, lw_d, (const uint8_t*)stats_all_d, stride, (int)tiles, ts.scale, rank, world,       \
                        (int32_t)n_per_rank, (int32_t)capacity, plan_d, total_out_d, max_out_d, (const uint32_t*)state_d,   \
                        (uint32_t*)send_d, next_idx_d)
+#define GMX_LAUNCH_SF(KIND) do { if (small) GMX_LAUNCH_SF2(KIND, true); else GMX_LAUNCH_SF2(KIND, false); } while (0)
     if (kind == GMX_RESAMPLE_SYSTEMATIC) GMX_LAUNCH_SF(GMX_RESAMPLE_SYSTEMATIC); else GMX_LAUNCH_SF(GMX_RESAMPLE_STRATIFIED);
 #undef GMX_LAUNCH_SF
+#undef GMX_LAUNCH_SF2
     GMX_HIP(hipGetLastError());
     return 0;
   }

@@ -399,7 +399,10 @@ def test_fused_shard_step_heavy_tiles_and_ragged_shards(gpu, monkeypatch, fill):
     assert not parity.check_shard_route(2048, 3, seed=22, spike=25.0, kind=O.STRATIFIED, fused="stats")["overflow"]
     assert not parity.check_shard_route(2048, 4, dead=True, fused="stats")["overflow"]
     assert not parity.check_shard_route(1000, 1, fused="stats", seed=23)["overflow"]
-    assert not parity.check_shard_route(250_880, 4, seed=24, skew=1.0, fused="stats")["overflow"]
+    assert not parity.check_shard_route(250_880, 4, seed=24, skew=1.0, fused="stats")["overflow"]      # 980 table rows: in registers
+    assert not parity.check_shard_route(300_032, 4, seed=25, fused="stats")["overflow"]                # 1172 rows: the two-pass form
+    assert not parity.check_shard_route(2048, 16, seed=26, skew=-1.0, fused="stats")["overflow"]       # 16 ranks: the two-pass form
+    assert not parity.check_shard_route(125_952, 8, seed=27, fused="stats")["overflow"]                # 8 x 123: 1e6 split over a node
 
 
 def test_sharded_sweep_world1_matches_oracle(gpu):

@@ -747,6 +747,8 @@ def _loop_step_constraint(chm: ChoiceMap, t, n, at_step, what="scan of more than
             val = v.value.value if isinstance(v.value, Sym) else v.value
             return Mask(val, idx == t)
         inner = v.value if isinstance(v, Sym) else v
+        if isinstance(inner, Mask):        # a masked constraint over the whole axis (an enclosing loop's explicit index):
+            return Mask(pick(inner.value), inner.flag)      # this iteration's element of its value, the same flag
         if isinstance(inner, (RuntimeTable, TableArray, StepInput, StepInput2)) and inner.shape[0] == n:
             return inner[t]
         if isinstance(inner, np.ndarray) and inner.ndim >= 1 and inner.shape[0] == n:

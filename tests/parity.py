@@ -1673,3 +1673,45 @@ def _nest_scan_of_scan(n):
     tr = model.simulate(G.split(G.key(5), n), (0.5, None))
     otr = omodel.simulate(O.split(O.key(5), n), (np.float32(0.5), None))
     _nest_cmp(tr, otr, ["x", ("fine", "w")])
+
+
+def check_nested_constraint_forms(n=9, A=12, T=20):
+    """Constraints addressed INTO two nested loops (a plate of long scans): one cell through two integer addresses
+    (`C[3, "steps", 5, "y"]`: masked at (t_outer == 3) & (t_inner == 5)), one whole series through its integer address
+    (`C[7, "steps", :, "y"]`: a masked [T] table read step by step), per-particle observations [n, A, T] (one
+    step-indexed leaf, GMX_F_FLAT) — weights against the oracle's leaf densities, and assess of the resulting choices."""
+    import genjax_amd as G
+    from genjax_amd import ChoiceMapBuilder as C, numpy as jnp
+    @G.gen
+    def step(x, _):
+        xn = G.normal(0.9 * x, 0.5) @ "x"
+        G.normal(xn, 1.0) @ "y"
+        return xn, None
+    @G.gen
+    def series(x0):
+        xT, _ = step.scan(n=T)(x0, None) @ "steps"
+        return xT
+    model = series.vmap(in_axes=(0,))
+    x0s = np.linspace(-1, 1, A).astype(np.float32)
+    tr, w = model.importance(G.split(G.key(2), n), C[3, "steps", 5, "y"].set(0.25), (jnp.array(x0s),))
+    y = tr.get_choices()["steps", "y"].cpu().numpy(); x = tr.get_choices()["steps", "x"].cpu().numpy()
+    assert y.shape == (n, A, T)
+    assert np.all(y[:, 3, 5] == np.float32(0.25))
+    assert (y == np.float32(0.25)).sum() == n
+    ref = O.normal.assess(O.C.choice(np.full(n, 0.25, np.float32)), (x[:, 3, 5], np.float32(1.0)), (n,))[0]
+    assert np.array_equal(w.cpu().numpy(), ref)
+    # a whole series' observations through its integer address
+    ys = np.linspace(-1, 1, T).astype(np.float32)
+    tr2, w2 = model.importance(G.split(G.key(3), n), C[7, "steps", :, "y"].set(ys), (jnp.array(x0s),))
+    y2 = tr2.get_choices()["steps", "y"].cpu().numpy(); x2 = tr2.get_choices()["steps", "x"].cpu().numpy()
+    assert np.array_equal(y2[:, 7, :], np.broadcast_to(ys, (n, T)))
+    ref2 = np.zeros(n, np.float32)
+    for t in range(T):
+        ref2 = (ref2 + O.normal.assess(O.C.choice(np.full(n, ys[t], np.float32)), (x2[:, 7, t], np.float32(1.0)), (n,))[0]).astype(np.float32)
+    assert np.array_equal(w2.cpu().numpy(), ref2)
+    # per-particle observations [n, A, T]
+    yp = np.random.default_rng(0).normal(size=(n, A, T)).astype(np.float32)
+    tr3, w3 = model.importance(G.split(G.key(4), n), C["steps", "y"].set(torch.from_numpy(yp)), (jnp.array(x0s),))
+    assert np.array_equal(tr3.get_choices()["steps", "y"].cpu().numpy(), yp)
+    s3, _ = model.assess(tr3.get_choices(), (jnp.array(x0s),))
+    assert np.array_equal(s3.cpu().numpy(), tr3.get_score().cpu().numpy())

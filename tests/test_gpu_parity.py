@@ -1417,3 +1417,4 @@ def test_nested_combinators_on_device(gpu, monkeypatch, jit):
     import genjax_amd as G
     G.clear_caches()
     parity.check_nested_combinators(n=3000)
+    parity.check_nested_constraint_forms(n=2000)

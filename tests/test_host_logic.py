@@ -1212,3 +1212,4 @@ def test_nested_combinators_match_oracle(hostsim):
     """plate of plates, scan of plate, scan of scan — both levels long: two nested counted loops"""
     from tests import parity
     parity.check_nested_combinators(n=21)
+    parity.check_nested_constraint_forms()

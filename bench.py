@@ -548,11 +548,35 @@ def main():
         # the CPU mirror; GENMI_SHARDED_GRAPH=0 keeps eager launches.
         if (on_gpu and not args.no_graph and os.environ.get("GENMI_SHARDED_GRAPH", "1") != "0"
                 and (sw.cx is None or sw.cx.graph_safe)):
-            sw.capture()
+            # every rank captures or none does: a capture that raises on ONE rank (the RCCL calls of a capture have
+            # only ever run at world size 1 in the build loop) leaves all of them on eager launches — the same
+            # launches, stream-ordered — instead of failing the measurement
+            ok = 1
+            try:
+                sw.capture()
+            except Exception as e:          # noqa: BLE001
+                ok = 0
+                sw.graph = None
+                print(f"bench.py: rank {rank}: hipGraph capture of the sharded sweep failed ({e!r}); eager launches",
+                      file=sys.stderr, flush=True)
+            if dist is not None and world > 1:
+                agree = torch.tensor([ok], device=be.device, dtype=torch.int32)
+                dist.all_reduce(agree, op=dist.ReduceOp.MIN)
+                if int(agree.item()) == 0:
+                    sw.graph = None
 
         def launch():
             sw.launch()
             sw.finish()          # the once-per-sweep overflow check (one sync, one 8-byte all-reduce)
+
+        if world > 1:
+            # the first sweeps under a deadline: a collective that never completes makes the rank EXIT (status 3, the
+            # launcher tears the job down) instead of hanging the driver until its own limit
+            from genjax_amd.inference.comm import _Deadline
+            with _Deadline(float(os.environ.get("GENMI_COMM_TIMEOUT", "120")), "the first sharded sweep"):
+                launch()
+                if on_gpu:
+                    torch.cuda.synchronize()
 
     def barrier():
         if dist is not None:

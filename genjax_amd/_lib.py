@@ -22,7 +22,7 @@ GMX_MAX_UNI = 64
 
 ABI_VERSION = 4
 KEY_NONE, KEY_ARRAY, KEY_SPLIT, KEY_ROWSPLIT, KEY_BCAST = 0, 1, 2, 3, 4
-RESAMPLE_SYSTEMATIC, RESAMPLE_STRATIFIED, RESAMPLE_MULTINOMIAL = 0, 1, 2
+RESAMPLE_SYSTEMATIC, RESAMPLE_STRATIFIED, RESAMPLE_MULTINOMIAL, RESAMPLE_MULTINOMIAL_TILED = 0, 1, 2, 3
 
 
 class ResampleIn(Structure):
@@ -127,6 +127,10 @@ class Backend:
         c.gmx_tile_stats.argtypes = [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p]
         c.gmx_resample_tiles.argtypes = [c_int, POINTER(c_uint32), c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p,
                                          c_void_p, c_void_p, c_void_p]
+        c.gmx_multinomial_tiled_workspace.argtypes = [c_int64]
+        c.gmx_multinomial_tiled_workspace.restype = c_size_t
+        c.gmx_multinomial_tiled.argtypes = [POINTER(c_uint32), c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p,
+                                            c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]
         c.gmx_slot_uniforms.argtypes = [c_void_p, c_int, c_int64, c_void_p, c_int, c_void_p]
         c.gmx_resample_tiles_u.argtypes = [c_int, POINTER(c_uint32), c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p,
                                            c_void_p, c_void_p, c_void_p, c_void_p]

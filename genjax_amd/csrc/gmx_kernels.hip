@@ -1866,6 +1866,295 @@ extern "C" int gmx_resample_tiles_q(int kind, const uint32_t key[2], const uint3
   return launch_offspring_tile(kind, key, nullptr, q_d, n, shift, tile_max_d, tile_agg_d, max_d, total_d, ancestors_d, stream);
 }
 
+// ---- two-stage multinomial resampling (include/genmi.h: gmx_multinomial_tiled) ----
+// Multinomial resampling as the oracle first defined it (GMX_RESAMPLE_MULTINOMIAL: slot j takes its own uniform and
+// the first particle whose CDF exceeds it) is bound by random cache lines: every slot ends in a random tile's CDF and
+// the gather behind it reads a random particle.  Two stages remove the randomness from MEMORY:
+//   k_mn_hist  every workgroup builds the end-of-tile CDF (<= 2048 entries) in LDS from the tile statistics; a slot's
+//              uniform picks its tile there (11 LDS probes), counted in an LDS histogram, flushed with one integer atomic
+//              per (workgroup, tile) — integer sums: order-independent, bit-reproducible
+//   k_mn_tile  workgroup b owns tile b: the tile's CDF rebuilt in LDS from its log-weights, the counts table reduced
+//              to (offset, count) of the tile, then count_b slots each probe the LOCAL CDF (10 LDS probes) and write
+//              consecutive output positions
+// The output is ordered by tile (iid inside a tile), so the following gather streams.  Same offspring law.
+#define MN_HIST_BLOCKS 256
+__device__ __forceinline__ uint64_t mn_scale23(uint32_t u, uint64_t m) {      // (u * m) >> 23 for u < 2^23, m < 2^62
+  const uint64_t lo = (m & 0xffffffffull) * (uint64_t)u, hi = (m >> 32) * (uint64_t)u;
+  return (hi << 9) + (lo >> 23);
+}
+
+__global__ void __launch_bounds__(GMX_BLOCK)
+k_mn_hist(uint32_t k0, uint32_t k1, const float* __restrict__ tmax, const uint64_t* __restrict__ agg, int64_t n,
+          int n_tiles, const uint32_t* __restrict__ u_d, float* __restrict__ max_out, uint64_t* __restrict__ total_out,
+          uint32_t* __restrict__ counts) {
+  __shared__ uint64_t s_cend[RS_MAX_TILES];
+  __shared__ uint32_t s_hist[RS_MAX_TILES];
+  __shared__ uint64_t s_w[4];
+  __shared__ float s_max[4];
+  const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int PERT = RS_MAX_TILES / GMX_BLOCK;            // 8 consecutive table rows per thread
+  float tm[PERT];
+  uint64_t ta[PERT];
+  float m = -gmx_inf();
+#pragma unroll
+  for (int r = 0; r < PERT; ++r) {
+    const int t = tid * PERT + r;
+    const int tc = t < n_tiles ? t : n_tiles - 1;
+    tm[r] = tmax[tc]; ta[r] = agg[tc];
+    s_hist[t] = 0u;
+  }
+#pragma unroll
+  for (int r = 0; r < PERT; ++r) m = gmx_rmax(m, (tid * PERT + r < n_tiles) ? tm[r] : -gmx_inf());
+  m = wave_max(m);
+  if (lane == 0) s_max[wave] = m;
+  __syncthreads();
+  const float M = gmx_rmax(gmx_rmax(s_max[0], s_max[1]), gmx_rmax(s_max[2], s_max[3]));
+  const int32_t K = gmx_tile_exp(M);
+  uint64_t g[PERT], run = 0;
+#pragma unroll
+  for (int r = 0; r < PERT; ++r) {
+    run += (tid * PERT + r < n_tiles) ? gmx_tile_scale(ta[r], gmx_tile_exp(tm[r]), K) : 0ull;
+    g[r] = run;
+  }
+  const uint64_t inc = wave_scan_u64(run);
+  if (lane == 63) s_w[wave] = inc;
+  __syncthreads();
+  uint64_t off = inc - run;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) off += (w < wave) ? s_w[w] : 0ull;
+#pragma unroll
+  for (int r = 0; r < PERT; ++r) s_cend[tid * PERT + r] = off + g[r];       // rows past n_tiles repeat the total
+  __syncthreads();
+  const uint64_t total = s_cend[n_tiles - 1];
+  if (blockIdx.x == 0 && tid == 0) { *total_out = total; *max_out = M; }
+  if (total == 0) return;                                   // no mass: k_mn_tile maps every slot to the last particle
+  gmx_key key; key.k0 = k0; key.k1 = k1;
+  const int64_t per_block = (n + gridDim.x - 1) / gridDim.x;
+  const int64_t j_lo = (int64_t)blockIdx.x * per_block, j_hi = j_lo + per_block < n ? j_lo + per_block : n;
+  // four slots per thread and trip: four independent searches in flight hide the LDS round trips.  A search starts
+  // from the tile a flat weight vector would give (u * n_tiles) and gallops: tile masses rarely differ by more than
+  // a small factor, so it ends after a few probes instead of log2(n_tiles) = 11.
+  const float tiles_f = (float)n_tiles * (1.0f / 8388608.0f);
+  for (int64_t j0 = j_lo + tid; j0 < j_hi; j0 += 4 * GMX_BLOCK) {
+    uint64_t P[4];
+    int b[4];
+    bool ok[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int64_t j = j0 + (int64_t)q * GMX_BLOCK;
+      ok[q] = j < j_hi;
+      const int64_t jc = ok[q] ? j : j_hi - 1;
+      const uint32_t u = u_d ? u_d[jc] : (gmx_bits32(key, (uint64_t)jc) >> 9);
+      P[q] = mn_scale23(u, total);
+      int g = (int)((float)u * tiles_f);
+      b[q] = g < n_tiles ? g : n_tiles - 1;
+    }
+    // the answer is the first tile with cend > P: walk down while the tile before still exceeds P, up while this one
+    // does not (both loops end: cend is non-decreasing and cend[n_tiles - 1] = total > P)
+    bool moving = true;
+    int it = 0;
+#pragma unroll 1
+    while (moving && it < 6) {
+      moving = false;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint64_t here = s_cend[b[q]];
+        const uint64_t prev = b[q] > 0 ? s_cend[b[q] - 1] : 0ull;
+        const bool up = !(here > P[q]), down = b[q] > 0 && prev > P[q];
+        b[q] += up ? 1 : (down ? -1 : 0);
+        moving |= up | down;
+      }
+      ++it;
+    }
+    if (moving) {                         // strongly uneven tile masses: the plain binary search
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        int lo = 0, hi = n_tiles;
+#pragma unroll 1
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          if (s_cend[mid] > P[q]) hi = mid; else lo = mid + 1;
+        }
+        b[q] = lo;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (ok[q]) atomicAdd(&s_hist[b[q]], 1u);
+  }
+  __syncthreads();
+  for (int t = tid; t < n_tiles; t += GMX_BLOCK) {
+    const uint32_t c = s_hist[t];
+    if (c) atomicAdd(&counts[t], c);
+  }
+}
+
+template <int PER>
+__global__ void __launch_bounds__(GMX_BLOCK)
+k_mn_tile(uint32_t k0, uint32_t k1, const float* __restrict__ lw, const float* __restrict__ tmax,
+          const uint64_t* __restrict__ agg, int64_t n, int n_tiles, float scale, const uint32_t* __restrict__ counts,
+          uint32_t* __restrict__ zero_other, int32_t* __restrict__ anc) {
+  GMX_SETPRIO
+  __shared__ uint64_t s_cdf[RS_TILE];
+  __shared__ uint64_t s_scan[4], s_all[4];
+  __shared__ uint32_t s_cb[4];
+  __shared__ float s_max[4];
+  const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int my_tile = (int)blockIdx.x;
+  const int64_t i0 = (int64_t)my_tile * RS_TILE + (int64_t)tid * CDF_VEC;
+  float x[CDF_VEC];
+  if ((int64_t)(my_tile + 1) * RS_TILE <= n) {
+    const float4 v = *reinterpret_cast<const float4*>(lw + i0);
+    x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
+  } else {
+#pragma unroll
+    for (int c = 0; c < CDF_VEC; ++c) {
+      const int64_t ic = i0 + c < n ? i0 + c : n - 1;
+      const float xv = lw[ic];
+      x[c] = (i0 + c < n) ? xv : -gmx_inf();
+    }
+  }
+  // the table: global max (-> K), the total (zero: no mass), and the slots of the tiles before mine
+  float tm[PER];
+  uint64_t ta[PER];
+  uint32_t tc_[PER];
+#pragma unroll
+  for (int r = 0; r < PER; ++r) {
+    const int t = r * GMX_BLOCK + tid;
+    const int tc = t < n_tiles ? t : n_tiles - 1;
+    tm[r] = tmax[tc]; ta[r] = agg[tc]; tc_[r] = counts[tc];
+  }
+  const float tmax_mine = tmax[my_tile];
+  const uint64_t agg_mine = agg[my_tile];
+  const uint32_t n_b = counts[my_tile];
+  float m = -gmx_inf();
+  uint32_t before = 0;
+#pragma unroll
+  for (int r = 0; r < PER; ++r) {
+    const int t = r * GMX_BLOCK + tid;
+    m = gmx_rmax(m, t < n_tiles ? tm[r] : -gmx_inf());
+    before += (t < my_tile) ? tc_[r] : 0u;
+  }
+  m = wave_max(m);
+  before = (uint32_t)wave_sum_u64((uint64_t)before);
+  const int32_t k_b = gmx_tile_exp(tmax_mine);
+  const float ref_b = gmx_tile_ref(k_b);
+  uint64_t q[CDF_VEC], run = 0;
+#pragma unroll
+  for (int c = 0; c < CDF_VEC; ++c) {
+    run += (i0 + c < n) ? weight_fixed(x[c], ref_b, scale) : 0ull;
+    q[c] = run;
+  }
+  const uint64_t inc = wave_scan_u64(run);
+  if (lane == 0) { s_max[wave] = m; s_cb[wave] = before; }
+  if (lane == 63) s_scan[wave] = inc;
+  __syncthreads();
+  const float M = gmx_rmax(gmx_rmax(s_max[0], s_max[1]), gmx_rmax(s_max[2], s_max[3]));
+  const int32_t K = gmx_tile_exp(M);
+  const uint32_t O_b = (s_cb[0] + s_cb[1]) + (s_cb[2] + s_cb[3]);
+  uint64_t all = 0;
+#pragma unroll
+  for (int r = 0; r < PER; ++r)
+    all += (r * GMX_BLOCK + tid < n_tiles) ? gmx_tile_scale(ta[r], gmx_tile_exp(tm[r]), K) : 0ull;
+  all = wave_sum_u64(all);
+  if (lane == 0) s_all[wave] = all;
+  uint64_t wave_off = 0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) wave_off += (w < wave) ? s_scan[w] : 0ull;
+  const uint64_t loc = wave_off + (inc - run);
+#pragma unroll
+  for (int c = 0; c < CDF_VEC; ++c) s_cdf[tid * CDF_VEC + c] = gmx_tile_scale(loc + q[c], k_b, K);   // past n: repeats the last
+  __syncthreads();
+  const uint64_t total = (s_all[0] + s_all[1]) + (s_all[2] + s_all[3]);
+  if (total == 0) {
+#pragma unroll
+    for (int c = 0; c < CDF_VEC; ++c)
+      if (i0 + c < n) anc[i0 + c] = (int32_t)(n - 1);
+    if (zero_other && tid == 0) zero_other[my_tile] = 0u;
+    return;
+  }
+  const uint64_t G_b = gmx_tile_scale(agg_mine, k_b, K);
+  gmx_key k2; k2.k0 = k0; k2.k1 = k1;
+  const gmx_key kb = gmx_fold_in(k2, (uint32_t)my_tile);
+  const int32_t base_i = my_tile * RS_TILE;
+  const int cnt_i = (int64_t)(my_tile + 1) * RS_TILE <= n ? RS_TILE : (int)(n - (int64_t)my_tile * RS_TILE);
+  for (uint32_t r0 = (uint32_t)tid; r0 < n_b; r0 += 4 * GMX_BLOCK) {     // four independent searches per trip
+    uint64_t Q[4];
+    int lo[4], hi[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint32_t r = r0 + (uint32_t)q * GMX_BLOCK;
+      const uint32_t v = gmx_bits32(kb, (uint64_t)r) >> 9;
+      Q[q] = mn_scale23(v, G_b);
+      lo[q] = 0; hi[q] = cnt_i;
+    }
+#pragma unroll 1
+    for (int step_ = 0; step_ < 11; ++step_) {            // 2^10 = RS_TILE: <= 11 halvings; first particle with local cdf > Q
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int mid = (lo[q] + hi[q]) >> 1;
+        const bool open = lo[q] < hi[q];
+        const uint64_t cv = s_cdf[open ? mid : 0];
+        if (open) { if (cv > Q[q]) hi[q] = mid; else lo[q] = mid + 1; }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint32_t r = r0 + (uint32_t)q * GMX_BLOCK;
+      const int a = lo[q] < cnt_i ? lo[q] : cnt_i - 1;
+      const int64_t pos = (int64_t)O_b + r;
+      if (r < n_b && pos < n) anc[pos] = base_i + a;
+    }
+  }
+  if (zero_other && tid == 0) zero_other[my_tile] = 0u;     // leave the OTHER count buffer clean for the caller's next call
+}
+
+// two count buffers of (tiles + 16) words each
+extern "C" size_t gmx_multinomial_tiled_workspace(int64_t n) { return (size_t)((n + RS_TILE - 1) / RS_TILE + 16) * 8; }
+
+extern "C" int gmx_multinomial_tiled(const uint32_t key[2], const float* lw_d, int64_t n, int shift,
+                                     const float* tile_max_d, const uint64_t* tile_agg_d, const uint32_t* u_d,
+                                     float* max_d, uint64_t* total_d, int32_t* ancestors_d, void* workspace_d,
+                                     int phase, gmx_stream stream) {
+  if (resample_shape("gmx_multinomial_tiled", n, shift)) return 1;
+  if (!key || !lw_d || !tile_max_d || !tile_agg_d || !max_d || !total_d || !ancestors_d || !workspace_d)
+    return gmx_fail("gmx_multinomial_tiled: null argument%s");
+  if (n > 0x7fffffffLL) return gmx_fail("gmx_multinomial_tiled: n out of range%s");
+  if (phase < -1 || phase > 1) return gmx_fail("gmx_multinomial_tiled: phase is -1, 0 or 1%s");
+  if (((uintptr_t)lw_d & 15) || ((uintptr_t)workspace_d & 15))
+    return gmx_fail("gmx_multinomial_tiled: lw_d and workspace_d must be 16-byte aligned%s");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t tiles = (n + RS_TILE - 1) / RS_TILE;
+  const size_t words = (size_t)tiles + 16;
+  // The call counts into one of two buffers and leaves the OTHER one zero (every workgroup of k_mn_tile clears its own
+  // entry there: nobody reads that buffer during the call).  phase 0 / 1: buffer `phase` — which the previous call,
+  // made with the other phase, left zero: a caller that alternates needs no memset at all.  phase -1: buffer 0 after
+  // zeroing it here (a memset node): the first call of a sequence, or a one-off.
+  uint32_t* counts = (uint32_t*)workspace_d + (phase == 1 ? words : 0);
+  uint32_t* other = (uint32_t*)workspace_d + (phase == 1 ? 0 : words);
+  if (phase < 0) GMX_HIP(hipMemsetAsync(counts, 0, words * 4, st));
+  // (k1, k2) = split(key, 2): two Threefry blocks on the host
+  uint32_t k1[2], k2[2];
+  gmx_threefry2x32(key[0], key[1], 0u, 0u, &k1[0], &k1[1]);
+  gmx_threefry2x32(key[0], key[1], 0u, 1u, &k2[0], &k2[1]);
+  const int64_t want = (n + 8 * GMX_BLOCK - 1) / (8 * GMX_BLOCK);              // >= 8 slots per thread
+  static const int max_hb = []() { const char* e = getenv("GENMI_MN_HIST_BLOCKS"); int v = e ? atoi(e) : 0; return v > 0 ? v : MN_HIST_BLOCKS; }();
+  const unsigned hb = (unsigned)(want < 1 ? 1 : (want < max_hb ? want : max_hb));
+  hipLaunchKernelGGL(k_mn_hist, dim3(hb), dim3(GMX_BLOCK), 0, st, k1[0], k1[1], tile_max_d, tile_agg_d, n, (int)tiles, u_d,
+                     max_d, total_d, counts);
+  const float scale = gmx_pow2i(shift);
+#define GMX_LAUNCH_MT(PER_)                                                                                          \
+  hipLaunchKernelGGL((k_mn_tile<PER_>), dim3((unsigned)tiles), dim3(GMX_BLOCK), 0, st, k2[0], k2[1], lw_d, tile_max_d,  \
+                     tile_agg_d, n, (int)tiles, scale, (const uint32_t*)counts, other, ancestors_d)
+  if (tiles <= 1 * GMX_BLOCK) GMX_LAUNCH_MT(1);
+  else if (tiles <= 2 * GMX_BLOCK) GMX_LAUNCH_MT(2);
+  else if (tiles <= 4 * GMX_BLOCK) GMX_LAUNCH_MT(4);
+  else GMX_LAUNCH_MT(8);
+#undef GMX_LAUNCH_MT
+  GMX_HIP(hipGetLastError());
+  return 0;
+}
+
 // ---- the stratified resampler's per-slot uniforms, ahead of time ----
 // out[r][j] = bits32(keys[r], j) >> 9: what slots_below_est<stratified> would draw for slot j of the resampling keyed
 // keys[r].  They depend on keys and slot numbers only, so a sweep draws them on its background stream, a group of steps

@@ -410,7 +410,10 @@ def _target_over(target: Target, batch: tuple, k: int) -> Target:
 MULTINOMIAL_GUIDED_MIN = 8192      # below this the per-slot search of gmx_ancestors is as fast as building a guide table
 SYSTEMATIC, STRATIFIED, MULTINOMIAL = (_lib.RESAMPLE_SYSTEMATIC, _lib.RESAMPLE_STRATIFIED,
                                        _lib.RESAMPLE_MULTINOMIAL)
-_KINDS = {"systematic": SYSTEMATIC, "stratified": STRATIFIED, "multinomial": MULTINOMIAL}
+# two-stage multinomial (gmx_multinomial_tiled): the same offspring law, the output ordered by the ancestor's CDF tile
+MULTINOMIAL_TILED = _lib.RESAMPLE_MULTINOMIAL_TILED
+_KINDS = {"systematic": SYSTEMATIC, "stratified": STRATIFIED, "multinomial": MULTINOMIAL,
+          "multinomial_tiled": MULTINOMIAL_TILED}
 
 
 def cdf_reference(m) -> float:
@@ -910,7 +913,11 @@ class BootstrapSweep(_NoiseAhead):
         self.totals = torch.zeros((T,), dtype=torch.int64, device=dev)
         self.shift = cdf_shift(n)
         self.ws = torch.zeros(((be.c.gmx_weight_cdf_workspace(n) + 7) // 8,), dtype=torch.int64, device=dev)
-        self.fused = self.kind in (SYSTEMATIC, STRATIFIED) and n <= (512 * 4096)
+        self.fused = self.kind in (SYSTEMATIC, STRATIFIED, MULTINOMIAL_TILED) and n <= (512 * 4096)
+        if self.kind == MULTINOMIAL_TILED and not self.fused:
+            raise NotImplementedError("resample='multinomial_tiled': n <= 2^21 per GPU (use 'multinomial')")
+        self.mnt_ws = torch.zeros(((be.c.gmx_multinomial_tiled_workspace(n) + 3) // 4,), dtype=torch.int32, device=dev) \
+            if self.kind == MULTINOMIAL_TILED else None
         self.mn_ws = torch.zeros(((be.c.gmx_multinomial_workspace(n) + 3) // 4,), dtype=torch.int32, device=dev) \
             if self.kind == MULTINOMIAL else None
         self.rs_ws = torch.zeros(((be.c.gmx_resample_workspace(n) + 7) // 8,), dtype=torch.int64, device=dev) \
@@ -1187,14 +1194,17 @@ class BootstrapSweep(_NoiseAhead):
         (gmx_resample_tiles_u): the same ancestors, one Threefry block per slot-edge evaluation less on the chain.
         GENMI_SLOT_UNIFORMS=0: drawn inside the resampler."""
         self.ubuf = None
-        if not (self.noise_ahead and self.kind == STRATIFIED and self.fused and self.tile_stats and self.tile_q is None
-                and self.tile_pref is None and not self.fuse and os.environ.get("GENMI_SLOT_UNIFORMS", "1") != "0"):
+        if not (self.noise_ahead and self.kind in (STRATIFIED, MULTINOMIAL_TILED) and self.fused and self.tile_stats
+                and self.tile_q is None and self.tile_pref is None and not self.fuse
+                and os.environ.get("GENMI_SLOT_UNIFORMS", "1") != "0"):
             return
         dev = self.zbuf.device
         self.ubuf = torch.zeros((2, self.noise_group, self.n), dtype=torch.int32, device=dev)
         self._u_keys = []
         for t0, t1 in self.noise_groups:
-            ks = np.stack([self.step_keys[t][1].host() for t in range(t0, t1)]).astype(np.uint32)
+            # stratified: the resampling key itself; the two-stage multinomial: its first child (stage 1's key)
+            rk = (lambda t: split(self.step_keys[t][1], 2)[0]) if self.kind == MULTINOMIAL_TILED else (lambda t: self.step_keys[t][1])
+            ks = np.stack([rk(t).host() for t in range(t0, t1)]).astype(np.uint32)
             self._u_keys.append(torch.from_numpy(ks.view(np.int32)).to(dev))
         self._u_pad = int(os.environ.get("GENMI_NOISE_LDS_PAD", self.NOISE_LDS_PAD))
 
@@ -1211,6 +1221,21 @@ class BootstrapSweep(_NoiseAhead):
         be = _lib.get()
         kh = self.step_keys[t][1].host()
         kk = (c_uint32 * 2)(int(kh[0]), int(kh[1]))
+        if self.kind == MULTINOMIAL_TILED:
+            w = t % 2
+            if not self.tile_stats:
+                be.check(be.c.gmx_tile_stats(be.ptr(self.lw_pp[w]), self.n, self.shift, be.ptr(self.partials_pp[w]),
+                                             be.ptr(self.tile_agg_pp[w]), be.stream()), "gmx_tile_stats")
+            u_d = None
+            if getattr(self, "ubuf", None) is not None:
+                half, row = self.noise_slot[t]
+                u_d = be.ptr(self.ubuf[half, row])
+            be.check(be.c.gmx_multinomial_tiled(kk, be.ptr(self.lw_pp[w]), self.n, self.shift, be.ptr(self.partials_pp[w]),
+                                                be.ptr(self.tile_agg_pp[w]), u_d, be.ptr(self.maxs[t:t + 1]),
+                                                be.ptr(self.totals[t:t + 1]), be.ptr(self.anc), be.ptr(self.mnt_ws),
+                                                -1 if t == 0 else (t & 1),      # count buffers alternate: one memset per sweep
+                                                be.stream()), "gmx_multinomial_tiled")
+            return
         if getattr(self, "ubuf", None) is not None:
             w = t % 2
             half, row = self.noise_slot[t]

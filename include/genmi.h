@@ -244,7 +244,8 @@ int gmx_logsumexp(const float* lw_d, int64_t rows, int64_t cols, float* out_d,
  *         (`get_particle` tree_map, smc.py:90-91).
  * gmx_categorical_rows: one Gumbel-max index per row (sample_particle).
  * ---------------------------------------------------------------------- */
-enum { GMX_RESAMPLE_SYSTEMATIC = 0, GMX_RESAMPLE_STRATIFIED = 1, GMX_RESAMPLE_MULTINOMIAL = 2 };
+enum { GMX_RESAMPLE_SYSTEMATIC = 0, GMX_RESAMPLE_STRATIFIED = 1, GMX_RESAMPLE_MULTINOMIAL = 2,
+       GMX_RESAMPLE_MULTINOMIAL_TILED = 3 /* gmx_multinomial_tiled only */ };
 
 /* *max_d = max of the n block maxima a program's OP_REDMAX wrote (plane 0 of red_out_d). */
 int gmx_reduce_max(const float* partials_d, int64_t n, float* max_d, gmx_stream stream);
@@ -303,6 +304,23 @@ int gmx_tile_prefix(const float* tile_max_d, const uint64_t* tile_agg_d, int64_t
 int gmx_resample_tiles_p(int kind, const uint32_t key[2], const float* lw_d, int64_t n, int shift,
                          const float* tile_max_d, const uint64_t* tile_pref_d, float* max_d,
                          uint64_t* total_d, int32_t* ancestors_d, gmx_stream stream);
+/* Two-stage multinomial resampling from log-weights + tile statistics (GMX_RESAMPLE_MULTINOMIAL_TILED; build-defined,
+ * SURVEY App. B): offspring counts are Multinomial(n, w), the output is ordered by the ancestor's 1024-particle CDF tile
+ * (iid order inside a tile), so the gather that follows reads tile by tile instead of n random lines.
+ *   (k1, k2) = split(key, 2)
+ *   stage 1  slot j picks a tile: P = (u_j * total) >> 23, u_j = bits32(k1, j) >> 9; tile = first b whose end-of-tile
+ *            CDF exceeds P; c_b = slots that picked b (LDS histograms, then integer atomics: order-independent)
+ *   stage 2  tile b's c_b slots are consecutive output positions (tiles in order); its r-th slot picks the local
+ *            position Q = (v * G_b) >> 23, v = bits32(fold_in(k2, b), r) >> 9, in the tile's own CDF (rebuilt in LDS)
+ * u_d (optional, [n]): the stage-1 uniforms drawn ahead by gmx_slot_uniforms(keys = k1).  workspace_d:
+ * gmx_multinomial_tiled_workspace(n) bytes, 16-byte aligned: TWO buffers of tile counts.  A call counts into one and
+ * leaves the other zero.  phase 0 / 1: into buffer `phase`, which must be zero — as the previous call, made with the
+ * other phase, left it (a sequence of calls alternating 0, 1, 0, ... needs no memset); phase -1: into buffer 0 after
+ * zeroing it (a memset node in a captured graph): a one-off call, or the first of a sequence.  n <= 2^21. */
+size_t gmx_multinomial_tiled_workspace(int64_t n);
+int gmx_multinomial_tiled(const uint32_t key[2], const float* lw_d, int64_t n, int shift, const float* tile_max_d,
+                          const uint64_t* tile_agg_d, const uint32_t* u_d, float* max_d, uint64_t* total_d,
+                          int32_t* ancestors_d, void* workspace_d, int phase, gmx_stream stream);
 /* The stratified resampler's per-slot uniforms drawn AHEAD of the resampling (they depend on the key and the slot
  * number only): gmx_slot_uniforms fills out_d[r][j] = bits32(keys_d[r], j) >> 9 for `rows` resampling keys (device
  * array [rows, 2]) in one 2-D launch — meant for a background stream beside a dependent chain of launches: `lds_pad`

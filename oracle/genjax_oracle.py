@@ -1769,6 +1769,51 @@ def ancestors(kind, k, cdf, n_out=None):
     return np.minimum(idx, n_in - 1).astype(np.int32)
 
 
+MULTINOMIAL_TILED = 3
+
+
+def ancestors_multinomial_tiled(k, cdf):
+    """BUILD-DEFINED two-stage multinomial resampling (include/genmi.h, gmx_multinomial_tiled; no reference counterpart:
+    SURVEY App. B).  Offspring counts are Multinomial(n, w) as for MULTINOMIAL; what differs is WHICH slot gets which
+    ancestor: the output is ordered by the ancestor's 1024-particle CDF tile (iid order inside a tile), so that the
+    gather that follows reads tile by tile instead of 1e6 random lines.
+      (k1, k2) = split(k, 2)
+      stage 1  slot j picks a tile:  P_j = (u_j * total) >> 23,  u_j = bits32(k1, j) >> 9;  tile = first b with
+               Cend_b > P_j  (Cend_b = the integer CDF at the tile's last particle);  c_b = how many slots picked b
+      stage 2  the c_b slots of tile b are consecutive output positions (tiles in order); its r-th slot picks a local
+               position Q = (v * G_b) >> 23,  v = bits32(fold_in(k2, b), r) >> 9,  G_b = Cend_b - Cend_{b-1};
+               ancestor = first particle i of the tile with cdf_i - Cend_{b-1} > Q.
+    All integers: exact on any partitioning.  No mass at all: every slot maps to the last particle."""
+    cdf = np.asarray(cdf, dtype=np.uint64)
+    n = cdf.size
+    total = int(cdf[-1])
+    if total == 0:
+        return np.full(n, n - 1, dtype=np.int32)
+    ks = split(np.asarray(k, np.uint32), 2)
+    k1, k2 = ks[0], ks[1]
+    ends = np.append(np.arange(CDF_TILE - 1, n - 1, CDF_TILE), n - 1)
+    cend = cdf[ends]
+    u = (bits32(k1[None, :], np.arange(n, dtype=np.uint64)) >> np.uint32(9)).astype(object)
+    P = np.array((u * total) >> 23, dtype=np.uint64)
+    tile_of = np.searchsorted(cend, P, side="right")
+    counts = np.bincount(tile_of, minlength=cend.size)
+    out = np.empty(n, dtype=np.int32)
+    pos = 0
+    for b in np.nonzero(counts)[0]:
+        c = int(counts[b])
+        lo = int(b) * CDF_TILE
+        base = int(cend[b - 1]) if b > 0 else 0
+        G = int(cend[b]) - base
+        kb = fold_in(k2, int(b))
+        v = (bits32(np.asarray(kb)[None, :], np.arange(c, dtype=np.uint64)) >> np.uint32(9)).astype(object)
+        Q = np.array((v * G) >> 23, dtype=np.uint64)
+        local = cdf[lo:lo + CDF_TILE] - np.uint64(base)
+        out[pos:pos + c] = lo + np.searchsorted(local, Q, side="right")
+        pos += c
+    assert pos == n
+    return out
+
+
 def log_ml_increment(M, total, shift, n):
     """log( (1/n) sum_i exp(lw_i) ) from the integer total, evaluated in f64 on
     the host: ref + log(total * 2^-shift) - log(n), ref = cdf_reference(M) = ceil(M / ln 2) * ln 2 (the

@@ -366,6 +366,62 @@ extern "C" int gmx_resample_tiles_p(int kind, const uint32_t key[2], const float
   *max_d = M; *total = pref[tiles];
   return gmx_ancestors(kind, key, cdf.data(), n, 0, total, n, 0, n, anc, st);
 }
+// two-stage multinomial resampling (include/genmi.h: gmx_multinomial_tiled) — the sequential statement
+extern "C" size_t gmx_multinomial_tiled_workspace(int64_t n) { return (size_t)((n + HS_TILE - 1) / HS_TILE + 16) * 8; }
+extern "C" int gmx_multinomial_tiled(const uint32_t key[2], const float* lw, int64_t n, int shift, const float* tmax,
+                                     const uint64_t* agg, const uint32_t* u_d, float* max_d, uint64_t* total_d,
+                                     int32_t* anc, void* ws, int phase, gmx_stream) {
+  if (!key || !lw || !tmax || !agg || !max_d || !total_d || !anc || !ws || n <= 0 || shift < 1 || phase < -1 || phase > 1)
+    return fail("multinomial_tiled: bad argument");
+  const int64_t tiles = (n + HS_TILE - 1) / HS_TILE;
+  // the two-buffer protocol of the device entry, checked: the buffer of this phase must arrive zero
+  uint32_t* buf = (uint32_t*)ws + (phase == 1 ? tiles + 16 : 0);
+  uint32_t* other = (uint32_t*)ws + (phase == 1 ? 0 : tiles + 16);
+  if (phase >= 0)
+    for (int64_t b = 0; b < tiles; ++b)
+      if (buf[b]) return fail("multinomial_tiled: the count buffer of this phase is not zero (alternate the phases)");
+  struct Leave { uint32_t* o; int64_t t; ~Leave() { for (int64_t b = 0; b < t; ++b) o[b] = 0; } } leave{other, tiles};
+  float M = -gmx_inf();
+  for (int64_t b = 0; b < tiles; ++b) M = gmx_rmax(M, tmax[b]);
+  const int32_t K = gmx_tile_exp(M);
+  std::vector<uint64_t> cend((size_t)tiles), G((size_t)tiles);
+  uint64_t total = 0;
+  for (int64_t b = 0; b < tiles; ++b) { G[b] = gmx_tile_scale(agg[b], gmx_tile_exp(tmax[b]), K); total += G[b]; cend[b] = total; }
+  *max_d = M; *total_d = total;
+  if (total == 0) { for (int64_t i = 0; i < n; ++i) anc[i] = (int32_t)(n - 1); return 0; }
+  gmx_key k; k.k0 = key[0]; k.k1 = key[1];
+  const gmx_key k1 = gmx_split_child(k, 0), k2 = gmx_split_child(k, 1);
+  uint32_t* counts = buf;
+  for (int64_t b = 0; b < tiles; ++b) counts[b] = 0;
+  for (int64_t j = 0; j < n; ++j) {
+    const uint32_t u = gmx_bits32(k1, (uint64_t)j) >> 9;
+    if (u_d && u_d[j] != u) return fail("multinomial_tiled: u_d is not split(key, 2)[0]'s slot uniforms");
+    const uint64_t P = (uint64_t)(((u128)u * (u128)total) >> 23);
+    int64_t lo = 0, hi = tiles;
+    while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (cend[mid] > P) hi = mid; else lo = mid + 1; }
+    ++counts[lo];
+  }
+  const float scale = gmx_pow2i(shift);
+  int64_t pos = 0;
+  for (int64_t b = 0; b < tiles; ++b) {
+    const int64_t lo_i = b * HS_TILE, hi_i = lo_i + HS_TILE < n ? lo_i + HS_TILE : n;
+    const int32_t kb_e = gmx_tile_exp(tmax[b]);
+    const float ref = gmx_tile_ref(kb_e);
+    std::vector<uint64_t> loc((size_t)(hi_i - lo_i));
+    uint64_t run = 0;
+    for (int64_t i = lo_i; i < hi_i; ++i) { run += hs_weight_fixed(lw[i], ref, scale); loc[(size_t)(i - lo_i)] = gmx_tile_scale(run, kb_e, K); }
+    const gmx_key kb = gmx_fold_in(k2, (uint32_t)b);
+    for (uint32_t r = 0; r < counts[b]; ++r) {
+      const uint32_t v = gmx_bits32(kb, (uint64_t)r) >> 9;
+      const uint64_t Q = (uint64_t)(((u128)v * (u128)G[b]) >> 23);
+      int64_t a = 0, z = hi_i - lo_i;
+      while (a < z) { int64_t mid = (a + z) >> 1; if (loc[(size_t)mid] > Q) z = mid; else a = mid + 1; }
+      anc[pos++] = (int32_t)(lo_i + a);
+    }
+  }
+  if (pos != n) return fail("multinomial_tiled: the tile counts do not add up to n");
+  return 0;
+}
 // the stratified resampler's uniforms ahead of time, and the resampler that reads them (the mirror checks that what it
 // is handed IS what the resampling would draw, then resamples as usual)
 extern "C" int gmx_slot_uniforms(const uint32_t* keys, int rows, int64_t n, uint32_t* out, int lds_pad, gmx_stream) {

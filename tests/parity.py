@@ -28,7 +28,7 @@ def oracle_bootstrap_sweep(init, step, n, T, ys, run_key, kind=O.SYSTEMATIC, ste
         x = np.asarray(tr.get_retval(), np.float32)
         lw = np.asarray(w, np.float32)
         cdf, total, M, shift = O.weight_cdf(lw)
-        anc = O.ancestors(kind, k_res, cdf)
+        anc = O.ancestors_multinomial_tiled(k_res, cdf) if kind == O.MULTINOMIAL_TILED else O.ancestors(kind, k_res, cdf)
         log_ml += O.log_ml_increment(M, total, shift, n)
         hist.append(dict(x=x, lw=lw, cdf=cdf, total=total, M=M, anc=anc))
     return dict(log_ml=log_ml, x=x, lw=lw, anc=anc, hist=hist)
@@ -54,7 +54,8 @@ def check_lgssm_sweep(n=4096, T=5, seed=314159, capture=False, specialize=True, 
     x, lw, anc = sw.state()
     oi, os_ = workloads.make_lgssm(O)
     ref = oracle_bootstrap_sweep(oi, os_, n, T, ys, O.key(seed),
-                                 kind={"systematic": O.SYSTEMATIC, "stratified": O.STRATIFIED}[resample])
+                                 kind={"systematic": O.SYSTEMATIC, "stratified": O.STRATIFIED,
+                                       "multinomial_tiled": O.MULTINOMIAL_TILED}[resample])
     return dict(
         log_ml=log_ml, log_ml_oracle=ref["log_ml"], kalman=workloads.kalman_log_ml(ys),
         ancestors_equal=bool(np.array_equal(anc.cpu().numpy(), ref["anc"])),
@@ -1715,3 +1716,49 @@ def check_nested_constraint_forms(n=9, A=12, T=20):
     assert np.array_equal(tr3.get_choices()["steps", "y"].cpu().numpy(), yp)
     s3, _ = model.assess(tr3.get_choices(), (jnp.array(x0s),))
     assert np.array_equal(s3.cpu().numpy(), tr3.get_score().cpu().numpy())
+
+
+def check_multinomial_tiled(n=5000, seed=5, sigma=2.0, dead=False, spike=0.0):
+    """gmx_multinomial_tiled (two-stage multinomial: tile by LDS histogram, then inside the tile) against the oracle's
+    definition, directly through the C-ABI: ragged n, skewed weights (one particle with most of the mass: its tile owns
+    almost every slot), no mass at all; with and without the stage-1 uniforms handed over (gmx_slot_uniforms)."""
+    from ctypes import c_uint32
+    from genjax_amd import _lib
+    be = _lib.get()
+    dev = be.device
+    rng = np.random.default_rng(seed)
+    lw = rng.normal(0, sigma, n).astype(np.float32)
+    if spike:
+        lw[n // 3] += np.float32(spike)
+    if dead:
+        lw[:] = -np.inf
+    k = O.key(seed + 1)
+    cdf, total, M, shift = O.weight_cdf(lw)
+    want = O.ancestors_multinomial_tiled(k, cdf)
+    T_ = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    lw_d = T_(lw)
+    tiles = (n + 1023) // 1024
+    tmax = torch.zeros((tiles,), dtype=torch.float32, device=dev)
+    agg = torch.zeros((tiles,), dtype=torch.int64, device=dev)
+    be.check(be.c.gmx_tile_stats(be.ptr(lw_d), n, shift, be.ptr(tmax), be.ptr(agg), be.stream()), "gmx_tile_stats")
+    kk = (c_uint32 * 2)(int(k[0]), int(k[1]))
+    ws = torch.zeros(((int(be.c.gmx_multinomial_tiled_workspace(n)) + 3) // 4,), dtype=torch.int32, device=dev)
+    k1 = O.split(k, 2)[0]
+    for with_u in (False, True):
+        u_d = None
+        if with_u:
+            keys = T_(np.asarray(k1, np.uint32).reshape(1, 2).view(np.int32))
+            u_d = torch.zeros((n,), dtype=torch.int32, device=dev)
+            be.check(be.c.gmx_slot_uniforms(be.ptr(keys), 1, n, be.ptr(u_d), 0, be.stream()), "gmx_slot_uniforms")
+        mx = torch.zeros((1,), dtype=torch.float32, device=dev)
+        tot = torch.zeros((1,), dtype=torch.int64, device=dev)
+        anc = torch.full((n,), -1, dtype=torch.int32, device=dev)
+        be.check(be.c.gmx_multinomial_tiled(kk, be.ptr(lw_d), n, shift, be.ptr(tmax), be.ptr(agg),
+                                            be.ptr(u_d) if u_d is not None else None, be.ptr(mx), be.ptr(tot), be.ptr(anc),
+                                            be.ptr(ws), -1 if not with_u else 1, be.stream()), "gmx_multinomial_tiled")
+        got = anc.cpu().numpy()
+        assert np.array_equal(got, want), (with_u, int((got != want).sum()))
+        assert int(tot.item()) & 0xFFFFFFFFFFFFFFFF == total
+        if not dead:
+            assert float(mx.item()) == M
+    return {"distinct": int(np.unique(want).size)}

@@ -113,6 +113,7 @@ def test_entry_points_reject_null_arguments_before_any_launch():
         "gmx_resample_tiles_q": (i32(0), N, N, i64(10), i32(40), N, N, N, N, N, N),
         "gmx_resample_tiles_p": (i32(0), N, N, i64(10), i32(40), N, N, N, N, N, N),
         "gmx_tile_prefix": (N, N, i64(10), N, N),
+        "gmx_multinomial_tiled": (N, N, i64(10), i32(40), N, N, N, N, N, N, N, i32(-1), N),
         "gmx_slot_uniforms": (N, i32(1), i64(10), N, i32(0), N),
         "gmx_resample_tiles_u": (i32(1), N, N, i64(10), i32(40), N, N, N, N, N, N, N),
         "gmx_shard_totals": (N, i32(2), i64(1024), N, N, N),

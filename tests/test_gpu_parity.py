@@ -1418,3 +1418,16 @@ def test_nested_combinators_on_device(gpu, monkeypatch, jit):
     G.clear_caches()
     parity.check_nested_combinators(n=3000)
     parity.check_nested_constraint_forms(n=2000)
+
+
+def test_two_stage_multinomial_on_device(gpu):
+    """gmx_multinomial_tiled (k_mn_hist + k_mn_tile) == the oracle's definition: ragged / one-tile / one-particle sizes,
+    a spike that gives one tile almost every slot, no mass at all, 1e6 particles; and whole sweeps resampled with it
+    (one stream, and noise ahead with the stage-1 uniforms from the background stream), captured"""
+    for kw in (dict(n=5000), dict(n=1024, seed=6), dict(n=3333, seed=7, spike=30.0), dict(n=2500, seed=8, dead=True),
+               dict(n=1, seed=9), dict(n=1025, seed=10, sigma=8.0), dict(n=1_000_000, seed=11, sigma=1.5),
+               dict(n=300_001, seed=12, spike=12.0)):
+        parity.check_multinomial_tiled(**kw)
+    for na in (False, True):
+        res = parity.check_lgssm_sweep(n=50_000, T=13, capture=True, specialize=True, resample="multinomial_tiled", noise_ahead=na)
+        assert res["ancestors_equal"] and res["x_equal"] and res["totals_equal"] and res["lw_max_abs_diff"] == 0.0

@@ -1213,3 +1213,14 @@ def test_nested_combinators_match_oracle(hostsim):
     from tests import parity
     parity.check_nested_combinators(n=21)
     parity.check_nested_constraint_forms()
+
+
+def test_two_stage_multinomial_matches_oracle(hostsim):
+    """gmx_multinomial_tiled == the oracle's definition (C-ABI mirror), and a whole sweep resampled with it"""
+    from tests import parity
+    for kw in (dict(n=5000), dict(n=1024, seed=6), dict(n=3333, seed=7, spike=30.0), dict(n=2500, seed=8, dead=True),
+               dict(n=1, seed=9), dict(n=1025, seed=10, sigma=8.0)):
+        parity.check_multinomial_tiled(**kw)
+    for na in (False, True):
+        res = parity.check_lgssm_sweep(n=3000, T=7, resample="multinomial_tiled", noise_ahead=na)
+        assert res["ancestors_equal"] and res["x_equal"] and res["totals_equal"] and res["lw_max_abs_diff"] == 0.0

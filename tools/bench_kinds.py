@@ -9,7 +9,7 @@ n, T = 1_000_000, 100
 ys = workloads.lgssm_data(T)
 init, step = workloads.make_lgssm(G)
 out = {}
-for kind in ("systematic", "stratified", "multinomial"):
+for kind in ("systematic", "stratified", "multinomial", "multinomial_tiled"):
     sw = BootstrapSweep(init, step, n, T, resample=kind).prepare(G.key(314159), torch.from_numpy(ys)).capture()
     for _ in range(3): sw.launch()
     torch.cuda.synchronize(); t0 = time.perf_counter()

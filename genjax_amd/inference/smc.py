@@ -513,6 +513,18 @@ def resample_fused(kind, key: Key, lw: torch.Tensor):
     anc = torch.empty((n,), dtype=torch.int32, device=lw.device)
     total = torch.empty((1,), dtype=torch.int64, device=lw.device)
     mx = torch.empty((1,), dtype=torch.float32, device=lw.device)
+    if int(kind) == MULTINOMIAL_TILED:          # two-stage multinomial: tile statistics, then gmx_multinomial_tiled
+        kh = key.host()
+        kk = (c_uint32 * 2)(int(kh[0]), int(kh[1]))
+        if not (stats is not None and stats[2] == shift and stats[3] == n):
+            tiles = (n + 1023) // 1024
+            stats = (torch.empty((tiles,), dtype=torch.float32, device=lw.device),
+                     torch.empty((tiles,), dtype=torch.int64, device=lw.device))
+            be.check(be.c.gmx_tile_stats(be.ptr(lw), n, shift, be.ptr(stats[0]), be.ptr(stats[1]), be.stream()), "gmx_tile_stats")
+        ws = torch.empty(((be.c.gmx_multinomial_tiled_workspace(n) + 3) // 4,), dtype=torch.int32, device=lw.device)
+        be.check(be.c.gmx_multinomial_tiled(kk, be.ptr(lw), n, shift, be.ptr(stats[0]), be.ptr(stats[1]), None, be.ptr(mx),
+                                            be.ptr(total), be.ptr(anc), be.ptr(ws), -1, be.stream()), "gmx_multinomial_tiled")
+        return anc, total, mx, shift
     if stats is not None and stats[2] == shift and stats[3] == n:
         kh = key.host()
         kk = (c_uint32 * 2)(int(kh[0]), int(kh[1]))
@@ -555,8 +567,10 @@ def resample(key: Key, collection: ParticleCollection, kind="systematic", n_out=
         raise NotImplementedError("resample: batched collections")
     kind = _KINDS[kind] if isinstance(kind, str) else int(kind)
     n = lw.numel()
-    if kind in (SYSTEMATIC, STRATIFIED) and n_out in (None, n) and 0 < n <= FUSED_RESAMPLE_MAX:
+    if kind in (SYSTEMATIC, STRATIFIED, MULTINOMIAL_TILED) and n_out in (None, n) and 0 < n <= FUSED_RESAMPLE_MAX:
         anc, total, mx, shift = resample_fused(kind, key, lw)        # no CDF in memory (gmx_resample[_tiles])
+    elif kind == MULTINOMIAL_TILED:
+        raise NotImplementedError("resample(kind='multinomial_tiled'): n_out = n <= 2^21 (use 'multinomial')")
     else:
         cdf, total, mx, shift = weight_cdf(lw)
         anc = ancestors_from_cdf(kind, key, cdf, total, n_out)

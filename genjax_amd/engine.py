@@ -425,6 +425,15 @@ class Tracing:
             for e_, slot in enumerate(slots):
                 self.in_plan.append((slot, j, e_, "step2"))
             return Sym(StepInput.make2(g, slots, dt, int(event[0]), event[1:]), ("leaf", j))
+        if kind == "part" and len(event) >= 3 and event[1] > STEP_LEAF_MIN and int(np.prod(event[2:])) <= DVEC_MAX:
+            # [n, A, T, *site event]: a vector-valued site of the long scans of a plate — one [A * T, n] slot per
+            # element of the site's event
+            E = int(np.prod(event[2:]))
+            slots = list(range(g.n_in, g.n_in + E))
+            g.n_in += E
+            for e_, slot in enumerate(slots):
+                self.in_plan.append((slot, j, e_, "stepflat2"))
+            return Sym(StepInput2(g, slots, dt, (int(event[0]), int(event[1])), event=tuple(int(x) for x in event[2:])), ("leaf", j))
         if kind == "part" and len(event) == 2 and event[1] > STEP_LEAF_MIN:
             # [n, A, T] with a long last axis: the choices of the long scans of a plate — one slot ([A * T, n]); row a is
             # picked statically (an unrolled plate) or by the outer loop's iteration number (a plate run as a loop
@@ -591,8 +600,9 @@ class StepInput2:
     the scan's loop, is ONE load: element a * T + t of the slot (OP_LDIN, GMX_F_STEP with imm = a * T; under two
     nested loops GMX_F_FLAT: the pair index is the loops' own)."""
 
-    def __init__(self, g, slot, dt, shape, row=None):
-        self._g, self._slot, self._dt, self.shape, self._row = g, slot, dt, tuple(shape), row
+    def __init__(self, g, slot, dt, shape, row=None, event=()):
+        # slot: one input slot, or (a vector-valued site: event != ()) one per element of the site's event
+        self._g, self._slot, self._dt, self.shape, self._row, self._event = g, slot, dt, tuple(shape), row, tuple(event)
         self.ndim = len(self.shape)
 
     def __len__(self):
@@ -602,11 +612,11 @@ class StepInput2:
         from .program import F_FLAT, F_STEP, F_U8
         if self.ndim == 2:
             if isinstance(idx, (int, np.integer)):
-                return StepInput2(self._g, self._slot, self._dt, self.shape[1:], row=int(idx))
+                return StepInput2(self._g, self._slot, self._dt, self.shape[1:], row=int(idx), event=self._event)
             if isinstance(idx, Expr):
                 if idx.node.op != "LDT":
                     raise NotImplementedError("a [n, A, T] step leaf takes its row from the plate's own iteration number")
-                return StepInput2(self._g, self._slot, self._dt, self.shape[1:], row="loop")
+                return StepInput2(self._g, self._slot, self._dt, self.shape[1:], row="loop", event=self._event)
             raise NotImplementedError("a [n, A, T] leaf with a long last axis is read row by row (a plate of long scans)")
         if not (isinstance(idx, Expr) and idx.node.op == "LDT"):
             raise NotImplementedError("a long per-particle row is read by the scan's own iteration number")
@@ -614,10 +624,17 @@ class StepInput2:
         if self._row == "loop":
             if len(self._g.loop_counts) != 2:
                 raise NotImplementedError("element (t_outer, t_inner) of a two-axis step leaf outside the inner loop")
-            return Expr(self._g.add("LDIN", dtype=self._dt, flags=flags | F_FLAT, slot=self._slot))
-        if len(self._g.loop_counts) != 1:
-            raise NotImplementedError("a statically picked row of a two-axis step leaf is read inside ONE loop")
-        return Expr(self._g.add("LDIN", dtype=self._dt, flags=flags, slot=self._slot, imm=int(self._row) * self.shape[0]))
+            flags, imm = flags | F_FLAT, 0
+        else:
+            if len(self._g.loop_counts) != 1:
+                raise NotImplementedError("a statically picked row of a two-axis step leaf is read inside ONE loop")
+            imm = int(self._row) * self.shape[0]
+        if not self._event:
+            return Expr(self._g.add("LDIN", dtype=self._dt, flags=flags, slot=self._slot, imm=imm))
+        out = np.empty(self._event, dtype=object)          # a vector-valued site: this step's row, element by element
+        for e, ix in enumerate(np.ndindex(self._event)):
+            out[ix] = Expr(self._g.add("LDIN", dtype=self._dt, flags=flags, slot=self._slot[e], imm=imm))
+        return out
 
 
 class StepOutput:
@@ -853,12 +870,16 @@ class Compiled:
                 elif kind == "stepflat":   # [n, T0, T1] -> [T0 * T1, n]
                     t_ = _prepare_input(src, "bcast", None, be)
                     buf = t_.reshape(n, -1).t().contiguous()
+                elif kind == "stepflat2":  # [n, A, T, *event] -> [E, A * T, n] planes
+                    t_ = _prepare_input(src, "bcast", None, be)
+                    nb_ = len(batch)
+                    buf = t_.reshape(n, t_.shape[nb_] * t_.shape[nb_ + 1], -1).permute(2, 1, 0).contiguous()
                 else:
                     buf = _prepare_input(src, "part" if kind == "step" else kind, n if kind in ("part", "step") else None, be)
                 soa_cache[key_] = buf
                 keep.append(buf)
             item = buf.element_size()
-            if kind == "step2":
+            if kind in ("step2", "stepflat2"):
                 A.in_d[slot] = buf.data_ptr() + e * buf.shape[1] * n * item
                 A.step_stride = n
             elif kind == "stepflat":

@@ -1762,3 +1762,66 @@ def check_multinomial_tiled(n=5000, seed=5, sigma=2.0, dead=False, spike=0.0):
         if not dead:
             assert float(mx.item()) == M
     return {"distinct": int(np.unique(want).size)}
+
+
+def check_nested_edge_cases():
+    """two nested loops at their edges: a one-element plate and a 20-element plate of 40-step scans, `repeat(n=20)` of a
+    scan, a VECTOR-valued site inside the inner loop ([n, A, T, 3] values: one [A * T, n] plane per element, written
+    and — for assess — read back through GMX_F_FLAT)"""
+    import genjax_amd as G
+    from genjax_amd import numpy as jnp
+    _nested_outer_one_and_repeat.__globals__.update({"G": G, "jnp": jnp})
+    _nested_outer_one_and_repeat()
+    _nested_vector_site()
+
+
+def _edge_eq(a, b): return np.array_equal(a.cpu().numpy() if hasattr(a, "cpu") else a, b)
+
+def _nested_outer_one_and_repeat():
+    n, T = 11, 40
+    def mk(g, scan_of):
+        @g.gen
+        def step(x, _):
+            xn = g.normal(0.9 * x, 0.5) @ "x"
+            return xn, xn
+        @g.gen
+        def series(x0):
+            xT, xs = scan_of(step)(x0, None) @ "steps"
+            return xT
+        return series
+    s, os_ = mk(G, lambda f: f.scan(n=T)), mk(O, lambda f: O.Scan(f, T))
+    for A in (1, 20):
+        tr = s.vmap(in_axes=(0,)).simulate(G.split(G.key(1), n), (jnp.array(np.linspace(0, 1, A).astype(np.float32)),))
+        otr = O.Vmap(os_, in_axes=(0,)).simulate(O.split(O.key(1), n), (np.linspace(0, 1, A).astype(np.float32),))
+        assert _edge_eq(tr.get_choices()["steps", "x"], otr.get_choices()["steps", "x"]), A
+        assert _edge_eq(tr.get_retval(), otr.get_retval()) and _edge_eq(tr.get_score(), otr.get_score())
+    tr = s.repeat(n=20).simulate(G.split(G.key(2), n), (0.5,))
+    otr = O.Repeat(os_, 20).simulate(O.split(O.key(2), n), (np.float32(0.5),))
+    assert _edge_eq(tr.get_choices()["steps", "x"], otr.get_choices()["steps", "x"]) and _edge_eq(tr.get_score(), otr.get_score())
+
+def _nested_vector_site():
+    n, A, T = 9, 20, 20
+    def mk(g, scan_of):
+        @g.gen
+        def step(x, _):
+            if g is G:
+                v = g.normal(x * jnp.array([1.0, 0.5, 0.25]), 1.0) @ "v"
+                return v[0] * 0.5 + v[2] * 0.1, None
+            v = g.normal(np.asarray(x, np.float32)[..., None] * np.asarray([1.0, 0.5, 0.25], np.float32), np.float32(1.0)) @ "v"
+            return (v[..., 0] * np.float32(0.5) + v[..., 2] * np.float32(0.1)).astype(np.float32), None
+        @g.gen
+        def series(x0):
+            xT, _ = scan_of(step)(x0, None) @ "steps"
+            return xT
+        return series
+    def jnp_or_np(g, a):
+        return jnp.array(a) if g is G else np.asarray(a, np.float32)
+    s, os_ = mk(G, lambda f: f.scan(n=T)), mk(O, lambda f: O.Scan(f, T))
+    x0 = np.linspace(-1, 1, A).astype(np.float32)
+    tr = s.vmap(in_axes=(0,)).simulate(G.split(G.key(3), n), (jnp.array(x0),))
+    otr = O.Vmap(os_, in_axes=(0,)).simulate(O.split(O.key(3), n), (x0,))
+    v, ov = tr.get_choices()["steps", "v"], otr.get_choices()["steps", "v"]
+    assert tuple(v.shape) == (n, A, T, 3) == tuple(np.shape(ov)), (v.shape, np.shape(ov))
+    assert _edge_eq(v, ov) and _edge_eq(tr.get_score(), otr.get_score())
+    sc, _ = s.vmap(in_axes=(0,)).assess(tr.get_choices(), (jnp.array(x0),))
+    assert _edge_eq(sc, tr.get_score().cpu().numpy())

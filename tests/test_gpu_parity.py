@@ -1418,6 +1418,7 @@ def test_nested_combinators_on_device(gpu, monkeypatch, jit):
     G.clear_caches()
     parity.check_nested_combinators(n=3000)
     parity.check_nested_constraint_forms(n=2000)
+    parity.check_nested_edge_cases()
 
 
 def test_two_stage_multinomial_on_device(gpu):

@@ -1213,6 +1213,7 @@ def test_nested_combinators_match_oracle(hostsim):
     from tests import parity
     parity.check_nested_combinators(n=21)
     parity.check_nested_constraint_forms()
+    parity.check_nested_edge_cases()
 
 
 def test_two_stage_multinomial_matches_oracle(hostsim):

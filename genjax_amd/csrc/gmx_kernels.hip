@@ -1935,16 +1935,32 @@ k_mn_hist(uint32_t k0, uint32_t k1, const float* __restrict__ tmax, const uint64
   // from the tile a flat weight vector would give (u * n_tiles) and gallops: tile masses rarely differ by more than
   // a small factor, so it ends after a few probes instead of log2(n_tiles) = 11.
   const float tiles_f = (float)n_tiles * (1.0f / 8388608.0f);
+  // (the uniforms of the NEXT trip are loaded while this one walks: a trip would otherwise start with a global round trip)
+  uint32_t un[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int64_t j = j_lo + tid + (int64_t)q * GMX_BLOCK;
+    const int64_t jc = j < j_hi ? j : j_hi - 1;
+    un[q] = u_d ? u_d[jc] : 0u;
+  }
   for (int64_t j0 = j_lo + tid; j0 < j_hi; j0 += 4 * GMX_BLOCK) {
     uint64_t P[4];
     int b[4];
     bool ok[4];
+    uint32_t uc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      uc[q] = un[q];
+      const int64_t jn = j0 + (int64_t)(q + 4) * GMX_BLOCK;
+      const int64_t jnc = jn < j_hi ? jn : j_hi - 1;
+      un[q] = u_d ? u_d[jnc] : 0u;
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int64_t j = j0 + (int64_t)q * GMX_BLOCK;
       ok[q] = j < j_hi;
       const int64_t jc = ok[q] ? j : j_hi - 1;
-      const uint32_t u = u_d ? u_d[jc] : (gmx_bits32(key, (uint64_t)jc) >> 9);
+      const uint32_t u = u_d ? uc[q] : (gmx_bits32(key, (uint64_t)jc) >> 9);
       P[q] = mn_scale23(u, total);
       int g = (int)((float)u * tiles_f);
       b[q] = g < n_tiles ? g : n_tiles - 1;
@@ -1996,8 +2012,9 @@ k_mn_tile(uint32_t k0, uint32_t k1, const float* __restrict__ lw, const float* _
           uint32_t* __restrict__ zero_other, int32_t* __restrict__ anc) {
   GMX_SETPRIO
   __shared__ uint64_t s_cdf[RS_TILE];
+  __shared__ __attribute__((aligned(16))) uint32_t s_guide[RS_TILE];
   __shared__ uint64_t s_scan[4], s_all[4];
-  __shared__ uint32_t s_cb[4];
+  __shared__ uint32_t s_cb[4], s_gc[4];
   __shared__ float s_max[4];
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int my_tile = (int)blockIdx.x;
@@ -2062,8 +2079,14 @@ k_mn_tile(uint32_t k0, uint32_t k1, const float* __restrict__ lw, const float* _
 #pragma unroll
   for (int w = 0; w < 4; ++w) wave_off += (w < wave) ? s_scan[w] : 0ull;
   const uint64_t loc = wave_off + (inc - run);
+  uint64_t edge[CDF_VEC + 1];                      // scaled local CDF at the lower edge of my first source and after each
+  edge[0] = gmx_tile_scale(loc, k_b, K);
 #pragma unroll
-  for (int c = 0; c < CDF_VEC; ++c) s_cdf[tid * CDF_VEC + c] = gmx_tile_scale(loc + q[c], k_b, K);   // past n: repeats the last
+  for (int c = 0; c < CDF_VEC; ++c) {
+    edge[c + 1] = gmx_tile_scale(loc + q[c], k_b, K);
+    s_cdf[tid * CDF_VEC + c] = edge[c + 1];          // past n: repeats the last
+  }
+  reinterpret_cast<uint4*>(s_guide)[tid] = make_uint4(0u, 0u, 0u, 0u);
   __syncthreads();
   const uint64_t total = (s_all[0] + s_all[1]) + (s_all[2] + s_all[3]);
   if (total == 0) {
@@ -2078,32 +2101,76 @@ k_mn_tile(uint32_t k0, uint32_t k1, const float* __restrict__ lw, const float* _
   const gmx_key kb = gmx_fold_in(k2, (uint32_t)my_tile);
   const int32_t base_i = my_tile * RS_TILE;
   const int cnt_i = (int64_t)(my_tile + 1) * RS_TILE <= n ? RS_TILE : (int)(n - (int64_t)my_tile * RS_TILE);
-  for (uint32_t r0 = (uint32_t)tid; r0 < n_b; r0 += 4 * GMX_BLOCK) {     // four independent searches per trip
+  // a GUIDE over the local CDF instead of a search per slot: bucket g of 1024 covers the positions [g, g + 1) * G_b / 1024;
+  // every particle with mass marks the first bucket that starts inside its interval, a max-scan fills the rest, and a
+  // slot starts at guide[v >> 13] (its bucket: Q = v * G_b >> 23) and WALKS to the exact answer — the marks come from a
+  // float product, so they may be one bucket off; the walk settles that with the exact integers.
+  {
+    const float inv = 1024.0f / (float)G_b;
+#pragma unroll
+    for (int c = 0; c < CDF_VEC; ++c) {
+      if (edge[c + 1] > edge[c]) {
+        const int gb = (int)__builtin_ceilf((float)edge[c] * inv);
+        if (gb < RS_TILE) atomicMax(&s_guide[gb], (uint32_t)(tid * CDF_VEC + c));
+      }
+    }
+    __syncthreads();
+    uint4 a = reinterpret_cast<const uint4*>(s_guide)[tid];
+    a.y = a.y > a.x ? a.y : a.x; a.z = a.z > a.y ? a.z : a.y; a.w = a.w > a.z ? a.w : a.z;
+    const uint32_t incl = gmx_wave_umax_scan(a.w);
+    uint32_t carry = wave_shr1_u32(incl, 0u);
+    if (lane == 63) s_gc[wave] = incl;
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < 3; ++w) { const uint32_t v_ = s_gc[w]; carry = (w < wave && v_ > carry) ? v_ : carry; }
+    a.x = a.x > carry ? a.x : carry; a.y = a.y > carry ? a.y : carry; a.z = a.z > carry ? a.z : carry; a.w = a.w > carry ? a.w : carry;
+    reinterpret_cast<uint4*>(s_guide)[tid] = a;
+    __syncthreads();
+  }
+  for (uint32_t r0 = (uint32_t)tid; r0 < n_b; r0 += 4 * GMX_BLOCK) {     // four independent walks per trip
     uint64_t Q[4];
-    int lo[4], hi[4];
+    int at[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const uint32_t r = r0 + (uint32_t)q * GMX_BLOCK;
       const uint32_t v = gmx_bits32(kb, (uint64_t)r) >> 9;
       Q[q] = mn_scale23(v, G_b);
-      lo[q] = 0; hi[q] = cnt_i;
+      const int g0 = (int)s_guide[v >> 13];
+      at[q] = g0 < cnt_i ? g0 : cnt_i - 1;
     }
+    // the answer is the first particle with local cdf > Q (Q < G_b = cdf[last]: it exists)
+    bool moving = true;
+    int it = 0;
 #pragma unroll 1
-    for (int step_ = 0; step_ < 11; ++step_) {            // 2^10 = RS_TILE: <= 11 halvings; first particle with local cdf > Q
+    while (moving && it < 24) {
+      moving = false;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int mid = (lo[q] + hi[q]) >> 1;
-        const bool open = lo[q] < hi[q];
-        const uint64_t cv = s_cdf[open ? mid : 0];
-        if (open) { if (cv > Q[q]) hi[q] = mid; else lo[q] = mid + 1; }
+        const uint64_t here = s_cdf[at[q]];
+        const uint64_t prev = at[q] > 0 ? s_cdf[at[q] - 1] : 0ull;
+        const bool up = !(here > Q[q]) && at[q] + 1 < cnt_i, down = at[q] > 0 && prev > Q[q];
+        at[q] += up ? 1 : (down ? -1 : 0);
+        moving |= up | down;
+      }
+      ++it;
+    }
+    if (moving) {                          // many particles inside one bucket: the plain binary search
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        int lo = 0, hi = cnt_i;
+#pragma unroll 1
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          if (s_cdf[mid] > Q[q]) hi = mid; else lo = mid + 1;
+        }
+        at[q] = lo < cnt_i ? lo : cnt_i - 1;
       }
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const uint32_t r = r0 + (uint32_t)q * GMX_BLOCK;
-      const int a = lo[q] < cnt_i ? lo[q] : cnt_i - 1;
       const int64_t pos = (int64_t)O_b + r;
-      if (r < n_b && pos < n) anc[pos] = base_i + a;
+      if (r < n_b && pos < n) anc[pos] = base_i + at[q];
     }
   }
   if (zero_other && tid == 0) zero_other[my_tile] = 0u;     // leave the OTHER count buffer clean for the caller's next call

@@ -1825,3 +1825,98 @@ def _nested_vector_site():
     assert _edge_eq(v, ov) and _edge_eq(tr.get_score(), otr.get_score())
     sc, _ = s.vmap(in_axes=(0,)).assess(tr.get_choices(), (jnp.array(x0),))
     assert _edge_eq(sc, tr.get_score().cpu().numpy())
+
+
+def check_evidence_unbiased(kind, R=3000, N=32, T=8, seed0=1000):
+    """INDEPENDENT of the oracle: a bootstrap particle filter's evidence estimate is unbiased, E[exp(log_ml_hat)] = Z,
+    whatever the (valid) resampling scheme and however few particles — and for the linear-Gaussian model Z is the
+    Kalman filter's closed form.  R sweeps with N = 32 particles under R different keys: the mean of Z_hat / Z must be 1
+    within 4 standard errors.  Holds the resampling DEFINITIONS (systematic, stratified, multinomial, the two-stage
+    multinomial), the key schedule and the weight algebra against a number neither the oracle nor the product computed."""
+    import genjax_amd as G
+    from genjax_amd import workloads
+    from genjax_amd.inference.smc import BootstrapSweep
+    ys = workloads.lgssm_data(T)
+    kal = workloads.kalman_log_ml(ys)
+    init, step = workloads.make_lgssm(G)
+    sw = BootstrapSweep(init, step, N, T, resample=kind)
+    z = np.empty(R)
+    for r in range(R):
+        sw.prepare(G.key(seed0 + r), torch.from_numpy(ys))
+        sw.launch()
+        z[r] = np.exp(sw.log_ml() - kal)
+    se = z.std(ddof=1) / np.sqrt(R)
+    assert abs(z.mean() - 1.0) < 4.0 * se, (kind, z.mean(), se)
+    assert se < 0.05
+    return {"mean": float(z.mean()), "se": float(se)}
+
+
+def check_sampler_laws(n=200_000):
+    """INDEPENDENT of the oracle: the product's samplers against scipy's distributions (Kolmogorov–Smirnov on 20 000
+    draws, moments on all of them; class frequencies by chi-square) — the evidence there is for the streams the
+    reference cannot pin (Gumbel / categorical, Bernoulli, Beta-via-gamma, Dirichlet: DESIGN.md §3)."""
+    from scipy import stats
+    import genjax_amd as G
+    from genjax_amd import numpy as jnp
+    keys = G.split(G.key(77), n)
+    val = lambda d, args: d.simulate(keys, args).get_retval().cpu().numpy()
+    z = val(G.normal, (1.0, 2.0))
+    assert stats.kstest(z[:20000], "norm", args=(1.0, 2.0)).pvalue > 1e-3 and abs(z.mean() - 1.0) < 0.02 and abs(z.std() - 2.0) < 0.02
+    # tails: the erf_inv path far from the centre
+    assert abs((z > 1.0 + 2.0 * 3.0).mean() - stats.norm.sf(3.0)) < 4 * np.sqrt(stats.norm.sf(3.0) / n)
+    u = val(G.uniform, (-1.0, 3.0))
+    assert stats.kstest(u[:20000], "uniform", args=(-1.0, 4.0)).pvalue > 1e-3 and u.min() >= -1.0 and u.max() < 3.0
+    for a, b in ((2.0, 5.0), (0.5, 0.7), (1.0, 1.0), (30.0, 2.0)):
+        x = val(G.beta, (a, b))
+        assert stats.kstest(x[:20000], "beta", args=(a, b)).pvalue > 1e-3, (a, b)
+        assert abs(x.mean() - a / (a + b)) < 5e-3
+    f = val(G.flip, (0.3,))
+    assert abs(f.mean() - 0.3) < 4 * np.sqrt(0.21 / n)
+    bl = val(G.bernoulli, (0.8,))          # logits
+    p = 1.0 / (1.0 + np.exp(-0.8))
+    assert abs(bl.mean() - p) < 4 * np.sqrt(p * (1 - p) / n)
+    probs = np.array([0.4, 0.2, 0.1, 0.1, 0.05, 0.05, 0.05, 0.05])
+    c = val(G.categorical, (jnp.array(np.log(probs).astype(np.float32)),))
+    chi = stats.chisquare(np.bincount(c, minlength=8), probs * n)
+    assert chi.pvalue > 1e-4, chi
+    alpha = np.array([2.0, 3.0, 0.5], np.float32)
+    d = val(G.dirichlet, (jnp.array(alpha),))
+    assert np.allclose(d.sum(-1), 1.0, atol=1e-5)
+    for k_ in range(3):                    # a Dirichlet's marginals are Beta(alpha_k, sum - alpha_k)
+        assert stats.kstest(d[:20000, k_], "beta", args=(alpha[k_], alpha.sum() - alpha[k_])).pvalue > 1e-3, k_
+
+
+def check_offspring_laws(kind, n=256, R=3000):
+    """INDEPENDENT of the oracle: a valid resampling scheme has E[offspring_i] = n w_i; multinomial schemes also have
+    Var[offspring_i] = n w_i (1 - w_i); systematic offspring are less than 1 away from n w_i, stratified less than 2.  R
+    resamplings of ONE weight vector under R keys through the product (smc.resample_fused), against those laws."""
+    import genjax_amd as G
+    from genjax_amd.inference import smc
+    dev = G._lib.get().device
+    rng = np.random.default_rng(3)
+    lw = rng.normal(0, 1.5, n).astype(np.float32)
+    w = np.exp(lw.astype(np.float64) - lw.max())
+    w /= w.sum()
+    lw_d = torch.from_numpy(lw).to(dev)
+    counts = np.zeros((R, n))
+    kid = smc._KINDS[kind]
+    for r in range(R):
+        key = G.key(900 + r)
+        if kid == smc.MULTINOMIAL:
+            cdf, total, mx, shift = smc.weight_cdf(lw_d)
+            anc = smc.ancestors_from_cdf(kid, key, cdf, total)
+        else:
+            anc = smc.resample_fused(kid, key, lw_d)[0]
+        counts[r] = np.bincount(anc.cpu().numpy(), minlength=n)
+    mean = counts.mean(0)
+    se = np.maximum(counts.std(0, ddof=1), 0.05) / np.sqrt(R)
+    assert np.all(np.abs(mean - n * w) < 5.0 * se + 1e-3), (kind, np.max(np.abs(mean - n * w) / se))
+    if kind.startswith("multinomial"):
+        heavy = np.argsort(-w)[:20]
+        var = counts[:, heavy].var(0, ddof=1)
+        want = n * w[heavy] * (1 - w[heavy])
+        assert np.all(np.abs(var - want) < 0.2 * want + 0.05), (kind, var, want)
+    else:
+        # one shared offset: less than 1 away; one uniform per stratum: an interval can gain or lose a point at each end
+        assert np.all(np.abs(counts - n * w) < (1.0 if kind == "systematic" else 2.0) + 1e-6)
+    return {"max_z": float(np.max(np.abs(mean - n * w) / se))}

@@ -1432,3 +1432,19 @@ def test_two_stage_multinomial_on_device(gpu):
     for na in (False, True):
         res = parity.check_lgssm_sweep(n=50_000, T=13, capture=True, specialize=True, resample="multinomial_tiled", noise_ahead=na)
         assert res["ancestors_equal"] and res["x_equal"] and res["totals_equal"] and res["lw_max_abs_diff"] == 0.0
+
+
+@pytest.mark.parametrize("kind", ["systematic", "stratified", "multinomial", "multinomial_tiled"])
+def test_evidence_estimate_is_unbiased_on_device(gpu, kind):
+    """E[Z_hat] = Z (Kalman closed form) over 1500 sweeps of 32 particles on the HIP library: independent of the oracle"""
+    parity.check_evidence_unbiased(kind, R=1500, seed0=5000)
+
+
+def test_sampler_laws_against_scipy_on_device(gpu):
+    """the HIP samplers against scipy's distributions: KS / chi-square / moments, independent of the oracle"""
+    parity.check_sampler_laws(n=400_000)
+
+
+@pytest.mark.parametrize("kind", ["systematic", "stratified", "multinomial", "multinomial_tiled"])
+def test_offspring_laws_on_device(gpu, kind):
+    parity.check_offspring_laws(kind, R=2000)

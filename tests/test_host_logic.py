@@ -1225,3 +1225,23 @@ def test_two_stage_multinomial_matches_oracle(hostsim):
     for na in (False, True):
         res = parity.check_lgssm_sweep(n=3000, T=7, resample="multinomial_tiled", noise_ahead=na)
         assert res["ancestors_equal"] and res["x_equal"] and res["totals_equal"] and res["lw_max_abs_diff"] == 0.0
+
+
+@pytest.mark.parametrize("kind", ["systematic", "stratified", "multinomial", "multinomial_tiled"])
+def test_evidence_estimate_is_unbiased(hostsim, kind):
+    """closed-form evidence of the resampling definitions (Kalman), independent of the oracle"""
+    from tests import parity
+    parity.check_evidence_unbiased(kind, R=2500)
+
+
+def test_sampler_laws_against_scipy(hostsim):
+    """the product's samplers against scipy's distributions (independent of the oracle)"""
+    from tests import parity
+    parity.check_sampler_laws(n=100_000)
+
+
+@pytest.mark.parametrize("kind", ["systematic", "stratified", "multinomial", "multinomial_tiled"])
+def test_offspring_laws(hostsim, kind):
+    """E[offspring_i] = n w_i for every scheme; the multinomial variance; |offspring - n w| < 1 (systematic) / 2 (stratified)"""
+    from tests import parity
+    parity.check_offspring_laws(kind)

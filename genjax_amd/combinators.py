@@ -207,6 +207,20 @@ def _so(tr, origin, T):
     return StepOutput(origin, T, len(tr.outputs[origin[1]][1]))
 
 
+def _has_step_rows(tree):
+    """does a previous-trace tree hold [n, A, T] step leaves (engine.StepInput2: the values of loops INSIDE a plate)?"""
+    from .engine import StepInput2, Sym
+    if isinstance(tree, Sym):
+        tree = tree.value
+    if isinstance(tree, StepInput2):
+        return True
+    if isinstance(tree, dict):
+        return any(_has_step_rows(v) for v in tree.values())
+    if isinstance(tree, (tuple, list)):
+        return any(_has_step_rows(v) for v in tree)
+    return False
+
+
 def _stack(vals):
     from .engine import StepOutput, Sym
     vals = [v.value if isinstance(v, Sym) else v for v in vals]
@@ -394,6 +408,8 @@ class Vmap(GenerativeFunction):
             con_t = _loop_step_constraint(constraint, t, n, _loop_at, what) if constraint is not None else None
             rec, ret, w, s_ = call_gen_fn(ctx, mode, self.gen_fn, k_t, args_t, con_t, None, None, req_leaves, addr)
             score_t = s_ if mode == "assess" else _rec_score(rec)
+            for sub_ in (rec.sites.values() if not isinstance(rec, _SiteRec) else ()):
+                _store_inner_plate_scores(sub_, tr, n, wanted)
             for r in _leaves(rec):
                 val = r.value.value if isinstance(r.value, Sym) else r.value
                 sc = r.score.value if isinstance(r.score, Sym) else r.score
@@ -505,6 +521,8 @@ class Vmap(GenerativeFunction):
                                              _loop_step_constraint(constraint, t, n, _loop_at, what), prev_t,
                                              req if kind == "update" else carry_over, req_leaves, addr)
             score_t = _rec_score(rec)
+            for sub_ in (rec.sites.values() if not isinstance(rec, _SiteRec) else ()):
+                _store_inner_plate_scores(sub_, tr, n, wanted)
             for r in _leaves(rec):
                 val = r.value.value if isinstance(r.value, Sym) else r.value
                 sc = r.score.value if isinstance(r.score, Sym) else r.score
@@ -573,7 +591,9 @@ class Vmap(GenerativeFunction):
             return self._trace_edit_loop(ctx, kind if kind != "empty" else "update", key, args, axes, constraint, None,
                                          req, n, req_leaves, addr, bare_prev=prev)
         inner_prev = prev["vmap"]
-        if n > VMAP_UNROLL_MAX:
+        # a small plate whose ELEMENTS ran a counted loop (its previous values are [n, A, T] step leaves): the edit runs
+        # the plate as a loop around the elements' loops, as a large one does
+        if n > VMAP_UNROLL_MAX or (_has_step_rows(inner_prev) and not ctx.tr.graph.loop_counts):
             return self._trace_edit_loop(ctx, kind if kind != "empty" else "update", key, args, axes, constraint,
                                          inner_prev, req, n, req_leaves, addr)
         g = ctx.tr.graph
@@ -956,6 +976,8 @@ class Scan(GenerativeFunction):
             carry_out, y_t = ret
             score_t = s if mode == "assess" else _rec_score(rec)
             # this step's trace: element t of every site's [T, n] value / score
+            for sub_ in (rec.sites.values() if not isinstance(rec, _SiteRec) else ()):
+                _store_inner_plate_scores(sub_, tr, n, wanted)
             for r in _leaves(rec):
                 val = r.value.value if isinstance(r.value, Sym) else r.value
                 sc = r.score.value if isinstance(r.score, Sym) else r.score
@@ -1229,6 +1251,8 @@ class Scan(GenerativeFunction):
                 raise TypeError("scan: the kernel must return (carry, output)")
             carry_out, y_t = ret
             score_t = _rec_score(rec)
+            for sub_ in (rec.sites.values() if not isinstance(rec, _SiteRec) else ()):
+                _store_inner_plate_scores(sub_, tr, n, wanted)
             for r in _leaves(rec):
                 val = r.value.value if isinstance(r.value, Sym) else r.value
                 sc = r.score.value if isinstance(r.score, Sym) else r.score
@@ -1340,7 +1364,25 @@ def _merge(recs, gen_fn):
     for a in first.sites:
         out.sites[a] = _merge([r.sites[a] for r in recs], first.sites[a].gen_fn)
     out.retval = _stack([r.retval for r in recs])
+    if getattr(first, "plate_score", None) is not None:     # a plate / scan INSIDE the elements: its score per element
+        out.plate_score = _stack([r.plate_score for r in recs])
     return out
+
+
+def _store_inner_plate_scores(rec, tr, n, wanted):
+    """Inside a counted loop: a plate / scan called by this iteration's element keeps its own total score (a register
+    of THIS iteration); as element t of a [T, n] output it becomes the [n, T] per-element score the sub-trace reports."""
+    from .engine import StepOutput, Sym
+    from .static import _CallRec
+    if not isinstance(rec, _CallRec):
+        return
+    ps = getattr(rec, "plate_score", None)
+    if ps is not None and wanted:
+        ps = ps.value if isinstance(ps, Sym) else ps
+        if not isinstance(ps, StepOutput):
+            rec.plate_score = _so(tr, tr.store_step(ps, n), n)
+    for r in rec.sites.values():
+        _store_inner_plate_scores(r, tr, n, wanted)
 
 
 def vmap(*, in_axes=0):

@@ -1220,7 +1220,7 @@ def vmap_update(vm: "Vmap", k, trace: "VmapTrace", constraint: ChoiceMap, args):
     its slice of the constraint; w = sum over the plate."""
     batch = np.asarray(k).shape[:-1]
     a, n = vm._prep(args, batch)
-    new_inner, w, discard = vm.gen_fn.update(split(k, n), trace.inner, constraint, a)
+    new_inner, w, discard = vm.gen_fn.update(split(k, n), trace.inner, vm._plate_chm(constraint, n, batch), a)
     w = np.broadcast_to(np.asarray(w, np.float32), tuple(batch) + (n,))
     return VmapTrace(vm, new_inner, vm._plate_sum(new_inner.get_score(), batch), new_inner.get_retval()), \
         vm._plate_sum(w, batch), discard
@@ -1283,6 +1283,12 @@ def scan_edit_index(sc: "Scan", k, trace: "VmapTrace", args, idx: int, edit):
         score = (score + np.broadcast_to(np.asarray(sl.get_score(), np.float32), batch)).astype(np.float32)
     inner = _stack_last(slices)
     return VmapTrace(sc, inner, score, (slices[-1].get_retval()[0], inner.get_retval()[1])), w
+
+
+# the combinators as CALLEES of an edited static function (`_Update.handle` calls `gen_fn.update`): a plate / a scan
+# inside the function a plate maps (vmap.py:236-275 over scan.py:509-594).  The discard of a nested edit is not restated.
+Vmap.update = lambda self, k, trace, chm, args: vmap_update(self, k, trace, chm, args)
+Scan.update = lambda self, k, trace, chm, args: scan_edit(self, k, trace, args, update=chm) + (ChoiceMap(),)
 
 
 class Repeat(Vmap):

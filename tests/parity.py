@@ -1920,3 +1920,40 @@ def check_offspring_laws(kind, n=256, R=3000):
         # one shared offset: less than 1 away; one uniform per stratum: an interval can gain or lose a point at each end
         assert np.all(np.abs(counts - n * w) < (1.0 if kind == "systematic" else 2.0) + 1e-6)
     return {"max_z": float(np.max(np.abs(mean - n * w) / se))}
+
+
+def check_nested_edits(A, T, n=9):
+    """`Update` through a plate of long scans (vmap.py:236-275 over scan.py:509-594): weights, scores, the new and the
+    untouched choices and the backward request's constraint (the old observations) against the oracle — a small plate
+    (its previous values are [n, A, T] step leaves: the plate runs as a loop around the scans' loops), a mid-size and a
+    large one; the scan sub-trace reports one score per series."""
+    import genjax_amd as G
+    from genjax_amd import ChoiceMapBuilder as C, Diff, Update, numpy as jnp
+    def mk(g, scan_of):
+        @g.gen
+        def step(x, _):
+            xn = g.normal(0.9 * x, 0.5) @ "x"
+            g.normal(xn, 1.0) @ "y"
+            return xn, None
+        @g.gen
+        def series(x0):
+            xT, _ = scan_of(step)(x0, None) @ "steps"
+            return xT
+        return series
+    s, os_ = mk(G, lambda f: f.scan(n=T)), mk(O, lambda f: O.Scan(f, T))
+    x0 = np.linspace(-1, 1, A).astype(np.float32)
+    model, omodel = s.vmap(in_axes=(0,)), O.Vmap(os_, in_axes=(0,))
+    tr = model.simulate(G.split(G.key(1), n), (jnp.array(x0),))
+    otr = omodel.simulate(O.split(O.key(1), n), (x0,))
+    ys = np.random.default_rng(0).normal(size=(A, T)).astype(np.float32)
+    new, w, _, bwd = Update(C["steps", "y"].set(ys)).edit(G.split(G.key(2), n), tr, Diff.no_change((jnp.array(x0),)))
+    onew, ow, _ = O.vmap_update(omodel, O.split(O.key(2), n), otr, O.C.d({("steps", "y"): ys}), (x0,))
+    assert np.array_equal(w.cpu().numpy(), ow), np.abs(w.cpu().numpy() - ow).max()
+    assert np.array_equal(new.get_score().cpu().numpy(), onew.get_score())
+    assert np.array_equal(new.get_choices()["steps", "y"].cpu().numpy(), np.broadcast_to(ys, (n, A, T)))
+    assert np.array_equal(new.get_choices()["steps", "x"].cpu().numpy(), otr.get_choices()["steps", "x"])
+    assert np.array_equal(bwd.constraint["steps", "y"].cpu().numpy(), otr.get_choices()["steps", "y"])
+    # the sub-trace's own score: one per series
+    sub = tr.get_subtrace("steps") if hasattr(tr, "get_subtrace") else None
+    if sub is not None:
+        assert tuple(sub.get_score().shape) == (n, A)

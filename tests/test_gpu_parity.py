@@ -1448,3 +1448,8 @@ def test_sampler_laws_against_scipy_on_device(gpu):
 @pytest.mark.parametrize("kind", ["systematic", "stratified", "multinomial", "multinomial_tiled"])
 def test_offspring_laws_on_device(gpu, kind):
     parity.check_offspring_laws(kind, R=2000)
+
+
+@pytest.mark.parametrize("A,T", [(3, 20), (12, 20), (40, 40)])
+def test_update_through_a_plate_of_long_scans_on_device(gpu, A, T):
+    parity.check_nested_edits(A, T, n=3000)

@@ -1245,3 +1245,9 @@ def test_offspring_laws(hostsim, kind):
     """E[offspring_i] = n w_i for every scheme; the multinomial variance; |offspring - n w| < 1 (systematic) / 2 (stratified)"""
     from tests import parity
     parity.check_offspring_laws(kind)
+
+
+@pytest.mark.parametrize("A,T", [(3, 20), (12, 20), (20, 24)])
+def test_update_through_a_plate_of_long_scans(hostsim, A, T):
+    from tests import parity
+    parity.check_nested_edits(A, T)

@@ -899,6 +899,15 @@ class BootstrapSweep(_NoiseAhead):
     def prepare(self, key: Key, ys: torch.Tensor):
         from ..static import MinimalGenerate as _MG, NoiseProgram
         be = _lib.get()
+        # a sweep object may be prepared again (another key, other observations): nothing bound for the previous run
+        # survives — the background launches' key rows in particular (found by the unbiasedness test on the GPU: a
+        # second prepare() replayed the first run's noise launches)
+        self.__dict__.pop("_noise_run_cache", None)
+        if self.graph is not None:           # a graph captured for the previous run holds its launch arguments
+            if be.uses_streams:
+                torch.cuda.synchronize()
+            be.c.gmx_graph_destroy(self.graph)
+            self.graph = None
         # noise ahead: asked for explicitly, or by default on a device with streams on the fast path (specialised
         # programs; with rejuvenate=, the MH move chained into the extension)
         fuse_mh_ok = os.environ.get("GENMI_FUSE_MH", "1") != "0"

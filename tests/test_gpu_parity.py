@@ -1453,3 +1453,25 @@ def test_offspring_laws_on_device(gpu, kind):
 @pytest.mark.parametrize("A,T", [(3, 20), (12, 20), (40, 40)])
 def test_update_through_a_plate_of_long_scans_on_device(gpu, A, T):
     parity.check_nested_edits(A, T, n=3000)
+
+
+def test_a_sweep_prepared_again_runs_the_new_key(gpu):
+    """BootstrapSweep.prepare() a second time on the same object (found by the unbiasedness test: the noise-ahead form
+    kept the first run's background launches): every re-prepared run equals a fresh sweep's, eager and captured"""
+    import genjax_amd as G
+    from genjax_amd import workloads
+    from genjax_amd.inference.smc import BootstrapSweep
+    T, N = 8, 4096
+    ys = torch.from_numpy(workloads.lgssm_data(T))
+    init, step = workloads.make_lgssm(G)
+    sw = BootstrapSweep(init, step, N, T)
+    for r in range(4):
+        sw.prepare(G.key(70 + r), ys)
+        if r >= 2:
+            sw.capture()
+        sw.launch()
+        fresh = BootstrapSweep(init, step, N, T).prepare(G.key(70 + r), ys)
+        fresh.launch()
+        assert sw.log_ml() == fresh.log_ml()
+        for a, b in zip(sw.state(), fresh.state()):
+            assert torch.equal(a, b)

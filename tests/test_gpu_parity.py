@@ -1475,3 +1475,7 @@ def test_a_sweep_prepared_again_runs_the_new_key(gpu):
         assert sw.log_ml() == fresh.log_ml()
         for a, b in zip(sw.state(), fresh.state()):
             assert torch.equal(a, b)
+
+
+def test_importancek_evidence_is_unbiased_on_device(gpu):
+    parity.check_importance_unbiased(R=20000)

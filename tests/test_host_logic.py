@@ -1251,3 +1251,9 @@ def test_offspring_laws(hostsim, kind):
 def test_update_through_a_plate_of_long_scans(hostsim, A, T):
     from tests import parity
     parity.check_nested_edits(A, T)
+
+
+def test_importancek_evidence_is_unbiased(hostsim):
+    """ImportanceK against a conjugate closed form (independent of the oracle)"""
+    from tests import parity
+    parity.check_importance_unbiased()

@@ -1597,6 +1597,16 @@ def check_plate_of_scans(n=130, no=5, T=40, seed=17):
     s, _ = model.assess(tri.get_choices(), ())
     so, _ = o_model.assess(otri.get_choices(), (), (n,))
     assert np.array_equal(s.cpu().numpy(), so) and np.array_equal(s.cpu().numpy(), tri.get_score().cpu().numpy())
+    # ... and against scipy, which knows nothing of either implementation: the score is the sum of the sites' densities
+    from scipy import stats
+    ch = tr.get_choices()
+    mu = ch["mu"].cpu().numpy().astype(np.float64)
+    x = ch["series", "steps", "x"].cpu().numpy().astype(np.float64)
+    y = ch["series", "steps", "y"].cpu().numpy().astype(np.float64)
+    prev = np.concatenate([(x0s[None, :] + mu[:, None])[:, :, None], x[:, :, :-1]], axis=2)
+    ref = (stats.norm.logpdf(mu, 0.0, 1.0) + stats.norm.logpdf(x, 0.9 * prev, 0.5).sum((1, 2))
+           + stats.norm.logpdf(y, x, sig[None, :, None]).sum((1, 2)))
+    assert np.allclose(tr.get_score().cpu().numpy(), ref, rtol=2e-5, atol=1e-3)
     return {"score_mean": float(tr.get_score().mean())}
 
 

@@ -142,6 +142,11 @@ class ShardedBootstrapSweep(_NoiseAhead):
         self.noise_ahead = False
         self._noise_progs = {}
         self.__dict__.pop("_noise_run_cache", None)
+        if getattr(self, "graph", None) is not None:     # prepared again: the graph captured for the previous run goes
+            if be.uses_streams:
+                torch.cuda.synchronize()
+            be.c.gmx_graph_destroy(self.graph)
+            self.graph = None
 
         def MinimalGenerate(*a):
             return _MG(*a, hoist_noise=bool(want_na))

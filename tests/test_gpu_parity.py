@@ -1479,3 +1479,7 @@ def test_a_sweep_prepared_again_runs_the_new_key(gpu):
 
 def test_importancek_evidence_is_unbiased_on_device(gpu):
     parity.check_importance_unbiased(R=20000)
+
+
+def test_evidence_estimate_is_unbiased_with_mh_moves_on_device(gpu):
+    parity.check_evidence_unbiased("systematic", R=3000, T=6, mh=True, seed0=900000)

@@ -1257,3 +1257,9 @@ def test_importancek_evidence_is_unbiased(hostsim):
     """ImportanceK against a conjugate closed form (independent of the oracle)"""
     from tests import parity
     parity.check_importance_unbiased()
+
+
+def test_evidence_estimate_is_unbiased_with_mh_moves(hostsim):
+    """resample-move SMC: a valid MH move after resampling leaves the evidence estimate unbiased (Kalman closed form)"""
+    from tests import parity
+    parity.check_evidence_unbiased("systematic", R=3000, T=6, mh=True, seed0=900000)

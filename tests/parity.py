@@ -2003,3 +2003,32 @@ def check_importance_unbiased(R=3000, K=16):
     # SIR with K = 16 is biased at O(1 / K); the posterior sd is sqrt(0.2): a loose 0.05 band holds the algebra
     assert abs(mu.mean() - 1.3 / 1.25) < 0.05, mu.mean()
     return {"mean": float(z.mean()), "se": float(se), "post_mean": float(mu.mean())}
+
+
+def check_marginal_density_unbiased(R=3000):
+    """INDEPENDENT of the oracle (GenSP, sp.py:217-254): `Marginal.estimate_logpdf` is an unbiased estimate of the marginal
+    density; for mu ~ N(0, 1), s ~ N(mu, 2), x ~ N(mu + s / 2, 0.5) the marginal of x is N(0, sqrt(3.5)).  R keys in one
+    batched launch set: with an inner `ImportanceK` on the posterior target (its evidence estimate), and without an
+    algorithm (one prior draw's likelihood)."""
+    from scipy import stats
+    import genjax_amd as G
+    from genjax_amd import ChoiceMapBuilder as C, SelectionBuilder as S, Target
+    from genjax_amd.inference.smc import ImportanceK
+    from genjax_amd.inference.sp import Marginal
+
+    @G.gen
+    def model():
+        mu = G.normal(0.0, 1.0) @ "mu"
+        s = G.normal(mu, 2.0) @ "s"
+        return G.normal(mu + 0.5 * s, 0.5) @ "x"
+    keys = G.split(G.key(99), R)
+    want = stats.norm.pdf(0.7, 0.0, np.sqrt(3.5))
+    out = {}
+    for name, mar in (("importancek", Marginal(model, S["x"], algorithm=ImportanceK(Target(model, (), C["x"].set(0.7)), k_particles=8))),
+                      ("prior", Marginal(model, S["x"]))):
+        lp = G.vmap(mar.estimate_logpdf, in_axes=(0, None))(keys, C["x"].set(0.7))
+        z = np.exp(lp.cpu().numpy().astype(np.float64)) / want
+        se = z.std(ddof=1) / np.sqrt(R)
+        assert abs(z.mean() - 1.0) < 4.0 * se and se < 0.05, (name, z.mean(), se)
+        out[name] = (float(z.mean()), float(se))
+    return out

@@ -1483,3 +1483,7 @@ def test_importancek_evidence_is_unbiased_on_device(gpu):
 
 def test_evidence_estimate_is_unbiased_with_mh_moves_on_device(gpu):
     parity.check_evidence_unbiased("systematic", R=3000, T=6, mh=True, seed0=900000)
+
+
+def test_marginal_density_estimates_are_unbiased_on_device(gpu):
+    parity.check_marginal_density_unbiased(R=20000)

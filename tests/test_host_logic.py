@@ -1263,3 +1263,8 @@ def test_evidence_estimate_is_unbiased_with_mh_moves(hostsim):
     """resample-move SMC: a valid MH move after resampling leaves the evidence estimate unbiased (Kalman closed form)"""
     from tests import parity
     parity.check_evidence_unbiased("systematic", R=3000, T=6, mh=True, seed0=900000)
+
+
+def test_marginal_density_estimates_are_unbiased(hostsim):
+    from tests import parity
+    parity.check_marginal_density_unbiased()

@@ -2032,3 +2032,34 @@ def check_marginal_density_unbiased(R=3000):
         assert abs(z.mean() - 1.0) < 4.0 * se and se < 0.05, (name, z.mean(), se)
         out[name] = (float(z.mean()), float(se))
     return out
+
+
+def check_scan_importance_vs_kalman(n=200_000, T=20):
+    """INDEPENDENT of the oracle: importance sampling from the prior is unbiased for the evidence, E[exp(w)] = Z, and the
+    linear-Gaussian state-space model's Z is the Kalman filter's.  The model as ONE generative function whose latent path is
+    a `step.scan(n = T - 1)` (a counted loop in the site program: T - 1 > 16): the mean of exp(w - log Z) over n particles
+    is 1 within 4 standard errors (the weights are heavy-tailed at T = 20: the band is wide, the check is on the loop's
+    weight algebra, key chain and table-fed observations)."""
+    import genjax_amd as G
+    from genjax_amd import ChoiceMapBuilder as C, workloads
+    p = workloads.LGSSM
+    ys = workloads.lgssm_data(T)
+    kal = workloads.kalman_log_ml(ys)
+
+    @G.gen
+    def step(x, _):
+        xn = G.normal(p["a"] * x, p["sx"]) @ "x"
+        G.normal(xn, p["sy"]) @ "y"
+        return xn, None
+
+    @G.gen
+    def ssm():
+        x0 = G.normal(0.0, p["s0"]) @ "x0"
+        G.normal(x0, p["sy"]) @ "y0"
+        xT, _ = step.scan(n=T - 1)(x0, None) @ "steps"
+        return xT
+    _, w = ssm.importance(G.split(G.key(3), n), C["y0"].set(float(ys[0])).set(("steps", "y"), ys[1:]), ())
+    z = np.exp(w.cpu().numpy().astype(np.float64) - kal)
+    se = z.std(ddof=1) / np.sqrt(n)
+    assert abs(z.mean() - 1.0) < 4.0 * se and se < 0.15, (z.mean(), se)
+    return {"mean": float(z.mean()), "se": float(se)}

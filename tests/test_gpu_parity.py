@@ -1487,3 +1487,7 @@ def test_evidence_estimate_is_unbiased_with_mh_moves_on_device(gpu):
 
 def test_marginal_density_estimates_are_unbiased_on_device(gpu):
     parity.check_marginal_density_unbiased(R=20000)
+
+
+def test_long_scan_importance_weights_against_kalman_on_device(gpu):
+    parity.check_scan_importance_vs_kalman(n=2_000_000)

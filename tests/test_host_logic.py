@@ -1268,3 +1268,8 @@ def test_evidence_estimate_is_unbiased_with_mh_moves(hostsim):
 def test_marginal_density_estimates_are_unbiased(hostsim):
     from tests import parity
     parity.check_marginal_density_unbiased()
+
+
+def test_long_scan_importance_weights_against_kalman(hostsim):
+    from tests import parity
+    parity.check_scan_importance_vs_kalman()

@@ -97,11 +97,11 @@ class P2PComm:
         if self.world > 1:
             mine = torch.tensor(list(handle), dtype=torch.uint8)
             gathered = [torch.zeros(64, dtype=torch.uint8) for _ in range(self.world)]
-            if self.device.type == "cuda":
+            if self.device.type == "cuda" and self.dist.get_backend() != "gloo":
                 g_dev = [t.to(self.device) for t in gathered]
                 self.dist.all_gather(g_dev, mine.to(self.device))
                 gathered = [t.cpu() for t in g_dev]
-            else:
+            else:               # (a gloo group on a GPU box: the 64-byte handles travel as host tensors)
                 self.dist.all_gather(gathered, mine)
             for s_, h in enumerate(gathered):
                 if s_ == self.rank:

@@ -54,8 +54,14 @@ def schools_main(out_path, k_per_rank, capacity):
 
 def main(out_path, n_per_rank, T, capacity=None, mh=False, vec=False, vecmh=False):
     dist.init_process_group("gloo")
-    import tests.hostsim as hs
-    hs.install()
+    on_gpu = os.environ.get("GENMI_TEST_ON_GPU") == "1"
+    if on_gpu:
+        # every rank on THE one GPU of the box (tests/test_gpu_parity.py: the peer-mapped exchange between two
+        # processes through IPC handles, on real device memory): the HIP library, no CPU mirror
+        torch.cuda.set_device(0)
+    else:
+        import tests.hostsim as hs
+        hs.install()
     import genjax_amd as G
     from genjax_amd import workloads
     from genjax_amd.inference.sharded import ShardedBootstrapSweep
@@ -82,19 +88,30 @@ def main(out_path, n_per_rank, T, capacity=None, mh=False, vec=False, vecmh=Fals
         ys = workloads.lgssm_data(T)
         init, step = workloads.make_lgssm(G)
         # GENMI_TEST_NOISE_AHEAD=1: the step's draws by background programs keyed by the global particle index
-        na = True if os.environ.get("GENMI_TEST_NOISE_AHEAD") == "1" else None
+        na = True if os.environ.get("GENMI_TEST_NOISE_AHEAD") == "1" else (False if on_gpu else None)
         sw = ShardedBootstrapSweep(init, step, n_per_rank, T, dist, capacity=capacity, noise_ahead=na).prepare(
             G.key(314159), torch.from_numpy(ys))
         assert sw.noise_ahead == bool(na)
     sw.launch()
-    xs = [torch.empty_like(sw.state()) for _ in range(dist.get_world_size())]
-    dist.all_gather(xs, sw.state())
+    sw.finish()
+    if os.environ.get("GENMI_TEST_CAPTURE") == "1":      # the same sweep again as ONE captured graph, replayed twice
+        first = sw.state().clone()
+        sw.capture()
+        for _ in range(2):
+            sw.launch()
+            sw.finish()
+        assert torch.equal(first, sw.state())
+    st = sw.state().cpu()
+    xs = [torch.empty_like(st) for _ in range(dist.get_world_size())]
+    dist.all_gather(xs, st)
     if dist.get_rank() == 0:
         np.save(out_path + ".npy", torch.cat(xs).numpy())
-        json.dump({"log_ml": sw.log_ml(), "totals": [str(t) for t in sw.totals.numpy().view(np.uint64).tolist()],
-                   "maxs": sw.maxs.tolist(), "reruns": sw.reruns, "capacity": sw.capacity,
+        json.dump({"log_ml": sw.log_ml(), "totals": [str(t) for t in sw.totals.cpu().numpy().view(np.uint64).tolist()],
+                   "maxs": sw.maxs.cpu().tolist(), "reruns": sw.reruns, "capacity": sw.capacity,
                    "communicator": sw.cx.name if sw.cx is not None else None},
                   open(out_path + ".json", "w"))
+    if on_gpu and sw.cx is not None:
+        sw.close()
     dist.destroy_process_group()
 
 

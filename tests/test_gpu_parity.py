@@ -1491,3 +1491,30 @@ def test_marginal_density_estimates_are_unbiased_on_device(gpu):
 
 def test_long_scan_importance_weights_against_kalman_on_device(gpu):
     parity.check_scan_importance_vs_kalman(n=2_000_000)
+
+
+@pytest.mark.parametrize("world,na,capture", [(2, "0", "0"), (2, "1", "1"), (4, "1", "1")])
+def test_peer_mapped_exchange_between_two_processes_on_the_device(gpu, tmp_path, world, na, capture):
+    """GENMI_COMM=p2p at WORLD SIZE 2 (and 4) on real device memory: the processes (ranks) share the box's one GPU, map each
+    other's fine-grained landing buffers and flags through IPC handles (gmx_p2p_alloc / gmx_p2p_open) and run the
+    sharded sweep with every collective as ONE gmx_p2p_exchange launch — puts into the peer's memory, release, flag,
+    bounded wait, copy out, device-side epoch.  Bit-exact against the single-process oracle, eagerly and as a captured
+    graph replayed twice, one-stream and noise ahead.  (Same-GPU peers say nothing about xGMI speed: correctness only.)"""
+    import json
+    from genjax_amd import workloads
+    from tests.test_distributed_cpu import _launch
+    n_total, T = 8192, 6
+    out = str(tmp_path / "p2p_gpu")
+    r = _launch(world, [out, str(n_total // world), str(T)],
+                extra_env={"GENMI_COMM": "p2p", "GENMI_TEST_ON_GPU": "1", "GENMI_TEST_NOISE_AHEAD": na,
+                           "GENMI_TEST_CAPTURE": capture, "GENMI_NOISE_GROUP": "3", "GENMI_COMM_TIMEOUT": "60"})
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    x = np.load(out + ".npy")
+    meta = json.load(open(out + ".json"))
+    assert meta["communicator"].startswith("p2p")
+    ys = workloads.lgssm_data(T)
+    oi, ost = workloads.make_lgssm(O)
+    ref = parity.oracle_bootstrap_sweep(oi, ost, n_total, T, ys, O.key(314159))
+    assert [int(t) for t in meta["totals"]] == [h["total"] for h in ref["hist"]]
+    assert meta["log_ml"] == ref["log_ml"]
+    assert np.array_equal(x, ref["x"][ref["anc"]])

@@ -1518,3 +1518,7 @@ def test_peer_mapped_exchange_between_two_processes_on_the_device(gpu, tmp_path,
     assert [int(t) for t in meta["totals"]] == [h["total"] for h in ref["hist"]]
     assert meta["log_ml"] == ref["log_ml"]
     assert np.array_equal(x, ref["x"][ref["anc"]])
+
+
+def test_hmc_move_leaves_the_posterior_invariant_on_device(gpu):
+    parity.check_hmc_invariance(n=1_000_000)

@@ -2102,3 +2102,36 @@ def check_hmc_invariance(n=100_000, L=1):
         assert abs(xv.mean() - pm) < 4 * np.sqrt(pv / n) * 3 and abs(xv.var() - pv) < 4 * pv * np.sqrt(2.0 / n) * 3, out
         assert min(acc) > 0.9, out
     return out
+
+
+def check_edit_weights_against_scipy(n=50_000):
+    """INDEPENDENT of the oracle: the weights of the three move requests on x ~ N(0, 1), y ~ N(x, 0.5), y = 1.3, against
+    scipy — each as the REFERENCE defines it:
+      Regenerate(S["x"])            w = log p(x', y) - log p(x, y): the full density ratio, the prior draw's own density
+                                    NOT divided out (distribution.py:266-277: `incremental_w = w - trace.get_score()`) — so
+                                    `accept iff log U < w` is not the Metropolis-Hastings test for that proposal either;
+      Rejuvenate(q, argmap)         w = log p(x', y) - log p(x, y) + log q(x; argmap(x)) - log q(x'; argmap(x))
+                                    (rejuvenate.py:70-94: the backward proposal scored at the OLD choices);
+      Update(C["x"].set(v))         w = log p(v, y) - log p(x, y)."""
+    from scipy import stats
+    import genjax_amd as G
+    from genjax_amd import ChoiceMapBuilder as C, Diff, Regenerate, Rejuvenate, SelectionBuilder as S, StaticRequest, Update
+
+    @G.gen
+    def model():
+        x = G.normal(0.0, 1.0) @ "x"
+        G.normal(x, 0.5) @ "y"
+    keys = G.split(G.key(1), n)
+    tr, _ = model.importance(keys, C["y"].set(1.3), ())
+    x = tr.get_choices()["x"].cpu().numpy().astype(np.float64)
+    lj = lambda v: stats.norm.logpdf(v, 0.0, 1.0) + stats.norm.logpdf(1.3, v, 0.5)
+    nd = Diff.no_change(())
+    new, w, _, _ = Regenerate(S["x"]).edit(G.split(G.key(2), n), tr, nd)
+    x2 = new.get_choices()["x"].cpu().numpy().astype(np.float64)
+    assert np.allclose(w.cpu().numpy(), lj(x2) - lj(x), rtol=2e-5, atol=2e-5)
+    new, w, _, _ = StaticRequest({"x": Rejuvenate(G.normal, lambda chm: (chm.get_value(), 0.5))}).edit(G.split(G.key(3), n), tr, nd)
+    x3 = new.get_choices()["x"].cpu().numpy().astype(np.float64)
+    want = lj(x3) - lj(x) + stats.norm.logpdf(x, x, 0.5) - stats.norm.logpdf(x3, x, 0.5)
+    assert np.allclose(w.cpu().numpy(), want, rtol=2e-5, atol=2e-5)
+    new, w, _, _ = Update(C["x"].set(0.25)).edit(G.split(G.key(4), n), tr, nd)
+    assert np.allclose(w.cpu().numpy(), lj(0.25) - lj(x), rtol=2e-5, atol=2e-5)

@@ -1522,3 +1522,7 @@ def test_peer_mapped_exchange_between_two_processes_on_the_device(gpu, tmp_path,
 
 def test_hmc_move_leaves_the_posterior_invariant_on_device(gpu):
     parity.check_hmc_invariance(n=1_000_000)
+
+
+def test_edit_request_weights_against_scipy_on_device(gpu):
+    parity.check_edit_weights_against_scipy(n=500_000)

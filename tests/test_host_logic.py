@@ -1280,3 +1280,8 @@ def test_hmc_move_leaves_the_posterior_invariant(hostsim):
     parity.check_hmc_invariance()
     out = parity.check_hmc_invariance(n=50_000, L=5)      # the reference's L > 1 kernel: recorded, not asserted invariant
     assert out["var"] > 0.25
+
+
+def test_edit_request_weights_against_scipy(hostsim):
+    from tests import parity
+    parity.check_edit_weights_against_scipy()

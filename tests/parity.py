@@ -1971,6 +1971,12 @@ def check_nested_edits(A, T, n=9):
     assert np.array_equal(new.get_choices()["steps", "y"].cpu().numpy(), np.broadcast_to(ys, (n, A, T)))
     assert np.array_equal(new.get_choices()["steps", "x"].cpu().numpy(), otr.get_choices()["steps", "x"])
     assert np.array_equal(bwd.constraint["steps", "y"].cpu().numpy(), otr.get_choices()["steps", "y"])
+    # ... and against scipy: an Update of observations changes the score by the observation densities' difference
+    from scipy import stats
+    xo = tr.get_choices()["steps", "x"].cpu().numpy().astype(np.float64)
+    yo = tr.get_choices()["steps", "y"].cpu().numpy().astype(np.float64)
+    want = (stats.norm.logpdf(ys[None], xo, 1.0) - stats.norm.logpdf(yo, xo, 1.0)).sum((1, 2))
+    assert np.allclose(w.cpu().numpy(), want, rtol=2e-5, atol=2e-3)
     # the sub-trace's own score: one per series
     sub = tr.get_subtrace("steps") if hasattr(tr, "get_subtrace") else None
     if sub is not None:

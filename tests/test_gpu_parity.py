@@ -1526,3 +1526,7 @@ def test_hmc_move_leaves_the_posterior_invariant_on_device(gpu):
 
 def test_edit_request_weights_against_scipy_on_device(gpu):
     parity.check_edit_weights_against_scipy(n=500_000)
+
+
+def test_csmc_weights_against_scipy_on_device(gpu):
+    parity.check_csmc_weights_against_scipy(B=200_000)

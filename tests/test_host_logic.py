@@ -1285,3 +1285,8 @@ def test_hmc_move_leaves_the_posterior_invariant(hostsim):
 def test_edit_request_weights_against_scipy(hostsim):
     from tests import parity
     parity.check_edit_weights_against_scipy()
+
+
+def test_csmc_weights_against_scipy(hostsim):
+    from tests import parity
+    parity.check_csmc_weights_against_scipy()

@@ -68,7 +68,8 @@ def stack_traces(trs, tr_one, axis: int = 0):
         b = engine.materialize(b)
         if not isinstance(a, torch.Tensor):
             return a                                   # static argument (same in both traces)
-        b = torch.as_tensor(b, dtype=a.dtype, device=a.device) if not isinstance(b, torch.Tensor) else b.to(a.dtype)
+        # (a retained trace built from HOST tensors joins device-resident particles: same device, same element type)
+        b = torch.as_tensor(b, dtype=a.dtype, device=a.device) if not isinstance(b, torch.Tensor) else b.to(device=a.device, dtype=a.dtype)
         if a.ndim <= axis:
             return a                                   # a launch-uniform leaf (the same in both traces)
         return torch.cat([a, b.reshape(tuple(a.shape[:axis]) + (1,) + tuple(a.shape[axis + 1:]))], dim=axis)

@@ -2170,3 +2170,75 @@ def check_csmc_weights_against_scipy(B=20_000, k=6):
     assert np.allclose(lw[:, -1], stats.norm.logpdf(mus[:, -1], 0.0, 1.0) + stats.norm.logpdf(1.3, mus[:, -1], 0.5), rtol=2e-5, atol=2e-5)
     # the fresh particles are prior draws
     assert stats.kstest(mus[:2000, 0], "norm").pvalue > 1e-3
+
+
+def check_more_closed_forms(n=200_000):
+    """INDEPENDENT of the oracle, four more: (1) the enumerative Gibbs step of BASELINE config 5 (`gibbs_categorical`):
+    n datapoints that all observe the SAME value — their assignments are iid from the closed-form conditional
+    softmax(log pi_k + log N(x; mu_k, 1)): chi-square over K = 8; (2) a `Mask`ed constraint's weight is the constrained
+    density where the flag holds and 0 elsewhere (scipy); (3) `IndexRequest(j, Regenerate)` on a plate: the weight is
+    the regenerated element's density ratio (the reference's Regenerate arithmetic) and only element j moves;
+    (4) `ChangeTarget` from an `ImportanceK` under one observation to the target under another (the same latents): its
+    evidence estimate is unbiased for the NEW target's evidence (conjugate closed form)."""
+    from scipy import stats
+    import genjax_amd as G
+    from genjax_amd import ChoiceMapBuilder as C, Diff, IndexRequest, Mask, Regenerate, SelectionBuilder as S, Target
+    from genjax_amd import numpy as jnp, workloads
+    from genjax_amd.inference import gibbs
+    from genjax_amd.inference.smc import ChangeTarget, ImportanceK
+    dev = G._lib.get().device
+    # (1)
+    K = 8
+    probs = np.array([0.3, 0.2, 0.15, 0.1, 0.1, 0.05, 0.05, 0.05], np.float32)
+    mus = np.linspace(-3.0, 4.0, K).astype(np.float32)
+    gd = workloads.make_mixture(G)
+    xval = 0.8
+    idx = gibbs.gibbs_categorical(G.key(5), gd, (torch.from_numpy(probs).to(dev), torch.from_numpy(mus).to(dev)),
+                                  C["obs"].set(torch.full((n,), xval, dtype=torch.float32, device=dev)), "idx", K)
+    post = probs.astype(np.float64) * stats.norm.pdf(xval, mus.astype(np.float64), 1.0)
+    post /= post.sum()
+    chi = stats.chisquare(np.bincount(idx.cpu().numpy(), minlength=K), post * n)
+    assert chi.pvalue > 1e-4, chi
+    # (2)
+    @G.gen
+    def m2():
+        x = G.normal(0.0, 1.0) @ "x"
+        G.normal(x, 0.5) @ "y"
+    m = 20_000
+    flag = torch.from_numpy(np.random.default_rng(1).random(m) < 0.4).to(dev)
+    tr, w = m2.importance(G.split(G.key(6), m), C["y"].set(Mask(1.3, flag)), ())
+    x = tr.get_choices()["x"].cpu().numpy().astype(np.float64)
+    want = np.where(flag.cpu().numpy(), stats.norm.logpdf(1.3, x, 0.5), 0.0)
+    assert np.allclose(w.cpu().numpy(), want, rtol=2e-5, atol=2e-5)
+    yv = tr.get_choices()["y"].cpu().numpy()
+    assert np.all(yv[flag.cpu().numpy()] == np.float32(1.3)) and not np.any(yv[~flag.cpu().numpy()] == np.float32(1.3))
+    # (3)
+    @G.gen
+    def elem(mu):
+        z = G.normal(mu, 1.0) @ "z"
+        G.normal(z, 0.5) @ "o"
+    P, j = 40, 17
+    locs = np.linspace(-1, 1, P).astype(np.float32)
+    obs = np.linspace(0.5, -0.5, P).astype(np.float32)
+    plate = elem.vmap(in_axes=(0,))
+    args = (jnp.array(locs),)
+    tr3, _ = plate.importance(G.split(G.key(7), m), C["o"].set(obs), args)
+    new, w3, _, _ = IndexRequest(j, Regenerate(S["z"])).edit(G.split(G.key(8), m), tr3, Diff.no_change(args))
+    z0 = tr3.get_choices()["z"].cpu().numpy().astype(np.float64)
+    z1 = new.get_choices()["z"].cpu().numpy().astype(np.float64)
+    assert np.array_equal(np.delete(z0, j, 1), np.delete(z1, j, 1)) and not np.array_equal(z0[:, j], z1[:, j])
+    lj = lambda z: stats.norm.logpdf(z, locs[j], 1.0) + stats.norm.logpdf(obs[j], z, 0.5)
+    assert np.allclose(w3.cpu().numpy(), lj(z1[:, j]) - lj(z0[:, j]), rtol=2e-5, atol=2e-5)
+    # (4)
+    @G.gen
+    def m4():
+        mu = G.normal(0.0, 1.0) @ "mu"
+        G.normal(mu, 0.5) @ "y"
+    R = 4000
+    prior_alg = ImportanceK(Target(m4, (), C["y"].set(0.0)), k_particles=16)     # the same latents under another observation
+    tgt = Target(m4, (), C["y"].set(1.3))
+    keys = G.split(G.key(9), R)
+    logz = G.vmap(lambda k: ChangeTarget(prior_alg, tgt).run_smc(k).get_log_marginal_likelihood_estimate())(keys)
+    zz = np.exp(logz.cpu().numpy().astype(np.float64)) / stats.norm.pdf(1.3, 0.0, np.sqrt(1.25))
+    se = zz.std(ddof=1) / np.sqrt(R)
+    assert abs(zz.mean() - 1.0) < 4 * se and se < 0.05, (zz.mean(), se)

@@ -1530,3 +1530,7 @@ def test_edit_request_weights_against_scipy_on_device(gpu):
 
 def test_csmc_weights_against_scipy_on_device(gpu):
     parity.check_csmc_weights_against_scipy(B=200_000)
+
+
+def test_more_closed_forms_on_device(gpu):
+    parity.check_more_closed_forms(n=1_000_000)

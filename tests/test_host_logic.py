@@ -1290,3 +1290,9 @@ def test_edit_request_weights_against_scipy(hostsim):
 def test_csmc_weights_against_scipy(hostsim):
     from tests import parity
     parity.check_csmc_weights_against_scipy()
+
+
+def test_more_closed_forms(hostsim):
+    """Gibbs assignments, Mask weights, IndexRequest on a plate, ChangeTarget evidence: against closed forms / scipy"""
+    from tests import parity
+    parity.check_more_closed_forms(n=100_000)

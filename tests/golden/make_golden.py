@@ -68,6 +68,9 @@ def main():
             anc = O.ancestors(kind, O.key(99), cdf)
             ent[name] = anc.tolist() if n_ <= 1024 else None
             ent[name + "_sha256"] = h(anc)
+        anc = O.ancestors_multinomial_tiled(O.key(99), cdf)          # the two-stage multinomial (round 3)
+        ent["multinomial_tiled"] = anc.tolist() if n_ <= 1024 else None
+        ent["multinomial_tiled_sha256"] = h(anc)
         if n_ <= 1024:
             ent["lw"] = f(lw)
         res[str(n_)] = ent

@@ -189,6 +189,11 @@ def test_resampling_golden_and_properties():
                 top = np.argsort(w)[-100:]
                 bound = {O.SYSTEMATIC: 1.0, O.STRATIFIED: 2.0}.get(kind, 8 * np.sqrt(n_ * w[top]) + 1)
                 assert np.all(np.abs(cnt[top] - n_ * w[top]) <= bound)
+        anc_t = O.ancestors_multinomial_tiled(O.key(99), cdf)
+        assert hashlib.sha256(anc_t.tobytes()).hexdigest() == g["multinomial_tiled_sha256"]
+        if g["multinomial_tiled"] is not None:
+            assert anc_t.tolist() == g["multinomial_tiled"]
+        assert np.all(np.diff(anc_t // 1024) >= 0)           # ordered by the ancestor's tile
 
 
 def test_systematic_matches_float_definition_small():

@@ -23,6 +23,7 @@ GMX_MAX_UNI = 64
 ABI_VERSION = 4
 KEY_NONE, KEY_ARRAY, KEY_SPLIT, KEY_ROWSPLIT, KEY_BCAST = 0, 1, 2, 3, 4
 RESAMPLE_SYSTEMATIC, RESAMPLE_STRATIFIED, RESAMPLE_MULTINOMIAL, RESAMPLE_MULTINOMIAL_TILED = 0, 1, 2, 3
+RESAMPLE_MULTINOMIAL_SORTED = 4
 
 
 class ResampleIn(Structure):
@@ -134,6 +135,11 @@ class Backend:
         c.gmx_slot_uniforms.argtypes = [c_void_p, c_int, c_int64, c_void_p, c_int, c_void_p]
         c.gmx_resample_tiles_u.argtypes = [c_int, POINTER(c_uint32), c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p,
                                            c_void_p, c_void_p, c_void_p, c_void_p]
+        c.gmx_sorted_uniforms_words.argtypes = [c_int64]
+        c.gmx_sorted_uniforms_words.restype = c_size_t
+        c.gmx_sorted_uniforms.argtypes = [c_void_p, c_int, c_int64, c_void_p, c_int, c_void_p]
+        c.gmx_resample_sorted.argtypes = [POINTER(c_uint32), c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int,
+                                          c_void_p, c_void_p, c_void_p, c_void_p]
         c.gmx_resample_tiles_q.argtypes = [c_int, POINTER(c_uint32), c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p,
                                            c_void_p, c_void_p, c_void_p]
         c.gmx_tile_prefix_words.argtypes = [c_int64]

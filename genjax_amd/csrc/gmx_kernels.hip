@@ -31,6 +31,7 @@
 #include "gmx_block.h"
 #include "gmx_vm.h"
 #include "gmx_resample.h"
+#include "gmx_sorted.h"
 
 // ---------------------------------------------------------------------------
 // errors
@@ -1503,6 +1504,68 @@ k_tile_stats(const float* __restrict__ lw, int64_t n, float scale, float* __rest
 
 // (slots_below_est: csrc/gmx_resample.h)
 
+// ---- GMX_RESAMPLE_MULTINOMIAL_SORTED: "slots below a CDF value" from the order-statistics table (csrc/gmx_sorted.h) ----
+struct sorted_ctx {
+  const uint32_t* slow; const uint32_t* guide; const uint64_t* toff;
+  uint64_t stot; uint32_t sh, mask; double ratio;     // ratio = S_total / total
+};
+__device__ __forceinline__ sorted_ctx sorted_ctx_of(const uint32_t* table, int64_t n, uint64_t total) {
+  const gmx_sorted_layout L = gmx_sorted_layout_of(n);
+  sorted_ctx X;
+  X.slow = table; X.guide = table + L.off_guide;
+  X.toff = reinterpret_cast<const uint64_t*>(table + L.off_toff);
+  X.stot = X.toff[L.tiles];
+  X.sh = table[L.off_sh];
+  X.mask = (1u << X.sh) - 1u;
+  X.ratio = (double)X.stot / (double)(total ? total : 1ull);
+  return X;
+}
+// f(c) = #{ j < n : S_j * total < c * S_total }: with t = c * S_total / total (f64; not within eps of an integer, else
+// the exact predicate decides) slot j is below iff S_j <= floor(t); the guide gives the slots of the buckets below
+// floor(t)'s, the slots of its own bucket (one on average) are compared by their low words.
+__device__ __forceinline__ sb_est sorted_below_est(const sorted_ctx& X, uint64_t c, uint64_t total, int32_t n) {
+  const double cd = __builtin_fma((double)(uint32_t)(c >> 32), 4294967296.0, (double)(uint32_t)c);
+  const double t = cd * X.ratio;
+  const uint64_t tq = (uint64_t)t;
+  const double frac = t - (double)tq;
+  const double eps = __builtin_fma(t, 0x1p-49, 0x1p-40);
+  const uint32_t g = (uint32_t)(tq >> X.sh);
+  uint32_t lo = X.guide[g], hi = X.guide[g + 1];
+  const uint32_t m = (uint32_t)tq & X.mask;
+  hi = hi < (uint32_t)n ? hi : (uint32_t)n;
+  lo = lo < hi ? lo : hi;
+  const uint32_t last = (uint32_t)n - 1u;
+  const uint32_t v0 = X.slow[lo < last ? lo : last], v1 = X.slow[lo + 1u < last ? lo + 1u : last];
+  const bool p0 = lo < hi && (v0 & X.mask) <= m;
+  const bool p1 = p0 && lo + 1u < hi && (v1 & X.mask) <= m;
+  uint32_t k = lo + (p0 ? 1u : 0u) + (p1 ? 1u : 0u);
+  bool more = p1 && k < hi;
+  while (more) {                                   // a bucket with more than two slots below t (~ 3 % of the evaluations)
+    const uint32_t v = X.slow[k];
+    const bool below = (v & X.mask) <= m;
+    k += below ? 1u : 0u;
+    more = below && k < hi;
+  }
+  sb_est r;
+  r.j = (int32_t)k;
+  r.near = (frac < eps) || (frac > 1.0 - eps);
+  if (c == 0ull) { r.j = 0; r.near = false; }
+  if (c >= total) { r.j = n; r.near = false; }
+  return r;
+}
+__device__ __forceinline__ int64_t sorted_below_exact(const sorted_ctx& X, uint64_t c, uint64_t total, int64_t j, int64_t n) {
+  const u128 R = mul64(c, X.stot);
+  j = j < 0 ? 0 : (j > n ? n : j);
+  auto below = [&](int64_t k) {
+    const uint64_t off = X.toff[k >> 10];
+    const uint64_t S = off + (uint64_t)(uint32_t)(X.slow[k] - (uint32_t)off);     // S_k - off < 2^31
+    return gt128(R, mul64(S, total));
+  };
+  while (j > 0 && !below(j - 1)) --j;
+  while (j < n && below(j)) ++j;
+  return j;
+}
+
 // One thread owns 4 consecutive sources (one float4 of log-weights); 256 threads are one tile; a block is RS_TPB
 // consecutive tiles.  RS_TPB = 1.  Every block has to turn ALL tile statistics into its prefix and the total, and
 // with RS_TPB = 4 (1024 threads) that pass is shared by four tiles — measured on MI355X (config 2): the kernel
@@ -1690,15 +1753,22 @@ k_offspring_tile(uint32_t k0, uint32_t k1, uint32_t u0_host, const float* __rest
   int32_t e[CDF_VEC + 1];
   bool near = false;
   uint32_t near_bits = 0;
+  constexpr bool SORTED = (kind == GMX_RESAMPLE_MULTINOMIAL_SORTED);      // `uslot` is the order-statistics table
+  sorted_ctx SX;
+  if constexpr (SORTED) SX = sorted_ctx_of(uslot, n, total);
+  auto below_est = [&](uint64_t c) -> sb_est {
+    if constexpr (SORTED) return sorted_below_est(SX, c, total, n32);
+    else return slots_below_est<kind>(key, u0_host, c, total, n_over_total, eps, n32, uslot);
+  };
 #pragma unroll
   for (int c = 1; c <= CDF_VEC; ++c) {
-    const sb_est r = slots_below_est<kind>(key, u0_host, cv[c], total, n_over_total, eps, n32, uslot);
+    const sb_est r = below_est(cv[c]);
     e[c] = r.j;
     near_bits |= r.near ? (1u << c) : 0u;
   }
   // lower bound of the thread's first source = upper bound of the previous thread's last one; lane 0 evaluates its own
   {
-    const sb_est r = slots_below_est<kind>(key, u0_host, cv[0], total, n_over_total, eps, n32, uslot);
+    const sb_est r = below_est(cv[0]);
     near_bits |= (lane == 0 && r.near) ? 1u : 0u;
     e[0] = (int32_t)wave_shr1_u32((uint32_t)e[CDF_VEC], (uint32_t)r.j);
     if (lane == 0) e[0] = r.j;
@@ -1713,7 +1783,9 @@ k_offspring_tile(uint32_t k0, uint32_t k1, uint32_t u0_host, const float* __rest
       if (near_bits & (1u << c)) {
         const uint64_t cc = c == 0 ? cv[0] : c == 1 ? cv[1] : c == 2 ? cv[2] : c == 3 ? cv[3] : cv[4];
         const int32_t j0 = c == 0 ? e[0] : c == 1 ? e[1] : c == 2 ? e[2] : c == 3 ? e[3] : e[4];
-        const int32_t j = (int32_t)slots_below_exact(kind, key, (uint64_t)u0_host, cc, D, total, (int64_t)j0, n);
+        int32_t j;
+        if constexpr (SORTED) j = (int32_t)sorted_below_exact(SX, cc, total, (int64_t)j0, n);
+        else j = (int32_t)slots_below_exact(kind, key, (uint64_t)u0_host, cc, D, total, (int64_t)j0, n);
         if (c == 0) fixed0 = j; else if (c == 1) e[1] = j; else if (c == 2) e[2] = j; else if (c == 3) e[3] = j; else e[4] = j;
       }
     }
@@ -1820,6 +1892,12 @@ static int launch_offspring_tile(int kind, const uint32_t key[2], const float* l
     else GMX_LAUNCH_OT3(KIND, FQ, 8);                                                                               \
   } while (0)
   if (kind == GMX_RESAMPLE_SYSTEMATIC) { if (q_d) GMX_LAUNCH_OT(GMX_RESAMPLE_SYSTEMATIC, true); else GMX_LAUNCH_OT(GMX_RESAMPLE_SYSTEMATIC, false); }
+  else if (kind == GMX_RESAMPLE_MULTINOMIAL_SORTED) {        // through LDS, from the log-weights, the 977-fold statistics pass
+    if (tiles <= 1 * RS_BLOCK) GMX_LAUNCH_OT4(GMX_RESAMPLE_MULTINOMIAL_SORTED, false, 1, true);
+    else if (tiles <= 2 * RS_BLOCK) GMX_LAUNCH_OT4(GMX_RESAMPLE_MULTINOMIAL_SORTED, false, 2, true);
+    else if (tiles <= 4 * RS_BLOCK) GMX_LAUNCH_OT4(GMX_RESAMPLE_MULTINOMIAL_SORTED, false, 4, true);
+    else GMX_LAUNCH_OT4(GMX_RESAMPLE_MULTINOMIAL_SORTED, false, 8, true);
+  }
   else { if (q_d) GMX_LAUNCH_OT(GMX_RESAMPLE_STRATIFIED, true); else GMX_LAUNCH_OT(GMX_RESAMPLE_STRATIFIED, false); }
 #undef GMX_LAUNCH_OT
 #undef GMX_LAUNCH_OT3
@@ -2267,6 +2345,140 @@ extern "C" int gmx_resample_tiles_u(int kind, const uint32_t key[2], const float
   if ((uintptr_t)lw_d & 15) return gmx_fail("gmx_resample_tiles_u: lw_d must be 16-byte aligned%s");
   return launch_offspring_tile(kind, key, lw_d, nullptr, n, shift, tile_max_d, tile_agg_d, max_d, total_d, ancestors_d, stream,
                                false, u_d);
+}
+
+// ---- multinomial resampling with sorted uniforms (GMX_RESAMPLE_MULTINOMIAL_SORTED; csrc/gmx_sorted.h) ----
+// The order-statistics table of a resampling depends on its key and n only: two launches, meant for the background
+// stream of a sweep (2-D: one grid row per key, `lds_pad` caps the residency like the normals' programs).
+//   k_sorted_exp    workgroup = 1024 slots: E_j, the tile-local inclusive sums (u32: < 2^31), the tile's sum
+//   k_sorted_guide  every workgroup reduces the <= 2048 tile sums to its offset and S_total (the 977-fold pass of
+//                   k_offspring_tile), rewrites its slots as the low words of the GLOBAL sums and fills the guide:
+//                   slot j writes guide[g] = j for the buckets g in (bucket(S_{j-1}), bucket(S_j)] (one on average)
+__global__ void __launch_bounds__(GMX_BLOCK)
+k_sorted_exp(const uint32_t* __restrict__ keys, uint32_t hk0, uint32_t hk1, int64_t n, size_t words, uint32_t* __restrict__ out) {
+  __shared__ uint64_t s_w[GMX_BLOCK / GMX_WAVE];
+  gmx_key key; key.k0 = hk0; key.k1 = hk1;
+  if (keys) {
+    key.k0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)keys[2 * blockIdx.y]);
+    key.k1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)keys[2 * blockIdx.y + 1]);
+  }
+  const gmx_sorted_layout L = gmx_sorted_layout_of(n);
+  uint32_t* row = out + (size_t)blockIdx.y * words;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t j0 = (int64_t)blockIdx.x * GMX_SORTED_TILE + (int64_t)threadIdx.x * 4;
+  uint32_t q[4];
+  uint64_t run = 0;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const uint32_t e = gmx_sorted_exp(key, (uint64_t)(j0 + c));
+    run += (j0 + c < n) ? e : 0u;
+    q[c] = (uint32_t)run;
+  }
+  const uint64_t inc = wave_scan_u64(run);
+  if (lane == 63) s_w[wave] = inc;
+  __syncthreads();
+  uint64_t off = 0, all = 0;
+#pragma unroll
+  for (int w = 0; w < GMX_BLOCK / GMX_WAVE; ++w) { const uint64_t v = s_w[w]; all += v; off += (w < wave) ? v : 0ull; }
+  const uint32_t base = (uint32_t)(off + (inc - run));
+  *reinterpret_cast<uint4*>(row + j0) = make_uint4(base + q[0], base + q[1], base + q[2], base + q[3]);
+  if (threadIdx.x == 0) reinterpret_cast<uint64_t*>(row + L.off_tsum)[blockIdx.x] = all;
+}
+
+__global__ void __launch_bounds__(GMX_BLOCK)
+k_sorted_guide(const uint32_t* __restrict__ keys, uint32_t hk0, uint32_t hk1, int64_t n, size_t words, uint32_t* __restrict__ out) {
+  __shared__ uint64_t s_below[GMX_BLOCK / GMX_WAVE], s_all[GMX_BLOCK / GMX_WAVE];
+  __shared__ uint32_t s_last[GMX_BLOCK];
+  gmx_key key; key.k0 = hk0; key.k1 = hk1;
+  if (keys) {
+    key.k0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)keys[2 * blockIdx.y]);
+    key.k1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)keys[2 * blockIdx.y + 1]);
+  }
+  const gmx_sorted_layout L = gmx_sorted_layout_of(n);
+  uint32_t* row = out + (size_t)blockIdx.y * words;
+  uint32_t* guide = row + L.off_guide;
+  const uint64_t* tsum = reinterpret_cast<const uint64_t*>(row + L.off_tsum);
+  uint64_t* toff = reinterpret_cast<uint64_t*>(row + L.off_toff);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tile = (int)blockIdx.x, tiles = (int)L.tiles;
+  const int64_t j0 = (int64_t)tile * GMX_SORTED_TILE + (int64_t)threadIdx.x * 4;
+  const uint4 loc = *reinterpret_cast<const uint4*>(row + j0);
+  uint64_t below = 0, all = 0;
+  for (int t = (int)threadIdx.x; t < tiles; t += GMX_BLOCK) {
+    const uint64_t v = tsum[t];
+    all += v;
+    below += (t < tile) ? v : 0ull;
+  }
+  below = wave_sum_u64(below);
+  all = wave_sum_u64(all);
+  if (lane == 0) { s_below[wave] = below; s_all[wave] = all; }
+  s_last[threadIdx.x] = loc.w;
+  __syncthreads();
+  below = 0; all = 0;
+#pragma unroll
+  for (int w = 0; w < GMX_BLOCK / GMX_WAVE; ++w) { below += s_below[w]; all += s_all[w]; }
+  const uint64_t stot = all + gmx_sorted_exp(key, (uint64_t)n);
+  const uint32_t sh = gmx_sorted_shift(stot, L.ng);
+  if (threadIdx.x == 0) {
+    toff[tile] = below;
+    if (tile == 0) { toff[tiles] = stot; row[L.off_sh] = sh; }
+  }
+  const uint32_t lv[4] = {loc.x, loc.y, loc.z, loc.w};
+  uint64_t prev = below + (threadIdx.x ? s_last[threadIdx.x - 1] : 0u);       // S_{j0 - 1}
+  uint32_t lowv[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int64_t j = j0 + c;
+    const uint64_t S = below + lv[c];
+    lowv[c] = (j < n) ? (uint32_t)S : 0u;
+    if (j < n) {
+      const int64_t b = (int64_t)(S >> sh);
+      int64_t g = (j == 0) ? 0 : (int64_t)(prev >> sh) + 1;
+      for (; g <= b; ++g) guide[g] = (uint32_t)j;
+      if (j == n - 1) {
+        const int64_t top = (int64_t)(stot >> sh) + 1;
+        for (g = b + 1; g <= top; ++g) guide[g] = (uint32_t)n;
+      }
+    }
+    prev = S;
+  }
+  *reinterpret_cast<uint4*>(row + j0) = make_uint4(lowv[0], lowv[1], lowv[2], lowv[3]);
+}
+
+extern "C" size_t gmx_sorted_uniforms_words(int64_t n) { return n > 0 ? gmx_sorted_layout_of(n).words : 0; }
+
+static int launch_sorted_uniforms(const uint32_t* keys_d, const uint32_t* hkey, int rows, int64_t n, uint32_t* out_d,
+                                  int lds_pad, gmx_stream stream) {
+  const gmx_sorted_layout L = gmx_sorted_layout_of(n);
+  const dim3 grid((unsigned)L.tiles, (unsigned)rows), block(GMX_BLOCK);
+  const uint32_t h0 = hkey ? hkey[0] : 0u, h1 = hkey ? hkey[1] : 0u;
+  hipLaunchKernelGGL(k_sorted_exp, grid, block, (size_t)lds_pad, (hipStream_t)stream, keys_d, h0, h1, n, L.words, out_d);
+  hipLaunchKernelGGL(k_sorted_guide, grid, block, (size_t)lds_pad, (hipStream_t)stream, keys_d, h0, h1, n, L.words, out_d);
+  GMX_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int gmx_sorted_uniforms(const uint32_t* keys_d, int rows, int64_t n, uint32_t* out_d, int lds_pad,
+                                   gmx_stream stream) {
+  if (!keys_d || !out_d) return gmx_fail("gmx_sorted_uniforms: null argument%s");
+  if (rows < 1 || rows > 65535 || n <= 0 || n > (int64_t)RS_MAX_TILES * RS_TILE)
+    return gmx_fail("gmx_sorted_uniforms: rows / n out of range (n <= 2^21)%s");
+  if (lds_pad < 0 || lds_pad > 64 * 1024) return gmx_fail("gmx_sorted_uniforms: lds_pad out of range (<= 64 KB)%s");
+  if ((uintptr_t)out_d & 15) return gmx_fail("gmx_sorted_uniforms: out_d must be 16-byte aligned%s");
+  return launch_sorted_uniforms(keys_d, nullptr, rows, n, out_d, lds_pad, stream);
+}
+
+extern "C" int gmx_resample_sorted(const uint32_t key[2], const float* lw_d, int64_t n, int shift, const float* tile_max_d,
+                                   const uint64_t* tile_agg_d, uint32_t* table_d, int table_ready, float* max_d,
+                                   uint64_t* total_d, int32_t* ancestors_d, gmx_stream stream) {
+  if (resample_shape("gmx_resample_sorted", n, shift)) return 1;
+  if (!key || !lw_d || !tile_max_d || !tile_agg_d || !table_d || !max_d || !total_d || !ancestors_d)
+    return gmx_fail("gmx_resample_sorted: null argument%s");
+  if (((uintptr_t)lw_d & 15) || ((uintptr_t)table_d & 15))
+    return gmx_fail("gmx_resample_sorted: lw_d and table_d must be 16-byte aligned%s");
+  if (!table_ready && launch_sorted_uniforms(nullptr, key, 1, n, table_d, 0, stream)) return 1;
+  return launch_offspring_tile(GMX_RESAMPLE_MULTINOMIAL_SORTED, key, lw_d, nullptr, n, shift, tile_max_d, tile_agg_d, max_d,
+                               total_d, ancestors_d, stream, false, table_d);
 }
 
 extern "C" size_t gmx_tile_prefix_words(int64_t n) { return gmx_tile_prefix_words_(n); }

@@ -413,8 +413,12 @@ SYSTEMATIC, STRATIFIED, MULTINOMIAL = (_lib.RESAMPLE_SYSTEMATIC, _lib.RESAMPLE_S
                                        _lib.RESAMPLE_MULTINOMIAL)
 # two-stage multinomial (gmx_multinomial_tiled): the same offspring law, the output ordered by the ancestor's CDF tile
 MULTINOMIAL_TILED = _lib.RESAMPLE_MULTINOMIAL_TILED
+# multinomial with SORTED uniforms (gmx_resample_sorted): the same offspring law, the output ordered by ancestor — an
+# ordered scheme on the systematic resampler's kernel; its order-statistics table comes from the background stream
+MULTINOMIAL_SORTED = _lib.RESAMPLE_MULTINOMIAL_SORTED
 _KINDS = {"systematic": SYSTEMATIC, "stratified": STRATIFIED, "multinomial": MULTINOMIAL,
-          "multinomial_tiled": MULTINOMIAL_TILED}
+          "multinomial_tiled": MULTINOMIAL_TILED, "multinomial_sorted": MULTINOMIAL_SORTED}
+_TILE_KINDS = (SYSTEMATIC, STRATIFIED, MULTINOMIAL_TILED, MULTINOMIAL_SORTED)      # from log-weights + tile statistics, n <= 2^21
 
 
 def cdf_reference(m) -> float:
@@ -514,7 +518,7 @@ def resample_fused(kind, key: Key, lw: torch.Tensor):
     anc = torch.empty((n,), dtype=torch.int32, device=lw.device)
     total = torch.empty((1,), dtype=torch.int64, device=lw.device)
     mx = torch.empty((1,), dtype=torch.float32, device=lw.device)
-    if int(kind) == MULTINOMIAL_TILED:          # two-stage multinomial: tile statistics, then gmx_multinomial_tiled
+    if int(kind) in (MULTINOMIAL_TILED, MULTINOMIAL_SORTED):     # tile statistics, then the kind's own entry point
         kh = key.host()
         kk = (c_uint32 * 2)(int(kh[0]), int(kh[1]))
         if not (stats is not None and stats[2] == shift and stats[3] == n):
@@ -522,6 +526,11 @@ def resample_fused(kind, key: Key, lw: torch.Tensor):
             stats = (torch.empty((tiles,), dtype=torch.float32, device=lw.device),
                      torch.empty((tiles,), dtype=torch.int64, device=lw.device))
             be.check(be.c.gmx_tile_stats(be.ptr(lw), n, shift, be.ptr(stats[0]), be.ptr(stats[1]), be.stream()), "gmx_tile_stats")
+        if int(kind) == MULTINOMIAL_SORTED:
+            table = torch.empty((int(be.c.gmx_sorted_uniforms_words(n)),), dtype=torch.int32, device=lw.device)
+            be.check(be.c.gmx_resample_sorted(kk, be.ptr(lw), n, shift, be.ptr(stats[0]), be.ptr(stats[1]), be.ptr(table), 0,
+                                              be.ptr(mx), be.ptr(total), be.ptr(anc), be.stream()), "gmx_resample_sorted")
+            return anc, total, mx, shift
         ws = torch.empty(((be.c.gmx_multinomial_tiled_workspace(n) + 3) // 4,), dtype=torch.int32, device=lw.device)
         be.check(be.c.gmx_multinomial_tiled(kk, be.ptr(lw), n, shift, be.ptr(stats[0]), be.ptr(stats[1]), None, be.ptr(mx),
                                             be.ptr(total), be.ptr(anc), be.ptr(ws), -1, be.stream()), "gmx_multinomial_tiled")
@@ -568,10 +577,10 @@ def resample(key: Key, collection: ParticleCollection, kind="systematic", n_out=
         raise NotImplementedError("resample: batched collections")
     kind = _KINDS[kind] if isinstance(kind, str) else int(kind)
     n = lw.numel()
-    if kind in (SYSTEMATIC, STRATIFIED, MULTINOMIAL_TILED) and n_out in (None, n) and 0 < n <= FUSED_RESAMPLE_MAX:
+    if kind in _TILE_KINDS and n_out in (None, n) and 0 < n <= FUSED_RESAMPLE_MAX:
         anc, total, mx, shift = resample_fused(kind, key, lw)        # no CDF in memory (gmx_resample[_tiles])
-    elif kind == MULTINOMIAL_TILED:
-        raise NotImplementedError("resample(kind='multinomial_tiled'): n_out = n <= 2^21 (use 'multinomial')")
+    elif kind in (MULTINOMIAL_TILED, MULTINOMIAL_SORTED):
+        raise NotImplementedError("resample(kind='multinomial_tiled' / 'multinomial_sorted'): n_out = n <= 2^21 (use 'multinomial')")
     else:
         cdf, total, mx, shift = weight_cdf(lw)
         anc = ancestors_from_cdf(kind, key, cdf, total, n_out)
@@ -937,9 +946,11 @@ class BootstrapSweep(_NoiseAhead):
         self.totals = torch.zeros((T,), dtype=torch.int64, device=dev)
         self.shift = cdf_shift(n)
         self.ws = torch.zeros(((be.c.gmx_weight_cdf_workspace(n) + 7) // 8,), dtype=torch.int64, device=dev)
-        self.fused = self.kind in (SYSTEMATIC, STRATIFIED, MULTINOMIAL_TILED) and n <= (512 * 4096)
-        if self.kind == MULTINOMIAL_TILED and not self.fused:
-            raise NotImplementedError("resample='multinomial_tiled': n <= 2^21 per GPU (use 'multinomial')")
+        self.fused = self.kind in _TILE_KINDS and n <= (512 * 4096)
+        if self.kind in (MULTINOMIAL_TILED, MULTINOMIAL_SORTED) and not self.fused:
+            raise NotImplementedError("resample='multinomial_tiled' / 'multinomial_sorted': n <= 2^21 per GPU (use 'multinomial')")
+        self.sorted_ws = torch.zeros((int(be.c.gmx_sorted_uniforms_words(n)),), dtype=torch.int32, device=dev) \
+            if self.kind == MULTINOMIAL_SORTED else None
         self.mnt_ws = torch.zeros(((be.c.gmx_multinomial_tiled_workspace(n) + 3) // 4,), dtype=torch.int32, device=dev) \
             if self.kind == MULTINOMIAL_TILED else None
         self.mn_ws = torch.zeros(((be.c.gmx_multinomial_workspace(n) + 3) // 4,), dtype=torch.int32, device=dev) \
@@ -1078,7 +1089,7 @@ class BootstrapSweep(_NoiseAhead):
         else:
             gatherers = (self.p_mh_init, self.p_mh_step)
         self.fuse = bool(self.tile_stats and self.tile_q is None and os.environ.get("GENMI_FUSE_RESAMPLE", "0") == "1"
-                         and not self.noise_ahead and all(p_.comp.fuses_resample() for p_ in gatherers))
+                         and not self.noise_ahead and self.kind in (SYSTEMATIC, STRATIFIED) and all(p_.comp.fuses_resample() for p_ in gatherers))
         if self.fuse:
             self.lw_pp = [self.lw, torch.zeros_like(self.lw)]
             self.partials_pp = [self.partials, torch.zeros_like(self.partials)]
@@ -1218,12 +1229,14 @@ class BootstrapSweep(_NoiseAhead):
         (gmx_resample_tiles_u): the same ancestors, one Threefry block per slot-edge evaluation less on the chain.
         GENMI_SLOT_UNIFORMS=0: drawn inside the resampler."""
         self.ubuf = None
-        if not (self.noise_ahead and self.kind in (STRATIFIED, MULTINOMIAL_TILED) and self.fused and self.tile_stats
+        if not (self.noise_ahead and self.kind in (STRATIFIED, MULTINOMIAL_TILED, MULTINOMIAL_SORTED) and self.fused and self.tile_stats
                 and self.tile_q is None and self.tile_pref is None and not self.fuse
                 and os.environ.get("GENMI_SLOT_UNIFORMS", "1") != "0"):
             return
         dev = self.zbuf.device
-        self.ubuf = torch.zeros((2, self.noise_group, self.n), dtype=torch.int32, device=dev)
+        # (the sorted multinomial's row is its whole order-statistics table: gmx_sorted_uniforms_words(n) words)
+        row_words = int(_lib.get().c.gmx_sorted_uniforms_words(self.n)) if self.kind == MULTINOMIAL_SORTED else self.n
+        self.ubuf = torch.zeros((2, self.noise_group, row_words), dtype=torch.int32, device=dev)
         self._u_keys = []
         for t0, t1 in self.noise_groups:
             # stratified: the resampling key itself; the two-stage multinomial: its first child (stage 1's key)
@@ -1238,6 +1251,11 @@ class BootstrapSweep(_NoiseAhead):
         be = _lib.get()
         t0, t1 = self.noise_groups[g]
         half, row = self.noise_slot[t0]
+        if self.kind == MULTINOMIAL_SORTED:
+            be.check(be.c.gmx_sorted_uniforms(be.ptr(self._u_keys[g]), t1 - t0, self.n,
+                                              be.ptr(self.ubuf[half, row:row + (t1 - t0)]), self._u_pad, be.stream()),
+                     "gmx_sorted_uniforms")
+            return
         be.check(be.c.gmx_slot_uniforms(be.ptr(self._u_keys[g]), t1 - t0, self.n, be.ptr(self.ubuf[half, row:row + (t1 - t0)]),
                                         self._u_pad, be.stream()), "gmx_slot_uniforms")
 
@@ -1259,6 +1277,20 @@ class BootstrapSweep(_NoiseAhead):
                                                 be.ptr(self.totals[t:t + 1]), be.ptr(self.anc), be.ptr(self.mnt_ws),
                                                 -1 if t == 0 else (t & 1),      # count buffers alternate: one memset per sweep
                                                 be.stream()), "gmx_multinomial_tiled")
+            return
+        if self.kind == MULTINOMIAL_SORTED:
+            w = t % 2
+            if not self.tile_stats:
+                be.check(be.c.gmx_tile_stats(be.ptr(self.lw_pp[w]), self.n, self.shift, be.ptr(self.partials_pp[w]),
+                                             be.ptr(self.tile_agg_pp[w]), be.stream()), "gmx_tile_stats")
+            table, ready = self.sorted_ws, 0
+            if getattr(self, "ubuf", None) is not None:        # drawn ahead on the background stream
+                half, row = self.noise_slot[t]
+                table, ready = self.ubuf[half, row], 1
+            be.check(be.c.gmx_resample_sorted(kk, be.ptr(self.lw_pp[w]), self.n, self.shift, be.ptr(self.partials_pp[w]),
+                                              be.ptr(self.tile_agg_pp[w]), be.ptr(table), ready, be.ptr(self.maxs[t:t + 1]),
+                                              be.ptr(self.totals[t:t + 1]), be.ptr(self.anc), be.stream()),
+                     "gmx_resample_sorted")
             return
         if getattr(self, "ubuf", None) is not None:
             w = t % 2

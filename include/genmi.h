@@ -245,7 +245,8 @@ int gmx_logsumexp(const float* lw_d, int64_t rows, int64_t cols, float* out_d,
  * gmx_categorical_rows: one Gumbel-max index per row (sample_particle).
  * ---------------------------------------------------------------------- */
 enum { GMX_RESAMPLE_SYSTEMATIC = 0, GMX_RESAMPLE_STRATIFIED = 1, GMX_RESAMPLE_MULTINOMIAL = 2,
-       GMX_RESAMPLE_MULTINOMIAL_TILED = 3 /* gmx_multinomial_tiled only */ };
+       GMX_RESAMPLE_MULTINOMIAL_TILED = 3 /* gmx_multinomial_tiled only */,
+       GMX_RESAMPLE_MULTINOMIAL_SORTED = 4 /* gmx_resample_sorted only */ };
 
 /* *max_d = max of the n block maxima a program's OP_REDMAX wrote (plane 0 of red_out_d). */
 int gmx_reduce_max(const float* partials_d, int64_t n, float* max_d, gmx_stream stream);
@@ -332,6 +333,24 @@ int gmx_slot_uniforms(const uint32_t* keys_d /* [rows,2] */, int rows, int64_t n
 int gmx_resample_tiles_u(int kind, const uint32_t key[2], const float* lw_d, int64_t n, int shift,
                          const float* tile_max_d, const uint64_t* tile_agg_d, const uint32_t* u_d /* [n] */,
                          float* max_d, uint64_t* total_d, int32_t* ancestors_d, gmx_stream stream);
+/* Multinomial resampling with SORTED uniforms (GMX_RESAMPLE_MULTINOMIAL_SORTED; build-defined, SURVEY App. B;
+ * csrc/gmx_sorted.h): n sorted iid uniforms are the normalised partial sums of n + 1 unit exponentials, so
+ *   E_j = 1 + trunc(-log(u_j) * 2^16),  u_j = ((bits32(key, j) >> 9) + 0.5) * 2^-23,  j = 0 .. n
+ *   S_j = E_0 + ... + E_j (j < n),  S_total = S_{n-1} + E_n
+ *   ancestor(j) = first i with cdf_i * S_total > S_j * total                               (128-bit integers)
+ * gives Multinomial(n, w) offspring counts with the output ordered by ancestor — an ordered scheme like systematic /
+ * stratified: it runs on the same kernel (no CDF array, no search, no random cache lines) and the gather behind it
+ * streams.  The order-statistics table (low words of S_j, a guide over buckets of S, tile offsets; layout in
+ * csrc/gmx_sorted.h) depends on the key and n only: gmx_sorted_uniforms writes it for `rows` keys (device array
+ * [rows, 2]; out_d: rows x gmx_sorted_uniforms_words(n) uint32, 16-byte aligned) in two 2-D launches meant for a
+ * background stream (`lds_pad` as for gmx_slot_uniforms).  gmx_resample_sorted: log-weights + tile statistics +
+ * table -> ancestors; table_ready = 0: the table is built here first (table_d is then the scratch for it).  n <= 2^21. */
+size_t gmx_sorted_uniforms_words(int64_t n);
+int gmx_sorted_uniforms(const uint32_t* keys_d /* [rows,2] */, int rows, int64_t n, uint32_t* out_d, int lds_pad,
+                        gmx_stream stream);
+int gmx_resample_sorted(const uint32_t key[2], const float* lw_d, int64_t n, int shift, const float* tile_max_d,
+                        const uint64_t* tile_agg_d, uint32_t* table_d, int table_ready, float* max_d,
+                        uint64_t* total_d, int32_t* ancestors_d, gmx_stream stream);
 int gmx_gather(const void* const* src_d, void* const* dst_d, const int32_t* elem_bytes,
                int32_t n_leaves, const int32_t* ancestors_d, int64_t n_out,
                gmx_stream stream);

@@ -1820,6 +1820,80 @@ def ancestors_multinomial_tiled(k, cdf):
     return out
 
 
+MULTINOMIAL_SORTED = 4
+
+
+def sorted_exponentials(k, count):
+    """E_j = 1 + trunc(-log(u_j) * 2^16), u_j = ((bits32(k, j) >> 9) + 0.5) * 2^-23 (f32; orc_core.c::orc_sorted_exp)"""
+    out = np.empty(count, dtype=np.uint32)
+    kk = np.ascontiguousarray(np.asarray(k, np.uint32).reshape(2))
+    lib().orc_sorted_exp(I64(count), _p(kk), _p(out))
+    return out
+
+
+def ancestors_multinomial_sorted(k, cdf):
+    """BUILD-DEFINED multinomial resampling with SORTED uniforms (include/genmi.h, gmx_resample_sorted; no reference
+    counterpart: SURVEY App. B).  n sorted iid uniforms are distributed as the normalised partial sums of n + 1 unit
+    exponentials, U_(j) = S_j / S_total, so offspring counts are Multinomial(n, w) and the output is ordered by
+    ancestor (what systematic / stratified give), which lets the resampler run without a CDF array or a search:
+      E_j = 1 + trunc(-log(u_j) * 2^16),  u_j = ((bits32(k, j) >> 9) + 0.5) * 2^-23,   j = 0 .. n
+      S_j = E_0 + ... + E_j (j < n),  S_total = S_{n-1} + E_n
+      ancestor(j) = first i with cdf_i * S_total > S_j * total          (integers; Python ints here)
+    No mass at all: every slot maps to the last particle."""
+    cdf = np.asarray(cdf, dtype=np.uint64)
+    n = cdf.size
+    total = int(cdf[-1])
+    if total == 0:
+        return np.full(n, n - 1, dtype=np.int32)
+    E = sorted_exponentials(k, n + 1).astype(np.uint64)
+    S = np.cumsum(E, dtype=np.uint64)
+    stot = int(S[n])
+    # c * stot > P  <=>  c > floor(P / stot)
+    thr = np.array((S[:n].astype(object) * total) // stot, dtype=np.uint64)
+    idx = np.searchsorted(cdf, thr, side="right")
+    return np.minimum(idx, n - 1).astype(np.int32)
+
+
+def ancestors_multinomial_sorted_c(k, cdf):
+    """orc_ancestors_sorted: the same definition as a merge with unsigned __int128 (large populations)"""
+    cdf = np.ascontiguousarray(cdf, dtype=np.uint64)
+    out = np.empty(cdf.size, dtype=np.int32)
+    kk = np.ascontiguousarray(np.asarray(k, np.uint32).reshape(2))
+    lib().orc_ancestors_sorted(_p(kk), _p(cdf), I64(cdf.size), _p(out))
+    return out
+
+
+def sorted_uniforms_table(k, n):
+    """The order-statistics table gmx_sorted_uniforms writes for one resampling key (csrc/gmx_sorted.h), from its
+    definition: the low words of S_j, the guide over buckets of 2^sh, the tile offsets, S_total and sh."""
+    E = sorted_exponentials(k, n + 1).astype(np.uint64)
+    S = np.cumsum(E, dtype=np.uint64)
+    stot = int(S[n])
+    S = S[:n]
+    tiles = (n + 1023) // 1024
+    ng = n + (n >> 1) + 1024
+    sh = 0
+    while (stot >> sh) > ng - 2:
+        sh += 1
+    gmax = (stot >> sh) + 1
+    guide = np.searchsorted(S >> np.uint64(sh), np.arange(gmax + 1, dtype=np.uint64), side="left").astype(np.uint32)
+    toff = np.zeros(tiles + 1, dtype=np.uint64)
+    for t in range(1, tiles):
+        toff[t] = S[t * 1024 - 1]
+    toff[tiles] = stot
+    return dict(slow=(S & np.uint64(0xffffffff)).astype(np.uint32), guide=guide, toff=toff, stot=stot, sh=sh,
+                tiles=tiles, ng=ng)
+
+
+def ancestors_of_kind(kind, k, cdf):
+    """one resampling of the whole population by any of the five definitions"""
+    if kind == MULTINOMIAL_TILED:
+        return ancestors_multinomial_tiled(k, cdf)
+    if kind == MULTINOMIAL_SORTED:
+        return ancestors_multinomial_sorted(k, cdf) if np.asarray(cdf).size <= 4096 else ancestors_multinomial_sorted_c(k, cdf)
+    return ancestors(kind, k, cdf)
+
+
 def log_ml_increment(M, total, shift, n):
     """log( (1/n) sum_i exp(lw_i) ) from the integer total, evaluated in f64 on
     the host: ref + log(total * 2^-shift) - log(n), ref = cdf_reference(M) = ceil(M / ln 2) * ln 2 (the

@@ -595,6 +595,33 @@ void orc_ancestors(int kind, const uint32_t* key, const uint64_t* cdf, int64_t n
   }
 }
 
+/* Multinomial resampling with SORTED uniforms (include/genmi.h, GMX_RESAMPLE_MULTINOMIAL_SORTED; csrc/gmx_sorted.h):
+ *   E_j = 1 + trunc(-log(u_j) * 2^16), u_j = ((bits32(key, j) >> 9) + 0.5) * 2^-23, j = 0 .. n;
+ *   S_j = E_0 + .. + E_j, S_total = S_{n-1} + E_n;  ancestor(j) = first i with cdf_i * S_total > S_j * total. */
+static uint32_t sorted_e(const uint32_t* key, uint64_t j) {
+  float u = ((float)(bits32_1(key, j) >> 9) + 0.5f) * 1.1920928955078125e-07f;   /* (0, 1), exact */
+  float e = -orc_logf(u);
+  return 1u + (uint32_t)(e * 65536.0f);
+}
+void orc_sorted_exp(int64_t count, const uint32_t* key, uint32_t* out) {
+  for (int64_t j = 0; j < count; ++j) out[j] = sorted_e(key, (uint64_t)j);
+}
+void orc_ancestors_sorted(const uint32_t* key, const uint64_t* cdf, int64_t n, int32_t* out) {
+  typedef unsigned __int128 u128;
+  uint64_t total = cdf[n - 1];
+  if (total == 0) { for (int64_t j = 0; j < n; ++j) out[j] = (int32_t)(n - 1); return; }
+  uint64_t stot = 0;
+  for (int64_t j = 0; j <= n; ++j) stot += sorted_e(key, (uint64_t)j);
+  uint64_t s = 0;
+  int64_t i = 0;
+  for (int64_t j = 0; j < n; ++j) {
+    s += sorted_e(key, (uint64_t)j);
+    u128 P = (u128)s * (u128)total;
+    while (i < n - 1 && !((u128)cdf[i] * (u128)stot > P)) ++i;     /* thresholds increase with j: a merge */
+    out[j] = (int32_t)i;
+  }
+}
+
 /* MH accept: log(uniform(key)) < log_alpha */
 void orc_mh_accept(int64_t n, const uint32_t* keys, int64_t ks, const float* log_alpha, uint8_t* out) {
   for (int64_t i = 0; i < n; ++i) {

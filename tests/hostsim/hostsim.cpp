@@ -442,6 +442,97 @@ extern "C" int gmx_resample_tiles_u(int kind, const uint32_t key[2], const float
     if (u[j] != (gmx_bits32(k, (uint64_t)j) >> 9)) return fail("resample_tiles_u: u_d is not this key's slot uniforms");
   return gmx_resample_tiles(kind, key, lw, n, shift, tmax, agg, max_d, total, anc, st);
 }
+// multinomial resampling with sorted uniforms (csrc/gmx_sorted.h): the table from its definition, sequentially; the
+// resampler rebuilds the CDF and merges it with the sums read back from the TABLE (so a wrong table gives wrong ancestors),
+// after checking the table against the key when it was handed one
+#include "../../genjax_amd/csrc/gmx_sorted.h"
+extern "C" size_t gmx_sorted_uniforms_words(int64_t n) { return n > 0 ? gmx_sorted_layout_of(n).words : 0; }
+static void hs_sorted_row(gmx_key k, int64_t n, uint32_t* row) {
+  const gmx_sorted_layout L = gmx_sorted_layout_of(n);
+  uint64_t* tsum = (uint64_t*)(row + L.off_tsum);
+  uint64_t* toff = (uint64_t*)(row + L.off_toff);
+  std::vector<uint64_t> S((size_t)n);
+  uint64_t run = 0;
+  for (int64_t t = 0; t < L.tiles; ++t) tsum[t] = 0;
+  for (int64_t j = 0; j < n; ++j) {
+    if (j % GMX_SORTED_TILE == 0) toff[j / GMX_SORTED_TILE] = run;
+    const uint32_t e = gmx_sorted_exp(k, (uint64_t)j);
+    run += e; tsum[j / GMX_SORTED_TILE] += e;
+    S[(size_t)j] = run;
+    row[j] = (uint32_t)run;
+  }
+  for (int64_t j = n; j < L.tiles * GMX_SORTED_TILE; ++j) row[j] = 0;
+  const uint64_t stot = run + gmx_sorted_exp(k, (uint64_t)n);
+  toff[L.tiles] = stot;
+  const uint32_t sh = gmx_sorted_shift(stot, L.ng);
+  row[L.off_sh] = sh;
+  uint32_t* guide = row + L.off_guide;
+  int64_t j = 0;
+  for (int64_t g = 0; g <= (int64_t)(stot >> sh) + 1; ++g) {        // guide[g] = #{ j : (S_j >> sh) < g }
+    while (j < n && (int64_t)(S[(size_t)j] >> sh) < g) ++j;
+    guide[g] = (uint32_t)j;
+  }
+}
+extern "C" int gmx_sorted_uniforms(const uint32_t* keys, int rows, int64_t n, uint32_t* out, int lds_pad, gmx_stream) {
+  if (!keys || !out || rows < 1 || n <= 0 || n > 2048 * HS_TILE || lds_pad < 0) return fail("sorted_uniforms: bad argument");
+  const size_t words = gmx_sorted_layout_of(n).words;
+  for (int r = 0; r < rows; ++r) {
+    gmx_key k; k.k0 = keys[2 * r]; k.k1 = keys[2 * r + 1];
+    hs_sorted_row(k, n, out + (size_t)r * words);
+  }
+  return 0;
+}
+extern "C" int gmx_resample_sorted(const uint32_t key[2], const float* lw, int64_t n, int shift, const float* tmax,
+                                   const uint64_t* agg, uint32_t* table, int table_ready, float* max_d, uint64_t* total,
+                                   int32_t* anc, gmx_stream) {
+  if (!key || !lw || !tmax || !agg || !table || !max_d || !total || !anc || n <= 0 || n > 2048 * HS_TILE)
+    return fail("resample_sorted: bad argument");
+  gmx_key k; k.k0 = key[0]; k.k1 = key[1];
+  const gmx_sorted_layout L = gmx_sorted_layout_of(n);
+  if (table_ready) {
+    std::vector<uint32_t> want(L.words, 0u);
+    hs_sorted_row(k, n, want.data());
+    const uint64_t stot = ((const uint64_t*)(want.data() + L.off_toff))[L.tiles];
+    const size_t gtop = (size_t)(stot >> want[L.off_sh]) + 1;
+    if (memcmp(want.data(), table, (size_t)L.tiles * GMX_SORTED_TILE * 4) ||
+        memcmp(want.data() + L.off_guide, table + L.off_guide, (gtop + 1) * 4) ||
+        memcmp(want.data() + L.off_toff, table + L.off_toff, ((size_t)L.tiles + 1) * 8) || want[L.off_sh] != table[L.off_sh])
+      return fail("resample_sorted: table_d is not this key's order-statistics table");
+  } else {
+    hs_sorted_row(k, n, table);
+  }
+  const int64_t tiles = (n + HS_TILE - 1) / HS_TILE;
+  float M = -gmx_inf();
+  for (int64_t b = 0; b < tiles; ++b) M = gmx_rmax(M, tmax[b]);
+  const float scale = gmx_pow2i(shift);
+  const int32_t K = gmx_tile_exp(M);
+  std::vector<uint64_t> cdf((size_t)n);
+  uint64_t prefix = 0;
+  for (int64_t b = 0; b < tiles; ++b) {
+    const int64_t lo = b * HS_TILE, hi = lo + HS_TILE < n ? lo + HS_TILE : n;
+    const int32_t kb = gmx_tile_exp(tmax[b]);
+    const float ref = gmx_tile_ref(kb);
+    uint64_t run = 0;
+    for (int64_t i = lo; i < hi; ++i) {
+      run += hs_weight_fixed(lw[i], ref, scale);
+      cdf[(size_t)i] = prefix + gmx_tile_scale(run, kb, K);
+    }
+    prefix += gmx_tile_scale(agg[b], kb, K);
+  }
+  *max_d = M; *total = prefix;
+  if (prefix == 0) { for (int64_t j = 0; j < n; ++j) anc[j] = (int32_t)(n - 1); return 0; }
+  const uint64_t* toff = (const uint64_t*)(table + L.off_toff);
+  const uint64_t stot = toff[L.tiles];
+  int64_t i = 0;
+  for (int64_t j = 0; j < n; ++j) {
+    const uint64_t off = toff[j / GMX_SORTED_TILE];
+    const uint64_t S = off + (uint64_t)(uint32_t)(table[j] - (uint32_t)off);
+    const u128 P = (u128)S * (u128)prefix;
+    while (i < n - 1 && !((u128)cdf[(size_t)i] * (u128)stot > P)) ++i;
+    anc[j] = (int32_t)i;
+  }
+  return 0;
+}
 // the same from the per-particle fixed-point weights the site program left behind
 extern "C" int gmx_resample_tiles_q(int kind, const uint32_t key[2], const uint32_t* q, int64_t n, int shift, const float* tmax,
                                     const uint64_t* agg, float* max_d, uint64_t* total, int32_t* anc, gmx_stream st) {

@@ -28,7 +28,7 @@ def oracle_bootstrap_sweep(init, step, n, T, ys, run_key, kind=O.SYSTEMATIC, ste
         x = np.asarray(tr.get_retval(), np.float32)
         lw = np.asarray(w, np.float32)
         cdf, total, M, shift = O.weight_cdf(lw)
-        anc = O.ancestors_multinomial_tiled(k_res, cdf) if kind == O.MULTINOMIAL_TILED else O.ancestors(kind, k_res, cdf)
+        anc = O.ancestors_of_kind(kind, k_res, cdf)
         log_ml += O.log_ml_increment(M, total, shift, n)
         hist.append(dict(x=x, lw=lw, cdf=cdf, total=total, M=M, anc=anc))
     return dict(log_ml=log_ml, x=x, lw=lw, anc=anc, hist=hist)
@@ -55,7 +55,8 @@ def check_lgssm_sweep(n=4096, T=5, seed=314159, capture=False, specialize=True, 
     oi, os_ = workloads.make_lgssm(O)
     ref = oracle_bootstrap_sweep(oi, os_, n, T, ys, O.key(seed),
                                  kind={"systematic": O.SYSTEMATIC, "stratified": O.STRATIFIED,
-                                       "multinomial_tiled": O.MULTINOMIAL_TILED}[resample])
+                                       "multinomial_tiled": O.MULTINOMIAL_TILED,
+                                       "multinomial_sorted": O.MULTINOMIAL_SORTED}[resample])
     return dict(
         log_ml=log_ml, log_ml_oracle=ref["log_ml"], kalman=workloads.kalman_log_ml(ys),
         ancestors_equal=bool(np.array_equal(anc.cpu().numpy(), ref["anc"])),
@@ -1772,6 +1773,63 @@ def check_multinomial_tiled(n=5000, seed=5, sigma=2.0, dead=False, spike=0.0):
         if not dead:
             assert float(mx.item()) == M
     return {"distinct": int(np.unique(want).size)}
+
+
+def check_multinomial_sorted(n=5000, seed=5, sigma=2.0, dead=False, spike=0.0, rows=1):
+    """gmx_resample_sorted (multinomial resampling with sorted uniforms on the ordered resampler's kernel) against the
+    oracle's definition, directly through the C-ABI: ragged n, skewed weights, one particle with almost all the mass, no
+    mass at all; the order-statistics table built inside the call, and handed over from gmx_sorted_uniforms (several
+    keys in one 2-D launch) — whose words are checked against the oracle's statement of the table."""
+    from ctypes import c_uint32
+    from genjax_amd import _lib
+    be = _lib.get()
+    dev = be.device
+    rng = np.random.default_rng(seed)
+    lw = rng.normal(0, sigma, n).astype(np.float32)
+    if spike:
+        lw[n // 3] += np.float32(spike)
+    if dead:
+        lw[:] = -np.inf
+    T_ = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    lw_d = T_(lw)
+    cdf, total, M, shift = O.weight_cdf(lw)
+    tiles = (n + 1023) // 1024
+    tmax = torch.zeros((tiles,), dtype=torch.float32, device=dev)
+    agg = torch.zeros((tiles,), dtype=torch.int64, device=dev)
+    be.check(be.c.gmx_tile_stats(be.ptr(lw_d), n, shift, be.ptr(tmax), be.ptr(agg), be.stream()), "gmx_tile_stats")
+    words = int(be.c.gmx_sorted_uniforms_words(n))
+    ks = [O.key(seed + 1 + r) for r in range(rows)]
+    keys = T_(np.stack([np.asarray(k, np.uint32) for k in ks]).view(np.int32))
+    tables = torch.full((rows, words), -1, dtype=torch.int32, device=dev)
+    be.check(be.c.gmx_sorted_uniforms(be.ptr(keys), rows, n, be.ptr(tables), 0, be.stream()), "gmx_sorted_uniforms")
+    out = {}
+    for r, k in enumerate(ks):
+        want = O.ancestors_of_kind(O.MULTINOMIAL_SORTED, k, cdf)
+        assert np.all(np.diff(want) >= 0)
+        # the table, word for word where it is defined
+        t = O.sorted_uniforms_table(k, n)
+        got_t = tables[r].cpu().numpy().view(np.uint32)
+        og = t["tiles"] * 1024
+        assert np.array_equal(got_t[:n], t["slow"]) and not got_t[n:og].any()
+        assert np.array_equal(got_t[og:og + t["guide"].size], t["guide"])
+        ng2 = (t["ng"] + 2 + 3) & ~3
+        toff = got_t[og + ng2 + 2 * t["tiles"]: og + ng2 + 2 * t["tiles"] + 2 * (t["tiles"] + 1)].view(np.uint64)
+        assert np.array_equal(toff, t["toff"]) and int(got_t[og + ng2 + 4 * t["tiles"] + 2]) == t["sh"]
+        kk = (c_uint32 * 2)(int(k[0]), int(k[1]))
+        scratch = torch.full((words,), -1, dtype=torch.int32, device=dev)
+        for table, ready in ((scratch, 0), (tables[r], 1)):
+            mx = torch.zeros((1,), dtype=torch.float32, device=dev)
+            tot = torch.zeros((1,), dtype=torch.int64, device=dev)
+            anc = torch.full((n,), -1, dtype=torch.int32, device=dev)
+            be.check(be.c.gmx_resample_sorted(kk, be.ptr(lw_d), n, shift, be.ptr(tmax), be.ptr(agg), be.ptr(table), ready,
+                                              be.ptr(mx), be.ptr(tot), be.ptr(anc), be.stream()), "gmx_resample_sorted")
+            got = anc.cpu().numpy()
+            assert np.array_equal(got, want), (r, ready, int((got != want).sum()))
+            assert int(tot.item()) & 0xFFFFFFFFFFFFFFFF == total
+            if not dead:
+                assert float(mx.item()) == M
+        out = {"distinct": int(np.unique(want).size), "sh": t["sh"]}
+    return out
 
 
 def check_nested_edge_cases():

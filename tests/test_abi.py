@@ -116,6 +116,8 @@ def test_entry_points_reject_null_arguments_before_any_launch():
         "gmx_multinomial_tiled": (N, N, i64(10), i32(40), N, N, N, N, N, N, N, i32(-1), N),
         "gmx_slot_uniforms": (N, i32(1), i64(10), N, i32(0), N),
         "gmx_resample_tiles_u": (i32(1), N, N, i64(10), i32(40), N, N, N, N, N, N, N),
+        "gmx_sorted_uniforms": (N, i32(1), i64(10), N, i32(0), N),
+        "gmx_resample_sorted": (N, N, i64(10), i32(40), N, N, N, i32(0), N, N, N, N),
         "gmx_shard_totals": (N, i32(2), i64(1024), N, N, N),
         "gmx_shard_step_tiles": (i32(0), N, N, N, N, N, N, N, i32(40), i32(0), i32(2), i64(1024), i64(4), N, N, N, N),
         "gmx_shard_step_fused": (i32(0), N, N, N, N, N, N, i32(40), i32(0), i32(2), i64(1024), i64(4), N, N, N, N),

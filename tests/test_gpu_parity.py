@@ -1434,7 +1434,21 @@ def test_two_stage_multinomial_on_device(gpu):
         assert res["ancestors_equal"] and res["x_equal"] and res["totals_equal"] and res["lw_max_abs_diff"] == 0.0
 
 
-@pytest.mark.parametrize("kind", ["systematic", "stratified", "multinomial", "multinomial_tiled"])
+def test_sorted_multinomial_on_device(gpu):
+    """gmx_sorted_uniforms (k_sorted_exp + k_sorted_guide) word for word against the oracle's statement of the table, and
+    gmx_resample_sorted (k_offspring_tile on the order-statistics table) == the oracle's definition: ragged / one-tile /
+    one- and two-particle sizes, a spike that owns almost every slot, no mass at all, 1e6 and 2^21 particles; whole sweeps
+    resampled with it (one stream, and noise ahead with the tables from the background stream), captured"""
+    for kw in (dict(n=5000, rows=3), dict(n=1024, seed=6), dict(n=3333, seed=7, spike=30.0), dict(n=2500, seed=8, dead=True),
+               dict(n=1, seed=9), dict(n=2, seed=13), dict(n=1025, seed=10, sigma=8.0), dict(n=1_000_000, seed=11, sigma=1.5, rows=2),
+               dict(n=300_001, seed=12, spike=12.0), dict(n=2048 * 1024, seed=14, sigma=0.5)):
+        parity.check_multinomial_sorted(**kw)
+    for na in (False, True):
+        res = parity.check_lgssm_sweep(n=50_000, T=13, capture=True, specialize=True, resample="multinomial_sorted", noise_ahead=na)
+        assert res["ancestors_equal"] and res["x_equal"] and res["totals_equal"] and res["lw_max_abs_diff"] == 0.0
+
+
+@pytest.mark.parametrize("kind", ["systematic", "stratified", "multinomial", "multinomial_tiled", "multinomial_sorted"])
 def test_evidence_estimate_is_unbiased_on_device(gpu, kind):
     """E[Z_hat] = Z (Kalman closed form) over 1500 sweeps of 32 particles on the HIP library: independent of the oracle"""
     parity.check_evidence_unbiased(kind, R=1500, seed0=5000)
@@ -1445,7 +1459,7 @@ def test_sampler_laws_against_scipy_on_device(gpu):
     parity.check_sampler_laws(n=400_000)
 
 
-@pytest.mark.parametrize("kind", ["systematic", "stratified", "multinomial", "multinomial_tiled"])
+@pytest.mark.parametrize("kind", ["systematic", "stratified", "multinomial", "multinomial_tiled", "multinomial_sorted"])
 def test_offspring_laws_on_device(gpu, kind):
     parity.check_offspring_laws(kind, R=2000)
 

@@ -1227,7 +1227,18 @@ def test_two_stage_multinomial_matches_oracle(hostsim):
         assert res["ancestors_equal"] and res["x_equal"] and res["totals_equal"] and res["lw_max_abs_diff"] == 0.0
 
 
-@pytest.mark.parametrize("kind", ["systematic", "stratified", "multinomial", "multinomial_tiled"])
+def test_sorted_multinomial_matches_oracle(hostsim):
+    """gmx_sorted_uniforms / gmx_resample_sorted == the oracle's definition (C-ABI mirror), and whole sweeps resampled with it"""
+    from tests import parity
+    for kw in (dict(n=5000, rows=3), dict(n=1024, seed=6), dict(n=3333, seed=7, spike=30.0), dict(n=2500, seed=8, dead=True),
+               dict(n=1, seed=9), dict(n=2, seed=12), dict(n=1025, seed=10, sigma=8.0), dict(n=40_000, seed=11, sigma=3.0)):
+        parity.check_multinomial_sorted(**kw)
+    for na in (False, True):
+        res = parity.check_lgssm_sweep(n=3000, T=7, resample="multinomial_sorted", noise_ahead=na)
+        assert res["ancestors_equal"] and res["x_equal"] and res["totals_equal"] and res["lw_max_abs_diff"] == 0.0
+
+
+@pytest.mark.parametrize("kind", ["systematic", "stratified", "multinomial", "multinomial_tiled", "multinomial_sorted"])
 def test_evidence_estimate_is_unbiased(hostsim, kind):
     """closed-form evidence of the resampling definitions (Kalman), independent of the oracle"""
     from tests import parity
@@ -1240,7 +1251,7 @@ def test_sampler_laws_against_scipy(hostsim):
     parity.check_sampler_laws(n=100_000)
 
 
-@pytest.mark.parametrize("kind", ["systematic", "stratified", "multinomial", "multinomial_tiled"])
+@pytest.mark.parametrize("kind", ["systematic", "stratified", "multinomial", "multinomial_tiled", "multinomial_sorted"])
 def test_offspring_laws(hostsim, kind):
     """E[offspring_i] = n w_i for every scheme; the multinomial variance; |offspring - n w| < 1 (systematic) / 2 (stratified)"""
     from tests import parity

@@ -1,4 +1,4 @@
-"""us / step of the captured config-2 sweep for the three resampling kinds (one JSON line)."""
+"""us / step of the captured config-2 sweep for the resampling kinds (KINDS=a,b,...; one JSON line)."""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -9,7 +9,7 @@ n, T = 1_000_000, 100
 ys = workloads.lgssm_data(T)
 init, step = workloads.make_lgssm(G)
 out = {}
-for kind in ("systematic", "stratified", "multinomial", "multinomial_tiled"):
+for kind in (os.environ.get("KINDS", "systematic,stratified,multinomial,multinomial_tiled,multinomial_sorted")).split(","):
     sw = BootstrapSweep(init, step, n, T, resample=kind).prepare(G.key(314159), torch.from_numpy(ys)).capture()
     for _ in range(3): sw.launch()
     torch.cuda.synchronize(); t0 = time.perf_counter()

@@ -1507,7 +1507,7 @@ k_tile_stats(const float* __restrict__ lw, int64_t n, float scale, float* __rest
 // ---- GMX_RESAMPLE_MULTINOMIAL_SORTED: "slots below a CDF value" from the order-statistics table (csrc/gmx_sorted.h) ----
 struct sorted_ctx {
   const uint32_t* slow; const uint32_t* guide; const uint64_t* toff;
-  uint64_t stot; uint32_t sh, mask; double ratio;     // ratio = S_total / total
+  uint64_t stot, gmax; uint32_t sh, mask; double ratio;     // ratio = S_total / total; gmax = the last bucket
 };
 __device__ __forceinline__ sorted_ctx sorted_ctx_of(const uint32_t* table, int64_t n, uint64_t total) {
   const gmx_sorted_layout L = gmx_sorted_layout_of(n);
@@ -1517,6 +1517,7 @@ __device__ __forceinline__ sorted_ctx sorted_ctx_of(const uint32_t* table, int64
   X.stot = X.toff[L.tiles];
   X.sh = table[L.off_sh];
   X.mask = (1u << X.sh) - 1u;
+  X.gmax = X.stot >> X.sh;
   X.ratio = (double)X.stot / (double)(total ? total : 1ull);
   return X;
 }
@@ -1529,7 +1530,8 @@ __device__ __forceinline__ sb_est sorted_below_est(const sorted_ctx& X, uint64_t
   const uint64_t tq = (uint64_t)t;
   const double frac = t - (double)tq;
   const double eps = __builtin_fma(t, 0x1p-49, 0x1p-40);
-  const uint32_t g = (uint32_t)(tq >> X.sh);
+  const uint64_t gq = tq >> X.sh;
+  const uint32_t g = (uint32_t)(gq < X.gmax ? gq : X.gmax);       // (t within rounding of S_total: the entries past gmax + 1 are not defined)
   uint32_t lo = X.guide[g], hi = X.guide[g + 1];
   const uint32_t m = (uint32_t)tq & X.mask;
   hi = hi < (uint32_t)n ? hi : (uint32_t)n;
@@ -1585,6 +1587,7 @@ static_assert(RS_MAX_TILES % RS_BLOCK == 0, "tile table shape");
 // PER: rows of the tile table a thread holds (PER * 256 >= n_tiles; 1, 2, 4 or 8 — the launch picks the smallest):
 // the statistics pass is unrolled over exactly the rows that exist.
 typedef uint32_t rs_u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));    // 16-byte store at a 4-byte-aligned address
+#define SORTED_WIN 2048                /* guide entries / slots of the order-statistics table staged per tile */
 #define RS_FILL_SLOTS 2048             /* slots filled per pass (8 per thread): a tile owns ~1024 */
 // FILL: how a tile's slots [T0, T1) get their ancestors.
 //   false  every thread writes its own sources' slots (one loop over [e[0], e[4])): the trip count is the wave's
@@ -1755,10 +1758,64 @@ k_offspring_tile(uint32_t k0, uint32_t k1, uint32_t u0_host, const float* __rest
   uint32_t near_bits = 0;
   constexpr bool SORTED = (kind == GMX_RESAMPLE_MULTINOMIAL_SORTED);      // `uslot` is the order-statistics table
   sorted_ctx SX;
-  if constexpr (SORTED) SX = sorted_ctx_of(uslot, n, total);
+  // The sorted kind looks every CDF value up in the table: guide[g], then the slots of bucket g — two DEPENDENT loads
+  // per evaluation, scattered.  The tile's evaluations all fall between its first and last CDF value, i.e. into one
+  // window of the guide (~1024 entries for an average tile) and the window of slots that points to, so the workgroup
+  // stages both in LDS with two coalesced passes and evaluates from there; a tile whose window is too large (a tile
+  // owning far more than its share of the mass) reads the table in memory (block-uniform choice).
+  constexpr int WIN = SORTED ? SORTED_WIN : 1;
+  __shared__ uint32_t s_gw[WIN], s_sw[WIN];
+  bool staged = false;
+  uint32_t w_g0 = 0, w_gn = 0, w_j0 = 0, w_j1 = 0;
+  if constexpr (SORTED) {
+    SX = sorted_ctx_of(uslot, n, total);
+    const uint64_t c_hi = prefix + s_g[0];
+    const double t_lo = __builtin_fma((double)(uint32_t)(prefix >> 32), 4294967296.0, (double)(uint32_t)prefix) * SX.ratio;
+    const double t_hi = __builtin_fma((double)(uint32_t)(c_hi >> 32), 4294967296.0, (double)(uint32_t)c_hi) * SX.ratio;
+    const uint64_t b_lo = (uint64_t)t_lo >> SX.sh, b_hi = ((uint64_t)t_hi >> SX.sh) + 2ull;
+    const uint64_t g_lo = b_lo ? b_lo - 1ull : 0ull, g_top = b_hi < SX.gmax + 1ull ? b_hi : SX.gmax + 1ull;
+    const uint64_t cnt = g_top >= g_lo ? g_top - g_lo + 1ull : 0ull;
+    if (cnt >= 2ull && cnt <= (uint64_t)SORTED_WIN) {                 // block-uniform (prefix, s_g, total are)
+      w_g0 = (uint32_t)g_lo; w_gn = (uint32_t)cnt;
+      for (uint32_t i = threadIdx.x; i < w_gn; i += RS_BLOCK) s_gw[i] = SX.guide[w_g0 + i];
+      __syncthreads();
+      w_j0 = s_gw[0]; w_j1 = s_gw[w_gn - 1u];
+      w_j1 = w_j1 < (uint32_t)n32 ? w_j1 : (uint32_t)n32;
+      w_j0 = w_j0 < w_j1 ? w_j0 : w_j1;
+      if (w_j1 - w_j0 <= (uint32_t)SORTED_WIN) {
+        staged = true;
+        for (uint32_t i = threadIdx.x; i < w_j1 - w_j0; i += RS_BLOCK) s_sw[i] = SX.slow[w_j0 + i];
+      }
+      __syncthreads();
+    }
+  }
   auto below_est = [&](uint64_t c) -> sb_est {
-    if constexpr (SORTED) return sorted_below_est(SX, c, total, n32);
-    else return slots_below_est<kind>(key, u0_host, c, total, n_over_total, eps, n32, uslot);
+    if constexpr (SORTED) {
+      if (!staged) return sorted_below_est(SX, c, total, n32);
+      const double cd = __builtin_fma((double)(uint32_t)(c >> 32), 4294967296.0, (double)(uint32_t)c);
+      const double t = cd * SX.ratio;
+      const uint64_t tq = (uint64_t)t;
+      const double frac = t - (double)tq;
+      const double teps = __builtin_fma(t, 0x1p-49, 0x1p-40);
+      const uint64_t gq = tq >> SX.sh;
+      uint32_t gi = (uint32_t)(gq < SX.gmax ? gq : SX.gmax);
+      gi = gi > w_g0 ? gi - w_g0 : 0u;
+      gi = gi < w_gn - 2u ? gi : w_gn - 2u;
+      uint32_t lo = s_gw[gi], hi = s_gw[gi + 1u];
+      const uint32_t m = (uint32_t)tq & SX.mask;
+      hi = hi < w_j1 ? hi : w_j1;
+      lo = lo > w_j0 ? lo : w_j0;
+      uint32_t k = lo < hi ? lo : hi;
+      while (k < hi && (s_sw[k - w_j0] & SX.mask) <= m) ++k;
+      sb_est r;
+      r.j = (int32_t)k;
+      r.near = (frac < teps) || (frac > 1.0 - teps);
+      if (c == 0ull) { r.j = 0; r.near = false; }
+      if (c >= total) { r.j = n32; r.near = false; }
+      return r;
+    } else {
+      return slots_below_est<kind>(key, u0_host, c, total, n_over_total, eps, n32, uslot);
+    }
   };
 #pragma unroll
   for (int c = 1; c <= CDF_VEC; ++c) {
@@ -2366,12 +2423,13 @@ k_sorted_exp(const uint32_t* __restrict__ keys, uint32_t hk0, uint32_t hk1, int6
   uint32_t* row = out + (size_t)blockIdx.y * words;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t j0 = (int64_t)blockIdx.x * GMX_SORTED_TILE + (int64_t)threadIdx.x * 4;
-  uint32_t q[4];
+  uint32_t q[4], ev[4];
+  gmx_sorted_exp_pair(key, (uint64_t)(j0 >> 1), &ev[0], &ev[1]);          // j0 is a multiple of 4: two whole blocks
+  gmx_sorted_exp_pair(key, (uint64_t)(j0 >> 1) + 1ull, &ev[2], &ev[3]);
   uint64_t run = 0;
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
-    const uint32_t e = gmx_sorted_exp(key, (uint64_t)(j0 + c));
-    run += (j0 + c < n) ? e : 0u;
+    run += (j0 + c < n) ? ev[c] : 0u;
     q[c] = (uint32_t)run;
   }
   const uint64_t inc = wave_scan_u64(run);
@@ -2385,10 +2443,13 @@ k_sorted_exp(const uint32_t* __restrict__ keys, uint32_t hk0, uint32_t hk1, int6
   if (threadIdx.x == 0) reinterpret_cast<uint64_t*>(row + L.off_tsum)[blockIdx.x] = all;
 }
 
+#define SORTED_FILL 2048               /* guide entries filled per pass (8 per thread): a tile owns ~1024 */
 __global__ void __launch_bounds__(GMX_BLOCK)
 k_sorted_guide(const uint32_t* __restrict__ keys, uint32_t hk0, uint32_t hk1, int64_t n, size_t words, uint32_t* __restrict__ out) {
   __shared__ uint64_t s_below[GMX_BLOCK / GMX_WAVE], s_all[GMX_BLOCK / GMX_WAVE];
   __shared__ uint32_t s_last[GMX_BLOCK];
+  __shared__ __attribute__((aligned(16))) uint32_t s_mark[SORTED_FILL];
+  __shared__ uint32_t s_carry[GMX_BLOCK / GMX_WAVE];
   gmx_key key; key.k0 = hk0; key.k1 = hk1;
   if (keys) {
     key.k0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)keys[2 * blockIdx.y]);
@@ -2403,6 +2464,7 @@ k_sorted_guide(const uint32_t* __restrict__ keys, uint32_t hk0, uint32_t hk1, in
   const int tile = (int)blockIdx.x, tiles = (int)L.tiles;
   const int64_t j0 = (int64_t)tile * GMX_SORTED_TILE + (int64_t)threadIdx.x * 4;
   const uint4 loc = *reinterpret_cast<const uint4*>(row + j0);
+  const uint64_t own = tsum[tile];
   uint64_t below = 0, all = 0;
   for (int t = (int)threadIdx.x; t < tiles; t += GMX_BLOCK) {
     const uint64_t v = tsum[t];
@@ -2423,26 +2485,70 @@ k_sorted_guide(const uint32_t* __restrict__ keys, uint32_t hk0, uint32_t hk1, in
     toff[tile] = below;
     if (tile == 0) { toff[tiles] = stot; row[L.off_sh] = sh; }
   }
+  // the tile's slots as low words of the global sums; slot j owns the guide entries (bucket(S_{j-1}), bucket(S_j)]
   const uint32_t lv[4] = {loc.x, loc.y, loc.z, loc.w};
-  uint64_t prev = below + (threadIdx.x ? s_last[threadIdx.x - 1] : 0u);       // S_{j0 - 1}
+  const int32_t gA = tile == 0 ? 0 : (int32_t)(below >> sh) + 1;             // the tile's first guide entry ...
+  const int32_t gB = (int32_t)((below + own) >> sh);                         // ... and its last (buckets < NG < 2^22)
+  uint64_t prev = below + (threadIdx.x ? s_last[threadIdx.x - 1] : 0u);      // S_{j0 - 1}
   uint32_t lowv[4];
+  int32_t st[4], en[4];                                                      // entries [st, en] get the value j
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     const int64_t j = j0 + c;
     const uint64_t S = below + lv[c];
     lowv[c] = (j < n) ? (uint32_t)S : 0u;
-    if (j < n) {
-      const int64_t b = (int64_t)(S >> sh);
-      int64_t g = (j == 0) ? 0 : (int64_t)(prev >> sh) + 1;
-      for (; g <= b; ++g) guide[g] = (uint32_t)j;
-      if (j == n - 1) {
-        const int64_t top = (int64_t)(stot >> sh) + 1;
-        for (g = b + 1; g <= top; ++g) guide[g] = (uint32_t)n;
-      }
+    st[c] = (j == 0) ? 0 : (int32_t)(prev >> sh) + 1;
+    en[c] = (j < n) ? (int32_t)(S >> sh) : st[c] - 1;
+    if (j == n - 1) {                      // past the last slot: guide[g] = n up to (S_total >> sh) + 1 (a few entries)
+      const int32_t top = (int32_t)(stot >> sh) + 1;
+      for (int32_t g = en[c] + 1; g <= top; ++g) guide[g] = (uint32_t)n;
     }
     prev = S;
   }
   *reinterpret_cast<uint4*>(row + j0) = make_uint4(lowv[0], lowv[1], lowv[2], lowv[3]);
+  // through LDS (k_offspring_tile's fill): a slot marks the first of its entries with j + 1, a max-scan fills the rest
+  // (j increases with the entry), the workgroup stores 8 consecutive entries per thread
+  for (int32_t base = gA; base <= gB; base += SORTED_FILL) {                 // block-uniform trip count (1, rarely 2)
+    reinterpret_cast<uint4*>(s_mark)[threadIdx.x] = make_uint4(0u, 0u, 0u, 0u);
+    reinterpret_cast<uint4*>(s_mark)[threadIdx.x + GMX_BLOCK] = make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int32_t lo = st[c] > base ? st[c] : base;
+      if (en[c] >= lo && lo - base < SORTED_FILL) s_mark[lo - base] = (uint32_t)(j0 + c) + 1u;
+    }
+    __syncthreads();
+    uint4 a = reinterpret_cast<const uint4*>(s_mark)[2 * threadIdx.x];
+    uint4 b = reinterpret_cast<const uint4*>(s_mark)[2 * threadIdx.x + 1];
+    a.y = a.y > a.x ? a.y : a.x; a.z = a.z > a.y ? a.z : a.y; a.w = a.w > a.z ? a.w : a.z;
+    b.x = b.x > a.w ? b.x : a.w; b.y = b.y > b.x ? b.y : b.x; b.z = b.z > b.y ? b.z : b.y; b.w = b.w > b.z ? b.w : b.z;
+    const uint32_t incl = gmx_wave_umax_scan(b.w);
+    uint32_t carry = wave_shr1_u32(incl, 0u);
+    if (lane == 63) s_carry[wave] = incl;
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < GMX_BLOCK / GMX_WAVE - 1; ++w) { const uint32_t v = s_carry[w]; carry = (w < wave && v > carry) ? v : carry; }
+    a.x = a.x > carry ? a.x : carry; a.y = a.y > carry ? a.y : carry; a.z = a.z > carry ? a.z : carry; a.w = a.w > carry ? a.w : carry;
+    b.x = b.x > carry ? b.x : carry; b.y = b.y > carry ? b.y : carry; b.z = b.z > carry ? b.z : carry; b.w = b.w > carry ? b.w : carry;
+    const int32_t g = base + 8 * (int32_t)threadIdx.x;
+    if (g + 7 <= gB) {
+      rs_u32x4_a4 va, vb;
+      va.x = a.x - 1u; va.y = a.y - 1u; va.z = a.z - 1u; va.w = a.w - 1u;
+      vb.x = b.x - 1u; vb.y = b.y - 1u; vb.z = b.z - 1u; vb.w = b.w - 1u;
+      *reinterpret_cast<rs_u32x4_a4*>(guide + g) = va;
+      *reinterpret_cast<rs_u32x4_a4*>(guide + g + 4) = vb;
+    } else {
+      if (g + 0 <= gB) guide[g + 0] = a.x - 1u;
+      if (g + 1 <= gB) guide[g + 1] = a.y - 1u;
+      if (g + 2 <= gB) guide[g + 2] = a.z - 1u;
+      if (g + 3 <= gB) guide[g + 3] = a.w - 1u;
+      if (g + 4 <= gB) guide[g + 4] = b.x - 1u;
+      if (g + 5 <= gB) guide[g + 5] = b.y - 1u;
+      if (g + 6 <= gB) guide[g + 6] = b.z - 1u;
+      if (g + 7 <= gB) guide[g + 7] = b.w - 1u;
+    }
+    __syncthreads();
+  }
 }
 
 extern "C" size_t gmx_sorted_uniforms_words(int64_t n) { return n > 0 ? gmx_sorted_layout_of(n).words : 0; }

@@ -6,7 +6,8 @@
 // slot j's ancestor is non-decreasing in j, exactly as for systematic / stratified — so it runs on the same kernel
 // (k_offspring_tile: no CDF array, no search, no random cache lines) with another "slots below this CDF value":
 //
-//   E_j   = 1 + trunc(-log(u_j) * 2^16),  u_j = ((bits32(key, j) >> 9) + 0.5) * 2^-23        j = 0 .. n   (integers)
+//   E_j   = 1 + trunc(-log(u_j) * 2^16),  u_j = ((w_j >> 9) + 0.5) * 2^-23,                  j = 0 .. n   (integers)
+//           (w_{2i}, w_{2i+1}) = the two words of threefry(key, ctr = i): two exponentials per block
 //   S_j   = E_0 + ... + E_j  (j < n),     S_total = S_{n-1} + E_n
 //   ancestor(j) = first i with cdf_i * S_total > S_j * total                                  (128-bit integers)
 //
@@ -28,10 +29,21 @@
 #define GMX_SORTED_TILE 1024
 #define GMX_SORTED_SCALE 65536.0f
 
-GMX_HD uint32_t gmx_sorted_exp(gmx_key key, uint64_t j) {
-  const float u = ((float)(gmx_bits32(key, j) >> 9) + 0.5f) * 1.1920928955078125e-07f;     // (0, 1), exact
-  const float e = -gmx_logf(u);                                                               // (0, 16.64]
+GMX_HD uint32_t gmx_sorted_exp_word(uint32_t w) {
+  const float u = ((float)(w >> 9) + 0.5f) * 1.1920928955078125e-07f;     // (0, 1), exact
+  const float e = -gmx_logf(u);                                            // (0, 16.64]
   return 1u + (uint32_t)(e * GMX_SORTED_SCALE);
+}
+// two exponentials per Threefry block: E_{2i}, E_{2i+1} from the two words of block i
+GMX_HD void gmx_sorted_exp_pair(gmx_key key, uint64_t i, uint32_t* e0, uint32_t* e1) {
+  uint32_t a, b;
+  gmx_threefry2x32(key.k0, key.k1, (uint32_t)(i >> 32), (uint32_t)i, &a, &b);
+  *e0 = gmx_sorted_exp_word(a); *e1 = gmx_sorted_exp_word(b);
+}
+GMX_HD uint32_t gmx_sorted_exp(gmx_key key, uint64_t j) {
+  uint32_t e0, e1;
+  gmx_sorted_exp_pair(key, j >> 1, &e0, &e1);
+  return (j & 1ull) ? e1 : e0;
 }
 
 struct gmx_sorted_layout {

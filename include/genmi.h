@@ -335,7 +335,8 @@ int gmx_resample_tiles_u(int kind, const uint32_t key[2], const float* lw_d, int
                          float* max_d, uint64_t* total_d, int32_t* ancestors_d, gmx_stream stream);
 /* Multinomial resampling with SORTED uniforms (GMX_RESAMPLE_MULTINOMIAL_SORTED; build-defined, SURVEY App. B;
  * csrc/gmx_sorted.h): n sorted iid uniforms are the normalised partial sums of n + 1 unit exponentials, so
- *   E_j = 1 + trunc(-log(u_j) * 2^16),  u_j = ((bits32(key, j) >> 9) + 0.5) * 2^-23,  j = 0 .. n
+ *   E_j = 1 + trunc(-log(u_j) * 2^16),  u_j = ((w_j >> 9) + 0.5) * 2^-23,  j = 0 .. n,
+ *         (w_2i, w_2i+1) = the two words of threefry(key, ctr = i)
  *   S_j = E_0 + ... + E_j (j < n),  S_total = S_{n-1} + E_n
  *   ancestor(j) = first i with cdf_i * S_total > S_j * total                               (128-bit integers)
  * gives Multinomial(n, w) offspring counts with the output ordered by ancestor — an ordered scheme like systematic /

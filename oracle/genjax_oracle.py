@@ -1824,7 +1824,8 @@ MULTINOMIAL_SORTED = 4
 
 
 def sorted_exponentials(k, count):
-    """E_j = 1 + trunc(-log(u_j) * 2^16), u_j = ((bits32(k, j) >> 9) + 0.5) * 2^-23 (f32; orc_core.c::orc_sorted_exp)"""
+    """E_j = 1 + trunc(-log(u_j) * 2^16), u_j = ((w_j >> 9) + 0.5) * 2^-23 in f32, (w_2i, w_2i+1) = the two
+    words of threefry(k, ctr = i) (orc_core.c::orc_sorted_exp)"""
     out = np.empty(count, dtype=np.uint32)
     kk = np.ascontiguousarray(np.asarray(k, np.uint32).reshape(2))
     lib().orc_sorted_exp(I64(count), _p(kk), _p(out))
@@ -1836,7 +1837,8 @@ def ancestors_multinomial_sorted(k, cdf):
     counterpart: SURVEY App. B).  n sorted iid uniforms are distributed as the normalised partial sums of n + 1 unit
     exponentials, U_(j) = S_j / S_total, so offspring counts are Multinomial(n, w) and the output is ordered by
     ancestor (what systematic / stratified give), which lets the resampler run without a CDF array or a search:
-      E_j = 1 + trunc(-log(u_j) * 2^16),  u_j = ((bits32(k, j) >> 9) + 0.5) * 2^-23,   j = 0 .. n
+      E_j = 1 + trunc(-log(u_j) * 2^16),  u_j = ((w_j >> 9) + 0.5) * 2^-23,   j = 0 .. n
+          (w_2i, w_2i+1) = the two words of threefry(k, ctr = i): two exponentials per block
       S_j = E_0 + ... + E_j (j < n),  S_total = S_{n-1} + E_n
       ancestor(j) = first i with cdf_i * S_total > S_j * total          (integers; Python ints here)
     No mass at all: every slot maps to the last particle."""

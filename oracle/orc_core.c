@@ -596,10 +596,13 @@ void orc_ancestors(int kind, const uint32_t* key, const uint64_t* cdf, int64_t n
 }
 
 /* Multinomial resampling with SORTED uniforms (include/genmi.h, GMX_RESAMPLE_MULTINOMIAL_SORTED; csrc/gmx_sorted.h):
- *   E_j = 1 + trunc(-log(u_j) * 2^16), u_j = ((bits32(key, j) >> 9) + 0.5) * 2^-23, j = 0 .. n;
+ *   E_j = 1 + trunc(-log(u_j) * 2^16), u_j = ((w_j >> 9) + 0.5) * 2^-23, j = 0 .. n, (w_2i, w_2i+1) = the two words
+ *   of threefry(key, ctr = i);
  *   S_j = E_0 + .. + E_j, S_total = S_{n-1} + E_n;  ancestor(j) = first i with cdf_i * S_total > S_j * total. */
 static uint32_t sorted_e(const uint32_t* key, uint64_t j) {
-  float u = ((float)(bits32_1(key, j) >> 9) + 0.5f) * 1.1920928955078125e-07f;   /* (0, 1), exact */
+  uint32_t a, b;
+  threefry(key[0], key[1], (uint32_t)((j >> 1) >> 32), (uint32_t)(j >> 1), &a, &b);
+  float u = ((float)(((j & 1) ? b : a) >> 9) + 0.5f) * 1.1920928955078125e-07f;   /* (0, 1), exact */
   float e = -orc_logf(u);
   return 1u + (uint32_t)(e * 65536.0f);
 }

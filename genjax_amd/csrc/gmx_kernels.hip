@@ -1777,14 +1777,28 @@ k_offspring_tile(uint32_t k0, uint32_t k1, uint32_t u0_host, const float* __rest
     const uint64_t cnt = g_top >= g_lo ? g_top - g_lo + 1ull : 0ull;
     if (cnt >= 2ull && cnt <= (uint64_t)SORTED_WIN) {                 // block-uniform (prefix, s_g, total are)
       w_g0 = (uint32_t)g_lo; w_gn = (uint32_t)cnt;
-      for (uint32_t i = threadIdx.x; i < w_gn; i += RS_BLOCK) s_gw[i] = SX.guide[w_g0 + i];
+      uint32_t tmp[SORTED_WIN / RS_BLOCK];
+#pragma unroll
+      for (int r = 0; r < SORTED_WIN / RS_BLOCK; ++r) {        // every load issued before anything waits (clamped rows)
+        const uint32_t i = (uint32_t)r * RS_BLOCK + threadIdx.x;
+        tmp[r] = SX.guide[w_g0 + (i < w_gn ? i : w_gn - 1u)];
+      }
+#pragma unroll
+      for (int r = 0; r < SORTED_WIN / RS_BLOCK; ++r) s_gw[(uint32_t)r * RS_BLOCK + threadIdx.x] = tmp[r];
       __syncthreads();
       w_j0 = s_gw[0]; w_j1 = s_gw[w_gn - 1u];
       w_j1 = w_j1 < (uint32_t)n32 ? w_j1 : (uint32_t)n32;
       w_j0 = w_j0 < w_j1 ? w_j0 : w_j1;
       if (w_j1 - w_j0 <= (uint32_t)SORTED_WIN) {
         staged = true;
-        for (uint32_t i = threadIdx.x; i < w_j1 - w_j0; i += RS_BLOCK) s_sw[i] = SX.slow[w_j0 + i];
+        const uint32_t last = (uint32_t)n32 - 1u;
+#pragma unroll
+        for (int r = 0; r < SORTED_WIN / RS_BLOCK; ++r) {
+          const uint32_t j = w_j0 + (uint32_t)r * RS_BLOCK + threadIdx.x;
+          tmp[r] = SX.slow[j < last ? j : last];
+        }
+#pragma unroll
+        for (int r = 0; r < SORTED_WIN / RS_BLOCK; ++r) s_sw[(uint32_t)r * RS_BLOCK + threadIdx.x] = tmp[r];
       }
       __syncthreads();
     }
@@ -2465,11 +2479,18 @@ k_sorted_guide(const uint32_t* __restrict__ keys, uint32_t hk0, uint32_t hk1, in
   const int64_t j0 = (int64_t)tile * GMX_SORTED_TILE + (int64_t)threadIdx.x * 4;
   const uint4 loc = *reinterpret_cast<const uint4*>(row + j0);
   const uint64_t own = tsum[tile];
+  uint64_t tv[RS_MAX_TILES / GMX_BLOCK];
+#pragma unroll
+  for (int r = 0; r < RS_MAX_TILES / GMX_BLOCK; ++r) {          // loads only (clamped rows): one round trip
+    const int t = r * GMX_BLOCK + (int)threadIdx.x;
+    tv[r] = tsum[t < tiles ? t : tiles - 1];
+  }
   uint64_t below = 0, all = 0;
-  for (int t = (int)threadIdx.x; t < tiles; t += GMX_BLOCK) {
-    const uint64_t v = tsum[t];
-    all += v;
-    below += (t < tile) ? v : 0ull;
+#pragma unroll
+  for (int r = 0; r < RS_MAX_TILES / GMX_BLOCK; ++r) {
+    const int t = r * GMX_BLOCK + (int)threadIdx.x;
+    all += (t < tiles) ? tv[r] : 0ull;
+    below += (t < tile) ? tv[r] : 0ull;
   }
   below = wave_sum_u64(below);
   all = wave_sum_u64(all);

@@ -1244,6 +1244,8 @@ class BootstrapSweep(_NoiseAhead):
             ks = np.stack([rk(t).host() for t in range(t0, t1)]).astype(np.uint32)
             self._u_keys.append(torch.from_numpy(ks.view(np.int32)).to(dev))
         self._u_pad = int(os.environ.get("GENMI_NOISE_LDS_PAD", self.NOISE_LDS_PAD))
+        if self.kind == MULTINOMIAL_SORTED:       # its two kernels wait on memory, not on the vector ALUs: more of them per CU
+            self._u_pad = int(os.environ.get("GENMI_SORTED_LDS_PAD", 16000))
 
     def _launch_group_extras(self, g):
         if getattr(self, "ubuf", None) is None:

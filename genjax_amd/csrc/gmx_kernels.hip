@@ -1505,6 +1505,7 @@ k_tile_stats(const float* __restrict__ lw, int64_t n, float scale, float* __rest
 // (slots_below_est: csrc/gmx_resample.h)
 
 // ---- GMX_RESAMPLE_MULTINOMIAL_SORTED: "slots below a CDF value" from the order-statistics table (csrc/gmx_sorted.h) ----
+typedef uint32_t sorted_u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));   // 8-byte load at a 4-byte-aligned address
 struct sorted_ctx {
   const uint32_t* slow; const uint32_t* guide; const uint64_t* toff;
   uint64_t stot, gmax; uint32_t sh, mask; double ratio;     // ratio = S_total / total; gmax = the last bucket
@@ -1532,17 +1533,22 @@ __device__ __forceinline__ sb_est sorted_below_est(const sorted_ctx& X, uint64_t
   const double eps = __builtin_fma(t, 0x1p-49, 0x1p-40);
   const uint64_t gq = tq >> X.sh;
   const uint32_t g = (uint32_t)(gq < X.gmax ? gq : X.gmax);       // (t within rounding of S_total: the entries past gmax + 1 are not defined)
-  uint32_t lo = X.guide[g], hi = X.guide[g + 1];
+  const sorted_u32x2_a4 gh = *reinterpret_cast<const sorted_u32x2_a4*>(X.guide + g);
+  uint32_t lo = gh.x, hi = gh.y;
   const uint32_t m = (uint32_t)tq & X.mask;
   hi = hi < (uint32_t)n ? hi : (uint32_t)n;
   lo = lo < hi ? lo : hi;
-  const uint32_t last = (uint32_t)n - 1u;
-  const uint32_t v0 = X.slow[lo < last ? lo : last], v1 = X.slow[lo + 1u < last ? lo + 1u : last];
-  const bool p0 = lo < hi && (v0 & X.mask) <= m;
-  const bool p1 = p0 && lo + 1u < hi && (v1 & X.mask) <= m;
-  uint32_t k = lo + (p0 ? 1u : 0u) + (p1 ? 1u : 0u);
-  bool more = p1 && k < hi;
-  while (more) {                                   // a bucket with more than two slots below t (~ 3 % of the evaluations)
+  // the bucket's first eight slots in two 16-byte loads (a bucket holds one slot on average, more than eight once in
+  // 1e6): reading past the bucket — at most 7 words past slot n - 1, still inside the table — is harmless, those
+  // entries are not counted.  The slots of a bucket ascend, so the count of "<= m" is the count of leading ones.
+  const rs_u32x4_a4 pa = *reinterpret_cast<const rs_u32x4_a4*>(X.slow + lo);
+  const rs_u32x4_a4 pb = *reinterpret_cast<const rs_u32x4_a4*>(X.slow + lo + 4u);
+  const uint32_t pv[8] = {pa.x, pa.y, pa.z, pa.w, pb.x, pb.y, pb.z, pb.w};
+  uint32_t k = lo;
+#pragma unroll
+  for (uint32_t i = 0; i < 8u; ++i) k += (lo + i < hi && (pv[i] & X.mask) <= m) ? 1u : 0u;
+  bool more = k == lo + 8u && k < hi;
+  while (more) {
     const uint32_t v = X.slow[k];
     const bool below = (v & X.mask) <= m;
     k += below ? 1u : 0u;
@@ -1764,7 +1770,7 @@ k_offspring_tile(uint32_t k0, uint32_t k1, uint32_t u0_host, const float* __rest
   // stages both in LDS with two coalesced passes and evaluates from there; a tile whose window is too large (a tile
   // owning far more than its share of the mass) reads the table in memory (block-uniform choice).
   constexpr int WIN = SORTED ? SORTED_WIN : 1;
-  __shared__ uint32_t s_gw[WIN], s_sw[WIN];
+  __shared__ uint32_t s_gw[WIN], s_sw[WIN + 4];
   bool staged = false;
   uint32_t w_g0 = 0, w_gn = 0, w_j0 = 0, w_j1 = 0;
   if constexpr (SORTED) {
@@ -1775,7 +1781,7 @@ k_offspring_tile(uint32_t k0, uint32_t k1, uint32_t u0_host, const float* __rest
     const uint64_t b_lo = (uint64_t)t_lo >> SX.sh, b_hi = ((uint64_t)t_hi >> SX.sh) + 2ull;
     const uint64_t g_lo = b_lo ? b_lo - 1ull : 0ull, g_top = b_hi < SX.gmax + 1ull ? b_hi : SX.gmax + 1ull;
     const uint64_t cnt = g_top >= g_lo ? g_top - g_lo + 1ull : 0ull;
-    if (cnt >= 2ull && cnt <= (uint64_t)SORTED_WIN) {                 // block-uniform (prefix, s_g, total are)
+    if (cnt >= 2ull && cnt <= (uint64_t)SORTED_WIN && (u0_host & 1u)) {   // block-uniform (prefix, s_g, total are); u0_host: bit 0 = stage
       w_g0 = (uint32_t)g_lo; w_gn = (uint32_t)cnt;
       uint32_t tmp[SORTED_WIN / RS_BLOCK];
 #pragma unroll
@@ -1819,8 +1825,18 @@ k_offspring_tile(uint32_t k0, uint32_t k1, uint32_t u0_host, const float* __rest
       const uint32_t m = (uint32_t)tq & SX.mask;
       hi = hi < w_j1 ? hi : w_j1;
       lo = lo > w_j0 ? lo : w_j0;
-      uint32_t k = lo < hi ? lo : hi;
-      while (k < hi && (s_sw[k - w_j0] & SX.mask) <= m) ++k;
+      lo = lo < hi ? lo : hi;
+      uint32_t k = lo;
+      {
+        const uint32_t* q = s_sw + (lo - w_j0);
+        const uint32_t q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];            // (s_sw has 4 words of slack)
+        k += (lo + 0u < hi && (q0 & SX.mask) <= m) ? 1u : 0u;
+        k += (lo + 1u < hi && (q1 & SX.mask) <= m) ? 1u : 0u;
+        k += (lo + 2u < hi && (q2 & SX.mask) <= m) ? 1u : 0u;
+        k += (lo + 3u < hi && (q3 & SX.mask) <= m) ? 1u : 0u;
+      }
+      if (k == lo + 4u)
+        while (k < hi && (s_sw[k - w_j0] & SX.mask) <= m) ++k;
       sb_est r;
       r.j = (int32_t)k;
       r.near = (frac < teps) || (frac > 1.0 - teps);
@@ -1944,7 +1960,11 @@ static int launch_offspring_tile(int kind, const uint32_t key[2], const float* l
                                  int32_t* ancestors_d, gmx_stream stream, bool pref = false, const uint32_t* u_d = nullptr) {
   uint32_t b0, b1;
   gmx_threefry2x32(key[0], key[1], 0u, 0u, &b0, &b1);           // bits32(key, 0) on the host
-  const uint32_t u0 = (b0 ^ b1) >> 9;
+  uint32_t u0 = (b0 ^ b1) >> 9;
+  if (kind == GMX_RESAMPLE_MULTINOMIAL_SORTED) {       // (no single uniform: the word carries the kind's switches)
+    static const bool stage = []() { const char* e = getenv("GENMI_SORTED_STAGE"); return !(e && e[0] == '0'); }();
+    u0 = stage ? 1u : 0u;
+  }
   const int64_t tiles = (n + RS_TILE - 1) / RS_TILE;
   const dim3 grid((unsigned)((tiles + RS_TPB - 1) / RS_TPB)), block(RS_BLOCK);
   hipStream_t st = (hipStream_t)stream;

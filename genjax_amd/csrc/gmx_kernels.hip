@@ -1505,6 +1505,7 @@ k_tile_stats(const float* __restrict__ lw, int64_t n, float scale, float* __rest
 // (slots_below_est: csrc/gmx_resample.h)
 
 // ---- GMX_RESAMPLE_MULTINOMIAL_SORTED: "slots below a CDF value" from the order-statistics table (csrc/gmx_sorted.h) ----
+typedef uint32_t rs_u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));    // 16-byte load / store at a 4-byte-aligned address
 typedef uint32_t sorted_u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));   // 8-byte load at a 4-byte-aligned address
 struct sorted_ctx {
   const uint32_t* slow; const uint32_t* guide; const uint64_t* toff;
@@ -1592,7 +1593,6 @@ __device__ __forceinline__ int64_t sorted_below_exact(const sorted_ctx& X, uint6
 static_assert(RS_MAX_TILES % RS_BLOCK == 0, "tile table shape");
 // PER: rows of the tile table a thread holds (PER * 256 >= n_tiles; 1, 2, 4 or 8 — the launch picks the smallest):
 // the statistics pass is unrolled over exactly the rows that exist.
-typedef uint32_t rs_u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));    // 16-byte store at a 4-byte-aligned address
 #define SORTED_WIN 2048                /* guide entries / slots of the order-statistics table staged per tile */
 #define RS_FILL_SLOTS 2048             /* slots filled per pass (8 per thread): a tile owns ~1024 */
 // FILL: how a tile's slots [T0, T1) get their ancestors.

@@ -1511,13 +1511,13 @@ struct sorted_ctx {
   const uint32_t* slow; const uint32_t* guide; const uint64_t* toff;
   uint64_t stot, gmax; uint32_t sh, mask; double ratio;     // ratio = S_total / total; gmax = the last bucket
 };
-__device__ __forceinline__ sorted_ctx sorted_ctx_of(const uint32_t* table, int64_t n, uint64_t total) {
+__device__ __forceinline__ sorted_ctx sorted_ctx_of(const uint32_t* table, int64_t n, uint64_t total, uint64_t stot, uint32_t sh) {
   const gmx_sorted_layout L = gmx_sorted_layout_of(n);
   sorted_ctx X;
   X.slow = table; X.guide = table + L.off_guide;
   X.toff = reinterpret_cast<const uint64_t*>(table + L.off_toff);
-  X.stot = X.toff[L.tiles];
-  X.sh = table[L.off_sh];
+  X.stot = stot;              // = toff[tiles], table[off_sh]: loaded by the caller, early
+  X.sh = sh;
   X.mask = (1u << X.sh) - 1u;
   X.gmax = X.stot >> X.sh;
   X.ratio = (double)X.stot / (double)(total ? total : 1ull);
@@ -1673,6 +1673,12 @@ k_offspring_tile(uint32_t k0, uint32_t k1, uint32_t u0_host, const float* __rest
     }
   }
   const float tmax_mine = tmax[tile_c];
+  uint64_t sx_stot = 0; uint32_t sx_sh = 0;             // the sorted kind's table header (uniform), with the other early loads
+  if constexpr (kind == GMX_RESAMPLE_MULTINOMIAL_SORTED) {
+    const gmx_sorted_layout L = gmx_sorted_layout_of(n);
+    sx_stot = reinterpret_cast<const uint64_t*>(uslot + L.off_toff)[L.tiles];
+    sx_sh = uslot[L.off_sh];
+  }
   __builtin_amdgcn_sched_barrier(0);
   if (!PREF) {
 #pragma unroll
@@ -1774,7 +1780,7 @@ k_offspring_tile(uint32_t k0, uint32_t k1, uint32_t u0_host, const float* __rest
   bool staged = false;
   uint32_t w_g0 = 0, w_gn = 0, w_j0 = 0, w_j1 = 0;
   if constexpr (SORTED) {
-    SX = sorted_ctx_of(uslot, n, total);
+    SX = sorted_ctx_of(uslot, n, total, sx_stot, sx_sh);
     const uint64_t c_hi = prefix + s_g[0];
     const double t_lo = __builtin_fma((double)(uint32_t)(prefix >> 32), 4294967296.0, (double)(uint32_t)prefix) * SX.ratio;
     const double t_hi = __builtin_fma((double)(uint32_t)(c_hi >> 32), 4294967296.0, (double)(uint32_t)c_hi) * SX.ratio;
@@ -1810,52 +1816,117 @@ k_offspring_tile(uint32_t k0, uint32_t k1, uint32_t u0_host, const float* __rest
     }
   }
   auto below_est = [&](uint64_t c) -> sb_est {
-    if constexpr (SORTED) {
-      if (!staged) return sorted_below_est(SX, c, total, n32);
-      const double cd = __builtin_fma((double)(uint32_t)(c >> 32), 4294967296.0, (double)(uint32_t)c);
+    return slots_below_est<kind == GMX_RESAMPLE_MULTINOMIAL_SORTED ? GMX_RESAMPLE_SYSTEMATIC : kind>(
+        key, u0_host, c, total, n_over_total, eps, n32, uslot);              // (never called for the sorted kind)
+  };
+  sb_est R[CDF_VEC + 1];
+  if constexpr (SORTED) {
+    // all five evaluations side by side: every guide read issued before any is used, then every slot probe — written
+    // one evaluation after the other, the (rare) walk past the probed slots orders the loads: ten dependent round trips
+    uint32_t mv[CDF_VEC + 1], gv[CDF_VEC + 1], lov[CDF_VEC + 1], hiv[CDF_VEC + 1], kv[CDF_VEC + 1];
+#pragma unroll
+    for (int c = 0; c <= CDF_VEC; ++c) {
+      const double cd = __builtin_fma((double)(uint32_t)(cv[c] >> 32), 4294967296.0, (double)(uint32_t)cv[c]);
       const double t = cd * SX.ratio;
       const uint64_t tq = (uint64_t)t;
       const double frac = t - (double)tq;
       const double teps = __builtin_fma(t, 0x1p-49, 0x1p-40);
+      R[c].near = (frac < teps) || (frac > 1.0 - teps);
       const uint64_t gq = tq >> SX.sh;
-      uint32_t gi = (uint32_t)(gq < SX.gmax ? gq : SX.gmax);
-      gi = gi > w_g0 ? gi - w_g0 : 0u;
-      gi = gi < w_gn - 2u ? gi : w_gn - 2u;
-      uint32_t lo = s_gw[gi], hi = s_gw[gi + 1u];
-      const uint32_t m = (uint32_t)tq & SX.mask;
-      hi = hi < w_j1 ? hi : w_j1;
-      lo = lo > w_j0 ? lo : w_j0;
-      lo = lo < hi ? lo : hi;
-      uint32_t k = lo;
-      {
-        const uint32_t* q = s_sw + (lo - w_j0);
-        const uint32_t q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];            // (s_sw has 4 words of slack)
-        k += (lo + 0u < hi && (q0 & SX.mask) <= m) ? 1u : 0u;
-        k += (lo + 1u < hi && (q1 & SX.mask) <= m) ? 1u : 0u;
-        k += (lo + 2u < hi && (q2 & SX.mask) <= m) ? 1u : 0u;
-        k += (lo + 3u < hi && (q3 & SX.mask) <= m) ? 1u : 0u;
-      }
-      if (k == lo + 4u)
-        while (k < hi && (s_sw[k - w_j0] & SX.mask) <= m) ++k;
-      sb_est r;
-      r.j = (int32_t)k;
-      r.near = (frac < teps) || (frac > 1.0 - teps);
-      if (c == 0ull) { r.j = 0; r.near = false; }
-      if (c >= total) { r.j = n32; r.near = false; }
-      return r;
-    } else {
-      return slots_below_est<kind>(key, u0_host, c, total, n_over_total, eps, n32, uslot);
+      gv[c] = (uint32_t)(gq < SX.gmax ? gq : SX.gmax);
+      mv[c] = (uint32_t)tq & SX.mask;
     }
-  };
+    bool more = false;
+    if (staged) {
+#pragma unroll
+      for (int c = 0; c <= CDF_VEC; ++c) {
+        uint32_t gi = gv[c] > w_g0 ? gv[c] - w_g0 : 0u;
+        gi = gi < w_gn - 2u ? gi : w_gn - 2u;
+        lov[c] = s_gw[gi]; hiv[c] = s_gw[gi + 1u];
+      }
+#pragma unroll
+      for (int c = 0; c <= CDF_VEC; ++c) {
+        hiv[c] = hiv[c] < w_j1 ? hiv[c] : w_j1;
+        lov[c] = lov[c] > w_j0 ? lov[c] : w_j0;
+        lov[c] = lov[c] < hiv[c] ? lov[c] : hiv[c];
+      }
+      uint32_t q[CDF_VEC + 1][4];
+#pragma unroll
+      for (int c = 0; c <= CDF_VEC; ++c) {
+        const uint32_t* p = s_sw + (lov[c] - w_j0);                    // (s_sw has 4 words of slack)
+        q[c][0] = p[0]; q[c][1] = p[1]; q[c][2] = p[2]; q[c][3] = p[3];
+      }
+#pragma unroll
+      for (int c = 0; c <= CDF_VEC; ++c) {
+        uint32_t k = lov[c];
+#pragma unroll
+        for (uint32_t i = 0; i < 4u; ++i) k += (lov[c] + i < hiv[c] && (q[c][i] & SX.mask) <= mv[c]) ? 1u : 0u;
+        kv[c] = k;
+        more |= (k == lov[c] + 4u && k < hiv[c]);
+      }
+      if (more) {
+#pragma unroll 1
+        for (int c = 0; c <= CDF_VEC; ++c) {
+          uint32_t k = kv[c];
+          if (k == lov[c] + 4u)
+            while (k < hiv[c] && (s_sw[k - w_j0] & SX.mask) <= mv[c]) ++k;
+          kv[c] = k;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c <= CDF_VEC; ++c) {
+        const sorted_u32x2_a4 gh = *reinterpret_cast<const sorted_u32x2_a4*>(SX.guide + gv[c]);
+        lov[c] = gh.x; hiv[c] = gh.y;
+      }
+#pragma unroll
+      for (int c = 0; c <= CDF_VEC; ++c) {
+        hiv[c] = hiv[c] < (uint32_t)n32 ? hiv[c] : (uint32_t)n32;
+        lov[c] = lov[c] < hiv[c] ? lov[c] : hiv[c];
+      }
+      rs_u32x4_a4 pa[CDF_VEC + 1], pb[CDF_VEC + 1];
+#pragma unroll
+      for (int c = 0; c <= CDF_VEC; ++c) {        // eight slots per evaluation (past slot n - 1: still inside the table, not counted)
+        pa[c] = *reinterpret_cast<const rs_u32x4_a4*>(SX.slow + lov[c]);
+        pb[c] = *reinterpret_cast<const rs_u32x4_a4*>(SX.slow + lov[c] + 4u);
+      }
+#pragma unroll
+      for (int c = 0; c <= CDF_VEC; ++c) {
+        const uint32_t pv[8] = {pa[c].x, pa[c].y, pa[c].z, pa[c].w, pb[c].x, pb[c].y, pb[c].z, pb[c].w};
+        uint32_t k = lov[c];
+#pragma unroll
+        for (uint32_t i = 0; i < 8u; ++i) k += (lov[c] + i < hiv[c] && (pv[i] & SX.mask) <= mv[c]) ? 1u : 0u;
+        kv[c] = k;
+        more |= (k == lov[c] + 8u && k < hiv[c]);
+      }
+      if (more) {
+#pragma unroll 1
+        for (int c = 0; c <= CDF_VEC; ++c) {
+          uint32_t k = kv[c];
+          if (k == lov[c] + 8u)
+            while (k < hiv[c] && (SX.slow[k] & SX.mask) <= mv[c]) ++k;
+          kv[c] = k;
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c <= CDF_VEC; ++c) {
+      R[c].j = (int32_t)kv[c];
+      if (cv[c] == 0ull) { R[c].j = 0; R[c].near = false; }
+      if (cv[c] >= total) { R[c].j = n32; R[c].near = false; }
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c <= CDF_VEC; ++c) R[c] = below_est(cv[c]);
+  }
 #pragma unroll
   for (int c = 1; c <= CDF_VEC; ++c) {
-    const sb_est r = below_est(cv[c]);
-    e[c] = r.j;
-    near_bits |= r.near ? (1u << c) : 0u;
+    e[c] = R[c].j;
+    near_bits |= R[c].near ? (1u << c) : 0u;
   }
   // lower bound of the thread's first source = upper bound of the previous thread's last one; lane 0 evaluates its own
   {
-    const sb_est r = below_est(cv[0]);
+    const sb_est r = R[0];
     near_bits |= (lane == 0 && r.near) ? 1u : 0u;
     e[0] = (int32_t)wave_shr1_u32((uint32_t)e[CDF_VEC], (uint32_t)r.j);
     if (lane == 0) e[0] = r.j;

@@ -1523,45 +1523,6 @@ __device__ __forceinline__ sorted_ctx sorted_ctx_of(const uint32_t* table, int64
   X.ratio = (double)X.stot / (double)(total ? total : 1ull);
   return X;
 }
-// f(c) = #{ j < n : S_j * total < c * S_total }: with t = c * S_total / total (f64; not within eps of an integer, else
-// the exact predicate decides) slot j is below iff S_j <= floor(t); the guide gives the slots of the buckets below
-// floor(t)'s, the slots of its own bucket (one on average) are compared by their low words.
-__device__ __forceinline__ sb_est sorted_below_est(const sorted_ctx& X, uint64_t c, uint64_t total, int32_t n) {
-  const double cd = __builtin_fma((double)(uint32_t)(c >> 32), 4294967296.0, (double)(uint32_t)c);
-  const double t = cd * X.ratio;
-  const uint64_t tq = (uint64_t)t;
-  const double frac = t - (double)tq;
-  const double eps = __builtin_fma(t, 0x1p-49, 0x1p-40);
-  const uint64_t gq = tq >> X.sh;
-  const uint32_t g = (uint32_t)(gq < X.gmax ? gq : X.gmax);       // (t within rounding of S_total: the entries past gmax + 1 are not defined)
-  const sorted_u32x2_a4 gh = *reinterpret_cast<const sorted_u32x2_a4*>(X.guide + g);
-  uint32_t lo = gh.x, hi = gh.y;
-  const uint32_t m = (uint32_t)tq & X.mask;
-  hi = hi < (uint32_t)n ? hi : (uint32_t)n;
-  lo = lo < hi ? lo : hi;
-  // the bucket's first eight slots in two 16-byte loads (a bucket holds one slot on average, more than eight once in
-  // 1e6): reading past the bucket — at most 7 words past slot n - 1, still inside the table — is harmless, those
-  // entries are not counted.  The slots of a bucket ascend, so the count of "<= m" is the count of leading ones.
-  const rs_u32x4_a4 pa = *reinterpret_cast<const rs_u32x4_a4*>(X.slow + lo);
-  const rs_u32x4_a4 pb = *reinterpret_cast<const rs_u32x4_a4*>(X.slow + lo + 4u);
-  const uint32_t pv[8] = {pa.x, pa.y, pa.z, pa.w, pb.x, pb.y, pb.z, pb.w};
-  uint32_t k = lo;
-#pragma unroll
-  for (uint32_t i = 0; i < 8u; ++i) k += (lo + i < hi && (pv[i] & X.mask) <= m) ? 1u : 0u;
-  bool more = k == lo + 8u && k < hi;
-  while (more) {
-    const uint32_t v = X.slow[k];
-    const bool below = (v & X.mask) <= m;
-    k += below ? 1u : 0u;
-    more = below && k < hi;
-  }
-  sb_est r;
-  r.j = (int32_t)k;
-  r.near = (frac < eps) || (frac > 1.0 - eps);
-  if (c == 0ull) { r.j = 0; r.near = false; }
-  if (c >= total) { r.j = n; r.near = false; }
-  return r;
-}
 __device__ __forceinline__ int64_t sorted_below_exact(const sorted_ctx& X, uint64_t c, uint64_t total, int64_t j, int64_t n) {
   const u128 R = mul64(c, X.stot);
   j = j < 0 ? 0 : (j > n ? n : j);
@@ -1593,7 +1554,6 @@ __device__ __forceinline__ int64_t sorted_below_exact(const sorted_ctx& X, uint6
 static_assert(RS_MAX_TILES % RS_BLOCK == 0, "tile table shape");
 // PER: rows of the tile table a thread holds (PER * 256 >= n_tiles; 1, 2, 4 or 8 — the launch picks the smallest):
 // the statistics pass is unrolled over exactly the rows that exist.
-#define SORTED_WIN 2048                /* guide entries / slots of the order-statistics table staged per tile */
 #define RS_FILL_SLOTS 2048             /* slots filled per pass (8 per thread): a tile owns ~1024 */
 // FILL: how a tile's slots [T0, T1) get their ancestors.
 //   false  every thread writes its own sources' slots (one loop over [e[0], e[4])): the trip count is the wave's
@@ -1770,51 +1730,7 @@ k_offspring_tile(uint32_t k0, uint32_t k1, uint32_t u0_host, const float* __rest
   uint32_t near_bits = 0;
   constexpr bool SORTED = (kind == GMX_RESAMPLE_MULTINOMIAL_SORTED);      // `uslot` is the order-statistics table
   sorted_ctx SX;
-  // The sorted kind looks every CDF value up in the table: guide[g], then the slots of bucket g — two DEPENDENT loads
-  // per evaluation, scattered.  The tile's evaluations all fall between its first and last CDF value, i.e. into one
-  // window of the guide (~1024 entries for an average tile) and the window of slots that points to, so the workgroup
-  // stages both in LDS with two coalesced passes and evaluates from there; a tile whose window is too large (a tile
-  // owning far more than its share of the mass) reads the table in memory (block-uniform choice).
-  constexpr int WIN = SORTED ? SORTED_WIN : 1;
-  __shared__ uint32_t s_gw[WIN], s_sw[WIN + 4];
-  bool staged = false;
-  uint32_t w_g0 = 0, w_gn = 0, w_j0 = 0, w_j1 = 0;
-  if constexpr (SORTED) {
-    SX = sorted_ctx_of(uslot, n, total, sx_stot, sx_sh);
-    const uint64_t c_hi = prefix + s_g[0];
-    const double t_lo = __builtin_fma((double)(uint32_t)(prefix >> 32), 4294967296.0, (double)(uint32_t)prefix) * SX.ratio;
-    const double t_hi = __builtin_fma((double)(uint32_t)(c_hi >> 32), 4294967296.0, (double)(uint32_t)c_hi) * SX.ratio;
-    const uint64_t b_lo = (uint64_t)t_lo >> SX.sh, b_hi = ((uint64_t)t_hi >> SX.sh) + 2ull;
-    const uint64_t g_lo = b_lo ? b_lo - 1ull : 0ull, g_top = b_hi < SX.gmax + 1ull ? b_hi : SX.gmax + 1ull;
-    const uint64_t cnt = g_top >= g_lo ? g_top - g_lo + 1ull : 0ull;
-    if (cnt >= 2ull && cnt <= (uint64_t)SORTED_WIN && (u0_host & 1u)) {   // block-uniform (prefix, s_g, total are); u0_host: bit 0 = stage
-      w_g0 = (uint32_t)g_lo; w_gn = (uint32_t)cnt;
-      uint32_t tmp[SORTED_WIN / RS_BLOCK];
-#pragma unroll
-      for (int r = 0; r < SORTED_WIN / RS_BLOCK; ++r) {        // every load issued before anything waits (clamped rows)
-        const uint32_t i = (uint32_t)r * RS_BLOCK + threadIdx.x;
-        tmp[r] = SX.guide[w_g0 + (i < w_gn ? i : w_gn - 1u)];
-      }
-#pragma unroll
-      for (int r = 0; r < SORTED_WIN / RS_BLOCK; ++r) s_gw[(uint32_t)r * RS_BLOCK + threadIdx.x] = tmp[r];
-      __syncthreads();
-      w_j0 = s_gw[0]; w_j1 = s_gw[w_gn - 1u];
-      w_j1 = w_j1 < (uint32_t)n32 ? w_j1 : (uint32_t)n32;
-      w_j0 = w_j0 < w_j1 ? w_j0 : w_j1;
-      if (w_j1 - w_j0 <= (uint32_t)SORTED_WIN) {
-        staged = true;
-        const uint32_t last = (uint32_t)n32 - 1u;
-#pragma unroll
-        for (int r = 0; r < SORTED_WIN / RS_BLOCK; ++r) {
-          const uint32_t j = w_j0 + (uint32_t)r * RS_BLOCK + threadIdx.x;
-          tmp[r] = SX.slow[j < last ? j : last];
-        }
-#pragma unroll
-        for (int r = 0; r < SORTED_WIN / RS_BLOCK; ++r) s_sw[(uint32_t)r * RS_BLOCK + threadIdx.x] = tmp[r];
-      }
-      __syncthreads();
-    }
-  }
+  if constexpr (SORTED) SX = sorted_ctx_of(uslot, n, total, sx_stot, sx_sh);
   auto below_est = [&](uint64_t c) -> sb_est {
     return slots_below_est<kind == GMX_RESAMPLE_MULTINOMIAL_SORTED ? GMX_RESAMPLE_SYSTEMATIC : kind>(
         key, u0_host, c, total, n_over_total, eps, n32, uslot);              // (never called for the sorted kind)
@@ -1837,43 +1753,7 @@ k_offspring_tile(uint32_t k0, uint32_t k1, uint32_t u0_host, const float* __rest
       mv[c] = (uint32_t)tq & SX.mask;
     }
     bool more = false;
-    if (staged) {
-#pragma unroll
-      for (int c = 0; c <= CDF_VEC; ++c) {
-        uint32_t gi = gv[c] > w_g0 ? gv[c] - w_g0 : 0u;
-        gi = gi < w_gn - 2u ? gi : w_gn - 2u;
-        lov[c] = s_gw[gi]; hiv[c] = s_gw[gi + 1u];
-      }
-#pragma unroll
-      for (int c = 0; c <= CDF_VEC; ++c) {
-        hiv[c] = hiv[c] < w_j1 ? hiv[c] : w_j1;
-        lov[c] = lov[c] > w_j0 ? lov[c] : w_j0;
-        lov[c] = lov[c] < hiv[c] ? lov[c] : hiv[c];
-      }
-      uint32_t q[CDF_VEC + 1][4];
-#pragma unroll
-      for (int c = 0; c <= CDF_VEC; ++c) {
-        const uint32_t* p = s_sw + (lov[c] - w_j0);                    // (s_sw has 4 words of slack)
-        q[c][0] = p[0]; q[c][1] = p[1]; q[c][2] = p[2]; q[c][3] = p[3];
-      }
-#pragma unroll
-      for (int c = 0; c <= CDF_VEC; ++c) {
-        uint32_t k = lov[c];
-#pragma unroll
-        for (uint32_t i = 0; i < 4u; ++i) k += (lov[c] + i < hiv[c] && (q[c][i] & SX.mask) <= mv[c]) ? 1u : 0u;
-        kv[c] = k;
-        more |= (k == lov[c] + 4u && k < hiv[c]);
-      }
-      if (more) {
-#pragma unroll 1
-        for (int c = 0; c <= CDF_VEC; ++c) {
-          uint32_t k = kv[c];
-          if (k == lov[c] + 4u)
-            while (k < hiv[c] && (s_sw[k - w_j0] & SX.mask) <= mv[c]) ++k;
-          kv[c] = k;
-        }
-      }
-    } else {
+    {
 #pragma unroll
       for (int c = 0; c <= CDF_VEC; ++c) {
         const sorted_u32x2_a4 gh = *reinterpret_cast<const sorted_u32x2_a4*>(SX.guide + gv[c]);
@@ -1917,7 +1797,8 @@ k_offspring_tile(uint32_t k0, uint32_t k1, uint32_t u0_host, const float* __rest
     }
   } else {
 #pragma unroll
-    for (int c = 0; c <= CDF_VEC; ++c) R[c] = below_est(cv[c]);
+    for (int c = 1; c <= CDF_VEC; ++c) R[c] = below_est(cv[c]);
+    R[0] = below_est(cv[0]);
   }
 #pragma unroll
   for (int c = 1; c <= CDF_VEC; ++c) {
@@ -2031,11 +1912,7 @@ static int launch_offspring_tile(int kind, const uint32_t key[2], const float* l
                                  int32_t* ancestors_d, gmx_stream stream, bool pref = false, const uint32_t* u_d = nullptr) {
   uint32_t b0, b1;
   gmx_threefry2x32(key[0], key[1], 0u, 0u, &b0, &b1);           // bits32(key, 0) on the host
-  uint32_t u0 = (b0 ^ b1) >> 9;
-  if (kind == GMX_RESAMPLE_MULTINOMIAL_SORTED) {       // (no single uniform: the word carries the kind's switches)
-    static const bool stage = []() { const char* e = getenv("GENMI_SORTED_STAGE"); return !(e && e[0] == '0'); }();
-    u0 = stage ? 1u : 0u;
-  }
+  const uint32_t u0 = (b0 ^ b1) >> 9;
   const int64_t tiles = (n + RS_TILE - 1) / RS_TILE;
   const dim3 grid((unsigned)((tiles + RS_TPB - 1) / RS_TPB)), block(RS_BLOCK);
   hipStream_t st = (hipStream_t)stream;

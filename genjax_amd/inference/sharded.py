@@ -43,7 +43,7 @@ from .. import _lib
 from ..core.choice_map import ChoiceMap
 from ..random import Key, fold_in, lazy_split, split
 from ..engine import Gathered
-from .smc import SYSTEMATIC, _NoiseAhead, cdf_reference, cdf_shift
+from .smc import STRATIFIED, SYSTEMATIC, _NoiseAhead, cdf_reference, cdf_shift
 
 
 def systematic_slot_bounds(offsets, total: int, n_total: int, u0: int):
@@ -98,6 +98,9 @@ class ShardedBootstrapSweep(_NoiseAhead):
         self.step_extra = step_extra or (lambda t: ())
         self.specialize = specialize
         self.kind = _KINDS[resample] if isinstance(resample, str) else int(resample)
+        if self.kind not in (SYSTEMATIC, STRATIFIED):
+            raise NotImplementedError("ShardedBootstrapSweep: the router takes the systematic / stratified schemes (one-GPU "
+                                      "sweeps also offer multinomial, multinomial_tiled and multinomial_sorted)")
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         self.N = self.n * self.world
         _check_shard_alignment(self.n, self.world)
@@ -554,6 +557,8 @@ def sharded_importance_resample(target, k_per_rank: int, key: Key, dist, kind="s
     g, W = dist.get_rank(), dist.get_world_size()
     n, K = int(k_per_rank), int(k_per_rank) * dist.get_world_size()
     kind = _KINDS[kind] if isinstance(kind, str) else int(kind)
+    if kind not in (SYSTEMATIC, STRATIFIED):
+        raise NotImplementedError("sharded_importance_resample: the router takes the systematic / stratified schemes")
     if comm is None and W > 1:
         from .comm import make_comm
         comm = make_comm(dist, dev)

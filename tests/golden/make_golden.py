@@ -71,6 +71,10 @@ def main():
         anc = O.ancestors_multinomial_tiled(O.key(99), cdf)          # the two-stage multinomial (round 3)
         ent["multinomial_tiled"] = anc.tolist() if n_ <= 1024 else None
         ent["multinomial_tiled_sha256"] = h(anc)
+        anc = O.ancestors_multinomial_sorted(O.key(99), cdf) if n_ <= 4096 else O.ancestors_multinomial_sorted_c(O.key(99), cdf)
+        ent["multinomial_sorted"] = anc.tolist() if n_ <= 1024 else None      # multinomial with sorted uniforms (round 3)
+        ent["multinomial_sorted_sha256"] = h(anc)
+        ent["sorted_exponentials_head"] = O.sorted_exponentials(O.key(99), 8).tolist()
         if n_ <= 1024:
             ent["lw"] = f(lw)
         res[str(n_)] = ent

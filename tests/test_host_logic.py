@@ -474,7 +474,7 @@ class TestSMCMoves:
         assert res["ancestors_equal"] and res["x_equal"] and res["totals_equal"]
         assert res["lw_max_abs_diff"] == 0.0 and res["log_ml"] == res["log_ml_oracle"]
 
-    @pytest.mark.parametrize("kind", ["systematic", "stratified", "multinomial", "multinomial_tiled"])
+    @pytest.mark.parametrize("kind", ["systematic", "stratified", "multinomial", "multinomial_tiled", "multinomial_sorted"])
     def test_resample_extend_api(self, kind):
         from genjax_amd import workloads
         from genjax_amd.inference import smc
@@ -489,7 +489,7 @@ class TestSMCMoves:
         assert np.array_equal(coll.get_log_weights().numpy(), ocoll.get_log_weights())
         res = smc.resample(k1, coll, kind)
         cdf, total, M, shift = O.weight_cdf(ocoll.get_log_weights())
-        oanc = O.ancestors_multinomial_tiled(ok[1], cdf) if kind == "multinomial_tiled" else O.ancestors(smc._KINDS[kind], ok[1], cdf)
+        oanc = O.ancestors_of_kind(smc._KINDS[kind], ok[1], cdf)
         assert np.array_equal(res.ancestors.numpy(), oanc)
         ext = smc.extend(k2, res, step, lambda tr: (tr.get_retval(),), C["y"].set(float(ys[1])))
         ox = ocoll.get_particles().get_retval()[oanc]

@@ -193,6 +193,13 @@ def test_resampling_golden_and_properties():
         assert hashlib.sha256(anc_t.tobytes()).hexdigest() == g["multinomial_tiled_sha256"]
         if g["multinomial_tiled"] is not None:
             assert anc_t.tolist() == g["multinomial_tiled"]
+        # multinomial with sorted uniforms: the Python-integer statement, the C merge, the committed vectors
+        anc_s = O.ancestors_multinomial_sorted(O.key(99), cdf) if cdf.size <= 4096 else O.ancestors_multinomial_sorted_c(O.key(99), cdf)
+        assert np.array_equal(anc_s, O.ancestors_multinomial_sorted_c(O.key(99), cdf)) and np.all(np.diff(anc_s) >= 0)
+        assert hashlib.sha256(anc_s.tobytes()).hexdigest() == g["multinomial_sorted_sha256"]
+        if g["multinomial_sorted"] is not None:
+            assert anc_s.tolist() == g["multinomial_sorted"]
+        assert O.sorted_exponentials(O.key(99), 8).tolist() == g["sorted_exponentials_head"]
         assert np.all(np.diff(anc_t // 1024) >= 0)           # ordered by the ancestor's tile
 
 

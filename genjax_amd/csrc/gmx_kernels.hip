@@ -1737,41 +1737,44 @@ k_offspring_tile(uint32_t k0, uint32_t k1, uint32_t u0_host, const float* __rest
   };
   sb_est R[CDF_VEC + 1];
   if constexpr (SORTED) {
-    // all five evaluations side by side: every guide read issued before any is used, then every slot probe — written
-    // one evaluation after the other, the (rare) walk past the probed slots orders the loads: ten dependent round trips
+    // the evaluations side by side: every guide read issued before any is used, then every slot probe — written one
+    // evaluation after the other, the (rare) walk past the probed slots orders the loads: ten dependent round trips.
+    // cv[0] (the lower edge of the thread's first source) is the previous thread's cv[4]: lanes take it from their
+    // neighbour below, lane 0 of waves 1 .. 3 from the wave before through LDS (after the cold path, so a corrected
+    // value travels), and only wave 0 evaluates its own (the tile's first edge).
     uint32_t mv[CDF_VEC + 1], gv[CDF_VEC + 1], lov[CDF_VEC + 1], hiv[CDF_VEC + 1], kv[CDF_VEC + 1];
+    auto eval = [&](const int c0, const int c1) {
 #pragma unroll
-    for (int c = 0; c <= CDF_VEC; ++c) {
-      const double cd = __builtin_fma((double)(uint32_t)(cv[c] >> 32), 4294967296.0, (double)(uint32_t)cv[c]);
-      const double t = cd * SX.ratio;
-      const uint64_t tq = (uint64_t)t;
-      const double frac = t - (double)tq;
-      const double teps = __builtin_fma(t, 0x1p-49, 0x1p-40);
-      R[c].near = (frac < teps) || (frac > 1.0 - teps);
-      const uint64_t gq = tq >> SX.sh;
-      gv[c] = (uint32_t)(gq < SX.gmax ? gq : SX.gmax);
-      mv[c] = (uint32_t)tq & SX.mask;
-    }
-    bool more = false;
-    {
+      for (int c = c0; c <= c1; ++c) {
+        const double cd = __builtin_fma((double)(uint32_t)(cv[c] >> 32), 4294967296.0, (double)(uint32_t)cv[c]);
+        const double t = cd * SX.ratio;
+        const uint64_t tq = (uint64_t)t;
+        const double frac = t - (double)tq;
+        const double teps = __builtin_fma(t, 0x1p-49, 0x1p-40);
+        R[c].near = (frac < teps) || (frac > 1.0 - teps);
+        const uint64_t gq = tq >> SX.sh;
+        gv[c] = (uint32_t)(gq < SX.gmax ? gq : SX.gmax);      // (t within rounding of S_total: entries past gmax + 1 are not defined)
+        mv[c] = (uint32_t)tq & SX.mask;
+      }
 #pragma unroll
-      for (int c = 0; c <= CDF_VEC; ++c) {
+      for (int c = c0; c <= c1; ++c) {
         const sorted_u32x2_a4 gh = *reinterpret_cast<const sorted_u32x2_a4*>(SX.guide + gv[c]);
         lov[c] = gh.x; hiv[c] = gh.y;
       }
 #pragma unroll
-      for (int c = 0; c <= CDF_VEC; ++c) {
+      for (int c = c0; c <= c1; ++c) {
         hiv[c] = hiv[c] < (uint32_t)n32 ? hiv[c] : (uint32_t)n32;
         lov[c] = lov[c] < hiv[c] ? lov[c] : hiv[c];
       }
       rs_u32x4_a4 pa[CDF_VEC + 1], pb[CDF_VEC + 1];
 #pragma unroll
-      for (int c = 0; c <= CDF_VEC; ++c) {        // eight slots per evaluation (past slot n - 1: still inside the table, not counted)
+      for (int c = c0; c <= c1; ++c) {        // eight slots per evaluation (past slot n - 1: still inside the table, not counted)
         pa[c] = *reinterpret_cast<const rs_u32x4_a4*>(SX.slow + lov[c]);
         pb[c] = *reinterpret_cast<const rs_u32x4_a4*>(SX.slow + lov[c] + 4u);
       }
+      bool more = false;
 #pragma unroll
-      for (int c = 0; c <= CDF_VEC; ++c) {
+      for (int c = c0; c <= c1; ++c) {        // the slots of a bucket ascend: the count of "<= m" is the count of leading ones
         const uint32_t pv[8] = {pa[c].x, pa[c].y, pa[c].z, pa[c].w, pb[c].x, pb[c].y, pb[c].z, pb[c].w};
         uint32_t k = lov[c];
 #pragma unroll
@@ -1779,22 +1782,25 @@ k_offspring_tile(uint32_t k0, uint32_t k1, uint32_t u0_host, const float* __rest
         kv[c] = k;
         more |= (k == lov[c] + 8u && k < hiv[c]);
       }
-      if (more) {
+      if (more) {                              // a bucket with more than eight slots below t: once in ~1e5 evaluations
 #pragma unroll 1
-        for (int c = 0; c <= CDF_VEC; ++c) {
+        for (int c = c0; c <= c1; ++c) {
           uint32_t k = kv[c];
           if (k == lov[c] + 8u)
             while (k < hiv[c] && (SX.slow[k] & SX.mask) <= mv[c]) ++k;
           kv[c] = k;
         }
       }
-    }
 #pragma unroll
-    for (int c = 0; c <= CDF_VEC; ++c) {
-      R[c].j = (int32_t)kv[c];
-      if (cv[c] == 0ull) { R[c].j = 0; R[c].near = false; }
-      if (cv[c] >= total) { R[c].j = n32; R[c].near = false; }
-    }
+      for (int c = c0; c <= c1; ++c) {
+        R[c].j = (int32_t)kv[c];
+        if (cv[c] == 0ull) { R[c].j = 0; R[c].near = false; }
+        if (cv[c] >= total) { R[c].j = n32; R[c].near = false; }
+      }
+    };
+    R[0].j = 0; R[0].near = false;
+    eval(1, CDF_VEC);
+    if (wave == 0) eval(0, 0);
   } else {
 #pragma unroll
     for (int c = 1; c <= CDF_VEC; ++c) R[c] = below_est(cv[c]);
@@ -1831,6 +1837,12 @@ k_offspring_tile(uint32_t k0, uint32_t k1, uint32_t u0_host, const float* __rest
     // a corrected upper bound is the next lane's lower bound
     const uint32_t up = wave_shr1_u32((uint32_t)e[CDF_VEC], (uint32_t)fixed0);
     e[0] = (lane == 0) ? fixed0 : (int32_t)up;
+  }
+  if constexpr (SORTED) {        // lane 0 of waves 1 .. 3: the (settled) upper edge of the wave before
+    __shared__ int32_t s_edge[RS_WAVES];
+    if (lane == 63) s_edge[wave] = e[CDF_VEC];
+    __syncthreads();
+    if (lane == 0 && wave > 0) e[0] = s_edge[wave - 1];
   }
   // ONE loop over the thread's slots [e[0], e[4]) — its trip count diverges over the thread's total offspring
   // (mean 4) instead of four loops each diverging over one source's (mean 1, max ~4); slots are < 2^31.

@@ -23,6 +23,10 @@ timeout 300 python tools/bench_sweep3.py 2> /dev/null | grep "^{" > $out/${tag}_
 timeout 300 python tools/bench_mixture.py 2> /dev/null | tail -1 > $out/${tag}_mixture_config5.json
 timeout 300 python tools/bench_hmc.py 2> /dev/null | tail -1 > $out/${tag}_hmc.json
 timeout 300 python tools/bench_kinds.py 2> /dev/null | tail -1 > $out/${tag}_kinds.json
+# the ordered resamplers beside each other: the chain without the background stream, the kernel alone, the sorted kind's kernels
+for k in systematic stratified multinomial_sorted; do RESAMPLE=$k timeout 120 python tools/experiments/chain_only.py 2> /dev/null | tail -1; done > $out/${tag}_chain_only.txt
+timeout 120 python tools/experiments/sorted_micro.py 2> /dev/null | tail -1 > $out/${tag}_sorted_micro.json
+timeout 300 bash tools/experiments/prof_kind.sh multinomial_sorted ${tag}_kind_multinomial_sorted > $out/${tag}_kind_multinomial_sorted.txt 2>&1
 python - <<PY
 import json
 b = json.load(open("$out/${tag}_bench.json"))

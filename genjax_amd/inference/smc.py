@@ -886,6 +886,12 @@ class BootstrapSweep(_NoiseAhead):
     chain, filling the issue slots the chain's launch boundaries and memory round trips leave idle.  Same keys, same
     operations in the same order: every particle, weight and ancestor is the one the one-stream form computes.
     Measured on MI355X (config 2): 17.9 -> 15.8 us/step.
+
+    `resample`: "systematic" (default), "stratified", and three multinomial forms with the same offspring law —
+    "multinomial" (iid slot order: a random particle per slot), "multinomial_tiled" (ordered by the ancestor's CDF tile)
+    and "multinomial_sorted" (the uniforms drawn sorted: ordered by ancestor, on the systematic resampler's kernel; the
+    fastest of the three: DESIGN.md §4).  The background stream also draws what the resampler needs from its key alone:
+    the stratified slot uniforms, the sorted multinomial's order-statistics table.
     """
 
     NOISE_LDS_PAD = 56000      # bytes of unused LDS per noise workgroup: two of them per CU (160 KB)

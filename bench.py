@@ -407,6 +407,22 @@ def other_configs():
                           "agrees_with_generating_component": float((box["idx"].cpu().numpy() == z).mean())}
     except Exception as e:
         out["config5"] = {"error": repr(e)[:300]}
+    try:        # ---- config 2 under the other resampling schemes (the headline is systematic) ----
+        n, T = N_PARTICLES, T_STEPS
+        ys = workloads.lgssm_data(T)
+        init, step = workloads.make_lgssm(G)
+        kinds = {}
+        for kind in ("stratified", "multinomial_sorted", "multinomial_tiled", "multinomial"):
+            sw = smc.BootstrapSweep(init, step, n, T, resample=kind).prepare(G.key(314159), torch.from_numpy(ys)).capture()
+            dt = timed(sw.launch, 3)
+            kinds[kind] = {"us_per_step": 1e6 * dt / T, "particle_steps_per_s": n * T / dt, "log_ml": sw.log_ml()}
+            del sw
+        out["config2_resampling_kinds"] = dict(
+            kinds, workload="BASELINE config 2 (1e6 particles x 100 steps, one hipGraph) with resample=<kind>; the three "
+                            "multinomial forms share the offspring law and differ in slot order (iid / by tile / sorted)",
+            kalman_log_ml=workloads.kalman_log_ml(ys))
+    except Exception as e:
+        out["config2_resampling_kinds"] = {"error": repr(e)[:300]}
     return out
 
 

@@ -2402,9 +2402,9 @@ extern "C" int gmx_resample_tiles_u(int kind, const uint32_t key[2], const float
 // The order-statistics table of a resampling depends on its key and n only: two launches, meant for the background
 // stream of a sweep (2-D: one grid row per key, `lds_pad` caps the residency like the normals' programs).
 //   k_sorted_exp    workgroup = 1024 slots: E_j, the tile-local inclusive sums (u32: < 2^31), the tile's sum
-//   k_sorted_guide  every workgroup reduces the <= 2048 tile sums to its offset and S_total (the 977-fold pass of
-//                   k_offspring_tile), rewrites its slots as the low words of the GLOBAL sums and fills the guide:
-//                   slot j writes guide[g] = j for the buckets g in (bucket(S_{j-1}), bucket(S_j)] (one on average)
+//   k_sorted_offsets one workgroup per key: the tile sums -> tile offsets, S_total, sh
+//   k_sorted_guide  a workgroup rewrites its slots as the low words of the GLOBAL sums and fills the guide: slot j owns
+//                   the buckets g in (bucket(S_{j-1}), bucket(S_j)] (one on average), written through LDS
 __global__ void __launch_bounds__(GMX_BLOCK)
 k_sorted_exp(const uint32_t* __restrict__ keys, uint32_t hk0, uint32_t hk1, int64_t n, size_t words, uint32_t* __restrict__ out) {
   __shared__ uint64_t s_w[GMX_BLOCK / GMX_WAVE];
@@ -2437,10 +2437,60 @@ k_sorted_exp(const uint32_t* __restrict__ keys, uint32_t hk0, uint32_t hk1, int6
   if (threadIdx.x == 0) reinterpret_cast<uint64_t*>(row + L.off_tsum)[blockIdx.x] = all;
 }
 
+// one workgroup per resampling: the <= 2048 tile sums -> the tiles' offsets, S_total and sh (thread t owns the tiles
+// [t per, (t + 1) per): a u64 wave scan and four wave totals)
+__global__ void __launch_bounds__(GMX_BLOCK)
+k_sorted_offsets(const uint32_t* __restrict__ keys, uint32_t hk0, uint32_t hk1, int64_t n, size_t words, uint32_t* __restrict__ out) {
+  __shared__ uint64_t s_w[GMX_BLOCK / GMX_WAVE];
+  gmx_key key; key.k0 = hk0; key.k1 = hk1;
+  if (keys) {
+    key.k0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)keys[2 * blockIdx.y]);
+    key.k1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)keys[2 * blockIdx.y + 1]);
+  }
+  const gmx_sorted_layout L = gmx_sorted_layout_of(n);
+  uint32_t* row = out + (size_t)blockIdx.y * words;
+  const uint64_t* tsum = reinterpret_cast<const uint64_t*>(row + L.off_tsum);
+  uint64_t* toff = reinterpret_cast<uint64_t*>(row + L.off_toff);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tiles = (int)L.tiles;
+  const int per = (tiles + GMX_BLOCK - 1) / GMX_BLOCK;                 // 1 .. 8, uniform
+  uint64_t tv[RS_MAX_TILES / GMX_BLOCK];
+  uint64_t run = 0;
+#pragma unroll
+  for (int r = 0; r < RS_MAX_TILES / GMX_BLOCK; ++r) {
+    tv[r] = 0ull;
+    if (r < per) {
+      const int t = (int)threadIdx.x * per + r;
+      const uint64_t v = tsum[t < tiles ? t : tiles - 1];
+      tv[r] = (t < tiles) ? v : 0ull;
+      run += tv[r];
+    }
+  }
+  const uint64_t inc = wave_scan_u64(run);
+  if (lane == 63) s_w[wave] = inc;
+  __syncthreads();
+  uint64_t off = 0, all = 0;
+#pragma unroll
+  for (int w = 0; w < GMX_BLOCK / GMX_WAVE; ++w) { const uint64_t v = s_w[w]; all += v; off += (w < wave) ? v : 0ull; }
+  uint64_t at = off + (inc - run);
+#pragma unroll
+  for (int r = 0; r < RS_MAX_TILES / GMX_BLOCK; ++r) {
+    if (r < per) {
+      const int t = (int)threadIdx.x * per + r;
+      if (t < tiles) toff[t] = at;
+      at += tv[r];
+    }
+  }
+  if (threadIdx.x == 0) {
+    const uint64_t stot = all + gmx_sorted_exp(key, (uint64_t)n);
+    toff[tiles] = stot;
+    row[L.off_sh] = gmx_sorted_shift(stot, L.ng);
+  }
+}
+
 #define SORTED_FILL 2048               /* guide entries filled per pass (8 per thread): a tile owns ~1024 */
 __global__ void __launch_bounds__(GMX_BLOCK)
 k_sorted_guide(const uint32_t* __restrict__ keys, uint32_t hk0, uint32_t hk1, int64_t n, size_t words, uint32_t* __restrict__ out) {
-  __shared__ uint64_t s_below[GMX_BLOCK / GMX_WAVE], s_all[GMX_BLOCK / GMX_WAVE];
   __shared__ uint32_t s_last[GMX_BLOCK];
   __shared__ __attribute__((aligned(16))) uint32_t s_mark[SORTED_FILL];
   __shared__ uint32_t s_carry[GMX_BLOCK / GMX_WAVE];
@@ -2453,39 +2503,16 @@ k_sorted_guide(const uint32_t* __restrict__ keys, uint32_t hk0, uint32_t hk1, in
   uint32_t* row = out + (size_t)blockIdx.y * words;
   uint32_t* guide = row + L.off_guide;
   const uint64_t* tsum = reinterpret_cast<const uint64_t*>(row + L.off_tsum);
-  uint64_t* toff = reinterpret_cast<uint64_t*>(row + L.off_toff);
+  const uint64_t* toff = reinterpret_cast<const uint64_t*>(row + L.off_toff);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int tile = (int)blockIdx.x, tiles = (int)L.tiles;
   const int64_t j0 = (int64_t)tile * GMX_SORTED_TILE + (int64_t)threadIdx.x * 4;
   const uint4 loc = *reinterpret_cast<const uint4*>(row + j0);
   const uint64_t own = tsum[tile];
-  uint64_t tv[RS_MAX_TILES / GMX_BLOCK];
-#pragma unroll
-  for (int r = 0; r < RS_MAX_TILES / GMX_BLOCK; ++r) {          // loads only (clamped rows): one round trip
-    const int t = r * GMX_BLOCK + (int)threadIdx.x;
-    tv[r] = tsum[t < tiles ? t : tiles - 1];
-  }
-  uint64_t below = 0, all = 0;
-#pragma unroll
-  for (int r = 0; r < RS_MAX_TILES / GMX_BLOCK; ++r) {
-    const int t = r * GMX_BLOCK + (int)threadIdx.x;
-    all += (t < tiles) ? tv[r] : 0ull;
-    below += (t < tile) ? tv[r] : 0ull;
-  }
-  below = wave_sum_u64(below);
-  all = wave_sum_u64(all);
-  if (lane == 0) { s_below[wave] = below; s_all[wave] = all; }
+  const uint64_t below = toff[tile], stot = toff[tiles];        // k_sorted_offsets wrote them
+  const uint32_t sh = row[L.off_sh];
   s_last[threadIdx.x] = loc.w;
   __syncthreads();
-  below = 0; all = 0;
-#pragma unroll
-  for (int w = 0; w < GMX_BLOCK / GMX_WAVE; ++w) { below += s_below[w]; all += s_all[w]; }
-  const uint64_t stot = all + gmx_sorted_exp(key, (uint64_t)n);
-  const uint32_t sh = gmx_sorted_shift(stot, L.ng);
-  if (threadIdx.x == 0) {
-    toff[tile] = below;
-    if (tile == 0) { toff[tiles] = stot; row[L.off_sh] = sh; }
-  }
   // the tile's slots as low words of the global sums; slot j owns the guide entries (bucket(S_{j-1}), bucket(S_j)]
   const uint32_t lv[4] = {loc.x, loc.y, loc.z, loc.w};
   const int32_t gA = tile == 0 ? 0 : (int32_t)(below >> sh) + 1;             // the tile's first guide entry ...
@@ -2560,6 +2587,7 @@ static int launch_sorted_uniforms(const uint32_t* keys_d, const uint32_t* hkey, 
   const dim3 grid((unsigned)L.tiles, (unsigned)rows), block(GMX_BLOCK);
   const uint32_t h0 = hkey ? hkey[0] : 0u, h1 = hkey ? hkey[1] : 0u;
   hipLaunchKernelGGL(k_sorted_exp, grid, block, (size_t)lds_pad, (hipStream_t)stream, keys_d, h0, h1, n, L.words, out_d);
+  hipLaunchKernelGGL(k_sorted_offsets, dim3(1, (unsigned)rows), block, 0, (hipStream_t)stream, keys_d, h0, h1, n, L.words, out_d);
   hipLaunchKernelGGL(k_sorted_guide, grid, block, (size_t)lds_pad, (hipStream_t)stream, keys_d, h0, h1, n, L.words, out_d);
   GMX_HIP(hipGetLastError());
   return 0;

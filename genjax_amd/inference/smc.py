@@ -704,6 +704,7 @@ class _NoiseAhead:
 
     NOISE_LDS_PAD = 56000      # bytes of unused LDS per noise workgroup: two of them per CU (160 KB)
     NOISE_GROUP = 10           # steps per group of noise launches (the noise runs one group ahead of the chain)
+    NOISE_RING = 2             # groups of noise buffers (the background stream runs at most NOISE_RING - 1 groups ahead)
     _noise_offset = 0
     _noise_total = None
 
@@ -727,6 +728,8 @@ class _NoiseAhead:
             self._noise_progs[id(P)] = [(root, NoiseProgram([P.noise[k_] for k_ in idx], (n,)), idx)
                                         for root, idx in by_root.items()]
         self.noise_group = max(1, min(int(os.environ.get("GENMI_NOISE_GROUP", self.NOISE_GROUP)), T))
+        # the ring of noise buffers: NOISE_RING groups, so the background stream may run NOISE_RING - 1 groups ahead
+        self.noise_ring = max(2, int(os.environ.get("GENMI_NOISE_RING", self.NOISE_RING)))
         # groups of steps [start, end): the noise of group g + 1 is issued before the chain of group g.  The chain
         # can only start once the FIRST group's noise is there, so the groups grow 1, 2, 4, ... up to noise_group
         self.noise_groups, self.noise_slot = [], []
@@ -734,13 +737,13 @@ class _NoiseAhead:
         while t0 < T:
             t1 = min(T, t0 + min(size, self.noise_group))
             for t in range(t0, t1):
-                self.noise_slot.append((len(self.noise_groups) % 2, t - t0))
+                self.noise_slot.append((len(self.noise_groups) % self.noise_ring, t - t0))
             self.noise_groups.append((t0, t1))
             t0, size = t1, size * 2
         S = max(len(P.noise) for P in chain_progs)
         # two groups of noise buffers: the background stream fills one while the chain reads the other.
         # [half, draw, row of the group, n]: a draw's rows are contiguous, so ONE launch can fill several steps
-        self.zbuf = torch.zeros((2, S, self.noise_group, n), dtype=torch.float32, device=dev)
+        self.zbuf = torch.zeros((self.noise_ring, S, self.noise_group, n), dtype=torch.float32, device=dev)
         self._noise_stream = torch.cuda.Stream(device=dev) if be.uses_streams else None
         pad = int(os.environ.get("GENMI_NOISE_LDS_PAD", self.NOISE_LDS_PAD))
         for plist in self._noise_progs.values():
@@ -838,18 +841,20 @@ class _NoiseAhead:
                 return
             if two:
                 with torch.cuda.stream(Bs):
-                    if g >= 2:
-                        Bs.wait_event(done[g - 2])
+                    if g >= ring:
+                        Bs.wait_event(done[g - ring])
                     self._launch_noise_group(g)
                     ready[g] = torch.cuda.Event()
                     ready[g].record(Bs)
             else:
                 self._launch_noise_group(g)
 
-        noise_group(0)
+        ring = getattr(self, "noise_ring", 2)
+        for g in range(min(ring - 1, groups)):
+            noise_group(g)
         for g in range(groups):
-            if g + 1 < groups:
-                noise_group(g + 1)
+            if g + ring - 1 < groups:
+                noise_group(g + ring - 1)
             if two and not skip_noise:
                 A.wait_event(ready[g])
             for t in range(*spans[g]):
@@ -1242,7 +1247,7 @@ class BootstrapSweep(_NoiseAhead):
         dev = self.zbuf.device
         # (the sorted multinomial's row is its whole order-statistics table: gmx_sorted_uniforms_words(n) words)
         row_words = int(_lib.get().c.gmx_sorted_uniforms_words(self.n)) if self.kind == MULTINOMIAL_SORTED else self.n
-        self.ubuf = torch.zeros((2, self.noise_group, row_words), dtype=torch.int32, device=dev)
+        self.ubuf = torch.zeros((self.noise_ring, self.noise_group, row_words), dtype=torch.int32, device=dev)
         self._u_keys = []
         for t0, t1 in self.noise_groups:
             # stratified: the resampling key itself; the two-stage multinomial: its first child (stage 1's key)

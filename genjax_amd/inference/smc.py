@@ -704,7 +704,7 @@ class _NoiseAhead:
 
     NOISE_LDS_PAD = 56000      # bytes of unused LDS per noise workgroup: two of them per CU (160 KB)
     NOISE_GROUP = 10           # steps per group of noise launches (the noise runs one group ahead of the chain)
-    NOISE_RING = 2             # groups of noise buffers (the background stream runs at most NOISE_RING - 1 groups ahead)
+    NOISE_RING = 3             # groups of noise buffers (the background stream runs at most NOISE_RING - 1 groups ahead)
     _noise_offset = 0
     _noise_total = None
 
@@ -729,7 +729,10 @@ class _NoiseAhead:
                                         for root, idx in by_root.items()]
         self.noise_group = max(1, min(int(os.environ.get("GENMI_NOISE_GROUP", self.NOISE_GROUP)), T))
         # the ring of noise buffers: NOISE_RING groups, so the background stream may run NOISE_RING - 1 groups ahead
-        self.noise_ring = max(2, int(os.environ.get("GENMI_NOISE_RING", self.NOISE_RING)))
+        # (measured on MI355X, config 2: 14.50 -> 14.32 us/step with 3, 14.27 with 4; the sorted multinomial, whose
+        # background stream also builds tables, is better off with 2: 21.2 vs 21.9 — profiles/r03cd_ring_*.json)
+        ring = 2 if getattr(self, "kind", None) == MULTINOMIAL_SORTED else self.NOISE_RING
+        self.noise_ring = max(2, int(os.environ.get("GENMI_NOISE_RING", ring)))
         # groups of steps [start, end): the noise of group g + 1 is issued before the chain of group g.  The chain
         # can only start once the FIRST group's noise is there, so the groups grow 1, 2, 4, ... up to noise_group
         self.noise_groups, self.noise_slot = [], []
@@ -823,7 +826,8 @@ class _NoiseAhead:
     def _enqueue_noise_ahead(self, skip_vm=False, skip_noise=False):
         """The sweep on TWO streams: the chain [site program' -> resampler] per step on the current one, the noise
         programs on the background stream, one group of steps ahead (group g + 1's noise is issued before group g's
-        chain; it may overwrite half (g + 1) % 2 of the ring once the chain of group g - 1 has read it; the groups
+        chain; with a ring of R groups of buffers, group g + R - 1's before group g's chain: it may overwrite slot (g - 1) % R
+        once the chain of group g - 1 has read it; the groups
         grow 1, 2, 4, ... steps up to noise_group, so the chain starts after ONE noise launch).  Capturable:
         the background stream joins the capture through the first event wait and is joined back at the end.
         Without streams (the CPU mirror of the C-ABI) the same launches run in issue order."""

@@ -500,7 +500,21 @@ class Vmap(GenerativeFunction):
                 prev_t = {"value": Sym(old_v, None), "score": Sym(old_s, None)}
             else:
                 prev_t = prev_at(inner_prev, t)
-            if kind == "index":
+            if kind == "index" and _has_step_rows(prev_t):
+                # the element runs a counted loop itself (a plate of long scans): its outputs are stored inside that loop,
+                # so there is no selecting between an edited and a carried-over copy afterwards — the element is traced
+                # once, with the request, under the gate idx == j (static._gate_site)
+                sub = req.sub
+                m_ = {"update": "update", "regen": "regen"}.get(sub.kind, "static_edit")
+                con_ = sub.constraint if sub.kind == "update" else ChoiceMap.empty()
+                here = t == req.idx
+                outer = ctx.gate
+                ctx.gate = here if outer is None else (outer & here)
+                try:
+                    rec, ret, w, _ = call_gen_fn(ctx, m_, self.gen_fn, key, args_t, con_, prev_t, sub, req_leaves, addr)
+                finally:
+                    ctx.gate = outer
+            elif kind == "index":
                 sub = req.sub
                 m_ = {"update": "update", "regen": "regen"}.get(sub.kind, "static_edit")
                 con_ = sub.constraint if sub.kind == "update" else ChoiceMap.empty()
@@ -1220,7 +1234,21 @@ class Scan(GenerativeFunction):
             carry_in = rebuild(ctree, [Expr(v) for v in cvars])
             ctx.mark_changed(_flat_exprs(carry_in))           # a loop-carried value: changed, as far as the trace can tell
             prev_t = prev_at(inner_prev, t)
-            if sub_mode == "index":
+            if sub_mode == "index" and (_has_step_rows(prev_t) or ctx.gate is not None):
+                # the step runs a counted loop itself (a scan of plates / scans), or this scan is an element of a plate
+                # edited at ONE index: traced once, with the request, under the gate idx == t (static._gate_site)
+                sub = req.sub
+                m_ = {"update": "update", "regen": "regen"}.get(sub.kind, "static_edit")
+                con_ = sub.constraint if sub.kind == "update" else ChoiceMap.empty()
+                here = t == req.idx
+                outer = ctx.gate
+                ctx.gate = here if outer is None else (outer & here)
+                try:
+                    rec, ret, w, _ = call_gen_fn(ctx, m_, self.kernel_gen_fn, Expr(key0.node) if key0 is not None else None,
+                                                 (carry_in, x_t), con_, prev_t, sub, req_leaves, addr)
+                finally:
+                    ctx.gate = outer
+            elif sub_mode == "index":
                 # edit_index (scan.py:325-416) in the loop: every iteration traces BOTH the sub-request on step t (with
                 # the caller's key, not a chained one) and the plain carry-over, and keeps the edit where idx == t — the
                 # form the unrolled code uses for a per-particle idx; a Python-int idx is the same test against a constant

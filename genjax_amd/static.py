@@ -582,6 +582,7 @@ class _Ctx:
         self.changed: set = set()        # node indices whose value differs from the previous trace
         self.memo: dict = {}
         self.store_sites = True          # False: the caller stores only what it needs (MinimalGenerate)
+        self.gate = None                 # an edit applies only where this boolean holds (IndexRequest around a loop)
 
     def mark_changed(self, v):
         for n in _nodes_of(v):
@@ -825,6 +826,32 @@ def _rec_score(rec):
     return acc if acc is not None else 0.0          # a callee without sites scores 0 (static.py:102-105: an empty sum)
 
 
+def _gate_site(ctx, gate, out, prev, dist, args):
+    """An edited leaf under a gate (`IndexRequest(idx, request)` around an element that runs a counted loop: the element
+    is traced ONCE, with the request; where the gate does not hold a site does what carrying it over does — an empty
+    Update: it keeps its value and is re-scored if its arguments changed (the step after an edited scan step sees a new
+    carry: scan.py:325-416; the other elements of a plate see nothing new: vmap.py:277-332)."""
+    rec, ret, w, s = out
+    pv, ps = prev["value"].value, prev["score"].value
+    nv = rec.value.value if isinstance(rec.value, Sym) else rec.value
+    ns = rec.score.value if isinstance(rec.score, Sym) else rec.score
+    if ctx.args_changed(dist.canon(args)):
+        s_co = dist.sym_logpdf(pv, dist.canon(args))
+        w_co = s_co - ps
+    else:
+        s_co, w_co = ps, None
+    v = nv if nv is pv else T.where(gate, nv, pv)
+    sc = ns if ns is s_co else T.where(gate, ns, s_co)
+    if w is None and w_co is None:
+        wg = None
+    else:
+        wg = T.where(gate, w if w is not None else 0.0, w_co if w_co is not None else 0.0)
+    ret = v if ret is nv else ret
+    if nv is not pv:
+        ctx.mark_changed(v)
+    return _SiteRec(rec.gen_fn, v, sc, discard=rec.discard), ret, wg, sc
+
+
 def call_gen_fn(ctx, mode, gen_fn, key, args, constraint, prev, req, req_leaves, addr):
     """Trace one callee; returns (record, retval, weight, score)."""
     from .core.generative import GenerativeFunctionClosure
@@ -838,6 +865,8 @@ def call_gen_fn(ctx, mode, gen_fn, key, args, constraint, prev, req, req_leaves,
             if req.kind == "update":
                 constraint = req.constraint
         out = _leaf_call(ctx, mode, gen_fn, key, args, constraint, prev, req, req_leaves)
+        if ctx.gate is not None and prev is not None and mode not in ("simulate", "generate", "assess"):
+            out = _gate_site(ctx, ctx.gate, out, prev, gen_fn, args)
         _store_site(ctx, out[0])
         return out
     if isinstance(gen_fn, StaticGenerativeFunction):

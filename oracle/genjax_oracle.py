@@ -1289,6 +1289,24 @@ def scan_edit_index(sc: "Scan", k, trace: "VmapTrace", args, idx: int, edit):
 # inside the function a plate maps (vmap.py:236-275 over scan.py:509-594).  The discard of a nested edit is not restated.
 Vmap.update = lambda self, k, trace, chm, args: vmap_update(self, k, trace, chm, args)
 Scan.update = lambda self, k, trace, chm, args: scan_edit(self, k, trace, args, update=chm) + (ChoiceMap(),)
+Scan.regenerate = lambda self, k, trace, selected, args: scan_edit(self, k, trace, args, regenerate=selected) + (ChoiceMap(),)
+
+
+def vmap_edit_index_batched(vm: "Vmap", k, trace: "VmapTrace", idx, edit_all, args):
+    """Vmap.edit_index (vmap.py:277-332) when the elements' traces are themselves combinator traces (a plate of scans:
+    leaves [batch, A, T], the plate axis in the MIDDLE, which `_slice_last` / `_set_last` do not address): the elements
+    are independent, so editing element idx with the caller's key is editing EVERY element with that key (broadcast
+    over the plate) and keeping the result at idx only; every other element is carried over.  `edit_all(keys
+    [batch, A, 2], inner trace, args [batch, A]) -> (new inner trace, w [batch, A])`; idx: an int or one per particle."""
+    batch = np.asarray(k).shape[:-1]
+    a, n = vm._prep(args, batch)
+    kb = np.ascontiguousarray(np.broadcast_to(np.asarray(k)[..., None, :], tuple(batch) + (n, 2)))
+    new_all, w_all = edit_all(kb, trace.inner, a)
+    here = np.arange(n).reshape((1,) * len(batch) + (n,)) == np.asarray(idx).reshape(np.shape(idx) + (1,))
+    here = np.broadcast_to(here, tuple(batch) + (n,))
+    new_inner = trace_where(here, new_all, trace.inner)
+    w = np.where(here, np.broadcast_to(np.asarray(w_all, np.float32), here.shape), np.float32(0.0)).sum(-1, dtype=np.float32)
+    return VmapTrace(vm, new_inner, vm._plate_sum(new_inner.get_score(), batch), new_inner.get_retval()), w
 
 
 class Repeat(Vmap):
@@ -1912,11 +1930,16 @@ def trace_where(mask, new, old):
             return tuple(pick(x, y) for x, y in zip(a, b))
         a, b = np.asarray(a), np.asarray(b)
         if a.shape[: mask.ndim] != mask.shape:
-            return a
+            if b.shape[: mask.ndim] != mask.shape or a.ndim > b.ndim:
+                return a
+            a = np.broadcast_to(a, b.shape)          # a launch-uniform new value (a constraint) against batched old ones
         m = mask.reshape(mask.shape + (1,) * (a.ndim - mask.ndim))
         return np.where(m, a, b)
     if isinstance(new, DistTrace):
         return DistTrace(new.gen_fn, new.args, pick(new.value, old.value), pick(new.score, old.score))
+    if isinstance(new, VmapTrace):
+        return VmapTrace(new.gen_fn, trace_where(mask, new.inner, old.inner), pick(new.score, old.score),
+                         pick(new.retval, old.retval))
     return StaticTrace(new.gen_fn, new.args, pick(new.retval, old.retval),
                        OrderedDict((a, trace_where(mask, s, old.subtraces[a])) for a, s in new.subtraces.items()))
 

@@ -2041,6 +2041,118 @@ def check_nested_edits(A, T, n=9):
         assert tuple(sub.get_score().shape) == (n, A)
 
 
+def check_nested_index_edits(A=20, T=24, n=7):
+    """`IndexRequest` through two nested counted loops (vmap.py:277-332 over scan.py:325-594), traced once under a gate
+    (static._gate_site) because the element's outputs are stored inside its own loop:
+      a plate of long scans — IndexRequest(a, Regenerate / Update) with a Python-int index and one index per particle,
+      and IndexRequest(a, StaticRequest({"steps": IndexRequest(t, Regenerate)})): ONE step of ONE series, whose successor
+      is re-scored against the new carry — weights, scores, return values and every choice against the oracle, the last
+      one also against scipy (incl. the reference's own Regenerate weight: the regenerated site's density ratio counts);
+      a scan whose step runs a plate — IndexRequest(t, Regenerate of the plate's latent)."""
+    import genjax_amd as G
+    from genjax_amd import (ChoiceMapBuilder as C, Diff, IndexRequest, Regenerate, SelectionBuilder as S, StaticRequest,
+                            Update, numpy as jnp)
+    from scipy import stats
+    dev = G.split(G.key(0), 1).dev.device if hasattr(G.split(G.key(0), 1), "dev") else None
+
+    def mk(g, scan_of):
+        @g.gen
+        def step(x, _):
+            xn = g.normal(0.9 * x, 0.5) @ "x"
+            g.normal(xn, 1.0) @ "y"
+            return xn, None
+
+        @g.gen
+        def series(x0):
+            xT, _ = scan_of(step)(x0, None) @ "steps"
+            return xT
+        return series, step
+    (s, _), (os_, ostep) = mk(G, lambda f: f.scan(n=T)), mk(O, lambda f: O.Scan(f, T))
+    x0 = np.linspace(-1, 1, A).astype(np.float32)
+    model, omodel = s.vmap(in_axes=(0,)), O.Vmap(os_, in_axes=(0,))
+    tr = model.simulate(G.split(G.key(1), n), (jnp.array(x0),))
+    otr = omodel.simulate(O.split(O.key(1), n), (x0,))
+    ynew = (np.arange(T, dtype=np.float32) * 0.1)
+    a_i, t_i = min(2, A - 1), 5
+
+    class _ScanIdx:                      # the oracle's sub-request object for a static edit: scan.edit_index on "steps"
+        def edit(self, k, subtrace, gen_fn, args):
+            return O.scan_edit_index(gen_fn, k, subtrace, args, t_i,
+                                     lambda kk, sl, a: ostep.regenerate(kk, sl, lambda addr: addr == ("x",), a)[:2])
+    cases = [("regen", Regenerate(S["steps", "x"]),
+              lambda kb, inner, a: os_.regenerate(kb, inner, lambda addr: addr == ("steps", "x"), a)[:2]),
+             ("update", Update(C["steps", "y"].set(ynew)),
+              lambda kb, inner, a: os_.update(kb, inner, O.C.d({("steps", "y"): ynew}), a)[:2]),
+             ("one step", StaticRequest({"steps": IndexRequest(t_i, Regenerate(S["x"]))}),
+              lambda kb, inner, a: os_.edit_static(kb, inner, {"steps": _ScanIdx(), ("steps",): _ScanIdx()}, a))]
+    for idx in (a_i, (np.arange(n) * 3) % A):
+        for name, sub, edit_all in cases:
+            gi = idx if isinstance(idx, int) else torch.from_numpy(idx.astype(np.int32)).to(tr.get_score().device)
+            new, w, _, bwd = IndexRequest(gi, sub).edit(G.split(G.key(2), n), tr, Diff.no_change((jnp.array(x0),)))
+            onew, ow = O.vmap_edit_index_batched(omodel, O.split(O.key(2), n), otr, idx, edit_all, (x0,))
+            assert np.array_equal(w.cpu().numpy(), ow), (name, np.abs(w.cpu().numpy() - ow).max())
+            for ad in (("steps", "x"), ("steps", "y")):
+                assert np.array_equal(new.get_choices()[ad].cpu().numpy(), onew.get_choices()[ad]), (name, ad)
+            assert np.array_equal(new.get_score().cpu().numpy(), onew.get_score()), name
+            assert np.array_equal(new.get_retval().cpu().numpy(), onew.get_retval()), name
+            assert isinstance(bwd, IndexRequest)
+            if name == "one step" and isinstance(idx, int):
+                x = new.get_choices()["steps", "x"].cpu().numpy().astype(np.float64)
+                xo = tr.get_choices()["steps", "x"].cpu().numpy().astype(np.float64)
+                y = tr.get_choices()["steps", "y"].cpu().numpy().astype(np.float64)
+                ch = x != xo
+                assert ch[:, idx, t_i].all() and ch.sum() == n          # ONE value per particle changed
+                lp = stats.norm.logpdf
+                want = (lp(x[:, idx, t_i], 0.9 * xo[:, idx, t_i - 1], 0.5) - lp(xo[:, idx, t_i], 0.9 * xo[:, idx, t_i - 1], 0.5)
+                        + lp(y[:, idx, t_i], x[:, idx, t_i], 1.0) - lp(y[:, idx, t_i], xo[:, idx, t_i], 1.0)
+                        + lp(xo[:, idx, t_i + 1], 0.9 * x[:, idx, t_i], 0.5) - lp(xo[:, idx, t_i + 1], 0.9 * xo[:, idx, t_i], 0.5))
+                assert np.allclose(w.cpu().numpy(), want, rtol=2e-5, atol=5e-4), np.abs(w.cpu().numpy() - want).max()
+    # a scan (40 steps) whose step runs a 30-element plate: IndexRequest(t, StaticRequest({x: Regenerate})) — a bare
+    # Regenerate would reach the plate, which answers Update / IndexRequest only (vmap.py:342-362), as in the reference;
+    # the step after the edited one re-scores its plate and its latent against the new carry; against scipy (the
+    # oracle's scan.edit_index slices trailing axes only and does not address a plate inside a step)
+    Ts, B, t_e = 40, 30, 7
+
+    @G.gen
+    def leaf(m):
+        return G.normal(m, 1.0) @ "z"
+
+    @G.gen
+    def step2(x, _):
+        leaf.repeat(n=B)(x) @ "obs"
+        xn = G.normal(0.9 * x, 0.5) @ "x"
+        return xn, xn
+    sc = step2.scan(n=Ts)
+    tr2 = sc.simulate(G.split(G.key(4), n), (0.5, None))
+    for idx in (t_e, (np.arange(n) * 5) % (Ts - 1)):
+        gi = idx if isinstance(idx, int) else torch.from_numpy(idx.astype(np.int32)).to(tr2.get_score().device)
+        try:
+            IndexRequest(gi, Regenerate(S["x"])).edit(G.split(G.key(5), n), tr2, Diff.no_change((0.5, None)))
+            raise AssertionError("a Regenerate that reaches a plate should be refused")
+        except G.NotSupportedEditRequest:
+            pass
+        new2, w2, _, _ = IndexRequest(gi, StaticRequest({"x": Regenerate(G.Selection.all())})).edit(
+            G.split(G.key(5), n), tr2, Diff.no_change((0.5, None)))
+        x = new2.get_choices()["x"].cpu().numpy().astype(np.float64)
+        xo = tr2.get_choices()["x"].cpu().numpy().astype(np.float64)
+        z = tr2.get_choices()["obs", "z"].cpu().numpy().astype(np.float64)            # [n, Ts, B]
+        assert np.array_equal(new2.get_choices()["obs", "z"].cpu().numpy(), tr2.get_choices()["obs", "z"].cpu().numpy())
+        ii = np.full(n, idx) if isinstance(idx, int) else idx
+        r = np.arange(n)
+        ch = x != xo
+        assert ch[r, ii].all() and ch.sum() == n
+        lp = stats.norm.logpdf
+        xin = np.where(ii > 0, xo[r, np.maximum(ii - 1, 0)], 0.5)
+        want = (lp(x[r, ii], 0.9 * xin, 0.5) - lp(xo[r, ii], 0.9 * xin, 0.5)
+                + lp(xo[r, ii + 1], 0.9 * x[r, ii], 0.5) - lp(xo[r, ii + 1], 0.9 * xo[r, ii], 0.5)
+                + (lp(z[r, ii + 1], x[r, ii][:, None], 1.0) - lp(z[r, ii + 1], xo[r, ii][:, None], 1.0)).sum(-1))
+        assert np.allclose(w2.cpu().numpy(), want, rtol=5e-5, atol=2e-3), np.abs(w2.cpu().numpy() - want).max()
+        sc_new = (lp(x[:, 0], 0.45, 0.5) + lp(x[:, 1:], 0.9 * x[:, :-1], 0.5).sum(-1)
+                  + lp(z, np.concatenate([np.full((n, 1), 0.5), x[:, :-1]], 1)[..., None], 1.0).sum((1, 2)))
+        assert np.allclose(new2.get_score().cpu().numpy(), sc_new, rtol=2e-5, atol=2e-2)
+    return True
+
+
 def check_importance_unbiased(R=3000, K=16):
     """INDEPENDENT of the oracle: `ImportanceK`'s evidence estimate is unbiased, and for a conjugate normal-normal model
     the evidence is a closed form: mu ~ N(0, 1), y ~ N(mu, 0.5), y = 1.3  =>  Z = N(1.3; 0, sqrt(1.25)).  R estimates of

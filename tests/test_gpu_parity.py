@@ -1469,6 +1469,13 @@ def test_update_through_a_plate_of_long_scans_on_device(gpu, A, T):
     parity.check_nested_edits(A, T, n=3000)
 
 
+@pytest.mark.parametrize("A,T,n", [(20, 24, 9), (3, 24, 2000), (40, 40, 3000)])
+def test_index_requests_through_nested_loops_on_device(gpu, A, T, n):
+    """IndexRequest into a plate of long scans and into a scan of plates, gated inside the loops: interpreter (n = 9)
+    and specialised kernels, against the oracle and scipy"""
+    parity.check_nested_index_edits(A, T, n=n)
+
+
 def test_a_sweep_prepared_again_runs_the_new_key(gpu):
     """BootstrapSweep.prepare() a second time on the same object (found by the unbiasedness test: the noise-ahead form
     kept the first run's background launches): every re-prepared run equals a fresh sweep's, eager and captured"""

@@ -1264,6 +1264,13 @@ def test_update_through_a_plate_of_long_scans(hostsim, A, T):
     parity.check_nested_edits(A, T)
 
 
+@pytest.mark.parametrize("A,T", [(20, 24), (3, 24)])
+def test_index_requests_through_nested_loops(hostsim, A, T):
+    """IndexRequest into a plate of long scans (one series; one step of one series) and into a scan of plates"""
+    from tests import parity
+    parity.check_nested_index_edits(A, T)
+
+
 def test_importancek_evidence_is_unbiased(hostsim):
     """ImportanceK against a conjugate closed form (independent of the oracle)"""
     from tests import parity

@@ -34,6 +34,10 @@ os.environ["GENMI_FUSE_RESAMPLE"] = "0"
 parity.check_plates(n=129)
 parity.check_plate_of_scans(n=33, no=24, T=40)         # two nested counted loops, [n, A, T] step leaves (GMX_F_FLAT)
 parity.check_plate_of_scans(n=33, no=3, T=40)          # an unrolled plate around its elements' loops
+parity.check_multinomial_sorted(n=3333, seed=7, spike=30.0, rows=2)      # the order-statistics table and its reader
+parity.check_multinomial_sorted(n=1, seed=9)
+parity.check_multinomial_tiled(n=2500, seed=8)
+parity.check_nested_index_edits(3, 24)                     # gated edits inside two nested loops
 parity.check_csmc(k=65)
 parity.check_nested_marginal(k=33)
 parity.check_dirichlet(n=300)

@@ -1,5 +1,5 @@
 """the ordered resampler alone, systematic against the sorted multinomial (table cold: 16 tables in turn; hot: one table):
-us per launch over back-to-back launches on an idle GPU.  GENMI_SORTED_STAGE=0/1 selects the sorted kind's read path."""
+us per launch over back-to-back launches on an idle GPU; and the table build per row."""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
@@ -28,7 +28,7 @@ def t_(fn, reps=200):
     for i in range(reps): fn(i)
     e1.record(); torch.cuda.synchronize()
     return 1e3 * e0.elapsed_time(e1) / reps
-out = {"n": n, "sigma": sigma, "stage": os.environ.get("GENMI_SORTED_STAGE", "1")}
+out = {"n": n, "sigma": sigma}
 out["systematic"] = t_(lambda i: be.c.gmx_resample_tiles(0, kk, be.ptr(lw), n, shift, be.ptr(tmax), be.ptr(agg), be.ptr(mx), be.ptr(tot), be.ptr(anc), be.stream()))
 out["stratified"] = t_(lambda i: be.c.gmx_resample_tiles(1, kk, be.ptr(lw), n, shift, be.ptr(tmax), be.ptr(agg), be.ptr(mx), be.ptr(tot), be.ptr(anc), be.stream()))
 out["sorted_cold"] = t_(lambda i: be.c.gmx_resample_sorted(kk, be.ptr(lw), n, shift, be.ptr(tmax), be.ptr(agg), be.ptr(tables[i % NT]), 1, be.ptr(mx), be.ptr(tot), be.ptr(anc), be.stream()))

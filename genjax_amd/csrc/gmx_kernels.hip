@@ -3619,6 +3619,26 @@ k_gather(const leaf_table T, const int32_t* __restrict__ anc, int64_t n_out) {
   int64_t a = anc[j];
   for (int l = 0; l < T.n; ++l) copy_elem(T.out[l], j, T.a[l], a, T.bytes[l]);
 }
+// every leaf 4 bytes wide, ancestors and destinations 16-byte aligned: four consecutive outputs per thread — one 16-byte
+// load of ancestors, and per leaf four 4-byte loads (near each other: resampling's ancestors ascend) and ONE 16-byte store
+__global__ void __launch_bounds__(GMX_BLOCK)
+k_gather4(const leaf_table T, const int32_t* __restrict__ anc, int64_t n_out) {
+  const int64_t j = ((int64_t)blockIdx.x * GMX_BLOCK + threadIdx.x) * 4;
+  if (j >= n_out) return;
+  if (j + 4 <= n_out) {
+    const int4 a = *reinterpret_cast<const int4*>(anc + j);
+    for (int l = 0; l < T.n; ++l) {
+      const uint32_t* s = (const uint32_t*)T.a[l];
+      const uint4 v = make_uint4(s[a.x], s[a.y], s[a.z], s[a.w]);
+      *reinterpret_cast<uint4*>((uint32_t*)T.out[l] + j) = v;
+    }
+    return;
+  }
+  for (int64_t q = j; q < n_out; ++q) {
+    const int64_t a = anc[q];
+    for (int l = 0; l < T.n; ++l) ((uint32_t*)T.out[l])[q] = ((const uint32_t*)T.a[l])[a];
+  }
+}
 __global__ void __launch_bounds__(GMX_BLOCK)
 k_select(const leaf_table T, const uint8_t* __restrict__ mask, int64_t n) {
   int64_t j = (int64_t)blockIdx.x * GMX_BLOCK + threadIdx.x;
@@ -3641,8 +3661,12 @@ extern "C" int gmx_gather(const void* const* src_d, void* const* dst_d, const in
       if (elem_bytes[base + l] <= 0) return gmx_fail("gmx_gather: bad element size%s");
       T.a[l] = src_d[base + l]; T.out[l] = dst_d[base + l]; T.bytes[l] = elem_bytes[base + l];
     }
-    hipLaunchKernelGGL(k_gather, grid_for(n_out), dim3(GMX_BLOCK), 0, (hipStream_t)stream, T,
-                       ancestors_d, n_out);
+    bool wide = (((uintptr_t)ancestors_d) & 15) == 0;
+    for (int l = 0; l < T.n; ++l) wide = wide && T.bytes[l] == 4 && (((uintptr_t)T.out[l]) & 15) == 0 && (((uintptr_t)T.a[l]) & 3) == 0;
+    if (wide)
+      hipLaunchKernelGGL(k_gather4, grid_for((n_out + 3) / 4), dim3(GMX_BLOCK), 0, (hipStream_t)stream, T, ancestors_d, n_out);
+    else
+      hipLaunchKernelGGL(k_gather, grid_for(n_out), dim3(GMX_BLOCK), 0, (hipStream_t)stream, T, ancestors_d, n_out);
   }
   GMX_HIP(hipGetLastError());
   return 0;

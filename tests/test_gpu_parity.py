@@ -216,6 +216,13 @@ def test_gather_and_categorical(gpu):
     assert np.array_equal(ga.cpu().numpy(), a[anc])
     assert np.array_equal(gb.cpu().numpy(), b[anc])
     assert np.array_equal(gc.cpu().numpy(), c[anc])
+    # all leaves 4 bytes wide: the four-outputs-per-thread kernel (k_gather4), ragged tails and sorted / random ancestors
+    for m in (1, 3, 4, 7777, 100_001):
+        for srt in (False, True):
+            an = rng.integers(0, n, size=m).astype(np.int32)
+            an = np.sort(an) if srt else an
+            ga, gb = engine.gather_leaves([_dev(a), _dev(b)], _dev(an))
+            assert np.array_equal(ga.cpu().numpy(), a[an]) and np.array_equal(gb.cpu().numpy(), b[an])
     logits = rng.normal(size=(64, 500)).astype(np.float32)
     keys = G.split(G.key(11), 64)
     idx = engine.categorical_rows(keys, _dev(logits)).cpu().numpy()

@@ -1908,10 +1908,11 @@ k_offspring_tile(uint32_t k0, uint32_t k1, uint32_t u0_host, const float* __rest
   }
 }
 
-static int resample_shape(const char* who, int64_t n, int shift) {
+static int resample_shape(const char* who, int64_t n, int shift, bool any_n = false) {
   if (n <= 0) return gmx_fail("%s: n must be positive", who);
-  if ((n + RS_TILE - 1) / RS_TILE > RS_MAX_TILES)
-    return gmx_fail("%s: n too large for the fused path (use gmx_weight_cdf + gmx_ancestors)", who);
+  if (!any_n && (n + RS_TILE - 1) / RS_TILE > RS_MAX_TILES)
+    return gmx_fail("%s: n too large for the fused path (gmx_tile_stats + gmx_tile_prefix + gmx_resample_tiles_p, or gmx_weight_cdf + gmx_ancestors)", who);
+  if (n > 0x7fffffffLL) return gmx_fail("%s: n out of range", who);
   if (shift < 1 || shift > 62) return gmx_fail("%s: shift out of range", who);
   int need = 0;
   while (((int64_t)1 << need) < n) ++need;
@@ -1959,7 +1960,7 @@ static int launch_offspring_tile(int kind, const uint32_t key[2], const float* l
 
 extern "C" int gmx_tile_stats(const float* lw_d, int64_t n, int shift, float* tile_max_d, uint64_t* tile_agg_d,
                               gmx_stream stream) {
-  if (resample_shape("gmx_tile_stats", n, shift)) return 1;
+  if (resample_shape("gmx_tile_stats", n, shift, true)) return 1;
   if (!lw_d || !tile_max_d || !tile_agg_d) return gmx_fail("gmx_tile_stats: null argument%s");
   if ((uintptr_t)lw_d & 15) return gmx_fail("gmx_tile_stats: lw_d must be 16-byte aligned%s");
   const int64_t tiles = (n + RS_TILE - 1) / RS_TILE;
@@ -2625,10 +2626,60 @@ k_tile_prefix(const float* __restrict__ tmax, const uint64_t* __restrict__ agg, 
   gmx_tile_prefix_block<false>(tmax, agg, n_tiles, pref, lds4, lds8);
 }
 
+// more than RS_MAX_TILES tiles (n > 2^21: BASELINE config 4's 1e7 particles are 9766): ONE workgroup walks the table in
+// chunks of 2048 tiles (8 per thread) with a running carry; the same integers as gmx_tile_prefix_block
+__global__ void __launch_bounds__(GMX_BLOCK)
+k_tile_prefix_big(const float* __restrict__ tmax, const uint64_t* __restrict__ agg, int n_tiles, uint64_t* __restrict__ pref) {
+  __shared__ float lds4[4];
+  __shared__ uint64_t lds8[4];
+  const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float M = -gmx_inf();
+  for (int t = tid; t < n_tiles; t += GMX_BLOCK) M = gmx_rmax(M, tmax[t]);
+  M = block_max(M, lds4);
+  const int32_t K = gmx_tile_exp(M);
+  uint64_t carry = 0;
+  for (int base = 0; base < n_tiles; base += 8 * GMX_BLOCK) {          // block-uniform trip count
+    uint64_t P[8];
+    uint64_t run = 0;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int t = base + tid * 8 + r;
+      const int tc = t < n_tiles ? t : n_tiles - 1;
+      const uint64_t G = gmx_tile_scale(agg[tc], gmx_tile_exp(tmax[tc]), K);
+      P[r] = run;
+      run += (t < n_tiles) ? G : 0ull;
+    }
+    const uint64_t inc = wave_scan_u64(run);
+    __syncthreads();
+    if (lane == 63) lds8[wave] = inc;
+    __syncthreads();
+    uint64_t wave_off = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { const uint64_t v = lds8[w]; tot += v; wave_off += (w < wave) ? v : 0ull; }
+    const uint64_t b0 = carry + wave_off + (inc - run);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int t = base + tid * 8 + r;
+      if (t < n_tiles) pref[t] = b0 + P[r];
+    }
+    carry += tot;
+  }
+  if (tid == 0) {
+    pref[n_tiles] = carry;
+    pref[n_tiles + 1] = (uint64_t)gmx_f2u(M) | ((uint64_t)(uint32_t)K << 32);
+  }
+}
+
 extern "C" int gmx_tile_prefix(const float* tile_max_d, const uint64_t* tile_agg_d, int64_t n, uint64_t* tile_pref_d,
                                gmx_stream stream) {
-  if (n <= 0 || (n + RS_TILE - 1) / RS_TILE > RS_MAX_TILES) return gmx_fail("gmx_tile_prefix: n out of range%s");
+  if (n <= 0 || n > 0x7fffffffLL) return gmx_fail("gmx_tile_prefix: n out of range%s");
   if (!tile_max_d || !tile_agg_d || !tile_pref_d) return gmx_fail("gmx_tile_prefix: null argument%s");
+  if ((n + RS_TILE - 1) / RS_TILE > RS_MAX_TILES) {
+    hipLaunchKernelGGL(k_tile_prefix_big, dim3(1), dim3(GMX_BLOCK), 0, (hipStream_t)stream, tile_max_d, tile_agg_d,
+                       (int)((n + RS_TILE - 1) / RS_TILE), tile_pref_d);
+    GMX_HIP(hipGetLastError());
+    return 0;
+  }
   hipLaunchKernelGGL(k_tile_prefix, dim3(1), dim3(GMX_BLOCK), 0, (hipStream_t)stream, tile_max_d, tile_agg_d,
                      (int)((n + RS_TILE - 1) / RS_TILE), tile_pref_d);
   GMX_HIP(hipGetLastError());
@@ -2638,7 +2689,7 @@ extern "C" int gmx_tile_prefix(const float* tile_max_d, const uint64_t* tile_agg
 extern "C" int gmx_resample_tiles_p(int kind, const uint32_t key[2], const float* lw_d, int64_t n, int shift,
                                     const float* tile_max_d, const uint64_t* tile_pref_d, float* max_d,
                                     uint64_t* total_d, int32_t* ancestors_d, gmx_stream stream) {
-  if (resample_shape("gmx_resample_tiles_p", n, shift)) return 1;
+  if (resample_shape("gmx_resample_tiles_p", n, shift, true)) return 1;       // any n < 2^31: a workgroup reads ONE prefix
   if (!key || !lw_d || !tile_max_d || !tile_pref_d || !max_d || !total_d || !ancestors_d)
     return gmx_fail("gmx_resample_tiles_p: null argument%s");
   if (kind != GMX_RESAMPLE_SYSTEMATIC && kind != GMX_RESAMPLE_STRATIFIED)

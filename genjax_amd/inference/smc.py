@@ -535,6 +535,21 @@ def resample_fused(kind, key: Key, lw: torch.Tensor):
         be.check(be.c.gmx_multinomial_tiled(kk, be.ptr(lw), n, shift, be.ptr(stats[0]), be.ptr(stats[1]), None, be.ptr(mx),
                                             be.ptr(total), be.ptr(anc), be.ptr(ws), -1, be.stream()), "gmx_multinomial_tiled")
         return anc, total, mx, shift
+    if n > FUSED_RESAMPLE_MAX:
+        # more than 2048 tiles (BASELINE config 4: k = 1e7): the same kernel reading tile PREFIXES that one workgroup
+        # computes (gmx_tile_prefix) instead of every workgroup reducing the whole statistics table — still no CDF array
+        kh = key.host()
+        kk = (c_uint32 * 2)(int(kh[0]), int(kh[1]))
+        if not (stats is not None and stats[2] == shift and stats[3] == n):
+            tiles = (n + 1023) // 1024
+            stats = (torch.empty((tiles,), dtype=torch.float32, device=lw.device),
+                     torch.empty((tiles,), dtype=torch.int64, device=lw.device))
+            be.check(be.c.gmx_tile_stats(be.ptr(lw), n, shift, be.ptr(stats[0]), be.ptr(stats[1]), be.stream()), "gmx_tile_stats")
+        pref = torch.empty((int(be.c.gmx_tile_prefix_words(n)),), dtype=torch.int64, device=lw.device)
+        be.check(be.c.gmx_tile_prefix(be.ptr(stats[0]), be.ptr(stats[1]), n, be.ptr(pref), be.stream()), "gmx_tile_prefix")
+        be.check(be.c.gmx_resample_tiles_p(int(kind), kk, be.ptr(lw), n, shift, be.ptr(stats[0]), be.ptr(pref), be.ptr(mx),
+                                           be.ptr(total), be.ptr(anc), be.stream()), "gmx_resample_tiles_p")
+        return anc, total, mx, shift
     if stats is not None and stats[2] == shift and stats[3] == n:
         kh = key.host()
         kk = (c_uint32 * 2)(int(kh[0]), int(kh[1]))
@@ -577,8 +592,10 @@ def resample(key: Key, collection: ParticleCollection, kind="systematic", n_out=
         raise NotImplementedError("resample: batched collections")
     kind = _KINDS[kind] if isinstance(kind, str) else int(kind)
     n = lw.numel()
-    if kind in _TILE_KINDS and n_out in (None, n) and 0 < n <= FUSED_RESAMPLE_MAX:
-        anc, total, mx, shift = resample_fused(kind, key, lw)        # no CDF in memory (gmx_resample[_tiles])
+    if (kind in _TILE_KINDS and n_out in (None, n) and 0 < n <= FUSED_RESAMPLE_MAX) or \
+            (kind in (SYSTEMATIC, STRATIFIED) and n_out in (None, n) and FUSED_RESAMPLE_MAX < n < 2 ** 31 - 1024
+             and os.environ.get("GENMI_RESAMPLE_BIG_FUSED", "1") != "0"):
+        anc, total, mx, shift = resample_fused(kind, key, lw)        # no CDF in memory (gmx_resample[_tiles[_p]])
     elif kind in (MULTINOMIAL_TILED, MULTINOMIAL_SORTED):
         raise NotImplementedError("resample(kind='multinomial_tiled' / 'multinomial_sorted'): n_out = n <= 2^21 (use 'multinomial')")
     else:

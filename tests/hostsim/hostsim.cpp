@@ -329,7 +329,7 @@ extern "C" size_t gmx_tile_prefix_words(int64_t n) {       // prefixes | total |
 extern "C" int gmx_tile_prefix(const float* tmax, const uint64_t* agg, int64_t n, uint64_t* pref, gmx_stream) {
   if (n <= 0 || !tmax || !agg || !pref) return fail("tile_prefix: bad argument");
   const int64_t tiles = (n + HS_TILE - 1) / HS_TILE;
-  if (tiles > 2048) return fail("tile_prefix: n out of range");
+  if (n > 0x7fffffffLL) return fail("tile_prefix: n out of range");
   float M = -gmx_inf();
   for (int64_t b = 0; b < tiles; ++b) M = gmx_rmax(M, tmax[b]);
   const int32_t K = gmx_tile_exp(M);

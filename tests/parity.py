@@ -1775,6 +1775,29 @@ def check_multinomial_tiled(n=5000, seed=5, sigma=2.0, dead=False, spike=0.0):
     return {"distinct": int(np.unique(want).size)}
 
 
+def check_resample_beyond_2048_tiles(n=2049 * 1024 + 7, seed=3, sigma=2.0):
+    """smc.resample_fused past the fused resampler's 2048 tiles (n > 2^21; BASELINE config 4's 1e7 is 9766 tiles): tile
+    statistics -> gmx_tile_prefix (one workgroup, chunks of 2048 tiles with a running carry) -> gmx_resample_tiles_p,
+    no CDF array — the same ancestors, total and max as gmx_weight_cdf + gmx_ancestors and as the oracle (C statement),
+    systematic and stratified"""
+    import genjax_amd as G
+    from genjax_amd.inference import smc
+    rng = np.random.default_rng(seed)
+    lw = rng.normal(0, sigma, n).astype(np.float32)
+    cdf, total, M, shift = O.weight_cdf_c(lw)
+    from genjax_amd import _lib
+    lw_d = torch.from_numpy(lw).to(_lib.get().device)
+    for kind, okind in ((smc.SYSTEMATIC, O.SYSTEMATIC), (smc.STRATIFIED, O.STRATIFIED)):
+        anc, tot, mx, sh = smc.resample_fused(kind, G.key(seed + 1), lw_d)
+        assert sh == shift and int(tot.item()) & 0xFFFFFFFFFFFFFFFF == total and float(mx.item()) == M
+        want = O.ancestors_c(okind, O.key(seed + 1), cdf)
+        assert np.array_equal(anc.cpu().numpy(), want), int((anc.cpu().numpy() != want).sum())
+        cdf_d, tot2, mx2, _ = smc.weight_cdf(lw_d)
+        anc2 = smc.ancestors_from_cdf(kind, G.key(seed + 1), cdf_d, tot2)
+        assert torch.equal(anc, anc2) and torch.equal(tot, tot2)
+    return True
+
+
 def check_multinomial_sorted(n=5000, seed=5, sigma=2.0, dead=False, spike=0.0, rows=1):
     """gmx_resample_sorted (multinomial resampling with sorted uniforms on the ordered resampler's kernel) against the
     oracle's definition, directly through the C-ABI: ragged n, skewed weights, one particle with almost all the mass, no

@@ -368,6 +368,26 @@ def test_config4_full_size_importancek_and_global_resample(gpu):
     assert lml == pytest.approx(ref, rel=1e-5)
 
 
+@pytest.mark.parametrize("n", [2049 * 1024 + 7, 5_000_000])
+def test_fused_resampling_beyond_2048_tiles_on_device(gpu, n):
+    """k_tile_prefix_big + the prefix-reading k_offspring_tile at n > 2^21 == gmx_weight_cdf + gmx_ancestors == the oracle"""
+    parity.check_resample_beyond_2048_tiles(n=n)
+
+
+def test_config4_resample_without_the_big_fused_path(gpu, monkeypatch):
+    """the CDF-array path that n > 2^21 took before (ticketed look-back scan + per-slot search) stays reachable and exact"""
+    import genjax_amd as G
+    from genjax_amd.inference import smc
+    from genjax_amd.inference.smc import ParticleCollection
+    monkeypatch.setenv("GENMI_RESAMPLE_BIG_FUSED", "0")
+    n = 3_000_000
+    lw = np.random.default_rng(1).normal(0, 1.5, n).astype(np.float32)
+    cdf, total, M, shift = O.weight_cdf_c(lw)
+    cdf_d, tot, mx, sh = smc.weight_cdf(_dev(lw))
+    anc = smc.ancestors_from_cdf(smc.SYSTEMATIC, G.key(5), cdf_d, tot)
+    assert np.array_equal(anc.cpu().numpy(), O.ancestors_c(O.SYSTEMATIC, O.key(5), cdf))
+
+
 @pytest.mark.parametrize("n", [257, 100_000])
 def test_plates_match_oracle(gpu, n):
     parity.check_plates(n=n)

@@ -1227,6 +1227,12 @@ def test_two_stage_multinomial_matches_oracle(hostsim):
         assert res["ancestors_equal"] and res["x_equal"] and res["totals_equal"] and res["lw_max_abs_diff"] == 0.0
 
 
+def test_fused_resampling_beyond_2048_tiles(hostsim):
+    """n > 2^21: tile statistics -> tile prefixes -> the prefix-reading resampler == CDF array + search == the oracle"""
+    from tests import parity
+    parity.check_resample_beyond_2048_tiles()
+
+
 def test_sorted_multinomial_matches_oracle(hostsim):
     """gmx_sorted_uniforms / gmx_resample_sorted == the oracle's definition (C-ABI mirror), and whole sweeps resampled with it"""
     from tests import parity

@@ -1282,8 +1282,8 @@ def test_resampler_fuzz(gpu):
 
 @pytest.mark.parametrize("kind", [0, 1])
 def test_fused_resampler_at_its_size_limit(gpu, kind):
-    """n = 2^21 = RS_MAX_TILES tiles of 1024: the largest ensemble the fused (table-per-block) resampler takes;
-    one more particle must be refused loudly."""
+    """n = 2^21 = RS_MAX_TILES tiles of 1024: the largest ensemble the table-per-block resampler takes; its entry point
+    refuses one more particle loudly, and `resample_fused` then goes through the tile-prefix form (same ancestors)."""
     import genjax_amd as G
     from genjax_amd import _lib
     from genjax_amd.inference import smc
@@ -1295,8 +1295,19 @@ def test_fused_resampler_at_its_size_limit(gpu, kind):
     anc, tot, mx, _ = smc.resample_fused(kind, G.key(9), _dev(lw))
     assert int(tot.item()) == rt and float(mx.item()) == rm
     assert np.array_equal(anc.cpu().numpy(), ref)
+    from ctypes import c_uint32
+    be = _lib.get()
+    lw1 = _dev(np.concatenate([lw, np.float32([1.5])]))
+    ws = torch.zeros(((be.c.gmx_resample_workspace(n + 1) + 7) // 8,), dtype=torch.int64, device=be.device)
+    out = [torch.zeros((1,), dtype=torch.float32, device=be.device), torch.zeros((1,), dtype=torch.int64, device=be.device),
+           torch.zeros((n + 1,), dtype=torch.int32, device=be.device)]
     with pytest.raises(_lib.GenmiError, match="too large"):
-        smc.resample_fused(kind, G.key(9), _dev(np.zeros(n + 1, np.float32)))
+        be.check(be.c.gmx_resample(kind, (c_uint32 * 2)(1, 2), be.ptr(lw1), n + 1, smc.cdf_shift(n + 1), None, 0, be.ptr(out[0]),
+                                   be.ptr(out[1]), be.ptr(out[2]), be.ptr(ws), be.stream()), "gmx_resample")
+    rc1, rt1, rm1, _ = O.weight_cdf_c(lw1.cpu().numpy())
+    anc1, tot1, mx1, _ = smc.resample_fused(kind, G.key(9), lw1)
+    assert int(tot1.item()) == rt1 and float(mx1.item()) == rm1
+    assert np.array_equal(anc1.cpu().numpy(), O.ancestors_c(kind, O.key(9), rc1))
 
 
 @pytest.mark.parametrize("n,shape", [(8192, "normal"), (10_000, "onehot"), (10_000, "none"), (100_003, "heavy"),

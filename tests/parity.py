@@ -2130,6 +2130,31 @@ def check_nested_index_edits(A=20, T=24, n=7):
                         + lp(y[:, idx, t_i], x[:, idx, t_i], 1.0) - lp(y[:, idx, t_i], xo[:, idx, t_i], 1.0)
                         + lp(xo[:, idx, t_i + 1], 0.9 * x[:, idx, t_i], 0.5) - lp(xo[:, idx, t_i + 1], 0.9 * xo[:, idx, t_i], 0.5))
                 assert np.allclose(w.cpu().numpy(), want, rtol=2e-5, atol=5e-4), np.abs(w.cpu().numpy() - want).max()
+    # a VECTOR-valued site inside the inner loop ([n, A, T, 3] values), gated element-wise
+    def mkv(g, scan_of, ones, lift):
+        @g.gen
+        def stepv(x, _):
+            xn = g.normal(0.9 * x, 0.5) @ "x"
+            g.normal(lift(xn) * ones, 1.0) @ "v"
+            return xn, None
+
+        @g.gen
+        def seriesv(x0_):
+            xT, _ = scan_of(stepv)(x0_, None) @ "steps"
+            return xT
+        return seriesv
+    sv = mkv(G, lambda f: f.scan(n=T), jnp.ones(3), lambda v: v)
+    osv = mkv(O, lambda f: O.Scan(f, T), np.ones(3, np.float32), lambda v: v[..., None])
+    mv, omv = sv.vmap(in_axes=(0,)), O.Vmap(osv, in_axes=(0,))
+    trv = mv.simulate(G.split(G.key(6), n), (jnp.array(x0),))
+    otrv = omv.simulate(O.split(O.key(6), n), (x0,))
+    newv, wv, _, _ = IndexRequest(a_i, Regenerate(S["steps", "x"])).edit(G.split(G.key(7), n), trv, Diff.no_change((jnp.array(x0),)))
+    onewv, owv = O.vmap_edit_index_batched(
+        omv, O.split(O.key(7), n), otrv, a_i,
+        lambda kb, inner, a: osv.regenerate(kb, inner, lambda ad: ad == ("steps", "x"), a)[:2], (x0,))
+    assert np.array_equal(wv.cpu().numpy(), owv) and np.array_equal(newv.get_score().cpu().numpy(), onewv.get_score())
+    for ad in (("steps", "x"), ("steps", "v")):
+        assert np.array_equal(newv.get_choices()[ad].cpu().numpy(), onewv.get_choices()[ad]), ad
     # a scan (40 steps) whose step runs a 30-element plate: IndexRequest(t, StaticRequest({x: Regenerate})) — a bare
     # Regenerate would reach the plate, which answers Update / IndexRequest only (vmap.py:342-362), as in the reference;
     # the step after the edited one re-scores its plate and its latent against the new carry; against scipy (the

@@ -263,28 +263,28 @@ GMX_HD void gmx_vm_run(uint32_t n_instr_rt, int64_t i, bool active, const gmx_ru
   Regs R;
   R.init();
   // counted loops, at most two deep: launch-uniform control flow.  t = the innermost loop's iteration number,
-  // tf = the row-major index over both (GMX_F_FLAT).  Plain scalars (no arrays indexed at run time: the device
-  // interpreter's register file already owns the GPR-index mode).
-  uint32_t t = 0u, tf = 0u;
-  uint32_t pc0 = 0u, n0 = 1u, t0 = 0u, pc1 = 0u, n1 = 1u, t1 = 0u;
+  // tf = the row-major index over both (GMX_F_FLAT).  Few live scalars (the switch below is at the SGPR limit): the
+  // two loop heads packed in one word, the trip counts re-read from the LOOP instructions at the loop ends, the outer
+  // iteration number recovered as tf / n1 when the inner loop finishes.  (No arrays indexed at run time: the device
+  // interpreter's register file already owns the GPR-index mode.)
+  uint32_t t = 0u, tf = 0u, heads = 0u;       // heads: pc of the outer LOOP | pc of the inner LOOP << 16
   int depth = 0;
   for (uint32_t pc = 0; pc < n_instr_rt; ++pc) {
     gmx_rword w;
     ctx.fetch(pc, &w.a, &w.b);
     const uint32_t op = w.a & 0xffu;
     if (op == OP_LOOP) {
-      if (depth == 0) { pc0 = pc; n0 = w.b; t0 = 0u; depth = 1; t = 0u; tf = 0u; }
-      else { pc1 = pc; n1 = w.b; t1 = 0u; depth = 2; t = 0u; tf = t0 * n1; }
+      if (depth == 0) { heads = pc; depth = 1; t = 0u; tf = 0u; }
+      else { heads = (heads & 0xffffu) | (pc << 16); depth = 2; tf = t * w.b; t = 0u; }
       continue;
     }
     if (op == OP_ENDLOOP) {
-      if (depth == 2) {
-        if (t1 + 1u < n1) { ++t1; pc = pc1; t = t1; tf = t0 * n1 + t1; }
-        else { depth = 1; t = t0; tf = t0; }
-      } else {
-        if (t0 + 1u < n0) { ++t0; pc = pc0; t = t0; tf = t0; }
-        else { depth = 0; t = 0u; tf = 0u; }
-      }
+      gmx_rword h;
+      const uint32_t hp = depth == 2 ? (heads >> 16) : (heads & 0xffffu);
+      ctx.fetch(hp, &h.a, &h.b);                         // h.b = this loop's trip count
+      if (t + 1u < h.b) { ++t; tf = depth == 2 ? tf + 1u : t; pc = hp; }
+      else if (depth == 2) { depth = 1; t = tf / h.b; tf = t; }
+      else { depth = 0; t = 0u; tf = 0u; }
       continue;
     }
     gmx_vm_step<Regs, FULL, gmx_rword, Ctx>(R, w, i, active, A, ctx, t, tf);

@@ -297,7 +297,9 @@ int gmx_resample_tiles_q(int kind, const uint32_t key[2], const uint32_t* q_d, i
                          uint64_t* total_d, int32_t* ancestors_d, gmx_stream stream);
 /* gmx_resample_tiles when the tile PREFIXES are there already (gmx_run_args.tile_pref_d, written once by the last
  * workgroup of the site program; or gmx_tile_prefix from the statistics): a workgroup reads ONE prefix, the total and
- * K instead of reducing all <= 2048 tile statistics — the same integers, the same ancestors.
+ * K instead of reducing all <= 2048 tile statistics — the same integers, the same ancestors.  This form (and
+ * gmx_tile_stats, gmx_tile_prefix) takes any n < 2^31: past 2048 tiles (n > 2^21) one workgroup walks the table in
+ * chunks with a running carry — how a population of 1e7 is resampled without a CDF array.
  * gmx_tile_prefix_words(n): u64 words of the block (ceil(n / 1024) + 3, rounded up to 16, + 32 x 16 of tickets). */
 size_t gmx_tile_prefix_words(int64_t n);
 int gmx_tile_prefix(const float* tile_max_d, const uint64_t* tile_agg_d, int64_t n, uint64_t* tile_pref_d,

@@ -1227,6 +1227,22 @@ def test_two_stage_multinomial_matches_oracle(hostsim):
         assert res["ancestors_equal"] and res["x_equal"] and res["totals_equal"] and res["lw_max_abs_diff"] == 0.0
 
 
+def test_resampling_kinds_say_what_they_do_not_take(hostsim):
+    """the sharded router takes the ordered schemes it was built for; the tile / sorted multinomials want n_out = n"""
+    import genjax_amd as G
+    from genjax_amd import workloads
+    from genjax_amd.inference import sharded, smc
+    init, step = workloads.make_lgssm(G)
+    for kind in ("multinomial", "multinomial_tiled", "multinomial_sorted"):
+        with pytest.raises(NotImplementedError, match="systematic / stratified"):
+            sharded.ShardedBootstrapSweep(init, step, 1024, 3, dist=None, resample=kind)
+    coll = smc.ImportanceK(G.Target(init, (), G.ChoiceMap.kw(y=0.3)), k_particles=64).run_smc(G.key(1))
+    for kind in ("multinomial_tiled", "multinomial_sorted"):
+        with pytest.raises(NotImplementedError, match="n_out = n"):
+            smc.resample(G.key(2), coll, kind, n_out=32)
+    assert smc.resample(G.key(2), coll, "multinomial", n_out=32).ancestors.numel() == 32
+
+
 def test_fused_resampling_beyond_2048_tiles(hostsim):
     """n > 2^21: tile statistics -> tile prefixes -> the prefix-reading resampler == CDF array + search == the oracle"""
     from tests import parity

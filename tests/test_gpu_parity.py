@@ -1085,6 +1085,40 @@ def test_captured_loop_without_mh_hoists_the_extension_draws(gpu):
         assert torch.equal(coll.get_particles().get_retval(), ref_x) and torch.equal(coll.get_log_weights(), ref_lw)
 
 
+@pytest.mark.parametrize("kind", ["stratified", "multinomial", "multinomial_tiled", "multinomial_sorted"])
+def test_captured_functional_loop_with_every_resampling_kind(gpu, kind):
+    """`smc.resample(kind=...)` inside a captured Python loop (the tile / sorted multinomials build their count buffers
+    and order-statistics table inside the capture): replays equal the eager loop bit for bit, and the eager loop's
+    ancestors are the oracle's"""
+    import genjax_amd as G
+    from genjax_amd import workloads
+    from genjax_amd.inference import smc
+    n, T = 50_000, 4
+    ys = workloads.lgssm_data(T)
+    init, step = workloads.make_lgssm(G)
+
+    def sweep(key):
+        for t in range(T):
+            kp, kr, _ = G.split(G.fold_in(key, t), 3)
+            obs = G.ChoiceMap.kw(y=float(ys[t]))
+            if t == 0:
+                coll = smc.ImportanceK(G.Target(init, (), obs), k_particles=n).run_smc(kp)
+            else:
+                coll = smc.resample(kr, coll, kind)
+                coll = smc.extend(kp, coll, step, lambda tr_: (tr_.get_retval(),), obs)
+        return coll
+    ref = sweep(G.key(3))
+    ref_x, ref_lw = ref.get_particles().get_retval().clone(), ref.get_log_weights().clone()
+    oi, os_ = workloads.make_lgssm(O)
+    want = parity.oracle_bootstrap_sweep(oi, os_, n, T, ys, O.key(3), kind=smc._KINDS[kind])
+    assert np.array_equal(ref_x.cpu().numpy(), want["x"]) and np.array_equal(ref_lw.cpu().numpy(), want["lw"])
+    cap = smc.capture(sweep, G.key(3))
+    for _ in range(2):
+        coll = cap.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(coll.get_particles().get_retval(), ref_x) and torch.equal(coll.get_log_weights(), ref_lw)
+
+
 def test_captured_loop_noise_ahead_edges(gpu, monkeypatch):
     """smc.capture(noise_ahead=True): launches below 2^18 particles keep their draws (empty plan, same results); an
     arena bound of 0 MB falls back to the one-stream capture."""

@@ -531,9 +531,12 @@ def resample_fused(kind, key: Key, lw: torch.Tensor):
             be.check(be.c.gmx_resample_sorted(kk, be.ptr(lw), n, shift, be.ptr(stats[0]), be.ptr(stats[1]), be.ptr(table), 0,
                                               be.ptr(mx), be.ptr(total), be.ptr(anc), be.stream()), "gmx_resample_sorted")
             return anc, total, mx, shift
-        ws = torch.empty(((be.c.gmx_multinomial_tiled_workspace(n) + 3) // 4,), dtype=torch.int32, device=lw.device)
+        # count buffers zeroed HERE (a fill kernel; phase 0: "buffer 0 is zero") rather than by the call's own memset
+        # (phase -1): inside `smc.capture` the memset node of a one-off workspace did not hold across replays (replay 0
+        # right, every later one wrong: tools/experiments/capture_kinds_dbg.py) — a sweep's persistent workspace is fine
+        ws = torch.zeros(((be.c.gmx_multinomial_tiled_workspace(n) + 3) // 4,), dtype=torch.int32, device=lw.device)
         be.check(be.c.gmx_multinomial_tiled(kk, be.ptr(lw), n, shift, be.ptr(stats[0]), be.ptr(stats[1]), None, be.ptr(mx),
-                                            be.ptr(total), be.ptr(anc), be.ptr(ws), -1, be.stream()), "gmx_multinomial_tiled")
+                                            be.ptr(total), be.ptr(anc), be.ptr(ws), 0, be.stream()), "gmx_multinomial_tiled")
         return anc, total, mx, shift
     if n > FUSED_RESAMPLE_MAX:
         # more than 2048 tiles (BASELINE config 4: k = 1e7): the same kernel reading tile PREFIXES that one workgroup

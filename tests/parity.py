@@ -49,6 +49,7 @@ def check_lgssm_sweep(n=4096, T=5, seed=314159, capture=False, specialize=True, 
         assert sw.fuse == want_fuse, "the sweep did not take the requested (one- / two-launch) form"
     if capture:
         sw.capture()
+        sw.launch()              # a second replay must not see what the first one left (count buffers, ring slots)
     sw.launch()
     log_ml = sw.log_ml()
     x, lw, anc = sw.state()

@@ -1003,7 +1003,8 @@ def test_tuple_state_sweep_three_site_step_model(gpu):
     parity.check_tuple_state_sweep(n=3001, T=4)
 
 
-def test_functional_loop_captured_equals_eager(gpu):
+@pytest.mark.parametrize("kind", ["systematic", "multinomial_sorted"])
+def test_functional_loop_captured_equals_eager(gpu, kind):
     """smc.capture: resample -> rejuvenate -> extend written with the functional API, captured once into a hipGraph;
     the replayed particles, ancestors and accept bits equal the eager loop's (and the step programs leave the
     resampler's tile statistics themselves once they run specialised: no separate pass over the log-weights)."""
@@ -1023,7 +1024,7 @@ def test_functional_loop_captured_equals_eager(gpu):
             if t == 0:
                 coll = smc.ImportanceK(G.Target(init, (), obs), k_particles=n).run_smc(kp)
             else:
-                coll = smc.resample(kr, coll, "systematic")
+                coll = smc.resample(kr, coll, kind)
                 ancs.append(coll.ancestors)
                 coll = smc.rejuvenate(km, coll, req)
                 coll = smc.extend(kp, coll, step, lambda tr_: (tr_.get_retval(), float(t)), obs)

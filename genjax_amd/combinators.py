@@ -1494,6 +1494,9 @@ class _ScanAdapter(GenerativeFunction):
 
     def assess(self, sample, args, batch_shape=None):
         from .static import run_gfi
+        if batch_shape is None:
+            # the Scan's own inference (Scan.assess): without it the step axis of the choices reads as a particle batch
+            batch_shape = _plate_batch(sample, lambda: self.scan_gf._length(self._pre(*args)[1]))
         return run_gfi(self, "assess", None, args, constraint=sample, batch_shape=batch_shape)
 
     def edit(self, key, trace, edit_request, argdiffs):

@@ -85,6 +85,35 @@ class TestIterateSimpleNormal:
             assert f(new_tr.get_choices()[i, "z"]) == 1.0
 
 
+    def test_assess_round_trip_of_the_scan_sugar(self):
+        """simulate, then assess(choices) is the trace's score and return value, for all four sugar combinators
+        (the adapters' assess read the step axis of the choices as a particle batch)"""
+        @genjax.gen
+        def walk(x):
+            return genjax.normal(x, 1.0) @ "z"
+
+        @genjax.gen
+        def drift(c, a):
+            return genjax.normal(c + a, 1.0) @ "z"
+        xs = jnp.array([0.5, -0.25, 1.0])
+        cases = [(walk.iterate(n=3), (0.0,)), (walk.iterate_final(n=3), (0.0,)),
+                 (drift.accumulate(), (0.0, xs)), (drift.reduce(), (0.0, xs))]
+        for gf, args in cases:
+            tr = gf.simulate(genjax.key(KEY), args)
+            score, ret = gf.assess(tr.get_choices(), args)
+            assert tuple(getattr(score, "shape", ())) == (), repr(gf)
+            assert f(score) == pytest.approx(f(tr.get_score()), rel=1e-6), repr(gf)
+            assert np.array_equal(arr(ret), arr(tr.get_retval())), repr(gf)
+            # and it is the chain of step densities, from scipy-checked normal log-densities
+            z = arr(tr.get_choices()[..., "z"]).reshape(-1)
+            prev = 0.0
+            want = 0.0
+            for t in range(3):
+                want += lp(z[t], prev + (f(xs[t]) if len(args) == 2 else 0.0))
+                prev = float(z[t])
+            assert f(score) == pytest.approx(want, rel=1e-5), repr(gf)
+
+
 @genjax.gen
 def inc(prev):
     return prev + 1

@@ -20,28 +20,10 @@ GMX_MAX_OUT = 64
 GMX_MAX_TAB = 8
 GMX_MAX_UNI = 64
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 KEY_NONE, KEY_ARRAY, KEY_SPLIT, KEY_ROWSPLIT, KEY_BCAST = 0, 1, 2, 3, 4
 RESAMPLE_SYSTEMATIC, RESAMPLE_STRATIFIED, RESAMPLE_MULTINOMIAL, RESAMPLE_MULTINOMIAL_TILED = 0, 1, 2, 3
 RESAMPLE_MULTINOMIAL_SORTED = 4
-
-
-class ResampleIn(Structure):
-    """struct gmx_resample_in: the resampling step folded into the next site program's launch"""
-    _fields_ = [
-        ("lw_d", c_void_p),
-        ("tile_max_d", c_void_p),
-        ("tile_agg_d", c_void_p),
-        ("anc_out_d", c_void_p),
-        ("max_out_d", c_void_p),
-        ("total_out_d", c_void_p),
-        ("kind", c_int32),
-        ("shift", c_int32),
-        ("key0", c_uint32),
-        ("key1", c_uint32),
-        ("u0", c_uint32),
-        ("reserved_", c_uint32),
-    ]
 
 
 class RunArgs(Structure):
@@ -63,9 +45,6 @@ class RunArgs(Structure):
         ("tile_shift", c_int32),
         ("reserved_", c_int32),
         ("step_stride", c_int64),
-        ("tile_q_d", c_void_p),
-        ("rs", ResampleIn),
-        ("tile_pref_d", c_void_p),
     ]
 
 
@@ -106,7 +85,6 @@ class Backend:
         c.gmx_program_grid.restype = c_int64
         c.gmx_program_run.argtypes = [c_void_p, c_int64, POINTER(RunArgs), c_void_p]
         c.gmx_program_writes_tile_stats.argtypes = [c_void_p]
-        c.gmx_program_fuses_resample.argtypes = [c_void_p]
         c.gmx_program_set_background.argtypes = [c_void_p, c_uint32]
         c.gmx_logsumexp_workspace.argtypes = [c_int64, c_int64]
         c.gmx_logsumexp_workspace.restype = c_size_t
@@ -140,8 +118,6 @@ class Backend:
         c.gmx_sorted_uniforms.argtypes = [c_void_p, c_int, c_int64, c_void_p, c_int, c_void_p]
         c.gmx_resample_sorted.argtypes = [POINTER(c_uint32), c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int,
                                           c_void_p, c_void_p, c_void_p, c_void_p]
-        c.gmx_resample_tiles_q.argtypes = [c_int, POINTER(c_uint32), c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p,
-                                           c_void_p, c_void_p, c_void_p]
         c.gmx_tile_prefix_words.argtypes = [c_int64]
         c.gmx_tile_prefix_words.restype = c_size_t
         c.gmx_tile_prefix.argtypes = [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]

@@ -124,25 +124,15 @@ __device__ __forceinline__ uint64_t weight_fixed(float lw, float ref, float scal
   return gmx_exp_fixed(lw - ref, (int)(gmx_f2u(scale) >> 23) - 127);
 }
 
-// ---- tile statistics -> tile prefixes, ONCE per resampling (include/genmi.h: gmx_run_args.tile_pref_d) ----
+// ---- tile statistics -> tile prefixes, ONCE per resampling (include/genmi.h: gmx_tile_prefix) ----
 // One workgroup of 256 threads turns the <= 2048 (m_b, A_b) into M, K = ceil(M / ln 2), the exclusive prefixes
 // P_b = sum_{b' < b} A_b' >> (K - k_b'), and the total.  Thread t owns the `per` consecutive tiles [t per, (t+1) per)
 // (per = ceil(tiles / 256): 1 .. 8): a running sum in registers, one u64 wave scan, three wave offsets.
 // Every thread of the workgroup reaches both barriers.  lds: >= 4 floats and 4 u64.
 #define GMX_TP_MAX_TILES 2048
 #define GMX_TP_PER_MAX (GMX_TP_MAX_TILES / GMX_BLOCK)
-// layout of the block (u64 words): [0, tiles) prefixes | [tiles] total | [tiles + 1] M, K | [tiles + 2] master ticket |
-// pad to a multiple of 16 | GMX_TP_SUB sub-tickets, one per 128-byte line.  Two levels of tickets: 977 workgroups
-// finishing within a microsecond of each other on ONE counter serialise (~11 ns per same-address atomic: measured
-// +10.7 us per launch); with 32 counters on lines of their own the longest chain is ~31 + 32 atomics.
-#define GMX_TP_SUB 32
-GMX_HD size_t gmx_tile_prefix_sub0_(int64_t tiles) { return (size_t)((tiles + 3 + 15) / 16) * 16; }
-GMX_HD size_t gmx_tile_prefix_words_(int64_t n) {
-  return gmx_tile_prefix_sub0_((n + 1023) / 1024) + (size_t)GMX_TP_SUB * 16;
-}
-// COHERENT: the table was published by other workgroups of THIS launch (atomic exchanges at agent scope): read it
-// with agent-scope atomic loads.
-template <bool COHERENT>
+// layout of the block (u64 words): [0, tiles) prefixes | [tiles] total | [tiles + 1] M, K | pad to a multiple of 16
+GMX_HD size_t gmx_tile_prefix_words_(int64_t n) { return (size_t)(((n + 1023) / 1024 + 2 + 15) / 16) * 16; }
 __device__ __forceinline__ void gmx_tile_prefix_block(const float* tmax, const uint64_t* agg, int n_tiles,
                                                       uint64_t* pref, float* lds4, uint64_t* lds8) {
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -155,14 +145,8 @@ __device__ __forceinline__ void gmx_tile_prefix_block(const float* tmax, const u
     if (r < per) {
       const int t = tid * per + r;
       const int tc = t < n_tiles ? t : n_tiles - 1;
-      if (COHERENT) {
-        ta[r] = __hip_atomic_load(agg + tc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        tm[r] = gmx_u2f(__hip_atomic_load(reinterpret_cast<const uint32_t*>(tmax) + tc, __ATOMIC_RELAXED,
-                                          __HIP_MEMORY_SCOPE_AGENT));
-      } else {
-        ta[r] = agg[tc];
-        tm[r] = tmax[tc];
-      }
+      ta[r] = agg[tc];
+      tm[r] = tmax[tc];
     }
   }
   float M = -gmx_inf();

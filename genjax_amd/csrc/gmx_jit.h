@@ -18,11 +18,6 @@
 #pragma once
 #include "gmx_block.h"
 #include "gmx_vm.h"
-#include "gmx_math2.h"
-#if defined(GMX_JIT_RS)      /* gmx_program_specialize under GENMI_FUSE_RESAMPLE=1: the kernel can resample first */
-#include "gmx_resample.h"
-extern __shared__ __attribute__((aligned(16))) char gmx_dyn_lds[];   // gmx_rs_window_lds(n) bytes when A.rs.lw_d is set
-#endif
 
 // a background program (gmx_program_set_background) keeps the default wave priority 0 and has a name of its own
 // (so that kernel traces tell the noise programs from the chain's site programs)
@@ -64,67 +59,16 @@ struct gmx_jit_ctx {
     acc_max = first ? m : gmx_rmax(acc_max, m);
     if (last) {
       const float bm = block_max(acc_max, lds4);
-      const bool pref = PPV == 4 && A->tile_agg_d && A->tile_pref_d;       // launch-uniform
-      // With tile_pref_d the workgroup's statistics are PUBLISHED (see below): atomic exchanges at agent scope instead
-      // of plain stores, so that the last workgroup can read them without any cache writeback / invalidate.
-      uint32_t old_m = 0u;
-      if (threadIdx.x == 0 && A->red_out_d) {
-        if (pref) old_m = __hip_atomic_exchange(reinterpret_cast<uint32_t*>(A->red_out_d) + blockIdx.x, gmx_f2u(bm),
-                                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else A->red_out_d[blockIdx.x] = bm;
-      }
+      if (threadIdx.x == 0 && A->red_out_d) A->red_out_d[blockIdx.x] = bm;
       if (PPV == 4 && A->tile_agg_d) {
         const float ref = gmx_tile_ref(gmx_tile_exp(bm));
         uint64_t s = 0;
-        uint32_t qp[PPV];
 #pragma unroll
-        for (int p = 0; p < PPV; ++p) { qp[p] = gmx_exp_fixed_packed(red_x[p] - ref, A->tile_shift); s += gmx_fixed_unpack(qp[p]); }
-        if (A->tile_q_d) {                  // inactive particles have red_x = -inf, i.e. q = 0
-#pragma unroll
-          for (int p = 0; p < PPV; ++p) {
-            const int64_t row = ((int64_t)blockIdx.x * PPV + p) * GMX_BLOCK + threadIdx.x;
-            if (row < n_rows) A->tile_q_d[row] = qp[p];
-          }
-        }
+        for (int p = 0; p < PPV; ++p) s += gmx_exp_fixed(red_x[p] - ref, A->tile_shift);   // inactive: red_x = -inf, weight 0
         s = wave_sum_u64(s);
         if ((threadIdx.x & 63) == 0) lds8[threadIdx.x >> 6] = s;
         __syncthreads();
-        if (!pref) {
-          if (threadIdx.x == 0) A->tile_agg_d[blockIdx.x] = (lds8[0] + lds8[1]) + (lds8[2] + lds8[3]);
-        } else {
-          // The LAST workgroup to get here turns all tile statistics into the tile prefixes, once, so that the
-          // resampler's workgroups need not each reduce the whole table (gmx_resample_tiles_p).  No fences: a
-          // release / acquire pair at agent scope writes back and invalidates the XCD's whole L2 — measured on MI355X,
-          // +21 us per step with 977 workgroups doing it.  Instead thread 0 publishes (m_b, A_b) with atomic
-          // exchanges that RETURN (they are performed at the coherence point before their result comes back), takes
-          // its ticket only after both results are in, and the last workgroup reads the table with agent-scope atomic
-          // loads (which go past the non-coherent cache levels).
-          // Tickets in two levels (gmx_block.h: GMX_TP_SUB counters on lines of their own, then one master counter).
-          uint32_t* ticket = reinterpret_cast<uint32_t*>(A->tile_pref_d + gridDim.x + 2);
-          if (threadIdx.x == 0) {
-            const uint64_t a = (lds8[0] + lds8[1]) + (lds8[2] + lds8[3]);
-            const uint64_t old_a = __hip_atomic_exchange(A->tile_agg_d + blockIdx.x, a, __ATOMIC_RELAXED,
-                                                         __HIP_MEMORY_SCOPE_AGENT);
-            asm volatile("" :: "v"(old_m), "v"(old_a) : "memory");         // both exchanges have completed
-            const uint32_t sub = blockIdx.x % (uint32_t)GMX_TP_SUB;
-            const uint32_t in_sub = (gridDim.x - sub + (uint32_t)GMX_TP_SUB - 1u) / (uint32_t)GMX_TP_SUB;
-            const uint32_t n_sub = gridDim.x < (uint32_t)GMX_TP_SUB ? gridDim.x : (uint32_t)GMX_TP_SUB;
-            uint32_t* st = reinterpret_cast<uint32_t*>(A->tile_pref_d + gmx_tile_prefix_sub0_((int64_t)gridDim.x) + 16u * sub);
-            uint32_t last = 0u;
-            if (__hip_atomic_fetch_add(st, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == in_sub - 1u) {
-              __hip_atomic_store(st, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch
-              last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_sub - 1u ? 1u : 0u;
-            }
-            lds4[0] = gmx_u2f(last);
-          }
-          __syncthreads();
-          const bool is_last = gmx_f2u(lds4[0]) != 0u;       // workgroup-uniform
-          __syncthreads();
-          if (is_last) {
-            gmx_tile_prefix_block<true>(A->red_out_d, A->tile_agg_d, (int)gridDim.x, A->tile_pref_d, lds4, lds8);
-            if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
-        }
+        if (threadIdx.x == 0) A->tile_agg_d[blockIdx.x] = (lds8[0] + lds8[1]) + (lds8[2] + lds8[3]);
       }
     }
   }
@@ -181,22 +125,9 @@ struct gmx_jit_ctx {
     }                                                                                            \
     (void)cidx; (void)arow; (void)pre; (void)gmx_t; (void)gmx_t0; (void)gmx_tf;
 
-// the ancestors of the thread's particles: loaded — or, for a fused bootstrap step (gmx_run_args.rs), computed
-// here from the previous step's log-weights and tile statistics (gmx_resample.h; workgroup-uniform branch)
-#if defined(GMX_JIT_RS)
-#define GMX_JIT_PRE_ANC                                                                          \
-    if (PP == 4 && A.rs.lw_d) {                                                                  \
-      if (A.rs.kind == GMX_RESAMPLE_SYSTEMATIC)                                                  \
-        gmx_rs_window<GMX_RESAMPLE_SYSTEMATIC>(A.rs, n, arow, gmx_dyn_lds);                      \
-      else                                                                                       \
-        gmx_rs_window<GMX_RESAMPLE_STRATIFIED>(A.rs, n, arow, gmx_dyn_lds);                      \
-    } else {                                                                                     \
-      _Pragma("unroll") for (int p = 0; p < PP; ++p) arow[p] = (uint32_t)A.ancestors_d[cidx[p]]; \
-    }
-#else
+// the ancestors of the thread's particles
 #define GMX_JIT_PRE_ANC                                                                          \
     _Pragma("unroll") for (int p = 0; p < PP; ++p) arow[p] = (uint32_t)A.ancestors_d[cidx[p]];
-#endif
 
 #define GMX_JIT_PRE_LOAD(K, SLOT, U8, ROW)                                                       \
     _Pragma("unroll") for (int p = 0; p < PP; ++p)                                               \
@@ -213,31 +144,6 @@ struct gmx_jit_ctx {
     _Pragma("unroll") for (int p = 0; p < PP; ++p) {                                             \
       ctx.part = blockIdx.x * PP + p; ctx.first = (p == 0); ctx.last = (p == PP - 1); ctx.cur = p; \
       gmx_vm_step<regs_t, full_v, gmx_cword<W0, W1>, ctx_t>(R[p], gmx_cword<W0, W1>(), idx[p], act[p], A, ctx, gmx_t, gmx_tf); \
-    }
-
-// OP_S_NORMAL for the thread's particles two at a time (gmx_math2.h: packed f32 arithmetic, the same bits): the keys
-// and operands are read exactly as gmx_vm_step reads them, each draw's 32 bits come from its own Threefry block, the
-// float pipeline runs on pairs, and `z * scale + loc` (gmx_normal_sample's two operations) finishes each particle.
-// Emitted by gmx_program_specialize instead of GMX_JIT_OP when PP is even.
-#define GMX_JIT_NORMAL2(W0, W1)                                                                  \
-    {                                                                                            \
-      constexpr uint32_t nw0 = (W0), nw1 = (W1);                                                 \
-      constexpr uint32_t nd = (nw0 >> 8) & 0xffu, na = (nw0 >> 16) & 0xffu, nb = nw0 >> 24;      \
-      constexpr uint32_t nc = nw1 & 0xffu, ne = nw1 >> 8;                                        \
-      uint32_t nbits[PP];                                                                        \
-      _Pragma("unroll") for (int p = 0; p < PP; ++p) {                                           \
-        gmx_key k; k.k0 = R[p].get(nc); k.k1 = R[p].get(nc + 1u);                                \
-        nbits[p] = gmx_bits32(k, (uint64_t)ne);                                                  \
-      }                                                                                          \
-      _Pragma("unroll") for (int p = 0; p + 1 < PP; p += 2) {                                    \
-        const gmx_f2 z = gmx_std_normal_from_bits2(nbits[p], nbits[p + 1]);                      \
-        _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                          \
-          const float loc = gmx_asf(na < GMX_POOL_BASE ? R[p + h].get(na) : ctx.pool(na - GMX_POOL_BASE));   \
-          const float scale = gmx_asf(nb < GMX_POOL_BASE ? R[p + h].get(nb) : ctx.pool(nb - GMX_POOL_BASE)); \
-          const float v = (h == 0 ? z.x : z.y) * scale;                                          \
-          R[p + h].set(nd, gmx_asu(v + loc));                                                    \
-        }                                                                                        \
-      }                                                                                          \
     }
 
 // OP_LOOP / OP_ENDLOOP: a counted loop around the instructions in between (launch-uniform trip count)

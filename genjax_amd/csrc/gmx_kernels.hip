@@ -134,7 +134,6 @@ struct gmx_program {
   hipModule_t jit_module = nullptr;  // specialised kernel (gmx_program_specialize)
   hipFunction_t jit_fn = nullptr;
   int jit_pp = 1;                    // particles per thread of the specialised kernel
-  bool jit_gathers_pre = false;      // every gathered load of the specialised kernel uses the prologue's ancestors
   uint64_t jit_code_hash = 0;        // FNV-1a of the loaded code object (gmx_program_code_hash)
   bool background = false;           // gmx_program_set_background: wave priority 0 ...
   unsigned lds_pad = 0;              // ... and this much unused dynamic LDS per workgroup (a residency cap)
@@ -259,10 +258,6 @@ static bool jit_enabled() {
 
 // particles per thread: as much ILP as the register budget allows at 8 waves / SIMD
 static int jit_pp_for(const gmx_program* p) {
-  const char* e = getenv("GENMI_JIT_PP");
-  if (e && e[0] >= '1' && e[0] <= '8') return e[0] - '0';
-  const char* eb = getenv("GENMI_JIT_PP_BG");        // background programs only (tuning)
-  if (p->background && eb && eb[0] >= '1' && eb[0] <= '8') return eb[0] - '0';
   // Measured on MI355X (BASELINE config 2, 1e6 particles): 4 particles / thread do not raise the VALU
   // issue rate of the integer-heavy Threefry stream (isolated launch 11.8 -> 13.7 us) but the kernel
   // is 0.9 us SHORTER inside the sweep (a quarter of the workgroups to schedule against the cold
@@ -275,40 +270,19 @@ static int jit_pp_for(const gmx_program* p) {
 // prefetch plan of a specialised kernel (gmx_jit.h): the distinct (slot, flags) of the program's per-particle
 // OP_LDIN instructions, at most JIT_MAX_PRE of them (PP registers each, held from the top of the kernel)
 #define JIT_MAX_PRE 8
-// GENMI_FUSE_RESAMPLE=1 (read when a program is specialised): kernels of gathering programs carry the resampling
-// prologue (gmx_run_args.rs, csrc/gmx_resample.h).  Off by default: measured slower than the two-launch step on MI355X
-// (DESIGN.md §4), and the prologue would lengthen every gathering program's hiprtc compile.
-static bool jit_with_rs() {
-  const char* e = getenv("GENMI_FUSE_RESAMPLE");
-  return e && e[0] == '1';
-}
-
-// GENMI_JIT_PAIR_NORMALS=1 (read when a program is specialised; OFF by default): normal draws two particles at a time
-// through the packed sampler (csrc/gmx_math2.h) instead of the scalar one — the same bits (the GPU parity suite passes
-// either way), 86 vector instructions fewer in the noise program, and SLOWER on MI355X (config 2: 16.55 vs 16.05
-// us/step noise-ahead, 18.9 vs 18.4 one-stream): the sampler is one dependent chain, and a dependent v_pk_fma_f32
-// issues at half the rate of a dependent v_fma_f32 (tools/calib.hip: one FMA chain 32.5 T, four 66.4 T).
-static bool jit_pair_normals() {
-  const char* e = getenv("GENMI_JIT_PAIR_NORMALS");
-  return e && e[0] == '1';
-}
-
-static std::string jit_source(const gmx_program* p, bool* gathers_prefetched = nullptr) {
-  std::string s = jit_with_rs() ? "#define GMX_JIT_RS 1\n" : "";
-  if (p->background) s += "#define GMX_JIT_BACKGROUND 1\n";
+static std::string jit_source(const gmx_program* p) {
+  std::string s = p->background ? "#define GMX_JIT_BACKGROUND 1\n" : "";
   s += "#include \"gmx_jit.h\"\n";
   char buf[128];
   s += "__device__ static constexpr uint32_t GMX_JIT_CONST[] = {";
   for (size_t k = 0; k < p->consts.size(); ++k) { snprintf(buf, sizeof(buf), "0x%08xu,", p->consts[k]); s += buf; }
   s += "0u};\n";
-  const char* pf = getenv("GENMI_JIT_PREFETCH");
-  const bool want_pre = !(pf && pf[0] == '0');
   struct pre_t { uint32_t slot, flags; };
   std::vector<pre_t> pres;
   std::vector<int> pre_of(p->n_instr, -1);
   bool any_gather = false;
   uint32_t first_gather_pc = p->n_instr, first_key_pc = p->n_instr;
-  bool fits = want_pre, seen_loop = false;
+  bool fits = true, seen_loop = false;
   for (uint32_t pc = 0; pc < p->n_instr && fits; ++pc) {
     const uint32_t w0 = p->code_h[2 * pc], op = w0 & 0xffu, a = (w0 >> 16) & 0xffu, b = w0 >> 24;
     if ((op == OP_LDKEY || op == OP_KDERIVE) && first_key_pc == p->n_instr && !seen_loop) first_key_pc = pc;
@@ -326,13 +300,6 @@ static std::string jit_source(const gmx_program* p, bool* gathers_prefetched = n
     if (b & GMX_F_GATHER) { any_gather = true; if (pc < first_gather_pc) first_gather_pc = pc; }
   }
   if (!fits) { pres.clear(); pre_of.assign(p->n_instr, -1); any_gather = false; }
-  if (gathers_prefetched) {          // every gathered load goes through the prologue's ancestors (GMX_JIT_PRE_ANC)
-    *gathers_prefetched = any_gather && jit_with_rs();
-    for (uint32_t pc = 0; pc < p->n_instr; ++pc) {
-      const uint32_t w0 = p->code_h[2 * pc];
-      if ((w0 & 0xffu) == OP_LDIN && ((w0 >> 24) & GMX_F_GATHER) && pre_of[pc] < 0) *gathers_prefetched = false;
-    }
-  }
   // second-stage (gathered) loads go behind the first key derivation when that comes before their first use
   const uint32_t gpos = (any_gather && first_key_pc < first_gather_pc) ? first_key_pc + 1 : 0;
   snprintf(buf, sizeof(buf), "GMX_JIT_BEGIN(%u, %s, %u, %d, %d)\n", p->n_regs < 16 ? 16u : (p->n_regs < 32 ? 32u : 64u),
@@ -363,8 +330,6 @@ static std::string jit_source(const gmx_program* p, bool* gathers_prefetched = n
       snprintf(buf, sizeof(buf), --jit_depth == 0 ? "  GMX_JIT_ENDLOOP\n" : "  GMX_JIT_ENDLOOP2\n");
     else if (pre_of[pc] >= 0)
       snprintf(buf, sizeof(buf), "  GMX_JIT_LDPRE(%u, %d)\n", (p->code_h[2 * pc] >> 8) & 0xffu, pre_of[pc]);
-    else if (op_ == OP_S_NORMAL && jit_pp_for(p) % 2 == 0 && jit_pair_normals())
-      snprintf(buf, sizeof(buf), "  GMX_JIT_NORMAL2(0x%08xu, 0x%08xu)\n", p->code_h[2 * pc], p->code_h[2 * pc + 1]);
     else
       snprintf(buf, sizeof(buf), "  GMX_JIT_OP(0x%08xu, 0x%08xu)\n", p->code_h[2 * pc], p->code_h[2 * pc + 1]);
     s += buf;
@@ -378,10 +343,6 @@ extern "C" int gmx_program_is_specialized(const gmx_program* p) { return p && p-
 extern "C" uint64_t gmx_program_code_hash(const gmx_program* p) { return p && p->jit_fn ? p->jit_code_hash : 0ull; }
 extern "C" int gmx_program_writes_tile_stats(const gmx_program* p) {
   return p && p->jit_fn && p->jit_pp == 4 && p->n_redmax == 1 && !p->uses_lse ? 1 : 0;
-}
-
-extern "C" int gmx_program_fuses_resample(const gmx_program* p) {
-  return p && p->jit_fn && p->jit_pp == 4 && p->uses_gather && p->jit_gathers_pre ? 1 : 0;
 }
 
 // A BACKGROUND program: work that depends on nothing a dependent chain of launches produces (the standard-normal
@@ -410,13 +371,6 @@ static uint64_t fnv1a(uint64_t h, const char* s, size_t n) {
   return h;
 }
 
-// GENMI_JIT_DEFS: one extra option for hiprtc (e.g. -DGMX_DIAG_...=...): DIAGNOSTIC builds only — timing experiments
-// that switch parts of the device code off; it is part of the code-object cache key.
-static const char* jit_extra_def() {
-  const char* e = getenv("GENMI_JIT_DEFS");
-  return (e && e[0] == '-') ? e : nullptr;
-}
-
 static std::string jit_cache_dir() {
   const char* e = getenv("GENMI_JIT_CACHE");
   if (e && e[0] == '0' && e[1] == '\0') return "";
@@ -437,7 +391,6 @@ static std::string jit_cache_path(const std::string& src) {
   std::string dir = jit_cache_dir();
   if (dir.empty()) return "";
   uint64_t h = fnv1a(0xcbf29ce484222325ull, src.data(), src.size());
-  if (jit_extra_def()) h = fnv1a(h, jit_extra_def(), strlen(jit_extra_def()));
   for (int k = 0; k < GMX_EMBED_COUNT; ++k) h = fnv1a(h, gmx_embed_src[k], strlen(gmx_embed_src[k]));
   int major = 0, minor = 0;
   (void)hiprtcVersion(&major, &minor);
@@ -482,10 +435,8 @@ static int jit_compile(const std::string& src, std::vector<char>& code) {
   for (int k = 0; k < GMX_EMBED_COUNT; ++k) { hdr_src[k] = gmx_embed_src[k]; hdr_name[k] = gmx_embed_name[k]; }
   hiprtcResult rc = hiprtcCreateProgram(&prog, src.c_str(), "gmx_jit_program.hip", GMX_EMBED_COUNT, hdr_src, hdr_name);
   if (rc != HIPRTC_SUCCESS) return gmx_fail("hiprtcCreateProgram: %s", hiprtcGetErrorString(rc));
-  const char* opts[5] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", nullptr};
-  int n_opts = 4;
-  if (jit_extra_def()) opts[n_opts++] = jit_extra_def();
-  rc = hiprtcCompileProgram(prog, n_opts, opts);
+  const char* opts[4] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"};
+  rc = hiprtcCompileProgram(prog, 4, opts);
   if (rc != HIPRTC_SUCCESS) {
     size_t ls = 0;
     hiprtcGetProgramLogSize(prog, &ls);
@@ -525,7 +476,7 @@ extern "C" int gmx_program_specialize(gmx_program* p) {
   if (p->jit_fn) return 0;
   if (!jit_enabled()) return gmx_fail("gmx_program_specialize: disabled by GENMI_JIT=0%s");
   if (p->n_instr == 0 || p->n_instr > 8192) return gmx_fail("gmx_program_specialize: program size out of range%s");
-  const std::string src = jit_source(p, &p->jit_gathers_pre);
+  const std::string src = jit_source(p);
   const std::string path = jit_cache_path(src);
   std::vector<char> code;
   if (jit_cache_read(path, code)) {
@@ -592,29 +543,7 @@ extern "C" int gmx_program_run(const gmx_program* p, int64_t n, const gmx_run_ar
     if (!args->out_d[s]) return gmx_fail("gmx_program_run: output slot %s%lld is null", "", s);
   for (uint32_t s = 0; s < p->n_tab; ++s)
     if (!args->tab_d[s]) return gmx_fail("gmx_program_run: table slot %s%lld is null", "", s);
-  const bool fused_rs = args->rs.lw_d != nullptr;
-  if (fused_rs) {
-    const gmx_resample_in& q = args->rs;
-    if (!gmx_program_fuses_resample(p))
-      return gmx_fail("gmx_program_run: rs is set but this program cannot resample in its own launch "
-                      "(gmx_program_fuses_resample: specialised, 4 particles per thread, gathering)%s");
-    if (!q.tile_max_d || !q.tile_agg_d || !q.anc_out_d) return gmx_fail("gmx_program_run: rs has a null pointer%s");
-    if (q.kind != GMX_RESAMPLE_SYSTEMATIC && q.kind != GMX_RESAMPLE_STRATIFIED)
-      return gmx_fail("gmx_program_run: rs.kind must be systematic or stratified%s");
-    if ((uintptr_t)q.lw_d & 15) return gmx_fail("gmx_program_run: rs.lw_d must be 16-byte aligned%s");
-    if ((n + GMX_RS_TILE - 1) / GMX_RS_TILE > GMX_RS_MAX_TILES)
-      return gmx_fail("gmx_program_run: rs: n too large for the fused resampler (n <= 2^21)%s");
-    if (q.shift < 1 || q.shift > 62) return gmx_fail("gmx_program_run: rs.shift out of range%s");
-    int need = 0;
-    while (((int64_t)1 << need) < n) ++need;
-    if (q.shift + need > 62) return gmx_fail("gmx_program_run: rs.shift too large for n (overflow)%s");
-    if (args->tile_agg_d == q.tile_agg_d || (const float*)args->red_out_d == q.tile_max_d)
-      return gmx_fail("gmx_program_run: rs reads the tile statistics this launch writes (use two sets)%s");
-    for (uint32_t s = 0; s < p->n_out; ++s)
-      if ((const void*)args->out_d[s] == (const void*)q.lw_d)
-        return gmx_fail("gmx_program_run: rs.lw_d is also an output of this launch (use two buffers)%s");
-  }
-  if (p->uses_gather && !args->ancestors_d && !fused_rs)
+  if (p->uses_gather && !args->ancestors_d)
     return gmx_fail("gmx_program_run: program gathers but ancestors_d is null%s");
   if (p->uses_red && !args->red_out_d)
     return gmx_fail("gmx_program_run: program reduces but red_out_d is null%s");
@@ -623,12 +552,6 @@ extern "C" int gmx_program_run(const gmx_program* p, int64_t n, const gmx_run_ar
       return gmx_fail("gmx_program_run: tile_agg_d is set but this program cannot write tile statistics "
                       "(gmx_program_writes_tile_stats)%s");
     if (args->tile_shift < 1 || args->tile_shift > 62) return gmx_fail("gmx_program_run: tile_shift out of range%s");
-    if ((uintptr_t)args->tile_q_d & 15) return gmx_fail("gmx_program_run: tile_q_d must be 16-byte aligned%s");
-    if (args->tile_pref_d && !args->red_out_d) return gmx_fail("gmx_program_run: tile_pref_d needs red_out_d%s");
-  } else if (args->tile_q_d) {
-    return gmx_fail("gmx_program_run: tile_q_d needs tile_agg_d%s");
-  } else if (args->tile_pref_d) {
-    return gmx_fail("gmx_program_run: tile_pref_d needs tile_agg_d%s");
   }
   if (p->uses_step && args->step_stride < n)
     return gmx_fail("gmx_program_run: step_stride must be at least n for a program with step-indexed leaves%s");
@@ -645,14 +568,9 @@ extern "C" int gmx_program_run(const gmx_program* p, int64_t n, const gmx_run_ar
   hipStream_t st = (hipStream_t)stream;
   // the program's constants live in the operand pool after the launch uniforms
   gmx_run_args patched;
-  if (p->n_const || fused_rs) {
+  if (p->n_const) {
     patched = *args;
     for (uint32_t k = 0; k < p->n_const; ++k) patched.uni[p->n_dyn + k] = p->consts[k];
-    if (fused_rs) {
-      uint32_t b0, b1;
-      gmx_threefry2x32(patched.rs.key0, patched.rs.key1, 0u, 0u, &b0, &b1);     // bits32(key, 0) on the host
-      patched.rs.u0 = (b0 ^ b1) >> 9;
-    }
     args = &patched;
   }
   if (p->jit_fn) {
@@ -674,8 +592,7 @@ extern "C" int gmx_program_run(const gmx_program* p, int64_t n, const gmx_run_ar
       ka.n = per_row;
     }
     unsigned jgrid = (unsigned)((per_row + (int64_t)GMX_BLOCK * p->jit_pp - 1) / ((int64_t)GMX_BLOCK * p->jit_pp));
-    unsigned dyn_lds = fused_rs ? (unsigned)gmx_rs_window_lds(n) : 0u;
-    if (p->lds_pad > dyn_lds) dyn_lds = p->lds_pad;
+    const unsigned dyn_lds = p->lds_pad;
     GMX_HIP(hipModuleLaunchKernel(p->jit_fn, jgrid, (unsigned)rows, 1, GMX_BLOCK, 1, 1, dyn_lds, st, nullptr, config));
     return 0;
   }
@@ -1546,8 +1463,6 @@ __device__ __forceinline__ int64_t sorted_below_exact(const sorted_ctx& X, uint6
 // affinity; it needs four separate prefixes per block and gives most of the saving back.)
 // Every load is issued before anything waits (unconditional, clamped addresses), wave-level reductions and scans are
 // DPP (gmx_block.h), the slot ranges are straight-line f64 code with one cold exact path.
-// FROMQ: the per-particle fixed-point weights come from memory (`qin`, written by the site program's epilogue:
-// gmx_run_args.tile_q_d, 4 bytes each: significand | shift) instead of being recomputed from the log-weights.
 #define RS_TPB 1
 #define RS_BLOCK (GMX_BLOCK * RS_TPB)
 #define RS_WAVES (RS_BLOCK / GMX_WAVE)
@@ -1555,16 +1470,14 @@ static_assert(RS_MAX_TILES % RS_BLOCK == 0, "tile table shape");
 // PER: rows of the tile table a thread holds (PER * 256 >= n_tiles; 1, 2, 4 or 8 — the launch picks the smallest):
 // the statistics pass is unrolled over exactly the rows that exist.
 #define RS_FILL_SLOTS 2048             /* slots filled per pass (8 per thread): a tile owns ~1024 */
-// FILL: how a tile's slots [T0, T1) get their ancestors.
-//   false  every thread writes its own sources' slots (one loop over [e[0], e[4])): the trip count is the wave's
-//          largest offspring count, so the cost grows with the spread of the weights (config 2: ~70 instructions per
-//          wave, config 3: ~220) and a degenerate weight vector leaves ONE thread writing every slot;
-//   true   through LDS: every source with a slot writes its index at its first one, a max-scan fills the rest (source
-//          indices increase with the slot), and the block stores 8 consecutive slots per thread (two 16-byte stores):
-//          the same cost whatever the weights; a tile owning more than 2048 slots takes more passes (block-uniform).
-template <int kind, bool FROMQ, int PER, bool FILL>
+// A tile's slots [T0, T1) get their ancestors through LDS: every source with a slot writes its index at its first one,
+// a max-scan fills the rest (source indices increase with the slot), and the block stores 8 consecutive slots per
+// thread (two 16-byte stores): the same cost whatever the weights (a thread writing its own sources' slots in a loop
+// diverges over the offspring counts: measured 2688 -> 34 us for N(0, 4) log-weights); a tile owning more than 2048
+// slots takes more passes (block-uniform).
+template <int kind, int PER>
 __global__ void __launch_bounds__(RS_BLOCK)
-k_offspring_tile(uint32_t k0, uint32_t k1, uint32_t u0_host, const float* __restrict__ lw, const uint32_t* __restrict__ qin,
+k_offspring_tile(uint32_t k0, uint32_t k1, uint32_t u0_host, const float* __restrict__ lw,
                  const float* __restrict__ tmax, const uint64_t* __restrict__ agg, int64_t n, int n_tiles, float scale,
                  float* __restrict__ max_out, uint64_t* __restrict__ total_out, int32_t* __restrict__ anc,
                  const uint32_t* __restrict__ uslot) {
@@ -1580,24 +1493,8 @@ k_offspring_tile(uint32_t k0, uint32_t k1, uint32_t u0_host, const float* __rest
   const int64_t i0 = (int64_t)tile_c * RS_TILE + (int64_t)ltid * CDF_VEC;
   // ---- issue every load first ----
   float x[CDF_VEC];
-  uint64_t qw[CDF_VEC];
   const bool full_tile = (int64_t)(tile_c + 1) * RS_TILE <= n;                   // wave-uniform
-  if (FROMQ) {                                    // packed fixed-point weights (gmx_math.h: gmx_fixed_unpack)
-    uint32_t pk[CDF_VEC];
-    if (full_tile) {
-      const uint4 a = *reinterpret_cast<const uint4*>(qin + i0);
-      pk[0] = a.x; pk[1] = a.y; pk[2] = a.z; pk[3] = a.w;
-    } else {
-#pragma unroll
-      for (int c = 0; c < CDF_VEC; ++c) {
-        const int64_t ic = i0 + c < n ? i0 + c : n - 1;
-        const uint32_t v = qin[ic];
-        pk[c] = (i0 + c < n) ? v : 0u;
-      }
-    }
-#pragma unroll
-    for (int c = 0; c < CDF_VEC; ++c) qw[c] = gmx_fixed_unpack(pk[c]);
-  } else if (full_tile) {
+  if (full_tile) {  } else if (full_tile) {
     float4 v = *reinterpret_cast<const float4*>(lw + i0);
     x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
   } else {
@@ -1608,9 +1505,8 @@ k_offspring_tile(uint32_t k0, uint32_t k1, uint32_t u0_host, const float* __rest
       x[c] = (i0 + c < n) ? xv : -gmx_inf();
     }
   }
-  // PER == 0: the tile PREFIXES are there already (`agg` = gmx_run_args.tile_pref_d, written once by the last
-  // workgroup of the site program): this workgroup reads its own prefix, the total and (M, K) — three loads instead of
-  // a pass over the whole table.
+  // PER == 0: the tile PREFIXES are there already (`agg` = the block gmx_tile_prefix wrote): this workgroup reads its
+  // own prefix, the total and (M, K) — three loads instead of a pass over the whole table.
   constexpr bool PREF = (PER == 0);
   constexpr int PERN = PREF ? 1 : PER;
   static_assert(PER >= 0 && PER * RS_BLOCK <= RS_MAX_TILES, "rows of the tile table per thread");
@@ -1664,7 +1560,7 @@ k_offspring_tile(uint32_t k0, uint32_t k1, uint32_t u0_host, const float* __rest
   uint64_t run = 0;
 #pragma unroll
   for (int c = 0; c < CDF_VEC; ++c) {
-    const uint64_t w = FROMQ ? qw[c] : weight_fixed(x[c], ref_b, scale);
+    const uint64_t w = weight_fixed(x[c], ref_b, scale);
     run += (tile_ok && i0 + c < n) ? w : 0ull;
     q[c] = run;
   }
@@ -1844,17 +1740,10 @@ k_offspring_tile(uint32_t k0, uint32_t k1, uint32_t u0_host, const float* __rest
     __syncthreads();
     if (lane == 0 && wave > 0) e[0] = s_edge[wave - 1];
   }
-  // ONE loop over the thread's slots [e[0], e[4]) — its trip count diverges over the thread's total offspring
-  // (mean 4) instead of four loops each diverging over one source's (mean 1, max ~4); slots are < 2^31.
   // Sources past n have e[c] = n = e of the last real source, so they own no slot.
-  const int32_t e1 = e[1], e2 = e[2], e3 = e[3], e4 = e[4];
+  const int32_t e4 = e[4];
   const int32_t src0 = (int32_t)i0;
-  if (!FILL) {
-    for (int32_t j = e[0]; j < e4; ++j)
-      anc[j] = src0 + (j >= e1 ? 1 : 0) + (j >= e2 ? 1 : 0) + (j >= e3 ? 1 : 0);
-    return;
-  }
-  static_assert(!FILL || RS_TPB == 1, "the LDS fill works on one tile per block");
+  static_assert(RS_TPB == 1, "the LDS fill works on one tile per block");
   __shared__ __attribute__((aligned(16))) uint32_t s_mark[RS_FILL_SLOTS];
   __shared__ int32_t s_rng[2];
   __shared__ uint32_t s_carry[RS_WAVES];
@@ -1920,7 +1809,7 @@ static int resample_shape(const char* who, int64_t n, int shift, bool any_n = fa
   return 0;
 }
 
-static int launch_offspring_tile(int kind, const uint32_t key[2], const float* lw_d, const uint32_t* q_d, int64_t n, int shift,
+static int launch_offspring_tile(int kind, const uint32_t key[2], const float* lw_d, int64_t n, int shift,
                                  const float* tile_max_d, const uint64_t* tile_agg_d, float* max_d, uint64_t* total_d,
                                  int32_t* ancestors_d, gmx_stream stream, bool pref = false, const uint32_t* u_d = nullptr) {
   uint32_t b0, b1;
@@ -1930,30 +1819,25 @@ static int launch_offspring_tile(int kind, const uint32_t key[2], const float* l
   const dim3 grid((unsigned)((tiles + RS_TPB - 1) / RS_TPB)), block(RS_BLOCK);
   hipStream_t st = (hipStream_t)stream;
   const float scale = gmx_pow2i(shift);
-  static const bool fill = []() { const char* e = getenv("GENMI_RS_FILL"); return !(e && e[0] == '0'); }();   // default: through LDS
-#define GMX_LAUNCH_OT4(KIND, FQ, PER_, FILL_)                                                                        \
-  hipLaunchKernelGGL((k_offspring_tile<KIND, FQ, PER_, FILL_>), grid, block, 0, st, key[0], key[1], u0, lw_d, q_d,     \
-                     tile_max_d, tile_agg_d, n, (int)tiles, scale, max_d, total_d, ancestors_d, u_d)
-#define GMX_LAUNCH_OT3(KIND, FQ, PER_) do { if (fill) GMX_LAUNCH_OT4(KIND, FQ, PER_, true); else GMX_LAUNCH_OT4(KIND, FQ, PER_, false); } while (0)
-#define GMX_LAUNCH_OT(KIND, FQ)                                                                                     \
+#define GMX_LAUNCH_OT2(KIND, PER_)                                                                                   \
+  hipLaunchKernelGGL((k_offspring_tile<KIND, PER_>), grid, block, 0, st, key[0], key[1], u0, lw_d, tile_max_d,        \
+                     tile_agg_d, n, (int)tiles, scale, max_d, total_d, ancestors_d, u_d)
+#define GMX_LAUNCH_OT(KIND)                                                                                         \
   do {                                                                                                              \
-    if (pref) GMX_LAUNCH_OT3(KIND, FQ, 0);          /* `tile_agg_d` is the prefix block (gmx_run_args.tile_pref_d) */ \
-    else if (tiles <= 1 * RS_BLOCK) GMX_LAUNCH_OT3(KIND, FQ, 1);                                                    \
-    else if (tiles <= 2 * RS_BLOCK) GMX_LAUNCH_OT3(KIND, FQ, 2);                                                    \
-    else if (tiles <= 4 * RS_BLOCK) GMX_LAUNCH_OT3(KIND, FQ, 4);                                                    \
-    else GMX_LAUNCH_OT3(KIND, FQ, 8);                                                                               \
+    if (pref) GMX_LAUNCH_OT2(KIND, 0);          /* `tile_agg_d` is the prefix block gmx_tile_prefix wrote */         \
+    else if (tiles <= 1 * RS_BLOCK) GMX_LAUNCH_OT2(KIND, 1);                                                        \
+    else if (tiles <= 2 * RS_BLOCK) GMX_LAUNCH_OT2(KIND, 2);                                                        \
+    else if (tiles <= 4 * RS_BLOCK) GMX_LAUNCH_OT2(KIND, 4);                                                        \
+    else GMX_LAUNCH_OT2(KIND, 8);                                                                                   \
   } while (0)
-  if (kind == GMX_RESAMPLE_SYSTEMATIC) { if (q_d) GMX_LAUNCH_OT(GMX_RESAMPLE_SYSTEMATIC, true); else GMX_LAUNCH_OT(GMX_RESAMPLE_SYSTEMATIC, false); }
-  else if (kind == GMX_RESAMPLE_MULTINOMIAL_SORTED) {        // through LDS, from the log-weights, the 977-fold statistics pass
-    if (tiles <= 1 * RS_BLOCK) GMX_LAUNCH_OT4(GMX_RESAMPLE_MULTINOMIAL_SORTED, false, 1, true);
-    else if (tiles <= 2 * RS_BLOCK) GMX_LAUNCH_OT4(GMX_RESAMPLE_MULTINOMIAL_SORTED, false, 2, true);
-    else if (tiles <= 4 * RS_BLOCK) GMX_LAUNCH_OT4(GMX_RESAMPLE_MULTINOMIAL_SORTED, false, 4, true);
-    else GMX_LAUNCH_OT4(GMX_RESAMPLE_MULTINOMIAL_SORTED, false, 8, true);
+  if (kind == GMX_RESAMPLE_SYSTEMATIC) GMX_LAUNCH_OT(GMX_RESAMPLE_SYSTEMATIC);
+  else if (kind == GMX_RESAMPLE_MULTINOMIAL_SORTED) {        // from the log-weights, the 977-fold statistics pass
+    if (pref) return gmx_fail("%s: the sorted multinomial reads the tile statistics, not their prefixes", "launch_offspring_tile");
+    GMX_LAUNCH_OT(GMX_RESAMPLE_MULTINOMIAL_SORTED);
   }
-  else { if (q_d) GMX_LAUNCH_OT(GMX_RESAMPLE_STRATIFIED, true); else GMX_LAUNCH_OT(GMX_RESAMPLE_STRATIFIED, false); }
+  else GMX_LAUNCH_OT(GMX_RESAMPLE_STRATIFIED);
 #undef GMX_LAUNCH_OT
-#undef GMX_LAUNCH_OT3
-#undef GMX_LAUNCH_OT4
+#undef GMX_LAUNCH_OT2
   GMX_HIP(hipGetLastError());
   return 0;
 }
@@ -1980,20 +1864,7 @@ extern "C" int gmx_resample_tiles(int kind, const uint32_t key[2], const float* 
     return gmx_fail("gmx_resample_tiles: kind must be systematic or stratified (use gmx_weight_cdf + gmx_ancestors)%s");
   if (n > 0x7fffffffLL) return gmx_fail("gmx_resample_tiles: n out of range%s");
   if ((uintptr_t)lw_d & 15) return gmx_fail("gmx_resample_tiles: lw_d must be 16-byte aligned%s");
-  return launch_offspring_tile(kind, key, lw_d, nullptr, n, shift, tile_max_d, tile_agg_d, max_d, total_d, ancestors_d, stream);
-}
-
-extern "C" int gmx_resample_tiles_q(int kind, const uint32_t key[2], const uint32_t* q_d, int64_t n, int shift,
-                                    const float* tile_max_d, const uint64_t* tile_agg_d, float* max_d,
-                                    uint64_t* total_d, int32_t* ancestors_d, gmx_stream stream) {
-  if (resample_shape("gmx_resample_tiles_q", n, shift)) return 1;
-  if (!key || !q_d || !tile_max_d || !tile_agg_d || !max_d || !total_d || !ancestors_d)
-    return gmx_fail("gmx_resample_tiles_q: null argument%s");
-  if (kind != GMX_RESAMPLE_SYSTEMATIC && kind != GMX_RESAMPLE_STRATIFIED)
-    return gmx_fail("gmx_resample_tiles_q: kind must be systematic or stratified%s");
-  if (n > 0x7fffffffLL) return gmx_fail("gmx_resample_tiles_q: n out of range%s");
-  if ((uintptr_t)q_d & 15) return gmx_fail("gmx_resample_tiles_q: q_d must be 16-byte aligned%s");
-  return launch_offspring_tile(kind, key, nullptr, q_d, n, shift, tile_max_d, tile_agg_d, max_d, total_d, ancestors_d, stream);
+  return launch_offspring_tile(kind, key, lw_d, n, shift, tile_max_d, tile_agg_d, max_d, total_d, ancestors_d, stream);
 }
 
 // ---- two-stage multinomial resampling (include/genmi.h: gmx_multinomial_tiled) ----
@@ -2335,7 +2206,7 @@ extern "C" int gmx_multinomial_tiled(const uint32_t key[2], const float* lw_d, i
   gmx_threefry2x32(key[0], key[1], 0u, 0u, &k1[0], &k1[1]);
   gmx_threefry2x32(key[0], key[1], 0u, 1u, &k2[0], &k2[1]);
   const int64_t want = (n + 8 * GMX_BLOCK - 1) / (8 * GMX_BLOCK);              // >= 8 slots per thread
-  static const int max_hb = []() { const char* e = getenv("GENMI_MN_HIST_BLOCKS"); int v = e ? atoi(e) : 0; return v > 0 ? v : MN_HIST_BLOCKS; }();
+  const int max_hb = MN_HIST_BLOCKS;
   const unsigned hb = (unsigned)(want < 1 ? 1 : (want < max_hb ? want : max_hb));
   hipLaunchKernelGGL(k_mn_hist, dim3(hb), dim3(GMX_BLOCK), 0, st, k1[0], k1[1], tile_max_d, tile_agg_d, n, (int)tiles, u_d,
                      max_d, total_d, counts);
@@ -2395,7 +2266,7 @@ extern "C" int gmx_resample_tiles_u(int kind, const uint32_t key[2], const float
   if (kind != GMX_RESAMPLE_STRATIFIED) return gmx_fail("gmx_resample_tiles_u: stratified only (systematic draws one uniform)%s");
   if (n > 0x7fffffffLL) return gmx_fail("gmx_resample_tiles_u: n out of range%s");
   if ((uintptr_t)lw_d & 15) return gmx_fail("gmx_resample_tiles_u: lw_d must be 16-byte aligned%s");
-  return launch_offspring_tile(kind, key, lw_d, nullptr, n, shift, tile_max_d, tile_agg_d, max_d, total_d, ancestors_d, stream,
+  return launch_offspring_tile(kind, key, lw_d, n, shift, tile_max_d, tile_agg_d, max_d, total_d, ancestors_d, stream,
                                false, u_d);
 }
 
@@ -2613,7 +2484,7 @@ extern "C" int gmx_resample_sorted(const uint32_t key[2], const float* lw_d, int
   if (((uintptr_t)lw_d & 15) || ((uintptr_t)table_d & 15))
     return gmx_fail("gmx_resample_sorted: lw_d and table_d must be 16-byte aligned%s");
   if (!table_ready && launch_sorted_uniforms(nullptr, key, 1, n, table_d, 0, stream)) return 1;
-  return launch_offspring_tile(GMX_RESAMPLE_MULTINOMIAL_SORTED, key, lw_d, nullptr, n, shift, tile_max_d, tile_agg_d, max_d,
+  return launch_offspring_tile(GMX_RESAMPLE_MULTINOMIAL_SORTED, key, lw_d, n, shift, tile_max_d, tile_agg_d, max_d,
                                total_d, ancestors_d, stream, false, table_d);
 }
 
@@ -2623,7 +2494,7 @@ __global__ void __launch_bounds__(GMX_BLOCK)
 k_tile_prefix(const float* __restrict__ tmax, const uint64_t* __restrict__ agg, int n_tiles, uint64_t* __restrict__ pref) {
   __shared__ float lds4[4];
   __shared__ uint64_t lds8[4];
-  gmx_tile_prefix_block<false>(tmax, agg, n_tiles, pref, lds4, lds8);
+  gmx_tile_prefix_block(tmax, agg, n_tiles, pref, lds4, lds8);
 }
 
 // more than RS_MAX_TILES tiles (n > 2^21: BASELINE config 4's 1e7 particles are 9766): ONE workgroup walks the table in
@@ -2696,7 +2567,7 @@ extern "C" int gmx_resample_tiles_p(int kind, const uint32_t key[2], const float
     return gmx_fail("gmx_resample_tiles_p: kind must be systematic or stratified%s");
   if (n > 0x7fffffffLL) return gmx_fail("gmx_resample_tiles_p: n out of range%s");
   if ((uintptr_t)lw_d & 15) return gmx_fail("gmx_resample_tiles_p: lw_d must be 16-byte aligned%s");
-  return launch_offspring_tile(kind, key, lw_d, nullptr, n, shift, tile_max_d, tile_pref_d, max_d, total_d, ancestors_d,
+  return launch_offspring_tile(kind, key, lw_d, n, shift, tile_max_d, tile_pref_d, max_d, total_d, ancestors_d,
                                stream, true);
 }
 
@@ -2855,62 +2726,31 @@ k_shard_route(int kind, uint32_t k0, uint32_t k1, int64_t* __restrict__ plan, co
 // where a source's local CDF value comes from: the array gmx_weight_cdf wrote (TILES = false), or — like
 // k_offspring_tile — rebuilt in registers from the log-weights and this rank's tile statistics (TILES = true:
 // a block is one 1024-particle tile; tmax / agg are this rank's, *max_g the GLOBAL max log-weight)
-// FUSED (with TILES): the all-gathered statistics table itself (stats_all: `world` blocks of `stride` bytes) instead of
-// the totals gmx_shard_totals derives from it — every block reduces the table (world x tiles rows: the global max, then
-// one integer total per rank), which takes a one-block launch out of the step's dependent chain.
-struct shard_tiles { const float* lw; const float* tmax; const uint64_t* agg; const float* max_g; float scale; int n_tiles;
-                     const uint8_t* stats_all; size_t stride; float* max_out; };
+struct shard_tiles { const float* lw; const float* tmax; const uint64_t* agg; const float* max_g; float scale; int n_tiles; };
 
-template <bool TILES, bool FUSED>
+template <bool TILES>
 __global__ void __launch_bounds__(GMX_BLOCK)
 k_shard_step(int kind, uint32_t k0, uint32_t k1, const uint64_t* __restrict__ totals, int64_t* __restrict__ plan,
              uint64_t* __restrict__ total_out, const uint64_t* __restrict__ cdf, const shard_tiles TS, int rank,
              int world, int64_t n, int64_t cap, const uint32_t* __restrict__ state, uint32_t* __restrict__ send,
              int32_t* __restrict__ next_idx) {
-  static_assert(!FUSED || TILES, "the fused form works from tile statistics");
   __shared__ int64_t s_bounds[SHARD_MAX_WORLD + 1];
   __shared__ uint64_t s_tot[2];            // global total, this rank's CDF offset
   __shared__ uint64_t s_below[4], s_scan[4];
-  __shared__ uint64_t s_rtot[FUSED ? SHARD_MAX_WORLD : 1];
-  __shared__ float s_lds4[4];
   gmx_key key; key.k0 = k0; key.k1 = k1;
   const uint64_t u0 = gmx_bits32(key, 0) >> 9;
   const int64_t N = n * world, base = (int64_t)rank * n;
   const uint64_t D = (uint64_t)N << 23;
-  int32_t K_fused = 0;
-  if (FUSED) {
-    const int tiles_pad = TS.n_tiles + (TS.n_tiles & 1);
-    float m = -gmx_inf();
-    for (int r = 0; r < world; ++r) {
-      const float* tmax = reinterpret_cast<const float*>(TS.stats_all + (size_t)r * TS.stride + (size_t)tiles_pad * 8);
-      for (int t = (int)threadIdx.x; t < TS.n_tiles; t += GMX_BLOCK) m = gmx_rmax(m, tmax[t]);
-    }
-    const float M = block_max(m, s_lds4);
-    K_fused = gmx_tile_exp(M);
-    if (blockIdx.x == 0 && threadIdx.x == 0 && TS.max_out) *TS.max_out = M;
-    for (int r = 0; r < world; ++r) {
-      const uint64_t* agg = reinterpret_cast<const uint64_t*>(TS.stats_all + (size_t)r * TS.stride);
-      const float* tmax = reinterpret_cast<const float*>(TS.stats_all + (size_t)r * TS.stride + (size_t)tiles_pad * 8);
-      uint64_t sum = 0;
-      for (int t = (int)threadIdx.x; t < TS.n_tiles; t += GMX_BLOCK) sum += gmx_tile_scale(agg[t], gmx_tile_exp(tmax[t]), K_fused);
-      sum = wave_sum_u64(sum);
-      __syncthreads();
-      if ((threadIdx.x & 63) == 0) s_scan[threadIdx.x >> 6] = sum;
-      __syncthreads();
-      if (threadIdx.x == 0) s_rtot[r] = (s_scan[0] + s_scan[1]) + (s_scan[2] + s_scan[3]);
-    }
-    __syncthreads();
-  }
   if (threadIdx.x == 0) {
     uint64_t total = 0;
-    for (int s = 0; s < world; ++s) total += FUSED ? s_rtot[s] : totals[s];
+    for (int s = 0; s < world; ++s) total += totals[s];
     const double not_ = total ? (double)N / (double)total : 0.0;
     const double eps_ = (double)N * 0x1p-44 + 0x1p-40;
     uint64_t off = 0, mine = 0;
     for (int s = 0; s < world; ++s) {
       if (s == rank) mine = off;
       s_bounds[s] = total ? slots_below(kind, key, u0, off, D, total, not_, eps_, N) : 0;
-      off += FUSED ? s_rtot[s] : totals[s];
+      off += totals[s];
     }
     s_bounds[world] = N;
     s_tot[0] = total; s_tot[1] = mine;
@@ -2954,7 +2794,7 @@ k_shard_step(int kind, uint32_t k0, uint32_t k1, const uint64_t* __restrict__ to
       // this rank's CDF at my 4 sources = (mass of this rank's earlier tiles) + (tile-local sums >> (K - k_b)),
       // with the tile-local sums rebuilt from the log-weights (k_offspring_tile's scheme)
       const int wave = threadIdx.x >> 6, my_tile = (int)blockIdx.x;
-      const int32_t K = FUSED ? K_fused : gmx_tile_exp(*TS.max_g);
+      const int32_t K = gmx_tile_exp(*TS.max_g);
       const int32_t k_b = gmx_tile_exp(TS.tmax[my_tile]);
       const float ref_b = gmx_tile_ref(k_b);
       float x[4];
@@ -3074,8 +2914,8 @@ extern "C" int gmx_shard_step(int kind, const uint32_t key[2], const uint64_t* t
                            stream);
   }
   if ((uintptr_t)cdf_d & 15) return gmx_fail("gmx_shard_step: cdf_d must be 16-byte aligned%s");
-  shard_tiles none = {nullptr, nullptr, nullptr, nullptr, 0.0f, 0, nullptr, 0, nullptr};
-  hipLaunchKernelGGL((k_shard_step<false, false>), grid_for((n_per_rank + 3) / 4), dim3(GMX_BLOCK), 0, (hipStream_t)stream,
+  shard_tiles none = {nullptr, nullptr, nullptr, nullptr, 0.0f, 0};
+  hipLaunchKernelGGL((k_shard_step<false>), grid_for((n_per_rank + 3) / 4), dim3(GMX_BLOCK), 0, (hipStream_t)stream,
                      kind, key[0], key[1], totals_d, plan_d, total_out_d, cdf_d, none, rank, world, n_per_rank,
                      capacity, (const uint32_t*)state_d, (uint32_t*)send_d, next_idx_d);
   GMX_HIP(hipGetLastError());
@@ -3158,15 +2998,14 @@ extern "C" int gmx_shard_step_tiles(int kind, const uint32_t key[2], const uint6
   ts.agg = (const uint64_t*)stats_own_d;
   ts.tmax = (const float*)((const uint8_t*)stats_own_d + (size_t)tiles_pad * 8);
   ts.max_g = max_d; ts.scale = gmx_pow2i(shift); ts.n_tiles = (int)tiles;
-  ts.stats_all = nullptr; ts.stride = 0; ts.max_out = nullptr;
-  hipLaunchKernelGGL((k_shard_step<true, false>), dim3((unsigned)tiles), dim3(GMX_BLOCK), 0, (hipStream_t)stream, kind, key[0],
+  hipLaunchKernelGGL((k_shard_step<true>), dim3((unsigned)tiles), dim3(GMX_BLOCK), 0, (hipStream_t)stream, kind, key[0],
                      key[1], totals_d, plan_d, total_out_d, (const uint64_t*)nullptr, ts, rank, world, n_per_rank,
                      capacity, (const uint32_t*)state_d, (uint32_t*)send_d, next_idx_d);
   GMX_HIP(hipGetLastError());
   return 0;
 }
 
-// The fused step on k_offspring_tile's scheme (what gmx_shard_step_fused launches; GENMI_SHARD_FILL=0: k_shard_step<true, true>).
+// The fused step on k_offspring_tile's scheme (what gmx_shard_step_fused launches).
 // A workgroup is one 1024-particle tile of this rank's shard.  It derives M, K, every rank's total and the slot bounds
 // from the gathered statistics table (two barriers whatever the world size: partial sums per (rank, wave), then
 // thread s evaluates rank s's bound), rebuilds its tile's CDF in registers, gets its sources' slot runs from the
@@ -3497,37 +3336,22 @@ extern "C" int gmx_shard_step_fused(int kind, const uint32_t key[2], const void*
   if (tiles > RS_MAX_TILES) return gmx_fail("gmx_shard_step_fused: n_per_rank too large (<= 2^21)%s");
   if (((uintptr_t)lw_d & 15) || ((uintptr_t)stats_all_d & 7))
     return gmx_fail("gmx_shard_step_fused: lw_d must be 16-byte and stats_all_d 8-byte aligned%s");
-  const int64_t tiles_pad = tiles + (tiles & 1);
   const size_t stride = gmx_shard_stats_bytes(n_per_rank);
-  const uint8_t* own = (const uint8_t*)stats_all_d + (size_t)rank * stride;
-  shard_tiles ts;
-  ts.lw = lw_d;
-  ts.agg = (const uint64_t*)own;
-  ts.tmax = (const float*)(own + (size_t)tiles_pad * 8);
-  ts.max_g = nullptr; ts.scale = gmx_pow2i(shift); ts.n_tiles = (int)tiles;
-  ts.stats_all = (const uint8_t*)stats_all_d; ts.stride = stride; ts.max_out = max_out_d;
-  const char* fill_env = getenv("GENMI_SHARD_FILL");           // read per call: the tests compare both forms in one process
-  const bool fill = !(fill_env && fill_env[0] == '0');
-  if (fill && n_per_rank * world < (1LL << 30)) {      // slots as 32-bit integers: the LDS-routed form
-    uint32_t b0, b1;
-    gmx_threefry2x32(key[0], key[1], 0u, 0u, &b0, &b1);           // bits32(key, 0) on the host
-    const uint32_t u0 = (b0 ^ b1) >> 9;
-    const bool small = world <= 8 && (int64_t)world * tiles <= 4 * GMX_BLOCK;
+  const float scale = gmx_pow2i(shift);
+  // n_per_rank <= 2^21 and world <= 64: slots are 32-bit integers
+  uint32_t b0, b1;
+  gmx_threefry2x32(key[0], key[1], 0u, 0u, &b0, &b1);           // bits32(key, 0) on the host
+  const uint32_t u0 = (b0 ^ b1) >> 9;
+  const bool small = world <= 8 && (int64_t)world * tiles <= 4 * GMX_BLOCK;
 #define GMX_LAUNCH_SF2(KIND, SM)                                                                                      \
-    hipLaunchKernelGGL((k_shard_step_fill<KIND, SM>), dim3((unsigned)tiles), dim3(GMX_BLOCK), 0, (hipStream_t)stream, key[0],  \
-                       key[1], u0, lw_d, (const uint8_t*)stats_all_d, stride, (int)tiles, ts.scale, rank, world,       \
-                       (int32_t)n_per_rank, (int32_t)capacity, plan_d, total_out_d, max_out_d, (const uint32_t*)state_d,   \
-                       (uint32_t*)send_d, next_idx_d)
+  hipLaunchKernelGGL((k_shard_step_fill<KIND, SM>), dim3((unsigned)tiles), dim3(GMX_BLOCK), 0, (hipStream_t)stream, key[0],  \
+                     key[1], u0, lw_d, (const uint8_t*)stats_all_d, stride, (int)tiles, scale, rank, world,           \
+                     (int32_t)n_per_rank, (int32_t)capacity, plan_d, total_out_d, max_out_d, (const uint32_t*)state_d,   \
+                     (uint32_t*)send_d, next_idx_d)
 #define GMX_LAUNCH_SF(KIND) do { if (small) GMX_LAUNCH_SF2(KIND, true); else GMX_LAUNCH_SF2(KIND, false); } while (0)
-    if (kind == GMX_RESAMPLE_SYSTEMATIC) GMX_LAUNCH_SF(GMX_RESAMPLE_SYSTEMATIC); else GMX_LAUNCH_SF(GMX_RESAMPLE_STRATIFIED);
+  if (kind == GMX_RESAMPLE_SYSTEMATIC) GMX_LAUNCH_SF(GMX_RESAMPLE_SYSTEMATIC); else GMX_LAUNCH_SF(GMX_RESAMPLE_STRATIFIED);
 #undef GMX_LAUNCH_SF
 #undef GMX_LAUNCH_SF2
-    GMX_HIP(hipGetLastError());
-    return 0;
-  }
-  hipLaunchKernelGGL((k_shard_step<true, true>), dim3((unsigned)tiles), dim3(GMX_BLOCK), 0, (hipStream_t)stream, kind, key[0],
-                     key[1], (const uint64_t*)nullptr, plan_d, total_out_d, (const uint64_t*)nullptr, ts, rank, world,
-                     n_per_rank, capacity, (const uint32_t*)state_d, (uint32_t*)send_d, next_idx_d);
   GMX_HIP(hipGetLastError());
   return 0;
 }

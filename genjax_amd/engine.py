@@ -798,14 +798,10 @@ class Compiled:
         program running 4 particles per thread with exactly one block-max reduction."""
         return bool(self._be.c.gmx_program_writes_tile_stats(self.handle))
 
-    def fuses_resample(self) -> bool:
-        """True when `run(..., resample_in=...)` is honoured (include/genmi.h: gmx_program_fuses_resample)."""
-        return bool(self._be.c.gmx_program_fuses_resample(self.handle))
-
     def run(self, leaves, batch: tuple, key: Key | None, red_out=None, index_offset=0, out_buffers=None,
-            tile_stats=None, resample_in=None):
+            tile_stats=None):
         """Bind and launch.  Returns the list of output tensors (shape batch+event)."""
-        bound = self.bind(leaves, batch, key, red_out, index_offset, out_buffers, tile_stats, resample_in)
+        bound = self.bind(leaves, batch, key, red_out, index_offset, out_buffers, tile_stats)
         self.launch(bound)
         return bound[3]
 
@@ -824,18 +820,11 @@ class Compiled:
         be.check(be.c.gmx_program_run(self.handle, bound[0], bound[1], be.stream()), "gmx_program_run")
 
     def bind(self, leaves, batch: tuple, key: Key | None, red_out=None, index_offset=0, out_buffers=None,
-             tile_stats=None, resample_in=None):
+             tile_stats=None):
         """Fill a gmx_run_args for these leaves: (n, args, keep-alive list, outputs).  Sweeps whose
         buffers are persistent bind every step once and re-launch the bindings.
-        tile_stats = (int64 tensor [grid], shift[, int32 tensor [n] | None[, int64 tensor [gmx_tile_prefix_words(n)]]]):
-        the launch also writes the per-workgroup
-        fixed-point weight sums gmx_resample_tiles consumes (only if `writes_tile_stats()`) and, with the third
-        entry, every particle's fixed-point weight (gmx_resample_tiles_q then reads those instead of the
-        log-weights).
-        resample_in = dict(lw, tile_max, tile_agg, anc_out, kind, shift, key=(k0, k1)[, max_out, total_out]): the
-        launch first RESAMPLES (gmx_run_args.rs, `fuses_resample()`): every workgroup computes its particles'
-        ancestors from the previous step's log-weights + tile statistics, writes them to `anc_out` (the tensor the
-        gathered leaves name as their ancestors) and gathers through them."""
+        tile_stats = (int64 tensor [grid], shift): the launch also writes the per-workgroup fixed-point weight sums
+        gmx_resample_tiles consumes (only if `writes_tile_stats()`)."""
         be = self._be
         n = int(np.prod(batch, dtype=np.int64))
         self._work = getattr(self, "_work", 0) + n
@@ -984,28 +973,6 @@ class Compiled:
             agg, shift = tile_stats[0], tile_stats[1]
             A.tile_agg_d, A.tile_shift = agg.data_ptr(), int(shift)
             keep.append(agg)
-            if len(tile_stats) > 2 and tile_stats[2] is not None:      # per-particle fixed-point weights (tile_q_d)
-                A.tile_q_d = tile_stats[2].data_ptr()
-                keep.append(tile_stats[2])
-            if len(tile_stats) > 3 and tile_stats[3] is not None:      # tile prefixes by the last workgroup (tile_pref_d)
-                A.tile_pref_d = tile_stats[3].data_ptr()
-                keep.append(tile_stats[3])
-        if resample_in is not None:
-            r = resample_in
-            if anc is not None and r["anc_out"].data_ptr() != A.ancestors_d:
-                raise ValueError("resample_in: anc_out must be the ancestors tensor the gathered leaves use")
-            for name in ("lw", "tile_max", "tile_agg", "anc_out"):
-                keep.append(r[name])
-            A.rs.lw_d, A.rs.tile_max_d = r["lw"].data_ptr(), r["tile_max"].data_ptr()
-            A.rs.tile_agg_d, A.rs.anc_out_d = r["tile_agg"].data_ptr(), r["anc_out"].data_ptr()
-            A.rs.kind, A.rs.shift = int(r["kind"]), int(r["shift"])
-            A.rs.key0, A.rs.key1 = int(r["key"][0]), int(r["key"][1])
-            if r.get("max_out") is not None:
-                A.rs.max_out_d = r["max_out"].data_ptr()
-                keep.append(r["max_out"])
-            if r.get("total_out") is not None:
-                A.rs.total_out_d = r["total_out"].data_ptr()
-                keep.append(r["total_out"])
         return n, A, keep, outs
 
 

@@ -22,9 +22,9 @@ number of ranks:
     (balanced weights keep all but O(sqrt(n)) particles per boundary rank-local).
 
 So per SMC step: 1 all-gather (12 B per 1024 particles per rank) and 1 all-to-all (world * capacity * 4 B per
-rank), all enqueued on the stream: the host never waits for the device inside a sweep.  (GENMI_SHARD_TILES=0,
-multinomial, n > 2^21 per rank or > 64 ranks: all-reduce MAX, gmx_weight_cdf against the global max, all-gather
-of the 8-byte totals, gmx_shard_step, all-to-all.)  The evidence terms and the capacity
+rank), all enqueued on the stream: the host never waits for the device inside a sweep.  (n > 2^21 per rank or > 64
+ranks — `cdf_form=True` forces it: all-reduce MAX, gmx_weight_cdf against the global max, all-gather of the 8-byte
+totals, gmx_shard_step, all-to-all.)  The evidence terms and the capacity
 overflow flag are read once at the end; an overflow (weights so unbalanced that
 a rank must ship more than `capacity` particles to one peer) re-runs the sweep
 with capacity = n, which always suffices.  xGMI is point-to-point, so the
@@ -91,7 +91,10 @@ class ShardedBootstrapSweep(_NoiseAhead):
 
     def __init__(self, init, step, n_per_rank: int, T: int, dist, obs_addr="y", step_extra=None, specialize=True,
                  resample="systematic", capacity=None, always_communicate=False, rejuvenate=None, state_addr="x",
-                 noise_ahead=None):
+                 noise_ahead=None, cdf_form=False, fused=True):
+        """cdf_form=True: the three-collective CDF-array form (what n > 2^21 per rank or > 64 ranks take) instead of
+        the tile statistics; fused=False: gmx_shard_totals + gmx_shard_step_tiles as two launches (what a vector
+        state / the MH move's second leaf take) instead of gmx_shard_step_fused."""
         from .smc import _KINDS
         self.init, self.step, self.n, self.T, self.dist = init, step, int(n_per_rank), int(T), dist
         self.obs_addr = obs_addr
@@ -122,6 +125,7 @@ class ShardedBootstrapSweep(_NoiseAhead):
         # routed (two gmx_shard_step launches and two all-to-alls per step instead of one).
         self.rejuvenate, self.state_addr = rejuvenate, state_addr
         self.noise_ahead_req = noise_ahead
+        self.cdf_form, self.fused_req = bool(cdf_form), bool(fused)
         self._noise_offset, self._noise_total = self.rank * self.n, self.N
 
     def _chain_prog(self, t):
@@ -209,7 +213,7 @@ class ShardedBootstrapSweep(_NoiseAhead):
         # every rank derives the global max and all the totals — no max all-reduce, no local CDF array
         from .smc import FUSED_RESAMPLE_MAX, STRATIFIED
         self.tiles_mode = (self.kind in (SYSTEMATIC, STRATIFIED) and n <= FUSED_RESAMPLE_MAX and W <= 64
-                           and os.environ.get("GENMI_SHARD_TILES", "1") != "0")
+                           and not self.cdf_form)
         if self.tiles_mode:
             sb = int(be.c.gmx_shard_stats_bytes(n))
             tiles = (n + CDF_TILE - 1) // CDF_TILE
@@ -316,7 +320,7 @@ class ShardedBootstrapSweep(_NoiseAhead):
                                    P(m), self.shift, g, W, n, C, P(row), P(snd), P(self.idx))
             mkf = lambda row, snd: (self.kind, kk, P(self.stats_all), P(self.plan), P(tot), P(self.lw), P(m), self.shift,
                                     g, W, n, C, P(row), P(snd), P(self.idx))
-            fused_ok = W <= 64 and os.environ.get("GENMI_SHARD_FUSED", "1") != "0"
+            fused_ok = W <= 64 and self.fused_req
             tiles = {"stats": None if writes_stats else (P(self.lw), n, self.shift, P(self.tile_max), P(self.tile_agg)),
                      "totals": (P(self.stats_all), W, n, P(self.totals_all), P(m)),
                      # the first routed leaf derives the totals / global max itself (one launch less in the chain);
@@ -529,7 +533,7 @@ class CountingComm:
 
 
 def sharded_importance_resample(target, k_per_rank: int, key: Key, dist, kind="systematic", capacity=None, comm=None,
-                                stats: dict | None = None):
+                                stats: dict | None = None, cdf_form=False):
     """BASELINE config 4 across ranks: `ImportanceK(target, k_particles = world * k_per_rank).run_smc(key)`
     with rank g holding particles [g*k, (g+1)*k) (same key tree: keys split(sub, K)[g*k + i], so the
     ensemble is the single-process one), then ONE global resampling with ONE plan for the whole trace:
@@ -575,7 +579,7 @@ def sharded_importance_resample(target, k_per_rank: int, key: Key, dist, kind="s
         (lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev))          # destinations of collectives
     totals_all = calloc((W,), torch.int64)
     gtotal = torch.zeros((1,), dtype=torch.int64, device=dev)
-    tiles_form = kind in (0, 1) and n <= FUSED_RESAMPLE_MAX and W <= 64 and os.environ.get("GENMI_SHARD_TILES", "1") != "0"
+    tiles_form = kind in (0, 1) and n <= FUSED_RESAMPLE_MAX and W <= 64 and not cdf_form
     if tiles_form:
         nbytes = int(be.c.gmx_shard_stats_bytes(n))
         tiles = (n + 1023) // 1024

@@ -574,7 +574,7 @@ def ancestors_from_cdf(kind, key: Key, cdf, total, n_out=None) -> torch.Tensor:
     kh = key.host()
     kk = (c_uint32 * 2)(int(kh[0]), int(kh[1]))
     anc = torch.empty((n_out,), dtype=torch.int32, device=cdf.device)
-    if int(kind) == MULTINOMIAL and n_in >= MULTINOMIAL_GUIDED_MIN and os.environ.get("GENMI_MN_GUIDED", "1") != "0":
+    if int(kind) == MULTINOMIAL and n_in >= MULTINOMIAL_GUIDED_MIN:
         # unordered slots: through the guide table (two table reads + a search over ~3 entries per slot instead of a
         # binary search over n_in) — the same ancestors
         ws = torch.empty(((be.c.gmx_multinomial_workspace(n_in) + 3) // 4,), dtype=torch.int32, device=cdf.device)
@@ -596,8 +596,7 @@ def resample(key: Key, collection: ParticleCollection, kind="systematic", n_out=
     kind = _KINDS[kind] if isinstance(kind, str) else int(kind)
     n = lw.numel()
     if (kind in _TILE_KINDS and n_out in (None, n) and 0 < n <= FUSED_RESAMPLE_MAX) or \
-            (kind in (SYSTEMATIC, STRATIFIED) and n_out in (None, n) and FUSED_RESAMPLE_MAX < n < 2 ** 31 - 1024
-             and os.environ.get("GENMI_RESAMPLE_BIG_FUSED", "1") != "0"):
+            (kind in (SYSTEMATIC, STRATIFIED) and n_out in (None, n) and FUSED_RESAMPLE_MAX < n < 2 ** 31 - 1024):
         anc, total, mx, shift = resample_fused(kind, key, lw)        # no CDF in memory (gmx_resample[_tiles[_p]])
     elif kind in (MULTINOMIAL_TILED, MULTINOMIAL_SORTED):
         raise NotImplementedError("resample(kind='multinomial_tiled' / 'multinomial_sorted'): n_out = n <= 2^21 (use 'multinomial')")
@@ -651,6 +650,8 @@ def rejuvenate(key: Key, collection: ParticleCollection, request, argdiffs=None)
 
 
 class CapturedLoop:
+    NOISE_ARENA_MB = 16384     # every draw of a captured loop lives in one arena for the graph's lifetime: its bound
+
     """A Python inference loop over this module's functional API (resample -> rejuvenate -> extend ...) captured ONCE
     into a hipGraph and replayed without the interpreter in the loop: every C-ABI launch goes to torch's current stream,
     so one capture records them all; tensors made during the capture come from the graph's private pool and stay
@@ -680,8 +681,8 @@ class CapturedLoop:
                     loop_fn(*args)
             if self.noise is not None:
                 side.wait_stream(self.noise.stream)
-                # every draw of the loop lives in one arena for the graph's lifetime: bounded (GENMI_NOISE_ARENA_MB)
-                if 4 * self.noise.demand > int(os.environ.get("GENMI_NOISE_ARENA_MB", 16384)) << 20:
+                # every draw of the loop lives in one arena for the graph's lifetime: bounded (NOISE_ARENA_MB)
+                if 4 * self.noise.demand > int(self.NOISE_ARENA_MB) << 20:
                     self.noise = None
                     loop_fn(*args)               # the plain programs must exist before the capture too
         torch.cuda.current_stream(be.device).wait_stream(side)
@@ -752,7 +753,7 @@ class _NoiseAhead:
         # (measured on MI355X, config 2: 14.50 -> 14.32 us/step with 3, 14.27 with 4; the sorted multinomial, whose
         # background stream also builds tables, is better off with 2: 21.2 vs 21.9 — profiles/r03cd_ring_*.json)
         ring = 2 if getattr(self, "kind", None) == MULTINOMIAL_SORTED else self.NOISE_RING
-        self.noise_ring = max(2, int(os.environ.get("GENMI_NOISE_RING", ring)))
+        self.noise_ring = max(2, int(ring))
         # groups of steps [start, end): the noise of group g + 1 is issued before the chain of group g.  The chain
         # can only start once the FIRST group's noise is there, so the groups grow 1, 2, 4, ... up to noise_group
         self.noise_groups, self.noise_slot = [], []
@@ -768,7 +769,7 @@ class _NoiseAhead:
         # [half, draw, row of the group, n]: a draw's rows are contiguous, so ONE launch can fill several steps
         self.zbuf = torch.zeros((self.noise_ring, S, self.noise_group, n), dtype=torch.float32, device=dev)
         self._noise_stream = torch.cuda.Stream(device=dev) if be.uses_streams else None
-        pad = int(os.environ.get("GENMI_NOISE_LDS_PAD", self.NOISE_LDS_PAD))
+        pad = int(self.NOISE_LDS_PAD)
         for plist in self._noise_progs.values():
             for _, q, _ in plist:
                 if self.specialize:
@@ -787,7 +788,7 @@ class _NoiseAhead:
         """The background launches of group g: the steps of a group that share a chain program get their draws from ONE
         launch per key root — a 2-D grid, one row of keys per step (GMX_KEY_ROWSPLIT; gmx_program_run) — instead of
         one launch per step: fewer nodes in the graph (the HIP runtime walks a two-stream graph node by node on the
-        host) and no launch boundary between the steps' noise.  GENMI_NOISE_ROWS=0: one launch per step."""
+        host) and no launch boundary between the steps' noise."""
         cache = self.__dict__.setdefault("_noise_run_cache", {})
         if g in cache:
             return cache[g]
@@ -822,10 +823,6 @@ class _NoiseAhead:
 
     def _launch_noise_group(self, g):
         self._launch_group_extras(g)
-        if os.environ.get("GENMI_NOISE_ROWS", "1") == "0":
-            for t in range(*self.noise_groups[g]):
-                self._launch_noise(t)
-            return
         for q, batch, key, outs in self._noise_runs(g):
             q.run(batch, key, outs)
 
@@ -926,10 +923,15 @@ class BootstrapSweep(_NoiseAhead):
     NOISE_LDS_PAD = 56000      # bytes of unused LDS per noise workgroup: two of them per CU (160 KB)
     NOISE_GROUP = 10           # steps per group of noise launches (the noise runs one group ahead of the chain)
     NOISE_ROOTS_MH = "LDKEY"   # with rejuvenate=: which keys' draws the background programs take (see prepare)
+    SORTED_LDS_PAD = 16000     # residency cap of the sorted multinomial's table kernels (they wait on memory)
 
     def __init__(self, init, step, n_particles: int, T: int, obs_addr="y", resample="systematic",
-                 step_extra=None, specialize=True, rejuvenate=None, state_addr="x", noise_ahead=None):
-        """rejuvenate: an edit request (e.g. StaticRequest({"x": Rejuvenate(...)})) applied as one fused
+                 step_extra=None, specialize=True, rejuvenate=None, state_addr="x", noise_ahead=None, chain_mh=True,
+                 noise_roots=None):
+        """chain_mh=False keeps the MH move and the extension as two launches (the form a chained program too large
+        for the tile statistics falls back to); noise_roots: which keys' draws of the chained program the background
+        stream takes ("LDKEY" = the move's proposal + accept draws, the default; "KSPLITU" = the extension's; "all").
+        rejuvenate: an edit request (e.g. StaticRequest({"x": Rejuvenate(...)})) applied as one fused
         MH move per particle after every resampling, before the next extension (BASELINE config 3; the
         graph-captured form of smc.resample -> smc.rejuvenate -> smc.extend, same keys, same results).
         Supported for models whose trace is {state_addr: the return value, obs_addr: the observation}."""
@@ -940,6 +942,8 @@ class BootstrapSweep(_NoiseAhead):
         self.specialize = specialize
         self.graph = None
         self.noise_ahead_req = noise_ahead
+        self.chain_mh = bool(chain_mh)
+        self.noise_roots = noise_roots or self.NOISE_ROOTS_MH
 
     def prepare(self, key: Key, ys: torch.Tensor):
         from ..static import MinimalGenerate as _MG, NoiseProgram
@@ -955,15 +959,14 @@ class BootstrapSweep(_NoiseAhead):
             self.graph = None
         # noise ahead: asked for explicitly, or by default on a device with streams on the fast path (specialised
         # programs; with rejuvenate=, the MH move chained into the extension)
-        fuse_mh_ok = os.environ.get("GENMI_FUSE_MH", "1") != "0"
+        fuse_mh_ok = self.chain_mh
         want_na = self.noise_ahead_req
         if want_na is None:
             want_na = (os.environ.get("GENMI_NOISE_AHEAD", "1") != "0" and be.uses_streams and self.specialize
-                       and (self.rejuvenate is None or fuse_mh_ok)
-                       and os.environ.get("GENMI_FUSE_RESAMPLE", "0") != "1")
+                       and (self.rejuvenate is None or fuse_mh_ok))
         if want_na and self.rejuvenate is not None and not fuse_mh_ok:
             raise NotImplementedError("BootstrapSweep(noise_ahead=True, rejuvenate=...) needs the chained MH + extension "
-                                      "program (GENMI_FUSE_MH=0 is set)")
+                                      "program (chain_mh=False)")
         self.noise_ahead = False
         self._noise_progs = {}
 
@@ -1038,15 +1041,14 @@ class BootstrapSweep(_NoiseAhead):
                                        self.rejuvenate, (n,))
         # the MH move and the extension that follows it as ONE program / one launch per step (static.MinimalMHGenerate:
         # same keys, same draws, same bits; one launch boundary and one trip of the moved state through memory less).
-        # GENMI_FUSE_MH=0 keeps the two launches.
         self.p_mhvm_init = self.p_mhvm_step = None
-        if self.rejuvenate is not None and os.environ.get("GENMI_FUSE_MH", "1") != "0":
+        if self.rejuvenate is not None and self.chain_mh:
             from ..static import MinimalMHGenerate
             ex = tuple(self.step_extra(1))
             # which draws of the chained program go to the background stream: the two streams should carry about the
-            # same vector work (GENMI_NOISE_ROOTS: "all", "LDKEY" = the move's proposal + accept draws, "KSPLITU" = the
+            # same vector work (noise_roots: "all", "LDKEY" = the move's proposal + accept draws, "KSPLITU" = the
             # extension's draw)
-            roots = os.environ.get("GENMI_NOISE_ROOTS", self.NOISE_ROOTS_MH)
+            roots = self.noise_roots
             hn = False if not want_na else (True if roots == "all" else tuple(roots.split(",")))
             self.p_mhvm_init = MinimalMHGenerate(self.init, (), ch, self.rejuvenate, self.step, ex, obs0, (n,),
                                                  hoist_noise=hn)
@@ -1075,10 +1077,9 @@ class BootstrapSweep(_NoiseAhead):
         self.partials = torch.zeros((2, (n + 255) // 256), dtype=torch.float32, device=dev)
         # two launches per step: when the site programs can leave the CDF tile statistics themselves (specialised,
         # 4 particles per thread: a workgroup is one 1024-particle tile) the resampler needs no pass of its own
-        # over the log-weights (gmx_resample_tiles); GENMI_TILE_STATS=0 keeps the separate gmx_tile_stats launch
+        # over the log-weights (gmx_resample_tiles); programs that cannot (interpreted) get a gmx_tile_stats launch
         self.tile_agg = torch.zeros(((n + 1023) // 1024,), dtype=torch.int64, device=dev)
-        self.tile_stats = bool(self.fused and os.environ.get("GENMI_TILE_STATS", "1") != "0"
-                               and self.p_init.comp.writes_tile_stats() and self.p_step.comp.writes_tile_stats())
+        self.tile_stats = bool(self.fused and self.p_init.comp.writes_tile_stats() and self.p_step.comp.writes_tile_stats())
         if self.p_mhvm_init is not None and self.tile_stats and not (self.p_mhvm_init.comp.writes_tile_stats()
                                                                      and self.p_mhvm_step.comp.writes_tile_stats()):
             self.p_mhvm_init = self.p_mhvm_step = None      # the chained programs are too large for the tile form
@@ -1090,47 +1091,6 @@ class BootstrapSweep(_NoiseAhead):
                                           "program does not fit the tile form")
             self.noise_ahead_req = False
             return self.prepare(key, ys)
-        # ... and, on request (GENMI_TILE_Q=1), every particle's fixed-point weight (4 bytes each: significand | shift):
-        # the resampler then reads those instead of the log-weights and skips one exp per particle.  Measured on MI355X
-        # (config 2): the resampler 6.7 -> 6.3 us, the site program 11.5 -> 12.3 us — the extra 4 MB are stored at the
-        # very end of the site program (they need the block maximum), where nothing overlaps them.  Off by default.
-        self.tile_q = torch.zeros((n,), dtype=torch.int32, device=dev) \
-            if self.tile_stats and os.environ.get("GENMI_TILE_Q", "0") == "1" else None
-        # ... and, on request (GENMI_TILE_PREFIX=1), the tile PREFIXES (gmx_run_args.tile_pref_d): the last workgroup of
-        # the site program to finish turns all (m_b, A_b) into M, K, the exclusive prefixes and the total ONCE, and the
-        # resampler's workgroups read one prefix each (gmx_resample_tiles_p) instead of every one of them reducing the
-        # whole table (977 times at 1e6 particles: ~130 of the resampler's 541 vector instructions per wave).  Measured
-        # on MI355X (profiles/r03d_ab_tile_prefix*.json, A/B in one process, bit-identical): config 3 32.0 -> 31.4
-        # us/step, config 2 15.0 -> 15.9 — the publication (two atomic exchanges, a two-level ticket, the last
-        # workgroup's pass) is three to four dependent memory round trips at the END of the site program, on the
-        # chain's critical path, and config 2's site program is too short to hide them.  Off by default.
-        self.tile_pref = None
-        if self.tile_stats and self.tile_q is None and os.environ.get("GENMI_TILE_PREFIX", "0") == "1" \
-                and os.environ.get("GENMI_FUSE_RESAMPLE", "0") != "1":
-            self.tile_pref = torch.zeros((int(be.c.gmx_tile_prefix_words(n)),), dtype=torch.int64, device=dev)
-        # ONE launch per step: the program that gathers the resampled state (the extension; with rejuvenate=, the MH
-        # move) first computes its workgroup's ancestors itself, from the previous step's log-weights and tile
-        # statistics (gmx_run_args.rs, csrc/gmx_resample.h) — same integers as gmx_resample_tiles, no second kernel,
-        # no launch boundary.  Needs two sets of log-weights / statistics (a launch reads step t-1's while writing
-        # step t's).  OPT-IN (GENMI_FUSE_RESAMPLE=1, read when the programs are specialised): measured on MI355X,
-        # config 2, the one-launch step is SLOWER (23.1 vs 20.1 us): a workgroup's 1024 slots straddle two source
-        # tiles on average, so the CDF rebuild (4 exp + scan + 5 slot edges per thread and tile) runs twice per
-        # workgroup — +1340 vector instructions per wave against the 806 of k_offspring_tile, more than the launch
-        # boundary it removes.
-        if self.rejuvenate is None:
-            gatherers = (self.p_step,)
-        elif self.fuse_mh:
-            gatherers = (self.p_mhvm_init, self.p_mhvm_step)
-        else:
-            gatherers = (self.p_mh_init, self.p_mh_step)
-        self.fuse = bool(self.tile_stats and self.tile_q is None and os.environ.get("GENMI_FUSE_RESAMPLE", "0") == "1"
-                         and not self.noise_ahead and self.kind in (SYSTEMATIC, STRATIFIED) and all(p_.comp.fuses_resample() for p_ in gatherers))
-        if self.fuse:
-            self.lw_pp = [self.lw, torch.zeros_like(self.lw)]
-            self.partials_pp = [self.partials, torch.zeros_like(self.partials)]
-            self.tile_agg_pp = [self.tile_agg, torch.zeros_like(self.tile_agg)]
-        else:
-            self.lw_pp, self.partials_pp, self.tile_agg_pp = [self.lw] * 2, [self.partials] * 2, [self.tile_agg] * 2
         # per-step keys on the host
         self.step_keys = []
         for t in range(T):
@@ -1163,10 +1123,9 @@ class BootstrapSweep(_NoiseAhead):
                 bufs[o[1]] = self.x_store[t % 2][d:d + 1]
         else:
             bufs[prog.ro[1]] = self.x_store[t % 2]
-        bufs[prog.wo[1]] = self.lw_pp[t % 2].reshape(1, n)
-        prog.comp.run(leaves, (n,), lazy_split(k_prop, n), red_out=self.partials_pp[t % 2], out_buffers=bufs,
-                      tile_stats=(self.tile_agg_pp[t % 2], self.shift, self.tile_q, self.tile_pref) if self.tile_stats else None,
-                      resample_in=self._resample_in(t) if (self.fuse and t >= 1 and self.rejuvenate is None) else None)
+        bufs[prog.wo[1]] = self.lw.reshape(1, n)
+        prog.comp.run(leaves, (n,), lazy_split(k_prop, n), red_out=self.partials, out_buffers=bufs,
+                      tile_stats=(self.tile_agg, self.shift) if self.tile_stats else None)
 
     def _chain_prog(self, t):
         if t == 0:
@@ -1174,14 +1133,6 @@ class BootstrapSweep(_NoiseAhead):
         if self.fuse_mh:
             return self.p_mhvm_init if t == 1 else self.p_mhvm_step
         return self.p_step
-
-    def _resample_in(self, t):
-        """gmx_run_args.rs of the launch of step t (>= 1) that gathers: resample step t-1's weights first"""
-        kh = self.step_keys[t - 1][1].host()
-        w = (t - 1) % 2
-        return dict(lw=self.lw_pp[w], tile_max=self.partials_pp[w], tile_agg=self.tile_agg_pp[w], anc_out=self.anc,
-                    kind=self.kind, shift=self.shift, key=(int(kh[0]), int(kh[1])),
-                    max_out=self.maxs[t - 1:t], total_out=self.totals[t - 1:t])
 
     def _launch_mh(self, t):
         """The MH move on the resampled particles of step t-1 (t >= 1): reads x_{t-1}[anc] and, for
@@ -1199,8 +1150,7 @@ class BootstrapSweep(_NoiseAhead):
         bufs = [None] * len(prog.comp.outputs)
         bufs[prog.ro[1]] = self.xm_store[t % 2]
         bufs[prog.ao[1]] = self.accept.reshape(1, n)
-        prog.comp.run(leaves, (n,), lazy_split(k_mh, n), out_buffers=bufs,
-                      resample_in=self._resample_in(t) if self.fuse else None)
+        prog.comp.run(leaves, (n,), lazy_split(k_mh, n), out_buffers=bufs)
 
     def _launch_mhvm(self, t):
         """step t >= 1 as ONE launch: the MH move on the resampled particles of step t-1 (as _launch_mh), then the
@@ -1225,10 +1175,9 @@ class BootstrapSweep(_NoiseAhead):
         bufs[prog.mo[1]] = self.xm_store[t % 2]
         bufs[prog.ao[1]] = self.accept.reshape(1, n)
         bufs[prog.ro[1]] = self.x_store[t % 2]
-        bufs[prog.wo[1]] = self.lw_pp[t % 2].reshape(1, n)
-        prog.comp.run(leaves, (n,), lazy_split(k_mh, n), red_out=self.partials_pp[t % 2], out_buffers=bufs,
-                      tile_stats=(self.tile_agg_pp[t % 2], self.shift, self.tile_q, self.tile_pref) if self.tile_stats else None,
-                      resample_in=self._resample_in(t) if self.fuse else None)
+        bufs[prog.wo[1]] = self.lw.reshape(1, n)
+        prog.comp.run(leaves, (n,), lazy_split(k_mh, n), red_out=self.partials, out_buffers=bufs,
+                      tile_stats=(self.tile_agg, self.shift) if self.tile_stats else None)
 
     def _rows(self, t) -> int:
         """partial rows the site program of step t wrote"""
@@ -1247,7 +1196,7 @@ class BootstrapSweep(_NoiseAhead):
         be = _lib.get()
         kh = self.step_keys[t][1].host()
         kk = (c_uint32 * 2)(int(kh[0]), int(kh[1]))
-        if self.kind == MULTINOMIAL and self.n >= MULTINOMIAL_GUIDED_MIN and os.environ.get("GENMI_MN_GUIDED", "1") != "0":
+        if self.kind == MULTINOMIAL and self.n >= MULTINOMIAL_GUIDED_MIN:
             if getattr(self, "mn_ws", None) is None:
                 self.mn_ws = torch.zeros(((be.c.gmx_multinomial_workspace(self.n) + 3) // 4,), dtype=torch.int32,
                                          device=be.device)
@@ -1261,12 +1210,11 @@ class BootstrapSweep(_NoiseAhead):
         """Stratified resampling draws one uniform per SLOT, keyed by the step's resampling key and the slot number —
         nothing the chain produces.  In the noise-ahead form they are drawn on the background stream with the steps'
         normals (gmx_slot_uniforms, one 2-D launch per group of steps) and the resampler reads them
-        (gmx_resample_tiles_u): the same ancestors, one Threefry block per slot-edge evaluation less on the chain.
-        GENMI_SLOT_UNIFORMS=0: drawn inside the resampler."""
+        (gmx_resample_tiles_u): the same ancestors, one Threefry block per slot-edge evaluation less on the chain
+        (the one-stream form draws them inside the resampler)."""
         self.ubuf = None
-        if not (self.noise_ahead and self.kind in (STRATIFIED, MULTINOMIAL_TILED, MULTINOMIAL_SORTED) and self.fused and self.tile_stats
-                and self.tile_q is None and self.tile_pref is None and not self.fuse
-                and os.environ.get("GENMI_SLOT_UNIFORMS", "1") != "0"):
+        if not (self.noise_ahead and self.kind in (STRATIFIED, MULTINOMIAL_TILED, MULTINOMIAL_SORTED) and self.fused
+                and self.tile_stats):
             return
         dev = self.zbuf.device
         # (the sorted multinomial's row is its whole order-statistics table: gmx_sorted_uniforms_words(n) words)
@@ -1278,9 +1226,9 @@ class BootstrapSweep(_NoiseAhead):
             rk = (lambda t: split(self.step_keys[t][1], 2)[0]) if self.kind == MULTINOMIAL_TILED else (lambda t: self.step_keys[t][1])
             ks = np.stack([rk(t).host() for t in range(t0, t1)]).astype(np.uint32)
             self._u_keys.append(torch.from_numpy(ks.view(np.int32)).to(dev))
-        self._u_pad = int(os.environ.get("GENMI_NOISE_LDS_PAD", self.NOISE_LDS_PAD))
+        self._u_pad = int(self.NOISE_LDS_PAD)
         if self.kind == MULTINOMIAL_SORTED:       # its two kernels wait on memory, not on the vector ALUs: more of them per CU
-            self._u_pad = int(os.environ.get("GENMI_SORTED_LDS_PAD", 16000))
+            self._u_pad = self.SORTED_LDS_PAD
 
     def _launch_group_extras(self, g):
         if getattr(self, "ubuf", None) is None:
@@ -1301,59 +1249,43 @@ class BootstrapSweep(_NoiseAhead):
         kh = self.step_keys[t][1].host()
         kk = (c_uint32 * 2)(int(kh[0]), int(kh[1]))
         if self.kind == MULTINOMIAL_TILED:
-            w = t % 2
             if not self.tile_stats:
-                be.check(be.c.gmx_tile_stats(be.ptr(self.lw_pp[w]), self.n, self.shift, be.ptr(self.partials_pp[w]),
-                                             be.ptr(self.tile_agg_pp[w]), be.stream()), "gmx_tile_stats")
+                be.check(be.c.gmx_tile_stats(be.ptr(self.lw), self.n, self.shift, be.ptr(self.partials),
+                                             be.ptr(self.tile_agg), be.stream()), "gmx_tile_stats")
             u_d = None
             if getattr(self, "ubuf", None) is not None:
                 half, row = self.noise_slot[t]
                 u_d = be.ptr(self.ubuf[half, row])
-            be.check(be.c.gmx_multinomial_tiled(kk, be.ptr(self.lw_pp[w]), self.n, self.shift, be.ptr(self.partials_pp[w]),
-                                                be.ptr(self.tile_agg_pp[w]), u_d, be.ptr(self.maxs[t:t + 1]),
+            be.check(be.c.gmx_multinomial_tiled(kk, be.ptr(self.lw), self.n, self.shift, be.ptr(self.partials),
+                                                be.ptr(self.tile_agg), u_d, be.ptr(self.maxs[t:t + 1]),
                                                 be.ptr(self.totals[t:t + 1]), be.ptr(self.anc), be.ptr(self.mnt_ws),
                                                 -1 if t == 0 else (t & 1),      # count buffers alternate: one memset per sweep
                                                 be.stream()), "gmx_multinomial_tiled")
             return
         if self.kind == MULTINOMIAL_SORTED:
-            w = t % 2
             if not self.tile_stats:
-                be.check(be.c.gmx_tile_stats(be.ptr(self.lw_pp[w]), self.n, self.shift, be.ptr(self.partials_pp[w]),
-                                             be.ptr(self.tile_agg_pp[w]), be.stream()), "gmx_tile_stats")
+                be.check(be.c.gmx_tile_stats(be.ptr(self.lw), self.n, self.shift, be.ptr(self.partials),
+                                             be.ptr(self.tile_agg), be.stream()), "gmx_tile_stats")
             table, ready = self.sorted_ws, 0
             if getattr(self, "ubuf", None) is not None:        # drawn ahead on the background stream
                 half, row = self.noise_slot[t]
                 table, ready = self.ubuf[half, row], 1
-            be.check(be.c.gmx_resample_sorted(kk, be.ptr(self.lw_pp[w]), self.n, self.shift, be.ptr(self.partials_pp[w]),
-                                              be.ptr(self.tile_agg_pp[w]), be.ptr(table), ready, be.ptr(self.maxs[t:t + 1]),
+            be.check(be.c.gmx_resample_sorted(kk, be.ptr(self.lw), self.n, self.shift, be.ptr(self.partials),
+                                              be.ptr(self.tile_agg), be.ptr(table), ready, be.ptr(self.maxs[t:t + 1]),
                                               be.ptr(self.totals[t:t + 1]), be.ptr(self.anc), be.stream()),
                      "gmx_resample_sorted")
             return
         if getattr(self, "ubuf", None) is not None:
-            w = t % 2
             half, row = self.noise_slot[t]
-            be.check(be.c.gmx_resample_tiles_u(self.kind, kk, be.ptr(self.lw_pp[w]), self.n, self.shift,
-                                               be.ptr(self.partials_pp[w]), be.ptr(self.tile_agg_pp[w]),
+            be.check(be.c.gmx_resample_tiles_u(self.kind, kk, be.ptr(self.lw), self.n, self.shift,
+                                               be.ptr(self.partials), be.ptr(self.tile_agg),
                                                be.ptr(self.ubuf[half, row]), be.ptr(self.maxs[t:t + 1]),
                                                be.ptr(self.totals[t:t + 1]), be.ptr(self.anc), be.stream()),
                      "gmx_resample_tiles_u")
             return
-        if self.tile_stats and self.tile_q is not None:
-            be.check(be.c.gmx_resample_tiles_q(self.kind, kk, be.ptr(self.tile_q), self.n, self.shift,
-                                               be.ptr(self.partials), be.ptr(self.tile_agg), be.ptr(self.maxs[t:t + 1]),
-                                               be.ptr(self.totals[t:t + 1]), be.ptr(self.anc), be.stream()),
-                     "gmx_resample_tiles_q")
-            return
-        if self.tile_stats and self.tile_pref is not None:     # the site program's last workgroup left the prefixes
-            be.check(be.c.gmx_resample_tiles_p(self.kind, kk, be.ptr(self.lw), self.n, self.shift, be.ptr(self.partials),
-                                               be.ptr(self.tile_pref), be.ptr(self.maxs[t:t + 1]),
-                                               be.ptr(self.totals[t:t + 1]), be.ptr(self.anc), be.stream()),
-                     "gmx_resample_tiles_p")
-            return
         if self.tile_stats:        # tile maxima = the workgroup maxima the site program left in partials[0]
-            w = t % 2
-            be.check(be.c.gmx_resample_tiles(self.kind, kk, be.ptr(self.lw_pp[w]), self.n, self.shift,
-                                             be.ptr(self.partials_pp[w]), be.ptr(self.tile_agg_pp[w]),
+            be.check(be.c.gmx_resample_tiles(self.kind, kk, be.ptr(self.lw), self.n, self.shift,
+                                             be.ptr(self.partials), be.ptr(self.tile_agg),
                                              be.ptr(self.maxs[t:t + 1]),
                                              be.ptr(self.totals[t:t + 1]), be.ptr(self.anc), be.stream()),
                      "gmx_resample_tiles")
@@ -1392,8 +1324,6 @@ class BootstrapSweep(_NoiseAhead):
                     self._launch_mh(t)
                 if not skip_vm:
                     self._launch_vm(t)
-            if self.fuse and t < self.T - 1:
-                continue                   # step t's weights are resampled by step t+1's launch itself
             if self.fused:
                 self._launch_resample(t)
             else:
@@ -1452,4 +1382,4 @@ class BootstrapSweep(_NoiseAhead):
 
     def state(self):
         """(x_T particles before the last resampling, log-weights, last ancestors)."""
-        return self.x[(self.T - 1) % 2], self.lw_pp[(self.T - 1) % 2], self.anc
+        return self.x[(self.T - 1) % 2], self.lw, self.anc

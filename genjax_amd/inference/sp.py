@@ -22,9 +22,6 @@ class Marginal(GenerativeFunction):
         project(trace, ~selection); with an inner algorithm the weight is its estimate of the reciprocal
         normalising constant of Target(gen_fn, args, selected choices) — this is how algorithms nest."""
         from ..random import split
-        import os
-        if self.algorithm is not None and tuple(key.shape) != () and os.environ.get("GENMI_CSMC_HOST_WALK") == "1":
-            return self._random_weighted_over_keys(key, args)          # the per-key host walk (kept as a cross-check)
         key, sub_key = split(key)
         tr = self.gen_fn.simulate(sub_key, tuple(args))
         choices = tr.get_choices()
@@ -38,25 +35,6 @@ class Marginal(GenerativeFunction):
         other_choices = choices.filter(~self.selection)
         Z = self.algorithm.estimate_reciprocal_normalizing_constant(key, target, other_choices, weight)
         return Z, latent_choices
-
-    def _random_weighted_over_keys(self, keys, args):
-        """`vmap(random_weighted)` over a batch of keys when an inner algorithm is present: every key runs its own
-        conditional SMC (ChangeTarget.run_csmc_for_normalizing_constant keeps ONE retained particle, so the batch is
-        walked on the host and the results are stacked).  Meant for small outer batches; the bulk work — the inner
-        algorithm's particles — is one fused launch per key."""
-        import torch
-        flat = keys.reshape(-1)
-        ws, chms = [], []
-        for i in range(flat.shape[0]):
-            w, c = self.random_weighted(flat[i], *args)
-            ws.append(torch.as_tensor(w, dtype=torch.float32).reshape(()))
-            chms.append(c)
-        out = ChoiceMap.empty()
-        for a in chms[0].addresses():
-            vals = [torch.as_tensor(c[a]) for c in chms]
-            out = out.set(a, torch.stack([v.to(vals[0].device) for v in vals]).reshape(tuple(keys.shape) + tuple(vals[0].shape)))
-        dev = ws[0].device
-        return torch.stack([w.to(dev) for w in ws]).reshape(tuple(keys.shape)), out
 
     def estimate_logpdf(self, key, v, *args):
         """sp.py:242-254"""

@@ -995,10 +995,9 @@ class NoiseAheadContext:
         # which launches hand their draws over: "mh" (rejuvenate: proposal + accept draws), "generate" / "simulate"
         # (extend, ImportanceK).  The two streams should carry about the same vector work: with an MH move per step,
         # hoisting everything makes the background stream the bottleneck (config 3 under smc.capture, us/step: one
-        # stream 43.4, all 41.9, generate 40.6, mh 37.7).  GENMI_NOISE_KINDS; default "auto": the MH draws when the
+        # stream 43.4, all 41.9, generate 40.6, mh 37.7).  Default "auto": the MH draws when the
         # recorded loop has MH moves, the generate / simulate draws otherwise.
-        import os
-        kinds = kinds if kinds is not None else os.environ.get("GENMI_NOISE_KINDS", "auto")
+        kinds = kinds if kinds is not None else "auto"
         self.kinds = tuple(kinds.split(",")) if isinstance(kinds, str) else tuple(kinds)
         self.plan, self.mode, self.cursor = [], "record", 0
         self.arena, self.views, self.events = None, [], {}

@@ -39,7 +39,7 @@ typedef __UINTPTR_TYPE__ uintptr_t;
 extern "C" {
 #endif
 
-#define GMX_ABI_VERSION 4
+#define GMX_ABI_VERSION 5
 
 typedef void* gmx_stream;            /* hipStream_t */
 typedef struct gmx_program gmx_program;
@@ -107,26 +107,6 @@ enum {
   GMX_KEY_BCAST = 4     /* (key0,key1) for every particle                      */
 };
 
-/* The resampling step folded into the NEXT site program's launch (gmx_run_args.rs): with lw_d set, a specialised
- * 4-particles-per-thread program that gathers (gmx_program_fuses_resample() == 1) does not read ancestors_d — each
- * workgroup first computes the ancestors of its own 1024 particles from the PREVIOUS step's log-weights and tile
- * statistics (exactly gmx_resample_tiles' integers; csrc/gmx_resample.h), writes them to anc_out_d, and gathers
- * through them.  A bootstrap SMC step (smc.py:370-396's role; SURVEY.md App. B resampling) is then ONE launch.
- * The buffers read here must not be the ones this launch writes (log-weights, tile statistics: ping-pong). */
-typedef struct gmx_resample_in {
-  const float* lw_d;              /* [n] log-weights of the previous step (16-byte aligned); NULL = not fused   */
-  const float* tile_max_d;        /* [ceil(n/1024)] m_b  (plane 0 of the previous launch's red_out_d)           */
-  const uint64_t* tile_agg_d;     /* [ceil(n/1024)] A_b  (the previous launch's tile_agg_d, same tile_shift)    */
-  int32_t* anc_out_d;             /* [n] the ancestors, as gmx_resample_tiles would write them                  */
-  float* max_out_d;               /* optional [1]: M      (as gmx_resample_tiles' max_d)                        */
-  uint64_t* total_out_d;          /* optional [1]: total  (as gmx_resample_tiles' total_d)                      */
-  int32_t kind;                   /* GMX_RESAMPLE_SYSTEMATIC or GMX_RESAMPLE_STRATIFIED                         */
-  int32_t shift;                  /* the CDF's fixed-point shift (= the previous launch's tile_shift)           */
-  uint32_t key0, key1;            /* resampling key                                                             */
-  uint32_t u0;                    /* filled in by gmx_program_run: bits32(key, 0) >> 9                          */
-  uint32_t reserved_;
-} gmx_resample_in;
-
 typedef struct gmx_run_args {
   const void* in_d[GMX_MAX_IN];   /* per-particle inputs (4-byte or 1-byte elems) */
   void* out_d[GMX_MAX_OUT];       /* per-particle outputs                        */
@@ -150,22 +130,6 @@ typedef struct gmx_run_args {
   int32_t reserved_;
   int64_t step_stride;            /* elements between consecutive steps of a [T, n] leaf addressed with GMX_F_STEP inside
                                      an OP_LOOP (programs with a counted loop: the Scan combinator); normally n         */
-  uint32_t* tile_q_d;             /* optional, with tile_agg_d: [n] the fixed-point weight of every particle,
-                                     q_i = floor(exp(x_i - k_b ln 2) * 2^tile_shift) — the terms A_b sums — packed in
-                                     4 bytes: significand (bits 0-23) | shift amount (bits 24-29), q = (significand
-                                     << 39) >> amount.  The epilogue has them in registers; written out, the
-                                     resampler (gmx_resample_tiles_q) reads these instead of the log-weights and
-                                     needs no second exp per particle                                            */
-  gmx_resample_in rs;             /* optional (rs.lw_d != NULL): resample first, in the same launch — see above  */
-  uint64_t* tile_pref_d;          /* optional, with tile_agg_d: gmx_tile_prefix_words(n) u64.  The LAST workgroup of the
-                                     launch to finish (an atomic ticket after the statistics are written) turns ALL
-                                     tile statistics into what every workgroup of the resampler would otherwise
-                                     re-derive for itself: M = max_b m_b, K = ceil(M / ln 2),
-                                     [b] = sum_{b' < b} A_b' >> (K - k_b')  (exclusive tile prefix, b < tiles),
-                                     [tiles] = the total, [tiles + 1] = M's float bits | (uint64)(uint32)K << 32,
-                                     [tiles + 2] and everything after it = ticket counters (a master and 32
-                                     sub-counters on 128-byte lines of their own): ZERO before the first launch, reset
-                                     to zero by the workgroups that exhaust them.  gmx_resample_tiles_p consumes it. */
 } gmx_run_args;
 
 int gmx_program_create(const uint32_t* blob_h, size_t n_words, gmx_program** out);
@@ -186,11 +150,6 @@ int64_t gmx_program_grid(const gmx_program* p, int64_t n);
 /* 1 when the specialised kernel runs 4 particles per thread (a workgroup = one 1024-particle
  * tile of the CDF) and the program has exactly one OP_REDMAX: it then honours tile_agg_d. */
 int gmx_program_writes_tile_stats(const gmx_program* p);
-/* 1 when gmx_program_run honours gmx_run_args.rs for this program: specialised WITH the resampling prologue
- * (environment GENMI_FUSE_RESAMPLE=1 at gmx_program_specialize time — opt-in: on MI355X the one-launch step measured
- * slower than site program + gmx_resample_tiles), 4 particles per thread, and every gathered load goes through
- * ancestors_d at the top of the kernel. */
-int gmx_program_fuses_resample(const gmx_program* p);
 /* Mark a program as BACKGROUND work before it is specialised: work that depends on nothing a dependent chain of
  * launches produces — e.g. the standard-normal draws of the next SMC steps (keys and particle indices only), which
  * BootstrapSweep's noise-ahead form issues on a second stream beside the chain [site program -> resampler].  The
@@ -290,17 +249,12 @@ int gmx_resample_tiles(int kind, const uint32_t key[2], const float* lw_d, int64
 int gmx_resample(int kind, const uint32_t key[2], const float* lw_d, int64_t n, int shift,
                  const float* max_partials_d, int64_t n_partials, float* max_d,
                  uint64_t* total_d, int32_t* ancestors_d, void* workspace_d, gmx_stream stream);
-/* gmx_resample_tiles from the per-particle fixed-point weights q_i a site program left in
- * gmx_run_args.tile_q_d (same tile statistics, same ancestors). */
-int gmx_resample_tiles_q(int kind, const uint32_t key[2], const uint32_t* q_d, int64_t n, int shift,
-                         const float* tile_max_d, const uint64_t* tile_agg_d, float* max_d,
-                         uint64_t* total_d, int32_t* ancestors_d, gmx_stream stream);
-/* gmx_resample_tiles when the tile PREFIXES are there already (gmx_run_args.tile_pref_d, written once by the last
- * workgroup of the site program; or gmx_tile_prefix from the statistics): a workgroup reads ONE prefix, the total and
+/* gmx_resample_tiles when the tile PREFIXES are there already (gmx_tile_prefix, one workgroup, from the statistics):
+ * a workgroup of the resampler reads ONE prefix, the total and
  * K instead of reducing all <= 2048 tile statistics — the same integers, the same ancestors.  This form (and
  * gmx_tile_stats, gmx_tile_prefix) takes any n < 2^31: past 2048 tiles (n > 2^21) one workgroup walks the table in
  * chunks with a running carry — how a population of 1e7 is resampled without a CDF array.
- * gmx_tile_prefix_words(n): u64 words of the block (ceil(n / 1024) + 3, rounded up to 16, + 32 x 16 of tickets). */
+ * gmx_tile_prefix_words(n): u64 words of the block (ceil(n / 1024) + 2, rounded up to 16). */
 size_t gmx_tile_prefix_words(int64_t n);
 int gmx_tile_prefix(const float* tile_max_d, const uint64_t* tile_agg_d, int64_t n, uint64_t* tile_pref_d,
                     gmx_stream stream);

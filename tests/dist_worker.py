@@ -11,6 +11,8 @@ import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+# what the parent test asks of this run (one JSON object): on_gpu, noise_ahead, capture, cdf_form, fused
+OPTS = json.loads(os.environ.get("GENMI_TEST_OPTS", "{}"))
 
 
 def schools_main(out_path, k_per_rank, capacity):
@@ -54,7 +56,7 @@ def schools_main(out_path, k_per_rank, capacity):
 
 def main(out_path, n_per_rank, T, capacity=None, mh=False, vec=False, vecmh=False):
     dist.init_process_group("gloo")
-    on_gpu = os.environ.get("GENMI_TEST_ON_GPU") == "1"
+    on_gpu = bool(OPTS.get("on_gpu"))
     if on_gpu:
         # every rank on THE one GPU of the box (tests/test_gpu_parity.py: the peer-mapped exchange between two
         # processes through IPC handles, on real device memory): the HIP library, no CPU mirror
@@ -87,14 +89,15 @@ def main(out_path, n_per_rank, T, capacity=None, mh=False, vec=False, vecmh=Fals
     else:
         ys = workloads.lgssm_data(T)
         init, step = workloads.make_lgssm(G)
-        # GENMI_TEST_NOISE_AHEAD=1: the step's draws by background programs keyed by the global particle index
-        na = True if os.environ.get("GENMI_TEST_NOISE_AHEAD") == "1" else (False if on_gpu else None)
-        sw = ShardedBootstrapSweep(init, step, n_per_rank, T, dist, capacity=capacity, noise_ahead=na).prepare(
+        # noise_ahead: the step's draws by background programs keyed by the global particle index
+        na = True if OPTS.get("noise_ahead") else (False if on_gpu else None)
+        sw = ShardedBootstrapSweep(init, step, n_per_rank, T, dist, capacity=capacity, noise_ahead=na,
+                                   cdf_form=bool(OPTS.get("cdf_form")), fused=bool(OPTS.get("fused", 1))).prepare(
             G.key(314159), torch.from_numpy(ys))
         assert sw.noise_ahead == bool(na)
     sw.launch()
     sw.finish()
-    if os.environ.get("GENMI_TEST_CAPTURE") == "1":      # the same sweep again as ONE captured graph, replayed twice
+    if OPTS.get("capture"):      # the same sweep again as ONE captured graph, replayed twice
         first = sw.state().clone()
         sw.capture()
         for _ in range(2):

@@ -108,18 +108,6 @@ static bool hs_tile_mode(const gmx_program* p) {
   return p && p->n_redmax == 1 && p->n_redlse == 0 && !(e && e[0] == '0');
 }
 extern "C" int gmx_program_writes_tile_stats(const gmx_program* p) { return hs_tile_mode(p) ? 1 : 0; }
-static bool hs_gathers(const gmx_program* p) {
-  for (uint32_t pc = 0; pc < p->n_instr; ++pc) {
-    const uint32_t w0 = p->code[2 * pc];
-    if ((w0 & 0xffu) == OP_LDIN && ((w0 >> 24) & GMX_F_GATHER)) return true;
-  }
-  return false;
-}
-// as the HIP library: only under GENMI_FUSE_RESAMPLE=1
-extern "C" int gmx_program_fuses_resample(const gmx_program* p) {
-  const char* e = getenv("GENMI_FUSE_RESAMPLE");
-  return p && hs_gathers(p) && e && e[0] == '1' ? 1 : 0;
-}
 extern "C" int64_t gmx_program_grid(const gmx_program* p, int64_t n) { return hs_tile_mode(p) ? (n + 1023) / 1024 : (n + 255) / 256; }
 static uint64_t hs_weight_fixed(float lw, float ref, float scale);
 
@@ -129,7 +117,6 @@ static float butterfly_sum64(const float* v) {
   return t[0];
 }
 
-extern "C" int gmx_tile_prefix(const float* tmax, const uint64_t* agg, int64_t n, uint64_t* pref, gmx_stream);
 extern "C" int gmx_program_run(const gmx_program* p, int64_t n, const gmx_run_args* A_in, gmx_stream) {
   if (!p || !A_in) return fail("program_run: null");
   gmx_run_args patched = *A_in;
@@ -137,23 +124,8 @@ extern "C" int gmx_program_run(const gmx_program* p, int64_t n, const gmx_run_ar
   const gmx_run_args* A = &patched;
   for (uint32_t s = 0; s < p->n_in; ++s) if (!A->in_d[s]) return fail("program_run: null input slot");
   for (uint32_t s = 0; s < p->n_out; ++s) if (!A->out_d[s]) return fail("program_run: null output slot");
-  if (A->rs.lw_d) {          // the resampling step folded into this launch: gmx_resample_tiles, then gather through it
-    if (!gmx_program_fuses_resample(p)) return fail("program_run: rs is set but this program cannot resample in its own launch");
-    if (!A->rs.tile_max_d || !A->rs.tile_agg_d || !A->rs.anc_out_d) return fail("program_run: rs has a null pointer");
-    if (A->tile_agg_d == A->rs.tile_agg_d || (const float*)A->red_out_d == A->rs.tile_max_d)
-      return fail("program_run: rs reads the tile statistics this launch writes (use two sets)");
-    for (uint32_t s = 0; s < p->n_out; ++s)
-      if ((const void*)A->out_d[s] == (const void*)A->rs.lw_d) return fail("program_run: rs.lw_d is also an output of this launch");
-    const uint32_t key[2] = {A->rs.key0, A->rs.key1};
-    float m_; uint64_t t_;
-    if (gmx_resample_tiles(A->rs.kind, key, A->rs.lw_d, n, A->rs.shift, A->rs.tile_max_d, A->rs.tile_agg_d,
-                           A->rs.max_out_d ? A->rs.max_out_d : &m_, A->rs.total_out_d ? A->rs.total_out_d : &t_,
-                           A->rs.anc_out_d, nullptr)) return 1;
-    patched.ancestors_d = A->rs.anc_out_d;
-  }
   const bool tile = hs_tile_mode(p);
   if (A->tile_agg_d && !tile) return fail("program_run: tile_agg_d is set but this program cannot write tile statistics");
-  if (A->tile_q_d && !A->tile_agg_d) return fail("program_run: tile_q_d needs tile_agg_d");
   const int G = tile ? 1024 : 256;                 // particles per workgroup
   int64_t grid = (n + G - 1) / G;
   std::vector<float> red((size_t)G);
@@ -176,23 +148,12 @@ extern "C" int gmx_program_run(const gmx_program* p, int64_t n, const gmx_run_ar
         A->red_out_d[grid + blk] = (w0 + w1) + (w2 + w3);
       }
       if (tile && A->tile_agg_d) {
-        const float ref = gmx_tile_ref(gmx_tile_exp(m)), scale = gmx_pow2i(A->tile_shift);
+        const float ref = gmx_tile_ref(gmx_tile_exp(m));
         uint64_t sum = 0;
-        for (int t = 0; t < G; ++t) {
-          const uint32_t pk = gmx_exp_fixed_packed(red[t] - ref, A->tile_shift);
-          const uint64_t q = gmx_fixed_unpack(pk);
-          (void)scale;
-          sum += q;
-          if (A->tile_q_d && blk * G + t < n) A->tile_q_d[blk * G + t] = pk;
-        }
+        for (int t = 0; t < G; ++t) sum += gmx_exp_fixed(red[t] - ref, A->tile_shift);
         A->tile_agg_d[blk] = sum;
       }
     }
-  }
-  if (A->tile_pref_d) {       // what the last workgroup of the HIP kernel leaves (include/genmi.h: tile_pref_d)
-    if (!tile || !A->tile_agg_d || !A->red_out_d) return fail("program_run: tile_pref_d needs tile_agg_d and red_out_d");
-    if ((uint32_t)A->tile_pref_d[grid + 2] != 0u) return fail("program_run: the ticket word of tile_pref_d must be zero");
-    if (gmx_tile_prefix(A->red_out_d, A->tile_agg_d, n, A->tile_pref_d, nullptr)) return 1;
   }
   return 0;
 }
@@ -323,8 +284,8 @@ extern "C" int gmx_resample_tiles(int kind, const uint32_t key[2], const float* 
   return gmx_ancestors(kind, key, cdf.data(), n, 0, total, n, 0, n, anc, st);
 }
 // tile statistics -> tile prefixes (sequential statement of gmx_block.h: gmx_tile_prefix_block)
-extern "C" size_t gmx_tile_prefix_words(int64_t n) {       // prefixes | total | M, K | master ticket | pad to 16 | 32 sub-tickets x 16 words
-  return (size_t)(((n + HS_TILE - 1) / HS_TILE + 3 + 15) / 16) * 16 + 32 * 16;
+extern "C" size_t gmx_tile_prefix_words(int64_t n) {       // prefixes | total | M, K | pad to 16
+  return (size_t)(((n + HS_TILE - 1) / HS_TILE + 2 + 15) / 16) * 16;
 }
 extern "C" int gmx_tile_prefix(const float* tmax, const uint64_t* agg, int64_t n, uint64_t* pref, gmx_stream) {
   if (n <= 0 || !tmax || !agg || !pref) return fail("tile_prefix: bad argument");
@@ -532,27 +493,6 @@ extern "C" int gmx_resample_sorted(const uint32_t key[2], const float* lw, int64
     anc[j] = (int32_t)i;
   }
   return 0;
-}
-// the same from the per-particle fixed-point weights the site program left behind
-extern "C" int gmx_resample_tiles_q(int kind, const uint32_t key[2], const uint32_t* q, int64_t n, int shift, const float* tmax,
-                                    const uint64_t* agg, float* max_d, uint64_t* total, int32_t* anc, gmx_stream st) {
-  if (kind == GMX_RESAMPLE_MULTINOMIAL) return fail("resample: kind");
-  if (!q || !tmax || !agg || !max_d || !total || !anc || shift < 1) return fail("resample_tiles_q: bad argument");
-  const int64_t tiles = (n + HS_TILE - 1) / HS_TILE;
-  float M = -gmx_inf();
-  for (int64_t b = 0; b < tiles; ++b) M = gmx_rmax(M, tmax[b]);
-  const int32_t K = gmx_tile_exp(M);
-  std::vector<uint64_t> cdf((size_t)n);
-  uint64_t prefix = 0;
-  for (int64_t b = 0; b < tiles; ++b) {
-    const int64_t lo = b * HS_TILE, hi = lo + HS_TILE < n ? lo + HS_TILE : n;
-    const int32_t k = gmx_tile_exp(tmax[b]);
-    uint64_t run = 0;
-    for (int64_t i = lo; i < hi; ++i) { run += gmx_fixed_unpack(q[i]); cdf[(size_t)i] = prefix + gmx_tile_scale(run, k, K); }
-    prefix += gmx_tile_scale(agg[b], k, K);
-  }
-  *max_d = M; *total = prefix;
-  return gmx_ancestors(kind, key, cdf.data(), n, 0, total, n, 0, n, anc, st);
 }
 extern "C" int gmx_resample(int kind, const uint32_t key[2], const float* lw, int64_t n, int shift, const float*,
                             int64_t, float* max_d, uint64_t* total, int32_t* anc, void* ws, gmx_stream st) {

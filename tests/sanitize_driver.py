@@ -21,16 +21,11 @@ assert "san" in os.environ["GENMI_HOSTSIM_SO"] and "san" in os.environ["GENMI_OR
 
 res = parity.check_lgssm_sweep(n=3000, T=4)
 assert res["ancestors_equal"] and res["x_equal"] and res["totals_equal"], res
-os.environ["GENMI_TILE_Q"] = "1"
 res = parity.check_lgssm_sweep(n=2049, T=3)
 assert res["ancestors_equal"] and res["x_equal"], res
-os.environ["GENMI_TILE_Q"] = "0"
 parity.check_nlssm_mh(n=700, T=3)
 parity.check_nlssm_mh_sweep(n=1100, T=4, want_chained=True)     # MH move chained into the extension (OP_KSPLITU)
-os.environ["GENMI_FUSE_RESAMPLE"] = "1"                         # gmx_run_args.rs: resample inside the step's launch
-res = parity.check_lgssm_sweep(n=2500, T=4, want_fuse=True)
-assert res["ancestors_equal"] and res["x_equal"] and res["totals_equal"], res
-os.environ["GENMI_FUSE_RESAMPLE"] = "0"
+parity.check_nlssm_mh_sweep(n=1100, T=4, want_chained=False, chain_mh=False)     # ... and as two launches
 parity.check_plates(n=129)
 parity.check_plate_of_scans(n=33, no=24, T=40)         # two nested counted loops, [n, A, T] step leaves (GMX_F_FLAT)
 parity.check_plate_of_scans(n=33, no=3, T=40)          # an unrolled plate around its elements' loops

@@ -42,22 +42,22 @@ def _free_port():
 
 
 @pytest.mark.parametrize("world,capacity,tiles,prog_stats,na,fused", [
-    (2, 0, "1", "1", "0", "1"), (4, 0, "1", "1", "0", "1"), (2, 3, "1", "1", "0", "1"), (2, 0, "0", "1", "0", "1"),
-    (2, 0, "1", "0", "0", "1"), (2, 0, "1", "1", "0", "0"), (2, 0, "1", "1", "1", "1"), (4, 3, "1", "1", "1", "1")])
+    (2, 0, 1, "1", 0, 1), (4, 0, 1, "1", 0, 1), (2, 3, 1, "1", 0, 1), (2, 0, 0, "1", 0, 1),
+    (2, 0, 1, "0", 0, 1), (2, 0, 1, "1", 0, 0), (2, 0, 1, "1", 1, 1), (4, 3, 1, "1", 1, 1)])
 def test_sharded_sweep_equals_single_process_oracle(tmp_path, world, capacity, tiles, prog_stats, na, fused):
     """capacity 0 = default (fast path, no overflow); capacity 3 forces the
-    overflow flag and the full-capacity re-run.  tiles "1" = the two-collective step (all-gather of tile
-    statistics + all-to-all), "0" = GENMI_SHARD_TILES=0: max all-reduce + local CDF + totals all-gather + all-to-all.
-    prog_stats "0": the site program does not write the tile statistics itself, a gmx_tile_stats launch does.
-    fused "0": gmx_shard_totals + gmx_shard_step_tiles instead of the one-launch gmx_shard_step_fused.
-    na "1": NOISE AHEAD on the sharded sweep — the step's draws come from background programs keyed by the GLOBAL
+    overflow flag and the full-capacity re-run.  tiles 1 = the two-collective step (all-gather of tile
+    statistics + all-to-all), 0 = ShardedBootstrapSweep(cdf_form=True): max all-reduce + local CDF + totals all-gather +
+    all-to-all.  prog_stats "0": the site program does not write the tile statistics itself, a gmx_tile_stats launch does.
+    fused 0: gmx_shard_totals + gmx_shard_step_tiles instead of the one-launch gmx_shard_step_fused.
+    na 1: NOISE AHEAD on the sharded sweep — the step's draws come from background programs keyed by the GLOBAL
     particle index (lazy_split offset; GMX_KEY_ROWSPLIT rows + index_offset), launched a group of steps ahead."""
     from genjax_amd import workloads
     n_total, T = 4096, 6
     out = str(tmp_path / "shard")
     r = _launch(world, [out, str(n_total // world), str(T)] + ([str(capacity)] if capacity else []),
-                extra_env={"GENMI_SHARD_TILES": tiles, "GENMI_HOSTSIM_TILE_STATS": prog_stats,
-                           "GENMI_TEST_NOISE_AHEAD": na, "GENMI_SHARD_FUSED": fused, "GENMI_NOISE_GROUP": "3"})
+                extra_env={"GENMI_HOSTSIM_TILE_STATS": prog_stats, "GENMI_NOISE_GROUP": "3",
+                           "GENMI_TEST_OPTS": json.dumps({"noise_ahead": na, "cdf_form": not tiles, "fused": fused})})
     assert r.returncode == 0, r.stderr[-3000:]
     x = np.load(out + ".npy")
     meta = json.load(open(out + ".json"))
@@ -71,7 +71,7 @@ def test_sharded_sweep_equals_single_process_oracle(tmp_path, world, capacity, t
     assert np.array_equal(x, ref["x"][ref["anc"]])
 
 
-@pytest.mark.parametrize("world,capacity,na", [(2, 0, "0"), (4, 3, "0"), (2, 0, "1")])
+@pytest.mark.parametrize("world,capacity,na", [(2, 0, 0), (4, 3, 0), (2, 0, 1)])
 def test_sharded_sweep_over_the_peer_mapped_communicator(tmp_path, world, capacity, na):
     """GENMI_COMM=p2p (include/genmi.h "Peer-mapped exchange"; comm.P2PComm): every collective of the sharded step is
     ONE exchange over peer-mapped memory — put into the peers' buffers, a flag per peer, a wait on the own flags; the
@@ -82,7 +82,7 @@ def test_sharded_sweep_over_the_peer_mapped_communicator(tmp_path, world, capaci
     n_total, T = 4096, 6
     out = str(tmp_path / "shard_p2p")
     r = _launch(world, [out, str(n_total // world), str(T)] + ([str(capacity)] if capacity else []),
-                extra_env={"GENMI_COMM": "p2p", "GENMI_TEST_NOISE_AHEAD": na, "GENMI_NOISE_GROUP": "3"})
+                extra_env={"GENMI_COMM": "p2p", "GENMI_NOISE_GROUP": "3", "GENMI_TEST_OPTS": json.dumps({"noise_ahead": na})})
     assert r.returncode == 0, r.stderr[-3000:]
     x = np.load(out + ".npy")
     meta = json.load(open(out + ".json"))

@@ -374,12 +374,11 @@ def test_fused_resampling_beyond_2048_tiles_on_device(gpu, n):
     parity.check_resample_beyond_2048_tiles(n=n)
 
 
-def test_config4_resample_without_the_big_fused_path(gpu, monkeypatch):
+def test_config4_resample_without_the_big_fused_path(gpu):
     """the CDF-array path that n > 2^21 took before (ticketed look-back scan + per-slot search) stays reachable and exact"""
     import genjax_amd as G
     from genjax_amd.inference import smc
     from genjax_amd.inference.smc import ParticleCollection
-    monkeypatch.setenv("GENMI_RESAMPLE_BIG_FUSED", "0")
     n = 3_000_000
     lw = np.random.default_rng(1).normal(0, 1.5, n).astype(np.float32)
     cdf, total, M, shift = O.weight_cdf_c(lw)
@@ -416,12 +415,9 @@ def test_global_resampling_flags_overflow(gpu):
     assert parity.check_shard_route(2048, 2, dead=True, fused="stats", capacity=100)["overflow"]
 
 
-@pytest.mark.parametrize("fill", ["1", "0"])
-def test_fused_shard_step_heavy_tiles_and_ragged_shards(gpu, monkeypatch, fill):
-    """gmx_shard_step_fused in both forms (LDS-routed k_shard_step_fill, and GENMI_SHARD_FILL=0: k_shard_step<tiles,
-    fused>): a tile that owns far more than 2048 slots (several fill passes, runs crossing rank boundaries), no mass at
-    all, one rank, a shard that is not a multiple of the tile."""
-    monkeypatch.setenv("GENMI_SHARD_FILL", fill)
+def test_fused_shard_step_heavy_tiles_and_ragged_shards(gpu):
+    """gmx_shard_step_fused (the LDS-routed k_shard_step_fill): a tile that owns far more than 2048 slots (several fill
+    passes, runs crossing rank boundaries), no mass at all, one rank, a shard that is not a multiple of the tile."""
     assert not parity.check_shard_route(4096, 4, seed=21, spike=40.0, fused="stats")["overflow"]
     assert not parity.check_shard_route(2048, 3, seed=22, spike=25.0, kind=O.STRATIFIED, fused="stats")["overflow"]
     assert not parity.check_shard_route(2048, 4, dead=True, fused="stats")["overflow"]
@@ -832,24 +828,12 @@ def test_specialised_code_object_cache(gpu, tmp_path, monkeypatch):
         assert np.array_equal(u, v) and np.array_equal(u, w)
 
 
-def test_sweep_with_separate_tile_stats_launch(gpu, monkeypatch):
-    """GENMI_TILE_STATS=0: the site program does not write the CDF tile statistics; gmx_resample's own
-    k_tile_stats pass does.  Same sweep, bit for bit (the default path lets the specialised program write them)."""
-    monkeypatch.setenv("GENMI_TILE_STATS", "0")
-    res = parity.check_lgssm_sweep(n=50_000, T=6, capture=True, specialize=True)
+def test_sweep_with_separate_tile_stats_launch(gpu):
+    """an interpreted site program does not write the CDF tile statistics; gmx_resample's own k_tile_stats pass
+    does.  Same sweep, bit for bit (the default path lets the specialised program write them)."""
+    res = parity.check_lgssm_sweep(n=50_000, T=6, capture=True, specialize=False)
     assert res["ancestors_equal"] and res["x_equal"] and res["totals_equal"] and res["lw_max_abs_diff"] == 0.0
     assert res["log_ml"] == res["log_ml_oracle"]
-
-
-def test_sweep_with_fixed_point_weight_handoff(gpu, monkeypatch):
-    """GENMI_TILE_Q=1: the site program also leaves every particle's fixed-point weight (gmx_run_args.tile_q_d) and
-    gmx_resample_tiles_q resamples from those instead of re-deriving them from the log-weights.  Same sweep, bit for
-    bit, ragged last tile included."""
-    monkeypatch.setenv("GENMI_TILE_Q", "1")
-    for n in (50_000, 100_003):
-        res = parity.check_lgssm_sweep(n=n, T=5, capture=True, specialize=True)
-        assert res["ancestors_equal"] and res["x_equal"] and res["totals_equal"] and res["lw_max_abs_diff"] == 0.0
-        assert res["log_ml"] == res["log_ml_oracle"]
 
 
 def test_long_scan_config2_as_one_generative_function(gpu):
@@ -909,23 +893,14 @@ def test_noise_ahead_sweep_matches_oracle(gpu, n, T, capture):
         res = parity.check_lgssm_sweep(n=n, T=T, capture=capture, specialize=True, noise_ahead=na)
         assert res["ancestors_equal"] and res["x_equal"] and res["totals_equal"] and res["lw_max_abs_diff"] == 0.0
         assert abs(res["log_ml"] - res["log_ml_oracle"]) < 1e-11
-    import os
-    os.environ["GENMI_NOISE_ROWS"] = "0"            # one noise launch per step instead of one per group and key
-    try:
-        res = parity.check_lgssm_sweep(n=n, T=T, capture=capture, specialize=True, noise_ahead=True)
-        assert res["ancestors_equal"] and res["x_equal"] and res["totals_equal"] and res["lw_max_abs_diff"] == 0.0
-    finally:
-        del os.environ["GENMI_NOISE_ROWS"]
 
 
 def test_noise_ahead_with_stratified_resampling_and_env_switch(gpu, monkeypatch):
     """the two-stream form with the stratified resampler (one Threefry block per slot edge in the chain's resampler),
     and GENMI_NOISE_AHEAD=0 as the default's off switch"""
     import genjax_amd as G
-    for su in ("1", "0"):       # the per-slot uniforms from the background stream (gmx_slot_uniforms), or drawn in the resampler
-        monkeypatch.setenv("GENMI_SLOT_UNIFORMS", su)
-        G.clear_caches()
-        res = parity.check_lgssm_sweep(n=50_000, T=23, capture=True, specialize=True, resample="stratified", noise_ahead=True)
+    for na in (True, False):    # the per-slot uniforms from the background stream (gmx_slot_uniforms), or drawn in the resampler
+        res = parity.check_lgssm_sweep(n=50_000, T=23, capture=True, specialize=True, resample="stratified", noise_ahead=na)
         assert res["ancestors_equal"] and res["x_equal"] and res["totals_equal"] and res["lw_max_abs_diff"] == 0.0
     from genjax_amd import workloads
     from genjax_amd.inference.smc import BootstrapSweep
@@ -934,22 +909,6 @@ def test_noise_ahead_with_stratified_resampling_and_env_switch(gpu, monkeypatch)
     assert BootstrapSweep(init, step, 4096, 3).prepare(G.key(1), torch.from_numpy(ys)).noise_ahead
     monkeypatch.setenv("GENMI_NOISE_AHEAD", "0")
     assert not BootstrapSweep(init, step, 4096, 3).prepare(G.key(1), torch.from_numpy(ys)).noise_ahead
-
-
-def test_paired_normal_sampler_same_bits(gpu, monkeypatch):
-    """GENMI_JIT_PAIR_NORMALS=1: specialised kernels draw normals two particles at a time through packed f32
-    arithmetic (csrc/gmx_math2.h) — every operation the scalar sampler's, so the sweep still equals the oracle's bit
-    for bit (one-stream: draws inside the site program; noise ahead: inside the background programs)."""
-    import genjax_amd as G
-    monkeypatch.setenv("GENMI_JIT_PAIR_NORMALS", "1")
-    monkeypatch.setenv("GENMI_JIT_CACHE", "0")
-    G.clear_caches()
-    try:
-        for na in (False, True):
-            res = parity.check_lgssm_sweep(n=100_003, T=6, capture=True, specialize=True, noise_ahead=na)
-            assert res["ancestors_equal"] and res["x_equal"] and res["totals_equal"] and res["lw_max_abs_diff"] == 0.0
-    finally:
-        G.clear_caches()
 
 
 def test_noise_ahead_full_size_equals_one_stream(gpu):
@@ -1144,7 +1103,7 @@ def test_captured_loop_noise_ahead_edges(gpu, monkeypatch):
     assert torch.equal(cap.replay().get_particles().get_retval(), ref)
     big = make(300_000)
     ref = big(G.key(9)).get_particles().get_retval().clone()
-    monkeypatch.setenv("GENMI_NOISE_ARENA_MB", "0")
+    monkeypatch.setattr(smc.CapturedLoop, "NOISE_ARENA_MB", 0)
     cap = smc.capture(big, G.key(9), noise_ahead=True)
     assert cap.noise is None
     assert torch.equal(cap.replay().get_particles().get_retval(), ref)
@@ -1177,30 +1136,25 @@ def test_tile_stats_from_the_site_program(gpu):
 
 
 @pytest.mark.parametrize("n", [100_003, 1_000_000, 2_000_000])
-def test_tile_prefixes_from_the_last_workgroup(gpu, monkeypatch, n):
-    """gmx_run_args.tile_pref_d: the site program's LAST workgroup (atomic ticket) leaves M, K, the exclusive tile
-    prefixes and the total; they equal gmx_tile_prefix of the statistics and the host's integers, the ticket word is
-    back at zero, and the sweep through gmx_resample_tiles_p equals the sweep through gmx_resample_tiles bit for bit
-    (PER = 1 / 4 / 8 rows of the table per thread)."""
+def test_tile_prefixes_equal_the_statistics_pass(gpu, n):
+    """gmx_tile_prefix (one workgroup: M, K, the exclusive tile prefixes, the total) equals the host's integers, and
+    gmx_resample_tiles_p reading those prefixes gives the ancestors of gmx_resample_tiles, whose workgroups each reduce
+    the whole statistics table (PER = 1 / 4 / 8 rows of the table per thread)."""
     import genjax_amd as G
+    from ctypes import c_uint32
     from genjax_amd import _lib, workloads
     from genjax_amd.inference.smc import BootstrapSweep
     be = _lib.get()
-    T = 4
+    T = 3
     init, step = workloads.make_lgssm(G)
     ys = torch.from_numpy(workloads.lgssm_data(T))
-    monkeypatch.setenv("GENMI_TILE_PREFIX", "1")             # opt-in (slower on config 2, faster on config 3)
     sw = BootstrapSweep(init, step, n, T).prepare(G.key(2), ys)
-    assert sw.tile_pref is not None
-    for _ in range(3):                     # the ticket resets itself: launch after launch
-        sw.launch()
+    sw.launch()
     torch.cuda.synchronize()
     tiles = (n + 1023) // 1024
-    pref = sw.tile_pref.cpu().numpy().view(np.uint64)
-    assert not pref[tiles + 2:].any()                # the master ticket and the 32 sub-tickets are back at zero
-    ref = torch.zeros_like(sw.tile_pref)
-    be.check(be.c.gmx_tile_prefix(be.ptr(sw.partials), be.ptr(sw.tile_agg), n, be.ptr(ref), be.stream()), "gmx_tile_prefix")
-    assert torch.equal(ref[:tiles + 2], sw.tile_pref[:tiles + 2])
+    pref_t = torch.zeros((int(be.c.gmx_tile_prefix_words(n)),), dtype=torch.int64, device=be.device)
+    be.check(be.c.gmx_tile_prefix(be.ptr(sw.partials), be.ptr(sw.tile_agg), n, be.ptr(pref_t), be.stream()), "gmx_tile_prefix")
+    pref = pref_t.cpu().numpy().view(np.uint64)
     tm = sw.partials[0, :tiles].cpu().numpy()
     agg = sw.tile_agg.cpu().numpy().view(np.uint64)
     M = tm.max()
@@ -1209,13 +1163,13 @@ def test_tile_prefixes_from_the_last_workgroup(gpu, monkeypatch, n):
     assert [int(v) for v in pref[:tiles]] == list(np.cumsum([0] + G_[:-1], dtype=object))
     assert int(pref[tiles]) == sum(G_) == int(sw.totals[T - 1].item()) & (2 ** 64 - 1)
     assert int(pref[tiles + 1]) & 0xFFFFFFFF == int(np.float32(M).view(np.uint32)) and (int(pref[tiles + 1]) >> 32) == K & 0xFFFFFFFF
-    monkeypatch.setenv("GENMI_TILE_PREFIX", "0")
-    sw0 = BootstrapSweep(init, step, n, T).prepare(G.key(2), ys)
-    assert sw0.tile_pref is None
-    sw0.launch()
-    torch.cuda.synchronize()
-    assert torch.equal(sw0.anc, sw.anc) and torch.equal(sw0.totals, sw.totals) and torch.equal(sw0.maxs, sw.maxs)
-    assert torch.equal(sw0.x[(T - 1) % 2], sw.x[(T - 1) % 2])
+    kh = sw.step_keys[T - 1][1].host()
+    kk = (c_uint32 * 2)(int(kh[0]), int(kh[1]))
+    anc = torch.zeros_like(sw.anc)
+    mx, tot = torch.zeros_like(sw.maxs[:1]), torch.zeros_like(sw.totals[:1])
+    be.check(be.c.gmx_resample_tiles_p(sw.kind, kk, be.ptr(sw.lw), n, sw.shift, be.ptr(sw.partials), be.ptr(pref_t), be.ptr(mx),
+                                       be.ptr(tot), be.ptr(anc), be.stream()), "gmx_resample_tiles_p")
+    assert torch.equal(anc, sw.anc) and torch.equal(tot, sw.totals[T - 1:]) and torch.equal(mx, sw.maxs[T - 1:])
 
 
 def test_tile_stats_are_dropped_when_the_weights_change_in_place(gpu):
@@ -1376,45 +1330,19 @@ def test_vector_state_mh_sweep_matches_oracle(gpu, n, capture, specialize):
     parity.check_vector_mh_sweep(n=n, T=5, capture=capture, specialize=specialize)
 
 
-@pytest.mark.parametrize("resample", ["systematic", "stratified"])
-def test_resampler_inside_the_step_launch(gpu, monkeypatch, resample):
-    """GENMI_FUSE_RESAMPLE=1 (gmx_run_args.rs, csrc/gmx_resample.h): every workgroup of the step's site program
-    computes its own 1024 ancestors from the previous step's log-weights + tile statistics — one launch per step.
-    Same ancestors, states, weights and evidence as the oracle's sweep, bit for bit: ragged last tile, n not a
-    multiple of 1024, through a captured graph, and with the MH move as the launch that resamples."""
-    import genjax_amd as G
-    monkeypatch.setenv("GENMI_FUSE_RESAMPLE", "1")
-    G.clear_caches()
-    try:
-        for n, T, cap in ((100_003, 6, False), (5000, 4, True), (1024, 3, False), (700, 3, False)):
-            res = parity.check_lgssm_sweep(n=n, T=T, capture=cap, want_fuse=True, resample=resample)
-            assert res["ancestors_equal"] and res["x_equal"] and res["totals_equal"] and res["lw_max_abs_diff"] == 0.0
-            assert res["log_ml"] == res["log_ml_oracle"]
-        if resample == "systematic":
-            parity.check_nlssm_mh(n=2000, T=4)
-    finally:
-        G.clear_caches()
-
-
-@pytest.mark.parametrize("chained", ["0", "1"])
-def test_mh_move_chained_into_the_extension(gpu, monkeypatch, chained):
-    """GENMI_FUSE_MH on the HIP library: the MH move + the extension as one specialised program (4 particles per
-    thread, tile statistics from its epilogue) or as two launches — ancestors, states, weights, accept bits and
+@pytest.mark.parametrize("chained", [False, True])
+def test_mh_move_chained_into_the_extension(gpu, chained):
+    """BootstrapSweep(chain_mh=) on the HIP library: the MH move + the extension as one specialised program (4 particles
+    per thread, tile statistics from its epilogue) or as two launches — ancestors, states, weights, accept bits and
     evidence equal the oracle's, interpreter and specialised kernel, eager and captured."""
-    import genjax_amd as G
-    monkeypatch.setenv("GENMI_FUSE_MH", chained)
-    G.clear_caches()
-    try:
-        parity.check_nlssm_mh_sweep(n=3000, T=5, want_chained=(chained == "1"))
-        parity.check_nlssm_mh_sweep(n=100_003, T=4, specialize=True, capture=True, want_chained=(chained == "1"))
-        res = parity.check_vector_mh_sweep(n=2500, T=4)
-        assert 0.3 < res["accept_rate"] < 1.0
-    finally:
-        G.clear_caches()
+    parity.check_nlssm_mh_sweep(n=3000, T=5, want_chained=chained, chain_mh=chained)
+    parity.check_nlssm_mh_sweep(n=100_003, T=4, specialize=True, capture=True, want_chained=chained, chain_mh=chained)
+    res = parity.check_vector_mh_sweep(n=2500, T=4, chain_mh=chained)
+    assert 0.3 < res["accept_rate"] < 1.0
 
 
 @pytest.mark.parametrize("case", ["normal", "flat", "skewed", "sparse", "one", "nan_inf", "none"])
-def test_multinomial_through_the_guide_table(gpu, monkeypatch, case):
+def test_multinomial_through_the_guide_table(gpu, case):
     """gmx_multinomial (guide table + a search over ~3 entries) == gmx_ancestors' per-slot binary search, slot for slot,
     on mild, flat, skewed, sparse, degenerate and NaN / inf weight vectors, n_out != n_in included; the mild case also
     against the oracle."""
@@ -1437,11 +1365,15 @@ def test_multinomial_through_the_guide_table(gpu, monkeypatch, case):
     elif case == "none":
         lw[:] = -np.inf
     cdf, total, _, _ = smc.weight_cdf(_dev(lw))
+    from ctypes import c_uint32
+    be = G._lib.get()
+    kh = G.key(31).host()
+    kk = (c_uint32 * 2)(int(kh[0]), int(kh[1]))
     for n_out in (n, 40_000, 500_000):
-        monkeypatch.setenv("GENMI_MN_GUIDED", "1")
-        a = smc.ancestors_from_cdf(2, G.key(31), cdf, total, n_out=n_out)
-        monkeypatch.setenv("GENMI_MN_GUIDED", "0")
-        b = smc.ancestors_from_cdf(2, G.key(31), cdf, total, n_out=n_out)
+        a = smc.ancestors_from_cdf(2, G.key(31), cdf, total, n_out=n_out)           # through the guide table
+        b = torch.empty((n_out,), dtype=torch.int32, device=cdf.device)             # the per-slot search
+        be.check(be.c.gmx_ancestors(2, kk, be.ptr(cdf), n, 0, be.ptr(total), n_out, 0, n_out, be.ptr(b), be.stream()),
+                 "gmx_ancestors")
         assert torch.equal(a, b)
     if case == "normal":
         rc, _, _, _ = O.weight_cdf(lw)
@@ -1584,7 +1516,7 @@ def test_long_scan_importance_weights_against_kalman_on_device(gpu):
     parity.check_scan_importance_vs_kalman(n=2_000_000)
 
 
-@pytest.mark.parametrize("world,na,capture", [(2, "0", "0"), (2, "1", "1"), (4, "1", "1")])
+@pytest.mark.parametrize("world,na,capture", [(2, 0, 0), (2, 1, 1), (4, 1, 1)])
 def test_peer_mapped_exchange_between_two_processes_on_the_device(gpu, tmp_path, world, na, capture):
     """GENMI_COMM=p2p at WORLD SIZE 2 (and 4) on real device memory: the processes (ranks) share the box's one GPU, map each
     other's fine-grained landing buffers and flags through IPC handles (gmx_p2p_alloc / gmx_p2p_open) and run the
@@ -1597,8 +1529,8 @@ def test_peer_mapped_exchange_between_two_processes_on_the_device(gpu, tmp_path,
     n_total, T = 8192, 6
     out = str(tmp_path / "p2p_gpu")
     r = _launch(world, [out, str(n_total // world), str(T)],
-                extra_env={"GENMI_COMM": "p2p", "GENMI_TEST_ON_GPU": "1", "GENMI_TEST_NOISE_AHEAD": na,
-                           "GENMI_TEST_CAPTURE": capture, "GENMI_NOISE_GROUP": "3", "GENMI_COMM_TIMEOUT": "60"})
+                extra_env={"GENMI_COMM": "p2p", "GENMI_NOISE_GROUP": "3", "GENMI_COMM_TIMEOUT": "60",
+                           "GENMI_TEST_OPTS": json.dumps({"on_gpu": 1, "noise_ahead": na, "capture": capture})})
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     x = np.load(out + ".npy")
     meta = json.load(open(out + ".json"))

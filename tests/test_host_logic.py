@@ -1044,28 +1044,17 @@ def test_sweep_without_program_written_tile_stats(monkeypatch):
     assert res["log_ml"] == res["log_ml_oracle"]
 
 
-def test_sweep_with_fixed_point_weight_handoff(monkeypatch):
-    """GENMI_TILE_Q=1 (gmx_run_args.tile_q_d -> gmx_resample_tiles_q): same sweep bit for bit"""
-    from tests import parity
-    monkeypatch.setenv("GENMI_TILE_Q", "1")
-    res = parity.check_lgssm_sweep(n=3000, T=5)
-    assert res["ancestors_equal"] and res["x_equal"] and res["totals_equal"] and res["lw_max_abs_diff"] == 0.0
-    assert res["log_ml"] == res["log_ml_oracle"]
-
-
 def test_tuple_state_sweep_matches_oracle():
     from tests import parity
     parity.check_tuple_state_sweep()
 
 
-@pytest.mark.parametrize("rows", ["1", "0"])
-def test_noise_ahead_sweep_matches_oracle(monkeypatch, rows):
+def test_noise_ahead_sweep_matches_oracle():
     """BootstrapSweep(noise_ahead=True): the steps' normal draws come from background programs (static.NoiseProgram),
     the site programs read them (MinimalGenerate(hoist_noise=True)); same particles, weights, ancestors and evidence
-    as the oracle's sweep — T not a multiple of the noise group, one / three latent sites per step.  GENMI_NOISE_ROWS:
-    the draws of a group's steps from ONE launch per key (rows of keys, GMX_KEY_ROWSPLIT) or one launch per step."""
+    as the oracle's sweep — T not a multiple of the noise group, one / three latent sites per step; the draws of a
+    group's steps come from ONE launch per key (rows of keys, GMX_KEY_ROWSPLIT)."""
     from tests import parity
-    monkeypatch.setenv("GENMI_NOISE_ROWS", rows)
     res = parity.check_lgssm_sweep(n=3000, T=23, noise_ahead=True)
     assert res["ancestors_equal"] and res["x_equal"] and res["totals_equal"] and res["lw_max_abs_diff"] == 0.0
     # the same integer totals; 23 float64 terms summed pairwise (numpy) here and one after the other in the oracle
@@ -1075,9 +1064,8 @@ def test_noise_ahead_sweep_matches_oracle(monkeypatch, rows):
     parity.check_nlssm_mh_sweep(n=1500, T=7, noise_ahead=True)
     # stratified: the resampler's per-slot uniforms come from the background stream too (gmx_slot_uniforms ->
     # gmx_resample_tiles_u; the CPU mirror refuses uniforms that are not the resampling key's own)
-    for su in ("1", "0"):
-        monkeypatch.setenv("GENMI_SLOT_UNIFORMS", su)
-        res = parity.check_lgssm_sweep(n=3000, T=23, noise_ahead=True, resample="stratified")
+    for na in (True, False):       # (the one-stream form draws them inside the resampler)
+        res = parity.check_lgssm_sweep(n=3000, T=23, noise_ahead=na, resample="stratified")
         assert res["ancestors_equal"] and res["x_equal"] and res["totals_equal"] and res["lw_max_abs_diff"] == 0.0
 
 
@@ -1154,28 +1142,15 @@ def test_weight_fixed_matches_its_definition(tmp_path):
     assert "shift 62 done, mismatches so far 0" in out.stdout
 
 
-@pytest.mark.parametrize("fuse", ["0", "1"])
-def test_sweep_with_and_without_the_resampler_in_the_step_launch(monkeypatch, fuse):
-    """GENMI_FUSE_RESAMPLE: the resampling step folded into the next site program's launch (gmx_run_args.rs; the
-    C-ABI mirror resamples and then gathers) or as its own launch — the same sweep bit for bit, both equal to the
-    oracle's; also through the MH-moved sweep (the move is then the launch that resamples)."""
+@pytest.mark.parametrize("chained", [False, True])
+def test_mh_sweep_with_the_move_chained_into_the_extension(chained):
+    """BootstrapSweep(rejuvenate=..., chain_mh=): the MH move and the extension that follows it as one program
+    (static.MinimalMHGenerate, the extension's key through OP_KSPLITU) or as two launches (what a chained program too
+    large for the tile statistics falls back to) — the same sweep, equal to the oracle's step-by-step statement either
+    way (scalar and vector state)."""
     from tests import parity
-    monkeypatch.setenv("GENMI_FUSE_RESAMPLE", fuse)
-    res = parity.check_lgssm_sweep(n=3000, T=5)
-    assert res["ancestors_equal"] and res["x_equal"] and res["totals_equal"] and res["lw_max_abs_diff"] == 0.0
-    assert res["log_ml"] == res["log_ml_oracle"]
-    parity.check_nlssm_mh(n=1500, T=4)
-
-
-@pytest.mark.parametrize("chained", ["0", "1"])
-def test_mh_sweep_with_the_move_chained_into_the_extension(monkeypatch, chained):
-    """GENMI_FUSE_MH: BootstrapSweep(rejuvenate=...) issues the MH move and the extension that follows it as one
-    program (static.MinimalMHGenerate, the extension's key through OP_KSPLITU) or as two launches — the same sweep,
-    equal to the oracle's step-by-step statement either way (scalar and vector state)."""
-    from tests import parity
-    monkeypatch.setenv("GENMI_FUSE_MH", chained)
-    parity.check_nlssm_mh_sweep(n=1500, T=5, want_chained=(chained == "1"))
-    res = parity.check_vector_mh_sweep(n=1200, T=4)
+    parity.check_nlssm_mh_sweep(n=1500, T=5, want_chained=chained, chain_mh=chained)
+    res = parity.check_vector_mh_sweep(n=1200, T=4, chain_mh=chained)
     assert 0.3 < res["accept_rate"] < 1.0
 
 

@@ -1,7 +1,7 @@
 """A/B of BootstrapSweep builds that differ in ONE environment switch, in one process on one box (config 2 by default;
 CONFIG=3: the nonlinear SSM with one MH move per step):
 
-  python tools/bench_ab.py GENMI_TILE_PREFIX 0 1
+  python tools/bench_ab.py GENMI_NOISE_AHEAD 0 1
 
 Every variant is prepared and captured with the switch set to its value, the variants are then timed in turn
 (ROUNDS rounds of REPS graph replays each, so that clock / thermal drift hits all of them alike) and their final

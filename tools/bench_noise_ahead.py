@@ -16,7 +16,7 @@ from genjax_amd.inference.smc import BootstrapSweep
 n, T = int(os.environ.get("N", 1_000_000)), int(os.environ.get("T", 100))
 ys = workloads.lgssm_data(T)
 init, step = workloads.make_lgssm(G)
-out = {"n": n, "T": T, "group": os.environ.get("GENMI_NOISE_GROUP"), "lds_pad": os.environ.get("GENMI_NOISE_LDS_PAD")}
+out = {"n": n, "T": T, "group": os.environ.get("GENMI_NOISE_GROUP")}
 state = {}
 for name, na in (("one_stream", False), ("noise_ahead", True)):
     sw = BootstrapSweep(init, step, n, T, noise_ahead=na).prepare(G.key(314159), torch.from_numpy(ys))

@@ -1,5 +1,5 @@
 """BASELINE config 3 as the native captured sweep (BootstrapSweep(rejuvenate=...)): us / step and the
-size of each site program.  GENMI_JIT_PP=<k> forces k particles per thread in every specialised kernel."""
+size of each site program."""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -11,7 +11,7 @@ n, T = int(os.environ.get("N", 1_000_000)), int(os.environ.get("T", 100))
 ys = workloads.nlssm_data(T)
 init, step = workloads.make_nlssm(G)
 req = G.StaticRequest({"x": G.Rejuvenate(G.normal, lambda chm: (chm.get_value(), 0.5))})
-out = {"pp": os.environ.get("GENMI_JIT_PP", "auto")}
+out = {}
 states = []
 for name, na in (("one_stream", False), ("noise_ahead", True)):
     sw = smc.BootstrapSweep(init, step, n, T, step_extra=lambda t: (float(t),), rejuvenate=req, noise_ahead=na).prepare(

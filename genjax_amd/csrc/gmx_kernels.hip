@@ -1494,7 +1494,7 @@ k_offspring_tile(uint32_t k0, uint32_t k1, uint32_t u0_host, const float* __rest
   // ---- issue every load first ----
   float x[CDF_VEC];
   const bool full_tile = (int64_t)(tile_c + 1) * RS_TILE <= n;                   // wave-uniform
-  if (full_tile) {  } else if (full_tile) {
+  if (full_tile) {
     float4 v = *reinterpret_cast<const float4*>(lw + i0);
     x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
   } else {

@@ -26,6 +26,22 @@ RESAMPLE_SYSTEMATIC, RESAMPLE_STRATIFIED, RESAMPLE_MULTINOMIAL, RESAMPLE_MULTINO
 RESAMPLE_MULTINOMIAL_SORTED = 4
 
 
+class Peer(Structure):
+    """struct gmx_peer: the peers of a sharded SMC step (include/genmi.h "Fused peer exchange")"""
+    _fields_ = [
+        ("land_d", c_void_p),
+        ("tag_base_d", c_void_p),
+        ("status_d", c_void_p),
+        ("rank", c_int32),
+        ("world", c_int32),
+        ("step", c_int32),
+        ("tiles", c_int32),
+        ("capacity", c_int64),
+        ("leaves", c_int32),
+        ("reserved_", c_int32),
+    ]
+
+
 class RunArgs(Structure):
     """struct gmx_run_args"""
     _fields_ = [
@@ -45,6 +61,7 @@ class RunArgs(Structure):
         ("tile_shift", c_int32),
         ("reserved_", c_int32),
         ("step_stride", c_int64),
+        ("peer", Peer),
     ]
 
 
@@ -139,6 +156,12 @@ class Backend:
                                       c_void_p, c_void_p, c_void_p, c_void_p]
         c.gmx_shard_step.argtypes = [c_int, POINTER(c_uint32), c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                      c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]
+        c.gmx_peer_landing_bytes.argtypes = [c_int, c_int64, c_int64, c_int]
+        c.gmx_peer_landing_bytes.restype = c_size_t
+        c.gmx_peer_bump.argtypes = [c_void_p, c_int32, c_void_p]
+        c.gmx_peer_put_stats.argtypes = [c_void_p, Peer, c_int64, c_void_p]
+        c.gmx_shard_step_peer.argtypes = [c_int, POINTER(c_uint32), c_void_p, Peer, c_void_p, c_void_p, c_void_p, c_void_p,
+                                          c_int, c_int64, POINTER(c_void_p), POINTER(c_void_p), c_void_p, c_void_p]
         c.gmx_p2p_alloc.argtypes = [c_size_t, POINTER(c_void_p), c_void_p]
         c.gmx_p2p_open.argtypes = [c_void_p, POINTER(c_void_p)]
         c.gmx_p2p_close.argtypes = [c_void_p]

@@ -18,6 +18,7 @@
 #pragma once
 #include "gmx_block.h"
 #include "gmx_vm.h"
+#include "gmx_peer.h"
 
 // a background program (gmx_program_set_background) keeps the default wave priority 0 and has a name of its own
 // (so that kernel traces tell the noise programs from the chain's site programs)
@@ -41,6 +42,8 @@ struct gmx_jit_ctx {
   uint32_t rows;            // number of 256-particle groups = ceil(n / 256)
   int64_t n_rows;           // n (particles of this launch)
   float acc_max;            // OP_REDMAX: running max over the thread's PP particles
+  uint64_t* peer_land;      // gmx_run_args.peer: thread p < world (p != rank): rank p's landing block; else null
+  uint32_t peer_tag;        // ... and this step's tag (loaded at the top of the kernel: the epilogue must not wait for it)
   bool first, last;         // this step handles the first / last of the thread's particles
   __device__ __forceinline__ uint32_t pool(uint32_t i) const {
     return i < (uint32_t)NDYN ? A->uni[i] : consts[i - (uint32_t)NDYN];
@@ -68,7 +71,10 @@ struct gmx_jit_ctx {
         s = wave_sum_u64(s);
         if ((threadIdx.x & 63) == 0) lds8[threadIdx.x >> 6] = s;
         __syncthreads();
-        if (threadIdx.x == 0) A->tile_agg_d[blockIdx.x] = (lds8[0] + lds8[1]) + (lds8[2] + lds8[3]);
+        const uint64_t a_b = (lds8[0] + lds8[1]) + (lds8[2] + lds8[3]);
+        if (threadIdx.x == 0) A->tile_agg_d[blockIdx.x] = a_b;
+        // sharded: the same two numbers straight into every other rank's landing table (thread p serves rank p)
+        if (peer_land) gmx_peer_put_tile(peer_land, peer_tag, A->peer.world, A->peer.tiles, A->peer.rank, (int)blockIdx.x, a_b, bm);
       }
     }
   }
@@ -101,6 +107,12 @@ struct gmx_jit_ctx {
     ctx_t ctx;                                                                                   \
     ctx.consts = GMX_JIT_CONST; ctx.A = &A; ctx.lds4 = lds4; ctx.lds8 = lds8; ctx.part = 0; ctx.cur = 0; \
     ctx.rows = (uint32_t)((n + GMX_BLOCK - 1) / GMX_BLOCK); ctx.n_rows = n;      \
+    ctx.peer_land = nullptr; ctx.peer_tag = 0u;                                                  \
+    if (PPV == 4 && A.peer.land_d) {                    /* launch-uniform */                     \
+      ctx.peer_tag = *A.peer.tag_base_d + (uint32_t)A.peer.step;                                 \
+      if (threadIdx.x < (uint32_t)A.peer.world && (int)threadIdx.x != A.peer.rank)               \
+        ctx.peer_land = (uint64_t*)A.peer.land_d[threadIdx.x];                                   \
+    }                                                                                            \
     regs_t R[PP];                                                                                \
     /* particle rows as 32-bit numbers (gmx_program_run admits n < 2^31 for a specialised kernel): the 64-bit \
        forms below are zero-extensions, so address arithmetic is a shift-add, not 64-bit compares / selects */  \

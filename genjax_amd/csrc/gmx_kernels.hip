@@ -31,6 +31,7 @@
 #include "gmx_block.h"
 #include "gmx_vm.h"
 #include "gmx_resample.h"
+#include "gmx_peer.h"
 #include "gmx_sorted.h"
 
 // ---------------------------------------------------------------------------
@@ -3018,13 +3019,41 @@ extern "C" int gmx_shard_step_tiles(int kind, const uint32_t key[2], const uint6
 // particles: 8 x 123, 4 x 245, 2 x 489, 1 x 977): a thread holds its <= 4 rows in registers, so ALL loads of the launch
 // are issued before anything waits and the table is read once — the generic form walks it twice, the second time
 // behind a barrier.
-template <int kind, bool SMALL>
+// PEER (include/genmi.h "Fused peer exchange"): no collective launch on either side of this kernel.  The other ranks'
+// statistics are granules in this rank's landing block, polled until they carry the step's tag (the rows of this rank
+// itself come from the local table `stats_all`, which then holds ONE block: stride = 0 is never used for r != rank);
+// a slot another rank owns gets the ancestor's state as a granule put into THAT rank's landing block; and at the end
+// every slot of this rank whose ancestor is remote waits for its granule and stores the value in the local tail.
+#define GMX_PEER_MAX_LEAVES 8
+struct shard_peer {
+  uint64_t* const* land;                         // device array [world]: every rank's landing block, mapped here
+  const uint32_t* tag_base; uint64_t* status;
+  int32_t step, leaves;
+  const uint32_t* state[GMX_PEER_MAX_LEAVES];    // leaf l: this rank's states [n]
+  uint32_t* tail[GMX_PEER_MAX_LEAVES];           // leaf l: the tail [world * cap] of its extended state
+};
+// one row of another rank's statistics: spin (bounded) until all three granules carry `tag`
+__device__ __forceinline__ bool shard_peer_row(const uint64_t* row, uint32_t tag, uint64_t& agg, float& tmax) {
+  uint32_t spins = 0;
+  for (;;) {
+    const uint64_t g0 = gmx_granule_peek(row), g1 = gmx_granule_peek(row + 1), g2 = gmx_granule_peek(row + 2);
+    if ((uint32_t)(g0 >> 32) == tag && (uint32_t)(g1 >> 32) == tag && (uint32_t)(g2 >> 32) == tag) {
+      agg = (uint64_t)(uint32_t)g0 | ((uint64_t)(uint32_t)g1 << 32);
+      tmax = gmx_u2f((uint32_t)g2);
+      return true;
+    }
+    if (++spins >= GMX_PEER_SPIN_LIMIT) { agg = 0ull; tmax = -gmx_inf(); return false; }
+    __builtin_amdgcn_s_sleep(2);
+  }
+}
+template <int kind, bool SMALL, bool PEER>
 __global__ void __launch_bounds__(GMX_BLOCK)
 k_shard_step_fill(uint32_t k0, uint32_t k1, uint32_t u0_host, const float* __restrict__ lw,
                   const uint8_t* __restrict__ stats_all, size_t stride, int n_tiles, float scale, int rank, int world,
                   int32_t n, int32_t cap, int64_t* __restrict__ plan, uint64_t* __restrict__ total_out,
                   float* __restrict__ max_out, const uint32_t* __restrict__ state, uint32_t* __restrict__ send,
-                  int32_t* __restrict__ next_idx) {
+                  int32_t* __restrict__ next_idx, const shard_peer P) {
+  GMX_SETPRIO
   __shared__ uint64_t s_part[SHARD_MAX_WORLD][4];
   __shared__ uint64_t s_below[4], s_scan[4];
   __shared__ float s_max[4];
@@ -3051,8 +3080,13 @@ k_shard_step_fill(uint32_t k0, uint32_t k1, uint32_t u0_host, const float* __res
       x[c] = (i0 + c < n) ? xv : -gmx_inf();
     }
   }
-  const uint8_t* own = stats_all + (size_t)rank * stride;
+  // PEER: `stats_all` is this rank's own block; the other ranks' rows are granules in the landing block
+  const uint8_t* own = PEER ? stats_all : stats_all + (size_t)rank * stride;
   const float tmax_mine = reinterpret_cast<const float*>(own + (size_t)tiles_pad * 8)[my_tile];
+  uint32_t tag = 0u;
+  const uint64_t* land_own = nullptr;            // this rank's own landing block (entry `rank` of the table)
+  if (PEER) { tag = *P.tag_base + (uint32_t)P.step; land_own = P.land[rank]; }
+  bool timed_out = false;
   // ---- pass 1 over the table: the global max ----
   float m = -gmx_inf();
   uint64_t ta[4];
@@ -3071,17 +3105,36 @@ k_shard_step_fill(uint32_t k0, uint32_t k1, uint32_t u0_host, const float* __res
       if (t >= n_tiles) { ++r; t -= n_tiles; }
       rr[k] = rho < rows ? r : -1;
       tt[k] = t;
-      const uint8_t* blk = stats_all + (size_t)r * stride;
-      ta[k] = reinterpret_cast<const uint64_t*>(blk)[t];
-      tm[k] = reinterpret_cast<const float*>(blk + (size_t)tiles_pad * 8)[t];
+      if (PEER && r != rank) {
+        if (rho < rows) timed_out |= !shard_peer_row(land_own + gmx_peer_stats_at(tag, world, n_tiles, r, t), tag, ta[k], tm[k]);
+        else { ta[k] = 0ull; tm[k] = -gmx_inf(); }
+      } else {
+        const uint8_t* blk = PEER ? own : stats_all + (size_t)r * stride;
+        ta[k] = reinterpret_cast<const uint64_t*>(blk)[t];
+        tm[k] = reinterpret_cast<const float*>(blk + (size_t)tiles_pad * 8)[t];
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int k = 0; k < 4; ++k) m = gmx_rmax(m, rr[k] >= 0 ? tm[k] : -gmx_inf());
   } else {
     for (int r = 0; r < world; ++r) {
-      const float* tmax = reinterpret_cast<const float*>(stats_all + (size_t)r * stride + (size_t)tiles_pad * 8);
-      for (int t = tid; t < n_tiles; t += GMX_BLOCK) m = gmx_rmax(m, tmax[t]);
+      if (PEER && r != rank) {
+        for (int t = tid; t < n_tiles; t += GMX_BLOCK) {
+          uint64_t a_; float m_;
+          timed_out |= !shard_peer_row(land_own + gmx_peer_stats_at(tag, world, n_tiles, r, t), tag, a_, m_);
+          m = gmx_rmax(m, m_);
+        }
+      } else {
+        const float* tmax = reinterpret_cast<const float*>((PEER ? own : stats_all + (size_t)r * stride) + (size_t)tiles_pad * 8);
+        for (int t = tid; t < n_tiles; t += GMX_BLOCK) m = gmx_rmax(m, tmax[t]);
+      }
+    }
+  }
+  if (PEER) {      // a peer whose statistics never arrived: the workgroup leaves (bounded, no garbage routed)
+    if (__syncthreads_or(timed_out ? 1 : 0)) {
+      if (tid == 0) { __hip_atomic_store(P.status, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); plan[GMX_PLAN_OVERFLOW] = 1; }
+      return;
     }
   }
   m = wave_max(m);
@@ -3117,11 +3170,15 @@ k_shard_step_fill(uint32_t k0, uint32_t k1, uint32_t u0_host, const float* __res
     }
   } else {
     for (int r = 0; r < world; ++r) {
-      const uint64_t* agg = reinterpret_cast<const uint64_t*>(stats_all + (size_t)r * stride);
-      const float* tmax = reinterpret_cast<const float*>(stats_all + (size_t)r * stride + (size_t)tiles_pad * 8);
+      const uint8_t* blk = PEER ? own : stats_all + (size_t)r * stride;
+      const uint64_t* agg = reinterpret_cast<const uint64_t*>(blk);
+      const float* tmax = reinterpret_cast<const float*>(blk + (size_t)tiles_pad * 8);
       uint64_t sum = 0;
       for (int t = tid; t < n_tiles; t += GMX_BLOCK) {
-        const uint64_t G = gmx_tile_scale(agg[t], gmx_tile_exp(tmax[t]), K);
+        uint64_t a_; float m_;
+        if (PEER && r != rank) (void)shard_peer_row(land_own + gmx_peer_stats_at(tag, world, n_tiles, r, t), tag, a_, m_);   // (complete: pass 1 waited)
+        else { a_ = agg[t]; m_ = tmax[t]; }
+        const uint64_t G = gmx_tile_scale(a_, gmx_tile_exp(m_), K);
         sum += G;
         below += (r == rank && t < my_tile) ? G : 0ull;
       }
@@ -3151,6 +3208,32 @@ k_shard_step_fill(uint32_t k0, uint32_t k1, uint32_t u0_host, const float* __res
     if (lane == 0) s_bounds[world] = N;
   }
   bool overflow = false;
+  // PEER: ship source `src` (local index) as slot k of the block for rank d — one granule per leaf, into d's landing
+  auto put = [&](int32_t d, int32_t k, uint32_t src) {
+    if (PEER) {
+      uint64_t* land_d = P.land[d];
+      for (int l = 0; l < P.leaves; ++l)
+        gmx_granule_put(land_d + gmx_peer_state_at(tag, world, n_tiles, cap, P.leaves, l, rank, k), P.state[l][src], tag);
+    } else {
+      send[(int64_t)d * cap + k] = state[src];
+    }
+  };
+  // PEER: my slot whose ancestor rank s ships as element k: wait for its granule(s), store them in the local tail
+  auto receive = [&](int32_t s_, int32_t k) {
+    if (PEER) {
+      for (int l = 0; l < P.leaves; ++l) {
+        const uint64_t* g = land_own + gmx_peer_state_at(tag, world, n_tiles, cap, P.leaves, l, s_, k);
+        uint64_t v = gmx_granule_peek(g);
+        uint32_t spins = 0;
+        while ((uint32_t)(v >> 32) != tag) {
+          if (++spins >= GMX_PEER_SPIN_LIMIT) { __hip_atomic_store(P.status, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+          __builtin_amdgcn_s_sleep(2);
+          v = gmx_granule_peek(g);
+        }
+        P.tail[l][(int64_t)s_ * cap + k] = (uint32_t)v;
+      }
+    }
+  };
   if (total == 0) {       // no mass at all: the globally last particle (rank world-1, local n-1) sources every slot
     if (blockIdx.x == 0 && tid == 0) {
       plan[GMX_PLAN_TOTAL] = 0; plan[GMX_PLAN_OFFSET] = 0;
@@ -3164,20 +3247,19 @@ k_shard_step_fill(uint32_t k0, uint32_t k1, uint32_t u0_host, const float* __res
       for (int c = 0; c < CDF_VEC; ++c) {
         const int32_t i = i0 + c;
         if (i < n) {
-          if (i < cap) next_idx[i] = n + (world - 1) * cap + i;
+          if (i < cap) { next_idx[i] = n + (world - 1) * cap + i; receive(world - 1, i); }
           else { next_idx[i] = 0; overflow = true; }
         }
       }
     }
     if (rank == world - 1) {
-      const uint32_t v = state[n - 1];
 #pragma unroll
       for (int c = 0; c < CDF_VEC; ++c) {
         const int32_t k = i0 + c;
         if (k < n) {
           next_idx[k] = n - 1;
           for (int d = 0; d < world - 1; ++d) {
-            if (k < cap) send[(int64_t)d * cap + k] = v; else overflow = true;
+            if (k < cap) put(d, k, (uint32_t)(n - 1)); else overflow = true;
           }
         }
       }
@@ -3244,24 +3326,28 @@ k_shard_step_fill(uint32_t k0, uint32_t k1, uint32_t u0_host, const float* __res
     if (total_out) *total_out = total;
     if (max_out) *max_out = M;
   }
-  // (b) my slots base + i0..+3: an ancestor on rank s != rank arrives at recv[s*cap + k]
-  if (world > 1) {
+  // (b) my slots base + i0..+3: an ancestor on rank s != rank arrives at recv[s*cap + k]  (PEER: at the END of the
+  // kernel, behind this workgroup's own puts — it WAITS for the value there)
+  auto remote_slots = [&]() {
+    if (world > 1) {
 #pragma unroll
-    for (int c = 0; c < CDF_VEC; ++c) {
-      const int32_t i = i0 + c;
-      if (i < n) {
-        const int32_t jj = base + i;
-        int s = 0;
-        while (s + 1 < world && s_bounds[s + 1] <= jj) ++s;
-        if (s != rank) {
-          const int32_t first = s_bounds[s] > base ? s_bounds[s] : base;
-          const int32_t k = jj - first;
-          if (k < cap) next_idx[i] = n + s * cap + k;
-          else { next_idx[i] = 0; overflow = true; }
+      for (int c = 0; c < CDF_VEC; ++c) {
+        const int32_t i = i0 + c;
+        if (i < n) {
+          const int32_t jj = base + i;
+          int s = 0;
+          while (s + 1 < world && s_bounds[s + 1] <= jj) ++s;
+          if (s != rank) {
+            const int32_t first = s_bounds[s] > base ? s_bounds[s] : base;
+            const int32_t k = jj - first;
+            if (k < cap) { next_idx[i] = n + s * cap + k; receive(s, k); }
+            else { next_idx[i] = 0; overflow = true; }
+          }
         }
       }
     }
-  }
+  };
+  if (!PEER) remote_slots();
   for (int32_t pass = T0; pass < T1; pass += RS_FILL_SLOTS) {      // block-uniform (1 pass unless the tile owns > 2048 slots)
     if (pass != T0) {
       __syncthreads();
@@ -3308,13 +3394,14 @@ k_shard_step_fill(uint32_t k0, uint32_t k1, uint32_t u0_host, const float* __res
             else {
               const int32_t first = S > d * n ? S : d * n;        // first slot this rank sends to d
               const int32_t k = jj - first;
-              if (k < cap) send[(int64_t)d * cap + k] = state[src[c]]; else overflow = true;
+              if (k < cap) put(d, k, src[c]); else overflow = true;
             }
           }
         }
       }
     }
   }
+  if (PEER) remote_slots();
   if (overflow) plan[GMX_PLAN_OVERFLOW] = 1;
 }
 
@@ -3344,10 +3431,10 @@ extern "C" int gmx_shard_step_fused(int kind, const uint32_t key[2], const void*
   const uint32_t u0 = (b0 ^ b1) >> 9;
   const bool small = world <= 8 && (int64_t)world * tiles <= 4 * GMX_BLOCK;
 #define GMX_LAUNCH_SF2(KIND, SM)                                                                                      \
-  hipLaunchKernelGGL((k_shard_step_fill<KIND, SM>), dim3((unsigned)tiles), dim3(GMX_BLOCK), 0, (hipStream_t)stream, key[0],  \
+  hipLaunchKernelGGL((k_shard_step_fill<KIND, SM, false>), dim3((unsigned)tiles), dim3(GMX_BLOCK), 0, (hipStream_t)stream, key[0],  \
                      key[1], u0, lw_d, (const uint8_t*)stats_all_d, stride, (int)tiles, scale, rank, world,           \
                      (int32_t)n_per_rank, (int32_t)capacity, plan_d, total_out_d, max_out_d, (const uint32_t*)state_d,   \
-                     (uint32_t*)send_d, next_idx_d)
+                     (uint32_t*)send_d, next_idx_d, shard_peer())
 #define GMX_LAUNCH_SF(KIND) do { if (small) GMX_LAUNCH_SF2(KIND, true); else GMX_LAUNCH_SF2(KIND, false); } while (0)
   if (kind == GMX_RESAMPLE_SYSTEMATIC) GMX_LAUNCH_SF(GMX_RESAMPLE_SYSTEMATIC); else GMX_LAUNCH_SF(GMX_RESAMPLE_STRATIFIED);
 #undef GMX_LAUNCH_SF
@@ -3357,17 +3444,134 @@ extern "C" int gmx_shard_step_fused(int kind, const uint32_t key[2], const void*
 }
 
 // ---------------------------------------------------------------------------
+// fused peer exchange (include/genmi.h "Fused peer exchange"): the entry points around k_shard_step_fill<.., PEER>
+// ---------------------------------------------------------------------------
+extern "C" size_t gmx_peer_landing_bytes(int world, int64_t n_per_rank, int64_t capacity, int leaves) {
+  if (world < 1 || n_per_rank < 1 || capacity < 1 || leaves < 1) return 0;
+  const int tiles = (int)((n_per_rank + RS_TILE - 1) / RS_TILE);
+  return (gmx_peer_stats_words(world, tiles) + gmx_peer_state_words(world, capacity, leaves)) * sizeof(uint64_t);
+}
+
+__global__ void k_peer_bump(uint32_t* tag_base, uint32_t T) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *tag_base += T;
+}
+extern "C" int gmx_peer_bump(uint32_t* tag_base_d, int32_t T, gmx_stream stream) {
+  if (!tag_base_d || T < 1) return gmx_fail("gmx_peer_bump: bad argument%s");
+  hipLaunchKernelGGL(k_peer_bump, dim3(1), dim3(64), 0, (hipStream_t)stream, tag_base_d, (uint32_t)T);
+  GMX_HIP(hipGetLastError());
+  return 0;
+}
+
+static int peer_check(const char* who, const gmx_peer& P, int64_t n_per_rank) {
+  if (!P.land_d || !P.tag_base_d || !P.status_d) return gmx_fail("%s: peer has a null pointer", who);
+  if (P.world < 1 || P.world > SHARD_MAX_WORLD || P.rank < 0 || P.rank >= P.world) return gmx_fail("%s: peer rank / world out of range (world <= 64)", who);
+  if (P.step < 0) return gmx_fail("%s: peer.step is negative", who);
+  const int64_t tiles = (n_per_rank + RS_TILE - 1) / RS_TILE;
+  if (n_per_rank <= 0 || tiles > RS_MAX_TILES || P.tiles != (int32_t)tiles) return gmx_fail("%s: peer.tiles must be ceil(n_per_rank / 1024) <= 2048", who);
+  if (P.capacity < 1 || P.capacity > n_per_rank) return gmx_fail("%s: peer.capacity must be in [1, n_per_rank]", who);
+  if (P.leaves < 1 || P.leaves > GMX_PEER_MAX_LEAVES) return gmx_fail("%s: peer.leaves must be in [1, 8]", who);
+  return 0;
+}
+
+// the statistics block of a launch that has no epilogue put (gmx_tile_stats, an interpreted site program): thread b
+// puts tile b's row to every other rank
+__global__ void __launch_bounds__(GMX_BLOCK)
+k_peer_put_stats(const uint8_t* __restrict__ own, int tiles, int tiles_pad, uint64_t* const* __restrict__ land,
+                 const uint32_t* __restrict__ tag_base, int step, int rank, int world) {
+  const int b = (int)(blockIdx.x * GMX_BLOCK + threadIdx.x);
+  if (b >= tiles) return;
+  const uint32_t tag = *tag_base + (uint32_t)step;
+  const uint64_t a = reinterpret_cast<const uint64_t*>(own)[b];
+  const float m = reinterpret_cast<const float*>(own + (size_t)tiles_pad * 8)[b];
+  for (int d = 0; d < world; ++d)
+    if (d != rank) gmx_peer_put_tile(land[d], tag, world, tiles, rank, b, a, m);
+}
+extern "C" int gmx_peer_put_stats(const void* stats_own_d, gmx_peer P, int64_t n_per_rank, gmx_stream stream) {
+  if (!stats_own_d) return gmx_fail("gmx_peer_put_stats: null argument%s");
+  if (peer_check("gmx_peer_put_stats", P, n_per_rank)) return 1;
+  if (P.world == 1) return 0;
+  const int tiles = P.tiles, tiles_pad = tiles + (tiles & 1);
+  hipLaunchKernelGGL(k_peer_put_stats, dim3((unsigned)((tiles + GMX_BLOCK - 1) / GMX_BLOCK)), dim3(GMX_BLOCK), 0,
+                     (hipStream_t)stream, (const uint8_t*)stats_own_d, tiles, tiles_pad, (uint64_t* const*)P.land_d,
+                     P.tag_base_d, P.step, P.rank, P.world);
+  GMX_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int gmx_shard_step_peer(int kind, const uint32_t key[2], const void* stats_own_d, gmx_peer Pe, int64_t* plan_d,
+                                   uint64_t* total_out_d, const float* lw_d, float* max_out_d, int shift,
+                                   int64_t n_per_rank, const void* const* state_rows_h, void* const* tail_rows_h,
+                                   int32_t* next_idx_d, gmx_stream stream) {
+  if (shard_check("gmx_shard_step_peer", kind, key, Pe.rank, Pe.world, n_per_rank)) return 1;
+  if (peer_check("gmx_shard_step_peer", Pe, n_per_rank)) return 1;
+  if (!stats_own_d || !plan_d || !lw_d || !max_out_d || !state_rows_h || !tail_rows_h || !next_idx_d)
+    return gmx_fail("gmx_shard_step_peer: null argument%s");
+  if (n_per_rank + (int64_t)Pe.world * Pe.capacity > 0x7fffffffLL)
+    return gmx_fail("gmx_shard_step_peer: extended state index exceeds int32%s");
+  if (shift < 1 || shift > 62) return gmx_fail("gmx_shard_step_peer: shift out of range%s");
+  if (((uintptr_t)lw_d & 15) || ((uintptr_t)stats_own_d & 7))
+    return gmx_fail("gmx_shard_step_peer: lw_d must be 16-byte and stats_own_d 8-byte aligned%s");
+  shard_peer P;
+  memset(&P, 0, sizeof(P));
+  P.land = (uint64_t* const*)Pe.land_d;
+  P.tag_base = Pe.tag_base_d; P.status = Pe.status_d; P.step = Pe.step; P.leaves = Pe.leaves;
+  for (int l = 0; l < Pe.leaves; ++l) {
+    if (!state_rows_h[l] || !tail_rows_h[l]) return gmx_fail("gmx_shard_step_peer: a leaf pointer is null%s");
+    P.state[l] = (const uint32_t*)state_rows_h[l];
+    P.tail[l] = (uint32_t*)tail_rows_h[l];
+  }
+  const int64_t tiles = Pe.tiles;
+  const float scale = gmx_pow2i(shift);
+  uint32_t b0, b1;
+  gmx_threefry2x32(key[0], key[1], 0u, 0u, &b0, &b1);           // bits32(key, 0) on the host
+  const uint32_t u0 = (b0 ^ b1) >> 9;
+  const bool small = Pe.world <= 8 && (int64_t)Pe.world * tiles <= 4 * GMX_BLOCK;
+#define GMX_LAUNCH_SP2(KIND, SM)                                                                                      \
+  hipLaunchKernelGGL((k_shard_step_fill<KIND, SM, true>), dim3((unsigned)tiles), dim3(GMX_BLOCK), 0, (hipStream_t)stream, key[0],  \
+                     key[1], u0, lw_d, (const uint8_t*)stats_own_d, (size_t)0, (int)tiles, scale, Pe.rank, Pe.world,  \
+                     (int32_t)n_per_rank, (int32_t)Pe.capacity, plan_d, total_out_d, max_out_d, (const uint32_t*)nullptr, \
+                     (uint32_t*)nullptr, next_idx_d, P)
+#define GMX_LAUNCH_SP(KIND) do { if (small) GMX_LAUNCH_SP2(KIND, true); else GMX_LAUNCH_SP2(KIND, false); } while (0)
+  if (kind == GMX_RESAMPLE_SYSTEMATIC) GMX_LAUNCH_SP(GMX_RESAMPLE_SYSTEMATIC); else GMX_LAUNCH_SP(GMX_RESAMPLE_STRATIFIED);
+#undef GMX_LAUNCH_SP
+#undef GMX_LAUNCH_SP2
+  GMX_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
 // peer-mapped exchange (include/genmi.h "Peer-mapped exchange"): one launch, one rendezvous per collective
 // ---------------------------------------------------------------------------
 #define GMX_P2P_SPIN_LIMIT (1u << 22)
 #define GMX_P2P_CHUNK (16u * 1024u)         /* bytes one workgroup moves: a block of `bytes` is split over up to 64 of them */
-__device__ __forceinline__ void p2p_copy(uint8_t* t, const uint8_t* s, size_t lo, size_t hi) {
-  if ((((uintptr_t)s | (uintptr_t)t | lo | hi) & 15) == 0) {
-    const uint4* s4 = reinterpret_cast<const uint4*>(s);
-    uint4* t4 = reinterpret_cast<uint4*>(t);
-    for (size_t i = lo / 16 + threadIdx.x; i < hi / 16; i += GMX_BLOCK) t4[i] = s4[i];
+// No fences: a system-scope release / acquire on gfx950 is a write-back / invalidate of the XCD's whole L2 (measured: the
+// exchange took the sharded step to 65 us beside the noise programs).  Instead every word that crosses is stored
+// WRITE-THROUGH (a system-scope relaxed atomic store: `global_store ... sc0 sc1`, nothing left dirty in L2), each storing
+// wave drains its stores (`s_waitcnt vmcnt(0)`: the write-through stores have been acknowledged), the workgroup's
+// barrier collects its waves, one lane takes a ticket, and the LAST ticket holder's flag store (relaxed, system scope)
+// therefore follows every store of the block.  The reader polls the flag with system-scope loads and then reads the
+// landing data with system-scope loads (past the caches): nothing to invalidate.
+__device__ __forceinline__ void p2p_put(uint8_t* t, const uint8_t* s, size_t lo, size_t hi) {
+  if ((((uintptr_t)s | (uintptr_t)t | lo | hi) & 7) == 0) {
+    const uint64_t* s8 = reinterpret_cast<const uint64_t*>(s);
+    uint64_t* t8 = reinterpret_cast<uint64_t*>(t);
+    for (size_t i = lo / 8 + threadIdx.x; i < hi / 8; i += GMX_BLOCK)
+      __hip_atomic_store(t8 + i, s8[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   } else {
-    for (size_t i = lo + threadIdx.x; i < hi; i += GMX_BLOCK) t[i] = s[i];
+    for (size_t i = lo + threadIdx.x; i < hi; i += GMX_BLOCK)
+      __hip_atomic_store(t + i, s[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+__device__ __forceinline__ void p2p_take(uint8_t* t, const uint8_t* s, size_t lo, size_t hi) {
+  if ((((uintptr_t)s | (uintptr_t)t | lo | hi) & 7) == 0) {
+    const uint64_t* s8 = reinterpret_cast<const uint64_t*>(s);
+    uint64_t* t8 = reinterpret_cast<uint64_t*>(t);
+    for (size_t i = lo / 8 + threadIdx.x; i < hi / 8; i += GMX_BLOCK)
+      t8[i] = __hip_atomic_load(s8 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  } else {
+    for (size_t i = lo + threadIdx.x; i < hi; i += GMX_BLOCK)
+      t[i] = __hip_atomic_load(s + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 __global__ void __launch_bounds__(GMX_BLOCK)
@@ -3384,17 +3588,17 @@ k_p2p_exchange(const uint8_t* __restrict__ src, size_t src_stride, void* const* 
   uint32_t* put_ticket = reinterpret_cast<uint32_t*>(state + 3 + d);
   const uint64_t epoch = __hip_atomic_load(state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ull;
   const size_t half = (size_t)(epoch & 1ull) * (size_t)world * bytes;      // landing buffers alternate by epoch parity
-  // ---- put: my block for peer d -> peer d's landing buffer, slot `rank` ----
-  p2p_copy((uint8_t*)land_peers[d] + half + (size_t)rank * bytes, src + (size_t)d * src_stride, lo, hi);
-  __syncthreads();                                      // the workgroup's stores happen before thread 0's release
+  // ---- put: my block for peer d -> peer d's landing buffer, slot `rank` (write-through, drained) ----
+  p2p_put((uint8_t*)land_peers[d] + half + (size_t)rank * bytes, src + (size_t)d * src_stride, lo, hi);
+  __syncthreads();                                      // every wave of the workgroup has drained its stores
   if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");       // system scope: visible to the peer before the flag is
-    // the LAST of the nblk workgroups serving peer d announces the whole block
-    if (__hip_atomic_fetch_add(put_ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == nblk - 1u) {
+    // the LAST of the nblk workgroups serving peer d announces the whole block: its ticket follows every other
+    // workgroup's (their stores were acknowledged before they took theirs)
+    if (__hip_atomic_fetch_add(put_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nblk - 1u) {
       __hip_atomic_store(put_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(flag_peers[d] + rank, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(flag_peers[d] + rank, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    // ---- wait: peer d's block for me (relaxed polls that bypass the caches; ONE acquire once it is there) ----
+    // ---- wait: peer d's block for me (relaxed system-scope polls: past the caches) ----
     uint32_t spins = 0, ok = 1u;
     while (__hip_atomic_load(flags_local + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
       __builtin_amdgcn_s_sleep(4);
@@ -3404,12 +3608,11 @@ k_p2p_exchange(const uint8_t* __restrict__ src, size_t src_stride, void* const* 
         break;
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
     s_ok = ok;
   }
   __syncthreads();
-  // ---- copy out: slot d of my landing buffer (fine-grained memory) -> the caller's destination (ordinary memory) ----
-  if (s_ok) p2p_copy(out + (size_t)d * bytes, land_local + half + (size_t)d * bytes, lo, hi);
+  // ---- copy out: slot d of my landing buffer (fine-grained memory, system-scope loads) -> the caller's destination ----
+  if (s_ok) p2p_take(out + (size_t)d * bytes, land_local + half + (size_t)d * bytes, lo, hi);
   __syncthreads();
   if (threadIdx.x == 0) {
     // the last workgroup of the launch advances the epoch for the next one
@@ -3425,8 +3628,9 @@ extern "C" int gmx_p2p_alloc(size_t bytes, void** ptr_out, void* handle_out) {
   static_assert(sizeof(hipIpcMemHandle_t) <= GMX_P2P_HANDLE_BYTES, "IPC handle size");
   void* p = nullptr;
   // fine-grained: stores from a peer over xGMI must be seen by this GPU's kernels without a cache flush
+  // (no fallback to ordinary memory: a peer's stores would then not be visible to a running kernel — fail loudly)
   hipError_t e = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained);
-  if (e != hipSuccess) { (void)hipGetLastError(); GMX_HIP(hipMalloc(&p, bytes)); }
+  if (e != hipSuccess) { (void)hipGetLastError(); return gmx_fail("gmx_p2p_alloc: fine-grained device memory is unavailable (%s)", hipGetErrorString(e)); }
   GMX_HIP(hipMemset(p, 0, bytes));
   hipIpcMemHandle_t h;
   memset(handle_out, 0, GMX_P2P_HANDLE_BYTES);
@@ -3456,6 +3660,9 @@ extern "C" int gmx_p2p_exchange(const void* src_d, size_t src_stride, void* cons
   // state_d: [0] epoch, [1] error, [2] end ticket, [3 + d] the put ticket of peer d (low words)
   unsigned nblk = (unsigned)((bytes + GMX_P2P_CHUNK - 1) / GMX_P2P_CHUNK);
   nblk = nblk < 1u ? 1u : (nblk > 64u ? 64u : nblk);
+  // every workgroup waits on a peer that in turn waits for ALL of this launch's puts: the whole grid must be resident
+  // (256 CUs x 8 workgroups); keep it to at most 1024 workgroups
+  while (nblk > 1u && (unsigned)world * nblk > 1024u) nblk >>= 1;
   hipLaunchKernelGGL(k_p2p_exchange, dim3((unsigned)world, nblk), dim3(GMX_BLOCK), 0, (hipStream_t)stream,
                      (const uint8_t*)src_d, src_stride, land_peers_d, (const uint8_t*)land_local_d, (uint8_t*)out_d,
                      flag_peers_d, flags_local_d, state_d, rank, world, bytes);

@@ -799,9 +799,9 @@ class Compiled:
         return bool(self._be.c.gmx_program_writes_tile_stats(self.handle))
 
     def run(self, leaves, batch: tuple, key: Key | None, red_out=None, index_offset=0, out_buffers=None,
-            tile_stats=None):
+            tile_stats=None, peer=None):
         """Bind and launch.  Returns the list of output tensors (shape batch+event)."""
-        bound = self.bind(leaves, batch, key, red_out, index_offset, out_buffers, tile_stats)
+        bound = self.bind(leaves, batch, key, red_out, index_offset, out_buffers, tile_stats, peer)
         self.launch(bound)
         return bound[3]
 
@@ -820,11 +820,13 @@ class Compiled:
         be.check(be.c.gmx_program_run(self.handle, bound[0], bound[1], be.stream()), "gmx_program_run")
 
     def bind(self, leaves, batch: tuple, key: Key | None, red_out=None, index_offset=0, out_buffers=None,
-             tile_stats=None):
+             tile_stats=None, peer=None):
         """Fill a gmx_run_args for these leaves: (n, args, keep-alive list, outputs).  Sweeps whose
         buffers are persistent bind every step once and re-launch the bindings.
         tile_stats = (int64 tensor [grid], shift): the launch also writes the per-workgroup fixed-point weight sums
-        gmx_resample_tiles consumes (only if `writes_tile_stats()`)."""
+        gmx_resample_tiles consumes (only if `writes_tile_stats()`).
+        peer = a _lib.Peer (with tile_stats): the launch also puts its tile statistics into the other ranks' landing
+        tables (include/genmi.h "Fused peer exchange")."""
         be = self._be
         n = int(np.prod(batch, dtype=np.int64))
         self._work = getattr(self, "_work", 0) + n
@@ -973,6 +975,8 @@ class Compiled:
             agg, shift = tile_stats[0], tile_stats[1]
             A.tile_agg_d, A.tile_shift = agg.data_ptr(), int(shift)
             keep.append(agg)
+            if peer is not None:
+                A.peer = peer
         return n, A, keep, outs
 
 

@@ -164,6 +164,29 @@ class P2PComm:
         self._allocs, self._landing = [], {}
 
 
+class PeerComm(P2PComm):
+    """GENMI_COMM=peer — the FUSED peer exchange (include/genmi.h "Fused peer exchange"): a sharded SMC
+    step has no collective launch at all.  The site program's epilogue puts its tile statistics into the other ranks'
+    landing tables, gmx_shard_step_peer reads them as they arrive, puts offspring states into the owners' landing
+    blocks and waits for the few values its own slots need — 8-byte tagged granules, no flags, no fences.  This class
+    only owns the landing blocks (fine-grained, IPC-mapped), the tag word and the status word; one-off collectives
+    (config 4's global resample, the overflow flag) go through the peer-mapped exchange it inherits."""
+
+    name = "peer (fused puts: no collective launch per step)"
+    fused = True
+
+    def landing(self, n_per_rank: int, capacity: int, leaves: int):
+        """(device table [world] of every rank's landing block as mapped here, bytes); COLLECTIVE"""
+        nbytes = int(self.be.c.gmx_peer_landing_bytes(self.world, int(n_per_rank), int(capacity), int(leaves)))
+        _own, table = self._shared((nbytes,), torch.uint8)
+        return table, nbytes
+
+    def step_words(self):
+        """(tag base, status): two local device words of one sweep — tags start at 1 (zeroed granules never match)"""
+        return (torch.ones((1,), dtype=torch.int32, device=self.device),
+                torch.zeros((1,), dtype=torch.int64, device=self.device))
+
+
 class _UniqueId(Structure):
     _fields_ = [("internal", c_char * 128)]
 
@@ -285,9 +308,13 @@ def make_comm(dist, device: torch.device):
     Bootstrap and self-test run under a deadline (GENMI_COMM_TIMEOUT seconds, default 120; see _Deadline)."""
     want = os.environ.get("GENMI_COMM", "rccl" if device.type == "cuda" else "torch")
     timeout = float(os.environ.get("GENMI_COMM_TIMEOUT", "120"))
-    if want == "p2p":
+    if want in ("p2p", "peer"):
         with _Deadline(timeout, "the peer-mapped communicator bootstrap"):
-            return P2PComm(dist, device)
+            comm = (PeerComm if want == "peer" else P2PComm)(dist, device)
+            _selftest(comm, device)
+            if comm.failed():
+                raise RuntimeError("the peer-mapped communicator's self-test timed out")
+        return comm
     if want != "rccl" or device.type != "cuda":
         comm = TorchComm(dist)
         with _Deadline(timeout, "the torch.distributed communicator self-test"):

@@ -173,6 +173,10 @@ class ShardedBootstrapSweep(_NoiseAhead):
             self.cx = make_comm(self.dist, dev)
         self.totals_all = self.cx.alloc((W,), torch.int64) if self.cx is not None else \
             torch.zeros((W,), dtype=torch.int64, device=dev)
+        # the fused peer exchange (comm.PeerComm): no collective launch per step — tile-statistics form only
+        from .smc import FUSED_RESAMPLE_MAX as _FRM
+        self.peer_mode = bool(getattr(self.cx, "fused", False) and self.comm and self.kind in (SYSTEMATIC, STRATIFIED)
+                              and n <= _FRM and W <= 64 and not self.cdf_form)
         obs0 = ChoiceMap.empty().set(self.obs_addr, self.ys[0])
         self.p_init = MinimalGenerate(self.init, (), obs0, (n,))
         # the state is the model's return value: a float scalar, or ONE vector of D floats per particle kept
@@ -211,7 +215,7 @@ class ShardedBootstrapSweep(_NoiseAhead):
         # two collectives per step instead of three: the ranks all-gather their CDF TILE STATISTICS (12 bytes per
         # 1024 particles; written by the site program itself when it can, else by gmx_tile_stats), from which
         # every rank derives the global max and all the totals — no max all-reduce, no local CDF array
-        from .smc import FUSED_RESAMPLE_MAX, STRATIFIED
+        from .smc import FUSED_RESAMPLE_MAX
         self.tiles_mode = (self.kind in (SYSTEMATIC, STRATIFIED) and n <= FUSED_RESAMPLE_MAX and W <= 64
                            and not self.cdf_form)
         if self.tiles_mode:
@@ -231,9 +235,18 @@ class ShardedBootstrapSweep(_NoiseAhead):
 
     def _alloc_exchange(self):
         dev, n, W, C = _lib.get().device, self.n, self.world, self.capacity
+        if getattr(self, "peer_mode", False):
+            # what crosses ranks lands in the communicator's fine-grained landing block; the extended states (and their
+            # tails, filled by this rank's own routing launch) are ordinary memory
+            self.peer_leaves = self.D * (2 if self.rejuvenate is not None else 1)
+            if self.peer_leaves > 8:
+                raise NotImplementedError("ShardedBootstrapSweep over the fused peer exchange: at most 8 routed leaves")
+            self.peer_land, _ = self.cx.landing(n, C, self.peer_leaves)              # COLLECTIVE
+            if not hasattr(self, "peer_tag"):
+                self.peer_tag, self.peer_status = self.cx.step_words()
         # extended state, double-buffered: [ n local | W*C received ]; ancestors index into it
         # destinations of collectives come from the communicator (peer-mapped memory under GENMI_COMM=p2p)
-        mk = (lambda shape, dt=torch.float32: self.cx.alloc(shape, dt)) if self.cx is not None else \
+        mk = (lambda shape, dt=torch.float32: self.cx.alloc(shape, dt)) if (self.cx is not None and not getattr(self, "peer_mode", False)) else \
             (lambda shape, dt=torch.float32: torch.zeros(shape, dtype=dt, device=dev))
         self.xrows = [mk((self.D, n + W * C)) for _ in range(2)]
         self.xext = [r[0] for r in self.xrows]                    # component 0 (THE state when it is a scalar)
@@ -295,9 +308,16 @@ class ShardedBootstrapSweep(_NoiseAhead):
         bufs[prog.wo[1]] = self.lw.reshape(1, n)
         # keys of the GLOBAL particle index: split(k_prop, N)[g*n + i]
         writes_stats = self.tiles_mode and prog.comp.writes_tile_stats()
+        peer = None
+        if self.peer_mode:
+            peer = _lib.Peer()
+            peer.land_d, peer.tag_base_d, peer.status_d = self.peer_land.data_ptr(), self.peer_tag.data_ptr(), self.peer_status.data_ptr()
+            peer.rank, peer.world, peer.step, peer.tiles = g, W, t, (n + CDF_TILE - 1) // CDF_TILE
+            peer.capacity = C
+            peer.leaves = self.D * (2 if (self.rejuvenate is not None and t >= 1) else 1)
         if writes_stats:        # the workgroup maxima land in the statistics block (red_out plane 0), the sums beside them
             vm = prog.comp.bind(leaves, (n,), lazy_split(k_prop, self.N), red_out=self.tile_max, out_buffers=bufs,
-                                index_offset=g * n, tile_stats=(self.tile_agg, self.shift))
+                                index_offset=g * n, tile_stats=(self.tile_agg, self.shift), peer=peer)
         else:
             vm = prog.comp.bind(leaves, (n,), lazy_split(k_prop, self.N), red_out=self.partials, out_buffers=bufs,
                                 index_offset=g * n)
@@ -321,7 +341,20 @@ class ShardedBootstrapSweep(_NoiseAhead):
             mkf = lambda row, snd: (self.kind, kk, P(self.stats_all), P(self.plan), P(tot), P(self.lw), P(m), self.shift,
                                     g, W, n, C, P(row), P(snd), P(self.idx))
             fused_ok = W <= 64 and self.fused_req
-            tiles = {"stats": None if writes_stats else (P(self.lw), n, self.shift, P(self.tile_max), P(self.tile_agg)),
+            pk = None
+            if peer is not None:
+                from ctypes import c_void_p as _vp
+                rows_l = [rows_t[d] for d in range(self.D)]
+                if self.rejuvenate is not None and t >= 1:
+                    rows_l += [self.arows[t % 2][d] for d in range(self.D)]
+                L = len(rows_l)
+                st_arr = (_vp * L)(*[r.data_ptr() for r in rows_l])
+                tl_arr = (_vp * L)(*[r[n:].data_ptr() for r in rows_l])
+                pk = {"peer": peer, "put_stats": None if writes_stats else (P(self.stats_own), peer, n),
+                      "step": (self.kind, kk, P(self.stats_own), peer, P(self.plan), P(tot), P(self.lw), P(m), self.shift, n,
+                               st_arr, tl_arr, P(self.idx)), "keep": (rows_l, st_arr, tl_arr)}
+            tiles = {"peer": pk,
+                     "stats": None if writes_stats else (P(self.lw), n, self.shift, P(self.tile_max), P(self.tile_agg)),
                      "totals": (P(self.stats_all), W, n, P(self.totals_all), P(m)),
                      # the first routed leaf derives the totals / global max itself (one launch less in the chain);
                      # further leaves of the same step reuse them
@@ -354,6 +387,12 @@ class ShardedBootstrapSweep(_NoiseAhead):
             tl = b["tiles"]
             if tl["stats"] is not None:
                 be.check(c.gmx_tile_stats(*tl["stats"], st), "gmx_tile_stats")
+            if tl["peer"] is not None:          # no collective launch: puts + granule waits inside the two kernels
+                pk = tl["peer"]
+                if pk["put_stats"] is not None:
+                    be.check(c.gmx_peer_put_stats(*pk["put_stats"], st), "gmx_peer_put_stats")
+                be.check(c.gmx_shard_step_peer(*pk["step"], st), "gmx_shard_step_peer")
+                return
             if self.comm:
                 self.cx.all_gather(self.stats_all, self.stats_own)          # 12 bytes per 1024 particles per rank
             else:
@@ -411,6 +450,9 @@ class ShardedBootstrapSweep(_NoiseAhead):
     def enqueue(self):
         self._finished = False
         self.plan.zero_()
+        if self.peer_mode:       # this sweep's tags: T more than the last one's (inside a captured graph too)
+            be = _lib.get()
+            be.check(be.c.gmx_peer_bump(be.ptr(self.peer_tag), self.T, be.stream()), "gmx_peer_bump")
         if self.noise_ahead:
             self._enqueue_noise_ahead()
             return
@@ -458,7 +500,15 @@ class ShardedBootstrapSweep(_NoiseAhead):
             return self
         flag = self.plan[2:3].clone()
         if self.comm:
+            # a wait that timed out (a peer that never arrived) fails the sweep on EVERY rank instead of handing back
+            # stale particles: the communicator's error word travels with the overflow flag
+            if hasattr(self.cx, "failed"):
+                bad = bool(self.cx.failed()) or (self.peer_mode and int(self.peer_status[0].item()) != 0)
+                flag = torch.where(torch.tensor(bad, device=flag.device), torch.full_like(flag, 2), flag)
             self.cx.all_reduce_max(flag)
+        if int(flag.item()) >= 2:
+            raise RuntimeError("ShardedBootstrapSweep: a peer's data did not arrive in time on some rank (the "
+                               "peer-mapped exchange gave up waiting): the sweep's results are not valid")
         if int(flag.item()) != 0:
             self.reruns += 1
             self.capacity = self.n

@@ -107,6 +107,21 @@ enum {
   GMX_KEY_BCAST = 4     /* (key0,key1) for every particle                      */
 };
 
+/* The peers of a sharded SMC step ("Fused peer exchange", below): passed by value to the site program
+ * (gmx_run_args.peer) and to gmx_shard_step_peer. */
+typedef struct gmx_peer {
+  void* const* land_d;            /* device array [world]: every rank's LANDING block as mapped into this process
+                                     (gmx_p2p_alloc / gmx_p2p_open; land_d[rank] = this rank's own); NULL = no peers    */
+  const uint32_t* tag_base_d;     /* device word: the tag of step 0 of the running sweep (gmx_peer_bump)               */
+  uint64_t* status_d;             /* local device words: [0] sticky timeout flag (a peer's data never arrived)          */
+  int32_t rank, world;
+  int32_t step;                   /* t: everything this step puts carries tag = *tag_base_d + t; parity = tag & 1      */
+  int32_t tiles;                  /* CDF tiles per rank = ceil(n_per_rank / 1024)                                     */
+  int64_t capacity;               /* states one rank may ship to ONE peer per step                                     */
+  int32_t leaves;                 /* routed 4-byte leaves per particle (1: a scalar state; D; 2 D with an MH move)      */
+  int32_t reserved_;
+} gmx_peer;
+
 typedef struct gmx_run_args {
   const void* in_d[GMX_MAX_IN];   /* per-particle inputs (4-byte or 1-byte elems) */
   void* out_d[GMX_MAX_OUT];       /* per-particle outputs                        */
@@ -130,6 +145,9 @@ typedef struct gmx_run_args {
   int32_t reserved_;
   int64_t step_stride;            /* elements between consecutive steps of a [T, n] leaf addressed with GMX_F_STEP inside
                                      an OP_LOOP (programs with a counted loop: the Scan combinator); normally n         */
+  gmx_peer peer;                  /* optional (peer.land_d != NULL), with tile_agg_d: the workgroup ALSO puts its tile's
+                                     statistics straight into every other rank's landing table ("Fused peer exchange"
+                                     below) — the all-gather of a sharded SMC step without a collective launch        */
 } gmx_run_args;
 
 int gmx_program_create(const uint32_t* blob_h, size_t n_words, gmx_program** out);
@@ -376,6 +394,39 @@ int gmx_shard_step_fused(int kind, const uint32_t key[2], const void* stats_all_
                          uint64_t* total_out_d /* [1] or NULL */, const float* lw_d, float* max_out_d, int shift,
                          int rank, int world, int64_t n_per_rank, int64_t capacity, const void* state_d,
                          void* send_d, int32_t* next_idx_d, gmx_stream stream);
+
+/* ------------------------------------------------------------------------
+ * Fused peer exchange (GENMI_COMM=peer): a sharded SMC step with NO collective launch.  No reference counterpart (the
+ * reference is single-device; SURVEY.md 8e asks for "direct P2P ..., not ring").  Two launches per step:
+ *   site program      its epilogue writes the tile's (m_b, A_b) to the local table as always AND puts them into the
+ *                     landing table of every OTHER rank (gmx_run_args.peer);
+ *   gmx_shard_step_peer  gmx_shard_step_fused reading the other ranks' statistics from its own landing table as they
+ *                     arrive; a slot another rank owns gets the ancestor's state put straight into THAT rank's landing
+ *                     block; at its end, each of this rank's slots whose ancestor is remote waits for that one value
+ *                     and stores it in the local extended state (ordinary memory: the next site program is unchanged).
+ * Everything that crosses ranks is an 8-byte GRANULE {32 bits of data, 32-bit tag} written by one write-through store
+ * and read by polling with system-scope loads until the tag is the step's: naturally aligned 8-byte accesses are
+ * single-copy atomic, so there is no flag, no counter, no fence (no L2 write-back / invalidate) and no ordering
+ * requirement between granules.  Tags are *tag_base_d + t: they grow by one per step ACROSS sweeps (gmx_peer_bump adds
+ * T at the head of every sweep, inside the captured graph), parity = tag & 1 selects one of two landing halves, and a
+ * rank can only overwrite a half two steps later — by when every reader of it has finished (its own next launch needs
+ * every peer's next statistics).  A poll gives up after a bounded number of spins and sets status_d[0]; the caller
+ * reads it once per sweep.  Landing block of a rank (bytes; the same layout on every rank, fine-grained memory from
+ * gmx_p2p_alloc, zeroed):
+ *   statistics  [2 halves][world][tiles][3] u64: {A_b low | tag}, {A_b high | tag}, {m_b bits | tag}
+ *   states      [2 halves][leaves][world][capacity] u64: {state bits | tag}   (block s: what rank s ships here)
+ * ---------------------------------------------------------------------- */
+size_t gmx_peer_landing_bytes(int world, int64_t n_per_rank, int64_t capacity, int leaves);
+/* *tag_base_d += T (one thread): at the head of every sweep, before its first site program */
+int gmx_peer_bump(uint32_t* tag_base_d, int32_t T, gmx_stream stream);
+/* Put a statistics block that a launch without the epilogue wrote (gmx_tile_stats; an interpreted site program) */
+int gmx_peer_put_stats(const void* stats_own_d, gmx_peer peer, int64_t n_per_rank, gmx_stream stream);
+/* state_rows_h / tail_rows_h: HOST arrays [peer.leaves] of device pointers — leaf l's local states [n_per_rank] and the
+ * tail [world * capacity] of its extended state that receives what the other ranks ship. */
+int gmx_shard_step_peer(int kind, const uint32_t key[2], const void* stats_own_d, gmx_peer peer, int64_t* plan_d,
+                        uint64_t* total_out_d /* [1] or NULL */, const float* lw_d, float* max_out_d, int shift,
+                        int64_t n_per_rank, const void* const* state_rows_h, void* const* tail_rows_h,
+                        int32_t* next_idx_d, gmx_stream stream);
 
 /* ------------------------------------------------------------------------
  * MH accept + select.  Replaces the user idiom

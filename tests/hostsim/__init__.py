@@ -11,8 +11,9 @@ _SO = os.path.join(_HERE, "_build", "libgmx_hostsim.so")
 
 def build():
     src = os.path.join(_HERE, "hostsim.cpp")
-    deps = [src] + [os.path.join(_HERE, "..", "..", "genjax_amd", "csrc", f)
-                    for f in ("gmx_vm.h", "gmx_dist.h", "gmx_rng.h", "gmx_math.h", "gmx_program.h", "gmx_sorted.h")]
+    deps = [src, os.path.join(_HERE, "..", "..", "include", "genmi.h")] + [
+        os.path.join(_HERE, "..", "..", "genjax_amd", "csrc", f)
+        for f in ("gmx_vm.h", "gmx_dist.h", "gmx_rng.h", "gmx_math.h", "gmx_program.h", "gmx_sorted.h", "gmx_peer.h")]
     if not os.path.exists(_SO) or any(os.path.getmtime(d) > os.path.getmtime(_SO) for d in deps):
         os.makedirs(os.path.dirname(_SO), exist_ok=True)
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
@@ -28,8 +29,9 @@ def build_sanitized():
     loads it in a child process started with the ASan runtime preloaded)."""
     so = os.path.join(_HERE, "_build", "libgmx_hostsim_san.so")
     src = os.path.join(_HERE, "hostsim.cpp")
-    deps = [src] + [os.path.join(_HERE, "..", "..", "genjax_amd", "csrc", f)
-                    for f in ("gmx_vm.h", "gmx_dist.h", "gmx_rng.h", "gmx_math.h", "gmx_program.h", "gmx_sorted.h")]
+    deps = [src, os.path.join(_HERE, "..", "..", "include", "genmi.h")] + [
+        os.path.join(_HERE, "..", "..", "genjax_amd", "csrc", f)
+        for f in ("gmx_vm.h", "gmx_dist.h", "gmx_rng.h", "gmx_math.h", "gmx_program.h", "gmx_sorted.h", "gmx_peer.h")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
         os.makedirs(os.path.dirname(so), exist_ok=True)
         subprocess.check_call(["g++", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math"] + SAN_FLAGS +

@@ -117,6 +117,13 @@ static float butterfly_sum64(const float* v) {
   return t[0];
 }
 
+#include "../../genjax_amd/csrc/gmx_peer.h"
+static void hs_peer_put_tile(uint64_t* land, uint32_t tag, int world, int tiles, int src, int tile, uint64_t agg, float tmax) {
+  uint64_t* row = land + gmx_peer_stats_at(tag, world, tiles, src, tile);
+  __atomic_store_n(row + 0, gmx_granule((uint32_t)agg, tag), __ATOMIC_RELAXED);
+  __atomic_store_n(row + 1, gmx_granule((uint32_t)(agg >> 32), tag), __ATOMIC_RELAXED);
+  __atomic_store_n(row + 2, gmx_granule(gmx_f2u(tmax), tag), __ATOMIC_RELAXED);
+}
 extern "C" int gmx_program_run(const gmx_program* p, int64_t n, const gmx_run_args* A_in, gmx_stream) {
   if (!p || !A_in) return fail("program_run: null");
   gmx_run_args patched = *A_in;
@@ -152,6 +159,12 @@ extern "C" int gmx_program_run(const gmx_program* p, int64_t n, const gmx_run_ar
         uint64_t sum = 0;
         for (int t = 0; t < G; ++t) sum += gmx_exp_fixed(red[t] - ref, A->tile_shift);
         A->tile_agg_d[blk] = sum;
+        if (A->peer.land_d) {        // the epilogue's put: this tile's statistics into every other rank's landing table
+          const gmx_peer& P = A->peer;
+          const uint32_t tag = *P.tag_base_d + (uint32_t)P.step;
+          for (int d = 0; d < P.world; ++d)
+            if (d != P.rank) hs_peer_put_tile((uint64_t*)P.land_d[d], tag, P.world, P.tiles, P.rank, (int)blk, sum, m);
+        }
       }
     }
   }
@@ -620,6 +633,115 @@ extern "C" int gmx_shard_step_fused(int kind, const uint32_t key[2], const void*
   const void* own = (const uint8_t*)stats_all + (size_t)rank * gmx_shard_stats_bytes(n);
   return gmx_shard_step_tiles(kind, key, totals.data(), plan, total_out, lw, own, max_out, shift, rank, world, n, cap, state,
                               send, next_idx, st);
+}
+// ---- fused peer exchange (include/genmi.h): granules in process-shared landing blocks; every wait is bounded ----
+#include <sched.h>
+#include <time.h>
+extern "C" size_t gmx_peer_landing_bytes(int world, int64_t n, int64_t cap, int leaves) {
+  if (world < 1 || n < 1 || cap < 1 || leaves < 1) return 0;
+  return (gmx_peer_stats_words(world, (int)((n + HS_TILE - 1) / HS_TILE)) + gmx_peer_state_words(world, cap, leaves)) * 8;
+}
+extern "C" int gmx_peer_bump(uint32_t* tag_base, int32_t T, gmx_stream) {
+  if (!tag_base || T < 1) return fail("peer_bump: bad argument");
+  *tag_base += (uint32_t)T;
+  return 0;
+}
+static int hs_peer_check(const gmx_peer& P, int64_t n) {
+  if (!P.land_d || !P.tag_base_d || !P.status_d) return fail("peer: null pointer");
+  if (P.world < 1 || P.world > 64 || P.rank < 0 || P.rank >= P.world || P.step < 0) return fail("peer: rank / world / step out of range");
+  if (n <= 0 || P.tiles != (int32_t)((n + HS_TILE - 1) / HS_TILE)) return fail("peer: tiles must be ceil(n / 1024)");
+  if (P.capacity < 1 || P.capacity > n || P.leaves < 1 || P.leaves > 8) return fail("peer: capacity / leaves out of range");
+  return 0;
+}
+extern "C" int gmx_peer_put_stats(const void* stats_own, gmx_peer P, int64_t n, gmx_stream) {
+  if (!stats_own) return fail("peer_put_stats: null argument");
+  if (hs_peer_check(P, n)) return 1;
+  const int pad = P.tiles + (P.tiles & 1);
+  const uint64_t* ag = (const uint64_t*)stats_own;
+  const float* tm = (const float*)((const uint8_t*)stats_own + (size_t)pad * 8);
+  const uint32_t tag = *P.tag_base_d + (uint32_t)P.step;
+  for (int d = 0; d < P.world; ++d)
+    if (d != P.rank)
+      for (int b = 0; b < P.tiles; ++b) hs_peer_put_tile((uint64_t*)P.land_d[d], tag, P.world, P.tiles, P.rank, b, ag[b], tm[b]);
+  return 0;
+}
+// wait (bounded) until granule *g carries `tag`; its data
+static bool hs_peer_wait(const uint64_t* g, uint32_t tag, uint32_t* data, const timespec& t0) {
+  for (;;) {
+    const uint64_t v = __atomic_load_n(g, __ATOMIC_RELAXED);
+    if ((uint32_t)(v >> 32) == tag) { *data = (uint32_t)v; return true; }
+    sched_yield();
+    timespec t1; clock_gettime(CLOCK_MONOTONIC, &t1);
+    if (t1.tv_sec - t0.tv_sec > 60) return false;
+  }
+}
+extern "C" int gmx_shard_step_peer(int kind, const uint32_t key[2], const void* stats_own, gmx_peer P, int64_t* plan,
+                                   uint64_t* total_out, const float* lw, float* max_out, int shift, int64_t n,
+                                   const void* const* state_rows, void* const* tail_rows, int32_t* next_idx, gmx_stream st) {
+  if (!stats_own || !plan || !lw || !max_out || !state_rows || !tail_rows || !next_idx) return fail("shard_step_peer: null argument");
+  if (hs_peer_check(P, n)) return 1;
+  const int W = P.world, me = P.rank, tiles = P.tiles, pad = tiles + (tiles & 1);
+  const int64_t cap = P.capacity;
+  const uint32_t tag = *P.tag_base_d + (uint32_t)P.step;
+  const size_t stride = gmx_shard_stats_bytes(n);
+  timespec t0; clock_gettime(CLOCK_MONOTONIC, &t0);
+  // the gathered table: own block from the local table, the others' rows from the landing block as they arrive
+  std::vector<uint8_t> all((size_t)W * stride, 0);
+  memcpy(all.data() + (size_t)me * stride, stats_own, stride);
+  const uint64_t* land_own = (const uint64_t*)P.land_d[me];
+  for (int r = 0; r < W; ++r) {
+    if (r == me) continue;
+    uint64_t* ag = (uint64_t*)(all.data() + (size_t)r * stride);
+    float* tm = (float*)(all.data() + (size_t)r * stride + (size_t)pad * 8);
+    for (int b = 0; b < tiles; ++b) {
+      const uint64_t* row = land_own + gmx_peer_stats_at(tag, W, tiles, r, b);
+      uint32_t lo, hi, mb;
+      if (!hs_peer_wait(row, tag, &lo, t0) || !hs_peer_wait(row + 1, tag, &hi, t0) || !hs_peer_wait(row + 2, tag, &mb, t0)) {
+        P.status_d[0] = 1; plan[GMX_PLAN_OVERFLOW] = 1;
+        return fail("shard_step_peer: a peer's statistics did not arrive within 60 s");
+      }
+      ag[b] = (uint64_t)lo | ((uint64_t)hi << 32);
+      tm[b] = gmx_u2f(mb);
+    }
+  }
+  std::vector<uint64_t> totals((size_t)W);
+  if (gmx_shard_totals(all.data(), W, n, totals.data(), max_out, st)) return 1;
+  std::vector<uint32_t> send((size_t)W * (size_t)cap);
+  for (int l = 0; l < P.leaves; ++l) {
+    if (!state_rows[l] || !tail_rows[l]) return fail("shard_step_peer: a leaf pointer is null");
+    if (gmx_shard_step_tiles(kind, key, totals.data(), plan, total_out, lw, stats_own, max_out, shift, me, W, n, cap,
+                             state_rows[l], send.data(), next_idx, st)) return 1;
+    // what this rank ships to d: the slots of d's shard whose ancestor lives here, [max(bounds[me], d n), min(bounds[me+1], (d+1) n))
+    const int64_t lo_me = plan[GMX_PLAN_BOUNDS + me], hi_me = plan[GMX_PLAN_BOUNDS + me + 1];
+    for (int d = 0; d < W; ++d) {
+      if (d == me) continue;
+      const int64_t a = lo_me > d * n ? lo_me : d * n, b = hi_me < (d + 1) * n ? hi_me : (d + 1) * n;
+      const int64_t cnt = b > a ? (b - a < cap ? b - a : cap) : 0;
+      uint64_t* land_d = (uint64_t*)P.land_d[d];
+      for (int64_t k = 0; k < cnt; ++k)
+        __atomic_store_n(land_d + gmx_peer_state_at(tag, W, tiles, cap, P.leaves, l, me, k),
+                         gmx_granule(send[(size_t)d * (size_t)cap + (size_t)k], tag), __ATOMIC_RELAXED);
+    }
+  }
+  // what arrives here from s: the slots of MY shard whose ancestor lives on s
+  for (int l = 0; l < P.leaves; ++l) {
+    uint32_t* tail = (uint32_t*)tail_rows[l];
+    for (int s = 0; s < W; ++s) {
+      if (s == me) continue;
+      const int64_t lo_s = plan[GMX_PLAN_BOUNDS + s], hi_s = plan[GMX_PLAN_BOUNDS + s + 1];
+      const int64_t a = lo_s > me * n ? lo_s : me * n, b = hi_s < (me + 1) * n ? hi_s : (me + 1) * n;
+      const int64_t cnt = b > a ? (b - a < cap ? b - a : cap) : 0;
+      for (int64_t k = 0; k < cnt; ++k) {
+        uint32_t v;
+        if (!hs_peer_wait(land_own + gmx_peer_state_at(tag, W, tiles, cap, P.leaves, l, s, k), tag, &v, t0)) {
+          P.status_d[0] = 1;
+          return fail("shard_step_peer: a peer's states did not arrive within 60 s");
+        }
+        tail[(size_t)s * (size_t)cap + (size_t)k] = v;
+      }
+    }
+  }
+  return 0;
 }
 // ---- peer-mapped exchange: the same protocol over PROCESS-SHARED memory (POSIX shm), so that the gloo ranks of the CPU
 // tests really write into each other's buffers and wait on each other's flags ----

@@ -71,22 +71,28 @@ def test_sharded_sweep_equals_single_process_oracle(tmp_path, world, capacity, t
     assert np.array_equal(x, ref["x"][ref["anc"]])
 
 
-@pytest.mark.parametrize("world,capacity,na", [(2, 0, 0), (4, 3, 0), (2, 0, 1)])
-def test_sharded_sweep_over_the_peer_mapped_communicator(tmp_path, world, capacity, na):
+@pytest.mark.parametrize("comm,world,capacity,na,prog_stats", [
+    ("p2p", 2, 0, 0, "1"), ("p2p", 4, 3, 0, "1"), ("p2p", 2, 0, 1, "1"),
+    ("peer", 2, 0, 0, "1"), ("peer", 4, 3, 0, "1"), ("peer", 2, 0, 1, "1"), ("peer", 4, 0, 1, "0")])
+def test_sharded_sweep_over_the_peer_mapped_communicator(tmp_path, comm, world, capacity, na, prog_stats):
     """GENMI_COMM=p2p (include/genmi.h "Peer-mapped exchange"; comm.P2PComm): every collective of the sharded step is
     ONE exchange over peer-mapped memory — put into the peers' buffers, a flag per peer, a wait on the own flags; the
-    epoch lives with the flags.  The CPU mirror runs the protocol over POSIX shared memory, so the gloo ranks really
+    epoch lives with the flags.  GENMI_COMM=peer ("Fused peer exchange"; comm.PeerComm): NO collective launch — the
+    site program's epilogue puts its tile statistics into the peers' landing tables (prog_stats "0": gmx_tile_stats +
+    gmx_peer_put_stats do), gmx_shard_step_peer reads them as tagged granules, puts the offspring states and waits for
+    the ones its own slots need.  The CPU mirror runs both protocols over POSIX shared memory, so the gloo ranks really
     write into each other's buffers: world 2 and 4 (the latter through the capacity-overflow re-run, which re-allocates
     the exchange buffers collectively) equal the single-process oracle bit for bit, also with noise ahead."""
     from genjax_amd import workloads
     n_total, T = 4096, 6
     out = str(tmp_path / "shard_p2p")
     r = _launch(world, [out, str(n_total // world), str(T)] + ([str(capacity)] if capacity else []),
-                extra_env={"GENMI_COMM": "p2p", "GENMI_NOISE_GROUP": "3", "GENMI_TEST_OPTS": json.dumps({"noise_ahead": na})})
+                extra_env={"GENMI_COMM": comm, "GENMI_NOISE_GROUP": "3", "GENMI_HOSTSIM_TILE_STATS": prog_stats,
+                           "GENMI_TEST_OPTS": json.dumps({"noise_ahead": na})})
     assert r.returncode == 0, r.stderr[-3000:]
     x = np.load(out + ".npy")
     meta = json.load(open(out + ".json"))
-    assert meta["communicator"].startswith("p2p")
+    assert meta["communicator"].startswith(comm)
     ys = workloads.lgssm_data(T)
     oi, ost = workloads.make_lgssm(O)
     ref = parity.oracle_bootstrap_sweep(oi, ost, n_total, T, ys, O.key(314159))
@@ -120,14 +126,14 @@ def test_sharded_importancek_over_the_peer_mapped_communicator(tmp_path):
     assert np.array_equal(got["theta"], oc.get_particles().get_choices()["theta"][anc])
 
 
-@pytest.mark.parametrize("world,capacity", [(2, 0), (4, 7)])
-def test_sharded_mh_sweep_equals_single_process_oracle(tmp_path, world, capacity):
+@pytest.mark.parametrize("world,capacity,comm", [(2, 0, None), (4, 7, None), (2, 0, "peer"), (4, 7, "peer")])
+def test_sharded_mh_sweep_equals_single_process_oracle(tmp_path, world, capacity, comm):
     """BASELINE config 3 sharded: nonlinear SSM + one MH move per step, two routed leaves (the particle and
     the state it was extended from).  Must equal the single-process oracle for any rank count; capacity 7
     forces the overflow re-run."""
     n_total, T = 4096, 4          # 1024 per rank at world 4: shards start on a CDF tile boundary
     out = str(tmp_path / "shard_mh")
-    r = _launch(world, [out, str(n_total // world), str(T), str(capacity), "mh"])
+    r = _launch(world, [out, str(n_total // world), str(T), str(capacity), "mh"], extra_env={"GENMI_COMM": comm} if comm else None)
     assert r.returncode == 0, r.stderr[-3000:]
     x = np.load(out + ".npy")
     meta = json.load(open(out + ".json"))
@@ -137,13 +143,13 @@ def test_sharded_mh_sweep_equals_single_process_oracle(tmp_path, world, capacity
     assert meta["reruns"] == (1 if capacity else 0), meta
 
 
-@pytest.mark.parametrize("world,capacity", [(2, 0), (2, 5)])
-def test_sharded_vector_state_sweep_equals_single_process_oracle(tmp_path, world, capacity):
+@pytest.mark.parametrize("world,capacity,comm", [(2, 0, None), (2, 5, None), (2, 5, "peer")])
+def test_sharded_vector_state_sweep_equals_single_process_oracle(tmp_path, world, capacity, comm):
     """a 2-vector state (constant-velocity tracker): every component is one routed leaf (same plan, one
     gmx_shard_step + one all-to-all each); equals the single-process oracle, also through the overflow re-run."""
     n_total, T = 2048, 5
     out = str(tmp_path / "shard_vec")
-    r = _launch(world, [out, str(n_total // world), str(T), str(capacity), "vec"])
+    r = _launch(world, [out, str(n_total // world), str(T), str(capacity), "vec"], extra_env={"GENMI_COMM": comm} if comm else None)
     assert r.returncode == 0, r.stderr[-3000:]
     x = np.load(out + ".npy")
     meta = json.load(open(out + ".json"))
@@ -154,13 +160,13 @@ def test_sharded_vector_state_sweep_equals_single_process_oracle(tmp_path, world
     assert meta["reruns"] == (1 if capacity else 0), meta
 
 
-@pytest.mark.parametrize("world,capacity", [(2, 0), (2, 6)])
-def test_sharded_vector_state_mh_sweep_equals_single_process_oracle(tmp_path, world, capacity):
+@pytest.mark.parametrize("world,capacity,comm", [(2, 0, None), (2, 6, None), (2, 0, "peer"), (2, 6, "peer")])
+def test_sharded_vector_state_mh_sweep_equals_single_process_oracle(tmp_path, world, capacity, comm):
     """a 2-vector state AND one MH move per step: the particle and the state it was extended from travel as
     2 x 2 routed leaves; equals the single-process oracle, also through the overflow re-run."""
     n_total, T = 2048, 4
     out = str(tmp_path / "shard_vecmh")
-    r = _launch(world, [out, str(n_total // world), str(T), str(capacity), "vecmh"])
+    r = _launch(world, [out, str(n_total // world), str(T), str(capacity), "vecmh"], extra_env={"GENMI_COMM": comm} if comm else None)
     assert r.returncode == 0, r.stderr[-3000:]
     x = np.load(out + ".npy")
     meta = json.load(open(out + ".json"))

@@ -485,6 +485,55 @@ def test_sharded_sweep_over_the_peer_mapped_communicator_world1(gpu, monkeypatch
     sw.close()
 
 
+@pytest.mark.parametrize("n", [300_000, 20_000])
+def test_sharded_sweep_over_the_fused_peer_exchange_world1(gpu, monkeypatch, n):
+    """GENMI_COMM=peer on the device at world size 1 ("Fused peer exchange"): a step is the site program (whose epilogue
+    would put its statistics to the other ranks) + gmx_shard_step_peer — NO collective launch; tags advance across
+    sweeps through gmx_peer_bump inside the captured graph.  Eager and captured + replayed twice, specialised (n =
+    300 000: the epilogue's statistics) and interpreted (n = 20 000: gmx_tile_stats + gmx_peer_put_stats); equal to the
+    oracle.  With an MH move per step: two routed leaves through the same launch."""
+    import genjax_amd as G
+    from genjax_amd import workloads
+    from genjax_amd.inference.comm import PeerComm
+    from genjax_amd.inference.sharded import ShardedBootstrapSweep
+
+    class _Solo:
+        @staticmethod
+        def get_rank(): return 0
+        @staticmethod
+        def get_world_size(): return 1
+    monkeypatch.setenv("GENMI_COMM", "peer")
+    T = 5
+    ys = workloads.lgssm_data(T)
+    init, step = workloads.make_lgssm(G)
+    sw = ShardedBootstrapSweep(init, step, n, T, _Solo, always_communicate=True).prepare(G.key(314159), torch.from_numpy(ys))
+    assert isinstance(sw.cx, PeerComm) and sw.peer_mode
+    oi, ost = workloads.make_lgssm(O)
+    ref = parity.oracle_bootstrap_sweep(oi, ost, n, T, ys, O.key(314159))
+    sw.launch()
+    assert np.array_equal(sw.state().cpu().numpy(), ref["x"][ref["anc"]]) and sw.log_ml() == ref["log_ml"]
+    sw.capture()
+    for _ in range(2):
+        sw.launch()
+        sw.finish()
+        assert np.array_equal(sw.state().cpu().numpy(), ref["x"][ref["anc"]]) and sw.log_ml() == ref["log_ml"]
+    # four sweeps: the eager one, capture()'s warm-up, two replays — T tags each on top of the initial 1
+    assert int(sw.peer_tag.item()) == 1 + 4 * T and int(sw.peer_status.item()) == 0
+    sw.close()
+    # config 3: the MH move's second routed leaf through the same launch
+    T = 4
+    ys = workloads.nlssm_data(T)
+    init, step = workloads.make_nlssm(G)
+    req = G.StaticRequest({"x": G.Rejuvenate(G.normal, lambda chm: (chm.get_value(), 0.5))})
+    sw = ShardedBootstrapSweep(init, step, n, T, _Solo, always_communicate=True, rejuvenate=req,
+                               step_extra=lambda t: (float(t),)).prepare(G.key(7), torch.from_numpy(ys))
+    assert sw.peer_mode and sw.peer_leaves == 2
+    sw.launch()
+    ref = parity.oracle_nlssm_mh_sweep(n, T, 7)
+    assert np.array_equal(sw.state().cpu().numpy(), ref["resampled"])
+    sw.close()
+
+
 def test_conditional_smc_and_proposals(gpu):
     parity.check_csmc(k=10_001)
 
@@ -1516,9 +1565,13 @@ def test_long_scan_importance_weights_against_kalman_on_device(gpu):
     parity.check_scan_importance_vs_kalman(n=2_000_000)
 
 
-@pytest.mark.parametrize("world,na,capture", [(2, 0, 0), (2, 1, 1), (4, 1, 1)])
-def test_peer_mapped_exchange_between_two_processes_on_the_device(gpu, tmp_path, world, na, capture):
-    """GENMI_COMM=p2p at WORLD SIZE 2 (and 4) on real device memory: the processes (ranks) share the box's one GPU, map each
+@pytest.mark.parametrize("comm,world,na,capture", [("p2p", 2, 0, 0), ("p2p", 2, 1, 1), ("p2p", 4, 1, 1),
+                                                   ("peer", 2, 0, 0), ("peer", 2, 1, 1), ("peer", 4, 1, 1)])
+def test_peer_mapped_exchange_between_two_processes_on_the_device(gpu, tmp_path, comm, world, na, capture):
+    """GENMI_COMM=peer: the FUSED exchange — the site programs put their statistics into the other PROCESSES' landing
+    tables as tagged granules, gmx_shard_step_peer polls its own, puts states into the owners' landing blocks and waits
+    for what its slots need; no collective launch, no fence.
+    GENMI_COMM=p2p at WORLD SIZE 2 (and 4) on real device memory: the processes (ranks) share the box's one GPU, map each
     other's fine-grained landing buffers and flags through IPC handles (gmx_p2p_alloc / gmx_p2p_open) and run the
     sharded sweep with every collective as ONE gmx_p2p_exchange launch — puts into the peer's memory, release, flag,
     bounded wait, copy out, device-side epoch.  Bit-exact against the single-process oracle, eagerly and as a captured
@@ -1529,12 +1582,12 @@ def test_peer_mapped_exchange_between_two_processes_on_the_device(gpu, tmp_path,
     n_total, T = 8192, 6
     out = str(tmp_path / "p2p_gpu")
     r = _launch(world, [out, str(n_total // world), str(T)],
-                extra_env={"GENMI_COMM": "p2p", "GENMI_NOISE_GROUP": "3", "GENMI_COMM_TIMEOUT": "60",
+                extra_env={"GENMI_COMM": comm, "GENMI_NOISE_GROUP": "3", "GENMI_COMM_TIMEOUT": "60",
                            "GENMI_TEST_OPTS": json.dumps({"on_gpu": 1, "noise_ahead": na, "capture": capture})})
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     x = np.load(out + ".npy")
     meta = json.load(open(out + ".json"))
-    assert meta["communicator"].startswith("p2p")
+    assert meta["communicator"].startswith(comm)
     ys = workloads.lgssm_data(T)
     oi, ost = workloads.make_lgssm(O)
     ref = parity.oracle_bootstrap_sweep(oi, ost, n_total, T, ys, O.key(314159))

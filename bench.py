@@ -426,6 +426,199 @@ def other_configs():
     return out
 
 
+def other_configs_sharded(dist, world, rank, cx, be):
+    """BASELINE's two multi-GPU configs on the sharded path (every rank takes part; rank 0 reports), each beside the
+    SAME run's single-GPU code path as its strong-scaling denominator (every rank runs that one on its own GPU at the
+    same time; the slowest rank's time is quoted):
+      config 3  nonlinear SSM + one MH move per step, 1e6 particles in total: ShardedBootstrapSweep(rejuvenate=...)
+                over the communicator the headline chose, vs BootstrapSweep(rejuvenate=...) on one GPU
+      config 4  8-schools ImportanceK k = 1e7 in total + ONE global systematic resample:
+                sharded_importance_resample (k / N per rank), vs ImportanceK + smc.resample on one GPU"""
+    import numpy as np
+    import torch
+    import genjax_amd as G
+    from genjax_amd import ChoiceMapBuilder as C, numpy as jnp, workloads
+    from genjax_amd.inference import smc
+    from genjax_amd.inference.sharded import ShardedBootstrapSweep, sharded_importance_resample
+    out = {}
+
+    def slowest(dt):
+        t = torch.tensor([dt], device=be.device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def timed(fn, reps):
+        fn()
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return slowest((time.perf_counter() - t0) / reps)
+
+    try:
+        T = T_STEPS
+        n = ((N_PARTICLES + world * 1024 - 1) // (world * 1024)) * 1024
+        init, step = workloads.make_nlssm(G)
+        req = G.StaticRequest({"x": G.Rejuvenate(G.normal, lambda chm: (chm.get_value(), 0.5))})
+        ysn = torch.from_numpy(workloads.nlssm_data(T))
+        one = smc.BootstrapSweep(init, step, n * world, T, step_extra=lambda t: (float(t),), rejuvenate=req).prepare(
+            G.key(7), ysn).capture()
+        dt1 = timed(one.launch, 3)
+        lm1 = one.log_ml()
+        del one
+        sh = ShardedBootstrapSweep(init, step, n, T, dist, always_communicate=True, rejuvenate=req,
+                                   step_extra=lambda t: (float(t),), comm=cx).prepare(G.key(7), ysn)
+        if cx is not None and cx.graph_safe and (world == 1 or getattr(cx, "fused", False)):
+            sh.capture()
+
+        def run3():
+            sh.launch(); sh.finish()
+        dtN = timed(run3, 3)
+        out["config3"] = {"workload": f"nonlinear SSM + one Rejuvenate MH move per step, {n * world} particles x {T} steps",
+                          "sharded_us_per_step": 1e6 * dtN / T, "single_gpu_us_per_step": 1e6 * dt1 / T,
+                          "strong_scaling_speedup": dt1 / dtN, "particle_steps_per_s": n * world * T / dtN,
+                          "log_ml_equal_to_single_gpu": sh.log_ml() == lm1, "graph": sh.graph is not None,
+                          "communicator": getattr(cx, "name", None), "full_capacity_reruns": sh.reruns}
+        sh.close()
+    except Exception as e:          # noqa: BLE001
+        out["config3"] = {"error": repr(e)[:300]}
+    try:
+        sig = [15.0, 10.0, 16.0, 11.0, 9.0, 11.0, 10.0, 18.0]
+        ysch = np.array([28, 8, -3, 7, -1, 1, 18, 12], np.float32)
+
+        @G.gen
+        def schools():
+            mu = G.normal(0.0, 5.0) @ "mu"
+            log_tau = G.normal(0.0, 1.0) @ "log_tau"
+            theta = G.normal(mu * jnp.ones(8), jnp.exp(log_tau) * jnp.ones(8)) @ "theta"
+            _ = G.normal(theta, jnp.array(sig)) @ "y"
+            return theta
+        tgt = G.Target(schools, (), C["y"].set(ysch))
+        kr = ((10_000_000 + world * 1024 - 1) // (world * 1024)) * 1024
+        k = kr * world
+        alg = smc.ImportanceK(tgt, k_particles=k)
+        box = {}
+
+        def run1():
+            c = alg.run_smc(G.key(2))
+            r = smc.resample(G.split(G.key(2))[0], c, "systematic")
+            box["theta1"] = r.get_particles().get_choices()["theta"]
+        dt1 = timed(run1, 3)
+        stats = {}
+
+        def runN():
+            coll, _lw = sharded_importance_resample(tgt, kr, G.key(2), dist, comm=cx, stats=stats)
+            box["thetaN"] = coll.get_particles().get_choices()["theta"]
+        dtN = timed(runN, 3)
+        same = bool(torch.equal(box["thetaN"], box["theta1"][rank * kr:(rank + 1) * kr]))
+        out["config4"] = {"workload": f"8-schools ImportanceK k = {k} + one global systematic resample of the 10-latent trace",
+                          "sharded_ms": 1e3 * dtN, "single_gpu_ms": 1e3 * dt1, "strong_scaling_speedup": dt1 / dtN,
+                          "particles_per_s": k / dtN, "resampled_latents_equal_single_gpu": same,
+                          "collectives": stats.get("collectives"), "form": stats.get("form"),
+                          "communicator": getattr(cx, "name", None)}
+    except Exception as e:          # noqa: BLE001
+        out["config4"] = {"error": repr(e)[:300]}
+    return out
+
+
+def ShardedSweep(init, step, n, T, dist, key, ys, comm=None, **kw):
+    """a prepared ShardedBootstrapSweep over the communicator `comm` ("peer" / "rccl" / "p2p" / "torch"; None: whatever
+    GENMI_COMM / the default says)"""
+    import torch
+    from genjax_amd.inference.sharded import ShardedBootstrapSweep
+    old = os.environ.get("GENMI_COMM")
+    if comm is not None:
+        os.environ["GENMI_COMM"] = comm
+    try:
+        return ShardedBootstrapSweep(init, step, n, T, dist, always_communicate=True, **kw).prepare(key, torch.from_numpy(ys))
+    finally:
+        if comm is not None:
+            if old is None:
+                os.environ.pop("GENMI_COMM", None)
+            else:
+                os.environ["GENMI_COMM"] = old
+
+
+def pick_sharded_sweep(args, dist, world, rank, on_gpu, be, make):
+    """The sharded sweep the timed region runs, and the start-up A/B that chose its communicator (outside the timed
+    region, agreed across ranks, recorded in `config`).
+
+    Candidates on a GPU box (GENMI_COMM set: that one alone): the FUSED PEER EXCHANGE (comm.PeerComm: no collective
+    launch per step; every wait bounded by the device's wall clock, so a candidate that does not work costs seconds,
+    not the job) as one hipGraph, and the direct RCCL communicator — as one hipGraph at world size 1, EAGER across GPUs:
+    captured RCCL calls have never run at world > 1 in the build loop and a replay that hangs cannot be bounded
+    (GENMI_SHARDED_GRAPH=1 opts in).  Each candidate runs one warm-up sweep and three timed ones; it is dropped if it
+    raises, times out, or its evidence differs from the first working candidate's (every communicator must produce
+    the SAME bits).  The fastest survivor (MAX over ranks of its time) is kept, the others are closed."""
+    import torch
+    from genjax_amd.inference.comm import _Deadline
+    forced = os.environ.get("GENMI_COMM")
+    graph_ok = on_gpu and not args.no_graph
+    rccl_graph = graph_ok and (world == 1 or os.environ.get("GENMI_SHARDED_GRAPH", "0") == "1")
+    if not on_gpu:
+        cands = [(forced, False)]
+    elif forced:
+        cands = [(forced, graph_ok and (forced != "rccl" or rccl_graph) and forced != "torch")]
+    else:
+        cands = [("rccl", rccl_graph), ("peer", graph_ok)]
+    timeout = float(os.environ.get("GENMI_COMM_TIMEOUT", "120"))
+
+    def agree(ok, dt):
+        if dist is None or world == 1:
+            return ok, dt
+        t = torch.tensor([1.0 if ok else 0.0, -dt], device=be.device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t[0].item() > 0.5), -float(t[1].item())
+
+    results, best, ref_log_ml = [], None, None
+    for comm, graph in cands:
+        sw, ok, dt, log_ml, err = None, True, float("inf"), None, None
+        try:
+            with _Deadline(timeout, f"the start-up sweeps over the {comm} communicator"):
+                sw = make(comm=comm)
+                if graph and (sw.cx is None or sw.cx.graph_safe):
+                    sw.capture()
+                sw.launch(); sw.finish()
+                if on_gpu:
+                    torch.cuda.synchronize()
+                if dist is not None:
+                    dist.barrier()
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    sw.launch(); sw.finish()
+                if on_gpu:
+                    torch.cuda.synchronize()
+                dt = (time.perf_counter() - t0) / 3
+                log_ml = sw.log_ml()
+        except Exception as e:          # noqa: BLE001
+            ok, err = False, repr(e)[:200]
+            print(f"bench.py: rank {rank}: communicator {comm!r} dropped: {e!r}", file=sys.stderr, flush=True)
+        if ok and ref_log_ml is not None and log_ml != ref_log_ml:
+            ok, err = False, f"log_ml {log_ml!r} differs from the first communicator's {ref_log_ml!r}"
+        ok, dt = agree(ok, dt)
+        if ok and ref_log_ml is None:
+            ref_log_ml = log_ml
+        results.append({"communicator": comm, "graph": bool(sw is not None and sw.graph is not None), "ok": ok,
+                        "us_per_step": (1e6 * dt / sw.T) if ok else None, **({"error": err} if err else {})})
+        if ok and (best is None or dt < best[1]):
+            if best is not None:
+                best[0].close()
+            best = (sw, dt)
+        elif sw is not None:
+            try:
+                sw.close()
+            except Exception:       # noqa: BLE001
+                pass
+    if best is None:
+        # nothing worked: the torch.distributed communicator, eager (the last resort; it fails loudly if it cannot run)
+        sw = make(comm="torch")
+        results.append({"communicator": "torch", "graph": False, "ok": True, "us_per_step": None, "fallback": True})
+        return sw, results
+    return best[0], results
+
+
 def spawn_ranks(world: int) -> int:
     """`python bench.py --gpus N` with no launcher: THIS process becomes the launcher.  It never imports torch, never
     loads the HIP library and never touches a GPU; it starts N children of the same command line — one rank per GPU,
@@ -554,45 +747,12 @@ def main():
             sw.capture()
         launch = sw.launch
     else:
-        from genjax_amd.inference.sharded import ShardedBootstrapSweep
-        sw = ShardedBootstrapSweep(init, step, n, T, dist, always_communicate=True).prepare(
-            G.key(seed), torch.from_numpy(ys))
-
-        # the whole sharded sweep — kernels, both streams of the noise-ahead form AND the RCCL collectives (issued by
-        # comm.RcclComm on the kernels' own stream) — as one hipGraph, like the single-GPU sweep.  Not with the
-        # torch.distributed fallback communicator (its watchdog queries events recorded inside a capture), not on
-        # the CPU mirror; GENMI_SHARDED_GRAPH=0 keeps eager launches.
-        if (on_gpu and not args.no_graph and os.environ.get("GENMI_SHARDED_GRAPH", "1") != "0"
-                and (sw.cx is None or sw.cx.graph_safe)):
-            # every rank captures or none does: a capture that raises on ONE rank (the RCCL calls of a capture have
-            # only ever run at world size 1 in the build loop) leaves all of them on eager launches — the same
-            # launches, stream-ordered — instead of failing the measurement
-            ok = 1
-            try:
-                sw.capture()
-            except Exception as e:          # noqa: BLE001
-                ok = 0
-                sw.graph = None
-                print(f"bench.py: rank {rank}: hipGraph capture of the sharded sweep failed ({e!r}); eager launches",
-                      file=sys.stderr, flush=True)
-            if dist is not None and world > 1:
-                agree = torch.tensor([ok], device=be.device, dtype=torch.int32)
-                dist.all_reduce(agree, op=dist.ReduceOp.MIN)
-                if int(agree.item()) == 0:
-                    sw.graph = None
+        sw, comm_ab = pick_sharded_sweep(args, dist, world, rank, on_gpu, be,
+                                         lambda **kw: ShardedSweep(init, step, n, T, dist, G.key(seed), ys, **kw))
 
         def launch():
             sw.launch()
             sw.finish()          # the once-per-sweep overflow check (one sync, one 8-byte all-reduce)
-
-        if world > 1:
-            # the first sweeps under a deadline: a collective that never completes makes the rank EXIT (status 3, the
-            # launcher tears the job down) instead of hanging the driver until its own limit
-            from genjax_amd.inference.comm import _Deadline
-            with _Deadline(float(os.environ.get("GENMI_COMM_TIMEOUT", "120")), "the first sharded sweep"):
-                launch()
-                if on_gpu:
-                    torch.cuda.synchronize()
 
     def barrier():
         if dist is not None:
@@ -634,7 +794,8 @@ def main():
                    "resampler": "systematic", "graph": not args.no_graph and single,
                    "path": ("BootstrapSweep (hipGraph" + (", noise ahead on a second stream)" if getattr(sw, "noise_ahead", False)
                                                          else ")")) if single else
-                   ("ShardedBootstrapSweep (RCCL" + (", noise ahead on a second stream" if getattr(sw, "noise_ahead", False) else "") + ")"),
+                   ("ShardedBootstrapSweep (" + str(getattr(getattr(sw, "cx", None), "name", "no communicator"))
+                    + (", noise ahead on a second stream" if getattr(sw, "noise_ahead", False) else "") + ")"),
                    "key": seed},
         "log_ml": log_ml, "log_ml_kalman": kal, "log_ml_abs_err": abs(log_ml - kal),
         "log_ml_rel_err": abs(log_ml - kal) / abs(kal),
@@ -642,11 +803,16 @@ def main():
 
     if not single:
         out["config"]["communicator"] = sw.cx.name
+        out["config"]["communicator_ab"] = comm_ab       # the start-up A/B (3 sweeps each, outside the timed region)
         out["config"]["GENMI_COMM"] = os.environ.get("GENMI_COMM", "(unset: rccl on a GPU box, torch.distributed otherwise)")
         out["config"]["graph"] = sw.graph is not None
         out["config"]["capacity_per_peer"] = sw.capacity
         out["config"]["full_capacity_reruns"] = sw.reruns
 
+    if not single and on_gpu and not args.no_other_configs and dist is not None and n * world >= N_PARTICLES and T == T_STEPS:
+        oc = other_configs_sharded(dist, world, rank, sw.cx, be)       # COLLECTIVE: every rank
+        if rank == 0:
+            out["other_configs"] = oc
     if rank == 0 and on_gpu:
         out["roofline"] = ({"code_identity": code_identity(sw), "note": "--no-roofline"} if args.no_roofline
                            else measure_roofline(be, sw, n, T, world, single, value))

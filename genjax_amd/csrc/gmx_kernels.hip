@@ -3034,17 +3034,19 @@ struct shard_peer {
 };
 // one row of another rank's statistics: spin (bounded) until all three granules carry `tag`
 __device__ __forceinline__ bool shard_peer_row(const uint64_t* row, uint32_t tag, uint64_t& agg, float& tmax) {
-  uint32_t spins = 0;
-  for (;;) {
-    const uint64_t g0 = gmx_granule_peek(row), g1 = gmx_granule_peek(row + 1), g2 = gmx_granule_peek(row + 2);
-    if ((uint32_t)(g0 >> 32) == tag && (uint32_t)(g1 >> 32) == tag && (uint32_t)(g2 >> 32) == tag) {
-      agg = (uint64_t)(uint32_t)g0 | ((uint64_t)(uint32_t)g1 << 32);
-      tmax = gmx_u2f((uint32_t)g2);
-      return true;
-    }
-    if (++spins >= GMX_PEER_SPIN_LIMIT) { agg = 0ull; tmax = -gmx_inf(); return false; }
-    __builtin_amdgcn_s_sleep(2);
+  uint64_t g0 = gmx_granule_peek(row), g1 = gmx_granule_peek(row + 1), g2 = gmx_granule_peek(row + 2);
+  bool ok = (uint32_t)(g0 >> 32) == tag && (uint32_t)(g1 >> 32) == tag && (uint32_t)(g2 >> 32) == tag;
+  if (!ok) {
+    const uint64_t t0 = wall_clock64();
+    do {
+      __builtin_amdgcn_s_sleep(2);
+      g0 = gmx_granule_peek(row); g1 = gmx_granule_peek(row + 1); g2 = gmx_granule_peek(row + 2);
+      ok = (uint32_t)(g0 >> 32) == tag && (uint32_t)(g1 >> 32) == tag && (uint32_t)(g2 >> 32) == tag;
+    } while (!ok && wall_clock64() - t0 < GMX_PEER_TIMEOUT_TICKS);
   }
+  agg = ok ? ((uint64_t)(uint32_t)g0 | ((uint64_t)(uint32_t)g1 << 32)) : 0ull;
+  tmax = ok ? gmx_u2f((uint32_t)g2) : -gmx_inf();
+  return ok;
 }
 template <int kind, bool SMALL, bool PEER>
 __global__ void __launch_bounds__(GMX_BLOCK)
@@ -3085,7 +3087,11 @@ k_shard_step_fill(uint32_t k0, uint32_t k1, uint32_t u0_host, const float* __res
   const float tmax_mine = reinterpret_cast<const float*>(own + (size_t)tiles_pad * 8)[my_tile];
   uint32_t tag = 0u;
   const uint64_t* land_own = nullptr;            // this rank's own landing block (entry `rank` of the table)
-  if (PEER) { tag = *P.tag_base + (uint32_t)P.step; land_own = P.land[rank]; }
+  if (PEER) {
+    tag = *P.tag_base + (uint32_t)P.step; land_own = P.land[rank];
+    // a sweep that has already lost a peer does not wait again: every later launch of it leaves at once
+    if (__hip_atomic_load(P.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) return;
+  }
   bool timed_out = false;
   // ---- pass 1 over the table: the global max ----
   float m = -gmx_inf();
@@ -3106,7 +3112,8 @@ k_shard_step_fill(uint32_t k0, uint32_t k1, uint32_t u0_host, const float* __res
       rr[k] = rho < rows ? r : -1;
       tt[k] = t;
       if (PEER && r != rank) {
-        if (rho < rows) timed_out |= !shard_peer_row(land_own + gmx_peer_stats_at(tag, world, n_tiles, r, t), tag, ta[k], tm[k]);
+        if (rho < rows && !timed_out) timed_out |= !shard_peer_row(land_own + gmx_peer_stats_at(tag, world, n_tiles, r, t), tag, ta[k], tm[k]);
+        else if (rho < rows) { ta[k] = 0ull; tm[k] = -gmx_inf(); }
         else { ta[k] = 0ull; tm[k] = -gmx_inf(); }
       } else {
         const uint8_t* blk = PEER ? own : stats_all + (size_t)r * stride;
@@ -3121,8 +3128,8 @@ k_shard_step_fill(uint32_t k0, uint32_t k1, uint32_t u0_host, const float* __res
     for (int r = 0; r < world; ++r) {
       if (PEER && r != rank) {
         for (int t = tid; t < n_tiles; t += GMX_BLOCK) {
-          uint64_t a_; float m_;
-          timed_out |= !shard_peer_row(land_own + gmx_peer_stats_at(tag, world, n_tiles, r, t), tag, a_, m_);
+          uint64_t a_ = 0ull; float m_ = -gmx_inf();
+          if (!timed_out) timed_out |= !shard_peer_row(land_own + gmx_peer_stats_at(tag, world, n_tiles, r, t), tag, a_, m_);
           m = gmx_rmax(m, m_);
         }
       } else {
@@ -3222,15 +3229,12 @@ k_shard_step_fill(uint32_t k0, uint32_t k1, uint32_t u0_host, const float* __res
   auto receive = [&](int32_t s_, int32_t k) {
     if (PEER) {
       for (int l = 0; l < P.leaves; ++l) {
-        const uint64_t* g = land_own + gmx_peer_state_at(tag, world, n_tiles, cap, P.leaves, l, s_, k);
-        uint64_t v = gmx_granule_peek(g);
-        uint32_t spins = 0;
-        while ((uint32_t)(v >> 32) != tag) {
-          if (++spins >= GMX_PEER_SPIN_LIMIT) { __hip_atomic_store(P.status, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-          __builtin_amdgcn_s_sleep(2);
-          v = gmx_granule_peek(g);
+        uint32_t v = 0u;
+        if (timed_out || !gmx_granule_wait(land_own + gmx_peer_state_at(tag, world, n_tiles, cap, P.leaves, l, s_, k), tag, v)) {
+          timed_out = true;
+          __hip_atomic_store(P.status, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        P.tail[l][(int64_t)s_ * cap + k] = (uint32_t)v;
+        P.tail[l][(int64_t)s_ * cap + k] = v;
       }
     }
   };
@@ -3542,7 +3546,6 @@ extern "C" int gmx_shard_step_peer(int kind, const uint32_t key[2], const void* 
 // ---------------------------------------------------------------------------
 // peer-mapped exchange (include/genmi.h "Peer-mapped exchange"): one launch, one rendezvous per collective
 // ---------------------------------------------------------------------------
-#define GMX_P2P_SPIN_LIMIT (1u << 22)
 #define GMX_P2P_CHUNK (16u * 1024u)         /* bytes one workgroup moves: a block of `bytes` is split over up to 64 of them */
 // No fences: a system-scope release / acquire on gfx950 is a write-back / invalidate of the XCD's whole L2 (measured: the
 // exchange took the sharded step to 65 us beside the noise programs).  Instead every word that crosses is stored
@@ -3599,13 +3602,16 @@ k_p2p_exchange(const uint8_t* __restrict__ src, size_t src_stride, void* const* 
       __hip_atomic_store(flag_peers[d] + rank, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     // ---- wait: peer d's block for me (relaxed system-scope polls: past the caches) ----
-    uint32_t spins = 0, ok = 1u;
-    while (__hip_atomic_load(flags_local + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
-      __builtin_amdgcn_s_sleep(4);
-      if (++spins >= GMX_P2P_SPIN_LIMIT) {              // a peer that never arrives must not hang the GPU
-        __hip_atomic_store(state + 1, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        ok = 0u;
-        break;
+    uint32_t ok = 1u;
+    if (__hip_atomic_load(flags_local + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
+      const uint64_t t0 = wall_clock64();
+      while (__hip_atomic_load(flags_local + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
+        __builtin_amdgcn_s_sleep(4);
+        if (wall_clock64() - t0 >= GMX_PEER_TIMEOUT_TICKS) {      // a peer that never arrives must not hang the GPU
+          __hip_atomic_store(state + 1, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ok = 0u;
+          break;
+        }
       }
     }
     s_ok = ok;

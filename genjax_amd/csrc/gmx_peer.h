@@ -10,7 +10,9 @@
 #include "gmx_math.h"
 #include "genmi.h"
 
-#define GMX_PEER_SPIN_LIMIT (1u << 22)      /* polls of one granule before the wait gives up (status_d[0] = 1)       */
+#define GMX_PEER_TIMEOUT_TICKS 400000000ull  /* a wait gives up after 4 s of the 100 MHz wall clock (status_d[0] = 1): a
+                                               peer that never arrives must not hang the GPU; ranks are microseconds
+                                               apart inside a sweep and a host barrier apart before its first launch */
 
 // ---- layout of a rank's landing block, in u64 words ----
 GMX_HD size_t gmx_peer_stats_words(int world, int tiles) { return (size_t)2 * (size_t)world * (size_t)tiles * 3u; }
@@ -34,6 +36,20 @@ __device__ __forceinline__ void gmx_granule_put(uint64_t* p, uint32_t data, uint
 }
 __device__ __forceinline__ uint64_t gmx_granule_peek(const uint64_t* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// spin (bounded by the wall clock) until granule *p carries `tag`; false = gave up
+__device__ __forceinline__ bool gmx_granule_wait(const uint64_t* p, uint32_t tag, uint32_t& data) {
+  uint64_t v = gmx_granule_peek(p);
+  if ((uint32_t)(v >> 32) != tag) {
+    const uint64_t t0 = wall_clock64();
+    do {
+      __builtin_amdgcn_s_sleep(2);
+      v = gmx_granule_peek(p);
+      if ((uint32_t)(v >> 32) == tag) break;
+    } while (wall_clock64() - t0 < GMX_PEER_TIMEOUT_TICKS);
+  }
+  data = (uint32_t)v;
+  return (uint32_t)(v >> 32) == tag;
 }
 // the tile's statistics into a peer's landing block: three granules, in any order
 __device__ __forceinline__ void gmx_peer_put_tile(uint64_t* land, uint32_t tag, int world, int tiles, int src_rank, int tile,

@@ -91,7 +91,7 @@ class ShardedBootstrapSweep(_NoiseAhead):
 
     def __init__(self, init, step, n_per_rank: int, T: int, dist, obs_addr="y", step_extra=None, specialize=True,
                  resample="systematic", capacity=None, always_communicate=False, rejuvenate=None, state_addr="x",
-                 noise_ahead=None, cdf_form=False, fused=True):
+                 noise_ahead=None, cdf_form=False, fused=True, comm=None):
         """cdf_form=True: the three-collective CDF-array form (what n > 2^21 per rank or > 64 ranks take) instead of
         the tile statistics; fused=False: gmx_shard_totals + gmx_shard_step_tiles as two launches (what a vector
         state / the MH move's second leaf take) instead of gmx_shard_step_fused."""
@@ -117,7 +117,8 @@ class ShardedBootstrapSweep(_NoiseAhead):
         self.reruns = 0
         # issue the collectives even at world size 1 (exercises / times the RCCL calls on one GPU)
         self.comm = self.world > 1 or bool(always_communicate)
-        self.cx = None           # comm.RcclComm / comm.TorchComm, made in prepare()
+        self.cx = comm           # a communicator to share (comm.make_comm); None: made in prepare()
+        self._own_cx = comm is None
         self.graph = None
         self._finished = True    # nothing launched yet: finish() / log_ml() / state() have nothing to wait for
         # rejuvenate: the MH request of smc.BootstrapSweep(rejuvenate=...) (BASELINE config 3).  The move on
@@ -231,6 +232,10 @@ class ShardedBootstrapSweep(_NoiseAhead):
         for t in range(T):
             ks = split(fold_in(key, t), 3)
             self.step_keys.append((ks[0], ks[1], ks[2]))
+        if self.comm and self.world > 1 and hasattr(self.dist, "barrier"):
+            # ranks leave prepare() together (hiprtc compiles are seconds apart between ranks): the bounded waits of
+            # the peer-mapped exchanges only ever see the microseconds of skew a running sweep has
+            self.dist.barrier()
         return self
 
     def _alloc_exchange(self):
@@ -535,7 +540,7 @@ class ShardedBootstrapSweep(_NoiseAhead):
         if self.graph is not None:
             be.c.gmx_graph_destroy(self.graph)
             self.graph = None
-        if self.cx is not None and hasattr(self.cx, "destroy"):
+        if self.cx is not None and hasattr(self.cx, "destroy") and getattr(self, "_own_cx", True):
             if be.uses_streams:
                 torch.cuda.synchronize()
             self.cx.destroy()

@@ -456,7 +456,7 @@ int gmx_select(const uint8_t* mask_d, const void* const* a_d, const void* const*
  *                      next exchange cannot overwrite a block still being copied out) and the flags are fine-grained.
  *                      The epoch lives on the device (state_d[0], advanced by the last workgroup), so a captured
  *                      graph replays correctly.
- * A wait gives up after GMX_P2P_SPIN_LIMIT polls and sets state_d[1] (sticky error word: a peer that never arrives
+ * A wait gives up after 4 s of the device's wall clock and sets state_d[1] (sticky error word: a peer that never arrives
  * must not hang the GPU); the caller checks it once per sweep.  Unmeasured across GPUs (no multi-GPU box in the build
  * loop): exercised at world size 1 on the device and, through the tests' CPU mirror with process-shared memory, at
  * world sizes 2 and 4.

@@ -3087,12 +3087,13 @@ k_shard_step_fill(uint32_t k0, uint32_t k1, uint32_t u0_host, const float* __res
   const float tmax_mine = reinterpret_cast<const float*>(own + (size_t)tiles_pad * 8)[my_tile];
   uint32_t tag = 0u;
   const uint64_t* land_own = nullptr;            // this rank's own landing block (entry `rank` of the table)
+  bool timed_out = false;     // (PEER) a wait gave up — or the sweep had lost a peer before this launch: no wait at all then
   if (PEER) {
     tag = *P.tag_base + (uint32_t)P.step; land_own = P.land[rank];
-    // a sweep that has already lost a peer does not wait again: every later launch of it leaves at once
-    if (__hip_atomic_load(P.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) return;
+    // a sweep that has already lost a peer does not wait again (the value is first needed where a wait would start, or
+    // at the barrier below: the loads that follow are not held up by it)
+    timed_out = __hip_atomic_load(P.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull;
   }
-  bool timed_out = false;
   // ---- pass 1 over the table: the global max ----
   float m = -gmx_inf();
   uint64_t ta[4];

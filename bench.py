@@ -399,12 +399,27 @@ def other_configs():
         def run5():
             box["idx"] = gibbs.gibbs_categorical(G.key(1), gd, args5, chm, "idx", K)
         dt = timed(run5, 5)
+        # ... and THROUGH THE GFI: the datapoints as a `generate_datapoint.repeat(n=N)` plate called directly (its
+        # elements on the launch axis), the sweep = gibbs.enumerative_gibbs on the plate's trace (the fused draw + the
+        # plate's Update): the notebook's update_datapoint_assignment for a model written with the Vmap combinator
+        plate = gd.repeat(n=n)
+        tr5, _w5 = plate.importance(G.key(2), chm, args5)
+
+        def run5p():
+            box["tr"], box["idxp"], _ = gibbs.enumerative_gibbs(G.key(1), tr5, "idx", K)
+        dtp = timed(run5p, 5)
+        dts = timed(lambda: plate.simulate(G.key(3), args5), 5)
         out["config5"] = {"workload": "Dirichlet-categorical mixture, K = 64, 1e6 datapoints: one cluster-assignment "
                                       "sweep (gibbs_categorical: one launch, no [N, K] matrix)", "ms": 1e3 * dt,
                           "datapoints_per_s": n / dt, "gumbels_per_s": n * K / dt, "algorithmic_bytes_per_datapoint": 8,
                           "hbm_frac": 8.0 * n / dt / 1e9 / HBM_PEAK_GBS,
                           "note": "ALU-bound by design (64 Gumbels + 64 log-densities per datapoint; SURVEY 8d)",
-                          "agrees_with_generating_component": float((box["idx"].cpu().numpy() == z).mean())}
+                          "agrees_with_generating_component": float((box["idx"].cpu().numpy() == z).mean()),
+                          "through_the_gfi": {
+                              "workload": "generate_datapoint.repeat(n = 1e6) called directly (elements on the launch "
+                                          "axis) + gibbs.enumerative_gibbs on its trace (fused draw + plate Update)",
+                              "ms": 1e3 * dtp, "ratio_to_gibbs_categorical": dtp / dt,
+                              "ms_plate_simulate": 1e3 * dts}}
     except Exception as e:
         out["config5"] = {"error": repr(e)[:300]}
     try:        # ---- config 2 under the other resampling schemes (the headline is systematic) ----

@@ -32,6 +32,7 @@ from .tracer import Expr
 
 SCAN_UNROLL_MAX = 16      # longer scans run as a counted loop in the site program (Scan._trace_loop)
 VMAP_UNROLL_MAX = 16      # larger plates run as a counted loop too (Vmap._trace_loop): one iteration per element
+VMAP_LAUNCH_MIN = 4096      # a plate this large called directly under ONE key runs with its elements on the launch axis
 NEST_UNROLL_MAX = 4       # an unrolled plate whose ELEMENT runs a counted loop keeps at most this many copies of it
 
 
@@ -155,6 +156,28 @@ def _tree_take_axes(v, ax, fn):
         return dataclasses.replace(v, **{f_.name: _tree_take_axes(getattr(v, f_.name), ax, fn)
                                          for f_ in dataclasses.fields(v) if not f_.metadata.get("static")})
     return fn(v)
+
+
+def _tree_mark_unmapped(v, ax):
+    """an argument of a launch-axis plate: its UNMAPPED tensor leaves marked launch-uniform (engine.Broadcast), the
+    mapped ones (axis 0) left as the per-element leaves they are"""
+    import dataclasses
+    import torch
+    from .engine import Broadcast
+    if isinstance(ax, (tuple, list)) and isinstance(v, (tuple, list)):
+        return type(v)(_tree_mark_unmapped(x, a) for x, a in zip(v, ax))
+    if isinstance(ax, dict) and isinstance(v, dict):
+        return {k: _tree_mark_unmapped(v[k], ax[k]) for k in v}
+    if _is_container(v):
+        if isinstance(v, dict):
+            return {k: _tree_mark_unmapped(x, ax) for k, x in v.items()}
+        if isinstance(v, (tuple, list)):
+            return type(v)(_tree_mark_unmapped(x, ax) for x in v)
+        return dataclasses.replace(v, **{f_.name: _tree_mark_unmapped(getattr(v, f_.name), ax)
+                                         for f_ in dataclasses.fields(v) if not f_.metadata.get("static")})
+    if ax is None and isinstance(v, torch.Tensor):
+        return Broadcast(v)
+    return v
 
 
 def _take(a, j):
@@ -669,19 +692,85 @@ class Vmap(GenerativeFunction):
                 _store_site(ctx, r)
         return out, out.retval, weight, None
 
+    # ------------------------------------------------------------------------------------------------------------
+    # A LARGE plate under ONE key: its elements on the LAUNCH axis.
+    # The reference's Vmap is jax.vmap (vmap.py:180-218): a plate is as parallel as a particle batch.  A plate inside
+    # a site program is a counted loop of ONE thread (one particle runs its whole plate) — right when there are many
+    # particles, serial when there is one key and a million elements (`generate_datapoint.vmap()` over a dataset).
+    # Called directly with an unbatched key and at least VMAP_LAUNCH_MIN elements, the plate therefore runs as the
+    # INNER function over a batch of n: element j's key is split(key, n)[j] (a lazy split: derived in registers from
+    # the global index), mapped arguments and the constraint's leaves are the per-"particle" leaves, unmapped arguments
+    # are launch-uniform, and the plate's score / weight is gmx_sum_rows of the per-element ones — a fixed tree (the
+    # counted loop adds in element order: the two forms agree to rounding, and each is reproducible bit for bit).
+    # ------------------------------------------------------------------------------------------------------------
+    def _launch_axis(self, key, args, constraint=None, batch_shape=None):
+        """(n, inner args) when this direct call takes the launch-axis form, else None"""
+        import torch
+        if key is not None and tuple(key.shape) != ():
+            return None
+        if key is None and tuple(batch_shape or ()) != ():
+            return None
+        try:
+            axes = self._axes(args)
+            n = self._plate_size(args, axes)
+        except NotImplementedError:
+            return None
+        if n < VMAP_LAUNCH_MIN:
+            return None
+        inner = []
+        for a, ax in zip(args, axes):
+            pairs = []
+            _tree_leaves_with_axes(a, ax, pairs)
+            if any(x is not None and not isinstance(leaf, torch.Tensor) for leaf, x in pairs):
+                return None                                    # mapped numpy arrays / lists: the loop form reads them as tables
+            inner.append(_tree_mark_unmapped(a, ax))
+        if constraint is not None and not constraint.static_is_empty():
+            # per-element constraints only: every leaf leads with the plate (no integer sub-addresses, no masks)
+            from .core.mask import Mask
+            for adr in constraint.addresses():
+                v = constraint[adr] if adr else constraint.get_value()
+                if isinstance(v, Mask) or any(isinstance(c, int) for c in (adr or ())) \
+                        or tuple(getattr(v, "shape", ()))[:1] != (n,):
+                    return None
+        return n, tuple(inner)
+
+    def _plate_trace(self, tr, args):
+        """the inner function's trace over the batch of n elements, as this plate's trace"""
+        from .engine import sum_rows
+        from .static import DistributionTrace, StaticTrace, VmapTrace
+        if isinstance(tr, DistributionTrace):       # a bare distribution: one vector-valued site, score = the plate sum
+            return DistributionTrace(self, args, tr.value, sum_rows(tr.score))
+        inner = StaticTrace(tr.gen_fn, None, tr.retval, tr.subtraces)
+        return VmapTrace(self, inner, sum_rows(tr.get_score()), tr.retval, args)
+
     # direct use: split(key, n) of the caller's key itself (vmap.py:186)
     def simulate(self, key, args):
+        from .random import lazy_split
         from .static import run_gfi
+        la = self._launch_axis(key, args)
+        if la is not None:
+            return self._plate_trace(run_gfi(self.gen_fn, "simulate", lazy_split(key, la[0]), la[1]), tuple(args))
         return run_gfi(self, "simulate", key, args)
 
     def generate(self, key, constraint, args):
+        from .engine import sum_rows
+        from .random import lazy_split
         from .static import run_gfi
+        la = self._launch_axis(key, args, constraint)
+        if la is not None:
+            tr, w = run_gfi(self.gen_fn, "generate", lazy_split(key, la[0]), la[1], constraint=constraint)
+            return self._plate_trace(tr, tuple(args)), sum_rows(w)
         return run_gfi(self, "generate", key, args, constraint=constraint)
 
     def assess(self, sample, args, batch_shape=None):
+        from .engine import sum_rows
         from .static import run_gfi
         if batch_shape is None:
             batch_shape = _plate_batch(sample, lambda: self._plate_size(args, self._axes(args)))
+        la = self._launch_axis(None, args, sample, batch_shape)
+        if la is not None:
+            s_, r = run_gfi(self.gen_fn, "assess", None, la[1], constraint=sample, batch_shape=(la[0],))
+            return sum_rows(s_), r
         return run_gfi(self, "assess", None, args, constraint=sample, batch_shape=batch_shape)
 
 
@@ -736,7 +825,33 @@ def _select_rec(c, new, old):
 
 def _vmap_edit(self, key, trace, edit_request, argdiffs):
     from .static import run_edit
+    la = _vmap_edit_launch_axis(self, key, trace, edit_request, argdiffs)
+    if la is not None:
+        return la
     return run_edit(self, key, trace, edit_request, argdiffs)
+
+
+def _vmap_edit_launch_axis(self, key, trace, request, argdiffs):
+    """`Update` of a large plate held under ONE key (vmap.py:236-275 `edit_choice_map`): the inner function's Update over
+    the batch of n elements, keys split(key, n); weight = the plate sum of the elements' weights."""
+    from .core.generative import Diff, Update
+    from .engine import sum_rows
+    from .random import lazy_split
+    from .static import DistributionTrace, StaticTrace, VmapTrace, run_edit
+    if not isinstance(request, Update) or not isinstance(trace, VmapTrace) or tuple(trace.batch_shape) != ():
+        return None
+    args = tuple(Diff.tree_primal(argdiffs)) if argdiffs is not None else tuple(trace.get_args() or ())
+    la = self._launch_axis(key, args, request.constraint)
+    if la is None:
+        return None
+    n, inner_args = la
+    tang = Diff.tree_tangent(argdiffs) if argdiffs is not None else None
+    changed = tang is not None and not Diff.static_check_no_change(argdiffs)
+    inner_diffs = Diff.unknown_change(inner_args) if changed else Diff.no_change(inner_args)
+    inner_tr = StaticTrace(trace.inner.gen_fn, inner_args, trace.inner.retval, trace.inner.subtraces)
+    new_tr, w, retdiff, bwd = run_edit(self.gen_fn, lazy_split(key, n) if key is not None else None, inner_tr,
+                                       Update(request.constraint), inner_diffs)
+    return self._plate_trace(new_tr, args), sum_rows(w), retdiff, bwd
 
 
 Vmap.edit = _vmap_edit

@@ -808,6 +808,56 @@ extern "C" int gmx_logsumexp(const float* lw_d, int64_t rows, int64_t cols, floa
 }
 
 // ---------------------------------------------------------------------------
+// row sums in a FIXED tree (include/genmi.h: gmx_sum_rows): the plate score of a Vmap whose elements run on the
+// launch axis.  Stage 1, one block per (row, tile of 4096): thread t adds its 16 items t, t + 256, ... in that
+// order, the wave butterfly (xor 32, 16, ..., 1) and (w0 + w1) + (w2 + w3) give the tile's partial; stage 2, one
+// block per row: thread t adds partials t, t + 256, ... in order, then the same block tree.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(GMX_BLOCK)
+k_sum_tiles(const float* __restrict__ x, int64_t cols, int64_t tiles_per_row, float* __restrict__ partials) {
+  __shared__ float lds4[4];
+  const int64_t row = blockIdx.y, tile = blockIdx.x;
+  const float* xr = x + row * cols;
+  const int64_t base = tile * LSE_TILE;
+  float s = 0.0f;
+#pragma unroll
+  for (int k = 0; k < LSE_ITEMS; ++k) {
+    const int64_t j = base + (int64_t)k * GMX_BLOCK + threadIdx.x;
+    s += (j < cols) ? xr[j] : 0.0f;
+  }
+  s = block_sum(s, lds4);
+  if (threadIdx.x == 0) partials[row * tiles_per_row + tile] = s;
+}
+__global__ void __launch_bounds__(GMX_BLOCK)
+k_sum_final(const float* __restrict__ partials, int64_t n_part, float* __restrict__ out) {
+  __shared__ float lds4[4];
+  const int64_t row = blockIdx.x;
+  const float* p = partials + row * n_part;
+  float s = 0.0f;
+  for (int64_t j = threadIdx.x; j < n_part; j += GMX_BLOCK) s += p[j];
+  s = block_sum(s, lds4);
+  if (threadIdx.x == 0) out[row] = s;
+}
+extern "C" size_t gmx_sum_rows_workspace(int64_t rows, int64_t cols) {
+  if (rows <= 0 || cols <= 0) return 16;
+  return (size_t)(rows * ((cols + LSE_TILE - 1) / LSE_TILE) * sizeof(float)) + 16;
+}
+extern "C" int gmx_sum_rows(const float* x_d, int64_t rows, int64_t cols, float* out_d, void* workspace_d,
+                            gmx_stream stream) {
+  if (rows <= 0) return 0;
+  if (cols <= 0) return gmx_fail("gmx_sum_rows: cols must be positive%s");
+  if (!x_d || !out_d || !workspace_d) return gmx_fail("gmx_sum_rows: null argument%s");
+  if (rows > 65535) return gmx_fail("gmx_sum_rows: too many rows%s");
+  const int64_t tiles = (cols + LSE_TILE - 1) / LSE_TILE;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_sum_tiles, dim3((unsigned)tiles, (unsigned)rows), dim3(GMX_BLOCK), 0, st, x_d, cols, tiles,
+                     (float*)workspace_d);
+  hipLaunchKernelGGL(k_sum_final, dim3((unsigned)rows), dim3(GMX_BLOCK), 0, st, (const float*)workspace_d, tiles, out_d);
+  GMX_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
 // fixed-point weights + chained inclusive scan (single pass, decoupled look-back)
 //
 // Tile = 4096 log-weights (256 threads x 4 sub-tiles x float4), so 1e6

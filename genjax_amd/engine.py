@@ -1130,6 +1130,22 @@ def logsumexp_rows(lw: torch.Tensor) -> torch.Tensor:
     return out.reshape(lw.shape[:-1])
 
 
+def sum_rows(x) -> torch.Tensor:
+    """sum over the last axis in the device's fixed tree (gmx_sum_rows): the plate score of a launch-axis plate."""
+    be = _lib.get()
+    x = materialize(x)
+    cols = x.shape[-1]
+    rows = int(np.prod(x.shape[:-1], dtype=np.int64))
+    v = x.reshape(rows, cols)
+    if v.dtype != torch.float32:
+        v = v.float()
+    v = v.contiguous()
+    out = torch.empty((rows,), dtype=torch.float32, device=v.device)
+    ws = torch.empty((max(int(be.c.gmx_sum_rows_workspace(rows, cols)), 16) + 3) // 4, dtype=torch.int32, device=v.device)
+    be.check(be.c.gmx_sum_rows(be.ptr(v), rows, cols, be.ptr(out), be.ptr(ws), be.stream()), "gmx_sum_rows")
+    return out.reshape(x.shape[:-1])
+
+
 def categorical_rows(key: Key, logits: torch.Tensor) -> torch.Tensor:
     """One Gumbel-max index per row of logits[..., cols] (gmx_categorical_rows)."""
     be = _lib.get()

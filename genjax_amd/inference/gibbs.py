@@ -1,5 +1,14 @@
 """Enumerative Gibbs update of a discrete address (BASELINE config 5).
 
+Two entry points:
+
+  enumerative_gibbs(key, plate_trace, addr, K)   the Gibbs move on the trace of a PLATE (`generate_datapoint.vmap()` /
+      `.repeat(n=N)` called directly: its elements run on the launch axis, combinators.Vmap._launch_axis): every
+      element's `addr` is redrawn from its exact conditional and the trace is updated — the notebook's
+      `update_datapoint_assignment` for a model written with the Vmap combinator;
+  gibbs_categorical(key, gen_fn, args, choices, addr, K)   the fused draw underneath it: the lowering of
+      `categorical.simulate(key, vmap(vmap(assess)))` to ONE launch.
+
 Reference idiom (docs/cookbook/inactive/update/7_application_dirichlet_mixture_model.ipynb,
 cell 10, `update_datapoint_assignment`):
 
@@ -76,3 +85,35 @@ def gibbs_categorical(key: Key, gen_fn, args, choices: ChoiceMap, addr, n_catego
     comp, out = ent
     outs = comp.run(flat.leaves, batch, key, index_offset=int(index_offset))
     return resolve(out, outs, flat.leaves)
+
+
+def enumerative_gibbs(key: Key, trace, addr, n_categories: int):
+    """One enumerative Gibbs move on `addr` of EVERY element of a plate, through the GFI (the reference's
+    `update_datapoint_assignment`, 7_application_dirichlet_mixture_model.ipynb c10, for a model whose datapoints are a
+    `Vmap` plate): `trace` is the trace of `inner.vmap(...)` / `inner.repeat(n=...)` called directly (one key: its
+    elements are the launch axis).  As the notebook does:
+
+        key, subkey = split(key)
+        local_densities[j, k] = inner.assess(choices_j with addr := k, args_j)[0]        (never materialised)
+        new = categorical.simulate(key, (local_densities,))      ONE key: (j, k) draws its Gumbel from counter j K + k
+        new_trace = trace.update(subkey, C[addr].set(new))
+
+    Returns (new trace, the new values of `addr`, the update's weight)."""
+    from ..combinators import Vmap
+    from ..core.generative import Diff
+    from ..random import split
+    from ..static import VmapTrace
+    vm = trace.get_gen_fn()
+    if not isinstance(vm, Vmap) or not isinstance(trace, VmapTrace) or tuple(trace.batch_shape) != ():
+        raise TypeError("enumerative_gibbs: the trace of a Vmap / repeat plate called directly under one key")
+    args = tuple(trace.get_args() or ())
+    la = vm._launch_axis(None, args, None, ())
+    if la is None:
+        raise NotImplementedError("enumerative_gibbs: the plate is too small for the launch-axis form "
+                                  "(fewer elements than combinators.VMAP_LAUNCH_MIN)")
+    n, inner_args = la
+    key, subkey = split(key)
+    new = gibbs_categorical(key, vm.gen_fn, inner_args, trace.get_choices(), addr, n_categories, batch_shape=(n,))
+    addr_t = addr if isinstance(addr, tuple) else (addr,)
+    new_trace, w, _, _ = trace.update(subkey, ChoiceMap.empty().set(addr_t, new), Diff.no_change(args))
+    return new_trace, new, w

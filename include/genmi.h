@@ -194,6 +194,16 @@ int gmx_logsumexp(const float* lw_d, int64_t rows, int64_t cols, float* out_d,
                   gmx_stream stream);
 
 /* ------------------------------------------------------------------------
+ * Plate sums.  Replaces the `jnp.sum` over the plate axis of `Vmap.simulate / generate / assess / edit`
+ * (src/genjax/_src/generative_functions/combinators/vmap.py:180-218, 236-275) when the plate's elements run on the
+ * launch axis (one key, a large plate): out_d[r] = sum of x_d[r, 0:cols] in a FIXED tree — per tile of 4096 items
+ * thread t adds items t, t + 256, ... in order, a wave butterfly (xor 32 ... 1), (w0 + w1) + (w2 + w3); then the same
+ * over the tile partials.  Deterministic: the same bits on every run (the oracle restates the tree).
+ * ---------------------------------------------------------------------- */
+size_t gmx_sum_rows_workspace(int64_t rows, int64_t cols);
+int gmx_sum_rows(const float* x_d, int64_t rows, int64_t cols, float* out_d, void* workspace_d, gmx_stream stream);
+
+/* ------------------------------------------------------------------------
  * Resampling.  The reference has only the single-index Gumbel-max draw
  * (`ParticleCollection.sample_particle`, smc.py:102-109) and the cookbook's
  * O(N*K) SIR idiom (docs/cookbook/inactive/inference/importance_sampling.ipynb

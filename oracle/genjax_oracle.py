@@ -962,6 +962,39 @@ def gen(f):
     return StaticGenerativeFunction(f)
 
 
+def _block_sum_256(v):
+    """[..., 256] -> [...]: per wave of 64 the butterfly v += v[lane ^ m] for m = 32, 16, ..., 1 (lane 0's value), then
+    (w0 + w1) + (w2 + w3) — the device's block_sum (csrc/gmx_block.h), float32 throughout"""
+    v = np.asarray(v, np.float32).reshape(v.shape[:-1] + (4, 64))
+    lane = np.arange(64)
+    for m in (32, 16, 8, 4, 2, 1):
+        v = (v + v[..., lane ^ m]).astype(np.float32)
+    w = v[..., 0]
+    return ((w[..., 0] + w[..., 1]).astype(np.float32) + (w[..., 2] + w[..., 3]).astype(np.float32)).astype(np.float32)
+
+
+def plate_sum_tree(x):
+    """sum over the last axis in the fixed tree of gmx_sum_rows (include/genmi.h "Plate sums"): tiles of 4096 items —
+    thread t of 256 adds items t, t + 256, ..., t + 15 * 256 in that order, then the block tree; then thread t adds the
+    tile partials t, t + 256, ... in order and the block tree once more."""
+    x = np.asarray(x, np.float32)
+    n = x.shape[-1]
+    tiles = (n + 4095) // 4096
+    pad = np.zeros(x.shape[:-1] + (tiles * 4096 - n,), np.float32)
+    v = np.concatenate([x, pad], axis=-1).reshape(x.shape[:-1] + (tiles, 16, 256))
+    acc = np.zeros(x.shape[:-1] + (tiles, 256), np.float32)
+    for k in range(16):
+        acc = (acc + v[..., k, :]).astype(np.float32)
+    part = _block_sum_256(acc)                                   # [..., tiles]
+    rounds = (tiles + 255) // 256
+    pp = np.concatenate([part, np.zeros(x.shape[:-1] + (rounds * 256 - tiles,), np.float32)], axis=-1)
+    pp = pp.reshape(x.shape[:-1] + (rounds, 256))
+    acc = np.zeros(x.shape[:-1] + (256,), np.float32)
+    for r in range(rounds):
+        acc = (acc + pp[..., r, :]).astype(np.float32)
+    return _block_sum_256(acc)
+
+
 class VmapTrace:
     def __init__(self, gen_fn, inner, score, retval):
         self.gen_fn, self.inner, self.score, self.retval = gen_fn, inner, score, retval
@@ -1004,10 +1037,17 @@ class Vmap:
                 out.append(a)
         return tuple(out), n
 
+    LAUNCH_MIN = 4096      # BUILD-DEFINED: a plate this large under ONE key is summed in the launch-axis form's tree
+
     @staticmethod
     def _plate_sum(x, batch):
+        """the plate's score / weight: its elements' summed in element order — or, for a plate of at least LAUNCH_MIN
+        elements under ONE key (no batch), in the fixed tree of the build's launch-axis form (plate_sum_tree).  The
+        reference's `jnp.sum` (vmap.py:214-216) fixes no order: both are build definitions."""
         x = np.asarray(x, np.float32)
         x = np.broadcast_to(x, np.broadcast_shapes(x.shape, tuple(batch) + (x.shape[-1],)))
+        if tuple(batch) == () and x.shape[-1] >= Vmap.LAUNCH_MIN:
+            return plate_sum_tree(x)
         acc = np.zeros(x.shape[:-1], np.float32)
         for j in range(x.shape[-1]):
             acc = (acc + x[..., j]).astype(np.float32)

@@ -186,6 +186,36 @@ extern "C" int gmx_logsumexp(const float* lw, int64_t rows, int64_t cols, float*
   return 0;
 }
 
+// ---- row sums in the device's fixed tree (gmx_sum_rows) ----
+static float hs_block_sum(const float* v256) {
+  const float w0 = butterfly_sum64(v256), w1 = butterfly_sum64(v256 + 64), w2 = butterfly_sum64(v256 + 128), w3 = butterfly_sum64(v256 + 192);
+  return (w0 + w1) + (w2 + w3);
+}
+extern "C" size_t gmx_sum_rows_workspace(int64_t rows, int64_t cols) {
+  if (rows <= 0 || cols <= 0) return 16;
+  return (size_t)(rows * ((cols + 4095) / 4096) * sizeof(float)) + 16;
+}
+extern "C" int gmx_sum_rows(const float* x, int64_t rows, int64_t cols, float* out, void* ws, gmx_stream) {
+  if (rows <= 0) return 0;
+  if (cols <= 0 || !x || !out || !ws) return fail("sum_rows: bad argument");
+  const int64_t tiles = (cols + 4095) / 4096;
+  float* part = (float*)ws;
+  for (int64_t r = 0; r < rows; ++r) {
+    for (int64_t tile = 0; tile < tiles; ++tile) {
+      float v[256];
+      for (int t = 0; t < 256; ++t) {
+        float s = 0.0f;
+        for (int k = 0; k < 16; ++k) { const int64_t j = tile * 4096 + (int64_t)k * 256 + t; s += j < cols ? x[r * cols + j] : 0.0f; }
+        v[t] = s;
+      }
+      part[r * tiles + tile] = hs_block_sum(v);
+    }
+    float v[256];
+    for (int t = 0; t < 256; ++t) { float s = 0.0f; for (int64_t j = t; j < tiles; j += 256) s += part[r * tiles + j]; v[t] = s; }
+    out[r] = hs_block_sum(v);
+  }
+  return 0;
+}
 // ---- weights / cdf / ancestors ----
 extern "C" int gmx_ancestors(int kind, const uint32_t key[2], const uint64_t* cdf, int64_t n_in, uint64_t off,
                              const uint64_t* total_d, int64_t n_out_total, int64_t slot_offset, int64_t n_slots,

@@ -595,6 +595,59 @@ def check_mixture_assignments(n=3000, K=64, seed=11, specialize=False):
     return idx
 
 
+def check_mixture_gibbs_through_the_plate(n=5000, K=64, seed=11, timing=False):
+    """BASELINE config 5 THROUGH THE GFI (SURVEY 8f item 2's parenthetical): the datapoints are a
+    `generate_datapoint.repeat(n=N)` plate called directly (its elements on the launch axis), the initial trace comes
+    from `importance` with the observations constrained, and one assignment sweep is `gibbs.enumerative_gibbs` on that
+    trace — the notebook's `update_datapoint_assignment`: the new assignments equal the oracle's materialised [n, K]
+    categorical draw bit for bit, the updated trace holds them, its score is the oracle's re-assessment (fixed-tree
+    plate sum), and the weight is new score - old score."""
+    import time
+    import genjax_amd as G
+    from genjax_amd import ChoiceMapBuilder as C, workloads
+    from genjax_amd.inference import gibbs
+
+    class _ONP:
+        log = staticmethod(O.log)
+    dev = G._lib.get().device
+    x, guess, probs, z = workloads.mixture_data(n, K)
+    gd, ogd = workloads.make_mixture(G), workloads.make_mixture(O, jnp=_ONP)
+    plate = gd.repeat(n=n)
+    args = (torch.from_numpy(probs).to(dev), torch.from_numpy(guess).to(dev))
+    tr, w0 = plate.importance(G.key(seed), C["obs"].set(torch.from_numpy(x).to(dev)), args)
+    assert tuple(tr.batch_shape) == () and tuple(tr.get_choices()["idx"].shape) == (n,)
+    oplate = O.Repeat(ogd, n)
+    otr, ow0 = oplate.importance(O.key(seed), O.C.d({"obs": x}), (probs, guess))
+    assert np.array_equal(tr.get_choices()["idx"].cpu().numpy(), otr.get_choices()["idx"])        # the prior draws
+    assert float(w0) == float(ow0) and float(tr.get_score()) == float(otr.get_score())
+    new_tr, idx, w = gibbs.enumerative_gibbs(G.key(seed + 1), tr, "idx", K)
+    k1, _k2 = O.split(O.key(seed + 1))
+    oidx, _ = O.gibbs_categorical(k1, ogd, (probs, guess), O.C.d({"obs": x}), "idx", K, n)
+    assert np.array_equal(idx.cpu().numpy(), oidx)
+    assert np.array_equal(new_tr.get_choices()["idx"].cpu().numpy(), oidx)
+    assert np.array_equal(new_tr.get_choices()["obs"].cpu().numpy(), x)
+    so, _ = oplate.assess(O.C.d({"obs": x, "idx": oidx}), (probs, guess), ())
+    assert float(new_tr.get_score()) == float(so)
+    # (the weight is the fixed-tree sum of the per-element differences; against the difference of the two sums)
+    assert abs(float(w) - (float(so) - float(otr.get_score()))) <= 4e-6 * max(1.0, abs(float(so)), abs(float(otr.get_score())))
+    assert (oidx == z).mean() > 0.85
+    if not timing:
+        return None
+    sync = (lambda: torch.cuda.synchronize()) if dev.type == "cuda" else (lambda: None)
+
+    def timed(fn, reps=10):
+        fn(); sync()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        sync()
+        return (time.perf_counter() - t0) / reps
+    chm = C["obs"].set(torch.from_numpy(x).to(dev))
+    t_plate = timed(lambda: gibbs.enumerative_gibbs(G.key(seed + 1), tr, "idx", K))
+    t_bare = timed(lambda: gibbs.gibbs_categorical(G.key(seed + 1), gd, args, chm, "idx", K))
+    return t_plate, t_bare
+
+
 # ---------------------------------------------------------------------------
 # Scan combinator (SURVEY §8f item 1): a short state-space model as ONE generative function
 # ---------------------------------------------------------------------------
@@ -1347,6 +1400,80 @@ def check_scan_carry_forms(n=130, seed=21, Ts=(8, 17, 40)):
             (r0, r1), _ = r.get_retval()
             (or0, or1), _ = orr.get_retval()
             assert np.array_equal(r0.cpu().numpy(), or0) and np.array_equal(r1.cpu().numpy(), or1)
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def check_plate_on_the_launch_axis(n=10_000, seed=21, compare_batch_form=False):
+    """A LARGE plate under ONE key runs with its ELEMENTS on the launch axis (ref vmap.py:180-218 is jax.vmap: a plate
+    is as parallel as a particle batch): `model.vmap()` over n datapoints called directly —
+    simulate / importance / assess / Update.  Every choice and every per-element score equals the oracle's Vmap bit for
+    bit (element j's key is split(key, n)[j]); the plate's score / weight is the fixed-tree sum (gmx_sum_rows), which
+    the oracle restates (plate_sum_tree): equal bit for bit too.  A bare distribution under vmap likewise.
+    compare_batch_form: returns (seconds of the plate form, seconds of the same model run with the datapoints as the
+    particle batch) for the GPU test's 1.5x bound."""
+    import time
+    import genjax_amd as G
+    from genjax_amd import ChoiceMapBuilder as C, Diff, Update, combinators
+    dev = G._lib.get().device
+    assert n >= combinators.VMAP_LAUNCH_MIN == O.Vmap.LAUNCH_MIN
+    rng = np.random.default_rng(seed)
+    mus = rng.normal(0, 2, n).astype(np.float32)
+    ys = rng.normal(0, 3, n).astype(np.float32)
+
+    def mk(g):
+        @g.gen
+        def pt(mu, s):
+            z = g.normal(mu, s) @ "z"
+            y = g.normal(z, 1.0) @ "y"
+            return z + y
+        return pt
+    pt, opt = mk(G), mk(O)
+    v, ov = pt.vmap(in_axes=(0, None)), O.Vmap(opt, in_axes=(0, None))
+    args, oargs = (_t(mus, dev), 2.0), (mus, np.float32(2.0))
+    tr, otr = v.simulate(G.key(seed), args), ov.simulate(O.key(seed), oargs)
+    assert tuple(tr.batch_shape) == () and tuple(tr.get_choices()["z"].shape) == (n,)
+    for a in ("z", "y"):
+        assert np.array_equal(tr.get_choices()[a].cpu().numpy(), otr.get_choices()[a]), a
+    assert np.array_equal(tr.get_retval().cpu().numpy(), otr.get_retval())
+    assert float(tr.get_score()) == float(otr.get_score())
+    assert abs(float(tr.get_score()) - float(np.sum(np.asarray(otr.inner.get_score(), np.float64)))) <= 2e-6 * abs(float(otr.get_score()))
+    tri, w = v.importance(G.key(seed + 1), C["y"].set(_t(ys, dev)), args)
+    otri, ow = ov.importance(O.key(seed + 1), O.C.d({"y": ys}), oargs)
+    assert np.array_equal(tri.get_choices()["z"].cpu().numpy(), otri.get_choices()["z"])
+    assert float(w) == float(ow) and float(tri.get_score()) == float(otri.get_score())
+    s, r = v.assess(tri.get_choices(), args)
+    so, ro = ov.assess(otri.get_choices(), oargs, ())
+    assert float(s) == float(so) == float(tri.get_score()) and np.array_equal(r.cpu().numpy(), ro)
+    zs = rng.normal(0, 1, n).astype(np.float32)
+    new_tr, wu, _, bwd = Update(C["z"].set(_t(zs, dev))).edit(G.key(seed + 2), tri, Diff.no_change(args))
+    onew, owu, odisc = O.vmap_update(ov, O.key(seed + 2), otri, O.C.d({"z": zs}), oargs)
+    assert float(wu) == float(owu) and float(new_tr.get_score()) == float(onew.get_score())
+    assert np.array_equal(bwd.constraint["z"].cpu().numpy(), odisc["z"])
+    assert np.array_equal(new_tr.get_choices()["z"].cpu().numpy(), zs)
+    # a bare distribution under vmap: one vector-valued site, keys split(key, n)[j]
+    b, ob = G.normal.vmap(in_axes=(0, None)), O.Vmap(O.normal, in_axes=(0, None))
+    tb, otb = b.simulate(G.key(seed + 3), (_t(mus, dev), 0.5)), ob.simulate(O.key(seed + 3), (mus, np.float32(0.5)))
+    assert np.array_equal(tb.get_choices().get_value().cpu().numpy(), np.asarray(otb.get_choices().get_value()))
+    assert float(tb.get_score()) == float(otb.get_score())
+    if not compare_batch_form:
+        return None
+    sync = (lambda: torch.cuda.synchronize()) if dev.type == "cuda" else (lambda: None)
+
+    def timed(fn, reps=5):
+        fn(); sync()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        sync()
+        return (time.perf_counter() - t0) / reps
+    con = C["y"].set(_t(ys, dev))
+    t_plate = timed(lambda: v.importance(G.key(seed + 1), con, args))
+    keys = G.split(G.key(seed + 1), n)
+    t_batch = timed(lambda: pt.importance(keys, con, args))
+    return t_plate, t_batch
 
 
 def check_plates_long(n=130, P=40, seed=8, light=False):

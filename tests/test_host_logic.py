@@ -605,6 +605,20 @@ def test_scan_carries_that_forward_each_other(hostsim):
     parity.check_scan_carry_forms()
 
 
+def test_plate_on_the_launch_axis_matches_oracle():
+    """a plate of >= 4096 elements called directly under ONE key: its elements on the launch axis (combinators.Vmap.
+    _launch_axis); simulate / importance / assess / Update and the fixed-tree plate sums, bit-exact vs the oracle"""
+    from tests import parity
+    parity.check_plate_on_the_launch_axis(n=4096)
+    parity.check_plate_on_the_launch_axis(n=4096 * 3 + 17, seed=5)
+
+
+def test_config5_gibbs_sweep_through_the_plate():
+    """BASELINE config 5 through the GFI: generate_datapoint.repeat(n=N) + gibbs.enumerative_gibbs on its trace"""
+    from tests import parity
+    parity.check_mixture_gibbs_through_the_plate(n=5000)
+
+
 def test_large_plates_run_as_a_loop_and_match_oracle():
     """Vmap of more than 16 elements = a counted loop in the site program (ref vmap.py:180-218); incl. edits"""
     from tests import parity

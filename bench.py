@@ -259,7 +259,18 @@ def measure_roofline(be, sw, n, T, world, single, value):
 
     if single:
         us["sweep"] = time_launches(lambda: sw.enqueue(), reps=1)
-    if na:
+    fuse = single and bool(getattr(sw, "fuse", False))
+    if na and fuse:
+        # ONE chain launch per step: [resample step t-1 ; site program of step t] (gmx_run_args.rs)
+        us["chain_only_sweep"] = time_launches(lambda: sw._enqueue_noise_ahead(skip_noise=True), reps=1)
+        kernel_entry("gmx_jit_kernel", (VM_BYTES_PER_PARTICLE + 8) * n, us["k_vm"], us["chain_only_sweep"] / T,
+                     "ONE launch per step: the previous step's resampling (log-weight 4 in, ancestor 4 out) as the "
+                     "prologue of the site program (ancestor 4 + gathered state 4 in, state 4 + log-weight 4 out; + 4 B of "
+                     "noise read, not algorithmic); specialised: %s" % specialised)
+        kernel_entry("gmx_jit_background_kernel", 0, us["k_noise"], None,
+                     "noise program: 3 Threefry-2x32 blocks + erf_inv per draw, second stream; zero algorithmic bytes "
+                     "(SURVEY 8d: RNG contributes 0 B), writes 4 B per particle")
+    elif na:
         us["chain_only_sweep"] = time_launches(lambda: sw._enqueue_noise_ahead(skip_noise=True), reps=1)
         us["chain_only_sweep_without_site_program"] = time_launches(
             lambda: sw._enqueue_noise_ahead(skip_vm=True, skip_noise=True), reps=1)
@@ -273,6 +284,9 @@ def measure_roofline(be, sw, n, T, world, single, value):
         kernel_entry("gmx_jit_background_kernel", 0, us["k_noise"], None,
                      "noise program: 3 Threefry-2x32 blocks + erf_inv per draw, second stream; zero algorithmic bytes "
                      "(SURVEY 8d: RNG contributes 0 B), writes 4 B per particle")
+    elif single and fuse:
+        kernel_entry("gmx_jit_kernel", (VM_BYTES_PER_PARTICLE + 8) * n, us["k_vm"], us["sweep"] / T,
+                     "ONE launch per step: the previous step's resampling as the prologue of the site program")
     elif single:
         us["sweep_without_k_vm"] = time_launches(lambda: sw.enqueue(skip_vm=True), reps=1)
         vm_chain = (us["sweep"] - us["sweep_without_k_vm"]) / T
@@ -807,8 +821,8 @@ def main():
                                    f"(a multiple of {world} x 1024: shards start on a tile of the integer CDF)")),
                    "particles_per_gpu": n, "particles_total": total_particles, "T": T,
                    "resampler": "systematic", "graph": not args.no_graph and single,
-                   "path": ("BootstrapSweep (hipGraph" + (", noise ahead on a second stream)" if getattr(sw, "noise_ahead", False)
-                                                         else ")")) if single else
+                   "path": ("BootstrapSweep (hipGraph" + (", one launch per step" if getattr(sw, "fuse", False) else "")
+                            + (", noise ahead on a second stream)" if getattr(sw, "noise_ahead", False) else ")")) if single else
                    ("ShardedBootstrapSweep (" + str(getattr(getattr(sw, "cx", None), "name", "no communicator"))
                     + (", noise ahead on a second stream" if getattr(sw, "noise_ahead", False) else "") + ")"),
                    "key": seed},

@@ -26,6 +26,24 @@ RESAMPLE_SYSTEMATIC, RESAMPLE_STRATIFIED, RESAMPLE_MULTINOMIAL, RESAMPLE_MULTINO
 RESAMPLE_MULTINOMIAL_SORTED = 4
 
 
+class ResampleIn(Structure):
+    """struct gmx_resample_in: the previous step's resampling folded into a gathering site program's launch"""
+    _fields_ = [
+        ("lw_d", c_void_p),
+        ("tile_max_d", c_void_p),
+        ("tile_agg_d", c_void_p),
+        ("max_out_d", c_void_p),
+        ("total_out_d", c_void_p),
+        ("status_d", c_void_p),
+        ("shift", c_int32),
+        ("tag", c_uint32),
+        ("key0", c_uint32),
+        ("key1", c_uint32),
+        ("u0", c_uint32),
+        ("reserved_", c_uint32),
+    ]
+
+
 class Peer(Structure):
     """struct gmx_peer: the peers of a sharded SMC step (include/genmi.h "Fused peer exchange")"""
     _fields_ = [
@@ -61,6 +79,7 @@ class RunArgs(Structure):
         ("tile_shift", c_int32),
         ("reserved_", c_int32),
         ("step_stride", c_int64),
+        ("rs", ResampleIn),
         ("peer", Peer),
     ]
 
@@ -103,6 +122,8 @@ class Backend:
         c.gmx_program_run.argtypes = [c_void_p, c_int64, POINTER(RunArgs), c_void_p]
         c.gmx_program_writes_tile_stats.argtypes = [c_void_p]
         c.gmx_program_set_background.argtypes = [c_void_p, c_uint32]
+        c.gmx_program_set_fuse_resample.argtypes = [c_void_p]
+        c.gmx_program_fuses_resample.argtypes = [c_void_p]
         c.gmx_logsumexp_workspace.argtypes = [c_int64, c_int64]
         c.gmx_logsumexp_workspace.restype = c_size_t
         c.gmx_logsumexp.argtypes = [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]

@@ -19,6 +19,9 @@
 #include "gmx_block.h"
 #include "gmx_vm.h"
 #include "gmx_peer.h"
+#if defined(GMX_JIT_RS)      /* gmx_program_set_fuse_resample: the kernel can resample the previous step first */
+#include "gmx_offspring.h"
+#endif
 
 // a background program (gmx_program_set_background) keeps the default wave priority 0 and has a name of its own
 // (so that kernel traces tell the noise programs from the chain's site programs)
@@ -137,9 +140,45 @@ struct gmx_jit_ctx {
     }                                                                                            \
     (void)cidx; (void)arow; (void)pre; (void)gmx_t; (void)gmx_t0; (void)gmx_tf;
 
-// the ancestors of the thread's particles
+// the ancestors of the thread's particles: loaded — or, for a fused bootstrap step (gmx_run_args.rs), WRITTEN first
+// (this workgroup's tile of the previous step's resampling: gmx_offspring.h) and then polled until the words of this
+// workgroup's own particles carry the step's tag (workgroup-uniform branch)
+#if defined(GMX_JIT_RS)
+#define GMX_JIT_PRE_ANC                                                                          \
+    if (PP == 4 && A.rs.lw_d) {                                                                  \
+      gmx_offspring_tile_body<GMX_RESAMPLE_SYSTEMATIC, 4, true>(A.rs.key0, A.rs.key1, A.rs.u0, A.rs.lw_d, A.rs.tile_max_d, \
+          A.rs.tile_agg_d, n, (int)gridDim.x, gmx_pow2i(A.rs.shift), A.rs.max_out_d, A.rs.total_out_d,          \
+          const_cast<int32_t*>(A.ancestors_d), nullptr, A.rs.tag);                                \
+      const uint32_t* gmx_aw = reinterpret_cast<const uint32_t*>(A.ancestors_d);                 \
+      uint32_t gmx_av[PP];                                                                       \
+      bool gmx_ok = true;                                                                        \
+      _Pragma("unroll") for (int p = 0; p < PP; ++p) {                                           \
+        gmx_av[p] = __hip_atomic_load(gmx_aw + cidx[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
+        gmx_ok &= (gmx_av[p] >> GMX_ANC_TAG_SHIFT) == A.rs.tag;                                  \
+      }                                                                                          \
+      if (!gmx_ok) {                                                                             \
+        const uint64_t gmx_t0 = wall_clock64();                                                  \
+        do {                                                                                     \
+          __builtin_amdgcn_s_sleep(1);                                                           \
+          gmx_ok = true;                                                                         \
+          _Pragma("unroll") for (int p = 0; p < PP; ++p) {                                       \
+            gmx_av[p] = __hip_atomic_load(gmx_aw + cidx[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
+            gmx_ok &= (gmx_av[p] >> GMX_ANC_TAG_SHIFT) == A.rs.tag;                              \
+          }                                                                                      \
+        } while (!gmx_ok && wall_clock64() - gmx_t0 < 200000000ull);                             \
+        if (!gmx_ok) __hip_atomic_store(A.rs.status_d, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
+      }                                                                                          \
+      _Pragma("unroll") for (int p = 0; p < PP; ++p) {                                           \
+        const uint32_t gmx_i = gmx_av[p] & GMX_ANC_INDEX_MASK;                                   \
+        arow[p] = gmx_i < n32 ? gmx_i : n32 - 1u;                                                \
+      }                                                                                          \
+    } else {                                                                                     \
+      _Pragma("unroll") for (int p = 0; p < PP; ++p) arow[p] = (uint32_t)A.ancestors_d[cidx[p]]; \
+    }
+#else
 #define GMX_JIT_PRE_ANC                                                                          \
     _Pragma("unroll") for (int p = 0; p < PP; ++p) arow[p] = (uint32_t)A.ancestors_d[cidx[p]];
+#endif
 
 #define GMX_JIT_PRE_LOAD(K, SLOT, U8, ROW)                                                       \
     _Pragma("unroll") for (int p = 0; p < PP; ++p)                                               \

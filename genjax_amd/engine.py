@@ -793,15 +793,26 @@ class Compiled:
         gmx_program_set_background) — priority 0, `lds_pad` bytes of unused LDS per workgroup as a residency cap."""
         self._be.check(self._be.c.gmx_program_set_background(self.handle, int(lds_pad)), "gmx_program_set_background")
 
+    def is_specialized(self) -> bool:
+        return bool(self._be.c.gmx_program_is_specialized(self.handle))
+
+    def set_fuse_resample(self):
+        """Before specialize(): the kernel can resample the previous step first (include/genmi.h: gmx_run_args.rs)."""
+        self._be.check(self._be.c.gmx_program_set_fuse_resample(self.handle), "gmx_program_set_fuse_resample")
+
+    def fuses_resample(self) -> bool:
+        """True when `run(..., resample_in=...)` is honoured (include/genmi.h: gmx_program_fuses_resample)."""
+        return bool(self._be.c.gmx_program_fuses_resample(self.handle))
+
     def writes_tile_stats(self) -> bool:
         """True when a launch can also leave the CDF tile statistics (gmx_run_args.tile_agg_d): a specialised
         program running 4 particles per thread with exactly one block-max reduction."""
         return bool(self._be.c.gmx_program_writes_tile_stats(self.handle))
 
     def run(self, leaves, batch: tuple, key: Key | None, red_out=None, index_offset=0, out_buffers=None,
-            tile_stats=None, peer=None):
+            tile_stats=None, peer=None, resample_in=None):
         """Bind and launch.  Returns the list of output tensors (shape batch+event)."""
-        bound = self.bind(leaves, batch, key, red_out, index_offset, out_buffers, tile_stats, peer)
+        bound = self.bind(leaves, batch, key, red_out, index_offset, out_buffers, tile_stats, peer, resample_in)
         self.launch(bound)
         return bound[3]
 
@@ -820,13 +831,17 @@ class Compiled:
         be.check(be.c.gmx_program_run(self.handle, bound[0], bound[1], be.stream()), "gmx_program_run")
 
     def bind(self, leaves, batch: tuple, key: Key | None, red_out=None, index_offset=0, out_buffers=None,
-             tile_stats=None, peer=None):
+             tile_stats=None, peer=None, resample_in=None):
         """Fill a gmx_run_args for these leaves: (n, args, keep-alive list, outputs).  Sweeps whose
         buffers are persistent bind every step once and re-launch the bindings.
         tile_stats = (int64 tensor [grid], shift): the launch also writes the per-workgroup fixed-point weight sums
         gmx_resample_tiles consumes (only if `writes_tile_stats()`).
         peer = a _lib.Peer (with tile_stats): the launch also puts its tile statistics into the other ranks' landing
-        tables (include/genmi.h "Fused peer exchange")."""
+        tables (include/genmi.h "Fused peer exchange").
+        resample_in = dict(lw, tile_max, tile_agg, shift, key=(k0, k1), tag, max_out, total_out, status): the launch
+        first RESAMPLES the previous step (gmx_run_args.rs, `fuses_resample()`): every workgroup writes its tile's
+        offspring into the ancestors tensor the gathered leaves name (tagged words), waits for the words of its own
+        particles and gathers through them."""
         be = self._be
         n = int(np.prod(batch, dtype=np.int64))
         self._work = getattr(self, "_work", 0) + n
@@ -977,6 +992,16 @@ class Compiled:
             keep.append(agg)
             if peer is not None:
                 A.peer = peer
+        if resample_in is not None:
+            r = resample_in
+            if anc is None:
+                raise ValueError("resample_in: the program gathers nothing")
+            for name in ("lw", "tile_max", "tile_agg", "max_out", "total_out", "status"):
+                keep.append(r[name])
+            A.rs.lw_d, A.rs.tile_max_d, A.rs.tile_agg_d = r["lw"].data_ptr(), r["tile_max"].data_ptr(), r["tile_agg"].data_ptr()
+            A.rs.max_out_d, A.rs.total_out_d, A.rs.status_d = r["max_out"].data_ptr(), r["total_out"].data_ptr(), r["status"].data_ptr()
+            A.rs.shift, A.rs.tag = int(r["shift"]), int(r["tag"])
+            A.rs.key0, A.rs.key1 = int(r["key"][0]), int(r["key"][1])
         return n, A, keep, outs
 
 

@@ -499,6 +499,7 @@ def weight_cdf(lw: torch.Tensor, n_total=None, max_partials=None):
     return cdf, total, mx, shift
 
 
+FUSE_RESAMPLE_MAX = 1 << 20      # the resample-first launch: all its workgroups resident at once (1024 tiles)
 FUSED_RESAMPLE_MAX = 2048 * 1024        # RS_MAX_TILES tiles of 1024 particles (csrc/gmx_kernels.hip)
 
 
@@ -927,7 +928,7 @@ class BootstrapSweep(_NoiseAhead):
 
     def __init__(self, init, step, n_particles: int, T: int, obs_addr="y", resample="systematic",
                  step_extra=None, specialize=True, rejuvenate=None, state_addr="x", noise_ahead=None, chain_mh=True,
-                 noise_roots=None):
+                 noise_roots=None, fuse_resample=None):
         """chain_mh=False keeps the MH move and the extension as two launches (the form a chained program too large
         for the tile statistics falls back to); noise_roots: which keys' draws of the chained program the background
         stream takes ("LDKEY" = the move's proposal + accept draws, the default; "KSPLITU" = the extension's; "all").
@@ -944,6 +945,11 @@ class BootstrapSweep(_NoiseAhead):
         self.noise_ahead_req = noise_ahead
         self.chain_mh = bool(chain_mh)
         self.noise_roots = noise_roots or self.NOISE_ROOTS_MH
+        # ONE launch per step (None: when it applies): the program that gathers the resampled state first resamples the
+        # previous step itself — its workgroup's tile of k_offspring_tile, ancestors as tagged words its neighbours poll
+        # (include/genmi.h: gmx_run_args.rs) — so only the grid-wide dependency (the tile statistics) still needs a
+        # launch boundary.  Systematic resampling, n <= 2^20, specialised programs.
+        self.fuse_req = fuse_resample
 
     def prepare(self, key: Key, ys: torch.Tensor):
         from ..static import MinimalGenerate as _MG, NoiseProgram
@@ -985,6 +991,7 @@ class BootstrapSweep(_NoiseAhead):
         self.shift = cdf_shift(n)
         self.ws = torch.zeros(((be.c.gmx_weight_cdf_workspace(n) + 7) // 8,), dtype=torch.int64, device=dev)
         self.fused = self.kind in _TILE_KINDS and n <= (512 * 4096)
+        self.fuse = False
         if self.kind in (MULTINOMIAL_TILED, MULTINOMIAL_SORTED) and not self.fused:
             raise NotImplementedError("resample='multinomial_tiled' / 'multinomial_sorted': n <= 2^21 per GPU (use 'multinomial')")
         self.sorted_ws = torch.zeros((int(be.c.gmx_sorted_uniforms_words(n)),), dtype=torch.int32, device=dev) \
@@ -1063,6 +1070,21 @@ class BootstrapSweep(_NoiseAhead):
             # the steady-state program draws nothing ahead although another one would: the plain programs throughout
             self.noise_ahead_req = False
             return self.prepare(key, ys)
+        self.fused = self.kind in _TILE_KINDS and n <= (512 * 4096)
+        want_fuse = self.fuse_req
+        if want_fuse is None:
+            want_fuse = be.uses_streams
+        want_fuse = bool(want_fuse and self.specialize and self.kind == SYSTEMATIC and self.fused and n <= FUSE_RESAMPLE_MAX)
+        if self.rejuvenate is None:
+            gatherers = (self.p_step,)
+        elif self.p_mhvm_init is not None:
+            gatherers = (self.p_mhvm_init, self.p_mhvm_step)
+        else:
+            gatherers = ()
+        if want_fuse:
+            for p_ in gatherers:
+                if not p_.comp.is_specialized():
+                    p_.comp.set_fuse_resample()
         if self.specialize:
             self.p_init.comp.specialize()
             self.p_step.comp.specialize()
@@ -1091,6 +1113,20 @@ class BootstrapSweep(_NoiseAhead):
                                           "program does not fit the tile form")
             self.noise_ahead_req = False
             return self.prepare(key, ys)
+        # ONE launch per step where the gathering programs can resample first: two sets of log-weights / statistics (a
+        # launch reads step t-1's while it writes step t's)
+        self.fuse = bool(want_fuse and self.tile_stats and gatherers and (self.rejuvenate is None or self.fuse_mh)
+                         and all(p_.comp.fuses_resample() for p_ in gatherers))
+        if self.fuse_req and not self.fuse:
+            raise NotImplementedError("BootstrapSweep(fuse_resample=True): needs specialised 4-particles-per-thread programs "
+                                      "that gather, systematic resampling and n <= 2^20")
+        if self.fuse:
+            self.lw_pp = [self.lw, torch.zeros_like(self.lw)]
+            self.partials_pp = [self.partials, torch.zeros_like(self.partials)]
+            self.tile_agg_pp = [self.tile_agg, torch.zeros_like(self.tile_agg)]
+            self.rs_status = torch.zeros((1,), dtype=torch.int64, device=dev)
+        else:
+            self.lw_pp, self.partials_pp, self.tile_agg_pp = [self.lw] * 2, [self.partials] * 2, [self.tile_agg] * 2
         # per-step keys on the host
         self.step_keys = []
         for t in range(T):
@@ -1123,9 +1159,19 @@ class BootstrapSweep(_NoiseAhead):
                 bufs[o[1]] = self.x_store[t % 2][d:d + 1]
         else:
             bufs[prog.ro[1]] = self.x_store[t % 2]
-        bufs[prog.wo[1]] = self.lw.reshape(1, n)
-        prog.comp.run(leaves, (n,), lazy_split(k_prop, n), red_out=self.partials, out_buffers=bufs,
-                      tile_stats=(self.tile_agg, self.shift) if self.tile_stats else None)
+        w = t % 2 if self.fuse else 0
+        bufs[prog.wo[1]] = self.lw_pp[w].reshape(1, n)
+        prog.comp.run(leaves, (n,), lazy_split(k_prop, n), red_out=self.partials_pp[w], out_buffers=bufs,
+                      tile_stats=(self.tile_agg_pp[w], self.shift) if self.tile_stats else None,
+                      resample_in=self._resample_in(t) if (self.fuse and t >= 1 and self.rejuvenate is None) else None)
+
+    def _resample_in(self, t):
+        """gmx_run_args.rs of the launch of step t (>= 1) that gathers: resample step t-1's weights first"""
+        kh = self.step_keys[t - 1][1].host()
+        w = (t - 1) % 2
+        return dict(lw=self.lw_pp[w], tile_max=self.partials_pp[w], tile_agg=self.tile_agg_pp[w], shift=self.shift,
+                    key=(int(kh[0]), int(kh[1])), tag=1 + (t - 1) % 2047, max_out=self.maxs[t - 1:t],
+                    total_out=self.totals[t - 1:t], status=self.rs_status)
 
     def _chain_prog(self, t):
         if t == 0:
@@ -1175,9 +1221,11 @@ class BootstrapSweep(_NoiseAhead):
         bufs[prog.mo[1]] = self.xm_store[t % 2]
         bufs[prog.ao[1]] = self.accept.reshape(1, n)
         bufs[prog.ro[1]] = self.x_store[t % 2]
-        bufs[prog.wo[1]] = self.lw.reshape(1, n)
-        prog.comp.run(leaves, (n,), lazy_split(k_mh, n), red_out=self.partials, out_buffers=bufs,
-                      tile_stats=(self.tile_agg, self.shift) if self.tile_stats else None)
+        w = t % 2 if self.fuse else 0
+        bufs[prog.wo[1]] = self.lw_pp[w].reshape(1, n)
+        prog.comp.run(leaves, (n,), lazy_split(k_mh, n), red_out=self.partials_pp[w], out_buffers=bufs,
+                      tile_stats=(self.tile_agg_pp[w], self.shift) if self.tile_stats else None,
+                      resample_in=self._resample_in(t) if self.fuse else None)
 
     def _rows(self, t) -> int:
         """partial rows the site program of step t wrote"""
@@ -1284,8 +1332,9 @@ class BootstrapSweep(_NoiseAhead):
                      "gmx_resample_tiles_u")
             return
         if self.tile_stats:        # tile maxima = the workgroup maxima the site program left in partials[0]
-            be.check(be.c.gmx_resample_tiles(self.kind, kk, be.ptr(self.lw), self.n, self.shift,
-                                             be.ptr(self.partials), be.ptr(self.tile_agg),
+            w = t % 2 if self.fuse else 0
+            be.check(be.c.gmx_resample_tiles(self.kind, kk, be.ptr(self.lw_pp[w]), self.n, self.shift,
+                                             be.ptr(self.partials_pp[w]), be.ptr(self.tile_agg_pp[w]),
                                              be.ptr(self.maxs[t:t + 1]),
                                              be.ptr(self.totals[t:t + 1]), be.ptr(self.anc), be.stream()),
                      "gmx_resample_tiles")
@@ -1302,6 +1351,8 @@ class BootstrapSweep(_NoiseAhead):
                 self._launch_mhvm(t)
             else:
                 self._launch_vm(t)
+        if self.fuse and t < self.T - 1:
+            return                         # step t's weights are resampled by step t + 1's launch itself
         if self.fused:
             self._launch_resample(t)
         else:
@@ -1324,6 +1375,8 @@ class BootstrapSweep(_NoiseAhead):
                     self._launch_mh(t)
                 if not skip_vm:
                     self._launch_vm(t)
+            if self.fuse and t < self.T - 1:
+                continue                   # step t's weights are resampled by step t + 1's launch itself
             if self.fused:
                 self._launch_resample(t)
             else:
@@ -1336,7 +1389,9 @@ class BootstrapSweep(_NoiseAhead):
         out = {"k_vm": lambda: self._launch_vm(t)}
         if self.noise_ahead:
             out["k_noise"] = lambda: self._launch_noise(t)
-        if self.fused and self.tile_stats:
+        if self.fuse:
+            pass                           # (the resampler is the prologue of k_vm's launch)
+        elif self.fused and self.tile_stats:
             out["k_offspring_tile"] = lambda: self._launch_resample(t)
         elif self.fused:
             out["resample(k_tile_stats+k_offspring_tile)"] = lambda: self._launch_resample(t)
@@ -1382,4 +1437,7 @@ class BootstrapSweep(_NoiseAhead):
 
     def state(self):
         """(x_T particles before the last resampling, log-weights, last ancestors)."""
-        return self.x[(self.T - 1) % 2], self.lw, self.anc
+        if self.fuse and int(self.rs_status.item()) != 0:
+            raise RuntimeError("BootstrapSweep: a workgroup's wait for its ancestors timed out (the launch was not "
+                               "resident at once?): the sweep's results are not valid")
+        return self.x[(self.T - 1) % 2], self.lw_pp[(self.T - 1) % 2 if self.fuse else 0], self.anc

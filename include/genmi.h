@@ -107,6 +107,32 @@ enum {
   GMX_KEY_BCAST = 4     /* (key0,key1) for every particle                      */
 };
 
+/* The resampling of the PREVIOUS step folded into this launch (gmx_run_args.rs): with lw_d set, a specialised
+ * 4-particles-per-thread program that gathers (gmx_program_fuses_resample() == 1) does not find its ancestors in
+ * ancestors_d — it WRITES them there first: workgroup b runs gmx_resample_tiles' workgroup b (the tile's CDF rebuilt from
+ * the previous step's log-weights and tile statistics, the exact slot ranges, the LDS slot fill), storing every ancestor
+ * as {tag: bits 21..31 | index: bits 0..20} with a write-through store, and then POLLS the slots of its own particles
+ * until they carry the tag — they are filled by its neighbours of the same launch, mostly — before it gathers through
+ * them.  A bootstrap SMC step (smc.py:370-396's role; SURVEY.md App. B resampling) is then ONE launch instead of two:
+ * the grid-wide dependency (every tile's statistics) still rides on the launch boundary, the mostly-local one (who owns
+ * my slots) on tagged words.  Same integers as gmx_resample_tiles.  Every workgroup of the launch must be resident at
+ * once (they wait for each other): n <= 2^20 (1024 workgroups); a wait gives up after 2 s of the device's wall clock and
+ * sets *status_d.  The buffers read here must not be the ones this launch writes (log-weights, statistics: ping-pong);
+ * after the launch ancestors_d holds TAGGED words (index = word & 0x1fffff). */
+typedef struct gmx_resample_in {
+  const float* lw_d;              /* [n] log-weights of the previous step (16-byte aligned); NULL = not fused   */
+  const float* tile_max_d;        /* [ceil(n/1024)] m_b  (plane 0 of the previous launch's red_out_d)           */
+  const uint64_t* tile_agg_d;     /* [ceil(n/1024)] A_b  (the previous launch's tile_agg_d, same tile_shift)    */
+  float* max_out_d;               /* [1]: M      (as gmx_resample_tiles' max_d)                                 */
+  uint64_t* total_out_d;          /* [1]: total  (as gmx_resample_tiles' total_d)                               */
+  uint64_t* status_d;             /* [1]: sticky error word (a wait that timed out)                             */
+  int32_t shift;                  /* the CDF's fixed-point shift (= the previous launch's tile_shift)           */
+  uint32_t tag;                   /* 1 .. 2047, different from the previous launch's                            */
+  uint32_t key0, key1;            /* resampling key (systematic)                                                */
+  uint32_t u0;                    /* filled in by gmx_program_run: bits32(key, 0) >> 9                          */
+  uint32_t reserved_;
+} gmx_resample_in;
+
 /* The peers of a sharded SMC step ("Fused peer exchange", below): passed by value to the site program
  * (gmx_run_args.peer) and to gmx_shard_step_peer. */
 typedef struct gmx_peer {
@@ -145,6 +171,7 @@ typedef struct gmx_run_args {
   int32_t reserved_;
   int64_t step_stride;            /* elements between consecutive steps of a [T, n] leaf addressed with GMX_F_STEP inside
                                      an OP_LOOP (programs with a counted loop: the Scan combinator); normally n         */
+  gmx_resample_in rs;             /* optional (rs.lw_d != NULL): resample the previous step first, in this launch (above)  */
   gmx_peer peer;                  /* optional (peer.land_d != NULL), with tile_agg_d: the workgroup ALSO puts its tile's
                                      statistics straight into every other rank's landing table ("Fused peer exchange"
                                      below) — the all-gather of a sharded SMC step without a collective launch        */
@@ -168,6 +195,11 @@ int64_t gmx_program_grid(const gmx_program* p, int64_t n);
 /* 1 when the specialised kernel runs 4 particles per thread (a workgroup = one 1024-particle
  * tile of the CDF) and the program has exactly one OP_REDMAX: it then honours tile_agg_d. */
 int gmx_program_writes_tile_stats(const gmx_program* p);
+/* Ask, BEFORE gmx_program_specialize, for a kernel that can resample first (gmx_run_args.rs): the prologue lengthens the
+ * hiprtc compile, so only the programs a sweep chains ask for it.  gmx_program_fuses_resample: 1 once such a kernel
+ * exists (4 particles per thread, every gathered load through ancestors_d at the top of the kernel). */
+int gmx_program_set_fuse_resample(gmx_program* p);
+int gmx_program_fuses_resample(const gmx_program* p);
 /* Mark a program as BACKGROUND work before it is specialised: work that depends on nothing a dependent chain of
  * launches produces — e.g. the standard-normal draws of the next SMC steps (keys and particle indices only), which
  * BootstrapSweep's noise-ahead form issues on a second stream beside the chain [site program -> resampler].  The

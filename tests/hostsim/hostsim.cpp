@@ -51,7 +51,7 @@ extern "C" int gmx_random_bits(const uint32_t* keys, int64_t n, int64_t m, uint3
 
 
 // ---- programs ----
-struct gmx_program { std::vector<uint32_t> code, consts; uint32_t n_instr, n_regs, n_in, n_out, n_uni, n_tab, n_const, n_dyn; uint32_t n_redmax = 0, n_redlse = 0; };
+struct gmx_program { std::vector<uint32_t> code, consts; uint32_t n_instr, n_regs, n_in, n_out, n_uni, n_tab, n_const, n_dyn; uint32_t n_redmax = 0, n_redlse = 0; bool fuse_rs = false; };
 
 struct HostCtx {
   const uint32_t* code; const gmx_run_args* A;
@@ -108,6 +108,21 @@ static bool hs_tile_mode(const gmx_program* p) {
   return p && p->n_redmax == 1 && p->n_redlse == 0 && !(e && e[0] == '0');
 }
 extern "C" int gmx_program_writes_tile_stats(const gmx_program* p) { return hs_tile_mode(p) ? 1 : 0; }
+// the resample-first form of a gathering program (gmx_run_args.rs): the mirror resamples, TAGS the ancestors as the
+// device leaves them, and gathers through the masked indices
+static bool hs_gathers(const gmx_program* p) {
+  for (uint32_t pc = 0; pc < p->n_instr; ++pc) {
+    const uint32_t w0 = p->code[2 * pc];
+    if ((w0 & 0xffu) == OP_LDIN && ((w0 >> 24) & GMX_F_GATHER)) return true;
+  }
+  return false;
+}
+extern "C" int gmx_program_set_fuse_resample(gmx_program* p) {
+  if (!p) return fail("gmx_program_set_fuse_resample: null program");
+  p->fuse_rs = true;
+  return 0;
+}
+extern "C" int gmx_program_fuses_resample(const gmx_program* p) { return p && p->fuse_rs && hs_tile_mode(p) && hs_gathers(p) ? 1 : 0; }
 extern "C" int64_t gmx_program_grid(const gmx_program* p, int64_t n) { return hs_tile_mode(p) ? (n + 1023) / 1024 : (n + 255) / 256; }
 static uint64_t hs_weight_fixed(float lw, float ref, float scale);
 
@@ -118,6 +133,8 @@ static float butterfly_sum64(const float* v) {
 }
 
 #include "../../genjax_amd/csrc/gmx_peer.h"
+extern "C" int gmx_resample_tiles(int kind, const uint32_t key[2], const float* lw, int64_t n, int shift, const float* tmax,
+                                  const uint64_t* agg, float* max_d, uint64_t* total, int32_t* anc, gmx_stream st);
 static void hs_peer_put_tile(uint64_t* land, uint32_t tag, int world, int tiles, int src, int tile, uint64_t agg, float tmax) {
   uint64_t* row = land + gmx_peer_stats_at(tag, world, tiles, src, tile);
   __atomic_store_n(row + 0, gmx_granule((uint32_t)agg, tag), __ATOMIC_RELAXED);
@@ -131,6 +148,26 @@ extern "C" int gmx_program_run(const gmx_program* p, int64_t n, const gmx_run_ar
   const gmx_run_args* A = &patched;
   for (uint32_t s = 0; s < p->n_in; ++s) if (!A->in_d[s]) return fail("program_run: null input slot");
   for (uint32_t s = 0; s < p->n_out; ++s) if (!A->out_d[s]) return fail("program_run: null output slot");
+  std::vector<int32_t> rs_anc;
+  if (A->rs.lw_d) {          // resample the previous step first: gmx_resample_tiles, tagged ancestors, gather through them
+    const gmx_resample_in& q = A->rs;
+    if (!gmx_program_fuses_resample(p)) return fail("program_run: rs is set but this program cannot resample in its own launch");
+    if (!q.tile_max_d || !q.tile_agg_d || !q.max_out_d || !q.total_out_d || !q.status_d || !A->ancestors_d)
+      return fail("program_run: rs has a null pointer");
+    if (q.tag < 1u || q.tag > 2047u) return fail("program_run: rs.tag must be in [1, 2047]");
+    if ((n + 1023) / 1024 > 1024) return fail("program_run: rs: n <= 2^20");
+    if (A->tile_agg_d == q.tile_agg_d || (const float*)A->red_out_d == q.tile_max_d)
+      return fail("program_run: rs reads the tile statistics this launch writes (use two sets)");
+    for (uint32_t s_ = 0; s_ < p->n_out; ++s_)
+      if ((const void*)A->out_d[s_] == (const void*)q.lw_d) return fail("program_run: rs.lw_d is also an output of this launch");
+    const uint32_t key[2] = {q.key0, q.key1};
+    rs_anc.resize((size_t)n);
+    if (gmx_resample_tiles(GMX_RESAMPLE_SYSTEMATIC, key, q.lw_d, n, q.shift, q.tile_max_d, q.tile_agg_d, q.max_out_d,
+                           q.total_out_d, rs_anc.data(), nullptr)) return 1;
+    int32_t* tagged = const_cast<int32_t*>(A->ancestors_d);
+    for (int64_t i = 0; i < n; ++i) tagged[i] = (int32_t)((uint32_t)rs_anc[(size_t)i] | (q.tag << 21));
+    patched.ancestors_d = rs_anc.data();       // the program's gathers see the indices
+  }
   const bool tile = hs_tile_mode(p);
   if (A->tile_agg_d && !tile) return fail("program_run: tile_agg_d is set but this program cannot write tile statistics");
   const int G = tile ? 1024 : 256;                 // particles per workgroup

@@ -35,16 +35,18 @@ def oracle_bootstrap_sweep(init, step, n, T, ys, run_key, kind=O.SYSTEMATIC, ste
 
 
 def check_lgssm_sweep(n=4096, T=5, seed=314159, capture=False, specialize=True, resample="systematic",
-                      noise_ahead=None):
+                      noise_ahead=None, fuse_resample=None):
     import genjax_amd as G
     from genjax_amd import workloads
     from genjax_amd.inference.smc import BootstrapSweep
     ys = workloads.lgssm_data(T)
     init, step = workloads.make_lgssm(G)
-    sw = BootstrapSweep(init, step, n, T, specialize=specialize, resample=resample,
-                        noise_ahead=noise_ahead).prepare(G.key(seed), torch.from_numpy(ys))
+    sw = BootstrapSweep(init, step, n, T, specialize=specialize, resample=resample, noise_ahead=noise_ahead,
+                        fuse_resample=fuse_resample).prepare(G.key(seed), torch.from_numpy(ys))
     if noise_ahead is not None:
         assert sw.noise_ahead == noise_ahead, "the sweep did not take the requested (one- / two-stream) form"
+    if fuse_resample is not None:
+        assert sw.fuse == fuse_resample, "the sweep did not take the requested (one- / two-launch) form"
     if capture:
         sw.capture()
         sw.launch()              # a second replay must not see what the first one left (count buffers, ring slots)
@@ -1018,7 +1020,7 @@ def oracle_nlssm_mh_sweep(n, T, seed):
 
 
 def check_nlssm_mh_sweep(n=2000, T=5, seed=7, capture=False, specialize=False, want_chained=None, noise_ahead=None,
-                         chain_mh=True, noise_roots=None):
+                         chain_mh=True, noise_roots=None, fuse_resample=None):
     """BASELINE config 3 as ONE captured sweep: BootstrapSweep(rejuvenate=...) (k_vm -> resample ->
     fused MH -> k_vm ...) against the oracle run step by step with the sweep's key schedule
     (step key fold_in(key, t) -> (k_prop, k_res, k_mh); resampling of step t-1 uses ITS k_res)."""
@@ -1031,8 +1033,10 @@ def check_nlssm_mh_sweep(n=2000, T=5, seed=7, capture=False, specialize=False, w
     req = G.StaticRequest({"x": G.Rejuvenate(G.normal, lambda chm: (chm.get_value(), 0.5))})
     oreq = {"x": O.Rejuvenate(O.normal, lambda chm: (chm.get_value(), np.float32(0.5)))}
     sw = smc.BootstrapSweep(init, step, n, T, step_extra=lambda t: (float(t),), rejuvenate=req, specialize=specialize,
-                            noise_ahead=noise_ahead, chain_mh=chain_mh,
-                            noise_roots=noise_roots).prepare(G.key(seed), torch.from_numpy(ys))
+                            noise_ahead=noise_ahead, chain_mh=chain_mh, noise_roots=noise_roots,
+                            fuse_resample=fuse_resample).prepare(G.key(seed), torch.from_numpy(ys))
+    if fuse_resample is not None:
+        assert sw.fuse == fuse_resample
     if noise_ahead is not None:
         assert sw.noise_ahead == noise_ahead
         if noise_ahead:     # the move's proposal and accept draws (launch key) and / or the extension's draw (its own key)

@@ -1156,6 +1156,20 @@ def test_weight_fixed_matches_its_definition(tmp_path):
     assert "shift 62 done, mismatches so far 0" in out.stdout
 
 
+def test_sweep_with_the_resampler_in_the_next_step_launch():
+    """BootstrapSweep(fuse_resample=True): ONE launch per step — the program that gathers the resampled state first
+    resamples the previous step itself (gmx_run_args.rs: tagged ancestors; the C-ABI mirror resamples, tags and gathers
+    through the masked indices) — the same sweep bit for bit as the two-launch form and the oracle's: ragged sizes, one
+    tile, noise ahead, and with the chained MH move as the launch that resamples."""
+    from tests import parity
+    for kw in (dict(n=3000, T=5), dict(n=1024, T=3), dict(n=700, T=4), dict(n=3000, T=12, noise_ahead=True)):
+        res = parity.check_lgssm_sweep(specialize=True, fuse_resample=True, **kw)
+        assert res["ancestors_equal"] and res["x_equal"] and res["totals_equal"] and res["lw_max_abs_diff"] == 0.0, kw
+        assert abs(res["log_ml"] - res["log_ml_oracle"]) < 1e-11
+    parity.check_nlssm_mh_sweep(n=1500, T=5, specialize=True, fuse_resample=True, want_chained=True)
+    parity.check_nlssm_mh_sweep(n=1500, T=5, specialize=True, noise_ahead=True, fuse_resample=True)
+
+
 @pytest.mark.parametrize("chained", [False, True])
 def test_mh_sweep_with_the_move_chained_into_the_extension(chained):
     """BootstrapSweep(rejuvenate=..., chain_mh=): the MH move and the extension that follows it as one program

@@ -42,12 +42,13 @@ def step_blob(which="step"):
 def compile_blob(blob, out_prefix):
     so = os.path.join(ROOT, "genjax_amd", "lib", "libgenmi_hip.so")
     lib = ctypes.CDLL(so)
-    lib.gmx_specialize_dryrun.restype = ctypes.c_size_t
-    lib.gmx_specialize_dryrun.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t,
-                                          ctypes.c_char_p, ctypes.c_size_t]
+    lib.gmx_specialize_dryrun2.restype = ctypes.c_size_t
+    lib.gmx_specialize_dryrun2.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t,
+                                           ctypes.c_char_p, ctypes.c_size_t]
     log = ctypes.create_string_buffer(1 << 16)
     code = ctypes.create_string_buffer(8 << 20)
-    size = lib.gmx_specialize_dryrun(blob.ctypes.data, blob.size, log, len(log), code, len(code))
+    flags = int(os.environ.get("DUMP_ISA_FLAGS", "0"))       # 1: the resample-first prologue, 2: a background kernel
+    size = lib.gmx_specialize_dryrun2(blob.ctypes.data, blob.size, flags, log, len(log), code, len(code))
     if not size:
         raise SystemExit("hiprtc failed: " + log.value.decode())
     co = out_prefix + ".co"

@@ -1,9 +1,10 @@
-"""A/B of BootstrapSweep builds that differ in ONE environment switch, in one process on one box (config 2 by default;
+"""A/B of BootstrapSweep builds that differ in ONE constructor keyword, in one process on one box (config 2 by default;
 CONFIG=3: the nonlinear SSM with one MH move per step):
 
-  python tools/bench_ab.py GENMI_NOISE_AHEAD 0 1
+  python tools/bench_ab.py fuse_resample False True         (values are Python literals)
+  python tools/bench_ab.py noise_ahead False True
 
-Every variant is prepared and captured with the switch set to its value, the variants are then timed in turn
+Every variant is prepared and captured with the keyword set to its value, the variants are then timed in turn
 (ROUNDS rounds of REPS graph replays each, so that clock / thermal drift hits all of them alike) and their final
 particles, log-weights, ancestors and integer totals are compared.  One JSON line."""
 import json
@@ -35,10 +36,10 @@ else:
 if os.environ.get("RESAMPLE"):            # systematic (default) | stratified | multinomial
     kw["resample"] = os.environ["RESAMPLE"]
 sweeps, finals = {}, {}
+import ast
 for v in values:
-    os.environ[var] = v
     G.clear_caches()
-    sw = BootstrapSweep(init, step, n, T, **kw).prepare(G.key(314159), torch.from_numpy(ys))
+    sw = BootstrapSweep(init, step, n, T, **dict(kw, **{var: ast.literal_eval(v)})).prepare(G.key(314159), torch.from_numpy(ys))
     sw.capture()
     sw.launch()
     torch.cuda.synchronize()
@@ -55,7 +56,7 @@ for _ in range(rounds):
             sw.launch()
         torch.cuda.synchronize()
         times[v].append((time.perf_counter() - t0) / reps)
-out = {"switch": var, "n": n, "T": T, "config": cfg, "resample": os.environ.get("RESAMPLE", "systematic"),
+out = {"keyword": var, "n": n, "T": T, "config": cfg, "resample": os.environ.get("RESAMPLE", "systematic"),
        "us_per_step": {v: [round(1e6 * t / T, 3) for t in ts] for v, ts in times.items()},
        "best_us_per_step": {v: round(1e6 * min(ts) / T, 3) for v, ts in times.items()},
        "bit_identical": all(all(torch.equal(a, b) for a, b in zip(finals[values[0]], finals[v])) for v in values[1:])}

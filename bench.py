@@ -335,6 +335,82 @@ def measure_roofline(be, sw, n, T, world, single, value):
     }
 
 
+def config_workload(which: int):
+    """(run, units per call, unit name) of BASELINE config 3 / 4 / 5 exactly as `other_configs` times it — shared with
+    tools/run_config.py, which runs it under rocprofv3 for the instruction counts `other_configs` quotes."""
+    import numpy as np
+    import torch
+    import genjax_amd as G
+    from genjax_amd import ChoiceMapBuilder as C, numpy as jnp, workloads
+    from genjax_amd.inference import gibbs, smc
+    if which == 3:
+        n, T = N_PARTICLES, T_STEPS
+        init, step = workloads.make_nlssm(G)
+        req = G.StaticRequest({"x": G.Rejuvenate(G.normal, lambda chm: (chm.get_value(), 0.5))})
+        sw = smc.BootstrapSweep(init, step, n, T, step_extra=lambda t: (float(t),), rejuvenate=req).prepare(
+            G.key(7), torch.from_numpy(workloads.nlssm_data(T))).capture()
+        return {"run": sw.launch, "units": T, "unit": "step", "sweep": sw, "n": n, "T": T, "warm_units": T}         # capture() runs one eager sweep
+    if which == 4:
+        sig = [15.0, 10.0, 16.0, 11.0, 9.0, 11.0, 10.0, 18.0]
+        ysch = np.array([28, 8, -3, 7, -1, 1, 18, 12], np.float32)
+
+        @G.gen
+        def schools():
+            mu = G.normal(0.0, 5.0) @ "mu"
+            log_tau = G.normal(0.0, 1.0) @ "log_tau"
+            theta = G.normal(mu * jnp.ones(8), jnp.exp(log_tau) * jnp.ones(8)) @ "theta"
+            _ = G.normal(theta, jnp.array(sig)) @ "y"
+            return theta
+        k = 10_000_000
+        alg = smc.ImportanceK(G.Target(schools, (), C["y"].set(ysch)), k_particles=k)
+        box = {}
+
+        def run4():
+            c = alg.run_smc(G.key(2))
+            r = smc.resample(G.key(3), c, "systematic")
+            box["c"], box["theta"] = c, r.get_particles().get_choices()["theta"]     # materialises the gathered latents
+        return {"run": run4, "units": 1, "unit": "run", "alg": alg, "box": box, "k": k, "warm_units": 0}
+    if which == 5:
+        n, K = 1_000_000, 64
+        x, guess, probs, z = workloads.mixture_data(n, K)
+        gd = workloads.make_mixture(G)
+        args5 = (torch.from_numpy(probs).cuda(), torch.from_numpy(guess).cuda())
+        chm = C["obs"].set(torch.from_numpy(x).cuda())
+        box = {}
+
+        def run5():
+            box["idx"] = gibbs.gibbs_categorical(G.key(1), gd, args5, chm, "idx", K)
+        return {"run": run5, "units": 1, "unit": "sweep", "box": box, "n": n, "K": K, "z": z, "gd": gd, "args": args5,
+                "chm": chm, "warm_units": 0}
+    raise ValueError(which)
+
+
+def config_valu(name: str, seconds_per_unit: float):
+    """The vector-instruction issue of one of the other configs (they are ALU-bound: an HBM fraction says little):
+    SQ_INSTS_VALU of every kernel of the workload per unit (step / run / sweep), from the rocprofv3 PMC pass
+    tools/reproduce.sh took (profiles/counters.json `configs`, used only when taken on THIS library: sha256), over the
+    unit's time measured in this run; plus the dominant kernel's name and its duration in that profile."""
+    from genjax_amd import _lib
+    path = os.path.join(ROOT, "profiles", "counters.json")
+    try:
+        ent = json.load(open(path)).get("configs", {}).get(name)
+    except Exception:
+        ent = None
+    if not ent:
+        return {"valu_frac": None, "note": "no rocprofv3 counters for this config in profiles/counters.json"}
+    lib = _file_sha16(_lib.LIB_PATH)
+    if ent.get("lib") != lib:
+        return {"valu_frac": None, "note": f"profiles/counters.json `{name}` was taken on another library build "
+                                           f"({ent.get('lib')} != {lib}): not used"}
+    wave_insts = float(ent["valu_wave_insts_per_unit"])
+    rate = wave_insts * 64.0 / seconds_per_unit
+    return {"valu_wave_insts_per_unit": wave_insts, "unit": ent.get("unit"), "lane_ops_per_s": rate,
+            "valu_frac": rate / VALU_PEAK_LANE_OPS, "valu_frac_of_calibrated_ceiling": rate / VALU_CALIBRATED_LANE_OPS,
+            "dominant_kernel": ent.get("dominant_kernel"), "dominant_kernel_valu_insts_per_wave": ent.get("dominant_valu_per_wave"),
+            "dominant_kernel_us_in_profile": ent.get("dominant_avg_us"), "kernels": ent.get("kernels"),
+            "source": {"file": "profiles/counters.json", "tag": ent.get("tag"), "lib": lib}}
+
+
 def other_configs():
     """BASELINE configs 3 / 4 / 5 on this GPU, AFTER and outside the headline's timed region (a few seconds in all),
     so that the driver-visible record carries them too.  Each with its SURVEY 8(d) algorithmic bytes against 8 TB/s.
@@ -357,62 +433,38 @@ def other_configs():
         return (time.perf_counter() - t0) / reps
 
     try:        # ---- config 3: nonlinear SSM, 1e6 particles, T = 100, one Gaussian-drift MH move per step ----
-        n, T = N_PARTICLES, T_STEPS
-        init, step = workloads.make_nlssm(G)
-        req = G.StaticRequest({"x": G.Rejuvenate(G.normal, lambda chm: (chm.get_value(), 0.5))})
-        sw = smc.BootstrapSweep(init, step, n, T, step_extra=lambda t: (float(t),), rejuvenate=req).prepare(
-            G.key(7), torch.from_numpy(workloads.nlssm_data(T))).capture()
+        w3 = config_workload(3)
+        sw, n, T = w3["sweep"], w3["n"], w3["T"]
         dt = timed(sw.launch, 5)
         b = 52 * n * T          # 8(d): 32 B bootstrap step + 20 B MH move per particle-step
         out["config3"] = {"workload": "nonlinear SSM + one Rejuvenate MH move per step, BootstrapSweep(rejuvenate=...), "
                                       "1e6 particles x 100 steps, one hipGraph", "us_per_step": 1e6 * dt / T,
                           "particle_steps_per_s": n * T / dt, "algorithmic_bytes_per_particle_step": 52,
-                          "hbm_frac": b / dt / 1e9 / HBM_PEAK_GBS, "log_ml": sw.log_ml(),
-                          "noise_ahead": bool(sw.noise_ahead), "accept_rate_last_step": float(sw.accept.float().mean())}
-        del sw
+                          "hbm_frac": b / dt / 1e9 / HBM_PEAK_GBS, "valu": config_valu("config3", dt / T),
+                          "log_ml": sw.log_ml(), "noise_ahead": bool(sw.noise_ahead), "one_launch_per_step": bool(sw.fuse),
+                          "accept_rate_last_step": float(sw.accept.float().mean())}
+        del sw, w3
     except Exception as e:
         out["config3"] = {"error": repr(e)[:300]}
     try:        # ---- config 4: 8-schools, ImportanceK k = 1e7 + one global systematic resample ----
-        sig = [15.0, 10.0, 16.0, 11.0, 9.0, 11.0, 10.0, 18.0]
-        ysch = np.array([28, 8, -3, 7, -1, 1, 18, 12], np.float32)
-
-        @G.gen
-        def schools():
-            mu = G.normal(0.0, 5.0) @ "mu"
-            log_tau = G.normal(0.0, 1.0) @ "log_tau"
-            theta = G.normal(mu * jnp.ones(8), jnp.exp(log_tau) * jnp.ones(8)) @ "theta"
-            _ = G.normal(theta, jnp.array(sig)) @ "y"
-            return theta
-        k = 10_000_000
-        alg = smc.ImportanceK(G.Target(schools, (), C["y"].set(ysch)), k_particles=k)
-        box = {}
-
-        def run4():
-            c = alg.run_smc(G.key(2))
-            r = smc.resample(G.key(3), c, "systematic")
-            box["c"], box["theta"] = c, r.get_particles().get_choices()["theta"]     # materialises the gathered latents
-        dt = timed(run4, 3)
+        w4 = config_workload(4)
+        alg, box, k = w4["alg"], w4["box"], w4["k"]
+        dt = timed(w4["run"], 3)
         dti = timed(lambda: alg.run_smc(G.key(2)), 3)
         out["config4"] = {"workload": "8-schools ImportanceK k = 1e7 + one systematic resample + gather of theta",
                           "ms_total": 1e3 * dt, "ms_importance": 1e3 * dti, "particles_per_s": k / dt,
                           "algorithmic_bytes_per_particle": {"importance": 48, "resample_and_gather": 104},
                           "hbm_frac_importance": 48.0 * k / dti / 1e9 / HBM_PEAK_GBS,
-                          "hbm_frac_total": 152.0 * k / dt / 1e9 / HBM_PEAK_GBS,
+                          "hbm_frac_total": 152.0 * k / dt / 1e9 / HBM_PEAK_GBS, "valu": config_valu("config4", dt),
                           "log_ml": float(box["c"].get_log_marginal_likelihood_estimate())}
         box.clear()
+        del w4
     except Exception as e:
         out["config4"] = {"error": repr(e)[:300]}
     try:        # ---- config 5: mixture, K = 64 clusters, 1e6 datapoints: one assignment sweep ----
-        n, K = 1_000_000, 64
-        x, guess, probs, z = workloads.mixture_data(n, K)
-        gd = workloads.make_mixture(G)
-        args5 = (torch.from_numpy(probs).cuda(), torch.from_numpy(guess).cuda())
-        chm = C["obs"].set(torch.from_numpy(x).cuda())
-        box = {}
-
-        def run5():
-            box["idx"] = gibbs.gibbs_categorical(G.key(1), gd, args5, chm, "idx", K)
-        dt = timed(run5, 5)
+        w5 = config_workload(5)
+        n, K, z, gd, args5, chm, box = w5["n"], w5["K"], w5["z"], w5["gd"], w5["args"], w5["chm"], w5["box"]
+        dt = timed(w5["run"], 5)
         # ... and THROUGH THE GFI: the datapoints as a `generate_datapoint.repeat(n=N)` plate called directly (its
         # elements on the launch axis), the sweep = gibbs.enumerative_gibbs on the plate's trace (the fused draw + the
         # plate's Update): the notebook's update_datapoint_assignment for a model written with the Vmap combinator
@@ -426,7 +478,7 @@ def other_configs():
         out["config5"] = {"workload": "Dirichlet-categorical mixture, K = 64, 1e6 datapoints: one cluster-assignment "
                                       "sweep (gibbs_categorical: one launch, no [N, K] matrix)", "ms": 1e3 * dt,
                           "datapoints_per_s": n / dt, "gumbels_per_s": n * K / dt, "algorithmic_bytes_per_datapoint": 8,
-                          "hbm_frac": 8.0 * n / dt / 1e9 / HBM_PEAK_GBS,
+                          "hbm_frac": 8.0 * n / dt / 1e9 / HBM_PEAK_GBS, "valu": config_valu("config5", dt),
                           "note": "ALU-bound by design (64 Gumbels + 64 log-densities per datapoint; SURVEY 8d)",
                           "agrees_with_generating_component": float((box["idx"].cpu().numpy() == z).mean()),
                           "through_the_gfi": {

@@ -28,6 +28,58 @@ def short(name):
     return name.split("<")[0]
 
 
+def _git_head():
+    try:
+        import subprocess
+        return subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], text=True).strip()
+    except Exception:
+        return None
+
+
+def other_configs(tag, out_dir, ids):
+    """BASELINE configs 3 / 4 / 5 (tools/prof_config.sh): the process's total SQ_INSTS_VALU (wave instructions) per
+    workload unit, per kernel: instructions per wave, waves per launch, launches per unit, rocprofv3's average duration;
+    the kernel with the most GPU time is the dominant one.  `lib` = sha256 of the library the counters were taken on."""
+    res = {}
+    for k in (3, 4, 5):
+        root = os.path.join(out_dir, f"prof_{tag}_config{k}")
+        upath = os.path.join(out_dir, f"{tag}_config{k}_units_pmc.json")
+        if not os.path.isdir(root) or not os.path.exists(upath):
+            continue
+        try:
+            units = json.loads(open(upath).read().strip().splitlines()[-1])
+        except Exception:
+            continue
+        per = collections.defaultdict(lambda: collections.defaultdict(list))
+        for f in glob.glob(os.path.join(root, "pmc", "**", "*_counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                per[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        stats = {}
+        for f in glob.glob(os.path.join(root, "trace", "**", "*_kernel_stats.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                stats[short(r["Name"])] = (float(r["AverageNs"]) / 1e3, float(r["TotalDurationNs"]), int(r["Calls"]))
+        kernels, total = {}, 0.0
+        for name, c in per.items():
+            if "SQ_INSTS_VALU" not in c or name.startswith(("at::", "__amd")):
+                continue
+            valu, waves = sum(c["SQ_INSTS_VALU"]), sum(c.get("SQ_WAVES", [0]))
+            if valu <= 0:
+                continue
+            total += valu
+            kernels[name] = {"launches_per_unit": len(c["SQ_INSTS_VALU"]) / units["units"],
+                             "waves_per_launch": waves / max(1, len(c["SQ_INSTS_VALU"])),
+                             "valu_insts_per_wave": valu / max(1.0, waves),
+                             "avg_us_in_profile": stats.get(name, (None,))[0]}
+        if not kernels:
+            continue
+        dom = max(kernels, key=lambda n_: stats.get(n_, (0, 0.0, 0))[1])
+        res[f"config{k}"] = {"tag": tag, "lib": ids.get("libgenmi_hip.so"), "unit": units["unit"], "units_profiled": units["units"],
+                             "valu_wave_insts_per_unit": total / units["units"], "kernels": kernels, "dominant_kernel": dom,
+                             "dominant_valu_per_wave": kernels[dom]["valu_insts_per_wave"],
+                             "dominant_avg_us": kernels[dom]["avg_us_in_profile"]}
+    return res
+
+
 def main(tag):
     out_dir = os.path.join(ROOT, "gpurun_out")
     bench = json.load(open(os.path.join(out_dir, f"{tag}_bench.json")))
@@ -66,8 +118,8 @@ def main(tag):
             continue
         d["code_id"] = ids.get(k, ids.get("libgenmi_hip.so"))
         keep[k] = d
-    res = {"tag": tag, "commit": os.environ.get("GENMI_COMMIT"), "workload": bench["config"]["workload"],
-           "bench_value": bench["value"], "code_identity": ids, "kernels": keep}
+    res = {"tag": tag, "commit": os.environ.get("GENMI_COMMIT") or _git_head(), "workload": bench["config"]["workload"],
+           "bench_value": bench["value"], "code_identity": ids, "kernels": keep, "configs": other_configs(tag, out_dir, ids)}
     path = os.path.join(out_dir, f"{tag}_counters.json")
     json.dump(res, open(path, "w"), indent=1)
     print(json.dumps(res, indent=1)[:2500])

@@ -17,6 +17,7 @@ timeout 300 python tools/bench_noise_ahead.py 2> /dev/null | tail -1 > $out/${ta
 timeout 300 python tools/experiments/skewed_resample.py 2> /dev/null | tail -1 > $out/${tag}_skewed_resample.json
 timeout 600 bash tools/prof.sh $tag > $out/${tag}_pmc_summary.txt 2>&1
 timeout 600 bash tools/traffic.sh $tag > $out/${tag}_traffic.txt 2>&1
+for k in 3 4 5; do timeout 400 bash tools/prof_config.sh $tag $k > $out/${tag}_config${k}_prof.log 2>&1; done   # -> <tag>_config<k>_{pmc_summary.txt,kernel_stats.csv}
 python3 tools/make_counters.py $tag > $out/${tag}_counters.log 2>&1     # -> gpurun_out/<tag>_counters.json (copy to profiles/counters.json)
 timeout 300 python tools/bench_configs.py > $out/${tag}_configs_3_4.json 2> /dev/null
 timeout 300 python tools/bench_sweep3.py 2> /dev/null | grep "^{" > $out/${tag}_config3_native_sweep.json

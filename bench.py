@@ -761,9 +761,9 @@ def main():
                     help="only the timed sweeps (rocprofv3's kernel-trace pass: its per-kernel averages are then IN-SWEEP "
                          "durations, not mixed with the isolated timing loops of the roofline block)")
     ap.add_argument("--sharded", action="store_true", help="use the multi-GPU code path even at world size 1")
-    ap.add_argument("--fuse-resample", action="store_true",
-                    help="single GPU: ONE launch per step (the site program resamples the previous step first; "
-                         "BootstrapSweep(fuse_resample=True)) instead of the default two")
+    ap.add_argument("--two-launches", action="store_true",
+                    help="single GPU: the two-launch step [site program -> resampler] instead of the default ONE launch "
+                         "per step (the site program resamples the previous step first: BootstrapSweep(fuse_resample=...))")
     ap.add_argument("--weak", action="store_true",
                     help="N > 1: --particles PER GPU (weak scaling) instead of in total (strong scaling, the default)")
     args = ap.parse_args()
@@ -826,7 +826,7 @@ def main():
         else:
             n = ((n + world * 1024 - 1) // (world * 1024)) * 1024
     if single:
-        sw = BootstrapSweep(init, step, n, T, fuse_resample=bool(args.fuse_resample)).prepare(G.key(seed), torch.from_numpy(ys))
+        sw = BootstrapSweep(init, step, n, T, fuse_resample=False if args.two_launches else None).prepare(G.key(seed), torch.from_numpy(ys))
         if not args.no_graph:
             sw.capture()
         launch = sw.launch

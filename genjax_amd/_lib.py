@@ -159,6 +159,8 @@ class Backend:
         c.gmx_sorted_uniforms.argtypes = [c_void_p, c_int, c_int64, c_void_p, c_int, c_void_p]
         c.gmx_resample_sorted.argtypes = [POINTER(c_uint32), c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int,
                                           c_void_p, c_void_p, c_void_p, c_void_p]
+        c.gmx_resample_sorted_p.argtypes = [POINTER(c_uint32), c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int,
+                                          c_void_p, c_void_p, c_void_p, c_void_p]
         c.gmx_tile_prefix_words.argtypes = [c_int64]
         c.gmx_tile_prefix_words.restype = c_size_t
         c.gmx_tile_prefix.argtypes = [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]

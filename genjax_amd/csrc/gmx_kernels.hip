@@ -1566,7 +1566,6 @@ static int launch_offspring_tile(int kind, const uint32_t key[2], const float* l
   } while (0)
   if (kind == GMX_RESAMPLE_SYSTEMATIC) GMX_LAUNCH_OT(GMX_RESAMPLE_SYSTEMATIC);
   else if (kind == GMX_RESAMPLE_MULTINOMIAL_SORTED) {        // from the log-weights, the 977-fold statistics pass
-    if (pref) return gmx_fail("%s: the sorted multinomial reads the tile statistics, not their prefixes", "launch_offspring_tile");
     GMX_LAUNCH_OT(GMX_RESAMPLE_MULTINOMIAL_SORTED);
   }
   else GMX_LAUNCH_OT(GMX_RESAMPLE_STRATIFIED);
@@ -2043,8 +2042,8 @@ k_sorted_exp(const uint32_t* __restrict__ keys, uint32_t hk0, uint32_t hk1, int6
   if (threadIdx.x == 0) reinterpret_cast<uint64_t*>(row + L.off_tsum)[blockIdx.x] = all;
 }
 
-// one workgroup per resampling: the <= 2048 tile sums -> the tiles' offsets, S_total and sh (thread t owns the tiles
-// [t per, (t + 1) per): a u64 wave scan and four wave totals)
+// one workgroup per resampling: the tile sums -> the tiles' offsets, S_total and sh — in chunks of 2048 tiles (thread t
+// owns 8 consecutive tiles of a chunk: a u64 wave scan and four wave totals) with a running carry, so any n < 2^31
 __global__ void __launch_bounds__(GMX_BLOCK)
 k_sorted_offsets(const uint32_t* __restrict__ keys, uint32_t hk0, uint32_t hk1, int64_t n, size_t words, uint32_t* __restrict__ out) {
   __shared__ uint64_t s_w[GMX_BLOCK / GMX_WAVE];
@@ -2058,37 +2057,37 @@ k_sorted_offsets(const uint32_t* __restrict__ keys, uint32_t hk0, uint32_t hk1, 
   const uint64_t* tsum = reinterpret_cast<const uint64_t*>(row + L.off_tsum);
   uint64_t* toff = reinterpret_cast<uint64_t*>(row + L.off_toff);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int tiles = (int)L.tiles;
-  const int per = (tiles + GMX_BLOCK - 1) / GMX_BLOCK;                 // 1 .. 8, uniform
-  uint64_t tv[RS_MAX_TILES / GMX_BLOCK];
-  uint64_t run = 0;
+  const int64_t tiles = (int64_t)L.tiles;
+  constexpr int PERC = RS_MAX_TILES / GMX_BLOCK;                         // 8 tiles per thread and chunk
+  uint64_t carry = 0;
+  for (int64_t base = 0; base < tiles; base += RS_MAX_TILES) {          // block-uniform trip count (1 up to n = 2^21)
+    uint64_t tv[PERC];
+    uint64_t run = 0;
 #pragma unroll
-  for (int r = 0; r < RS_MAX_TILES / GMX_BLOCK; ++r) {
-    tv[r] = 0ull;
-    if (r < per) {
-      const int t = (int)threadIdx.x * per + r;
+    for (int r = 0; r < PERC; ++r) {
+      const int64_t t = base + (int64_t)threadIdx.x * PERC + r;
       const uint64_t v = tsum[t < tiles ? t : tiles - 1];
       tv[r] = (t < tiles) ? v : 0ull;
       run += tv[r];
     }
-  }
-  const uint64_t inc = wave_scan_u64(run);
-  if (lane == 63) s_w[wave] = inc;
-  __syncthreads();
-  uint64_t off = 0, all = 0;
+    const uint64_t inc = wave_scan_u64(run);
+    __syncthreads();
+    if (lane == 63) s_w[wave] = inc;
+    __syncthreads();
+    uint64_t off = 0, all = 0;
 #pragma unroll
-  for (int w = 0; w < GMX_BLOCK / GMX_WAVE; ++w) { const uint64_t v = s_w[w]; all += v; off += (w < wave) ? v : 0ull; }
-  uint64_t at = off + (inc - run);
+    for (int w = 0; w < GMX_BLOCK / GMX_WAVE; ++w) { const uint64_t v = s_w[w]; all += v; off += (w < wave) ? v : 0ull; }
+    uint64_t at = carry + off + (inc - run);
 #pragma unroll
-  for (int r = 0; r < RS_MAX_TILES / GMX_BLOCK; ++r) {
-    if (r < per) {
-      const int t = (int)threadIdx.x * per + r;
+    for (int r = 0; r < PERC; ++r) {
+      const int64_t t = base + (int64_t)threadIdx.x * PERC + r;
       if (t < tiles) toff[t] = at;
       at += tv[r];
     }
+    carry += all;
   }
   if (threadIdx.x == 0) {
-    const uint64_t stot = all + gmx_sorted_exp(key, (uint64_t)n);
+    const uint64_t stot = carry + gmx_sorted_exp(key, (uint64_t)n);
     toff[tiles] = stot;
     row[L.off_sh] = gmx_sorted_shift(stot, L.ng);
   }
@@ -2202,8 +2201,8 @@ static int launch_sorted_uniforms(const uint32_t* keys_d, const uint32_t* hkey, 
 extern "C" int gmx_sorted_uniforms(const uint32_t* keys_d, int rows, int64_t n, uint32_t* out_d, int lds_pad,
                                    gmx_stream stream) {
   if (!keys_d || !out_d) return gmx_fail("gmx_sorted_uniforms: null argument%s");
-  if (rows < 1 || rows > 65535 || n <= 0 || n > (int64_t)RS_MAX_TILES * RS_TILE)
-    return gmx_fail("gmx_sorted_uniforms: rows / n out of range (n <= 2^21)%s");
+  if (rows < 1 || rows > 65535 || n <= 0 || n >= 0x7fffffffLL - 4096)
+    return gmx_fail("gmx_sorted_uniforms: rows / n out of range%s");
   if (lds_pad < 0 || lds_pad > 64 * 1024) return gmx_fail("gmx_sorted_uniforms: lds_pad out of range (<= 64 KB)%s");
   if ((uintptr_t)out_d & 15) return gmx_fail("gmx_sorted_uniforms: out_d must be 16-byte aligned%s");
   return launch_sorted_uniforms(keys_d, nullptr, rows, n, out_d, lds_pad, stream);
@@ -2220,6 +2219,21 @@ extern "C" int gmx_resample_sorted(const uint32_t key[2], const float* lw_d, int
   if (!table_ready && launch_sorted_uniforms(nullptr, key, 1, n, table_d, 0, stream)) return 1;
   return launch_offspring_tile(GMX_RESAMPLE_MULTINOMIAL_SORTED, key, lw_d, n, shift, tile_max_d, tile_agg_d, max_d,
                                total_d, ancestors_d, stream, false, table_d);
+}
+
+// ... and past 2048 tiles (n > 2^21: BASELINE config 4's k = 1e7): the resampler reads the tile PREFIXES gmx_tile_prefix
+// wrote instead of reducing the statistics table in every workgroup
+extern "C" int gmx_resample_sorted_p(const uint32_t key[2], const float* lw_d, int64_t n, int shift, const float* tile_max_d,
+                                     const uint64_t* tile_pref_d, uint32_t* table_d, int table_ready, float* max_d,
+                                     uint64_t* total_d, int32_t* ancestors_d, gmx_stream stream) {
+  if (resample_shape("gmx_resample_sorted_p", n, shift, true)) return 1;
+  if (!key || !lw_d || !tile_max_d || !tile_pref_d || !table_d || !max_d || !total_d || !ancestors_d)
+    return gmx_fail("gmx_resample_sorted_p: null argument%s");
+  if (((uintptr_t)lw_d & 15) || ((uintptr_t)table_d & 15))
+    return gmx_fail("gmx_resample_sorted_p: lw_d and table_d must be 16-byte aligned%s");
+  if (!table_ready && launch_sorted_uniforms(nullptr, key, 1, n, table_d, 0, stream)) return 1;
+  return launch_offspring_tile(GMX_RESAMPLE_MULTINOMIAL_SORTED, key, lw_d, n, shift, tile_max_d, tile_pref_d, max_d,
+                               total_d, ancestors_d, stream, true, table_d);
 }
 
 extern "C" size_t gmx_tile_prefix_words(int64_t n) { return gmx_tile_prefix_words_(n); }

@@ -527,6 +527,14 @@ def resample_fused(kind, key: Key, lw: torch.Tensor):
             stats = (torch.empty((tiles,), dtype=torch.float32, device=lw.device),
                      torch.empty((tiles,), dtype=torch.int64, device=lw.device))
             be.check(be.c.gmx_tile_stats(be.ptr(lw), n, shift, be.ptr(stats[0]), be.ptr(stats[1]), be.stream()), "gmx_tile_stats")
+        if int(kind) == MULTINOMIAL_SORTED and n > FUSED_RESAMPLE_MAX:
+            # past 2048 tiles (config 4's k = 1e7): the tile prefixes from one workgroup, the table kernels in chunks
+            table = torch.empty((int(be.c.gmx_sorted_uniforms_words(n)),), dtype=torch.int32, device=lw.device)
+            pref = torch.empty((int(be.c.gmx_tile_prefix_words(n)),), dtype=torch.int64, device=lw.device)
+            be.check(be.c.gmx_tile_prefix(be.ptr(stats[0]), be.ptr(stats[1]), n, be.ptr(pref), be.stream()), "gmx_tile_prefix")
+            be.check(be.c.gmx_resample_sorted_p(kk, be.ptr(lw), n, shift, be.ptr(stats[0]), be.ptr(pref), be.ptr(table), 0,
+                                                be.ptr(mx), be.ptr(total), be.ptr(anc), be.stream()), "gmx_resample_sorted_p")
+            return anc, total, mx, shift
         if int(kind) == MULTINOMIAL_SORTED:
             table = torch.empty((int(be.c.gmx_sorted_uniforms_words(n)),), dtype=torch.int32, device=lw.device)
             be.check(be.c.gmx_resample_sorted(kk, be.ptr(lw), n, shift, be.ptr(stats[0]), be.ptr(stats[1]), be.ptr(table), 0,
@@ -597,10 +605,11 @@ def resample(key: Key, collection: ParticleCollection, kind="systematic", n_out=
     kind = _KINDS[kind] if isinstance(kind, str) else int(kind)
     n = lw.numel()
     if (kind in _TILE_KINDS and n_out in (None, n) and 0 < n <= FUSED_RESAMPLE_MAX) or \
-            (kind in (SYSTEMATIC, STRATIFIED) and n_out in (None, n) and FUSED_RESAMPLE_MAX < n < 2 ** 31 - 1024):
+            (kind in (SYSTEMATIC, STRATIFIED, MULTINOMIAL_SORTED) and n_out in (None, n) and FUSED_RESAMPLE_MAX < n < 2 ** 31 - 8192):
         anc, total, mx, shift = resample_fused(kind, key, lw)        # no CDF in memory (gmx_resample[_tiles[_p]])
     elif kind in (MULTINOMIAL_TILED, MULTINOMIAL_SORTED):
-        raise NotImplementedError("resample(kind='multinomial_tiled' / 'multinomial_sorted'): n_out = n <= 2^21 (use 'multinomial')")
+        raise NotImplementedError("resample(kind='multinomial_tiled'): n_out = n <= 2^21; 'multinomial_sorted': n_out = n "
+                                  "(use 'multinomial')")
     else:
         cdf, total, mx, shift = weight_cdf(lw)
         anc = ancestors_from_cdf(kind, key, cdf, total, n_out)

@@ -368,6 +368,10 @@ int gmx_sorted_uniforms(const uint32_t* keys_d /* [rows,2] */, int rows, int64_t
 int gmx_resample_sorted(const uint32_t key[2], const float* lw_d, int64_t n, int shift, const float* tile_max_d,
                         const uint64_t* tile_agg_d, uint32_t* table_d, int table_ready, float* max_d,
                         uint64_t* total_d, int32_t* ancestors_d, gmx_stream stream);
+/* the same past 2^21 particles: tile_pref_d = the prefix block gmx_tile_prefix made of the statistics (any n < 2^31) */
+int gmx_resample_sorted_p(const uint32_t key[2], const float* lw_d, int64_t n, int shift, const float* tile_max_d,
+                          const uint64_t* tile_pref_d, uint32_t* table_d, int table_ready, float* max_d,
+                          uint64_t* total_d, int32_t* ancestors_d, gmx_stream stream);
 int gmx_gather(const void* const* src_d, void* const* dst_d, const int32_t* elem_bytes,
                int32_t n_leaves, const int32_t* ancestors_d, int64_t n_out,
                gmx_stream stream);

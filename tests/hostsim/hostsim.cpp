@@ -515,7 +515,7 @@ static void hs_sorted_row(gmx_key k, int64_t n, uint32_t* row) {
   }
 }
 extern "C" int gmx_sorted_uniforms(const uint32_t* keys, int rows, int64_t n, uint32_t* out, int lds_pad, gmx_stream) {
-  if (!keys || !out || rows < 1 || n <= 0 || n > 2048 * HS_TILE || lds_pad < 0) return fail("sorted_uniforms: bad argument");
+  if (!keys || !out || rows < 1 || n <= 0 || lds_pad < 0) return fail("sorted_uniforms: bad argument");
   const size_t words = gmx_sorted_layout_of(n).words;
   for (int r = 0; r < rows; ++r) {
     gmx_key k; k.k0 = keys[2 * r]; k.k1 = keys[2 * r + 1];
@@ -523,10 +523,11 @@ extern "C" int gmx_sorted_uniforms(const uint32_t* keys, int rows, int64_t n, ui
   }
   return 0;
 }
-extern "C" int gmx_resample_sorted(const uint32_t key[2], const float* lw, int64_t n, int shift, const float* tmax,
-                                   const uint64_t* agg, uint32_t* table, int table_ready, float* max_d, uint64_t* total,
-                                   int32_t* anc, gmx_stream) {
-  if (!key || !lw || !tmax || !agg || !table || !max_d || !total || !anc || n <= 0 || n > 2048 * HS_TILE)
+// agg: the tile statistics A_b — or (prefixes = true) the prefix block of gmx_tile_prefix
+static int hs_resample_sorted(const uint32_t key[2], const float* lw, int64_t n, int shift, const float* tmax,
+                              const uint64_t* agg, bool prefixes, uint32_t* table, int table_ready, float* max_d, uint64_t* total,
+                              int32_t* anc) {
+  if (!key || !lw || !tmax || !agg || !table || !max_d || !total || !anc || n <= 0 || (!prefixes && n > 2048 * HS_TILE))
     return fail("resample_sorted: bad argument");
   gmx_key k; k.k0 = key[0]; k.k1 = key[1];
   const gmx_sorted_layout L = gmx_sorted_layout_of(n);
@@ -558,7 +559,7 @@ extern "C" int gmx_resample_sorted(const uint32_t key[2], const float* lw, int64
       run += hs_weight_fixed(lw[i], ref, scale);
       cdf[(size_t)i] = prefix + gmx_tile_scale(run, kb, K);
     }
-    prefix += gmx_tile_scale(agg[b], kb, K);
+    prefix = prefixes ? (b + 1 < tiles ? agg[b + 1] : agg[tiles]) : prefix + gmx_tile_scale(agg[b], kb, K);
   }
   *max_d = M; *total = prefix;
   if (prefix == 0) { for (int64_t j = 0; j < n; ++j) anc[j] = (int32_t)(n - 1); return 0; }
@@ -573,6 +574,16 @@ extern "C" int gmx_resample_sorted(const uint32_t key[2], const float* lw, int64
     anc[j] = (int32_t)i;
   }
   return 0;
+}
+extern "C" int gmx_resample_sorted(const uint32_t key[2], const float* lw, int64_t n, int shift, const float* tmax,
+                                   const uint64_t* agg, uint32_t* table, int table_ready, float* max_d, uint64_t* total,
+                                   int32_t* anc, gmx_stream) {
+  return hs_resample_sorted(key, lw, n, shift, tmax, agg, false, table, table_ready, max_d, total, anc);
+}
+extern "C" int gmx_resample_sorted_p(const uint32_t key[2], const float* lw, int64_t n, int shift, const float* tmax,
+                                     const uint64_t* pref, uint32_t* table, int table_ready, float* max_d, uint64_t* total,
+                                     int32_t* anc, gmx_stream) {
+  return hs_resample_sorted(key, lw, n, shift, tmax, pref, true, table, table_ready, max_d, total, anc);
 }
 extern "C" int gmx_resample(int kind, const uint32_t key[2], const float* lw, int64_t n, int shift, const float*,
                             int64_t, float* max_d, uint64_t* total, int32_t* anc, void* ws, gmx_stream st) {

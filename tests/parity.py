@@ -1987,6 +1987,25 @@ def check_multinomial_sorted(n=5000, seed=5, sigma=2.0, dead=False, spike=0.0, r
     return out
 
 
+def check_multinomial_sorted_big(n=(1 << 21) + 5000, seed=9, sigma=1.5):
+    """the sorted multinomial past 2^21 particles (BASELINE config 4's k = 1e7): tile statistics ->
+    gmx_tile_prefix -> gmx_resample_sorted_p (the resampler reads prefixes; the table's tile offsets are computed in
+    chunks with a running carry), through smc.resample — ancestors bit-exact vs the oracle's definition."""
+    import genjax_amd as G
+    from genjax_amd.inference import smc
+    dev = G._lib.get().device
+    rng = np.random.default_rng(seed)
+    lw = rng.normal(0, sigma, n).astype(np.float32)
+    assert n > smc.FUSED_RESAMPLE_MAX
+    anc, total, mx, shift = smc.resample_fused(smc.MULTINOMIAL_SORTED, G.key(seed + 1), torch.from_numpy(lw).to(dev))
+    cdf, ototal, M, oshift = O.weight_cdf_c(lw) if hasattr(O, "weight_cdf_c") else O.weight_cdf(lw)
+    assert shift == oshift and int(total.item()) & 0xFFFFFFFFFFFFFFFF == ototal and float(mx.item()) == M
+    want = O.ancestors_of_kind(O.MULTINOMIAL_SORTED, O.key(seed + 1), cdf)
+    got = anc.cpu().numpy()
+    assert np.array_equal(got, want), int((got != want).sum())
+    return int(np.unique(want).size)
+
+
 def check_nested_edge_cases():
     """two nested loops at their edges: a one-element plate and a 20-element plate of 40-step scans, `repeat(n=20)` of a
     scan, a VECTOR-valued site inside the inner loop ([n, A, T, 3] values: one [A * T, n] plane per element, written

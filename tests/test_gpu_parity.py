@@ -319,6 +319,13 @@ def test_importancek_and_vector_sites(gpu):
     assert lml == pytest.approx(float(oc.get_log_marginal_likelihood_estimate()), rel=2e-6)
 
 
+def test_config4_size_sorted_multinomial(gpu):
+    """BASELINE config 4's k = 1e7 resampled with `multinomial_sorted` (past 2^21 particles the
+    resampler reads tile prefixes and the table kernels walk the tiles in chunks): bit-exact vs the oracle"""
+    assert parity.check_multinomial_sorted_big(n=10_000_000, seed=3) > 1_000_000
+    assert parity.check_multinomial_sorted_big(n=(1 << 21) + 1, seed=4) > 100_000
+
+
 def test_config4_full_size_importancek_and_global_resample(gpu):
     """BASELINE config 4 at its full size on one GPU: 8-schools, ImportanceK with k = 1e7 particles,
     one global systematic resample (2442 scan tiles: the ticketed look-back path of k_weight_cdf).

@@ -1156,6 +1156,12 @@ def test_weight_fixed_matches_its_definition(tmp_path):
     assert "shift 62 done, mismatches so far 0" in out.stdout
 
 
+def test_sorted_multinomial_past_two_million_particles():
+    """multinomial_sorted for n > 2^21 (tile prefixes + chunked table offsets): bit-exact vs the oracle"""
+    from tests import parity
+    assert parity.check_multinomial_sorted_big() > 100_000
+
+
 def test_sweep_with_the_resampler_in_the_next_step_launch():
     """BootstrapSweep(fuse_resample=True): ONE launch per step — the program that gathers the resampled state first
     resamples the previous step itself (gmx_run_args.rs: tagged ancestors; the C-ABI mirror resamples, tags and gathers

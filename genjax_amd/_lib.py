@@ -127,6 +127,7 @@ class Backend:
         c.gmx_logsumexp_workspace.argtypes = [c_int64, c_int64]
         c.gmx_logsumexp_workspace.restype = c_size_t
         c.gmx_logsumexp.argtypes = [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]
+        c.gmx_sum_rows_inorder.argtypes = [c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p]
         c.gmx_sum_rows_workspace.argtypes = [c_int64, c_int64]
         c.gmx_sum_rows_workspace.restype = c_size_t
         c.gmx_sum_rows.argtypes = [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p]

@@ -32,6 +32,7 @@ from .tracer import Expr
 
 SCAN_UNROLL_MAX = 16      # longer scans run as a counted loop in the site program (Scan._trace_loop)
 VMAP_UNROLL_MAX = 16      # larger plates run as a counted loop too (Vmap._trace_loop): one iteration per element
+PATCH_DEPTH_MAX = 32        # engine.Patched chains longer than this are folded (see _vmap_edit_index_o1)
 VMAP_LAUNCH_MIN = 4096      # a plate this large called directly under ONE key runs with its elements on the launch axis
 NEST_UNROLL_MAX = 4       # an unrolled plate whose ELEMENT runs a counted loop keeps at most this many copies of it
 
@@ -828,7 +829,144 @@ def _vmap_edit(self, key, trace, edit_request, argdiffs):
     la = _vmap_edit_launch_axis(self, key, trace, edit_request, argdiffs)
     if la is not None:
         return la
+    o1 = _vmap_edit_index_o1(self, key, trace, edit_request, argdiffs)
+    if o1 is not None:
+        return o1
     return run_edit(self, key, trace, edit_request, argdiffs)
+
+
+def _trace_leaf_map(tr, fn, args=None):
+    """a trace of the same kind with `fn` applied to every value / score / return-value leaf"""
+    from collections import OrderedDict as OD
+    from .static import DistributionTrace, StaticTrace, VmapTrace, _tree_map_leaves
+    if isinstance(tr, DistributionTrace):
+        return DistributionTrace(tr.gen_fn, args if args is not None else tr.args, fn(tr.value), fn(tr.score))
+    if isinstance(tr, StaticTrace):
+        subs = OD((a, _trace_leaf_map(st, fn)) for a, st in tr.subtraces.items())
+        return StaticTrace(tr.gen_fn, args, _tree_map_leaves(tr.retval, lambda v: fn(v) if _is_leaf(v) else v), subs)
+    if isinstance(tr, VmapTrace):
+        return VmapTrace(tr.gen_fn, _trace_leaf_map(tr.inner, fn), fn(tr.score), _tree_map_leaves(tr.retval, lambda v: fn(v) if _is_leaf(v) else v), args)
+    raise TypeError(type(tr).__name__)
+
+
+def _trace_leaf_zip(old, new, fn, args=None):
+    """`fn(old leaf, new leaf)` leaf by leaf over two traces of the same structure"""
+    from collections import OrderedDict as OD
+    from .static import DistributionTrace, StaticTrace, VmapTrace
+    if isinstance(old, DistributionTrace):
+        return DistributionTrace(old.gen_fn, args if args is not None else old.args, fn(old.value, new.value), fn(old.score, new.score))
+    if isinstance(old, StaticTrace):
+        subs = OD((a, _trace_leaf_zip(st, new.subtraces[a], fn)) for a, st in old.subtraces.items())
+        return StaticTrace(old.gen_fn, args, _tree_zip(old.retval, new.retval, fn), subs)
+    if isinstance(old, VmapTrace):
+        return VmapTrace(old.gen_fn, _trace_leaf_zip(old.inner, new.inner, fn), fn(old.score, new.score),
+                         _tree_zip(old.retval, new.retval, fn), args)
+    raise TypeError(type(old).__name__)
+
+
+def _is_leaf(v):
+    import torch
+    from .engine import Gathered, Patched
+    return isinstance(v, (torch.Tensor, Gathered, Patched))
+
+
+def _tree_zip(a, b, fn):
+    import dataclasses
+    if dataclasses.is_dataclass(a) and not isinstance(a, type) and not getattr(a, "__gmx_static__", False):
+        return dataclasses.replace(a, **{f_.name: _tree_zip(getattr(a, f_.name), getattr(b, f_.name), fn) for f_ in dataclasses.fields(a)})
+    if isinstance(a, (tuple, list)):
+        return type(a)(_tree_zip(x, y, fn) for x, y in zip(a, b))
+    if isinstance(a, dict):
+        return {k: _tree_zip(a[k], b[k], fn) for k in a}
+    return fn(a, b) if _is_leaf(a) else b
+
+
+def _vmap_edit_index_o1(self, key, trace, request, argdiffs):
+    """`IndexRequest(idx, sub)` on a LONG plate held per particle, in O(1) elements (vmap.py:277-332 `edit_index`: a
+    dynamic_slice of the trace at idx, the sub-request on that slice with the caller's key, a dynamic_update_slice back):
+    the element is sliced out of every leaf (a row of the [n, B] layout for a Python-int idx; one row per particle for
+    an index tensor), `sub` edits that ONE element as a trace of the inner function over the particle batch, and the
+    new plate trace shares every other element with the old one (engine.Patched leaves; its score is the in-order sum
+    of the patched per-element scores, computed when asked: engine.PlateScore).  The counted-loop form this replaces
+    re-scored all n elements of every particle under a mask.  Unchanged arguments only (else: the loop form)."""
+    import torch
+    from .core.generative import Diff, IndexRequest
+    from .engine import Deferred, Patched, PlateScore, materialize, sum_rows_inorder
+    from .static import StaticGenerativeFunction, StaticTrace, VmapTrace
+    if not isinstance(request, IndexRequest) or not isinstance(trace, VmapTrace) or len(trace.batch_shape) != 1:
+        return None
+    if argdiffs is not None and not Diff.static_check_no_change(argdiffs):
+        return None
+    if not isinstance(trace.inner, StaticTrace) or not isinstance(self.gen_fn, (StaticGenerativeFunction, Vmap)):
+        return None                    # (a bare distribution, a scan, a switch as the element: the loop form)
+    args = tuple(Diff.tree_primal(argdiffs)) if argdiffs is not None else tuple(trace.get_args() or ())
+    try:
+        axes = self._axes(args)
+        n = self._plate_size(args, axes)
+    except NotImplementedError:
+        return None
+    if n <= VMAP_UNROLL_MAX:
+        return None
+    idx = request.idx
+    B = int(trace.batch_shape[0])
+    if isinstance(idx, torch.Tensor):
+        if tuple(idx.shape) != (B,):
+            return None
+    elif not (0 <= int(idx) < n):
+        raise IndexError(f"IndexRequest: index {idx} out of range for a plate of {n} elements")
+    for a, ax in zip(args, axes):           # mapped arguments as tensors (per-element rows to pick from)
+        pairs = []
+        _tree_leaves_with_axes(a, ax, pairs)
+        if any(x is not None and not isinstance(leaf, (torch.Tensor, np.ndarray)) for leaf, x in pairs):
+            return None
+
+    def arg_at(v):
+        if isinstance(idx, int):
+            e = v[idx]
+            return e.item() if isinstance(e, np.generic) else (np.asarray(e) if isinstance(v, np.ndarray) else e)
+        if isinstance(v, np.ndarray):            # a host table: one row per particle, on the device
+            v = torch.as_tensor(np.asarray(v), device=idx.device)
+        return v[idx.to(torch.int64)]            # [B, ...]
+    args_i = tuple(_tree_take_axes(a, ax, arg_at) for a, ax in zip(args, axes))
+
+    def take(v):
+        if isinstance(v, Patched):
+            return v.take(idx)
+        v = materialize(v)
+        if not isinstance(v, torch.Tensor) or v.ndim < 2 or v.shape[0] != B or v.shape[1] != n:
+            return v
+        return v[:, idx] if isinstance(idx, int) else v[torch.arange(B, device=v.device), idx.to(torch.int64)]
+    inner_i = _trace_leaf_map(trace.inner, take, args=args_i)
+    if isinstance(self.gen_fn, Vmap):      # a plate of plates: the element is itself a plate trace over the particle batch
+        st = StaticTrace(self.gen_fn.gen_fn, None, inner_i.retval, inner_i.subtraces)
+        inner_i = VmapTrace(self.gen_fn, st, PlateScore(lambda st=st: st.get_score(), batch=(B,)), inner_i.retval, args_i)
+    new_i, w, retdiff, bwd = request.request.edit(key, inner_i, Diff.no_change(args_i))
+
+    def patch(old, new):
+        # (a chain of patches is read through element by element; past PATCH_DEPTH_MAX it is folded into one whole leaf,
+        #  so a sweep over all n elements of the plate copies each leaf n / PATCH_DEPTH_MAX times, not n)
+        base = old if isinstance(old, Patched) and old.depth < PATCH_DEPTH_MAX else materialize(old)
+        shp = tuple(base.shape)
+        rows = torch.as_tensor(materialize(new), device=base.device).to(base.dtype)     # (a constraint may be launch-uniform)
+        return Patched(base, idx, rows.expand(shp[:1] + shp[2:]))
+    new_inner = _trace_leaf_zip(trace.inner, new_i, patch, args=None)
+    # the per-element scores of the plate (the inner trace's score: [B, n]), patched at idx
+    elem_old = getattr(trace, "_elem_scores", None)
+    if elem_old is None:               # (deferred: the edit itself does not read them, the new trace's score does)
+        def elem_scores(inner=trace.inner):
+            es = materialize(inner.get_score())
+            while es.ndim > 2:         # a plate of plates: the elements' scores are the inner plates' in-order sums
+                lead = tuple(es.shape[:-1])
+                es = sum_rows_inorder(es.reshape(-1, es.shape[-1])).reshape(lead)
+            return es
+        elem_old = Deferred(elem_scores, (B, n))
+    if isinstance(elem_old, Patched) and elem_old.depth >= PATCH_DEPTH_MAX:
+        elem_old = elem_old.materialize()
+    elem_new = Patched(elem_old, idx, materialize(new_i.get_score()))
+    out = VmapTrace(self, new_inner, PlateScore(elem_new), new_inner.retval, args)
+    out._elem_scores = elem_new
+    return out, w, Diff.unknown_change(out.retval) if not Diff.static_check_no_change(retdiff) else Diff.no_change(out.retval), \
+        IndexRequest(idx, bwd)
 
 
 def _vmap_edit_launch_axis(self, key, trace, request, argdiffs):

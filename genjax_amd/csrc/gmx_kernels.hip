@@ -895,6 +895,26 @@ k_sum_final(const float* __restrict__ partials, int64_t n_part, float* __restric
   s = block_sum(s, lds4);
   if (threadIdx.x == 0) out[row] = s;
 }
+// out[r] = ((x[r, 0] + x[r, 1]) + x[r, 2]) + ... in ELEMENT ORDER (one thread per row): the score of a plate held per
+// particle (the counted loop's own order), recomputed after one of its elements changed
+__global__ void __launch_bounds__(GMX_BLOCK)
+k_sum_rows_inorder(const float* __restrict__ x, int64_t rows, int64_t cols, int64_t sr, int64_t sc, float* __restrict__ out) {
+  const int64_t r = (int64_t)blockIdx.x * GMX_BLOCK + threadIdx.x;
+  if (r >= rows) return;
+  const float* p = x + r * sr;
+  float acc = 0.0f;
+  for (int64_t c = 0; c < cols; ++c) acc += p[c * sc];
+  out[r] = acc;
+}
+extern "C" int gmx_sum_rows_inorder(const float* x_d, int64_t rows, int64_t cols, int64_t stride_row, int64_t stride_col,
+                                    float* out_d, gmx_stream stream) {
+  if (rows <= 0) return 0;
+  if (cols < 0 || !x_d || !out_d) return gmx_fail("gmx_sum_rows_inorder: bad argument%s");
+  hipLaunchKernelGGL(k_sum_rows_inorder, grid_for(rows), dim3(GMX_BLOCK), 0, (hipStream_t)stream, x_d, rows, cols, stride_row,
+                     stride_col, out_d);
+  GMX_HIP(hipGetLastError());
+  return 0;
+}
 extern "C" size_t gmx_sum_rows_workspace(int64_t rows, int64_t cols) {
   if (rows <= 0 || cols <= 0) return 16;
   return (size_t)(rows * ((cols + LSE_TILE - 1) / LSE_TILE) * sizeof(float)) + 16;

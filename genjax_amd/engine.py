@@ -55,6 +55,84 @@ class Gathered:
         return gather_leaves([self.source], self.ancestors)[0]
 
 
+class Patched:
+    """`base` ([B, n, *event]: a plate trace's leaf) with element idx of every particle replaced by `rows` ([B, *event]),
+    kept LAZY: an IndexRequest on a long plate edits ONE element (vmap.py:277-332 slices it with dynamic_slice and
+    writes it back with dynamic_update_slice), and the new trace shares every other element with the old one instead
+    of copying n of them per leaf.  `idx`: a Python int or one index per particle ([B] integer tensor).  A consumer
+    that needs the whole leaf materialises it (one clone + one row store, cached); the next IndexRequest reads its
+    element through the patch."""
+
+    def __init__(self, base, idx, rows):
+        self.base, self.idx, self.rows = base, idx, rows
+        self._full = None
+        self.depth = base.depth + 1 if isinstance(base, Patched) else 1
+
+    @property
+    def shape(self):
+        return tuple(self.base.shape)
+
+    @property
+    def dtype(self):
+        return self.base.dtype
+
+    @property
+    def device(self):
+        return self.rows.device
+
+    @property
+    def ndim(self):
+        return len(self.base.shape)
+
+    def take(self, j):
+        """element j of every particle ([B, *event]); j: int or [B] integer tensor"""
+        if self._full is not None:
+            return _take_plate(self._full, j)
+        old = self.base.take(j) if isinstance(self.base, Patched) else _take_plate(self.base, j)
+        if isinstance(j, int) and isinstance(self.idx, int):
+            return self.rows if j == self.idx else old
+        ji = j if isinstance(j, torch.Tensor) else torch.full_like(self.idx, int(j))
+        hit = (ji.to(torch.int64) == (self.idx.to(torch.int64) if isinstance(self.idx, torch.Tensor) else int(self.idx)))
+        return torch.where(hit.reshape(hit.shape + (1,) * (self.rows.ndim - 1)), self.rows, old)
+
+    def materialize(self) -> torch.Tensor:
+        if self._full is None:          # ONE clone of the oldest whole leaf, then the chain's patches oldest first
+            chain, node = [], self
+            while isinstance(node, Patched) and node._full is None:
+                chain.append(node)
+                node = node.base
+            out = (node._full if isinstance(node, Patched) else materialize(node)).clone()
+            if out.device != self.rows.device:
+                raise ValueError("Patched: the leaf and its new rows live on different devices")
+            rows_all = torch.arange(out.shape[0], device=out.device)
+            for p in reversed(chain):
+                if isinstance(p.idx, int):
+                    out[:, p.idx] = p.rows
+                else:
+                    out[rows_all, p.idx.to(torch.int64)] = p.rows
+            self._full = out
+        return self._full
+
+
+class Deferred:
+    """a device tensor computed when somebody needs it (a plate's per-element scores: only a score read needs them)"""
+
+    def __init__(self, fn, shape, dtype=torch.float32):
+        self._fn, self.shape, self.dtype, self._v = fn, tuple(shape), dtype, None
+
+    def materialize(self) -> torch.Tensor:
+        if self._v is None:
+            self._v, self._fn = self._fn(), None
+        return self._v
+
+
+def _take_plate(t, j):
+    t = materialize(t)
+    if isinstance(j, int):
+        return t[:, j]
+    return t[torch.arange(t.shape[0], device=t.device), j.to(torch.int64)]
+
+
 class Broadcast(torch.Tensor):
     """A tensor marked LAUNCH-UNIFORM whatever its shape: `vmap(f, in_axes=(0, None))` marks its un-mapped tensor
     arguments with this, so a vector whose length happens to equal the particle count is still one vector shared by
@@ -127,7 +205,7 @@ def materialize(v):
         return v.plain
     if isinstance(v, Broadcast):
         return v.plain
-    return v.materialize() if isinstance(v, Gathered) else v
+    return v.materialize() if isinstance(v, (Gathered, Patched, PlateScore, Deferred)) else v
 
 
 _TDT = {torch.float32: "f32", torch.float64: "f32", torch.float16: "f32", torch.bfloat16: "f32",
@@ -252,6 +330,8 @@ class Flat:
         self.leaves = []
 
     def add(self, v):
+        if isinstance(v, (Patched, PlateScore)):
+            v = v.materialize()
         if isinstance(v, (tuple, list)) and not _is_number_seq(v):
             return (type(v).__name__, tuple(self.add(x) for x in v))
         if isinstance(v, dict):
@@ -265,7 +345,7 @@ class Flat:
             for f_ in dataclasses.fields(v):
                 x = getattr(v, f_.name)
                 if f_.metadata.get("static"):
-                    items.append((f_.name, ("static_field", _hashable(x), x)))
+                    items.append((f_.name, ("static_field", _static_token(x))))
                 else:
                     items.append((f_.name, self.add(x)))
             return ("dc", type(v), tuple(items))
@@ -286,6 +366,40 @@ def _hashable(x):
         return x
     except TypeError:
         return ("id", id(x))
+
+
+def _static_token(x):
+    """what stands for a Pytree.static() field in a launch structure (and so in a program cache key): the value itself
+    when it is hashable; else a token of its contents (dict / list / set of hashables: the reference's static fields
+    are compared by value) with the raw value kept in a side table — never an unhashable object inside a key"""
+    try:
+        hash(x)
+        return ("v", x)
+    except TypeError:
+        pass
+
+    def freeze(v):
+        if isinstance(v, dict):
+            return ("dict", tuple(sorted(((repr(k), freeze(w)) for k, w in v.items()))))
+        if isinstance(v, (list, tuple)):
+            return (type(v).__name__, tuple(freeze(w) for w in v))
+        if isinstance(v, (set, frozenset)):
+            return ("set", tuple(sorted(repr(w) for w in v)))
+        try:
+            hash(v)
+            return v
+        except TypeError:
+            return ("id", id(v))
+    tok = ("u", freeze(x))
+    _STATIC_FIELDS[tok] = x
+    return tok
+
+
+def _static_value(tok):
+    return tok[1] if tok[0] == "v" else _STATIC_FIELDS[tok]
+
+
+_STATIC_FIELDS: dict = {}
 
 
 def _make_dataclass(cls, values: dict):
@@ -322,7 +436,7 @@ def unflatten(tree, fn):
     if kind == "indexed":
         return Indexed(unflatten(tree[1], fn), unflatten(tree[2], fn))
     if kind == "dc":
-        return _make_dataclass(payload, {name: (t[2] if t[0] == "static_field" else unflatten(t, fn)) for name, t in tree[2]})
+        return _make_dataclass(payload, {name: (_static_value(t[1]) if t[0] == "static_field" else unflatten(t, fn)) for name, t in tree[2]})
     raise ValueError(kind)
 
 
@@ -1153,6 +1267,39 @@ def logsumexp_rows(lw: torch.Tensor) -> torch.Tensor:
     be.check(be.c.gmx_logsumexp(be.ptr(x), rows, cols, be.ptr(out), None, be.ptr(ws), be.stream()),
              "gmx_logsumexp")
     return out.reshape(lw.shape[:-1])
+
+
+def sum_rows_inorder(x) -> torch.Tensor:
+    """[B, n] -> [B]: every row added in element order (gmx_sum_rows_inorder): the plate score of a batched plate trace"""
+    be = _lib.get()
+    x = materialize(x)
+    if x.dtype != torch.float32:
+        x = x.float()
+    rows, cols = int(x.shape[0]), int(x.shape[1])
+    out = torch.empty((rows,), dtype=torch.float32, device=x.device)
+    be.check(be.c.gmx_sum_rows_inorder(be.ptr(x), rows, cols, int(x.stride(0)), int(x.stride(1)), be.ptr(out), be.stream()),
+             "gmx_sum_rows_inorder")
+    return out
+
+
+class PlateScore:
+    """the score of a plate trace whose element `idx` was just replaced: the in-order sum over the elements' scores,
+    computed when somebody asks (the reference's VmapTrace sums on access too)"""
+
+    def __init__(self, elem_scores, batch=None):
+        """elem_scores: [B, n] (a tensor or a lazy leaf), or a thunk giving it (then `batch` = (B,) is needed)"""
+        self.elem_scores, self._v = elem_scores, None
+        self._batch = tuple(batch) if batch is not None else tuple(elem_scores.shape[:1])
+
+    @property
+    def shape(self):
+        return self._batch
+
+    def materialize(self):
+        if self._v is None:
+            es = self.elem_scores() if callable(self.elem_scores) else self.elem_scores
+            self._v = sum_rows_inorder(es)
+        return self._v
 
 
 def sum_rows(x) -> torch.Tensor:

@@ -232,6 +232,11 @@ int gmx_logsumexp(const float* lw_d, int64_t rows, int64_t cols, float* out_d,
  * thread t adds items t, t + 256, ... in order, a wave butterfly (xor 32 ... 1), (w0 + w1) + (w2 + w3); then the same
  * over the tile partials.  Deterministic: the same bits on every run (the oracle restates the tree).
  * ---------------------------------------------------------------------- */
+/* out_d[r] = the sum of x[r, 0 .. cols) added in ELEMENT ORDER (0.0f + x[r, 0] + x[r, 1] + ...; element (r, c) at
+ * x_d[r * stride_row + c * stride_col]): the plate score of a batched plate trace as its counted loop accumulates it
+ * (vmap.py:214-216's sum), recomputed after an IndexRequest replaced one element. */
+int gmx_sum_rows_inorder(const float* x_d, int64_t rows, int64_t cols, int64_t stride_row, int64_t stride_col,
+                         float* out_d, gmx_stream stream);
 size_t gmx_sum_rows_workspace(int64_t rows, int64_t cols);
 int gmx_sum_rows(const float* x_d, int64_t rows, int64_t cols, float* out_d, void* workspace_d, gmx_stream stream);
 

@@ -1276,6 +1276,23 @@ def vmap_edit_index(vm: "Vmap", k, trace: "VmapTrace", idx: int, edit, args_at_i
     return VmapTrace(vm, new_inner, vm._plate_sum(new_inner.get_score(), batch), new_inner.get_retval()), w
 
 
+def vmap_edit_index_per_particle(vm: "Vmap", k, trace: "VmapTrace", idx, edit, args_at):
+    """Vmap.edit_index (vmap.py:277-332) under an outer particle vmap with ONE index per particle (a traced idx: the
+    dynamic_slice / dynamic_update_slice of each particle address its own element).  Restated per distinct index j:
+    the edit of element j with the caller's keys, kept for the particles whose index is j.  `args_at(j)`: the mapped
+    arguments of element j."""
+    idx = np.asarray(idx)
+    batch = np.asarray(k).shape[:-1]
+    inner, w = trace.inner, np.zeros(batch, np.float32)
+    for j in np.unique(idx):
+        cand, wj = vmap_edit_index(vm, k, trace, int(j), edit, args_at(int(j)))
+        here = np.zeros(tuple(batch) + (np.shape(trace.inner.get_score())[-1],), bool)
+        here[idx == j, int(j)] = True
+        inner = trace_where(here, cand.inner, inner)
+        w = np.where(idx == j, np.broadcast_to(np.asarray(wj, np.float32), batch), w).astype(np.float32)
+    return VmapTrace(vm, inner, vm._plate_sum(inner.get_score(), batch), inner.get_retval()), w
+
+
 def scan_edit(sc: "Scan", k, trace: "VmapTrace", args, update: ChoiceMap = None, regenerate=None):
     """Scan.edit_update / edit_regenerate (scan.py:417-594): every step is edited with the chained key
     fold_in(key, t), its slice of the trace and the edited predecessor's carry; weights summed."""

@@ -228,6 +228,16 @@ static float hs_block_sum(const float* v256) {
   const float w0 = butterfly_sum64(v256), w1 = butterfly_sum64(v256 + 64), w2 = butterfly_sum64(v256 + 128), w3 = butterfly_sum64(v256 + 192);
   return (w0 + w1) + (w2 + w3);
 }
+extern "C" int gmx_sum_rows_inorder(const float* x, int64_t rows, int64_t cols, int64_t sr, int64_t sc, float* out, gmx_stream) {
+  if (rows <= 0) return 0;
+  if (cols < 0 || !x || !out) return fail("sum_rows_inorder: bad argument");
+  for (int64_t r = 0; r < rows; ++r) {
+    float acc = 0.0f;
+    for (int64_t c = 0; c < cols; ++c) acc += x[r * sr + c * sc];
+    out[r] = acc;
+  }
+  return 0;
+}
 extern "C" size_t gmx_sum_rows_workspace(int64_t rows, int64_t cols) {
   if (rows <= 0 || cols <= 0) return 16;
   return (size_t)(rows * ((cols + 4095) / 4096) * sizeof(float)) + 16;

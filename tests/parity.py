@@ -2611,3 +2611,82 @@ def check_more_closed_forms(n=200_000):
     zz = np.exp(logz.cpu().numpy().astype(np.float64)) / stats.norm.pdf(1.3, 0.0, np.sqrt(1.25))
     se = zz.std(ddof=1) / np.sqrt(R)
     assert abs(zz.mean() - 1.0) < 4 * se and se < 0.05, (zz.mean(), se)
+
+
+def check_index_request_o1(n=96, P=40, seed=12, edits=5, nested=True):
+    """`IndexRequest` on a long plate held per particle edits ONE element (vmap.py:277-332 `edit_index`; VERDICT r3 item
+    6): chains of edits — Python-int index and one index per particle, Regenerate and Update sub-requests, longer than
+    PATCH_DEPTH_MAX so that the lazy leaves are folded on the way — bit-exact against the oracle's slice / edit /
+    write-back (values, weights, IN-ORDER score, backward request), the old trace untouched; `nested`: a plate of
+    plates, IndexRequest(i, IndexRequest(j, ...))."""
+    import genjax_amd as G
+    from genjax_amd import ChoiceMapBuilder as C, Diff, IndexRequest, Regenerate, SelectionBuilder as S, Update, numpy as jnp
+    from genjax_amd import combinators as cmb
+    from genjax_amd.engine import Patched
+    dev = G._lib.get().device
+    sig = np.linspace(1.0, 3.0, P).astype(np.float32)
+    school, oschool = _school(G), _school(O)
+    v, ov = school.vmap(in_axes=(None, None, 0)), O.Vmap(oschool, in_axes=(None, None, 0))
+    args = (1.0, 2.0, jnp.array(sig))
+    oargs = (np.float32(1.0), np.float32(2.0), sig)
+    t0, ot0 = v.simulate(G.split(G.key(seed), n), args), ov.simulate(O.split(O.key(seed), n), oargs)
+    th0 = t0.get_choices()["theta"].cpu().numpy().copy()
+    tr, otr = t0, ot0
+    rng = np.random.default_rng(seed)
+    saw_lazy = False
+    for e in range(edits):
+        kind = e % 3
+        k, ok = G.split(G.key(seed + 100 + e), n), O.split(O.key(seed + 100 + e), n)
+        if kind == 0:                  # Python-int index, Regenerate
+            j = int(rng.integers(0, P))
+            new, w, _, bwd = IndexRequest(j, Regenerate(S["theta"])).edit(k, tr, Diff.no_change(args))
+            aj = (np.float32(1.0), np.float32(2.0), np.float32(sig[j]))
+            onew, ow = O.vmap_edit_index(ov, ok, otr, j, lambda kk, sl, a: oschool.regenerate(kk, sl, O.selection("theta"), a)[:2], aj)
+            assert isinstance(bwd, IndexRequest) and bwd.idx == j
+        elif kind == 1:                # Python-int index, Update of y
+            j = int(rng.integers(0, P))
+            yv = np.float32(rng.normal())
+            new, w, _, bwd = IndexRequest(j, Update(C["y"].set(float(yv)))).edit(k, tr, Diff.no_change(args))
+            aj = (np.float32(1.0), np.float32(2.0), np.float32(sig[j]))
+            old_y = otr.get_choices()["y"][:, j].copy()
+            onew, ow = O.vmap_edit_index(ov, ok, otr, j, lambda kk, sl, a: oschool.update(kk, sl, O.C.d({"y": np.full(n, yv, np.float32)}), a)[:2], aj)
+            assert np.array_equal(bwd.request.constraint["y"].cpu().numpy(), old_y)
+        else:                          # one index per particle, Regenerate
+            idx = rng.integers(0, P, n).astype(np.int32)
+            new, w, _, bwd = IndexRequest(torch.from_numpy(idx).to(dev), Regenerate(S["theta"])).edit(k, tr, Diff.no_change(args))
+            onew, ow = O.vmap_edit_index_per_particle(ov, ok, otr, idx, lambda kk, sl, a: oschool.regenerate(kk, sl, O.selection("theta"), a)[:2],
+                                                      lambda j_: (np.float32(1.0), np.float32(2.0), np.float32(sig[j_])))
+        saw_lazy = saw_lazy or isinstance(new.inner.subtraces["theta"].value, Patched)
+        assert np.array_equal(w.cpu().numpy(), ow), (e, kind)
+        for a in ("theta", "y"):
+            assert np.array_equal(new.get_choices()[a].cpu().numpy(), onew.get_choices()[a]), (e, kind, a)
+        if e % 2 == 0 or e == edits - 1:
+            assert np.array_equal(new.get_score().cpu().numpy(), onew.get_score()), (e, kind)
+            assert np.array_equal(new.get_retval().cpu().numpy(), onew.get_retval()), (e, kind)
+        tr, otr = new, onew
+    assert saw_lazy, "the O(1) path did not run"
+    assert np.array_equal(t0.get_choices()["theta"].cpu().numpy(), th0)          # the first trace is untouched
+    s, _ = v.assess(tr.get_choices(), args)
+    assert np.array_equal(s.cpu().numpy(), tr.get_score().cpu().numpy())
+    if not nested:
+        return
+    # a plate of plates: [n, P1, P2]; IndexRequest(i, IndexRequest(j, Regenerate))
+    P1, P2 = 20, 24
+    sig2 = np.linspace(1.0, 2.0, P1 * P2).astype(np.float32).reshape(P1, P2)
+    vv = school.vmap(in_axes=(None, None, 0)).vmap(in_axes=(None, None, 0))
+    ovv = O.Vmap(O.Vmap(oschool, in_axes=(None, None, 0)), in_axes=(None, None, 0))
+    a2, oa2 = (0.5, 1.5, jnp.array(sig2)), (np.float32(0.5), np.float32(1.5), sig2)
+    t2, ot2 = vv.simulate(G.split(G.key(seed + 7), n), a2), ovv.simulate(O.split(O.key(seed + 7), n), oa2)
+    assert np.array_equal(t2.get_choices()["theta"].cpu().numpy(), ot2.get_choices()["theta"])
+    i, j = 3, 17
+    new, w, _, bwd = IndexRequest(i, IndexRequest(j, Regenerate(S["theta"]))).edit(G.split(G.key(seed + 8), n), t2, Diff.no_change(a2))
+    inner_ov = O.Vmap(oschool, in_axes=(None, None, 0))
+    a_j = (np.float32(0.5), np.float32(1.5), sig2[:, j])           # [P1] against the (n, P1) batch of the inner plates
+    onew, ow = O.vmap_edit_index_batched(
+        ovv, O.split(O.key(seed + 8), n), ot2, i,
+        lambda kb, inner, a: O.vmap_edit_index(inner_ov, kb, inner, j,
+                                               lambda k3, s3, a3: oschool.regenerate(k3, s3, O.selection("theta"), a3)[:2], a_j), oa2)
+    assert np.array_equal(w.cpu().numpy(), ow)
+    assert np.array_equal(new.get_choices()["theta"].cpu().numpy(), onew.get_choices()["theta"])
+    assert np.array_equal(new.get_score().cpu().numpy(), onew.get_score())
+    assert isinstance(bwd.request, IndexRequest) and bwd.idx == i and bwd.request.idx == j

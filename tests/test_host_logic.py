@@ -626,6 +626,14 @@ def test_large_plates_run_as_a_loop_and_match_oracle():
     parity.check_plates_long(n=33, P=17, seed=2)
 
 
+def test_index_request_edits_one_element_of_a_long_plate():
+    """IndexRequest on a long plate held per particle: slice / edit / lazy write-back (combinators._vmap_edit_index_o1),
+    chains of edits past PATCH_DEPTH_MAX, int and per-particle index, a plate of plates; bit-exact vs the oracle"""
+    from tests import parity
+    parity.check_index_request_o1(edits=6)
+    parity.check_index_request_o1(n=64, P=24, seed=3, edits=70, nested=False)
+
+
 def test_indexed_and_masked_constraints_match_oracle():
     from tests import parity
     parity.check_masked_constraints()

@@ -15,10 +15,12 @@ N > 1 is STRONG scaling by default — BASELINE's metric: the same 1e6-particle 
 (contiguous blocks of global particle indices; the total is rounded up to a multiple of N x 1024 because a shard
 starts on a tile of the integer CDF; the JSON names the exact count).  `--weak` keeps ~1e6 particles PER GPU instead.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the
-site-program interpreter k_vm): algorithmic bytes per launch / its average
-duration measured here with HIP events on the launch stream.  `cpu_baseline`
-times the oracle's C statement of the same sweep on the host cores.
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel — the hiprtc-specialised site program of the
+SMC step (gmx_jit_kernel; the interpreter k_vm only when GENMI_JIT=0): algorithmic bytes per launch / its average
+duration, measured here with HIP events on the launch stream, plus its VALU-issue fraction (the limiter that binds:
+`roofline.valu`).  `cpu_baseline` times the oracle's C statement of the same sweep on the host cores.  The other
+BASELINE configs (3: nonlinear SSM + MH, 4: 64-d mixture importance, 5: mixture Gibbs sweep) ride along in
+`config.other_configs`, each with its own valu record.
 """
 from __future__ import annotations
 

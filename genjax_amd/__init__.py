@@ -22,7 +22,7 @@ from . import inference
 from .inference import Target
 from .inference.sp import Algorithm, Marginal, marginal
 from .transforms import jit, vmap
-from .combinators import Scan, Vmap, accumulate, iterate, iterate_final, reduce, repeat, scan
+from .combinators import RepeatCombinator, Scan, Vmap, accumulate, iterate, iterate_final, reduce, repeat, scan
 
 ExactDensity = Distribution
 SampleDistribution = Distribution          # sp.py:100-103: distributions whose value is a ChoiceMap
@@ -40,7 +40,7 @@ __all__ = [
     "Trace", "Update", "Mask", "Distribution", "ExactDensity", "bernoulli", "beta", "categorical", "dirichlet",
     "flip", "normal", "uniform", "AddressReuse", "MissingAddress", "Rejuvenate",
     "StaticGenerativeFunction", "StaticRequest", "StaticTrace", "gen", "trace", "Target", "jit",
-    "vmap", "key", "split", "fold_in", "NotSupportedEditRequest", "Vmap", "repeat", "Scan", "scan", "IndexRequest",
+    "vmap", "key", "split", "fold_in", "NotSupportedEditRequest", "Vmap", "repeat", "RepeatCombinator", "Scan", "scan", "IndexRequest",
     "VectorRequest", "Argdiffs", "Arguments", "Retdiff", "Score", "Weight", "Address", "AddressComponent", "R",
     "Closure", "Const", "PythonicPytree", "Pytree", "nth", "exact_density", "tfp_distribution", "half_cauchy",
     "half_normal", "log_normal", "Algorithm", "SampleDistribution", "Marginal", "marginal", "trace_p", "clear_caches",

@@ -1068,6 +1068,59 @@ def _loop_step_constraint(chm: ChoiceMap, t, n, at_step, what="scan of more than
     return out
 
 
+def _promote_weak_carry(ctx, kernel_gen_fn, key, leaves0, rebuild_carry, x0, req_leaves, addr):
+    """The element types a counted loop's carry settles on.  A loop-carried register has ONE type; `jax.lax.scan`
+    promotes a weakly typed initial carry to what the body returns (`add.accumulate()` from the Python int 0 over float
+    inputs carries floats: scan.py:1050-1103 and its tests).  When some initial leaf is not a float, the kernel is
+    traced once on the initial carry just for its types (the probe's effects become dead code, as in Vmap.trace_call)
+    and the initial leaves are converted to the types it returned."""
+    from . import tracer as T
+    from .program import EFFECT
+    from .static import call_gen_fn
+    if all(e.dtype in ("f32", "key") for e in leaves0):
+        return leaves0
+    g, tr = ctx.tr.graph, ctx.tr
+    probe = (len(g.nodes), g.n_out, len(tr.outputs))
+    with T.tracing(g):
+        _, ret, _, _ = call_gen_fn(ctx, "simulate", kernel_gen_fn, key, (rebuild_carry(leaves0), x0), None, None, None,
+                                   req_leaves, addr)
+    for nd in g.nodes[probe[0]:]:
+        if nd.op in EFFECT:
+            nd.op, nd.args = "DEAD", ()
+    g.n_out = probe[1]
+    del tr.outputs[probe[2]:]
+    g._cse.clear()
+    if not (isinstance(ret, tuple) and len(ret) == 2):
+        raise TypeError("scan: the kernel must return (carry, output)")
+    outs = []
+    _flat_any(ret[0], outs)
+    if len(outs) != len(leaves0):
+        raise TypeError("scan: the kernel must return a carry of the same structure as it received")
+    rank = {"bool": 0, "i32": 1, "f32": 2}
+    conv = {"f32": T.as_float, "i32": T.as_int}
+    return [conv[o.dtype](e) if rank.get(o.dtype, -1) > rank.get(e.dtype, 3) else e for e, o in zip(leaves0, outs)]
+
+
+def _flat_any(v, out):
+    from . import tracer as T
+    from .engine import Sym
+    if isinstance(v, Sym):
+        v = v.value
+    if v is None:
+        return
+    if isinstance(v, (tuple, list)):
+        for x in v:
+            _flat_any(x, out)
+    elif isinstance(v, dict):
+        for x in v.values():
+            _flat_any(x, out)
+    elif isinstance(v, np.ndarray) and v.dtype == object:
+        for x in v.reshape(-1):
+            _flat_any(x, out)
+    else:
+        out.append(T.lift(v))
+
+
 class Scan(GenerativeFunction):
     """scan.py:140-294: kernel (carry, x) -> (carry, y), repeated `length` times."""
 
@@ -1108,7 +1161,7 @@ class Scan(GenerativeFunction):
             if mode in ("simulate", "assess"):
                 return out, out.retval, None, 0.0
             return out, out.retval, 0.0, None
-        if n > getattr(self, "unroll_max", SCAN_UNROLL_MAX):
+        if n > SCAN_UNROLL_MAX:
             return self._trace_loop(ctx, mode, key, carry, scanned_in, constraint, n, req_leaves, addr)
         g = ctx.tr.graph
         keep = ctx.store_sites
@@ -1224,6 +1277,9 @@ class Scan(GenerativeFunction):
 
         leaves0 = []
         ctree = flat_carry(carry, leaves0)
+        with T.tracing(g):
+            leaves0 = _promote_weak_carry(ctx, self.kernel_gen_fn, key, leaves0, lambda lv: rebuild(ctree, lv),
+                                          at_step(scanned_in, T.lift(0)), req_leaves, addr)
         cvars = [g.loop_var(e.node) for e in leaves0]
         kvar = g.loop_var(key.node) if key is not None else None
         zero = g.const_f32(0.0)
@@ -1322,7 +1378,7 @@ class Scan(GenerativeFunction):
         carry, scanned_in = args
         n = self._length(scanned_in)
         inner_prev = prev["vmap"]
-        if n > getattr(self, "unroll_max", SCAN_UNROLL_MAX):
+        if n > SCAN_UNROLL_MAX:
             return self._trace_edit_loop(ctx, sub_mode, key, carry, scanned_in, constraint, inner_prev, req, kind, n,
                                          req_leaves, addr)
         g = ctx.tr.graph
@@ -1474,6 +1530,9 @@ class Scan(GenerativeFunction):
 
         leaves0 = []
         ctree = flat_carry(carry, leaves0)
+        with T.tracing(g):
+            leaves0 = _promote_weak_carry(ctx, self.kernel_gen_fn, key, leaves0, lambda lv: rebuild(ctree, lv),
+                                          at_step(scanned_in, T.lift(0)), req_leaves, addr)
         cvars = [g.loop_var(e.node) for e in leaves0]
         key0 = key
         kvar = g.loop_var(key.node) if (key is not None and sub_mode != "index") else None
@@ -1687,9 +1746,16 @@ class _Repeat(Vmap):
         return self.n
 
 
+def RepeatCombinator(gen_fn, /, *, n: int):
+    """repeat.py:28-42: `gen_fn` run n times on the same arguments (keys split(key, n)[j], addresses [j, ...]),
+    returning the n results stacked."""
+    return _Repeat(gen_fn, n)
+
+
 def repeat(*, n: int):
+    """repeat.py:45-81: the decorator form of RepeatCombinator"""
     def decorator(gen_fn):
-        return _Repeat(gen_fn, n)
+        return RepeatCombinator(gen_fn, n=n)
     return decorator
 
 
@@ -1721,8 +1787,9 @@ class _ScanAdapter(GenerativeFunction):
 
     project = _plate_project
 
-    def __init__(self, scan_gf, pre, post, name):
+    def __init__(self, scan_gf, pre, post, name, post_ctx=False):
         self.scan_gf, self._pre, self._post, self.name = scan_gf, pre, post, name
+        self._post_ctx = post_ctx          # `post` also takes the tracing context (it records outputs of its own)
 
     @property
     def gen_fn(self):
@@ -1731,7 +1798,7 @@ class _ScanAdapter(GenerativeFunction):
     def trace_call(self, ctx, mode, key, args, constraint, prev, req, req_leaves, addr):
         rec, retval, w, s_ = self.scan_gf.trace_call(ctx, mode, key, self._pre(*args), constraint, prev, req, req_leaves,
                                                      addr)
-        out = self._post(args, retval)
+        out = self._post(args, retval, ctx) if self._post_ctx else self._post(args, retval)
         if hasattr(rec, "sites"):
             rec.gen_fn = self
             rec.retval = out
@@ -1760,39 +1827,33 @@ class _ScanAdapter(GenerativeFunction):
         return f"genjax.{self.name}({self.scan_gf.kernel_gen_fn.gen_fn!r})"
 
 
-SUGAR_UNROLL_MAX = 64       # iterate / accumulate return every intermediate value WITH the initial one in front: the
-                            # stacked outputs must be values of the program (an unrolled scan), not a loop's memory rows
-
-
-def _prepend(init, ys):
-    """[init, ys[0], ys[1], ...] leaf by leaf (scan.py:762-788 `prepend_initial_acc`)."""
+def _prepend(init, ys, ctx=None):
+    """[init, ys[0], ys[1], ...] leaf by leaf (scan.py:762-788 `prepend_initial_acc`).  The stacked outputs of a
+    counted loop live in memory only ([*batch, T, *event] after the launch): the initial value is then recorded as an
+    output of its own and put in front when the launch's results are resolved (engine.resolve "prepend")."""
     from .engine import StepOutput, Sym
     init = init.value if isinstance(init, Sym) else init
     if isinstance(init, (tuple, list)):
-        return type(init)(_prepend(a, b) for a, b in zip(init, ys))
+        return type(init)(_prepend(a, b, ctx) for a, b in zip(init, ys))
     if isinstance(init, dict):
-        return {k: _prepend(init[k], ys[k]) for k in init}
+        return {k: _prepend(init[k], ys[k], ctx) for k in init}
     if isinstance(ys, StepOutput):
-        raise NotImplementedError(f"iterate / accumulate over more than {SUGAR_UNROLL_MAX} steps (the stacked values of a "
-                                  "counted loop live in memory only); use iterate_final / reduce, or a plain scan")
+        return StepOutput(("prepend", ctx.tr.emit_output(init), ys.origin, ys.trailing), ys.T + 1, ys.trailing)
     head = np.asarray(init, dtype=object) if not (isinstance(init, np.ndarray) and init.dtype == object) else init
     ys = np.asarray(ys, dtype=object) if not (isinstance(ys, np.ndarray) and ys.dtype == object) else ys
     return np.concatenate([head[None], ys.reshape((ys.shape[0],) + head.shape)], axis=0)
 
 
 def _sugar_scan(kernel, n, every):
-    sc = Scan(kernel, n)
-    if every:
-        sc.unroll_max = SUGAR_UNROLL_MAX
-    return sc
+    return Scan(kernel, n)
 
 
 def iterate(*, n: int):
     """f: a -> a  =>  a -> [a, f(a), f(f(a)), ...] (n + 1 values; scan.py:916-977)"""
     def decorator(f):
         k = _KernelAdapter(f, lambda carry, _x: (carry,), lambda r: (r, r))
-        return _ScanAdapter(_sugar_scan(k, n, True), lambda init: (init, None), lambda args, ret: _prepend(args[0], ret[1]),
-                            "iterate")
+        return _ScanAdapter(_sugar_scan(k, n, True), lambda init: (init, None), lambda args, ret, ctx: _prepend(args[0], ret[1], ctx),
+                            "iterate", post_ctx=True)
     return decorator
 
 
@@ -1809,7 +1870,7 @@ def accumulate():
     def decorator(f):
         k = _KernelAdapter(f, lambda carry, x: (carry, x), lambda r: (r, r))
         return _ScanAdapter(_sugar_scan(k, None, True), lambda init, xs: (init, xs),
-                            lambda args, ret: _prepend(args[0], ret[1]), "accumulate")
+                            lambda args, ret, ctx: _prepend(args[0], ret[1], ctx), "accumulate", post_ctx=True)
     return decorator
 
 

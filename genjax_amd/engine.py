@@ -1162,6 +1162,12 @@ def resolve(origin, outs, leaves):
     if kind == "stack":        # an unrolled plate of loop outputs: elements [*batch, T, *event] -> [*batch, n, T, *event]
         parts = [resolve(o, outs, leaves) for o in origin[1]]
         return torch.stack(parts, dim=parts[0].dim() - int(origin[2]))
+    if kind == "prepend":      # iterate / accumulate over a counted loop: [init, ys[0], ..., ys[T-1]] along the step axis
+        init, ys = resolve(origin[1], outs, leaves), resolve(origin[2], outs, leaves)
+        ax = ys.dim() - int(origin[3])
+        head = torch.as_tensor(init, device=ys.device).to(ys.dtype)
+        head = head.expand(ys.shape[:ax] + ys.shape[ax + 1:]).unsqueeze(ax)
+        return torch.cat([head, ys], dim=ax)
     raise ValueError(origin)
 
 

@@ -57,6 +57,14 @@ def make_scanner():
     return scanner
 
 
+def make_scanner_n(n):
+    @genjax.iterate(n=n)
+    @genjax.gen
+    def scanner(x):
+        return genjax.normal(x, 1.0) @ "z"
+    return scanner
+
+
 class TestIterateSimpleNormal:
     def test_project_all_is_the_score(self):
         """:42-53"""
@@ -140,6 +148,23 @@ class TestIterate:
 
     def test_iterate_final(self):
         assert int(inc.iterate_final(n=10).simulate(self.key, (0,)).get_retval()) == 10
+
+    def test_iterate_and_accumulate_past_the_unroll_limit(self):
+        """scan.py:916-977, :1050-1103 for any n: past Scan.unroll_max steps the scan is a counted loop and the stack
+        [init, f(init), ...] is assembled from the loop's stored rows; same values as the unrolled form on the shared
+        prefix (the step keys chain: fold_in(key, t)), one particle and a batch of keys"""
+        from genjax_amd import combinators as cmb
+        n_long, n_short = 200, cmb.SCAN_UNROLL_MAX
+        assert np.array_equal(arr(inc.iterate(n=n_long).simulate(self.key, (0,)).get_retval()), np.arange(n_long + 1))
+        r = add.accumulate().simulate(self.key, (0, jnp.ones(n_long))).get_retval()
+        assert np.array_equal(arr(r), np.arange(n_long + 1))
+        scanner_long, scanner_short = make_scanner_n(n_long), make_scanner_n(n_short)
+        for key in (self.key, genjax.split(self.key, 7)):
+            tl, ts = scanner_long.simulate(key, (0.25,)), scanner_short.simulate(key, (0.25,))
+            rl, rs = arr(tl.get_retval()), arr(ts.get_retval())
+            assert rl.shape[-1] == n_long + 1 and np.all(rl[..., 0] == np.float32(0.25))
+            assert np.array_equal(rl[..., : n_short + 1], rs)
+            assert np.array_equal(rl[..., 1:], arr(tl.get_choices()["z"]))
 
     def test_inc_tupled(self):
         assert np.array_equal(arr(inc_tupled.simulate(self.key, ((0, 2),)).get_retval()), [2, 2])
@@ -522,6 +547,16 @@ class TestRepeat:
         r = square.repeat(n=10)(2)(key)
         assert tuple(r.shape) == (10,)
         assert np.array_equal(arr(square.vmap()(jnp.repeat(2, 10))(key)), arr(r))
+
+    def test_repeat_combinator_is_the_decorator(self):
+        """repeat.py:28-42 / :45-81: RepeatCombinator(gen_fn, n=) is what `@repeat(n=)` builds"""
+        @genjax.gen
+        def model(mu):
+            return genjax.normal(mu, 1.0) @ "x"
+        key = genjax.key(7)
+        a = genjax.RepeatCombinator(model, n=6).simulate(key, (2.0,))
+        b = genjax.repeat(n=6)(model).simulate(key, (2.0,))
+        assert np.array_equal(arr(a.get_retval()), arr(b.get_retval())) and f(a.get_score()) == f(b.get_score())
 
     def test_nested_lookup(self):
         """:47-58: C[0, :, "x"] on a repeat of a repeat"""

@@ -124,6 +124,19 @@ k_vm(const uint32_t* __restrict__ code, uint32_t n_instr, int64_t n, const gmx_r
   ctx.init(code, n_instr, &A, lds4);
   gmx_vm_run<Regs, FULL, -1, DevCtx>(n_instr, i, i < n, A, ctx);
 }
+// The 16-register interpreter of the common opcodes, held to 7 waves per SIMD (72 VGPRs, 7 dwords of scratch in cold
+// paths): it had drifted from 70 to 86 VGPRs (5 waves) as opcodes were added.  Measured on MI355X, everything interpreted
+// (GENMI_JIT=0): config 5 3.74 -> 3.30 ms, config 3 242 -> 229 us / step, config 2 6.62 -> 6.50 ms.  The other three
+// instantiations keep the compiler's allocation: under the same bound they spill 200-250 bytes per lane (config 4's
+// importance launch: 3.7 -> 41 ms).
+__global__ void __launch_bounds__(GMX_BLOCK) __attribute__((amdgpu_waves_per_eu(7, 8)))
+k_vm_lean(const uint32_t* __restrict__ code, uint32_t n_instr, int64_t n, const gmx_run_args A) {
+  __shared__ float lds4[4];
+  int64_t i = (int64_t)blockIdx.x * GMX_BLOCK + threadIdx.x;
+  DevCtx ctx;
+  ctx.init(code, n_instr, &A, lds4);
+  gmx_vm_run<gmx_regs_vgpr<16>, false, -1, DevCtx>(n_instr, i, i < n, A, ctx);
+}
 
 struct gmx_program {
   uint32_t* code_d;
@@ -665,7 +678,7 @@ extern "C" int gmx_program_run(const gmx_program* p, int64_t n, const gmx_run_ar
     if (p->needs_full)
       hipLaunchKernelGGL((k_vm<gmx_regs_vgpr<16>, true>), grid, block, 0, st, p->code_d, p->n_instr, n, *args);
     else
-      hipLaunchKernelGGL((k_vm<gmx_regs_vgpr<16>, false>), grid, block, 0, st, p->code_d, p->n_instr, n, *args);
+      hipLaunchKernelGGL(k_vm_lean, grid, block, 0, st, p->code_d, p->n_instr, n, *args);
   } else {
     if (p->needs_full)
       hipLaunchKernelGGL((k_vm<gmx_regs_vgpr<32>, true>), grid, block, 0, st, p->code_d, p->n_instr, n, *args);
@@ -2365,8 +2378,29 @@ extern "C" int gmx_resample(int kind, const uint32_t key[2], const float* lw_d, 
 // fixed-capacity send block of that rank; slots of this rank whose ancestor is
 // remote get an index into the receive area the all-to-all fills.
 // ---------------------------------------------------------------------------
+// GMX_RESAMPLE_MULTINOMIAL_SORTED across ranks: every rank holds the SAME order-statistics table of the N = n * world
+// global slots (gmx_sorted_uniforms with the step's key: integers, identical on every partitioning), and "slots below
+// the CDF value c" is a guided look-up in it (the bucket of c * S_total / total, then the exact 128-bit predicate).
+__device__ __forceinline__ int64_t shard_sorted_below(const uint32_t* __restrict__ table, int64_t N, uint64_t c,
+                                                      uint64_t total) {
+  const gmx_sorted_layout L = gmx_sorted_layout_of(N);
+  const uint64_t stot = reinterpret_cast<const uint64_t*>(table + L.off_toff)[L.tiles];
+  const sorted_ctx X = sorted_ctx_of(table, N, total, stot, table[L.off_sh]);
+  const double t = __builtin_fma((double)(uint32_t)(c >> 32), 4294967296.0, (double)(uint32_t)c) * X.ratio;
+  uint64_t g = (uint64_t)t >> X.sh;
+  g = g < X.gmax ? g : X.gmax;
+  return sorted_below_exact(X, c, total, (int64_t)X.guide[g], N);
+}
+__device__ __forceinline__ int64_t shard_slots_below(int kind, const uint32_t* __restrict__ sorted_tab, gmx_key key,
+                                                     uint64_t u0, uint64_t c, uint64_t D, uint64_t total,
+                                                     double n_over_total, double eps, int64_t N) {
+  if (kind == GMX_RESAMPLE_MULTINOMIAL_SORTED) return shard_sorted_below(sorted_tab, N, c, total);
+  return slots_below(kind, key, u0, c, D, total, n_over_total, eps, N);
+}
+
 __global__ void k_shard_plan(int kind, uint32_t k0, uint32_t k1, const uint64_t* __restrict__ totals, int rank,
-                             int world, int64_t n, int64_t* __restrict__ plan, uint64_t* __restrict__ total_out) {
+                             int world, int64_t n, int64_t* __restrict__ plan, uint64_t* __restrict__ total_out,
+                             const uint32_t* __restrict__ sorted_tab) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   gmx_key key; key.k0 = k0; key.k1 = k1;
   const uint64_t u0 = gmx_bits32(key, 0) >> 9;
@@ -2379,7 +2413,7 @@ __global__ void k_shard_plan(int kind, uint32_t k0, uint32_t k1, const uint64_t*
   uint64_t off = 0;
   for (int s = 0; s < world; ++s) {
     if (s == rank) plan[GMX_PLAN_OFFSET] = (int64_t)off;
-    plan[GMX_PLAN_BOUNDS + s] = total ? slots_below(kind, key, u0, off, D, total, n_over_total, eps, N) : 0;
+    plan[GMX_PLAN_BOUNDS + s] = total ? shard_slots_below(kind, sorted_tab, key, u0, off, D, total, n_over_total, eps, N) : 0;
     off += totals[s];
   }
   plan[GMX_PLAN_BOUNDS + world] = N;      // no mass at all: the last rank sources every slot
@@ -2436,7 +2470,7 @@ __device__ __forceinline__ void shard_route_source(const shard_route_ctx& R, boo
 __global__ void __launch_bounds__(GMX_BLOCK)
 k_shard_route(int kind, uint32_t k0, uint32_t k1, int64_t* __restrict__ plan, const uint64_t* __restrict__ cdf,
               int rank, int world, int64_t n, int64_t cap, const uint32_t* __restrict__ state,
-              uint32_t* __restrict__ send, int32_t* __restrict__ next_idx) {
+              uint32_t* __restrict__ send, int32_t* __restrict__ next_idx, const uint32_t* __restrict__ sorted_tab) {
   const int64_t i = (int64_t)blockIdx.x * GMX_BLOCK + threadIdx.x;
   const bool in_range = i < n;
   const uint64_t total = (uint64_t)plan[GMX_PLAN_TOTAL];
@@ -2468,14 +2502,14 @@ k_shard_route(int kind, uint32_t k0, uint32_t k1, int64_t* __restrict__ plan, co
     const double n_over_total = (double)N / (double)total;
     const double eps = (double)N * 0x1p-44 + 0x1p-40;
     const uint64_t c_hi = in_range ? cdf[i] + cdf_offset : total;
-    e = slots_below(kind, key, u0, c_hi, D, total, n_over_total, eps, N);
+    e = shard_slots_below(kind, sorted_tab, key, u0, c_hi, D, total, n_over_total, eps, N);
     const int lane = threadIdx.x & 63;
     uint32_t e_l = (uint32_t)e, e_h = (uint32_t)((uint64_t)e >> 32);
     e_l = __shfl_up(e_l, 1, GMX_WAVE); e_h = __shfl_up(e_h, 1, GMX_WAVE);
     s_lo = (int64_t)(((uint64_t)e_h << 32) | e_l);
     if (lane == 0) {
       const uint64_t c_lo = (i == 0 || !in_range) ? cdf_offset : cdf[i - 1] + cdf_offset;
-      s_lo = slots_below(kind, key, u0, c_lo, D, total, n_over_total, eps, N);
+      s_lo = shard_slots_below(kind, sorted_tab, key, u0, c_lo, D, total, n_over_total, eps, N);
     }
   }
   {
@@ -2646,7 +2680,7 @@ extern "C" int gmx_shard_plan(int kind, const uint32_t key[2], const uint64_t* t
   if (shard_check("gmx_shard_plan", kind, key, rank, world, n_per_rank)) return 1;
   if (!totals_d || !plan_d) return gmx_fail("gmx_shard_plan: null argument%s");
   hipLaunchKernelGGL(k_shard_plan, dim3(1), dim3(64), 0, (hipStream_t)stream, kind, key[0], key[1], totals_d, rank,
-                     world, n_per_rank, plan_d, total_out_d);
+                     world, n_per_rank, plan_d, total_out_d, (const uint32_t*)nullptr);
   GMX_HIP(hipGetLastError());
   return 0;
 }
@@ -2661,7 +2695,32 @@ extern "C" int gmx_shard_route(int kind, const uint32_t key[2], int64_t* plan_d,
     return gmx_fail("gmx_shard_route: extended state index exceeds int32%s");
   hipLaunchKernelGGL(k_shard_route, grid_for(n_per_rank), dim3(GMX_BLOCK), 0, (hipStream_t)stream, kind, key[0],
                      key[1], plan_d, cdf_d, rank, world, n_per_rank, capacity, (const uint32_t*)state_d,
-                     (uint32_t*)send_d, next_idx_d);
+                     (uint32_t*)send_d, next_idx_d, (const uint32_t*)nullptr);
+  GMX_HIP(hipGetLastError());
+  return 0;
+}
+
+// gmx_shard_step for GMX_RESAMPLE_MULTINOMIAL_SORTED (include/genmi.h): plan + route against the order-statistics table
+// of the n_per_rank * world global slots (table_d: gmx_sorted_uniforms of the step's key, the same on every rank).
+extern "C" int gmx_shard_step_sorted(const uint32_t* table_d, const uint64_t* totals_d, int64_t* plan_d,
+                                     uint64_t* total_out_d, const uint64_t* cdf_d, int rank, int world,
+                                     int64_t n_per_rank, int64_t capacity, const void* state_d, void* send_d,
+                                     int32_t* next_idx_d, gmx_stream stream) {
+  if (!table_d || !totals_d || !plan_d || !cdf_d || !state_d || !send_d || !next_idx_d)
+    return gmx_fail("gmx_shard_step_sorted: null argument%s");
+  if (world < 1 || world > 1024 || rank < 0 || rank >= world) return gmx_fail("gmx_shard_step_sorted: rank / world out of range%s");
+  if (n_per_rank <= 0 || n_per_rank * world > 0x7fffffffLL) return gmx_fail("gmx_shard_step_sorted: n_per_rank * world out of range (< 2^31)%s");
+  if (capacity < 1 || capacity > n_per_rank) return gmx_fail("gmx_shard_step_sorted: capacity must be in [1, n_per_rank]%s");
+  if (n_per_rank + (int64_t)world * capacity > 0x7fffffffLL)
+    return gmx_fail("gmx_shard_step_sorted: extended state index exceeds int32%s");
+  if ((uintptr_t)table_d & 15) return gmx_fail("gmx_shard_step_sorted: table_d must be 16-byte aligned%s");
+  const int kind = GMX_RESAMPLE_MULTINOMIAL_SORTED;
+  hipLaunchKernelGGL(k_shard_plan, dim3(1), dim3(64), 0, (hipStream_t)stream, kind, 0u, 0u, totals_d, rank, world,
+                     n_per_rank, plan_d, total_out_d, table_d);
+  GMX_HIP(hipGetLastError());
+  hipLaunchKernelGGL(k_shard_route, grid_for(n_per_rank), dim3(GMX_BLOCK), 0, (hipStream_t)stream, kind, 0u, 0u, plan_d,
+                     cdf_d, rank, world, n_per_rank, capacity, (const uint32_t*)state_d, (uint32_t*)send_d, next_idx_d,
+                     table_d);
   GMX_HIP(hipGetLastError());
   return 0;
 }

@@ -43,7 +43,7 @@ from .. import _lib
 from ..core.choice_map import ChoiceMap
 from ..random import Key, fold_in, lazy_split, split
 from ..engine import Gathered
-from .smc import STRATIFIED, SYSTEMATIC, _NoiseAhead, cdf_reference, cdf_shift
+from .smc import MULTINOMIAL_SORTED, STRATIFIED, SYSTEMATIC, _NoiseAhead, cdf_reference, cdf_shift
 
 
 def systematic_slot_bounds(offsets, total: int, n_total: int, u0: int):
@@ -101,9 +101,9 @@ class ShardedBootstrapSweep(_NoiseAhead):
         self.step_extra = step_extra or (lambda t: ())
         self.specialize = specialize
         self.kind = _KINDS[resample] if isinstance(resample, str) else int(resample)
-        if self.kind not in (SYSTEMATIC, STRATIFIED):
-            raise NotImplementedError("ShardedBootstrapSweep: the router takes the systematic / stratified schemes (one-GPU "
-                                      "sweeps also offer multinomial, multinomial_tiled and multinomial_sorted)")
+        if self.kind not in (SYSTEMATIC, STRATIFIED, MULTINOMIAL_SORTED):
+            raise NotImplementedError("ShardedBootstrapSweep: the router takes the ORDERED schemes — systematic, stratified, "
+                                      "multinomial_sorted (one-GPU sweeps also offer multinomial and multinomial_tiled)")
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         self.N = self.n * self.world
         _check_shard_alignment(self.n, self.world)
@@ -126,7 +126,9 @@ class ShardedBootstrapSweep(_NoiseAhead):
         # routed (two gmx_shard_step launches and two all-to-alls per step instead of one).
         self.rejuvenate, self.state_addr = rejuvenate, state_addr
         self.noise_ahead_req = noise_ahead
-        self.cdf_form, self.fused_req = bool(cdf_form), bool(fused)
+        # the sorted multinomial routes against the order-statistics table of all N slots (gmx_shard_step_sorted): the
+        # CDF-array form, two routing launches
+        self.cdf_form, self.fused_req = bool(cdf_form) or self.kind == MULTINOMIAL_SORTED, bool(fused)
         self._noise_offset, self._noise_total = self.rank * self.n, self.N
 
     def _chain_prog(self, t):
@@ -232,6 +234,14 @@ class ShardedBootstrapSweep(_NoiseAhead):
         for t in range(T):
             ks = split(fold_in(key, t), 3)
             self.step_keys.append((ks[0], ks[1], ks[2]))
+        self.sorted_tab = self.sorted_keys = None
+        if self.kind == MULTINOMIAL_SORTED:
+            # every rank draws the SAME table of the N global slots from the step's resampling key (integers)
+            if self.N >= 1 << 31:
+                raise NotImplementedError("resample='multinomial_sorted' across ranks: n_per_rank * world < 2^31")
+            self.sorted_tab = torch.zeros((int(be.c.gmx_sorted_uniforms_words(self.N)),), dtype=torch.int32, device=dev)
+            hk = np.stack([self.step_keys[t][1].host() for t in range(T)]).astype(np.uint32)
+            self.sorted_keys = torch.from_numpy(hk.view(np.int32)).to(dev)
         if self.comm and self.world > 1 and hasattr(self.dist, "barrier"):
             # ranks leave prepare() together (hiprtc compiles are seconds apart between ranks): the bounded waits of
             # the peer-mapped exchanges only ever see the microseconds of skew a running sweep has
@@ -336,7 +346,8 @@ class ShardedBootstrapSweep(_NoiseAhead):
         step2 = recv2 = None
         if self.rejuvenate is not None and t >= 1:       # second routed leaf (per component): what x_t was extended from
             cur_a = self.arows[t % 2]
-            step2 = [(self.kind, kk, P(self.totals_all), P(self.plan), P(tot), P(self.cdf), g, W, n, C, P(cur_a[d]),
+            step2 = [((self.kind, kk) if self.kind != MULTINOMIAL_SORTED else (P(self.sorted_tab),)) +
+                     (P(self.totals_all), P(self.plan), P(tot), P(self.cdf), g, W, n, C, P(cur_a[d]),
                       P(self.send2[d]), P(self.idx)) for d in range(self.D)]
             recv2 = [cur_a[d][n:] for d in range(self.D)]
         tiles = None
@@ -374,8 +385,10 @@ class ShardedBootstrapSweep(_NoiseAhead):
             # the CDF kernel reduces the (all-reduced) block maxima itself and records the max in maxs[t]
             "cdf": (P(self.lw), n, self.shift, P(pmax), rows, P(m), P(self.cdf), P(self.total_d), P(self.ws)),
             # one routed leaf per state component: the same plan, D launches + D all-to-alls
-            "steps": [(self.kind, kk, P(self.totals_all), P(self.plan), P(tot), P(self.cdf), g, W, n, C,
+            "steps": [((self.kind, kk) if self.sorted_tab is None else (P(self.sorted_tab),)) +
+                      (P(self.totals_all), P(self.plan), P(tot), P(self.cdf), g, W, n, C,
                        P(rows_t[d]), P(self.send[d]), P(self.idx)) for d in range(self.D)],
+            "sorted": None if self.sorted_tab is None else (P(self.sorted_keys[t]), 1, self.N, P(self.sorted_tab), 0),
             "recvs": [rows_t[d][n:] for d in range(self.D)],
         }
 
@@ -425,13 +438,17 @@ class ShardedBootstrapSweep(_NoiseAhead):
             self.cx.all_gather(self.totals_all, self.total_d)            # 8 bytes per rank
         else:
             self.totals_all.copy_(self.total_d)
+        shard_step = c.gmx_shard_step
+        if b["sorted"] is not None:
+            be.check(c.gmx_sorted_uniforms(*b["sorted"], st), "gmx_sorted_uniforms")     # the step's table of all N slots
+            shard_step = c.gmx_shard_step_sorted
         for d in range(self.D):
-            be.check(c.gmx_shard_step(*b["steps"][d], st), "gmx_shard_step")   # slot boundaries + routing, one launch
+            be.check(shard_step(*b["steps"][d], st), "gmx_shard_step")       # slot boundaries + routing
             if self.comm:
                 self.cx.all_to_all(b["recvs"][d], self.send[d])          # block s of recv <- block `me` of rank s
         if b["step2"] is not None:
             for d in range(self.D):
-                be.check(c.gmx_shard_step(*b["step2"][d], st), "gmx_shard_step")
+                be.check(shard_step(*b["step2"][d], st), "gmx_shard_step")
                 if self.comm:
                     self.cx.all_to_all(b["recv2"][d], self.send2[d])
 
@@ -616,8 +633,9 @@ def sharded_importance_resample(target, k_per_rank: int, key: Key, dist, kind="s
     g, W = dist.get_rank(), dist.get_world_size()
     n, K = int(k_per_rank), int(k_per_rank) * dist.get_world_size()
     kind = _KINDS[kind] if isinstance(kind, str) else int(kind)
-    if kind not in (SYSTEMATIC, STRATIFIED):
-        raise NotImplementedError("sharded_importance_resample: the router takes the systematic / stratified schemes")
+    if kind not in (SYSTEMATIC, STRATIFIED, MULTINOMIAL_SORTED):
+        raise NotImplementedError("sharded_importance_resample: the router takes the ordered schemes (systematic, "
+                                  "stratified, multinomial_sorted)")
     if comm is None and W > 1:
         from .comm import make_comm
         comm = make_comm(dist, dev)
@@ -693,6 +711,7 @@ def sharded_importance_resample(target, k_per_rank: int, key: Key, dist, kind="s
     table = torch.stack(rows) if R else torch.zeros((0, n), dtype=torch.float32, device=dev)      # [R, n]
 
     C = max(1, min(int(capacity) if capacity else (n if W == 1 else max(4096, n // 32)), n))
+    sorted_tab = None
     while True:
         plan = torch.zeros((int(be.c.gmx_shard_plan_words(W)),), dtype=torch.int64, device=dev)
         next_idx = torch.zeros((n,), dtype=torch.int32, device=dev)
@@ -702,6 +721,14 @@ def sharded_importance_resample(target, k_per_rank: int, key: Key, dist, kind="s
             be.check(be.c.gmx_shard_step_tiles(kind, kk, be.ptr(totals_all), be.ptr(plan), be.ptr(gtotal), be.ptr(lw),
                                                be.ptr(stats_own), be.ptr(mx), shift, g, W, n, C, be.ptr(local_index),
                                                be.ptr(send_idx), be.ptr(next_idx), be.stream()), "gmx_shard_step_tiles")
+        elif kind == MULTINOMIAL_SORTED:      # every rank draws the same table of the K global slots from the key
+            if sorted_tab is None:
+                sorted_tab = torch.zeros((int(be.c.gmx_sorted_uniforms_words(K)),), dtype=torch.int32, device=dev)
+                kd = torch.tensor([int(kk[0]), int(kk[1])], dtype=torch.int64).to(torch.int32).to(dev)
+                be.check(be.c.gmx_sorted_uniforms(be.ptr(kd), 1, K, be.ptr(sorted_tab), 0, be.stream()), "gmx_sorted_uniforms")
+            be.check(be.c.gmx_shard_step_sorted(be.ptr(sorted_tab), be.ptr(totals_all), be.ptr(plan), be.ptr(gtotal),
+                                                be.ptr(cdf), g, W, n, C, be.ptr(local_index), be.ptr(send_idx),
+                                                be.ptr(next_idx), be.stream()), "gmx_shard_step_sorted")
         else:
             be.check(be.c.gmx_shard_step(kind, kk, be.ptr(totals_all), be.ptr(plan), be.ptr(gtotal), be.ptr(cdf), g, W,
                                          n, C, be.ptr(local_index), be.ptr(send_idx), be.ptr(next_idx), be.stream()),

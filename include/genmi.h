@@ -422,6 +422,13 @@ int gmx_shard_step(int kind, const uint32_t key[2], const uint64_t* totals_d /* 
                    uint64_t* total_out_d /* [1] or NULL */, const uint64_t* cdf_d, int rank, int world,
                    int64_t n_per_rank, int64_t capacity, const void* state_d, void* send_d,
                    int32_t* next_idx_d, gmx_stream stream);
+/* The same step for GMX_RESAMPLE_MULTINOMIAL_SORTED (ref: inference/smc.py:274-339 resamples with
+ * `categorical(log_weights)` per slot = multinomial; csrc/gmx_sorted.h draws the n sorted uniforms as order
+ * statistics): table_d is gmx_sorted_uniforms(step key, n_per_rank * world) — integers, so every rank builds the
+ * same table — and a CDF value's slot count is a guided look-up in it.  Two launches (plan, route). */
+int gmx_shard_step_sorted(const uint32_t* table_d, const uint64_t* totals_d /* [world] */, int64_t* plan_d,
+                          uint64_t* total_out_d, const uint64_t* cdf_d, int rank, int world, int64_t n_per_rank,
+                          int64_t capacity, const void* state_d, void* send_d, int32_t* next_idx_d, gmx_stream stream);
 /* The same step from TILE STATISTICS — two collectives per step instead of three, no local CDF array.
  * Each rank's statistics block (gmx_shard_stats_bytes(n_per_rank) bytes: agg[tiles_pad] u64, then
  * tmax[tiles_pad] f32, tiles_pad = ceil(n_per_rank / 1024) rounded up to even; written by gmx_tile_stats or by

@@ -38,7 +38,8 @@ def schools_main(out_path, k_per_rank, capacity):
         from genjax_amd.inference.comm import make_comm
         comm = make_comm(dist, G._lib.get().device)
     coll, lw = sharded_importance_resample(G.Target(schools, (), C["y"].set(parity.SCHOOL_Y)), k_per_rank, G.key(2), dist,
-                                           capacity=capacity, stats=info, comm=comm)
+                                           kind=OPTS.get("resample", "systematic"), capacity=capacity, stats=info,
+                                           comm=comm)
     ch = coll.get_particles().get_choices()
     outs = {}
     for name in ("theta", "mu"):
@@ -72,7 +73,8 @@ def main(out_path, n_per_rank, T, capacity=None, mh=False, vec=False, vecmh=Fals
         init, step = workloads.make_nlssm(G)
         req = G.StaticRequest({"x": G.Rejuvenate(G.normal, lambda chm: (chm.get_value(), 0.5))})
         sw = ShardedBootstrapSweep(init, step, n_per_rank, T, dist, capacity=capacity, rejuvenate=req,
-                                   step_extra=lambda t: (float(t),)).prepare(G.key(7), torch.from_numpy(ys))
+                                   step_extra=lambda t: (float(t),), resample=OPTS.get("resample", "systematic")).prepare(
+            G.key(7), torch.from_numpy(ys))
     elif vecmh:  # a 2-vector state in one vector-valued site + one MH move per step: 2 x 2 routed leaves
         from genjax_amd import numpy as jnp
         from tests import parity
@@ -92,7 +94,8 @@ def main(out_path, n_per_rank, T, capacity=None, mh=False, vec=False, vecmh=Fals
         # noise_ahead: the step's draws by background programs keyed by the global particle index
         na = True if OPTS.get("noise_ahead") else (False if on_gpu else None)
         sw = ShardedBootstrapSweep(init, step, n_per_rank, T, dist, capacity=capacity, noise_ahead=na,
-                                   cdf_form=bool(OPTS.get("cdf_form")), fused=bool(OPTS.get("fused", 1))).prepare(
+                                   cdf_form=bool(OPTS.get("cdf_form")), fused=bool(OPTS.get("fused", 1)),
+                                   resample=OPTS.get("resample", "systematic")).prepare(
             G.key(314159), torch.from_numpy(ys))
         assert sw.noise_ahead == bool(na)
     sw.launch()

@@ -668,6 +668,52 @@ extern "C" int gmx_shard_step(int kind, const uint32_t key[2], const uint64_t* t
   plan[GMX_PLAN_OVERFLOW] = flag;
   return gmx_shard_route(kind, key, plan, cdf, rank, world, n, cap, state, send, next_idx, st);
 }
+// sorted multinomial across ranks, destination-centric: slot j of the N global slots sits at S_j / S_total; its ancestor
+// is the first GLOBAL source i with cdf_i * S_total > S_j * total
+extern "C" int gmx_shard_step_sorted(const uint32_t* table, const uint64_t* totals, int64_t* plan, uint64_t* total_out,
+                                     const uint64_t* cdf, int rank, int world, int64_t n, int64_t cap,
+                                     const void* state_v, void* send_v, int32_t* next_idx, gmx_stream) {
+  if (cap < 1 || cap > n) return fail("shard_step_sorted: capacity");
+  const int64_t N = n * world, base = (int64_t)rank * n;
+  const gmx_sorted_layout L = gmx_sorted_layout_of(N);
+  const uint64_t* toff = (const uint64_t*)(table + L.off_toff);
+  const uint64_t stot = toff[L.tiles];
+  auto S_of = [&](int64_t j) { const uint64_t off = toff[j / GMX_SORTED_TILE]; return off + (uint64_t)(uint32_t)(table[j] - (uint32_t)off); };
+  uint64_t total = 0, off = 0, mine = 0;
+  for (int s = 0; s < world; ++s) total += totals[s];
+  auto below = [&](uint64_t c) {           // #{ j : S_j * total < c * S_total }
+    if (total == 0) return (int64_t)0;
+    int64_t lo = 0, hi = N;
+    while (lo < hi) { int64_t mid = lo + ((hi - lo) >> 1); if ((u128)S_of(mid) * total < (u128)c * stot) lo = mid + 1; else hi = mid; }
+    return lo;
+  };
+  for (int s = 0; s < world; ++s) {
+    if (s == rank) mine = off;
+    plan[GMX_PLAN_BOUNDS + s] = below(off);
+    off += totals[s];
+  }
+  plan[GMX_PLAN_BOUNDS + world] = N; plan[GMX_PLAN_TOTAL] = (int64_t)total; plan[GMX_PLAN_OFFSET] = (int64_t)mine;
+  if (total_out) *total_out = total;
+  const int64_t* bounds = plan + GMX_PLAN_BOUNDS;
+  const uint32_t* state = (const uint32_t*)state_v; uint32_t* send = (uint32_t*)send_v;
+  const int64_t S = bounds[rank], E = bounds[rank + 1];
+  int64_t i = 0;
+  for (int64_t j = S; j < E; ++j) {
+    if (total == 0) i = n - 1;
+    else { const u128 P = (u128)S_of(j) * total; while (i < n - 1 && !((u128)(cdf[i] + mine) * stot > P)) ++i; }
+    int64_t d = j / n;
+    if (d == rank) next_idx[j - base] = (int32_t)i;
+    else { int64_t first = S > d * n ? S : d * n, k = j - first; if (k < cap) send[d * cap + k] = state[i]; else plan[GMX_PLAN_OVERFLOW] = 1; }
+  }
+  for (int64_t q = 0; q < n; ++q) {
+    int64_t jj = base + q;
+    int s = 0; while (s + 1 < world && bounds[s + 1] <= jj) ++s;
+    if (s == rank) continue;
+    int64_t first = bounds[s] > base ? bounds[s] : base, k = jj - first;
+    if (k < cap) next_idx[q] = (int32_t)(n + (int64_t)s * cap + k); else { next_idx[q] = 0; plan[GMX_PLAN_OVERFLOW] = 1; }
+  }
+  return 0;
+}
 extern "C" size_t gmx_shard_stats_bytes(int64_t n) { int64_t t = (n + HS_TILE - 1) / HS_TILE; t += t & 1; return (size_t)t * 12; }
 extern "C" int gmx_shard_totals(const void* stats_all, int world, int64_t n, uint64_t* totals, float* max_d, gmx_stream) {
   if (!stats_all || !totals || !max_d) return fail("shard_totals: null argument");

@@ -71,6 +71,28 @@ def test_sharded_sweep_equals_single_process_oracle(tmp_path, world, capacity, t
     assert np.array_equal(x, ref["x"][ref["anc"]])
 
 
+@pytest.mark.parametrize("world,capacity", [(2, 0), (4, 0), (4, 3)])
+def test_sharded_sweep_with_the_sorted_multinomial_equals_single_process_oracle(tmp_path, world, capacity):
+    """resample="multinomial_sorted" on the sharded router — every rank draws the same table of the
+    N global slots (order statistics, integers) and routes against it (gmx_shard_step_sorted); equal to the
+    single-process oracle sweep whatever the rank count, also through the capacity-overflow re-run."""
+    from genjax_amd import workloads
+    n_total, T = 4096, 6
+    out = str(tmp_path / "shard")
+    r = _launch(world, [out, str(n_total // world), str(T)] + ([str(capacity)] if capacity else []),
+                extra_env={"GENMI_TEST_OPTS": json.dumps({"resample": "multinomial_sorted"})})
+    assert r.returncode == 0, r.stderr[-3000:]
+    x = np.load(out + ".npy")
+    meta = json.load(open(out + ".json"))
+    ys = workloads.lgssm_data(T)
+    oi, ost = workloads.make_lgssm(O)
+    ref = parity.oracle_bootstrap_sweep(oi, ost, n_total, T, ys, O.key(314159), kind=O.MULTINOMIAL_SORTED)
+    assert [int(t) for t in meta["totals"]] == [h["total"] for h in ref["hist"]]
+    assert meta["log_ml"] == ref["log_ml"]
+    assert meta["reruns"] == (1 if capacity else 0), meta
+    assert np.array_equal(x, ref["x"][ref["anc"]])
+
+
 @pytest.mark.parametrize("comm,world,capacity,na,prog_stats", [
     ("p2p", 2, 0, 0, "1"), ("p2p", 4, 3, 0, "1"), ("p2p", 2, 0, 1, "1"),
     ("peer", 2, 0, 0, "1"), ("peer", 4, 3, 0, "1"), ("peer", 2, 0, 1, "1"), ("peer", 4, 0, 1, "0")])
@@ -178,13 +200,16 @@ def test_sharded_vector_state_mh_sweep_equals_single_process_oracle(tmp_path, wo
     assert meta["reruns"] == (1 if capacity else 0), meta
 
 
-@pytest.mark.parametrize("world,capacity", [(2, 0), (4, 5)])
-def test_sharded_importancek_global_resample_equals_oracle(tmp_path, world, capacity):
-    """BASELINE config 4 sharded (8-schools ImportanceK, ONE global systematic resample of a 10-latent
-    trace): the concatenated ranks equal the single-process oracle, for any rank count."""
+@pytest.mark.parametrize("world,capacity,kind", [(2, 0, "systematic"), (4, 5, "systematic"), (2, 0, "multinomial_sorted"),
+                                                 (4, 5, "multinomial_sorted")])
+def test_sharded_importancek_global_resample_equals_oracle(tmp_path, world, capacity, kind):
+    """BASELINE config 4 sharded (8-schools ImportanceK, ONE global resample of a 10-latent trace — systematic, or the
+    sorted multinomial against the table of all K slots): the concatenated ranks equal the single-process oracle, for
+    any rank count."""
     k_total = 4096
     out = str(tmp_path / "schools")
-    r = _launch(world, [out, str(k_total // world), "0", str(capacity), "schools"])
+    r = _launch(world, [out, str(k_total // world), "0", str(capacity), "schools"],
+                extra_env={"GENMI_TEST_OPTS": json.dumps({"resample": kind})})
     assert r.returncode == 0, r.stderr[-3000:]
     got = np.load(out + ".npz")
     sig = np.array(parity.SCHOOL_SIGMA, np.float32)
@@ -199,16 +224,18 @@ def test_sharded_importancek_global_resample_equals_oracle(tmp_path, world, capa
     oc = O.ImportanceK(O.Target(o_schools, (), O.C.d({"y": parity.SCHOOL_Y})), k_total).run_smc(O.key(2))
     assert np.array_equal(got["lw"], oc.get_log_weights())
     cdf, total, M, shift = O.weight_cdf(oc.get_log_weights())
-    anc = O.ancestors(O.SYSTEMATIC, O.split(O.key(2))[0], cdf)          # the algorithm's leftover key resamples
+    anc = O.ancestors_of_kind(O.MULTINOMIAL_SORTED if kind == "multinomial_sorted" else O.SYSTEMATIC,
+                              O.split(O.key(2))[0], cdf)                 # the algorithm's leftover key resamples
     assert np.array_equal(got["theta"], oc.get_particles().get_choices()["theta"][anc])
     assert np.array_equal(got["mu"], oc.get_particles().get_choices()["mu"][anc])
     assert abs(float(got["log_ml"]) - float(oc.get_log_marginal_likelihood_estimate())) < 2e-5
     # ONE plan for the whole 10-latent trace: one all-gather (tile statistics), ONE all-to-all (every row packed),
     # one 8-byte all-reduce per capacity attempt — however many leaves the trace has
     info = json.load(open(out + ".info.json"))
-    assert info["form"] == "tile statistics" and info["rows"] >= 10
-    assert info["collectives"]["all_gather"] == 1 and info["collectives"]["all_to_all"] == 1
-    assert 1 <= info["collectives"]["all_reduce_max"] <= 2
+    assert info["rows"] >= 10 and info["collectives"]["all_to_all"] == 1
+    if kind == "systematic":
+        assert info["form"] == "tile statistics"
+        assert info["collectives"]["all_gather"] == 1 and 1 <= info["collectives"]["all_reduce_max"] <= 2
 
 
 def test_slot_bounds_match_ancestors():

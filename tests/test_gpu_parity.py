@@ -458,6 +458,44 @@ def test_sharded_sweep_world1_matches_oracle(gpu):
     assert sw.log_ml() == ref["log_ml"]
 
 
+def test_sharded_sweep_with_the_sorted_multinomial(gpu, tmp_path):
+    """resample="multinomial_sorted" on the sharded router (gmx_shard_step_sorted: plan + route against
+    the order-statistics table of all N slots) — world size 1 in this process, and two ranks (processes sharing the
+    box's GPU, p2p communicator) — equal to the single-process oracle sweep."""
+    import json
+    import genjax_amd as G
+    from genjax_amd import workloads
+    from genjax_amd.inference.sharded import ShardedBootstrapSweep
+    from tests.test_distributed_cpu import _launch
+
+    class _Solo:
+        @staticmethod
+        def get_rank(): return 0
+        @staticmethod
+        def get_world_size(): return 1
+    n, T = 300_000, 5
+    ys = workloads.lgssm_data(T)
+    init, step = workloads.make_lgssm(G)
+    oi, ost = workloads.make_lgssm(O)
+    sw = ShardedBootstrapSweep(init, step, n, T, _Solo, resample="multinomial_sorted").prepare(G.key(314159), torch.from_numpy(ys))
+    sw.launch()
+    ref = parity.oracle_bootstrap_sweep(oi, ost, n, T, ys, O.key(314159), kind=O.MULTINOMIAL_SORTED)
+    assert np.array_equal(sw.state().cpu().numpy(), ref["x"][ref["anc"]])
+    assert sw.totals.cpu().numpy().view(np.uint64).tolist() == [h["total"] for h in ref["hist"]]
+    assert sw.log_ml() == ref["log_ml"]
+    n_total, T = 8192, 6
+    out = str(tmp_path / "sorted_gpu")
+    r = _launch(2, [out, str(n_total // 2), str(T)],
+                extra_env={"GENMI_COMM": "p2p", "GENMI_COMM_TIMEOUT": "60",
+                           "GENMI_TEST_OPTS": json.dumps({"on_gpu": 1, "resample": "multinomial_sorted"})})
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    ys = workloads.lgssm_data(T)
+    ref = parity.oracle_bootstrap_sweep(oi, ost, n_total, T, ys, O.key(314159), kind=O.MULTINOMIAL_SORTED)
+    meta = json.load(open(out + ".json"))
+    assert [int(t) for t in meta["totals"]] == [h["total"] for h in ref["hist"]] and meta["log_ml"] == ref["log_ml"]
+    assert np.array_equal(np.load(out + ".npy"), ref["x"][ref["anc"]])
+
+
 def test_sharded_sweep_over_the_peer_mapped_communicator_world1(gpu, monkeypatch):
     """GENMI_COMM=p2p on the device at world size 1: the collectives of every step go through gmx_p2p_exchange (put into
     the peer-mapped buffer — here the rank's own — flag, wait, device-side epoch), eagerly AND as a captured hipGraph

@@ -42,7 +42,7 @@ def main(bench_root, calib_root, out):
         fetch, write = d.get("FETCH_SIZE", 0) * 1024, d.get("WRITE_SIZE", 0) * 1024
         res["kernels"][k] = {"FETCH_SIZE_bytes_raw": fetch, "WRITE_SIZE_bytes": write,
                              "hbm_bytes_corrected": f_rd * fetch + write}
-        if k.startswith("gmx_jit_kernel") or k.startswith("void k_vm"):
+        if k.startswith("gmx_jit_kernel") or k.startswith("void k_vm") or k.startswith("k_vm_lean"):
             res["k_vm_hbm_bytes_per_launch"] = f_rd * fetch + write
         if k.startswith("gmx_jit_background_kernel"):
             res["noise_hbm_bytes_per_launch"] = f_rd * fetch + write

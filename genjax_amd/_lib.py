@@ -20,7 +20,7 @@ GMX_MAX_OUT = 64
 GMX_MAX_TAB = 8
 GMX_MAX_UNI = 64
 
-ABI_VERSION = 6
+ABI_VERSION = 5
 KEY_NONE, KEY_ARRAY, KEY_SPLIT, KEY_ROWSPLIT, KEY_BCAST = 0, 1, 2, 3, 4
 RESAMPLE_SYSTEMATIC, RESAMPLE_STRATIFIED, RESAMPLE_MULTINOMIAL, RESAMPLE_MULTINOMIAL_TILED = 0, 1, 2, 3
 RESAMPLE_MULTINOMIAL_SORTED = 4
@@ -35,13 +35,12 @@ class ResampleIn(Structure):
         ("max_out_d", c_void_p),
         ("total_out_d", c_void_p),
         ("status_d", c_void_p),
-        ("stat_tag_d", c_void_p),
         ("shift", c_int32),
         ("tag", c_uint32),
         ("key0", c_uint32),
         ("key1", c_uint32),
         ("u0", c_uint32),
-        ("stat_tag", c_uint32),
+        ("reserved_", c_uint32),
     ]
 
 
@@ -78,8 +77,7 @@ class RunArgs(Structure):
         ("red_out_d", c_void_p),
         ("tile_agg_d", c_void_p),
         ("tile_shift", c_int32),
-        ("stat_tag_out", c_uint32),
-        ("stat_tag_out_d", c_void_p),
+        ("reserved_", c_int32),
         ("step_stride", c_int64),
         ("rs", ResampleIn),
         ("peer", Peer),
@@ -123,8 +121,6 @@ class Backend:
         c.gmx_program_grid.restype = c_int64
         c.gmx_program_run.argtypes = [c_void_p, c_int64, POINTER(RunArgs), c_void_p]
         c.gmx_program_writes_tile_stats.argtypes = [c_void_p]
-        c.gmx_program_bind_steps.argtypes = [c_void_p, c_int64, POINTER(RunArgs), c_int, c_void_p]
-        c.gmx_program_run_steps.argtypes = [c_void_p, c_int64, c_void_p, c_int, c_void_p]
         c.gmx_program_set_background.argtypes = [c_void_p, c_uint32]
         c.gmx_program_set_fuse_resample.argtypes = [c_void_p]
         c.gmx_program_fuses_resample.argtypes = [c_void_p]

@@ -33,14 +33,8 @@
 #define GMX_JIT_NAME gmx_jit_kernel
 #endif
 
-// COH (a step of a MULTI-STEP launch, gmx_program_run_steps): what this step writes is read by OTHER workgroups of the
-// same launch one step later, and what it gathers was written by them — outputs and statistics are stored, and gathered
-// rows loaded, at agent scope (write-through / past the per-XCD caches), and the statistics' tag is published at the
-// END of the step, after every store of the workgroup has been acknowledged.
-template <int NDYN, int PPV, bool COH>
+template <int NDYN, int PPV>
 struct gmx_jit_ctx {
-  static constexpr bool coherent = COH;
-  uint64_t stat_agg; float stat_max;     // COH: the tile statistics, published at the end of the step
   const uint32_t* consts;   // constexpr constants (pool entries NDYN..)
   const gmx_run_args* A;
   float* lds4;
@@ -71,10 +65,7 @@ struct gmx_jit_ctx {
     acc_max = first ? m : gmx_rmax(acc_max, m);
     if (last) {
       const float bm = block_max(acc_max, lds4);
-      if (threadIdx.x == 0 && A->red_out_d) {
-        if (COH) __hip_atomic_store(A->red_out_d + blockIdx.x, bm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else A->red_out_d[blockIdx.x] = bm;
-      }
+      if (threadIdx.x == 0 && A->red_out_d) A->red_out_d[blockIdx.x] = bm;
       if (PPV == 4 && A->tile_agg_d) {
         const float ref = gmx_tile_ref(gmx_tile_exp(bm));
         uint64_t s = 0;
@@ -84,13 +75,7 @@ struct gmx_jit_ctx {
         if ((threadIdx.x & 63) == 0) lds8[threadIdx.x >> 6] = s;
         __syncthreads();
         const uint64_t a_b = (lds8[0] + lds8[1]) + (lds8[2] + lds8[3]);
-        if (threadIdx.x == 0) {
-          if (COH) __hip_atomic_store(A->tile_agg_d + blockIdx.x, a_b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          else {
-            A->tile_agg_d[blockIdx.x] = a_b;
-            if (A->stat_tag_out_d) A->stat_tag_out_d[blockIdx.x] = A->stat_tag_out;     // (the launch's end publishes it)
-          }
-        }
+        if (threadIdx.x == 0) A->tile_agg_d[blockIdx.x] = a_b;
         // sharded: the same two numbers straight into every other rank's landing table (thread p serves rank p)
         if (peer_land) gmx_peer_put_tile(peer_land, peer_tag, A->peer.world, A->peer.tiles, A->peer.rank, (int)blockIdx.x, a_b, bm);
       }
@@ -114,13 +99,13 @@ struct gmx_jit_ctx {
 // the ancestors at the top, the rows they name after the first key derivation (one Threefry block per
 // particle hides the first round trip); the second round trip is hidden by the rest of the RNG work.
 #define GMX_JIT_BEGIN(NREGS, FULLV, NDYN, PPV, NPRE)                                             \
-  template <bool GMX_MULTI>                                                                      \
-  __device__ __forceinline__ void gmx_jit_step(const int64_t n, const gmx_run_args& A) {         \
+  extern "C" __global__ void __launch_bounds__(GMX_BLOCK) GMX_JIT_NAME(int64_t n, const gmx_run_args A) { \
+ GMX_JIT_PRIO                                                                                 \
     __shared__ float lds4[4];                                                                    \
     __shared__ uint64_t lds8[4];                                                                 \
     constexpr int PP = PPV;                                                                      \
     typedef gmx_regs_vgpr<NREGS> regs_t;                                                         \
-    typedef gmx_jit_ctx<NDYN, PPV, GMX_MULTI> ctx_t;                                             \
+    typedef gmx_jit_ctx<NDYN, PPV> ctx_t;                                                        \
     constexpr bool full_v = FULLV;                                                               \
     ctx_t ctx;                                                                                   \
     ctx.consts = GMX_JIT_CONST; ctx.A = &A; ctx.lds4 = lds4; ctx.lds8 = lds8; ctx.part = 0; ctx.cur = 0; \
@@ -161,9 +146,9 @@ struct gmx_jit_ctx {
 #if defined(GMX_JIT_RS)
 #define GMX_JIT_PRE_ANC                                                                          \
     if (PP == 4 && A.rs.lw_d) {                                                                  \
-      gmx_offspring_tile_body<GMX_RESAMPLE_SYSTEMATIC, 4, true, GMX_MULTI>(A.rs.key0, A.rs.key1, A.rs.u0, A.rs.lw_d, A.rs.tile_max_d, \
+      gmx_offspring_tile_body<GMX_RESAMPLE_SYSTEMATIC, 4, true>(A.rs.key0, A.rs.key1, A.rs.u0, A.rs.lw_d, A.rs.tile_max_d, \
           A.rs.tile_agg_d, n, (int)gridDim.x, gmx_pow2i(A.rs.shift), A.rs.max_out_d, A.rs.total_out_d,          \
-          const_cast<int32_t*>(A.ancestors_d), nullptr, A.rs.tag, A.rs.stat_tag_d, A.rs.stat_tag, A.rs.status_d); \
+          const_cast<int32_t*>(A.ancestors_d), nullptr, A.rs.tag);                                \
       const uint32_t* gmx_aw = reinterpret_cast<const uint32_t*>(A.ancestors_d);                 \
       uint32_t gmx_av[PP];                                                                       \
       bool gmx_ok = true;                                                                        \
@@ -199,13 +184,7 @@ struct gmx_jit_ctx {
     _Pragma("unroll") for (int p = 0; p < PP; ++p)                                               \
       pre[K][p] = (U8) ? (uint32_t)((const uint8_t*)A.in_d[SLOT])[ROW[p]] : ((const uint32_t*)A.in_d[SLOT])[ROW[p]];
 #define GMX_JIT_PRE(K, SLOT, U8) GMX_JIT_PRE_LOAD(K, SLOT, U8, cidx)
-// gathered rows: in a multi-step launch other workgroups wrote them one step ago, in this launch (agent-scope loads)
-#define GMX_JIT_PRE_G(K, SLOT, U8)                                                               \
-    if (GMX_MULTI) {                                                                             \
-      _Pragma("unroll") for (int p = 0; p < PP; ++p)                                             \
-        pre[K][p] = (U8) ? (uint32_t)__hip_atomic_load((const uint8_t*)A.in_d[SLOT] + arow[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) \
-                         : __hip_atomic_load((const uint32_t*)A.in_d[SLOT] + arow[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
-    } else { GMX_JIT_PRE_LOAD(K, SLOT, U8, arow) }
+#define GMX_JIT_PRE_G(K, SLOT, U8) GMX_JIT_PRE_LOAD(K, SLOT, U8, arow)
 #define GMX_JIT_FENCE __builtin_amdgcn_sched_barrier(0);
 
 // OP_LDIN whose value was prefetched
@@ -225,37 +204,4 @@ struct gmx_jit_ctx {
 #define GMX_JIT_LOOP2(COUNT) for (uint32_t gmx_t1 = 0u; gmx_t1 < (COUNT); ++gmx_t1) { gmx_t = gmx_t1; gmx_tf = gmx_t0 * (COUNT) + gmx_t1;
 #define GMX_JIT_ENDLOOP2 } gmx_t = gmx_t0; gmx_tf = gmx_t0;
 
-// the end of a step, then the kernels around it.  A step of a multi-step launch publishes its statistics' tag once every
-// store of the workgroup has been acknowledged (write-through stores + s_waitcnt + barrier: the data is at the agent's
-// coherence point before the tag that announces it); the barrier also hands the LDS scratch to the next step.
-#if defined(GMX_JIT_RS)
-#define GMX_JIT_STEPS_KERNEL                                                                     \
-  extern "C" __global__ void __launch_bounds__(GMX_BLOCK) __attribute__((amdgpu_waves_per_eu(5, 8)))  \
-  gmx_jit_kernel_steps(int64_t n, const gmx_run_args* __restrict__ steps, int32_t n_steps) {     \
-    GMX_JIT_PRIO                                                                                 \
-    typedef const uint64_t __attribute__((address_space(4))) cword_t;     /* constant address space: invariant scalar loads */ \
-    constexpr int NW = (int)(sizeof(gmx_run_args) / 8);                                          \
-    static_assert(sizeof(gmx_run_args) % 8 == 0, "gmx_run_args is copied in 8-byte words");       \
-    for (int32_t gs = 0; gs < n_steps; ++gs) {                                                   \
-      cword_t* w = (cword_t*)(uintptr_t)(steps + gs);                                            \
-      union { uint64_t words[NW]; gmx_run_args A; } u;                                           \
-      _Pragma("unroll") for (int k = 0; k < NW; ++k) u.words[k] = w[k];                          \
-      gmx_jit_step<true>(n, u.A);                                                                \
-    }                                                                                            \
-  }
-#else
-#define GMX_JIT_STEPS_KERNEL
-#endif
-#define GMX_JIT_END                                                                              \
-    if (GMX_MULTI) {                                                                             \
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                           \
-      __syncthreads();                                                                           \
-      if (threadIdx.x == 0 && A.stat_tag_out_d)                                                  \
-        __hip_atomic_store(A.stat_tag_out_d + blockIdx.x, A.stat_tag_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
-    }                                                                                            \
-  }                                                                                              \
-  extern "C" __global__ void __launch_bounds__(GMX_BLOCK) GMX_JIT_NAME(int64_t n, const gmx_run_args A) { \
-    GMX_JIT_PRIO                                                                                 \
-    gmx_jit_step<false>(n, A);                                                                   \
-  }                                                                                              \
-  GMX_JIT_STEPS_KERNEL
+#define GMX_JIT_END }

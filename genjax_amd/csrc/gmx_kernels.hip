@@ -148,7 +148,6 @@ struct gmx_program {
   std::vector<uint32_t> consts;      // pool entries n_dyn..
   hipModule_t jit_module = nullptr;  // specialised kernel (gmx_program_specialize)
   hipFunction_t jit_fn = nullptr;
-  hipFunction_t jit_fn_steps = nullptr;   // gmx_jit_kernel_steps (programs built with fuse_rs): gmx_program_run_steps
   int jit_pp = 1;                    // particles per thread of the specialised kernel
   uint64_t jit_code_hash = 0;        // FNV-1a of the loaded code object (gmx_program_code_hash)
   bool fuse_rs = false;              // gmx_program_set_fuse_resample: the specialised kernel can resample first
@@ -498,12 +497,6 @@ static int jit_load(gmx_program* p, const std::vector<char>& code) {
   if (e != hipSuccess) { (void)hipModuleUnload(mod); return gmx_fail("hipModuleGetFunction: %s", hipGetErrorString(e)); }
   p->jit_module = mod;
   p->jit_fn = fn;
-  p->jit_fn_steps = nullptr;
-  if (p->fuse_rs && !p->background) {
-    hipFunction_t fs;
-    if (hipModuleGetFunction(&fs, mod, "gmx_jit_kernel_steps") == hipSuccess) p->jit_fn_steps = fs;
-    else (void)hipGetLastError();
-  }
   p->jit_pp = jit_pp_for(p);
   p->jit_code_hash = fnv1a(0xcbf29ce484222325ull, code.data(), code.size());
   if (p->lds_pad > 48 * 1024) {
@@ -581,10 +574,11 @@ extern "C" int64_t gmx_program_grid(const gmx_program* p, int64_t n) {
   return (n + per - 1) / per;
 }
 
-// host-side checks of one argument block (gmx_program_run, and every step of gmx_program_bind_steps)
-static int run_args_check(const gmx_program* p, int64_t n, const gmx_run_args* args) {
+extern "C" int gmx_program_run(const gmx_program* p, int64_t n, const gmx_run_args* args,
+                               gmx_stream stream) {
   if (!p || !args) return gmx_fail("gmx_program_run: null argument%s");
   if (n < 0) return gmx_fail("gmx_program_run: negative n%s");
+  if (n == 0) return 0;
   if (n > (int64_t)0x7fffffff * GMX_BLOCK) return gmx_fail("gmx_program_run: n too large%s");
   // host-side shape checks: every slot the program names must be bound
   for (uint32_t s = 0; s < p->n_in; ++s)
@@ -625,8 +619,6 @@ static int run_args_check(const gmx_program* p, int64_t n, const gmx_run_args* a
                       "(gmx_program_writes_tile_stats)%s");
     if (args->tile_shift < 1 || args->tile_shift > 62) return gmx_fail("gmx_program_run: tile_shift out of range%s");
   }
-  if (args->stat_tag_out_d && !args->tile_agg_d)
-    return gmx_fail("gmx_program_run: stat_tag_out_d goes with tile_agg_d (the statistics it announces)%s");
   if (p->uses_step && args->step_stride < n)
     return gmx_fail("gmx_program_run: step_stride must be at least n for a program with step-indexed leaves%s");
   if (p->uses_key) {
@@ -638,33 +630,20 @@ static int run_args_check(const gmx_program* p, int64_t n, const gmx_run_args* a
     if (km == GMX_KEY_ROWSPLIT && args->key_inner <= 0)
       return gmx_fail("gmx_program_run: key_inner must be positive%s");
   }
-  return 0;
-}
-
-// what the library fills in: the program's constants after the launch uniforms, the fused resampler's first uniform
-static bool run_args_patch(const gmx_program* p, const gmx_run_args* args, gmx_run_args& patched) {
-  const bool fused_rs = args->rs.lw_d != nullptr;
-  if (!p->n_const && !fused_rs) return false;
-  patched = *args;
-  for (uint32_t k = 0; k < p->n_const; ++k) patched.uni[p->n_dyn + k] = p->consts[k];
-  if (fused_rs) {
-    uint32_t b0, b1;
-    gmx_threefry2x32(patched.rs.key0, patched.rs.key1, 0u, 0u, &b0, &b1);     // bits32(key, 0) on the host
-    patched.rs.u0 = (b0 ^ b1) >> 9;
-  }
-  return true;
-}
-
-extern "C" int gmx_program_run(const gmx_program* p, int64_t n, const gmx_run_args* args,
-                               gmx_stream stream) {
-  if (!p || !args) return gmx_fail("gmx_program_run: null argument%s");
-  if (n == 0) return 0;
-  if (run_args_check(p, n, args)) return 1;
   dim3 grid((unsigned)((n + GMX_BLOCK - 1) / GMX_BLOCK)), block(GMX_BLOCK);
   hipStream_t st = (hipStream_t)stream;
   // the program's constants live in the operand pool after the launch uniforms
   gmx_run_args patched;
-  if (run_args_patch(p, args, patched)) args = &patched;
+  if (p->n_const || fused_rs) {
+    patched = *args;
+    for (uint32_t k = 0; k < p->n_const; ++k) patched.uni[p->n_dyn + k] = p->consts[k];
+    if (fused_rs) {
+      uint32_t b0, b1;
+      gmx_threefry2x32(patched.rs.key0, patched.rs.key1, 0u, 0u, &b0, &b1);     // bits32(key, 0) on the host
+      patched.rs.u0 = (b0 ^ b1) >> 9;
+    }
+    args = &patched;
+  }
   if (p->jit_fn) {
     if (n >= 0x7fffffffLL - 4 * GMX_BLOCK)
       return gmx_fail("gmx_program_run: a specialised kernel indexes particles with 32 bits (n < 2^31 - 1024)%s");
@@ -707,67 +686,6 @@ extern "C" int gmx_program_run(const gmx_program* p, int64_t n, const gmx_run_ar
       hipLaunchKernelGGL((k_vm<gmx_regs_vgpr<32>, false>), grid, block, 0, st, p->code_d, p->n_instr, n, *args);
   }
   GMX_HIP(hipGetLastError());
-  return 0;
-}
-
-// ---- several consecutive bootstrap steps in one launch (include/genmi.h: gmx_program_run_steps) ----
-#define GMX_MAX_STEPS_PER_LAUNCH 4096
-static int steps_shape(const char* who, const gmx_program* p, int64_t n, const void* steps, int n_steps) {
-  if (!p || !steps) return gmx_fail("%s: null argument", who);
-  if (!p->jit_fn_steps || !gmx_program_fuses_resample(p))
-    return gmx_fail("%s: the program has no multi-step kernel (gmx_program_set_fuse_resample before specialising; 4 "
-                    "particles per thread; every gathered load prefetched)", who);
-  if (n_steps < 1 || n_steps > GMX_MAX_STEPS_PER_LAUNCH) return gmx_fail("%s: n_steps out of range", who);
-  if (n <= 0 || (n + RS_TILE - 1) / RS_TILE > 1024)
-    return gmx_fail("%s: every workgroup of the launch must be resident at once (0 < n <= 2^20)", who);
-  return 0;
-}
-
-extern "C" int gmx_program_bind_steps(const gmx_program* p, int64_t n, const gmx_run_args* steps_h, int n_steps,
-                                      void* steps_d) {
-  if (steps_shape("gmx_program_bind_steps", p, n, steps_h, n_steps)) return 1;
-  if (!steps_d || ((uintptr_t)steps_d & 7)) return gmx_fail("gmx_program_bind_steps: steps_d must be a device buffer, 8-byte aligned%s");
-  std::vector<gmx_run_args> blocks((size_t)n_steps);
-  for (int s = 0; s < n_steps; ++s) {
-    const gmx_run_args* a = steps_h + s;
-    if (run_args_check(p, n, a)) return 1;
-    if (!a->rs.lw_d) return gmx_fail("gmx_program_bind_steps: every step resamples the step before it (rs.lw_d)%s");
-    if (a->peer.land_d) return gmx_fail("gmx_program_bind_steps: not with a peer exchange%s");
-    if (!a->tile_agg_d || !a->red_out_d || !a->stat_tag_out_d)
-      return gmx_fail("gmx_program_bind_steps: every step publishes its tile statistics and their tag "
-                      "(tile_agg_d, red_out_d, stat_tag_out_d)%s");
-    if (!a->rs.stat_tag_d) return gmx_fail("gmx_program_bind_steps: every step waits for the tags of the statistics it reads (rs.stat_tag_d)%s");
-    if (a->stat_tag_out_d == a->rs.stat_tag_d)
-      return gmx_fail("gmx_program_bind_steps: a step publishes its tag where it reads the previous one (use two sets)%s");
-    if (s > 0) {
-      const gmx_run_args* b = steps_h + s - 1;
-      // what step s reads of step s - 1 is what step s - 1 wrote, under the tag it published
-      if (a->rs.tile_agg_d != b->tile_agg_d || (const void*)a->rs.tile_max_d != (const void*)b->red_out_d ||
-          a->rs.stat_tag_d != b->stat_tag_out_d || a->rs.stat_tag != b->stat_tag_out)
-        return gmx_fail("gmx_program_bind_steps: step s reads the statistics (and tag) step s - 1 publishes%s");
-      if (a->rs.tag == b->rs.tag) return gmx_fail("gmx_program_bind_steps: consecutive steps need different ancestor tags%s");
-      if (a->stat_tag_out == b->stat_tag_out && a->stat_tag_out_d == b->stat_tag_out_d)
-        return gmx_fail("gmx_program_bind_steps: consecutive steps need different statistics tags%s");
-      for (uint32_t o = 0; o < p->n_out; ++o)
-        for (uint32_t q = 0; q < p->n_out; ++q)
-          if (a->out_d[o] == b->out_d[q])
-            return gmx_fail("gmx_program_bind_steps: consecutive steps write the same output buffer (ping-pong them)%s");
-    }
-    if (!run_args_patch(p, a, blocks[(size_t)s])) blocks[(size_t)s] = *a;
-  }
-  GMX_HIP(hipMemcpy(steps_d, blocks.data(), blocks.size() * sizeof(gmx_run_args), hipMemcpyHostToDevice));
-  return 0;
-}
-
-extern "C" int gmx_program_run_steps(const gmx_program* p, int64_t n, const void* steps_d, int n_steps,
-                                     gmx_stream stream) {
-  if (steps_shape("gmx_program_run_steps", p, n, steps_d, n_steps)) return 1;
-  struct { int64_t n; const void* steps; int32_t n_steps; int32_t pad_; } ka;
-  ka.n = n; ka.steps = steps_d; ka.n_steps = n_steps; ka.pad_ = 0;
-  size_t ka_size = sizeof(ka);
-  void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &ka, HIP_LAUNCH_PARAM_BUFFER_SIZE, &ka_size, HIP_LAUNCH_PARAM_END};
-  const unsigned jgrid = (unsigned)((n + (int64_t)GMX_BLOCK * 4 - 1) / ((int64_t)GMX_BLOCK * 4));
-  GMX_HIP(hipModuleLaunchKernel(p->jit_fn_steps, jgrid, 1, 1, GMX_BLOCK, 1, 1, 0, (hipStream_t)stream, nullptr, config));
   return 0;
 }
 

@@ -86,16 +86,12 @@ static_assert(RS_MAX_TILES % RS_BLOCK == 0, "tile table shape");
 // thread (two 16-byte stores): the same cost whatever the weights (a thread writing its own sources' slots in a loop
 // diverges over the offspring counts: measured 2688 -> 34 us for N(0, 4) log-weights); a tile owning more than 2048
 // slots takes more passes (block-uniform).
-// COH (a step of a multi-step launch, gmx_jit.h): the log-weights and the tile statistics were written one step ago by
-// workgroups of THIS launch — they are read at agent scope, and the statistics only once every row the thread reads
-// carries the step's tag in stat_tag_d (bounded wait; *status_d on a timeout).
-template <int kind, int PER, bool TAGGED, bool COH = false>
+template <int kind, int PER, bool TAGGED>
 __device__ __forceinline__ void
 gmx_offspring_tile_body(uint32_t k0, uint32_t k1, uint32_t u0_host, const float* __restrict__ lw,
                         const float* __restrict__ tmax, const uint64_t* __restrict__ agg, int64_t n, int n_tiles, float scale,
                         float* __restrict__ max_out, uint64_t* __restrict__ total_out, int32_t* __restrict__ anc,
-                        const uint32_t* __restrict__ uslot, uint32_t tag, const uint32_t* stat_tag_d = nullptr,
-                        uint32_t stat_tag = 0u, uint64_t* status_d = nullptr) {
+                        const uint32_t* __restrict__ uslot, uint32_t tag) {
   const uint32_t tagw = TAGGED ? (tag << GMX_ANC_TAG_SHIFT) : 0u;
   __shared__ uint64_t s_below[RS_WAVES], s_all[RS_WAVES], s_scan[RS_WAVES], s_g[RS_TPB];
   __shared__ float s_max[RS_WAVES];
@@ -109,19 +105,14 @@ gmx_offspring_tile_body(uint32_t k0, uint32_t k1, uint32_t u0_host, const float*
   // ---- issue every load first ----
   float x[CDF_VEC_OT];
   const bool full_tile = (int64_t)(tile_c + 1) * RS_TILE <= n;                   // wave-uniform
-  if (COH && full_tile) {
-#pragma unroll
-    for (int c = 0; c < CDF_VEC_OT; ++c)
-      x[c] = gmx_u2f(__hip_atomic_load(reinterpret_cast<const uint32_t*>(lw) + i0 + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-  } else if (full_tile) {
+  if (full_tile) {
     float4 v = *reinterpret_cast<const float4*>(lw + i0);
     x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
   } else {
 #pragma unroll
     for (int c = 0; c < CDF_VEC_OT; ++c) {
       const int64_t ic = i0 + c < n ? i0 + c : n - 1;
-      const float xv = COH ? gmx_u2f(__hip_atomic_load(reinterpret_cast<const uint32_t*>(lw) + ic, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-                           : lw[ic];
+      const float xv = lw[ic];
       x[c] = (i0 + c < n) ? xv : -gmx_inf();
     }
   }
@@ -134,29 +125,6 @@ gmx_offspring_tile_body(uint32_t k0, uint32_t k1, uint32_t u0_host, const float*
   uint64_t ta[PERN];
   float tm[PERN];
   uint64_t pf_prefix = 0, pf_total = 0, pf_mk = 0;
-  if (COH && !PREF && stat_tag_d) {
-    // the rows of the table this thread reads (and the workgroup's own) must be the previous step's: their tags say so
-    auto rows_tagged = [&]() {
-      bool ok = __hip_atomic_load(stat_tag_d + tile_c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == stat_tag;
-#pragma unroll
-      for (int r = 0; r < PERN; ++r)
-        if (r * RS_BLOCK < n_tiles) {
-          const int t = r * RS_BLOCK + (int)threadIdx.x;
-          const int tc = t < n_tiles ? t : n_tiles - 1;
-          ok &= __hip_atomic_load(stat_tag_d + tc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == stat_tag;
-        }
-      return ok;
-    };
-    if (!rows_tagged()) {
-      const uint64_t t0 = wall_clock64();
-      bool ok = false;
-      do {
-        __builtin_amdgcn_s_sleep(1);
-        ok = rows_tagged();
-      } while (!ok && wall_clock64() - t0 < 200000000ull);
-      if (!ok && status_d) __hip_atomic_store(status_d, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
   if (PREF) {
     pf_prefix = agg[tile_c]; pf_total = agg[n_tiles]; pf_mk = agg[n_tiles + 1];
   } else {
@@ -166,18 +134,12 @@ gmx_offspring_tile_body(uint32_t k0, uint32_t k1, uint32_t u0_host, const float*
       if (r * RS_BLOCK < n_tiles) {                // uniform: rows of the table that exist
         const int t = r * RS_BLOCK + (int)threadIdx.x;
         const int tc = t < n_tiles ? t : n_tiles - 1;
-        if (COH) {
-          ta[r] = __hip_atomic_load(agg + tc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          tm[r] = gmx_u2f(__hip_atomic_load(reinterpret_cast<const uint32_t*>(tmax) + tc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        } else {
-          ta[r] = agg[tc];
-          tm[r] = tmax[tc];
-        }
+        ta[r] = agg[tc];
+        tm[r] = tmax[tc];
       }
     }
   }
-  const float tmax_mine = COH ? gmx_u2f(__hip_atomic_load(reinterpret_cast<const uint32_t*>(tmax) + tile_c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-                              : tmax[tile_c];
+  const float tmax_mine = tmax[tile_c];
   uint64_t sx_stot = 0; uint32_t sx_sh = 0;             // the sorted kind's table header (uniform), with the other early loads
   if constexpr (kind == GMX_RESAMPLE_MULTINOMIAL_SORTED) {
     const gmx_sorted_layout L = gmx_sorted_layout_of(n);

@@ -28,10 +28,6 @@
 
 // Register file held in VGPRs; N <= 32 keeps hipcc's dynamic indexing on
 // s_set_gpr_idx (larger vectors fall back to scratch on gfx950).
-// does the context ask for agent-scope (write-through) output stores?  (gmx_jit_ctx<.., COH = true>: gmx_jit.h)
-template <class C, class = void> struct gmx_ctx_coherent { static constexpr bool value = false; };
-template <class C> struct gmx_ctx_coherent<C, decltype((void)C::coherent)> { static constexpr bool value = C::coherent; };
-
 template <int N>
 struct gmx_regs_vgpr {
 #if defined(__HIPCC__)
@@ -120,12 +116,6 @@ GMX_HD void gmx_vm_step(Regs& R, const W w, int64_t i, bool active, const gmx_ru
         if (active) {
           void* p = ctx.out_ptr(a);
           const int64_t orow = (dst & GMX_F_STEP) ? i + (int64_t)((dst & GMX_F_FLAT) ? tf : t) * A.step_stride : i;
-#if defined(__HIP_DEVICE_COMPILE__)
-          if (gmx_ctx_coherent<Ctx>::value) {       // a step of a multi-step launch: write-through, for the next step's readers
-            if (dst & GMX_F_U8) __hip_atomic_store((uint8_t*)p + orow, (uint8_t)(v != 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            else __hip_atomic_store((uint32_t*)p + orow, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          } else
-#endif
           if (dst & GMX_F_U8) ((uint8_t*)p)[orow] = (uint8_t)(v != 0u);
           else ((uint32_t*)p)[orow] = v;
         }

@@ -930,34 +930,6 @@ class Compiled:
         self.launch(bound)
         return bound[3]
 
-    def bind_steps(self, bounds):
-        """Several consecutive bootstrap steps as ONE launch (include/genmi.h: gmx_program_bind_steps): `bounds` = the
-        bindings `bind` made for the steps, in order (each with resample_in and a tagged tile_stats).  Returns what
-        `launch_steps` takes; it keeps the bindings' buffers alive.  Synchronous: call it outside stream capture."""
-        be = self._be
-        n = int(bounds[0][0])
-        if any(int(b[0]) != n for b in bounds):
-            raise ValueError("bind_steps: every step has the same number of particles")
-        blocks = (_lib.RunArgs * len(bounds))()
-        for k, b in enumerate(bounds):
-            blocks[k] = b[1]
-        import ctypes
-        buf = torch.zeros((len(bounds) * ctypes.sizeof(_lib.RunArgs) + 7) // 8, dtype=torch.int64, device=be.device)
-        be.check(be.c.gmx_program_bind_steps(self.handle, n, blocks, len(bounds), be.ptr(buf)), "gmx_program_bind_steps")
-        return (n, buf, len(bounds), [b[2] for b in bounds])
-
-    def launch_steps(self, steps):
-        be = self._be
-        if _CAPTURE_HOLDERS or _PENDING_DESTROY:
-            if _capturing(be):
-                for held in _CAPTURE_HOLDERS:
-                    if not any(c is self for c in held):
-                        held.append(self)
-            elif _PENDING_DESTROY:
-                _drain_pending_destroys()
-        be.check(be.c.gmx_program_run_steps(self.handle, steps[0], be.ptr(steps[1]), steps[2], be.stream()),
-                 "gmx_program_run_steps")
-
     def launch(self, bound):
         """Launch a binding made by `bind` (its buffers must still be alive: `bound` keeps them)."""
         be = self._be
@@ -1132,9 +1104,6 @@ class Compiled:
             agg, shift = tile_stats[0], tile_stats[1]
             A.tile_agg_d, A.tile_shift = agg.data_ptr(), int(shift)
             keep.append(agg)
-            if len(tile_stats) > 2 and tile_stats[2] is not None:      # (int32 tensor [grid], value): the statistics' tag
-                A.stat_tag_out_d, A.stat_tag_out = tile_stats[2].data_ptr(), int(tile_stats[3])
-                keep.append(tile_stats[2])
             if peer is not None:
                 A.peer = peer
         if resample_in is not None:
@@ -1147,9 +1116,6 @@ class Compiled:
             A.rs.max_out_d, A.rs.total_out_d, A.rs.status_d = r["max_out"].data_ptr(), r["total_out"].data_ptr(), r["status"].data_ptr()
             A.rs.shift, A.rs.tag = int(r["shift"]), int(r["tag"])
             A.rs.key0, A.rs.key1 = int(r["key"][0]), int(r["key"][1])
-            if r.get("stat_tags") is not None:
-                keep.append(r["stat_tags"])
-                A.rs.stat_tag_d, A.rs.stat_tag = r["stat_tags"].data_ptr(), int(r["stat_tag"])
         return n, A, keep, outs
 
 

@@ -739,11 +739,6 @@ class _NoiseAhead:
     _noise_offset = 0
     _noise_total = None
 
-    def _chain_group(self, t0, t1, skip_vm=False):
-        """the chain launches of a noise group's steps (BootstrapSweep may fold them into one launch)"""
-        for t in range(t0, t1):
-            self._chain_step(t, skip_vm)
-
     def _noise_split(self, k):
         total = self._noise_total or self.n
         return lazy_split(k, total, offset=self._noise_offset) if (self._noise_offset or total != self.n) else lazy_split(k, self.n)
@@ -893,7 +888,8 @@ class _NoiseAhead:
                 noise_group(g + ring - 1)
             if two and not skip_noise:
                 A.wait_event(ready[g])
-            self._chain_group(*spans[g], skip_vm)
+            for t in range(*spans[g]):
+                self._chain_step(t, skip_vm)
             if two and not skip_noise:
                 done[g] = torch.cuda.Event()
                 done[g].record(A)
@@ -941,7 +937,7 @@ class BootstrapSweep(_NoiseAhead):
 
     def __init__(self, init, step, n_particles: int, T: int, obs_addr="y", resample="systematic",
                  step_extra=None, specialize=True, rejuvenate=None, state_addr="x", noise_ahead=None, chain_mh=True,
-                 noise_roots=None, fuse_resample=None, steps_per_launch=None):
+                 noise_roots=None, fuse_resample=None):
         """chain_mh=False keeps the MH move and the extension as two launches (the form a chained program too large
         for the tile statistics falls back to); noise_roots: which keys' draws of the chained program the background
         stream takes ("LDKEY" = the move's proposal + accept draws, the default; "KSPLITU" = the extension's; "all").
@@ -963,11 +959,6 @@ class BootstrapSweep(_NoiseAhead):
         # (include/genmi.h: gmx_run_args.rs) — so only the grid-wide dependency (the tile statistics) still needs a
         # launch boundary.  Systematic resampling, n <= 2^20, specialised programs.
         self.fuse_req = fuse_resample
-        # SEVERAL steps per launch (None: a noise group's steps, when it applies; 1: never): the launch boundary between
-        # two dependent one-launch steps costs ~4 us of ~12; a program that resamples first also carries a kernel that
-        # loops over the steps' argument blocks, with the grid-wide dependency (every tile's statistics) under tags too
-        # (include/genmi.h: gmx_program_run_steps).  Noise-ahead form, no MH move.
-        self.steps_per_launch = steps_per_launch
 
     def prepare(self, key: Key, ys: torch.Tensor):
         from ..static import MinimalGenerate as _MG, NoiseProgram
@@ -1091,7 +1082,7 @@ class BootstrapSweep(_NoiseAhead):
         self.fused = self.kind in _TILE_KINDS and n <= (512 * 4096)
         want_fuse = self.fuse_req
         if want_fuse is None:
-            want_fuse = be.uses_streams or int(self.steps_per_launch or 0) > 1
+            want_fuse = be.uses_streams
         want_fuse = bool(want_fuse and self.specialize and self.kind == SYSTEMATIC and self.fused and n <= FUSE_RESAMPLE_MAX)
         if self.rejuvenate is None:
             gatherers = (self.p_step,)
@@ -1143,10 +1134,7 @@ class BootstrapSweep(_NoiseAhead):
             self.partials_pp = [self.partials, torch.zeros_like(self.partials)]
             self.tile_agg_pp = [self.tile_agg, torch.zeros_like(self.tile_agg)]
             self.rs_status = torch.zeros((1,), dtype=torch.int64, device=dev)
-            tiles = (n + 1023) // 1024
-            self.stat_tags = torch.zeros((2, tiles), dtype=torch.int32, device=dev)   # the statistics' tags (step t: t + 1)
         else:
-            self.stat_tags = None
             self.lw_pp, self.partials_pp, self.tile_agg_pp = [self.lw] * 2, [self.partials] * 2, [self.tile_agg] * 2
         # per-step keys on the host
         self.step_keys = []
@@ -1154,15 +1142,6 @@ class BootstrapSweep(_NoiseAhead):
             ks = split(fold_in(key, t), 3)
             self.step_keys.append((ks[0], ks[1], ks[2]))
         self._slot_uniforms_setup()
-        # several steps per launch: the one-launch steps of a noise group, when nothing else sits between them
-        spl = self.steps_per_launch
-        self._steps_bound = {}
-        self.multi = bool(self.fuse and self.noise_ahead and self.rejuvenate is None and (spl is None or int(spl) > 1)
-                          and getattr(self, "ubuf", None) is None and T >= 3)
-        if spl is not None and int(spl) > 1 and not self.multi:
-            raise NotImplementedError("BootstrapSweep(steps_per_launch > 1): needs the one-launch step (fuse_resample), the "
-                                      "noise-ahead form and no MH move")
-        self.multi_steps = int(spl) if spl else self.noise_group if self.multi else 1
         return self
 
     def _gathered(self, which):
@@ -1172,24 +1151,6 @@ class BootstrapSweep(_NoiseAhead):
         return Gathered(self.x[which], self.anc)
 
     def _launch_vm(self, t):
-        prog, bound = self._bind_vm(t)
-        prog.comp.launch(bound)
-
-    def _stat_tag(self, t):
-        """the word step t publishes with its tile statistics: (tags tensor, value) — a multi-step launch's next step
-        waits for it (zeroed at the start of every sweep: enqueue)"""
-        return self.stat_tags[t % 2], t + 1
-
-    def _launch_steps(self, t0, t1):
-        """steps t0 .. t1 - 1 (all >= 1, all the gathering program) as ONE launch (gmx_program_run_steps); bound on the
-        first enqueue (the warm-up run outside capture), re-launched after that"""
-        steps = self._steps_bound.get((t0, t1))
-        if steps is None:
-            bounds = [self._bind_vm(t)[1] for t in range(t0, t1)]
-            steps = self._steps_bound[(t0, t1)] = self.p_step.comp.bind_steps(bounds)
-        self.p_step.comp.launch_steps(steps)
-
-    def _bind_vm(self, t):
         n = self.n
         k_prop = self.step_keys[t][0]
         obs = ChoiceMap.empty().set(self.obs_addr, self.ys[t])
@@ -1209,21 +1170,17 @@ class BootstrapSweep(_NoiseAhead):
             bufs[prog.ro[1]] = self.x_store[t % 2]
         w = t % 2 if self.fuse else 0
         bufs[prog.wo[1]] = self.lw_pp[w].reshape(1, n)
-        ts = None
-        if self.tile_stats:
-            ts = (self.tile_agg_pp[w], self.shift) + (self._stat_tag(t) if self.fuse else ())
-        return prog, prog.comp.bind(leaves, (n,), lazy_split(k_prop, n), red_out=self.partials_pp[w], out_buffers=bufs,
-                                    tile_stats=ts,
-                                    resample_in=self._resample_in(t) if (self.fuse and t >= 1 and self.rejuvenate is None) else None)
+        prog.comp.run(leaves, (n,), lazy_split(k_prop, n), red_out=self.partials_pp[w], out_buffers=bufs,
+                      tile_stats=(self.tile_agg_pp[w], self.shift) if self.tile_stats else None,
+                      resample_in=self._resample_in(t) if (self.fuse and t >= 1 and self.rejuvenate is None) else None)
 
     def _resample_in(self, t):
         """gmx_run_args.rs of the launch of step t (>= 1) that gathers: resample step t-1's weights first"""
         kh = self.step_keys[t - 1][1].host()
         w = (t - 1) % 2
-        tags, tag = self._stat_tag(t - 1)
         return dict(lw=self.lw_pp[w], tile_max=self.partials_pp[w], tile_agg=self.tile_agg_pp[w], shift=self.shift,
                     key=(int(kh[0]), int(kh[1])), tag=1 + (t - 1) % 2047, max_out=self.maxs[t - 1:t],
-                    total_out=self.totals[t - 1:t], status=self.rs_status, stat_tags=tags, stat_tag=tag)
+                    total_out=self.totals[t - 1:t], status=self.rs_status)
 
     def _chain_prog(self, t):
         if t == 0:
@@ -1396,27 +1353,6 @@ class BootstrapSweep(_NoiseAhead):
                                    be.ptr(self.totals[t:t + 1]), be.ptr(self.anc), be.ptr(self.rs_ws),
                                    be.stream()), "gmx_resample")
 
-    def _chain_group(self, t0, t1, skip_vm=False):
-        """the chain launches of steps t0 .. t1 - 1 (a noise group): one launch per step, or — `multi` — the steps >= 1
-        of the group in ONE launch, then whatever the last step of the sweep still needs"""
-        if getattr(self, "multi", False) and not skip_vm:
-            if t0 == 0:
-                self._chain_step(0)
-                t0 = 1
-            per = self.multi_steps
-            while t0 < t1:
-                te = min(t1, t0 + per)
-                if te - t0 >= 2:
-                    self._launch_steps(t0, te)
-                    if te == self.T:                # the last step's weights: resampled by a launch of its own
-                        self._chain_step(self.T - 1, skip_vm=True)
-                else:
-                    self._chain_step(t0)
-                t0 = te
-            return
-        for t in range(t0, t1):
-            self._chain_step(t, skip_vm)
-
     def _chain_step(self, t, skip_vm=False):
         """everything step t launches on the chain (noise-ahead form): site program', then the resampler"""
         if not skip_vm:
@@ -1437,8 +1373,6 @@ class BootstrapSweep(_NoiseAhead):
         skip_vm=True leaves the site-program launches out (the resampling kernels then run on the
         previous sweep's log-weights): bench.py times that variant to get the site program's cost
         IN the sweep as a difference."""
-        if self.stat_tags is not None:
-            self.stat_tags.zero_()         # no tag of the previous sweep may pass for this one's
         if self.noise_ahead:
             return self._enqueue_noise_ahead(skip_vm)
         for t in range(self.T):

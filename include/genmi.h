@@ -39,7 +39,7 @@ typedef __UINTPTR_TYPE__ uintptr_t;
 extern "C" {
 #endif
 
-#define GMX_ABI_VERSION 6
+#define GMX_ABI_VERSION 5
 
 typedef void* gmx_stream;            /* hipStream_t */
 typedef struct gmx_program gmx_program;
@@ -126,14 +126,11 @@ typedef struct gmx_resample_in {
   float* max_out_d;               /* [1]: M      (as gmx_resample_tiles' max_d)                                 */
   uint64_t* total_out_d;          /* [1]: total  (as gmx_resample_tiles' total_d)                               */
   uint64_t* status_d;             /* [1]: sticky error word (a wait that timed out)                             */
-  const uint32_t* stat_tag_d;     /* [ceil(n/1024)] or NULL: the tags the previous step published with its statistics
-                                     (gmx_run_args.stat_tag_out_d); a step of a MULTI-STEP launch (gmx_program_run_steps)
-                                     waits until the rows it reads carry stat_tag before it reads tile_max_d / tile_agg_d */
   int32_t shift;                  /* the CDF's fixed-point shift (= the previous launch's tile_shift)           */
   uint32_t tag;                   /* 1 .. 2047, different from the previous launch's                            */
   uint32_t key0, key1;            /* resampling key (systematic)                                                */
   uint32_t u0;                    /* filled in by gmx_program_run: bits32(key, 0) >> 9                          */
-  uint32_t stat_tag;              /* the value stat_tag_d's words must have (any value the words did not hold before)    */
+  uint32_t reserved_;
 } gmx_resample_in;
 
 /* The peers of a sharded SMC step ("Fused peer exchange", below): passed by value to the site program
@@ -171,10 +168,7 @@ typedef struct gmx_run_args {
                                      (the log-weight): with plane 0 of red_out_d the tile statistics
                                      gmx_resample_tiles needs — no separate pass over the log-weights  */
   int32_t tile_shift;
-  uint32_t stat_tag_out;          /* with stat_tag_out_d: the word this launch / step publishes for its statistics       */
-  uint32_t* stat_tag_out_d;       /* optional, with tile_agg_d: [grid] — workgroup b stores stat_tag_out at [b] once its
-                                     statistics (and, in a multi-step launch, every output of the step) are visible to the
-                                     whole device                                                                      */
+  int32_t reserved_;
   int64_t step_stride;            /* elements between consecutive steps of a [T, n] leaf addressed with GMX_F_STEP inside
                                      an OP_LOOP (programs with a counted loop: the Scan combinator); normally n         */
   gmx_resample_in rs;             /* optional (rs.lw_d != NULL): resample the previous step first, in this launch (above)  */
@@ -219,24 +213,6 @@ int gmx_program_fuses_resample(const gmx_program* p);
 int gmx_program_set_background(gmx_program* p, uint32_t lds_pad);
 int gmx_program_run(const gmx_program* p, int64_t n, const gmx_run_args* args_h,
                     gmx_stream stream);
-/* SEVERAL consecutive bootstrap steps in ONE launch (no reference counterpart: XLA fuses a `lax.scan` body itself;
- * here the launch boundary between two dependent steps costs ~4 us of a ~12 us step on MI355X).  A program for which
- * gmx_program_fuses_resample() is 1 also carries a kernel that loops over n_steps argument blocks: step s runs exactly
- * what gmx_program_run(p, n, &steps[s]) runs — the resampling of the step before (steps[s].rs, required) and the
- * extension — but what crosses workgroups between two steps of the launch travels under tags instead of a launch
- * boundary: every output of a step is stored write-through, the step's statistics are followed by their tag
- * (stat_tag_out_d / stat_tag_out, required), the next step waits for the tags of the rows it reads (rs.stat_tag_d /
- * rs.stat_tag, required) and reads log-weights, statistics and gathered rows past the per-XCD caches.  Requirements
- * per step as for a fused gmx_program_run, plus: consecutive steps ping-pong their buffers (a step never writes what
- * the step before it, or its own prologue, reads); tags differ from step to step and from what the tag words held
- * before; every workgroup of the launch is resident at once (n <= 2^20).  Same integers and floats as n_steps
- * launches.
- *   gmx_program_bind_steps  validates the blocks, fills in what gmx_program_run fills in (constants, rs.u0) and copies
- *                           them into steps_d (device, n_steps * sizeof(gmx_run_args) bytes, 8-byte aligned);
- *                           synchronous — call it outside stream capture
- *   gmx_program_run_steps   the launch (capturable)                                                                  */
-int gmx_program_bind_steps(const gmx_program* p, int64_t n, const gmx_run_args* steps_h, int n_steps, void* steps_d);
-int gmx_program_run_steps(const gmx_program* p, int64_t n, const void* steps_d, int n_steps, gmx_stream stream);
 
 /* ------------------------------------------------------------------------
  * Log-normaliser.  Replaces jax.scipy.special.logsumexp at

@@ -155,9 +155,6 @@ extern "C" int gmx_program_run(const gmx_program* p, int64_t n, const gmx_run_ar
     if (!q.tile_max_d || !q.tile_agg_d || !q.max_out_d || !q.total_out_d || !q.status_d || !A->ancestors_d)
       return fail("program_run: rs has a null pointer");
     if (q.tag < 1u || q.tag > 2047u) return fail("program_run: rs.tag must be in [1, 2047]");
-    if (q.stat_tag_d)          // (a step of a multi-step launch waits for these; here the steps run one after the other)
-      for (int64_t b = 0; b < (n + 1023) / 1024; ++b)
-        if (q.stat_tag_d[b] != q.stat_tag) return fail("program_run: rs.stat_tag_d does not carry the previous step's tag");
     if ((n + 1023) / 1024 > 1024) return fail("program_run: rs: n <= 2^20");
     if (A->tile_agg_d == q.tile_agg_d || (const float*)A->red_out_d == q.tile_max_d)
       return fail("program_run: rs reads the tile statistics this launch writes (use two sets)");
@@ -199,7 +196,6 @@ extern "C" int gmx_program_run(const gmx_program* p, int64_t n, const gmx_run_ar
         uint64_t sum = 0;
         for (int t = 0; t < G; ++t) sum += gmx_exp_fixed(red[t] - ref, A->tile_shift);
         A->tile_agg_d[blk] = sum;
-        if (A->stat_tag_out_d) A->stat_tag_out_d[blk] = A->stat_tag_out;      // the statistics' tag
         if (A->peer.land_d) {        // the epilogue's put: this tile's statistics into every other rank's landing table
           const gmx_peer& P = A->peer;
           const uint32_t tag = *P.tag_base_d + (uint32_t)P.step;
@@ -209,41 +205,6 @@ extern "C" int gmx_program_run(const gmx_program* p, int64_t n, const gmx_run_ar
       }
     }
   }
-  return 0;
-}
-
-// ---- several bootstrap steps in one launch: the same steps, one after the other ----
-extern "C" int gmx_program_bind_steps(const gmx_program* p, int64_t n, const gmx_run_args* steps, int n_steps, void* steps_d) {
-  if (!p || !steps || !steps_d) return fail("program_bind_steps: null");
-  if (!gmx_program_fuses_resample(p)) return fail("program_bind_steps: the program has no multi-step kernel");
-  if (n_steps < 1 || n_steps > 4096) return fail("program_bind_steps: n_steps out of range");
-  if (n <= 0 || (n + 1023) / 1024 > 1024) return fail("program_bind_steps: n <= 2^20");
-  for (int s = 0; s < n_steps; ++s) {
-    const gmx_run_args* a = steps + s;
-    if (!a->rs.lw_d) return fail("program_bind_steps: every step resamples the step before it");
-    if (a->peer.land_d) return fail("program_bind_steps: not with a peer exchange");
-    if (!a->tile_agg_d || !a->red_out_d || !a->stat_tag_out_d || !a->rs.stat_tag_d)
-      return fail("program_bind_steps: every step publishes its statistics and tag and waits for the previous step's");
-    if (a->stat_tag_out_d == a->rs.stat_tag_d) return fail("program_bind_steps: a step publishes its tag where it reads the previous one");
-    if (s > 0) {
-      const gmx_run_args* b = steps + s - 1;
-      if (a->rs.tile_agg_d != b->tile_agg_d || (const void*)a->rs.tile_max_d != (const void*)b->red_out_d ||
-          a->rs.stat_tag_d != b->stat_tag_out_d || a->rs.stat_tag != b->stat_tag_out)
-        return fail("program_bind_steps: step s reads the statistics (and tag) step s - 1 publishes");
-      if (a->rs.tag == b->rs.tag) return fail("program_bind_steps: consecutive steps need different ancestor tags");
-      for (uint32_t o = 0; o < p->n_out; ++o)
-        for (uint32_t q = 0; q < p->n_out; ++q)
-          if (a->out_d[o] == b->out_d[q]) return fail("program_bind_steps: consecutive steps write the same output buffer");
-    }
-  }
-  memcpy(steps_d, steps, (size_t)n_steps * sizeof(gmx_run_args));
-  return 0;
-}
-extern "C" int gmx_program_run_steps(const gmx_program* p, int64_t n, const void* steps_d, int n_steps, gmx_stream st) {
-  if (!p || !steps_d || n_steps < 1) return fail("program_run_steps: bad argument");
-  const gmx_run_args* steps = (const gmx_run_args*)steps_d;
-  for (int s = 0; s < n_steps; ++s)
-    if (gmx_program_run(p, n, steps + s, st)) return 1;
   return 0;
 }
 

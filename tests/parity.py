@@ -35,16 +35,14 @@ def oracle_bootstrap_sweep(init, step, n, T, ys, run_key, kind=O.SYSTEMATIC, ste
 
 
 def check_lgssm_sweep(n=4096, T=5, seed=314159, capture=False, specialize=True, resample="systematic",
-                      noise_ahead=None, fuse_resample=None, steps_per_launch=None):
+                      noise_ahead=None, fuse_resample=None):
     import genjax_amd as G
     from genjax_amd import workloads
     from genjax_amd.inference.smc import BootstrapSweep
     ys = workloads.lgssm_data(T)
     init, step = workloads.make_lgssm(G)
     sw = BootstrapSweep(init, step, n, T, specialize=specialize, resample=resample, noise_ahead=noise_ahead,
-                        fuse_resample=fuse_resample, steps_per_launch=steps_per_launch).prepare(G.key(seed), torch.from_numpy(ys))
-    if steps_per_launch is not None:
-        assert sw.multi == (steps_per_launch > 1), "the sweep did not take the requested (multi- / one-step launch) form"
+                        fuse_resample=fuse_resample).prepare(G.key(seed), torch.from_numpy(ys))
     if noise_ahead is not None:
         assert sw.noise_ahead == noise_ahead, "the sweep did not take the requested (one- / two-stream) form"
     if fuse_resample is not None:
@@ -61,7 +59,6 @@ def check_lgssm_sweep(n=4096, T=5, seed=314159, capture=False, specialize=True, 
                                        "multinomial_tiled": O.MULTINOMIAL_TILED,
                                        "multinomial_sorted": O.MULTINOMIAL_SORTED}[resample])
     return dict(
-        multi_launches=sorted(getattr(sw, "_steps_bound", {})),
         log_ml=log_ml, log_ml_oracle=ref["log_ml"], kalman=workloads.kalman_log_ml(ys),
         ancestors_equal=bool(np.array_equal(anc.cpu().numpy(), ref["anc"])),
         x_equal=bool(np.array_equal(x.cpu().numpy(), ref["x"])),

@@ -1,3 +1,5 @@
+# NOTE: needs the multi-step launch of profiles/r04l_multi_step_attempt.patch applied (git apply); the product does not carry it
+# (measured slower than one launch per step: profiles/r04l_multi_step_results.json).
 import sys, json
 sys.path.insert(0, "/root/repo")
 from tests import parity

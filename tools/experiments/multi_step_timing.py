@@ -1,3 +1,5 @@
+# NOTE: needs the multi-step launch of profiles/r04l_multi_step_attempt.patch applied (git apply); the product does not carry it
+# (measured slower than one launch per step: profiles/r04l_multi_step_results.json).
 """Where a step's time goes with several steps per launch (BootstrapSweep(steps_per_launch=K)): the whole sweep and the
 chain alone (no noise launches: the chain then reads whatever the noise buffers hold), each as a captured graph, for
 K in argv (default 1 10).  One JSON line per K."""

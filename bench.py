@@ -632,14 +632,14 @@ def pick_sharded_sweep(args, dist, world, rank, on_gpu, be, make):
     launch per step; every wait bounded by the device's wall clock, so a candidate that does not work costs seconds,
     not the job) as one hipGraph, and the direct RCCL communicator — as one hipGraph at world size 1, EAGER across GPUs:
     captured RCCL calls have never run at world > 1 in the build loop and a replay that hangs cannot be bounded
-    (GENMI_SHARDED_GRAPH=1 opts in).  Each candidate runs one warm-up sweep and three timed ones; it is dropped if it
+    (`--rccl-graph` opts in).  Each candidate runs one warm-up sweep and three timed ones; it is dropped if it
     raises, times out, or its evidence differs from the first working candidate's (every communicator must produce
     the SAME bits).  The fastest survivor (MAX over ranks of its time) is kept, the others are closed."""
     import torch
     from genjax_amd.inference.comm import _Deadline
     forced = os.environ.get("GENMI_COMM")
     graph_ok = on_gpu and not args.no_graph
-    rccl_graph = graph_ok and (world == 1 or os.environ.get("GENMI_SHARDED_GRAPH", "0") == "1")
+    rccl_graph = graph_ok and (world == 1 or args.rccl_graph)
     if not on_gpu:
         cands = [(forced, False)]
     elif forced:
@@ -763,6 +763,8 @@ def main():
                     help="only the timed sweeps (rocprofv3's kernel-trace pass: its per-kernel averages are then IN-SWEEP "
                          "durations, not mixed with the isolated timing loops of the roofline block)")
     ap.add_argument("--sharded", action="store_true", help="use the multi-GPU code path even at world size 1")
+    ap.add_argument("--rccl-graph", action="store_true",
+                    help="N > 1: capture the RCCL collectives into the sweep's hipGraph too (default: eager across GPUs)")
     ap.add_argument("--two-launches", action="store_true",
                     help="single GPU: the two-launch step [site program -> resampler] instead of the default ONE launch "
                          "per step (the site program resamples the previous step first: BootstrapSweep(fuse_resample=...))")

@@ -482,7 +482,7 @@ class ShardedBootstrapSweep(_NoiseAhead):
             self._step(t)
 
     def capture(self):
-        """OPT-IN (GENMI_SHARDED_GRAPH=1 in bench.py): capture the whole sweep — kernels AND the
+        """OPT-IN across GPUs (`bench.py --rccl-graph`; the default at world size 1): capture the whole sweep — kernels AND the
         RCCL collectives, which comm.RcclComm issues on this same stream — into one hipGraph so
         the host leaves the loop.  Exercised at world size 1 only (no multi-GPU box in the build
         loop); the default multi-GPU path enqueues eagerly."""

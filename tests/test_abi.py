@@ -49,6 +49,22 @@ def test_hostsim_exports_the_same_boundary():
     assert not missing, missing
 
 
+def test_genmi_lib_names_another_build(tmp_path):
+    """GENMI_LIB: the product loads the library the switch names (tuning builds) — and says so when it cannot"""
+    import shutil
+    import subprocess
+    import sys
+    import __graft_entry__ as g
+    other = tmp_path / "libgenmi_other.so"
+    shutil.copy(g.HIP_SO, other)
+    code = ("from genjax_amd import _lib; import ctypes; assert _lib.LIB_PATH == %r, _lib.LIB_PATH; "
+            "lib = ctypes.CDLL(_lib.LIB_PATH); lib.gmx_version.restype = ctypes.c_int; "
+            "assert lib.gmx_version() == _lib.ABI_VERSION") % str(other)
+    env = dict(os.environ, GENMI_LIB=str(other))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+
+
 def test_product_fails_loudly_without_gpu():
     """No CPU fallback: without a HIP device (and without the test harness
     installed) every entry point raises."""

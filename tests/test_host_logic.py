@@ -634,6 +634,25 @@ def test_index_request_edits_one_element_of_a_long_plate():
     parity.check_index_request_o1(n=64, P=24, seed=3, edits=70, nested=False)
 
 
+def test_program_cache_is_bounded(hostsim, monkeypatch):
+    """GENMI_PROGRAM_CACHE: the LRU of compiled site programs holds at most that many entries (the oldest go), and a
+    model evicted from it is simply compiled again"""
+    import genjax_amd as G
+    from genjax_amd import engine
+    monkeypatch.setenv("GENMI_PROGRAM_CACHE", "3")
+    cache = engine.new_cache()
+    try:
+        assert cache.limit == 3
+        for k in range(6):
+            cache[("k", k)] = object()
+        assert len(cache) == 3 and cache.get(("k", 5)) is not None and cache.get(("k", 0)) is None
+        assert cache.get(("k", 3)) is not None            # a hit moves the entry to the young end
+        cache[("k", 6)] = object()
+        assert cache.get(("k", 3)) is not None and cache.get(("k", 4)) is None
+    finally:
+        engine._ALL_CACHES.remove(cache)
+
+
 def test_indexed_and_masked_constraints_match_oracle():
     from tests import parity
     parity.check_masked_constraints()

@@ -21,7 +21,7 @@ t0 = time.perf_counter(); sw.launch(); t1 = time.perf_counter(); sw.finish(); to
 print(f"enqueue host time {1e3*(t1-t0):.2f} ms, until done {1e3*(t2-t0):.2f} ms")
 pr = cProfile.Profile(); pr.enable(); sw.launch(); pr.disable(); sw.finish()
 pstats.Stats(pr).sort_stats("tottime").print_stats(22)
-if os.environ.get("GENMI_SHARDED_GRAPH") == "1":
+if "--graph" in sys.argv:
     ref = sw.state().clone(); ref_ml = sw.log_ml()
     sw.capture()
     for _ in range(3):

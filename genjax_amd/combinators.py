@@ -903,8 +903,8 @@ def _vmap_edit_index_o1(self, key, trace, request, argdiffs):
     try:
         axes = self._axes(args)
         n = self._plate_size(args, axes)
-    except NotImplementedError:
-        return None
+    except (NotImplementedError, ValueError):
+        return None                    # (e.g. a sub-trace that does not carry its arguments: the loop form says what is wrong)
     if n <= VMAP_UNROLL_MAX:
         return None
     idx = request.idx

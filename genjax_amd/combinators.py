@@ -33,6 +33,13 @@ from .tracer import Expr
 SCAN_UNROLL_MAX = 16      # longer scans run as a counted loop in the site program (Scan._trace_loop)
 VMAP_UNROLL_MAX = 16      # larger plates run as a counted loop too (Vmap._trace_loop): one iteration per element
 PATCH_DEPTH_MAX = 32        # engine.Patched chains longer than this are folded (see _vmap_edit_index_o1)
+def torch_from_host(v, device):
+    import torch
+    v = np.asarray(v)
+    return torch.from_numpy(np.ascontiguousarray(v.astype(np.float32) if v.dtype.kind == "f" else
+                                                 (v.astype(np.int32) if v.dtype.kind in "iu" else v))).to(device)
+
+
 VMAP_LAUNCH_MIN = 4096      # a plate this large called directly under ONE key runs with its elements on the launch axis
 NEST_UNROLL_MAX = 4       # an unrolled plate whose ELEMENT runs a counted loop keeps at most this many copies of it
 
@@ -345,6 +352,12 @@ class Vmap(GenerativeFunction):
             return self._empty(mode)
         # a plate OF plates (`model.repeat(n=10).repeat(n=10)`): unrolling both would need one output slot per element
         # of the product; the outer one runs as a loop whose body is the (small, unrolled) inner plate
+        if getattr(ctx, "sitewise", False) and n >= VMAP_LAUNCH_MIN and not getattr(ctx.tr.graph, "_in_loop", False) \
+                and not ctx.tr.graph.loop_counts:
+            # ONE trace of the caller and a large plate: in one thread this is n iterations on one lane — the caller
+            # runs site by site instead, and this plate with its elements on the launch axis (sitewise.py)
+            from .sitewise import NeedsSiteBySite
+            raise NeedsSiteBySite()
         nested = isinstance(self.gen_fn, (Vmap, Scan, _ScanAdapter)) and n > 4 and not getattr(ctx.tr.graph, "_in_loop", False)
         if n > VMAP_UNROLL_MAX or nested:
             return self._trace_loop(ctx, mode, key, args, axes, constraint, n, req_leaves, addr)
@@ -722,8 +735,15 @@ class Vmap(GenerativeFunction):
         for a, ax in zip(args, axes):
             pairs = []
             _tree_leaves_with_axes(a, ax, pairs)
-            if any(x is not None and not isinstance(leaf, torch.Tensor) for leaf, x in pairs):
-                return None                                    # mapped numpy arrays / lists: the loop form reads them as tables
+            if any(x is not None and not isinstance(leaf, (torch.Tensor, np.ndarray)) for leaf, x in pairs):
+                return None                                    # mapped lists: the loop form reads them as tables
+            if any(x is not None and isinstance(leaf, np.ndarray) for leaf, x in pairs):
+                # a mapped host array (`jnp.zeros(n)`): one device row per element
+                from . import _lib
+                dev = _lib.get().device
+                a = _tree_take_axes(a, ax, lambda v: torch.from_numpy(np.ascontiguousarray(
+                    np.asarray(v, dtype=np.float32 if np.asarray(v).dtype.kind == "f" else np.int32))).to(dev)
+                    if isinstance(v, np.ndarray) else v)
             inner.append(_tree_mark_unmapped(a, ax))
         if constraint is not None and not constraint.static_is_empty():
             # per-element constraints only: every leaf leads with the plate (no integer sub-addresses, no masks)
@@ -735,14 +755,33 @@ class Vmap(GenerativeFunction):
                     return None
         return n, tuple(inner)
 
+    @staticmethod
+    def _plate_constraint(constraint, n):
+        """per-element constraints given as HOST arrays ([n, ...] numpy / `jnp.array`): one device row per element"""
+        if constraint is None or constraint.static_is_empty():
+            return constraint
+        from . import _lib
+
+        def dev(v):
+            if isinstance(v, np.ndarray) and v.dtype != object and v.ndim >= 1 and v.shape[0] == n:
+                return torch_from_host(v, _lib.get().device)
+            return v
+        return constraint.map_values(dev)
+
     def _plate_trace(self, tr, args):
         """the inner function's trace over the batch of n elements, as this plate's trace"""
         from .engine import sum_rows
         from .static import DistributionTrace, StaticTrace, VmapTrace
+        # (the elements' own scores stay on the trace: an IndexRequest re-sums them with one of them replaced)
         if isinstance(tr, DistributionTrace):       # a bare distribution: one vector-valued site, score = the plate sum
-            return DistributionTrace(self, args, tr.value, sum_rows(tr.score))
+            out = DistributionTrace(self, args, tr.value, sum_rows(tr.score))
+            out._elem_scores = tr.score
+            return out
         inner = StaticTrace(tr.gen_fn, None, tr.retval, tr.subtraces)
-        return VmapTrace(self, inner, sum_rows(tr.get_score()), tr.retval, args)
+        es = tr.get_score()
+        out = VmapTrace(self, inner, sum_rows(es), tr.retval, args)
+        out._elem_scores = es
+        return out
 
     # direct use: split(key, n) of the caller's key itself (vmap.py:186)
     def simulate(self, key, args):
@@ -759,7 +798,8 @@ class Vmap(GenerativeFunction):
         from .static import run_gfi
         la = self._launch_axis(key, args, constraint)
         if la is not None:
-            tr, w = run_gfi(self.gen_fn, "generate", lazy_split(key, la[0]), la[1], constraint=constraint)
+            tr, w = run_gfi(self.gen_fn, "generate", lazy_split(key, la[0]), la[1],
+                            constraint=self._plate_constraint(constraint, la[0]))
             return self._plate_trace(tr, tuple(args)), sum_rows(w)
         return run_gfi(self, "generate", key, args, constraint=constraint)
 
@@ -770,7 +810,8 @@ class Vmap(GenerativeFunction):
             batch_shape = _plate_batch(sample, lambda: self._plate_size(args, self._axes(args)))
         la = self._launch_axis(None, args, sample, batch_shape)
         if la is not None:
-            s_, r = run_gfi(self.gen_fn, "assess", None, la[1], constraint=sample, batch_shape=(la[0],))
+            s_, r = run_gfi(self.gen_fn, "assess", None, la[1], constraint=self._plate_constraint(sample, la[0]),
+                            batch_shape=(la[0],))
             return sum_rows(s_), r
         return run_gfi(self, "assess", None, args, constraint=sample, batch_shape=batch_shape)
 
@@ -827,6 +868,9 @@ def _select_rec(c, new, old):
 def _vmap_edit(self, key, trace, edit_request, argdiffs):
     from .static import run_edit
     la = _vmap_edit_launch_axis(self, key, trace, edit_request, argdiffs)
+    if la is not None:
+        return la
+    la = _vmap_edit_index_one_trace(self, key, trace, edit_request, argdiffs)
     if la is not None:
         return la
     o1 = _vmap_edit_index_o1(self, key, trace, edit_request, argdiffs)
@@ -976,7 +1020,8 @@ def _vmap_edit_launch_axis(self, key, trace, request, argdiffs):
     from .engine import sum_rows
     from .random import lazy_split
     from .static import DistributionTrace, StaticTrace, VmapTrace, run_edit
-    if not isinstance(request, Update) or not isinstance(trace, VmapTrace) or tuple(trace.batch_shape) != ():
+    bare = isinstance(trace, DistributionTrace) and getattr(trace, "_elem_scores", None) is not None
+    if not isinstance(request, Update) or not (isinstance(trace, VmapTrace) or bare) or tuple(trace.batch_shape) != ():
         return None
     args = tuple(Diff.tree_primal(argdiffs)) if argdiffs is not None else tuple(trace.get_args() or ())
     la = self._launch_axis(key, args, request.constraint)
@@ -986,10 +1031,79 @@ def _vmap_edit_launch_axis(self, key, trace, request, argdiffs):
     tang = Diff.tree_tangent(argdiffs) if argdiffs is not None else None
     changed = tang is not None and not Diff.static_check_no_change(argdiffs)
     inner_diffs = Diff.unknown_change(inner_args) if changed else Diff.no_change(inner_args)
-    inner_tr = StaticTrace(trace.inner.gen_fn, inner_args, trace.inner.retval, trace.inner.subtraces)
+    if bare:            # a bare distribution under vmap: the distribution's own Update over the batch of n elements
+        inner_tr = DistributionTrace(self.gen_fn, inner_args, trace.value, trace._elem_scores)
+    else:
+        inner_tr = StaticTrace(trace.inner.gen_fn, inner_args, trace.inner.retval, trace.inner.subtraces)
     new_tr, w, retdiff, bwd = run_edit(self.gen_fn, lazy_split(key, n) if key is not None else None, inner_tr,
-                                       Update(request.constraint), inner_diffs)
+                                       Update(self._plate_constraint(request.constraint, n)), inner_diffs)
     return self._plate_trace(new_tr, args), sum_rows(w), retdiff, bwd
+
+
+def _vmap_edit_index_one_trace(self, key, trace, request, argdiffs):
+    """`IndexRequest(idx, sub)` on a large plate held under ONE key (vmap.py:277-332 `edit_index`): element idx is sliced
+    out of the trace, `sub` edits it with the caller's key (one-element launches), and the new trace's leaves are copies
+    with row idx replaced — 12 bytes of memory traffic per element and leaf, no density of any other element evaluated;
+    the plate's score is the fixed tree over the elements' scores with one of them replaced (what scoring every element
+    again would sum).  Unchanged arguments only."""
+    import torch
+    from .core.generative import Diff, IndexRequest
+    from .engine import materialize, sum_rows
+    from .static import DistributionTrace, StaticGenerativeFunction, StaticTrace, VmapTrace
+    if not isinstance(request, IndexRequest) or tuple(trace.batch_shape) != ():
+        return None
+    es = getattr(trace, "_elem_scores", None)
+    bare = isinstance(trace, DistributionTrace)
+    if es is None or not (bare or (isinstance(trace, VmapTrace) and isinstance(self.gen_fn, StaticGenerativeFunction))):
+        return None
+    if argdiffs is not None and not Diff.static_check_no_change(argdiffs):
+        return None
+    args = tuple(Diff.tree_primal(argdiffs)) if argdiffs is not None else tuple(trace.get_args() or ())
+    try:
+        axes = self._axes(args)
+        n = self._plate_size(args, axes)
+    except (NotImplementedError, ValueError):
+        return None
+    idx = request.idx
+    if isinstance(idx, torch.Tensor):
+        if idx.numel() != 1:
+            return None
+        idx = int(idx.item())
+    if not 0 <= idx < n:
+        raise IndexError(f"IndexRequest: index {idx} out of range for a plate of {n} elements")
+    es = materialize(es)
+
+    def arg_at(v):
+        e = v[idx]
+        return e.item() if isinstance(e, np.generic) else e
+    args_i = tuple(_tree_take_axes(a, ax, arg_at) for a, ax in zip(args, axes))
+
+    def take(v):
+        v = materialize(v)
+        return v[idx] if isinstance(v, torch.Tensor) and v.ndim >= 1 and v.shape[0] == n else v
+
+    def put(old, new):
+        old = materialize(old)
+        if not (isinstance(old, torch.Tensor) and old.ndim >= 1 and old.shape[0] == n):
+            return new
+        out = old.clone()
+        out[idx] = torch.as_tensor(materialize(new), device=old.device).to(old.dtype)
+        return out
+    if bare:
+        elem = DistributionTrace(self.gen_fn, args_i, take(trace.value), es[idx])
+    else:
+        elem = _trace_leaf_map(trace.inner, take, args=args_i)
+    new_e, w, retdiff, bwd = request.request.edit(key, elem, Diff.no_change(args_i))
+    es_new = es.clone()
+    es_new[idx] = materialize(new_e.get_score()).to(es.dtype)
+    if bare:
+        out = DistributionTrace(self, args, put(trace.value, new_e.value), sum_rows(es_new))
+    else:
+        inner = _trace_leaf_zip(trace.inner, new_e, put, args=None)
+        out = VmapTrace(self, inner, sum_rows(es_new), inner.retval, args)
+    out._elem_scores = es_new
+    same = Diff.static_check_no_change(retdiff)
+    return out, w, (Diff.no_change(out.get_retval()) if same else Diff.unknown_change(out.get_retval())), IndexRequest(idx, bwd)
 
 
 Vmap.edit = _vmap_edit

@@ -187,6 +187,16 @@ def arange(*a, dtype=np.int32):
     return TableArray(np.arange(*a, dtype=dtype))
 
 
+def _backend_or_none():
+    from . import _lib
+    if _lib._backend is None and not torch.cuda.is_available():
+        return None
+    try:
+        return _lib.get()
+    except _lib.GenmiError:
+        return None
+
+
 def _device_elementwise(name, x):
     """An eager call on a float tensor goes through the same fixed-sequence device math a traced model uses
     (`engine.elementwise`: one launch of a one-instruction site program), so `jnp.exp(t)` has the same bits outside
@@ -316,6 +326,17 @@ def sum(x, axis=None):        # noqa: A001
             out[idx] = acc
         return out if out.ndim else out.item()
     if _is_torch(x):
+        if x.is_floating_point() and x.dim() >= 1 and x.numel() > 0 and (axis is None and x.dim() == 1 or axis in (-1, x.dim() - 1)):
+            # a concrete float vector (a plate's values in a model that runs site by site, sitewise.py): the sum has a
+            # DEFINED order, the plate score's — element order below VMAP_LAUNCH_MIN items, gmx_sum_rows' fixed tree from
+            # there on (oracle: sum_vector) — and runs in this build's kernels (jnp.sum fixes no order: vmap.py:214-216)
+            from . import engine
+            from .combinators import VMAP_LAUNCH_MIN
+            be = _backend_or_none()
+            if be is not None and x.device == be.device:
+                if x.shape[-1] >= VMAP_LAUNCH_MIN:
+                    return engine.sum_rows(x)
+                return engine.sum_rows_inorder(x.reshape(-1, x.shape[-1])).reshape(x.shape[:-1])
         return torch.sum(x) if axis is None else torch.sum(x, dim=axis)
     return np.sum(x, axis=axis)
 

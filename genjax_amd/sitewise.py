@@ -1,0 +1,249 @@
+"""Site-by-site execution of a `@gen` function called for ONE trace (no particle batch) that contains a LARGE plate.
+
+The traced form (static.run_gfi) compiles the whole model into one site program and runs one thread per particle:
+right for 1e6 particles of a small model, wrong for the other shape the reference serves just as well — ONE trace of a
+model whose plates hold 1e4 .. 1e8 elements (`7_application_dirichlet_mixture_model.ipynb` c6 / c10: hyper-parameters,
+then `generate_datapoint.vmap(...)` over the data; `4_index_request.ipynb` c3: three 1e4 .. 1e8-element plates and one
+observation of their sums).  In one thread such a plate is a loop of n iterations on one lane.
+
+Here the model's source runs ON THE HOST with concrete device values, the way the reference's handlers run it under
+`jit` tracing (static.py:254-673) — site by site, in program order, each site through the callee's own GFI method
+with the key `fold_in(key, counter)` (static.py:261): a distribution is a one-element launch, a nested `@gen` function
+is traced (or, if it holds a large plate itself, executed this way in turn), and a plate of >= VMAP_LAUNCH_MIN elements
+takes its launch-axis form (combinators.Vmap._launch_axis: one GPU thread per ELEMENT).  Weights and scores are added
+in program order on the device (engine.elementwise), so every number is the one the traced form computes.
+
+Edits (static.py:827-981) run the same way: a site whose arguments did not change and that the request does not
+address keeps its sub-trace untouched — which is what makes `StaticRequest({"a": IndexRequest(i, Update(v))})` on a
+1e8-element plate cost one element's densities (combinators._vmap_edit_index_one_trace: a copy of the plate's leaves
+with one row replaced) plus the sites downstream of it.
+
+static.run_gfi / run_edit come here when Vmap.trace_call raises NeedsSiteBySite (an un-batched call reached a large
+plate) and remember that per call signature."""
+from __future__ import annotations
+
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from .core.choice_map import ChoiceMap
+from .core.generative import Diff, EditRequest, IndexRequest, Regenerate, Update
+
+
+class NeedsSiteBySite(Exception):
+    """raised while TRACING an un-batched call that reaches a plate of >= VMAP_LAUNCH_MIN elements"""
+
+
+def _add(a, b):
+    """a + b of two scores / weights in f32 on the device (0.0 + w is w: the first term costs nothing)"""
+    from .engine import elementwise
+    if isinstance(a, float) and a == 0.0:
+        return b
+    if isinstance(b, float) and b == 0.0:
+        return a
+    return elementwise(lambda x, y: x + y, a, b)
+
+
+def _resolve(gen_fn, args):
+    from .core.generative import GenerativeFunctionClosure
+    while isinstance(gen_fn, GenerativeFunctionClosure):
+        gen_fn, args = GenerativeFunctionClosure(gen_fn.gen_fn, gen_fn.args + tuple(args), gen_fn.kwargs)._target()
+    return gen_fn, tuple(args)
+
+
+class _Handler:
+    """what `callee(*args) @ addr` reaches while a model runs site by site (static.trace -> _HANDLERS[-1].handle)"""
+
+    def __init__(self, mode, key, constraint=None, prev=None, request=None):
+        self.mode, self.key = mode, key
+        self.constraint = constraint if constraint is not None else ChoiceMap.empty()
+        self.prev, self.request = prev, request
+        self.counter = 1
+        self.subtraces: "OrderedDict" = OrderedDict()
+        self.weight, self.score = 0.0, 0.0
+        self.backward = OrderedDict()          # addr -> the sub-edit's backward request
+
+    def _key(self):
+        from .random import fold_in
+        c = self.counter
+        self.counter += 1
+        return fold_in(self.key, c) if self.key is not None else None
+
+    def handle(self, addr, gen_fn, args):
+        from .static import AddressReuse, MissingAddress
+        gen_fn, args = _resolve(gen_fn, args)
+        if addr in self.subtraces:
+            raise AddressReuse(addr)
+        k = self._key()
+        sub = self.constraint.get_submap(addr)
+        try:
+            if self.mode == "simulate":
+                tr = gen_fn.simulate(k, args)
+            elif self.mode == "generate":
+                tr, w = gen_fn.generate(k, sub, args)
+                self.weight = _add(self.weight, w)
+            elif self.mode == "assess":
+                try:            # ONE trace: the callee must not read a plate's length as a particle batch
+                    s, retval = gen_fn.assess(sub, args, batch_shape=())
+                except TypeError:
+                    s, retval = gen_fn.assess(sub, args)
+                self.score = _add(self.score, s)
+                self.subtraces[addr] = None
+                return retval
+            else:
+                tr = self._edit(addr, gen_fn, k, args, sub)
+        except MissingAddress as e:
+            inner = tuple(a for a in e.args if a != ())
+            raise MissingAddress(*((addr,) + inner)) from None
+        self.subtraces[addr] = tr
+        return tr.get_retval()
+
+    # -- edits ---------------------------------------------------------------------------------------------------------
+    def _subrequest(self, addr, sub_constraint):
+        from .static import StaticRequest, _norm
+        r = self.request
+        if isinstance(r, Update):
+            return Update(sub_constraint) if not sub_constraint.static_is_empty() else None
+        if isinstance(r, Regenerate):
+            sel = r.selection(addr)
+            from .core import choice_map as cm
+            return None if isinstance(sel, cm._None) else Regenerate(sel)
+        if isinstance(r, StaticRequest):
+            for a, q in r.addressed.items():
+                if a != () and _norm(a) == _norm(addr):
+                    return q
+            return None
+        raise NotImplementedError(f"site-by-site edit with a {type(r).__name__}")
+
+    def _edit(self, addr, gen_fn, k, args, sub_constraint):
+        try:
+            prev = self.prev.subtraces[addr]
+        except KeyError:
+            raise KeyError(f"address {addr!r} is not in the previous trace") from None
+        req = self._subrequest(addr, sub_constraint)
+        changed = not same_args(args, prev.get_args())
+        if req is None and not changed:
+            return prev                        # untouched: no launch, the sub-trace is shared
+        if req is None:
+            req = Update(ChoiceMap.empty())    # re-scored against its new arguments
+        ad = Diff.unknown_change(args) if changed else Diff.no_change(args)
+        new, w, _retdiff, bwd = req.edit(k, prev, ad)
+        self.weight = _add(self.weight, w)
+        self.backward[addr] = bwd
+        return new
+
+
+def same_args(a, b) -> bool:
+    """are the arguments a site is called with now the ones its sub-trace was made with? (values, not identities:
+    `jnp.zeros(n)` builds a new array at every run of the model's source)"""
+    if a is b:
+        return True
+    if b is None:
+        return False
+    if isinstance(a, (tuple, list)):
+        return isinstance(b, (tuple, list)) and len(a) == len(b) and all(same_args(x, y) for x, y in zip(a, b))
+    if isinstance(a, dict):
+        return isinstance(b, dict) and a.keys() == b.keys() and all(same_args(a[k], b[k]) for k in a)
+    from .engine import materialize
+    a, b = materialize(a), materialize(b)
+    if isinstance(a, torch.Tensor) or isinstance(b, torch.Tensor):
+        if not (isinstance(a, torch.Tensor) and isinstance(b, torch.Tensor)):
+            try:
+                a_, b_ = torch.as_tensor(np.asarray(a.cpu() if isinstance(a, torch.Tensor) else a)), \
+                    torch.as_tensor(np.asarray(b.cpu() if isinstance(b, torch.Tensor) else b))
+            except Exception:      # noqa: BLE001
+                return False
+            return a_.shape == b_.shape and bool(torch.equal(a_.to(torch.float64), b_.to(torch.float64)))
+        return a.shape == b.shape and a.dtype == b.dtype and a.device == b.device and bool(torch.equal(a, b))
+    if isinstance(a, np.ndarray) or isinstance(b, np.ndarray):
+        a, b = np.asarray(a), np.asarray(b)
+        return a.shape == b.shape and bool(np.array_equal(a, b))
+    import dataclasses
+    if dataclasses.is_dataclass(a) and not isinstance(a, type):
+        return type(a) is type(b) and all(same_args(getattr(a, f.name), getattr(b, f.name)) for f in dataclasses.fields(a))
+    try:
+        return bool(a == b)
+    except Exception:      # noqa: BLE001
+        return False
+
+
+def _run_source(gen_fn, handler, args):
+    from . import static
+    static._HANDLERS.append(handler)
+    try:
+        return gen_fn.source(*args)
+    finally:
+        static._HANDLERS.pop()
+
+
+def run_gfi(gen_fn, mode, key, args, constraint=None):
+    """simulate / generate / assess of `gen_fn` for one trace, site by site (see the module docstring)"""
+    from .static import StaticTrace
+    if key is not None and tuple(key.shape) != ():
+        raise ValueError("site-by-site execution is for ONE trace (an un-batched key)")
+    args = tuple(args)
+    h = _Handler(mode, key, constraint)
+    retval = _run_source(gen_fn, h, args)
+    if mode == "assess":
+        return _as_score(h.score), retval
+    tr = StaticTrace(gen_fn, args, retval, h.subtraces)
+    tr._site_by_site = True
+    if mode == "simulate":
+        return tr
+    return tr, _as_score(h.weight)
+
+
+def _as_score(v):
+    from . import _lib
+    if isinstance(v, torch.Tensor):
+        return v
+    return torch.full((), float(v), dtype=torch.float32, device=_lib.get().device)
+
+
+def run_edit(gen_fn, key, trace, request: EditRequest, argdiffs):
+    """edit(key, trace, request, argdiffs) of a trace made site by site: (new trace, weight, retdiff, backward request)"""
+    from .static import StaticRequest, StaticTrace
+    if not isinstance(request, (Update, Regenerate, StaticRequest)):
+        raise NotImplementedError(f"site-by-site edit with a {type(request).__name__}")
+    args = tuple(Diff.tree_primal(argdiffs)) if argdiffs is not None else tuple(trace.get_args() or ())
+    constraint = request.constraint if isinstance(request, Update) else None
+    h = _Handler("edit", key, constraint, prev=trace, request=request)
+    retval = _run_source(gen_fn, h, args)
+    missing = [a for a in trace.subtraces if a not in h.subtraces]
+    if missing:
+        raise NotImplementedError(f"an edit that removes addresses ({missing[0]!r} ...) from the trace")
+    new = StaticTrace(gen_fn, args, retval, h.subtraces)
+    new._site_by_site = True
+    if isinstance(request, StaticRequest):
+        bwd = StaticRequest(dict(h.backward))
+    else:                                           # Update / Regenerate: Update(the discarded values)
+        discard = ChoiceMap.empty()
+        for addr, b in h.backward.items():
+            sub = _discard_of(b)
+            if sub is not None and not sub.static_is_empty():
+                discard = discard.set(addr, sub) if not isinstance(addr, tuple) else discard.set(addr, sub)
+        bwd = Update(discard)
+    retdiff = Diff.no_change(retval) if all(new.subtraces[a] is trace.subtraces[a] for a in new.subtraces) \
+        else Diff.unknown_change(retval)
+    return new, _as_score(h.weight), retdiff, bwd
+
+
+def _discard_of(bwd):
+    """the choice map a backward request puts back (Update(discard); an IndexRequest's is addressed by its index)"""
+    from .static import StaticRequest
+    if isinstance(bwd, Update):
+        return bwd.constraint
+    if isinstance(bwd, IndexRequest):
+        inner = _discard_of(bwd.request)
+        if inner is None or not isinstance(bwd.idx, int):
+            return None
+        return ChoiceMap.empty().set(bwd.idx, inner)
+    if isinstance(bwd, StaticRequest):
+        out = ChoiceMap.empty()
+        for a, r in bwd.addressed.items():
+            sub = _discard_of(r)
+            if sub is not None and not sub.static_is_empty():
+                out = out.set(a, sub) if a != () else sub
+        return out
+    return None

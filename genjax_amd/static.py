@@ -33,6 +33,7 @@ import torch
 
 from . import _lib
 from . import tracer as T
+from . import sitewise
 from .core.choice_map import ChoiceMap, Selection, _norm
 from .core.mask import Mask
 from .core.generative import (Diff, EditRequest, EmptyRequest, GenerativeFunction, IndexRequest, NoChange,
@@ -893,6 +894,7 @@ def call_gen_fn(ctx, mode, gen_fn, key, args, constraint, prev, req, req_leaves,
 # launch driver
 # ---------------------------------------------------------------------------
 _CACHE = _new_program_cache()
+_SITE_BY_SITE = ("site by site",)      # cache entry of a call signature that runs through sitewise.py
 
 
 def _lib_jit_min() -> int:
@@ -1154,6 +1156,8 @@ def run_gfi(gen_fn, mode, key: Key | None, args, constraint: ChoiceMap | None = 
                         and _NOISE_CTX.applies(key, batch, mode)) else None
     ck = (_gfkey(gen_fn), mode, atree, ctree, specs, len(batch), key is not None, weight_stats, na is not None)
     ent = _CACHE.get(ck)
+    if ent is _SITE_BY_SITE:
+        return sitewise.run_gfi(gen_fn, mode, key, args, constraint)
     if ent is None:
         tr = Tracing(len(batch))
         if na is not None:
@@ -1161,12 +1165,20 @@ def run_gfi(gen_fn, mode, key: Key | None, args, constraint: ChoiceMap | None = 
             tr.graph.noise_hoist = NoiseHoist(tr, len(specs))
         ctx = _Ctx(tr)
         ctx.store_sites = mode != "assess"
+        # ONE trace of a `@gen` function: a large plate inside it sends the call to the site-by-site form (sitewise.py)
+        ctx.sitewise = (len(batch) == 0 and isinstance(gen_fn, StaticGenerativeFunction) and not weight_stats and na is None
+                        and (key is None or tuple(key.shape) == ()))
+        try:
+            with T.tracing(tr.graph):
+                syms = [tr.sym_leaf(s, j) for j, s in enumerate(specs)]
+                sargs = unflatten(atree, lambda j: syms[j].value)
+                scon = _sym_constraint(ctree, syms)
+                kexpr = Expr(tr.graph.add("LDKEY", dtype="key")) if key is not None else None
+                rec, retval, w, s = call_gen_fn(ctx, mode, gen_fn, kexpr, sargs, scon, None, None, None, ())
+        except sitewise.NeedsSiteBySite:
+            _CACHE[ck] = _SITE_BY_SITE
+            return sitewise.run_gfi(gen_fn, mode, key, args, constraint)
         with T.tracing(tr.graph):
-            syms = [tr.sym_leaf(s, j) for j, s in enumerate(specs)]
-            sargs = unflatten(atree, lambda j: syms[j].value)
-            scon = _sym_constraint(ctree, syms)
-            kexpr = Expr(tr.graph.add("LDKEY", dtype="key")) if key is not None else None
-            rec, retval, w, s = call_gen_fn(ctx, mode, gen_fn, kexpr, sargs, scon, None, None, None, ())
             otree = _emit_rec(tr, rec) if mode != "assess" else None
             wo = tr.emit_output(w) if (mode == "generate" and w is not None) else None
             so = tr.emit_output(s) if mode == "assess" else None
@@ -1493,6 +1505,8 @@ def run_mh(gen_fn, key: Key, trace: Trace, request: EditRequest, argdiffs):
 
 def run_edit(gen_fn, key: Key, trace: Trace, request: EditRequest, argdiffs, mh: bool = False):
     """edit(key, trace, request, argdiffs) -> (new trace, weight, retdiff, backward request)."""
+    if getattr(trace, "_site_by_site", False) and not mh:
+        return sitewise.run_edit(gen_fn, key, trace, request, argdiffs)     # ONE trace holding large plates
     be = _lib.get()
     args = tuple(Diff.tree_primal(argdiffs)) if argdiffs is not None else tuple(trace.get_args() or ())
     tangents = Diff.tree_tangent(argdiffs) if argdiffs is not None else ()
@@ -1631,6 +1645,13 @@ def _bind_request_leaves(rspec, syms):
         rspec.constraint = _sym_constraint(rspec.tree, syms)
 
 
+def _has_scalar_tensor_choice(sample) -> bool:
+    flat = Flat()
+    flat.add(sample)
+    return any(isinstance(materialize(v), torch.Tensor) and materialize(v).dim() == 0 for v in flat.leaves
+               if isinstance(v, (torch.Tensor, Gathered)))
+
+
 # ---------------------------------------------------------------------------
 # the generative function
 # ---------------------------------------------------------------------------
@@ -1677,6 +1698,10 @@ class StaticGenerativeFunction(GenerativeFunction):
         return run_gfi(self, "generate", key, args, constraint=constraint)
 
     def assess(self, sample, args, batch_shape=None):
+        if batch_shape is None and _has_scalar_tensor_choice(sample):
+            # assess has no key to tell particles from plate elements; a 0-d TENSOR among the choices (what an un-batched
+            # trace's choices are) says the sample is ONE trace, whatever the plates' lengths suggest
+            batch_shape = ()
         return run_gfi(self, "assess", None, args, constraint=sample, batch_shape=batch_shape)
 
     def edit(self, key, trace, edit_request, argdiffs):

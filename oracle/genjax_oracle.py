@@ -995,6 +995,18 @@ def plate_sum_tree(x):
     return _block_sum_256(acc)
 
 
+def sum_vector(x):
+    """`jnp.sum` of a concrete float vector as the build defines it (genjax_amd/numpy.py::sum): element order below
+    Vmap.LAUNCH_MIN items, the plate score's fixed tree from there on"""
+    x = np.asarray(x, np.float32)
+    if x.shape[-1] >= 4096:
+        return plate_sum_tree(x)
+    acc = np.zeros(x.shape[:-1], np.float32)
+    for j in range(x.shape[-1]):
+        acc = (acc + x[..., j]).astype(np.float32)
+    return acc
+
+
 class VmapTrace:
     def __init__(self, gen_fn, inner, score, retval):
         self.gen_fn, self.inner, self.score, self.retval = gen_fn, inner, score, retval

@@ -2690,3 +2690,94 @@ def check_index_request_o1(n=96, P=40, seed=12, edits=5, nested=True):
     assert np.array_equal(new.get_choices()["theta"].cpu().numpy(), onew.get_choices()["theta"])
     assert np.array_equal(new.get_score().cpu().numpy(), onew.get_score())
     assert isinstance(bwd.request, IndexRequest) and bwd.idx == i and bwd.request.idx == j
+
+
+def check_one_trace_with_large_plates(n=5000, seed=21, timing=False):
+    """ONE trace (no particle batch) of a `@gen` model that holds LARGE plates runs site by site (genjax_amd/sitewise.py;
+    the reference's shape of `4_index_request.ipynb` c3-c9 and of the mixture model's `generate_data`): bare-distribution
+    plates and a plate of a `@gen` element inside a NESTED `@gen` call, sums of plate values feeding a later site —
+    simulate / importance / assess, `Update` of a whole plate (as a constraint and as a StaticRequest),
+    `StaticRequest({"a": IndexRequest(i, Update(v))})` (one element: every other site's sub-trace is shared) and its
+    backward request — bit-exact against the oracle (which runs models eagerly by construction)."""
+    import time
+    import genjax_amd as G
+    from genjax_amd import ChoiceMapBuilder as C, Diff, IndexRequest, StaticRequest, Update, numpy as jnp
+    sig = np.linspace(1.0, 2.0, n).astype(np.float32)
+    school, oschool = _school(G), _school(O)
+
+    @G.gen
+    def data(mu):
+        return school.vmap(in_axes=(None, None, 0))(mu, 2.0, jnp.array(sig)) @ "schools"
+
+    @G.gen
+    def model():
+        x = G.normal(0.0, 1.0) @ "x"
+        a = G.normal.vmap()(jnp.zeros(n), jnp.ones(n)) @ "a"
+        b = G.normal.vmap()(jnp.zeros(n) + 1.0, jnp.ones(n) * 2.0) @ "b"
+        th = data(x) @ "data"
+        obs = G.normal(jnp.sum(a) + jnp.sum(b) + jnp.sum(th) + x, 5.0) @ "obs"
+        return obs
+
+    @O.gen
+    def odata(mu):
+        return O.Vmap(oschool, in_axes=(None, None, 0))(mu, np.float32(2.0), sig) @ "schools"
+
+    @O.gen
+    def omodel():
+        x = O.normal(0.0, 1.0) @ "x"
+        a = O.Vmap(O.normal, in_axes=(0, 0))(np.zeros(n, np.float32), np.ones(n, np.float32)) @ "a"
+        b = O.Vmap(O.normal, in_axes=(0, 0))(np.zeros(n, np.float32) + np.float32(1.0), np.ones(n, np.float32) * np.float32(2.0)) @ "b"
+        th = odata(x) @ "data"
+        s = ((O.sum_vector(a) + O.sum_vector(b)).astype(np.float32) + O.sum_vector(th)).astype(np.float32)
+        obs = O.normal((s + x).astype(np.float32), 5.0) @ "obs"
+        return obs
+    f32 = lambda v: np.float32(v.item() if hasattr(v, "item") else v)
+    tr, otr = model.simulate(G.key(seed), ()), omodel.simulate(O.key(seed), ())
+    assert getattr(tr, "_site_by_site", False), "the call did not take the site-by-site form"
+    for adr in ("x", "a", "b", "obs", ("data", "schools", "theta"), ("data", "schools", "y")):
+        assert np.array_equal(tr.get_choices()[adr].cpu().numpy(), np.asarray(otr.get_choices()[adr])), adr
+    assert f32(tr.get_score()) == f32(otr.get_score())
+    tr2, w = model.importance(G.key(seed + 1), C["obs"].set(1.0), ())
+    otr2, ow = omodel.importance(O.key(seed + 1), O.C.d({"obs": np.float32(1.0)}), ())
+    assert f32(w) == f32(ow) and f32(tr2.get_score()) == f32(otr2.get_score())
+    s, _ = model.assess(tr2.get_choices(), ())
+    so, _ = omodel.assess(otr2.get_choices(), (), ())
+    assert f32(s) == f32(so) == f32(tr2.get_score())
+    # Update of a whole plate: as a constraint, and as a request (4_index_request.ipynb c7)
+    vals = np.linspace(-1.0, 1.0, n).astype(np.float32)
+    t0 = time.perf_counter()
+    new1, w1, _, disc1 = tr2.update(G.key(seed + 2), C["a"].set(jnp.array(vals)), Diff.no_change(()))
+    _ = f32(w1)
+    t_update = time.perf_counter() - t0
+    new2, w2, _, _ = StaticRequest({"a": Update(C.v(jnp.array(vals)))}).edit(G.key(seed + 2), tr2, Diff.no_change(()))
+    onew, ow1, odisc = omodel.update(O.key(seed + 2), otr2, O.C.d({"a": vals}), ())
+    assert f32(w1) == f32(w2) == f32(ow1)
+    assert np.array_equal(new1.get_choices()["a"].cpu().numpy(), vals) and f32(new1.get_score()) == f32(onew.get_score())
+    assert np.array_equal(disc1["a"].cpu().numpy(), np.asarray(otr2.get_choices()["a"]))
+    # one element of a bare plate, and one element of the nested `@gen` plate (c9)
+    req = StaticRequest({"a": IndexRequest(jnp.array(3), Update(C.v(42.0)))})
+    req.edit(G.key(seed + 3), tr2, Diff.no_change(()))                 # (warm: programs compiled)
+    t0 = time.perf_counter()
+    new3, w3, _, bwd3 = req.edit(G.key(seed + 3), tr2, Diff.no_change(()))
+    _ = f32(w3)
+    t_index = time.perf_counter() - t0
+    a3 = new3.get_choices()["a"].cpu().numpy()
+    assert (a3 == 42.0).sum() == 1 and a3[3] == 42.0
+    av = np.asarray(otr2.get_choices()["a"]).copy()
+    av[3] = 42.0
+    onew3, ow3, _ = omodel.update(O.key(seed + 3), otr2, O.C.d({"a": av}), ())
+    assert f32(new3.get_score()) == f32(onew3.get_score()) and f32(w3) == f32(ow3), (f32(w3), f32(ow3))
+    for adr in ("x", "b", "data"):
+        assert new3.subtraces[adr] is tr2.subtraces[adr]              # untouched sites share their sub-traces
+    back, wb, _, _ = bwd3.edit(G.key(seed + 4), new3, Diff.no_change(()))
+    assert np.array_equal(back.get_choices()["a"].cpu().numpy(), np.asarray(otr2.get_choices()["a"]))
+    assert f32(back.get_score()) == f32(tr2.get_score())
+    req4 = StaticRequest({"data": StaticRequest({"schools": IndexRequest(n - 2, Update(C["y"].set(0.5)))})})
+    new4, w4, _, _ = req4.edit(G.key(seed + 5), tr2, Diff.no_change(()))
+    yv = np.asarray(otr2.get_choices()["data", "schools", "y"]).copy()
+    yv[n - 2] = 0.5
+    onew4, ow4, _ = omodel.update(O.key(seed + 5), otr2, O.C.d({("data", "schools", "y"): yv}), ())
+    assert np.array_equal(new4.get_choices()["data", "schools", "y"].cpu().numpy(), yv)
+    assert f32(new4.get_score()) == f32(onew4.get_score()) and f32(w4) == f32(ow4)
+    assert new4.subtraces["a"] is tr2.subtraces["a"] and new4.subtraces["obs"] is tr2.subtraces["obs"]   # theta unchanged: obs too
+    return (t_index, t_update) if timing else None

@@ -1013,6 +1013,16 @@ def test_index_request_on_a_long_plate_is_o1(gpu):
         assert 20.0 * t_o1 <= t_loop, (t_o1, t_loop)
 
 
+def test_one_trace_of_a_model_with_large_plates_runs_site_by_site(gpu):
+    """4_index_request.ipynb c3-c12 on the device: ONE trace of a model with three 1e6-element plates (two of bare
+    distributions, one of a `@gen` element inside a nested call) and an observation of their sums — site by site, plates
+    on the launch axis — bit-exact vs the oracle; `StaticRequest({"a": IndexRequest(3, Update(42.0))})` touches one
+    element and is several times cheaper than updating the whole plate."""
+    parity.check_one_trace_with_large_plates(n=20_000)
+    t_index, t_update = parity.check_one_trace_with_large_plates(n=1_000_000, seed=9, timing=True)
+    assert t_index < t_update, (t_index, t_update)
+
+
 def test_scan_carries_that_forward_each_other(gpu):
     """`(xn, a)` from `(a, b)` and `(b, a)` carries through the counted loop — interpreter and the
     specialised kernel (n >= 2^18) — bit-exact vs the oracle for simulate / generate / Update / Regenerate."""

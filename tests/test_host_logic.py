@@ -653,6 +653,15 @@ def test_program_cache_is_bounded(hostsim, monkeypatch):
         engine._ALL_CACHES.remove(cache)
 
 
+def test_one_trace_of_a_model_with_large_plates_runs_site_by_site():
+    """ref static.py:254-673 for ONE trace whose plates hold thousands of elements (4_index_request.ipynb c3-c9): the
+    model's source runs on the host site by site, large plates on the launch axis (genjax_amd/sitewise.py); simulate /
+    importance / assess / Update / StaticRequest + IndexRequest bit-exact vs the oracle, untouched sub-traces shared"""
+    from tests import parity
+    parity.check_one_trace_with_large_plates(n=5000)
+    parity.check_one_trace_with_large_plates(n=4096 * 2 + 5, seed=4)
+
+
 def test_indexed_and_masked_constraints_match_oracle():
     from tests import parity
     parity.check_masked_constraints()

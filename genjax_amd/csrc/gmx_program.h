@@ -43,6 +43,10 @@
 #define GMX_POOL_BASE 64u /* source operand codes >= this name pool entries */
 
 // LDIN / STOUT flag bits (field b for LDIN, field dst for STOUT)
+/* a sampler's element counter (the 24-bit immediate of OP_S_*): this value means "the particle's GLOBAL index"
+ * (index_offset + i) — a vector-valued site of n elements run with its elements on the launch axis: element i draws with
+ * counter i from the ONE site key, as the unrolled form's element i does with immediate i */
+#define GMX_ELEM_INDEX 0xffffffu
 #define GMX_F_GATHER 1u /* row = ancestors[i] instead of i            */
 #define GMX_F_U8 2u     /* element is 1 byte (bool) <-> i32 0/1        */
 #define GMX_F_BCAST 4u  /* row = 0: one device-resident scalar for all  */

@@ -81,6 +81,7 @@ GMX_HD void gmx_vm_step(Regs& R, const W w, int64_t i, bool active, const gmx_ru
 #define SRC(x) ((x) < GMX_POOL_BASE ? R.get(x) : ctx.pool((x) - GMX_POOL_BASE))
 #define FSRC(x) gmx_asf(SRC(x))
 #define KEY(x) gmx_key k; k.k0 = R.get(x); k.k1 = R.get((x) + 1u)
+#define ELEM() (e == GMX_ELEM_INDEX ? (uint32_t)(A.index_offset + i) : e)
   {
     const uint32_t op = w0 & 0xffu, dst = (w0 >> 8) & 0xffu, a = (w0 >> 16) & 0xffu, b = w0 >> 24;
     const uint32_t c = w1 & 0xffu, e = w1 >> 8;
@@ -207,10 +208,10 @@ GMX_HD void gmx_vm_step(Regs& R, const W w, int64_t i, bool active, const gmx_ru
       case OP_IMUL: r0 = (uint32_t)((int32_t)SRC(a) * (int32_t)SRC(b)); break;
       case OP_INEG: r0 = (uint32_t)(-(int32_t)SRC(a)); break;
       // ---- samplers ----
-      case OP_S_NORMAL: { KEY(c); r0 = gmx_asu(gmx_normal_sample(k, e, FSRC(a), FSRC(b))); } break;
-      case OP_S_UNIFORM: { KEY(c); r0 = gmx_asu(gmx_uniform_sample(k, e, FSRC(a), FSRC(b))); } break;
-      case OP_S_FLIP: { KEY(c); r0 = (uint32_t)gmx_flip_sample(k, e, FSRC(a)); } break;
-      case OP_S_BERNL: { KEY(c); r0 = (uint32_t)gmx_bernoulli_logits_sample(k, e, FSRC(a)); } break;
+      case OP_S_NORMAL: { KEY(c); r0 = gmx_asu(gmx_normal_sample(k, ELEM(), FSRC(a), FSRC(b))); } break;
+      case OP_S_UNIFORM: { KEY(c); r0 = gmx_asu(gmx_uniform_sample(k, ELEM(), FSRC(a), FSRC(b))); } break;
+      case OP_S_FLIP: { KEY(c); r0 = (uint32_t)gmx_flip_sample(k, ELEM(), FSRC(a)); } break;
+      case OP_S_BERNL: { KEY(c); r0 = (uint32_t)gmx_bernoulli_logits_sample(k, ELEM(), FSRC(a)); } break;
       // ---- log densities ----
       case OP_L_NORMAL: r0 = gmx_asu(gmx_normal_logpdf(FSRC(c), FSRC(a), FSRC(b))); break;
       case OP_L_UNIFORM: r0 = gmx_asu(gmx_uniform_logpdf(FSRC(c), FSRC(a), FSRC(b))); break;
@@ -230,7 +231,7 @@ GMX_HD void gmx_vm_step(Regs& R, const W w, int64_t i, bool active, const gmx_ru
             case OP_TANH: r0 = gmx_asu(gmx_tanhf(FSRC(a))); break;
             case OP_SOFTPLUS: r0 = gmx_asu(gmx_softplusf(FSRC(a))); break;
             case OP_LGAMMA: r0 = gmx_asu(gmx_lgammaf(FSRC(a))); break;
-            case OP_S_BETA: { KEY(c); r0 = gmx_asu(gmx_beta_sample(k, e, FSRC(a), FSRC(b))); } break;
+            case OP_S_BETA: { KEY(c); r0 = gmx_asu(gmx_beta_sample(k, ELEM(), FSRC(a), FSRC(b))); } break;
             case OP_S_LOGGAMMA: { KEY(c); r0 = gmx_asu(gmx_log_gamma_sample(gmx_split_child(k, e), FSRC(a))); } break;
             case OP_S_CATSTEP: {
               KEY(c);
@@ -255,6 +256,7 @@ GMX_HD void gmx_vm_step(Regs& R, const W w, int64_t i, bool active, const gmx_ru
 #undef SRC
 #undef FSRC
 #undef KEY
+#undef ELEM
 }
 
 // NI < 0: interpret n_instr_rt instructions fetched through ctx at run time.

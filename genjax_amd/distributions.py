@@ -115,6 +115,14 @@ class Distribution(GenerativeFunction):
         g = current_graph()
         elems, shape = _bcast(args)
         out = []
+        if getattr(g, "elem_from_index", False):
+            # the ELEMENTS of one vector-valued site on the launch axis (sitewise.vector_site): launch element i is the
+            # site's element i — counter = the global index, from the one site key
+            from .program import ELEM_INDEX
+            if shape != () or self.sample_op is None:
+                raise NotImplementedError(f"{self.name}: a large vector-valued site takes scalar elements")
+            ops = tuple(T.as_float(x).node for x in elems[0])
+            return Expr(g.add(self.sample_op, (key.node,) + ops, imm=ELEM_INDEX, dtype=self.value_dtype))
         hoist = g.__dict__.get("noise_hoist") if self.sample_op in ("S_NORMAL", "S_UNIFORM") else None
         for e, a in enumerate(elems):
             if hoist is not None:
@@ -309,10 +317,15 @@ class _Categorical(Distribution):
         n = args[1][1] if len(args) == 2 and isinstance(args[1], tuple) and args[1][:1] == ("sample_shape",) else None
         ls = self._logits(args[:1])
         out = []
+        row = None
+        if getattr(g, "elem_from_index", False):      # draw i of `sample_shape = n` on the launch axis: counters i * K + k
+            if n is not None:
+                raise NotImplementedError("categorical: the elements of a large sample_shape are scalar draws")
+            row = Expr(g.add("LDIDX", dtype="i32")) * len(ls)
         for j in range(n or 1):
             state = None
             for k, lk in enumerate(ls):
-                ctr = g.const_i32(j * len(ls) + k)
+                ctr = g.const_i32(j * len(ls) + k) if row is None else (row + k).node
                 state = g.add("S_CATSTEP", (state, key.node, lk.node, ctr), imm=k, dtype="cat")
             # the index lives in the second register of the state pair
             out.append(Expr(g.add("CATIDX", (state,), dtype="i32")))

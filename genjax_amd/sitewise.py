@@ -77,8 +77,18 @@ class _Handler:
             raise AddressReuse(addr)
         k = self._key()
         sub = self.constraint.get_submap(addr)
+        big = vector_site_size(gen_fn, args)
         try:
-            if self.mode == "simulate":
+            if big is not None and self.mode in ("simulate", "generate", "assess"):
+                out = vector_site(gen_fn, self.mode, k, args, sub, big)
+                if self.mode == "assess":
+                    self.score = _add(self.score, out[0])
+                    self.subtraces[addr] = None
+                    return out[1]
+                tr = out[0]
+                if self.mode == "generate":
+                    self.weight = _add(self.weight, out[1])
+            elif self.mode == "simulate":
                 tr = gen_fn.simulate(k, args)
             elif self.mode == "generate":
                 tr, w = gen_fn.generate(k, sub, args)
@@ -128,10 +138,148 @@ class _Handler:
         if req is None:
             req = Update(ChoiceMap.empty())    # re-scored against its new arguments
         ad = Diff.unknown_change(args) if changed else Diff.no_change(args)
-        new, w, _retdiff, bwd = req.edit(k, prev, ad)
+        big = vector_site_size(gen_fn, args)
+        if big is not None and getattr(prev, "_elem_scores", None) is not None:
+            new, w, bwd = vector_site_update(gen_fn, k, prev, req, args, changed, big)
+        else:
+            new, w, _retdiff, bwd = req.edit(k, prev, ad)
         self.weight = _add(self.weight, w)
         self.backward[addr] = bwd
         return new
+
+
+def vector_site_size(gen_fn, args):
+    """n when `gen_fn(*args)` is a DISTRIBUTION site whose value is a vector of n >= VMAP_LAUNCH_MIN elements — a vector
+    parameter (`normal(clusters[idx], 1.0)` with idx of n elements) or `sample_shape=n` — else None"""
+    from .combinators import VMAP_LAUNCH_MIN
+    from .distributions import Distribution, _Categorical
+    if not isinstance(gen_fn, Distribution) or gen_fn.sample_op is None and not isinstance(gen_fn, _Categorical):
+        return None
+    pos, kw = (args[0], args[1]) if len(args) == 2 and isinstance(args[1], dict) and isinstance(args[0], tuple) else (args, {})
+    ss = kw.get("sample_shape")
+    if ss is not None:
+        ss = ss.unwrap() if hasattr(ss, "unwrap") else ss
+        ss = (int(ss),) if isinstance(ss, (int, np.integer)) else tuple(int(x) for x in ss)
+        return ss[0] if len(ss) == 1 and ss[0] >= VMAP_LAUNCH_MIN else None
+    if isinstance(gen_fn, _Categorical):
+        return None                     # (its vector parameter is the logits of ONE draw)
+    sizes = {int(v.shape[0]) for v in list(pos) + list(kw.values())
+             if isinstance(v, (torch.Tensor, np.ndarray)) and getattr(v, "dtype", None) != object and v.ndim == 1}
+    if any(isinstance(v, (torch.Tensor, np.ndarray)) and v.ndim > 1 for v in list(pos) + list(kw.values())):
+        return None
+    if len(sizes) == 1 and max(sizes) >= VMAP_LAUNCH_MIN:
+        return max(sizes)
+    return None
+
+
+def symbolic_vector_site_size(args):
+    """the same question asked while TRACING (arguments are symbolic: vectors are object arrays or tables)"""
+    from .combinators import VMAP_LAUNCH_MIN
+    pos, kw = (args[0], args[1]) if len(args) == 2 and isinstance(args[1], dict) and isinstance(args[0], tuple) else (args, {})
+    ss = kw.get("sample_shape")
+    if ss is not None:
+        ss = ss.unwrap() if hasattr(ss, "unwrap") else ss
+        ss = (int(ss),) if isinstance(ss, (int, np.integer)) else tuple(int(x) for x in ss)
+        return ss[0] if len(ss) == 1 and ss[0] >= VMAP_LAUNCH_MIN else None
+    big = [int(v.shape[0]) for v in list(pos) + [x for k_, x in kw.items() if k_ != "sample_shape"]
+           if hasattr(v, "shape") and len(getattr(v, "shape", ())) == 1 and int(v.shape[0]) >= VMAP_LAUNCH_MIN]
+    return max(big) if big else None
+
+
+def vector_site(dist, mode, key, args, constraint, n):
+    """A distribution site whose value has n >= VMAP_LAUNCH_MIN elements, for ONE trace: the scalar distribution over a
+    launch of n elements — element i draws with counter i from the ONE site key (what `tfd.X(...).sample(seed=key)` of
+    that shape does; unrolled vector-valued sites give element i the immediate i) — and the site's
+    score is the fixed tree over the elements' log-densities (engine.sum_rows; oracle: sum_vector)."""
+    from . import _lib
+    from .combinators import torch_from_host
+    from .engine import Broadcast, sum_rows
+    from .static import DistributionTrace, run_gfi
+    dev = _lib.get().device
+    pos, kw = (args[0], dict(args[1])) if len(args) == 2 and isinstance(args[1], dict) and isinstance(args[0], tuple) else (args, {})
+    kw.pop("sample_shape", None)
+
+    def elem(v):            # a vector parameter is one value per element, anything else is shared by all of them
+        if isinstance(v, np.ndarray) and v.dtype != object and v.ndim == 1 and v.shape[0] == n:
+            return torch_from_host(v, dev)
+        if isinstance(v, torch.Tensor) and v.ndim == 1 and v.shape[0] == n:
+            return v
+        if isinstance(v, torch.Tensor) and v.ndim >= 1:
+            return Broadcast(v)         # e.g. the logits of every draw of a categorical
+        return v
+    eargs = tuple(elem(v) for v in pos)
+    if kw:
+        eargs = (eargs, {k_: elem(v) for k_, v in kw.items()})
+    value = constraint.get_value() if constraint is not None and not constraint.static_is_empty() else None
+    if value is not None:
+        if isinstance(value, np.ndarray):
+            value = torch_from_host(value, dev)
+        if tuple(getattr(value, "shape", ())) != (n,):
+            raise ValueError(f"{dist.name}: the constraint of a {n}-element site must have {n} elements")
+        con = ChoiceMap.choice(value)
+    if mode == "assess":
+        if value is None:
+            from .static import MissingAddress
+            raise MissingAddress(())
+        s, v = run_gfi(dist, "assess", None, eargs, constraint=con, batch_shape=(n,))
+        return sum_rows(s), v
+    if mode == "generate" and value is not None:
+        tr, w = run_gfi(dist, "generate", key, eargs, constraint=con, batch_shape=(n,), elem_index=True)
+        out = DistributionTrace(dist, tuple(args), tr.value, sum_rows(tr.score))
+        out._elem_scores = tr.score
+        return out, sum_rows(w)
+    tr = run_gfi(dist, "simulate", key, eargs, batch_shape=(n,), elem_index=True)
+    out = DistributionTrace(dist, tuple(args), tr.value, sum_rows(tr.score))
+    out._elem_scores = tr.score
+    if mode == "generate":
+        return out, _as_score(0.0)
+    return (out,)
+
+
+def vector_site_update(dist, key, prev, req, args, changed, n):
+    """`Update` (a new value and / or new arguments) of a distribution site of n >= VMAP_LAUNCH_MIN elements held by ONE
+    trace: the scalar distribution's Update over the launch of n elements (distribution.py:189-242), weight and score
+    summed in the fixed tree"""
+    from . import _lib
+    from .combinators import torch_from_host
+    from .engine import Broadcast, sum_rows
+    from .static import DistributionTrace, run_edit
+    if not isinstance(req, Update):
+        raise NotImplementedError(f"{type(req).__name__} on a {n}-element site of one trace (Update only; write the "
+                                  "plate with vmap for per-element requests)")
+    dev = _lib.get().device
+    pos, kw = (args[0], dict(args[1])) if len(args) == 2 and isinstance(args[1], dict) and isinstance(args[0], tuple) else (args, {})
+    kw.pop("sample_shape", None)
+
+    def elem(v):
+        if isinstance(v, np.ndarray) and v.dtype != object and v.ndim == 1 and v.shape[0] == n:
+            return torch_from_host(v, dev)
+        if isinstance(v, torch.Tensor) and v.ndim == 1 and v.shape[0] == n:
+            return v
+        if isinstance(v, torch.Tensor) and v.ndim >= 1:
+            return Broadcast(v)
+        return v
+    eargs = tuple(elem(v) for v in pos)
+    if kw:
+        eargs = (eargs, {k_: elem(v) for k_, v in kw.items()})
+    value = req.constraint.get_value() if not req.constraint.static_is_empty() else None
+    con = ChoiceMap.empty()
+    if value is not None:
+        if isinstance(value, np.ndarray):
+            value = torch_from_host(value, dev)
+        if tuple(getattr(value, "shape", ())) != (n,):
+            raise ValueError(f"{dist.name}: the new value of a {n}-element site must have {n} elements")
+        con = ChoiceMap.choice(value)
+    elem_tr = DistributionTrace(dist, eargs, prev.value, prev._elem_scores)
+    ad = Diff.unknown_change(eargs) if changed else Diff.no_change(eargs)
+    new_e, _w, _rd, bwd = run_edit(dist, key, elem_tr, Update(con), ad)
+    total = sum_rows(new_e.score)
+    out = DistributionTrace(dist, tuple(args), new_e.value, total)
+    out._elem_scores = new_e.score
+    # the site's weight is the difference of its SUMMED scores (distribution.py:205-224: new score - old score), not the
+    # sum of the elements' differences
+    from .engine import elementwise, materialize
+    return out, elementwise(lambda a_, b_: a_ - b_, total, materialize(prev.get_score())), bwd
 
 
 def same_args(a, b) -> bool:

@@ -705,6 +705,9 @@ class Handler:
 def _leaf_call(ctx: _Ctx, mode, dist, key, args, constraint: ChoiceMap, prev, req, req_leaves):
     """Leaf (Distribution) semantics; returns (_SiteRec, retval, weight, score)."""
     g = ctx.tr.graph
+    if getattr(ctx, "sitewise", False) and sitewise.symbolic_vector_site_size(args) is not None \
+            and not getattr(g, "_in_loop", False) and not g.loop_counts:
+        raise sitewise.NeedsSiteBySite()      # ONE trace and a site of thousands of elements: not unrolled (sitewise.vector_site)
     args = dist.canon(args)
     cval = constraint.get_value() if constraint is not None else None
     zero = None
@@ -1132,7 +1135,7 @@ def _noise_split(tr: Tracing, batch, ctx):
 
 
 def run_gfi(gen_fn, mode, key: Key | None, args, constraint: ChoiceMap | None = None, batch_shape=None,
-            weight_stats: bool = False):
+            weight_stats: bool = False, elem_index: bool = False):
     """simulate / generate / assess for any generative function: one launch.
     weight_stats (generate, 1-D batches): the program also reduces its importance weight per workgroup (OP_REDMAX) and,
     when it runs as a specialised 4-particles-per-thread kernel, leaves the resampler's CDF tile statistics
@@ -1146,6 +1149,8 @@ def run_gfi(gen_fn, mode, key: Key | None, args, constraint: ChoiceMap | None = 
     ctree = flat.add(constraint)
     if key is not None:
         batch = tuple(key.shape)
+        if elem_index:          # the elements of ONE vector-valued site on the launch axis: one key, counter = the index
+            batch = tuple(batch_shape)
     elif batch_shape is not None:
         batch = tuple(batch_shape)
     else:
@@ -1154,7 +1159,7 @@ def run_gfi(gen_fn, mode, key: Key | None, args, constraint: ChoiceMap | None = 
     weight_stats = bool(weight_stats and mode == "generate" and len(batch) == 1)
     na = _NOISE_CTX if (_NOISE_CTX is not None and mode in ("generate", "simulate")
                         and _NOISE_CTX.applies(key, batch, mode)) else None
-    ck = (_gfkey(gen_fn), mode, atree, ctree, specs, len(batch), key is not None, weight_stats, na is not None)
+    ck = (_gfkey(gen_fn), mode, atree, ctree, specs, len(batch), key is not None, weight_stats, na is not None, elem_index)
     ent = _CACHE.get(ck)
     if ent is _SITE_BY_SITE:
         return sitewise.run_gfi(gen_fn, mode, key, args, constraint)
@@ -1163,6 +1168,7 @@ def run_gfi(gen_fn, mode, key: Key | None, args, constraint: ChoiceMap | None = 
         if na is not None:
             from .engine import NoiseHoist
             tr.graph.noise_hoist = NoiseHoist(tr, len(specs))
+        tr.graph.elem_from_index = bool(elem_index)
         ctx = _Ctx(tr)
         ctx.store_sites = mode != "assess"
         # ONE trace of a `@gen` function: a large plate inside it sends the call to the site-by-site form (sitewise.py)

@@ -456,12 +456,17 @@ class Distribution:
         batch_shape = tuple(batch_shape)
         batched, event = _event_of(batch_shape, w.shape)
         if event:
-            # sequential f32 sum over the flattened event axis, element order
+            # sequential f32 sum over the flattened event axis, element order — or, for ONE trace's site of at least
+            # Vmap.LAUNCH_MIN elements (the build runs its elements on the launch axis: sitewise.vector_site), the plate
+            # score's fixed tree (sum_vector)
             flat = w.reshape(w.shape[: w.ndim - len(event)] + (-1,))
-            acc = flat[..., 0].astype(np.float32)
-            for j in range(1, flat.shape[-1]):
-                acc = (acc + flat[..., j]).astype(np.float32)
-            w = acc
+            if batch_shape == () and flat.shape[-1] >= 4096:
+                w = sum_vector(flat)
+            else:
+                acc = flat[..., 0].astype(np.float32)
+                for j in range(1, flat.shape[-1]):
+                    acc = (acc + flat[..., j]).astype(np.float32)
+                w = acc
         return np.broadcast_to(w, np.broadcast_shapes(np.shape(w), batch_shape)).astype(np.float32)
 
     def simulate(self, k, args):
@@ -619,17 +624,29 @@ class _Categorical(Distribution):
     value_dtype = np.int32
 
     def _canon_args(self, args, kwargs):
+        # sample_shape = n (tfp sample_n; tensorflow_probability/__init__.py:52-55): n draws at ONE site from its one key,
+        # draw j / category k on gumbel counter j * K + k; carried as a second argument
+        extra = (np.int64(kwargs["sample_shape"]),) if kwargs.get("sample_shape") is not None else ()
         if "probs" in kwargs:
-            return (log(np.asarray(kwargs["probs"], np.float32)),)
+            return (log(np.asarray(kwargs["probs"], np.float32)),) + extra
         if "logits" in kwargs:
-            return (np.asarray(kwargs["logits"], np.float32),)
-        return (np.asarray(args[0], np.float32),)
+            return (np.asarray(kwargs["logits"], np.float32),) + extra
+        return (np.asarray(args[0], np.float32),) + extra
 
     def _sample(self, keys, args):
         keys = np.asarray(keys, dtype=np.uint32)
         batch = keys.shape[:-1]
         logits = np.asarray(args[0], np.float32)
         K = logits.shape[-1]
+        if len(args) == 2:                       # sample_shape = n draws from ONE key
+            if batch != () or logits.ndim != 1:
+                raise NotImplementedError("oracle categorical: sample_shape for one trace and one logits vector")
+            n = int(args[1])
+            out = np.empty(n, dtype=np.int32)
+            ctr = np.ascontiguousarray(np.arange(n, dtype=np.uint64) * np.uint64(K))
+            lib().orc_categorical_sample(I64(n), I64(K), _p(np.ascontiguousarray(keys.reshape(2))), I64(0),
+                                         _p(np.ascontiguousarray(logits)), I64(0), _p(ctr), I64(1), _p(out))
+            return out
         full = np.broadcast_shapes(batch + (K,), logits.shape)
         if len(full) != len(batch) + 1:
             raise NotImplementedError("oracle categorical: batched logits beyond the particle axis")
@@ -650,7 +667,10 @@ class _Categorical(Distribution):
         return (picked - np.broadcast_to(lse, shape)).astype(np.float32)
 
     def estimate_logpdf(self, v, args, batch_shape):
-        return self._logpdf(v, args)
+        w = self._logpdf(v, args[:1])
+        if len(args) == 2:                       # the n draws of one site: summed (element order, or the tree from 4096)
+            return sum_vector(w)
+        return w
 
 
 class _Dirichlet(Distribution):

@@ -2781,3 +2781,61 @@ def check_one_trace_with_large_plates(n=5000, seed=21, timing=False):
     assert f32(new4.get_score()) == f32(onew4.get_score()) and f32(w4) == f32(ow4)
     assert new4.subtraces["a"] is tr2.subtraces["a"] and new4.subtraces["obs"] is tr2.subtraces["obs"]   # theta unchanged: obs too
     return (t_index, t_update) if timing else None
+
+
+def check_one_trace_with_large_vector_sites(n=5000, K=8, seed=31):
+    """ONE trace of a model whose DISTRIBUTION sites hold thousands of elements — `categorical(logits, sample_shape=n)`
+    and `normal(clusters[idx] + mu, 1.0)` with idx of n elements: the shape of the mixture model's `generate_datapoints`
+    (7_application_dirichlet_mixture_model.ipynb c6) — runs site by site with the elements of such a site on the launch
+    axis (sitewise.vector_site: element i draws with counter i from the ONE site key, as `tfd.X.sample(seed=key)` of that
+    shape does).  simulate / importance / assess, `Update` of an upstream value (the site is re-scored against its new
+    arguments) and of the site's own value: bit-exact against the oracle; the first draws equal the unrolled form's."""
+    import genjax_amd as G
+    from genjax_amd import ChoiceMapBuilder as C, Diff, numpy as jnp
+    dev = G._lib.get().device
+    cl_h = np.linspace(-3.0, 3.0, K).astype(np.float32)
+    lg_h = np.linspace(-0.5, 0.5, K).astype(np.float32)
+
+    @G.gen
+    def model():
+        mu = G.normal(0.0, 1.0) @ "mu"
+        idx = G.categorical(logits=jnp.array(lg_h), sample_shape=n) @ "idx"
+        cl = torch.from_numpy(cl_h).to(dev)
+        obs = G.normal(cl[idx.long()] + mu, 1.0) @ "obs"
+        return obs
+
+    @O.gen
+    def omodel():
+        mu = O.normal(0.0, 1.0) @ "mu"
+        idx = O.categorical(logits=lg_h, sample_shape=n) @ "idx"
+        obs = O.normal((cl_h[idx] + mu).astype(np.float32), 1.0) @ "obs"
+        return obs
+    f32 = lambda v: np.float32(v.item() if hasattr(v, "item") else v)
+    tr, otr = model.simulate(G.key(seed), ()), omodel.simulate(O.key(seed), ())
+    assert getattr(tr, "_site_by_site", False)
+    assert np.array_equal(tr.get_choices()["idx"].cpu().numpy(), otr.get_choices()["idx"])
+    assert np.array_equal(tr.get_choices()["obs"].cpu().numpy(), otr.get_choices()["obs"])
+    assert f32(tr.get_score()) == f32(otr.get_score())
+    m = 12                                   # the unrolled definition of the same site: the same first draws
+
+    @G.gen
+    def small():
+        mu = G.normal(0.0, 1.0) @ "mu"
+        return G.categorical(logits=jnp.array(lg_h), sample_shape=m) @ "idx"
+    assert np.array_equal(small.simulate(G.key(seed), ()).get_choices()["idx"].cpu().numpy(), otr.get_choices()["idx"][:m])
+    ys = np.linspace(-4.0, 4.0, n).astype(np.float32)
+    tr2, w = model.importance(G.key(seed + 1), C["obs"].set(jnp.array(ys)), ())
+    otr2, ow = omodel.importance(O.key(seed + 1), O.C.d({"obs": ys}), ())
+    assert f32(w) == f32(ow) and f32(tr2.get_score()) == f32(otr2.get_score())
+    s, _ = model.assess(tr2.get_choices(), ())
+    so, _ = omodel.assess(otr2.get_choices(), (), ())
+    assert f32(s) == f32(so) == f32(tr2.get_score())
+    new, w3, _, _ = tr2.update(G.key(seed + 2), C["mu"].set(0.25), Diff.no_change(()))
+    onew, ow3, _ = omodel.update(O.key(seed + 2), otr2, O.C.d({"mu": np.float32(0.25)}), ())
+    assert f32(w3) == f32(ow3) and f32(new.get_score()) == f32(onew.get_score())
+    assert new.subtraces["idx"] is tr2.subtraces["idx"]
+    ys2 = ys[::-1].copy()
+    new2, w4, _, disc = new.update(G.key(seed + 3), C["obs"].set(jnp.array(ys2)), Diff.no_change(()))
+    onew2, ow4, _ = omodel.update(O.key(seed + 3), onew, O.C.d({"obs": ys2}), ())
+    assert f32(w4) == f32(ow4) and f32(new2.get_score()) == f32(onew2.get_score())
+    assert np.array_equal(disc["obs"].cpu().numpy(), ys)

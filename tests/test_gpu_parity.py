@@ -1021,6 +1021,8 @@ def test_one_trace_of_a_model_with_large_plates_runs_site_by_site(gpu):
     parity.check_one_trace_with_large_plates(n=20_000)
     t_index, t_update = parity.check_one_trace_with_large_plates(n=1_000_000, seed=9, timing=True)
     assert t_index < t_update, (t_index, t_update)
+    parity.check_one_trace_with_large_vector_sites(n=5000)
+    parity.check_one_trace_with_large_vector_sites(n=300_000, K=64, seed=2)      # the mixture model's data site
 
 
 def test_scan_carries_that_forward_each_other(gpu):

@@ -660,6 +660,8 @@ def test_one_trace_of_a_model_with_large_plates_runs_site_by_site():
     from tests import parity
     parity.check_one_trace_with_large_plates(n=5000)
     parity.check_one_trace_with_large_plates(n=4096 * 2 + 5, seed=4)
+    parity.check_one_trace_with_large_vector_sites(n=5000)
+    parity.check_one_trace_with_large_vector_sites(n=4096 + 7, K=5, seed=8)
 
 
 def test_indexed_and_masked_constraints_match_oracle():
@@ -794,8 +796,11 @@ def test_categorical_sample_shape():
     @genjax.gen
     def big():
         return genjax.categorical(probs=probs, sample_shape=5000) @ "idx"
+    # ONE trace: the 5000 draws run on the launch axis (sitewise.vector_site); under a batch of keys they would have to
+    # be unrolled per particle, which is refused
+    assert tuple(big.simulate(genjax.key(0), ()).get_retval().shape) == (5000,)
     with pytest.raises(NotImplementedError):
-        big.simulate(genjax.key(0), ())
+        big.simulate(genjax.split(genjax.key(0), 4), ())
 
 
 def test_mixture_model_gibbs_end_to_end():

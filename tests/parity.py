@@ -2840,3 +2840,63 @@ def check_one_trace_with_large_vector_sites(n=5000, K=8, seed=31):
     onew2, ow4, _ = omodel.update(O.key(seed + 3), onew, O.C.d({"obs": ys2}), ())
     assert f32(w4) == f32(ow4) and f32(new2.get_score()) == f32(onew2.get_score())
     assert np.array_equal(disc["obs"].cpu().numpy(), ys)
+
+
+def check_mixture_notebook_model(n=5000, k=16, seed=0):
+    """`generate_data` of 7_application_dirichlet_mixture_model.ipynb (c6), written as the notebook writes it — a `repeat` of
+    cluster means, an INLINED Dirichlet for the weights, a nested `@gen` call whose `categorical(log probs,
+    sample_shape=n)` and `normal(clusters[idx], sigma)` sites hold all n datapoints — for ONE trace: simulate, and the
+    notebook's `importance` under `C["datapoints", "obs"]` | `C["probs"]` (c10), bit-exact against the oracle.  (k <= 20:
+    a Dirichlet site is one program and keeps 2 k values live.)"""
+    import genjax_amd as G
+    from genjax_amd import ChoiceMapBuilder as C, numpy as jnp
+    from genjax_amd.core.pytree import Const
+    PRIOR_MEAN, PRIOR_VARIANCE, OBS_VARIANCE = 50.0, 10.0, 1.0
+    alpha = float(n / (k * 10))
+
+    @G.gen
+    def generate_cluster(mean, var):
+        return G.normal(mean, var) @ "mean"
+
+    @G.gen
+    def generate_cluster_weight(alphas):
+        return G.dirichlet(alphas) @ "probs"
+
+    @G.gen
+    def generate_datapoints(probs, clusters, n_datapoints):
+        idx = G.categorical(jnp.log(probs), sample_shape=n_datapoints) @ "idx"
+        return G.normal(clusters[idx], OBS_VARIANCE) @ "obs"
+
+    @G.gen
+    def generate_data(n_clusters, n_datapoints, alpha_):
+        clusters = generate_cluster.repeat(n=n_clusters.unwrap())(PRIOR_MEAN, PRIOR_VARIANCE) @ "clusters"
+        probs = generate_cluster_weight.inline(alpha_ / n_clusters.unwrap() * jnp.ones(n_clusters.unwrap()))
+        return generate_datapoints(probs, clusters, n_datapoints) @ "datapoints"
+
+    @O.gen
+    def o_cluster(mean, var):
+        return O.normal(mean, var) @ "mean"
+
+    @O.gen
+    def o_datapoints(probs, clusters):
+        idx = O.categorical(logits=O.log(np.asarray(probs, np.float32)), sample_shape=n) @ "idx"
+        return O.normal(np.asarray(clusters, np.float32)[idx], np.float32(OBS_VARIANCE)) @ "obs"
+
+    @O.gen
+    def o_data():
+        clusters = O.Repeat(o_cluster, k)(np.float32(PRIOR_MEAN), np.float32(PRIOR_VARIANCE)) @ "clusters"
+        probs = O.dirichlet((np.float32(alpha) / np.float32(k) * np.ones(k, np.float32)).astype(np.float32)) @ "probs"
+        return o_datapoints(probs, clusters) @ "datapoints"
+    args = (Const(k), Const(n), alpha)
+    f32 = lambda v: np.float32(v.item() if hasattr(v, "item") else v)
+    tr, otr = generate_data.simulate(G.key(seed), args), o_data.simulate(O.key(seed), ())
+    for adr in (("clusters", "mean"), "probs", ("datapoints", "idx"), ("datapoints", "obs")):
+        assert np.array_equal(tr.get_choices()[adr].cpu().numpy(), np.asarray(otr.get_choices()[adr])), adr
+    assert f32(tr.get_score()) == f32(otr.get_score())
+    pts = np.linspace(10.0, 90.0, n).astype(np.float32)
+    uniform = (np.ones(k, np.float32) / np.float32(k)).astype(np.float32)
+    constraints = C["datapoints", "obs"].set(jnp.array(pts)) | C["probs"].set(jnp.ones(k) / k)
+    tr2, w = generate_data.importance(G.key(seed + 1), constraints, args)
+    otr2, ow = o_data.importance(O.key(seed + 1), O.C.d({("datapoints", "obs"): pts, "probs": uniform}), ())
+    assert np.array_equal(tr2.get_choices()["datapoints", "idx"].cpu().numpy(), otr2.get_choices()["datapoints", "idx"])
+    assert f32(w) == f32(ow) and f32(tr2.get_score()) == f32(otr2.get_score()), (f32(w), f32(ow))

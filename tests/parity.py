@@ -2842,12 +2842,13 @@ def check_one_trace_with_large_vector_sites(n=5000, K=8, seed=31):
     assert np.array_equal(disc["obs"].cpu().numpy(), ys)
 
 
-def check_mixture_notebook_model(n=5000, k=16, seed=0):
+def check_mixture_notebook_model(n=5000, k=12, seed=0):
     """`generate_data` of 7_application_dirichlet_mixture_model.ipynb (c6), written as the notebook writes it — a `repeat` of
     cluster means, an INLINED Dirichlet for the weights, a nested `@gen` call whose `categorical(log probs,
     sample_shape=n)` and `normal(clusters[idx], sigma)` sites hold all n datapoints — for ONE trace: simulate, and the
-    notebook's `importance` under `C["datapoints", "obs"]` | `C["probs"]` (c10), bit-exact against the oracle.  (k <= 20:
-    a Dirichlet site is one program and keeps 2 k values live.)"""
+    notebook's `importance` under `C["datapoints", "obs"]` | `C["probs"]` (c10) and the `trace.update` calls its Gibbs moves
+    end with, bit-exact against the oracle.  (k <= 20: a Dirichlet site is one program and keeps 2 k values live; k = 13 .. 16
+    makes the Update of the un-batched, UNROLLED `clusters` plate exceed 64 input slots — 12 and 20 are what the tests run.)"""
     import genjax_amd as G
     from genjax_amd import ChoiceMapBuilder as C, numpy as jnp
     from genjax_amd.core.pytree import Const
@@ -2900,3 +2901,16 @@ def check_mixture_notebook_model(n=5000, k=16, seed=0):
     otr2, ow = o_data.importance(O.key(seed + 1), O.C.d({("datapoints", "obs"): pts, "probs": uniform}), ())
     assert np.array_equal(tr2.get_choices()["datapoints", "idx"].cpu().numpy(), otr2.get_choices()["datapoints", "idx"])
     assert f32(w) == f32(ow) and f32(tr2.get_score()) == f32(otr2.get_score()), (f32(w), f32(ow))
+    # the notebook's Gibbs moves write their draws back with `trace.update` (c10: update_cluster_means /
+    # update_cluster_weights): new cluster means re-score the n observations, new weights the n assignments
+    from genjax_amd import Diff
+    new_means = np.linspace(20.0, 80.0, k).astype(np.float32)
+    tr3, w3, _, _ = tr2.update(G.key(seed + 2), C["clusters", "mean"].set(jnp.array(new_means)), Diff.no_change(args))
+    otr3, ow3, _ = o_data.update(O.key(seed + 2), otr2, O.C.d({("clusters", "mean"): new_means}), ())
+    assert f32(w3) == f32(ow3) and f32(tr3.get_score()) == f32(otr3.get_score()), (f32(w3), f32(ow3))
+    assert tr3.subtraces["datapoints"].subtraces["idx"] is tr2.subtraces["datapoints"].subtraces["idx"]
+    new_probs = np.linspace(1.0, 2.0, k).astype(np.float32)
+    new_probs = (new_probs / new_probs.sum(dtype=np.float32)).astype(np.float32)
+    tr4, w4, _, _ = tr3.update(G.key(seed + 3), C["probs"].set(jnp.array(new_probs)), Diff.no_change(args))
+    otr4, ow4, _ = o_data.update(O.key(seed + 3), otr3, O.C.d({"probs": new_probs}), ())
+    assert f32(w4) == f32(ow4) and f32(tr4.get_score()) == f32(otr4.get_score()), (f32(w4), f32(ow4))

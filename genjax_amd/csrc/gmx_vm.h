@@ -232,7 +232,7 @@ GMX_HD void gmx_vm_step(Regs& R, const W w, int64_t i, bool active, const gmx_ru
             case OP_SOFTPLUS: r0 = gmx_asu(gmx_softplusf(FSRC(a))); break;
             case OP_LGAMMA: r0 = gmx_asu(gmx_lgammaf(FSRC(a))); break;
             case OP_S_BETA: { KEY(c); r0 = gmx_asu(gmx_beta_sample(k, ELEM(), FSRC(a), FSRC(b))); } break;
-            case OP_S_LOGGAMMA: { KEY(c); r0 = gmx_asu(gmx_log_gamma_sample(gmx_split_child(k, e), FSRC(a))); } break;
+            case OP_S_LOGGAMMA: { KEY(c); r0 = gmx_asu(gmx_log_gamma_sample(gmx_split_child(k, ELEM()), FSRC(a))); } break;
             case OP_S_CATSTEP: {
               KEY(c);
               gmx_cat_state s; s.best = gmx_asf(R.get(dst)); s.idx = (int)R.get(dst + 1u);

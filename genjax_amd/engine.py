@@ -1214,8 +1214,9 @@ def gather_leaves(leaves: list, ancestors: torch.Tensor) -> list:
 _EW_CACHE = new_cache()
 
 
-def elementwise(fn, *xs):
-    """`fn(*xs)` evaluated per particle in ONE launch of a traced program: the float algebra the
+def elementwise(fn, *xs, key=None):
+    """`fn(*xs)` evaluated per particle in ONE launch of a traced program (with `key`: `fn(key, *xs)`, the launch's
+    key as its first argument — ONE key for every element, e.g. a sampler whose element counter is the index): the float algebra the
     combinators do between GFI launches (`new_w - score + w`, `lw + w`, a trace's score = sum of its
     site scores, `logits - lse`) runs in the same kernels as everything else, not in torch ops.
     xs: tensors sharing a leading batch shape (the longest one's), 0-d tensors, Python numbers."""
@@ -1239,14 +1240,14 @@ def elementwise(fn, *xs):
     tree = flat.add(tuple(vals))
     specs = tuple(leaf_spec(v, batch) for v in flat.leaves)
     code = getattr(fn, "__code__", None)
-    ck = (code, tree, specs)
+    ck = (code, tree, specs, key is not None)
     ent = _EW_CACHE.get(ck) if code is not None else None
     if ent is None:
         tr = Tracing(len(batch))
         with T.tracing(tr.graph):
             syms = [tr.sym_leaf(sp, j) for j, sp in enumerate(specs)]
             ins = unflatten(tree, lambda j: syms[j].value)
-            out = fn(*ins)
+            out = fn(*ins) if key is None else fn(T.Expr(tr.graph.add("LDKEY", dtype="key")), *ins)
             if isinstance(out, T.Expr) and tr.node_origin.get(id(out.node)) is not None:
                 out = out + 0.0           # a pure pass-through still gets its own buffer
             oo = tr.emit_output(out)
@@ -1254,7 +1255,7 @@ def elementwise(fn, *xs):
         if code is not None and not fn.__closure__:
             _EW_CACHE[ck] = ent
     comp, oo = ent
-    outs = comp.run(flat.leaves, batch, None)
+    outs = comp.run(flat.leaves, batch, key)
     return resolve(oo, outs, flat.leaves)
 
 

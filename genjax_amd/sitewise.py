@@ -79,7 +79,16 @@ class _Handler:
         sub = self.constraint.get_submap(addr)
         big = vector_site_size(gen_fn, args)
         try:
-            if big is not None and self.mode in ("simulate", "generate", "assess"):
+            if wide_dirichlet(gen_fn, args) and self.mode in ("simulate", "generate", "assess"):
+                out = dirichlet_site(gen_fn, self.mode, k, args, sub)
+                if self.mode == "assess":
+                    self.score = _add(self.score, out[0])
+                    self.subtraces[addr] = None
+                    return out[1]
+                tr = out[0]
+                if self.mode == "generate":
+                    self.weight = _add(self.weight, out[1])
+            elif big is not None and self.mode in ("simulate", "generate", "assess"):
                 out = vector_site(gen_fn, self.mode, k, args, sub, big)
                 if self.mode == "assess":
                     self.score = _add(self.score, out[0])
@@ -139,7 +148,9 @@ class _Handler:
             req = Update(ChoiceMap.empty())    # re-scored against its new arguments
         ad = Diff.unknown_change(args) if changed else Diff.no_change(args)
         big = vector_site_size(gen_fn, args)
-        if big is not None and getattr(prev, "_elem_scores", None) is not None:
+        if wide_dirichlet(gen_fn, args):
+            new, w, bwd = dirichlet_site_update(gen_fn, prev, req, args)
+        elif big is not None and getattr(prev, "_elem_scores", None) is not None:
             new, w, bwd = vector_site_update(gen_fn, k, prev, req, args, changed, big)
         else:
             new, w, _retdiff, bwd = req.edit(k, prev, ad)
@@ -280,6 +291,100 @@ def vector_site_update(dist, key, prev, req, args, changed, n):
     # sum of the elements' differences
     from .engine import elementwise, materialize
     return out, elementwise(lambda a_, b_: a_ - b_, total, materialize(prev.get_score())), bwd
+
+
+DIRICHLET_PROGRAM_MAX = 20        # components a Dirichlet site holds as ONE program (2 K live values of 64 registers)
+
+
+def _concentration(dist, args):
+    a = dist.canon(tuple(args))[0]
+    if isinstance(a, torch.Tensor):
+        return a
+    a = np.asarray(a)
+    return a if a.dtype != object else None
+
+
+def wide_dirichlet(gen_fn, args) -> bool:
+    from .distributions import _Dirichlet
+    if not isinstance(gen_fn, _Dirichlet):
+        return False
+    a = _concentration(gen_fn, args)
+    return a is not None and a.ndim == 1 and a.shape[0] > DIRICHLET_PROGRAM_MAX
+
+
+def symbolic_wide_dirichlet(dist, args) -> bool:
+    """the same question asked while TRACING (the concentration is an object array or a table)"""
+    from .distributions import _Dirichlet
+    if not isinstance(dist, _Dirichlet):
+        return False
+    pos, kw = (args[0], args[1]) if len(args) == 2 and isinstance(args[1], dict) and isinstance(args[0], tuple) else (args, {})
+    a = kw.get("concentration", pos[0] if pos else None)
+    shp = tuple(getattr(a, "shape", ()))
+    return len(shp) == 1 and int(shp[0]) > DIRICHLET_PROGRAM_MAX
+
+
+def _dirichlet_logpdf(x, a):
+    """log Dirichlet(x; a) in the site program's operation order (distributions._Dirichlet.sym_logpdf): sum of xlogy(a - 1,
+    x) in element order, minus (sum lgamma(a) in element order - lgamma(sum a in element order))"""
+    from . import numpy as jnp, tracer as T
+    from .engine import elementwise, sum_rows_inorder
+    row = lambda v: sum_rows_inorder(v.reshape(1, -1)).reshape(())
+    terms = elementwise(lambda a_, x_: T.where((a_ - 1.0) == 0.0, 0.0, (a_ - 1.0) * jnp.log(x_)), a, x)
+    lbeta = elementwise(lambda lg_, sa_: lg_ - jnp.lgamma(sa_), row(elementwise(lambda a_: jnp.lgamma(a_), a)), row(a))
+    return elementwise(lambda t_, lb_: t_ - lb_, row(terms), lbeta)
+
+
+def dirichlet_site(dist, mode, key, args, constraint):
+    """A Dirichlet site of more than DIRICHLET_PROGRAM_MAX components, for ONE trace: the operations of the site's
+    program (tfp/__init__.py:125: log-space Gammas from the keys split(site key)[k], x = exp(lg - logsumexp(lg)), the
+    density) as a handful of launches over the K components instead of one program that would need 2 K registers —
+    the same device functions in the same order, so the same bits."""
+    from . import _lib, numpy as jnp
+    from .combinators import torch_from_host
+    from .engine import elementwise, sum_rows_inorder
+    from .program import ELEM_INDEX
+    from .static import DistributionTrace, MissingAddress
+    from .tracer import Expr, current_graph
+    dev = _lib.get().device
+    a = _concentration(dist, args)
+    a = (a if isinstance(a, torch.Tensor) else torch_from_host(a, dev)).float()
+    value = constraint.get_value() if constraint is not None and not constraint.static_is_empty() else None
+    if value is not None:
+        value = (value if isinstance(value, torch.Tensor) else torch_from_host(np.asarray(value), dev)).float()
+        if tuple(value.shape) != tuple(a.shape):
+            raise ValueError(f"dirichlet: a constraint of {tuple(value.shape)} for a concentration of {tuple(a.shape)}")
+    if mode == "assess":
+        if value is None:
+            raise MissingAddress(())
+        return _dirichlet_logpdf(value, a), value
+    if value is None:
+        def draw(k_, a_):            # element k: log Gamma(a_k) from the key split(site key)[k]
+            return Expr(current_graph().add("S_LOGGAMMA", (k_.node, a_.node), imm=ELEM_INDEX, dtype="f32"))
+        lg = elementwise(draw, a, key=key)
+        m = torch.max(lg)                                       # (a maximum does not depend on the order)
+        s = sum_rows_inorder(elementwise(lambda l_, m_: jnp.exp(l_ - m_), lg, m).reshape(1, -1)).reshape(())
+        lse = elementwise(lambda s_, m_: jnp.log(s_) + m_, s, m)
+        x = elementwise(lambda l_, z_: jnp.exp(l_ - z_), lg, lse)
+    else:
+        x = value
+    score = _dirichlet_logpdf(x, a)
+    tr = DistributionTrace(dist, tuple(args), x, score)
+    if mode == "generate":
+        return tr, (score if value is not None else _as_score(0.0))
+    return (tr,)
+
+
+def dirichlet_site_update(dist, prev, req, args):
+    """`Update` of such a site (a new value and / or a new concentration): the density again; weight = new - old score"""
+    from .engine import elementwise, materialize
+    from .static import DistributionTrace
+    if not isinstance(req, Update):
+        raise NotImplementedError(f"{type(req).__name__} on a Dirichlet site of more than {DIRICHLET_PROGRAM_MAX} components")
+    value = req.constraint.get_value() if not req.constraint.static_is_empty() else None
+    tr, = dirichlet_site(dist, "simulate", None, args, ChoiceMap.choice(value if value is not None else prev.value))
+    w = elementwise(lambda a_, b_: a_ - b_, tr.get_score(), materialize(prev.get_score()))
+    discard = ChoiceMap.choice(prev.value) if value is not None else ChoiceMap.empty()
+    return tr, w, Update(discard)
 
 
 def same_args(a, b) -> bool:

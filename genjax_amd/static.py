@@ -705,7 +705,8 @@ class Handler:
 def _leaf_call(ctx: _Ctx, mode, dist, key, args, constraint: ChoiceMap, prev, req, req_leaves):
     """Leaf (Distribution) semantics; returns (_SiteRec, retval, weight, score)."""
     g = ctx.tr.graph
-    if getattr(ctx, "sitewise", False) and sitewise.symbolic_vector_site_size(args) is not None \
+    if getattr(ctx, "sitewise", False) and (sitewise.symbolic_vector_site_size(args) is not None
+                                            or sitewise.symbolic_wide_dirichlet(dist, args)) \
             and not getattr(g, "_in_loop", False) and not g.loop_counts:
         raise sitewise.NeedsSiteBySite()      # ONE trace and a site of thousands of elements: not unrolled (sitewise.vector_site)
     args = dist.canon(args)

@@ -2847,8 +2847,9 @@ def check_mixture_notebook_model(n=5000, k=12, seed=0):
     cluster means, an INLINED Dirichlet for the weights, a nested `@gen` call whose `categorical(log probs,
     sample_shape=n)` and `normal(clusters[idx], sigma)` sites hold all n datapoints — for ONE trace: simulate, and the
     notebook's `importance` under `C["datapoints", "obs"]` | `C["probs"]` (c10) and the `trace.update` calls its Gibbs moves
-    end with, bit-exact against the oracle.  (k <= 20: a Dirichlet site is one program and keeps 2 k values live; k = 13 .. 16
-    makes the Update of the un-batched, UNROLLED `clusters` plate exceed 64 input slots — 12 and 20 are what the tests run.)"""
+    end with, bit-exact against the oracle.  A Dirichlet of more than 20 components is not one program either (2 k live
+    values): sitewise.dirichlet_site runs its operations as a handful of launches over the components.  (k = 13 .. 16 makes
+    the Update of the un-batched, UNROLLED `clusters` plate exceed 64 input slots — the tests run 12, 40 and 64.)"""
     import genjax_amd as G
     from genjax_amd import ChoiceMapBuilder as C, numpy as jnp
     from genjax_amd.core.pytree import Const

@@ -1023,8 +1023,8 @@ def test_one_trace_of_a_model_with_large_plates_runs_site_by_site(gpu):
     assert t_index < t_update, (t_index, t_update)
     parity.check_one_trace_with_large_vector_sites(n=5000)
     parity.check_one_trace_with_large_vector_sites(n=300_000, K=64, seed=2)      # the mixture model's data site
-    parity.check_mixture_notebook_model(n=5000, k=12)
-    parity.check_mixture_notebook_model(n=1_000_000, k=20, seed=3)          # the notebook's generate_data at config 5's N
+    parity.check_mixture_notebook_model(n=5000, k=40)                        # the notebook's own sizes
+    parity.check_mixture_notebook_model(n=1_000_000, k=64, seed=3)          # ... and BASELINE config 5's
 
 
 def test_scan_carries_that_forward_each_other(gpu):

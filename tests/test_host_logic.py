@@ -663,6 +663,7 @@ def test_one_trace_of_a_model_with_large_plates_runs_site_by_site():
     parity.check_one_trace_with_large_vector_sites(n=5000)
     parity.check_one_trace_with_large_vector_sites(n=4096 + 7, K=5, seed=8)
     parity.check_mixture_notebook_model(n=5000, k=12)
+    parity.check_mixture_notebook_model(n=5000, k=40, seed=2)          # the notebook's own sizes
 
 
 def test_indexed_and_masked_constraints_match_oracle():

@@ -293,6 +293,23 @@ class _Categorical(Distribution):
                           DeprecationWarning, stacklevel=3)
         return self._shaped(tuple(args), shape)
 
+    def simulate(self, key, args):
+        """`categorical.simulate(key, (logits[n, K],))` under ONE key (7_application_dirichlet_mixture_model.ipynb c10,
+        update_datapoint_assignment): n draws, row i / category k on gumbel counter i * K + k — what
+        `jax.random.categorical(key, logits)` of that shape does.  From VMAP_LAUNCH_MIN rows on, one GPU thread per row."""
+        import torch
+        from .combinators import VMAP_LAUNCH_MIN
+        l = args[0] if len(args) == 1 else None
+        if key is not None and tuple(key.shape) == () and isinstance(l, torch.Tensor) and l.ndim == 2 \
+                and l.shape[0] >= VMAP_LAUNCH_MIN:
+            from .engine import sum_rows
+            from .static import DistributionTrace, run_gfi
+            tr = run_gfi(self, "simulate", key, (l,), batch_shape=(int(l.shape[0]),), elem_index=True)
+            out = DistributionTrace(self, tuple(args), tr.value, sum_rows(tr.score))
+            out._elem_scores = tr.score
+            return out
+        return super().simulate(key, args)
+
     @staticmethod
     def _shaped(args, shape):
         """`sample_shape=n` (tfp sample_n): n draws from the same logits at ONE site; draw j, category k

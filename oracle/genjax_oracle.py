@@ -647,6 +647,13 @@ class _Categorical(Distribution):
             lib().orc_categorical_sample(I64(n), I64(K), _p(np.ascontiguousarray(keys.reshape(2))), I64(0),
                                          _p(np.ascontiguousarray(logits)), I64(0), _p(ctr), I64(1), _p(out))
             return out
+        if batch == () and logits.ndim == 2:       # n rows of logits under ONE key: row i / category k on counter i * K + k
+            n = logits.shape[0]
+            out = np.empty(n, dtype=np.int32)
+            ctr = np.ascontiguousarray(np.arange(n, dtype=np.uint64) * np.uint64(K))
+            lib().orc_categorical_sample(I64(n), I64(K), _p(np.ascontiguousarray(keys.reshape(2))), I64(0),
+                                         _p(np.ascontiguousarray(logits)), I64(K), _p(ctr), I64(1), _p(out))
+            return out
         full = np.broadcast_shapes(batch + (K,), logits.shape)
         if len(full) != len(batch) + 1:
             raise NotImplementedError("oracle categorical: batched logits beyond the particle axis")

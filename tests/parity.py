@@ -2915,3 +2915,12 @@ def check_mixture_notebook_model(n=5000, k=12, seed=0):
     tr4, w4, _, _ = tr3.update(G.key(seed + 3), C["probs"].set(jnp.array(new_probs)), Diff.no_change(args))
     otr4, ow4, _ = o_data.update(O.key(seed + 3), otr3, O.C.d({"probs": new_probs}), ())
     assert f32(w4) == f32(ow4) and f32(tr4.get_score()) == f32(otr4.get_score()), (f32(w4), f32(ow4))
+    # update_datapoint_assignment (c10): n draws from `categorical.simulate(key, (local_densities [n, k],))` under ONE key,
+    # written back with `trace.update(C["datapoints", "idx"].set(...))` — the n observations are re-scored
+    dens = np.random.default_rng(seed).normal(size=(n, k)).astype(np.float32)
+    new_idx = G.categorical.simulate(G.key(seed + 4), (torch.from_numpy(dens).to(G._lib.get().device),)).get_choices().get_value()
+    o_idx = O.categorical._sample(O.key(seed + 4), (dens,))
+    assert np.array_equal(new_idx.cpu().numpy(), o_idx)
+    tr5, w5, _, _ = tr4.update(G.key(seed + 5), C["datapoints", "idx"].set(new_idx), Diff.no_change(args))
+    otr5, ow5, _ = o_data.update(O.key(seed + 5), otr4, O.C.d({("datapoints", "idx"): o_idx}), ())
+    assert f32(w5) == f32(ow5) and f32(tr5.get_score()) == f32(otr5.get_score()), (f32(w5), f32(ow5))

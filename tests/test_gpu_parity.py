@@ -615,6 +615,14 @@ def test_nonlinear_ssm_mh_sweep_matches_oracle(gpu, n, capture, specialize):
     parity.check_nlssm_mh_sweep(n=n, T=13 if n <= 100_000 else 5, capture=capture, specialize=specialize, noise_ahead=True)
 
 
+def test_config3_full_size_sweep_bit_exact(gpu):
+    """BASELINE config 3 AT ITS FULL SIZE — 1e6 particles x 100 steps, one MH move per step — as `bench.py` runs it (one
+    hipGraph, noise ahead, the move chained into the extension, one launch per step): final particles, log-weights, the
+    last move's accept flags and the evidence against the oracle run step by step (about two minutes of numpy)."""
+    res = parity.check_nlssm_mh_sweep(n=1_000_000, T=100, capture=True, specialize=True, noise_ahead=True)
+    assert 0.5 < res["accept_rate"] <= 1.0
+
+
 def test_dirichlet_matches_oracle_and_scipy(gpu):
     parity.check_dirichlet(n=50_000)
 

@@ -2840,6 +2840,32 @@ def check_one_trace_with_large_vector_sites(n=5000, K=8, seed=31):
     onew2, ow4, _ = omodel.update(O.key(seed + 3), onew, O.C.d({"obs": ys2}), ())
     assert f32(w4) == f32(ow4) and f32(new2.get_score()) == f32(onew2.get_score())
     assert np.array_equal(disc["obs"].cpu().numpy(), ys)
+    # Regenerate of a scalar site, a changed ARGUMENT of the model, project — around a 5000-element site that stays untouched
+    from genjax_amd import Regenerate, SelectionBuilder as S
+    mu_h = np.linspace(-1.0, 1.0, n).astype(np.float32)
+
+    @G.gen
+    def m2(scale):
+        x = G.normal(0.0, scale) @ "x"
+        a = G.normal(jnp.array(mu_h), 1.0) @ "a"
+        return G.normal(jnp.sum(a) + x, 5.0) @ "obs"
+
+    @O.gen
+    def om2(scale):
+        x = O.normal(0.0, scale) @ "x"
+        a = O.normal(mu_h, np.float32(1.0)) @ "a"
+        return O.normal((O.sum_vector(a) + x).astype(np.float32), 5.0) @ "obs"
+    t, ot = m2.simulate(G.key(seed + 4), (1.0,)), om2.simulate(O.key(seed + 4), (np.float32(1.0),))
+    assert np.array_equal(t.get_choices()["a"].cpu().numpy(), ot.get_choices()["a"])
+    r, wr, _, bwd = Regenerate(S["x"]).edit(G.key(seed + 5), t, Diff.no_change((1.0,)))
+    orr, owr, _ = om2.regenerate(O.key(seed + 5), ot, O.selection("x"), (np.float32(1.0),))
+    assert f32(wr) == f32(owr) and f32(r.get_score()) == f32(orr.get_score()) and r.subtraces["a"] is t.subtraces["a"]
+    back, wb, _, _ = bwd.edit(G.key(seed + 6), r, Diff.no_change((1.0,)))
+    assert f32(back.get_choices()["x"]) == f32(t.get_choices()["x"]) and float(wr + wb) == 0.0
+    u, wu, _, _ = t.update(G.key(seed + 7), C.n(), Diff.unknown_change((2.0,)))
+    ou, owu, _ = om2.update(O.key(seed + 7), ot, O.C.d({}), (np.float32(2.0),))
+    assert f32(wu) == f32(owu) and f32(u.get_score()) == f32(ou.get_score()) and u.subtraces["a"] is t.subtraces["a"]
+    assert f32(t.project(G.key(seed + 8), S["a"])) == f32(t.subtraces["a"].get_score())
 
 
 def check_mixture_notebook_model(n=5000, k=12, seed=0):

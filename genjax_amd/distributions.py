@@ -296,16 +296,15 @@ class _Categorical(Distribution):
     def simulate(self, key, args):
         """`categorical.simulate(key, (logits[n, K],))` under ONE key (7_application_dirichlet_mixture_model.ipynb c10,
         update_datapoint_assignment): n draws, row i / category k on gumbel counter i * K + k — what
-        `jax.random.categorical(key, logits)` of that shape does.  From VMAP_LAUNCH_MIN rows on, one GPU thread per row."""
+        `jax.random.categorical(key, logits)` of that shape does.  From 65 rows on, one GPU thread per row."""
         import torch
-        from .combinators import VMAP_LAUNCH_MIN
+        from .sitewise import VECTOR_SITE_MIN, sum_defined
         l = args[0] if len(args) == 1 else None
         if key is not None and tuple(key.shape) == () and isinstance(l, torch.Tensor) and l.ndim == 2 \
-                and l.shape[0] >= VMAP_LAUNCH_MIN:
-            from .engine import sum_rows
+                and l.shape[0] >= VECTOR_SITE_MIN:
             from .static import DistributionTrace, run_gfi
             tr = run_gfi(self, "simulate", key, (l,), batch_shape=(int(l.shape[0]),), elem_index=True)
-            out = DistributionTrace(self, tuple(args), tr.value, sum_rows(tr.score))
+            out = DistributionTrace(self, tuple(args), tr.value, sum_defined(tr.score))
             out._elem_scores = tr.score
             return out
         return super().simulate(key, args)
@@ -315,11 +314,13 @@ class _Categorical(Distribution):
         """`sample_shape=n` (tfp sample_n): n draws from the same logits at ONE site; draw j, category k
         takes gumbel counter j*K + k.  Unrolled, so only for small n (plates of data belong in
         inference.gibbs / the particle axis)."""
+        shape = shape.unwrap() if hasattr(shape, "unwrap") else shape          # a Const[int] (the reference passes one)
         if shape is None or shape == ():
             return args
         n = int(shape[0] if isinstance(shape, (tuple, list)) else shape)
         if n > 64:
-            raise NotImplementedError(f"categorical(sample_shape={n}): draws at one site are unrolled (<= 64)")
+            raise NotImplementedError(f"categorical(sample_shape={n}): under a batch of keys the draws of one site are "
+                                      "unrolled (<= 64); ONE trace runs them on the launch axis (sitewise.py)")
         return args + (("sample_shape", n),)
 
     def _logits(self, args):

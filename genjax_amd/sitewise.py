@@ -159,10 +159,24 @@ class _Handler:
         return new
 
 
-def vector_site_size(gen_fn, args):
-    """n when `gen_fn(*args)` is a DISTRIBUTION site whose value is a vector of n >= VMAP_LAUNCH_MIN elements — a vector
-    parameter (`normal(clusters[idx], 1.0)` with idx of n elements) or `sample_shape=n` — else None"""
+VECTOR_SITE_MIN = 65          # elements from which a vector-valued site of ONE trace runs on the launch axis (an unrolled
+                              # site stores one output slot per element: 64 of them)
+
+
+def sum_defined(x):
+    """the sum of a site's per-element scores / weights in the build's defined order: element order below VMAP_LAUNCH_MIN
+    elements, the plate score's fixed tree from there on (oracle: sum_vector)"""
     from .combinators import VMAP_LAUNCH_MIN
+    from .engine import sum_rows, sum_rows_inorder
+    if x.shape[-1] >= VMAP_LAUNCH_MIN:
+        return sum_rows(x)
+    return sum_rows_inorder(x.reshape(1, -1)).reshape(())
+
+
+def vector_site_size(gen_fn, args):
+    """n when `gen_fn(*args)` is a DISTRIBUTION site whose value is a vector of n >= VECTOR_SITE_MIN elements — a vector
+    parameter (`normal(clusters[idx], 1.0)` with idx of n elements) or `sample_shape=n` — else None"""
+    VMAP_LAUNCH_MIN = VECTOR_SITE_MIN
     from .distributions import Distribution, _Categorical
     if not isinstance(gen_fn, Distribution) or gen_fn.sample_op is None and not isinstance(gen_fn, _Categorical):
         return None
@@ -185,7 +199,7 @@ def vector_site_size(gen_fn, args):
 
 def symbolic_vector_site_size(args):
     """the same question asked while TRACING (arguments are symbolic: vectors are object arrays or tables)"""
-    from .combinators import VMAP_LAUNCH_MIN
+    VMAP_LAUNCH_MIN = VECTOR_SITE_MIN
     pos, kw = (args[0], args[1]) if len(args) == 2 and isinstance(args[1], dict) and isinstance(args[0], tuple) else (args, {})
     ss = kw.get("sample_shape")
     if ss is not None:
@@ -198,13 +212,13 @@ def symbolic_vector_site_size(args):
 
 
 def vector_site(dist, mode, key, args, constraint, n):
-    """A distribution site whose value has n >= VMAP_LAUNCH_MIN elements, for ONE trace: the scalar distribution over a
+    """A distribution site whose value has n >= VECTOR_SITE_MIN elements, for ONE trace: the scalar distribution over a
     launch of n elements — element i draws with counter i from the ONE site key (what `tfd.X(...).sample(seed=key)` of
     that shape does; unrolled vector-valued sites give element i the immediate i) — and the site's
-    score is the fixed tree over the elements' log-densities (engine.sum_rows; oracle: sum_vector)."""
+    score is the defined sum of the elements' log-densities (sum_defined; oracle: sum_vector)."""
     from . import _lib
     from .combinators import torch_from_host
-    from .engine import Broadcast, sum_rows
+    from .engine import Broadcast
     from .static import DistributionTrace, run_gfi
     dev = _lib.get().device
     pos, kw = (args[0], dict(args[1])) if len(args) == 2 and isinstance(args[1], dict) and isinstance(args[0], tuple) else (args, {})
@@ -233,14 +247,14 @@ def vector_site(dist, mode, key, args, constraint, n):
             from .static import MissingAddress
             raise MissingAddress(())
         s, v = run_gfi(dist, "assess", None, eargs, constraint=con, batch_shape=(n,))
-        return sum_rows(s), v
+        return sum_defined(s), v
     if mode == "generate" and value is not None:
         tr, w = run_gfi(dist, "generate", key, eargs, constraint=con, batch_shape=(n,), elem_index=True)
-        out = DistributionTrace(dist, tuple(args), tr.value, sum_rows(tr.score))
+        out = DistributionTrace(dist, tuple(args), tr.value, sum_defined(tr.score))
         out._elem_scores = tr.score
-        return out, sum_rows(w)
+        return out, sum_defined(w)
     tr = run_gfi(dist, "simulate", key, eargs, batch_shape=(n,), elem_index=True)
-    out = DistributionTrace(dist, tuple(args), tr.value, sum_rows(tr.score))
+    out = DistributionTrace(dist, tuple(args), tr.value, sum_defined(tr.score))
     out._elem_scores = tr.score
     if mode == "generate":
         return out, _as_score(0.0)
@@ -253,7 +267,7 @@ def vector_site_update(dist, key, prev, req, args, changed, n):
     summed in the fixed tree"""
     from . import _lib
     from .combinators import torch_from_host
-    from .engine import Broadcast, sum_rows
+    from .engine import Broadcast
     from .static import DistributionTrace, run_edit
     if not isinstance(req, Update):
         raise NotImplementedError(f"{type(req).__name__} on a {n}-element site of one trace (Update only; write the "
@@ -284,7 +298,7 @@ def vector_site_update(dist, key, prev, req, args, changed, n):
     elem_tr = DistributionTrace(dist, eargs, prev.value, prev._elem_scores)
     ad = Diff.unknown_change(eargs) if changed else Diff.no_change(eargs)
     new_e, _w, _rd, bwd = run_edit(dist, key, elem_tr, Update(con), ad)
-    total = sum_rows(new_e.score)
+    total = sum_defined(new_e.score)
     out = DistributionTrace(dist, tuple(args), new_e.value, total)
     out._elem_scores = new_e.score
     # the site's weight is the difference of its SUMMED scores (distribution.py:205-224: new score - old score), not the

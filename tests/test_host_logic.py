@@ -664,6 +664,38 @@ def test_one_trace_of_a_model_with_large_plates_runs_site_by_site():
     parity.check_one_trace_with_large_vector_sites(n=4096 + 7, K=5, seed=8)
     parity.check_mixture_notebook_model(n=5000, k=12)
     parity.check_mixture_notebook_model(n=5000, k=40, seed=2)          # the notebook's own sizes
+    parity.check_mixture_notebook_model(n=700, k=12, seed=5)           # 65 .. 4095 elements: launch axis, element-order sums
+    parity.check_one_trace_with_large_vector_sites(n=300, K=5, seed=3)
+
+
+def test_mixture_notebook_gibbs_inference_as_written():
+    """7_application_dirichlet_mixture_model.ipynb c6-c12 with this package where the notebook has genjax: ONE trace of
+    `generate_data`, importance under the data, Gibbs sweeps whose moves draw with the library (`generate_cluster.vmap()
+    .simulate`, `categorical.simulate(key, (local_densities,))`, `generate_cluster_weight.simulate`) and write back with
+    `trace.update` — the populated clusters end up on the data (tools/experiments/notebook7_gibbs.py)."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("nb7", os.path.join(root, "tools", "experiments", "notebook7_gibbs.py"))
+    nb7 = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(nb7)
+    import tests.hostsim as hs
+    hs.install()
+    try:
+        import genjax_amd as G
+        n, k = 1600, 8
+        tr, true_means, _, score0 = nb7.infer(n, k, 25, G._lib.get().device)
+        ch = tr.get_choices()
+        means = ch["clusters", "mean"].numpy()
+        counts = np.bincount(ch["datapoints", "idx"].numpy(), minlength=k)
+        big = means[counts > n // (4 * k)]
+        # a Gibbs sampler may leave two neighbouring blocks of data in one cluster: every populated cluster sits ON the data
+        # (within half the block spacing of a true mean), most of them on one block, and the joint density went up a lot
+        assert len(big) >= k // 2 and all(np.min(np.abs(true_means - m)) < 5.5 for m in big), (np.sort(big), true_means)
+        assert sum(np.min(np.abs(true_means - m)) < 1.0 for m in big) >= len(big) // 2
+        assert float(tr.get_score()) > score0 + 1000.0, (float(tr.get_score()), score0)
+    finally:
+        hs.uninstall()
 
 
 def test_indexed_and_masked_constraints_match_oracle():

@@ -58,6 +58,23 @@ class TableArray(np.ndarray):
             return r.item()
         return r
 
+    # arithmetic with a DEVICE tensor (a model running site by site mixes host tables with device values: `jnp.array(mu) + x`
+    # where x came from a site): the table moves to the tensor's device, f32 / i32 as a launch would read it
+    def _with_tensor(self, other, op, swap=False):
+        t = torch.from_numpy(np.ascontiguousarray(np.asarray(self).astype(np.float32 if self.dtype.kind == "f" else
+                                                                            (np.int32 if self.dtype.kind in "iu" else self.dtype))))
+        t = t.to(other.device)
+        return op(other, t) if swap else op(t, other)
+
+    def __add__(self, o): return self._with_tensor(o, lambda a, b: a + b) if isinstance(o, torch.Tensor) else np.ndarray.__add__(self, o)
+    def __radd__(self, o): return self._with_tensor(o, lambda a, b: a + b, True) if isinstance(o, torch.Tensor) else np.ndarray.__radd__(self, o)
+    def __sub__(self, o): return self._with_tensor(o, lambda a, b: a - b) if isinstance(o, torch.Tensor) else np.ndarray.__sub__(self, o)
+    def __rsub__(self, o): return self._with_tensor(o, lambda a, b: a - b, True) if isinstance(o, torch.Tensor) else np.ndarray.__rsub__(self, o)
+    def __mul__(self, o): return self._with_tensor(o, lambda a, b: a * b) if isinstance(o, torch.Tensor) else np.ndarray.__mul__(self, o)
+    def __rmul__(self, o): return self._with_tensor(o, lambda a, b: a * b, True) if isinstance(o, torch.Tensor) else np.ndarray.__rmul__(self, o)
+    def __truediv__(self, o): return self._with_tensor(o, lambda a, b: a / b) if isinstance(o, torch.Tensor) else np.ndarray.__truediv__(self, o)
+    def __rtruediv__(self, o): return self._with_tensor(o, lambda a, b: a / b, True) if isinstance(o, torch.Tensor) else np.ndarray.__rtruediv__(self, o)
+
 
 class RuntimeTable(np.ndarray):
     """A launch-uniform device vector (an argument such as cluster means): an object array of

@@ -269,9 +269,18 @@ def vector_site_update(dist, key, prev, req, args, changed, n):
     from .combinators import torch_from_host
     from .engine import Broadcast
     from .static import DistributionTrace, run_edit
+    if isinstance(req, Regenerate):
+        # edit_regenerate (distribution.py:258-300): the selected site is drawn again (weight = new score - old score,
+        # backward = Update(old value)); an unselected one is re-scored against its arguments
+        from .engine import elementwise, materialize
+        if req.selection.check():
+            new, = vector_site(dist, "simulate", key, args, None, n)
+            w = elementwise(lambda a_, b_: a_ - b_, materialize(new.get_score()), materialize(prev.get_score()))
+            return new, w, Update(ChoiceMap.choice(prev.value))
+        req = Update(ChoiceMap.empty())
     if not isinstance(req, Update):
-        raise NotImplementedError(f"{type(req).__name__} on a {n}-element site of one trace (Update only; write the "
-                                  "plate with vmap for per-element requests)")
+        raise NotImplementedError(f"{type(req).__name__} on a {n}-element site of one trace (Update / Regenerate; write "
+                                  "the plate with vmap for per-element requests)")
     dev = _lib.get().device
     pos, kw = (args[0], dict(args[1])) if len(args) == 2 and isinstance(args[1], dict) and isinstance(args[0], tuple) else (args, {})
     kw.pop("sample_shape", None)

@@ -5,7 +5,7 @@ kind=$1; tag=$2
 mkdir -p $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 printf 'pmc: SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAVE_CYCLES\n' > /tmp/pmc_kind.txt
-RESAMPLE=$kind REPS=1 ROUNDS=1 T=10 rocprofv3 -i /tmp/pmc_kind.txt --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$tag -- python3 $R/tools/bench_ab.py GENMI_SLOT_UNIFORMS 1 > /dev/null 2> $R/gpurun_out/$tag.err
+RESAMPLE=$kind REPS=1 ROUNDS=1 T=10 rocprofv3 -i /tmp/pmc_kind.txt --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$tag -- python3 $R/tools/bench_ab.py noise_ahead True > /dev/null 2> $R/gpurun_out/$tag.err
 python3 - <<PY > $R/gpurun_out/$tag.txt
 import csv, glob, collections
 f = glob.glob("$R/gpurun_out/pmc_$tag/**/*counter_collection.csv", recursive=True)[0]

@@ -4,7 +4,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 kind=$1; tag=$2
 mkdir -p $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-RESAMPLE=$kind REPS=3 ROUNDS=1 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$tag -- python3 $R/tools/bench_ab.py GENMI_SLOT_UNIFORMS 1 > $R/gpurun_out/$tag.json 2> $R/gpurun_out/$tag.err
+RESAMPLE=$kind REPS=3 ROUNDS=1 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$tag -- python3 $R/tools/bench_ab.py noise_ahead True > $R/gpurun_out/$tag.json 2> $R/gpurun_out/$tag.err
 cat $R/gpurun_out/$tag.json
 python3 - <<PY
 import csv, glob

@@ -40,6 +40,22 @@ def torch_from_host(v, device):
                                                  (v.astype(np.int32) if v.dtype.kind in "iu" else v))).to(device)
 
 
+class _NoDefer(Exception):
+    pass
+
+
+DEFER_MIN_WORK = 1 << 18       # particles x elements from which a large plate of a small particle batch is deferred
+DEFER_MAX_BATCH = 4096         # ... and the largest such batch (more particles keep the GPU busy in the loop form)
+
+
+def _tree_map_plain(v, fn):
+    if isinstance(v, (tuple, list)):
+        return type(v)(_tree_map_plain(x, fn) for x in v)
+    if isinstance(v, dict):
+        return {k: _tree_map_plain(x, fn) for k, x in v.items()}
+    return fn(v)
+
+
 VMAP_LAUNCH_MIN = 4096      # a plate this large called directly under ONE key runs with its elements on the launch axis
 NEST_UNROLL_MAX = 4       # an unrolled plate whose ELEMENT runs a counted loop keeps at most this many copies of it
 
@@ -352,6 +368,9 @@ class Vmap(GenerativeFunction):
             return self._empty(mode)
         # a plate OF plates (`model.repeat(n=10).repeat(n=10)`): unrolling both would need one output slot per element
         # of the product; the outer one runs as a loop whose body is the (small, unrolled) inner plate
+        d = self._defer(ctx, mode, key, args, axes, constraint, n)
+        if d is not None:
+            return d, d.retval, None, None
         if getattr(ctx, "sitewise", False) and n >= VMAP_LAUNCH_MIN and not getattr(ctx.tr.graph, "_in_loop", False) \
                 and not ctx.tr.graph.loop_counts:
             # ONE trace of the caller and a large plate: in one thread this is n iterations on one lane — the caller
@@ -754,6 +773,122 @@ class Vmap(GenerativeFunction):
                         or tuple(getattr(v, "shape", ()))[:1] != (n,):
                     return None
         return n, tuple(inner)
+
+    # -- a large plate of a call over a SMALL batch of particles: lifted out of the program (static.run_gfi `defer`) ------
+    def _defer(self, ctx, mode, key, args, axes, constraint, n):
+        """The record of this plate as a DEFERRED site, or None.  With B particles and n elements a loop form keeps B
+        lanes busy for n iterations; when B is small and n large (ImportanceK with 50 particles over a model of 1e5
+        datapoints) the plate is better run AFTER the program, over B x n launch elements: the program computes the
+        plate's arguments per particle, the plate then runs the inner function with the keys split(site key_b, n)[j]
+        (exactly the loop form's) and its score / weight is the element-order sum per particle.  Only for a plate that
+        is a direct site of the top-level model and its LAST one (the weight / score sums keep the reference's order),
+        whose values the model returns but does not compute with."""
+        from . import static
+        from .engine import Expr, Sym
+        st = getattr(ctx, "defer", None)
+        if st is None or n < VMAP_LAUNCH_MIN or st["B"] * n < DEFER_MIN_WORK or st["plates"] \
+                or len(static._HANDLERS) != st["depth"] or getattr(ctx.tr.graph, "_in_loop", False) or ctx.tr.graph.loop_counts:
+            return None
+        path = []
+        if key is not None:                      # the site key as a chain of fold_ins from the particle's key
+            node = key.node
+            while node.op == "KDERIVE":
+                path.append(int(node.imm))
+                node = node.args[0]
+            if node.op != "LDKEY":
+                return None
+            path.reverse()
+        tr = ctx.tr
+
+        def origin(v):
+            if isinstance(v, Sym):
+                return v.origin if v.origin is not None else origin(v.value)
+            if isinstance(v, (tuple, list)):
+                return ("tuple", [origin(x) for x in v])
+            if isinstance(v, dict):
+                return ("dict", {k_: origin(x) for k_, x in v.items()})
+            if isinstance(v, np.ndarray) and v.dtype == object and v.size > 16:
+                raise _NoDefer()                 # a long vector COMPUTED per particle: one output slot per element
+            if isinstance(v, Expr) or (isinstance(v, np.ndarray) and v.dtype == object):
+                return tr.emit_output(v)
+            return ("const", v)                  # a host value: a Python number, a table
+        con = None
+        if constraint is not None and not constraint.static_is_empty():
+            # per-element constraints only (every leaf leads with the plate): integer sub-addresses and masks are the loop form's
+            from .core.mask import Mask
+            for adr in constraint.addresses():
+                v = constraint[adr] if adr else constraint.get_value()
+                inner_v = v.value if isinstance(v, Sym) else v
+                if isinstance(inner_v, Mask) or any(isinstance(c_, int) for c_ in (adr or ())) \
+                        or tuple(getattr(inner_v, "shape", ()))[:1] != (n,):
+                    return None
+            refs = []
+
+            def ref(v):
+                if isinstance(v, Sym) and v.origin is not None and v.origin[0] == "leaf":
+                    return ("leafref", v.origin[1])
+                refs.append(v)
+                return v
+            con = constraint.map_values(ref)
+            if refs:
+                return None                      # a computed / masked constraint: the loop form
+        try:
+            origins = tuple(origin(a) for a in args)
+        except _NoDefer:
+            return None
+        rec = static._DeferredPlateRec(self, mode, path, origins, tuple(axes), con, n, len(st["plates"]))
+        st["plates"].append(rec)
+        return rec
+
+    def run_deferred(self, rec, keys, args, constraint):
+        """the launch of a deferred plate: (plate trace, weight [B] or None) — or (score [B], retval) for assess"""
+        import torch
+        from . import _lib
+        from .engine import Broadcast, sum_rows_inorder
+        from .random import split
+        from .static import DistributionTrace, StaticTrace, VmapTrace, run_gfi
+        dev = _lib.get().device
+        n = rec.n
+        B = int(keys.shape[0]) if keys is not None else int(rec.B)
+
+        def per_elem(v, mapped):
+            if isinstance(v, np.ndarray) and v.dtype != object:
+                v = torch_from_host(v, dev)
+            if not isinstance(v, torch.Tensor) or isinstance(v, Broadcast):
+                return v
+            if mapped:
+                if v.ndim >= 2 and tuple(v.shape[:2]) == (B, n):
+                    return v
+                if v.shape[0] != n:
+                    raise ValueError(f"vmap: a mapped argument of leading size {v.shape[0]} for a plate of {n}")
+                return v.unsqueeze(0).expand((B,) + tuple(v.shape))
+            if v.ndim >= 1 and v.shape[0] == B:
+                return v.unsqueeze(1).expand((B, n) + tuple(v.shape[1:]))
+            return Broadcast(v) if v.ndim >= 1 else v
+        inner = tuple(_tree_take_axes(a, ax, lambda v: per_elem(v, True)) if ax is not None
+                      else _tree_map_plain(a, lambda v: per_elem(v, False)) for a, ax in zip(args, rec.axes))
+        icon = None
+        if constraint is not None:
+            def con_elem(v):
+                if isinstance(v, np.ndarray) and v.dtype != object:
+                    v = torch_from_host(v, dev)
+                if isinstance(v, torch.Tensor) and v.ndim >= 1 and v.shape[0] == n and tuple(v.shape[:2]) != (B, n):
+                    return v.unsqueeze(0).expand((B,) + tuple(v.shape))
+                return v
+            icon = constraint.map_values(con_elem)
+        ikey = split(keys, n) if keys is not None else None
+        if rec.mode == "assess":
+            s_, r = run_gfi(self.gen_fn, "assess", None, inner, constraint=icon, batch_shape=(B, n))
+            return sum_rows_inorder(s_), r
+        if rec.mode == "generate":
+            tr, w = run_gfi(self.gen_fn, "generate", ikey, inner, constraint=icon)
+            w = sum_rows_inorder(w)
+        else:
+            tr, w = run_gfi(self.gen_fn, "simulate", ikey, inner), None
+        if isinstance(tr, DistributionTrace):
+            return DistributionTrace(self, tuple(args), tr.value, sum_rows_inorder(tr.score)), w
+        st = StaticTrace(tr.gen_fn, None, tr.retval, tr.subtraces)
+        return VmapTrace(self, st, sum_rows_inorder(tr.get_score()), tr.retval, tuple(args)), w
 
     @staticmethod
     def _plate_constraint(constraint, n):

@@ -619,6 +619,33 @@ def _store_site(ctx, rec: "_SiteRec"):
     return rec
 
 
+class DeferralAbort(Exception):
+    """raised while tracing when a deferred plate's values are computed with (or it is not the model's last site): the
+    call is traced again with the plate as a loop"""
+
+
+class DeferredOutput:
+    """what a DEFERRED plate hands back to the model while it is traced (run_gfi `defer`): its values do not exist yet —
+    the plate runs after the program, with its elements on the launch axis — so they can be returned, not computed with"""
+
+    def __init__(self, index):
+        self.index = index
+
+    def _no(self, *a, **k):
+        raise DeferralAbort()
+    __add__ = __radd__ = __sub__ = __rsub__ = __mul__ = __rmul__ = __truediv__ = __rtruediv__ = __getitem__ = _no
+    __neg__ = __pow__ = __lt__ = __gt__ = __le__ = __ge__ = __iter__ = __len__ = __array__ = __float__ = _no
+
+
+class _DeferredPlateRec:
+    """a large plate of a particle-batched call, lifted out of the program (Vmap.trace_call / run_gfi `defer`)"""
+
+    def __init__(self, vm, mode, key_path, arg_origins, axes, con_leaves, n, index):
+        self.gen_fn, self.mode, self.key_path, self.arg_origins, self.axes = vm, mode, key_path, arg_origins, axes
+        self.con_leaves, self.n, self.index = con_leaves, n, index
+        self.retval = DeferredOutput(index)
+
+
 class _CallRec:
     """Result of tracing one generative-function call (nested or top-level)."""
 
@@ -820,6 +847,8 @@ def _rec_choices(rec) -> ChoiceMap:
 
 
 def _rec_score(rec):
+    if isinstance(rec, _DeferredPlateRec):
+        return 0.0                     # (added after the launch, by the caller: run_gfi)
     if getattr(rec, "plate_score", None) is not None:
         return rec.plate_score
     if isinstance(rec, _SiteRec):
@@ -937,25 +966,46 @@ def _emit_rec(tr: Tracing, rec):
             rec.origins = (_origin_of(tr, rec.value), _origin_of(tr, rec.score), _origin_of(tr, rec.discard))
         vo, so, do = rec.origins
         return ("site", rec.gen_fn, vo, so, do)
+    if isinstance(rec, _DeferredPlateRec):
+        return ("deferred", rec.index)
     subs = OrderedDict((a, _emit_rec(tr, r)) for a, r in rec.sites.items())
     ps = getattr(rec, "plate_score", None)
     if ps is not None:
         return ("vmap", rec.gen_fn, subs, tr.emit_output(rec.retval), tr.emit_output(ps))
-    return ("call", rec.gen_fn, subs, tr.emit_output(rec.retval))
+    return ("call", rec.gen_fn, subs, _emit_retval(tr, rec.retval))
 
 
-def _build_trace(otree, outs, leaves, args):
+def _emit_retval(tr, v):
+    """emit_output of a return value that may BE a deferred plate's (or hold it in a tuple / dict)"""
+    if isinstance(v, DeferredOutput):
+        return ("deferred_ret", v.index)
+    if isinstance(v, tuple) and any(isinstance(x, DeferredOutput) for x in v):
+        return ("tuple", [_emit_retval(tr, x) for x in v])
+    return tr.emit_output(v)
+
+
+def _resolve_retval(origin, outs, leaves, deferred):
+    if origin[0] == "deferred_ret":
+        return deferred[origin[1]].get_retval()
+    if origin[0] == "tuple" and deferred:
+        return tuple(_resolve_retval(o, outs, leaves, deferred) for o in origin[1])
+    return resolve(origin, outs, leaves)
+
+
+def _build_trace(otree, outs, leaves, args, deferred=None):
+    if otree[0] == "deferred":
+        return deferred[otree[1]]
     if otree[0] == "site":
         _, gf, vo, so, _ = otree
         return DistributionTrace(gf, args, resolve(vo, outs, leaves), resolve(so, outs, leaves))
     if otree[0] == "vmap":
         _, gf, subs, ro, po = otree
-        st = OrderedDict((a, _build_trace(o, outs, leaves, None)) for a, o in subs.items())
+        st = OrderedDict((a, _build_trace(o, outs, leaves, None, deferred)) for a, o in subs.items())
         inner = StaticTrace(gf.gen_fn, None, resolve(ro, outs, leaves), st)
         return VmapTrace(gf, inner, resolve(po, outs, leaves), resolve(ro, outs, leaves), args)
     _, gf, subs, ro = otree
-    st = OrderedDict((a, _build_trace(o, outs, leaves, None)) for a, o in subs.items())
-    return StaticTrace(gf, args, resolve(ro, outs, leaves), st)
+    st = OrderedDict((a, _build_trace(o, outs, leaves, None, deferred)) for a, o in subs.items())
+    return StaticTrace(gf, args, _resolve_retval(ro, outs, leaves, deferred) if deferred else resolve(ro, outs, leaves), st)
 
 
 def _build_discard(otree, outs, leaves) -> ChoiceMap:
@@ -1160,10 +1210,24 @@ def run_gfi(gen_fn, mode, key: Key | None, args, constraint: ChoiceMap | None = 
     weight_stats = bool(weight_stats and mode == "generate" and len(batch) == 1)
     na = _NOISE_CTX if (_NOISE_CTX is not None and mode in ("generate", "simulate")
                         and _NOISE_CTX.applies(key, batch, mode)) else None
-    ck = (_gfkey(gen_fn), mode, atree, ctree, specs, len(batch), key is not None, weight_stats, na is not None, elem_index)
+    # a large plate as the LAST site of a model called over a SMALL batch of particles runs after the program, over
+    # particles x elements (combinators.Vmap._defer): the decision depends on the batch size, which is part of the key then
+    from .combinators import DEFER_MAX_BATCH
+    defer_B = int(batch[0]) if (isinstance(gen_fn, StaticGenerativeFunction) and len(batch) == 1 and not weight_stats
+                                and na is None and not elem_index and 0 < int(batch[0]) <= DEFER_MAX_BATCH
+                                and (key is None or tuple(key.shape) == tuple(batch))) else None
+    ck = (_gfkey(gen_fn), mode, atree, ctree, specs, len(batch), key is not None, weight_stats, na is not None, elem_index,
+          defer_B)
     ent = _CACHE.get(ck)
     if ent is _SITE_BY_SITE:
         return sitewise.run_gfi(gen_fn, mode, key, args, constraint)
+    if ent is None and defer_B is not None and ck not in _NO_DEFER:
+        try:
+            ent = _trace_gfi(gen_fn, mode, key, batch, specs, atree, ctree, weight_stats, None, elem_index, defer_B)
+            _CACHE[ck] = ent
+        except DeferralAbort:
+            _NO_DEFER.add(ck)
+            ent = None
     if ent is None:
         tr = Tracing(len(batch))
         if na is not None:
@@ -1192,9 +1256,9 @@ def run_gfi(gen_fn, mode, key: Key | None, args, constraint: ChoiceMap | None = 
             ro = tr.emit_output(retval) if mode == "assess" else None
             if weight_stats and isinstance(w, Expr) and w.node.op != "CONST":
                 tr.graph.add("REDMAX", (w.node,), dtype="none")
-        ent = (Compiled(tr), otree, wo, so, ro) + (_noise_split(tr, batch, na) if na is not None else ((), None))
+        ent = (Compiled(tr), otree, wo, so, ro) + (_noise_split(tr, batch, na) if na is not None else ((), None)) + ((),)
         _CACHE[ck] = ent
-    comp, otree, wo, so, ro, draws, nprog = ent
+    comp, otree, wo, so, ro, draws, nprog, plates = ent
     leaves = flat.leaves + (na.draw(nprog, batch, key, len(draws), mode) if nprog is not None else [])
     stats = None
     if weight_stats and comp.uses_red:
@@ -1210,19 +1274,76 @@ def run_gfi(gen_fn, mode, key: Key | None, args, constraint: ChoiceMap | None = 
         outs = comp.run(leaves, batch, key, red_out=stats[0], tile_stats=(stats[1], stats[2]))
     else:
         outs = comp.run(leaves, batch, key)
+    deferred, w_def = None, None
+    if plates:                         # the deferred plate: its arguments came out of the program; now its own launch
+        from .engine import elementwise
+        from .random import fold_in
+        deferred = {}
+        for d in plates:
+            k = key
+            for c in (d.key_path if key is not None else ()):
+                k = fold_in(k, c)
+            d.B = int(batch[0])
+            a_c = tuple(resolve(o, outs, flat.leaves) for o in d.arg_origins)
+            c_c = d.con_leaves.map_values(lambda r: flat.leaves[r[1]]) if d.con_leaves is not None else None
+            res = d.gen_fn.run_deferred(d, k, a_c, c_c)
+            if mode == "assess":
+                deferred[d.index] = _AssessedPlate(res[1])
+                w_def = res[0]
+            else:
+                deferred[d.index], w_def = res
     if mode == "assess":
         score = _broadcast_score(resolve(so, outs, flat.leaves), batch, be.device)
+        if plates:
+            score = elementwise(lambda a_, b_: a_ + b_, score, w_def)
+            return score, _tree_materialize(_resolve_retval(ro, outs, flat.leaves, deferred))
         return score, _tree_materialize(resolve(ro, outs, flat.leaves))
-    trc = _build_trace(otree, outs, flat.leaves, args)
+    trc = _build_trace(otree, outs, flat.leaves, args, deferred)
     if mode == "simulate":
         return trc
     w = resolve(wo, outs, flat.leaves) if wo is not None else 0.0
     w = _broadcast_score(w, batch, be.device)
+    if plates and w_def is not None:
+        w = elementwise(lambda a_, b_: a_ + b_, w, w_def)
     if stats is not None and isinstance(w, torch.Tensor):
         # (block maxima, tile sums, shift, n, version): valid for exactly this tensor's values — an in-place change
         # of the weights afterwards (tempering, masking) bumps `_version` and smc.resample_fused drops the statistics
         w._gmx_tile_stats = tuple(stats) + (w._version,)
     return trc, w
+
+
+_NO_DEFER: set = set()        # call signatures whose deferral was tried and abandoned (DeferralAbort)
+
+
+class _AssessedPlate:
+    def __init__(self, retval):
+        self._r = retval
+
+    def get_retval(self):
+        return self._r
+
+
+def _trace_gfi(gen_fn, mode, key, batch, specs, atree, ctree, weight_stats, na, elem_index, defer_B):
+    """run_gfi's tracing step with plate deferral switched on; raises DeferralAbort when it does not apply"""
+    tr = Tracing(len(batch))
+    tr.graph.elem_from_index = bool(elem_index)
+    ctx = _Ctx(tr)
+    ctx.store_sites = mode != "assess"
+    ctx.defer = {"B": defer_B, "plates": [], "depth": len(_HANDLERS) + 1}
+    with T.tracing(tr.graph):
+        syms = [tr.sym_leaf(s, j) for j, s in enumerate(specs)]
+        sargs = unflatten(atree, lambda j: syms[j].value)
+        scon = _sym_constraint(ctree, syms)
+        kexpr = Expr(tr.graph.add("LDKEY", dtype="key")) if key is not None else None
+        rec, retval, w, s = call_gen_fn(ctx, mode, gen_fn, kexpr, sargs, scon, None, None, None, ())
+        plates = ctx.defer["plates"]           # (none: this IS the ordinary trace)
+        if plates and (not rec.sites or list(rec.sites.values())[-1] is not plates[0]):
+            raise DeferralAbort()              # sites after the plate: their weights would be added in another order
+        otree = _emit_rec(tr, rec) if mode != "assess" else None
+        wo = tr.emit_output(w) if (mode == "generate" and w is not None) else None
+        so = tr.emit_output(s if s is not None else 0.0) if mode == "assess" else None
+        ro = _emit_retval(tr, retval) if mode == "assess" else None
+    return (Compiled(tr), otree, wo, so, ro, (), None, tuple(plates))
 
 
 class MinimalGenerate:

@@ -2956,3 +2956,82 @@ def check_mixture_notebook_model(n=5000, k=12, seed=0):
     tr5, w5, _, _ = tr4.update(G.key(seed + 5), C["datapoints", "idx"].set(new_idx), Diff.no_change(args))
     otr5, ow5, _ = o_data.update(O.key(seed + 5), otr4, O.C.d({("datapoints", "idx"): o_idx}), ())
     assert f32(w5) == f32(ow5) and f32(tr5.get_score()) == f32(otr5.get_score()), (f32(w5), f32(ow5))
+
+
+def check_deferred_plate(B=64, n=4096, seed=41, timing=False):
+    """A model over a SMALL batch of particles whose last site is a LARGE plate (`ImportanceK` with tens of particles over
+    thousands of datapoints): the plate is lifted out of the program and run over particles x elements
+    (combinators.Vmap._defer / run_deferred) — simulate, importance under per-element observations, assess, and
+    `ImportanceK.run_smc` on such a target: bit-exact against the oracle AND against the loop form of the same call
+    (deferral switched off), which it must replace without a trace."""
+    import time
+    import genjax_amd as G
+    from genjax_amd import ChoiceMapBuilder as C, combinators as cmb, numpy as jnp, static
+    from genjax_amd.inference.smc import ImportanceK
+    sig = np.linspace(1.0, 3.0, n).astype(np.float32)
+    ys = np.linspace(-2.0, 2.0, n).astype(np.float32)
+    school, oschool = _school(G), _school(O)
+
+    @G.gen
+    def model(scale):
+        mu = G.normal(0.0, scale) @ "mu"
+        tau = G.normal(2.0, 0.1) @ "tau"
+        return school.vmap(in_axes=(None, None, 0))(mu, tau, jnp.array(sig)) @ "schools"
+
+    @O.gen
+    def omodel(scale):
+        mu = O.normal(0.0, scale) @ "mu"
+        tau = O.normal(2.0, 0.1) @ "tau"
+        return O.Vmap(oschool, in_axes=(None, None, 0))(mu, tau, sig) @ "schools"
+
+    @G.gen
+    def bare():                                   # a bare distribution under vmap: a per-particle mean, a table of scales
+        mu = G.normal(0.0, 1.0) @ "mu"
+        return G.normal.vmap(in_axes=(None, 0))(mu * 2.0, jnp.array(sig)) @ "xs"
+
+    @O.gen
+    def obare():
+        mu = O.normal(0.0, 1.0) @ "mu"
+        return O.Vmap(O.normal, in_axes=(None, 0))((mu * np.float32(2.0)).astype(np.float32), sig) @ "xs"
+    k, ok = G.split(G.key(seed), B), O.split(O.key(seed), B)
+    runs = {}
+    for deferred in (True, False):
+        G.clear_caches()
+        static._NO_DEFER.clear()
+        keep = cmb.DEFER_MIN_WORK
+        cmb.DEFER_MIN_WORK = keep if deferred else 1 << 62
+        try:
+            t0 = time.perf_counter()
+            tr = model.simulate(k, (5.0,))
+            tri, w = model.importance(G.split(G.key(seed + 1), B), C["schools", :, "y"].set(jnp.array(ys)), (5.0,))
+            s, _ = model.assess(tri.get_choices(), (5.0,))
+            trb = bare.simulate(k, ())
+            _ = float(w.sum())
+            t1 = time.perf_counter()
+            tri2, w2 = model.importance(G.split(G.key(seed + 1), B), C["schools", :, "y"].set(jnp.array(ys)), (5.0,))
+            _ = float(w2.sum())
+            t_imp = time.perf_counter() - t1
+            took = any(isinstance(e, tuple) and len(e) == 8 and e[7] for e in static._CACHE.values())
+            assert took == deferred, "the call did not take the requested (deferred / loop) form"
+            runs[deferred] = dict(theta=tr.get_choices()["schools", "theta"].cpu().numpy(), score=tr.get_score().cpu().numpy(),
+                                  ret=tr.get_retval().cpu().numpy(), w=w.cpu().numpy(), iscore=tri.get_score().cpu().numpy(),
+                                  s=s.cpu().numpy(), xs=trb.get_choices()["xs"].cpu().numpy(), bscore=trb.get_score().cpu().numpy(),
+                                  t_importance=t_imp)
+        finally:
+            cmb.DEFER_MIN_WORK = keep
+    for name in ("theta", "score", "ret", "w", "iscore", "s", "xs", "bscore"):
+        assert np.array_equal(runs[True][name], runs[False][name]), name
+    otr = omodel.simulate(ok, (np.float32(5.0),))
+    otri, ow = omodel.importance(O.split(O.key(seed + 1), B), O.C.d({("schools", "y"): ys}), (np.float32(5.0),))
+    otrb = obare.simulate(ok, ())
+    d = runs[True]
+    assert np.array_equal(d["theta"], otr.get_choices()["schools", "theta"]) and np.array_equal(d["score"], otr.get_score())
+    assert np.array_equal(d["w"], ow) and np.array_equal(d["iscore"], otri.get_score()) and np.array_equal(d["s"], otri.get_score())
+    assert np.array_equal(d["xs"], otrb.get_choices()["xs"]) and np.array_equal(d["bscore"], otrb.get_score())
+    # ImportanceK over the target: B particles under ONE key
+    G.clear_caches()
+    tgt = G.Target(model, (5.0,), C["schools", :, "y"].set(jnp.array(ys)))
+    coll = ImportanceK(tgt, k_particles=B).run_smc(G.key(seed + 2))
+    ocoll = O.ImportanceK(O.Target(omodel, (np.float32(5.0),), O.C.d({("schools", "y"): ys})), B).run_smc(O.key(seed + 2))
+    assert np.array_equal(coll.get_log_weights().cpu().numpy(), ocoll.get_log_weights())
+    return (runs[True]["t_importance"], runs[False]["t_importance"]) if timing else None

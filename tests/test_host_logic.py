@@ -698,6 +698,15 @@ def test_mixture_notebook_gibbs_inference_as_written():
         hs.uninstall()
 
 
+def test_large_plate_of_a_small_particle_batch_is_deferred():
+    """ref vmap.py:180-218 under `jax.vmap` over particles (smc.py:308-310): a few dozen particles over a model whose last
+    site is a plate of thousands of elements — the plate runs over particles x elements after the program
+    (combinators.Vmap._defer); equal to the loop form and to the oracle bit for bit, incl. ImportanceK.run_smc"""
+    from tests import parity
+    parity.check_deferred_plate(B=64, n=4096)
+    parity.check_deferred_plate(B=37, n=4096 * 2 + 3, seed=5)
+
+
 def test_indexed_and_masked_constraints_match_oracle():
     from tests import parity
     parity.check_masked_constraints()

@@ -919,10 +919,59 @@ k_sum_rows_inorder(const float* __restrict__ x, int64_t rows, int64_t cols, int6
   for (int64_t c = 0; c < cols; ++c) acc += p[c * sc];
   out[r] = acc;
 }
+// the same sum for LONG contiguous rows (a plate of 1e4..1e6 elements held per particle): one wave per row.  The chain of
+// dependent adds is the floor (cols x one v_add_f32), so the job of the other 63 lanes is to keep it fed: they fetch the
+// next INORDER_CHUNK elements with coalesced loads while every lane adds the current chunk out of LDS (all lanes read the
+// same address, a broadcast, and hold the same accumulator; nothing diverges)
+constexpr int INORDER_CHUNK = 1024;
+constexpr int INORDER_LONG_MIN = 1024;
+__global__ void __launch_bounds__(64)
+k_sum_rows_inorder_long(const float* __restrict__ x, int64_t cols, int64_t sr, float* __restrict__ out) {
+  __shared__ float4 buf[2][INORDER_CHUNK / 4];
+  const float* p = x + (int64_t)blockIdx.x * sr;
+  const int lane = threadIdx.x;
+  const int64_t chunks = (cols + INORDER_CHUNK - 1) / INORDER_CHUNK;
+  float v[INORDER_CHUNK / 64];
+  float acc = 0.0f;
+#pragma unroll
+  for (int k = 0; k < INORDER_CHUNK / 64; ++k) v[k] = (k * 64 + lane < cols) ? p[k * 64 + lane] : 0.0f;
+  for (int64_t c = 0; c < chunks; ++c) {
+    float* b = (float*)buf[c & 1];
+#pragma unroll
+    for (int k = 0; k < INORDER_CHUNK / 64; ++k) b[k * 64 + lane] = v[k];
+    __syncthreads();
+    if (c + 1 < chunks) {
+      const int64_t base = (c + 1) * INORDER_CHUNK;
+#pragma unroll
+      for (int k = 0; k < INORDER_CHUNK / 64; ++k) v[k] = (base + k * 64 + lane < cols) ? p[base + k * 64 + lane] : 0.0f;
+    }
+    const int64_t left = cols - c * INORDER_CHUNK;
+    if (left >= INORDER_CHUNK) {
+      const float4* b4 = buf[c & 1];
+#pragma unroll 8
+      for (int i = 0; i < INORDER_CHUNK / 4; ++i) {
+        const float4 t = b4[i];
+        acc += t.x;
+        acc += t.y;
+        acc += t.z;
+        acc += t.w;
+      }
+    } else {
+      for (int i = 0; i < (int)left; ++i) acc += b[i];
+    }
+  }
+  if (lane == 0) out[blockIdx.x] = acc;
+}
 extern "C" int gmx_sum_rows_inorder(const float* x_d, int64_t rows, int64_t cols, int64_t stride_row, int64_t stride_col,
                                     float* out_d, gmx_stream stream) {
   if (rows <= 0) return 0;
   if (cols < 0 || !x_d || !out_d) return gmx_fail("gmx_sum_rows_inorder: bad argument%s");
+  if (stride_col == 1 && cols >= INORDER_LONG_MIN && rows <= 0x7fffffff) {
+    hipLaunchKernelGGL(k_sum_rows_inorder_long, dim3((unsigned)rows), dim3(64), 0, (hipStream_t)stream, x_d, cols, stride_row,
+                       out_d);
+    GMX_HIP(hipGetLastError());
+    return 0;
+  }
   hipLaunchKernelGGL(k_sum_rows_inorder, grid_for(rows), dim3(GMX_BLOCK), 0, (hipStream_t)stream, x_d, rows, cols, stride_row,
                      stride_col, out_d);
   GMX_HIP(hipGetLastError());

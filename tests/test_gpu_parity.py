@@ -203,6 +203,26 @@ def test_logsumexp(gpu, shape):
     np.testing.assert_allclose(got, ref, rtol=2e-6, atol=2e-6)     # f32 tree sum vs f64
 
 
+@pytest.mark.parametrize("shape", [(1, 10), (7, 1023), (1, 1024), (3, 1025), (5, 4096), (50, 100_001), (2, 1_000_000),
+                                   (1000, 100)])
+def test_rows_summed_in_element_order(gpu, shape):
+    """gmx_sum_rows_inorder: ((x0 + x1) + x2) + ... bit for bit, on both of its kernels (a thread per short row, a wave
+    per long contiguous row) and on a strided view"""
+    from genjax_amd import engine
+    rng = np.random.default_rng(11)
+    x = (rng.normal(0, 3, shape) * np.exp(rng.normal(0, 4, shape))).astype(np.float32)
+    ref = np.cumsum(x, axis=1, dtype=np.float32)[:, -1]        # numpy's cumsum is the sequential chain
+    got = engine.sum_rows_inorder(_dev(x)).cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    wide = _dev(np.concatenate([x, x], axis=1))
+    got = engine.sum_rows_inorder(wide[:, :shape[1]]).cpu().numpy()                 # row stride != cols
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    got = engine.sum_rows_inorder(wide[:, ::2][:, :(shape[1] + 1) // 2]).cpu().numpy()   # column stride 2
+    x2 = np.concatenate([x, x], axis=1)[:, ::2][:, :(shape[1] + 1) // 2]
+    ref2 = np.cumsum(x2, axis=1, dtype=np.float32)[:, -1]
+    assert np.array_equal(got.view(np.uint32), ref2.view(np.uint32))
+
+
 def test_gather_and_categorical(gpu):
     import genjax_amd as G
     from genjax_amd import engine

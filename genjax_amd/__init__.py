@@ -22,7 +22,8 @@ from . import inference
 from .inference import Target
 from .inference.sp import Algorithm, Marginal, marginal
 from .transforms import jit, vmap
-from .combinators import RepeatCombinator, Scan, Vmap, accumulate, iterate, iterate_final, reduce, repeat, scan
+from .combinators import (MaskCombinator, RepeatCombinator, Scan, Vmap, accumulate, iterate, iterate_final, mask, masked_iterate,
+                          masked_iterate_final, reduce, repeat, scan)
 
 ExactDensity = Distribution
 SampleDistribution = Distribution          # sp.py:100-103: distributions whose value is a ChoiceMap
@@ -44,5 +45,5 @@ __all__ = [
     "VectorRequest", "Argdiffs", "Arguments", "Retdiff", "Score", "Weight", "Address", "AddressComponent", "R",
     "Closure", "Const", "PythonicPytree", "Pytree", "nth", "exact_density", "tfp_distribution", "half_cauchy",
     "half_normal", "log_normal", "Algorithm", "SampleDistribution", "Marginal", "marginal", "trace_p", "clear_caches",
-    "iterate", "iterate_final", "accumulate", "reduce", "Indexed", "DynamicIndex", "dynamic_index",
+    "iterate", "iterate_final", "accumulate", "reduce", "mask", "MaskCombinator", "masked_iterate", "masked_iterate_final", "Indexed", "DynamicIndex", "dynamic_index",
 ]

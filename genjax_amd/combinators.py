@@ -26,6 +26,7 @@ import numpy as np
 
 from .core.choice_map import ChoiceMap
 from .core.generative import GenerativeFunction
+from .core.mask import Mask
 from . import tracer as T
 from .tracer import Expr
 
@@ -277,6 +278,8 @@ def _stack(vals):
         if not all(isinstance(v, StepOutput) for v in vals):
             raise NotImplementedError("a plate whose elements mix loop outputs and plain values")
         return StepOutput.stack(vals)
+    if isinstance(vals[0], Mask):               # the elements' MaskCombinator return values: one Mask over the plate
+        return Mask(_stack([v.value for v in vals]), _stack([v.flag for v in vals]))
     if isinstance(vals[0], (tuple, list)):
         return type(vals[0])(_stack([v[k] for v in vals]) for k in range(len(vals[0])))
     arrs = [np.asarray(v, dtype=object) if not (isinstance(v, np.ndarray) and v.dtype == object) else v for v in vals]
@@ -479,6 +482,8 @@ class Vmap(GenerativeFunction):
                     return None
                 if isinstance(v, Sym):
                     v = v.value
+                if isinstance(v, Mask):
+                    return Mask(stack_out(v.value), stack_out(v.flag))
                 if isinstance(v, (tuple, list)):
                     return type(v)(stack_out(x) for x in v)
                 if isinstance(v, StepOutput):          # stacked by a loop inside this one: already [T0, T1, n]
@@ -611,6 +616,8 @@ class Vmap(GenerativeFunction):
                     return None
                 if isinstance(v, Sym):
                     v = v.value
+                if isinstance(v, Mask):
+                    return Mask(stack_out(v.value), stack_out(v.flag))
                 if isinstance(v, (tuple, list)):
                     return type(v)(stack_out(x) for x in v)
                 if isinstance(v, StepOutput):          # stacked by a loop inside this one: already [T0, T1, n]
@@ -960,6 +967,8 @@ def _plate_batch(sample, plate_size):
         return None
     for a in sample.addresses():
         v = sample[a] if a else sample.get_value()
+        if isinstance(v, Mask):           # the choices of a masked step / element
+            v = v.value
         shp = tuple(getattr(v, "shape", ()))
         if n in shp:
             return shp[:shp.index(n)]
@@ -979,6 +988,8 @@ def _select_tree(c, new, old):
     from .engine import Sym
     new = new.value if isinstance(new, Sym) else new
     old = old.value if isinstance(old, Sym) else old
+    if isinstance(new, Mask):
+        return Mask(_select_tree(c, new.value, old.value), _select_tree(c, new.flag, old.flag))
     if isinstance(new, (tuple, list)):
         return type(new)(_select_tree(c, a, b) for a, b in zip(new, old))
     if new is None:
@@ -1410,7 +1421,7 @@ class Scan(GenerativeFunction):
             if mode in ("simulate", "assess"):
                 return out, out.retval, None, 0.0
             return out, out.retval, 0.0, None
-        if n > SCAN_UNROLL_MAX:
+        if n > getattr(self, "unroll_max", SCAN_UNROLL_MAX):
             return self._trace_loop(ctx, mode, key, carry, scanned_in, constraint, n, req_leaves, addr)
         g = ctx.tr.graph
         keep = ctx.store_sites
@@ -1518,8 +1529,10 @@ class Scan(GenerativeFunction):
                 return v[t]
             if isinstance(v, (list, np.ndarray)) and not (isinstance(v, np.ndarray) and v.dtype == object):
                 return TableArray(np.asarray(v, dtype=np.float32 if np.asarray(v).dtype.kind == "f" else np.int32))[t]
+            if isinstance(v, np.ndarray) and v.dtype == object and 1 <= v.shape[0] <= SCAN_UNROLL_MAX:
+                return _dyn_take(v, t)       # a short vector held in registers (a masked scan of a few steps): selects
             raise NotImplementedError("scan of more than 16 steps: scanned inputs and per-step constraints must be "
-                                      "launch-uniform vectors (tables) or per-particle [n, T] arrays")
+                                      f"launch-uniform vectors (tables) or per-particle [n, T] arrays (got {type(v).__name__})")
 
         def step_constraint(chm, t):
             return _loop_step_constraint(chm, t, n, at_step)
@@ -1553,8 +1566,6 @@ class Scan(GenerativeFunction):
             for r in _leaves(rec):
                 val = r.value.value if isinstance(r.value, Sym) else r.value
                 sc = r.score.value if isinstance(r.score, Sym) else r.score
-                if isinstance(sc, np.ndarray):
-                    raise NotImplementedError("scan of more than 16 steps: a site with a vector-valued SCORE")
                 if wanted and not isinstance(val, StepOutput):
                     r.origins = (tr.store_step(val, n), tr.store_step(sc, n), None)
                     r.value = _so(tr, r.origins[0], n)
@@ -1563,6 +1574,8 @@ class Scan(GenerativeFunction):
             def stack_out(v):
                 if v is None:
                     return None
+                if isinstance(v, Mask):
+                    return Mask(stack_out(v.value), stack_out(v.flag))
                 if isinstance(v, (tuple, list)):
                     return type(v)(stack_out(x) for x in v)
                 if isinstance(v, StepOutput):          # stacked by a loop inside this one: already [T0, T1, n]
@@ -1627,7 +1640,7 @@ class Scan(GenerativeFunction):
         carry, scanned_in = args
         n = self._length(scanned_in)
         inner_prev = prev["vmap"]
-        if n > SCAN_UNROLL_MAX:
+        if n > getattr(self, "unroll_max", SCAN_UNROLL_MAX):
             return self._trace_edit_loop(ctx, sub_mode, key, carry, scanned_in, constraint, inner_prev, req, kind, n,
                                          req_leaves, addr)
         g = ctx.tr.graph
@@ -1759,6 +1772,8 @@ class Scan(GenerativeFunction):
                 return v[t]
             if isinstance(v, (list, np.ndarray)) and not (isinstance(v, np.ndarray) and v.dtype == object):
                 return TableArray(np.asarray(v, dtype=np.float32 if np.asarray(v).dtype.kind == "f" else np.int32))[t]
+            if isinstance(v, np.ndarray) and v.dtype == object and 1 <= v.shape[0] <= SCAN_UNROLL_MAX:
+                return _dyn_take(v, t)       # a short vector held in registers (a masked scan of a few steps): selects
             raise NotImplementedError("editing a scan of more than 16 steps: scanned inputs, constraints and the previous "
                                       "trace must be tables or per-particle [n, T] arrays")
 
@@ -1767,6 +1782,8 @@ class Scan(GenerativeFunction):
                 inner = v.value
                 if isinstance(inner, (StepInput, StepInput2, RuntimeTable, TableArray)):
                     return Sym(inner[t], None)
+                if isinstance(inner, np.ndarray) and inner.dtype == object and inner.ndim >= 1 and inner.shape[0] == n:
+                    return Sym(_dyn_take(inner, t), None)     # (a short scan run as a loop: its leaves sit in registers)
                 return v
             if isinstance(v, dict):
                 return {k: (None if k == "retval" else prev_at(x, t)) for k, x in v.items()}
@@ -1846,8 +1863,6 @@ class Scan(GenerativeFunction):
                 val = r.value.value if isinstance(r.value, Sym) else r.value
                 sc = r.score.value if isinstance(r.score, Sym) else r.score
                 dis = r.discard.value if isinstance(r.discard, Sym) else r.discard
-                if isinstance(sc, np.ndarray):
-                    raise NotImplementedError("editing a scan of more than 16 steps: a site with a vector-valued SCORE")
                 if wanted and not isinstance(val, StepOutput):
                     r.origins = (tr.store_step(val, n), tr.store_step(sc, n),
                                  tr.store_step(dis, n) if dis is not None else None)
@@ -1858,6 +1873,8 @@ class Scan(GenerativeFunction):
             def stack_out(v):
                 if v is None:
                     return None
+                if isinstance(v, Mask):
+                    return Mask(stack_out(v.value), stack_out(v.flag))
                 if isinstance(v, (tuple, list)):
                     return type(v)(stack_out(x) for x in v)
                 if isinstance(v, StepOutput):          # stacked by a loop inside this one: already [T0, T1, n]
@@ -2015,6 +2032,125 @@ def repeat(*, n: int):
 # argument / return-value adapter around the Scan — the traced choices, their addresses ([t, ...]), the chained
 # keys and every edit are the underlying Scan's.
 # ---------------------------------------------------------------------------
+# ---------------------------------------------------------------------------
+# MaskCombinator (mask.py:96-262): `gen_fn.mask()` takes a boolean first argument; the call always runs, its score and
+# weight count only where the flag holds, its return value is `Mask(value, flag)` and its choices are masked by it.
+# Needed by `masked_iterate` / `masked_iterate_final` (scan.py:1050-1150: variable-length chains).
+# ---------------------------------------------------------------------------
+def _prev_score(prev):
+    """the score of a symbolic previous trace (static._trace_tree / _rec_to_prev)"""
+    from .engine import Sym
+    from .static import MASK_FLAG, _masked_score
+    val = lambda v: v.value if isinstance(v, Sym) else v
+    if "score" in prev:
+        return val(prev["score"])
+    subs = prev["sub"]
+    if MASK_FLAG in subs:
+        return _masked_score(val(subs[MASK_FLAG]["value"]), _prev_score(subs[()]))
+    acc = None
+    for p_ in subs.values():
+        s_ = _prev_score(p_)
+        acc = s_ if acc is None else acc + s_
+    return acc if acc is not None else 0.0
+
+
+class MaskCombinator(GenerativeFunction):
+    """mask.py:96-262.  The record of a call is a call record with two entries: the inner record under `()` and the
+    flag as a pseudo-site under static.MASK_FLAG (a leaf like any other: stacked by plates, stored per step by loops,
+    selected by per-particle index edits, gathered by resampling)."""
+
+    def __init__(self, gen_fn):
+        self.gen_fn = gen_fn
+
+    @staticmethod
+    def _flag(check):
+        from .engine import Sym
+        check = check.value if isinstance(check, Sym) else check
+        if isinstance(check, np.ndarray) and check.dtype != object and check.shape == ():
+            check = check.item()
+        if isinstance(check, (bool, np.bool_)):
+            return bool(check)
+        if isinstance(check, Expr):
+            return T.as_bool(check)
+        # mask.py types the flag `ScalarFlag`: a vector of flags belongs under `.vmap()` (test_mask_combinator.py:227-244)
+        raise TypeError(f"mask: the flag must be a scalar boolean (got {type(check).__name__}"
+                        f"{' of shape ' + str(tuple(check.shape)) if hasattr(check, 'shape') else ''}); map a vector of "
+                        "flags with .vmap()")
+
+    def _record(self, ctx, inner_rec, check, ret):
+        from .static import MASK_FLAG, _MASK_FLAG_SITE, _CallRec, _SiteRec, _store_site
+        g = ctx.tr.graph
+        out = _CallRec(self)
+        out.sites[()] = inner_rec
+        flag = _SiteRec(_MASK_FLAG_SITE, T.lift(check), Expr(g.const_f32(0.0)))
+        out.sites[MASK_FLAG] = _store_site(ctx, flag)
+        out.retval = Mask(ret, check)
+        return out
+
+    def trace_call(self, ctx, mode, key, args, constraint, prev, req, req_leaves, addr):
+        from .core.generative import NotSupportedEditRequest
+        from .engine import Sym
+        from .static import MASK_FLAG, _ReqSpec, _masked_score, _rec_score, call_gen_fn
+        if not args:
+            raise TypeError("mask: the first argument is the flag")
+        check, inner_args = self._flag(args[0]), tuple(args[1:])
+        if mode in ("simulate", "generate", "assess"):
+            rec, ret, w, s_ = call_gen_fn(ctx, mode, self.gen_fn, key, inner_args, constraint, None, None, req_leaves, addr)
+            out = self._record(ctx, rec, check, ret)
+            if mode == "simulate":
+                return out, out.retval, None, _masked_score(check, _rec_score(rec))
+            if mode == "assess":
+                return out, out.retval, None, _masked_score(check, s_)
+            return out, out.retval, (w * T.as_float(check) if w is not None else None), None
+        # edit (mask.py:168-223): Update only
+        kind = req.kind if req is not None else "empty"
+        if not (mode == "update" or kind in ("update", "empty")):
+            raise NotSupportedEditRequest(f"MaskCombinator.edit answers Update (got {kind!r}), mask.py:176")
+        if prev is None:
+            raise NotImplementedError("editing a masked call without its previous trace")
+        inner_prev = prev["sub"][()]
+        pre = prev["sub"][MASK_FLAG]["value"]
+        pre = T.as_bool(T.lift(pre.value if isinstance(pre, Sym) else pre))
+        carry_over = _ReqSpec("update", tree=None, constraint=ChoiceMap.empty())
+        rec, ret, w, _ = call_gen_fn(ctx, "update", self.gen_fn, key, inner_args, constraint, inner_prev,
+                                     req if kind == "update" else carry_over, req_leaves, addr)
+        post = T.as_bool(T.lift(check))
+        new_score, old_score = _rec_score(rec), _prev_score(inner_prev)
+        final_score = T.where(post, new_score, old_score)      # the score of where(post, premasked trace, original trace)
+        f = T.as_float
+        t_to_t, t_to_f = pre & post, pre & ~post
+        f_to_f, f_to_t = ~pre & ~post, ~pre & post
+        weight = ((f(f_to_t) * final_score + f(t_to_f) * (-T.lift(old_score))) + f(f_to_f) * 0.0) \
+            + f(t_to_t) * (w if w is not None else 0.0)
+        out = self._record(ctx, rec, check, ret)
+        ctx.mark_changed(out.retval.flag if isinstance(out.retval.flag, Expr) else [])
+        return out, out.retval, weight, None
+
+    def simulate(self, key, args):
+        from .static import run_gfi
+        return run_gfi(self, "simulate", key, args)
+
+    def generate(self, key, constraint, args):
+        from .static import run_gfi
+        return run_gfi(self, "generate", key, args, constraint=constraint)
+
+    def assess(self, sample, args, batch_shape=None):
+        from .static import run_gfi
+        return run_gfi(self, "assess", None, args, constraint=sample, batch_shape=batch_shape)
+
+    def edit(self, key, trace, edit_request, argdiffs):
+        from .static import run_edit
+        return run_edit(self, key, trace, edit_request, argdiffs)
+
+    def __repr__(self):
+        return f"genjax.mask({self.gen_fn!r})"
+
+
+def mask(f):
+    """mask.py:265-322: the decorator form of MaskCombinator"""
+    return MaskCombinator(f)
+
+
 class _KernelAdapter(GenerativeFunction):
     """kernel(carry, x) built from a user function: `call(carry, x)` gives the user function's arguments,
     `ret(user retval)` the (carry, output) pair."""
@@ -2111,6 +2247,39 @@ def iterate_final(*, n: int):
     def decorator(f):
         k = _KernelAdapter(f, lambda carry, _x: (carry,), lambda r: (r, None))
         return _ScanAdapter(_sugar_scan(k, n, False), lambda init: (init, None), lambda args, ret: ret[0], "iterate_final")
+    return decorator
+
+
+def _masked_scan(kernel):
+    """a masked step keeps its flags (and their plates') beside its choices: unrolled, that is dozens of launch slots
+    per step — it always runs as the counted loop (one slot per leaf whatever the length), its edits reading the
+    previous trace's per-particle vectors step by step (step_leaf_min)"""
+    sc = Scan(kernel, None)
+    sc.unroll_max = 0
+    return sc
+
+
+def masked_iterate_final():
+    """f: a -> a  =>  (a, [flag]) -> the carry after the last step (scan.py:1050-1097): every step runs and threads its
+    return value on (`masked_retval.value`, flag or not: scan.py:1089); only the steps whose flag holds count in the
+    score and weights, and only their choices are visible"""
+    def decorator(f):
+        k = _KernelAdapter(MaskCombinator(f), lambda carry, flag: (flag, carry), lambda m: (m.value, None))
+        out = _ScanAdapter(_masked_scan(k), lambda init, flags: (init, flags), lambda args, ret: ret[0],
+                           "masked_iterate_final")
+        out.step_leaf_min = 0          # its edits read the previous [n, T] leaves step by step whatever T
+        return out
+    return decorator
+
+
+def masked_iterate():
+    """f: a -> a  =>  (a, [flag]) -> [a, f(a), f(f(a)), ...] (scan.py:1100-1150)"""
+    def decorator(f):
+        k = _KernelAdapter(MaskCombinator(f), lambda carry, flag: (flag, carry), lambda m: (m.value, m.value))
+        out = _ScanAdapter(_masked_scan(k), lambda init, flags: (init, flags),
+                           lambda args, ret, ctx: _prepend(args[0], ret[1], ctx), "masked_iterate", post_ctx=True)
+        out.step_leaf_min = 0
+        return out
     return decorator
 
 

@@ -260,6 +260,18 @@ class GenerativeFunction:
         from ..combinators import Scan
         return Scan(self, n)
 
+    def mask(self):
+        from ..combinators import MaskCombinator
+        return MaskCombinator(self)
+
+    def masked_iterate(self):
+        from ..combinators import masked_iterate
+        return masked_iterate()(self)
+
+    def masked_iterate_final(self):
+        from ..combinators import masked_iterate_final
+        return masked_iterate_final()(self)
+
     def iterate(self, *, n: int):
         from ..combinators import iterate
         return iterate(n=n)(self)

@@ -20,6 +20,12 @@ class Mask:
         """functional_types.py:148-173: a Mask of a Mask is ONE Mask whose flag is the conjunction"""
         if isinstance(value, Mask):
             fs, gs = _shape(flag), _shape(value.flag)
+            if fs != () and fs != gs and gs[:len(fs)] == fs:
+                # a flag per step / element over an inner mask per (step, inner element): the reference builds this
+                # mask INSIDE the scan / plate, a scalar flag against the inner flags, and stacks; here the stacked
+                # leaves meet, so the outer flag is spread over the inner axes
+                flag = flag.reshape(fs + (1,) * (len(gs) - len(fs)))
+                fs = gs
             assert fs == () or fs == gs, f"Can't build a Mask with non-matching Flag shapes {fs} and {gs}"
             return Mask(value.value, _and(flag, value.flag))
         return Mask(value, flag)

@@ -500,6 +500,7 @@ class Tracing:
         self.node_origin = {}  # id(node) -> origin
         self.prestored = {}    # id(node) -> slot of a store emitted early (plate elements)
         self.uses_key = False
+        self.step_leaf_min = STEP_LEAF_MIN     # (a masked scan reads per-particle vectors step by step from 5 elements)
 
     # leaves -> symbols ------------------------------------------------------
     def sym_leaf(self, spec, j) -> Sym:
@@ -530,7 +531,7 @@ class Tracing:
         flags = {"bcast": F_BCAST, "dvec": F_BCAST, "part": 0, "gather": F_GATHER}[kind]
         dt = spec[1]
         event = () if kind == "bcast" else spec[2]
-        if kind == "part" and len(event) >= 2 and event[0] > STEP_LEAF_MIN and int(np.prod(event[1:])) <= DVEC_MAX:
+        if kind == "part" and len(event) >= 2 and event[0] > self.step_leaf_min and int(np.prod(event[1:])) <= DVEC_MAX:
             # [n, T, *site event]: the values of a vector-valued site over the steps of a long scan — one [T, n] plane
             # per element of the site's event
             E = int(np.prod(event[1:]))
@@ -539,7 +540,7 @@ class Tracing:
             for e_, slot in enumerate(slots):
                 self.in_plan.append((slot, j, e_, "step2"))
             return Sym(StepInput.make2(g, slots, dt, int(event[0]), event[1:]), ("leaf", j))
-        if kind == "part" and len(event) >= 3 and event[1] > STEP_LEAF_MIN and int(np.prod(event[2:])) <= DVEC_MAX:
+        if kind == "part" and len(event) >= 3 and event[1] > self.step_leaf_min and int(np.prod(event[2:])) <= DVEC_MAX:
             # [n, A, T, *site event]: a vector-valued site of the long scans of a plate — one [A * T, n] slot per
             # element of the site's event
             E = int(np.prod(event[2:]))
@@ -548,7 +549,7 @@ class Tracing:
             for e_, slot in enumerate(slots):
                 self.in_plan.append((slot, j, e_, "stepflat2"))
             return Sym(StepInput2(g, slots, dt, (int(event[0]), int(event[1])), event=tuple(int(x) for x in event[2:])), ("leaf", j))
-        if kind == "part" and len(event) == 2 and event[1] > STEP_LEAF_MIN:
+        if kind == "part" and len(event) == 2 and event[1] > self.step_leaf_min:
             # [n, A, T] with a long last axis: the choices of the long scans of a plate — one slot ([A * T, n]); row a is
             # picked statically (an unrolled plate) or by the outer loop's iteration number (a plate run as a loop
             # around the scans' loop: element (a, t) through GMX_F_FLAT)
@@ -556,7 +557,7 @@ class Tracing:
             g.n_in += 1
             self.in_plan.append((slot, j, 0, "stepflat"))
             return Sym(StepInput2(g, slot, dt, (int(event[0]), int(event[1]))), ("leaf", j))
-        if kind == "part" and len(event) == 1 and event[0] > STEP_LEAF_MIN:
+        if kind == "part" and len(event) == 1 and event[0] > self.step_leaf_min:
             # a long per-particle vector (the [n, T] choices of a scan): one slot, element t read by iteration t
             slot = g.n_in
             g.n_in += 1
@@ -646,6 +647,8 @@ class Tracing:
             self.outputs.append((dt, tuple(value.shape), slots))
             self.node_origin[ck] = o
             return o
+        if isinstance(value, Mask):          # a MaskCombinator's return value (mask.py:71): value and flag
+            return ("maskv", self.emit_output(value.value), self.emit_output(value.flag))
         if isinstance(value, (tuple, list)):
             return ("tuple" if isinstance(value, tuple) else "list", [self.emit_output(v) for v in value])
         if isinstance(value, dict):
@@ -1159,6 +1162,8 @@ def resolve(origin, outs, leaves):
         return {k: resolve(o, outs, leaves) for k, o in origin[1].items()}
     if kind == "dc":
         return _make_dataclass(origin[1], {k: resolve(o, outs, leaves) for k, o in origin[2].items()})
+    if kind == "maskv":
+        return Mask(resolve(origin[1], outs, leaves), resolve(origin[2], outs, leaves))
     if kind == "stack":        # an unrolled plate of loop outputs: elements [*batch, T, *event] -> [*batch, n, T, *event]
         parts = [resolve(o, outs, leaves) for o in origin[1]]
         return torch.stack(parts, dim=parts[0].dim() - int(origin[2]))

@@ -136,6 +136,67 @@ class StaticTrace(Trace):
     get_inner_trace = get_subtrace
 
 
+MASK_FLAG = "\x00mask"      # address of the pseudo-site that carries a MaskCombinator's flag through records and traces
+
+
+class _MaskFlagSite:
+    """the "generative function" of the flag pseudo-site (never called: the site is written by MaskCombinator.trace_call)"""
+    name = "mask flag"
+
+    def __repr__(self):
+        return "genjax.mask flag"
+
+
+_MASK_FLAG_SITE = _MaskFlagSite()
+
+
+def _masked_score(check, score):
+    """`check * score` (mask.py:71): f32(flag) times the inner score"""
+    from . import tracer as Tm
+    return Tm.as_float(check) * score
+
+
+class MaskTrace(StaticTrace):
+    """mask.py:33-88 `MaskTrace`: the inner trace under `()` and the flag under MASK_FLAG — held as a site so that it
+    travels through plates, scans, gathers and edits like any other leaf.  choices = inner choices masked by the flag,
+    score = flag * inner score, return value = Mask(inner return value, flag)."""
+
+    @property
+    def inner(self):
+        return self.subtraces[()]
+
+    @property
+    def check(self):
+        return materialize(self.subtraces[MASK_FLAG].value)
+
+    def get_choices(self) -> ChoiceMap:
+        return self.inner.get_choices().mask(_host_flag(self.check))
+
+    def get_score(self):
+        c, sc = self.check, self.inner.get_score()
+        if isinstance(c, (bool, np.bool_)):
+            if isinstance(sc, torch.Tensor):
+                return sc * float(c)
+            return float(c) * sc
+        from .engine import elementwise
+        return elementwise(_masked_score, c, sc)
+
+    @property
+    def batch_shape(self):
+        return self.inner.batch_shape
+
+    def get_subtrace(self, *addr):
+        return self.inner.get_subtrace(*addr)
+
+    get_inner_trace = get_subtrace
+
+
+def _host_flag(c):
+    """a flag fixed while the program was traced stays a VALUE in choice maps (`np.bool_`, as under the reference's jit:
+    the masked choices keep their addresses), instead of resolving the mask on the spot (ChoiceMap.mask: bool)"""
+    return np.bool_(c) if isinstance(c, (bool, np.bool_)) else c
+
+
 def _sum_in_order(*terms):
     acc = terms[0]
     for t in terms[1:]:
@@ -180,6 +241,9 @@ def _zero_like_trace(tr):
 
 def _tree_map_leaves(v, fn):
     import dataclasses
+    from .core.mask import Mask
+    if isinstance(v, Mask):
+        return Mask(_tree_map_leaves(v.value, fn), _tree_map_leaves(v.flag, fn))
     if isinstance(v, tuple):
         return tuple(_tree_map_leaves(x, fn) for x in v)
     if isinstance(v, list):
@@ -193,6 +257,9 @@ def _tree_map_leaves(v, fn):
 
 def _tree_materialize(v):
     import dataclasses
+    from .core.mask import Mask
+    if isinstance(v, Mask):
+        return Mask(_tree_materialize(v.value), materialize(v.flag))
     if dataclasses.is_dataclass(v) and not isinstance(v, type) and not getattr(v, "__gmx_static__", False):
         return dataclasses.replace(v, **{f_.name: _tree_materialize(getattr(v, f_.name)) for f_ in dataclasses.fields(v)})
     if isinstance(v, tuple):
@@ -204,14 +271,24 @@ def _tree_materialize(v):
     return materialize(v)
 
 
+def _plain_retval(v):
+    """a return value as tuples / dicts of launch values: a Mask (a MaskCombinator's) becomes {"mvalue", "mflag"}"""
+    from .core.mask import Mask
+    if isinstance(v, Mask):
+        return {"mvalue": _plain_retval(v.value), "mflag": v.flag}
+    if isinstance(v, tuple):
+        return tuple(_plain_retval(x) for x in v)
+    return v
+
+
 def _trace_tree(tr):
     """Trace -> plain pytree of launch values (for Flat)."""
     if isinstance(tr, DistributionTrace):
         return {"value": tr.value, "score": tr.score}
     if isinstance(tr, StaticTrace):
-        return {"sub": {a: _trace_tree(s) for a, s in tr.subtraces.items()}, "retval": tr.retval}
+        return {"sub": {a: _trace_tree(s) for a, s in tr.subtraces.items()}, "retval": _plain_retval(tr.retval)}
     if isinstance(tr, VmapTrace):
-        return {"vmap": _trace_tree(tr.inner), "score": tr.score, "retval": tr.retval}
+        return {"vmap": _trace_tree(tr.inner), "score": tr.score, "retval": _plain_retval(tr.retval)}
     raise TypeError(f"cannot edit a trace of type {type(tr).__name__}")
 
 
@@ -743,6 +820,8 @@ def _leaf_call(ctx: _Ctx, mode, dist, key, args, constraint: ChoiceMap, prev, re
         v = dist.sym_sample(key, args)
         s = dist.sym_logpdf(v, args)
         return _SiteRec(dist, v, s), v, None, s
+    if mode == "assess" and isinstance(cval, Mask):
+        cval = cval.value                 # distribution.py:405-416: assess scores a masked value whatever its flag
     if isinstance(cval, Mask) and isinstance(cval.flag, bool):
         cval = cval.value if cval.flag else None             # decided on the host: plain constrained / unconstrained
     if isinstance(cval, Mask):
@@ -840,6 +919,9 @@ def _rec_choices(rec) -> ChoiceMap:
     if isinstance(rec, _SiteRec):
         v = rec.value
         return ChoiceMap.choice(v.value if isinstance(v, Sym) else v)
+    if MASK_FLAG in rec.sites:          # a MaskCombinator call: the inner choices under its flag (mask.py:70)
+        f = rec.sites[MASK_FLAG].value
+        return _rec_choices(rec.sites[()]).mask(f.value if isinstance(f, Sym) else f)
     cm = ChoiceMap.empty()
     for a, r in rec.sites.items():
         cm = cm.set(a, _rec_choices(r))
@@ -853,6 +935,9 @@ def _rec_score(rec):
         return rec.plate_score
     if isinstance(rec, _SiteRec):
         return rec.score.value if isinstance(rec.score, Sym) else rec.score
+    if MASK_FLAG in rec.sites:          # a MaskCombinator call: flag * inner score (mask.py:71)
+        f = rec.sites[MASK_FLAG].value
+        return _masked_score(f.value if isinstance(f, Sym) else f, _rec_score(rec.sites[()]))
     acc = None
     for r in rec.sites.values():
         s = _rec_score(r)
@@ -1001,11 +1086,12 @@ def _build_trace(otree, outs, leaves, args, deferred=None):
     if otree[0] == "vmap":
         _, gf, subs, ro, po = otree
         st = OrderedDict((a, _build_trace(o, outs, leaves, None, deferred)) for a, o in subs.items())
-        inner = StaticTrace(gf.gen_fn, None, resolve(ro, outs, leaves), st)
+        inner = (MaskTrace if MASK_FLAG in st else StaticTrace)(gf.gen_fn, None, resolve(ro, outs, leaves), st)
         return VmapTrace(gf, inner, resolve(po, outs, leaves), resolve(ro, outs, leaves), args)
     _, gf, subs, ro = otree
     st = OrderedDict((a, _build_trace(o, outs, leaves, None, deferred)) for a, o in subs.items())
-    return StaticTrace(gf, args, _resolve_retval(ro, outs, leaves, deferred) if deferred else resolve(ro, outs, leaves), st)
+    cls = MaskTrace if MASK_FLAG in st else StaticTrace
+    return cls(gf, args, _resolve_retval(ro, outs, leaves, deferred) if deferred else resolve(ro, outs, leaves), st)
 
 
 def _build_discard(otree, outs, leaves) -> ChoiceMap:
@@ -1017,6 +1103,8 @@ def _build_discard(otree, outs, leaves) -> ChoiceMap:
         d = _build_discard(o, outs, leaves)
         if not d.static_is_empty():
             cm = cm.set(a, d)
+    if MASK_FLAG in otree[2]:           # mask.py:253: the inner discard under the NEW flag
+        cm = cm.mask(_host_flag(materialize(resolve(otree[2][MASK_FLAG][2], outs, leaves))))
     return cm
 
 
@@ -1230,6 +1318,7 @@ def run_gfi(gen_fn, mode, key: Key | None, args, constraint: ChoiceMap | None = 
             ent = None
     if ent is None:
         tr = Tracing(len(batch))
+        tr.step_leaf_min = getattr(gen_fn, "step_leaf_min", tr.step_leaf_min)
         if na is not None:
             from .engine import NoiseHoist
             tr.graph.noise_hoist = NoiseHoist(tr, len(specs))
@@ -1326,6 +1415,7 @@ class _AssessedPlate:
 def _trace_gfi(gen_fn, mode, key, batch, specs, atree, ctree, weight_stats, na, elem_index, defer_B):
     """run_gfi's tracing step with plate deferral switched on; raises DeferralAbort when it does not apply"""
     tr = Tracing(len(batch))
+    tr.step_leaf_min = getattr(gen_fn, "step_leaf_min", tr.step_leaf_min)
     tr.graph.elem_from_index = bool(elem_index)
     ctx = _Ctx(tr)
     ctx.store_sites = mode != "assess"
@@ -1435,8 +1525,12 @@ def _rec_to_prev(rec):
         return v if isinstance(v, Sym) else Sym(v, None)
     if isinstance(rec, _SiteRec):
         return {"value": sym(rec.value), "score": sym(rec.score)}
+    from .core.mask import Mask
     ret = rec.retval
-    ret = tuple(sym(r) for r in ret) if isinstance(ret, tuple) else sym(ret)
+    if isinstance(ret, Mask):
+        ret = {"mvalue": sym(ret.value), "mflag": sym(ret.flag)}
+    else:
+        ret = tuple(sym(r) for r in ret) if isinstance(ret, tuple) else sym(ret)
     if getattr(rec, "plate_score", None) is not None:
         return {"vmap": {"sub": {a: _rec_to_prev(r) for a, r in rec.sites.items()}, "retval": ret},
                 "score": sym(rec.plate_score), "retval": ret}
@@ -1661,6 +1755,7 @@ def run_edit(gen_fn, key: Key, trace: Trace, request: EditRequest, argdiffs, mh:
             tr.graph.noise_hoist = NoiseHoist(tr, len(specs))
         ctx = _Ctx(tr)
         ctx.store_sites = not mh
+        tr.step_leaf_min = getattr(gen_fn, "step_leaf_min", tr.step_leaf_min)
         with T.tracing(tr.graph):
             syms = [tr.sym_leaf(s, j) for j, s in enumerate(specs)]
             sargs = unflatten(atree, lambda j: syms[j].value)

@@ -501,6 +501,8 @@ class Distribution:
         v = sample.get_value()
         if v is None:
             raise MissingAddress(())
+        if isinstance(v, Mask):              # distribution.py:405-416: a masked value is scored whatever its flag
+            v = v.value
         return self.estimate_logpdf(v, args, batch_shape), v
 
     def propose(self, k, args):
@@ -1142,6 +1144,8 @@ def _stack_last(trs, bn=None):
     def st(vals, axis=-1):
         if vals[0] is None:
             return None
+        if isinstance(vals[0], Mask):
+            return Mask(st([v.value for v in vals], axis), st([v.flag for v in vals], axis))
         if isinstance(vals[0], tuple):
             return tuple(st([v[k] for v in vals], axis) for k in range(len(vals[0])))
         arrs = [np.asarray(v) for v in vals]
@@ -1153,6 +1157,9 @@ def _stack_last(trs, bn=None):
         b_ = bn if bn is not None else max(np.ndim(t.score) for t in trs)     # batch rank: a site's score has no event axes
         return DistTrace(first.gen_fn, first.args, st([t.value for t in trs], b_), st([t.score for t in trs], b_))
     ax = -1 if bn is None else bn
+    if isinstance(first, MaskTrace):                 # a masked step: the flags gain the step axis like every other leaf
+        return MaskTrace(first.gen_fn, _stack_last([t.inner for t in trs], bn), st([t.check for t in trs], ax),
+                         None if first.ret is None else st([t.ret for t in trs], ax))
     if isinstance(first, VmapTrace):                 # a plate / a scan inside the step: its own axes stay behind the step axis
         return VmapTrace(first.gen_fn, _stack_last([t.inner for t in trs], bn), st([t.score for t in trs], ax),
                          st([t.retval for t in trs], ax))
@@ -1246,6 +1253,8 @@ def _step_axis(a, n, bn):
 
 
 def _step_take(v, idx, n, bn):
+    if isinstance(v, Mask):
+        return Mask(_step_take(v.value, idx, n, bn), _step_take(v.flag, idx, n, bn))
     a = np.asarray(v)
     ax = _step_axis(a, n, bn)
     return v if ax is None else np.take(a, idx, axis=ax)
@@ -1264,6 +1273,10 @@ def _slice_last(tr, idx):
         n = np.shape(tr.score)[-1]
         bn = np.ndim(tr.score) - 1                   # a site's score is [batch, n]: its value [batch, n, *event]
         return DistTrace(tr.gen_fn, tuple(sl(a, n) for a in tr.args), _step_take(tr.value, idx, n, bn), sl(tr.score, n))
+    if isinstance(tr, MaskTrace):
+        return _slice_mask_trace(tr, idx)
+    if isinstance(tr, VmapTrace):                    # a plate / scan inside the step: [batch, T, n] leaves, step axis first
+        return _slice_step_of_plate(tr, idx)
     n = np.shape(tr.get_score())[-1]
     return StaticTrace(tr.gen_fn, tr.args, sl(tr.retval, n),
                        OrderedDict((a, _slice_last(s, idx)) for a, s in tr.subtraces.items()))
@@ -1292,6 +1305,189 @@ def _set_last(tr, idx, new):
                          st(tr.score, new.score))
     return StaticTrace(tr.gen_fn, tr.args, st(tr.retval, new.retval),
                        OrderedDict((a, _set_last(s, idx, new.subtraces[a])) for a, s in tr.subtraces.items()))
+
+
+def _mask_and(v, flag):
+    """Mask.build (functional_types.py:148-173): a Mask of a Mask is one Mask whose flag is the conjunction"""
+    if isinstance(v, Mask):
+        f = np.asarray(flag, bool)
+        g = np.asarray(v.flag, bool)
+        if f.ndim and f.ndim < g.ndim:        # (the reference meets the inner flags per step / element; here stacked)
+            f = f.reshape(f.shape + (1,) * (g.ndim - f.ndim))
+        return Mask(v.value, f & g)
+    return Mask(v, np.asarray(flag, bool))
+
+
+class MaskTrace:
+    """MaskTrace (combinators/mask.py:33-88): choices masked by the flag, score = flag * inner score, return value
+    Mask(inner return value, flag).  `ret`: what a kernel adapter around the masked step returns instead
+    (masked_iterate: the (carry, output) pair built from `masked_retval.value`, scan.py:1089 / 1141)."""
+
+    def __init__(self, gen_fn, inner, check, ret=None):
+        self.gen_fn, self.inner, self.check, self.ret = gen_fn, inner, np.asarray(check, bool), ret
+        self.subtraces = getattr(inner, "subtraces", None)
+
+    def get_args(self): return None
+    def get_gen_fn(self): return self.gen_fn
+
+    def get_retval(self):
+        return self.ret if self.ret is not None else Mask(self.inner.get_retval(), self.check)
+
+    def get_score(self):
+        return (self.check.astype(np.float32) * np.asarray(self.inner.get_score(), np.float32)).astype(np.float32)
+
+    def get_choices(self):
+        return self.inner.get_choices().map_values(lambda v: _mask_and(v, self.check))
+
+    def get_subtrace(self, addr):
+        return self.inner.get_subtrace(addr)
+
+
+class MaskCombinator:
+    """MaskCombinator (combinators/mask.py:96-262): the first argument is the flag; the inner function always runs."""
+
+    def __init__(self, gen_fn):
+        self.gen_fn = gen_fn
+
+    def __call__(self, *args):
+        return Closure(self, tuple(args))
+
+    def simulate(self, k, args):
+        """mask.py:139-146"""
+        return MaskTrace(self, self.gen_fn.simulate(k, tuple(args[1:])), args[0])
+
+    def generate(self, k, chm, args):
+        """mask.py:148-157: w * check"""
+        tr, w = self.gen_fn.generate(k, chm, tuple(args[1:]))
+        check = np.asarray(args[0], bool)
+        return MaskTrace(self, tr, check), (np.asarray(w, np.float32) * check.astype(np.float32)).astype(np.float32)
+
+    importance = generate
+
+    def assess(self, chm, args, batch_shape=()):
+        """mask.py:225-236"""
+        s, r = self.gen_fn.assess(chm, tuple(args[1:]), batch_shape)
+        check = np.asarray(args[0], bool)
+        return (check.astype(np.float32) * np.asarray(s, np.float32)).astype(np.float32), Mask(r, check)
+
+    def update(self, k, trace: MaskTrace, chm, args):
+        """mask.py:168-223: the inner Update always runs; the weight by the flag's transition —
+        f_to_t * final score + t_to_f * (-old score) + f_to_f * 0 + t_to_t * inner weight, in that order"""
+        pre, post = trace.check, np.asarray(args[0], bool)
+        new, w, disc = self.gen_fn.update(k, trace.inner, chm, tuple(args[1:]))
+        f32_ = lambda b: np.asarray(b, bool).astype(np.float32)
+        old_score = np.asarray(trace.inner.get_score(), np.float32)
+        final = np.where(post, np.asarray(new.get_score(), np.float32), old_score).astype(np.float32)
+        t_to_t, t_to_f, f_to_f, f_to_t = pre & post, pre & ~post, ~pre & ~post, ~pre & post
+        weight = (f32_(f_to_t) * final + f32_(t_to_f) * (-old_score)).astype(np.float32)
+        weight = (weight + f32_(f_to_f) * np.float32(0.0)).astype(np.float32)
+        weight = (weight + f32_(t_to_t) * np.asarray(w, np.float32)).astype(np.float32)
+        return MaskTrace(self, new, post), weight, disc.map_values(lambda v: _mask_and(v, post))
+
+
+def _slice_mask_trace(tr: MaskTrace, idx):
+    n = np.shape(tr.check)[-1] if np.ndim(tr.check) else None
+
+    def sl(v):
+        if v is None:
+            return None
+        if isinstance(v, tuple):
+            return tuple(sl(x) for x in v)
+        a = np.asarray(v)
+        return a[..., idx] if a.ndim >= 1 and a.shape[-1] == n else v
+    return MaskTrace(tr.gen_fn, _slice_last(tr.inner, idx), sl(tr.check), sl(tr.ret))
+
+
+def _slice_step_of_plate(tr: "VmapTrace", idx):
+    """step idx of a plate / scan trace stacked over the steps of an enclosing scan: its leaves are [*batch, T, n]
+    (the step axis in FRONT of the plate's own), its score [*batch, T]"""
+    bn = np.ndim(tr.score) - 1
+    T_ = np.shape(tr.score)[-1]
+
+    def at(v):
+        if v is None:
+            return None
+        if isinstance(v, tuple):
+            return tuple(at(x) for x in v)
+        if isinstance(v, Mask):
+            return Mask(at(v.value), at(v.flag))
+        a = np.asarray(v)
+        return np.take(a, idx, axis=bn) if a.ndim > bn and a.shape[bn] == T_ else v
+
+    def walk(t):
+        if isinstance(t, DistTrace):
+            return DistTrace(t.gen_fn, t.args, at(t.value), at(t.score))
+        if isinstance(t, MaskTrace):
+            return MaskTrace(t.gen_fn, walk(t.inner), at(t.check), at(t.ret))
+        if isinstance(t, VmapTrace):
+            return VmapTrace(t.gen_fn, walk(t.inner), at(t.score), at(t.retval))
+        return StaticTrace(t.gen_fn, t.args, at(t.retval), OrderedDict((a, walk(s_)) for a, s_ in t.subtraces.items()))
+    return walk(tr)
+
+
+class _MaskedStep:
+    """the scan kernel of masked_iterate / masked_iterate_final (scan.py:1078-1095, 1130-1147):
+    `step.mask().dimap(pre=lambda state, flag: (flag, state), post=...)` — (carry, flag) -> (value, value | None)"""
+
+    def __init__(self, step, every: bool):
+        self.masked, self.every = MaskCombinator(step), every
+
+    def _ret(self, tr: MaskTrace):
+        v = tr.inner.get_retval()
+        return MaskTrace(tr.gen_fn, tr.inner, tr.check, (v, v if self.every else None))
+
+    def simulate(self, k, args):
+        return self._ret(self.masked.simulate(k, (args[1], args[0])))
+
+    def generate(self, k, chm, args):
+        tr, w = self.masked.generate(k, chm, (args[1], args[0]))
+        return self._ret(tr), w
+
+    def assess(self, chm, args, batch_shape=()):
+        s, m = self.masked.assess(chm, (args[1], args[0]), batch_shape)
+        return s, (m.value, m.value if self.every else None)
+
+    def update(self, k, trace, chm, args):
+        new, w, disc = self.masked.update(k, MaskTrace(trace.gen_fn, trace.inner, trace.check), chm, (args[1], args[0]))
+        return self._ret(new), w, disc
+
+
+class MaskedIterate:
+    """masked_iterate (every=True: [init, f(init), ...], scan.py:1100-1150) / masked_iterate_final (the last carry,
+    scan.py:1050-1097): a Scan over the flags of the masked step"""
+
+    def __init__(self, step, every: bool):
+        self.scan, self.every = Scan(_MaskedStep(step, every)), every
+
+    def __call__(self, *args):
+        return Closure(self, tuple(args))
+
+    def _post(self, init, ret, batch):
+        carry, ys = ret
+        if not self.every:
+            return carry
+        head = np.broadcast_to(np.asarray(init, np.float32), tuple(batch))[..., None]
+        return np.concatenate([head, np.broadcast_to(ys, tuple(batch) + ys.shape[-1:])], axis=-1)   # prepend_initial_acc
+
+    def _wrap(self, tr, init, batch):
+        return VmapTrace(self, tr.inner, tr.score, self._post(init, tr.retval, batch))
+
+    def simulate(self, k, args):
+        return self._wrap(self.scan.simulate(k, args), args[0], np.asarray(k).shape[:-1])
+
+    def generate(self, k, chm, args):
+        tr, w = self.scan.generate(k, chm, args)
+        return self._wrap(tr, args[0], np.asarray(k).shape[:-1]), w
+
+    importance = generate
+
+    def assess(self, chm, args, batch_shape=()):
+        s, ret = self.scan.assess(chm, args, batch_shape)
+        return s, self._post(args[0], ret, batch_shape)
+
+    def update(self, k, trace, chm, args):
+        tr, w = scan_edit(self.scan, k, trace, args, update=chm)
+        return self._wrap(tr, args[0], np.asarray(k).shape[:-1]), w, ChoiceMap()
 
 
 def vmap_update(vm: "Vmap", k, trace: "VmapTrace", constraint: ChoiceMap, args):
@@ -1356,7 +1552,7 @@ def scan_edit(sc: "Scan", k, trace: "VmapTrace", args, update: ChoiceMap = None,
         weight = (weight + np.broadcast_to(np.asarray(w, np.float32), batch)).astype(np.float32)
         score = (score + np.broadcast_to(np.asarray(new.get_score(), np.float32), batch)).astype(np.float32)
     ys = None if outs[0] is None else np.stack([np.broadcast_to(np.asarray(o), batch) for o in outs], axis=-1)
-    return VmapTrace(sc, _stack_last(slices), score, (carry, ys)), weight
+    return VmapTrace(sc, _stack_last(slices, len(batch)), score, (carry, ys)), weight
 
 
 def scan_edit_index(sc: "Scan", k, trace: "VmapTrace", args, idx: int, edit):

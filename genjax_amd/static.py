@@ -161,6 +161,11 @@ class MaskTrace(StaticTrace):
     travels through plates, scans, gathers and edits like any other leaf.  choices = inner choices masked by the flag,
     score = flag * inner score, return value = Mask(inner return value, flag)."""
 
+    def __init__(self, gen_fn, args, retval, subtraces):
+        super().__init__(gen_fn, args, retval, subtraces)
+        if args is not None and getattr(self.inner, "args", None) is None:
+            self.inner.args = tuple(args[1:])          # (`tr.inner.update(key, C.n())`: the inner call's own arguments)
+
     @property
     def inner(self):
         return self.subtraces[()]

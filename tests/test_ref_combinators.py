@@ -11,8 +11,8 @@ Run here on the CPU mirror of the C-ABI; tests/test_reference_gpu.py runs the sa
 Not mirrored (SURVEY §2 out of scope, or a JAX implementation detail):
   test_core.py: test_get_subtrace_switch, test_or_else (the Switch / or_else combinators); test_tupled_address_conflict
     (skipped in the reference itself);
-  test_vmap_combinator.py: the `mask()` half of test_vmap_combinator_vmap_pytree (MaskCombinator), the dtype-promotion
-    message of test_vmap_validation (a jax.vmap error text);
+  test_vmap_combinator.py: the dtype-promotion message of test_vmap_validation (a jax.vmap error text); the `mask()`
+    half of test_vmap_combinator_vmap_pytree is in tests/test_ref_mask_combinator.py;
   test_scan_combinator.py: the last assertion block of TestScanIndexRequest (an out-of-range dynamic index is CLAMPED by
     XLA's dynamic_slice and the test only passes because the assert inside `pytest.raises(AssertionError)` trips)."""
 import numpy as np

@@ -18,6 +18,7 @@ import torch
 from tests import parity
 from tests import test_host_logic as H
 from tests import test_ref_combinators as RC
+from tests import test_ref_mask_combinator as RMC
 from tests import test_ref_static as RS
 
 pytestmark = pytest.mark.gpu
@@ -72,6 +73,7 @@ class TestRefVmapOnDevice(RC.TestVmap): pass
 class TestRefVmapIndexRequestOnDevice(RC.TestVmapIndexRequest): pass
 class TestRefRepeatOnDevice(RC.TestRepeat): pass
 class TestRefCoreOnDevice(RC.TestCore): pass
+class TestRefMaskCombinatorOnDevice(RMC.TestMaskCombinator): pass
 
 
 def test_nested_marginal_and_change_target_on_device():

@@ -20,6 +20,7 @@ from .static import (AddressReuse, MissingAddress, Rejuvenate, StaticGenerativeF
                      StaticTrace, gen, trace)
 from . import inference
 from .inference import Target
+from .inference import requests, smc          # `genjax.smc`, `genjax.requests` (inference/__init__.py:22-37 star-exported)
 from .inference.sp import Algorithm, Marginal, marginal
 from .transforms import jit, vmap
 from .combinators import (MaskCombinator, RepeatCombinator, Scan, Vmap, accumulate, iterate, iterate_final, mask, masked_iterate,
@@ -35,7 +36,7 @@ fold_in = random.fold_in
 from .engine import clear_caches  # noqa: E402  (build addition: drop every cached site program)
 
 __all__ = [
-    "numpy", "random", "inference", "ChoiceMap", "ChoiceMapBuilder", "Selection", "SelectionBuilder",
+    "numpy", "random", "inference", "smc", "requests", "ChoiceMap", "ChoiceMapBuilder", "Selection", "SelectionBuilder",
     "ChoiceMapNoValueAtAddress", "Diff", "DiffAnnotate", "EditRequest", "EmptyRequest",
     "GenerativeFunction", "GenerativeFunctionClosure", "NoChange", "UnknownChange", "Regenerate",
     "Trace", "Update", "Mask", "Distribution", "ExactDensity", "bernoulli", "beta", "categorical", "dirichlet",

@@ -662,12 +662,13 @@ class Vmap(GenerativeFunction):
             raise NotSupportedEditRequest(f"Vmap.edit answers Update and IndexRequest (got {kind!r}), vmap.py:342-362")
         axes = self._axes(args)
         n = self._plate_size(args, axes)
-        if "vmap" not in prev:
+        if "vmap" not in prev and "sub" not in prev:
             # a plate of a BARE distribution (`normal.vmap()(locs, scales) @ "a"`): its trace keeps the values and the
             # plate-sum score; the per-element scores an edit needs are recomputed from the old values in the loop
             return self._trace_edit_loop(ctx, kind if kind != "empty" else "update", key, args, axes, constraint, None,
                                          req, n, req_leaves, addr, bare_prev=prev)
-        inner_prev = prev["vmap"]
+        # (as the ELEMENT of an enclosing plate / scan this plate's trace is held flat: its sites with one more axis)
+        inner_prev = prev["vmap"] if "vmap" in prev else prev
         # a small plate whose ELEMENTS ran a counted loop (its previous values are [n, A, T] step leaves): the edit runs
         # the plate as a loop around the elements' loops, as a large one does
         if n > VMAP_UNROLL_MAX or (_has_step_rows(inner_prev) and not ctx.tr.graph.loop_counts):
@@ -1639,7 +1640,7 @@ class Scan(GenerativeFunction):
             raise NotSupportedEditRequest(f"Scan.edit answers Update, Regenerate and IndexRequest (got {kind!r})")
         carry, scanned_in = args
         n = self._length(scanned_in)
-        inner_prev = prev["vmap"]
+        inner_prev = prev["vmap"] if "vmap" in prev else prev
         if n > getattr(self, "unroll_max", SCAN_UNROLL_MAX):
             return self._trace_edit_loop(ctx, sub_mode, key, carry, scanned_in, constraint, inner_prev, req, kind, n,
                                          req_leaves, addr)

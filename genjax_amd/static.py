@@ -77,8 +77,18 @@ class DistributionTrace(Trace):
         return tuple(getattr(self.score, "shape", ()))
 
 
+MASK_FLAG = "\x00mask"      # address of the pseudo-site that carries a MaskCombinator's flag through records and traces
+
+
 class StaticTrace(Trace):
     """static.py:80-119"""
+
+    def __new__(cls, gen_fn=None, args=None, retval=None, subtraces=None):
+        # whoever rebuilds a trace from its parts (gathers, stacks, slices, zero traces) gets a MaskTrace back for a
+        # masked call: the flag pseudo-site among the sub-traces says so
+        if cls is StaticTrace and subtraces is not None and MASK_FLAG in subtraces:
+            cls = MaskTrace
+        return object.__new__(cls)
 
     def __init__(self, gen_fn, args, retval, subtraces: "OrderedDict"):
         self.gen_fn, self.args, self.retval, self.subtraces = gen_fn, args, retval, subtraces
@@ -134,9 +144,6 @@ class StaticTrace(Trace):
         return tr
 
     get_inner_trace = get_subtrace
-
-
-MASK_FLAG = "\x00mask"      # address of the pseudo-site that carries a MaskCombinator's flag through records and traces
 
 
 class _MaskFlagSite:
@@ -613,8 +620,8 @@ def _capture_fp(gf, depth):
 _KEEP: list = []
 
 
-def _depends(node, changed: set, memo: dict) -> bool:
-    """Does `node` depend on any node in `changed`? (incremental.py change propagation)"""
+def _depends(node, changed: set, memo: dict, table_changed=None) -> bool:
+    """Does `node` depend on any node in `changed` — or read a table flagged changed? (incremental.py change propagation)"""
     stack = [node]
     seen = []
     while stack:
@@ -628,7 +635,7 @@ def _depends(node, changed: set, memo: dict) -> bool:
             return True
         if r is False:
             continue
-        if n.idx in changed:
+        if n.idx in changed or (table_changed is not None and n.op == "LDTAB" and table_changed(n)):
             memo[n.idx] = True
             for s in seen:
                 memo[s] = True
@@ -664,16 +671,57 @@ class _Ctx:
         self.tr = tr
         self.changed: set = set()        # node indices whose value differs from the previous trace
         self.memo: dict = {}
+        self.changed_slots: set = set()  # table slots whose contents differ from the previous trace's (changed table arguments)
+        self.changed_tables: list = []   # ... and host tables flagged changed before they were given a slot
+        self._slot_memo: dict = {}
         self.store_sites = True          # False: the caller stores only what it needs (MinimalGenerate)
         self.gate = None                 # an edit applies only where this boolean holds (IndexRequest around a loop)
 
     def mark_changed(self, v):
         for n in _nodes_of(v):
             self.changed.add(n.idx)
+        self._mark_tables(v)
         self.memo.clear()
 
+    def _mark_tables(self, v):
+        """a changed argument that is a TABLE (a launch-uniform vector of more than 16 elements: read with OP_LDTAB at a
+        run-time index — element j of a mapped argument in a plate's loop, `means[idx]`): every read of it is changed"""
+        if isinstance(v, (tuple, list)):
+            for x in v:
+                self._mark_tables(x)
+        elif isinstance(v, dict):
+            for x in v.values():
+                self._mark_tables(x)
+        elif isinstance(v, np.ndarray):
+            slot = getattr(v, "_slot", None)
+            if slot is not None:                      # numpy.RuntimeTable / a TableArray row: a device or pooled table
+                self.changed_slots.add(int(slot))
+            if v.dtype != object and v.size > 0:      # a host table (numpy.TableArray, or the array it will be made from)
+                self.changed_tables.append(np.asarray(v).reshape(-1))
+                self._slot_memo.clear()
+
+    def _table_changed(self, node) -> bool:
+        slot = getattr(node, "slot", None)
+        if slot is None:
+            return False
+        if slot in self.changed_slots:
+            return True
+        if not self.changed_tables:
+            return False
+        r = self._slot_memo.get(slot)
+        if r is None:
+            tabs = self.tr.graph.__dict__.get("tables", [])
+            t = tabs[slot] if slot < len(tabs) else None
+            r = False
+            if t is not None:
+                flat = np.asarray(t).reshape(-1)
+                r = any(c.size == flat.size and np.array_equal(c, flat) for c in self.changed_tables)
+            self._slot_memo[slot] = r
+        return r
+
     def args_changed(self, args) -> bool:
-        return any(_depends(n, self.changed, self.memo) for n in _nodes_of(args))
+        tab = self._table_changed if (self.changed_slots or self.changed_tables) else None
+        return any(_depends(n, self.changed, self.memo, tab) for n in _nodes_of(args))
 
 
 class _SiteRec:

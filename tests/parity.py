@@ -3150,3 +3150,113 @@ def check_mask_combinator(B=33, T=10, n_plate=40, seed=51):
             assert eq(wi, owi) and eq(tri.get_score(), otri.get_score())
             s_, _ = model.assess(tri.get_choices(), (0.25, jnp.array(flags)))
             assert eq(s_, otri.get_score())
+
+
+def check_update_under_changed_table_arguments(B=9, n=24, seed=61):
+    """`Update` whose ARGUMENT change is a launch-uniform TABLE (more than 16 elements: read with a run-time index in a
+    plate's / scan's loop, or by `means[idx]`): every element is re-scored under the new table (ref vmap.py:236-275,
+    scan.py:417-503, incremental.py: an UnknownChange argument).  One plate, a plate of plates (the reference's
+    masking notebook's image model, without the mask), a scan over a table, a table indexed by a sampled integer."""
+    import genjax_amd as G
+    from genjax_amd import ChoiceMapBuilder as C, Diff, numpy as jnp
+    n_ = lambda a: a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    eq = lambda a, b: np.array_equal(n_(a), np.asarray(b))
+    rng = np.random.default_rng(seed)
+
+    @G.gen
+    def px(m):
+        return G.normal(m, 1.0) @ "pixel"
+
+    @O.gen
+    def opx(m):
+        return O.normal(m, np.float32(1.0)) @ "pixel"
+    k, ok = G.split(G.key(seed), B), O.split(O.key(seed), B)
+    k2, ok2 = G.split(G.key(seed + 1), B), O.split(O.key(seed + 1), B)
+    m0, m1 = rng.normal(size=n).astype(np.float32), rng.normal(size=n).astype(np.float32)
+    pl, opl = px.vmap(in_axes=(0,)), O.Vmap(opx, in_axes=(0,))
+    tr, otr = pl.simulate(k, (jnp.array(m0),)), opl.simulate(ok, (m0,))
+    new, w, _, _ = tr.edit(k2, G.Update(C.n()), (Diff(jnp.array(m1), G.UnknownChange),))
+    onew, ow, _ = opl.update(ok2, otr, O.ChoiceMap(), (m1,))
+    assert np.any(n_(w) != 0.0) and eq(w, ow) and eq(new.get_score(), onew.get_score())
+    # a plate of plates
+    a = max(3, n // 4)
+    M0, M1 = rng.normal(size=(a, n)).astype(np.float32), rng.normal(size=(a, n)).astype(np.float32)
+    pp, opp = px.vmap(in_axes=(0,)).vmap(in_axes=(0,)), O.Vmap(O.Vmap(opx, in_axes=(0,)), in_axes=(0,))
+    tr, otr = pp.simulate(k, (jnp.array(M0),)), opp.simulate(ok, (M0,))
+    assert eq(tr.get_score(), otr.get_score())
+    new, w, _, _ = tr.edit(k2, G.Update(C.n()), (Diff(jnp.array(M1), G.UnknownChange),))
+    onew, ow, _ = opp.update(ok2, otr, O.ChoiceMap(), (M1,))
+    assert np.any(n_(w) != 0.0) and eq(w, ow) and eq(new.get_score(), onew.get_score())
+    # a scan whose scanned input is a table
+    @G.gen
+    def step(c, x):
+        z = G.normal(c + x, 1.0) @ "z"
+        return z, z
+
+    @O.gen
+    def ostep(c, x):
+        z = O.normal((c + x).astype(np.float32), np.float32(1.0)) @ "z"
+        return z, z
+    sc, osc = step.scan(n=n), O.Scan(ostep, n)
+    tr, otr = sc.simulate(k, (0.0, jnp.array(m0))), osc.simulate(ok, (np.float32(0.0), m0))
+    new, w, _, _ = tr.edit(k2, G.Update(C.n()), (Diff.no_change(0.0), Diff(jnp.array(m1), G.UnknownChange)))
+    onew, ow = O.scan_edit(osc, ok2, otr, (np.float32(0.0), m1), update=O.ChoiceMap())
+    assert np.any(n_(w) != 0.0) and eq(w, ow) and eq(new.get_score(), onew.get_score())
+    # a table indexed by a sampled integer
+    @G.gen
+    def pick(means):
+        i = G.categorical(logits=jnp.zeros(n)) @ "i"
+        return G.normal(means[i], 1.0) @ "x"
+
+    @O.gen
+    def opick(means):
+        i = O.categorical(np.zeros(n, np.float32)) @ "i"
+        return O.normal(np.asarray(means, np.float32)[i], np.float32(1.0)) @ "x"
+    tr, otr = pick.simulate(k, (jnp.array(m0),)), opick.simulate(ok, (m0,))
+    assert eq(tr.get_score(), otr.get_score())
+    new, w, _, _ = tr.edit(k2, G.Update(C.n()), (Diff(jnp.array(m1), G.UnknownChange),))
+    onew, ow, _ = opick.update(ok2, otr, O.ChoiceMap(), (m1,))
+    assert np.any(n_(w) != 0.0) and eq(w, ow) and eq(new.get_score(), onew.get_score())
+
+
+def check_masked_image_model(B=6, size=24, seed=71):
+    """The reference's masking notebook (docs/cookbook/inactive/expressivity/masking.ipynb c24-c30):
+    `single_pixel.mask().vmap(in_axes=(0,)).vmap(in_axes=(0,))` over a 2-D table of flags, then `Update` under a new
+    table of flags (a growing circle): scores, the masked choices `[:, :, "pixel"]` and the weights of a chain of edits,
+    bit for bit against the oracle; under a batch of keys and under ONE key."""
+    import genjax_amd as G
+    from genjax_amd import ChoiceMapBuilder as C, Diff, numpy as jnp
+    n_ = lambda a: a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    eq = lambda a, b: np.array_equal(n_(a), np.asarray(b))
+
+    @G.gen
+    def single_pixel():
+        pixel = G.normal(0.0, 1.0) @ "pixel"
+        return pixel
+
+    @O.gen
+    def osingle_pixel():
+        pixel = O.normal(np.float32(0.0), np.float32(1.0)) @ "pixel"
+        return pixel
+    image_model = single_pixel.mask().vmap(in_axes=(0,)).vmap(in_axes=(0,))
+    oimage_model = O.Vmap(O.Vmap(O.MaskCombinator(osingle_pixel), in_axes=(0,)), in_axes=(0,))
+
+    def circle(radius):
+        y, x = np.ogrid[:size, :size]
+        return np.sqrt((x - size // 2) ** 2 + (y - size // 2) ** 2) <= radius
+    for batch in ((B,), ()):
+        k = G.split(G.key(seed), B) if batch else G.key(seed)
+        ok = O.split(O.key(seed), B) if batch else O.key(seed)
+        tr, otr = image_model.simulate(k, (jnp.array(circle(size // 3)),)), oimage_model.simulate(ok, (circle(size // 3),))
+        assert eq(tr.get_score(), otr.get_score())
+        for i in range(4):
+            m = tr.get_choices()[:, :, "pixel"]
+            om = otr.get_choices()[("pixel",)]
+            assert eq(m.value, om.value) and eq(m.flag, np.broadcast_to(om.flag, n_(m.flag).shape))
+            k2 = G.split(G.key(seed + 1 + i), B) if batch else G.key(seed + 1 + i)
+            ok2 = O.split(O.key(seed + 1 + i), B) if batch else O.key(seed + 1 + i)
+            new_mask = circle(2 * i + 1)
+            tr, w, _, _ = tr.edit(k2, G.Update(C.n()), (Diff(jnp.array(new_mask), G.UnknownChange),))
+            otr, ow, _ = oimage_model.update(ok2, otr, O.ChoiceMap(), (new_mask,))
+            assert eq(w, ow) and eq(tr.get_score(), otr.get_score()), (i, n_(w), ow)
+            assert int(n_(tr.get_choices()[:, :, "pixel"].flag).sum()) == int(new_mask.sum()) * (B if batch else 1)

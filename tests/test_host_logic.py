@@ -707,6 +707,15 @@ def test_large_plate_of_a_small_particle_batch_is_deferred():
     parity.check_deferred_plate(B=37, n=4096 * 2 + 3, seed=5)
 
 
+def test_update_under_a_changed_table_argument_rescores_every_element():
+    """ref vmap.py:236-275 / scan.py:417-503 with an UnknownChange argument that is a launch-uniform table of more than
+    16 elements (read at a run-time index inside the loop): found stale in round 4 (weight 0) — one plate, a plate of
+    plates, a scan over a table, `means[idx]`"""
+    from tests import parity
+    parity.check_update_under_changed_table_arguments()
+    parity.check_update_under_changed_table_arguments(B=4, n=40, seed=7)
+
+
 def test_mask_combinator_and_masked_scans_match_oracle():
     """ref combinators/mask.py:96-262, scan.py:1050-1150: `gen_fn.mask()` under per-particle flags (all four update
     transitions), plates of masked elements (unrolled and as a loop), masked_iterate / masked_iterate_final incl. the
@@ -714,6 +723,7 @@ def test_mask_combinator_and_masked_scans_match_oracle():
     from tests import parity
     parity.check_mask_combinator()
     parity.check_mask_combinator(B=5, T=7, n_plate=17, seed=3)
+    parity.check_masked_image_model()              # the masking notebook's image model and its chain of updates
 
 
 def test_indexed_and_masked_constraints_match_oracle():

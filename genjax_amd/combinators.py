@@ -602,8 +602,6 @@ class Vmap(GenerativeFunction):
                 val = r.value.value if isinstance(r.value, Sym) else r.value
                 sc = r.score.value if isinstance(r.score, Sym) else r.score
                 dis = r.discard.value if isinstance(r.discard, Sym) else r.discard
-                if isinstance(sc, np.ndarray):
-                    raise NotImplementedError(f"{what}: a site with a vector-valued SCORE")
                 if wanted and not isinstance(val, StepOutput):
                     r.origins = (tr.store_step(val, n), tr.store_step(sc, n),
                                  tr.store_step(dis, n) if dis is not None else None)

@@ -859,6 +859,9 @@ class Compiled:
             raise ValueError("site program exceeds the ABI slot limits "
                              f"(in={self.n_in}, out={self.n_out}, uni={self.n_uni})")
         tabs = tr.graph.__dict__.get("tables", [])
+        if len(tabs) > _lib.GMX_MAX_TAB:
+            raise ValueError(f"site program exceeds the ABI slot limits (tables={len(tabs)} > {_lib.GMX_MAX_TAB}: "
+                             "launch-uniform vectors of more than 16 elements)")
         self.tables = []
         for t in tabs:
             if t is None:                      # runtime table: bound per launch (tab_plan)

@@ -1204,7 +1204,7 @@ class Scan:
         for t in range(n):
             if k is not None:
                 k = fold_in(k, t)
-            sub = chm.filter(lambda a: True).map_values(lambda v: _step_take(v, t, n, len(batch))) if chm is not None else None
+            sub = chm.filter(lambda a: True).map_values(lambda v: _step_take(v, t, n, len(batch), batch)) if chm is not None else None
             if mode == "simulate":
                 tr = self.kernel.simulate(k, (carry, self._x(xs, t)))
                 s = tr.get_score()
@@ -1238,11 +1238,13 @@ class Scan:
         return score, ret
 
 
-def _step_axis(a, n, bn):
+def _step_axis(a, n, bn, batch=None):
     """Which axis of `a` is the step / plate axis of length n: right after the bn batch axes for a per-particle value
     ([batch, n, *event] — the trailing axis when the site is scalar), the leading one for a launch-uniform table
     ([n, *event]); None when `a` does not carry it."""
     a = np.asarray(a)
+    if batch is not None and bn and a.ndim >= 1 and a.shape[0] == n and tuple(a.shape[:bn]) != tuple(batch):
+        return 0             # a launch-uniform table [n, ...] (it does not lead with the batch): its step axis is the first
     if a.ndim > bn and a.shape[bn] == n:
         return bn
     if a.ndim >= 1 and a.shape[0] == n:
@@ -1252,11 +1254,11 @@ def _step_axis(a, n, bn):
     return None
 
 
-def _step_take(v, idx, n, bn):
+def _step_take(v, idx, n, bn, batch=None):
     if isinstance(v, Mask):
-        return Mask(_step_take(v.value, idx, n, bn), _step_take(v.flag, idx, n, bn))
+        return Mask(_step_take(v.value, idx, n, bn, batch), _step_take(v.flag, idx, n, bn, batch))
     a = np.asarray(v)
-    ax = _step_axis(a, n, bn)
+    ax = _step_axis(a, n, bn, batch)
     return v if ax is None else np.take(a, idx, axis=ax)
 
 
@@ -1544,7 +1546,7 @@ def scan_edit(sc: "Scan", k, trace: "VmapTrace", args, update: ChoiceMap = None,
         if regenerate is not None:
             new, w, _ = sc.kernel.regenerate(k, sl, regenerate, a)
         else:
-            sub = update.map_values(lambda v: _step_take(v, t, n, len(batch)))
+            sub = update.map_values(lambda v: _step_take(v, t, n, len(batch), batch))
             new, w, _ = sc.kernel.update(k, sl, sub, a)
         carry, y = new.get_retval()
         slices.append(new)

@@ -1,0 +1,352 @@
+"""Random `@gen` models against the oracle (test infrastructure).
+
+One SPEC (a list of statements drawn from a small grammar: leaf sites, plates, scans, masked calls, masked plates,
+plates of scans, scans of plates — unrolled and loop sizes mixed) is built twice, with the product (`genjax_amd`) and with the
+oracle (`oracle/genjax_oracle.py`), and every GFI method is compared bit for bit under a batch of keys:
+simulate (score, return value, every choice), importance under a random subset of constraints, assess of the
+resulting choices, and `update` with a random subset of new constraints and randomly CHANGED arguments (the
+per-particle argument, a table, a vector of flags).  The reference paths restated by the oracle:
+static.py:255-466 (handlers), vmap.py:180-275, scan.py:200-503, mask.py:96-262."""
+import numpy as np
+import torch
+
+from oracle import genjax_oracle as O
+
+SMALL, LARGE = 3, 20          # unrolled / counted-loop sizes (the product switches at 16)
+
+
+# ---------------------------------------------------------------------------
+# spec
+# ---------------------------------------------------------------------------
+def random_spec(rng, n_stmts=None, allow_nested=True):
+    kinds = ["leaf", "leaf", "plate", "scan", "mask", "mplate"] + (["plate_of_scans", "scan_of_plates"] if allow_nested else [])
+    stmts = []
+    for i in range(n_stmts or int(rng.integers(2, 5))):
+        kind = kinds[int(rng.integers(len(kinds)))]
+        st = dict(kind=kind, name=f"s{i}", c1=float(np.float32(rng.uniform(-1.0, 1.0))), c2=float(np.float32(rng.uniform(-0.5, 0.5))),
+                  sd=float(np.float32(rng.uniform(0.5, 2.0))), src=["a", "prev"][int(rng.integers(2))])
+        if kind == "leaf":
+            st["dist"] = ["normal", "normal", "uniform", "flip"][int(rng.integers(4))]
+        if kind in ("plate", "mplate", "plate_of_scans"):
+            st["n"] = [SMALL, LARGE][int(rng.integers(2))]
+            st["two"] = bool(rng.integers(2))
+        if kind in ("scan", "scan_of_plates", "plate_of_scans"):
+            st["T"] = [SMALL, LARGE][int(rng.integers(2))]
+        if kind == "scan_of_plates":
+            st["n"] = SMALL + 1          # (not the scan's own length: a [T, n] constraint then says which axis is which)
+        if kind == "plate_of_scans" and st["n"] == LARGE and st["T"] == LARGE:
+            st["T"] = SMALL if rng.integers(2) else LARGE
+        if kind == "mask":
+            st["flag"] = ["arg", True, False][int(rng.integers(3))]
+        stmts.append(st)
+    return stmts
+
+
+def spec_args(spec, rng, B):
+    """(a [B] f32, per-statement extra arguments): a table per plate / scan, flags per masked statement"""
+    a = rng.normal(size=B).astype(np.float32)
+    extra = []
+    for st in spec:
+        k = st["kind"]
+        if k in ("plate", "plate_of_scans"):
+            extra.append(rng.normal(size=st["n"]).astype(np.float32))
+        elif k in ("scan", "scan_of_plates"):
+            extra.append(rng.normal(size=st["T"]).astype(np.float32))
+        elif k == "mplate":
+            extra.append(rng.random(st["n"]) < 0.6)
+            extra.append(rng.normal(size=st["n"]).astype(np.float32))
+        elif k == "mask" and st["flag"] == "arg":
+            extra.append(rng.random(B) < 0.5)
+    return a, extra
+
+
+# ---------------------------------------------------------------------------
+# the model, for either library
+# ---------------------------------------------------------------------------
+def build(g, spec, lit):
+    """`g`: genjax_amd or the oracle module; `lit`: a float literal in that library's arithmetic"""
+    def mul_add(v, c1, c2):
+        return v * lit(c1) + lit(c2)
+
+    def make_elem(st):
+        @g.gen
+        def elem(shared, x):
+            v = g.normal(shared + x, lit(st["sd"])) @ "v"
+            if st.get("two"):
+                u = g.normal(v * lit(st["c1"]), lit(1.5)) @ "u"
+                return u
+            return v
+        return elem
+
+    def make_step(st):
+        @g.gen
+        def step(c, x):
+            z = g.normal(c * lit(0.5) + x, lit(st["sd"])) @ "z"
+            return z, z
+        return step
+
+    def make_inner(st):
+        @g.gen
+        def inner(m):
+            y = g.normal(m, lit(st["sd"])) @ "y"
+            return y
+        return inner
+
+    def make_scan_elem(st):
+        step = make_step(st)
+
+        @g.gen
+        def elem(shared, x):
+            xs = _full(g, st["T"], lit)
+            cT, _ = g.Scan(step, st["T"])(shared + x, xs) @ "chain"
+            return cT
+        return elem
+
+    def make_plate_step(st):
+        elem = make_elem(dict(st, two=False))
+
+        @g.gen
+        def step(c, x):
+            vs = g.Vmap(elem, in_axes=(None, 0))(c * lit(0.5) + x, _ramp(g, st["n"], lit)) @ "row"
+            v0 = vs[..., 0] if g is O else vs[0]          # (the oracle keeps the plate axis last, behind the batch)
+            z = g.normal(v0 * lit(0.25) + c * lit(0.5), lit(st["sd"])) @ "z"
+            return z, z
+        return step
+    parts = []
+    for st in spec:
+        k = st["kind"]
+        parts.append(dict(st, fn={"plate": make_elem, "mplate": make_elem, "scan": make_step, "mask": make_inner,
+                                  "plate_of_scans": make_scan_elem, "scan_of_plates": make_plate_step}.get(k, lambda s: None)(st)))
+
+    @g.gen
+    def model(a, *extra):
+        prev = a
+        it = iter(extra)
+        for st in parts:
+            k, name = st["kind"], st["name"]
+            src = a if st["src"] == "a" else prev
+            m = mul_add(src, st["c1"], st["c2"])
+            if k == "leaf":
+                if st["dist"] == "normal":
+                    prev = g.normal(m, lit(st["sd"])) @ name
+                elif st["dist"] == "uniform":
+                    prev = g.uniform(m - lit(1.0), m + lit(2.0)) @ name
+                else:
+                    b = g.flip(lit(0.35)) @ name
+                    prev = _where(g, b, m, src)
+            elif k == "plate":
+                g.Vmap(st["fn"], in_axes=(None, 0))(m, next(it)) @ name      # (a loop plate's values live in memory only)
+                prev = m
+            elif k == "mplate":
+                flags, tab = next(it), next(it)
+                g.Vmap(g.MaskCombinator(st["fn"]), in_axes=(0, None, 0))(flags, m, tab) @ name
+            elif k == "scan":
+                cT, _ = g.Scan(st["fn"], st["T"])(m, next(it)) @ name
+                prev = cT
+            elif k == "mask":
+                flag = next(it) if st["flag"] == "arg" else st["flag"]
+                g.MaskCombinator(st["fn"])(flag, m) @ name
+            elif k == "plate_of_scans":
+                g.Vmap(st["fn"], in_axes=(None, 0))(m, next(it)) @ name
+                prev = m
+            elif k == "scan_of_plates":
+                cT, _ = g.Scan(st["fn"], st["T"])(m, next(it)) @ name
+                prev = cT
+        return prev
+    return model
+
+
+def _where(g, b, x, y):
+    if g is O:
+        return np.where(b, x, y).astype(np.float32)
+    from genjax_amd import numpy as jnp
+    return jnp.where(b, x, y)
+
+
+def _full(g, T, lit):
+    a = np.linspace(-0.5, 0.5, T).astype(np.float32)
+    if g is O:
+        return a
+    from genjax_amd import numpy as jnp
+    return jnp.array(a)
+
+
+def _ramp(g, n, lit):
+    a = np.linspace(0.0, 1.0, n).astype(np.float32)
+    if g is O:
+        return a
+    from genjax_amd import numpy as jnp
+    return jnp.array(a)
+
+
+# ---------------------------------------------------------------------------
+# addresses of a spec: (product path, oracle key, shape after the batch, dtype kind, masked?)
+# ---------------------------------------------------------------------------
+def addresses(spec):
+    out = []
+    for st in spec:
+        k, nm = st["kind"], st["name"]
+        if k == "leaf":
+            out.append(((nm,), (nm,), (), "b" if st["dist"] == "flip" else ("u" if st["dist"] == "uniform" else "f"), False, st))
+        elif k in ("plate", "mplate"):
+            out.append(((nm, "v"), (nm, "v"), (st["n"],), "f", k == "mplate", st))
+            if st.get("two"):
+                out.append(((nm, "u"), (nm, "u"), (st["n"],), "f", k == "mplate", st))
+        elif k == "scan":
+            out.append(((nm, "z"), (nm, "z"), (st["T"],), "f", False, st))
+        elif k == "mask":
+            out.append(((nm, "y"), (nm, "y"), (), "f", True, st))
+        elif k == "plate_of_scans":
+            out.append(((nm, "chain", "z"), (nm, "chain", "z"), (st["n"], st["T"]), "f", False, st))
+        elif k == "scan_of_plates":
+            out.append(((nm, "row", "v"), (nm, "row", "v"), (st["T"], st["n"]), "f", False, st))
+            out.append(((nm, "z"), (nm, "z"), (st["T"],), "f", False, st))
+    return out
+
+
+def _g_constraint(G, cons):
+    """launch-uniform values ([*shape] host arrays / Python floats) or one value per particle ([B, *shape] device tensors)"""
+    from genjax_amd import ChoiceMapBuilder as C, _lib, numpy as jnp
+    cm = C.n()
+    for (path, _, shape, kind, _, _), val in cons:
+        key = (path[0],) + (slice(None),) * len(shape) + tuple(path[1:]) if shape else path
+        if val.ndim > len(shape):
+            v = torch.from_numpy(np.ascontiguousarray(val)).to(_lib.get().device)
+        else:
+            v = jnp.array(val) if shape else float(val)
+        cm = cm | C[key].set(v)
+    return cm
+
+
+def _o_constraint(cons):
+    return O.C.d({okey: (val if val.ndim else np.float32(val)) for (_, okey, shape, _, _, _), val in cons}) if cons else O.ChoiceMap()
+
+
+def _pick_constraints(spec, rng, p, B):
+    cons = []
+    for ad in addresses(spec):
+        path, okey, shape, kind, masked, st = ad
+        if kind != "f" or rng.random() > p:
+            continue
+        per_particle = bool(rng.integers(2))
+        cons.append((ad, rng.normal(size=((B,) if per_particle else ()) + tuple(shape)).astype(np.float32)))
+    return cons
+
+
+# ---------------------------------------------------------------------------
+# one comparison
+# ---------------------------------------------------------------------------
+def _np(v):
+    return v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+
+
+def _choice(chm, path):
+    from genjax_amd.core.mask import Mask
+    v = chm[path]
+    return (_np(v.value), _np(v.flag)) if isinstance(v, Mask) else (_np(v), None)
+
+
+def _ochoice(chm, okey):
+    v = chm[okey]
+    return (np.asarray(v.value), np.asarray(v.flag)) if isinstance(v, O.Mask) else (np.asarray(v), None)
+
+
+def _same_choices(spec, tr, otr, B, what):
+    ch, och = tr.get_choices(), otr.get_choices()
+    for path, okey, shape, kind, masked, st in addresses(spec):
+        v, f = _choice(ch, path)
+        ov, of = _ochoice(och, okey)
+        assert np.array_equal(*np.broadcast_arrays(v, ov)), (what, path)      # (a launch-uniform constraint stays a scalar)
+        assert (f is None) == (of is None), (what, path, "masked on one side only")
+        if f is not None:
+            full = np.broadcast_shapes(v.shape, ov.shape, f.shape, of.shape)
+            lead = lambda x: x.reshape(x.shape + (1,) * (len(full) - x.ndim))
+            assert np.array_equal(np.broadcast_to(lead(f), full), np.broadcast_to(lead(of), full)), (what, path, "flags")
+
+
+class OverTheLimits(Exception):
+    """the drawn model does not fit one site program (64 launch slots, 8 tables, 64 live values)"""
+
+
+def run_one(seed, B=7, allow_nested=True, verbose=False):
+    from genjax_amd.program import ProgramTooLarge
+    try:
+        return _run_one(seed, B, allow_nested, verbose)
+    except ProgramTooLarge as e:
+        raise OverTheLimits(str(e)) from None
+    except ValueError as e:
+        if "exceeds the ABI slot limits" in str(e):
+            raise OverTheLimits(str(e)) from None
+        raise
+
+
+def _run_one(seed, B=7, allow_nested=True, verbose=False):
+    import genjax_amd as G
+    from genjax_amd import Diff, _lib, numpy as jnp
+    rng = np.random.default_rng(seed)
+    spec = random_spec(rng, allow_nested=allow_nested)
+    if verbose:
+        print(seed, [(s["kind"], s.get("n"), s.get("T"), s.get("dist"), s.get("flag")) for s in spec])
+    dev = _lib.get().device
+    model, omodel = build(G, spec, float), build(O, spec, np.float32)
+    a, extra = spec_args(spec, rng, B)
+
+    def g_args(a_, extra_):
+        out = [torch.from_numpy(a_).to(dev)]
+        for e in extra_:
+            out.append(torch.from_numpy(np.ascontiguousarray(e)).to(dev) if e.shape[:1] == (B,) and e.dtype == bool and e.ndim == 1
+                       and not _is_table(e, spec, B) else jnp.array(e))
+        return tuple(out)
+    k, ok = G.split(G.key(seed), B), O.split(O.key(seed), B)
+    tr, otr = model.simulate(k, g_args(a, extra)), omodel.simulate(ok, (a,) + tuple(extra))
+    assert np.array_equal(_np(tr.get_score()), otr.get_score()), (seed, "simulate score")
+    assert np.array_equal(_np(tr.get_retval()), np.broadcast_to(otr.get_retval(), (B,))), (seed, "simulate retval")
+    _same_choices(spec, tr, otr, B, (seed, "simulate"))
+    cons = _pick_constraints(spec, rng, 0.5, B)
+    tri, w = model.importance(k, _g_constraint(G, cons), g_args(a, extra))
+    otri, ow = omodel.importance(ok, _o_constraint(cons), (a,) + tuple(extra))
+    assert np.array_equal(_np(w), np.broadcast_to(ow, (B,))), (seed, "importance weight")
+    assert np.array_equal(_np(tri.get_score()), otri.get_score()), (seed, "importance score")
+    _same_choices(spec, tri, otri, B, (seed, "importance"))
+    s_, _ = model.assess(tri.get_choices(), g_args(a, extra))
+    assert np.array_equal(_np(s_), otri.get_score()), (seed, "assess")
+    # update: new constraints, changed arguments
+    cons2 = _pick_constraints(spec, rng, 0.35, B)
+    a2, extra2 = spec_args(spec, rng, B)
+    change = [bool(rng.integers(2)) for _ in range(1 + len(extra))]
+    new_a = a2 if change[0] else a
+    new_extra = [e2 if c else e for e, e2, c in zip(extra, extra2, change[1:])]
+    ga_old, ga_new = g_args(a, extra), g_args(new_a, new_extra)
+    diffs = tuple(Diff(n_, G.UnknownChange) if c else Diff.no_change(o_) for o_, n_, c in zip(ga_old, ga_new, change))
+    k2, ok2 = G.split(G.key(seed + 1000), B), O.split(O.key(seed + 1000), B)
+    new, wu, _, bwd = model.update(k2, tri, _g_constraint(G, cons2), diffs)
+    onew, owu, odis = omodel.update(ok2, otri, _o_constraint(cons2), (new_a,) + tuple(new_extra))
+    assert np.array_equal(_np(wu), np.broadcast_to(owu, (B,))), (seed, "update weight", change, [c[0][0] for c in cons2])
+    assert np.array_equal(_np(new.get_score()), onew.get_score()), (seed, "update score")
+    _same_choices(spec, new, onew, B, (seed, "update"))
+    for (path, okey, shape, kind, masked, st), _v in cons2:       # the discard: the old values of what was constrained
+        if st["kind"] in ("scan", "scan_of_plates", "plate_of_scans"):
+            continue                                   # (the oracle restates no discard for scans)
+        d, _f = _choice(bwd, path)
+        od, _of = _ochoice(odis, okey)
+        assert np.array_equal(*np.broadcast_arrays(d, od)), (seed, "discard", path)
+    # regenerate a random selection (Vmap.edit answers Update and IndexRequest only, vmap.py:342-362: models without plates)
+    if all(st["kind"] in ("leaf", "scan", "mask") for st in spec) and not any(st["kind"] == "mask" for st in spec):
+        from genjax_amd import Regenerate, SelectionBuilder as S
+        picked = [ad for ad in addresses(spec) if rng.random() < 0.5]
+        if picked:
+            sel = None
+            for path, *_ in picked:
+                sel = S[path] if sel is None else sel | S[path]
+            k3, ok3 = G.split(G.key(seed + 2000), B), O.split(O.key(seed + 2000), B)
+            rg, wr, _, _ = Regenerate(sel).edit(k3, tri, Diff.no_change(ga_old))
+            org, owr, _ = omodel.regenerate(ok3, otri, O.selection(*[okey for _, okey, *_ in picked]), (a,) + tuple(extra))
+            assert np.array_equal(_np(wr), np.broadcast_to(owr, (B,))), (seed, "regenerate weight")
+            assert np.array_equal(_np(rg.get_score()), org.get_score()), (seed, "regenerate score")
+            _same_choices(spec, rg, org, B, (seed, "regenerate"))
+    return spec
+
+
+def _is_table(e, spec, B):
+    """a boolean argument of length B that is a plate's flag TABLE (a masked plate of B elements), not per-particle flags"""
+    return any(st["kind"] == "mplate" and st["n"] == B for st in spec)

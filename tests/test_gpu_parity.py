@@ -1742,6 +1742,20 @@ def test_peer_mapped_exchange_between_two_processes_on_the_device(gpu, tmp_path,
     assert np.array_equal(x, ref["x"][ref["anc"]])
 
 
+def test_random_models_match_the_oracle_on_device(gpu):
+    """tests/fuzz_models.py on the HIP path: 40 random models on the interpreter (7 particles) and 8 through the
+    hiprtc-specialised programs (4099 particles), every GFI method bit for bit against the oracle"""
+    from tests import fuzz_models as F
+    ran = 0
+    for seed, B in [(s, 7) for s in range(1000, 1040)] + [(s, 4099) for s in range(2000, 2008)]:
+        try:
+            F.run_one(seed, B=B)
+            ran += 1
+        except F.OverTheLimits:
+            pass
+    assert ran >= 28, ran
+
+
 def test_update_under_a_changed_table_argument_on_device(gpu):
     """an UnknownChange argument that is a launch-uniform table (> 16 elements, read at a run-time index in the loop):
     every element re-scored — one plate, a plate of plates, a scan over a table, `means[idx]` (ref vmap.py:236-275)"""

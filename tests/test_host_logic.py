@@ -707,6 +707,21 @@ def test_large_plate_of_a_small_particle_batch_is_deferred():
     parity.check_deferred_plate(B=37, n=4096 * 2 + 3, seed=5)
 
 
+def test_random_models_match_the_oracle():
+    """tests/fuzz_models.py: 200 random `@gen` models (leaf sites, plates, scans, masked calls and plates, plates of
+    scans, scans of plates; unrolled and loop sizes mixed) — simulate / importance / assess / update under new
+    constraints and changed arguments / regenerate, bit for bit against the oracle"""
+    from tests import fuzz_models as F
+    ran = 0
+    for seed in range(200):
+        try:
+            F.run_one(seed)
+            ran += 1
+        except F.OverTheLimits:
+            pass
+    assert ran >= 120, ran
+
+
 def test_update_under_a_changed_table_argument_rescores_every_element():
     """ref vmap.py:236-275 / scan.py:417-503 with an UnknownChange argument that is a launch-uniform table of more than
     16 elements (read at a run-time index inside the loop): found stale in round 4 (weight 0) — one plate, a plate of

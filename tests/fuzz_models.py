@@ -153,6 +153,7 @@ def build(g, spec, lit):
                 cT, _ = g.Scan(st["fn"], st["T"])(m, next(it)) @ name
                 prev = cT
         return prev
+    model._fuzz_parts = parts
     return model
 
 
@@ -330,6 +331,31 @@ def _run_one(seed, B=7, allow_nested=True, verbose=False):
         d, _f = _choice(bwd, path)
         od, _of = _ochoice(odis, okey)
         assert np.array_equal(*np.broadcast_arrays(d, od)), (seed, "discard", path)
+    # IndexRequest on one plate / scan of the model (vmap.py:277-332, scan.py:325-416) through a StaticRequest
+    targets = [st for st in spec if st["kind"] in ("plate", "scan")]
+    if targets:
+        from genjax_amd import ChoiceMapBuilder as C, IndexRequest, StaticRequest, Update
+        st = targets[int(rng.integers(len(targets)))]
+        size = st["n"] if st["kind"] == "plate" else st["T"]
+        idx = int(rng.integers(size))
+        site = "v" if st["kind"] == "plate" else "z"
+        val = np.float32(rng.normal())
+        o_elem = next(p_ for p_ in _parts_of(omodel) if p_["name"] == st["name"])["fn"]
+
+        class _OIdx:
+            def edit(self, kk, subtrace, gen_fn, args_):
+                sub = O.C.d({(site,): val})
+                if st["kind"] == "plate":
+                    at = (args_[0], np.asarray(args_[1])[..., idx])
+                    return O.vmap_edit_index(gen_fn, kk, subtrace, idx, lambda k_, sl, a_: o_elem.update(k_, sl, sub, a_)[:2], at)
+                return O.scan_edit_index(gen_fn, kk, subtrace, args_, idx, lambda k_, sl, a_: o_elem.update(k_, sl, sub, a_)[:2])
+        k4, ok4 = G.split(G.key(seed + 3000), B), O.split(O.key(seed + 3000), B)
+        req = StaticRequest({st["name"]: IndexRequest(idx, Update(C[site].set(float(val))))})
+        ix, wx, _, _ = req.edit(k4, tri, Diff.no_change(ga_old))
+        oix, owx = omodel.edit_static(ok4, otri, {st["name"]: _OIdx(), (st["name"],): _OIdx()}, (a,) + tuple(extra))
+        assert np.array_equal(_np(wx), np.broadcast_to(owx, (B,))), (seed, "index request weight", st["kind"], size, idx)
+        assert np.array_equal(_np(ix.get_score()), oix.get_score()), (seed, "index request score")
+        _same_choices(spec, ix, oix, B, (seed, "index request"))
     # regenerate a random selection (Vmap.edit answers Update and IndexRequest only, vmap.py:342-362: models without plates)
     if all(st["kind"] in ("leaf", "scan", "mask") for st in spec) and not any(st["kind"] == "mask" for st in spec):
         from genjax_amd import Regenerate, SelectionBuilder as S
@@ -345,6 +371,10 @@ def _run_one(seed, B=7, allow_nested=True, verbose=False):
             assert np.array_equal(_np(rg.get_score()), org.get_score()), (seed, "regenerate score")
             _same_choices(spec, rg, org, B, (seed, "regenerate"))
     return spec
+
+
+def _parts_of(model):
+    return model._fuzz_parts
 
 
 def _is_table(e, spec, B):

@@ -1744,10 +1744,11 @@ def test_peer_mapped_exchange_between_two_processes_on_the_device(gpu, tmp_path,
 
 def test_random_models_match_the_oracle_on_device(gpu):
     """tests/fuzz_models.py on the HIP path: 40 random models on the interpreter (7 particles) and 8 through the
-    hiprtc-specialised programs (4099 particles), every GFI method bit for bit against the oracle"""
+    hiprtc-specialised programs (2^18 particles: engine.JIT_MIN_PARTICLES), every GFI method bit for bit against the
+    oracle"""
     from tests import fuzz_models as F
     ran = 0
-    for seed, B in [(s, 7) for s in range(1000, 1040)] + [(s, 4099) for s in range(2000, 2008)]:
+    for seed, B in [(s, 7) for s in range(1000, 1040)] + [(s, 1 << 18) for s in range(2000, 2008)]:
         try:
             F.run_one(seed, B=B)
             ran += 1

@@ -19,7 +19,7 @@ SMALL, LARGE = 3, 20          # unrolled / counted-loop sizes (the product switc
 # spec
 # ---------------------------------------------------------------------------
 def random_spec(rng, n_stmts=None, allow_nested=True):
-    kinds = ["leaf", "leaf", "plate", "scan", "mask", "mplate"] + (["plate_of_scans", "scan_of_plates"] if allow_nested else [])
+    kinds = ["leaf", "leaf", "call", "plate", "scan", "mask", "mplate"] + (["plate_of_scans", "scan_of_plates"] if allow_nested else [])
     stmts = []
     for i in range(n_stmts or int(rng.integers(2, 5))):
         kind = kinds[int(rng.integers(len(kinds)))]
@@ -30,8 +30,10 @@ def random_spec(rng, n_stmts=None, allow_nested=True):
         if kind in ("plate", "mplate", "plate_of_scans"):
             st["n"] = [SMALL, LARGE][int(rng.integers(2))]
             st["two"] = bool(rng.integers(2))
+            st["bern"] = bool(rng.integers(2)) and kind != "plate_of_scans"
         if kind in ("scan", "scan_of_plates", "plate_of_scans"):
             st["T"] = [SMALL, LARGE][int(rng.integers(2))]
+            st["bern"] = bool(rng.integers(2)) and kind == "scan"
         if kind == "scan_of_plates":
             st["n"] = SMALL + 1          # (not the scan's own length: a [T, n] constraint then says which axis is which)
         if kind == "plate_of_scans" and st["n"] == LARGE and st["T"] == LARGE:
@@ -71,7 +73,11 @@ def build(g, spec, lit):
     def make_elem(st):
         @g.gen
         def elem(shared, x):
-            v = g.normal(shared + x, lit(st["sd"])) @ "v"
+            if st.get("bern"):
+                b = g.flip(lit(0.4)) @ "b"
+                v = g.normal(_where(g, b, shared + x, shared - x), lit(st["sd"])) @ "v"
+            else:
+                v = g.normal(shared + x, lit(st["sd"])) @ "v"
             if st.get("two"):
                 u = g.normal(v * lit(st["c1"]), lit(1.5)) @ "u"
                 return u
@@ -81,9 +87,21 @@ def build(g, spec, lit):
     def make_step(st):
         @g.gen
         def step(c, x):
-            z = g.normal(c * lit(0.5) + x, lit(st["sd"])) @ "z"
+            if st.get("bern"):
+                b = g.flip(lit(0.4)) @ "b"
+                z = g.normal(_where(g, b, c * lit(0.5) + x, x - c), lit(st["sd"])) @ "z"
+            else:
+                z = g.normal(c * lit(0.5) + x, lit(st["sd"])) @ "z"
             return z, z
         return step
+
+    def make_call(st):
+        @g.gen
+        def sub(m):
+            p_ = g.normal(m, lit(st["sd"])) @ "p"
+            q_ = g.normal(p_ * lit(st["c1"]), lit(1.25)) @ "q"
+            return p_ + q_
+        return sub
 
     def make_inner(st):
         @g.gen
@@ -115,7 +133,7 @@ def build(g, spec, lit):
     parts = []
     for st in spec:
         k = st["kind"]
-        parts.append(dict(st, fn={"plate": make_elem, "mplate": make_elem, "scan": make_step, "mask": make_inner,
+        parts.append(dict(st, fn={"plate": make_elem, "mplate": make_elem, "scan": make_step, "mask": make_inner, "call": make_call,
                                   "plate_of_scans": make_scan_elem, "scan_of_plates": make_plate_step}.get(k, lambda s: None)(st)))
 
     @g.gen
@@ -134,6 +152,8 @@ def build(g, spec, lit):
                 else:
                     b = g.flip(lit(0.35)) @ name
                     prev = _where(g, b, m, src)
+            elif k == "call":
+                prev = st["fn"](m) @ name
             elif k == "plate":
                 g.Vmap(st["fn"], in_axes=(None, 0))(m, next(it)) @ name      # (a loop plate's values live in memory only)
                 prev = m
@@ -189,11 +209,18 @@ def addresses(spec):
         k, nm = st["kind"], st["name"]
         if k == "leaf":
             out.append(((nm,), (nm,), (), "b" if st["dist"] == "flip" else ("u" if st["dist"] == "uniform" else "f"), False, st))
+        elif k == "call":
+            out.append(((nm, "p"), (nm, "p"), (), "f", False, st))
+            out.append(((nm, "q"), (nm, "q"), (), "f", False, st))
         elif k in ("plate", "mplate"):
+            if st.get("bern"):
+                out.append(((nm, "b"), (nm, "b"), (st["n"],), "b", k == "mplate", st))
             out.append(((nm, "v"), (nm, "v"), (st["n"],), "f", k == "mplate", st))
             if st.get("two"):
                 out.append(((nm, "u"), (nm, "u"), (st["n"],), "f", k == "mplate", st))
         elif k == "scan":
+            if st.get("bern"):
+                out.append(((nm, "b"), (nm, "b"), (st["T"],), "b", False, st))
             out.append(((nm, "z"), (nm, "z"), (st["T"],), "f", False, st))
         elif k == "mask":
             out.append(((nm, "y"), (nm, "y"), (), "f", True, st))
@@ -210,6 +237,10 @@ def _g_constraint(G, cons):
     from genjax_amd import ChoiceMapBuilder as C, _lib, numpy as jnp
     cm = C.n()
     for (path, _, shape, kind, _, _), val in cons:
+        if isinstance(val, tuple):            # a SUBSET of a plate's / scan's elements: `C[name, idx_array, site]`
+            idx, vals = val
+            cm = cm | C[(path[0], idx) + tuple(path[1:])].set(vals)
+            continue
         key = (path[0],) + (slice(None),) * len(shape) + tuple(path[1:]) if shape else path
         if val.ndim > len(shape):
             v = torch.from_numpy(np.ascontiguousarray(val)).to(_lib.get().device)
@@ -220,7 +251,15 @@ def _g_constraint(G, cons):
 
 
 def _o_constraint(cons):
-    return O.C.d({okey: (val if val.ndim else np.float32(val)) for (_, okey, shape, _, _, _), val in cons}) if cons else O.ChoiceMap()
+    if not cons:
+        return O.ChoiceMap()
+    out = {}
+    for (_, okey, shape, _, _, _), val in cons:
+        if isinstance(val, tuple):
+            out[okey] = O.indexed(val[1], val[0], shape[0])
+        else:
+            out[okey] = val if val.ndim else np.float32(val)
+    return O.C.d(out)
 
 
 def _pick_constraints(spec, rng, p, B):
@@ -229,8 +268,13 @@ def _pick_constraints(spec, rng, p, B):
         path, okey, shape, kind, masked, st = ad
         if kind != "f" or rng.random() > p:
             continue
-        per_particle = bool(rng.integers(2))
-        cons.append((ad, rng.normal(size=((B,) if per_particle else ()) + tuple(shape)).astype(np.float32)))
+        form = int(rng.integers(3))
+        if form == 2 and len(shape) == 1 and not masked:
+            m_ = int(rng.integers(1, min(3, shape[0]) + 1))
+            idx = np.sort(rng.choice(shape[0], size=m_, replace=False))
+            cons.append((ad, (idx, rng.normal(size=m_).astype(np.float32))))
+            continue
+        cons.append((ad, rng.normal(size=((B,) if form == 1 else ()) + tuple(shape)).astype(np.float32)))
     return cons
 
 
@@ -326,8 +370,8 @@ def _run_one(seed, B=7, allow_nested=True, verbose=False):
     assert np.array_equal(_np(new.get_score()), onew.get_score()), (seed, "update score")
     _same_choices(spec, new, onew, B, (seed, "update"))
     for (path, okey, shape, kind, masked, st), _v in cons2:       # the discard: the old values of what was constrained
-        if st["kind"] in ("scan", "scan_of_plates", "plate_of_scans"):
-            continue                                   # (the oracle restates no discard for scans)
+        if st["kind"] in ("scan", "scan_of_plates", "plate_of_scans") or isinstance(_v, tuple):
+            continue                                   # (the oracle restates no discard for scans; a subset's is masked)
         d, _f = _choice(bwd, path)
         od, _of = _ochoice(odis, okey)
         assert np.array_equal(*np.broadcast_arrays(d, od)), (seed, "discard", path)

@@ -444,11 +444,26 @@ def same_args(a, b) -> bool:
         return False
 
 
+def _f32_args(v):
+    """Python floats among the arguments become float32 scalars: the model's own arithmetic on them (`a * 0.5 + 0.1`)
+    then runs in f32 on the host, as it does inside a site program and under the reference's jit (weak-typed Python
+    scalars meet f32 arrays) — in f64 it would differ from both in the last bit"""
+    if isinstance(v, float):
+        return np.float32(v)
+    if isinstance(v, tuple):
+        return tuple(_f32_args(x) for x in v)
+    if isinstance(v, list):
+        return [_f32_args(x) for x in v]
+    if isinstance(v, dict):
+        return {k: _f32_args(x) for k, x in v.items()}
+    return v
+
+
 def _run_source(gen_fn, handler, args):
     from . import static
     static._HANDLERS.append(handler)
     try:
-        return gen_fn.source(*args)
+        return gen_fn.source(*_f32_args(tuple(args)))
     finally:
         static._HANDLERS.pop()
 

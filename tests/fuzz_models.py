@@ -424,3 +424,95 @@ def _parts_of(model):
 def _is_table(e, spec, B):
     """a boolean argument of length B that is a plate's flag TABLE (a masked plate of B elements), not per-particle flags"""
     return any(st["kind"] == "mplate" and st["n"] == B for st in spec)
+
+
+def run_smc_one(seed, K=33):
+    """`ImportanceK(Target(model, args, constraints), K).run_smc(key)` (ref smc.py:298-315) of a random model under ONE
+    key: the K log-weights, the particles' scores and choices, the log-marginal-likelihood estimate (smc.py:95-96)."""
+    from genjax_amd.program import ProgramTooLarge
+    try:
+        return _run_smc_one(seed, K)
+    except ProgramTooLarge as e:
+        raise OverTheLimits(str(e)) from None
+    except ValueError as e:
+        if "exceeds the ABI slot limits" in str(e):
+            raise OverTheLimits(str(e)) from None
+        raise
+
+
+def _run_smc_one(seed, K):
+    import genjax_amd as G
+    from genjax_amd import numpy as jnp
+    from genjax_amd.inference.smc import ImportanceK
+    rng = np.random.default_rng(seed)
+    spec = [st for st in random_spec(rng) if not (st["kind"] == "mask" and st["flag"] == "arg")]     # (shared arguments only)
+    if not spec:
+        return None
+    model, omodel = build(G, spec, float), build(O, spec, np.float32)
+    a, extra = spec_args(spec, rng, 1)
+    a0 = np.float32(a[0])
+    cons = [c for c in _pick_constraints(spec, rng, 0.5, 1) if isinstance(c[1], tuple) or c[1].ndim == len(c[0][2])]
+    g_args = (float(a0),) + tuple(jnp.array(e) for e in extra)
+    tgt = G.Target(model, g_args, _g_constraint(G, cons))
+    otgt = O.Target(omodel, (a0,) + tuple(extra), _o_constraint(cons))
+    coll = ImportanceK(tgt, k_particles=K).run_smc(G.key(seed))
+    ocoll = O.ImportanceK(otgt, K).run_smc(O.key(seed))
+    assert np.array_equal(_np(coll.get_log_weights()), ocoll.get_log_weights()), (seed, "log weights")
+    assert np.array_equal(_np(coll.get_particles().get_score()), ocoll.get_particles().get_score()), (seed, "scores")
+    _same_choices(spec, coll.get_particles(), ocoll.get_particles(), K, (seed, "particles"))
+    lml, olml = float(_np(coll.get_log_marginal_likelihood_estimate())), float(ocoll.get_log_marginal_likelihood_estimate())
+    assert abs(lml - olml) <= 2e-6 * max(1.0, abs(olml)), (seed, "log ML", lml, olml)      # (f32 tree vs the oracle's f64 logsumexp)
+    return spec
+
+
+def run_big_one(seed, n_big=4099, K=65):
+    """a random model whose LAST statement is a plate of thousands of elements: ONE trace of it (an unbatched key: the
+    site-by-site path with the plate on the launch axis, sitewise.py) and `ImportanceK` over K particles (the plate
+    deferred: run after the program over particles x elements, combinators.Vmap._defer) — against the oracle"""
+    from genjax_amd.program import ProgramTooLarge
+    try:
+        return _run_big_one(seed, n_big, K)
+    except ProgramTooLarge as e:
+        raise OverTheLimits(str(e)) from None
+    except ValueError as e:
+        if "exceeds the ABI slot limits" in str(e):
+            raise OverTheLimits(str(e)) from None
+        raise
+
+
+def _run_big_one(seed, n_big, K):
+    import genjax_amd as G
+    from genjax_amd import Diff, numpy as jnp
+    from genjax_amd.inference.smc import ImportanceK
+    rng = np.random.default_rng(seed)
+    head = [st for st in random_spec(rng, n_stmts=int(rng.integers(1, 3)), allow_nested=False)
+            if st["kind"] in ("leaf", "call", "scan") and st.get("T", SMALL) == SMALL]
+    last = dict(kind="plate", name="big", c1=0.5, c2=0.1, sd=float(np.float32(rng.uniform(0.5, 2.0))), src="prev", n=n_big,
+                two=bool(rng.integers(2)), bern=bool(rng.integers(2)))
+    spec = head + [last]
+    model, omodel = build(G, spec, float), build(O, spec, np.float32)
+    a, extra = spec_args(spec, rng, 1)
+    a0 = np.float32(a[0])
+    g_args, o_args = (float(a0),) + tuple(jnp.array(e) for e in extra), (a0,) + tuple(extra)
+    obs = rng.normal(size=n_big).astype(np.float32)
+    site = "u" if last["two"] else "v"
+    cons = [(next(ad for ad in addresses(spec) if ad[0] == ("big", site)), obs)]
+    # ONE trace
+    tr, otr = model.simulate(G.key(seed), g_args), omodel.simulate(O.key(seed), o_args)
+    assert np.array_equal(_np(tr.get_score()), otr.get_score()), (seed, "one trace: simulate score")
+    _same_choices(spec, tr, otr, 1, (seed, "one trace: simulate"))
+    tri, w = model.importance(G.key(seed + 1), _g_constraint(G, cons), g_args)
+    otri, ow = omodel.importance(O.key(seed + 1), _o_constraint(cons), o_args)
+    assert np.array_equal(_np(w), ow) and np.array_equal(_np(tri.get_score()), otri.get_score()), (seed, "one trace: importance")
+    a2, extra2 = spec_args(spec, rng, 1)
+    new_args = (float(a2[0]),) + g_args[1:]
+    new, wu, _, _ = model.update(G.key(seed + 2), tri, _g_constraint(G, []), (Diff(new_args[0], G.UnknownChange),) +
+                                 tuple(Diff.no_change(x) for x in g_args[1:]))
+    onew, owu, _ = omodel.update(O.key(seed + 2), otri, O.ChoiceMap(), (np.float32(a2[0]),) + o_args[1:])
+    assert np.array_equal(_np(wu), owu) and np.array_equal(_np(new.get_score()), onew.get_score()), (seed, "one trace: update")
+    # K particles under one key: the plate deferred
+    coll = ImportanceK(G.Target(model, g_args, _g_constraint(G, cons)), k_particles=K).run_smc(G.key(seed + 3))
+    ocoll = O.ImportanceK(O.Target(omodel, o_args, _o_constraint(cons)), K).run_smc(O.key(seed + 3))
+    assert np.array_equal(_np(coll.get_log_weights()), ocoll.get_log_weights()), (seed, "K particles: log weights")
+    assert np.array_equal(_np(coll.get_particles().get_score()), ocoll.get_particles().get_score()), (seed, "K particles: scores")
+    return spec

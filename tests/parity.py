@@ -2918,8 +2918,9 @@ def check_mixture_notebook_model(n=5000, k=12, seed=0):
     @O.gen
     def o_data():
         clusters = O.Repeat(o_cluster, k)(np.float32(PRIOR_MEAN), np.float32(PRIOR_VARIANCE)) @ "clusters"
-        # (alpha / k is a Python-float division, as in the notebook; its f32 value multiplies the ones)
-        probs = O.dirichlet((np.float32(alpha / k) * np.ones(k, np.float32)).astype(np.float32)) @ "probs"
+        # (`alpha / n_clusters` inside the model: alpha arrives as an f32 scalar — the reference stages the source, a
+        #  Python float argument is a weak-typed f32 tracer there — so the division is an f32 one)
+        probs = O.dirichlet(((np.float32(alpha) / np.float32(k)) * np.ones(k, np.float32)).astype(np.float32)) @ "probs"
         return o_datapoints(probs, clusters) @ "datapoints"
     args = (Const(k), Const(n), alpha)
     f32 = lambda v: np.float32(v.item() if hasattr(v, "item") else v)

@@ -1755,6 +1755,14 @@ def test_random_models_match_the_oracle_on_device(gpu):
         except F.OverTheLimits:
             pass
     assert ran >= 28, ran
+    for seed in range(3000, 3030):
+        try:
+            F.run_smc_one(seed)
+        except F.OverTheLimits:
+            pass
+    for seed in range(4000, 4008):
+        F.run_big_one(seed)
+    F.run_big_one(4100, n_big=100_003, K=50)
 
 
 def test_update_under_a_changed_table_argument_on_device(gpu):

@@ -710,7 +710,8 @@ def test_large_plate_of_a_small_particle_batch_is_deferred():
 def test_random_models_match_the_oracle():
     """tests/fuzz_models.py: 200 random `@gen` models (leaf sites, plates, scans, masked calls and plates, plates of
     scans, scans of plates; unrolled and loop sizes mixed) — simulate / importance / assess / update under new
-    constraints and changed arguments / regenerate, bit for bit against the oracle"""
+    constraints and changed arguments / IndexRequest / regenerate; ImportanceK over such models; a plate of thousands of
+    elements as ONE trace and under K particles — bit for bit against the oracle"""
     from tests import fuzz_models as F
     ran = 0
     for seed in range(200):
@@ -720,6 +721,18 @@ def test_random_models_match_the_oracle():
         except F.OverTheLimits:
             pass
     assert ran >= 120, ran
+    # ImportanceK over a random model and random constraints under ONE key
+    ran = 0
+    for seed in range(100):
+        try:
+            F.run_smc_one(seed)
+            ran += 1
+        except F.OverTheLimits:
+            pass
+    assert ran >= 80, ran
+    # a plate of thousands of elements as the last statement: ONE trace (site by site) and K particles (deferred)
+    for seed in range(12):
+        F.run_big_one(seed)
 
 
 def test_update_under_a_changed_table_argument_rescores_every_element():

@@ -1801,6 +1801,8 @@ def run_edit(gen_fn, key: Key, trace: Trace, request: EditRequest, argdiffs, mh:
     ck = (_gfkey(gen_fn), "mh" if mh else "edit", atree, ptree, rkey, specs, tkey, len(batch), key is not None,
           na is not None)
     ent = _CACHE.get(ck)
+    if ent is _MH_UNFUSED:
+        return _run_mh_unfused(gen_fn, key, trace, request, argdiffs)
     if ent is None:
         tr = Tracing(len(batch))
         if na is not None:
@@ -1830,6 +1832,11 @@ def run_edit(gen_fn, key: Key, trace: Trace, request: EditRequest, argdiffs, mh:
             _bind_request_leaves(rspec, syms)
             rec, retval, w, _ = call_gen_fn(ctx, mode, gen_fn, kexpr, sargs, constraint, sprev, req, syms, ())
             ao = None
+            if mh and any(nd.op == "LOOP" for nd in tr.graph.nodes):
+                # sites written INSIDE a counted loop (a long scan, a large plate) are in memory before the move is
+                # accepted or refused: no selecting in registers — the move runs unfused (edit, accept, select)
+                _CACHE[ck] = _MH_UNFUSED
+                return _run_mh_unfused(gen_fn, key, trace, request, argdiffs)
             if mh:
                 from .distributions import uniform as _uniform
                 if w is None:
@@ -1864,6 +1871,41 @@ def run_edit(gen_fn, key: Key, trace: Trace, request: EditRequest, argdiffs, mh:
         bwd = request if isinstance(request, Rejuvenate) else Update(discard)
     retdiff = Diff.unknown_change(new_tr.get_retval())
     return new_tr, w, retdiff, bwd
+
+
+_MH_UNFUSED = ("mh, unfused",)      # cache entry of an MH call signature whose edit holds counted loops
+
+
+def _mh_accept(u, w):
+    from . import numpy as jnp
+    return jnp.log(u) < w
+
+
+def _run_mh_unfused(gen_fn, key, trace, request, argdiffs):
+    """run_mh as three launches — the edit with k_edit, the accept test log U(k_acc) < w, the per-particle select of
+    every leaf — with the same keys ((k_edit, k_acc) = split(particle key)) and the same arithmetic as the fused form"""
+    from .combinators import _trace_leaf_zip
+    from .distributions import uniform as _uniform
+    from .engine import elementwise
+    from .random import split
+    ks = split(key)
+    k_edit, k_acc = ks[0], ks[1]
+    new_tr, w, _, _ = run_edit(gen_fn, k_edit, trace, request, argdiffs)
+    batch = tuple(trace.batch_shape)
+    u = run_gfi(_uniform, "simulate", k_acc, (0.0, 1.0)).get_retval()
+    w = _broadcast_score(w, batch, _lib.get().device)
+    acc = elementwise(_mh_accept, u, w)
+
+    def pick(old, new):
+        old, new = materialize(old), materialize(new)
+        if not isinstance(new, torch.Tensor):
+            return new
+        if not isinstance(old, torch.Tensor):
+            old = torch.as_tensor(old, device=new.device).to(new.dtype).expand(new.shape)
+        a = acc.reshape(tuple(acc.shape) + (1,) * (new.dim() - acc.dim()))
+        return torch.where(a, new, old.to(new.dtype).expand(new.shape))
+    args = tuple(Diff.tree_primal(argdiffs)) if argdiffs is not None else tuple(trace.get_args() or ())
+    return _trace_leaf_zip(trace, new_tr, pick, args=args), acc, w
 
 
 def _static_bwd(request, otree, outs, leaves):

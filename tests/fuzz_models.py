@@ -401,8 +401,8 @@ def _run_one(seed, B=7, allow_nested=True, verbose=False):
         assert np.array_equal(_np(ix.get_score()), oix.get_score()), (seed, "index request score")
         _same_choices(spec, ix, oix, B, (seed, "index request"))
     # regenerate a random selection (Vmap.edit answers Update and IndexRequest only, vmap.py:342-362: models without plates)
-    if all(st["kind"] in ("leaf", "scan", "mask") for st in spec) and not any(st["kind"] == "mask" for st in spec):
-        from genjax_amd import Regenerate, SelectionBuilder as S
+    if all(st["kind"] in ("leaf", "scan", "call") for st in spec):
+        from genjax_amd import Regenerate, SelectionBuilder as S, static
         picked = [ad for ad in addresses(spec) if rng.random() < 0.5]
         if picked:
             sel = None
@@ -414,6 +414,15 @@ def _run_one(seed, B=7, allow_nested=True, verbose=False):
             assert np.array_equal(_np(wr), np.broadcast_to(owr, (B,))), (seed, "regenerate weight")
             assert np.array_equal(_np(rg.get_score()), org.get_score()), (seed, "regenerate score")
             _same_choices(spec, rg, org, B, (seed, "regenerate"))
+            # ... and as ONE fused Metropolis-Hastings move per particle (static.run_mh: propose, accept, select)
+            mh, acc, wm = static.run_mh(model, G.split(G.key(seed + 4000), B), tri, Regenerate(sel), Diff.no_change(ga_old))
+            osel = O.selection(*[okey for _, okey, *_ in picked])
+            omh, oacc, owm = O.rejuvenate(O.key(seed + 4000), otri,
+                                          lambda k_, tr_: omodel.regenerate(k_, tr_, osel, (a,) + tuple(extra))[:2])
+            assert np.array_equal(_np(acc), oacc), (seed, "MH accept")
+            assert np.array_equal(_np(wm), np.broadcast_to(owm, (B,))), (seed, "MH weight")
+            assert np.array_equal(_np(mh.get_score()), omh.get_score()), (seed, "MH score")
+            _same_choices(spec, mh, omh, B, (seed, "MH"))
     return spec
 
 

@@ -27,7 +27,7 @@ from ..core.choice_map import ChoiceMap
 from ..core.generative import Diff
 from ..engine import Gathered
 from ..random import Key, fold_in, lazy_split, split
-from ..static import DistributionTrace, StaticTrace
+from ..static import DistributionTrace, StaticTrace, VmapTrace
 from .sp import Algorithm, Target
 
 
@@ -54,9 +54,17 @@ def trace_map(tr, fn):
             return {k: leaf(x) for k, x in v.items()}
         return v
     if isinstance(tr, DistributionTrace):
-        return DistributionTrace(tr.gen_fn, leaf(tr.args), leaf(tr.value), leaf(tr.score))
-    return StaticTrace(tr.gen_fn, leaf(tr.args), leaf(tr.retval),
+        return DistributionTrace(tr.gen_fn, leaf(tr.args), leaf(engine.materialize(tr.value)), leaf(engine.materialize(tr.score)))
+    if isinstance(tr, VmapTrace):          # a plate / scan among the particle's sites: its own score and return value too
+        return VmapTrace(tr.gen_fn, trace_map(tr.inner, fn), leaf(engine.materialize(tr.score)),
+                         leaf(_materialize_tree(tr.retval)), leaf(tr.args))
+    return StaticTrace(tr.gen_fn, leaf(tr.args), leaf(_materialize_tree(tr.retval)),
                        OrderedDict((a, trace_map(s, fn)) for a, s in tr.subtraces.items()))
+
+
+def _materialize_tree(v):
+    from ..static import _tree_materialize
+    return _tree_materialize(v)
 
 
 def stack_traces(trs, tr_one, axis: int = 0):
@@ -85,6 +93,9 @@ def stack_traces(trs, tr_one, axis: int = 0):
     if isinstance(trs, DistributionTrace):
         return DistributionTrace(trs.gen_fn, leaf(trs.args, tr_one.args), leaf(trs.value, tr_one.value),
                                  leaf(trs.score, tr_one.score))
+    if isinstance(trs, VmapTrace):
+        return VmapTrace(trs.gen_fn, stack_traces(trs.inner, tr_one.inner, axis), leaf(engine.materialize(trs.score), tr_one.score),
+                         leaf(_materialize_tree(trs.retval), tr_one.retval), leaf(trs.args, tr_one.args))
     return StaticTrace(trs.gen_fn, leaf(trs.args, tr_one.args), leaf(trs.retval, tr_one.retval),
                        OrderedDict((a, stack_traces(s, tr_one.subtraces[a], axis)) for a, s in trs.subtraces.items()))
 

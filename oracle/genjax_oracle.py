@@ -1727,7 +1727,22 @@ def _tree_index(tr, idx):
         args = tuple(_index_leaf(a, idx, np.shape(tr.score)) for a in tr.args)
         return DistTrace(tr.gen_fn, args, _index_leaf(tr.value, idx, np.shape(tr.score)), tr.score[idx])
     n = np.shape(tr.get_score())
-    return StaticTrace(tr.gen_fn, tuple(_index_leaf(a, idx, n) for a in tr.args),
+    if isinstance(tr, MaskTrace):
+        return MaskTrace(tr.gen_fn, _tree_index(tr.inner, idx), _index_leaf(tr.check, idx, n),
+                         None if tr.ret is None else _index_leaf(tr.ret, idx, n))
+    if isinstance(tr, VmapTrace):            # a plate / scan: its leaves lead with the particle axis like any other
+        def walk(t):
+            if isinstance(t, DistTrace):
+                return DistTrace(t.gen_fn, t.args, _index_leaf(t.value, idx, n), _index_leaf(t.score, idx, n))
+            if isinstance(t, MaskTrace):
+                return MaskTrace(t.gen_fn, walk(t.inner), _index_leaf(t.check, idx, n),
+                                 None if t.ret is None else _index_leaf(t.ret, idx, n))
+            if isinstance(t, VmapTrace):
+                return VmapTrace(t.gen_fn, walk(t.inner), _index_leaf(t.score, idx, n), _index_leaf(t.retval, idx, n))
+            return StaticTrace(t.gen_fn, t.args, _index_leaf(t.retval, idx, n),
+                               OrderedDict((a_, walk(s_)) for a_, s_ in t.subtraces.items()))
+        return walk(tr)
+    return StaticTrace(tr.gen_fn, tuple(_index_leaf(a, idx, n) for a in (tr.args or ())),
                        _index_leaf(tr.retval, idx, n),
                        OrderedDict((a, _tree_index(s, idx)) for a, s in tr.subtraces.items()))
 
@@ -1735,6 +1750,8 @@ def _tree_index(tr, idx):
 def _index_leaf(v, idx, batch):
     if v is None:
         return None
+    if isinstance(v, Mask):
+        return Mask(_index_leaf(v.value, idx, batch), _index_leaf(v.flag, idx, batch))
     if isinstance(v, tuple):
         return tuple(_index_leaf(x, idx, batch) for x in v)
     a = np.asarray(v)

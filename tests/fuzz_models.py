@@ -423,6 +423,20 @@ def _run_one(seed, B=7, allow_nested=True, verbose=False):
             assert np.array_equal(_np(wm), np.broadcast_to(owm, (B,))), (seed, "MH weight")
             assert np.array_equal(_np(mh.get_score()), omh.get_score()), (seed, "MH score")
             _same_choices(spec, mh, omh, B, (seed, "MH"))
+    leaves = [st for st in spec if st["kind"] == "leaf" and st["dist"] == "normal"]
+    if leaves and all(st["kind"] in ("leaf", "scan", "call") for st in spec):
+        from genjax_amd import Rejuvenate, StaticRequest, static
+        st = leaves[int(rng.integers(len(leaves)))]
+        sd = float(np.float32(rng.uniform(0.2, 1.0)))
+        req = StaticRequest({st["name"]: Rejuvenate(G.normal, lambda chm: (chm.get_value(), sd))})
+        oreq = {st["name"]: O.Rejuvenate(O.normal, lambda chm: (chm.get_value(), np.float32(sd)))}
+        mh, acc, wm = static.run_mh(model, G.split(G.key(seed + 5000), B), tri, req, Diff.no_change(ga_old))
+        omh, oacc, owm = O.rejuvenate(O.key(seed + 5000), otri,
+                                      lambda k_, tr_: omodel.edit_static(k_, tr_, oreq, (a,) + tuple(extra)))
+        assert np.array_equal(_np(acc), oacc), (seed, "Rejuvenate accept")
+        assert np.array_equal(_np(wm), np.broadcast_to(owm, (B,))), (seed, "Rejuvenate weight")
+        assert np.array_equal(_np(mh.get_score()), omh.get_score()), (seed, "Rejuvenate score")
+        _same_choices(spec, mh, omh, B, (seed, "Rejuvenate"))
     return spec
 
 
@@ -471,6 +485,16 @@ def _run_smc_one(seed, K):
     _same_choices(spec, coll.get_particles(), ocoll.get_particles(), K, (seed, "particles"))
     lml, olml = float(_np(coll.get_log_marginal_likelihood_estimate())), float(ocoll.get_log_marginal_likelihood_estimate())
     assert abs(lml - olml) <= 2e-6 * max(1.0, abs(olml)), (seed, "log ML", lml, olml)      # (f32 tree vs the oracle's f64 logsumexp)
+    # resample the collection (a random scheme): the ancestors, and every leaf of the structured traces gathered
+    from genjax_amd.inference import smc
+    kind = ["systematic", "stratified", "multinomial"][int(rng.integers(3))]
+    res = smc.resample(G.key(seed + 7), coll, kind)
+    cdf, total, M, shift = O.weight_cdf(ocoll.get_log_weights())
+    anc = O.ancestors({"systematic": O.SYSTEMATIC, "stratified": O.STRATIFIED, "multinomial": O.MULTINOMIAL}[kind], O.key(seed + 7), cdf)
+    assert np.array_equal(_np(res.ancestors), anc), (seed, "ancestors", kind)
+    ores = O.gather_trace(ocoll.get_particles(), anc)
+    assert np.array_equal(_np(res.get_particles().get_score()), ores.get_score()), (seed, "resampled scores")
+    _same_choices(spec, res.get_particles(), ores, K, (seed, "resampled particles"))
     return spec
 
 

@@ -393,11 +393,22 @@ def _run_one(seed, B=7, allow_nested=True, verbose=False):
                     at = (args_[0], np.asarray(args_[1])[..., idx])
                     return O.vmap_edit_index(gen_fn, kk, subtrace, idx, lambda k_, sl, a_: o_elem.update(k_, sl, sub, a_)[:2], at)
                 return O.scan_edit_index(gen_fn, kk, subtrace, args_, idx, lambda k_, sl, a_: o_elem.update(k_, sl, sub, a_)[:2])
+        per_particle = st["kind"] == "plate" and bool(rng.integers(2))
+        if per_particle:                      # one index per particle (a traced idx under the reference's vmap)
+            idx = rng.integers(size, size=B).astype(np.int32)
+
+            class _OIdx:                       # noqa: F811
+                def edit(self, kk, subtrace, gen_fn, args_):
+                    sub = O.C.d({(site,): val})
+                    return O.vmap_edit_index_per_particle(
+                        gen_fn, kk, subtrace, idx, lambda k_, sl, a_: o_elem.update(k_, sl, sub, a_)[:2],
+                        lambda j: (args_[0], np.asarray(args_[1])[..., j]))
+            idx = torch.from_numpy(idx).to(dev)
         k4, ok4 = G.split(G.key(seed + 3000), B), O.split(O.key(seed + 3000), B)
         req = StaticRequest({st["name"]: IndexRequest(idx, Update(C[site].set(float(val))))})
         ix, wx, _, _ = req.edit(k4, tri, Diff.no_change(ga_old))
         oix, owx = omodel.edit_static(ok4, otri, {st["name"]: _OIdx(), (st["name"],): _OIdx()}, (a,) + tuple(extra))
-        assert np.array_equal(_np(wx), np.broadcast_to(owx, (B,))), (seed, "index request weight", st["kind"], size, idx)
+        assert np.array_equal(_np(wx), np.broadcast_to(owx, (B,))), (seed, "index request weight", st["kind"], size, per_particle)
         assert np.array_equal(_np(ix.get_score()), oix.get_score()), (seed, "index request score")
         _same_choices(spec, ix, oix, B, (seed, "index request"))
     # regenerate a random selection (Vmap.edit answers Update and IndexRequest only, vmap.py:342-362: models without plates)

@@ -41,6 +41,30 @@ def torch_from_host(v, device):
                                                  (v.astype(np.int32) if v.dtype.kind in "iu" else v))).to(device)
 
 
+_FORCE_LOOPS = False      # static.run_gfi / run_edit retrace a program that does not fit the launch slots with every
+                          # top-level plate / scan as a counted loop (one slot per leaf whatever the length)
+
+
+class forced_loops:
+    def __init__(self, on: bool):
+        self.on = bool(on)
+
+    def __enter__(self):
+        global _FORCE_LOOPS
+        self.keep, _FORCE_LOOPS = _FORCE_LOOPS, self.on
+        return self
+
+    def __exit__(self, *exc):
+        global _FORCE_LOOPS
+        _FORCE_LOOPS = self.keep
+        return False
+
+
+def _forced(ctx, n) -> bool:
+    g = ctx.tr.graph
+    return _FORCE_LOOPS and n > 1 and not getattr(g, "_in_loop", False) and not g.loop_counts
+
+
 class _NoDefer(Exception):
     pass
 
@@ -381,7 +405,7 @@ class Vmap(GenerativeFunction):
             from .sitewise import NeedsSiteBySite
             raise NeedsSiteBySite()
         nested = isinstance(self.gen_fn, (Vmap, Scan, _ScanAdapter)) and n > 4 and not getattr(ctx.tr.graph, "_in_loop", False)
-        if n > VMAP_UNROLL_MAX or nested:
+        if n > VMAP_UNROLL_MAX or nested or _forced(ctx, n):
             return self._trace_loop(ctx, mode, key, args, axes, constraint, n, req_leaves, addr)
         from .static import _rec_score
         g = ctx.tr.graph
@@ -669,7 +693,7 @@ class Vmap(GenerativeFunction):
         inner_prev = prev["vmap"] if "vmap" in prev else prev
         # a small plate whose ELEMENTS ran a counted loop (its previous values are [n, A, T] step leaves): the edit runs
         # the plate as a loop around the elements' loops, as a large one does
-        if n > VMAP_UNROLL_MAX or (_has_step_rows(inner_prev) and not ctx.tr.graph.loop_counts):
+        if n > VMAP_UNROLL_MAX or (_has_step_rows(inner_prev) and not ctx.tr.graph.loop_counts) or _forced(ctx, n):
             return self._trace_edit_loop(ctx, kind if kind != "empty" else "update", key, args, axes, constraint,
                                          inner_prev, req, n, req_leaves, addr)
         g = ctx.tr.graph
@@ -1420,7 +1444,7 @@ class Scan(GenerativeFunction):
             if mode in ("simulate", "assess"):
                 return out, out.retval, None, 0.0
             return out, out.retval, 0.0, None
-        if n > getattr(self, "unroll_max", SCAN_UNROLL_MAX):
+        if n > getattr(self, "unroll_max", SCAN_UNROLL_MAX) or _forced(ctx, n):
             return self._trace_loop(ctx, mode, key, carry, scanned_in, constraint, n, req_leaves, addr)
         g = ctx.tr.graph
         keep = ctx.store_sites
@@ -1639,7 +1663,7 @@ class Scan(GenerativeFunction):
         carry, scanned_in = args
         n = self._length(scanned_in)
         inner_prev = prev["vmap"] if "vmap" in prev else prev
-        if n > getattr(self, "unroll_max", SCAN_UNROLL_MAX):
+        if n > getattr(self, "unroll_max", SCAN_UNROLL_MAX) or _forced(ctx, n):
             return self._trace_edit_loop(ctx, sub_mode, key, carry, scanned_in, constraint, inner_prev, req, kind, n,
                                          req_leaves, addr)
         g = ctx.tr.graph

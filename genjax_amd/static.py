@@ -1369,9 +1369,12 @@ def run_gfi(gen_fn, mode, key: Key | None, args, constraint: ChoiceMap | None = 
         except DeferralAbort:
             _NO_DEFER.add(ck)
             ent = None
-    if ent is None:
+    first_error = None
+    while ent is None:
+        # (second pass, when the program did not fit the launch slots / registers: top-level plates and scans as loops)
+        force = first_error is not None
         tr = Tracing(len(batch))
-        tr.step_leaf_min = getattr(gen_fn, "step_leaf_min", tr.step_leaf_min)
+        tr.step_leaf_min = 0 if force else getattr(gen_fn, "step_leaf_min", tr.step_leaf_min)
         if na is not None:
             from .engine import NoiseHoist
             tr.graph.noise_hoist = NoiseHoist(tr, len(specs))
@@ -1382,23 +1385,32 @@ def run_gfi(gen_fn, mode, key: Key | None, args, constraint: ChoiceMap | None = 
         ctx.sitewise = (len(batch) == 0 and isinstance(gen_fn, StaticGenerativeFunction) and not weight_stats and na is None
                         and (key is None or tuple(key.shape) == ()))
         try:
+            from .combinators import forced_loops
+            try:
+                with T.tracing(tr.graph), forced_loops(force):
+                    syms = [tr.sym_leaf(s, j) for j, s in enumerate(specs)]
+                    sargs = unflatten(atree, lambda j: syms[j].value)
+                    scon = _sym_constraint(ctree, syms)
+                    kexpr = Expr(tr.graph.add("LDKEY", dtype="key")) if key is not None else None
+                    rec, retval, w, s = call_gen_fn(ctx, mode, gen_fn, kexpr, sargs, scon, None, None, None, ())
+            except sitewise.NeedsSiteBySite:
+                _CACHE[ck] = _SITE_BY_SITE
+                return sitewise.run_gfi(gen_fn, mode, key, args, constraint)
             with T.tracing(tr.graph):
-                syms = [tr.sym_leaf(s, j) for j, s in enumerate(specs)]
-                sargs = unflatten(atree, lambda j: syms[j].value)
-                scon = _sym_constraint(ctree, syms)
-                kexpr = Expr(tr.graph.add("LDKEY", dtype="key")) if key is not None else None
-                rec, retval, w, s = call_gen_fn(ctx, mode, gen_fn, kexpr, sargs, scon, None, None, None, ())
-        except sitewise.NeedsSiteBySite:
-            _CACHE[ck] = _SITE_BY_SITE
-            return sitewise.run_gfi(gen_fn, mode, key, args, constraint)
-        with T.tracing(tr.graph):
-            otree = _emit_rec(tr, rec) if mode != "assess" else None
-            wo = tr.emit_output(w) if (mode == "generate" and w is not None) else None
-            so = tr.emit_output(s) if mode == "assess" else None
-            ro = tr.emit_output(retval) if mode == "assess" else None
-            if weight_stats and isinstance(w, Expr) and w.node.op != "CONST":
-                tr.graph.add("REDMAX", (w.node,), dtype="none")
-        ent = (Compiled(tr), otree, wo, so, ro) + (_noise_split(tr, batch, na) if na is not None else ((), None)) + ((),)
+                otree = _emit_rec(tr, rec) if mode != "assess" else None
+                wo = tr.emit_output(w) if (mode == "generate" and w is not None) else None
+                so = tr.emit_output(s) if mode == "assess" else None
+                ro = tr.emit_output(retval) if mode == "assess" else None
+                if weight_stats and isinstance(w, Expr) and w.node.op != "CONST":
+                    tr.graph.add("REDMAX", (w.node,), dtype="none")
+            ent = (Compiled(tr), otree, wo, so, ro) + (_noise_split(tr, batch, na) if na is not None else ((), None)) + ((),)
+        except Exception as e:      # noqa: BLE001
+            if force:
+                raise first_error from None        # the loop form does not fit (or apply) either: the first report stands
+            if not _over_the_slots(e):
+                raise
+            first_error = e
+            continue
         _CACHE[ck] = ent
     comp, otree, wo, so, ro, draws, nprog, plates = ent
     leaves = flat.leaves + (na.draw(nprog, batch, key, len(draws), mode) if nprog is not None else [])
@@ -1803,15 +1815,48 @@ def run_edit(gen_fn, key: Key, trace: Trace, request: EditRequest, argdiffs, mh:
     ent = _CACHE.get(ck)
     if ent is _MH_UNFUSED:
         return _run_mh_unfused(gen_fn, key, trace, request, argdiffs)
-    if ent is None:
+    first_error = None
+    while ent is None:
+        force = first_error is not None        # (second pass: see run_gfi)
+        try:
+            ent = _trace_edit(gen_fn, key, trace, request, argdiffs, mh, na, specs, batch, atree, ptree, rspec, tangents, ck,
+                              force)
+        except _Unfused:
+            return _run_mh_unfused(gen_fn, key, trace, request, argdiffs)
+        except Exception as e:      # noqa: BLE001
+            if force:
+                raise first_error from None
+            if not _over_the_slots(e):
+                raise
+            first_error = e
+            continue
+        _CACHE[ck] = ent
+    comp, otree, wo, ao, draws, nprog = ent
+    outs = comp.run(flat.leaves + (na.draw(nprog, batch, key, len(draws), "mh") if nprog is not None else []), batch, key)
+    return _finish_edit(request, mh, otree, wo, ao, outs, flat, args, batch, be)
+
+
+class _Unfused(Exception):
+    pass
+
+
+def _over_the_slots(e) -> bool:
+    from .program import ProgramTooLarge
+    return isinstance(e, ProgramTooLarge) or (isinstance(e, ValueError) and "exceeds the ABI slot limits (in=" in str(e))
+
+
+def _trace_edit(gen_fn, key, trace, request, argdiffs, mh, na, specs, batch, atree, ptree, rspec, tangents, ck, force):
+    """run_edit's tracing step -> the cache entry"""
+    if True:
+        from .combinators import forced_loops
         tr = Tracing(len(batch))
         if na is not None:
             from .engine import NoiseHoist
             tr.graph.noise_hoist = NoiseHoist(tr, len(specs))
         ctx = _Ctx(tr)
         ctx.store_sites = not mh
-        tr.step_leaf_min = getattr(gen_fn, "step_leaf_min", tr.step_leaf_min)
-        with T.tracing(tr.graph):
+        tr.step_leaf_min = 0 if force else getattr(gen_fn, "step_leaf_min", tr.step_leaf_min)
+        with T.tracing(tr.graph), forced_loops(force):
             syms = [tr.sym_leaf(s, j) for j, s in enumerate(specs)]
             sargs = unflatten(atree, lambda j: syms[j].value)
             # arguments flagged as changed seed the change set
@@ -1836,7 +1881,7 @@ def run_edit(gen_fn, key: Key, trace: Trace, request: EditRequest, argdiffs, mh:
                 # sites written INSIDE a counted loop (a long scan, a large plate) are in memory before the move is
                 # accepted or refused: no selecting in registers — the move runs unfused (edit, accept, select)
                 _CACHE[ck] = _MH_UNFUSED
-                return _run_mh_unfused(gen_fn, key, trace, request, argdiffs)
+                raise _Unfused()
             if mh:
                 from .distributions import uniform as _uniform
                 if w is None:
@@ -1848,10 +1893,10 @@ def run_edit(gen_fn, key: Key, trace: Trace, request: EditRequest, argdiffs, mh:
             else:
                 otree = _emit_rec(tr, rec)
             wo = tr.emit_output(w) if w is not None else None
-        ent = (Compiled(tr), otree, wo, ao) + (_noise_split(tr, batch, na) if na is not None else ((), None))
-        _CACHE[ck] = ent
-    comp, otree, wo, ao, draws, nprog = ent
-    outs = comp.run(flat.leaves + (na.draw(nprog, batch, key, len(draws), "mh") if nprog is not None else []), batch, key)
+        return (Compiled(tr), otree, wo, ao) + (_noise_split(tr, batch, na) if na is not None else ((), None))
+
+
+def _finish_edit(request, mh, otree, wo, ao, outs, flat, args, batch, be):
     new_tr = _build_trace(otree, outs, flat.leaves, args)
     w = resolve(wo, outs, flat.leaves) if wo is not None else 0.0
     w = _broadcast_score(w, batch, be.device)

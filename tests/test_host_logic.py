@@ -720,7 +720,7 @@ def test_random_models_match_the_oracle():
             ran += 1
         except F.OverTheLimits:
             pass
-    assert ran >= 120, ran
+    assert ran >= 180, ran      # (a model that does not fit the launch slots unrolled is retraced with loops: few are left over)
     # ImportanceK over a random model and random constraints under ONE key
     ran = 0
     for seed in range(100):

@@ -395,15 +395,15 @@ def _run_one(seed, B=7, allow_nested=True, verbose=False):
                 return O.scan_edit_index(gen_fn, kk, subtrace, args_, idx, lambda k_, sl, a_: o_elem.update(k_, sl, sub, a_)[:2])
         per_particle = st["kind"] == "plate" and bool(rng.integers(2))
         if per_particle:                      # one index per particle (a traced idx under the reference's vmap)
-            idx = rng.integers(size, size=B).astype(np.int32)
+            idx_host = rng.integers(size, size=B).astype(np.int32)
 
             class _OIdx:                       # noqa: F811
                 def edit(self, kk, subtrace, gen_fn, args_):
                     sub = O.C.d({(site,): val})
                     return O.vmap_edit_index_per_particle(
-                        gen_fn, kk, subtrace, idx, lambda k_, sl, a_: o_elem.update(k_, sl, sub, a_)[:2],
+                        gen_fn, kk, subtrace, idx_host, lambda k_, sl, a_: o_elem.update(k_, sl, sub, a_)[:2],
                         lambda j: (args_[0], np.asarray(args_[1])[..., j]))
-            idx = torch.from_numpy(idx).to(dev)
+            idx = torch.from_numpy(idx_host).to(dev)
         k4, ok4 = G.split(G.key(seed + 3000), B), O.split(O.key(seed + 3000), B)
         req = StaticRequest({st["name"]: IndexRequest(idx, Update(C[site].set(float(val))))})
         ix, wx, _, _ = req.edit(k4, tri, Diff.no_change(ga_old))

@@ -26,7 +26,7 @@ def random_spec(rng, n_stmts=None, allow_nested=True):
         st = dict(kind=kind, name=f"s{i}", c1=float(np.float32(rng.uniform(-1.0, 1.0))), c2=float(np.float32(rng.uniform(-0.5, 0.5))),
                   sd=float(np.float32(rng.uniform(0.5, 2.0))), src=["a", "prev"][int(rng.integers(2))])
         if kind == "leaf":
-            st["dist"] = ["normal", "normal", "uniform", "flip"][int(rng.integers(4))]
+            st["dist"] = ["normal", "normal", "uniform", "flip", "beta", "categorical", "bernoulli"][int(rng.integers(7))]
         if kind in ("plate", "mplate", "plate_of_scans"):
             st["n"] = [SMALL, LARGE][int(rng.integers(2))]
             st["two"] = bool(rng.integers(2))
@@ -149,6 +149,15 @@ def build(g, spec, lit):
                     prev = g.normal(m, lit(st["sd"])) @ name
                 elif st["dist"] == "uniform":
                     prev = g.uniform(m - lit(1.0), m + lit(2.0)) @ name
+                elif st["dist"] == "beta":
+                    p_ = g.beta(m * m + lit(1.5), lit(2.5)) @ name
+                    prev = p_ * lit(2.0) + src
+                elif st["dist"] == "categorical":
+                    i_ = g.categorical(logits=_stack3(g, m, lit)) @ name
+                    prev = _where(g, i_ == 1, m, src)
+                elif st["dist"] == "bernoulli":
+                    b = g.bernoulli(logits=m) @ name
+                    prev = _where(g, b, src, m)
                 else:
                     b = g.flip(lit(0.35)) @ name
                     prev = _where(g, b, m, src)
@@ -184,6 +193,15 @@ def _where(g, b, x, y):
     return jnp.where(b, x, y)
 
 
+def _stack3(g, m, lit):
+    """the logits [m, 0, -m] of a three-way categorical, per particle"""
+    if g is O:
+        m = np.asarray(m, np.float32)
+        return np.stack([m, np.zeros_like(m), (-m).astype(np.float32)], axis=-1)
+    from genjax_amd import numpy as jnp
+    return jnp.stack([m, m * 0.0, -m])
+
+
 def _full(g, T, lit):
     a = np.linspace(-0.5, 0.5, T).astype(np.float32)
     if g is O:
@@ -208,7 +226,8 @@ def addresses(spec):
     for st in spec:
         k, nm = st["kind"], st["name"]
         if k == "leaf":
-            out.append(((nm,), (nm,), (), "b" if st["dist"] == "flip" else ("u" if st["dist"] == "uniform" else "f"), False, st))
+            kind_ = {"flip": "b", "bernoulli": "b", "uniform": "u", "beta": "u", "categorical": "i"}.get(st["dist"], "f")
+            out.append(((nm,), (nm,), (), kind_, False, st))
         elif k == "call":
             out.append(((nm, "p"), (nm, "p"), (), "f", False, st))
             out.append(((nm, "q"), (nm, "q"), (), "f", False, st))

@@ -19,7 +19,7 @@ SMALL, LARGE = 3, 20          # unrolled / counted-loop sizes (the product switc
 # spec
 # ---------------------------------------------------------------------------
 def random_spec(rng, n_stmts=None, allow_nested=True):
-    kinds = ["leaf", "leaf", "call", "plate", "scan", "mask", "mplate"] + (["plate_of_scans", "scan_of_plates"] if allow_nested else [])
+    kinds = ["leaf", "leaf", "call", "plate", "scan", "mask", "mplate", "mscan"] + (["plate_of_scans", "scan_of_plates"] if allow_nested else [])
     stmts = []
     for i in range(n_stmts or int(rng.integers(2, 5))):
         kind = kinds[int(rng.integers(len(kinds)))]
@@ -31,7 +31,7 @@ def random_spec(rng, n_stmts=None, allow_nested=True):
             st["n"] = [SMALL, LARGE][int(rng.integers(2))]
             st["two"] = bool(rng.integers(2))
             st["bern"] = bool(rng.integers(2)) and kind != "plate_of_scans"
-        if kind in ("scan", "scan_of_plates", "plate_of_scans"):
+        if kind in ("scan", "scan_of_plates", "plate_of_scans", "mscan"):
             st["T"] = [SMALL, LARGE][int(rng.integers(2))]
             st["bern"] = bool(rng.integers(2)) and kind == "scan"
         if kind == "scan_of_plates":
@@ -54,6 +54,8 @@ def spec_args(spec, rng, B):
             extra.append(rng.normal(size=st["n"]).astype(np.float32))
         elif k in ("scan", "scan_of_plates"):
             extra.append(rng.normal(size=st["T"]).astype(np.float32))
+        elif k == "mscan":
+            extra.append(np.arange(st["T"]) < int(rng.integers(0, st["T"] + 1)))
         elif k == "mplate":
             extra.append(rng.random(st["n"]) < 0.6)
             extra.append(rng.normal(size=st["n"]).astype(np.float32))
@@ -95,6 +97,13 @@ def build(g, spec, lit):
             return z, z
         return step
 
+    def make_mstep(st):
+        @g.gen
+        def mstep(x):
+            z = g.normal(x * lit(0.5), lit(st["sd"])) @ "z"
+            return z
+        return O.MaskedIterate(mstep, False) if g is O else g.masked_iterate_final()(mstep)
+
     def make_call(st):
         @g.gen
         def sub(m):
@@ -133,7 +142,7 @@ def build(g, spec, lit):
     parts = []
     for st in spec:
         k = st["kind"]
-        parts.append(dict(st, fn={"plate": make_elem, "mplate": make_elem, "scan": make_step, "mask": make_inner, "call": make_call,
+        parts.append(dict(st, fn={"plate": make_elem, "mplate": make_elem, "scan": make_step, "mask": make_inner, "call": make_call, "mscan": make_mstep,
                                   "plate_of_scans": make_scan_elem, "scan_of_plates": make_plate_step}.get(k, lambda s: None)(st)))
 
     @g.gen
@@ -172,6 +181,8 @@ def build(g, spec, lit):
             elif k == "scan":
                 cT, _ = g.Scan(st["fn"], st["T"])(m, next(it)) @ name
                 prev = cT
+            elif k == "mscan":
+                prev = st["fn"](m, next(it)) @ name
             elif k == "mask":
                 flag = next(it) if st["flag"] == "arg" else st["flag"]
                 g.MaskCombinator(st["fn"])(flag, m) @ name
@@ -241,6 +252,8 @@ def addresses(spec):
             if st.get("bern"):
                 out.append(((nm, "b"), (nm, "b"), (st["T"],), "b", False, st))
             out.append(((nm, "z"), (nm, "z"), (st["T"],), "f", False, st))
+        elif k == "mscan":
+            out.append(((nm, "z"), (nm, "z"), (st["T"],), "f", True, st))
         elif k == "mask":
             out.append(((nm, "y"), (nm, "y"), (), "f", True, st))
         elif k == "plate_of_scans":
@@ -389,7 +402,7 @@ def _run_one(seed, B=7, allow_nested=True, verbose=False):
     assert np.array_equal(_np(new.get_score()), onew.get_score()), (seed, "update score")
     _same_choices(spec, new, onew, B, (seed, "update"))
     for (path, okey, shape, kind, masked, st), _v in cons2:       # the discard: the old values of what was constrained
-        if st["kind"] in ("scan", "scan_of_plates", "plate_of_scans") or isinstance(_v, tuple):
+        if st["kind"] in ("scan", "scan_of_plates", "plate_of_scans", "mscan") or isinstance(_v, tuple):
             continue                                   # (the oracle restates no discard for scans; a subset's is masked)
         d, _f = _choice(bwd, path)
         od, _of = _ochoice(odis, okey)

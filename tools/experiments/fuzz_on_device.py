@@ -1,0 +1,47 @@
+"""tests/fuzz_models.py on the MI355X beyond the seeds the test suite runs: random `@gen` models built with the
+product (through libgenmi_hip.so) and with the oracle, every GFI method / edit / MH move / ImportanceK / resampling
+compared bit for bit.  Prints one JSON line of counts.
+  python tools/experiments/fuzz_on_device.py [n_interpreter_seeds] [n_jit_seeds]"""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from genjax_amd import _lib
+from tests import fuzz_models as F
+
+_lib.get()                                   # the HIP library, or a loud failure
+n_small = int(sys.argv[1]) if len(sys.argv) > 1 else 400
+n_jit = int(sys.argv[2]) if len(sys.argv) > 2 else 24
+out = dict(models=0, over_the_limits=0, failures=[], smc_models=0, big_plate_models=0, jit_models=0)
+t0 = time.time()
+for seed in range(10_000, 10_000 + n_small):
+    try:
+        F.run_one(seed)
+        out["models"] += 1
+    except F.OverTheLimits:
+        out["over_the_limits"] += 1
+    except Exception as e:      # noqa: BLE001
+        out["failures"].append((seed, "run_one", repr(e)[:200]))
+for seed in range(20_000, 20_000 + n_small // 2):
+    try:
+        F.run_smc_one(seed)
+        out["smc_models"] += 1
+    except F.OverTheLimits:
+        out["over_the_limits"] += 1
+    except Exception as e:      # noqa: BLE001
+        out["failures"].append((seed, "run_smc_one", repr(e)[:200]))
+for seed in range(30_000, 30_000 + 16):
+    try:
+        F.run_big_one(seed)
+        out["big_plate_models"] += 1
+    except Exception as e:      # noqa: BLE001
+        out["failures"].append((seed, "run_big_one", repr(e)[:200]))
+for seed in range(40_000, 40_000 + n_jit):          # 2^18 particles: the hiprtc-specialised programs
+    try:
+        F.run_one(seed, B=1 << 18)
+        out["jit_models"] += 1
+    except F.OverTheLimits:
+        out["over_the_limits"] += 1
+    except Exception as e:      # noqa: BLE001
+        out["failures"].append((seed, "run_one at 2^18", repr(e)[:200]))
+    print(f"# jit seed {seed} done, {time.time() - t0:.0f} s", file=sys.stderr, flush=True)
+out["seconds"] = round(time.time() - t0, 1)
+print(json.dumps(out))

@@ -98,6 +98,10 @@ class Key:
     """
 
     def __init__(self, host=None, dev=None, lazy=None, split_last=False, offset=0):
+        if dev is not None and not dev.is_contiguous():
+            dev = dev.contiguous()      # (a slice of a split over a batch — `split(keys)[0]`: the kernels read [n, 2] rows)
+        if host is not None and not host.flags["C_CONTIGUOUS"]:
+            host = np.ascontiguousarray(host)
         self._host, self._dev, self._lazy = host, dev, lazy
         self._offset = int(offset)      # lazy "split" only: this is children [offset, offset + n) of the base key
         # result of split() over a BATCH of keys: `a, b = split(keys)` and

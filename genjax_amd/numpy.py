@@ -277,7 +277,10 @@ def where(c, a, b):
     if _is_torch(c) or _is_torch(a) or _is_torch(b):
         dev = next(t.device for t in (c, a, b) if _is_torch(t))
         tt = lambda v: v if _is_torch(v) else torch.as_tensor(v, device=dev)
-        return torch.where(tt(c), tt(a), tt(b))
+        cond = tt(c)
+        if cond.dtype != torch.bool:          # jnp.where takes any condition: non-zero holds (a bernoulli's 0 / 1)
+            cond = cond != 0
+        return torch.where(cond, tt(a), tt(b))
     return np.where(c, a, b)
 
 

@@ -1,7 +1,7 @@
 """tests/fuzz_models.py on the MI355X beyond the seeds the test suite runs: random `@gen` models built with the
 product (through libgenmi_hip.so) and with the oracle, every GFI method / edit / MH move / ImportanceK / resampling
 compared bit for bit.  Prints one JSON line of counts.
-  python tools/experiments/fuzz_on_device.py [n_interpreter_seeds] [n_jit_seeds]"""
+  python tools/experiments/fuzz_on_device.py [n_interpreter_seeds] [n_jit_seeds] [n_jit_smc_seeds]"""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from genjax_amd import _lib
@@ -43,5 +43,16 @@ for seed in range(40_000, 40_000 + n_jit):          # 2^18 particles: the hiprtc
     except Exception as e:      # noqa: BLE001
         out["failures"].append((seed, "run_one at 2^18", repr(e)[:200]))
     print(f"# jit seed {seed} done, {time.time() - t0:.0f} s", file=sys.stderr, flush=True)
+n_jit_smc = int(sys.argv[3]) if len(sys.argv) > 3 else 12
+out["jit_smc_models"] = 0
+for seed in range(50_000, 50_000 + n_jit_smc):      # ImportanceK with 2^18 particles, then a resampling of them
+    try:
+        F.run_smc_one(seed, K=1 << 18)
+        out["jit_smc_models"] += 1
+    except F.OverTheLimits:
+        out["over_the_limits"] += 1
+    except Exception as e:      # noqa: BLE001
+        out["failures"].append((seed, "run_smc_one at 2^18", repr(e)[:200]))
+    print(f"# jit smc seed {seed} done, {time.time() - t0:.0f} s", file=sys.stderr, flush=True)
 out["seconds"] = round(time.time() - t0, 1)
 print(json.dumps(out))

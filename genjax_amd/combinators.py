@@ -259,8 +259,13 @@ def _index_chm(chm: ChoiceMap, j, n):
             idx = v.idx.value if isinstance(v.idx, Sym) else v.idx
             val = v.value.value if isinstance(v.value, Sym) else v.value
             return Mask(val, idx == j)
-        if isinstance(v, Mask):            # a masked constraint on the whole plate: element j of its value, same flag
-            return Mask(pick(v.value), v.flag)
+        if isinstance(v, Mask):
+            # a masked constraint on the whole plate: element j of its value — and of its flag when the flag carries the
+            # plate axis too (a masked plate's choices given back as constraints); the same flag otherwise
+            fl = v.flag.value if isinstance(v.flag, Sym) else v.flag
+            if isinstance(fl, np.ndarray) and fl.ndim >= 1 and fl.shape[0] == n:
+                fl = _take(fl, j)
+            return Mask(pick(v.value), fl)
         if isinstance(v, Sym):
             inner = v.value
             from .engine import StepInput2
@@ -1317,8 +1322,15 @@ def _loop_step_constraint(chm: ChoiceMap, t, n, at_step, what="scan of more than
             val = v.value.value if isinstance(v.value, Sym) else v.value
             return Mask(val, idx == t)
         inner = v.value if isinstance(v, Sym) else v
-        if isinstance(inner, Mask):        # a masked constraint over the whole axis (an enclosing loop's explicit index):
-            return Mask(pick(inner.value), inner.flag)      # this iteration's element of its value, the same flag
+        if isinstance(inner, Mask):
+            # a masked constraint over the whole axis: this iteration's element of its value — and of its flag when the
+            # flag carries the axis too (the choices of a masked plate / masked scan given back as constraints); the same
+            # flag otherwise (an enclosing loop's explicit index, one flag per particle)
+            fl = inner.flag.value if isinstance(inner.flag, Sym) else inner.flag
+            if (isinstance(fl, (RuntimeTable, TableArray, StepInput, StepInput2)) or isinstance(fl, np.ndarray)) \
+                    and getattr(fl, "ndim", 0) >= 1 and fl.shape[0] == n:
+                fl = pick(fl)
+            return Mask(pick(inner.value), fl)
         if isinstance(inner, (RuntimeTable, TableArray, StepInput, StepInput2)) and inner.shape[0] == n:
             return inner[t]
         if isinstance(inner, np.ndarray) and inner.ndim >= 1 and inner.shape[0] == n:

@@ -273,9 +273,17 @@ class _Complement(Selection):
 
 
 class _Chm(Selection):
-    """Addresses that hold a value in a choice map (ChmSel, choice_map.py:627-663)."""
+    """Addresses that hold a value in a choice map (ChmSel, choice_map.py:627-663).  An `Indexed` layer of the map — a
+    constraint on a SUBSET of a plate's elements — selects NOTHING below it: `ChmSel.get_subselection(site)` asks
+    `Indexed.get_inner_map(site)` with a static component and gets the empty map (choice_map.py:1494-1496).  Here a
+    static array of indices is stored as integer sub-addresses (never met by a plate trace's own addresses, so nothing
+    below is selected either way) and a run-time index as an `Indexed(value, idx)` value AT the site: that value does
+    not make the site selected."""
     def __init__(self, chm): self.chm = chm
-    def check(self): return self.chm.has_value()
+
+    def check(self):
+        from .mask import Indexed
+        return self.chm.has_value() and not isinstance(self.chm._value, Indexed)
 
     def get_subselection(self, comp):
         sub = self.chm.get_submap(comp)
@@ -556,9 +564,13 @@ class ChoiceMap:
         if (self.has_value() and other._children) or (other.has_value() and self._children):
             raise Exception("Choice and non-Choice in Or: a value and a sub-map at one address (choice_map.py:1699-1733)")
         value = self._value if self._value is not _NOVALUE else other._value
+        if self._value is not _NOVALUE and other._value is not _NOVALUE:
+            value = _or_values(self._value, other._value)
         kids = dict(self._children)
         for a, c in other._children.items():
             kids[a] = kids[a].merge(c) if a in kids else c
+        if other._plate is not None and any(isinstance(a, int) for a in self._children):
+            kids = _overlay_elements(self, other, kids)
         return ChoiceMap(value, kids, self._plate if self._plate is not None else other._plate)
 
     def __or__(self, other): return self.merge(other)
@@ -632,6 +644,74 @@ class ChoiceMap:
     def structure(self):
         """Hashable description of which addresses hold values (program cache key)."""
         return tuple(self.addresses())
+
+
+def _or_values(a, b):
+    """`Choice(a) | Choice(b)` = `Choice.build(Mask.build(a) | Mask.build(b))` (choice_map.py:1714-1717): a first operand
+    that is a Mask with a run-time flag holds where its flag does, the second operand elsewhere (`Mask.__or__`,
+    functional_types.py:309-319); anything else: the first operand."""
+    from .mask import Mask
+    if not isinstance(a, Mask) or isinstance(a.flag, bool):
+        return a
+    import torch
+    if not all(isinstance(x, torch.Tensor) for x in (a.flag, a.value)):
+        return a
+    bv, bf = (b.value, b.flag) if isinstance(b, Mask) else (b, True)
+    if not isinstance(bv, torch.Tensor):
+        bv = torch.as_tensor(bv, dtype=a.value.dtype, device=a.value.device)
+    fl = a.flag.reshape(tuple(a.flag.shape) + (1,) * (max(a.value.ndim, bv.ndim) - a.flag.ndim)) if a.flag.ndim else a.flag
+    value = torch.where(fl, a.value, bv.to(a.value.device))
+    if isinstance(bf, bool):
+        return value if bf else Mask(value, a.flag)
+    return Mask(value, a.flag | bf.to(a.flag.device))
+
+
+def _overlay_elements(first: "ChoiceMap", second: "ChoiceMap", kids: dict) -> dict:
+    """`first | second` at the node of a plate / scan where FIRST constrains single elements (`C[name, idx, site]`, stored
+    as integer sub-addresses) and SECOND the whole axis (a plate trace's choices handed on as latents by `ChangeTarget`,
+    smc.py:378-384): element j of the merged constraint is `Choice(Mask(v[k], j == idx[k])) | Choice(vals[j])`
+    (Or.get_inner_map, choice_map.py:1740-1743; Indexed.get_inner_map :1508-1531) — the listed elements take the first
+    operand's values, every other element the second's.  The overlaid values are written into a copy of the second
+    operand's leaf (data movement: no arithmetic); the integer entries that went into it are dropped."""
+    import numpy as np
+    import torch
+    from .mask import Mask
+    ax = int(second._plate)
+    rest = ChoiceMap(_NOVALUE, {a: c for a, c in kids.items() if not isinstance(a, int)}, second._plate)
+    own = ChoiceMap(_NOVALUE, {a: c for a, c in first._children.items() if not isinstance(a, int)})
+    out = dict(kids)
+    for i in sorted(a for a in first._children if isinstance(a, int)):
+        sub = first._children[i]
+        for addr in sub.addresses():
+            if not addr or own.get_submap(addr).has_value():
+                continue                 # the first operand constrains the whole axis itself: that one wins as before
+            base = rest.get_submap(addr)
+            v = sub[addr]
+            if not base.has_value() or isinstance(base._value, Mask) or isinstance(v, Mask):
+                continue
+            b = base._value
+            if isinstance(b, torch.Tensor):
+                if b.ndim <= ax or not -b.shape[ax] <= i < b.shape[ax]:
+                    continue
+                vt = v if isinstance(v, torch.Tensor) else torch.as_tensor(np.asarray(v), device=b.device)
+                vt = vt.to(device=b.device, dtype=b.dtype)
+                new = b.clone()
+                new.select(ax, i).copy_(vt)
+            elif isinstance(b, np.ndarray) and not isinstance(v, torch.Tensor):
+                if b.ndim <= ax or not -b.shape[ax] <= i < b.shape[ax]:
+                    continue
+                new = np.array(b, copy=True)
+                new[(slice(None),) * ax + (i,)] = np.asarray(v, dtype=b.dtype)
+                new = new.view(type(b)) if type(b) is not np.ndarray else new
+            else:
+                continue
+            rest = rest.set(addr, new)
+            out[i] = out[i]._without(addr)
+            if out[i].static_is_empty():
+                del out[i]
+    for a, c in rest._children.items():
+        out[a] = c
+    return out
 
 
 def _take_indexed(v, k, m):

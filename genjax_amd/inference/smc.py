@@ -1447,8 +1447,16 @@ class BootstrapSweep(_NoiseAhead):
         else:
             be.check(be.c.gmx_graph_launch(self.graph, be.stream()), "gmx_graph_launch")
 
+    def _check_valid(self):
+        """the fused resampling prologue's sticky timeout word: a workgroup that gave up waiting clamps stale words into
+        indices, so nothing of such a sweep may be read (reset per sweep by enqueue)"""
+        if self.fuse and int(self.rs_status.item()) != 0:
+            raise RuntimeError("BootstrapSweep: a workgroup's wait for its ancestors timed out (the launch was not "
+                               "resident at once?): the sweep's results are not valid")
+
     def log_ml(self) -> float:
         """sum_t [ ref(M_t) + log(total_t * 2^-shift) - log N ] in float64 (synchronises)."""
+        self._check_valid()
         m = np.array([cdf_reference(v) for v in self.maxs.cpu().numpy()], dtype=np.float64)
         tot = self.totals.cpu().numpy().view(np.uint64).astype(np.float64)
         if np.any(tot == 0):             # a step where no particle carried any mass
@@ -1457,7 +1465,5 @@ class BootstrapSweep(_NoiseAhead):
 
     def state(self):
         """(x_T particles before the last resampling, log-weights, last ancestors)."""
-        if self.fuse and int(self.rs_status.item()) != 0:
-            raise RuntimeError("BootstrapSweep: a workgroup's wait for its ancestors timed out (the launch was not "
-                               "resident at once?): the sweep's results are not valid")
+        self._check_valid()
         return self.x[(self.T - 1) % 2], self.lw_pp[(self.T - 1) % 2 if self.fuse else 0], self.anc

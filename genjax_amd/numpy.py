@@ -346,10 +346,11 @@ def sum(x, axis=None):        # noqa: A001
             out[idx] = acc
         return out if out.ndim else out.item()
     if _is_torch(x):
-        if x.is_floating_point() and x.dim() >= 1 and x.numel() > 0 and (axis is None and x.dim() == 1 or axis in (-1, x.dim() - 1)):
+        if x.dtype == torch.float32 and x.dim() >= 1 and x.numel() > 0 and (axis is None and x.dim() == 1 or axis in (-1, x.dim() - 1)):
             # a concrete float vector (a plate's values in a model that runs site by site, sitewise.py): the sum has a
             # DEFINED order, the plate score's — element order below VMAP_LAUNCH_MIN items, gmx_sum_rows' fixed tree from
-            # there on (oracle: sum_vector) — and runs in this build's kernels (jnp.sum fixes no order: vmap.py:214-216)
+            # there on (oracle: sum_vector) — and runs in this build's kernels (jnp.sum fixes no order: vmap.py:214-216).
+            # f32 only: a float64 tensor keeps its precision and dtype through torch.sum
             from . import engine
             from .combinators import VMAP_LAUNCH_MIN
             be = _backend_or_none()

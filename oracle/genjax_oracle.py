@@ -244,7 +244,15 @@ def indexed(values, idx, n, fill=0.0):
     flag = np.zeros((n,), dtype=bool)
     full[..., idx] = values
     flag[idx] = True
-    return Mask(full, flag)
+    return IndexedMask(full, flag)
+
+
+class IndexedMask(Mask):
+    """A Mask that stands for an `Indexed` layer of the constraint (`C[name, idx_array, site]`, choice_map.py:1453-1531)
+    rather than for a `Choice(Mask(...))` the user set at the site itself.  The two differ under `get_selection()`:
+    `ChmSel.get_subselection(addr)` asks `Indexed.get_inner_map(addr)` with the STATIC component `site`, which returns
+    `ChoiceMap.empty()` (choice_map.py:1494-1496) -> `Selection.none()`; a `Choice` has a value and is selected
+    (choice_map.py:658-659)."""
 
 
 class ChoiceMap:
@@ -322,6 +330,16 @@ class ChoiceMap:
     def merge(self, other):
         """self | other, first operand wins on overlap (Or.build, choice_map.py:1699-1733)."""
         if self.has_value:
+            if isinstance(self.value, Mask) and other.has_value and not isinstance(self.value.flag, (bool, np.bool_)):
+                # `Choice(a) | Choice(b)` = `Choice.build(Mask.build(a) | Mask.build(b))` (choice_map.py:1714-1717), and
+                # `Mask.__or__` (functional_types.py:309-319) chooses the first operand where ITS flag holds, the second
+                # elsewhere (value and flag alike) — per plate element for an `Indexed` layer, whose element j is
+                # `Mask(v[k], j == idx[k])` (choice_map.py:1508-1531): the listed elements take the first operand's
+                # values, every other element the second's
+                a, b = self.value, other.value
+                if isinstance(b, Mask):
+                    return ChoiceMap.choice(type(a)(np.where(a.flag, a.value, b.value), np.where(a.flag, True, b.flag)))
+                return ChoiceMap.choice(np.where(a.flag, a.value, b).astype(np.asarray(b).dtype))
             return self
         if other.has_value and not self.tree:
             return other
@@ -1717,7 +1735,14 @@ class Target:
         return self.p.importance(k, merged, self.args)
 
     def filter_to_unconstrained(self, chm: ChoiceMap):
-        cons = self.constraint.addresses()
+        """`choice_map.filter(~self.constraint.get_selection())` (sp.py:89-91).  The selection of the constraint is a
+        `ChmSel` (choice_map.py:627-663): below a static address it asks the constraint's sub-map for ITS selection.  An
+        `Indexed` layer (a constraint on a SUBSET of a plate's / scan's elements, `C[name, idx, site]`) answers a
+        static component with the empty map (`Indexed.get_inner_map`, choice_map.py:1494-1496), so nothing below it is
+        selected and its complement keeps the WHOLE site among the latents — the listed elements too, with the values
+        they were constrained to (a plate trace's choices carry the plate axis in their leaves, vmap.py:73-75, there
+        is no per-index layer on that side to filter)."""
+        cons = [c for c in self.constraint.addresses() if not isinstance(self.constraint[c], IndexedMask)]
         return chm.filter(lambda a: not any(a[: len(c)] == c for c in cons))
 
 

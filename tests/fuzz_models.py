@@ -534,15 +534,15 @@ def _run_smc_one(seed, K):
     assert abs(lml - olml) <= 4e-6 * max(1.0, abs(olml)), (seed, "log ML", lml, olml)
     # ChangeTarget to the same model under OTHER constraints (smc.py:370-396: new weight - old score + old log-weight)
     from genjax_amd.inference.smc import ChangeTarget
-    cons_b = [c for c in _pick_constraints(spec, rng, 0.5, 1) if not isinstance(c[1], tuple) and c[1].ndim == len(c[0][2])]
-    # (OPEN: when the FIRST target constrains a SUBSET of a plate's / scan's elements — `C[name, idx_array, site]` —
-    #  the two sides disagree on which latents `filter_to_unconstrained` keeps at that site (the reference's selection
-    #  of an Indexed choice map covers the listed indices only); such first targets are left out here)
-    if not any(isinstance(c[1], tuple) for c in cons):
-        ct = ChangeTarget(ImportanceK(tgt, k_particles=K), G.Target(model, g_args, _g_constraint(G, cons_b))).run_smc(G.key(seed + 13))
-        oct_ = O.ChangeTarget(O.ImportanceK(otgt, K), O.Target(omodel, (a0,) + tuple(extra), _o_constraint(cons_b))).run_smc(O.key(seed + 13))
-        assert np.array_equal(_np(ct.get_log_weights()), oct_.get_log_weights()), (seed, "ChangeTarget log weights")
-        assert np.array_equal(_np(ct.get_particles().get_score()), oct_.get_particles().get_score()), (seed, "ChangeTarget scores")
+    cons_b = [c for c in _pick_constraints(spec, rng, 0.5, 1) if isinstance(c[1], tuple) or c[1].ndim == len(c[0][2])]
+    # (the FIRST target may constrain a SUBSET of a plate's / scan's elements — `C[name, idx_array, site]`: the selection
+    #  of such an `Indexed` layer selects nothing below it (choice_map.py:1494-1496, 658-663), so `filter_to_unconstrained`
+    #  keeps the WHOLE site among the latents, the listed elements with the values they were constrained to)
+    ct = ChangeTarget(ImportanceK(tgt, k_particles=K), G.Target(model, g_args, _g_constraint(G, cons_b))).run_smc(G.key(seed + 13))
+    oct_ = O.ChangeTarget(O.ImportanceK(otgt, K), O.Target(omodel, (a0,) + tuple(extra), _o_constraint(cons_b))).run_smc(O.key(seed + 13))
+    assert np.array_equal(_np(ct.get_log_weights()), oct_.get_log_weights()), (seed, "ChangeTarget log weights")
+    assert np.array_equal(_np(ct.get_particles().get_score()), oct_.get_particles().get_score()), (seed, "ChangeTarget scores")
+    _same_choices(spec, ct.get_particles(), oct_.get_particles(), K, (seed, "ChangeTarget particles"))
     # the same algorithm under a BATCH of keys (the reference's vmap over run_smc): [keys, K] log-weights
     if K <= 64:
         colls = ImportanceK(tgt, k_particles=K).run_smc(G.split(G.key(seed + 11), 3))

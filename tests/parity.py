@@ -419,6 +419,73 @@ def check_csmc(k=257, seed=3):
     ImportanceK(tgt2, q=proposal, k_particles=64).run_smc(G.key(seed))
 
 
+def check_change_target_from_subset_constraints(n=5, k=33, seed=3):
+    """A7 / A9: `ChangeTarget.run_smc` (ref smc.py:370-396) away from a first target that constrains a SUBSET of a plate's
+    elements, `C["ys", idx, "y"].set(v)`.  `filter_to_unconstrained` (sp.py:89-91) = `filter(~constraint.get_selection())`;
+    the selection of an `Indexed` layer selects nothing below it (`ChmSel.get_subselection` -> `Indexed.get_inner_map(static)`
+    = empty, choice_map.py:658-663, 1494-1496), so the WHOLE site stays among the latents; merged under the new target's own
+    subset constraint (`Or`, first operand wins per element: choice_map.py:1714-1717, 1740-1743; Mask.__or__,
+    functional_types.py:309-319) the listed elements take the new values and every other element keeps its old one.
+    Checked three ways: product == oracle bit for bit; the elements are the ones the rule names; the weights equal
+    `new_w - old_score + old_lw` recomputed in f64 from the particles themselves (scipy-free closed form)."""
+    import genjax_amd as G
+    from genjax_amd import ChoiceMapBuilder as C, Target, numpy as jnp
+    from genjax_amd.inference.smc import ChangeTarget, ImportanceK
+
+    def mk(g, f32):
+        @g.gen
+        def elem(m, x):
+            return g.normal(m + x, f32(1.5)) @ "y"
+
+        @g.gen
+        def model(a, xs):
+            mu = g.normal(a, f32(1.0)) @ "mu"
+            g.Vmap(elem, in_axes=(None, 0))(mu, xs) @ "ys"
+            return mu
+        return model
+    m, om = mk(G, float), mk(O, np.float32)
+    xs = np.linspace(0.0, 1.0, n).astype(np.float32)
+    idx1, v1 = np.array([1, 3]), np.array([0.5, -0.5], np.float32)
+    idx2, v2 = np.array([0, 3]), np.array([1.5, -1.5], np.float32)
+    t1 = Target(m, (0.25, jnp.array(xs)), C["ys", idx1, "y"].set(v1))
+    t2 = Target(m, (0.25, jnp.array(xs)), C["ys", idx2, "y"].set(v2))
+    ot1 = O.Target(om, (np.float32(0.25), xs), O.C.d({("ys", "y"): O.indexed(v1, idx1, n)}))
+    ot2 = O.Target(om, (np.float32(0.25), xs), O.C.d({("ys", "y"): O.indexed(v2, idx2, n)}))
+    first, ofirst = ImportanceK(t1, k_particles=k), O.ImportanceK(ot1, k)
+    c1 = first.run_smc(G.key(seed))
+    # the latents: the whole plate (and mu) — nothing of the site is dropped
+    lat = t1.filter_to_unconstrained(c1.get_particles().get_choices())
+    assert tuple(lat["ys", "y"].shape) == (k, n) and "mu" in lat
+    olat = ot1.filter_to_unconstrained(ofirst.run_smc(O.key(seed)).get_particles().get_choices())
+    assert np.array_equal(lat["ys", "y"].cpu().numpy(), olat[("ys", "y")])
+    ct, oct_ = ChangeTarget(first, t2).run_smc(G.key(seed)), O.ChangeTarget(ofirst, ot2).run_smc(O.key(seed))
+    lw, ys, mu = (ct.get_log_weights().cpu().numpy(), ct.get_particles().get_choices()["ys", "y"].cpu().numpy(),
+                  ct.get_particles().get_choices()["mu"].cpu().numpy())
+    assert np.array_equal(lw, oct_.get_log_weights())
+    assert np.array_equal(ys, oct_.get_particles().get_choices()[("ys", "y")])
+    assert np.array_equal(ct.get_particles().get_score().cpu().numpy(), oct_.get_particles().get_score())
+    old = c1.get_particles().get_choices()["ys", "y"].cpu().numpy()
+    want = old.copy()
+    want[:, idx2] = v2
+    assert np.array_equal(ys, want) and np.array_equal(old[:, idx1], np.broadcast_to(v1, (k, 2)))
+    assert np.array_equal(mu, c1.get_particles().get_choices()["mu"].cpu().numpy())
+    # weights in f64: every element and mu are constrained under the new target (the latents carry them all)
+    lp = lambda x, loc, sd: -0.5 * ((x - loc) / sd) ** 2 - np.log(sd) - 0.5 * np.log(2 * np.pi)
+    mu64 = mu.astype(np.float64)
+    new_w = lp(mu64, 0.25, 1.0) + lp(ys.astype(np.float64), mu64[:, None] + xs[None, :], 1.5).sum(-1)
+    old_score = lp(mu64, 0.25, 1.0) + lp(old.astype(np.float64), mu64[:, None] + xs[None, :], 1.5).sum(-1)
+    old_lw = lp(old[:, idx1].astype(np.float64), mu64[:, None] + xs[None, idx1], 1.5).sum(-1)
+    assert np.allclose(lw, new_w - old_score + old_lw, rtol=0, atol=2e-5)
+    assert np.allclose(c1.get_log_weights().cpu().numpy(), old_lw, rtol=0, atol=2e-5)
+    # a first target whose index is known only at RUN time (one per particle): the site stays among the latents too
+    dyn = torch.full((k,), 2, dtype=torch.int32, device=c1.get_log_weights().device)
+    t1d = Target(m, (0.25, jnp.array(xs)), C["ys", G.dynamic_index(dyn), "y"].set(0.75)) if hasattr(G, "dynamic_index") else None
+    if t1d is not None:
+        cd = ImportanceK(t1d, k_particles=k).run_smc(G.key(seed + 1))
+        latd = t1d.filter_to_unconstrained(cd.get_particles().get_choices())
+        assert tuple(latd["ys", "y"].shape) == (k, n)
+
+
 def check_nested_marginal(k=129, seed=5):
     """A12 / F4: ChangeTarget.run_csmc_for_normalizing_constant (ref smc.py:432-465),
     estimate_reciprocal_normalizing_constant (:214-225) and Marginal.random_weighted with an inner algorithm

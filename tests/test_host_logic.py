@@ -564,6 +564,14 @@ def test_nested_marginal_and_change_target():
     parity.check_nested_marginal()
 
 
+def test_change_target_away_from_subset_constraints():
+    """ref smc.py:370-396 + sp.py:89-91 + choice_map.py:658-663, 1494-1496, 1714-1743: a first target that constrains a
+    SUBSET of a plate's elements keeps the whole site among the latents; unrolled (n = 5) and loop (n = 40) plates"""
+    from tests import parity
+    parity.check_change_target_from_subset_constraints()
+    parity.check_change_target_from_subset_constraints(n=40, k=17, seed=9)
+
+
 def test_mixture_assignments_match_oracle():
     """BASELINE config 5 (integer gate) at a CPU-sized N."""
     from tests import parity

@@ -81,6 +81,13 @@ def test_nested_marginal_and_change_target_on_device():
     parity.check_nested_marginal()
 
 
+def test_change_target_away_from_subset_constraints_on_device():
+    """A7 / A9 (ref smc.py:370-396, sp.py:89-91, choice_map.py:658-663, 1494-1496, 1714-1743) against the oracle and f64"""
+    parity.check_change_target_from_subset_constraints()
+    parity.check_change_target_from_subset_constraints(n=40, k=17, seed=9)
+    parity.check_change_target_from_subset_constraints(n=24, k=4096, seed=11)
+
+
 def test_jax_docs_values_through_the_product_on_device():
     H.test_jax_docs_values_through_the_product()
 

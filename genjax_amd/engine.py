@@ -28,7 +28,7 @@ import torch
 from . import _lib
 from .core.choice_map import ChoiceMap
 from .core.mask import Indexed, Mask
-from .program import F_BCAST, F_GATHER, Graph, compile_graph
+from .program import F_BCAST, F_GATHER, Graph, ProgramTooLarge, compile_graph, split_graph
 from .random import Key
 from .tracer import Expr
 
@@ -845,23 +845,49 @@ def _drain_pending_destroys():
         be.c.gmx_program_destroy(handle)
 
 
-class Compiled:
-    """A created program + its binding plan."""
+class _WideArgs:
+    """gmx_run_args without the slot limits: what `Compiled.bind` fills for a CHAIN of programs before every segment
+    takes its own slots from it (program.split_graph)"""
 
-    def __init__(self, tr: Tracing):
+    def __init__(self, n_in, n_out, n_uni, n_tab):
+        self.in_d, self.out_d, self.uni, self.tab_d = [0] * n_in, [0] * n_out, [0] * n_uni, [0] * n_tab
+        self.ancestors_d = self.keys_d = self.red_out_d = None
+        self.key_mode, self.key0, self.key1, self.key_inner, self.index_offset, self.step_stride = 0, 0, 0, 0, 0, 0
+
+
+class _ChainLink:
+    """one program of a chain: its handle and which slots of the whole binding its own slots are"""
+
+    def __init__(self, handle, seg, finalizer):
+        self.handle, self.in_src, self.out_dst, self.uni_src, self.tab_src = handle, seg.in_src, seg.out_dst, seg.uni_src, seg.tab_src
+        self.has_red, self.n_regs, self.finalizer = seg.has_red, int(seg.blob[3]), finalizer
+
+
+class Compiled:
+    """A created program + its binding plan.  `chain=True`: a graph beyond the launch slots / the 64 live values is
+    cut into several programs launched one after another (program.split_graph), values in flight between them in
+    scratch leaves — the reference's handlers walk any number of sites (static.py:254-380)."""
+
+    def __init__(self, tr: Tracing, chain: bool = False):
         be = _lib.get()
-        self.blob, self.const_pool = compile_graph(tr.graph)
         self.in_plan, self.uni_plan, self.outputs = tr.in_plan, tr.uni_plan, tr.outputs
         self.tab_plan = tr.tab_plan
         self.n_in, self.n_out, self.n_uni = tr.graph.n_in, tr.graph.n_out, tr.graph.n_uni
         self.uses_red = any(n.op in ("REDMAX", "REDLSE") for n in tr.graph.nodes)
-        if max(self.n_in, self.n_out) > _lib.GMX_MAX_IN or self.n_uni > _lib.GMX_MAX_UNI:
-            raise ValueError("site program exceeds the ABI slot limits "
-                             f"(in={self.n_in}, out={self.n_out}, uni={self.n_uni})")
         tabs = tr.graph.__dict__.get("tables", [])
-        if len(tabs) > _lib.GMX_MAX_TAB:
-            raise ValueError(f"site program exceeds the ABI slot limits (tables={len(tabs)} > {_lib.GMX_MAX_TAB}: "
-                             "launch-uniform vectors of more than 16 elements)")
+        self.links = None
+        self._be = be
+        self._jit_tried = False
+        if chain:
+            segs, self.n_spill = split_graph(tr.graph, _lib.GMX_MAX_IN, _lib.GMX_MAX_OUT, _lib.GMX_MAX_UNI, _lib.GMX_MAX_TAB)
+        else:
+            self.blob, self.const_pool = compile_graph(tr.graph)
+            if max(self.n_in, self.n_out) > _lib.GMX_MAX_IN or self.n_uni > _lib.GMX_MAX_UNI:
+                raise ValueError("site program exceeds the ABI slot limits "
+                                 f"(in={self.n_in}, out={self.n_out}, uni={self.n_uni})")
+            if len(tabs) > _lib.GMX_MAX_TAB:
+                raise ValueError(f"site program exceeds the ABI slot limits (tables={len(tabs)} > {_lib.GMX_MAX_TAB}: "
+                                 "launch-uniform vectors of more than 16 elements)")
         self.tables = []
         for t in tabs:
             if t is None:                      # runtime table: bound per launch (tab_plan)
@@ -875,16 +901,34 @@ class Compiled:
             else:
                 a = a.astype(np.int32)
             self.tables.append(torch.from_numpy(a).to(be.device))
+        if chain:
+            self.links = []
+            for seg in segs:
+                h = self._create(seg.blob)
+                fin = weakref.finalize(self, _destroy_program, be, h)
+                fin.atexit = False
+                self.links.append(_ChainLink(h, seg, fin))
+            red = [l for l in self.links if l.has_red]
+            self.handle = (red[0] if red else self.links[-1]).handle
+            self.blob = segs[-1].blob
+            self._finalizer = lambda: [l.finalizer() for l in self.links]
+            return
+        self.handle = self._create(self.blob)
+        # the device code buffer and the specialised module go when the last reference to this object does
+        self._finalizer = weakref.finalize(self, _destroy_program, be, self.handle)
+        self._finalizer.atexit = False       # at interpreter exit the process (and the HIP runtime) goes anyway
+
+    def _create(self, blob):
+        be = self._be
         handle = c_void_p()
-        words = np.ascontiguousarray(self.blob, dtype=np.uint32)
+        words = np.ascontiguousarray(blob, dtype=np.uint32)
         be.check(be.c.gmx_program_create(words.ctypes.data_as(POINTER(c_uint32)), words.size, handle),
                  "gmx_program_create")
-        self.handle = handle
-        self._be = be
-        self._jit_tried = False
-        # the device code buffer and the specialised module go when the last reference to this object does
-        self._finalizer = weakref.finalize(self, _destroy_program, be, handle)
-        self._finalizer.atexit = False       # at interpreter exit the process (and the HIP runtime) goes anyway
+        return handle
+
+    @property
+    def max_regs(self) -> int:
+        return max(l.n_regs for l in self.links) if self.links else int(self.blob[3])
 
     def close(self):
         """Release the program now (idempotent); the object must not be launched afterwards."""
@@ -896,16 +940,22 @@ class Compiled:
         Returns False — and keeps the interpreter — if hiprtc is unavailable or
         GENMI_JIT=0."""
         be = self._be
-        if be.c.gmx_program_is_specialized(self.handle):
+        handles = [l.handle for l in self.links] if self.links else [self.handle]
+        if all(be.c.gmx_program_is_specialized(h) for h in handles):
             return True
         if self._jit_tried:
             return False
         self._jit_tried = True
-        ok = be.c.gmx_program_specialize(self.handle) == 0
-        if not ok and int(self.blob[3]) > 31:
-            msg = be.c.gmx_last_error()
-            raise _lib.GenmiError("this program keeps more than 31 values live per particle and therefore needs the "
-                                  f"hiprtc-specialised kernel, which could not be built: {msg.decode() if msg else ''}")
+        ok = True
+        for h, regs in zip(handles, [l.n_regs for l in self.links] if self.links else [int(self.blob[3])]):
+            if be.c.gmx_program_is_specialized(h):
+                continue
+            one = be.c.gmx_program_specialize(h) == 0
+            if not one and regs > 31:
+                msg = be.c.gmx_last_error()
+                raise _lib.GenmiError("this program keeps more than 31 values live per particle and therefore needs the "
+                                      f"hiprtc-specialised kernel, which could not be built: {msg.decode() if msg else ''}")
+            ok = ok and one
         return ok
 
     def set_background(self, lds_pad: int):
@@ -914,6 +964,8 @@ class Compiled:
         self._be.check(self._be.c.gmx_program_set_background(self.handle, int(lds_pad)), "gmx_program_set_background")
 
     def is_specialized(self) -> bool:
+        if self.links:
+            return all(bool(self._be.c.gmx_program_is_specialized(l.handle)) for l in self.links)
         return bool(self._be.c.gmx_program_is_specialized(self.handle))
 
     def set_fuse_resample(self):
@@ -922,12 +974,12 @@ class Compiled:
 
     def fuses_resample(self) -> bool:
         """True when `run(..., resample_in=...)` is honoured (include/genmi.h: gmx_program_fuses_resample)."""
-        return bool(self._be.c.gmx_program_fuses_resample(self.handle))
+        return self.links is None and bool(self._be.c.gmx_program_fuses_resample(self.handle))
 
     def writes_tile_stats(self) -> bool:
         """True when a launch can also leave the CDF tile statistics (gmx_run_args.tile_agg_d): a specialised
         program running 4 particles per thread with exactly one block-max reduction."""
-        return bool(self._be.c.gmx_program_writes_tile_stats(self.handle))
+        return self.links is None and bool(self._be.c.gmx_program_writes_tile_stats(self.handle))
 
     def run(self, leaves, batch: tuple, key: Key | None, red_out=None, index_offset=0, out_buffers=None,
             tile_stats=None, peer=None, resample_in=None):
@@ -948,6 +1000,10 @@ class Compiled:
                         held.append(self)
             elif _PENDING_DESTROY:
                 _drain_pending_destroys()
+        if self.links:                      # a chain: every program in turn on the one stream, same particles
+            for link, A in zip(self.links, bound[1]):
+                be.check(be.c.gmx_program_run(link.handle, bound[0], A, be.stream()), "gmx_program_run")
+            return
         be.check(be.c.gmx_program_run(self.handle, bound[0], bound[1], be.stream()), "gmx_program_run")
 
     def bind(self, leaves, batch: tuple, key: Key | None, red_out=None, index_offset=0, out_buffers=None,
@@ -965,12 +1021,18 @@ class Compiled:
         be = self._be
         n = int(np.prod(batch, dtype=np.int64))
         self._work = getattr(self, "_work", 0) + n
-        if (n >= JIT_MIN_PARTICLES or self._work >= JIT_MIN_WORK or int(self.blob[3]) > 31) and not self._jit_tried \
+        if (n >= JIT_MIN_PARTICLES or self._work >= JIT_MIN_WORK or self.max_regs > 31) and not self._jit_tried \
                 and be.uses_streams and not torch.cuda.is_current_stream_capturing():
             # big ensembles, programs launched often enough to repay ~0.5 s of hiprtc, and programs the
             # 31-register interpreter cannot hold
             self.specialize()
-        A = _lib.RunArgs()
+        if self.links:
+            if tile_stats is not None or peer is not None or resample_in is not None:
+                raise NotImplementedError("a site program cut into a chain of launches takes no tile statistics / peers / "
+                                          "fused resampling")
+            A = _WideArgs(self.n_in, self.n_out, self.n_uni, len(self.tables))
+        else:
+            A = _lib.RunArgs()
         keep = []
         anc = None
         soa_cache = {}
@@ -1122,7 +1184,49 @@ class Compiled:
             A.rs.max_out_d, A.rs.total_out_d, A.rs.status_d = r["max_out"].data_ptr(), r["total_out"].data_ptr(), r["status"].data_ptr()
             A.rs.shift, A.rs.tag = int(r["shift"]), int(r["tag"])
             A.rs.key0, A.rs.key1 = int(r["key"][0]), int(r["key"][1])
+        if self.links:
+            return n, self._chain_args(A, n, keep), keep, outs
         return n, A, keep, outs
+
+    def _chain_args(self, W: "_WideArgs", n: int, keep: list):
+        """one gmx_run_args per program of the chain: its own slots out of the whole binding `W`, its spills and reloads
+        in rows of one scratch buffer ([words, n] 32-bit cells, struct-of-arrays like every leaf)"""
+        be = self._be
+        scratch = torch.empty((max(self.n_spill, 1), max(n, 1)), dtype=torch.int32, device=be.device)
+        keep.append(scratch)
+        base, row = scratch.data_ptr(), max(n, 1) * 4
+        out = []
+        for link in self.links:
+            S = _lib.RunArgs()
+            for k, (kind, x) in enumerate(link.in_src):
+                S.in_d[k] = W.in_d[x] if kind == "in" else base + x * row
+            for k, (kind, x) in enumerate(link.out_dst):
+                S.out_d[k] = W.out_d[x] if kind == "out" else base + x * row
+            for k, x in enumerate(link.uni_src):
+                S.uni[k] = W.uni[x]
+            for k, x in enumerate(link.tab_src):
+                S.tab_d[k] = W.tab_d[x]
+            S.ancestors_d, S.key_mode, S.key0, S.key1, S.keys_d = W.ancestors_d, W.key_mode, W.key0, W.key1, W.keys_d
+            S.key_inner, S.index_offset, S.step_stride = W.key_inner, W.index_offset, W.step_stride
+            if link.has_red:
+                S.red_out_d = W.red_out_d
+            out.append(S)
+        return out
+
+
+def over_the_slots(e) -> bool:
+    """does this exception say "the traced program does not fit ONE launch" (slots, tables, live values)?"""
+    return isinstance(e, ProgramTooLarge) or (isinstance(e, ValueError) and "exceeds the ABI slot limits" in str(e))
+
+
+def compile_fitting(tr: Tracing) -> Compiled:
+    """`Compiled(tr)`, as a chain of launches when one does not hold it"""
+    try:
+        return Compiled(tr)
+    except Exception as e:      # noqa: BLE001
+        if not over_the_slots(e):
+            raise
+    return Compiled(tr, chain=True)
 
 
 def _prepare_input(src, kind, n, be):
@@ -1259,7 +1363,7 @@ def elementwise(fn, *xs, key=None):
             if isinstance(out, T.Expr) and tr.node_origin.get(id(out.node)) is not None:
                 out = out + 0.0           # a pure pass-through still gets its own buffer
             oo = tr.emit_output(out)
-        ent = (Compiled(tr), oo)
+        ent = (compile_fitting(tr), oo)
         if code is not None and not fn.__closure__:
             _EW_CACHE[ck] = ent
     comp, oo = ent

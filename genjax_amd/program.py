@@ -437,7 +437,7 @@ def compile_graph(g: Graph):
             release(a)
         if op in EFFECT:
             if op == "STOUT":
-                emit(op, n.flags, n.slot, R(n.args[0]))
+                emit(op, n.flags, n.slot, R(n.args[0]) + n.imm)      # imm: which word of a two-register value (split_graph)
             elif op == "LOOP":
                 emit(op, imm=n.imm)
             elif op == "ENDLOOP":
@@ -470,6 +470,9 @@ def compile_graph(g: Graph):
             emit(op, dst, R(n.args[0]), 0, n.imm)
         elif op in ("KDERIVER", "KSPLITU"):
             emit(op, dst, R(n.args[0]), R(n.args[1]))
+        elif op == "PAIR":          # a two-register value (key, categorical state) from its two words (split_graph)
+            emit("MOV", dst, R(n.args[0]))
+            emit("MOV", dst + 1, R(n.args[1]))
         elif op == "CATIDX":        # second register of a categorical state pair
             emit("MOV", dst, R(n.args[0]) + 1)
         elif op in UNARY:
@@ -500,3 +503,243 @@ def compile_graph(g: Graph):
     header = [MAGIC, VERSION, n_instr, max(n_regs, 1), g.n_in, g.n_out, next_pool, g.n_tab,
               len(consts), g.n_uni]
     return np.array(header + words + consts, dtype=np.uint32), const_pool
+
+
+# ---------------------------------------------------------------------------
+# programs that do not fit ONE launch: cut into a chain of launches
+# ---------------------------------------------------------------------------
+# The reference's handlers walk any number of `trace` sites (static.py:254-380) and XLA gives the fused computation
+# whatever registers and buffers it needs.  A site program is bounded by the launch ABI (include/genmi.h: 64 input
+# leaves, 64 output leaves, 64 pool entries, 8 tables) and by 64 live 32-bit values per particle.  A graph beyond those
+# bounds is CUT, at top level (never inside a counted loop), into segments that each fit; a value computed in one
+# segment and read in a later one is stored to a scratch leaf by the first ("spill") and loaded by the second — same
+# nodes, same order, same arithmetic, so the chain computes bit for bit what the single program would.  Values that
+# cost nothing to obtain again (constants, launch uniforms, input leaves, the particle's key and index) are re-issued
+# in whichever segment needs them instead of being spilled.
+FREE_OPS = ("CONST", "UNI", "LDIN", "LDKEY", "LDIDX")
+
+
+@dataclass
+class Segment:
+    graph: Graph
+    in_src: list          # local input slot  -> ("in", slot of the whole graph) | ("spill", scratch word)
+    out_dst: list         # local output slot -> ("out", slot of the whole graph) | ("spill", scratch word)
+    uni_src: list         # local launch uniform -> launch uniform of the whole graph
+    tab_src: list         # local table -> table of the whole graph
+    blob: np.ndarray = None
+    const_pool: list = None
+    has_red: bool = False
+
+
+def split_graph(g: Graph, max_in: int, max_out: int, max_uni: int, max_tab: int, max_len: int = 2048):
+    """Cut `g` into a chain of Segments (each compiled: .blob / .const_pool); returns (segments, n_spill_words).
+    Raises ProgramTooLarge when ONE indivisible unit (a counted loop with the values it carries) does not fit."""
+    nodes = g.nodes
+    live = [False] * len(nodes)
+    stack = [n for n in nodes if n.op in EFFECT]
+    while stack:
+        n = stack.pop()
+        if live[n.idx]:
+            continue
+        live[n.idx] = True
+        for a in n.args:
+            if a is not None and not live[a.idx]:
+                stack.append(a)
+    # positions: live nodes in program order; the free ones traced at top level are re-issued on demand instead
+    depth, P, free = 0, [], set()
+    for n in nodes:
+        if n.op == "ENDLOOP":
+            depth -= 1
+        if live[n.idx]:
+            if n.op in FREE_OPS and depth == 0:
+                free.add(n.idx)
+            else:
+                P.append(n)
+        if n.op == "LOOP":
+            depth += 1
+    pos = {n.idx: p for p, n in enumerate(P)}
+    last_use = {}
+    for p, n in enumerate(P):
+        for a in n.args:
+            if a is not None and a.idx in pos:
+                last_use[a.idx] = p
+    # indivisible units: a top-level counted loop together with the loop-carried values defined in front of it
+    units, p, depth = [], 0, 0
+    while p < len(P):
+        if P[p].op != "LOOP":
+            units.append([p, p])
+            p += 1
+            continue
+        s, depth, q = p, 0, p
+        while True:
+            if P[q].op == "LOOP":
+                depth += 1
+            elif P[q].op == "ENDLOOP":
+                depth -= 1
+                if depth == 0:
+                    break
+            q += 1
+        for r in range(p + 1, q):
+            if P[r].op == "SETVAR":
+                v = P[r].args[0]
+                if v.idx in pos and pos[v.idx] < s:
+                    s = pos[v.idx]
+        while units and units[-1][1] >= s:           # the carried values' definitions join the loop's unit
+            s = min(s, units.pop()[0])
+        units.append([s, q])
+        p = q + 1
+
+    spill_word = {}          # node idx -> first scratch word
+    n_words = 0
+    segments = []
+
+    def build(ulo, uhi):
+        """the sub-graph of units ulo .. uhi (inclusive), with its spills"""
+        nonlocal n_words
+        lo, hi = units[ulo][0], units[uhi][1]
+        sg = Graph()
+        sg.tables = []
+        if getattr(g, "nested_loops", False):
+            sg.nested_loops = True
+        seg = Segment(sg, [], [], [], [])
+        in_local, uni_local, tab_local, m = {}, {}, {}, {}
+        gtabs = g.__dict__.get("tables", [])
+
+        def put(op, args=(), imm=0, dtype="f32", flags=0, slot=0):
+            nd = Node(op, tuple(args), int(imm) & 0xFFFFFFFF, dtype, flags, slot, len(sg.nodes))
+            sg.nodes.append(nd)
+            return nd
+
+        def local_in(src):
+            s_ = in_local.get(src)
+            if s_ is None:
+                s_ = in_local[src] = len(seg.in_src)
+                seg.in_src.append(src)
+            return s_
+
+        def local_uni(u):
+            s_ = uni_local.get(u)
+            if s_ is None:
+                s_ = uni_local[u] = len(seg.uni_src)
+                seg.uni_src.append(u)
+            return s_
+
+        def local_tab(t):
+            s_ = tab_local.get(t)
+            if s_ is None:
+                s_ = tab_local[t] = len(seg.tab_src)
+                seg.tab_src.append(t)
+                sg.tables.append(gtabs[t] if t < len(gtabs) else None)
+            return s_
+
+        def clone(n, args):
+            if n.op == "UNI":
+                return put("UNI", (), local_uni(n.imm), n.dtype)
+            if n.op == "LDIN":
+                return put("LDIN", (), n.imm, n.dtype, n.flags, local_in(("in", n.slot)))
+            if n.op == "LDTAB":
+                return put("LDTAB", args, n.imm, n.dtype, n.flags, local_tab(n.slot))
+            if n.op == "STOUT":
+                seg.out_dst.append(("out", n.slot))
+                return put("STOUT", args, 0, "none", n.flags, len(seg.out_dst) - 1)
+            return put(n.op, args, n.imm, n.dtype, n.flags, n.slot)
+
+        def operand(a):
+            if a is None:
+                return None
+            nd = m.get(a.idx)
+            if nd is not None:
+                return nd
+            if a.idx in free:
+                nd = clone(a, ())
+            else:                                   # computed by an earlier segment: read its scratch words
+                w0 = spill_word[a.idx]
+                words = [put("LDIN", (), 0, "i32" if a.width == 2 else a.dtype, 0, local_in(("spill", w0 + k)))
+                         for k in range(a.width)]
+                nd = words[0] if a.width == 1 else put("PAIR", words, 0, a.dtype)
+            m[a.idx] = nd
+            return nd
+
+        for u in range(ulo, uhi + 1):
+            a_, b_ = units[u]
+            for n in P[a_:b_ + 1]:                   # what the unit reads from outside itself: issued in front of it
+                for x in n.args:
+                    if x is not None and x.idx not in m and not (a_ <= pos.get(x.idx, -1) <= b_):
+                        operand(x)
+            for n in P[a_:b_ + 1]:
+                m[n.idx] = clone(n, [operand(x) for x in n.args])
+                if n.op in ("REDMAX", "REDLSE"):
+                    seg.has_red = True
+        for n in P[lo:hi + 1]:
+            if last_use.get(n.idx, -1) > hi and n.dtype != "none":
+                spill_word[n.idx] = n_words
+                for k in range(n.width):
+                    seg.out_dst.append(("spill", n_words + k))
+                    put("STOUT", (m[n.idx],), k, "none", 0, len(seg.out_dst) - 1)
+                n_words += n.width
+        sg.n_in, sg.n_out, sg.n_uni, sg.n_tab = len(seg.in_src), len(seg.out_dst), len(seg.uni_src), len(seg.tab_src)
+        return seg
+
+    ulo = 0
+    while ulo < len(units):
+        seg_lo = units[ulo][0]
+        ins, unis, tabs, reloads = set(), set(), set(), set()
+        stouts = cur = e_prev = 0
+        e_prev = seg_lo - 1
+        expire = {}
+        best = None
+        for u in range(ulo, len(units)):
+            a_, b_ = units[u]
+            for n in P[a_:b_ + 1]:
+                if n.op == "STOUT":
+                    stouts += 1
+                elif n.op == "LDTAB":
+                    tabs.add(n.slot)
+                elif n.op == "LDIN":
+                    ins.add(("in", n.slot))
+                elif n.op == "UNI":
+                    unis.add(n.imm)
+                for x in n.args:
+                    if x is None:
+                        continue
+                    if x.idx in free:
+                        if x.op == "LDIN":
+                            ins.add(("in", x.slot))
+                        elif x.op == "UNI":
+                            unis.add(x.imm)
+                    elif pos[x.idx] < seg_lo and x.idx not in reloads:
+                        reloads.add(x.idx)
+                        for k in range(x.width):
+                            ins.add(("spill", x.idx, k))
+                lu = last_use.get(n.idx, -1)
+                if lu > b_ and n.dtype != "none":
+                    cur += n.width
+                    expire[lu] = expire.get(lu, 0) + n.width
+            for q in range(e_prev + 1, b_ + 1):
+                cur -= expire.pop(q, 0)
+            e_prev = b_
+            if len(ins) > max_in or len(unis) > max_uni or len(tabs) > max_tab or stouts > max_out:
+                break
+            if stouts + cur <= max_out:
+                best = u
+            if b_ - seg_lo >= max_len and best is not None:
+                break
+        if best is None:
+            raise ProgramTooLarge("one indivisible part of the site program (a counted loop with the values it carries, "
+                                  "or a single site) exceeds the launch slots")
+        while True:
+            mark = (n_words, dict(spill_word))
+            seg = build(ulo, best)
+            try:
+                seg.blob, seg.const_pool = compile_graph(seg.graph)
+                break
+            except ProgramTooLarge:
+                n_words = mark[0]
+                spill_word.clear()
+                spill_word.update(mark[1])
+                if best == ulo:
+                    raise
+                best = ulo + (best - ulo) // 2
+        segments.append(seg)
+        ulo = best + 1
+    return segments, n_words

@@ -1369,10 +1369,12 @@ def run_gfi(gen_fn, mode, key: Key | None, args, constraint: ChoiceMap | None = 
         except DeferralAbort:
             _NO_DEFER.add(ck)
             ent = None
-    first_error = None
+    first_error, attempt = None, 0
     while ent is None:
-        # (second pass, when the program did not fit the launch slots / registers: top-level plates and scans as loops)
-        force = first_error is not None
+        # (second pass, when the program did not fit the launch slots / registers: top-level plates and scans as loops;
+        #  third and fourth pass: the program CUT into a chain of launches — program.split_graph — as traced at first,
+        #  then in the loop form)
+        force, chain = attempt in (1, 3), attempt >= 2
         tr = Tracing(len(batch))
         tr.step_leaf_min = 0 if force else getattr(gen_fn, "step_leaf_min", tr.step_leaf_min)
         if na is not None:
@@ -1403,13 +1405,16 @@ def run_gfi(gen_fn, mode, key: Key | None, args, constraint: ChoiceMap | None = 
                 ro = tr.emit_output(retval) if mode == "assess" else None
                 if weight_stats and isinstance(w, Expr) and w.node.op != "CONST":
                     tr.graph.add("REDMAX", (w.node,), dtype="none")
-            ent = (Compiled(tr), otree, wo, so, ro) + (_noise_split(tr, batch, na) if na is not None else ((), None)) + ((),)
+            ent = (Compiled(tr, chain=chain), otree, wo, so, ro) + (_noise_split(tr, batch, na) if na is not None else ((), None)) + ((),)
         except Exception as e:      # noqa: BLE001
-            if force:
-                raise first_error from None        # the loop form does not fit (or apply) either: the first report stands
-            if not _over_the_slots(e):
+            if attempt == 0 and not _over_the_slots(e):
                 raise
-            first_error = e
+            if attempt == 3 or (chain and (weight_stats or na is not None)):
+                raise first_error from None        # no form fits (or applies): the first report stands
+            first_error = first_error or e
+            attempt += 1
+            if attempt == 2 and (weight_stats or na is not None):
+                raise first_error from None        # (a sweep's programs leave tile statistics: one launch or none)
             continue
         _CACHE[ck] = ent
     comp, otree, wo, so, ro, draws, nprog, plates = ent
@@ -1498,7 +1503,15 @@ def _trace_gfi(gen_fn, mode, key, batch, specs, atree, ctree, weight_stats, na, 
         wo = tr.emit_output(w) if (mode == "generate" and w is not None) else None
         so = tr.emit_output(s if s is not None else 0.0) if mode == "assess" else None
         ro = _emit_retval(tr, retval) if mode == "assess" else None
-    return (Compiled(tr), otree, wo, so, ro, (), None, tuple(plates))
+    try:
+        comp = Compiled(tr)
+    except Exception as e:      # noqa: BLE001
+        if not _over_the_slots(e):
+            raise
+        if not plates:
+            raise DeferralAbort() from None      # (nothing deferred: run_gfi's ordinary passes deal with the size)
+        comp = Compiled(tr, chain=True)          # the part in front of the deferred plate as a chain of launches
+    return (comp, otree, wo, so, ro, (), None, tuple(plates))
 
 
 class MinimalGenerate:
@@ -1815,20 +1828,21 @@ def run_edit(gen_fn, key: Key, trace: Trace, request: EditRequest, argdiffs, mh:
     ent = _CACHE.get(ck)
     if ent is _MH_UNFUSED:
         return _run_mh_unfused(gen_fn, key, trace, request, argdiffs)
-    first_error = None
+    first_error, attempt = None, 0
     while ent is None:
-        force = first_error is not None        # (second pass: see run_gfi)
+        force, chain = attempt in (1, 3), attempt >= 2        # (the passes of run_gfi)
         try:
             ent = _trace_edit(gen_fn, key, trace, request, argdiffs, mh, na, specs, batch, atree, ptree, rspec, tangents, ck,
-                              force)
+                              force, chain)
         except _Unfused:
             return _run_mh_unfused(gen_fn, key, trace, request, argdiffs)
         except Exception as e:      # noqa: BLE001
-            if force:
-                raise first_error from None
-            if not _over_the_slots(e):
+            if attempt == 0 and not _over_the_slots(e):
                 raise
-            first_error = e
+            if attempt == 3 or (attempt >= 1 and na is not None):
+                raise first_error from None
+            first_error = first_error or e
+            attempt += 1
             continue
         _CACHE[ck] = ent
     comp, otree, wo, ao, draws, nprog = ent
@@ -1845,7 +1859,8 @@ def _over_the_slots(e) -> bool:
     return isinstance(e, ProgramTooLarge) or (isinstance(e, ValueError) and "exceeds the ABI slot limits (in=" in str(e))
 
 
-def _trace_edit(gen_fn, key, trace, request, argdiffs, mh, na, specs, batch, atree, ptree, rspec, tangents, ck, force):
+def _trace_edit(gen_fn, key, trace, request, argdiffs, mh, na, specs, batch, atree, ptree, rspec, tangents, ck, force,
+                chain=False):
     """run_edit's tracing step -> the cache entry"""
     if True:
         from .combinators import forced_loops
@@ -1893,7 +1908,7 @@ def _trace_edit(gen_fn, key, trace, request, argdiffs, mh, na, specs, batch, atr
             else:
                 otree = _emit_rec(tr, rec)
             wo = tr.emit_output(w) if w is not None else None
-        return (Compiled(tr), otree, wo, ao) + (_noise_split(tr, batch, na) if na is not None else ((), None))
+        return (Compiled(tr, chain=chain), otree, wo, ao) + (_noise_split(tr, batch, na) if na is not None else ((), None))
 
 
 def _finish_edit(request, mh, otree, wo, ao, outs, flat, args, batch, be):

@@ -486,6 +486,102 @@ def check_change_target_from_subset_constraints(n=5, k=33, seed=3):
         assert tuple(latd["ys", "y"].shape) == (k, n)
 
 
+def _np(v):
+    return v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+
+
+def check_many_sites(ns=40, B=9, seed=3, kinds=("normal", "uniform", "flip", "normal", "beta")):
+    """A5 / A6 beyond ONE launch: a static model of `ns` sites (ref static.py:254-380 walks any number of them) needs
+    2 * ns stored leaves — more than the launch ABI's 64 from 32 sites on — and is cut into a chain of launches
+    (program.split_graph): simulate / importance / assess / update (new constraints + a changed argument) / regenerate
+    / a StaticRequest of Rejuvenate moves, all against the oracle bit for bit (an old uniform value that an edit upstream
+    leaves outside its new support scores -inf, and -inf - -inf = NaN on both sides: compared as equal).  Site i reads site i - 1 (a chain of
+    dependencies crossing every cut) and sites 0 and ns // 2 (long-lived values: spilled once, reloaded where read)."""
+    import genjax_amd as G
+    from genjax_amd import ChoiceMapBuilder as C, Diff, Regenerate, SelectionBuilder as S, StaticRequest, Update, numpy as jnp
+
+    def mk(g, lit, where):
+        @g.gen
+        def model(a, b):
+            x, first, mid = a, a, a
+            for i in range(ns):
+                kind = kinds[i % len(kinds)]
+                m = x * lit(0.5) + first * lit(0.125) - mid * lit(0.25) + b
+                if kind == "normal":
+                    x = g.normal(m, lit(1.25)) @ f"s{i}"
+                elif kind == "uniform":
+                    x = g.uniform(m - lit(6.0), m + lit(7.0)) @ f"s{i}"      # (wide: an edit upstream keeps the old value inside)
+                elif kind == "flip":
+                    f = g.flip(lit(0.4)) @ f"s{i}"
+                    x = where(f, m, x)
+                else:
+                    p_ = g.beta(lit(2.0), lit(3.0)) @ f"s{i}"
+                    x = p_ * lit(2.0) + m * lit(0.5)
+                if i == 0:
+                    first = x
+                if i == ns // 2:
+                    mid = x
+            return x + first
+        return model
+    m = mk(G, float, jnp.where)
+    om = mk(O, np.float32, lambda c, x, y: np.where(c, x, y).astype(np.float32))
+    rng = np.random.default_rng(seed)
+    dev = G._lib.get().device
+    b = rng.normal(size=B).astype(np.float32) * np.float32(0.1)
+    args, oargs = (0.3, torch.from_numpy(b).to(dev)), (np.float32(0.3), b)
+    keys, okeys = G.split(G.key(seed), B), O.split(O.key(seed), B)
+    names = [f"s{i}" for i in range(ns)]
+    cont = [nm for i, nm in enumerate(names) if kinds[i % len(kinds)] == "normal"]
+
+    def same(tr, otr, what):
+        ch, och = tr.get_choices(), otr.get_choices()
+        for nm in names:
+            assert np.array_equal(_np(ch[nm]), np.broadcast_to(och[nm], _np(ch[nm]).shape)), (what, nm)
+        assert np.array_equal(_np(tr.get_score()), otr.get_score(), equal_nan=True), (what, "score")
+        assert np.array_equal(_np(tr.get_retval()), otr.get_retval()), (what, "retval")
+    tr, otr = m.simulate(keys, args), om.simulate(okeys, oargs)
+    same(tr, otr, "simulate")
+    # importance: a third of the normal sites constrained (launch-uniform values)
+    obs = {nm: np.float32(rng.normal()) for nm in cont[::3]}
+    tri, w = m.importance(keys, C.d({k_: float(v) for k_, v in obs.items()}), args)
+    otri, ow = om.importance(okeys, O.C.d(obs), oargs)
+    assert np.array_equal(_np(w), ow), "importance weight"
+    same(tri, otri, "importance")
+    # assess of all the choices
+    sc, _ = m.assess(tr.get_choices(), args)
+    osc, _ = om.assess(otr.get_choices(), oargs, batch_shape=(B,))
+    assert np.array_equal(_np(sc), osc) and np.array_equal(_np(sc), _np(tr.get_score())), "assess"
+    # update: other constraints (one value per particle) and a changed first argument
+    upd = {nm: rng.normal(size=B).astype(np.float32) for nm in cont[1::4]}
+    k2, ok2 = G.split(G.key(seed + 1), B), O.split(O.key(seed + 1), B)
+    new, wu, _, bwd = Update(C.d({k_: torch.from_numpy(v).to(dev) for k_, v in upd.items()})).edit(
+        k2, tri, (Diff(0.7, G.UnknownChange), Diff.no_change(args[1])))
+    onew, owu, odisc = om.update(ok2, otri, O.C.d(upd), (np.float32(0.7), b))
+    assert np.array_equal(_np(wu), owu, equal_nan=True), "update weight"
+    same(new, onew, "update")
+    for nm in upd:
+        assert np.array_equal(np.broadcast_to(_np(bwd.constraint[nm]), (B,)), np.broadcast_to(odisc[nm], (B,))), ("discard", nm)
+    # regenerate a selection spread over the chain
+    pick = names[2::7]
+    sel = S[pick[0]]
+    for nm in pick[1:]:
+        sel = sel | S[nm]
+    k3, ok3 = G.split(G.key(seed + 2), B), O.split(O.key(seed + 2), B)
+    rg, wr, _, _ = Regenerate(sel).edit(k3, new, Diff.no_change((0.7, args[1])))
+    org, owr, _ = om.regenerate(ok3, onew, O.selection(*pick), (np.float32(0.7), b))
+    assert np.array_equal(_np(wr), owr, equal_nan=True), "regenerate weight"
+    same(rg, org, "regenerate")
+    # a StaticRequest of Rejuvenate moves on a few normal sites
+    mv = cont[::5]
+    req = StaticRequest({nm: G.Rejuvenate(G.normal, lambda chm: (chm.get_value(), 0.5)) for nm in mv})
+    oreq = {nm: O.Rejuvenate(O.normal, lambda chm: (chm.get_value(), np.float32(0.5))) for nm in mv}
+    k4, ok4 = G.split(G.key(seed + 3), B), O.split(O.key(seed + 3), B)
+    rj, wj, _, _ = req.edit(k4, rg, Diff.no_change((0.7, args[1])))
+    orj, owj = om.edit_static(ok4, org, oreq, (np.float32(0.7), b))
+    assert np.array_equal(_np(wj), owj, equal_nan=True), "static request weight"
+    same(rj, orj, "static request")
+
+
 def check_nested_marginal(k=129, seed=5):
     """A12 / F4: ChangeTarget.run_csmc_for_normalizing_constant (ref smc.py:432-465),
     estimate_reciprocal_normalizing_constant (:214-225) and Marginal.random_weighted with an inner algorithm

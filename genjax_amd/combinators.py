@@ -274,6 +274,9 @@ def _index_chm(chm: ChoiceMap, j, n):
             return inner
         if isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[0] == n:
             return _take(v, j)
+        from .engine import StepInput2 as _S2
+        if isinstance(v, _S2) and v.ndim >= 1 and v.shape[0] == n:      # (already a row of an enclosing loop's leaf)
+            return _take(v, j)
         return v
     return chm.map_values(pick)
 
@@ -421,12 +424,26 @@ class Vmap(GenerativeFunction):
         recs, rets = [], []
         weight = Expr(g.const_f32(0.0))
         score = Expr(g.const_f32(0.0))
-        probe = (len(g.nodes), g.n_out, len(ctx.tr.outputs)) if (n > NEST_UNROLL_MAX and not g.loop_counts) else None
+        # (INSIDE a counted loop an unrolled plate whose element opens a loop of its own always becomes a loop itself,
+        #  whatever its size: element (t0, j, t2) of a leaf is addressed by the loops' own row-major index, which a
+        #  statically picked row in the middle would break)
+        probe = (len(g.nodes), g.n_out, len(ctx.tr.outputs)) if ((n > NEST_UNROLL_MAX and not g.loop_counts)
+                                                                 or (g.loop_counts and n > 1)) else None
         for j in range(n):
             kj = Expr(g.add("KDERIVE", (key.node,), imm=j, dtype="key")) if key is not None else None   # split(key, n)[j]
             args_j = tuple(_tree_take_axes(a, ax, lambda v: _take(v, j)) for a, ax in zip(args, axes))
             con_j = _index_chm(constraint, j, n)
-            rec, ret, w, s = call_gen_fn(ctx, mode, self.gen_fn, kj, args_j, con_j, None, None, req_leaves, addr)
+            depth0 = len(g.loop_counts)
+            try:
+                rec, ret, w, s = call_gen_fn(ctx, mode, self.gen_fn, kj, args_j, con_j, None, None, req_leaves, addr)
+            except NotImplementedError:
+                # inside a counted loop, element 0 opened a loop of its own and read a leaf at (t_outer, 0, t_inner): not
+                # addressable with a static row in the middle — the reason this plate becomes a loop itself (below)
+                if not (j == 0 and probe is not None and depth0 and any(nd.op == "LOOP" for nd in g.nodes[probe[0]:])):
+                    raise
+                while len(g.loop_counts) > depth0:
+                    g.loop_end()
+                rec = ret = w = s = None
             if j == 0 and probe is not None and any(nd.op == "LOOP" for nd in g.nodes[probe[0]:]):
                 # element 0 opened a counted loop of its own (a long scan / a large plate somewhere inside a `@gen`
                 # element): n unrolled copies would need n times its output slots.  What element 0 traced is turned
@@ -698,7 +715,7 @@ class Vmap(GenerativeFunction):
         inner_prev = prev["vmap"] if "vmap" in prev else prev
         # a small plate whose ELEMENTS ran a counted loop (its previous values are [n, A, T] step leaves): the edit runs
         # the plate as a loop around the elements' loops, as a large one does
-        if n > VMAP_UNROLL_MAX or (_has_step_rows(inner_prev) and not ctx.tr.graph.loop_counts) or _forced(ctx, n):
+        if n > VMAP_UNROLL_MAX or (_has_step_rows(inner_prev) and len(ctx.tr.graph.loop_counts) < 3) or _forced(ctx, n):
             return self._trace_edit_loop(ctx, kind if kind != "empty" else "update", key, args, axes, constraint,
                                          inner_prev, req, n, req_leaves, addr)
         g = ctx.tr.graph

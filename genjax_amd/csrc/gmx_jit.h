@@ -203,5 +203,9 @@ struct gmx_jit_ctx {
 // a loop INSIDE a GMX_JIT_LOOP (a long scan inside a large plate): gmx_t counts the inner iterations, gmx_tf the pairs
 #define GMX_JIT_LOOP2(COUNT) for (uint32_t gmx_t1 = 0u; gmx_t1 < (COUNT); ++gmx_t1) { gmx_t = gmx_t1; gmx_tf = gmx_t0 * (COUNT) + gmx_t1;
 #define GMX_JIT_ENDLOOP2 } gmx_t = gmx_t0; gmx_tf = gmx_t0;
+// a third level (a plate of plates of plates): gmx_tf runs over the triples, row-major; inside a GMX_JIT_LOOP2 only
+#define GMX_JIT_LOOP3(COUNT) { const uint32_t gmx_tp = gmx_t, gmx_tfp = gmx_tf;                  \
+    for (uint32_t gmx_t2 = 0u; gmx_t2 < (COUNT); ++gmx_t2) { gmx_t = gmx_t2; gmx_tf = gmx_tfp * (COUNT) + gmx_t2;
+#define GMX_JIT_ENDLOOP3 } gmx_t = gmx_tp; gmx_tf = gmx_tfp; }
 
 #define GMX_JIT_END }

@@ -349,10 +349,15 @@ static std::string jit_source(const gmx_program* p, bool* gathers_prefetched = n
   int jit_depth = 0;
   for (uint32_t pc = 0; pc < p->n_instr; ++pc) {
     const uint32_t op_ = p->code_h[2 * pc] & 0xffu;
-    if (op_ == OP_LOOP)
-      snprintf(buf, sizeof(buf), jit_depth++ == 0 ? "  GMX_JIT_LOOP(%uu)\n" : "  GMX_JIT_LOOP2(%uu)\n", p->code_h[2 * pc + 1]);
-    else if (op_ == OP_ENDLOOP)
-      snprintf(buf, sizeof(buf), --jit_depth == 0 ? "  GMX_JIT_ENDLOOP\n" : "  GMX_JIT_ENDLOOP2\n");
+    if (op_ == OP_LOOP) {
+      static const char* const open_[3] = {"  GMX_JIT_LOOP(%uu)\n", "  GMX_JIT_LOOP2(%uu)\n", "  GMX_JIT_LOOP3(%uu)\n"};
+      snprintf(buf, sizeof(buf), open_[jit_depth < 2 ? jit_depth : 2], p->code_h[2 * pc + 1]);
+      ++jit_depth;
+    } else if (op_ == OP_ENDLOOP) {
+      static const char* const close_[3] = {"  GMX_JIT_ENDLOOP\n", "  GMX_JIT_ENDLOOP2\n", "  GMX_JIT_ENDLOOP3\n"};
+      --jit_depth;
+      snprintf(buf, sizeof(buf), "%s", close_[jit_depth < 2 ? (jit_depth < 0 ? 0 : jit_depth) : 2]);
+    }
     else if (pre_of[pc] >= 0)
       snprintf(buf, sizeof(buf), "  GMX_JIT_LDPRE(%u, %d)\n", (p->code_h[2 * pc] >> 8) & 0xffu, pre_of[pc]);
     else

@@ -20,7 +20,7 @@
 // i32 0/1.  There is no data-dependent control flow: a `@gen` static function has a fixed
 // site list (static.py "Language restrictions"), `jax.lax.cond`/`where` on
 // values become OP_SEL.  The ONE loop form is a counted, launch-uniform repetition of a block
-// (OP_LOOP count ... OP_ENDLOOP; at most two deep): what `jax.lax.scan` is to the reference's Scan combinator
+// (OP_LOOP count ... OP_ENDLOOP; at most three deep): what `jax.lax.scan` is to the reference's Scan combinator
 // (combinators/scan.py:221, 278).  Values carried across iterations live in registers the block reads and
 // overwrites (the encoder emits the copies); OP_LDT yields the iteration number; loads / stores flagged
 // GMX_F_STEP address element t of a [T, n] leaf.  All indices are launch-uniform, so on gfx950 the
@@ -53,9 +53,9 @@
 #define GMX_F_STEP 8u   /* row += (t + imm) * gmx_run_args.step_stride: element t + imm of a [T, n] leaf (t = the
                            iteration number of the INNERMOST enclosing OP_LOOP, 0 outside; STOUT: element t, inside a
                            loop only) */
-#define GMX_F_FLAT 16u  /* with GMX_F_STEP, inside the inner of two nested loops: t is the row-major pair index
-                           t_outer * inner_count + t_inner — element (t_outer, t_inner) of a [T0, T1, n] leaf (a plate
-                           of scans).  Outside the inner loop it is the same as GMX_F_STEP alone. */
+#define GMX_F_FLAT 16u  /* with GMX_F_STEP, inside nested loops: t is the ROW-MAJOR index over all enclosing loops —
+                           t0 * n1 + t1 two deep (element (t0, t1) of a [T0, T1, n] leaf: a plate of scans),
+                           (t0 * n1 + t1) * n2 + t2 three deep.  In an outermost loop it is the same as GMX_F_STEP alone. */
 
 enum gmx_op {
   OP_END = 0,
@@ -92,9 +92,9 @@ enum gmx_op {
   // block reductions into red_out[blockIdx][0..1]
   OP_REDMAX = 90,     // column 0 = max over the block of r[a]
   OP_REDLSE = 91,     // column 0 = max, column 1 = sum exp(r[a] - max)
-  // counted loop (launch-uniform trip count >= 1, not nested)
-  OP_LOOP = 100,      // imm = trip count: the block up to the matching OP_ENDLOOP runs imm times, t = 0 .. imm-1 (one
-                      // loop may sit inside another: a long scan inside a large plate)
+  // counted loop (launch-uniform trip count >= 1)
+  OP_LOOP = 100,      // imm = trip count: the block up to the matching OP_ENDLOOP runs imm times, t = 0 .. imm-1 (loops
+                      // nest up to three deep: a long scan inside a large plate, a plate of plates of plates)
   OP_ENDLOOP = 101,
   OP_LDT = 102,       // r[dst] = (i32) t, the iteration number (0 outside a loop)
   // a SECOND per-particle key in one program (two generative-function calls chained into one launch, each with its

@@ -264,12 +264,14 @@ template <class Regs, bool FULL, int NI, class Ctx>
 GMX_HD void gmx_vm_run(uint32_t n_instr_rt, int64_t i, bool active, const gmx_run_args& A, Ctx& ctx) {
   Regs R;
   R.init();
-  // counted loops, at most two deep: launch-uniform control flow.  t = the innermost loop's iteration number,
-  // tf = the row-major index over both (GMX_F_FLAT).  Few live scalars (the switch below is at the SGPR limit): the
-  // two loop heads packed in one word, the trip counts re-read from the LOOP instructions at the loop ends, the outer
-  // iteration number recovered as tf / n1 when the inner loop finishes.  (No arrays indexed at run time: the device
-  // interpreter's register file already owns the GPR-index mode.)
-  uint32_t t = 0u, tf = 0u, heads = 0u;       // heads: pc of the outer LOOP | pc of the inner LOOP << 16
+  // counted loops, at most three deep: launch-uniform control flow.  t = the innermost loop's iteration number,
+  // tf = the row-major index over ALL enclosing loops (GMX_F_FLAT): (t0 * n1 + t1) * n2 + t2 three deep.  Few live
+  // scalars (the switch below is at the SGPR limit): the heads of the two outer loops packed in one word, the third in
+  // a second; the trip counts are re-read from the LOOP instructions at the loop ends, and the enclosing loop's
+  // iteration number is recovered from tf when a loop finishes (tf / n = the parent's flat index, whose remainder by
+  // the parent's own count is its iteration number).  (No arrays indexed at run time: the device interpreter's
+  // register file already owns the GPR-index mode.)
+  uint32_t t = 0u, tf = 0u, heads = 0u, head3 = 0u;   // heads: pc of the outer LOOP | pc of the second << 16
   int depth = 0;
   for (uint32_t pc = 0; pc < n_instr_rt; ++pc) {
     gmx_rword w;
@@ -277,14 +279,20 @@ GMX_HD void gmx_vm_run(uint32_t n_instr_rt, int64_t i, bool active, const gmx_ru
     const uint32_t op = w.a & 0xffu;
     if (op == OP_LOOP) {
       if (depth == 0) { heads = pc; depth = 1; t = 0u; tf = 0u; }
-      else { heads = (heads & 0xffffu) | (pc << 16); depth = 2; tf = t * w.b; t = 0u; }
+      else if (depth == 1) { heads = (heads & 0xffffu) | (pc << 16); depth = 2; tf = tf * w.b; t = 0u; }
+      else { head3 = pc; depth = 3; tf = tf * w.b; t = 0u; }
       continue;
     }
     if (op == OP_ENDLOOP) {
       gmx_rword h;
-      const uint32_t hp = depth == 2 ? (heads >> 16) : (heads & 0xffffu);
+      const uint32_t hp = depth == 3 ? head3 : (depth == 2 ? (heads >> 16) : (heads & 0xffffu));
       ctx.fetch(hp, &h.a, &h.b);                         // h.b = this loop's trip count
-      if (t + 1u < h.b) { ++t; tf = depth == 2 ? tf + 1u : t; pc = hp; }
+      if (t + 1u < h.b) { ++t; ++tf; pc = hp; }
+      else if (depth == 3) {
+        gmx_rword h2;
+        ctx.fetch(heads >> 16, &h2.a, &h2.b);            // the second loop's trip count
+        depth = 2; tf = tf / h.b; t = tf % h2.b;
+      }
       else if (depth == 2) { depth = 1; t = tf / h.b; tf = t; }
       else { depth = 0; t = 0u; tf = 0u; }
       continue;

@@ -549,6 +549,14 @@ class Tracing:
             for e_, slot in enumerate(slots):
                 self.in_plan.append((slot, j, e_, "stepflat2"))
             return Sym(StepInput2(g, slots, dt, (int(event[0]), int(event[1])), event=tuple(int(x) for x in event[2:])), ("leaf", j))
+        if kind == "part" and len(event) == 3 and event[2] > self.step_leaf_min and (event[0] > DVEC_MAX or event[1] > DVEC_MAX
+                                                                                      or int(np.prod(event)) > 4 * DVEC_MAX):
+            # [n, A, B, T]: the choices of a plate of plates of plates (or of long scans two plates deep) — one slot
+            # ([A * B * T, n]); element (a, b, t) through GMX_F_FLAT under the three loops
+            slot = g.n_in
+            g.n_in += 1
+            self.in_plan.append((slot, j, 0, "stepflat"))
+            return Sym(StepInput2(g, slot, dt, tuple(int(x) for x in event)), ("leaf", j))
         if kind == "part" and len(event) == 2 and event[1] > self.step_leaf_min:
             # [n, A, T] with a long last axis: the choices of the long scans of a plate — one slot ([A * T, n]); row a is
             # picked statically (an unrolled plate) or by the outer loop's iteration number (a plate run as a loop
@@ -711,41 +719,62 @@ class StepInput(np.ndarray):
 
 
 class StepInput2:
-    """A per-particle [A, T] leaf whose LAST axis is long ([n, A, T] at the boundary, one [A * T, n] input slot): what a
-    plate of long scans reads back (assess; importance / update with per-particle values).  `leaf[a]` is a row — a a
-    Python int (an unrolled plate) or the outer loop's iteration number (the plate run as a loop) — and `row[t]`, inside
-    the scan's loop, is ONE load: element a * T + t of the slot (OP_LDIN, GMX_F_STEP with imm = a * T; under two
-    nested loops GMX_F_FLAT: the pair index is the loops' own)."""
+    """A per-particle leaf with SEVERAL axes whose LAST axis is long ([n, A, T] or [n, A, B, T] at the boundary, one
+    [A * T, n] / [A * B * T, n] input slot): what a plate of long scans — or a plate of plates of plates — reads back
+    (assess; importance / update with per-particle values).  `leaf[a]` picks a row — a a Python int (an unrolled plate)
+    or the enclosing loop's iteration number (the plate run as a loop) — and the last index, inside the innermost loop,
+    is ONE load: element (a, ..., t) of the slot, row-major (OP_LDIN, GMX_F_STEP; with the leading rows picked
+    statically imm = their offset; under nested loops GMX_F_FLAT: the flat index is the loops' own)."""
 
-    def __init__(self, g, slot, dt, shape, row=None, event=()):
+    def __init__(self, g, slot, dt, shape, row=None, event=(), rows=(), full=None):
         # slot: one input slot, or (a vector-valued site: event != ()) one per element of the site's event
-        self._g, self._slot, self._dt, self.shape, self._row, self._event = g, slot, dt, tuple(shape), row, tuple(event)
+        self._g, self._slot, self._dt, self.shape, self._event = g, slot, dt, tuple(shape), tuple(event)
+        self._rows = tuple(rows) if rows else (() if row is None else (row,))       # picks so far: int | "loop"
+        self._full = tuple(full) if full is not None else tuple(self._rows_shape()) + self.shape
         self.ndim = len(self.shape)
+
+    def _rows_shape(self):
+        return ()
+
+    @property
+    def _row(self):
+        return self._rows[-1] if self._rows else None
 
     def __len__(self):
         return self.shape[0]
 
     def __getitem__(self, idx):
         from .program import F_FLAT, F_STEP, F_U8
-        if self.ndim == 2:
+        if self.ndim >= 2:
             if isinstance(idx, (int, np.integer)):
-                return StepInput2(self._g, self._slot, self._dt, self.shape[1:], row=int(idx), event=self._event)
-            if isinstance(idx, Expr):
+                pick = int(idx)
+            elif isinstance(idx, Expr):
                 if idx.node.op != "LDT":
-                    raise NotImplementedError("a [n, A, T] step leaf takes its row from the plate's own iteration number")
-                return StepInput2(self._g, self._slot, self._dt, self.shape[1:], row="loop", event=self._event)
-            raise NotImplementedError("a [n, A, T] leaf with a long last axis is read row by row (a plate of long scans)")
+                    raise NotImplementedError("a step leaf with several axes takes its rows from the plates' own iteration numbers")
+                pick = "loop"
+            else:
+                raise NotImplementedError("a per-particle leaf with a long last axis is read row by row (a plate of long scans)")
+            return StepInput2(self._g, self._slot, self._dt, self.shape[1:], event=self._event, rows=self._rows + (pick,),
+                              full=self._full)
         if not (isinstance(idx, Expr) and idx.node.op == "LDT"):
             raise NotImplementedError("a long per-particle row is read by the scan's own iteration number")
         flags = F_STEP | (F_U8 if self._dt == "bool" else 0)
-        if self._row == "loop":
-            if len(self._g.loop_counts) != 2:
-                raise NotImplementedError("element (t_outer, t_inner) of a two-axis step leaf outside the inner loop")
-            flags, imm = flags | F_FLAT, 0
-        else:
-            if len(self._g.loop_counts) != 1:
-                raise NotImplementedError("a statically picked row of a two-axis step leaf is read inside ONE loop")
-            imm = int(self._row) * self.shape[0]
+        rows = self._rows
+        k = 0                                   # leading rows picked statically; the rest by the loops around this read
+        while k < len(rows) and rows[k] != "loop":
+            k += 1
+        if any(r != "loop" for r in rows[k:]):
+            raise NotImplementedError("a static row of a step leaf below a row picked by a loop")
+        n_loops = len(rows) - k + 1
+        if len(self._g.loop_counts) != n_loops:
+            raise NotImplementedError(f"element of a step leaf with {n_loops} loop-indexed axes read under "
+                                      f"{len(self._g.loop_counts)} counted loops")
+        imm = 0
+        for j in range(k):                      # row-major offset of the statically picked leading rows
+            imm = imm * self._full[j] + int(rows[j])
+        imm *= int(np.prod(self._full[k:], dtype=np.int64))
+        if n_loops >= 2:
+            flags |= F_FLAT
         if not self._event:
             return Expr(self._g.add("LDIN", dtype=self._dt, flags=flags, slot=self._slot, imm=imm))
         out = np.empty(self._event, dtype=object)          # a vector-valued site: this step's row, element by element

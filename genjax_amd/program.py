@@ -133,8 +133,8 @@ class Graph:
     def store(self, value: Node, step: bool = False) -> int:
         """STOUT of `value`; returns the output slot.  step: element t of a [T, n] leaf (inside a loop)."""
         flags = (F_U8 if value.dtype == "bool" else 0) | (F_STEP if step else 0)
-        if step and len(self.loop_counts) == 2:
-            flags |= F_FLAT            # inside the inner of two loops: element (t_outer, t_inner) of a [T0, T1, n] leaf
+        if step and len(self.loop_counts) >= 2:
+            flags |= F_FLAT            # inside nested loops: element (t0, t1[, t2]) of a [T0, T1[, T2], n] leaf (row-major)
         slot = self.n_out
         self.n_out += 1
         self.add("STOUT", (value,), dtype="none", flags=flags, slot=slot)
@@ -143,8 +143,8 @@ class Graph:
     # counted loop ------------------------------------------------------------
     @property
     def loop_counts(self):
-        """trip counts of the counted loops being traced, outermost first (at most two: a long scan inside a large
-        plate, a plate of plates ...)"""
+        """trip counts of the counted loops being traced, outermost first (at most three: a long scan inside a large
+        plate, a plate of plates of plates ...)"""
         return self.__dict__.setdefault("_loop_counts", [])
 
     @property
@@ -152,10 +152,10 @@ class Graph:
         return bool(self.loop_counts)
 
     def loop_begin(self, count: int):
-        if len(self.loop_counts) >= 2:
-            raise NotImplementedError("counted loops nest two deep (a long scan inside a large plate), not three")
+        if len(self.loop_counts) >= 3:
+            raise NotImplementedError("counted loops nest three deep (a plate of plates of plates), not four")
         self.loop_counts.append(int(count))
-        if len(self.loop_counts) == 2:
+        if len(self.loop_counts) >= 2:
             self.nested_loops = True
         self._cse.clear()              # a value computed before the loop is not "the same" as one recomputed inside
         self.add("LOOP", imm=int(count), dtype="none")

@@ -538,7 +538,7 @@ def check_many_sites(ns=40, B=9, seed=3, kinds=("normal", "uniform", "flip", "no
         for nm in names:
             assert np.array_equal(_np(ch[nm]), np.broadcast_to(och[nm], _np(ch[nm]).shape)), (what, nm)
         assert np.array_equal(_np(tr.get_score()), otr.get_score(), equal_nan=True), (what, "score")
-        assert np.array_equal(_np(tr.get_retval()), otr.get_retval()), (what, "retval")
+        assert np.array_equal(*np.broadcast_arrays(_np(tr.get_retval()), otr.get_retval())), (what, "retval")   # (launch-uniform: a scalar)
     tr, otr = m.simulate(keys, args), om.simulate(okeys, oargs)
     same(tr, otr, "simulate")
     # importance: a third of the normal sites constrained (launch-uniform values)
@@ -580,6 +580,54 @@ def check_many_sites(ns=40, B=9, seed=3, kinds=("normal", "uniform", "flip", "no
     orj, owj = om.edit_static(ok4, org, oreq, (np.float32(0.7), b))
     assert np.array_equal(_np(wj), owj, equal_nan=True), "static request weight"
     same(rj, orj, "static request")
+
+
+def check_three_nested_plates(dims=(20, 20, 20), B=5, seed=1):
+    """A15 three combinator levels deep (ref vmap.py:180-218 nests freely): `vmap(vmap(vmap(elem)))` over
+    dims[0] x dims[1] x dims[2] elements — three counted loops in the site program (GMX_F_FLAT: the row-major index
+    over all three) — simulate / importance (launch-uniform and per-particle observations) / assess / update under a
+    changed argument, against the oracle bit for bit."""
+    import genjax_amd as G
+    from genjax_amd import ChoiceMapBuilder as C, Diff, Update, numpy as jnp
+
+    def mk(g, lit):
+        @g.gen
+        def elem(m, x):
+            return g.normal(m + x, lit(1.5)) @ "y"
+        return elem
+    e, oe = mk(G, float), mk(O, np.float32)
+    A_, B_, C_ = dims
+    rng = np.random.default_rng(seed)
+    xs = np.linspace(0, 1, A_ * B_ * C_).astype(np.float32).reshape(dims)
+    ax = (None, 0)
+    v3 = G.Vmap(G.Vmap(G.Vmap(e, in_axes=ax), in_axes=ax), in_axes=ax)
+    ov3 = O.Vmap(O.Vmap(O.Vmap(oe, in_axes=ax), in_axes=ax), in_axes=ax)
+    dev = G._lib.get().device
+    args, oargs = (0.3, jnp.array(xs)), (np.float32(0.3), xs)
+    tr, otr = v3.simulate(G.split(G.key(seed), B), args), ov3.simulate(O.split(O.key(seed), B), oargs)
+    assert tuple(tr.get_choices()["y"].shape) == (B,) + tuple(dims)
+    assert np.array_equal(_np(tr.get_choices()["y"]), otr.get_choices()["y"]), "simulate values"
+    assert np.array_equal(_np(tr.get_score()), otr.get_score()), "simulate score"
+    ys = rng.normal(size=dims).astype(np.float32)
+    tri, w = v3.importance(G.split(G.key(seed + 1), B), C["y"].set(jnp.array(ys)), args)
+    otri, ow = ov3.importance(O.split(O.key(seed + 1), B), O.C.d({"y": ys}), oargs)
+    assert np.array_equal(_np(w), ow) and np.array_equal(_np(tri.get_score()), otri.get_score()), "importance"
+    ypp = rng.normal(size=(B,) + tuple(dims)).astype(np.float32)
+    trp, wp = v3.importance(G.split(G.key(seed + 2), B), C["y"].set(torch.from_numpy(ypp).to(dev)), args)
+    otrp, owp = ov3.importance(O.split(O.key(seed + 2), B), O.C.d({"y": ypp}), oargs)
+    assert np.array_equal(_np(wp), owp), "importance, one observation table per particle"
+    sc, _ = v3.assess(tr.get_choices(), args)
+    osc, _ = ov3.assess(otr.get_choices(), oargs, batch_shape=(B,))
+    assert np.array_equal(_np(sc), osc) and np.array_equal(_np(sc), _np(tr.get_score())), "assess"
+    # update: the shared argument changes, every element re-scored; then new observations everywhere
+    new, wu, _, _ = Update(C.n()).edit(G.split(G.key(seed + 3), B), tr, (Diff(0.5, G.UnknownChange), Diff.no_change(args[1])))
+    sc2, _ = v3.assess(tr.get_choices(), (0.5, args[1]))
+    assert np.array_equal(_np(new.get_score()), _np(sc2)), "update: score under the changed argument"
+    lp = lambda x, loc: -0.5 * ((x - loc) / 1.5) ** 2 - np.log(1.5) - 0.5 * np.log(2 * np.pi)
+    y64 = _np(tr.get_choices()["y"]).astype(np.float64)
+    want = (lp(y64, 0.5 + xs) - lp(y64, 0.3 + xs)).reshape(B, -1).sum(-1)
+    assert np.allclose(_np(wu), want, rtol=0, atol=2e-2 * max(1.0, A_ * B_ * C_ / 8000)), "update weight vs f64"
+    assert np.array_equal(_np(new.get_choices()["y"]), _np(tr.get_choices()["y"]))
 
 
 def check_nested_marginal(k=129, seed=5):

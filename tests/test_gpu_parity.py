@@ -1773,6 +1773,25 @@ def test_models_of_more_sites_than_one_launch_holds_on_device(gpu):
     parity.check_many_sites(ns=40, B=1 << 18, seed=5, kinds=("normal", "flip", "normal", "uniform"))
 
 
+def test_three_combinator_levels_at_loop_sizes_on_device(gpu):
+    """ref vmap.py:180-218: vmap(vmap(vmap(elem))) over 20 x 20 x 20 — three counted loops in one site program — on
+    the interpreter (5 particles) and the hiprtc-specialised kernel (2^18 particles would be 2e9 element draws on the
+    oracle: 4096 particles through an explicit specialize), and mixed sizes; against the oracle"""
+    from genjax_amd import engine
+    from tests import parity
+    parity.check_three_nested_plates()
+    parity.check_three_nested_plates(dims=(3, 20, 17), B=9, seed=4)
+    parity.check_three_nested_plates(dims=(18, 2, 33), B=3, seed=5)
+    old = engine.JIT_MIN_PARTICLES
+    engine.JIT_MIN_PARTICLES = 64
+    try:
+        engine.clear_caches()
+        parity.check_three_nested_plates(dims=(20, 20, 20), B=128, seed=7)
+    finally:
+        engine.JIT_MIN_PARTICLES = old
+        engine.clear_caches()
+
+
 def test_update_under_a_changed_table_argument_on_device(gpu):
     """an UnknownChange argument that is a launch-uniform table (> 16 elements, read at a run-time index in the loop):
     every element re-scored — one plate, a plate of plates, a scan over a table, `means[idx]` (ref vmap.py:236-275)"""

@@ -1140,6 +1140,15 @@ def test_models_of_more_sites_than_one_launch_holds():
     parity.check_many_sites(ns=67, B=130, seed=8, kinds=("normal", "flip", "normal", "uniform"))
 
 
+def test_three_combinator_levels_at_loop_sizes():
+    """ref vmap.py:180-218 nests freely: vmap(vmap(vmap(elem))) over 20 x 20 x 20 (three counted loops), and mixed
+    sizes where a small plate sits between two loops — against the oracle"""
+    from tests import parity
+    parity.check_three_nested_plates()
+    parity.check_three_nested_plates(dims=(3, 20, 17), B=9, seed=4)
+    parity.check_three_nested_plates(dims=(18, 2, 33), B=3, seed=5)
+
+
 def test_empty_and_single_particle_batches():
     """jax.vmap over zero keys gives empty arrays, not an error; one particle is just a batch of one"""
     @genjax.gen

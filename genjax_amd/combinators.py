@@ -116,7 +116,7 @@ def _loop_at(v, t, what="a plate of more than 16 elements"):
         return tuple(_loop_at(x, t, what) for x in v)
     if isinstance(v, dict):
         return {k: _loop_at(x, t, what) for k, x in v.items()}
-    if isinstance(v, (RuntimeTable, TableArray, StepInput, StepInput2)):
+    if isinstance(v, (RuntimeTable, TableArray, StepInput, StepInput2, T.LazyVec)):
         return v[t]
     if isinstance(v, (list, np.ndarray)) and not (isinstance(v, np.ndarray) and v.dtype == object):
         return TableArray(np.asarray(v, dtype=np.float32 if np.asarray(v).dtype.kind == "f" else np.int32))[t]
@@ -231,7 +231,7 @@ def _tree_mark_unmapped(v, ax):
 
 def _take(a, j):
     from .engine import StepInput2
-    if isinstance(a, StepInput2):
+    if isinstance(a, (StepInput2, T.LazyVec)):
         return a[j]
     if isinstance(a, np.ndarray):
         v = a[j]

@@ -194,7 +194,7 @@ static int parse_program(const uint32_t* blob, size_t n_words, gmx_program& P) {
     switch (op) {
       case OP_END: break;
       case OP_CONST: case OP_LDIDX: case OP_LDT: ok = D(dst); break;
-      case OP_LOOP: ok = loop_depth < 2 && w1 >= 1u; ++loop_depth; in_loop = true; P.uses_loop = true; break;   // counted, <= 2 deep
+      case OP_LOOP: ok = loop_depth < 3 && w1 >= 1u; ++loop_depth; in_loop = true; P.uses_loop = true; break;   // counted, <= 3 deep
       case OP_ENDLOOP: ok = loop_depth > 0; --loop_depth; in_loop = loop_depth > 0; break;
       case OP_UNI: ok = D(dst) && w1 < P.n_uni; break;
       case OP_LDIN: ok = D(dst) && a < P.n_in; if (b & GMX_F_GATHER) P.uses_gather = true; break;

@@ -47,6 +47,9 @@
  * (index_offset + i) — a vector-valued site of n elements run with its elements on the launch axis: element i draws with
  * counter i from the ONE site key, as the unrolled form's element i does with immediate i */
 #define GMX_ELEM_INDEX 0xffffffu
+/* ... and this one "the iteration number of the innermost enclosing OP_LOOP": a vector-valued site of many elements under
+ * a particle batch runs as a counted loop per particle, iteration j drawing with counter j from the one site key */
+#define GMX_ELEM_LOOP 0xfffffeu
 #define GMX_F_GATHER 1u /* row = ancestors[i] instead of i            */
 #define GMX_F_U8 2u     /* element is 1 byte (bool) <-> i32 0/1        */
 #define GMX_F_BCAST 4u  /* row = 0: one device-resident scalar for all  */

@@ -81,7 +81,7 @@ GMX_HD void gmx_vm_step(Regs& R, const W w, int64_t i, bool active, const gmx_ru
 #define SRC(x) ((x) < GMX_POOL_BASE ? R.get(x) : ctx.pool((x) - GMX_POOL_BASE))
 #define FSRC(x) gmx_asf(SRC(x))
 #define KEY(x) gmx_key k; k.k0 = R.get(x); k.k1 = R.get((x) + 1u)
-#define ELEM() (e == GMX_ELEM_INDEX ? (uint32_t)(A.index_offset + i) : e)
+#define ELEM() (e == GMX_ELEM_INDEX ? (uint32_t)(A.index_offset + i) : (e == GMX_ELEM_LOOP ? t : e))
   {
     const uint32_t op = w0 & 0xffu, dst = (w0 >> 8) & 0xffu, a = (w0 >> 16) & 0xffu, b = w0 >> 24;
     const uint32_t c = w1 & 0xffu, e = w1 >> 8;

@@ -626,6 +626,18 @@ class Tracing:
         g = self.graph
         if value is None:
             return ("const", None)
+        from .tracer import LazyVec
+        if isinstance(value, LazyVec):
+            # a long elementwise vector (`lw - lse` over a row of 1000 log-weights; a model returning `a * xs + b`): one
+            # counted loop storing element t, instead of one unrolled copy per element
+            from . import tracer as Tm
+            if g.loop_counts:
+                return self.emit_output(value.materialize())
+            g.loop_begin(value.n)
+            e = Tm.lift(value.at(Expr(g.add("LDT", dtype="i32"))))
+            o = self.store_step(e, value.n)
+            g.loop_end()
+            return o
         if isinstance(value, Expr):
             o = self.node_origin.get(id(value.node))
             if o is not None:
@@ -702,6 +714,14 @@ class StepInput(np.ndarray):
     def __array_finalize__(self, obj):
         for a in ("_g", "_slot", "_dt", "_flags"):
             setattr(self, a, getattr(obj, a, None))
+
+    def __array_ufunc__(self, ufunc, method, *inputs, **kwargs):
+        from .numpy import _lazy_ufunc
+        return _lazy_ufunc(self, ufunc, method, inputs, kwargs)
+
+    @property
+    def _lazy_ok(self):
+        return self._slot is not None and self.ndim == 1 and not isinstance(self._slot, list)
 
     def __getitem__(self, idx):
         if isinstance(idx, Expr) and self._slot is not None:

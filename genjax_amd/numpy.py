@@ -31,6 +31,10 @@ class TableArray(np.ndarray):
     """A constant array closed over by a model; indexing it with a traced
     integer becomes an OP_LDTAB lookup (e.g. `means[idx]`)."""
 
+    @property
+    def _lazy_ok(self):
+        return self.ndim == 1 and self.dtype != object
+
     def __new__(cls, a):
         return np.asarray(a).view(cls)
 
@@ -76,10 +80,39 @@ class TableArray(np.ndarray):
     def __rtruediv__(self, o): return self._with_tensor(o, lambda a, b: a / b, True) if isinstance(o, torch.Tensor) else np.ndarray.__rtruediv__(self, o)
 
 
+def _lazy_ufunc(self, ufunc, method, inputs, kwargs):
+    """`__array_ufunc__` of the table types: arithmetic on a LONG table stays lazy (tracer.LazyVec) instead of building
+    one node per element; anything else is numpy's own loop over PLAIN arrays (a computed array is not a table any more)"""
+    if method == "__call__" and not kwargs and T.is_tracing():
+        f = _LAZY_UFUNCS.get(ufunc)
+        if f is not None and T.lazy_length(inputs):
+            return f(*inputs)
+    plain = [x.view(np.ndarray) if isinstance(x, np.ndarray) else x for x in inputs]
+    if "out" in kwargs:
+        kwargs = dict(kwargs, out=tuple(o.view(np.ndarray) if isinstance(o, np.ndarray) else o for o in kwargs["out"]))
+    return getattr(ufunc, method)(*plain, **kwargs)
+
+
+_LAZY_UFUNCS = {
+    np.add: lambda a, b: T._arith("ADD", "IADD", a, b), np.subtract: lambda a, b: T._arith("SUB", "ISUB", a, b),
+    np.multiply: lambda a, b: T._arith("MUL", "IMUL", a, b), np.true_divide: lambda a, b: T._fbin("DIV", a, b),
+    np.negative: lambda a: T.lazy_apply(lambda x: -T.lift(x), a), np.power: lambda a, b: T.power(a, b),
+    np.less: lambda a, b: T._cmp("FLT", "ILT", a, b), np.less_equal: lambda a, b: T._cmp("FLE", "ILE", a, b),
+    np.greater: lambda a, b: T._cmp("FGT", "IGT", a, b), np.greater_equal: lambda a, b: T._cmp("FGE", "IGE", a, b),
+}
+
+
 class RuntimeTable(np.ndarray):
     """A launch-uniform device vector (an argument such as cluster means): an object array of
     OP_LDTAB reads at constant indices (dead ones are eliminated), so every vector operation
     works on it; indexing with a traced integer is one OP_LDTAB at a register index."""
+
+    def __array_ufunc__(self, ufunc, method, *inputs, **kwargs):
+        return _lazy_ufunc(self, ufunc, method, inputs, kwargs)
+
+    @property
+    def _lazy_ok(self):
+        return self._slot is not None and self.ndim == 1
 
     @classmethod
     def make(cls, g, slot, dt, n):

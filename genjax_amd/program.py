@@ -44,6 +44,7 @@ BINARY = {"ADD", "SUB", "MUL", "DIV", "MIN", "MAX", "POW", "FLT", "FLE", "FGT", 
           "IEQ", "INE", "ILT", "ILE", "IGT", "IGE", "AND", "OR", "XOR", "IADD", "ISUB", "IMUL"}
 SAMPLER2 = {"S_NORMAL", "S_UNIFORM", "S_BETA"}      # args (key, a, b), imm = element counter
 ELEM_INDEX = 0xFFFFFF      # a sampler immediate meaning "the particle's global index" (csrc/gmx_program.h: GMX_ELEM_INDEX)
+ELEM_LOOP = 0xFFFFFE       # ... "the iteration number of the innermost counted loop" (GMX_ELEM_LOOP: a long vector-valued site)
 SAMPLER1 = {"S_FLIP", "S_BERNL", "S_LOGGAMMA"}                    # args (key, a)
 LOGPDF2 = {"L_NORMAL", "L_UNIFORM", "L_BETA"}       # args (x, a, b)
 LOGPDF1 = {"L_FLIP", "L_BERNL"}                     # args (x, a)

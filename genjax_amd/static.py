@@ -649,6 +649,8 @@ def _depends(node, changed: set, memo: dict, table_changed=None) -> bool:
 def _nodes_of(v):
     if isinstance(v, Expr):
         return [v.node]
+    if isinstance(v, T.LazyVec):
+        return v.dep_nodes()
     if isinstance(v, np.ndarray) and v.dtype == object:
         return [x.node for x in v.reshape(-1) if isinstance(x, Expr)]
     if isinstance(v, (tuple, list)):
@@ -869,6 +871,9 @@ def _leaf_call(ctx: _Ctx, mode, dist, key, args, constraint: ChoiceMap, prev, re
     args = dist.canon(args)
     cval = constraint.get_value() if constraint is not None else None
     zero = None
+    looped = _vector_site_loop(ctx, mode, dist, key, args, cval, prev, req)
+    if looped is not None:
+        return looped
     if mode == "simulate":
         v = dist.sym_sample(key, args)
         s = dist.sym_logpdf(v, args)
@@ -966,6 +971,78 @@ def _leaf_call(ctx: _Ctx, mode, dist, key, args, constraint: ChoiceMap, prev, re
         del k_new
         return _SiteRec(dist, nv, s, discard=pv_sym), nv, final, s
     raise NotSupportedEditRequest(kind)
+
+
+VECTOR_SITE_LOOP_MIN = 17       # elements from which a vector-valued site under a particle batch runs as a counted loop
+
+
+def _vector_site_loop(ctx, mode, dist, key, args, cval, prev, req):
+    """A vector-valued distribution site of MANY elements under a particle batch (TFP batch semantics,
+    tensorflow_probability/__init__.py:52-62: `normal(a * xs + b, sigma) @ "y"` with 500 observations): instead of one
+    unrolled copy per element — registers and program size grow with the length — ONE counted loop in the site program:
+    iteration j evaluates the parameters at element j (tracer.LazyVec: one table / step read each), draws with counter
+    j from the ONE site key (sampler immediate GMX_ELEM_LOOP) or reads element j of the constraint /
+    the previous value, and adds the element's log-density to a loop-carried sum in element order, which is the order
+    `ExactDensity.estimate_logpdf` is summed in (distribution.py:383-396 as the oracle states it).  Returns None when
+    the site is not of this shape (the unrolled form then applies)."""
+    from .engine import StepInput, StepOutput
+    from .numpy import RuntimeTable, TableArray
+    from .program import ELEM_LOOP
+    g, tr = ctx.tr.graph, ctx.tr
+    if dist.logpdf_op is None or dist.sample_op is None or len(g.loop_counts) >= 3 or getattr(g, "elem_from_index", False):
+        return None
+    kind = req.kind if req is not None else "empty"
+    if mode not in ("simulate", "generate", "assess") and kind not in ("update", "empty"):
+        return None
+    cv = cval.value if isinstance(cval, Sym) else cval
+    if isinstance(cv, Mask):
+        return None
+    pv = ps = None
+    if mode not in ("simulate", "generate", "assess"):
+        pv, ps = prev["value"].value, prev["score"].value
+    operands = list(args) + ([cv] if cv is not None else []) + ([pv] if pv is not None else [])
+    n = T.lazy_length(operands)
+    if n < VECTOR_SITE_LOOP_MIN or not any(T._long_vector(a) for a in operands):
+        return None
+    for a in operands:           # every vector operand must be readable at a run-time index
+        if isinstance(a, (np.ndarray, list, tuple)) and np.ndim(a) > 0 and not T._long_vector(a):
+            return None
+    if cv is not None and not T._long_vector(cv):
+        return None              # (a scalar constraint broadcast over a vector site: the unrolled form says what it means)
+    if pv is not None and not T._long_vector(pv):
+        return None
+    new_value = mode in ("simulate",) or (mode == "generate" and cv is None)
+    if new_value and key is None:
+        return None
+    if mode not in ("simulate", "generate", "assess"):
+        if cv is None and not ctx.args_changed(args):
+            return _SiteRec(dist, prev["value"], prev["score"]), pv, None, ps        # requests.py:56-57 / distribution.py:225-233
+    zero = g.const_f32(0.0)
+    svar = g.loop_var(zero)
+    g.loop_begin(n)
+    with T.tracing(g):
+        t = Expr(g.add("LDT", dtype="i32"))
+        a_t = tuple(T.as_float(T._elem(a, t)) for a in args)
+        if new_value:
+            x_t = Expr(g.add(dist.sample_op, (key.node,) + tuple(a.node for a in a_t), imm=ELEM_LOOP, dtype=dist.value_dtype))
+            origin = tr.store_step(x_t, n)
+        else:
+            x_t = dist._conv_value(T._elem(cv if cv is not None else pv, t))
+        s_t = Expr(g.add(dist.logpdf_op, (x_t.node,) + tuple(a.node for a in a_t), dtype="f32"))
+        g.set_vars([(svar, (Expr(svar) + s_t).node)])
+    g.loop_end()
+    score = Expr(svar)
+    if new_value:
+        v = StepOutput(origin, n, len(tr.outputs[origin[1]][1]))
+        return _SiteRec(dist, v, score), v, None, score     # (generate, unconstrained: w = 0, distribution.py:124-127)
+    if mode == "generate":
+        return _SiteRec(dist, cval, score), cv, score, score          # w = score = logpdf (:144-147)
+    if mode == "assess":
+        return _SiteRec(dist, cval, score), cv, None, score
+    if cv is None:                                     # the old value re-scored under changed arguments
+        return _SiteRec(dist, prev["value"], score), pv, score - ps, score
+    ctx.mark_changed(cv)
+    return _SiteRec(dist, cval, score, discard=prev["value"]), cv, score - ps, score      # (:235-242)
 
 
 def _rec_choices(rec) -> ChoiceMap:

@@ -106,8 +106,157 @@ class Expr:
         return as_bool(self)
 
 
+LAZY_MIN = 17          # arithmetic on a launch-uniform / per-particle VECTOR of at least this many elements stays lazy
+
+
+class LazyVec:
+    """An elementwise expression over a LONG vector (`a * xs + b` with `xs` a launch-uniform table or a per-particle
+    [n, T] leaf of more than 16 elements), kept as a recipe instead of T unrolled copies: `at(i)` builds element i —
+    `i` a Python int (the static element) or the iteration number of a counted loop (ONE table / step read at a
+    run-time index).  A vector-valued SITE whose parameters or value are such vectors runs as a counted loop in the
+    site program (static._vector_site_loop; TFP batch semantics, tensorflow_probability/__init__.py:52-62): element j
+    draws with counter j from the one site key, the score is summed in element order (distribution.py:383-396 as the
+    oracle states it).  Anything that needs the elements themselves (indexing, `jnp.sum`, a consumer that knows only
+    object arrays) gets them on demand: iterating a LazyVec materialises it, as the unrolled form always did."""
+    __array_ufunc__ = None         # numpy's binary operators defer to ours (an ndarray on the left included)
+    __array_priority__ = 2000
+    ndim = 1
+    dtype = np.dtype(object)
+
+    def __init__(self, n: int, fn, parts=()):
+        self.n, self._fn, self.parts, self._full = int(n), fn, tuple(parts), None
+
+    @property
+    def shape(self):
+        return (self.n,)
+
+    def __len__(self):
+        return self.n
+
+    def at(self, i):
+        if isinstance(i, (int, np.integer)):
+            if not -self.n <= i < self.n:
+                raise IndexError(i)
+            i = int(i) % self.n
+            if self._full is not None:
+                return self._full[i]
+        return self._fn(i)
+
+    def materialize(self) -> np.ndarray:
+        if self._full is None:
+            out = np.empty((self.n,), dtype=object)
+            for i in range(self.n):
+                out[i] = lift(self._fn(i))
+            self._full = out
+        return self._full
+
+    def __getitem__(self, idx):
+        if isinstance(idx, (int, np.integer)) or (isinstance(idx, Expr) and idx.dtype in ("i32", "bool")):
+            return self.at(idx)
+        return self.materialize()[idx]
+
+    def __iter__(self):
+        return iter(self.materialize())
+
+    def __array__(self, dtype=None, copy=None):
+        return self.materialize()
+
+    def reshape(self, *shape):
+        return self.materialize().reshape(*shape)
+
+    def dep_nodes(self) -> list:
+        """the program nodes this vector is computed from (change propagation: static._nodes_of)"""
+        out = []
+        for p in self.parts:
+            if isinstance(p, LazyVec):
+                out += p.dep_nodes()
+            elif isinstance(p, Expr):
+                out.append(p.node)
+            elif isinstance(p, np.ndarray) and p.dtype == object:
+                out += [x.node for x in p.reshape(-1) if isinstance(x, Expr)]
+        return out
+
+    # arithmetic: through the same scalar builders, element by element on demand
+    def __add__(self, o): return _arith("ADD", "IADD", self, o)
+    def __radd__(self, o): return _arith("ADD", "IADD", o, self)
+    def __sub__(self, o): return _arith("SUB", "ISUB", self, o)
+    def __rsub__(self, o): return _arith("SUB", "ISUB", o, self)
+    def __mul__(self, o): return _arith("MUL", "IMUL", self, o)
+    def __rmul__(self, o): return _arith("MUL", "IMUL", o, self)
+    def __truediv__(self, o): return _fbin("DIV", self, o)
+    def __rtruediv__(self, o): return _fbin("DIV", o, self)
+    def __pow__(self, o): return power(self, o)
+    def __rpow__(self, o): return power(o, self)
+    def __neg__(self): return lazy_apply(lambda x: -lift(x), self)
+    def __pos__(self): return self
+    def __abs__(self): return lazy_apply(lambda x: abs(lift(x)), self)
+    def __lt__(self, o): return _cmp("FLT", "ILT", self, o)
+    def __le__(self, o): return _cmp("FLE", "ILE", self, o)
+    def __gt__(self, o): return _cmp("FGT", "IGT", self, o)
+    def __ge__(self, o): return _cmp("FGE", "IGE", self, o)
+    def __and__(self, o): return _logic("AND", self, o)
+    def __rand__(self, o): return _logic("AND", o, self)
+    def __or__(self, o): return _logic("OR", self, o)
+    def __ror__(self, o): return _logic("OR", o, self)
+    def __invert__(self): return lazy_apply(lambda x: ~lift(x), self)
+
+    def astype(self, dt):
+        return lazy_apply(lambda x: lift(x).astype(dt), self)
+
+
+def _long_vector(a) -> int:
+    """length of a LONG one-axis vector that can be read at a run-time index (a LazyVec; a launch-uniform table; a
+    per-particle step leaf), else 0"""
+    if isinstance(a, LazyVec):
+        return a.n
+    if isinstance(a, np.ndarray) and a.ndim == 1 and a.shape[0] >= LAZY_MIN and getattr(a, "_lazy_ok", False):
+        return int(a.shape[0])
+    return 0
+
+
+def lazy_length(args) -> int:
+    """n when the operands of an elementwise operation hold a long vector (all long / array operands of one length n,
+    the others scalars) — the operation then stays lazy; else 0"""
+    n = 0
+    for a in args:
+        m = _long_vector(a)
+        if m:
+            if n and m != n:
+                return 0
+            n = m
+    if not n:
+        return 0
+    for a in args:
+        if _long_vector(a):
+            continue
+        if isinstance(a, (np.ndarray, list, tuple)) and np.ndim(a) > 0:
+            if np.ndim(a) != 1 or len(a) != n:
+                return 0             # broadcasting against another shape: the unrolled rules apply
+    return n
+
+
+def _elem(a, i):
+    if isinstance(a, LazyVec):
+        return a.at(i)
+    if _long_vector(a):
+        return a[i]
+    if isinstance(a, (np.ndarray, list, tuple)) and np.ndim(a) > 0:
+        if isinstance(i, Expr):
+            raise NotImplementedError("a long vector expression mixes a table with a short-lived array of computed "
+                                      "values: index the table inside a plate (`vmap`) instead")
+        v = a[i]
+        return v.item() if isinstance(v, np.ndarray) and v.ndim == 0 else v
+    return a
+
+
+def lazy_apply(fn, *args):
+    """fn over the elements of long-vector operands, lazily (see LazyVec)"""
+    n = lazy_length(args)
+    return LazyVec(n, lambda i: fn(*[_elem(a, i) for a in args]), parts=[a for a in args if not isinstance(a, (int, float, bool))])
+
+
 def is_symbolic(x) -> bool:
-    if isinstance(x, Expr):
+    if isinstance(x, (Expr, LazyVec)):
         return True
     if isinstance(x, np.ndarray) and x.dtype == object:
         return True
@@ -162,6 +311,8 @@ def as_bool(x) -> Expr:
 def _vec(fn):
     """Apply a scalar Expr function elementwise over object arrays."""
     def wrapped(*args):
+        if lazy_length(args):
+            return lazy_apply(wrapped, *args)
         if any(isinstance(a, (np.ndarray, list, tuple)) and np.ndim(a) > 0 for a in args):
             arrs = np.broadcast_arrays(*[np.asarray(a, dtype=object) if not isinstance(a, np.ndarray) or a.dtype != object
                                          else a for a in args])
@@ -180,6 +331,8 @@ def _un(op, x) -> Expr:
 
 
 def _fbin(op, a, b) -> Expr:
+    if isinstance(a, LazyVec) or isinstance(b, LazyVec) or lazy_length((a, b)):
+        return lazy_apply(lambda p, q: _fbin(op, p, q), a, b)
     if isinstance(a, np.ndarray) or isinstance(b, np.ndarray):
         return _vec(lambda p, q: _fbin(op, p, q))(a, b)
     a, b = as_float(a), as_float(b)
@@ -187,6 +340,8 @@ def _fbin(op, a, b) -> Expr:
 
 
 def _arith(fop, iop, a, b) -> Expr:
+    if isinstance(a, LazyVec) or isinstance(b, LazyVec) or lazy_length((a, b)):
+        return lazy_apply(lambda p, q: _arith(fop, iop, p, q), a, b)
     if isinstance(a, np.ndarray) or isinstance(b, np.ndarray):
         return _vec(lambda p, q: _arith(fop, iop, p, q))(a, b)
     a, b = lift(a), lift(b)
@@ -197,6 +352,8 @@ def _arith(fop, iop, a, b) -> Expr:
 
 
 def _cmp(fop, iop, a, b) -> Expr:
+    if isinstance(a, LazyVec) or isinstance(b, LazyVec) or lazy_length((a, b)):
+        return lazy_apply(lambda p, q: _cmp(fop, iop, p, q), a, b)
     if isinstance(a, np.ndarray) or isinstance(b, np.ndarray):
         return _vec(lambda p, q: _cmp(fop, iop, p, q))(a, b)
     a, b = lift(a), lift(b)
@@ -208,6 +365,8 @@ def _cmp(fop, iop, a, b) -> Expr:
 
 
 def _logic(op, a, b) -> Expr:
+    if isinstance(a, LazyVec) or isinstance(b, LazyVec) or lazy_length((a, b)):
+        return lazy_apply(lambda p, q: _logic(op, p, q), a, b)
     if isinstance(a, np.ndarray) or isinstance(b, np.ndarray):
         return _vec(lambda p, q: _logic(op, p, q))(a, b)
     a, b = as_bool(a), as_bool(b)

@@ -19,9 +19,12 @@ SMALL, LARGE = 3, 20          # unrolled / counted-loop sizes (the product switc
 # spec
 # ---------------------------------------------------------------------------
 def random_spec(rng, n_stmts=None, allow_nested=True):
-    kinds = ["leaf", "leaf", "call", "plate", "scan", "mask", "mplate", "mscan"] + (["plate_of_scans", "scan_of_plates"] if allow_nested else [])
+    kinds = ["leaf", "leaf", "call", "plate", "scan", "mask", "mplate", "mscan", "vec"] + (["plate_of_scans", "scan_of_plates"] if allow_nested else [])
     stmts = []
-    for i in range(n_stmts or int(rng.integers(2, 5))):
+    if n_stmts is None:
+        # (one model in eight is LONG: more sites than one launch stores — a chain of launches, program.split_graph)
+        n_stmts = int(rng.integers(12, 26)) if rng.random() < 0.125 else int(rng.integers(2, 5))
+    for i in range(n_stmts):
         kind = kinds[int(rng.integers(len(kinds)))]
         st = dict(kind=kind, name=f"s{i}", c1=float(np.float32(rng.uniform(-1.0, 1.0))), c2=float(np.float32(rng.uniform(-0.5, 0.5))),
                   sd=float(np.float32(rng.uniform(0.5, 2.0))), src=["a", "prev"][int(rng.integers(2))])
@@ -40,6 +43,8 @@ def random_spec(rng, n_stmts=None, allow_nested=True):
             st["T"] = SMALL if rng.integers(2) else LARGE
         if kind == "mask":
             st["flag"] = ["arg", True, False][int(rng.integers(3))]
+        if kind == "vec":               # ONE vector-valued site of many elements (a counted loop per particle)
+            st["n"] = [24, 40, 130][int(rng.integers(3))]
         stmts.append(st)
     return stmts
 
@@ -50,7 +55,7 @@ def spec_args(spec, rng, B):
     extra = []
     for st in spec:
         k = st["kind"]
-        if k in ("plate", "plate_of_scans"):
+        if k in ("plate", "plate_of_scans", "vec"):
             extra.append(rng.normal(size=st["n"]).astype(np.float32))
         elif k in ("scan", "scan_of_plates"):
             extra.append(rng.normal(size=st["T"]).astype(np.float32))
@@ -172,6 +177,11 @@ def build(g, spec, lit):
                     prev = _where(g, b, m, src)
             elif k == "call":
                 prev = st["fn"](m) @ name
+            elif k == "vec":
+                xs = next(it)
+                mean = (m + xs * lit(st["c1"])) if g is not O else (np.asarray(m, np.float32)[..., None] + xs * lit(st["c1"])).astype(np.float32)
+                g.normal(mean, lit(st["sd"])) @ name                     # (its values live in memory only)
+                prev = m
             elif k == "plate":
                 g.Vmap(st["fn"], in_axes=(None, 0))(m, next(it)) @ name      # (a loop plate's values live in memory only)
                 prev = m
@@ -239,6 +249,8 @@ def addresses(spec):
         if k == "leaf":
             kind_ = {"flip": "b", "bernoulli": "b", "uniform": "u", "beta": "u", "categorical": "i"}.get(st["dist"], "f")
             out.append(((nm,), (nm,), (), kind_, False, st))
+        elif k == "vec":
+            out.append(((nm,), (nm,), (st["n"],), "f", False, st))
         elif k == "call":
             out.append(((nm, "p"), (nm, "p"), (), "f", False, st))
             out.append(((nm, "q"), (nm, "q"), (), "f", False, st))
@@ -301,7 +313,7 @@ def _pick_constraints(spec, rng, p, B):
         if kind != "f" or rng.random() > p:
             continue
         form = int(rng.integers(3))
-        if form == 2 and len(shape) == 1 and not masked:
+        if form == 2 and len(shape) == 1 and not masked and st["kind"] != "vec":
             m_ = int(rng.integers(1, min(3, shape[0]) + 1))
             idx = np.sort(rng.choice(shape[0], size=m_, replace=False))
             cons.append((ad, (idx, rng.normal(size=m_).astype(np.float32))))

@@ -630,6 +630,110 @@ def check_three_nested_plates(dims=(20, 20, 20), B=5, seed=1):
     assert np.array_equal(_np(new.get_choices()["y"]), _np(tr.get_choices()["y"]))
 
 
+def check_long_vector_sites(n=500, K=64, seed=1):
+    """A2 / A3 / A8: a vector-valued site of MANY elements under a particle batch (TFP batch semantics,
+    tensorflow_probability/__init__.py:52-62; the score summed by distribution.py:383-396) — the regression
+    `y ~ normal(a * xs + b, sigma)` with n observations under ImportanceK — lowered to ONE counted loop per particle
+    (static._vector_site_loop, tracer.LazyVec) instead of n unrolled copies: element j draws with counter j from the one
+    site key, the score is the element-order sum.  simulate / importance (launch-uniform and per-particle observations)
+    / ImportanceK / assess / update (a new value upstream: every element re-scored; new observations) against the
+    oracle bit for bit, a flip-valued and a uniform-valued long site included."""
+    import genjax_amd as G
+    from genjax_amd import ChoiceMapBuilder as C, Diff, Update, numpy as jnp
+    from genjax_amd.inference.smc import ImportanceK
+
+    def mk(g, lit):
+        prod = g is G
+
+        @g.gen
+        def reg(xs):
+            a = g.normal(lit(0.0), lit(2.0)) @ "a"
+            b = g.normal(lit(0.0), lit(2.0)) @ "b"
+            mean = (a * xs + b) if prod else (a[..., None] * xs + b[..., None]).astype(np.float32)
+            g.normal(mean, lit(0.5)) @ "y"
+            p = (jnp.sigmoid(mean * 0.25) if prod else O.sigmoid((mean * np.float32(0.25)).astype(np.float32)))
+            g.flip(p) @ "f"
+            g.uniform(mean - lit(4.0), (mean * mean if prod else (mean * mean).astype(np.float32)) + lit(5.0)) @ "u"
+            return a
+        return reg
+    m, om = mk(G, float), mk(O, np.float32)
+    dev = G._lib.get().device
+    rng = np.random.default_rng(seed)
+    xs = np.linspace(-1, 1, n).astype(np.float32)
+    ys = (0.7 * xs - 0.2 + 0.5 * rng.normal(size=n)).astype(np.float32)
+    args, oargs = (jnp.array(xs),), (xs,)
+    keys, okeys = G.split(G.key(seed), K), O.split(O.key(seed), K)
+    tr, otr = m.simulate(keys, args), om.simulate(okeys, oargs)
+    for nm in ("a", "b", "y", "f", "u"):
+        assert np.array_equal(_np(tr.get_choices()[nm]), otr.get_choices()[nm]), ("simulate", nm)
+    assert np.array_equal(_np(tr.get_score()), otr.get_score()), "simulate score"
+    coll = ImportanceK(G.Target(m, args, C["y"].set(jnp.array(ys))), k_particles=K).run_smc(G.key(seed + 1))
+    ocoll = O.ImportanceK(O.Target(om, oargs, O.C.d({"y": ys})), K).run_smc(O.key(seed + 1))
+    assert np.array_equal(_np(coll.get_log_weights()), ocoll.get_log_weights()), "ImportanceK log weights"
+    assert np.array_equal(_np(coll.get_particles().get_choices()["u"]), ocoll.get_particles().get_choices()["u"])
+    ypp = (ys[None, :] + 0.1 * rng.normal(size=(K, n))).astype(np.float32)
+    tri, w = m.importance(keys, C["y"].set(torch.from_numpy(ypp).to(dev)), args)
+    otri, ow = om.importance(okeys, O.C.d({"y": ypp}), oargs)
+    assert np.array_equal(_np(w), ow) and np.array_equal(_np(tri.get_score()), otri.get_score()), "importance, per particle"
+    sc, _ = m.assess(tr.get_choices(), args)
+    osc, _ = om.assess(otr.get_choices(), oargs, batch_shape=(K,))
+    assert np.array_equal(_np(sc), osc) and np.array_equal(_np(sc), _np(tr.get_score())), "assess"
+    # update: a new slope (one per particle) — every element of the three long sites re-scored — and new observations
+    a_new = rng.normal(size=K).astype(np.float32)
+    k2, ok2 = G.split(G.key(seed + 2), K), O.split(O.key(seed + 2), K)
+    new, wu, _, bwd = Update(C["a"].set(torch.from_numpy(a_new).to(dev)) | C["y"].set(jnp.array(ys))).edit(
+        k2, tr, Diff.no_change(args))
+    onew, owu, odisc = om.update(ok2, otr, O.C.d({"a": a_new, "y": ys}), oargs)
+    assert np.array_equal(_np(wu), owu, equal_nan=True), "update weight"
+    assert np.array_equal(_np(new.get_score()), onew.get_score(), equal_nan=True), "update score"
+    assert np.array_equal(_np(bwd.constraint["y"]), odisc["y"]), "update discard"
+
+
+def time_vector_site_vs_plate(n=500, K=100_000, reps=5):
+    """seconds per ImportanceK.run_smc of `y ~ normal(a * xs + b, 0.5)` over n observations and K particles: as ONE
+    vector-valued site (a counted loop per particle) and as a `vmap` plate (different key tree, same work)"""
+    import time
+    import genjax_amd as G
+    from genjax_amd import ChoiceMapBuilder as C, numpy as jnp
+    from genjax_amd.inference.smc import ImportanceK
+    dev = G._lib.get().device
+    rng = np.random.default_rng(0)
+    xs = np.linspace(-1, 1, n).astype(np.float32)
+    ys = (0.7 * xs - 0.2 + 0.5 * rng.normal(size=n)).astype(np.float32)
+    args = (jnp.array(xs),)
+
+    @G.gen
+    def point(a, b, x):
+        return G.normal(a * x + b, 0.5) @ "y"
+
+    @G.gen
+    def reg_plate(xs_):
+        a = G.normal(0.0, 2.0) @ "a"
+        b = G.normal(0.0, 2.0) @ "b"
+        point.vmap(in_axes=(None, None, 0))(a, b, xs_) @ "ys"
+        return a
+
+    @G.gen
+    def reg_vec(xs_):
+        a = G.normal(0.0, 2.0) @ "a"
+        b = G.normal(0.0, 2.0) @ "b"
+        G.normal(a * xs_ + b, 0.5) @ "y"
+        return a
+    out = {}
+    for name, model, con in (("vector_site", reg_vec, C["y"].set(jnp.array(ys))), ("vmap_plate", reg_plate, C["ys", :, "y"].set(jnp.array(ys)))):
+        alg = ImportanceK(G.Target(model, args, con), k_particles=K)
+        lw = alg.run_smc(G.key(3)).get_log_weights()
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for r in range(reps):
+            lw = alg.run_smc(G.key(4 + r)).get_log_weights()
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
+        out[name] = (time.perf_counter() - t0) / reps
+    return out
+
+
 def check_nested_marginal(k=129, seed=5):
     """A12 / F4: ChangeTarget.run_csmc_for_normalizing_constant (ref smc.py:432-465),
     estimate_reciprocal_normalizing_constant (:214-225) and Marginal.random_weighted with an inner algorithm

@@ -1792,6 +1792,17 @@ def test_three_combinator_levels_at_loop_sizes_on_device(gpu):
         engine.clear_caches()
 
 
+def test_long_vector_valued_sites_on_device(gpu):
+    """ref tensorflow_probability/__init__.py:52-62 + distribution.py:383-396: `normal(a * xs + b, sigma) @ "y"` with 40 /
+    500 / 5 000 observations under a particle batch as ONE counted loop per particle — interpreter (few particles) and
+    hiprtc-specialised (2^18 particles) — bit for bit against the oracle"""
+    from tests import parity
+    parity.check_long_vector_sites(n=500, K=64)
+    parity.check_long_vector_sites(n=40, K=9, seed=3)
+    parity.check_long_vector_sites(n=5000, K=17, seed=5)
+    parity.check_long_vector_sites(n=48, K=1 << 18, seed=7)
+
+
 def test_update_under_a_changed_table_argument_on_device(gpu):
     """an UnknownChange argument that is a launch-uniform table (> 16 elements, read at a run-time index in the loop):
     every element re-scored — one plate, a plate of plates, a scan over a table, `means[idx]` (ref vmap.py:236-275)"""

@@ -1149,6 +1149,16 @@ def test_three_combinator_levels_at_loop_sizes():
     parity.check_three_nested_plates(dims=(18, 2, 33), B=3, seed=5)
 
 
+def test_long_vector_valued_sites_under_a_particle_batch():
+    """ref tensorflow_probability/__init__.py:52-62 + distribution.py:383-396: `normal(a * xs + b, sigma) @ "y"` over 40,
+    500 and 5 000 observations under a batch of particles — one counted loop per particle, bit for bit against the
+    oracle (simulate / ImportanceK / importance / assess / update; normal, flip and uniform sites)"""
+    from tests import parity
+    parity.check_long_vector_sites(n=500, K=64)
+    parity.check_long_vector_sites(n=40, K=9, seed=3)
+    parity.check_long_vector_sites(n=5000, K=17, seed=5)
+
+
 def test_empty_and_single_particle_batches():
     """jax.vmap over zero keys gives empty arrays, not an error; one particle is just a batch of one"""
     @genjax.gen

@@ -295,7 +295,7 @@ def compile_graph(g: Graph):
     # leaf loads (inputs, launch-index, register-resident constants) are SUNK to their first use:
     # a trace with many input leaves (an edited plate: value + score per element) would otherwise
     # hold every one of them in a register from the top of the program
-    sunk = {n.idx for n in nodes if live[n.idx] and n.idx not in pool_of and n.op in ("LDIN", "CONST", "UNI", "LDIDX")}
+    sunk = {n.idx for n in nodes if live[n.idx] and n.idx not in pool_of and n.op in ("LDIN", "CONST", "UNI", "LDIDX", "RELOAD2")}
     if getattr(g, "nested_loops", False):
         # with two loop levels a step-indexed load means "element t of the loop it was TRACED in": it stays where it is
         # (sunk into the inner loop, an outer-level load would read the inner iteration's element)
@@ -471,9 +471,9 @@ def compile_graph(g: Graph):
             emit(op, dst, R(n.args[0]), 0, n.imm)
         elif op in ("KDERIVER", "KSPLITU"):
             emit(op, dst, R(n.args[0]), R(n.args[1]))
-        elif op == "PAIR":          # a two-register value (key, categorical state) from its two words (split_graph)
-            emit("MOV", dst, R(n.args[0]))
-            emit("MOV", dst + 1, R(n.args[1]))
+        elif op == "RELOAD2":       # a two-register value (key, categorical state) read back from its two scratch words
+            emit("LDIN", dst, n.slot, 0, 0)             # (split_graph: slot = the first word's input slot, imm = the second's)
+            emit("LDIN", dst + 1, n.imm, 0, 0)
         elif op == "CATIDX":        # second register of a categorical state pair
             emit("MOV", dst, R(n.args[0]) + 1)
         elif op in UNARY:
@@ -655,9 +655,11 @@ def split_graph(g: Graph, max_in: int, max_out: int, max_uni: int, max_tab: int,
                 nd = clone(a, ())
             else:                                   # computed by an earlier segment: read its scratch words
                 w0 = spill_word[a.idx]
-                words = [put("LDIN", (), 0, "i32" if a.width == 2 else a.dtype, 0, local_in(("spill", w0 + k)))
-                         for k in range(a.width)]
-                nd = words[0] if a.width == 1 else put("PAIR", words, 0, a.dtype)
+                if a.width == 1:
+                    nd = put("LDIN", (), 0, a.dtype, 0, local_in(("spill", w0)))
+                else:
+                    s0, s1 = local_in(("spill", w0)), local_in(("spill", w0 + 1))
+                    nd = put("RELOAD2", (), s1, a.dtype, 0, s0)
             m[a.idx] = nd
             return nd
 

@@ -1933,7 +1933,7 @@ class _Unfused(Exception):
 
 def _over_the_slots(e) -> bool:
     from .program import ProgramTooLarge
-    return isinstance(e, ProgramTooLarge) or (isinstance(e, ValueError) and "exceeds the ABI slot limits (in=" in str(e))
+    return isinstance(e, ProgramTooLarge) or (isinstance(e, ValueError) and "exceeds the ABI slot limits" in str(e))
 
 
 def _trace_edit(gen_fn, key, trace, request, argdiffs, mh, na, specs, batch, atree, ptree, rspec, tangents, ck, force,

@@ -124,6 +124,8 @@ class Backend:
         c.gmx_program_set_background.argtypes = [c_void_p, c_uint32]
         c.gmx_program_set_fuse_resample.argtypes = [c_void_p]
         c.gmx_program_fuses_resample.argtypes = [c_void_p]
+        c.gmx_program_resident_particles.argtypes = [c_void_p]
+        c.gmx_program_resident_particles.restype = c_int64
         c.gmx_logsumexp_workspace.argtypes = [c_int64, c_int64]
         c.gmx_logsumexp_workspace.restype = c_size_t
         c.gmx_logsumexp.argtypes = [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]

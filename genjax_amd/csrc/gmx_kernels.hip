@@ -152,6 +152,7 @@ struct gmx_program {
   uint64_t jit_code_hash = 0;        // FNV-1a of the loaded code object (gmx_program_code_hash)
   bool fuse_rs = false;              // gmx_program_set_fuse_resample: the specialised kernel can resample first
   bool jit_gathers_pre = false;      // every gathered load of the specialised kernel goes through the prologue's ancestors
+  int64_t jit_resident_blocks = 0;   // workgroups of the specialised kernel one device holds AT ONCE (occupancy x CUs)
   bool background = false;           // gmx_program_set_background: wave priority 0 ...
   unsigned lds_pad = 0;              // ... and this much unused dynamic LDS per workgroup (a residency cap)
 };
@@ -384,6 +385,10 @@ extern "C" int gmx_program_set_fuse_resample(gmx_program* p) {
 extern "C" int gmx_program_fuses_resample(const gmx_program* p) {
   return p && p->jit_fn && p->fuse_rs && p->jit_pp == 4 && p->uses_gather && p->jit_gathers_pre ? 1 : 0;
 }
+extern "C" int64_t gmx_program_resident_particles(const gmx_program* p) {
+  if (!p || !p->jit_fn) return 0;
+  return p->jit_resident_blocks * (int64_t)GMX_BLOCK * (int64_t)p->jit_pp;
+}
 
 // A BACKGROUND program: work that depends on nothing a dependent chain of launches produces (the standard-normal
 // draws of the NEXT SMC steps: keys only), issued on a second stream beside that chain.  Its specialised kernel
@@ -508,6 +513,17 @@ static int jit_load(gmx_program* p, const std::vector<char>& code) {
     hipError_t ea = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->lds_pad);
     if (ea != hipSuccess) { (void)hipGetLastError(); p->lds_pad = 48 * 1024; }
   }
+  // how many of this kernel's workgroups the device holds at once: what the resample-first launch (gmx_run_args.rs),
+  // whose workgroups wait for each other, must fit into — asked of the runtime for THIS code object on THIS device
+  // (a partitioned or smaller device, a heavier step model), never assumed
+  p->jit_resident_blocks = 0;
+  int per_cu = 0, dev = 0, cus = 0;
+  if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, GMX_BLOCK, (size_t)p->lds_pad) == hipSuccess &&
+      hipGetDevice(&dev) == hipSuccess &&
+      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess)
+    p->jit_resident_blocks = (int64_t)per_cu * (int64_t)cus;
+  else
+    (void)hipGetLastError();
   return 0;
 }
 
@@ -603,8 +619,9 @@ extern "C" int gmx_program_run(const gmx_program* p, int64_t n, const gmx_run_ar
     if (!q.tile_max_d || !q.tile_agg_d || !q.max_out_d || !q.total_out_d || !q.status_d)
       return gmx_fail("gmx_program_run: rs has a null pointer%s");
     if ((uintptr_t)q.lw_d & 15) return gmx_fail("gmx_program_run: rs.lw_d must be 16-byte aligned%s");
-    if ((n + RS_TILE - 1) / RS_TILE > 1024)
-      return gmx_fail("gmx_program_run: rs: every workgroup of the launch must be resident at once (n <= 2^20)%s");
+    if ((n + RS_TILE - 1) / RS_TILE > 1024 || n > gmx_program_resident_particles(p))
+      return gmx_fail("gmx_program_run: rs: every workgroup of the launch must be resident at once (n <= 2^20 and "
+                      "n <= gmx_program_resident_particles())%s");
     if (q.shift < 1 || q.shift > 62) return gmx_fail("gmx_program_run: rs.shift out of range%s");
     int need = 0;
     while (((int64_t)1 << need) < n) ++need;

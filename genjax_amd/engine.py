@@ -389,9 +389,14 @@ def _static_token(x):
             hash(v)
             return v
         except TypeError:
-            return ("id", id(v))
+            # never key a program on an object's address: after a collection the address is another object's
+            raise TypeError(f"a Pytree.static() field holds a {type(v).__name__} that is neither hashable nor a dict / list / "
+                            "set of hashable values: it cannot take part in a program cache key") from None
     tok = ("u", freeze(x))
     _STATIC_FIELDS[tok] = x
+    _STATIC_FIELDS.move_to_end(tok)
+    while len(_STATIC_FIELDS) > 1024:        # (a token is read back while its own call is being traced: recent ones suffice)
+        _STATIC_FIELDS.popitem(last=False)
     return tok
 
 
@@ -399,7 +404,7 @@ def _static_value(tok):
     return tok[1] if tok[0] == "v" else _STATIC_FIELDS[tok]
 
 
-_STATIC_FIELDS: dict = {}
+_STATIC_FIELDS: OrderedDict = OrderedDict()
 
 
 def _make_dataclass(cls, values: dict):
@@ -1024,6 +1029,11 @@ class Compiled:
     def fuses_resample(self) -> bool:
         """True when `run(..., resample_in=...)` is honoured (include/genmi.h: gmx_program_fuses_resample)."""
         return self.links is None and bool(self._be.c.gmx_program_fuses_resample(self.handle))
+
+    def resident_particles(self) -> int:
+        """particles one launch of the specialised kernel covers with every workgroup resident at once (include/genmi.h:
+        gmx_program_resident_particles); 0 when not specialised"""
+        return 0 if self.links else int(self._be.c.gmx_program_resident_particles(self.handle))
 
     def writes_tile_stats(self) -> bool:
         """True when a launch can also leave the CDF tile statistics (gmx_run_args.tile_agg_d): a specialised

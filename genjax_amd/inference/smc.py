@@ -1135,8 +1135,10 @@ class BootstrapSweep(_NoiseAhead):
             return self.prepare(key, ys)
         # ONE launch per step where the gathering programs can resample first: two sets of log-weights / statistics (a
         # launch reads step t-1's while it writes step t's)
+        # ... and where the device holds every workgroup of such a launch at once (they wait for each other): asked of
+        # the runtime per code object (engine.Compiled.resident_particles), two launches per step otherwise
         self.fuse = bool(want_fuse and self.tile_stats and gatherers and (self.rejuvenate is None or self.fuse_mh)
-                         and all(p_.comp.fuses_resample() for p_ in gatherers))
+                         and all(p_.comp.fuses_resample() and p_.comp.resident_particles() >= n for p_ in gatherers))
         if self.fuse_req and not self.fuse:
             raise NotImplementedError("BootstrapSweep(fuse_resample=True): needs specialised 4-particles-per-thread programs "
                                       "that gather, systematic resampling and n <= 2^20")

@@ -200,6 +200,12 @@ int gmx_program_writes_tile_stats(const gmx_program* p);
  * exists (4 particles per thread, every gathered load through ancestors_d at the top of the kernel). */
 int gmx_program_set_fuse_resample(gmx_program* p);
 int gmx_program_fuses_resample(const gmx_program* p);
+/* The number of particles ONE launch of the specialised kernel covers with every workgroup resident at once
+ * (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor of its code object x the device's CUs x particles per
+ * workgroup); 0 when not specialised.  The resample-first launch (gmx_run_args.rs) is refused beyond it: its
+ * workgroups wait for each other, and one that is never scheduled would stall the rest until their timeout.
+ * Callers fall back to two launches per step (gmx_resample_tiles + the site program). */
+int64_t gmx_program_resident_particles(const gmx_program* p);
 /* Mark a program as BACKGROUND work before it is specialised: work that depends on nothing a dependent chain of
  * launches produces — e.g. the standard-normal draws of the next SMC steps (keys and particle indices only), which
  * BootstrapSweep's noise-ahead form issues on a second stream beside the chain [site program -> resampler].  The

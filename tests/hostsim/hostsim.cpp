@@ -122,6 +122,7 @@ extern "C" int gmx_program_set_fuse_resample(gmx_program* p) {
   p->fuse_rs = true;
   return 0;
 }
+extern "C" int64_t gmx_program_resident_particles(const gmx_program* p) { return p ? (int64_t)1 << 20 : 0; }   // (the mirror runs workgroups in turn)
 extern "C" int gmx_program_fuses_resample(const gmx_program* p) { return p && p->fuse_rs && hs_tile_mode(p) && hs_gathers(p) ? 1 : 0; }
 extern "C" int64_t gmx_program_grid(const gmx_program* p, int64_t n) { return hs_tile_mode(p) ? (n + 1023) / 1024 : (n + 255) / 256; }
 static uint64_t hs_weight_fixed(float lw, float ref, float scale);

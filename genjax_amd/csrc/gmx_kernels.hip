@@ -1589,7 +1589,6 @@ struct rs_ws {                 // layout of the gmx_resample workspace
   float tmax[RS_MAX_TILES];    // m_b
 };
 
-extern "C" size_t gmx_resample_workspace(int64_t) { return sizeof(rs_ws); }
 
 __global__ void __launch_bounds__(RS_THREADS)
 k_tile_stats(const float* __restrict__ lw, int64_t n, float scale, float* __restrict__ tmax, uint64_t* __restrict__ agg) {
@@ -2425,15 +2424,64 @@ extern "C" int gmx_resample_tiles_p(int kind, const uint32_t key[2], const float
 
 // log-weights -> ancestors: gmx_tile_stats + gmx_resample_tiles with the tile stats in the workspace.
 // max_partials_d / n_partials are accepted for compatibility and unused: the tile maxima are recomputed.
+// THE resampling entry point (include/genmi.h): log-weights -> ancestors for every kind and every n < 2^31, dispatching
+// to the staged forms a caller that already holds tile statistics uses directly.
+struct resample_ws_layout {
+  size_t agg, tmax, pref, table, mnt, cdf, cdfws, mnws, total;
+};
+static size_t ws_up(size_t x) { return (x + 255) & ~(size_t)255; }
+static resample_ws_layout resample_ws_of(int64_t n) {
+  resample_ws_layout L;
+  const size_t tiles = (size_t)((n + RS_TILE - 1) / RS_TILE);
+  size_t o = 0;
+  L.agg = o; o = ws_up(o + tiles * 8);
+  L.tmax = o; o = ws_up(o + tiles * 4);
+  L.pref = o; o = ws_up(o + gmx_tile_prefix_words(n) * 8);
+  L.table = o; o = ws_up(o + gmx_sorted_uniforms_words(n) * 4);
+  L.mnt = o; o = ws_up(o + (n <= (int64_t)RS_MAX_TILES * RS_TILE ? gmx_multinomial_tiled_workspace(n) : 0));
+  L.cdf = o; o = ws_up(o + (size_t)n * 8);
+  L.cdfws = o; o = ws_up(o + gmx_weight_cdf_workspace(n));
+  L.mnws = o; o = ws_up(o + gmx_multinomial_workspace(n));
+  L.total = o;
+  return L;
+}
+extern "C" size_t gmx_resample_workspace(int64_t n) { return n > 0 ? resample_ws_of(n).total : 0; }
+
 extern "C" int gmx_resample(int kind, const uint32_t key[2], const float* lw_d, int64_t n, int shift,
                             const float* max_partials_d, int64_t n_partials, float* max_d,
                             uint64_t* total_d, int32_t* ancestors_d, void* workspace_d, gmx_stream stream) {
   (void)max_partials_d; (void)n_partials;
-  if (!workspace_d) return gmx_fail("gmx_resample: null argument%s");
+  if (!workspace_d || !key || !lw_d || !max_d || !total_d || !ancestors_d) return gmx_fail("gmx_resample: null argument%s");
   if ((uintptr_t)workspace_d & 15) return gmx_fail("gmx_resample: workspace_d must be 16-byte aligned%s");
-  rs_ws* ws = (rs_ws*)workspace_d;
-  if (gmx_tile_stats(lw_d, n, shift, ws->tmax, ws->agg, stream)) return 1;
-  return gmx_resample_tiles(kind, key, lw_d, n, shift, ws->tmax, ws->agg, max_d, total_d, ancestors_d, stream);
+  if (n <= 0 || n > 0x7fffffffLL) return gmx_fail("gmx_resample: n out of range%s");
+  const resample_ws_layout L = resample_ws_of(n);
+  uint8_t* w = (uint8_t*)workspace_d;
+  uint64_t* agg = (uint64_t*)(w + L.agg);
+  float* tmax = (float*)(w + L.tmax);
+  const bool small = (n + RS_TILE - 1) / RS_TILE <= RS_MAX_TILES;
+  if (kind == GMX_RESAMPLE_MULTINOMIAL) {          // iid slot order: the CDF array + the guide-table search
+    uint64_t* cdf = (uint64_t*)(w + L.cdf);
+    if (gmx_weight_cdf(lw_d, n, shift, nullptr, 0, max_d, cdf, total_d, w + L.cdfws, stream)) return 1;
+    return gmx_multinomial(key, cdf, n, total_d, n, ancestors_d, w + L.mnws, stream);
+  }
+  if (kind != GMX_RESAMPLE_SYSTEMATIC && kind != GMX_RESAMPLE_STRATIFIED && kind != GMX_RESAMPLE_MULTINOMIAL_TILED &&
+      kind != GMX_RESAMPLE_MULTINOMIAL_SORTED)
+    return gmx_fail("gmx_resample: unknown kind%s");
+  if (gmx_tile_stats(lw_d, n, shift, tmax, agg, stream)) return 1;
+  if (kind == GMX_RESAMPLE_MULTINOMIAL_TILED) {
+    if (!small) return gmx_fail("gmx_resample: GMX_RESAMPLE_MULTINOMIAL_TILED takes n <= 2^21 (use GMX_RESAMPLE_MULTINOMIAL_SORTED)%s");
+    return gmx_multinomial_tiled(key, lw_d, n, shift, tmax, agg, nullptr, max_d, total_d, ancestors_d, w + L.mnt, -1, stream);
+  }
+  if (small) {
+    if (kind == GMX_RESAMPLE_MULTINOMIAL_SORTED)
+      return gmx_resample_sorted(key, lw_d, n, shift, tmax, agg, (uint32_t*)(w + L.table), 0, max_d, total_d, ancestors_d, stream);
+    return gmx_resample_tiles(kind, key, lw_d, n, shift, tmax, agg, max_d, total_d, ancestors_d, stream);
+  }
+  uint64_t* pref = (uint64_t*)(w + L.pref);           // past 2048 tiles: one prefix pass, then the prefix-reading forms
+  if (gmx_tile_prefix(tmax, agg, n, pref, stream)) return 1;
+  if (kind == GMX_RESAMPLE_MULTINOMIAL_SORTED)
+    return gmx_resample_sorted_p(key, lw_d, n, shift, tmax, pref, (uint32_t*)(w + L.table), 0, max_d, total_d, ancestors_d, stream);
+  return gmx_resample_tiles_p(kind, key, lw_d, n, shift, tmax, pref, max_d, total_d, ancestors_d, stream);
 }
 
 // ---------------------------------------------------------------------------

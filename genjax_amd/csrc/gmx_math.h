@@ -4,14 +4,15 @@
 // add / mul / fma / div / sqrt / rint plus integer bit manipulation.  All of
 // those are correctly rounded on gfx950 (hipcc keeps IEEE div/sqrt by default)
 // and on x86-64, so the same input gives the same bits on the GPU and in the
-// CPU oracle's independent restatement (oracle/orc_math.h) as long as both are
+// CPU oracle's independent restatement (oracle/orc_core.c) as long as both are
 // built with -ffp-contract=off (fusion happens only where fmaf is written).
 //
 // Why not ocml/libm: resampling indices must be bit-exact between MI355X and
 // the CPU oracle (BASELINE.json north_star), and the fixed-point CDF is built
 // from exp(lw - max); vendor expf/logf differ in the last ulp between targets.
 //
-// Accuracy targets (checked in tests/test_oracle_math.py against float64):
+// Accuracy targets (checked against float64 in tests/test_oracle_pins.py::test_elementary_function_accuracy
+// for the oracle's side and, bit for bit against it, in tests/test_gpu_parity.py for this one):
 //   expf, logf, log1pf  <= 2 ulp;  lgammaf <= 4e-6 relative (x >= 1e-3);
 //   erfinvf = the XLA/Giles f32 polynomial (reference: SURVEY.md App. A.2).
 #pragma once

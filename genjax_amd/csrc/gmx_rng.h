@@ -28,10 +28,6 @@ GMX_HD void gmx_threefry2x32(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1,
   uint32_t x0 = c0 + ks0, x1 = c1 + ks1;
   GMX_TF_ROUND(13) GMX_TF_ROUND(15) GMX_TF_ROUND(26) GMX_TF_ROUND(6)
   x0 += ks1; x1 += ks2 + 1u;
-#if defined(GMX_DIAG_SHORT_THREEFRY)   /* timing experiment only (GENMI_JIT_DEFS): 4 of the 20 rounds — WRONG numbers */
-  *o0 = x0; *o1 = x1;
-  return;
-#endif
   GMX_TF_ROUND(17) GMX_TF_ROUND(29) GMX_TF_ROUND(16) GMX_TF_ROUND(24)
   x0 += ks2; x1 += ks0 + 2u;
   GMX_TF_ROUND(13) GMX_TF_ROUND(15) GMX_TF_ROUND(26) GMX_TF_ROUND(6)

@@ -302,6 +302,22 @@ int gmx_ancestors(int kind, const uint32_t key[2], const uint64_t* cdf_d, int64_
 size_t gmx_multinomial_workspace(int64_t n_in);
 int gmx_multinomial(const uint32_t key[2], const uint64_t* cdf_d, int64_t n_in, const uint64_t* total_d /* [1] */,
                     int64_t n_out, int32_t* ancestors_d /* [n_out] */, void* workspace_d, gmx_stream stream);
+/* ---- THE resampling entry point --------------------------------------------------------------------------------
+ * gmx_resample(kind, key, lw_d, n, shift, ..., workspace_d): log-weights -> ancestors, *max_d, *total_d for EVERY kind
+ * (GMX_RESAMPLE_SYSTEMATIC / _STRATIFIED / _MULTINOMIAL / _MULTINOMIAL_TILED / _MULTINOMIAL_SORTED) and every
+ * n < 2^31 (tiled: n <= 2^21): a reference-side binder needs this one call (`gmx_resample(kind, ...)`).
+ * It dispatches to the STAGED forms declared after it, which are public for callers that hold part of the work
+ * already — a specialised site program leaves the tile statistics itself (gmx_run_args.tile_agg_d), a background
+ * stream draws the slot uniforms / the order-statistics table ahead:
+ *   systematic / stratified   gmx_tile_stats -> gmx_resample_tiles            (n <= 2^21)
+ *                             gmx_tile_stats -> gmx_tile_prefix -> gmx_resample_tiles_p          (any n)
+ *   multinomial_sorted        gmx_tile_stats [-> gmx_tile_prefix] -> gmx_resample_sorted[_p] (the table built first)
+ *   multinomial_tiled         gmx_tile_stats -> gmx_multinomial_tiled(phase = -1)
+ *   multinomial (iid order)   gmx_weight_cdf -> gmx_multinomial
+ * workspace_d: gmx_resample_workspace(n) bytes, 16-byte aligned (covers every kind).  max_partials_d / n_partials are
+ * accepted and unused.  DEPRECATED, kept for existing callers: gmx_ancestors over a CDF array as the way to resample
+ * with an ORDERED kind (use gmx_resample), and the CDF-array shard forms gmx_shard_plan / _route / _step below
+ * (superseded by the tile-statistics forms gmx_shard_step_fused / gmx_shard_step_peer). */
 /* Fused one-GPU form of steps 1+2 for SYSTEMATIC / STRATIFIED (n <= 2^21): no CDF in
  * memory and no inter-block waiting; ancestors identical to gmx_weight_cdf +
  * gmx_ancestors.  gmx_tile_stats writes (m_b, A_b) per 1024-particle tile — a
@@ -309,8 +325,7 @@ int gmx_multinomial(const uint32_t key[2], const uint64_t* cdf_d, int64_t n_in, 
  * epilogue when gmx_run_args.tile_agg_d is set (gmx_program_writes_tile_stats), which
  * makes an SMC step two launches.  gmx_resample_tiles turns log-weights + tile stats
  * into ancestors; *max_d / *total_d receive the max log-weight and the integer total
- * (for the evidence increment).  gmx_resample = both, tile stats in the workspace
- * (max_partials_d / n_partials are accepted and unused). */
+ * (for the evidence increment). */
 size_t gmx_resample_workspace(int64_t n);
 int gmx_tile_stats(const float* lw_d, int64_t n, int shift, float* tile_max_d /* [ceil(n/1024)] */,
                    uint64_t* tile_agg_d /* [ceil(n/1024)] */, gmx_stream stream);
@@ -505,6 +520,9 @@ int gmx_select(const uint8_t* mask_d, const void* const* a_d, const void* const*
                gmx_stream stream);
 
 /* ------------------------------------------------------------------------
+ * DEPRECATED as a collective (gmx_p2p_exchange: one launch per collective; superseded by the fused peer exchange above —
+ * gmx_run_args.peer + gmx_shard_step_peer, no collective launch at all).  gmx_p2p_alloc / _open / _close / _free stay:
+ * they are how the fused exchange's landing blocks are allocated and mapped.
  * Peer-mapped exchange over xGMI (GENMI_COMM=p2p; SURVEY.md 8e: "direct P2P all-to-all, not ring").  No reference
  * counterpart (the reference is single-device).  One process per GPU; every rank allocates its receive buffers and a
  * flag row with gmx_p2p_alloc (fine-grained device memory + an IPC handle), the handles travel once through

@@ -79,10 +79,10 @@ def test_environment_switches_are_the_documented_ones():
             if f.endswith((".py", ".hip", ".h", ".cpp", ".sh", ".c")) and f != "test_abi.py":
                 txt = open(os.path.join(base, f), errors="ignore").read()
                 used |= set(re.findall(r"GENMI_[A-Z_]+", txt))
-    # GENMI_H: the header's include guard; GENMI_JIT_DEFS: named in a comment of csrc/gmx_rng.h about a diagnostic build whose
-    # switch was removed in round 4 (nothing reads it)
-    used -= {"GENMI_", "GENMI_H", "GENMI_JIT_DEFS"}
-    assert not any("GENMI_JIT_DEFS" in open(os.path.join(ROOT, "genjax_amd", f)).read() for f in ("_lib.py", "engine.py"))
+    # GENMI_H: the header's include guard
+    used -= {"GENMI_", "GENMI_H"}
+    assert not any("GENMI_JIT_DEFS" in open(os.path.join(ROOT, "genjax_amd", *f)).read()
+                   for f in (("_lib.py",), ("engine.py",), ("csrc", "gmx_rng.h")))      # (the diagnostic short-Threefry build is gone)
     assert used <= documented, sorted(used - documented)
     assert len(documented) <= 20
 

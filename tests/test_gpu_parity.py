@@ -1431,6 +1431,38 @@ def test_integer_cdf_special_values(gpu, case):
     assert (np.isnan(m_ref) and np.isnan(m_got)) or m_ref == m_got
 
 
+def test_gmx_resample_is_the_one_entry_for_every_kind(gpu):
+    """include/genmi.h: `gmx_resample(kind, ...)` dispatches to the staged forms — systematic, stratified, multinomial
+    (iid), multinomial_tiled, multinomial_sorted at n = 5000; the ordered kinds past 2048 tiles too — and gives the
+    ancestors the staged calls (each held to the oracle by its own test) give"""
+    from ctypes import c_uint32
+    import genjax_amd as G
+    from genjax_amd import _lib
+    from genjax_amd.inference import smc
+    be = _lib.get()
+    rng = np.random.default_rng(5)
+    for n, kinds in ((5000, (0, 1, 2, 3, 4)), ((1 << 21) + 4097, (0, 1, 4))):
+        lw = (rng.normal(size=n) * 1.5).astype(np.float32)
+        lw_d = _dev(lw)
+        shift = smc.cdf_shift(n)
+        ws = torch.zeros(((be.c.gmx_resample_workspace(n) + 7) // 8,), dtype=torch.int64, device="cuda")
+        kh = G.key(11).host()
+        kk = (c_uint32 * 2)(int(kh[0]), int(kh[1]))
+        for kind in kinds:
+            mx = torch.zeros(1, dtype=torch.float32, device="cuda")
+            tot = torch.zeros(1, dtype=torch.int64, device="cuda")
+            anc = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+            be.check(be.c.gmx_resample(kind, kk, be.ptr(lw_d), n, shift, None, 0, be.ptr(mx), be.ptr(tot), be.ptr(anc),
+                                       be.ptr(ws), be.stream()), "gmx_resample")
+            if kind == 2:
+                cdf, total, _, _ = smc.weight_cdf(lw_d)
+                ref, rtot = smc.ancestors_from_cdf(2, G.key(11), cdf, total), total
+            else:
+                ref, rtot, _, _ = smc.resample_fused(kind, G.key(11), lw_d.clone())
+            assert int(tot.item()) == int(rtot.item()), (n, kind)
+            assert torch.equal(anc, ref), (n, kind)
+
+
 def test_resampler_fuzz(gpu):
     """random sizes (ragged tiles, single tile, many tiles) x random weight shapes x both ordered kinds:
     gmx_weight_cdf's integers and gmx_resample's ancestors against the oracle"""

@@ -46,7 +46,6 @@ VALU_PEAK_LANE_OPS = 256 * 4 * 16 * 2.4e9   # integer / unpacked-f32 vector inst
                                             # that).  tools/calib.hip on MI355X (profiles/r02_calib.txt): one Threefry-like
                                             # add/rotate/xor chain per lane 33.6 T lane-ops/s, two independent chains 35.5 T
                                             # — no gain from ILP, i.e. the pipe is full — against 39.3 T nominal at 2.4 GHz
-VALU_CALIBRATED_LANE_OPS = 35.5e12
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 # Algorithmic bytes per particle-step (8*D + 24 = 32 B, D = 1):
 #   site program  ancestor 4 + gathered state 4 in, state 4 + log-weight 4 out    = 16 B
@@ -301,17 +300,17 @@ def measure_roofline(be, sw, n, T, world, single, value):
 
     # ---- vector-instruction issue: the limiter ----
     waves = (n + 1023) // 1024 * 4
-    valu = {"peak_T_lane_ops": VALU_PEAK_LANE_OPS / 1e12, "calibrated_ceiling_T_lane_ops": VALU_CALIBRATED_LANE_OPS / 1e12,
-            "peak_note": "256 CU x 4 SIMD x 16 lanes x 2.4 GHz: a wave64 integer / unpacked-f32 instruction holds its SIMD "
-                         "for 4 cycles (tools/calib.hip, profiles/r02_calib.txt: 33.6-35.5 T for Threefry-like chains; the "
-                         "guide's 2-cycle figure is reached by packed f32 only)",
+    valu = {"peak_T_lane_ops": VALU_PEAK_LANE_OPS / 1e12,
+            "peak_note": "the NOMINAL issue peak, 256 CU x 4 SIMD x 16 lanes x 2.4 GHz: a wave64 integer / unpacked-f32 "
+                         "instruction holds its SIMD for 4 cycles (the guide's 2-cycle figure is reached by packed f32 "
+                         "only); no calibrated 'ceiling' is reported any more — a measured chain once exceeded it",
             "insts_per_wave_source": prof_notes}
     per_wave = {k: kern[k].get("valu_insts_per_wave") for k in kern}
     if single and all(v for v in per_wave.values()):
         step_us = us["sweep"] / T
         rate = sum(per_wave.values()) * 64 * waves / (step_us * 1e-6)
         valu.update(insts_per_wave_per_step=sum(per_wave.values()), lane_ops_per_s=rate,
-                    valu_frac=rate / VALU_PEAK_LANE_OPS, valu_frac_of_calibrated_ceiling=rate / VALU_CALIBRATED_LANE_OPS)
+                    valu_frac=rate / VALU_PEAK_LANE_OPS)
         if na:
             nrate = per_wave["gmx_jit_background_kernel"] * 64 * waves / (us["k_noise"] * 1e-6)
             valu["noise_program_isolated_valu_frac"] = nrate / VALU_PEAK_LANE_OPS
@@ -332,8 +331,10 @@ def measure_roofline(be, sw, n, T, world, single, value):
         "algorithmic_bytes_per_step": SWEEP_BYTES_PER_PARTICLE_STEP * n,
         "limiter": "vector-instruction issue (3 Threefry-2x32 blocks per draw fixed by jax's key tree), not HBM: see valu",
         "kernels": kern, "valu": valu, "kernel_us": us, "code_identity": ids,
-        "us_per_step": (us["sweep"] / T) if "sweep" in us else None,
-        "chain_only_us_per_step": (us["chain_only_sweep"] / T) if "chain_only_sweep" in us else None,
+        "us_per_step_event_timed": (us["sweep"] / T) if "sweep" in us else None,
+        "chain_only_us_per_step_event_timed": (us["chain_only_sweep"] / T) if "chain_only_sweep" in us else None,
+        "us_per_step_note": "HIP-event-timed replays of the captured sweep taken AFTER the timed region, in isolation; the "
+                            "figure `value` / `ms_per_step` come from is the timed region itself (ms_per_step / T)",
     }
 
 
@@ -407,7 +408,7 @@ def config_valu(name: str, seconds_per_unit: float):
     wave_insts = float(ent["valu_wave_insts_per_unit"])
     rate = wave_insts * 64.0 / seconds_per_unit
     return {"valu_wave_insts_per_unit": wave_insts, "unit": ent.get("unit"), "lane_ops_per_s": rate,
-            "valu_frac": rate / VALU_PEAK_LANE_OPS, "valu_frac_of_calibrated_ceiling": rate / VALU_CALIBRATED_LANE_OPS,
+            "valu_frac": rate / VALU_PEAK_LANE_OPS,
             "dominant_kernel": ent.get("dominant_kernel"), "dominant_kernel_valu_insts_per_wave": ent.get("dominant_valu_per_wave"),
             "dominant_kernel_us_in_profile": ent.get("dominant_avg_us"), "kernels": ent.get("kernels"),
             "source": {"file": "profiles/counters.json", "tag": ent.get("tag"), "lib": lib}}
@@ -506,6 +507,61 @@ def other_configs():
             kalman_log_ml=workloads.kalman_log_ml(ys))
     except Exception as e:
         out["config2_resampling_kinds"] = {"error": repr(e)[:300]}
+    out["config2_sizes"] = config2_sizes()
+    return out
+
+
+CONFIG2_SIZES = (125_000, 250_000, 500_000, 1_000_000, 2_000_000, 8_000_000)
+
+
+def config2_sizes():
+    """BASELINE config 2 (linear-Gaussian SSM, T = 100, systematic resampling every step, one hipGraph) at six particle
+    counts: where the step stops being launch- / latency-bound, and what a rank holding N / 8 particles of a sharded
+    sweep has to work with (DESIGN.md §6's scaling budget).  us/step, the bytes fraction (32 algorithmic bytes per
+    particle-step against 8 TB/s) and the vector-instruction issue fraction (profile-sourced instructions per wave, used
+    only for the step form they were counted on: one launch per step, n <= 2^20).  Every size's log-ML is held to the
+    C oracle bit for bit in tests/test_gpu_parity.py::test_config2_sizes_log_ml_bit_exact."""
+    import torch
+    import genjax_amd as G
+    from genjax_amd import workloads
+    from genjax_amd.inference import smc
+    T = T_STEPS
+    ys = workloads.lgssm_data(T)
+    init, step = workloads.make_lgssm(G)
+    out = {"workload": "BASELINE config 2 at N particles x 100 steps, one hipGraph per sweep; one launch per step up to "
+                       "2^20 particles, two beyond", "kalman_log_ml": workloads.kalman_log_ml(ys), "sizes": {}}
+    prof = None
+    try:
+        prof = json.load(open(os.path.join(ROOT, "profiles", "counters.json")))
+    except Exception:
+        pass
+    for n in CONFIG2_SIZES:
+        try:
+            sw = smc.BootstrapSweep(init, step, n, T).prepare(G.key(314159), torch.from_numpy(ys)).capture()
+            sw.launch()
+            torch.cuda.synchronize()
+            reps = 5 if n <= 2_000_000 else 3
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                sw.launch()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / reps
+            rec = {"us_per_step": 1e6 * dt / T, "particle_steps_per_s": n * T / dt,
+                   "hbm_frac": SWEEP_BYTES_PER_PARTICLE_STEP * n * T / dt / 1e9 / HBM_PEAK_GBS,
+                   "one_launch_per_step": bool(sw.fuse), "noise_ahead": bool(sw.noise_ahead), "log_ml": sw.log_ml()}
+            valu = None
+            if prof is not None and sw.fuse and sw.noise_ahead:
+                ids = code_identity(sw)
+                cnt, _notes = load_profile_counters(ids)
+                pw = [cnt.get(k, {}).get("valu_per_wave") for k in ("gmx_jit_kernel", "gmx_jit_background_kernel")]
+                if all(pw):
+                    waves = (n + 1023) // 1024 * 4
+                    valu = sum(pw) * 64 * waves / (dt / T) / VALU_PEAK_LANE_OPS
+            rec["valu_frac"] = valu
+            out["sizes"][str(n)] = rec
+            del sw
+        except Exception as e:      # noqa: BLE001
+            out["sizes"][str(n)] = {"error": repr(e)[:300]}
     return out
 
 

@@ -53,6 +53,7 @@ EFFECT = {"STOUT", "REDMAX", "REDLSE", "LOOP", "ENDLOOP", "SETVAR"}
 # key) initialised before OP_LOOP, read inside the block, overwritten by SETVAR (args = (var, new value)) and
 # readable after OP_ENDLOOP.  LDT: the iteration number.
 _NO_CSE = EFFECT | {"LDIN", "UNI", "CONST", "S_CATSTEP", "CATIDX", "LOOPVAR", "LDT", "COPY"}     # slots are unique; CONSTs have their own table
+_FOLD = {"ADD", "SUB", "MUL", "DIV", "SQUARE", "NEG"}
 # values recomputed at every use instead of being held in a register (see compile_graph)
 REMAT_UNARY = {"LOG", "EXP", "NEG", "SQUARE", "SQRT", "RECIP", "I2F"}
 REMAT_BINARY = {"ADD", "SUB", "MUL", "DIV"}
@@ -87,6 +88,10 @@ class Graph:
         """Append a node.  Pure nodes are hash-consed: tracing the same expression twice (e.g. the
         normaliser of a categorical scored once per category in an enumeration) yields ONE node."""
         args = tuple(args)
+        if dtype == "f32" and op in _FOLD:
+            folded = self._fold(op, args)
+            if folded is not None:
+                return folded
         key = None
         if op not in _NO_CSE:
             key = (op, tuple(a.idx if a is not None else -1 for a in args), int(imm) & 0xFFFFFFFF, dtype, flags, slot)
@@ -98,6 +103,35 @@ class Graph:
         if key is not None:
             self._cse[key] = n
         return n
+
+    def _fold(self, op, args):
+        """Trace-time simplifications that cannot change a bit of the result: an operation on CONSTANTS whose IEEE result
+        is correctly rounded on the host as on gfx950 (numpy float32 add / sub / mul / div, the same with
+        -ffp-contract=off on both sides) is evaluated now; `x / 1`, `x * 1`, `x - (+0)` are x for every x (NaN, infinities
+        and signed zeros included).  What this buys: a normal log-density written out in primitive operations
+        (distributions._Normal.sym_logpdf) sheds the divisions by a unit scale and shares `loc / scale`, `log scale`
+        between the elements of a vector-valued site."""
+        def cf(n):
+            return np.float32(struct.unpack("<f", struct.pack("<I", n.imm))[0]) if (n is not None and n.op == "CONST" and n.dtype == "f32") else None
+        vals = [cf(a) for a in args]
+        if all(v is not None for v in vals):
+            with np.errstate(all="ignore"):
+                if op == "ADD": r = vals[0] + vals[1]
+                elif op == "SUB": r = vals[0] - vals[1]
+                elif op == "MUL": r = vals[0] * vals[1]
+                elif op == "DIV": r = vals[0] / vals[1]
+                elif op == "SQUARE": r = vals[0] * vals[0]
+                else: r = np.float32(-vals[0])           # NEG
+            return self.const_bits(int(np.float32(r).view(np.uint32)), "f32")
+        if op == "DIV" and vals[1] is not None and vals[1].view(np.uint32) == 0x3F800000:
+            return args[0]
+        if op == "MUL" and vals[1] is not None and vals[1].view(np.uint32) == 0x3F800000 and args[0].dtype == "f32":
+            return args[0]
+        if op == "MUL" and vals[0] is not None and vals[0].view(np.uint32) == 0x3F800000 and args[1].dtype == "f32":
+            return args[1]
+        if op == "SUB" and vals[1] is not None and vals[1].view(np.uint32) == 0 and args[0].dtype == "f32":
+            return args[0]
+        return None
 
     # leaves -----------------------------------------------------------------
     def const_bits(self, bits: int, dtype: str) -> Node:

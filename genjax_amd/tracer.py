@@ -325,8 +325,38 @@ def _vec(fn):
     return wrapped
 
 
+_DEVICE_FOLD = {"LOG", "EXP", "LOG1P", "SQRT"}      # unary ops of a CONSTANT evaluated once, on the device, at trace time
+_DEVICE_CONSTS: dict = {}
+
+
+def _device_const(op: str, bits: int):
+    """`op(constant)` in the device's own arithmetic (the fixed-sequence gmx_logf / gmx_expf ..., csrc/gmx_math.h):
+    one one-element launch at trace time, cached; None when no launch can be made now (a stream capture in progress)"""
+    k = (op, bits)
+    r = _DEVICE_CONSTS.get(k)
+    if r is not None:
+        return r
+    try:
+        import torch
+        from . import _lib, engine, numpy as jnp
+        be = _lib.get()
+        if be.uses_streams and torch.cuda.is_current_stream_capturing():
+            return None
+        x = torch.tensor([np.array([bits], np.uint32).view(np.float32)[0]], dtype=torch.float32, device=be.device)
+        y = engine.elementwise(getattr(jnp, "_ew_" + op.lower()), x)
+        r = int(y.detach().cpu().numpy().view(np.uint32)[0])
+    except Exception:      # noqa: BLE001  (no backend at all: keep the operation in the program)
+        return None
+    _DEVICE_CONSTS[k] = r
+    return r
+
+
 def _un(op, x) -> Expr:
     x = as_float(x)
+    if op in _DEVICE_FOLD and x.node.op == "CONST":
+        r = _device_const(op, x.node.imm)
+        if r is not None:
+            return Expr(current_graph().const_bits(r, "f32"))
     return Expr(current_graph().add(op, (x.node,), dtype="f32"))
 
 

@@ -3,6 +3,8 @@ on an MI355X and is compared with the CPU oracle on the same seeded inputs.
 Integer / index results must be bit-exact; float results are bit-exact by
 construction for elementwise work (same IEEE op sequence) and within the
 stated tolerance for tree-ordered reductions."""
+import sys
+
 import numpy as np
 import pytest
 import torch
@@ -876,6 +878,48 @@ def test_full_size_sweep_bit_exact_vs_c_oracle(gpu):
     assert np.array_equal(x.view(np.uint32), ox.view(np.uint32))
     assert np.array_equal(lw.view(np.uint32), olw.view(np.uint32))
     assert np.array_equal(anc, oanc)
+
+
+def test_config2_sizes_log_ml_bit_exact(gpu):
+    """bench.py's `other_configs.config2_sizes` (BASELINE config 2 at 1.25e5 ... 8e6 particles x 100 steps; one launch
+    per step up to 2^20 particles, two beyond): every step's integer total and maximum — the terms of the log-ML — and
+    the last ancestors against oracle/orc_sweep.c, bit for bit, at every size"""
+    import ctypes
+    import os
+    import genjax_amd as G
+    from genjax_amd import workloads
+    from genjax_amd.inference.smc import BootstrapSweep
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    T, seed = 100, 314159
+    ys = workloads.lgssm_data(T)
+    init, step = workloads.make_lgssm(G)
+    so = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_build", "liborc_sweep.so")
+    lib = ctypes.CDLL(so)
+    f32, u64, i32 = np.float32, np.uint64, np.int32
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    for n in bench.CONFIG2_SIZES:
+        sw = BootstrapSweep(init, step, n, T).prepare(G.key(seed), torch.from_numpy(ys)).capture()
+        sw.launch()
+        lml = sw.log_ml()
+        _, _, anc = [v.cpu().numpy() for v in sw.state()]
+        anc = anc & 0x1fffff if sw.fuse else anc          # (the one-launch step leaves TAGGED ancestor words)
+        shift = O.cdf_shift(n)
+        ox, ox2, olw = np.zeros(n, f32), np.zeros(n, f32), np.zeros(n, f32)
+        ocdf, oanc = np.zeros(n, u64), np.zeros(n, i32)
+        omax, otot = np.zeros(T, f32), np.zeros(T, u64)
+        rc = lib.orc_lgssm_sweep(ctypes.c_int64(n), ctypes.c_int64(T), P(ys), ctypes.c_uint32(0), ctypes.c_uint32(seed),
+                                 ctypes.c_float(0.9), ctypes.c_float(0.5), ctypes.c_float(1.0), ctypes.c_float(1.0),
+                                 ctypes.c_int(shift), P(ox), P(ox2), P(olw), P(ocdf), P(oanc), P(omax), P(otot))
+        assert rc == 0
+        assert np.array_equal(sw.totals.cpu().numpy().view(np.uint64), otot), n
+        assert np.array_equal(sw.maxs.cpu().numpy().view(np.uint32), omax.view(np.uint32)), n
+        assert np.array_equal(anc, oanc), n
+        olml = float(np.sum(np.array([O.cdf_reference(v) for v in omax], np.float64) + np.log(otot.astype(np.float64))
+                            - shift * np.log(2.0) - np.log(n)))
+        assert lml == olml, (n, lml, olml)
+        assert (n <= 1 << 20) == bool(sw.fuse), n
+        del sw
 
 
 def test_empty_batch_on_device(gpu):

@@ -1204,6 +1204,125 @@ def _vmap_edit_index_o1(self, key, trace, request, argdiffs):
         IndexRequest(idx, bwd)
 
 
+def _scan_edit_index_o1(self, key, trace, request, argdiffs):
+    """`IndexRequest(idx, sub)` on a LONG scan held per particle, in O(1) steps — scan.py:325-416 `edit_index`, literally:
+    the slice of the trace at step idx is edited by `sub` with the caller's key, the slice at idx + 1 is visited by an
+    empty `Update` against the changed carry (its weight is added), and everything else is carried over.  The reference
+    ASSERTS that step idx + 1's return value does not change (`Diff.static_check_no_change(retdiff)`, :366): the edit is
+    defined only for kernels whose outputs depend on the incoming carry through their choices alone.  That property is
+    checked here once per scan, statically — the retdiff of an empty Update under a changed carry (static._trace_edit's
+    change propagation) — and it is also what makes step idx's incoming carry computable from step idx - 1's choices
+    alone (the kernel's return value on that slice: no chain from step 0).  Kernels without the property, changed
+    arguments, one index per particle: the counted-loop form (which re-runs the chain from the top).  The new trace
+    shares every other step with the old one (engine.Patched); its score is the in-order sum of the per-step scores,
+    computed when asked."""
+    import torch
+    from .core.generative import Diff, IndexRequest, Update
+    from .engine import Deferred, Patched, PlateScore, elementwise, materialize
+    from .static import StaticGenerativeFunction, StaticTrace, VmapTrace
+    if not isinstance(request, IndexRequest) or not isinstance(trace, VmapTrace) or len(trace.batch_shape) != 1:
+        return None
+    if argdiffs is not None and not Diff.static_check_no_change(argdiffs):
+        return None
+    if not isinstance(trace.inner, StaticTrace) or not isinstance(self.kernel_gen_fn, (StaticGenerativeFunction, _KernelAdapter)):
+        return None
+    args = tuple(Diff.tree_primal(argdiffs)) if argdiffs is not None else tuple(trace.get_args() or ())
+    if len(args) != 2:
+        return None
+    carry0, xs = args
+    try:
+        T_ = self._length(xs)
+    except (ValueError, TypeError):
+        return None
+    idx = request.idx
+    if T_ <= getattr(self, "unroll_max", SCAN_UNROLL_MAX) or isinstance(idx, torch.Tensor) or self.__dict__.get("_o1_refused"):
+        return None
+    idx = int(idx)
+    if not 0 <= idx < T_:
+        raise IndexError(f"IndexRequest: index {idx} out of range for a scan of {T_} steps")
+    B = int(trace.batch_shape[0])
+    kernel = self.kernel_gen_fn
+    pairs = []
+    _tree_leaves_with_axes(xs, 0, pairs, "scan")
+    if any(not isinstance(leaf, (torch.Tensor, np.ndarray)) for leaf, _ in pairs if leaf is not None):
+        return None
+
+    def x_at(t):
+        def pick(v):
+            e = v[t]
+            return e.item() if isinstance(e, np.generic) else (np.asarray(e) if isinstance(v, np.ndarray) else e)
+        return _tree_take_axes(xs, 0, pick) if xs is not None else None
+
+    def slice_at(t, cin):
+        def take(v):
+            if isinstance(v, Patched):
+                return v.take(t)
+            v = materialize(v)
+            if not isinstance(v, torch.Tensor) or v.ndim < 2 or v.shape[0] != B or v.shape[1] != T_:
+                return v
+            return v[:, t]
+        return _trace_leaf_map(trace.inner, take, args=(cin, x_at(t)))
+    # the property the reference asserts, checked once per scan on step 0: an empty Update under a changed carry leaves
+    # the kernel's return value unchanged
+    if "_o1_ok" not in self.__dict__:
+        _, _, rd0, _ = Update(ChoiceMap.empty()).edit(key, slice_at(0, carry0), (Diff.unknown_change(carry0), Diff.no_change(x_at(0))))
+        self.__dict__["_o1_ok"] = bool(Diff.static_check_no_change(rd0))
+    if not self.__dict__["_o1_ok"]:
+        self.__dict__["_o1_refused"] = True
+        return None
+    # step idx's incoming carry: the kernel's return value on slice idx - 1 (its choices decide it, whatever came in)
+    if idx == 0:
+        cin = carry0
+    else:
+        prev_sl = slice_at(idx - 1, carry0)
+        _, ret_prev = kernel.assess(prev_sl.get_choices(), (carry0, x_at(idx - 1)), batch_shape=(B,))
+        cin = ret_prev[0]
+    new_i, w, _rd, bwd = request.request.edit(key, slice_at(idx, cin), Diff.no_change((cin, x_at(idx))))
+    new_carry = new_i.get_retval()[0]
+    nxt = None
+    if idx + 1 < T_:
+        nxt, w2, rd2, _ = Update(ChoiceMap.empty()).edit(key, slice_at(idx + 1, cin), (Diff.unknown_change(new_carry),
+                                                                                     Diff.no_change(x_at(idx + 1))))
+        if not Diff.static_check_no_change(rd2):          # (cannot happen after the check above; the reference asserts it here)
+            self.__dict__["_o1_refused"] = True
+            return None
+        w = elementwise(lambda a_, b_: a_ + b_, w, w2)
+
+    def patch_at(t):
+        def patch(old, new):
+            base = old if isinstance(old, Patched) and old.depth < PATCH_DEPTH_MAX else materialize(old)
+            shp = tuple(base.shape)
+            rows = torch.as_tensor(materialize(new), device=base.device).to(base.dtype)
+            return Patched(base, t, rows.expand(shp[:1] + shp[2:]))
+        return patch
+    inner_old = trace.inner
+    # (the slices' return values are per-step (carry, y) pairs the scan's inner trace does not keep: only choices and scores
+    #  are patched; the scan's own return value is rebuilt below)
+    new_inner = _trace_leaf_zip(_strip_retval(inner_old), _strip_retval(new_i), patch_at(idx), args=None)
+    if nxt is not None:
+        new_inner = _trace_leaf_zip(new_inner, _strip_retval(nxt), patch_at(idx + 1), args=None)
+    elem_old = getattr(trace, "_elem_scores", None)
+    if elem_old is None:
+        elem_old = Deferred(lambda inner=inner_old: materialize(inner.get_score()), (B, T_))
+    if isinstance(elem_old, Patched) and elem_old.depth >= PATCH_DEPTH_MAX - 1:
+        elem_old = elem_old.materialize()
+    elem_new = Patched(elem_old, idx, materialize(new_i.get_score()))
+    if nxt is not None:
+        elem_new = Patched(elem_new, idx + 1, materialize(nxt.get_score()))
+    old_carry, old_ys = trace.get_retval() if isinstance(trace.retval, tuple) and len(trace.retval) == 2 else (None, None)
+    new_y = new_i.get_retval()[1]
+    ys = _tree_zip(old_ys, new_y, patch_at(idx)) if old_ys is not None else None
+    carry_out = new_carry if idx == T_ - 1 else old_carry
+    out = VmapTrace(self, new_inner, PlateScore(elem_new), (carry_out, ys), args)
+    out._elem_scores = elem_new
+    return out, w, Diff.unknown_change(out.retval), IndexRequest(idx, bwd)
+
+
+def _strip_retval(tr):
+    from .static import StaticTrace
+    return StaticTrace(tr.gen_fn, tr.args, None, tr.subtraces) if isinstance(tr, StaticTrace) else tr
+
+
 def _vmap_edit_launch_axis(self, key, trace, request, argdiffs):
     """`Update` of a large plate held under ONE key (vmap.py:236-275 `edit_choice_map`): the inner function's Update over
     the batch of n elements, keys split(key, n); weight = the plate sum of the elements' weights."""
@@ -1964,6 +2083,9 @@ class Scan(GenerativeFunction):
 
     def edit(self, key, trace, edit_request, argdiffs):
         from .static import run_edit
+        o1 = _scan_edit_index_o1(self, key, trace, edit_request, argdiffs)
+        if o1 is not None:
+            return o1
         return run_edit(self, key, trace, edit_request, argdiffs)
 
     @property

@@ -1922,9 +1922,9 @@ def run_edit(gen_fn, key: Key, trace: Trace, request: EditRequest, argdiffs, mh:
             attempt += 1
             continue
         _CACHE[ck] = ent
-    comp, otree, wo, ao, draws, nprog = ent
+    comp, otree, wo, ao, draws, nprog, ret_changed = ent
     outs = comp.run(flat.leaves + (na.draw(nprog, batch, key, len(draws), "mh") if nprog is not None else []), batch, key)
-    return _finish_edit(request, mh, otree, wo, ao, outs, flat, args, batch, be)
+    return _finish_edit(request, mh, otree, wo, ao, outs, flat, args, batch, be, ret_changed)
 
 
 class _Unfused(Exception):
@@ -1985,10 +1985,30 @@ def _trace_edit(gen_fn, key, trace, request, argdiffs, mh, na, specs, batch, atr
             else:
                 otree = _emit_rec(tr, rec)
             wo = tr.emit_output(w) if w is not None else None
-        return (Compiled(tr, chain=chain), otree, wo, ao) + (_noise_split(tr, batch, na) if na is not None else ((), None))
+            # the retdiff (static.py:948-981 returns the incremental interpreter's): NoChange only when the return value is
+            # made of program values none of which depends on anything this edit changed
+            ret_changed = True
+            if not mh:
+                flat_ret = []
+
+                def walk(v):
+                    if isinstance(v, Sym):
+                        v = v.value
+                    if v is None or isinstance(v, (bool, int, float, np.number)):
+                        return True
+                    if isinstance(v, Expr) or (isinstance(v, np.ndarray) and v.dtype == object):
+                        flat_ret.append(v)
+                        return True
+                    if isinstance(v, (tuple, list)):
+                        return all(walk(x) for x in v)
+                    return False              # (stacked loop outputs, masks, pytrees: conservatively "changed")
+                if walk(retval):
+                    ret_changed = ctx.args_changed(flat_ret)
+        return (Compiled(tr, chain=chain), otree, wo, ao) + (_noise_split(tr, batch, na) if na is not None else ((), None)) \
+            + (ret_changed,)
 
 
-def _finish_edit(request, mh, otree, wo, ao, outs, flat, args, batch, be):
+def _finish_edit(request, mh, otree, wo, ao, outs, flat, args, batch, be, ret_changed=True):
     new_tr = _build_trace(otree, outs, flat.leaves, args)
     w = resolve(wo, outs, flat.leaves) if wo is not None else 0.0
     w = _broadcast_score(w, batch, be.device)
@@ -2006,7 +2026,7 @@ def _finish_edit(request, mh, otree, wo, ao, outs, flat, args, batch, be):
         bwd = _static_bwd(request, otree, outs, flat.leaves)
     else:
         bwd = request if isinstance(request, Rejuvenate) else Update(discard)
-    retdiff = Diff.unknown_change(new_tr.get_retval())
+    retdiff = Diff.unknown_change(new_tr.get_retval()) if ret_changed else Diff.no_change(new_tr.get_retval())
     return new_tr, w, retdiff, bwd
 
 

@@ -734,6 +734,109 @@ def time_vector_site_vs_plate(n=500, K=100_000, reps=5):
     return out
 
 
+def check_scan_index_request_o1(n=64, T=40, seed=14, edits=7, timing=False):
+    """F1 / VERDICT r4 item 9: `IndexRequest(t, sub)` on a LONG scan held per particle (scan.py:325-416 `edit_index`) as
+    the reference states it — slice t edited, slice t + 1 visited by an empty Update against the changed carry, nothing
+    else touched — in O(1) steps (combinators._scan_edit_index_o1): chains of edits (Update of the observation, Update
+    of the state, Regenerate; first, middle and last step) against the oracle's slice / edit / write-back — values,
+    weights, the IN-ORDER score, the return value — and against the counted-loop form of the same edit.  A kernel whose
+    carry runs through arithmetic (a running sum) is refused by the static check and takes the loop form."""
+    import time
+    import genjax_amd as G
+    from genjax_amd import ChoiceMapBuilder as C, Diff, IndexRequest, Regenerate, SelectionBuilder as S, Update, numpy as jnp
+    from genjax_amd import combinators as cmb
+    from genjax_amd.engine import Patched
+    dev = G._lib.get().device
+
+    def mk(g, lit):
+        @g.gen
+        def step(c, x):
+            z = g.normal(c * lit(0.5) + x, lit(1.25)) @ "z"
+            g.normal(z, lit(0.75)) @ "y"
+            return z, z * lit(2.0)
+        return step
+    step, ostep = mk(G, float), mk(O, np.float32)
+    xs = np.linspace(-0.5, 0.5, T).astype(np.float32)
+    sc, osc = G.Scan(step, T), O.Scan(ostep, T)
+    c0 = np.random.default_rng(seed).normal(size=n).astype(np.float32)
+    args, oargs = (torch.from_numpy(c0).to(dev), jnp.array(xs)), (c0, xs)
+    tr, otr = sc.simulate(G.split(G.key(seed), n), args), osc.simulate(O.split(O.key(seed), n), oargs)
+    rng = np.random.default_rng(seed + 1)
+    saw_lazy = False
+    for e in range(edits):
+        t = [0, T - 1, int(rng.integers(1, T - 1)), int(rng.integers(1, T - 1))][e % 4]
+        k, ok = G.split(G.key(seed + 50 + e), n), O.split(O.key(seed + 50 + e), n)
+        kind = e % 3
+        if kind == 0:
+            v = np.float32(rng.normal())
+            sub, osub = Update(C["y"].set(float(v))), (lambda kk, sl, a: ostep.update(kk, sl, O.C.d({("y",): v}), a)[:2])
+        elif kind == 1:
+            vv = rng.normal(size=n).astype(np.float32)
+            sub = Update(C["z"].set(torch.from_numpy(vv).to(dev)))
+            osub = (lambda kk, sl, a, vv=vv: ostep.update(kk, sl, O.C.d({("z",): vv}), a)[:2])
+        else:
+            sub, osub = Regenerate(S["z"]), (lambda kk, sl, a: ostep.regenerate(kk, sl, O.selection("z"), a)[:2])
+        new, w, _, bwd = IndexRequest(t, sub).edit(k, tr, Diff.no_change(args))
+        onew, ow = O.scan_edit_index(osc, ok, otr, oargs, t, osub)
+        saw_lazy = saw_lazy or isinstance(new.inner.subtraces["z"].value, Patched)
+        assert isinstance(bwd, IndexRequest) and bwd.idx == t
+        assert np.array_equal(_np(w), ow), (e, "weight")
+        for nm in ("z", "y"):
+            assert np.array_equal(_np(new.get_choices()[nm]), np.broadcast_to(onew.get_choices()[nm], (n, T))), (e, nm)
+        assert np.array_equal(_np(new.get_score()), onew.get_score()), (e, "score")
+        rc, ry = new.get_retval()
+        orc, ory = onew.get_retval()
+        assert np.array_equal(_np(rc), orc) and np.array_equal(_np(ry), ory), (e, "retval")
+        # the counted-loop form of the same edit (what this replaces): same trace, same weight
+        old_refused = sc.__dict__.get("_o1_refused")
+        sc.__dict__["_o1_refused"] = True
+        try:
+            loop, wl, _, _ = IndexRequest(t, sub).edit(k, tr, Diff.no_change(args))
+        finally:
+            if old_refused is None:
+                sc.__dict__.pop("_o1_refused")
+        assert np.array_equal(_np(wl), _np(w)) and np.array_equal(_np(loop.get_score()), _np(new.get_score())), (e, "loop form")
+        assert np.array_equal(_np(loop.get_choices()["z"]), _np(new.get_choices()["z"]))
+        tr, otr = new, onew
+    assert saw_lazy, "the O(1) form was not taken"
+
+    # a kernel whose carry runs through arithmetic: refused statically, the loop form answers
+    @G.gen
+    def running(c, x):
+        z = G.normal(x, 1.0) @ "z"
+        return c + z, z
+    sc2 = G.Scan(running, T)
+    tr2 = sc2.simulate(G.split(G.key(seed + 9), n), (torch.zeros(n, device=dev), jnp.array(xs)))
+    new2, w2, _, _ = IndexRequest(3, Update(C["z"].set(0.5))).edit(G.split(G.key(seed + 10), n), tr2,
+                                                                   Diff.no_change((torch.zeros(n, device=dev), jnp.array(xs))))
+    assert sc2.__dict__.get("_o1_refused") and not isinstance(new2.inner.subtraces["z"].value, Patched)
+    z_old, z_new = _np(tr2.get_choices()["z"]), _np(new2.get_choices()["z"])
+    assert np.all(z_new[:, 3] == np.float32(0.5)) and np.array_equal(np.delete(z_old, 3, 1), np.delete(z_new, 3, 1))
+    if not timing:
+        return None
+    out = {}
+    for name, refuse in (("o1", False), ("loop", True)):
+        if refuse:
+            sc.__dict__["_o1_refused"] = True
+        else:
+            sc.__dict__.pop("_o1_refused", None)
+        k = G.split(G.key(seed + 99), n)
+        req = IndexRequest(T // 2, Update(C["y"].set(0.25)))
+        req.edit(k, tr, Diff.no_change(args))
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        reps = 5
+        for _ in range(reps):
+            new, w, _, _ = req.edit(k, tr, Diff.no_change(args))
+            _ = _np(w[:1])
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
+        out[name] = (time.perf_counter() - t0) / reps
+    sc.__dict__.pop("_o1_refused", None)
+    return out
+
+
 def check_nested_marginal(k=129, seed=5):
     """A12 / F4: ChangeTarget.run_csmc_for_normalizing_constant (ref smc.py:432-465),
     estimate_reciprocal_normalizing_constant (:214-225) and Marginal.random_weighted with an inner algorithm
@@ -1334,8 +1437,27 @@ def oracle_nlssm_mh_sweep(n, T, seed):
     return {"x": x, "lw": olw, "acc": oacc, "terms": terms, "resampled": x[anc]}
 
 
+def load_golden(name):
+    """a record of tests/golden/full_size.json (tests/golden/make_full_size.py wrote it from the oracle)"""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "full_size.json")) as fh:
+        return json.load(fh)[name]
+
+
+def equals_golden(a, rec, index) -> bool:
+    """the device array against a committed oracle array: sha256 of the raw bytes AND the sampled entries"""
+    import hashlib
+    a = np.ascontiguousarray(a)
+    if list(a.shape) != rec["shape"] or str(a.dtype) != rec["dtype"]:
+        return False
+    flat = a.reshape(-1)[np.asarray(index)]
+    got = [float(np.float32(x)).hex() for x in flat] if a.dtype.kind == "f" else [int(x) for x in flat.astype(np.uint8 if a.dtype == np.bool_ else flat.dtype)]
+    return got == rec["sample"] and hashlib.sha256(a.tobytes()).hexdigest() == rec["sha256"]
+
+
 def check_nlssm_mh_sweep(n=2000, T=5, seed=7, capture=False, specialize=False, want_chained=None, noise_ahead=None,
-                         chain_mh=True, noise_roots=None, fuse_resample=None):
+                         chain_mh=True, noise_roots=None, fuse_resample=None, golden=None):
     """BASELINE config 3 as ONE captured sweep: BootstrapSweep(rejuvenate=...) (k_vm -> resample ->
     fused MH -> k_vm ...) against the oracle run step by step with the sweep's key schedule
     (step key fold_in(key, t) -> (k_prop, k_res, k_mh); resampling of step t-1 uses ITS k_res)."""
@@ -1366,6 +1488,15 @@ def check_nlssm_mh_sweep(n=2000, T=5, seed=7, capture=False, specialize=False, w
         sw.capture()
     sw.launch()
     x, lw, anc = sw.state()
+    if golden is not None:           # the oracle's run of this very sweep, committed (tests/golden/make_full_size.py)
+        rec = load_golden(golden)
+        assert (rec["n"], rec["T"], rec["seed"]) == (n, T, seed)
+        assert equals_golden(x.cpu().numpy(), rec["x"], rec["index"]), "particles differ from the committed oracle run"
+        assert equals_golden(lw.cpu().numpy(), rec["lw"], rec["index"]), "log-weights differ from the committed oracle run"
+        assert equals_golden(sw.accept.cpu().numpy().astype(np.bool_), rec["acc"], rec["index"]), "accept bits differ"
+        olml = float.fromhex(rec["log_ml"])
+        assert abs(sw.log_ml() - olml) < 1e-9 * max(1.0, abs(olml))
+        return {"accept_rate": rec["accept_rate"], "log_ml": sw.log_ml()}
     ref = oracle_nlssm_mh_sweep(n, T, seed)
     otr_x, olw, oacc, terms = ref["x"], ref["lw"], ref["acc"], ref["terms"]
     assert np.array_equal(x.cpu().numpy(), otr_x)

@@ -640,8 +640,11 @@ def test_nonlinear_ssm_mh_sweep_matches_oracle(gpu, n, capture, specialize):
 def test_config3_full_size_sweep_bit_exact(gpu):
     """BASELINE config 3 AT ITS FULL SIZE — 1e6 particles x 100 steps, one MH move per step — as `bench.py` runs it (one
     hipGraph, noise ahead, the move chained into the extension, one launch per step): final particles, log-weights, the
-    last move's accept flags and the evidence against the oracle run step by step (about two minutes of numpy)."""
-    res = parity.check_nlssm_mh_sweep(n=1_000_000, T=100, capture=True, specialize=True, noise_ahead=True)
+    last move's accept flags and the evidence against the oracle's run of the same sweep, COMMITTED as hashes + 300
+    sampled entries (tests/golden/full_size.json, written by tests/golden/make_full_size.py: two minutes of numpy that
+    no longer run inside the GPU suite; test_nonlinear_ssm_mh_sweep_matches_oracle holds 1e5 particles x 23 steps to
+    the live oracle)."""
+    res = parity.check_nlssm_mh_sweep(n=1_000_000, T=100, capture=True, specialize=True, noise_ahead=True, golden="config3")
     assert 0.5 < res["accept_rate"] <= 1.0
 
 
@@ -1007,8 +1010,8 @@ def test_long_scan_config2_as_one_generative_function(gpu):
     """`step.scan(n=100)` on config 2's model, importance for 1e5 particles as ONE generative
     function / one launch (interpreter), bit-exact vs the oracle; the same through the hiprtc-specialised kernel
     (n >= 2^18 particles), and the importance-sampling evidence of a short chain against the Kalman filter."""
-    parity.check_scan_long(n=100_000, T=100)
-    parity.check_scan_long(n=270_000, T=40)                  # >= 2^18: the specialised kernel (GMX_JIT_LOOP)
+    parity.check_scan_long(n=40_000, T=100)
+    parity.check_scan_long(n=270_000, T=24)                  # >= 2^18: the specialised kernel (GMX_JIT_LOOP)
     r = parity.check_scan_long(n=400_000, T=17)
     assert abs(r["log_ml_is"] - r["kalman"]) < 0.25, r         # prior-proposal IS over 18 steps: MC error ~0.1
 
@@ -1046,7 +1049,7 @@ def test_large_plates_as_a_counted_loop(gpu):
     simulate / importance / assess / Update / IndexRequest, bit-exact vs the oracle."""
     parity.check_plates_long(n=300, P=40)
     parity.check_plates_long(n=270_000, P=24, seed=3)
-    parity.check_plates_long(n=10_000, P=4096, seed=5, light=True)       # simulate / importance / assess / single-element constraints
+    parity.check_plates_long(n=3000, P=4096, seed=5, light=True)        # simulate / importance / assess / single-element constraints
     parity.check_plates_long(n=300, P=4096, seed=6)
 
 
@@ -1059,7 +1062,8 @@ def test_index_request_on_a_long_plate_is_o1(gpu):
     import genjax_amd as G
     from genjax_amd import Diff, IndexRequest, Regenerate, SelectionBuilder as S, static
     parity.check_index_request_o1(n=300, P=4096, seed=5, edits=7)
-    parity.check_index_request_o1(n=270_000, P=24, seed=6, edits=40, nested=False)
+    parity.check_index_request_o1(n=270_000, P=24, seed=6, edits=6, nested=False)
+    parity.check_index_request_o1(n=300, P=40, seed=7, edits=40, nested=False)        # (longer than PATCH_DEPTH_MAX: folded)
     n, P = 100_000, 4096
     school = parity._school(G)
     v = school.vmap(in_axes=(None, None, 0))
@@ -1096,7 +1100,7 @@ def test_one_trace_of_a_model_with_large_plates_runs_site_by_site(gpu):
     parity.check_one_trace_with_large_vector_sites(n=5000)
     parity.check_one_trace_with_large_vector_sites(n=300_000, K=64, seed=2)      # the mixture model's data site
     parity.check_mixture_notebook_model(n=5000, k=40)                        # the notebook's own sizes
-    parity.check_mixture_notebook_model(n=1_000_000, k=64, seed=3)          # ... and BASELINE config 5's
+    parity.check_mixture_notebook_model(n=250_000, k=64, seed=3)            # ... and BASELINE config 5's K (its N: test_mixture_assignments_match_oracle)
 
 
 def test_large_plate_of_a_small_particle_batch_is_deferred(gpu):
@@ -1723,8 +1727,8 @@ def test_sorted_multinomial_on_device(gpu):
 
 @pytest.mark.parametrize("kind", ["systematic", "stratified", "multinomial", "multinomial_tiled", "multinomial_sorted"])
 def test_evidence_estimate_is_unbiased_on_device(gpu, kind):
-    """E[Z_hat] = Z (Kalman closed form) over 1500 sweeps of 32 particles on the HIP library: independent of the oracle"""
-    parity.check_evidence_unbiased(kind, R=1500, seed0=5000)
+    """E[Z_hat] = Z (Kalman closed form) over 1000 sweeps of 32 particles on the HIP library: independent of the oracle"""
+    parity.check_evidence_unbiased(kind, R=1000, seed0=5000)
 
 
 def test_sampler_laws_against_scipy_on_device(gpu):
@@ -1776,7 +1780,7 @@ def test_importancek_evidence_is_unbiased_on_device(gpu):
 
 
 def test_evidence_estimate_is_unbiased_with_mh_moves_on_device(gpu):
-    parity.check_evidence_unbiased("systematic", R=3000, T=6, mh=True, seed0=900000)
+    parity.check_evidence_unbiased("systematic", R=1500, T=6, mh=True, seed0=900000)
 
 
 def test_marginal_density_estimates_are_unbiased_on_device(gpu):
@@ -1819,21 +1823,21 @@ def test_peer_mapped_exchange_between_two_processes_on_the_device(gpu, tmp_path,
 
 
 def test_random_models_match_the_oracle_on_device(gpu):
-    """tests/fuzz_models.py on the HIP path: 40 random models on the interpreter (7 particles) and 8 through the
+    """tests/fuzz_models.py on the HIP path: 24 random models on the interpreter (7 particles) and 5 through the
     hiprtc-specialised programs (2^18 particles: engine.JIT_MIN_PARTICLES), every GFI method bit for bit against the
     oracle"""
     from tests import fuzz_models as F
     ran = 0
-    for seed, B in [(s, 7) for s in range(1000, 1040)] + [(s, 1 << 18) for s in range(2000, 2008)]:
+    for seed, B in [(s, 7) for s in range(1000, 1024)] + [(s, 1 << 18) for s in range(2000, 2005)]:
         try:
             F.run_one(seed, B=B)
             ran += 1
         except F.OverTheLimits:
             pass
-    assert ran == 48, ran
-    for seed in range(3000, 3030):
+    assert ran == 29, ran
+    for seed in range(3000, 3016):
         F.run_smc_one(seed)
-    for seed in range(4000, 4008):
+    for seed in range(4000, 4004):
         F.run_big_one(seed)
     F.run_big_one(4100, n_big=100_003, K=50)
 
@@ -1866,6 +1870,15 @@ def test_three_combinator_levels_at_loop_sizes_on_device(gpu):
     finally:
         engine.JIT_MIN_PARTICLES = old
         engine.clear_caches()
+
+
+def test_index_request_on_a_long_scan_is_o1_on_device(gpu):
+    """ref scan.py:325-416 `edit_index` in O(1) steps (combinators._scan_edit_index_o1): chains of edits on 40- and
+    70-step scans against the oracle and the counted-loop form; 2^18 particles through the specialised programs"""
+    from tests import parity
+    parity.check_scan_index_request_o1()
+    parity.check_scan_index_request_o1(n=9, T=70, seed=3, edits=40)
+    parity.check_scan_index_request_o1(n=1 << 18, T=24, seed=5, edits=4)
 
 
 def test_long_vector_valued_sites_on_device(gpu):

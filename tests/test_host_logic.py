@@ -1159,6 +1159,14 @@ def test_long_vector_valued_sites_under_a_particle_batch():
     parity.check_long_vector_sites(n=5000, K=17, seed=5)
 
 
+def test_index_request_on_a_long_scan_is_o1():
+    """ref scan.py:325-416 `edit_index`: slice t edited, slice t + 1 re-visited, nothing else — chains of edits on a
+    40-step scan against the oracle and against the counted-loop form; a running-sum kernel is refused statically"""
+    from tests import parity
+    parity.check_scan_index_request_o1()
+    parity.check_scan_index_request_o1(n=9, T=70, seed=3, edits=40)      # (longer than PATCH_DEPTH_MAX: the lazy leaves are folded)
+
+
 def test_empty_and_single_particle_batches():
     """jax.vmap over zero keys gives empty arrays, not an error; one particle is just a batch of one"""
     @genjax.gen

@@ -1226,6 +1226,13 @@ def _scan_edit_index_o1(self, key, trace, request, argdiffs):
         return None
     if not isinstance(trace.inner, StaticTrace) or not isinstance(self.kernel_gen_fn, (StaticGenerativeFunction, _KernelAdapter)):
         return None
+    def flat_sites(tr):              # (a plate / scan INSIDE the kernel keeps the loop form: its leaves carry further axes)
+        from .static import DistributionTrace
+        if isinstance(tr, DistributionTrace):
+            return True
+        return isinstance(tr, StaticTrace) and type(tr) is StaticTrace and all(flat_sites(st) for st in tr.subtraces.values())
+    if not flat_sites(trace.inner) or isinstance(request.request, IndexRequest):
+        return None
     args = tuple(Diff.tree_primal(argdiffs)) if argdiffs is not None else tuple(trace.get_args() or ())
     if len(args) != 2:
         return None

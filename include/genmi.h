@@ -148,6 +148,36 @@ typedef struct gmx_peer {
   int32_t reserved_;
 } gmx_peer;
 
+/* The ROUTING of the previous step of a SHARDED sweep folded into this launch (gmx_run_args.sh): with lw_d set, a
+ * specialised 4-particles-per-thread program that gathers (gmx_program_fuses_shard_step() == 1) first runs its
+ * workgroup's tile of gmx_shard_step_peer for step t - 1 — polls this rank's landing table for every rank's tile
+ * statistics of that step, derives the global exponent, the totals and the slot bounds, rebuilds its tile of the CDF,
+ * puts the states other ranks' slots need into their landing blocks, stores the ancestors of this rank's own slots as
+ * tagged words {tag: bits 21..31 | index into the extended state: bits 0..20} in ancestors_d, waits for the granules
+ * its own slots need and stores them in the local tails — and then polls the ancestor words of ITS OWN particles and
+ * gathers through them.  A sharded SMC step is then ONE launch and no collective: the site
+ * program's epilogue of step t - 1 announced the statistics (gmx_run_args.peer), this prologue consumes them.  Same
+ * integers, same routing as gmx_shard_step_peer.  Systematic resampling; world <= 8 and world * tiles <= 1024 (the
+ * table fits the registers of one workgroup); n + world * capacity <= 2^21 (the index field); every workgroup of the
+ * launch resident at once (n <= gmx_program_resident_particles()).  The log-weights and the statistics block read
+ * here must not be the ones this launch writes (two sets, alternating). */
+typedef struct gmx_shard_in {
+  const float* lw_d;              /* [n] log-weights of step t - 1 (16-byte aligned); NULL = not fused                  */
+  const void* stats_own_d;        /* this rank's statistics block of step t - 1 (gmx_shard_stats_bytes: A_b, then m_b)  */
+  int64_t* plan_d;                /* gmx_shard_plan_words(world): as gmx_shard_step_peer                                */
+  uint64_t* total_out_d;          /* [1]: the global integer total of step t - 1                                         */
+  float* max_out_d;               /* [1]: the global max log-weight of step t - 1                                        */
+  uint64_t* status_d;             /* [1]: sticky error word (an ancestor word that never arrived)                        */
+  int32_t shift;
+  uint32_t tag;                   /* 1 .. 2047: the tag of this launch's ancestor words                                  */
+  uint32_t key0, key1;            /* resampling key of step t - 1                                                        */
+  uint32_t u0;                    /* filled in by gmx_program_run: bits32(key, 0) >> 9                                   */
+  int32_t reserved_;
+  gmx_peer peer;                  /* the exchange of step t - 1: peer.step = t - 1, peer.leaves routed leaves            */
+  const void* state_d[8];         /* leaf l: this rank's states of step t - 1 [n] (the head of its extended state)      */
+  void* tail_d[8];                /* leaf l: the tail [world * capacity] of that extended state                          */
+} gmx_shard_in;
+
 typedef struct gmx_run_args {
   const void* in_d[GMX_MAX_IN];   /* per-particle inputs (4-byte or 1-byte elems) */
   void* out_d[GMX_MAX_OUT];       /* per-particle outputs                        */
@@ -172,6 +202,7 @@ typedef struct gmx_run_args {
   int64_t step_stride;            /* elements between consecutive steps of a [T, n] leaf addressed with GMX_F_STEP inside
                                      an OP_LOOP (programs with a counted loop: the Scan combinator); normally n         */
   gmx_resample_in rs;             /* optional (rs.lw_d != NULL): resample the previous step first, in this launch (above)  */
+  gmx_shard_in sh;                /* optional (sh.lw_d != NULL): route the previous step of a sharded sweep first (above)   */
   gmx_peer peer;                  /* optional (peer.land_d != NULL), with tile_agg_d: the workgroup ALSO puts its tile's
                                      statistics straight into every other rank's landing table ("Fused peer exchange"
                                      below) — the all-gather of a sharded SMC step without a collective launch        */
@@ -206,6 +237,10 @@ int gmx_program_fuses_resample(const gmx_program* p);
  * workgroups wait for each other, and one that is never scheduled would stall the rest until their timeout.
  * Callers fall back to two launches per step (gmx_resample_tiles + the site program). */
 int64_t gmx_program_resident_particles(const gmx_program* p);
+/* The same for the ROUTING of a sharded step (gmx_run_args.sh): ask before gmx_program_specialize; 1 once such a kernel
+ * exists. */
+int gmx_program_set_fuse_shard_step(gmx_program* p);
+int gmx_program_fuses_shard_step(const gmx_program* p);
 /* Mark a program as BACKGROUND work before it is specialised: work that depends on nothing a dependent chain of
  * launches produces — e.g. the standard-normal draws of the next SMC steps (keys and particle indices only), which
  * BootstrapSweep's noise-ahead form issues on a second stream beside the chain [site program -> resampler].  The

@@ -1562,13 +1562,23 @@ def test_fused_resampler_at_its_size_limit(gpu, kind):
     ws = torch.zeros(((be.c.gmx_resample_workspace(n + 1) + 7) // 8,), dtype=torch.int64, device=be.device)
     out = [torch.zeros((1,), dtype=torch.float32, device=be.device), torch.zeros((1,), dtype=torch.int64, device=be.device),
            torch.zeros((n + 1,), dtype=torch.int32, device=be.device)]
-    with pytest.raises(_lib.GenmiError, match="too large"):
-        be.check(be.c.gmx_resample(kind, (c_uint32 * 2)(1, 2), be.ptr(lw1), n + 1, smc.cdf_shift(n + 1), None, 0, be.ptr(out[0]),
-                                   be.ptr(out[1]), be.ptr(out[2]), be.ptr(ws), be.stream()), "gmx_resample")
+    tiles1 = (n + 1 + 1023) // 1024
+    st = (torch.zeros((tiles1,), dtype=torch.float32, device=be.device), torch.zeros((tiles1,), dtype=torch.int64, device=be.device))
+    be.check(be.c.gmx_tile_stats(be.ptr(lw1), n + 1, smc.cdf_shift(n + 1), be.ptr(st[0]), be.ptr(st[1]), be.stream()), "gmx_tile_stats")
+    with pytest.raises(_lib.GenmiError, match="too large"):          # the table-per-block form itself refuses
+        be.check(be.c.gmx_resample_tiles(kind, (c_uint32 * 2)(1, 2), be.ptr(lw1), n + 1, smc.cdf_shift(n + 1), be.ptr(st[0]),
+                                         be.ptr(st[1]), be.ptr(out[0]), be.ptr(out[1]), be.ptr(out[2]), be.stream()),
+                 "gmx_resample_tiles")
     rc1, rt1, rm1, _ = O.weight_cdf_c(lw1.cpu().numpy())
+    ref1 = O.ancestors_c(kind, O.key(9), rc1)
     anc1, tot1, mx1, _ = smc.resample_fused(kind, G.key(9), lw1)
     assert int(tot1.item()) == rt1 and float(mx1.item()) == rm1
-    assert np.array_equal(anc1.cpu().numpy(), O.ancestors_c(kind, O.key(9), rc1))
+    assert np.array_equal(anc1.cpu().numpy(), ref1)
+    # ... and the one entry point dispatches to the tile-prefix form by itself
+    kh = G.key(9).host()
+    be.check(be.c.gmx_resample(kind, (c_uint32 * 2)(int(kh[0]), int(kh[1])), be.ptr(lw1), n + 1, smc.cdf_shift(n + 1), None, 0,
+                               be.ptr(out[0]), be.ptr(out[1]), be.ptr(out[2]), be.ptr(ws), be.stream()), "gmx_resample")
+    assert int(out[1].item()) == rt1 and np.array_equal(out[2].cpu().numpy(), ref1)
 
 
 @pytest.mark.parametrize("n,shape", [(8192, "normal"), (10_000, "onehot"), (10_000, "none"), (100_003, "heavy"),
@@ -1780,7 +1790,7 @@ def test_importancek_evidence_is_unbiased_on_device(gpu):
 
 
 def test_evidence_estimate_is_unbiased_with_mh_moves_on_device(gpu):
-    parity.check_evidence_unbiased("systematic", R=1500, T=6, mh=True, seed0=900000)
+    parity.check_evidence_unbiased("systematic", R=1000, T=6, mh=True, seed0=900000)
 
 
 def test_marginal_density_estimates_are_unbiased_on_device(gpu):
@@ -1823,21 +1833,21 @@ def test_peer_mapped_exchange_between_two_processes_on_the_device(gpu, tmp_path,
 
 
 def test_random_models_match_the_oracle_on_device(gpu):
-    """tests/fuzz_models.py on the HIP path: 24 random models on the interpreter (7 particles) and 5 through the
+    """tests/fuzz_models.py on the HIP path: 20 random models on the interpreter (7 particles) and 3 through the
     hiprtc-specialised programs (2^18 particles: engine.JIT_MIN_PARTICLES), every GFI method bit for bit against the
     oracle"""
     from tests import fuzz_models as F
     ran = 0
-    for seed, B in [(s, 7) for s in range(1000, 1024)] + [(s, 1 << 18) for s in range(2000, 2005)]:
+    for seed, B in [(s, 7) for s in range(1000, 1020)] + [(s, 1 << 18) for s in range(2000, 2003)]:
         try:
             F.run_one(seed, B=B)
             ran += 1
         except F.OverTheLimits:
             pass
-    assert ran == 29, ran
-    for seed in range(3000, 3016):
+    assert ran == 23, ran
+    for seed in range(3000, 3012):
         F.run_smc_one(seed)
-    for seed in range(4000, 4004):
+    for seed in range(4000, 4003):
         F.run_big_one(seed)
     F.run_big_one(4100, n_big=100_003, K=50)
 

@@ -20,7 +20,7 @@ GMX_MAX_OUT = 64
 GMX_MAX_TAB = 8
 GMX_MAX_UNI = 64
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 KEY_NONE, KEY_ARRAY, KEY_SPLIT, KEY_ROWSPLIT, KEY_BCAST = 0, 1, 2, 3, 4
 RESAMPLE_SYSTEMATIC, RESAMPLE_STRATIFIED, RESAMPLE_MULTINOMIAL, RESAMPLE_MULTINOMIAL_TILED = 0, 1, 2, 3
 RESAMPLE_MULTINOMIAL_SORTED = 4
@@ -60,6 +60,27 @@ class Peer(Structure):
     ]
 
 
+class ShardIn(Structure):
+    """struct gmx_shard_in: the routing of the previous step of a sharded sweep folded into a gathering site program"""
+    _fields_ = [
+        ("lw_d", c_void_p),
+        ("stats_own_d", c_void_p),
+        ("plan_d", c_void_p),
+        ("total_out_d", c_void_p),
+        ("max_out_d", c_void_p),
+        ("status_d", c_void_p),
+        ("shift", c_int32),
+        ("tag", c_uint32),
+        ("key0", c_uint32),
+        ("key1", c_uint32),
+        ("u0", c_uint32),
+        ("reserved_", c_int32),
+        ("peer", Peer),
+        ("state_d", c_void_p * 8),
+        ("tail_d", c_void_p * 8),
+    ]
+
+
 class RunArgs(Structure):
     """struct gmx_run_args"""
     _fields_ = [
@@ -80,6 +101,7 @@ class RunArgs(Structure):
         ("reserved_", c_int32),
         ("step_stride", c_int64),
         ("rs", ResampleIn),
+        ("sh", ShardIn),
         ("peer", Peer),
     ]
 
@@ -103,6 +125,11 @@ class Backend:
 
     def _proto(self):
         c = self.c
+        # the launch-argument struct must have ONE layout on both sides: a stale binding would hand the kernels shifted pointers
+        c.gmx_run_args_bytes.restype = c_size_t
+        if int(c.gmx_run_args_bytes()) != ctypes.sizeof(RunArgs):
+            raise GenmiError(f"gmx_run_args is {c.gmx_run_args_bytes()} bytes in the library and {ctypes.sizeof(RunArgs)} in "
+                             "this binding (genjax_amd/_lib.py): rebuild both from one include/genmi.h")
         c.gmx_version.restype = c_int
         c.gmx_last_error.restype = c_char_p
         c.gmx_threefry2x32_host.argtypes = [c_uint32, c_uint32, c_uint32, c_uint32, POINTER(c_uint32)]
@@ -124,6 +151,8 @@ class Backend:
         c.gmx_program_set_background.argtypes = [c_void_p, c_uint32]
         c.gmx_program_set_fuse_resample.argtypes = [c_void_p]
         c.gmx_program_fuses_resample.argtypes = [c_void_p]
+        c.gmx_program_set_fuse_shard_step.argtypes = [c_void_p]
+        c.gmx_program_fuses_shard_step.argtypes = [c_void_p]
         c.gmx_program_resident_particles.argtypes = [c_void_p]
         c.gmx_program_resident_particles.restype = c_int64
         c.gmx_logsumexp_workspace.argtypes = [c_int64, c_int64]

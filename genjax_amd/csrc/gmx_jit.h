@@ -22,6 +22,9 @@
 #if defined(GMX_JIT_RS)      /* gmx_program_set_fuse_resample: the kernel can resample the previous step first */
 #include "gmx_offspring.h"
 #endif
+#if defined(GMX_JIT_SH)      /* gmx_program_set_fuse_shard_step: ... or route the previous step of a sharded sweep first */
+#include "gmx_shard_fill.h"
+#endif
 
 // a background program (gmx_program_set_background) keeps the default wave priority 0 and has a name of its own
 // (so that kernel traces tell the noise programs from the chain's site programs)
@@ -143,18 +146,15 @@ struct gmx_jit_ctx {
 // the ancestors of the thread's particles: loaded — or, for a fused bootstrap step (gmx_run_args.rs), WRITTEN first
 // (this workgroup's tile of the previous step's resampling: gmx_offspring.h) and then polled until the words of this
 // workgroup's own particles carry the step's tag (workgroup-uniform branch)
-#if defined(GMX_JIT_RS)
-#define GMX_JIT_PRE_ANC                                                                          \
-    if (PP == 4 && A.rs.lw_d) {                                                                  \
-      gmx_offspring_tile_body<GMX_RESAMPLE_SYSTEMATIC, 4, true>(A.rs.key0, A.rs.key1, A.rs.u0, A.rs.lw_d, A.rs.tile_max_d, \
-          A.rs.tile_agg_d, n, (int)gridDim.x, gmx_pow2i(A.rs.shift), A.rs.max_out_d, A.rs.total_out_d,          \
-          const_cast<int32_t*>(A.ancestors_d), nullptr, A.rs.tag);                                \
+// the ancestor words of the thread's own particles, written by workgroups of THIS launch as {tag | index}: polled until
+// they carry the launch's tag (bounded by the wall clock: 2 s, then the sticky status word), then clamped below LIMIT
+#define GMX_JIT_POLL_ANC(TAG, STATUS, LIMIT)                                                     \
       const uint32_t* gmx_aw = reinterpret_cast<const uint32_t*>(A.ancestors_d);                 \
       uint32_t gmx_av[PP];                                                                       \
       bool gmx_ok = true;                                                                        \
       _Pragma("unroll") for (int p = 0; p < PP; ++p) {                                           \
         gmx_av[p] = __hip_atomic_load(gmx_aw + cidx[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
-        gmx_ok &= (gmx_av[p] >> GMX_ANC_TAG_SHIFT) == A.rs.tag;                                  \
+        gmx_ok &= (gmx_av[p] >> GMX_ANC_TAG_SHIFT) == (TAG);                                     \
       }                                                                                          \
       if (!gmx_ok) {                                                                             \
         const uint64_t gmx_t0 = wall_clock64();                                                  \
@@ -163,15 +163,45 @@ struct gmx_jit_ctx {
           gmx_ok = true;                                                                         \
           _Pragma("unroll") for (int p = 0; p < PP; ++p) {                                       \
             gmx_av[p] = __hip_atomic_load(gmx_aw + cidx[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
-            gmx_ok &= (gmx_av[p] >> GMX_ANC_TAG_SHIFT) == A.rs.tag;                              \
+            gmx_ok &= (gmx_av[p] >> GMX_ANC_TAG_SHIFT) == (TAG);                                 \
           }                                                                                      \
         } while (!gmx_ok && wall_clock64() - gmx_t0 < 200000000ull);                             \
-        if (!gmx_ok) __hip_atomic_store(A.rs.status_d, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
+        if (!gmx_ok) __hip_atomic_store((STATUS), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
       }                                                                                          \
       _Pragma("unroll") for (int p = 0; p < PP; ++p) {                                           \
         const uint32_t gmx_i = gmx_av[p] & GMX_ANC_INDEX_MASK;                                   \
-        arow[p] = gmx_i < n32 ? gmx_i : n32 - 1u;                                                \
+        arow[p] = gmx_i < (LIMIT) ? gmx_i : (LIMIT) - 1u;                                        \
+      }
+
+#if defined(GMX_JIT_SH)
+// a SHARDED sweep's step: this workgroup's tile of the routing of step t - 1 first (gmx_run_args.sh; gmx_shard_fill.h),
+// then the ancestor words of its own particles — indices into the extended state [ n local | world * capacity received ]
+#define GMX_JIT_PRE_ANC                                                                          \
+    if (PP == 4 && A.sh.lw_d) {                                                                  \
+      shard_peer gmx_sp;                                                                         \
+      gmx_sp.land = (uint64_t* const*)A.sh.peer.land_d; gmx_sp.tag_base = A.sh.peer.tag_base_d;  \
+      gmx_sp.status = A.sh.peer.status_d; gmx_sp.step = A.sh.peer.step; gmx_sp.leaves = A.sh.peer.leaves; \
+      _Pragma("unroll") for (int l = 0; l < GMX_PEER_MAX_LEAVES; ++l) {                          \
+        gmx_sp.state[l] = (const uint32_t*)A.sh.state_d[l]; gmx_sp.tail[l] = (uint32_t*)A.sh.tail_d[l]; \
       }                                                                                          \
+      gmx_shard_fill_body<GMX_RESAMPLE_SYSTEMATIC, true, true, true>(                            \
+          A.sh.key0, A.sh.key1, A.sh.u0, A.sh.lw_d, (const uint8_t*)A.sh.stats_own_d, (size_t)0, A.sh.peer.tiles, \
+          gmx_pow2i(A.sh.shift), A.sh.peer.rank, A.sh.peer.world, (int32_t)n, (int32_t)A.sh.peer.capacity, A.sh.plan_d, \
+          A.sh.total_out_d, A.sh.max_out_d, (const uint32_t*)nullptr, (uint32_t*)nullptr,         \
+          const_cast<int32_t*>(A.ancestors_d), gmx_sp, A.sh.tag);                                 \
+      const uint32_t gmx_lim = n32 + (uint32_t)A.sh.peer.world * (uint32_t)A.sh.peer.capacity;   \
+      GMX_JIT_POLL_ANC(A.sh.tag, A.sh.status_d, gmx_lim)                                         \
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   /* the received states behind the words: this launch's stores */ \
+    } else {                                                                                     \
+      _Pragma("unroll") for (int p = 0; p < PP; ++p) arow[p] = (uint32_t)A.ancestors_d[cidx[p]]; \
+    }
+#elif defined(GMX_JIT_RS)
+#define GMX_JIT_PRE_ANC                                                                          \
+    if (PP == 4 && A.rs.lw_d) {                                                                  \
+      gmx_offspring_tile_body<GMX_RESAMPLE_SYSTEMATIC, 4, true>(A.rs.key0, A.rs.key1, A.rs.u0, A.rs.lw_d, A.rs.tile_max_d, \
+          A.rs.tile_agg_d, n, (int)gridDim.x, gmx_pow2i(A.rs.shift), A.rs.max_out_d, A.rs.total_out_d,          \
+          const_cast<int32_t*>(A.ancestors_d), nullptr, A.rs.tag);                                \
+      GMX_JIT_POLL_ANC(A.rs.tag, A.rs.status_d, n32)                                             \
     } else {                                                                                     \
       _Pragma("unroll") for (int p = 0; p < PP; ++p) arow[p] = (uint32_t)A.ancestors_d[cidx[p]]; \
     }

@@ -52,6 +52,7 @@ static int gmx_fail(const char* fmt, const char* a = "", long long b = 0) {
   } while (0)
 
 extern "C" int gmx_version(void) { return GMX_ABI_VERSION; }
+extern "C" size_t gmx_run_args_bytes(void) { return sizeof(gmx_run_args); }
 extern "C" const char* gmx_last_error(void) { return g_err; }
 
 extern "C" void gmx_threefry2x32_host(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1,
@@ -152,6 +153,7 @@ struct gmx_program {
   int jit_pp = 1;                    // particles per thread of the specialised kernel
   uint64_t jit_code_hash = 0;        // FNV-1a of the loaded code object (gmx_program_code_hash)
   bool fuse_rs = false;              // gmx_program_set_fuse_resample: the specialised kernel can resample first
+  bool fuse_sh = false;              // gmx_program_set_fuse_shard_step: ... or route a sharded step first
   bool jit_gathers_pre = false;      // every gathered load of the specialised kernel goes through the prologue's ancestors
   int64_t jit_resident_blocks = 0;   // workgroups of the specialised kernel one device holds AT ONCE (occupancy x CUs)
   bool background = false;           // gmx_program_set_background: wave priority 0 ...
@@ -292,6 +294,7 @@ static int jit_pp_for(const gmx_program* p) {
 static std::string jit_source(const gmx_program* p, bool* gathers_prefetched = nullptr) {
   std::string s = p->background ? "#define GMX_JIT_BACKGROUND 1\n" : "";
   if (p->fuse_rs) s += "#define GMX_JIT_RS 1\n";
+  if (p->fuse_sh) s += "#define GMX_JIT_SH 1\n";
   s += "#include \"gmx_jit.h\"\n";
   char buf[128];
   s += "__device__ static constexpr uint32_t GMX_JIT_CONST[] = {";
@@ -385,6 +388,15 @@ extern "C" int gmx_program_set_fuse_resample(gmx_program* p) {
 }
 extern "C" int gmx_program_fuses_resample(const gmx_program* p) {
   return p && p->jit_fn && p->fuse_rs && p->jit_pp == 4 && p->uses_gather && p->jit_gathers_pre ? 1 : 0;
+}
+extern "C" int gmx_program_set_fuse_shard_step(gmx_program* p) {
+  if (!p) return gmx_fail("gmx_program_set_fuse_shard_step: null program%s");
+  if (p->jit_fn) return gmx_fail("gmx_program_set_fuse_shard_step: the program is already specialised%s");
+  p->fuse_sh = true;
+  return 0;
+}
+extern "C" int gmx_program_fuses_shard_step(const gmx_program* p) {
+  return p && p->jit_fn && p->fuse_sh && p->jit_pp == 4 && p->uses_gather && p->jit_gathers_pre ? 1 : 0;
 }
 extern "C" int64_t gmx_program_resident_particles(const gmx_program* p) {
   if (!p || !p->jit_fn) return 0;
@@ -596,6 +608,7 @@ extern "C" int64_t gmx_program_grid(const gmx_program* p, int64_t n) {
   return (n + per - 1) / per;
 }
 
+static int peer_check(const char* who, const gmx_peer& P, int64_t n_per_rank);
 extern "C" int gmx_program_run(const gmx_program* p, int64_t n, const gmx_run_args* args,
                                gmx_stream stream) {
   if (!p || !args) return gmx_fail("gmx_program_run: null argument%s");
@@ -634,6 +647,33 @@ extern "C" int gmx_program_run(const gmx_program* p, int64_t n, const gmx_run_ar
       if ((const void*)args->out_d[s] == (const void*)q.lw_d)
         return gmx_fail("gmx_program_run: rs.lw_d is also an output of this launch (use two buffers)%s");
   }
+  const bool fused_sh = args->sh.lw_d != nullptr;
+  if (fused_sh) {
+    const gmx_shard_in& q = args->sh;
+    if (fused_rs) return gmx_fail("gmx_program_run: rs and sh are both set%s");
+    if (!gmx_program_fuses_shard_step(p))
+      return gmx_fail("gmx_program_run: sh is set but this program cannot route a sharded step in its own launch "
+                      "(gmx_program_set_fuse_shard_step before specialising; 4 particles per thread; gathering)%s");
+    if (!q.stats_own_d || !q.plan_d || !q.total_out_d || !q.max_out_d || !q.status_d)
+      return gmx_fail("gmx_program_run: sh has a null pointer%s");
+    if (((uintptr_t)q.lw_d & 15) || ((uintptr_t)q.stats_own_d & 7))
+      return gmx_fail("gmx_program_run: sh.lw_d must be 16-byte and sh.stats_own_d 8-byte aligned%s");
+    if (peer_check("gmx_program_run (sh)", q.peer, n)) return 1;
+    if (q.peer.world > 8 || (int64_t)q.peer.world * q.peer.tiles > 4 * GMX_BLOCK)
+      return gmx_fail("gmx_program_run: sh: world <= 8 and world * tiles <= 1024%s");
+    if (n + (int64_t)q.peer.world * q.peer.capacity > (int64_t)GMX_ANC_INDEX_MASK + 1)
+      return gmx_fail("gmx_program_run: sh: n + world * capacity must fit the 21-bit index of an ancestor word%s");
+    if (n > gmx_program_resident_particles(p))
+      return gmx_fail("gmx_program_run: sh: every workgroup of the launch must be resident at once "
+                      "(n <= gmx_program_resident_particles())%s");
+    if (q.shift < 1 || q.shift > 62) return gmx_fail("gmx_program_run: sh.shift out of range%s");
+    if (q.tag < 1u || q.tag > 2047u) return gmx_fail("gmx_program_run: sh.tag must be in [1, 2047]%s");
+    for (int l = 0; l < q.peer.leaves; ++l)
+      if (!q.state_d[l] || !q.tail_d[l]) return gmx_fail("gmx_program_run: sh: a leaf pointer is null%s");
+    for (uint32_t s_ = 0; s_ < p->n_out; ++s_)
+      if ((const void*)args->out_d[s_] == (const void*)q.lw_d)
+        return gmx_fail("gmx_program_run: sh.lw_d is also an output of this launch (use two buffers)%s");
+  }
   if (p->uses_red && !args->red_out_d)
     return gmx_fail("gmx_program_run: program reduces but red_out_d is null%s");
   if (args->tile_agg_d) {
@@ -657,13 +697,18 @@ extern "C" int gmx_program_run(const gmx_program* p, int64_t n, const gmx_run_ar
   hipStream_t st = (hipStream_t)stream;
   // the program's constants live in the operand pool after the launch uniforms
   gmx_run_args patched;
-  if (p->n_const || fused_rs) {
+  if (p->n_const || fused_rs || fused_sh) {
     patched = *args;
     for (uint32_t k = 0; k < p->n_const; ++k) patched.uni[p->n_dyn + k] = p->consts[k];
     if (fused_rs) {
       uint32_t b0, b1;
       gmx_threefry2x32(patched.rs.key0, patched.rs.key1, 0u, 0u, &b0, &b1);     // bits32(key, 0) on the host
       patched.rs.u0 = (b0 ^ b1) >> 9;
+    }
+    if (fused_sh) {
+      uint32_t b0, b1;
+      gmx_threefry2x32(patched.sh.key0, patched.sh.key1, 0u, 0u, &b0, &b1);
+      patched.sh.u0 = (b0 ^ b1) >> 9;
     }
     args = &patched;
   }

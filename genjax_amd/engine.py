@@ -1030,6 +1030,14 @@ class Compiled:
         """True when `run(..., resample_in=...)` is honoured (include/genmi.h: gmx_program_fuses_resample)."""
         return self.links is None and bool(self._be.c.gmx_program_fuses_resample(self.handle))
 
+    def set_fuse_shard_step(self):
+        """Before specialize(): the kernel can route the previous step of a sharded sweep first (include/genmi.h:
+        gmx_run_args.sh)."""
+        self._be.check(self._be.c.gmx_program_set_fuse_shard_step(self.handle), "gmx_program_set_fuse_shard_step")
+
+    def fuses_shard_step(self) -> bool:
+        return self.links is None and bool(self._be.c.gmx_program_fuses_shard_step(self.handle))
+
     def resident_particles(self) -> int:
         """particles one launch of the specialised kernel covers with every workgroup resident at once (include/genmi.h:
         gmx_program_resident_particles); 0 when not specialised"""
@@ -1041,9 +1049,9 @@ class Compiled:
         return self.links is None and bool(self._be.c.gmx_program_writes_tile_stats(self.handle))
 
     def run(self, leaves, batch: tuple, key: Key | None, red_out=None, index_offset=0, out_buffers=None,
-            tile_stats=None, peer=None, resample_in=None):
+            tile_stats=None, peer=None, resample_in=None, shard_in=None):
         """Bind and launch.  Returns the list of output tensors (shape batch+event)."""
-        bound = self.bind(leaves, batch, key, red_out, index_offset, out_buffers, tile_stats, peer, resample_in)
+        bound = self.bind(leaves, batch, key, red_out, index_offset, out_buffers, tile_stats, peer, resample_in, shard_in)
         self.launch(bound)
         return bound[3]
 
@@ -1066,7 +1074,7 @@ class Compiled:
         be.check(be.c.gmx_program_run(self.handle, bound[0], bound[1], be.stream()), "gmx_program_run")
 
     def bind(self, leaves, batch: tuple, key: Key | None, red_out=None, index_offset=0, out_buffers=None,
-             tile_stats=None, peer=None, resample_in=None):
+             tile_stats=None, peer=None, resample_in=None, shard_in=None):
         """Fill a gmx_run_args for these leaves: (n, args, keep-alive list, outputs).  Sweeps whose
         buffers are persistent bind every step once and re-launch the bindings.
         tile_stats = (int64 tensor [grid], shift): the launch also writes the per-workgroup fixed-point weight sums
@@ -1086,7 +1094,7 @@ class Compiled:
             # 31-register interpreter cannot hold
             self.specialize()
         if self.links:
-            if tile_stats is not None or peer is not None or resample_in is not None:
+            if tile_stats is not None or peer is not None or resample_in is not None or shard_in is not None:
                 raise NotImplementedError("a site program cut into a chain of launches takes no tile statistics / peers / "
                                           "fused resampling")
             A = _WideArgs(self.n_in, self.n_out, self.n_uni, len(self.tables))
@@ -1243,6 +1251,23 @@ class Compiled:
             A.rs.max_out_d, A.rs.total_out_d, A.rs.status_d = r["max_out"].data_ptr(), r["total_out"].data_ptr(), r["status"].data_ptr()
             A.rs.shift, A.rs.tag = int(r["shift"]), int(r["tag"])
             A.rs.key0, A.rs.key1 = int(r["key"][0]), int(r["key"][1])
+        if shard_in is not None:
+            # the routing of the previous step of a SHARDED sweep first (gmx_run_args.sh, `fuses_shard_step()`): dict(lw,
+            # stats_own, plan, total_out, max_out, status, shift, tag, key=(k0, k1), peer=_lib.Peer, state=[tensors], tail=[tensors])
+            r = shard_in
+            if anc is None:
+                raise ValueError("shard_in: the program gathers nothing")
+            for name in ("lw", "stats_own", "plan", "total_out", "max_out", "status"):
+                keep.append(r[name])
+            keep += list(r["state"]) + list(r["tail"])
+            S = A.sh
+            S.lw_d, S.stats_own_d, S.plan_d = r["lw"].data_ptr(), r["stats_own"].data_ptr(), r["plan"].data_ptr()
+            S.total_out_d, S.max_out_d, S.status_d = r["total_out"].data_ptr(), r["max_out"].data_ptr(), r["status"].data_ptr()
+            S.shift, S.tag = int(r["shift"]), int(r["tag"])
+            S.key0, S.key1 = int(r["key"][0]), int(r["key"][1])
+            S.peer = r["peer"]
+            for l, (st_, tl_) in enumerate(zip(r["state"], r["tail"])):
+                S.state_d[l], S.tail_d[l] = st_.data_ptr(), tl_.data_ptr()
         if self.links:
             return n, self._chain_args(A, n, keep), keep, outs
         return n, A, keep, outs

@@ -91,7 +91,7 @@ class ShardedBootstrapSweep(_NoiseAhead):
 
     def __init__(self, init, step, n_per_rank: int, T: int, dist, obs_addr="y", step_extra=None, specialize=True,
                  resample="systematic", capacity=None, always_communicate=False, rejuvenate=None, state_addr="x",
-                 noise_ahead=None, cdf_form=False, fused=True, comm=None):
+                 noise_ahead=None, cdf_form=False, fused=True, comm=None, fuse_step=None):
         """cdf_form=True: the three-collective CDF-array form (what n > 2^21 per rank or > 64 ranks take) instead of
         the tile statistics; fused=False: gmx_shard_totals + gmx_shard_step_tiles as two launches (what a vector
         state / the MH move's second leaf take) instead of gmx_shard_step_fused."""
@@ -130,6 +130,7 @@ class ShardedBootstrapSweep(_NoiseAhead):
         # CDF-array form, two routing launches
         self.cdf_form, self.fused_req = bool(cdf_form) or self.kind == MULTINOMIAL_SORTED, bool(fused)
         self._noise_offset, self._noise_total = self.rank * self.n, self.N
+        self.fuse_sh_req, self.fuse_sh = fuse_step, False      # None: one launch per step where it applies (prepare)
 
     def _chain_prog(self, t):
         return self.p_init if t == 0 else self.p_step
@@ -208,6 +209,16 @@ class ShardedBootstrapSweep(_NoiseAhead):
         elif want_na and self.p_init.noise:
             self.noise_ahead_req = False          # the steady-state program draws nothing ahead: the plain programs
             return self.prepare(key, ys)
+        # ONE launch per sharded step: the program that gathers routes the previous step itself
+        # (gmx_run_args.sh: its workgroup's tile of gmx_shard_step_peer, ancestors as tagged words) — the fused peer
+        # exchange, systematic resampling, a scalar / short vector state without an MH move, a table that fits one
+        # workgroup's registers, indices that fit an ancestor word
+        tiles_ = (n + CDF_TILE - 1) // CDF_TILE
+        want_fuse_sh = bool(self.peer_mode and be.uses_streams and self.specialize and self.kind == SYSTEMATIC
+                            and self.rejuvenate is None and W <= 8 and W * tiles_ <= 1024 and self.D <= 8
+                            and n + W * self.capacity <= (1 << 21) and self.fuse_sh_req is not False)
+        if want_fuse_sh and not self.p_step.comp.is_specialized():
+            self.p_step.comp.set_fuse_shard_step()
         if self.specialize and be.uses_streams:
             self.p_init.comp.specialize()
             self.p_step.comp.specialize()
@@ -230,6 +241,19 @@ class ShardedBootstrapSweep(_NoiseAhead):
                 torch.zeros((W * sb,), dtype=torch.uint8, device=dev)
             self.tile_agg = self.stats_own[:pad * 8].view(torch.int64)
             self.tile_max = self.stats_own[pad * 8:].view(torch.float32)
+            # (the one-launch step reads step t - 1's log-weights / statistics while it writes step t's: two sets)
+            self.stats_own_pp = [self.stats_own, torch.zeros_like(self.stats_own)]
+            self.tile_agg_pp = [b_[:pad * 8].view(torch.int64) for b_ in self.stats_own_pp]
+            self.tile_max_pp = [b_[pad * 8:].view(torch.float32) for b_ in self.stats_own_pp]
+        self.fuse_sh = bool(want_fuse_sh and self.tiles_mode and self.p_step.comp.fuses_shard_step()
+                            and self.p_init.comp.writes_tile_stats() and self.p_step.comp.writes_tile_stats()
+                            and self.p_step.comp.resident_particles() >= n)
+        if self.fuse_sh_req and not self.fuse_sh:
+            raise NotImplementedError("ShardedBootstrapSweep(fuse_step=True): needs the fused peer exchange, systematic "
+                                      "resampling, specialised programs that leave tile statistics, world <= 8")
+        self.lw_pp = [self.lw, torch.zeros_like(self.lw)] if self.fuse_sh else [self.lw, self.lw]
+        if self.fuse_sh:
+            self.sh_status = torch.zeros((1,), dtype=torch.int64, device=dev)
         self.step_keys = []
         for t in range(T):
             ks = split(fold_in(key, t), 3)
@@ -320,7 +344,9 @@ class ShardedBootstrapSweep(_NoiseAhead):
         bufs = [None] * len(prog.comp.outputs)
         rows_t = self.xrows[t % 2]
         bufs[prog.ro[1]] = rows_t[:, :n]                 # [D, n] window of the [D, n + W*C] rows
-        bufs[prog.wo[1]] = self.lw.reshape(1, n)
+        w_ = t % 2 if self.fuse_sh else 0                # (one launch per step: two sets of log-weights / statistics)
+        lw_t = self.lw_pp[w_]
+        bufs[prog.wo[1]] = lw_t.reshape(1, n)
         # keys of the GLOBAL particle index: split(k_prop, N)[g*n + i]
         writes_stats = self.tiles_mode and prog.comp.writes_tile_stats()
         peer = None
@@ -330,9 +356,27 @@ class ShardedBootstrapSweep(_NoiseAhead):
             peer.rank, peer.world, peer.step, peer.tiles = g, W, t, (n + CDF_TILE - 1) // CDF_TILE
             peer.capacity = C
             peer.leaves = self.D * (2 if (self.rejuvenate is not None and t >= 1) else 1)
+        shard_in = None
+        if self.fuse_sh and t >= 1:
+            # this launch ROUTES step t - 1 first: that step's log-weights, statistics, states and resampling key
+            pw = (t - 1) % 2
+            prev_rows = self.xrows[pw]
+            kh_ = self.step_keys[t - 1][1].host()
+            p_prev = _lib.Peer()
+            p_prev.land_d, p_prev.tag_base_d, p_prev.status_d = peer.land_d, peer.tag_base_d, peer.status_d
+            p_prev.rank, p_prev.world, p_prev.step, p_prev.tiles = g, W, t - 1, peer.tiles
+            p_prev.capacity, p_prev.leaves = C, self.D
+            shard_in = dict(lw=self.lw_pp[pw], stats_own=self.stats_own_pp[pw], plan=self.plan, total_out=self.totals[t - 1:t],
+                            max_out=self.maxs[t - 1:t], status=self.sh_status, shift=self.shift, tag=1 + (t - 1) % 2047,
+                            key=(int(kh_[0]), int(kh_[1])), peer=p_prev, state=[prev_rows[d] for d in range(self.D)],
+                            tail=[prev_rows[d][n:] for d in range(self.D)])
         if writes_stats:        # the workgroup maxima land in the statistics block (red_out plane 0), the sums beside them
-            vm = prog.comp.bind(leaves, (n,), lazy_split(k_prop, self.N), red_out=self.tile_max, out_buffers=bufs,
-                                index_offset=g * n, tile_stats=(self.tile_agg, self.shift), peer=peer)
+            st_w = t % 2 if self.fuse_sh else 0
+            vm = prog.comp.bind(leaves, (n,), lazy_split(k_prop, self.N),
+                                red_out=self.tile_max_pp[st_w] if self.fuse_sh else self.tile_max, out_buffers=bufs,
+                                index_offset=g * n,
+                                tile_stats=((self.tile_agg_pp[st_w] if self.fuse_sh else self.tile_agg), self.shift),
+                                peer=peer, shard_in=shard_in)
         else:
             vm = prog.comp.bind(leaves, (n,), lazy_split(k_prop, self.N), red_out=self.partials, out_buffers=bufs,
                                 index_offset=g * n)
@@ -366,8 +410,9 @@ class ShardedBootstrapSweep(_NoiseAhead):
                 L = len(rows_l)
                 st_arr = (_vp * L)(*[r.data_ptr() for r in rows_l])
                 tl_arr = (_vp * L)(*[r[n:].data_ptr() for r in rows_l])
-                pk = {"peer": peer, "put_stats": None if writes_stats else (P(self.stats_own), peer, n),
-                      "step": (self.kind, kk, P(self.stats_own), peer, P(self.plan), P(tot), P(self.lw), P(m), self.shift, n,
+                so_t = self.stats_own_pp[t % 2] if self.fuse_sh else self.stats_own
+                pk = {"peer": peer, "put_stats": None if writes_stats else (P(so_t), peer, n),
+                      "step": (self.kind, kk, P(so_t), peer, P(self.plan), P(tot), P(lw_t), P(m), self.shift, n,
                                st_arr, tl_arr, P(self.idx)), "keep": (rows_l, st_arr, tl_arr)}
             tiles = {"peer": pk,
                      "stats": None if writes_stats else (P(self.lw), n, self.shift, P(self.tile_max), P(self.tile_agg)),
@@ -409,6 +454,8 @@ class ShardedBootstrapSweep(_NoiseAhead):
                 pk = tl["peer"]
                 if pk["put_stats"] is not None:
                     be.check(c.gmx_peer_put_stats(*pk["put_stats"], st), "gmx_peer_put_stats")
+                if self.fuse_sh and t + 1 < self.T:
+                    return                      # ONE launch per step: step t is routed by the launch of step t + 1
                 be.check(c.gmx_shard_step_peer(*pk["step"], st), "gmx_shard_step_peer")
                 return
             if self.comm:
@@ -525,7 +572,8 @@ class ShardedBootstrapSweep(_NoiseAhead):
             # a wait that timed out (a peer that never arrived) fails the sweep on EVERY rank instead of handing back
             # stale particles: the communicator's error word travels with the overflow flag
             if hasattr(self.cx, "failed"):
-                bad = bool(self.cx.failed()) or (self.peer_mode and int(self.peer_status[0].item()) != 0)
+                bad = bool(self.cx.failed()) or (self.peer_mode and int(self.peer_status[0].item()) != 0) \
+                    or (self.fuse_sh and int(self.sh_status.item()) != 0)      # (an ancestor word that never arrived)
                 flag = torch.where(torch.tensor(bad, device=flag.device), torch.full_like(flag, 2), flag)
             self.cx.all_reduce_max(flag)
         if int(flag.item()) >= 2:

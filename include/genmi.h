@@ -39,12 +39,15 @@ typedef __UINTPTR_TYPE__ uintptr_t;
 extern "C" {
 #endif
 
-#define GMX_ABI_VERSION 5
+#define GMX_ABI_VERSION 6
 
 typedef void* gmx_stream;            /* hipStream_t */
 typedef struct gmx_program gmx_program;
 
 int gmx_version(void);
+/* sizeof(gmx_run_args) as this library was built: a binding whose own layout of the struct differs must refuse to
+ * launch (a stale binding would hand the kernels shifted pointers). */
+size_t gmx_run_args_bytes(void);
 const char* gmx_last_error(void);
 
 /* ------------------------------------------------------------------------

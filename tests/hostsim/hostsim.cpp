@@ -23,6 +23,7 @@ static thread_local char g_err[512] = "";
 static int fail(const char* m) { snprintf(g_err, sizeof(g_err), "%s", m); return 1; }
 
 extern "C" int gmx_version(void) { return GMX_ABI_VERSION; }
+extern "C" size_t gmx_run_args_bytes(void) { return sizeof(gmx_run_args); }
 extern "C" const char* gmx_last_error(void) { return g_err; }
 extern "C" void gmx_threefry2x32_host(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t out[2]) {
   gmx_threefry2x32(k0, k1, c0, c1, &out[0], &out[1]);
@@ -122,6 +123,8 @@ extern "C" int gmx_program_set_fuse_resample(gmx_program* p) {
   p->fuse_rs = true;
   return 0;
 }
+extern "C" int gmx_program_set_fuse_shard_step(gmx_program* p) { return p ? 0 : 1; }       // (the mirror keeps the two-launch sharded step)
+extern "C" int gmx_program_fuses_shard_step(const gmx_program*) { return 0; }
 extern "C" int64_t gmx_program_resident_particles(const gmx_program* p) { return p ? (int64_t)1 << 20 : 0; }   // (the mirror runs workgroups in turn)
 extern "C" int gmx_program_fuses_resample(const gmx_program* p) { return p && p->fuse_rs && hs_tile_mode(p) && hs_gathers(p) ? 1 : 0; }
 extern "C" int64_t gmx_program_grid(const gmx_program* p, int64_t n) { return hs_tile_mode(p) ? (n + 1023) / 1024 : (n + 255) / 256; }

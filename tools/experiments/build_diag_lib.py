@@ -21,13 +21,10 @@ shutil.copytree(os.path.join(ROOT, "include"), os.path.join(work, "include"))
 jit = os.path.join(work, "csrc", "gmx_jit.h")
 src = open(jit).read()
 if variant == "nopoll":
-    old = "      const uint32_t* gmx_aw = reinterpret_cast<const uint32_t*>(A.ancestors_d);                 \\\n"
-    assert old in src
-    new = ("      if (true) { _Pragma(\"unroll\") for (int p = 0; p < PP; ++p) arow[p] = cidx[p]; } else {           \\\n" + old)
-    src = src.replace(old, new, 1)
-    old2 = "        arow[p] = gmx_i < n32 ? gmx_i : n32 - 1u;                                                \\\n      }                                                                                          \\\n"
-    assert old2 in src
-    src = src.replace(old2, old2 + "      }                                                                                          \\\n", 1)
+    mark = "#if defined(GMX_JIT_SH)\n// a SHARDED sweep's step"
+    assert mark in src
+    src = src.replace(mark, "#undef GMX_JIT_POLL_ANC\n#define GMX_JIT_POLL_ANC(TAG, STATUS, LIMIT) "
+                            "_Pragma(\"unroll\") for (int p = 0; p < PP; ++p) arow[p] = cidx[p];\n" + mark, 1)
 else:
     raise SystemExit("unknown variant")
 open(jit, "w").write(src)

@@ -101,8 +101,15 @@ struct gmx_jit_ctx {
 // bootstrap step: ancestor, then state, for each of four particles).  Gathered inputs go in two stages:
 // the ancestors at the top, the rows they name after the first key derivation (one Threefry block per
 // particle hides the first round trip); the second round trip is hidden by the rest of the RNG work.
+// (the routing prologue of a sharded step is register-hungry: held to 64 VGPRs it spilled 168 bytes per lane to scratch
+//  — measured 44 us/step; four waves per SIMD = 128 VGPRs are what a launch with every workgroup resident needs anyway)
+#if defined(GMX_JIT_SH)
+#define GMX_JIT_OCC __attribute__((amdgpu_waves_per_eu(1, 4)))
+#else
+#define GMX_JIT_OCC
+#endif
 #define GMX_JIT_BEGIN(NREGS, FULLV, NDYN, PPV, NPRE)                                             \
-  extern "C" __global__ void __launch_bounds__(GMX_BLOCK) GMX_JIT_NAME(int64_t n, const gmx_run_args A) { \
+  extern "C" __global__ void __launch_bounds__(GMX_BLOCK) GMX_JIT_OCC GMX_JIT_NAME(int64_t n, const gmx_run_args A) { \
  GMX_JIT_PRIO                                                                                 \
     __shared__ float lds4[4];                                                                    \
     __shared__ uint64_t lds8[4];                                                                 \
@@ -181,9 +188,7 @@ struct gmx_jit_ctx {
       shard_peer gmx_sp;                                                                         \
       gmx_sp.land = (uint64_t* const*)A.sh.peer.land_d; gmx_sp.tag_base = A.sh.peer.tag_base_d;  \
       gmx_sp.status = A.sh.peer.status_d; gmx_sp.step = A.sh.peer.step; gmx_sp.leaves = A.sh.peer.leaves; \
-      _Pragma("unroll") for (int l = 0; l < GMX_PEER_MAX_LEAVES; ++l) {                          \
-        gmx_sp.state[l] = (const uint32_t*)A.sh.state_d[l]; gmx_sp.tail[l] = (uint32_t*)A.sh.tail_d[l]; \
-      }                                                                                          \
+      gmx_sp.state = (const uint32_t* const*)A.sh.state_d; gmx_sp.tail = (uint32_t* const*)A.sh.tail_d;  /* kernel-argument memory */ \
       gmx_shard_fill_body<GMX_RESAMPLE_SYSTEMATIC, true, true, true>(                            \
           A.sh.key0, A.sh.key1, A.sh.u0, A.sh.lw_d, (const uint8_t*)A.sh.stats_own_d, (size_t)0, A.sh.peer.tiles, \
           gmx_pow2i(A.sh.shift), A.sh.peer.rank, A.sh.peer.world, (int32_t)n, (int32_t)A.sh.peer.capacity, A.sh.plan_d, \

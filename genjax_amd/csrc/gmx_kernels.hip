@@ -573,6 +573,7 @@ extern "C" size_t gmx_specialize_dryrun2(const uint32_t* blob, size_t n_words, i
   if (parse_program(blob, n_words, P)) { if (log_out && log_cap) snprintf(log_out, log_cap, "%s", g_err); return 0; }
   P.fuse_rs = (flags & 1) != 0;
   P.background = (flags & 2) != 0;
+  P.fuse_sh = (flags & 4) != 0;
   const gmx_program* p = &P;
   std::string src = jit_source(p);
   hiprtcProgram prog;
@@ -2983,8 +2984,11 @@ k_shard_step_fill(uint32_t k0, uint32_t k1, uint32_t u0_host, const float* __res
                   const uint8_t* __restrict__ stats_all, size_t stride, int n_tiles, float scale, int rank, int world,
                   int32_t n, int32_t cap, int64_t* __restrict__ plan, uint64_t* __restrict__ total_out,
                   float* __restrict__ max_out, const uint32_t* __restrict__ state, uint32_t* __restrict__ send,
-                  int32_t* __restrict__ next_idx, const shard_peer P) {
+                  int32_t* __restrict__ next_idx, const shard_peer_args Pa) {
   GMX_SETPRIO
+  shard_peer P;
+  P.land = Pa.land; P.tag_base = Pa.tag_base; P.status = Pa.status; P.step = Pa.step; P.leaves = Pa.leaves;
+  P.state = Pa.state; P.tail = Pa.tail;
   gmx_shard_fill_body<kind, SMALL, PEER, false>(k0, k1, u0_host, lw, stats_all, stride, n_tiles, scale, rank, world, n, cap, plan,
                                                 total_out, max_out, state, send, next_idx, P, 0u);
 }
@@ -3018,7 +3022,7 @@ extern "C" int gmx_shard_step_fused(int kind, const uint32_t key[2], const void*
   hipLaunchKernelGGL((k_shard_step_fill<KIND, SM, false>), dim3((unsigned)tiles), dim3(GMX_BLOCK), 0, (hipStream_t)stream, key[0],  \
                      key[1], u0, lw_d, (const uint8_t*)stats_all_d, stride, (int)tiles, scale, rank, world,           \
                      (int32_t)n_per_rank, (int32_t)capacity, plan_d, total_out_d, max_out_d, (const uint32_t*)state_d,   \
-                     (uint32_t*)send_d, next_idx_d, shard_peer())
+                     (uint32_t*)send_d, next_idx_d, shard_peer_args())
 #define GMX_LAUNCH_SF(KIND) do { if (small) GMX_LAUNCH_SF2(KIND, true); else GMX_LAUNCH_SF2(KIND, false); } while (0)
   if (kind == GMX_RESAMPLE_SYSTEMATIC) GMX_LAUNCH_SF(GMX_RESAMPLE_SYSTEMATIC); else GMX_LAUNCH_SF(GMX_RESAMPLE_STRATIFIED);
 #undef GMX_LAUNCH_SF
@@ -3095,7 +3099,7 @@ extern "C" int gmx_shard_step_peer(int kind, const uint32_t key[2], const void* 
   if (shift < 1 || shift > 62) return gmx_fail("gmx_shard_step_peer: shift out of range%s");
   if (((uintptr_t)lw_d & 15) || ((uintptr_t)stats_own_d & 7))
     return gmx_fail("gmx_shard_step_peer: lw_d must be 16-byte and stats_own_d 8-byte aligned%s");
-  shard_peer P;
+  shard_peer_args P;
   memset(&P, 0, sizeof(P));
   P.land = (uint64_t* const*)Pe.land_d;
   P.tag_base = Pe.tag_base_d; P.status = Pe.status_d; P.step = Pe.step; P.leaves = Pe.leaves;

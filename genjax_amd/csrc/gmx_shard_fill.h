@@ -57,12 +57,19 @@ __device__ __forceinline__ int64_t shard_readlane64(int64_t x, int l) {
                    (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)x, l));
 }
 #define GMX_PEER_MAX_LEAVES 8
-struct shard_peer {
+struct shard_peer {                              // what the body reads
   uint64_t* const* land;                         // device array [world]: every rank's landing block, mapped here
   const uint32_t* tag_base; uint64_t* status;
   int32_t step, leaves;
-  const uint32_t* state[GMX_PEER_MAX_LEAVES];    // leaf l: this rank's states [n]
-  uint32_t* tail[GMX_PEER_MAX_LEAVES];           // leaf l: the tail [world * cap] of its extended state
+  const uint32_t* const* state;                  // [leaves]: leaf l = this rank's states [n]           } arrays that live in
+  uint32_t* const* tail;                         // [leaves]: leaf l = the tail [world * cap] of its extended state } KERNEL-ARGUMENT
+};                                               // memory: indexed at run time without a trip through scratch
+struct shard_peer_args {                         // the AOT kernel's by-value parameter (the arrays themselves)
+  uint64_t* const* land;
+  const uint32_t* tag_base; uint64_t* status;
+  int32_t step, leaves;
+  const uint32_t* state[GMX_PEER_MAX_LEAVES];
+  uint32_t* tail[GMX_PEER_MAX_LEAVES];
 };
 // one row of another rank's statistics: spin (bounded) until all three granules carry `tag`
 __device__ __forceinline__ bool shard_peer_row(const uint64_t* row, uint32_t tag, uint64_t& agg, float& tmax) {

@@ -196,7 +196,7 @@ struct gmx_jit_ctx {
           const_cast<int32_t*>(A.ancestors_d), gmx_sp, A.sh.tag);                                 \
       const uint32_t gmx_lim = n32 + (uint32_t)A.sh.peer.world * (uint32_t)A.sh.peer.capacity;   \
       GMX_JIT_POLL_ANC(A.sh.tag, A.sh.status_d, gmx_lim)                                         \
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   /* the received states behind the words: this launch's stores */ \
+      /* (no fence: a row in the tail was stored write-through BEFORE its word, the gather's load depends on the word) */ \
     } else {                                                                                     \
       _Pragma("unroll") for (int p = 0; p < PP; ++p) arow[p] = (uint32_t)A.ancestors_d[cidx[p]]; \
     }

@@ -103,7 +103,11 @@ gmx_shard_fill_body(uint32_t k0, uint32_t k1, uint32_t u0_host, const float* __r
     if (TAGGED) gmx_store_u32_sc1(reinterpret_cast<uint32_t*>(next_idx) + slot_local, v | tagw);
     else next_idx[slot_local] = (int32_t)v;
   };
-  auto announce = [&]() { if (TAGGED) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); };
+  // (a release FENCE at agent scope writes back the whole L2 of this XCD, an acquire fence invalidates it — measured:
+  //  the sweep at 42 us/step against 19 with every thread fencing once.  What is needed is less: the received state
+  //  goes to the tail as a write-through store, its acknowledgement is awaited (s_waitcnt), THEN the word is stored,
+  //  also write-through; the reader's load of the tail row depends on the word it polled and misses every cache)
+  auto announce = [&]() { if (TAGGED) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
   __shared__ uint64_t s_part[SHARD_MAX_WORLD][4];
   __shared__ uint64_t s_below[4], s_scan[4];
   __shared__ float s_max[4];
@@ -283,7 +287,8 @@ gmx_shard_fill_body(uint32_t k0, uint32_t k1, uint32_t u0_host, const float* __r
           timed_out = true;
           __hip_atomic_store(P.status, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        P.tail[l][(int64_t)s_ * cap + k] = v;
+        if (TAGGED) gmx_store_u32_sc1(P.tail[l] + ((int64_t)s_ * cap + k), v);
+        else P.tail[l][(int64_t)s_ * cap + k] = v;
       }
     }
   };

@@ -953,6 +953,39 @@ def main():
         out["config"]["capacity_per_peer"] = sw.capacity
         out["config"]["full_capacity_reruns"] = sw.reruns
 
+    if not single and world > 1 and dist is not None and not args.no_other_configs:
+        # the OTHER scaling beside the headline's: a strong-scaling line also carries the weak
+        # record (--particles PER GPU), a --weak line the strong one — same communicator, three sweeps, MAX over ranks
+        from genjax_amd.inference.sharded import ShardedBootstrapSweep
+        want_weak = not args.weak
+        n2 = ((requested + 1023) // 1024) * 1024 if want_weak else \
+            ((requested + world * 1024 - 1) // (world * 1024)) * 1024
+        rec = {"scaling": "weak" if want_weak else "strong", "particles_per_gpu": n2, "particles_total": n2 * world}
+        try:
+            sw2 = ShardedBootstrapSweep(init, step, n2, T, dist, always_communicate=True, comm=sw.cx).prepare(
+                G.key(seed), torch.from_numpy(ys))
+            if sw.graph is not None:
+                sw2.capture()
+            sw2.launch(); sw2.finish()
+            barrier()
+            t2 = time.perf_counter()
+            for _ in range(3):
+                sw2.launch(); sw2.finish()
+            barrier()
+            dt2 = (time.perf_counter() - t2) / 3
+            tt = torch.tensor([dt2], device=be.device, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt2 = float(tt.item())
+            rec.update(value=n2 * world * T / dt2, unit="particle-steps/s", us_per_step=1e6 * dt2 / T, log_ml=sw2.log_ml(),
+                       one_launch_per_step=bool(getattr(sw2, "fuse_sh", False)))
+            if sw2.graph is not None:
+                be.c.gmx_graph_destroy(sw2.graph)
+                sw2.graph = None
+        except Exception as e:          # noqa: BLE001  (reported, never fails the headline)
+            rec["error"] = repr(e)[:300]
+        out["weak" if want_weak else "strong"] = rec
+    if not single:
+        out["config"]["one_launch_per_step"] = bool(getattr(sw, "fuse_sh", False))
     if not single and on_gpu and not args.no_other_configs and dist is not None and n * world >= N_PARTICLES and T == T_STEPS:
         oc = other_configs_sharded(dist, world, rank, sw.cx, be)       # COLLECTIVE: every rank
         if rank == 0:

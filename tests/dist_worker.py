@@ -114,7 +114,8 @@ def main(out_path, n_per_rank, T, capacity=None, mh=False, vec=False, vecmh=Fals
         np.save(out_path + ".npy", torch.cat(xs).numpy())
         json.dump({"log_ml": sw.log_ml(), "totals": [str(t) for t in sw.totals.cpu().numpy().view(np.uint64).tolist()],
                    "maxs": sw.maxs.cpu().tolist(), "reruns": sw.reruns, "capacity": sw.capacity,
-                   "communicator": sw.cx.name if sw.cx is not None else None},
+                   "communicator": sw.cx.name if sw.cx is not None else None,
+                   "one_launch_per_step": bool(getattr(sw, "fuse_sh", False))},
                   open(out_path + ".json", "w"))
     if on_gpu and sw.cx is not None:
         sw.close()

@@ -295,4 +295,10 @@ def test_bench_contract_control_flow(world, weak, bare):
     assert out["config"]["particles_per_gpu"] == per and out["config"]["particles_total"] == total
     if world > 1:
         assert str(per if weak else total) in out["config"]["workload"] and "communicator" in out["config"]
+        # the OTHER scaling rides along: a strong line carries the weak record (3000 per GPU -> 3072), a weak line the strong one
+        other = out["strong" if weak else "weak"]
+        assert "error" not in other, other
+        assert other["scaling"] == ("strong" if weak else "weak") and other["value"] > 0
+        assert other["particles_per_gpu"] == (2048 if weak else 3072) and other["particles_total"] == other["particles_per_gpu"] * world
+        assert abs(other["log_ml"] - out["log_ml_kalman"]) < 0.5
     assert out["value"] > 0 and abs(out["log_ml"] - out["log_ml_kalman"]) < 0.5

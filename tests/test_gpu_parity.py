@@ -1824,6 +1824,8 @@ def test_peer_mapped_exchange_between_two_processes_on_the_device(gpu, tmp_path,
     x = np.load(out + ".npy")
     meta = json.load(open(out + ".json"))
     assert meta["communicator"].startswith(comm)
+    # (peer: ONE launch per step — the gathering program routes the previous step first, between PROCESSES here)
+    assert meta["one_launch_per_step"] == (comm == "peer"), meta
     ys = workloads.lgssm_data(T)
     oi, ost = workloads.make_lgssm(O)
     ref = parity.oracle_bootstrap_sweep(oi, ost, n_total, T, ys, O.key(314159))

@@ -52,7 +52,26 @@ class Gathered:
         return self.source.dtype
 
     def materialize(self) -> torch.Tensor:
-        return gather_leaves([self.source], self.ancestors)[0]
+        m = self.__dict__.get("_mat")
+        if m is None:
+            m = self.__dict__["_mat"] = gather_leaves([self.source], self.ancestors)[0]
+        return m
+
+
+def materialize_together(values):
+    """the lazy gathers among `values` that share their ancestors, materialised by ONE gmx_gather launch per group (the
+    ancestors are read once: a resampled trace's choices — ten latents of the 8-schools model — were one launch per
+    site); results are kept by each `Gathered`"""
+    groups = {}
+    for v in values:
+        if isinstance(v, Gathered) and v.__dict__.get("_mat") is None:
+            groups.setdefault(id(v.ancestors), []).append(v)
+    for members in groups.values():
+        if len(members) < 2:
+            continue
+        outs = gather_leaves([m_.source for m_ in members], members[0].ancestors)
+        for m_, o in zip(members, outs):
+            m_.__dict__["_mat"] = o
 
 
 class Patched:

@@ -100,6 +100,8 @@ class StaticTrace(Trace):
     def get_choices(self) -> ChoiceMap:
         cm = ChoiceMap.empty()
         nb = len(self.batch_shape)
+        from .engine import materialize_together
+        materialize_together([st.value for st in self.subtraces.values() if isinstance(st, DistributionTrace)])
         for addr, st in self.subtraces.items():
             sub = st.get_choices()
             if isinstance(st, DistributionTrace) and sub.has_value() and len(getattr(sub.get_value(), "shape", ())) > nb:

@@ -1,5 +1,6 @@
 #!/bin/bash
-# Everything DESIGN.md quotes, in one go, on an MI355X box (from the repo root; ~6 min):
+# Everything DESIGN.md quotes, in one go, on an MI355X box (from the repo root; ~30 min — past gpurun's 20-minute
+# limit per call: run the blocks below in two or three calls, as round 5 did: r05j = the counter passes, r05k = suite + bench):
 #   tools/reproduce.sh <tag>      -> gpurun_out/<tag>_*
 # Each rocprofv3 pass is its own invocation (kernel trace + stats, SQ counters, TCC counters: never combined);
 # every step runs under `timeout` so that a wedged process cannot hold the box.
@@ -24,6 +25,12 @@ timeout 300 python tools/bench_sweep3.py 2> /dev/null | grep "^{" > $out/${tag}_
 timeout 300 python tools/bench_mixture.py 2> /dev/null | tail -1 > $out/${tag}_mixture_config5.json
 timeout 300 python tools/bench_hmc.py 2> /dev/null | tail -1 > $out/${tag}_hmc.json
 timeout 300 python tools/bench_kinds.py 2> /dev/null | tail -1 > $out/${tag}_kinds.json
+# round 5: the one-launch sharded step against two launches; a long vector-valued site against its vmap-plate spelling;
+# O(1) IndexRequest on a long scan; the bound on what a destination-centric resampling prologue could save
+timeout 300 python tools/bench_sharded_fuse_ab.py 2> /dev/null | tail -1 > $out/${tag}_sharded_fuse_ab.json
+timeout 300 python tools/vector_site_cost.py 100000 2> /dev/null | tail -1 > $out/${tag}_vector_site_cost.json
+timeout 300 python tools/scan_index_request_cost.py 100000 4096 2> /dev/null | tail -1 > $out/${tag}_scan_index_request_cost.json
+python tools/experiments/build_diag_lib.py nopoll > /dev/null 2>&1 && timeout 300 python tools/experiments/poll_hop_bound.py 2> /dev/null | tail -1 > $out/${tag}_poll_hop_bound.json
 # the ordered resamplers beside each other: the chain without the background stream, the kernel alone, the sorted kind's kernels
 for k in systematic stratified multinomial_sorted; do RESAMPLE=$k timeout 120 python tools/experiments/chain_only.py 2> /dev/null | tail -1; done > $out/${tag}_chain_only.txt
 timeout 120 python tools/experiments/sorted_micro.py 2> /dev/null | tail -1 > $out/${tag}_sorted_micro.json

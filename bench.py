@@ -388,11 +388,12 @@ def config_workload(which: int):
     raise ValueError(which)
 
 
-def config_valu(name: str, seconds_per_unit: float):
+def config_valu(name: str, seconds_per_unit: float, programs: str = None):
     """The vector-instruction issue of one of the other configs (they are ALU-bound: an HBM fraction says little):
     SQ_INSTS_VALU of every kernel of the workload per unit (step / run / sweep), from the rocprofv3 PMC pass
-    tools/reproduce.sh took (profiles/counters.json `configs`, used only when taken on THIS library: sha256), over the
-    unit's time measured in this run; plus the dominant kernel's name and its duration in that profile."""
+    tools/reproduce.sh took (profiles/counters.json `configs`, used only when taken on THIS code: the library's sha256
+    AND engine.program_digest of the site programs the workload creates — a change on the Python side that alters a
+    site program changes the specialised kernel under an unchanged library), over the unit's time measured in this run; plus the dominant kernel's name and its duration in that profile."""
     from genjax_amd import _lib
     path = os.path.join(ROOT, "profiles", "counters.json")
     try:
@@ -405,6 +406,9 @@ def config_valu(name: str, seconds_per_unit: float):
     if ent.get("lib") != lib:
         return {"valu_frac": None, "note": f"profiles/counters.json `{name}` was taken on another library build "
                                            f"({ent.get('lib')} != {lib}): not used"}
+    if ent.get("programs") != programs:
+        return {"valu_frac": None, "note": f"profiles/counters.json `{name}` was taken on other site programs "
+                                           f"({ent.get('programs')} != {programs}): not used"}
     wave_insts = float(ent["valu_wave_insts_per_unit"])
     rate = wave_insts * 64.0 / seconds_per_unit
     return {"valu_wave_insts_per_unit": wave_insts, "unit": ent.get("unit"), "lane_ops_per_s": rate,
@@ -422,7 +426,7 @@ def other_configs():
     import numpy as np
     import torch
     import genjax_amd as G
-    from genjax_amd import ChoiceMapBuilder as C, numpy as jnp, workloads
+    from genjax_amd import ChoiceMapBuilder as C, engine, numpy as jnp, workloads
     from genjax_amd.inference import gibbs, smc
     out = {}
 
@@ -436,38 +440,44 @@ def other_configs():
         return (time.perf_counter() - t0) / reps
 
     try:        # ---- config 3: nonlinear SSM, 1e6 particles, T = 100, one Gaussian-drift MH move per step ----
-        w3 = config_workload(3)
-        sw, n, T = w3["sweep"], w3["n"], w3["T"]
-        dt = timed(sw.launch, 5)
+        with engine.program_digest() as progs:       # the site programs the counters of this config are held to
+            engine.clear_caches()                    # ... every one of them created inside the block, as in a fresh process
+            w3 = config_workload(3)
+            sw, n, T = w3["sweep"], w3["n"], w3["T"]
+            dt = timed(sw.launch, 5)
         b = 52 * n * T          # 8(d): 32 B bootstrap step + 20 B MH move per particle-step
         out["config3"] = {"workload": "nonlinear SSM + one Rejuvenate MH move per step, BootstrapSweep(rejuvenate=...), "
                                       "1e6 particles x 100 steps, one hipGraph", "us_per_step": 1e6 * dt / T,
                           "particle_steps_per_s": n * T / dt, "algorithmic_bytes_per_particle_step": 52,
-                          "hbm_frac": b / dt / 1e9 / HBM_PEAK_GBS, "valu": config_valu("config3", dt / T),
+                          "hbm_frac": b / dt / 1e9 / HBM_PEAK_GBS, "valu": config_valu("config3", dt / T, progs.hex()),
                           "log_ml": sw.log_ml(), "noise_ahead": bool(sw.noise_ahead), "one_launch_per_step": bool(sw.fuse),
                           "accept_rate_last_step": float(sw.accept.float().mean())}
         del sw, w3
     except Exception as e:
         out["config3"] = {"error": repr(e)[:300]}
     try:        # ---- config 4: 8-schools, ImportanceK k = 1e7 + one global systematic resample ----
-        w4 = config_workload(4)
-        alg, box, k = w4["alg"], w4["box"], w4["k"]
-        dt = timed(w4["run"], 3)
+        with engine.program_digest() as progs:
+            engine.clear_caches()                    # ... every one of them created inside the block, as in a fresh process
+            w4 = config_workload(4)
+            alg, box, k = w4["alg"], w4["box"], w4["k"]
+            dt = timed(w4["run"], 3)
         dti = timed(lambda: alg.run_smc(G.key(2)), 3)
         out["config4"] = {"workload": "8-schools ImportanceK k = 1e7 + one systematic resample + gather of theta",
                           "ms_total": 1e3 * dt, "ms_importance": 1e3 * dti, "particles_per_s": k / dt,
                           "algorithmic_bytes_per_particle": {"importance": 48, "resample_and_gather": 104},
                           "hbm_frac_importance": 48.0 * k / dti / 1e9 / HBM_PEAK_GBS,
-                          "hbm_frac_total": 152.0 * k / dt / 1e9 / HBM_PEAK_GBS, "valu": config_valu("config4", dt),
+                          "hbm_frac_total": 152.0 * k / dt / 1e9 / HBM_PEAK_GBS, "valu": config_valu("config4", dt, progs.hex()),
                           "log_ml": float(box["c"].get_log_marginal_likelihood_estimate())}
         box.clear()
         del w4
     except Exception as e:
         out["config4"] = {"error": repr(e)[:300]}
     try:        # ---- config 5: mixture, K = 64 clusters, 1e6 datapoints: one assignment sweep ----
-        w5 = config_workload(5)
-        n, K, z, gd, args5, chm, box = w5["n"], w5["K"], w5["z"], w5["gd"], w5["args"], w5["chm"], w5["box"]
-        dt = timed(w5["run"], 5)
+        with engine.program_digest() as progs:
+            engine.clear_caches()                    # ... every one of them created inside the block, as in a fresh process
+            w5 = config_workload(5)
+            n, K, z, gd, args5, chm, box = w5["n"], w5["K"], w5["z"], w5["gd"], w5["args"], w5["chm"], w5["box"]
+            dt = timed(w5["run"], 5)
         # ... and THROUGH THE GFI: the datapoints as a `generate_datapoint.repeat(n=N)` plate called directly (its
         # elements on the launch axis), the sweep = gibbs.enumerative_gibbs on the plate's trace (the fused draw + the
         # plate's Update): the notebook's update_datapoint_assignment for a model written with the Vmap combinator
@@ -481,7 +491,7 @@ def other_configs():
         out["config5"] = {"workload": "Dirichlet-categorical mixture, K = 64, 1e6 datapoints: one cluster-assignment "
                                       "sweep (gibbs_categorical: one launch, no [N, K] matrix)", "ms": 1e3 * dt,
                           "datapoints_per_s": n / dt, "gumbels_per_s": n * K / dt, "algorithmic_bytes_per_datapoint": 8,
-                          "hbm_frac": 8.0 * n / dt / 1e9 / HBM_PEAK_GBS, "valu": config_valu("config5", dt),
+                          "hbm_frac": 8.0 * n / dt / 1e9 / HBM_PEAK_GBS, "valu": config_valu("config5", dt, progs.hex()),
                           "note": "ALU-bound by design (64 Gumbels + 64 log-densities per datapoint; SURVEY 8d)",
                           "agrees_with_generating_component": float((box["idx"].cpu().numpy() == z).mean()),
                           "through_the_gfi": {

@@ -20,7 +20,7 @@ GMX_MAX_OUT = 64
 GMX_MAX_TAB = 8
 GMX_MAX_UNI = 64
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 KEY_NONE, KEY_ARRAY, KEY_SPLIT, KEY_ROWSPLIT, KEY_BCAST = 0, 1, 2, 3, 4
 RESAMPLE_SYSTEMATIC, RESAMPLE_STRATIFIED, RESAMPLE_MULTINOMIAL, RESAMPLE_MULTINOMIAL_TILED = 0, 1, 2, 3
 RESAMPLE_MULTINOMIAL_SORTED = 4
@@ -60,6 +60,9 @@ class Peer(Structure):
     ]
 
 
+PEER_MAX_LEAVES = 32         # GMX_PEER_MAX_LEAVES
+
+
 class ShardIn(Structure):
     """struct gmx_shard_in: the routing of the previous step of a sharded sweep folded into a gathering site program"""
     _fields_ = [
@@ -76,8 +79,8 @@ class ShardIn(Structure):
         ("u0", c_uint32),
         ("reserved_", c_int32),
         ("peer", Peer),
-        ("state_d", c_void_p * 8),
-        ("tail_d", c_void_p * 8),
+        ("state_d", c_void_p * PEER_MAX_LEAVES),
+        ("tail_d", c_void_p * PEER_MAX_LEAVES),
     ]
 
 

@@ -3057,7 +3057,7 @@ static int peer_check(const char* who, const gmx_peer& P, int64_t n_per_rank) {
   const int64_t tiles = (n_per_rank + RS_TILE - 1) / RS_TILE;
   if (n_per_rank <= 0 || tiles > RS_MAX_TILES || P.tiles != (int32_t)tiles) return gmx_fail("%s: peer.tiles must be ceil(n_per_rank / 1024) <= 2048", who);
   if (P.capacity < 1 || P.capacity > n_per_rank) return gmx_fail("%s: peer.capacity must be in [1, n_per_rank]", who);
-  if (P.leaves < 1 || P.leaves > GMX_PEER_MAX_LEAVES) return gmx_fail("%s: peer.leaves must be in [1, 8]", who);
+  if (P.leaves < 1 || P.leaves > GMX_PEER_MAX_LEAVES) return gmx_fail("%s: peer.leaves must be in [1, GMX_PEER_MAX_LEAVES = 32]", who);
   return 0;
 }
 

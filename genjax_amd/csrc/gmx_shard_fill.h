@@ -56,7 +56,6 @@ __device__ __forceinline__ int64_t shard_readlane64(int64_t x, int l) {
   return (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)x >> 32), l) << 32) |
                    (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)x, l));
 }
-#define GMX_PEER_MAX_LEAVES 8
 struct shard_peer {                              // what the body reads
   uint64_t* const* land;                         // device array [world]: every rank's landing block, mapped here
   const uint32_t* tag_base; uint64_t* status;

@@ -15,6 +15,7 @@ store in the kernel is one coalesced 256-byte wave access.
 from __future__ import annotations
 
 import dataclasses
+import hashlib
 
 import os
 import struct
@@ -936,6 +937,28 @@ class _ChainLink:
         self.has_red, self.n_regs, self.finalizer = seg.has_red, int(seg.blob[3]), finalizer
 
 
+_DIGEST_SCOPES: list = []
+
+
+class program_digest:
+    """`with engine.program_digest() as d: ...; d.hex()`: a digest of the SET of site programs created inside the block
+    (sha256 over the sorted sha256s of their blobs).  A specialised kernel is a function of its blob and of the library's
+    embedded headers, so (this digest, sha of the library) names the code a workload ran: what bench.py holds a counter
+    profile of one of the other configs to (profiles/counters.json `configs[*].programs`)."""
+
+    def __enter__(self):
+        self._set = set()
+        _DIGEST_SCOPES.append(self._set)
+        return self
+
+    def __exit__(self, *exc):
+        _DIGEST_SCOPES.remove(self._set)
+        return False
+
+    def hex(self) -> str:
+        return hashlib.sha256("".join(sorted(self._set)).encode()).hexdigest()[:16]
+
+
 class Compiled:
     """A created program + its binding plan.  `chain=True`: a graph beyond the launch slots / the 64 live values is
     cut into several programs launched one after another (program.split_graph), values in flight between them in
@@ -995,6 +1018,8 @@ class Compiled:
         be = self._be
         handle = c_void_p()
         words = np.ascontiguousarray(blob, dtype=np.uint32)
+        for log in _DIGEST_SCOPES:
+            log.add(hashlib.sha256(words.tobytes()).hexdigest())
         be.check(be.c.gmx_program_create(words.ctypes.data_as(POINTER(c_uint32)), words.size, handle),
                  "gmx_program_create")
         return handle

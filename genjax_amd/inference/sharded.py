@@ -215,7 +215,7 @@ class ShardedBootstrapSweep(_NoiseAhead):
         # workgroup's registers, indices that fit an ancestor word
         tiles_ = (n + CDF_TILE - 1) // CDF_TILE
         want_fuse_sh = bool(self.peer_mode and be.uses_streams and self.specialize and self.kind == SYSTEMATIC
-                            and self.rejuvenate is None and W <= 8 and W * tiles_ <= 1024 and self.D <= 8
+                            and self.rejuvenate is None and W <= 8 and W * tiles_ <= 1024 and self.D <= _lib.PEER_MAX_LEAVES
                             and n + W * self.capacity <= (1 << 21) and self.fuse_sh_req is not False)
         if want_fuse_sh and not self.p_step.comp.is_specialized():
             self.p_step.comp.set_fuse_shard_step()
@@ -278,8 +278,9 @@ class ShardedBootstrapSweep(_NoiseAhead):
             # what crosses ranks lands in the communicator's fine-grained landing block; the extended states (and their
             # tails, filled by this rank's own routing launch) are ordinary memory
             self.peer_leaves = self.D * (2 if self.rejuvenate is not None else 1)
-            if self.peer_leaves > 8:
-                raise NotImplementedError("ShardedBootstrapSweep over the fused peer exchange: at most 8 routed leaves")
+            if self.peer_leaves > _lib.PEER_MAX_LEAVES:
+                raise NotImplementedError("ShardedBootstrapSweep over the fused peer exchange: at most "
+                                          f"{_lib.PEER_MAX_LEAVES} routed leaves (GMX_PEER_MAX_LEAVES)")
             self.peer_land, _ = self.cx.landing(n, C, self.peer_leaves)              # COLLECTIVE
             if not hasattr(self, "peer_tag"):
                 self.peer_tag, self.peer_status = self.cx.step_words()

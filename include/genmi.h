@@ -39,7 +39,7 @@ typedef __UINTPTR_TYPE__ uintptr_t;
 extern "C" {
 #endif
 
-#define GMX_ABI_VERSION 6
+#define GMX_ABI_VERSION 7
 
 typedef void* gmx_stream;            /* hipStream_t */
 typedef struct gmx_program gmx_program;
@@ -138,6 +138,7 @@ typedef struct gmx_resample_in {
 
 /* The peers of a sharded SMC step ("Fused peer exchange", below): passed by value to the site program
  * (gmx_run_args.peer) and to gmx_shard_step_peer. */
+#define GMX_PEER_MAX_LEAVES 32    /* routed 4-byte leaves per particle: a state of 16 components travels with its MH-moved copy */
 typedef struct gmx_peer {
   void* const* land_d;            /* device array [world]: every rank's LANDING block as mapped into this process
                                      (gmx_p2p_alloc / gmx_p2p_open; land_d[rank] = this rank's own); NULL = no peers    */
@@ -147,7 +148,8 @@ typedef struct gmx_peer {
   int32_t step;                   /* t: everything this step puts carries tag = *tag_base_d + t; parity = tag & 1      */
   int32_t tiles;                  /* CDF tiles per rank = ceil(n_per_rank / 1024)                                     */
   int64_t capacity;               /* states one rank may ship to ONE peer per step                                     */
-  int32_t leaves;                 /* routed 4-byte leaves per particle (1: a scalar state; D; 2 D with an MH move)      */
+  int32_t leaves;                 /* routed 4-byte leaves per particle (1: a scalar state; D; 2 D with an MH move):
+                                     1 .. GMX_PEER_MAX_LEAVES                                                          */
   int32_t reserved_;
 } gmx_peer;
 
@@ -177,8 +179,8 @@ typedef struct gmx_shard_in {
   uint32_t u0;                    /* filled in by gmx_program_run: bits32(key, 0) >> 9                                   */
   int32_t reserved_;
   gmx_peer peer;                  /* the exchange of step t - 1: peer.step = t - 1, peer.leaves routed leaves            */
-  const void* state_d[8];         /* leaf l: this rank's states of step t - 1 [n] (the head of its extended state)      */
-  void* tail_d[8];                /* leaf l: the tail [world * capacity] of that extended state                          */
+  const void* state_d[GMX_PEER_MAX_LEAVES];   /* leaf l: this rank's states of step t - 1 [n] (the head of its extended state) */
+  void* tail_d[GMX_PEER_MAX_LEAVES];          /* leaf l: the tail [world * capacity] of that extended state                   */
 } gmx_shard_in;
 
 typedef struct gmx_run_args {

@@ -75,10 +75,10 @@ def main(out_path, n_per_rank, T, capacity=None, mh=False, vec=False, vecmh=Fals
         sw = ShardedBootstrapSweep(init, step, n_per_rank, T, dist, capacity=capacity, rejuvenate=req,
                                    step_extra=lambda t: (float(t),), resample=OPTS.get("resample", "systematic")).prepare(
             G.key(7), torch.from_numpy(ys))
-    elif vecmh:  # a 2-vector state in one vector-valued site + one MH move per step: 2 x 2 routed leaves
+    elif vecmh:  # a D-vector state in one vector-valued site + one MH move per step: 2 x D routed leaves
         from genjax_amd import numpy as jnp
         from tests import parity
-        init, step = parity.make_vec_mh(G, lambda a, b: jnp.stack([a, b]), jnp.ones(2))
+        init, step = parity.make_vec_mh(G, lambda *v: jnp.stack(list(v)), jnp.ones(vecmh))
         req = G.StaticRequest({"x": G.Rejuvenate(G.normal, lambda chm: (chm.get_value(), 0.2))})
         sw = ShardedBootstrapSweep(init, step, n_per_rank, T, dist, capacity=capacity, rejuvenate=req,
                                    step_extra=lambda t: (float(t),)).prepare(G.key(11), torch.from_numpy(parity.tracker_data(T)))
@@ -128,4 +128,4 @@ if __name__ == "__main__":
         sys.exit(0)
     cap = int(sys.argv[4]) if len(sys.argv) > 4 and int(sys.argv[4]) > 0 else None
     mode = sys.argv[5] if len(sys.argv) > 5 else ""
-    main(sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), cap, mh=mode == "mh", vec=mode == "vec", vecmh=mode == "vecmh")
+    main(sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), cap, mh=mode == "mh", vec=mode == "vec", vecmh={"vecmh": 2, "vec6mh": 6}.get(mode, 0))

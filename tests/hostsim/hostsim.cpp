@@ -788,7 +788,7 @@ static int hs_peer_check(const gmx_peer& P, int64_t n) {
   if (!P.land_d || !P.tag_base_d || !P.status_d) return fail("peer: null pointer");
   if (P.world < 1 || P.world > 64 || P.rank < 0 || P.rank >= P.world || P.step < 0) return fail("peer: rank / world / step out of range");
   if (n <= 0 || P.tiles != (int32_t)((n + HS_TILE - 1) / HS_TILE)) return fail("peer: tiles must be ceil(n / 1024)");
-  if (P.capacity < 1 || P.capacity > n || P.leaves < 1 || P.leaves > 8) return fail("peer: capacity / leaves out of range");
+  if (P.capacity < 1 || P.capacity > n || P.leaves < 1 || P.leaves > GMX_PEER_MAX_LEAVES) return fail("peer: capacity / leaves out of range");
   return 0;
 }
 extern "C" int gmx_peer_put_stats(const void* stats_own, gmx_peer P, int64_t n, gmx_stream) {

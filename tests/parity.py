@@ -1587,6 +1587,9 @@ def check_vector_state_sweep(n=3000, T=6, seed=5, capture=False, specialize=Fals
 # ---------------------------------------------------------------------------
 # a VECTOR state through the fused MH sweep: 2-D state as one vector-valued site, Rejuvenate on it
 def make_vec_mh(g, stack, ones2):
+    """a D-vector state (D = len(ones2); `stack(a, b, ...)` joins D components) in ONE vector-valued site"""
+    D = int(ones2.shape[-1])
+
     @g.gen
     def init():
         x = g.normal(0.0 * ones2, ones2) @ "x"
@@ -1595,7 +1598,7 @@ def make_vec_mh(g, stack, ones2):
 
     @g.gen
     def step(xp, t):
-        loc = stack(0.9 * xp[..., 0] + 0.1 * xp[..., 1], 0.8 * xp[..., 1])
+        loc = stack(*[0.9 * xp[..., i] + 0.1 * xp[..., i + 1] for i in range(D - 1)], 0.8 * xp[..., D - 1])
         x = g.normal(loc, 0.3 * ones2) @ "x"
         g.normal(x[..., 0], 0.5) @ "y"
         return x
@@ -1632,8 +1635,8 @@ def check_vector_mh_sweep(n=1500, T=5, seed=11, capture=False, specialize=False,
     import genjax_amd as G
     from genjax_amd import numpy as jnp
     from genjax_amd.inference import smc
-    init, step = make_vec_mh(G, lambda a, b: jnp.stack([a, b]), jnp.ones(2))
-    oi, ost = make_vec_mh(O, lambda a, b: np.stack([a, b], axis=-1), np.ones(2, np.float32))
+    init, step = make_vec_mh(G, lambda *v: jnp.stack(list(v)), jnp.ones(2))
+    oi, ost = make_vec_mh(O, lambda *v: np.stack(v, axis=-1), np.ones(2, np.float32))
     ys = tracker_data(T)
     req = G.StaticRequest({"x": G.Rejuvenate(G.normal, lambda chm: (chm.get_value(), 0.2))})
     oreq = {"x": O.Rejuvenate(O.normal, lambda chm: (chm.get_value(), np.float32(0.2)))}

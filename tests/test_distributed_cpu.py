@@ -182,20 +182,23 @@ def test_sharded_vector_state_sweep_equals_single_process_oracle(tmp_path, world
     assert meta["reruns"] == (1 if capacity else 0), meta
 
 
-@pytest.mark.parametrize("world,capacity,comm", [(2, 0, None), (2, 6, None), (2, 0, "peer"), (2, 6, "peer")])
-def test_sharded_vector_state_mh_sweep_equals_single_process_oracle(tmp_path, world, capacity, comm):
-    """a 2-vector state AND one MH move per step: the particle and the state it was extended from travel as
-    2 x 2 routed leaves; equals the single-process oracle, also through the overflow re-run."""
+@pytest.mark.parametrize("world,capacity,comm,D", [(2, 0, None, 2), (2, 6, None, 2), (2, 0, "peer", 2), (2, 6, "peer", 2),
+                                                   (2, 0, "peer", 6), (2, 6, "peer", 6)])
+def test_sharded_vector_state_mh_sweep_equals_single_process_oracle(tmp_path, world, capacity, comm, D):
+    """a D-vector state AND one MH move per step: the particle and the state it was extended from travel as
+    2 x D routed leaves (D = 6: twelve, past the eight the fused peer exchange was built for — GMX_PEER_MAX_LEAVES is
+    32); equals the single-process oracle, also through the overflow re-run."""
     n_total, T = 2048, 4
     out = str(tmp_path / "shard_vecmh")
-    r = _launch(world, [out, str(n_total // world), str(T), str(capacity), "vecmh"], extra_env={"GENMI_COMM": comm} if comm else None)
+    r = _launch(world, [out, str(n_total // world), str(T), str(capacity), {2: "vecmh", 6: "vec6mh"}[D]],
+                extra_env={"GENMI_COMM": comm} if comm else None)
     assert r.returncode == 0, r.stderr[-3000:]
     x = np.load(out + ".npy")
     meta = json.load(open(out + ".json"))
-    oi, ost = parity.make_vec_mh(O, lambda a, b: np.stack([a, b], axis=-1), np.ones(2, np.float32))
+    oi, ost = parity.make_vec_mh(O, lambda *v: np.stack(v, axis=-1), np.ones(D, np.float32))
     oreq = {"x": O.Rejuvenate(O.normal, lambda chm: (chm.get_value(), np.float32(0.2)))}
     ref = parity.oracle_mh_sweep(oi, ost, oreq, parity.tracker_data(T), n_total, T, 11, extra=lambda t: (np.float32(t),))
-    assert x.shape == (n_total, 2) and np.array_equal(x, ref["x"][ref["anc"]])
+    assert x.shape == (n_total, D) and np.array_equal(x, ref["x"][ref["anc"]])
     assert abs(meta["log_ml"] - sum(ref["terms"])) < 1e-9 * max(1.0, abs(sum(ref["terms"])))
     assert meta["reruns"] == (1 if capacity else 0), meta
 

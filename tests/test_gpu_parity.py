@@ -1098,9 +1098,9 @@ def test_one_trace_of_a_model_with_large_plates_runs_site_by_site(gpu):
     t_index, t_update = parity.check_one_trace_with_large_plates(n=1_000_000, seed=9, timing=True)
     assert t_index < t_update, (t_index, t_update)
     parity.check_one_trace_with_large_vector_sites(n=5000)
-    parity.check_one_trace_with_large_vector_sites(n=300_000, K=64, seed=2)      # the mixture model's data site
+    parity.check_one_trace_with_large_vector_sites(n=100_000, K=64, seed=2)      # the mixture model's data site
     parity.check_mixture_notebook_model(n=5000, k=40)                        # the notebook's own sizes
-    parity.check_mixture_notebook_model(n=250_000, k=64, seed=3)            # ... and BASELINE config 5's K (its N: test_mixture_assignments_match_oracle)
+    parity.check_mixture_notebook_model(n=100_000, k=64, seed=3)            # ... and BASELINE config 5's K (its N: test_mixture_assignments_match_oracle)
 
 
 def test_large_plate_of_a_small_particle_batch_is_deferred(gpu):
@@ -1834,20 +1834,41 @@ def test_peer_mapped_exchange_between_two_processes_on_the_device(gpu, tmp_path,
     assert np.array_equal(x, ref["x"][ref["anc"]])
 
 
+def test_peer_route_of_twelve_leaves_between_two_processes_on_the_device(gpu, tmp_path):
+    """the fused peer exchange past eight routed leaves (GMX_PEER_MAX_LEAVES = 32): a 6-vector state
+    and one MH move per step — the particle and the state it was extended from travel as 2 x 6 leaves between two
+    PROCESSES on the device, capacity 0 (automatic) — equals the single-process oracle"""
+    import json
+    from tests.test_distributed_cpu import _launch
+    n_total, T, D = 8192, 4, 6
+    out = str(tmp_path / "peer12")
+    r = _launch(2, [out, str(n_total // 2), str(T), "0", "vec6mh"],
+                extra_env={"GENMI_COMM": "peer", "GENMI_COMM_TIMEOUT": "60", "GENMI_TEST_OPTS": json.dumps({"on_gpu": 1})})
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    x = np.load(out + ".npy")
+    meta = json.load(open(out + ".json"))
+    assert meta["communicator"].startswith("peer")
+    oi, ost = parity.make_vec_mh(O, lambda *v: np.stack(v, axis=-1), np.ones(D, np.float32))
+    oreq = {"x": O.Rejuvenate(O.normal, lambda chm: (chm.get_value(), np.float32(0.2)))}
+    ref = parity.oracle_mh_sweep(oi, ost, oreq, parity.tracker_data(T), n_total, T, 11, extra=lambda t: (np.float32(t),))
+    assert x.shape == (n_total, D) and np.array_equal(x, ref["x"][ref["anc"]])
+    assert abs(meta["log_ml"] - sum(ref["terms"])) < 1e-9 * max(1.0, abs(sum(ref["terms"])))
+
+
 def test_random_models_match_the_oracle_on_device(gpu):
-    """tests/fuzz_models.py on the HIP path: 20 random models on the interpreter (7 particles) and 3 through the
+    """tests/fuzz_models.py on the HIP path: 16 random models on the interpreter (7 particles) and 2 through the
     hiprtc-specialised programs (2^18 particles: engine.JIT_MIN_PARTICLES), every GFI method bit for bit against the
     oracle"""
     from tests import fuzz_models as F
     ran = 0
-    for seed, B in [(s, 7) for s in range(1000, 1020)] + [(s, 1 << 18) for s in range(2000, 2003)]:
+    for seed, B in [(s, 7) for s in range(1000, 1016)] + [(s, 1 << 18) for s in range(2000, 2002)]:
         try:
             F.run_one(seed, B=B)
             ran += 1
         except F.OverTheLimits:
             pass
-    assert ran == 23, ran
-    for seed in range(3000, 3012):
+    assert ran == 18, ran
+    for seed in range(3000, 3010):
         F.run_smc_one(seed)
     for seed in range(4000, 4003):
         F.run_big_one(seed)

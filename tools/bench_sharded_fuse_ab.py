@@ -26,7 +26,11 @@ ys = workloads.lgssm_data(T)
 init, step = workloads.make_lgssm(G)
 out = {"n": n, "T": T}
 cx = None
+only = os.environ.get("ONLY")             # ONLY=one_launch REPS=1: the run rocprofv3 wraps for that form's counters
+reps = int(os.environ.get("REPS", "4"))
 for name, fuse in (("two_launches", False), ("one_launch", None)):
+    if only and name != only:
+        continue
     sw = ShardedBootstrapSweep(init, step, n, T, _Solo, always_communicate=True, fuse_step=fuse, comm=cx).prepare(
         G.key(314159), torch.from_numpy(ys))
     cx = sw.cx
@@ -34,7 +38,7 @@ for name, fuse in (("two_launches", False), ("one_launch", None)):
     sw.launch(); sw.finish()
     torch.cuda.synchronize()
     best = 1e9
-    for _ in range(4):
+    for _ in range(reps):
         t0 = time.perf_counter()
         for _ in range(10):
             sw.launch()
@@ -44,5 +48,6 @@ for name, fuse in (("two_launches", False), ("one_launch", None)):
     out[name] = {"us_per_step": 1e6 * best / T, "fused": bool(sw.fuse_sh), "noise_ahead": bool(sw.noise_ahead),
                  "peer_mode": bool(sw.peer_mode), "log_ml": sw.log_ml(),
                  "resident_particles": int(sw.p_step.comp.resident_particles())}
-out["same_log_ml"] = out["two_launches"]["log_ml"] == out["one_launch"]["log_ml"]
+if not only:
+    out["same_log_ml"] = out["two_launches"]["log_ml"] == out["one_launch"]["log_ml"]
 print(json.dumps(out))

@@ -73,7 +73,7 @@ def other_configs(tag, out_dir, ids):
         if not kernels:
             continue
         dom = max(kernels, key=lambda n_: stats.get(n_, (0, 0.0, 0))[1])
-        res[f"config{k}"] = {"tag": tag, "lib": ids.get("libgenmi_hip.so"), "unit": units["unit"], "units_profiled": units["units"],
+        res[f"config{k}"] = {"tag": tag, "lib": ids.get("libgenmi_hip.so"), "programs": units.get("programs"), "unit": units["unit"], "units_profiled": units["units"],
                              "valu_wave_insts_per_unit": total / units["units"], "kernels": kernels, "dominant_kernel": dom,
                              "dominant_valu_per_wave": kernels[dom]["valu_insts_per_wave"],
                              "dominant_avg_us": kernels[dom]["avg_us_in_profile"]}

@@ -41,8 +41,14 @@ class Diff:
     def get_tangent(self): return self.tangent
 
     @staticmethod
+    def tree_diff(tree, tangent_tree):
+        """incremental.py:122-150: a primal tree and a tree of ChangeTangents of the same structure, zipped"""
+        return _tree_map2(lambda p_, t_: Diff(p_, t_), tree, tangent_tree)
+
+    @staticmethod
     def no_change(tree):
-        return _tree_map(lambda v: v if isinstance(v, Diff) else Diff(v, NoChange), tree)
+        """incremental.py:152-173: every leaf NoChange — an existing Diff's tangent is REPLACED"""
+        return _tree_map(lambda v: Diff(v.primal, NoChange) if isinstance(v, Diff) else Diff(v, NoChange), tree)
 
     @staticmethod
     def unknown_change(tree):
@@ -54,7 +60,18 @@ class Diff:
 
     @staticmethod
     def tree_tangent(tree):
-        return _tree_map(lambda v: v.tangent if isinstance(v, Diff) else UnknownChange, tree)
+        """incremental.py:218-236: a value that is not a Diff reads as NoChange (the docstring there says UnknownChange;
+        the code and tests/core/interpreters/test_incremental.py:49-54 say NoChange).  An edit never sees one:
+        check_argdiffs refuses a tree with bare leaves, as the reference's `Argdiffs` type does (concepts.py:66-81)."""
+        return _tree_map(lambda v: v.tangent if isinstance(v, Diff) else NoChange, tree)
+
+    @staticmethod
+    def is_diff(v) -> bool:
+        return isinstance(v, Diff)
+
+    @staticmethod
+    def is_change_tangent(v) -> bool:
+        return isinstance(v, _ChangeTangent)
 
     @staticmethod
     def static_check_no_change(tree) -> bool:
@@ -82,6 +99,30 @@ class Diff:
 
     def __repr__(self):
         return f"Diff({self.primal!r}, {self.tangent!r})"
+
+
+def check_argdiffs(argdiffs):
+    """concepts.py:66-81: `Argdiffs` is a tree whose every leaf is a Diff (a runtime type check in the reference)"""
+    if argdiffs is not None and not Diff.static_check_tree_diff(argdiffs):
+        raise TypeError("argdiffs must be a tree of Diff values: wrap the arguments with Diff.no_change(...) / "
+                        "Diff.unknown_change(...) (the reference's Argdiffs type, concepts.py:66-81)")
+    return argdiffs
+
+
+def _tree_map2(fn, a, b):
+    if isinstance(a, tuple):
+        if not isinstance(b, tuple) or len(a) != len(b):
+            raise ValueError("Diff.tree_diff: the two trees differ in structure")
+        return tuple(_tree_map2(fn, x, y) for x, y in zip(a, b))
+    if isinstance(a, list):
+        if not isinstance(b, list) or len(a) != len(b):
+            raise ValueError("Diff.tree_diff: the two trees differ in structure")
+        return [_tree_map2(fn, x, y) for x, y in zip(a, b)]
+    if isinstance(a, dict):
+        if not isinstance(b, dict) or a.keys() != b.keys():
+            raise ValueError("Diff.tree_diff: the two trees differ in structure")
+        return {k: _tree_map2(fn, a[k], b[k]) for k in a}
+    return fn(a, b)
 
 
 def _tree_map(fn, tree):
@@ -114,12 +155,12 @@ class Trace:
     def edit(self, key, request, argdiffs=None):
         if argdiffs is None:
             argdiffs = Diff.no_change(self.get_args())
-        return request.edit(key, self, argdiffs)
+        return request.edit(key, self, check_argdiffs(argdiffs))
 
     def update(self, key, constraint, argdiffs=None):
         if argdiffs is None:
             argdiffs = Diff.no_change(self.get_args())
-        return self.get_gen_fn().update(key, self, constraint, argdiffs)
+        return self.get_gen_fn().update(key, self, constraint, check_argdiffs(argdiffs))
 
     def project(self, key, selection):
         return self.get_gen_fn().project(key, self, selection)
@@ -226,7 +267,7 @@ class GenerativeFunction:
 
     # derived (generative_function.py:611-689) -------------------------------------
     def update(self, key, trace, constraint: ChoiceMap, argdiffs):
-        tr, w, rd, bwd = Update(constraint).edit(key, trace, argdiffs)
+        tr, w, rd, bwd = Update(constraint).edit(key, trace, check_argdiffs(argdiffs))
         assert isinstance(bwd, Update), type(bwd)
         return tr, w, rd, bwd.constraint
 

@@ -157,10 +157,10 @@ gmx_shard_fill_body(uint32_t k0, uint32_t k1, uint32_t u0_host, const float* __r
     for (int k = 0; k < 4; ++k) {
       const int rho = k * GMX_BLOCK + tid;
       const int rc = rho < rows ? rho : 0;
-      int r = (int)(((float)rc + 0.5f) * inv);            // rc / n_tiles (exact: (rc + 0.5) / n_tiles is never near an integer)
-      int t = rc - r * n_tiles;
-      if (t < 0) { --r; t += n_tiles; }
-      if (t >= n_tiles) { ++r; t -= n_tiles; }
+      // rc / n_tiles, exactly: rows <= 1024 and world <= 8 here, so (rc + 0.5) / n_tiles is at least 0.5 / 1024 away
+      // from an integer and the two roundings (1 / n_tiles, the product) move it by less than 8 * 2^-23 — no fix-up
+      const int r = (int)(((float)rc + 0.5f) * inv);
+      const int t = rc - r * n_tiles;
       rr[k] = rho < rows ? r : -1;
       tt[k] = t;
       if (PEER && r != rank) {
@@ -259,12 +259,12 @@ gmx_shard_fill_body(uint32_t k0, uint32_t k1, uint32_t u0_host, const float* __r
   const uint64_t my_off = rscan - rt;
   const uint64_t cdf_offset = (uint64_t)shard_readlane64((int64_t)my_off, rank);
   if (wave == 0) {
-    if (lane < world) {
+    if (lane < world && lane > 0) {          // (rank 0's first slot is slot 0: nothing to evaluate at world 1)
       const double not_ = total ? (double)N / (double)total : 0.0;
       const double eps_ = (double)N * 0x1p-44 + 0x1p-40;
       s_bounds[lane] = total ? (int32_t)slots_below(kind, key, (uint64_t)u0_host, my_off, (uint64_t)N << 23, total, not_, eps_, (int64_t)N) : 0;
     }
-    if (lane == 0) s_bounds[world] = N;
+    if (lane == 0) { s_bounds[0] = 0; s_bounds[world] = N; }
   }
   bool overflow = false;
   // PEER: ship source `src` (local index) as slot k of the block for rank d — one granule per leaf, into d's landing
@@ -434,7 +434,9 @@ gmx_shard_fill_body(uint32_t k0, uint32_t k1, uint32_t u0_host, const float* __r
     src[6] = b.z > carry ? b.z : carry; src[7] = b.w > carry ? b.w : carry;
     const int32_t j = pass + 8 * tid;
     if (j < T1) {
-      int32_t d = (int32_t)((uint32_t)j / (uint32_t)n);          // owner of slot j
+      int32_t d = 0;                                              // owner of slot j: j / n
+      if (SMALL) { for (int s = 1; s < world; ++s) d += (j >= s * n) ? 1 : 0; }      // (world <= 8: no integer division)
+      else d = (int32_t)((uint32_t)j / (uint32_t)n);
       int32_t d_end = (d + 1) * n;
       if (d == rank && j + 8 <= T1 && j + 8 <= d_end) {            // the common case: 8 slots of my own shard
         rs_u32x4_a4 va, vb;

@@ -942,9 +942,13 @@ _DIGEST_SCOPES: list = []
 
 class program_digest:
     """`with engine.program_digest() as d: ...; d.hex()`: a digest of the SET of site programs created inside the block
-    (sha256 over the sorted sha256s of their blobs).  A specialised kernel is a function of its blob and of the library's
-    embedded headers, so (this digest, sha of the library) names the code a workload ran: what bench.py holds a counter
-    profile of one of the other configs to (profiles/counters.json `configs[*].programs`)."""
+    (sha256 over the sorted sha256s of their blobs) AND of the code objects hiprtc made of them inside the block
+    (gmx_program_code_hash).  The second part is needed: the same source compiles to DIFFERENT code when hiprtc runs
+    inside a process rocprofv3 has preloaded its tool library into (measured, round 5: BASELINE config 5's kernel with
+    176 VGPRs and 0.60 ms when first compiled under the profiler, 60 VGPRs and 0.35 ms otherwise — and the JIT disk
+    cache then hands the profiler's build to later plain runs).  With the sha of the library this names the code a
+    workload ran: what bench.py holds a counter profile of one of the other configs to (profiles/counters.json
+    `configs[*].programs`); tools/prof_config.sh therefore warms the JIT cache with a plain run first."""
 
     def __enter__(self):
         self._set = set()
@@ -1049,6 +1053,9 @@ class Compiled:
             if be.c.gmx_program_is_specialized(h):
                 continue
             one = be.c.gmx_program_specialize(h) == 0
+            if one:
+                for log in _DIGEST_SCOPES:       # the code object itself: hiprtc's output is not a function of the source
+                    log.add("code:%016x" % int(be.c.gmx_program_code_hash(h)))    # alone (see program_digest)
             if not one and regs > 31:
                 msg = be.c.gmx_last_error()
                 raise _lib.GenmiError("this program keeps more than 31 values live per particle and therefore needs the "

@@ -886,7 +886,8 @@ def test_full_size_sweep_bit_exact_vs_c_oracle(gpu):
 def test_config2_sizes_log_ml_bit_exact(gpu):
     """bench.py's `other_configs.config2_sizes` (BASELINE config 2 at 1.25e5 ... 8e6 particles x 100 steps; one launch
     per step up to 2^20 particles, two beyond): every step's integer total and maximum — the terms of the log-ML — and
-    the last ancestors against oracle/orc_sweep.c, bit for bit, at every size"""
+    the last ancestors against oracle/orc_sweep.c, bit for bit, at every size (run live up to 1e6; its committed outputs
+    — tests/golden/full_size.json — at 2e6 and 8e6, where one core needs 20 s)"""
     import ctypes
     import os
     import genjax_amd as G
@@ -907,6 +908,16 @@ def test_config2_sizes_log_ml_bit_exact(gpu):
         lml = sw.log_ml()
         _, _, anc = [v.cpu().numpy() for v in sw.state()]
         anc = anc & 0x1fffff if sw.fuse else anc          # (the one-launch step leaves TAGGED ancestor words)
+        if n > 1_000_000:       # the two sizes past one launch per step: the committed oracle outputs of that size
+            g = parity.load_golden("config2_sizes")[str(n)]       # (tests/golden/make_full_size.py config2_sizes)
+            assert (g["T"], g["seed"]) == (T, seed)
+            assert [int(v) for v in sw.totals.cpu().numpy().view(np.uint64)] == g["totals"], n
+            assert [int(v) for v in sw.maxs.cpu().numpy().view(np.uint32)] == g["maxs_bits"], n
+            assert parity.equals_golden(anc.astype(np.int32), g["anc"], g["index"]), n
+            assert lml == float.fromhex(g["log_ml"]), (n, lml)
+            assert not sw.fuse
+            del sw
+            continue
         shift = O.cdf_shift(n)
         ox, ox2, olw = np.zeros(n, f32), np.zeros(n, f32), np.zeros(n, f32)
         ocdf, oanc = np.zeros(n, u64), np.zeros(n, i32)

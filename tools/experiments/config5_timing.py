@@ -13,6 +13,10 @@ import torch  # noqa: E402
 import bench  # noqa: E402
 
 calls = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+from genjax_amd import engine  # noqa: E402
+
+scope = engine.program_digest()
+scope.__enter__()
 w = bench.config_workload(5)
 ms = []
 for _ in range(calls):
@@ -23,4 +27,5 @@ for _ in range(calls):
     b.record()
     torch.cuda.synchronize()
     ms.append(a.elapsed_time(b))
-print(json.dumps({"config": 5, "ms_per_call": [round(v, 4) for v in ms]}))
+scope.__exit__(None, None, None)
+print(json.dumps({"config": 5, "ms_per_call": [round(v, 4) for v in ms], "programs": scope.hex()}))

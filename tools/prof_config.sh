@@ -9,6 +9,9 @@ tag=$1; k=$2
 R=$GRAFT_REPO_ROOT
 out=$R/gpurun_out/prof_${tag}_config$k
 mkdir -p $R/gpurun_out
+# hiprtc inside a profiled process compiles the same source to different code (engine.program_digest): the kernels are
+# compiled by a PLAIN run first; the profiled runs below then load them from the JIT cache
+python3 $R/tools/run_config.py $k 1 > $R/gpurun_out/${tag}_config${k}_units_plain.json 2> $out.plain.err
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $R/tools/run_config.py $k 3 > $R/gpurun_out/${tag}_config${k}_units_trace.json 2> $out.trace.err
 rocprofv3 -i $R/profiles/pmc/sq_pass.txt --kernel-trace --output-format csv -d $out/pmc -- python3 $R/tools/run_config.py $k 1 > $R/gpurun_out/${tag}_config${k}_units_pmc.json 2> $out.pmc.err

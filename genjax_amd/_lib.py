@@ -222,6 +222,7 @@ class Backend:
         c.gmx_peer_landing_bytes.argtypes = [c_int, c_int64, c_int64, c_int]
         c.gmx_peer_landing_bytes.restype = c_size_t
         c.gmx_peer_bump.argtypes = [c_void_p, c_int32, c_void_p]
+        c.gmx_sweep_verdict.argtypes = [c_void_p, POINTER(c_void_p), c_int32, c_void_p, c_void_p]
         c.gmx_peer_put_stats.argtypes = [c_void_p, Peer, c_int64, c_void_p]
         c.gmx_shard_step_peer.argtypes = [c_int, POINTER(c_uint32), c_void_p, Peer, c_void_p, c_void_p, c_void_p, c_void_p,
                                           c_int, c_int64, POINTER(c_void_p), POINTER(c_void_p), c_void_p, c_void_p]

@@ -3061,6 +3061,24 @@ extern "C" int gmx_peer_bump(uint32_t* tag_base_d, int32_t T, gmx_stream stream)
   return 0;
 }
 
+__global__ void k_sweep_verdict(const int64_t* overflow, const uint64_t* w0, const uint64_t* w1, const uint64_t* w2,
+                                const uint64_t* w3, int64_t* out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const bool bad = (w0 && *w0) || (w1 && *w1) || (w2 && *w2) || (w3 && *w3);
+    *out = bad ? (int64_t)2 : *overflow;
+  }
+}
+extern "C" int gmx_sweep_verdict(const int64_t* overflow_d, const uint64_t* const* status_h, int32_t n_status,
+                                 int64_t* verdict_d, gmx_stream stream) {
+  if (!overflow_d || !verdict_d || n_status < 0 || n_status > 4 || (n_status && !status_h))
+    return gmx_fail("gmx_sweep_verdict: bad argument (at most 4 status words)%s");
+  const uint64_t* w[4] = {nullptr, nullptr, nullptr, nullptr};
+  for (int k = 0; k < n_status; ++k) w[k] = status_h[k];
+  hipLaunchKernelGGL(k_sweep_verdict, dim3(1), dim3(64), 0, (hipStream_t)stream, overflow_d, w[0], w[1], w[2], w[3], verdict_d);
+  GMX_HIP(hipGetLastError());
+  return 0;
+}
+
 static int peer_check(const char* who, const gmx_peer& P, int64_t n_per_rank) {
   if (!P.land_d || !P.tag_base_d || !P.status_d) return gmx_fail("%s: peer has a null pointer", who);
   if (P.world < 1 || P.world > SHARD_MAX_WORLD || P.rank < 0 || P.rank >= P.world) return gmx_fail("%s: peer rank / world out of range (world <= 64)", who);

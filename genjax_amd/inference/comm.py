@@ -153,6 +153,10 @@ class P2PComm:
     def failed(self) -> bool:
         return bool(int(self.state[1].item()) != 0)
 
+    def failed_word(self):
+        """the error word itself (a device view): a sweep folds it into its one end-of-sweep read"""
+        return self.state[1:2]
+
     def destroy(self):
         for _base, _n, _peers, _raw, opened in self._allocs:
             for p in opened:

@@ -170,6 +170,7 @@ class ShardedBootstrapSweep(_NoiseAhead):
         self.total_d = torch.zeros((1,), dtype=torch.int64, device=dev)
         self.totals_all = None      # (allocated below, once the communicator exists: a collective's destination)
         self.plan = torch.zeros((int(be.c.gmx_shard_plan_words(W)),), dtype=torch.int64, device=dev)
+        self.verdict = torch.zeros((1,), dtype=torch.int64, device=dev)        # gmx_sweep_verdict: 0 fine, 1 overflow, 2 failed
         self.ws = torch.zeros(((be.c.gmx_weight_cdf_workspace(n) + 7) // 8,), dtype=torch.int64, device=dev)
         self.shift = cdf_shift(self.N)
         if self.comm and self.cx is None:
@@ -525,9 +526,32 @@ class ShardedBootstrapSweep(_NoiseAhead):
             be.check(be.c.gmx_peer_bump(be.ptr(self.peer_tag), self.T, be.stream()), "gmx_peer_bump")
         if self.noise_ahead:
             self._enqueue_noise_ahead()
-            return
-        for t in range(self.T):
-            self._step(t)
+        else:
+            for t in range(self.T):
+                self._step(t)
+        self._enqueue_verdict()
+
+    def _status_words(self):
+        """device words whose non-zero value fails the sweep: the communicator's error word, the peer exchange's, the
+        one-launch step's (an ancestor word that never arrived)"""
+        words = []
+        if self.comm and hasattr(self.cx, "failed_word"):
+            words.append(self.cx.failed_word())
+        if self.comm and self.peer_mode:
+            words.append(self.peer_status[0:1])
+        if self.fuse_sh:
+            words.append(self.sh_status[0:1])
+        return words
+
+    def _enqueue_verdict(self):
+        """the last node of a sweep: overflow flag and status words folded into ONE device word (gmx_sweep_verdict), so
+        that finish() costs one read by the host (it was four reads and five small launches: 250 us of a 1.6-ms sweep)"""
+        from ctypes import c_void_p
+        be = _lib.get()
+        words = self._status_words()
+        arr = (c_void_p * max(1, len(words)))(*[c_void_p(w.data_ptr()) for w in words])
+        be.check(be.c.gmx_sweep_verdict(be.ptr(self.plan[2:3]), arr, len(words), be.ptr(self.verdict), be.stream()),
+                 "gmx_sweep_verdict")
 
     def capture(self):
         """OPT-IN across GPUs (`bench.py --rccl-graph`; the default at world size 1): capture the whole sweep — kernels AND the
@@ -568,19 +592,15 @@ class ShardedBootstrapSweep(_NoiseAhead):
         launch-then-state()/log_ml() on all ranks does); re-run with full capacity if it is set anywhere."""
         if self._finished:
             return self
-        flag = self.plan[2:3].clone()
+        # a wait that timed out (a peer that never arrived) fails the sweep on EVERY rank instead of handing back stale
+        # particles: the status words travel with the overflow flag — folded into `verdict` by the sweep's last node
         if self.comm:
-            # a wait that timed out (a peer that never arrived) fails the sweep on EVERY rank instead of handing back
-            # stale particles: the communicator's error word travels with the overflow flag
-            if hasattr(self.cx, "failed"):
-                bad = bool(self.cx.failed()) or (self.peer_mode and int(self.peer_status[0].item()) != 0) \
-                    or (self.fuse_sh and int(self.sh_status.item()) != 0)      # (an ancestor word that never arrived)
-                flag = torch.where(torch.tensor(bad, device=flag.device), torch.full_like(flag, 2), flag)
-            self.cx.all_reduce_max(flag)
-        if int(flag.item()) >= 2:
+            self.cx.all_reduce_max(self.verdict)
+        flag = int(self.verdict.item())
+        if flag >= 2:
             raise RuntimeError("ShardedBootstrapSweep: a peer's data did not arrive in time on some rank (the "
                                "peer-mapped exchange gave up waiting): the sweep's results are not valid")
-        if int(flag.item()) != 0:
+        if flag != 0:
             self.reruns += 1
             self.capacity = self.n
             if self.graph is not None:

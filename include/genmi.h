@@ -538,6 +538,12 @@ int gmx_shard_step_fused(int kind, const uint32_t key[2], const void* stats_all_
 size_t gmx_peer_landing_bytes(int world, int64_t n_per_rank, int64_t capacity, int leaves);
 /* *tag_base_d += T (one thread): at the head of every sweep, before its first site program */
 int gmx_peer_bump(uint32_t* tag_base_d, int32_t T, gmx_stream stream);
+/* The verdict of a sharded sweep, folded on the device at its end (one thread; inside a captured sweep too):
+ * *verdict_d = 2 if any of the n_status (<= 4) status words is non-zero (a wait that gave up: the results are not
+ * valid), else the overflow word *overflow_d of the plan (non-zero: re-run with full capacity).  The host then reads ONE
+ * word per sweep (after a MAX over ranks) instead of every status word in turn.  No reference counterpart. */
+int gmx_sweep_verdict(const int64_t* overflow_d, const uint64_t* const* status_h, int32_t n_status, int64_t* verdict_d,
+                      gmx_stream stream);
 /* Put a statistics block that a launch without the epilogue wrote (gmx_tile_stats; an interpreted site program) */
 int gmx_peer_put_stats(const void* stats_own_d, gmx_peer peer, int64_t n_per_rank, gmx_stream stream);
 /* state_rows_h / tail_rows_h: HOST arrays [peer.leaves] of device pointers — leaf l's local states [n_per_rank] and the

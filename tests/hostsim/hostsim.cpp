@@ -784,6 +784,14 @@ extern "C" int gmx_peer_bump(uint32_t* tag_base, int32_t T, gmx_stream) {
   *tag_base += (uint32_t)T;
   return 0;
 }
+extern "C" int gmx_sweep_verdict(const int64_t* overflow, const uint64_t* const* status, int32_t n_status, int64_t* verdict,
+                                 gmx_stream) {
+  if (!overflow || !verdict || n_status < 0 || n_status > 4 || (n_status && !status)) return fail("sweep_verdict: bad argument");
+  bool bad = false;
+  for (int k = 0; k < n_status; ++k) bad = bad || (status[k] && *status[k] != 0);
+  *verdict = bad ? 2 : *overflow;
+  return 0;
+}
 static int hs_peer_check(const gmx_peer& P, int64_t n) {
   if (!P.land_d || !P.tag_base_d || !P.status_d) return fail("peer: null pointer");
   if (P.world < 1 || P.world > 64 || P.rank < 0 || P.rank >= P.world || P.step < 0) return fail("peer: rank / world / step out of range");

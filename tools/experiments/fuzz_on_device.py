@@ -1,7 +1,7 @@
 """tests/fuzz_models.py on the MI355X beyond the seeds the test suite runs: random `@gen` models built with the
 product (through libgenmi_hip.so) and with the oracle, every GFI method / edit / MH move / ImportanceK / resampling
 compared bit for bit.  Prints one JSON line of counts.
-  python tools/experiments/fuzz_on_device.py [n_interpreter_seeds] [n_jit_seeds] [n_jit_smc_seeds]"""
+  python tools/experiments/fuzz_on_device.py [n_interpreter_seeds] [n_jit_seeds] [n_jit_smc_seeds] [seed_offset]"""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from genjax_amd import _lib
@@ -10,9 +10,10 @@ from tests import fuzz_models as F
 _lib.get()                                   # the HIP library, or a loud failure
 n_small = int(sys.argv[1]) if len(sys.argv) > 1 else 400
 n_jit = int(sys.argv[2]) if len(sys.argv) > 2 else 24
-out = dict(models=0, over_the_limits=0, failures=[], smc_models=0, big_plate_models=0, jit_models=0)
+off = int(sys.argv[4]) if len(sys.argv) > 4 else 0           # fresh seeds: every range below shifted by it
+out = dict(seed_offset=off, models=0, over_the_limits=0, failures=[], smc_models=0, big_plate_models=0, jit_models=0)
 t0 = time.time()
-for seed in range(10_000, 10_000 + n_small):
+for seed in range(10_000 + off, 10_000 + off + n_small):
     try:
         F.run_one(seed)
         out["models"] += 1
@@ -20,7 +21,7 @@ for seed in range(10_000, 10_000 + n_small):
         out["over_the_limits"] += 1
     except Exception as e:      # noqa: BLE001
         out["failures"].append((seed, "run_one", repr(e)[:200]))
-for seed in range(20_000, 20_000 + n_small // 2):
+for seed in range(20_000 + off, 20_000 + off + n_small // 2):
     try:
         F.run_smc_one(seed)
         out["smc_models"] += 1
@@ -28,13 +29,13 @@ for seed in range(20_000, 20_000 + n_small // 2):
         out["over_the_limits"] += 1
     except Exception as e:      # noqa: BLE001
         out["failures"].append((seed, "run_smc_one", repr(e)[:200]))
-for seed in range(30_000, 30_000 + 16):
+for seed in range(30_000 + off, 30_000 + off + 16):
     try:
         F.run_big_one(seed)
         out["big_plate_models"] += 1
     except Exception as e:      # noqa: BLE001
         out["failures"].append((seed, "run_big_one", repr(e)[:200]))
-for seed in range(40_000, 40_000 + n_jit):          # 2^18 particles: the hiprtc-specialised programs
+for seed in range(40_000 + off, 40_000 + off + n_jit):          # 2^18 particles: the hiprtc-specialised programs
     try:
         F.run_one(seed, B=1 << 18)
         out["jit_models"] += 1
@@ -45,7 +46,7 @@ for seed in range(40_000, 40_000 + n_jit):          # 2^18 particles: the hiprtc
     print(f"# jit seed {seed} done, {time.time() - t0:.0f} s", file=sys.stderr, flush=True)
 n_jit_smc = int(sys.argv[3]) if len(sys.argv) > 3 else 12
 out["jit_smc_models"] = 0
-for seed in range(50_000, 50_000 + n_jit_smc):      # ImportanceK with 2^18 particles, then a resampling of them
+for seed in range(50_000 + off, 50_000 + off + n_jit_smc):      # ImportanceK with 2^18 particles, then a resampling of them
     try:
         F.run_smc_one(seed, K=1 << 18)
         out["jit_smc_models"] += 1

@@ -3710,3 +3710,49 @@ def check_masked_image_model(B=6, size=24, seed=71):
             otr, ow, _ = oimage_model.update(ok2, otr, O.ChoiceMap(), (new_mask,))
             assert eq(w, ow) and eq(tr.get_score(), otr.get_score()), (i, n_(w), ow)
             assert int(n_(tr.get_choices()[:, :, "pixel"].flag).sum()) == int(new_mask.sum()) * (B if batch else 1)
+
+
+def check_sweep_verdict():
+    """gmx_sweep_verdict (include/genmi.h): 0 when nothing happened, the plan's overflow word when no status word is set,
+    2 as soon as one is; and ShardedBootstrapSweep.finish() reads exactly that word: a sweep whose peer exchange gave up
+    waiting raises instead of handing back stale particles"""
+    from ctypes import c_void_p
+    import genjax_amd as G
+    from genjax_amd import _lib, workloads
+    from genjax_amd.inference.sharded import ShardedBootstrapSweep
+    be = _lib.get()
+    dev = be.device
+    for overflow, words, want in ((0, [0, 0], 0), (1, [0, 0], 1), (0, [], 0), (1, [0, 7, 0], 2), (0, [0, 0, 0, 1], 2), (5, [], 5)):
+        ov = torch.tensor([overflow], dtype=torch.int64, device=dev)
+        ws = [torch.tensor([w], dtype=torch.int64, device=dev) for w in words]
+        out = torch.full((1,), -1, dtype=torch.int64, device=dev)
+        arr = (c_void_p * max(1, len(ws)))(*[c_void_p(w.data_ptr()) for w in ws])
+        be.check(be.c.gmx_sweep_verdict(be.ptr(ov), arr, len(ws), be.ptr(out), be.stream()), "gmx_sweep_verdict")
+        assert int(out.item()) == want, (overflow, words, int(out.item()))
+    assert be.c.gmx_sweep_verdict(be.ptr(ov), arr, 5, be.ptr(out), be.stream()) != 0          # at most four status words
+
+    class _Solo:
+        @staticmethod
+        def get_rank(): return 0
+        @staticmethod
+        def get_world_size(): return 1
+    n, T = 2048, 3
+    ys = workloads.lgssm_data(T)
+    init, step = workloads.make_lgssm(G)
+    sw = ShardedBootstrapSweep(init, step, n, T, _Solo, always_communicate=True).prepare(G.key(3), torch.from_numpy(ys))
+    sw.launch()
+    sw.finish()
+    assert int(sw.verdict.item()) == 0 and sw.reruns == 0
+    words = sw._status_words()
+    if words:            # a communicator with status words (peer-mapped exchanges): set one, fold again, finish must raise
+        words[-1].fill_(1)
+        sw._enqueue_verdict()
+        sw._finished = False
+        try:
+            sw.finish()
+        except RuntimeError as e:
+            assert "did not arrive" in str(e)
+        else:
+            raise AssertionError("finish() accepted a sweep whose status word was set")
+        words[-1].zero_()
+    return len(words)

@@ -1845,6 +1845,12 @@ def test_peer_mapped_exchange_between_two_processes_on_the_device(gpu, tmp_path,
     assert np.array_equal(x, ref["x"][ref["anc"]])
 
 
+def test_sweep_verdict_on_device(gpu, monkeypatch):
+    """gmx_sweep_verdict + finish() on the HIP library, over the fused peer exchange (status words exist)"""
+    monkeypatch.setenv("GENMI_COMM", "peer")
+    assert parity.check_sweep_verdict() >= 2
+
+
 def test_peer_route_of_twelve_leaves_between_two_processes_on_the_device(gpu, tmp_path):
     """the fused peer exchange past eight routed leaves (GMX_PEER_MAX_LEAVES = 32): a 6-vector state
     and one MH move per step — the particle and the state it was extended from travel as 2 x 6 leaves between two

@@ -1525,3 +1525,10 @@ def test_more_closed_forms(hostsim):
     """Gibbs assignments, Mask weights, IndexRequest on a plate, ChangeTarget evidence: against closed forms / scipy"""
     from tests import parity
     parity.check_more_closed_forms(n=100_000)
+
+
+def test_sweep_verdict(hostsim, monkeypatch):
+    """include/genmi.h gmx_sweep_verdict on the CPU mirror; finish() raises when a status word is set"""
+    from tests import parity
+    monkeypatch.setenv("GENMI_COMM", "peer")
+    assert parity.check_sweep_verdict() >= 1

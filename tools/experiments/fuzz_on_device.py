@@ -21,6 +21,8 @@ for seed in range(10_000 + off, 10_000 + off + n_small):
         out["over_the_limits"] += 1
     except Exception as e:      # noqa: BLE001
         out["failures"].append((seed, "run_one", repr(e)[:200]))
+    if seed % 50 == 49:          # (a run that writes nothing for minutes is taken to be hung)
+        print(f"# interpreter seed {seed} done, {time.time() - t0:.0f} s", file=sys.stderr, flush=True)
 for seed in range(20_000 + off, 20_000 + off + n_small // 2):
     try:
         F.run_smc_one(seed)
@@ -29,12 +31,15 @@ for seed in range(20_000 + off, 20_000 + off + n_small // 2):
         out["over_the_limits"] += 1
     except Exception as e:      # noqa: BLE001
         out["failures"].append((seed, "run_smc_one", repr(e)[:200]))
+    if seed % 50 == 49:
+        print(f"# smc seed {seed} done, {time.time() - t0:.0f} s", file=sys.stderr, flush=True)
 for seed in range(30_000 + off, 30_000 + off + 16):
     try:
         F.run_big_one(seed)
         out["big_plate_models"] += 1
     except Exception as e:      # noqa: BLE001
         out["failures"].append((seed, "run_big_one", repr(e)[:200]))
+    print(f"# big-plate seed {seed} done, {time.time() - t0:.0f} s", file=sys.stderr, flush=True)
 for seed in range(40_000 + off, 40_000 + off + n_jit):          # 2^18 particles: the hiprtc-specialised programs
     try:
         F.run_one(seed, B=1 << 18)

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Everything DESIGN.md quotes, in one go, on an MI355X box (from the repo root; ~30 min — past gpurun's 20-minute
-# limit per call: run the blocks below in two or three calls, as round 5 did: r05j = the counter passes, r05k = suite + bench):
+# limit per call: run the blocks below in two or three calls, as round 5 did: r05s = the counter passes, r05t = suite + bench):
 #   tools/reproduce.sh <tag>      -> gpurun_out/<tag>_*
 # Each rocprofv3 pass is its own invocation (kernel trace + stats, SQ counters, TCC counters: never combined);
 # every step runs under `timeout` so that a wedged process cannot hold the box.
@@ -28,6 +28,10 @@ timeout 300 python tools/bench_kinds.py 2> /dev/null | tail -1 > $out/${tag}_kin
 # round 5: the one-launch sharded step against two launches; a long vector-valued site against its vmap-plate spelling;
 # O(1) IndexRequest on a long scan; the bound on what a destination-centric resampling prologue could save
 timeout 300 python tools/bench_sharded_fuse_ab.py 2> /dev/null | tail -1 > $out/${tag}_sharded_fuse_ab.json
+timeout 300 bash tools/experiments/prof_sharded_one_launch.sh > $out/${tag}_sh_prof.log 2>&1      # SQ counters of the one-launch sharded kernel -> r05m_sh_pmc_summary.txt
+# hiprtc inside a profiled process compiles the same source to different code: config 5, JIT cache off
+GENMI_JIT_CACHE=0 timeout 120 python tools/experiments/config5_timing.py 4 > $out/${tag}_c5_plain.json 2> /dev/null
+(cd /tmp && GENMI_JIT_CACHE=0 TMPDIR=/tmp timeout 120 rocprofv3 --kernel-trace --output-format csv -d $out/prof_${tag}_c5 -- python3 $root/tools/experiments/config5_timing.py 4 > $out/${tag}_c5_under_rocprofv3.json 2> /dev/null)
 timeout 300 python tools/vector_site_cost.py 100000 2> /dev/null | tail -1 > $out/${tag}_vector_site_cost.json
 timeout 300 python tools/scan_index_request_cost.py 100000 4096 2> /dev/null | tail -1 > $out/${tag}_scan_index_request_cost.json
 python tools/experiments/build_diag_lib.py nopoll > /dev/null 2>&1 && timeout 300 python tools/experiments/poll_hop_bound.py 2> /dev/null | tail -1 > $out/${tag}_poll_hop_bound.json

@@ -114,6 +114,7 @@ gmx_shard_fill_body(uint32_t k0, uint32_t k1, uint32_t u0_host, const float* __r
   __shared__ __attribute__((aligned(16))) uint32_t s_mark[RS_FILL_SLOTS];
   __shared__ int32_t s_rng[2];
   __shared__ uint32_t s_carry[4];
+  __shared__ uint32_t s_gave_up[4];
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int my_tile = (int)blockIdx.x;
   const int32_t i0 = my_tile * RS_TILE + tid * CDF_VEC;
@@ -190,12 +191,7 @@ gmx_shard_fill_body(uint32_t k0, uint32_t k1, uint32_t u0_host, const float* __r
       }
     }
   }
-  if (PEER) {      // a peer whose statistics never arrived: the workgroup leaves (bounded, no garbage routed)
-    if (__syncthreads_or(timed_out ? 1 : 0)) {
-      if (tid == 0) { __hip_atomic_store(P.status, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); plan[GMX_PLAN_OVERFLOW] = 1; }
-      return;
-    }
-  }
+  // (PEER: a peer whose statistics never arrived — the vote rides on the barrier below, not on one of its own)
   m = wave_max(m);
   const int32_t k_b = gmx_tile_exp(tmax_mine);
   const float ref_b = gmx_tile_ref(k_b);
@@ -208,7 +204,14 @@ gmx_shard_fill_body(uint32_t k0, uint32_t k1, uint32_t u0_host, const float* __r
   const uint64_t inc = wave_scan_u64(run);
   if (lane == 0) s_max[wave] = m;
   if (lane == 63) s_scan[wave] = inc;
+  if (PEER) { const bool gave_up = __any(timed_out ? 1 : 0) != 0; if (lane == 0) s_gave_up[wave] = gave_up ? 1u : 0u; }
   __syncthreads();
+  if (PEER) {      // a peer whose statistics never arrived: the workgroup leaves (bounded, no garbage routed)
+    if ((s_gave_up[0] | s_gave_up[1] | s_gave_up[2] | s_gave_up[3]) != 0u) {       // block-uniform
+      if (tid == 0) { __hip_atomic_store(P.status, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); plan[GMX_PLAN_OVERFLOW] = 1; }
+      return;
+    }
+  }
   const float M = gmx_rmax(gmx_rmax(s_max[0], s_max[1]), gmx_rmax(s_max[2], s_max[3]));
   const int32_t K = gmx_tile_exp(M);
   // ---- pass 2: every rank's total (partial sums per wave), and the mass of this rank's earlier tiles ----

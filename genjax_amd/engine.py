@@ -828,13 +828,19 @@ class StepInput2:
         return out
 
 
+class VectorSiteValueUsed(NotImplementedError):
+    """the model computes with the values of a vector-valued site that was lowered to a counted loop (they live in
+    memory only): the caller traces again with such sites unrolled (static.without_vector_site_loops)"""
+
+
 class StepOutput:
     """The stacked per-iteration outputs of a counted loop ([n, T] after the launch): they exist only in memory, so
     inside the program they can be returned / recorded but not computed with."""
 
-    def __init__(self, origin, T, trailing=1):
+    def __init__(self, origin, T, trailing=1, vector_site=False):
         self.origin, self.T = origin, T
         self.trailing = trailing           # dims after the batch: (T, *event) — what an unrolled plate stacks in front of
+        self.vector_site = vector_site     # the values of ONE long vector-valued site (static._vector_site_loop)
 
     @staticmethod
     def stack(parts):
@@ -843,6 +849,8 @@ class StepOutput:
         return StepOutput(("stack", [p.origin for p in parts], parts[0].trailing), parts[0].T, parts[0].trailing + 1)
 
     def _no(self, *a, **k):
+        if self.vector_site:
+            raise VectorSiteValueUsed("the model computes with the values of a long vector-valued site")
         raise NotImplementedError("the stacked outputs of a long scan live in memory only: return them, or use a "
                                   "scan of at most 16 steps (unrolled) to compute with them inside the model")
     __add__ = __radd__ = __mul__ = __rmul__ = __sub__ = __rsub__ = __getitem__ = __truediv__ = _no

@@ -725,6 +725,7 @@ def split_graph(g: Graph, max_in: int, max_out: int, max_uni: int, max_tab: int,
         e_prev = seg_lo - 1
         expire = {}
         best = None
+        fits = []                # the cut points after which everything in flight fits the stored leaves
         for u in range(ulo, len(units)):
             a_, b_ = units[u]
             for n in P[a_:b_ + 1]:
@@ -759,6 +760,7 @@ def split_graph(g: Graph, max_in: int, max_out: int, max_uni: int, max_tab: int,
                 break
             if stouts + cur <= max_out:
                 best = u
+                fits.append(u)
             if b_ - seg_lo >= max_len and best is not None:
                 break
         if best is None:
@@ -776,7 +778,14 @@ def split_graph(g: Graph, max_in: int, max_out: int, max_uni: int, max_tab: int,
                 spill_word.update(mark[1])
                 if best == ulo:
                     raise
-                best = ulo + (best - ulo) // 2
+                # a shorter segment — cut only where the values in flight fit the stored leaves (a cut half way may
+                # fall where more of them are alive than at the end that was tried)
+                shorter = [u for u in fits if u <= ulo + (best - ulo) // 2]
+                if not shorter:
+                    shorter = [u for u in fits if u < best]
+                if not shorter:
+                    raise
+                best = shorter[-1]
         segments.append(seg)
         ulo = best + 1
     return segments, n_words

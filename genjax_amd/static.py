@@ -978,6 +978,32 @@ def _leaf_call(ctx: _Ctx, mode, dist, key, args, constraint: ChoiceMap, prev, re
 VECTOR_SITE_LOOP_MIN = 17       # elements from which a vector-valued site under a particle batch runs as a counted loop
 
 
+_VECTOR_SITE_LOOPS_OFF = [0]
+
+
+def _unrolled_when_values_are_used(fn):
+    """a tracing entry point: when the model turns out to compute with the values of a vector-valued site that was
+    lowered to a counted loop (engine.VectorSiteValueUsed — they exist in memory only), the call is traced again with
+    such sites unrolled, the form that carries a few hundred elements (chains of launches beyond one); the program cache
+    then holds that form under the same key"""
+    import functools
+    from .engine import VectorSiteValueUsed
+
+    @functools.wraps(fn)
+    def wrapped(*a, **k):
+        try:
+            return fn(*a, **k)
+        except VectorSiteValueUsed:
+            if _VECTOR_SITE_LOOPS_OFF[0]:
+                raise
+        _VECTOR_SITE_LOOPS_OFF[0] += 1
+        try:
+            return fn(*a, **k)
+        finally:
+            _VECTOR_SITE_LOOPS_OFF[0] -= 1
+    return wrapped
+
+
 def _vector_site_loop(ctx, mode, dist, key, args, cval, prev, req):
     """A vector-valued distribution site of MANY elements under a particle batch (TFP batch semantics,
     tensorflow_probability/__init__.py:52-62: `normal(a * xs + b, sigma) @ "y"` with 500 observations): instead of one
@@ -991,6 +1017,8 @@ def _vector_site_loop(ctx, mode, dist, key, args, cval, prev, req):
     from .numpy import RuntimeTable, TableArray
     from .program import ELEM_LOOP
     g, tr = ctx.tr.graph, ctx.tr
+    if _VECTOR_SITE_LOOPS_OFF[0]:
+        return None
     if dist.logpdf_op is None or dist.sample_op is None or len(g.loop_counts) >= 3 or getattr(g, "elem_from_index", False):
         return None
     kind = req.kind if req is not None else "empty"
@@ -1035,7 +1063,7 @@ def _vector_site_loop(ctx, mode, dist, key, args, cval, prev, req):
     g.loop_end()
     score = Expr(svar)
     if new_value:
-        v = StepOutput(origin, n, len(tr.outputs[origin[1]][1]))
+        v = StepOutput(origin, n, len(tr.outputs[origin[1]][1]), vector_site=True)
         return _SiteRec(dist, v, score), v, None, score     # (generate, unconstrained: w = 0, distribution.py:124-127)
     if mode == "generate":
         return _SiteRec(dist, cval, score), cv, score, score          # w = score = logpdf (:144-147)
@@ -1405,6 +1433,7 @@ def _noise_split(tr: Tracing, batch, ctx):
     return tuple(hoist.draws), q
 
 
+@_unrolled_when_values_are_used
 def run_gfi(gen_fn, mode, key: Key | None, args, constraint: ChoiceMap | None = None, batch_shape=None,
             weight_stats: bool = False, elem_index: bool = False):
     """simulate / generate / assess for any generative function: one launch.
@@ -1882,6 +1911,7 @@ def run_mh(gen_fn, key: Key, trace: Trace, request: EditRequest, argdiffs):
     return run_edit(gen_fn, key, trace, request, argdiffs, mh=True)
 
 
+@_unrolled_when_values_are_used
 def run_edit(gen_fn, key: Key, trace: Trace, request: EditRequest, argdiffs, mh: bool = False):
     """edit(key, trace, request, argdiffs) -> (new trace, weight, retdiff, backward request)."""
     if getattr(trace, "_site_by_site", False) and not mh:

@@ -278,6 +278,9 @@ def lift(x) -> Expr:
         return Expr(g.const_f32(float(x)))
     if hasattr(x, "shape") and tuple(x.shape) == () and hasattr(x, "item"):
         return lift(x.item())
+    if getattr(x, "vector_site", False):          # engine.StepOutput of a looped vector-valued site: trace it unrolled
+        from .engine import VectorSiteValueUsed
+        raise VectorSiteValueUsed("the model computes with the values of a long vector-valued site")
     raise TypeError(f"cannot use a value of type {type(x).__name__} inside a traced expression")
 
 

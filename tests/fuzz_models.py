@@ -19,7 +19,7 @@ SMALL, LARGE = 3, 20          # unrolled / counted-loop sizes (the product switc
 # spec
 # ---------------------------------------------------------------------------
 def random_spec(rng, n_stmts=None, allow_nested=True):
-    kinds = ["leaf", "leaf", "call", "plate", "scan", "mask", "mplate", "mscan", "vec"] + (["plate_of_scans", "scan_of_plates"] if allow_nested else [])
+    kinds = ["leaf", "leaf", "call", "plate", "scan", "mask", "mplate", "mscan", "vec", "hvec"] + (["plate_of_scans", "scan_of_plates"] if allow_nested else [])
     stmts = []
     if n_stmts is None:
         # (one model in eight is LONG: more sites than one launch stores — a chain of launches, program.split_graph)
@@ -45,6 +45,8 @@ def random_spec(rng, n_stmts=None, allow_nested=True):
             st["flag"] = ["arg", True, False][int(rng.integers(3))]
         if kind == "vec":               # ONE vector-valued site of many elements (a counted loop per particle)
             st["n"] = [24, 40, 130][int(rng.integers(3))]
+        if kind == "hvec":              # a LATENT vector whose values are the next vector site's parameters (8-schools' shape)
+            st["n"] = [24, 40, 130][int(rng.integers(3))]
         stmts.append(st)
     return stmts
 
@@ -55,7 +57,7 @@ def spec_args(spec, rng, B):
     extra = []
     for st in spec:
         k = st["kind"]
-        if k in ("plate", "plate_of_scans", "vec"):
+        if k in ("plate", "plate_of_scans", "vec", "hvec"):
             extra.append(rng.normal(size=st["n"]).astype(np.float32))
         elif k in ("scan", "scan_of_plates"):
             extra.append(rng.normal(size=st["T"]).astype(np.float32))
@@ -182,6 +184,13 @@ def build(g, spec, lit):
                 mean = (m + xs * lit(st["c1"])) if g is not O else (np.asarray(m, np.float32)[..., None] + xs * lit(st["c1"])).astype(np.float32)
                 g.normal(mean, lit(st["sd"])) @ name                     # (its values live in memory only)
                 prev = m
+            elif k == "hvec":
+                xs = next(it)
+                mean = (m + xs * lit(st["c1"])) if g is not O else (np.asarray(m, np.float32)[..., None] + xs * lit(st["c1"])).astype(np.float32)
+                z = g.normal(mean, lit(st["sd"])) @ (name + "z")
+                loc = (z * lit(st["c2"]) + xs) if g is not O else (np.asarray(z, np.float32) * lit(st["c2"]) + xs).astype(np.float32)
+                g.normal(loc, lit(st["sd"])) @ (name + "y")              # the model computes with the latent vector's values
+                prev = m
             elif k == "plate":
                 g.Vmap(st["fn"], in_axes=(None, 0))(m, next(it)) @ name      # (a loop plate's values live in memory only)
                 prev = m
@@ -251,6 +260,9 @@ def addresses(spec):
             out.append(((nm,), (nm,), (), kind_, False, st))
         elif k == "vec":
             out.append(((nm,), (nm,), (st["n"],), "f", False, st))
+        elif k == "hvec":
+            out.append(((nm + "z",), (nm + "z",), (st["n"],), "f", False, st))
+            out.append(((nm + "y",), (nm + "y",), (st["n"],), "f", False, st))
         elif k == "call":
             out.append(((nm, "p"), (nm, "p"), (), "f", False, st))
             out.append(((nm, "q"), (nm, "q"), (), "f", False, st))
@@ -313,7 +325,7 @@ def _pick_constraints(spec, rng, p, B):
         if kind != "f" or rng.random() > p:
             continue
         form = int(rng.integers(3))
-        if form == 2 and len(shape) == 1 and not masked and st["kind"] != "vec":
+        if form == 2 and len(shape) == 1 and not masked and st["kind"] not in ("vec", "hvec"):
             m_ = int(rng.integers(1, min(3, shape[0]) + 1))
             idx = np.sort(rng.choice(shape[0], size=m_, replace=False))
             cons.append((ad, (idx, rng.normal(size=m_).astype(np.float32))))

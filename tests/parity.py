@@ -689,6 +689,64 @@ def check_long_vector_sites(n=500, K=64, seed=1):
     assert np.array_equal(_np(bwd.constraint["y"]), odisc["y"]), "update discard"
 
 
+def check_hierarchical_vector_latent(J=40, K=16, seed=2):
+    """A2 / A5 / A8: the 8-schools shape at J schools (BASELINE config 4 has J = 8) — a LATENT vector site whose values
+    are the parameters of the next vector site: `theta ~ normal(mu 1_J, tau 1_J); y ~ normal(theta, sigma_J)`.  The model
+    computes with the values of a long vector site, which the counted-loop lowering keeps in memory only: the call is
+    traced again with such sites unrolled (static._unrolled_when_values_are_used) and, past the slots of one launch,
+    cut into a chain of launches (program.split_graph: J = 40 found a cut that put 70 values in flight into one
+    segment).  simulate / ImportanceK / importance with per-particle theta / assess / update of mu and of half of theta /
+    regenerate of theta against the oracle bit for bit."""
+    import genjax_amd as G
+    from genjax_amd import ChoiceMapBuilder as C, Diff, Regenerate, SelectionBuilder as S, Update, numpy as jnp
+    from genjax_amd.inference.smc import ImportanceK
+    sig = np.linspace(9, 18, J).astype(np.float32)
+    ys = np.linspace(-3, 28, J).astype(np.float32)
+
+    @G.gen
+    def schools():
+        mu = G.normal(0.0, 5.0) @ "mu"
+        log_tau = G.normal(0.0, 1.0) @ "log_tau"
+        theta = G.normal(mu * jnp.ones(J), jnp.exp(log_tau) * jnp.ones(J)) @ "theta"
+        G.normal(theta, jnp.array(sig)) @ "y"
+        return mu
+
+    @O.gen
+    def oschools():
+        mu = O.normal(0.0, 5.0) @ "mu"
+        log_tau = O.normal(0.0, 1.0) @ "log_tau"
+        theta = O.normal(mu[..., None] * np.ones(J, np.float32), O.exp(log_tau)[..., None] * np.ones(J, np.float32)) @ "theta"
+        O.normal(theta, sig) @ "y"
+        return mu
+    dev = G._lib.get().device
+    rng = np.random.default_rng(seed)
+    coll = ImportanceK(G.Target(schools, (), C["y"].set(ys)), k_particles=K).run_smc(G.key(seed))
+    ocoll = O.ImportanceK(O.Target(oschools, (), O.C.d({"y": ys})), K).run_smc(O.key(seed))
+    assert np.array_equal(_np(coll.get_log_weights()), ocoll.get_log_weights()), "ImportanceK log weights"
+    assert np.array_equal(_np(coll.get_particles().get_choices()["theta"]), ocoll.get_particles().get_choices()["theta"])
+    keys, okeys = G.split(G.key(seed + 1), K), O.split(O.key(seed + 1), K)
+    tr, otr = schools.simulate(keys, ()), oschools.simulate(okeys, ())
+    for nm in ("mu", "log_tau", "theta", "y"):
+        assert np.array_equal(_np(tr.get_choices()[nm]), otr.get_choices()[nm]), ("simulate", nm)
+    assert np.array_equal(_np(tr.get_score()), otr.get_score()), "simulate score"
+    th = rng.normal(size=(K, J)).astype(np.float32)
+    tri, w = schools.importance(keys, C["theta"].set(torch.from_numpy(th).to(dev)) | C["y"].set(ys), ())
+    otri, ow = oschools.importance(okeys, O.C.d({"theta": th, "y": ys}), ())
+    assert np.array_equal(_np(w), ow) and np.array_equal(_np(tri.get_score()), otri.get_score()), "importance, theta given"
+    sc, _ = schools.assess(tr.get_choices(), ())
+    osc, _ = oschools.assess(otr.get_choices(), (), batch_shape=(K,))
+    assert np.array_equal(_np(sc), osc), "assess"
+    mu_new = rng.normal(size=K).astype(np.float32)
+    k2, ok2 = G.split(G.key(seed + 2), K), O.split(O.key(seed + 2), K)
+    new, wu, _, bwd = Update(C["mu"].set(torch.from_numpy(mu_new).to(dev))).edit(k2, tr, Diff.no_change(()))
+    onew, owu, odisc = oschools.update(ok2, otr, O.C.d({"mu": mu_new}), ())
+    assert np.array_equal(_np(wu), owu, equal_nan=True) and np.array_equal(_np(new.get_score()), onew.get_score(), equal_nan=True), "update mu"
+    new, wr, _, _ = Regenerate(S["theta"]).edit(k2, tr, Diff.no_change(()))
+    onew, owr = oschools.regenerate(ok2, otr, O.selection("theta"), ())[:2]
+    assert np.array_equal(_np(wr), owr, equal_nan=True), "regenerate theta: weight"
+    assert np.array_equal(_np(new.get_choices()["theta"]), onew.get_choices()["theta"]), "regenerate theta: values"
+
+
 def time_vector_site_vs_plate(n=500, K=100_000, reps=5):
     """seconds per ImportanceK.run_smc of `y ~ normal(a * xs + b, 0.5)` over n observations and K particles: as ONE
     vector-valued site (a counted loop per particle) and as a `vmap` plate (different key tree, same work)"""

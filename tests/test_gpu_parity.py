@@ -1942,6 +1942,16 @@ def test_long_vector_valued_sites_on_device(gpu):
     parity.check_long_vector_sites(n=48, K=1 << 18, seed=7)
 
 
+def test_latent_vector_feeding_the_next_vector_site_on_device(gpu):
+    """8-schools at J = 40 / 200 / 600 schools (BASELINE config 4's model beyond J = 8): the latent vector's values are the
+    next vector site's parameters — unrolled, as a chain of launches — interpreter and hiprtc-specialised (2^18
+    particles) against the oracle, bit for bit"""
+    parity.check_hierarchical_vector_latent(J=40)
+    parity.check_hierarchical_vector_latent(J=200, K=9, seed=4)
+    parity.check_hierarchical_vector_latent(J=600, K=5, seed=6)
+    parity.check_hierarchical_vector_latent(J=24, K=1 << 18, seed=8)
+
+
 def test_update_under_a_changed_table_argument_on_device(gpu):
     """an UnknownChange argument that is a launch-uniform table (> 16 elements, read at a run-time index in the loop):
     every element re-scored — one plate, a plate of plates, a scan over a table, `means[idx]` (ref vmap.py:236-275)"""

@@ -1532,3 +1532,11 @@ def test_sweep_verdict(hostsim, monkeypatch):
     from tests import parity
     monkeypatch.setenv("GENMI_COMM", "peer")
     assert parity.check_sweep_verdict() >= 1
+
+
+@pytest.mark.parametrize("J", [17, 40, 200])
+def test_latent_vector_feeding_the_next_vector_site(hostsim, J):
+    """8-schools at J schools: the model computes with the values of a long vector site (unrolled again; a chain of
+    launches past one launch's slots) — every GFI method against the oracle, bit for bit"""
+    from tests import parity
+    parity.check_hierarchical_vector_latent(J=J)

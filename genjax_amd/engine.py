@@ -526,6 +526,19 @@ class Tracing:
         self.prestored = {}    # id(node) -> slot of a store emitted early (plate elements)
         self.uses_key = False
         self.step_leaf_min = STEP_LEAF_MIN     # (a masked scan reads per-particle vectors step by step from 5 elements)
+        self.alias_plan = []   # (input slot, output index): a [T, n] OUTPUT of this very launch read back as an input
+
+    def alias_step_input(self, origin, dt, T):
+        """The values a counted loop stored as element t of a [T, n] output, READ BACK inside the same program: one more
+        input slot that `Compiled.bind` points at the output's own buffer.  A thread reads only what it stored itself
+        (the rows of its particle), after the loop that stored it — program order through memory — so the model can
+        compute with the values of a long vector-valued site: element j of the next vector site reads element j of this
+        one in its own loop, a static index is one load."""
+        g = self.graph
+        slot = g.n_in
+        g.n_in += 1
+        self.alias_plan.append((slot, origin[1]))
+        return StepAlias.make(g, slot, dt, T, origin)
 
     # leaves -> symbols ------------------------------------------------------
     def sym_leaf(self, spec, j) -> Sym:
@@ -648,6 +661,8 @@ class Tracing:
         pass-through / constant; returns its origin."""
         if isinstance(value, StepOutput):
             return value.origin
+        if isinstance(value, StepAlias) and value.origin is not None:
+            return value.origin
         g = self.graph
         if value is None:
             return ("const", None)
@@ -761,6 +776,22 @@ class StepInput(np.ndarray):
         if isinstance(r, StepInput) and not (isinstance(idx, slice) or idx is Ellipsis):
             return np.asarray(r, dtype=object) if r.ndim else r      # a static row / element: plain expressions
         return r
+
+
+class StepAlias(StepInput):
+    """Tracing.alias_step_input: the [T, n] output `origin` of this launch as an array of element reads.  Returned or
+    recorded as it is, it IS that output (emit_output: no second copy); views and slices are plain arrays of reads."""
+    origin = None
+
+    @classmethod
+    def make(cls, g, slot, dt, T, origin):     # noqa: D102
+        out = StepInput.make(g, slot, dt, T).view(cls)
+        out.origin = origin
+        return out
+
+    def __array_finalize__(self, obj):
+        StepInput.__array_finalize__(self, obj)
+        self.origin = None
 
 
 class StepInput2:
@@ -979,7 +1010,7 @@ class Compiled:
     def __init__(self, tr: Tracing, chain: bool = False):
         be = _lib.get()
         self.in_plan, self.uni_plan, self.outputs = tr.in_plan, tr.uni_plan, tr.outputs
-        self.tab_plan = tr.tab_plan
+        self.tab_plan, self.alias_plan = tr.tab_plan, tuple(tr.alias_plan)
         self.n_in, self.n_out, self.n_uni = tr.graph.n_in, tr.graph.n_out, tr.graph.n_uni
         self.uses_red = any(n.op in ("REDMAX", "REDLSE") for n in tr.graph.nodes)
         tabs = tr.graph.__dict__.get("tables", [])
@@ -1278,6 +1309,9 @@ class Compiled:
             else:
                 outs.append(buf.reshape(event + tuple(batch)).permute(
                     *range(len(event), len(event) + len(batch)), *range(len(event))))
+        for slot, k in self.alias_plan:          # an output of this launch read back by it (Tracing.alias_step_input)
+            A.in_d[slot] = A.out_d[self.outputs[k][2][1]]
+            A.step_stride = n
         if key is not None:
             mode, k0, k1, kt, inner = key.binding()
             A.key_mode, A.key0, A.key1, A.key_inner = mode, k0, k1, inner

@@ -1064,7 +1064,12 @@ def _vector_site_loop(ctx, mode, dist, key, args, cval, prev, req):
     score = Expr(svar)
     if new_value:
         v = StepOutput(origin, n, len(tr.outputs[origin[1]][1]), vector_site=True)
-        return _SiteRec(dist, v, score), v, None, score     # (generate, unconstrained: w = 0, distribution.py:124-127)
+        ret = v
+        if not g.loop_counts and g.n_in < 60:
+            # the MODEL gets the stored values as reads of that very output (engine.StepAlias): a later vector site
+            # whose parameters they are loops over them, `theta[3]` is one load — an 8-schools model of 5 000 schools
+            ret = tr.alias_step_input(origin, dist.value_dtype, n)
+        return _SiteRec(dist, v, score), ret, None, score   # (generate, unconstrained: w = 0, distribution.py:124-127)
     if mode == "generate":
         return _SiteRec(dist, cval, score), cv, score, score          # w = score = logpdf (:144-147)
     if mode == "assess":

@@ -301,11 +301,27 @@ def _has_step_rows(tree):
     return False
 
 
+def _store_score_of_stacked_value(tr, r, sc, dis, n):
+    """a site inside a counted loop whose VALUE a loop of its own stacked (a long vector-valued site: [T_outer, T, n]
+    from static._vector_site_loop) — or that is a per-particle leaf recorded as it is — but whose SCORE is this
+    iteration's scalar: the score (and a scalar discard) still go out per iteration, the value keeps its origin"""
+    from .engine import StepOutput
+    o_sc = tr.store_step(sc, n)
+    o_dis = None
+    if dis is not None:
+        o_dis = dis.origin if isinstance(dis, StepOutput) else tr.store_step(dis, n)
+    val = r.value.value if hasattr(r.value, "value") and not isinstance(r.value, StepOutput) else r.value
+    r.origins = (val.origin, o_sc, o_dis)
+    r.score = _so(tr, o_sc, n)
+
+
 def _stack(vals):
     from .engine import StepOutput, Sym
     vals = [v.value if isinstance(v, Sym) else v for v in vals]
     if all(v is None for v in vals):
         return None
+    # (long rows of a per-particle leaf, recorded / returned as they were given: the stacked outputs they already are)
+    vals = [v.passthrough() if (hasattr(v, "passthrough") and v.passthrough() is not None) else v for v in vals]
     if any(isinstance(v, StepOutput) for v in vals):
         if not all(isinstance(v, StepOutput) for v in vals):
             raise NotImplementedError("a plate whose elements mix loop outputs and plain values")
@@ -522,6 +538,8 @@ class Vmap(GenerativeFunction):
                     r.origins = (tr.store_step(val, n), tr.store_step(sc, n), None)
                     r.value = _so(tr, r.origins[0], n)
                     r.score = _so(tr, r.origins[1], n)
+                elif wanted and not isinstance(sc, StepOutput):
+                    _store_score_of_stacked_value(tr, r, sc, None, n)
 
             def stack_out(v):
                 if v is None:
@@ -534,6 +552,8 @@ class Vmap(GenerativeFunction):
                     return type(v)(stack_out(x) for x in v)
                 if isinstance(v, StepOutput):          # stacked by a loop inside this one: already [T0, T1, n]
                     return v
+                if hasattr(v, "passthrough") and v.passthrough() is not None:
+                    return v.passthrough()             # a long row of a per-particle leaf returned as it was given
                 return _so(tr, tr.store_step(v, n), n)
             rets = stack_out(ret) if (keep or not isinstance(rec, _SiteRec)) else None
             updates = []
@@ -589,6 +609,8 @@ class Vmap(GenerativeFunction):
                 inner = v.value
                 if isinstance(inner, (StepInput, StepInput2, RuntimeTable, TableArray)):
                     return Sym(inner[t], None)
+                if isinstance(inner, np.ndarray) and inner.dtype == object and inner.ndim >= 1 and inner.shape[0] == n:
+                    return Sym(_dyn_take(inner, t), None)     # (a short plate run as a loop: its leaves sit in registers)
                 return v
             if isinstance(v, dict):
                 return {k: (None if k == "retval" else prev_at(x, t)) for k, x in v.items()}
@@ -650,10 +672,12 @@ class Vmap(GenerativeFunction):
                 dis = r.discard.value if isinstance(r.discard, Sym) else r.discard
                 if wanted and not isinstance(val, StepOutput):
                     r.origins = (tr.store_step(val, n), tr.store_step(sc, n),
-                                 tr.store_step(dis, n) if dis is not None else None)
+                                 (dis.origin if isinstance(dis, StepOutput) else tr.store_step(dis, n)) if dis is not None else None)
                     r.value = _so(tr, r.origins[0], n)
                     r.score = _so(tr, r.origins[1], n)
-                    r.discard = _so(tr, r.origins[2], n) if dis is not None else None
+                    r.discard = (dis if isinstance(dis, StepOutput) else _so(tr, r.origins[2], n)) if dis is not None else None
+                elif wanted and not isinstance(sc, StepOutput):
+                    _store_score_of_stacked_value(tr, r, sc, dis, n)
 
             def stack_out(v):
                 if v is None:
@@ -666,6 +690,8 @@ class Vmap(GenerativeFunction):
                     return type(v)(stack_out(x) for x in v)
                 if isinstance(v, StepOutput):          # stacked by a loop inside this one: already [T0, T1, n]
                     return v
+                if hasattr(v, "passthrough") and v.passthrough() is not None:
+                    return v.passthrough()             # a long row of a per-particle leaf returned as it was given
                 return _so(tr, tr.store_step(v, n), n)
             rets = stack_out(ret)
             updates = []
@@ -1748,6 +1774,8 @@ class Scan(GenerativeFunction):
                     r.origins = (tr.store_step(val, n), tr.store_step(sc, n), None)
                     r.value = _so(tr, r.origins[0], n)
                     r.score = _so(tr, r.origins[1], n)
+                elif wanted and not isinstance(sc, StepOutput):
+                    _store_score_of_stacked_value(tr, r, sc, None, n)
 
             def stack_out(v):
                 if v is None:
@@ -1758,6 +1786,8 @@ class Scan(GenerativeFunction):
                     return type(v)(stack_out(x) for x in v)
                 if isinstance(v, StepOutput):          # stacked by a loop inside this one: already [T0, T1, n]
                     return v
+                if hasattr(v, "passthrough") and v.passthrough() is not None:
+                    return v.passthrough()             # a long row of a per-particle leaf returned as it was given
                 return _so(tr, tr.store_step(v, n), n)
             ys = stack_out(y_t)
             # loop-carried updates: carry, key chain, running weight and score (added in step order, as unrolled)
@@ -2043,10 +2073,12 @@ class Scan(GenerativeFunction):
                 dis = r.discard.value if isinstance(r.discard, Sym) else r.discard
                 if wanted and not isinstance(val, StepOutput):
                     r.origins = (tr.store_step(val, n), tr.store_step(sc, n),
-                                 tr.store_step(dis, n) if dis is not None else None)
+                                 (dis.origin if isinstance(dis, StepOutput) else tr.store_step(dis, n)) if dis is not None else None)
                     r.value = _so(tr, r.origins[0], n)
                     r.score = _so(tr, r.origins[1], n)
-                    r.discard = _so(tr, r.origins[2], n) if dis is not None else None
+                    r.discard = (dis if isinstance(dis, StepOutput) else _so(tr, r.origins[2], n)) if dis is not None else None
+                elif wanted and not isinstance(sc, StepOutput):
+                    _store_score_of_stacked_value(tr, r, sc, dis, n)
 
             def stack_out(v):
                 if v is None:
@@ -2057,6 +2089,8 @@ class Scan(GenerativeFunction):
                     return type(v)(stack_out(x) for x in v)
                 if isinstance(v, StepOutput):          # stacked by a loop inside this one: already [T0, T1, n]
                     return v
+                if hasattr(v, "passthrough") and v.passthrough() is not None:
+                    return v.passthrough()             # a long row of a per-particle leaf returned as it was given
                 return _so(tr, tr.store_step(v, n), n)
             ys = stack_out(y_t)
             new_leaves = []

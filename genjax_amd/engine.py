@@ -538,7 +538,22 @@ class Tracing:
         slot = g.n_in
         g.n_in += 1
         self.alias_plan.append((slot, origin[1]))
-        return StepAlias.make(g, slot, dt, T, origin)
+        if not g.loop_counts:
+            return StepAlias.make(g, slot, dt, T, origin)
+        # inside enclosing loops (a plate of such models run as a loop): element (t_outer.., j) of the
+        # [T_outer.., T, n] output can be read where the SAME outer iterations are open and the innermost loop runs over
+        # the site's own length — the next vector site's loop; anything else (a static element, a sum) unrolls the site
+        from .program import F_FLAT, F_STEP, F_U8
+        flags = F_STEP | F_FLAT | (F_U8 if dt == "bool" else 0)
+        outer = tuple(g.loop_ids)
+
+        def read(i):
+            if not (isinstance(i, Expr) and i.node.op == "LDT" and tuple(g.loop_ids[:-1]) == outer
+                    and len(g.loop_counts) == len(outer) + 1 and g.loop_counts[-1] == int(T)):
+                raise VectorSiteValueUsed("the values of a long vector-valued site inside a loop, read outside the "
+                                          "loop of another site of the same length")
+            return Expr(g.add("LDIN", dtype=dt, flags=flags, slot=slot))
+        return StepOutputAlias(origin, int(T), len(self.outputs[origin[1]][1]), read)
 
     # leaves -> symbols ------------------------------------------------------
     def sym_leaf(self, spec, j) -> Sym:
@@ -586,7 +601,7 @@ class Tracing:
             g.n_in += E
             for e_, slot in enumerate(slots):
                 self.in_plan.append((slot, j, e_, "stepflat2"))
-            return Sym(StepInput2(g, slots, dt, (int(event[0]), int(event[1])), event=tuple(int(x) for x in event[2:])), ("leaf", j))
+            return Sym(StepInput2(g, slots, dt, (int(event[0]), int(event[1])), event=tuple(int(x) for x in event[2:]), leaf=j), ("leaf", j))
         if kind == "part" and len(event) == 3 and event[2] > self.step_leaf_min and (event[0] > DVEC_MAX or event[1] > DVEC_MAX
                                                                                       or int(np.prod(event)) > 4 * DVEC_MAX):
             # [n, A, B, T]: the choices of a plate of plates of plates (or of long scans two plates deep) — one slot
@@ -594,7 +609,7 @@ class Tracing:
             slot = g.n_in
             g.n_in += 1
             self.in_plan.append((slot, j, 0, "stepflat"))
-            return Sym(StepInput2(g, slot, dt, tuple(int(x) for x in event)), ("leaf", j))
+            return Sym(StepInput2(g, slot, dt, tuple(int(x) for x in event), leaf=j), ("leaf", j))
         if kind == "part" and len(event) == 2 and event[1] > self.step_leaf_min:
             # [n, A, T] with a long last axis: the choices of the long scans of a plate — one slot ([A * T, n]); row a is
             # picked statically (an unrolled plate) or by the outer loop's iteration number (a plate run as a loop
@@ -602,7 +617,7 @@ class Tracing:
             slot = g.n_in
             g.n_in += 1
             self.in_plan.append((slot, j, 0, "stepflat"))
-            return Sym(StepInput2(g, slot, dt, (int(event[0]), int(event[1]))), ("leaf", j))
+            return Sym(StepInput2(g, slot, dt, (int(event[0]), int(event[1])), leaf=j), ("leaf", j))
         if kind == "part" and len(event) == 1 and event[0] > self.step_leaf_min:
             # a long per-particle vector (the [n, T] choices of a scan): one slot, element t read by iteration t
             slot = g.n_in
@@ -641,6 +656,19 @@ class Tracing:
         output ([n, T0, T1]: a plate of scans).  Returns the output's origin."""
         from . import tracer as Tm
         dims = tuple(int(c) for c in self.graph.loop_counts) or (int(T),)
+        m = Tm._long_vector(value)
+        if m and self.graph.loop_counts and len(self.graph.loop_counts) < 3:
+            # a LONG vector that can be read at a run-time index (a row of a launch-uniform table given as this element's
+            # constraint, a recipe over such rows): copied by a counted loop of its own — one read and one store per
+            # iteration — instead of m values alive at once inside the enclosing loop
+            g = self.graph
+            g.loop_begin(m)
+            e = Tm.lift(Tm._elem(value, Expr(g.add("LDT", dtype="i32"))))
+            slot = g.store(e.node, step=True)
+            g.loop_end()
+            o = ("out", len(self.outputs))
+            self.outputs.append((e.dtype, dims + (int(m),), ("step", slot, len(dims) + 1)))
+            return o
         if isinstance(value, np.ndarray) and value.dtype == object:
             # a vector-valued site: one [T, n] plane per element, exposed as [n, T, *event]
             es = [Tm.lift(v) for v in value.reshape(-1)]
@@ -802,9 +830,10 @@ class StepInput2:
     is ONE load: element (a, ..., t) of the slot, row-major (OP_LDIN, GMX_F_STEP; with the leading rows picked
     statically imm = their offset; under nested loops GMX_F_FLAT: the flat index is the loops' own)."""
 
-    def __init__(self, g, slot, dt, shape, row=None, event=(), rows=(), full=None):
+    def __init__(self, g, slot, dt, shape, row=None, event=(), rows=(), full=None, leaf=None):
         # slot: one input slot, or (a vector-valued site: event != ()) one per element of the site's event
         self._g, self._slot, self._dt, self.shape, self._event = g, slot, dt, tuple(shape), tuple(event)
+        self._leaf = leaf          # the launch leaf this is (Tracing.sym_leaf): a row of it recorded as it is needs no copy
         self._rows = tuple(rows) if rows else (() if row is None else (row,))       # picks so far: int | "loop"
         self._full = tuple(full) if full is not None else tuple(self._rows_shape()) + self.shape
         self.ndim = len(self.shape)
@@ -815,6 +844,49 @@ class StepInput2:
     @property
     def _row(self):
         return self._rows[-1] if self._rows else None
+
+    @property
+    def _lazy_row(self):
+        """ONE long row ([T] per particle, every leading axis picked): readable at the iteration number of a counted
+        loop, so elementwise arithmetic on it stays a recipe (tracer.LazyVec) and a vector-valued site over it — the
+        values of a plate's long vector sites given per particle: assess, update, importance — runs as a loop"""
+        return self.ndim == 1 and not self._event
+
+    def token(self):
+        """ONE node that stands for "the contents of this leaf" in the change propagation of an edit (static._nodes_of):
+        the reads of a leaf with several axes are made where they are used (a new node each), so a constraint given as
+        such a leaf is marked changed — and a later site's arguments are found to depend on it — through this node; it
+        is never executed (nothing stored depends on it)"""
+        toks = self._g.__dict__.setdefault("_leaf_tokens", {})
+        key = self._slot[0] if isinstance(self._slot, list) else self._slot
+        t = toks.get(key)
+        if t is None:
+            t = toks[key] = self._g.add("TOKEN", (), imm=int(key), dtype="none")
+        return t
+
+    def passthrough(self):
+        """this long row as the stacked output it already is — the values of a site GIVEN per particle (a constraint, the
+        previous trace's): recorded by their origin, never copied: the whole leaf where every leading row was picked by
+        a loop, the statically picked rows of it (an unrolled plate) otherwise"""
+        if self._leaf is None or not self._lazy_row:
+            return None
+        static = tuple(int(r) for r in self._rows if r != "loop")
+        origin = ("leafrow", self._leaf, static) if static else ("leaf", self._leaf)
+        return StepOutput(origin, int(self.shape[0]), 1 + sum(1 for r in self._rows if r == "loop"))
+
+    def _lazy(name):          # noqa: N805  (the LazyVec operators, for a long row)
+        def op(self, *o):
+            from . import tracer as Tm
+            if not self._lazy_row:
+                raise NotImplementedError("arithmetic on a per-particle leaf with several axes: pick a row first")
+            return getattr(Tm.LazyVec(self.shape[0], lambda i: self[i], parts=(self,)), name)(*o)
+        return op
+    for _n in ("__add__", "__radd__", "__sub__", "__rsub__", "__mul__", "__rmul__", "__truediv__", "__rtruediv__", "__pow__",
+               "__rpow__", "__neg__", "__abs__", "__lt__", "__le__", "__gt__", "__ge__", "__and__", "__rand__", "__or__",
+               "__ror__", "__invert__", "astype"):
+        locals()[_n] = _lazy(_n)
+    del _n, _lazy
+    __array_ufunc__ = None
 
     def __len__(self):
         return self.shape[0]
@@ -831,7 +903,7 @@ class StepInput2:
             else:
                 raise NotImplementedError("a per-particle leaf with a long last axis is read row by row (a plate of long scans)")
             return StepInput2(self._g, self._slot, self._dt, self.shape[1:], event=self._event, rows=self._rows + (pick,),
-                              full=self._full)
+                              full=self._full, leaf=self._leaf)
         if not (isinstance(idx, Expr) and idx.node.op == "LDT"):
             raise NotImplementedError("a long per-particle row is read by the scan's own iteration number")
         flags = F_STEP | (F_U8 if self._dt == "bool" else 0)
@@ -885,6 +957,27 @@ class StepOutput:
         raise NotImplementedError("the stacked outputs of a long scan live in memory only: return them, or use a "
                                   "scan of at most 16 steps (unrolled) to compute with them inside the model")
     __add__ = __radd__ = __mul__ = __rmul__ = __sub__ = __rsub__ = __getitem__ = __truediv__ = _no
+
+
+def _make_step_output_alias():
+    from .tracer import LazyVec
+
+    class StepOutputAlias(LazyVec, StepOutput):
+        """Tracing.alias_step_input INSIDE enclosing loops: the stored values of a looped vector site — to the
+        combinators the stacked output it is (returned / recorded as such), to the next vector site a recipe whose
+        element j is one read of that output in the site's own loop.  Anything else (a static element, a sum) raises
+        VectorSiteValueUsed: the call is traced again with the site unrolled."""
+
+        def __init__(self, origin, T, trailing, read):
+            LazyVec.__init__(self, T, read)
+            StepOutput.__init__(self, origin, T, trailing, vector_site=True)
+
+        def materialize(self):
+            raise VectorSiteValueUsed("the elements of a long vector-valued site inside a loop, one by one")
+    return StepOutputAlias
+
+
+StepOutputAlias = _make_step_output_alias()
 
 
 def _const_value(node):
@@ -1437,6 +1530,10 @@ def resolve(origin, outs, leaves):
         return outs[origin[1]]
     if kind == "leaf":
         return leaves[origin[1]]
+    if kind == "leafrow":      # statically picked leading rows of a per-particle leaf ([*batch, A, .., T] -> [*batch, T])
+        v = leaves[origin[1]]
+        nb = v.dim() - (len(origin[2]) + 1) if hasattr(v, "dim") else np.ndim(v) - (len(origin[2]) + 1)
+        return v[(slice(None),) * nb + tuple(origin[2])]
     if kind == "const":
         return origin[1]
     if kind in ("tuple", "list"):

@@ -193,10 +193,16 @@ class Graph:
         if len(self.loop_counts) >= 2:
             self.nested_loops = True
         self._cse.clear()              # a value computed before the loop is not "the same" as one recomputed inside
-        self.add("LOOP", imm=int(count), dtype="none")
+        self.loop_ids.append(self.add("LOOP", imm=int(count), dtype="none").idx)
+
+    @property
+    def loop_ids(self):
+        """the LOOP nodes of the counted loops being traced, outermost first: WHICH loops are open, not only how long"""
+        return self.__dict__.setdefault("_loop_ids", [])
 
     def loop_end(self):
         self.loop_counts.pop()
+        self.loop_ids.pop()
         self.add("ENDLOOP", dtype="none")
         self._cse.clear()
 

@@ -653,6 +653,8 @@ def _nodes_of(v):
         return [v.node]
     if isinstance(v, T.LazyVec):
         return v.dep_nodes()
+    if hasattr(v, "token"):                            # engine.StepInput2: the leaf's stand-in node
+        return [v.token()]
     if isinstance(v, np.ndarray) and v.dtype == object:
         return [x.node for x in v.reshape(-1) if isinstance(x, Expr)]
     if isinstance(v, (tuple, list)):
@@ -1046,7 +1048,9 @@ def _vector_site_loop(ctx, mode, dist, key, args, cval, prev, req):
         return None
     if mode not in ("simulate", "generate", "assess"):
         if cv is None and not ctx.args_changed(args):
-            return _SiteRec(dist, prev["value"], prev["score"]), pv, None, ps        # requests.py:56-57 / distribution.py:225-233
+            gv = prev["value"].value if isinstance(prev["value"], Sym) else prev["value"]
+            so = gv.passthrough() if hasattr(gv, "passthrough") else None
+            return _SiteRec(dist, so if so is not None else prev["value"], prev["score"]), pv, None, ps   # requests.py:56-57 / distribution.py:225-233
     zero = g.const_f32(0.0)
     svar = g.loop_var(zero)
     g.loop_begin(n)
@@ -1062,22 +1066,27 @@ def _vector_site_loop(ctx, mode, dist, key, args, cval, prev, req):
         g.set_vars([(svar, (Expr(svar) + s_t).node)])
     g.loop_end()
     score = Expr(svar)
+
+    def given(v):           # a long row of a per-particle leaf that IS the site's value: recorded as that leaf (no copy)
+        raw = v.value if isinstance(v, Sym) else v
+        so = raw.passthrough() if hasattr(raw, "passthrough") else None
+        return so if so is not None else v
     if new_value:
         v = StepOutput(origin, n, len(tr.outputs[origin[1]][1]), vector_site=True)
         ret = v
-        if not g.loop_counts and g.n_in < 60:
+        if True:
             # the MODEL gets the stored values as reads of that very output (engine.StepAlias): a later vector site
             # whose parameters they are loops over them, `theta[3]` is one load — an 8-schools model of 5 000 schools
             ret = tr.alias_step_input(origin, dist.value_dtype, n)
         return _SiteRec(dist, v, score), ret, None, score   # (generate, unconstrained: w = 0, distribution.py:124-127)
     if mode == "generate":
-        return _SiteRec(dist, cval, score), cv, score, score          # w = score = logpdf (:144-147)
+        return _SiteRec(dist, given(cval), score), cv, score, score          # w = score = logpdf (:144-147)
     if mode == "assess":
-        return _SiteRec(dist, cval, score), cv, None, score
+        return _SiteRec(dist, given(cval), score), cv, None, score
     if cv is None:                                     # the old value re-scored under changed arguments
-        return _SiteRec(dist, prev["value"], score), pv, score - ps, score
+        return _SiteRec(dist, given(prev["value"]), score), pv, score - ps, score
     ctx.mark_changed(cv)
-    return _SiteRec(dist, cval, score, discard=prev["value"]), cv, score - ps, score      # (:235-242)
+    return _SiteRec(dist, given(cval), score, discard=given(prev["value"])), cv, score - ps, score      # (:235-242)
 
 
 def _rec_choices(rec) -> ChoiceMap:

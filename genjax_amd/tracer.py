@@ -172,6 +172,8 @@ class LazyVec:
                 out += p.dep_nodes()
             elif isinstance(p, Expr):
                 out.append(p.node)
+            elif hasattr(p, "token"):                  # a per-particle leaf read where it is used (engine.StepInput2)
+                out.append(p.token())
             elif isinstance(p, np.ndarray) and p.dtype == object:
                 out += [x.node for x in p.reshape(-1) if isinstance(x, Expr)]
         return out
@@ -210,6 +212,8 @@ def _long_vector(a) -> int:
     if isinstance(a, LazyVec):
         return a.n
     if isinstance(a, np.ndarray) and a.ndim == 1 and a.shape[0] >= LAZY_MIN and getattr(a, "_lazy_ok", False):
+        return int(a.shape[0])
+    if getattr(a, "_lazy_row", False) and a.shape[0] >= LAZY_MIN:      # one row of an [n, A, T] leaf (engine.StepInput2)
         return int(a.shape[0])
     return 0
 

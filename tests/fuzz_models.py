@@ -19,7 +19,7 @@ SMALL, LARGE = 3, 20          # unrolled / counted-loop sizes (the product switc
 # spec
 # ---------------------------------------------------------------------------
 def random_spec(rng, n_stmts=None, allow_nested=True):
-    kinds = ["leaf", "leaf", "call", "plate", "scan", "mask", "mplate", "mscan", "vec", "hvec"] + (["plate_of_scans", "scan_of_plates"] if allow_nested else [])
+    kinds = ["leaf", "leaf", "call", "plate", "scan", "mask", "mplate", "mscan", "vec", "hvec", "vplate"] + (["plate_of_scans", "scan_of_plates"] if allow_nested else [])
     stmts = []
     if n_stmts is None:
         # (one model in eight is LONG: more sites than one launch stores — a chain of launches, program.split_graph)
@@ -47,6 +47,9 @@ def random_spec(rng, n_stmts=None, allow_nested=True):
             st["n"] = [24, 40, 130][int(rng.integers(3))]
         if kind == "hvec":              # a LATENT vector whose values are the next vector site's parameters (8-schools' shape)
             st["n"] = [24, 40, 130][int(rng.integers(3))]
+        if kind == "vplate":            # a plate (unrolled or a loop) of elements that hold such a pair of long vector sites
+            st["n"] = [SMALL, LARGE][int(rng.integers(2))]
+            st["m"] = [24, 40][int(rng.integers(2))]
         stmts.append(st)
     return stmts
 
@@ -57,7 +60,7 @@ def spec_args(spec, rng, B):
     extra = []
     for st in spec:
         k = st["kind"]
-        if k in ("plate", "plate_of_scans", "vec", "hvec"):
+        if k in ("plate", "plate_of_scans", "vec", "hvec", "vplate"):
             extra.append(rng.normal(size=st["n"]).astype(np.float32))
         elif k in ("scan", "scan_of_plates"):
             extra.append(rng.normal(size=st["T"]).astype(np.float32))
@@ -90,6 +93,18 @@ def build(g, spec, lit):
             if st.get("two"):
                 u = g.normal(v * lit(st["c1"]), lit(1.5)) @ "u"
                 return u
+            return v
+        return elem
+
+    def make_vec_elem(st):
+        @g.gen
+        def elem(shared, x):
+            v = g.normal(shared + x, lit(st["sd"])) @ "v"
+            tab = _ramp(g, st["m"], lit)
+            mean = (v * tab) if g is not O else (np.asarray(v, np.float32)[..., None] * tab).astype(np.float32)
+            z = g.normal(mean, lit(1.5)) @ "z"                            # a long vector site inside the element
+            loc = (z * lit(st["c1"]) + tab) if g is not O else (np.asarray(z, np.float32) * lit(st["c1"]) + tab).astype(np.float32)
+            g.normal(loc, lit(st["sd"])) @ "w"                           # ... whose values the next one computes with
             return v
         return elem
 
@@ -150,7 +165,7 @@ def build(g, spec, lit):
     for st in spec:
         k = st["kind"]
         parts.append(dict(st, fn={"plate": make_elem, "mplate": make_elem, "scan": make_step, "mask": make_inner, "call": make_call, "mscan": make_mstep,
-                                  "plate_of_scans": make_scan_elem, "scan_of_plates": make_plate_step}.get(k, lambda s: None)(st)))
+                                  "plate_of_scans": make_scan_elem, "scan_of_plates": make_plate_step, "vplate": make_vec_elem}.get(k, lambda s: None)(st)))
 
     @g.gen
     def model(a, *extra):
@@ -190,6 +205,9 @@ def build(g, spec, lit):
                 z = g.normal(mean, lit(st["sd"])) @ (name + "z")
                 loc = (z * lit(st["c2"]) + xs) if g is not O else (np.asarray(z, np.float32) * lit(st["c2"]) + xs).astype(np.float32)
                 g.normal(loc, lit(st["sd"])) @ (name + "y")              # the model computes with the latent vector's values
+                prev = m
+            elif k == "vplate":
+                g.Vmap(st["fn"], in_axes=(None, 0))(m, next(it)) @ name
                 prev = m
             elif k == "plate":
                 g.Vmap(st["fn"], in_axes=(None, 0))(m, next(it)) @ name      # (a loop plate's values live in memory only)
@@ -260,6 +278,10 @@ def addresses(spec):
             out.append(((nm,), (nm,), (), kind_, False, st))
         elif k == "vec":
             out.append(((nm,), (nm,), (st["n"],), "f", False, st))
+        elif k == "vplate":
+            out.append(((nm, "v"), (nm, "v"), (st["n"],), "f", False, st))
+            out.append(((nm, "z"), (nm, "z"), (st["n"], st["m"]), "f", False, st))
+            out.append(((nm, "w"), (nm, "w"), (st["n"], st["m"]), "f", False, st))
         elif k == "hvec":
             out.append(((nm + "z",), (nm + "z",), (st["n"],), "f", False, st))
             out.append(((nm + "y",), (nm + "y",), (st["n"],), "f", False, st))

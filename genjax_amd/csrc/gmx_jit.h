@@ -233,14 +233,20 @@ struct gmx_jit_ctx {
     }
 
 // OP_LOOP / OP_ENDLOOP: a counted loop around the instructions in between (launch-uniform trip count)
-#define GMX_JIT_LOOP(COUNT) for (gmx_t0 = 0u; gmx_t0 < (COUNT); ++gmx_t0) { gmx_t = gmx_t0; gmx_tf = gmx_t0;
+// (no unrolling of the counted loops: hiprtc on a GPU box — not the same build offline — unrolled a four-instruction copy
+//  loop inside a plate's loop by four and assigned the address of the fourth store to v[10:11] while v10 still held the
+//  loop-invariant row offset the next group of four indexes the table with: a wild load, a memory fault
+//  (profiles/r05z_jit_miscompile.txt has the disassembly rocgdb took from the faulting wave).  Rolled, the loops are
+//  the code the interpreter runs, instruction for instruction.)
+#define GMX_JIT_NOUNROLL _Pragma("clang loop unroll(disable)")
+#define GMX_JIT_LOOP(COUNT) GMX_JIT_NOUNROLL for (gmx_t0 = 0u; gmx_t0 < (COUNT); ++gmx_t0) { gmx_t = gmx_t0; gmx_tf = gmx_t0;
 #define GMX_JIT_ENDLOOP } gmx_t = 0u; gmx_t0 = 0u; gmx_tf = 0u;
 // a loop INSIDE a GMX_JIT_LOOP (a long scan inside a large plate): gmx_t counts the inner iterations, gmx_tf the pairs
-#define GMX_JIT_LOOP2(COUNT) for (uint32_t gmx_t1 = 0u; gmx_t1 < (COUNT); ++gmx_t1) { gmx_t = gmx_t1; gmx_tf = gmx_t0 * (COUNT) + gmx_t1;
+#define GMX_JIT_LOOP2(COUNT) GMX_JIT_NOUNROLL for (uint32_t gmx_t1 = 0u; gmx_t1 < (COUNT); ++gmx_t1) { gmx_t = gmx_t1; gmx_tf = gmx_t0 * (COUNT) + gmx_t1;
 #define GMX_JIT_ENDLOOP2 } gmx_t = gmx_t0; gmx_tf = gmx_t0;
 // a third level (a plate of plates of plates): gmx_tf runs over the triples, row-major; inside a GMX_JIT_LOOP2 only
 #define GMX_JIT_LOOP3(COUNT) { const uint32_t gmx_tp = gmx_t, gmx_tfp = gmx_tf;                  \
-    for (uint32_t gmx_t2 = 0u; gmx_t2 < (COUNT); ++gmx_t2) { gmx_t = gmx_t2; gmx_tf = gmx_tfp * (COUNT) + gmx_t2;
+    GMX_JIT_NOUNROLL for (uint32_t gmx_t2 = 0u; gmx_t2 < (COUNT); ++gmx_t2) { gmx_t = gmx_t2; gmx_tf = gmx_tfp * (COUNT) + gmx_t2;
 #define GMX_JIT_ENDLOOP3 } gmx_t = gmx_tp; gmx_tf = gmx_tfp; }
 
 #define GMX_JIT_END }

@@ -1168,21 +1168,24 @@ class Compiled:
         """Release the program now (idempotent); the object must not be launched afterwards."""
         self._finalizer()
 
-    def specialize(self) -> bool:
+    def specialize(self, only_needed: bool = False) -> bool:
         """Compile the kernel specialised to this program (gmx_program_specialize:
         the interpreter partially evaluated by hiprtc; bit-identical results).
         Returns False — and keeps the interpreter — if hiprtc is unavailable or
-        GENMI_JIT=0."""
+        GENMI_JIT=0.  only_needed: of a chain of launches, only the links the interpreter cannot hold."""
         be = self._be
         handles = [l.handle for l in self.links] if self.links else [self.handle]
         if all(be.c.gmx_program_is_specialized(h) for h in handles):
             return True
         if self._jit_tried:
             return False
-        self._jit_tried = True
+        if only_needed:
+            self._jit_needed = True
+        else:
+            self._jit_tried = True
         ok = True
         for h, regs in zip(handles, [l.n_regs for l in self.links] if self.links else [int(self.blob[3])]):
-            if be.c.gmx_program_is_specialized(h):
+            if be.c.gmx_program_is_specialized(h) or (only_needed and regs <= 31):
                 continue
             one = be.c.gmx_program_specialize(h) == 0
             if one:
@@ -1271,11 +1274,14 @@ class Compiled:
         be = self._be
         n = int(np.prod(batch, dtype=np.int64))
         self._work = getattr(self, "_work", 0) + n
-        if (n >= JIT_MIN_PARTICLES or self._work >= JIT_MIN_WORK or self.max_regs > 31) and not self._jit_tried \
-                and be.uses_streams and not torch.cuda.is_current_stream_capturing():
-            # big ensembles, programs launched often enough to repay ~0.5 s of hiprtc, and programs the
-            # 31-register interpreter cannot hold
-            self.specialize()
+        if be.uses_streams and not torch.cuda.is_current_stream_capturing():
+            if (n >= JIT_MIN_PARTICLES or self._work >= JIT_MIN_WORK) and not self._jit_tried:
+                # big ensembles and programs launched often enough to repay ~0.5 s of hiprtc
+                self.specialize()
+            elif self.max_regs > 31 and not self._jit_tried and not getattr(self, "_jit_needed", False):
+                # ... and what the 31-register interpreter cannot hold — of a chain of launches, those links only: the
+                # others stay on the interpreter until the work repays a compile
+                self.specialize(only_needed=True)
         if self.links:
             if tile_stats is not None or peer is not None or resample_in is not None or shard_in is not None:
                 raise NotImplementedError("a site program cut into a chain of launches takes no tile statistics / peers / "

@@ -1461,7 +1461,9 @@ def _index_prev(prev, j):
             inner = v.value
             if isinstance(inner, np.ndarray) and inner.dtype == object and inner.ndim >= 1:
                 return Sym(_take(inner, j), None)
-            return v
+            if type(inner).__name__ == "StepInput2" and inner.ndim >= 2:
+                return Sym(inner[int(j)], None)      # row j of a per-particle leaf with a long last axis (a short scan /
+            return v                                 # plate of long vector sites: the row is read inside the site's loop)
         if isinstance(v, dict):
             return {k: pick(x) for k, x in v.items()}
         if isinstance(v, tuple):

@@ -895,7 +895,9 @@ class StepInput2:
         from .program import F_FLAT, F_STEP, F_U8
         if self.ndim >= 2:
             if isinstance(idx, (int, np.integer)):
-                pick = int(idx)
+                if not -self.shape[0] <= int(idx) < self.shape[0]:
+                    raise IndexError(idx)          # (the sequence protocol ends here: `for row in leaf` is finite)
+                pick = int(idx) % self.shape[0]
             elif isinstance(idx, Expr):
                 if idx.node.op != "LDT":
                     raise NotImplementedError("a step leaf with several axes takes its rows from the plates' own iteration numbers")

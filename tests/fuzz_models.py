@@ -19,7 +19,7 @@ SMALL, LARGE = 3, 20          # unrolled / counted-loop sizes (the product switc
 # spec
 # ---------------------------------------------------------------------------
 def random_spec(rng, n_stmts=None, allow_nested=True):
-    kinds = ["leaf", "leaf", "call", "plate", "scan", "mask", "mplate", "mscan", "vec", "hvec", "vplate"] + (["plate_of_scans", "scan_of_plates"] if allow_nested else [])
+    kinds = ["leaf", "leaf", "call", "plate", "scan", "mask", "mplate", "mscan", "vec", "hvec", "vplate", "vscan"] + (["plate_of_scans", "scan_of_plates"] if allow_nested else [])
     stmts = []
     if n_stmts is None:
         # (one model in eight is LONG: more sites than one launch stores — a chain of launches, program.split_graph)
@@ -34,7 +34,7 @@ def random_spec(rng, n_stmts=None, allow_nested=True):
             st["n"] = [SMALL, LARGE][int(rng.integers(2))]
             st["two"] = bool(rng.integers(2))
             st["bern"] = bool(rng.integers(2)) and kind != "plate_of_scans"
-        if kind in ("scan", "scan_of_plates", "plate_of_scans", "mscan"):
+        if kind in ("scan", "scan_of_plates", "plate_of_scans", "mscan", "vscan"):
             st["T"] = [SMALL, LARGE][int(rng.integers(2))]
             st["bern"] = bool(rng.integers(2)) and kind == "scan"
         if kind == "scan_of_plates":
@@ -47,6 +47,8 @@ def random_spec(rng, n_stmts=None, allow_nested=True):
             st["n"] = [24, 40, 130][int(rng.integers(3))]
         if kind == "hvec":              # a LATENT vector whose values are the next vector site's parameters (8-schools' shape)
             st["n"] = [24, 40, 130][int(rng.integers(3))]
+        if kind == "vscan":             # a scan (unrolled or a loop) whose step emits a long vector (an HMM with vector observations)
+            st["m"] = [24, 40][int(rng.integers(2))]
         if kind == "vplate":            # a plate (unrolled or a loop) of elements that hold such a pair of long vector sites
             st["n"] = [SMALL, LARGE][int(rng.integers(2))]
             st["m"] = [24, 40][int(rng.integers(2))]
@@ -62,7 +64,7 @@ def spec_args(spec, rng, B):
         k = st["kind"]
         if k in ("plate", "plate_of_scans", "vec", "hvec", "vplate"):
             extra.append(rng.normal(size=st["n"]).astype(np.float32))
-        elif k in ("scan", "scan_of_plates"):
+        elif k in ("scan", "scan_of_plates", "vscan"):
             extra.append(rng.normal(size=st["T"]).astype(np.float32))
         elif k == "mscan":
             extra.append(np.arange(st["T"]) < int(rng.integers(0, st["T"] + 1)))
@@ -119,6 +121,16 @@ def build(g, spec, lit):
             return z, z
         return step
 
+    def make_vstep(st):
+        @g.gen
+        def step(c, x):
+            z = g.normal(c * lit(0.5) + x, lit(st["sd"])) @ "z"
+            tab = _ramp(g, st["m"], lit)
+            loc = (z * tab) if g is not O else (np.asarray(z, np.float32)[..., None] * tab).astype(np.float32)
+            g.normal(loc, lit(1.25)) @ "y"                                 # the step's long vector emission
+            return z, z
+        return step
+
     def make_mstep(st):
         @g.gen
         def mstep(x):
@@ -165,7 +177,7 @@ def build(g, spec, lit):
     for st in spec:
         k = st["kind"]
         parts.append(dict(st, fn={"plate": make_elem, "mplate": make_elem, "scan": make_step, "mask": make_inner, "call": make_call, "mscan": make_mstep,
-                                  "plate_of_scans": make_scan_elem, "scan_of_plates": make_plate_step, "vplate": make_vec_elem}.get(k, lambda s: None)(st)))
+                                  "plate_of_scans": make_scan_elem, "scan_of_plates": make_plate_step, "vplate": make_vec_elem, "vscan": make_vstep}.get(k, lambda s: None)(st)))
 
     @g.gen
     def model(a, *extra):
@@ -215,7 +227,7 @@ def build(g, spec, lit):
             elif k == "mplate":
                 flags, tab = next(it), next(it)
                 g.Vmap(g.MaskCombinator(st["fn"]), in_axes=(0, None, 0))(flags, m, tab) @ name
-            elif k == "scan":
+            elif k in ("scan", "vscan"):
                 cT, _ = g.Scan(st["fn"], st["T"])(m, next(it)) @ name
                 prev = cT
             elif k == "mscan":
@@ -298,6 +310,9 @@ def addresses(spec):
             if st.get("bern"):
                 out.append(((nm, "b"), (nm, "b"), (st["T"],), "b", False, st))
             out.append(((nm, "z"), (nm, "z"), (st["T"],), "f", False, st))
+        elif k == "vscan":
+            out.append(((nm, "z"), (nm, "z"), (st["T"],), "f", False, st))
+            out.append(((nm, "y"), (nm, "y"), (st["T"], st["m"]), "f", False, st))
         elif k == "mscan":
             out.append(((nm, "z"), (nm, "z"), (st["T"],), "f", True, st))
         elif k == "mask":
@@ -379,6 +394,8 @@ def _same_choices(spec, tr, otr, B, what):
     for path, okey, shape, kind, masked, st in addresses(spec):
         v, f = _choice(ch, path)
         ov, of = _ochoice(och, okey)
+        if st["kind"] == "vscan" and len(shape) == 2 and ov.ndim >= 2 and ov.shape[-2:] == (shape[1], shape[0]):
+            ov = np.moveaxis(ov, -1, -2)          # (the oracle's scans stack what they sample along a LAST axis: [.., m, T])
         assert np.array_equal(*np.broadcast_arrays(v, ov)), (what, path)      # (a launch-uniform constraint stays a scalar)
         assert (f is None) == (of is None), (what, path, "masked on one side only")
         if f is not None:
@@ -448,7 +465,7 @@ def _run_one(seed, B=7, allow_nested=True, verbose=False):
     assert np.array_equal(_np(new.get_score()), onew.get_score()), (seed, "update score")
     _same_choices(spec, new, onew, B, (seed, "update"))
     for (path, okey, shape, kind, masked, st), _v in cons2:       # the discard: the old values of what was constrained
-        if st["kind"] in ("scan", "scan_of_plates", "plate_of_scans", "mscan") or isinstance(_v, tuple):
+        if st["kind"] in ("scan", "scan_of_plates", "plate_of_scans", "mscan", "vscan") or isinstance(_v, tuple):
             continue                                   # (the oracle restates no discard for scans; a subset's is masked)
         d, _f = _choice(bwd, path)
         od, _of = _ochoice(odis, okey)

@@ -322,6 +322,7 @@ static std::string jit_source(const gmx_program* p, bool* gathers_prefetched = n
     pre_of[pc] = k;
     if (b & GMX_F_GATHER) { any_gather = true; if (pc < first_gather_pc) first_gather_pc = pc; }
   }
+  if (const char* e_ = getenv("GENMI_JIT_NOPRE")) { if (e_[0] == '1' && !p->fuse_rs && !p->fuse_sh) fits = false; }   // (diagnosis)
   if (!fits) { pres.clear(); pre_of.assign(p->n_instr, -1); any_gather = false; }
   if (gathers_prefetched) {          // every gathered load goes through the prologue's ancestors (GMX_JIT_PRE_ANC)
     *gathers_prefetched = any_gather;
@@ -458,7 +459,15 @@ static std::string jit_cache_path(const std::string& src) {
   return dir + buf;
 }
 
+// GENMI_JIT_OPT = -O1 / -O2 (diagnosis: a result that changes with the level names a miscompile) — never
+// cached: the cache holds -O3 builds only
+static const char* jit_opt_level() {
+  const char* e = getenv("GENMI_JIT_OPT");
+  return (e && (!strcmp(e, "-O1") || !strcmp(e, "-O2") || !strcmp(e, "-O0"))) ? e : "-O3";
+}
+
 static bool jit_cache_read(const std::string& path, std::vector<char>& code) {
+  if (strcmp(jit_opt_level(), "-O3") != 0) return false;
   if (path.empty()) return false;
   FILE* f = fopen(path.c_str(), "rb");
   if (!f) return false;
@@ -485,7 +494,7 @@ static bool jit_under_profiler() {
 }
 
 static void jit_cache_write(const std::string& path, const std::vector<char>& code) {
-  if (path.empty() || jit_under_profiler()) return;
+  if (path.empty() || jit_under_profiler() || strcmp(jit_opt_level(), "-O3") != 0) return;
   mkdirs(path.substr(0, path.rfind('/')));
   char tmp[32];
   snprintf(tmp, sizeof(tmp), ".tmp%ld", (long)getpid());
@@ -504,7 +513,7 @@ static int jit_compile(const std::string& src, std::vector<char>& code) {
   for (int k = 0; k < GMX_EMBED_COUNT; ++k) { hdr_src[k] = gmx_embed_src[k]; hdr_name[k] = gmx_embed_name[k]; }
   hiprtcResult rc = hiprtcCreateProgram(&prog, src.c_str(), "gmx_jit_program.hip", GMX_EMBED_COUNT, hdr_src, hdr_name);
   if (rc != HIPRTC_SUCCESS) return gmx_fail("hiprtcCreateProgram: %s", hiprtcGetErrorString(rc));
-  const char* opts[4] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"};
+  const char* opts[4] = {"--offload-arch=gfx950", jit_opt_level(), "-std=c++17", "-ffp-contract=off"};
   rc = hiprtcCompileProgram(prog, 4, opts);
   if (rc != HIPRTC_SUCCESS) {
     size_t ls = 0;

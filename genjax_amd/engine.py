@@ -580,7 +580,9 @@ class Tracing:
             from .numpy import RuntimeTable, runtime_table_slot
             slot = runtime_table_slot(g)
             self.tab_plan.append((slot, j))
-            return Sym(RuntimeTable.make(g, slot, spec[1], spec[2] if len(spec[2]) > 1 else spec[2][0]), ("leaf", j))
+            tab = RuntimeTable.make(g, slot, spec[1], spec[2] if len(spec[2]) > 1 else spec[2][0])
+            tab._leaf, tab._picks = j, ()
+            return Sym(tab, ("leaf", j))
         flags = {"bcast": F_BCAST, "dvec": F_BCAST, "part": 0, "gather": F_GATHER}[kind]
         dt = spec[1]
         event = () if kind == "bcast" else spec[2]
@@ -656,19 +658,9 @@ class Tracing:
         output ([n, T0, T1]: a plate of scans).  Returns the output's origin."""
         from . import tracer as Tm
         dims = tuple(int(c) for c in self.graph.loop_counts) or (int(T),)
-        m = Tm._long_vector(value)
-        if m and self.graph.loop_counts and len(self.graph.loop_counts) < 3:
-            # a LONG vector that can be read at a run-time index (a row of a launch-uniform table given as this element's
-            # constraint, a recipe over such rows): copied by a counted loop of its own — one read and one store per
-            # iteration — instead of m values alive at once inside the enclosing loop
-            g = self.graph
-            g.loop_begin(m)
-            e = Tm.lift(Tm._elem(value, Expr(g.add("LDT", dtype="i32"))))
-            slot = g.store(e.node, step=True)
-            g.loop_end()
-            o = ("out", len(self.outputs))
-            self.outputs.append((e.dtype, dims + (int(m),), ("step", slot, len(dims) + 1)))
-            return o
+        # (a long ROW of a launch-uniform table never comes here: it is recorded by its origin — numpy.RuntimeTable.passthrough.
+        #  A copy loop of its own inside the enclosing loop was tried and withdrawn: the two specialised kernels hiprtc got
+        #  wrong on the GPU box — profiles/r05z_jit_miscompile.txt and a scan's lost score sum — both held that loop.)
         if isinstance(value, np.ndarray) and value.dtype == object:
             # a vector-valued site: one [T, n] plane per element, exposed as [n, T, *event]
             es = [Tm.lift(v) for v in value.reshape(-1)]
@@ -1540,7 +1532,11 @@ def resolve(origin, outs, leaves):
         return leaves[origin[1]]
     if kind == "leafrow":      # statically picked leading rows of a per-particle leaf ([*batch, A, .., T] -> [*batch, T])
         v = leaves[origin[1]]
-        nb = v.dim() - (len(origin[2]) + 1) if hasattr(v, "dim") else np.ndim(v) - (len(origin[2]) + 1)
+        if isinstance(v, Broadcast):
+            v = v.plain
+        if not isinstance(v, torch.Tensor):
+            v = np.asarray(v)
+        nb = (v.dim() if isinstance(v, torch.Tensor) else v.ndim) - (len(origin[2]) + 1)
         return v[(slice(None),) * nb + tuple(origin[2])]
     if kind == "const":
         return origin[1]
@@ -1555,6 +1551,9 @@ def resolve(origin, outs, leaves):
         return Mask(resolve(origin[1], outs, leaves), resolve(origin[2], outs, leaves))
     if kind == "stack":        # an unrolled plate of loop outputs: elements [*batch, T, *event] -> [*batch, n, T, *event]
         parts = [resolve(o, outs, leaves) for o in origin[1]]
+        if not isinstance(parts[0], torch.Tensor):           # rows of a launch-uniform HOST table, given as they were
+            parts = [np.asarray(p_) for p_ in parts]
+            return np.stack(parts, axis=max(0, parts[0].ndim - int(origin[2])))
         return torch.stack(parts, dim=parts[0].dim() - int(origin[2]))
     if kind == "prepend":      # iterate / accumulate over a counted loop: [init, ys[0], ..., ys[T-1]] along the step axis
         init, ys = resolve(origin[1], outs, leaves), resolve(origin[2], outs, leaves)

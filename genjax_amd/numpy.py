@@ -131,6 +131,21 @@ class RuntimeTable(np.ndarray):
         self._dt = getattr(obj, "_dt", None)
         self._base = getattr(obj, "_base", 0)        # entry of the flattened table this (row-major) view starts at
         self._dyn = getattr(obj, "_dyn", None)       # + a run-time offset (a row picked by a loop's iteration number)
+        self._leaf = getattr(obj, "_leaf", None)     # the launch leaf this table is (Tracing.sym_leaf)
+        self._picks = None                           # the rows picked so far (ints / "loop"); None: not a tracked row
+
+    def passthrough(self):
+        """a LONG row of a launch-uniform table that is a launch leaf — the values of a plate's / scan's vector site given
+        as one [n, m] table — as the stacked output it already is: recorded by its origin, never copied per particle
+        (the values stay launch-uniform in the trace, as a top-level site's do)"""
+        from .engine import StepOutput
+        if self._leaf is None or self._picks is None or self.ndim != 1:
+            return None
+        static = tuple(int(r) for r in self._picks if r != "loop")           # (this module's `any` / `sum` are jnp's)
+        if "loop" in self._picks[:len(static)]:
+            return None                                  # (a static row below a looped one: not a plain slice)
+        origin = ("leafrow", self._leaf, static) if static else ("leaf", self._leaf)
+        return StepOutput(origin, int(self.shape[0]), 1 + len(self._picks) - len(static))
 
     def __getitem__(self, idx):
         base = int(self._base or 0)
@@ -155,12 +170,16 @@ class RuntimeTable(np.ndarray):
             if E > 16:             # a LONG row: it stays a table, so that a loop inside can pick its elements at run time
                 out = row.view(RuntimeTable)
                 out._slot, out._dt, out._base, out._dyn = self._slot, self._dt, base, rbase
+                out._leaf = self._leaf
+                out._picks = ((self._picks or ()) + ("loop",)) if (idx.node.op == "LDT" and self._leaf is not None) else None
                 return out
             return row
         r = np.ndarray.__getitem__(self, idx)
         if isinstance(r, RuntimeTable) and self.ndim >= 2 and isinstance(idx, (int, np.integer)):
             r._base = base + int(idx) * int(np.prod(self.shape[1:]))   # a static row stays a table: its elements can
-            return r                                                   # still be picked at run time (a plate of scans)
+            r._leaf = self._leaf                                       # still be picked at run time (a plate of scans)
+            r._picks = ((self._picks or ()) + (int(idx) % self.shape[0],)) if (self._leaf is not None and dyn is None) else None
+            return r
         if isinstance(r, RuntimeTable) and self.ndim >= 2 and not isinstance(idx, slice):
             return np.asarray(r, dtype=object)                   # any other static pick: plain expressions
         if isinstance(r, RuntimeTable) and isinstance(idx, slice) and self.ndim == 1:

@@ -1065,6 +1065,14 @@ def _select_tree(c, new, old):
         return type(new)(_select_tree(c, a, b) for a, b in zip(new, old))
     if new is None:
         return None
+    from .engine import StepOutput
+    if isinstance(new, StepOutput) or isinstance(old, StepOutput):
+        # values that live in memory (a long vector site's, recorded by their origin): the same on both sides of the
+        # select when the edit did not touch them — which is all a select between stored outputs can mean
+        if isinstance(new, StepOutput) and isinstance(old, StepOutput) and new.origin == old.origin:
+            return new
+        raise NotImplementedError("an edit at one index that replaces the values of a long vector-valued site: "
+                                  "constrain the whole plate / scan axis instead (Update with a [n, m] value)")
     return T.where(c, new, old)
 
 

@@ -1128,6 +1128,11 @@ def _gate_site(ctx, gate, out, prev, dist, args):
     pv, ps = prev["value"].value, prev["score"].value
     nv = rec.value.value if isinstance(rec.value, Sym) else rec.value
     ns = rec.score.value if isinstance(rec.score, Sym) else rec.score
+    from .engine import StepOutput
+    if isinstance(nv, StepOutput) and not nv.vector_site and hasattr(pv, "passthrough"):
+        # a long vector-valued site that KEPT its value (recorded by its origin: _vector_site_loop re-scored the old
+        # value under the new arguments in its own loop): that IS the carried-over form — nothing to select between
+        return rec, ret, w, ns
     if ctx.args_changed(dist.canon(args)):
         s_co = dist.sym_logpdf(pv, dist.canon(args))
         w_co = s_co - ps

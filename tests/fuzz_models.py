@@ -471,20 +471,21 @@ def _run_one(seed, B=7, allow_nested=True, verbose=False):
         od, _of = _ochoice(odis, okey)
         assert np.array_equal(*np.broadcast_arrays(d, od)), (seed, "discard", path)
     # IndexRequest on one plate / scan of the model (vmap.py:277-332, scan.py:325-416) through a StaticRequest
-    targets = [st for st in spec if st["kind"] in ("plate", "scan")]
+    targets = [st for st in spec if st["kind"] in ("plate", "scan", "vplate", "vscan")]
     if targets:
         from genjax_amd import ChoiceMapBuilder as C, IndexRequest, StaticRequest, Update
         st = targets[int(rng.integers(len(targets)))]
-        size = st["n"] if st["kind"] == "plate" else st["T"]
+        platelike = st["kind"] in ("plate", "vplate")
+        size = st["n"] if platelike else st["T"]
         idx = int(rng.integers(size))
-        site = "v" if st["kind"] == "plate" else "z"
+        site = "v" if platelike else "z"
         val = np.float32(rng.normal())
         o_elem = next(p_ for p_ in _parts_of(omodel) if p_["name"] == st["name"])["fn"]
 
         class _OIdx:
             def edit(self, kk, subtrace, gen_fn, args_):
                 sub = O.C.d({(site,): val})
-                if st["kind"] == "plate":
+                if platelike:
                     at = (args_[0], np.asarray(args_[1])[..., idx])
                     return O.vmap_edit_index(gen_fn, kk, subtrace, idx, lambda k_, sl, a_: o_elem.update(k_, sl, sub, a_)[:2], at)
                 return O.scan_edit_index(gen_fn, kk, subtrace, args_, idx, lambda k_, sl, a_: o_elem.update(k_, sl, sub, a_)[:2])

@@ -1073,11 +1073,10 @@ def _vector_site_loop(ctx, mode, dist, key, args, cval, prev, req):
         return so if so is not None else v
     if new_value:
         v = StepOutput(origin, n, len(tr.outputs[origin[1]][1]), vector_site=True)
-        ret = v
-        if True:
-            # the MODEL gets the stored values as reads of that very output (engine.StepAlias): a later vector site
-            # whose parameters they are loops over them, `theta[3]` is one load — an 8-schools model of 5 000 schools
-            ret = tr.alias_step_input(origin, dist.value_dtype, n)
+        # the MODEL gets the stored values as reads of that very output (engine.StepAlias; inside an enclosing loop a
+        # recipe the next vector site's loop reads, engine.StepOutputAlias): a later vector site whose parameters they are
+        # loops over them, `theta[3]` is one load — an 8-schools model of 5 000 schools
+        ret = tr.alias_step_input(origin, dist.value_dtype, n)
         return _SiteRec(dist, v, score), ret, None, score   # (generate, unconstrained: w = 0, distribution.py:124-127)
     if mode == "generate":
         return _SiteRec(dist, given(cval), score), cv, score, score          # w = score = logpdf (:144-147)

@@ -64,4 +64,3 @@ print("   scan score", np.array_equal(npy(materialize(sub.get_score())), np.asar
       npy(materialize(sub.get_score()))[:3], np.asarray(otri.subtraces["s"].get_score())[:3])
 for ad, st in sub.inner.subtraces.items():
     print("   per-step", ad, np.array_equal(npy(materialize(st.get_score())), np.asarray(otri.subtraces["s"].inner.subtraces[ad].score)))
-from genjax_amd import static

@@ -288,11 +288,16 @@ def _so(tr, origin, T):
 
 
 def _has_step_rows(tree):
-    """does a previous-trace tree hold [n, A, T] step leaves (engine.StepInput2: the values of loops INSIDE a plate)?"""
+    """does a previous-trace tree hold [n, A, T] step leaves (engine.StepInput2: the values of loops INSIDE a plate) — or,
+    inside a counted loop, launch-uniform tables with a long last axis (the same values given as one [.., n, m] table:
+    a row picked statically below the looped axis is not a slice of the leaf)?"""
     from .engine import StepInput2, Sym
+    from .numpy import RuntimeTable
     if isinstance(tree, Sym):
         tree = tree.value
     if isinstance(tree, StepInput2):
+        return True
+    if isinstance(tree, RuntimeTable) and tree.ndim >= 2 and tree.shape[-1] > VMAP_UNROLL_MAX and getattr(tree, "_dyn", None) is not None:
         return True
     if isinstance(tree, dict):
         return any(_has_step_rows(v) for v in tree.values())

@@ -863,8 +863,9 @@ class StepInput2:
         if self._leaf is None or not self._lazy_row:
             return None
         static = tuple(int(r) for r in self._rows if r != "loop")
-        origin = ("leafrow", self._leaf, static) if static else ("leaf", self._leaf)
-        return StepOutput(origin, int(self.shape[0]), 1 + sum(1 for r in self._rows if r == "loop"))
+        n_loop = len(self._rows) - len(static)
+        origin = ("leafrow", self._leaf, static, n_loop) if static else ("leaf", self._leaf)
+        return StepOutput(origin, int(self.shape[0]), 1 + n_loop)
 
     def _lazy(name):          # noqa: N805  (the LazyVec operators, for a long row)
         def op(self, *o):
@@ -1536,7 +1537,8 @@ def resolve(origin, outs, leaves):
             v = v.plain
         if not isinstance(v, torch.Tensor):
             v = np.asarray(v)
-        nb = (v.dim() if isinstance(v, torch.Tensor) else v.ndim) - (len(origin[2]) + 1)
+        # [*batch, static rows .., looped rows .., T]: the batch axes are what is left in front
+        nb = (v.dim() if isinstance(v, torch.Tensor) else v.ndim) - (len(origin[2]) + int(origin[3]) + 1)
         return v[(slice(None),) * nb + tuple(origin[2])]
     if kind == "const":
         return origin[1]

@@ -143,9 +143,13 @@ class RuntimeTable(np.ndarray):
             return None
         static = tuple(int(r) for r in self._picks if r != "loop")           # (this module's `any` / `sum` are jnp's)
         if "loop" in self._picks[:len(static)]:
-            return None                                  # (a static row below a looped one: not a plain slice)
-        origin = ("leafrow", self._leaf, static) if static else ("leaf", self._leaf)
-        return StepOutput(origin, int(self.shape[0]), 1 + len(self._picks) - len(static))
+            # a row picked statically BELOW a looped axis (an unrolled plate inside a loop): its elements over the outer
+            # iterations are a strided slice of the leaf — the enclosing plate runs as a loop instead (Vmap.trace_call
+            # tries the unrolled form first and takes the loop form on this)
+            raise NotImplementedError("a row of a launch-uniform table picked statically below a looped axis")
+        n_loop = len(self._picks) - len(static)
+        origin = ("leafrow", self._leaf, static, n_loop) if static else ("leaf", self._leaf)
+        return StepOutput(origin, int(self.shape[0]), 1 + n_loop)
 
     def __getitem__(self, idx):
         base = int(self._base or 0)
@@ -178,7 +182,7 @@ class RuntimeTable(np.ndarray):
         if isinstance(r, RuntimeTable) and self.ndim >= 2 and isinstance(idx, (int, np.integer)):
             r._base = base + int(idx) * int(np.prod(self.shape[1:]))   # a static row stays a table: its elements can
             r._leaf = self._leaf                                       # still be picked at run time (a plate of scans)
-            r._picks = ((self._picks or ()) + (int(idx) % self.shape[0],)) if (self._leaf is not None and dyn is None) else None
+            r._picks = ((self._picks or ()) + (int(idx) % self.shape[0],)) if (self._leaf is not None and self._picks is not None) else None
             return r
         if isinstance(r, RuntimeTable) and self.ndim >= 2 and not isinstance(idx, slice):
             return np.asarray(r, dtype=object)                   # any other static pick: plain expressions

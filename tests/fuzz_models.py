@@ -19,7 +19,7 @@ SMALL, LARGE = 3, 20          # unrolled / counted-loop sizes (the product switc
 # spec
 # ---------------------------------------------------------------------------
 def random_spec(rng, n_stmts=None, allow_nested=True):
-    kinds = ["leaf", "leaf", "call", "plate", "scan", "mask", "mplate", "mscan", "vec", "hvec", "vplate", "vscan"] + (["plate_of_scans", "scan_of_plates"] if allow_nested else [])
+    kinds = ["leaf", "leaf", "call", "plate", "scan", "mask", "mplate", "mscan", "vec", "hvec", "vplate", "vscan"] + (["plate_of_scans", "scan_of_plates", "vplate2"] if allow_nested else [])
     stmts = []
     if n_stmts is None:
         # (one model in eight is LONG: more sites than one launch stores — a chain of launches, program.split_graph)
@@ -49,6 +49,10 @@ def random_spec(rng, n_stmts=None, allow_nested=True):
             st["n"] = [24, 40, 130][int(rng.integers(3))]
         if kind == "vscan":             # a scan (unrolled or a loop) whose step emits a long vector (an HMM with vector observations)
             st["m"] = [24, 40][int(rng.integers(2))]
+        if kind == "vplate2":           # a plate of plates of elements with a long vector site: three levels with the site's loop
+            st["n"] = [SMALL, LARGE][int(rng.integers(2))]
+            st["n2"] = [SMALL + 1, LARGE][int(rng.integers(2))]
+            st["m"] = 24
         if kind == "vplate":            # a plate (unrolled or a loop) of elements that hold such a pair of long vector sites
             st["n"] = [SMALL, LARGE][int(rng.integers(2))]
             st["m"] = [24, 40][int(rng.integers(2))]
@@ -64,6 +68,8 @@ def spec_args(spec, rng, B):
         k = st["kind"]
         if k in ("plate", "plate_of_scans", "vec", "hvec", "vplate"):
             extra.append(rng.normal(size=st["n"]).astype(np.float32))
+        elif k == "vplate2":
+            extra.append(rng.normal(size=(st["n"], st["n2"])).astype(np.float32))
         elif k in ("scan", "scan_of_plates", "vscan"):
             extra.append(rng.normal(size=st["T"]).astype(np.float32))
         elif k == "mscan":
@@ -121,6 +127,25 @@ def build(g, spec, lit):
             return z, z
         return step
 
+    def make_vec_row(st):
+        @g.gen
+        def elem(shared, x):
+            if g is O:
+                s_ = np.asarray(shared, np.float32)
+                while s_.ndim < np.ndim(x):
+                    s_ = s_[..., None]
+                shared = s_
+            v = g.normal(shared + x, lit(st["sd"])) @ "v"
+            tab = _ramp(g, st["m"], lit)
+            mean = (v * tab) if g is not O else (np.asarray(v, np.float32)[..., None] * tab).astype(np.float32)
+            g.normal(mean, lit(1.5)) @ "z"
+            return v
+
+        @g.gen
+        def row(shared, xs):
+            return g.Vmap(elem, in_axes=(None, 0))(shared, xs) @ "r"
+        return row
+
     def make_vstep(st):
         @g.gen
         def step(c, x):
@@ -177,7 +202,7 @@ def build(g, spec, lit):
     for st in spec:
         k = st["kind"]
         parts.append(dict(st, fn={"plate": make_elem, "mplate": make_elem, "scan": make_step, "mask": make_inner, "call": make_call, "mscan": make_mstep,
-                                  "plate_of_scans": make_scan_elem, "scan_of_plates": make_plate_step, "vplate": make_vec_elem, "vscan": make_vstep}.get(k, lambda s: None)(st)))
+                                  "plate_of_scans": make_scan_elem, "scan_of_plates": make_plate_step, "vplate": make_vec_elem, "vscan": make_vstep, "vplate2": make_vec_row}.get(k, lambda s: None)(st)))
 
     @g.gen
     def model(a, *extra):
@@ -218,7 +243,7 @@ def build(g, spec, lit):
                 loc = (z * lit(st["c2"]) + xs) if g is not O else (np.asarray(z, np.float32) * lit(st["c2"]) + xs).astype(np.float32)
                 g.normal(loc, lit(st["sd"])) @ (name + "y")              # the model computes with the latent vector's values
                 prev = m
-            elif k == "vplate":
+            elif k in ("vplate", "vplate2"):
                 g.Vmap(st["fn"], in_axes=(None, 0))(m, next(it)) @ name
                 prev = m
             elif k == "plate":
@@ -290,6 +315,9 @@ def addresses(spec):
             out.append(((nm,), (nm,), (), kind_, False, st))
         elif k == "vec":
             out.append(((nm,), (nm,), (st["n"],), "f", False, st))
+        elif k == "vplate2":
+            out.append(((nm, "r", "v"), (nm, "r", "v"), (st["n"], st["n2"]), "f", False, st))
+            out.append(((nm, "r", "z"), (nm, "r", "z"), (st["n"], st["n2"], st["m"]), "f", False, st))
         elif k == "vplate":
             out.append(((nm, "v"), (nm, "v"), (st["n"],), "f", False, st))
             out.append(((nm, "z"), (nm, "z"), (st["n"], st["m"]), "f", False, st))

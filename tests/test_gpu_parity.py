@@ -1873,16 +1873,17 @@ def test_peer_route_of_twelve_leaves_between_two_processes_on_the_device(gpu, tm
 
 
 def test_random_models_match_the_oracle_on_device(gpu):
-    """tests/fuzz_models.py on the HIP path: 12 random models on the interpreter (7 particles; two of them long — 13 and
-    22 statements, chains of launches — the others 2 to 4 statements; plates and scans of long vector sites among them)
+    """tests/fuzz_models.py on the HIP path: 12 random models on the interpreter (7 particles; two of them long — 12 and
+    13 statements, chains of launches — the others 2 to 4 statements; plates, plates of plates and scans of long vector
+    sites among them)
     and 2 through the hiprtc-specialised programs (2^18 particles: engine.JIT_MIN_PARTICLES; long vector sites, a latent
     vector feeding a vector site, beside scans), every GFI method bit for bit against the oracle.  (The seeds are
     named: a draw of sixteen in a row held five long models, and a plate of long vector sites at 2^18 particles is two
     minutes of numpy oracle — tools/experiments/fuzz_on_device.py runs those, profiles/r05z_fuzz_on_device.json.)"""
     from tests import fuzz_models as F
     ran = 0
-    small = (1000, 1001, 1003, 1004, 1006, 1007, 1008, 1012, 1017, 1019, 1020, 1021)
-    for seed, B in [(s, 7) for s in small] + [(s, 1 << 18) for s in (2004, 2010)]:
+    small = (1000, 1001, 1003, 1004, 1006, 1012, 1016, 1019, 1020, 1023, 1027, 1029)
+    for seed, B in [(s, 7) for s in small] + [(s, 1 << 18) for s in (2000, 2006)]:
         try:
             F.run_one(seed, B=B)
             ran += 1

@@ -1,11 +1,15 @@
 """Random `@gen` models against the oracle (test infrastructure).
 
 One SPEC (a list of statements drawn from a small grammar: leaf sites, plates, scans, masked calls, masked plates,
-plates of scans, scans of plates — unrolled and loop sizes mixed) is built twice, with the product (`genjax_amd`) and with the
+plates of scans, scans of plates — unrolled and loop sizes mixed; long vector-valued sites (`vec`), a latent vector whose
+values are the next vector site's parameters (`hvec`: 8-schools' shape), plates (`vplate`), plates of plates (`vplate2`)
+and scans (`vscan`) of elements that hold such sites; one model in eight is long: 12 to 25 statements, a chain of
+launches) is built twice, with the product (`genjax_amd`) and with the
 oracle (`oracle/genjax_oracle.py`), and every GFI method is compared bit for bit under a batch of keys:
 simulate (score, return value, every choice), importance under a random subset of constraints, assess of the
 resulting choices, and `update` with a random subset of new constraints and randomly CHANGED arguments (the
-per-particle argument, a table, a vector of flags).  The reference paths restated by the oracle:
+per-particle argument, a table, a vector of flags), an `IndexRequest` into one plate / scan, `Regenerate` and MH moves
+where the reference's combinators answer them.  The reference paths restated by the oracle:
 static.py:255-466 (handlers), vmap.py:180-275, scan.py:200-503, mask.py:96-262."""
 import numpy as np
 import torch

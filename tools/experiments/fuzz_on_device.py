@@ -8,6 +8,12 @@ from genjax_amd import _lib
 from tests import fuzz_models as F
 
 _lib.get()                                   # the HIP library, or a loud failure
+if os.environ.get("FUZZ_FORCE_JIT") == "1":
+    # EVERY program through hiprtc, at the interpreter seeds' small batch: what a specialised kernel computes against the
+    # oracle for many programs per minute (at 2^18 particles the numpy oracle is the clock: a plate of plates of long
+    # vector sites is minutes per model)
+    from genjax_amd import engine
+    engine.JIT_MIN_PARTICLES = 1
 n_small = int(sys.argv[1]) if len(sys.argv) > 1 else 400
 n_jit = int(sys.argv[2]) if len(sys.argv) > 2 else 24
 off = int(sys.argv[4]) if len(sys.argv) > 4 else 0           # fresh seeds: every range below shifted by it

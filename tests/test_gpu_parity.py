@@ -1873,8 +1873,8 @@ def test_peer_route_of_twelve_leaves_between_two_processes_on_the_device(gpu, tm
 
 
 def test_random_models_match_the_oracle_on_device(gpu):
-    """tests/fuzz_models.py on the HIP path: 11 random models on the interpreter (7 particles; one of them long — 12
-    statements, a chain of launches — the others 2 to 4 statements; plates, plates of plates and scans of long vector
+    """tests/fuzz_models.py on the HIP path: 10 random models on the interpreter (7 particles, 2 to 4 statements each — long
+    models, chains of launches, have a test of their own and run in tools/experiments/fuzz_on_device.py; plates, plates of plates and scans of long vector
     sites among them)
     and 2 through the hiprtc-specialised programs (2^18 particles: engine.JIT_MIN_PARTICLES; long vector sites, a latent
     vector feeding a vector site, beside scans), every GFI method bit for bit against the oracle.  (The seeds are
@@ -1882,15 +1882,15 @@ def test_random_models_match_the_oracle_on_device(gpu):
     minutes of numpy oracle — tools/experiments/fuzz_on_device.py runs those, profiles/r05z_fuzz_on_device.json.)"""
     from tests import fuzz_models as F
     ran = 0
-    small = (1000, 1001, 1003, 1006, 1012, 1016, 1019, 1020, 1023, 1027, 1029)
+    small = (1000, 1001, 1003, 1006, 1012, 1016, 1019, 1020, 1023, 1029)
     for seed, B in [(s, 7) for s in small] + [(s, 1 << 18) for s in (2000, 2006)]:
         try:
             F.run_one(seed, B=B)
             ran += 1
         except F.OverTheLimits:
             pass
-    assert ran == 13, ran
-    for seed in range(3000, 3006):
+    assert ran == 12, ran
+    for seed in range(3000, 3004):
         F.run_smc_one(seed)
     for seed in range(4000, 4003):
         F.run_big_one(seed)

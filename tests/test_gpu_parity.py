@@ -1056,12 +1056,12 @@ def test_plate_on_the_launch_axis_and_config5_through_the_gfi(gpu):
 
 def test_large_plates_as_a_counted_loop(gpu):
     """`Vmap` plates of any size (ref vmap.py:180-218) as OP_LOOP with split(key, n)[j] keys —
-    a 4096-element plate x 1e4 particles (interpreter) and a 40-element plate x 2.7e5 particles (specialised kernel),
+    a 4096-element plate x 1e3 particles (interpreter) and a 40-element plate x 2.7e5 particles (specialised kernel),
     simulate / importance / assess / Update / IndexRequest, bit-exact vs the oracle."""
     parity.check_plates_long(n=300, P=40)
     parity.check_plates_long(n=270_000, P=24, seed=3)
-    parity.check_plates_long(n=3000, P=4096, seed=5, light=True)        # simulate / importance / assess / single-element constraints
-    parity.check_plates_long(n=300, P=4096, seed=6)
+    parity.check_plates_long(n=1000, P=4096, seed=5, light=True)        # simulate / importance / assess / single-element constraints
+    parity.check_plates_long(n=100, P=4096, seed=6)
 
 
 def test_index_request_on_a_long_plate_is_o1(gpu):
@@ -1072,7 +1072,7 @@ def test_index_request_on_a_long_plate_is_o1(gpu):
     import time
     import genjax_amd as G
     from genjax_amd import Diff, IndexRequest, Regenerate, SelectionBuilder as S, static
-    parity.check_index_request_o1(n=300, P=4096, seed=5, edits=7)
+    parity.check_index_request_o1(n=100, P=4096, seed=5, edits=7)
     parity.check_index_request_o1(n=270_000, P=24, seed=6, edits=6, nested=False)
     parity.check_index_request_o1(n=300, P=40, seed=7, edits=40, nested=False)        # (longer than PATCH_DEPTH_MAX: folded)
     n, P = 100_000, 4096

@@ -1113,13 +1113,16 @@ def check_mixture_gibbs_through_the_plate(n=5000, K=64, seed=11, timing=False):
         return None
     sync = (lambda: torch.cuda.synchronize()) if dev.type == "cuda" else (lambda: None)
 
-    def timed(fn, reps=10):
+    def timed(fn, reps=10, rounds=3):
         fn(); sync()
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            fn()
-        sync()
-        return (time.perf_counter() - t0) / reps
+        best = float("inf")
+        for _ in range(rounds):          # (the best of three rounds: one round was seen at twice its usual time on a shared box)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            sync()
+            best = min(best, (time.perf_counter() - t0) / reps)
+        return best
     chm = C["obs"].set(torch.from_numpy(x).to(dev))
     t_plate = timed(lambda: gibbs.enumerative_gibbs(G.key(seed + 1), tr, "idx", K))
     t_bare = timed(lambda: gibbs.gibbs_categorical(G.key(seed + 1), gd, args, chm, "idx", K))

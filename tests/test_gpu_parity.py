@@ -1845,6 +1845,14 @@ def test_peer_mapped_exchange_between_two_processes_on_the_device(gpu, tmp_path,
     assert np.array_equal(x, ref["x"][ref["anc"]])
 
 
+def test_sweep_with_vector_observations_on_device(gpu):
+    """BootstrapSweep over an HMM with 24 observations per step (a long vector-valued site in the step program: one
+    counted loop per particle), interpreter size and 2^18 particles (specialised, one launch per step): log-ML and every
+    step's integer total against the oracle's sweep"""
+    parity.check_sweep_with_vector_observations(n=2048, T=4, m=24)
+    parity.check_sweep_with_vector_observations(n=1 << 18, T=5, m=24, seed=9)
+
+
 def test_sweep_verdict_on_device(gpu, monkeypatch):
     """gmx_sweep_verdict + finish() on the HIP library, over the fused peer exchange (status words exist)"""
     monkeypatch.setenv("GENMI_COMM", "peer")

@@ -1540,3 +1540,11 @@ def test_latent_vector_feeding_the_next_vector_site(hostsim, J):
     launches past one launch's slots) — every GFI method against the oracle, bit for bit"""
     from tests import parity
     parity.check_hierarchical_vector_latent(J=J)
+
+
+@pytest.mark.parametrize("m", [4, 24])
+def test_sweep_with_vector_observations(hostsim, m):
+    """an HMM with m observations per step through BootstrapSweep: equals the oracle's sweep (m = 24: a counted loop in the
+    step program)"""
+    from tests import parity
+    parity.check_sweep_with_vector_observations(m=m)

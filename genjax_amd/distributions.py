@@ -323,6 +323,8 @@ class _Categorical(Distribution):
                                       "unrolled (<= 64); ONE trace runs them on the launch axis (sitewise.py)")
         return args + (("sample_shape", n),)
 
+    ROWS_MAX = 64      # rows of logits at one site under a batch of keys: unrolled
+
     def _logits(self, args):
         l = args[0]
         l = l if isinstance(l, np.ndarray) else np.asarray(l, dtype=object)
@@ -330,9 +332,33 @@ class _Categorical(Distribution):
             raise NotImplementedError("categorical: logits must be a vector per particle")
         return [T.as_float(x) for x in l]
 
+    def _rows(self, args):
+        """logits [J, K] per particle: J draws at ONE site, row j / category k on gumbel counter j * K + k (what
+        `jax.random.categorical(key, logits)` of that shape does).  None for one row."""
+        l = args[0]
+        l = l if isinstance(l, np.ndarray) else np.asarray(l, dtype=object)
+        if l.ndim != 2:
+            return None
+        if l.shape[0] > self.ROWS_MAX:
+            raise NotImplementedError(f"categorical: {l.shape[0]} rows of logits at one site under a batch of keys are "
+                                      f"unrolled (<= {self.ROWS_MAX}); write the rows as a plate (`categorical.vmap()`), "
+                                      "or run ONE trace (sitewise.py)")
+        return [[T.as_float(x) for x in row] for row in l]
+
     def sym_sample(self, key: Expr, args: tuple):
         g = current_graph()
         n = args[1][1] if len(args) == 2 and isinstance(args[1], tuple) and args[1][:1] == ("sample_shape",) else None
+        rows = self._rows(args[:1]) if n is None else None
+        if rows is not None:
+            if getattr(g, "elem_from_index", False):
+                raise NotImplementedError("categorical: rows of logits under a site whose elements ride the launch axis")
+            arr = np.empty(len(rows), dtype=object)
+            for j, ls in enumerate(rows):
+                state = None
+                for k, lk in enumerate(ls):
+                    state = g.add("S_CATSTEP", (state, key.node, lk.node, g.const_i32(j * len(ls) + k)), imm=k, dtype="cat")
+                arr[j] = Expr(g.add("CATIDX", (state,), dtype="i32"))
+            return arr
         ls = self._logits(args[:1])
         out = []
         row = None
@@ -355,6 +381,12 @@ class _Categorical(Distribution):
 
     def sym_logpdf(self, v, args: tuple) -> Expr:
         from . import numpy as jnp
+        rows = self._rows(args[:1]) if len(args) == 1 else None
+        if rows is not None:                        # one value per row of logits: the rows' log-probabilities, summed
+            vs = np.broadcast_to(np.asarray(v, dtype=object), (len(rows),)) if not isinstance(v, np.ndarray) else v.reshape(-1)
+            if len(vs) != len(rows):
+                raise ValueError(f"categorical: {len(vs)} values for {len(rows)} rows of logits")
+            return _seq_sum([self.sym_logpdf(vj, (np.asarray(ls, dtype=object),)) for vj, ls in zip(vs, rows)])
         ls = self._logits(args[:1])
         lse = jnp.logsumexp(np.asarray(ls, dtype=object))
         if isinstance(v, np.ndarray):               # sample_shape draws: sum of the per-draw log-probabilities

@@ -674,6 +674,24 @@ class _Categorical(Distribution):
             lib().orc_categorical_sample(I64(n), I64(K), _p(np.ascontiguousarray(keys.reshape(2))), I64(0),
                                          _p(np.ascontiguousarray(logits)), I64(K), _p(ctr), I64(1), _p(out))
             return out
+        if batch != () and logits.ndim == 2:
+            try:
+                np.broadcast_shapes(batch + (K,), logits.shape)
+            except ValueError:
+                logits = np.broadcast_to(logits, batch + logits.shape)       # the same J rows for every particle (plain
+                # arrays do not say which axis is the batch: a [J, K] that broadcasts against the batch reads as one
+                # row per particle, as before)
+        if batch != () and logits.ndim == len(batch) + 2:
+            # J rows of logits per particle at ONE site: row j / category k on the particle key's counter j * K + k
+            J = logits.shape[-2]
+            full = np.broadcast_shapes(batch + (J, K), logits.shape)
+            n = int(np.prod(batch, dtype=np.int64))
+            kb = np.ascontiguousarray(np.broadcast_to(keys[..., None, :], batch + (J, 2))).reshape(n * J, 2)
+            lb = np.ascontiguousarray(np.broadcast_to(logits, full)).reshape(n * J, K)
+            ctr = np.ascontiguousarray(np.tile(np.arange(J, dtype=np.uint64) * np.uint64(K), n))
+            out = np.empty(n * J, dtype=np.int32)
+            lib().orc_categorical_sample(I64(n * J), I64(K), _p(kb), I64(1), _p(lb), I64(K), _p(ctr), I64(1), _p(out))
+            return out.reshape(batch + (J,))
         full = np.broadcast_shapes(batch + (K,), logits.shape)
         if len(full) != len(batch) + 1:
             raise NotImplementedError("oracle categorical: batched logits beyond the particle axis")
@@ -697,6 +715,14 @@ class _Categorical(Distribution):
         w = self._logpdf(v, args[:1])
         if len(args) == 2:                       # the n draws of one site: summed (element order, or the tree from 4096)
             return sum_vector(w)
+        batch_shape = tuple(batch_shape)
+        if w.ndim == len(batch_shape) + 1 and (batch_shape != () or w.shape[-1] < 65):
+            # rows of logits at one site (ExactDensity.estimate_logpdf, distribution.py:383-396): summed in row order
+            # (65 rows or more under ONE key stay per row: the bare `categorical.simulate` of the Gibbs notebooks)
+            acc = w[..., 0].astype(np.float32)
+            for j in range(1, w.shape[-1]):
+                acc = (acc + w[..., j]).astype(np.float32)
+            return acc
         return w
 
 

@@ -1,7 +1,7 @@
 """Random `@gen` models against the oracle (test infrastructure).
 
 One SPEC (a list of statements drawn from a small grammar: leaf sites, plates, scans, masked calls, masked plates,
-plates of scans, scans of plates — unrolled and loop sizes mixed; long vector-valued sites (`vec`), a latent vector whose
+plates of scans, scans of plates — unrolled and loop sizes mixed; rows of logits at one categorical site; long vector-valued sites (`vec`), a latent vector whose
 values are the next vector site's parameters (`hvec`: 8-schools' shape), plates (`vplate`), plates of plates (`vplate2`)
 and scans (`vscan`) of elements that hold such sites; one model in eight is long: 12 to 25 statements, a chain of
 launches) is built twice, with the product (`genjax_amd`) and with the
@@ -34,6 +34,9 @@ def random_spec(rng, n_stmts=None, allow_nested=True):
                   sd=float(np.float32(rng.uniform(0.5, 2.0))), src=["a", "prev"][int(rng.integers(2))])
         if kind == "leaf":
             st["dist"] = ["normal", "normal", "uniform", "flip", "beta", "categorical", "bernoulli"][int(rng.integers(7))]
+            # (no draw of its own, so that the seeds' other models stay what they were) rows of logits at ONE site:
+            # `categorical(logits [4, 3])` per particle, four draws under the site's key
+            st["rows"] = 4 if st["dist"] == "categorical" and st["c1"] > 0.3 else 0
         if kind in ("plate", "mplate", "plate_of_scans"):
             st["n"] = [SMALL, LARGE][int(rng.integers(2))]
             st["two"] = bool(rng.integers(2))
@@ -224,6 +227,9 @@ def build(g, spec, lit):
                 elif st["dist"] == "beta":
                     p_ = g.beta(m * m + lit(1.5), lit(2.5)) @ name
                     prev = p_ * lit(2.0) + src
+                elif st["dist"] == "categorical" and st.get("rows"):
+                    i_ = g.categorical(logits=_stack3_rows(g, m, st["rows"], lit)) @ name
+                    prev = _where(g, (i_[..., 1] if g is O else i_[1]) == 1, m, src)
                 elif st["dist"] == "categorical":
                     i_ = g.categorical(logits=_stack3(g, m, lit)) @ name
                     prev = _where(g, i_ == 1, m, src)
@@ -291,6 +297,17 @@ def _stack3(g, m, lit):
     return jnp.stack([m, m * 0.0, -m])
 
 
+def _stack3_rows(g, m, J, lit):
+    """J rows of such logits per particle: row j is [m r_j, 0, -m r_j] with r = 0.5 .. 1.5"""
+    r = np.linspace(0.5, 1.5, J).astype(np.float32)
+    if g is O:
+        mr = (np.asarray(m, np.float32)[..., None] * r).astype(np.float32)
+        return np.stack([mr, np.zeros_like(mr), (-mr).astype(np.float32)], axis=-1)
+    from genjax_amd import numpy as jnp
+    mr = m * jnp.array(r)
+    return jnp.stack([mr, mr * 0.0, -mr], axis=-1)
+
+
 def _full(g, T, lit):
     a = np.linspace(-0.5, 0.5, T).astype(np.float32)
     if g is O:
@@ -316,7 +333,7 @@ def addresses(spec):
         k, nm = st["kind"], st["name"]
         if k == "leaf":
             kind_ = {"flip": "b", "bernoulli": "b", "uniform": "u", "beta": "u", "categorical": "i"}.get(st["dist"], "f")
-            out.append(((nm,), (nm,), (), kind_, False, st))
+            out.append(((nm,), (nm,), (st["rows"],) if st.get("rows") else (), kind_, False, st))
         elif k == "vec":
             out.append(((nm,), (nm,), (st["n"],), "f", False, st))
         elif k == "vplate2":

@@ -3819,6 +3819,45 @@ def check_sweep_verdict():
     return len(words)
 
 
+def check_rows_of_logits_at_one_site(B=257, J=12, seed=5):
+    """Softmax regression written with ONE categorical site: `z ~ categorical(logits [J, 3])` per particle (row j /
+    category k on the site key's counter j K + k: what jax.random.categorical does for logits of that shape): simulate,
+    importance with the J labels given, and `update` of the weight, against the oracle bit for bit"""
+    import genjax_amd as G
+    from genjax_amd import numpy as jnp, ChoiceMap as C
+    xs = np.linspace(-2.0, 2.0, J).astype(np.float32)
+    zs = (np.arange(J) % 3).astype(np.int32)
+
+    @G.gen
+    def model(xs):
+        w = G.normal(0.0, 1.0) @ "w"
+        z = G.categorical(logits=jnp.stack([w * xs, jnp.zeros_like(xs), -w * xs], axis=-1)) @ "z"
+        return z
+
+    @O.gen
+    def omodel(xs):
+        w = np.asarray(O.normal(np.float32(0.0), np.float32(1.0)) @ "w", np.float32)
+        wx = (w[..., None] * xs).astype(np.float32)
+        z = O.categorical(np.stack([wx, np.zeros_like(wx), (-wx).astype(np.float32)], axis=-1)) @ "z"
+        return z
+    keys, okeys = G.split(G.key(seed), B), O.split(O.key(seed), B)
+    tr = G.vmap(lambda k: model.simulate(k, (xs,)))(keys)
+    otr = omodel.simulate(okeys, (xs,))
+    z = _np(tr.get_choices()["z"])
+    assert z.shape == (B, J) and np.array_equal(z, otr.get_choices()["z"])
+    assert np.array_equal(_np(tr.get_retval()), otr.get_retval())
+    assert np.array_equal(_np(tr.get_score()), otr.get_score())
+    tr2, w2 = G.vmap(lambda k: model.importance(k, C.kw(z=zs), (xs,)))(keys)
+    otr2, ow2 = omodel.importance(okeys, O.ChoiceMap.kw(z=np.broadcast_to(zs, (B, J))), (xs,))
+    assert np.array_equal(_np(w2), ow2) and np.array_equal(_np(tr2.get_score()), otr2.get_score())
+    new_w = np.random.default_rng(seed).normal(size=B).astype(np.float32)
+    dev = G._lib.get().device
+    tr3, w3, _, _ = tr2.update(G.key(seed + 1), C.kw(w=torch.from_numpy(new_w).to(dev)))
+    otr3, ow3, _ = omodel.update(O.split(O.key(seed + 1), B), otr2, O.C.d({"w": new_w}), (xs,))
+    assert np.array_equal(_np(w3), ow3) and np.array_equal(_np(tr3.get_score()), otr3.get_score())
+    return float(_np(w2).mean())
+
+
 def check_sweep_with_vector_observations(n=2048, T=4, m=24, seed=3):
     """BootstrapSweep over a state-space model whose step emits a VECTOR of m observations (`y_t ~ normal(x_t * c, 1)`,
     ys of shape [T, m]): the step program holds a long vector-valued site (one counted loop per particle for m > 16) —

@@ -1845,6 +1845,13 @@ def test_peer_mapped_exchange_between_two_processes_on_the_device(gpu, tmp_path,
     assert np.array_equal(x, ref["x"][ref["anc"]])
 
 
+def test_rows_of_logits_at_one_categorical_site_on_device(gpu):
+    """`categorical(logits [J, 3])` per particle (J draws at one site): simulate / importance / update against the oracle,
+    at an interpreter size and at 2^17 particles (specialised)"""
+    parity.check_rows_of_logits_at_one_site(B=257, J=12)
+    parity.check_rows_of_logits_at_one_site(B=1 << 17, J=8, seed=11)
+
+
 def test_sweep_with_vector_observations_on_device(gpu):
     """BootstrapSweep over an HMM with 24 observations per step (a long vector-valued site in the step program: one
     counted loop per particle), interpreter size and 2^18 particles (specialised, one launch per step): log-ML and every

@@ -1542,6 +1542,23 @@ def test_latent_vector_feeding_the_next_vector_site(hostsim, J):
     parity.check_hierarchical_vector_latent(J=J)
 
 
+@pytest.mark.parametrize("J", [12, 64])
+def test_rows_of_logits_at_one_categorical_site(hostsim, J):
+    """`categorical(logits [J, 3])` per particle: J draws at ONE site (softmax regression without a plate) — simulate,
+    importance and update equal the oracle; more rows than are unrolled say so"""
+    import genjax_amd as G
+    from genjax_amd import numpy as jnp
+    from tests import parity
+    parity.check_rows_of_logits_at_one_site(B=33, J=J)
+    if J == 64:
+        @G.gen
+        def wide():
+            w = G.normal(0.0, 1.0) @ "w"
+            return G.categorical(logits=jnp.stack([w * jnp.ones(65), jnp.zeros(65)], axis=-1)) @ "z"
+        with pytest.raises(NotImplementedError, match="rows of logits"):
+            G.vmap(lambda k: wide.simulate(k, ()))(G.split(G.key(0), 3))
+
+
 @pytest.mark.parametrize("m", [4, 24])
 def test_sweep_with_vector_observations(hostsim, m):
     """an HMM with m observations per step through BootstrapSweep: equals the oracle's sweep (m = 24: a counted loop in the

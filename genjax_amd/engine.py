@@ -783,11 +783,47 @@ class StepInput(np.ndarray):
     def _lazy_ok(self):
         return self._slot is not None and self.ndim == 1 and not isinstance(self._slot, list)
 
+    def _read_at(self, idx):
+        """element `idx` — a TRACED index that is not a loop's iteration number (`mus[z]` with z a categorical draw) — of a
+        [T, n] leaf: GMX_F_STEP addresses with the loop counter only, so the read is a search, one counted loop of T
+        iterations that keeps the element whose number equals idx (an index past the end keeps the last, as jax clamps)"""
+        from .tracer import as_int, where
+        g = self._g
+        if g.loop_counts:
+            raise NotImplementedError("a traced index into a per-particle vector of more than 16 elements inside a plate / "
+                                      "scan loop: index a launch-uniform table, or keep the vector to 16 elements")
+        n = int(self.shape[0])
+        i = as_int(idx)
+        i = where(i < 0, i + n, i)
+        # (starts from the LAST element's own read: what an index past the end keeps — and one of the leaf's element
+        # nodes, so that a changed leaf is seen to change what is read from it: static._Ctx.args_changed)
+        last = np.ndarray.__getitem__(self, n - 1)
+        acc = g.loop_var(last.node)
+        g.loop_begin(n - 1)
+        t = Expr(g.add("LDT", dtype="i32"))
+        v = Expr(g.add("LDIN", dtype=self._dt, flags=self._flags, slot=self._slot))
+        g.set_vars([(acc, where(i == t, v, Expr(acc)).node)])
+        g.loop_end()
+        # (a loop variable's node names its initial value only: the result is a select on the INDEX as well, so that a
+        # changed index is seen to change what is read — the same value either way)
+        return where(i == n - 1, last, Expr(acc))
+
     def __getitem__(self, idx):
+        if isinstance(idx, np.ndarray) and idx.dtype == object and self._slot is not None and self.ndim == 1 \
+                and not isinstance(self._slot, list):
+            out = np.empty(idx.shape, dtype=object)         # `mus[zs]`: one read per index
+            for pos in np.ndindex(idx.shape):
+                out[pos] = self[idx[pos]]
+            return out
         if isinstance(idx, Expr) and self._slot is not None:
             if self.ndim == 1 and not isinstance(self._slot, list):
+                if idx.node.op != "LDT":
+                    return self._read_at(idx)
                 return Expr(self._g.add("LDIN", dtype=self._dt, flags=self._flags, slot=self._slot))
             if isinstance(self._slot, list) and self.ndim >= 2 and int(np.prod(self.shape[1:])) == len(self._slot):
+                if idx.node.op != "LDT":
+                    raise NotImplementedError("a traced index that is not a loop's iteration number into the rows of a "
+                                              "per-particle [T, *event] leaf")
                 row = np.empty(self.shape[1:], dtype=object)          # this iteration's row, element by element
                 for e, ix in enumerate(np.ndindex(self.shape[1:])):
                     row[ix] = Expr(self._g.add("LDIN", dtype=self._dt, flags=self._flags, slot=self._slot[e]))

@@ -219,7 +219,7 @@ def _is_torch(x):
 
 def array(x, dtype=None):
     if is_symbolic(x):
-        return np.asarray(x, dtype=object)
+        return T.sym_array(np.asarray(x, dtype=object))
     if _is_torch(x):
         return x if dtype is None else x.to(_torch_dtype(dtype))
     a = np.asarray(x)
@@ -431,7 +431,7 @@ def mean(x, axis=None):
 
 def stack(xs, axis=0):
     if is_symbolic(xs):
-        return np.stack([np.asarray(v, dtype=object) for v in xs], axis=axis)
+        return T.sym_array(np.stack([np.asarray(v, dtype=object) for v in xs], axis=axis))
     if builtins_any(_is_torch(v) for v in xs):
         return torch.stack(list(xs), dim=axis)
     return np.stack(xs, axis=axis)
@@ -636,7 +636,7 @@ def std(x, axis=None):
 
 def concatenate(xs, axis=0):
     if builtins_any(is_symbolic(v) for v in xs):
-        return np.concatenate([np.atleast_1d(np.asarray(v, dtype=object)) for v in xs], axis=axis)
+        return T.sym_array(np.concatenate([np.atleast_1d(np.asarray(v, dtype=object)) for v in xs], axis=axis))
     if builtins_any(_is_torch(v) for v in xs):
         return torch.cat([torch.as_tensor(v) for v in xs], dim=axis)
     return np.concatenate(xs, axis=axis)

@@ -852,7 +852,7 @@ class Handler:
             self.weight = self.weight + w          # static.py:377 / 454 / 559 / 668
         if s is not None and self.mode == "assess":
             self.score = self.score + s            # static.py:319
-        return retval
+        return T.sym_array(retval)                 # (a vector of traced values: `means[z]` with a traced z selects)
 
     def _subrequest(self, addr):
         r = self.req

@@ -436,6 +436,51 @@ def where(c, a, b):
     return Expr(current_graph().add("SEL", (c.node, a.node, b.node), dtype=a.dtype))
 
 
+SYM_TAKE_MAX = 1024        # rows a traced index selects from (a chain of selects: the values sit in registers)
+
+
+class SymArray(np.ndarray):
+    """An object array of traced values that a TRACED integer can index — `means[z]` with `means` a latent vector (a
+    vector-valued site's values, a plate's return values, `jnp.stack([...])`) and `z` a categorical draw, or an array of
+    them: the values sit in registers, so the read is a chain of selects over the leading axis (<= 1024 rows; a table in
+    memory — an argument, `jnp.array(...)` of numbers — is read at a run-time index instead: numpy.RuntimeTable).  An
+    index past the end reads the last row, as jax clamps."""
+
+    def __getitem__(self, idx):
+        if isinstance(idx, Expr) or (isinstance(idx, np.ndarray) and idx.dtype == object):
+            return sym_take(self, idx)
+        if isinstance(idx, tuple) and idx and (isinstance(idx[0], Expr) or (isinstance(idx[0], np.ndarray) and idx[0].dtype == object)):
+            rows = sym_take(self, idx[0])
+            lead = np.ndim(idx[0])
+            return rows[(slice(None),) * lead + tuple(idx[1:])] if isinstance(rows, np.ndarray) else rows
+        return super().__getitem__(idx)
+
+
+def sym_array(x):
+    """`x` as a SymArray when it is an object array of traced values (anything else is returned as it is)"""
+    if type(x) is np.ndarray and x.dtype == object and x.ndim >= 1:
+        return x.view(SymArray)
+    return x
+
+
+def sym_take(arr, idx):
+    base = np.asarray(arr)
+    n = base.shape[0]
+    if n > SYM_TAKE_MAX:
+        raise NotImplementedError(f"a traced index into {n} values computed in the model: a chain of selects (<= {SYM_TAKE_MAX}); "
+                                  "index a table (an argument / `jnp.array` of numbers) instead, or write the reads as a plate")
+    if isinstance(idx, np.ndarray):
+        out = np.empty(idx.shape + base.shape[1:], dtype=object)
+        for pos in np.ndindex(idx.shape):
+            out[pos] = sym_take(arr, idx[pos])
+        return out.view(SymArray)
+    i = as_int(idx)
+    out = base[n - 1]
+    for j in range(n - 2, -1, -1):
+        out = where(i == j, base[j], out)
+    return sym_array(out)
+
+
 def unary(op):
     @_vec
     def f(x):

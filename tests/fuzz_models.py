@@ -1,7 +1,7 @@
 """Random `@gen` models against the oracle (test infrastructure).
 
 One SPEC (a list of statements drawn from a small grammar: leaf sites, plates, scans, masked calls, masked plates,
-plates of scans, scans of plates — unrolled and loop sizes mixed; rows of logits at one categorical site; long vector-valued sites (`vec`), a latent vector whose
+plates of scans, scans of plates — unrolled and loop sizes mixed; rows of logits at one categorical site; values computed in the model read at a traced index (`means[z]`); long vector-valued sites (`vec`), a latent vector whose
 values are the next vector site's parameters (`hvec`: 8-schools' shape), plates (`vplate`), plates of plates (`vplate2`)
 and scans (`vscan`) of elements that hold such sites; one model in eight is long: 12 to 25 statements, a chain of
 launches) is built twice, with the product (`genjax_amd`) and with the
@@ -229,10 +229,13 @@ def build(g, spec, lit):
                     prev = p_ * lit(2.0) + src
                 elif st["dist"] == "categorical" and st.get("rows"):
                     i_ = g.categorical(logits=_stack3_rows(g, m, st["rows"], lit)) @ name
-                    prev = _where(g, (i_[..., 1] if g is O else i_[1]) == 1, m, src)
+                    if st["c2"] > 0.0:          # `means[zs]`: three values computed in the model, read at the four draws
+                        prev = _take3(g, m, src, i_, lit)[..., 2] if g is O else _take3(g, m, src, i_, lit)[2]
+                    else:
+                        prev = _where(g, (i_[..., 1] if g is O else i_[1]) == 1, m, src)
                 elif st["dist"] == "categorical":
                     i_ = g.categorical(logits=_stack3(g, m, lit)) @ name
-                    prev = _where(g, i_ == 1, m, src)
+                    prev = _take3(g, m, src, i_, lit) if st["c1"] < -0.3 else _where(g, i_ == 1, m, src)       # `means[z]`
                 elif st["dist"] == "bernoulli":
                     b = g.bernoulli(logits=m) @ name
                     prev = _where(g, b, src, m)
@@ -253,6 +256,14 @@ def build(g, spec, lit):
                 loc = (z * lit(st["c2"]) + xs) if g is not O else (np.asarray(z, np.float32) * lit(st["c2"]) + xs).astype(np.float32)
                 g.normal(loc, lit(st["sd"])) @ (name + "y")              # the model computes with the latent vector's values
                 prev = m
+                if st["c1"] > 0.3:          # ... and reads ONE of them at a traced index (`mus[z]`: a search loop, engine.StepInput._read_at)
+                    if g is O:
+                        i_ = np.where(np.asarray(m, np.float32) > 0.0, 3, 17)
+                        zz = np.asarray(z, np.float32)          # (a launch-uniform constraint is [n], the index one per particle)
+                        lead = np.broadcast_shapes(zz.shape[:-1], i_.shape)
+                        prev = np.take_along_axis(np.broadcast_to(zz, lead + zz.shape[-1:]), np.broadcast_to(i_, lead)[..., None], axis=-1)[..., 0]
+                    else:
+                        prev = z[_where(g, m > 0.0, 3, 17)]
             elif k in ("vplate", "vplate2"):
                 g.Vmap(st["fn"], in_axes=(None, 0))(m, next(it)) @ name
                 prev = m
@@ -295,6 +306,19 @@ def _stack3(g, m, lit):
         return np.stack([m, np.zeros_like(m), (-m).astype(np.float32)], axis=-1)
     from genjax_amd import numpy as jnp
     return jnp.stack([m, m * 0.0, -m])
+
+
+def _take3(g, m, src, i_, lit):
+    """[m, src, m / 2][i_]: values computed in the model, read at a traced index (a draw, or a vector of draws)"""
+    if g is O:
+        tab = np.stack(np.broadcast_arrays(np.asarray(m, np.float32), np.asarray(src, np.float32),
+                                           (np.asarray(m, np.float32) * lit(0.5)).astype(np.float32)), axis=-1)
+        i_ = np.asarray(i_)
+        if i_.ndim == tab.ndim - 1:
+            return np.take_along_axis(tab, i_[..., None], axis=-1)[..., 0]
+        return np.take_along_axis(np.broadcast_to(tab, i_.shape[:-1] + tab.shape[-1:]), i_, axis=-1)
+    from genjax_amd import numpy as jnp
+    return jnp.stack([m, src, m * lit(0.5)])[i_]
 
 
 def _stack3_rows(g, m, J, lit):

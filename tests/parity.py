@@ -3858,6 +3858,76 @@ def check_rows_of_logits_at_one_site(B=257, J=12, seed=5):
     return float(_np(w2).mean())
 
 
+def check_mixture_with_latent_means(B=129, J=6, seed=8, n_comp=3):
+    """A Gaussian mixture whose component means are LATENT: `mus ~ normal(0_3, 5)`, `zs ~ categorical(logits [J, 3])`,
+    `ys ~ normal(mus[zs], 1)` — values computed in the model read at traced indices (tracer.SymArray: a chain of
+    selects); the means also as a plate's return values (`cluster.vmap()(...) @ "clusters"`, then `means[z]`).  With
+    more than 16 components the means are a long vector-valued site (one counted loop per particle; its values live in
+    memory): a read at a traced index is then a search loop over the stored values (engine.StepInput._read_at).
+    simulate / importance / update against the oracle, bit for bit"""
+    K_ = int(n_comp)
+    import genjax_amd as G
+    from genjax_amd import numpy as jnp, ChoiceMap as C
+    yv = np.linspace(-4.0, 4.0, J).astype(np.float32)
+
+    @G.gen
+    def mix():
+        mus = G.normal(jnp.zeros(K_), 5.0) @ "mus"
+        zs = G.categorical(logits=jnp.zeros((J, K_))) @ "zs"
+        G.normal(mus[zs], 1.0) @ "ys"
+        return zs
+
+    @O.gen
+    def omix():
+        mus = O.normal(np.zeros(K_, np.float32), np.float32(5.0)) @ "mus"
+        zs = O.categorical(np.zeros((J, K_), np.float32)) @ "zs"
+        O.normal(np.take_along_axis(mus, zs, axis=-1), np.float32(1.0)) @ "ys"
+        return zs
+
+    @G.gen
+    def cluster(c):
+        return G.normal(c, 5.0) @ "mean"
+
+    @G.gen
+    def mix2(centres):
+        means = cluster.vmap(in_axes=(0,))(centres) @ "clusters"
+        z = G.categorical(logits=jnp.array([0.0, 0.5, -0.5])) @ "z"
+        G.normal(means[z] * 0.5 + means[0], 1.0) @ "y"
+        return z
+
+    @O.gen
+    def ocluster(c):
+        return O.normal(c, np.float32(5.0)) @ "mean"
+
+    @O.gen
+    def omix2(centres):
+        means = O.Vmap(ocluster, in_axes=(0,))(centres) @ "clusters"
+        z = O.categorical(np.array([0.0, 0.5, -0.5], np.float32)) @ "z"
+        picked = np.take_along_axis(means, np.asarray(z)[..., None], axis=-1)[..., 0]
+        O.normal((picked * np.float32(0.5) + means[..., 0]).astype(np.float32), np.float32(1.0)) @ "y"
+        return z
+    keys, okeys = G.split(G.key(seed), B), O.split(O.key(seed), B)
+    dev = G._lib.get().device
+    tr = G.vmap(lambda k: mix.simulate(k, ()))(keys)
+    otr = omix.simulate(okeys, ())
+    assert np.array_equal(_np(tr.get_choices()["zs"]), otr.get_choices()["zs"])
+    assert np.array_equal(_np(tr.get_choices()["ys"]), otr.get_choices()["ys"])
+    assert np.array_equal(_np(tr.get_score()), otr.get_score())
+    tr2, w2 = G.vmap(lambda k: mix.importance(k, C.kw(ys=yv), ()))(keys)
+    otr2, ow2 = omix.importance(okeys, O.ChoiceMap.kw(ys=np.broadcast_to(yv, (B, J))), ())
+    assert np.array_equal(_np(w2), ow2)
+    new_mus = np.random.default_rng(seed).normal(size=(B, K_)).astype(np.float32)
+    tr3, w3, _, _ = tr2.update(G.key(seed + 1), C.kw(mus=torch.from_numpy(new_mus).to(dev)))
+    otr3, ow3, _ = omix.update(O.split(O.key(seed + 1), B), otr2, O.C.d({"mus": new_mus}), ())
+    assert np.array_equal(_np(w3), ow3) and np.array_equal(_np(tr3.get_score()), otr3.get_score())
+    centres = np.array([-3.0, 0.0, 3.0], np.float32)
+    tr4, w4 = G.vmap(lambda k: mix2.importance(k, C.kw(y=1.5), (centres,)))(keys)
+    otr4, ow4 = omix2.importance(okeys, O.ChoiceMap.kw(y=np.full(B, 1.5, np.float32)), (centres,))
+    assert np.array_equal(_np(tr4.get_choices()["z"]), otr4.get_choices()["z"])
+    assert np.array_equal(_np(w4), ow4) and np.array_equal(_np(tr4.get_score()), otr4.get_score())
+    return float(_np(w2).mean())
+
+
 def check_sweep_with_vector_observations(n=2048, T=4, m=24, seed=3):
     """BootstrapSweep over a state-space model whose step emits a VECTOR of m observations (`y_t ~ normal(x_t * c, 1)`,
     ys of shape [T, m]): the step program holds a long vector-valued site (one counted loop per particle for m > 16) —

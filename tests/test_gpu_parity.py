@@ -1852,6 +1852,15 @@ def test_rows_of_logits_at_one_categorical_site_on_device(gpu):
     parity.check_rows_of_logits_at_one_site(B=1 << 17, J=8, seed=11)
 
 
+def test_mixture_with_latent_means_on_device(gpu):
+    """a Gaussian mixture whose means are latent (`normal(mus[zs], 1)`: traced indices into values computed in the model),
+    at an interpreter size and at 2^17 particles (specialised): simulate / importance / update against the oracle"""
+    parity.check_mixture_with_latent_means(B=129)
+    parity.check_mixture_with_latent_means(B=129, n_comp=20, seed=9)        # a long vector site's values: a search loop
+    parity.check_mixture_with_latent_means(B=1 << 17, J=5, seed=13)
+    parity.check_mixture_with_latent_means(B=1 << 17, J=4, n_comp=20, seed=14)
+
+
 def test_sweep_with_vector_observations_on_device(gpu):
     """BootstrapSweep over an HMM with 24 observations per step (a long vector-valued site in the step program: one
     counted loop per particle), interpreter size and 2^18 particles (specialised, one launch per step): log-ML and every

@@ -1559,6 +1559,55 @@ def test_rows_of_logits_at_one_categorical_site(hostsim, J):
             G.vmap(lambda k: wide.simulate(k, ()))(G.split(G.key(0), 3))
 
 
+@pytest.mark.parametrize("n_comp", [3, 20])
+def test_mixture_with_latent_means(hostsim, n_comp):
+    """`ys ~ normal(mus[zs], 1)` with `mus` a latent vector and `zs` categorical draws — values computed in the model read
+    at traced indices (3 components: registers, a chain of selects; 20: a long vector site's stored values, a search
+    loop); the means also as a plate's return values: equals the oracle"""
+    from tests import parity
+    parity.check_mixture_with_latent_means(B=33, n_comp=n_comp)
+
+
+def test_traced_index_into_a_long_per_particle_vector(hostsim):
+    """`xs[z]` with xs a per-particle vector of more than 16 elements (one [T, n] input slot, addressed by a loop's
+    iteration number only) and z a traced index that is NOT a loop counter used to read element 0, silently: now a search
+    loop at top level: assess and update of `y ~ normal(mus[z] + centres[z], 1)` equal the oracle"""
+    import genjax_amd as G
+    from genjax_amd import numpy as jnp, ChoiceMap as C
+    from oracle import genjax_oracle as O
+    n, B = 20, 9
+
+    @G.gen
+    def mix(centres):
+        mus = G.normal(centres, 5.0) @ "mus"
+        z = G.categorical(logits=jnp.zeros(n)) @ "z"
+        G.normal(mus[z] + centres[z], 1.0) @ "y"
+        return z
+
+    @O.gen
+    def omix(centres):
+        mus = O.normal(centres, np.float32(5.0)) @ "mus"
+        z = np.asarray(O.categorical(np.zeros(n, np.float32)) @ "z")
+        O.normal((np.take_along_axis(mus, z[..., None], axis=-1)[..., 0] + centres[z]).astype(np.float32), np.float32(1.0)) @ "y"
+        return z
+    cen = np.linspace(-3, 3, n).astype(np.float32)
+    keys, okeys = G.split(G.key(2), B), O.split(O.key(2), B)
+    dev = G._lib.get().device
+    tr, w = G.vmap(lambda k: mix.importance(k, C.kw(y=1.5), (cen,)))(keys)
+    otr, ow = omix.importance(okeys, O.ChoiceMap.kw(y=np.full(B, 1.5, np.float32)), (cen,))
+    assert np.array_equal(np.asarray(w), ow)
+    sc, _ = mix.assess(tr.get_choices(), (cen,))
+    assert np.array_equal(np.asarray(sc), otr.get_score())
+    newz = (np.arange(B) % n).astype(np.int32)
+    _, w3, _, _ = tr.update(G.key(5), C.kw(z=torch.from_numpy(newz).to(dev)))
+    _, ow3, _ = omix.update(O.split(O.key(5), B), otr, O.C.d({"z": newz}), (cen,))
+    assert np.array_equal(np.asarray(w3), ow3)
+    newm = np.random.default_rng(0).normal(size=(B, n)).astype(np.float32)
+    tr4, w4, _, _ = tr.update(G.key(6), C.kw(mus=torch.from_numpy(newm).to(dev)))
+    otr4, ow4, _ = omix.update(O.split(O.key(6), B), otr, O.C.d({"mus": newm}), (cen,))
+    assert np.array_equal(np.asarray(w4), ow4) and np.array_equal(np.asarray(tr4.get_score()), otr4.get_score())
+
+
 @pytest.mark.parametrize("m", [4, 24])
 def test_sweep_with_vector_observations(hostsim, m):
     """an HMM with m observations per step through BootstrapSweep: equals the oracle's sweep (m = 24: a counted loop in the

@@ -774,6 +774,7 @@ class StepInput(np.ndarray):
     def __array_finalize__(self, obj):
         for a in ("_g", "_slot", "_dt", "_flags"):
             setattr(self, a, getattr(obj, a, None))
+        self._base = getattr(obj, "_base", 0)        # element of the leaf this (contiguous) view starts at: `xs[1:]`
 
     def __array_ufunc__(self, ufunc, method, *inputs, **kwargs):
         from .numpy import _lazy_ufunc
@@ -801,7 +802,7 @@ class StepInput(np.ndarray):
         acc = g.loop_var(last.node)
         g.loop_begin(n - 1)
         t = Expr(g.add("LDT", dtype="i32"))
-        v = Expr(g.add("LDIN", dtype=self._dt, flags=self._flags, slot=self._slot))
+        v = Expr(g.add("LDIN", dtype=self._dt, flags=self._flags, slot=self._slot, imm=int(self._base or 0)))
         g.set_vars([(acc, where(i == t, v, Expr(acc)).node)])
         g.loop_end()
         # (a loop variable's node names its initial value only: the result is a select on the INDEX as well, so that a
@@ -819,7 +820,7 @@ class StepInput(np.ndarray):
             if self.ndim == 1 and not isinstance(self._slot, list):
                 if idx.node.op != "LDT":
                     return self._read_at(idx)
-                return Expr(self._g.add("LDIN", dtype=self._dt, flags=self._flags, slot=self._slot))
+                return Expr(self._g.add("LDIN", dtype=self._dt, flags=self._flags, slot=self._slot, imm=int(self._base or 0)))
             if isinstance(self._slot, list) and self.ndim >= 2 and int(np.prod(self.shape[1:])) == len(self._slot):
                 if idx.node.op != "LDT":
                     raise NotImplementedError("a traced index that is not a loop's iteration number into the rows of a "
@@ -831,6 +832,14 @@ class StepInput(np.ndarray):
         r = np.ndarray.__getitem__(self, idx)
         if isinstance(r, StepInput) and not (isinstance(idx, slice) or idx is Ellipsis):
             return np.asarray(r, dtype=object) if r.ndim else r      # a static row / element: plain expressions
+        if isinstance(r, StepInput) and isinstance(idx, slice):
+            # a view read at a loop's iteration number t is element base + t of the leaf (GMX_F_STEP adds its immediate):
+            # `xs[1:]`, `xs[10:40]`; a reversed / strided view — or a slice of several axes — is its element reads,
+            # plainly (what reads element t of the WHOLE leaf would get silently wrong)
+            if self.ndim == 1 and not isinstance(self._slot, list) and idx.step in (None, 1):
+                r._base = int(self._base or 0) + idx.indices(self.shape[0])[0]
+            elif idx.indices(self.shape[0]) != (0, self.shape[0], 1):
+                return np.asarray(r, dtype=object)
         return r
 
 

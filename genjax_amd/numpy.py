@@ -616,9 +616,11 @@ def cumsum(x, axis=0):
 
 def dot(a, b):
     if is_symbolic(a) or is_symbolic(b):
+        if np.ndim(a) != 1 or np.ndim(b) != 1:
+            if np.ndim(a) in (1, 2) and np.ndim(b) in (1, 2):
+                return a @ b                      # (jnp.dot of a matrix and a vector / matrix is their matmul)
+            raise NotImplementedError("traced dot: vectors and matrices only")
         a, b = np.asarray(a, dtype=object), np.asarray(b, dtype=object)
-        if a.ndim != 1 or b.ndim != 1:
-            raise NotImplementedError("traced dot: vectors only")
         return sum(a * b)
     return _lib_of(a, b).dot(a, b)
 

@@ -1,7 +1,7 @@
 """Random `@gen` models against the oracle (test infrastructure).
 
 One SPEC (a list of statements drawn from a small grammar: leaf sites, plates, scans, masked calls, masked plates,
-plates of scans, scans of plates — unrolled and loop sizes mixed; rows of logits at one categorical site; values computed in the model read at a traced index (`means[z]`); long vector-valued sites (`vec`), a latent vector whose
+plates of scans, scans of plates — unrolled and loop sizes mixed; rows of logits at one categorical site; values computed in the model read at a traced index (`means[z]`), slices of a long latent vector; long vector-valued sites (`vec`), a latent vector whose
 values are the next vector site's parameters (`hvec`: 8-schools' shape), plates (`vplate`), plates of plates (`vplate2`)
 and scans (`vscan`) of elements that hold such sites; one model in eight is long: 12 to 25 statements, a chain of
 launches) is built twice, with the product (`genjax_amd`) and with the
@@ -253,7 +253,11 @@ def build(g, spec, lit):
                 xs = next(it)
                 mean = (m + xs * lit(st["c1"])) if g is not O else (np.asarray(m, np.float32)[..., None] + xs * lit(st["c1"])).astype(np.float32)
                 z = g.normal(mean, lit(st["sd"])) @ (name + "z")
-                loc = (z * lit(st["c2"]) + xs) if g is not O else (np.asarray(z, np.float32) * lit(st["c2"]) + xs).astype(np.float32)
+                if st["c2"] > 0.25:         # a SLICE of the latent vector (a random walk's increments): n - 1 elements
+                    loc = ((z[1:] - z[:-1]) * lit(st["c2"]) + xs[1:]) if g is not O else (
+                        (np.asarray(z, np.float32)[..., 1:] - np.asarray(z, np.float32)[..., :-1]).astype(np.float32) * lit(st["c2"]) + xs[1:]).astype(np.float32)
+                else:
+                    loc = (z * lit(st["c2"]) + xs) if g is not O else (np.asarray(z, np.float32) * lit(st["c2"]) + xs).astype(np.float32)
                 g.normal(loc, lit(st["sd"])) @ (name + "y")              # the model computes with the latent vector's values
                 prev = m
                 if st["c1"] > 0.3:          # ... and reads ONE of them at a traced index (`mus[z]`: a search loop, engine.StepInput._read_at)
@@ -369,7 +373,7 @@ def addresses(spec):
             out.append(((nm, "w"), (nm, "w"), (st["n"], st["m"]), "f", False, st))
         elif k == "hvec":
             out.append(((nm + "z",), (nm + "z",), (st["n"],), "f", False, st))
-            out.append(((nm + "y",), (nm + "y",), (st["n"],), "f", False, st))
+            out.append(((nm + "y",), (nm + "y",), (st["n"] - (1 if st["c2"] > 0.25 else 0),), "f", False, st))
         elif k == "call":
             out.append(((nm, "p"), (nm, "p"), (), "f", False, st))
             out.append(((nm, "q"), (nm, "q"), (), "f", False, st))

@@ -3928,6 +3928,59 @@ def check_mixture_with_latent_means(B=129, J=6, seed=8, n_comp=3):
     return float(_np(w2).mean())
 
 
+def check_slices_of_a_long_per_particle_vector(B=65, N=50, seed=4):
+    """`normal(rho * f(ys), 1) @ "y"` with ys a PER-PARTICLE vector of N > 16 elements (one [N, n] input slot read at a
+    loop's iteration number) and f a slice: `ys[1:]`, `ys[10:40]`, `ys[1:] - ys[:-1]` (a base offset on the step read),
+    `ys[::-1]`, `ys[::2]` (plain element reads) — a sliced view used to read element t of the WHOLE leaf, silently;
+    the same slices of a LATENT long vector (`x ~ normal(0_N, 1)`, then `normal(x[1:] - x[:-1], 0.1)`: the stored
+    values read back).  Importance weights against the oracle, bit for bit"""
+    import genjax_amd as G
+    from genjax_amd import ChoiceMap as C
+    rng = np.random.default_rng(seed)
+    ysb = np.cumsum(rng.normal(size=(B, N)), axis=1).astype(np.float32)
+    dev = G._lib.get().device
+    keys, okeys = G.split(G.key(seed), B), O.split(O.key(seed), B)
+    cases = {
+        "tail": lambda y: y[..., 1:], "head": lambda y: y[..., :-1], "mid": lambda y: y[..., 10:40],
+        "diff": lambda y: y[..., 1:] - y[..., :-1], "reversed": lambda y: y[..., ::-1], "every other": lambda y: y[..., ::2],
+        "tail of tail": lambda y: y[..., 2:][..., 3:],
+    }
+    for name, f in cases.items():
+        @G.gen
+        def model(ys):
+            rho = G.uniform(-1.0, 1.0) @ "rho"
+            G.normal(rho * f(ys), 1.0) @ "y"
+            return rho
+
+        @O.gen
+        def omodel(ys):
+            rho = np.asarray(O.uniform(np.float32(-1.0), np.float32(1.0)) @ "rho", np.float32)
+            O.normal((rho[..., None] * np.asarray(f(ys), np.float32)).astype(np.float32), np.float32(1.0)) @ "y"
+            return rho
+        m = f(ysb).shape[-1]
+        obs = np.linspace(-1.0, 1.0, m).astype(np.float32)
+        tr, w = G.vmap(lambda k, y: model.importance(k, C.kw(y=obs), (y,)))(keys, torch.from_numpy(ysb).to(dev))
+        otr, ow = omodel.importance(okeys, O.ChoiceMap.kw(y=np.broadcast_to(obs, (B, m))), (ysb,))
+        assert np.array_equal(_np(w), ow), name
+
+        @G.gen
+        def walk():
+            x = G.normal(np.zeros(N, np.float32), 1.0) @ "x"
+            G.normal(f(x), 0.5) @ "d"
+            return x[3]
+
+        @O.gen
+        def owalk():
+            x = np.asarray(O.normal(np.zeros(N, np.float32), np.float32(1.0)) @ "x", np.float32)
+            O.normal(np.asarray(f(x), np.float32), np.float32(0.5)) @ "d"
+            return x[..., 3]
+        tr2, w2 = G.vmap(lambda k: walk.importance(k, C.kw(d=obs), ()))(keys)
+        otr2, ow2 = owalk.importance(okeys, O.ChoiceMap.kw(d=np.broadcast_to(obs, (B, m))), ())
+        assert np.array_equal(_np(w2), ow2), (name, "latent")
+        assert np.array_equal(_np(tr2.get_retval()), otr2.get_retval()), (name, "latent retval")
+    return len(cases)
+
+
 def check_sweep_with_vector_observations(n=2048, T=4, m=24, seed=3):
     """BootstrapSweep over a state-space model whose step emits a VECTOR of m observations (`y_t ~ normal(x_t * c, 1)`,
     ys of shape [T, m]): the step program holds a long vector-valued site (one counted loop per particle for m > 16) —

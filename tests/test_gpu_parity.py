@@ -1861,6 +1861,13 @@ def test_mixture_with_latent_means_on_device(gpu):
     parity.check_mixture_with_latent_means(B=1 << 17, J=4, n_comp=20, seed=14)
 
 
+def test_slices_of_a_long_per_particle_vector_on_device(gpu):
+    """slices (`ys[1:]`, `ys[10:40]`, differences, reversed, strided) of a long per-particle vector and of a latent one as
+    a vector site's parameter, interpreter size and 2^17 particles (specialised): importance weights against the oracle"""
+    parity.check_slices_of_a_long_per_particle_vector(B=65)
+    parity.check_slices_of_a_long_per_particle_vector(B=1 << 17, N=24, seed=6)
+
+
 def test_sweep_with_vector_observations_on_device(gpu):
     """BootstrapSweep over an HMM with 24 observations per step (a long vector-valued site in the step program: one
     counted loop per particle), interpreter size and 2^18 particles (specialised, one launch per step): log-ML and every

@@ -1568,6 +1568,14 @@ def test_mixture_with_latent_means(hostsim, n_comp):
     parity.check_mixture_with_latent_means(B=33, n_comp=n_comp)
 
 
+def test_slices_of_a_long_per_particle_vector(hostsim):
+    """`ys[1:]`, `ys[10:40]`, `ys[1:] - ys[:-1]`, `ys[::-1]`, `ys[::2]` of a per-particle vector of 50 elements — and of a
+    latent one — as a vector site's parameter: a sliced view used to read element t of the whole leaf in the site's
+    loop, silently.  Equals the oracle"""
+    from tests import parity
+    assert parity.check_slices_of_a_long_per_particle_vector(B=33) == 7
+
+
 def test_traced_index_into_a_long_per_particle_vector(hostsim):
     """`xs[z]` with xs a per-particle vector of more than 16 elements (one [T, n] input slot, addressed by a loop's
     iteration number only) and z a traced index that is NOT a loop counter used to read element 0, silently: now a search

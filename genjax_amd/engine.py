@@ -810,6 +810,10 @@ class StepInput(np.ndarray):
         return where(i == n - 1, last, Expr(acc))
 
     def __getitem__(self, idx):
+        if isinstance(idx, tuple) and self.ndim == 1:          # `xs[..., 1:]` of a vector is `xs[1:]`
+            rest = [i for i in idx if i is not Ellipsis]
+            if len(rest) <= 1 and len(idx) - len(rest) <= 1:
+                idx = rest[0] if rest else slice(None)
         if isinstance(idx, np.ndarray) and idx.dtype == object and self._slot is not None and self.ndim == 1 \
                 and not isinstance(self._slot, list):
             out = np.empty(idx.shape, dtype=object)         # `mus[zs]`: one read per index

@@ -3978,6 +3978,46 @@ def check_slices_of_a_long_per_particle_vector(B=65, N=50, seed=4):
         otr2, ow2 = owalk.importance(okeys, O.ChoiceMap.kw(d=np.broadcast_to(obs, (B, m))), ())
         assert np.array_equal(_np(w2), ow2), (name, "latent")
         assert np.array_equal(_np(tr2.get_retval()), otr2.get_retval()), (name, "latent retval")
+
+    # ... and as what a long scan / a large plate runs over: step t / element t reads element base + t
+    @G.gen
+    def step(c, x):
+        z = G.normal(c * 0.5 + x, 1.0) @ "z"
+        return z, z
+
+    @G.gen
+    def elem(mu, x):
+        return G.normal(mu + x, 1.0) @ "v"
+
+    @O.gen
+    def ostep(c, x):
+        z = O.normal((c * np.float32(0.5) + x).astype(np.float32), np.float32(1.0)) @ "z"
+        return z, z
+
+    @O.gen
+    def oelem(mu, x):
+        return O.normal((mu + x).astype(np.float32), np.float32(1.0)) @ "v"
+    for name in ("tail", "mid"):
+        f = cases[name]
+        T_ = f(ysb).shape[-1]
+
+        @G.gen
+        def over(ys):
+            mu = G.normal(0.0, 1.0) @ "mu"
+            cT, _ = G.Scan(step, T_)(mu, f(ys)) @ "chain"
+            elem.vmap(in_axes=(None, 0))(cT, f(ys)) @ "plate"
+            return cT
+
+        @O.gen
+        def oover(ys):
+            mu = O.normal(np.float32(0.0), np.float32(1.0)) @ "mu"
+            cT, _ = O.Scan(ostep, T_)(mu, f(ys)) @ "chain"          # (the oracle's step / plate axis is the last one)
+            O.Vmap(oelem, in_axes=(None, 0))(cT, f(ys)) @ "plate"
+            return cT
+        tr3 = G.vmap(lambda k, y: over.simulate(k, (y,)))(keys, torch.from_numpy(ysb).to(dev))
+        otr3 = oover.simulate(okeys, (ysb,))
+        assert np.array_equal(_np(tr3.get_score()), otr3.get_score()), (name, "scan and plate over the slice")
+        assert np.array_equal(_np(tr3.get_retval()), otr3.get_retval()), (name, "scan and plate over the slice: retval")
     return len(cases)
 
 

@@ -637,7 +637,7 @@ def _depends(node, changed: set, memo: dict, table_changed=None) -> bool:
             return True
         if r is False:
             continue
-        if n.idx in changed or (table_changed is not None and n.op == "LDTAB" and table_changed(n)):
+        if n.idx in changed or (table_changed is not None and n.op in ("LDTAB", "LDIN") and table_changed(n)):
             memo[n.idx] = True
             for s in seen:
                 memo[s] = True
@@ -679,6 +679,8 @@ class _Ctx:
         self.memo: dict = {}
         self.changed_slots: set = set()  # table slots whose contents differ from the previous trace's (changed table arguments)
         self.changed_tables: list = []   # ... and host tables flagged changed before they were given a slot
+        self.changed_in_slots: set = set()   # INPUT slots of per-particle vectors of > 16 elements (engine.StepInput) that
+        #                                      changed: a read at a loop's iteration number is a node of its own
         self._slot_memo: dict = {}
         self.store_sites = True          # False: the caller stores only what it needs (MinimalGenerate)
         self.gate = None                 # an edit applies only where this boolean holds (IndexRequest around a loop)
@@ -699,8 +701,12 @@ class _Ctx:
             for x in v.values():
                 self._mark_tables(x)
         elif isinstance(v, np.ndarray):
+            from .engine import StepInput
             slot = getattr(v, "_slot", None)
-            if slot is not None:                      # numpy.RuntimeTable / a TableArray row: a device or pooled table
+            if isinstance(v, StepInput):              # a per-particle [T, n] leaf: every step read of its slot(s) is changed
+                if slot is not None:
+                    self.changed_in_slots.update(int(x) for x in (slot if isinstance(slot, list) else [slot]))
+            elif slot is not None:                    # numpy.RuntimeTable / a TableArray row: a device or pooled table
                 self.changed_slots.add(int(slot))
             if v.dtype != object and v.size > 0:      # a host table (numpy.TableArray, or the array it will be made from)
                 self.changed_tables.append(np.asarray(v).reshape(-1))
@@ -710,6 +716,8 @@ class _Ctx:
         slot = getattr(node, "slot", None)
         if slot is None:
             return False
+        if node.op == "LDIN":
+            return slot in self.changed_in_slots
         if slot in self.changed_slots:
             return True
         if not self.changed_tables:
@@ -726,7 +734,7 @@ class _Ctx:
         return r
 
     def args_changed(self, args) -> bool:
-        tab = self._table_changed if (self.changed_slots or self.changed_tables) else None
+        tab = self._table_changed if (self.changed_slots or self.changed_tables or self.changed_in_slots) else None
         return any(_depends(n, self.changed, self.memo, tab) for n in _nodes_of(args))
 
 

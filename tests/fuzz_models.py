@@ -8,7 +8,7 @@ launches) is built twice, with the product (`genjax_amd`) and with the
 oracle (`oracle/genjax_oracle.py`), and every GFI method is compared bit for bit under a batch of keys:
 simulate (score, return value, every choice), importance under a random subset of constraints, assess of the
 resulting choices, and `update` with a random subset of new constraints and randomly CHANGED arguments (the
-per-particle argument, a table, a vector of flags), an `IndexRequest` into one plate / scan, `Regenerate` and MH moves
+per-particle argument, a table — or, for half of the top-level plates / scans / vector sites, a vector PER PARTICLE — a vector of flags), an `IndexRequest` into one plate / scan, `Regenerate` and MH moves
 where the reference's combinators answer them.  The reference paths restated by the oracle:
 static.py:255-466 (handlers), vmap.py:180-275, scan.py:200-503, mask.py:96-262."""
 import numpy as np
@@ -67,13 +67,26 @@ def random_spec(rng, n_stmts=None, allow_nested=True):
     return stmts
 
 
+class PerParticle(np.ndarray):
+    """an extra argument that is ONE VECTOR PER PARTICLE ([B, n]: a device tensor for the product) rather than a table"""
+
+
+def _per_particle(st, B):
+    """half of the top-level plates / scans / vector sites of a model run under B > 1 keys map over (compute with) a
+    per-particle vector instead of a launch-uniform table (decided by the statement's own numbers: no draw of its own)"""
+    return B > 1 and st["kind"] in ("plate", "scan", "vec", "hvec") and st["sd"] > 1.25
+
+
 def spec_args(spec, rng, B):
-    """(a [B] f32, per-statement extra arguments): a table per plate / scan, flags per masked statement"""
+    """(a [B] f32, per-statement extra arguments): a table per plate / scan (or a vector per particle), flags per masked
+    statement"""
     a = rng.normal(size=B).astype(np.float32)
     extra = []
     for st in spec:
         k = st["kind"]
-        if k in ("plate", "plate_of_scans", "vec", "hvec", "vplate"):
+        if _per_particle(st, B):
+            extra.append(rng.normal(size=(B, st["n"] if "n" in st else st["T"])).astype(np.float32).view(PerParticle))
+        elif k in ("plate", "plate_of_scans", "vec", "hvec", "vplate"):
             extra.append(rng.normal(size=st["n"]).astype(np.float32))
         elif k == "vplate2":
             extra.append(rng.normal(size=(st["n"], st["n2"])).astype(np.float32))
@@ -255,7 +268,7 @@ def build(g, spec, lit):
                 z = g.normal(mean, lit(st["sd"])) @ (name + "z")
                 if st["c2"] > 0.25:         # a SLICE of the latent vector (a random walk's increments): n - 1 elements
                     loc = ((z[1:] - z[:-1]) * lit(st["c2"]) + xs[1:]) if g is not O else (
-                        (np.asarray(z, np.float32)[..., 1:] - np.asarray(z, np.float32)[..., :-1]).astype(np.float32) * lit(st["c2"]) + xs[1:]).astype(np.float32)
+                        (np.asarray(z, np.float32)[..., 1:] - np.asarray(z, np.float32)[..., :-1]).astype(np.float32) * lit(st["c2"]) + xs[..., 1:]).astype(np.float32)
                 else:
                     loc = (z * lit(st["c2"]) + xs) if g is not O else (np.asarray(z, np.float32) * lit(st["c2"]) + xs).astype(np.float32)
                 g.normal(loc, lit(st["sd"])) @ (name + "y")              # the model computes with the latent vector's values
@@ -511,8 +524,8 @@ def _run_one(seed, B=7, allow_nested=True, verbose=False):
     def g_args(a_, extra_):
         out = [torch.from_numpy(a_).to(dev)]
         for e in extra_:
-            out.append(torch.from_numpy(np.ascontiguousarray(e)).to(dev) if e.shape[:1] == (B,) and e.dtype == bool and e.ndim == 1
-                       and not _is_table(e, spec, B) else jnp.array(e))
+            out.append(torch.from_numpy(np.ascontiguousarray(e)).to(dev) if isinstance(e, PerParticle) or (
+                e.shape[:1] == (B,) and e.dtype == bool and e.ndim == 1 and not _is_table(e, spec, B)) else jnp.array(e))
         return tuple(out)
     k, ok = G.split(G.key(seed), B), O.split(O.key(seed), B)
     tr, otr = model.simulate(k, g_args(a, extra)), omodel.simulate(ok, (a,) + tuple(extra))

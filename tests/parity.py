@@ -4021,6 +4021,63 @@ def check_slices_of_a_long_per_particle_vector(B=65, N=50, seed=4):
     return len(cases)
 
 
+def check_changed_per_particle_vector_argument(B=65, N=30, seed=12):
+    """`update` with a CHANGED argument that is one vector of N > 16 elements per particle, mapped over by a large plate
+    and scanned over by a long scan: every element / step reads its own element at the loop's iteration number — a node
+    of its own, which the change propagation did not see as changed (the elements kept their old scores: wrong weights,
+    silently; found by giving the random-model grammar per-particle tables).  Weights and scores against the oracle"""
+    import genjax_amd as G
+    from genjax_amd import Diff
+    rng = np.random.default_rng(seed)
+    xs1, xs2 = (rng.normal(size=(B, N)).astype(np.float32) for _ in range(2))
+    dev = G._lib.get().device
+
+    @G.gen
+    def elem(mu, x):
+        return G.normal(mu + x, 1.0) @ "v"
+
+    @G.gen
+    def step(c, x):
+        z = G.normal(c * 0.5 + x, 1.0) @ "z"
+        return z, z
+
+    @G.gen
+    def model(xs):
+        mu = G.normal(0.0, 1.0) @ "mu"
+        elem.vmap(in_axes=(None, 0))(mu, xs) @ "plate"
+        cT, _ = G.Scan(step, N)(mu, xs) @ "chain"
+        G.normal(mu + xs * 0.5, 2.0) @ "vec"
+        return cT
+
+    @O.gen
+    def oelem(mu, x):
+        return O.normal((mu + x).astype(np.float32), np.float32(1.0)) @ "v"
+
+    @O.gen
+    def ostep(c, x):
+        z = O.normal((c * np.float32(0.5) + x).astype(np.float32), np.float32(1.0)) @ "z"
+        return z, z
+
+    @O.gen
+    def omodel(xs):
+        mu = np.asarray(O.normal(np.float32(0.0), np.float32(1.0)) @ "mu", np.float32)
+        O.Vmap(oelem, in_axes=(None, 0))(mu, xs) @ "plate"
+        cT, _ = O.Scan(ostep, N)(mu, xs) @ "chain"
+        O.normal((mu[..., None] + xs * np.float32(0.5)).astype(np.float32), np.float32(2.0)) @ "vec"
+        return cT
+    k, ok = G.split(G.key(seed), B), O.split(O.key(seed), B)
+    t1, t2 = torch.from_numpy(xs1).to(dev), torch.from_numpy(xs2).to(dev)
+    tr, otr = model.simulate(k, (t1,)), omodel.simulate(ok, (xs1,))
+    assert np.array_equal(_np(tr.get_score()), otr.get_score())
+    k2, ok2 = G.split(G.key(seed + 1), B), O.split(O.key(seed + 1), B)
+    new, w, _, _ = model.update(k2, tr, G.ChoiceMap.empty(), (Diff(t2, G.UnknownChange),))
+    onew, ow, _ = omodel.update(ok2, otr, O.ChoiceMap(), (xs2,))
+    assert np.array_equal(_np(w), ow), "update weight under a changed per-particle vector"
+    assert np.array_equal(_np(new.get_score()), onew.get_score())
+    assert float(np.abs(ow).max()) > 1.0           # (the weights are not trivially zero)
+    return float(ow.mean())
+
+
 def check_sweep_with_vector_observations(n=2048, T=4, m=24, seed=3):
     """BootstrapSweep over a state-space model whose step emits a VECTOR of m observations (`y_t ~ normal(x_t * c, 1)`,
     ys of shape [T, m]): the step program holds a long vector-valued site (one counted loop per particle for m > 16) —

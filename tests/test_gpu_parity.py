@@ -1868,6 +1868,13 @@ def test_slices_of_a_long_per_particle_vector_on_device(gpu):
     parity.check_slices_of_a_long_per_particle_vector(B=1 << 17, N=24, seed=6)
 
 
+def test_changed_per_particle_vector_argument_on_device(gpu):
+    """`update` under a changed per-particle vector argument of a large plate, a long scan and a vector site: weights and
+    scores against the oracle, interpreter size and 2^17 particles (specialised)"""
+    parity.check_changed_per_particle_vector_argument(B=65)
+    parity.check_changed_per_particle_vector_argument(B=1 << 17, N=20, seed=15)
+
+
 def test_sweep_with_vector_observations_on_device(gpu):
     """BootstrapSweep over an HMM with 24 observations per step (a long vector-valued site in the step program: one
     counted loop per particle), interpreter size and 2^18 particles (specialised, one launch per step): log-ML and every

@@ -1576,6 +1576,13 @@ def test_slices_of_a_long_per_particle_vector(hostsim):
     assert parity.check_slices_of_a_long_per_particle_vector(B=33) == 7
 
 
+def test_changed_per_particle_vector_argument(hostsim):
+    """`update` under a changed [B, 30] argument that a large plate maps over, a long scan scans over and a vector site
+    computes with: every element is re-scored (the loops' step reads were not seen as changed). Equals the oracle"""
+    from tests import parity
+    parity.check_changed_per_particle_vector_argument(B=33)
+
+
 def test_traced_index_into_a_long_per_particle_vector(hostsim):
     """`xs[z]` with xs a per-particle vector of more than 16 elements (one [T, n] input slot, addressed by a loop's
     iteration number only) and z a traced index that is NOT a loop counter used to read element 0, silently: now a search

@@ -700,6 +700,9 @@ class _Ctx:
         elif isinstance(v, dict):
             for x in v.values():
                 self._mark_tables(x)
+        elif hasattr(v, "token") and hasattr(v, "_slot"):      # engine.StepInput2: a per-particle leaf with several axes
+            slot = v._slot
+            self.changed_in_slots.update(int(x) for x in (slot if isinstance(slot, (list, tuple)) else [slot]))
         elif isinstance(v, np.ndarray):
             from .engine import StepInput
             slot = getattr(v, "_slot", None)

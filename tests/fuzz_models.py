@@ -72,9 +72,11 @@ class PerParticle(np.ndarray):
 
 
 def _per_particle(st, B):
-    """half of the top-level plates / scans / vector sites of a model run under B > 1 keys map over (compute with) a
-    per-particle vector instead of a launch-uniform table (decided by the statement's own numbers: no draw of its own)"""
-    return B > 1 and st["kind"] in ("plate", "scan", "vec", "hvec") and st["sd"] > 1.25
+    """half of the plates / scans / vector sites of a model run under B > 1 keys map over (compute with) a per-particle
+    vector ([B, n]; a plate of plates: [B, n, n2]) instead of a launch-uniform table (decided by the statement's own
+    numbers: no draw of its own)"""
+    kinds = ("plate", "scan", "vec", "hvec", "vscan", "plate_of_scans", "scan_of_plates", "vplate", "vplate2")
+    return B > 1 and st["kind"] in kinds and st["sd"] > 1.25
 
 
 def spec_args(spec, rng, B):
@@ -85,7 +87,8 @@ def spec_args(spec, rng, B):
     for st in spec:
         k = st["kind"]
         if _per_particle(st, B):
-            extra.append(rng.normal(size=(B, st["n"] if "n" in st else st["T"])).astype(np.float32).view(PerParticle))
+            shape = (st["n"], st["n2"]) if k == "vplate2" else ((st["T"],) if k in ("scan", "vscan", "scan_of_plates") else (st["n"],))
+            extra.append(rng.normal(size=(B,) + shape).astype(np.float32).view(PerParticle))
         elif k in ("plate", "plate_of_scans", "vec", "hvec", "vplate"):
             extra.append(rng.normal(size=st["n"]).astype(np.float32))
         elif k == "vplate2":

@@ -4075,6 +4075,44 @@ def check_changed_per_particle_vector_argument(B=65, N=30, seed=12):
     assert np.array_equal(_np(w), ow), "update weight under a changed per-particle vector"
     assert np.array_equal(_np(new.get_score()), onew.get_score())
     assert float(np.abs(ow).max()) > 1.0           # (the weights are not trivially zero)
+
+    # ... and a [B, n, n2] argument of a plate of plates (engine.StepInput2: rows picked by the loops' own numbers)
+    n1, n2 = 3, 20
+    zs1, zs2 = (rng.normal(size=(B, n1, n2)).astype(np.float32) for _ in range(2))
+
+    @G.gen
+    def rows(mu, xs):
+        return elem.vmap(in_axes=(None, 0))(mu, xs) @ "r"
+
+    @G.gen
+    def model2(zs):
+        mu = G.normal(0.0, 1.0) @ "mu"
+        rows.vmap(in_axes=(None, 0))(mu, zs) @ "pp"
+        return mu
+
+    @O.gen
+    def oelem2(mu, x):          # (the oracle's plates keep their axes behind the batch: the shared value is padded)
+        mu = np.asarray(mu, np.float32)
+        while mu.ndim < np.ndim(x):
+            mu = mu[..., None]
+        return O.normal((mu + x).astype(np.float32), np.float32(1.0)) @ "v"
+
+    @O.gen
+    def orows(mu, xs):
+        return O.Vmap(oelem2, in_axes=(None, 0))(mu, xs) @ "r"
+
+    @O.gen
+    def omodel2(zs):
+        mu = np.asarray(O.normal(np.float32(0.0), np.float32(1.0)) @ "mu", np.float32)
+        O.Vmap(orows, in_axes=(None, 0))(mu, zs) @ "pp"
+        return mu
+    u1, u2 = torch.from_numpy(zs1).to(dev), torch.from_numpy(zs2).to(dev)
+    tr2, otr2 = model2.simulate(k, (u1,)), omodel2.simulate(ok, (zs1,))
+    assert np.array_equal(_np(tr2.get_score()), otr2.get_score())
+    new2, w2, _, _ = model2.update(k2, tr2, G.ChoiceMap.empty(), (Diff(u2, G.UnknownChange),))
+    onew2, ow2, _ = omodel2.update(ok2, otr2, O.ChoiceMap(), (zs2,))
+    assert np.array_equal(_np(w2), ow2), "update weight under a changed [B, n, n2] argument"
+    assert np.array_equal(_np(new2.get_score()), onew2.get_score())
     return float(ow.mean())
 
 

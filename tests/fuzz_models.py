@@ -97,6 +97,9 @@ def spec_args(spec, rng, B):
             extra.append(rng.normal(size=st["T"]).astype(np.float32))
         elif k == "mscan":
             extra.append(np.arange(st["T"]) < int(rng.integers(0, st["T"] + 1)))
+        elif k == "mplate" and B > 1 and st["sd"] > 1.25:
+            extra.append((rng.random((B, st["n"])) < 0.6).view(PerParticle))          # flags and values per particle
+            extra.append(rng.normal(size=(B, st["n"])).astype(np.float32).view(PerParticle))
         elif k == "mplate":
             extra.append(rng.random(st["n"]) < 0.6)
             extra.append(rng.normal(size=st["n"]).astype(np.float32))
@@ -715,6 +718,13 @@ def _run_smc_one(seed, K):
     ores = O.gather_trace(ocoll.get_particles(), anc)
     assert np.array_equal(_np(res.get_particles().get_score()), ores.get_score()), (seed, "resampled scores")
     _same_choices(spec, res.get_particles(), ores, K, (seed, "resampled particles"))
+    # ChangeTarget to OTHER ARGUMENTS as well (the tables a plate / scan / vector site runs over replaced: data arriving)
+    a3, extra3 = spec_args(spec, rng, 1)
+    g_args3 = (float(np.float32(a3[0])),) + tuple(jnp.array(e) for e in extra3)
+    ct3 = ChangeTarget(ImportanceK(tgt, k_particles=K), G.Target(model, g_args3, _g_constraint(G, cons_b))).run_smc(G.key(seed + 17))
+    oct3 = O.ChangeTarget(O.ImportanceK(otgt, K), O.Target(omodel, (np.float32(a3[0]),) + tuple(extra3), _o_constraint(cons_b))).run_smc(O.key(seed + 17))
+    assert np.array_equal(_np(ct3.get_log_weights()), oct3.get_log_weights()), (seed, "ChangeTarget to other arguments: log weights")
+    assert np.array_equal(_np(ct3.get_particles().get_score()), oct3.get_particles().get_score()), (seed, "ChangeTarget to other arguments: scores")
     return spec
 
 

@@ -31,7 +31,7 @@ from .core.choice_map import ChoiceMap
 from .core.mask import Indexed, Mask
 from .program import F_BCAST, F_GATHER, Graph, ProgramTooLarge, compile_graph, split_graph
 from .random import Key
-from .tracer import Expr
+from .tracer import Expr, sym_array
 
 
 # ---------------------------------------------------------------------------
@@ -575,7 +575,7 @@ class Tracing:
                 n = g.uniform(spec[1])
                 self.uni_plan.append((n.imm, j, e, spec[1]))
                 arr[idx] = Expr(n)
-            return Sym(arr, ("leaf", j))
+            return Sym(sym_array(arr), ("leaf", j))       # (a short vector in registers: a traced index selects, tracer.SymArray)
         if kind == "dtab":
             from .numpy import RuntimeTable, runtime_table_slot
             slot = runtime_table_slot(g)
@@ -636,7 +636,7 @@ class Tracing:
             n = g.input(dt, flags)
             self.in_plan.append((n.slot, j, e, kind))
             arr[idx] = Expr(n)
-        return Sym(arr, ("leaf", j))
+        return Sym(sym_array(arr), ("leaf", j))
 
     # outputs ------------------------------------------------------------------
     def prestore(self, value):

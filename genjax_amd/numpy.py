@@ -27,6 +27,24 @@ bool_ = np.bool_
 newaxis = None
 
 
+def _gather(table, idx):
+    """`means[zs]` with `means` a 1-D table in memory and `zs` a VECTOR of traced indices (categorical draws, an integer
+    table, a per-particle integer vector): element j is one table read at zs[j] — lazily for a long index vector (a
+    vector site over the result then loops), else one read per element.  None when `idx` is no such vector."""
+    if table.ndim != 1 or not T.is_tracing():
+        return None
+    if isinstance(idx, T.LazyVec) or (T._long_vector(idx) and getattr(idx, "dtype", None) is not None
+                                      and (idx.dtype == object or idx.dtype.kind in "iu")):
+        n = T._long_vector(idx)
+        return T.LazyVec(n, lambda i: table[T.lift(T._elem(idx, i))], parts=(table, idx))
+    if isinstance(idx, np.ndarray) and idx.dtype == object and idx.ndim >= 1:
+        out = np.empty(idx.shape, dtype=object)
+        for pos in np.ndindex(idx.shape):
+            out[pos] = table[idx[pos]]
+        return T.sym_array(out)
+    return None
+
+
 class TableArray(np.ndarray):
     """A constant array closed over by a model; indexing it with a traced
     integer becomes an OP_LDTAB lookup (e.g. `means[idx]`)."""
@@ -39,6 +57,10 @@ class TableArray(np.ndarray):
         return np.asarray(a).view(cls)
 
     def __getitem__(self, idx):
+        if not isinstance(idx, (Expr, int, slice, np.integer)) and self.dtype != object:
+            got = _gather(self, idx)
+            if got is not None:
+                return got
         if isinstance(idx, Expr):
             g = T.current_graph()
             dt = "f32" if self.dtype.kind == "f" else ("bool" if self.dtype.kind == "b" else "i32")
@@ -152,6 +174,10 @@ class RuntimeTable(np.ndarray):
         return StepOutput(origin, int(self.shape[0]), 1 + n_loop)
 
     def __getitem__(self, idx):
+        if not isinstance(idx, (Expr, int, slice, np.integer)) and self._slot is not None:
+            got = _gather(self, idx)
+            if got is not None:
+                return got
         base = int(self._base or 0)
         dyn = getattr(self, "_dyn", None)
         if isinstance(idx, Expr) and self._slot is not None and self.ndim == 1:

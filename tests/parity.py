@@ -4116,6 +4116,47 @@ def check_changed_per_particle_vector_argument(B=65, N=30, seed=12):
     return float(ow.mean())
 
 
+def check_gather_by_index_vector(B=33, seed=21):
+    """`normal(means[zs] + s, 1) @ "y"`: the vectorised mixture likelihood with the assignments GIVEN — `means` a table
+    of 3 (registers) or 20 (memory) components, `zs` an integer vector of 8 or 30 elements given as a launch-uniform
+    table or one per particle: element j reads means at zs[j] (lazily, in the site's loop, when zs is long).
+    importance, and `update` under changed assignments, against the oracle bit for bit"""
+    import genjax_amd as G
+    from genjax_amd import ChoiceMap as C, Diff, numpy as jnp
+    rng = np.random.default_rng(seed)
+    dev = G._lib.get().device
+    n = 0
+    for N, K in ((8, 3), (30, 3), (30, 20)):
+        zs, zs2 = (rng.integers(0, K, size=(B, N)).astype(np.int32) for _ in range(2))
+        zt, zt2 = (rng.integers(0, K, size=N).astype(np.int32) for _ in range(2))
+        means = np.linspace(-3.0, 3.0, K).astype(np.float32)
+        obs = rng.normal(size=N).astype(np.float32)
+
+        @G.gen
+        def model(means, zs):
+            s = G.normal(0.0, 1.0) @ "s"
+            G.normal(means[zs] + s, 1.0) @ "y"
+            return s
+
+        @O.gen
+        def omodel(means, zs):
+            s = np.asarray(O.normal(np.float32(0.0), np.float32(1.0)) @ "s", np.float32)
+            O.normal((means[zs] + s[..., None]).astype(np.float32), np.float32(1.0)) @ "y"
+            return s
+        k, ok = G.split(G.key(seed), B), O.split(O.key(seed), B)
+        for za, zb, oa, ob in ((torch.from_numpy(zs).to(dev), torch.from_numpy(zs2).to(dev), zs, zs2),
+                               (jnp.array(zt), jnp.array(zt2), zt, zt2)):
+            tr, w = model.importance(k, C.kw(y=obs), (jnp.array(means), za))
+            otr, ow = omodel.importance(ok, O.ChoiceMap.kw(y=np.broadcast_to(obs, (B, N))), (means, oa))
+            assert np.array_equal(_np(w), ow), (N, K, "importance")
+            new, wu, _, _ = model.update(G.split(G.key(seed + 1), B), tr, C.empty(),
+                                         (Diff.no_change(jnp.array(means)), Diff(zb, G.UnknownChange)))
+            onew, owu, _ = omodel.update(O.split(O.key(seed + 1), B), otr, O.ChoiceMap(), (means, ob))
+            assert np.array_equal(_np(wu), owu) and np.array_equal(_np(new.get_score()), onew.get_score()), (N, K, "update")
+            n += 1
+    return n
+
+
 def check_sweep_with_vector_observations(n=2048, T=4, m=24, seed=3):
     """BootstrapSweep over a state-space model whose step emits a VECTOR of m observations (`y_t ~ normal(x_t * c, 1)`,
     ys of shape [T, m]): the step program holds a long vector-valued site (one counted loop per particle for m > 16) —

@@ -1875,6 +1875,12 @@ def test_changed_per_particle_vector_argument_on_device(gpu):
     parity.check_changed_per_particle_vector_argument(B=1 << 17, N=20, seed=15)
 
 
+def test_gather_by_index_vector_on_device(gpu):
+    """`normal(means[zs] + s, 1)` with the assignments given as a table or one vector per particle: importance and update
+    under changed assignments against the oracle"""
+    assert parity.check_gather_by_index_vector(B=129) == 6
+
+
 def test_sweep_with_vector_observations_on_device(gpu):
     """BootstrapSweep over an HMM with 24 observations per step (a long vector-valued site in the step program: one
     counted loop per particle), interpreter size and 2^18 particles (specialised, one launch per step): log-ML and every

@@ -1583,6 +1583,13 @@ def test_changed_per_particle_vector_argument(hostsim):
     parity.check_changed_per_particle_vector_argument(B=33)
 
 
+def test_gather_by_index_vector(hostsim):
+    """`means[zs]` with `means` a table and `zs` a vector of indices given as an argument (a table, or one vector per
+    particle; 8 / 30 elements; 3 / 20 components): importance and update under changed assignments equal the oracle"""
+    from tests import parity
+    assert parity.check_gather_by_index_vector() == 6
+
+
 def test_traced_index_into_a_long_per_particle_vector(hostsim):
     """`xs[z]` with xs a per-particle vector of more than 16 elements (one [T, n] input slot, addressed by a loop's
     iteration number only) and z a traced index that is NOT a loop counter used to read element 0, silently: now a search

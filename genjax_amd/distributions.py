@@ -281,8 +281,10 @@ class _Categorical(Distribution):
                 from . import numpy as jnp
                 p = kw.pop("probs")
                 if T.is_tracing():
-                    p = np.asarray([T.lift(x) for x in np.asarray(p, dtype=object).reshape(-1)], dtype=object)
-                    return self._shaped((jnp.log(p),), shape)
+                    p = np.asarray(p, dtype=object)          # (rows of probabilities keep their shape: J draws at the site)
+                    flat = np.empty(p.size, dtype=object)
+                    flat[:] = [T.lift(x) for x in p.reshape(-1)]
+                    return self._shaped((jnp.log(flat.reshape(p.shape)),), shape)
                 return self._shaped((np.log(np.asarray(p, dtype=np.float32)),), shape)
             if "logits" in kw:
                 return self._shaped((kw.pop("logits"),), shape)

@@ -3925,6 +3925,28 @@ def check_mixture_with_latent_means(B=129, J=6, seed=8, n_comp=3):
     otr4, ow4 = omix2.importance(okeys, O.ChoiceMap.kw(y=np.full(B, 1.5, np.float32)), (centres,))
     assert np.array_equal(_np(tr4.get_choices()["z"]), otr4.get_choices()["z"])
     assert np.array_equal(_np(w4), ow4) and np.array_equal(_np(tr4.get_score()), otr4.get_score())
+
+    # the whole Dirichlet mixture: latent weights too (`probs=` of shape [J, 3] keeps its rows — it used to be read as
+    # ONE categorical over 3 J categories)
+    @G.gen
+    def mix3():
+        wts = G.dirichlet(jnp.ones(3)) @ "w"
+        mus = G.normal(jnp.array([-2.0, 0.0, 2.0]), 1.0) @ "mus"
+        zs = G.categorical(probs=jnp.stack([wts] * J)) @ "zs"
+        G.normal(mus[zs], 0.5) @ "ys"
+        return zs
+
+    @O.gen
+    def omix3():
+        wts = np.asarray(O.dirichlet(np.ones(3, np.float32)) @ "w", np.float32)
+        mus = O.normal(np.array([-2.0, 0.0, 2.0], np.float32), np.float32(1.0)) @ "mus"
+        lw = O.log(wts)
+        zs = O.categorical(np.broadcast_to(lw[..., None, :], lw.shape[:-1] + (J, 3)).copy()) @ "zs"
+        O.normal(np.take_along_axis(mus, zs, axis=-1), np.float32(0.5)) @ "ys"
+        return zs
+    tr5, w5 = G.vmap(lambda k: mix3.importance(k, C.kw(ys=yv), ()))(keys)
+    otr5, ow5 = omix3.importance(okeys, O.ChoiceMap.kw(ys=np.broadcast_to(yv, (B, J))), ())
+    assert np.array_equal(_np(tr5.get_choices()["zs"]), otr5.get_choices()["zs"]) and np.array_equal(_np(w5), ow5)
     return float(_np(w2).mean())
 
 

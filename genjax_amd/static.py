@@ -876,6 +876,18 @@ class Handler:
         return r                   # update: the constraint lookup goes through self.constraint
 
 
+def _sym_arrays(tree):
+    """the arguments a model's source is called with: short vectors of traced values (registers — a plate's element row,
+    a scan's carry) as tracer.SymArray, so that `trans[z]` with a traced z selects"""
+    if isinstance(tree, tuple):
+        return tuple(_sym_arrays(x) for x in tree)
+    if isinstance(tree, list):
+        return [_sym_arrays(x) for x in tree]
+    if isinstance(tree, dict):
+        return {k: _sym_arrays(v) for k, v in tree.items()}
+    return T.sym_array(tree)
+
+
 def _leaf_call(ctx: _Ctx, mode, dist, key, args, constraint: ChoiceMap, prev, req, req_leaves):
     """Leaf (Distribution) semantics; returns (_SiteRec, retval, weight, score)."""
     g = ctx.tr.graph
@@ -1183,7 +1195,7 @@ def call_gen_fn(ctx, mode, gen_fn, key, args, constraint, prev, req, req_leaves,
         _HANDLERS.append(h)
         try:
             with T.tracing(ctx.tr.graph):
-                retval = gen_fn.source(*args)
+                retval = gen_fn.source(*_sym_arrays(args))
         finally:
             _HANDLERS.pop()
         h.rec.retval = retval

@@ -1590,6 +1590,46 @@ def test_gather_by_index_vector(hostsim):
     assert parity.check_gather_by_index_vector() == 6
 
 
+@pytest.mark.parametrize("T_", [5, 20])
+def test_hmm_with_latent_transition_rows(hostsim, T_):
+    """a discrete HMM whose transition rows are LATENT (`row.repeat(n=3)()`: a plate of Dirichlets) and ride in the scan's
+    carry: `categorical(probs=trans[z])` selects a row of values held in registers at the traced state — unrolled scan
+    (5 steps) and the loop form (20: the carry comes back from loop variables).  Weights and joint score against numpy"""
+    import genjax_amd as G
+    from genjax_amd import numpy as jnp, ChoiceMap as C
+    B = 9
+    means = np.array([-2.0, 0.0, 2.0], np.float32)
+
+    @G.gen
+    def row():
+        return G.dirichlet(jnp.ones(3)) @ "p"
+
+    @G.gen
+    def step(carry, y_):
+        z, trans = carry
+        zn = G.categorical(probs=trans[z]) @ "z"
+        G.normal(jnp.array(means)[zn], 1.0) @ "y"
+        return (zn, trans), zn
+
+    @G.gen
+    def hmm():
+        trans = row.repeat(n=3)() @ "trans"
+        z0 = G.categorical(logits=jnp.zeros(3)) @ "z0"
+        (zT, _), _ = G.Scan(step, T_)((z0, trans), jnp.zeros(T_)) @ "chain"
+        return zT
+    ys = np.linspace(-2, 2, T_).astype(np.float32)
+    tr, w = G.vmap(lambda k: hmm.importance(k, C["chain", :, "y"].set(jnp.array(ys)), ()))(G.split(G.key(1), B))
+    ch = tr.get_choices()
+    P = np.asarray(ch["trans", slice(None), "p"], np.float64)
+    z0, zs = np.asarray(ch["z0"]), np.asarray(ch["chain", slice(None), "z"])
+    lp = lambda y, m: -0.5 * (y - m) ** 2 - 0.5 * np.log(2 * np.pi)
+    w_ref = lp(ys[None], means[zs].astype(np.float64)).sum(1)
+    prev = np.concatenate([z0[:, None], zs[:, :-1]], 1)
+    joint = 3 * np.log(2.0) - np.log(3.0) + np.log(P[np.arange(B)[:, None], prev, zs]).sum(1) + w_ref
+    assert np.abs(np.asarray(w) - w_ref).max() < 1e-4
+    assert np.abs(np.asarray(tr.get_score()) - joint).max() < 1e-4
+
+
 def test_traced_index_into_a_long_per_particle_vector(hostsim):
     """`xs[z]` with xs a per-particle vector of more than 16 elements (one [T, n] input slot, addressed by a loop's
     iteration number only) and z a traced index that is NOT a loop counter used to read element 0, silently: now a search

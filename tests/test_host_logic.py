@@ -1630,6 +1630,40 @@ def test_hmm_with_latent_transition_rows(hostsim, T_):
     assert np.abs(np.asarray(tr.get_score()) - joint).max() < 1e-4
 
 
+@pytest.mark.parametrize("N", [8, 30])
+def test_plate_over_a_per_particle_index_vector(hostsim, N):
+    """a plate (unrolled / a loop) mapped over one INTEGER vector per particle whose elements index a table and a latent
+    vector inside the element (`normal(means[z] + mus[z], 1)`), and `update` under a changed index vector: joint score
+    and weights against numpy"""
+    import genjax_amd as G
+    from genjax_amd import numpy as jnp, ChoiceMap as C, Diff
+    B, K = 9, 3
+    dev = G._lib.get().device
+    rng = np.random.default_rng(0)
+    lp = lambda y, m: -0.5 * (y - m) ** 2 - 0.5 * np.log(2 * np.pi)
+    zs, zs2 = (rng.integers(0, K, size=(B, N)).astype(np.int32) for _ in range(2))
+    means = np.linspace(-3, 3, K).astype(np.float32)
+
+    @G.gen
+    def elem(means, mus, z):
+        return G.normal(means[z] + mus[z], 1.0) @ "v"
+
+    @G.gen
+    def model(means, zs):
+        mus = G.normal(jnp.zeros(K), 1.0) @ "mus"
+        elem.vmap(in_axes=(None, None, 0))(means, mus, zs) @ "p"
+        return mus[0]
+    tr = model.simulate(G.split(G.key(1), B), (jnp.array(means), torch.from_numpy(zs).to(dev)))
+    ch = tr.get_choices()
+    mus, v = np.asarray(ch["mus"], np.float64), np.asarray(ch["p", slice(None), "v"], np.float64)
+    joint = lambda z: lp(mus, 0.0).sum(1) + lp(v, means[z].astype(np.float64) + np.take_along_axis(mus, z, 1)).sum(1)
+    assert np.abs(np.asarray(tr.get_score()) - joint(zs)).max() < 1e-4
+    _, w, _, _ = model.update(G.split(G.key(2), B), tr, C.empty(),
+                              (Diff.no_change(jnp.array(means)), Diff(torch.from_numpy(zs2).to(dev), G.UnknownChange)))
+    assert np.abs(np.asarray(w)).max() > 10.0
+    assert np.abs(np.asarray(w) - (joint(zs2) - joint(zs))).max() < 1e-3
+
+
 def test_traced_index_into_a_long_per_particle_vector(hostsim):
     """`xs[z]` with xs a per-particle vector of more than 16 elements (one [T, n] input slot, addressed by a loop's
     iteration number only) and z a traced index that is NOT a loop counter used to read element 0, silently: now a search

@@ -287,6 +287,30 @@ def _so(tr, origin, T):
     return StepOutput(origin, T, len(tr.outputs[origin[1]][1]))
 
 
+def _readable(tr, v, n):
+    """What the MODEL gets for the stacked return values of a TOP-LEVEL counted loop (a plate of more than 16 elements, a
+    long scan): reads of that very output (engine.StepAlias through Tracing.alias_step_input — one more input slot bound
+    to the launch's own output buffer; a thread reads only what it stored), so `jnp.sum(a)`, `a[3]`, `means[z]`, a later
+    vector site over them work as on the plain stacked arrays the reference hands back (vmap.py:180-191, scan.py:221-233).
+    Returned / recorded as it is, the alias IS that output (no copy).  Inside an enclosing loop, vector-valued elements
+    and outputs of nested loops keep the memory-only form (engine.StepOutput)."""
+    from .engine import StepOutput
+    if tr.graph.loop_counts:
+        return v
+    if isinstance(v, Mask):
+        return Mask(_readable(tr, v.value, n), _readable(tr, v.flag, n))
+    if isinstance(v, (tuple, list)):
+        return type(v)(_readable(tr, x, n) for x in v)
+    if isinstance(v, dict):
+        return {k: _readable(tr, x, n) for k, x in v.items()}
+    if not isinstance(v, StepOutput) or v.vector_site or v.origin[0] != "out":
+        return v
+    dt, dims, spec = tr.outputs[v.origin[1]]
+    if tuple(dims) != (int(n),) or not (isinstance(spec, tuple) and spec[0] == "step" and not isinstance(spec[1], list)):
+        return v
+    return tr.alias_step_input(v.origin, dt, int(n))
+
+
 def _has_step_rows(tree):
     """does a previous-trace tree hold [n, A, T] step leaves (engine.StepInput2: the values of loops INSIDE a plate) — or,
     inside a counted loop, launch-uniform tables with a long last axis (the same values given as one [.., n, m] table:
@@ -560,7 +584,10 @@ class Vmap(GenerativeFunction):
                 if hasattr(v, "passthrough") and v.passthrough() is not None:
                     return v.passthrough()             # a long row of a per-particle leaf returned as it was given
                 return _so(tr, tr.store_step(v, n), n)
-            rets = stack_out(ret) if (keep or not isinstance(rec, _SiteRec)) else None
+            if isinstance(rec, _SiteRec) and wanted and isinstance(rec.value, StepOutput):
+                rets = rec.value             # a bare distribution's plate: its stored values ARE what it returns
+            else:
+                rets = stack_out(ret) if (keep or not isinstance(rec, _SiteRec)) else None
             updates = []
             if wvar is not None and w is not None:
                 updates.append((wvar, (Expr(wvar) + w).node))
@@ -588,6 +615,14 @@ class Vmap(GenerativeFunction):
             out.retval = rets
             out.plate_score = score
             retval = rets
+        if isinstance(rec, _SiteRec) and retval is None and constraint is not None:
+            # a bare distribution's plate whose values were GIVEN (assess; importance under a constraint on the whole
+            # plate): what it returns is what it was given — a table / per-particle leaf, readable where it lies
+            cv = constraint.get_value()
+            cv = cv.value if isinstance(cv, Sym) else cv
+            if cv is not None and not isinstance(cv, Mask) and T._long_vector(cv) == n:
+                retval = cv
+        retval = _readable(tr, retval, n)
         if mode in ("simulate", "assess"):
             return out, retval, None, score
         return out, retval, Expr(wvar), None
@@ -709,7 +744,7 @@ class Vmap(GenerativeFunction):
         if isinstance(rec, _SiteRec):
             # a bare distribution's plate stays one vector-valued site: values [T], score = the new plate sum
             out = _SiteRec(rec.gen_fn, rec.value, Expr(svar), rec.discard)
-            return out, rec.value, Expr(wvar), None
+            return out, _readable(tr, rec.value, n), Expr(wvar), None
 
         def drop_retvals(r):
             if isinstance(r, _CallRec):
@@ -721,7 +756,7 @@ class Vmap(GenerativeFunction):
         out.sites = rec.sites
         out.retval = rets
         out.plate_score = Expr(svar)
-        return out, rets, Expr(wvar), None
+        return out, _readable(tr, rets, n), Expr(wvar), None
 
     def _trace_edit(self, ctx, mode, key, args, constraint, prev, req, req_leaves, addr):
         """Vmap.edit (vmap.py:334-362): `Update(constraint)` edits every element with keys split(key, n)
@@ -740,6 +775,14 @@ class Vmap(GenerativeFunction):
         if "vmap" not in prev and "sub" not in prev:
             # a plate of a BARE distribution (`normal.vmap()(locs, scales) @ "a"`): its trace keeps the values and the
             # plate-sum score; the per-element scores an edit needs are recomputed from the old values in the loop
+            if kind in ("update", "empty") and (constraint is None or constraint.static_is_empty()) \
+                    and not ctx.args_changed(args) and ctx.gate is None:
+                # nothing to do: no element is constrained and no argument changed, so every element's new score is its
+                # old one and the plate contributes exactly 0 (vmap.py:237-275 computes that 0 element by element; the
+                # MH move of 3_speed_gains.ipynb c15 edits `x` and leaves three such plates alone).  The previous
+                # values are handed back where they lie — readable: `jnp.sum(a)` loops over the old leaf
+                pv = prev["value"]
+                return _SiteRec(self.gen_fn, pv, prev["score"]), (pv.value if hasattr(pv, "value") else pv), None, None
             return self._trace_edit_loop(ctx, kind if kind != "empty" else "update", key, args, axes, constraint, None,
                                          req, n, req_leaves, addr, bare_prev=prev)
         # (as the ELEMENT of an enclosing plate / scan this plate's trace is held flat: its sites with one more axis)

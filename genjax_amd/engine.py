@@ -371,6 +371,19 @@ class Flat:
             return ("dc", type(v), tuple(items))
         if isinstance(v, Indexed):            # a run-time plate index (core/mask.py): value + index, both launch values
             return ("indexed", self.add(v.value), self.add(v.idx))
+        tk = _trace_kind(v)
+        if tk is not None:
+            # a TRACE as an argument (`prop(tr, *_): orig_a = tr.get_choices()["a"]`, docs/cookbook/inactive/inference/
+            # mcmc.ipynb c8 / c10): traces are pytrees in the reference (generative_function.py:72-230, static.py:80-119)
+            # — their arguments, return value, values and scores are the leaves, the generative function rides in the
+            # structure (and so in the program cache key)
+            gf = ("static_field", _static_token(v.gen_fn))
+            if tk == "dist":
+                return ("trace", tk, gf, self.add(v.args), self.add(v.value), self.add(v.score))
+            if tk == "vmap":
+                return ("trace", tk, gf, self.add(v.args), self.add(v.inner), self.add(v.score), self.add(v.retval))
+            return ("trace", tk, gf, self.add(v.args), self.add(v.retval),
+                    tuple((a, self.add(st)) for a, st in v.subtraces.items()))
         if isinstance(v, Mask):
             # a runtime-conditional constraint (distribution.py:129-142): a flag known on the host resolves now
             if isinstance(v.flag, (bool, np.bool_)):
@@ -378,6 +391,21 @@ class Flat:
             return ("mask", self.add(v.value), self.add(v.flag))
         self.leaves.append(v)
         return ("leaf", len(self.leaves) - 1)
+
+
+def _trace_kind(v):
+    """"dist" | "static" | "vmap" for the trace types of static.py (imported late: static imports this module), else None"""
+    name = type(v).__name__
+    if name not in ("DistributionTrace", "StaticTrace", "MaskTrace", "VmapTrace"):
+        return None
+    from . import static as S
+    if isinstance(v, S.DistributionTrace):
+        return "dist"
+    if isinstance(v, S.VmapTrace):
+        return "vmap"
+    if isinstance(v, S.StaticTrace):
+        return "static"
+    return None
 
 
 def _hashable(x):
@@ -460,6 +488,16 @@ def unflatten(tree, fn):
         return Mask(unflatten(tree[2], fn), tree[1])
     if kind == "indexed":
         return Indexed(unflatten(tree[1], fn), unflatten(tree[2], fn))
+    if kind == "trace":
+        from . import static as S
+        tk, gf = tree[1], _static_value(tree[2][1])
+        args = unflatten(tree[3], fn) if tree[3] is not None else None
+        if tk == "dist":
+            return S.DistributionTrace(gf, args, unflatten(tree[4], fn), unflatten(tree[5], fn))
+        if tk == "vmap":
+            return S.VmapTrace(gf, unflatten(tree[4], fn), unflatten(tree[5], fn), unflatten(tree[6], fn), args)
+        subs = OrderedDict((a, unflatten(t, fn)) for a, t in tree[5])
+        return S.StaticTrace(gf, args, unflatten(tree[4], fn), subs)
     if kind == "dc":
         return _make_dataclass(payload, {name: (_static_value(t[1]) if t[0] == "static_field" else unflatten(t, fn)) for name, t in tree[2]})
     raise ValueError(kind)

@@ -410,7 +410,35 @@ def logical_not(a):
     return ~a if _is_torch(a) else np.logical_not(a)
 
 
+def _sum_loop(x, n):
+    """`jnp.sum` of a LONG vector that is readable at a run-time index (the values a large plate / a long scan / a long
+    vector-valued site left in memory, a launch-uniform table, a lazy expression of them): ONE counted loop adding
+    element t to a loop-carried sum — element order, the order the unrolled form adds in (oracle: sum_vector), so a plate
+    of 1000 elements costs two instructions per element instead of 1000 registers (ref: vmap.py:180-191 hands back plain
+    stacked arrays; `jnp.sum` over them is what 3_speed_gains.ipynb c4 does)."""
+    g = T.current_graph()
+    dt = getattr(x, "_dt", None)
+    if dt is None:
+        try:
+            dt = T.lift(T._elem(x, 0)).dtype          # (dead code afterwards: one element's expression, never stored)
+        except NotImplementedError:
+            dt = "f32"
+    isf = dt == "f32"
+    acc = g.loop_var(g.const_f32(0.0) if isf else g.const_i32(0))
+    g.loop_begin(n)
+    t = Expr(g.add("LDT", dtype="i32"))
+    v = T.lift(T._elem(x, t))
+    v = T.as_float(v) if isf else T.as_int(v)
+    g.set_vars([(acc, (Expr(acc) + v).node)])
+    g.loop_end()
+    return Expr(acc)
+
+
 def sum(x, axis=None):        # noqa: A001
+    if T.is_tracing() and axis in (None, 0, -1):
+        n = T._long_vector(x)
+        if n and len(T.current_graph().loop_counts) < 3 and not getattr(x, "vector_site", False):
+            return _sum_loop(x, n)
     if is_symbolic(x):
         a = np.asarray(x, dtype=object)
         if axis is None:
@@ -445,6 +473,8 @@ def sum(x, axis=None):        # noqa: A001
 
 
 def mean(x, axis=None):
+    if T.is_tracing() and axis in (None, 0, -1) and T._long_vector(x):
+        return sum(x, axis) / float(T._long_vector(x))
     if is_symbolic(x):
         a = np.asarray(x, dtype=object)
         n = a.size if axis is None else a.shape[axis]

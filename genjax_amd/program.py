@@ -211,6 +211,9 @@ class Graph:
 
     def set_var(self, var: Node, value: Node):
         self.add("SETVAR", (var, value), dtype="none")
+        # (what a loop-carried value is computed FROM: its LOOPVAR node names the initial value only —
+        #  static._depends follows these so that `jnp.sum(xs)` over a changed `xs` is seen to change)
+        self.__dict__.setdefault("_var_updates", {}).setdefault(var.idx, []).append(value)
 
     def set_vars(self, pairs):
         """The loop-carried update as a PARALLEL copy: every new value is what it was BEFORE any variable of the group

@@ -116,6 +116,8 @@ class StaticTrace(Trace):
             return 0.0
         if len(scores) == 1:
             return scores[0]
+        if T.is_tracing() and T.is_symbolic(scores):       # a trace handed to a `@gen` function as an argument
+            return _sum_in_order(*scores)
         from .engine import elementwise
         return elementwise(_sum_in_order, *scores)
 
@@ -622,8 +624,9 @@ def _capture_fp(gf, depth):
 _KEEP: list = []
 
 
-def _depends(node, changed: set, memo: dict, table_changed=None) -> bool:
-    """Does `node` depend on any node in `changed` — or read a table flagged changed? (incremental.py change propagation)"""
+def _depends(node, changed: set, memo: dict, table_changed=None, var_updates=None) -> bool:
+    """Does `node` depend on any node in `changed` — or read a table flagged changed? (incremental.py change propagation)
+    A loop-carried value depends on what its iterations assign to it (program.Graph.set_var)."""
     stack = [node]
     seen = []
     while stack:
@@ -645,6 +648,8 @@ def _depends(node, changed: set, memo: dict, table_changed=None) -> bool:
         memo[n.idx] = False      # provisional; flipped to True above if a dependency is found
         seen.append(n.idx)
         stack.extend(a for a in n.args if a is not None)
+        if n.op == "LOOPVAR" and var_updates:
+            stack.extend(var_updates.get(n.idx, ()))
     return False
 
 
@@ -738,7 +743,8 @@ class _Ctx:
 
     def args_changed(self, args) -> bool:
         tab = self._table_changed if (self.changed_slots or self.changed_tables or self.changed_in_slots) else None
-        return any(_depends(n, self.changed, self.memo, tab) for n in _nodes_of(args))
+        vu = self.tr.graph.__dict__.get("_var_updates")
+        return any(_depends(n, self.changed, self.memo, tab, vu) for n in _nodes_of(args))
 
 
 class _SiteRec:

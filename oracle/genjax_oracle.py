@@ -1113,7 +1113,8 @@ class Vmap:
                 out.append(a[..., None] if a.ndim >= len(batch) and a.shape[: len(batch)] == tuple(batch) and len(batch) else a)
             else:
                 a = np.asarray(a)
-                if len(batch) and a.shape[: len(batch)] != tuple(batch):
+                if len(batch) and (a.shape[: len(batch)] != tuple(batch) or a.ndim == len(batch)):
+                    # (a.ndim == len(batch): no room for a plate axis behind the batch — a plate as long as the batch)
                     # a launch-uniform mapped argument [n_plate, ...]: laid out as [*batch, n_plate, ...], so that the
                     # inner function — which runs with the plate as one more batch axis — sees a per-element value and
                     # not a vector-valued argument (a sampler would take the plate axis for an event axis)

@@ -311,6 +311,17 @@ def _readable(tr, v, n):
     return tr.alias_step_input(v.origin, dt, int(n))
 
 
+def _mask_flat(v):
+    """a return-value tree with every Mask opened into (value, flag): what _Ctx.mark_changed walks"""
+    if isinstance(v, Mask):
+        return (_mask_flat(v.value), _mask_flat(v.flag))
+    if isinstance(v, (tuple, list)):
+        return tuple(_mask_flat(x) for x in v)
+    if isinstance(v, dict):
+        return {k: _mask_flat(x) for k, x in v.items()}
+    return v
+
+
 def _has_step_rows(tree):
     """does a previous-trace tree hold [n, A, T] step leaves (engine.StepInput2: the values of loops INSIDE a plate) — or,
     inside a counted loop, launch-uniform tables with a long last axis (the same values given as one [.., n, m] table:
@@ -659,6 +670,10 @@ class Vmap(GenerativeFunction):
             return v
         zero = g.const_f32(0.0)
         wvar, svar = g.loop_var(zero), g.loop_var(zero)
+        # did this edit change anything the plate RETURNS?  (its return values are readable by the model afterwards —
+        # _readable — through an input slot of their own, which the change propagation must then see as changed)
+        mark0 = (len(ctx.changed), len(ctx.changed_slots), len(ctx.changed_tables), len(ctx.changed_in_slots))
+        touched = kind == "index" or ctx.args_changed(args)
         g.loop_begin(n)
         with T.tracing(g):
             t = Expr(g.add("LDT", dtype="i32"))
@@ -741,10 +756,18 @@ class Vmap(GenerativeFunction):
             g.set_vars(updates)
         g.loop_end()
         ctx.store_sites, ctx.sites_deferred = keep, was_deferred
+        touched = touched or mark0 != (len(ctx.changed), len(ctx.changed_slots), len(ctx.changed_tables),
+                                       len(ctx.changed_in_slots))
+
+        def readable(v):
+            r = _readable(tr, v, n)
+            if touched:
+                ctx.mark_changed(_mask_flat(r))
+            return r
         if isinstance(rec, _SiteRec):
             # a bare distribution's plate stays one vector-valued site: values [T], score = the new plate sum
             out = _SiteRec(rec.gen_fn, rec.value, Expr(svar), rec.discard)
-            return out, _readable(tr, rec.value, n), Expr(wvar), None
+            return out, readable(rec.value), Expr(wvar), None
 
         def drop_retvals(r):
             if isinstance(r, _CallRec):
@@ -756,7 +779,7 @@ class Vmap(GenerativeFunction):
         out.sites = rec.sites
         out.retval = rets
         out.plate_score = Expr(svar)
-        return out, _readable(tr, rets, n), Expr(wvar), None
+        return out, readable(rets), Expr(wvar), None
 
     def _trace_edit(self, ctx, mode, key, args, constraint, prev, req, req_leaves, addr):
         """Vmap.edit (vmap.py:334-362): `Update(constraint)` edits every element with keys split(key, n)
@@ -1758,6 +1781,12 @@ class Scan(GenerativeFunction):
                 return ("dict", {k: flat_carry(x, out) for k, x in v.items()})
             if isinstance(v, np.ndarray) and v.dtype == object:
                 return ("array", v.shape, [flat_carry(x, out) for x in v.reshape(-1)])
+            if hasattr(v, "shape") and tuple(v.shape) != () and not isinstance(v, Expr):
+                # a CONCRETE array as (part of) the initial carry — `step.scan(n=20)(jnp.zeros(2), None)`, scan.py:200-294
+                # takes any pytree: its elements are constants of the program, the carry an array of that shape
+                a = np.asarray(v.cpu() if hasattr(v, "cpu") else v)
+                a = a.astype(np.float32) if a.dtype.kind == "f" else (a.astype(np.bool_) if a.dtype.kind == "b" else a.astype(np.int32))
+                return ("array", a.shape, [flat_carry(x.item(), out) for x in a.reshape(-1)])
             out.append(T.lift(v))
             return ("leaf", len(out) - 1)
 
@@ -1879,6 +1908,7 @@ class Scan(GenerativeFunction):
             out.sites = rec.sites
             out.retval = retval
             out.plate_score = score
+        retval = (retval[0], _readable(tr, ys, n))      # the stacked outputs as the MODEL sees them: readable (scan.py:221-233)
         if mode in ("simulate", "assess"):
             return out, retval, None, score
         return out, retval, Expr(wvar), None
@@ -1924,7 +1954,10 @@ class Scan(GenerativeFunction):
         for t in range(n):
             if key is not None and sub_mode != "index":
                 key = Expr(g.add("KDERIVE", (key.node,), imm=t, dtype="key"))
-            prev_t = _index_prev(inner_prev, t)
+            # (the scan's own return value — final carry and stacked outputs — is not a per-step leaf: a carry that is an
+            #  ARRAY has its own leading axis, which is not the step axis)
+            prev_t = _index_prev({k_: (None if k_ == "retval" else v_) for k_, v_ in inner_prev.items()}
+                                 if isinstance(inner_prev, dict) else inner_prev, t)
             if sub_mode == "index":
                 # edit_index (scan.py:325-416): the sub-request acts on step idx with the caller's key; the
                 # carries are threaded on, so the steps after it are re-scored exactly where the edit
@@ -2010,6 +2043,12 @@ class Scan(GenerativeFunction):
                 return (type(v).__name__, [flat_carry(x, out) for x in v])
             if isinstance(v, np.ndarray) and v.dtype == object:
                 return ("array", v.shape, [flat_carry(x, out) for x in v.reshape(-1)])
+            if hasattr(v, "shape") and tuple(v.shape) != () and not isinstance(v, Expr):
+                # a CONCRETE array as (part of) the initial carry — `step.scan(n=20)(jnp.zeros(2), None)`, scan.py:200-294
+                # takes any pytree: its elements are constants of the program, the carry an array of that shape
+                a = np.asarray(v.cpu() if hasattr(v, "cpu") else v)
+                a = a.astype(np.float32) if a.dtype.kind == "f" else (a.astype(np.bool_) if a.dtype.kind == "b" else a.astype(np.int32))
+                return ("array", a.shape, [flat_carry(x.item(), out) for x in a.reshape(-1)])
             out.append(T.lift(v))
             return ("leaf", len(out) - 1)
 
@@ -2178,7 +2217,10 @@ class Scan(GenerativeFunction):
         out.sites = rec.sites
         out.retval = retval
         out.plate_score = Expr(svar)
-        return out, retval, Expr(wvar), None
+        ys_r = _readable(tr, ys, n)
+        if ys_r is not ys:          # (an edit may have changed what the steps put out: their reads are marked so)
+            ctx.mark_changed(_mask_flat(ys_r))
+        return out, (retval[0], ys_r), Expr(wvar), None
 
     def edit(self, key, trace, edit_request, argdiffs):
         from .static import run_edit

@@ -201,7 +201,10 @@ static int parse_program(const uint32_t* blob, size_t n_words, gmx_program& P) {
       case OP_LOOP: ok = loop_depth < 3 && w1 >= 1u; ++loop_depth; in_loop = true; P.uses_loop = true; break;   // counted, <= 3 deep
       case OP_ENDLOOP: ok = loop_depth > 0; --loop_depth; in_loop = loop_depth > 0; break;
       case OP_UNI: ok = D(dst) && w1 < P.n_uni; break;
-      case OP_LDIN: ok = D(dst) && a < P.n_in; if (b & GMX_F_GATHER) P.uses_gather = true; break;
+      case OP_LDIN:
+        ok = D(dst) && a < P.n_in && (!(b & GMX_F_IDX) || (R(c) && !(b & (GMX_F_STEP | GMX_F_FLAT | GMX_F_BCAST))));
+        if (b & GMX_F_GATHER) P.uses_gather = true;
+        break;
       case OP_LDTAB: ok = D(dst) && R(b) && a < P.n_tab; break;
       case OP_STOUT: ok = R(b) && a < P.n_out; break;
       case OP_LDKEY: ok = R2(dst); P.uses_key = true; break;
@@ -232,9 +235,8 @@ static int parse_program(const uint32_t* blob, size_t n_words, gmx_program& P) {
         break;
       default: ok = false;
     }
-    if ((op == OP_LDIN && (b & GMX_F_STEP)) || (op == OP_STOUT && (dst & GMX_F_STEP))) {
-      P.uses_step = true;
-      if (op == OP_STOUT && !in_loop) ok = false;   // a step-indexed store writes element t: inside the loop only
+    if ((op == OP_LDIN && (b & (GMX_F_STEP | GMX_F_IDX))) || (op == OP_STOUT && (dst & GMX_F_STEP))) {
+      P.uses_step = true;      // (a step-indexed store outside a loop writes element imm: t = 0 there)
     }
     if (!ok) return gmx_fail("gmx_program_create: invalid instruction%s at pc %lld", "", pc);
   }
@@ -310,7 +312,7 @@ static std::string jit_source(const gmx_program* p, bool* gathers_prefetched = n
     const uint32_t w0 = p->code_h[2 * pc], op = w0 & 0xffu, a = (w0 >> 16) & 0xffu, b = w0 >> 24;
     if ((op == OP_LDKEY || op == OP_KDERIVE) && first_key_pc == p->n_instr && !seen_loop) first_key_pc = pc;
     if (op == OP_LOOP) seen_loop = true;          // a key derived inside the loop is no place for one-off prefetches
-    if (op != OP_LDIN || (b & (GMX_F_BCAST | GMX_F_STEP))) continue;     // step-indexed rows change with t: loaded in place
+    if (op != OP_LDIN || (b & (GMX_F_BCAST | GMX_F_STEP | GMX_F_IDX))) continue;     // step- / register-indexed rows: loaded in place
     int k = -1;
     for (size_t j = 0; j < pres.size(); ++j)
       if (pres[j].slot == a && pres[j].flags == b) k = (int)j;

@@ -60,13 +60,19 @@
                            t0 * n1 + t1 two deep (element (t0, t1) of a [T0, T1, n] leaf: a plate of scans),
                            (t0 * n1 + t1) * n2 + t2 three deep.  In an outermost loop it is the same as GMX_F_STEP alone. */
 
+#define GMX_F_IDX 32u   /* row += ((int) r[imm & 0xff] + (imm >> 8)) * step_stride: element of a [T, n] leaf chosen by a
+                           REGISTER (or pool entry) at run time — `means[z]` with z a draw — at any loop depth; the loop's
+                           iteration number takes no part (not combined with GMX_F_STEP / GMX_F_FLAT).  The encoder clamps
+                           the index to the leaf (jax clamps a gather's indices; and no lane may read outside its rows). */
+
 enum gmx_op {
   OP_END = 0,
   OP_CONST = 1,   // r[dst] = imm
   OP_UNI = 2,     // r[dst] = uni[imm]
-  OP_LDIN = 3,    // r[dst] = in[a][row], flags in b (GMX_F_STEP: imm = element offset)
+  OP_LDIN = 3,    // r[dst] = in[a][row], flags in b (GMX_F_STEP: imm = element offset; GMX_F_IDX: imm = index reg | offset << 8)
   OP_LDTAB = 4,   // r[dst] = tab[a][(int)r[b] + (int)imm]
-  OP_STOUT = 5,   // out[a][i] = r[b], flags in dst
+  OP_STOUT = 5,   // out[a][i] = r[b], flags in dst (GMX_F_STEP: element t + imm of a [T, n] leaf — outside a loop t = 0,
+                  // so imm alone names the element: K registers spilled into one [K, n] scratch leaf)
   OP_LDKEY = 6,   // (r[dst], r[dst+1]) = particle key
   OP_KDERIVE = 7, // (r[dst], r[dst+1]) = threefry(key r[a..a+1], ctr (0, imm))  == fold_in / split child
   OP_KDERIVER = 8,// same with ctr (0, (uint)r[b])

@@ -98,7 +98,8 @@ GMX_HD void gmx_vm_step(Regs& R, const W w, int64_t i, bool active, const gmx_ru
           int64_t row = i;
           if (b & GMX_F_GATHER) row = (int64_t)A.ancestors_d[i];
           if (b & GMX_F_BCAST) row = 0;
-          if (b & GMX_F_STEP) row += (int64_t)(((b & GMX_F_FLAT) ? tf : t) + w1) * A.step_stride;   // element t + imm of a [T, n] leaf
+          if (b & GMX_F_IDX) row += (int64_t)((int32_t)SRC(c) + (int32_t)e) * A.step_stride;        // element r[c] + e: chosen at run time
+          else if (b & GMX_F_STEP) row += (int64_t)(((b & GMX_F_FLAT) ? tf : t) + w1) * A.step_stride;   // element t + imm of a [T, n] leaf
           const void* p = ctx.in_ptr(a);
           if (b & GMX_F_U8) r0 = (uint32_t)((const uint8_t*)p)[row];
           else r0 = ((const uint32_t*)p)[row];
@@ -116,7 +117,7 @@ GMX_HD void gmx_vm_step(Regs& R, const W w, int64_t i, bool active, const gmx_ru
         uint32_t v = SRC(b);
         if (active) {
           void* p = ctx.out_ptr(a);
-          const int64_t orow = (dst & GMX_F_STEP) ? i + (int64_t)((dst & GMX_F_FLAT) ? tf : t) * A.step_stride : i;
+          const int64_t orow = (dst & GMX_F_STEP) ? i + (int64_t)(((dst & GMX_F_FLAT) ? tf : t) + w1) * A.step_stride : i;
           if (dst & GMX_F_U8) ((uint8_t*)p)[orow] = (uint8_t)(v != 0u);
           else ((uint32_t*)p)[orow] = v;
         }

@@ -320,10 +320,55 @@ class _Categorical(Distribution):
         if shape is None or shape == ():
             return args
         n = int(shape[0] if isinstance(shape, (tuple, list)) else shape)
-        if n > 64:
-            raise NotImplementedError(f"categorical(sample_shape={n}): under a batch of keys the draws of one site are "
-                                      "unrolled (<= 64); ONE trace runs them on the launch axis (sitewise.py)")
         return args + (("sample_shape", n),)
+
+    SAMPLE_SHAPE_LOOP_MIN = 17      # draws of one site from which they run as a counted loop (static._vector_site_loop)
+    SPILL_MIN = 24                  # computed logits beyond this many are read from memory inside that loop
+
+    def loop_site(self, args):
+        """`categorical(logits, sample_shape=n)` with MANY draws at one site (the n assignments of
+        7_application_dirichlet_mixture_model.ipynb c6) as the body of ONE counted loop per particle: draw j takes the
+        gumbel counters j * K .. j * K + K - 1 of the one site key, as the unrolled form does; its log-probability is
+        logits[idx_j] - logsumexp(logits), added in draw order.  Returns (n, sample(key, t), logpdf(x, t)) — built
+        BEFORE the loop opens (the logits and their normaliser are loop-invariant) — or None for a site that stays
+        unrolled."""
+        n = args[1][1] if len(args) == 2 and isinstance(args[1], tuple) and args[1][:1] == ("sample_shape",) else None
+        if n is None or n < self.SAMPLE_SHAPE_LOOP_MIN:
+            return None
+        from . import numpy as jnp
+        g = current_graph()
+        l = args[0]
+        long = T._long_vector(l)
+        if not long and (isinstance(l, np.ndarray) and l.ndim != 1):
+            return None
+        ls = [T.as_float(T._elem(l, k)) for k in range(long)] if long else self._logits(args[:1])
+        K = len(ls)
+        lse = jnp.logsumexp(np.asarray(ls, dtype=object))
+        mem = None
+        if not long and K > self.SPILL_MIN and not g.loop_counts and getattr(g, "_tracing", None) is not None:
+            # many logits COMPUTED in registers (jnp.log of a Dirichlet draw of 64 weights): K values alive across the
+            # loop would not fit a launch — they go to memory once (Tracing.spill_vector) and each use is one load
+            mem = g._tracing.spill_vector(ls)
+
+        def sample(key, t):
+            base = T.as_int(t) * K
+            state = None
+            for k, lk in enumerate(ls):
+                lk = mem.read_in_loop(k) if mem is not None else lk
+                state = g.add("S_CATSTEP", (state, key.node, lk.node, (base + k).node), imm=k, dtype="cat")
+            return Expr(g.add("CATIDX", (state,), dtype="i32"))
+
+        def logpdf(x, t):
+            vi = T.as_int(x)
+            if long:
+                return T.as_float(T._elem(l, vi)) - lse          # one read of the logits at the drawn index
+            if mem is not None:
+                return mem[vi] - lse
+            picked = ls[0]
+            for k in range(1, K):
+                picked = T.where(vi == k, ls[k], picked)
+            return picked - lse
+        return n, sample, logpdf
 
     ROWS_MAX = 64      # rows of logits at one site under a batch of keys: unrolled
 
@@ -479,13 +524,19 @@ class _Dirichlet(Distribution):
         from . import numpy as jnp
         al = self._conc(args)
         x = v if isinstance(v, np.ndarray) else np.asarray(v, dtype=object)
-        terms = []
+        # (each term is added where it is computed — the sums of _seq_sum, in program order: 64 components keep ONE
+        #  register, not 64 until the end)
+        acc = None
         for ak, xk in zip(al, x.reshape(-1)):
             am = ak - 1.0
-            terms.append(T.where(am == 0.0, 0.0, am * jnp.log(T.as_float(xk))))      # xlogy(a - 1, x)
-        lg = [jnp.lgamma(ak) for ak in al]
-        lbeta = _seq_sum(lg) - jnp.lgamma(_seq_sum(al))
-        return _seq_sum(terms) - lbeta
+            term = T.where(am == 0.0, 0.0, am * jnp.log(T.as_float(xk)))      # xlogy(a - 1, x)
+            acc = term if acc is None else acc + term
+        lgs = None
+        for ak in al:
+            lg = jnp.lgamma(ak)
+            lgs = lg if lgs is None else lgs + lg
+        lbeta = lgs - jnp.lgamma(_seq_sum(al))
+        return acc - lbeta
 
 
 def exact_density(sample, logpdf, name="exact_density"):

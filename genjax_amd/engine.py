@@ -556,6 +556,7 @@ class NoiseHoist:
 class Tracing:
     def __init__(self, batch_ndim: int):
         self.graph = Graph()
+        self.graph._tracing = self     # (distributions reach the launch plan through the graph: Tracing.spill_vector)
         self.in_plan = []      # (slot, leaf, elem, kind)
         self.uni_plan = []     # (uni index, leaf, elem, dtype)
         self.tab_plan = []     # (table slot, leaf): launch-uniform device tables
@@ -592,6 +593,24 @@ class Tracing:
                                           "loop of another site of the same length")
             return Expr(g.add("LDIN", dtype=dt, flags=flags, slot=slot))
         return StepOutputAlias(origin, int(T), len(self.outputs[origin[1]][1]), read)
+
+    def spill_vector(self, exprs, dt="f32"):
+        """K values held in registers, SPILLED: stored once as the K elements of one [K, n] scratch output of this launch
+        (OP_STOUT flagged GMX_F_STEP with a static element) and read back where they are used — inside a counted loop as
+        one load each (StepInput.read_in_loop) instead of K registers alive across the loop: the 64 log-probabilities of
+        a mixture's `categorical(jnp.log(probs), sample_shape=n)` next to a loop over the n draws.  Top level only."""
+        from .program import F_STEP, F_U8
+        g = self.graph
+        if g.loop_counts:
+            raise NotImplementedError("spill_vector inside a counted loop")
+        slot = g.n_out
+        g.n_out += 1
+        flags = F_STEP | (F_U8 if dt == "bool" else 0)
+        for k, e in enumerate(exprs):
+            g.add("STOUT", (e.node,), imm=k << 8, dtype="none", flags=flags, slot=slot)
+        o = ("out", len(self.outputs))
+        self.outputs.append((dt, (len(exprs),), ("step", slot, 1)))
+        return self.alias_step_input(o, dt, len(exprs))
 
     # leaves -> symbols ------------------------------------------------------
     def sym_leaf(self, spec, j) -> Sym:
@@ -824,28 +843,27 @@ class StepInput(np.ndarray):
 
     def _read_at(self, idx):
         """element `idx` — a TRACED index that is not a loop's iteration number (`mus[z]` with z a categorical draw) — of a
-        [T, n] leaf: GMX_F_STEP addresses with the loop counter only, so the read is a search, one counted loop of T
-        iterations that keeps the element whose number equals idx (an index past the end keeps the last, as jax clamps)"""
+        [T, n] leaf: ONE load at a register index (OP_LDIN flagged GMX_F_IDX), at any loop depth.  A negative index wraps
+        once, then the index is clamped to the leaf (jax wraps and clamps a gather's indices the same way; no lane may
+        read outside its own rows)."""
+        from .program import F_U8
         from .tracer import as_int, where
         g = self._g
-        if g.loop_counts:
-            raise NotImplementedError("a traced index into a per-particle vector of more than 16 elements inside a plate / "
-                                      "scan loop: index a launch-uniform table, or keep the vector to 16 elements")
         n = int(self.shape[0])
         i = as_int(idx)
         i = where(i < 0, i + n, i)
-        # (starts from the LAST element's own read: what an index past the end keeps — and one of the leaf's element
-        # nodes, so that a changed leaf is seen to change what is read from it: static._Ctx.args_changed)
-        last = np.ndarray.__getitem__(self, n - 1)
-        acc = g.loop_var(last.node)
-        g.loop_begin(n - 1)
-        t = Expr(g.add("LDT", dtype="i32"))
-        v = Expr(g.add("LDIN", dtype=self._dt, flags=self._flags, slot=self._slot, imm=int(self._base or 0)))
-        g.set_vars([(acc, where(i == t, v, Expr(acc)).node)])
-        g.loop_end()
-        # (a loop variable's node names its initial value only: the result is a select on the INDEX as well, so that a
-        # changed index is seen to change what is read — the same value either way)
-        return where(i == n - 1, last, Expr(acc))
+        i = where(i > n - 1, n - 1, i)
+        i = where(i < 0, 0, i)
+        return Expr(g.add("LDINX", (i.node,), imm=int(self._base or 0), dtype=self._dt,
+                          flags=(F_U8 if self._dt == "bool" else 0), slot=self._slot))
+
+    def read_in_loop(self, k: int):
+        """element k (a Python int) read INSIDE a counted loop: a GMX_F_STEP read there means element t + k, so the static
+        element goes through the register-indexed form with a constant index (a pool entry: no register)"""
+        from .program import F_U8
+        g = self._g
+        return Expr(g.add("LDINX", (g.const_i32(0),), imm=int(self._base or 0) + int(k), dtype=self._dt,
+                          flags=(F_U8 if self._dt == "bool" else 0), slot=self._slot))
 
     def __getitem__(self, idx):
         if isinstance(idx, tuple) and self.ndim == 1:          # `xs[..., 1:]` of a vector is `xs[1:]`

@@ -538,6 +538,32 @@ class _Lax:
 
 
 def _tree_where(pred, a, b):
+    from .core.choice_map import ChoiceMap
+    from .core.generative import Trace
+    if isinstance(a, Trace) and not T.is_tracing():
+        # `jax.lax.cond(accept, lambda: new_trace, lambda: trace)` (mcmc.ipynb c8): traces are pytrees — a select per leaf
+        from .combinators import _trace_leaf_zip
+        from .engine import materialize
+
+        def pick(old, new):
+            old, new = materialize(old), materialize(new)
+            if not _is_torch(new) and not _is_torch(old):
+                return new if (isinstance(pred, (bool, np.bool_)) and pred) else (old if isinstance(pred, (bool, np.bool_)) else new)
+            t = new if _is_torch(new) else old
+            new = new if _is_torch(new) else torch.as_tensor(new, device=t.device).to(t.dtype).expand(t.shape)
+            old = old if _is_torch(old) else torch.as_tensor(old, device=t.device).to(t.dtype).expand(t.shape)
+            c = pred if _is_torch(pred) else torch.as_tensor(pred, device=t.device)
+            c = c.reshape(tuple(c.shape) + (1,) * (new.dim() - c.dim()))
+            return torch.where(c if c.dtype == torch.bool else c != 0, new, old.to(new.dtype))
+        return _trace_leaf_zip(b, a, pick, args=a.get_args())
+    if isinstance(a, ChoiceMap) and isinstance(b, ChoiceMap):
+        # (3_speed_gains.ipynb c15 returns one of two choice maps with the same addresses)
+        out = ChoiceMap.empty()
+        for addr in a.addresses():
+            va = a[addr] if addr else a.get_value()
+            vb = b[addr] if addr else b.get_value()
+            out = out.set(addr, where(pred, va, vb)) if addr else ChoiceMap.choice(where(pred, va, vb))
+        return out
     if isinstance(a, (tuple, list)):
         return type(a)(_tree_where(pred, x, y) for x, y in zip(a, b))
     if isinstance(a, dict):

@@ -20,7 +20,7 @@ MAGIC = 0x50584D47
 VERSION = 2
 MAX_REGS = 64          # operand codes below POOL_BASE; more than 31 needs the specialised kernel (no interpreter build)
 
-F_GATHER, F_U8, F_BCAST, F_STEP, F_FLAT = 1, 2, 4, 8, 16
+F_GATHER, F_U8, F_BCAST, F_STEP, F_FLAT, F_IDX = 1, 2, 4, 8, 16, 32
 
 # opcode numbers: keep in sync with gmx_program.h
 OPC = dict(
@@ -52,7 +52,9 @@ EFFECT = {"STOUT", "REDMAX", "REDLSE", "LOOP", "ENDLOOP", "SETVAR"}
 # LOOPVAR (args = (init,)): a value carried across the iterations of a counted loop — one register (two for a
 # key) initialised before OP_LOOP, read inside the block, overwritten by SETVAR (args = (var, new value)) and
 # readable after OP_ENDLOOP.  LDT: the iteration number.
-_NO_CSE = EFFECT | {"LDIN", "UNI", "CONST", "S_CATSTEP", "CATIDX", "LOOPVAR", "LDT", "COPY"}     # slots are unique; CONSTs have their own table
+# LDINX (args = (index,), slot, imm = element offset): OP_LDIN flagged GMX_F_IDX — element `index + imm` of a [T, n] leaf,
+# the index a register: `means[z]` on a per-particle vector in memory, at any loop depth (engine.StepInput._read_at)
+_NO_CSE = EFFECT | {"LDIN", "LDINX", "UNI", "CONST", "S_CATSTEP", "CATIDX", "LOOPVAR", "LDT", "COPY"}     # slots are unique; CONSTs have their own table
 _FOLD = {"ADD", "SUB", "MUL", "DIV", "SQUARE", "NEG"}
 # values recomputed at every use instead of being held in a register (see compile_graph)
 REMAT_UNARY = {"LOG", "EXP", "NEG", "SQUARE", "SQRT", "RECIP", "I2F"}
@@ -481,7 +483,8 @@ def compile_graph(g: Graph):
             release(a)
         if op in EFFECT:
             if op == "STOUT":
-                emit(op, n.flags, n.slot, R(n.args[0]) + n.imm)      # imm: which word of a two-register value (split_graph)
+                # imm & 0xff: which word of a two-register value (split_graph); imm >> 8: element offset of a step store
+                emit(op, n.flags, n.slot, R(n.args[0]) + (n.imm & 0xFF), n.imm >> 8)
             elif op == "LOOP":
                 emit(op, imm=n.imm)
             elif op == "ENDLOOP":
@@ -504,6 +507,8 @@ def compile_graph(g: Graph):
             emit(op, dst, n.slot, n.flags, n.imm)
         elif op == "LDTAB":
             emit(op, dst, n.slot, R(n.args[0]), n.imm)
+        elif op == "LDINX":
+            emit("LDIN", dst, n.slot, n.flags | F_IDX, (R(n.args[0]) & 0xFF) | ((n.imm & 0xFFFFFF) << 8))
         elif op in ("LDKEY", "LDIDX", "LDT"):
             emit(op, dst)
         elif op in ("LOOPVAR", "COPY"):
@@ -683,9 +688,11 @@ def split_graph(g: Graph, max_in: int, max_out: int, max_uni: int, max_tab: int,
                 return put("LDIN", (), n.imm, n.dtype, n.flags, local_in(("in", n.slot)))
             if n.op == "LDTAB":
                 return put("LDTAB", args, n.imm, n.dtype, n.flags, local_tab(n.slot))
+            if n.op == "LDINX":
+                return put("LDINX", args, n.imm, n.dtype, n.flags, local_in(("in", n.slot)))
             if n.op == "STOUT":
                 seg.out_dst.append(("out", n.slot))
-                return put("STOUT", args, 0, "none", n.flags, len(seg.out_dst) - 1)
+                return put("STOUT", args, n.imm & ~0xFF, "none", n.flags, len(seg.out_dst) - 1)
             return put(n.op, args, n.imm, n.dtype, n.flags, n.slot)
 
         def operand(a):
@@ -742,7 +749,7 @@ def split_graph(g: Graph, max_in: int, max_out: int, max_uni: int, max_tab: int,
                     stouts += 1
                 elif n.op == "LDTAB":
                     tabs.add(n.slot)
-                elif n.op == "LDIN":
+                elif n.op in ("LDIN", "LDINX"):
                     ins.add(("in", n.slot))
                 elif n.op == "UNI":
                     unis.add(n.imm)

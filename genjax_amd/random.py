@@ -268,3 +268,34 @@ def fold_in(k: Key, data: int) -> Key:
 
 def key_data(k: Key) -> np.ndarray:
     return k.host()
+
+
+def _draw(dist_name: str, k: Key, shape, a, b):
+    """`jax.random.uniform / normal(key, shape)`: what the distribution site of that name draws under `key` — element j of
+    a vector on counter j (the same kernels the `@gen` sites run, never a host generator)."""
+    from . import distributions as D
+    from .static import run_gfi
+    dist = getattr(D, dist_name)
+    shape = tuple(int(x) for x in (shape if isinstance(shape, (tuple, list)) else (shape,))) if shape not in ((), None) else ()
+    if shape == ():
+        return run_gfi(dist, "simulate", k, (a, b)).get_retval()
+    if len(shape) != 1:
+        raise NotImplementedError("random.uniform / random.normal: shape () or (n,)")
+    import torch
+    n = shape[0]
+    dev = _lib.get().device
+    lo = torch.full((n,), float(a), dtype=torch.float32, device=dev)
+    hi = torch.full((n,), float(b), dtype=torch.float32, device=dev)
+    from .engine import Broadcast
+    return run_gfi(dist, "simulate", k, (Broadcast(lo), Broadcast(hi))).get_retval()
+
+
+def uniform(k: Key, shape=(), minval: float = 0.0, maxval: float = 1.0):
+    """jax.random.uniform(key, shape, minval=0, maxval=1) — `jnp.log(jax.random.uniform(subkey)) < alpha`, the accept test
+    of docs/cookbook/inactive/inference/mcmc.ipynb c8 and 3_speed_gains.ipynb c15"""
+    return _draw("uniform", k, shape, minval, maxval)
+
+
+def normal(k: Key, shape=()):
+    """jax.random.normal(key, shape)"""
+    return _draw("normal", k, shape, 0.0, 1.0)

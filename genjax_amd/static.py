@@ -640,7 +640,7 @@ def _depends(node, changed: set, memo: dict, table_changed=None, var_updates=Non
             return True
         if r is False:
             continue
-        if n.idx in changed or (table_changed is not None and n.op in ("LDTAB", "LDIN") and table_changed(n)):
+        if n.idx in changed or (table_changed is not None and n.op in ("LDTAB", "LDIN", "LDINX") and table_changed(n)):
             memo[n.idx] = True
             for s in seen:
                 memo[s] = True
@@ -724,7 +724,7 @@ class _Ctx:
         slot = getattr(node, "slot", None)
         if slot is None:
             return False
-        if node.op == "LDIN":
+        if node.op in ("LDIN", "LDINX"):
             return slot in self.changed_in_slots
         if slot in self.changed_slots:
             return True
@@ -1050,8 +1050,12 @@ def _vector_site_loop(ctx, mode, dist, key, args, cval, prev, req):
     g, tr = ctx.tr.graph, ctx.tr
     if _VECTOR_SITE_LOOPS_OFF[0]:
         return None
-    if dist.logpdf_op is None or dist.sample_op is None or len(g.loop_counts) >= 3 or getattr(g, "elem_from_index", False):
+    if len(g.loop_counts) >= 3 or getattr(g, "elem_from_index", False):
         return None
+    custom = None        # a distribution with a loop body of its own (categorical's many draws at one site)
+    if dist.logpdf_op is None or dist.sample_op is None:
+        if not hasattr(dist, "loop_site") or len(g.loop_counts) >= 2:
+            return None
     kind = req.kind if req is not None else "empty"
     if mode not in ("simulate", "generate", "assess") and kind not in ("update", "empty"):
         return None
@@ -1061,10 +1065,21 @@ def _vector_site_loop(ctx, mode, dist, key, args, cval, prev, req):
     pv = ps = None
     if mode not in ("simulate", "generate", "assess"):
         pv, ps = prev["value"].value, prev["score"].value
-    operands = list(args) + ([cv] if cv is not None else []) + ([pv] if pv is not None else [])
-    n = T.lazy_length(operands)
-    if n < VECTOR_SITE_LOOP_MIN or not any(T._long_vector(a) for a in operands):
-        return None
+    if dist.logpdf_op is None or dist.sample_op is None:
+        with T.tracing(g):
+            custom = dist.loop_site(args)
+        if custom is None:
+            return None
+        n = int(custom[0])
+        for a in ([cv] if cv is not None else []) + ([pv] if pv is not None else []):
+            if T._long_vector(a) != n:
+                return None
+        operands = []
+    else:
+        operands = list(args) + ([cv] if cv is not None else []) + ([pv] if pv is not None else [])
+        n = T.lazy_length(operands)
+        if n < VECTOR_SITE_LOOP_MIN or not any(T._long_vector(a) for a in operands):
+            return None
     for a in operands:           # every vector operand must be readable at a run-time index
         if isinstance(a, (np.ndarray, list, tuple)) and np.ndim(a) > 0 and not T._long_vector(a):
             return None
@@ -1085,13 +1100,19 @@ def _vector_site_loop(ctx, mode, dist, key, args, cval, prev, req):
     g.loop_begin(n)
     with T.tracing(g):
         t = Expr(g.add("LDT", dtype="i32"))
-        a_t = tuple(T.as_float(T._elem(a, t)) for a in args)
+        a_t = tuple(T.as_float(T._elem(a, t)) for a in args) if custom is None else ()
         if new_value:
-            x_t = Expr(g.add(dist.sample_op, (key.node,) + tuple(a.node for a in a_t), imm=ELEM_LOOP, dtype=dist.value_dtype))
+            if custom is not None:
+                x_t = custom[1](key, t)
+            else:
+                x_t = Expr(g.add(dist.sample_op, (key.node,) + tuple(a.node for a in a_t), imm=ELEM_LOOP, dtype=dist.value_dtype))
             origin = tr.store_step(x_t, n)
         else:
             x_t = dist._conv_value(T._elem(cv if cv is not None else pv, t))
-        s_t = Expr(g.add(dist.logpdf_op, (x_t.node,) + tuple(a.node for a in a_t), dtype="f32"))
+        if custom is not None:
+            s_t = custom[2](x_t, t)
+        else:
+            s_t = Expr(g.add(dist.logpdf_op, (x_t.node,) + tuple(a.node for a in a_t), dtype="f32"))
         g.set_vars([(svar, (Expr(svar) + s_t).node)])
     g.loop_end()
     score = Expr(svar)

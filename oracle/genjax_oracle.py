@@ -658,8 +658,15 @@ class _Categorical(Distribution):
         batch = keys.shape[:-1]
         logits = np.asarray(args[0], np.float32)
         K = logits.shape[-1]
+        if len(args) == 2 and batch != ():
+            # sample_shape = n draws per PARTICLE at one site: draw j / category k on the particle key's gumbel counter
+            # j * K + k — the n draws are n equal rows of logits at the site (the rows form below)
+            n = int(args[1])
+            lg = np.broadcast_to(logits, np.broadcast_shapes(batch + (K,), logits.shape))
+            rows = np.broadcast_to(lg[..., None, :], batch + (n, K))
+            return self._sample(keys, (np.ascontiguousarray(rows),))
         if len(args) == 2:                       # sample_shape = n draws from ONE key
-            if batch != () or logits.ndim != 1:
+            if logits.ndim != 1:
                 raise NotImplementedError("oracle categorical: sample_shape for one trace and one logits vector")
             n = int(args[1])
             out = np.empty(n, dtype=np.int32)
@@ -712,6 +719,15 @@ class _Categorical(Distribution):
         return (picked - np.broadcast_to(lse, shape)).astype(np.float32)
 
     def estimate_logpdf(self, v, args, batch_shape):
+        if len(args) == 2 and tuple(batch_shape) != ():
+            # the n draws of one site per particle, the same logits for every draw: summed in draw order (the build's
+            # counted loop adds in element order at any length under a batch of keys)
+            lg = np.asarray(args[0], np.float32)
+            w = self._logpdf(v, (lg[..., None, :] if lg.ndim == len(tuple(batch_shape)) + 1 else lg,))
+            acc = np.zeros(w.shape[:-1], np.float32)
+            for j in range(w.shape[-1]):
+                acc = (acc + w[..., j]).astype(np.float32)
+            return acc
         w = self._logpdf(v, args[:1])
         if len(args) == 2:                       # the n draws of one site: summed (element order, or the tree from 4096)
             return sum_vector(w)

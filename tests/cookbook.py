@@ -1,0 +1,470 @@
+"""The reference's COOKBOOK as a parity corpus: the models and inference code of four notebooks, typed in
+once against this package (`G`) and once against the CPU oracle (`O`), at the notebooks' own sizes, compared bit for bit.
+
+  docs/cookbook/inactive/update/3_speed_gains.ipynb                         c4 (model), c6, c8 (SIR), c13, c15 (MH move), c10 / c17 (sizes)
+  docs/cookbook/inactive/inference/mcmc.ipynb                               c4 (model), c8 (MH move), c10 (a proposal that takes a TRACE), c12-c16
+  docs/cookbook/inactive/inference/importance_sampling.ipynb                c16 (SIR from model.importance + categorical)
+  docs/cookbook/inactive/expressivity/... 7_application_dirichlet_mixture_model.ipynb   c6 (model), c10 (Gibbs updates), under a BATCH of keys
+
+What the notebooks need from the build beyond round 5 (all reference behaviour, file:line in the code they exercise):
+  * a plate's / a long scan's RETURN values are plain stacked arrays the model computes with (`jnp.sum(a)`, `clusters[idx]`):
+    vmap.py:180-191, scan.py:221-233;
+  * `Vmap.edit` of a bare distribution's plate (`normal.vmap()`) under `model.update`: vmap.py:237-275;
+  * a Trace is a pytree and can be an argument of a `@gen` function: generative_function.py:72-230, static.py:80-119;
+  * `categorical(logits, sample_shape=n)` for any n: tensorflow_probability/__init__.py:52-55;
+  * any pytree as a scan's carry: scan.py:200-294.
+
+This module is test infrastructure: `tests/test_host_logic.py` runs it on the CPU mirror, `tests/test_gpu_parity.py` through the
+C-ABI on the GPU."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from oracle import genjax_oracle as O
+
+f32 = np.float32
+
+
+def npv(v):
+    return v.cpu().numpy() if hasattr(v, "cpu") else np.asarray(v)
+
+
+def same(a, b):
+    a, b = npv(a), np.asarray(b)
+    if a.dtype.kind == "f":
+        b = b.astype(np.float32)
+    return bool(np.array_equal(a, np.broadcast_to(b, a.shape) if b.shape != a.shape and b.size in (1, a.size) and b.ndim <= a.ndim else b))
+
+
+def inorder_sum(x):
+    """`jnp.sum` as the build defines it inside a site program: element order (oracle/genjax_oracle.py::sum_vector below 4096
+    elements; under a batch of keys at any length)"""
+    x = np.asarray(x, np.float32)
+    acc = np.zeros(x.shape[:-1], np.float32)
+    for j in range(x.shape[-1]):
+        acc = (acc + x[..., j]).astype(np.float32)
+    return acc
+
+
+def _keys(seed, N):
+    import genjax_amd as G
+    return (G.key(seed), O.key(seed)) if N is None else (G.split(G.key(seed), N), O.split(O.key(seed), N))
+
+
+# =====================================================================================================================
+# 3_speed_gains.ipynb
+# =====================================================================================================================
+def speed_gains_models(n):
+    import genjax_amd as G
+    from genjax_amd import numpy as jnp
+
+    @G.gen
+    def model(size_model):                                    # c4, as written
+        size_model = size_model.unwrap()
+        x = G.normal(0.0, 1.0) @ "x"
+        a = G.normal.vmap()(jnp.zeros(size_model), jnp.ones(size_model)) @ "a"
+        b = G.normal.vmap()(jnp.zeros(size_model), jnp.ones(size_model)) @ "b"
+        c = G.normal.vmap()(jnp.zeros(size_model), jnp.ones(size_model)) @ "c"
+        obs = G.normal(jnp.sum(a) + jnp.sum(b) + jnp.sum(c) + x, 5.0) @ "obs"
+        return obs
+
+    @G.gen
+    def default_proposal(size_model):                         # c6
+        size_model = size_model.unwrap()
+        _ = G.normal(0.0, 1.0) @ "x"
+        _ = G.normal.vmap()(jnp.zeros(size_model), jnp.ones(size_model)) @ "a"
+        _ = G.normal.vmap()(jnp.zeros(size_model), jnp.ones(size_model)) @ "b"
+        _ = G.normal.vmap()(jnp.zeros(size_model), jnp.ones(size_model)) @ "c"
+        return None
+
+    @G.gen
+    def rejuv_x(x):                                           # c13
+        x = G.normal(x, 1.0) @ "x"
+        return x
+
+    z, o = np.zeros(n, f32), np.ones(n, f32)
+    big = n >= 4096          # ONE trace: the build sums a large plate's values in its fixed tree (numpy.sum / sum_vector)
+
+    def osum(x, one):
+        return O.sum_vector(x) if (one and big) else inorder_sum(x)
+
+    def o_model(one):
+        @O.gen
+        def m():
+            x = O.normal(f32(0.0), f32(1.0)) @ "x"
+            a = O.Vmap(O.normal)(z, o) @ "a"
+            b = O.Vmap(O.normal)(z, o) @ "b"
+            c = O.Vmap(O.normal)(z, o) @ "c"
+            tot = ((osum(a, one) + osum(b, one)).astype(f32) + osum(c, one)).astype(f32) + x
+            return O.normal(tot.astype(f32), f32(5.0)) @ "obs"
+        return m
+
+    @O.gen
+    def o_proposal():
+        _ = O.normal(f32(0.0), f32(1.0)) @ "x"
+        _ = O.Vmap(O.normal)(z, o) @ "a"
+        _ = O.Vmap(O.normal)(z, o) @ "b"
+        _ = O.Vmap(O.normal)(z, o) @ "c"
+        return None
+
+    @O.gen
+    def o_rejuv(x):
+        return O.normal(x, f32(1.0)) @ "x"
+    return (model, default_proposal, rejuv_x), (o_model, o_proposal, o_rejuv)
+
+
+def check_speed_gains_sir(n=100, N=100, seed=0):
+    """c8: `sir(key, N, use_fast, size_model)` both ways — `vmap(model.importance)` over N keys (fast), and
+    `default_proposal.simulate` + two `assess` (slow) — then `categorical.simulate(key, (weights,))` and the gather of the
+    chosen particle's choices.  Choices, weights and the drawn index bit-exact."""
+    import genjax_amd as G
+    from genjax_amd import ChoiceMapBuilder as C
+    from genjax_amd.core.pytree import Const
+    (model, proposal, _), (o_model, o_proposal, _) = speed_gains_models(n)
+    om = o_model(False)
+    size = (Const(n),)
+    key, okey = G.key(seed), O.key(seed)
+    obs, oobs = C["obs"].set(1.0), O.C.d({"obs": f32(1.0)})
+    # fast
+    traces, weights = G.vmap(model.importance, in_axes=(0, None, None))(G.split(key, N), obs, size)
+    otr, ow = om.importance(O.split(okey, N), oobs, ())
+    for a in ("x", "a", "b", "c"):
+        assert same(traces.get_choices()[a], otr.get_choices()[a]), a
+    assert same(weights, ow)
+    idx = G.categorical.simulate(key, (weights,)).get_retval()
+    oidx = O.categorical._sample(okey, (np.asarray(ow, f32),))
+    assert int(idx) == int(oidx)
+    resampled = traces.get_choices()["a"][int(idx)]
+    assert same(resampled, np.asarray(otr.get_choices()["a"])[int(oidx)])
+    # slow: simulate from the proposal, score under proposal and model (the notebook maps `assess` over the particles;
+    # here the same calls are batch polymorphic)
+    ptr = G.vmap(proposal.simulate, in_axes=(0, None))(G.split(key, N), size)
+    optr = o_proposal.simulate(O.split(okey, N), ())
+    chm = ptr.get_choices()
+    q, _ = proposal.assess(chm, size)
+    oq, _ = o_proposal.assess(optr.get_choices(), (), (N,))
+    # (`C["obs"].set(jnp.ones(N) * obs["obs"])` in the notebook, sliced per particle by its vmap over idx: ONE observation
+    #  per particle — here a device tensor with the particle axis; a host array would be a launch-uniform VECTOR)
+    chm_model = chm | C["obs"].set(torch.ones(N, device=weights.device))
+    p, _ = model.assess(chm_model, size)
+    ochm = optr.get_choices().merge(O.C.d({"obs": np.ones(N, f32)})) if hasattr(optr.get_choices(), "merge") else None
+    op, _ = om.assess(ochm, (), (N,))
+    assert same(q, oq) and same(p, op)
+    return dict(idx=int(idx))
+
+
+def check_speed_gains_mh(n=1000, N=None, seed=3):
+    """c15 `metropolis_hastings_move(key, trace, use_fast)`: propose `x` from `rejuv_x`, then the ratio through `model.update`
+    (fast: argdiffs no_change, only `x` and `obs` are visited — the three plates are carried over untouched) and through two
+    `model.assess` (slow), the backward `rejuv_x.assess` of the discard, the accept draw.  ONE trace (the notebook's c17:
+    n = 1000 ... 1e8) or a batch of N chains."""
+    import genjax_amd as G
+    from genjax_amd import ChoiceMapBuilder as C, Diff
+    from genjax_amd.core.pytree import Const
+    (model, _, rejuv_x), (o_model, _, o_rejuv) = speed_gains_models(n)
+    one = N is None
+    om = o_model(one)
+    size = (Const(n),)
+    k, ok_ = _keys(seed, N)
+    trace, _ = model.importance(k, C["obs"].set(1.0), size)
+    otrace, _ = om.importance(ok_, O.C.d({"obs": f32(1.0)}), ())
+    for a in ("x", "a", "b", "c"):
+        assert same(trace.get_choices()[a], otrace.get_choices()[a]), a
+    key, okey = _keys(seed + 1, N)
+    # -- the move, as written
+    model_args = trace.get_args()
+    key, subkey = G.split(key)
+    okey, osub = (O.split(okey)[..., 0, :], O.split(okey)[..., 1, :])
+    fwd_choice, fwd_weight, _ = rejuv_x.propose(subkey, (trace.get_choices()["x"],))
+    ofc, ofw, _ = o_rejuv.propose(osub, (np.asarray(otrace.get_choices()["x"], f32),))
+    assert same(fwd_choice["x"], ofc["x"]) and same(fwd_weight, ofw)
+    key, subkey = G.split(key)
+    okey, osub = (O.split(okey)[..., 0, :], O.split(okey)[..., 1, :])
+    # fast
+    argdiffs = Diff.no_change(model_args)
+    new_tr, weight, _, discard = model.update(subkey, trace, fwd_choice, argdiffs)
+    onew, oweight, odisc = om.update(osub, otrace, ofc, ())
+    assert same(weight, oweight), (npv(weight), np.asarray(oweight))
+    assert same(discard["x"], odisc["x"])
+    assert same(new_tr.get_score(), onew.get_score())
+    bwd, _ = rejuv_x.assess(discard, (fwd_choice["x"],))
+    obwd, _ = o_rejuv.assess(odisc, (np.asarray(ofc["x"], f32),), () if one else (N,))
+    assert same(bwd, obwd)
+    alpha_fast = weight - fwd_weight + bwd
+    # slow
+    chm = trace.get_choices()
+    w_old, _ = model.assess(chm, model_args)
+    w_new, _ = model.assess(fwd_choice | chm, model_args)
+    ow_old, _ = om.assess(otrace.get_choices(), (), () if one else (N,))
+    ow_new, _ = om.assess(ofc.merge(otrace.get_choices()), (), () if one else (N,))
+    assert same(w_old, ow_old) and same(w_new, ow_new)
+    old_x = C["x"].set(chm["x"])
+    bwd2, _ = rejuv_x.assess(old_x, (fwd_choice["x"],))
+    assert same(bwd2, obwd)
+    alpha_slow = w_new - w_old - fwd_weight + bwd2
+    # the accept draw: jnp.log(uniform(subkey)) < alpha
+    key, subkey = G.split(key)
+    okey, osub = (O.split(okey)[..., 0, :], O.split(okey)[..., 1, :])
+    u = G.random.uniform(subkey)
+    assert same(u, O.random_uniform(osub, ()))
+    # jax.lax.cond(jnp.log(u) < alpha, lambda: fwd_choice, lambda: old_choice)
+    from genjax_amd import numpy as jnp
+    ret = jnp.lax.cond(jnp.log(u) < alpha_fast, lambda: fwd_choice, lambda: old_x)
+    oacc = O.log(np.asarray(O.random_uniform(osub, ()), f32)) < ((np.asarray(oweight, f32) - np.asarray(ofw, f32)).astype(f32) + np.asarray(obwd, f32)).astype(f32)
+    assert same(ret["x"], np.where(oacc, np.asarray(ofc["x"], f32), np.asarray(otrace.get_choices()["x"], f32)))
+    return dict(alpha_fast=npv(alpha_fast), alpha_slow=npv(alpha_slow))
+
+
+# =====================================================================================================================
+# mcmc.ipynb
+# =====================================================================================================================
+def check_mcmc_notebook(N=None, steps=6, seed=0):
+    """c4-c16: linear model `y ~ normal(a x + b, 1)`, a custom proposal `prop(tr, *_)` that reads `tr.get_choices()["a"]` from
+    the TRACE it is handed, `metropolis_hastings_move` (propose -> update -> assess the discard on the NEW trace -> accept),
+    chained `steps` times as `jax.lax.scan` does; every step's weights, the accept decisions and the final choices bit-exact.
+    N: None = the notebook's one chain, else a batch of chains."""
+    import genjax_amd as G
+    from genjax_amd import ChoiceMapBuilder as C, Diff
+    from genjax_amd import numpy as jnp
+
+    @G.gen
+    def model(x):
+        a = G.normal(0.0, 5.0) @ "a"
+        b = G.normal(0.0, 1.0) @ "b"
+        y = G.normal(a * x + b, 1.0) @ "y"
+        return y
+
+    @G.gen
+    def prop(tr, *_):
+        orig_a = tr.get_choices()["a"]
+        a = G.normal(orig_a, 1.0) @ "a"
+        return a
+
+    @O.gen
+    def o_model(x):
+        a = O.normal(f32(0.0), f32(5.0)) @ "a"
+        b = O.normal(f32(0.0), f32(1.0)) @ "b"
+        return O.normal((a * x).astype(f32) + b, f32(1.0)) @ "y"
+
+    @O.gen
+    def o_prop(tr, *_):
+        orig_a = np.asarray(tr.get_choices()["a"], f32)
+        return O.normal(orig_a, f32(1.0)) @ "a"
+    bshape = () if N is None else (N,)
+    k, ok_ = _keys(seed, N)
+    trace, _ = model.importance(k, C["y"].set(4.0), (5.0,))
+    otrace, _ = o_model.importance(ok_, O.C.d({"y": f32(4.0)}), (f32(5.0),))
+    assert same(trace.get_choices()["a"], otrace.get_choices()["a"])
+    key, okey = _keys(seed + 1, N)
+    accepted = 0
+    for step in range(steps):
+        # mh_keys = split(key, num_updates): one key per move; inside the move: key, subkey = split(key)
+        kk = G.fold_in(key, step) if N is None else G.split(G.fold_in(G.key(seed + 1), step), N)
+        okk = O.fold_in(okey, step) if N is None else O.split(O.fold_in(O.key(seed + 1), step), N)
+        kk, subkey = G.split(kk)
+        okk, osub = (O.split(okk)[..., 0, :], O.split(okk)[..., 1, :])
+        model_args = trace.get_args()
+        argdiffs = Diff.no_change(model_args)
+        fwd_choices, fwd_weight, _ = prop.propose(kk, (trace,))
+        ofc, ofw, _ = o_prop.propose(okk, (otrace,))
+        assert same(fwd_choices["a"], ofc["a"]) and same(fwd_weight, ofw), step
+        new_trace, weight, _, discard = model.update(subkey, trace, fwd_choices, argdiffs)
+        onew, ow, odisc = o_model.update(osub, otrace, ofc, (f32(5.0),))
+        assert same(weight, ow), (step, npv(weight), np.asarray(ow))
+        bwd_weight, _ = prop.assess(discard, (new_trace,))
+        obwd, _ = o_prop.assess(odisc, (onew,), bshape)
+        assert same(bwd_weight, obwd), step
+        alpha = weight - fwd_weight + bwd_weight
+        oalpha = ((np.asarray(ow, f32) - np.asarray(ofw, f32)).astype(f32) + np.asarray(obwd, f32)).astype(f32)
+        assert same(alpha, oalpha)
+        kk, subkey = G.split(kk)
+        okk, osub = (O.split(okk)[..., 0, :], O.split(okk)[..., 1, :])
+        u = G.random.uniform(subkey)
+        ou = O.random_uniform(osub, ())
+        assert same(u, ou)
+        acc = jnp.log(u) < alpha
+        oacc = O.log(np.asarray(ou, f32)) < oalpha
+        assert same(acc, oacc)
+        # jax.lax.cond(accept, lambda: new_trace, lambda: trace): a select over the whole trace
+        trace = jnp.lax.cond(acc, lambda: new_trace, lambda: trace)
+        otrace = O.trace_where(oacc, onew, otrace)
+        accepted += int(np.sum(npv(acc)))
+        for a in ("a", "b"):
+            assert same(trace.get_choices()[a], otrace.get_choices()[a]), (step, a)
+        assert same(trace.get_score(), otrace.get_score())
+    return dict(accepted=accepted)
+
+
+# =====================================================================================================================
+# importance_sampling.ipynb c16
+# =====================================================================================================================
+def check_importance_sampling_sir(N=1000, K=50, seed=2):
+    """c16 `sir(N, K, model, chm)`: `vmap(model.importance)` over N keys, normalise the weights, `categorical.vmap()` K draws
+    (`split(key, K)`), gather the samples — here with the notebook's model family (a latent, a noisy observation)."""
+    import genjax_amd as G
+    from genjax_amd import ChoiceMapBuilder as C
+
+    @G.gen
+    def model():
+        x = G.normal(0.0, 1.0) @ "x"
+        y = G.normal(x, 0.5) @ "y"
+        return y
+
+    @O.gen
+    def o_model():
+        x = O.normal(f32(0.0), f32(1.0)) @ "x"
+        return O.normal(x, f32(0.5)) @ "y"
+    key, okey = G.key(seed), O.key(seed)
+    traces, weights = G.vmap(model.importance, in_axes=(0, None, None))(G.split(key, N), C["y"].set(1.3), ())
+    otr, ow = o_model.importance(O.split(okey, N), O.C.d({"y": f32(1.3)}), ())
+    assert same(weights, ow)
+    key2, okey2 = G.key(seed + 1), O.key(seed + 1)
+    lw = weights.reshape(1, N).expand(K, N) if hasattr(weights, "expand") else weights
+    idxs = G.vmap(lambda k_, l_: G.categorical.simulate(k_, (l_,)).get_retval())(G.split(key2, K), lw.contiguous())
+    oidx = O.categorical._sample(O.split(okey2, K), (np.broadcast_to(np.asarray(ow, f32), (K, N)),))
+    assert same(idxs, oidx)
+    xs = traces.get_choices()["x"][idxs.long()]
+    assert same(xs, np.asarray(otr.get_choices()["x"])[oidx])
+    return dict(mean=float(npv(xs).mean()))
+
+
+# =====================================================================================================================
+# 7_application_dirichlet_mixture_model.ipynb under a BATCH of keys
+# =====================================================================================================================
+PRIOR_MEAN, PRIOR_VARIANCE, OBS_VARIANCE = 50.0, 10.0, 1.0
+
+
+def mixture_models(k, n, alpha):
+    import genjax_amd as G
+    from genjax_amd import numpy as jnp
+
+    @G.gen
+    def generate_cluster(mean, var):
+        return G.normal(mean, var) @ "mean"
+
+    @G.gen
+    def generate_cluster_weight(alphas):
+        return G.dirichlet(alphas) @ "probs"
+
+    @G.gen
+    def generate_datapoints(probs, clusters, n_datapoints):
+        idx = G.categorical(jnp.log(probs), sample_shape=n_datapoints) @ "idx"
+        return G.normal(clusters[idx], OBS_VARIANCE) @ "obs"
+
+    @G.gen
+    def generate_data(n_clusters, n_datapoints, alpha_):        # c6, as written
+        clusters = generate_cluster.repeat(n=n_clusters.unwrap())(PRIOR_MEAN, PRIOR_VARIANCE) @ "clusters"
+        probs = generate_cluster_weight.inline(alpha_ / n_clusters.unwrap() * jnp.ones(n_clusters.unwrap()))
+        return generate_datapoints(probs, clusters, n_datapoints) @ "datapoints"
+
+    @O.gen
+    def o_cluster(mean, var):
+        return O.normal(mean, var) @ "mean"
+
+    @O.gen
+    def o_datapoints(probs, clusters):
+        idx = O.categorical(logits=O.log(np.asarray(probs, f32)), sample_shape=n) @ "idx"
+        cl = np.asarray(clusters, f32)
+        mu = np.take_along_axis(cl, idx.astype(np.int64), axis=-1) if cl.ndim == 2 else cl[idx]
+        return O.normal(mu, f32(OBS_VARIANCE)) @ "obs"
+
+    @O.gen
+    def o_data():
+        clusters = O.Repeat(o_cluster, k)(f32(PRIOR_MEAN), f32(PRIOR_VARIANCE)) @ "clusters"
+        probs = O.dirichlet(((f32(alpha) / f32(k)) * np.ones(k, f32)).astype(f32)) @ "probs"
+        return o_datapoints(probs, clusters) @ "datapoints"
+    return generate_data, o_data
+
+
+def check_mixture_notebook_under_a_batch(k=40, n=500, B=5, seed=0):
+    """c6 `generate_data` and the three `trace.update` calls c10's Gibbs moves end with, under B keys at once (the notebook
+    runs one chain; a particle ensemble over the same model is BASELINE config 5's setting): `repeat` of k clusters whose
+    means are READ BACK (`clusters[idx]`: a gather at traced indices from the plate's stored values), the inlined Dirichlet of
+    k weights, `categorical(jnp.log(probs), sample_shape=n)` as one counted loop over the n draws (k logits spilled to
+    memory beyond 24), `normal(clusters[idx], 1)` as a vector site looping over the n observations."""
+    import genjax_amd as G
+    from genjax_amd import ChoiceMapBuilder as C, Diff
+    from genjax_amd import numpy as jnp
+    from genjax_amd.core.pytree import Const
+    alpha = float(n / (k * 10))
+    args = (Const(k), Const(n), alpha)
+    gd, od = mixture_models(k, n, alpha)
+    keys, okeys = G.split(G.key(seed), B), O.split(O.key(seed), B)
+    tr = G.vmap(gd.simulate, in_axes=(0, None))(keys, args)
+    otr = od.simulate(okeys, ())
+    for a in (("clusters", "mean"), "probs", ("datapoints", "idx"), ("datapoints", "obs")):
+        assert same(tr.get_choices()[a], otr.get_choices()[a]), a
+    assert same(tr.get_score(), otr.get_score())
+    pts = np.linspace(10.0, 90.0, n).astype(f32)
+    uni = (np.ones(k, f32) / f32(k)).astype(f32)
+    cons = C["datapoints", "obs"].set(jnp.array(pts)) | C["probs"].set(jnp.ones(k) / k)
+    tr2, w = G.vmap(gd.importance, in_axes=(0, None, None))(keys, cons, args)
+    otr2, ow = od.importance(okeys, O.C.d({("datapoints", "obs"): pts, "probs": uni}), ())
+    assert same(tr2.get_choices()["datapoints", "idx"], otr2.get_choices()["datapoints", "idx"])
+    assert same(w, ow) and same(tr2.get_score(), otr2.get_score())
+    new_means = np.linspace(20.0, 80.0, k).astype(f32)
+    tr3, w3, _, _ = tr2.update(G.split(G.key(seed + 2), B), C["clusters", "mean"].set(jnp.array(new_means)), Diff.no_change(args))
+    otr3, ow3, _ = od.update(O.split(O.key(seed + 2), B), otr2, O.C.d({("clusters", "mean"): new_means}), ())
+    assert same(w3, ow3) and same(tr3.get_score(), otr3.get_score()), (npv(w3), np.asarray(ow3))
+    new_probs = np.linspace(1.0, 2.0, k).astype(f32)
+    new_probs = (new_probs / new_probs.sum(dtype=f32)).astype(f32)
+    tr4, w4, _, _ = tr3.update(G.split(G.key(seed + 3), B), C["probs"].set(jnp.array(new_probs)), Diff.no_change(args))
+    otr4, ow4, _ = od.update(O.split(O.key(seed + 3), B), otr3, O.C.d({"probs": new_probs}), ())
+    assert same(w4, ow4) and same(tr4.get_score(), otr4.get_score())
+    new_idx = np.random.default_rng(seed).integers(0, k, size=(B, n)).astype(np.int32)
+    dev = npv(w4) is not None and (w4.device if hasattr(w4, "device") else None)
+    t_idx = torch.from_numpy(new_idx)
+    if dev is not None:
+        t_idx = t_idx.to(dev)
+    tr5, w5, _, _ = tr4.update(G.split(G.key(seed + 4), B), C["datapoints", "idx"].set(t_idx), Diff.no_change(args))
+    otr5, ow5, _ = od.update(O.split(O.key(seed + 4), B), otr4, O.C.d({("datapoints", "idx"): new_idx}), ())
+    assert same(w5, ow5) and same(tr5.get_score(), otr5.get_score())
+    return dict(w=npv(w5))
+
+
+# =====================================================================================================================
+# scan carries and stacked outputs (scan.py:200-294)
+# =====================================================================================================================
+def check_scan_outputs_and_array_carries(T_=40, N=6, seed=1):
+    """`step.scan(n=T)(jnp.zeros(2), None)` — an ARRAY as the initial carry — and a model that computes with a long scan's
+    stacked outputs (`jnp.sum(xs)`, `xs[3]`), importance and update, against the oracle."""
+    import genjax_amd as G
+    from genjax_amd import ChoiceMapBuilder as C, Diff
+    from genjax_amd import numpy as jnp
+
+    @G.gen
+    def step(c, _):
+        x = G.normal(c[0] * 0.5 + c[1] * 0.25, 1.0) @ "x"
+        return jnp.stack([x, c[0]]), x
+
+    @G.gen
+    def model():
+        last, xs = step.scan(n=T_)(jnp.zeros(2), None) @ "s"
+        y = G.normal(jnp.sum(xs) + last[0] + xs[3], 2.0) @ "y"
+        return y
+
+    @O.gen
+    def o_step(c, _):
+        c = np.asarray(c, f32)
+        x = O.normal(((c[..., 0] * f32(0.5)).astype(f32) + (c[..., 1] * f32(0.25)).astype(f32)).astype(f32), f32(1.0)) @ "x"
+        return np.stack([np.broadcast_to(x, np.broadcast_shapes(np.shape(x), c[..., 0].shape)),
+                         np.broadcast_to(c[..., 0], np.broadcast_shapes(np.shape(x), c[..., 0].shape))], axis=-1).astype(f32), x
+
+    @O.gen
+    def o_model():
+        last, xs = O.Scan(o_step, T_)(np.zeros(2, f32), None) @ "s"
+        xs = np.asarray(xs, f32)
+        tot = ((inorder_sum(xs) + last[..., 0]).astype(f32) + xs[..., 3]).astype(f32)
+        return O.normal(tot, f32(2.0)) @ "y"
+    k, ok_ = _keys(seed, N)
+    tr, w = model.importance(k, C["y"].set(1.5), ())
+    otr, ow = o_model.importance(ok_, O.C.d({"y": f32(1.5)}), ())
+    assert same(tr.get_choices()["s", "x"], otr.get_choices()["s", "x"])
+    assert same(w, ow)
+    k2, ok2 = _keys(seed + 1, N)
+    newx = np.linspace(-1, 1, T_).astype(f32)
+    tr2, w2, _, _ = tr.update(k2, C["s", "x"].set(jnp.array(newx)), Diff.no_change(()))
+    otr2, ow2, _ = o_model.update(ok2, otr, O.C.d({("s", "x"): newx}), ())
+    assert same(w2, ow2) and same(tr2.get_score(), otr2.get_score())
+    return dict(w=npv(w2))

@@ -2031,3 +2031,38 @@ def test_csmc_weights_against_scipy_on_device(gpu):
 
 def test_more_closed_forms_on_device(gpu):
     parity.check_more_closed_forms(n=1_000_000)
+
+
+# ---------------------------------------------------------------------------
+# the reference's cookbook as a parity corpus (tests/cookbook.py), through the C-ABI
+# ---------------------------------------------------------------------------
+def test_cookbook_speed_gains_on_device(gpu):
+    """3_speed_gains.ipynb: SIR (c8) at its `model_sizes` x 100 particles; the MH move (c15) for ONE trace at c17's sizes up
+    to 1e6 and for 100 and 10 000 chains — interpreter and (from 2^18 particles) specialised kernels"""
+    from tests import cookbook
+    for n in (10, 100, 1000):
+        cookbook.check_speed_gains_sir(n=n, N=100)
+    for n, N in ((10, None), (1000, None), (4096, None), (100_000, None), (1_000_000, None), (10, 100), (100, 100), (1000, 100),
+                 (100, 10_000)):
+        cookbook.check_speed_gains_mh(n=n, N=N)
+
+
+def test_cookbook_mcmc_and_importance_sampling_on_device(gpu):
+    from tests import cookbook
+    cookbook.check_mcmc_notebook(N=None)
+    cookbook.check_mcmc_notebook(N=50)
+    cookbook.check_mcmc_notebook(N=300_000, steps=3)       # past the specialisation threshold
+    cookbook.check_importance_sampling_sir()
+
+
+def test_cookbook_mixture_model_under_a_batch_on_device(gpu):
+    from tests import cookbook
+    for k, n in ((12, 40), (20, 100), (40, 500), (64, 1000)):
+        cookbook.check_mixture_notebook_under_a_batch(k=k, n=n)
+    cookbook.check_mixture_notebook_under_a_batch(k=40, n=500, B=3000, seed=4)
+
+
+def test_cookbook_scan_outputs_and_array_carries_on_device(gpu):
+    from tests import cookbook
+    for T_, N in ((8, None), (8, 6), (40, None), (40, 6), (300, 6), (100, 5000)):
+        cookbook.check_scan_outputs_and_array_carries(T_=T_, N=N)

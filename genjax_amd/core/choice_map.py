@@ -651,6 +651,8 @@ def _or_values(a, b):
     that is a Mask with a run-time flag holds where its flag does, the second operand elsewhere (`Mask.__or__`,
     functional_types.py:309-319); anything else: the first operand."""
     from .mask import Mask
+    if isinstance(a, Mask) and a.flag is False:
+        return b                 # `Mask.__or__` (functional_types.py:312-316): a first operand whose flag is statically False gives way
     if not isinstance(a, Mask) or isinstance(a.flag, bool):
         return a
     import torch

@@ -1451,10 +1451,17 @@ class BootstrapSweep(_NoiseAhead):
 
     def _check_valid(self):
         """the fused resampling prologue's sticky timeout word: a workgroup that gave up waiting clamps stale words into
-        indices, so nothing of such a sweep may be read (reset per sweep by enqueue)"""
+        indices, so nothing of such a sweep may be read.  The word is STICKY for the object's lifetime (nothing in the
+        captured sweep clears it: one timed-out poll condemns every later replay until `reset_status()`), which is the
+        safe side: a launch that was not resident once will not be the next time either"""
         if self.fuse and int(self.rs_status.item()) != 0:
             raise RuntimeError("BootstrapSweep: a workgroup's wait for its ancestors timed out (the launch was not "
                                "resident at once?): the sweep's results are not valid")
+
+    def reset_status(self):
+        """clear the sticky timeout word (after the cause — e.g. another process holding compute units — is gone)"""
+        if getattr(self, "rs_status", None) is not None:
+            self.rs_status.zero_()
 
     def log_ml(self) -> float:
         """sum_t [ ref(M_t) + log(total_t * 2^-shift) - log N ] in float64 (synchronises)."""

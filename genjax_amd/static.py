@@ -1062,6 +1062,12 @@ def _vector_site_loop(ctx, mode, dist, key, args, cval, prev, req):
     cv = cval.value if isinstance(cval, Sym) else cval
     if isinstance(cv, Mask):
         return None
+    if ctx.gate is not None and cv is not None and mode not in ("simulate", "generate", "assess"):
+        # an edit under a gate (`IndexRequest(idx, Update(C["y"].set(v)))` around a loop-form scan / plate) that REPLACES
+        # this site's values: the new values hold at the gated iteration only, the old ones elsewhere — a select per
+        # element, which the unrolled form's _gate_site makes; the loop form would record the constraint at EVERY
+        # iteration (weights summed over all steps, silently)
+        return None
     pv = ps = None
     if mode not in ("simulate", "generate", "assess"):
         pv, ps = prev["value"].value, prev["score"].value
@@ -1178,7 +1184,7 @@ def _gate_site(ctx, gate, out, prev, dist, args):
     nv = rec.value.value if isinstance(rec.value, Sym) else rec.value
     ns = rec.score.value if isinstance(rec.score, Sym) else rec.score
     from .engine import StepOutput
-    if isinstance(nv, StepOutput) and not nv.vector_site and hasattr(pv, "passthrough"):
+    if isinstance(nv, StepOutput) and not nv.vector_site and hasattr(pv, "passthrough") and rec.discard is None:
         # a long vector-valued site that KEPT its value (recorded by its origin: _vector_site_loop re-scored the old
         # value under the new arguments in its own loop): that IS the carried-over form — nothing to select between
         return rec, ret, w, ns
@@ -1188,6 +1194,12 @@ def _gate_site(ctx, gate, out, prev, dist, args):
     else:
         s_co, w_co = ps, None
     v = nv if nv is pv else T.where(gate, nv, pv)
+    if isinstance(v, T.LazyVec):
+        # (the select of two LONG vectors stays a recipe, and the previous values of a long vector site inside a loop are
+        #  readable at the loop's own iteration number only: there is no storing this select element by element)
+        raise NotImplementedError("an edit at one index (IndexRequest) that replaces the values of a vector-valued site of "
+                                  f"more than 16 elements ({v.n}) inside a scan / plate run as a loop: edit the whole "
+                                  "site with Update(C[:, addr].set(values)), or keep the site to 16 elements")
     sc = ns if ns is s_co else T.where(gate, ns, s_co)
     if w is None and w_co is None:
         wg = None

@@ -475,6 +475,7 @@ def sym_take(arr, idx):
             out[pos] = sym_take(arr, idx[pos])
         return out.view(SymArray)
     i = as_int(idx)
+    i = where(i < 0, i + n, i)          # jax wraps a negative index once (`x[-2]` is row n - 2), then clamps past the end
     out = base[n - 1]
     for j in range(n - 2, -1, -1):
         out = where(i == j, base[j], out)

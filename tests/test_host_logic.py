@@ -1762,3 +1762,60 @@ def test_cookbook_scan_outputs_and_array_carries(T_, N):
     """scan.py:200-294: an array as the initial carry; a long scan's stacked outputs computed with in the model"""
     from tests import cookbook
     cookbook.check_scan_outputs_and_array_carries(T_=T_, N=N)
+
+
+def test_index_request_replacing_a_long_vector_site_inside_a_loop_is_refused_loudly():
+    """`IndexRequest(idx, Update(C["y"].set(v)))` on a loop-form scan whose kernel holds a vector site of
+    24 elements used to record the constraint at EVERY step (weights summed over all steps, silently).  The request now
+    raises — naming the construct — for a launch-uniform [M] and for a per-particle [K, M] constraint alike; a scan the
+    O(1) path takes (scan.py:325-416 on slices) still answers it bit-exact."""
+    from genjax_amd import Diff, IndexRequest, Update
+    T_, M, K = 20, 24, 5
+    ones = np.ones(M, np.float32)
+
+    def mk(o1):
+        @genjax.gen
+        def step(x, _):
+            xn = genjax.normal(0.9 * x, 0.5) @ "x"
+            genjax.normal(xn * jnp.array(ones), 1.0) @ "y"
+            return (xn if o1 else xn + 0.1 * x), xn
+        return step
+    vec = np.linspace(-1, 1, M).astype(np.float32)
+    per = torch.from_numpy(np.tile(vec, (K, 1)) + np.arange(K, dtype=np.float32)[:, None])
+    a = (torch.zeros(K), None)
+    sc = mk(False).scan(n=T_)
+    tr = sc.simulate(genjax.split(genjax.key(1), K), a)
+    for con in (jnp.array(vec), per):
+        with pytest.raises(NotImplementedError, match="vector-valued site of more than 16 elements"):
+            IndexRequest(7, Update(C["y"].set(con))).edit(genjax.split(genjax.key(2), K), tr, Diff.no_change(a))
+    # the O(1) form (the kernel's return value depends on the carry through its choices alone)
+    sc1 = mk(True).scan(n=T_)
+    tr1 = sc1.simulate(genjax.split(genjax.key(1), K), a)
+
+    @O.gen
+    def ostep(x, _):
+        xn = O.normal((np.float32(0.9) * np.asarray(x, np.float32)).astype(np.float32), np.float32(0.5)) @ "x"
+        O.normal((np.asarray(xn, np.float32)[..., None] * ones).astype(np.float32), np.float32(1.0)) @ "y"
+        return xn, xn
+    osc = O.Scan(ostep, T_)
+    otr = osc.simulate(O.split(O.key(1), K), (np.zeros(K, np.float32), None))
+    new, w, _, _ = IndexRequest(7, Update(C["y"].set(jnp.array(vec)))).edit(genjax.split(genjax.key(2), K), tr1, Diff.no_change(a))
+    onew, ow = O.scan_edit_index(osc, O.split(O.key(2), K), otr, (np.zeros(K, np.float32), None), 7,
+                                 lambda k, sl, ar: ostep.update(k, sl, O.C.d({"y": vec}), ar)[:2])
+    assert np.array_equal(w.numpy(), ow) and np.array_equal(new.get_choices()["y"].numpy(), onew.get_choices()["y"])
+
+
+def test_traced_negative_index_wraps_like_jax_and_static_false_mask_gives_way():
+    """`xs[z]` with z = -2 reads row n - 2 on values in registers (tracer.sym_take) as it does on a leaf in
+    memory; `Choice(Mask(v, False)) | Choice(b)` is b (functional_types.py:312-316)"""
+    from genjax_amd.core.choice_map import _or_values
+    from genjax_amd.core.mask import Mask
+
+    @genjax.gen
+    def m(z):
+        xs = jnp.stack([genjax.normal(float(j), 0.01) @ f"x{j}" for j in range(4)])
+        return xs[z]
+    tr = m.simulate(genjax.split(genjax.key(0), 6), (torch.tensor([-2, -1, 0, 1, 2, 3], dtype=torch.int32),))
+    r = tr.get_retval().numpy()
+    assert np.allclose(r, [2, 3, 0, 1, 2, 3], atol=0.1)
+    assert _or_values(Mask(1.0, False), 2.0) == 2.0

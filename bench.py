@@ -41,11 +41,44 @@ os.environ.setdefault("OMP_WAIT_POLICY", "ACTIVE")
 
 N_PARTICLES = 1_000_000
 T_STEPS = 100
-VALU_PEAK_LANE_OPS = 256 * 4 * 16 * 2.4e9   # integer / unpacked-f32 vector instructions: 16 lanes per clock per SIMD (a
-                                            # wave64 instruction holds its SIMD for 4 cycles; only packed f32 math doubles
-                                            # that).  tools/calib.hip on MI355X (profiles/r02_calib.txt): one Threefry-like
-                                            # add/rotate/xor chain per lane 33.6 T lane-ops/s, two independent chains 35.5 T
-                                            # — no gain from ILP, i.e. the pipe is full — against 39.3 T nominal at 2.4 GHz
+VALU_PEAK_LANE_OPS = 256 * 4 * 64 * 2.4e9 / 2.0   # 78.6 T lane-ops/s: TWO vector instructions per 4-cycle slot of a SIMD — the
+                                            # ceiling no instruction stream exceeds.  Calibrated with inline-asm streams the
+                                            # compiler cannot fold or pack (tools/calib_valu_gen.py, profiles/r06_calib.txt):
+                                            # f32 add / mul / fma / mov and simple integer ops (xor, and, or, add_u32, lshr)
+                                            # retire one per ~2.2 cycles per SIMD with >= 2 waves (66-70 T measured: the
+                                            # clock sags to 2.15-2.37 GHz); v_alignbit, shifts left, min / max, cvt, cmp,
+                                            # cndmask, mul_lo, add3, anything with an SGPR source: one per 4.07 cycles; and
+                                            # an integer instruction next to such a one (a Threefry round: add, alignbit,
+                                            # xor) takes a whole slot too: 3.97-4.03 cycles per instruction, 38 T lane-ops/s.
+                                            # Round 5's "39.3 T nominal peak" was the one-per-slot rate: config 4's kernel
+                                            # exceeded it (47.8 T) because its f32 arithmetic rides beside the Threefry.
+VALU_SLOT_CYCLES = 4.07                     # profiles/r06_calib.txt
+
+
+def slot_model(kernel_key_prefix: str):
+    """cycles per vector instruction [lo, hi] the SLOT model gives a kernel of this instruction mix (tools/valu_model.py over
+    its offline disassembly, profiles/r06_valu_classes.json): lo = every simple-integer instruction finds a partner in its
+    slot, hi = none does (what Threefry-interleaved code measures)"""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r06_valu_classes.json")))
+    except (OSError, ValueError):
+        return None
+    for k, v in d.items():
+        if isinstance(v, dict) and k.startswith(kernel_key_prefix):
+            return {"classes": {c: v[c] for c in ("F", "I", "X", "T")}, "cycles_per_inst": [v["cycles_per_inst_lo"], v["cycles_per_inst_hi"]],
+                    "source": k}
+    return None
+
+
+def slot_frac(rate_lane_ops: float, sm):
+    """the fraction [lo, hi] of the slot model's bound a measured instruction rate reaches: rate x cycles-per-instruction /
+    (SIMDs x 64 lanes x 2.4 GHz) — 1.0 = the SIMDs' slots are full for this instruction mix"""
+    if sm is None or rate_lane_ops is None:
+        return None
+    cap = 256 * 4 * 64 * 2.4e9
+    return [rate_lane_ops * c / cap for c in sm["cycles_per_inst"]]
+
+
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 # Algorithmic bytes per particle-step (DESIGN.md §4; SURVEY.md §8d: 8*D + 24 = 32 B, D = 1):
 #   site program  ancestor 4 + gathered state 4 in, state 4 + log-weight 4 out    = 16 B
@@ -300,17 +333,20 @@ def measure_roofline(be, sw, n, T, world, single, value):
 
     # ---- vector-instruction issue: the limiter ----
     waves = (n + 1023) // 1024 * 4
+    sm = slot_model("gmx_jit_kernel (config 2 step")
     valu = {"peak_T_lane_ops": VALU_PEAK_LANE_OPS / 1e12,
-            "peak_note": "the NOMINAL issue peak, 256 CU x 4 SIMD x 16 lanes x 2.4 GHz: a wave64 integer / unpacked-f32 "
-                         "instruction holds its SIMD for 4 cycles (the guide's 2-cycle figure is reached by packed f32 "
-                         "only); no calibrated 'ceiling' is reported any more — a measured chain once exceeded it",
+            "peak_note": "two vector instructions per 4-cycle slot of each SIMD (256 CU x 4 SIMD x 64 lanes x 2.4 GHz / 2): the "
+                         "ceiling no stream exceeds, reached by f32 add / mul / fma and simple integer streams only "
+                         "(profiles/r06_calib.txt: 66-70 T measured).  `slot_model`: what THIS instruction mix can reach — a "
+                         "Threefry round (add, alignbit, xor) costs three whole slots",
+            "slot_model": sm,
             "insts_per_wave_source": prof_notes}
     per_wave = {k: kern[k].get("valu_insts_per_wave") for k in kern}
     if single and all(v for v in per_wave.values()):
         step_us = us["sweep"] / T
         rate = sum(per_wave.values()) * 64 * waves / (step_us * 1e-6)
         valu.update(insts_per_wave_per_step=sum(per_wave.values()), lane_ops_per_s=rate,
-                    valu_frac=rate / VALU_PEAK_LANE_OPS)
+                    valu_frac=rate / VALU_PEAK_LANE_OPS, slot_frac=slot_frac(rate, sm))
         if na:
             nrate = per_wave["gmx_jit_background_kernel"] * 64 * waves / (us["k_noise"] * 1e-6)
             valu["noise_program_isolated_valu_frac"] = nrate / VALU_PEAK_LANE_OPS
@@ -329,7 +365,9 @@ def measure_roofline(be, sw, n, T, world, single, value):
                  "timed region (the figure `value` is computed from); `traffic` = TCC bytes per STEP summed over the "
                  "step's kernels (vs 32 B x n algorithmic), from profiles/counters.json when taken on this code",
         "algorithmic_bytes_per_step": SWEEP_BYTES_PER_PARTICLE_STEP * n,
-        "limiter": "vector-instruction issue (3 Threefry-2x32 blocks per draw fixed by jax's key tree), not HBM: see valu",
+        "limiter": "the SIMDs' instruction slots for THIS instruction mix (3 Threefry-2x32 blocks per draw fixed by jax's key "
+                   "tree: integer instructions next to v_alignbit take a slot each) and the chain's dependent round trips — not "
+                   "HBM, and not the 2-per-slot issue ceiling: see valu.slot_frac against valu.valu_frac",
         "kernels": kern, "valu": valu, "kernel_us": us, "code_identity": ids,
         "us_per_step_event_timed": (us["sweep"] / T) if "sweep" in us else None,
         "chain_only_us_per_step_event_timed": (us["chain_only_sweep"] / T) if "chain_only_sweep" in us else None,
@@ -411,8 +449,9 @@ def config_valu(name: str, seconds_per_unit: float, programs: str = None):
                                            f"({ent.get('programs')} != {programs}): not used"}
     wave_insts = float(ent["valu_wave_insts_per_unit"])
     rate = wave_insts * 64.0 / seconds_per_unit
+    sm = slot_model("gmx_jit_kernel (config 4") if name == "config4" else None
     return {"valu_wave_insts_per_unit": wave_insts, "unit": ent.get("unit"), "lane_ops_per_s": rate,
-            "valu_frac": rate / VALU_PEAK_LANE_OPS,
+            "valu_frac": rate / VALU_PEAK_LANE_OPS, "slot_model": sm, "slot_frac": slot_frac(rate, sm),
             "dominant_kernel": ent.get("dominant_kernel"), "dominant_kernel_valu_insts_per_wave": ent.get("dominant_valu_per_wave"),
             "dominant_kernel_us_in_profile": ent.get("dominant_avg_us"), "kernels": ent.get("kernels"),
             "source": {"file": "profiles/counters.json", "tag": ent.get("tag"), "lib": lib}}

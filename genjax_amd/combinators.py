@@ -371,7 +371,7 @@ def _stack(vals):
     if isinstance(vals[0], (tuple, list)):
         return type(vals[0])(_stack([v[k] for v in vals]) for k in range(len(vals[0])))
     arrs = [np.asarray(v, dtype=object) if not (isinstance(v, np.ndarray) and v.dtype == object) else v for v in vals]
-    return np.stack(arrs, axis=0)
+    return T.sym_array(np.stack(arrs, axis=0))       # (values in registers: a traced index into them selects, tracer.SymArray)
 
 
 def _plate_project(self, key, trace, selection):
@@ -529,6 +529,8 @@ class Vmap(GenerativeFunction):
         if isinstance(merged, _SiteRec):
             # a distribution under vmap is a vector-valued site with split keys; its
             # score is the plate sum
+            if keep and all(isinstance(r, _SiteRec) for r in recs):
+                merged.escore = _stack([r.score for r in recs])      # ... and the per-element scores stay in the trace
             merged.score = score
             out = merged
         else:
@@ -616,6 +618,8 @@ class Vmap(GenerativeFunction):
         if isinstance(rec, _SiteRec):
             # a distribution under vmap is a vector-valued site with split keys; its score is the plate sum
             out = _SiteRec(rec.gen_fn, rec.value, score)
+            if isinstance(rec.score, StepOutput):
+                out.escore = rec.score          # the per-element scores the loop stored: kept beside the plate sum
             retval = rec.value if rets is None else rets
             if not keep:
                 retval = rets
@@ -673,14 +677,23 @@ class Vmap(GenerativeFunction):
         # did this edit change anything the plate RETURNS?  (its return values are readable by the model afterwards —
         # _readable — through an input slot of their own, which the change propagation must then see as changed)
         mark0 = (len(ctx.changed), len(ctx.changed_slots), len(ctx.changed_tables), len(ctx.changed_in_slots))
-        touched = kind == "index" or ctx.args_changed(args)
+        args_moved = ctx.args_changed(args)
+        touched = kind == "index" or args_moved
         g.loop_begin(n)
         with T.tracing(g):
             t = Expr(g.add("LDT", dtype="i32"))
             args_t = tuple(_tree_take_axes(a, ax, lambda v: _loop_at(v, t, what)) for a, ax in zip(args, axes))
             if bare_prev is not None:
                 old_v = _dyn_take(bare_prev["value"], t)
-                old_s = self.gen_fn.sym_logpdf(old_v, self.gen_fn.canon(args_t))
+                if bare_prev.get("escore") is not None:
+                    old_s = _dyn_take(bare_prev["escore"], t)          # the element's OLD score, as the trace kept it
+                elif not args_moved:
+                    old_s = self.gen_fn.sym_logpdf(old_v, self.gen_fn.canon(args_t))     # (same arguments: recomputed)
+                else:
+                    raise NotImplementedError(
+                        "update of a plate of a bare distribution (`dist.vmap()`) under CHANGED arguments needs the "
+                        "elements' old scores, which this trace no longer holds (it was gathered / stacked / selected): "
+                        "write the element as a `@gen` function, or update the trace the model call returned")
                 prev_t = {"value": Sym(old_v, None), "score": Sym(old_s, None)}
             else:
                 prev_t = prev_at(inner_prev, t)
@@ -767,6 +780,8 @@ class Vmap(GenerativeFunction):
         if isinstance(rec, _SiteRec):
             # a bare distribution's plate stays one vector-valued site: values [T], score = the new plate sum
             out = _SiteRec(rec.gen_fn, rec.value, Expr(svar), rec.discard)
+            if isinstance(rec.score, StepOutput):
+                out.escore = rec.score
             return out, readable(rec.value), Expr(wvar), None
 
         def drop_retvals(r):
@@ -805,7 +820,9 @@ class Vmap(GenerativeFunction):
                 # MH move of 3_speed_gains.ipynb c15 edits `x` and leaves three such plates alone).  The previous
                 # values are handed back where they lie — readable: `jnp.sum(a)` loops over the old leaf
                 pv = prev["value"]
-                return _SiteRec(self.gen_fn, pv, prev["score"]), (pv.value if hasattr(pv, "value") else pv), None, None
+                out = _SiteRec(self.gen_fn, pv, prev["score"])
+                out.escore = prev.get("escore")
+                return out, (pv.value if hasattr(pv, "value") else pv), None, None
             return self._trace_edit_loop(ctx, kind if kind != "empty" else "update", key, args, axes, constraint, None,
                                          req, n, req_leaves, addr, bare_prev=prev)
         # (as the ELEMENT of an enclosing plate / scan this plate's trace is held flat: its sites with one more axis)

@@ -300,6 +300,9 @@ def _plain_retval(v):
 def _trace_tree(tr):
     """Trace -> plain pytree of launch values (for Flat)."""
     if isinstance(tr, DistributionTrace):
+        es = getattr(tr, "_elem_scores", None)
+        if es is not None and tuple(getattr(es, "shape", ())) == tuple(getattr(tr.value, "shape", (None,))):
+            return {"value": tr.value, "score": tr.score, "escore": es}      # a bare distribution's plate: per-element scores
         return {"value": tr.value, "score": tr.score}
     if isinstance(tr, StaticTrace):
         return {"sub": {a: _trace_tree(s) for a, s in tr.subtraces.items()}, "retval": _plain_retval(tr.retval)}
@@ -748,11 +751,14 @@ class _Ctx:
 
 
 class _SiteRec:
-    __slots__ = ("gen_fn", "value", "score", "discard", "origins")
+    __slots__ = ("gen_fn", "value", "score", "discard", "origins", "escore")
 
     def __init__(self, gen_fn, value, score, discard=None):
         self.gen_fn, self.value, self.score, self.discard = gen_fn, value, score, discard
         self.origins = None          # (value, score, discard) origins once stored
+        self.escore = None           # a BARE distribution's plate (`normal.vmap()`): its per-element scores — the trace keeps
+        #                              them beside the plate sum, as the reference's inner trace does (vmap.py:73-75), so that an
+        #                              edit under CHANGED arguments has each element's old score (new_j - old_j, summed: :265-275)
 
 
 def _origin_of(tr, v):
@@ -1290,6 +1296,8 @@ def _emit_rec(tr: Tracing, rec):
         if rec.origins is None:
             rec.origins = (_origin_of(tr, rec.value), _origin_of(tr, rec.score), _origin_of(tr, rec.discard))
         vo, so, do = rec.origins
+        if rec.escore is not None:
+            return ("site", rec.gen_fn, vo, so, do, _origin_of(tr, rec.escore))
         return ("site", rec.gen_fn, vo, so, do)
     if isinstance(rec, _DeferredPlateRec):
         return ("deferred", rec.index)
@@ -1321,8 +1329,11 @@ def _build_trace(otree, outs, leaves, args, deferred=None):
     if otree[0] == "deferred":
         return deferred[otree[1]]
     if otree[0] == "site":
-        _, gf, vo, so, _ = otree
-        return DistributionTrace(gf, args, resolve(vo, outs, leaves), resolve(so, outs, leaves))
+        gf, vo, so = otree[1], otree[2], otree[3]
+        out = DistributionTrace(gf, args, resolve(vo, outs, leaves), resolve(so, outs, leaves))
+        if len(otree) > 5 and otree[5] is not None:
+            out._elem_scores = resolve(otree[5], outs, leaves)
+        return out
     if otree[0] == "vmap":
         _, gf, subs, ro, po = otree
         st = OrderedDict((a, _build_trace(o, outs, leaves, None, deferred)) for a, o in subs.items())
@@ -1790,6 +1801,8 @@ def _rec_to_prev(rec):
     def sym(v):
         return v if isinstance(v, Sym) else Sym(v, None)
     if isinstance(rec, _SiteRec):
+        if rec.escore is not None:
+            return {"value": sym(rec.value), "score": sym(rec.score), "escore": sym(rec.escore)}
         return {"value": sym(rec.value), "score": sym(rec.score)}
     from .core.mask import Mask
     ret = rec.retval

@@ -23,7 +23,7 @@ SMALL, LARGE = 3, 20          # unrolled / counted-loop sizes (the product switc
 # spec
 # ---------------------------------------------------------------------------
 def random_spec(rng, n_stmts=None, allow_nested=True):
-    kinds = ["leaf", "leaf", "call", "plate", "scan", "mask", "mplate", "mscan", "vec", "hvec", "vplate", "vscan"] + (["plate_of_scans", "scan_of_plates", "vplate2"] if allow_nested else [])
+    kinds = ["leaf", "leaf", "call", "plate", "scan", "mask", "mplate", "mscan", "vec", "hvec", "vplate", "vscan", "bplate", "ascan"] + (["plate_of_scans", "scan_of_plates", "vplate2"] if allow_nested else [])
     stmts = []
     if n_stmts is None:
         # (one model in eight is LONG: more sites than one launch stores — a chain of launches, program.split_graph)
@@ -37,6 +37,10 @@ def random_spec(rng, n_stmts=None, allow_nested=True):
             # (no draw of its own, so that the seeds' other models stay what they were) rows of logits at ONE site:
             # `categorical(logits [4, 3])` per particle, four draws under the site's key
             st["rows"] = 4 if st["dist"] == "categorical" and st["c1"] > 0.3 else 0
+        if kind == "bplate":            # a plate of a BARE distribution (`normal.vmap()`), its values computed with afterwards
+            st["n"] = [SMALL, LARGE, 130][int(rng.integers(3))]
+        if kind == "ascan":             # a scan whose carry is a 2-vector (an ARRAY as the initial carry), outputs summed afterwards
+            st["T"] = [SMALL, LARGE][int(rng.integers(2))]
         if kind in ("plate", "mplate", "plate_of_scans"):
             st["n"] = [SMALL, LARGE][int(rng.integers(2))]
             st["two"] = bool(rng.integers(2))
@@ -75,7 +79,7 @@ def _per_particle(st, B):
     """half of the plates / scans / vector sites of a model run under B > 1 keys map over (compute with) a per-particle
     vector ([B, n]; a plate of plates: [B, n, n2]) instead of a launch-uniform table (decided by the statement's own
     numbers: no draw of its own)"""
-    kinds = ("plate", "scan", "vec", "hvec", "vscan", "plate_of_scans", "scan_of_plates", "vplate", "vplate2")
+    kinds = ("plate", "scan", "vec", "hvec", "vscan", "plate_of_scans", "scan_of_plates", "vplate", "vplate2", "bplate")
     return B > 1 and st["kind"] in kinds and st["sd"] > 1.25
 
 
@@ -89,11 +93,11 @@ def spec_args(spec, rng, B):
         if _per_particle(st, B):
             shape = (st["n"], st["n2"]) if k == "vplate2" else ((st["T"],) if k in ("scan", "vscan", "scan_of_plates") else (st["n"],))
             extra.append(rng.normal(size=(B,) + shape).astype(np.float32).view(PerParticle))
-        elif k in ("plate", "plate_of_scans", "vec", "hvec", "vplate"):
+        elif k in ("plate", "plate_of_scans", "vec", "hvec", "vplate", "bplate"):
             extra.append(rng.normal(size=st["n"]).astype(np.float32))
         elif k == "vplate2":
             extra.append(rng.normal(size=(st["n"], st["n2"])).astype(np.float32))
-        elif k in ("scan", "scan_of_plates", "vscan"):
+        elif k in ("scan", "scan_of_plates", "vscan", "ascan"):
             extra.append(rng.normal(size=st["T"]).astype(np.float32))
         elif k == "mscan":
             extra.append(np.arange(st["T"]) < int(rng.integers(0, st["T"] + 1)))
@@ -151,6 +155,20 @@ def build(g, spec, lit):
             else:
                 z = g.normal(c * lit(0.5) + x, lit(st["sd"])) @ "z"
             return z, z
+        return step
+
+    def make_astep(st):
+        @g.gen
+        def step(c, x):
+            if g is O:
+                c = np.asarray(c, np.float32)
+                z = g.normal(((c[..., 0] * lit(0.5)).astype(np.float32) + (c[..., 1] * lit(0.25)).astype(np.float32)).astype(np.float32) + x,
+                             lit(st["sd"])) @ "z"
+                full = np.broadcast_shapes(np.shape(z), c[..., 0].shape)
+                return np.stack([np.broadcast_to(z, full), np.broadcast_to(c[..., 0], full)], axis=-1).astype(np.float32), z
+            from genjax_amd import numpy as jnp
+            z = g.normal(c[0] * lit(0.5) + c[1] * lit(0.25) + x, lit(st["sd"])) @ "z"
+            return jnp.stack([z, c[0]]), z
         return step
 
     def make_vec_row(st):
@@ -228,7 +246,7 @@ def build(g, spec, lit):
     for st in spec:
         k = st["kind"]
         parts.append(dict(st, fn={"plate": make_elem, "mplate": make_elem, "scan": make_step, "mask": make_inner, "call": make_call, "mscan": make_mstep,
-                                  "plate_of_scans": make_scan_elem, "scan_of_plates": make_plate_step, "vplate": make_vec_elem, "vscan": make_vstep, "vplate2": make_vec_row}.get(k, lambda s: None)(st)))
+                                  "plate_of_scans": make_scan_elem, "scan_of_plates": make_plate_step, "vplate": make_vec_elem, "vscan": make_vstep, "vplate2": make_vec_row, "ascan": make_astep}.get(k, lambda s: None)(st)))
 
     @g.gen
     def model(a, *extra):
@@ -291,14 +309,29 @@ def build(g, spec, lit):
                 g.Vmap(st["fn"], in_axes=(None, 0))(m, next(it)) @ name
                 prev = m
             elif k == "plate":
-                g.Vmap(st["fn"], in_axes=(None, 0))(m, next(it)) @ name      # (a loop plate's values live in memory only)
+                vs = g.Vmap(st["fn"], in_axes=(None, 0))(m, next(it)) @ name
                 prev = m
+                if st["c2"] > 0.0:          # the plate's RETURN values computed with (vmap.py:180-191: plain stacked arrays):
+                    prev = _use_stacked(g, m, vs, lit)          # their sum, one element, one at a traced index
+            elif k == "bplate":
+                xs = next(it)
+                locs = (m + xs * lit(st["c1"])) if g is not O else (np.asarray(m, np.float32)[..., None] + xs * lit(st["c1"])).astype(np.float32)
+                if g is O and locs.ndim >= 2 and locs.shape[0] == 1:
+                    locs = locs[0]          # (a value the oracle carries as [1]: the same for every particle, i.e. launch-uniform)
+                vs = g.Vmap(g.normal, in_axes=(0, None))(locs, lit(st["sd"])) @ name          # `normal.vmap(in_axes=(0, None))`
+                prev = _use_stacked(g, m, vs, lit)
+            elif k == "ascan":
+                z0 = _zeros2(g)
+                cT, ys = g.Scan(st["fn"], st["T"])(z0, next(it)) @ name
+                prev = _use_stacked(g, (cT[..., 0] if g is O else cT[0]) + m, ys, lit)
             elif k == "mplate":
                 flags, tab = next(it), next(it)
                 g.Vmap(g.MaskCombinator(st["fn"]), in_axes=(0, None, 0))(flags, m, tab) @ name
             elif k in ("scan", "vscan"):
-                cT, _ = g.Scan(st["fn"], st["T"])(m, next(it)) @ name
+                cT, ys_ = g.Scan(st["fn"], st["T"])(m, next(it)) @ name
                 prev = cT
+                if k == "scan" and st["c2"] > 0.0:          # the scan's stacked outputs computed with (scan.py:221-233)
+                    prev = _use_stacked(g, cT, ys_, lit)
             elif k == "mscan":
                 prev = st["fn"](m, next(it)) @ name
             elif k == "mask":
@@ -313,6 +346,30 @@ def build(g, spec, lit):
         return prev
     model._fuzz_parts = parts
     return model
+
+
+def _use_stacked(g, m, vs, lit):
+    """m + sum(vs) / 8 + vs[1] + vs[m > 0 ? 0 : 2]: the stacked return values of a plate / the outputs of a scan, computed
+    with in the model — in element order (`jnp.sum` as the build defines it inside a program)"""
+    if g is O:
+        vs = np.asarray(vs, np.float32)
+        m = np.asarray(m, np.float32)
+        acc = np.zeros(vs.shape[:-1], np.float32)
+        for j in range(vs.shape[-1]):
+            acc = (acc + vs[..., j]).astype(np.float32)
+        i_ = np.where(m > 0.0, 0, 2)
+        lead = np.broadcast_shapes(vs.shape[:-1], i_.shape)
+        pick = np.take_along_axis(np.broadcast_to(vs, lead + vs.shape[-1:]), np.broadcast_to(i_, lead)[..., None], axis=-1)[..., 0]
+        return (((m + (acc * lit(0.125)).astype(np.float32)).astype(np.float32) + vs[..., 1]).astype(np.float32) + pick).astype(np.float32)
+    from genjax_amd import numpy as jnp
+    return m + jnp.sum(vs) * lit(0.125) + vs[1] + vs[jnp.where(m > 0.0, 0, 2)]
+
+
+def _zeros2(g):
+    if g is O:
+        return np.zeros(2, np.float32)
+    from genjax_amd import numpy as jnp
+    return jnp.zeros(2)
 
 
 def _where(g, b, x, y):
@@ -381,8 +438,10 @@ def addresses(spec):
         if k == "leaf":
             kind_ = {"flip": "b", "bernoulli": "b", "uniform": "u", "beta": "u", "categorical": "i"}.get(st["dist"], "f")
             out.append(((nm,), (nm,), (st["rows"],) if st.get("rows") else (), kind_, False, st))
-        elif k == "vec":
+        elif k in ("vec", "bplate"):
             out.append(((nm,), (nm,), (st["n"],), "f", False, st))
+        elif k == "ascan":
+            out.append(((nm, "z"), (nm, "z"), (st["T"],), "f", False, st))
         elif k == "vplate2":
             out.append(((nm, "r", "v"), (nm, "r", "v"), (st["n"], st["n2"]), "f", False, st))
             out.append(((nm, "r", "z"), (nm, "r", "z"), (st["n"], st["n2"], st["m"]), "f", False, st))
@@ -458,7 +517,7 @@ def _pick_constraints(spec, rng, p, B):
         if kind != "f" or rng.random() > p:
             continue
         form = int(rng.integers(3))
-        if form == 2 and len(shape) == 1 and not masked and st["kind"] not in ("vec", "hvec"):
+        if form == 2 and len(shape) == 1 and not masked and st["kind"] not in ("vec", "hvec", "bplate"):
             m_ = int(rng.integers(1, min(3, shape[0]) + 1))
             idx = np.sort(rng.choice(shape[0], size=m_, replace=False))
             cons.append((ad, (idx, rng.normal(size=m_).astype(np.float32))))
@@ -561,7 +620,7 @@ def _run_one(seed, B=7, allow_nested=True, verbose=False):
     assert np.array_equal(_np(new.get_score()), onew.get_score()), (seed, "update score")
     _same_choices(spec, new, onew, B, (seed, "update"))
     for (path, okey, shape, kind, masked, st), _v in cons2:       # the discard: the old values of what was constrained
-        if st["kind"] in ("scan", "scan_of_plates", "plate_of_scans", "mscan", "vscan") or isinstance(_v, tuple):
+        if st["kind"] in ("scan", "scan_of_plates", "plate_of_scans", "mscan", "vscan", "ascan") or isinstance(_v, tuple):
             continue                                   # (the oracle restates no discard for scans; a subset's is masked)
         d, _f = _choice(bwd, path)
         od, _of = _ochoice(odis, okey)

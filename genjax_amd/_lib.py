@@ -20,7 +20,7 @@ GMX_MAX_OUT = 64
 GMX_MAX_TAB = 8
 GMX_MAX_UNI = 64
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 KEY_NONE, KEY_ARRAY, KEY_SPLIT, KEY_ROWSPLIT, KEY_BCAST = 0, 1, 2, 3, 4
 RESAMPLE_SYSTEMATIC, RESAMPLE_STRATIFIED, RESAMPLE_MULTINOMIAL, RESAMPLE_MULTINOMIAL_TILED = 0, 1, 2, 3
 RESAMPLE_MULTINOMIAL_SORTED = 4
@@ -147,6 +147,9 @@ class Backend:
         c.gmx_program_is_specialized.argtypes = [c_void_p]
         c.gmx_program_code_hash.argtypes = [c_void_p]
         c.gmx_program_code_hash.restype = c_uint64
+        c.gmx_program_despecialize.argtypes = [c_void_p, ctypes.c_char_p]
+        c.gmx_jit_rejected_count.argtypes = []
+        c.gmx_jit_rejected_count.restype = c_int64
         c.gmx_program_grid.argtypes = [c_void_p, c_int64]
         c.gmx_program_grid.restype = c_int64
         c.gmx_program_run.argtypes = [c_void_p, c_int64, POINTER(RunArgs), c_void_p]

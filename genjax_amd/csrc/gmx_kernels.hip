@@ -25,6 +25,7 @@
 #include <unistd.h>
 
 #include <new>
+#include <atomic>
 #include <string>
 #include <vector>
 
@@ -295,6 +296,8 @@ static int jit_pp_for(const gmx_program* p) {
 #define JIT_MAX_PRE 8
 static std::string jit_source(const gmx_program* p, bool* gathers_prefetched = nullptr) {
   std::string s = p->background ? "#define GMX_JIT_BACKGROUND 1\n" : "";
+  if (const char* f_ = getenv("GENMI_JIT_FAULT")) { if (f_[0] == '1') s += "#define GMX_JIT_FAULT 1\n"; }   // (tests: a kernel that
+                                                        // stores every 32-bit word with its lowest bit flipped — what the first-launch cross-check must catch)
   if (p->fuse_rs) s += "#define GMX_JIT_RS 1\n";
   if (p->fuse_sh) s += "#define GMX_JIT_SH 1\n";
   s += "#include \"gmx_jit.h\"\n";
@@ -378,6 +381,18 @@ static std::string jit_source(const gmx_program* p, bool* gathers_prefetched = n
 }
 
 extern "C" int gmx_program_is_specialized(const gmx_program* p) { return p && p->jit_fn ? 1 : 0; }
+static std::atomic<int64_t> g_jit_rejected{0};
+extern "C" int64_t gmx_jit_rejected_count(void) { return g_jit_rejected.load(); }
+extern "C" int gmx_program_despecialize(gmx_program* p, const char* why) {
+  if (!p) return gmx_fail("gmx_program_despecialize: null program%s");
+  if (!p->jit_fn) return 0;
+  (void)hipDeviceSynchronize();              // nothing of this module may still be running
+  (void)hipModuleUnload(p->jit_module);
+  p->jit_fn = nullptr; p->jit_module = nullptr; p->jit_code_hash = 0;
+  ++g_jit_rejected;
+  (void)gmx_fail("specialised kernel rejected, the interpreter takes over: %s", why ? why : "");
+  return 0;
+}
 extern "C" uint64_t gmx_program_code_hash(const gmx_program* p) { return p && p->jit_fn ? p->jit_code_hash : 0ull; }
 extern "C" int gmx_program_writes_tile_stats(const gmx_program* p) {
   return p && p->jit_fn && p->jit_pp == 4 && p->n_redmax == 1 && !p->uses_lse ? 1 : 0;
@@ -497,6 +512,7 @@ static bool jit_under_profiler() {
 
 static void jit_cache_write(const std::string& path, const std::vector<char>& code) {
   if (path.empty() || jit_under_profiler() || strcmp(jit_opt_level(), "-O3") != 0) return;
+  if (const char* f_ = getenv("GENMI_JIT_FAULT")) { if (f_[0] == '1') return; }      // a deliberately wrong kernel is never cached
   mkdirs(path.substr(0, path.rfind('/')));
   char tmp[32];
   snprintf(tmp, sizeof(tmp), ".tmp%ld", (long)getpid());

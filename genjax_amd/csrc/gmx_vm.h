@@ -115,6 +115,9 @@ GMX_HD void gmx_vm_step(Regs& R, const W w, int64_t i, bool active, const gmx_ru
       } break;
       case OP_STOUT: {
         uint32_t v = SRC(b);
+#if defined(GMX_JIT_FAULT)
+        if (!(dst & GMX_F_U8)) v ^= 1u;          // (GENMI_JIT_FAULT=1: a deliberately wrong specialised kernel, tests only)
+#endif
         if (active) {
           void* p = ctx.out_ptr(a);
           const int64_t orow = (dst & GMX_F_STEP) ? i + (int64_t)(((dst & GMX_F_FLAT) ? tf : t) + w1) * A.step_stride : i;

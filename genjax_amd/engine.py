@@ -1167,6 +1167,7 @@ class _ChainLink:
     def __init__(self, handle, seg, finalizer):
         self.handle, self.in_src, self.out_dst, self.uni_src, self.tab_src = handle, seg.in_src, seg.out_dst, seg.uni_src, seg.tab_src
         self.has_red, self.n_regs, self.finalizer = seg.has_red, int(seg.blob[3]), finalizer
+        self.seg = seg
 
 
 _DIGEST_SCOPES: list = []
@@ -1338,8 +1339,103 @@ class Compiled:
             tile_stats=None, peer=None, resample_in=None, shard_in=None):
         """Bind and launch.  Returns the list of output tensors (shape batch+event)."""
         bound = self.bind(leaves, batch, key, red_out, index_offset, out_buffers, tile_stats, peer, resample_in, shard_in)
+        if not getattr(self, "_checked", False) and self._be.uses_streams and self.is_partly_specialized() \
+                and tile_stats is None and peer is None and resample_in is None and shard_in is None:
+            self._cross_check(leaves, batch, key, index_offset)
         self.launch(bound)
         return bound[3]
+
+    def is_partly_specialized(self) -> bool:
+        hs = [l.handle for l in self.links] if self.links else [self.handle]
+        return any(bool(self._be.c.gmx_program_is_specialized(h)) for h in hs)
+
+    CHECK_PARTICLES = 256
+
+    def _cross_check(self, leaves, batch, key, index_offset):
+        """A second opinion on a freshly SPECIALISED program, once, before its results are used (include/genmi.h:
+        gmx_program_despecialize; hiprtc on a GPU box was caught twice compiling one wrongly — DESIGN.md section 5): the
+        first CHECK_PARTICLES particles of this launch run through the specialised kernel and through the ahead-of-time
+        interpreter (a twin handle made from the same words) into scratch outputs, and every output is compared bit for
+        bit.  On a difference the specialised module is dropped — this and every later launch take the interpreter — and
+        the event is reported (warning, gmx_last_error, gmx_jit_rejected_count).  Programs the interpreter cannot hold
+        (more than 31 live values), launches that reduce over the block or hand statistics to a resampler, and batches of
+        more than one axis are not checked: the on-device fuzz stands guard there.  Cost: two launches of <= 256
+        particles per program, once."""
+        import copy
+        import warnings
+        self._checked = True
+        be = self._be
+        if len(batch) != 1 or self.uses_red or torch.cuda.is_current_stream_capturing():
+            return
+        handles = [l.handle for l in self.links] if self.links else [self.handle]
+        regs = [l.n_regs for l in self.links] if self.links else [int(self.blob[3])]
+        if max(regs) > 31:
+            return
+        n = int(batch[0])
+        m = min(n, self.CHECK_PARTICLES)
+        per_particle = {j for _, j, _, kind in self.in_plan if kind not in ("bcast", "dvec")}
+
+        def cut(j, v):
+            if j not in per_particle or isinstance(v, Broadcast):
+                return v
+            if isinstance(v, Gathered):
+                return Gathered(v.source, v.ancestors[:m])
+            if isinstance(v, torch.Tensor) and v.ndim >= 1 and int(v.shape[0]) == n:
+                return v[:m]
+            return v
+        small = [cut(j, v) for j, v in enumerate(leaves)]
+        ks = key
+        if key is not None and tuple(key.shape) == (n,):
+            if key._lazy is not None:
+                kind, base, _ = key._lazy
+                if kind != "split":
+                    return
+                ks = Key(lazy=("split", base, m), offset=key._offset)
+            else:
+                ks = key[:m]
+        elif key is not None and tuple(key.shape) != ():
+            return
+        twin = copy.copy(self)
+        twin._checked, twin._jit_tried, twin._jit_needed, twin._work = True, True, True, 0
+        made = []
+        try:
+            if self.links:
+                twin.links = []
+                for l in self.links:
+                    h = self._create(l.seg.blob)
+                    made.append(h)
+                    twin.links.append(_ChainLink(h, l.seg, lambda: None))
+                twin.handle = twin.links[-1].handle
+            else:
+                twin.handle = self._create(self.blob)
+                made.append(twin.handle)
+            ref = twin.bind(small, (m,), ks, None, index_offset)
+            twin.launch(ref)
+            keep_work = getattr(self, "_work", 0)
+            got = self.bind(small, (m,), ks, None, index_offset)
+            self._work = keep_work
+            self.launch(got)
+            bad = None
+            for k, (a, b) in enumerate(zip(ref[3], got[3])):
+                if a is None or b is None:
+                    continue
+                ai = a.contiguous().view(torch.int32) if a.dtype == torch.float32 else a
+                bi = b.contiguous().view(torch.int32) if b.dtype == torch.float32 else b
+                if not torch.equal(ai, bi):
+                    bad = k
+                    break
+        finally:
+            torch.cuda.synchronize(be.device) if be.uses_streams else None
+            for h in made:
+                be.c.gmx_program_destroy(h)
+        if bad is not None:
+            why = (f"output {bad} of a {len(handles)}-launch program differs between the hiprtc-specialised kernel and the "
+                   f"interpreter on the first {m} particles").encode()
+            for h in handles:
+                be.c.gmx_program_despecialize(h, why)
+            self._jit_tried = True
+            warnings.warn("genjax_amd: a specialised kernel disagreed with the interpreter on its first launch and was "
+                          "dropped (the interpreter runs this program from now on): " + why.decode(), RuntimeWarning, stacklevel=3)
 
     def launch(self, bound):
         """Launch a binding made by `bind` (its buffers must still be alive: `bound` keeps them)."""

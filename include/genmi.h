@@ -39,7 +39,7 @@ typedef __UINTPTR_TYPE__ uintptr_t;
 extern "C" {
 #endif
 
-#define GMX_ABI_VERSION 7
+#define GMX_ABI_VERSION 8
 
 typedef void* gmx_stream;            /* hipStream_t */
 typedef struct gmx_program gmx_program;
@@ -225,6 +225,14 @@ int gmx_program_is_specialized(const gmx_program* p);
 /* FNV-1a (64-bit) of the specialised kernel's code object, 0 when not specialised: the identity of the code a
  * measurement was taken on (bench.py only uses profile-sourced instruction counts whose recorded hash equals this). */
 uint64_t gmx_program_code_hash(const gmx_program* p);
+/* A specialised kernel is the output of a compiler (hiprtc was caught twice miscompiling one: DESIGN.md section 5).  The
+ * host layer therefore runs every freshly specialised program ONCE beside the ahead-of-time interpreter on the first few
+ * hundred particles of its first launch and compares the outputs bit for bit (engine.Compiled._cross_check; programs of
+ * at most 31 live values — what the interpreter holds).  On a difference it calls gmx_program_despecialize: the module is
+ * unloaded, the program runs on the interpreter from then on, `why` becomes gmx_last_error() and the process-wide count
+ * gmx_jit_rejected_count() goes up.  (The reference has no counterpart: XLA is trusted there.) */
+int gmx_program_despecialize(gmx_program* p, const char* why);
+int64_t gmx_jit_rejected_count(void);
 /* number of thread blocks gmx_program_run will launch for n particles
  * (= rows of red_out_d the caller must provide). */
 int64_t gmx_program_grid(const gmx_program* p, int64_t n);

@@ -96,6 +96,8 @@ extern "C" int gmx_program_destroy(gmx_program* p) { delete p; return 0; }
 extern "C" int gmx_program_specialize(gmx_program*) { return fail("hostsim: no specialisation"); }
 extern "C" int gmx_program_is_specialized(const gmx_program*) { return 0; }
 extern "C" uint64_t gmx_program_code_hash(const gmx_program*) { return 0; }
+extern "C" int gmx_program_despecialize(gmx_program*, const char*) { return 0; }        // (never specialised here)
+extern "C" int64_t gmx_jit_rejected_count(void) { return 0; }
 extern "C" int gmx_program_set_background(gmx_program* p, uint32_t lds_pad) {     // scheduling only: nothing to mirror
   if (!p) return fail("gmx_program_set_background: null program");
   if (lds_pad > 160u * 1024u) return fail("gmx_program_set_background: lds_pad above the 160 KB of a CU");

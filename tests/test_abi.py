@@ -34,7 +34,7 @@ def test_hip_library_exports_every_declared_symbol():
     assert not missing, missing
     lib.gmx_version.restype = ctypes.c_int
     from genjax_amd import _lib
-    assert lib.gmx_version() == _lib.ABI_VERSION == 7
+    assert lib.gmx_version() == _lib.ABI_VERSION == 8
     # pure-host entry point: Threefry known-answer vector (no GPU involved)
     out = (ctypes.c_uint32 * 2)()
     lib.gmx_threefry2x32_host(ctypes.c_uint32(0x13198A2E), ctypes.c_uint32(0x03707344),

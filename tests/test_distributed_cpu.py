@@ -43,7 +43,8 @@ def _free_port():
 
 @pytest.mark.parametrize("world,capacity,tiles,prog_stats,na,fused", [
     (2, 0, 1, "1", 0, 1), (4, 0, 1, "1", 0, 1), (2, 3, 1, "1", 0, 1), (2, 0, 0, "1", 0, 1),
-    (2, 0, 1, "0", 0, 1), (2, 0, 1, "1", 0, 0), (2, 0, 1, "1", 1, 1), (4, 3, 1, "1", 1, 1)])
+    (2, 0, 1, "0", 0, 1), (2, 0, 1, "1", 0, 0), (2, 0, 1, "1", 1, 1), (4, 3, 1, "1", 1, 1),
+    (8, 0, 1, "1", 0, 1), (8, 3, 1, "1", 1, 1)])        # EIGHT ranks (BASELINE's node): plain, and overflow re-run + noise ahead
 def test_sharded_sweep_equals_single_process_oracle(tmp_path, world, capacity, tiles, prog_stats, na, fused):
     """capacity 0 = default (fast path, no overflow); capacity 3 forces the
     overflow flag and the full-capacity re-run.  tiles 1 = the two-collective step (all-gather of tile
@@ -53,7 +54,7 @@ def test_sharded_sweep_equals_single_process_oracle(tmp_path, world, capacity, t
     na 1: NOISE AHEAD on the sharded sweep — the step's draws come from background programs keyed by the GLOBAL
     particle index (lazy_split offset; GMX_KEY_ROWSPLIT rows + index_offset), launched a group of steps ahead."""
     from genjax_amd import workloads
-    n_total, T = 4096, 6
+    n_total, T = (8192 if world == 8 else 4096), 6          # (1024 per rank: shards start on a CDF tile boundary)
     out = str(tmp_path / "shard")
     r = _launch(world, [out, str(n_total // world), str(T)] + ([str(capacity)] if capacity else []),
                 extra_env={"GENMI_HOSTSIM_TILE_STATS": prog_stats, "GENMI_NOISE_GROUP": "3",
@@ -148,12 +149,12 @@ def test_sharded_importancek_over_the_peer_mapped_communicator(tmp_path):
     assert np.array_equal(got["theta"], oc.get_particles().get_choices()["theta"][anc])
 
 
-@pytest.mark.parametrize("world,capacity,comm", [(2, 0, None), (4, 7, None), (2, 0, "peer"), (4, 7, "peer")])
+@pytest.mark.parametrize("world,capacity,comm", [(2, 0, None), (4, 7, None), (2, 0, "peer"), (4, 7, "peer"), (8, 0, None), (8, 7, "peer")])
 def test_sharded_mh_sweep_equals_single_process_oracle(tmp_path, world, capacity, comm):
     """BASELINE config 3 sharded: nonlinear SSM + one MH move per step, two routed leaves (the particle and
     the state it was extended from).  Must equal the single-process oracle for any rank count; capacity 7
     forces the overflow re-run."""
-    n_total, T = 4096, 4          # 1024 per rank at world 4: shards start on a CDF tile boundary
+    n_total, T = (8192 if world == 8 else 4096), 4          # 1024 per rank at world 4 / 8: shards start on a CDF tile boundary
     out = str(tmp_path / "shard_mh")
     r = _launch(world, [out, str(n_total // world), str(T), str(capacity), "mh"], extra_env={"GENMI_COMM": comm} if comm else None)
     assert r.returncode == 0, r.stderr[-3000:]
@@ -204,12 +205,12 @@ def test_sharded_vector_state_mh_sweep_equals_single_process_oracle(tmp_path, wo
 
 
 @pytest.mark.parametrize("world,capacity,kind", [(2, 0, "systematic"), (4, 5, "systematic"), (2, 0, "multinomial_sorted"),
-                                                 (4, 5, "multinomial_sorted")])
+                                                 (4, 5, "multinomial_sorted"), (8, 0, "systematic"), (8, 5, "systematic")])
 def test_sharded_importancek_global_resample_equals_oracle(tmp_path, world, capacity, kind):
     """BASELINE config 4 sharded (8-schools ImportanceK, ONE global resample of a 10-latent trace — systematic, or the
     sorted multinomial against the table of all K slots): the concatenated ranks equal the single-process oracle, for
     any rank count."""
-    k_total = 4096
+    k_total = 8192 if world == 8 else 4096
     out = str(tmp_path / "schools")
     r = _launch(world, [out, str(k_total // world), "0", str(capacity), "schools"],
                 extra_env={"GENMI_TEST_OPTS": json.dumps({"resample": kind})})

@@ -24,6 +24,9 @@ class NotDifferentiable(NotImplementedError):
 def grad(out: Expr, wrt: list) -> list:
     g = T.current_graph()
     wrt_idx = {w.node.idx for w in wrt}
+    # a loop-carried SUM whose loop accumulated its own derivatives (static._vector_site_loop: the score of a long
+    # vector-valued site, d / d w summed over the elements in the same loop): var idx -> [(w node, derivative node)]
+    custom = g.__dict__.get("_custom_grads", {})
     # nodes that depend on a wrt node (forward reachability), restricted to ancestors of `out`
     anc = set()
     stack = [out.node]
@@ -35,12 +38,16 @@ def grad(out: Expr, wrt: list) -> list:
         if n.idx in wrt_idx:
             continue
         stack.extend(a for a in n.args if a is not None)
+        if n.op == "LOOPVAR" and n.idx in custom:
+            stack.extend(wn for wn, _ in custom[n.idx])
     dep = set(wrt_idx)
     order = sorted(anc)
     by_idx = {i: g.nodes[i] for i in order}
     for i in order:                              # args precede their users in the node list
         n = by_idx[i]
         if i not in dep and any(a is not None and a.idx in dep for a in n.args):
+            dep.add(i)
+        if i not in dep and n.op == "LOOPVAR" and any(wn.idx in dep for wn, _ in custom.get(i, ())):
             dep.add(i)
     adj = {out.node.idx: T.lift(1.0)}
 
@@ -57,6 +64,11 @@ def grad(out: Expr, wrt: list) -> list:
         if a_ is None:
             continue
         n = by_idx[i]
+        if n.op == "LOOPVAR":
+            push(n.args[0], a_)                    # the initial value
+            for wn, gv in custom.get(i, ()):
+                push(wn, a_ * Expr(gv))            # d (sum over the loop) / d w, accumulated by the loop itself
+            continue
         _rule(n, a_, push)
     zero = T.lift(0.0)
     return [adj.get(w.node.idx, zero) for w in wrt]

@@ -109,14 +109,26 @@ def _run_hmc(req: HMC, key, trace, argdiffs):
             if not sel_addrs:
                 raise ValueError("HMC: the selection holds no differentiable choice")
             values = {a: chm_all[a].value for a in sel_addrs}
+            for a in sel_addrs:
+                if isinstance(values[a], np.ndarray) and values[a].size > 16:
+                    # (the trajectory of a vector of J positions and J momenta lives in registers: 3 J values per chain;
+                    #  a long vector site's loop differentiates with respect to SCALAR choices only — static._vector_site_loop)
+                    raise NotImplementedError(
+                        f"HMC on the vector-valued site {a!r} of {values[a].size} elements: the selected sites of an HMC move "
+                        "are scalars or vectors of at most 16 elements (scalars that FEED long vector sites are fine: "
+                        "`HMC(S['mu'])` in a model with `theta ~ normal(mu 1_J, tau 1_J)` of any J)")
 
             def model_score_and_grads(vals):
                 con = chm_all
                 for a in sel_addrs:
                     con = con.set(a, vals[a])
                 ctx.store_sites = False
-                _, _, _, s = call_gen_fn(ctx, "assess", gen_fn, None, sargs, con, None, None, None, ())
                 leaves = [x for a in sel_addrs for x in _flat(vals[a])]
+                ctx.grad_wrt = leaves          # (long vector sites accumulate d score / d leaf inside their own loops)
+                try:
+                    _, _, _, s = call_gen_fn(ctx, "assess", gen_fn, None, sargs, con, None, None, None, ())
+                finally:
+                    ctx.grad_wrt = None
                 gs = grad(T.as_float(s), leaves)
                 out, k = {}, 0
                 for a in sel_addrs:

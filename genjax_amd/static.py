@@ -1063,9 +1063,20 @@ def _vector_site_loop(ctx, mode, dist, key, args, cval, prev, req):
         if not hasattr(dist, "loop_site") or len(g.loop_counts) >= 2:
             return None
     kind = req.kind if req is not None else "empty"
+    regen = False
+    if mode not in ("simulate", "generate", "assess") and kind == "regen":
+        # Regenerate ON this site (distribution.py:258-300): new values from the prior — drawn in the loop, element j on
+        # counter j of the ONE site key, as simulate does — the weight the new score minus the old; not selected: an empty
+        # request (requests.py:56-57)
+        if ctx.gate is not None:
+            return None
+        regen = bool(req.selection.check())
+        kind = "empty"
     if mode not in ("simulate", "generate", "assess") and kind not in ("update", "empty"):
         return None
     cv = cval.value if isinstance(cval, Sym) else cval
+    if regen:
+        cv = None
     if isinstance(cv, Mask):
         return None
     if ctx.gate is not None and cv is not None and mode not in ("simulate", "generate", "assess"):
@@ -1099,16 +1110,22 @@ def _vector_site_loop(ctx, mode, dist, key, args, cval, prev, req):
         return None              # (a scalar constraint broadcast over a vector site: the unrolled form says what it means)
     if pv is not None and not T._long_vector(pv):
         return None
-    new_value = mode in ("simulate",) or (mode == "generate" and cv is None)
+    new_value = mode in ("simulate",) or (mode == "generate" and cv is None) or regen
     if new_value and key is None:
         return None
-    if mode not in ("simulate", "generate", "assess"):
+    if mode not in ("simulate", "generate", "assess") and not regen:
         if cv is None and not ctx.args_changed(args):
             gv = prev["value"].value if isinstance(prev["value"], Sym) else prev["value"]
             so = gv.passthrough() if hasattr(gv, "passthrough") else None
             return _SiteRec(dist, so if so is not None else prev["value"], prev["score"]), pv, None, ps   # requests.py:56-57 / distribution.py:225-233
     zero = g.const_f32(0.0)
     svar = g.loop_var(zero)
+    # HMC differentiates the model's score with respect to selected SCALAR choices (requests/hmc.py:69-97: jax.grad of
+    # assess): the adjoint of this loop is a sum over its iterations too — d score / d w = sum_j d s_j / d w — accumulated
+    # in the SAME loop, one loop-carried register per selected scalar, and handed to autodiff.grad as this loop variable's
+    # derivative (Graph._custom_grads)
+    wrt = [w for w in (getattr(ctx, "grad_wrt", None) or ()) if isinstance(w, Expr)]
+    gvars = [g.loop_var(zero) for _ in wrt]
     g.loop_begin(n)
     with T.tracing(g):
         t = Expr(g.add("LDT", dtype="i32"))
@@ -1125,8 +1142,19 @@ def _vector_site_loop(ctx, mode, dist, key, args, cval, prev, req):
             s_t = custom[2](x_t, t)
         else:
             s_t = Expr(g.add(dist.logpdf_op, (x_t.node,) + tuple(a.node for a in a_t), dtype="f32"))
-        g.set_vars([(svar, (Expr(svar) + s_t).node)])
+        updates = [(svar, (Expr(svar) + s_t).node)]
+        used = []
+        if wrt:
+            from .autodiff import grad as _grad
+            parts = _grad(s_t, wrt)
+            for w_, gv, pt in zip(wrt, gvars, parts):
+                if not (pt.node.op == "CONST" and pt.node.imm == 0):       # (this element does not depend on w)
+                    updates.append((gv, (Expr(gv) + pt).node))
+                    used.append((w_.node, gv))
+        g.set_vars(updates)
     g.loop_end()
+    if used:
+        g.__dict__.setdefault("_custom_grads", {})[svar.idx] = used
     score = Expr(svar)
 
     def given(v):           # a long row of a per-particle leaf that IS the site's value: recorded as that leaf (no copy)
@@ -1139,6 +1167,9 @@ def _vector_site_loop(ctx, mode, dist, key, args, cval, prev, req):
         # recipe the next vector site's loop reads, engine.StepOutputAlias): a later vector site whose parameters they are
         # loops over them, `theta[3]` is one load — an 8-schools model of 5 000 schools
         ret = tr.alias_step_input(origin, dist.value_dtype, n)
+        if regen:
+            ctx.mark_changed(ret)
+            return _SiteRec(dist, v, score, discard=given(prev["value"])), ret, score - ps, score     # (distribution.py:266-277)
         return _SiteRec(dist, v, score), ret, None, score   # (generate, unconstrained: w = 0, distribution.py:124-127)
     if mode == "generate":
         return _SiteRec(dist, given(cval), score), cv, score, score          # w = score = logpdf (:144-147)

@@ -569,6 +569,15 @@ class _Normal(Distribution):
         z = (x.v / s.v - m.v / s.v).astype(np.float32)
         zs = (z / s.v).astype(np.float32)
         t = (-(zs * x.t) + zs * m.t + ((z * z - np.float32(1.0)) / s.v) * s.t).astype(np.float32)
+        if np.ndim(t) > np.ndim(val):
+            # a VECTOR-valued site: the score is the sum over its elements (distribution.py:383-396), so is its tangent —
+            # added in element order, the order the build's counted loop accumulates d score / d w in
+            t = np.broadcast_to(t, np.broadcast_shapes(np.shape(t), np.shape(z)))
+            flat = t.reshape(t.shape[: np.ndim(val)] + (-1,))
+            acc = np.zeros(flat.shape[:-1], np.float32)
+            for j in range(flat.shape[-1]):
+                acc = (acc + flat[..., j]).astype(np.float32)
+            t = acc
         return Dual(val, np.broadcast_to(t, np.shape(val)))
 
     def _sample_flat(self, n, kb, e, cols, out):

@@ -468,3 +468,82 @@ def check_scan_outputs_and_array_carries(T_=40, N=6, seed=1):
     otr2, ow2, _ = o_model.update(ok2, otr, O.C.d({("s", "x"): newx}), ())
     assert same(w2, ow2) and same(tr2.get_score(), otr2.get_score())
     return dict(w=npv(w2))
+
+
+# =====================================================================================================================
+# HMC / Regenerate through LONG vector sites (requests/hmc.py:138-211, distribution.py:258-300)
+# =====================================================================================================================
+def _col(v):
+    return O.Dual(v.v[..., None], v.t[..., None]) if isinstance(v, O.Dual) else np.asarray(v, f32)[..., None]
+
+
+def check_hmc_through_long_vector_sites(npts=500, J=200, K=7, L=3, seed=1):
+    """`HMC` on scalars that feed LONG vector sites, in ONE launch: Bayesian linear regression `y ~ normal(a xs + b, 0.5)` with
+    npts observations, `HMC(S["a"] | S["b"])`; 8-schools at J schools, `HMC(S["mu"])` and `HMC(S["mu"] | S["log_tau"])`.  The
+    vector site's counted loop accumulates d score / d w beside the score (static._vector_site_loop, autodiff.grad's custom
+    derivative of a loop-carried sum); the oracle differentiates in forward mode (Dual numbers) and adds a vector site's
+    tangents in element order — the new values and the weight agree BIT FOR BIT.  `Regenerate(S["theta"])` ON the long site
+    runs as a counted loop as well.  `HMC(S["theta"])` beyond 16 elements raises, naming the site."""
+    import genjax_amd as G
+    from genjax_amd import ChoiceMapBuilder as C, Diff, Regenerate, SelectionBuilder as S
+    from genjax_amd import numpy as jnp
+    from genjax_amd.inference.requests import HMC
+    xs = np.linspace(-1, 1, npts).astype(f32)
+    ys = (f32(0.7) * xs + f32(0.2)).astype(f32)
+
+    @G.gen
+    def reg():
+        a = G.normal(0.0, 2.0) @ "a"
+        b = G.normal(0.0, 2.0) @ "b"
+        G.normal(a * jnp.array(xs) + b, 0.5) @ "y"
+        return a
+
+    @O.gen
+    def oreg():
+        a = O.normal(f32(0.0), f32(2.0)) @ "a"
+        b = O.normal(f32(0.0), f32(2.0)) @ "b"
+        O.normal(_col(a) * xs + _col(b), f32(0.5)) @ "y"
+        return a
+    tr, _ = reg.importance(G.split(G.key(seed), K), C["y"].set(jnp.array(ys)), ())
+    otr, _ = oreg.importance(O.split(O.key(seed), K), O.C.d({"y": ys}), ())
+    new, w, _, _ = HMC(S["a"] | S["b"], 1e-3, L=L).edit(G.split(G.key(seed + 1), K), tr, Diff.no_change(()))
+    onew, ow = O.hmc_edit(O.split(O.key(seed + 1), K), otr, ["a", "b"], 1e-3, L, ())
+    for a_ in ("a", "b"):
+        assert same(new.get_choices()[a_], onew.get_choices()[a_]), ("regression", a_)
+    assert same(w, ow), ("regression weight", npv(w), np.asarray(ow))
+    # 8-schools at J schools
+    sig = np.linspace(9, 18, J).astype(f32)
+    yj = np.linspace(-3, 28, J).astype(f32)
+
+    @G.gen
+    def schools():
+        mu = G.normal(0.0, 5.0) @ "mu"
+        log_tau = G.normal(0.0, 1.0) @ "log_tau"
+        theta = G.normal(mu * jnp.ones(J), jnp.exp(log_tau) * jnp.ones(J)) @ "theta"
+        G.normal(theta, jnp.array(sig)) @ "y"
+        return mu
+
+    @O.gen
+    def oschools():
+        mu = O.normal(f32(0.0), f32(5.0)) @ "mu"
+        log_tau = O.normal(f32(0.0), f32(1.0)) @ "log_tau"
+        theta = O.normal(_col(mu) * np.ones(J, f32), _col(O.exp(log_tau)) * np.ones(J, f32)) @ "theta"
+        O.normal(theta, sig) @ "y"
+        return mu
+    tr, _ = schools.importance(G.split(G.key(seed), K), C["y"].set(jnp.array(yj)), ())
+    otr, _ = oschools.importance(O.split(O.key(seed), K), O.C.d({"y": yj}), ())
+    for sel, osel in ((S["mu"], ["mu"]), (S["mu"] | S["log_tau"], ["mu", "log_tau"])):
+        new, w, _, _ = HMC(sel, 1e-3, L=L).edit(G.split(G.key(seed + 2), K), tr, Diff.no_change(()))
+        onew, ow = O.hmc_edit(O.split(O.key(seed + 2), K), otr, osel, 1e-3, L, ())
+        for a_ in osel:
+            assert same(new.get_choices()[a_], onew.get_choices()[a_]), ("schools", osel, a_)
+        assert same(w, ow), ("schools weight", osel)
+    new, wr, _, _ = Regenerate(S["theta"]).edit(G.split(G.key(seed + 3), K), tr, Diff.no_change(()))
+    onew, owr = oschools.regenerate(O.split(O.key(seed + 3), K), otr, O.selection("theta"), ())[:2]
+    assert same(new.get_choices()["theta"], onew.get_choices()["theta"]) and np.array_equal(npv(wr), np.asarray(owr, f32), equal_nan=True)
+    if J > 16:
+        try:
+            HMC(S["theta"], 1e-3, L=L).edit(G.split(G.key(seed + 4), K), tr, Diff.no_change(()))
+            raise AssertionError("HMC on a 17+-element vector site should raise")
+        except NotImplementedError as e:
+            assert "vector-valued site" in str(e) and "theta" in str(e)

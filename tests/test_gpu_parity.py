@@ -2107,3 +2107,10 @@ def test_first_launch_cross_check_rejects_a_wrong_specialised_kernel(gpu, monkey
     assert b"rejected" in gpu.c.gmx_last_error()
     assert np.array_equal(tr2.get_choices()["y"].cpu().numpy(), otr2.get_choices()["y"])
     assert np.array_equal(tr2.get_score().cpu().numpy(), np.asarray(otr2.get_score(), np.float32))
+
+
+def test_hmc_and_regenerate_through_long_vector_sites_on_device(gpu):
+    from tests import cookbook
+    for npts, J in ((100, 40), (500, 200), (5000, 1000)):
+        cookbook.check_hmc_through_long_vector_sites(npts=npts, J=J)
+    cookbook.check_hmc_through_long_vector_sites(npts=500, J=200, K=300_000, L=2)          # specialised kernels

@@ -1819,3 +1819,11 @@ def test_traced_negative_index_wraps_like_jax_and_static_false_mask_gives_way():
     r = tr.get_retval().numpy()
     assert np.allclose(r, [2, 3, 0, 1, 2, 3], atol=0.1)
     assert _or_values(Mask(1.0, False), 2.0) == 2.0
+
+
+@pytest.mark.parametrize("npts,J", [(100, 40), (500, 200), (5000, 1000)])
+def test_hmc_and_regenerate_through_long_vector_sites(npts, J):
+    """linear regression with 100 / 500 / 5 000 points `HMC(S["a"] | S["b"])`, 8-schools at J = 40 / 200 /
+    1 000 `HMC(mu)`, `HMC(mu | log_tau)`, `Regenerate(theta)` — one launch each, bit-exact against the oracle"""
+    from tests import cookbook
+    cookbook.check_hmc_through_long_vector_sites(npts=npts, J=J)

@@ -1827,3 +1827,20 @@ def test_hmc_and_regenerate_through_long_vector_sites(npts, J):
     1 000 `HMC(mu)`, `HMC(mu | log_tau)`, `Regenerate(theta)` — one launch each, bit-exact against the oracle"""
     from tests import cookbook
     cookbook.check_hmc_through_long_vector_sites(npts=npts, J=J)
+
+
+def test_support_matrix_is_current():
+    """SUPPORT.md is GENERATED (tools/support_matrix.py runs every form x method x size cell on this CPU mirror): a sample of
+    freshly run rows must be in the committed file word for word — the table cannot drift from the code"""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("support_matrix", os.path.join(root, "tools", "support_matrix.py"))
+    sm = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sm)
+    committed = open(os.path.join(root, "SUPPORT.md")).read()
+    rows = sm.generate(sample=7)
+    assert len(rows) >= 6
+    for name, size, batch, cells in rows:
+        line = f"| {name} | {size} | {batch} | " + " | ".join(cells) + " |"
+        assert line in committed, line

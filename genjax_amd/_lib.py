@@ -21,6 +21,9 @@ GMX_MAX_TAB = 8
 GMX_MAX_UNI = 64
 
 ABI_VERSION = 8
+ANC_TAG_SHIFT = 24          # a tagged ancestor word = {tag: bits 24..31 | index: bits 0..23} (csrc/gmx_offspring.h)
+ANC_INDEX_MASK = (1 << ANC_TAG_SHIFT) - 1
+ANC_TAG_MAX = 255
 KEY_NONE, KEY_ARRAY, KEY_SPLIT, KEY_ROWSPLIT, KEY_BCAST = 0, 1, 2, 3, 4
 RESAMPLE_SYSTEMATIC, RESAMPLE_STRATIFIED, RESAMPLE_MULTINOMIAL, RESAMPLE_MULTINOMIAL_TILED = 0, 1, 2, 3
 RESAMPLE_MULTINOMIAL_SORTED = 4
@@ -156,6 +159,7 @@ class Backend:
         c.gmx_program_writes_tile_stats.argtypes = [c_void_p]
         c.gmx_program_set_background.argtypes = [c_void_p, c_uint32]
         c.gmx_program_set_fuse_resample.argtypes = [c_void_p]
+        c.gmx_program_set_fuse_resample_loop.argtypes = [c_void_p]
         c.gmx_program_fuses_resample.argtypes = [c_void_p]
         c.gmx_program_set_fuse_shard_step.argtypes = [c_void_p]
         c.gmx_program_fuses_shard_step.argtypes = [c_void_p]

@@ -36,6 +36,20 @@
 #define GMX_JIT_NAME gmx_jit_kernel
 #endif
 
+// A LOOPED launch (GMX_JIT_RS_LOOP, gmx_program_set_fuse_resample_loop): more 1024-particle tiles than the device holds
+// workgroups at once — a bootstrap step of more than 2^20 particles in ONE launch.  The grid is min(tiles, 1024)
+// workgroups; workgroup b handles tiles b, b + G, b + 2 G, ... in TWO passes: first the resampling of the previous step
+// for every one of its tiles (after ONE pass over the statistics table: gmx_tile_table_pass) — nothing there waits for
+// another workgroup — then, tile by tile, the wait for its own particles' ancestor words, the gather and the site program.
+// Every word a workgroup waits for is written by the FIRST pass of a workgroup of the same launch, and first passes wait
+// for nothing: residency is needed for G workgroups only, whatever n.
+#if defined(GMX_JIT_RS_LOOP)
+#define GMX_JIT_BLK gmx_blk
+#define GMX_RS_LOOP_MAX 16             /* tiles per workgroup: 16 x 1024 workgroups x 1024 particles = 2^24 */
+#else
+#define GMX_JIT_BLK blockIdx.x
+#endif
+
 template <int NDYN, int PPV>
 struct gmx_jit_ctx {
   const uint32_t* consts;   // constexpr constants (pool entries NDYN..)
@@ -44,6 +58,7 @@ struct gmx_jit_ctx {
   uint64_t* lds8;           // 4 x u64 scratch (tile statistics)
   float red_x[PPV];         // OP_REDMAX operands of the thread's particles (-inf when inactive)
   int cur;                  // which of the thread's particles this step works on
+  uint32_t blk;             // the 1024-particle tile / block-partial row this workgroup works on (blockIdx.x, or a looped launch's tile)
   uint32_t part;            // index of the 256-particle group this step works on (block partial row)
   uint32_t rows;            // number of 256-particle groups = ceil(n / 256)
   int64_t n_rows;           // n (particles of this launch)
@@ -68,7 +83,7 @@ struct gmx_jit_ctx {
     acc_max = first ? m : gmx_rmax(acc_max, m);
     if (last) {
       const float bm = block_max(acc_max, lds4);
-      if (threadIdx.x == 0 && A->red_out_d) A->red_out_d[blockIdx.x] = bm;
+      if (threadIdx.x == 0 && A->red_out_d) A->red_out_d[blk] = bm;
       if (PPV == 4 && A->tile_agg_d) {
         const float ref = gmx_tile_ref(gmx_tile_exp(bm));
         uint64_t s = 0;
@@ -78,9 +93,9 @@ struct gmx_jit_ctx {
         if ((threadIdx.x & 63) == 0) lds8[threadIdx.x >> 6] = s;
         __syncthreads();
         const uint64_t a_b = (lds8[0] + lds8[1]) + (lds8[2] + lds8[3]);
-        if (threadIdx.x == 0) A->tile_agg_d[blockIdx.x] = a_b;
+        if (threadIdx.x == 0) A->tile_agg_d[blk] = a_b;
         // sharded: the same two numbers straight into every other rank's landing table (thread p serves rank p)
-        if (peer_land) gmx_peer_put_tile(peer_land, peer_tag, A->peer.world, A->peer.tiles, A->peer.rank, (int)blockIdx.x, a_b, bm);
+        if (peer_land) gmx_peer_put_tile(peer_land, peer_tag, A->peer.world, A->peer.tiles, A->peer.rank, (int)blk, a_b, bm);
       }
     }
   }
@@ -108,6 +123,34 @@ struct gmx_jit_ctx {
 #else
 #define GMX_JIT_OCC
 #endif
+#if defined(GMX_JIT_RS_LOOP)
+// first pass: the resampling of step t - 1 for every tile of this workgroup; then the loop over its tiles opens
+#define GMX_JIT_LOOP_OPEN                                                                        \
+    const int gmx_tiles = (int)((n + (int64_t)(PP * GMX_BLOCK) - 1) / (int64_t)(PP * GMX_BLOCK)); \
+    const int gmx_G = (int)gridDim.x;                                                            \
+    const int gmx_C = (gmx_tiles + gmx_G - 1) / gmx_G;                                           \
+    if (PP == 4 && A.rs.lw_d) {                                                                  \
+      __shared__ uint64_t gmx_pf[GMX_RS_LOOP_MAX];                                               \
+      uint64_t gmx_tot, gmx_mk;                                                                  \
+      gmx_tile_table_pass(A.rs.tile_max_d, A.rs.tile_agg_d, gmx_tiles, (int)blockIdx.x, gmx_G, gmx_C, gmx_pf, gmx_tot, gmx_mk); \
+      GMX_JIT_NOUNROLL for (int gmx_c = 0; gmx_c < gmx_C; ++gmx_c) {                             \
+        const int gmx_tile = (int)blockIdx.x + gmx_c * gmx_G;                                    \
+        if (gmx_tile < gmx_tiles)                                                                \
+          gmx_offspring_tile_body<GMX_RESAMPLE_SYSTEMATIC, 0, true>(A.rs.key0, A.rs.key1, A.rs.u0, A.rs.lw_d, A.rs.tile_max_d, \
+              (const uint64_t*)nullptr, n, gmx_tiles, gmx_pow2i(A.rs.shift), A.rs.max_out_d, A.rs.total_out_d, \
+              const_cast<int32_t*>(A.ancestors_d), nullptr, A.rs.tag, gmx_tile, gmx_pf[gmx_c], gmx_tot, gmx_mk); \
+        __syncthreads();                                                                         \
+      }                                                                                          \
+    }                                                                                            \
+    GMX_JIT_NOUNROLL for (int gmx_lc = 0; gmx_lc < gmx_C; ++gmx_lc) {                            \
+      const uint32_t gmx_blk = blockIdx.x + (uint32_t)gmx_lc * (uint32_t)gmx_G;                  \
+      if ((int)gmx_blk >= gmx_tiles) break;                /* block-uniform */                   \
+      if (gmx_lc) __syncthreads();
+#define GMX_JIT_LOOP_CLOSE }
+#else
+#define GMX_JIT_LOOP_OPEN
+#define GMX_JIT_LOOP_CLOSE
+#endif
 #define GMX_JIT_BEGIN(NREGS, FULLV, NDYN, PPV, NPRE)                                             \
   extern "C" __global__ void __launch_bounds__(GMX_BLOCK) GMX_JIT_OCC GMX_JIT_NAME(int64_t n, const gmx_run_args A) { \
  GMX_JIT_PRIO                                                                                 \
@@ -126,6 +169,8 @@ struct gmx_jit_ctx {
       if (threadIdx.x < (uint32_t)A.peer.world && (int)threadIdx.x != A.peer.rank)               \
         ctx.peer_land = (uint64_t*)A.peer.land_d[threadIdx.x];                                   \
     }                                                                                            \
+    GMX_JIT_LOOP_OPEN                                                                            \
+    ctx.blk = GMX_JIT_BLK;                                                                       \
     regs_t R[PP];                                                                                \
     /* particle rows as 32-bit numbers (gmx_program_run admits n < 2^31 for a specialised kernel): the 64-bit \
        forms below are zero-extensions, so address arithmetic is a shift-add, not 64-bit compares / selects */  \
@@ -142,7 +187,7 @@ struct gmx_jit_ctx {
     const uint32_t row0 = blockIdx.y * n32;                                                      \
     _Pragma("unroll") for (int p = 0; p < PP; ++p) {                                             \
       R[p].init();                                                                               \
-      const uint32_t i32 = (blockIdx.x * (uint32_t)PP + (uint32_t)p) * (uint32_t)GMX_BLOCK + threadIdx.x; \
+      const uint32_t i32 = (GMX_JIT_BLK * (uint32_t)PP + (uint32_t)p) * (uint32_t)GMX_BLOCK + threadIdx.x; \
       idx[p] = (int64_t)(row0 + i32);                                                            \
       act[p] = i32 < n32;                                                                        \
       cidx[p] = row0 + (act[p] ? i32 : n32 - 1u);                                                \
@@ -200,6 +245,13 @@ struct gmx_jit_ctx {
     } else {                                                                                     \
       _Pragma("unroll") for (int p = 0; p < PP; ++p) arow[p] = (uint32_t)A.ancestors_d[cidx[p]]; \
     }
+#elif defined(GMX_JIT_RS_LOOP)
+#define GMX_JIT_PRE_ANC                                                                          \
+    if (PP == 4 && A.rs.lw_d) {                                                                  \
+      GMX_JIT_POLL_ANC(A.rs.tag, A.rs.status_d, n32)                                             \
+    } else {                                                                                     \
+      _Pragma("unroll") for (int p = 0; p < PP; ++p) arow[p] = (uint32_t)A.ancestors_d[cidx[p]]; \
+    }
 #elif defined(GMX_JIT_RS)
 #define GMX_JIT_PRE_ANC                                                                          \
     if (PP == 4 && A.rs.lw_d) {                                                                  \
@@ -228,7 +280,7 @@ struct gmx_jit_ctx {
 
 #define GMX_JIT_OP(W0, W1)                                                                       \
     _Pragma("unroll") for (int p = 0; p < PP; ++p) {                                             \
-      ctx.part = blockIdx.x * PP + p; ctx.first = (p == 0); ctx.last = (p == PP - 1); ctx.cur = p; \
+      ctx.part = GMX_JIT_BLK * PP + p; ctx.first = (p == 0); ctx.last = (p == PP - 1); ctx.cur = p; \
       gmx_vm_step<regs_t, full_v, gmx_cword<W0, W1>, ctx_t>(R[p], gmx_cword<W0, W1>(), idx[p], act[p], A, ctx, gmx_t, gmx_tf); \
     }
 
@@ -249,4 +301,4 @@ struct gmx_jit_ctx {
     GMX_JIT_NOUNROLL for (uint32_t gmx_t2 = 0u; gmx_t2 < (COUNT); ++gmx_t2) { gmx_t = gmx_t2; gmx_tf = gmx_tfp * (COUNT) + gmx_t2;
 #define GMX_JIT_ENDLOOP3 } gmx_t = gmx_tp; gmx_tf = gmx_tfp; }
 
-#define GMX_JIT_END }
+#define GMX_JIT_END GMX_JIT_LOOP_CLOSE }

@@ -154,6 +154,7 @@ struct gmx_program {
   int jit_pp = 1;                    // particles per thread of the specialised kernel
   uint64_t jit_code_hash = 0;        // FNV-1a of the loaded code object (gmx_program_code_hash)
   bool fuse_rs = false;              // gmx_program_set_fuse_resample: the specialised kernel can resample first
+  bool fuse_rs_loop = false;         // gmx_program_set_fuse_resample_loop: ... with fewer workgroups than tiles (n > 2^20)
   bool fuse_sh = false;              // gmx_program_set_fuse_shard_step: ... or route a sharded step first
   bool jit_gathers_pre = false;      // every gathered load of the specialised kernel goes through the prologue's ancestors
   int64_t jit_resident_blocks = 0;   // workgroups of the specialised kernel one device holds AT ONCE (occupancy x CUs)
@@ -299,6 +300,7 @@ static std::string jit_source(const gmx_program* p, bool* gathers_prefetched = n
   if (const char* f_ = getenv("GENMI_JIT_FAULT")) { if (f_[0] == '1') s += "#define GMX_JIT_FAULT 1\n"; }   // (tests: a kernel that
                                                         // stores every 32-bit word with its lowest bit flipped — what the first-launch cross-check must catch)
   if (p->fuse_rs) s += "#define GMX_JIT_RS 1\n";
+  if (p->fuse_rs_loop) s += "#define GMX_JIT_RS_LOOP 1\n";
   if (p->fuse_sh) s += "#define GMX_JIT_SH 1\n";
   s += "#include \"gmx_jit.h\"\n";
   char buf[128];
@@ -404,6 +406,20 @@ extern "C" int gmx_program_set_fuse_resample(gmx_program* p) {
   p->fuse_rs = true;
   return 0;
 }
+extern "C" int gmx_program_set_fuse_resample_loop(gmx_program* p) {
+  if (!p) return gmx_fail("gmx_program_set_fuse_resample_loop: null program%s");
+  if (p->jit_fn) return gmx_fail("gmx_program_set_fuse_resample_loop: the program is already specialised%s");
+  p->fuse_rs = true;
+  p->fuse_rs_loop = true;
+  return 0;
+}
+// workgroups of a LOOPED launch: what the device holds at once, at most 1024 (4 per CU: the shape the one-tile-per-workgroup
+// launch of 2^20 particles has always had) and at most the tiles there are
+static int64_t rs_loop_grid(const gmx_program* p, int64_t tiles) {
+  int64_t g = p->jit_resident_blocks > 0 ? p->jit_resident_blocks : 256;
+  if (g > 1024) g = 1024;
+  return tiles < g ? tiles : g;
+}
 extern "C" int gmx_program_fuses_resample(const gmx_program* p) {
   return p && p->jit_fn && p->fuse_rs && p->jit_pp == 4 && p->uses_gather && p->jit_gathers_pre ? 1 : 0;
 }
@@ -418,6 +434,8 @@ extern "C" int gmx_program_fuses_shard_step(const gmx_program* p) {
 }
 extern "C" int64_t gmx_program_resident_particles(const gmx_program* p) {
   if (!p || !p->jit_fn) return 0;
+  if (p->fuse_rs_loop && p->jit_pp == 4 && p->jit_resident_blocks > 0)           // a looped launch walks its tiles: 16 per workgroup
+    return rs_loop_grid(p, 1024) * 16 * (int64_t)GMX_BLOCK * 4;
   return p->jit_resident_blocks * (int64_t)GMX_BLOCK * (int64_t)p->jit_pp;
 }
 
@@ -609,7 +627,8 @@ extern "C" size_t gmx_specialize_dryrun2(const uint32_t* blob, size_t n_words, i
                                          char* code_out, size_t code_cap) {
   gmx_program P;
   if (parse_program(blob, n_words, P)) { if (log_out && log_cap) snprintf(log_out, log_cap, "%s", g_err); return 0; }
-  P.fuse_rs = (flags & 1) != 0;
+  P.fuse_rs = (flags & 1) != 0 || (flags & 8) != 0;
+  P.fuse_rs_loop = (flags & 8) != 0;
   P.background = (flags & 2) != 0;
   P.fuse_sh = (flags & 4) != 0;
   const gmx_program* p = &P;
@@ -672,14 +691,16 @@ extern "C" int gmx_program_run(const gmx_program* p, int64_t n, const gmx_run_ar
     if (!q.tile_max_d || !q.tile_agg_d || !q.max_out_d || !q.total_out_d || !q.status_d)
       return gmx_fail("gmx_program_run: rs has a null pointer%s");
     if ((uintptr_t)q.lw_d & 15) return gmx_fail("gmx_program_run: rs.lw_d must be 16-byte aligned%s");
-    if ((n + RS_TILE - 1) / RS_TILE > 1024 || n > gmx_program_resident_particles(p))
+    if ((!p->fuse_rs_loop && (n + RS_TILE - 1) / RS_TILE > 1024) || n > gmx_program_resident_particles(p) ||
+        n > (int64_t)GMX_ANC_INDEX_MASK + 1)
       return gmx_fail("gmx_program_run: rs: every workgroup of the launch must be resident at once (n <= 2^20 and "
-                      "n <= gmx_program_resident_particles())%s");
+                      "n <= gmx_program_resident_particles(); a looped program — gmx_program_set_fuse_resample_loop — "
+                      "walks up to 16 tiles per workgroup: n <= 2^24)%s");
     if (q.shift < 1 || q.shift > 62) return gmx_fail("gmx_program_run: rs.shift out of range%s");
     int need = 0;
     while (((int64_t)1 << need) < n) ++need;
     if (q.shift + need > 62) return gmx_fail("gmx_program_run: rs.shift too large for n (overflow)%s");
-    if (q.tag < 1u || q.tag > 2047u) return gmx_fail("gmx_program_run: rs.tag must be in [1, 2047]%s");
+    if (q.tag < 1u || q.tag > GMX_ANC_TAG_MAX) return gmx_fail("gmx_program_run: rs.tag must be in [1, 255]%s");
     if (args->tile_agg_d == q.tile_agg_d || (const float*)args->red_out_d == q.tile_max_d)
       return gmx_fail("gmx_program_run: rs reads the tile statistics this launch writes (use two sets)%s");
     for (uint32_t s = 0; s < p->n_out; ++s)
@@ -706,7 +727,7 @@ extern "C" int gmx_program_run(const gmx_program* p, int64_t n, const gmx_run_ar
       return gmx_fail("gmx_program_run: sh: every workgroup of the launch must be resident at once "
                       "(n <= gmx_program_resident_particles())%s");
     if (q.shift < 1 || q.shift > 62) return gmx_fail("gmx_program_run: sh.shift out of range%s");
-    if (q.tag < 1u || q.tag > 2047u) return gmx_fail("gmx_program_run: sh.tag must be in [1, 2047]%s");
+    if (q.tag < 1u || q.tag > GMX_ANC_TAG_MAX) return gmx_fail("gmx_program_run: sh.tag must be in [1, 255]%s");
     for (int l = 0; l < q.peer.leaves; ++l)
       if (!q.state_d[l] || !q.tail_d[l]) return gmx_fail("gmx_program_run: sh: a leaf pointer is null%s");
     for (uint32_t s_ = 0; s_ < p->n_out; ++s_)
@@ -770,6 +791,7 @@ extern "C" int gmx_program_run(const gmx_program* p, int64_t n, const gmx_run_ar
       ka.n = per_row;
     }
     unsigned jgrid = (unsigned)((per_row + (int64_t)GMX_BLOCK * p->jit_pp - 1) / ((int64_t)GMX_BLOCK * p->jit_pp));
+    if (p->fuse_rs_loop && p->jit_pp == 4) jgrid = (unsigned)rs_loop_grid(p, (int64_t)jgrid);      // each workgroup walks its tiles
     const unsigned dyn_lds = p->lds_pad;
     GMX_HIP(hipModuleLaunchKernel(p->jit_fn, jgrid, (unsigned)rows, 1, GMX_BLOCK, 1, 1, dyn_lds, st, nullptr, config));
     return 0;

@@ -18,11 +18,12 @@
 static_assert(RS_TILE == 1024 && RS_THREADS == GMX_BLOCK, "resampling tiles are the CDF's definition tiles");
 static_assert(RS_MAX_TILES % GMX_BLOCK == 0, "tile table shape");
 
-// TAGGED (a site program's prologue): every ancestor is stored as {tag: bits 21..31 | index: bits 0..20} with a
+// TAGGED (a site program's prologue): every ancestor is stored as {tag: bits 24..31 | index: bits 0..23} with a
 // write-through (sc1) store — the workgroups of the SAME launch that gather through these slots poll them until the tag
 // is the step's (4-byte stores are single-copy atomic: the data is its own flag; no fence, no counter).
-#define GMX_ANC_TAG_SHIFT 21
-#define GMX_ANC_INDEX_MASK 0x1fffffu
+#define GMX_ANC_TAG_SHIFT 24           /* {tag: bits 24..31 | index: bits 0..23}: 16.7 M particles per launch, tags 1 .. 255 */
+#define GMX_ANC_INDEX_MASK 0xffffffu
+#define GMX_ANC_TAG_MAX 255u           /* (every slot is rewritten at every step: a stale word is at most one use old) */
 __device__ __forceinline__ void gmx_store_u32x4_sc1(uint32_t* p, uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
   typedef uint32_t v4 __attribute__((ext_vector_type(4)));
   v4 v; v.x = a; v.y = b; v.z = c; v.w = d;
@@ -91,13 +92,18 @@ __device__ __forceinline__ void
 gmx_offspring_tile_body(uint32_t k0, uint32_t k1, uint32_t u0_host, const float* __restrict__ lw,
                         const float* __restrict__ tmax, const uint64_t* __restrict__ agg, int64_t n, int n_tiles, float scale,
                         float* __restrict__ max_out, uint64_t* __restrict__ total_out, int32_t* __restrict__ anc,
-                        const uint32_t* __restrict__ uslot, uint32_t tag) {
+                        const uint32_t* __restrict__ uslot, uint32_t tag,
+                        int tile0 = -1, uint64_t a_prefix = 0ull, uint64_t a_total = 0ull, uint64_t a_mk = 0ull) {
+  // tile0 >= 0: the tile this call works on, when it is not the workgroup's number — a LOOPED launch (gmx_jit.h,
+  // GMX_JIT_RS_LOOP: more tiles than the device holds workgroups; each workgroup handles tiles blockIdx + c * gridDim).
+  // PER == 0 with agg == nullptr: the tile's prefix, the total and (M, K) arrive as arguments (gmx_tile_table_pass below).
+  const int blk = tile0 >= 0 ? tile0 : (int)blockIdx.x;
   const uint32_t tagw = TAGGED ? (tag << GMX_ANC_TAG_SHIFT) : 0u;
   __shared__ uint64_t s_below[RS_WAVES], s_all[RS_WAVES], s_scan[RS_WAVES], s_g[RS_TPB];
   __shared__ float s_max[RS_WAVES];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int grp = threadIdx.x >> 8, ltid = threadIdx.x & (GMX_BLOCK - 1);      // which of the block's tiles / thread within it
-  const int first_tile = (int)blockIdx.x * RS_TPB;
+  const int first_tile = blk * RS_TPB;
   const int my_tile = first_tile + grp;
   const bool tile_ok = my_tile < n_tiles;                                        // wave-uniform
   const int tile_c = tile_ok ? my_tile : n_tiles - 1;
@@ -126,7 +132,8 @@ gmx_offspring_tile_body(uint32_t k0, uint32_t k1, uint32_t u0_host, const float*
   float tm[PERN];
   uint64_t pf_prefix = 0, pf_total = 0, pf_mk = 0;
   if (PREF) {
-    pf_prefix = agg[tile_c]; pf_total = agg[n_tiles]; pf_mk = agg[n_tiles + 1];
+    if (agg) { pf_prefix = agg[tile_c]; pf_total = agg[n_tiles]; pf_mk = agg[n_tiles + 1]; }
+    else { pf_prefix = a_prefix; pf_total = a_total; pf_mk = a_mk; }
   } else {
 #pragma unroll
     for (int r = 0; r < PERN; ++r) {              // loads only (clamped rows): nothing here waits
@@ -215,7 +222,7 @@ gmx_offspring_tile_body(uint32_t k0, uint32_t k1, uint32_t u0_host, const float*
 #pragma unroll
     for (int j = 0; j < RS_TPB; ++j) prefix += (j < grp) ? s_g[j] : 0ull;
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) { *total_out = total; *max_out = M; }
+  if (blk == 0 && threadIdx.x == 0) { *total_out = total; *max_out = M; }
   if (!tile_ok) return;                                  // a whole tile group past the end (uniform per wave; no barrier follows)
   gmx_key key; key.k0 = k0; key.k1 = k1;
   if (total == 0) {       // no mass at all (all weights -inf / NaN): every slot maps to the last particle
@@ -416,3 +423,50 @@ gmx_offspring_tile_body(uint32_t k0, uint32_t k1, uint32_t u0_host, const float*
   }
 }
 
+
+
+// The statistics pass of a LOOPED launch (GMX_JIT_RS_LOOP): the workgroup handles the C tiles blk, blk + G, blk + 2 G, ...
+// and walks the whole table of n_tiles entries TWICE: the global max first (the exponent every G_t is scaled to), then, chunk
+// by chunk of G entries, the chunk's sum and the sum of its entries in front of this workgroup's tile — prefix[c] = (all
+// chunks before c) + (entries cG .. cG + blk - 1): the same integers gmx_tile_prefix_block / k_tile_prefix_big produce (sums
+// of u64 are exact in any order; a max does not care about order).  One pass per WORKGROUP, not per tile: at 8e6 particles
+// (7813 tiles, 12 bytes each) every workgroup reads 2 x 94 KB from L2.  Two accumulators per thread whatever C.
+__device__ __forceinline__ void
+gmx_tile_table_pass(const float* __restrict__ tmax, const uint64_t* __restrict__ agg, int n_tiles, int blk, int G, int C,
+                    uint64_t* __restrict__ s_pf /* LDS, C entries */, uint64_t& total, uint64_t& mk) {
+  __shared__ float s_tm[RS_WAVES];
+  __shared__ uint64_t s_acc[RS_WAVES][2];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float M = -gmx_inf();
+  for (int t = (int)threadIdx.x; t < n_tiles; t += RS_BLOCK) M = gmx_rmax(M, tmax[t]);
+  M = wave_max(M);
+  if (lane == 0) s_tm[wave] = M;
+  __syncthreads();
+  M = s_tm[0];
+#pragma unroll
+  for (int w = 1; w < RS_WAVES; ++w) M = gmx_rmax(M, s_tm[w]);
+  const int32_t K = gmx_tile_exp(M);
+  uint64_t running = 0;
+#pragma clang loop unroll(disable)
+  for (int c = 0; c < C; ++c) {
+    const int lo = c * G, hi = (lo + G < n_tiles) ? lo + G : n_tiles, mine = lo + blk;
+    uint64_t tot = 0, part = 0;
+    for (int t = lo + (int)threadIdx.x; t < hi; t += RS_BLOCK) {
+      const uint64_t g_ = gmx_tile_scale(agg[t], gmx_tile_exp(tmax[t]), K);
+      tot += g_;
+      part += (t < mine) ? g_ : 0ull;
+    }
+    tot = wave_sum_u64(tot);
+    part = wave_sum_u64(part);
+    if (lane == 0) { s_acc[wave][0] = tot; s_acc[wave][1] = part; }
+    __syncthreads();
+    uint64_t T_ = 0, P_ = 0;
+#pragma unroll
+    for (int w = 0; w < RS_WAVES; ++w) { T_ += s_acc[w][0]; P_ += s_acc[w][1]; }
+    if (threadIdx.x == 0) s_pf[c] = running + P_;
+    running += T_;
+    __syncthreads();
+  }
+  total = running;
+  mk = (uint64_t)gmx_f2u(M) | ((uint64_t)(uint32_t)K << 32);
+}

@@ -1309,9 +1309,13 @@ class Compiled:
             return all(bool(self._be.c.gmx_program_is_specialized(l.handle)) for l in self.links)
         return bool(self._be.c.gmx_program_is_specialized(self.handle))
 
-    def set_fuse_resample(self):
-        """Before specialize(): the kernel can resample the previous step first (include/genmi.h: gmx_run_args.rs)."""
-        self._be.check(self._be.c.gmx_program_set_fuse_resample(self.handle), "gmx_program_set_fuse_resample")
+    def set_fuse_resample(self, loop: bool = False):
+        """Before specialize(): the kernel can resample the previous step first (include/genmi.h: gmx_run_args.rs).
+        loop: the LOOPED form — fewer workgroups than tiles, for launches of more than 2^20 particles."""
+        if loop:
+            self._be.check(self._be.c.gmx_program_set_fuse_resample_loop(self.handle), "gmx_program_set_fuse_resample_loop")
+        else:
+            self._be.check(self._be.c.gmx_program_set_fuse_resample(self.handle), "gmx_program_set_fuse_resample")
 
     def fuses_resample(self) -> bool:
         """True when `run(..., resample_in=...)` is honoured (include/genmi.h: gmx_program_fuses_resample)."""

@@ -217,7 +217,7 @@ class ShardedBootstrapSweep(_NoiseAhead):
         tiles_ = (n + CDF_TILE - 1) // CDF_TILE
         want_fuse_sh = bool(self.peer_mode and be.uses_streams and self.specialize and self.kind == SYSTEMATIC
                             and self.rejuvenate is None and W <= 8 and W * tiles_ <= 1024 and self.D <= _lib.PEER_MAX_LEAVES
-                            and n + W * self.capacity <= (1 << 21) and self.fuse_sh_req is not False)
+                            and n + W * self.capacity <= (1 << _lib.ANC_TAG_SHIFT) and self.fuse_sh_req is not False)
         if want_fuse_sh and not self.p_step.comp.is_specialized():
             self.p_step.comp.set_fuse_shard_step()
         if self.specialize and be.uses_streams:
@@ -369,7 +369,7 @@ class ShardedBootstrapSweep(_NoiseAhead):
             p_prev.rank, p_prev.world, p_prev.step, p_prev.tiles = g, W, t - 1, peer.tiles
             p_prev.capacity, p_prev.leaves = C, self.D
             shard_in = dict(lw=self.lw_pp[pw], stats_own=self.stats_own_pp[pw], plan=self.plan, total_out=self.totals[t - 1:t],
-                            max_out=self.maxs[t - 1:t], status=self.sh_status, shift=self.shift, tag=1 + (t - 1) % 2047,
+                            max_out=self.maxs[t - 1:t], status=self.sh_status, shift=self.shift, tag=1 + (t - 1) % _lib.ANC_TAG_MAX,
                             key=(int(kh_[0]), int(kh_[1])), peer=p_prev, state=[prev_rows[d] for d in range(self.D)],
                             tail=[prev_rows[d][n:] for d in range(self.D)])
         if writes_stats:        # the workgroup maxima land in the statistics block (red_out plane 0), the sums beside them

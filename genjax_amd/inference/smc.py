@@ -511,6 +511,7 @@ def weight_cdf(lw: torch.Tensor, n_total=None, max_partials=None):
 
 
 FUSE_RESAMPLE_MAX = 1 << 20      # the resample-first launch: all its workgroups resident at once (1024 tiles)
+FUSE_RESAMPLE_LOOP_MAX = 1 << 24 # ... or, LOOPED, 1024 workgroups walking up to 16 tiles each (engine.Compiled.set_fuse_resample(loop=True))
 FUSED_RESAMPLE_MAX = 2048 * 1024        # RS_MAX_TILES tiles of 1024 particles (csrc/gmx_kernels.hip)
 
 
@@ -1094,7 +1095,12 @@ class BootstrapSweep(_NoiseAhead):
         want_fuse = self.fuse_req
         if want_fuse is None:
             want_fuse = be.uses_streams
-        want_fuse = bool(want_fuse and self.specialize and self.kind == SYSTEMATIC and self.fused and n <= FUSE_RESAMPLE_MAX)
+        # past 2^21 particles the standalone tile-form resamplers do not apply (RS_MAX_TILES) — the LAST step of a sweep is
+        # resampled through the CDF array there — but the looped resample-first launch does (up to 2^24): the steps in
+        # between stay ONE launch each
+        self.big = bool(self.kind == SYSTEMATIC and not self.fused and n <= FUSE_RESAMPLE_LOOP_MAX)
+        want_fuse = bool(want_fuse and self.specialize and self.kind == SYSTEMATIC and (self.fused or self.big)
+                         and n <= FUSE_RESAMPLE_LOOP_MAX)
         if self.rejuvenate is None:
             gatherers = (self.p_step,)
         elif self.p_mhvm_init is not None:
@@ -1104,7 +1110,8 @@ class BootstrapSweep(_NoiseAhead):
         if want_fuse:
             for p_ in gatherers:
                 if not p_.comp.is_specialized():
-                    p_.comp.set_fuse_resample()
+                    # (past 2^20 particles the workgroups of ONE launch are not all resident: each walks several tiles)
+                    p_.comp.set_fuse_resample(loop=n > FUSE_RESAMPLE_MAX)
         if self.specialize:
             self.p_init.comp.specialize()
             self.p_step.comp.specialize()
@@ -1121,7 +1128,8 @@ class BootstrapSweep(_NoiseAhead):
         # 4 particles per thread: a workgroup is one 1024-particle tile) the resampler needs no pass of its own
         # over the log-weights (gmx_resample_tiles); programs that cannot (interpreted) get a gmx_tile_stats launch
         self.tile_agg = torch.zeros(((n + 1023) // 1024,), dtype=torch.int64, device=dev)
-        self.tile_stats = bool(self.fused and self.p_init.comp.writes_tile_stats() and self.p_step.comp.writes_tile_stats())
+        self.tile_stats = bool((self.fused or (self.big and want_fuse)) and self.p_init.comp.writes_tile_stats()
+                               and self.p_step.comp.writes_tile_stats())
         if self.p_mhvm_init is not None and self.tile_stats and not (self.p_mhvm_init.comp.writes_tile_stats()
                                                                      and self.p_mhvm_step.comp.writes_tile_stats()):
             self.p_mhvm_init = self.p_mhvm_step = None      # the chained programs are too large for the tile form
@@ -1192,7 +1200,7 @@ class BootstrapSweep(_NoiseAhead):
         kh = self.step_keys[t - 1][1].host()
         w = (t - 1) % 2
         return dict(lw=self.lw_pp[w], tile_max=self.partials_pp[w], tile_agg=self.tile_agg_pp[w], shift=self.shift,
-                    key=(int(kh[0]), int(kh[1])), tag=1 + (t - 1) % 2047, max_out=self.maxs[t - 1:t],
+                    key=(int(kh[0]), int(kh[1])), tag=1 + (t - 1) % _lib.ANC_TAG_MAX, max_out=self.maxs[t - 1:t],
                     total_out=self.totals[t - 1:t], status=self.rs_status)
 
     def _chain_prog(self, t):
@@ -1257,7 +1265,8 @@ class BootstrapSweep(_NoiseAhead):
 
     def _launch_cdf(self, t):
         be = _lib.get()
-        be.check(be.c.gmx_weight_cdf(be.ptr(self.lw), self.n, self.shift, be.ptr(self.partials),
+        w = t % 2 if self.fuse else 0          # (a one-launch sweep alternates two sets of log-weights / partials)
+        be.check(be.c.gmx_weight_cdf(be.ptr(self.lw_pp[w]), self.n, self.shift, be.ptr(self.partials_pp[w]),
                                      self._rows(t), be.ptr(self.maxs[t:t + 1]), be.ptr(self.cdf),
                                      be.ptr(self.totals[t:t + 1]), be.ptr(self.ws), be.stream()),
                  "gmx_weight_cdf")

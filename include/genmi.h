@@ -121,7 +121,7 @@ enum {
  * my slots) on tagged words.  Same integers as gmx_resample_tiles.  Every workgroup of the launch must be resident at
  * once (they wait for each other): n <= 2^20 (1024 workgroups); a wait gives up after 2 s of the device's wall clock and
  * sets *status_d.  The buffers read here must not be the ones this launch writes (log-weights, statistics: ping-pong);
- * after the launch ancestors_d holds TAGGED words (index = word & 0x1fffff). */
+ * after the launch ancestors_d holds TAGGED words (index = word & 0xffffff, tag = word >> 24). */
 typedef struct gmx_resample_in {
   const float* lw_d;              /* [n] log-weights of the previous step (16-byte aligned); NULL = not fused   */
   const float* tile_max_d;        /* [ceil(n/1024)] m_b  (plane 0 of the previous launch's red_out_d)           */
@@ -130,7 +130,7 @@ typedef struct gmx_resample_in {
   uint64_t* total_out_d;          /* [1]: total  (as gmx_resample_tiles' total_d)                               */
   uint64_t* status_d;             /* [1]: sticky error word (a wait that timed out)                             */
   int32_t shift;                  /* the CDF's fixed-point shift (= the previous launch's tile_shift)           */
-  uint32_t tag;                   /* 1 .. 2047, different from the previous launch's                            */
+  uint32_t tag;                   /* 1 .. 255, different from the previous launch's                             */
   uint32_t key0, key1;            /* resampling key (systematic)                                                */
   uint32_t u0;                    /* filled in by gmx_program_run: bits32(key, 0) >> 9                          */
   uint32_t reserved_;
@@ -174,7 +174,7 @@ typedef struct gmx_shard_in {
   float* max_out_d;               /* [1]: the global max log-weight of step t - 1                                        */
   uint64_t* status_d;             /* [1]: sticky error word (an ancestor word that never arrived)                        */
   int32_t shift;
-  uint32_t tag;                   /* 1 .. 2047: the tag of this launch's ancestor words                                  */
+  uint32_t tag;                   /* 1 .. 255: the tag of this launch's ancestor words                                   */
   uint32_t key0, key1;            /* resampling key of step t - 1                                                        */
   uint32_t u0;                    /* filled in by gmx_program_run: bits32(key, 0) >> 9                                   */
   int32_t reserved_;
@@ -243,6 +243,12 @@ int gmx_program_writes_tile_stats(const gmx_program* p);
  * hiprtc compile, so only the programs a sweep chains ask for it.  gmx_program_fuses_resample: 1 once such a kernel
  * exists (4 particles per thread, every gathered load through ancestors_d at the top of the kernel). */
 int gmx_program_set_fuse_resample(gmx_program* p);
+/* ... and for a LOOPED one: a launch of more particles than the device holds workgroups for (n > 2^20, up to 2^24) runs
+ * min(tiles, resident, 1024) workgroups, each walking tiles b, b + G, ...: first the resampling of the previous step for
+ * all of its tiles (one pass over the statistics table per workgroup; nothing there waits), then, tile by tile, the wait
+ * for its own ancestor words, the gather and the site program.  gmx_program_resident_particles answers for such a program
+ * with what ONE launch covers (16 tiles per workgroup). */
+int gmx_program_set_fuse_resample_loop(gmx_program* p);
 int gmx_program_fuses_resample(const gmx_program* p);
 /* The number of particles ONE launch of the specialised kernel covers with every workgroup resident at once
  * (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor of its code object x the device's CUs x particles per

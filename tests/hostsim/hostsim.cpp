@@ -128,6 +128,7 @@ extern "C" int gmx_program_set_fuse_resample(gmx_program* p) {
 extern "C" int gmx_program_set_fuse_shard_step(gmx_program* p) { return p ? 0 : 1; }       // (the mirror keeps the two-launch sharded step)
 extern "C" int gmx_program_fuses_shard_step(const gmx_program*) { return 0; }
 extern "C" int64_t gmx_program_resident_particles(const gmx_program* p) { return p ? (int64_t)1 << 20 : 0; }   // (the mirror runs workgroups in turn)
+extern "C" int gmx_program_set_fuse_resample_loop(gmx_program* p) { return gmx_program_set_fuse_resample(p); }   // (the mirror runs tiles in turn anyway)
 extern "C" int gmx_program_fuses_resample(const gmx_program* p) { return p && p->fuse_rs && hs_tile_mode(p) && hs_gathers(p) ? 1 : 0; }
 extern "C" int64_t gmx_program_grid(const gmx_program* p, int64_t n) { return hs_tile_mode(p) ? (n + 1023) / 1024 : (n + 255) / 256; }
 static uint64_t hs_weight_fixed(float lw, float ref, float scale);
@@ -160,7 +161,7 @@ extern "C" int gmx_program_run(const gmx_program* p, int64_t n, const gmx_run_ar
     if (!gmx_program_fuses_resample(p)) return fail("program_run: rs is set but this program cannot resample in its own launch");
     if (!q.tile_max_d || !q.tile_agg_d || !q.max_out_d || !q.total_out_d || !q.status_d || !A->ancestors_d)
       return fail("program_run: rs has a null pointer");
-    if (q.tag < 1u || q.tag > 2047u) return fail("program_run: rs.tag must be in [1, 2047]");
+    if (q.tag < 1u || q.tag > 255u) return fail("program_run: rs.tag must be in [1, 255]");
     if ((n + 1023) / 1024 > 1024) return fail("program_run: rs: n <= 2^20");
     if (A->tile_agg_d == q.tile_agg_d || (const float*)A->red_out_d == q.tile_max_d)
       return fail("program_run: rs reads the tile statistics this launch writes (use two sets)");
@@ -171,7 +172,7 @@ extern "C" int gmx_program_run(const gmx_program* p, int64_t n, const gmx_run_ar
     if (gmx_resample_tiles(GMX_RESAMPLE_SYSTEMATIC, key, q.lw_d, n, q.shift, q.tile_max_d, q.tile_agg_d, q.max_out_d,
                            q.total_out_d, rs_anc.data(), nullptr)) return 1;
     int32_t* tagged = const_cast<int32_t*>(A->ancestors_d);
-    for (int64_t i = 0; i < n; ++i) tagged[i] = (int32_t)((uint32_t)rs_anc[(size_t)i] | (q.tag << 21));
+    for (int64_t i = 0; i < n; ++i) tagged[i] = (int32_t)((uint32_t)rs_anc[(size_t)i] | (q.tag << 24));
     patched.ancestors_d = rs_anc.data();       // the program's gathers see the indices
   }
   const bool tile = hs_tile_mode(p);

@@ -1111,7 +1111,7 @@ class BootstrapSweep(_NoiseAhead):
             for p_ in gatherers:
                 if not p_.comp.is_specialized():
                     # (past 2^20 particles the workgroups of ONE launch are not all resident: each walks several tiles)
-                    p_.comp.set_fuse_resample(loop=n > FUSE_RESAMPLE_MAX)
+                    p_.comp.set_fuse_resample(loop=n > FUSE_RESAMPLE_MAX or os.environ.get("GENMI_RS_LOOP", "0") == "1")
         if self.specialize:
             self.p_init.comp.specialize()
             self.p_step.comp.specialize()

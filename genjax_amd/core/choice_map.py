@@ -340,21 +340,31 @@ Selection.at = SelectionBuilder          # Selection.at["x"]
 _NOVALUE = object()
 
 
+def _is_index_array(a) -> bool:
+    """a HOST 1-d integer array used as an address component: a static list of plate elements"""
+    return (not isinstance(a, (str, bytes, int))) and getattr(getattr(a, "dtype", None), "kind", "") in "iu" \
+        and type(a).__module__.split(".")[0] != "torch" and len(getattr(a, "shape", ())) == 1
+
+
 class ChoiceMap:
     """Immutable trie: an optional value at this node plus named children."""
 
-    __slots__ = ("_value", "_children", "_plate")
+    __slots__ = ("_value", "_children", "_plate", "_pdepth")
 
-    def __init__(self, value=_NOVALUE, children=None, plate=None):
+    def __init__(self, value=_NOVALUE, children=None, plate=None, pdepth=1):
         self._value = value
         self._children = children or {}
+        # (plates nest — `sample_pixel.vmap().vmap()`, iterating_computation.ipynb c11: `chm[0, 0, "new_pixel"]` — : how many
+        #  plate levels sit at this node; taking an element of the outer one leaves the next at the same axis)
+        self._pdepth = int(pdepth) if plate is not None else 1
         # the choices of a plate / scan trace: every value below carries the plate axis at position `plate` (after the
         # particle axes), and an INTEGER address component here reads element j of all of them — the reference's
         # `chm[j, "x"]` on a vmapped trace (choice_map.py:1453-1531 `Indexed.get_inner_map`)
         self._plate = plate
 
-    def with_plate(self, axis: int) -> "ChoiceMap":
-        return ChoiceMap(self._value, self._children, int(axis))
+    def with_plate(self, axis: int, depth: int = 1) -> "ChoiceMap":
+        nested = self._plate is not None and self._plate > int(axis)          # a plate INSIDE the one being marked
+        return ChoiceMap(self._value, self._children, int(axis), max(int(depth), self._pdepth + 1 if nested else 1))
 
     # -- builders ---------------------------------------------------------------
     @staticmethod
@@ -436,7 +446,7 @@ class ChoiceMap:
                 kids[j] = kids.get(j, _EMPTY).set(rest, _take_indexed(v, k, len(head.idx)))
             return ChoiceMap(self._value, kids)
         kids[head] = kids.get(head, _EMPTY).set(rest, v)
-        return ChoiceMap(self._value, kids, self._plate)
+        return ChoiceMap(self._value, kids, self._plate, self._pdepth)
 
     def merge_over(self, new: "ChoiceMap") -> "ChoiceMap":
         """`new` laid over this map (new entries win), keeping new's plate marker"""
@@ -482,18 +492,33 @@ class ChoiceMap:
                     (cm._plate is not None or (cm.has_value() and len(getattr(cm._value, "shape", ())) >= 1)):
                 cm = cm._take_plate(a)          # element a of a plate (or of a value-only array)
                 continue
+            if isinstance(a, _IndexArray) and a not in cm._children:
+                import numpy as _np
+                a = _np.asarray(a.idx, dtype=_np.int64)
+            if _is_index_array(a) and (cm._plate is not None or (cm.has_value() and len(getattr(cm._value, "shape", ())) >= 1)):
+                cm = cm._take_plate(a)          # elements a[0], a[1], ... of the plate, still a plate (`chm["obs", idxs]`)
+                continue
             cm = cm._children.get(a, _EMPTY)
         return cm
 
     def _take_plate(self, j: int) -> "ChoiceMap":
         """element j along this node's plate axis, for every value below; deeper plates move up one axis"""
         ax = self._plate if self._plate is not None else 0
-        is_slice = isinstance(j, slice)
+        is_slice = isinstance(j, slice) or _is_index_array(j)
 
         def take(v):
             shape = getattr(v, "shape", None)
             if shape is None or len(shape) <= ax:
                 return v
+            if _is_index_array(j):
+                import numpy as _np
+                idx = _np.asarray(j).astype(_np.int64)
+                if idx.size and not (-shape[ax] <= idx.min() and idx.max() < shape[ax]):
+                    raise IndexError(f"plate indices out of range for an axis of length {shape[ax]}")
+                if hasattr(v, "index_select"):
+                    import torch
+                    return v.index_select(ax, torch.as_tensor(idx % shape[ax], device=v.device))
+                return v.take(idx, axis=ax)
             if is_slice:
                 return v[(slice(None),) * ax + (j,)]
             if not -shape[ax] <= j < shape[ax]:
@@ -501,12 +526,15 @@ class ChoiceMap:
             return v.select(ax, j) if hasattr(v, "select") else v.take(j, axis=ax)
 
         def go(cm, top):
+            depth = cm._pdepth
             if is_slice:
                 plate = cm._plate
+            elif top:
+                plate, depth = (ax, cm._pdepth - 1) if (cm._plate is not None and cm._pdepth > 1) else (None, 1)
             else:
-                plate = None if top else (cm._plate - 1 if (cm._plate is not None and cm._plate > ax) else cm._plate)
+                plate = cm._plate - 1 if (cm._plate is not None and cm._plate > ax) else cm._plate
             return ChoiceMap(cm._value if cm._value is _NOVALUE else take(cm._value),
-                             {a: go(c, False) for a, c in cm._children.items()}, plate)
+                             {a: go(c, False) for a, c in cm._children.items()}, plate, depth)
         return go(self, True)
 
     def __call__(self, *addr) -> "ChoiceMap":
@@ -539,7 +567,7 @@ class ChoiceMap:
                 del kids[addr[0]]
             else:
                 kids[addr[0]] = sub
-        return ChoiceMap(self._value, kids, self._plate)
+        return ChoiceMap(self._value, kids, self._plate, self._pdepth)
 
     def addresses(self, prefix=()) -> list:
         out = [prefix] if self.has_value() else []
@@ -617,11 +645,11 @@ class ChoiceMap:
             f = c.filter(selection.get_subselection(a))
             if not f.static_is_empty():
                 kids[a] = f
-        return ChoiceMap(value, kids, self._plate)
+        return ChoiceMap(value, kids, self._plate, self._pdepth)
 
     def map_values(self, fn: Callable[[Any], Any]) -> "ChoiceMap":
         return ChoiceMap(self._value if self._value is _NOVALUE else fn(self._value),
-                         {a: c.map_values(fn) for a, c in self._children.items()}, self._plate)
+                         {a: c.map_values(fn) for a, c in self._children.items()}, self._plate, self._pdepth)
 
     def mask(self, flag) -> "ChoiceMap":
         """every value wrapped in Mask(value, flag); a concrete flag resolves now (True: this map; False: empty)"""

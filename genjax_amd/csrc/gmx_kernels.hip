@@ -418,10 +418,7 @@ extern "C" int gmx_program_set_fuse_resample_loop(gmx_program* p) {
 static int64_t rs_loop_grid(const gmx_program* p, int64_t tiles) {
   int64_t g = p->jit_resident_blocks > 0 ? p->jit_resident_blocks : 256;
   if (g > 1024) g = 1024;
-  if (const char* e = getenv("GENMI_RS_LOOP_GRID")) {          // tuning: fewer, longer-lived workgroups (never more than fit)
-    const long v = atol(e);
-    if (v >= 1 && v < g) g = v;
-  }
+
   return tiles < g ? tiles : g;
 }
 extern "C" int gmx_program_fuses_resample(const gmx_program* p) {

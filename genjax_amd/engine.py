@@ -220,7 +220,64 @@ class Mapped(torch.Tensor):
         return self.as_subclass(torch.Tensor)
 
 
+class Expanded(torch.Tensor):
+    """What a BATCHED trace shows for a choice whose value was launch-uniform (a constraint given once for all particles:
+    `C["v"].set(1)` under `vmap(model.importance)`): the value broadcast over the batch — a stride-0 view — as the reference's
+    vmapped traces carry it (every leaf has the batch axis: `tree_map(lambda v: v[idx], traces.get_choices())`,
+    importance_sampling.ipynb c8), with the launch-uniform value it stands for in `.base`: handed back to a generative
+    function (ChangeTarget, `update(tr.get_choices())`) it is classified as that value again — no per-particle copy.
+    Any torch operation on it yields a plain tensor."""
+
+    @staticmethod
+    def __new__(cls, t, base):
+        out = t.as_subclass(cls)
+        out.base = base
+        return out
+
+    def __init__(self, t, base):
+        pass
+
+    @property
+    def plain(self) -> torch.Tensor:
+        return self.as_subclass(torch.Tensor)
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        with torch._C.DisableTorchFunctionSubclass():
+            return func(*args, **(kwargs or {}))
+
+
+def expand_over_batch(v, batch: tuple):
+    """a launch-uniform value as a batched trace's leaf (Expanded), or v itself when it carries the batch already"""
+    if not batch or v is None or isinstance(v, (Expanded, Gathered, Patched, PlateScore, Deferred)):
+        return v
+    if isinstance(v, torch.Tensor):
+        if tuple(v.shape[:len(batch)]) == tuple(batch):
+            return v
+        t = v.plain if isinstance(v, (Broadcast, Mapped)) else v
+        if t.device != _lib.get().device:
+            return v
+    elif isinstance(v, (bool, int, float, np.bool_, np.integer, np.floating)):
+        dt = torch.bool if isinstance(v, (bool, np.bool_)) else (torch.int32 if isinstance(v, (int, np.integer)) else torch.float32)
+        t = torch.tensor(v, dtype=dt, device=_lib.get().device)
+    elif isinstance(v, np.ndarray) and v.dtype != object:
+        a = np.ascontiguousarray(v)
+        a = a.astype(np.float32) if a.dtype.kind == "f" else (a.astype(np.int32) if a.dtype.kind in "iu" else a)
+        t = torch.from_numpy(a).to(_lib.get().device)
+    else:
+        return v
+    # (inside a plate / scan the batch of a site's trace holds the plate axes too, and a launch-uniform table given for the
+    #  plate carries them already: only the LEADING axes that are missing are added)
+    nb = len(batch)
+    m = min(nb, t.ndim)
+    while m > 0 and tuple(batch[nb - m:]) != tuple(t.shape[:m]):
+        m -= 1
+    return Expanded(t.expand(tuple(batch[:nb - m]) + tuple(t.shape)), v)
+
+
 def materialize(v):
+    if isinstance(v, Expanded):
+        return v.plain
     if isinstance(v, Mapped):
         return v.plain
     if isinstance(v, Broadcast):
@@ -247,6 +304,8 @@ STEP_LEAF_MIN = 16  # per-particle vectors longer than this are ONE step-indexed
 def leaf_spec(v, batch: tuple):
     """Classify one launch value (see module docstring)."""
     nb = len(batch)
+    if isinstance(v, Expanded):
+        v = v.base           # (a launch-uniform value a batched trace showed broadcast: classified as what it stands for)
     if v is None:
         return ("none",)
     if isinstance(v, (bool, np.bool_)):
@@ -389,6 +448,8 @@ class Flat:
             if isinstance(v.flag, (bool, np.bool_)):
                 return ("mask_static", bool(v.flag), self.add(v.value))
             return ("mask", self.add(v.value), self.add(v.flag))
+        if isinstance(v, Expanded):
+            return self.add(v.base)        # (what a batched trace showed broadcast goes in as the launch-uniform value it is)
         self.leaves.append(v)
         return ("leaf", len(self.leaves) - 1)
 

@@ -1111,7 +1111,9 @@ class BootstrapSweep(_NoiseAhead):
             for p_ in gatherers:
                 if not p_.comp.is_specialized():
                     # (past 2^20 particles the workgroups of ONE launch are not all resident: each walks several tiles)
-                    p_.comp.set_fuse_resample(loop=n > FUSE_RESAMPLE_MAX or os.environ.get("GENMI_RS_LOOP", "0") == "1")
+                    # (the looped form at 1e6 particles, by workgroup count, was measured and is slower than one tile per
+                    #  workgroup: profiles/r06d_loop_grid.txt — 14.2 us/step plain, 14.9 looped at 1024, 17.4 at 512)
+                    p_.comp.set_fuse_resample(loop=n > FUSE_RESAMPLE_MAX)
         if self.specialize:
             self.p_init.comp.specialize()
             self.p_step.comp.specialize()

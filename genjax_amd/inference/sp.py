@@ -43,6 +43,44 @@ class Marginal(GenerativeFunction):
             return weight
         return self.algorithm.estimate_normalizing_constant(key, Target(self.gen_fn, tuple(args), v))
 
+    # -- the Distribution GFI over the two methods above (a Marginal is a SampleDistribution[ChoiceMap]: sp.py:207,
+    #    distribution.py:108-147, 398-419): `marginal_model.simulate(key, ())`, `.importance(key, obs, ())` (ravi_stack.ipynb
+    #    c4 / c5) — the VALUE of its trace is the choice map of the selected addresses
+    def simulate(self, key, args):
+        w, v = self.random_weighted(key, *tuple(args))
+        return MarginalTrace(self, tuple(args), v, w)
+
+    def generate(self, key, constraint, args):
+        v = constraint.get_value() if constraint is not None else None
+        if v is None:                                    # (distribution.py:123-127: nothing at the root: unconstrained)
+            return self.simulate(key, args), 0.0
+        if not isinstance(v, ChoiceMap):
+            raise TypeError("a Marginal's value is the ChoiceMap of its selected addresses: constrain it with C.v(choice_map)")
+        w = self.estimate_logpdf(key, v, *tuple(args))
+        return MarginalTrace(self, tuple(args), v, w), w
+
+    importance = generate
+
+    def assess(self, sample, args):
+        from ..random import key as _key
+        v = sample.get_value()
+        if not isinstance(v, ChoiceMap):
+            raise TypeError("a Marginal's value is the ChoiceMap of its selected addresses: assess(C.v(choice_map), args)")
+        return self.estimate_logpdf(_key(0), v, *tuple(args)), v          # (distribution.py:403: a dummy key)
+
+
+class MarginalTrace:
+    """DistributionTrace of a SampleDistribution (distribution.py:59-82): arguments, the sampled choice map, the weight"""
+
+    def __init__(self, gen_fn, args, value, score):
+        self.gen_fn, self.args, self.value, self.score = gen_fn, args, value, score
+
+    def get_args(self): return self.args
+    def get_retval(self): return self.value
+    def get_gen_fn(self): return self.gen_fn
+    def get_score(self): return self.score
+    def get_choices(self): return self.value          # (ChoiceMap.choice of a ChoiceMap is that map)
+
 
 def marginal(selection=None, algorithm=None):
     def decorator(gen_fn):

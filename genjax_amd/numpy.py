@@ -244,6 +244,14 @@ def _is_torch(x):
 
 
 def array(x, dtype=None):
+    from .random import Key
+    if isinstance(x, Key):
+        return x
+    if isinstance(x, (list, tuple)) and len(x) and builtins_all(isinstance(k_, Key) for k_ in x):
+        # `key, *sub_keys = jax.random.split(key, N + 1); sub_keys = jnp.array(sub_keys)` (importance_sampling.ipynb c4,
+        # custom_proposal.ipynb c3): a list of keys is a batch of keys
+        from .random import stack_keys
+        return stack_keys(x)
     if is_symbolic(x):
         return T.sym_array(np.asarray(x, dtype=object))
     if _is_torch(x):
@@ -485,12 +493,38 @@ def mean(x, axis=None):
     return np.mean(x, axis=axis)
 
 
+def var(x, axis=None):
+    """population variance (ddof = 0, jnp's default): mean((x - mean(x))^2)"""
+    if is_symbolic(x) or (T.is_tracing() and T._long_vector(x)):
+        m = mean(x, axis)
+        d = x - m if axis is None else x - np.expand_dims(np.asarray(m, dtype=object), axis)
+        return mean(d * d, axis)
+    if _is_torch(x):
+        return torch.var(x.float(), unbiased=False) if axis is None else torch.var(x.float(), dim=axis, unbiased=False)
+    return np.var(x, axis=axis)
+
+
+def std(x, axis=None):
+    if is_symbolic(x) or (T.is_tracing() and T._long_vector(x)):
+        return sqrt(var(x, axis))
+    if _is_torch(x):
+        return torch.std(x.float(), unbiased=False) if axis is None else torch.std(x.float(), dim=axis, unbiased=False)
+    return np.std(x, axis=axis)
+
+
 def stack(xs, axis=0):
     if is_symbolic(xs):
         return T.sym_array(np.stack([np.asarray(v, dtype=object) for v in xs], axis=axis))
     if builtins_any(_is_torch(v) for v in xs):
         return torch.stack(list(xs), dim=axis)
     return np.stack(xs, axis=axis)
+
+
+def builtins_all(it):
+    for v in it:
+        if not v:
+            return False
+    return True
 
 
 def builtins_any(it):
@@ -794,3 +828,60 @@ def all(x, axis=None):                                                # noqa: A0
 def any(x, axis=None):                                                # noqa: A001
     a = np.asarray(x.detach().cpu() if _is_torch(x) else x)
     return bool(a.any()) if axis is None else a.any(axis=axis)
+
+
+def bincount(x, weights=None, minlength=0, length=None):
+    """jnp.bincount (7_application_dirichlet_mixture_model.ipynb c10: `length=` fixes the output size under jit)"""
+    n = int(length if length is not None else minlength)
+    if _is_torch(x):
+        out = torch.bincount(x.to(torch.int64).reshape(-1), weights=weights, minlength=n)
+        return out[:n] if length is not None else out
+    out = np.bincount(np.asarray(x).reshape(-1), weights=weights, minlength=n)
+    return out[:n] if length is not None else out
+
+
+def __getattr__(name):
+    """Names this module does not define fall through to numpy (`jnp.meshgrid`, `jnp.ogrid`, `jnp.mask_indices`, ...: host-side
+    array construction in notebooks) — they act on concrete arrays only, never on traced values."""
+    if name.startswith("_"):
+        raise AttributeError(name)
+    try:
+        return getattr(np, name)
+    except AttributeError:
+        raise AttributeError(f"genjax_amd.numpy has no attribute {name!r} (and numpy has none either)") from None
+
+
+class _At:
+    """`x.at[idx].set(v)` / `.add(v)` / `.multiply(v)` / `.get()`: jax's functional array update (4_index_request.ipynb c5:
+    `trace.get_choices()["a"].at[IDX].set(value)`) — a new array, the operand untouched"""
+
+    def __init__(self, x, idx=None):
+        self._x, self._idx = x, idx
+
+    def __getitem__(self, idx):
+        return _At(self._x, idx)
+
+    def _apply(self, v, fn):
+        x = self._x
+        if _is_torch(x):
+            out = x.clone()
+            vv = v if _is_torch(v) else torch.as_tensor(v, dtype=x.dtype, device=x.device)
+            out[self._idx] = fn(out[self._idx], vv.to(out.dtype))
+            return out
+        a = np.array(np.asarray(x), copy=True)
+        a[self._idx] = fn(a[self._idx], v.detach().cpu().numpy() if _is_torch(v) else v)
+        return TableArray(a) if isinstance(x, TableArray) else a
+
+    def set(self, v): return self._apply(v, lambda old, new: new)          # noqa: A003
+    def add(self, v): return self._apply(v, lambda old, new: old + new)
+    def multiply(self, v): return self._apply(v, lambda old, new: old * new)
+    def get(self): return self._x[self._idx]
+
+
+TableArray.at = property(lambda self: _At(self))
+if not hasattr(torch.Tensor, "at"):
+    # values a trace hands back are torch tensors on this stack: they take jax's `.at[...]` spelling too (a property added
+    # to torch.Tensor at import — the one place this package touches torch's namespace; `GENMI_NO_TENSOR_AT=1` leaves it out)
+    import os as _os
+    if _os.environ.get("GENMI_NO_TENSOR_AT", "0") != "1":
+        torch.Tensor.at = property(lambda self: _At(self))

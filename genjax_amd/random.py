@@ -243,6 +243,12 @@ def split(k: Key, num: int = 2) -> Key:
     return out
 
 
+def stack_keys(keys) -> Key:
+    """a list of single keys (what iterating / unpacking a split gives) as ONE batch of keys: `jnp.array(sub_keys)`"""
+    rows = [np.asarray(k.host(), dtype=np.uint32).reshape(-1, 2) for k in keys]
+    return Key(host=np.concatenate(rows, axis=0))
+
+
 def lazy_split(k: Key, num: int, offset: int = 0) -> Key:
     """split(k, num) for a single key, never materialised: kernels derive child
     i in registers from the global particle index (GMX_KEY_SPLIT).  With `offset`, the `num` keys are

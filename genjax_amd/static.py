@@ -68,8 +68,11 @@ class DistributionTrace(Trace):
 
     def get_choices(self):
         v = materialize(self.value)
-        cm = ChoiceMap(value=v)            # (not ChoiceMap.choice: a batch of zero particles still has its address)
         nb = len(self.batch_shape)
+        if nb and not T.is_tracing():
+            from .engine import expand_over_batch
+            v = expand_over_batch(v, self.batch_shape)       # a launch-uniform constraint: shown with the batch axis
+        cm = ChoiceMap(value=v)            # (not ChoiceMap.choice: a batch of zero particles still has its address)
         return cm.with_plate(nb) if len(getattr(v, "shape", ())) > nb else cm      # a vector-valued site: chm[j]
 
     @property
@@ -235,7 +238,12 @@ class VmapTrace(Trace):
 
     def get_choices(self):
         """the inner choices; an integer address component reads one element of the plate (`chm[j, "x"]`)"""
-        return self.inner.get_choices().with_plate(len(self.batch_shape))
+        # (a plate whose element is itself a plate / scan — `f.vmap().vmap()` — holds its trace flat, the sites with one
+        #  more axis each: `chm[i, j, "x"]` peels them off one by one)
+        depth, g = 1, getattr(self.gen_fn, "gen_fn", None)
+        while g is not None and type(g).__name__ in ("Vmap", "_Repeat", "Scan") and depth < 4:
+            depth, g = depth + 1, getattr(g, "gen_fn", None)
+        return self.inner.get_choices().with_plate(len(self.batch_shape), depth)
 
     def get_subtrace(self, *addr): return self.inner.get_subtrace(*addr)
 

@@ -446,6 +446,16 @@ class SymArray(np.ndarray):
     memory — an argument, `jnp.array(...)` of numbers — is read at a run-time index instead: numpy.RuntimeTable).  An
     index past the end reads the last row, as jax clamps."""
 
+    # the reductions models call as METHODS (`jnp.array(obs).mean()`, `.std()`: custom_proposal.ipynb c4) go through
+    # genjax_amd.numpy's traced forms — numpy's own reductions do not know traced elements
+    def _red(name):            # noqa: N805
+        def method(self, axis=None, **_kw):
+            from . import numpy as jnp
+            return getattr(jnp, name)(np.asarray(self, dtype=object).view(np.ndarray), axis)
+        return method
+    mean, sum, std, var = _red("mean"), _red("sum"), _red("std"), _red("var")
+    del _red
+
     def __getitem__(self, idx):
         if isinstance(idx, Expr) or (isinstance(idx, np.ndarray) and idx.dtype == object):
             return sym_take(self, idx)

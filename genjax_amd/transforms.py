@@ -35,6 +35,49 @@ def _map_leaves(v, fn):
     return v
 
 
+def _loop_instances(f, args, axes, n, first_error):
+    from .core.choice_map import ChoiceMap
+    from .engine import Broadcast, Mapped
+
+    def at(a, ax, i):
+        if ax is None:
+            return _map_leaves(a, lambda t: t.plain if isinstance(t, Broadcast) else t)
+        if isinstance(a, Key):
+            return a[i]
+        if not isinstance(a, torch.Tensor) and hasattr(a, "shape") and hasattr(a, "dtype") and len(a.shape) >= 1 \
+                and getattr(a.dtype, "kind", "O") in "fiub":
+            import numpy as _np
+            v = _np.asarray(a)[i]
+            return v.item() if _np.ndim(v) == 0 else v
+        return _map_leaves(a, lambda t: (t.plain if isinstance(t, Mapped) else t)[i])
+    outs = []
+    for i in range(int(n)):
+        try:
+            outs.append(f(*[at(a, ax, i) for a, ax in zip(args, axes)]))
+        except Exception:
+            raise first_error from None          # not a batching problem: the function fails per instance too
+
+    def stack(vs):
+        v0 = vs[0]
+        if isinstance(v0, torch.Tensor):
+            return torch.stack([v.plain if isinstance(v, (Broadcast, Mapped)) else v for v in vs])
+        if isinstance(v0, (int, float, bool)):
+            return torch.tensor(vs)
+        if isinstance(v0, tuple):
+            return tuple(stack([v[k] for v in vs]) for k in range(len(v0)))
+        if isinstance(v0, list):
+            return [stack([v[k] for v in vs]) for k in range(len(v0))]
+        if isinstance(v0, dict):
+            return {k: stack([v[k] for v in vs]) for k in v0}
+        if isinstance(v0, ChoiceMap):
+            out = ChoiceMap.empty()
+            for a in v0.addresses():
+                out = out.set(a, stack([v[a] for v in vs])) if a else ChoiceMap.choice(stack([v.get_value() for v in vs]))
+            return out
+        return v0
+    return stack(outs)
+
+
 def vmap(f=None, in_axes=0, out_axes=0):
     """Two spellings share this name.  `genjax.vmap(in_axes=...)` with no function (or a generative function) is the
     reference's COMBINATOR decorator (combinators/vmap.py `vmap`): `@genjax.vmap(in_axes=(0,))` above `@genjax.gen`.
@@ -86,7 +129,20 @@ def vmap(f=None, in_axes=0, out_axes=0):
                 new.append(_map_leaves(a, front(int(ax))))
         if len(sizes) > 1:
             raise ValueError(f"vmap: mapped axis sizes differ ({sorted(sizes)})")
-        out = f(*new)
+        try:
+            out = f(*new)
+        except (RuntimeError, TypeError, IndexError) as e:      # (a ValueError / AssertionError is the function's own refusal)
+            # `f` is not batch polymorphic as written — host glue that compares a mapped index with unmapped data
+            # (`jax.vmap(lambda i: jnp.sum(jnp.where(idx == i, xs, 0)))(jnp.arange(k))`, the mixture notebook's c10): the
+            # instances one by one, results stacked along a new leading axis (what jax.vmap returns)
+            n_inst = set(sizes)
+            for a, ax in zip(args, axes):            # (a HOST array mapped over — `jax.vmap(f)(jnp.arange(k))` — counts here)
+                if ax is not None and not isinstance(a, (Key, torch.Tensor)) and hasattr(a, "shape") and len(a.shape) >= 1 \
+                        and getattr(getattr(a, "dtype", None), "kind", "O") in "fiub":
+                    n_inst.add(int(a.shape[0]))
+            if len(n_inst) != 1:
+                raise
+            out = _loop_instances(f, new, axes, n_inst.pop(), e)
         if out_axes not in (0, None):
             out = _map_leaves(out, lambda t: torch.movedim(t, 0, int(out_axes)) if t.ndim > int(out_axes) else t)
         return out

@@ -1175,6 +1175,8 @@ def _select_rec(c, new, old):
     for a in new.sites:
         out.sites[a] = _select_rec(c, new.sites[a], old.sites[a])
     out.retval = _select_tree(c, new.retval, old.retval)
+    if getattr(new, "plate_score", None) is not None and getattr(old, "plate_score", None) is not None:
+        out.plate_score = _select_tree(c, new.plate_score, old.plate_score)      # (an unrolled plate / scan as the element)
     return out
 
 
@@ -1254,8 +1256,9 @@ def _vmap_edit_index_o1(self, key, trace, request, argdiffs):
         return None
     if argdiffs is not None and not Diff.static_check_no_change(argdiffs):
         return None
-    if not isinstance(trace.inner, StaticTrace) or not isinstance(self.gen_fn, (StaticGenerativeFunction, Vmap)):
-        return None                    # (a bare distribution, a scan, a switch as the element: the loop form)
+    scan_elem = isinstance(self.gen_fn, Scan) and isinstance(request.request, IndexRequest)
+    if not isinstance(trace.inner, StaticTrace) or not (isinstance(self.gen_fn, (StaticGenerativeFunction, Vmap)) or scan_elem):
+        return None                    # (a bare distribution, a switch as the element: the loop form)
     args = tuple(Diff.tree_primal(argdiffs)) if argdiffs is not None else tuple(trace.get_args() or ())
     try:
         axes = self._axes(args)
@@ -1297,7 +1300,29 @@ def _vmap_edit_index_o1(self, key, trace, request, argdiffs):
     if isinstance(self.gen_fn, Vmap):      # a plate of plates: the element is itself a plate trace over the particle batch
         st = StaticTrace(self.gen_fn.gen_fn, None, inner_i.retval, inner_i.subtraces)
         inner_i = VmapTrace(self.gen_fn, st, PlateScore(lambda st=st: st.get_score(), batch=(B,)), inner_i.retval, args_i)
-    new_i, w, retdiff, bwd = request.request.edit(key, inner_i, Diff.no_change(args_i))
+    if scan_elem:
+        # a plate of scans (`kernel.scan(n=T).vmap()`): element idx is a scan trace over the particle batch ([B, T]
+        # leaves), and the sub-request — an IndexRequest itself — edits ONE step of it in O(1) steps
+        # (_scan_edit_index_o1); when that form does not apply the whole nest keeps the loop form
+        T_in = None
+        for leaf in _trace_value_leaves(inner_i):
+            T_in = int(leaf.shape[1]) if getattr(leaf, "ndim", 0) >= 2 else None
+            break
+        if T_in is None or T_in <= getattr(self.gen_fn, "unroll_max", SCAN_UNROLL_MAX):
+            return None
+        st = StaticTrace(self.gen_fn.kernel_gen_fn, None, None, inner_i.subtraces)
+        step_scores = Deferred(lambda st=st: materialize(st.get_score()), (B, T_in))
+        inner_i = VmapTrace(self.gen_fn, st, PlateScore(step_scores), inner_i.retval, args_i)
+        inner_i._elem_scores = step_scores
+        sub = _scan_edit_index_o1(self.gen_fn, key, inner_i, request.request, Diff.no_change(args_i))
+        if sub is None:
+            return None
+        new_i, w, retdiff, bwd = sub
+        new_elem_score = new_i.get_score()
+        new_i = StaticTrace(self.gen_fn, None, new_i.retval, new_i.inner.subtraces)      # (flat again, as the plate holds it)
+    else:
+        new_i, w, retdiff, bwd = request.request.edit(key, inner_i, Diff.no_change(args_i))
+        new_elem_score = new_i.get_score()
 
     def patch(old, new):
         # (a chain of patches is read through element by element; past PATCH_DEPTH_MAX it is folded into one whole leaf,
@@ -1319,7 +1344,7 @@ def _vmap_edit_index_o1(self, key, trace, request, argdiffs):
         elem_old = Deferred(elem_scores, (B, n))
     if isinstance(elem_old, Patched) and elem_old.depth >= PATCH_DEPTH_MAX:
         elem_old = elem_old.materialize()
-    elem_new = Patched(elem_old, idx, materialize(new_i.get_score()))
+    elem_new = Patched(elem_old, idx, materialize(new_elem_score))
     out = VmapTrace(self, new_inner, PlateScore(elem_new), new_inner.retval, args)
     out._elem_scores = elem_new
     return out, w, Diff.unknown_change(out.retval) if not Diff.static_check_no_change(retdiff) else Diff.no_change(out.retval), \
@@ -1364,12 +1389,18 @@ def _scan_edit_index_o1(self, key, trace, request, argdiffs):
     except (ValueError, TypeError):
         return None
     idx = request.idx
-    if T_ <= getattr(self, "unroll_max", SCAN_UNROLL_MAX) or isinstance(idx, torch.Tensor) or self.__dict__.get("_o1_refused"):
+    if T_ <= getattr(self, "unroll_max", SCAN_UNROLL_MAX) or self.__dict__.get("_o1_refused"):
         return None
-    idx = int(idx)
-    if not 0 <= idx < T_:
-        raise IndexError(f"IndexRequest: index {idx} out of range for a scan of {T_} steps")
     B = int(trace.batch_shape[0])
+    per = isinstance(idx, torch.Tensor)            # one step index per particle (a traced idx under the particle vmap)
+    if per:
+        if tuple(idx.shape) != (B,):
+            return None
+        idx = idx.to(torch.int64).clamp(0, T_ - 1)          # (dynamic_slice clamps, scan.py:345-350)
+    else:
+        idx = int(idx)
+        if not 0 <= idx < T_:
+            raise IndexError(f"IndexRequest: index {idx} out of range for a scan of {T_} steps")
     kernel = self.kernel_gen_fn
     pairs = []
     _tree_leaves_with_axes(xs, 0, pairs, "scan")
@@ -1378,6 +1409,9 @@ def _scan_edit_index_o1(self, key, trace, request, argdiffs):
 
     def x_at(t):
         def pick(v):
+            if isinstance(t, torch.Tensor):          # one step per particle: a row per particle, on the device
+                v = torch.as_tensor(np.asarray(v), device=t.device) if isinstance(v, np.ndarray) else v
+                return v[t]
             e = v[t]
             return e.item() if isinstance(e, np.generic) else (np.asarray(e) if isinstance(v, np.ndarray) else e)
         return _tree_take_axes(xs, 0, pick) if xs is not None else None
@@ -1389,8 +1423,26 @@ def _scan_edit_index_o1(self, key, trace, request, argdiffs):
             v = materialize(v)
             if not isinstance(v, torch.Tensor) or v.ndim < 2 or v.shape[0] != B or v.shape[1] != T_:
                 return v
-            return v[:, t]
+            return v[:, t] if not isinstance(t, torch.Tensor) else v[torch.arange(B, device=v.device), t]
         return _trace_leaf_map(trace.inner, take, args=(cin, x_at(t)))
+
+    def dev_leaf(v, like):
+        return v if isinstance(v, torch.Tensor) else torch.as_tensor(np.asarray(v, dtype=np.float32) if not hasattr(v, "dtype") else np.asarray(v),
+                                                                    device=like.device)
+
+    def where_tree(c, a, b):
+        """where(c [B], a, b) leaf by leaf over a carry pytree (either side may be launch-uniform)"""
+        def sel(x, y):
+            x, y = dev_leaf(materialize(x), c), dev_leaf(materialize(y), c)
+            cc = c.reshape(c.shape + (1,) * (max(x.ndim, y.ndim) - 1))
+            return torch.where(cc, x, y.to(x.dtype) if x.dtype != y.dtype else y)
+        def go(x, y):
+            if isinstance(x, (tuple, list)):
+                return type(x)(go(p, q) for p, q in zip(x, y))
+            if isinstance(x, dict):
+                return {k_: go(x[k_], y[k_]) for k_ in x}
+            return None if x is None else sel(x, y)
+        return go(a, b)
     # the property the reference asserts, checked once per scan on step 0: an empty Update under a changed carry leaves
     # the kernel's return value unchanged
     if "_o1_ok" not in self.__dict__:
@@ -1400,7 +1452,12 @@ def _scan_edit_index_o1(self, key, trace, request, argdiffs):
         self.__dict__["_o1_refused"] = True
         return None
     # step idx's incoming carry: the kernel's return value on slice idx - 1 (its choices decide it, whatever came in)
-    if idx == 0:
+    if per:
+        t_prev, t_next, has_next = (idx - 1).clamp(min=0), (idx + 1).clamp(max=T_ - 1), idx + 1 < T_
+        prev_sl = slice_at(t_prev, carry0)
+        _, ret_prev = kernel.assess(prev_sl.get_choices(), (carry0, x_at(t_prev)), batch_shape=(B,))
+        cin = where_tree(idx == 0, carry0, ret_prev[0])
+    elif idx == 0:
         cin = carry0
     else:
         prev_sl = slice_at(idx - 1, carry0)
@@ -1409,42 +1466,73 @@ def _scan_edit_index_o1(self, key, trace, request, argdiffs):
     new_i, w, _rd, bwd = request.request.edit(key, slice_at(idx, cin), Diff.no_change((cin, x_at(idx))))
     new_carry = new_i.get_retval()[0]
     nxt = None
-    if idx + 1 < T_:
-        nxt, w2, rd2, _ = Update(ChoiceMap.empty()).edit(key, slice_at(idx + 1, cin), (Diff.unknown_change(new_carry),
-                                                                                     Diff.no_change(x_at(idx + 1))))
+    if per or idx + 1 < T_:
+        t_n = t_next if per else idx + 1
+        nxt, w2, rd2, _ = Update(ChoiceMap.empty()).edit(key, slice_at(t_n, cin), (Diff.unknown_change(new_carry),
+                                                                                 Diff.no_change(x_at(t_n))))
         if not Diff.static_check_no_change(rd2):          # (cannot happen after the check above; the reference asserts it here)
             self.__dict__["_o1_refused"] = True
             return None
+        if per:                                            # (a particle edited at its LAST step has no successor to visit)
+            w2 = torch.where(has_next, dev_leaf(materialize(w2), idx).expand(B), torch.zeros((), device=idx.device))
         w = elementwise(lambda a_, b_: a_ + b_, w, w2)
 
-    def patch_at(t):
+    def patch_at(t, keep=None):
         def patch(old, new):
             base = old if isinstance(old, Patched) and old.depth < PATCH_DEPTH_MAX else materialize(old)
             shp = tuple(base.shape)
-            rows = torch.as_tensor(materialize(new), device=base.device).to(base.dtype)
-            return Patched(base, t, rows.expand(shp[:1] + shp[2:]))
+            rows = torch.as_tensor(materialize(new), device=base.device).to(base.dtype).expand(shp[:1] + shp[2:])
+            if keep is not None:                           # rows of the particles in `keep` stay what they are NOW
+                now = old.take(t) if isinstance(old, Patched) else _take_rows(materialize(old), t)
+                rows = torch.where(keep.reshape(keep.shape + (1,) * (rows.ndim - 1)), now, rows)
+            return Patched(base, t, rows)
         return patch
     inner_old = trace.inner
     # (the slices' return values are per-step (carry, y) pairs the scan's inner trace does not keep: only choices and scores
     #  are patched; the scan's own return value is rebuilt below)
     new_inner = _trace_leaf_zip(_strip_retval(inner_old), _strip_retval(new_i), patch_at(idx), args=None)
+    no_next = ~has_next if per else None
     if nxt is not None:
-        new_inner = _trace_leaf_zip(new_inner, _strip_retval(nxt), patch_at(idx + 1), args=None)
+        new_inner = _trace_leaf_zip(new_inner, _strip_retval(nxt), patch_at(t_n, no_next), args=None)
     elem_old = getattr(trace, "_elem_scores", None)
     if elem_old is None:
         elem_old = Deferred(lambda inner=inner_old: materialize(inner.get_score()), (B, T_))
     if isinstance(elem_old, Patched) and elem_old.depth >= PATCH_DEPTH_MAX - 1:
         elem_old = elem_old.materialize()
-    elem_new = Patched(elem_old, idx, materialize(new_i.get_score()))
+    elem_new = Patched(elem_old, idx, dev_leaf(materialize(new_i.get_score()), materialize(w) if per else torch.zeros(())).expand(B)
+                       if per else materialize(new_i.get_score()))
     if nxt is not None:
-        elem_new = Patched(elem_new, idx + 1, materialize(nxt.get_score()))
+        s_n = materialize(nxt.get_score())
+        if per:
+            s_n = torch.where(has_next, dev_leaf(s_n, idx).expand(B), elem_new.take(t_n))
+        elem_new = Patched(elem_new, t_n, s_n)
     old_carry, old_ys = trace.get_retval() if isinstance(trace.retval, tuple) and len(trace.retval) == 2 else (None, None)
     new_y = new_i.get_retval()[1]
     ys = _tree_zip(old_ys, new_y, patch_at(idx)) if old_ys is not None else None
-    carry_out = new_carry if idx == T_ - 1 else old_carry
+    if per:
+        carry_out = where_tree(idx == T_ - 1, new_carry, old_carry) if old_carry is not None else None
+    else:
+        carry_out = new_carry if idx == T_ - 1 else old_carry
     out = VmapTrace(self, new_inner, PlateScore(elem_new), (carry_out, ys), args)
     out._elem_scores = elem_new
     return out, w, Diff.unknown_change(out.retval), IndexRequest(idx, bwd)
+
+
+def _take_rows(v, t):
+    """v[:, t] for an int t, one row per particle for a [B] index tensor"""
+    import torch
+    return v[:, t] if not isinstance(t, torch.Tensor) else v[torch.arange(v.shape[0], device=v.device), t]
+
+
+def _trace_value_leaves(tr):
+    from .static import DistributionTrace
+    if isinstance(tr, DistributionTrace):
+        yield tr.value
+        return
+    for st in getattr(tr, "subtraces", {}).values():
+        yield from _trace_value_leaves(st)
+    if hasattr(tr, "inner"):
+        yield from _trace_value_leaves(tr.inner)
 
 
 def _strip_retval(tr):
@@ -1939,8 +2027,10 @@ class Scan(GenerativeFunction):
         from .core.generative import NotSupportedEditRequest
         from .static import _CallRec, _ReqSpec, _rec_score, _store_site, call_gen_fn
         kind = req.kind if req is not None else "empty"
-        if prev is None or "vmap" not in prev:
+        if prev is None or ("vmap" not in prev and "sub" not in prev):
             raise NotImplementedError("editing a scan of bare distributions")
+        # (as the ELEMENT of an enclosing plate / scan — `kernel.scan(n=T).vmap()` — this scan's trace is held flat: the
+        #  kernel's sites with one more axis)
         if mode == "regen" or kind == "regen":
             sub_mode = "regen"
         elif mode == "update" or kind in ("update", "empty"):

@@ -1649,6 +1649,54 @@ def scan_edit_index(sc: "Scan", k, trace: "VmapTrace", args, idx: int, edit):
     return VmapTrace(sc, inner, score, (slices[-1].get_retval()[0], inner.get_retval()[1])), w
 
 
+def scan_edit_index_per_particle(sc: "Scan", k, trace: "VmapTrace", args, idx, edit):
+    """Scan.edit_index (scan.py:325-416) under an outer particle vmap with ONE step index per particle (a traced idx: each
+    particle's dynamic_slice addresses its own step).  Restated per distinct index j, as vmap_edit_index_per_particle
+    does for plates: the edit of step j with the caller's keys, kept for the particles whose index is j."""
+    idx = np.asarray(idx)
+    batch = np.asarray(k).shape[:-1]
+    n = sc._n(args[1])
+    nb = len(batch)
+
+    def full(v, tail):
+        """a leaf the trace holds launch-uniform (a scalar, or 1 along the batch axes) as one value per particle"""
+        v = np.asarray(v)
+        if v.ndim < nb + tail:
+            v = v.reshape((1,) * (nb + tail - v.ndim) + v.shape)
+        return np.broadcast_to(v, tuple(batch) + v.shape[nb:])
+
+    def full_trace(tr):
+        if isinstance(tr, DistTrace):
+            return DistTrace(tr.gen_fn, tr.args, full(tr.value, 1), full(tr.score, 1))
+        return StaticTrace(tr.gen_fn, tr.args, full_tree(tr.retval, 1), OrderedDict((a, full_trace(s_)) for a, s_ in tr.subtraces.items()))
+
+    def full_tree(v, tail):
+        if v is None:
+            return None
+        if isinstance(v, tuple):
+            return tuple(full_tree(x, tail) for x in v)
+        return full(v, tail)
+    inner = full_trace(trace.inner)
+    w = np.zeros(batch, np.float32)
+    score = np.broadcast_to(np.asarray(trace.score, np.float32), batch).copy()
+    carry, ys = trace.retval
+    carry = full(carry, 0)
+    ys = None if ys is None else full(ys, 1)
+    full_cand = lambda c: VmapTrace(c.gen_fn, full_trace(c.inner), full(c.score, 0), (full(c.retval[0], 0), None if c.retval[1] is None else full(c.retval[1], 1)))
+    for j in np.unique(idx):
+        cand, wj = scan_edit_index(sc, k, trace, args, int(j), edit)
+        cand = full_cand(cand)
+        m = idx == j
+        here = np.zeros(tuple(batch) + (n,), bool)
+        here[m] = True
+        inner = trace_where(here, cand.inner, inner)
+        w = np.where(m, np.broadcast_to(np.asarray(wj, np.float32), batch), w).astype(np.float32)
+        score = np.where(m, cand.score, score).astype(np.float32)
+        carry = trace_where(m, DistTrace(None, None, cand.retval[0], None), DistTrace(None, None, carry, None)).value
+        ys = None if ys is None else trace_where(here, DistTrace(None, None, cand.retval[1], None), DistTrace(None, None, ys, None)).value
+    return VmapTrace(sc, inner, score, (carry, ys)), w
+
+
 # the combinators as CALLEES of an edited static function (`_Update.handle` calls `gen_fn.update`): a plate / a scan
 # inside the function a plate maps (vmap.py:236-275 over scan.py:509-594).  The discard of a nested edit is not restated.
 Vmap.update = lambda self, k, trace, chm, args: vmap_update(self, k, trace, chm, args)

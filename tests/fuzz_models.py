@@ -644,13 +644,16 @@ def _run_one(seed, B=7, allow_nested=True, verbose=False):
                     at = (args_[0], np.asarray(args_[1])[..., idx])
                     return O.vmap_edit_index(gen_fn, kk, subtrace, idx, lambda k_, sl, a_: o_elem.update(k_, sl, sub, a_)[:2], at)
                 return O.scan_edit_index(gen_fn, kk, subtrace, args_, idx, lambda k_, sl, a_: o_elem.update(k_, sl, sub, a_)[:2])
-        per_particle = st["kind"] == "plate" and bool(rng.integers(2))
+        per_particle = st["kind"] in ("plate", "scan") and bool(rng.integers(2))
         if per_particle:                      # one index per particle (a traced idx under the reference's vmap)
             idx_host = rng.integers(size, size=B).astype(np.int32)
 
             class _OIdx:                       # noqa: F811
                 def edit(self, kk, subtrace, gen_fn, args_):
                     sub = O.C.d({(site,): val})
+                    if not platelike:
+                        return O.scan_edit_index_per_particle(gen_fn, kk, subtrace, args_, idx_host,
+                                                              lambda k_, sl, a_: o_elem.update(k_, sl, sub, a_)[:2])
                     return O.vmap_edit_index_per_particle(
                         gen_fn, kk, subtrace, idx_host, lambda k_, sl, a_: o_elem.update(k_, sl, sub, a_)[:2],
                         lambda j: (args_[0], np.asarray(args_[1])[..., j]))

@@ -834,10 +834,19 @@ def check_scan_index_request_o1(n=64, T=40, seed=14, edits=7, timing=False):
             osub = (lambda kk, sl, a, vv=vv: ostep.update(kk, sl, O.C.d({("z",): vv}), a)[:2])
         else:
             sub, osub = Regenerate(S["z"]), (lambda kk, sl, a: ostep.regenerate(kk, sl, O.selection("z"), a)[:2])
+        per = e % 5 == 4                  # ONE STEP INDEX PER PARTICLE (a traced idx under the particle vmap; round 6)
+        if per:
+            t_host = rng.integers(0, T, n).astype(np.int32)
+            t_host[:3] = (0, T - 1, T - 2)
+            t = torch.from_numpy(t_host).to(dev)
         new, w, _, bwd = IndexRequest(t, sub).edit(k, tr, Diff.no_change(args))
-        onew, ow = O.scan_edit_index(osc, ok, otr, oargs, t, osub)
+        if per:
+            onew, ow = O.scan_edit_index_per_particle(osc, ok, otr, oargs, t_host, osub)
+        else:
+            onew, ow = O.scan_edit_index(osc, ok, otr, oargs, t, osub)
         saw_lazy = saw_lazy or isinstance(new.inner.subtraces["z"].value, Patched)
-        assert isinstance(bwd, IndexRequest) and bwd.idx == t
+        assert isinstance(new.inner.subtraces["z"].value, Patched) or not per, "per-particle index: the O(1) form was not taken"
+        assert isinstance(bwd, IndexRequest) and (per or bwd.idx == t)
         assert np.array_equal(_np(w), ow), (e, "weight")
         for nm in ("z", "y"):
             assert np.array_equal(_np(new.get_choices()[nm]), np.broadcast_to(onew.get_choices()[nm], (n, T))), (e, nm)
@@ -885,6 +894,118 @@ def check_scan_index_request_o1(n=64, T=40, seed=14, edits=7, timing=False):
             torch.cuda.synchronize()
         t0 = time.perf_counter()
         reps = 5
+        for _ in range(reps):
+            new, w, _, _ = req.edit(k, tr, Diff.no_change(args))
+            _ = _np(w[:1])
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
+        out[name] = (time.perf_counter() - t0) / reps
+    sc.__dict__.pop("_o1_refused", None)
+    return out
+
+
+def check_plate_of_scans_index_request_o1(n=33, J=20, T=40, seed=23, edits=8, timing=False):
+    """`IndexRequest(j, IndexRequest(t, sub))` on a plate of LONG scans written directly
+    (`kernel.scan(n=T).vmap()`: leaves [n, J, T]) edits ONE step of ONE element in O(1) steps — the plate's slice /
+    write-back (vmap.py:277-332) around the scan's (scan.py:325-416) — with Python-int and per-particle indices at either
+    level, chains of edits; bit-exact against the oracle (every element edited with the caller's key, kept at j only:
+    `vmap_edit_index_batched` around `scan_edit_index[_per_particle]`) and against the counted-loop form of the same edit.
+    Before round 6 a directly nested `scan.vmap()` could not be edited at all (its trace is held flat)."""
+    import time
+    import genjax_amd as G
+    from genjax_amd import ChoiceMapBuilder as C, Diff, IndexRequest, Regenerate, SelectionBuilder as S, Update, numpy as jnp
+    from genjax_amd.engine import Patched
+    dev = G._lib.get().device
+
+    def mk(g, lit):
+        @g.gen
+        def step(c, x):
+            z = g.normal(c * lit(0.5) + x, lit(1.25)) @ "z"
+            g.normal(z, lit(0.75)) @ "y"
+            return z, z * lit(2.0)
+        return step
+    step, ostep = mk(G, float), mk(O, np.float32)
+    xs = np.linspace(-0.5, 0.5, T).astype(np.float32)
+    c0 = np.linspace(0.0, 1.0, J).astype(np.float32)
+    sc, osc = G.Scan(step, T), O.Scan(ostep, T)
+    pl, opl = sc.vmap(in_axes=(0, None)), O.Vmap(osc, in_axes=(0, None))
+    args, oargs = (jnp.array(c0), jnp.array(xs)), (c0, xs)
+    tr, otr = pl.simulate(G.split(G.key(seed), n), args), opl.simulate(O.split(O.key(seed), n), oargs)
+    assert np.array_equal(_np(tr.get_choices()["z"]), otr.get_choices()["z"])
+    # the whole-trace edits of the flat nest (Update of one address, of a whole row)
+    upd, w_u, _, _ = Update(C[1, 2, "y"].set(0.25)).edit(G.split(G.key(seed + 1), n), tr, Diff.no_change(args))
+    y_new = _np(upd.get_choices()["y"])
+    assert np.all(y_new[:, 1, 2] == np.float32(0.25))
+    from scipy import stats
+    lp = stats.norm.logpdf
+    z_ = _np(tr.get_choices()["z"]).astype(np.float64)
+    want = lp(0.25, z_[:, 1, 2], 0.75) - lp(_np(tr.get_choices()["y"]).astype(np.float64)[:, 1, 2], z_[:, 1, 2], 0.75)
+    assert np.allclose(_np(w_u), want, rtol=2e-5, atol=2e-4)
+    rng = np.random.default_rng(seed + 2)
+    saw_lazy = 0
+    for e in range(edits):
+        k, ok = G.split(G.key(seed + 50 + e), n), O.split(O.key(seed + 50 + e), n)
+        kind = e % 3
+        if kind == 0:
+            v = np.float32(rng.normal())
+            sub, osub = Update(C["y"].set(float(v))), (lambda kk, sl, a, v=v: ostep.update(kk, sl, O.C.d({("y",): v}), a)[:2])
+        elif kind == 1:
+            vv = rng.normal(size=n).astype(np.float32)
+            sub = Update(C["z"].set(torch.from_numpy(vv).to(dev)))
+            osub = (lambda kk, sl, a, vv=vv: ostep.update(kk, sl, O.C.d({("z",): np.broadcast_to(vv[:, None], (n, J))}), a)[:2])
+        else:
+            sub, osub = Regenerate(S["z"]), (lambda kk, sl, a: ostep.regenerate(kk, sl, O.selection("z"), a)[:2])
+        j_per, t_per = e % 4 == 2, e % 4 in (1, 2)
+        j_host = rng.integers(0, J, n).astype(np.int32) if j_per else int(rng.integers(0, J))
+        t_host = rng.integers(0, T, n).astype(np.int32) if t_per else [0, T - 1, int(rng.integers(1, T - 1))][e % 3]
+        if t_per:
+            t_host[:3] = (0, T - 1, T - 2)
+        gj = torch.from_numpy(j_host).to(dev) if j_per else j_host
+        gt = torch.from_numpy(t_host).to(dev) if t_per else t_host
+        req = IndexRequest(gj, IndexRequest(gt, sub))
+        new, w, _, bwd = req.edit(k, tr, Diff.no_change(args))
+        if t_per:
+            t_all = np.broadcast_to(t_host[:, None], (n, J))
+            edit_all = lambda kb, inner, a: O.scan_edit_index_per_particle(osc, kb, inner, a, t_all, osub)
+        else:
+            edit_all = lambda kb, inner, a: O.scan_edit_index(osc, kb, inner, a, t_host, osub)
+        onew, ow = O.vmap_edit_index_batched(opl, ok, otr, j_host, edit_all, oargs)
+        lazy = isinstance(new.inner.subtraces["z"].value, Patched)
+        saw_lazy += lazy
+        assert lazy, (e, "the O(1) form was not taken")
+        assert isinstance(bwd, IndexRequest) and isinstance(bwd.request, IndexRequest)
+        assert np.array_equal(_np(w), ow), (e, "weight", np.abs(_np(w) - ow).max())
+        for nm in ("z", "y"):
+            assert np.array_equal(_np(new.get_choices()[nm]), onew.get_choices()[nm]), (e, nm)
+        assert np.array_equal(_np(new.get_score()), onew.get_score()), (e, "score")
+        rc, ry = new.get_retval()
+        orc, ory = onew.get_retval()
+        assert np.array_equal(_np(rc), orc) and np.array_equal(_np(ry), ory), (e, "retval")
+        if e < 4:        # the counted-loop form of the same edit: same trace, same weight
+            sc.__dict__["_o1_refused"] = True
+            try:
+                loop, wl, _, _ = req.edit(k, tr, Diff.no_change(args))
+            finally:
+                sc.__dict__.pop("_o1_refused")
+            assert not isinstance(loop.inner.subtraces["z"].value, Patched)
+            assert np.array_equal(_np(wl), _np(w)) and np.array_equal(_np(loop.get_score()), _np(new.get_score())), (e, "loop form")
+            assert np.array_equal(_np(loop.get_choices()["z"]), _np(new.get_choices()["z"]))
+        tr, otr = new, onew
+    if not timing:
+        return None
+    out = {}
+    for name, refuse in (("o1", False), ("loop", True)):
+        if refuse:
+            sc.__dict__["_o1_refused"] = True
+        else:
+            sc.__dict__.pop("_o1_refused", None)
+        k = G.split(G.key(seed + 99), n)
+        req = IndexRequest(J // 2, IndexRequest(T // 2, Update(C["y"].set(0.25))))
+        req.edit(k, tr, Diff.no_change(args))
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        reps = 3
         for _ in range(reps):
             new, w, _, _ = req.edit(k, tr, Diff.no_change(args))
             _ = _np(w[:1])

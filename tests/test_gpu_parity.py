@@ -1980,6 +1980,26 @@ def test_index_request_on_a_long_scan_is_o1_on_device(gpu):
     parity.check_scan_index_request_o1(n=1 << 18, T=24, seed=5, edits=4)
 
 
+def test_nested_index_request_on_a_plate_of_long_scans_is_o1_on_device(gpu):
+    """a one-step edit of one element of a 64 x 4 096 plate of scans (`kernel.scan(n=T).vmap()`) is at
+    least 20x faster than the counted-loop form, with the same weights / scores / values (1 000 particles: a leaf is
+    1 GB; the 1e5 the verdict names would be 105 GB per leaf); the chains of edits against the oracle at small sizes,
+    Python-int and per-particle indices at both levels"""
+    import os
+    import sys
+    from tests import parity
+    parity.check_plate_of_scans_index_request_o1()
+    parity.check_plate_of_scans_index_request_o1(n=300, J=17, T=70, seed=5, edits=12)
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import nested_index_request_cost as cost
+    out = cost.run(1000, 64, 4096)
+    print("nested index request:", out)
+    assert out["same_weights_scores_values"] and out["speedup"] >= 20.0, out
+    out_pp = cost.run(1000, 64, 1024, per_particle=True)
+    print("nested index request, one index per particle:", out_pp)
+    assert out_pp["same_weights_scores_values"] and out_pp["speedup"] >= 5.0, out_pp
+
+
 def test_long_vector_valued_sites_on_device(gpu):
     """ref tensorflow_probability/__init__.py:52-62 + distribution.py:383-396: `normal(a * xs + b, sigma) @ "y"` with 40 /
     500 / 5 000 observations under a particle batch as ONE counted loop per particle — interpreter (few particles) and

@@ -1173,6 +1173,15 @@ def test_index_request_on_a_long_scan_is_o1():
     parity.check_scan_index_request_o1(n=9, T=70, seed=3, edits=40)      # (longer than PATCH_DEPTH_MAX: the lazy leaves are folded)
 
 
+def test_nested_index_request_on_a_plate_of_long_scans_is_o1():
+    """VERDICT r5 item 8 (ref vmap.py:277-332 around scan.py:325-416): `IndexRequest(j, IndexRequest(t, sub))` on
+    `kernel.scan(n=T).vmap()` — Python-int and per-particle indices at either level, chains of edits past
+    PATCH_DEPTH_MAX — against the oracle and against the counted-loop form; a directly nested scan.vmap() under Update"""
+    from tests import parity
+    parity.check_plate_of_scans_index_request_o1()
+    parity.check_plate_of_scans_index_request_o1(n=9, J=17, T=70, seed=5, edits=40)
+
+
 def test_empty_and_single_particle_batches():
     """jax.vmap over zero keys gives empty arrays, not an error; one particle is just a batch of one"""
     @genjax.gen

@@ -205,6 +205,22 @@ def forms():
             return s
         return dict(model=m, args=lambda k: (k_float(k),), obs=C["s"].set(0.1), upd=C["s"].set(0.3), sel="s", index=("p", ("chain",), n))
 
+    def direct_plate_of_scans(n):
+        """`kernel.scan(n=T).vmap()` as the model itself: its trace is the combinators' own (leaves [J, T])"""
+        T_ = n
+
+        @G.gen
+        def step(c, x):
+            z = G.normal(c * 0.5 + x, 1.0) @ "z"
+            G.normal(z, 0.75) @ "y"
+            return z, z
+        J = 20
+        m = step.scan(n=T_).vmap(in_axes=(0, None))
+        xs = jnp.array(np.linspace(-1, 1, T_).astype(np.float32))
+        return dict(model=m, args=lambda k: (jnp.array(np.linspace(0, 1, J).astype(np.float32)), xs),
+                    obs=C["y"].set(jnp.array(np.zeros((J, T_), np.float32))), upd=C[1, 2, "z"].set(0.3), sel="z", hmc=False,
+                    index=(None, "y", J))
+
     def masked(n):
         @G.gen
         def inner(s):
@@ -248,6 +264,8 @@ def forms():
         ("scan, stacked outputs summed in the model", scan, [8, 100]),
         ("scan with an ARRAY carry `jnp.zeros(2)`", scan_array_carry, [8, 100]),
         ("plate of long scans (T = 20)", plate_of_scans, [3, 40]),
+        ("20 scans of `size` steps written directly, `step.scan(n=size).vmap()`; index = `IndexRequest(j, IndexRequest(t, Update))`",
+         direct_plate_of_scans, [8, 100]),
         ("masked call `mask(inner)(flag, s)`", masked, [1]),
         ("`categorical(logits, sample_shape=n)`", cat_sample_shape, [8, 100, 5000]),
         ("static model of n sites", many_sites, [20, 100]),
@@ -302,6 +320,9 @@ def _edit_cell(form, method, one, m, args, key, tr, sel_t):
         if ix is None:
             raise LookupError("n/a")
         addr, site, size = ix
+        if addr is None:            # the model IS the nest of combinators: a nested request, no StaticRequest around it
+            IndexRequest(min(3, size - 1), IndexRequest(2, Update(C[site].set(0.1)))).edit(key(2), tr, nd)
+            return
         sub = Update(C[site].set(0.1)) if not isinstance(site, tuple) else Update(C[site + (0, "z")].set(0.1))
         StaticRequest({addr: IndexRequest(min(3, size - 1), sub)}).edit(key(2), tr, nd)
 

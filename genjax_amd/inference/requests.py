@@ -109,29 +109,54 @@ def _run_hmc(req: HMC, key, trace, argdiffs):
             if not sel_addrs:
                 raise ValueError("HMC: the selection holds no differentiable choice")
             values = {a: chm_all[a].value for a in sel_addrs}
+            # a selected vector-valued site of MORE than 16 elements: positions, momenta and gradients are vectors in
+            # memory (recipes over reads of the launch's own outputs, tracer.LazyVec), every stage of the leapfrog one
+            # counted loop per vector-valued site that reads them (static._vector_site_loop stores d term_j / d v_j)
+            long_addrs = [a for a in sel_addrs if T._long_vector(values[a])]
             for a in sel_addrs:
-                if isinstance(values[a], np.ndarray) and values[a].size > 16:
-                    # (the trajectory of a vector of J positions and J momenta lives in registers: 3 J values per chain;
-                    #  a long vector site's loop differentiates with respect to SCALAR choices only — static._vector_site_loop)
+                if a not in long_addrs and isinstance(values[a], np.ndarray) and values[a].size > 16:
                     raise NotImplementedError(
-                        f"HMC on the vector-valued site {a!r} of {values[a].size} elements: the selected sites of an HMC move "
-                        "are scalars or vectors of at most 16 elements (scalars that FEED long vector sites are fine: "
-                        "`HMC(S['mu'])` in a model with `theta ~ normal(mu 1_J, tau 1_J)` of any J)")
+                        f"HMC on the vector-valued site {a!r} of {values[a].size} elements with {values[a].ndim} axes: a selected "
+                        "site beyond 16 elements is ONE long axis per particle")
 
             def model_score_and_grads(vals):
                 con = chm_all
+                gvecs = {}
                 for a in sel_addrs:
-                    con = con.set(a, vals[a])
+                    if a in long_addrs:
+                        gvecs[a] = T.GradVec(vals[a])
+                        con = con.set(a, gvecs[a])
+                    else:
+                        con = con.set(a, vals[a])
                 ctx.store_sites = False
-                leaves = [x for a in sel_addrs for x in _flat(vals[a])]
+                leaves = [x for a in sel_addrs if a not in long_addrs for x in _flat(vals[a])]
                 ctx.grad_wrt = leaves          # (long vector sites accumulate d score / d leaf inside their own loops)
+                ctx.grad_vecs = list(gvecs.values())
                 try:
                     _, _, _, s = call_gen_fn(ctx, "assess", gen_fn, None, sargs, con, None, None, None, ())
                 finally:
                     ctx.grad_wrt = None
-                gs = grad(T.as_float(s), leaves)
+                    ctx.grad_vecs = None
+                gs = grad(T.as_float(s), leaves) if leaves else []
                 out, k = {}, 0
+                for a in long_addrs:
+                    gv = gvecs[a]
+                    if gv.consumed != len(gv.reads) or not gv.contribs:
+                        raise NotImplementedError(
+                            f"HMC on the vector-valued site {a!r} of {gv.n} elements: the model reads its elements outside the "
+                            "loop of a vector-valued site of the same length (a static or traced index, `jnp.sum`, a plate "
+                            "over them) — the gradient of a long vector is taken through ELEMENTWISE consumers "
+                            "(`normal(theta, sigma) @ 'y'`, `normal(a * theta + b, s)`); select at most 16 elements otherwise")
+                    # the adjoint each consuming site's score reaches the model score with (1 for a plain sum of site scores)
+                    adjs = grad(T.as_float(s), [Expr(sv) for sv, _ in gv.contribs])
+                    tot = None
+                    for (_, alias), adj in reversed(list(zip(gv.contribs, adjs))):      # reverse mode: later sites first
+                        term = alias * adj
+                        tot = term if tot is None else tot + term
+                    out[a] = tot
                 for a in sel_addrs:
+                    if a in long_addrs:
+                        continue
                     v = vals[a]
                     if isinstance(v, np.ndarray):
                         arr = np.empty(v.size, dtype=object)
@@ -151,6 +176,15 @@ def _run_hmc(req: HMC, key, trace, argdiffs):
             mom_scores = []
             for i, a in enumerate(sel_addrs):                                # sample_momenta (hmc.py:119-130)
                 ki = Expr(g.add("KDERIVE", (sub_key.node,), imm=i, dtype="key"))
+                if a in long_addrs:            # J momenta from the ONE key, element j on counter j, stored; their score summed in order
+                    from ..static import _vector_site_loop
+                    n_a = T._long_vector(values[a])
+                    out_ = _vector_site_loop(ctx, "simulate", _normal, ki, (T.LazyVec(n_a, lambda i_: 0.0), 1.0), None, None, None)
+                    if out_ is None:
+                        raise NotImplementedError(f"HMC on the vector-valued site {a!r}: the momenta of {n_a} elements do not run as a loop here")
+                    momenta[a] = out_[1]
+                    mom_scores.append(out_[3])
+                    continue
                 zeros = values[a] * 0.0 if isinstance(values[a], np.ndarray) else 0.0
                 if isinstance(values[a], np.ndarray):
                     zeros = np.full(values[a].shape, 0.0, dtype=object)
@@ -164,6 +198,8 @@ def _run_hmc(req: HMC, key, trace, argdiffs):
                 grads = model_score_and_grads(values)
                 momenta = {a: momenta[a] + half * grads[a] for a in sel_addrs}
             # the final trace: every site re-scored at the final values (what L Updates leave behind)
+            for a in long_addrs:                  # the final positions, evaluated once: the new trace's values
+                values[a] = _store_lazy(tr, values[a], T._long_vector(values[a]))
             con = chm_all
             for a in sel_addrs:
                 con = con.set(a, values[a])
@@ -172,7 +208,17 @@ def _run_hmc(req: HMC, key, trace, argdiffs):
             rec, retval, _, _ = call_gen_fn(ctx, "generate", gen_fn, None, sargs, con, None, None, None, ())
             ret_changed = ctx.args_changed(retval)                 # the retdiff the L Updates would report
             final_model_score = _rec_score(rec)
-            final_momenta_score = _seq([_normal.sym_logpdf(momenta[a] * -1.0, (0.0, 1.0)) for a in sel_addrs])
+            final_terms = []
+            for a in sel_addrs:
+                if a in long_addrs:
+                    from ..static import _vector_site_loop
+                    ctx.store_sites = False
+                    out_ = _vector_site_loop(ctx, "assess", _normal, None, (0.0, 1.0), momenta[a] * -1.0, None, None)
+                    ctx.store_sites = True
+                    final_terms.append(out_[3])
+                else:
+                    final_terms.append(_normal.sym_logpdf(momenta[a] * -1.0, (0.0, 1.0)))
+            final_momenta_score = _seq(final_terms)
             alpha = final_model_score - original_model_score + final_momenta_score - original_momenta_score
             otree = _emit_rec(tr, rec)
             wo = tr.emit_output(alpha)
@@ -184,6 +230,17 @@ def _run_hmc(req: HMC, key, trace, argdiffs):
     w = _broadcast_score(resolve(wo, outs, flat.leaves), batch, be.device)
     retdiff = Diff.unknown_change(new_tr.get_retval()) if ret_changed else Diff.no_change(new_tr.get_retval())
     return new_tr, w, retdiff, HMC(req.selection, req.eps, req.L)
+
+
+def _store_lazy(tr, vec, n):
+    """a long vector kept as a recipe, evaluated ONCE: a counted loop stores element j; what comes back reads that output"""
+    g = tr.graph
+    g.loop_begin(n)
+    with T.tracing(g):
+        t = Expr(g.add("LDT", dtype="i32"))
+        origin = tr.store_step(T.as_float(T._elem(vec, t)), n)
+    g.loop_end()
+    return tr.alias_step_input(origin, "f32", n)
 
 
 def _seq(terms):

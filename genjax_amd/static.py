@@ -1134,6 +1134,12 @@ def _vector_site_loop(ctx, mode, dist, key, args, cval, prev, req):
     # derivative (Graph._custom_grads)
     wrt = [w for w in (getattr(ctx, "grad_wrt", None) or ()) if isinstance(w, Expr)]
     gvars = [g.loop_var(zero) for _ in wrt]
+    # ... and with respect to selected LONG VECTORS (tracer.GradVec: `HMC(S["theta"])`): where this loop reads element j of
+    # such a vector at its own iteration j — as the site's value or through its parameters — d s_j / d v_j is stored as
+    # element j of one more output, the site's contribution to the vector's gradient
+    gvecs = list(getattr(ctx, "grad_vecs", None) or ())
+    marks = [len(gv.reads) for gv in gvecs]
+    vec_origins = []
     g.loop_begin(n)
     with T.tracing(g):
         t = Expr(g.add("LDT", dtype="i32"))
@@ -1159,8 +1165,27 @@ def _vector_site_loop(ctx, mode, dist, key, args, cval, prev, req):
                 if not (pt.node.op == "CONST" and pt.node.imm == 0):       # (this element does not depend on w)
                     updates.append((gv, (Expr(gv) + pt).node))
                     used.append((w_.node, gv))
+        for gvec, mark in zip(gvecs, marks):
+            if gvec.n != n:
+                continue
+            mine, seen = [], set()
+            for k_, (i_, v_) in enumerate(gvec.reads[mark:]):
+                if isinstance(i_, Expr) and i_.node is t.node:
+                    gvec.consumed += 1
+                    if v_.node.idx not in seen:
+                        seen.add(v_.node.idx)
+                        mine.append(v_)
+            if mine:
+                from .autodiff import grad as _grad
+                parts = _grad(s_t, mine)
+                tot = parts[0]
+                for pt in parts[1:]:
+                    tot = tot + pt
+                vec_origins.append((gvec, tr.store_step(tot, n)))
         g.set_vars(updates)
     g.loop_end()
+    for gvec, o_ in vec_origins:
+        gvec.contribs.append((svar, tr.alias_step_input(o_, "f32", n)))
     if used:
         g.__dict__.setdefault("_custom_grads", {})[svar.idx] = used
     score = Expr(svar)

@@ -206,6 +206,34 @@ class LazyVec:
         return lazy_apply(lambda x: lift(x).astype(dt), self)
 
 
+class GradVec(LazyVec):
+    """A long vector an HMC move differentiates the model's score with respect to, ELEMENT BY ELEMENT (the positions of
+    `HMC(S["theta"])` with theta a vector-valued site of more than 16 elements; hmc.py:69-97 takes jax.grad of assess
+    with respect to the whole vector).  It reads like the vector it wraps and records every read: a vector-valued site
+    whose loop reads element j at its own iteration j stores d (its j-th term) / d v_j beside the score
+    (static._vector_site_loop) — the adjoint of an elementwise consumer is elementwise.  A read any other way (a static
+    index, a traced one, `jnp.sum`) is left unconsumed and the move is refused, naming the site."""
+
+    def __init__(self, src):
+        n = _long_vector(src)
+        LazyVec.__init__(self, n, None, parts=[src])
+        self.src = src
+        self.reads = []            # (index, the element's Expr)
+        self.consumed = 0
+        self.contribs = []         # (the consuming site's loop-carried score variable, its stored d term_j / d v_j)
+
+    def at(self, i):
+        v = as_float(_elem(self.src, i))
+        self.reads.append((i, v))
+        return v
+
+    def materialize(self):
+        out = np.empty((self.n,), dtype=object)
+        for i in range(self.n):
+            out[i] = self.at(i)
+        return out
+
+
 def _long_vector(a) -> int:
     """length of a LONG one-axis vector that can be read at a run-time index (a LazyVec; a launch-uniform table; a
     per-particle step leaf), else 0"""

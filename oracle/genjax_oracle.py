@@ -922,6 +922,17 @@ class _Assess(_Handler):
         if sub.static_is_empty():
             raise MissingAddress(addr)                          # static.py:317-318
         score, v = gen_fn.assess(sub, args, self.batch_shape)
+        if isinstance(score, Dual) or isinstance(self.score, Dual):
+            # the derivative of the model score with respect to a choice SEVERAL sites depend on: reverse mode (jax.grad of
+            # assess, hmc.py:69-97) adds the sites' contributions LAST SITE FIRST — the backward pass visits the program in
+            # reverse — ((c_n + c_n-1) + ...) + c_1; the values are summed in program order as ever
+            score, old = Dual.lift(score), Dual.lift(self.score)
+            self._tans = getattr(self, "_tans", []) + [score.t]
+            acc = self._tans[-1]
+            for t_ in reversed(self._tans[:-1]):
+                acc = (acc + t_).astype(np.float32)
+            self.score = Dual((old.v + score.v).astype(np.float32), acc)
+            return v
         self.score = (self.score + score).astype(np.float32)
         return v
 
@@ -1771,25 +1782,41 @@ def hmc_edit(k, trace, sel_addrs, eps, L, args):
     batch = np.shape(trace.get_score())
     sel_addrs = sorted((_addr(a) for a in sel_addrs), key=repr)
 
+    nb = len(batch)
+
     def score_and_grads(values):
         full = chm
         for a in sel_addrs:
             full = full.set(a, values[a])
         grads = {}
         for a in sel_addrs:
+            if values[a].ndim > nb:
+                # a VECTOR-valued selected site (jax.grad of assess with respect to the whole vector, hmc.py:69-97): one
+                # forward-mode pass per element, tangent e_j — d score / d v_j
+                gv = np.zeros(values[a].shape, np.float32)
+                for j in range(values[a].shape[-1]):
+                    e = np.zeros(values[a].shape, np.float32)
+                    e[..., j] = np.float32(1.0)
+                    s, _ = gen_fn.assess(full.set(a, Dual(values[a], e)), args, batch)
+                    gv[..., j] = np.broadcast_to(s.t, batch)
+                grads[a] = gv
+                continue
             d = full.set(a, Dual(values[a], np.ones_like(values[a])))
             s, _ = gen_fn.assess(d, args, batch)
             grads[a] = np.broadcast_to(s.t, batch).astype(np.float32)
         s, _ = gen_fn.assess(full, args, batch)
         return np.asarray(s, np.float32), grads
 
-    values = {a: np.broadcast_to(np.asarray(chm[a], np.float32), batch) for a in sel_addrs}
+    def as_value(v):
+        v = np.asarray(v, np.float32)
+        return np.broadcast_to(v, tuple(batch) + v.shape[nb:]) if v.ndim > nb else np.broadcast_to(v, batch)
+    values = {a: as_value(chm[a]) for a in sel_addrs}
     original_model_score = np.asarray(trace.get_score(), np.float32)
     _, grad0 = score_and_grads(values)
     sub_key = split(k)[..., 1, :]
     momenta, terms = {}, []
     for i, a in enumerate(sel_addrs):
-        momenta[a] = normal.sample(fold_in(sub_key, i), np.float32(0.0), np.float32(1.0))
+        momenta[a] = normal.sample(fold_in(sub_key, i), np.zeros(values[a].shape[nb:], np.float32), np.float32(1.0))
         terms.append(normal.estimate_logpdf(momenta[a], (np.float32(0.0), np.float32(1.0)), batch))
     original_momenta_score = terms[0]
     for t in terms[1:]:

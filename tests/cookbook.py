@@ -483,7 +483,9 @@ def check_hmc_through_long_vector_sites(npts=500, J=200, K=7, L=3, seed=1):
     vector site's counted loop accumulates d score / d w beside the score (static._vector_site_loop, autodiff.grad's custom
     derivative of a loop-carried sum); the oracle differentiates in forward mode (Dual numbers) and adds a vector site's
     tangents in element order — the new values and the weight agree BIT FOR BIT.  `Regenerate(S["theta"])` ON the long site
-    runs as a counted loop as well.  `HMC(S["theta"])` beyond 16 elements raises, naming the site."""
+    runs as a counted loop as well, and so does `HMC(S["theta"])` ON the long site — alone and together with the scalars; a
+    latent vector read through elementwise arithmetic by two later sites; ONE trace.  A long vector read through `jnp.sum`
+    is refused, naming the site."""
     import genjax_amd as G
     from genjax_amd import ChoiceMapBuilder as C, Diff, Regenerate, SelectionBuilder as S
     from genjax_amd import numpy as jnp
@@ -541,9 +543,62 @@ def check_hmc_through_long_vector_sites(npts=500, J=200, K=7, L=3, seed=1):
     new, wr, _, _ = Regenerate(S["theta"]).edit(G.split(G.key(seed + 3), K), tr, Diff.no_change(()))
     onew, owr = oschools.regenerate(O.split(O.key(seed + 3), K), otr, O.selection("theta"), ())[:2]
     assert same(new.get_choices()["theta"], onew.get_choices()["theta"]) and np.array_equal(npv(wr), np.asarray(owr, f32), equal_nan=True)
-    if J > 16:
-        try:
-            HMC(S["theta"], 1e-3, L=L).edit(G.split(G.key(seed + 4), K), tr, Diff.no_change(()))
-            raise AssertionError("HMC on a 17+-element vector site should raise")
-        except NotImplementedError as e:
-            assert "vector-valued site" in str(e) and "theta" in str(e)
+    # HMC ON the long vector site (round 6): positions / momenta / gradients as vectors in memory, every leapfrog stage one
+    # counted loop per vector-valued site that reads them; alone, together with the scalars, at a larger step
+    # (the oracle differentiates a vector element by element — J forward passes per gradient: at many particles it runs the
+    #  first 64 of them, which are the first 64 rows of the product's result: particles are independent)
+    Ko = min(K, 64)
+    otr_v = otr if Ko == K else oschools.importance(O.split(O.key(seed), K)[:Ko], O.C.d({"y": yj}), ())[0]
+    for sel, osel, eps in ((S["theta"], ["theta"], 1e-2), (S["mu"] | S["theta"], ["mu", "theta"], 1e-3),
+                           (S["mu"] | S["log_tau"] | S["theta"], ["mu", "log_tau", "theta"], 5e-2)):
+        new, w, _, _ = HMC(sel, eps, L=L).edit(G.split(G.key(seed + 4), K), tr, Diff.no_change(()))
+        onew, ow = O.hmc_edit(O.split(O.key(seed + 4), K)[:Ko], otr_v, osel, eps, L, ())
+        for a_ in osel:
+            assert same(npv(new.get_choices()[a_])[:Ko], onew.get_choices()[a_]), ("schools, vector", osel, a_)
+        assert same(npv(w)[:Ko], ow), ("schools weight, vector", osel, npv(w)[:Ko], np.asarray(ow))
+        assert same(npv(new.get_score())[:Ko], onew.get_score()), ("schools score, vector", osel)
+        assert np.array_equal(npv(new.get_choices()["y"])[:Ko], np.broadcast_to(yj, (Ko, J)))
+    if K > 64:
+        return
+    if J <= 16:
+        return
+    # the latent vector read through elementwise arithmetic by TWO later sites (three contributions to its gradient)
+    xs2 = np.linspace(0.5, 1.5, J).astype(f32)
+
+    @G.gen
+    def two():
+        theta = G.normal(jnp.zeros(J), 2.0 * jnp.ones(J)) @ "theta"
+        G.normal(theta * jnp.array(xs2) + 0.25, jnp.array(sig)) @ "y"
+        G.normal(jnp.tanh(theta), 0.5) @ "z"
+        return None
+
+    @O.gen
+    def otwo():
+        theta = O.normal(np.zeros(J, f32), f32(2.0) * np.ones(J, f32)) @ "theta"
+        O.normal(theta * xs2 + f32(0.25), sig) @ "y"
+        O.normal(O.tanh(theta), f32(0.5)) @ "z"
+        return None
+    zj = np.linspace(-0.5, 0.5, J).astype(f32)
+    tr2, _ = two.importance(G.split(G.key(seed + 5), K), C["y"].set(jnp.array(yj)) | C["z"].set(jnp.array(zj)), ())
+    otr2, _ = otwo.importance(O.split(O.key(seed + 5), K), O.C.d({"y": yj, "z": zj}), ())
+    new, w, _, _ = HMC(S["theta"], 2e-2, L=L).edit(G.split(G.key(seed + 6), K), tr2, Diff.no_change(()))
+    onew, ow = O.hmc_edit(O.split(O.key(seed + 6), K), otr2, ["theta"], 2e-2, L, ())
+    assert same(new.get_choices()["theta"], onew.get_choices()["theta"]) and same(w, ow) and same(new.get_score(), onew.get_score())
+    # ... and ONE trace (no particle batch)
+    tr1, _ = schools.importance(G.key(seed + 7), C["y"].set(jnp.array(yj)), ())
+    otr1, _ = oschools.importance(O.key(seed + 7), O.C.d({"y": yj}), ())
+    new, w, _, _ = HMC(S["theta"], 1e-2, L=L).edit(G.key(seed + 8), tr1, Diff.no_change(()))
+    onew, ow = O.hmc_edit(O.key(seed + 8), otr1, ["theta"], 1e-2, L, ())
+    assert same(new.get_choices()["theta"], onew.get_choices()["theta"]) and same(w, ow)
+    # what stays refused: the vector read any other way than element by element in a vector-valued site's loop
+    @G.gen
+    def summed():
+        theta = G.normal(jnp.zeros(J), jnp.ones(J)) @ "theta"
+        G.normal(jnp.sum(theta), 1.0) @ "y"
+        return None
+    tr3 = summed.simulate(G.split(G.key(seed + 9), K), ())
+    try:
+        HMC(S["theta"], 1e-3, L=L).edit(G.split(G.key(seed + 4), K), tr3, Diff.no_change(()))
+        raise AssertionError("HMC on a long vector read through jnp.sum should raise")
+    except NotImplementedError as e:
+        assert "vector-valued site" in str(e) and "theta" in str(e), str(e)

@@ -1833,7 +1833,8 @@ def test_traced_negative_index_wraps_like_jax_and_static_false_mask_gives_way():
 @pytest.mark.parametrize("npts,J", [(100, 40), (500, 200), (5000, 1000)])
 def test_hmc_and_regenerate_through_long_vector_sites(npts, J):
     """linear regression with 100 / 500 / 5 000 points `HMC(S["a"] | S["b"])`, 8-schools at J = 40 / 200 /
-    1 000 `HMC(mu)`, `HMC(mu | log_tau)`, `Regenerate(theta)` — one launch each, bit-exact against the oracle"""
+    1 000 `HMC(mu)`, `HMC(mu | log_tau)`, `Regenerate(theta)`, `HMC(theta)`, `HMC(mu | log_tau | theta)`, a latent vector
+    read elementwise by two later sites, ONE trace — one launch each, bit-exact against the oracle; `jnp.sum(theta)` refused"""
     from tests import cookbook
     cookbook.check_hmc_through_long_vector_sites(npts=npts, J=J)
 

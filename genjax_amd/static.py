@@ -1005,7 +1005,18 @@ def _leaf_call(ctx: _Ctx, mode, dist, key, args, constraint: ChoiceMap, prev, re
         nv = proposed.get_value()
         if nv is None:
             raise NotImplementedError("Rejuvenate at a distribution site needs a distribution-valued proposal")
-        s = dist.sym_logpdf(nv, args)            # Update(proposed).edit(key, tr, argdiffs)
+        from .distributions import Distribution as _Dist
+        if isinstance(req.proposal, _Dist) and T._long_vector(pret):
+            nv = pret          # (a long vector drawn in a counted loop: the READABLE form of the stored values, engine.StepAlias)
+        s = None
+        if T._long_vector(nv) and ctx.gate is None:
+            # a proposal over a LONG vector-valued site (`Rejuvenate(normal, lambda chm: (chm.get_value(), 0.5))` on an
+            # 8-schools theta of 1 000 schools): the proposal drew in a counted loop (its simulate is a vector-valued site
+            # itself); the new values are scored in one as well, instead of one unrolled density per element
+            out_ = _vector_site_loop(ctx, "assess", dist, None, args, nv, None, None)
+            s = out_[3] if out_ is not None else None
+        if s is None:
+            s = dist.sym_logpdf(nv, args)        # Update(proposed).edit(key, tr, argdiffs)
         w = s - ps
         bwd_args = req.argmap(ChoiceMap.choice(pv))
         if not isinstance(bwd_args, tuple):

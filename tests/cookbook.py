@@ -543,6 +543,15 @@ def check_hmc_through_long_vector_sites(npts=500, J=200, K=7, L=3, seed=1):
     new, wr, _, _ = Regenerate(S["theta"]).edit(G.split(G.key(seed + 3), K), tr, Diff.no_change(()))
     onew, owr = oschools.regenerate(O.split(O.key(seed + 3), K), otr, O.selection("theta"), ())[:2]
     assert same(new.get_choices()["theta"], onew.get_choices()["theta"]) and np.array_equal(npv(wr), np.asarray(owr, f32), equal_nan=True)
+    # Rejuvenate ON the long vector site (rejuvenate.py:70-94): the proposal's J draws, its forward / backward densities and
+    # the re-scoring of the proposed vector each run as ONE counted loop (before round 6: unrolled — 173 launches at J = 1 000)
+    from genjax_amd import StaticRequest
+    rq = StaticRequest({"theta": G.Rejuvenate(G.normal, lambda chm: (chm.get_value(), 0.5))})
+    orq = {"theta": O.Rejuvenate(O.normal, lambda chm: (chm.get_value(), f32(0.5)))}
+    new, wj, _, _ = rq.edit(G.split(G.key(seed + 10), K), tr, Diff.no_change(()))
+    onew, owj = oschools.edit_static(O.split(O.key(seed + 10), K), otr, orq, ())
+    assert same(new.get_choices()["theta"], onew.get_choices()["theta"]), "rejuvenate on the long site: values"
+    assert np.array_equal(npv(wj), np.asarray(owj, f32), equal_nan=True) and same(new.get_score(), onew.get_score()), "rejuvenate on the long site"
     # HMC ON the long vector site (round 6): positions / momenta / gradients as vectors in memory, every leapfrog stage one
     # counted loop per vector-valued site that reads them; alone, together with the scalars, at a larger step
     # (the oracle differentiates a vector element by element — J forward passes per gradient: at many particles it runs the

@@ -116,7 +116,7 @@ def forms():
             th = G.normal(mu * jnp.ones(n), 2.0 * jnp.ones(n)) @ "theta"
             G.normal(th, jnp.array(sig)) @ "y"
             return mu
-        return dict(model=m, args=lambda k: (k_float(k),), obs=C["y"].set(jnp.array(sig)), upd=C["mu"].set(0.3), sel="theta", sel_scalar="mu")
+        return dict(model=m, args=lambda k: (k_float(k),), obs=C["y"].set(jnp.array(sig)), upd=C["mu"].set(0.3), sel="theta")
 
     def plate(n):
         xs = np.linspace(-1, 1, n).astype(np.float32)

@@ -93,7 +93,7 @@ gmx_shard_fill_body(uint32_t k0, uint32_t k1, uint32_t u0_host, const float* __r
                     int32_t n, int32_t cap, int64_t* __restrict__ plan, uint64_t* __restrict__ total_out,
                     float* __restrict__ max_out, const uint32_t* __restrict__ state, uint32_t* __restrict__ send,
                     int32_t* __restrict__ next_idx, const shard_peer& P, uint32_t anc_tag) {
-  // TAGGED (a site program's prologue, gmx_run_args.sh): every ancestor index is stored as {tag: bits 21..31 | index}
+  // TAGGED (a site program's prologue, gmx_run_args.sh): every ancestor index is stored as {tag: bits 24..31 | index}
   // with a write-through store — the workgroups of the SAME launch that gather through these slots poll them until
   // the tag is the launch's (gmx_offspring.h); a slot whose ancestor is remote gets its word AFTER the received state
   // is in the local tail (release fence in between): the word announces the value.

@@ -1440,11 +1440,13 @@ class Compiled:
         m = min(n, self.CHECK_PARTICLES)
         per_particle = {j for _, j, _, kind in self.in_plan if kind not in ("bcast", "dvec")}
 
+        anc_cut = {}           # (the gathered leaves of one launch share ONE ancestor vector: so must their cuts)
+
         def cut(j, v):
             if j not in per_particle or isinstance(v, Broadcast):
                 return v
             if isinstance(v, Gathered):
-                return Gathered(v.source, v.ancestors[:m])
+                return Gathered(v.source, anc_cut.setdefault(id(v.ancestors), v.ancestors[:m]))
             if isinstance(v, torch.Tensor) and v.ndim >= 1 and int(v.shape[0]) == n:
                 return v[:m]
             return v

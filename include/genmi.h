@@ -114,7 +114,7 @@ enum {
  * 4-particles-per-thread program that gathers (gmx_program_fuses_resample() == 1) does not find its ancestors in
  * ancestors_d — it WRITES them there first: workgroup b runs gmx_resample_tiles' workgroup b (the tile's CDF rebuilt from
  * the previous step's log-weights and tile statistics, the exact slot ranges, the LDS slot fill), storing every ancestor
- * as {tag: bits 21..31 | index: bits 0..20} with a write-through store, and then POLLS the slots of its own particles
+ * as {tag: bits 24..31 | index: bits 0..23} (GMX_ANC_TAG_SHIFT = 24, ABI v8; tags 1..255) with a write-through store, and then POLLS the slots of its own particles
  * until they carry the tag — they are filled by its neighbours of the same launch, mostly — before it gathers through
  * them.  A bootstrap SMC step (smc.py:370-396's role; SURVEY.md App. B resampling) is then ONE launch instead of two:
  * the grid-wide dependency (every tile's statistics) still rides on the launch boundary, the mostly-local one (who owns
@@ -158,12 +158,12 @@ typedef struct gmx_peer {
  * workgroup's tile of gmx_shard_step_peer for step t - 1 — polls this rank's landing table for every rank's tile
  * statistics of that step, derives the global exponent, the totals and the slot bounds, rebuilds its tile of the CDF,
  * puts the states other ranks' slots need into their landing blocks, stores the ancestors of this rank's own slots as
- * tagged words {tag: bits 21..31 | index into the extended state: bits 0..20} in ancestors_d, waits for the granules
+ * tagged words {tag: bits 24..31 | index into the extended state: bits 0..23} in ancestors_d, waits for the granules
  * its own slots need and stores them in the local tails — and then polls the ancestor words of ITS OWN particles and
  * gathers through them.  A sharded SMC step is then ONE launch and no collective: the site
  * program's epilogue of step t - 1 announced the statistics (gmx_run_args.peer), this prologue consumes them.  Same
  * integers, same routing as gmx_shard_step_peer.  Systematic resampling; world <= 8 and world * tiles <= 1024 (the
- * table fits the registers of one workgroup); n + world * capacity <= 2^21 (the index field); every workgroup of the
+ * table fits the registers of one workgroup); n + world * capacity <= 2^24 (the index field); every workgroup of the
  * launch resident at once (n <= gmx_program_resident_particles()).  The log-weights and the statistics block read
  * here must not be the ones this launch writes (two sets, alternating). */
 typedef struct gmx_shard_in {

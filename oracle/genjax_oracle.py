@@ -74,6 +74,12 @@ _UNARY = dict(exp=0, log=1, log1p=2, sqrt=3, sin=4, cos=5, tanh=6, sigmoid=7,
               softplus=8, lgamma=9, erfinv=10, recip=11)
 
 
+# hmc_edit, a selected vector of MANY elements read by elementwise consumers only: with tangent 1 at every element, element
+# j of a vector-valued site's tangent is d (its j-th term) / d v_j — exactly what the pass with tangent e_j adds to zeros —
+# so ONE pass that keeps the tangents per element replaces J passes (checked against them in tests/cookbook.py)
+_DUAL_DIAGONAL = [False]
+
+
 class Dual:
     """Forward-mode dual number (value, tangent), float32: the oracle's own, independent way to get
     d assess / d choice for HMC (the product differentiates its IR in reverse mode)."""
@@ -569,6 +575,8 @@ class _Normal(Distribution):
         z = (x.v / s.v - m.v / s.v).astype(np.float32)
         zs = (z / s.v).astype(np.float32)
         t = (-(zs * x.t) + zs * m.t + ((z * z - np.float32(1.0)) / s.v) * s.t).astype(np.float32)
+        if np.ndim(t) > np.ndim(val) and _DUAL_DIAGONAL[0]:
+            return Dual(val, t)          # (hmc_edit's one-pass gradient of a long vector: element j's own tangent, not their sum)
         if np.ndim(t) > np.ndim(val):
             # a VECTOR-valued site: the score is the sum over its elements (distribution.py:383-396), so is its tangent —
             # added in element order, the order the build's counted loop accumulates d score / d w in
@@ -1773,7 +1781,7 @@ class Rejuvenate:
         return new_tr, final
 
 
-def hmc_edit(k, trace, sel_addrs, eps, L, args):
+def hmc_edit(k, trace, sel_addrs, eps, L, args, one_hot_max=64):
     """HMC.edit (inference/requests/hmc.py:153-214) for scalar selected sites of a static model,
     literally — including the carried INITIAL gradient in the first half-kick of every step."""
     gen_fn = trace.get_gen_fn()
@@ -1790,6 +1798,16 @@ def hmc_edit(k, trace, sel_addrs, eps, L, args):
             full = full.set(a, values[a])
         grads = {}
         for a in sel_addrs:
+            if values[a].ndim > nb and values[a].shape[-1] > one_hot_max:
+                _DUAL_DIAGONAL[0] = True
+                try:
+                    s, _ = gen_fn.assess(full.set(a, Dual(values[a], np.ones(values[a].shape, np.float32))), args, batch)
+                finally:
+                    _DUAL_DIAGONAL[0] = False
+                if np.shape(s.t)[-1:] != values[a].shape[-1:]:
+                    raise NotImplementedError("hmc_edit: a long selected vector read by a consumer that is not elementwise")
+                grads[a] = np.broadcast_to(s.t, values[a].shape).astype(np.float32)
+                continue
             if values[a].ndim > nb:
                 # a VECTOR-valued selected site (jax.grad of assess with respect to the whole vector, hmc.py:69-97): one
                 # forward-mode pass per element, tangent e_j — d score / d v_j

@@ -5,6 +5,8 @@ construction for elementwise work (same IEEE op sequence) and within the
 stated tolerance for tree-ordered reductions."""
 import sys
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -2075,10 +2077,21 @@ def test_cookbook_mcmc_and_importance_sampling_on_device(gpu):
 
 
 def test_cookbook_mixture_model_under_a_batch_on_device(gpu):
+    """(programs of more than 31 live values are hiprtc-specialised at ANY particle count, and the compile of a mixture
+    program grows with k: 14 / 21 / 83 / 147 s of hiprtc for the five programs at k = 12 / 20 / 40 / 64
+    (profiles/r06i_slow_tests.txt) — the two large ones run in the test below, outside the default suite, and on the CPU
+    mirror in tests/test_host_logic.py)"""
     from tests import cookbook
-    for k, n in ((12, 40), (20, 100), (40, 500), (64, 1000)):
+    for k, n in ((12, 40), (20, 100)):
         cookbook.check_mixture_notebook_under_a_batch(k=k, n=n)
     cookbook.check_mixture_notebook_under_a_batch(k=20, n=100, B=3000, seed=4)
+
+
+@pytest.mark.skipif(not os.environ.get("GENMI_SLOW_TESTS"), reason="4 minutes of hiprtc: GENMI_SLOW_TESTS=1 (profiles/r06a_cookbook_gpu.log, r06i)")
+def test_cookbook_mixture_model_at_the_notebook_sizes_on_device(gpu):
+    from tests import cookbook
+    for k, n in ((40, 500), (64, 1000)):
+        cookbook.check_mixture_notebook_under_a_batch(k=k, n=n)
 
 
 def test_cookbook_scan_outputs_and_array_carries_on_device(gpu):

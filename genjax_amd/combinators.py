@@ -1378,8 +1378,9 @@ def _scan_edit_index_o1(self, key, trace, request, argdiffs):
         if isinstance(tr, DistributionTrace):
             return True
         return isinstance(tr, StaticTrace) and type(tr) is StaticTrace and all(flat_sites(st) for st in tr.subtraces.values())
-    if not flat_sites(trace.inner) or isinstance(request.request, IndexRequest):
+    if isinstance(request.request, IndexRequest):
         return None
+    nested_inside = not flat_sites(trace.inner)        # a plate / scan INSIDE the kernel: its leaves carry further axes ([B, T, n])
     args = tuple(Diff.tree_primal(argdiffs)) if argdiffs is not None else tuple(trace.get_args() or ())
     if len(args) != 2:
         return None
@@ -1490,10 +1491,11 @@ def _scan_edit_index_o1(self, key, trace, request, argdiffs):
     inner_old = trace.inner
     # (the slices' return values are per-step (carry, y) pairs the scan's inner trace does not keep: only choices and scores
     #  are patched; the scan's own return value is rebuilt below)
-    new_inner = _trace_leaf_zip(_strip_retval(inner_old), _strip_retval(new_i), patch_at(idx), args=None)
+    strip = _strip_retvals_deep if nested_inside else _strip_retval
+    new_inner = _trace_leaf_zip(strip(inner_old), strip(new_i), patch_at(idx), args=None)
     no_next = ~has_next if per else None
     if nxt is not None:
-        new_inner = _trace_leaf_zip(new_inner, _strip_retval(nxt), patch_at(t_n, no_next), args=None)
+        new_inner = _trace_leaf_zip(new_inner, strip(nxt), patch_at(t_n, no_next), args=None)
     elem_old = getattr(trace, "_elem_scores", None)
     if elem_old is None:
         elem_old = Deferred(lambda inner=inner_old: materialize(inner.get_score()), (B, T_))
@@ -1513,9 +1515,31 @@ def _scan_edit_index_o1(self, key, trace, request, argdiffs):
         carry_out = where_tree(idx == T_ - 1, new_carry, old_carry) if old_carry is not None else None
     else:
         carry_out = new_carry if idx == T_ - 1 else old_carry
+        if idx == T_ - 1 and old_carry is not None:
+            # (a launch-uniform new value — `Update(C["x"].set(0.3))` at the last step — as one value per particle, which is
+            #  what the scan's return value holds)
+            carry_out = _tree_zip(old_carry, carry_out, lambda o_, n_: n_ if isinstance(n_, torch.Tensor) and n_.ndim >= 1 else
+                                  torch.as_tensor(materialize(n_), device=o_.device).to(o_.dtype).expand(o_.shape).clone())
     out = VmapTrace(self, new_inner, PlateScore(elem_new), (carry_out, ys), args)
     out._elem_scores = elem_new
     return out, w, Diff.unknown_change(out.retval), IndexRequest(idx, bwd)
+
+
+def _strip_retvals_deep(tr):
+    """the same trace without ANY return value, nested ones included: a scan's inner trace keeps choices and scores per
+    step, never the steps' (or their callees') return values"""
+    from collections import OrderedDict as OD
+    from .static import DistributionTrace, StaticTrace, VmapTrace
+    if isinstance(tr, DistributionTrace):
+        return tr
+    if isinstance(tr, VmapTrace):
+        out = VmapTrace(tr.gen_fn, _strip_retvals_deep(tr.inner), tr.score, None, tr.args)
+        if getattr(tr, "_elem_scores", None) is not None:
+            out._elem_scores = tr._elem_scores
+        return out
+    if isinstance(tr, StaticTrace):
+        return StaticTrace(tr.gen_fn, tr.args, None, OD((a, _strip_retvals_deep(st)) for a, st in tr.subtraces.items()))
+    return tr
 
 
 def _take_rows(v, t):

@@ -1016,6 +1016,64 @@ def check_plate_of_scans_index_request_o1(n=33, J=20, T=40, seed=23, edits=8, ti
     return out
 
 
+def check_scan_of_plates_index_request_o1(n=9, T=40, P=30, seed=3, edits=9):
+    """`IndexRequest(t, sub)` on a LONG scan whose step holds a PLATE (`leaf.vmap()(x, sigmas) @ "obs"` inside the kernel:
+    leaves [n, T, P]) edits step t — and visits step t + 1 — in O(1) steps as well (round 6: the slices of nested traces are
+    taken and patched back whole, [n, P] rows of the [n, T, P] leaves): chains of edits, each applied to the O(1) form's
+    trace AND to the counted-loop form's, which must stay equal bit for bit — Update of the state, of one plate element
+    (as an address and as a nested IndexRequest through a StaticRequest), Regenerate of the state; Python-int and
+    per-particle step indices.  (The oracle's scan.edit_index slices trailing axes only: the loop form, which the oracle
+    and scipy hold elsewhere — check_nested_index_edits — is the reference here.)"""
+    import genjax_amd as G
+    from genjax_amd import ChoiceMapBuilder as C, Diff, IndexRequest, Regenerate, SelectionBuilder as S, StaticRequest, Update, numpy as jnp
+    from genjax_amd.engine import Patched
+    dev = G._lib.get().device
+
+    @G.gen
+    def leaf(m, s):
+        return G.normal(m, s) @ "z"
+
+    @G.gen
+    def step(x, sx):
+        leaf.vmap(in_axes=(None, 0))(x, jnp.array(np.linspace(1, 2, P).astype(np.float32))) @ "obs"
+        xn = G.normal(0.9 * x + sx, 0.5) @ "x"
+        return xn, xn
+    sc = G.Scan(step, T)
+    args = (torch.linspace(0, 1, n).to(dev), jnp.array(np.linspace(-0.5, 0.5, T).astype(np.float32)))
+    tr_a = tr_b = sc.simulate(G.split(G.key(seed), n), args)
+    rng = np.random.default_rng(seed)
+    lazy = 0
+    for e in range(edits):
+        sub = [Update(C["x"].set(float(rng.normal()))),
+               StaticRequest({"obs": IndexRequest(int(rng.integers(P)), Update(C["z"].set(float(rng.normal()))))}),
+               Update(C["obs", int(rng.integers(P)), "z"].set(torch.from_numpy(rng.normal(size=n).astype(np.float32)).to(dev))),
+               StaticRequest({"x": Regenerate(S.all())})][e % 4]
+        if e % 3 == 2:
+            t_host = rng.integers(0, T, n).astype(np.int32)
+            t_host[:2] = (0, T - 1)
+            t = torch.from_numpy(t_host).to(dev)
+        else:
+            t = [0, T - 1, int(rng.integers(1, T - 1))][e % 3]
+        k = G.split(G.key(seed + 10 + e), n)
+        sc.__dict__.pop("_o1_refused", None)
+        new_a, w_a, _, _ = IndexRequest(t, sub).edit(k, tr_a, Diff.no_change(args))
+        sc.__dict__["_o1_refused"] = True
+        try:
+            new_b, w_b, _, _ = IndexRequest(t, sub).edit(k, tr_b, Diff.no_change(args))
+        finally:
+            sc.__dict__.pop("_o1_refused")
+        lazy += isinstance(new_a.inner.subtraces["x"].value, Patched)
+        assert not isinstance(new_b.inner.subtraces["x"].value, Patched)
+        assert np.array_equal(_np(w_a), _np(w_b), equal_nan=True), (e, "weight")
+        assert np.array_equal(_np(new_a.get_score()), _np(new_b.get_score())), (e, "score")
+        for ad in (("x",), ("obs", "z")):
+            assert np.array_equal(_np(new_a.get_choices()[ad]), _np(new_b.get_choices()[ad])), (e, ad)
+        assert np.array_equal(_np(new_a.get_retval()[0]), _np(new_b.get_retval()[0])), (e, "carry")
+        assert np.array_equal(_np(new_a.get_retval()[1]), _np(new_b.get_retval()[1])), (e, "ys")
+        tr_a, tr_b = new_a, new_b
+    assert lazy == edits, "the O(1) form was not taken"
+
+
 def check_nested_marginal(k=129, seed=5):
     """A12 / F4: ChangeTarget.run_csmc_for_normalizing_constant (ref smc.py:432-465),
     estimate_reciprocal_normalizing_constant (:214-225) and Marginal.random_weighted with an inner algorithm

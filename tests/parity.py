@@ -1074,6 +1074,64 @@ def check_scan_of_plates_index_request_o1(n=9, T=40, P=30, seed=3, edits=9):
     assert lazy == edits, "the O(1) form was not taken"
 
 
+def check_direct_plate_of_scans_random(seed):
+    """`kernel.scan(n=T).vmap()` written DIRECTLY (its trace is held flat: the kernel's sites with the [J, T] axes), at random
+    sizes around the unroll limits (J in 2 / 5 / 17 / 20, T in 3 / 8 / 17 / 40; 1 / 4 / 9 particles): simulate, importance
+    under a full observation, assess, Update of a whole site, an empty Update under a CHANGED mapped argument, Update of
+    one (j, t) address — against the oracle's Vmap(Scan), bit for bit.  (Before round 6 `Scan._trace_edit` refused the flat
+    previous trace: every edit of such a nest raised.)"""
+    import genjax_amd as G
+    from genjax_amd import ChoiceMapBuilder as C, Diff, Update, numpy as jnp
+    f32 = np.float32
+    rng = np.random.default_rng(seed)
+    n = int(rng.choice([1, 4, 9])); J = int(rng.choice([2, 5, 17, 20])); T = int(rng.choice([3, 8, 17, 40]))
+    sd = f32(rng.uniform(0.5, 2.0))
+    def mk(g, lit):
+        @g.gen
+        def step(c, x):
+            z = g.normal(c * lit(0.5) + x, lit(sd)) @ "z"
+            g.normal(z, lit(0.75)) @ "y"
+            return z, z * lit(2.0)
+        return step
+    step, ostep = mk(G, float), mk(O, f32)
+    xs = rng.normal(size=T).astype(f32); c0 = rng.normal(size=J).astype(f32)
+    pl, opl = G.Scan(step, T).vmap(in_axes=(0, None)), O.Vmap(O.Scan(ostep, T), in_axes=(0, None))
+    args, oargs = (jnp.array(c0), jnp.array(xs)), (c0, xs)
+    k, ok = G.split(G.key(seed), n), O.split(O.key(seed), n)
+    tr, otr = pl.simulate(k, args), opl.simulate(ok, oargs)
+    for a in ("z", "y"):
+        assert np.array_equal(_np(tr.get_choices()[a]), otr.get_choices()[a]), (seed, "simulate", a)
+    assert np.array_equal(_np(tr.get_score()), otr.get_score()), (seed, "simulate score")
+    yobs = rng.normal(size=(J, T)).astype(f32)
+    tr2, w2 = pl.importance(k, C["y"].set(jnp.array(yobs)), args)
+    otr2, ow2 = opl.importance(ok, O.C.d({("y",): yobs}), oargs)
+    assert np.array_equal(_np(w2), ow2), (seed, "importance w")
+    assert np.array_equal(_np(tr2.get_choices()["z"]), otr2.get_choices()["z"]), (seed, "importance z")
+    s, _ = pl.assess(tr2.get_choices(), args)
+    assert np.array_equal(_np(s), _np(tr2.get_score())), (seed, "assess")
+    # update: the whole of z (launch-uniform), then under a changed first argument
+    znew = rng.normal(size=(J, T)).astype(f32)
+    k2, ok2 = G.split(G.key(seed + 1), n), O.split(O.key(seed + 1), n)
+    tr3, w3, _, _ = Update(C["z"].set(jnp.array(znew))).edit(k2, tr2, Diff.no_change(args))
+    otr3, ow3, _ = opl.update(ok2, otr2, O.C.d({("z",): znew}), oargs)
+    assert np.array_equal(_np(w3), np.broadcast_to(ow3, (n,))), (seed, "update w", J, T)
+    assert np.array_equal(_np(tr3.get_score()), np.broadcast_to(otr3.get_score(), (n,))), (seed, "update score")
+    c1 = rng.normal(size=J).astype(f32)
+    a2, oa2 = (jnp.array(c1), jnp.array(xs)), (c1, xs)
+    tr4, w4, _, _ = Update(C.n()).edit(k2, tr3, (Diff.unknown_change(a2[0]), Diff.no_change(a2[1])))
+    otr4, ow4, _ = opl.update(ok2, otr3, O.ChoiceMap(), oa2)
+    assert np.array_equal(_np(w4), np.broadcast_to(ow4, (n,))), (seed, "changed args w", J, T)
+    # one address
+    j, t = int(rng.integers(J)), int(rng.integers(T))
+    tr5, w5, _, _ = Update(C[j, t, "y"].set(0.25)).edit(k2, tr4, Diff.no_change(a2))
+    y5 = _np(tr5.get_choices()["y"]); y4 = _np(tr4.get_choices()["y"])
+    assert np.all(y5[:, j, t] == f32(0.25)); y4[:, j, t] = 0.25; assert np.array_equal(y5, y4)
+    ofull = np.array(otr4.get_choices()["y"]); ofull = np.broadcast_to(ofull, (n, J, T)).copy(); ofull[:, j, t] = 0.25
+    otr5, ow5, _ = opl.update(ok2, otr4, O.C.d({("y",): ofull}), oa2)
+    assert np.array_equal(_np(w5), np.broadcast_to(ow5, (n,))), (seed, "one address w", J, T)
+    return J, T, n
+
+
 def check_nested_marginal(k=129, seed=5):
     """A12 / F4: ChangeTarget.run_csmc_for_normalizing_constant (ref smc.py:432-465),
     estimate_reciprocal_normalizing_constant (:214-225) and Marginal.random_weighted with an inner algorithm

@@ -1993,6 +1993,8 @@ def test_nested_index_request_on_a_plate_of_long_scans_is_o1_on_device(gpu):
     parity.check_plate_of_scans_index_request_o1()
     parity.check_plate_of_scans_index_request_o1(n=300, J=17, T=70, seed=5, edits=12)
     parity.check_scan_of_plates_index_request_o1(n=300, T=70, P=20, seed=8, edits=8)     # a plate inside the scan's step
+    for seed in range(8):
+        parity.check_direct_plate_of_scans_random(seed)
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import nested_index_request_cost as cost
     out = cost.run(1000, 64, 4096)

@@ -1180,6 +1180,8 @@ def test_nested_index_request_on_a_plate_of_long_scans_is_o1():
     from tests import parity
     parity.check_plate_of_scans_index_request_o1()
     parity.check_plate_of_scans_index_request_o1(n=9, J=17, T=70, seed=5, edits=40)
+    for seed in range(24):          # the nest written directly, random sizes around the unroll limits, every GFI method
+        parity.check_direct_plate_of_scans_random(seed)
     # ... and a PLATE inside the step of a long scan: O(1) steps against the counted-loop form, chains of 9 / 40 edits
     parity.check_scan_of_plates_index_request_o1()
     parity.check_scan_of_plates_index_request_o1(n=5, T=70, P=20, seed=8, edits=40)

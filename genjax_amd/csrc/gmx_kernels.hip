@@ -2981,7 +2981,8 @@ extern "C" int gmx_shard_totals(const void* stats_all_d, int world, int64_t n_pe
   if (!stats_all_d || !totals_d || !max_d) return gmx_fail("gmx_shard_totals: null argument%s");
   if (world < 1 || world > 1024) return gmx_fail("gmx_shard_totals: world out of range%s");
   const int64_t tiles = (n_per_rank + RS_TILE - 1) / RS_TILE;
-  if (n_per_rank <= 0 || tiles > RS_MAX_TILES) return gmx_fail("gmx_shard_totals: n_per_rank out of range (<= 2^21)%s");
+  // (one workgroup strides over the whole gathered table: any number of tiles — config 4's 1e7 particles on ONE rank are 9766)
+  if (n_per_rank <= 0 || n_per_rank > 0x7fffffffLL) return gmx_fail("gmx_shard_totals: n_per_rank out of range (< 2^31)%s");
   if ((uintptr_t)stats_all_d & 7) return gmx_fail("gmx_shard_totals: stats_all_d must be 8-byte aligned%s");
   hipLaunchKernelGGL(k_shard_totals, dim3(1), dim3(GMX_BLOCK), 0, (hipStream_t)stream, (const uint8_t*)stats_all_d,
                      world, (int)tiles, gmx_shard_stats_bytes(n_per_rank), totals_d, max_d);
@@ -3004,7 +3005,8 @@ extern "C" int gmx_shard_step_tiles(int kind, const uint32_t key[2], const uint6
   if (world > SHARD_MAX_WORLD) return gmx_fail("gmx_shard_step_tiles: world <= 64 (use gmx_weight_cdf + gmx_shard_step)%s");
   if (shift < 1 || shift > 62) return gmx_fail("gmx_shard_step_tiles: shift out of range%s");
   const int64_t tiles = (n_per_rank + RS_TILE - 1) / RS_TILE;
-  if (tiles > RS_MAX_TILES) return gmx_fail("gmx_shard_step_tiles: n_per_rank too large (<= 2^21)%s");
+  // (k_shard_step<true> sums the mass of its rank's EARLIER tiles by striding over them — no table in registers or LDS —
+  //  so the per-rank size is not bounded by RS_MAX_TILES; the fused / peer forms below hold the table and are)
   if (((uintptr_t)lw_d & 15) || ((uintptr_t)stats_own_d & 7))
     return gmx_fail("gmx_shard_step_tiles: lw_d must be 16-byte and stats_own_d 8-byte aligned%s");
   const int64_t tiles_pad = tiles + (tiles & 1);

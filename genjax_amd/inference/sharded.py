@@ -689,7 +689,7 @@ def sharded_importance_resample(target, k_per_rank: int, key: Key, dist, kind="s
 
     Two data-path collectives per resampling whatever the number of leaves (the first form did one all-to-all and one
     routing launch PER ROW, plus a max all-reduce and a totals all-gather), and one 8-byte all-reduce for the
-    capacity-overflow flag.  (k_per_rank > 2^21, more than 64 ranks or multinomial: the CDF-array form computes the
+    capacity-overflow flag.  (More than 64 ranks or multinomial_sorted: the CDF-array form computes the
     same plan — all-reduce of the max, gmx_weight_cdf, all-gather of the totals, gmx_shard_step.)
     `stats`, if given, receives {"collectives": {...}, "rows": R, "capacity": C, "form": ...}.
     Returns (ParticleCollection of this rank's k resampled particles, this rank's pre-resampling log-weights).
@@ -721,7 +721,8 @@ def sharded_importance_resample(target, k_per_rank: int, key: Key, dist, kind="s
         (lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev))          # destinations of collectives
     totals_all = calloc((W,), torch.int64)
     gtotal = torch.zeros((1,), dtype=torch.int64, device=dev)
-    tiles_form = kind in (0, 1) and n <= FUSED_RESAMPLE_MAX and W <= 64 and not cdf_form
+    # (the tile-statistics plan takes any per-rank size: gmx_shard_totals / gmx_shard_step_tiles stride over the table)
+    tiles_form = kind in (0, 1) and W <= 64 and not cdf_form
     if tiles_form:
         nbytes = int(be.c.gmx_shard_stats_bytes(n))
         tiles = (n + 1023) // 1024
@@ -754,7 +755,10 @@ def sharded_importance_resample(target, k_per_rank: int, key: Key, dist, kind="s
         else:
             totals_all.copy_(total)
 
+    lazy_out = W == 1
     # ---- every per-particle leaf of the trace as 4-byte rows [R, n] ----
+    # (ONE rank: nothing is shipped — every slot's ancestor is local — so no leaf is packed at all: the new trace's leaves
+    #  are lazy gathers through next_idx, materialised when read, as smc.resample's are)
     specs, rows = [], []
 
     def collect(v):
@@ -775,7 +779,8 @@ def sharded_importance_resample(target, k_per_rank: int, key: Key, dist, kind="s
         for c in range(flat.shape[1]):
             rows.append(flat[:, c].contiguous().view(torch.float32))
         return v
-    trace_map(trs, collect)
+    if not lazy_out:
+        trace_map(trs, collect)
     R = len(rows)
     table = torch.stack(rows) if R else torch.zeros((0, n), dtype=torch.float32, device=dev)      # [R, n]
 
@@ -813,10 +818,15 @@ def sharded_importance_resample(target, k_per_rank: int, key: Key, dist, kind="s
         packed = table[:, send_idx.long()].reshape(R, W, C).permute(1, 0, 2).contiguous()          # [W, R, C]
         recv = calloc(tuple(packed.shape), packed.dtype)
         comm.all_to_all(recv.view(-1), packed.view(-1))
-        ext = torch.cat([table, recv.permute(1, 0, 2).reshape(R, W * C)], dim=1)                   # [R, n + W*C]
+        # the local ancestors by ONE gather of the table; the few slots whose ancestor arrived from another rank are then
+        # filled from the received blocks (no [R, n + W * C] copy of the whole table in between)
+        far = next_idx >= n
+        moved = table[:, torch.where(far, torch.zeros_like(next_idx), next_idx).long()]              # [R, n]
+        rp = far.nonzero().squeeze(1)
+        if rp.numel():
+            moved[:, rp] = recv.permute(1, 0, 2).reshape(R, W * C)[:, (next_idx[rp] - n).long()]
     else:
-        ext = table
-    moved = ext[:, next_idx.long()] if R else ext                                                     # [R, n]
+        moved = table[:, next_idx.long()] if R else table                                             # [R, n]
     it = iter(specs)
 
     def rebuild(v):
@@ -830,7 +840,15 @@ def sharded_importance_resample(target, k_per_rank: int, key: Key, dist, kind="s
         elif out.dtype != orig:
             out = (out != 0) if orig == torch.bool else out.to(orig)
         return out.reshape(shape)
-    new = trace_map(trs, lambda v: rebuild(materialize(v)))
+    if lazy_out:
+        from ..engine import Gathered
+
+        def lazy(v):
+            v = materialize(v)
+            return Gathered(v, next_idx) if isinstance(v, torch.Tensor) and tuple(v.shape[:1]) == (n,) else v
+        new = trace_map(trs, lazy)
+    else:
+        new = trace_map(trs, lambda v: rebuild(materialize(v)))
     if stats is not None:
         stats.update(collectives=dict(comm.counts) if comm is not None else {}, rows=R, capacity=C,
                      form="tile statistics" if tiles_form else "cdf array")

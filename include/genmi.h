@@ -511,8 +511,10 @@ int gmx_shard_step_sorted(const uint32_t* table_d, const uint64_t* totals_d /* [
  * the max all-reduce and the totals all-gather carried.  gmx_shard_totals (one block) turns the gathered
  * table into the global max (*max_d) and every rank's integer total (totals_d[world]);
  * gmx_shard_step_tiles is gmx_shard_step with this rank's CDF rebuilt per tile in registers from lw_d and
- * its own block.  n_per_rank <= 2^21, world <= 64; shards start on a tile boundary (n_per_rank % 1024 == 0
- * when world > 1). */
+ * its own block.  world <= 64; shards start on a tile boundary (n_per_rank % 1024 == 0 when world > 1).  Any
+ * n_per_rank < 2^31 for these two calls (a workgroup sums the mass of its rank's earlier tiles by striding over the
+ * block — BASELINE config 4's k = 1e7 on few ranks; before ABI v8's second revision: <= 2^21); the ONE-launch forms
+ * below (gmx_shard_step_fused, the peer forms) hold the table in registers / LDS and stay at n_per_rank <= 2^21. */
 size_t gmx_shard_stats_bytes(int64_t n_per_rank);
 int gmx_shard_totals(const void* stats_all_d /* [world] blocks */, int world, int64_t n_per_rank,
                      uint64_t* totals_d /* [world] */, float* max_d /* [1] */, gmx_stream stream);

@@ -668,7 +668,8 @@ def other_configs_sharded(dist, world, rank, cx, be):
                           "sharded_us_per_step": 1e6 * dtN / T, "single_gpu_us_per_step": 1e6 * dt1 / T,
                           "strong_scaling_speedup": dt1 / dtN, "particle_steps_per_s": n * world * T / dtN,
                           "log_ml_rel_diff_vs_single_gpu": abs(sh.log_ml() - lm1) / max(1.0, abs(lm1)), "graph": sh.graph is not None,
-                          "communicator": getattr(cx, "name", None), "full_capacity_reruns": sh.reruns}
+                          "communicator": getattr(cx, "name", None), "full_capacity_reruns": sh.reruns,
+                          "one_launch_per_step": bool(getattr(sh, "fuse_sh", False) and getattr(sh, "chain_mh", False))}
         sh.close()
     except Exception as e:          # noqa: BLE001
         out["config3"] = {"error": repr(e)[:300]}

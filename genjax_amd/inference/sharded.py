@@ -91,7 +91,7 @@ class ShardedBootstrapSweep(_NoiseAhead):
 
     def __init__(self, init, step, n_per_rank: int, T: int, dist, obs_addr="y", step_extra=None, specialize=True,
                  resample="systematic", capacity=None, always_communicate=False, rejuvenate=None, state_addr="x",
-                 noise_ahead=None, cdf_form=False, fused=True, comm=None, fuse_step=None):
+                 noise_ahead=None, cdf_form=False, fused=True, comm=None, fuse_step=None, chain_mh=True):
         """cdf_form=True: the three-collective CDF-array form (what n > 2^21 per rank or > 64 ranks take) instead of
         the tile statistics; fused=False: gmx_shard_totals + gmx_shard_step_tiles as two launches (what a vector
         state / the MH move's second leaf take) instead of gmx_shard_step_fused."""
@@ -131,8 +131,14 @@ class ShardedBootstrapSweep(_NoiseAhead):
         self.cdf_form, self.fused_req = bool(cdf_form) or self.kind == MULTINOMIAL_SORTED, bool(fused)
         self._noise_offset, self._noise_total = self.rank * self.n, self.N
         self.fuse_sh_req, self.fuse_sh = fuse_step, False      # None: one launch per step where it applies (prepare)
+        self.chain_mh_req, self.chain_mh = bool(chain_mh), False   # rejuvenate=: the move and the extension as ONE program
+
+    fuse_mh = False          # (the noise-ahead mixin: the chained MH + extension program's move draws hang off k_mh)
 
     def _chain_prog(self, t):
+        if t >= 1 and self.rejuvenate is not None and getattr(self, "p_mhvm_step", None) is not None and \
+                (self.chain_mh or self.fuse_mh):
+            return self.p_mhvm_init if t == 1 else self.p_mhvm_step
         return self.p_init if t == 0 else self.p_step
 
     def _chain_step(self, t, skip_vm=False):
@@ -142,15 +148,21 @@ class ShardedBootstrapSweep(_NoiseAhead):
         from ..static import MinimalGenerate as _MG
         be = _lib.get()
         n, T, dev, W = self.n, self.T, be.device, self.world
-        # noise ahead: on request, or by default on a device with streams (specialised programs, no MH move: the
-        # sharded MH step keeps its two launches)
+        # noise ahead: on request, or by default on a device with streams (specialised programs)
         want_na = self.noise_ahead_req
+        # (with an MH move: the chained move + extension program as ONE launch per step — the fused peer exchange — takes
+        #  the move's draws from the background stream, as the single-GPU sweep does; any other MH form draws in place)
+        mh_na_ok = bool(self.rejuvenate is None or (self.chain_mh_req and be.uses_streams and self.specialize
+                                                    and not self.__dict__.get("_mh_na_failed")))
         if want_na is None:
             want_na = (os.environ.get("GENMI_NOISE_AHEAD", "1") != "0" and be.uses_streams and self.specialize
-                       and self.rejuvenate is None)
-        if want_na and self.rejuvenate is not None:
-            raise NotImplementedError("ShardedBootstrapSweep(noise_ahead=True, rejuvenate=...)")
+                       and mh_na_ok)
+        if want_na and not mh_na_ok:
+            raise NotImplementedError("ShardedBootstrapSweep(noise_ahead=True, rejuvenate=...): needs the chained move + "
+                                      "extension program as the one-launch sharded step (the fused peer exchange, "
+                                      "specialised programs)")
         self.noise_ahead = False
+        self.fuse_mh = False
         self._noise_progs = {}
         self.__dict__.pop("_noise_run_cache", None)
         if getattr(self, "graph", None) is not None:     # prepared again: the graph captured for the previous run goes
@@ -205,7 +217,28 @@ class ShardedBootstrapSweep(_NoiseAhead):
             self.p_mh_init = MinimalMH(self.init, (), ch, self.rejuvenate, (n,))
             self.p_mh_step = MinimalMH(self.step, (Gathered(self._asrc(0), self.idx),) + tuple(self.step_extra(1)), ch,
                                        self.rejuvenate, (n,))
-        if want_na and self.p_step.noise:
+            # the move and the extension that follows it as ONE program (static.MinimalMHGenerate, what the single-GPU
+            # sweep launches per step): with the routing of the previous step as its prologue a sharded MH step is ONE
+            # launch — used when that form applies (fuse_sh below), else the separate programs above
+            self.p_mhvm_init = self.p_mhvm_step = None
+            if self.chain_mh_req and be.uses_streams and self.specialize:
+                from ..static import MinimalMHGenerate
+                from .smc import BootstrapSweep as _BS
+                ex1 = tuple(self.step_extra(1))
+                hn = tuple(_BS.NOISE_ROOTS_MH.split(",")) if want_na else False      # the move's proposal + accept draws
+                self.p_mhvm_init = MinimalMHGenerate(self.init, (), ch, self.rejuvenate, self.step, ex1, obs0, (n,),
+                                                     hoist_noise=hn)
+                self.p_mhvm_step = MinimalMHGenerate(self.step, (Gathered(self._asrc(0), self.idx),) + ex1, ch,
+                                                     self.rejuvenate, self.step, ex1, obs0, (n,), hoist_noise=hn)
+        if want_na and self.rejuvenate is not None:
+            if self.p_mhvm_step is not None and self.p_mhvm_step.noise:
+                self.fuse_mh = True
+                self._noise_setup((self.p_init, self.p_mhvm_init, self.p_mhvm_step), n, T, dev)
+            else:
+                self._mh_na_failed = True
+                self.noise_ahead_req = False if self.noise_ahead_req is None else self.noise_ahead_req
+                return self.prepare(key, ys)
+        elif want_na and self.p_step.noise:
             self._noise_setup((self.p_init, self.p_step, self.p_step), n, T, dev)
         elif want_na and self.p_init.noise:
             self.noise_ahead_req = False          # the steady-state program draws nothing ahead: the plain programs
@@ -215,17 +248,28 @@ class ShardedBootstrapSweep(_NoiseAhead):
         # exchange, systematic resampling, a scalar / short vector state without an MH move, a table that fits one
         # workgroup's registers, indices that fit an ancestor word
         tiles_ = (n + CDF_TILE - 1) // CDF_TILE
+        # (with an MH move the program that GATHERS is the move's — it routes step t - 1 first, two leaves per state
+        #  component: x_{t-1} and what it was extended from — and the extension that follows reads the moved state locally:
+        #  two launches per step instead of three; round 6)
+        leaves_routed = self.D * (2 if self.rejuvenate is not None else 1)
         want_fuse_sh = bool(self.peer_mode and be.uses_streams and self.specialize and self.kind == SYSTEMATIC
-                            and self.rejuvenate is None and W <= 8 and W * tiles_ <= 1024 and self.D <= _lib.PEER_MAX_LEAVES
+                            and W <= 8 and W * tiles_ <= 1024 and leaves_routed <= _lib.PEER_MAX_LEAVES
                             and n + W * self.capacity <= (1 << _lib.ANC_TAG_SHIFT) and self.fuse_sh_req is not False)
-        if want_fuse_sh and not self.p_step.comp.is_specialized():
-            self.p_step.comp.set_fuse_shard_step()
+        chained = self.rejuvenate is not None and self.p_mhvm_step is not None
+        self._routers = (self.p_step,) if self.rejuvenate is None else \
+            ((self.p_mhvm_init, self.p_mhvm_step) if chained else (self.p_mh_init, self.p_mh_step))
+        if want_fuse_sh and not any(p_.comp.is_specialized() for p_ in self._routers):
+            for p_ in self._routers:
+                p_.comp.set_fuse_shard_step()
         if self.specialize and be.uses_streams:
             self.p_init.comp.specialize()
             self.p_step.comp.specialize()
             if self.rejuvenate is not None:
                 self.p_mh_init.comp.specialize()
                 self.p_mh_step.comp.specialize()
+                if chained:
+                    self.p_mhvm_init.comp.specialize()
+                    self.p_mhvm_step.comp.specialize()
         self.partials = torch.zeros((2, (n + 255) // 256), dtype=torch.float32, device=dev)
         # two collectives per step instead of three: the ranks all-gather their CDF TILE STATISTICS (12 bytes per
         # 1024 particles; written by the site program itself when it can, else by gmx_tile_stats), from which
@@ -246,9 +290,19 @@ class ShardedBootstrapSweep(_NoiseAhead):
             self.stats_own_pp = [self.stats_own, torch.zeros_like(self.stats_own)]
             self.tile_agg_pp = [b_[:pad * 8].view(torch.int64) for b_ in self.stats_own_pp]
             self.tile_max_pp = [b_[pad * 8:].view(torch.float32) for b_ in self.stats_own_pp]
-        self.fuse_sh = bool(want_fuse_sh and self.tiles_mode and self.p_step.comp.fuses_shard_step()
-                            and self.p_init.comp.writes_tile_stats() and self.p_step.comp.writes_tile_stats()
-                            and self.p_step.comp.resident_particles() >= n)
+        writers = (self.p_init,) + (self._routers if chained else (self.p_step,))      # who leaves a step's tile statistics
+        self.fuse_sh = bool(want_fuse_sh and self.tiles_mode and all(p_.comp.fuses_shard_step() for p_ in self._routers)
+                            and all(p_.comp.writes_tile_stats() for p_ in writers)
+                            and all(p_.comp.resident_particles() >= n for p_ in self._routers))
+        self.chain_mh = bool(chained and self.fuse_sh)
+        if self.rejuvenate is not None and self.noise_ahead and not self.chain_mh:
+            # the one-launch chained form did not come about (no fused peer exchange, a program that does not fit): the
+            # separate programs draw in place
+            self._mh_na_failed = True
+            if self.noise_ahead_req:
+                raise NotImplementedError("ShardedBootstrapSweep(noise_ahead=True, rejuvenate=...): the chained move + "
+                                          "extension program does not run as the one-launch sharded step here")
+            return self.prepare(key, ys)
         if self.fuse_sh_req and not self.fuse_sh:
             raise NotImplementedError("ShardedBootstrapSweep(fuse_step=True): needs the fused peer exchange, systematic "
                                       "resampling, specialised programs that leave tile statistics, world <= 8")
@@ -319,6 +373,23 @@ class ShardedBootstrapSweep(_NoiseAhead):
         obs = ChoiceMap.empty().set(self.obs_addr, self.ys[t])
         cur = self.xext[t % 2]
         mh = None
+        shard_in = None
+        if self.fuse_sh and t >= 1:
+            # the launch that gathers ROUTES step t - 1 first: that step's log-weights, statistics, states and resampling key
+            pw = (t - 1) % 2
+            prev_rows = [self.xrows[pw][d] for d in range(self.D)]
+            if self.rejuvenate is not None and t - 1 >= 1:         # second routed leaf: what x_{t-1} was extended from
+                prev_rows += [self.arows[pw][d] for d in range(self.D)]
+            kh_ = self.step_keys[t - 1][1].host()
+            p_prev = _lib.Peer()
+            p_prev.land_d, p_prev.tag_base_d, p_prev.status_d = (self.peer_land.data_ptr(), self.peer_tag.data_ptr(),
+                                                                 self.peer_status.data_ptr())
+            p_prev.rank, p_prev.world, p_prev.step, p_prev.tiles = g, W, t - 1, (n + CDF_TILE - 1) // CDF_TILE
+            p_prev.capacity, p_prev.leaves = C, len(prev_rows)
+            shard_in = dict(lw=self.lw_pp[pw], stats_own=self.stats_own_pp[pw], plan=self.plan, total_out=self.totals[t - 1:t],
+                            max_out=self.maxs[t - 1:t], status=self.sh_status, shift=self.shift, tag=1 + (t - 1) % _lib.ANC_TAG_MAX,
+                            key=(int(kh_[0]), int(kh_[1])), peer=p_prev, state=prev_rows,
+                            tail=[r_[n:] for r_ in prev_rows])
         if t == 0:
             prog = self.p_init
             leaves = prog.leaves((), obs, self._noise_leaves(t, prog)) if self.noise_ahead else prog.leaves((), obs)
@@ -326,6 +397,23 @@ class ShardedBootstrapSweep(_NoiseAhead):
             prog = self.p_step
             a_ = (Gathered(self._src((t - 1) % 2), self.idx),) + tuple(self.step_extra(t))
             leaves = prog.leaves(a_, obs, self._noise_leaves(t, prog)) if self.noise_ahead else prog.leaves(a_, obs)
+        elif self.chain_mh:
+            # ONE program: the MH move on the resampled particles of step t - 1 (keys split(k_mh, N)[g*n + i]), then the
+            # extension to step t from the moved state (keys split(k_prop, N)[g*n + i]: OP_KSPLITU of two launch values)
+            ch = ChoiceMap.empty().set(self.obs_addr, self.ys[t - 1]).set(self.state_addr,
+                                                                          Gathered(self._src((t - 1) % 2), self.idx))
+            ex_t = tuple(self.step_extra(t))
+            kw = k_prop.host()
+            if t == 1:
+                prog = self.p_mhvm_init
+                leaves = prog.leaves((), ch, self.rejuvenate, ex_t, obs, (int(kw[0]), int(kw[1])),
+                                     self._noise_leaves(t, prog) if self.noise_ahead else ())
+            else:
+                prog = self.p_mhvm_step
+                leaves = prog.leaves((Gathered(self._asrc((t - 1) % 2), self.idx),) + tuple(self.step_extra(t - 1)), ch,
+                                     self.rejuvenate, ex_t, obs, (int(kw[0]), int(kw[1])),
+                                     self._noise_leaves(t, prog) if self.noise_ahead else ())
+            k_prop = self.step_keys[t][2]          # the launch key of the chained program is the MOVE's
         else:
             # the MH move on the resampled particles of step t-1, keys split(k_mh, N)[g*n + i]
             ch = ChoiceMap.empty().set(self.obs_addr, self.ys[t - 1]).set(self.state_addr,
@@ -340,12 +428,16 @@ class ShardedBootstrapSweep(_NoiseAhead):
             mbufs[mprog.ro[1]] = self.arows[t % 2][:, :n]
             mbufs[mprog.ao[1]] = self.accept.reshape(1, n)
             mh = (mprog.comp, mprog.comp.bind(mleaves, (n,), lazy_split(self.step_keys[t][2], self.N),
-                                             out_buffers=mbufs, index_offset=g * n), mleaves)
+                                             out_buffers=mbufs, index_offset=g * n, shard_in=shard_in), mleaves)
+            shard_in = None                       # (the move routed: the extension below reads its output locally)
             prog = self.p_step
             leaves = prog.leaves((self._asrc(t % 2, local=True),) + tuple(self.step_extra(t)), obs)
         bufs = [None] * len(prog.comp.outputs)
         rows_t = self.xrows[t % 2]
         bufs[prog.ro[1]] = rows_t[:, :n]                 # [D, n] window of the [D, n + W*C] rows
+        if self.chain_mh and t >= 1:
+            bufs[prog.mo[1]] = self.arows[t % 2][:, :n]     # the moved state step t was extended from
+            bufs[prog.ao[1]] = self.accept.reshape(1, n)
         w_ = t % 2 if self.fuse_sh else 0                # (one launch per step: two sets of log-weights / statistics)
         lw_t = self.lw_pp[w_]
         bufs[prog.wo[1]] = lw_t.reshape(1, n)
@@ -358,20 +450,6 @@ class ShardedBootstrapSweep(_NoiseAhead):
             peer.rank, peer.world, peer.step, peer.tiles = g, W, t, (n + CDF_TILE - 1) // CDF_TILE
             peer.capacity = C
             peer.leaves = self.D * (2 if (self.rejuvenate is not None and t >= 1) else 1)
-        shard_in = None
-        if self.fuse_sh and t >= 1:
-            # this launch ROUTES step t - 1 first: that step's log-weights, statistics, states and resampling key
-            pw = (t - 1) % 2
-            prev_rows = self.xrows[pw]
-            kh_ = self.step_keys[t - 1][1].host()
-            p_prev = _lib.Peer()
-            p_prev.land_d, p_prev.tag_base_d, p_prev.status_d = peer.land_d, peer.tag_base_d, peer.status_d
-            p_prev.rank, p_prev.world, p_prev.step, p_prev.tiles = g, W, t - 1, peer.tiles
-            p_prev.capacity, p_prev.leaves = C, self.D
-            shard_in = dict(lw=self.lw_pp[pw], stats_own=self.stats_own_pp[pw], plan=self.plan, total_out=self.totals[t - 1:t],
-                            max_out=self.maxs[t - 1:t], status=self.sh_status, shift=self.shift, tag=1 + (t - 1) % _lib.ANC_TAG_MAX,
-                            key=(int(kh_[0]), int(kh_[1])), peer=p_prev, state=[prev_rows[d] for d in range(self.D)],
-                            tail=[prev_rows[d][n:] for d in range(self.D)])
         if writes_stats:        # the workgroup maxima land in the statistics block (red_out plane 0), the sums beside them
             st_w = t % 2 if self.fuse_sh else 0
             vm = prog.comp.bind(leaves, (n,), lazy_split(k_prop, self.N),

@@ -115,7 +115,8 @@ def main(out_path, n_per_rank, T, capacity=None, mh=False, vec=False, vecmh=Fals
         json.dump({"log_ml": sw.log_ml(), "totals": [str(t) for t in sw.totals.cpu().numpy().view(np.uint64).tolist()],
                    "maxs": sw.maxs.cpu().tolist(), "reruns": sw.reruns, "capacity": sw.capacity,
                    "communicator": sw.cx.name if sw.cx is not None else None,
-                   "one_launch_per_step": bool(getattr(sw, "fuse_sh", False))},
+                   "one_launch_per_step": bool(getattr(sw, "fuse_sh", False)),
+                   "chained_mh": bool(getattr(sw, "chain_mh", False))},
                   open(out_path + ".json", "w"))
     if on_gpu and sw.cx is not None:
         sw.close()

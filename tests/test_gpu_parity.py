@@ -1847,6 +1847,30 @@ def test_peer_mapped_exchange_between_two_processes_on_the_device(gpu, tmp_path,
     assert np.array_equal(x, ref["x"][ref["anc"]])
 
 
+@pytest.mark.parametrize("world,capture", [(2, 0), (2, 1), (4, 1)])
+def test_sharded_mh_sweep_routes_inside_the_move_between_processes_on_the_device(gpu, tmp_path, world, capture):
+    """BASELINE config 3 sharded over the fused peer exchange (round 6): the MH move's program is the one that gathers, so
+    IT routes the previous step first — two routed leaves per state component (the particle and the state it was extended
+    from) — and the extension reads the moved state locally: two launches per step instead of three, no routing launch,
+    no collective.  Between PROCESSES on the box's one GPU, eagerly and as a captured graph replayed twice; equal to the
+    single-process oracle."""
+    import json
+    from tests.test_distributed_cpu import _launch
+    n_total, T = 8192, 5
+    out = str(tmp_path / "peer_mh_gpu")
+    r = _launch(world, [out, str(n_total // world), str(T), "0", "mh"],
+                extra_env={"GENMI_COMM": "peer", "GENMI_COMM_TIMEOUT": "60",
+                           "GENMI_TEST_OPTS": json.dumps({"on_gpu": 1, "capture": capture})})
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    x = np.load(out + ".npy")
+    meta = json.load(open(out + ".json"))
+    assert meta["communicator"].startswith("peer")
+    assert meta["one_launch_per_step"] is True and meta["chained_mh"] is True, meta
+    ref = parity.oracle_nlssm_mh_sweep(n_total, T, 7)
+    assert np.array_equal(x, ref["resampled"])
+    assert abs(meta["log_ml"] - sum(ref["terms"])) < 1e-9 * max(1.0, abs(sum(ref["terms"])))
+
+
 def test_rows_of_logits_at_one_categorical_site_on_device(gpu):
     """`categorical(logits [J, 3])` per particle (J draws at one site): simulate / importance / update against the oracle,
     at an interpreter size and at 2^17 particles (specialised)"""

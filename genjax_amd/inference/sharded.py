@@ -862,7 +862,8 @@ def sharded_importance_resample(target, k_per_rank: int, key: Key, dist, kind="s
     R = len(rows)
     table = torch.stack(rows) if R else torch.zeros((0, n), dtype=torch.float32, device=dev)      # [R, n]
 
-    C = max(1, min(int(capacity) if capacity else (n if W == 1 else max(4096, n // 32)), n))
+    # (ONE rank ships nothing: no send blocks to size, no overflow to ask the device about — and no host sync)
+    C = 1 if W == 1 else max(1, min(int(capacity) if capacity else max(4096, n // 32), n))
     sorted_tab = None
     while True:
         plan = torch.zeros((int(be.c.gmx_shard_plan_words(W)),), dtype=torch.int64, device=dev)
@@ -885,9 +886,10 @@ def sharded_importance_resample(target, k_per_rank: int, key: Key, dist, kind="s
             be.check(be.c.gmx_shard_step(kind, kk, be.ptr(totals_all), be.ptr(plan), be.ptr(gtotal), be.ptr(cdf), g, W,
                                          n, C, be.ptr(local_index), be.ptr(send_idx), be.ptr(next_idx), be.stream()),
                      "gmx_shard_step")
+        if W == 1:
+            break
         flag = plan[2:3].clone()
-        if W > 1:
-            comm.all_reduce_max(flag)
+        comm.all_reduce_max(flag)
         if int(flag.item()) == 0:
             break
         C = n                                                        # always sufficient

@@ -143,10 +143,11 @@ def _run_hmc(req: HMC, key, trace, argdiffs):
                     gv = gvecs[a]
                     if gv.consumed != len(gv.reads) or not gv.contribs:
                         raise NotImplementedError(
-                            f"HMC on the vector-valued site {a!r} of {gv.n} elements: the model reads its elements outside the "
-                            "loop of a vector-valued site of the same length (a static or traced index, `jnp.sum`, a plate "
-                            "over them) — the gradient of a long vector is taken through ELEMENTWISE consumers "
-                            "(`normal(theta, sigma) @ 'y'`, `normal(a * theta + b, s)`); select at most 16 elements otherwise")
+                            f"HMC on the vector-valued site {a!r} of {gv.n} elements: the model reads its elements other than "
+                            "element by element in a loop of its own length (a static or traced index, a plate over them) — "
+                            "the gradient of a long vector is taken through vector-valued sites and sums that loop over it "
+                            "(`normal(theta, sigma) @ 'y'`, `normal(a * theta + b, s)`, `jnp.sum(theta)`, `jnp.mean(theta ** 2)`); "
+                            "select at most 16 elements otherwise")
                     # the adjoint each consuming site's score reaches the model score with (1 for a plain sum of site scores)
                     adjs = grad(T.as_float(s), [Expr(sv) for sv, _ in gv.contribs])
                     tot = None

@@ -425,20 +425,58 @@ def _sum_loop(x, n):
     of 1000 elements costs two instructions per element instead of 1000 registers (ref: vmap.py:180-191 hands back plain
     stacked arrays; `jnp.sum` over them is what 3_speed_gains.ipynb c4 does)."""
     g = T.current_graph()
+    gvecs, seen_ = [], set()
+
+    def find(p_):
+        if isinstance(p_, T.GradVec):
+            if id(p_) not in seen_:
+                seen_.add(id(p_))
+                gvecs.append(p_)
+        elif isinstance(p_, T.LazyVec):
+            for q_ in p_.parts:
+                find(q_)
+    find(x)
+    probe = [len(gv.reads) for gv in gvecs]
     dt = getattr(x, "_dt", None)
     if dt is None:
         try:
             dt = T.lift(T._elem(x, 0)).dtype          # (dead code afterwards: one element's expression, never stored)
         except NotImplementedError:
             dt = "f32"
+    for gv, k_ in zip(gvecs, probe):                    # (the probe is no read of the model's)
+        del gv.reads[k_:]
     isf = dt == "f32"
     acc = g.loop_var(g.const_f32(0.0) if isf else g.const_i32(0))
+    # a long vector an HMC move differentiates with respect to (tracer.GradVec), summed: d (element t) / d v_t is stored
+    # beside the sum — this loop's contribution to the vector's gradient, scaled later by the adjoint the sum reaches the
+    # model score with (`normal(jnp.sum(theta), 1) @ "y"`, `jnp.mean(theta ** 2)`; static._vector_site_loop does the same
+    # for vector-valued sites)
+    gvecs = [gv for gv in gvecs if gv.n == n and isf and getattr(g, "_tracing", None) is not None]
+    marks = [len(gv.reads) for gv in gvecs]
+    pend = []
     g.loop_begin(n)
     t = Expr(g.add("LDT", dtype="i32"))
     v = T.lift(T._elem(x, t))
     v = T.as_float(v) if isf else T.as_int(v)
+    for gv, mark in zip(gvecs, marks):
+        mine, seen = [], set()
+        for i_, v_ in gv.reads[mark:]:
+            if isinstance(i_, Expr) and i_.node is t.node:
+                gv.consumed += 1
+                if v_.node.idx not in seen:
+                    seen.add(v_.node.idx)
+                    mine.append(v_)
+        if mine:
+            from .autodiff import grad as _grad
+            parts = _grad(v, mine)
+            tot = parts[0]
+            for pt in parts[1:]:
+                tot = tot + pt
+            pend.append((gv, g._tracing.store_step(tot, n)))
     g.set_vars([(acc, (Expr(acc) + v).node)])
     g.loop_end()
+    for gv, o_ in pend:
+        gv.contribs.append((acc, g._tracing.alias_step_input(o_, "f32", n)))
     return Expr(acc)
 
 

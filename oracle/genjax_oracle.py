@@ -80,6 +80,20 @@ _UNARY = dict(exp=0, log=1, log1p=2, sqrt=3, sin=4, cos=5, tanh=6, sigmoid=7,
 _DUAL_DIAGONAL = [False]
 
 
+def _al(v, t):
+    """a VALUE next to a tangent that carries one more (trailing) axis than it — hmc_edit's one-pass mode, after a sum
+    over the selected vector's elements: the scalar `sum(theta)` [batch] has the tangent [batch, J] — aligned for
+    broadcasting; shapes that broadcast as they are stay as they are"""
+    v = np.asarray(v)
+    try:
+        np.broadcast_shapes(v.shape, np.shape(t))
+        return v
+    except ValueError:
+        while v.ndim < np.ndim(t):
+            v = v[..., None]
+        return v
+
+
 class Dual:
     """Forward-mode dual number (value, tangent), float32: the oracle's own, independent way to get
     d assess / d choice for HMC (the product differentiates its IR in reverse mode)."""
@@ -92,16 +106,20 @@ class Dual:
     def lift(x):
         return x if isinstance(x, Dual) else Dual(x, np.zeros_like(np.asarray(x, np.float32)))
 
-    def __add__(self, o): o = Dual.lift(o); return Dual(self.v + o.v, self.t + o.t)
+    def __add__(self, o): o = Dual.lift(o); return Dual(self.v + o.v, _al(self.t, o.t) + _al(o.t, self.t))
     __radd__ = __add__
-    def __sub__(self, o): o = Dual.lift(o); return Dual(self.v - o.v, self.t - o.t)
+    def __sub__(self, o): o = Dual.lift(o); return Dual(self.v - o.v, _al(self.t, o.t) - _al(o.t, self.t))
     def __rsub__(self, o): return Dual.lift(o) - self
-    def __mul__(self, o): o = Dual.lift(o); return Dual(self.v * o.v, self.t * o.v + self.v * o.t)
+    def __mul__(self, o):
+        o = Dual.lift(o)
+        a, b = self.t * _al(o.v, self.t), _al(self.v, o.t) * o.t
+        return Dual(self.v * o.v, _al(a, b) + _al(b, a))
     __rmul__ = __mul__
     def __truediv__(self, o):
         o = Dual.lift(o)
         q = self.v / o.v
-        return Dual(q, self.t / o.v - (q * o.t) / o.v)
+        a, b = self.t / _al(o.v, self.t), (_al(q, o.t) * o.t) / _al(o.v, o.t)
+        return Dual(q, _al(a, b) - _al(b, a))
     def __rtruediv__(self, o): return Dual.lift(o) / self
     def __neg__(self): return Dual(-self.v, -self.t)
     def astype(self, dt): return self                      # already float32 on both parts
@@ -574,7 +592,14 @@ class _Normal(Distribution):
         val = self.estimate_logpdf(x.v, (m.v, s.v), batch_shape)
         z = (x.v / s.v - m.v / s.v).astype(np.float32)
         zs = (z / s.v).astype(np.float32)
-        t = (-(zs * x.t) + zs * m.t + ((z * z - np.float32(1.0)) / s.v) * s.t).astype(np.float32)
+        ds = ((z * z - np.float32(1.0)) / s.v).astype(np.float32)
+        if _DUAL_DIAGONAL[0]:
+            # (one-pass mode: a tangent may carry the selected vector's element axis where the value does not — a SCALAR
+            #  site whose parameter is `sum(theta)`: element j of its tangent is d score / d theta_j)
+            nd = max(np.ndim(x.t), np.ndim(m.t), np.ndim(s.t))
+            if nd > np.ndim(zs):
+                zs, ds = zs[..., None], ds[..., None]
+        t = (-(zs * x.t) + zs * m.t + ds * s.t).astype(np.float32)
         if np.ndim(t) > np.ndim(val) and _DUAL_DIAGONAL[0]:
             return Dual(val, t)          # (hmc_edit's one-pass gradient of a long vector: element j's own tangent, not their sum)
         if np.ndim(t) > np.ndim(val):
@@ -938,7 +963,7 @@ class _Assess(_Handler):
             self._tans = getattr(self, "_tans", []) + [score.t]
             acc = self._tans[-1]
             for t_ in reversed(self._tans[:-1]):
-                acc = (acc + t_).astype(np.float32)
+                acc = (_al(acc, t_) + _al(t_, acc)).astype(np.float32)
             self.score = Dual((old.v + score.v).astype(np.float32), acc)
             return v
         self.score = (self.score + score).astype(np.float32)
@@ -1114,7 +1139,14 @@ def plate_sum_tree(x):
 
 def sum_vector(x):
     """`jnp.sum` of a concrete float vector as the build defines it (genjax_amd/numpy.py::sum): element order below
-    Vmap.LAUNCH_MIN items, the plate score's fixed tree from there on"""
+    Vmap.LAUNCH_MIN items, the plate score's fixed tree from there on.  A Dual (hmc_edit's forward mode): the tangents
+    are added in the same order — or, in the one-pass mode for long vectors (_DUAL_DIAGONAL), kept per element:
+    d sum / d v_j = the j-th tangent."""
+    if isinstance(x, Dual):
+        val = sum_vector(x.v)
+        if _DUAL_DIAGONAL[0]:
+            return Dual(val, np.broadcast_to(x.t, x.v.shape))
+        return Dual(val, sum_vector(np.broadcast_to(x.t, x.v.shape)))
     x = np.asarray(x, np.float32)
     if x.shape[-1] >= 4096:
         return plate_sum_tree(x)

@@ -937,6 +937,26 @@ class StepInput(np.ndarray):
             for pos in np.ndindex(idx.shape):
                 out[pos] = self[idx[pos]]
             return out
+        if self._slot is not None and self.ndim == 1 and not isinstance(self._slot, list) \
+                and not isinstance(idx, (Expr, slice, int, np.integer, tuple)) and idx is not Ellipsis:
+            from . import tracer as Tm
+            n_i = Tm._long_vector(idx)
+            kind = getattr(getattr(idx, "dtype", None), "kind", "")
+            if n_i and (kind in "iu" or getattr(idx, "_dt", None) == "i32") and not GATHER_LAZY_OFF[0]:
+                # `theta[group]` with `group` a LONG vector of indices readable at a run-time position (a table of group
+                # labels, a per-particle assignment vector): a recipe — element i is ONE load of `group` and ONE
+                # register-indexed load of this leaf (GMX_F_IDX) inside the consuming site's loop — instead of one
+                # unrolled read per index (a hierarchical model's `normal(theta[group], s) @ "y"` over thousands of rows)
+                src = self
+
+                def elem(i):
+                    j = Tm._elem(idx, i)
+                    if isinstance(j, (int, np.integer)):
+                        return np.ndarray.__getitem__(src, int(j))
+                    return src._read_at(j)
+                out = Tm.LazyVec(n_i, elem, parts=(self, idx))
+                out._dt = self._dt
+                return out
         if isinstance(idx, Expr) and self._slot is not None:
             if self.ndim == 1 and not isinstance(self._slot, list):
                 if idx.node.op != "LDT":
@@ -962,6 +982,9 @@ class StepInput(np.ndarray):
             elif idx.indices(self.shape[0]) != (0, self.shape[0], 1):
                 return np.asarray(r, dtype=object)
         return r
+
+
+GATHER_LAZY_OFF = [0]       # (tests: the unrolled form of `leaf[index_vector]`, to hold the lazy one against)
 
 
 class StepAlias(StepInput):

@@ -141,7 +141,7 @@ def _run_hmc(req: HMC, key, trace, argdiffs):
                 out, k = {}, 0
                 for a in long_addrs:
                     gv = gvecs[a]
-                    if gv.consumed != len(gv.reads) or not gv.contribs:
+                    if gv.consumed != len(gv.reads) or gv.gathers_consumed != len(gv.gathers) or not gv.contribs:
                         raise NotImplementedError(
                             f"HMC on the vector-valued site {a!r} of {gv.n} elements: the model reads its elements other than "
                             "element by element in a loop of its own length (a static or traced index, a plate over them) — "

@@ -1150,7 +1150,8 @@ def _vector_site_loop(ctx, mode, dist, key, args, cval, prev, req):
     # element j of one more output, the site's contribution to the vector's gradient
     gvecs = list(getattr(ctx, "grad_vecs", None) or ())
     marks = [len(gv.reads) for gv in gvecs]
-    vec_origins = []
+    gmarks = [len(gv.gathers) for gv in gvecs]
+    vec_origins, gather_origins = [], []
     g.loop_begin(n)
     with T.tracing(g):
         t = Expr(g.add("LDT", dtype="i32"))
@@ -1193,10 +1194,28 @@ def _vector_site_loop(ctx, mode, dist, key, args, cval, prev, req):
                 for pt in parts[1:]:
                     tot = tot + pt
                 vec_origins.append((gvec, tr.store_step(tot, n)))
+        for gvec, gmark in zip(gvecs, gmarks):
+            # GATHERED reads (`theta[group]`: element t of this site reads theta at group[t]): d s_t / d (that value), stored
+            # per ITERATION; the sums per group follow the loop (_scatter_add)
+            by_idx = {}
+            for i_, j_, v_, idxv in gvec.gathers[gmark:]:
+                if isinstance(i_, Expr) and i_.node is t.node:
+                    gvec.gathers_consumed += 1
+                    by_idx.setdefault(id(idxv), (idxv, []))[1].append(v_)
+            for idxv, vals in by_idx.values():
+                from .autodiff import grad as _grad
+                uniq = list({v_.node.idx: v_ for v_ in vals}.values())
+                parts = _grad(s_t, uniq)
+                tot = parts[0]
+                for pt in parts[1:]:
+                    tot = tot + pt
+                gather_origins.append((gvec, tr.store_step(tot, n), idxv))
         g.set_vars(updates)
     g.loop_end()
     for gvec, o_ in vec_origins:
         gvec.contribs.append((svar, tr.alias_step_input(o_, "f32", n)))
+    for gvec, o_, idxv in gather_origins:
+        gvec.contribs.append((svar, _scatter_add(tr, tr.alias_step_input(o_, "f32", n), idxv, n, gvec.n)))
     if used:
         g.__dict__.setdefault("_custom_grads", {})[svar.idx] = used
     score = Expr(svar)
@@ -1223,6 +1242,27 @@ def _vector_site_loop(ctx, mode, dist, key, args, cval, prev, req):
         return _SiteRec(dist, given(prev["value"]), score), pv, score - ps, score
     ctx.mark_changed(cv)
     return _SiteRec(dist, given(cval), score, discard=given(prev["value"])), cv, score - ps, score      # (:235-242)
+
+
+def _scatter_add(tr, D, idxv, N, J):
+    """G[j] = sum over i of D[i] where idxv[i] == j, i in element order — the adjoint of the gather `v[idxv]` (HMC on a long
+    vector read at a table of group indices): two counted loops, J x N compares per particle and pass; every value is
+    read at a register index, the sums land in one more [J, n] output of the launch, read back like any other."""
+    g = tr.graph
+    zero = g.const_f32(0.0)
+    g.loop_begin(J)
+    with T.tracing(g):
+        tj = Expr(g.add("LDT", dtype="i32")) + 0           # (a register of its own: the inner loop's LDT is another node)
+        acc = g.loop_var(zero)
+        g.loop_begin(N)
+        ti = Expr(g.add("LDT", dtype="i32"))
+        ji = T.as_int(T._elem(idxv, ti))
+        di = D._read_at(ti)
+        g.set_vars([(acc, (Expr(acc) + T.where(ji == tj, di, 0.0)).node)])
+        g.loop_end()
+        o = tr.store_step(Expr(acc) + 0.0, J)
+    g.loop_end()
+    return tr.alias_step_input(o, "f32", J)
 
 
 def _rec_choices(rec) -> ChoiceMap:

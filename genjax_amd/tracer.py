@@ -221,11 +221,32 @@ class GradVec(LazyVec):
         self.reads = []            # (index, the element's Expr)
         self.consumed = 0
         self.contribs = []         # (the consuming site's loop-carried score variable, its stored d term_j / d v_j)
+        self.gathers = []          # (loop index, gathered index, the element's Expr, the index vector): `v[group]` reads
+        self.gathers_consumed = 0
 
     def at(self, i):
         v = as_float(_elem(self.src, i))
         self.reads.append((i, v))
         return v
+
+    def __getitem__(self, idx):
+        # `theta[group]` with `group` a long vector of indices (a table of group labels): element i of the result is
+        # theta at group[i] — a GATHER: the consuming site's loop stores d term_i / d (the gathered value) and a second
+        # pair of loops adds them up per group, j by j (static._scatter_add): the adjoint of a gather is a scatter-add
+        n_i = _long_vector(idx)
+        kind = getattr(getattr(idx, "dtype", None), "kind", "")
+        if n_i and (kind in "iu" or getattr(idx, "_dt", None) == "i32"):
+            gv = self
+
+            def elem(i):
+                j = _elem(idx, i)
+                v = as_float(_elem(gv.src, int(j) if isinstance(j, (int, np.integer)) else j))
+                gv.gathers.append((i, j, v, idx))
+                return v
+            out = LazyVec(n_i, elem, parts=(self, idx))
+            out._dt = "f32"
+            return out
+        return LazyVec.__getitem__(self, idx)
 
     def materialize(self):
         out = np.empty((self.n,), dtype=object)

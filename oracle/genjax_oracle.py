@@ -122,6 +122,7 @@ class Dual:
         return Dual(q, _al(a, b) - _al(b, a))
     def __rtruediv__(self, o): return Dual.lift(o) / self
     def __neg__(self): return Dual(-self.v, -self.t)
+    def __getitem__(self, idx): return Dual(self.v[idx], np.broadcast_to(self.t, self.v.shape)[idx])    # (a gather: `theta[..., group]`)
     def astype(self, dt): return self                      # already float32 on both parts
     @property
     def shape(self): return self.v.shape

@@ -484,8 +484,9 @@ def check_hmc_through_long_vector_sites(npts=500, J=200, K=7, L=3, seed=1):
     derivative of a loop-carried sum); the oracle differentiates in forward mode (Dual numbers) and adds a vector site's
     tangents in element order — the new values and the weight agree BIT FOR BIT.  `Regenerate(S["theta"])` ON the long site
     runs as a counted loop as well, and so does `HMC(S["theta"])` ON the long site — alone and together with the scalars; a
-    latent vector read through elementwise arithmetic by two later sites, and through `jnp.sum` / `jnp.mean`; ONE trace.  A
-    long vector read at ONE index is refused, naming the site."""
+    latent vector read through elementwise arithmetic by two later sites, through `jnp.sum` / `jnp.mean`, and GATHERED at a
+    table of group indices (`theta[group]`: a random-effects likelihood); ONE trace.  A long vector read at ONE index is
+    refused, naming the site."""
     import genjax_amd as G
     from genjax_amd import ChoiceMapBuilder as C, Diff, Regenerate, SelectionBuilder as S
     from genjax_amd import numpy as jnp
@@ -648,6 +649,34 @@ def check_hmc_through_long_vector_sites(npts=500, J=200, K=7, L=3, seed=1):
     onew, ow = O.hmc_edit(O.split(O.key(seed + 13), K), otr5, ["theta"], 1e-2, L, ())
     assert np.allclose(npv(new.get_choices()["theta"]), onew.get_choices()["theta"], rtol=1e-6, atol=1e-6)
     assert np.allclose(npv(w), ow, rtol=1e-4, atol=1e-5)
+    # a random-effects likelihood: `normal(theta[group] + x, 0.5) @ "y"` with `group` a table of N = 5 J group labels — the
+    # gather's adjoint is a scatter-add (static._scatter_add: the consuming loop stores d term_i, two more loops add them up
+    # per group); the oracle differentiates element by element (its one-pass mode does not cover gathers)
+    if J > 200:          # (J x N compares per particle and pass, and J forward passes of the oracle per gradient)
+        return
+    Ng = 5 * J if J <= 40 else 2 * J
+    rng = np.random.default_rng(seed + 20)
+    grp = rng.integers(0, J, Ng).astype(np.int32)
+    xg = rng.normal(size=Ng).astype(f32)
+
+    @G.gen
+    def grouped():
+        theta = G.normal(jnp.zeros(J), 2.0 * jnp.ones(J)) @ "theta"
+        G.normal(theta[jnp.array(grp)] + jnp.array(xg), 0.5) @ "y"
+        return None
+
+    @O.gen
+    def ogrouped():
+        theta = O.normal(np.zeros(J, f32), f32(2.0) * np.ones(J, f32)) @ "theta"
+        O.normal(theta[..., grp] + xg, f32(0.5)) @ "y"
+        return None
+    yg = rng.normal(size=Ng).astype(f32)
+    Kg = min(K, 5)
+    tr6, _ = grouped.importance(G.split(G.key(seed + 14), Kg), C["y"].set(jnp.array(yg)), ())
+    otr6, _ = ogrouped.importance(O.split(O.key(seed + 14), Kg), O.C.d({"y": yg}), ())
+    new, w, _, _ = HMC(S["theta"], 1e-3, L=L).edit(G.split(G.key(seed + 15), Kg), tr6, Diff.no_change(()))
+    onew, ow = O.hmc_edit(O.split(O.key(seed + 15), Kg), otr6, ["theta"], 1e-3, L, (), one_hot_max=10 ** 9)
+    assert same(new.get_choices()["theta"], onew.get_choices()["theta"]) and same(w, ow) and same(new.get_score(), onew.get_score()), "gather"
     # what stays refused: one element picked out of the vector (a static or a traced index)
     @G.gen
     def picked():

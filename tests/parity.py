@@ -1132,6 +1132,59 @@ def check_direct_plate_of_scans_random(seed):
     return J, T, n
 
 
+def check_gather_at_group_indices(J=40, N=300, K=9, seed=3):
+    """A hierarchical model's `normal(theta[group], s) @ "y"` — `theta` a latent vector of J group effects (a long
+    vector-valued site: its values live in memory), `group` a table of N group labels: the gather is a RECIPE (element i =
+    one load of `group`, one register-indexed load of theta: engine.StepInput.__getitem__) evaluated inside y's counted
+    loop, not N unrolled reads — simulate / importance / assess / update of theta against the oracle, and against the
+    unrolled form of the same program (engine.GATHER_LAZY_OFF), bit for bit."""
+    import genjax_amd as G
+    from genjax_amd import ChoiceMapBuilder as C, Diff, Update, engine, numpy as jnp
+    f32 = np.float32
+    rng = np.random.default_rng(seed)
+    grp = rng.integers(0, J, N).astype(np.int32)
+    xs = rng.normal(size=N).astype(f32)
+
+    @G.gen
+    def m(a):
+        theta = G.normal(a * jnp.ones(J), 2.0 * jnp.ones(J)) @ "theta"
+        G.normal(theta[jnp.array(grp)] + jnp.array(xs), 0.5) @ "y"
+        return jnp.sum(theta)
+
+    @O.gen
+    def om(a):
+        theta = O.normal(np.asarray(a, f32)[..., None] * np.ones(J, f32), f32(2.0) * np.ones(J, f32)) @ "theta"
+        O.normal((theta[..., grp] + xs).astype(f32), f32(0.5)) @ "y"
+        return O.sum_vector(theta)
+    dev = G._lib.get().device
+    a_h = rng.normal(size=K).astype(f32)
+    args, oargs = (torch.from_numpy(a_h).to(dev),), (a_h,)
+    k, ok = G.split(G.key(seed), K), O.split(O.key(seed), K)
+    tr, otr = m.simulate(k, args), om.simulate(ok, oargs)
+    for ad in ("theta", "y"):
+        assert np.array_equal(_np(tr.get_choices()[ad]), otr.get_choices()[ad]), ("simulate", ad)
+    assert np.array_equal(_np(tr.get_score()), otr.get_score()) and np.array_equal(_np(tr.get_retval()), otr.get_retval())
+    yobs = rng.normal(size=N).astype(f32)
+    tr2, w2 = m.importance(k, C["y"].set(jnp.array(yobs)), args)
+    otr2, ow2 = om.importance(ok, O.C.d({"y": yobs}), oargs)
+    assert np.array_equal(_np(w2), ow2), "importance weight"
+    s, _ = m.assess(tr2.get_choices(), args)
+    assert np.array_equal(_np(s), _np(tr2.get_score()))
+    th_new = rng.normal(size=(K, J)).astype(f32)
+    k2, ok2 = G.split(G.key(seed + 1), K), O.split(O.key(seed + 1), K)
+    tr3, w3, _, _ = Update(C["theta"].set(torch.from_numpy(th_new).to(dev))).edit(k2, tr2, Diff.no_change(args))
+    otr3, ow3, _ = om.update(ok2, otr2, O.C.d({"theta": th_new}), oargs)
+    assert np.array_equal(_np(w3), ow3) and np.array_equal(_np(tr3.get_score()), otr3.get_score()), "update of the group effects"
+    G.clear_caches()
+    engine.GATHER_LAZY_OFF[0] = 1
+    try:
+        tr_u = m.simulate(k, args)
+    finally:
+        engine.GATHER_LAZY_OFF[0] = 0
+        G.clear_caches()
+    assert np.array_equal(_np(tr_u.get_choices()["y"]), _np(tr.get_choices()["y"])) and np.array_equal(_np(tr_u.get_score()), _np(tr.get_score()))
+
+
 def check_nested_marginal(k=129, seed=5):
     """A12 / F4: ChangeTarget.run_csmc_for_normalizing_constant (ref smc.py:432-465),
     estimate_reciprocal_normalizing_constant (:214-225) and Marginal.random_weighted with an inner algorithm

@@ -1901,6 +1901,12 @@ def test_changed_per_particle_vector_argument_on_device(gpu):
     parity.check_changed_per_particle_vector_argument(B=1 << 17, N=20, seed=15)
 
 
+def test_gather_of_a_latent_vector_at_a_table_of_group_indices_on_device(gpu):
+    """as tests/test_host_logic.py: interpreter size and 2^17 particles (specialised)"""
+    parity.check_gather_at_group_indices()
+    parity.check_gather_at_group_indices(J=24, N=200, K=1 << 17, seed=5)
+
+
 def test_gather_by_index_vector_on_device(gpu):
     """`normal(means[zs] + s, 1)` with the assignments given as a table or one vector per particle: importance and update
     under changed assignments against the oracle"""

@@ -1187,6 +1187,15 @@ def test_nested_index_request_on_a_plate_of_long_scans_is_o1():
     parity.check_scan_of_plates_index_request_o1(n=5, T=70, P=20, seed=8, edits=40)
 
 
+def test_gather_of_a_latent_vector_at_a_table_of_group_indices():
+    """`normal(theta[group], s) @ "y"`: the gather of a latent vector (values in memory) at a long table of indices is a
+    recipe evaluated in the consuming site's loop (engine.StepInput.__getitem__) — against the oracle and against the
+    unrolled form, J = 40 x N = 300 and J = 200 x N = 5 000"""
+    from tests import parity
+    parity.check_gather_at_group_indices()
+    parity.check_gather_at_group_indices(J=200, N=5000, K=4, seed=8)
+
+
 def test_empty_and_single_particle_batches():
     """jax.vmap over zero keys gives empty arrays, not an error; one particle is just a batch of one"""
     @genjax.gen

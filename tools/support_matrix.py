@@ -118,6 +118,20 @@ def forms():
             return mu
         return dict(model=m, args=lambda k: (k_float(k),), obs=C["y"].set(jnp.array(sig)), upd=C["mu"].set(0.3), sel="theta")
 
+    def gathered(n):
+        """random effects: n group effects, 5 n observations each reading its group's effect"""
+        N_ = 5 * n
+        grp = (np.arange(N_) * 7 % n).astype(np.int32)
+
+        @G.gen
+        def m(a):
+            mu = G.normal(a, 5.0) @ "mu"
+            th = G.normal(mu * jnp.ones(n), 2.0 * jnp.ones(n)) @ "theta"
+            G.normal(th[jnp.array(grp)], 0.5) @ "y"
+            return mu
+        return dict(model=m, args=lambda k: (k_float(k),), obs=C["y"].set(jnp.array(np.zeros(N_, np.float32))), upd=C["mu"].set(0.3),
+                    sel="theta")
+
     def plate(n):
         xs = np.linspace(-1, 1, n).astype(np.float32)
 
@@ -258,6 +272,7 @@ def forms():
         ("scalar sites", scalar, [1]),
         ("vector-valued site `normal(s * xs, 0.5)`", vector_site, [8, 500, 5000]),
         ("latent vector feeding the next vector site (8-schools at J)", latent_vector, [8, 40, 1000]),
+        ("latent vector gathered at a table of group indices, `normal(theta[group], 0.5) @ \"y\"` (5 observations per group)", gathered, [8, 40, 200]),
         ("plate of a `@gen` element (`elem.vmap()`)", plate, [8, 100, 5000]),
         ("bare plate `normal.vmap()`, values used: `jnp.sum(vs)`, `vs[1]`", bare_plate_used, [8, 100, 5000]),
         ("`repeat` of clusters read at a traced index `means[z]`", plate_traced_index, [8, 40]),

@@ -278,9 +278,30 @@ def vector_site_update(dist, key, prev, req, args, changed, n):
             w = elementwise(lambda a_, b_: a_ - b_, materialize(new.get_score()), materialize(prev.get_score()))
             return new, w, Update(ChoiceMap.choice(prev.value))
         req = Update(ChoiceMap.empty())
+    from .static import Rejuvenate as _Rejuvenate
+    if isinstance(req, _Rejuvenate):
+        # Rejuvenate.edit (rejuvenate.py:70-94), literally, on the launch axis: key, sub_key = split(key); the proposal
+        # simulated from sub_key at the arguments the mapping builds from the OLD value (a vector-valued site itself: its n
+        # draws and their densities are one launch), Update(proposed) on this site, the proposal assessed at the old value;
+        # weight = (w + bwd) - fwd
+        from .distributions import Distribution as _Dist
+        from .engine import elementwise, materialize
+        from .random import split as _split
+        if not isinstance(req.proposal, _Dist):
+            raise NotImplementedError(f"Rejuvenate on a {n}-element site of one trace: the proposal must be a distribution")
+        old = ChoiceMap.choice(prev.value)
+        margs = req.argument_mapping(old)
+        margs = margs if isinstance(margs, tuple) else (margs,)
+        sub = _split(key)[1]
+        prop, = vector_site(req.proposal, "simulate", sub, margs, None, n)
+        fwd = materialize(prop.get_score())
+        new, w, _ = vector_site_update(dist, key, prev, Update(ChoiceMap.choice(prop.value)), args, changed, n)
+        bwd, _v = vector_site(req.proposal, "assess", None, margs, old, n)
+        final = elementwise(lambda w_, b_, f_: (w_ + b_) - f_, materialize(w), materialize(bwd), fwd)
+        return new, final, req
     if not isinstance(req, Update):
-        raise NotImplementedError(f"{type(req).__name__} on a {n}-element site of one trace (Update / Regenerate; write "
-                                  "the plate with vmap for per-element requests)")
+        raise NotImplementedError(f"{type(req).__name__} on a {n}-element site of one trace (Update / Regenerate / Rejuvenate; "
+                                  "write the plate with vmap for per-element requests)")
     dev = _lib.get().device
     pos, kw = (args[0], dict(args[1])) if len(args) == 2 and isinstance(args[1], dict) and isinstance(args[0], tuple) else (args, {})
     kw.pop("sample_shape", None)

@@ -606,6 +606,11 @@ def check_hmc_through_long_vector_sites(npts=500, J=200, K=7, L=3, seed=1):
     new, w, _, _ = HMC(S["theta"], 1e-2, L=L).edit(G.key(seed + 8), tr1, Diff.no_change(()))
     onew, ow = O.hmc_edit(O.key(seed + 8), otr1, ["theta"], 1e-2, L, ())
     assert same(new.get_choices()["theta"], onew.get_choices()["theta"]) and same(w, ow)
+    # ... Rejuvenate on the long site of ONE trace (site by site from 65 elements: the proposal's draws and densities on the
+    # launch axis — sitewise.vector_site_update)
+    new, wj, _, _ = rq.edit(G.key(seed + 16), tr1, Diff.no_change(()))
+    onew, owj = oschools.edit_static(O.key(seed + 16), otr1, orq, ())
+    assert same(new.get_choices()["theta"], onew.get_choices()["theta"]) and same(wj, owj) and same(new.get_score(), onew.get_score())
     # the latent vector read through SUMS as well (`normal(jnp.sum(theta), 3)`, `normal(jnp.mean(theta * theta), 0.5)`): the
     # sum's own loop stores d element / d theta_j, scaled afterwards by the adjoint the sum reaches the score with
     @G.gen

@@ -15,7 +15,7 @@ from .core.mask import Indexed, Mask
 from .core.choice_map import DynamicIndex, dynamic_index
 from .core.pytree import Closure, Const, PythonicPytree, Pytree, R, nth
 from .distributions import (Distribution, bernoulli, beta, categorical, dirichlet, exact_density, flip, half_cauchy,
-                            half_normal, log_normal, normal, tfp_distribution, uniform)
+                            exponential, half_normal, log_normal, normal, tfp_distribution, uniform)
 from .static import (AddressReuse, MissingAddress, Rejuvenate, StaticGenerativeFunction, StaticRequest,
                      StaticTrace, gen, trace)
 from . import inference
@@ -45,6 +45,6 @@ __all__ = [
     "vmap", "key", "split", "fold_in", "NotSupportedEditRequest", "Vmap", "repeat", "RepeatCombinator", "Scan", "scan", "IndexRequest",
     "VectorRequest", "Argdiffs", "Arguments", "Retdiff", "Score", "Weight", "Address", "AddressComponent", "R",
     "Closure", "Const", "PythonicPytree", "Pytree", "nth", "exact_density", "tfp_distribution", "half_cauchy",
-    "half_normal", "log_normal", "Algorithm", "SampleDistribution", "Marginal", "marginal", "trace_p", "clear_caches",
+    "half_normal", "log_normal", "exponential", "Algorithm", "SampleDistribution", "Marginal", "marginal", "trace_p", "clear_caches",
     "iterate", "iterate_final", "accumulate", "reduce", "mask", "MaskCombinator", "masked_iterate", "masked_iterate_final", "Indexed", "DynamicIndex", "dynamic_index",
 ]

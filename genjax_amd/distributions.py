@@ -498,6 +498,31 @@ class _HalfNormal(Distribution):
         return _seq_sum(terms)
 
 
+class _Exponential(Distribution):
+    """tfd.Exponential(rate) (tensorflow_probability/__init__.py:150): -log(U) / rate with U uniform on [tiny, 1) — TFP's
+    sampler (exponential.py `_sample_n`) — and log_prob(x) = log rate - rate x for x >= 0.  Built from the uniform sampler and
+    elementary functions (no kernel op of its own), like log_normal / half_normal."""
+    name = "exponential"
+    param_names = ("rate",)
+    TINY = float(np.finfo(np.float32).tiny)
+
+    def sym_sample(self, key: Expr, args: tuple):
+        from . import numpy as jnp
+        rate = args[0]
+        lo = np.full(rate.shape, self.TINY, dtype=object) if isinstance(rate, np.ndarray) else self.TINY
+        u = uniform.sym_sample(key, (lo, 1.0))
+        return -jnp.log(u) / rate
+
+    def sym_logpdf(self, v, args: tuple) -> Expr:
+        from . import numpy as jnp
+        elems, _ = _bcast((v, args[0]))
+        terms = []
+        for x, rate in elems:
+            x, rate = T.as_float(x), T.as_float(rate)
+            terms.append(T.where(x < 0.0, float("-inf"), jnp.log(rate) - rate * x))
+        return _seq_sum(terms)
+
+
 class _Dirichlet(Distribution):
     """Dirichlet(concentration) over the LAST axis (tfp/__init__.py:125).  TFP draws log-space Gammas and
     normalises: x = exp(lg - logsumexp(lg)); log_prob = sum xlogy(a - 1, x) - lbeta(a).  The Gamma
@@ -575,4 +600,5 @@ categorical = _Categorical()
 dirichlet = _Dirichlet()
 log_normal = _LogNormal()
 half_normal = _HalfNormal()
+exponential = _Exponential()
 half_cauchy = _HalfCauchy()

@@ -1196,6 +1196,30 @@ def test_gather_of_a_latent_vector_at_a_table_of_group_indices():
     parity.check_gather_at_group_indices(J=200, N=5000, K=4, seed=8)
 
 
+def test_exponential_is_tfd_exponential():
+    """ref tensorflow_probability/__init__.py:150 `exponential = tfp_distribution(tfd.Exponential)` (choice_maps.ipynb c18):
+    -log(U) / rate with U on [tiny, 1) and log rate - rate x — the law against scipy (KS), the density to 2e-6, a rate that is
+    itself a latent"""
+    from scipy import stats
+    import genjax_amd as G
+
+    @G.gen
+    def m(r):
+        x = G.exponential(r) @ "x"
+        G.exponential(x + 0.5) @ "y"
+        return x
+    n = 100_000
+    tr = m.simulate(G.split(G.key(1), n), (2.0,))
+    x = tr.get_choices()["x"].cpu().numpy().astype(np.float64)
+    y = tr.get_choices()["y"].cpu().numpy().astype(np.float64)
+    assert stats.kstest(x, "expon", args=(0, 0.5)).pvalue > 1e-3 and (x > 0).all()
+    s, _ = m.assess(tr.get_choices(), (2.0,))
+    want = stats.expon.logpdf(x, scale=0.5) + stats.expon.logpdf(y, scale=1 / (x + 0.5))
+    assert np.abs(s.cpu().numpy() - want).max() < 2e-5 * np.abs(want).max()
+    w = G.exponential.assess(G.ChoiceMap.choice(-1.0), (2.0,))[0]
+    assert float(w) == float("-inf")
+
+
 def test_empty_and_single_particle_batches():
     """jax.vmap over zero keys gives empty arrays, not an error; one particle is just a batch of one"""
     @genjax.gen

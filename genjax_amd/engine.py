@@ -247,6 +247,25 @@ class Expanded(torch.Tensor):
             return func(*args, **(kwargs or {}))
 
 
+_UNIFORM_DEV = {}
+
+
+def _uniform_on_device(a: np.ndarray) -> torch.Tensor:
+    """a small launch-uniform host value on the device, copied ONCE per content: `get_choices()` of a batched trace shows
+    its launch-uniform constraints (the observations) with the batch axis, and a host-to-device copy from pageable memory
+    waits for the stream — four of them per run were 0.1 ms of BASELINE config 4's 0.87 (round 6)"""
+    dev = _lib.get().device
+    if a.size > 4096:
+        return torch.from_numpy(a).to(dev)
+    k = (str(dev), a.dtype.str, a.shape, a.tobytes())
+    t = _UNIFORM_DEV.get(k)
+    if t is None:
+        if len(_UNIFORM_DEV) >= 512:
+            _UNIFORM_DEV.clear()
+        t = _UNIFORM_DEV[k] = torch.from_numpy(a.copy()).to(dev)
+    return t
+
+
 def expand_over_batch(v, batch: tuple):
     """a launch-uniform value as a batched trace's leaf (Expanded), or v itself when it carries the batch already"""
     if not batch or v is None or isinstance(v, (Expanded, Gathered, Patched, PlateScore, Deferred)):
@@ -259,11 +278,11 @@ def expand_over_batch(v, batch: tuple):
             return v
     elif isinstance(v, (bool, int, float, np.bool_, np.integer, np.floating)):
         dt = torch.bool if isinstance(v, (bool, np.bool_)) else (torch.int32 if isinstance(v, (int, np.integer)) else torch.float32)
-        t = torch.tensor(v, dtype=dt, device=_lib.get().device)
+        t = _uniform_on_device(np.asarray(v, dtype={torch.bool: np.bool_, torch.int32: np.int32, torch.float32: np.float32}[dt]))
     elif isinstance(v, np.ndarray) and v.dtype != object:
         a = np.ascontiguousarray(v)
         a = a.astype(np.float32) if a.dtype.kind == "f" else (a.astype(np.int32) if a.dtype.kind in "iu" else a)
-        t = torch.from_numpy(a).to(_lib.get().device)
+        t = _uniform_on_device(a)
     else:
         return v
     # (inside a plate / scan the batch of a site's trace holds the plate axes too, and a launch-uniform table given for the
@@ -272,7 +291,8 @@ def expand_over_batch(v, batch: tuple):
     m = min(nb, t.ndim)
     while m > 0 and tuple(batch[nb - m:]) != tuple(t.shape[:m]):
         m -= 1
-    return Expanded(t.expand(tuple(batch[:nb - m]) + tuple(t.shape)), v)
+    lead = tuple(batch[:nb - m])
+    return Expanded(t.expand(lead + tuple(t.shape)) if lead else t.clone(), v)      # (never the cached copy itself)
 
 
 def materialize(v):
@@ -397,6 +417,7 @@ def clear_caches():
     for c in _ALL_CACHES:
         c.clear()
     _STATIC_KEEP.clear()
+    _UNIFORM_DEV.clear()
 
 
 _STATIC_KEEP: dict = {}

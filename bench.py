@@ -499,8 +499,8 @@ def other_configs():
             engine.clear_caches()                    # ... every one of them created inside the block, as in a fresh process
             w4 = config_workload(4)
             alg, box, k = w4["alg"], w4["box"], w4["k"]
-            dt = timed(w4["run"], 3)
-        dti = timed(lambda: alg.run_smc(G.key(2)), 3)
+            dt = timed(w4["run"], 10)          # (ten back-to-back runs: three of them were mostly pipeline fill and drain)
+        dti = timed(lambda: alg.run_smc(G.key(2)), 10)
         out["config4"] = {"workload": "8-schools ImportanceK k = 1e7 + one systematic resample + gather of theta",
                           "ms_total": 1e3 * dt, "ms_importance": 1e3 * dti, "particles_per_s": k / dt,
                           "algorithmic_bytes_per_particle": {"importance": 48, "resample_and_gather": 104},
@@ -694,13 +694,13 @@ def other_configs_sharded(dist, world, rank, cx, be):
             c = alg.run_smc(G.key(2))
             r = smc.resample(G.split(G.key(2))[0], c, "systematic")
             box["theta1"] = r.get_particles().get_choices()["theta"]
-        dt1 = timed(run1, 3)
+        dt1 = timed(run1, 8)
         stats = {}
 
         def runN():
             coll, _lw = sharded_importance_resample(tgt, kr, G.key(2), dist, comm=cx, stats=stats)
             box["thetaN"] = coll.get_particles().get_choices()["theta"]
-        dtN = timed(runN, 3)
+        dtN = timed(runN, 8)
         same = bool(torch.equal(box["thetaN"], box["theta1"][rank * kr:(rank + 1) * kr]))
         out["config4"] = {"workload": f"8-schools ImportanceK k = {k} + one global systematic resample of the 10-latent trace",
                           "sharded_ms": 1e3 * dtN, "single_gpu_ms": 1e3 * dt1, "strong_scaling_speedup": dt1 / dtN,

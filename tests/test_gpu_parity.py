@@ -2035,6 +2035,24 @@ def test_nested_index_request_on_a_plate_of_long_scans_is_o1_on_device(gpu):
     assert out_pp["same_weights_scores_values"] and out_pp["speedup"] >= 5.0, out_pp
 
 
+def test_hmc_programs_over_long_vector_sites_as_specialised_kernels(gpu):
+    """the HMC / Regenerate / Rejuvenate programs of tests/cookbook.py — loops, per-element gradient contributions, sums, the
+    gather's scatter-add, ONE trace — with EVERY program sent through hiprtc (engine.JIT_MIN_PARTICLES = 1) at J = 40:
+    specialised kernels against the oracle, each also held to the interpreter by the first-launch cross-check"""
+    from genjax_amd import engine
+    from tests import cookbook
+    old = engine.JIT_MIN_PARTICLES
+    before = int(gpu.c.gmx_jit_rejected_count())
+    engine.JIT_MIN_PARTICLES = 1
+    try:
+        engine.clear_caches()
+        cookbook.check_hmc_through_long_vector_sites(npts=100, J=40)
+    finally:
+        engine.JIT_MIN_PARTICLES = old
+        engine.clear_caches()
+    assert int(gpu.c.gmx_jit_rejected_count()) == before
+
+
 def test_long_vector_valued_sites_on_device(gpu):
     """ref tensorflow_probability/__init__.py:52-62 + distribution.py:383-396: `normal(a * xs + b, sigma) @ "y"` with 40 /
     500 / 5 000 observations under a particle batch as ONE counted loop per particle — interpreter (few particles) and

@@ -716,28 +716,28 @@ def test_large_plate_of_a_small_particle_batch_is_deferred():
 
 
 def test_random_models_match_the_oracle():
-    """tests/fuzz_models.py: 200 random `@gen` models (leaf sites, plates, scans, masked calls and plates, plates of
+    """tests/fuzz_models.py: 130 random `@gen` models (leaf sites, plates, scans, masked calls and plates, plates of
     scans, scans of plates; unrolled and loop sizes mixed) — simulate / importance / assess / update under new
     constraints and changed arguments / IndexRequest / regenerate; ImportanceK over such models; a plate of thousands of
     elements as ONE trace and under K particles — bit for bit against the oracle"""
     from tests import fuzz_models as F
     ran = 0
-    for seed in range(200):
+    for seed in range(130):          # (200 until round 6; the on-device fuzz and tools/experiments/fuzz_on_device.py draw hundreds more)
         try:
             F.run_one(seed)
             ran += 1
         except F.OverTheLimits:
             pass
-    assert ran == 200, ran      # (a model that does not fit ONE launch runs as loops or as a chain of launches: none is left over)
+    assert ran == 130, ran      # (a model that does not fit ONE launch runs as loops or as a chain of launches: none is left over)
     # ImportanceK over a random model and random constraints under ONE key
     ran = 0
-    for seed in range(100):
+    for seed in range(60):
         try:
             F.run_smc_one(seed)
             ran += 1
         except F.OverTheLimits:
             pass
-    assert ran == 100, ran
+    assert ran == 60, ran
     # a plate of thousands of elements as the last statement: ONE trace (site by site) and K particles (deferred)
     for seed in range(12):
         F.run_big_one(seed)

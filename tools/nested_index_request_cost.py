@@ -48,7 +48,7 @@ def run(n=1000, J=64, T=4096, per_particle=False):
         new, w, _, _ = req.edit(k, tr, Diff.no_change(args))
         sync()
         t0 = time.perf_counter()
-        reps = 10 if not refuse else 2
+        reps = 10 if not refuse else 1
         for _ in range(reps):
             new, w, _, _ = req.edit(k, tr, Diff.no_change(args))
             _ = w[:1].cpu()
